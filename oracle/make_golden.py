@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference) on CPU.
+
+TEST INFRASTRUCTURE.  Run in the build container only (the GPU box has no /root/reference):
+    python oracle/make_golden.py
+The reference ships no golden vectors, so these fixtures -- outputs of the
+reference's own modules on seeded inputs/weights -- are what pins both the oracle restatement
+(oracle/otrans_oracle.py) and the HIP path.  Weights are NOT stored: they are regenerated on
+any machine by opentransformer_amd.synthetic.fill_state_dict_ (numpy Generator, crc32-keyed).
+"""
+import os
+import sys
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+# second entry only satisfies the bare `from activation import Swish` at otrans/module/ffn.py:9
+sys.path[:0] = ['/root/reference', '/root/reference/otrans/module']
+
+from otrans.model import End2EndModel, LanguageModel            # noqa: E402
+from otrans.model.ctc import CTCAssistor                        # noqa: E402
+from otrans.recognize.speech2text import SpeechToTextRecognizer  # noqa: E402
+from otrans.recognize.ctc import CTCRecognizer                  # noqa: E402
+
+from opentransformer_amd import synthetic as syn                # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def probe_vector(key, numel):
+    rng = np.random.default_rng(zlib.crc32(('probe:' + key).encode()))
+    return rng.standard_normal(numel).astype(np.float32)
+
+
+def grad_summary(named_params):
+    """Per-parameter [L2 norm, dot with a crc-seeded probe vector] (2 scalars pin a tensor)."""
+    keys, vals = [], []
+    for k, p in named_params:
+        if p.grad is None:
+            continue
+        g = p.grad.detach().double().reshape(-1).numpy()
+        keys.append(k)
+        vals.append([np.sqrt((g * g).sum()), float((g * probe_vector(k, g.size)).sum())])
+    return np.array(keys), np.array(vals, dtype=np.float64)
+
+
+def build(model_cfg, seed=1234):
+    torch.manual_seed(seed)
+    model = End2EndModel[model_cfg['type']](model_cfg)
+    syn.fill_state_dict_(model.state_dict(), seed)
+    return model
+
+
+def parts_state(model):
+    return {'frontend': model.frontend.state_dict(), 'encoder': model.encoder.state_dict(),
+            'decoder': model.decoder.state_dict()}
+
+
+def golden_train(name, cfg, batch_kw, store_full_grads=()):
+    model = build(cfg)
+    model.train()       # dropout rates are 0 in cfg
+    inputs, targets = syn.synthetic_batch(**batch_kw)
+    fe_out, fe_mask = model.frontend(inputs['inputs'], inputs['mask'])
+    memory, mem_mask, _ = model.encoder(fe_out, fe_mask)
+    logits, _ = model.decoder(targets['targets'][:, :-1].clone(), memory, mem_mask)
+    ce = model.crit(logits, targets['targets'][:, 1:].clone())
+    loss, aux = model(inputs, targets)
+    loss.backward()
+    keys, gsum = grad_summary(list(model.named_parameters()))
+    out = dict(loss=loss.item(), ce=ce.item(), ctc=(aux or {}).get('CTCLoss', np.nan),
+               fe_out=fe_out.detach().numpy(), fe_mask=fe_mask.numpy(), memory=memory.detach().numpy(),
+               logits=logits.detach().numpy(), grad_keys=keys, grad_summary=gsum)
+    named = dict(model.named_parameters())
+    for k in store_full_grads:
+        out['grad:' + k] = named[k].grad.numpy()
+    if cfg['ctc_weight'] > 0:
+        lp, ln = model.assistor.inference(memory.detach(), mem_mask)
+        out['ctc_log_probs'] = lp.detach().numpy()
+        out['ctc_len'] = ln.numpy()
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, 'loss', out['loss'], 'ce', out['ce'], 'ctc', out['ctc'], 'nparams',
+          sum(p.numel() for p in model.parameters()))
+    return model
+
+
+TEMPLATE_SEED = 5
+
+
+def template_batch(B, rng, V=100, F=80):
+    """Learnable synthetic ASR task: every token id has a fixed random F-dim template that is
+    held for 12-19 frames, plus noise.  Used to train C1 briefly so hypotheses are not
+    degenerate (a random-init model emits EOS at once: SURVEY.md 8c)."""
+    templ = np.random.default_rng(TEMPLATE_SEED).standard_normal((V, F)).astype(np.float32)
+    feats, toks = [], []
+    for _ in range(B):
+        n = rng.integers(3, 10)
+        tk = rng.integers(3, V, n)
+        seg = rng.integers(12, 20, n)
+        f = np.concatenate([np.repeat(templ[t][None], s, 0) for t, s in zip(tk, seg)])
+        feats.append((f + 0.3 * rng.standard_normal(f.shape)).astype(np.float32))
+        toks.append(tk)
+    T = max(len(f) for f in feats)
+    L = max(len(t) for t in toks)
+    x = np.zeros((B, T, F), np.float32)
+    m = np.zeros((B, T), bool)
+    tg = np.zeros((B, L + 2), np.int64)
+    tl = []
+    for b in range(B):
+        x[b, :len(feats[b])] = feats[b]
+        m[b, :len(feats[b])] = True
+        tg[b, 0] = 1
+        tg[b, 1:1 + len(toks[b])] = toks[b]
+        tg[b, 1 + len(toks[b])] = 1
+        tl.append(len(toks[b]) + 1)
+    return ({'inputs': torch.from_numpy(x), 'mask': torch.from_numpy(m)},
+            {'targets': torch.from_numpy(tg), 'targets_length': torch.tensor(tl, dtype=torch.int32)})
+
+
+def train_c1(cfg, steps=1500):
+    """Brief CPU training of the reference C1 model (reference modules, torch Adam)."""
+    torch.manual_seed(1234)
+    model = End2EndModel[cfg['type']](cfg)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    rng = np.random.default_rng(6)
+    model.train()
+    for step in range(steps):
+        for g in opt.param_groups:
+            g['lr'] = 1e-3 * min(1.0, (step + 1) / 300.0)
+        i, t = template_batch(16, rng)
+        loss, _ = model(i, t)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        opt.step()
+        if step % 250 == 0:
+            print('train_c1', step, loss.item(), flush=True)
+    return model
+
+
+def golden_decode(name, cfg):
+    """Beam / greedy hypotheses from the reference recognizers on a briefly trained C1 model
+    (weights stored in the fixture as 'w:<state_dict key>')."""
+    model = train_c1(cfg)
+    model.eval()
+    inputs, tgt = template_batch(4, np.random.default_rng(77))
+    V = cfg['decoder']['vocab_size']
+    idx2unit = {i: str(i) for i in range(V)}
+    out = {'inputs': inputs['inputs'].numpy(), 'mask': inputs['mask'].numpy(), 'truth': tgt['targets'].numpy()}
+    for k, v in model.state_dict().items():
+        out['w:' + k] = v.detach().numpy()
+
+    def to_arr(nbest):   # [[str,...],...] -> int array padded with -1
+        rows = [[[int(t) for t in s.split()] for s in utt] for utt in nbest]
+        L = max(1, max(len(h) for u in rows for h in u))
+        a = -np.ones((len(rows), len(rows[0]), L), dtype=np.int64)
+        for i, u in enumerate(rows):
+            for j, h in enumerate(u):
+                a[i, j, :len(h)] = h
+        return a
+
+    lm_cfg = syn.lm_config(V, d_model=cfg['decoder']['d_model'], d_ff=128, num_blocks=2)
+    torch.manual_seed(7)
+    lm = LanguageModel['transformer_lm'](lm_cfg)
+    syn.fill_state_dict_(lm.state_dict(), 4321)
+    lm.eval()
+    for tag, kw in [('greedy', dict(beam_width=1, nbest=1, max_len=12, penalty=0.0)),
+                    ('beam5', dict(beam_width=5, nbest=5, max_len=12, penalty=0.6, lamda=5)),
+                    ('beam5_lm', dict(beam_width=5, nbest=3, max_len=12, penalty=0.6, lamda=5, lm=lm, lm_weight=0.3))]:
+        rec = SpeechToTextRecognizer(model, idx2unit=idx2unit, ngpu=0, **kw)
+        nbest, scores = rec.recognize(inputs['inputs'], inputs['mask'])
+        out[tag + '_hyp'] = to_arr(nbest)
+        out[tag + '_score'] = scores.numpy()
+        print(name, tag, [u[0] for u in nbest], scores[:, 0].tolist())
+    # one decoder.inference call pinned exactly
+    with torch.no_grad():
+        fe, fm, _ = model.frontend.inference(inputs['inputs'], inputs['mask'], None)
+        mem, mm, _ = model.encoder(fe, fm)
+        preds = torch.tensor([[1, 5, 9], [1, 7, 3], [1, 4, 4], [1, 50, 60]])[:mem.size(0)]
+        lp, _, _ = model.decoder.inference(preds, mem, mm)
+        out['inference_preds'] = preds.numpy()
+        out['inference_logp'] = lp.numpy()
+        out['lm_logp'] = lm.predict(preds, last_frame=True).squeeze(1).numpy()
+    # CTC greedy via the assistor head (CTCModel.inference is broken in the reference: SURVEY 3.4)
+    with torch.no_grad():
+        lp, ln = model.assistor.inference(mem, mm)
+
+    class _M:                                   # minimal stand-in for the model CTCRecognizer expects
+        def eval(self):
+            return self
+
+        def inference(self, a, b):
+            return lp, ln
+    greedy = CTCRecognizer(_M(), idx2unit=idx2unit, ngpu=0, mode='greedy', beam_width=1).recognize_greedy(None, None)
+    L = max(1, max(len(g) for g in greedy))
+    ga = -np.ones((len(greedy), L), dtype=np.int64)
+    for i, g in enumerate(greedy):
+        ga[i, :len(g)] = g
+    out['ctc_greedy'] = ga
+    out['ctc_head_logp'] = lp.numpy()
+    np.savez_compressed(os.path.join(OUT, name), **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    c1 = syn.c1_model(residual_dropout=0.0, ctc_weight=0.3)
+    c1_batch = dict(batch=4, frames=200, feat_dim=80, vocab=100, tgt_len=10, seed=0,
+                    lengths=[200, 180, 150, 97], tgt_lengths=[10, 8, 10, 5])
+    golden_train('c1_train.npz', c1, c1_batch,
+                 store_full_grads=('frontend.conv1.conv_layer.weight', 'frontend.conv1.conv_layer.bias',
+                                   'encoder.blocks.0.slf_attn.qvk_proj.bias', 'decoder.embedding.weight',
+                                   'encoder.blocks.1.norm2.weight', 'assistor.output_layer.bias'))
+    c1d = syn.c1_model(residual_dropout=0.0, ctc_weight=0.3)
+    golden_decode('c1_decode.npz', c1d)
+    # full-size transformer_baseline (+80-d), tiny batch, ragged, dropout 0: pins C2 numerics
+    c2 = syn.c2_model(residual_dropout=0.0)
+    c2_batch = dict(batch=2, frames=1000, feat_dim=80, vocab=4234, tgt_len=15, seed=0,
+                    lengths=[1000, 873], tgt_lengths=[15, 11])
+    golden_train('c2_train_b2.npz', c2, c2_batch)
+
+
+if __name__ == '__main__':
+    main()

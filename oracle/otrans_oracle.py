@@ -1,0 +1,406 @@
+"""CPU oracle for the otrans speech-transformer hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch, functional (state_dict-in, tensors-out) fp32 CPU
+restatement of the reference algorithm for the path SURVEY.md section 8 names.
+It is NOT the product: only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import it.  The product path (opentransformer_amd) never
+touches it and fails loudly when the HIP library is missing.
+
+Parity pinning: the reference ships no golden vectors, so the
+oracle is pinned against outputs of the reference itself, generated in the build
+container by oracle/make_golden.py (which imports /root/reference) and committed
+under tests/golden/.  tests/test_oracle_golden.py checks every function here
+against those fixtures.
+
+Every function cites the reference file:line it restates (paths relative to
+/root/reference).  Arithmetic is third-party torch CPU fp32 kernels, exactly as
+in the reference (SURVEY.md 8c "third-party arithmetic").
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+PAD = 0   # otrans/data/__init__.py:7-12
+BLK = 0
+BOS = 1
+EOS = 1
+
+
+def _sub(sd, prefix):
+    n = len(prefix)
+    return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+# --------------------------------------------------------------------------- frontend
+def conv_out_len(t):
+    """3x3 stride-2 conv, no time padding: otrans/frontend/conv.py:11-12,28 (time pad 0)."""
+    return (t - 3) // 2 + 1
+
+
+def conv2d_layer(w, b, x, mask):
+    """Conv2dLayer.forward + return_output_mask: otrans/frontend/conv.py:50-83.
+
+    relu(conv2d(x, 3x3, stride 2, pad (0,1))); mask[:, 1::2][:, :t]."""
+    out = F.relu(F.conv2d(x, w, b, stride=2, padding=(0, 1)))
+    mask = mask[:, 1::2][:, :out.size(2)]
+    return out, mask
+
+
+def conv_frontend(sd, x, mask):
+    """ConvFrontEnd.forward: otrans/frontend/conv.py:131-153.
+
+    x [B,T,F] -> [B,T2,d]; flatten order c*F2+f (conv.py:145)."""
+    x = x.unsqueeze(1)
+    x, mask = conv2d_layer(sd['conv1.conv_layer.weight'], sd['conv1.conv_layer.bias'], x, mask)
+    x, mask = conv2d_layer(sd['conv2.conv_layer.weight'], sd['conv2.conv_layer.bias'], x, mask)
+    b, c, t, f = x.shape
+    x = x.permute(0, 2, 1, 3).reshape(b, t, c * f)
+    x = F.linear(x, sd['output_layer.weight'], sd['output_layer.bias'])
+    return x, mask
+
+
+# --------------------------------------------------------------------------- primitives
+def sinusoid(positions, d):
+    """PositionalEncoding._embedding_from_positions: otrans/module/pos.py:30-42."""
+    pos = positions.float().unsqueeze(-1)
+    div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe = torch.zeros(positions.shape + (d,), dtype=torch.float32)
+    pe[..., 0::2] = torch.sin(pos * div)
+    pe[..., 1::2] = torch.cos(pos * div)
+    return pe
+
+
+def add_posenc(x):
+    """PositionalEncoding.forward, scale_learnable False: otrans/module/pos.py:44-57."""
+    d = x.size(-1)
+    pe = sinusoid(torch.arange(x.size(1)).reshape(1, -1), d)
+    return x * math.sqrt(d) + pe
+
+
+def _heads(x, h):
+    b, t, d = x.shape
+    return x.reshape(b, t, h, d // h).transpose(1, 2)
+
+
+def _context(sd, v, scores, mask):
+    """BasedAttention.compute_context: otrans/module/attention.py:23-46."""
+    if mask is not None:
+        scores = scores.masked_fill(~mask, -float('inf'))
+    w = torch.softmax(scores, dim=-1)
+    ctx = torch.matmul(w, v)
+    b, n, t, dv = ctx.shape
+    ctx = ctx.transpose(1, 2).reshape(b, t, n * dv)
+    return F.linear(ctx, sd['output_proj.weight'], sd['output_proj.bias'])
+
+
+def self_attention(sd, x, mask, h):
+    """MultiHeadedSelfAttention.forward: otrans/module/attention.py:60-84.
+
+    qvk_proj rows are ordered q,k,v (attention.py:73); mask [B,1|T,T]."""
+    d = x.size(-1)
+    q, k, v = torch.split(F.linear(x, sd['qvk_proj.weight'], sd['qvk_proj.bias']), d, dim=-1)
+    q, k, v = _heads(q, h), _heads(k, h), _heads(v, h)
+    scores = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(d // h)
+    return _context(sd, v, scores, mask.unsqueeze(1) if mask is not None else None)
+
+
+def cross_attention(sd, x, memory, memory_mask, h):
+    """MultiHeadedCrossAttention.forward: otrans/module/attention.py:119-145.
+
+    vk_proj rows are ordered k,v (attention.py:134)."""
+    d = x.size(-1)
+    q = F.linear(x, sd['q_proj.weight'], sd['q_proj.bias'])
+    k, v = torch.split(F.linear(memory, sd['vk_proj.weight'], sd['vk_proj.bias']), d, dim=-1)
+    q, k, v = _heads(q, h), _heads(k, h), _heads(v, h)
+    scores = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(d // h)
+    return _context(sd, v, scores, memory_mask.unsqueeze(1))
+
+
+def feed_forward(sd, x, activation):
+    """PositionwiseFeedForward.forward: otrans/module/ffn.py:38-41 (+ _ACTIVATION :15-21)."""
+    hdn = F.linear(x, sd['w_1.weight'], sd['w_1.bias'])
+    if activation == 'glu':
+        hdn = F.glu(hdn, dim=-1)
+    elif activation == 'relu':
+        hdn = F.relu(hdn)
+    elif activation == 'gelu':
+        hdn = F.gelu(hdn)
+    elif activation == 'tanh':
+        hdn = torch.tanh(hdn)
+    elif activation == 'swish':
+        hdn = hdn * torch.sigmoid(hdn)
+    else:
+        raise ValueError(activation)
+    return F.linear(hdn, sd['w_2.weight'], sd['w_2.bias'])
+
+
+def _ln(sd, name, x):
+    return F.layer_norm(x, (x.size(-1),), sd[name + '.weight'], sd[name + '.bias'], 1e-5)
+
+
+# --------------------------------------------------------------------------- encoder
+def encoder_layer(sd, x, mask, h, activation, normalize_before=False):
+    """TransformerEncoderLayer.forward: otrans/encoder/transformer.py:41-65 (dropout off).
+
+    The pre-norm variant takes the residual AFTER the norm (transformer.py:42-44)."""
+    if normalize_before:
+        x = _ln(sd, 'norm1', x)
+    x = x + self_attention(_sub(sd, 'slf_attn.'), x, mask, h)
+    if not normalize_before:
+        x = _ln(sd, 'norm1', x)
+    if normalize_before:
+        x = _ln(sd, 'norm2', x)
+    x = x + feed_forward(_sub(sd, 'feed_forward.'), x, activation)
+    if not normalize_before:
+        x = _ln(sd, 'norm2', x)
+    return x
+
+
+def transformer_encoder(sd, x, mask, cfg):
+    """TransformerEncoder.forward: otrans/encoder/transformer.py:114-134."""
+    x = add_posenc(x)
+    nb = cfg.get('normalize_before', False)
+    for i in range(cfg['n_blocks']):
+        x = encoder_layer(_sub(sd, 'blocks.%d.' % i), x, mask.unsqueeze(1), cfg['n_heads'],
+                          cfg.get('activation', 'relu'), nb)
+    if nb:
+        x = _ln(sd, 'norm', x)
+    return x, mask
+
+
+# --------------------------------------------------------------------------- decoder
+def decoder_layer(sd, x, tgt_mask, memory, memory_mask, h, activation, normalize_before=False):
+    """TransformerDecoderLayer.forward: otrans/decoder/transformer.py:47-90 (dropout off)."""
+    if normalize_before:
+        x = _ln(sd, 'norm1', x)
+    x = x + self_attention(_sub(sd, 'slf_attn.'), x, tgt_mask, h)
+    if not normalize_before:
+        x = _ln(sd, 'norm1', x)
+    if normalize_before:
+        x = _ln(sd, 'norm2', x)
+    x = x + cross_attention(_sub(sd, 'src_attn.'), x, memory, memory_mask, h)
+    if not normalize_before:
+        x = _ln(sd, 'norm2', x)
+    if normalize_before:
+        x = _ln(sd, 'norm3', x)
+    x = x + feed_forward(_sub(sd, 'feed_forward.'), x, activation)
+    if not normalize_before:
+        x = _ln(sd, 'norm3', x)
+    return x
+
+
+def transformer_decoder(sd, targets, memory, memory_mask, cfg):
+    """TransformerDecoder.forward: otrans/decoder/transformer.py:161-183.
+
+    Causal tril mask only, no target-pad mask (decoder/utils.py:7-11)."""
+    x = add_posenc(F.embedding(targets, sd['embedding.weight']))
+    L = targets.size(1)
+    tgt_mask = torch.tril(torch.ones(targets.size(0), L, L)).bool()
+    nb = cfg.get('normalize_before', True)
+    for i in range(cfg['n_blocks']):
+        x = decoder_layer(_sub(sd, 'blocks.%d.' % i), x, tgt_mask, memory, memory_mask.unsqueeze(1),
+                          cfg['n_heads'], cfg.get('activation', 'relu'), nb)
+    if nb:
+        x = _ln(sd, 'after_norm', x)
+    return F.linear(x, sd['output_layer.weight'], sd['output_layer.bias'])
+
+
+def decoder_inference(sd, preds, memory, memory_mask, cfg):
+    """TransformerDecoder.inference: otrans/decoder/transformer.py:185-208 (full re-forward)."""
+    logits = transformer_decoder(sd, preds, memory, memory_mask, cfg)
+    return F.log_softmax(logits[:, -1, :], dim=-1)
+
+
+# --------------------------------------------------------------------------- losses
+def label_smoothing_loss(logits, target, smoothing, padding_idx=PAD):
+    """LabelSmoothingLoss.forward: otrans/module/loss.py:21-48.
+
+    Off-target mass eps/(V-1); rows with target==PAD zeroed; divided by #non-pad."""
+    V = logits.size(-1)
+    logits = logits.reshape(-1, V)
+    tgt = target.reshape(-1)
+    conf = torch.full_like(logits, smoothing / (V - 1))
+    conf.scatter_(1, tgt.unsqueeze(1), 1.0 - smoothing)
+    logp = F.log_softmax(logits, dim=-1)
+    row = torch.sum(conf * (torch.log(conf) - logp), dim=-1)
+    pad = tgt == padding_idx
+    return torch.sum(row.masked_fill(pad, 0.0)) / torch.sum(~pad)
+
+
+def ctc_nll(log_probs, targets, in_len, tgt_len, blank=BLK):
+    """Per-utterance CTC negative log likelihood (the algorithm behind nn.CTCLoss,
+    third-party torch; used by otrans/model/ctc.py:30,50-53).
+
+    log_probs [B,T,V] (log-softmaxed), targets [B,Lmax].  Standard log-domain alpha
+    recursion over the blank-extended label sequence (Graves et al. 2006, eq. 6-8)."""
+    B = log_probs.size(0)
+    out = []
+    for b in range(B):
+        T, L = int(in_len[b]), int(tgt_len[b])
+        lab = targets[b, :L]
+        ext = torch.full((2 * L + 1,), blank, dtype=torch.long)
+        ext[1::2] = lab
+        S = 2 * L + 1
+        lp = log_probs[b, :T][:, ext]                      # [T,S]
+        neg = torch.full((S,), -1e30)     # finite "log 0": keeps autograd through logsumexp NaN-free
+        alpha = neg.clone()
+        alpha[0] = lp[0, 0]
+        if S > 1:
+            alpha[1] = lp[0, 1]
+        skip_ok = torch.zeros(S, dtype=torch.bool)
+        if S > 2:
+            skip_ok[2:] = (ext[2:] != blank) & (ext[2:] != ext[:-2])
+        for t in range(1, T):
+            a1 = torch.cat([neg[:1], alpha[:-1]])
+            a2 = torch.cat([neg[:2], alpha[:-2]])
+            a2 = torch.where(skip_ok, a2, neg)
+            alpha = torch.logsumexp(torch.stack([alpha, a1, a2]), dim=0) + lp[t]
+        tail = alpha[-1:] if S == 1 else alpha[-2:]
+        out.append(-torch.logsumexp(tail, dim=0))
+    return torch.stack(out)
+
+
+def ctc_loss(logits, in_len, targets, tgt_len):
+    """CTCAssistor.compute_loss: otrans/model/ctc.py:50-53 with nn.CTCLoss(blank=0,
+    zero_infinity=True), default reduction 'mean' = mean_b(nll_b / clamp(tgt_len_b,1))."""
+    nll = ctc_nll(F.log_softmax(logits, dim=-1), targets, in_len, tgt_len)
+    nll = torch.where(nll > 1e29, torch.zeros_like(nll), nll)      # zero_infinity=True
+    return torch.mean(nll / tgt_len.clamp(min=1).to(nll.dtype))
+
+
+# --------------------------------------------------------------------------- model
+def speech2text_forward(sd, params, inputs, targets):
+    """SpeechToText.forward: otrans/model/speech2text.py:39-64.
+
+    sd: {'frontend':..,'encoder':..,'decoder':..,['ctc':..]} (checkpoint layout :72-82).
+    Returns (loss, aux) with aux = {'logits','memory','memory_mask',['ctc_loss']}."""
+    x, mask = conv_frontend(sd['frontend'], inputs['inputs'], inputs['mask'])
+    memory, memory_mask = transformer_encoder(sd['encoder'], x, mask, params['encoder'])
+    truth = targets['targets']
+    logits = transformer_decoder(sd['decoder'], truth[:, :-1], memory, memory_mask, params['decoder'])
+    target_out = truth[:, 1:]
+    loss = label_smoothing_loss(logits, target_out, params['smoothing'])
+    aux = {'logits': logits, 'memory': memory, 'memory_mask': memory_mask}
+    w = params.get('ctc_weight', 0.0)
+    if w > 0:
+        ctc_logits = F.linear(memory, sd['ctc']['output_layer.weight'], sd['ctc']['output_layer.bias'])
+        lctc = ctc_loss(ctc_logits, memory_mask.sum(-1), target_out, targets['targets_length'])
+        aux['ctc_loss'] = lctc
+        loss = (1 - w) * loss + w * lctc
+    return loss, aux
+
+
+def ctc_inference(sd_ctc, memory, memory_mask):
+    """CTCAssistor.inference (no look-ahead): otrans/model/ctc.py:55-66."""
+    logits = F.linear(memory, sd_ctc['output_layer.weight'], sd_ctc['output_layer.bias'])
+    return F.log_softmax(logits, dim=-1), memory_mask.sum(-1)
+
+
+def ctc_greedy(log_probs, lengths):
+    """CTCRecognizer.recognize_greedy: otrans/recognize/ctc.py:38-58
+    (argmax per frame, collapse repeats, drop id 0)."""
+    best = log_probs.argmax(-1)
+    res = []
+    for b in range(best.size(0)):
+        last, out = PAD, []
+        for i in range(int(lengths[b])):
+            k = int(best[b, i])
+            if k != last and k != PAD:
+                out.append(k)
+            last = k
+        res.append(out)
+    return res
+
+
+# --------------------------------------------------------------------------- LM + beam search
+def transformer_lm_predict(sd, cfg, tokens):
+    """TransformerLanguageModel.predict(last_frame=True): otrans/model/lm.py:143-163.
+
+    embed + posenc + post-norm GLU encoder layers with causal mask + tied output."""
+    x = add_posenc(F.embedding(tokens, sd['embedding.weight']))
+    L = tokens.size(1)
+    mask = torch.tril(torch.ones(tokens.size(0), L, L)).bool()
+    for i in range(cfg['num_blocks']):
+        x = encoder_layer(_sub(sd, 'blocks.%d.' % i), x, mask, cfg['n_heads'], 'glu', False)
+    logits = F.linear(x, sd['output_project.weight'], sd['output_project.bias'])
+    return F.log_softmax(logits[:, -1, :], dim=-1)
+
+
+def beam_search(sd, params, inputs, inputs_mask, beam=5, max_len=50, penalty=0.0, lamda=5,
+                nbest=1, lm=None, lm_weight=0.1):
+    """SpeechToTextRecognizer.recognize/decode_step + mask_finished_*:
+    otrans/recognize/speech2text.py:39-192.  Returns (token lists [B][nbest], scores [B,nbest]).
+
+    lm: optional (lm_state_dict, lm_cfg) for shallow fusion (recognize/base.py:26-37)."""
+    with torch.no_grad():
+        x, mask = conv_frontend(sd['frontend'], inputs, inputs_mask)
+        memory, mmask = transformer_encoder(sd['encoder'], x, mask, params['encoder'])
+        B, T, D = memory.shape
+        bm = memory.unsqueeze(1).repeat(1, beam, 1, 1).view(B * beam, T, D)
+        bmask = mmask.unsqueeze(1).repeat(1, beam, 1).view(B * beam, T)
+        preds = torch.full((B * beam, 1), BOS, dtype=torch.long)
+        scores = torch.tensor([0.0] + [-float('inf')] * (beam - 1)).repeat(B).unsqueeze(1)
+        flag = torch.zeros_like(scores, dtype=torch.bool)
+        for _ in range(max_len):
+            lp = decoder_inference(sd['decoder'], preds, bm, bmask, params['decoder'])
+            if lm is not None:
+                lp = lp + lm_weight * transformer_lm_predict(lm[0], lm[1], preds)
+            k_scores, k_preds = lp.topk(beam)
+            # finished beams: one live branch with score 0 that emits EOS (speech2text.py:156-192)
+            fin = flag.expand(-1, beam)
+            first = torch.zeros_like(fin)
+            first[:, 0] = True
+            k_scores = torch.where(fin & ~first, torch.full_like(k_scores, -float('inf')), k_scores)
+            k_scores = torch.where(fin & first, torch.zeros_like(k_scores), k_scores)
+            k_preds = torch.where(fin, torch.full_like(k_preds, EOS), k_preds)
+            cand = (scores + k_scores).view(B, beam * beam)
+            top, off = torch.topk(cand, k=beam)
+            scores = top.view(-1, 1)
+            best = (torch.arange(B).view(-1, 1) * beam * beam + off).view(-1)
+            tok = k_preds.reshape(-1)[best]
+            src = best // beam
+            preds = torch.cat([preds[src], tok.view(-1, 1)], dim=1)
+            flag = (preds[:, -1] == EOS).view(-1, 1)
+            if int(flag.sum()) == B * beam:
+                break
+        scores = scores.view(B, beam)
+        preds = preds.view(B, beam, -1)
+        if penalty:
+            lengths = (preds != EOS).float().sum(-1)
+            scores = scores / torch.pow((lamda + lengths) / (lamda + 1), penalty)
+        ss, idx = torch.sort(scores, dim=-1, descending=True)
+        preds = torch.gather(preds, 1, idx.unsqueeze(-1).expand_as(preds))[:, :min(beam, nbest), 1:]
+        hyps = []
+        for b in range(B):
+            row = []
+            for n in range(preds.size(1)):
+                out = []
+                for tkn in preds[b, n].tolist():
+                    if tkn == EOS:
+                        break
+                    out.append(tkn)
+                row.append(out)
+            hyps.append(row)
+        return hyps, ss[:, :min(beam, nbest)]
+
+
+# --------------------------------------------------------------------------- train step (a21)
+def noam_lr(step, model_size, warmup_steps, factor=1.0):
+    """TransformerScheduler.get_step_lr: otrans/train/scheduler.py:137-138."""
+    return factor * model_size ** (-0.5) * min(step ** (-0.5), step * warmup_steps ** (-1.5))
+
+
+def dp_mean_loss_grads(sd_flat_params, loss_fn, shards):
+    """nn.DataParallel semantics (otrans/train/trainer.py:64-66,206-209): loss = mean of
+    per-replica losses, each normalised by its own token count => grad = (1/N) * sum_i grad_i."""
+    grads = None
+    losses = []
+    for sh in shards:
+        loss = loss_fn(sh)
+        g = torch.autograd.grad(loss, sd_flat_params, allow_unused=True)
+        losses.append(loss.detach())
+        grads = g if grads is None else [a + b if (a is not None and b is not None) else (a if b is None else b)
+                                         for a, b in zip(grads, g)]
+    n = len(shards)
+    return torch.stack(losses).mean(), [None if g is None else g / n for g in grads]

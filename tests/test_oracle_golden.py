@@ -1,0 +1,127 @@
+"""CPU (-m "not gpu"): pin the oracle restatement against fixtures produced by the REAL reference
+(oracle/make_golden.py).  fp32 CPU torch on both sides => tolerances are roundoff-level."""
+import numpy as np
+import torch
+
+from opentransformer_amd import synthetic as syn
+from oracle import otrans_oracle as orc
+from tests import helpers as H
+
+C1_BATCH = dict(batch=4, frames=200, feat_dim=80, vocab=100, tgt_len=10, seed=0,
+                lengths=[200, 180, 150, 97], tgt_lengths=[10, 8, 10, 5])
+C2_BATCH = dict(batch=2, frames=1000, feat_dim=80, vocab=4234, tgt_len=15, seed=0,
+                lengths=[1000, 873], tgt_lengths=[15, 11])
+
+
+def _check_train(g, cfg, batch_kw, rtol):
+    parts = H.require_grad(H.filled_state(cfg))
+    inputs, targets = syn.synthetic_batch(**batch_kw)
+    loss, aux = orc.speech2text_forward(parts, cfg, inputs, targets)
+    fe_out, fe_mask = orc.conv_frontend(parts['frontend'], inputs['inputs'], inputs['mask'])
+    assert np.array_equal(fe_mask.numpy(), g['fe_mask'])
+    np.testing.assert_allclose(fe_out.detach().numpy(), g['fe_out'], rtol=rtol, atol=rtol)
+    np.testing.assert_allclose(aux['memory'].detach().numpy(), g['memory'], rtol=rtol, atol=10 * rtol)
+    np.testing.assert_allclose(aux['logits'].detach().numpy(), g['logits'], rtol=rtol, atol=10 * rtol)
+    assert abs(loss.item() - float(g['loss'])) <= rtol * abs(float(g['loss']))
+    if cfg['ctc_weight'] > 0:
+        assert abs(aux['ctc_loss'].item() - float(g['ctc'])) <= rtol * abs(float(g['ctc']))
+    flat = H.flat_named(parts)
+    loss.backward()
+    keys = [str(k) for k in g['grad_keys']]
+    seen = set()
+    for k, (nrm, dot) in zip(keys, g['grad_summary']):
+        t = flat[k]
+        if t.data_ptr() in seen:
+            continue
+        seen.add(t.data_ptr())
+        gr = t.grad.double().reshape(-1).numpy()
+        assert abs(np.sqrt((gr * gr).sum()) - nrm) <= 5 * rtol * max(nrm, 1e-6), k
+        assert abs((gr * H.probe_vector(k, gr.size)).sum() - dot) <= 5 * rtol * max(nrm * np.sqrt(gr.size), 1e-6), k
+    for name in g.files:
+        if name.startswith('grad:'):
+            np.testing.assert_allclose(flat[name[5:]].grad.numpy(), g[name], rtol=10 * rtol, atol=rtol)
+
+
+def test_c1_train_matches_reference(golden):
+    _check_train(golden('c1_train.npz'), syn.c1_model(0.0, ctc_weight=0.3), C1_BATCH, 2e-5)
+
+
+def test_c2_train_matches_reference(golden):
+    _check_train(golden('c2_train_b2.npz'), syn.c2_model(0.0), C2_BATCH, 5e-5)
+
+
+def test_ctc_head_and_recursion_match_reference(golden):
+    g = golden('c1_train.npz')
+    cfg = syn.c1_model(0.0, ctc_weight=0.3)
+    parts = H.filled_state(cfg)
+    lp, ln = orc.ctc_inference(parts['ctc'], torch.from_numpy(g['memory']), torch.from_numpy(g['fe_mask']))
+    np.testing.assert_allclose(lp.numpy(), g['ctc_log_probs'], rtol=1e-4, atol=1e-4)
+    assert np.array_equal(ln.numpy(), g['ctc_len'])
+    # the hand-written alpha recursion vs torch's own ctc_loss on the same log-probs
+    _, targets = syn.synthetic_batch(**C1_BATCH)
+    tgt = targets['targets'][:, 1:]
+    tl = targets['targets_length']
+    mine = orc.ctc_nll(lp, tgt, ln, tl)
+    ref = torch.nn.functional.ctc_loss(lp.transpose(0, 1), tgt, ln, tl, blank=0, reduction='none',
+                                       zero_infinity=True)
+    np.testing.assert_allclose(mine.numpy(), ref.numpy(), rtol=1e-4)
+
+
+def _decode_state(g):
+    parts = {'frontend': {}, 'encoder': {}, 'decoder': {}, 'ctc': {}}
+    for name in g.files:
+        if name.startswith('w:'):
+            top, key = name[2:].split('.', 1)
+            parts[{'assistor': 'ctc'}.get(top, top)][key] = torch.from_numpy(g[name])
+    return parts
+
+
+def _hyp_arr(hyps, like):
+    a = -np.ones_like(like)
+    for i, u in enumerate(hyps):
+        for j, h in enumerate(u):
+            a[i, j, :len(h)] = h
+    return a
+
+
+def test_beam_search_hypotheses_match_reference(golden):
+    g = golden('c1_decode.npz')
+    cfg = syn.c1_model(0.0, ctc_weight=0.3)
+    parts = _decode_state(g)
+    x, m = torch.from_numpy(g['inputs']), torch.from_numpy(g['mask'])
+    lm_cfg = syn.lm_config(100, d_model=64, d_ff=128, num_blocks=2)
+    lm = (H.lm_state(lm_cfg), lm_cfg)
+    for tag, kw in [('greedy', dict(beam=1, nbest=1, max_len=12, penalty=0.0)),
+                    ('beam5', dict(beam=5, nbest=5, max_len=12, penalty=0.6, lamda=5)),
+                    ('beam5_lm', dict(beam=5, nbest=3, max_len=12, penalty=0.6, lamda=5, lm=lm, lm_weight=0.3))]:
+        hyps, scores = orc.beam_search(parts, cfg, x, m, **kw)
+        assert np.array_equal(_hyp_arr(hyps, g[tag + '_hyp']), g[tag + '_hyp']), tag
+        np.testing.assert_allclose(scores.numpy(), g[tag + '_score'], rtol=1e-4, atol=1e-4)
+
+
+def test_decoder_inference_lm_and_ctc_greedy_match_reference(golden):
+    g = golden('c1_decode.npz')
+    cfg = syn.c1_model(0.0, ctc_weight=0.3)
+    parts = _decode_state(g)
+    x, m = torch.from_numpy(g['inputs']), torch.from_numpy(g['mask'])
+    with torch.no_grad():
+        fe, fm = orc.conv_frontend(parts['frontend'], x, m)
+        mem, mm = orc.transformer_encoder(parts['encoder'], fe, fm, cfg['encoder'])
+        preds = torch.from_numpy(g['inference_preds'])
+        lp = orc.decoder_inference(parts['decoder'], preds, mem, mm, cfg['decoder'])
+        np.testing.assert_allclose(lp.numpy(), g['inference_logp'], rtol=1e-4, atol=1e-4)
+        lm_cfg = syn.lm_config(100, d_model=64, d_ff=128, num_blocks=2)
+        llp = orc.transformer_lm_predict(H.lm_state(lm_cfg), lm_cfg, preds)
+        np.testing.assert_allclose(llp.numpy(), g['lm_logp'], rtol=1e-4, atol=1e-4)
+        clp, cln = orc.ctc_inference(parts['ctc'], mem, mm)
+        np.testing.assert_allclose(clp.numpy(), g['ctc_head_logp'], rtol=1e-4, atol=1e-4)
+        greedy = orc.ctc_greedy(clp, cln)
+    want = [[t for t in row if t >= 0] for row in g['ctc_greedy'].tolist()]
+    assert greedy == want
+
+
+def test_flop_model_matches_survey():
+    # fwd 13 613.96 MFLOP, fwd+bwd 40 818.87 MFLOP per utterance
+    m = syn.c2_model()
+    assert abs(syn.flops_per_utt(m, 1000, 15, fwd_only=True) / 1e6 - 13613.96) < 0.5
+    assert abs(syn.flops_per_utt(m, 1000, 15) / 1e6 - 40818.87) < 1.5
