@@ -1,0 +1,171 @@
+/* libotrans_hip.so -- C ABI of the MI355X (gfx950) hot path for ZhengkunTian/OpenTransformer.
+ *
+ * The reference has no FFI (it is pure PyTorch); every entry below names the reference code it
+ * replaces (paths relative to the reference root).  The reference-side binding a maintainer would
+ * add is the ctypes stub shown in INTEGRATION.md (opentransformer_amd/_lib.py is that stub).
+ *
+ * Conventions:
+ *  - plain pointers + sizes; the CALLER owns every buffer (inputs, outputs, saved-for-backward,
+ *    workspace).  The library never allocates or frees device memory and keeps no pointer after
+ *    a call returns.
+ *  - every launch is asynchronous on the hipStream_t passed in (as void*); no hidden syncs, so all
+ *    entries are legal inside hipGraph stream capture.
+ *  - return 0 = OK, negative = bad argument (nothing launched), positive = hipError_t.
+ *    otr_last_error_string() describes the last failure on the calling thread.
+ *  - dtype codes: OTR_F32 = 0, OTR_BF16 = 1 (raw bf16 bits).  `compute` selects the MFMA type:
+ *    OTR_BF16 -> v_mfma_f32_16x16x32_bf16 (fp32 accumulate), OTR_F32 -> v_mfma_f32_16x16x4_f32
+ *    (exact fp32, the parity mode).
+ */
+#ifndef OTRANS_HIP_H
+#define OTRANS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OTR_F32 0
+#define OTR_BF16 1
+#define OTR_ACT_NONE 0
+#define OTR_ACT_RELU 1
+
+int32_t otr_version(void);
+const char* otr_last_error_string(void);
+
+/* ---- nn.Linear and its gradients (module/attention.py:43,68,128-129; module/ffn.py:39-41;
+ *      frontend/conv.py:146; decoder/transformer.py:181; model/ctc.py:47).
+ * All matrices row-major with leading dimensions in elements.  `accumulate` != 0 adds into out. */
+typedef struct {
+  int32_t M, N, K;              /* y[M,N] = x[M,K] * w[N,K]^T */
+  int32_t x_dtype, w_dtype, y_dtype, compute;
+  int64_t ldx, ldw, ldy;
+  int32_t act;                  /* OTR_ACT_* applied after bias (forward only) */
+  int32_t accumulate;
+} otr_linear_desc_t;
+/* y = act(x w^T + bias); bias f32[N] or NULL */
+int32_t otr_linear_fwd(const otr_linear_desc_t* d, const void* x, const void* w, const float* bias, void* y,
+                       void* stream);
+/* dx[M,K] (dtype x_dtype, ld ldx) = dy[M,N] (dtype y_dtype, ld ldy) * w[N,K] */
+int32_t otr_linear_dgrad(const otr_linear_desc_t* d, const void* dy, const void* w, void* dx, void* stream);
+/* dw[N,K] (dtype w_dtype, ld ldw) = dy[M,N]^T * x[M,K] */
+int32_t otr_linear_wgrad(const otr_linear_desc_t* d, const void* dy, const void* x, void* dw, void* stream);
+/* out[N] (f32) (+)= sum over M rows of a[M,N]  (bias gradients) */
+int32_t otr_colsum(const void* a, int32_t dtype, int64_t M, int64_t N, int64_t lda, float* out, int32_t accumulate,
+                   void* stream);
+
+/* ---- scaled-dot-product attention, flash style: scores are never materialised
+ *      (module/attention.py:23-46 compute_context, :76-82 self, :137-143 cross).
+ * q/k/v/o are [B, T, H*dk] slices addressed by (batch stride, time stride) in elements; head h
+ * occupies columns [h*dk, (h+1)*dk).  key_mask: uint8 [B, Tk] (1 = valid) or NULL; causal != 0
+ * additionally masks key > query (decoder/utils.py:7-11).  lse: f32 [B,H,Tq] (saved for bwd). */
+typedef struct {
+  int32_t B, H, Tq, Tk, dk;
+  int32_t dtype;                /* element type of q,k,v,o and their grads; also the MFMA type */
+  int64_t q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
+  int32_t causal;
+  float scale;                  /* 1/sqrt(dk) */
+} otr_attn_desc_t;
+int32_t otr_attention_fwd(const otr_attn_desc_t* d, const void* q, const void* k, const void* v,
+                          const uint8_t* key_mask, void* o, float* lse, void* stream);
+/* do_/dq/dk/dv use the strides of o/q/k/v.  delta: f32 [B,H,Tq] workspace. */
+int32_t otr_attention_bwd(const otr_attn_desc_t* d, const void* q, const void* k, const void* v,
+                          const uint8_t* key_mask, const void* o, const void* do_, const float* lse,
+                          float* delta, void* dq, void* dk, void* dv, void* stream);
+
+/* ---- y = LayerNorm(x + dropout(a)) (encoder/transformer.py:54-56,61-63; decoder/transformer.py:
+ *      66-68,76-78,84-86).  x f32 [M,d]; a [M,d] of a_dtype or NULL; z (= x+drop(a), f32) and
+ *      mean/rstd (f32 [M]) are saved for backward.  Dropout masks come from a counter RNG keyed by
+ *      (*seed, rng_offset + element index) and are regenerated, never stored. */
+typedef struct {
+  int64_t M;
+  int32_t d;
+  int32_t a_dtype;
+  float eps, p_drop;            /* p_drop = 0 -> no dropout */
+  uint64_t rng_offset;
+} otr_ln_desc_t;
+int32_t otr_add_layernorm_fwd(const otr_ln_desc_t* d, const float* x, const void* a, const float* gamma,
+                              const float* beta, const uint64_t* seed, float* y, float* z, float* mean,
+                              float* rstd, void* stream);
+/* dx f32 [M,d] (residual grad), da [M,d] a_dtype (branch grad, may be NULL), dgamma/dbeta f32[d] +=. */
+int32_t otr_add_layernorm_bwd(const otr_ln_desc_t* d, const float* dy, const float* z, const float* mean,
+                              const float* rstd, const float* gamma, const uint64_t* seed, float* dx, void* da,
+                              float* dgamma, float* dbeta, void* stream);
+
+/* ---- F.glu / F.relu on the FFN hidden (module/ffn.py:15-21,40): u[M,F] = h[:, :F]*sigmoid(h[:, F:]) */
+int32_t otr_glu_fwd(const void* h, void* u, int32_t dtype, int64_t M, int64_t F, void* stream);
+/* dh[M,2F] from du[M,F]; if dbias != NULL, dbias[2F] (f32) += column sums of dh */
+int32_t otr_glu_bwd(const void* h, const void* du, void* dh, float* dbias, int32_t dtype, int64_t M, int64_t F,
+                    void* stream);
+
+/* ---- PositionalEncoding (module/pos.py:30-57): y = x*scale + PE[t], t = row % T.
+ *      x may alias y. */
+int32_t otr_posenc_fwd(const float* x, float* y, int64_t rows, int32_t T, int32_t d, float scale, void* stream);
+/* decoder embedding + posenc (decoder/transformer.py:163-169): y[r,:] = E[tok[r],:]*scale + PE[r % L] */
+int32_t otr_embed_posenc_fwd(const int64_t* tok, const float* E, float* y, int64_t rows, int32_t L, int32_t d,
+                             int32_t vocab, float scale, void* stream);
+/* dE[tok[r],:] += scale * dy[r,:]  (atomic f32) */
+int32_t otr_embed_bwd(const int64_t* tok, const float* dy, float* dE, int64_t rows, int32_t d, int32_t vocab,
+                      float scale, void* stream);
+/* y = x * (*s_dev) * s_host, elementwise f32 (n elements); x may alias y; s_dev may be NULL */
+int32_t otr_scale(const float* x, float* y, int64_t n, const float* s_dev, float s_host, void* stream);
+
+/* ---- Conv2d-subsampling frontend (frontend/conv.py:50-83 Conv2dLayer, :131-153 ConvFrontEnd).
+ *      Activations are channel-last: act1 [B,T1,F1,C1], act2 [B,T2,F2,C2] == [B*T2, F2*C2] rows
+ *      (the flatten of conv.py:145 becomes a column permutation of output_layer.weight). */
+typedef struct {
+  int32_t B, T, F;              /* input fbank [B,T,F] f32 */
+  int32_t C1, C2;               /* mid / out channels */
+  int32_t T1, F1, T2, F2;       /* derived: T1=(T-3)/2+1, F1=(F-1)/2+1, ... */
+  int32_t act_dtype, compute;
+} otr_conv_desc_t;
+/* conv1: 1->C1, 3x3, stride 2, pad (0,1), +bias, ReLU.  w1 f32 [C1,1,3,3] */
+int32_t otr_conv1_fwd(const otr_conv_desc_t* d, const float* x, const float* w1, const float* b1, void* act1,
+                      void* stream);
+/* dw1 [C1,9] f32 +=, db1 [C1] f32 += ; dact1 already masked by ReLU */
+int32_t otr_conv1_wgrad(const otr_conv_desc_t* d, const float* x, const void* dact1, float* dw1, float* db1,
+                        void* stream);
+/* conv2 as implicit GEMM on MFMA: w2r = w2 permuted to [C2,3,3,C1] (f32). +bias, ReLU */
+int32_t otr_conv2_fwd(const otr_conv_desc_t* d, const void* act1, const float* w2r, const float* b2, void* act2,
+                      void* stream);
+/* dcol[B*T2*F2, 9*C1] (act dtype) = dact2 * w2r  (dact2 already masked by ReLU) */
+int32_t otr_conv2_dgrad_cols(const otr_conv_desc_t* d, const void* dact2, const float* w2r, void* dcol,
+                             void* stream);
+/* dact1 = col2im(dcol) * (act1 > 0) */
+int32_t otr_conv2_col2im(const otr_conv_desc_t* d, const void* dcol, const void* act1, void* dact1, void* stream);
+/* dw2r [C2, 9*C1] f32 = dact2^T * im2col(act1) */
+int32_t otr_conv2_wgrad(const otr_conv_desc_t* d, const void* dact2, const void* act1, float* dw2r, void* stream);
+/* g = g * (y > 0) elementwise (ReLU backward through a stored post-ReLU activation); g may alias out */
+int32_t otr_relu_bwd(const void* y, const void* g, void* out, int32_t dtype, int64_t n, void* stream);
+
+/* ---- LabelSmoothingLoss (module/loss.py:21-48): logits f32 [R,V], target int64 [R].
+ *      loss (f32 scalar) = sum_nonpad KL(conf || softmax) / #nonpad ; dlogits = d loss / d logits.
+ *      scratch: f32[2] workspace. */
+int32_t otr_label_smoothing_loss(const float* logits, const int64_t* target, int64_t R, int32_t V, float smoothing,
+                                 int32_t pad_idx, float* loss, float* dlogits, float* scratch, void* stream);
+
+/* ---- log_softmax over the last dim, f32 [R,V] (model/ctc.py:51,66; decoder/transformer.py:206) */
+int32_t otr_log_softmax(const float* x, float* y, int64_t R, int32_t V, void* stream);
+
+/* ---- CTC loss with gradient w.r.t. the logits (nn.CTCLoss(blank, zero_infinity=True), reduction
+ *      'mean', as built at model/ctc.py:30 and called at :50-53).  log_probs f32 [B,T,V] (already
+ *      log-softmaxed), targets int64 [B, ldt], in_len/tgt_len int32 [B], max_tgt >= max(tgt_len) (<=127).
+ *      alpha_ws: f32 [B, T, 2*max_tgt+1] workspace; nll: f32 [B] (0 where infeasible);
+ *      loss: f32 scalar; dlogits f32 [B,T,V] or NULL. */
+int32_t otr_ctc_loss(const float* log_probs, const int64_t* targets, int64_t ldt, const int32_t* in_len,
+                     const int32_t* tgt_len, int32_t B, int32_t T, int32_t V, int32_t max_tgt, int32_t blank,
+                     float* alpha_ws, float* nll, float* loss, float* dlogits, void* stream);
+
+/* ---- one optimizer update over a replica's FLAT buffers (train/trainer.py:221-234 clip_grad_norm_(5) +
+ *      NaN guard + scheduler.step + optimizer.step; train/scheduler.py:129-138 Noam lr; torch Adam with
+ *      L2 weight decay, train/scheduler.py:10-13).  grad_scale (1/world_size after the all-reduce-sum)
+ *      is folded into clip + update.  state: f32[8] device block {step, lr, bc1, bc2, sqnorm, skipped},
+ *      zero-initialised by the caller once.  noam_warmup <= 0 selects the constant base_lr. */
+int32_t otr_optimizer_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                           float* state, float base_lr, float beta1, float beta2, float eps, float weight_decay,
+                           float grad_scale, float clip_norm, float noam_model_size, float noam_warmup,
+                           float noam_factor, float noam_step_offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OTRANS_HIP_H */

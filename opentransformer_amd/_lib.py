@@ -1,0 +1,106 @@
+"""ctypes binding of libotrans_hip.so (include/otrans_hip.h).
+
+This file is the "reference-side binding": the only thing between Python and the C ABI.  There is
+no fallback: if the library is missing or a symbol is absent, importing the ops raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libotrans_hip.so')
+
+OTR_F32, OTR_BF16 = 0, 1
+ACT_NONE, ACT_RELU = 0, 1
+
+
+class LinearDesc(C.Structure):
+    _fields_ = [('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+                ('x_dtype', C.c_int32), ('w_dtype', C.c_int32), ('y_dtype', C.c_int32), ('compute', C.c_int32),
+                ('ldx', C.c_int64), ('ldw', C.c_int64), ('ldy', C.c_int64),
+                ('act', C.c_int32), ('accumulate', C.c_int32)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [('B', C.c_int32), ('H', C.c_int32), ('Tq', C.c_int32), ('Tk', C.c_int32), ('dk', C.c_int32),
+                ('dtype', C.c_int32),
+                ('q_bs', C.c_int64), ('q_ts', C.c_int64), ('k_bs', C.c_int64), ('k_ts', C.c_int64),
+                ('v_bs', C.c_int64), ('v_ts', C.c_int64), ('o_bs', C.c_int64), ('o_ts', C.c_int64),
+                ('causal', C.c_int32), ('scale', C.c_float)]
+
+
+class LnDesc(C.Structure):
+    _fields_ = [('M', C.c_int64), ('d', C.c_int32), ('a_dtype', C.c_int32),
+                ('eps', C.c_float), ('p_drop', C.c_float), ('rng_offset', C.c_uint64)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('B', C.c_int32), ('T', C.c_int32), ('F', C.c_int32), ('C1', C.c_int32), ('C2', C.c_int32),
+                ('T1', C.c_int32), ('F1', C.c_int32), ('T2', C.c_int32), ('F2', C.c_int32),
+                ('act_dtype', C.c_int32), ('compute', C.c_int32)]
+
+
+_P = C.c_void_p
+_I32, _I64, _F32 = C.c_int32, C.c_int64, C.c_float
+
+# name -> argtypes (restype is int32 unless listed in _RESTYPE).  Must list every symbol that
+# include/otrans_hip.h declares; tests/test_cabi.py cross-checks the two.
+SIGNATURES = {
+    'otr_version': [],
+    'otr_last_error_string': [],
+    'otr_linear_fwd': [C.POINTER(LinearDesc), _P, _P, _P, _P, _P],
+    'otr_linear_dgrad': [C.POINTER(LinearDesc), _P, _P, _P, _P],
+    'otr_linear_wgrad': [C.POINTER(LinearDesc), _P, _P, _P, _P],
+    'otr_colsum': [_P, _I32, _I64, _I64, _I64, _P, _I32, _P],
+    'otr_attention_fwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P],
+    'otr_attention_bwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    'otr_add_layernorm_fwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    'otr_add_layernorm_bwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    'otr_glu_fwd': [_P, _P, _I32, _I64, _I64, _P],
+    'otr_glu_bwd': [_P, _P, _P, _P, _I32, _I64, _I64, _P],
+    'otr_posenc_fwd': [_P, _P, _I64, _I32, _I32, _F32, _P],
+    'otr_embed_posenc_fwd': [_P, _P, _P, _I64, _I32, _I32, _I32, _F32, _P],
+    'otr_embed_bwd': [_P, _P, _P, _I64, _I32, _I32, _F32, _P],
+    'otr_scale': [_P, _P, _I64, _P, _F32, _P],
+    'otr_conv1_fwd': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
+    'otr_conv1_wgrad': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
+    'otr_conv2_fwd': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
+    'otr_conv2_dgrad_cols': [C.POINTER(ConvDesc), _P, _P, _P, _P],
+    'otr_conv2_col2im': [C.POINTER(ConvDesc), _P, _P, _P, _P],
+    'otr_conv2_wgrad': [C.POINTER(ConvDesc), _P, _P, _P, _P],
+    'otr_relu_bwd': [_P, _P, _P, _I32, _I64, _P],
+    'otr_label_smoothing_loss': [_P, _P, _I64, _I32, _F32, _I32, _P, _P, _P, _P],
+    'otr_log_softmax': [_P, _P, _I64, _I32, _P],
+    'otr_ctc_loss': [_P, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    'otr_optimizer_step': [_P, _P, _P, _P, _I64, _P] + [_F32] * 11 + [_P],
+}
+_RESTYPE = {'otr_last_error_string': C.c_char_p}
+
+_lib = None
+
+
+class OtransHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library or raise -- never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OtransHipError(
+            'libotrans_hip.so not found at %s. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(or `make -C opentransformer_amd/csrc`). There is no CPU/PyTorch fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, C.c_int32)
+    _lib = lib
+    return lib
+
+
+def check(ret, what):
+    if ret != 0:
+        msg = load().otr_last_error_string()
+        raise OtransHipError('%s failed (%d): %s' % (what, ret, msg.decode() if msg else '?'))

@@ -1,0 +1,157 @@
+// C-ABI entry points: error plumbing, nn.Linear family (on the GEMM core), conv2 implicit GEMMs.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "gemm_kernel.h"
+
+static thread_local char g_err[512] = "";
+
+void otr_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int32_t otr_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    otr_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return (int32_t)e;
+  }
+  return 0;
+}
+
+extern "C" int32_t otr_version(void) { return 100; }
+extern "C" const char* otr_last_error_string(void) { return g_err; }
+
+static inline int esize(int dtype) { return dtype == OTR_F32 ? 4 : 2; }
+static inline bool dtype_ok(int d) { return d == OTR_F32 || d == OTR_BF16; }
+// vector path of the row-major loaders: 16-byte aligned base and rows
+static inline int kc_vec(const void* p, int64_t ld, int dtype) {
+  return ((uintptr_t)p % 16 == 0) && (ld % (16 / esize(dtype)) == 0);
+}
+// 2-element vector path of the transposing loaders
+static inline int mc_vec(const void* p, int64_t ld, int dtype) {
+  return ((uintptr_t)p % (2 * esize(dtype)) == 0) && (ld % 2 == 0);
+}
+
+static int32_t run_gemm(const GemmArgs& a, int compute, int ad, int bd, int cd, int amode, int bmode, void* stream) {
+  if (a.M <= 0 || a.N <= 0) return 0;
+  OTR_REQUIRE(a.K > 0, "gemm: K must be positive (got %d)", a.K);
+  hipStream_t s = (hipStream_t)stream;
+  if (compute == OTR_BF16) return gemm_dispatch_bf16(a, ad, bd, cd, amode, bmode, s);
+  if (compute == OTR_F32) return gemm_dispatch_f32(a, ad, bd, cd, amode, bmode, s);
+  otr_set_error("gemm: bad compute type %d", compute);
+  return -1;
+}
+
+static int32_t check_linear(const otr_linear_desc_t* d) {
+  OTR_REQUIRE(d != nullptr, "linear: null descriptor");
+  OTR_REQUIRE(d->M >= 0 && d->N >= 0 && d->K > 0, "linear: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+  OTR_REQUIRE(dtype_ok(d->x_dtype) && dtype_ok(d->w_dtype) && dtype_ok(d->y_dtype), "linear: bad dtype code");
+  OTR_REQUIRE(d->ldx >= d->K && d->ldw >= d->K && d->ldy >= d->N, "linear: leading dimension smaller than row");
+  return 0;
+}
+
+extern "C" int32_t otr_linear_fwd(const otr_linear_desc_t* d, const void* x, const void* w, const float* bias,
+                                  void* y, void* stream) {
+  if (int32_t e = check_linear(d)) return e;
+  OTR_REQUIRE(x && w && y, "linear_fwd: null pointer");
+  GemmArgs a{};
+  a.A = x; a.B = w; a.C = y; a.bias = bias;
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.lda = d->ldx; a.ldb = d->ldw; a.ldc = d->ldy;
+  a.act = d->act; a.accumulate = d->accumulate;
+  a.a_vec = kc_vec(x, d->ldx, d->x_dtype);
+  a.b_vec = kc_vec(w, d->ldw, d->w_dtype);
+  return run_gemm(a, d->compute, d->x_dtype, d->w_dtype, d->y_dtype, MODE_KC, MODE_KC, stream);
+}
+
+extern "C" int32_t otr_linear_dgrad(const otr_linear_desc_t* d, const void* dy, const void* w, void* dx,
+                                    void* stream) {
+  if (int32_t e = check_linear(d)) return e;
+  OTR_REQUIRE(dy && w && dx, "linear_dgrad: null pointer");
+  GemmArgs a{};  // dx[M,K] = dy[M,N] * w[N,K]: contraction over N; w is "rows(K)-contiguous"
+  a.A = dy; a.B = w; a.C = dx; a.bias = nullptr;
+  a.M = d->M; a.N = d->K; a.K = d->N;
+  a.lda = d->ldy; a.ldb = d->ldw; a.ldc = d->ldx;
+  a.act = OTR_ACT_NONE; a.accumulate = d->accumulate;
+  a.a_vec = kc_vec(dy, d->ldy, d->y_dtype);
+  a.b_vec = mc_vec(w, d->ldw, d->w_dtype);
+  return run_gemm(a, d->compute, d->y_dtype, d->w_dtype, d->x_dtype, MODE_KC, MODE_MC, stream);
+}
+
+extern "C" int32_t otr_linear_wgrad(const otr_linear_desc_t* d, const void* dy, const void* x, void* dw,
+                                    void* stream) {
+  if (int32_t e = check_linear(d)) return e;
+  OTR_REQUIRE(dy && x && dw, "linear_wgrad: null pointer");
+  GemmArgs a{};  // dw[N,K] = dy[M,N]^T * x[M,K]: contraction over M; both operands rows-contiguous
+  a.A = dy; a.B = x; a.C = dw; a.bias = nullptr;
+  a.M = d->N; a.N = d->K; a.K = d->M;
+  a.lda = d->ldy; a.ldb = d->ldx; a.ldc = d->ldw;
+  a.act = OTR_ACT_NONE; a.accumulate = d->accumulate;
+  a.a_vec = mc_vec(dy, d->ldy, d->y_dtype);
+  a.b_vec = mc_vec(x, d->ldx, d->x_dtype);
+  if (d->M == 0) return 0;
+  return run_gemm(a, d->compute, d->y_dtype, d->x_dtype, d->w_dtype, MODE_MC, MODE_MC, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv2 as implicit GEMM (frontend/conv.py:63-64 second Conv2dLayer)
+static int32_t conv_geom(const otr_conv_desc_t* d, ConvGeom& g) {
+  OTR_REQUIRE(d != nullptr, "conv: null descriptor");
+  OTR_REQUIRE(d->B > 0 && d->T >= 7 && d->F >= 3, "conv: bad input shape B=%d T=%d F=%d", d->B, d->T, d->F);
+  OTR_REQUIRE(d->T1 == (d->T - 3) / 2 + 1 && d->T2 == (d->T1 - 3) / 2 + 1, "conv: T1/T2 inconsistent with T");
+  OTR_REQUIRE(d->F1 == (d->F - 1) / 2 + 1 && d->F2 == (d->F1 - 1) / 2 + 1, "conv: F1/F2 inconsistent with F");
+  OTR_REQUIRE(d->C1 > 0 && d->C2 > 0 && d->C1 % 8 == 0, "conv: C1 must be a positive multiple of 8 (got %d)", d->C1);
+  OTR_REQUIRE(dtype_ok(d->act_dtype), "conv: bad act dtype");
+  OTR_REQUIRE((int64_t)d->B * d->T1 * d->F1 * d->C1 < (1ll << 31), "conv: act1 too large for 32-bit pixel index");
+  g.T1 = d->T1; g.F1 = d->F1; g.C1 = d->C1; g.T2 = d->T2; g.F2 = d->F2;
+  g.divF2 = make_fastdiv((uint32_t)d->F2);
+  g.divT2 = make_fastdiv((uint32_t)d->T2);
+  g.divC1 = make_fastdiv((uint32_t)d->C1);
+  return 0;
+}
+
+extern "C" int32_t otr_conv2_fwd(const otr_conv_desc_t* d, const void* act1, const float* w2r, const float* b2,
+                                 void* act2, void* stream) {
+  GemmArgs a{};
+  if (int32_t e = conv_geom(d, a.cg)) return e;
+  OTR_REQUIRE(act1 && w2r && act2, "conv2_fwd: null pointer");
+  a.A = act1; a.B = w2r; a.C = act2; a.bias = b2;
+  a.M = d->B * d->T2 * d->F2; a.N = d->C2; a.K = 9 * d->C1;
+  a.lda = 0; a.ldb = a.K; a.ldc = d->C2;
+  a.act = OTR_ACT_RELU; a.accumulate = 0;
+  a.a_vec = ((uintptr_t)act1 % 16 == 0);
+  a.b_vec = kc_vec(w2r, a.ldb, OTR_F32);
+  return run_gemm(a, d->compute, d->act_dtype, OTR_F32, d->act_dtype, MODE_IM2K, MODE_KC, stream);
+}
+
+extern "C" int32_t otr_conv2_dgrad_cols(const otr_conv_desc_t* d, const void* dact2, const float* w2r, void* dcol,
+                                        void* stream) {
+  GemmArgs a{};
+  if (int32_t e = conv_geom(d, a.cg)) return e;
+  OTR_REQUIRE(dact2 && w2r && dcol, "conv2_dgrad_cols: null pointer");
+  a.A = dact2; a.B = w2r; a.C = dcol; a.bias = nullptr;  // dcol[M2, 9*C1] = dact2[M2,C2] * w2r[C2, 9*C1]
+  a.M = d->B * d->T2 * d->F2; a.N = 9 * d->C1; a.K = d->C2;
+  a.lda = d->C2; a.ldb = 9 * d->C1; a.ldc = 9 * d->C1;
+  a.act = OTR_ACT_NONE; a.accumulate = 0;
+  a.a_vec = kc_vec(dact2, a.lda, d->act_dtype);
+  a.b_vec = mc_vec(w2r, a.ldb, OTR_F32);
+  return run_gemm(a, d->compute, d->act_dtype, OTR_F32, d->act_dtype, MODE_KC, MODE_MC, stream);
+}
+
+extern "C" int32_t otr_conv2_wgrad(const otr_conv_desc_t* d, const void* dact2, const void* act1, float* dw2r,
+                                   void* stream) {
+  GemmArgs a{};
+  if (int32_t e = conv_geom(d, a.cg)) return e;
+  OTR_REQUIRE(dact2 && act1 && dw2r, "conv2_wgrad: null pointer");
+  a.A = dact2; a.B = act1; a.C = dw2r; a.bias = nullptr;  // dw2r[C2, 9*C1] = dact2^T * im2col(act1)
+  a.M = d->C2; a.N = 9 * d->C1; a.K = d->B * d->T2 * d->F2;
+  a.lda = d->C2; a.ldb = 0; a.ldc = 9 * d->C1;
+  a.act = OTR_ACT_NONE; a.accumulate = 0;
+  a.a_vec = mc_vec(dact2, a.lda, d->act_dtype);
+  a.b_vec = 0;
+  return run_gemm(a, d->compute, d->act_dtype, d->act_dtype, OTR_F32, MODE_MC, MODE_IM2M, stream);
+}

@@ -1,0 +1,508 @@
+// Fused scaled-dot-product attention for gfx950, forward + backward, scores never leave registers.
+// Replaces module/attention.py:23-46 (compute_context) and the bmm/softmax/bmm around it.
+//
+// Layout trick used throughout: a 16x16 MFMA accumulator tile (col = lane&15, row = (lane>>4)*4+r)
+// can be fed straight back as an MFMA *input* chunk whose free index is the tile's column and whose
+// contraction index is the tile's row (any slot->k bijection is legal if A and B agree).  So we
+// always compute the score tile with the *contraction index of the next GEMM as its row*:
+//   forward / dQ : S^T = K Q^T   (rows = keys,  cols = queries)  -> O^T = V^T P^T, dQ^T = K^T dS^T
+//   dK,dV        : S   = Q K^T   (rows = queries, cols = keys)   -> dV^T = dO^T P, dK^T = Q^T dS
+// and P / dS go from accumulator registers to MFMA operands with only a bf16 pack: no LDS round trip,
+// no cross-lane shuffles except the 2-step row reductions across the four 16-lane groups.
+//
+// Workgroup = 4 waves; each wave owns 16 queries (fwd, dQ) or 16 keys (dKdV); the other side is
+// streamed through LDS in blocks of 64 rows: a row-major [64][dk] image (XOR-swizzled 16-B chunks)
+// for operands contracted over dk, and a transposed [dk][64] image for operands contracted over the
+// streamed index.
+#include <initializer_list>
+
+#include "common.h"
+
+struct AttnArgs {
+  const void *q, *k, *v, *o, *do_;
+  void *out, *dq, *dk, *dv;
+  const uint8_t* key_mask;
+  float* lse;
+  float* delta;
+  int B, H, Tq, Tk;
+  int64_t q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
+  int causal;
+  float scale;
+  int vec;  // all strides/base pointers allow 16-byte row chunks
+};
+
+template <class CT, int DK> struct ACfg {
+  static constexpr int CE = MMA<CT>::CE;
+  static constexpr int KSTEP = MMA<CT>::KSTEP;
+  static constexpr int TPC = MMA<CT>::TPC;
+  static constexpr int DKP = (DK + KSTEP - 1) / KSTEP * KSTEP;  // head dim padded to the MFMA k-step
+  static constexpr int NCH = DKP / CE;                          // 16-B chunks per row-major row
+  static constexpr int KS = DKP / KSTEP;                        // k-steps over the head dim
+  static constexpr int ROWB = NCH * 16;                         // bytes per row-major row
+  static constexpr int DT = DK / 16;                            // 16-wide d tiles
+  static constexpr int TSTRIDE = 64 * (int)sizeof(CT) + (sizeof(CT) == 2 ? 8 : 16);  // transposed row bytes
+  static constexpr int NC = 64 / KSTEP;                         // contraction chunks per 64-row block
+  static constexpr int RM_BYTES = 64 * ROWB;
+  static constexpr int TR_BYTES = DK * TSTRIDE;
+  static_assert(DK % 16 == 0, "head dim must be a multiple of 16");
+};
+
+// ---- row-major [64][DKP] tile: rows row0.. of a [T, ...] tensor (row stride ts elements) ----------
+template <class CT, int DK>
+__device__ __forceinline__ void load_tile_rm(unsigned char* lds, const CT* g, int64_t ts, int nvalid, bool vec, int tid) {
+  using C = ACfg<CT, DK>;
+  for (int id = tid; id < 64 * C::NCH; id += 256) {
+    int row = id / C::NCH, c = id - row * C::NCH;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (row < nvalid && c * C::CE < DK) {
+      const CT* p = g + (int64_t)row * ts + c * C::CE;
+      if (vec) {
+        val = *reinterpret_cast<const uint4*>(p);
+      } else {
+        float f[C::CE];
+#pragma unroll
+        for (int e = 0; e < C::CE; ++e) f[e] = ElemIO<CT>::ld(p + e);
+        val = MMA<CT>::pack(f);
+      }
+    }
+    *reinterpret_cast<uint4*>(lds + row * C::ROWB + ((c ^ swz<C::NCH>(row)) << 4)) = val;
+  }
+}
+template <class CT, int DK>
+__device__ __forceinline__ uint4 read_rm(const unsigned char* lds, int row, int chunk) {
+  using C = ACfg<CT, DK>;
+  return *reinterpret_cast<const uint4*>(lds + row * C::ROWB + ((chunk ^ swz<C::NCH>(row)) << 4));
+}
+
+// ---- transposed [DK][64] tile: element (d, j) = g[j*ts + d] -------------------------------------
+template <class CT, int DK>
+__device__ __forceinline__ void load_tile_tr(unsigned char* lds, const CT* g, int64_t ts, int nvalid, bool vec, int tid) {
+  using C = ACfg<CT, DK>;
+  constexpr int DP = DK / 2;
+  for (int id = tid; id < DP * 16; id += 256) {
+    int dp = id % DP, kg = id / DP;
+    float v0[4], v1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int row = kg * 4 + j;
+      v0[j] = 0.f; v1[j] = 0.f;
+      if (row < nvalid) {
+        const CT* p = g + (int64_t)row * ts + 2 * dp;
+        if (vec) {
+          if constexpr (sizeof(CT) == 4) {
+            float2 t = *reinterpret_cast<const float2*>(p);
+            v0[j] = t.x; v1[j] = t.y;
+          } else {
+            uint32_t t = *reinterpret_cast<const uint32_t*>(p);
+            v0[j] = __uint_as_float(t << 16); v1[j] = __uint_as_float(t & 0xffff0000u);
+          }
+        } else {
+          v0[j] = ElemIO<CT>::ld(p); v1[j] = ElemIO<CT>::ld(p + 1);
+        }
+      }
+    }
+    unsigned char* d0 = lds + (2 * dp) * C::TSTRIDE + kg * 4 * (int)sizeof(CT);
+    unsigned char* d1 = d0 + C::TSTRIDE;
+    if constexpr (sizeof(CT) == 2) {
+      *reinterpret_cast<uint2*>(d0) = make_uint2(pack2bf(v0[0], v0[1]), pack2bf(v0[2], v0[3]));
+      *reinterpret_cast<uint2*>(d1) = make_uint2(pack2bf(v1[0], v1[1]), pack2bf(v1[2], v1[3]));
+    } else {
+      *reinterpret_cast<float4*>(d0) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+      *reinterpret_cast<float4*>(d1) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+    }
+  }
+}
+// operand chunk c (KSTEP streamed rows) for row `row` of the transposed tile; slot layout matches
+// MMA<CT>::from_tiles: elements 0-3 <- streamed rows c*KSTEP + g*4.., elements 4-7 <- +16 (bf16)
+template <class CT, int DK>
+__device__ __forceinline__ uint4 read_tr(const unsigned char* lds, int row, int c, int g) {
+  using C = ACfg<CT, DK>;
+  const unsigned char* p = lds + row * C::TSTRIDE;
+  if constexpr (sizeof(CT) == 2) {
+    uint2 lo = *reinterpret_cast<const uint2*>(p + ((2 * c) * 16 + g * 4) * 2);
+    uint2 hi = *reinterpret_cast<const uint2*>(p + ((2 * c + 1) * 16 + g * 4) * 2);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+  } else {
+    return *reinterpret_cast<const uint4*>(p + (c * 16 + g * 4) * 4);
+  }
+}
+
+// per-wave register operand: 16 rows (row = lane&15) x DKP, chunk ks*4+g per k-step
+template <class CT, int DK>
+__device__ __forceinline__ void load_reg_frags(uint4* fr, const CT* g, int64_t ts, int row, int nrows, bool vec, int lg) {
+  using C = ACfg<CT, DK>;
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    int e0 = (ks * 4 + lg) * C::CE;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (row < nrows && e0 < DK) {
+      const CT* p = g + (int64_t)row * ts + e0;
+      if (vec) {
+        val = *reinterpret_cast<const uint4*>(p);
+      } else {
+        float f[C::CE];
+#pragma unroll
+        for (int e = 0; e < C::CE; ++e) f[e] = ElemIO<CT>::ld(p + e);
+        val = MMA<CT>::pack(f);
+      }
+    }
+    fr[ks] = val;
+  }
+}
+
+template <class CT> __device__ __forceinline__ float attn_exp(float x) {
+  if constexpr (sizeof(CT) == 4) return expf(x);
+  else return __expf(x);
+}
+
+// store 4 consecutive head-dim elements
+template <class CT> __device__ __forceinline__ void store4(CT* p, float a, float b, float c, float d, bool vec) {
+  if constexpr (sizeof(CT) == 4) {
+    if (vec) *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+    else { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+  } else {
+    if (vec) *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(a, b), pack2bf(c, d));
+    else { p[0] = f2bf(a); p[1] = f2bf(b); p[2] = f2bf(c); p[3] = f2bf(d); }
+  }
+}
+
+#define NEG_INF (-__builtin_huge_valf())
+
+// ================================================================================================ forward
+template <class CT, int DK> __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+  using C = ACfg<CT, DK>;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C::RM_BYTES + C::TR_BYTES];
+  unsigned char* sK = smem;
+  unsigned char* sVt = smem + C::RM_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lg = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 64 + wid * 16;
+  const bool vec = p.vec != 0;
+  const CT* Q = reinterpret_cast<const CT*>(p.q) + b * p.q_bs + h * DK;
+  const CT* K = reinterpret_cast<const CT*>(p.k) + b * p.k_bs + h * DK;
+  const CT* V = reinterpret_cast<const CT*>(p.v) + b * p.v_bs + h * DK;
+  const uint8_t* km = p.key_mask ? p.key_mask + (int64_t)b * p.Tk : nullptr;
+
+  uint4 qf[C::KS];
+  load_reg_frags<CT, DK>(qf, Q, p.q_ts, q0 + lr, p.Tq, vec, lg);
+  const int qrow = q0 + lr;
+
+  f32x4 acc[C::DT];
+#pragma unroll
+  for (int i = 0; i < C::DT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = NEG_INF, l = 0.f;
+
+  const int nkb = (p.Tk + 63) / 64;
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();
+    int nvalid = min(64, p.Tk - kb * 64);
+    load_tile_rm<CT, DK>(sK, K + (int64_t)kb * 64 * p.k_ts, p.k_ts, nvalid, vec, tid);
+    load_tile_tr<CT, DK>(sVt, V + (int64_t)kb * 64 * p.v_ts, p.v_ts, nvalid, vec, tid);
+    __syncthreads();
+
+    f32x4 st[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) MMA<CT>::mma(st[kt], read_rm<CT, DK>(sK, kt * 16 + lr, ks * 4 + lg), qf[ks]);
+    }
+    float bm = NEG_INF;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = kb * 64 + kt * 16 + lg * 4 + r;
+        bool ok = key < p.Tk && (!km || km[key]) && (!p.causal || key <= qrow);
+        float s = ok ? st[kt][r] * p.scale : NEG_INF;
+        st[kt][r] = s;
+        bm = fmaxf(bm, s);
+      }
+    bm = fmaxf(bm, __shfl_xor(bm, 16));
+    bm = fmaxf(bm, __shfl_xor(bm, 32));
+    float m_new = fmaxf(m, bm);
+    float m_safe = (m_new == NEG_INF) ? 0.f : m_new;
+    float alpha = attn_exp<CT>(m - m_safe);
+    float rs = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float e = attn_exp<CT>(st[kt][r] - m_safe);
+        st[kt][r] = e;
+        rs += e;
+      }
+    rs += __shfl_xor(rs, 16);
+    rs += __shfl_xor(rs, 32);
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < C::DT; ++i) acc[i] *= alpha;
+#pragma unroll
+    for (int c = 0; c < C::NC; ++c) {
+      uint4 pf = MMA<CT>::from_tiles(&st[c * C::TPC]);
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) MMA<CT>::mma(acc[dt], read_tr<CT, DK>(sVt, dt * 16 + lr, c, lg), pf);
+    }
+  }
+
+  if (qrow < p.Tq) {
+    float inv = l > 0.f ? 1.f / l : 0.f;
+    CT* O = reinterpret_cast<CT*>(p.out) + b * p.o_bs + (int64_t)qrow * p.o_ts + h * DK;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+      store4<CT>(O + dt * 16 + lg * 4, acc[dt][0] * inv, acc[dt][1] * inv, acc[dt][2] * inv, acc[dt][3] * inv, vec);
+    if (lg == 0) p.lse[((int64_t)b * p.H + h) * p.Tq + qrow] = (l > 0.f) ? m + logf(l) : NEG_INF;
+  }
+}
+
+// ================================================================================================ delta = rowsum(dO * O)
+template <class CT> __global__ void attn_delta_kernel(AttnArgs p, int dk) {
+  int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);  // (b,h,q) flattened
+  int sub = threadIdx.x & 15;
+  int64_t total = (int64_t)p.B * p.H * p.Tq;
+  float s = 0.f;
+  if (row < total) {
+    int q = (int)(row % p.Tq);
+    int64_t bh = row / p.Tq;
+    int h = (int)(bh % p.H), b = (int)(bh / p.H);
+    const CT* O = reinterpret_cast<const CT*>(p.o) + b * p.o_bs + (int64_t)q * p.o_ts + h * dk;
+    const CT* dO = reinterpret_cast<const CT*>(p.do_) + b * p.o_bs + (int64_t)q * p.o_ts + h * dk;
+    for (int d = sub; d < dk; d += 16) s += ElemIO<CT>::ld(O + d) * ElemIO<CT>::ld(dO + d);
+  }
+  s += __shfl_xor(s, 8);
+  s += __shfl_xor(s, 4);
+  s += __shfl_xor(s, 2);
+  s += __shfl_xor(s, 1);
+  if (row < total && sub == 0) p.delta[row] = s;
+}
+
+// ================================================================================================ dK, dV
+// wave owns 16 keys (columns); streams 64-query blocks.
+template <class CT, int DK> __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
+  using C = ACfg<CT, DK>;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C::RM_BYTES + 2 * C::TR_BYTES + 512];
+  unsigned char* sQ = smem;
+  unsigned char* sdO = smem + C::RM_BYTES;
+  unsigned char* sQt = smem + 2 * C::RM_BYTES;
+  unsigned char* sdOt = sQt + C::TR_BYTES;
+  float* sLse = reinterpret_cast<float*>(sdOt + C::TR_BYTES);
+  float* sDel = sLse + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lg = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int k0 = blockIdx.x * 64 + wid * 16;
+  const bool vec = p.vec != 0;
+  const CT* Q = reinterpret_cast<const CT*>(p.q) + b * p.q_bs + h * DK;
+  const CT* K = reinterpret_cast<const CT*>(p.k) + b * p.k_bs + h * DK;
+  const CT* V = reinterpret_cast<const CT*>(p.v) + b * p.v_bs + h * DK;
+  const CT* dO = reinterpret_cast<const CT*>(p.do_) + b * p.o_bs + h * DK;
+  const float* lse = p.lse + ((int64_t)b * p.H + h) * p.Tq;
+  const float* del = p.delta + ((int64_t)b * p.H + h) * p.Tq;
+  const int key = k0 + lr;
+  bool key_ok = key < p.Tk && (!p.key_mask || p.key_mask[(int64_t)b * p.Tk + key]);
+
+  uint4 kf[C::KS], vf[C::KS];
+  load_reg_frags<CT, DK>(kf, K, p.k_ts, key, p.Tk, vec, lg);
+  load_reg_frags<CT, DK>(vf, V, p.v_ts, key, p.Tk, vec, lg);
+
+  f32x4 dk_acc[C::DT], dv_acc[C::DT];
+#pragma unroll
+  for (int i = 0; i < C::DT; ++i) { dk_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int nqb = (p.Tq + 63) / 64;
+  for (int qb = 0; qb < nqb; ++qb) {
+    __syncthreads();
+    int nvalid = min(64, p.Tq - qb * 64);
+    load_tile_rm<CT, DK>(sQ, Q + (int64_t)qb * 64 * p.q_ts, p.q_ts, nvalid, vec, tid);
+    load_tile_rm<CT, DK>(sdO, dO + (int64_t)qb * 64 * p.o_ts, p.o_ts, nvalid, vec, tid);
+    load_tile_tr<CT, DK>(sQt, Q + (int64_t)qb * 64 * p.q_ts, p.q_ts, nvalid, vec, tid);
+    load_tile_tr<CT, DK>(sdOt, dO + (int64_t)qb * 64 * p.o_ts, p.o_ts, nvalid, vec, tid);
+    if (tid < 64) {
+      sLse[tid] = (tid < nvalid) ? lse[qb * 64 + tid] : 0.f;
+      sDel[tid] = (tid < nvalid) ? del[qb * 64 + tid] : 0.f;
+    }
+    __syncthreads();
+
+    f32x4 pt[4], ds[4];  // tiles over q (rows), cols = keys
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        MMA<CT>::mma(s, read_rm<CT, DK>(sQ, qt * 16 + lr, ks * 4 + lg), kf[ks]);
+        MMA<CT>::mma(dp, read_rm<CT, DK>(sdO, qt * 16 + lr, ks * 4 + lg), vf[ks]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int ql = qt * 16 + lg * 4 + r, qg = qb * 64 + ql;
+        float ls = sLse[ql];
+        bool ok = key_ok && qg < p.Tq && (!p.causal || key <= qg) && ls != NEG_INF;
+        float pe = ok ? attn_exp<CT>(s[r] * p.scale - ls) : 0.f;
+        pt[qt][r] = pe;
+        ds[qt][r] = pe * (dp[r] - sDel[ql]) * p.scale;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C::NC; ++c) {
+      uint4 pf = MMA<CT>::from_tiles(&pt[c * C::TPC]);
+      uint4 dsf = MMA<CT>::from_tiles(&ds[c * C::TPC]);
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        MMA<CT>::mma(dv_acc[dt], read_tr<CT, DK>(sdOt, dt * 16 + lr, c, lg), pf);
+        MMA<CT>::mma(dk_acc[dt], read_tr<CT, DK>(sQt, dt * 16 + lr, c, lg), dsf);
+      }
+    }
+  }
+  if (key < p.Tk) {
+    CT* dK = reinterpret_cast<CT*>(p.dk) + b * p.k_bs + (int64_t)key * p.k_ts + h * DK;
+    CT* dV = reinterpret_cast<CT*>(p.dv) + b * p.v_bs + (int64_t)key * p.v_ts + h * DK;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) {
+      store4<CT>(dK + dt * 16 + lg * 4, dk_acc[dt][0], dk_acc[dt][1], dk_acc[dt][2], dk_acc[dt][3], vec);
+      store4<CT>(dV + dt * 16 + lg * 4, dv_acc[dt][0], dv_acc[dt][1], dv_acc[dt][2], dv_acc[dt][3], vec);
+    }
+  }
+}
+
+// ================================================================================================ dQ
+// wave owns 16 queries (columns); streams 64-key blocks.
+template <class CT, int DK> __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+  using C = ACfg<CT, DK>;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C::RM_BYTES + C::TR_BYTES];
+  unsigned char* sK = smem;
+  unsigned char* sV = smem + C::RM_BYTES;
+  unsigned char* sKt = smem + 2 * C::RM_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lg = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 64 + wid * 16;
+  const bool vec = p.vec != 0;
+  const CT* Q = reinterpret_cast<const CT*>(p.q) + b * p.q_bs + h * DK;
+  const CT* K = reinterpret_cast<const CT*>(p.k) + b * p.k_bs + h * DK;
+  const CT* V = reinterpret_cast<const CT*>(p.v) + b * p.v_bs + h * DK;
+  const CT* dO = reinterpret_cast<const CT*>(p.do_) + b * p.o_bs + h * DK;
+  const uint8_t* km = p.key_mask ? p.key_mask + (int64_t)b * p.Tk : nullptr;
+  const int qrow = q0 + lr;
+  const bool q_ok = qrow < p.Tq;
+  const float ls = q_ok ? p.lse[((int64_t)b * p.H + h) * p.Tq + qrow] : NEG_INF;
+  const float dl = q_ok ? p.delta[((int64_t)b * p.H + h) * p.Tq + qrow] : 0.f;
+
+  uint4 qf[C::KS], dof[C::KS];
+  load_reg_frags<CT, DK>(qf, Q, p.q_ts, qrow, p.Tq, vec, lg);
+  load_reg_frags<CT, DK>(dof, dO, p.o_ts, qrow, p.Tq, vec, lg);
+
+  f32x4 acc[C::DT];
+#pragma unroll
+  for (int i = 0; i < C::DT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkb = (p.Tk + 63) / 64;
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();
+    int nvalid = min(64, p.Tk - kb * 64);
+    load_tile_rm<CT, DK>(sK, K + (int64_t)kb * 64 * p.k_ts, p.k_ts, nvalid, vec, tid);
+    load_tile_rm<CT, DK>(sV, V + (int64_t)kb * 64 * p.v_ts, p.v_ts, nvalid, vec, tid);
+    load_tile_tr<CT, DK>(sKt, K + (int64_t)kb * 64 * p.k_ts, p.k_ts, nvalid, vec, tid);
+    __syncthreads();
+
+    f32x4 ds[4];  // tiles over keys (rows), cols = queries
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        MMA<CT>::mma(s, read_rm<CT, DK>(sK, kt * 16 + lr, ks * 4 + lg), qf[ks]);
+        MMA<CT>::mma(dp, read_rm<CT, DK>(sV, kt * 16 + lr, ks * 4 + lg), dof[ks]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = kb * 64 + kt * 16 + lg * 4 + r;
+        bool ok = q_ok && ls != NEG_INF && key < p.Tk && (!km || km[key]) && (!p.causal || key <= qrow);
+        float pe = ok ? attn_exp<CT>(s[r] * p.scale - ls) : 0.f;
+        ds[kt][r] = pe * (dp[r] - dl) * p.scale;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C::NC; ++c) {
+      uint4 dsf = MMA<CT>::from_tiles(&ds[c * C::TPC]);
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) MMA<CT>::mma(acc[dt], read_tr<CT, DK>(sKt, dt * 16 + lr, c, lg), dsf);
+    }
+  }
+  if (q_ok) {
+    CT* dQ = reinterpret_cast<CT*>(p.dq) + b * p.q_bs + (int64_t)qrow * p.q_ts + h * DK;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+      store4<CT>(dQ + dt * 16 + lg * 4, acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3], vec);
+  }
+}
+
+// ================================================================================================ host side
+static int32_t fill_args(const otr_attn_desc_t* d, AttnArgs& a) {
+  OTR_REQUIRE(d != nullptr, "attention: null descriptor");
+  OTR_REQUIRE(d->B > 0 && d->H > 0 && d->Tq > 0 && d->Tk > 0, "attention: bad shape B=%d H=%d Tq=%d Tk=%d", d->B, d->H,
+              d->Tq, d->Tk);
+  OTR_REQUIRE(d->dtype == OTR_F32 || d->dtype == OTR_BF16, "attention: bad dtype %d", d->dtype);
+  OTR_REQUIRE(d->dk == 16 || d->dk == 32 || d->dk == 64 || d->dk == 96 || d->dk == 128,
+              "attention: head dim %d not built (16/32/64/96/128)", d->dk);
+  a.B = d->B; a.H = d->H; a.Tq = d->Tq; a.Tk = d->Tk;
+  a.q_bs = d->q_bs; a.q_ts = d->q_ts; a.k_bs = d->k_bs; a.k_ts = d->k_ts;
+  a.v_bs = d->v_bs; a.v_ts = d->v_ts; a.o_bs = d->o_bs; a.o_ts = d->o_ts;
+  a.causal = d->causal; a.scale = d->scale;
+  return 0;
+}
+static int vec_ok(const otr_attn_desc_t* d, std::initializer_list<const void*> ptrs) {
+  int ce = d->dtype == OTR_F32 ? 4 : 8;
+  int64_t strides[] = {d->q_bs, d->q_ts, d->k_bs, d->k_ts, d->v_bs, d->v_ts, d->o_bs, d->o_ts};
+  for (int64_t s : strides)
+    if (s % ce) return 0;
+  if (d->dk % ce) return 0;
+  for (const void* p : ptrs)
+    if (p && ((uintptr_t)p % 16)) return 0;
+  return 1;
+}
+
+#define DK_SWITCH(CTYPE, KERNEL, GRID)                                                                    \
+  switch (d->dk) {                                                                                        \
+    case 16: hipLaunchKernelGGL((KERNEL<CTYPE, 16>), GRID, dim3(256), 0, s, a); break;                    \
+    case 32: hipLaunchKernelGGL((KERNEL<CTYPE, 32>), GRID, dim3(256), 0, s, a); break;                    \
+    case 64: hipLaunchKernelGGL((KERNEL<CTYPE, 64>), GRID, dim3(256), 0, s, a); break;                    \
+    case 96: hipLaunchKernelGGL((KERNEL<CTYPE, 96>), GRID, dim3(256), 0, s, a); break;                    \
+    default: hipLaunchKernelGGL((KERNEL<CTYPE, 128>), GRID, dim3(256), 0, s, a); break;                   \
+  }
+
+extern "C" int32_t otr_attention_fwd(const otr_attn_desc_t* d, const void* q, const void* k, const void* v,
+                                     const uint8_t* key_mask, void* o, float* lse, void* stream) {
+  AttnArgs a{};
+  if (int32_t e = fill_args(d, a)) return e;
+  OTR_REQUIRE(q && k && v && o && lse, "attention_fwd: null pointer");
+  a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse; a.key_mask = key_mask;
+  a.vec = vec_ok(d, {q, k, v, o});
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((d->Tq + 63) / 64, d->H, d->B);
+  if (d->dtype == OTR_BF16) { DK_SWITCH(bf16_t, attn_fwd_kernel, grid) } else { DK_SWITCH(float, attn_fwd_kernel, grid) }
+  return otr_check_launch("attention_fwd");
+}
+
+extern "C" int32_t otr_attention_bwd(const otr_attn_desc_t* d, const void* q, const void* k, const void* v,
+                                     const uint8_t* key_mask, const void* o, const void* do_, const float* lse,
+                                     float* delta, void* dq, void* dk, void* dv, void* stream) {
+  AttnArgs a{};
+  if (int32_t e = fill_args(d, a)) return e;
+  OTR_REQUIRE(q && k && v && o && do_ && lse && delta && dq && dk && dv, "attention_bwd: null pointer");
+  a.q = q; a.k = k; a.v = v; a.o = o; a.do_ = do_; a.lse = const_cast<float*>(lse); a.delta = delta;
+  a.dq = dq; a.dk = dk; a.dv = dv; a.key_mask = key_mask;
+  a.vec = vec_ok(d, {q, k, v, o, do_, dq, dk, dv});
+  hipStream_t s = (hipStream_t)stream;
+  int64_t rows = (int64_t)d->B * d->H * d->Tq;
+  dim3 gd((unsigned)((rows + 15) / 16));
+  if (d->dtype == OTR_BF16) hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, gd, dim3(256), 0, s, a, d->dk);
+  else hipLaunchKernelGGL(attn_delta_kernel<float>, gd, dim3(256), 0, s, a, d->dk);
+  dim3 gk((d->Tk + 63) / 64, d->H, d->B), gq((d->Tq + 63) / 64, d->H, d->B);
+  if (d->dtype == OTR_BF16) {
+    DK_SWITCH(bf16_t, attn_bwd_dkdv_kernel, gk)
+    DK_SWITCH(bf16_t, attn_bwd_dq_kernel, gq)
+  } else {
+    DK_SWITCH(float, attn_bwd_dkdv_kernel, gk)
+    DK_SWITCH(float, attn_bwd_dq_kernel, gq)
+  }
+  return otr_check_launch("attention_bwd");
+}

@@ -1,0 +1,197 @@
+// Shared device/host helpers for libotrans_hip.so (gfx950 / CDNA4 only).
+//
+// Conventions used by every kernel in this library:
+//  * wave = 64 lanes; workgroups are 256 threads (4 waves) unless stated.
+//  * "chunk" = 16 bytes of the compute type CT: 8 bf16 or 4 f32.  One MFMA k-step consumes one
+//    chunk per lane for A and one for B:
+//      bf16: v_mfma_f32_16x16x32_bf16, lane l holds row (l&15), k = (l>>4)*8 + 0..7
+//      f32 : 4 x v_mfma_f32_16x16x4_f32; instruction i contracts k = {g*4+i : g=0..3}, so lane l
+//            again holds row (l&15), k = (l>>4)*4 + 0..3   (any k-bijection is legal as long as
+//            A and B use the same one)
+//    so both compute types share one LDS geometry: a 16-byte chunk per (row, l>>4).
+//  * C/D layout of every 16x16 MFMA (dtype independent): col = lane&15, row = (lane>>4)*4 + reg.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/otrans_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef uint16_t bf16_t;  // raw bf16 bits in memory
+
+// ---------------------------------------------------------------- error plumbing (host)
+void otr_set_error(const char* fmt, ...);
+int32_t otr_check_launch(const char* what);
+#define OTR_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      otr_set_error(__VA_ARGS__);       \
+      return -1;                        \
+    }                                   \
+  } while (0)
+
+// ---------------------------------------------------------------- scalar conversions
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // RNE, lowers to v_cvt_pk_bf16_f32
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  f32x2 v = {lo, hi};
+  bf16x2 h = __builtin_convertvector(v, bf16x2);
+  return __builtin_bit_cast(uint32_t, h);
+}
+
+template <class T> struct ElemIO;
+template <> struct ElemIO<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct ElemIO<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// ---------------------------------------------------------------- compute-type traits
+// CT = float | bf16_t.  Chunk = uint4 (16 B) holding CE elements of CT.
+template <class CT> struct MMA;
+template <> struct MMA<bf16_t> {
+  static constexpr int CE = 8;       // elements per 16-byte chunk
+  static constexpr int KSTEP = 32;   // contraction length of one mma() call
+  static constexpr int TPC = 2;      // 16-wide C tiles that make up one contraction chunk
+  static __device__ __forceinline__ void mma(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                  acc, 0, 0, 0);
+  }
+  // pack CE floats into a chunk
+  static __device__ __forceinline__ uint4 pack(const float* f) {
+    uint4 r;
+    r.x = pack2bf(f[0], f[1]);
+    r.y = pack2bf(f[2], f[3]);
+    r.z = pack2bf(f[4], f[5]);
+    r.w = pack2bf(f[6], f[7]);
+    return r;
+  }
+  // Build the contraction-operand chunk from TPC accumulator tiles (C layout, rows = contraction
+  // index).  Element j<4 <- tile0[j] (contraction row g*4+j of the first 16), j>=4 <- tile1[j-4].
+  static __device__ __forceinline__ uint4 from_tiles(const f32x4* t) {
+    uint4 r;
+    r.x = pack2bf(t[0][0], t[0][1]);
+    r.y = pack2bf(t[0][2], t[0][3]);
+    r.z = pack2bf(t[1][0], t[1][1]);
+    r.w = pack2bf(t[1][2], t[1][3]);
+    return r;
+  }
+};
+template <> struct MMA<float> {
+  static constexpr int CE = 4;
+  static constexpr int KSTEP = 16;
+  static constexpr int TPC = 1;
+  static __device__ __forceinline__ void mma(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint4 pack(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+  }
+  static __device__ __forceinline__ uint4 from_tiles(const f32x4* t) {
+    return make_uint4(__float_as_uint(t[0][0]), __float_as_uint(t[0][1]), __float_as_uint(t[0][2]),
+                      __float_as_uint(t[0][3]));
+  }
+};
+
+// Load N consecutive elements of source type ST starting at p into floats.  `nvalid` elements are
+// in range (rest become 0); `vec` says p is 16-byte aligned for the vector path.
+template <class ST, int N>
+__device__ __forceinline__ void load_row(const ST* p, int nvalid, bool vec, float* out) {
+  if (vec && nvalid >= N) {
+    if constexpr (sizeof(ST) == 4) {
+#pragma unroll
+      for (int i = 0; i < N; i += 4) {
+        float4 v = *reinterpret_cast<const float4*>(p + i);
+        out[i] = v.x; out[i + 1] = v.y; out[i + 2] = v.z; out[i + 3] = v.w;
+      }
+    } else {
+      if constexpr (N == 8) {
+        uint4 v = *reinterpret_cast<const uint4*>(p);
+        out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xffff0000u);
+        out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xffff0000u);
+        out[4] = __uint_as_float(v.z << 16); out[5] = __uint_as_float(v.z & 0xffff0000u);
+        out[6] = __uint_as_float(v.w << 16); out[7] = __uint_as_float(v.w & 0xffff0000u);
+      } else {
+        static_assert(N == 4, "bf16 rows are read 4 or 8 at a time");
+        uint2 v = *reinterpret_cast<const uint2*>(p);
+        out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xffff0000u);
+        out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xffff0000u);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = (i < nvalid) ? ElemIO<ST>::ld(p + i) : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------- LDS swizzles
+// Row-major tile of 16-byte chunks, NCH chunks per row.  A 16-lane MFMA operand read touches 16
+// consecutive rows at one logical chunk; swz() spreads those 16 accesses over all 64 banks.
+// NCH=4 (64-B rows): ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27},{4-11,16-19,28-31}
+// (+32), i.e. rows {0-3,12-15} at chunk g together with rows {4-11} at chunk g^1; the lookup
+// {0,2,3,1}[(row>>2)&3] makes all 16 (row&3, chunk) slots of such a group distinct.
+template <int NCH> __device__ __forceinline__ int swz(int row) {
+  if constexpr (NCH == 4) return (0x78 >> (((row >> 2) & 3) * 2)) & 3;
+  else if constexpr (NCH == 8) return (row >> 1) & 7;
+  else if constexpr (NCH == 16) return row & 15;
+  else return 0;
+}
+
+// ---------------------------------------------------------------- wave reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// counter-based RNG for dropout: one 32-bit draw per element index (SplitMix64 finaliser)
+__device__ __forceinline__ uint32_t otr_rand32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+
+// fast unsigned division by a runtime constant (host-computed magic), valid for n < 2^31
+struct FastDiv {
+  uint32_t d, magic, shift;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  if (d == 1) {
+    f.magic = 0;
+    f.shift = 0;
+    return f;
+  }
+  uint32_t s = 0;
+  while ((1u << s) < d) ++s;
+  uint64_t m = ((1ull << (32 + s)) + d - 1) / d;  // ceil(2^(32+s)/d); fits in 33 bits
+  f.magic = (uint32_t)(m - (1ull << 32));         // store low 32 bits (the 2^32 term is added back)
+  f.shift = s;
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  if (f.d == 1) return n;
+  uint32_t t = __umulhi(n, f.magic);
+  // (n*(2^32+magic)) >> (32+shift) == (t + n) >> shift, computed without overflow
+  return (t + ((n - t) >> 1)) >> (f.shift - 1);
+}

@@ -1,0 +1,226 @@
+// Bandwidth-bound glue kernels: GLU, positional encoding, embedding, column sums, scaling.
+// All are vectorised 16 B per lane where the layout allows and sized as grid-stride loops.
+#include "common.h"
+
+static inline unsigned grid_for(int64_t work_items, int block = 256, int64_t cap = 2048 * 4) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (unsigned)g;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------ GLU
+// F.glu(h, -1): u = h[:, :F] * sigmoid(h[:, F:])     (module/ffn.py:18,40)
+template <class T> __global__ void glu_fwd_kernel(const T* h, T* u, int64_t M, int64_t F) {
+  constexpr int V = 16 / sizeof(T);
+  const int64_t per_row = F / V, total = M * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = i / per_row, c = (i - row * per_row) * V;
+    float a[V], g[V], o[V];
+    load_row<T, V>(h + row * 2 * F + c, V, true, a);
+    load_row<T, V>(h + row * 2 * F + F + c, V, true, g);
+#pragma unroll
+    for (int e = 0; e < V; ++e) o[e] = a[e] * sigmoidf_(g[e]);
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(u + row * F + c) = make_float4(o[0], o[1], o[2], o[3]);
+    else *reinterpret_cast<uint4*>(u + row * F + c) = MMA<bf16_t>::pack(o);
+  }
+}
+
+// dh[:, :F] = du * sig(g);  dh[:, F:] = du * a * sig(g) * (1 - sig(g));  optional dbias[2F] += colsum(dh)
+constexpr int GLU_RPB = 32;  // rows per block in the backward (each thread owns V columns)
+template <class T> __global__ void glu_bwd_kernel(const T* h, const T* du, T* dh, float* dbias, int64_t M, int64_t F) {
+  constexpr int V = 16 / sizeof(T);
+  const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+  if (c >= F) return;
+  float sa[V], sg[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { sa[e] = 0.f; sg[e] = 0.f; }
+  const int64_t r0 = (int64_t)blockIdx.y * GLU_RPB, r1 = min(M, r0 + GLU_RPB);
+  for (int64_t row = r0; row < r1; ++row) {
+    float a[V], g[V], d[V], oa[V], og[V];
+    load_row<T, V>(h + row * 2 * F + c, V, true, a);
+    load_row<T, V>(h + row * 2 * F + F + c, V, true, g);
+    load_row<T, V>(du + row * F + c, V, true, d);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float s = sigmoidf_(g[e]);
+      oa[e] = d[e] * s;
+      og[e] = d[e] * a[e] * s * (1.f - s);
+      sa[e] += oa[e]; sg[e] += og[e];
+    }
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(dh + row * 2 * F + c) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+      *reinterpret_cast<float4*>(dh + row * 2 * F + F + c) = make_float4(og[0], og[1], og[2], og[3]);
+    } else {
+      *reinterpret_cast<uint4*>(dh + row * 2 * F + c) = MMA<bf16_t>::pack(oa);
+      *reinterpret_cast<uint4*>(dh + row * 2 * F + F + c) = MMA<bf16_t>::pack(og);
+    }
+  }
+  if (dbias) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) { atomicAdd(dbias + c + e, sa[e]); atomicAdd(dbias + F + c + e, sg[e]); }
+  }
+}
+
+extern "C" int32_t otr_glu_fwd(const void* h, void* u, int32_t dtype, int64_t M, int64_t F, void* stream) {
+  OTR_REQUIRE(h && u, "glu_fwd: null pointer");
+  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_BF16, "glu_fwd: bad dtype");
+  OTR_REQUIRE(F > 0 && F % 8 == 0 && M >= 0, "glu_fwd: F=%lld must be a positive multiple of 8", (long long)F);
+  if (M == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OTR_F32) hipLaunchKernelGGL(glu_fwd_kernel<float>, dim3(grid_for(M * F / 4)), dim3(256), 0, s, (const float*)h, (float*)u, M, F);
+  else hipLaunchKernelGGL(glu_fwd_kernel<bf16_t>, dim3(grid_for(M * F / 8)), dim3(256), 0, s, (const bf16_t*)h, (bf16_t*)u, M, F);
+  return otr_check_launch("glu_fwd");
+}
+
+extern "C" int32_t otr_glu_bwd(const void* h, const void* du, void* dh, float* dbias, int32_t dtype, int64_t M,
+                               int64_t F, void* stream) {
+  OTR_REQUIRE(h && du && dh, "glu_bwd: null pointer");
+  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_BF16, "glu_bwd: bad dtype");
+  OTR_REQUIRE(F > 0 && F % 8 == 0 && M >= 0, "glu_bwd: F=%lld must be a positive multiple of 8", (long long)F);
+  if (M == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  int V = dtype == OTR_F32 ? 4 : 8;
+  dim3 grid((unsigned)((F / V + 255) / 256), (unsigned)((M + GLU_RPB - 1) / GLU_RPB));
+  if (dtype == OTR_F32) hipLaunchKernelGGL(glu_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)h, (const float*)du, (float*)dh, dbias, M, F);
+  else hipLaunchKernelGGL(glu_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)h, (const bf16_t*)du, (bf16_t*)dh, dbias, M, F);
+  return otr_check_launch("glu_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------ ReLU bwd
+template <class T> __global__ void relu_bwd_kernel(const T* y, const T* g, T* out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    ElemIO<T>::st(out + i, ElemIO<T>::ld(y + i) > 0.f ? ElemIO<T>::ld(g + i) : 0.f);
+}
+extern "C" int32_t otr_relu_bwd(const void* y, const void* g, void* out, int32_t dtype, int64_t n, void* stream) {
+  OTR_REQUIRE(y && g && out, "relu_bwd: null pointer");
+  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_BF16, "relu_bwd: bad dtype");
+  if (n <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OTR_F32) hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)y, (const float*)g, (float*)out, n);
+  else hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)y, (const bf16_t*)g, (bf16_t*)out, n);
+  return otr_check_launch("relu_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------ posenc / embedding
+// PE[t, 2i] = sin(t * exp(-2i ln(1e4)/d)), PE[t, 2i+1] = cos(same)        (module/pos.py:30-42)
+__device__ __forceinline__ float pe_value(int t, int col, float neg_ln_over_d) {
+  float div = expf((float)(col & ~1) * neg_ln_over_d);
+  float ang = (float)t * div;
+  return (col & 1) ? cosf(ang) : sinf(ang);
+}
+
+__global__ void posenc_kernel(const float* x, float* y, int64_t rows, int T, int d, float scale) {
+  const float nl = -logf(10000.f) / (float)d;
+  const int64_t total = rows * d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = i / d;
+    int col = (int)(i - row * d);
+    y[i] = x[i] * scale + pe_value((int)(row % T), col, nl);
+  }
+}
+extern "C" int32_t otr_posenc_fwd(const float* x, float* y, int64_t rows, int32_t T, int32_t d, float scale,
+                                  void* stream) {
+  OTR_REQUIRE(x && y, "posenc_fwd: null pointer");
+  OTR_REQUIRE(T > 0 && d > 0 && rows >= 0, "posenc_fwd: bad shape");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(posenc_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, x, y, rows, T, d, scale);
+  return otr_check_launch("posenc_fwd");
+}
+
+__global__ void embed_posenc_kernel(const int64_t* tok, const float* E, float* y, int64_t rows, int L, int d, int vocab,
+                                    float scale) {
+  const float nl = -logf(10000.f) / (float)d;
+  const int64_t total = rows * d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = i / d;
+    int col = (int)(i - row * d);
+    int64_t t = tok[row];
+    float e = (t >= 0 && t < vocab) ? E[t * d + col] : 0.f;
+    y[i] = e * scale + pe_value((int)(row % L), col, nl);
+  }
+}
+extern "C" int32_t otr_embed_posenc_fwd(const int64_t* tok, const float* E, float* y, int64_t rows, int32_t L, int32_t d,
+                                        int32_t vocab, float scale, void* stream) {
+  OTR_REQUIRE(tok && E && y, "embed_posenc_fwd: null pointer");
+  OTR_REQUIRE(L > 0 && d > 0 && vocab > 0 && rows >= 0, "embed_posenc_fwd: bad shape");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(embed_posenc_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, tok, E, y, rows, L, d, vocab, scale);
+  return otr_check_launch("embed_posenc_fwd");
+}
+
+__global__ void embed_bwd_kernel(const int64_t* tok, const float* dy, float* dE, int64_t rows, int d, int vocab, float scale) {
+  const int64_t total = rows * d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = i / d;
+    int col = (int)(i - row * d);
+    int64_t t = tok[row];
+    if (t >= 0 && t < vocab) atomicAdd(dE + t * d + col, dy[i] * scale);
+  }
+}
+extern "C" int32_t otr_embed_bwd(const int64_t* tok, const float* dy, float* dE, int64_t rows, int32_t d, int32_t vocab,
+                                 float scale, void* stream) {
+  OTR_REQUIRE(tok && dy && dE, "embed_bwd: null pointer");
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, tok, dy, dE, rows, d, vocab, scale);
+  return otr_check_launch("embed_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------ scale
+__global__ void scale_kernel(const float* x, float* y, int64_t n, const float* s_dev, float s_host) {
+  const float s = (s_dev ? *s_dev : 1.f) * s_host;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = x[i] * s;
+}
+extern "C" int32_t otr_scale(const float* x, float* y, int64_t n, const float* s_dev, float s_host, void* stream) {
+  OTR_REQUIRE(x && y, "scale: null pointer");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, s_dev, s_host);
+  return otr_check_launch("scale");
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+// out[n] (+)= sum_m a[m, n].  block (64 x 4): x -> 4 consecutive columns per lane, y -> row lanes.
+constexpr int CS_RPB = 128;
+template <class T> __global__ void colsum_kernel(const T* a, int64_t M, int64_t N, int64_t lda, float* out) {
+  __shared__ float red[4][64][4];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int64_t c = ((int64_t)blockIdx.x * 64 + tx) * 4;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < N) {
+    const int64_t r0 = (int64_t)blockIdx.y * CS_RPB, r1 = min(M, r0 + CS_RPB);
+    const bool full = c + 4 <= N && (lda % 4 == 0);
+    for (int64_t r = r0 + ty; r < r1; r += 4) {
+      float v[4];
+      load_row<T, 4>(a + r * lda + c, (int)min((int64_t)4, N - c), full, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[ty][tx][e] = s[e];
+  __syncthreads();
+  if (ty == 0 && c < N) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < N) atomicAdd(out + c + e, red[0][tx][e] + red[1][tx][e] + red[2][tx][e] + red[3][tx][e]);
+  }
+}
+extern "C" int32_t otr_colsum(const void* a, int32_t dtype, int64_t M, int64_t N, int64_t lda, float* out,
+                              int32_t accumulate, void* stream) {
+  OTR_REQUIRE(a && out, "colsum: null pointer");
+  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_BF16, "colsum: bad dtype");
+  OTR_REQUIRE(N > 0 && M >= 0 && lda >= N, "colsum: bad shape");
+  OTR_REQUIRE((uintptr_t)a % 16 == 0, "colsum: input must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
+    if (e != hipSuccess) { otr_set_error("colsum: memset failed: %s", hipGetErrorString(e)); return (int32_t)e; }
+  }
+  if (M == 0) return 0;
+  dim3 grid((unsigned)((N + 255) / 256), (unsigned)((M + CS_RPB - 1) / CS_RPB)), block(64, 4);
+  if (dtype == OTR_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)a, M, N, lda, out);
+  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)a, M, N, lda, out);
+  return otr_check_launch("colsum");
+}

@@ -1,0 +1,22 @@
+// fp32-MFMA instantiations of the GEMM core (v_mfma_f32_16x16x4_f32: exact fp32, the parity mode).
+#include "gemm_kernel.h"
+
+#define CASE(AM, BM_) return gemm_launch_tiles<float, float, float, float, AM, BM_>(a, s)
+
+int32_t gemm_dispatch_f32(const GemmArgs& a, int ad, int bd, int cd, int amode, int bmode, hipStream_t s) {
+  if (ad != OTR_F32 || bd != OTR_F32 || cd != OTR_F32) {
+    otr_set_error("gemm(f32): all operands must be f32 (got a=%d b=%d c=%d)", ad, bd, cd);
+    return -2;
+  }
+  const int key = (amode << 4) | bmode;
+  switch (key) {
+    case (MODE_KC << 4) | MODE_KC: CASE(MODE_KC, MODE_KC);
+    case (MODE_KC << 4) | MODE_MC: CASE(MODE_KC, MODE_MC);
+    case (MODE_MC << 4) | MODE_MC: CASE(MODE_MC, MODE_MC);
+    case (MODE_IM2K << 4) | MODE_KC: CASE(MODE_IM2K, MODE_KC);
+    case (MODE_MC << 4) | MODE_IM2M: CASE(MODE_MC, MODE_IM2M);
+    default:
+      otr_set_error("gemm(f32): unsupported combination amode=%d bmode=%d", amode, bmode);
+      return -2;
+  }
+}

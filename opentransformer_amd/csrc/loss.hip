@@ -1,0 +1,99 @@
+// Row-reduction kernels over the vocabulary axis:
+//  * LabelSmoothingLoss forward + gradient in one pass (module/loss.py:21-48)
+//  * log_softmax (model/ctc.py:51,66; decoder/transformer.py:206)
+// One 256-thread block per row; the row (V <= ~32k fp32) is read twice from L2/HBM.
+#include "common.h"
+
+__device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wid] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
+  return r;
+}
+
+// scratch[0] = number of non-pad rows; loss zeroed
+__global__ void ls_count_kernel(const int64_t* target, int64_t R, int pad_idx, float* scratch, float* loss) {
+  __shared__ float sh[4];
+  float c = 0.f;
+  for (int64_t i = threadIdx.x; i < R; i += blockDim.x) c += (target[i] != pad_idx) ? 1.f : 0.f;
+  c = block_reduce(c, sh, false);
+  if (threadIdx.x == 0) { scratch[0] = c; *loss = 0.f; }
+}
+
+// KL(conf || softmax(logits)) per row, conf = 1-eps on the target, eps/(V-1) elsewhere.
+//   row_loss = C - [ (1-eps) logp_t + eps/(V-1) (sum_v logp_v - logp_t) ],
+//   C = (1-eps) log(1-eps) + eps log(eps/(V-1))        (0 log 0 := 0, as torch's kl_div)
+//   d row_loss / d logit_v = softmax_v - conf_v
+__global__ __launch_bounds__(256) void ls_rows_kernel(const float* logits, const int64_t* target, int V, float eps,
+                                                     int pad_idx, const float* scratch, float* loss, float* dlogits) {
+  __shared__ float sh[4];
+  const int64_t row = blockIdx.x;
+  const float* x = logits + row * V;
+  float* dx = dlogits ? dlogits + row * V : nullptr;
+  const int64_t t = target[row];
+  if (t == pad_idx) {
+    if (dx) for (int v = threadIdx.x; v < V; v += blockDim.x) dx[v] = 0.f;
+    return;
+  }
+  float mx = -__builtin_huge_valf();
+  for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, x[v]);
+  mx = block_reduce(mx, sh, true);
+  float se = 0.f, sx = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) { float xv = x[v]; se += expf(xv - mx); sx += xv; }
+  se = block_reduce(se, sh, false);
+  sx = block_reduce(sx, sh, false);
+  const float lse = mx + logf(se);
+  const float inv_cnt = 1.f / scratch[0];
+  const float off = eps / (float)(V - 1), on = 1.f - eps;
+  if (dx) {
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+      float sm = expf(x[v] - lse);
+      dx[v] = (sm - (v == t ? on : off)) * inv_cnt;
+    }
+  }
+  if (threadIdx.x == 0) {
+    float logp_t = x[t] - lse;
+    float sum_logp = sx - (float)V * lse;
+    float C = (on > 0.f ? on * logf(on) : 0.f) + (eps > 0.f ? eps * logf(off) : 0.f);
+    float rl = C - (on * logp_t + off * (sum_logp - logp_t));
+    atomicAdd(loss, rl * inv_cnt);
+  }
+}
+
+extern "C" int32_t otr_label_smoothing_loss(const float* logits, const int64_t* target, int64_t R, int32_t V,
+                                            float smoothing, int32_t pad_idx, float* loss, float* dlogits,
+                                            float* scratch, void* stream) {
+  OTR_REQUIRE(logits && target && loss && scratch, "label_smoothing_loss: null pointer");
+  OTR_REQUIRE(R > 0 && V > 1, "label_smoothing_loss: bad shape R=%lld V=%d", (long long)R, V);
+  OTR_REQUIRE(smoothing >= 0.f && smoothing < 1.f, "label_smoothing_loss: smoothing out of [0,1)");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ls_count_kernel, dim3(1), dim3(256), 0, s, target, R, pad_idx, scratch, loss);
+  hipLaunchKernelGGL(ls_rows_kernel, dim3((unsigned)R), dim3(256), 0, s, logits, target, V, smoothing, pad_idx, scratch, loss, dlogits);
+  return otr_check_launch("label_smoothing_loss");
+}
+
+__global__ __launch_bounds__(256) void log_softmax_kernel(const float* x, float* y, int V) {
+  __shared__ float sh[4];
+  const float* xr = x + (int64_t)blockIdx.x * V;
+  float* yr = y + (int64_t)blockIdx.x * V;
+  float mx = -__builtin_huge_valf();
+  for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, xr[v]);
+  mx = block_reduce(mx, sh, true);
+  float se = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) se += expf(xr[v] - mx);
+  se = block_reduce(se, sh, false);
+  const float lse = mx + logf(se);
+  for (int v = threadIdx.x; v < V; v += blockDim.x) yr[v] = xr[v] - lse;
+}
+
+extern "C" int32_t otr_log_softmax(const float* x, float* y, int64_t R, int32_t V, void* stream) {
+  OTR_REQUIRE(x && y, "log_softmax: null pointer");
+  OTR_REQUIRE(R >= 0 && V > 0, "log_softmax: bad shape");
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(log_softmax_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, x, y, V);
+  return otr_check_launch("log_softmax");
+}

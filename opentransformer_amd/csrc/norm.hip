@@ -1,0 +1,217 @@
+// y = LayerNorm(x + dropout(a)) forward/backward (post-norm residual blocks of
+// encoder/transformer.py:54-56,61-63 and decoder/transformer.py:66-68,76-78,84-86).
+// HBM-bound: one wave per row, float4 lanes, fp32 statistics via 64-lane shuffles; the dropout mask
+// is a counter RNG regenerated in backward (never stored).
+#include "common.h"
+
+struct LnArgs {
+  const float* x; const void* a; const float* gamma; const float* beta; const uint64_t* seed;
+  float* y; float* z; float* mean; float* rstd;
+  const float* dy; float* dx; void* da; float* dgamma; float* dbeta; const float* zin;
+  int64_t M; int d;
+  float eps, p_drop;
+  uint64_t rng_offset;
+};
+
+constexpr int LN_MAXV = 4;  // float4 per lane -> d <= 1024
+
+template <class AT> __device__ __forceinline__ void ld4(const AT* p, float* o) {
+  if constexpr (sizeof(AT) == 4) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  } else {
+    uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  }
+}
+template <class AT> __device__ __forceinline__ void st4(AT* p, const float* o) {
+  if constexpr (sizeof(AT) == 4) *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  else *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+}
+
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {
+  return otr_rand32(seed, idx) >= thr ? inv_keep : 0.f;
+}
+
+template <class AT, bool HAS_A> __global__ __launch_bounds__(256) void add_ln_fwd_kernel(LnArgs p) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+  if (row >= p.M) return;
+  const int d = p.d;
+  const bool drop = HAS_A && p.p_drop > 0.f;
+  const uint64_t seed = drop ? *p.seed : 0;
+  const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
+  const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+  float v[LN_MAXV][4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int col = (i * 64 + lane) * 4;
+    if (col < d) {
+      ld4<float>(p.x + row * d + col, v[i]);
+      if constexpr (HAS_A) {
+        float a[4];
+        ld4<AT>(reinterpret_cast<const AT*>(p.a) + row * d + col, a);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float sc = drop ? drop_scale(seed, p.rng_offset + (uint64_t)(row * d + col + e), thr, inv_keep) : 1.f;
+          v[i][e] += a[e] * sc;
+        }
+      }
+      if (p.z) st4<float>(p.z + row * d + col, v[i]);
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+  }
+  const float mean = wave_sum(s) / d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int col = (i * 64 + lane) * 4;
+    if (col < d) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { float t = v[i][e] - mean; q += t * t; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / d + p.eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int col = (i * 64 + lane) * 4;
+    if (col < d) {
+      float g[4], bta[4], o[4];
+      ld4<float>(p.gamma + col, g);
+      ld4<float>(p.beta + col, bta);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + bta[e];
+      st4<float>(p.y + row * d + col, o);
+    }
+  }
+  if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
+}
+
+constexpr int LN_BWD_ROWS = 8;  // rows per wave -> 32 rows per block
+
+template <class AT, bool HAS_A> __global__ __launch_bounds__(256) void add_ln_bwd_kernel(LnArgs p) {
+  __shared__ float red[2][4][LN_MAXV * 64 * 4];  // [gamma|beta][wave][column]  (32 KB)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int d = p.d;
+  const bool drop = HAS_A && p.p_drop > 0.f;
+  const uint64_t seed = drop ? *p.seed : 0;
+  const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
+  const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+  float gam[LN_MAXV][4], dg[LN_MAXV][4], db[LN_MAXV][4];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int col = (i * 64 + lane) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; gam[i][e] = 0.f; }
+    if (col < d) ld4<float>(p.gamma + col, gam[i]);
+  }
+  for (int rr = 0; rr < LN_BWD_ROWS; ++rr) {
+    const int64_t row = ((int64_t)blockIdx.x * 4 + wid) * LN_BWD_ROWS + rr;
+    if (row >= p.M) break;
+    const float mean = p.mean[row], rstd = p.rstd[row];
+    float dyv[LN_MAXV][4], zh[LN_MAXV][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      int col = (i * 64 + lane) * 4;
+      if (col < d) {
+        ld4<float>(p.dy + row * d + col, dyv[i]);
+        ld4<float>(p.zin + row * d + col, zh[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          zh[i][e] = (zh[i][e] - mean) * rstd;
+          float g = dyv[i][e] * gam[i][e];
+          s1 += g; s2 += g * zh[i][e];
+          dg[i][e] += dyv[i][e] * zh[i][e];
+          db[i][e] += dyv[i][e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / d;
+    s2 = wave_sum(s2) / d;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      int col = (i * 64 + lane) * 4;
+      if (col < d) {
+        float dz[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dz[e] = rstd * (dyv[i][e] * gam[i][e] - s1 - zh[i][e] * s2);
+        st4<float>(p.dx + row * d + col, dz);
+        if constexpr (HAS_A) {
+          if (p.da) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float sc = drop ? drop_scale(seed, p.rng_offset + (uint64_t)(row * d + col + e), thr, inv_keep) : 1.f;
+              o[e] = dz[e] * sc;
+            }
+            st4<AT>(reinterpret_cast<AT*>(p.da) + row * d + col, o);
+          }
+        }
+      }
+    }
+  }
+  // block reduction of the affine gradients, then one atomic per column per block
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0][wid][(i * 64 + lane) * 4 + e] = dg[i][e];
+      red[1][wid][(i * 64 + lane) * 4 + e] = db[i][e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    atomicAdd(p.dgamma + c, a);
+    atomicAdd(p.dbeta + c, b);
+  }
+}
+
+static int32_t ln_check(const otr_ln_desc_t* d) {
+  OTR_REQUIRE(d != nullptr, "layernorm: null descriptor");
+  OTR_REQUIRE(d->M >= 0 && d->d > 0 && d->d % 4 == 0 && d->d <= LN_MAXV * 256,
+              "layernorm: d=%d must be a multiple of 4 and <= %d", d->d, LN_MAXV * 256);
+  OTR_REQUIRE(d->p_drop >= 0.f && d->p_drop < 1.f, "layernorm: p_drop=%f out of [0,1)", (double)d->p_drop);
+  OTR_REQUIRE(d->a_dtype == OTR_F32 || d->a_dtype == OTR_BF16, "layernorm: bad a_dtype");
+  return 0;
+}
+
+extern "C" int32_t otr_add_layernorm_fwd(const otr_ln_desc_t* d, const float* x, const void* a, const float* gamma,
+                                         const float* beta, const uint64_t* seed, float* y, float* z, float* mean,
+                                         float* rstd, void* stream) {
+  if (int32_t e = ln_check(d)) return e;
+  OTR_REQUIRE(x && gamma && beta && y && mean && rstd, "add_layernorm_fwd: null pointer");
+  OTR_REQUIRE(d->p_drop == 0.f || (a && seed), "add_layernorm_fwd: dropout needs a and seed");
+  if (d->M == 0) return 0;
+  LnArgs p{};
+  p.x = x; p.a = a; p.gamma = gamma; p.beta = beta; p.seed = seed; p.y = y; p.z = z; p.mean = mean; p.rstd = rstd;
+  p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
+  dim3 grid((unsigned)((d->M + 3) / 4));
+  hipStream_t s = (hipStream_t)stream;
+  if (!a) hipLaunchKernelGGL((add_ln_fwd_kernel<float, false>), grid, dim3(256), 0, s, p);
+  else if (d->a_dtype == OTR_F32) hipLaunchKernelGGL((add_ln_fwd_kernel<float, true>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, p);
+  return otr_check_launch("add_layernorm_fwd");
+}
+
+extern "C" int32_t otr_add_layernorm_bwd(const otr_ln_desc_t* d, const float* dy, const float* z, const float* mean,
+                                         const float* rstd, const float* gamma, const uint64_t* seed, float* dx,
+                                         void* da, float* dgamma, float* dbeta, void* stream) {
+  if (int32_t e = ln_check(d)) return e;
+  OTR_REQUIRE(dy && z && mean && rstd && gamma && dx && dgamma && dbeta, "add_layernorm_bwd: null pointer");
+  OTR_REQUIRE(d->p_drop == 0.f || seed, "add_layernorm_bwd: dropout needs seed");
+  if (d->M == 0) return 0;
+  LnArgs p{};
+  p.dy = dy; p.zin = z; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd); p.gamma = gamma;
+  p.seed = seed; p.dx = dx; p.da = da; p.dgamma = dgamma; p.dbeta = dbeta;
+  p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
+  dim3 grid((unsigned)((d->M + 4 * LN_BWD_ROWS - 1) / (4 * LN_BWD_ROWS)));
+  hipStream_t s = (hipStream_t)stream;
+  if (!da) hipLaunchKernelGGL((add_ln_bwd_kernel<float, false>), grid, dim3(256), 0, s, p);
+  else if (d->a_dtype == OTR_F32) hipLaunchKernelGGL((add_ln_bwd_kernel<float, true>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, p);
+  return otr_check_launch("add_layernorm_bwd");
+}

@@ -1,0 +1,105 @@
+"""Utterance-level data parallelism: one process per GPU, persistent replicas, ONE flat gradient
+buffer, ONE all-reduce (RCCL over xGMI; backend "nccl" on ROCm) per step.
+
+Replaces torch.nn.DataParallel in the reference (otrans/train/trainer.py:56-66): no per-step
+parameter broadcast (146 MB), no scatter/gather through GPU0, no GIL-bound replica threads.
+Equivalence: the reference's loss is mean_i(loss_i) with each replica's loss
+normalised by its own token count, so grad = (1/N) * sum_i grad_i  ==  all-reduce-sum, then 1/N
+folded into the clip/Adam step.
+
+The engine is model-agnostic host logic (it only touches .grad/.data of nn.Parameters), so the
+gloo/CPU tests in tests/test_dp.py exercise exactly this code with world_size 2.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+
+
+class FlatDataParallel:
+    def __init__(self, module, process_group=None, flatten_params=True):
+        self.module = module
+        self.group = process_group
+        seen, params = set(), []
+        for p in module.parameters():
+            if p.requires_grad and id(p) not in seen:      # tied weights appear once
+                seen.add(id(p))
+                params.append(p)
+        self.params = params
+        total = sum(p.numel() for p in params)
+        # pad to a multiple of 4 elements so every vectorised kernel can run over the whole buffer
+        self.numel = total
+        padded = (total + 3) // 4 * 4
+        dev, dt = params[0].device, params[0].dtype
+        self.flat_grad = torch.zeros(padded, device=dev, dtype=dt)
+        self.flat_param = torch.empty(padded, device=dev, dtype=dt) if flatten_params else None
+        off = 0
+        for p in params:
+            n = p.numel()
+            if flatten_params:
+                self.flat_param[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_param[off:off + n].view_as(p.data)
+            p.grad = self.flat_grad[off:off + n].view_as(p.data)
+            off += n
+        if flatten_params and padded > total:
+            self.flat_param[total:].zero_()
+
+    @property
+    def world_size(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def __call__(self, *args, **kw):
+        return self.module(*args, **kw)
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    def broadcast_parameters(self, src=0):
+        """one-time replica sync at start-up (the reference re-broadcasts every step)."""
+        if self.world_size > 1:
+            dist.broadcast(self.flat_param if self.flat_param is not None else self._pack_params(), src,
+                           group=self.group)
+
+    def all_reduce_gradients(self, async_op=False):
+        """single collective over the flat buffer; returns 1/world_size for the optimizer to fold in."""
+        ws = self.world_size
+        work = None
+        if ws > 1:
+            work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        return 1.0 / ws, work
+
+
+class FusedAdam:
+    """clip_grad_norm_(clip) + NaN guard + Adam(L2 wd) + Noam lr in three launches over the flat
+    buffers (include/otrans_hip.h: otr_optimizer_step).  State tensors are caller-owned."""
+
+    def __init__(self, dp, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6, clip_grad=5.0,
+                 noam=None):
+        """noam: dict(model_size, warmup_steps, factor) of train/scheduler.py:129-138, or None."""
+        assert dp.flat_param is not None, 'FusedAdam needs FlatDataParallel(flatten_params=True)'
+        self.dp = dp
+        self.lr, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip_grad
+        self.noam = noam
+        self.exp_avg = torch.zeros_like(dp.flat_param)
+        self.exp_avg_sq = torch.zeros_like(dp.flat_param)
+        self.state = torch.zeros(8, dtype=torch.float32, device=dp.flat_param.device)
+
+    def step(self, grad_scale=1.0):
+        if not self.dp.flat_param.is_cuda:
+            raise L.OtransHipError('FusedAdam runs on the GPU only')
+        n = self.dp.flat_param.numel()
+        nm = self.noam or {}
+        ret = L.load().otr_optimizer_step(
+            C.c_void_p(self.dp.flat_param.data_ptr()), C.c_void_p(self.dp.flat_grad.data_ptr()),
+            C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()), n,
+            C.c_void_p(self.state.data_ptr()), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+            grad_scale, self.clip, float(nm.get('model_size', 1.0)), float(nm.get('warmup_steps', 0.0)),
+            float(nm.get('factor', 1.0)), 2.0,   # scheduler.py:41-53: the first update sees global_step 3
+            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        L.check(ret, 'otr_optimizer_step')
+
+    def stats(self):
+        s = self.state.tolist()
+        return {'step': s[0], 'lr': s[1], 'grad_sqnorm': s[4], 'skipped': s[5]}

@@ -1,0 +1,93 @@
+"""Model assembly: SpeechToText (otrans/model/speech2text.py:15-90) and the CTC head
+(otrans/model/ctc.py:12-66) built from the drop-in registries of this package."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .nn import (BLK, ConvFrontEnd, LabelSmoothingLoss, TransformerDecoder, TransformerEncoder, _unsupported)
+
+BuildFrontEnd = {'conv': ConvFrontEnd}                 # otrans/frontend/__init__.py:8-12
+BuildEncoder = {'transformer': TransformerEncoder}     # otrans/encoder/__init__.py:10-13
+BuildDecoder = {'transformer': TransformerDecoder}     # otrans/decoder/__init__.py:8-10
+
+
+class CTCAssistor(nn.Module):
+    """model/ctc.py:12-66: Linear(d -> V) + log_softmax + CTC loss (blank 0, zero_infinity, 'mean')."""
+
+    def __init__(self, hidden_size, vocab_size, blank=BLK, lookahead_steps=-1):
+        super().__init__()
+        if lookahead_steps > 0:
+            _unsupported('CTCAssistor lookahead_steps > 0')
+        self.lookahead_steps, self.apply_look_ahead, self.blank = lookahead_steps, False, blank
+        self.output_layer = nn.Linear(hidden_size, vocab_size)
+
+    def compute_logits(self, enc_states):
+        return ops.linear(enc_states, self.output_layer.weight, self.output_layer.bias)
+
+    def forward(self, memory, memory_length=None, targets=None, tgt_length=None, return_logits=False):
+        logits = self.compute_logits(memory)
+        if return_logits:
+            return logits
+        return self.compute_loss(logits, memory_length, targets, tgt_length)
+
+    def compute_loss(self, logits, enc_length, targets, targets_length):
+        return ops.CTCLossFn.apply(logits, targets, enc_length, targets_length, self.blank)
+
+    def inference(self, memory, memory_mask):
+        logits = self.compute_logits(memory)
+        memory_length = torch.sum(memory_mask.squeeze(1) if memory_mask.dim() == 3 else memory_mask, dim=-1)
+        return ops.log_softmax(logits), memory_length
+
+
+class SpeechToText(nn.Module):
+    """model/speech2text.py:15-90.  forward(inputs: dict, targets: dict) -> (loss, aux | None)."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.frontend = BuildFrontEnd[params['frontend_type']](**params['frontend'])
+        self.encoder = BuildEncoder[params['encoder_type']](**params['encoder'])
+        self.decoder = BuildDecoder[params['decoder_type']](**params['decoder'])
+        self.crit = LabelSmoothingLoss(size=params['decoder']['vocab_size'], smoothing=params['smoothing'])
+        self.ctc_weight = params['ctc_weight']
+        if self.ctc_weight > 0.0:
+            self.assistor = CTCAssistor(hidden_size=params['encoder_output_size'],
+                                        vocab_size=params['decoder']['vocab_size'],
+                                        lookahead_steps=params['lookahead_steps'] if 'lookahead_steps' in params else 0)
+
+    def forward(self, inputs, targets):
+        enc_inputs, enc_mask = inputs['inputs'], inputs['mask']
+        truth, truth_length = targets['targets'], targets['targets_length']
+        enc_inputs, enc_mask = self.frontend(enc_inputs, enc_mask)
+        memory, memory_mask, _ = self.encoder(enc_inputs, enc_mask)
+        logits, _ = self.decoder(truth[:, :-1].contiguous(), memory, memory_mask)
+        target_out = truth[:, 1:].contiguous()
+        loss = self.crit(logits, target_out)
+        if self.ctc_weight > 0:
+            loss_ctc = self.compute_ctc_loss(memory, memory_mask, target_out, truth_length)
+            # the reference returns {'CTCLoss': loss_ctc.item()} (a host sync per step); we keep the tensor
+            return (1 - self.ctc_weight) * loss + self.ctc_weight * loss_ctc, {'CTCLoss': loss_ctc.detach()}
+        return loss, None
+
+    def compute_ctc_loss(self, memory, memory_mask, targets_out, targets_length):
+        memory_length = torch.sum(memory_mask, dim=-1)
+        return self.assistor(memory, memory_length, targets_out, targets_length)
+
+    def save_checkpoint(self, params, name):
+        checkpoint = {'params': params, 'frontend': self.frontend.state_dict(), 'encoder': self.encoder.state_dict(),
+                      'decoder': self.decoder.state_dict()}
+        if self.ctc_weight > 0.0:
+            checkpoint['ctc'] = self.assistor.state_dict()
+        torch.save(checkpoint, name)
+
+    def load_model(self, chkpt):
+        self.frontend.load_state_dict(chkpt['frontend'])
+        self.encoder.load_state_dict(chkpt['encoder'])
+        self.decoder.load_state_dict(chkpt['decoder'])
+        if 'ctc' in chkpt and self.ctc_weight > 0.0:
+            self.assistor.load_state_dict(chkpt['ctc'])
+
+    def set_epoch(self, epoch):
+        pass
+
+
+End2EndModel = {'speech2text': SpeechToText}           # otrans/model/__init__.py:6-9

@@ -1,0 +1,350 @@
+"""Drop-in modules for the otrans frontend / encoder / decoder / module stack.
+
+Same class names, constructor kwargs, forward signatures and state_dict keys as the reference
+(SURVEY.md 8b), so a reference checkpoint loads unchanged and the reference registries
+(BuildFrontEnd / BuildEncoder / BuildDecoder) can point here.  torch.nn.Linear / Conv2d / LayerNorm /
+Embedding objects are used only as *parameter containers* (identical shapes, names and default
+initialisation); their forward() is never called -- all math goes through opentransformer_amd.ops,
+i.e. through libotrans_hip.so.
+
+Not built yet (constructor raises NotImplementedError): normalize_before=True, concat_after=True,
+relative_positional=True (transformer encoder), FFN activations other than 'glu'/'relu',
+front_end_layer_norm=True, in_channel != 1.  The shipped AISHELL yamls use none of these.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+PAD, BLK, BOS, EOS = 0, 0, 1, 1       # otrans/data/__init__.py:7-12
+
+
+def _unsupported(what):
+    raise NotImplementedError('opentransformer_amd: %s is not built on the HIP path yet' % what)
+
+
+# ------------------------------------------------------------------------------------- frontend
+class Conv2dLayer(nn.Module):
+    """Parameter container mirroring frontend/conv.py:15-83 (the compute is fused in ConvFrontEnd)."""
+
+    def __init__(self, input_size, in_channel, out_channel, kernel_size, stride, dropout=0.1, batch_norm=False,
+                 residual=False, act_func_type='relu'):
+        super().__init__()
+        if list(kernel_size) != [3, 3] if not isinstance(kernel_size, int) else kernel_size != 3:
+            _unsupported('Conv2dLayer kernel_size != 3x3')
+        if stride != 2:
+            _unsupported('Conv2dLayer stride != 2')
+        if batch_norm or residual:
+            _unsupported('Conv2dLayer batch_norm/residual')
+        self.input_size, self.in_channel, self.out_channel = input_size, in_channel, out_channel
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, (0, 1)
+        self.conv_layer = nn.Conv2d(in_channel, out_channel, kernel_size=3, stride=2, padding=(0, 1))
+        self.output_size = (input_size + 2 - 3) // 2 + 1     # cal_width_dim_2d, conv.py:11-12
+
+    @staticmethod
+    def return_output_mask(mask, t):
+        return mask[:, 1::2][:, :t]                          # conv.py:78-83
+
+
+class ConvFrontEnd(nn.Module):
+    """frontend/conv.py:86-158.  forward(x [B,T,F], mask [B,T]) -> (x [B,T',d], mask [B,T'])."""
+
+    def __init__(self, input_size, output_size, in_channel=1, mid_channel=32, out_channel=128,
+                 kernel_size=[[3, 3], [3, 3]], stride=[2, 2], dropout=0.0, act_func_type='relu',
+                 front_end_layer_norm=False):
+        super().__init__()
+        if in_channel != 1:
+            _unsupported('ConvFrontEnd in_channel != 1')
+        if front_end_layer_norm:
+            _unsupported('front_end_layer_norm')
+        if dropout != 0.0:
+            _unsupported('ConvFrontEnd dropout > 0')
+        self.kernel_size, self.stride, self.output_size = kernel_size, stride, output_size
+        self.act_func_type, self.front_end_layer_norm = act_func_type, front_end_layer_norm
+        self.conv1 = Conv2dLayer(input_size, in_channel, mid_channel, kernel_size[0], stride[0], dropout)
+        self.conv2 = Conv2dLayer(self.conv1.output_size, mid_channel, out_channel, kernel_size[1], stride[1], dropout)
+        self.conv_output_size = self.conv2.output_size * out_channel
+        self.output_layer = nn.Linear(self.conv_output_size, output_size)
+
+    def forward(self, x, mask):
+        c1, c2 = self.conv1.conv_layer, self.conv2.conv_layer
+        C2, F2 = c2.out_channels, self.conv2.output_size
+        # layout prep of two small weights (autograd routes their gradients back):
+        w2r = c2.weight.permute(0, 2, 3, 1)                                   # [C2,3,3,C1] channel-last taps
+        wo = self.output_layer.weight.view(-1, C2, F2).permute(0, 2, 1).reshape(-1, F2 * C2)   # cols f*C2+c
+        act2 = ops.ConvSubsampleFn.apply(x, c1.weight, c1.bias, w2r.contiguous(), c2.bias)
+        y = ops.linear(act2, wo.contiguous(), self.output_layer.bias)
+        t1 = (x.size(1) - 3) // 2 + 1
+        mask = Conv2dLayer.return_output_mask(mask, t1)
+        mask = Conv2dLayer.return_output_mask(mask, act2.size(1))
+        return y, mask
+
+    def inference(self, x, mask, cache):
+        x, mask = self.forward(x, mask)
+        return x, mask, cache
+
+
+# ------------------------------------------------------------------------------------- primitives
+class PositionalEncoding(nn.Module):
+    """module/pos.py:11-72 (scale_learnable=False branch: x*sqrt(d) + PE).
+
+    NB the reference's callers pass pos_dropout into the scale_learnable slot
+    (encoder/transformer.py:102), so pos_dropout > 0 would switch formula; we refuse it."""
+
+    def __init__(self, emb_dim, scale_learnable=False, dropout=0.0):
+        super().__init__()
+        if scale_learnable or dropout:
+            _unsupported('PositionalEncoding scale_learnable / dropout (pos_dropout must be 0.0)')
+        self.emb_dim = emb_dim
+        self.xscale = math.sqrt(emb_dim)
+
+    def forward(self, x):
+        return ops.PosEncFn.apply(x), None
+
+
+def _key_mask(mask, B, Tk):
+    """reference masks are bool [B,1,Tk] (key mask) -> uint8 [B,Tk]"""
+    if mask is None:
+        return None
+    if mask.dim() == 3:
+        if mask.size(1) != 1:
+            raise ValueError('expected a [B,1,T] key mask')
+        mask = mask[:, 0]
+    return ops._mask_u8(mask, B, Tk)
+
+
+class MultiHeadedSelfAttention(nn.Module):
+    """module/attention.py:49-84."""
+
+    def __init__(self, n_heads, d_model, dropout_rate=0.0, share_qvk_proj=False):
+        super().__init__()
+        if share_qvk_proj:
+            _unsupported('share_qvk_proj')
+        if dropout_rate:
+            _unsupported('attention dropout > 0')
+        self.d_model, self.nheads, self.d_k = d_model, n_heads, d_model // n_heads
+        self.share_qvk_proj = share_qvk_proj
+        self.output_proj = nn.Linear(d_model, d_model)
+        self.qvk_proj = nn.Linear(d_model, d_model * 3)
+
+    def context(self, x, mask, causal=False):
+        """softmax(QK^T/sqrt(dk)) V merged over heads, before output_proj (act dtype)."""
+        B, T, _ = x.shape
+        if mask is not None and mask.dim() == 3 and mask.size(1) == T and T > 1:
+            # decoder-style [B,T,T] mask: only the causal tril mask is built (decoder/utils.py:7-11)
+            if not bool(torch.equal(mask, torch.tril(torch.ones_like(mask)))):
+                _unsupported('arbitrary [B,T,T] attention masks (only key masks and the causal mask)')
+            mask, causal = None, True
+        qkv = ops.linear(x, self.qvk_proj.weight, self.qvk_proj.bias, out_dtype=ops.act_dtype())
+        return ops.SelfAttentionFn.apply(qkv, _key_mask(mask, B, T), self.nheads, causal)
+
+    def forward(self, x, mask, causal=False):
+        ctx = self.context(x, mask, causal)
+        return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias), None
+
+    def inference(self, x, mask, cache=None):
+        out, w = self.forward(x, mask)
+        return out, w, cache
+
+
+class MultiHeadedCrossAttention(nn.Module):
+    """module/attention.py:107-173."""
+
+    def __init__(self, n_heads, d_model, memory_dim, dropout_rate=0.0, share_vk_proj=False):
+        super().__init__()
+        if share_vk_proj:
+            _unsupported('share_vk_proj')
+        if dropout_rate:
+            _unsupported('attention dropout > 0')
+        self.d_model, self.nheads, self.d_k = d_model, n_heads, d_model // n_heads
+        self.output_proj = nn.Linear(d_model, d_model)
+        self.q_proj = nn.Linear(d_model, d_model)
+        self.vk_proj = nn.Linear(memory_dim, d_model * 2)
+
+    def forward(self, query, memory, memory_mask):
+        B, T, _ = memory.shape
+        adt = ops.act_dtype()
+        q = ops.linear(query, self.q_proj.weight, self.q_proj.bias, out_dtype=adt)
+        kv = ops.linear(memory, self.vk_proj.weight, self.vk_proj.bias, out_dtype=adt)
+        ctx = ops.CrossAttentionFn.apply(q, kv, _key_mask(memory_mask, B, T), self.nheads)
+        return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias), None
+
+    def inference(self, query, memory, memory_mask, cache=None):
+        out, w = self.forward(query, memory, memory_mask)
+        return out, w, cache
+
+
+class PositionwiseFeedForward(nn.Module):
+    """module/ffn.py:24-41."""
+
+    def __init__(self, d_model, d_ff, dropout, activation='relu'):
+        super().__init__()
+        if activation not in ('glu', 'relu'):
+            _unsupported("FFN activation '%s' (only 'glu' and 'relu')" % activation)
+        if dropout:
+            _unsupported('ffn_dropout > 0')
+        self.activation = activation
+        self.w_1 = nn.Linear(d_model, d_ff * 2 if activation == 'glu' else d_ff)
+        self.w_2 = nn.Linear(d_ff, d_model)
+
+    def forward(self, x):
+        if self.activation == 'glu':
+            return ops.FeedForwardGLUFn.apply(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias)
+        h = ops.linear(x, self.w_1.weight, self.w_1.bias, relu=True, out_dtype=ops.act_dtype())
+        return ops.linear(h, self.w_2.weight, self.w_2.bias)
+
+
+def _post_norm(norm, x, branch, p, training):
+    """LN(x + dropout(branch)) in one kernel."""
+    return ops.add_layernorm(x, branch, norm.weight, norm.bias, p if training else 0.0, norm.eps)
+
+
+# ------------------------------------------------------------------------------------- encoder
+class TransformerEncoderLayer(nn.Module):
+    """encoder/transformer.py:16-90 (post-norm)."""
+
+    def __init__(self, n_heads, d_model, d_ff, slf_attn_dropout, ffn_dropout, residual_dropout,
+                 normalize_before=False, concat_after=False, relative_positional=False, activation='relu'):
+        super().__init__()
+        if normalize_before:
+            _unsupported('normalize_before=True')
+        if concat_after:
+            _unsupported('concat_after=True')
+        if relative_positional:
+            _unsupported('relative_positional=True')
+        self.relative_positional, self.normalize_before, self.concat_after = False, False, False
+        self.slf_attn = MultiHeadedSelfAttention(n_heads, d_model, slf_attn_dropout)
+        self.feed_forward = PositionwiseFeedForward(d_model, d_ff, ffn_dropout, activation)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.residual_dropout = residual_dropout
+
+    def forward(self, x, mask, pos=None, causal=False):
+        attn, _ = self.slf_attn(x, mask, causal)
+        x = _post_norm(self.norm1, x, attn, self.residual_dropout, self.training)
+        x = _post_norm(self.norm2, x, self.feed_forward(x), self.residual_dropout, self.training)
+        return x, {'slf_attn_weights': None}
+
+    def inference(self, x, mask, pos=None, cache=None):
+        was = self.training
+        self.training = False
+        try:
+            x, w = self.forward(x, mask, pos)
+        finally:
+            self.training = was
+        return x, cache, w
+
+
+class TransformerEncoder(nn.Module):
+    """encoder/transformer.py:93-134.  forward(inputs, mask [B,T]) -> (out, mask, attn_weights)."""
+
+    def __init__(self, d_model=256, n_heads=4, d_ff=2048, n_blocks=6, pos_dropout=0.0, slf_attn_dropout=0.0,
+                 ffn_dropout=0.0, residual_dropout=0.1, normalize_before=False, concat_after=False,
+                 relative_positional=False, activation='relu'):
+        super().__init__()
+        self.normalize_before, self.relative_positional = normalize_before, relative_positional
+        self.pos_emb = PositionalEncoding(d_model, pos_dropout)
+        self.blocks = nn.ModuleList([
+            TransformerEncoderLayer(n_heads, d_model, d_ff, slf_attn_dropout, ffn_dropout, residual_dropout,
+                                    normalize_before, concat_after, relative_positional, activation)
+            for _ in range(n_blocks)])
+
+    def forward(self, inputs, mask):
+        x, _ = self.pos_emb(inputs)
+        km = mask.unsqueeze(1)
+        for block in self.blocks:
+            x, _ = block(x, km)
+        # the reference returns every layer's [B,h,T,T] weights; nothing reads them
+        return x, mask, {}
+
+
+# ------------------------------------------------------------------------------------- decoder
+class TransformerDecoderLayer(nn.Module):
+    """decoder/transformer.py:18-126 (post-norm)."""
+
+    def __init__(self, n_heads, d_model, d_ff, memory_dim, slf_attn_dropout=0.0, src_attn_dropout=0.0,
+                 ffn_dropout=0.0, residual_dropout=0.1, normalize_before=False, concat_after=False,
+                 relative_positional=False, activation='relu'):
+        super().__init__()
+        if normalize_before:
+            _unsupported('normalize_before=True')
+        if concat_after:
+            _unsupported('concat_after=True')
+        if relative_positional:
+            _unsupported('relative_positional=True')
+        self.relative_positional, self.normalize_before, self.concat_after = False, False, False
+        self.slf_attn = MultiHeadedSelfAttention(n_heads, d_model, slf_attn_dropout)
+        self.src_attn = MultiHeadedCrossAttention(n_heads, d_model, memory_dim, src_attn_dropout)
+        self.feed_forward = PositionwiseFeedForward(d_model, d_ff, ffn_dropout, activation)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.residual_dropout = residual_dropout
+
+    def forward(self, tgt, tgt_mask, memory, memory_mask, pos=None):
+        """tgt_mask: the causal [B,L,L] tril mask of decoder/utils.py:7-11, or None meaning causal."""
+        p, tr = self.residual_dropout, self.training
+        if tgt_mask is None:
+            attn, _ = self.slf_attn(tgt, None, causal=True)
+        else:
+            attn, _ = self.slf_attn(tgt, tgt_mask)
+        x = _post_norm(self.norm1, tgt, attn, p, tr)
+        src, _ = self.src_attn(x, memory, memory_mask)
+        x = _post_norm(self.norm2, x, src, p, tr)
+        x = _post_norm(self.norm3, x, self.feed_forward(x), p, tr)
+        return x, {'slf_attn_weights': None, 'src_attn_weights': None}
+
+
+class TransformerDecoder(nn.Module):
+    """decoder/transformer.py:129-208."""
+
+    def __init__(self, vocab_size, d_model=256, n_heads=4, d_ff=2048, memory_dim=256, n_blocks=6, pos_dropout=0.0,
+                 slf_attn_dropout=0.0, src_attn_dropout=0.0, ffn_dropout=0.0, residual_dropout=0.1, activation='relu',
+                 normalize_before=True, concat_after=False, share_embedding=False):
+        super().__init__()
+        self.decoder_type = 'transformer'
+        self.normalize_before, self.relative_positional, self.d_model = normalize_before, False, d_model
+        self.embedding = nn.Embedding(vocab_size, d_model)
+        self.pos_emb = PositionalEncoding(d_model, pos_dropout)
+        self.blocks = nn.ModuleList([
+            TransformerDecoderLayer(n_heads, d_model, d_ff, memory_dim, slf_attn_dropout, src_attn_dropout,
+                                    ffn_dropout, residual_dropout, normalize_before=normalize_before,
+                                    concat_after=concat_after, relative_positional=False, activation=activation)
+            for _ in range(n_blocks)])
+        self.output_layer = nn.Linear(d_model, vocab_size)
+        if share_embedding:
+            self.output_layer.weight = self.embedding.weight      # decoder/transformer.py:156-158
+
+    def forward(self, targets, memory, memory_mask):
+        x = ops.EmbedPosEncFn.apply(targets, self.embedding.weight)
+        mm = memory_mask.unsqueeze(1)
+        for block in self.blocks:
+            x, _ = block(x, None, memory, mm)                    # None -> causal self-attention
+        logits = ops.linear(x, self.output_layer.weight, self.output_layer.bias)
+        return logits, {}
+
+    def inference(self, preds, memory, memory_mask=None, cache=None):
+        """Full re-forward + log_softmax of the last position, exactly the reference's behaviour
+        (decoder/transformer.py:185-208; its cache argument is ignored there too)."""
+        assert preds.dim() == 2
+        logits, attn = self.forward(preds, memory, memory_mask)
+        return ops.log_softmax(logits[:, -1, :]), cache, attn
+
+
+# ------------------------------------------------------------------------------------- losses / heads
+class LabelSmoothingLoss(nn.Module):
+    """module/loss.py:12-48 (mask argument of the reference is never passed by the model)."""
+
+    def __init__(self, size, smoothing=0.1, padding_idx=PAD, normalize_length=True):
+        super().__init__()
+        if not normalize_length:
+            _unsupported('normalize_length=False')
+        self.size, self.smoothing, self.padding_idx, self.normalize_length = size, smoothing, padding_idx, True
+
+    def forward(self, logits, target, mask=None):
+        if mask is not None:
+            _unsupported('LabelSmoothingLoss extra mask')
+        assert logits.dim() == 3 and logits.size(-1) == self.size
+        return ops.LabelSmoothingLossFn.apply(logits.float(), target, float(self.smoothing), int(self.padding_idx))

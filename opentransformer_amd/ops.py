@@ -1,0 +1,517 @@
+"""torch.autograd wrappers over the C ABI (include/otrans_hip.h).
+
+PyTorch is used for device memory, streams and autograd bookkeeping only: every forward/backward
+below hands raw data_ptr()s and torch's *current stream* to libotrans_hip.so.  There is no CPU path:
+a non-CUDA tensor raises.
+
+Precision policy (set_compute_dtype):
+  'bf16' (default): MFMA inputs bf16, fp32 accumulate; the residual stream, LayerNorm/softmax
+          statistics, losses and every parameter/gradient stay fp32; q/k/v, attention context, conv
+          activations and the FFN hidden are stored bf16.
+  'fp32': exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) everywhere, all activations fp32 -- parity mode.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+_state = {'compute': 'bf16', 'rng_offset': 0, 'seed': None}
+
+
+def set_compute_dtype(name):
+    assert name in ('bf16', 'fp32')
+    _state['compute'] = name
+
+
+def get_compute_dtype():
+    return _state['compute']
+
+
+def act_dtype():
+    return torch.bfloat16 if _state['compute'] == 'bf16' else torch.float32
+
+
+def _compute_code():
+    return L.OTR_BF16 if _state['compute'] == 'bf16' else L.OTR_F32
+
+
+def _code(dt):
+    if dt == torch.float32:
+        return L.OTR_F32
+    if dt == torch.bfloat16:
+        return L.OTR_BF16
+    raise TypeError('opentransformer_amd: unsupported dtype %s' % dt)
+
+
+def _cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.OtransHipError('opentransformer_amd ops need CUDA/HIP tensors (got a %s tensor); '
+                                   'there is no CPU fallback' % t.device)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, offset_elems=0):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr() + offset_elems * t.element_size())
+
+
+def rng_seed_tensor(device):
+    """Device-resident dropout seed (uint64 stored in an int64 tensor); bump it once per step with
+    `next_dropout_step()` so fwd and bwd of one step regenerate identical masks (graph-capture safe)."""
+    s = _state['seed']
+    device = torch.device(device)
+    if s is None or s.device.type != device.type or (device.index is not None and s.device.index != device.index):
+        s = torch.full((1,), 0x5EED, dtype=torch.int64, device=device)
+        _state['seed'] = s
+    return s
+
+
+def next_dropout_step(device):
+    rng_seed_tensor(device).add_(0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF)
+    _state['rng_offset'] = 0
+
+
+def _next_rng_offset(n):
+    off = _state['rng_offset']
+    _state['rng_offset'] = off + n
+    return off
+
+
+# ---------------------------------------------------------------------------------------- linear
+def _linear_desc(M, N, K, xdt, wdt, ydt, ldx, ldw, ldy, act=L.ACT_NONE, accumulate=0):
+    return L.LinearDesc(M, N, K, _code(xdt), _code(wdt), _code(ydt), _compute_code(), ldx, ldw, ldy, act, accumulate)
+
+
+def linear_fwd_raw(x2, w, b, out_dtype, act=L.ACT_NONE):
+    M, K = x2.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=out_dtype, device=x2.device)
+    d = _linear_desc(M, N, K, x2.dtype, w.dtype, out_dtype, x2.stride(0), w.stride(0), N, act)
+    L.check(L.load().otr_linear_fwd(C.byref(d), _p(x2), _p(w), _p(b), _p(y), _stream()), 'otr_linear_fwd')
+    return y
+
+
+def linear_dgrad_raw(dy2, w, dx_dtype):
+    M, N = dy2.shape
+    K = w.shape[1]
+    dx = torch.empty((M, K), dtype=dx_dtype, device=dy2.device)
+    d = _linear_desc(M, N, K, dx_dtype, w.dtype, dy2.dtype, K, w.stride(0), dy2.stride(0))
+    L.check(L.load().otr_linear_dgrad(C.byref(d), _p(dy2), _p(w), _p(dx), _stream()), 'otr_linear_dgrad')
+    return dx
+
+
+def linear_wgrad_raw(dy2, x2, w_like):
+    M, N = dy2.shape
+    K = x2.shape[1]
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
+    d = _linear_desc(M, N, K, x2.dtype, torch.float32, dy2.dtype, x2.stride(0), K, dy2.stride(0))
+    L.check(L.load().otr_linear_wgrad(C.byref(d), _p(dy2), _p(x2), _p(dw), _stream()), 'otr_linear_wgrad')
+    return dw
+
+
+def colsum_raw(a2, out=None):
+    M, N = a2.shape
+    acc = out is not None
+    if out is None:
+        out = torch.empty((N,), dtype=torch.float32, device=a2.device)
+    L.check(L.load().otr_colsum(_p(a2), _code(a2.dtype), M, N, a2.stride(0), _p(out), int(acc), _stream()), 'otr_colsum')
+    return out
+
+
+def _rows(x):
+    """View [..., K] as [M, K] with unit inner stride (copy only if the caller handed us a strange view)."""
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < x2.shape[1]):
+        x2 = x2.contiguous()
+    return x2
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x w^T + b): nn.Linear of the reference (e.g. module/attention.py:43,68)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu, out_dtype):
+        _cuda(x, w, b)
+        x2 = _rows(x)
+        y = linear_fwd_raw(x2, w, b, out_dtype, L.ACT_RELU if relu else L.ACT_NONE)
+        ctx.relu = relu
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x2, w, y if relu else None)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        dy2 = _rows(dy)
+        if ctx.relu:
+            dy2 = relu_bwd_raw(y, dy2.contiguous())
+        dx = linear_dgrad_raw(dy2, w, x2.dtype).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw = linear_wgrad_raw(dy2, x2, w) if ctx.needs_input_grad[1] else None
+        db = colsum_raw(dy2) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None, None
+
+
+def linear(x, w, b=None, relu=False, out_dtype=None):
+    return LinearFn.apply(x, w, b, relu, out_dtype if out_dtype is not None else torch.float32)
+
+
+def relu_bwd_raw(y, g):
+    out = torch.empty_like(g)
+    L.check(L.load().otr_relu_bwd(_p(y), _p(g), _p(out), _code(g.dtype), g.numel(), _stream()), 'otr_relu_bwd')
+    return out
+
+
+# ---------------------------------------------------------------------------------------- attention
+def _attn_desc(B, H, Tq, Tk, dk, dt, qs, ks, vs, os_, causal):
+    return L.AttnDesc(B, H, Tq, Tk, dk, _code(dt), qs[0], qs[1], ks[0], ks[1], vs[0], vs[1], os_[0], os_[1],
+                      int(causal), 1.0 / math.sqrt(dk))
+
+
+def _mask_u8(mask, B, Tk):
+    """[B,Tk] bool key mask -> uint8 (None if there is no mask)."""
+    if mask is None:
+        return None
+    m = mask.reshape(B, Tk)
+    return m.to(torch.uint8).contiguous()
+
+
+class SelfAttentionFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dk) + mask) v on a packed [B,T,3d] projection (columns q|k|v, the
+    split order of module/attention.py:73); returns the merged-head context [B,T,d]."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_mask_u8, n_heads, causal):
+        _cuda(qkv)
+        B, T, d3 = qkv.shape
+        d = d3 // 3
+        dk = d // n_heads
+        qkv = qkv.contiguous()
+        out = torch.empty((B, T, d), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((B, n_heads, T), dtype=torch.float32, device=qkv.device)
+        s3 = (T * d3, d3)
+        desc = _attn_desc(B, n_heads, T, T, dk, qkv.dtype, s3, s3, s3, (T * d, d), causal)
+        L.check(L.load().otr_attention_fwd(C.byref(desc), _p(qkv), _p(qkv, d), _p(qkv, 2 * d), _p(key_mask_u8),
+                                           _p(out), _p(lse), _stream()), 'otr_attention_fwd')
+        ctx.save_for_backward(qkv, out, lse, key_mask_u8)
+        ctx.cfg = (n_heads, causal)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, km = ctx.saved_tensors
+        n_heads, causal = ctx.cfg
+        B, T, d3 = qkv.shape
+        d = d3 // 3
+        dk = d // n_heads
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse)
+        s3 = (T * d3, d3)
+        desc = _attn_desc(B, n_heads, T, T, dk, qkv.dtype, s3, s3, s3, (T * d, d), causal)
+        L.check(L.load().otr_attention_bwd(C.byref(desc), _p(qkv), _p(qkv, d), _p(qkv, 2 * d), _p(km), _p(out),
+                                           _p(dout), _p(lse), _p(delta), _p(dqkv), _p(dqkv, d), _p(dqkv, 2 * d),
+                                           _stream()), 'otr_attention_bwd')
+        return dqkv, None, None, None
+
+
+class CrossAttentionFn(torch.autograd.Function):
+    """q [B,L,d] against packed kv [B,T,2d] (columns k|v: module/attention.py:134)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, key_mask_u8, n_heads):
+        _cuda(q, kv)
+        B, Lq, d = q.shape
+        T = kv.shape[1]
+        dk = d // n_heads
+        q = q.contiguous()
+        kv = kv.contiguous()
+        out = torch.empty((B, Lq, d), dtype=q.dtype, device=q.device)
+        lse = torch.empty((B, n_heads, Lq), dtype=torch.float32, device=q.device)
+        sq, skv = (Lq * d, d), (T * 2 * d, 2 * d)
+        desc = _attn_desc(B, n_heads, Lq, T, dk, q.dtype, sq, skv, skv, sq, False)
+        L.check(L.load().otr_attention_fwd(C.byref(desc), _p(q), _p(kv), _p(kv, d), _p(key_mask_u8), _p(out), _p(lse),
+                                           _stream()), 'otr_attention_fwd')
+        ctx.save_for_backward(q, kv, out, lse, key_mask_u8)
+        ctx.n_heads = n_heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, out, lse, km = ctx.saved_tensors
+        n_heads = ctx.n_heads
+        B, Lq, d = q.shape
+        T = kv.shape[1]
+        dk = d // n_heads
+        dout = dout.contiguous()
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        delta = torch.empty_like(lse)
+        sq, skv = (Lq * d, d), (T * 2 * d, 2 * d)
+        desc = _attn_desc(B, n_heads, Lq, T, dk, q.dtype, sq, skv, skv, sq, False)
+        L.check(L.load().otr_attention_bwd(C.byref(desc), _p(q), _p(kv), _p(kv, d), _p(km), _p(out), _p(dout), _p(lse),
+                                           _p(delta), _p(dq), _p(dkv), _p(dkv, d), _stream()), 'otr_attention_bwd')
+        return dq, dkv, None, None
+
+
+# ---------------------------------------------------------------------------------------- add + LayerNorm
+class AddLayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x + dropout(a)) (post-norm residual: encoder/transformer.py:54-56,61-63)."""
+
+    @staticmethod
+    def forward(ctx, x, a, gamma, beta, p_drop, eps):
+        _cuda(x, a, gamma, beta)
+        d = x.shape[-1]
+        x2 = x.reshape(-1, d).contiguous()
+        a2 = a.reshape(-1, d).contiguous() if a is not None else None
+        M = x2.shape[0]
+        need_grad = any(ctx.needs_input_grad)
+        y = torch.empty_like(x2)
+        z = torch.empty_like(x2) if need_grad else None
+        mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        seed = rng_seed_tensor(x.device) if p_drop > 0 else None
+        off = _next_rng_offset(M * d) if p_drop > 0 else 0
+        desc = L.LnDesc(M, d, _code(a2.dtype) if a2 is not None else L.OTR_F32, eps, p_drop, off)
+        L.check(L.load().otr_add_layernorm_fwd(C.byref(desc), _p(x2), _p(a2), _p(gamma), _p(beta), _p(seed), _p(y),
+                                               _p(z), _p(mean), _p(rstd), _stream()), 'otr_add_layernorm_fwd')
+        ctx.save_for_backward(z, mean, rstd, gamma, seed)
+        ctx.cfg = (M, d, a2.dtype if a2 is not None else None, eps, p_drop, off, x.shape,
+                   a.shape if a is not None else None)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, mean, rstd, gamma, seed = ctx.saved_tensors
+        M, d, adt, eps, p_drop, off, xshape, ashape = ctx.cfg
+        dy2 = dy.reshape(-1, d).contiguous()
+        dx = torch.empty_like(dy2)
+        da = torch.empty((M, d), dtype=adt, device=dy.device) if adt is not None else None
+        dgb = torch.zeros((2, d), dtype=torch.float32, device=dy.device)
+        desc = L.LnDesc(M, d, _code(adt) if adt is not None else L.OTR_F32, eps, p_drop, off)
+        L.check(L.load().otr_add_layernorm_bwd(C.byref(desc), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed),
+                                               _p(dx), _p(da), _p(dgb[0]), _p(dgb[1]), _stream()),
+                'otr_add_layernorm_bwd')
+        return dx.view(xshape), (da.view(ashape) if da is not None else None), dgb[0], dgb[1], None, None
+
+
+def add_layernorm(x, a, gamma, beta, p_drop=0.0, eps=1e-5):
+    return AddLayerNormFn.apply(x, a, gamma, beta, float(p_drop), float(eps))
+
+
+# ---------------------------------------------------------------------------------------- FFN (fused Function)
+class FeedForwardGLUFn(torch.autograd.Function):
+    """w_2(glu(w_1 x)) of module/ffn.py:38-41 with activation 'glu': three launches forward
+    (GEMM, GLU, GEMM); backward fuses the w_1 bias gradient into the GLU-backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        _cuda(x, w1, w2)
+        x2 = _rows(x)
+        adt = act_dtype()
+        h = linear_fwd_raw(x2, w1, b1, adt)
+        M, F2 = h.shape
+        F = F2 // 2
+        u = torch.empty((M, F), dtype=adt, device=x.device)
+        L.check(L.load().otr_glu_fwd(_p(h), _p(u), _code(adt), M, F, _stream()), 'otr_glu_fwd')
+        y = linear_fwd_raw(u, w2, b2, torch.float32)
+        ctx.save_for_backward(x2, w1, w2, h, u)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, h, u = ctx.saved_tensors
+        dy2 = _rows(dy)
+        M, F = u.shape
+        du = linear_dgrad_raw(dy2, w2, u.dtype)
+        dw2 = linear_wgrad_raw(dy2, u, w2)
+        db2 = colsum_raw(dy2)
+        dh = torch.empty_like(h)
+        db1 = torch.zeros((2 * F,), dtype=torch.float32, device=dy.device)
+        L.check(L.load().otr_glu_bwd(_p(h), _p(du), _p(dh), _p(db1), _code(h.dtype), M, F, _stream()), 'otr_glu_bwd')
+        dx = linear_dgrad_raw(dh, w1, x2.dtype).view(ctx.xshape)
+        dw1 = linear_wgrad_raw(dh, x2, w1)
+        return dx, dw1, db1, dw2, db2
+
+
+# ---------------------------------------------------------------------------------------- positional encoding
+class PosEncFn(torch.autograd.Function):
+    """x*sqrt(d) + PE (module/pos.py:44-57, scale_learnable=False)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _cuda(x)
+        B, T, d = x.shape
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        ctx.scale = math.sqrt(d)
+        L.check(L.load().otr_posenc_fwd(_p(x), _p(y), B * T, T, d, ctx.scale, _stream()), 'otr_posenc_fwd')
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        L.check(L.load().otr_scale(_p(dy), _p(dx), dy.numel(), None, ctx.scale, _stream()), 'otr_scale')
+        return dx
+
+
+class EmbedPosEncFn(torch.autograd.Function):
+    """embedding(tokens)*sqrt(d) + PE (decoder/transformer.py:163-169)."""
+
+    @staticmethod
+    def forward(ctx, tokens, E):
+        _cuda(tokens, E)
+        B, Lq = tokens.shape
+        V, d = E.shape
+        tokens = tokens.contiguous()
+        y = torch.empty((B, Lq, d), dtype=torch.float32, device=E.device)
+        ctx.scale = math.sqrt(d)
+        L.check(L.load().otr_embed_posenc_fwd(_p(tokens), _p(E), _p(y), B * Lq, Lq, d, V, ctx.scale, _stream()),
+                'otr_embed_posenc_fwd')
+        ctx.save_for_backward(tokens)
+        ctx.eshape = (V, d)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (tokens,) = ctx.saved_tensors
+        V, d = ctx.eshape
+        dy = dy.contiguous()
+        dE = torch.zeros((V, d), dtype=torch.float32, device=dy.device)
+        L.check(L.load().otr_embed_bwd(_p(tokens), _p(dy), _p(dE), tokens.numel(), d, V, ctx.scale, _stream()),
+                'otr_embed_bwd')
+        return None, dE
+
+
+# ---------------------------------------------------------------------------------------- conv frontend
+def conv_geometry(T, F):
+    T1 = (T - 3) // 2 + 1
+    T2 = (T1 - 3) // 2 + 1
+    F1 = (F - 1) // 2 + 1
+    F2 = (F1 - 1) // 2 + 1
+    return T1, F1, T2, F2
+
+
+class ConvSubsampleFn(torch.autograd.Function):
+    """Two Conv2dLayers of frontend/conv.py:141-142 (3x3, stride 2, pad (0,1), ReLU).
+
+    x [B,T,F] f32; w1 [C1,1,3,3]; w2r = conv2 weight permuted to [C2,3,3,C1] (channel-last taps).
+    Returns channel-last act2 viewed as [B, T2, F2*C2] (column index f*C2 + c)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2r, b2):
+        _cuda(x, w1, b1, w2r, b2)
+        B, T, F = x.shape
+        C1, C2 = w1.shape[0], w2r.shape[0]
+        T1, F1, T2, F2 = conv_geometry(T, F)
+        adt = act_dtype()
+        x = x.contiguous()
+        w1 = w1.contiguous()
+        w2r = w2r.contiguous()
+        desc = L.ConvDesc(B, T, F, C1, C2, T1, F1, T2, F2, _code(adt), _compute_code())
+        act1 = torch.empty((B, T1, F1, C1), dtype=adt, device=x.device)
+        act2 = torch.empty((B, T2, F2 * C2), dtype=adt, device=x.device)
+        lib = L.load()
+        L.check(lib.otr_conv1_fwd(C.byref(desc), _p(x), _p(w1), _p(b1), _p(act1), _stream()), 'otr_conv1_fwd')
+        L.check(lib.otr_conv2_fwd(C.byref(desc), _p(act1), _p(w2r), _p(b2), _p(act2), _stream()), 'otr_conv2_fwd')
+        ctx.save_for_backward(x, w2r, act1, act2)
+        ctx.desc_args = (B, T, F, C1, C2, T1, F1, T2, F2)
+        return act2
+
+    @staticmethod
+    def backward(ctx, dact2):
+        x, w2r, act1, act2 = ctx.saved_tensors
+        B, T, F, C1, C2, T1, F1, T2, F2 = ctx.desc_args
+        adt = act2.dtype
+        desc = L.ConvDesc(B, T, F, C1, C2, T1, F1, T2, F2, _code(adt), _compute_code())
+        lib = L.load()
+        g2 = relu_bwd_raw(act2, dact2.contiguous())
+        M2 = B * T2 * F2
+        db2 = colsum_raw(g2.view(M2, C2))
+        dw2r = torch.empty((C2, 3, 3, C1), dtype=torch.float32, device=x.device)
+        L.check(lib.otr_conv2_wgrad(C.byref(desc), _p(g2), _p(act1), _p(dw2r), _stream()), 'otr_conv2_wgrad')
+        dcol = torch.empty((M2, 9 * C1), dtype=adt, device=x.device)
+        L.check(lib.otr_conv2_dgrad_cols(C.byref(desc), _p(g2), _p(w2r), _p(dcol), _stream()), 'otr_conv2_dgrad_cols')
+        dact1 = torch.empty_like(act1)
+        L.check(lib.otr_conv2_col2im(C.byref(desc), _p(dcol), _p(act1), _p(dact1), _stream()), 'otr_conv2_col2im')
+        dwb = torch.zeros((C1 * 10,), dtype=torch.float32, device=x.device)
+        dw1, db1 = dwb[:C1 * 9], dwb[C1 * 9:]
+        L.check(lib.otr_conv1_wgrad(C.byref(desc), _p(x), _p(dact1), _p(dw1), _p(db1), _stream()), 'otr_conv1_wgrad')
+        return None, dw1.view(C1, 1, 3, 3), db1, dw2r, db2
+
+
+# ---------------------------------------------------------------------------------------- losses
+class LabelSmoothingLossFn(torch.autograd.Function):
+    """LabelSmoothingLoss.forward (module/loss.py:21-48) + its gradient in the same pass."""
+
+    @staticmethod
+    def forward(ctx, logits, target, smoothing, pad_idx):
+        _cuda(logits, target)
+        V = logits.shape[-1]
+        lg = logits.reshape(-1, V).contiguous()
+        tg = target.reshape(-1).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=lg.device)
+        dlogits = torch.empty_like(lg) if ctx.needs_input_grad[0] else None
+        scratch = torch.empty((2,), dtype=torch.float32, device=lg.device)
+        L.check(L.load().otr_label_smoothing_loss(_p(lg), _p(tg), lg.shape[0], V, smoothing, pad_idx, _p(loss),
+                                                  _p(dlogits), _p(scratch), _stream()), 'otr_label_smoothing_loss')
+        ctx.save_for_backward(dlogits)
+        ctx.shape = logits.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        out = torch.empty_like(dlogits)
+        g = g.contiguous().float()
+        L.check(L.load().otr_scale(_p(dlogits), _p(out), dlogits.numel(), _p(g), 1.0, _stream()), 'otr_scale')
+        return out.view(ctx.shape), None, None, None
+
+
+class CTCLossFn(torch.autograd.Function):
+    """CTCAssistor.compute_loss (model/ctc.py:50-53): log_softmax + CTC ('mean', zero_infinity)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, in_len, tgt_len, blank):
+        _cuda(logits, targets, in_len, tgt_len)
+        B, T, V = logits.shape
+        lp = log_softmax(logits)
+        tg = targets.contiguous()
+        il = in_len.to(torch.int32).contiguous()
+        tl = tgt_len.to(torch.int32).contiguous()
+        max_tgt = tg.shape[1]
+        ws = torch.empty((B, T, 2 * max_tgt + 1), dtype=torch.float32, device=logits.device)
+        nll = torch.empty((B,), dtype=torch.float32, device=logits.device)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty_like(lp) if ctx.needs_input_grad[0] else None
+        L.check(L.load().otr_ctc_loss(_p(lp), _p(tg), tg.stride(0), _p(il), _p(tl), B, T, V, max_tgt, blank, _p(ws),
+                                      _p(nll), _p(loss), _p(dlogits), _stream()), 'otr_ctc_loss')
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        out = torch.empty_like(dlogits)
+        g = g.contiguous().float()
+        L.check(L.load().otr_scale(_p(dlogits), _p(out), dlogits.numel(), _p(g), 1.0, _stream()), 'otr_scale')
+        return out, None, None, None, None
+
+
+def log_softmax(x):
+    """F.log_softmax(x, -1) for fp32 x (no autograd; decode / CTC inference paths)."""
+    _cuda(x)
+    V = x.shape[-1]
+    x2 = x.reshape(-1, V).contiguous().float()
+    y = torch.empty_like(x2)
+    L.check(L.load().otr_log_softmax(_p(x2), _p(y), x2.shape[0], V, _stream()), 'otr_log_softmax')
+    return y.view(x.shape)

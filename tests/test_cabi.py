@@ -1,0 +1,76 @@
+"""CPU (-m "not gpu"): the C-ABI library builds, loads and exports exactly what include/otrans_hip.h
+declares; argument validation works without a GPU (negative return, no launch); the product refuses
+CPU tensors instead of falling back."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from opentransformer_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'otrans_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(otr_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_binding_and_library_agree():
+    lib = _lib.load()
+    decl = declared_symbols()
+    assert decl, 'no declarations parsed'
+    assert sorted(_lib.SIGNATURES) == decl          # the ctypes stub binds exactly the header
+    for name in decl:
+        assert hasattr(lib, name), name             # and the .so exports every one of them
+    assert lib.otr_version() >= 100
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    lib = _lib.load()
+    d = _lib.LinearDesc(4, 4, 0, 0, 0, 0, 0, 4, 4, 4, 0, 0)       # K = 0
+    assert lib.otr_linear_fwd(C.byref(d), None, None, None, None, None) < 0
+    assert b'linear' in lib.otr_last_error_string()
+    a = _lib.AttnDesc(1, 1, 4, 4, 24, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1.0)   # head dim not built
+    assert lib.otr_attention_fwd(C.byref(a), None, None, None, None, None, None, None) < 0
+    ln = _lib.LnDesc(4, 6, 0, 1e-5, 0.0, 0)                          # d % 4 != 0
+    assert lib.otr_add_layernorm_fwd(C.byref(ln), None, None, None, None, None, None, None, None, None, None) < 0
+
+
+def test_product_refuses_cpu_tensors():
+    import opentransformer_amd as ota
+    from opentransformer_amd import synthetic as syn
+    model = ota.SpeechToText(syn.c1_model())
+    inputs, targets = syn.synthetic_batch(2, 100, 80, 100, 5)
+    with pytest.raises(_lib.OtransHipError):
+        model(inputs, targets)
+
+
+def test_state_dict_keys_match_reference_layout():
+    """a reference checkpoint must load unchanged."""
+    import opentransformer_amd as ota
+    from opentransformer_amd import synthetic as syn
+    from tests import helpers as H
+    cfg = syn.c1_model(ctc_weight=0.3)
+    model = ota.SpeechToText(cfg)
+    want = H.empty_state(cfg)
+    for part, mod in (('frontend', model.frontend), ('encoder', model.encoder), ('decoder', model.decoder),
+                      ('ctc', model.assistor)):
+        got = mod.state_dict()
+        assert sorted(got) == sorted(want[part]), part
+        for k in got:
+            assert tuple(got[k].shape) == tuple(want[part][k].shape), (part, k)
+    assert model.decoder.output_layer.weight is model.decoder.embedding.weight   # tied
+
+
+def test_reference_trained_checkpoint_loads(golden):
+    import opentransformer_amd as ota
+    from opentransformer_amd import synthetic as syn
+    g = golden('c1_decode.npz')
+    model = ota.SpeechToText(syn.c1_model(ctc_weight=0.3))
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('w:')}
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected

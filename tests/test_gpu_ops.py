@@ -1,0 +1,302 @@
+"""GPU (-m gpu): every C-ABI kernel family against a plain fp32 torch reference of the same op.
+
+fp32 mode (v_mfma_f32_16x16x4_f32) must agree to roundoff; bf16 mode to bf16 resolution.  Each test
+runs both modes.  Shapes include ragged / unaligned cases that force the scalar (non-vector) paths."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+MODES = ['fp32', 'bf16']
+TOL = {'fp32': 2e-5, 'bf16': 1.5e-2}
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+@pytest.fixture(params=MODES)
+def mode(request):
+    from opentransformer_amd import ops
+    ops.set_compute_dtype(request.param)
+    yield request.param
+    ops.set_compute_dtype('bf16')
+
+
+def adt(mode):
+    return torch.float32 if mode == 'fp32' else torch.bfloat16
+
+
+# ------------------------------------------------------------------------------------------ linear
+@pytest.mark.parametrize('M,N,K', [(128, 128, 32), (300, 200, 96), (7, 5, 3), (257, 131, 72), (1, 768, 256),
+                                   (480, 4234, 256), (1000, 64, 2560)])
+def test_linear_fwd_bwd(mode, M, N, K):
+    from opentransformer_amd import ops
+    for xdt in ([torch.float32] if mode == 'fp32' else [torch.float32, torch.bfloat16]):
+        x = rnd(M, K, seed=1).to(xdt).requires_grad_(True)
+        w = (rnd(N, K, seed=2) / math.sqrt(K)).requires_grad_(True)
+        b = rnd(N, seed=3).requires_grad_(True)
+        for odt in ([torch.float32] if mode == 'fp32' else [torch.float32, torch.bfloat16]):
+            y = ops.linear(x, w, b, out_dtype=odt)
+            yr = F.linear(x.float(), w, b)
+            assert rel(y.float(), yr) < TOL[mode], ('fwd', xdt, odt)
+            g = rnd(M, N, seed=4).to(odt)
+            dx, dw, db = torch.autograd.grad(y, (x, w, b), g)
+            dxr, dwr, dbr = torch.autograd.grad(yr, (x, w, b), g.float())
+            assert rel(dx.float(), dxr.float()) < TOL[mode], ('dgrad', xdt, odt)
+            assert rel(dw, dwr) < TOL[mode], ('wgrad', xdt, odt)
+            assert rel(db, dbr) < TOL[mode], ('dbias', xdt, odt)
+
+
+def test_linear_identity_asymmetric(mode):
+    """A = I with an asymmetric B catches operand / output transposes (guide rule G9)."""
+    from opentransformer_amd import ops
+    n = 64
+    x = torch.eye(n, device=DEV)
+    w = (torch.arange(n * n, device=DEV, dtype=torch.float32).reshape(n, n) % 97) / 16.0
+    y = ops.linear(x, w, None)
+    assert rel(y, w.t()) < TOL[mode]
+
+
+def test_linear_relu_and_strided_input(mode):
+    from opentransformer_amd import ops
+    big = rnd(50, 200, seed=5)
+    x = big[:, 8:104]                       # row stride 200, 96 columns
+    w = rnd(40, 96, seed=6) / 10
+    b = rnd(40, seed=7)
+    y = ops.linear(x, w, b, relu=True)
+    assert rel(y, F.relu(F.linear(x, w, b))) < TOL[mode]
+
+
+# ------------------------------------------------------------------------------------------ attention
+def ref_attention(q, k, v, key_mask, causal, H):
+    B, Tq, d = q.shape
+    Tk = k.shape[1]
+    dk = d // H
+    qh = q.float().view(B, Tq, H, dk).transpose(1, 2)
+    kh = k.float().view(B, Tk, H, dk).transpose(1, 2)
+    vh = v.float().view(B, Tk, H, dk).transpose(1, 2)
+    s = qh @ kh.transpose(2, 3) / math.sqrt(dk)
+    if key_mask is not None:
+        s = s.masked_fill(~key_mask.bool()[:, None, None, :], float('-inf'))
+    if causal:
+        s = s.masked_fill(~torch.tril(torch.ones(Tq, Tk, device=q.device)).bool(), float('-inf'))
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Tq, d)
+
+
+@pytest.mark.parametrize('B,T,H,dk,ragged,causal', [(3, 249, 4, 64, True, False), (2, 37, 4, 16, True, False),
+                                                     (2, 15, 4, 64, False, True), (1, 130, 2, 32, False, False),
+                                                     (2, 70, 4, 16, False, True)])
+def test_self_attention(mode, B, T, H, dk, ragged, causal):
+    from opentransformer_amd import ops
+    d = H * dk
+    qkv = (rnd(B, T, 3 * d, seed=11) * 0.7).to(adt(mode)).requires_grad_(True)
+    km = None
+    if ragged:
+        lens = [T - 13 * i for i in range(B)]
+        km = torch.zeros(B, T, dtype=torch.bool, device=DEV)
+        for i, n in enumerate(lens):
+            km[i, :n] = True
+    out = ops.SelfAttentionFn.apply(qkv, km.to(torch.uint8) if km is not None else None, H, causal)
+    qf = qkv.detach().float().requires_grad_(True)
+    ref = ref_attention(qf[..., :d], qf[..., d:2 * d], qf[..., 2 * d:], km, causal, H)
+    assert rel(out.float(), ref) < TOL[mode]
+    g = rnd(B, T, d, seed=12).to(adt(mode))
+    (dqkv,) = torch.autograd.grad(out, qkv, g)
+    (dref,) = torch.autograd.grad(ref, qf, g.float())
+    for nm, sl in (('dq', slice(0, d)), ('dk', slice(d, 2 * d)), ('dv', slice(2 * d, 3 * d))):
+        assert rel(dqkv[..., sl].float(), dref[..., sl]) < 2 * TOL[mode], nm
+
+
+@pytest.mark.parametrize('B,L,T,H,dk', [(3, 15, 249, 4, 64), (2, 1, 49, 4, 16), (2, 70, 100, 4, 16)])
+def test_cross_attention(mode, B, L, T, H, dk):
+    from opentransformer_amd import ops
+    d = H * dk
+    q = (rnd(B, L, d, seed=21) * 0.7).to(adt(mode)).requires_grad_(True)
+    kv = (rnd(B, T, 2 * d, seed=22) * 0.7).to(adt(mode)).requires_grad_(True)
+    km = torch.ones(B, T, dtype=torch.bool, device=DEV)
+    km[0, T - 9:] = False
+    out = ops.CrossAttentionFn.apply(q, kv, km.to(torch.uint8), H)
+    qf = q.detach().float().requires_grad_(True)
+    kvf = kv.detach().float().requires_grad_(True)
+    ref = ref_attention(qf, kvf[..., :d], kvf[..., d:], km, False, H)
+    assert rel(out.float(), ref) < TOL[mode]
+    g = rnd(B, L, d, seed=23).to(adt(mode))
+    dq, dkv = torch.autograd.grad(out, (q, kv), g)
+    dqr, dkvr = torch.autograd.grad(ref, (qf, kvf), g.float())
+    assert rel(dq.float(), dqr) < 2 * TOL[mode]
+    assert rel(dkv.float(), dkvr) < 2 * TOL[mode]
+
+
+# ------------------------------------------------------------------------------------------ add + layernorm
+@pytest.mark.parametrize('M,d', [(100, 256), (33, 64), (7, 384), (1000, 256)])
+def test_add_layernorm(mode, M, d):
+    from opentransformer_amd import ops
+    x = rnd(M, d, seed=31).requires_grad_(True)
+    a = rnd(M, d, seed=32).to(adt(mode)).requires_grad_(True)
+    gam = (1 + 0.1 * rnd(d, seed=33)).requires_grad_(True)
+    bet = (0.1 * rnd(d, seed=34)).requires_grad_(True)
+    y = ops.add_layernorm(x, a, gam, bet, 0.0)
+    yr = F.layer_norm(x + a.float(), (d,), gam, bet, 1e-5)
+    assert rel(y, yr) < 1e-5
+    g = rnd(M, d, seed=35)
+    grads = torch.autograd.grad(y, (x, a, gam, bet), g)
+    gref = torch.autograd.grad(yr, (x, a, gam, bet), g)
+    for nm, u, v in zip(('dx', 'da', 'dgamma', 'dbeta'), grads, gref):
+        assert rel(u.float(), v.float()) < (1e-4 if nm != 'da' or mode == 'fp32' else 1e-2), nm
+    # plain LayerNorm (a = None)
+    y2 = ops.add_layernorm(x, None, gam, bet, 0.0)
+    assert rel(y2, F.layer_norm(x, (d,), gam, bet, 1e-5)) < 1e-5
+
+
+def test_add_layernorm_dropout_statistics():
+    """Dropout parity is statistical: keep-rate, determinism per (seed, offset),
+    fresh masks per step, and the backward regenerating exactly the forward's mask."""
+    from opentransformer_amd import ops
+    ops.set_compute_dtype('fp32')
+    try:
+        M, d, p = 512, 256, 0.1
+        dev = torch.device(DEV)
+        x = torch.zeros(M, d, device=DEV, requires_grad=True)
+        a = torch.ones(M, d, device=DEV, requires_grad=True)
+        gam = torch.ones(d, device=DEV)
+        bet = torch.zeros(d, device=DEV)
+        ops.next_dropout_step(dev)
+        y = ops.add_layernorm(x, a, gam, bet, p)
+        ops._state['rng_offset'] = 0
+        assert torch.equal(y, ops.add_layernorm(x, a, gam, bet, p))      # same seed+offset -> same mask
+        ops.next_dropout_step(dev)
+        y2 = ops.add_layernorm(x, a, gam, bet, p)
+        assert not torch.equal(y, y2)                                     # new step -> new mask
+        dropped = y2 < 0            # z in {0, 1/(1-p)}: dropped elements sit below the row mean
+        assert abs(dropped.float().mean().item() - p) < 0.01
+        g = rnd(M, d, seed=36)
+        (da,) = torch.autograd.grad(y2, a, g)
+        assert bool(((da == 0) == dropped).all())                         # bwd mask == fwd mask
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
+# ------------------------------------------------------------------------------------------ FFN / GLU / misc
+@pytest.mark.parametrize('M,d,dff', [(200, 64, 256), (130, 256, 2048)])
+def test_ffn_glu(mode, M, d, dff):
+    from opentransformer_amd import ops
+    x = rnd(M, d, seed=41).requires_grad_(True)
+    w1 = (rnd(2 * dff, d, seed=42) / math.sqrt(d)).requires_grad_(True)
+    b1 = (0.1 * rnd(2 * dff, seed=43)).requires_grad_(True)
+    w2 = (rnd(d, dff, seed=44) / math.sqrt(dff)).requires_grad_(True)
+    b2 = (0.1 * rnd(d, seed=45)).requires_grad_(True)
+    y = ops.FeedForwardGLUFn.apply(x, w1, b1, w2, b2)
+    yr = F.linear(F.glu(F.linear(x, w1, b1), -1), w2, b2)
+    assert rel(y, yr) < TOL[mode]
+    g = rnd(M, d, seed=46)
+    grads = torch.autograd.grad(y, (x, w1, b1, w2, b2), g)
+    gref = torch.autograd.grad(yr, (x, w1, b1, w2, b2), g)
+    for nm, u, v in zip(('dx', 'dw1', 'db1', 'dw2', 'db2'), grads, gref):
+        assert rel(u, v) < 2 * TOL[mode], nm
+
+
+def test_posenc_and_embedding(mode):
+    from opentransformer_amd import ops
+    from oracle import otrans_oracle as orc
+    x = rnd(3, 49, 64, seed=51).requires_grad_(True)
+    y = ops.PosEncFn.apply(x)
+    yr = orc.add_posenc(x.detach().cpu())
+    assert rel(y.cpu(), yr) < 1e-5
+    (dx,) = torch.autograd.grad(y, x, torch.ones_like(y))
+    assert rel(dx, torch.full_like(dx, 8.0)) < 1e-6
+    E = rnd(100, 64, seed=52).requires_grad_(True)
+    tok = torch.randint(0, 100, (4, 11), generator=torch.Generator().manual_seed(1)).to(DEV)
+    tok[0, :3] = 7                                    # repeated ids exercise the atomic scatter
+    e = ops.EmbedPosEncFn.apply(tok, E)
+    er = orc.add_posenc(F.embedding(tok.cpu(), E.detach().cpu()))
+    assert rel(e.cpu(), er) < 1e-5
+    g = rnd(4, 11, 64, seed=53)
+    (dE,) = torch.autograd.grad(e, E, g)
+    Er = E.detach().clone().requires_grad_(True)
+    (dEr,) = torch.autograd.grad(F.embedding(tok, Er) * 8.0, Er, g)
+    assert rel(dE, dEr) < 1e-5
+
+
+def test_colsum_unaligned(mode):
+    from opentransformer_amd import ops
+    for M, N in [(1000, 256), (77, 4234), (5, 3)]:
+        a = rnd(M, N, seed=61).to(adt(mode))
+        assert rel(ops.colsum_raw(a), a.float().sum(0)) < (1e-5 if mode == 'fp32' else 1e-5)
+
+
+# ------------------------------------------------------------------------------------------ conv frontend
+@pytest.mark.parametrize('B,T,Fdim,C1,C2', [(2, 200, 80, 32, 64), (3, 97, 40, 64, 128), (1, 1000, 80, 64, 128)])
+def test_conv_subsample(mode, B, T, Fdim, C1, C2):
+    from opentransformer_amd import ops
+    x = rnd(B, T, Fdim, seed=71)
+    w1 = (rnd(C1, 1, 3, 3, seed=72) / 3).requires_grad_(True)
+    b1 = (0.1 * rnd(C1, seed=73)).requires_grad_(True)
+    w2 = (rnd(C2, C1, 3, 3, seed=74) / math.sqrt(9 * C1)).requires_grad_(True)
+    b2 = (0.1 * rnd(C2, seed=75)).requires_grad_(True)
+    w2r = w2.permute(0, 2, 3, 1).contiguous()
+    act2 = ops.ConvSubsampleFn.apply(x, w1, b1, w2r, b2)
+    h1 = F.relu(F.conv2d(x.unsqueeze(1), w1, b1, stride=2, padding=(0, 1)))
+    h2 = F.relu(F.conv2d(h1, w2, b2, stride=2, padding=(0, 1)))          # [B,C2,T2,F2]
+    ref = h2.permute(0, 2, 3, 1).reshape(B, h2.size(2), -1)               # [B,T2,F2*C2] channel-last
+    assert act2.shape == ref.shape
+    assert rel(act2.float(), ref) < TOL[mode]
+    g = rnd(*ref.shape, seed=76).to(adt(mode))
+    grads = torch.autograd.grad(act2, (w1, b1, w2, b2), g)
+    gref = torch.autograd.grad(ref, (w1, b1, w2, b2), g.float())
+    for nm, u, v in zip(('dw1', 'db1', 'dw2', 'db2'), grads, gref):
+        assert rel(u, v) < 3 * TOL[mode], nm
+
+
+# ------------------------------------------------------------------------------------------ losses
+def test_label_smoothing_loss():
+    from opentransformer_amd import ops
+    from oracle import otrans_oracle as orc
+    for R, V in [(44, 100), (480, 4234)]:
+        logits = rnd(4, R // 4, V, seed=81).requires_grad_(True)
+        tgt = torch.randint(1, V, (4, R // 4), generator=torch.Generator().manual_seed(2))
+        tgt[1, -3:] = 0
+        tgt[3, -1:] = 0
+        loss = ops.LabelSmoothingLossFn.apply(logits, tgt.to(DEV), 0.1, 0)
+        lc = logits.detach().cpu().requires_grad_(True)
+        ref = orc.label_smoothing_loss(lc, tgt, 0.1)
+        assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+        (dl,) = torch.autograd.grad(loss * 3.0, logits)
+        (dr,) = torch.autograd.grad(ref * 3.0, lc)
+        assert rel(dl.cpu(), dr) < 1e-5
+
+
+def test_log_softmax_and_ctc():
+    from opentransformer_amd import ops
+    B, T, V, Lm = 4, 49, 100, 11
+    logits = rnd(B, T, V, seed=91).requires_grad_(True)
+    assert rel(ops.log_softmax(logits.detach()), F.log_softmax(logits.detach(), -1)) < 1e-6
+    gen = torch.Generator().manual_seed(3)
+    tgt = torch.randint(1, V, (B, Lm), generator=gen)
+    tgt[0, 2] = tgt[0, 1]                               # repeated label needs the blank path
+    in_len = torch.tensor([49, 45, 30, 5])
+    tgt_len = torch.tensor([11, 8, 11, 6])              # last utterance is infeasible (T=5 < L=6)
+    loss = ops.CTCLossFn.apply(logits, tgt.to(DEV), in_len.to(DEV), tgt_len.to(DEV), 0)
+    lc = logits.detach().cpu().requires_grad_(True)
+    ref = F.ctc_loss(F.log_softmax(lc, -1).transpose(0, 1), tgt, in_len, tgt_len, blank=0, zero_infinity=True)
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
+    (dl,) = torch.autograd.grad(loss, logits)
+    (dr,) = torch.autograd.grad(ref, lc)
+    assert rel(dl.cpu(), dr) < 1e-4
+
+
+def test_cpu_tensor_is_refused():
+    from opentransformer_amd import ops, _lib
+    with pytest.raises(_lib.OtransHipError):
+        ops.linear(torch.zeros(4, 8), torch.zeros(3, 8), None)
