@@ -139,7 +139,7 @@ int32_t otr_relu_bwd(const void* y, const void* g, void* out, int32_t dtype, int
 
 /* ---- LabelSmoothingLoss (module/loss.py:21-48): logits f32 [R,V], target int64 [R].
  *      loss (f32 scalar) = sum_nonpad KL(conf || softmax) / #nonpad ; dlogits = d loss / d logits.
- *      scratch: f32[2] workspace. */
+ *      scratch: f32[R+2] workspace (per-row losses are reduced in a fixed order: deterministic). */
 int32_t otr_label_smoothing_loss(const float* logits, const int64_t* target, int64_t R, int32_t V, float smoothing,
                                  int32_t pad_idx, float* loss, float* dlogits, float* scratch, void* stream);
 

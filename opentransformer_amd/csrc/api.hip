@@ -31,9 +31,10 @@ static inline bool dtype_ok(int d) { return d == OTR_F32 || d == OTR_BF16; }
 static inline int kc_vec(const void* p, int64_t ld, int dtype) {
   return ((uintptr_t)p % 16 == 0) && (ld % (16 / esize(dtype)) == 0);
 }
-// 2-element vector path of the transposing loaders
-static inline int mc_vec(const void* p, int64_t ld, int dtype) {
-  return ((uintptr_t)p % (2 * esize(dtype)) == 0) && (ld % 2 == 0);
+// PM-element vector path of the transposing loaders (PM = 4 rows for bf16 compute, 2 for fp32)
+static inline int mc_vec(const void* p, int64_t ld, int dtype, int compute) {
+  int pm = compute == OTR_BF16 ? 4 : 2;
+  return ((uintptr_t)p % (pm * esize(dtype)) == 0) && (ld % pm == 0);
 }
 
 static int32_t run_gemm(const GemmArgs& a, int compute, int ad, int bd, int cd, int amode, int bmode, void* stream) {
@@ -78,7 +79,7 @@ extern "C" int32_t otr_linear_dgrad(const otr_linear_desc_t* d, const void* dy, 
   a.lda = d->ldy; a.ldb = d->ldw; a.ldc = d->ldx;
   a.act = OTR_ACT_NONE; a.accumulate = d->accumulate;
   a.a_vec = kc_vec(dy, d->ldy, d->y_dtype);
-  a.b_vec = mc_vec(w, d->ldw, d->w_dtype);
+  a.b_vec = mc_vec(w, d->ldw, d->w_dtype, d->compute);
   return run_gemm(a, d->compute, d->y_dtype, d->w_dtype, d->x_dtype, MODE_KC, MODE_MC, stream);
 }
 
@@ -91,8 +92,9 @@ extern "C" int32_t otr_linear_wgrad(const otr_linear_desc_t* d, const void* dy, 
   a.M = d->N; a.N = d->K; a.K = d->M;
   a.lda = d->ldy; a.ldb = d->ldx; a.ldc = d->ldw;
   a.act = OTR_ACT_NONE; a.accumulate = d->accumulate;
-  a.a_vec = mc_vec(dy, d->ldy, d->y_dtype);
-  a.b_vec = mc_vec(x, d->ldx, d->x_dtype);
+  a.a_vec = mc_vec(dy, d->ldy, d->y_dtype, d->compute);
+  a.b_vec = mc_vec(x, d->ldx, d->x_dtype, d->compute);
+  a.allow_split = 1;
   if (d->M == 0) return 0;
   return run_gemm(a, d->compute, d->y_dtype, d->x_dtype, d->w_dtype, MODE_MC, MODE_MC, stream);
 }
@@ -138,7 +140,7 @@ extern "C" int32_t otr_conv2_dgrad_cols(const otr_conv_desc_t* d, const void* da
   a.lda = d->C2; a.ldb = 9 * d->C1; a.ldc = 9 * d->C1;
   a.act = OTR_ACT_NONE; a.accumulate = 0;
   a.a_vec = kc_vec(dact2, a.lda, d->act_dtype);
-  a.b_vec = mc_vec(w2r, a.ldb, OTR_F32);
+  a.b_vec = mc_vec(w2r, a.ldb, OTR_F32, d->compute);
   return run_gemm(a, d->compute, d->act_dtype, OTR_F32, d->act_dtype, MODE_KC, MODE_MC, stream);
 }
 
@@ -151,7 +153,8 @@ extern "C" int32_t otr_conv2_wgrad(const otr_conv_desc_t* d, const void* dact2, 
   a.M = d->C2; a.N = 9 * d->C1; a.K = d->B * d->T2 * d->F2;
   a.lda = d->C2; a.ldb = 0; a.ldc = 9 * d->C1;
   a.act = OTR_ACT_NONE; a.accumulate = 0;
-  a.a_vec = mc_vec(dact2, a.lda, d->act_dtype);
-  a.b_vec = 0;
+  a.a_vec = mc_vec(dact2, a.lda, d->act_dtype, d->compute);
+  a.b_vec = ((uintptr_t)act1 % 16 == 0);
+  a.allow_split = 1;
   return run_gemm(a, d->compute, d->act_dtype, d->act_dtype, OTR_F32, MODE_MC, MODE_IM2M, stream);
 }

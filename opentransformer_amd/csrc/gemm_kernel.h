@@ -2,18 +2,24 @@
 //
 // One kernel template serves nn.Linear forward / dgrad / wgrad and the conv2 implicit GEMMs by
 // changing how each operand tile is gathered from HBM ("mode"); the LDS image and the MFMA loop are
-// always the same: tile rows x 64 bytes (4 chunks of 16 B = one MFMA k-step), XOR-swizzled so the
-// 16-lane ds_read_b128 operand reads are bank-conflict free.
+// always the same: tile rows x KCH 16-byte chunks (KCH/4 MFMA k-steps), XOR-swizzled so the 16-lane
+// ds_read_b128 operand reads are bank-conflict free.
 //
 //   MODE_KC      operand stored [rows][K], K contiguous            (x and w in y = x w^T)
 //   MODE_MC      operand stored [K][rows], rows contiguous         (w in dgrad; dy and x in wgrad)
-//                -> each thread gathers a 2(rows) x CE(k) patch and transposes it in registers
+//                -> each thread gathers a PM(rows) x CE(k) patch with PM-wide vector loads and
+//                   transposes it in registers (8x4 bf16 patches: 8-16 B per lane per load)
 //   MODE_IM2K    rows = conv2 output pixels, k = (kh,kw,c1) gathered from channel-last act1
 //   MODE_IM2M    rows = (kh,kw,c1), contraction = output pixels   (conv2 wgrad B operand)
 //
-// Pipeline: double-buffered LDS, global loads for tile t+1 are issued before the MFMAs of tile t
-// and written to the other buffer afterwards -> one barrier per k-step.
-// Workgroup = 4 waves in a 2x2 grid; wave tile (BM/2)x(BN/2) built from 16x16 MFMA tiles.
+// Pipeline: double-buffered LDS, global loads for stage t+1 are issued before the MFMAs of stage t
+// and written to the other buffer afterwards -> one barrier per BK = KCH*CE contraction elements
+// (64 for bf16).  Workgroup = 4 waves in a 2x2 grid; wave tile (BM/2)x(BN/2) of 16x16 MFMA tiles.
+// The accumulator is kept TRANSPOSED (mma(B-frag, A-frag)): lane holds row m = lane&15 and four
+// consecutive columns n = (lane>>4)*4.., so the epilogue stores 8-16 contiguous bytes per lane.
+//
+// Split-K (blockIdx.y): contraction-heavy / output-small problems (all weight gradients) are cut
+// into k-slices whose partial tiles are reduced with fp32 atomics into a pre-zeroed C.
 #pragma once
 #include <type_traits>
 
@@ -35,7 +41,17 @@ struct GemmArgs {
   int64_t lda, ldb, ldc;
   int act, accumulate;
   int a_vec, b_vec;  // operand base/ld satisfy the vector-load alignment
+  int ksplit;        // number of k-slices (grid.y); > 1 => atomic fp32 reduction
+  int allow_split;   // caller accepts the (order-nondeterministic) atomic reduction: weight gradients only
   ConvGeom cg;
+};
+
+template <class CT> struct GemmCfg {
+  static constexpr int CE = MMA<CT>::CE;
+  static constexpr int KCH = sizeof(CT) == 2 ? 8 : 4;   // chunks per tile row
+  static constexpr int BK = KCH * CE;                   // contraction elements per stage
+  static constexpr int ROWB = KCH * 16;                 // bytes per tile row
+  static constexpr int PM = sizeof(CT) == 2 ? 4 : 2;    // rows per transposing-loader patch
 };
 
 // pixel (b,t2,f2) -> element offset of act1[b, 2*t2, 2*f2-1, 0] (tap (0,0); may be "negative" in f)
@@ -48,24 +64,48 @@ __device__ __forceinline__ int64_t im2col_base(const ConvGeom& g, uint32_t m, in
   return (((int64_t)b * g.T1 + 2 * t2) * g.F1 + (2 * (int64_t)f2 - 1)) * g.C1;
 }
 
+template <class ST, int N> __device__ __forceinline__ void load_vec(const ST* p, float* out) {
+  if constexpr (sizeof(ST) == 4) {
+    if constexpr (N == 4) {
+      float4 v = *reinterpret_cast<const float4*>(p);
+      out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else {
+      float2 v = *reinterpret_cast<const float2*>(p);
+      out[0] = v.x; out[1] = v.y;
+    }
+  } else {
+    if constexpr (N == 4) {
+      uint2 v = *reinterpret_cast<const uint2*>(p);
+      out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xffff0000u);
+      out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xffff0000u);
+    } else {
+      uint32_t v = *reinterpret_cast<const uint32_t*>(p);
+      out[0] = __uint_as_float(v << 16); out[1] = __uint_as_float(v & 0xffff0000u);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
-// Operand tile loader.  ROWS x (4 chunks) per k-step, 256 threads.
+// Operand tile loader.  ROWS x KCH chunks per stage, 256 threads.
 template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
-  static constexpr int CE = MMA<CT>::CE;
+  using G = GemmCfg<CT>;
+  static constexpr int CE = G::CE, KCH = G::KCH, PM = G::PM;
   static constexpr bool ROWMAJOR = (MODE == MODE_KC || MODE == MODE_IM2K);
-  // row-major modes: NU chunk units per thread (unit u -> row = id>>2, chunk = id&3, id = tid+256u)
-  static constexpr int NU = ROWMAJOR ? (ROWS * 4 + 255) / 256 : 1;
-  // transposing modes: one (row pair, chunk) unit per thread: rp = tid % (ROWS/2), c = tid / (ROWS/2)
+  // row-major modes: NU chunk units per thread (unit id = tid + 256u -> row = id / KCH, chunk = id % KCH)
+  static constexpr int NU = ROWMAJOR ? (ROWS * KCH + 255) / 256 : 1;
+  // transposing modes: (ROWS/PM) x KCH patches of PM rows x CE k; patch id = tid + 256u
+  static constexpr int RG = ROWS / PM;
+  static constexpr int NP = ROWMAJOR ? 1 : (RG * KCH + 255) / 256;
 
   const ST* base;
   int64_t ld;
   int nrows, K, row0;
   bool vec;
-  float raw[ROWMAJOR ? NU : 2][CE];
+  float raw[ROWMAJOR ? NU : NP * PM][CE];
   // im2col state
   int64_t pix[ROWMAJOR ? NU : 1];
   int f2v[ROWMAJOR ? NU : 1];
-  int tapoff, tapkw;
+  int tapoff[ROWMAJOR ? 1 : NP], tapkw[ROWMAJOR ? 1 : NP];
 
   __device__ __forceinline__ void init(const void* p, int64_t ld_, int nrows_, int K_, int row0_, bool vec_,
                                        const ConvGeom& g, int tid) {
@@ -74,29 +114,33 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
     if constexpr (MODE == MODE_IM2K) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
-        int row = row0 + ((tid + 256 * u) >> 2);
+        int row = row0 + (tid + 256 * u) / KCH;
         pix[u] = (row < nrows) ? im2col_base(g, (uint32_t)row, f2v[u]) : 0;
       }
     }
     if constexpr (MODE == MODE_IM2M) {
-      int rp = tid % (ROWS / 2);
-      int n0 = row0 + 2 * rp;              // row index = tap*C1 + c1
-      uint32_t tap = fdiv((uint32_t)n0, g.divC1);
-      int ch = n0 - (int)tap * g.C1;
-      int kh = (int)tap / 3, kw = (int)tap - kh * 3;
-      tapoff = (kh * g.F1 + kw) * g.C1 + ch;
-      tapkw = kw;
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        int rg = (tid + 256 * u) % RG;
+        int n0 = row0 + PM * rg;             // row index = tap*C1 + c1 (PM channels share a tap)
+        uint32_t tap = fdiv((uint32_t)n0, g.divC1);
+        int ch = n0 - (int)tap * g.C1;
+        int kh = (int)tap / 3, kw = (int)tap - kh * 3;
+        tapoff[u] = (kh * g.F1 + kw) * g.C1 + ch;
+        tapkw[u] = kw;
+      }
     }
   }
 
-  // issue the global loads for the k-step starting at k0
+  // issue the global loads for the stage starting at k0
   __device__ __forceinline__ void load(int k0, const ConvGeom& g, int tid) {
     if constexpr (MODE == MODE_KC) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         int id = tid + 256 * u;
-        int row = row0 + (id >> 2), gk = k0 + (id & 3) * CE;
-        if ((id >> 2) < ROWS && row < nrows && gk < K) {
+        int lr = id / KCH;
+        int row = row0 + lr, gk = k0 + (id % KCH) * CE;
+        if (lr < ROWS && row < nrows && gk < K) {
           load_row<ST, CE>(base + (int64_t)row * ld + gk, K - gk, vec, raw[u]);
         } else {
 #pragma unroll
@@ -107,12 +151,13 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         int id = tid + 256 * u;
-        int row = row0 + (id >> 2), gk = k0 + (id & 3) * CE;
+        int lr = id / KCH;
+        int row = row0 + lr, gk = k0 + (id % KCH) * CE;
         uint32_t tap = fdiv((uint32_t)gk, g.divC1);
         int ch = gk - (int)tap * g.C1;
         int kh = (int)tap / 3, kw = (int)tap - kh * 3;
         int fin = 2 * f2v[u] + kw - 1;
-        if ((id >> 2) < ROWS && row < nrows && gk < K && fin >= 0 && fin < g.F1) {
+        if (lr < ROWS && row < nrows && gk < K && fin >= 0 && fin < g.F1) {
           load_row<ST, CE>(base + pix[u] + (int64_t)(kh * g.F1 + kw) * g.C1 + ch, CE, vec, raw[u]);
         } else {
 #pragma unroll
@@ -120,62 +165,69 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
         }
       }
     } else {
-      constexpr int RP = ROWS / 2;
-      int rp = tid % RP, c = tid / RP;
-      int r = row0 + 2 * rp;
-      bool active = c < 4;
 #pragma unroll
-      for (int j = 0; j < CE; ++j) {
-        int gk = k0 + c * CE + j;
-        float v0 = 0.f, v1 = 0.f;
-        if (active && gk < K) {
-          if constexpr (MODE == MODE_MC) {
-            const ST* p = base + (int64_t)gk * ld + r;
-            if (vec && r + 1 < nrows) {
-              if constexpr (sizeof(ST) == 4) {
-                float2 t = *reinterpret_cast<const float2*>(p);
-                v0 = t.x; v1 = t.y;
-              } else {
-                uint32_t t = *reinterpret_cast<const uint32_t*>(p);
-                v0 = __uint_as_float(t << 16); v1 = __uint_as_float(t & 0xffff0000u);
-              }
-            } else {
-              if (r < nrows) v0 = ElemIO<ST>::ld(p);
-              if (r + 1 < nrows) v1 = ElemIO<ST>::ld(p + 1);
+      for (int u = 0; u < NP; ++u) {
+        int id = tid + 256 * u;
+        int rg = id % RG, c = id / RG;
+        int r = row0 + PM * rg;
+        bool active = c < KCH;
+#pragma unroll
+        for (int j = 0; j < CE; ++j) {
+          int gk = k0 + c * CE + j;
+          float v[PM];
+#pragma unroll
+          for (int i = 0; i < PM; ++i) v[i] = 0.f;
+          if (active && gk < K) {
+            const ST* p;
+            bool ok = true;
+            if constexpr (MODE == MODE_MC) {
+              p = base + (int64_t)gk * ld + r;
+            } else {  // MODE_IM2M: contraction index gk = output pixel
+              int f2;
+              int64_t pb = im2col_base(g, (uint32_t)gk, f2);
+              int fin = 2 * f2 + tapkw[u] - 1;
+              ok = fin >= 0 && fin < g.F1;
+              p = base + pb + tapoff[u];
             }
-          } else {  // MODE_IM2M: contraction index gk = output pixel
-            int f2;
-            int64_t pb = im2col_base(g, (uint32_t)gk, f2);
-            int fin = 2 * f2 + tapkw - 1;
-            if (fin >= 0 && fin < g.F1) {
-              const ST* p = base + pb + tapoff;
-              if (r < nrows) v0 = ElemIO<ST>::ld(p);
-              if (r + 1 < nrows) v1 = ElemIO<ST>::ld(p + 1);
+            if (ok) {
+              if (vec && r + PM <= nrows) {
+                load_vec<ST, PM>(p, v);
+              } else {
+#pragma unroll
+                for (int i = 0; i < PM; ++i)
+                  if (r + i < nrows) v[i] = ElemIO<ST>::ld(p + i);
+              }
             }
           }
+#pragma unroll
+          for (int i = 0; i < PM; ++i) raw[u * PM + i][j] = v[i];
         }
-        raw[0][j] = v0;
-        raw[1][j] = v1;
       }
     }
   }
 
-  // convert to CT and write the tile image: byte(row, chunk) = row*64 + ((chunk ^ swz(row)) << 4)
+  // convert to CT and write the tile image: byte(row, chunk) = row*ROWB + ((chunk ^ swz(row)) << 4)
   __device__ __forceinline__ void store(unsigned char* lds, int tid) const {
     if constexpr (ROWMAJOR) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         int id = tid + 256 * u;
-        int row = id >> 2, c = id & 3;
-        if (row < ROWS) *reinterpret_cast<uint4*>(lds + row * 64 + ((c ^ swz<4>(row)) << 4)) = MMA<CT>::pack(raw[u]);
+        int row = id / KCH, c = id % KCH;
+        if (row < ROWS)
+          *reinterpret_cast<uint4*>(lds + row * G::ROWB + ((c ^ swz<KCH>(row)) << 4)) = MMA<CT>::pack(raw[u]);
       }
     } else {
-      constexpr int RP = ROWS / 2;
-      int rp = tid % RP, c = tid / RP;
-      if (c < 4) {
-        int row = 2 * rp;
-        *reinterpret_cast<uint4*>(lds + row * 64 + ((c ^ swz<4>(row)) << 4)) = MMA<CT>::pack(raw[0]);
-        *reinterpret_cast<uint4*>(lds + (row + 1) * 64 + ((c ^ swz<4>(row + 1)) << 4)) = MMA<CT>::pack(raw[1]);
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        int id = tid + 256 * u;
+        int rg = id % RG, c = id / RG;
+        if (c < KCH) {
+#pragma unroll
+          for (int i = 0; i < PM; ++i) {
+            int row = PM * rg + i;
+            *reinterpret_cast<uint4*>(lds + row * G::ROWB + ((c ^ swz<KCH>(row)) << 4)) = MMA<CT>::pack(raw[u * PM + i]);
+          }
+        }
       }
     }
   }
@@ -184,15 +236,23 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
 // ------------------------------------------------------------------------------------------------
 template <class CT, class AT, class BT, class OT, int AMODE, int BMODE, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
-  constexpr int CE = MMA<CT>::CE;
-  constexpr int BK = 4 * CE;
+  using G = GemmCfg<CT>;
+  constexpr int KCH = G::KCH, BK = G::BK, ROWB = G::ROWB;
   constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * 64];
+  constexpr int BUF = (BM + BN) * ROWB;  // bytes per pipeline stage: A tile then B tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+
+  // k-slice of this workgroup
+  const int nk_total = (p.K + BK - 1) / BK;
+  const int per = (nk_total + p.ksplit - 1) / p.ksplit;
+  const int kt0 = blockIdx.y * per;
+  const int kt1 = min(nk_total, kt0 + per);
+  if (kt0 >= kt1) return;
 
   TileLoader<CT, AT, AMODE, BM> la;
   TileLoader<CT, BT, BMODE, BN> lb;
@@ -205,77 +265,132 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  constexpr int BUF = (BM + BN) * 64;  // bytes per pipeline stage: A tile then B tile
-
-  const int nk = (p.K + BK - 1) / BK;
-  la.load(0, p.cg, tid);
-  lb.load(0, p.cg, tid);
+  la.load(kt0 * BK, p.cg, tid);
+  lb.load(kt0 * BK, p.cg, tid);
   la.store(smem, tid);
-  lb.store(smem + BM * 64, tid);
+  lb.store(smem + BM * ROWB, tid);
   __syncthreads();
 
   const int fr = lane & 15, fg = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nk;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    const bool more = kt + 1 < kt1;
     if (more) {
       la.load((kt + 1) * BK, p.cg, tid);
       lb.load((kt + 1) * BK, p.cg, tid);
     }
-    uint4 af[FM], bf[FN];
+    const unsigned char* sa = smem + cur * BUF;
+    const unsigned char* sb = sa + BM * ROWB;
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      int row = wm * WM + i * 16 + fr;
-      af[i] = *reinterpret_cast<const uint4*>(smem + cur * BUF + row * 64 + ((fg ^ swz<4>(row)) << 4));
+    for (int ks = 0; ks < KCH / 4; ++ks) {
+      uint4 af[FM], bf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        int row = wm * WM + i * 16 + fr;
+        af[i] = *reinterpret_cast<const uint4*>(sa + row * ROWB + (((ks * 4 + fg) ^ swz<KCH>(row)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        int row = wn * WN + j * 16 + fr;
+        bf[j] = *reinterpret_cast<const uint4*>(sb + row * ROWB + (((ks * 4 + fg) ^ swz<KCH>(row)) << 4));
+      }
+      // transposed accumulator: tile rows = n (B side), cols = m (A side)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) MMA<CT>::mma(acc[i][j], bf[j], af[i]);
     }
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      int row = wn * WN + j * 16 + fr;
-      bf[j] = *reinterpret_cast<const uint4*>(smem + cur * BUF + BM * 64 + row * 64 + ((fg ^ swz<4>(row)) << 4));
-    }
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) MMA<CT>::mma(acc[i][j], af[i], bf[j]);
     if (more) {
       la.store(smem + (cur ^ 1) * BUF, tid);
-      lb.store(smem + (cur ^ 1) * BUF + BM * 64, tid);
+      lb.store(smem + (cur ^ 1) * BUF + BM * ROWB, tid);
     }
     __syncthreads();
   }
 
-  // epilogue: C layout col = lane&15, row = (lane>>4)*4 + r
+  // epilogue: acc[i][j][r] = C[m = .. + i*16 + (lane&15)][n = .. + j*16 + (lane>>4)*4 + r]
   OT* C = reinterpret_cast<OT*>(p.C);
+  const bool split = p.ksplit > 1;
+  const bool add_bias = p.bias && (!split || blockIdx.y == 0);
+  const bool vec_out = (p.ldc % 4 == 0) && ((uintptr_t)p.C % 16 == 0);
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
+    int row = tile_m * BM + wm * WM + i * 16 + fr;
+    if (row >= p.M) continue;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      int col = tile_n * BN + wn * WN + j * 16 + fr;
+      int col = tile_n * BN + wn * WN + j * 16 + fg * 4;
       if (col >= p.N) continue;
-      float bv = p.bias ? p.bias[col] : 0.f;
+      OT* dst = C + (int64_t)row * p.ldc + col;
+      float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int row = tile_m * BM + wm * WM + i * 16 + fg * 4 + r;
-        if (row >= p.M) continue;
-        float v = acc[i][j][r] + bv;
-        OT* dst = C + (int64_t)row * p.ldc + col;
-        if (p.accumulate) v += ElemIO<OT>::ld(dst);
-        if (p.act == OTR_ACT_RELU) v = fmaxf(v, 0.f);
-        ElemIO<OT>::st(dst, v);
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + ((add_bias && col + r < p.N) ? p.bias[col + r] : 0.f);
+      if constexpr (std::is_same<OT, float>::value) {
+        if (split) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (col + r < p.N) atomicAdd(dst + r, v[r]);
+          continue;
+        }
+      }
+      const bool full = col + 4 <= p.N && vec_out;
+      if (p.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col + r < p.N) v[r] += ElemIO<OT>::ld(dst + r);
+      }
+      if (p.act == OTR_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (full) {
+        if constexpr (sizeof(OT) == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        else *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col + r < p.N) ElemIO<OT>::st(dst + r, v[r]);
       }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tile / split-K selection.  Goal: >= ~512 workgroups (2 per CU) whenever the problem allows it.
 template <class CT, class AT, class BT, class OT, int AMODE, int BMODE>
-static int32_t gemm_launch_tiles(const GemmArgs& a, hipStream_t s) {
-  int64_t blocks128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
-  if (blocks128 >= 256) {
-    hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 128, 128>), dim3((unsigned)blocks128), dim3(256), 0, s, a);
+static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
+  constexpr int BK = GemmCfg<CT>::BK;
+  const int nk = (a.K + BK - 1) / BK;
+  const bool can_split = a.allow_split && std::is_same<OT, float>::value && a.act == OTR_ACT_NONE;
+  const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
+  const int64_t t64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
+  auto splits_for = [&](int64_t tiles) {
+    if (!can_split) return 1;
+    int64_t want = (512 + tiles - 1) / tiles;
+    int64_t cap = nk / 4 > 0 ? nk / 4 : 1;
+    return (int)(want < cap ? want : cap);
+  };
+  bool big = a.M >= 128 && a.N >= 128;
+  int ks = 1;
+  if (big && t128 >= 256) {
+    ks = 1;
+  } else if (big && t128 * splits_for(t128) >= 256) {
+    ks = splits_for(t128);
   } else {
-    int64_t blocks64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
-    hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 64, 64>), dim3((unsigned)blocks64), dim3(256), 0, s, a);
+    big = false;
+    ks = splits_for(t64);
+  }
+  a.ksplit = ks;
+  if (ks > 1 && !a.accumulate) {  // atomic reduction needs a zeroed destination
+    hipError_t e = hipMemset2DAsync(a.C, (size_t)a.ldc * sizeof(float), 0, (size_t)a.N * sizeof(float), (size_t)a.M, s);
+    if (e != hipSuccess) {
+      otr_set_error("gemm: memset for split-K failed: %s", hipGetErrorString(e));
+      return (int32_t)e;
+    }
+  }
+  if (big) {
+    hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 128, 128>), dim3((unsigned)t128, ks), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 64, 64>), dim3((unsigned)t64, ks), dim3(256), 0, s, a);
   }
   return otr_check_launch("gemm");
 }

@@ -15,13 +15,22 @@ __device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
   return r;
 }
 
-// scratch[0] = number of non-pad rows; loss zeroed
-__global__ void ls_count_kernel(const int64_t* target, int64_t R, int pad_idx, float* scratch, float* loss) {
+// scratch[0] = number of non-pad rows
+__global__ void ls_count_kernel(const int64_t* target, int64_t R, int pad_idx, float* scratch) {
   __shared__ float sh[4];
   float c = 0.f;
   for (int64_t i = threadIdx.x; i < R; i += blockDim.x) c += (target[i] != pad_idx) ? 1.f : 0.f;
   c = block_reduce(c, sh, false);
-  if (threadIdx.x == 0) { scratch[0] = c; *loss = 0.f; }
+  if (threadIdx.x == 0) scratch[0] = c;
+}
+
+// deterministic final reduction: loss = sum_r row_loss[r] (fixed order, one block)
+__global__ void ls_finalize_kernel(const float* row_loss, int64_t R, float* loss) {
+  __shared__ float sh[4];
+  float c = 0.f;
+  for (int64_t i = threadIdx.x; i < R; i += blockDim.x) c += row_loss[i];
+  c = block_reduce(c, sh, false);
+  if (threadIdx.x == 0) *loss = c;
 }
 
 // KL(conf || softmax(logits)) per row, conf = 1-eps on the target, eps/(V-1) elsewhere.
@@ -29,7 +38,7 @@ __global__ void ls_count_kernel(const int64_t* target, int64_t R, int pad_idx, f
 //   C = (1-eps) log(1-eps) + eps log(eps/(V-1))        (0 log 0 := 0, as torch's kl_div)
 //   d row_loss / d logit_v = softmax_v - conf_v
 __global__ __launch_bounds__(256) void ls_rows_kernel(const float* logits, const int64_t* target, int V, float eps,
-                                                     int pad_idx, const float* scratch, float* loss, float* dlogits) {
+                                                     int pad_idx, const float* scratch, float* row_loss, float* dlogits) {
   __shared__ float sh[4];
   const int64_t row = blockIdx.x;
   const float* x = logits + row * V;
@@ -37,6 +46,7 @@ __global__ __launch_bounds__(256) void ls_rows_kernel(const float* logits, const
   const int64_t t = target[row];
   if (t == pad_idx) {
     if (dx) for (int v = threadIdx.x; v < V; v += blockDim.x) dx[v] = 0.f;
+    if (threadIdx.x == 0) row_loss[row] = 0.f;
     return;
   }
   float mx = -__builtin_huge_valf();
@@ -60,7 +70,7 @@ __global__ __launch_bounds__(256) void ls_rows_kernel(const float* logits, const
     float sum_logp = sx - (float)V * lse;
     float C = (on > 0.f ? on * logf(on) : 0.f) + (eps > 0.f ? eps * logf(off) : 0.f);
     float rl = C - (on * logp_t + off * (sum_logp - logp_t));
-    atomicAdd(loss, rl * inv_cnt);
+    row_loss[row] = rl * inv_cnt;
   }
 }
 
@@ -71,8 +81,9 @@ extern "C" int32_t otr_label_smoothing_loss(const float* logits, const int64_t* 
   OTR_REQUIRE(R > 0 && V > 1, "label_smoothing_loss: bad shape R=%lld V=%d", (long long)R, V);
   OTR_REQUIRE(smoothing >= 0.f && smoothing < 1.f, "label_smoothing_loss: smoothing out of [0,1)");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(ls_count_kernel, dim3(1), dim3(256), 0, s, target, R, pad_idx, scratch, loss);
-  hipLaunchKernelGGL(ls_rows_kernel, dim3((unsigned)R), dim3(256), 0, s, logits, target, V, smoothing, pad_idx, scratch, loss, dlogits);
+  hipLaunchKernelGGL(ls_count_kernel, dim3(1), dim3(256), 0, s, target, R, pad_idx, scratch);
+  hipLaunchKernelGGL(ls_rows_kernel, dim3((unsigned)R), dim3(256), 0, s, logits, target, V, smoothing, pad_idx, scratch, scratch + 2, dlogits);
+  hipLaunchKernelGGL(ls_finalize_kernel, dim3(1), dim3(256), 0, s, scratch + 2, R, loss);
   return otr_check_launch("label_smoothing_loss");
 }
 

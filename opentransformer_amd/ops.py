@@ -461,7 +461,7 @@ class LabelSmoothingLossFn(torch.autograd.Function):
         tg = target.reshape(-1).contiguous()
         loss = torch.empty((), dtype=torch.float32, device=lg.device)
         dlogits = torch.empty_like(lg) if ctx.needs_input_grad[0] else None
-        scratch = torch.empty((2,), dtype=torch.float32, device=lg.device)
+        scratch = torch.empty((lg.shape[0] + 2,), dtype=torch.float32, device=lg.device)
         L.check(L.load().otr_label_smoothing_loss(_p(lg), _p(tg), lg.shape[0], V, smoothing, pad_idx, _p(loss),
                                                   _p(dlogits), _p(scratch), _stream()), 'otr_label_smoothing_loss')
         ctx.save_for_backward(dlogits)
