@@ -201,6 +201,9 @@ def main():
             'model_tflops_per_s': utt_s * flops_utt / 1e12,
             'model_mfma_frac': utt_s * flops_utt / 1e12 / world / (PEAK_BF16_TFLOPS if args.mode == 'bf16' else PEAK_F32_TFLOPS),
         }
+        st = opt.stats()
+        if st['skipped'] != 0 or not (st['grad_sqnorm'] == st['grad_sqnorm'] and st['grad_sqnorm'] < float('inf')):
+            out['INVALID'] = 'non-finite gradient norm: %d optimizer updates were skipped' % int(st['skipped'])
         out['roofline'] = time_dominant_kernel(model, args.mode)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)

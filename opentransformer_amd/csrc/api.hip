@@ -22,6 +22,15 @@ int32_t otr_check_launch(const char* what) {
   return 0;
 }
 
+static __global__ void zero_f32_kernel(float* p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+void otr_zero_f32(float* p, int64_t n, hipStream_t s) {
+  if (n <= 0) return;
+  unsigned g = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  hipLaunchKernelGGL(zero_f32_kernel, dim3(g), dim3(256), 0, s, p, n);
+}
+
 extern "C" int32_t otr_version(void) { return 100; }
 extern "C" const char* otr_last_error_string(void) { return g_err; }
 
@@ -80,6 +89,7 @@ extern "C" int32_t otr_linear_dgrad(const otr_linear_desc_t* d, const void* dy, 
   a.act = OTR_ACT_NONE; a.accumulate = d->accumulate;
   a.a_vec = kc_vec(dy, d->ldy, d->y_dtype);
   a.b_vec = mc_vec(w, d->ldw, d->w_dtype, d->compute);
+  a.allow_split = 1;  // gradients may use the atomic k-slice reduction (fp32 outputs only)
   return run_gemm(a, d->compute, d->y_dtype, d->w_dtype, d->x_dtype, MODE_KC, MODE_MC, stream);
 }
 

@@ -25,6 +25,9 @@ typedef uint16_t bf16_t;  // raw bf16 bits in memory
 // ---------------------------------------------------------------- error plumbing (host)
 void otr_set_error(const char* fmt, ...);
 int32_t otr_check_launch(const char* what);
+// Zero n floats with a kernel.  The library never uses hipMemset*: under hipGraph capture on ROCm 7.2
+// a captured memset node was observed to leave every 4th float of a pool buffer stale on replay.
+void otr_zero_f32(float* p, int64_t n, hipStream_t s);
 #define OTR_REQUIRE(cond, ...)          \
   do {                                  \
     if (!(cond)) {                      \

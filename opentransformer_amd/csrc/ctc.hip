@@ -127,8 +127,7 @@ extern "C" int32_t otr_ctc_loss(const float* log_probs, const int64_t* targets, 
     unsigned g = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     hipLaunchKernelGGL(ctc_dense_kernel, dim3(g), dim3(256), 0, s, log_probs, dlogits, in_len, tgt_len, B, T, V, loss);
   } else {
-    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
-    if (e != hipSuccess) { otr_set_error("ctc_loss: memset failed"); return (int32_t)e; }
+    otr_zero_f32(loss, 1, s);
   }
   hipLaunchKernelGGL(ctc_alpha_beta_kernel, dim3(B), dim3(256), 0, s, log_probs, targets, ldt, in_len, tgt_len, B, T, V,
                      blank, alpha_ws, 2 * max_tgt + 1, nll, loss, dlogits);

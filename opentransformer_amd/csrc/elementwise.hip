@@ -214,10 +214,7 @@ extern "C" int32_t otr_colsum(const void* a, int32_t dtype, int64_t M, int64_t N
   OTR_REQUIRE(N > 0 && M >= 0 && lda >= N, "colsum: bad shape");
   OTR_REQUIRE((uintptr_t)a % 16 == 0, "colsum: input must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate) {
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
-    if (e != hipSuccess) { otr_set_error("colsum: memset failed: %s", hipGetErrorString(e)); return (int32_t)e; }
-  }
+  if (!accumulate) otr_zero_f32(out, N, s);
   if (M == 0) return 0;
   dim3 grid((unsigned)((N + 255) / 256), (unsigned)((M + CS_RPB - 1) / CS_RPB)), block(64, 4);
   if (dtype == OTR_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)a, M, N, lda, out);

@@ -354,6 +354,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
 }
 
+// zero an [M, N] fp32 matrix with leading dimension ldc (kernel, not hipMemset2D: stays a plain
+// kernel node under hipGraph capture)
+static __global__ void gemm_zero_kernel(float* C, int M, int N, int64_t ldc) {
+  const int64_t total = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / N;
+    C[r * ldc + (i - r * N)] = 0.f;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Tile / split-K selection.  Goal: >= ~512 workgroups (2 per CU) whenever the problem allows it.
 template <class CT, class AT, class BT, class OT, int AMODE, int BMODE>
@@ -381,11 +391,9 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
   }
   a.ksplit = ks;
   if (ks > 1 && !a.accumulate) {  // atomic reduction needs a zeroed destination
-    hipError_t e = hipMemset2DAsync(a.C, (size_t)a.ldc * sizeof(float), 0, (size_t)a.N * sizeof(float), (size_t)a.M, s);
-    if (e != hipSuccess) {
-      otr_set_error("gemm: memset for split-K failed: %s", hipGetErrorString(e));
-      return (int32_t)e;
-    }
+    int64_t total = (int64_t)a.M * a.N;
+    unsigned zg = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(gemm_zero_kernel, dim3(zg), dim3(256), 0, s, (float*)a.C, a.M, a.N, a.ldc);
   }
   if (big) {
     hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 128, 128>), dim3((unsigned)t128, ks), dim3(256), 0, s, a);

@@ -73,8 +73,7 @@ extern "C" int32_t otr_optimizer_step(float* param, const float* grad, float* ex
   OTR_REQUIRE((uintptr_t)grad % 16 == 0, "optimizer_step: grad buffer must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   OptState* st = reinterpret_cast<OptState*>(state);
-  hipError_t e = hipMemsetAsync(&st->sqnorm, 0, sizeof(float), s);
-  if (e != hipSuccess) { otr_set_error("optimizer_step: memset failed: %s", hipGetErrorString(e)); return (int32_t)e; }
+  otr_zero_f32(&st->sqnorm, 1, s);
   unsigned grid = (unsigned)((n / 4 + 255) / 256 > 2048 ? 2048 : (n / 4 + 255) / 256);
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(256), 0, s, grad, n, st);

@@ -1,0 +1,112 @@
+"""CPU (-m "not gpu"): the data-parallel engine with world_size 2 over gloo.
+
+FlatDataParallel is model-agnostic host logic, so it is exercised here on CPU tensors with a small
+torch module whose loss is normalised per replica by its own token count -- exactly the property
+that makes nn.DataParallel's result (mean of per-replica losses: trainer.py:208) equal to
+all-reduce-sum / N."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from opentransformer_amd.dp import FlatDataParallel
+
+
+class Tiny(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.emb = torch.nn.Embedding(11, 8)
+        self.l1 = torch.nn.Linear(8, 16)
+        self.out = torch.nn.Linear(16, 11)
+        self.out2 = torch.nn.Linear(8, 11, bias=False)
+        self.out2.weight = self.emb.weight          # tied, like decoder embedding/output_layer
+
+    def forward(self, tok, tgt):
+        h = torch.relu(self.l1(self.emb(tok)))
+        logits = self.out(h) + self.out2(self.emb(tok))
+        keep = tgt != 0
+        nll = torch.nn.functional.cross_entropy(logits.view(-1, 11), tgt.view(-1), reduction='none')
+        return (nll * keep.view(-1)).sum() / keep.sum()      # normalised by THIS replica's token count
+
+
+def _data():
+    g = torch.Generator().manual_seed(0)
+    tok = torch.randint(1, 11, (8, 6), generator=g)
+    tgt = torch.randint(1, 11, (8, 6), generator=g)
+    tgt[1, 3:] = 0
+    tgt[6, 1:] = 0
+    return tok, tgt
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model = Tiny()
+    if rank == 1:                                   # replicas start different; broadcast must fix that
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    dp = FlatDataParallel(model)
+    dp.broadcast_parameters(0)
+    tok, tgt = _data()
+    shard = slice(rank * 4, rank * 4 + 4)           # contiguous utterance shards, like DataParallel.scatter
+    dp.zero_grad()
+    loss = dp(tok[shard], tgt[shard])
+    loss.backward()
+    scale, _ = dp.all_reduce_gradients()
+    grads = dp.flat_grad[:dp.numel] * scale
+    if rank == 0:
+        torch.save({'grad': grads.clone(), 'loss': loss.detach(), 'n': dp.numel,
+                    'views_ok': all(p.grad.data_ptr() >= dp.flat_grad.data_ptr() for p in dp.params)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_allreduce_equals_dataparallel_semantics(tmp_path):
+    out = str(tmp_path / 'r0.pt')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    # reference semantics: loss = mean_i(loss_i), each shard normalised by its own token count
+    model = Tiny()
+    tok, tgt = _data()
+    loss = 0.5 * (model(tok[:4], tgt[:4]) + model(tok[4:], tgt[4:]))
+    params, seen = [], set()
+    for p in model.parameters():
+        if id(p) not in seen:
+            seen.add(id(p))
+            params.append(p)
+    ref = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, params)])
+    assert got['n'] == ref.numel() and got['views_ok']
+    torch.testing.assert_close(got['grad'], ref, rtol=1e-5, atol=1e-6)
+    # and it is NOT the globally token-normalised mean (shards have different token counts)
+    glob = torch.cat([g.reshape(-1) for g in torch.autograd.grad(model(tok, tgt), params)])
+    assert (glob - ref).abs().max() > 1e-4
+
+
+def test_flat_buffers_alias_parameters():
+    model = Tiny()
+    before = [p.detach().clone() for p in model.parameters()]
+    dp = FlatDataParallel(model)
+    for p, b in zip(model.parameters(), before):
+        assert torch.equal(p.detach(), b)                   # flattening preserves values
+    dp.flat_param.add_(1.0)
+    for p, b in zip(model.parameters(), before):
+        assert torch.equal(p.detach(), b + 1.0)             # parameters are views into the flat buffer
+    tok, tgt = _data()
+    dp.zero_grad()
+    dp(tok, tgt).backward()
+    assert float(dp.flat_grad.abs().sum()) > 0              # autograd accumulated into the flat views
+    assert model.emb.weight.grad.data_ptr() == model.out2.weight.grad.data_ptr()

@@ -48,7 +48,8 @@ def main():
         t = time.time()
         fwd_bwd()
         torch.cuda.synchronize()
-        say('eager fwd_bwd %d: %.1f ms loss %.5f' % (i, (time.time() - t) * 1e3, loss_buf.item()))
+        say('eager fwd_bwd %d: %.1f ms loss %.5f grad_norm %.5f' % (i, (time.time() - t) * 1e3, loss_buf.item(),
+                                                                float(dp.flat_grad.double().norm())))
     faulthandler.dump_traceback_later(120, exit=True)
     t = time.time()
     opt.step(1.0)
@@ -74,7 +75,15 @@ def main():
         t = time.time()
         g.replay()
         torch.cuda.synchronize()
-        say('replay %d: %.2f ms loss %.5f' % (i, (time.time() - t) * 1e3, loss_buf.item()))
+        say('replay %d: %.2f ms loss %.5f grad_norm %.5f' % (i, (time.time() - t) * 1e3, loss_buf.item(),
+                                                           float(dp.flat_grad.double().norm())))
+        bad = [(k, float(p.grad.abs().max()), int((p.grad.abs() > 1e6).sum()), p.grad.numel())
+               for k, p in model.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 1e6]
+        if bad:
+            say('HUGE grads (name, max, count>1e6, numel):', bad[:10], '(%d tensors)' % len(bad))
+            k, p = [(k, p) for k, p in model.named_parameters() if k == bad[0][0]][0]
+            idx = (p.grad.abs() > 1e6).nonzero()[:8].tolist()
+            say('  first bad indices:', idx, 'values', [float(p.grad[tuple(i)]) for i in idx])
     faulthandler.dump_traceback_later(120, exit=True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -85,7 +94,7 @@ def main():
     torch.cuda.synchronize()
     say('10x (replay + optimizer): %.2f ms / step' % (e0.elapsed_time(e1) / 10))
     faulthandler.cancel_dump_traceback_later()
-    if which != 'c1':
+    if which == 'cpu':
         from oracle import otrans_oracle as orc
         from tests import helpers as H
         parts = H.require_grad(H.filled_state(syn.c2_model(0.0)))
