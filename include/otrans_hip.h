@@ -165,6 +165,19 @@ int32_t otr_optimizer_step(float* param, const float* grad, float* exp_avg, floa
                            float grad_scale, float clip_norm, float noam_model_size, float noam_warmup,
                            float noam_factor, float noam_step_offset, void* stream);
 
+/* ---- batch beam search step (recognize/speech2text.py:95-192).
+ * beam_topk: rows = batch*beam hypotheses; logits f32 [rows, V] (row stride ld) are the decoder logits of
+ *   the last position; optional LM logits are fused as log_softmax(dec) + lm_weight*log_softmax(lm)
+ *   (speech2text.py:102-105); writes the k best (score, token) per row, descending (:112).
+ * beam_prune: finished-beam masking (:156-192), score update, top-k over beam^2 candidates, prefix
+ *   gather + token append (:118-146).  preds_* int64 [batch*beam, ldp] hold t tokens on entry, t+1 on
+ *   exit; n_finished (int32 device scalar) = number of hypotheses ending in EOS after the step. */
+int32_t otr_beam_topk(const float* logits, int64_t ld, const float* lm_logits, int64_t ld_lm, float lm_weight,
+                      int64_t rows, int32_t V, int32_t k, float* out_score, int64_t* out_idx, void* stream);
+int32_t otr_beam_prune(const float* k_score, const int64_t* k_idx, const float* scores_in, const uint8_t* flag_in,
+                       const int64_t* preds_in, int64_t ldp, int32_t batch, int32_t beam, int32_t t, int32_t eos,
+                       float* scores_out, uint8_t* flag_out, int64_t* preds_out, int32_t* n_finished, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

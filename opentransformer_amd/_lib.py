@@ -72,6 +72,8 @@ SIGNATURES = {
     'otr_log_softmax': [_P, _P, _I64, _I32, _P],
     'otr_ctc_loss': [_P, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     'otr_optimizer_step': [_P, _P, _P, _P, _I64, _P] + [_F32] * 11 + [_P],
+    'otr_beam_topk': [_P, _I64, _P, _I64, _F32, _I64, _I32, _I32, _P, _P, _P],
+    'otr_beam_prune': [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
 }
 _RESTYPE = {'otr_last_error_string': C.c_char_p}
 

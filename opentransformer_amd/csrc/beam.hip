@@ -1,0 +1,172 @@
+// Batch beam search scoring step (recognize/speech2text.py:95-192), device resident:
+//  * beam_topk:  per hypothesis row: log_softmax(decoder logits) [+ lm_weight * log_softmax(LM logits)]
+//                fused with top-k(beam) over the vocabulary -- the [rows, V] log-prob tensor is never
+//                written (speech2text.py:100-112).
+//  * beam_prune: per utterance: mask finished beams (one live branch with score 0 emitting EOS:
+//                speech2text.py:156-192), add to the running scores, top-k(beam) over beam^2
+//                candidates, gather the surviving prefixes and append the new token (:118-146).
+// Ties are broken towards the lower candidate index.
+#include "common.h"
+
+#define NEG_INF (-__builtin_huge_valf())
+constexpr int MAXK = 16;
+
+__device__ __forceinline__ void block_lse(const float* x, int V, float* sh, float& mx, float& lse) {
+  float m = NEG_INF;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) m = fmaxf(m, x[v]);
+  m = wave_max(m);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  float s = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) s += expf(x[v] - m);
+  s = wave_sum(s);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  s = sh[0] + sh[1] + sh[2] + sh[3];
+  mx = m;
+  lse = m + logf(s);
+}
+
+__global__ __launch_bounds__(256) void beam_topk_kernel(const float* logits, int64_t ld, const float* lm_logits,
+                                                       int64_t ld_lm, float lm_weight, int V, int k, float* out_score,
+                                                       int64_t* out_idx) {
+  __shared__ float sh[4];
+  __shared__ float cand_s[256];
+  __shared__ int cand_i[256];
+  const int64_t row = blockIdx.x;
+  const float* x = logits + row * ld;
+  const float* y = lm_logits ? lm_logits + row * ld_lm : nullptr;
+  float mx, lse, lmx, llse = 0.f;
+  block_lse(x, V, sh, mx, lse);
+  if (y) block_lse(y, V, sh, lmx, llse);
+  // per-thread sorted top-k over its strided slice (descending, ties -> lower index first)
+  float ts[MAXK];
+  int ti[MAXK];
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) { ts[j] = NEG_INF; ti[j] = 0x7fffffff; }
+  for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    float s = x[v] - lse;
+    if (y) s += lm_weight * (y[v] - llse);
+    if (s > ts[k - 1] || (s == ts[k - 1] && v < ti[k - 1])) {
+      ts[k - 1] = s; ti[k - 1] = v;
+#pragma unroll
+      for (int j = MAXK - 1; j > 0; --j) {
+        if (j < k && (ts[j] > ts[j - 1] || (ts[j] == ts[j - 1] && ti[j] < ti[j - 1]))) {
+          float a = ts[j]; ts[j] = ts[j - 1]; ts[j - 1] = a;
+          int b = ti[j]; ti[j] = ti[j - 1]; ti[j - 1] = b;
+        }
+      }
+    }
+  }
+  // k rounds of block-wide argmax over the threads' current heads
+  int head = 0;
+  for (int r = 0; r < k; ++r) {
+    float hs = NEG_INF;
+    int hi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j)
+      if (j == head) { hs = ts[j]; hi = ti[j]; }
+    __syncthreads();
+    cand_s[threadIdx.x] = hs;
+    cand_i[threadIdx.x] = hi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) {
+        float a = cand_s[threadIdx.x], b = cand_s[threadIdx.x + off];
+        int ia = cand_i[threadIdx.x], ib = cand_i[threadIdx.x + off];
+        if (b > a || (b == a && ib < ia)) { cand_s[threadIdx.x] = b; cand_i[threadIdx.x] = ib; }
+      }
+      __syncthreads();
+    }
+    float ws = cand_s[0];
+    int wi = cand_i[0];
+    if (threadIdx.x == 0) { out_score[row * k + r] = ws; out_idx[row * k + r] = wi; }
+    if (hi == wi && hs == ws && head < k) ++head;   // the owner pops its head
+  }
+}
+
+extern "C" int32_t otr_beam_topk(const float* logits, int64_t ld, const float* lm_logits, int64_t ld_lm, float lm_weight,
+                                 int64_t rows, int32_t V, int32_t k, float* out_score, int64_t* out_idx, void* stream) {
+  OTR_REQUIRE(logits && out_score && out_idx, "beam_topk: null pointer");
+  OTR_REQUIRE(k >= 1 && k <= MAXK && k <= V, "beam_topk: k=%d must be in [1, %d] and <= V", k, MAXK);
+  OTR_REQUIRE(rows >= 0 && V > 0 && ld >= V, "beam_topk: bad shape");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(beam_topk_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, ld, lm_logits,
+                     ld_lm, lm_weight, V, k, out_score, out_idx);
+  return otr_check_launch("beam_topk");
+}
+
+// one block per utterance; beam*beam <= 256 candidates
+__global__ __launch_bounds__(256) void beam_prune_kernel(const float* k_score, const int64_t* k_idx, const float* scores_in,
+                                                        const uint8_t* flag_in, const int64_t* preds_in, int64_t ldp,
+                                                        int beam, int t, int eos, float* scores_out, uint8_t* flag_out,
+                                                        int64_t* preds_out, int32_t* n_finished) {
+  __shared__ float cs[256];
+  __shared__ int ci[256];
+  __shared__ float c0[256];
+  __shared__ int win[MAXK];
+  const int b = blockIdx.x, tid = threadIdx.x, nc = beam * beam;
+  float s = NEG_INF;
+  if (tid < nc) {
+    int hyp = b * beam + tid / beam, br = tid % beam;
+    bool fin = flag_in[hyp] != 0;
+    float ks = k_score[(int64_t)hyp * beam + br];
+    if (fin) ks = (br == 0) ? 0.f : NEG_INF;        // mask_finished_scores
+    s = scores_in[hyp] + ks;
+  }
+  c0[tid] = s;
+  __syncthreads();
+  for (int r = 0; r < beam; ++r) {
+    cs[tid] = c0[tid];
+    ci[tid] = tid;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (tid < off) {
+        float a = cs[tid], bb = cs[tid + off];
+        int ia = ci[tid], ib = ci[tid + off];
+        if (bb > a || (bb == a && ib < ia)) { cs[tid] = bb; ci[tid] = ib; }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      win[r] = ci[0];
+      scores_out[b * beam + r] = cs[0];
+      c0[ci[0]] = NEG_INF;                          // remove the winner (NaN-free: -inf stays -inf)
+    }
+    __syncthreads();
+  }
+  // gather prefixes + append tokens: thread j < beam handles output hypothesis j
+  for (int r = 0; r < beam; ++r) {
+    int w = win[r];
+    int src = b * beam + w / beam;
+    bool fin = flag_in[src] != 0;
+    int64_t tok = fin ? (int64_t)eos : k_idx[(int64_t)src * beam + (w % beam)];   // mask_finished_preds
+    int64_t* dst = preds_out + (int64_t)(b * beam + r) * ldp;
+    const int64_t* sp = preds_in + (int64_t)src * ldp;
+    for (int i = tid; i < t; i += 256) dst[i] = sp[i];
+    if (tid == 0) {
+      dst[t] = tok;
+      bool f = tok == eos;
+      flag_out[b * beam + r] = f ? 1 : 0;
+      if (f) atomicAdd(n_finished, 1);
+    }
+  }
+}
+
+extern "C" int32_t otr_beam_prune(const float* k_score, const int64_t* k_idx, const float* scores_in,
+                                  const uint8_t* flag_in, const int64_t* preds_in, int64_t ldp, int32_t batch,
+                                  int32_t beam, int32_t t, int32_t eos, float* scores_out, uint8_t* flag_out,
+                                  int64_t* preds_out, int32_t* n_finished, void* stream) {
+  OTR_REQUIRE(k_score && k_idx && scores_in && flag_in && preds_in && scores_out && flag_out && preds_out && n_finished,
+              "beam_prune: null pointer");
+  OTR_REQUIRE(beam >= 1 && beam <= MAXK && beam * beam <= 256, "beam_prune: beam=%d must be in [1, 16]", beam);
+  OTR_REQUIRE(batch > 0 && t >= 1 && t < ldp, "beam_prune: bad shape batch=%d t=%d ldp=%lld", batch, t, (long long)ldp);
+  hipStream_t s = (hipStream_t)stream;
+  otr_zero_f32(reinterpret_cast<float*>(n_finished), 1, s);   // int32 0 == float 0 bit pattern
+  hipLaunchKernelGGL(beam_prune_kernel, dim3(batch), dim3(256), 0, s, k_score, k_idx, scores_in, flag_in, preds_in, ldp,
+                     beam, t, eos, scores_out, flag_out, preds_out, n_finished);
+  return otr_check_launch("beam_prune");
+}
