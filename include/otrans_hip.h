@@ -30,11 +30,16 @@ extern "C" {
 #define OTR_ACT_RELU 1
 
 int32_t otr_version(void);
+/* tuning hook for benchmarks: key 0 = force GEMM tile (0 auto / 64 / 128), key 1 = force split-K (0 auto) */
+int32_t otr_debug_set(int32_t key, int32_t value);
 const char* otr_last_error_string(void);
 
 /* ---- nn.Linear and its gradients (module/attention.py:43,68,128-129; module/ffn.py:39-41;
  *      frontend/conv.py:146; decoder/transformer.py:181; model/ctc.py:47).
- * All matrices row-major with leading dimensions in elements.  `accumulate` != 0 adds into out. */
+ * All matrices row-major with leading dimensions in elements.  `accumulate` != 0 adds into out.
+ * workspace (fp32, caller owned, may be NULL): enables split-K for contraction-heavy / output-small
+ * shapes; partial [M,N] slabs are reduced in a FIXED order by a second kernel, so results stay
+ * deterministic.  64 MiB covers every shape of the AISHELL configs. */
 typedef struct {
   int32_t M, N, K;              /* y[M,N] = x[M,K] * w[N,K]^T */
   int32_t x_dtype, w_dtype, y_dtype, compute;
@@ -44,11 +49,13 @@ typedef struct {
 } otr_linear_desc_t;
 /* y = act(x w^T + bias); bias f32[N] or NULL */
 int32_t otr_linear_fwd(const otr_linear_desc_t* d, const void* x, const void* w, const float* bias, void* y,
-                       void* stream);
+                       void* workspace, int64_t workspace_bytes, void* stream);
 /* dx[M,K] (dtype x_dtype, ld ldx) = dy[M,N] (dtype y_dtype, ld ldy) * w[N,K] */
-int32_t otr_linear_dgrad(const otr_linear_desc_t* d, const void* dy, const void* w, void* dx, void* stream);
+int32_t otr_linear_dgrad(const otr_linear_desc_t* d, const void* dy, const void* w, void* dx, void* workspace,
+                         int64_t workspace_bytes, void* stream);
 /* dw[N,K] (dtype w_dtype, ld ldw) = dy[M,N]^T * x[M,K] */
-int32_t otr_linear_wgrad(const otr_linear_desc_t* d, const void* dy, const void* x, void* dw, void* stream);
+int32_t otr_linear_wgrad(const otr_linear_desc_t* d, const void* dy, const void* x, void* dw, void* workspace,
+                         int64_t workspace_bytes, void* stream);
 /* out[N] (f32) (+)= sum over M rows of a[M,N]  (bias gradients) */
 int32_t otr_colsum(const void* a, int32_t dtype, int64_t M, int64_t N, int64_t lda, float* out, int32_t accumulate,
                    void* stream);
@@ -83,8 +90,9 @@ typedef struct {
   float eps, p_drop;            /* p_drop = 0 -> no dropout */
   uint64_t rng_offset;
 } otr_ln_desc_t;
+/* y_bf16 (may be NULL): bf16 copy of y, the GEMM-operand form of the residual stream */
 int32_t otr_add_layernorm_fwd(const otr_ln_desc_t* d, const float* x, const void* a, const float* gamma,
-                              const float* beta, const uint64_t* seed, float* y, float* z, float* mean,
+                              const float* beta, const uint64_t* seed, float* y, void* y_bf16, float* z, float* mean,
                               float* rstd, void* stream);
 /* dx f32 [M,d] (residual grad), da [M,d] a_dtype (branch grad, may be NULL), dgamma/dbeta f32[d] +=. */
 int32_t otr_add_layernorm_bwd(const otr_ln_desc_t* d, const float* dy, const float* z, const float* mean,
@@ -99,13 +107,16 @@ int32_t otr_glu_bwd(const void* h, const void* du, void* dh, float* dbias, int32
 
 /* ---- PositionalEncoding (module/pos.py:30-57): y = x*scale + PE[t], t = row % T.
  *      x may alias y. */
-int32_t otr_posenc_fwd(const float* x, float* y, int64_t rows, int32_t T, int32_t d, float scale, void* stream);
+int32_t otr_posenc_fwd(const float* x, float* y, void* y_bf16, int64_t rows, int32_t T, int32_t d, float scale,
+                       void* stream);
 /* decoder embedding + posenc (decoder/transformer.py:163-169): y[r,:] = E[tok[r],:]*scale + PE[r % L] */
-int32_t otr_embed_posenc_fwd(const int64_t* tok, const float* E, float* y, int64_t rows, int32_t L, int32_t d,
-                             int32_t vocab, float scale, void* stream);
+int32_t otr_embed_posenc_fwd(const int64_t* tok, const float* E, float* y, void* y_bf16, int64_t rows, int32_t L,
+                             int32_t d, int32_t vocab, float scale, void* stream);
 /* dE[tok[r],:] += scale * dy[r,:]  (atomic f32) */
 int32_t otr_embed_bwd(const int64_t* tok, const float* dy, float* dE, int64_t rows, int32_t d, int32_t vocab,
                       float scale, void* stream);
+/* dst (bf16) = src (f32), n elements: bf16 shadows of weights / activations */
+int32_t otr_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* y = x * (*s_dev) * s_host, elementwise f32 (n elements); x may alias y; s_dev may be NULL */
 int32_t otr_scale(const float* x, float* y, int64_t n, const float* s_dev, float s_host, void* stream);
 
@@ -117,6 +128,7 @@ typedef struct {
   int32_t C1, C2;               /* mid / out channels */
   int32_t T1, F1, T2, F2;       /* derived: T1=(T-3)/2+1, F1=(F-1)/2+1, ... */
   int32_t act_dtype, compute;
+  int32_t w_dtype;              /* dtype of w2r as passed (f32 master or its bf16 shadow) */
 } otr_conv_desc_t;
 /* conv1: 1->C1, 3x3, stride 2, pad (0,1), +bias, ReLU.  w1 f32 [C1,1,3,3] */
 int32_t otr_conv1_fwd(const otr_conv_desc_t* d, const float* x, const float* w1, const float* b1, void* act1,
@@ -125,15 +137,16 @@ int32_t otr_conv1_fwd(const otr_conv_desc_t* d, const float* x, const float* w1,
 int32_t otr_conv1_wgrad(const otr_conv_desc_t* d, const float* x, const void* dact1, float* dw1, float* db1,
                         void* stream);
 /* conv2 as implicit GEMM on MFMA: w2r = w2 permuted to [C2,3,3,C1] (f32). +bias, ReLU */
-int32_t otr_conv2_fwd(const otr_conv_desc_t* d, const void* act1, const float* w2r, const float* b2, void* act2,
+int32_t otr_conv2_fwd(const otr_conv_desc_t* d, const void* act1, const void* w2r, const float* b2, void* act2,
                       void* stream);
 /* dcol[B*T2*F2, 9*C1] (act dtype) = dact2 * w2r  (dact2 already masked by ReLU) */
-int32_t otr_conv2_dgrad_cols(const otr_conv_desc_t* d, const void* dact2, const float* w2r, void* dcol,
+int32_t otr_conv2_dgrad_cols(const otr_conv_desc_t* d, const void* dact2, const void* w2r, void* dcol,
                              void* stream);
 /* dact1 = col2im(dcol) * (act1 > 0) */
 int32_t otr_conv2_col2im(const otr_conv_desc_t* d, const void* dcol, const void* act1, void* dact1, void* stream);
 /* dw2r [C2, 9*C1] f32 = dact2^T * im2col(act1) */
-int32_t otr_conv2_wgrad(const otr_conv_desc_t* d, const void* dact2, const void* act1, float* dw2r, void* stream);
+int32_t otr_conv2_wgrad(const otr_conv_desc_t* d, const void* dact2, const void* act1, float* dw2r, void* workspace,
+                        int64_t workspace_bytes, void* stream);
 /* g = g * (y > 0) elementwise (ReLU backward through a stored post-ReLU activation); g may alias out */
 int32_t otr_relu_bwd(const void* y, const void* g, void* out, int32_t dtype, int64_t n, void* stream);
 
@@ -161,7 +174,8 @@ int32_t otr_ctc_loss(const float* log_probs, const int64_t* targets, int64_t ldt
  *      is folded into clip + update.  state: f32[8] device block {step, lr, bc1, bc2, sqnorm, skipped},
  *      zero-initialised by the caller once.  noam_warmup <= 0 selects the constant base_lr. */
 int32_t otr_optimizer_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                           float* state, float base_lr, float beta1, float beta2, float eps, float weight_decay,
+                           float* state, void* param_bf16 /* NULL or bf16 shadow[n] refreshed in the same pass */,
+                           float base_lr, float beta1, float beta2, float eps, float weight_decay,
                            float grad_scale, float clip_norm, float noam_model_size, float noam_warmup,
                            float noam_factor, float noam_step_offset, void* stream);
 

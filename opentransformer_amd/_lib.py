@@ -36,7 +36,7 @@ class LnDesc(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [('B', C.c_int32), ('T', C.c_int32), ('F', C.c_int32), ('C1', C.c_int32), ('C2', C.c_int32),
                 ('T1', C.c_int32), ('F1', C.c_int32), ('T2', C.c_int32), ('F2', C.c_int32),
-                ('act_dtype', C.c_int32), ('compute', C.c_int32)]
+                ('act_dtype', C.c_int32), ('compute', C.c_int32), ('w_dtype', C.c_int32)]
 
 
 _P = C.c_void_p
@@ -46,32 +46,34 @@ _I32, _I64, _F32 = C.c_int32, C.c_int64, C.c_float
 # include/otrans_hip.h declares; tests/test_cabi.py cross-checks the two.
 SIGNATURES = {
     'otr_version': [],
+    'otr_debug_set': [_I32, _I32],
     'otr_last_error_string': [],
-    'otr_linear_fwd': [C.POINTER(LinearDesc), _P, _P, _P, _P, _P],
-    'otr_linear_dgrad': [C.POINTER(LinearDesc), _P, _P, _P, _P],
-    'otr_linear_wgrad': [C.POINTER(LinearDesc), _P, _P, _P, _P],
+    'otr_linear_fwd': [C.POINTER(LinearDesc), _P, _P, _P, _P, _P, _I64, _P],
+    'otr_linear_dgrad': [C.POINTER(LinearDesc), _P, _P, _P, _P, _I64, _P],
+    'otr_linear_wgrad': [C.POINTER(LinearDesc), _P, _P, _P, _P, _I64, _P],
     'otr_colsum': [_P, _I32, _I64, _I64, _I64, _P, _I32, _P],
     'otr_attention_fwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P],
     'otr_attention_bwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    'otr_add_layernorm_fwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    'otr_add_layernorm_fwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_add_layernorm_bwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_glu_fwd': [_P, _P, _I32, _I64, _I64, _P],
     'otr_glu_bwd': [_P, _P, _P, _P, _I32, _I64, _I64, _P],
-    'otr_posenc_fwd': [_P, _P, _I64, _I32, _I32, _F32, _P],
-    'otr_embed_posenc_fwd': [_P, _P, _P, _I64, _I32, _I32, _I32, _F32, _P],
+    'otr_posenc_fwd': [_P, _P, _P, _I64, _I32, _I32, _F32, _P],
+    'otr_embed_posenc_fwd': [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _F32, _P],
     'otr_embed_bwd': [_P, _P, _P, _I64, _I32, _I32, _F32, _P],
     'otr_scale': [_P, _P, _I64, _P, _F32, _P],
+    'otr_cast_f32_to_bf16': [_P, _P, _I64, _P],
     'otr_conv1_fwd': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
     'otr_conv1_wgrad': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
     'otr_conv2_fwd': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
     'otr_conv2_dgrad_cols': [C.POINTER(ConvDesc), _P, _P, _P, _P],
     'otr_conv2_col2im': [C.POINTER(ConvDesc), _P, _P, _P, _P],
-    'otr_conv2_wgrad': [C.POINTER(ConvDesc), _P, _P, _P, _P],
+    'otr_conv2_wgrad': [C.POINTER(ConvDesc), _P, _P, _P, _P, _I64, _P],
     'otr_relu_bwd': [_P, _P, _P, _I32, _I64, _P],
     'otr_label_smoothing_loss': [_P, _P, _I64, _I32, _F32, _I32, _P, _P, _P, _P],
     'otr_log_softmax': [_P, _P, _I64, _I32, _P],
     'otr_ctc_loss': [_P, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
-    'otr_optimizer_step': [_P, _P, _P, _P, _I64, _P] + [_F32] * 11 + [_P],
+    'otr_optimizer_step': [_P, _P, _P, _P, _I64, _P, _P] + [_F32] * 11 + [_P],
     'otr_beam_topk': [_P, _I64, _P, _I64, _F32, _I64, _I32, _I32, _P, _P, _P],
     'otr_beam_prune': [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
 }

@@ -31,6 +31,15 @@ void otr_zero_f32(float* p, int64_t n, hipStream_t s) {
   hipLaunchKernelGGL(zero_f32_kernel, dim3(g), dim3(256), 0, s, p, n);
 }
 
+int g_otr_force_tile = 0;
+int g_otr_force_ksplit = 0;
+extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
+  if (key == 0) g_otr_force_tile = value;
+  else if (key == 1) g_otr_force_ksplit = value;
+  else { otr_set_error("debug_set: unknown key %d", key); return -1; }
+  return 0;
+}
+
 extern "C" int32_t otr_version(void) { return 100; }
 extern "C" const char* otr_last_error_string(void) { return g_err; }
 
@@ -65,7 +74,7 @@ static int32_t check_linear(const otr_linear_desc_t* d) {
 }
 
 extern "C" int32_t otr_linear_fwd(const otr_linear_desc_t* d, const void* x, const void* w, const float* bias,
-                                  void* y, void* stream) {
+                                  void* y, void* workspace, int64_t workspace_bytes, void* stream) {
   if (int32_t e = check_linear(d)) return e;
   OTR_REQUIRE(x && w && y, "linear_fwd: null pointer");
   GemmArgs a{};
@@ -75,11 +84,12 @@ extern "C" int32_t otr_linear_fwd(const otr_linear_desc_t* d, const void* x, con
   a.act = d->act; a.accumulate = d->accumulate;
   a.a_vec = kc_vec(x, d->ldx, d->x_dtype);
   a.b_vec = kc_vec(w, d->ldw, d->w_dtype);
+  a.allow_split = 1; a.ws = (float*)workspace; a.ws_bytes = workspace_bytes;
   return run_gemm(a, d->compute, d->x_dtype, d->w_dtype, d->y_dtype, MODE_KC, MODE_KC, stream);
 }
 
 extern "C" int32_t otr_linear_dgrad(const otr_linear_desc_t* d, const void* dy, const void* w, void* dx,
-                                    void* stream) {
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
   if (int32_t e = check_linear(d)) return e;
   OTR_REQUIRE(dy && w && dx, "linear_dgrad: null pointer");
   GemmArgs a{};  // dx[M,K] = dy[M,N] * w[N,K]: contraction over N; w is "rows(K)-contiguous"
@@ -89,12 +99,12 @@ extern "C" int32_t otr_linear_dgrad(const otr_linear_desc_t* d, const void* dy, 
   a.act = OTR_ACT_NONE; a.accumulate = d->accumulate;
   a.a_vec = kc_vec(dy, d->ldy, d->y_dtype);
   a.b_vec = mc_vec(w, d->ldw, d->w_dtype, d->compute);
-  a.allow_split = 1;  // gradients may use the atomic k-slice reduction (fp32 outputs only)
+  a.allow_split = 1; a.ws = (float*)workspace; a.ws_bytes = workspace_bytes;
   return run_gemm(a, d->compute, d->y_dtype, d->w_dtype, d->x_dtype, MODE_KC, MODE_MC, stream);
 }
 
 extern "C" int32_t otr_linear_wgrad(const otr_linear_desc_t* d, const void* dy, const void* x, void* dw,
-                                    void* stream) {
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
   if (int32_t e = check_linear(d)) return e;
   OTR_REQUIRE(dy && x && dw, "linear_wgrad: null pointer");
   GemmArgs a{};  // dw[N,K] = dy[M,N]^T * x[M,K]: contraction over M; both operands rows-contiguous
@@ -104,7 +114,7 @@ extern "C" int32_t otr_linear_wgrad(const otr_linear_desc_t* d, const void* dy, 
   a.act = OTR_ACT_NONE; a.accumulate = d->accumulate;
   a.a_vec = mc_vec(dy, d->ldy, d->y_dtype, d->compute);
   a.b_vec = mc_vec(x, d->ldx, d->x_dtype, d->compute);
-  a.allow_split = 1;
+  a.allow_split = 1; a.ws = (float*)workspace; a.ws_bytes = workspace_bytes;
   if (d->M == 0) return 0;
   return run_gemm(a, d->compute, d->y_dtype, d->x_dtype, d->w_dtype, MODE_MC, MODE_MC, stream);
 }
@@ -126,7 +136,7 @@ static int32_t conv_geom(const otr_conv_desc_t* d, ConvGeom& g) {
   return 0;
 }
 
-extern "C" int32_t otr_conv2_fwd(const otr_conv_desc_t* d, const void* act1, const float* w2r, const float* b2,
+extern "C" int32_t otr_conv2_fwd(const otr_conv_desc_t* d, const void* act1, const void* w2r, const float* b2,
                                  void* act2, void* stream) {
   GemmArgs a{};
   if (int32_t e = conv_geom(d, a.cg)) return e;
@@ -136,11 +146,12 @@ extern "C" int32_t otr_conv2_fwd(const otr_conv_desc_t* d, const void* act1, con
   a.lda = 0; a.ldb = a.K; a.ldc = d->C2;
   a.act = OTR_ACT_RELU; a.accumulate = 0;
   a.a_vec = ((uintptr_t)act1 % 16 == 0);
-  a.b_vec = kc_vec(w2r, a.ldb, OTR_F32);
-  return run_gemm(a, d->compute, d->act_dtype, OTR_F32, d->act_dtype, MODE_IM2K, MODE_KC, stream);
+  OTR_REQUIRE(dtype_ok(d->w_dtype), "conv2_fwd: bad w_dtype");
+  a.b_vec = kc_vec(w2r, a.ldb, d->w_dtype);
+  return run_gemm(a, d->compute, d->act_dtype, d->w_dtype, d->act_dtype, MODE_IM2K, MODE_KC, stream);
 }
 
-extern "C" int32_t otr_conv2_dgrad_cols(const otr_conv_desc_t* d, const void* dact2, const float* w2r, void* dcol,
+extern "C" int32_t otr_conv2_dgrad_cols(const otr_conv_desc_t* d, const void* dact2, const void* w2r, void* dcol,
                                         void* stream) {
   GemmArgs a{};
   if (int32_t e = conv_geom(d, a.cg)) return e;
@@ -150,12 +161,13 @@ extern "C" int32_t otr_conv2_dgrad_cols(const otr_conv_desc_t* d, const void* da
   a.lda = d->C2; a.ldb = 9 * d->C1; a.ldc = 9 * d->C1;
   a.act = OTR_ACT_NONE; a.accumulate = 0;
   a.a_vec = kc_vec(dact2, a.lda, d->act_dtype);
-  a.b_vec = mc_vec(w2r, a.ldb, OTR_F32, d->compute);
-  return run_gemm(a, d->compute, d->act_dtype, OTR_F32, d->act_dtype, MODE_KC, MODE_MC, stream);
+  OTR_REQUIRE(dtype_ok(d->w_dtype), "conv2_dgrad_cols: bad w_dtype");
+  a.b_vec = mc_vec(w2r, a.ldb, d->w_dtype, d->compute);
+  return run_gemm(a, d->compute, d->act_dtype, d->w_dtype, d->act_dtype, MODE_KC, MODE_MC, stream);
 }
 
 extern "C" int32_t otr_conv2_wgrad(const otr_conv_desc_t* d, const void* dact2, const void* act1, float* dw2r,
-                                   void* stream) {
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
   GemmArgs a{};
   if (int32_t e = conv_geom(d, a.cg)) return e;
   OTR_REQUIRE(dact2 && act1 && dw2r, "conv2_wgrad: null pointer");
@@ -165,6 +177,6 @@ extern "C" int32_t otr_conv2_wgrad(const otr_conv_desc_t* d, const void* dact2, 
   a.act = OTR_ACT_NONE; a.accumulate = 0;
   a.a_vec = mc_vec(dact2, a.lda, d->act_dtype, d->compute);
   a.b_vec = ((uintptr_t)act1 % 16 == 0);
-  a.allow_split = 1;
+  a.allow_split = 1; a.ws = (float*)workspace; a.ws_bytes = workspace_bytes;
   return run_gemm(a, d->compute, d->act_dtype, d->act_dtype, OTR_F32, MODE_MC, MODE_IM2M, stream);
 }

@@ -112,26 +112,28 @@ __device__ __forceinline__ float pe_value(int t, int col, float neg_ln_over_d) {
   return (col & 1) ? cosf(ang) : sinf(ang);
 }
 
-__global__ void posenc_kernel(const float* x, float* y, int64_t rows, int T, int d, float scale) {
+__global__ void posenc_kernel(const float* x, float* y, bf16_t* y_lp, int64_t rows, int T, int d, float scale) {
   const float nl = -logf(10000.f) / (float)d;
   const int64_t total = rows * d;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t row = i / d;
     int col = (int)(i - row * d);
-    y[i] = x[i] * scale + pe_value((int)(row % T), col, nl);
+    float v = x[i] * scale + pe_value((int)(row % T), col, nl);
+    y[i] = v;
+    if (y_lp) y_lp[i] = f2bf(v);
   }
 }
-extern "C" int32_t otr_posenc_fwd(const float* x, float* y, int64_t rows, int32_t T, int32_t d, float scale,
-                                  void* stream) {
+extern "C" int32_t otr_posenc_fwd(const float* x, float* y, void* y_bf16, int64_t rows, int32_t T, int32_t d,
+                                  float scale, void* stream) {
   OTR_REQUIRE(x && y, "posenc_fwd: null pointer");
   OTR_REQUIRE(T > 0 && d > 0 && rows >= 0, "posenc_fwd: bad shape");
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(posenc_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, x, y, rows, T, d, scale);
+  hipLaunchKernelGGL(posenc_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, x, y, (bf16_t*)y_bf16, rows, T, d, scale);
   return otr_check_launch("posenc_fwd");
 }
 
-__global__ void embed_posenc_kernel(const int64_t* tok, const float* E, float* y, int64_t rows, int L, int d, int vocab,
-                                    float scale) {
+__global__ void embed_posenc_kernel(const int64_t* tok, const float* E, float* y, bf16_t* y_lp, int64_t rows, int L, int d,
+                                    int vocab, float scale) {
   const float nl = -logf(10000.f) / (float)d;
   const int64_t total = rows * d;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -139,15 +141,17 @@ __global__ void embed_posenc_kernel(const int64_t* tok, const float* E, float* y
     int col = (int)(i - row * d);
     int64_t t = tok[row];
     float e = (t >= 0 && t < vocab) ? E[t * d + col] : 0.f;
-    y[i] = e * scale + pe_value((int)(row % L), col, nl);
+    float v = e * scale + pe_value((int)(row % L), col, nl);
+    y[i] = v;
+    if (y_lp) y_lp[i] = f2bf(v);
   }
 }
-extern "C" int32_t otr_embed_posenc_fwd(const int64_t* tok, const float* E, float* y, int64_t rows, int32_t L, int32_t d,
-                                        int32_t vocab, float scale, void* stream) {
+extern "C" int32_t otr_embed_posenc_fwd(const int64_t* tok, const float* E, float* y, void* y_bf16, int64_t rows, int32_t L,
+                                        int32_t d, int32_t vocab, float scale, void* stream) {
   OTR_REQUIRE(tok && E && y, "embed_posenc_fwd: null pointer");
   OTR_REQUIRE(L > 0 && d > 0 && vocab > 0 && rows >= 0, "embed_posenc_fwd: bad shape");
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(embed_posenc_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, tok, E, y, rows, L, d, vocab, scale);
+  hipLaunchKernelGGL(embed_posenc_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, tok, E, y, (bf16_t*)y_bf16, rows, L, d, vocab, scale);
   return otr_check_launch("embed_posenc_fwd");
 }
 
@@ -166,6 +170,23 @@ extern "C" int32_t otr_embed_bwd(const int64_t* tok, const float* dy, float* dE,
   if (rows <= 0) return 0;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, tok, dy, dE, rows, d, vocab, scale);
   return otr_check_launch("embed_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------ cast
+__global__ void cast_bf16_kernel(const float* src, bf16_t* dst, int64_t n) {
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<const float4*>(src)[i];
+    reinterpret_cast<uint2*>(dst)[i] = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] = f2bf(src[n4 * 4 + threadIdx.x]);
+}
+extern "C" int32_t otr_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  OTR_REQUIRE(src && dst, "cast_f32_to_bf16: null pointer");
+  OTR_REQUIRE((uintptr_t)src % 16 == 0 && (uintptr_t)dst % 8 == 0, "cast_f32_to_bf16: unaligned buffers");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+  return otr_check_launch("cast_f32_to_bf16");
 }
 
 // ------------------------------------------------------------------------------------------------ scale

@@ -11,11 +11,19 @@ int32_t gemm_dispatch_bf16(const GemmArgs& a, int ad, int bd, int cd, int amode,
     case (MODE_KC << 12) | (MODE_KC << 8) | (OTR_F32 << 2) | (OTR_F32 << 1) | OTR_BF16: CASE(float, float, bf16_t, MODE_KC, MODE_KC);
     case (MODE_KC << 12) | (MODE_KC << 8) | (OTR_BF16 << 2) | (OTR_F32 << 1) | OTR_F32: CASE(bf16_t, float, float, MODE_KC, MODE_KC);
     case (MODE_KC << 12) | (MODE_KC << 8) | (OTR_BF16 << 2) | (OTR_F32 << 1) | OTR_BF16: CASE(bf16_t, float, bf16_t, MODE_KC, MODE_KC);
+    case (MODE_KC << 12) | (MODE_KC << 8) | (OTR_F32 << 2) | (OTR_BF16 << 1) | OTR_F32: CASE(float, bf16_t, float, MODE_KC, MODE_KC);
+    case (MODE_KC << 12) | (MODE_KC << 8) | (OTR_F32 << 2) | (OTR_BF16 << 1) | OTR_BF16: CASE(float, bf16_t, bf16_t, MODE_KC, MODE_KC);
+    case (MODE_KC << 12) | (MODE_KC << 8) | (OTR_BF16 << 2) | (OTR_BF16 << 1) | OTR_F32: CASE(bf16_t, bf16_t, float, MODE_KC, MODE_KC);
+    case (MODE_KC << 12) | (MODE_KC << 8) | (OTR_BF16 << 2) | (OTR_BF16 << 1) | OTR_BF16: CASE(bf16_t, bf16_t, bf16_t, MODE_KC, MODE_KC);
     // dgrad: dy[M,N] KC x w[N,K] MC
     case (MODE_KC << 12) | (MODE_MC << 8) | (OTR_F32 << 2) | (OTR_F32 << 1) | OTR_F32: CASE(float, float, float, MODE_KC, MODE_MC);
     case (MODE_KC << 12) | (MODE_MC << 8) | (OTR_F32 << 2) | (OTR_F32 << 1) | OTR_BF16: CASE(float, float, bf16_t, MODE_KC, MODE_MC);
     case (MODE_KC << 12) | (MODE_MC << 8) | (OTR_BF16 << 2) | (OTR_F32 << 1) | OTR_F32: CASE(bf16_t, float, float, MODE_KC, MODE_MC);
     case (MODE_KC << 12) | (MODE_MC << 8) | (OTR_BF16 << 2) | (OTR_F32 << 1) | OTR_BF16: CASE(bf16_t, float, bf16_t, MODE_KC, MODE_MC);
+    case (MODE_KC << 12) | (MODE_MC << 8) | (OTR_F32 << 2) | (OTR_BF16 << 1) | OTR_F32: CASE(float, bf16_t, float, MODE_KC, MODE_MC);
+    case (MODE_KC << 12) | (MODE_MC << 8) | (OTR_F32 << 2) | (OTR_BF16 << 1) | OTR_BF16: CASE(float, bf16_t, bf16_t, MODE_KC, MODE_MC);
+    case (MODE_KC << 12) | (MODE_MC << 8) | (OTR_BF16 << 2) | (OTR_BF16 << 1) | OTR_F32: CASE(bf16_t, bf16_t, float, MODE_KC, MODE_MC);
+    case (MODE_KC << 12) | (MODE_MC << 8) | (OTR_BF16 << 2) | (OTR_BF16 << 1) | OTR_BF16: CASE(bf16_t, bf16_t, bf16_t, MODE_KC, MODE_MC);
     // wgrad: dy^T (MC) x x (MC) -> f32
     case (MODE_MC << 12) | (MODE_MC << 8) | (OTR_F32 << 2) | (OTR_F32 << 1) | OTR_F32: CASE(float, float, float, MODE_MC, MODE_MC);
     case (MODE_MC << 12) | (MODE_MC << 8) | (OTR_F32 << 2) | (OTR_BF16 << 1) | OTR_F32: CASE(float, bf16_t, float, MODE_MC, MODE_MC);
@@ -23,6 +31,7 @@ int32_t gemm_dispatch_bf16(const GemmArgs& a, int ad, int bd, int cd, int amode,
     case (MODE_MC << 12) | (MODE_MC << 8) | (OTR_BF16 << 2) | (OTR_BF16 << 1) | OTR_F32: CASE(bf16_t, bf16_t, float, MODE_MC, MODE_MC);
     // conv2 forward (implicit im2col A) and wgrad (implicit im2col B)
     case (MODE_IM2K << 12) | (MODE_KC << 8) | (OTR_BF16 << 2) | (OTR_F32 << 1) | OTR_BF16: CASE(bf16_t, float, bf16_t, MODE_IM2K, MODE_KC);
+    case (MODE_IM2K << 12) | (MODE_KC << 8) | (OTR_BF16 << 2) | (OTR_BF16 << 1) | OTR_BF16: CASE(bf16_t, bf16_t, bf16_t, MODE_IM2K, MODE_KC);
     case (MODE_MC << 12) | (MODE_IM2M << 8) | (OTR_BF16 << 2) | (OTR_BF16 << 1) | OTR_F32: CASE(bf16_t, bf16_t, float, MODE_MC, MODE_IM2M);
     default:
       otr_set_error("gemm(bf16): unsupported combination amode=%d bmode=%d a=%d b=%d c=%d", amode, bmode, ad, bd, cd);

@@ -42,7 +42,9 @@ struct GemmArgs {
   int act, accumulate;
   int a_vec, b_vec;  // operand base/ld satisfy the vector-load alignment
   int ksplit;        // number of k-slices (grid.y); > 1 => atomic fp32 reduction
-  int allow_split;   // caller accepts the (order-nondeterministic) atomic reduction: weight gradients only
+  int allow_split;   // caller permits split-K (needs a workspace)
+  float* ws;         // split-K workspace: ksplit partial [M,N] fp32 slabs, reduced in a fixed order
+  int64_t ws_bytes;
   ConvGeom cg;
 };
 
@@ -97,11 +99,18 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
   static constexpr int RG = ROWS / PM;
   static constexpr int NP = ROWMAJOR ? 1 : (RG * KCH + 255) / 256;
 
+  // same-type row-major operands are staged as raw 16-byte chunks (no float round trip)
+  static constexpr bool RAWQ = ROWMAJOR && std::is_same<ST, CT>::value;
+
   const ST* base;
   int64_t ld;
   int nrows, K, row0;
   bool vec;
-  float raw[ROWMAJOR ? NU : NP * PM][CE];
+  // stage-invariant part of every unit's global address (k = 0), computed once in init()
+  const ST* p0[ROWMAJOR ? NU : NP];
+  bool rok[ROWMAJOR ? NU : NP];
+  float raw[RAWQ ? 1 : (ROWMAJOR ? NU : NP * PM)][CE];
+  uint4 rawq[RAWQ ? NU : 1];
   // im2col state
   int64_t pix[ROWMAJOR ? NU : 1];
   int f2v[ROWMAJOR ? NU : 1];
@@ -111,6 +120,24 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
                                        const ConvGeom& g, int tid) {
     base = reinterpret_cast<const ST*>(p);
     ld = ld_; nrows = nrows_; K = K_; row0 = row0_; vec = vec_;
+    if constexpr (MODE == MODE_KC) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        int id = tid + 256 * u;
+        int lr = id / KCH;
+        rok[u] = lr < ROWS && row0 + lr < nrows;
+        p0[u] = base + (int64_t)(row0 + lr) * ld + (id % KCH) * CE;
+      }
+    }
+    if constexpr (MODE == MODE_MC) {
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        int id = tid + 256 * u;
+        int rg = id % RG, c = id / RG;
+        rok[u] = c < KCH;
+        p0[u] = base + (int64_t)(c * CE) * ld + row0 + PM * rg;
+      }
+    }
     if constexpr (MODE == MODE_IM2K) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
@@ -138,13 +165,27 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         int id = tid + 256 * u;
-        int lr = id / KCH;
-        int row = row0 + lr, gk = k0 + (id % KCH) * CE;
-        if (lr < ROWS && row < nrows && gk < K) {
-          load_row<ST, CE>(base + (int64_t)row * ld + gk, K - gk, vec, raw[u]);
+        int gk = k0 + (id % KCH) * CE;
+        const bool ok = rok[u] && gk < K;
+        if constexpr (RAWQ) {
+          rawq[u] = make_uint4(0, 0, 0, 0);
+          if (ok) {
+            const ST* src = p0[u] + k0;
+            if (vec && K - gk >= CE) {
+              rawq[u] = *reinterpret_cast<const uint4*>(src);
+            } else {
+              float tmp[CE];
+              load_row<ST, CE>(src, K - gk, false, tmp);
+              rawq[u] = MMA<CT>::pack(tmp);
+            }
+          }
         } else {
+          if (ok) {
+            load_row<ST, CE>(p0[u] + k0, K - gk, vec, raw[u]);
+          } else {
 #pragma unroll
-          for (int e = 0; e < CE; ++e) raw[u][e] = 0.f;
+            for (int e = 0; e < CE; ++e) raw[u][e] = 0.f;
+          }
         }
       }
     } else if constexpr (MODE == MODE_IM2K) {
@@ -157,11 +198,26 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
         int ch = gk - (int)tap * g.C1;
         int kh = (int)tap / 3, kw = (int)tap - kh * 3;
         int fin = 2 * f2v[u] + kw - 1;
-        if (lr < ROWS && row < nrows && gk < K && fin >= 0 && fin < g.F1) {
-          load_row<ST, CE>(base + pix[u] + (int64_t)(kh * g.F1 + kw) * g.C1 + ch, CE, vec, raw[u]);
+        const bool ok = lr < ROWS && row < nrows && gk < K && fin >= 0 && fin < g.F1;
+        const ST* src = base + pix[u] + (int64_t)(kh * g.F1 + kw) * g.C1 + ch;
+        if constexpr (RAWQ) {
+          rawq[u] = make_uint4(0, 0, 0, 0);
+          if (ok) {
+            if (vec) {
+              rawq[u] = *reinterpret_cast<const uint4*>(src);
+            } else {
+              float tmp[CE];
+              load_row<ST, CE>(src, CE, false, tmp);
+              rawq[u] = MMA<CT>::pack(tmp);
+            }
+          }
         } else {
+          if (ok) {
+            load_row<ST, CE>(src, CE, vec, raw[u]);
+          } else {
 #pragma unroll
-          for (int e = 0; e < CE; ++e) raw[u][e] = 0.f;
+            for (int e = 0; e < CE; ++e) raw[u][e] = 0.f;
+          }
         }
       }
     } else {
@@ -171,6 +227,8 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
         int rg = id % RG, c = id / RG;
         int r = row0 + PM * rg;
         bool active = c < KCH;
+        const ST* pstage = nullptr;
+        if constexpr (MODE == MODE_MC) pstage = p0[u] + (int64_t)k0 * ld;
 #pragma unroll
         for (int j = 0; j < CE; ++j) {
           int gk = k0 + c * CE + j;
@@ -181,7 +239,7 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
             const ST* p;
             bool ok = true;
             if constexpr (MODE == MODE_MC) {
-              p = base + (int64_t)gk * ld + r;
+              p = pstage + (int64_t)j * ld;
             } else {  // MODE_IM2M: contraction index gk = output pixel
               int f2;
               int64_t pb = im2col_base(g, (uint32_t)gk, f2);
@@ -213,8 +271,12 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
       for (int u = 0; u < NU; ++u) {
         int id = tid + 256 * u;
         int row = id / KCH, c = id % KCH;
-        if (row < ROWS)
-          *reinterpret_cast<uint4*>(lds + row * G::ROWB + ((c ^ swz<KCH>(row)) << 4)) = MMA<CT>::pack(raw[u]);
+        if (row < ROWS) {
+          uint4 q;
+          if constexpr (RAWQ) q = rawq[u];
+          else q = MMA<CT>::pack(raw[u]);
+          *reinterpret_cast<uint4*>(lds + row * G::ROWB + ((c ^ swz<KCH>(row)) << 4)) = q;
+        }
       }
     } else {
 #pragma unroll
@@ -308,10 +370,38 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
 
   // epilogue: acc[i][j][r] = C[m = .. + i*16 + (lane&15)][n = .. + j*16 + (lane>>4)*4 + r]
+  if (p.ksplit > 1) {  // partial tile -> workspace slab [split][M][N]; reduced by splitk_reduce_kernel
+    float* W = p.ws + (int64_t)blockIdx.y * p.M * p.N;
+    const bool v4 = (p.N % 4 == 0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      int row = tile_m * BM + wm * WM + i * 16 + fr;
+      if (row >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        int col = tile_n * BN + wn * WN + j * 16 + fg * 4;
+        if (col >= p.N) continue;
+        float* dst = W + (int64_t)row * p.N + col;
+        if (v4 && col + 4 <= p.N) {
+          *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (col + r < p.N) dst[r] = acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
   OT* C = reinterpret_cast<OT*>(p.C);
-  const bool split = p.ksplit > 1;
-  const bool add_bias = p.bias && (!split || blockIdx.y == 0);
   const bool vec_out = (p.ldc % 4 == 0) && ((uintptr_t)p.C % 16 == 0);
+  float bv[FN][4];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    int col = tile_n * BN + wn * WN + j * 16 + fg * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[j][r] = (p.bias && col + r < p.N) ? p.bias[col + r] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     int row = tile_m * BM + wm * WM + i * 16 + fr;
@@ -323,15 +413,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       OT* dst = C + (int64_t)row * p.ldc + col;
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + ((add_bias && col + r < p.N) ? p.bias[col + r] : 0.f);
-      if constexpr (std::is_same<OT, float>::value) {
-        if (split) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (col + r < p.N) atomicAdd(dst + r, v[r]);
-          continue;
-        }
-      }
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
       const bool full = col + 4 <= p.N && vec_out;
       if (p.accumulate) {
 #pragma unroll
@@ -354,29 +436,67 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
 }
 
-// zero an [M, N] fp32 matrix with leading dimension ldc (kernel, not hipMemset2D: stays a plain
-// kernel node under hipGraph capture)
-static __global__ void gemm_zero_kernel(float* C, int M, int N, int64_t ldc) {
-  const int64_t total = (int64_t)M * N;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = i / N;
-    C[r * ldc + (i - r * N)] = 0.f;
+// C = act( sum_s ws[s] + bias ) (+ C): the fixed-order (deterministic) second half of split-K
+template <class OT>
+static __global__ void splitk_reduce_kernel(const float* ws, int ks, int M, int N, OT* C, int64_t ldc, const float* bias,
+                                            int act, int accumulate) {
+  const int64_t total = (int64_t)M * N, slab = total;
+  const bool v4 = (N % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)C % 16 == 0);
+  if (v4) {
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * blockDim.x * 4) {
+      float4 a = *reinterpret_cast<const float4*>(ws + i);
+      for (int s = 1; s < ks; ++s) {
+        float4 b = *reinterpret_cast<const float4*>(ws + s * slab + i);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      int64_t r = i / N;
+      int c = (int)(i - r * N);
+      float v[4] = {a.x, a.y, a.z, a.w};
+      OT* dst = C + r * ldc + c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (bias) v[e] += bias[c + e];
+        if (accumulate) v[e] += ElemIO<OT>::ld(dst + e);
+        if (act == OTR_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+      }
+      if constexpr (sizeof(OT) == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      else *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      float a = ws[i];
+      for (int s = 1; s < ks; ++s) a += ws[s * slab + i];
+      int64_t r = i / N;
+      int c = (int)(i - r * N);
+      OT* dst = C + r * ldc + c;
+      if (bias) a += bias[c];
+      if (accumulate) a += ElemIO<OT>::ld(dst);
+      if (act == OTR_ACT_RELU) a = fmaxf(a, 0.f);
+      ElemIO<OT>::st(dst, a);
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tile / split-K selection.  Goal: >= ~512 workgroups (2 per CU) whenever the problem allows it.
+// Tile / split-K selection.  Goal: >= ~512 workgroups (2 per CU) whenever the problem allows it; split-K
+// only when the output grid alone cannot fill the chip and a workspace was provided.
+extern int g_otr_force_tile;    // 0 = heuristic, 64 / 128 = forced (tuning hook: otr_debug_set(0, v))
+extern int g_otr_force_ksplit;  // 0 = heuristic, n = forced                  (otr_debug_set(1, v))
+
 template <class CT, class AT, class BT, class OT, int AMODE, int BMODE>
 static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
   constexpr int BK = GemmCfg<CT>::BK;
   const int nk = (a.K + BK - 1) / BK;
-  const bool can_split = a.allow_split && std::is_same<OT, float>::value && a.act == OTR_ACT_NONE;
+  const int64_t slab_bytes = (int64_t)a.M * a.N * 4;
+  const int max_by_ws = (a.ws && slab_bytes > 0) ? (int)(a.ws_bytes / slab_bytes) : 0;
+  const bool can_split = a.allow_split && max_by_ws >= 2;
   const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
   const int64_t t64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
   auto splits_for = [&](int64_t tiles) {
     if (!can_split) return 1;
     int64_t want = (512 + tiles - 1) / tiles;
     int64_t cap = nk / 4 > 0 ? nk / 4 : 1;
+    if (cap > max_by_ws) cap = max_by_ws;
     return (int)(want < cap ? want : cap);
   };
   bool big = a.M >= 128 && a.N >= 128;
@@ -387,18 +507,32 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
     ks = splits_for(t128);
   } else {
     big = false;
-    ks = splits_for(t64);
+    ks = t64 >= 256 ? 1 : splits_for(t64);
+  }
+  if (g_otr_force_tile == 64) big = false;
+  if (g_otr_force_tile == 128) big = true;
+  if (g_otr_force_tile != 0) ks = splits_for(big ? t128 : t64);
+  if (g_otr_force_ksplit > 0 && can_split) {
+    ks = g_otr_force_ksplit < nk ? g_otr_force_ksplit : nk;
+    if (ks > max_by_ws) ks = max_by_ws;
+  }
+  if (ks < 1) ks = 1;
+  {  // every k-slice must own at least one stage: an empty slice would leave its workspace slab unwritten
+    int per = (nk + ks - 1) / ks;
+    ks = (nk + per - 1) / per;
   }
   a.ksplit = ks;
-  if (ks > 1 && !a.accumulate) {  // atomic reduction needs a zeroed destination
-    int64_t total = (int64_t)a.M * a.N;
-    unsigned zg = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-    hipLaunchKernelGGL(gemm_zero_kernel, dim3(zg), dim3(256), 0, s, (float*)a.C, a.M, a.N, a.ldc);
-  }
   if (big) {
-    hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 128, 128>), dim3((unsigned)t128, ks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 128, 128>), dim3((unsigned)t128, a.ksplit), dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 64, 64>), dim3((unsigned)t64, ks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 64, 64>), dim3((unsigned)t64, a.ksplit), dim3(256), 0, s, a);
+  }
+  if (a.ksplit > 1) {
+    int64_t total = (int64_t)a.M * a.N;
+    unsigned g = (unsigned)((total / 4 + 255) / 256 > 2048 ? 2048 : (total / 4 + 255) / 256);
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL((splitk_reduce_kernel<OT>), dim3(g), dim3(256), 0, s, a.ws, a.ksplit, a.M, a.N, (OT*)a.C, a.ldc,
+                       a.bias, a.act, a.accumulate);
   }
   return otr_check_launch("gemm");
 }

@@ -6,7 +6,7 @@
 
 struct LnArgs {
   const float* x; const void* a; const float* gamma; const float* beta; const uint64_t* seed;
-  float* y; float* z; float* mean; float* rstd;
+  float* y; float* z; float* mean; float* rstd; bf16_t* y_lp;
   const float* dy; float* dx; void* da; float* dgamma; float* dbeta; const float* zin;
   int64_t M; int d;
   float eps, p_drop;
@@ -84,6 +84,7 @@ template <class AT, bool HAS_A> __global__ __launch_bounds__(256) void add_ln_fw
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + bta[e];
       st4<float>(p.y + row * d + col, o);
+      if (p.y_lp) st4<bf16_t>(p.y_lp + row * d + col, o);
     }
   }
   if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
@@ -180,14 +181,14 @@ static int32_t ln_check(const otr_ln_desc_t* d) {
 }
 
 extern "C" int32_t otr_add_layernorm_fwd(const otr_ln_desc_t* d, const float* x, const void* a, const float* gamma,
-                                         const float* beta, const uint64_t* seed, float* y, float* z, float* mean,
-                                         float* rstd, void* stream) {
+                                         const float* beta, const uint64_t* seed, float* y, void* y_bf16, float* z,
+                                         float* mean, float* rstd, void* stream) {
   if (int32_t e = ln_check(d)) return e;
   OTR_REQUIRE(x && gamma && beta && y && mean && rstd, "add_layernorm_fwd: null pointer");
   OTR_REQUIRE(d->p_drop == 0.f || (a && seed), "add_layernorm_fwd: dropout needs a and seed");
   if (d->M == 0) return 0;
   LnArgs p{};
-  p.x = x; p.a = a; p.gamma = gamma; p.beta = beta; p.seed = seed; p.y = y; p.z = z; p.mean = mean; p.rstd = rstd;
+  p.x = x; p.a = a; p.gamma = gamma; p.beta = beta; p.seed = seed; p.y = y; p.z = z; p.mean = mean; p.rstd = rstd; p.y_lp = (bf16_t*)y_bf16;
   p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
   dim3 grid((unsigned)((d->M + 3) / 4));
   hipStream_t s = (hipStream_t)stream;

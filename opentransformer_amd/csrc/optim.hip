@@ -47,7 +47,7 @@ __global__ void opt_tick_kernel(OptState* st, float base_lr, float model_size, f
   }
 }
 
-__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, const OptState* st,
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, const OptState* st, bf16_t* p_lp,
                             float beta1, float beta2, float eps, float wd, float grad_scale, float clip) {
   const float norm = sqrtf(st->sqnorm) * grad_scale;
   if (!isfinite(norm)) return;
@@ -60,12 +60,14 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_
     float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
     m[i] = mi;
     v[i] = vi;
-    p[i] = pi - (lr / bc1) * mi / (sqrtf(vi) * rbc2 + eps);
+    pi = pi - (lr / bc1) * mi / (sqrtf(vi) * rbc2 + eps);
+    p[i] = pi;
+    if (p_lp) p_lp[i] = f2bf(pi);
   }
 }
 
 extern "C" int32_t otr_optimizer_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                                      float* state, float base_lr, float beta1, float beta2, float eps,
+                                      float* state, void* param_bf16, float base_lr, float beta1, float beta2, float eps,
                                       float weight_decay, float grad_scale, float clip_norm, float noam_model_size,
                                       float noam_warmup, float noam_factor, float noam_step_offset, void* stream) {
   OTR_REQUIRE(param && grad && exp_avg && exp_avg_sq && state, "optimizer_step: null pointer");
@@ -80,7 +82,7 @@ extern "C" int32_t otr_optimizer_step(float* param, const float* grad, float* ex
   hipLaunchKernelGGL(opt_tick_kernel, dim3(1), dim3(1), 0, s, st, base_lr, noam_model_size, noam_warmup, noam_factor,
                      noam_step_offset, beta1, beta2, grad_scale);
   unsigned g2 = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-  hipLaunchKernelGGL(adam_kernel, dim3(g2), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, st, beta1, beta2, eps,
+  hipLaunchKernelGGL(adam_kernel, dim3(g2), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, st, (bf16_t*)param_bf16, beta1, beta2, eps,
                      weight_decay, grad_scale, clip_norm);
   return otr_check_launch("optimizer_step");
 }

@@ -45,6 +45,41 @@ class FlatDataParallel:
             off += n
         if flatten_params and padded > total:
             self.flat_param[total:].zero_()
+        # bf16 shadow of every parameter (GEMM operand form), kept fresh by FusedAdam in the same pass
+        self.flat_param_lp = None
+        if flatten_params and dev.type == 'cuda' and dt == torch.float32:
+            from . import ops
+            if ops.get_compute_dtype() == 'bf16':
+                self.flat_param_lp = torch.empty(padded, device=dev, dtype=torch.bfloat16)
+                off = 0
+                for p in params:
+                    n = p.numel()
+                    p._otr_lp_view = self.flat_param_lp[off:off + n].view(p.shape)
+                    off += n
+                # transposed bf16 shadows of the 2-D weights ([K,N]: dgrad becomes a forward-type GEMM)
+                self.flat_param_lpt = torch.empty(padded, device=dev, dtype=torch.bfloat16)
+                self._lpt_pairs = []
+                off = 0
+                for p in params:
+                    n = p.numel()
+                    if p.dim() == 2:
+                        p._otr_lpt_view = self.flat_param_lpt[off:off + n].view(p.shape[1], p.shape[0])
+                        self._lpt_pairs.append((p._otr_lp_view, p._otr_lpt_view))
+                    off += n
+                self.refresh_lp()
+
+    def refresh_lp(self):
+        """re-cast the bf16 shadows after any out-of-band parameter change (load_state_dict, ...)."""
+        if self.flat_param_lp is not None:
+            from . import ops
+            ops.cast_bf16(self.flat_param, self.flat_param_lp)
+            self.refresh_transposed()
+
+    def refresh_transposed(self):
+        """W^T shadows follow the bf16 shadows (call after every optimizer step)."""
+        if self.flat_param_lp is not None:
+            for src, dst in self._lpt_pairs:
+                dst.copy_(src.t())
 
     @property
     def world_size(self):
@@ -94,11 +129,14 @@ class FusedAdam:
         ret = L.load().otr_optimizer_step(
             C.c_void_p(self.dp.flat_param.data_ptr()), C.c_void_p(self.dp.flat_grad.data_ptr()),
             C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()), n,
-            C.c_void_p(self.state.data_ptr()), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+            C.c_void_p(self.state.data_ptr()),
+            C.c_void_p(self.dp.flat_param_lp.data_ptr()) if self.dp.flat_param_lp is not None else None,
+            self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
             grad_scale, self.clip, float(nm.get('model_size', 1.0)), float(nm.get('warmup_steps', 0.0)),
             float(nm.get('factor', 1.0)), 2.0,   # scheduler.py:41-53: the first update sees global_step 3
             C.c_void_p(torch.cuda.current_stream().cuda_stream))
         L.check(ret, 'otr_optimizer_step')
+        self.dp.refresh_transposed()
 
     def stats(self):
         s = self.state.tolist()

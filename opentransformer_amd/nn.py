@@ -71,11 +71,8 @@ class ConvFrontEnd(nn.Module):
     def forward(self, x, mask):
         c1, c2 = self.conv1.conv_layer, self.conv2.conv_layer
         C2, F2 = c2.out_channels, self.conv2.output_size
-        # layout prep of two small weights (autograd routes their gradients back):
-        w2r = c2.weight.permute(0, 2, 3, 1)                                   # [C2,3,3,C1] channel-last taps
-        wo = self.output_layer.weight.view(-1, C2, F2).permute(0, 2, 1).reshape(-1, F2 * C2)   # cols f*C2+c
-        act2 = ops.ConvSubsampleFn.apply(x, c1.weight, c1.bias, w2r.contiguous(), c2.bias)
-        y = ops.linear(act2, wo.contiguous(), self.output_layer.bias)
+        act2 = ops.ConvSubsampleFn.apply(x, c1.weight, c1.bias, c2.weight, c2.bias)     # [B,T2,F2*C2] channel-last
+        y = ops.linear(act2, self.output_layer.weight, self.output_layer.bias, perm=(C2, F2))
         t1 = (x.size(1) - 3) // 2 + 1
         mask = Conv2dLayer.return_output_mask(mask, t1)
         mask = Conv2dLayer.return_output_mask(mask, act2.size(1))
@@ -101,7 +98,7 @@ class PositionalEncoding(nn.Module):
         self.xscale = math.sqrt(emb_dim)
 
     def forward(self, x):
-        return ops.PosEncFn.apply(x), None
+        return ops.posenc(x), None
 
 
 def _key_mask(mask, B, Tk):
@@ -318,7 +315,7 @@ class TransformerDecoder(nn.Module):
             self.output_layer.weight = self.embedding.weight      # decoder/transformer.py:156-158
 
     def forward(self, targets, memory, memory_mask):
-        x = ops.EmbedPosEncFn.apply(targets, self.embedding.weight)
+        x = ops.embed_posenc(targets, self.embedding.weight)
         mm = memory_mask.unsqueeze(1)
         for block in self.blocks:
             x, _ = block(x, None, memory, mm)                    # None -> causal self-attention

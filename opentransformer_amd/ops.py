@@ -84,6 +84,81 @@ def _next_rng_offset(n):
     return off
 
 
+# ---------------------------------------------------------------------------------------- bf16 shadows
+# In bf16 mode every GEMM operand is read as bf16 from memory:
+#  * activations of the fp32 residual stream carry a bf16 twin produced by the kernel that wrote them
+#    (add+LayerNorm, pos-enc, embedding); it rides along as a Python attribute of the fp32 tensor;
+#  * weights have bf16 shadows: a slice of FlatDataParallel's flat bf16 buffer that the fused optimizer
+#    refreshes in the same pass as the fp32 master, or (stand-alone modules) a cached cast keyed by
+#    the parameter's version counter.
+_LP_ATTR = '_otr_bf16'
+
+
+def lp_of(t):
+    if _state['compute'] != 'bf16' or t is None:
+        return None
+    return getattr(t, _LP_ATTR, None)
+
+
+def attach_lp(t, lp):
+    if lp is not None:
+        setattr(t, _LP_ATTR, lp)
+    return t
+
+
+def cast_bf16(src, dst=None):
+    src = src.contiguous()
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    L.check(L.load().otr_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()), 'otr_cast_f32_to_bf16')
+    return dst
+
+
+def weight_lp(w):
+    """bf16 shadow of an fp32 weight (None in fp32 mode)."""
+    if _state['compute'] != 'bf16' or w.dtype != torch.float32:
+        return None
+    view = getattr(w, '_otr_lp_view', None)
+    if view is not None:
+        return view
+    cache = getattr(w, '_otr_lp_cache', None)
+    if cache is not None and cache[0] == w._version and cache[1] == w.data_ptr():
+        return cache[2]
+    lp = cast_bf16(w.detach())
+    w._otr_lp_cache = (w._version, w.data_ptr(), lp)
+    return lp
+
+
+# ---------------------------------------------------------------------------------------- split-K workspace
+_WS_BYTES = 64 << 20
+
+
+def _workspace(device):
+    """Caller-owned split-K workspace (include/otrans_hip.h): one fp32 buffer per device, shared by all
+    GEMM calls (they are ordered on the launch stream)."""
+    ws = _state.get('ws')
+    if ws is None or ws.device != device:
+        ws = torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
+        _state['ws'] = ws
+    return ws
+
+
+def weight_lpt(w):
+    """TRANSPOSED bf16 shadow [K, N] of an fp32 weight [N, K] (None in fp32 mode): with it the input
+    gradient dx = dy . w becomes a forward-type GEMM (both operands k-contiguous)."""
+    if _state['compute'] != 'bf16' or w.dtype != torch.float32 or w.dim() != 2:
+        return None
+    view = getattr(w, '_otr_lpt_view', None)
+    if view is not None:
+        return view
+    cache = getattr(w, '_otr_lpt_cache', None)
+    if cache is not None and cache[0] == w._version and cache[1] == w.data_ptr():
+        return cache[2]
+    lpt = weight_lp(w).t().contiguous()
+    w._otr_lpt_cache = (w._version, w.data_ptr(), lpt)
+    return lpt
+
+
 # ---------------------------------------------------------------------------------------- linear
 def _linear_desc(M, N, K, xdt, wdt, ydt, ldx, ldw, ldy, act=L.ACT_NONE, accumulate=0):
     return L.LinearDesc(M, N, K, _code(xdt), _code(wdt), _code(ydt), _compute_code(), ldx, ldw, ldy, act, accumulate)
@@ -94,7 +169,8 @@ def linear_fwd_raw(x2, w, b, out_dtype, act=L.ACT_NONE):
     N = w.shape[0]
     y = torch.empty((M, N), dtype=out_dtype, device=x2.device)
     d = _linear_desc(M, N, K, x2.dtype, w.dtype, out_dtype, x2.stride(0), w.stride(0), N, act)
-    L.check(L.load().otr_linear_fwd(C.byref(d), _p(x2), _p(w), _p(b), _p(y), _stream()), 'otr_linear_fwd')
+    ws = _workspace(x2.device)
+    L.check(L.load().otr_linear_fwd(C.byref(d), _p(x2), _p(w), _p(b), _p(y), _p(ws), _WS_BYTES, _stream()), 'otr_linear_fwd')
     return y
 
 
@@ -103,7 +179,8 @@ def linear_dgrad_raw(dy2, w, dx_dtype):
     K = w.shape[1]
     dx = torch.empty((M, K), dtype=dx_dtype, device=dy2.device)
     d = _linear_desc(M, N, K, dx_dtype, w.dtype, dy2.dtype, K, w.stride(0), dy2.stride(0))
-    L.check(L.load().otr_linear_dgrad(C.byref(d), _p(dy2), _p(w), _p(dx), _stream()), 'otr_linear_dgrad')
+    ws = _workspace(dy2.device)
+    L.check(L.load().otr_linear_dgrad(C.byref(d), _p(dy2), _p(w), _p(dx), _p(ws), _WS_BYTES, _stream()), 'otr_linear_dgrad')
     return dx
 
 
@@ -112,7 +189,8 @@ def linear_wgrad_raw(dy2, x2, w_like):
     K = x2.shape[1]
     dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
     d = _linear_desc(M, N, K, x2.dtype, torch.float32, dy2.dtype, x2.stride(0), K, dy2.stride(0))
-    L.check(L.load().otr_linear_wgrad(C.byref(d), _p(dy2), _p(x2), _p(dw), _stream()), 'otr_linear_wgrad')
+    ws = _workspace(dy2.device)
+    L.check(L.load().otr_linear_wgrad(C.byref(d), _p(dy2), _p(x2), _p(dw), _p(ws), _WS_BYTES, _stream()), 'otr_linear_wgrad')
     return dw
 
 
@@ -134,33 +212,54 @@ def _rows(x):
 
 
 class LinearFn(torch.autograd.Function):
-    """y = act(x w^T + b): nn.Linear of the reference (e.g. module/attention.py:43,68)."""
+    """y = act(x w^T + b): nn.Linear of the reference (e.g. module/attention.py:43,68).
+
+    perm = (C, F): the GEMM uses the weight with its columns regrouped from c*F+f to f*C+c (the
+    channel-last flatten of the conv frontend, frontend/conv.py:145); dw is regrouped back."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu, out_dtype):
+    def forward(ctx, x, w, b, relu, out_dtype, perm):
         _cuda(x, w, b)
-        x2 = _rows(x)
-        y = linear_fwd_raw(x2, w, b, out_dtype, L.ACT_RELU if relu else L.ACT_NONE)
+        xc = lp_of(x)
+        x2 = _rows(xc if xc is not None else x)
+        wl = weight_lp(w)
+        wc = wl if wl is not None else w
+        if perm is not None:
+            C_, F_ = perm
+            wc = wc.view(-1, C_, F_).permute(0, 2, 1).reshape(w.shape[0], F_ * C_).contiguous()
+        y = linear_fwd_raw(x2, wc, b, out_dtype, L.ACT_RELU if relu else L.ACT_NONE)
         ctx.relu = relu
         ctx.has_bias = b is not None
-        ctx.save_for_backward(x2, w, y if relu else None)
-        ctx.xshape = x.shape
+        ctx.perm = perm
+        ctx.wt = weight_lpt(w) if (perm is None and ctx.needs_input_grad[0]) else None
+        ctx.save_for_backward(x2, wc, y if relu else None)
+        ctx.xshape, ctx.xdtype = x.shape, x.dtype
         return y.view(*x.shape[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w, y = ctx.saved_tensors
+        x2, wc, y = ctx.saved_tensors
         dy2 = _rows(dy)
         if ctx.relu:
             dy2 = relu_bwd_raw(y, dy2.contiguous())
-        dx = linear_dgrad_raw(dy2, w, x2.dtype).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw = linear_wgrad_raw(dy2, x2, w) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.wt is not None:      # dx = dy . w as a forward-type GEMM on the transposed shadow
+                dx = linear_fwd_raw(dy2, ctx.wt, None, ctx.xdtype).view(ctx.xshape)
+            else:
+                dx = linear_dgrad_raw(dy2, wc, ctx.xdtype).view(ctx.xshape)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = linear_wgrad_raw(dy2, x2, wc)
+            if ctx.perm is not None:
+                C_, F_ = ctx.perm
+                dw = dw.view(-1, F_, C_).permute(0, 2, 1).reshape(dw.shape[0], C_ * F_)
         db = colsum_raw(dy2) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def linear(x, w, b=None, relu=False, out_dtype=None):
-    return LinearFn.apply(x, w, b, relu, out_dtype if out_dtype is not None else torch.float32)
+def linear(x, w, b=None, relu=False, out_dtype=None, perm=None):
+    return LinearFn.apply(x, w, b, relu, out_dtype if out_dtype is not None else torch.float32, perm)
 
 
 def relu_bwd_raw(y, g):
@@ -274,6 +373,7 @@ class AddLayerNormFn(torch.autograd.Function):
         M = x2.shape[0]
         need_grad = any(ctx.needs_input_grad)
         y = torch.empty_like(x2)
+        ylp = torch.empty(x2.shape, dtype=torch.bfloat16, device=x.device) if _state['compute'] == 'bf16' else None
         z = torch.empty_like(x2) if need_grad else None
         mean = torch.empty((M,), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
@@ -281,14 +381,18 @@ class AddLayerNormFn(torch.autograd.Function):
         off = _next_rng_offset(M * d) if p_drop > 0 else 0
         desc = L.LnDesc(M, d, _code(a2.dtype) if a2 is not None else L.OTR_F32, eps, p_drop, off)
         L.check(L.load().otr_add_layernorm_fwd(C.byref(desc), _p(x2), _p(a2), _p(gamma), _p(beta), _p(seed), _p(y),
-                                               _p(z), _p(mean), _p(rstd), _stream()), 'otr_add_layernorm_fwd')
+                                               _p(ylp), _p(z), _p(mean), _p(rstd), _stream()), 'otr_add_layernorm_fwd')
         ctx.save_for_backward(z, mean, rstd, gamma, seed)
         ctx.cfg = (M, d, a2.dtype if a2 is not None else None, eps, p_drop, off, x.shape,
                    a.shape if a is not None else None)
-        return y.view(x.shape)
+        if ylp is None:
+            return y.view(x.shape), None
+        ylp = ylp.view(x.shape)
+        ctx.mark_non_differentiable(ylp)
+        return y.view(x.shape), ylp
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dylp=None):
         z, mean, rstd, gamma, seed = ctx.saved_tensors
         M, d, adt, eps, p_drop, off, xshape, ashape = ctx.cfg
         dy2 = dy.reshape(-1, d).contiguous()
@@ -303,7 +407,8 @@ class AddLayerNormFn(torch.autograd.Function):
 
 
 def add_layernorm(x, a, gamma, beta, p_drop=0.0, eps=1e-5):
-    return AddLayerNormFn.apply(x, a, gamma, beta, float(p_drop), float(eps))
+    y, ylp = AddLayerNormFn.apply(x, a, gamma, beta, float(p_drop), float(eps))
+    return attach_lp(y, ylp)
 
 
 # ---------------------------------------------------------------------------------------- FFN (fused Function)
@@ -314,8 +419,13 @@ class FeedForwardGLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
         _cuda(x, w1, w2)
-        x2 = _rows(x)
+        xc = lp_of(x)
+        x2 = _rows(xc if xc is not None else x)
         adt = act_dtype()
+        w1l, w2l = weight_lp(w1), weight_lp(w2)
+        ctx.w1t, ctx.w2t = weight_lpt(w1), weight_lpt(w2)
+        w1 = w1l if w1l is not None else w1
+        w2 = w2l if w2l is not None else w2
         h = linear_fwd_raw(x2, w1, b1, adt)
         M, F2 = h.shape
         F = F2 // 2
@@ -323,7 +433,7 @@ class FeedForwardGLUFn(torch.autograd.Function):
         L.check(L.load().otr_glu_fwd(_p(h), _p(u), _code(adt), M, F, _stream()), 'otr_glu_fwd')
         y = linear_fwd_raw(u, w2, b2, torch.float32)
         ctx.save_for_backward(x2, w1, w2, h, u)
-        ctx.xshape = x.shape
+        ctx.xshape, ctx.xdtype = x.shape, x.dtype
         return y.view(*x.shape[:-1], w2.shape[0])
 
     @staticmethod
@@ -331,13 +441,16 @@ class FeedForwardGLUFn(torch.autograd.Function):
         x2, w1, w2, h, u = ctx.saved_tensors
         dy2 = _rows(dy)
         M, F = u.shape
-        du = linear_dgrad_raw(dy2, w2, u.dtype)
+        du = linear_fwd_raw(dy2, ctx.w2t, None, u.dtype) if ctx.w2t is not None else linear_dgrad_raw(dy2, w2, u.dtype)
         dw2 = linear_wgrad_raw(dy2, u, w2)
         db2 = colsum_raw(dy2)
         dh = torch.empty_like(h)
         db1 = torch.zeros((2 * F,), dtype=torch.float32, device=dy.device)
         L.check(L.load().otr_glu_bwd(_p(h), _p(du), _p(dh), _p(db1), _code(h.dtype), M, F, _stream()), 'otr_glu_bwd')
-        dx = linear_dgrad_raw(dh, w1, x2.dtype).view(ctx.xshape)
+        if ctx.w1t is not None:
+            dx = linear_fwd_raw(dh, ctx.w1t, None, ctx.xdtype).view(ctx.xshape)
+        else:
+            dx = linear_dgrad_raw(dh, w1, ctx.xdtype).view(ctx.xshape)
         dw1 = linear_wgrad_raw(dh, x2, w1)
         return dx, dw1, db1, dw2, db2
 
@@ -350,14 +463,17 @@ class PosEncFn(torch.autograd.Function):
     def forward(ctx, x):
         _cuda(x)
         B, T, d = x.shape
-        x = x.contiguous()
+        x = x.contiguous().float()
         y = torch.empty_like(x)
+        ylp = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if _state['compute'] == 'bf16' else None
         ctx.scale = math.sqrt(d)
-        L.check(L.load().otr_posenc_fwd(_p(x), _p(y), B * T, T, d, ctx.scale, _stream()), 'otr_posenc_fwd')
-        return y
+        L.check(L.load().otr_posenc_fwd(_p(x), _p(y), _p(ylp), B * T, T, d, ctx.scale, _stream()), 'otr_posenc_fwd')
+        if ylp is not None:
+            ctx.mark_non_differentiable(ylp)
+        return y, ylp
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dylp=None):
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
         L.check(L.load().otr_scale(_p(dy), _p(dx), dy.numel(), None, ctx.scale, _stream()), 'otr_scale')
@@ -374,15 +490,18 @@ class EmbedPosEncFn(torch.autograd.Function):
         V, d = E.shape
         tokens = tokens.contiguous()
         y = torch.empty((B, Lq, d), dtype=torch.float32, device=E.device)
+        ylp = torch.empty((B, Lq, d), dtype=torch.bfloat16, device=E.device) if _state['compute'] == 'bf16' else None
         ctx.scale = math.sqrt(d)
-        L.check(L.load().otr_embed_posenc_fwd(_p(tokens), _p(E), _p(y), B * Lq, Lq, d, V, ctx.scale, _stream()),
+        L.check(L.load().otr_embed_posenc_fwd(_p(tokens), _p(E), _p(y), _p(ylp), B * Lq, Lq, d, V, ctx.scale, _stream()),
                 'otr_embed_posenc_fwd')
         ctx.save_for_backward(tokens)
         ctx.eshape = (V, d)
-        return y
+        if ylp is not None:
+            ctx.mark_non_differentiable(ylp)
+        return y, ylp
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dylp=None):
         (tokens,) = ctx.saved_tensors
         V, d = ctx.eshape
         dy = dy.contiguous()
@@ -390,6 +509,16 @@ class EmbedPosEncFn(torch.autograd.Function):
         L.check(L.load().otr_embed_bwd(_p(tokens), _p(dy), _p(dE), tokens.numel(), d, V, ctx.scale, _stream()),
                 'otr_embed_bwd')
         return None, dE
+
+
+def posenc(x):
+    y, ylp = PosEncFn.apply(x)
+    return attach_lp(y, ylp)
+
+
+def embed_posenc(tokens, E):
+    y, ylp = EmbedPosEncFn.apply(tokens, E)
+    return attach_lp(y, ylp)
 
 
 # ---------------------------------------------------------------------------------------- conv frontend
@@ -404,20 +533,22 @@ def conv_geometry(T, F):
 class ConvSubsampleFn(torch.autograd.Function):
     """Two Conv2dLayers of frontend/conv.py:141-142 (3x3, stride 2, pad (0,1), ReLU).
 
-    x [B,T,F] f32; w1 [C1,1,3,3]; w2r = conv2 weight permuted to [C2,3,3,C1] (channel-last taps).
-    Returns channel-last act2 viewed as [B, T2, F2*C2] (column index f*C2 + c)."""
+    x [B,T,F] f32; w1 [C1,1,3,3]; w2 [C2,C1,3,3] (reference layout; regrouped to channel-last taps
+    [C2,3,3,C1] here, in the compute dtype).  Returns channel-last act2 viewed as [B, T2, F2*C2]
+    (column index f*C2 + c)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2r, b2):
-        _cuda(x, w1, b1, w2r, b2)
+    def forward(ctx, x, w1, b1, w2, b2):
+        _cuda(x, w1, b1, w2, b2)
         B, T, F = x.shape
-        C1, C2 = w1.shape[0], w2r.shape[0]
+        C1, C2 = w1.shape[0], w2.shape[0]
         T1, F1, T2, F2 = conv_geometry(T, F)
         adt = act_dtype()
         x = x.contiguous()
         w1 = w1.contiguous()
-        w2r = w2r.contiguous()
-        desc = L.ConvDesc(B, T, F, C1, C2, T1, F1, T2, F2, _code(adt), _compute_code())
+        w2l = weight_lp(w2)
+        w2r = (w2l if w2l is not None else w2).view(C2, C1, 3, 3).permute(0, 2, 3, 1).contiguous()
+        desc = L.ConvDesc(B, T, F, C1, C2, T1, F1, T2, F2, _code(adt), _compute_code(), _code(w2r.dtype))
         act1 = torch.empty((B, T1, F1, C1), dtype=adt, device=x.device)
         act2 = torch.empty((B, T2, F2 * C2), dtype=adt, device=x.device)
         lib = L.load()
@@ -432,13 +563,14 @@ class ConvSubsampleFn(torch.autograd.Function):
         x, w2r, act1, act2 = ctx.saved_tensors
         B, T, F, C1, C2, T1, F1, T2, F2 = ctx.desc_args
         adt = act2.dtype
-        desc = L.ConvDesc(B, T, F, C1, C2, T1, F1, T2, F2, _code(adt), _compute_code())
+        desc = L.ConvDesc(B, T, F, C1, C2, T1, F1, T2, F2, _code(adt), _compute_code(), _code(w2r.dtype))
         lib = L.load()
         g2 = relu_bwd_raw(act2, dact2.contiguous())
         M2 = B * T2 * F2
         db2 = colsum_raw(g2.view(M2, C2))
         dw2r = torch.empty((C2, 3, 3, C1), dtype=torch.float32, device=x.device)
-        L.check(lib.otr_conv2_wgrad(C.byref(desc), _p(g2), _p(act1), _p(dw2r), _stream()), 'otr_conv2_wgrad')
+        L.check(lib.otr_conv2_wgrad(C.byref(desc), _p(g2), _p(act1), _p(dw2r), _p(_workspace(x.device)), _WS_BYTES, _stream()),
+                'otr_conv2_wgrad')
         dcol = torch.empty((M2, 9 * C1), dtype=adt, device=x.device)
         L.check(lib.otr_conv2_dgrad_cols(C.byref(desc), _p(g2), _p(w2r), _p(dcol), _stream()), 'otr_conv2_dgrad_cols')
         dact1 = torch.empty_like(act1)
@@ -446,7 +578,7 @@ class ConvSubsampleFn(torch.autograd.Function):
         dwb = torch.zeros((C1 * 10,), dtype=torch.float32, device=x.device)
         dw1, db1 = dwb[:C1 * 9], dwb[C1 * 9:]
         L.check(lib.otr_conv1_wgrad(C.byref(desc), _p(x), _p(dact1), _p(dw1), _p(db1), _stream()), 'otr_conv1_wgrad')
-        return None, dw1.view(C1, 1, 3, 3), db1, dw2r, db2
+        return None, dw1.view(C1, 1, 3, 3), db1, dw2r.permute(0, 3, 1, 2), db2
 
 
 # ---------------------------------------------------------------------------------------- losses

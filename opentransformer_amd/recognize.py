@@ -41,7 +41,7 @@ class TransformerLanguageModel(nn.Module):
         self.crit = LabelSmoothingLoss(size=self.vocab_size, smoothing=self.smoothing, padding_idx=PAD)
 
     def logits(self, tokens):
-        x = ops.EmbedPosEncFn.apply(tokens.contiguous(), self.embedding.weight)
+        x = ops.embed_posenc(tokens.contiguous(), self.embedding.weight)
         for block in self.blocks:
             x, _ = block(x, None, causal=True)
         return ops.linear(x, self.output_project.weight, self.output_project.bias)

@@ -32,12 +32,12 @@ def test_header_binding_and_library_agree():
 def test_argument_errors_are_reported_without_a_gpu():
     lib = _lib.load()
     d = _lib.LinearDesc(4, 4, 0, 0, 0, 0, 0, 4, 4, 4, 0, 0)       # K = 0
-    assert lib.otr_linear_fwd(C.byref(d), None, None, None, None, None) < 0
+    assert lib.otr_linear_fwd(C.byref(d), None, None, None, None, None, 0, None) < 0
     assert b'linear' in lib.otr_last_error_string()
     a = _lib.AttnDesc(1, 1, 4, 4, 24, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1.0)   # head dim not built
     assert lib.otr_attention_fwd(C.byref(a), None, None, None, None, None, None, None) < 0
     ln = _lib.LnDesc(4, 6, 0, 1e-5, 0.0, 0)                          # d % 4 != 0
-    assert lib.otr_add_layernorm_fwd(C.byref(ln), None, None, None, None, None, None, None, None, None, None) < 0
+    assert lib.otr_add_layernorm_fwd(C.byref(ln), None, None, None, None, None, None, None, None, None, None, None) < 0
 
 
 def test_product_refuses_cpu_tensors():
