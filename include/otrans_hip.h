@@ -101,7 +101,8 @@ int32_t otr_add_layernorm_bwd(const otr_ln_desc_t* d, const float* dy, const flo
 
 /* ---- F.glu / F.relu on the FFN hidden (module/ffn.py:15-21,40): u[M,F] = h[:, :F]*sigmoid(h[:, F:]) */
 int32_t otr_glu_fwd(const void* h, void* u, int32_t dtype, int64_t M, int64_t F, void* stream);
-/* dh[M,2F] from du[M,F]; if dbias != NULL, dbias[2F] (f32) += column sums of dh */
+/* dh[M,2F] from du[M,F]; if dbias_partial != NULL it receives per-row-block partial column sums of dh,
+ * f32 [ceil(M/32), 2F] (deterministic; column-sum them with otr_colsum to get the w_1 bias gradient) */
 int32_t otr_glu_bwd(const void* h, const void* du, void* dh, float* dbias, int32_t dtype, int64_t M, int64_t F,
                     void* stream);
 

@@ -28,7 +28,7 @@ template <class T> __global__ void glu_fwd_kernel(const T* h, T* u, int64_t M, i
   }
 }
 
-// dh[:, :F] = du * sig(g);  dh[:, F:] = du * a * sig(g) * (1 - sig(g));  optional dbias[2F] += colsum(dh)
+// dh[:, :F] = du * sig(g);  dh[:, F:] = du * a * sig(g) * (1 - sig(g));  optional bias-gradient partials
 constexpr int GLU_RPB = 32;  // rows per block in the backward (each thread owns V columns)
 template <class T> __global__ void glu_bwd_kernel(const T* h, const T* du, T* dh, float* dbias, int64_t M, int64_t F) {
   constexpr int V = 16 / sizeof(T);
@@ -58,9 +58,10 @@ template <class T> __global__ void glu_bwd_kernel(const T* h, const T* du, T* dh
       *reinterpret_cast<uint4*>(dh + row * 2 * F + F + c) = MMA<bf16_t>::pack(og);
     }
   }
-  if (dbias) {
+  if (dbias) {  // per-row-block partial column sums [gridDim.y][2F] (no atomics); the caller column-sums them
+    float* dst = dbias + (int64_t)blockIdx.y * 2 * F;
 #pragma unroll
-    for (int e = 0; e < V; ++e) { atomicAdd(dbias + c + e, sa[e]); atomicAdd(dbias + F + c + e, sg[e]); }
+    for (int e = 0; e < V; ++e) { dst[c + e] = sa[e]; dst[F + c + e] = sg[e]; }
   }
 }
 

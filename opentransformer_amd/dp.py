@@ -42,6 +42,7 @@ class FlatDataParallel:
                 self.flat_param[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_param[off:off + n].view_as(p.data)
             p.grad = self.flat_grad[off:off + n].view_as(p.data)
+            p._otr_grad_inplace = True      # ops.grad_target(): backward kernels accumulate straight into the view
             off += n
         if flatten_params and padded > total:
             self.flat_param[total:].zero_()

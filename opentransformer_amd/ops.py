@@ -129,6 +129,16 @@ def weight_lp(w):
     return lp
 
 
+# ---------------------------------------------------------------------------------------- in-place gradients
+def grad_target(p):
+    """FlatDataParallel pre-installs every parameter's .grad as a view of ONE flat buffer (zeroed once per
+    step).  Backward kernels then accumulate straight into that view and return None to autograd: no
+    temporary dw tensors, no AccumulateGrad add kernel per parameter, no zero-fills."""
+    if p is not None and getattr(p, '_otr_grad_inplace', False) and p.grad is not None:
+        return p.grad
+    return None
+
+
 # ---------------------------------------------------------------------------------------- split-K workspace
 _WS_BYTES = 64 << 20
 
@@ -184,11 +194,13 @@ def linear_dgrad_raw(dy2, w, dx_dtype):
     return dx
 
 
-def linear_wgrad_raw(dy2, x2, w_like):
+def linear_wgrad_raw(dy2, x2, w_like, out=None):
+    """dw = dy^T x; with `out` (an fp32 [N,K] gradient buffer) the result is ACCUMULATED into it."""
     M, N = dy2.shape
     K = x2.shape[1]
-    dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
-    d = _linear_desc(M, N, K, x2.dtype, torch.float32, dy2.dtype, x2.stride(0), K, dy2.stride(0))
+    dw = out if out is not None else torch.empty((N, K), dtype=torch.float32, device=dy2.device)
+    d = _linear_desc(M, N, K, x2.dtype, torch.float32, dy2.dtype, x2.stride(0), K, dy2.stride(0),
+                     accumulate=int(out is not None))
     ws = _workspace(dy2.device)
     L.check(L.load().otr_linear_wgrad(C.byref(d), _p(dy2), _p(x2), _p(dw), _p(ws), _WS_BYTES, _stream()), 'otr_linear_wgrad')
     return dw
@@ -232,6 +244,7 @@ class LinearFn(torch.autograd.Function):
         ctx.has_bias = b is not None
         ctx.perm = perm
         ctx.wt = weight_lpt(w) if (perm is None and ctx.needs_input_grad[0]) else None
+        ctx.w_ref, ctx.b_ref = w, b
         ctx.save_for_backward(x2, wc, y if relu else None)
         ctx.xshape, ctx.xdtype = x.shape, x.dtype
         return y.view(*x.shape[:-1], w.shape[0])
@@ -250,11 +263,21 @@ class LinearFn(torch.autograd.Function):
                 dx = linear_dgrad_raw(dy2, wc, ctx.xdtype).view(ctx.xshape)
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = linear_wgrad_raw(dy2, x2, wc)
-            if ctx.perm is not None:
-                C_, F_ = ctx.perm
-                dw = dw.view(-1, F_, C_).permute(0, 2, 1).reshape(dw.shape[0], C_ * F_)
-        db = colsum_raw(dy2) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            gt = grad_target(ctx.w_ref) if ctx.perm is None else None
+            if gt is not None:
+                linear_wgrad_raw(dy2, x2, wc, out=gt)
+            else:
+                dw = linear_wgrad_raw(dy2, x2, wc)
+                if ctx.perm is not None:
+                    C_, F_ = ctx.perm
+                    dw = dw.view(-1, F_, C_).permute(0, 2, 1).reshape(dw.shape[0], C_ * F_)
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gt = grad_target(ctx.b_ref)
+            if gt is not None:
+                colsum_raw(dy2, out=gt)
+            else:
+                db = colsum_raw(dy2)
         return dx, dw, db, None, None, None
 
 
@@ -383,6 +406,7 @@ class AddLayerNormFn(torch.autograd.Function):
         L.check(L.load().otr_add_layernorm_fwd(C.byref(desc), _p(x2), _p(a2), _p(gamma), _p(beta), _p(seed), _p(y),
                                                _p(ylp), _p(z), _p(mean), _p(rstd), _stream()), 'otr_add_layernorm_fwd')
         ctx.save_for_backward(z, mean, rstd, gamma, seed)
+        ctx.g_ref, ctx.b_ref = gamma, beta
         ctx.cfg = (M, d, a2.dtype if a2 is not None else None, eps, p_drop, off, x.shape,
                    a.shape if a is not None else None)
         if ylp is None:
@@ -398,12 +422,17 @@ class AddLayerNormFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, d).contiguous()
         dx = torch.empty_like(dy2)
         da = torch.empty((M, d), dtype=adt, device=dy.device) if adt is not None else None
-        dgb = torch.zeros((2, d), dtype=torch.float32, device=dy.device)
+        gg, gb = grad_target(ctx.g_ref), grad_target(ctx.b_ref)
+        inplace = gg is not None and gb is not None
+        if not inplace:
+            dgb = torch.zeros((2, d), dtype=torch.float32, device=dy.device)
+            gg, gb = dgb[0], dgb[1]
         desc = L.LnDesc(M, d, _code(adt) if adt is not None else L.OTR_F32, eps, p_drop, off)
         L.check(L.load().otr_add_layernorm_bwd(C.byref(desc), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed),
-                                               _p(dx), _p(da), _p(dgb[0]), _p(dgb[1]), _stream()),
+                                               _p(dx), _p(da), _p(gg), _p(gb), _stream()),
                 'otr_add_layernorm_bwd')
-        return dx.view(xshape), (da.view(ashape) if da is not None else None), dgb[0], dgb[1], None, None
+        return (dx.view(xshape), (da.view(ashape) if da is not None else None),
+                None if inplace else gg, None if inplace else gb, None, None)
 
 
 def add_layernorm(x, a, gamma, beta, p_drop=0.0, eps=1e-5):
@@ -419,6 +448,7 @@ class FeedForwardGLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
         _cuda(x, w1, w2)
+        ctx.refs = (w1, b1, w2, b2)
         xc = lp_of(x)
         x2 = _rows(xc if xc is not None else x)
         adt = act_dtype()
@@ -439,20 +469,28 @@ class FeedForwardGLUFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, w1, w2, h, u = ctx.saved_tensors
+        w1p, b1p, w2p, b2p = ctx.refs
         dy2 = _rows(dy)
         M, F = u.shape
         du = linear_fwd_raw(dy2, ctx.w2t, None, u.dtype) if ctx.w2t is not None else linear_dgrad_raw(dy2, w2, u.dtype)
-        dw2 = linear_wgrad_raw(dy2, u, w2)
-        db2 = colsum_raw(dy2)
+        gw2, gb2, gw1, gb1 = grad_target(w2p), grad_target(b2p), grad_target(w1p), grad_target(b1p)
+        dw2 = linear_wgrad_raw(dy2, u, w2, out=gw2)
+        db2 = colsum_raw(dy2, out=gb2)
         dh = torch.empty_like(h)
-        db1 = torch.zeros((2 * F,), dtype=torch.float32, device=dy.device)
-        L.check(L.load().otr_glu_bwd(_p(h), _p(du), _p(dh), _p(db1), _code(h.dtype), M, F, _stream()), 'otr_glu_bwd')
+        nblk = (M + GLU_RPB - 1) // GLU_RPB
+        part = torch.empty((nblk, 2 * F), dtype=torch.float32, device=dy.device)
+        L.check(L.load().otr_glu_bwd(_p(h), _p(du), _p(dh), _p(part), _code(h.dtype), M, F, _stream()), 'otr_glu_bwd')
+        db1 = colsum_raw(part, out=gb1)
         if ctx.w1t is not None:
             dx = linear_fwd_raw(dh, ctx.w1t, None, ctx.xdtype).view(ctx.xshape)
         else:
             dx = linear_dgrad_raw(dh, w1, ctx.xdtype).view(ctx.xshape)
-        dw1 = linear_wgrad_raw(dh, x2, w1)
-        return dx, dw1, db1, dw2, db2
+        dw1 = linear_wgrad_raw(dh, x2, w1, out=gw1)
+        return (dx, None if gw1 is not None else dw1, None if gb1 is not None else db1,
+                None if gw2 is not None else dw2, None if gb2 is not None else db2)
+
+
+GLU_RPB = 32        # rows per workgroup of otr_glu_bwd (csrc/elementwise.hip)
 
 
 # ---------------------------------------------------------------------------------------- positional encoding
@@ -496,6 +534,7 @@ class EmbedPosEncFn(torch.autograd.Function):
                 'otr_embed_posenc_fwd')
         ctx.save_for_backward(tokens)
         ctx.eshape = (V, d)
+        ctx.e_ref = E
         if ylp is not None:
             ctx.mark_non_differentiable(ylp)
         return y, ylp
@@ -505,10 +544,11 @@ class EmbedPosEncFn(torch.autograd.Function):
         (tokens,) = ctx.saved_tensors
         V, d = ctx.eshape
         dy = dy.contiguous()
-        dE = torch.zeros((V, d), dtype=torch.float32, device=dy.device)
+        gt = grad_target(ctx.e_ref)
+        dE = gt if gt is not None else torch.zeros((V, d), dtype=torch.float32, device=dy.device)
         L.check(L.load().otr_embed_bwd(_p(tokens), _p(dy), _p(dE), tokens.numel(), d, V, ctx.scale, _stream()),
                 'otr_embed_bwd')
-        return None, dE
+        return None, (None if gt is not None else dE)
 
 
 def posenc(x):
@@ -545,6 +585,7 @@ class ConvSubsampleFn(torch.autograd.Function):
         T1, F1, T2, F2 = conv_geometry(T, F)
         adt = act_dtype()
         x = x.contiguous()
+        w1_param = w1
         w1 = w1.contiguous()
         w2l = weight_lp(w2)
         w2r = (w2l if w2l is not None else w2).view(C2, C1, 3, 3).permute(0, 2, 3, 1).contiguous()
@@ -556,6 +597,7 @@ class ConvSubsampleFn(torch.autograd.Function):
         L.check(lib.otr_conv2_fwd(C.byref(desc), _p(act1), _p(w2r), _p(b2), _p(act2), _stream()), 'otr_conv2_fwd')
         ctx.save_for_backward(x, w2r, act1, act2)
         ctx.desc_args = (B, T, F, C1, C2, T1, F1, T2, F2)
+        ctx.refs = (w1_param, b1, b2)
         return act2
 
     @staticmethod
@@ -567,7 +609,9 @@ class ConvSubsampleFn(torch.autograd.Function):
         lib = L.load()
         g2 = relu_bwd_raw(act2, dact2.contiguous())
         M2 = B * T2 * F2
-        db2 = colsum_raw(g2.view(M2, C2))
+        w1p, b1p, b2p = ctx.refs
+        gw1, gb1, gb2 = grad_target(w1p), grad_target(b1p), grad_target(b2p)
+        db2 = colsum_raw(g2.view(M2, C2), out=gb2)
         dw2r = torch.empty((C2, 3, 3, C1), dtype=torch.float32, device=x.device)
         L.check(lib.otr_conv2_wgrad(C.byref(desc), _p(g2), _p(act1), _p(dw2r), _p(_workspace(x.device)), _WS_BYTES, _stream()),
                 'otr_conv2_wgrad')
@@ -575,10 +619,15 @@ class ConvSubsampleFn(torch.autograd.Function):
         L.check(lib.otr_conv2_dgrad_cols(C.byref(desc), _p(g2), _p(w2r), _p(dcol), _stream()), 'otr_conv2_dgrad_cols')
         dact1 = torch.empty_like(act1)
         L.check(lib.otr_conv2_col2im(C.byref(desc), _p(dcol), _p(act1), _p(dact1), _stream()), 'otr_conv2_col2im')
-        dwb = torch.zeros((C1 * 10,), dtype=torch.float32, device=x.device)
-        dw1, db1 = dwb[:C1 * 9], dwb[C1 * 9:]
+        if gw1 is not None and gb1 is not None:
+            dw1, db1 = gw1, gb1
+        else:
+            dwb = torch.zeros((C1 * 10,), dtype=torch.float32, device=x.device)
+            dw1, db1 = dwb[:C1 * 9], dwb[C1 * 9:]
         L.check(lib.otr_conv1_wgrad(C.byref(desc), _p(x), _p(dact1), _p(dw1), _p(db1), _stream()), 'otr_conv1_wgrad')
-        return None, dw1.view(C1, 1, 3, 3), db1, dw2r.permute(0, 3, 1, 2), db2
+        inpl = gw1 is not None and gb1 is not None
+        return (None, None if inpl else dw1.view(C1, 1, 3, 3), None if inpl else db1, dw2r.permute(0, 3, 1, 2),
+                None if gb2 is not None else db2)
 
 
 # ---------------------------------------------------------------------------------------- losses

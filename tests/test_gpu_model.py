@@ -199,3 +199,26 @@ def test_hipgraph_replay_matches_eager():
         torch.cuda.synchronize()
         assert bool(torch.isfinite(dp.flat_grad).all())
         assert rel(dp.flat_grad.cpu().numpy(), ref.cpu().numpy()) < 1e-4     # atomics reorder the last ulps
+
+
+def test_inplace_flat_gradients_match_autograd_gradients():
+    """FlatDataParallel makes the backward kernels accumulate straight into the flat gradient buffer
+    (ops.grad_target); the result must equal the ordinary autograd path parameter by parameter."""
+    from opentransformer_amd import ops
+    from opentransformer_amd.dp import FlatDataParallel
+    ops.set_compute_dtype('fp32')
+    try:
+        cfg = syn.c1_model(0.0, ctc_weight=0.3)
+        inputs, targets = syn.synthetic_batch(**C1_BATCH)
+        inputs, targets = to_dev(inputs), to_dev(targets)
+        plain = build(cfg)
+        plain(inputs, targets)[0].backward()
+        flat = build(cfg)
+        dp = FlatDataParallel(flat)
+        dp.zero_grad()
+        dp(inputs, targets)[0].backward()
+        for (k, p), (_, q) in zip(plain.named_parameters(), flat.named_parameters()):
+            assert q.grad.data_ptr() >= dp.flat_grad.data_ptr()
+            assert rel(q.grad.cpu().numpy(), p.grad.cpu().numpy()) < 1e-5, k
+    finally:
+        ops.set_compute_dtype('bf16')
