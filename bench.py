@@ -80,23 +80,31 @@ def time_dominant_kernel(model, mode):
     from opentransformer_amd import ops
     w1 = model.encoder.blocks[0].feed_forward.w_1
     M = time_dominant_kernel.rows
-    x = torch.randn(M, w1.in_features, device=w1.weight.device)
     adt = ops.act_dtype()
+    x = torch.randn(M, w1.in_features, device=w1.weight.device).to(adt)      # the model feeds the bf16 twin
+    wq = ops.weight_lp(w1.weight)
+    wq = wq if wq is not None else w1.weight
     for _ in range(5):
-        ops.linear_fwd_raw(x, w1.weight, w1.bias, adt)
+        ops.linear_fwd_raw(x, wq, w1.bias, adt)
     n = 50
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
-        ops.linear_fwd_raw(x, w1.weight, w1.bias, adt)
+        ops.linear_fwd_raw(x, wq, w1.bias, adt)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     flops = 2.0 * M * w1.out_features * w1.in_features
     peak = PEAK_BF16_TFLOPS if mode == 'bf16' else PEAK_F32_TFLOPS
     ach = flops / (ms * 1e-3) / 1e12
+    traffic = None
+    try:     # HBM bytes per launch measured offline with rocprofv3 PMC passes (profiles/r01_pmc_traffic.json)
+        key = 'gemm_fwd_%dx%dx%d_%s' % (M, w1.out_features, w1.in_features, mode)
+        traffic = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))[key]['hbm_bytes']
+    except Exception:                                          # noqa: BLE001
+        pass
     return {'bound': 'mfma', 'kernel': 'gemm_kernel (FFN w_1 forward, M=%d N=%d K=%d)' % (M, w1.out_features, w1.in_features),
-            'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+            'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
             'avg_launch_ms': ms}
 
 

@@ -58,6 +58,28 @@ def c1_model(residual_dropout=0.0, ctc_weight=0.0):
     return m
 
 
+def conformer_model(small=False, residual_dropout=0.0):
+    """egs/aishell/conf/conformer_baseline.yaml model section (80-d); small=True is a plumbing-size variant."""
+    m = copy.deepcopy(C2_MODEL)
+    if small:
+        m['frontend'].update(output_size=64, mid_channel=32, out_channel=64)
+        enc = dict(d_model=64, d_ff=128, cov_kernel_size=5, n_heads=4, nblocks=2)
+        m['decoder'].update(vocab_size=100, d_model=64, n_heads=4, d_ff=256, memory_dim=64, n_blocks=2)
+        m['encoder_output_size'] = 64
+    else:
+        m['frontend'].update(output_size=384, mid_channel=256, out_channel=256)
+        enc = dict(d_model=384, d_ff=768, cov_kernel_size=5, n_heads=4, nblocks=12)
+        m['decoder'].update(d_model=384, memory_dim=384)
+        m['encoder_output_size'] = 384
+    enc.update(pos_dropout=0.0, slf_attn_dropout=0.0, ffn_dropout=0.0, residual_dropout=residual_dropout,
+               conv_dropout=0.0, macaron_style=True, ffn_scale=0.5, conv_bias=True, activation='glu',
+               positional_encoding=True, relative_positional=True)
+    m['encoder_type'] = 'conformer'
+    m['encoder'] = enc
+    m['decoder']['residual_dropout'] = residual_dropout
+    return m
+
+
 def lm_config(vocab_size, d_model=256, n_heads=4, d_ff=2048, num_blocks=4):
     """egs/aishell/conf/transformer_lm.yaml model section with vocab forced equal to the ASR
     vocab (the shipped yaml's 4233 would fail the add)."""
@@ -77,7 +99,15 @@ def fill_state_dict_(sd, seed=1234):
             continue
         rng = np.random.default_rng((zlib.crc32(k.encode()) ^ seed) & 0xFFFFFFFF)
         shape = tuple(t.shape)
-        if 'norm' in k and k.endswith('weight'):
+        if k.endswith('num_batches_tracked'):
+            continue
+        if k.endswith('running_var'):
+            a = 1.0 + 0.2 * rng.uniform(0.0, 1.0, shape)
+        elif k.endswith('running_mean'):
+            a = 0.05 * rng.standard_normal(shape)
+        elif k.endswith('posu') or k.endswith('posv'):
+            a = 0.2 * rng.standard_normal(shape)
+        elif 'norm' in k and k.endswith('weight'):
             a = 1.0 + 0.1 * rng.standard_normal(shape)
         elif 'norm' in k and k.endswith('bias'):
             a = 0.05 * rng.standard_normal(shape)

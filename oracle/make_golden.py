@@ -221,6 +221,13 @@ def main():
     c2_batch = dict(batch=2, frames=1000, feat_dim=80, vocab=4234, tgt_len=15, seed=0,
                     lengths=[1000, 873], tgt_lengths=[15, 11])
     golden_train('c2_train_b2.npz', c2, c2_batch)
+    # Conformer (BASELINE configs[3]): plumbing size, ragged, dropout 0 (the reference applies F.dropout even
+    # in eval: SURVEY.md section 7), BatchNorm in training mode (batch statistics)
+    c4s = syn.conformer_model(small=True)
+    golden_train('c4_conformer_small.npz', c4s, c1_batch,
+                 store_full_grads=('encoder.blocks.0.mha.posu', 'encoder.blocks.0.mha.posv',
+                                   'encoder.blocks.0.mha.pos_proj.weight', 'encoder.blocks.1.conv.depthwise_conv.weight',
+                                   'encoder.blocks.1.conv.batch_norm.weight', 'encoder.blocks.0.conv.pointwise_conv1.bias'))
 
 
 if __name__ == '__main__':

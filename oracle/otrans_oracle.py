@@ -169,6 +169,71 @@ def transformer_encoder(sd, x, mask, cfg):
     return x, mask
 
 
+# --------------------------------------------------------------------------- conformer (C4)
+def relpos_self_attention(sd, x, mask, pos, h):
+    """MultiHeadedSelfAttentionWithRelPos.forward + _RelPosBias: otrans/module/attention.py:196-253.
+
+    scores = ((q+u) k^T + shift((q+v) p^T)) / sqrt(dk), p = pos_proj(sinusoid[-(T-1)..T-1]) (no bias);
+    shift by gather index j - i + T - 1 (:209-215).  As shipped (ctor bug at :178) the
+    module has NO output projection when slf_attn_dropout == 0: the merged heads are returned."""
+    B, T, d = x.shape
+    dk = d // h
+    q, k, v = torch.split(F.linear(x, sd['qvk_proj.weight'], sd['qvk_proj.bias']), d, dim=-1)
+    q = q.reshape(B, T, h, dk)
+    k, v = _heads(k, h), _heads(v, h)
+    p = F.linear(pos, sd['pos_proj.weight']).reshape(pos.size(0), -1, h, dk).transpose(1, 2)     # [1,h,2T-1,dk]
+    ac = torch.matmul((q + sd['posu']).transpose(1, 2), k.transpose(-2, -1))
+    bd_full = torch.matmul((q + sd['posv']).transpose(1, 2), p.transpose(-2, -1))                 # [B,h,T,2T-1]
+    idx = (torch.arange(T)[None] - torch.arange(T)[:, None] + (T - 1)).reshape(1, 1, T, T)
+    bd = torch.gather(bd_full, 3, idx.expand(B, h, T, T))
+    scores = (ac + bd) / math.sqrt(dk)
+    if mask is not None:
+        scores = scores.masked_fill(~mask.unsqueeze(1), -float('inf'))
+    ctx = torch.matmul(torch.softmax(scores, dim=-1), v)
+    ctx = ctx.transpose(1, 2).reshape(B, T, d)
+    if 'output_proj.weight' in sd:
+        ctx = F.linear(ctx, sd['output_proj.weight'], sd['output_proj.bias'])
+    return ctx
+
+
+def conformer_conv_module(sd, x, mask, training=True):
+    """ConformerConvolutionModule.forward: otrans/module/conformer.py:36-57.
+
+    Linear C->2C, GLU, zero padded frames, depthwise Conv1d(k, pad (k-1)/2), BatchNorm1d (batch
+    statistics over ALL B*T positions in training, padded ones included), swish, Linear C->C, zero
+    padded frames."""
+    m = mask.unsqueeze(2)
+    y = F.glu(F.linear(x, sd['pointwise_conv1.weight'], sd['pointwise_conv1.bias']), dim=-1)
+    y = y.masked_fill(~m, 0.0).transpose(1, 2)
+    wdw = sd['depthwise_conv.weight']
+    y = F.conv1d(y, wdw, sd.get('depthwise_conv.bias'), padding=(wdw.size(-1) - 1) // 2, groups=wdw.size(0))
+    y = F.batch_norm(y, sd['batch_norm.running_mean'].clone(), sd['batch_norm.running_var'].clone(),
+                     sd['batch_norm.weight'], sd['batch_norm.bias'], training, 0.1, 1e-5)
+    y = (y * torch.sigmoid(y)).transpose(1, 2)
+    y = F.linear(y, sd['pointwise_conv2.weight'], sd['pointwise_conv2.bias'])
+    return y.masked_fill(~m, 0.0)
+
+
+def conformer_block(sd, x, mask, pos, h, ffn_scale=0.5, training=True):
+    """ConformerEncoderBlock.forward: otrans/encoder/conformer.py:75-89 (dropout 0).
+
+    As shipped: post_ffn is NEVER applied -- only post_ffn_norm, then final_norm (:87-89)."""
+    x = x + ffn_scale * feed_forward(_sub(sd, 'pre_ffn.'), _ln(sd, 'macaron_ffn_norm', x), 'glu')
+    x = x + relpos_self_attention(_sub(sd, 'mha.'), _ln(sd, 'mha_norm', x), mask.unsqueeze(1), pos, h)
+    x = x + conformer_conv_module(_sub(sd, 'conv.'), _ln(sd, 'conv_norm', x), mask, training)
+    x = _ln(sd, 'post_ffn_norm', x)
+    return _ln(sd, 'final_norm', x)
+
+
+def conformer_encoder(sd, x, mask, cfg, training=True):
+    """ConformerEncoder.forward: otrans/encoder/conformer.py:141-164 (relative positional)."""
+    T = x.size(1)
+    pos = sinusoid(torch.arange(-(T - 1), T).reshape(1, -1), x.size(-1))
+    for i in range(cfg['nblocks']):
+        x = conformer_block(_sub(sd, 'blocks.%d.' % i), x, mask, pos, cfg['n_heads'], cfg.get('ffn_scale', 0.5), training)
+    return x, mask
+
+
 # --------------------------------------------------------------------------- decoder
 def decoder_layer(sd, x, tgt_mask, memory, memory_mask, h, activation, normalize_before=False):
     """TransformerDecoderLayer.forward: otrans/decoder/transformer.py:47-90 (dropout off)."""
@@ -276,7 +341,10 @@ def speech2text_forward(sd, params, inputs, targets):
     sd: {'frontend':..,'encoder':..,'decoder':..,['ctc':..]} (checkpoint layout :72-82).
     Returns (loss, aux) with aux = {'logits','memory','memory_mask',['ctc_loss']}."""
     x, mask = conv_frontend(sd['frontend'], inputs['inputs'], inputs['mask'])
-    memory, memory_mask = transformer_encoder(sd['encoder'], x, mask, params['encoder'])
+    if params.get('encoder_type', 'transformer') == 'conformer':
+        memory, memory_mask = conformer_encoder(sd['encoder'], x, mask, params['encoder'])
+    else:
+        memory, memory_mask = transformer_encoder(sd['encoder'], x, mask, params['encoder'])
     truth = targets['targets']
     logits = transformer_decoder(sd['decoder'], truth[:, :-1], memory, memory_mask, params['decoder'])
     target_out = truth[:, 1:]

@@ -42,7 +42,28 @@ def empty_state(cfg, with_ctc=None):
 
     e = {}
     d = en['d_model']
-    for i in range(en['n_blocks']):
+    if cfg.get('encoder_type', 'transformer') == 'conformer':
+        h = en['n_heads']
+        for i in range(en['nblocks']):
+            p = 'blocks.%d.' % i
+            for nm in ('pre_ffn', 'post_ffn'):
+                _linear(e, p + nm + '.w_1', en['d_ff'] * 2, d)
+                _linear(e, p + nm + '.w_2', d, en['d_ff'])
+            for nm in ('macaron_ffn_norm', 'mha_norm', 'conv_norm', 'post_ffn_norm', 'final_norm'):
+                _ln(e, p + nm, d)
+            e[p + 'mha.posu'] = torch.empty(1, 1, h, d // h)
+            e[p + 'mha.posv'] = torch.empty(1, 1, h, d // h)
+            _linear(e, p + 'mha.qvk_proj', 3 * d, d)
+            _linear(e, p + 'mha.pos_proj', d, d, bias=False)
+            _linear(e, p + 'conv.pointwise_conv1', 2 * d, d)
+            e[p + 'conv.depthwise_conv.weight'] = torch.empty(d, 1, en['cov_kernel_size'])
+            e[p + 'conv.depthwise_conv.bias'] = torch.empty(d)
+            _ln(e, p + 'conv.batch_norm', d)
+            e[p + 'conv.batch_norm.running_mean'] = torch.empty(d)
+            e[p + 'conv.batch_norm.running_var'] = torch.empty(d)
+            e[p + 'conv.batch_norm.num_batches_tracked'] = torch.zeros((), dtype=torch.long)
+            _linear(e, p + 'conv.pointwise_conv2', d, d)
+    for i in range(en.get('n_blocks', 0) if cfg.get('encoder_type', 'transformer') != 'conformer' else 0):
         p = 'blocks.%d.' % i
         _linear(e, p + 'slf_attn.output_proj', d, d)
         _linear(e, p + 'slf_attn.qvk_proj', 3 * d, d)
@@ -117,6 +138,7 @@ def lm_state(cfg, seed=4321):
 
 def require_grad(parts):
     for sd in parts.values():
-        for v in sd.values():
-            v.requires_grad_(True)
+        for k, v in sd.items():
+            if v.is_floating_point() and not k.endswith(('running_mean', 'running_var')):
+                v.requires_grad_(True)
     return parts

@@ -50,6 +50,10 @@ def test_c2_train_matches_reference(golden):
     _check_train(golden('c2_train_b2.npz'), syn.c2_model(0.0), C2_BATCH, 5e-5)
 
 
+def test_c4_conformer_train_matches_reference(golden):
+    _check_train(golden('c4_conformer_small.npz'), syn.conformer_model(small=True), C1_BATCH, 3e-5)
+
+
 def test_ctc_head_and_recursion_match_reference(golden):
     g = golden('c1_train.npz')
     cfg = syn.c1_model(0.0, ctc_weight=0.3)
