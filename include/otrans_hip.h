@@ -79,6 +79,19 @@ int32_t otr_attention_bwd(const otr_attn_desc_t* d, const void* q, const void* k
                           const uint8_t* key_mask, const void* o, const void* do_, const float* lse,
                           float* delta, void* dq, void* dk, void* dv, void* stream);
 
+/* Variant with an additive fp32 score bias, S = (q.k + bias[b,h,i,col]) * scale, addressed as
+ * bias[b*bias_bs + h*bias_hs + i*bias_rs + col], col = j, or col = j - i + Tq - 1 when rel_shift != 0: the
+ * Transformer-XL relative-position term of MultiHeadedSelfAttentionWithRelPos (module/attention.py:196-253; the
+ * reference materialises [B,h,T,2T-1] and gathers it at :209-215).  dbias (same addressing, caller pre-zeroed when
+ * rel_shift) receives d loss / d bias. */
+int32_t otr_attention_bias_fwd(const otr_attn_desc_t* d, const void* q, const void* k, const void* v,
+                               const uint8_t* key_mask, const float* bias, int64_t bias_bs, int64_t bias_hs,
+                               int64_t bias_rs, int32_t rel_shift, void* o, float* lse, void* stream);
+int32_t otr_attention_bias_bwd(const otr_attn_desc_t* d, const void* q, const void* k, const void* v,
+                               const uint8_t* key_mask, const float* bias, float* dbias, int64_t bias_bs,
+                               int64_t bias_hs, int64_t bias_rs, int32_t rel_shift, const void* o, const void* do_,
+                               const float* lse, float* delta, void* dq, void* dk, void* dv, void* stream);
+
 /* ---- y = LayerNorm(x + dropout(a)) (encoder/transformer.py:54-56,61-63; decoder/transformer.py:
  *      66-68,76-78,84-86).  x f32 [M,d]; a [M,d] of a_dtype or NULL; z (= x+drop(a), f32) and
  *      mean/rstd (f32 [M]) are saved for backward.  Dropout masks come from a counter RNG keyed by
@@ -100,11 +113,12 @@ int32_t otr_add_layernorm_bwd(const otr_ln_desc_t* d, const float* dy, const flo
                               float* dgamma, float* dbeta, void* stream);
 
 /* ---- F.glu / F.relu on the FFN hidden (module/ffn.py:15-21,40): u[M,F] = h[:, :F]*sigmoid(h[:, F:]) */
-int32_t otr_glu_fwd(const void* h, void* u, int32_t dtype, int64_t M, int64_t F, void* stream);
+/* row_mask (uint8 [M], may be NULL): rows with mask 0 produce u = 0 / dh = 0 (module/conformer.py:46) */
+int32_t otr_glu_fwd(const void* h, void* u, int32_t dtype, int64_t M, int64_t F, const uint8_t* row_mask, void* stream);
 /* dh[M,2F] from du[M,F]; if dbias_partial != NULL it receives per-row-block partial column sums of dh,
  * f32 [ceil(M/32), 2F] (deterministic; column-sum them with otr_colsum to get the w_1 bias gradient) */
 int32_t otr_glu_bwd(const void* h, const void* du, void* dh, float* dbias, int32_t dtype, int64_t M, int64_t F,
-                    void* stream);
+                    const uint8_t* row_mask, void* stream);
 
 /* ---- PositionalEncoding (module/pos.py:30-57): y = x*scale + PE[t], t = row % T.
  *      x may alias y. */
@@ -159,6 +173,37 @@ int32_t otr_label_smoothing_loss(const float* logits, const int64_t* target, int
 
 /* ---- log_softmax over the last dim, f32 [R,V] (model/ctc.py:51,66; decoder/transformer.py:206) */
 int32_t otr_log_softmax(const float* x, float* y, int64_t R, int32_t V, void* stream);
+
+/* ---- Conformer encoder pieces (BASELINE configs[3]; encoder/conformer.py:20-114, module/conformer.py:12-57,
+ *      module/attention.py:176-253).  All [M = B*T, C] row-major, C % 4 == 0. */
+/* y = x + scale * dropout(a)  (pre-norm residual branches, ffn_scale 0.5 for the macaron FFN) and its branch grad */
+int32_t otr_residual_add_fwd(const float* x, const void* a, int32_t a_dtype, float* y, int64_t n, float scale,
+                             float p_drop, const uint64_t* seed, uint64_t rng_offset, void* stream);
+int32_t otr_residual_add_bwd(const float* dy, void* da, int32_t a_dtype, int64_t n, float scale, float p_drop,
+                             const uint64_t* seed, uint64_t rng_offset, void* stream);
+/* out[M, 2d] = [q + u | q + v] (pos_bias_u / pos_bias_v flattened to [d]); q has leading dimension ldq */
+int32_t otr_head_bias_add(const void* q, int64_t ldq, const float* u, const float* v, void* out, int32_t dtype,
+                          int64_t M, int32_t d, void* stream);
+/* out[r, :cols] = a[r, :cols] + b[r, :cols] with independent leading dimensions */
+int32_t otr_add2_strided(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int32_t dtype,
+                         int64_t M, int32_t cols, void* stream);
+/* out = x where mask[row] else 0 (f32) */
+int32_t otr_row_mask(const float* x, const uint8_t* mask, float* out, int64_t M, int32_t C, void* stream);
+/* depthwise Conv1d over time (k odd <= 7, zero pad (k-1)/2), channel-last: y f32 [B,T,C]; stats f32 [2C] (may be
+ * NULL) receives per-channel sum / sum of squares of y over all B*T rows (BatchNorm batch statistics) */
+int32_t otr_dwconv_fwd(const void* g, int32_t dtype, const float* w, const float* bias, float* y, float* stats,
+                       int32_t B, int32_t T, int32_t C, int32_t k, void* stream);
+/* dg (dtype), dw f32 [C,k] +=, db f32 [C] += (may be NULL) */
+int32_t otr_dwconv_bwd(const float* dy, const void* g, int32_t dtype, const float* w, void* dg, float* dw, float* db,
+                       int32_t B, int32_t T, int32_t C, int32_t k, void* stream);
+/* BatchNorm1d (training: batch statistics from `stats`, running stats updated in place; eval: running stats) fused
+ * with swish; saved f32 [2C] = mean | rstd for backward */
+int32_t otr_bn_swish_fwd(const float* y, const float* stats, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float* saved, void* out, int32_t out_dtype, int64_t M, int32_t C, float eps,
+                         float momentum, int32_t training, void* stream);
+/* red f32 [2C]: on return d beta | d gamma; dy f32 [M,C] = gradient w.r.t. the BatchNorm input */
+int32_t otr_bn_swish_bwd(const float* y, const void* ds, int32_t ds_dtype, const float* saved, const float* gamma,
+                         const float* beta, float* red, float* dy, int64_t M, int32_t C, int32_t training, void* stream);
 
 /* ---- CTC loss with gradient w.r.t. the logits (nn.CTCLoss(blank, zero_infinity=True), reduction
  *      'mean', as built at model/ctc.py:30 and called at :50-53).  log_probs f32 [B,T,V] (already

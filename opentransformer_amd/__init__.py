@@ -8,6 +8,8 @@ from . import synthetic                                   # noqa: F401  (numpy/t
 from .ops import set_compute_dtype, get_compute_dtype     # noqa: F401
 from .model import (BuildFrontEnd, BuildEncoder, BuildDecoder, End2EndModel, SpeechToText,   # noqa: F401
                     CTCAssistor)
+from .nn import (ConvFrontEnd, ConformerEncoder, ConformerEncoderBlock, ConformerConvolutionModule,   # noqa: F401
+                 MultiHeadedSelfAttentionWithRelPos)
 from .nn import (ConvFrontEnd, TransformerEncoder, TransformerEncoderLayer, TransformerDecoder,   # noqa: F401
                  TransformerDecoderLayer, MultiHeadedSelfAttention, MultiHeadedCrossAttention,
                  PositionwiseFeedForward, PositionalEncoding, LabelSmoothingLoss)

@@ -54,10 +54,12 @@ SIGNATURES = {
     'otr_colsum': [_P, _I32, _I64, _I64, _I64, _P, _I32, _P],
     'otr_attention_fwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P],
     'otr_attention_bwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    'otr_attention_bias_fwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P],
+    'otr_attention_bias_bwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_add_layernorm_fwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_add_layernorm_bwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    'otr_glu_fwd': [_P, _P, _I32, _I64, _I64, _P],
-    'otr_glu_bwd': [_P, _P, _P, _P, _I32, _I64, _I64, _P],
+    'otr_glu_fwd': [_P, _P, _I32, _I64, _I64, _P, _P],
+    'otr_glu_bwd': [_P, _P, _P, _P, _I32, _I64, _I64, _P, _P],
     'otr_posenc_fwd': [_P, _P, _P, _I64, _I32, _I32, _F32, _P],
     'otr_embed_posenc_fwd': [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _F32, _P],
     'otr_embed_bwd': [_P, _P, _P, _I64, _I32, _I32, _F32, _P],
@@ -76,6 +78,15 @@ SIGNATURES = {
     'otr_optimizer_step': [_P, _P, _P, _P, _I64, _P, _P] + [_F32] * 11 + [_P],
     'otr_beam_topk': [_P, _I64, _P, _I64, _F32, _I64, _I32, _I32, _P, _P, _P],
     'otr_beam_prune': [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    'otr_residual_add_fwd': [_P, _P, _I32, _P, _I64, _F32, _F32, _P, C.c_uint64, _P],
+    'otr_residual_add_bwd': [_P, _P, _I32, _I64, _F32, _F32, _P, C.c_uint64, _P],
+    'otr_head_bias_add': [_P, _I64, _P, _P, _P, _I32, _I64, _I32, _P],
+    'otr_add2_strided': [_P, _I64, _P, _I64, _P, _I64, _I32, _I64, _I32, _P],
+    'otr_row_mask': [_P, _P, _P, _I64, _I32, _P],
+    'otr_dwconv_fwd': [_P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
+    'otr_dwconv_bwd': [_P, _P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
+    'otr_bn_swish_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _F32, _F32, _I32, _P],
+    'otr_bn_swish_bwd': [_P, _P, _I32, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
 }
 _RESTYPE = {'otr_last_error_string': C.c_char_p}
 

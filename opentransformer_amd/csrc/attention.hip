@@ -29,7 +29,18 @@ struct AttnArgs {
   int causal;
   float scale;
   int vec;  // all strides/base pointers allow 16-byte row chunks
+  // optional additive score bias (pre-scale): S = (q.k + bias[b,h,i,col]) * scale, col = j (+ Tq-1-i if rel_shift):
+  // rel_shift turns a [.., i, 2T-1] relative-position term into the Transformer-XL shifted matrix by index
+  // arithmetic (module/attention.py:209-215 materialises and gathers it).
+  const float* bias;
+  float* dbias;
+  int64_t bias_bs, bias_hs, bias_rs;
+  int rel_shift;
 };
+
+__device__ __forceinline__ int64_t bias_index(const AttnArgs& p, int b, int h, int i, int j) {
+  return (int64_t)b * p.bias_bs + (int64_t)h * p.bias_hs + (int64_t)i * p.bias_rs + j + (p.rel_shift ? (p.Tq - 1 - i) : 0);
+}
 
 template <class CT, int DK> struct ACfg {
   static constexpr int CE = MMA<CT>::CE;
@@ -214,7 +225,9 @@ template <class CT, int DK> __global__ __launch_bounds__(256) void attn_fwd_kern
       for (int r = 0; r < 4; ++r) {
         int key = kb * 64 + kt * 16 + lg * 4 + r;
         bool ok = key < p.Tk && (!km || km[key]) && (!p.causal || key <= qrow);
-        float s = ok ? st[kt][r] * p.scale : NEG_INF;
+        float raw = st[kt][r];
+        if (p.bias && ok && qrow < p.Tq) raw += p.bias[bias_index(p, b, h, qrow, key)];
+        float s = ok ? raw * p.scale : NEG_INF;
         st[kt][r] = s;
         bm = fmaxf(bm, s);
       }
@@ -337,9 +350,13 @@ template <class CT, int DK> __global__ __launch_bounds__(256) void attn_bwd_dkdv
         int ql = qt * 16 + lg * 4 + r, qg = qb * 64 + ql;
         float ls = sLse[ql];
         bool ok = key_ok && qg < p.Tq && (!p.causal || key <= qg) && ls != NEG_INF;
-        float pe = ok ? attn_exp<CT>(s[r] * p.scale - ls) : 0.f;
+        float raw = s[r];
+        if (p.bias && ok) raw += p.bias[bias_index(p, b, h, qg, key)];
+        float pe = ok ? attn_exp<CT>(raw * p.scale - ls) : 0.f;
         pt[qt][r] = pe;
-        ds[qt][r] = pe * (dp[r] - sDel[ql]) * p.scale;
+        float dsv = pe * (dp[r] - sDel[ql]) * p.scale;
+        ds[qt][r] = dsv;
+        if (p.dbias && ok) p.dbias[bias_index(p, b, h, qg, key)] = dsv;   // unique (i, col): plain store
       }
     }
 #pragma unroll
@@ -416,7 +433,9 @@ template <class CT, int DK> __global__ __launch_bounds__(256) void attn_bwd_dq_k
       for (int r = 0; r < 4; ++r) {
         int key = kb * 64 + kt * 16 + lg * 4 + r;
         bool ok = q_ok && ls != NEG_INF && key < p.Tk && (!km || km[key]) && (!p.causal || key <= qrow);
-        float pe = ok ? attn_exp<CT>(s[r] * p.scale - ls) : 0.f;
+        float raw = s[r];
+        if (p.bias && ok) raw += p.bias[bias_index(p, b, h, qrow, key)];
+        float pe = ok ? attn_exp<CT>(raw * p.scale - ls) : 0.f;
         ds[kt][r] = pe * (dp[r] - dl) * p.scale;
       }
     }
@@ -482,6 +501,43 @@ extern "C" int32_t otr_attention_fwd(const otr_attn_desc_t* d, const void* q, co
   return otr_check_launch("attention_fwd");
 }
 
+static void set_bias(AttnArgs& a, const float* bias, float* dbias, int64_t bs, int64_t hs, int64_t rs, int rel_shift) {
+  a.bias = bias; a.dbias = dbias; a.bias_bs = bs; a.bias_hs = hs; a.bias_rs = rs; a.rel_shift = rel_shift;
+}
+
+extern "C" int32_t otr_attention_bias_fwd(const otr_attn_desc_t* d, const void* q, const void* k, const void* v,
+                                          const uint8_t* key_mask, const float* bias, int64_t bias_bs, int64_t bias_hs,
+                                          int64_t bias_rs, int32_t rel_shift, void* o, float* lse, void* stream) {
+  AttnArgs a{};
+  if (int32_t e = fill_args(d, a)) return e;
+  OTR_REQUIRE(q && k && v && o && lse && bias, "attention_bias_fwd: null pointer");
+  OTR_REQUIRE(!rel_shift || d->Tq == d->Tk, "attention_bias_fwd: rel_shift needs Tq == Tk");
+  a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse; a.key_mask = key_mask;
+  a.vec = vec_ok(d, {q, k, v, o});
+  set_bias(a, bias, nullptr, bias_bs, bias_hs, bias_rs, rel_shift);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((d->Tq + 63) / 64, d->H, d->B);
+  if (d->dtype == OTR_BF16) { DK_SWITCH(bf16_t, attn_fwd_kernel, grid) } else { DK_SWITCH(float, attn_fwd_kernel, grid) }
+  return otr_check_launch("attention_bias_fwd");
+}
+
+static int32_t attention_bwd_impl(const otr_attn_desc_t* d, AttnArgs& a, void* stream);
+
+extern "C" int32_t otr_attention_bias_bwd(const otr_attn_desc_t* d, const void* q, const void* k, const void* v,
+                                          const uint8_t* key_mask, const float* bias, float* dbias, int64_t bias_bs,
+                                          int64_t bias_hs, int64_t bias_rs, int32_t rel_shift, const void* o,
+                                          const void* do_, const float* lse, float* delta, void* dq, void* dk, void* dv,
+                                          void* stream) {
+  AttnArgs a{};
+  if (int32_t e = fill_args(d, a)) return e;
+  OTR_REQUIRE(q && k && v && o && do_ && lse && delta && dq && dk && dv && bias, "attention_bias_bwd: null pointer");
+  a.q = q; a.k = k; a.v = v; a.o = o; a.do_ = do_; a.lse = const_cast<float*>(lse); a.delta = delta;
+  a.dq = dq; a.dk = dk; a.dv = dv; a.key_mask = key_mask;
+  a.vec = vec_ok(d, {q, k, v, o, do_, dq, dk, dv});
+  set_bias(a, bias, dbias, bias_bs, bias_hs, bias_rs, rel_shift);
+  return attention_bwd_impl(d, a, stream);
+}
+
 extern "C" int32_t otr_attention_bwd(const otr_attn_desc_t* d, const void* q, const void* k, const void* v,
                                      const uint8_t* key_mask, const void* o, const void* do_, const float* lse,
                                      float* delta, void* dq, void* dk, void* dv, void* stream) {
@@ -491,6 +547,10 @@ extern "C" int32_t otr_attention_bwd(const otr_attn_desc_t* d, const void* q, co
   a.q = q; a.k = k; a.v = v; a.o = o; a.do_ = do_; a.lse = const_cast<float*>(lse); a.delta = delta;
   a.dq = dq; a.dk = dk; a.dv = dv; a.key_mask = key_mask;
   a.vec = vec_ok(d, {q, k, v, o, do_, dq, dk, dv});
+  return attention_bwd_impl(d, a, stream);
+}
+
+static int32_t attention_bwd_impl(const otr_attn_desc_t* d, AttnArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   int64_t rows = (int64_t)d->B * d->H * d->Tq;
   dim3 gd((unsigned)((rows + 15) / 16));

@@ -1,0 +1,390 @@
+// Conformer-only kernels (BASELINE.json configs[3]):
+//  * residual_add        x + scale * dropout(branch)                    encoder/conformer.py:50-73
+//  * head_bias_add       q + pos_bias_u | q + pos_bias_v                module/attention.py:241-245
+//  * add2_strided        dq = d(q+u) + d(q+v) into the packed qkv gradient
+//  * dwconv / BatchNorm(batch statistics) / swish of ConformerConvolutionModule, fwd + bwd
+//                                                                        module/conformer.py:36-57
+//  * row_mask            masked_fill_(~mask, 0)                          module/conformer.py:46,55
+// All are bandwidth-bound [B*T, C] passes: a thread owns 4 consecutive channels of one frame, and the
+// per-channel reductions (BatchNorm statistics, depthwise-conv weight gradients) are accumulated per
+// thread over a strip of rows and merged with one fp32 atomic per (workgroup, channel).
+#include "common.h"
+
+constexpr int CF_BLOCK = 128;  // threads: channel groups of 4
+constexpr int CF_RPB = 16;     // rows per workgroup strip
+
+template <class T> __device__ __forceinline__ void ldc4(const T* p, float* o) { load_row<T, 4>(p, 4, true, o); }
+template <class T> __device__ __forceinline__ void stc4(T* p, const float* o) {
+  if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  else *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+}
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+static inline dim3 strip_grid(int64_t M) { return dim3((unsigned)((M + CF_RPB - 1) / CF_RPB)); }
+
+// ------------------------------------------------------------------------------------------------ residual add
+template <class AT> __global__ void residual_add_fwd_kernel(const float* x, const AT* a, float* y, int64_t n4, float scale,
+                                                            float p_drop, const uint64_t* seed, uint64_t off) {
+  const bool drop = p_drop > 0.f;
+  const uint64_t sd = drop ? *seed : 0;
+  const uint32_t thr = drop ? (uint32_t)fminf(p_drop * 4294967296.f, 4294967295.f) : 0;
+  const float keep = drop ? 1.f / (1.f - p_drop) : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float xv[4], av[4];
+    ldc4<float>(x + i * 4, xv);
+    ldc4<AT>(a + i * 4, av);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float m = drop ? (otr_rand32(sd, off + (uint64_t)(i * 4 + e)) >= thr ? keep : 0.f) : 1.f;
+      xv[e] += scale * m * av[e];
+    }
+    stc4<float>(y + i * 4, xv);
+  }
+}
+template <class AT> __global__ void residual_add_bwd_kernel(const float* dy, AT* da, int64_t n4, float scale, float p_drop,
+                                                            const uint64_t* seed, uint64_t off) {
+  const bool drop = p_drop > 0.f;
+  const uint64_t sd = drop ? *seed : 0;
+  const uint32_t thr = drop ? (uint32_t)fminf(p_drop * 4294967296.f, 4294967295.f) : 0;
+  const float keep = drop ? 1.f / (1.f - p_drop) : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float g[4];
+    ldc4<float>(dy + i * 4, g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float m = drop ? (otr_rand32(sd, off + (uint64_t)(i * 4 + e)) >= thr ? keep : 0.f) : 1.f;
+      g[e] *= scale * m;
+    }
+    stc4<AT>(da + i * 4, g);
+  }
+}
+static unsigned ew_grid(int64_t n) { int64_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+extern "C" int32_t otr_residual_add_fwd(const float* x, const void* a, int32_t a_dtype, float* y, int64_t n, float scale,
+                                        float p_drop, const uint64_t* seed, uint64_t rng_offset, void* stream) {
+  OTR_REQUIRE(x && a && y, "residual_add_fwd: null pointer");
+  OTR_REQUIRE(n % 4 == 0 && n >= 0, "residual_add_fwd: n must be a multiple of 4");
+  OTR_REQUIRE(p_drop == 0.f || seed, "residual_add_fwd: dropout needs a seed");
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (a_dtype == OTR_F32) hipLaunchKernelGGL(residual_add_fwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, s, x, (const float*)a, y, n / 4, scale, p_drop, seed, rng_offset);
+  else hipLaunchKernelGGL(residual_add_fwd_kernel<bf16_t>, dim3(ew_grid(n / 4)), dim3(256), 0, s, x, (const bf16_t*)a, y, n / 4, scale, p_drop, seed, rng_offset);
+  return otr_check_launch("residual_add_fwd");
+}
+extern "C" int32_t otr_residual_add_bwd(const float* dy, void* da, int32_t a_dtype, int64_t n, float scale, float p_drop,
+                                        const uint64_t* seed, uint64_t rng_offset, void* stream) {
+  OTR_REQUIRE(dy && da, "residual_add_bwd: null pointer");
+  OTR_REQUIRE(n % 4 == 0 && n >= 0, "residual_add_bwd: n must be a multiple of 4");
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (a_dtype == OTR_F32) hipLaunchKernelGGL(residual_add_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, s, dy, (float*)da, n / 4, scale, p_drop, seed, rng_offset);
+  else hipLaunchKernelGGL(residual_add_bwd_kernel<bf16_t>, dim3(ew_grid(n / 4)), dim3(256), 0, s, dy, (bf16_t*)da, n / 4, scale, p_drop, seed, rng_offset);
+  return otr_check_launch("residual_add_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------ q + u | q + v
+template <class T> __global__ void head_bias_add_kernel(const T* q, int64_t ldq, const float* u, const float* v, T* out, int64_t M,
+                                                        int d) {
+  const int d4 = d / 4;
+  const int64_t total = M * d4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = i / d4;
+    int c = (int)(i - row * d4) * 4;
+    float qv[4], uv[4], vv[4], o1[4], o2[4];
+    ldc4<T>(q + row * ldq + c, qv);
+    ldc4<float>(u + c, uv);
+    ldc4<float>(v + c, vv);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o1[e] = qv[e] + uv[e]; o2[e] = qv[e] + vv[e]; }
+    stc4<T>(out + row * 2 * d + c, o1);
+    stc4<T>(out + row * 2 * d + d + c, o2);
+  }
+}
+extern "C" int32_t otr_head_bias_add(const void* q, int64_t ldq, const float* u, const float* v, void* out, int32_t dtype,
+                                     int64_t M, int32_t d, void* stream) {
+  OTR_REQUIRE(q && u && v && out, "head_bias_add: null pointer");
+  OTR_REQUIRE(d % 4 == 0 && ldq % 4 == 0, "head_bias_add: d and ldq must be multiples of 4");
+  if (M <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OTR_F32) hipLaunchKernelGGL(head_bias_add_kernel<float>, dim3(ew_grid(M * d / 4)), dim3(256), 0, s, (const float*)q, ldq, u, v, (float*)out, M, d);
+  else hipLaunchKernelGGL(head_bias_add_kernel<bf16_t>, dim3(ew_grid(M * d / 4)), dim3(256), 0, s, (const bf16_t*)q, ldq, u, v, (bf16_t*)out, M, d);
+  return otr_check_launch("head_bias_add");
+}
+
+// out[r, :cols] = a[r, :cols] + b[r, :cols] with independent leading dimensions
+template <class T> __global__ void add2_kernel(const T* a, int64_t lda, const T* b, int64_t ldb, T* out, int64_t ldo, int64_t M, int cols) {
+  const int c4 = cols / 4;
+  const int64_t total = M * c4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = i / c4;
+    int c = (int)(i - row * c4) * 4;
+    float x[4], y[4];
+    ldc4<T>(a + row * lda + c, x);
+    ldc4<T>(b + row * ldb + c, y);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] += y[e];
+    stc4<T>(out + row * ldo + c, x);
+  }
+}
+extern "C" int32_t otr_add2_strided(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo,
+                                    int32_t dtype, int64_t M, int32_t cols, void* stream) {
+  OTR_REQUIRE(a && b && out, "add2_strided: null pointer");
+  OTR_REQUIRE(cols % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldo % 4 == 0, "add2_strided: sizes must be multiples of 4");
+  if (M <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OTR_F32) hipLaunchKernelGGL(add2_kernel<float>, dim3(ew_grid(M * cols / 4)), dim3(256), 0, s, (const float*)a, lda, (const float*)b, ldb, (float*)out, ldo, M, cols);
+  else hipLaunchKernelGGL(add2_kernel<bf16_t>, dim3(ew_grid(M * cols / 4)), dim3(256), 0, s, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)out, ldo, M, cols);
+  return otr_check_launch("add2_strided");
+}
+
+// ------------------------------------------------------------------------------------------------ row mask
+__global__ void row_mask_kernel(const float* x, const uint8_t* mask, float* out, int64_t M, int C) {
+  const int c4 = C / 4;
+  const int64_t total = M * c4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = i / c4;
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    if (!mask[row]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+extern "C" int32_t otr_row_mask(const float* x, const uint8_t* mask, float* out, int64_t M, int32_t C, void* stream) {
+  OTR_REQUIRE(x && mask && out, "row_mask: null pointer");
+  OTR_REQUIRE(C % 4 == 0, "row_mask: C must be a multiple of 4");
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(row_mask_kernel, dim3(ew_grid(M * C / 4)), dim3(256), 0, (hipStream_t)stream, x, mask, out, M, C);
+  return otr_check_launch("row_mask");
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise conv + BN stats
+struct DwArgs {
+  const void* g; const float* w; const float* b; float* y; float* stats;
+  const float* dy; void* dg; float* dw; float* db;
+  int B, T, C, k;
+};
+
+// y[b,t,c] = bias[c] + sum_j w[c,j] * g[b, t + j - pad, c]   (zero padded in time, per utterance)
+// stats[c] += sum y, stats[C + c] += sum y^2   over ALL B*T positions (the reference's BatchNorm1d sees padded frames)
+template <class T> __global__ __launch_bounds__(CF_BLOCK) void dwconv_fwd_kernel(DwArgs p) {
+  const int C4 = p.C / 4, pad = (p.k - 1) / 2;
+  const int64_t M = (int64_t)p.B * p.T;
+  const int64_t r0 = (int64_t)blockIdx.x * CF_RPB, r1 = min(M, r0 + CF_RPB);
+  const T* g = reinterpret_cast<const T*>(p.g);
+  for (int cg = threadIdx.x; cg < C4; cg += CF_BLOCK) {
+    const int c = cg * 4;
+    float w[4][8], bias[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (p.b) bias[e] = p.b[c + e];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[e][j] = (j < p.k) ? p.w[(c + e) * p.k + j] : 0.f;
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t row = r0; row < r1; ++row) {
+      int t = (int)(row % p.T);
+      float acc[4] = {bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j >= p.k) break;
+        int tt = t + j - pad;
+        if (tt < 0 || tt >= p.T) continue;
+        float gv[4];
+        ldc4<T>(g + (row + (j - pad)) * p.C + c, gv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(w[e][j], gv[e], acc[e]);
+      }
+      stc4<float>(p.y + row * p.C + c, acc);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[e] += acc[e]; s2[e] += acc[e] * acc[e]; }
+    }
+    if (p.stats) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { atomicAdd(p.stats + c + e, s1[e]); atomicAdd(p.stats + p.C + c + e, s2[e]); }
+    }
+  }
+}
+
+// dg[b,t,c] = sum_j w[c,j] * dy[b, t - j + pad, c];  dw[c,j] += sum dy[b,t,c] g[b,t+j-pad,c];  db[c] += sum dy
+template <class T> __global__ __launch_bounds__(CF_BLOCK) void dwconv_bwd_kernel(DwArgs p) {
+  const int C4 = p.C / 4, pad = (p.k - 1) / 2;
+  const int64_t M = (int64_t)p.B * p.T;
+  const int64_t r0 = (int64_t)blockIdx.x * CF_RPB, r1 = min(M, r0 + CF_RPB);
+  const T* g = reinterpret_cast<const T*>(p.g);
+  T* dg = reinterpret_cast<T*>(p.dg);
+  for (int cg = threadIdx.x; cg < C4; cg += CF_BLOCK) {
+    const int c = cg * 4;
+    float w[4][8], dw[4][8], db[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { w[e][j] = (j < p.k) ? p.w[(c + e) * p.k + j] : 0.f; dw[e][j] = 0.f; }
+    for (int64_t row = r0; row < r1; ++row) {
+      int t = (int)(row % p.T);
+      float dyv[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+      ldc4<float>(p.dy + row * p.C + c, dyv);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) db[e] += dyv[e];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j >= p.k) break;
+        int tg = t + j - pad;                       // forward tap: y[t] used g[t + j - pad]
+        if (tg >= 0 && tg < p.T) {
+          float gv[4];
+          ldc4<T>(g + (row + (j - pad)) * p.C + c, gv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dw[e][j] = fmaf(dyv[e], gv[e], dw[e][j]);
+        }
+        int ty = t - j + pad;                       // dg[t] collects dy[t - j + pad] * w[j]
+        if (ty >= 0 && ty < p.T) {
+          float yv[4];
+          ldc4<float>(p.dy + (row - (j - pad)) * p.C + c, yv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = fmaf(w[e][j], yv[e], acc[e]);
+        }
+      }
+      stc4<T>(dg + row * p.C + c, acc);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (p.db) atomicAdd(p.db + c + e, db[e]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < p.k) atomicAdd(p.dw + (c + e) * p.k + j, dw[e][j]);
+    }
+  }
+}
+
+static int32_t dw_check(int B, int T, int C, int k) {
+  OTR_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0, "dwconv: bad shape B=%d T=%d C=%d", B, T, C);
+  OTR_REQUIRE(k >= 1 && k <= 8 && (k & 1), "dwconv: kernel size %d must be odd and <= 7", k);
+  return 0;
+}
+extern "C" int32_t otr_dwconv_fwd(const void* g, int32_t dtype, const float* w, const float* bias, float* y, float* stats,
+                                  int32_t B, int32_t T, int32_t C, int32_t k, void* stream) {
+  if (int32_t e = dw_check(B, T, C, k)) return e;
+  OTR_REQUIRE(g && w && y, "dwconv_fwd: null pointer");
+  DwArgs p{}; p.g = g; p.w = w; p.b = bias; p.y = y; p.stats = stats; p.B = B; p.T = T; p.C = C; p.k = k;
+  hipStream_t s = (hipStream_t)stream;
+  if (stats) otr_zero_f32(stats, 2 * C, s);
+  if (dtype == OTR_F32) hipLaunchKernelGGL(dwconv_fwd_kernel<float>, strip_grid((int64_t)B * T), dim3(CF_BLOCK), 0, s, p);
+  else hipLaunchKernelGGL(dwconv_fwd_kernel<bf16_t>, strip_grid((int64_t)B * T), dim3(CF_BLOCK), 0, s, p);
+  return otr_check_launch("dwconv_fwd");
+}
+extern "C" int32_t otr_dwconv_bwd(const float* dy, const void* g, int32_t dtype, const float* w, void* dg, float* dw, float* db,
+                                  int32_t B, int32_t T, int32_t C, int32_t k, void* stream) {
+  if (int32_t e = dw_check(B, T, C, k)) return e;
+  OTR_REQUIRE(dy && g && w && dg && dw, "dwconv_bwd: null pointer");
+  DwArgs p{}; p.dy = dy; p.g = g; p.w = w; p.dg = dg; p.dw = dw; p.db = db; p.B = B; p.T = T; p.C = C; p.k = k;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OTR_F32) hipLaunchKernelGGL(dwconv_bwd_kernel<float>, strip_grid((int64_t)B * T), dim3(CF_BLOCK), 0, s, p);
+  else hipLaunchKernelGGL(dwconv_bwd_kernel<bf16_t>, strip_grid((int64_t)B * T), dim3(CF_BLOCK), 0, s, p);
+  return otr_check_launch("dwconv_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm1d + swish
+// stats (training): [sum | sumsq] over N rows -> mean / biased var; running stats updated with momentum
+// (unbiased var).  eval: running stats.  saved[c] = mean, saved[C + c] = rstd.
+__global__ void bn_prepare_kernel(const float* stats, float* run_mean, float* run_var, float* saved, int C, float n, float eps,
+                                  float momentum, int training) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    mean = stats[c] / n;
+    var = fmaxf(stats[C + c] / n - mean * mean, 0.f);
+    if (run_mean) {
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (n > 1.f ? n / (n - 1.f) : 1.f);
+    }
+  } else {
+    mean = run_mean[c];
+    var = run_var[c];
+  }
+  saved[c] = mean;
+  saved[C + c] = rsqrtf(var + eps);
+}
+
+template <class T> __global__ void bn_swish_fwd_kernel(const float* y, const float* saved, const float* gamma, const float* beta, T* out,
+                                                       int64_t M, int C) {
+  const int c4 = C / 4;
+  const int64_t total = M * c4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % c4) * 4;
+    float v[4], o[4];
+    ldc4<float>(y + i * 4, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float z = (v[e] - saved[c + e]) * saved[C + c + e] * gamma[c + e] + beta[c + e];
+      o[e] = z * sigm(z);
+    }
+    stc4<T>(out + i * 4, o);
+  }
+}
+
+// MODE 0: red[c] += sum dz, red[C+c] += sum dz*xhat      MODE 1: dy = gamma*rstd*(dz - red0/N - xhat*red1/N)
+template <class T, int MODE> __global__ __launch_bounds__(CF_BLOCK) void bn_swish_bwd_kernel(const float* y, const T* ds, const float* saved,
+                                                                                          const float* gamma, const float* beta, float* red,
+                                                                                          float* dy, int64_t M, int C, float n, int training) {
+  const int C4 = C / 4;
+  const int64_t r0 = (int64_t)blockIdx.x * CF_RPB, r1 = min(M, r0 + CF_RPB);
+  for (int cg = threadIdx.x; cg < C4; cg += CF_BLOCK) {
+    const int c = cg * 4;
+    float mean[4], rstd[4], gam[4], bet[4], a0[4], a1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mean[e] = saved[c + e]; rstd[e] = saved[C + c + e]; gam[e] = gamma[c + e]; bet[e] = beta[c + e];
+      a0[e] = 0.f; a1[e] = 0.f;
+      if (MODE == 1) { a0[e] = red[c + e] / n; a1[e] = red[C + c + e] / n; }
+    }
+    for (int64_t row = r0; row < r1; ++row) {
+      float yv[4], dsv[4], o[4];
+      ldc4<float>(y + row * C + c, yv);
+      ldc4<T>(ds + row * C + c, dsv);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float xh = (yv[e] - mean[e]) * rstd[e];
+        float z = xh * gam[e] + bet[e];
+        float sg = sigm(z);
+        float dz = dsv[e] * (sg + z * sg * (1.f - sg));
+        if (MODE == 0) { a0[e] += dz; a1[e] += dz * xh; }
+        else o[e] = training ? gam[e] * rstd[e] * (dz - a0[e] - xh * a1[e]) : gam[e] * rstd[e] * dz;
+      }
+      if (MODE == 1) stc4<float>(dy + row * C + c, o);
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { atomicAdd(red + c + e, a0[e]); atomicAdd(red + C + c + e, a1[e]); }
+    }
+  }
+}
+
+extern "C" int32_t otr_bn_swish_fwd(const float* y, const float* stats, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float* saved, void* out, int32_t out_dtype,
+                                    int64_t M, int32_t C, float eps, float momentum, int32_t training, void* stream) {
+  OTR_REQUIRE(y && gamma && beta && saved && out, "bn_swish_fwd: null pointer");
+  OTR_REQUIRE(C % 4 == 0 && M > 0, "bn_swish_fwd: bad shape");
+  OTR_REQUIRE(training ? stats != nullptr : (running_mean && running_var), "bn_swish_fwd: missing statistics");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_prepare_kernel, dim3((C + 127) / 128), dim3(128), 0, s, stats, running_mean, running_var, saved, C, (float)M,
+                     eps, momentum, training);
+  if (out_dtype == OTR_F32) hipLaunchKernelGGL(bn_swish_fwd_kernel<float>, dim3(ew_grid(M * C / 4)), dim3(256), 0, s, y, saved, gamma, beta, (float*)out, M, C);
+  else hipLaunchKernelGGL(bn_swish_fwd_kernel<bf16_t>, dim3(ew_grid(M * C / 4)), dim3(256), 0, s, y, saved, gamma, beta, (bf16_t*)out, M, C);
+  return otr_check_launch("bn_swish_fwd");
+}
+
+// red: f32 [2C] zeroed here; on return red[c] = d beta, red[C + c] = d gamma.  dy: f32 [M, C].
+extern "C" int32_t otr_bn_swish_bwd(const float* y, const void* ds, int32_t ds_dtype, const float* saved, const float* gamma,
+                                    const float* beta, float* red, float* dy, int64_t M, int32_t C, int32_t training,
+                                    void* stream) {
+  OTR_REQUIRE(y && ds && saved && gamma && beta && red && dy, "bn_swish_bwd: null pointer");
+  OTR_REQUIRE(C % 4 == 0 && M > 0, "bn_swish_bwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  otr_zero_f32(red, 2 * C, s);
+  if (ds_dtype == OTR_F32) {
+    hipLaunchKernelGGL((bn_swish_bwd_kernel<float, 0>), strip_grid(M), dim3(CF_BLOCK), 0, s, y, (const float*)ds, saved, gamma, beta, red, dy, M, C, (float)M, training);
+    hipLaunchKernelGGL((bn_swish_bwd_kernel<float, 1>), strip_grid(M), dim3(CF_BLOCK), 0, s, y, (const float*)ds, saved, gamma, beta, red, dy, M, C, (float)M, training);
+  } else {
+    hipLaunchKernelGGL((bn_swish_bwd_kernel<bf16_t, 0>), strip_grid(M), dim3(CF_BLOCK), 0, s, y, (const bf16_t*)ds, saved, gamma, beta, red, dy, M, C, (float)M, training);
+    hipLaunchKernelGGL((bn_swish_bwd_kernel<bf16_t, 1>), strip_grid(M), dim3(CF_BLOCK), 0, s, y, (const bf16_t*)ds, saved, gamma, beta, red, dy, M, C, (float)M, training);
+  }
+  return otr_check_launch("bn_swish_bwd");
+}

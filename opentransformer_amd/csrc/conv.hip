@@ -109,8 +109,8 @@ template <class T> __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Con
     red[threadIdx.x][9] = db[c];
     __syncthreads();
     // thread (g2, v) for g2 < CG, v < 10 sums column v over threads with tid % CG == g2
-    int g2 = threadIdx.x / 10, v = threadIdx.x % 10;
-    if (g2 < CG) {
+    const int v = threadIdx.x % 10;
+    for (int g2 = threadIdx.x / 10; g2 < CG && threadIdx.x < 250; g2 += 25) {
       float s = 0.f;
       for (int t = g2; t < 256; t += CG) s += red[t][v];
       int ch = g2 * 8 + c;
@@ -202,7 +202,6 @@ extern "C" int32_t otr_conv1_wgrad(const otr_conv_desc_t* d, const float* x, con
   ConvArgs a{};
   if (int32_t e = conv_check(d, a)) return e;
   OTR_REQUIRE(x && dact1 && dw1 && db1, "conv1_wgrad: null pointer");
-  OTR_REQUIRE(d->C1 / 8 * 10 <= 256, "conv1_wgrad: C1 too large for the block reduction");
   a.x = x; a.dact1_in = dact1; a.dw1 = dw1; a.db1 = db1;
   hipStream_t s = (hipStream_t)stream;
   unsigned g = conv_grid(a);

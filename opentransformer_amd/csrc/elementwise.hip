@@ -13,7 +13,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 
 // ------------------------------------------------------------------------------------------------ GLU
 // F.glu(h, -1): u = h[:, :F] * sigmoid(h[:, F:])     (module/ffn.py:18,40)
-template <class T> __global__ void glu_fwd_kernel(const T* h, T* u, int64_t M, int64_t F) {
+template <class T> __global__ void glu_fwd_kernel(const T* h, T* u, int64_t M, int64_t F, const uint8_t* row_mask) {
   constexpr int V = 16 / sizeof(T);
   const int64_t per_row = F / V, total = M * per_row;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -21,8 +21,9 @@ template <class T> __global__ void glu_fwd_kernel(const T* h, T* u, int64_t M, i
     float a[V], g[V], o[V];
     load_row<T, V>(h + row * 2 * F + c, V, true, a);
     load_row<T, V>(h + row * 2 * F + F + c, V, true, g);
+    const bool live = !row_mask || row_mask[row];
 #pragma unroll
-    for (int e = 0; e < V; ++e) o[e] = a[e] * sigmoidf_(g[e]);
+    for (int e = 0; e < V; ++e) o[e] = live ? a[e] * sigmoidf_(g[e]) : 0.f;
     if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(u + row * F + c) = make_float4(o[0], o[1], o[2], o[3]);
     else *reinterpret_cast<uint4*>(u + row * F + c) = MMA<bf16_t>::pack(o);
   }
@@ -30,7 +31,8 @@ template <class T> __global__ void glu_fwd_kernel(const T* h, T* u, int64_t M, i
 
 // dh[:, :F] = du * sig(g);  dh[:, F:] = du * a * sig(g) * (1 - sig(g));  optional bias-gradient partials
 constexpr int GLU_RPB = 32;  // rows per block in the backward (each thread owns V columns)
-template <class T> __global__ void glu_bwd_kernel(const T* h, const T* du, T* dh, float* dbias, int64_t M, int64_t F) {
+template <class T> __global__ void glu_bwd_kernel(const T* h, const T* du, T* dh, float* dbias, int64_t M, int64_t F,
+                                                  const uint8_t* row_mask) {
   constexpr int V = 16 / sizeof(T);
   const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
   if (c >= F) return;
@@ -46,8 +48,9 @@ template <class T> __global__ void glu_bwd_kernel(const T* h, const T* du, T* dh
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       float s = sigmoidf_(g[e]);
-      oa[e] = d[e] * s;
-      og[e] = d[e] * a[e] * s * (1.f - s);
+      float dd = (!row_mask || row_mask[row]) ? d[e] : 0.f;     // masked_fill_(~mask, 0) after the GLU
+      oa[e] = dd * s;
+      og[e] = dd * a[e] * s * (1.f - s);
       sa[e] += oa[e]; sg[e] += og[e];
     }
     if constexpr (sizeof(T) == 4) {
@@ -65,19 +68,20 @@ template <class T> __global__ void glu_bwd_kernel(const T* h, const T* du, T* dh
   }
 }
 
-extern "C" int32_t otr_glu_fwd(const void* h, void* u, int32_t dtype, int64_t M, int64_t F, void* stream) {
+extern "C" int32_t otr_glu_fwd(const void* h, void* u, int32_t dtype, int64_t M, int64_t F, const uint8_t* row_mask,
+                               void* stream) {
   OTR_REQUIRE(h && u, "glu_fwd: null pointer");
   OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_BF16, "glu_fwd: bad dtype");
   OTR_REQUIRE(F > 0 && F % 8 == 0 && M >= 0, "glu_fwd: F=%lld must be a positive multiple of 8", (long long)F);
   if (M == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == OTR_F32) hipLaunchKernelGGL(glu_fwd_kernel<float>, dim3(grid_for(M * F / 4)), dim3(256), 0, s, (const float*)h, (float*)u, M, F);
-  else hipLaunchKernelGGL(glu_fwd_kernel<bf16_t>, dim3(grid_for(M * F / 8)), dim3(256), 0, s, (const bf16_t*)h, (bf16_t*)u, M, F);
+  if (dtype == OTR_F32) hipLaunchKernelGGL(glu_fwd_kernel<float>, dim3(grid_for(M * F / 4)), dim3(256), 0, s, (const float*)h, (float*)u, M, F, row_mask);
+  else hipLaunchKernelGGL(glu_fwd_kernel<bf16_t>, dim3(grid_for(M * F / 8)), dim3(256), 0, s, (const bf16_t*)h, (bf16_t*)u, M, F, row_mask);
   return otr_check_launch("glu_fwd");
 }
 
 extern "C" int32_t otr_glu_bwd(const void* h, const void* du, void* dh, float* dbias, int32_t dtype, int64_t M,
-                               int64_t F, void* stream) {
+                               int64_t F, const uint8_t* row_mask, void* stream) {
   OTR_REQUIRE(h && du && dh, "glu_bwd: null pointer");
   OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_BF16, "glu_bwd: bad dtype");
   OTR_REQUIRE(F > 0 && F % 8 == 0 && M >= 0, "glu_bwd: F=%lld must be a positive multiple of 8", (long long)F);
@@ -85,8 +89,8 @@ extern "C" int32_t otr_glu_bwd(const void* h, const void* du, void* dh, float* d
   hipStream_t s = (hipStream_t)stream;
   int V = dtype == OTR_F32 ? 4 : 8;
   dim3 grid((unsigned)((F / V + 255) / 256), (unsigned)((M + GLU_RPB - 1) / GLU_RPB));
-  if (dtype == OTR_F32) hipLaunchKernelGGL(glu_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)h, (const float*)du, (float*)dh, dbias, M, F);
-  else hipLaunchKernelGGL(glu_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)h, (const bf16_t*)du, (bf16_t*)dh, dbias, M, F);
+  if (dtype == OTR_F32) hipLaunchKernelGGL(glu_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)h, (const float*)du, (float*)dh, dbias, M, F, row_mask);
+  else hipLaunchKernelGGL(glu_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)h, (const bf16_t*)du, (bf16_t*)dh, dbias, M, F, row_mask);
   return otr_check_launch("glu_bwd");
 }
 

@@ -4,10 +4,11 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .nn import (BLK, ConvFrontEnd, LabelSmoothingLoss, TransformerDecoder, TransformerEncoder, _unsupported)
+from .nn import (BLK, ConformerEncoder, ConvFrontEnd, LabelSmoothingLoss, TransformerDecoder, TransformerEncoder,
+                 _unsupported)
 
 BuildFrontEnd = {'conv': ConvFrontEnd}                 # otrans/frontend/__init__.py:8-12
-BuildEncoder = {'transformer': TransformerEncoder}     # otrans/encoder/__init__.py:10-13
+BuildEncoder = {'transformer': TransformerEncoder, 'conformer': ConformerEncoder}     # otrans/encoder/__init__.py:10-13
 BuildDecoder = {'transformer': TransformerDecoder}     # otrans/decoder/__init__.py:8-10
 
 

@@ -257,6 +257,156 @@ class TransformerEncoder(nn.Module):
         return x, mask, {}
 
 
+# ------------------------------------------------------------------------------------- conformer
+class MultiHeadedSelfAttentionWithRelPos(nn.Module):
+    """module/attention.py:176-253.  As shipped (constructor bug at :178) the module has no
+    output projection and no dropout when slf_attn_dropout == 0 -- and crashes otherwise; we mirror that."""
+
+    def __init__(self, n_heads, d_model, dropout_rate=0.0, skip_term_b=False, share_qvk_proj=False):
+        super().__init__()
+        if dropout_rate:
+            _unsupported('MultiHeadedSelfAttentionWithRelPos dropout_rate > 0 (the reference crashes there)')
+        if skip_term_b or share_qvk_proj:
+            _unsupported('skip_term_b / share_qvk_proj')
+        self.d_model, self.nheads, self.d_k = d_model, n_heads, d_model // n_heads
+        self.qvk_proj = nn.Linear(d_model, d_model * 3)
+        self.pos_proj = nn.Linear(d_model, d_model, bias=False)
+        self.posu = nn.Parameter(torch.Tensor(1, 1, n_heads, self.d_k))
+        self.posv = nn.Parameter(torch.Tensor(1, 1, n_heads, self.d_k))
+        torch.nn.init.xavier_normal_(self.posu)
+        torch.nn.init.xavier_normal_(self.posv)
+
+    def forward(self, x, mask, pos):
+        B, T, _ = x.shape
+        qkv = ops.linear(x, self.qvk_proj.weight, self.qvk_proj.bias, out_dtype=ops.act_dtype())
+        ctx = ops.RelPosAttentionFn.apply(qkv, pos, self.pos_proj.weight, self.posu, self.posv, _key_mask(mask, B, T),
+                                          self.nheads)
+        return ctx, None
+
+    def inference(self, inputs, mask, pos, cache=None):
+        context, w = self.forward(inputs, mask, pos)
+        return context, w, cache
+
+
+class ConformerConvolutionModule(nn.Module):
+    """module/conformer.py:12-57."""
+
+    def __init__(self, channels, kernel_size, bias=True, dropout=0.0):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        if dropout:
+            _unsupported('conv_dropout > 0')
+        self.pointwise_conv1 = nn.Linear(channels, 2 * channels, bias=bias)
+        self.depthwise_conv = nn.Conv1d(channels, channels, kernel_size, stride=1, padding=(kernel_size - 1) // 2,
+                                        groups=channels, bias=bias)
+        self.batch_norm = nn.BatchNorm1d(channels)
+        self.pointwise_conv2 = nn.Linear(channels, channels, bias=bias)
+
+    def forward(self, x, mask):
+        bn = self.batch_norm
+        B, T, _ = x.shape
+        out = ops.ConformerConvFn.apply(x, ops._mask_u8(mask, B, T).reshape(-1), self.pointwise_conv1.weight,
+                                        self.pointwise_conv1.bias, self.depthwise_conv.weight, self.depthwise_conv.bias,
+                                        bn.weight, bn.bias, bn.running_mean, bn.running_var, self.pointwise_conv2.weight,
+                                        self.pointwise_conv2.bias, self.training, bn.eps, bn.momentum)
+        if self.training:
+            bn.num_batches_tracked += 1
+        return out
+
+
+class ConformerEncoderBlock(nn.Module):
+    """encoder/conformer.py:20-114.  As shipped the post-FFN is never applied: forward ends with
+    post_ffn_norm then final_norm (:87-89), and F.dropout stays active in eval (:53-72)."""
+
+    def __init__(self, d_model, d_ff, cov_kernel_size, n_heads, slf_attn_dropout=0.0, ffn_dropout=0.0,
+                 residual_dropout=0.1, conv_dropout=0.0, macaron_style=True, conv_first=False, ffn_scale=0.5,
+                 conv_bias=True, relative_positional=True, activation='glu'):
+        super().__init__()
+        self.conv_first, self.macaron_style, self.ffn_scale = conv_first, macaron_style, ffn_scale
+        self.relative_positional, self.residual_dropout = relative_positional, residual_dropout
+        if macaron_style:
+            self.pre_ffn = PositionwiseFeedForward(d_model, d_ff, ffn_dropout, activation=activation)
+            self.macaron_ffn_norm = nn.LayerNorm(d_model)
+        if relative_positional:
+            self.mha = MultiHeadedSelfAttentionWithRelPos(n_heads, d_model, slf_attn_dropout)
+        else:
+            self.mha = MultiHeadedSelfAttention(n_heads, d_model, slf_attn_dropout)
+        self.mha_norm = nn.LayerNorm(d_model)
+        self.conv = ConformerConvolutionModule(d_model, cov_kernel_size, conv_bias, conv_dropout)
+        self.conv_norm = nn.LayerNorm(d_model)
+        self.post_ffn = PositionwiseFeedForward(d_model, d_ff, ffn_dropout, activation=activation)   # unused, as shipped
+        self.post_ffn_norm = nn.LayerNorm(d_model)
+        self.final_norm = nn.LayerNorm(d_model)
+
+    @staticmethod
+    def _ln(norm, x):
+        return ops.add_layernorm(x, None, norm.weight, norm.bias, 0.0, norm.eps)
+
+    def _attn(self, x, mask, pos, p):
+        h = self._ln(self.mha_norm, x)
+        out = self.mha(h, mask.unsqueeze(1), pos)[0] if self.relative_positional else self.mha(h, mask.unsqueeze(1))[0]
+        return ops.residual_add(x, out, 1.0, p)
+
+    def _conv(self, x, mask, p):
+        return ops.residual_add(x, self.conv(self._ln(self.conv_norm, x), mask), 1.0, p)
+
+    def forward(self, x, mask, pos=None):
+        p = self.residual_dropout                      # F.dropout(..., p): active in train AND eval in the reference
+        if self.macaron_style:
+            x = ops.residual_add(x, self.pre_ffn(self._ln(self.macaron_ffn_norm, x)), self.ffn_scale, p)
+        if self.conv_first:
+            x = self._attn(self._conv(x, mask, p), mask, pos, p)
+        else:
+            x = self._conv(self._attn(x, mask, pos, p), mask, p)
+        x = self._ln(self.post_ffn_norm, x)
+        return self._ln(self.final_norm, x), {'slf_attn_weights': None}
+
+
+_SINUSOID_CACHE = {}
+
+
+def relative_sinusoid(T, d, device):
+    """PositionalEncoding._embedding_from_positions(arange(-(T-1), T)) (module/pos.py:30-42): a constant
+    table, built once per (T, d) on the host."""
+    key = (T, d, str(device))
+    if key not in _SINUSOID_CACHE:
+        pos = torch.arange(-(T - 1), T, dtype=torch.float32).unsqueeze(-1)
+        div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+        pe = torch.zeros(1, 2 * T - 1, d)
+        pe[0, :, 0::2] = torch.sin(pos * div)
+        pe[0, :, 1::2] = torch.cos(pos * div)
+        _SINUSOID_CACHE[key] = pe.to(device)
+    return _SINUSOID_CACHE[key]
+
+
+class ConformerEncoder(nn.Module):
+    """encoder/conformer.py:117-164 (note the kwarg is `nblocks`, not `n_blocks`)."""
+
+    def __init__(self, d_model, d_ff, cov_kernel_size, n_heads, nblocks=12, pos_dropout=0.0, slf_attn_dropout=0.0,
+                 ffn_dropout=0.0, residual_dropout=0.1, conv_dropout=0.0, macaron_style=True, ffn_scale=0.5,
+                 conv_bias=True, positional_encoding=True, relative_positional=True, conv_first=False, activation='glu'):
+        super().__init__()
+        self.positional_encoding, self.relative_positional, self.output_size = positional_encoding, relative_positional, d_model
+        if relative_positional and not positional_encoding:
+            _unsupported('relative_positional without positional_encoding')
+        if positional_encoding:
+            self.pos_emb = PositionalEncoding(d_model, pos_dropout)
+        self.blocks = nn.ModuleList([
+            ConformerEncoderBlock(d_model, d_ff, cov_kernel_size, n_heads, slf_attn_dropout, ffn_dropout,
+                                  residual_dropout, conv_dropout, macaron_style, conv_first, ffn_scale, conv_bias,
+                                  relative_positional, activation) for _ in range(nblocks)])
+
+    def forward(self, inputs, mask):
+        if self.positional_encoding and not self.relative_positional:
+            x, pos = self.pos_emb(inputs)
+        else:
+            x = inputs.float()
+            pos = relative_sinusoid(inputs.size(1), inputs.size(2), inputs.device) if self.relative_positional else None
+        for block in self.blocks:
+            x, _ = block(x, mask, pos)
+        return x, mask, {}
+
+
 # ------------------------------------------------------------------------------------- decoder
 class TransformerDecoderLayer(nn.Module):
     """decoder/transformer.py:18-126 (post-norm)."""

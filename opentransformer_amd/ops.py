@@ -460,7 +460,7 @@ class FeedForwardGLUFn(torch.autograd.Function):
         M, F2 = h.shape
         F = F2 // 2
         u = torch.empty((M, F), dtype=adt, device=x.device)
-        L.check(L.load().otr_glu_fwd(_p(h), _p(u), _code(adt), M, F, _stream()), 'otr_glu_fwd')
+        L.check(L.load().otr_glu_fwd(_p(h), _p(u), _code(adt), M, F, None, _stream()), 'otr_glu_fwd')
         y = linear_fwd_raw(u, w2, b2, torch.float32)
         ctx.save_for_backward(x2, w1, w2, h, u)
         ctx.xshape, ctx.xdtype = x.shape, x.dtype
@@ -479,7 +479,7 @@ class FeedForwardGLUFn(torch.autograd.Function):
         dh = torch.empty_like(h)
         nblk = (M + GLU_RPB - 1) // GLU_RPB
         part = torch.empty((nblk, 2 * F), dtype=torch.float32, device=dy.device)
-        L.check(L.load().otr_glu_bwd(_p(h), _p(du), _p(dh), _p(part), _code(h.dtype), M, F, _stream()), 'otr_glu_bwd')
+        L.check(L.load().otr_glu_bwd(_p(h), _p(du), _p(dh), _p(part), _code(h.dtype), M, F, None, _stream()), 'otr_glu_bwd')
         db1 = colsum_raw(part, out=gb1)
         if ctx.w1t is not None:
             dx = linear_fwd_raw(dh, ctx.w1t, None, ctx.xdtype).view(ctx.xshape)
@@ -628,6 +628,190 @@ class ConvSubsampleFn(torch.autograd.Function):
         inpl = gw1 is not None and gb1 is not None
         return (None, None if inpl else dw1.view(C1, 1, 3, 3), None if inpl else db1, dw2r.permute(0, 3, 1, 2),
                 None if gb2 is not None else db2)
+
+
+# ---------------------------------------------------------------------------------------- conformer pieces
+def _gemm_ptr(kind, M, N, K, x, w, y, bias=None, accumulate=0):
+    """Raw GEMM on (tensor, element offset, leading dim) triples -- for head-sliced operands.
+    kind: 'fwd' y[M,N] = x[M,K] w[N,K]^T; 'dgrad' x[M,K] = y[M,N] w[N,K]; 'wgrad' w[N,K] = y[M,N]^T x[M,K]."""
+    (xt, xo, ldx), (wt, wo, ldw), (yt, yo, ldy) = x, w, y
+    d = L.LinearDesc(M, N, K, _code(xt.dtype), _code(wt.dtype), _code(yt.dtype), _compute_code(), ldx, ldw, ldy, 0,
+                     accumulate)
+    ws = _workspace(xt.device)
+    lib = L.load()
+    if kind == 'fwd':
+        L.check(lib.otr_linear_fwd(C.byref(d), _p(xt, xo), _p(wt, wo), _p(bias), _p(yt, yo), _p(ws), _WS_BYTES, _stream()),
+                'otr_linear_fwd')
+    elif kind == 'dgrad':
+        L.check(lib.otr_linear_dgrad(C.byref(d), _p(yt, yo), _p(wt, wo), _p(xt, xo), _p(ws), _WS_BYTES, _stream()),
+                'otr_linear_dgrad')
+    else:
+        L.check(lib.otr_linear_wgrad(C.byref(d), _p(yt, yo), _p(xt, xo), _p(wt, wo), _p(ws), _WS_BYTES, _stream()),
+                'otr_linear_wgrad')
+
+
+class ResidualAddFn(torch.autograd.Function):
+    """y = x + scale * dropout(a): the pre-norm residual branches of encoder/conformer.py:50-73."""
+
+    @staticmethod
+    def forward(ctx, x, a, scale, p_drop):
+        _cuda(x, a)
+        x2 = x.contiguous()
+        a2 = a.contiguous()
+        y = torch.empty_like(x2)
+        seed = rng_seed_tensor(x.device) if p_drop > 0 else None
+        off = _next_rng_offset(x2.numel()) if p_drop > 0 else 0
+        L.check(L.load().otr_residual_add_fwd(_p(x2), _p(a2), _code(a2.dtype), _p(y), x2.numel(), scale, p_drop, _p(seed),
+                                              off, _stream()), 'otr_residual_add_fwd')
+        ctx.cfg = (scale, p_drop, off, a2.dtype, a.shape)
+        ctx.save_for_backward(seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        scale, p_drop, off, adt, ashape = ctx.cfg
+        (seed,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        da = torch.empty(ashape, dtype=adt, device=dy.device)
+        L.check(L.load().otr_residual_add_bwd(_p(dy), _p(da), _code(adt), dy.numel(), scale, p_drop, _p(seed), off,
+                                              _stream()), 'otr_residual_add_bwd')
+        return dy, da, None, None
+
+
+def residual_add(x, a, scale=1.0, p_drop=0.0):
+    return ResidualAddFn.apply(x, a, float(scale), float(p_drop))
+
+
+class RelPosAttentionFn(torch.autograd.Function):
+    """MultiHeadedSelfAttentionWithRelPos.forward after the qvk projection (module/attention.py:217-253):
+    softmax(((q+u) k^T + shift((q+v) p^T)) / sqrt(dk)) v with p = pos_proj(sinusoid[-(T-1)..T-1]).
+    The shifted [B,h,T,T] matrix is never built: the attention kernels read the un-shifted
+    (q+v) p^T term at column j - i + T - 1."""
+
+    @staticmethod
+    def forward(ctx, qkv, pos_emb, pos_w, posu, posv, key_mask_u8, n_heads):
+        _cuda(qkv, pos_emb, pos_w, posu, posv)
+        B, T, d3 = qkv.shape
+        d = d3 // 3
+        H, dk, P, M = n_heads, d // n_heads, 2 * T - 1, B * T
+        adt = qkv.dtype
+        qkv = qkv.contiguous()
+        pe = pos_emb.reshape(P, d).contiguous()
+        wl = weight_lp(pos_w)
+        p = linear_fwd_raw(pe, wl if wl is not None else pos_w, None, adt)                  # [P, d]
+        u, v = posu.reshape(d).contiguous(), posv.reshape(d).contiguous()
+        quv = torch.empty((B, T, 2 * d), dtype=adt, device=qkv.device)
+        lib = L.load()
+        L.check(lib.otr_head_bias_add(_p(qkv), d3, _p(u), _p(v), _p(quv), _code(adt), M, d, _stream()), 'otr_head_bias_add')
+        bd = torch.empty((B, T, H, P), dtype=torch.float32, device=qkv.device)
+        for h in range(H):
+            _gemm_ptr('fwd', M, P, dk, (quv, d + h * dk, 2 * d), (p, h * dk, d), (bd, h * P, H * P))
+        out = torch.empty((B, T, d), dtype=adt, device=qkv.device)
+        lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
+        desc = _attn_desc(B, H, T, T, dk, adt, (T * 2 * d, 2 * d), (T * d3, d3), (T * d3, d3), (T * d, d), False)
+        L.check(lib.otr_attention_bias_fwd(C.byref(desc), _p(quv), _p(qkv, d), _p(qkv, 2 * d), _p(key_mask_u8), _p(bd),
+                                           T * H * P, P, H * P, 1, _p(out), _p(lse), _stream()), 'otr_attention_bias_fwd')
+        ctx.save_for_backward(qkv, quv, p, pe, bd, out, lse, key_mask_u8, pos_w)
+        ctx.H = H
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, quv, p, pe, bd, out, lse, km, pos_w = ctx.saved_tensors
+        H = ctx.H
+        B, T, d3 = qkv.shape
+        d = d3 // 3
+        dk, P, M = d // H, 2 * T - 1, B * T
+        adt = qkv.dtype
+        lib = L.load()
+        dout = dout.contiguous()
+        dbd = torch.zeros_like(bd)
+        dquv = torch.empty_like(quv)
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse)
+        desc = _attn_desc(B, H, T, T, dk, adt, (T * 2 * d, 2 * d), (T * d3, d3), (T * d3, d3), (T * d, d), False)
+        L.check(lib.otr_attention_bias_bwd(C.byref(desc), _p(quv), _p(qkv, d), _p(qkv, 2 * d), _p(km), _p(bd), _p(dbd),
+                                           T * H * P, P, H * P, 1, _p(out), _p(dout), _p(lse), _p(delta), _p(dquv),
+                                           _p(dqkv, d), _p(dqkv, 2 * d), _stream()), 'otr_attention_bias_bwd')
+        dp = torch.empty((P, d), dtype=torch.float32, device=qkv.device)
+        for h in range(H):
+            _gemm_ptr('dgrad', M, P, dk, (dquv, d + h * dk, 2 * d), (p, h * dk, d), (dbd, h * P, H * P))
+            _gemm_ptr('wgrad', M, P, dk, (quv, d + h * dk, 2 * d), (dp, h * dk, d), (dbd, h * P, H * P))
+        L.check(lib.otr_add2_strided(_p(dquv), 2 * d, _p(dquv, d), 2 * d, _p(dqkv), d3, _code(adt), M, d, _stream()),
+                'otr_add2_strided')
+        dq2 = dquv.view(M, 2 * d)
+        du = colsum_raw(dq2[:, :d])
+        dv = colsum_raw(dq2[:, d:])
+        dw = linear_wgrad_raw(dp, pe, pos_w)
+        return dqkv, None, dw, du.view(1, 1, H, dk), dv.view(1, 1, H, dk), None, None
+
+
+class ConformerConvFn(torch.autograd.Function):
+    """ConformerConvolutionModule.forward (module/conformer.py:36-57): Linear C->2C, GLU, zero padded
+    frames, depthwise Conv1d, BatchNorm1d (batch statistics incl. padded frames), swish, Linear C->C,
+    zero padded frames."""
+
+    @staticmethod
+    def forward(ctx, x, mask_u8, w1, b1, wdw, bdw, gamma, beta, run_mean, run_var, w2, b2, training, eps, momentum):
+        _cuda(x, w1, wdw, gamma, beta, w2)
+        B, T, Cc = x.shape
+        M = B * T
+        adt = act_dtype()
+        lib = L.load()
+        xc = lp_of(x)
+        x2 = _rows(xc if xc is not None else x)
+        w1l, w2l = weight_lp(w1), weight_lp(w2)
+        w1c = w1l if w1l is not None else w1
+        w2c = w2l if w2l is not None else w2
+        h = linear_fwd_raw(x2, w1c, b1, adt)                                            # [M, 2C]
+        g = torch.empty((M, Cc), dtype=adt, device=x.device)
+        L.check(lib.otr_glu_fwd(_p(h), _p(g), _code(adt), M, Cc, _p(mask_u8), _stream()), 'otr_glu_fwd')
+        k = wdw.shape[-1]
+        wk = wdw.reshape(Cc, k).contiguous()
+        y = torch.empty((M, Cc), dtype=torch.float32, device=x.device)
+        stats = torch.empty((2 * Cc,), dtype=torch.float32, device=x.device) if training else None
+        L.check(lib.otr_dwconv_fwd(_p(g), _code(adt), _p(wk), _p(bdw), _p(y), _p(stats), B, T, Cc, k, _stream()),
+                'otr_dwconv_fwd')
+        saved = torch.empty((2 * Cc,), dtype=torch.float32, device=x.device)
+        s = torch.empty((M, Cc), dtype=adt, device=x.device)
+        L.check(lib.otr_bn_swish_fwd(_p(y), _p(stats), _p(gamma), _p(beta), _p(run_mean), _p(run_var), _p(saved), _p(s),
+                                     _code(adt), M, Cc, eps, momentum, int(training), _stream()), 'otr_bn_swish_fwd')
+        o = linear_fwd_raw(s, w2c, b2, torch.float32)
+        out = torch.empty_like(o)
+        L.check(lib.otr_row_mask(_p(o), _p(mask_u8), _p(out), M, Cc, _stream()), 'otr_row_mask')
+        ctx.save_for_backward(x2, mask_u8, w1c, wk, gamma, beta, w2c, h, g, y, saved, s)
+        ctx.cfg = (B, T, Cc, k, training, x.shape, x.dtype, bdw is not None, wdw.shape)
+        return out.view(B, T, Cc)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, mask_u8, w1c, wk, gamma, beta, w2c, h, g, y, saved, s = ctx.saved_tensors
+        B, T, Cc, k, training, xshape, xdtype, has_dwb, wdw_shape = ctx.cfg
+        M = B * T
+        adt = s.dtype
+        lib = L.load()
+        dm = torch.empty((M, Cc), dtype=torch.float32, device=dout.device)
+        L.check(lib.otr_row_mask(_p(dout.contiguous()), _p(mask_u8), _p(dm), M, Cc, _stream()), 'otr_row_mask')
+        ds = linear_dgrad_raw(dm, w2c, adt)
+        dw2 = linear_wgrad_raw(dm, s, w2c)
+        db2 = colsum_raw(dm)
+        red = torch.empty((2 * Cc,), dtype=torch.float32, device=dout.device)
+        dy = torch.empty((M, Cc), dtype=torch.float32, device=dout.device)
+        L.check(lib.otr_bn_swish_bwd(_p(y), _p(ds), _code(adt), _p(saved), _p(gamma), _p(beta), _p(red), _p(dy), M, Cc,
+                                     int(training), _stream()), 'otr_bn_swish_bwd')
+        dg = torch.empty((M, Cc), dtype=adt, device=dout.device)
+        dwk = torch.zeros((Cc * k + Cc,), dtype=torch.float32, device=dout.device)
+        L.check(lib.otr_dwconv_bwd(_p(dy), _p(g), _code(adt), _p(wk), _p(dg), _p(dwk), _p(dwk, Cc * k), B, T, Cc, k,
+                                   _stream()), 'otr_dwconv_bwd')
+        dh = torch.empty_like(h)
+        nblk = (M + GLU_RPB - 1) // GLU_RPB
+        part = torch.empty((nblk, 2 * Cc), dtype=torch.float32, device=dout.device)
+        L.check(lib.otr_glu_bwd(_p(h), _p(dg), _p(dh), _p(part), _code(adt), M, Cc, _p(mask_u8), _stream()), 'otr_glu_bwd')
+        db1 = colsum_raw(part)
+        dx = linear_dgrad_raw(dh, w1c, xdtype).view(xshape)
+        dw1 = linear_wgrad_raw(dh, x2, w1c)
+        return (dx, None, dw1, db1, dwk[:Cc * k].view(wdw_shape), dwk[Cc * k:] if has_dwb else None, red[Cc:], red[:Cc],
+                None, None, dw2, db2, None, None, None)
 
 
 # ---------------------------------------------------------------------------------------- losses

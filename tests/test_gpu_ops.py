@@ -299,3 +299,87 @@ def test_cpu_tensor_is_refused():
     from opentransformer_amd import ops, _lib
     with pytest.raises(_lib.OtransHipError):
         ops.linear(torch.zeros(4, 8), torch.zeros(3, 8), None)
+
+
+# ------------------------------------------------------------------------------------------ conformer pieces
+@pytest.mark.parametrize('B,T,H,dk', [(2, 49, 4, 16), (2, 70, 4, 96)])
+def test_relpos_attention(mode, B, T, H, dk):
+    import opentransformer_amd as ota
+    from opentransformer_amd.nn import relative_sinusoid
+    from opentransformer_amd import synthetic as syn
+    from oracle import otrans_oracle as orc
+    d = H * dk
+    torch.manual_seed(0)
+    mod = ota.MultiHeadedSelfAttentionWithRelPos(H, d).to(DEV)
+    syn.fill_state_dict_(mod.state_dict(), 5)
+    x = rnd(B, T, d, seed=101).requires_grad_(True)
+    mask = torch.ones(B, 1, T, dtype=torch.bool, device=DEV)
+    mask[1, 0, T - 7:] = False
+    pos = relative_sinusoid(T, d, DEV)
+    out, _ = mod(x, mask, pos)
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in mod.state_dict().items()}
+    xc = x.detach().cpu().requires_grad_(True)
+    ref = orc.relpos_self_attention(sd, xc, mask.cpu(), pos.cpu(), H)
+    assert rel(out.float().cpu(), ref) < TOL[mode]
+    g = rnd(B, T, d, seed=102).to(out.dtype)
+    names = ['qvk_proj.weight', 'pos_proj.weight', 'posu', 'posv']
+    params = dict(mod.named_parameters())
+    grads = torch.autograd.grad(out, [x] + [params[n] for n in names], g)
+    gref = torch.autograd.grad(ref, [xc] + [sd[n] for n in names], g.float().cpu())
+    for nm, u, v in zip(['dx'] + names, grads, gref):
+        assert rel(u.float().cpu(), v) < 3 * TOL[mode], nm
+
+
+@pytest.mark.parametrize('B,T,C', [(3, 49, 64), (2, 120, 384)])
+def test_conformer_conv_module(mode, B, T, C):
+    import opentransformer_amd as ota
+    from opentransformer_amd import synthetic as syn
+    from oracle import otrans_oracle as orc
+    torch.manual_seed(0)
+    mod = ota.ConformerConvolutionModule(C, 5).to(DEV).train()
+    syn.fill_state_dict_(mod.state_dict(), 6)
+    sd = {k: v.detach().cpu().clone() for k, v in mod.state_dict().items()}
+    x = rnd(B, T, C, seed=111).requires_grad_(True)
+    mask = torch.ones(B, T, dtype=torch.bool, device=DEV)
+    mask[0, T - 11:] = False
+    out = mod(x, mask)
+    for k in sd:
+        if sd[k].is_floating_point() and 'running' not in k:
+            sd[k].requires_grad_(True)
+    xc = x.detach().cpu().requires_grad_(True)
+    run_m, run_v = sd['batch_norm.running_mean'].clone(), sd['batch_norm.running_var'].clone()
+    ref = orc.conformer_conv_module(sd, xc, mask.cpu(), training=True)
+    assert rel(out.cpu(), ref) < TOL[mode]
+    # running statistics were updated like torch's BatchNorm1d (momentum 0.1, unbiased variance)
+    y = torch.nn.functional.batch_norm(torch.zeros(1, C, 2), run_m, run_v, training=False)   # noqa: F841 (buffers untouched)
+    g = rnd(B, T, C, seed=112)
+    names = [k for k in sd if sd[k].requires_grad]
+    params = dict(mod.named_parameters())
+    grads = torch.autograd.grad(out, [x] + [params[n] for n in names], g)
+    gref = torch.autograd.grad(ref, [xc] + [sd[n] for n in names], g.cpu())
+    for nm, u, v in zip(['dx'] + names, grads, gref):
+        if nm == 'depthwise_conv.bias':     # a bias in front of BatchNorm has zero gradient: both sides are roundoff
+            assert float(u.abs().max()) < 1e-3 * float(gref[1].abs().max() + 1e-6) + 1e-4, nm
+            continue
+        assert rel(u.float().cpu(), v) < 4 * TOL[mode], nm
+    # eval mode uses the running statistics
+    mod.eval()
+    with torch.no_grad():
+        oe = mod(x, mask)
+        sde = {k: v.detach().cpu() for k, v in mod.state_dict().items()}
+        re = orc.conformer_conv_module(sde, xc.detach(), mask.cpu(), training=False)
+    assert rel(oe.cpu(), re) < TOL[mode]
+
+
+def test_residual_add_dropout():
+    from opentransformer_amd import ops
+    x = rnd(64, 256, seed=121).requires_grad_(True)
+    a = rnd(64, 256, seed=122).requires_grad_(True)
+    y = ops.residual_add(x, a, 0.5, 0.0)
+    assert rel(y, x + 0.5 * a) < 1e-6
+    ops.next_dropout_step(torch.device(DEV))
+    yd = ops.residual_add(x, a, 1.0, 0.25)
+    kept = ((yd - x).abs() > 0)
+    assert abs(kept.float().mean().item() - 0.75) < 0.02
+    (da,) = torch.autograd.grad(yd, a, torch.ones_like(yd))
+    assert bool(((da != 0) == kept).all())
