@@ -38,6 +38,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
     ap.add_argument('--frames', type=int, default=1000)
     ap.add_argument('--mode', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--model', default='transformer', choices=['transformer', 'conformer'],
+                    help='transformer = BASELINE configs[1] (the metric); conformer = configs[3] (informative)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=4)
@@ -125,13 +127,13 @@ def main():
     from opentransformer_amd.dp import FlatDataParallel, FusedAdam
     ops.set_compute_dtype(args.mode)
 
-    cfg = syn.c2_model(residual_dropout=0.1)
+    cfg = syn.c2_model(residual_dropout=0.1) if args.model == 'transformer' else syn.conformer_model(False, 0.1)
     model = ota.SpeechToText(cfg)
     syn.fill_state_dict_(model.state_dict(), 1234)           # identical replicas on every rank
     model = model.to(dev).train()
     dp = FlatDataParallel(model)
     opt = FusedAdam(dp, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6, clip_grad=5.0,
-                    noam=dict(model_size=256, warmup_steps=12000, factor=1.0))   # transformer_baseline.yaml:81-95
+                    noam=dict(model_size=cfg['encoder']['d_model'], warmup_steps=12000, factor=1.0))   # *_baseline.yaml train section
     inputs, targets = syn.synthetic_batch(args.batch, args.frames, 80, 4234, 15, seed=rank)
     inputs = {k: v.to(dev) for k, v in inputs.items()}
     targets = {k: v.to(dev) for k, v in targets.items()}
@@ -193,7 +195,7 @@ def main():
     if rank == 0:
         global_batch = args.batch * world
         utt_s = global_batch * args.steps / elapsed
-        flops_utt = syn.flops_per_utt(cfg, args.frames, 15)
+        flops_utt = syn.flops_per_utt(cfg, args.frames, 15) if args.model == 'transformer' else 63207.57e6
         time_dominant_kernel.rows = args.batch * (((args.frames - 3) // 2 + 1 - 3) // 2 + 1)
         out = {
             'metric': 'utterances/sec (80-d fbank, ~1000 frames) train fwd+bwd', 'value': utt_s,
@@ -212,7 +214,10 @@ def main():
         st = opt.stats()
         if st['skipped'] != 0 or not (st['grad_sqnorm'] == st['grad_sqnorm'] and st['grad_sqnorm'] < float('inf')):
             out['INVALID'] = 'non-finite gradient norm: %d optimizer updates were skipped' % int(st['skipped'])
-        out['roofline'] = time_dominant_kernel(model, args.mode)
+        if args.model == 'transformer':
+            out['roofline'] = time_dominant_kernel(model, args.mode)
+        else:
+            out['config']['workload'] = out['config']['workload'].replace('transformer_baseline.yaml (+input_size 80), 12 enc / 6 dec layers', 'conformer_baseline.yaml, 12 conformer blocks / 6 dec layers')
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(out))

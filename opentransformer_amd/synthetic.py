@@ -69,7 +69,7 @@ def conformer_model(small=False, residual_dropout=0.0):
     else:
         m['frontend'].update(output_size=384, mid_channel=256, out_channel=256)
         enc = dict(d_model=384, d_ff=768, cov_kernel_size=5, n_heads=4, nblocks=12)
-        m['decoder'].update(d_model=384, memory_dim=384)
+        m['decoder'].update(d_model=384, memory_dim=384, d_ff=768)
         m['encoder_output_size'] = 384
     enc.update(pos_dropout=0.0, slf_attn_dropout=0.0, ffn_dropout=0.0, residual_dropout=residual_dropout,
                conv_dropout=0.0, macaron_style=True, ffn_scale=0.5, conv_bias=True, activation='glu',

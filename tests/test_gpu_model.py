@@ -233,3 +233,34 @@ def test_inplace_flat_gradients_match_autograd_gradients():
             assert rel(q.grad.cpu().numpy(), p.grad.cpu().numpy()) < 1e-5, k
     finally:
         ops.set_compute_dtype('bf16')
+
+
+def test_c4_conformer_full_size_matches_cpu_oracle():
+    """conformer_baseline.yaml dimensions (d=384, dk=96, 256-channel frontend, 12 blocks, 50.4 M parameters) on a
+    small ragged batch against the CPU oracle (which is pinned to the reference on the small conformer fixture)."""
+    from opentransformer_amd import ops
+    from oracle import otrans_oracle as orc
+    cfg = syn.conformer_model(small=False)
+    kw = dict(batch=2, frames=240, feat_dim=80, vocab=4234, tgt_len=9, seed=4, lengths=[240, 173], tgt_lengths=[9, 6])
+    inputs, targets = syn.synthetic_batch(**kw)
+    parts = H.require_grad(H.filled_state(cfg, seed=31))
+    ref, _ = orc.speech2text_forward(parts, cfg, inputs, targets)
+    ref.backward()
+    flat = H.flat_named(parts)
+    for mode, tl, tg in (('fp32', 1e-4, 5e-3), ('bf16', 2e-3, 1e-1)):
+        ops.set_compute_dtype(mode)
+        try:
+            model = build(cfg, seed=31)
+            assert sum(p.numel() for p in model.parameters()) == 50405130        # SURVEY.md 2.4
+            loss, _ = model(to_dev(inputs), to_dev(targets))
+            loss.backward()
+            assert abs(loss.item() - ref.item()) < tl * abs(ref.item()), (mode, loss.item(), ref.item())
+            worst = 0.0
+            for k, p in model.named_parameters():
+                if p.grad is None:
+                    continue
+                gr, gg = flat[k].grad.numpy(), p.grad.cpu().numpy()
+                worst = max(worst, float(np.linalg.norm(gg - gr) / max(np.linalg.norm(gr), 1e-3)))
+            assert worst < tg, (mode, worst)
+        finally:
+            ops.set_compute_dtype('bf16')
