@@ -89,7 +89,15 @@ template <class ST, int N> __device__ __forceinline__ void load_vec(const ST* p,
 
 // ------------------------------------------------------------------------------------------------
 // Operand tile loader.  ROWS x KCH chunks per stage, 256 threads.
-template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
+//
+// FAST = true is the production path: every global load is UNCONDITIONAL (out-of-range rows are clamped to a
+// valid row -- their accumulators are never stored -- and out-of-range k is loaded from k = 0 and zeroed with
+// a select), so the compiler can issue a whole stage (or three) of loads back to back and wait with counted
+// vmcnt.  With loads inside `if (in range) { if (aligned) ... else scalar fallback }` control flow hipcc put an
+// `s_waitcnt vmcnt(0)` behind every single load (seen in the ISA; 2-3 us per k-stage).  FAST needs 16-byte
+// aligned rows and K % CE == 0 (row-major modes) / nrows % PM == 0 (transposing modes); everything else runs
+// the generic (FAST = false) instantiation.
+template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
   using G = GemmCfg<CT>;
   static constexpr int CE = G::CE, KCH = G::KCH, PM = G::PM;
   static constexpr bool ROWMAJOR = (MODE == MODE_KC || MODE == MODE_IM2K);
@@ -98,9 +106,13 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
   // transposing modes: (ROWS/PM) x KCH patches of PM rows x CE k; patch id = tid + 256u
   static constexpr int RG = ROWS / PM;
   static constexpr int NP = ROWMAJOR ? 1 : (RG * KCH + 255) / 256;
-
   // same-type row-major operands are staged as raw 16-byte chunks (no float round trip)
   static constexpr bool RAWQ = ROWMAJOR && std::is_same<ST, CT>::value;
+  // prefetch ring: FAST raw loaders keep DEPTH stages in registers (DEPTH-1 in flight beyond the one consumed)
+  static constexpr int DEPTH = (RAWQ && FAST && MODE == MODE_KC) ? 3 : 1;
+  // every thread owns a full set of units (true for all tile shapes instantiated): lets stores/loads drop the
+  // per-unit activity test the compiler cannot fold (it does not know threadIdx.x < 256)
+  static constexpr bool ALLACTIVE = ROWMAJOR ? ((ROWS * KCH) % 256 == 0) : ((RG * KCH) % 256 == 0);
 
   const ST* base;
   int64_t ld;
@@ -110,7 +122,7 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
   const ST* p0[ROWMAJOR ? NU : NP];
   bool rok[ROWMAJOR ? NU : NP];
   float raw[RAWQ ? 1 : (ROWMAJOR ? NU : NP * PM)][CE];
-  uint4 rawq[RAWQ ? NU : 1];
+  uint4 rawq[RAWQ ? DEPTH : 1][RAWQ ? NU : 1];
   // im2col state
   int64_t pix[ROWMAJOR ? NU : 1];
   int f2v[ROWMAJOR ? NU : 1];
@@ -126,7 +138,8 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
         int id = tid + 256 * u;
         int lr = id / KCH;
         rok[u] = lr < ROWS && row0 + lr < nrows;
-        p0[u] = base + (int64_t)(row0 + lr) * ld + (id % KCH) * CE;
+        if constexpr (FAST) p0[u] = base + (int64_t)min(row0 + lr, nrows - 1) * ld;      // row base, chunk added per stage
+        else p0[u] = base + (int64_t)(row0 + lr) * ld + (id % KCH) * CE;
       }
     }
     if constexpr (MODE == MODE_MC) {
@@ -135,7 +148,9 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
         int id = tid + 256 * u;
         int rg = id % RG, c = id / RG;
         rok[u] = c < KCH;
-        p0[u] = base + (int64_t)(c * CE) * ld + row0 + PM * rg;
+        int r = row0 + PM * rg;
+        if constexpr (FAST) p0[u] = base + ((r + PM <= nrows) ? r : 0);                     // k offset added per stage
+        else p0[u] = base + (int64_t)(c * CE) * ld + r;
       }
     }
     if constexpr (MODE == MODE_IM2K) {
@@ -159,24 +174,57 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
     }
   }
 
-  // issue the global loads for the stage starting at k0
-  __device__ __forceinline__ void load(int k0, const ConvGeom& g, int tid) {
-    if constexpr (MODE == MODE_KC) {
+  // issue the global loads for the stage starting at k0 into ring slot SLOT (compile-time)
+  template <int SLOT = 0> __device__ __forceinline__ void load(int k0, const ConvGeom& g, int tid) {
+    if constexpr (MODE == MODE_KC && FAST) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int gk = k0 + ((tid + 256 * u) % KCH) * CE;
+        // k tail: load from k = 0 (always valid) and zero the chunk with an AND mask when it is written to LDS
+        // (store()): the load stays unconditional and nothing consumes its result before the MFMAs of the
+        // current stage -- a select here gets turned back into a branch + vmcnt(0) by the compiler
+        const uint32_t m = (uint32_t)0 - (uint32_t)(gk < K);
+        const ST* src = p0[u] + (gk & (int)m);
+        if constexpr (RAWQ) {
+          rawq[SLOT][u] = *reinterpret_cast<const uint4*>(src);
+        } else {
+          load_row<ST, CE>(src, CE, true, raw[u]);
+#pragma unroll
+          for (int e = 0; e < CE; ++e) raw[u][e] = __uint_as_float(__float_as_uint(raw[u][e]) & m);
+        }
+      }
+    } else if constexpr (MODE == MODE_MC && FAST) {
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        const int c = (tid + 256 * u) / RG;
+        if (ALLACTIVE || rok[u]) {             // wave-uniform: RG is a multiple of 16
+          const int kb = k0 + c * CE;
+#pragma unroll
+          for (int j = 0; j < CE; ++j) {
+            const uint32_t m = (uint32_t)0 - (uint32_t)(kb + j < K);
+            float v[PM];
+            load_vec<ST, PM>(p0[u] + (int64_t)((kb + j) & (int)m) * ld, v);
+#pragma unroll
+            for (int i = 0; i < PM; ++i) raw[u * PM + i][j] = __uint_as_float(__float_as_uint(v[i]) & m);
+          }
+        }
+      }
+    } else if constexpr (MODE == MODE_KC) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         int id = tid + 256 * u;
         int gk = k0 + (id % KCH) * CE;
         const bool ok = rok[u] && gk < K;
         if constexpr (RAWQ) {
-          rawq[u] = make_uint4(0, 0, 0, 0);
+          rawq[SLOT][u] = make_uint4(0, 0, 0, 0);
           if (ok) {
             const ST* src = p0[u] + k0;
             if (vec && K - gk >= CE) {
-              rawq[u] = *reinterpret_cast<const uint4*>(src);
+              rawq[SLOT][u] = *reinterpret_cast<const uint4*>(src);
             } else {
               float tmp[CE];
               load_row<ST, CE>(src, K - gk, false, tmp);
-              rawq[u] = MMA<CT>::pack(tmp);
+              rawq[SLOT][u] = MMA<CT>::pack(tmp);
             }
           }
         } else {
@@ -201,14 +249,14 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
         const bool ok = lr < ROWS && row < nrows && gk < K && fin >= 0 && fin < g.F1;
         const ST* src = base + pix[u] + (int64_t)(kh * g.F1 + kw) * g.C1 + ch;
         if constexpr (RAWQ) {
-          rawq[u] = make_uint4(0, 0, 0, 0);
+          rawq[SLOT][u] = make_uint4(0, 0, 0, 0);
           if (ok) {
             if (vec) {
-              rawq[u] = *reinterpret_cast<const uint4*>(src);
+              rawq[SLOT][u] = *reinterpret_cast<const uint4*>(src);
             } else {
               float tmp[CE];
               load_row<ST, CE>(src, CE, false, tmp);
-              rawq[u] = MMA<CT>::pack(tmp);
+              rawq[SLOT][u] = MMA<CT>::pack(tmp);
             }
           }
         } else {
@@ -265,16 +313,22 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
   }
 
   // convert to CT and write the tile image: byte(row, chunk) = row*ROWB + ((chunk ^ swz(row)) << 4)
-  __device__ __forceinline__ void store(unsigned char* lds, int tid) const {
+  // k0 = first contraction index of the stage held in SLOT (used for the FAST k-tail mask)
+  template <int SLOT = 0> __device__ __forceinline__ void store(unsigned char* lds, int tid, int k0 = 0) const {
     if constexpr (ROWMAJOR) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         int id = tid + 256 * u;
         int row = id / KCH, c = id % KCH;
-        if (row < ROWS) {
+        if (ALLACTIVE || row < ROWS) {
           uint4 q;
-          if constexpr (RAWQ) q = rawq[u];
-          else q = MMA<CT>::pack(raw[u]);
+          if constexpr (RAWQ) {
+            q = rawq[SLOT][u];
+            if constexpr (FAST && MODE == MODE_KC) {
+              const uint32_t m = (uint32_t)0 - (uint32_t)(k0 + c * CE < K);
+              q = make_uint4(q.x & m, q.y & m, q.z & m, q.w & m);
+            }
+          } else q = MMA<CT>::pack(raw[u]);
           *reinterpret_cast<uint4*>(lds + row * G::ROWB + ((c ^ swz<KCH>(row)) << 4)) = q;
         }
       }
@@ -283,7 +337,7 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
       for (int u = 0; u < NP; ++u) {
         int id = tid + 256 * u;
         int rg = id % RG, c = id / RG;
-        if (c < KCH) {
+        if (ALLACTIVE || c < KCH) {
 #pragma unroll
           for (int i = 0; i < PM; ++i) {
             int row = PM * rg + i;
@@ -296,8 +350,8 @@ template <class CT, class ST, int MODE, int ROWS> struct TileLoader {
 };
 
 // ------------------------------------------------------------------------------------------------
-template <class CT, class AT, class BT, class OT, int AMODE, int BMODE, int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+template <class CT, class AT, class BT, class OT, int AMODE, int BMODE, int BM, int BN, bool FAST>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 VGPRs: two workgroups per CU
   using G = GemmCfg<CT>;
   constexpr int KCH = G::KCH, BK = G::BK, ROWB = G::ROWB;
   constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
@@ -316,8 +370,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const int kt1 = min(nk_total, kt0 + per);
   if (kt0 >= kt1) return;
 
-  TileLoader<CT, AT, AMODE, BM> la;
-  TileLoader<CT, BT, BMODE, BN> lb;
+  TileLoader<CT, AT, AMODE, BM, FAST> la;
+  TileLoader<CT, BT, BMODE, BN, FAST> lb;
   la.init(p.A, p.lda, p.M, p.K, tile_m * BM, p.a_vec != 0, p.cg, tid);
   lb.init(p.B, p.ldb, p.N, p.K, tile_n * BN, p.b_vec != 0, p.cg, tid);
 
@@ -327,20 +381,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  la.load(kt0 * BK, p.cg, tid);
-  lb.load(kt0 * BK, p.cg, tid);
-  la.store(smem, tid);
-  lb.store(smem + BM * ROWB, tid);
-  __syncthreads();
-
+  using LA = TileLoader<CT, AT, AMODE, BM, FAST>;
+  using LB = TileLoader<CT, BT, BMODE, BN, FAST>;
+  // prefetch distance: 3 register stages when both operands are staged raw, else the classic 1
+  constexpr int D = (LA::DEPTH == 3 && LB::DEPTH == 3) ? 3 : 1;
   const int fr = lane & 15, fg = lane >> 4;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    const bool more = kt + 1 < kt1;
-    if (more) {
-      la.load((kt + 1) * BK, p.cg, tid);
-      lb.load((kt + 1) * BK, p.cg, tid);
-    }
+
+  auto compute = [&](int cur) {
     const unsigned char* sa = smem + cur * BUF;
     const unsigned char* sb = sa + BM * ROWB;
 #pragma unroll
@@ -362,11 +409,63 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) MMA<CT>::mma(acc[i][j], bf[j], af[i]);
     }
-    if (more) {
-      la.store(smem + (cur ^ 1) * BUF, tid);
-      lb.store(smem + (cur ^ 1) * BUF + BM * ROWB, tid);
-    }
+  };
+
+  if constexpr (D == 1) {
+    la.template load<0>(kt0 * BK, p.cg, tid);
+    lb.template load<0>(kt0 * BK, p.cg, tid);
+    la.template store<0>(smem, tid, kt0 * BK);
+    lb.template store<0>(smem + BM * ROWB, tid, kt0 * BK);
     __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int cur = (kt - kt0) & 1;
+      const bool more = kt + 1 < kt1;
+      if (more) {
+        la.template load<0>((kt + 1) * BK, p.cg, tid);
+        lb.template load<0>((kt + 1) * BK, p.cg, tid);
+      }
+      compute(cur);
+      if (more) {
+        la.template store<0>(smem + (cur ^ 1) * BUF, tid, (kt + 1) * BK);
+        lb.template store<0>(smem + (cur ^ 1) * BUF + BM * ROWB, tid, (kt + 1) * BK);
+      }
+      __syncthreads();
+    }
+  } else {
+    // stage s lives in ring slot s % 3.  Sub-step for stage t (already in LDS buffer t&1):
+    //   issue loads of stage t+3 into the slot stage t just vacated -> MFMAs of stage t -> write stage t+1 from its
+    //   slot to the other LDS buffer (waits only for THAT stage's loads; two younger stages stay in flight) -> barrier
+    la.template load<0>(kt0 * BK, p.cg, tid);
+    lb.template load<0>(kt0 * BK, p.cg, tid);
+    if (kt0 + 1 < kt1) { la.template load<1>((kt0 + 1) * BK, p.cg, tid); lb.template load<1>((kt0 + 1) * BK, p.cg, tid); }
+    if (kt0 + 2 < kt1) { la.template load<2>((kt0 + 2) * BK, p.cg, tid); lb.template load<2>((kt0 + 2) * BK, p.cg, tid); }
+    la.template store<0>(smem, tid, kt0 * BK);
+    lb.template store<0>(smem + BM * ROWB, tid, kt0 * BK);
+    __syncthreads();
+#define OTR_GEMM_STEP(SLOT, NEXT)                                                              \
+    {                                                                                           \
+      const int cur = (kt - kt0) & 1;                                                           \
+      if (kt + 3 < kt1) {                                                                       \
+        la.template load<SLOT>((kt + 3) * BK, p.cg, tid);                                       \
+        lb.template load<SLOT>((kt + 3) * BK, p.cg, tid);                                       \
+      }                                                                                         \
+      compute(cur);                                                                             \
+      if (kt + 1 < kt1) {                                                                       \
+        la.template store<NEXT>(smem + (cur ^ 1) * BUF, tid, (kt + 1) * BK);                    \
+        lb.template store<NEXT>(smem + (cur ^ 1) * BUF + BM * ROWB, tid, (kt + 1) * BK);        \
+      }                                                                                         \
+      __syncthreads();                                                                          \
+      ++kt;                                                                                     \
+    }
+    int kt = kt0;
+    while (kt < kt1) {
+      OTR_GEMM_STEP(0, 1)
+      if (kt >= kt1) break;
+      OTR_GEMM_STEP(1, 2)
+      if (kt >= kt1) break;
+      OTR_GEMM_STEP(2, 0)
+    }
+#undef OTR_GEMM_STEP
   }
 
   // epilogue: acc[i][j][r] = C[m = .. + i*16 + (lane&15)][n = .. + j*16 + (lane>>4)*4 + r]
@@ -482,6 +581,7 @@ static __global__ void splitk_reduce_kernel(const float* ws, int ks, int M, int 
 // only when the output grid alone cannot fill the chip and a workspace was provided.
 extern int g_otr_force_tile;    // 0 = heuristic, 64 / 128 = forced (tuning hook: otr_debug_set(0, v))
 extern int g_otr_force_ksplit;  // 0 = heuristic, n = forced                  (otr_debug_set(1, v))
+extern int g_otr_force_generic; // 1 = never use the branch-free FAST loaders  (otr_debug_set(2, v))
 
 template <class CT, class AT, class BT, class OT, int AMODE, int BMODE>
 static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
@@ -522,10 +622,27 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
     ks = (nk + per - 1) / per;
   }
   a.ksplit = ks;
-  if (big) {
-    hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 128, 128>), dim3((unsigned)t128, a.ksplit), dim3(256), 0, s, a);
-  } else {
-    hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 64, 64>), dim3((unsigned)t64, a.ksplit), dim3(256), 0, s, a);
+  // branch-free loaders need aligned rows and whole chunks / whole row groups (see TileLoader)
+  constexpr int CE = GemmCfg<CT>::CE, PM = GemmCfg<CT>::PM;
+  auto side_fast = [&](int mode, int vec, int rows) {
+    if (mode == MODE_KC) return vec && (a.K % CE == 0) && rows > 0;
+    if (mode == MODE_MC) return vec && (rows % PM == 0);
+    return false;
+  };
+  const bool fast = (AMODE == MODE_KC || AMODE == MODE_MC) && (BMODE == MODE_KC || BMODE == MODE_MC) &&
+                    side_fast(AMODE, a.a_vec, a.M) && side_fast(BMODE, a.b_vec, a.N) && g_otr_force_generic == 0;
+  const dim3 grid((unsigned)(big ? t128 : t64), a.ksplit);
+  if constexpr (AMODE == MODE_KC || AMODE == MODE_MC) {
+    if constexpr (BMODE == MODE_KC || BMODE == MODE_MC) {
+      if (fast) {
+        if (big) hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 128, 128, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 64, 64, true>), grid, dim3(256), 0, s, a);
+      }
+    }
+  }
+  if (!fast) {
+    if (big) hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 128, 128, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 64, 64, false>), grid, dim3(256), 0, s, a);
   }
   if (a.ksplit > 1) {
     int64_t total = (int64_t)a.M * a.N;
