@@ -238,6 +238,29 @@ int32_t otr_beam_prune(const float* k_score, const int64_t* k_idx, const float* 
                        const int64_t* preds_in, int64_t ldp, int32_t batch, int32_t beam, int32_t t, int32_t eos,
                        float* scores_out, uint8_t* flag_out, int64_t* preds_out, int32_t* n_finished, void* stream);
 
+/* ---- incremental (KV-cached) decoding, SURVEY.md 8f rank 1.  The reference threads a `cache` argument through
+ *      decoder.inference / attention.inference but never fills it (decoder/transformer.py:185-208,
+ *      module/attention.py:86-104, README.md:13 TODO) and re-runs the decoder over the whole prefix each step.
+ *      Here one token per hypothesis is fed per step; every step-dependent scalar is read from DEVICE memory
+ *      (pos = index of the token being fed) so one captured hipGraph serves all steps.
+ * decode_embed: y[r,:] = E[preds[r, *pos], :]*scale + PE[*pos]  (decoder/transformer.py:163-169, model/lm.py:143-150)
+ * decode_self_attention: qkv [rows, 3*H*dk] (q|k|v of the new position); kcache/vcache [rows, maxlen, H*dk] are
+ *   write-once: the new k,v are stored at [r, *pos]; anc int32 [rows, maxlen]: anc[r,j] = cache row that holds
+ *   position j < *pos of hypothesis r (hypotheses form a tree under beam pruning, so caches are never gathered);
+ *   out [rows, H*dk] = softmax(q.k/sqrt(dk)) v over positions 0..*pos.
+ * beam_prune_cached: otr_beam_prune with t = *pos_in + 1, plus anc_out[r'] = anc_in[parent(r')] ++ parent(r') and
+ *   *pos_out = *pos_in + 1 (in/out buffers must be distinct). */
+int32_t otr_decode_embed(const int64_t* preds, int64_t ldp, const int32_t* pos, const float* E, float* y, void* y_bf16,
+                         int64_t rows, int32_t d, int32_t vocab, float scale, void* stream);
+int32_t otr_decode_self_attention(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const int32_t* pos,
+                                  void* out, int32_t dtype, int64_t rows, int32_t H, int32_t dk, int32_t maxlen,
+                                  float scale, void* stream);
+int32_t otr_beam_prune_cached(const float* k_score, const int64_t* k_idx, const float* scores_in, const uint8_t* flag_in,
+                              const int64_t* preds_in, int64_t ldp, int32_t batch, int32_t beam, int32_t eos,
+                              const int32_t* pos_in, int32_t* pos_out, const int32_t* anc_in, int32_t* anc_out,
+                              int32_t ld_anc, float* scores_out, uint8_t* flag_out, int64_t* preds_out,
+                              int32_t* n_finished, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

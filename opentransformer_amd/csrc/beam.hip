@@ -103,12 +103,15 @@ extern "C" int32_t otr_beam_topk(const float* logits, int64_t ld, const float* l
 __global__ __launch_bounds__(256) void beam_prune_kernel(const float* k_score, const int64_t* k_idx, const float* scores_in,
                                                         const uint8_t* flag_in, const int64_t* preds_in, int64_t ldp,
                                                         int beam, int t, int eos, float* scores_out, uint8_t* flag_out,
-                                                        int64_t* preds_out, int32_t* n_finished) {
+                                                        int64_t* preds_out, int32_t* n_finished, const int32_t* pos_in,
+                                                        int32_t* pos_out, const int32_t* anc_in, int32_t* anc_out,
+                                                        int ld_anc) {
   __shared__ float cs[256];
   __shared__ int ci[256];
   __shared__ float c0[256];
   __shared__ int win[MAXK];
   const int b = blockIdx.x, tid = threadIdx.x, nc = beam * beam;
+  if (pos_in) t = *pos_in + 1;                      // cached decoding: prefix length lives on the device
   float s = NEG_INF;
   if (tid < nc) {
     int hyp = b * beam + tid / beam, br = tid % beam;
@@ -147,6 +150,12 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(const float* k_score, c
     int64_t* dst = preds_out + (int64_t)(b * beam + r) * ldp;
     const int64_t* sp = preds_in + (int64_t)src * ldp;
     for (int i = tid; i < t; i += 256) dst[i] = sp[i];
+    if (anc_in) {                                   // re-parent the KV-cache ancestor table (decode.hip)
+      int32_t* ad = anc_out + (int64_t)(b * beam + r) * ld_anc;
+      const int32_t* as = anc_in + (int64_t)src * ld_anc;
+      for (int i = tid; i < t - 1; i += 256) ad[i] = as[i];
+      if (tid == 0) ad[t - 1] = src;
+    }
     if (tid == 0) {
       dst[t] = tok;
       bool f = tok == eos;
@@ -154,6 +163,7 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(const float* k_score, c
       if (f) atomicAdd(n_finished, 1);
     }
   }
+  if (pos_out && b == 0 && tid == 0) *pos_out = t;
 }
 
 extern "C" int32_t otr_beam_prune(const float* k_score, const int64_t* k_idx, const float* scores_in,
@@ -167,6 +177,27 @@ extern "C" int32_t otr_beam_prune(const float* k_score, const int64_t* k_idx, co
   hipStream_t s = (hipStream_t)stream;
   otr_zero_f32(reinterpret_cast<float*>(n_finished), 1, s);   // int32 0 == float 0 bit pattern
   hipLaunchKernelGGL(beam_prune_kernel, dim3(batch), dim3(256), 0, s, k_score, k_idx, scores_in, flag_in, preds_in, ldp,
-                     beam, t, eos, scores_out, flag_out, preds_out, n_finished);
+                     beam, t, eos, scores_out, flag_out, preds_out, n_finished, (const int32_t*)nullptr, (int32_t*)nullptr,
+                     (const int32_t*)nullptr, (int32_t*)nullptr, 0);
   return otr_check_launch("beam_prune");
+}
+
+extern "C" int32_t otr_beam_prune_cached(const float* k_score, const int64_t* k_idx, const float* scores_in,
+                                         const uint8_t* flag_in, const int64_t* preds_in, int64_t ldp, int32_t batch,
+                                         int32_t beam, int32_t eos, const int32_t* pos_in, int32_t* pos_out,
+                                         const int32_t* anc_in, int32_t* anc_out, int32_t ld_anc, float* scores_out,
+                                         uint8_t* flag_out, int64_t* preds_out, int32_t* n_finished, void* stream) {
+  OTR_REQUIRE(k_score && k_idx && scores_in && flag_in && preds_in && scores_out && flag_out && preds_out && n_finished,
+              "beam_prune_cached: null pointer");
+  OTR_REQUIRE(pos_in && pos_out && anc_in && anc_out, "beam_prune_cached: null position / ancestor pointer");
+  OTR_REQUIRE(pos_in != pos_out && anc_in != anc_out && preds_in != preds_out,
+              "beam_prune_cached: in/out buffers must be distinct (ping-pong)");
+  OTR_REQUIRE(beam >= 1 && beam <= MAXK && beam * beam <= 256, "beam_prune_cached: beam=%d must be in [1, 16]", beam);
+  OTR_REQUIRE(batch > 0 && ld_anc > 0 && ld_anc < ldp, "beam_prune_cached: bad shape batch=%d ld_anc=%d ldp=%lld", batch,
+              ld_anc, (long long)ldp);
+  hipStream_t s = (hipStream_t)stream;
+  otr_zero_f32(reinterpret_cast<float*>(n_finished), 1, s);
+  hipLaunchKernelGGL(beam_prune_kernel, dim3(batch), dim3(256), 0, s, k_score, k_idx, scores_in, flag_in, preds_in, ldp,
+                     beam, 0, eos, scores_out, flag_out, preds_out, n_finished, pos_in, pos_out, anc_in, anc_out, ld_anc);
+  return otr_check_launch("beam_prune_cached");
 }

@@ -164,6 +164,13 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// sinusoidal position table entry (module/pos.py:30-42): PE[t,2i] = sin(t*exp(-2i ln(1e4)/d)), PE[t,2i+1] = cos(same)
+__device__ __forceinline__ float pe_value(int t, int col, float neg_ln_over_d) {
+  float div = expf((float)(col & ~1) * neg_ln_over_d);
+  float ang = (float)t * div;
+  return (col & 1) ? cosf(ang) : sinf(ang);
+}
+
 // counter-based RNG for dropout: one 32-bit draw per element index (SplitMix64 finaliser)
 __device__ __forceinline__ uint32_t otr_rand32(uint64_t seed, uint64_t idx) {
   uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);

@@ -1,0 +1,121 @@
+// Incremental (KV-cached) decoding step for the batch beam search.
+//
+// The reference threads a `cache` argument through decoder.inference / attention.inference but never fills it
+// (decoder/transformer.py:185-208, module/attention.py:86-104): every step re-runs the decoder over the whole
+// prefix for every beam.  Here each step feeds ONE token per hypothesis:
+//   * decode_embed:            y[r] = E[preds[r, *pos]] * sqrt(d) + PE[*pos]        (decoder/transformer.py:163-169)
+//   * decode_self_attention:   the new position's q against the cached k/v of its ANCESTORS.  Hypotheses form a
+//                              tree (beam pruning re-parents rows), so instead of gathering the caches after every
+//                              prune, an ancestor table anc[r, j] = cache row holding position j of hypothesis r is
+//                              carried along (updated by beam_prune_cached); the caches themselves are write-once.
+//   * beam_prune_cached:       otr_beam_prune + ancestor-table update, prefix length read from device memory.
+// Every step-dependent scalar (position, prefix length) lives in device memory, so ONE captured hipGraph replays
+// for all steps.  These kernels are HBM/latency bound (one query row per hypothesis): no MFMA.
+#include "common.h"
+
+#define NEG_INF (-__builtin_huge_valf())
+
+__global__ void decode_embed_kernel(const int64_t* preds, int64_t ldp, const int32_t* pos, const float* E, float* y,
+                                    bf16_t* y_lp, int d, int vocab, float scale) {
+  const int64_t r = blockIdx.x;
+  const int p = *pos;
+  const int64_t t = preds[r * ldp + p];
+  const float nl = -logf(10000.f) / (float)d;
+  const bool ok = t >= 0 && t < vocab;
+  for (int col = threadIdx.x; col < d; col += blockDim.x) {
+    float e = ok ? E[t * d + col] : 0.f;
+    float v = e * scale + pe_value(p, col, nl);
+    y[r * d + col] = v;
+    if (y_lp) y_lp[r * d + col] = f2bf(v);
+  }
+}
+
+extern "C" int32_t otr_decode_embed(const int64_t* preds, int64_t ldp, const int32_t* pos, const float* E, float* y,
+                                    void* y_bf16, int64_t rows, int32_t d, int32_t vocab, float scale, void* stream) {
+  OTR_REQUIRE(preds && pos && E && y, "decode_embed: null pointer");
+  OTR_REQUIRE(rows >= 0 && d > 0 && vocab > 0 && ldp > 0, "decode_embed: bad shape");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(decode_embed_kernel, dim3((unsigned)rows), dim3(d >= 256 ? 256 : 64), 0, (hipStream_t)stream, preds,
+                     ldp, pos, E, y, (bf16_t*)y_bf16, d, vocab, scale);
+  return otr_check_launch("decode_embed");
+}
+
+// One wave per (hypothesis row, head).  qkv: [R, 3d] of the new position (columns q|k|v, module/attention.py:73).
+// Phase 0 stores the new k,v into cache[r, p]; phase 1: lane = key position (chunks of 64, online softmax),
+// each lane dots its ancestor's cached key with q (q staged in LDS); phase 2: lane = head dimension, the
+// probabilities are broadcast with shuffles and the value rows are read coalesced.
+template <class T>
+__global__ __launch_bounds__(64) void decode_self_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc,
+                                                             T* __restrict__ vc, const int32_t* __restrict__ anc,
+                                                             const int32_t* __restrict__ pos, T* __restrict__ out,
+                                                             int H, int dk, int maxlen, float scale) {
+  __shared__ float qs[128];
+  const int r = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+  const int d = H * dk;
+  const int p = *pos;                                  // keys 0..p
+  const T* q = qkv + (int64_t)r * 3 * d + h * dk;
+  const T* kn = q + d;
+  const T* vn = q + 2 * d;
+  for (int i = lane; i < dk; i += 64) {
+    qs[i] = ElemIO<T>::ld(q + i);
+    int64_t o = ((int64_t)r * maxlen + p) * d + h * dk + i;
+    kc[o] = kn[i];
+    vc[o] = vn[i];
+  }
+  __syncthreads();
+  float m = NEG_INF, l = 0.f, acc0 = 0.f, acc1 = 0.f;   // acc: dims lane, lane+64
+  for (int c0 = 0; c0 <= p; c0 += 64) {
+    const int j = c0 + lane;
+    float s = NEG_INF;
+    int row = r;
+    if (j <= p) {
+      const T* kp;
+      if (j == p) kp = kn;                              // not read back through the cache: no store->load hazard
+      else {
+        row = anc[(int64_t)r * maxlen + j];
+        kp = kc + ((int64_t)row * maxlen + j) * d + h * dk;
+      }
+      float a = 0.f;
+      for (int i = 0; i < dk; ++i) a += qs[i] * ElemIO<T>::ld(kp + i);
+      s = a * scale;
+    }
+    const float mn = fmaxf(m, wave_max(s));
+    const float pj = (j <= p) ? expf(s - mn) : 0.f;
+    const float corr = expf(m - mn);                    // m = -inf on the first chunk -> 0
+    l = l * corr + wave_sum(pj);
+    acc0 *= corr;
+    acc1 *= corr;
+    m = mn;
+    const int n = min(64, p + 1 - c0);
+    for (int jj = 0; jj < n; ++jj) {
+      const float pv = __shfl(pj, jj);
+      const int rw = __shfl(row, jj);
+      const int jabs = c0 + jj;
+      const T* vp = (jabs == p) ? vn : vc + ((int64_t)rw * maxlen + jabs) * d + h * dk;
+      if (lane < dk) acc0 += pv * ElemIO<T>::ld(vp + lane);
+      if (lane + 64 < dk) acc1 += pv * ElemIO<T>::ld(vp + lane + 64);
+    }
+  }
+  const float inv = 1.f / l;
+  T* o = out + (int64_t)r * d + h * dk;
+  if (lane < dk) ElemIO<T>::st(o + lane, acc0 * inv);
+  if (lane + 64 < dk) ElemIO<T>::st(o + lane + 64, acc1 * inv);
+}
+
+extern "C" int32_t otr_decode_self_attention(const void* qkv, void* kcache, void* vcache, const int32_t* anc,
+                                             const int32_t* pos, void* out, int32_t dtype, int64_t rows, int32_t H,
+                                             int32_t dk, int32_t maxlen, float scale, void* stream) {
+  OTR_REQUIRE(qkv && kcache && vcache && anc && pos && out, "decode_self_attention: null pointer");
+  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_BF16, "decode_self_attention: dtype must be f32 or bf16");
+  OTR_REQUIRE(H > 0 && dk > 0 && dk <= 128 && maxlen > 0 && rows >= 0, "decode_self_attention: bad shape (dk <= 128)");
+  OTR_REQUIRE(rows * H < (1ll << 31), "decode_self_attention: too many rows");
+  if (rows == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OTR_F32)
+    hipLaunchKernelGGL(decode_self_attn_kernel<float>, dim3((unsigned)(rows * H)), dim3(64), 0, s, (const float*)qkv,
+                       (float*)kcache, (float*)vcache, anc, pos, (float*)out, H, dk, maxlen, scale);
+  else
+    hipLaunchKernelGGL(decode_self_attn_kernel<bf16_t>, dim3((unsigned)(rows * H)), dim3(64), 0, s, (const bf16_t*)qkv,
+                       (bf16_t*)kcache, (bf16_t*)vcache, anc, pos, (bf16_t*)out, H, dk, maxlen, scale);
+  return otr_check_launch("decode_self_attention");
+}

@@ -111,11 +111,7 @@ extern "C" int32_t otr_relu_bwd(const void* y, const void* g, void* out, int32_t
 
 // ------------------------------------------------------------------------------------------------ posenc / embedding
 // PE[t, 2i] = sin(t * exp(-2i ln(1e4)/d)), PE[t, 2i+1] = cos(same)        (module/pos.py:30-42)
-__device__ __forceinline__ float pe_value(int t, int col, float neg_ln_over_d) {
-  float div = expf((float)(col & ~1) * neg_ln_over_d);
-  float ang = (float)t * div;
-  return (col & 1) ? cosf(ang) : sinf(ang);
-}
+// (pe_value lives in common.h: the incremental decoder must produce the same bits)
 
 __global__ void posenc_kernel(const float* x, float* y, bf16_t* y_lp, int64_t rows, int T, int d, float scale) {
   const float nl = -logf(10000.f) / (float)d;

@@ -561,6 +561,35 @@ def embed_posenc(tokens, E):
     return attach_lp(y, ylp)
 
 
+# ---------------------------------------------------------------------------------------- incremental decoding
+def decode_embed(preds, pos, E):
+    """y[r] = E[preds[r, *pos]]*sqrt(d) + PE[*pos]; pos is a DEVICE int32 scalar (hipGraph replay)."""
+    _cuda(preds, pos, E)
+    R, ldp = preds.shape
+    V, d = E.shape
+    y = torch.empty((R, d), dtype=torch.float32, device=E.device)
+    ylp = torch.empty((R, d), dtype=torch.bfloat16, device=E.device) if _state['compute'] == 'bf16' else None
+    L.check(L.load().otr_decode_embed(_p(preds), ldp, _p(pos), _p(E), _p(y), _p(ylp), R, d, V, math.sqrt(d), _stream()),
+            'otr_decode_embed')
+    return attach_lp(y, ylp)
+
+
+def decode_self_attention(qkv, kcache, vcache, anc, pos, n_heads):
+    """New-position query against the ancestors' cached keys/values (include/otrans_hip.h)."""
+    _cuda(qkv, kcache, vcache, anc, pos)
+    R, d3 = qkv.shape
+    d = d3 // 3
+    dk = d // n_heads
+    maxlen = kcache.shape[1]
+    assert qkv.is_contiguous() and kcache.dtype == qkv.dtype and kcache.shape == (R, maxlen, d) == vcache.shape
+    assert anc.shape == (R, maxlen) and anc.dtype == torch.int32
+    out = torch.empty((R, d), dtype=qkv.dtype, device=qkv.device)
+    L.check(L.load().otr_decode_self_attention(_p(qkv), _p(kcache), _p(vcache), _p(anc), _p(pos), _p(out), _code(qkv.dtype),
+                                               R, n_heads, dk, maxlen, 1.0 / math.sqrt(dk), _stream()),
+            'otr_decode_self_attention')
+    return out
+
+
 # ---------------------------------------------------------------------------------------- conv frontend
 def conv_geometry(T, F):
     T1 = (T - 3) // 2 + 1

@@ -1,11 +1,17 @@
 """Decode loop: batch beam search with length penalty + LM shallow fusion, CTC greedy
 (otrans/recognize/speech2text.py:6-192, recognize/base.py:26-37,104-119, recognize/ctc.py:38-58).
 
-Same constructor arguments and return values as the reference recognizers.  Per step the decoder is
-re-run over the whole prefix exactly like the reference (decoder/transformer.py:185-208; its KV cache
-is a TODO there -- SURVEY.md 8f rank 1), but the scoring is fused on the device: the [B*beam, V]
-log-prob tensor, the LM fusion add, both top-k's, the finished-beam masking and the prefix gather are
-two kernels (otr_beam_topk, otr_beam_prune) instead of ~25 aten launches.
+Same constructor arguments and return values as the reference recognizers.  Two decode loops:
+
+* apply_cache=False (the reference's behaviour; it forces this at recognize/speech2text.py:22): per step the
+  decoder is re-run over the whole prefix (decoder/transformer.py:185-208), but the scoring is fused on the
+  device: the [B*beam, V] log-prob tensor, the LM fusion add, both top-k's, the finished-beam masking and the
+  prefix gather are two kernels (otr_beam_topk, otr_beam_prune) instead of ~25 aten launches.
+* apply_cache=True (the KV cache is a TODO in the reference, README.md:13): one token per
+  hypothesis per step.  Cross-attention K/V are projected once per UTTERANCE (not per beam, not per step);
+  self-attention K/V live in write-once caches addressed through a beam-tree ancestor table; the position,
+  prefix length and ping-pong state are device-resident, so each step is ONE hipGraph replay
+  (decoder + LM + scoring + pruning).  Hypotheses are identical to the re-forward loop.
 """
 import ctypes as C
 
@@ -114,15 +120,48 @@ class SpeechToTextRecognizer(Recognizer):
         self.beam_width, self.max_len, self.nbest = beam_width, max_len, nbest
         self.penalty, self.lamda, self.ctc_weight, self.lm_weight = penalty, lamda, ctc_weight, lm_weight
         self.attn_weights = {}
-        self.apply_cache = False
+        self.apply_cache = bool(apply_cache)
+        self.use_hipgraph = True
+        self._cached_states = {}
 
     def encode(self, inputs, inputs_mask, cache=None):
         x, mask, fe_cache = self.model.frontend.inference(inputs, inputs_mask, None)
         memory, memory_mask, attn = self.model.encoder(x, mask)
         return memory, memory_mask, {'frontend': fe_cache}, attn
 
+    def _nbest(self, scores, preds, steps, b):
+        """n-best selection on the host: B*beam scalars (speech2text.py:70-93)"""
+        beam = self.beam_width
+        scores_h = scores.cpu().view(b, beam)
+        preds_h = preds[:, :steps + 1].cpu().view(b, beam, -1)
+        lengths = torch.sum(torch.ne(preds_h, EOS).float(), dim=-1)
+        if self.penalty:
+            scores_h = scores_h / torch.pow((self.lamda + lengths) / (self.lamda + 1), self.penalty)
+        sorted_scores, offset = torch.sort(scores_h, dim=-1, descending=True)
+        sorted_preds = torch.gather(preds_h, 1, offset.unsqueeze(-1).expand_as(preds_h))
+        nbest_preds = sorted_preds[:, :min(beam, self.nbest), 1:]
+        nbest_scores = sorted_scores[:, :min(beam, self.nbest)]
+        return self.nbest_translate(nbest_preds), nbest_scores
+
+    @torch.no_grad()
+    def recognize_cached(self, inputs, inputs_mask):
+        memory, memory_mask, _, _ = self.encode(inputs, inputs_mask)
+        b, t, _ = memory.size()
+        key = (b, t, self.beam_width, self.max_len, ops.get_compute_dtype(), str(memory.device),
+               self.lm is not None, bool(self.use_hipgraph))
+        st = self._cached_states.get(key)
+        if st is None:
+            if len(self._cached_states) >= 4:                # a few shapes; each holds caches + two graphs
+                self._cached_states.pop(next(iter(self._cached_states)))
+            st = self._cached_states[key] = CachedBeamState(self, b, t, memory.device)
+        st.load_memory(memory, memory_mask)
+        cur, steps = st.run()
+        return self._nbest(st.scores[cur], st.preds[cur], steps, b)
+
     @torch.no_grad()
     def recognize(self, inputs, inputs_mask):
+        if self.apply_cache:
+            return self.recognize_cached(inputs, inputs_mask)
         beam = self.beam_width
         lib = L.load()
         memory, memory_mask, _, _ = self.encode(inputs, inputs_mask)
@@ -159,17 +198,123 @@ class SpeechToTextRecognizer(Recognizer):
             steps = step
             if int(n_fin.item()) == R:           # the reference syncs here every step too (speech2text.py:67)
                 break
-        # n-best selection on the host: B*beam scalars (speech2text.py:70-93)
-        scores_h = scores[cur].cpu().view(b, beam)
-        preds_h = preds[cur][:, :steps + 1].cpu().view(b, beam, -1)
-        lengths = torch.sum(torch.ne(preds_h, EOS).float(), dim=-1)
-        if self.penalty:
-            scores_h = scores_h / torch.pow((self.lamda + lengths) / (self.lamda + 1), self.penalty)
-        sorted_scores, offset = torch.sort(scores_h, dim=-1, descending=True)
-        sorted_preds = torch.gather(preds_h, 1, offset.unsqueeze(-1).expand_as(preds_h))
-        nbest_preds = sorted_preds[:, :min(beam, self.nbest), 1:]
-        nbest_scores = sorted_scores[:, :min(beam, self.nbest)]
-        return self.nbest_translate(nbest_preds), nbest_scores
+        return self._nbest(scores[cur], preds[cur], steps, b)
+
+
+class CachedBeamState:
+    """Static device state of the cached beam search for one (batch, T', beam, max_len) shape: ping-pong beam
+    buffers, ancestor tables, write-once self-attention caches for the decoder and the LM, per-utterance
+    cross-attention K/V, and the two captured step graphs (even / odd ping-pong phase)."""
+
+    def __init__(self, rec, b, Tm, dev):
+        self.rec, self.b, self.Tm, self.dev = rec, b, Tm, dev
+        dec, lm = rec.model.decoder, rec.lm
+        beam = rec.beam_width
+        R = self.R = b * beam
+        self.maxlen = rec.max_len + 1
+        self.ldp = rec.max_len + 2
+        adt = ops.act_dtype()
+        new = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)    # noqa: E731
+        self.preds = [new((R, self.ldp), torch.long) for _ in range(2)]
+        self.scores = [new((R,), torch.float32) for _ in range(2)]
+        self.flags = [new((R,), torch.uint8) for _ in range(2)]
+        self.pos = [new((1,), torch.int32) for _ in range(2)]
+        self.anc = [new((R, self.maxlen), torch.int32) for _ in range(2)]
+        self.k_score = new((R, beam), torch.float32)
+        self.k_idx = new((R, beam), torch.long)
+        self.n_fin = new((1,), torch.int32)
+        self.score0 = torch.tensor([0.0] + [-float('inf')] * (beam - 1), device=dev).repeat([b]).contiguous()
+        d = dec.d_model
+        self.mem_kv = [new((b, Tm, 2 * d), adt) for _ in dec.blocks]
+        self.mem_mask = new((b, Tm), torch.uint8)
+        self.dec_cache = [(new((R, self.maxlen, d), adt), new((R, self.maxlen, d), adt)) for _ in dec.blocks]
+        self.lm_cache = None
+        if lm is not None:
+            dl = lm.embedding.weight.shape[1]
+            self.lm_cache = [(new((R, self.maxlen, dl), adt), new((R, self.maxlen, dl), adt)) for _ in lm.blocks]
+        self.graphs = [None, None]
+        self.warm = [False, False]
+
+    def load_memory(self, memory, memory_mask):
+        """Project the encoder memory to cross-attention K|V once per utterance and layer
+        (module/attention.py:128-134 does it per hypothesis and per step), then reset the beams."""
+        adt = ops.act_dtype()
+        for blk, kv in zip(self.rec.model.decoder.blocks, self.mem_kv):
+            a = blk.src_attn
+            kv.copy_(ops.linear(memory, a.vk_proj.weight, a.vk_proj.bias, out_dtype=adt))
+        self.mem_mask.copy_(memory_mask.reshape(self.b, self.Tm))
+        self.preds[0].fill_(EOS)
+        self.preds[0][:, 0] = BOS
+        self.scores[0].copy_(self.score0)
+        self.flags[0].zero_()
+        self.pos[0].zero_()
+
+    def _stack_step(self, x, blk, cache, cur):
+        """self-attention sub-layer of one post-norm layer for the new position (encoder/transformer.py:54-56,
+        decoder/transformer.py:66-68)"""
+        a = blk.slf_attn
+        qkv = ops.linear(x, a.qvk_proj.weight, a.qvk_proj.bias, out_dtype=ops.act_dtype())
+        ctx = ops.decode_self_attention(qkv, cache[0], cache[1], self.anc[cur], self.pos[cur], a.nheads)
+        att = ops.linear(ctx, a.output_proj.weight, a.output_proj.bias)
+        return ops.add_layernorm(x, att, blk.norm1.weight, blk.norm1.bias, 0.0, blk.norm1.eps)
+
+    def step(self, cur):
+        """One beam-search step (recognize/speech2text.py:95-146) reading phase `cur`, writing phase cur^1."""
+        rec, lib = self.rec, L.load()
+        dec, lm, beam = rec.model.decoder, rec.lm, rec.beam_width
+        adt = ops.act_dtype()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        x = ops.decode_embed(self.preds[cur], self.pos[cur], dec.embedding.weight)
+        for blk, cache, kv in zip(dec.blocks, self.dec_cache, self.mem_kv):
+            x = self._stack_step(x, blk, cache, cur)
+            a = blk.src_attn
+            q = ops.linear(x, a.q_proj.weight, a.q_proj.bias, out_dtype=adt)
+            # the beam hypotheses of an utterance are the query rows of ONE attention problem over its memory
+            ctx = ops.CrossAttentionFn.apply(q.view(self.b, beam, -1), kv, self.mem_mask, a.nheads)
+            att = ops.linear(ctx.view(self.R, -1), a.output_proj.weight, a.output_proj.bias)
+            x = ops.add_layernorm(x, att, blk.norm2.weight, blk.norm2.bias, 0.0, blk.norm2.eps)
+            x = ops.add_layernorm(x, blk.feed_forward(x), blk.norm3.weight, blk.norm3.bias, 0.0, blk.norm3.eps)
+        logits = ops.linear(x, dec.output_layer.weight, dec.output_layer.bias)
+        V = logits.size(-1)
+        lm_logits = None
+        if lm is not None:
+            y = ops.decode_embed(self.preds[cur], self.pos[cur], lm.embedding.weight)
+            for blk, cache in zip(lm.blocks, self.lm_cache):
+                y = self._stack_step(y, blk, cache, cur)
+                y = ops.add_layernorm(y, blk.feed_forward(y), blk.norm2.weight, blk.norm2.bias, 0.0, blk.norm2.eps)
+            lm_logits = ops.linear(y, lm.output_project.weight, lm.output_project.bias)
+        L.check(lib.otr_beam_topk(_ptr(logits), V, _ptr(lm_logits), V, float(rec.lm_weight or 0.0), self.R, V, beam,
+                                  _ptr(self.k_score), _ptr(self.k_idx), stream), 'otr_beam_topk')
+        nxt = cur ^ 1
+        L.check(lib.otr_beam_prune_cached(_ptr(self.k_score), _ptr(self.k_idx), _ptr(self.scores[cur]),
+                                          _ptr(self.flags[cur]), _ptr(self.preds[cur]), self.ldp, self.b, beam, EOS,
+                                          _ptr(self.pos[cur]), _ptr(self.pos[nxt]), _ptr(self.anc[cur]),
+                                          _ptr(self.anc[nxt]), self.maxlen, _ptr(self.scores[nxt]), _ptr(self.flags[nxt]),
+                                          _ptr(self.preds[nxt]), _ptr(self.n_fin), stream), 'otr_beam_prune_cached')
+
+    def _launch(self, cur):
+        if not self.rec.use_hipgraph:
+            return self.step(cur)
+        if self.graphs[cur] is not None:
+            return self.graphs[cur].replay()
+        if not self.warm[cur]:            # first visit runs eagerly: creates weight shadows, workspace, allocator state
+            self.warm[cur] = True
+            return self.step(cur)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.step(cur)
+        self.graphs[cur] = g
+        g.replay()
+
+    def run(self):
+        cur, steps = 0, 0
+        for step in range(1, self.rec.max_len + 1):
+            self._launch(cur)
+            cur ^= 1
+            steps = step
+            if int(self.n_fin.item()) == self.R:      # the reference syncs here every step too (speech2text.py:67)
+                break
+        return cur, steps
 
 
 class CTCRecognizer(Recognizer):

@@ -107,3 +107,171 @@ def test_beam_kernels_against_torch():
     rs, ri = ref.topk(k)
     assert torch.equal(ki, ri)
     torch.testing.assert_close(ks, rs, rtol=1e-5, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------- KV-cached decoding (8f rank 1)
+DECODE_CASES = [('greedy', dict(beam_width=1, nbest=1, max_len=12, penalty=0.0), False),
+                ('beam5', dict(beam_width=5, nbest=5, max_len=12, penalty=0.6, lamda=5), False),
+                ('beam5_lm', dict(beam_width=5, nbest=3, max_len=12, penalty=0.6, lamda=5, lm_weight=0.3), True)]
+
+
+def test_cached_beam_search_matches_reference_fp32(golden):
+    """apply_cache=True (one token per step, hipGraph replay) must reproduce the reference recognizer's
+    hypotheses and scores; eager-cached, graph-cached and a re-run on the warmed state all agree."""
+    from opentransformer_amd import ops
+    from opentransformer_amd.recognize import SpeechToTextRecognizer
+    g = golden('c1_decode.npz')
+    try:
+        model, lm = load_models(g, 'fp32')
+        x, m = torch.from_numpy(g['inputs']).to(DEV), torch.from_numpy(g['mask']).to(DEV)
+        idx2unit = {i: str(i) for i in range(100)}
+        for tag, kw, use_lm in DECODE_CASES:
+            kw = dict(kw, lm=lm) if use_lm else kw
+            want = g[tag + '_hyp']
+            for graph in (False, True):
+                rec = SpeechToTextRecognizer(model, idx2unit=idx2unit, ngpu=1, apply_cache=True, **kw)
+                rec.use_hipgraph = graph
+                for rerun in range(3 if graph else 1):          # re-runs replay the captured graphs from step 1
+                    nbest, scores = rec.recognize(x, m)
+                    assert np.array_equal(hyp_arr(nbest, want), want), (tag, graph, rerun)
+                    np.testing.assert_allclose(scores.numpy(), g[tag + '_score'], rtol=2e-4, atol=2e-4)
+                if graph:
+                    st = next(iter(rec._cached_states.values()))
+                    assert st.graphs[0] is not None and st.graphs[1] is not None
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
+def test_cached_beam_search_bf16_matches_uncached(golden):
+    from opentransformer_amd import ops
+    from opentransformer_amd.recognize import SpeechToTextRecognizer
+    g = golden('c1_decode.npz')
+    try:
+        model, lm = load_models(g, 'bf16')
+        x, m = torch.from_numpy(g['inputs']).to(DEV), torch.from_numpy(g['mask']).to(DEV)
+        idx2unit = {i: str(i) for i in range(100)}
+        for tag, kw, use_lm in DECODE_CASES:
+            kw = dict(kw, lm=lm) if use_lm else kw
+            want = g[tag + '_hyp']
+            ref_s = g[tag + '_score']
+            nbest, scores = SpeechToTextRecognizer(model, idx2unit=idx2unit, apply_cache=True, **kw).recognize(x, m)
+            clear = np.ones(len(want), bool) if ref_s.shape[1] < 2 else (ref_s[:, 0] - ref_s[:, 1]) > 0.1
+            assert np.array_equal(hyp_arr(nbest, want)[clear, 0], want[clear, 0]), tag
+            np.testing.assert_allclose(scores.numpy()[clear, 0], ref_s[clear, 0], rtol=5e-2, atol=5e-2)
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_cached_decode_full_size_c5(mode):
+    """C5 shape (transformer_baseline dims, beam 10, 4-block LM fusion, V=4234): with EOS suppressed so every
+    hypothesis runs the full max_len, the cached loop and the reference-style re-forward loop agree."""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops
+    from opentransformer_amd.recognize import SpeechToTextRecognizer, TransformerLanguageModel
+    ops.set_compute_dtype(mode)
+    try:
+        cfg = syn.c2_model(0.0, n_enc=2)
+        model = ota.SpeechToText(cfg)
+        syn.fill_state_dict_(model.state_dict(), 7)
+        lm = TransformerLanguageModel(syn.lm_config(4234, num_blocks=2))
+        syn.fill_state_dict_(lm.state_dict(), 8)
+        with torch.no_grad():
+            model.decoder.output_layer.bias[1] = -30.0          # EOS never wins: decode runs max_len steps
+        model, lm = model.to(DEV).eval(), lm.to(DEV).eval()
+        inputs, _ = syn.synthetic_batch(batch=3, frames=400, feat_dim=80, vocab=4234, tgt_len=5, seed=3,
+                                        lengths=[400, 333, 250])
+        x, m = inputs['inputs'].to(DEV), inputs['mask'].to(DEV)
+        idx2unit = {i: str(i) for i in range(4234)}
+        kw = dict(beam_width=10, nbest=10, max_len=16, penalty=0.6, lamda=5, lm=lm, lm_weight=0.1, idx2unit=idx2unit)
+        ref_h, ref_s = SpeechToTextRecognizer(model, apply_cache=False, **kw).recognize(x, m)
+        rec = SpeechToTextRecognizer(model, apply_cache=True, **kw)
+        for _ in range(2):
+            got_h, got_s = rec.recognize(x, m)
+            if mode == 'fp32':
+                assert got_h == ref_h
+                np.testing.assert_allclose(got_s.numpy(), ref_s.numpy(), rtol=1e-4, atol=1e-4)
+            else:
+                assert [h[0] for h in got_h] == [h[0] for h in ref_h] or \
+                    np.allclose(got_s.numpy()[:, 0], ref_s.numpy()[:, 0], rtol=2e-2, atol=5e-2)
+                np.testing.assert_allclose(got_s.numpy()[:, 0], ref_s.numpy()[:, 0], rtol=2e-2, atol=5e-2)
+        assert all(len(h[0].split()) == 16 for h in got_h)
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_decode_self_attention_kernel(dtype):
+    """One new query per hypothesis against a tree-structured cache (ancestor table), positions beyond one
+    64-lane chunk, vs a dense torch reference that gathers each hypothesis' ancestor rows."""
+    from opentransformer_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    R, H, dk, maxlen, p = 7, 4, 24, 150, 133
+    d = H * dk
+    qkv = torch.randn(R, 3 * d, generator=gen).to(DEV, dtype)
+    kc = torch.randn(R, maxlen, d, generator=gen).to(DEV, dtype)
+    vc = torch.randn(R, maxlen, d, generator=gen).to(DEV, dtype)
+    anc = torch.randint(0, R, (R, maxlen), generator=gen).to(DEV, torch.int32)
+    pos = torch.tensor([p], dtype=torch.int32, device=DEV)
+    kc0, vc0 = kc.clone(), vc.clone()
+    out = ops.decode_self_attention(qkv, kc, vc, anc, pos, H).float()
+    q, kn, vn = [t.float() for t in qkv.split(d, dim=-1)]
+    rows = anc[:, :p].long()                                                    # [R,p]
+    K = torch.cat([kc0.float()[rows, torch.arange(p, device=DEV)], kn[:, None]], 1)      # [R,p+1,d]
+    Vv = torch.cat([vc0.float()[rows, torch.arange(p, device=DEV)], vn[:, None]], 1)
+    s = torch.einsum('rhd,rjhd->rhj', q.view(R, H, dk), K.view(R, p + 1, H, dk)) / dk ** 0.5
+    ref = torch.einsum('rhj,rjhd->rhd', s.softmax(-1), Vv.view(R, p + 1, H, dk)).reshape(R, d)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    torch.testing.assert_close(out, ref, rtol=tol, atol=tol)
+    # the new k/v were stored at position p of the hypothesis' own row, everything else untouched
+    assert torch.equal(kc[:, p], qkv[:, d:2 * d]) and torch.equal(vc[:, p], qkv[:, 2 * d:])
+    kc[:, p], vc[:, p] = kc0[:, p], vc0[:, p]
+    assert torch.equal(kc, kc0) and torch.equal(vc, vc0)
+
+
+def test_decode_embed_and_prune_cached_kernels():
+    import ctypes as C
+    from opentransformer_amd import _lib as L
+    from opentransformer_amd import ops
+    lib = L.load()
+    gen = torch.Generator().manual_seed(9)
+    p = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # embed at a device-side position == column `pos` of the full embed+posenc
+    R, ldp, V, d, pos_i = 6, 9, 50, 32, 4
+    preds = torch.randint(0, V, (R, ldp), generator=gen).to(DEV)
+    E = torch.randn(V, d, generator=gen).to(DEV)
+    pos = torch.tensor([pos_i], dtype=torch.int32, device=DEV)
+    full = ops.embed_posenc(preds, E)
+    one = ops.decode_embed(preds, pos, E)
+    assert torch.equal(one, full[:, pos_i])
+    # prune_cached == prune (+ ancestor re-parenting, + position increment)
+    batch, beam, t = 3, 4, 5
+    Rb, ldp, maxlen = batch * beam, 12, 11
+    ks = torch.randn(Rb, beam, generator=gen).to(DEV)
+    ki = torch.randint(0, 30, (Rb, beam), generator=gen).to(DEV)
+    ki[2, 0] = 1
+    sc = torch.randn(Rb, generator=gen).to(DEV)
+    fl = (torch.rand(Rb, generator=gen) < 0.3).to(DEV, torch.uint8)
+    pr = torch.randint(2, 30, (Rb, ldp), generator=gen).to(DEV)
+    anc = torch.randint(0, Rb, (Rb, maxlen), generator=gen).to(DEV, torch.int32)
+    o = dict(s=torch.empty_like(sc), f=torch.empty_like(fl), p=torch.zeros_like(pr), n=torch.zeros(1, dtype=torch.int32, device=DEV))
+    L.check(lib.otr_beam_prune(p(ks), p(ki), p(sc), p(fl), p(pr), ldp, batch, beam, t, 1, p(o['s']), p(o['f']), p(o['p']),
+                               p(o['n']), st), 'prune')
+    c = dict(s=torch.empty_like(sc), f=torch.empty_like(fl), p=torch.zeros_like(pr), n=torch.zeros(1, dtype=torch.int32, device=DEV))
+    pin = torch.tensor([t - 1], dtype=torch.int32, device=DEV)
+    pout = torch.zeros(1, dtype=torch.int32, device=DEV)
+    anc2 = torch.full_like(anc, -1)
+    L.check(lib.otr_beam_prune_cached(p(ks), p(ki), p(sc), p(fl), p(pr), ldp, batch, beam, 1, p(pin), p(pout), p(anc), p(anc2),
+                                      maxlen, p(c['s']), p(c['f']), p(c['p']), p(c['n']), st), 'prune_cached')
+    for k in o:
+        assert torch.equal(o[k], c[k]), k
+    assert int(pout) == t
+    # parent of each surviving hypothesis = the row whose prefix it inherited
+    for r in range(Rb):
+        u = r // beam
+        parents = [q for q in range(u * beam, (u + 1) * beam) if torch.equal(pr[q, :t], c['p'][r, :t])]
+        par = int(anc2[r, t - 1])
+        assert par in parents
+        assert torch.equal(anc2[r, :t - 1], anc[par, :t - 1])
+        assert bool((anc2[r, t:] == -1).all())

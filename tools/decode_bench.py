@@ -1,0 +1,104 @@
+"""C5 decode benchmark: batch beam search, beam 10, TransformerLM shallow fusion (4 blocks),
+transformer_baseline dims, T=1000 frames, max_len 60, EOS suppressed so every hypothesis runs all 60 steps
+(random-init weights would stop at step 1).  Prints one JSON line: utterances/s and ms per decode step for the
+reference-style re-forward loop, the KV-cached loop (eager launches) and the KV-cached loop under hipGraph replay,
+plus (optional) the CPU oracle on a bounded sample.
+
+    python tools/decode_bench.py [--batch 8] [--beam 10] [--max-len 60] [--mode bf16] [--cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from opentransformer_amd import synthetic as syn      # noqa: E402
+
+
+def build(mode, dev):
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops
+    from opentransformer_amd.recognize import TransformerLanguageModel
+    ops.set_compute_dtype(mode)
+    model = ota.SpeechToText(syn.c2_model(0.0))
+    syn.fill_state_dict_(model.state_dict(), 1234)
+    lm = TransformerLanguageModel(syn.lm_config(4234))
+    syn.fill_state_dict_(lm.state_dict(), 4321)
+    with torch.no_grad():
+        model.decoder.output_layer.bias[1] = -30.0
+    return model.to(dev).eval(), lm.to(dev).eval()
+
+
+def timed(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--frames', type=int, default=1000)
+    ap.add_argument('--beam', type=int, default=10)
+    ap.add_argument('--max-len', type=int, default=60)
+    ap.add_argument('--mode', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--iters', type=int, default=3)
+    ap.add_argument('--cpu-baseline', action='store_true')
+    args = ap.parse_args()
+    from opentransformer_amd.recognize import SpeechToTextRecognizer
+    dev = torch.device('cuda:0')
+    model, lm = build(args.mode, dev)
+    inputs, _ = syn.synthetic_batch(args.batch, args.frames, 80, 4234, 15, seed=0)
+    x, m = inputs['inputs'].to(dev), inputs['mask'].to(dev)
+    idx2unit = {i: str(i) for i in range(4234)}
+    kw = dict(beam_width=args.beam, nbest=1, max_len=args.max_len, penalty=0.6, lamda=5, lm=lm, lm_weight=0.1,
+              idx2unit=idx2unit)
+    res = {}
+    hyps = {}
+    with torch.no_grad():
+        enc = SpeechToTextRecognizer(model, **kw)
+        t_enc, _ = timed(lambda: enc.encode(x, m), args.iters)
+    for tag, cache, graph in (('reforward', False, False), ('cached_eager', True, False), ('cached_hipgraph', True, True)):
+        rec = SpeechToTextRecognizer(model, apply_cache=cache, **kw)
+        rec.use_hipgraph = graph
+        t, (h, s) = timed(lambda: rec.recognize(x, m), args.iters)
+        hyps[tag] = [u[0] for u in h]
+        res[tag] = {'s_per_batch': t, 'utt_per_s': args.batch / t,
+                    'ms_per_step': (t - t_enc) * 1e3 / args.max_len}
+    same = sum(a == b for a, b in zip(hyps['reforward'], hyps['cached_hipgraph']))
+    out = {'metric': 'decode utterances/sec (C5: beam %d + TransformerLM fusion, max_len %d, %d frames)'
+                     % (args.beam, args.max_len, args.frames),
+           'value': res['cached_hipgraph']['utt_per_s'], 'unit': 'utterances/s', 'dtype': args.mode,
+           'batch': args.batch, 'encode_ms': t_enc * 1e3, 'loops': res,
+           'speedup_vs_reforward': res['reforward']['s_per_batch'] / res['cached_hipgraph']['s_per_batch'],
+           'identical_1best': '%d/%d' % (same, args.batch),
+           'tokens_per_hyp': len(hyps['cached_hipgraph'][0].split())}
+    if args.cpu_baseline:
+        from oracle import otrans_oracle as orc
+        from tests import helpers as H
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        cfg = syn.c2_model(0.0)
+        parts = H.filled_state(cfg)
+        parts['decoder']['output_layer.bias'][1] = -30.0
+        lm_cfg = syn.lm_config(4234)
+        lmp = H.lm_state(lm_cfg)
+        nb, ml = 1, min(args.max_len, 12)
+        t0 = time.perf_counter()
+        orc.beam_search(parts, cfg, inputs['inputs'][:nb], inputs['mask'][:nb], beam=args.beam, nbest=1, max_len=ml,
+                        penalty=0.6, lamda=5, lm=(lmp, lm_cfg), lm_weight=0.1)
+        dt = time.perf_counter() - t0
+        out['cpu_baseline'] = {'s_per_utt_at_max_len_%d' % ml: dt / nb, 'cores': torch.get_num_threads(), 'kind': 'port',
+                               'sample': 'CPU oracle beam search (re-forward, like the reference), %d utterance, '
+                                         'max_len %d' % (nb, ml)}
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
