@@ -32,6 +32,9 @@ extern "C" {
 int32_t otr_version(void);
 /* tuning hook for benchmarks: key 0 = force GEMM tile (0 auto / 64 / 128), key 1 = force split-K (0 auto) */
 int32_t otr_debug_set(int32_t key, int32_t value);
+/* tuning hook: when buf != NULL every GEMM workgroup writes 4 shader-clock timestamps (start, operands staged,
+ * k-loop done, stores issued) to buf[(blockIdx.y*gridDim.x + blockIdx.x)*4 ..]; NULL disables.  Not for production. */
+int32_t otr_debug_trace(void* buf);
 const char* otr_last_error_string(void);
 
 /* ---- nn.Linear and its gradients (module/attention.py:43,68,128-129; module/ffn.py:39-41;
@@ -107,10 +110,12 @@ typedef struct {
 int32_t otr_add_layernorm_fwd(const otr_ln_desc_t* d, const float* x, const void* a, const float* gamma,
                               const float* beta, const uint64_t* seed, float* y, void* y_bf16, float* z, float* mean,
                               float* rstd, void* stream);
-/* dx f32 [M,d] (residual grad), da [M,d] a_dtype (branch grad, may be NULL), dgamma/dbeta f32[d] +=. */
+/* dx f32 [M,d] (residual grad), da [M,d] a_dtype (branch grad, may be NULL), dgamma/dbeta f32[d] +=.
+ * da_colsum (f32[d] +=, may be NULL): column sums of da, i.e. the bias gradient of the Linear that produced the
+ * branch (module/attention.py:43 output_proj, module/ffn.py:41 w_2) without a separate reduction launch. */
 int32_t otr_add_layernorm_bwd(const otr_ln_desc_t* d, const float* dy, const float* z, const float* mean,
                               const float* rstd, const float* gamma, const uint64_t* seed, float* dx, void* da,
-                              float* dgamma, float* dbeta, void* stream);
+                              float* dgamma, float* dbeta, float* da_colsum, void* stream);
 
 /* ---- F.glu / F.relu on the FFN hidden (module/ffn.py:15-21,40): u[M,F] = h[:, :F]*sigmoid(h[:, F:]) */
 /* row_mask (uint8 [M], may be NULL): rows with mask 0 produce u = 0 / dh = 0 (module/conformer.py:46) */
@@ -237,6 +242,13 @@ int32_t otr_beam_topk(const float* logits, int64_t ld, const float* lm_logits, i
 int32_t otr_beam_prune(const float* k_score, const int64_t* k_idx, const float* scores_in, const uint8_t* flag_in,
                        const int64_t* preds_in, int64_t ldp, int32_t batch, int32_t beam, int32_t t, int32_t eos,
                        float* scores_out, uint8_t* flag_out, int64_t* preds_out, int32_t* n_finished, void* stream);
+
+/* ---- transposed copies of many matrices in ONE launch (the W^T bf16 shadows that turn dx = dy.W into a
+ *      forward-type GEMM; refreshed after every optimizer step).  table: DEVICE int64 [n_mats,4] rows of
+ *      {element offset, rows, cols, first tile}; matrix i is src+offset [rows,cols] row-major and is written to
+ *      dst+offset as [cols,rows]; tiles are 64x64, total_tiles = sum of ceil(rows/64)*ceil(cols/64). */
+int32_t otr_transpose_batched(const void* src, void* dst, const int64_t* table, int32_t n_mats, int64_t total_tiles,
+                              int32_t elem_bytes, void* stream);
 
 /* ---- incremental (KV-cached) decoding, SURVEY.md 8f rank 1.  The reference threads a `cache` argument through
  *      decoder.inference / attention.inference but never fills it (decoder/transformer.py:185-208,

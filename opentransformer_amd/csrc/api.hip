@@ -34,6 +34,8 @@ void otr_zero_f32(float* p, int64_t n, hipStream_t s) {
 int g_otr_force_tile = 0;
 int g_otr_force_ksplit = 0;
 int g_otr_force_generic = 0;
+unsigned long long* g_otr_trace = nullptr;
+extern "C" int32_t otr_debug_trace(void* buf) { g_otr_trace = (unsigned long long*)buf; return 0; }
 extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   if (key == 0) g_otr_force_tile = value;
   else if (key == 1) g_otr_force_ksplit = value;
@@ -86,7 +88,7 @@ extern "C" int32_t otr_linear_fwd(const otr_linear_desc_t* d, const void* x, con
   a.act = d->act; a.accumulate = d->accumulate;
   a.a_vec = kc_vec(x, d->ldx, d->x_dtype);
   a.b_vec = kc_vec(w, d->ldw, d->w_dtype);
-  a.allow_split = 1; a.ws = (float*)workspace; a.ws_bytes = workspace_bytes;
+  a.allow_split = 1; a.ws = (float*)workspace; a.ws_bytes = workspace_bytes; a.trace = g_otr_trace;
   return run_gemm(a, d->compute, d->x_dtype, d->w_dtype, d->y_dtype, MODE_KC, MODE_KC, stream);
 }
 
@@ -101,7 +103,7 @@ extern "C" int32_t otr_linear_dgrad(const otr_linear_desc_t* d, const void* dy, 
   a.act = OTR_ACT_NONE; a.accumulate = d->accumulate;
   a.a_vec = kc_vec(dy, d->ldy, d->y_dtype);
   a.b_vec = mc_vec(w, d->ldw, d->w_dtype, d->compute);
-  a.allow_split = 1; a.ws = (float*)workspace; a.ws_bytes = workspace_bytes;
+  a.allow_split = 1; a.ws = (float*)workspace; a.ws_bytes = workspace_bytes; a.trace = g_otr_trace;
   return run_gemm(a, d->compute, d->y_dtype, d->w_dtype, d->x_dtype, MODE_KC, MODE_MC, stream);
 }
 
@@ -116,7 +118,7 @@ extern "C" int32_t otr_linear_wgrad(const otr_linear_desc_t* d, const void* dy, 
   a.act = OTR_ACT_NONE; a.accumulate = d->accumulate;
   a.a_vec = mc_vec(dy, d->ldy, d->y_dtype, d->compute);
   a.b_vec = mc_vec(x, d->ldx, d->x_dtype, d->compute);
-  a.allow_split = 1; a.ws = (float*)workspace; a.ws_bytes = workspace_bytes;
+  a.allow_split = 1; a.ws = (float*)workspace; a.ws_bytes = workspace_bytes; a.trace = g_otr_trace;
   if (d->M == 0) return 0;
   return run_gemm(a, d->compute, d->y_dtype, d->x_dtype, d->w_dtype, MODE_MC, MODE_MC, stream);
 }
@@ -179,6 +181,6 @@ extern "C" int32_t otr_conv2_wgrad(const otr_conv_desc_t* d, const void* dact2, 
   a.act = OTR_ACT_NONE; a.accumulate = 0;
   a.a_vec = mc_vec(dact2, a.lda, d->act_dtype, d->compute);
   a.b_vec = ((uintptr_t)act1 % 16 == 0);
-  a.allow_split = 1; a.ws = (float*)workspace; a.ws_bytes = workspace_bytes;
+  a.allow_split = 1; a.ws = (float*)workspace; a.ws_bytes = workspace_bytes; a.trace = g_otr_trace;
   return run_gemm(a, d->compute, d->act_dtype, d->act_dtype, OTR_F32, MODE_MC, MODE_IM2M, stream);
 }

@@ -243,3 +243,46 @@ extern "C" int32_t otr_colsum(const void* a, int32_t dtype, int64_t M, int64_t N
   else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)a, M, N, lda, out);
   return otr_check_launch("colsum");
 }
+
+// ------------------------------------------------------------------------------------------------ batched transpose
+// One launch transposes every 2-D weight shadow: block -> (matrix, 64x64 tile) by binary search in the tile prefix.
+template <class T>
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                               const int64_t* __restrict__ table, int n_mats) {
+  __shared__ T tile[64][65];
+  const int64_t b = blockIdx.x;
+  int lo = 0, hi = n_mats - 1;
+  while (lo < hi) {                                   // last matrix whose first tile <= b
+    int mid = (lo + hi + 1) >> 1;
+    if (table[mid * 4 + 3] <= b) lo = mid; else hi = mid - 1;
+  }
+  const int64_t off = table[lo * 4], rows = table[lo * 4 + 1], cols = table[lo * 4 + 2];
+  const int64_t t = b - table[lo * 4 + 3];
+  const int64_t tc = (cols + 63) >> 6;
+  const int64_t r0 = (t / tc) << 6, c0 = (t % tc) << 6;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const T* s = src + off;
+  T* d = dst + off;
+  for (int r = ty; r < 64; r += 4)
+    if (r0 + r < rows && c0 + tx < cols) tile[r][tx] = s[(r0 + r) * cols + c0 + tx];
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4)
+    if (c0 + c < cols && r0 + tx < rows) d[(c0 + c) * rows + r0 + tx] = tile[tx][c];
+}
+
+extern "C" int32_t otr_transpose_batched(const void* src, void* dst, const int64_t* table, int32_t n_mats,
+                                         int64_t total_tiles, int32_t elem_bytes, void* stream) {
+  OTR_REQUIRE(src && dst && table, "transpose_batched: null pointer");
+  OTR_REQUIRE(src != dst, "transpose_batched: in-place transposition is not supported");
+  OTR_REQUIRE(elem_bytes == 2 || elem_bytes == 4, "transpose_batched: elem_bytes must be 2 or 4");
+  OTR_REQUIRE(n_mats >= 0 && total_tiles >= 0 && total_tiles < (1ll << 31), "transpose_batched: bad sizes");
+  if (n_mats == 0 || total_tiles == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (elem_bytes == 2)
+    hipLaunchKernelGGL(transpose_batched_kernel<uint16_t>, dim3((unsigned)total_tiles), dim3(256), 0, s,
+                       (const uint16_t*)src, (uint16_t*)dst, table, n_mats);
+  else
+    hipLaunchKernelGGL(transpose_batched_kernel<uint32_t>, dim3((unsigned)total_tiles), dim3(256), 0, s,
+                       (const uint32_t*)src, (uint32_t*)dst, table, n_mats);
+  return otr_check_launch("transpose_batched");
+}

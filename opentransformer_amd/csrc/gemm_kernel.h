@@ -45,6 +45,7 @@ struct GemmArgs {
   int allow_split;   // caller permits split-K (needs a workspace)
   float* ws;         // split-K workspace: ksplit partial [M,N] fp32 slabs, reduced in a fixed order
   int64_t ws_bytes;
+  unsigned long long* trace;  // tuning hook (otr_debug_trace): per-workgroup phase timestamps, or NULL
   ConvGeom cg;
 };
 
@@ -108,8 +109,8 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
   static constexpr int NP = ROWMAJOR ? 1 : (RG * KCH + 255) / 256;
   // same-type row-major operands are staged as raw 16-byte chunks (no float round trip)
   static constexpr bool RAWQ = ROWMAJOR && std::is_same<ST, CT>::value;
-  // prefetch ring: FAST raw loaders keep DEPTH stages in registers (DEPTH-1 in flight beyond the one consumed)
-  static constexpr int DEPTH = (RAWQ && FAST && MODE == MODE_KC) ? 3 : 1;
+  // prefetch ring: FAST raw loaders keep DEPTH stages in registers (a 3-slot ring spilled: 96 VGPRs + 64 accumulators)
+  static constexpr int DEPTH = (RAWQ && FAST && MODE == MODE_KC) ? 2 : 1;
   // every thread owns a full set of units (true for all tile shapes instantiated): lets stores/loads drop the
   // per-unit activity test the compiler cannot fold (it does not know threadIdx.x < 256)
   static constexpr bool ALLACTIVE = ROWMAJOR ? ((ROWS * KCH) % 256 == 0) : ((RG * KCH) % 256 == 0);
@@ -369,6 +370,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
   const int kt0 = blockIdx.y * per;
   const int kt1 = min(nk_total, kt0 + per);
   if (kt0 >= kt1) return;
+#define OTR_TRACE(slot)                                                                                    \
+  if (p.trace && tid == 0) p.trace[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (slot)] = __builtin_readcyclecounter();
+  OTR_TRACE(0)
 
   TileLoader<CT, AT, AMODE, BM, FAST> la;
   TileLoader<CT, BT, BMODE, BN, FAST> lb;
@@ -383,8 +387,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
 
   using LA = TileLoader<CT, AT, AMODE, BM, FAST>;
   using LB = TileLoader<CT, BT, BMODE, BN, FAST>;
-  // prefetch distance: 3 register stages when both operands are staged raw, else the classic 1
-  constexpr int D = (LA::DEPTH == 3 && LB::DEPTH == 3) ? 3 : 1;
+  // prefetch distance: 2 register stages when both operands are staged raw, else the classic 1
+  constexpr int D = (LA::DEPTH == 2 && LB::DEPTH == 2) ? 2 : 1;
   const int fr = lane & 15, fg = lane >> 4;
 
   auto compute = [&](int cur) {
@@ -411,63 +415,83 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
     }
   };
 
+  // Control flow inside the k-loop is kept free of conditional loads/stores: a load that is issued on only one
+  // side of a join makes hipcc's waitcnt insertion fall back to `s_waitcnt vmcnt(0)` at the join, which drains the
+  // whole prefetch ring every step (seen in the ISA).  So the steady-state bodies below issue their loads and LDS
+  // stores unconditionally and the loop tails are peeled into straight-line code.
   if constexpr (D == 1) {
     la.template load<0>(kt0 * BK, p.cg, tid);
     lb.template load<0>(kt0 * BK, p.cg, tid);
     la.template store<0>(smem, tid, kt0 * BK);
     lb.template store<0>(smem + BM * ROWB, tid, kt0 * BK);
     __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
+    OTR_TRACE(1)
+    int kt = kt0;
+    for (; kt + 1 < kt1; ++kt) {
       const int cur = (kt - kt0) & 1;
-      const bool more = kt + 1 < kt1;
-      if (more) {
-        la.template load<0>((kt + 1) * BK, p.cg, tid);
-        lb.template load<0>((kt + 1) * BK, p.cg, tid);
-      }
-      compute(cur);
-      if (more) {
-        la.template store<0>(smem + (cur ^ 1) * BUF, tid, (kt + 1) * BK);
-        lb.template store<0>(smem + (cur ^ 1) * BUF + BM * ROWB, tid, (kt + 1) * BK);
-      }
+      la.template load<0>((kt + 1) * BK, p.cg, tid);
+      lb.template load<0>((kt + 1) * BK, p.cg, tid);
+      __builtin_amdgcn_sched_barrier(0);   // the scheduler otherwise sinks the loads below the MFMAs and hoists
+      compute(cur);                        // their first use above them, i.e. waits for them with nothing to overlap
+      __builtin_amdgcn_sched_barrier(0);
+      la.template store<0>(smem + (cur ^ 1) * BUF, tid, (kt + 1) * BK);
+      lb.template store<0>(smem + (cur ^ 1) * BUF + BM * ROWB, tid, (kt + 1) * BK);
       __syncthreads();
     }
+    compute((kt - kt0) & 1);
   } else {
-    // stage s lives in ring slot s % 3.  Sub-step for stage t (already in LDS buffer t&1):
-    //   issue loads of stage t+3 into the slot stage t just vacated -> MFMAs of stage t -> write stage t+1 from its
-    //   slot to the other LDS buffer (waits only for THAT stage's loads; two younger stages stay in flight) -> barrier
+    // 2-slot register ring: stage s lives in slot (s - kt0) & 1 and is staged to LDS buffer (s - kt0) & 1.
+    // Sub-step for stage t (already in LDS): issue the loads of stage t+2 into the slot stage t vacated -> MFMAs of
+    // stage t -> write stage t+1 from its slot to the other LDS buffer (counted vmcnt: the 8 loads of stage t+2 stay
+    // in flight across the barrier) -> barrier.
+    const int klast = (kt1 - 1) * BK;              // a prologue load beyond the slice is clamped (redundant, unused)
     la.template load<0>(kt0 * BK, p.cg, tid);
     lb.template load<0>(kt0 * BK, p.cg, tid);
-    if (kt0 + 1 < kt1) { la.template load<1>((kt0 + 1) * BK, p.cg, tid); lb.template load<1>((kt0 + 1) * BK, p.cg, tid); }
-    if (kt0 + 2 < kt1) { la.template load<2>((kt0 + 2) * BK, p.cg, tid); lb.template load<2>((kt0 + 2) * BK, p.cg, tid); }
+    la.template load<1>(min((kt0 + 1) * BK, klast), p.cg, tid);
+    lb.template load<1>(min((kt0 + 1) * BK, klast), p.cg, tid);
     la.template store<0>(smem, tid, kt0 * BK);
     lb.template store<0>(smem + BM * ROWB, tid, kt0 * BK);
     __syncthreads();
-#define OTR_GEMM_STEP(SLOT, NEXT)                                                              \
+    OTR_TRACE(1)
+#define OTR_GEMM_STEP(CUR, DO_LOAD, DO_STORE)                                                  \
     {                                                                                           \
-      const int cur = (kt - kt0) & 1;                                                           \
-      if (kt + 3 < kt1) {                                                                       \
-        la.template load<SLOT>((kt + 3) * BK, p.cg, tid);                                       \
-        lb.template load<SLOT>((kt + 3) * BK, p.cg, tid);                                       \
+      if (DO_LOAD) {                                                                            \
+        la.template load<CUR>((kt + 2) * BK, p.cg, tid);                                        \
+        lb.template load<CUR>((kt + 2) * BK, p.cg, tid);                                        \
       }                                                                                         \
-      compute(cur);                                                                             \
-      if (kt + 1 < kt1) {                                                                       \
-        la.template store<NEXT>(smem + (cur ^ 1) * BUF, tid, (kt + 1) * BK);                    \
-        lb.template store<NEXT>(smem + (cur ^ 1) * BUF + BM * ROWB, tid, (kt + 1) * BK);        \
+      __builtin_amdgcn_sched_barrier(0); /* keep the loads ahead of the MFMAs ... */            \
+      compute(CUR);                                                                             \
+      __builtin_amdgcn_sched_barrier(0); /* ... and their first use (mask + LDS write) behind */ \
+      if (DO_STORE) {                                                                           \
+        la.template store<(CUR) ^ 1>(smem + ((CUR) ^ 1) * BUF, tid, (kt + 1) * BK);             \
+        lb.template store<(CUR) ^ 1>(smem + ((CUR) ^ 1) * BUF + BM * ROWB, tid, (kt + 1) * BK); \
+        __syncthreads();                                                                        \
       }                                                                                         \
-      __syncthreads();                                                                          \
       ++kt;                                                                                     \
     }
     int kt = kt0;
-    while (kt < kt1) {
-      OTR_GEMM_STEP(0, 1)
-      if (kt >= kt1) break;
-      OTR_GEMM_STEP(1, 2)
-      if (kt >= kt1) break;
-      OTR_GEMM_STEP(2, 0)
+    while (kt1 - kt >= 4) {                        // both loads stay inside the slice
+      OTR_GEMM_STEP(0, 1, 1)
+      OTR_GEMM_STEP(1, 1, 1)
+    }
+    switch (kt1 - kt) {                            // 1..3 stages left: straight-line drains, loads only where valid
+      case 3:
+        OTR_GEMM_STEP(0, 1, 1)
+        OTR_GEMM_STEP(1, 0, 1)
+        OTR_GEMM_STEP(0, 0, 0)
+        break;
+      case 2:
+        OTR_GEMM_STEP(0, 0, 1)
+        OTR_GEMM_STEP(1, 0, 0)
+        break;
+      default:
+        OTR_GEMM_STEP(0, 0, 0)
+        break;
     }
 #undef OTR_GEMM_STEP
   }
 
+  OTR_TRACE(2)
   // epilogue: acc[i][j][r] = C[m = .. + i*16 + (lane&15)][n = .. + j*16 + (lane>>4)*4 + r]
   if (p.ksplit > 1) {  // partial tile -> workspace slab [split][M][N]; reduced by splitk_reduce_kernel
     float* W = p.ws + (int64_t)blockIdx.y * p.M * p.N;
@@ -490,16 +514,80 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
         }
       }
     }
+    OTR_TRACE(3)
     return;
   }
   OT* C = reinterpret_cast<OT*>(p.C);
   const bool vec_out = (p.ldc % 4 == 0) && ((uintptr_t)p.C % 16 == 0);
   float bv[FN][4];
 #pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    int col = tile_n * BN + wn * WN + j * 16 + fg * 4;
+  for (int j = 0; j < FN; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bv[j][r] = (p.bias && col + r < p.N) ? p.bias[col + r] : 0.f;
+    for (int r = 0; r < 4; ++r) bv[j][r] = 0.f;
+  if (p.bias) {   // clamped, unconditional loads (a per-element branch serialises them behind vmcnt(0))
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      int col = tile_n * BN + wn * WN + j * 16 + fg * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[j][r] = p.bias[min(col + r, p.N - 1)];
+    }
+  }
+  // Staged epilogue: each lane owns 4 consecutive n of 16 different rows, so direct stores hit memory as 32-byte
+  // (bf16) / 64-byte (f32) pieces -- measured with otr_debug_trace that was 54 % of a K=256 workgroup's lifetime
+  // (11.4 k of 21 k cycles for the FFN w_1 GEMM).  Instead the tile goes through the (now idle) operand LDS and
+  // leaves as whole rows: 16 bytes per lane, a wave covers >= 4 rows x 256 B.
+  constexpr int EPC = 16 / (int)sizeof(OT);                  // elements per 16-byte chunk
+  constexpr int CROW = BN * (int)sizeof(OT) + 16;            // staged row pitch (pad: rows land on different banks)
+  constexpr int PASSES = (BM * CROW <= 2 * BUF) ? 1 : (BM / 2 * CROW <= 2 * BUF) ? 2 : 4;   // f32 tiles go in row slabs
+  constexpr int PROWS = BM / PASSES;
+  static_assert(PROWS * CROW <= 2 * BUF && PROWS % 16 == 0, "staged epilogue does not fit the operand LDS");
+  const bool staged = !p.accumulate && vec_out && (p.ldc % EPC == 0);
+  if (staged) {
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      __syncthreads();                                       // operand reads (ps = 0) / previous write-out (ps = 1) done
+      {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int trow = wm * WM + i * 16;                 // first tile row of this fragment (wave-uniform)
+          if (PASSES > 1 && trow / PROWS != ps) continue;
+          const int lrow = trow - ps * PROWS + fr;
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = acc[i][j][r] + bv[j][r];
+              if (p.act == OTR_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+            }
+            unsigned char* q = smem + lrow * CROW + (wn * WN + j * 16 + fg * 4) * (int)sizeof(OT);
+            if constexpr (sizeof(OT) == 4) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+            else *reinterpret_cast<uint2*>(q) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          }
+        }
+      }
+      __syncthreads();
+      constexpr int CPR = BN / EPC;                          // chunks per row
+#pragma unroll
+      for (int u = 0; u < (PROWS * CPR) / 256; ++u) {
+        const int c = tid + 256 * u;
+        const int lrow = c / CPR, ch = c % CPR;
+        const int row = tile_m * BM + ps * PROWS + lrow, col = tile_n * BN + ch * EPC;
+        if (row < p.M && col < p.N) {
+          const unsigned char* q = smem + lrow * CROW + ch * 16;
+          OT* dst = C + (int64_t)row * p.ldc + col;
+          if (col + EPC <= p.N) {
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(q);
+          } else {
+            const OT* qe = reinterpret_cast<const OT*>(q);
+            for (int e = 0; e < EPC; ++e)
+              if (col + e < p.N) dst[e] = qe[e];
+          }
+        }
+      }
+    }
+    OTR_TRACE(3)
+    return;
   }
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
@@ -533,6 +621,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
       }
     }
   }
+  OTR_TRACE(3)
+#undef OTR_TRACE
 }
 
 // C = act( sum_s ws[s] + bias ) (+ C): the fixed-order (deterministic) second half of split-K

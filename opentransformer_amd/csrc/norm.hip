@@ -7,7 +7,7 @@
 struct LnArgs {
   const float* x; const void* a; const float* gamma; const float* beta; const uint64_t* seed;
   float* y; float* z; float* mean; float* rstd; bf16_t* y_lp;
-  const float* dy; float* dx; void* da; float* dgamma; float* dbeta; const float* zin;
+  const float* dy; float* dx; void* da; float* dgamma; float* dbeta; const float* zin; float* da_colsum;
   int64_t M; int d;
   float eps, p_drop;
   uint64_t rng_offset;
@@ -100,12 +100,13 @@ template <class AT, bool HAS_A> __global__ __launch_bounds__(256) void add_ln_bw
   const uint64_t seed = drop ? *p.seed : 0;
   const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
   const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
-  float gam[LN_MAXV][4], dg[LN_MAXV][4], db[LN_MAXV][4];
+  float gam[LN_MAXV][4], dg[LN_MAXV][4], db[LN_MAXV][4], dab[LN_MAXV][4];
+  const bool want_ab = HAS_A && p.da_colsum != nullptr;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     int col = (i * 64 + lane) * 4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; gam[i][e] = 0.f; }
+    for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; gam[i][e] = 0.f; dab[i][e] = 0.f; }
     if (col < d) ld4<float>(p.gamma + col, gam[i]);
   }
   for (int rr = 0; rr < LN_BWD_ROWS; ++rr) {
@@ -147,6 +148,7 @@ template <class AT, bool HAS_A> __global__ __launch_bounds__(256) void add_ln_bw
             for (int e = 0; e < 4; ++e) {
               float sc = drop ? drop_scale(seed, p.rng_offset + (uint64_t)(row * d + col + e), thr, inv_keep) : 1.f;
               o[e] = dz[e] * sc;
+              dab[i][e] += o[e];
             }
             st4<AT>(reinterpret_cast<AT*>(p.da) + row * d + col, o);
           }
@@ -168,6 +170,19 @@ template <class AT, bool HAS_A> __global__ __launch_bounds__(256) void add_ln_bw
     float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
     atomicAdd(p.dgamma + c, a);
     atomicAdd(p.dbeta + c, b);
+  }
+  if constexpr (HAS_A) {
+    // column sums of da = the bias gradient of the Linear that produced the branch (saves its colsum launch)
+    if (want_ab) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[0][wid][(i * 64 + lane) * 4 + e] = dab[i][e];
+      __syncthreads();
+      for (int c = threadIdx.x; c < d; c += 256)
+        atomicAdd(p.da_colsum + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    }
   }
 }
 
@@ -200,14 +215,14 @@ extern "C" int32_t otr_add_layernorm_fwd(const otr_ln_desc_t* d, const float* x,
 
 extern "C" int32_t otr_add_layernorm_bwd(const otr_ln_desc_t* d, const float* dy, const float* z, const float* mean,
                                          const float* rstd, const float* gamma, const uint64_t* seed, float* dx,
-                                         void* da, float* dgamma, float* dbeta, void* stream) {
+                                         void* da, float* dgamma, float* dbeta, float* da_colsum, void* stream) {
   if (int32_t e = ln_check(d)) return e;
   OTR_REQUIRE(dy && z && mean && rstd && gamma && dx && dgamma && dbeta, "add_layernorm_bwd: null pointer");
   OTR_REQUIRE(d->p_drop == 0.f || seed, "add_layernorm_bwd: dropout needs seed");
   if (d->M == 0) return 0;
   LnArgs p{};
   p.dy = dy; p.zin = z; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd); p.gamma = gamma;
-  p.seed = seed; p.dx = dx; p.da = da; p.dgamma = dgamma; p.dbeta = dbeta;
+  p.seed = seed; p.dx = dx; p.da = da; p.dgamma = dgamma; p.dbeta = dbeta; p.da_colsum = da ? da_colsum : nullptr;
   p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
   dim3 grid((unsigned)((d->M + 4 * LN_BWD_ROWS - 1) / (4 * LN_BWD_ROWS)));
   hipStream_t s = (hipStream_t)stream;

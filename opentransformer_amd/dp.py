@@ -59,14 +59,18 @@ class FlatDataParallel:
                     off += n
                 # transposed bf16 shadows of the 2-D weights ([K,N]: dgrad becomes a forward-type GEMM)
                 self.flat_param_lpt = torch.empty(padded, device=dev, dtype=torch.bfloat16)
-                self._lpt_pairs = []
+                table, tiles = [], 0
                 off = 0
                 for p in params:
                     n = p.numel()
                     if p.dim() == 2:
                         p._otr_lpt_view = self.flat_param_lpt[off:off + n].view(p.shape[1], p.shape[0])
-                        self._lpt_pairs.append((p._otr_lp_view, p._otr_lpt_view))
+                        table.append([off, p.shape[0], p.shape[1], tiles])
+                        tiles += ((p.shape[0] + 63) // 64) * ((p.shape[1] + 63) // 64)
                     off += n
+                # one launch transposes every 2-D shadow (include/otrans_hip.h: otr_transpose_batched)
+                self._lpt_table = torch.tensor(table, dtype=torch.int64, device=dev).reshape(-1, 4)
+                self._lpt_tiles = tiles
                 self.refresh_lp()
 
     def refresh_lp(self):
@@ -78,9 +82,11 @@ class FlatDataParallel:
 
     def refresh_transposed(self):
         """W^T shadows follow the bf16 shadows (call after every optimizer step)."""
-        if self.flat_param_lp is not None:
-            for src, dst in self._lpt_pairs:
-                dst.copy_(src.t())
+        if self.flat_param_lp is not None and self._lpt_tiles:
+            L.check(L.load().otr_transpose_batched(
+                C.c_void_p(self.flat_param_lp.data_ptr()), C.c_void_p(self.flat_param_lpt.data_ptr()),
+                C.c_void_p(self._lpt_table.data_ptr()), self._lpt_table.shape[0], self._lpt_tiles, 2,
+                C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'otr_transpose_batched')
 
     @property
     def world_size(self):

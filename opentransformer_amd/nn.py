@@ -137,9 +137,10 @@ class MultiHeadedSelfAttention(nn.Module):
         qkv = ops.linear(x, self.qvk_proj.weight, self.qvk_proj.bias, out_dtype=ops.act_dtype())
         return ops.SelfAttentionFn.apply(qkv, _key_mask(mask, B, T), self.nheads, causal)
 
-    def forward(self, x, mask, causal=False):
+    def forward(self, x, mask, causal=False, defer_bias=False):
+        """defer_bias: the caller feeds the result to _post_norm(..., a_bias=self.output_proj.bias)."""
         ctx = self.context(x, mask, causal)
-        return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias), None
+        return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, defer_bias=defer_bias), None
 
     def inference(self, x, mask, cache=None):
         out, w = self.forward(x, mask)
@@ -160,13 +161,13 @@ class MultiHeadedCrossAttention(nn.Module):
         self.q_proj = nn.Linear(d_model, d_model)
         self.vk_proj = nn.Linear(memory_dim, d_model * 2)
 
-    def forward(self, query, memory, memory_mask):
+    def forward(self, query, memory, memory_mask, defer_bias=False):
         B, T, _ = memory.shape
         adt = ops.act_dtype()
         q = ops.linear(query, self.q_proj.weight, self.q_proj.bias, out_dtype=adt)
         kv = ops.linear(memory, self.vk_proj.weight, self.vk_proj.bias, out_dtype=adt)
         ctx = ops.CrossAttentionFn.apply(q, kv, _key_mask(memory_mask, B, T), self.nheads)
-        return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias), None
+        return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, defer_bias=defer_bias), None
 
     def inference(self, query, memory, memory_mask, cache=None):
         out, w = self.forward(query, memory, memory_mask)
@@ -186,16 +187,18 @@ class PositionwiseFeedForward(nn.Module):
         self.w_1 = nn.Linear(d_model, d_ff * 2 if activation == 'glu' else d_ff)
         self.w_2 = nn.Linear(d_ff, d_model)
 
-    def forward(self, x):
+    def forward(self, x, defer_bias=False):
         if self.activation == 'glu':
-            return ops.FeedForwardGLUFn.apply(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias)
+            return ops.FeedForwardGLUFn.apply(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias,
+                                              defer_bias)
         h = ops.linear(x, self.w_1.weight, self.w_1.bias, relu=True, out_dtype=ops.act_dtype())
-        return ops.linear(h, self.w_2.weight, self.w_2.bias)
+        return ops.linear(h, self.w_2.weight, self.w_2.bias, defer_bias=defer_bias)
 
 
-def _post_norm(norm, x, branch, p, training):
-    """LN(x + dropout(branch)) in one kernel."""
-    return ops.add_layernorm(x, branch, norm.weight, norm.bias, p if training else 0.0, norm.eps)
+def _post_norm(norm, x, branch, p, training, a_bias=None):
+    """LN(x + dropout(branch)) in one kernel; a_bias = bias of the Linear that produced `branch` when that Linear
+    was called with defer_bias=True (its gradient is then reduced inside the LayerNorm backward)."""
+    return ops.add_layernorm(x, branch, norm.weight, norm.bias, p if training else 0.0, norm.eps, a_bias=a_bias)
 
 
 # ------------------------------------------------------------------------------------- encoder
@@ -219,9 +222,10 @@ class TransformerEncoderLayer(nn.Module):
         self.residual_dropout = residual_dropout
 
     def forward(self, x, mask, pos=None, causal=False):
-        attn, _ = self.slf_attn(x, mask, causal)
-        x = _post_norm(self.norm1, x, attn, self.residual_dropout, self.training)
-        x = _post_norm(self.norm2, x, self.feed_forward(x), self.residual_dropout, self.training)
+        attn, _ = self.slf_attn(x, mask, causal, defer_bias=True)
+        x = _post_norm(self.norm1, x, attn, self.residual_dropout, self.training, self.slf_attn.output_proj.bias)
+        x = _post_norm(self.norm2, x, self.feed_forward(x, defer_bias=True), self.residual_dropout, self.training,
+                       self.feed_forward.w_2.bias)
         return x, {'slf_attn_weights': None}
 
     def inference(self, x, mask, pos=None, cache=None):
@@ -250,7 +254,7 @@ class TransformerEncoder(nn.Module):
 
     def forward(self, inputs, mask):
         x, _ = self.pos_emb(inputs)
-        km = mask.unsqueeze(1)
+        km = mask.to(torch.uint8).unsqueeze(1)              # cast once; every layer's key mask is this uint8 view
         for block in self.blocks:
             x, _ = block(x, km)
         # the reference returns every layer's [B,h,T,T] weights; nothing reads them
@@ -434,13 +438,13 @@ class TransformerDecoderLayer(nn.Module):
         """tgt_mask: the causal [B,L,L] tril mask of decoder/utils.py:7-11, or None meaning causal."""
         p, tr = self.residual_dropout, self.training
         if tgt_mask is None:
-            attn, _ = self.slf_attn(tgt, None, causal=True)
+            attn, _ = self.slf_attn(tgt, None, causal=True, defer_bias=True)
         else:
-            attn, _ = self.slf_attn(tgt, tgt_mask)
-        x = _post_norm(self.norm1, tgt, attn, p, tr)
-        src, _ = self.src_attn(x, memory, memory_mask)
-        x = _post_norm(self.norm2, x, src, p, tr)
-        x = _post_norm(self.norm3, x, self.feed_forward(x), p, tr)
+            attn, _ = self.slf_attn(tgt, tgt_mask, defer_bias=True)
+        x = _post_norm(self.norm1, tgt, attn, p, tr, self.slf_attn.output_proj.bias)
+        src, _ = self.src_attn(x, memory, memory_mask, defer_bias=True)
+        x = _post_norm(self.norm2, x, src, p, tr, self.src_attn.output_proj.bias)
+        x = _post_norm(self.norm3, x, self.feed_forward(x, defer_bias=True), p, tr, self.feed_forward.w_2.bias)
         return x, {'slf_attn_weights': None, 'src_attn_weights': None}
 
 
@@ -466,7 +470,7 @@ class TransformerDecoder(nn.Module):
 
     def forward(self, targets, memory, memory_mask):
         x = ops.embed_posenc(targets, self.embedding.weight)
-        mm = memory_mask.unsqueeze(1)
+        mm = memory_mask.to(torch.uint8).unsqueeze(1)
         for block in self.blocks:
             x, _ = block(x, None, memory, mm)                    # None -> causal self-attention
         logits = ops.linear(x, self.output_layer.weight, self.output_layer.bias)

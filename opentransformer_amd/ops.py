@@ -230,8 +230,9 @@ class LinearFn(torch.autograd.Function):
     channel-last flatten of the conv frontend, frontend/conv.py:145); dw is regrouped back."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu, out_dtype, perm):
+    def forward(ctx, x, w, b, relu, out_dtype, perm, defer_bias=False):
         _cuda(x, w, b)
+        ctx.defer_bias = defer_bias      # the consumer (AddLayerNormFn, a_bias=b) produces the bias gradient
         xc = lp_of(x)
         x2 = _rows(xc if xc is not None else x)
         wl = weight_lp(w)
@@ -272,17 +273,19 @@ class LinearFn(torch.autograd.Function):
                     C_, F_ = ctx.perm
                     dw = dw.view(-1, F_, C_).permute(0, 2, 1).reshape(dw.shape[0], C_ * F_)
         db = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and not ctx.defer_bias:
             gt = grad_target(ctx.b_ref)
             if gt is not None:
                 colsum_raw(dy2, out=gt)
             else:
                 db = colsum_raw(dy2)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def linear(x, w, b=None, relu=False, out_dtype=None, perm=None):
-    return LinearFn.apply(x, w, b, relu, out_dtype if out_dtype is not None else torch.float32, perm)
+def linear(x, w, b=None, relu=False, out_dtype=None, perm=None, defer_bias=False):
+    """defer_bias=True: the caller hands `b` to add_layernorm(..., a_bias=b), whose backward reduces the bias
+    gradient in the same pass that produces the branch gradient."""
+    return LinearFn.apply(x, w, b, relu, out_dtype if out_dtype is not None else torch.float32, perm, defer_bias)
 
 
 def relu_bwd_raw(y, g):
@@ -388,8 +391,10 @@ class AddLayerNormFn(torch.autograd.Function):
     """y = LayerNorm(x + dropout(a)) (post-norm residual: encoder/transformer.py:54-56,61-63)."""
 
     @staticmethod
-    def forward(ctx, x, a, gamma, beta, p_drop, eps):
+    def forward(ctx, x, a, gamma, beta, p_drop, eps, a_bias=None):
         _cuda(x, a, gamma, beta)
+        ctx.set_materialize_grads(False)      # no zero-filled bf16 'gradient' for the non-differentiable twin
+        ctx.ab_ref = a_bias
         d = x.shape[-1]
         x2 = x.reshape(-1, d).contiguous()
         a2 = a.reshape(-1, d).contiguous() if a is not None else None
@@ -417,6 +422,8 @@ class AddLayerNormFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dylp=None):
+        if dy is None:
+            return (None,) * 7
         z, mean, rstd, gamma, seed = ctx.saved_tensors
         M, d, adt, eps, p_drop, off, xshape, ashape = ctx.cfg
         dy2 = dy.reshape(-1, d).contiguous()
@@ -427,16 +434,23 @@ class AddLayerNormFn(torch.autograd.Function):
         if not inplace:
             dgb = torch.zeros((2, d), dtype=torch.float32, device=dy.device)
             gg, gb = dgb[0], dgb[1]
+        gab, dab = None, None
+        if ctx.ab_ref is not None and da is not None and ctx.needs_input_grad[6]:
+            gab = grad_target(ctx.ab_ref)
+            if gab is None:
+                gab = dab = torch.zeros((d,), dtype=torch.float32, device=dy.device)
         desc = L.LnDesc(M, d, _code(adt) if adt is not None else L.OTR_F32, eps, p_drop, off)
         L.check(L.load().otr_add_layernorm_bwd(C.byref(desc), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed),
-                                               _p(dx), _p(da), _p(gg), _p(gb), _stream()),
+                                               _p(dx), _p(da), _p(gg), _p(gb), _p(gab), _stream()),
                 'otr_add_layernorm_bwd')
         return (dx.view(xshape), (da.view(ashape) if da is not None else None),
-                None if inplace else gg, None if inplace else gb, None, None)
+                None if inplace else gg, None if inplace else gb, None, None, dab)
 
 
-def add_layernorm(x, a, gamma, beta, p_drop=0.0, eps=1e-5):
-    y, ylp = AddLayerNormFn.apply(x, a, gamma, beta, float(p_drop), float(eps))
+def add_layernorm(x, a, gamma, beta, p_drop=0.0, eps=1e-5, a_bias=None):
+    """a_bias: the bias parameter of the Linear that produced `a` (called with defer_bias=True); its gradient
+    (column sums of d loss / d a) is then reduced inside the LayerNorm backward kernel."""
+    y, ylp = AddLayerNormFn.apply(x, a, gamma, beta, float(p_drop), float(eps), a_bias)
     return attach_lp(y, ylp)
 
 
@@ -446,8 +460,9 @@ class FeedForwardGLUFn(torch.autograd.Function):
     (GEMM, GLU, GEMM); backward fuses the w_1 bias gradient into the GLU-backward kernel."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, defer_b2=False):
         _cuda(x, w1, w2)
+        ctx.defer_b2 = defer_b2          # see linear(defer_bias=True)
         ctx.refs = (w1, b1, w2, b2)
         xc = lp_of(x)
         x2 = _rows(xc if xc is not None else x)
@@ -475,7 +490,7 @@ class FeedForwardGLUFn(torch.autograd.Function):
         du = linear_fwd_raw(dy2, ctx.w2t, None, u.dtype) if ctx.w2t is not None else linear_dgrad_raw(dy2, w2, u.dtype)
         gw2, gb2, gw1, gb1 = grad_target(w2p), grad_target(b2p), grad_target(w1p), grad_target(b1p)
         dw2 = linear_wgrad_raw(dy2, u, w2, out=gw2)
-        db2 = colsum_raw(dy2, out=gb2)
+        db2 = None if ctx.defer_b2 else colsum_raw(dy2, out=gb2)
         dh = torch.empty_like(h)
         nblk = (M + GLU_RPB - 1) // GLU_RPB
         part = torch.empty((nblk, 2 * F), dtype=torch.float32, device=dy.device)
@@ -487,7 +502,7 @@ class FeedForwardGLUFn(torch.autograd.Function):
             dx = linear_dgrad_raw(dh, w1, ctx.xdtype).view(ctx.xshape)
         dw1 = linear_wgrad_raw(dh, x2, w1, out=gw1)
         return (dx, None if gw1 is not None else dw1, None if gb1 is not None else db1,
-                None if gw2 is not None else dw2, None if gb2 is not None else db2)
+                None if gw2 is not None else dw2, None if (gb2 is not None or ctx.defer_b2) else db2, None)
 
 
 GLU_RPB = 32        # rows per workgroup of otr_glu_bwd (csrc/elementwise.hip)
@@ -500,6 +515,7 @@ class PosEncFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         _cuda(x)
+        ctx.set_materialize_grads(False)
         B, T, d = x.shape
         x = x.contiguous().float()
         y = torch.empty_like(x)
@@ -512,6 +528,8 @@ class PosEncFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dylp=None):
+        if dy is None:
+            return None
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
         L.check(L.load().otr_scale(_p(dy), _p(dx), dy.numel(), None, ctx.scale, _stream()), 'otr_scale')
@@ -524,6 +542,7 @@ class EmbedPosEncFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tokens, E):
         _cuda(tokens, E)
+        ctx.set_materialize_grads(False)
         B, Lq = tokens.shape
         V, d = E.shape
         tokens = tokens.contiguous()
@@ -541,6 +560,8 @@ class EmbedPosEncFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dylp=None):
+        if dy is None:
+            return None, None
         (tokens,) = ctx.saved_tensors
         V, d = ctx.eshape
         dy = dy.contiguous()

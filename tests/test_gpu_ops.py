@@ -383,3 +383,60 @@ def test_residual_add_dropout():
     assert abs(kept.float().mean().item() - 0.75) < 0.02
     (da,) = torch.autograd.grad(yd, a, torch.ones_like(yd))
     assert bool(((da != 0) == kept).all())
+
+
+def test_transpose_batched():
+    """one launch transposes a list of ragged 2-D matrices packed in a flat buffer (bf16 weight shadows)"""
+    import ctypes as C
+    from opentransformer_amd import _lib as L
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(768, 256), (100, 64), (1, 7), (65, 129), (4234, 256), (3, 3)]
+    total = sum(a * b for a, b in shapes) + 5
+    src = torch.randn(total, generator=gen).to(DEV, torch.bfloat16)
+    dst = torch.zeros_like(src)
+    table, tiles, off = [], 0, 2          # leading gap: offsets need not start at 0
+    for a, b in shapes:
+        table.append([off, a, b, tiles])
+        tiles += ((a + 63) // 64) * ((b + 63) // 64)
+        off += a * b
+    tab = torch.tensor(table, dtype=torch.int64, device=DEV)
+    L.check(L.load().otr_transpose_batched(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_void_p(tab.data_ptr()),
+                                           len(shapes), tiles, 2, C.c_void_p(torch.cuda.current_stream().cuda_stream)), 't')
+    for (o, a, b, _) in table:
+        assert torch.equal(dst[o:o + a * b].view(b, a), src[o:o + a * b].view(a, b).t()), (a, b)
+    assert float(dst[:2].abs().sum()) == 0.0 and float(dst[off:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_deferred_bias_gradient_through_layernorm(mode):
+    """linear(defer_bias=True) + add_layernorm(a_bias=b): the bias gradient comes out of the LayerNorm backward
+    (with dropout) and equals the plain path's, both as a returned tensor and accumulated in place."""
+    from opentransformer_amd import ops
+    ops.set_compute_dtype(mode)
+    try:
+        gen = torch.Generator().manual_seed(11)
+        M, K, d = 300, 96, 128
+        x0 = torch.randn(M, d, generator=gen).to(DEV)
+        h = torch.randn(M, K, generator=gen).to(DEV)
+        w = (torch.randn(d, K, generator=gen) / 8).to(DEV).requires_grad_()
+        gam = torch.randn(d, generator=gen).to(DEV).requires_grad_()
+        bet = torch.randn(d, generator=gen).to(DEV).requires_grad_()
+        g = torch.randn(M, d, generator=gen).to(DEV)
+        res = []
+        for defer, inplace in ((False, False), (True, False), (True, True)):
+            b = torch.randn(d, generator=torch.Generator().manual_seed(1)).to(DEV).requires_grad_()
+            if inplace:
+                b.grad = torch.full((d,), 0.5, device=DEV)
+                b._otr_grad_inplace = True
+            ops._state['rng_offset'] = 0
+            a = ops.linear(h, w, b, defer_bias=defer)
+            y = ops.add_layernorm(x0, a, gam, bet, 0.1, a_bias=b if defer else None)
+            for t in (w, gam, bet):
+                t.grad = None
+            y.backward(g)
+            res.append((b.grad - 0.5) if inplace else b.grad.clone())
+        tol = 1e-4
+        torch.testing.assert_close(res[1], res[0], rtol=tol, atol=tol * float(res[0].abs().max()))
+        torch.testing.assert_close(res[2], res[0], rtol=tol, atol=tol * float(res[0].abs().max()))
+    finally:
+        ops.set_compute_dtype('bf16')
