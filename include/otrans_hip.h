@@ -30,7 +30,8 @@ extern "C" {
 #define OTR_ACT_RELU 1
 
 int32_t otr_version(void);
-/* tuning hook for benchmarks: key 0 = force GEMM tile (0 auto / 64 / 128), key 1 = force split-K (0 auto) */
+/* tuning hook for benchmarks: key 0 = force GEMM tile (0 auto / 64 / 128), key 1 = force split-K (0 auto),
+ * key 2 = 1: generic (bounds-checked) loaders only, key 3 = 1: no persistent tile loop */
 int32_t otr_debug_set(int32_t key, int32_t value);
 /* tuning hook: when buf != NULL every GEMM workgroup writes 4 shader-clock timestamps (start, operands staged,
  * k-loop done, stores issued) to buf[(blockIdx.y*gridDim.x + blockIdx.x)*4 ..]; NULL disables.  Not for production. */

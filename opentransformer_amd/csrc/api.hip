@@ -34,12 +34,14 @@ void otr_zero_f32(float* p, int64_t n, hipStream_t s) {
 int g_otr_force_tile = 0;
 int g_otr_force_ksplit = 0;
 int g_otr_force_generic = 0;
+int g_otr_no_persist = 0;
 unsigned long long* g_otr_trace = nullptr;
 extern "C" int32_t otr_debug_trace(void* buf) { g_otr_trace = (unsigned long long*)buf; return 0; }
 extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   if (key == 0) g_otr_force_tile = value;
   else if (key == 1) g_otr_force_ksplit = value;
   else if (key == 2) g_otr_force_generic = value;
+  else if (key == 3) g_otr_no_persist = value;
   else { otr_set_error("debug_set: unknown key %d", key); return -1; }
   return 0;
 }

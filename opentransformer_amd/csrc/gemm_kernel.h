@@ -351,7 +351,19 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
 };
 
 // ------------------------------------------------------------------------------------------------
-template <class CT, class AT, class BT, class OT, int AMODE, int BMODE, int BM, int BN, bool FAST>
+// partial last chunk of a staged row (N not a multiple of the chunk width): out of line, keeps branches with memory
+// operations out of the hot epilogue
+template <class OT> __device__ __noinline__ void store_tail(OT* dst, const OT* src, int n) {
+  for (int e = 0; e < n; ++e) dst[e] = src[e];
+}
+template <class OT> __device__ __noinline__ void store_tail_acc(OT* dst, const OT* src, int n, int relu) {
+  for (int e = 0; e < n; ++e) {
+    float v = ElemIO<OT>::ld(src + e) + ElemIO<OT>::ld(dst + e);
+    ElemIO<OT>::st(dst + e, relu ? fmaxf(v, 0.f) : v);
+  }
+}
+
+template <class CT, class AT, class BT, class OT, int AMODE, int BMODE, int BM, int BN, bool FAST, bool PERSIST = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 VGPRs: two workgroups per CU
   using G = GemmCfg<CT>;
   constexpr int KCH = G::KCH, BK = G::BK, ROWB = G::ROWB;
@@ -362,7 +374,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+  const int ntiles = tiles_n * ((p.M + BM - 1) / BM);
+  // PERSIST (ksplit == 1 only): the grid is capped at the number of resident workgroups and each one walks tiles
+  // blockIdx.x, +gridDim.x, ...; the operand loads of the next tile are issued before the epilogue of the current
+  // one, so the ~3 k-cycle stage-in latency and the epilogue overlap instead of adding up per tile.
+  int tile = blockIdx.x;
+  int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
 
   // k-slice of this workgroup
   const int nk_total = (p.K + BK - 1) / BK;
@@ -370,8 +387,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
   const int kt0 = blockIdx.y * per;
   const int kt1 = min(nk_total, kt0 + per);
   if (kt0 >= kt1) return;
-#define OTR_TRACE(slot)                                                                                    \
-  if (p.trace && tid == 0) p.trace[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (slot)] = __builtin_readcyclecounter();
+#define OTR_TRACE(slot) \
+  if (p.trace && tid == 0) p.trace[((int64_t)blockIdx.y * ntiles + tile) * 4 + (slot)] = __builtin_readcyclecounter();
   OTR_TRACE(0)
 
   TileLoader<CT, AT, AMODE, BM, FAST> la;
@@ -379,17 +396,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
   la.init(p.A, p.lda, p.M, p.K, tile_m * BM, p.a_vec != 0, p.cg, tid);
   lb.init(p.B, p.ldb, p.N, p.K, tile_n * BN, p.b_vec != 0, p.cg, tid);
 
-  f32x4 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   using LA = TileLoader<CT, AT, AMODE, BM, FAST>;
   using LB = TileLoader<CT, BT, BMODE, BN, FAST>;
   // prefetch distance: 2 register stages when both operands are staged raw, else the classic 1
   constexpr int D = (LA::DEPTH == 2 && LB::DEPTH == 2) ? 2 : 1;
   const int fr = lane & 15, fg = lane >> 4;
+  f32x4 acc[FM][FN];
 
   auto compute = [&](int cur) {
     const unsigned char* sa = smem + cur * BUF;
@@ -415,10 +427,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
     }
   };
 
+
   // Control flow inside the k-loop is kept free of conditional loads/stores: a load that is issued on only one
   // side of a join makes hipcc's waitcnt insertion fall back to `s_waitcnt vmcnt(0)` at the join, which drains the
   // whole prefetch ring every step (seen in the ISA).  So the steady-state bodies below issue their loads and LDS
   // stores unconditionally and the loop tails are peeled into straight-line code.
+  const int klast = (kt1 - 1) * BK;                // a prologue load beyond the slice is clamped (redundant, unused)
+  if constexpr (D == 2) {
+    la.template load<0>(kt0 * BK, p.cg, tid);
+    lb.template load<0>(kt0 * BK, p.cg, tid);
+    la.template load<1>(min((kt0 + 1) * BK, klast), p.cg, tid);
+    lb.template load<1>(min((kt0 + 1) * BK, klast), p.cg, tid);
+  }
+
+  for (;;) {
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if constexpr (D == 1) {
     la.template load<0>(kt0 * BK, p.cg, tid);
     lb.template load<0>(kt0 * BK, p.cg, tid);
@@ -444,11 +470,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
     // Sub-step for stage t (already in LDS): issue the loads of stage t+2 into the slot stage t vacated -> MFMAs of
     // stage t -> write stage t+1 from its slot to the other LDS buffer (counted vmcnt: the 8 loads of stage t+2 stay
     // in flight across the barrier) -> barrier.
-    const int klast = (kt1 - 1) * BK;              // a prologue load beyond the slice is clamped (redundant, unused)
-    la.template load<0>(kt0 * BK, p.cg, tid);
-    lb.template load<0>(kt0 * BK, p.cg, tid);
-    la.template load<1>(min((kt0 + 1) * BK, klast), p.cg, tid);
-    lb.template load<1>(min((kt0 + 1) * BK, klast), p.cg, tid);
     la.template store<0>(smem, tid, kt0 * BK);
     lb.template store<0>(smem + BM * ROWB, tid, kt0 * BK);
     __syncthreads();
@@ -493,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
 
   OTR_TRACE(2)
   // epilogue: acc[i][j][r] = C[m = .. + i*16 + (lane&15)][n = .. + j*16 + (lane>>4)*4 + r]
-  if (p.ksplit > 1) {  // partial tile -> workspace slab [split][M][N]; reduced by splitk_reduce_kernel
+  if (!PERSIST && p.ksplit > 1) {  // partial tile -> workspace slab [split][M][N]; reduced by splitk_reduce_kernel
     float* W = p.ws + (int64_t)blockIdx.y * p.M * p.N;
     const bool v4 = (p.N % 4 == 0);
 #pragma unroll
@@ -532,6 +553,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
       for (int r = 0; r < 4; ++r) bv[j][r] = p.bias[min(col + r, p.N - 1)];
     }
   }
+
+  const int done_m = tile_m, done_n = tile_n;
+  if constexpr (PERSIST && D == 2) {
+    // operands of this workgroup's next tile (clamped: the last round re-loads a valid tile and drops it); issued
+    // AFTER the bias loads so that waiting for the bias does not wait for them (vmcnt retires in order)
+    const int nxt = min(tile + (int)gridDim.x, ntiles - 1);
+    tile_m = nxt / tiles_n;
+    tile_n = nxt - tile_m * tiles_n;
+    la.init(p.A, p.lda, p.M, p.K, tile_m * BM, p.a_vec != 0, p.cg, tid);
+    lb.init(p.B, p.ldb, p.N, p.K, tile_n * BN, p.b_vec != 0, p.cg, tid);
+    la.template load<0>(kt0 * BK, p.cg, tid);
+    lb.template load<0>(kt0 * BK, p.cg, tid);
+    la.template load<1>(min((kt0 + 1) * BK, klast), p.cg, tid);
+    lb.template load<1>(min((kt0 + 1) * BK, klast), p.cg, tid);
+  }
   // Staged epilogue: each lane owns 4 consecutive n of 16 different rows, so direct stores hit memory as 32-byte
   // (bf16) / 64-byte (f32) pieces -- measured with otr_debug_trace that was 54 % of a K=256 workgroup's lifetime
   // (11.4 k of 21 k cycles for the FFN w_1 GEMM).  Instead the tile goes through the (now idle) operand LDS and
@@ -541,8 +577,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
   constexpr int PASSES = (BM * CROW <= 2 * BUF) ? 1 : (BM / 2 * CROW <= 2 * BUF) ? 2 : 4;   // f32 tiles go in row slabs
   constexpr int PROWS = BM / PASSES;
   static_assert(PROWS * CROW <= 2 * BUF && PROWS % 16 == 0, "staged epilogue does not fit the operand LDS");
-  const bool staged = !p.accumulate && vec_out && (p.ldc % EPC == 0);
-  if (staged) {
+  const bool acc_st = p.accumulate != 0;                    // C += ...: added (and activated) at write-out, f32 only
+  // FAST kernels are launched only when C is 16-byte aligned with a chunk-multiple pitch (and not bf16 +=): staged
+  // epilogue only.  The generic kernels keep the direct per-lane stores.
+  if constexpr (FAST) {
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       __syncthreads();                                       // operand reads (ps = 0) / previous write-out (ps = 1) done
@@ -558,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               v[r] = acc[i][j][r] + bv[j][r];
-              if (p.act == OTR_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+              if (p.act == OTR_ACT_RELU && !acc_st) v[r] = fmaxf(v[r], 0.f);
             }
             unsigned char* q = smem + lrow * CROW + (wn * WN + j * 16 + fg * 4) * (int)sizeof(OT);
             if constexpr (sizeof(OT) == 4) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
@@ -567,61 +605,91 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
         }
       }
       __syncthreads();
-      constexpr int CPR = BN / EPC;                          // chunks per row
+      constexpr int CPR = BN / EPC;                          // chunks per row; 256 % CPR == 0, so a thread keeps its chunk
+      constexpr int RSTEP = 256 / CPR;                       // column and its rows advance by RSTEP per unit
+      static_assert(256 % CPR == 0 && (PROWS * CPR) % 256 == 0, "write-out mapping");
+      const int lrow0 = tid / CPR, ch = tid % CPR;
+      const int col = done_n * BN + ch * EPC;
+      // one base pointer per tile + a uniform row step: per-unit addresses would be loop-invariant in the persistent
+      // tile loop, get hoisted, and spill (their reloads drained the prefetched loads with vmcnt(0))
+      OT* dstp = C + (int64_t)(done_m * BM + ps * PROWS + lrow0) * p.ldc + col;
+      const int64_t rstep = (int64_t)RSTEP * p.ldc;
 #pragma unroll
-      for (int u = 0; u < (PROWS * CPR) / 256; ++u) {
-        const int c = tid + 256 * u;
-        const int lrow = c / CPR, ch = c % CPR;
-        const int row = tile_m * BM + ps * PROWS + lrow, col = tile_n * BN + ch * EPC;
+      for (int u = 0; u < (PROWS * CPR) / 256; ++u, dstp += rstep) {     // incremental: u * rstep would be hoisted too
+        const int lrow = lrow0 + u * RSTEP;
+        const int row = done_m * BM + ps * PROWS + lrow;
         if (row < p.M && col < p.N) {
           const unsigned char* q = smem + lrow * CROW + ch * 16;
-          OT* dst = C + (int64_t)row * p.ldc + col;
-          if (col + EPC <= p.N) {
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(q);
-          } else {
-            const OT* qe = reinterpret_cast<const OT*>(q);
-            for (int e = 0; e < EPC; ++e)
-              if (col + e < p.N) dst[e] = qe[e];
+          OT* dst = dstp;
+          const int nv = min(EPC, p.N - col);
+          if constexpr (sizeof(OT) == 4) {
+            if (acc_st) {
+              if (nv == EPC) {
+                float4 a = *reinterpret_cast<const float4*>(q), c4 = *reinterpret_cast<const float4*>(dst);
+                a.x += c4.x; a.y += c4.y; a.z += c4.z; a.w += c4.w;
+                if (p.act == OTR_ACT_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+                *reinterpret_cast<float4*>(dst) = a;
+              } else {
+                store_tail_acc<OT>(dst, reinterpret_cast<const OT*>(q), nv, p.act == OTR_ACT_RELU);
+              }
+              continue;
+            }
           }
+          if (nv == EPC) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(q);
+          else store_tail<OT>(dst, reinterpret_cast<const OT*>(q), nv);
         }
       }
     }
-    OTR_TRACE(3)
-    return;
-  }
+  } else {
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    int row = tile_m * BM + wm * WM + i * 16 + fr;
-    if (row >= p.M) continue;
+    for (int i = 0; i < FM; ++i) {
+      int row = done_m * BM + wm * WM + i * 16 + fr;
+      if (row >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      int col = tile_n * BN + wn * WN + j * 16 + fg * 4;
-      if (col >= p.N) continue;
-      OT* dst = C + (int64_t)row * p.ldc + col;
-      float v[4];
+      for (int j = 0; j < FN; ++j) {
+        int col = done_n * BN + wn * WN + j * 16 + fg * 4;
+        if (col >= p.N) continue;
+        OT* dst = C + (int64_t)row * p.ldc + col;
+        float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
-      const bool full = col + 4 <= p.N && vec_out;
-      if (p.accumulate) {
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
+        const bool full = col + 4 <= p.N && vec_out;
+        if (p.accumulate) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (col + r < p.N) v[r] += ElemIO<OT>::ld(dst + r);
-      }
-      if (p.act == OTR_ACT_RELU) {
+          for (int r = 0; r < 4; ++r)
+            if (col + r < p.N) v[r] += ElemIO<OT>::ld(dst + r);
+        }
+        if (p.act == OTR_ACT_RELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      }
-      if (full) {
-        if constexpr (sizeof(OT) == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        else *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-      } else {
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (full) {
+          if constexpr (sizeof(OT) == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          else *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (col + r < p.N) ElemIO<OT>::st(dst + r, v[r]);
+          for (int r = 0; r < 4; ++r)
+            if (col + r < p.N) ElemIO<OT>::st(dst + r, v[r]);
+        }
       }
     }
   }
   OTR_TRACE(3)
+  if constexpr (!PERSIST) {
+    break;
+  } else {
+    tile += gridDim.x;
+    if (tile >= ntiles) break;
+    if constexpr (D != 2) {
+      tile_m = tile / tiles_n;
+      tile_n = tile - tile_m * tiles_n;
+      la.init(p.A, p.lda, p.M, p.K, tile_m * BM, p.a_vec != 0, p.cg, tid);
+      lb.init(p.B, p.ldb, p.N, p.K, tile_n * BN, p.b_vec != 0, p.cg, tid);
+    }
+    __syncthreads();            // epilogue staging reads / last operand reads finish before the next tile's LDS writes
+    OTR_TRACE(0)
+  }
+  }
 #undef OTR_TRACE
 }
 
@@ -672,6 +740,8 @@ static __global__ void splitk_reduce_kernel(const float* ws, int ks, int M, int 
 extern int g_otr_force_tile;    // 0 = heuristic, 64 / 128 = forced (tuning hook: otr_debug_set(0, v))
 extern int g_otr_force_ksplit;  // 0 = heuristic, n = forced                  (otr_debug_set(1, v))
 extern int g_otr_force_generic; // 1 = never use the branch-free FAST loaders  (otr_debug_set(2, v))
+extern int g_otr_no_persist;    // 1 = one workgroup per tile even without split-K (otr_debug_set(3, v))
+constexpr int OTR_RESIDENT_WG = 512;   // 256 CUs x 2 workgroups (launch_bounds(256, 2), 64 KB LDS each)
 
 template <class CT, class AT, class BT, class OT, int AMODE, int BMODE>
 static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
@@ -720,11 +790,18 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
     return false;
   };
   const bool fast = (AMODE == MODE_KC || AMODE == MODE_MC) && (BMODE == MODE_KC || BMODE == MODE_MC) &&
-                    side_fast(AMODE, a.a_vec, a.M) && side_fast(BMODE, a.b_vec, a.N) && g_otr_force_generic == 0;
-  const dim3 grid((unsigned)(big ? t128 : t64), a.ksplit);
+                    side_fast(AMODE, a.a_vec, a.M) && side_fast(BMODE, a.b_vec, a.N) && g_otr_force_generic == 0 &&
+                    ((uintptr_t)a.C % 16 == 0) && (a.ldc % (16 / (int)sizeof(OT)) == 0) && !(a.accumulate && sizeof(OT) == 2);
+  const int64_t ntiles = big ? t128 : t64;
+  // persistent variant (no split-K): at most OTR_RESIDENT_WG workgroups, each walking tiles b, b+grid, ...
+  const bool persist = fast && a.ksplit == 1 && g_otr_no_persist == 0;
+  const dim3 grid((unsigned)(persist && ntiles > OTR_RESIDENT_WG ? OTR_RESIDENT_WG : ntiles), a.ksplit);
   if constexpr (AMODE == MODE_KC || AMODE == MODE_MC) {
     if constexpr (BMODE == MODE_KC || BMODE == MODE_MC) {
-      if (fast) {
+      if (fast && persist) {
+        if (big) hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 128, 128, true, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 64, 64, true, true>), grid, dim3(256), 0, s, a);
+      } else if (fast) {
         if (big) hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 128, 128, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 64, 64, true>), grid, dim3(256), 0, s, a);
       }

@@ -1,0 +1,24 @@
+"""From a rocprofv3 kernel trace of the hipGraph bench: per-step busy time vs wall time (inter-kernel gaps)."""
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+rows = db.execute("select name,start,end from kernels order by start").fetchall()
+idx = [i for i, r in enumerate(rows) if r[0].startswith('adam_kernel')]
+print('adam launches', len(idx), 'kernels', len(rows))
+for a, b in zip(idx[-4:-1], idx[-3:]):
+    seg = rows[a + 1:b + 1]
+    wall = seg[-1][2] - seg[0][1]
+    busy = sum(r[2] - r[1] for r in seg)
+    # union of intervals (concurrency-aware)
+    cur_s, cur_e, union = seg[0][1], seg[0][2], 0
+    for _, s, e in seg[1:]:
+        if s > cur_e:
+            union += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    union += cur_e - cur_s
+    gaps = sorted((seg[i + 1][1] - seg[i][2]) for i in range(len(seg) - 1))
+    print('step: %d kernels, wall %.2f ms, sum of durations %.2f ms, covered %.2f ms, idle %.2f ms; gap median %.2f us, p90 %.2f us'
+          % (len(seg), wall / 1e6, busy / 1e6, union / 1e6, (wall - union) / 1e6, gaps[len(gaps) // 2] / 1e3, gaps[int(len(gaps) * .9)] / 1e3))
