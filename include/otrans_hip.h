@@ -64,6 +64,30 @@ int32_t otr_linear_wgrad(const otr_linear_desc_t* d, const void* dy, const void*
 int32_t otr_colsum(const void* a, int32_t dtype, int64_t M, int64_t N, int64_t lda, float* out, int32_t accumulate,
                    void* stream);
 
+/* ---- grouped weight / bias gradients: every dw_i[N,K] += dy_i[M,N]^T x_i[M,K] of a backward pass in a few launches
+ *      (one per operand-type group), likewise every bias gradient out_i[N] += column sums of a_i[M,N].  The per-layer
+ *      launches they replace are latency bound (a 4-k-step GEMM workgroup lives ~10 us, every launch costs 2-3 us);
+ *      grouped, the long-contraction tiles of all layers fill the chip at once, so no split-K, no workspace, no
+ *      reduce kernels.  Items that miss the alignment rules of the fast loaders run through otr_linear_wgrad
+ *      (accumulate) with the workspace given here.  Results are always ACCUMULATED. */
+typedef struct {
+  const void* dy;
+  const void* x;
+  float* dw;
+  int32_t M, N, K;
+  int64_t ldy, ldx, ldw;
+  int32_t dy_dtype, x_dtype;
+} otr_wgrad_item_t;
+int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32_t n, int32_t compute, void* workspace,
+                                 int64_t workspace_bytes, void* stream);
+typedef struct {
+  const void* a;
+  float* out;
+  int64_t M, N, lda;
+  int32_t dtype;
+} otr_colsum_item_t;
+int32_t otr_colsum_grouped(const otr_colsum_item_t* items, int32_t n, void* stream);
+
 /* ---- scaled-dot-product attention, flash style: scores are never materialised
  *      (module/attention.py:23-46 compute_context, :76-82 self, :137-143 cross).
  * q/k/v/o are [B, T, H*dk] slices addressed by (batch stride, time stride) in elements; head h

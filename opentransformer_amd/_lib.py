@@ -20,6 +20,17 @@ class LinearDesc(C.Structure):
                 ('act', C.c_int32), ('accumulate', C.c_int32)]
 
 
+class WgradItem(C.Structure):               # otr_wgrad_item_t
+    _fields_ = [('dy', C.c_void_p), ('x', C.c_void_p), ('dw', C.c_void_p), ('M', C.c_int32), ('N', C.c_int32),
+                ('K', C.c_int32), ('ldy', C.c_int64), ('ldx', C.c_int64), ('ldw', C.c_int64),
+                ('dy_dtype', C.c_int32), ('x_dtype', C.c_int32)]
+
+
+class ColsumItem(C.Structure):              # otr_colsum_item_t
+    _fields_ = [('a', C.c_void_p), ('out', C.c_void_p), ('M', C.c_int64), ('N', C.c_int64), ('lda', C.c_int64),
+                ('dtype', C.c_int32)]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [('B', C.c_int32), ('H', C.c_int32), ('Tq', C.c_int32), ('Tk', C.c_int32), ('dk', C.c_int32),
                 ('dtype', C.c_int32),
@@ -51,6 +62,8 @@ SIGNATURES = {
     'otr_linear_fwd': [C.POINTER(LinearDesc), _P, _P, _P, _P, _P, _I64, _P],
     'otr_linear_dgrad': [C.POINTER(LinearDesc), _P, _P, _P, _P, _I64, _P],
     'otr_linear_wgrad': [C.POINTER(LinearDesc), _P, _P, _P, _P, _I64, _P],
+    'otr_linear_wgrad_grouped': [_P, _I32, _I32, _P, _I64, _P],
+    'otr_colsum_grouped': [_P, _I32, _P],
     'otr_colsum': [_P, _I32, _I64, _I64, _I64, _P, _I32, _P],
     'otr_attention_fwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P],
     'otr_attention_bwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -2,6 +2,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "gemm_kernel.h"
 
 static thread_local char g_err[512] = "";
@@ -123,6 +126,59 @@ extern "C" int32_t otr_linear_wgrad(const otr_linear_desc_t* d, const void* dy, 
   a.allow_split = 1; a.ws = (float*)workspace; a.ws_bytes = workspace_bytes; a.trace = g_otr_trace;
   if (d->M == 0) return 0;
   return run_gemm(a, d->compute, d->y_dtype, d->x_dtype, d->w_dtype, MODE_MC, MODE_MC, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// All weight gradients of a backward pass in (a few) grouped launches: dw_i[N,K] += dy_i[M,N]^T x_i[M,K].
+extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32_t n, int32_t compute, void* workspace,
+                                            int64_t workspace_bytes, void* stream) {
+  OTR_REQUIRE(n >= 0 && (items || n == 0), "linear_wgrad_grouped: null items");
+  OTR_REQUIRE(compute == OTR_BF16 || compute == OTR_F32, "linear_wgrad_grouped: bad compute type");
+  const int pm = compute == OTR_BF16 ? 4 : 2;
+  std::vector<int> order[16];   // key = big(1) | dy dtype(1) | x dtype(1)
+  for (int i = 0; i < n; ++i) {
+    const otr_wgrad_item_t& it = items[i];
+    OTR_REQUIRE(it.dy && it.x && it.dw, "linear_wgrad_grouped: item %d has a null pointer", i);
+    OTR_REQUIRE(it.M >= 0 && it.N > 0 && it.K > 0 && it.ldy >= it.N && it.ldx >= it.K && it.ldw >= it.K,
+                "linear_wgrad_grouped: item %d has a bad shape", i);
+    OTR_REQUIRE(dtype_ok(it.dy_dtype) && dtype_ok(it.x_dtype), "linear_wgrad_grouped: item %d has a bad dtype", i);
+    if (it.M == 0) continue;
+    const bool fast = mc_vec(it.dy, it.ldy, it.dy_dtype, compute) && mc_vec(it.x, it.ldx, it.x_dtype, compute) &&
+                      it.N % pm == 0 && it.K % pm == 0 && (uintptr_t)it.dw % 16 == 0 && it.ldw % 4 == 0 &&
+                      it.ldy < (1ll << 31) && it.ldx < (1ll << 31) && it.ldw < (1ll << 31);
+    if (!fast) {   // odd alignment: the stand-alone path (generic loaders, split-K through the workspace)
+      otr_linear_desc_t d{};
+      d.M = it.M; d.N = it.N; d.K = it.K;
+      d.x_dtype = it.x_dtype; d.w_dtype = OTR_F32; d.y_dtype = it.dy_dtype; d.compute = compute;
+      d.ldx = it.ldx; d.ldw = it.ldw; d.ldy = it.ldy; d.act = OTR_ACT_NONE; d.accumulate = 1;
+      if (int32_t e = otr_linear_wgrad(&d, it.dy, it.x, it.dw, workspace, workspace_bytes, stream)) return e;
+      continue;
+    }
+    const int big = (it.N >= 128 && it.K >= 128) ? 1 : 0;
+    order[(big << 2) | (it.dy_dtype << 1) | it.x_dtype].push_back(i);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  for (int key = 0; key < 8; ++key) {
+    std::vector<int>& v = order[key];
+    if (v.empty()) continue;
+    // longest contraction first: the long tiles start early, the short ones fill the tail
+    std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return items[a].M > items[b].M; });
+    for (size_t c0 = 0; c0 < v.size(); c0 += OTR_GROUP_MAX) {
+      GroupDesc d[OTR_GROUP_MAX];
+      int m = 0;
+      for (size_t c = c0; c < v.size() && m < OTR_GROUP_MAX; ++c, ++m) {
+        const otr_wgrad_item_t& it = items[v[c]];
+        d[m].A = it.dy; d[m].B = it.x; d[m].C = it.dw;
+        d[m].M = it.N; d[m].N = it.K; d[m].K = it.M;
+        d[m].lda = (int)it.ldy; d[m].ldb = (int)it.ldx; d[m].ldc = (int)it.ldw;
+        d[m].a_vec = 1; d[m].b_vec = 1;
+      }
+      const int ad = (key >> 1) & 1, bd = key & 1, big = key >> 2;
+      int32_t e = compute == OTR_BF16 ? gemm_grouped_wgrad_bf16(d, m, ad, bd, big, s) : gemm_grouped_wgrad_f32(d, m, ad, bd, big, s);
+      if (e) return e;
+    }
+  }
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -244,6 +244,82 @@ extern "C" int32_t otr_colsum(const void* a, int32_t dtype, int64_t M, int64_t N
   return otr_check_launch("colsum");
 }
 
+// many column sums in one launch (all bias gradients of a backward pass): out_i[N_i] += colsum(a_i[M_i, N_i])
+constexpr int CSG_MAX = 64;
+struct ColsumGroup {
+  int n;
+  int first[CSG_MAX + 1];
+  const void* a[CSG_MAX];
+  float* out[CSG_MAX];
+  int M[CSG_MAX], N[CSG_MAX], lda[CSG_MAX], rblocks[CSG_MAX];
+};
+template <class T> __global__ void colsum_grouped_kernel(ColsumGroup g) {
+  __shared__ float red[4][64][4];
+  const int b = (int)blockIdx.x;
+  int i = 0;
+  for (int j = 1; j < g.n; ++j) i = (g.first[j] <= b) ? j : i;
+  const T* a = reinterpret_cast<const T*>(g.a[i]);
+  float* out = g.out[i];
+  const int64_t M = g.M[i], N = g.N[i], lda = g.lda[i];
+  const int lb = b - g.first[i], by = lb % g.rblocks[i], bx = lb / g.rblocks[i];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int64_t c = ((int64_t)bx * 64 + tx) * 4;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < N) {
+    const int64_t r0 = (int64_t)by * CS_RPB, r1 = min(M, r0 + CS_RPB);
+    const bool full = c + 4 <= N && (lda % 4 == 0);
+    for (int64_t r = r0 + ty; r < r1; r += 4) {
+      float v[4];
+      load_row<T, 4>(a + r * lda + c, (int)min((int64_t)4, N - c), full, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[ty][tx][e] = s[e];
+  __syncthreads();
+  if (ty == 0 && c < N) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < N) atomicAdd(out + c + e, red[0][tx][e] + red[1][tx][e] + red[2][tx][e] + red[3][tx][e]);
+  }
+}
+extern "C" int32_t otr_colsum_grouped(const otr_colsum_item_t* items, int32_t n, void* stream) {
+  OTR_REQUIRE(n >= 0 && (items || n == 0), "colsum_grouped: null items");
+  hipStream_t s = (hipStream_t)stream;
+  for (int dt = 0; dt < 2; ++dt) {
+    ColsumGroup g{};
+    int blocks = 0;
+    auto flush = [&]() -> int32_t {
+      if (g.n == 0) return 0;
+      g.first[g.n] = blocks;
+      if (dt == OTR_F32) hipLaunchKernelGGL(colsum_grouped_kernel<float>, dim3((unsigned)blocks), dim3(64, 4), 0, s, g);
+      else hipLaunchKernelGGL(colsum_grouped_kernel<bf16_t>, dim3((unsigned)blocks), dim3(64, 4), 0, s, g);
+      g.n = 0;
+      blocks = 0;
+      return otr_check_launch("colsum_grouped");
+    };
+    for (int i = 0; i < n; ++i) {
+      const otr_colsum_item_t& it = items[i];
+      OTR_REQUIRE(it.a && it.out, "colsum_grouped: item %d has a null pointer", i);
+      OTR_REQUIRE(it.dtype == OTR_F32 || it.dtype == OTR_BF16, "colsum_grouped: item %d has a bad dtype", i);
+      OTR_REQUIRE(it.N > 0 && it.M >= 0 && it.lda >= it.N && it.lda < (1ll << 31) && it.M < (1ll << 31),
+                  "colsum_grouped: item %d has a bad shape", i);
+      OTR_REQUIRE((uintptr_t)it.a % 16 == 0, "colsum_grouped: item %d input must be 16-byte aligned", i);
+      if (it.dtype != dt || it.M == 0) continue;
+      const int rb = (int)((it.M + CS_RPB - 1) / CS_RPB), cb = (int)((it.N + 255) / 256);
+      const int k = g.n++;
+      g.first[k] = blocks;
+      g.a[k] = it.a; g.out[k] = it.out; g.M[k] = (int)it.M; g.N[k] = (int)it.N; g.lda[k] = (int)it.lda; g.rblocks[k] = rb;
+      blocks += rb * cb;
+      if (g.n == CSG_MAX)
+        if (int32_t e = flush()) return e;
+    }
+    if (int32_t e = flush()) return e;
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ batched transpose
 // One launch transposes every 2-D weight shadow: block -> (matrix, 64x64 tile) by binary search in the tile prefix.
 template <class T>

@@ -363,8 +363,10 @@ template <class OT> __device__ __noinline__ void store_tail_acc(OT* dst, const O
   }
 }
 
-template <class CT, class AT, class BT, class OT, int AMODE, int BMODE, int BM, int BN, bool FAST, bool PERSIST = false>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 VGPRs: two workgroups per CU
+// One workgroup's share of a GEMM: tiles tile0, tile0 + tile_stride, ... (PERSIST) or just tile0, k-slice `kslice`.
+// Shared by the plain kernel (blockIdx -> tile) and the grouped kernel (blockIdx -> problem -> tile).
+template <class CT, class AT, class BT, class OT, int AMODE, int BMODE, int BM, int BN, bool FAST, bool PERSIST>
+__device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, const int tile_stride, const int kslice) {
   using G = GemmCfg<CT>;
   constexpr int KCH = G::KCH, BK = G::BK, ROWB = G::ROWB;
   constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
@@ -376,19 +378,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
   const int tiles_n = (p.N + BN - 1) / BN;
   const int ntiles = tiles_n * ((p.M + BM - 1) / BM);
   // PERSIST (ksplit == 1 only): the grid is capped at the number of resident workgroups and each one walks tiles
-  // blockIdx.x, +gridDim.x, ...; the operand loads of the next tile are issued before the epilogue of the current
+  // tile0, +tile_stride, ...; the operand loads of the next tile are issued before the epilogue of the current
   // one, so the ~3 k-cycle stage-in latency and the epilogue overlap instead of adding up per tile.
-  int tile = blockIdx.x;
+  int tile = tile0;
   int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
 
   // k-slice of this workgroup
   const int nk_total = (p.K + BK - 1) / BK;
   const int per = (nk_total + p.ksplit - 1) / p.ksplit;
-  const int kt0 = blockIdx.y * per;
+  const int kt0 = kslice * per;
   const int kt1 = min(nk_total, kt0 + per);
   if (kt0 >= kt1) return;
 #define OTR_TRACE(slot) \
-  if (p.trace && tid == 0) p.trace[((int64_t)blockIdx.y * ntiles + tile) * 4 + (slot)] = __builtin_readcyclecounter();
+  if (p.trace && tid == 0) p.trace[((int64_t)kslice * ntiles + tile) * 4 + (slot)] = __builtin_readcyclecounter();
   OTR_TRACE(0)
 
   TileLoader<CT, AT, AMODE, BM, FAST> la;
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
   OTR_TRACE(2)
   // epilogue: acc[i][j][r] = C[m = .. + i*16 + (lane&15)][n = .. + j*16 + (lane>>4)*4 + r]
   if (!PERSIST && p.ksplit > 1) {  // partial tile -> workspace slab [split][M][N]; reduced by splitk_reduce_kernel
-    float* W = p.ws + (int64_t)blockIdx.y * p.M * p.N;
+    float* W = p.ws + (int64_t)kslice * p.M * p.N;
     const bool v4 = (p.N % 4 == 0);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
   if constexpr (PERSIST && D == 2) {
     // operands of this workgroup's next tile (clamped: the last round re-loads a valid tile and drops it); issued
     // AFTER the bias loads so that waiting for the bias does not wait for them (vmcnt retires in order)
-    const int nxt = min(tile + (int)gridDim.x, ntiles - 1);
+    const int nxt = min(tile + tile_stride, ntiles - 1);
     tile_m = nxt / tiles_n;
     tile_n = nxt - tile_m * tiles_n;
     la.init(p.A, p.lda, p.M, p.K, tile_m * BM, p.a_vec != 0, p.cg, tid);
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
   if constexpr (!PERSIST) {
     break;
   } else {
-    tile += gridDim.x;
+    tile += tile_stride;
     if (tile >= ntiles) break;
     if constexpr (D != 2) {
       tile_m = tile / tiles_n;
@@ -691,6 +693,46 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
   }
   }
 #undef OTR_TRACE
+}
+
+template <class CT, class AT, class BT, class OT, int AMODE, int BMODE, int BM, int BN, bool FAST, bool PERSIST = false>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 VGPRs: two workgroups per CU
+  gemm_body<CT, AT, BT, OT, AMODE, BMODE, BM, BN, FAST, PERSIST>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Grouped GEMM: ONE launch runs many independent problems of the same operand types (all weight gradients of a
+// backward pass: dw_i += dy_i^T x_i).  Workgroup b serves problem i with first[i] <= b < first[i+1]; no split-K
+// (problem-level parallelism fills the chip), results accumulate straight into C.  The descriptors travel in the
+// kernel-argument segment (captured by value in a hipGraph; no device-side table to keep in sync).
+constexpr int OTR_GROUP_MAX = 48;
+struct GroupDesc {
+  const void* A;
+  const void* B;
+  void* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  int a_vec, b_vec;
+};
+struct GroupedArgs {
+  int n;
+  int first[OTR_GROUP_MAX + 1];
+  GroupDesc d[OTR_GROUP_MAX];
+};
+template <class CT, class AT, class BT, class OT, int AMODE, int BMODE, int BM, int BN, bool FAST>
+__global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(GroupedArgs g) {
+  const int b = (int)blockIdx.x;
+  int i = 0;
+  for (int j = 1; j < g.n; ++j) i = (g.first[j] <= b) ? j : i;     // uniform, scalar
+  const GroupDesc& d = g.d[i];
+  GemmArgs p{};
+  p.A = d.A; p.B = d.B; p.C = d.C; p.bias = nullptr;
+  p.M = d.M; p.N = d.N; p.K = d.K;
+  p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
+  p.act = OTR_ACT_NONE; p.accumulate = 1;
+  p.a_vec = d.a_vec; p.b_vec = d.b_vec;
+  p.ksplit = 1; p.allow_split = 0; p.ws = nullptr; p.ws_bytes = 0; p.trace = nullptr;
+  gemm_body<CT, AT, BT, OT, AMODE, BMODE, BM, BN, FAST, false>(p, b - g.first[i], 1 << 30, 0);
 }
 
 // C = act( sum_s ws[s] + bias ) (+ C): the fixed-order (deterministic) second half of split-K
@@ -791,7 +833,8 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
   };
   const bool fast = (AMODE == MODE_KC || AMODE == MODE_MC) && (BMODE == MODE_KC || BMODE == MODE_MC) &&
                     side_fast(AMODE, a.a_vec, a.M) && side_fast(BMODE, a.b_vec, a.N) && g_otr_force_generic == 0 &&
-                    ((uintptr_t)a.C % 16 == 0) && (a.ldc % (16 / (int)sizeof(OT)) == 0) && !(a.accumulate && sizeof(OT) == 2);
+                    (a.ksplit > 1 ||          // split-K slabs go to the workspace; C is written by the reduce kernel
+                     (((uintptr_t)a.C % 16 == 0) && (a.ldc % (16 / (int)sizeof(OT)) == 0) && !(a.accumulate && sizeof(OT) == 2)));
   const int64_t ntiles = big ? t128 : t64;
   // persistent variant (no split-K): at most OTR_RESIDENT_WG workgroups, each walking tiles b, b+grid, ...
   const bool persist = fast && a.ksplit == 1 && g_otr_no_persist == 0;
@@ -820,6 +863,26 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
   }
   return otr_check_launch("gemm");
 }
+
+// Launch one grouped kernel over `n` (<= OTR_GROUP_MAX) descriptors that all satisfy the FAST-loader conditions.
+template <class CT, class AT, class BT, int BM, int BN>
+static int32_t gemm_grouped_launch(const GroupDesc* d, int n, hipStream_t s) {
+  GroupedArgs g{};
+  g.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    g.first[i] = blocks;
+    g.d[i] = d[i];
+    blocks += ((d[i].M + BM - 1) / BM) * ((d[i].N + BN - 1) / BN);
+  }
+  g.first[n] = blocks;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL((gemm_grouped_kernel<CT, AT, BT, float, MODE_MC, MODE_MC, BM, BN, true>), dim3((unsigned)blocks), dim3(256),
+                     0, s, g);
+  return otr_check_launch("gemm_grouped");
+}
+int32_t gemm_grouped_wgrad_bf16(const GroupDesc* d, int n, int a_dtype, int b_dtype, int big, hipStream_t s);
+int32_t gemm_grouped_wgrad_f32(const GroupDesc* d, int n, int a_dtype, int b_dtype, int big, hipStream_t s);
 
 // dtype dispatch helpers implemented in gemm_bf16.hip / gemm_f32.hip
 int32_t gemm_dispatch_bf16(const GemmArgs& a, int a_dtype, int b_dtype, int c_dtype, int amode, int bmode, hipStream_t s);

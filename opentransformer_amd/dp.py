@@ -28,50 +28,54 @@ class FlatDataParallel:
                 seen.add(id(p))
                 params.append(p)
         self.params = params
-        total = sum(p.numel() for p in params)
-        # pad to a multiple of 4 elements so every vectorised kernel can run over the whole buffer
-        self.numel = total
-        padded = (total + 3) // 4 * 4
+        # every parameter starts on a 64-element (256-byte) boundary of the flat buffers: gradient kernels then see
+        # 16-byte aligned outputs whatever the sizes before them (a 4234-wide bias would misalign everything after it)
+        ALIGN = 64
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.offsets = offs
+        self.numel = total                                  # flat length incl. alignment gaps
+        self.param_numel = sum(p.numel() for p in params)   # true parameter count
+        padded = total
         dev, dt = params[0].device, params[0].dtype
         self.flat_grad = torch.zeros(padded, device=dev, dtype=dt)
         self.flat_param = torch.empty(padded, device=dev, dtype=dt) if flatten_params else None
-        off = 0
-        for p in params:
+        if flatten_params:
+            self.flat_param.zero_()         # alignment gaps stay zero: their gradient is zero, Adam leaves them at zero
+        for p, off in zip(params, offs):
             n = p.numel()
             if flatten_params:
                 self.flat_param[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_param[off:off + n].view_as(p.data)
             p.grad = self.flat_grad[off:off + n].view_as(p.data)
             p._otr_grad_inplace = True      # ops.grad_target(): backward kernels accumulate straight into the view
-            off += n
-        if flatten_params and padded > total:
-            self.flat_param[total:].zero_()
         # bf16 shadow of every parameter (GEMM operand form), kept fresh by FusedAdam in the same pass
         self.flat_param_lp = None
         if flatten_params and dev.type == 'cuda' and dt == torch.float32:
             from . import ops
             if ops.get_compute_dtype() == 'bf16':
                 self.flat_param_lp = torch.empty(padded, device=dev, dtype=torch.bfloat16)
-                off = 0
-                for p in params:
+                for p, off in zip(params, offs):
                     n = p.numel()
                     p._otr_lp_view = self.flat_param_lp[off:off + n].view(p.shape)
-                    off += n
                 # transposed bf16 shadows of the 2-D weights ([K,N]: dgrad becomes a forward-type GEMM)
                 self.flat_param_lpt = torch.empty(padded, device=dev, dtype=torch.bfloat16)
                 table, tiles = [], 0
-                off = 0
-                for p in params:
+                for p, off in zip(params, offs):
                     n = p.numel()
                     if p.dim() == 2:
                         p._otr_lpt_view = self.flat_param_lpt[off:off + n].view(p.shape[1], p.shape[0])
                         table.append([off, p.shape[0], p.shape[1], tiles])
                         tiles += ((p.shape[0] + 63) // 64) * ((p.shape[1] + 63) // 64)
-                    off += n
                 # one launch transposes every 2-D shadow (include/otrans_hip.h: otr_transpose_batched)
                 self._lpt_table = torch.tensor(table, dtype=torch.int64, device=dev).reshape(-1, 4)
                 self._lpt_tiles = tiles
                 self.refresh_lp()
+        if dev.type == 'cuda':
+            from . import ops
+            ops.defer_weight_grads(True)    # weight / bias gradients run as grouped launches at the end of backward
 
     def refresh_lp(self):
         """re-cast the bf16 shadows after any out-of-band parameter change (load_state_dict, ...)."""
@@ -87,6 +91,10 @@ class FlatDataParallel:
                 C.c_void_p(self.flat_param_lp.data_ptr()), C.c_void_p(self.flat_param_lpt.data_ptr()),
                 C.c_void_p(self._lpt_table.data_ptr()), self._lpt_table.shape[0], self._lpt_tiles, 2,
                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'otr_transpose_batched')
+
+    def packed_grads(self):
+        """gradients without the alignment gaps, in parameter order (tests / checkpointing)"""
+        return torch.cat([self.flat_grad[o:o + p.numel()] for p, o in zip(self.params, self.offsets)])
 
     @property
     def world_size(self):

@@ -194,10 +194,65 @@ def linear_dgrad_raw(dy2, w, dx_dtype):
     return dx
 
 
+# ---------------------------------------------------------------------------------------- deferred weight gradients
+# With in-place gradient buffers (FlatDataParallel) the weight / bias gradients of a backward pass do not have to
+# be launched where autograd reaches them: nothing downstream reads them before the optimizer.  They are queued
+# and, when the autograd engine finishes, run as a few GROUPED launches (otr_linear_wgrad_grouped /
+# otr_colsum_grouped): ~150 latency-bound GEMM + split-K-reduce + column-sum launches per step become ~6.
+_wq = {'on': False, 'w': [], 'b': [], 'armed': False}
+
+
+def defer_weight_grads(on):
+    _wq['on'] = bool(on)
+
+
+def _arm_flush():
+    if not _wq['armed']:
+        _wq['armed'] = True
+        torch.autograd.Variable._execution_engine.queue_callback(flush_weight_grads)
+
+
+def flush_weight_grads():
+    """Launch everything queued by linear_wgrad_raw / colsum_raw (called by the autograd engine at the end of
+    backward; safe to call by hand)."""
+    _wq['armed'] = False
+    w, b = _wq['w'], _wq['b']
+    _wq['w'], _wq['b'] = [], []
+    lib = L.load()
+    if w:
+        items = (L.WgradItem * len(w))()
+        for it, (dy2, x2, out) in zip(items, w):
+            it.dy, it.x, it.dw = dy2.data_ptr(), x2.data_ptr(), out.data_ptr()
+            it.M, it.N, it.K = dy2.shape[0], dy2.shape[1], x2.shape[1]
+            it.ldy, it.ldx, it.ldw = dy2.stride(0), x2.stride(0), out.stride(0)
+            it.dy_dtype, it.x_dtype = _code(dy2.dtype), _code(x2.dtype)
+        ws = _workspace(w[0][0].device)
+        L.check(lib.otr_linear_wgrad_grouped(items, len(w), _compute_code(), _p(ws), _WS_BYTES, _stream()),
+                'otr_linear_wgrad_grouped')
+    if b:
+        items = (L.ColsumItem * len(b))()
+        for it, (a2, out) in zip(items, b):
+            it.a, it.out = a2.data_ptr(), out.data_ptr()
+            it.M, it.N, it.lda, it.dtype = a2.shape[0], a2.shape[1], a2.stride(0), _code(a2.dtype)
+        L.check(lib.otr_colsum_grouped(items, len(b), _stream()), 'otr_colsum_grouped')
+
+
+def _in_backward():
+    """True while the autograd engine is executing a backward pass on this thread (queue_callback needs it)."""
+    try:
+        return torch._C._current_graph_task_id() != -1
+    except AttributeError:          # very old torch: no way to tell, never defer
+        return False
+
+
 def linear_wgrad_raw(dy2, x2, w_like, out=None):
     """dw = dy^T x; with `out` (an fp32 [N,K] gradient buffer) the result is ACCUMULATED into it."""
     M, N = dy2.shape
     K = x2.shape[1]
+    if out is not None and _wq['on'] and out.stride(1) == 1 and dy2.stride(1) == 1 and x2.stride(1) == 1 and _in_backward():
+        _wq['w'].append((dy2, x2, out))
+        _arm_flush()
+        return out
     dw = out if out is not None else torch.empty((N, K), dtype=torch.float32, device=dy2.device)
     d = _linear_desc(M, N, K, x2.dtype, torch.float32, dy2.dtype, x2.stride(0), K, dy2.stride(0),
                      accumulate=int(out is not None))
@@ -209,6 +264,10 @@ def linear_wgrad_raw(dy2, x2, w_like, out=None):
 def colsum_raw(a2, out=None):
     M, N = a2.shape
     acc = out is not None
+    if acc and _wq['on'] and a2.stride(1) == 1 and a2.data_ptr() % 16 == 0 and _in_backward():
+        _wq['b'].append((a2, out))
+        _arm_flush()
+        return out
     if out is None:
         out = torch.empty((N,), dtype=torch.float32, device=a2.device)
     L.check(L.load().otr_colsum(_p(a2), _code(a2.dtype), M, N, a2.stride(0), _p(out), int(acc), _stream()), 'otr_colsum')

@@ -67,9 +67,9 @@ def _worker(rank, world, port, out):
     loss = dp(tok[shard], tgt[shard])
     loss.backward()
     scale, _ = dp.all_reduce_gradients()
-    grads = dp.flat_grad[:dp.numel] * scale
+    grads = dp.packed_grads() * scale
     if rank == 0:
-        torch.save({'grad': grads.clone(), 'loss': loss.detach(), 'n': dp.numel,
+        torch.save({'grad': grads.clone(), 'loss': loss.detach(), 'n': dp.param_numel,
                     'views_ok': all(p.grad.data_ptr() >= dp.flat_grad.data_ptr() for p in dp.params)}, out)
     dist.barrier()
     dist.destroy_process_group()

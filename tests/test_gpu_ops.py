@@ -440,3 +440,42 @@ def test_deferred_bias_gradient_through_layernorm(mode):
         torch.testing.assert_close(res[2], res[0], rtol=tol, atol=tol * float(res[0].abs().max()))
     finally:
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_grouped_weight_and_bias_gradients(mode):
+    """otr_linear_wgrad_grouped / otr_colsum_grouped == the per-layer launches they replace (accumulating), over
+    ragged shapes: long and short contractions, small and large outputs, both dy dtypes, one misaligned item."""
+    import ctypes as C
+    from opentransformer_amd import _lib as L
+    from opentransformer_amd import ops
+    ops.set_compute_dtype(mode)
+    try:
+        gen = torch.Generator().manual_seed(21)
+        adt = ops.act_dtype()
+        shapes = [(1000, 768, 256), (1000, 256, 256), (480, 4096, 256), (1000, 256, 2048), (60, 64, 64), (7, 128, 200),
+                  (333, 100, 36), (1000, 130, 68)]
+        flat = torch.zeros(sum(n * k for _, n, k in shapes) + 64, device=DEV)
+        items_w, items_b, refs, off = [], [], [], 0
+        for idx, (m, n, k) in enumerate(shapes):
+            dyt = adt if idx % 2 == 0 else torch.float32
+            dy = torch.randn(m, n, generator=gen).to(DEV, dyt)
+            x = torch.randn(m, k, generator=gen).to(DEV, adt)
+            if idx == 6:
+                off += 1                                  # misaligned gradient view -> the stand-alone fallback
+            out = flat[off:off + n * k].view(n, k)
+            out.fill_(0.25)
+            off += n * k
+            bias = torch.full((n,), -1.0, device=DEV)
+            items_w.append((dy, x, out))
+            items_b.append((dy, bias))
+            refs.append((0.25 + dy.float().t() @ x.float(), -1.0 + dy.float().sum(0)))
+        ops._wq['w'], ops._wq['b'] = list(items_w), list(items_b)
+        ops.flush_weight_grads()
+        tol = 2e-5 if mode == 'fp32' else 2e-2
+        for (dy, x, out), (dyb, bias), (rw, rb) in zip(items_w, items_b, refs):
+            scale = float(rw.abs().max())
+            torch.testing.assert_close(out, rw, rtol=tol, atol=tol * scale)
+            torch.testing.assert_close(bias, rb, rtol=1e-4, atol=1e-3 * float(rb.abs().max()))
+    finally:
+        ops.set_compute_dtype('bf16')
