@@ -138,6 +138,87 @@ __device__ __forceinline__ uint4 read_tr(const unsigned char* lds, int row, int 
   }
 }
 
+// ---- two-phase versions of the tile loaders (16-byte aligned operands only): ld_* issues every global load of a
+// tile back to back into registers, st_* writes the LDS image later.  The kernels issue the loads of block i+1
+// before the MFMAs of block i, so the HBM/L2 latency of the streamed operand hides behind compute instead of being
+// paid once per block between two barriers.  All loads are unconditional (rows clamped, invalid rows zeroed with a
+// mask at store time): a load inside a branch gets its own vmcnt(0) from hipcc.
+template <class CT, int DK> struct RmRegs {
+  static constexpr int NU = (64 * ACfg<CT, DK>::NCH) / 256;
+  static_assert((64 * ACfg<CT, DK>::NCH) % 256 == 0, "row-major tile must divide evenly over 256 threads");
+  uint4 v[NU];
+};
+template <class CT, int DK>
+__device__ __forceinline__ void ld_rm(RmRegs<CT, DK>& r, const CT* g, int64_t ts, int nvalid, int tid) {
+  using C = ACfg<CT, DK>;
+#pragma unroll
+  for (int u = 0; u < RmRegs<CT, DK>::NU; ++u) {
+    const int id = tid + 256 * u, row = id / C::NCH, c = id - row * C::NCH;
+    const int rr = min(row, nvalid - 1), cc = (c * C::CE < DK) ? c * C::CE : 0;
+    r.v[u] = *reinterpret_cast<const uint4*>(g + (int64_t)rr * ts + cc);
+  }
+}
+template <class CT, int DK>
+__device__ __forceinline__ void st_rm(unsigned char* lds, const RmRegs<CT, DK>& r, int nvalid, int tid) {
+  using C = ACfg<CT, DK>;
+#pragma unroll
+  for (int u = 0; u < RmRegs<CT, DK>::NU; ++u) {
+    const int id = tid + 256 * u, row = id / C::NCH, c = id - row * C::NCH;
+    const uint32_t m = (uint32_t)0 - (uint32_t)(row < nvalid && c * C::CE < DK);
+    uint4 q = r.v[u];
+    q.x &= m; q.y &= m; q.z &= m; q.w &= m;
+    *reinterpret_cast<uint4*>(lds + row * C::ROWB + ((c ^ swz<C::NCH>(row)) << 4)) = q;
+  }
+}
+template <class CT, int DK> struct TrRegs {
+  static constexpr int DP = DK / 2;
+  static constexpr int NI = (DP * 16 + 255) / 256;
+  uint2 w[NI][4];   // two adjacent head-dim elements of 4 consecutive streamed rows (bf16 uses .x only)
+};
+template <class CT, int DK>
+__device__ __forceinline__ void ld_tr(TrRegs<CT, DK>& r, const CT* g, int64_t ts, int nvalid, int tid) {
+  constexpr int DP = DK / 2;
+#pragma unroll
+  for (int it = 0; it < TrRegs<CT, DK>::NI; ++it) {
+    const int id = min(tid + 256 * it, DP * 16 - 1), dp = id % DP, kg = id / DP;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int rr = min(kg * 4 + j, nvalid - 1);
+      const CT* p = g + (int64_t)rr * ts + 2 * dp;
+      if constexpr (sizeof(CT) == 4) r.w[it][j] = *reinterpret_cast<const uint2*>(p);
+      else r.w[it][j].x = *reinterpret_cast<const uint32_t*>(p);
+    }
+  }
+}
+template <class CT, int DK>
+__device__ __forceinline__ void st_tr(unsigned char* lds, const TrRegs<CT, DK>& r, int nvalid, int tid) {
+  using C = ACfg<CT, DK>;
+  constexpr int DP = DK / 2;
+#pragma unroll
+  for (int it = 0; it < TrRegs<CT, DK>::NI; ++it) {
+    const int id = tid + 256 * it;
+    if (id < DP * 16) {                 // LDS-only branch (DK = 16: half of the threads have no patch)
+      const int dp = id % DP, kg = id / DP;
+      uint32_t lo[4], hi[4];            // element 2dp / 2dp+1 of rows kg*4..+3, as raw bits
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t m = (uint32_t)0 - (uint32_t)(kg * 4 + j < nvalid);
+        if constexpr (sizeof(CT) == 4) { lo[j] = r.w[it][j].x & m; hi[j] = r.w[it][j].y & m; }
+        else { lo[j] = (r.w[it][j].x & 0xffffu) & m; hi[j] = (r.w[it][j].x >> 16) & m; }
+      }
+      unsigned char* d0 = lds + (2 * dp) * C::TSTRIDE + kg * 4 * (int)sizeof(CT);
+      unsigned char* d1 = d0 + C::TSTRIDE;
+      if constexpr (sizeof(CT) == 2) {
+        *reinterpret_cast<uint2*>(d0) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+        *reinterpret_cast<uint2*>(d1) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+      } else {
+        *reinterpret_cast<uint4*>(d0) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        *reinterpret_cast<uint4*>(d1) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+      }
+    }
+  }
+}
+
 // per-wave register operand: 16 rows (row = lane&15) x DKP, chunk ks*4+g per k-step
 template <class CT, int DK>
 __device__ __forceinline__ void load_reg_frags(uint4* fr, const CT* g, int64_t ts, int row, int nrows, bool vec, int lg) {
@@ -180,7 +261,7 @@ template <class CT> __device__ __forceinline__ void store4(CT* p, float a, float
 #define NEG_INF (-__builtin_huge_valf())
 
 // ================================================================================================ forward
-template <class CT, int DK> __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   using C = ACfg<CT, DK>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::RM_BYTES + C::TR_BYTES];
   unsigned char* sK = smem;
@@ -204,12 +285,29 @@ template <class CT, int DK> __global__ __launch_bounds__(256) void attn_fwd_kern
   float m = NEG_INF, l = 0.f;
 
   const int nkb = (p.Tk + 63) / 64;
+  RmRegs<CT, DK> kreg;
+  TrRegs<CT, DK> vreg;
+  if constexpr (PIPE) {
+    ld_rm<CT, DK>(kreg, K, p.k_ts, min(64, p.Tk), tid);
+    ld_tr<CT, DK>(vreg, V, p.v_ts, min(64, p.Tk), tid);
+  }
   for (int kb = 0; kb < nkb; ++kb) {
     __syncthreads();
     int nvalid = min(64, p.Tk - kb * 64);
-    load_tile_rm<CT, DK>(sK, K + (int64_t)kb * 64 * p.k_ts, p.k_ts, nvalid, vec, tid);
-    load_tile_tr<CT, DK>(sVt, V + (int64_t)kb * 64 * p.v_ts, p.v_ts, nvalid, vec, tid);
+    if constexpr (PIPE) {
+      st_rm<CT, DK>(sK, kreg, nvalid, tid);
+      st_tr<CT, DK>(sVt, vreg, nvalid, tid);
+    } else {
+      load_tile_rm<CT, DK>(sK, K + (int64_t)kb * 64 * p.k_ts, p.k_ts, nvalid, vec, tid);
+      load_tile_tr<CT, DK>(sVt, V + (int64_t)kb * 64 * p.v_ts, p.v_ts, nvalid, vec, tid);
+    }
     __syncthreads();
+    if constexpr (PIPE) {   // next block's loads fly during this block's MFMAs (last round: redundant re-load, dropped)
+      const int kn = min(kb + 1, nkb - 1), nv2 = min(64, p.Tk - kn * 64);
+      ld_rm<CT, DK>(kreg, K + (int64_t)kn * 64 * p.k_ts, p.k_ts, nv2, tid);
+      ld_tr<CT, DK>(vreg, V + (int64_t)kn * 64 * p.v_ts, p.v_ts, nv2, tid);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
     f32x4 st[4];
 #pragma unroll
@@ -292,7 +390,7 @@ template <class CT> __global__ void attn_delta_kernel(AttnArgs p, int dk) {
 
 // ================================================================================================ dK, dV
 // wave owns 16 keys (columns); streams 64-query blocks.
-template <class CT, int DK> __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
+template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
   using C = ACfg<CT, DK>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C::RM_BYTES + 2 * C::TR_BYTES + 512];
   unsigned char* sQ = smem;
@@ -323,18 +421,51 @@ template <class CT, int DK> __global__ __launch_bounds__(256) void attn_bwd_dkdv
   for (int i = 0; i < C::DT; ++i) { dk_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const int nqb = (p.Tq + 63) / 64;
+  RmRegs<CT, DK> qreg, doreg;
+  TrRegs<CT, DK> qtreg, dotreg;
+  float lreg = 0.f, dreg = 0.f;
+  if constexpr (PIPE) {
+    const int nv0 = min(64, p.Tq);
+    ld_rm<CT, DK>(qreg, Q, p.q_ts, nv0, tid);
+    ld_rm<CT, DK>(doreg, dO, p.o_ts, nv0, tid);
+    ld_tr<CT, DK>(qtreg, Q, p.q_ts, nv0, tid);
+    ld_tr<CT, DK>(dotreg, dO, p.o_ts, nv0, tid);
+    lreg = lse[min(tid & 63, p.Tq - 1)];
+    dreg = del[min(tid & 63, p.Tq - 1)];
+  }
   for (int qb = 0; qb < nqb; ++qb) {
     __syncthreads();
     int nvalid = min(64, p.Tq - qb * 64);
-    load_tile_rm<CT, DK>(sQ, Q + (int64_t)qb * 64 * p.q_ts, p.q_ts, nvalid, vec, tid);
-    load_tile_rm<CT, DK>(sdO, dO + (int64_t)qb * 64 * p.o_ts, p.o_ts, nvalid, vec, tid);
-    load_tile_tr<CT, DK>(sQt, Q + (int64_t)qb * 64 * p.q_ts, p.q_ts, nvalid, vec, tid);
-    load_tile_tr<CT, DK>(sdOt, dO + (int64_t)qb * 64 * p.o_ts, p.o_ts, nvalid, vec, tid);
-    if (tid < 64) {
-      sLse[tid] = (tid < nvalid) ? lse[qb * 64 + tid] : 0.f;
-      sDel[tid] = (tid < nvalid) ? del[qb * 64 + tid] : 0.f;
+    if constexpr (PIPE) {
+      st_rm<CT, DK>(sQ, qreg, nvalid, tid);
+      st_rm<CT, DK>(sdO, doreg, nvalid, tid);
+      st_tr<CT, DK>(sQt, qtreg, nvalid, tid);
+      st_tr<CT, DK>(sdOt, dotreg, nvalid, tid);
+      if (tid < 64) {
+        sLse[tid] = (tid < nvalid) ? lreg : 0.f;
+        sDel[tid] = (tid < nvalid) ? dreg : 0.f;
+      }
+    } else {
+      load_tile_rm<CT, DK>(sQ, Q + (int64_t)qb * 64 * p.q_ts, p.q_ts, nvalid, vec, tid);
+      load_tile_rm<CT, DK>(sdO, dO + (int64_t)qb * 64 * p.o_ts, p.o_ts, nvalid, vec, tid);
+      load_tile_tr<CT, DK>(sQt, Q + (int64_t)qb * 64 * p.q_ts, p.q_ts, nvalid, vec, tid);
+      load_tile_tr<CT, DK>(sdOt, dO + (int64_t)qb * 64 * p.o_ts, p.o_ts, nvalid, vec, tid);
+      if (tid < 64) {
+        sLse[tid] = (tid < nvalid) ? lse[qb * 64 + tid] : 0.f;
+        sDel[tid] = (tid < nvalid) ? del[qb * 64 + tid] : 0.f;
+      }
     }
     __syncthreads();
+    if constexpr (PIPE) {
+      const int qn = min(qb + 1, nqb - 1), nv2 = min(64, p.Tq - qn * 64);
+      ld_rm<CT, DK>(qreg, Q + (int64_t)qn * 64 * p.q_ts, p.q_ts, nv2, tid);
+      ld_rm<CT, DK>(doreg, dO + (int64_t)qn * 64 * p.o_ts, p.o_ts, nv2, tid);
+      ld_tr<CT, DK>(qtreg, Q + (int64_t)qn * 64 * p.q_ts, p.q_ts, nv2, tid);
+      ld_tr<CT, DK>(dotreg, dO + (int64_t)qn * 64 * p.o_ts, p.o_ts, nv2, tid);
+      lreg = lse[min(qn * 64 + (tid & 63), p.Tq - 1)];
+      dreg = del[min(qn * 64 + (tid & 63), p.Tq - 1)];
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
     f32x4 pt[4], ds[4];  // tiles over q (rows), cols = keys
 #pragma unroll
@@ -383,7 +514,7 @@ template <class CT, int DK> __global__ __launch_bounds__(256) void attn_bwd_dkdv
 
 // ================================================================================================ dQ
 // wave owns 16 queries (columns); streams 64-key blocks.
-template <class CT, int DK> __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
   using C = ACfg<CT, DK>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C::RM_BYTES + C::TR_BYTES];
   unsigned char* sK = smem;
@@ -412,13 +543,34 @@ template <class CT, int DK> __global__ __launch_bounds__(256) void attn_bwd_dq_k
   for (int i = 0; i < C::DT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkb = (p.Tk + 63) / 64;
+  RmRegs<CT, DK> kreg, vreg;
+  TrRegs<CT, DK> ktreg;
+  if constexpr (PIPE) {
+    const int nv0 = min(64, p.Tk);
+    ld_rm<CT, DK>(kreg, K, p.k_ts, nv0, tid);
+    ld_rm<CT, DK>(vreg, V, p.v_ts, nv0, tid);
+    ld_tr<CT, DK>(ktreg, K, p.k_ts, nv0, tid);
+  }
   for (int kb = 0; kb < nkb; ++kb) {
     __syncthreads();
     int nvalid = min(64, p.Tk - kb * 64);
-    load_tile_rm<CT, DK>(sK, K + (int64_t)kb * 64 * p.k_ts, p.k_ts, nvalid, vec, tid);
-    load_tile_rm<CT, DK>(sV, V + (int64_t)kb * 64 * p.v_ts, p.v_ts, nvalid, vec, tid);
-    load_tile_tr<CT, DK>(sKt, K + (int64_t)kb * 64 * p.k_ts, p.k_ts, nvalid, vec, tid);
+    if constexpr (PIPE) {
+      st_rm<CT, DK>(sK, kreg, nvalid, tid);
+      st_rm<CT, DK>(sV, vreg, nvalid, tid);
+      st_tr<CT, DK>(sKt, ktreg, nvalid, tid);
+    } else {
+      load_tile_rm<CT, DK>(sK, K + (int64_t)kb * 64 * p.k_ts, p.k_ts, nvalid, vec, tid);
+      load_tile_rm<CT, DK>(sV, V + (int64_t)kb * 64 * p.v_ts, p.v_ts, nvalid, vec, tid);
+      load_tile_tr<CT, DK>(sKt, K + (int64_t)kb * 64 * p.k_ts, p.k_ts, nvalid, vec, tid);
+    }
     __syncthreads();
+    if constexpr (PIPE) {
+      const int kn = min(kb + 1, nkb - 1), nv2 = min(64, p.Tk - kn * 64);
+      ld_rm<CT, DK>(kreg, K + (int64_t)kn * 64 * p.k_ts, p.k_ts, nv2, tid);
+      ld_rm<CT, DK>(vreg, V + (int64_t)kn * 64 * p.v_ts, p.v_ts, nv2, tid);
+      ld_tr<CT, DK>(ktreg, K + (int64_t)kn * 64 * p.k_ts, p.k_ts, nv2, tid);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
     f32x4 ds[4];  // tiles over keys (rows), cols = queries
 #pragma unroll
@@ -479,14 +631,18 @@ static int vec_ok(const otr_attn_desc_t* d, std::initializer_list<const void*> p
   return 1;
 }
 
-#define DK_SWITCH(CTYPE, KERNEL, GRID)                                                                    \
+#define DK_SWITCH_P(CTYPE, KERNEL, GRID, PIPE)                                                            \
   switch (d->dk) {                                                                                        \
-    case 16: hipLaunchKernelGGL((KERNEL<CTYPE, 16>), GRID, dim3(256), 0, s, a); break;                    \
-    case 32: hipLaunchKernelGGL((KERNEL<CTYPE, 32>), GRID, dim3(256), 0, s, a); break;                    \
-    case 64: hipLaunchKernelGGL((KERNEL<CTYPE, 64>), GRID, dim3(256), 0, s, a); break;                    \
-    case 96: hipLaunchKernelGGL((KERNEL<CTYPE, 96>), GRID, dim3(256), 0, s, a); break;                    \
-    default: hipLaunchKernelGGL((KERNEL<CTYPE, 128>), GRID, dim3(256), 0, s, a); break;                   \
+    case 16: hipLaunchKernelGGL((KERNEL<CTYPE, 16, PIPE>), GRID, dim3(256), 0, s, a); break;              \
+    case 32: hipLaunchKernelGGL((KERNEL<CTYPE, 32, PIPE>), GRID, dim3(256), 0, s, a); break;              \
+    case 64: hipLaunchKernelGGL((KERNEL<CTYPE, 64, PIPE>), GRID, dim3(256), 0, s, a); break;              \
+    case 96: hipLaunchKernelGGL((KERNEL<CTYPE, 96, PIPE>), GRID, dim3(256), 0, s, a); break;              \
+    default: hipLaunchKernelGGL((KERNEL<CTYPE, 128, PIPE>), GRID, dim3(256), 0, s, a); break;             \
   }
+// aligned operands take the software-pipelined (register-prefetch) instantiation
+#define DK_SWITCH(CTYPE, KERNEL, GRID)                    \
+  if (a.vec) { DK_SWITCH_P(CTYPE, KERNEL, GRID, true) }   \
+  else { DK_SWITCH_P(CTYPE, KERNEL, GRID, false) }
 
 extern "C" int32_t otr_attention_fwd(const otr_attn_desc_t* d, const void* q, const void* k, const void* v,
                                      const uint8_t* key_mask, void* o, float* lse, void* stream) {
