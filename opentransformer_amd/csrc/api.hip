@@ -163,20 +163,19 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
     if (v.empty()) continue;
     // longest contraction first: the long tiles start early, the short ones fill the tail
     std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return items[a].M > items[b].M; });
-    for (size_t c0 = 0; c0 < v.size(); c0 += OTR_GROUP_MAX) {
-      GroupDesc d[OTR_GROUP_MAX];
-      int m = 0;
-      for (size_t c = c0; c < v.size() && m < OTR_GROUP_MAX; ++c, ++m) {
-        const otr_wgrad_item_t& it = items[v[c]];
-        d[m].A = it.dy; d[m].B = it.x; d[m].C = it.dw;
-        d[m].M = it.N; d[m].N = it.K; d[m].K = it.M;
-        d[m].lda = (int)it.ldy; d[m].ldb = (int)it.ldx; d[m].ldc = (int)it.ldw;
-        d[m].a_vec = 1; d[m].b_vec = 1;
-      }
-      const int ad = (key >> 1) & 1, bd = key & 1, big = key >> 2;
-      int32_t e = compute == OTR_BF16 ? gemm_grouped_wgrad_bf16(d, m, ad, bd, big, s) : gemm_grouped_wgrad_f32(d, m, ad, bd, big, s);
-      if (e) return e;
+    std::vector<GroupDesc> d(v.size());
+    for (size_t c = 0; c < v.size(); ++c) {
+      const otr_wgrad_item_t& it = items[v[c]];
+      d[c].A = it.dy; d[c].B = it.x; d[c].C = it.dw;
+      d[c].M = it.N; d[c].N = it.K; d[c].K = it.M;
+      d[c].lda = (int)it.ldy; d[c].ldb = (int)it.ldx; d[c].ldc = (int)it.ldw;
+      d[c].a_vec = 1; d[c].b_vec = 1;
     }
+    const int ad = (key >> 1) & 1, bd = key & 1, big = key >> 2;
+    OTR_REQUIRE(workspace && workspace_bytes >= 4096, "linear_wgrad_grouped: needs a workspace (descriptor table)");
+    int32_t e = compute == OTR_BF16 ? gemm_grouped_wgrad_bf16(d.data(), (int)d.size(), ad, bd, big, workspace, workspace_bytes, s)
+                                    : gemm_grouped_wgrad_f32(d.data(), (int)d.size(), ad, bd, big, workspace, workspace_bytes, s);
+    if (e) return e;
   }
   return 0;
 }

@@ -39,9 +39,9 @@ int32_t gemm_dispatch_bf16(const GemmArgs& a, int ad, int bd, int cd, int amode,
   }
 }
 
-int32_t gemm_grouped_wgrad_bf16(const GroupDesc* d, int n, int ad, int bd, int big, hipStream_t s) {
+int32_t gemm_grouped_wgrad_bf16(const GroupDesc* d, int n, int ad, int bd, int big, void* tm, int64_t tb, hipStream_t s) {
 #define GCASE(AT, BT)                                                                  \
-  return big ? gemm_grouped_launch<bf16_t, AT, BT, 128, 128>(d, n, s) : gemm_grouped_launch<bf16_t, AT, BT, 64, 64>(d, n, s)
+  return big ? gemm_grouped_launch<bf16_t, AT, BT, 128, 128>(d, n, tm, tb, s) : gemm_grouped_launch<bf16_t, AT, BT, 64, 64>(d, n, tm, tb, s)
   if (ad == OTR_F32 && bd == OTR_F32) { GCASE(float, float); }
   if (ad == OTR_F32 && bd == OTR_BF16) { GCASE(float, bf16_t); }
   if (ad == OTR_BF16 && bd == OTR_F32) { GCASE(bf16_t, float); }

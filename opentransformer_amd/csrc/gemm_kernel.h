@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 
 // backward pass: dw_i += dy_i^T x_i).  Workgroup b serves problem i with first[i] <= b < first[i+1]; no split-K
 // (problem-level parallelism fills the chip), results accumulate straight into C.  The descriptors travel in the
 // kernel-argument segment (captured by value in a hipGraph; no device-side table to keep in sync).
-constexpr int OTR_GROUP_MAX = 48;
+constexpr int OTR_GROUP_MAX = 48;   // descriptors per writer launch (kernel-argument segment stays < 4 KB; < 64 threads)
 struct GroupDesc {
   const void* A;
   const void* B;
@@ -719,12 +719,28 @@ struct GroupedArgs {
   int first[OTR_GROUP_MAX + 1];
   GroupDesc d[OTR_GROUP_MAX];
 };
+// The descriptor table lives in device memory (head of the caller's workspace) so that ONE launch can serve every
+// problem of a group (>100 for a full model: with launches of <= 48 the small long-contraction problems ended up
+// alone in a second, badly filled launch).  It is filled by tiny writer kernels whose kernel-argument segments carry
+// OTR_GROUP_MAX descriptors each: hipGraph-capturable by value, no host staging buffer to keep alive.
+static __global__ void grouped_table_write_kernel(GroupedArgs g, GroupDesc* table, int* first, int offset) {
+  const int i = (int)threadIdx.x;
+  if (i < g.n) {
+    table[offset + i] = g.d[i];
+    first[offset + i] = g.first[i];
+  }
+  if (i == g.n) first[offset + i] = g.first[i];      // running end marker; overwritten by the next chunk's entry 0
+}
 template <class CT, class AT, class BT, class OT, int AMODE, int BMODE, int BM, int BN, bool FAST>
-__global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(GroupedArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GroupDesc* __restrict__ table, const int* __restrict__ first,
+                                                              int n) {
   const int b = (int)blockIdx.x;
-  int i = 0;
-  for (int j = 1; j < g.n; ++j) i = (g.first[j] <= b) ? j : i;     // uniform, scalar
-  const GroupDesc& d = g.d[i];
+  int lo = 0, hi = n - 1;                              // last problem whose first block <= b (uniform: scalar loads)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (first[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const GroupDesc d = table[lo];
   GemmArgs p{};
   p.A = d.A; p.B = d.B; p.C = d.C; p.bias = nullptr;
   p.M = d.M; p.N = d.N; p.K = d.K;
@@ -732,7 +748,7 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(GroupedArgs g) {
   p.act = OTR_ACT_NONE; p.accumulate = 1;
   p.a_vec = d.a_vec; p.b_vec = d.b_vec;
   p.ksplit = 1; p.allow_split = 0; p.ws = nullptr; p.ws_bytes = 0; p.trace = nullptr;
-  gemm_body<CT, AT, BT, OT, AMODE, BMODE, BM, BN, FAST, false>(p, b - g.first[i], 1 << 30, 0);
+  gemm_body<CT, AT, BT, OT, AMODE, BMODE, BM, BN, FAST, false>(p, b - first[lo], 1 << 30, 0);
 }
 
 // C = act( sum_s ws[s] + bias ) (+ C): the fixed-order (deterministic) second half of split-K
@@ -866,25 +882,44 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
   return otr_check_launch("gemm");
 }
 
-// Launch one grouped kernel over `n` (<= OTR_GROUP_MAX) descriptors that all satisfy the FAST-loader conditions.
+// Launch ONE grouped kernel over n descriptors that all satisfy the FAST-loader conditions.  `table_mem` (device,
+// table_bytes) receives the descriptor table; if it is too small the problems go in several launches.
+static inline int64_t grouped_table_bytes(int n) { return (int64_t)n * (int64_t)sizeof(GroupDesc) + ((int64_t)n + 1) * 4 + 64; }
 template <class CT, class AT, class BT, int BM, int BN>
-static int32_t gemm_grouped_launch(const GroupDesc* d, int n, hipStream_t s) {
-  GroupedArgs g{};
-  g.n = n;
-  int blocks = 0;
-  for (int i = 0; i < n; ++i) {
-    g.first[i] = blocks;
-    g.d[i] = d[i];
-    blocks += ((d[i].M + BM - 1) / BM) * ((d[i].N + BN - 1) / BN);
+static int32_t gemm_grouped_launch(const GroupDesc* d, int n, void* table_mem, int64_t table_bytes, hipStream_t s) {
+  int cap = n;
+  while (cap > 1 && grouped_table_bytes(cap) > table_bytes) cap /= 2;
+  if (grouped_table_bytes(cap) > table_bytes) {
+    otr_set_error("grouped gemm: workspace of %lld bytes cannot hold a descriptor table", (long long)table_bytes);
+    return -1;
   }
-  g.first[n] = blocks;
-  if (blocks == 0) return 0;
-  hipLaunchKernelGGL((gemm_grouped_kernel<CT, AT, BT, float, MODE_MC, MODE_MC, BM, BN, true>), dim3((unsigned)blocks), dim3(256),
-                     0, s, g);
+  for (int base = 0; base < n; base += cap) {
+    const int m = (n - base < cap) ? n - base : cap;
+    GroupDesc* table = reinterpret_cast<GroupDesc*>(table_mem);
+    int* first = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(table_mem) + (((int64_t)m * sizeof(GroupDesc) + 63) / 64) * 64);
+    int blocks = 0;
+    for (int c0 = 0; c0 < m; c0 += OTR_GROUP_MAX) {
+      GroupedArgs g{};
+      g.n = (m - c0 < OTR_GROUP_MAX) ? m - c0 : OTR_GROUP_MAX;
+      for (int i = 0; i < g.n; ++i) {
+        const GroupDesc& di = d[base + c0 + i];
+        g.first[i] = blocks;
+        g.d[i] = di;
+        blocks += ((di.M + BM - 1) / BM) * ((di.N + BN - 1) / BN);
+      }
+      g.first[g.n] = blocks;
+      hipLaunchKernelGGL(grouped_table_write_kernel, dim3(1), dim3(64), 0, s, g, table, first, c0);
+    }
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL((gemm_grouped_kernel<CT, AT, BT, float, MODE_MC, MODE_MC, BM, BN, true>), dim3((unsigned)blocks), dim3(256),
+                       0, s, table, first, m);
+  }
   return otr_check_launch("gemm_grouped");
 }
-int32_t gemm_grouped_wgrad_bf16(const GroupDesc* d, int n, int a_dtype, int b_dtype, int big, hipStream_t s);
-int32_t gemm_grouped_wgrad_f32(const GroupDesc* d, int n, int a_dtype, int b_dtype, int big, hipStream_t s);
+int32_t gemm_grouped_wgrad_bf16(const GroupDesc* d, int n, int a_dtype, int b_dtype, int big, void* table_mem, int64_t table_bytes,
+                                hipStream_t s);
+int32_t gemm_grouped_wgrad_f32(const GroupDesc* d, int n, int a_dtype, int b_dtype, int big, void* table_mem, int64_t table_bytes,
+                               hipStream_t s);
 
 // dtype dispatch helpers implemented in gemm_bf16.hip / gemm_f32.hip
 int32_t gemm_dispatch_bf16(const GemmArgs& a, int a_dtype, int b_dtype, int c_dtype, int amode, int bmode, hipStream_t s);

@@ -92,65 +92,83 @@ template <class AT, bool HAS_A> __global__ __launch_bounds__(256) void add_ln_fw
 
 constexpr int LN_BWD_ROWS = 8;  // rows per wave -> 32 rows per block
 
-template <class AT, bool HAS_A> __global__ __launch_bounds__(256) void add_ln_bwd_kernel(LnArgs p) {
-  __shared__ float red[2][4][LN_MAXV * 64 * 4];  // [gamma|beta][wave][column]  (32 KB)
+// NV = ceil(d / 256): float4 slots per lane actually used (d = 256 -> 1).  Each wave owns LN_BWD_ROWS rows; the loads of
+// ALL of them (dy, z, mean, rstd) are issued back to back before any arithmetic (rows clamped, tails masked), so a
+// wave has 2*LN_BWD_ROWS*NV 16-byte loads in flight instead of walking the rows one dependent round trip at a time.
+template <class AT, bool HAS_A, int NV> __global__ __launch_bounds__(256) void add_ln_bwd_kernel(LnArgs p) {
+  __shared__ float red[2][4][NV * 256];  // [gamma|beta][wave][column]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int d = p.d;
   const bool drop = HAS_A && p.p_drop > 0.f;
   const uint64_t seed = drop ? *p.seed : 0;
   const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
   const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
-  float gam[LN_MAXV][4], dg[LN_MAXV][4], db[LN_MAXV][4], dab[LN_MAXV][4];
   const bool want_ab = HAS_A && p.da_colsum != nullptr;
+  float gam[NV][4], dg[NV][4], db[NV][4], dab[NV][4];
+  int colv[NV];
+  float cmask[NV];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    int col = (i * 64 + lane) * 4;
+  for (int i = 0; i < NV; ++i) {
+    const int col = (i * 64 + lane) * 4;
+    cmask[i] = col < d ? 1.f : 0.f;
+    colv[i] = min(col, d - 4);              // clamped: loads stay unconditional, contributions are masked
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; gam[i][e] = 0.f; dab[i][e] = 0.f; }
-    if (col < d) ld4<float>(p.gamma + col, gam[i]);
+    for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; dab[i][e] = 0.f; }
+    ld4<float>(p.gamma + colv[i], gam[i]);
   }
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * LN_BWD_ROWS;
+  float dyv[LN_BWD_ROWS][NV][4], zh[LN_BWD_ROWS][NV][4], mean[LN_BWD_ROWS], rstd[LN_BWD_ROWS];
+#pragma unroll
   for (int rr = 0; rr < LN_BWD_ROWS; ++rr) {
-    const int64_t row = ((int64_t)blockIdx.x * 4 + wid) * LN_BWD_ROWS + rr;
-    if (row >= p.M) break;
-    const float mean = p.mean[row], rstd = p.rstd[row];
-    float dyv[LN_MAXV][4], zh[LN_MAXV][4];
+    const int64_t row = min(row0 + rr, p.M - 1);
+    mean[rr] = p.mean[row];
+    rstd[rr] = p.rstd[row];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      ld4<float>(p.dy + row * d + colv[i], dyv[rr][i]);
+      ld4<float>(p.zin + row * d + colv[i], zh[rr][i]);
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < LN_BWD_ROWS; ++rr) {
+    const int64_t row = row0 + rr;
+    const float rmask = row < p.M ? 1.f : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      int col = (i * 64 + lane) * 4;
-      if (col < d) {
-        ld4<float>(p.dy + row * d + col, dyv[i]);
-        ld4<float>(p.zin + row * d + col, zh[i]);
+    for (int i = 0; i < NV; ++i) {
+      const float w = rmask * cmask[i];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          zh[i][e] = (zh[i][e] - mean) * rstd;
-          float g = dyv[i][e] * gam[i][e];
-          s1 += g; s2 += g * zh[i][e];
-          dg[i][e] += dyv[i][e] * zh[i][e];
-          db[i][e] += dyv[i][e];
-        }
+      for (int e = 0; e < 4; ++e) {
+        dyv[rr][i][e] *= w;
+        zh[rr][i][e] = (zh[rr][i][e] - mean[rr]) * rstd[rr];
+        float g = dyv[rr][i][e] * gam[i][e];
+        s1 += g; s2 += g * zh[rr][i][e];
+        dg[i][e] += dyv[rr][i][e] * zh[rr][i][e];
+        db[i][e] += dyv[rr][i][e];
       }
     }
     s1 = wave_sum(s1) / d;
     s2 = wave_sum(s2) / d;
+    if (row < p.M) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      int col = (i * 64 + lane) * 4;
-      if (col < d) {
-        float dz[4];
+      for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        if (col < d) {
+          float dz[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dz[e] = rstd * (dyv[i][e] * gam[i][e] - s1 - zh[i][e] * s2);
-        st4<float>(p.dx + row * d + col, dz);
-        if constexpr (HAS_A) {
-          if (p.da) {
-            float o[4];
+          for (int e = 0; e < 4; ++e) dz[e] = rstd[rr] * (dyv[rr][i][e] * gam[i][e] - s1 - zh[rr][i][e] * s2);
+          st4<float>(p.dx + row * d + col, dz);
+          if constexpr (HAS_A) {
+            if (p.da) {
+              float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float sc = drop ? drop_scale(seed, p.rng_offset + (uint64_t)(row * d + col + e), thr, inv_keep) : 1.f;
-              o[e] = dz[e] * sc;
-              dab[i][e] += o[e];
+              for (int e = 0; e < 4; ++e) {
+                float sc = drop ? drop_scale(seed, p.rng_offset + (uint64_t)(row * d + col + e), thr, inv_keep) : 1.f;
+                o[e] = dz[e] * sc;
+                dab[i][e] += o[e];
+              }
+              st4<AT>(reinterpret_cast<AT*>(p.da) + row * d + col, o);
             }
-            st4<AT>(reinterpret_cast<AT*>(p.da) + row * d + col, o);
           }
         }
       }
@@ -158,7 +176,7 @@ template <class AT, bool HAS_A> __global__ __launch_bounds__(256) void add_ln_bw
   }
   // block reduction of the affine gradients, then one atomic per column per block
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i)
+  for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       red[0][wid][(i * 64 + lane) * 4 + e] = dg[i][e];
@@ -176,7 +194,7 @@ template <class AT, bool HAS_A> __global__ __launch_bounds__(256) void add_ln_bw
     if (want_ab) {
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < LN_MAXV; ++i)
+      for (int i = 0; i < NV; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) red[0][wid][(i * 64 + lane) * 4 + e] = dab[i][e];
       __syncthreads();
@@ -226,8 +244,14 @@ extern "C" int32_t otr_add_layernorm_bwd(const otr_ln_desc_t* d, const float* dy
   p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
   dim3 grid((unsigned)((d->M + 4 * LN_BWD_ROWS - 1) / (4 * LN_BWD_ROWS)));
   hipStream_t s = (hipStream_t)stream;
-  if (!da) hipLaunchKernelGGL((add_ln_bwd_kernel<float, false>), grid, dim3(256), 0, s, p);
-  else if (d->a_dtype == OTR_F32) hipLaunchKernelGGL((add_ln_bwd_kernel<float, true>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, p);
+#define LN_BWD_LAUNCH(NV)                                                                                   \
+  {                                                                                                         \
+    if (!da) hipLaunchKernelGGL((add_ln_bwd_kernel<float, false, NV>), grid, dim3(256), 0, s, p);           \
+    else if (d->a_dtype == OTR_F32) hipLaunchKernelGGL((add_ln_bwd_kernel<float, true, NV>), grid, dim3(256), 0, s, p); \
+    else hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t, true, NV>), grid, dim3(256), 0, s, p);               \
+  }
+  const int nv = (d->d + 255) / 256;
+  if (nv == 1) LN_BWD_LAUNCH(1) else if (nv == 2) LN_BWD_LAUNCH(2) else if (nv == 3) LN_BWD_LAUNCH(3) else LN_BWD_LAUNCH(4)
+#undef LN_BWD_LAUNCH
   return otr_check_launch("add_layernorm_bwd");
 }

@@ -140,7 +140,10 @@ class MultiHeadedSelfAttention(nn.Module):
     def forward(self, x, mask, causal=False, defer_bias=False):
         """defer_bias: the caller feeds the result to _post_norm(..., a_bias=self.output_proj.bias)."""
         ctx = self.context(x, mask, causal)
-        return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, defer_bias=defer_bias), None
+        # a branch that feeds the fused add+LayerNorm is written in the activation dtype (bf16 in bf16 mode, like every
+        # other GEMM output; the fp32 residual stream adds it in fp32): its gradient then comes back in bf16 too
+        return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, defer_bias=defer_bias,
+                          out_dtype=ops.act_dtype() if defer_bias else None), None
 
     def inference(self, x, mask, cache=None):
         out, w = self.forward(x, mask)
@@ -167,7 +170,8 @@ class MultiHeadedCrossAttention(nn.Module):
         q = ops.linear(query, self.q_proj.weight, self.q_proj.bias, out_dtype=adt)
         kv = ops.linear(memory, self.vk_proj.weight, self.vk_proj.bias, out_dtype=adt)
         ctx = ops.CrossAttentionFn.apply(q, kv, _key_mask(memory_mask, B, T), self.nheads)
-        return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, defer_bias=defer_bias), None
+        return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, defer_bias=defer_bias,
+                          out_dtype=ops.act_dtype() if defer_bias else None), None
 
     def inference(self, query, memory, memory_mask, cache=None):
         out, w = self.forward(query, memory, memory_mask)
@@ -190,9 +194,10 @@ class PositionwiseFeedForward(nn.Module):
     def forward(self, x, defer_bias=False):
         if self.activation == 'glu':
             return ops.FeedForwardGLUFn.apply(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias,
-                                              defer_bias)
+                                              defer_bias, ops.act_dtype() if defer_bias else torch.float32)
         h = ops.linear(x, self.w_1.weight, self.w_1.bias, relu=True, out_dtype=ops.act_dtype())
-        return ops.linear(h, self.w_2.weight, self.w_2.bias, defer_bias=defer_bias)
+        return ops.linear(h, self.w_2.weight, self.w_2.bias, defer_bias=defer_bias,
+                          out_dtype=ops.act_dtype() if defer_bias else None)
 
 
 def _post_norm(norm, x, branch, p, training, a_bias=None):

@@ -519,7 +519,7 @@ class FeedForwardGLUFn(torch.autograd.Function):
     (GEMM, GLU, GEMM); backward fuses the w_1 bias gradient into the GLU-backward kernel."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, defer_b2=False):
+    def forward(ctx, x, w1, b1, w2, b2, defer_b2=False, out_dtype=torch.float32):
         _cuda(x, w1, w2)
         ctx.defer_b2 = defer_b2          # see linear(defer_bias=True)
         ctx.refs = (w1, b1, w2, b2)
@@ -535,7 +535,7 @@ class FeedForwardGLUFn(torch.autograd.Function):
         F = F2 // 2
         u = torch.empty((M, F), dtype=adt, device=x.device)
         L.check(L.load().otr_glu_fwd(_p(h), _p(u), _code(adt), M, F, None, _stream()), 'otr_glu_fwd')
-        y = linear_fwd_raw(u, w2, b2, torch.float32)
+        y = linear_fwd_raw(u, w2, b2, out_dtype)
         ctx.save_for_backward(x2, w1, w2, h, u)
         ctx.xshape, ctx.xdtype = x.shape, x.dtype
         return y.view(*x.shape[:-1], w2.shape[0])
@@ -561,7 +561,7 @@ class FeedForwardGLUFn(torch.autograd.Function):
             dx = linear_dgrad_raw(dh, w1, ctx.xdtype).view(ctx.xshape)
         dw1 = linear_wgrad_raw(dh, x2, w1, out=gw1)
         return (dx, None if gw1 is not None else dw1, None if gb1 is not None else db1,
-                None if gw2 is not None else dw2, None if (gb2 is not None or ctx.defer_b2) else db2, None)
+                None if gw2 is not None else dw2, None if (gb2 is not None or ctx.defer_b2) else db2, None, None)
 
 
 GLU_RPB = 32        # rows per workgroup of otr_glu_bwd (csrc/elementwise.hip)
