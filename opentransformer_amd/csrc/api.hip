@@ -144,7 +144,8 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
     OTR_REQUIRE(dtype_ok(it.dy_dtype) && dtype_ok(it.x_dtype), "linear_wgrad_grouped: item %d has a bad dtype", i);
     if (it.M == 0) continue;
     const bool fast = mc_vec(it.dy, it.ldy, it.dy_dtype, compute) && mc_vec(it.x, it.ldx, it.x_dtype, compute) &&
-                      it.N % pm == 0 && it.K % pm == 0 && (uintptr_t)it.dw % 16 == 0 && it.ldw % 4 == 0 &&
+                      it.N % pm == 0 && it.K % pm == 0 && it.M % (compute == OTR_BF16 ? 8 : 4) == 0 &&
+                      (uintptr_t)it.dw % 16 == 0 && it.ldw % 4 == 0 &&
                       it.ldy < (1ll << 31) && it.ldx < (1ll << 31) && it.ldw < (1ll << 31);
     if (!fast) {   // odd alignment: the stand-alone path (generic loaders, split-K through the workspace)
       otr_linear_desc_t d{};

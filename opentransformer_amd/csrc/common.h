@@ -36,6 +36,26 @@ void otr_zero_f32(float* p, int64_t n, hipStream_t s);
     }                                   \
   } while (0)
 
+// ---------------------------------------------------------------- explicit global-memory accesses
+// A pointer that reaches a kernel through a table in memory (grouped GEMM) has no known address space and its
+// accesses compile to flat_load / flat_store, which count on lgkmcnt as well: every LDS wait then also waits for
+// the global prefetch.  These helpers pin the access to addrspace(1).
+typedef uint32_t otr_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t otr_u32x2 __attribute__((ext_vector_type(2)));
+#define OTR_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ uint4 ld_global_b128(const void* p) {
+  otr_u32x4 v = *(const OTR_GLOBAL otr_u32x4*)(p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint2 ld_global_b64(const void* p) {
+  otr_u32x2 v = *(const OTR_GLOBAL otr_u32x2*)(p);
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void st_global_b128(void* p, uint4 v) {
+  otr_u32x4 t = {v.x, v.y, v.z, v.w};
+  *(OTR_GLOBAL otr_u32x4*)(p) = t;
+}
+
 // ---------------------------------------------------------------- scalar conversions
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {  // RNE, lowers to v_cvt_pk_bf16_f32

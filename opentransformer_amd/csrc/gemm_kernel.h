@@ -109,8 +109,12 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
   static constexpr int NP = ROWMAJOR ? 1 : (RG * KCH + 255) / 256;
   // same-type row-major operands are staged as raw 16-byte chunks (no float round trip)
   static constexpr bool RAWQ = ROWMAJOR && std::is_same<ST, CT>::value;
+  // same-type bf16 transposing operands (dy, x of every weight gradient; w of dgrad) stay raw 16-bit as well: 8-byte
+  // loads of 4 rows per contraction index, transposed at LDS-store time with v_perm_b32 (one per output dword)
+  // instead of a bf16 -> f32 unpack + re-pack of every element
+  static constexpr bool RAWT = (MODE == MODE_MC) && FAST && std::is_same<ST, CT>::value && sizeof(CT) == 2;
   // prefetch ring: FAST raw loaders keep DEPTH stages in registers (a 3-slot ring spilled: 96 VGPRs + 64 accumulators)
-  static constexpr int DEPTH = (RAWQ && FAST && MODE == MODE_KC) ? 2 : 1;
+  static constexpr int DEPTH = ((RAWQ && FAST && MODE == MODE_KC) || RAWT) ? 2 : 1;
   // every thread owns a full set of units (true for all tile shapes instantiated): lets stores/loads drop the
   // per-unit activity test the compiler cannot fold (it does not know threadIdx.x < 256)
   static constexpr bool ALLACTIVE = ROWMAJOR ? ((ROWS * KCH) % 256 == 0) : ((RG * KCH) % 256 == 0);
@@ -122,8 +126,9 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
   // stage-invariant part of every unit's global address (k = 0), computed once in init()
   const ST* p0[ROWMAJOR ? NU : NP];
   bool rok[ROWMAJOR ? NU : NP];
-  float raw[RAWQ ? 1 : (ROWMAJOR ? NU : NP * PM)][CE];
+  float raw[(RAWQ || RAWT) ? 1 : (ROWMAJOR ? NU : NP * PM)][CE];
   uint4 rawq[RAWQ ? DEPTH : 1][RAWQ ? NU : 1];
+  uint2 rawt[RAWT ? DEPTH : 1][RAWT ? NP : 1][RAWT ? CE : 1];
   // im2col state
   int64_t pix[ROWMAJOR ? NU : 1];
   int f2v[ROWMAJOR ? NU : 1];
@@ -187,12 +192,21 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
         const uint32_t m = (uint32_t)0 - (uint32_t)(gk < K);
         const ST* src = p0[u] + (gk & (int)m);
         if constexpr (RAWQ) {
-          rawq[SLOT][u] = *reinterpret_cast<const uint4*>(src);
+          rawq[SLOT][u] = ld_global_b128(src);
         } else {
           load_row<ST, CE>(src, CE, true, raw[u]);
 #pragma unroll
           for (int e = 0; e < CE; ++e) raw[u][e] = __uint_as_float(__float_as_uint(raw[u][e]) & m);
         }
+      }
+    } else if constexpr (RAWT) {
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        const int kb = k0 + ((tid + 256 * u) / RG) * CE;          // K % CE == 0 (host): a chunk is valid as a whole
+        const int kbc = kb & (int)((uint32_t)0 - (uint32_t)(kb < K));
+        const ST* pj = p0[u] + (int64_t)kbc * ld;
+#pragma unroll
+        for (int j = 0; j < CE; ++j, pj += ld) rawt[SLOT][u][j] = ld_global_b64(pj);
       }
     } else if constexpr (MODE == MODE_MC && FAST) {
 #pragma unroll
@@ -331,6 +345,30 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
             }
           } else q = MMA<CT>::pack(raw[u]);
           *reinterpret_cast<uint4*>(lds + row * G::ROWB + ((c ^ swz<KCH>(row)) << 4)) = q;
+        }
+      }
+    } else if constexpr (RAWT) {
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        const int id = tid + 256 * u, rg = id % RG, c = id / RG;
+        if (ALLACTIVE || c < KCH) {
+          const uint32_t m = (uint32_t)0 - (uint32_t)(k0 + c * CE < K);
+          const uint2* r = rawt[SLOT][u];
+#pragma unroll
+          for (int i = 0; i < PM; ++i) {        // row i of the patch = 16-bit field i of every 8-byte load
+            const uint32_t sel = (i & 1) ? 0x07060302u : 0x05040100u;
+            uint4 q;
+            if (i < 2) {
+              q.x = __builtin_amdgcn_perm(r[1].x, r[0].x, sel); q.y = __builtin_amdgcn_perm(r[3].x, r[2].x, sel);
+              q.z = __builtin_amdgcn_perm(r[5].x, r[4].x, sel); q.w = __builtin_amdgcn_perm(r[7].x, r[6].x, sel);
+            } else {
+              q.x = __builtin_amdgcn_perm(r[1].y, r[0].y, sel); q.y = __builtin_amdgcn_perm(r[3].y, r[2].y, sel);
+              q.z = __builtin_amdgcn_perm(r[5].y, r[4].y, sel); q.w = __builtin_amdgcn_perm(r[7].y, r[6].y, sel);
+            }
+            q.x &= m; q.y &= m; q.z &= m; q.w &= m;
+            const int row = PM * rg + i;
+            *reinterpret_cast<uint4*>(lds + row * G::ROWB + ((c ^ swz<KCH>(row)) << 4)) = q;
+          }
         }
       }
     } else {
@@ -627,17 +665,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
           if constexpr (sizeof(OT) == 4) {
             if (acc_st) {
               if (nv == EPC) {
-                float4 a = *reinterpret_cast<const float4*>(q), c4 = *reinterpret_cast<const float4*>(dst);
+                float4 a = *reinterpret_cast<const float4*>(q);
+                const uint4 cu = ld_global_b128(dst);
+                const float4 c4 = make_float4(__uint_as_float(cu.x), __uint_as_float(cu.y), __uint_as_float(cu.z), __uint_as_float(cu.w));
                 a.x += c4.x; a.y += c4.y; a.z += c4.z; a.w += c4.w;
                 if (p.act == OTR_ACT_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-                *reinterpret_cast<float4*>(dst) = a;
+                st_global_b128(dst, make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w)));
               } else {
                 store_tail_acc<OT>(dst, reinterpret_cast<const OT*>(q), nv, p.act == OTR_ACT_RELU);
               }
               continue;
             }
           }
-          if (nv == EPC) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(q);
+          if (nv == EPC) st_global_b128(dst, *reinterpret_cast<const uint4*>(q));
           else store_tail<OT>(dst, reinterpret_cast<const OT*>(q), nv);
         }
       }
@@ -742,7 +782,7 @@ __global__ __launch_bounds__(256, 2) void gemm_grouped_kernel(const GroupDesc* _
   }
   const GroupDesc d = table[lo];
   GemmArgs p{};
-  p.A = d.A; p.B = d.B; p.C = d.C; p.bias = nullptr;
+  p.A = d.A; p.B = d.B; p.C = d.C; p.bias = nullptr;   // (accessed through ld_global / st_global: see common.h)
   p.M = d.M; p.N = d.N; p.K = d.K;
   p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
   p.act = OTR_ACT_NONE; p.accumulate = 1;
@@ -846,7 +886,7 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
   constexpr int CE = GemmCfg<CT>::CE, PM = GemmCfg<CT>::PM;
   auto side_fast = [&](int mode, int vec, int rows) {
     if (mode == MODE_KC) return vec && (a.K % CE == 0) && rows > 0;
-    if (mode == MODE_MC) return vec && (rows % PM == 0);
+    if (mode == MODE_MC) return vec && (rows % PM == 0) && (a.K % CE == 0);
     return false;
   };
   const bool fast = (AMODE == MODE_KC || AMODE == MODE_MC) && (BMODE == MODE_KC || BMODE == MODE_MC) &&
@@ -855,13 +895,18 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
                      (((uintptr_t)a.C % 16 == 0) && (a.ldc % (16 / (int)sizeof(OT)) == 0) && !(a.accumulate && sizeof(OT) == 2)));
   const int64_t ntiles = big ? t128 : t64;
   // persistent variant (no split-K): at most OTR_RESIDENT_WG workgroups, each walking tiles b, b+grid, ...
-  const bool persist = fast && a.ksplit == 1 && g_otr_no_persist == 0;
+  // (transposing operands: the cross-tile prefetch on top of their ring does not fit 256 VGPRs -- spills -- so they
+  //  keep one workgroup per tile)
+  constexpr bool CAN_PERSIST = (AMODE == MODE_KC && BMODE == MODE_KC);
+  const bool persist = CAN_PERSIST && fast && a.ksplit == 1 && g_otr_no_persist == 0;
   const dim3 grid((unsigned)(persist && ntiles > OTR_RESIDENT_WG ? OTR_RESIDENT_WG : ntiles), a.ksplit);
   if constexpr (AMODE == MODE_KC || AMODE == MODE_MC) {
     if constexpr (BMODE == MODE_KC || BMODE == MODE_MC) {
       if (fast && persist) {
-        if (big) hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 128, 128, true, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 64, 64, true, true>), grid, dim3(256), 0, s, a);
+        if constexpr (CAN_PERSIST) {
+          if (big) hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 128, 128, true, true>), grid, dim3(256), 0, s, a);
+          else hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 64, 64, true, true>), grid, dim3(256), 0, s, a);
+        }
       } else if (fast) {
         if (big) hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 128, 128, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 64, 64, true>), grid, dim3(256), 0, s, a);
