@@ -110,6 +110,37 @@ def time_dominant_kernel(model, mode):
             'avg_launch_ms': ms}
 
 
+def time_grouped_wgrad(ops, mode):
+    """Largest single kernel of the step: the grouped weight-gradient launch (every dW of the backward pass).  Re-run
+    it on the operands of the last backward pass (accumulating into the already-consumed gradient buffer)."""
+    w, b = ops._wq.get('last', ([], []))
+    if not w:
+        return None
+    flops = sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _ in w)
+    byts = sum(dy.numel() * dy.element_size() + x.numel() * x.element_size() + 2 * out.numel() * 4 for dy, x, out in w)
+
+    def run():
+        ops._wq['w'], ops._wq['b'] = list(w), []
+        ops.flush_weight_grads()
+    ops._wq['keep_last'] = False
+    for _ in range(2):
+        run()
+    n = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    peak = PEAK_BF16_TFLOPS if mode == 'bf16' else PEAK_F32_TFLOPS
+    ach = flops / (ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'kernel': 'gemm_grouped_kernel (all %d weight gradients of one backward pass, one launch per '
+                                       'operand-type group)' % len(w),
+            'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+            'algorithmic_bytes': byts, 'avg_launch_ms': ms}
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -192,6 +223,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # untimed extras (rank 0): where the step time goes, and the operands of one backward pass for the wgrad roofline
+    final_loss, final_stats = float(loss_buf.item()), opt.stats()      # state at the end of the timed region
+    parts = None
+    if True:                                                 # every rank: the collectives must match
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        acc = [0.0, 0.0]
+        for _ in range(5):
+            ev[0].record()
+            if graph is not None:
+                graph.replay()
+            else:
+                fwd_bwd()
+            ev[1].record()
+            scale, _ = dp.all_reduce_gradients()
+            opt.step(scale)
+            ev[2].record()
+            torch.cuda.synchronize()
+            acc[0] += ev[0].elapsed_time(ev[1])
+            acc[1] += ev[1].elapsed_time(ev[2])
+        parts = {'fwd_bwd_ms': acc[0] / 5, 'allreduce_optimizer_ms': acc[1] / 5}
+    if rank == 0:
+        ops._wq['keep_last'] = True
+        fwd_bwd()                                            # eager pass: queues and flushes once, keeping the items
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+
     if rank == 0:
         global_batch = args.batch * world
         utt_s = global_batch * args.steps / elapsed
@@ -207,15 +265,19 @@ def main():
                                    'step = fwd + bwd + grad all-reduce + clip/Adam/Noam' % (args.batch, args.frames),
                        'global_batch': global_batch, 'frames': args.frames, 'parallelism': 'dp%d' % world,
                        'hipgraph': graph is not None},
-            'loss': float(loss_buf.item()), 'optimizer': opt.stats(),
+            'loss': final_loss, 'optimizer': final_stats,
             'model_tflops_per_s': utt_s * flops_utt / 1e12,
             'model_mfma_frac': utt_s * flops_utt / 1e12 / world / (PEAK_BF16_TFLOPS if args.mode == 'bf16' else PEAK_F32_TFLOPS),
         }
-        st = opt.stats()
+        st = final_stats
         if st['skipped'] != 0 or not (st['grad_sqnorm'] == st['grad_sqnorm'] and st['grad_sqnorm'] < float('inf')):
             out['INVALID'] = 'non-finite gradient norm: %d optimizer updates were skipped' % int(st['skipped'])
+        out['step_breakdown'] = parts
         if args.model == 'transformer':
             out['roofline'] = time_dominant_kernel(model, args.mode)
+            rw = time_grouped_wgrad(ops, args.mode)
+            if rw is not None:
+                out['roofline_wgrad_grouped'] = rw
         else:
             out['config']['workload'] = out['config']['workload'].replace('transformer_baseline.yaml (+input_size 80), 12 enc / 6 dec layers', 'conformer_baseline.yaml, 12 conformer blocks / 6 dec layers')
         if world == 1 and not args.no_cpu_baseline:

@@ -268,11 +268,26 @@ template <class T> __global__ void colsum_grouped_kernel(ColsumGroup g) {
   if (c < N) {
     const int64_t r0 = (int64_t)by * CS_RPB, r1 = min(M, r0 + CS_RPB);
     const bool full = c + 4 <= N && (lda % 4 == 0);
-    for (int64_t r = r0 + ty; r < r1; r += 4) {
-      float v[4];
-      load_row<T, 4>(a + r * lda + c, (int)min((int64_t)4, N - c), full, v);
+    int64_t r = r0 + ty;
+    if (full) {   // 8 rows in flight per thread (rows clamped, tail rows weighted 0): the serial loop was latency bound
+      for (; r < r1; r += 32) {
+        float v[8][4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s[e] += v[e];
+        for (int u = 0; u < 8; ++u) load_row<T, 4>(a + min(r + 4 * u, M - 1) * lda + c, 4, true, v[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float w = (r + 4 * u < r1) ? 1.f : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[e] += w * v[u][e];
+        }
+      }
+    } else {
+      for (; r < r1; r += 4) {
+        float v[4];
+        load_row<T, 4>(a + r * lda + c, (int)min((int64_t)4, N - c), false, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += v[e];
+      }
     }
   }
 #pragma unroll

@@ -854,7 +854,7 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
     if (!can_split) return 1;
     // measured (tools/gemm_sweep.py): with >= 64 output tiles one k-slice per CU is enough (w_2 forward 7968x256x2048:
     // 35 us at 5 slices, 28 us at 2); tiny outputs need the second resident workgroup per CU as well
-    int64_t want = tiles >= 64 ? (256 + tiles - 1) / tiles : (512 + tiles - 1) / tiles;
+    int64_t want = tiles >= 64 ? (256 + tiles / 2) / tiles : (512 + tiles - 1) / tiles;   // >= 64 tiles: ~one wave of CUs
     int64_t cap = nk / 4 > 0 ? nk / 4 : 1;
     if (cap > max_by_ws) cap = max_by_ws;
     return (int)(want < cap ? want : cap);
