@@ -64,6 +64,16 @@ int32_t otr_linear_wgrad(const otr_linear_desc_t* d, const void* dy, const void*
 int32_t otr_colsum(const void* a, int32_t dtype, int64_t M, int64_t N, int64_t lda, float* out, int32_t accumulate,
                    void* stream);
 
+/* ---- FFN backward through w_2 and the GLU in ONE launch (module/ffn.py:38-41 backward): du = dy[M,d] . w2 (w2t = the
+ *      [F,d] transposed bf16 shadow of w_2; du is never stored), dh[M,2F] = GLU'(h) * du with h[M,2F] the saved GLU
+ *      input, and dbias_partial[rows, 2F] = column sums of dh per row tile (column-sum them for the w_1 bias gradient;
+ *      *partial_rows receives the number of rows written, <= partial_rows_cap, size it ceil(M/64)).  bf16 operands.
+ *      Returns 1 without launching anything when the operands do not qualify (alignment); use otr_linear_dgrad +
+ *      otr_glu_bwd then. */
+int32_t otr_ffn_glu_bwd(const void* dy, int32_t dy_dtype, int64_t ldy, const void* w2t, int64_t ldw, const void* h, void* dh,
+                        float* dbias_partial, int32_t partial_rows_cap, int32_t* partial_rows, int32_t M, int32_t F,
+                        int32_t d_model, void* stream);
+
 /* ---- grouped weight / bias gradients: every dw_i[N,K] += dy_i[M,N]^T x_i[M,K] of a backward pass in a few launches
  *      (one per operand-type group), likewise every bias gradient out_i[N] += column sums of a_i[M,N].  The per-layer
  *      launches they replace are latency bound (a 4-k-step GEMM workgroup lives ~10 us, every launch costs 2-3 us);

@@ -129,6 +129,40 @@ extern "C" int32_t otr_linear_wgrad(const otr_linear_desc_t* d, const void* dy, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// FFN backward through w_2 and the GLU in one launch: du = dy . w2 (never stored), dh = GLU'(h) * du, plus per-row-tile
+// column sums of dh (the w_1 bias gradient).  Returns 1 (nothing launched) when the operands do not qualify for the
+// fused kernel; the caller then runs otr_linear_dgrad / otr_glu_bwd.
+extern "C" int32_t otr_ffn_glu_bwd(const void* dy, int32_t dy_dtype, int64_t ldy, const void* w2t, int64_t ldw, const void* h,
+                                   void* dh, float* dbias_partial, int32_t partial_rows_cap, int32_t* partial_rows,
+                                   int32_t M, int32_t F, int32_t d_model, void* stream) {
+  OTR_REQUIRE(dy && w2t && h && dh && dbias_partial && partial_rows, "ffn_glu_bwd: null pointer");
+  OTR_REQUIRE(M >= 0 && F > 0 && d_model > 0 && ldy >= d_model && ldw >= d_model, "ffn_glu_bwd: bad shape");
+  *partial_rows = 0;
+  if (M == 0) return 0;
+  const bool ok = dy_dtype == OTR_BF16 && kc_vec(dy, ldy, OTR_BF16) && kc_vec(w2t, ldw, OTR_BF16) && d_model % 8 == 0 &&
+                  F % 8 == 0 && (uintptr_t)h % 16 == 0 && (uintptr_t)dh % 16 == 0 && g_otr_force_generic == 0;
+  const int64_t t128 = (int64_t)((M + 127) / 128) * ((F + 127) / 128);
+  const bool big = M >= 128 && F >= 128 && t128 >= 256 && g_otr_force_tile != 64;   // few tiles: 64x64 fills the chip better
+  const int rows = (M + (big ? 127 : 63)) / (big ? 128 : 64);
+  if (!ok || rows > partial_rows_cap) return 1;
+  GemmArgs a{};
+  a.A = dy; a.B = w2t; a.C = dh /* unused, must be aligned */; a.bias = nullptr;
+  a.M = M; a.N = F; a.K = d_model;
+  a.lda = ldy; a.ldb = ldw; a.ldc = 2 * (int64_t)F;
+  a.act = OTR_ACT_GLU_BWD; a.accumulate = 0;
+  a.a_vec = 1; a.b_vec = 1;
+  a.allow_split = 0; a.ws = nullptr; a.ws_bytes = 0; a.trace = g_otr_trace;
+  a.aux_in = h; a.aux_out = dh; a.aux_part = dbias_partial;
+  const int keep = g_otr_force_tile;
+  g_otr_force_tile = big ? 128 : 64;                  // the partial layout depends on the tile height: pin it
+  const int32_t e = run_gemm(a, OTR_BF16, OTR_BF16, OTR_BF16, OTR_BF16, MODE_KC, MODE_KC, stream);
+  g_otr_force_tile = keep;
+  if (e) return e;
+  *partial_rows = rows;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // All weight gradients of a backward pass in (a few) grouped launches: dw_i[N,K] += dy_i[M,N]^T x_i[M,K].
 extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32_t n, int32_t compute, void* workspace,
                                             int64_t workspace_bytes, void* stream) {

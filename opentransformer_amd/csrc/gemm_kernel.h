@@ -32,6 +32,8 @@ struct ConvGeom {
   FastDiv divF2, divT2, divC1;
 };
 
+constexpr int OTR_ACT_GLU_BWD = 2;   // internal epilogue mode (otr_ffn_glu_bwd)
+
 struct GemmArgs {
   const void* A;
   const void* B;
@@ -45,6 +47,11 @@ struct GemmArgs {
   int allow_split;   // caller permits split-K (needs a workspace)
   float* ws;         // split-K workspace: ksplit partial [M,N] fp32 slabs, reduced in a fixed order
   int64_t ws_bytes;
+  // act == OTR_ACT_GLU_BWD (FFN backward, see the epilogue): C is NOT written; aux_in = h [M, 2N] (GLU input saved by the
+  // forward), aux_out = dh [M, 2N], aux_part = per-row-tile column sums of dh [tiles_m, 2N] (the w_1 bias gradient)
+  const void* aux_in;
+  void* aux_out;
+  float* aux_part;
   unsigned long long* trace;  // tuning hook (otr_debug_trace): per-workgroup phase timestamps, or NULL
   ConvGeom cg;
 };
@@ -650,6 +657,75 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
       static_assert(256 % CPR == 0 && (PROWS * CPR) % 256 == 0, "write-out mapping");
       const int lrow0 = tid / CPR, ch = tid % CPR;
       const int col = done_n * BN + ch * EPC;
+      if constexpr (AMODE == MODE_KC && BMODE == MODE_KC && sizeof(OT) == 2 && PASSES == 1 &&
+                    PROWS * CROW + 2 * RSTEP * BN * 4 <= 2 * BUF) {
+        if (p.act == OTR_ACT_GLU_BWD) {
+          // The staged tile is du = dy . W2 for hidden units [col, col+8) of PROWS rows.  GLU backward right here:
+          //   dh[:, j] = du * sig(b),  dh[:, F+j] = du * a * sig(b) * (1 - sig(b)),   (a | b) = h[:, j], h[:, F+j]
+          // du never goes to HBM and the separate GLU-backward pass (read h + du, write dh) disappears.
+          constexpr int NU_ = (PROWS * CPR) / 256;
+          const int F = p.N;
+          const bf16_t* H = reinterpret_cast<const bf16_t*>(p.aux_in);
+          bf16_t* DH = reinterpret_cast<bf16_t*>(p.aux_out);
+          const int colc = min(col, F - EPC);                // clamped: loads unconditional, stores / sums masked
+          uint4 ha[NU_], hb[NU_];
+#pragma unroll
+          for (int u = 0; u < NU_; ++u) {                    // all h loads of this thread in flight at once
+            const int row = min(done_m * BM + lrow0 + u * RSTEP, p.M - 1);
+            const bf16_t* hp = H + (int64_t)row * (2 * F) + colc;
+            ha[u] = ld_global_b128(hp);
+            hb[u] = ld_global_b128(hp + F);
+          }
+          float sa[EPC], sb[EPC];
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) { sa[e] = 0.f; sb[e] = 0.f; }
+#pragma unroll
+          for (int u = 0; u < NU_; ++u) {
+            const int lrow = lrow0 + u * RSTEP, row = done_m * BM + lrow;
+            const bool live = row < p.M && col < F;
+            const uint4 dq = *reinterpret_cast<const uint4*>(smem + lrow * CROW + ch * 16);
+            const uint32_t dw[4] = {dq.x, dq.y, dq.z, dq.w}, aw[4] = {ha[u].x, ha[u].y, ha[u].z, ha[u].w},
+                           bw[4] = {hb[u].x, hb[u].y, hb[u].z, hb[u].w};
+            float oa[EPC], ob[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+              const int sh = (e & 1) ? 0 : 16;               // element e of a packed pair: low half first
+              const float d = __uint_as_float((e & 1) ? (dw[e >> 1] & 0xffff0000u) : (dw[e >> 1] << 16));
+              const float a = __uint_as_float((e & 1) ? (aw[e >> 1] & 0xffff0000u) : (aw[e >> 1] << 16));
+              const float b = __uint_as_float((e & 1) ? (bw[e >> 1] & 0xffff0000u) : (bw[e >> 1] << 16));
+              (void)sh;
+              const float sg = 1.f / (1.f + __expf(-b));
+              oa[e] = live ? d * sg : 0.f;
+              ob[e] = live ? d * a * sg * (1.f - sg) : 0.f;
+              sa[e] += oa[e]; sb[e] += ob[e];
+            }
+            if (live) {
+              bf16_t* dp_ = DH + (int64_t)row * (2 * F) + col;
+              st_global_b128(dp_, MMA<bf16_t>::pack(oa));
+              st_global_b128(dp_ + F, MMA<bf16_t>::pack(ob));
+            }
+          }
+          // column sums over the tile's rows: [RSTEP][BN] partials per half behind the staged tile, then one row of
+          // aux_part per (row tile, column) -- deterministic, no atomics
+          float* red = reinterpret_cast<float*>(smem + PROWS * CROW);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            red[lrow0 * BN + ch * EPC + e] = sa[e];
+            red[RSTEP * BN + lrow0 * BN + ch * EPC + e] = sb[e];
+          }
+          __syncthreads();
+          for (int t = tid; t < 2 * BN; t += 256) {
+            const int half = t / BN, c = t - half * BN, gc = done_n * BN + c;
+            if (gc < F) {
+              float acc_ = 0.f;
+#pragma unroll
+              for (int r = 0; r < RSTEP; ++r) acc_ += red[half * RSTEP * BN + r * BN + c];
+              p.aux_part[(int64_t)done_m * (2 * F) + half * F + gc] = acc_;
+            }
+          }
+          continue;                                          // (PASSES == 1: leaves the pass loop)
+        }
+      }
       // one base pointer per tile + a uniform row step: per-unit addresses would be loop-invariant in the persistent
       // tile loop, get hoisted, and spill (their reloads drained the prefetched loads with vmcnt(0))
       OT* dstp = C + (int64_t)(done_m * BM + ps * PROWS + lrow0) * p.ldc + col;

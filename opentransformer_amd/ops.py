@@ -11,6 +11,7 @@ Precision policy (set_compute_dtype):
   'fp32': exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) everywhere, all activations fp32 -- parity mode.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -548,14 +549,28 @@ class FeedForwardGLUFn(torch.autograd.Function):
         w1p, b1p, w2p, b2p = ctx.refs
         dy2 = _rows(dy)
         M, F = u.shape
-        du = linear_fwd_raw(dy2, ctx.w2t, None, u.dtype) if ctx.w2t is not None else linear_dgrad_raw(dy2, w2, u.dtype)
         gw2, gb2, gw1, gb1 = grad_target(w2p), grad_target(b2p), grad_target(w1p), grad_target(b1p)
         dw2 = linear_wgrad_raw(dy2, u, w2, out=gw2)
         db2 = None if ctx.defer_b2 else colsum_raw(dy2, out=gb2)
         dh = torch.empty_like(h)
-        nblk = (M + GLU_RPB - 1) // GLU_RPB
-        part = torch.empty((nblk, 2 * F), dtype=torch.float32, device=dy.device)
-        L.check(L.load().otr_glu_bwd(_p(h), _p(du), _p(dh), _p(part), _code(h.dtype), M, F, None, _stream()), 'otr_glu_bwd')
+        part = None
+        if ctx.w2t is not None and dy2.dtype == torch.bfloat16 and h.dtype == torch.bfloat16 and _FUSED_GLU_BWD:
+            # one launch: du = dy . w2 stays in registers / LDS, GLU backward and the bias partials in the GEMM epilogue
+            cap = (M + 63) // 64
+            part = torch.empty((cap, 2 * F), dtype=torch.float32, device=dy.device)
+            rows = C.c_int32(0)
+            rc = L.load().otr_ffn_glu_bwd(_p(dy2), _code(dy2.dtype), dy2.stride(0), _p(ctx.w2t), ctx.w2t.stride(0), _p(h),
+                                          _p(dh), _p(part), cap, C.byref(rows), M, F, dy2.shape[1], _stream())
+            if rc == 1:
+                part = None                     # operands do not qualify: two-kernel path below
+            else:
+                L.check(rc, 'otr_ffn_glu_bwd')
+                part = part[:rows.value]
+        if part is None:
+            du = linear_fwd_raw(dy2, ctx.w2t, None, u.dtype) if ctx.w2t is not None else linear_dgrad_raw(dy2, w2, u.dtype)
+            nblk = (M + GLU_RPB - 1) // GLU_RPB
+            part = torch.empty((nblk, 2 * F), dtype=torch.float32, device=dy.device)
+            L.check(L.load().otr_glu_bwd(_p(h), _p(du), _p(dh), _p(part), _code(h.dtype), M, F, None, _stream()), 'otr_glu_bwd')
         db1 = colsum_raw(part, out=gb1)
         if ctx.w1t is not None:
             dx = linear_fwd_raw(dh, ctx.w1t, None, ctx.xdtype).view(ctx.xshape)
@@ -567,6 +582,7 @@ class FeedForwardGLUFn(torch.autograd.Function):
 
 
 GLU_RPB = 32        # rows per workgroup of otr_glu_bwd (csrc/elementwise.hip)
+_FUSED_GLU_BWD = os.environ.get('OTR_NO_FUSED_GLU_BWD', '0') != '1'     # A/B switch for tuning runs
 
 
 # ---------------------------------------------------------------------------------------- positional encoding
