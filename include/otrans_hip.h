@@ -64,6 +64,12 @@ int32_t otr_linear_wgrad(const otr_linear_desc_t* d, const void* dy, const void*
 int32_t otr_colsum(const void* a, int32_t dtype, int64_t M, int64_t N, int64_t lda, float* out, int32_t accumulate,
                    void* stream);
 
+/* ---- FFN forward through w_1 and the GLU in ONE launch (module/ffn.py:38-40): h[M,2F] = x[M,d] . w1[2F,d]^T + b1 (kept
+ *      for backward) and u[M,F] = h[:, :F] * sigmoid(h[:, F:]).  Each GEMM tile holds 64 value columns and their 64 gate
+ *      columns, so the GLU runs in the epilogue on data that is already on chip.  bf16 operands and outputs.
+ *      Returns 1 without launching anything when the operands do not qualify; use otr_linear_fwd + otr_glu_fwd then. */
+int32_t otr_ffn_glu_fwd(const void* x, int64_t ldx, const void* w1, int64_t ldw, const float* b1, void* h, void* u, int32_t M,
+                        int32_t F, int32_t d_model, void* stream);
 /* ---- FFN backward through w_2 and the GLU in ONE launch (module/ffn.py:38-41 backward): du = dy[M,d] . w2 (w2t = the
  *      [F,d] transposed bf16 shadow of w_2; du is never stored), dh[M,2F] = GLU'(h) * du with h[M,2F] the saved GLU
  *      input, and dbias_partial[rows, 2F] = column sums of dh per row tile (column-sum them for the w_1 bias gradient;

@@ -62,6 +62,7 @@ SIGNATURES = {
     'otr_linear_fwd': [C.POINTER(LinearDesc), _P, _P, _P, _P, _P, _I64, _P],
     'otr_linear_dgrad': [C.POINTER(LinearDesc), _P, _P, _P, _P, _I64, _P],
     'otr_linear_wgrad': [C.POINTER(LinearDesc), _P, _P, _P, _P, _I64, _P],
+    'otr_ffn_glu_fwd': [_P, _I64, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _P],
     'otr_ffn_glu_bwd': [_P, _I32, _I64, _P, _I64, _P, _P, _P, _I32, _P, _I32, _I32, _I32, _P],
     'otr_linear_wgrad_grouped': [_P, _I32, _I32, _P, _I64, _P],
     'otr_colsum_grouped': [_P, _I32, _P],

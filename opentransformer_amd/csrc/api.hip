@@ -129,6 +129,35 @@ extern "C" int32_t otr_linear_wgrad(const otr_linear_desc_t* d, const void* dy, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// FFN forward through w_1 and the GLU in one launch: h = x . w1^T + b1 (saved for backward), u = h[:, :F] * sigmoid(h[:, F:]).
+// Returns 1 (nothing launched) when the operands do not qualify; the caller then runs otr_linear_fwd + otr_glu_fwd.
+extern "C" int32_t otr_ffn_glu_fwd(const void* x, int64_t ldx, const void* w1, int64_t ldw, const float* b1, void* h, void* u,
+                                   int32_t M, int32_t F, int32_t d_model, void* stream) {
+  OTR_REQUIRE(x && w1 && h && u, "ffn_glu_fwd: null pointer");
+  OTR_REQUIRE(M >= 0 && F > 0 && d_model > 0 && ldx >= d_model && ldw >= d_model, "ffn_glu_fwd: bad shape");
+  if (M == 0) return 0;
+  const int64_t t128 = (int64_t)((M + 127) / 128) * ((2 * F + 127) / 128);
+  const bool big = M >= 128 && F >= 128 && t128 >= 256 && g_otr_force_tile != 64;
+  const int half = big ? 64 : 32;                          // value columns per tile
+  const bool ok = kc_vec(x, ldx, OTR_BF16) && kc_vec(w1, ldw, OTR_BF16) && d_model % 8 == 0 && F % half == 0 &&
+                  (uintptr_t)h % 16 == 0 && (uintptr_t)u % 16 == 0 && g_otr_force_generic == 0;
+  if (!ok) return 1;
+  GemmArgs a{};
+  a.A = x; a.B = w1; a.C = h; a.bias = b1;
+  a.M = M; a.N = 2 * F; a.K = d_model;
+  a.lda = ldx; a.ldb = ldw; a.ldc = 2 * (int64_t)F;
+  a.act = OTR_ACT_GLU_FWD; a.accumulate = 0;
+  a.a_vec = 1; a.b_vec = 1;
+  a.allow_split = 0; a.ws = nullptr; a.ws_bytes = 0; a.trace = g_otr_trace;
+  a.aux_out = u;
+  const int keep = g_otr_force_tile;
+  g_otr_force_tile = big ? 128 : 64;                       // F % (tile/2) == 0 was checked for this tile width
+  const int32_t e = run_gemm(a, OTR_BF16, OTR_BF16, OTR_BF16, OTR_BF16, MODE_KC, MODE_KC, stream);
+  g_otr_force_tile = keep;
+  return e;
+}
+
+// ------------------------------------------------------------------------------------------------
 // FFN backward through w_2 and the GLU in one launch: du = dy . w2 (never stored), dh = GLU'(h) * du, plus per-row-tile
 // column sums of dh (the w_1 bias gradient).  Returns 1 (nothing launched) when the operands do not qualify for the
 // fused kernel; the caller then runs otr_linear_dgrad / otr_glu_bwd.

@@ -33,6 +33,7 @@ struct ConvGeom {
 };
 
 constexpr int OTR_ACT_GLU_BWD = 2;   // internal epilogue mode (otr_ffn_glu_bwd)
+constexpr int OTR_ACT_GLU_FWD = 3;   // internal epilogue mode (otr_ffn_glu_fwd): h = x.W1^T + b and u = GLU(h) in one launch
 
 struct GemmArgs {
   const void* A;
@@ -141,8 +142,11 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
   int f2v[ROWMAJOR ? NU : 1];
   int tapoff[ROWMAJOR ? 1 : NP], tapkw[ROWMAJOR ? 1 : NP];
 
+  // pair_F > 0 (FAST KC only; GLU-forward fusion): the tile's second half of rows comes from pair_F rows further down, i.e.
+  // tile row lr <-> operand row row0 + (lr mod ROWS/2) + (lr >= ROWS/2 ? pair_F : 0), so that one tile holds the GLU
+  // value columns [n0, n0+ROWS/2) AND their gate columns [F+n0, ...)
   __device__ __forceinline__ void init(const void* p, int64_t ld_, int nrows_, int K_, int row0_, bool vec_,
-                                       const ConvGeom& g, int tid) {
+                                       const ConvGeom& g, int tid, int pair_F = 0) {
     base = reinterpret_cast<const ST*>(p);
     ld = ld_; nrows = nrows_; K = K_; row0 = row0_; vec = vec_;
     if constexpr (MODE == MODE_KC) {
@@ -151,8 +155,10 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
         int id = tid + 256 * u;
         int lr = id / KCH;
         rok[u] = lr < ROWS && row0 + lr < nrows;
-        if constexpr (FAST) p0[u] = base + (int64_t)min(row0 + lr, nrows - 1) * ld;      // row base, chunk added per stage
-        else p0[u] = base + (int64_t)(row0 + lr) * ld + (id % KCH) * CE;
+        if constexpr (FAST) {
+          const int gr = pair_F > 0 ? row0 + (lr & (ROWS / 2 - 1)) + (lr >= ROWS / 2 ? pair_F : 0) : row0 + lr;
+          p0[u] = base + (int64_t)min(gr, nrows - 1) * ld;      // row base, chunk added per stage
+        } else p0[u] = base + (int64_t)(row0 + lr) * ld + (id % KCH) * CE;
       }
     }
     if constexpr (MODE == MODE_MC) {
@@ -438,10 +444,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
   if (p.trace && tid == 0) p.trace[((int64_t)kslice * ntiles + tile) * 4 + (slot)] = __builtin_readcyclecounter();
   OTR_TRACE(0)
 
+  // GLU-forward fusion (p.act == OTR_ACT_GLU_FWD, N = 2F): B tile n holds W1 rows [n*BN/2, +BN/2) and F + the same
+  constexpr bool GLU_OK = FAST && AMODE == MODE_KC && BMODE == MODE_KC && sizeof(OT) == 2;
+  const int pairF = (GLU_OK && p.act == OTR_ACT_GLU_FWD) ? p.N / 2 : 0;
+  const int bstep = pairF > 0 ? BN / 2 : BN;               // operand-row advance per n-tile
   TileLoader<CT, AT, AMODE, BM, FAST> la;
   TileLoader<CT, BT, BMODE, BN, FAST> lb;
   la.init(p.A, p.lda, p.M, p.K, tile_m * BM, p.a_vec != 0, p.cg, tid);
-  lb.init(p.B, p.ldb, p.N, p.K, tile_n * BN, p.b_vec != 0, p.cg, tid);
+  lb.init(p.B, p.ldb, p.N, p.K, tile_n * bstep, p.b_vec != 0, p.cg, tid, pairF);
 
   using LA = TileLoader<CT, AT, AMODE, BM, FAST>;
   using LB = TileLoader<CT, BT, BMODE, BN, FAST>;
@@ -595,7 +605,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
   if (p.bias) {   // clamped, unconditional loads (a per-element branch serialises them behind vmcnt(0))
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      int col = tile_n * BN + wn * WN + j * 16 + fg * 4;
+      const int tc = wn * WN + j * 16 + fg * 4;              // tile column -> output column (paired halves in GLU mode)
+      const int col = pairF > 0 ? tile_n * (BN / 2) + (tc & (BN / 2 - 1)) + (tc >= BN / 2 ? pairF : 0) : tile_n * BN + tc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[j][r] = p.bias[min(col + r, p.N - 1)];
     }
@@ -609,7 +620,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
     tile_m = nxt / tiles_n;
     tile_n = nxt - tile_m * tiles_n;
     la.init(p.A, p.lda, p.M, p.K, tile_m * BM, p.a_vec != 0, p.cg, tid);
-    lb.init(p.B, p.ldb, p.N, p.K, tile_n * BN, p.b_vec != 0, p.cg, tid);
+    lb.init(p.B, p.ldb, p.N, p.K, tile_n * bstep, p.b_vec != 0, p.cg, tid, pairF);
     la.template load<0>(kt0 * BK, p.cg, tid);
     lb.template load<0>(kt0 * BK, p.cg, tid);
     la.template load<1>(min((kt0 + 1) * BK, klast), p.cg, tid);
@@ -657,6 +668,39 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
       static_assert(256 % CPR == 0 && (PROWS * CPR) % 256 == 0, "write-out mapping");
       const int lrow0 = tid / CPR, ch = tid % CPR;
       const int col = done_n * BN + ch * EPC;
+      if constexpr (GLU_OK && PASSES == 1) {
+        if (p.act == OTR_ACT_GLU_FWD) {
+          // staged tile = h (bias added) for value columns [n0, n0+BN/2) in its left half and their gates in the right
+          // half.  Every thread writes its h chunk; threads on the left half also read the partner gate chunk from LDS
+          // and write u = a * sigmoid(b): the separate GLU pass (re-read h, write u) disappears.
+          const int F = pairF, n0 = done_n * (BN / 2);
+          const int hc = (ch < CPR / 2) ? n0 + ch * EPC : F + n0 + (ch - CPR / 2) * EPC;   // column in h
+          const int vcol = n0 + (ch & (CPR / 2 - 1)) * EPC;                                // value column (< F test)
+          bf16_t* Hh = reinterpret_cast<bf16_t*>(p.C);
+          bf16_t* Uu = reinterpret_cast<bf16_t*>(p.aux_out);
+#pragma unroll
+          for (int u = 0; u < (PROWS * CPR) / 256; ++u) {
+            const int lrow = lrow0 + u * RSTEP, row = done_m * BM + lrow;
+            if (row < p.M && vcol < F) {
+              const uint4 q = *reinterpret_cast<const uint4*>(smem + lrow * CROW + ch * 16);
+              st_global_b128(Hh + (int64_t)row * p.ldc + hc, q);
+              if (ch < CPR / 2) {
+                const uint4 g = *reinterpret_cast<const uint4*>(smem + lrow * CROW + (ch + CPR / 2) * 16);
+                const uint32_t aw[4] = {q.x, q.y, q.z, q.w}, bw[4] = {g.x, g.y, g.z, g.w};
+                float o[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                  const float a = __uint_as_float((e & 1) ? (aw[e >> 1] & 0xffff0000u) : (aw[e >> 1] << 16));
+                  const float b = __uint_as_float((e & 1) ? (bw[e >> 1] & 0xffff0000u) : (bw[e >> 1] << 16));
+                  o[e] = a * (1.f / (1.f + __expf(-b)));
+                }
+                st_global_b128(Uu + (int64_t)row * F + vcol, MMA<bf16_t>::pack(o));
+              }
+            }
+          }
+          continue;
+        }
+      }
       if constexpr (AMODE == MODE_KC && BMODE == MODE_KC && sizeof(OT) == 2 && PASSES == 1 &&
                     PROWS * CROW + 2 * RSTEP * BN * 4 <= 2 * BUF) {
         if (p.act == OTR_ACT_GLU_BWD) {
@@ -802,7 +846,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
       tile_m = tile / tiles_n;
       tile_n = tile - tile_m * tiles_n;
       la.init(p.A, p.lda, p.M, p.K, tile_m * BM, p.a_vec != 0, p.cg, tid);
-      lb.init(p.B, p.ldb, p.N, p.K, tile_n * BN, p.b_vec != 0, p.cg, tid);
+      lb.init(p.B, p.ldb, p.N, p.K, tile_n * bstep, p.b_vec != 0, p.cg, tid, pairF);
     }
     __syncthreads();            // epilogue staging reads / last operand reads finish before the next tile's LDS writes
     OTR_TRACE(0)

@@ -533,11 +533,21 @@ class FeedForwardGLUFn(torch.autograd.Function):
         ctx.w1t, ctx.w2t = weight_lpt(w1), weight_lpt(w2)
         w1 = w1l if w1l is not None else w1
         w2 = w2l if w2l is not None else w2
-        h = linear_fwd_raw(x2, w1, b1, adt)
-        M, F2 = h.shape
+        M, F2 = x2.shape[0], w1.shape[0]
         F = F2 // 2
+        h = None
         u = torch.empty((M, F), dtype=adt, device=x.device)
-        L.check(L.load().otr_glu_fwd(_p(h), _p(u), _code(adt), M, F, None, _stream()), 'otr_glu_fwd')
+        if adt == torch.bfloat16 and x2.dtype == adt and w1.dtype == adt and _FUSED_GLU_FWD:
+            h = torch.empty((M, F2), dtype=adt, device=x.device)
+            rc = L.load().otr_ffn_glu_fwd(_p(x2), x2.stride(0), _p(w1), w1.stride(0), _p(b1), _p(h), _p(u), M, F,
+                                          x2.shape[1], _stream())
+            if rc == 1:
+                h = None                         # operands do not qualify: two-kernel path below
+            else:
+                L.check(rc, 'otr_ffn_glu_fwd')
+        if h is None:
+            h = linear_fwd_raw(x2, w1, b1, adt)
+            L.check(L.load().otr_glu_fwd(_p(h), _p(u), _code(adt), M, F, None, _stream()), 'otr_glu_fwd')
         y = linear_fwd_raw(u, w2, b2, out_dtype)
         ctx.save_for_backward(x2, w1, w2, h, u)
         ctx.xshape, ctx.xdtype = x.shape, x.dtype
@@ -582,7 +592,8 @@ class FeedForwardGLUFn(torch.autograd.Function):
 
 
 GLU_RPB = 32        # rows per workgroup of otr_glu_bwd (csrc/elementwise.hip)
-_FUSED_GLU_BWD = os.environ.get('OTR_NO_FUSED_GLU_BWD', '0') != '1'     # A/B switch for tuning runs
+_FUSED_GLU_BWD = os.environ.get('OTR_NO_FUSED_GLU_BWD', '0') != '1'     # A/B switches for tuning runs
+_FUSED_GLU_FWD = os.environ.get('OTR_NO_FUSED_GLU_FWD', '0') != '1'
 
 
 # ---------------------------------------------------------------------------------------- positional encoding
