@@ -242,9 +242,22 @@ __device__ __forceinline__ void load_reg_frags(uint4* fr, const CT* g, int64_t t
   }
 }
 
-template <class CT> __device__ __forceinline__ float attn_exp(float x) {
-  if constexpr (sizeof(CT) == 4) return expf(x);
-  else return __expf(x);
+// bf16 mode works in the base-2 domain: scores are pre-multiplied by scale*log2(e) so that every exponential is a bare
+// v_exp_f32 (natural exp costs an extra multiply each, and these kernels are VALU bound: PMC showed ~2000 VALU
+// instructions per wave against 64 MFMAs).  fp32 (parity) mode keeps expf.
+template <class CT> struct ExpDom {
+  static constexpr float K = sizeof(CT) == 4 ? 1.f : 1.4426950408889634f;          // log2(e) in bf16 mode
+  static __device__ __forceinline__ float ex(float x) {
+    if constexpr (sizeof(CT) == 4) return expf(x);
+    else return __builtin_amdgcn_exp2f(x);
+  }
+};
+template <class CT> __device__ __forceinline__ float attn_exp(float x) { return ExpDom<CT>::ex(x); }
+// validity of the 64 streamed keys of a block as one wave-uniform bit mask (one byte load per lane instead of 16)
+__device__ __forceinline__ uint64_t key_block_mask(const uint8_t* km, int kb, int Tk, int lane) {
+  const int key = kb * 64 + lane;
+  const bool v = key < Tk && (!km || km[min(key, Tk - 1)] != 0);
+  return __ballot(v);
 }
 
 // store 4 consecutive head-dim elements
@@ -282,7 +295,8 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
   f32x4 acc[C::DT];
 #pragma unroll
   for (int i = 0; i < C::DT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m = NEG_INF, l = 0.f;
+  float m = NEG_INF, l = 0.f;                       // running max / sum in the ExpDom<CT> domain
+  const float sc2 = p.scale * ExpDom<CT>::K;
 
   const int nkb = (p.Tk + 63) / 64;
   RmRegs<CT, DK> kreg;
@@ -317,18 +331,29 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
       for (int ks = 0; ks < C::KS; ++ks) MMA<CT>::mma(st[kt], read_rm<CT, DK>(sK, kt * 16 + lr, ks * 4 + lg), qf[ks]);
     }
     float bm = NEG_INF;
+    const uint64_t kmask = key_block_mask(km, kb, p.Tk, lane);
+    if (kmask == ~0ull && !p.causal && !p.bias) {       // whole block valid: no per-element predicate at all
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int key = kb * 64 + kt * 16 + lg * 4 + r;
-        bool ok = key < p.Tk && (!km || km[key]) && (!p.causal || key <= qrow);
-        float raw = st[kt][r];
-        if (p.bias && ok && qrow < p.Tq) raw += p.bias[bias_index(p, b, h, qrow, key)];
-        float s = ok ? raw * p.scale : NEG_INF;
-        st[kt][r] = s;
-        bm = fmaxf(bm, s);
-      }
+        for (int r = 0; r < 4; ++r) {
+          st[kt][r] *= sc2;
+          bm = fmaxf(bm, st[kt][r]);
+        }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kl = kt * 16 + lg * 4 + r, key = kb * 64 + kl;
+          bool ok = ((kmask >> kl) & 1) && (!p.causal || key <= qrow);
+          float raw = st[kt][r];
+          if (p.bias && ok && qrow < p.Tq) raw += p.bias[bias_index(p, b, h, qrow, key)];
+          float s = ok ? raw * sc2 : NEG_INF;
+          st[kt][r] = s;
+          bm = fmaxf(bm, s);
+        }
+    }
     bm = fmaxf(bm, __shfl_xor(bm, 16));
     bm = fmaxf(bm, __shfl_xor(bm, 32));
     float m_new = fmaxf(m, bm);
@@ -363,7 +388,7 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt)
       store4<CT>(O + dt * 16 + lg * 4, acc[dt][0] * inv, acc[dt][1] * inv, acc[dt][2] * inv, acc[dt][3] * inv, vec);
-    if (lg == 0) p.lse[((int64_t)b * p.H + h) * p.Tq + qrow] = (l > 0.f) ? m + logf(l) : NEG_INF;
+    if (lg == 0) p.lse[((int64_t)b * p.H + h) * p.Tq + qrow] = (l > 0.f) ? m * (1.f / ExpDom<CT>::K) + logf(l) : NEG_INF;
   }
 }
 
@@ -403,6 +428,7 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
   const int h = blockIdx.y, b = blockIdx.z;
   const int k0 = blockIdx.x * 64 + wid * 16;
   const bool vec = p.vec != 0;
+  const float sc2 = p.scale * ExpDom<CT>::K;
   const CT* Q = reinterpret_cast<const CT*>(p.q) + b * p.q_bs + h * DK;
   const CT* K = reinterpret_cast<const CT*>(p.k) + b * p.k_bs + h * DK;
   const CT* V = reinterpret_cast<const CT*>(p.v) + b * p.v_bs + h * DK;
@@ -442,7 +468,7 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
       st_tr<CT, DK>(sQt, qtreg, nvalid, tid);
       st_tr<CT, DK>(sdOt, dotreg, nvalid, tid);
       if (tid < 64) {
-        sLse[tid] = (tid < nvalid) ? lreg : 0.f;
+        sLse[tid] = (tid < nvalid) ? lreg * ExpDom<CT>::K : 0.f;
         sDel[tid] = (tid < nvalid) ? dreg : 0.f;
       }
     } else {
@@ -451,7 +477,7 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
       load_tile_tr<CT, DK>(sQt, Q + (int64_t)qb * 64 * p.q_ts, p.q_ts, nvalid, vec, tid);
       load_tile_tr<CT, DK>(sdOt, dO + (int64_t)qb * 64 * p.o_ts, p.o_ts, nvalid, vec, tid);
       if (tid < 64) {
-        sLse[tid] = (tid < nvalid) ? lse[qb * 64 + tid] : 0.f;
+        sLse[tid] = (tid < nvalid) ? lse[qb * 64 + tid] * ExpDom<CT>::K : 0.f;
         sDel[tid] = (tid < nvalid) ? del[qb * 64 + tid] : 0.f;
       }
     }
@@ -468,6 +494,9 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
     }
 
     f32x4 pt[4], ds[4];  // tiles over q (rows), cols = keys
+    // whole query block valid with finite lse, no causal mask, no bias: no per-element predicate (masked KEYS only
+    // pollute their own dK/dV columns, which are zeroed at the store)
+    const bool fastblk = !p.causal && !p.bias && nvalid == 64 && __ballot(sLse[lane] == NEG_INF) == 0;
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -476,14 +505,24 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
         MMA<CT>::mma(s, read_rm<CT, DK>(sQ, qt * 16 + lr, ks * 4 + lg), kf[ks]);
         MMA<CT>::mma(dp, read_rm<CT, DK>(sdO, qt * 16 + lr, ks * 4 + lg), vf[ks]);
       }
+      if (fastblk) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = qt * 16 + lg * 4 + r;
+          const float pe = attn_exp<CT>(s[r] * sc2 - sLse[ql]);
+          pt[qt][r] = pe;
+          ds[qt][r] = pe * (dp[r] - sDel[ql]) * p.scale;
+        }
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int ql = qt * 16 + lg * 4 + r, qg = qb * 64 + ql;
-        float ls = sLse[ql];
+        float ls = sLse[ql];                               // pre-multiplied by ExpDom<CT>::K when it was staged
         bool ok = key_ok && qg < p.Tq && (!p.causal || key <= qg) && ls != NEG_INF;
         float raw = s[r];
         if (p.bias && ok) raw += p.bias[bias_index(p, b, h, qg, key)];
-        float pe = ok ? attn_exp<CT>(raw * p.scale - ls) : 0.f;
+        float pe = ok ? attn_exp<CT>(raw * sc2 - ls) : 0.f;
         pt[qt][r] = pe;
         float dsv = pe * (dp[r] - sDel[ql]) * p.scale;
         ds[qt][r] = dsv;
@@ -504,8 +543,11 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
   if (key < p.Tk) {
     CT* dK = reinterpret_cast<CT*>(p.dk) + b * p.k_bs + (int64_t)key * p.k_ts + h * DK;
     CT* dV = reinterpret_cast<CT*>(p.dv) + b * p.v_bs + (int64_t)key * p.v_ts + h * DK;
+    // masked key: zero gradient (the fast path did not predicate it)
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) {
+      dk_acc[dt] = key_ok ? dk_acc[dt] : f32x4{0.f, 0.f, 0.f, 0.f};
+      dv_acc[dt] = key_ok ? dv_acc[dt] : f32x4{0.f, 0.f, 0.f, 0.f};
       store4<CT>(dK + dt * 16 + lg * 4, dk_acc[dt][0], dk_acc[dt][1], dk_acc[dt][2], dk_acc[dt][3], vec);
       store4<CT>(dV + dt * 16 + lg * 4, dv_acc[dt][0], dv_acc[dt][1], dv_acc[dt][2], dv_acc[dt][3], vec);
     }
@@ -524,6 +566,7 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
   const int h = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 64 + wid * 16;
   const bool vec = p.vec != 0;
+  const float sc2 = p.scale * ExpDom<CT>::K;
   const CT* Q = reinterpret_cast<const CT*>(p.q) + b * p.q_bs + h * DK;
   const CT* K = reinterpret_cast<const CT*>(p.k) + b * p.k_bs + h * DK;
   const CT* V = reinterpret_cast<const CT*>(p.v) + b * p.v_bs + h * DK;
@@ -531,8 +574,10 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
   const uint8_t* km = p.key_mask ? p.key_mask + (int64_t)b * p.Tk : nullptr;
   const int qrow = q0 + lr;
   const bool q_ok = qrow < p.Tq;
-  const float ls = q_ok ? p.lse[((int64_t)b * p.H + h) * p.Tq + qrow] : NEG_INF;
+  const float ls = q_ok ? p.lse[((int64_t)b * p.H + h) * p.Tq + qrow] * ExpDom<CT>::K : NEG_INF;
   const float dl = q_ok ? p.delta[((int64_t)b * p.H + h) * p.Tq + qrow] : 0.f;
+  const bool row_live = q_ok && ls != NEG_INF;
+  const float lsf = row_live ? ls : 0.f;                // finite stand-in for the unpredicated fast path
 
   uint4 qf[C::KS], dof[C::KS];
   load_reg_frags<CT, DK>(qf, Q, p.q_ts, qrow, p.Tq, vec, lg);
@@ -572,6 +617,7 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    const uint64_t kmask = key_block_mask(km, kb, p.Tk, lane);
     f32x4 ds[4];  // tiles over keys (rows), cols = queries
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -581,13 +627,18 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
         MMA<CT>::mma(s, read_rm<CT, DK>(sK, kt * 16 + lr, ks * 4 + lg), qf[ks]);
         MMA<CT>::mma(dp, read_rm<CT, DK>(sV, kt * 16 + lr, ks * 4 + lg), dof[ks]);
       }
+      if (kmask == ~0ull && !p.causal && !p.bias) {    // (rows without a finite lse are zeroed at the store)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[kt][r] = attn_exp<CT>(s[r] * sc2 - lsf) * (dp[r] - dl) * p.scale;
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int key = kb * 64 + kt * 16 + lg * 4 + r;
-        bool ok = q_ok && ls != NEG_INF && key < p.Tk && (!km || km[key]) && (!p.causal || key <= qrow);
+        const int kl = kt * 16 + lg * 4 + r, key = kb * 64 + kl;
+        bool ok = q_ok && ls != NEG_INF && ((kmask >> kl) & 1) && (!p.causal || key <= qrow);
         float raw = s[r];
         if (p.bias && ok) raw += p.bias[bias_index(p, b, h, qrow, key)];
-        float pe = ok ? attn_exp<CT>(raw * p.scale - ls) : 0.f;
+        float pe = ok ? attn_exp<CT>(raw * sc2 - ls) : 0.f;
         ds[kt][r] = pe * (dp[r] - dl) * p.scale;
       }
     }
@@ -601,8 +652,10 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
   if (q_ok) {
     CT* dQ = reinterpret_cast<CT*>(p.dq) + b * p.q_bs + (int64_t)qrow * p.q_ts + h * DK;
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt)
+    for (int dt = 0; dt < C::DT; ++dt) {
+      if (!row_live) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
       store4<CT>(dQ + dt * 16 + lg * 4, acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3], vec);
+    }
   }
 }
 

@@ -983,7 +983,7 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
   int ks = 1;
   if (big && t128 >= 256) {
     ks = 1;
-  } else if (big && t128 * splits_for(t128) >= 256) {
+  } else if (big && t128 * splits_for(t128) >= 192) {   // (126 tiles x 2 slices = 252 workgroups is a full wave of CUs)
     ks = splits_for(t128);
   } else {
     big = false;
