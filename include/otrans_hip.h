@@ -64,21 +64,23 @@ int32_t otr_linear_wgrad(const otr_linear_desc_t* d, const void* dy, const void*
 int32_t otr_colsum(const void* a, int32_t dtype, int64_t M, int64_t N, int64_t lda, float* out, int32_t accumulate,
                    void* stream);
 
-/* ---- FFN forward through w_1 and the GLU in ONE launch (module/ffn.py:38-40): h[M,2F] = x[M,d] . w1[2F,d]^T + b1 (kept
- *      for backward) and u[M,F] = h[:, :F] * sigmoid(h[:, F:]).  Each GEMM tile holds 64 value columns and their 64 gate
+/* ---- FFN forward through w_1 and the GLU in ONE launch (module/ffn.py:38-40): t[M,2F] = x[M,d] . w1[2F,d]^T + b1,
+ *      u[M,F] = t[:, :F] * sigmoid(t[:, F:]); h[M,2F] = (t[:, :F] | sigmoid(t[:, F:])) is kept for backward (the
+ *      sigmoid is computed once; otr_ffn_glu_bwd / otr_glu_bwd take it with h_has_sigmoid = 1).  Each GEMM tile holds 64 value columns and their 64 gate
  *      columns, so the GLU runs in the epilogue on data that is already on chip.  bf16 operands and outputs.
  *      Returns 1 without launching anything when the operands do not qualify; use otr_linear_fwd + otr_glu_fwd then. */
 int32_t otr_ffn_glu_fwd(const void* x, int64_t ldx, const void* w1, int64_t ldw, const float* b1, void* h, void* u, int32_t M,
                         int32_t F, int32_t d_model, void* stream);
 /* ---- FFN backward through w_2 and the GLU in ONE launch (module/ffn.py:38-41 backward): du = dy[M,d] . w2 (w2t = the
  *      [F,d] transposed bf16 shadow of w_2; du is never stored), dh[M,2F] = GLU'(h) * du with h[M,2F] the saved GLU
- *      input, and dbias_partial[rows, 2F] = column sums of dh per row tile (column-sum them for the w_1 bias gradient;
+ *      input (h_has_sigmoid != 0: its second half already holds sigmoid(gate), as otr_ffn_glu_fwd writes it), and
+ *      dbias_partial[rows, 2F] = column sums of dh per row tile (column-sum them for the w_1 bias gradient;
  *      *partial_rows receives the number of rows written, <= partial_rows_cap, size it ceil(M/64)).  bf16 operands.
  *      Returns 1 without launching anything when the operands do not qualify (alignment); use otr_linear_dgrad +
  *      otr_glu_bwd then. */
-int32_t otr_ffn_glu_bwd(const void* dy, int32_t dy_dtype, int64_t ldy, const void* w2t, int64_t ldw, const void* h, void* dh,
-                        float* dbias_partial, int32_t partial_rows_cap, int32_t* partial_rows, int32_t M, int32_t F,
-                        int32_t d_model, void* stream);
+int32_t otr_ffn_glu_bwd(const void* dy, int32_t dy_dtype, int64_t ldy, const void* w2t, int64_t ldw, const void* h,
+                        int32_t h_has_sigmoid, void* dh, float* dbias_partial, int32_t partial_rows_cap,
+                        int32_t* partial_rows, int32_t M, int32_t F, int32_t d_model, void* stream);
 
 /* ---- grouped weight / bias gradients: every dw_i[N,K] += dy_i[M,N]^T x_i[M,K] of a backward pass in a few launches
  *      (one per operand-type group), likewise every bias gradient out_i[N] += column sums of a_i[M,N].  The per-layer
@@ -164,7 +166,7 @@ int32_t otr_glu_fwd(const void* h, void* u, int32_t dtype, int64_t M, int64_t F,
 /* dh[M,2F] from du[M,F]; if dbias_partial != NULL it receives per-row-block partial column sums of dh,
  * f32 [ceil(M/32), 2F] (deterministic; column-sum them with otr_colsum to get the w_1 bias gradient) */
 int32_t otr_glu_bwd(const void* h, const void* du, void* dh, float* dbias, int32_t dtype, int64_t M, int64_t F,
-                    const uint8_t* row_mask, void* stream);
+                    const uint8_t* row_mask, int32_t h_has_sigmoid, void* stream);
 
 /* ---- PositionalEncoding (module/pos.py:30-57): y = x*scale + PE[t], t = row % T.
  *      x may alias y. */

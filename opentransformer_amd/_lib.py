@@ -63,7 +63,7 @@ SIGNATURES = {
     'otr_linear_dgrad': [C.POINTER(LinearDesc), _P, _P, _P, _P, _I64, _P],
     'otr_linear_wgrad': [C.POINTER(LinearDesc), _P, _P, _P, _P, _I64, _P],
     'otr_ffn_glu_fwd': [_P, _I64, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _P],
-    'otr_ffn_glu_bwd': [_P, _I32, _I64, _P, _I64, _P, _P, _P, _I32, _P, _I32, _I32, _I32, _P],
+    'otr_ffn_glu_bwd': [_P, _I32, _I64, _P, _I64, _P, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _P],
     'otr_linear_wgrad_grouped': [_P, _I32, _I32, _P, _I64, _P],
     'otr_colsum_grouped': [_P, _I32, _P],
     'otr_colsum': [_P, _I32, _I64, _I64, _I64, _P, _I32, _P],
@@ -76,7 +76,7 @@ SIGNATURES = {
     'otr_debug_trace': [_P],
     'otr_transpose_batched': [_P, _P, _P, _I32, _I64, _I32, _P],
     'otr_glu_fwd': [_P, _P, _I32, _I64, _I64, _P, _P],
-    'otr_glu_bwd': [_P, _P, _P, _P, _I32, _I64, _I64, _P, _P],
+    'otr_glu_bwd': [_P, _P, _P, _P, _I32, _I64, _I64, _P, _I32, _P],
     'otr_posenc_fwd': [_P, _P, _P, _I64, _I32, _I32, _F32, _P],
     'otr_embed_posenc_fwd': [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _F32, _P],
     'otr_embed_bwd': [_P, _P, _P, _I64, _I32, _I32, _F32, _P],

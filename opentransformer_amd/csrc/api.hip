@@ -162,8 +162,8 @@ extern "C" int32_t otr_ffn_glu_fwd(const void* x, int64_t ldx, const void* w1, i
 // column sums of dh (the w_1 bias gradient).  Returns 1 (nothing launched) when the operands do not qualify for the
 // fused kernel; the caller then runs otr_linear_dgrad / otr_glu_bwd.
 extern "C" int32_t otr_ffn_glu_bwd(const void* dy, int32_t dy_dtype, int64_t ldy, const void* w2t, int64_t ldw, const void* h,
-                                   void* dh, float* dbias_partial, int32_t partial_rows_cap, int32_t* partial_rows,
-                                   int32_t M, int32_t F, int32_t d_model, void* stream) {
+                                   int32_t h_has_sigmoid, void* dh, float* dbias_partial, int32_t partial_rows_cap,
+                                   int32_t* partial_rows, int32_t M, int32_t F, int32_t d_model, void* stream) {
   OTR_REQUIRE(dy && w2t && h && dh && dbias_partial && partial_rows, "ffn_glu_bwd: null pointer");
   OTR_REQUIRE(M >= 0 && F > 0 && d_model > 0 && ldy >= d_model && ldw >= d_model, "ffn_glu_bwd: bad shape");
   *partial_rows = 0;
@@ -178,7 +178,7 @@ extern "C" int32_t otr_ffn_glu_bwd(const void* dy, int32_t dy_dtype, int64_t ldy
   a.A = dy; a.B = w2t; a.C = dh /* unused, must be aligned */; a.bias = nullptr;
   a.M = M; a.N = F; a.K = d_model;
   a.lda = ldy; a.ldb = ldw; a.ldc = 2 * (int64_t)F;
-  a.act = OTR_ACT_GLU_BWD; a.accumulate = 0;
+  a.act = OTR_ACT_GLU_BWD; a.accumulate = 0; a.aux_flag = h_has_sigmoid ? 1 : 0;
   a.a_vec = 1; a.b_vec = 1;
   a.allow_split = 0; a.ws = nullptr; a.ws_bytes = 0; a.trace = g_otr_trace;
   a.aux_in = h; a.aux_out = dh; a.aux_part = dbias_partial;

@@ -32,7 +32,7 @@ template <class T> __global__ void glu_fwd_kernel(const T* h, T* u, int64_t M, i
 // dh[:, :F] = du * sig(g);  dh[:, F:] = du * a * sig(g) * (1 - sig(g));  optional bias-gradient partials
 constexpr int GLU_RPB = 32;  // rows per block in the backward (each thread owns V columns)
 template <class T> __global__ void glu_bwd_kernel(const T* h, const T* du, T* dh, float* dbias, int64_t M, int64_t F,
-                                                  const uint8_t* row_mask) {
+                                                  const uint8_t* row_mask, int has_sig) {
   constexpr int V = 16 / sizeof(T);
   const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
   if (c >= F) return;
@@ -47,7 +47,7 @@ template <class T> __global__ void glu_bwd_kernel(const T* h, const T* du, T* dh
     load_row<T, V>(du + row * F + c, V, true, d);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      float s = sigmoidf_(g[e]);
+      float s = has_sig ? g[e] : sigmoidf_(g[e]);       // h[:, F:] may already hold sigmoid(gate) (otr_ffn_glu_fwd)
       float dd = (!row_mask || row_mask[row]) ? d[e] : 0.f;     // masked_fill_(~mask, 0) after the GLU
       oa[e] = dd * s;
       og[e] = dd * a[e] * s * (1.f - s);
@@ -81,7 +81,7 @@ extern "C" int32_t otr_glu_fwd(const void* h, void* u, int32_t dtype, int64_t M,
 }
 
 extern "C" int32_t otr_glu_bwd(const void* h, const void* du, void* dh, float* dbias, int32_t dtype, int64_t M,
-                               int64_t F, const uint8_t* row_mask, void* stream) {
+                               int64_t F, const uint8_t* row_mask, int32_t h_has_sigmoid, void* stream) {
   OTR_REQUIRE(h && du && dh, "glu_bwd: null pointer");
   OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_BF16, "glu_bwd: bad dtype");
   OTR_REQUIRE(F > 0 && F % 8 == 0 && M >= 0, "glu_bwd: F=%lld must be a positive multiple of 8", (long long)F);
@@ -89,8 +89,8 @@ extern "C" int32_t otr_glu_bwd(const void* h, const void* du, void* dh, float* d
   hipStream_t s = (hipStream_t)stream;
   int V = dtype == OTR_F32 ? 4 : 8;
   dim3 grid((unsigned)((F / V + 255) / 256), (unsigned)((M + GLU_RPB - 1) / GLU_RPB));
-  if (dtype == OTR_F32) hipLaunchKernelGGL(glu_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)h, (const float*)du, (float*)dh, dbias, M, F, row_mask);
-  else hipLaunchKernelGGL(glu_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)h, (const bf16_t*)du, (bf16_t*)dh, dbias, M, F, row_mask);
+  if (dtype == OTR_F32) hipLaunchKernelGGL(glu_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)h, (const float*)du, (float*)dh, dbias, M, F, row_mask, h_has_sigmoid);
+  else hipLaunchKernelGGL(glu_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)h, (const bf16_t*)du, (bf16_t*)dh, dbias, M, F, row_mask, h_has_sigmoid);
   return otr_check_launch("glu_bwd");
 }
 

@@ -53,6 +53,7 @@ struct GemmArgs {
   const void* aux_in;
   void* aux_out;
   float* aux_part;
+  int aux_flag;               // GLU_BWD: 1 = the second half of aux_in already holds sigmoid(gate)
   unsigned long long* trace;  // tuning hook (otr_debug_trace): per-workgroup phase timestamps, or NULL
   ConvGeom cg;
 };
@@ -416,7 +417,9 @@ template <class OT> __device__ __noinline__ void store_tail_acc(OT* dst, const O
 
 // One workgroup's share of a GEMM: tiles tile0, tile0 + tile_stride, ... (PERSIST) or just tile0, k-slice `kslice`.
 // Shared by the plain kernel (blockIdx -> tile) and the grouped kernel (blockIdx -> problem -> tile).
-template <class CT, class AT, class BT, class OT, int AMODE, int BMODE, int BM, int BN, bool FAST, bool PERSIST>
+// EPI: 0 = plain epilogue (bias / ReLU / accumulate), 1 = GLU forward, 2 = GLU backward (own instantiations: their
+// registers must not weigh on the plain kernel -- folded into it they made it spill)
+template <class CT, class AT, class BT, class OT, int AMODE, int BMODE, int BM, int BN, bool FAST, bool PERSIST, int EPI = 0>
 __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, const int tile_stride, const int kslice) {
   using G = GemmCfg<CT>;
   constexpr int KCH = G::KCH, BK = G::BK, ROWB = G::ROWB;
@@ -446,7 +449,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
 
   // GLU-forward fusion (p.act == OTR_ACT_GLU_FWD, N = 2F): B tile n holds W1 rows [n*BN/2, +BN/2) and F + the same
   constexpr bool GLU_OK = FAST && AMODE == MODE_KC && BMODE == MODE_KC && sizeof(OT) == 2;
-  const int pairF = (GLU_OK && p.act == OTR_ACT_GLU_FWD) ? p.N / 2 : 0;
+  static_assert(EPI == 0 || GLU_OK, "GLU epilogues exist for the bf16 KC/KC fast kernels only");
+  const int pairF = (EPI == 1) ? p.N / 2 : 0;
   const int bstep = pairF > 0 ? BN / 2 : BN;               // operand-row advance per n-tile
   TileLoader<CT, AT, AMODE, BM, FAST> la;
   TileLoader<CT, BT, BMODE, BN, FAST> lb;
@@ -668,42 +672,45 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
       static_assert(256 % CPR == 0 && (PROWS * CPR) % 256 == 0, "write-out mapping");
       const int lrow0 = tid / CPR, ch = tid % CPR;
       const int col = done_n * BN + ch * EPC;
-      if constexpr (GLU_OK && PASSES == 1) {
-        if (p.act == OTR_ACT_GLU_FWD) {
+      if constexpr (EPI == 1 && PASSES == 1) {
+        {
           // staged tile = h (bias added) for value columns [n0, n0+BN/2) in its left half and their gates in the right
           // half.  Every thread writes its h chunk; threads on the left half also read the partner gate chunk from LDS
           // and write u = a * sigmoid(b): the separate GLU pass (re-read h, write u) disappears.
           const int F = pairF, n0 = done_n * (BN / 2);
-          const int hc = (ch < CPR / 2) ? n0 + ch * EPC : F + n0 + (ch - CPR / 2) * EPC;   // column in h
-          const int vcol = n0 + (ch & (CPR / 2 - 1)) * EPC;                                // value column (< F test)
+          constexpr int VPR = CPR / 2;                       // value chunks per row; every thread gets whole items
+          constexpr int VSTEP = 256 / VPR;                   // (value chunk + its gate chunk): the exp work is balanced
+          const int vr0 = tid / VPR, vc = tid % VPR;
+          const int vcol = n0 + vc * EPC;                    // value column; gate column = F + vcol
           bf16_t* Hh = reinterpret_cast<bf16_t*>(p.C);
           bf16_t* Uu = reinterpret_cast<bf16_t*>(p.aux_out);
 #pragma unroll
-          for (int u = 0; u < (PROWS * CPR) / 256; ++u) {
-            const int lrow = lrow0 + u * RSTEP, row = done_m * BM + lrow;
+          for (int u = 0; u < (PROWS * VPR) / 256; ++u) {
+            const int lrow = vr0 + u * VSTEP, row = done_m * BM + lrow;
             if (row < p.M && vcol < F) {
-              const uint4 q = *reinterpret_cast<const uint4*>(smem + lrow * CROW + ch * 16);
-              st_global_b128(Hh + (int64_t)row * p.ldc + hc, q);
-              if (ch < CPR / 2) {
-                const uint4 g = *reinterpret_cast<const uint4*>(smem + lrow * CROW + (ch + CPR / 2) * 16);
-                const uint32_t aw[4] = {q.x, q.y, q.z, q.w}, bw[4] = {g.x, g.y, g.z, g.w};
-                float o[EPC];
+              const uint4 q = *reinterpret_cast<const uint4*>(smem + lrow * CROW + vc * 16);
+              const uint4 g = *reinterpret_cast<const uint4*>(smem + lrow * CROW + (vc + VPR) * 16);
+              const uint32_t aw[4] = {q.x, q.y, q.z, q.w}, bw[4] = {g.x, g.y, g.z, g.w};
+              float o[EPC], sg[EPC];
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                  const float a = __uint_as_float((e & 1) ? (aw[e >> 1] & 0xffff0000u) : (aw[e >> 1] << 16));
-                  const float b = __uint_as_float((e & 1) ? (bw[e >> 1] & 0xffff0000u) : (bw[e >> 1] << 16));
-                  o[e] = a * (1.f / (1.f + __expf(-b)));
-                }
-                st_global_b128(Uu + (int64_t)row * F + vcol, MMA<bf16_t>::pack(o));
+              for (int e = 0; e < EPC; ++e) {
+                const float a = __uint_as_float((e & 1) ? (aw[e >> 1] & 0xffff0000u) : (aw[e >> 1] << 16));
+                const float b = __uint_as_float((e & 1) ? (bw[e >> 1] & 0xffff0000u) : (bw[e >> 1] << 16));
+                sg[e] = 1.f / (1.f + __expf(-b));
+                o[e] = a * sg[e];
               }
+              // h keeps (value | sigmoid(gate)): the backward epilogue then needs no exponential at all
+              st_global_b128(Hh + (int64_t)row * p.ldc + vcol, q);
+              st_global_b128(Hh + (int64_t)row * p.ldc + F + vcol, MMA<bf16_t>::pack(sg));
+              st_global_b128(Uu + (int64_t)row * F + vcol, MMA<bf16_t>::pack(o));
             }
           }
           continue;
         }
       }
-      if constexpr (AMODE == MODE_KC && BMODE == MODE_KC && sizeof(OT) == 2 && PASSES == 1 &&
-                    PROWS * CROW + 2 * RSTEP * BN * 4 <= 2 * BUF) {
-        if (p.act == OTR_ACT_GLU_BWD) {
+      if constexpr (EPI == 2 && PASSES == 1) {
+        static_assert(EPI != 2 || PROWS * CROW + 2 * RSTEP * BN * 4 <= 2 * BUF, "GLU-backward partials do not fit the LDS");
+        {
           // The staged tile is du = dy . W2 for hidden units [col, col+8) of PROWS rows.  GLU backward right here:
           //   dh[:, j] = du * sig(b),  dh[:, F+j] = du * a * sig(b) * (1 - sig(b)),   (a | b) = h[:, j], h[:, F+j]
           // du never goes to HBM and the separate GLU-backward pass (read h + du, write dh) disappears.
@@ -738,7 +745,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
               const float a = __uint_as_float((e & 1) ? (aw[e >> 1] & 0xffff0000u) : (aw[e >> 1] << 16));
               const float b = __uint_as_float((e & 1) ? (bw[e >> 1] & 0xffff0000u) : (bw[e >> 1] << 16));
               (void)sh;
-              const float sg = 1.f / (1.f + __expf(-b));
+              const float sg = p.aux_flag ? b : 1.f / (1.f + __expf(-b));
               oa[e] = live ? d * sg : 0.f;
               ob[e] = live ? d * a * sg * (1.f - sg) : 0.f;
               sa[e] += oa[e]; sb[e] += ob[e];
@@ -855,9 +862,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
 #undef OTR_TRACE
 }
 
-template <class CT, class AT, class BT, class OT, int AMODE, int BMODE, int BM, int BN, bool FAST, bool PERSIST = false>
+template <class CT, class AT, class BT, class OT, int AMODE, int BMODE, int BM, int BN, bool FAST, bool PERSIST = false, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 VGPRs: two workgroups per CU
-  gemm_body<CT, AT, BT, OT, AMODE, BMODE, BM, BN, FAST, PERSIST>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
+  gemm_body<CT, AT, BT, OT, AMODE, BMODE, BM, BN, FAST, PERSIST, EPI>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1020,6 +1027,27 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
   constexpr bool CAN_PERSIST = (AMODE == MODE_KC && BMODE == MODE_KC);
   const bool persist = CAN_PERSIST && fast && a.ksplit == 1 && g_otr_no_persist == 0;
   const dim3 grid((unsigned)(persist && ntiles > OTR_RESIDENT_WG ? OTR_RESIDENT_WG : ntiles), a.ksplit);
+  if (a.act == OTR_ACT_GLU_FWD || a.act == OTR_ACT_GLU_BWD) {   // fused FFN epilogues: own (non-persistent) instantiations
+    if constexpr (CAN_PERSIST && std::is_same<CT, bf16_t>::value && std::is_same<AT, bf16_t>::value &&
+                  std::is_same<BT, bf16_t>::value && std::is_same<OT, bf16_t>::value) {
+      if (!fast || a.ksplit != 1) {
+        otr_set_error("gemm: fused GLU epilogue needs the fast path without split-K");
+        return -1;
+      }
+      const dim3 g1((unsigned)ntiles, 1);
+      if (a.act == OTR_ACT_GLU_FWD) {
+        if (big) hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 128, 128, true, false, 1>), g1, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 64, 64, true, false, 1>), g1, dim3(256), 0, s, a);
+      } else {
+        if (big) hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 128, 128, true, false, 2>), g1, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 64, 64, true, false, 2>), g1, dim3(256), 0, s, a);
+      }
+      return otr_check_launch("gemm(glu)");
+    } else {
+      otr_set_error("gemm: fused GLU epilogue is built for bf16 KC/KC operands only");
+      return -1;
+    }
+  }
   if constexpr (AMODE == MODE_KC || AMODE == MODE_MC) {
     if constexpr (BMODE == MODE_KC || BMODE == MODE_MC) {
       if (fast && persist) {

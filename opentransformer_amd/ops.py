@@ -545,6 +545,7 @@ class FeedForwardGLUFn(torch.autograd.Function):
                 h = None                         # operands do not qualify: two-kernel path below
             else:
                 L.check(rc, 'otr_ffn_glu_fwd')
+        ctx.h_sig = h is not None               # fused forward keeps (value | sigmoid(gate)) in h
         if h is None:
             h = linear_fwd_raw(x2, w1, b1, adt)
             L.check(L.load().otr_glu_fwd(_p(h), _p(u), _code(adt), M, F, None, _stream()), 'otr_glu_fwd')
@@ -570,7 +571,7 @@ class FeedForwardGLUFn(torch.autograd.Function):
             part = torch.empty((cap, 2 * F), dtype=torch.float32, device=dy.device)
             rows = C.c_int32(0)
             rc = L.load().otr_ffn_glu_bwd(_p(dy2), _code(dy2.dtype), dy2.stride(0), _p(ctx.w2t), ctx.w2t.stride(0), _p(h),
-                                          _p(dh), _p(part), cap, C.byref(rows), M, F, dy2.shape[1], _stream())
+                                          int(ctx.h_sig), _p(dh), _p(part), cap, C.byref(rows), M, F, dy2.shape[1], _stream())
             if rc == 1:
                 part = None                     # operands do not qualify: two-kernel path below
             else:
@@ -580,7 +581,8 @@ class FeedForwardGLUFn(torch.autograd.Function):
             du = linear_fwd_raw(dy2, ctx.w2t, None, u.dtype) if ctx.w2t is not None else linear_dgrad_raw(dy2, w2, u.dtype)
             nblk = (M + GLU_RPB - 1) // GLU_RPB
             part = torch.empty((nblk, 2 * F), dtype=torch.float32, device=dy.device)
-            L.check(L.load().otr_glu_bwd(_p(h), _p(du), _p(dh), _p(part), _code(h.dtype), M, F, None, _stream()), 'otr_glu_bwd')
+            L.check(L.load().otr_glu_bwd(_p(h), _p(du), _p(dh), _p(part), _code(h.dtype), M, F, None, int(ctx.h_sig), _stream()),
+                    'otr_glu_bwd')
         db1 = colsum_raw(part, out=gb1)
         if ctx.w1t is not None:
             dx = linear_fwd_raw(dh, ctx.w1t, None, ctx.xdtype).view(ctx.xshape)
@@ -944,7 +946,7 @@ class ConformerConvFn(torch.autograd.Function):
         dh = torch.empty_like(h)
         nblk = (M + GLU_RPB - 1) // GLU_RPB
         part = torch.empty((nblk, 2 * Cc), dtype=torch.float32, device=dout.device)
-        L.check(lib.otr_glu_bwd(_p(h), _p(dg), _p(dh), _p(part), _code(adt), M, Cc, _p(mask_u8), _stream()), 'otr_glu_bwd')
+        L.check(lib.otr_glu_bwd(_p(h), _p(dg), _p(dh), _p(part), _code(adt), M, Cc, _p(mask_u8), 0, _stream()), 'otr_glu_bwd')
         db1 = colsum_raw(part)
         dx = linear_dgrad_raw(dh, w1c, xdtype).view(xshape)
         dw1 = linear_wgrad_raw(dh, x2, w1c)

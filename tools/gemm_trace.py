@@ -18,7 +18,21 @@ def trace(name, m, n, k, ydt, kind='fwd'):
     w = (torch.randn(n, k, device='cuda') / 16).to(bf)
     b = torch.randn(n, device='cuda')
     dy = torch.randn(m, n, device='cuda').to(bf)
-    fn = (lambda: ops.linear_fwd_raw(x, w, b, ydt)) if kind == 'fwd' else (lambda: ops.linear_wgrad_raw(dy, x, w))
+    if kind == 'ffn_fwd':        # n = 2F
+        F = n // 2
+        h = torch.empty(m, n, device='cuda', dtype=bf)
+        u = torch.empty(m, F, device='cuda', dtype=bf)
+        fn = lambda: lib.otr_ffn_glu_fwd(ops._p(x), k, ops._p(w), k, ops._p(b), ops._p(h), ops._p(u), m, F, k, ops._stream())
+    elif kind == 'ffn_bwd':      # n = F: dy [m, k=d], w2t [F, d]
+        F = n
+        h = torch.randn(m, 2 * F, device='cuda').to(bf)
+        dh = torch.empty_like(h)
+        part = torch.empty((m + 63) // 64, 2 * F, device='cuda')
+        rows = C.c_int32(0)
+        fn = lambda: lib.otr_ffn_glu_bwd(ops._p(x), 1, k, ops._p(w), k, ops._p(h), 1, ops._p(dh), ops._p(part), part.shape[0],
+                                         C.byref(rows), m, F, k, ops._stream())
+    else:
+        fn = (lambda: ops.linear_fwd_raw(x, w, b, ydt)) if kind == 'fwd' else (lambda: ops.linear_wgrad_raw(dy, x, w))
     for _ in range(3):
         fn()
     buf = torch.zeros(1 << 16, dtype=torch.int64, device='cuda')
@@ -51,9 +65,8 @@ def trace(name, m, n, k, ydt, kind='fwd'):
 
 if __name__ == '__main__':
     ops.set_compute_dtype('bf16')
-    r = trace('out', 7968, 256, 256, f32)
-    print('  => us per tick ~ %.5f' % r)
     trace('w1', 7968, 4096, 256, bf)
+    trace('w1+glu', 7968, 4096, 256, bf, 'ffn_fwd')
+    trace('du', 7968, 2048, 256, bf)
+    trace('du+glu_bwd', 7968, 2048, 256, bf, 'ffn_bwd')
     trace('qkv', 7968, 768, 256, bf)
-    trace('w2', 7968, 256, 2048, f32)
-    trace('w1', 7968, 4096, 256, bf, 'wgrad')
