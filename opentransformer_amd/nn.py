@@ -126,7 +126,7 @@ class MultiHeadedSelfAttention(nn.Module):
         self.output_proj = nn.Linear(d_model, d_model)
         self.qvk_proj = nn.Linear(d_model, d_model * 3)
 
-    def context(self, x, mask, causal=False):
+    def context(self, x, mask, causal=False, link=None):
         """softmax(QK^T/sqrt(dk)) V merged over heads, before output_proj (act dtype)."""
         B, T, _ = x.shape
         if mask is not None and mask.dim() == 3 and mask.size(1) == T and T > 1:
@@ -134,12 +134,13 @@ class MultiHeadedSelfAttention(nn.Module):
             if not bool(torch.equal(mask, torch.tril(torch.ones_like(mask)))):
                 _unsupported('arbitrary [B,T,T] attention masks (only key masks and the causal mask)')
             mask, causal = None, True
-        qkv = ops.linear(x, self.qvk_proj.weight, self.qvk_proj.bias, out_dtype=ops.act_dtype())
+        qkv = ops.linear(x, self.qvk_proj.weight, self.qvk_proj.bias, out_dtype=ops.act_dtype(), link=link)
         return ops.SelfAttentionFn.apply(qkv, _key_mask(mask, B, T), self.nheads, causal)
 
-    def forward(self, x, mask, causal=False, defer_bias=False):
-        """defer_bias: the caller feeds the result to _post_norm(..., a_bias=self.output_proj.bias)."""
-        ctx = self.context(x, mask, causal)
+    def forward(self, x, mask, causal=False, defer_bias=False, link=None):
+        """defer_bias: the caller feeds the result to _post_norm(..., a_bias=self.output_proj.bias); link: ops.ResidualLink
+        shared with that _post_norm."""
+        ctx = self.context(x, mask, causal, link)
         # a branch that feeds the fused add+LayerNorm is written in the activation dtype (bf16 in bf16 mode, like every
         # other GEMM output; the fp32 residual stream adds it in fp32): its gradient then comes back in bf16 too
         return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, defer_bias=defer_bias,
@@ -164,10 +165,10 @@ class MultiHeadedCrossAttention(nn.Module):
         self.q_proj = nn.Linear(d_model, d_model)
         self.vk_proj = nn.Linear(memory_dim, d_model * 2)
 
-    def forward(self, query, memory, memory_mask, defer_bias=False):
+    def forward(self, query, memory, memory_mask, defer_bias=False, link=None):
         B, T, _ = memory.shape
         adt = ops.act_dtype()
-        q = ops.linear(query, self.q_proj.weight, self.q_proj.bias, out_dtype=adt)
+        q = ops.linear(query, self.q_proj.weight, self.q_proj.bias, out_dtype=adt, link=link)
         kv = ops.linear(memory, self.vk_proj.weight, self.vk_proj.bias, out_dtype=adt)
         ctx = ops.CrossAttentionFn.apply(q, kv, _key_mask(memory_mask, B, T), self.nheads)
         return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, defer_bias=defer_bias,
@@ -191,19 +192,19 @@ class PositionwiseFeedForward(nn.Module):
         self.w_1 = nn.Linear(d_model, d_ff * 2 if activation == 'glu' else d_ff)
         self.w_2 = nn.Linear(d_ff, d_model)
 
-    def forward(self, x, defer_bias=False):
+    def forward(self, x, defer_bias=False, link=None):
         if self.activation == 'glu':
             return ops.FeedForwardGLUFn.apply(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias,
-                                              defer_bias, ops.act_dtype() if defer_bias else torch.float32)
+                                              defer_bias, ops.act_dtype() if defer_bias else torch.float32, link)
         h = ops.linear(x, self.w_1.weight, self.w_1.bias, relu=True, out_dtype=ops.act_dtype())
         return ops.linear(h, self.w_2.weight, self.w_2.bias, defer_bias=defer_bias,
                           out_dtype=ops.act_dtype() if defer_bias else None)
 
 
-def _post_norm(norm, x, branch, p, training, a_bias=None):
+def _post_norm(norm, x, branch, p, training, a_bias=None, link=None):
     """LN(x + dropout(branch)) in one kernel; a_bias = bias of the Linear that produced `branch` when that Linear
     was called with defer_bias=True (its gradient is then reduced inside the LayerNorm backward)."""
-    return ops.add_layernorm(x, branch, norm.weight, norm.bias, p if training else 0.0, norm.eps, a_bias=a_bias)
+    return ops.add_layernorm(x, branch, norm.weight, norm.bias, p if training else 0.0, norm.eps, a_bias=a_bias, link=link)
 
 
 # ------------------------------------------------------------------------------------- encoder
@@ -227,10 +228,11 @@ class TransformerEncoderLayer(nn.Module):
         self.residual_dropout = residual_dropout
 
     def forward(self, x, mask, pos=None, causal=False):
-        attn, _ = self.slf_attn(x, mask, causal, defer_bias=True)
-        x = _post_norm(self.norm1, x, attn, self.residual_dropout, self.training, self.slf_attn.output_proj.bias)
-        x = _post_norm(self.norm2, x, self.feed_forward(x, defer_bias=True), self.residual_dropout, self.training,
-                       self.feed_forward.w_2.bias)
+        l1, l2 = ops.new_link(), ops.new_link()          # skip-connection gradients are summed in GEMM epilogues
+        attn, _ = self.slf_attn(x, mask, causal, defer_bias=True, link=l1)
+        x = _post_norm(self.norm1, x, attn, self.residual_dropout, self.training, self.slf_attn.output_proj.bias, l1)
+        x = _post_norm(self.norm2, x, self.feed_forward(x, defer_bias=True, link=l2), self.residual_dropout, self.training,
+                       self.feed_forward.w_2.bias, l2)
         return x, {'slf_attn_weights': None}
 
     def inference(self, x, mask, pos=None, cache=None):
@@ -442,14 +444,15 @@ class TransformerDecoderLayer(nn.Module):
     def forward(self, tgt, tgt_mask, memory, memory_mask, pos=None):
         """tgt_mask: the causal [B,L,L] tril mask of decoder/utils.py:7-11, or None meaning causal."""
         p, tr = self.residual_dropout, self.training
+        l1, l2, l3 = ops.new_link(), ops.new_link(), ops.new_link()
         if tgt_mask is None:
-            attn, _ = self.slf_attn(tgt, None, causal=True, defer_bias=True)
+            attn, _ = self.slf_attn(tgt, None, causal=True, defer_bias=True, link=l1)
         else:
-            attn, _ = self.slf_attn(tgt, tgt_mask, defer_bias=True)
-        x = _post_norm(self.norm1, tgt, attn, p, tr, self.slf_attn.output_proj.bias)
-        src, _ = self.src_attn(x, memory, memory_mask, defer_bias=True)
-        x = _post_norm(self.norm2, x, src, p, tr, self.src_attn.output_proj.bias)
-        x = _post_norm(self.norm3, x, self.feed_forward(x, defer_bias=True), p, tr, self.feed_forward.w_2.bias)
+            attn, _ = self.slf_attn(tgt, tgt_mask, defer_bias=True, link=l1)
+        x = _post_norm(self.norm1, tgt, attn, p, tr, self.slf_attn.output_proj.bias, l1)
+        src, _ = self.src_attn(x, memory, memory_mask, defer_bias=True, link=l2)
+        x = _post_norm(self.norm2, x, src, p, tr, self.src_attn.output_proj.bias, l2)
+        x = _post_norm(self.norm3, x, self.feed_forward(x, defer_bias=True, link=l3), p, tr, self.feed_forward.w_2.bias, l3)
         return x, {'slf_attn_weights': None, 'src_attn_weights': None}
 
 

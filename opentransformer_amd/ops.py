@@ -175,21 +175,42 @@ def _linear_desc(M, N, K, xdt, wdt, ydt, ldx, ldw, ldy, act=L.ACT_NONE, accumula
     return L.LinearDesc(M, N, K, _code(xdt), _code(wdt), _code(ydt), _compute_code(), ldx, ldw, ldy, act, accumulate)
 
 
-def linear_fwd_raw(x2, w, b, out_dtype, act=L.ACT_NONE):
+class ResidualLink:
+    """Pairs the first Linear of a residual branch with the add+LayerNorm that closes it: y = LN(x + f(x)).
+    x receives two gradients, one through the skip connection (written by the LayerNorm backward) and one through
+    f's first Linear; autograd would add them with an extra elementwise kernel per sub-layer.  With a link the
+    LayerNorm backward hands its dx over instead of returning it, and the Linear's input-gradient GEMM accumulates
+    into that buffer in its epilogue and returns the sum.  (The Linear's backward always runs after the LayerNorm's:
+    it depends on it through f.)"""
+    __slots__ = ('armed', 'buf')
+
+    def __init__(self):
+        self.armed = False
+        self.buf = None
+
+
+def new_link():
+    return ResidualLink() if torch.is_grad_enabled() else None
+
+
+def linear_fwd_raw(x2, w, b, out_dtype, act=L.ACT_NONE, out=None):
+    """y = act(x w^T + b); with `out` the product is ACCUMULATED into that [M,N] buffer."""
     M, K = x2.shape
     N = w.shape[0]
-    y = torch.empty((M, N), dtype=out_dtype, device=x2.device)
-    d = _linear_desc(M, N, K, x2.dtype, w.dtype, out_dtype, x2.stride(0), w.stride(0), N, act)
+    y = out if out is not None else torch.empty((M, N), dtype=out_dtype, device=x2.device)
+    d = _linear_desc(M, N, K, x2.dtype, w.dtype, y.dtype, x2.stride(0), w.stride(0), y.stride(0), act,
+                     accumulate=int(out is not None))
     ws = _workspace(x2.device)
     L.check(L.load().otr_linear_fwd(C.byref(d), _p(x2), _p(w), _p(b), _p(y), _p(ws), _WS_BYTES, _stream()), 'otr_linear_fwd')
     return y
 
 
-def linear_dgrad_raw(dy2, w, dx_dtype):
+def linear_dgrad_raw(dy2, w, dx_dtype, out=None):
     M, N = dy2.shape
     K = w.shape[1]
-    dx = torch.empty((M, K), dtype=dx_dtype, device=dy2.device)
-    d = _linear_desc(M, N, K, dx_dtype, w.dtype, dy2.dtype, K, w.stride(0), dy2.stride(0))
+    dx = out if out is not None else torch.empty((M, K), dtype=dx_dtype, device=dy2.device)
+    d = _linear_desc(M, N, K, dx.dtype, w.dtype, dy2.dtype, dx.stride(0), w.stride(0), dy2.stride(0),
+                     accumulate=int(out is not None))
     ws = _workspace(dy2.device)
     L.check(L.load().otr_linear_dgrad(C.byref(d), _p(dy2), _p(w), _p(dx), _p(ws), _WS_BYTES, _stream()), 'otr_linear_dgrad')
     return dx
@@ -292,9 +313,12 @@ class LinearFn(torch.autograd.Function):
     channel-last flatten of the conv frontend, frontend/conv.py:145); dw is regrouped back."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu, out_dtype, perm, defer_bias=False):
+    def forward(ctx, x, w, b, relu, out_dtype, perm, defer_bias=False, link=None):
         _cuda(x, w, b)
         ctx.defer_bias = defer_bias      # the consumer (AddLayerNormFn, a_bias=b) produces the bias gradient
+        ctx.link = link
+        if link is not None:             # see ResidualLink
+            link.armed = bool(ctx.needs_input_grad[0]) and x.dtype == torch.float32 and perm is None and not relu
         xc = lp_of(x)
         x2 = _rows(xc if xc is not None else x)
         wl = weight_lp(w)
@@ -320,10 +344,13 @@ class LinearFn(torch.autograd.Function):
             dy2 = relu_bwd_raw(y, dy2.contiguous())
         dx = None
         if ctx.needs_input_grad[0]:
+            skip = None
+            if ctx.link is not None and ctx.link.buf is not None:      # skip-connection gradient handed over by the LN
+                skip, ctx.link.buf = ctx.link.buf, None
             if ctx.wt is not None:      # dx = dy . w as a forward-type GEMM on the transposed shadow
-                dx = linear_fwd_raw(dy2, ctx.wt, None, ctx.xdtype).view(ctx.xshape)
+                dx = linear_fwd_raw(dy2, ctx.wt, None, ctx.xdtype, out=skip).view(ctx.xshape)
             else:
-                dx = linear_dgrad_raw(dy2, wc, ctx.xdtype).view(ctx.xshape)
+                dx = linear_dgrad_raw(dy2, wc, ctx.xdtype, out=skip).view(ctx.xshape)
         dw = None
         if ctx.needs_input_grad[1]:
             gt = grad_target(ctx.w_ref) if ctx.perm is None else None
@@ -341,13 +368,13 @@ class LinearFn(torch.autograd.Function):
                 colsum_raw(dy2, out=gt)
             else:
                 db = colsum_raw(dy2)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def linear(x, w, b=None, relu=False, out_dtype=None, perm=None, defer_bias=False):
+def linear(x, w, b=None, relu=False, out_dtype=None, perm=None, defer_bias=False, link=None):
     """defer_bias=True: the caller hands `b` to add_layernorm(..., a_bias=b), whose backward reduces the bias
     gradient in the same pass that produces the branch gradient."""
-    return LinearFn.apply(x, w, b, relu, out_dtype if out_dtype is not None else torch.float32, perm, defer_bias)
+    return LinearFn.apply(x, w, b, relu, out_dtype if out_dtype is not None else torch.float32, perm, defer_bias, link)
 
 
 def relu_bwd_raw(y, g):
@@ -453,8 +480,9 @@ class AddLayerNormFn(torch.autograd.Function):
     """y = LayerNorm(x + dropout(a)) (post-norm residual: encoder/transformer.py:54-56,61-63)."""
 
     @staticmethod
-    def forward(ctx, x, a, gamma, beta, p_drop, eps, a_bias=None):
+    def forward(ctx, x, a, gamma, beta, p_drop, eps, a_bias=None, link=None):
         _cuda(x, a, gamma, beta)
+        ctx.link = link
         ctx.set_materialize_grads(False)      # no zero-filled bf16 'gradient' for the non-differentiable twin
         ctx.ab_ref = a_bias
         d = x.shape[-1]
@@ -485,7 +513,7 @@ class AddLayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dylp=None):
         if dy is None:
-            return (None,) * 7
+            return (None,) * 8
         z, mean, rstd, gamma, seed = ctx.saved_tensors
         M, d, adt, eps, p_drop, off, xshape, ashape = ctx.cfg
         dy2 = dy.reshape(-1, d).contiguous()
@@ -505,14 +533,18 @@ class AddLayerNormFn(torch.autograd.Function):
         L.check(L.load().otr_add_layernorm_bwd(C.byref(desc), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed),
                                                _p(dx), _p(da), _p(gg), _p(gb), _p(gab), _stream()),
                 'otr_add_layernorm_bwd')
-        return (dx.view(xshape), (da.view(ashape) if da is not None else None),
-                None if inplace else gg, None if inplace else gb, None, None, dab)
+        dx_ret = dx.view(xshape)
+        if ctx.link is not None and ctx.link.armed and ctx.needs_input_grad[0]:
+            ctx.link.buf = dx           # the branch's first Linear adds its input gradient into this and returns the sum
+            dx_ret = None
+        return (dx_ret, (da.view(ashape) if da is not None else None),
+                None if inplace else gg, None if inplace else gb, None, None, dab, None)
 
 
-def add_layernorm(x, a, gamma, beta, p_drop=0.0, eps=1e-5, a_bias=None):
+def add_layernorm(x, a, gamma, beta, p_drop=0.0, eps=1e-5, a_bias=None, link=None):
     """a_bias: the bias parameter of the Linear that produced `a` (called with defer_bias=True); its gradient
     (column sums of d loss / d a) is then reduced inside the LayerNorm backward kernel."""
-    y, ylp = AddLayerNormFn.apply(x, a, gamma, beta, float(p_drop), float(eps), a_bias)
+    y, ylp = AddLayerNormFn.apply(x, a, gamma, beta, float(p_drop), float(eps), a_bias, link)
     return attach_lp(y, ylp)
 
 
@@ -522,9 +554,12 @@ class FeedForwardGLUFn(torch.autograd.Function):
     (GEMM, GLU, GEMM); backward fuses the w_1 bias gradient into the GLU-backward kernel."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, defer_b2=False, out_dtype=torch.float32):
+    def forward(ctx, x, w1, b1, w2, b2, defer_b2=False, out_dtype=torch.float32, link=None):
         _cuda(x, w1, w2)
         ctx.defer_b2 = defer_b2          # see linear(defer_bias=True)
+        ctx.link = link
+        if link is not None:
+            link.armed = bool(ctx.needs_input_grad[0]) and x.dtype == torch.float32
         ctx.refs = (w1, b1, w2, b2)
         xc = lp_of(x)
         x2 = _rows(xc if xc is not None else x)
@@ -584,13 +619,16 @@ class FeedForwardGLUFn(torch.autograd.Function):
             L.check(L.load().otr_glu_bwd(_p(h), _p(du), _p(dh), _p(part), _code(h.dtype), M, F, None, int(ctx.h_sig), _stream()),
                     'otr_glu_bwd')
         db1 = colsum_raw(part, out=gb1)
+        skip = None
+        if ctx.link is not None and ctx.link.buf is not None:
+            skip, ctx.link.buf = ctx.link.buf, None
         if ctx.w1t is not None:
-            dx = linear_fwd_raw(dh, ctx.w1t, None, ctx.xdtype).view(ctx.xshape)
+            dx = linear_fwd_raw(dh, ctx.w1t, None, ctx.xdtype, out=skip).view(ctx.xshape)
         else:
-            dx = linear_dgrad_raw(dh, w1, ctx.xdtype).view(ctx.xshape)
+            dx = linear_dgrad_raw(dh, w1, ctx.xdtype, out=skip).view(ctx.xshape)
         dw1 = linear_wgrad_raw(dh, x2, w1, out=gw1)
         return (dx, None if gw1 is not None else dw1, None if gb1 is not None else db1,
-                None if gw2 is not None else dw2, None if (gb2 is not None or ctx.defer_b2) else db2, None, None)
+                None if gw2 is not None else dw2, None if (gb2 is not None or ctx.defer_b2) else db2, None, None, None)
 
 
 GLU_RPB = 32        # rows per workgroup of otr_glu_bwd (csrc/elementwise.hip)
