@@ -162,100 +162,134 @@ struct DwArgs {
   int B, T, C, k;
 };
 
+// Thread layout of the depthwise-conv kernels: 256 threads = DW_NY row phases x (C/4 <= 256/DW_NY) channel groups;
+// a workgroup owns DW_RPB consecutive rows, thread (ty, cg) walks rows ty, ty+NY, ...  All loads are unconditional
+// (time index clamped into the utterance, contribution masked); the per-channel sums are reduced through LDS so each
+// workgroup issues one set of atomics.  (The first version: 16-row strips, 96 active threads, every tap load behind
+// its own bounds branch, 498 x 2304 atomics: 271 us for the backward at C=384.)
+constexpr int DW_RPB = 64;
+// KT = compile-time tap count (3 / 5 / 7: the smallest >= k), so only real taps are loaded
+
 // y[b,t,c] = bias[c] + sum_j w[c,j] * g[b, t + j - pad, c]   (zero padded in time, per utterance)
 // stats[c] += sum y, stats[C + c] += sum y^2   over ALL B*T positions (the reference's BatchNorm1d sees padded frames)
-template <class T> __global__ __launch_bounds__(CF_BLOCK) void dwconv_fwd_kernel(DwArgs p) {
+template <class T, int KT> __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwArgs p, int NY) {
+  extern __shared__ float dw_red[];                       // [NY][C][2]
   const int C4 = p.C / 4, pad = (p.k - 1) / 2;
   const int64_t M = (int64_t)p.B * p.T;
-  const int64_t r0 = (int64_t)blockIdx.x * CF_RPB, r1 = min(M, r0 + CF_RPB);
+  const int64_t r0 = (int64_t)blockIdx.x * DW_RPB, r1 = min(M, r0 + DW_RPB);
   const T* g = reinterpret_cast<const T*>(p.g);
-  for (int cg = threadIdx.x; cg < C4; cg += CF_BLOCK) {
-    const int c = cg * 4;
-    float w[4][8], bias[4] = {0.f, 0.f, 0.f, 0.f};
+  const int cg = threadIdx.x % C4, ty = threadIdx.x / C4;
+  const bool active = ty < NY;
+  const int c = cg * 4;
+  float w[4][KT], bias[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (p.b) bias[e] = p.b[c + e];
+  for (int e = 0; e < 4; ++e) {
+    if (p.b) bias[e] = p.b[c + e];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) w[e][j] = (j < p.k) ? p.w[(c + e) * p.k + j] : 0.f;
-    }
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t row = r0; row < r1; ++row) {
-      int t = (int)(row % p.T);
+    for (int j = 0; j < KT; ++j) w[e][j] = (j < p.k) ? p.w[(c + e) * p.k + j] : 0.f;
+  }
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    for (int64_t row = r0 + ty; row < r1; row += NY) {
+      const int t = (int)(row % p.T);
       float acc[4] = {bias[0], bias[1], bias[2], bias[3]};
+      float gv[KT][4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (j >= p.k) break;
-        int tt = t + j - pad;
-        if (tt < 0 || tt >= p.T) continue;
-        float gv[4];
-        ldc4<T>(g + (row + (j - pad)) * p.C + c, gv);
+      for (int j = 0; j < KT; ++j) {
+        const int tt = min(max(t + j - pad, 0), p.T - 1);    // clamped inside the utterance (tap masked below)
+        ldc4<T>(g + (row - t + tt) * p.C + c, gv[j]);
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fmaf(w[e][j], gv[e], acc[e]);
+      for (int j = 0; j < KT; ++j) {
+        const int tt = t + j - pad;
+        const float m = (j < p.k && tt >= 0 && tt < p.T) ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(w[e][j] * m, gv[j][e], acc[e]);
       }
       stc4<float>(p.y + row * p.C + c, acc);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s1[e] += acc[e]; s2[e] += acc[e] * acc[e]; }
     }
-    if (p.stats) {
+  }
+  if (p.stats) {
+    if (active) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { atomicAdd(p.stats + c + e, s1[e]); atomicAdd(p.stats + p.C + c + e, s2[e]); }
+      for (int e = 0; e < 4; ++e) { dw_red[(ty * p.C + c + e) * 2] = s1[e]; dw_red[(ty * p.C + c + e) * 2 + 1] = s2[e]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * p.C; i += 256) {
+      const int ch = i >> 1, which = i & 1;
+      float a = 0.f;
+      for (int y = 0; y < NY; ++y) a += dw_red[(y * p.C + ch) * 2 + which];
+      atomicAdd(p.stats + which * p.C + ch, a);
     }
   }
 }
 
 // dg[b,t,c] = sum_j w[c,j] * dy[b, t - j + pad, c];  dw[c,j] += sum dy[b,t,c] g[b,t+j-pad,c];  db[c] += sum dy
-template <class T> __global__ __launch_bounds__(CF_BLOCK) void dwconv_bwd_kernel(DwArgs p) {
-  const int C4 = p.C / 4, pad = (p.k - 1) / 2;
+template <class T, int KT> __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwArgs p, int NY) {
+  extern __shared__ float dw_red[];                       // [NY][C][k+1]
+  const int C4 = p.C / 4, pad = (p.k - 1) / 2, K1 = p.k + 1;
   const int64_t M = (int64_t)p.B * p.T;
-  const int64_t r0 = (int64_t)blockIdx.x * CF_RPB, r1 = min(M, r0 + CF_RPB);
+  const int64_t r0 = (int64_t)blockIdx.x * DW_RPB, r1 = min(M, r0 + DW_RPB);
   const T* g = reinterpret_cast<const T*>(p.g);
   T* dg = reinterpret_cast<T*>(p.dg);
-  for (int cg = threadIdx.x; cg < C4; cg += CF_BLOCK) {
-    const int c = cg * 4;
-    float w[4][8], dw[4][8], db[4] = {0.f, 0.f, 0.f, 0.f};
+  const int cg = threadIdx.x % C4, ty = threadIdx.x / C4;
+  const bool active = ty < NY;
+  const int c = cg * 4;
+  float w[4][KT], dw[4][KT], db[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+  for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { w[e][j] = (j < p.k) ? p.w[(c + e) * p.k + j] : 0.f; dw[e][j] = 0.f; }
-    for (int64_t row = r0; row < r1; ++row) {
-      int t = (int)(row % p.T);
+    for (int j = 0; j < KT; ++j) { w[e][j] = (j < p.k) ? p.w[(c + e) * p.k + j] : 0.f; dw[e][j] = 0.f; }
+  if (active) {
+    for (int64_t row = r0 + ty; row < r1; row += NY) {
+      const int t = (int)(row % p.T);
       float dyv[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+      float gv[KT][4], yv[KT][4];
       ldc4<float>(p.dy + row * p.C + c, dyv);
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        const int tg = min(max(t + j - pad, 0), p.T - 1), tyy = min(max(t - j + pad, 0), p.T - 1);
+        ldc4<T>(g + (row - t + tg) * p.C + c, gv[j]);
+        ldc4<float>(p.dy + (row - t + tyy) * p.C + c, yv[j]);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) db[e] += dyv[e];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (j >= p.k) break;
-        int tg = t + j - pad;                       // forward tap: y[t] used g[t + j - pad]
-        if (tg >= 0 && tg < p.T) {
-          float gv[4];
-          ldc4<T>(g + (row + (j - pad)) * p.C + c, gv);
+      for (int j = 0; j < KT; ++j) {
+        const int tg = t + j - pad, tyy = t - j + pad;
+        const float mg = (j < p.k && tg >= 0 && tg < p.T) ? 1.f : 0.f;       // forward tap: y[t] used g[t + j - pad]
+        const float my = (j < p.k && tyy >= 0 && tyy < p.T) ? 1.f : 0.f;     // dg[t] collects dy[t - j + pad] * w[j]
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dw[e][j] = fmaf(dyv[e], gv[e], dw[e][j]);
-        }
-        int ty = t - j + pad;                       // dg[t] collects dy[t - j + pad] * w[j]
-        if (ty >= 0 && ty < p.T) {
-          float yv[4];
-          ldc4<float>(p.dy + (row - (j - pad)) * p.C + c, yv);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] = fmaf(w[e][j], yv[e], acc[e]);
+        for (int e = 0; e < 4; ++e) {
+          dw[e][j] = fmaf(dyv[e] * mg, gv[j][e], dw[e][j]);
+          acc[e] = fmaf(w[e][j] * my, yv[j][e], acc[e]);
         }
       }
       stc4<T>(dg + row * p.C + c, acc);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (p.db) atomicAdd(p.db + c + e, db[e]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (j < p.k) atomicAdd(p.dw + (c + e) * p.k + j, dw[e][j]);
+      for (int j = 0; j < KT; ++j)
+        if (j < p.k) dw_red[(ty * p.C + c + e) * K1 + j] = dw[e][j];
+      dw_red[(ty * p.C + c + e) * K1 + p.k] = db[e];
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < p.C * K1; i += 256) {
+    float a = 0.f;
+    for (int y = 0; y < NY; ++y) a += dw_red[y * p.C * K1 + i];
+    const int ch = i / K1, j = i - ch * K1;
+    if (j < p.k) atomicAdd(p.dw + ch * p.k + j, a);
+    else if (p.db) atomicAdd(p.db + ch, a);
   }
 }
 
 static int32_t dw_check(int B, int T, int C, int k) {
-  OTR_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0, "dwconv: bad shape B=%d T=%d C=%d", B, T, C);
-  OTR_REQUIRE(k >= 1 && k <= 8 && (k & 1), "dwconv: kernel size %d must be odd and <= 7", k);
+  OTR_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 1024, "dwconv: bad shape B=%d T=%d C=%d (C % 4 == 0, C <= 1024)", B, T, C);
+  OTR_REQUIRE(k >= 1 && k <= 7 && (k & 1), "dwconv: kernel size %d must be odd and <= 7", k);
   return 0;
 }
 extern "C" int32_t otr_dwconv_fwd(const void* g, int32_t dtype, const float* w, const float* bias, float* y, float* stats,
@@ -265,8 +299,15 @@ extern "C" int32_t otr_dwconv_fwd(const void* g, int32_t dtype, const float* w, 
   DwArgs p{}; p.g = g; p.w = w; p.b = bias; p.y = y; p.stats = stats; p.B = B; p.T = T; p.C = C; p.k = k;
   hipStream_t s = (hipStream_t)stream;
   if (stats) otr_zero_f32(stats, 2 * C, s);
-  if (dtype == OTR_F32) hipLaunchKernelGGL(dwconv_fwd_kernel<float>, strip_grid((int64_t)B * T), dim3(CF_BLOCK), 0, s, p);
-  else hipLaunchKernelGGL(dwconv_fwd_kernel<bf16_t>, strip_grid((int64_t)B * T), dim3(CF_BLOCK), 0, s, p);
+  const int NY = 256 / (C / 4);
+  const dim3 grid((unsigned)(((int64_t)B * T + DW_RPB - 1) / DW_RPB));
+  const size_t lds = (size_t)NY * C * 2 * sizeof(float);
+#define DW_LAUNCH(KERNEL, KT)                                                                              \
+  {                                                                                                         \
+    if (dtype == OTR_F32) hipLaunchKernelGGL((KERNEL<float, KT>), grid, dim3(256), lds, s, p, NY);          \
+    else hipLaunchKernelGGL((KERNEL<bf16_t, KT>), grid, dim3(256), lds, s, p, NY);                          \
+  }
+  if (k <= 3) DW_LAUNCH(dwconv_fwd_kernel, 3) else if (k <= 5) DW_LAUNCH(dwconv_fwd_kernel, 5) else DW_LAUNCH(dwconv_fwd_kernel, 7)
   return otr_check_launch("dwconv_fwd");
 }
 extern "C" int32_t otr_dwconv_bwd(const float* dy, const void* g, int32_t dtype, const float* w, void* dg, float* dw, float* db,
@@ -275,8 +316,11 @@ extern "C" int32_t otr_dwconv_bwd(const float* dy, const void* g, int32_t dtype,
   OTR_REQUIRE(dy && g && w && dg && dw, "dwconv_bwd: null pointer");
   DwArgs p{}; p.dy = dy; p.g = g; p.w = w; p.dg = dg; p.dw = dw; p.db = db; p.B = B; p.T = T; p.C = C; p.k = k;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == OTR_F32) hipLaunchKernelGGL(dwconv_bwd_kernel<float>, strip_grid((int64_t)B * T), dim3(CF_BLOCK), 0, s, p);
-  else hipLaunchKernelGGL(dwconv_bwd_kernel<bf16_t>, strip_grid((int64_t)B * T), dim3(CF_BLOCK), 0, s, p);
+  const int NY = 256 / (C / 4);
+  const dim3 grid((unsigned)(((int64_t)B * T + DW_RPB - 1) / DW_RPB));
+  const size_t lds = (size_t)NY * C * (k + 1) * sizeof(float);
+  if (k <= 3) DW_LAUNCH(dwconv_bwd_kernel, 3) else if (k <= 5) DW_LAUNCH(dwconv_bwd_kernel, 5) else DW_LAUNCH(dwconv_bwd_kernel, 7)
+#undef DW_LAUNCH
   return otr_check_launch("dwconv_bwd");
 }
 

@@ -939,6 +939,8 @@ class ConformerConvFn(torch.autograd.Function):
         xc = lp_of(x)
         x2 = _rows(xc if xc is not None else x)
         w1l, w2l = weight_lp(w1), weight_lp(w2)
+        ctx.refs = (w1, b1, w2, b2)                    # in-place / deferred weight gradients (grad_target)
+        ctx.w1t, ctx.w2t = weight_lpt(w1), weight_lpt(w2)
         w1c = w1l if w1l is not None else w1
         w2c = w2l if w2l is not None else w2
         h = linear_fwd_raw(x2, w1c, b1, adt)                                            # [M, 2C]
@@ -970,9 +972,11 @@ class ConformerConvFn(torch.autograd.Function):
         lib = L.load()
         dm = torch.empty((M, Cc), dtype=torch.float32, device=dout.device)
         L.check(lib.otr_row_mask(_p(dout.contiguous()), _p(mask_u8), _p(dm), M, Cc, _stream()), 'otr_row_mask')
-        ds = linear_dgrad_raw(dm, w2c, adt)
-        dw2 = linear_wgrad_raw(dm, s, w2c)
-        db2 = colsum_raw(dm)
+        w1p, b1p, w2p, b2p = ctx.refs
+        gw1, gb1, gw2, gb2 = grad_target(w1p), grad_target(b1p), grad_target(w2p), grad_target(b2p)
+        ds = linear_fwd_raw(dm, ctx.w2t, None, adt) if ctx.w2t is not None else linear_dgrad_raw(dm, w2c, adt)
+        dw2 = linear_wgrad_raw(dm, s, w2c, out=gw2)
+        db2 = colsum_raw(dm, out=gb2) if b2p is not None else None
         red = torch.empty((2 * Cc,), dtype=torch.float32, device=dout.device)
         dy = torch.empty((M, Cc), dtype=torch.float32, device=dout.device)
         L.check(lib.otr_bn_swish_bwd(_p(y), _p(ds), _code(adt), _p(saved), _p(gamma), _p(beta), _p(red), _p(dy), M, Cc,
@@ -985,11 +989,12 @@ class ConformerConvFn(torch.autograd.Function):
         nblk = (M + GLU_RPB - 1) // GLU_RPB
         part = torch.empty((nblk, 2 * Cc), dtype=torch.float32, device=dout.device)
         L.check(lib.otr_glu_bwd(_p(h), _p(dg), _p(dh), _p(part), _code(adt), M, Cc, _p(mask_u8), 0, _stream()), 'otr_glu_bwd')
-        db1 = colsum_raw(part)
-        dx = linear_dgrad_raw(dh, w1c, xdtype).view(xshape)
-        dw1 = linear_wgrad_raw(dh, x2, w1c)
-        return (dx, None, dw1, db1, dwk[:Cc * k].view(wdw_shape), dwk[Cc * k:] if has_dwb else None, red[Cc:], red[:Cc],
-                None, None, dw2, db2, None, None, None)
+        db1 = colsum_raw(part, out=gb1) if b1p is not None else None
+        dx = (linear_fwd_raw(dh, ctx.w1t, None, xdtype) if ctx.w1t is not None else linear_dgrad_raw(dh, w1c, xdtype)).view(xshape)
+        dw1 = linear_wgrad_raw(dh, x2, w1c, out=gw1)
+        return (dx, None, None if gw1 is not None else dw1, None if gb1 is not None else db1, dwk[:Cc * k].view(wdw_shape),
+                dwk[Cc * k:] if has_dwb else None, red[Cc:], red[:Cc], None, None, None if gw2 is not None else dw2,
+                None if gb2 is not None else db2, None, None, None)
 
 
 # ---------------------------------------------------------------------------------------- losses
