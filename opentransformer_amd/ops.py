@@ -876,30 +876,37 @@ class RelPosAttentionFn(torch.autograd.Function):
         qkv = qkv.contiguous()
         pe = pos_emb.reshape(P, d).contiguous()
         wl = weight_lp(pos_w)
-        p = linear_fwd_raw(pe, wl if wl is not None else pos_w, None, adt)                  # [P, d]
+        # the relative-position axis (2T-1, odd) is padded to a multiple of 8 everywhere: every per-head GEMM then has
+        # 16-byte aligned operands / outputs and whole contraction chunks, i.e. takes the fast kernels (the unpadded
+        # layout ran the generic bounds-checked ones: 96 launches of 33-42 us per step)
+        Pp = (P + 7) // 8 * 8
+        p = torch.zeros((Pp, d), dtype=adt, device=qkv.device)
+        p[:P].copy_(linear_fwd_raw(pe, wl if wl is not None else pos_w, None, adt))         # [P, d] (+ zero rows)
+        pt = p.t().contiguous()                                                             # [d, Pp]: dgrad as a forward GEMM
         u, v = posu.reshape(d).contiguous(), posv.reshape(d).contiguous()
         quv = torch.empty((B, T, 2 * d), dtype=adt, device=qkv.device)
         lib = L.load()
         L.check(lib.otr_head_bias_add(_p(qkv), d3, _p(u), _p(v), _p(quv), _code(adt), M, d, _stream()), 'otr_head_bias_add')
-        bd = torch.empty((B, T, H, P), dtype=torch.float32, device=qkv.device)
+        bd = torch.empty((B, T, H, Pp), dtype=torch.float32, device=qkv.device)
         for h in range(H):
-            _gemm_ptr('fwd', M, P, dk, (quv, d + h * dk, 2 * d), (p, h * dk, d), (bd, h * P, H * P))
+            _gemm_ptr('fwd', M, Pp, dk, (quv, d + h * dk, 2 * d), (p, h * dk, d), (bd, h * Pp, H * Pp))
         out = torch.empty((B, T, d), dtype=adt, device=qkv.device)
         lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
         desc = _attn_desc(B, H, T, T, dk, adt, (T * 2 * d, 2 * d), (T * d3, d3), (T * d3, d3), (T * d, d), False)
         L.check(lib.otr_attention_bias_fwd(C.byref(desc), _p(quv), _p(qkv, d), _p(qkv, 2 * d), _p(key_mask_u8), _p(bd),
-                                           T * H * P, P, H * P, 1, _p(out), _p(lse), _stream()), 'otr_attention_bias_fwd')
-        ctx.save_for_backward(qkv, quv, p, pe, bd, out, lse, key_mask_u8, pos_w)
+                                           T * H * Pp, Pp, H * Pp, 1, _p(out), _p(lse), _stream()), 'otr_attention_bias_fwd')
+        ctx.save_for_backward(qkv, quv, pt, pe, bd, out, lse, key_mask_u8, pos_w)
         ctx.H = H
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, quv, p, pe, bd, out, lse, km, pos_w = ctx.saved_tensors
+        qkv, quv, pt, pe, bd, out, lse, km, pos_w = ctx.saved_tensors
         H = ctx.H
         B, T, d3 = qkv.shape
         d = d3 // 3
         dk, P, M = d // H, 2 * T - 1, B * T
+        Pp = pt.shape[1]
         adt = qkv.dtype
         lib = L.load()
         dout = dout.contiguous()
@@ -909,18 +916,19 @@ class RelPosAttentionFn(torch.autograd.Function):
         delta = torch.empty_like(lse)
         desc = _attn_desc(B, H, T, T, dk, adt, (T * 2 * d, 2 * d), (T * d3, d3), (T * d3, d3), (T * d, d), False)
         L.check(lib.otr_attention_bias_bwd(C.byref(desc), _p(quv), _p(qkv, d), _p(qkv, 2 * d), _p(km), _p(bd), _p(dbd),
-                                           T * H * P, P, H * P, 1, _p(out), _p(dout), _p(lse), _p(delta), _p(dquv),
+                                           T * H * Pp, Pp, H * Pp, 1, _p(out), _p(dout), _p(lse), _p(delta), _p(dquv),
                                            _p(dqkv, d), _p(dqkv, 2 * d), _stream()), 'otr_attention_bias_bwd')
-        dp = torch.empty((P, d), dtype=torch.float32, device=qkv.device)
+        dp = torch.empty((Pp, d), dtype=torch.float32, device=qkv.device)
         for h in range(H):
-            _gemm_ptr('dgrad', M, P, dk, (dquv, d + h * dk, 2 * d), (p, h * dk, d), (dbd, h * P, H * P))
-            _gemm_ptr('wgrad', M, P, dk, (quv, d + h * dk, 2 * d), (dp, h * dk, d), (dbd, h * P, H * P))
+            # d(q+v)_h = dbd_h . p_h  as a forward-type GEMM on the transposed p (contraction over the padded axis)
+            _gemm_ptr('fwd', M, dk, Pp, (dbd, h * Pp, H * Pp), (pt, h * dk * Pp, Pp), (dquv, d + h * dk, 2 * d))
+            _gemm_ptr('wgrad', M, Pp, dk, (quv, d + h * dk, 2 * d), (dp, h * dk, d), (dbd, h * Pp, H * Pp))
         L.check(lib.otr_add2_strided(_p(dquv), 2 * d, _p(dquv, d), 2 * d, _p(dqkv), d3, _code(adt), M, d, _stream()),
                 'otr_add2_strided')
         dq2 = dquv.view(M, 2 * d)
         du = colsum_raw(dq2[:, :d])
         dv = colsum_raw(dq2[:, d:])
-        dw = linear_wgrad_raw(dp, pe, pos_w)
+        dw = linear_wgrad_raw(dp[:P], pe, pos_w)
         return dqkv, None, dw, du.view(1, 1, H, dk), dv.view(1, 1, H, dk), None, None
 
 
