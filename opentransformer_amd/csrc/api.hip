@@ -258,6 +258,7 @@ static int32_t conv_geom(const otr_conv_desc_t* d, ConvGeom& g) {
   g.divF2 = make_fastdiv((uint32_t)d->F2);
   g.divT2 = make_fastdiv((uint32_t)d->T2);
   g.divC1 = make_fastdiv((uint32_t)d->C1);
+  g.a1_elems = (int64_t)d->B * d->T1 * d->F1 * d->C1;
   return 0;
 }
 

@@ -30,6 +30,7 @@ enum { MODE_KC = 0, MODE_MC = 1, MODE_IM2K = 2, MODE_IM2M = 3 };
 struct ConvGeom {
   int T1, F1, C1, T2, F2;
   FastDiv divF2, divT2, divC1;
+  int64_t a1_elems;   // elements of act1 (clamp range of the unconditional im2col loads)
 };
 
 constexpr int OTR_ACT_GLU_BWD = 2;   // internal epilogue mode (otr_ffn_glu_bwd)
@@ -122,8 +123,11 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
   // loads of 4 rows per contraction index, transposed at LDS-store time with v_perm_b32 (one per output dword)
   // instead of a bf16 -> f32 unpack + re-pack of every element
   static constexpr bool RAWT = (MODE == MODE_MC) && FAST && std::is_same<ST, CT>::value && sizeof(CT) == 2;
+  // implicit-im2col rows (conv2 weight gradient) the same way: (pixel, tap) -> 4 channels per 8-byte load, validity of
+  // the frequency tap kept as one bit per contraction index and applied with the transposition
+  static constexpr bool RAWI = (MODE == MODE_IM2M) && FAST && std::is_same<ST, CT>::value && sizeof(CT) == 2;
   // prefetch ring: FAST raw loaders keep DEPTH stages in registers (a 3-slot ring spilled: 96 VGPRs + 64 accumulators)
-  static constexpr int DEPTH = ((RAWQ && FAST && MODE == MODE_KC) || RAWT) ? 2 : 1;
+  static constexpr int DEPTH = ((RAWQ && FAST && MODE == MODE_KC) || RAWT || RAWI) ? 2 : 1;
   // every thread owns a full set of units (true for all tile shapes instantiated): lets stores/loads drop the
   // per-unit activity test the compiler cannot fold (it does not know threadIdx.x < 256)
   static constexpr bool ALLACTIVE = ROWMAJOR ? ((ROWS * KCH) % 256 == 0) : ((RG * KCH) % 256 == 0);
@@ -135,9 +139,10 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
   // stage-invariant part of every unit's global address (k = 0), computed once in init()
   const ST* p0[ROWMAJOR ? NU : NP];
   bool rok[ROWMAJOR ? NU : NP];
-  float raw[(RAWQ || RAWT) ? 1 : (ROWMAJOR ? NU : NP * PM)][CE];
+  float raw[(RAWQ || RAWT || RAWI) ? 1 : (ROWMAJOR ? NU : NP * PM)][CE];
   uint4 rawq[RAWQ ? DEPTH : 1][RAWQ ? NU : 1];
-  uint2 rawt[RAWT ? DEPTH : 1][RAWT ? NP : 1][RAWT ? CE : 1];
+  uint2 rawt[(RAWT || RAWI) ? DEPTH : 1][(RAWT || RAWI) ? NP : 1][(RAWT || RAWI) ? CE : 1];
+  uint32_t vbits[RAWI ? DEPTH : 1][RAWI ? NP : 1];   // RAWI: bit j = contraction index j of the patch is a real (unpadded) tap
   // im2col state
   int64_t pix[ROWMAJOR ? NU : 1];
   int f2v[ROWMAJOR ? NU : 1];
@@ -185,6 +190,7 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
       for (int u = 0; u < NP; ++u) {
         int rg = (tid + 256 * u) % RG;
         int n0 = row0 + PM * rg;             // row index = tap*C1 + c1 (PM channels share a tap)
+        if constexpr (FAST) n0 = (n0 + PM <= nrows) ? n0 : 0;      // rows past the end: any valid tap (results unused)
         uint32_t tap = fdiv((uint32_t)n0, g.divC1);
         int ch = n0 - (int)tap * g.C1;
         int kh = (int)tap / 3, kw = (int)tap - kh * 3;
@@ -221,6 +227,23 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
         const ST* pj = p0[u] + (int64_t)kbc * ld;
 #pragma unroll
         for (int j = 0; j < CE; ++j, pj += ld) rawt[SLOT][u][j] = ld_global_b64(pj);
+      }
+    } else if constexpr (RAWI) {
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        const int kb = k0 + ((tid + 256 * u) / RG) * CE;          // K % CE == 0 (host): a chunk is valid as a whole
+        const int kbc = kb & (int)((uint32_t)0 - (uint32_t)(kb < K));
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < CE; ++j) {
+          int f2;
+          const int64_t pb = im2col_base(g, (uint32_t)(kbc + j), f2);
+          const int fin = 2 * f2 + tapkw[u] - 1;
+          bits |= (uint32_t)(fin >= 0 && fin < g.F1) << j;
+          const int64_t off = min(max(pb + tapoff[u], (int64_t)0), g.a1_elems - PM);   // padded taps read a valid address
+          rawt[SLOT][u][j] = ld_global_b64(base + off);
+        }
+        vbits[SLOT][u] = bits;
       }
     } else if constexpr (MODE == MODE_MC && FAST) {
 #pragma unroll
@@ -361,13 +384,22 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
           *reinterpret_cast<uint4*>(lds + row * G::ROWB + ((c ^ swz<KCH>(row)) << 4)) = q;
         }
       }
-    } else if constexpr (RAWT) {
+    } else if constexpr (RAWT || RAWI) {
 #pragma unroll
       for (int u = 0; u < NP; ++u) {
         const int id = tid + 256 * u, rg = id % RG, c = id / RG;
         if (ALLACTIVE || c < KCH) {
           const uint32_t m = (uint32_t)0 - (uint32_t)(k0 + c * CE < K);
-          const uint2* r = rawt[SLOT][u];
+          uint2 rr[CE];
+#pragma unroll
+          for (int j = 0; j < CE; ++j) {
+            rr[j] = rawt[SLOT][u][j];
+            if constexpr (RAWI) {                       // zero the padded frequency taps before the transposition
+              const uint32_t mj = (uint32_t)0 - ((vbits[SLOT][u] >> j) & 1u);
+              rr[j].x &= mj; rr[j].y &= mj;
+            }
+          }
+          const uint2* r = rr;
 #pragma unroll
           for (int i = 0; i < PM; ++i) {        // row i of the patch = 16-bit field i of every 8-byte load
             const uint32_t sel = (i & 1) ? 0x07060302u : 0x05040100u;
@@ -1014,9 +1046,12 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
   auto side_fast = [&](int mode, int vec, int rows) {
     if (mode == MODE_KC) return vec && (a.K % CE == 0) && rows > 0;
     if (mode == MODE_MC) return vec && (rows % PM == 0) && (a.K % CE == 0);
+    if (mode == MODE_IM2M)   // raw bf16 path only (same-type operands)
+      return sizeof(CT) == 2 && std::is_same<BT, CT>::value && vec && (rows % PM == 0) && (a.K % CE == 0) && (a.cg.C1 % PM == 0) &&
+             a.cg.a1_elems >= PM;
     return false;
   };
-  const bool fast = (AMODE == MODE_KC || AMODE == MODE_MC) && (BMODE == MODE_KC || BMODE == MODE_MC) &&
+  const bool fast = (AMODE == MODE_KC || AMODE == MODE_MC) && (BMODE == MODE_KC || BMODE == MODE_MC || BMODE == MODE_IM2M) &&
                     side_fast(AMODE, a.a_vec, a.M) && side_fast(BMODE, a.b_vec, a.N) && g_otr_force_generic == 0 &&
                     (a.ksplit > 1 ||          // split-K slabs go to the workspace; C is written by the reduce kernel
                      (((uintptr_t)a.C % 16 == 0) && (a.ldc % (16 / (int)sizeof(OT)) == 0) && !(a.accumulate && sizeof(OT) == 2)));
@@ -1049,7 +1084,7 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
     }
   }
   if constexpr (AMODE == MODE_KC || AMODE == MODE_MC) {
-    if constexpr (BMODE == MODE_KC || BMODE == MODE_MC) {
+    if constexpr (BMODE == MODE_KC || BMODE == MODE_MC || BMODE == MODE_IM2M) {
       if (fast && persist) {
         if constexpr (CAN_PERSIST) {
           if (big) hipLaunchKernelGGL((gemm_kernel<CT, AT, BT, OT, AMODE, BMODE, 128, 128, true, true>), grid, dim3(256), 0, s, a);
