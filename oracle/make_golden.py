@@ -204,6 +204,24 @@ def golden_decode(name, cfg):
     np.savez_compressed(os.path.join(OUT, name), **out)
 
 
+def golden_tools():
+    """tests/golden/tools_average.npz: the reference's own average_parameters (otrans/utils.py:46-102) on the toy
+    checkpoints of tests/test_tools.py:make_checkpoints."""
+    import tempfile
+    from otrans.utils import average_parameters
+    from tests.test_tools import make_checkpoints
+    with tempfile.TemporaryDirectory() as d:
+        make_checkpoints(d, 5)
+        out = average_parameters(d, N=3)
+        state = torch.load(out)
+    arrs = {}
+    for part in ('frontend', 'encoder', 'decoder'):
+        for k, v in state[part].items():
+            arrs['%s/%s' % (part, k)] = v.numpy()
+    np.savez(os.path.join(OUT, 'tools_average.npz'), **arrs)
+    print('tools_average.npz', sorted(arrs))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -231,4 +249,8 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'tools':
+        golden_tools()
+    else:
+        main()
+        golden_tools()
