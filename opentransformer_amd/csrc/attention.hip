@@ -392,27 +392,6 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
   }
 }
 
-// ================================================================================================ delta = rowsum(dO * O)
-template <class CT> __global__ void attn_delta_kernel(AttnArgs p, int dk) {
-  int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);  // (b,h,q) flattened
-  int sub = threadIdx.x & 15;
-  int64_t total = (int64_t)p.B * p.H * p.Tq;
-  float s = 0.f;
-  if (row < total) {
-    int q = (int)(row % p.Tq);
-    int64_t bh = row / p.Tq;
-    int h = (int)(bh % p.H), b = (int)(bh / p.H);
-    const CT* O = reinterpret_cast<const CT*>(p.o) + b * p.o_bs + (int64_t)q * p.o_ts + h * dk;
-    const CT* dO = reinterpret_cast<const CT*>(p.do_) + b * p.o_bs + (int64_t)q * p.o_ts + h * dk;
-    for (int d = sub; d < dk; d += 16) s += ElemIO<CT>::ld(O + d) * ElemIO<CT>::ld(dO + d);
-  }
-  s += __shfl_xor(s, 8);
-  s += __shfl_xor(s, 4);
-  s += __shfl_xor(s, 2);
-  s += __shfl_xor(s, 1);
-  if (row < total && sub == 0) p.delta[row] = s;
-}
-
 // ================================================================================================ dK, dV
 // wave owns 16 keys (columns); streams 64-query blocks.
 template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
@@ -575,13 +554,37 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
   const int qrow = q0 + lr;
   const bool q_ok = qrow < p.Tq;
   const float ls = q_ok ? p.lse[((int64_t)b * p.H + h) * p.Tq + qrow] * ExpDom<CT>::K : NEG_INF;
-  const float dl = q_ok ? p.delta[((int64_t)b * p.H + h) * p.Tq + qrow] : 0.f;
   const bool row_live = q_ok && ls != NEG_INF;
   const float lsf = row_live ? ls : 0.f;                // finite stand-in for the unpredicated fast path
 
   uint4 qf[C::KS], dof[C::KS];
   load_reg_frags<CT, DK>(qf, Q, p.q_ts, qrow, p.Tq, vec, lg);
   load_reg_frags<CT, DK>(dof, dO, p.o_ts, qrow, p.Tq, vec, lg);
+  // delta = rowsum(dO * O) of this wave's 16 queries, from the dO fragments already in registers (each lane group holds
+  // a quarter of the row); written out for the dK/dV kernel, which runs after this one (no separate delta launch)
+  float dl;
+  {
+    uint4 of[C::KS];
+    load_reg_frags<CT, DK>(of, reinterpret_cast<const CT*>(p.o) + b * p.o_bs + h * DK, p.o_ts, qrow, p.Tq, vec, lg);
+    float acc_d = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const uint32_t aw[4] = {dof[ks].x, dof[ks].y, dof[ks].z, dof[ks].w}, bw[4] = {of[ks].x, of[ks].y, of[ks].z, of[ks].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (sizeof(CT) == 4) {
+          acc_d += __uint_as_float(aw[e]) * __uint_as_float(bw[e]);
+        } else {
+          acc_d += __uint_as_float(aw[e] << 16) * __uint_as_float(bw[e] << 16);
+          acc_d += __uint_as_float(aw[e] & 0xffff0000u) * __uint_as_float(bw[e] & 0xffff0000u);
+        }
+      }
+    }
+    acc_d += __shfl_xor(acc_d, 16);
+    acc_d += __shfl_xor(acc_d, 32);
+    dl = q_ok ? acc_d : 0.f;
+    if (lg == 0 && q_ok) p.delta[((int64_t)b * p.H + h) * p.Tq + qrow] = dl;
+  }
 
   f32x4 acc[C::DT];
 #pragma unroll
@@ -761,17 +764,14 @@ extern "C" int32_t otr_attention_bwd(const otr_attn_desc_t* d, const void* q, co
 
 static int32_t attention_bwd_impl(const otr_attn_desc_t* d, AttnArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  int64_t rows = (int64_t)d->B * d->H * d->Tq;
-  dim3 gd((unsigned)((rows + 15) / 16));
-  if (d->dtype == OTR_BF16) hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, gd, dim3(256), 0, s, a, d->dk);
-  else hipLaunchKernelGGL(attn_delta_kernel<float>, gd, dim3(256), 0, s, a, d->dk);
+  // dQ first: it also produces delta = rowsum(dO * O), which the dK/dV kernel reads
   dim3 gk((d->Tk + 63) / 64, d->H, d->B), gq((d->Tq + 63) / 64, d->H, d->B);
   if (d->dtype == OTR_BF16) {
-    DK_SWITCH(bf16_t, attn_bwd_dkdv_kernel, gk)
     DK_SWITCH(bf16_t, attn_bwd_dq_kernel, gq)
+    DK_SWITCH(bf16_t, attn_bwd_dkdv_kernel, gk)
   } else {
-    DK_SWITCH(float, attn_bwd_dkdv_kernel, gk)
     DK_SWITCH(float, attn_bwd_dq_kernel, gq)
+    DK_SWITCH(float, attn_bwd_dkdv_kernel, gk)
   }
   return otr_check_launch("attention_bwd");
 }
