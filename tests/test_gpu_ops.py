@@ -207,6 +207,33 @@ def test_ffn_glu(mode, M, d, dff):
         assert rel(u, v) < 2 * TOL[mode], nm
 
 
+@pytest.mark.parametrize('M,d,dff', [(200, 64, 256), (130, 256, 2048), (1030, 256, 2048), (77, 64, 40)])
+def test_ffn_glu_fused_bf16_path(M, d, dff):
+    """The production bf16 data path: x carries its bf16 twin and the output gradient arrives in bf16, so the fused
+    kernels run (otr_ffn_glu_fwd: w_1 GEMM + GLU epilogue keeping (a | sigmoid(b)); otr_ffn_glu_bwd: dy.W_2 GEMM + GLU'
+    epilogue) on 64- and 128-wide tiles; dff = 40 does not qualify and must fall back with the same result."""
+    from opentransformer_amd import ops
+    ops.set_compute_dtype('bf16')
+    try:
+        x = rnd(M, d, seed=41).requires_grad_(True)
+        ops.attach_lp(x, ops.cast_bf16(x.detach()))
+        w1 = (rnd(2 * dff, d, seed=42) / math.sqrt(d)).requires_grad_(True)
+        b1 = (0.1 * rnd(2 * dff, seed=43)).requires_grad_(True)
+        w2 = (rnd(d, dff, seed=44) / math.sqrt(dff)).requires_grad_(True)
+        b2 = (0.1 * rnd(d, seed=45)).requires_grad_(True)
+        y = ops.FeedForwardGLUFn.apply(x, w1, b1, w2, b2, False, torch.bfloat16)
+        assert y.dtype == torch.bfloat16
+        yr = F.linear(F.glu(F.linear(x, w1, b1), -1), w2, b2)
+        assert rel(y.float(), yr) < TOL['bf16']
+        g = rnd(M, d, seed=46)
+        grads = torch.autograd.grad(y, (x, w1, b1, w2, b2), g.to(torch.bfloat16))
+        gref = torch.autograd.grad(yr, (x, w1, b1, w2, b2), g)
+        for nm, u, v in zip(('dx', 'dw1', 'db1', 'dw2', 'db2'), grads, gref):
+            assert rel(u, v) < 2 * TOL['bf16'], nm
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
 def test_posenc_and_embedding(mode):
     from opentransformer_amd import ops
     from oracle import otrans_oracle as orc
@@ -479,3 +506,45 @@ def test_grouped_weight_and_bias_gradients(mode):
             torch.testing.assert_close(bias, rb, rtol=1e-4, atol=1e-3 * float(rb.abs().max()))
     finally:
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('M,d,F_', [(1030, 256, 2048), (130, 64, 96)])
+def test_ffn_glu_fused_entries_direct(M, d, F_):
+    """otr_ffn_glu_fwd / otr_ffn_glu_bwd through the C ABI: h = (value | sigmoid(gate)), u, dh and the bias partials;
+    an unqualified shape returns 1 and launches nothing."""
+    import ctypes as C
+    from opentransformer_amd import _lib as L
+    from opentransformer_amd import ops
+    lib = L.load()
+    bf = torch.bfloat16
+    x = rnd(M, d, seed=61).to(bf)
+    w1 = (rnd(2 * F_, d, seed=62) / math.sqrt(d)).to(bf)
+    b1 = 0.1 * rnd(2 * F_, seed=63)
+    h = torch.zeros(M, 2 * F_, device=DEV, dtype=bf)
+    u = torch.zeros(M, F_, device=DEV, dtype=bf)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
+    assert lib.otr_ffn_glu_fwd(p(x), d, p(w1), d, p(b1), p(h), p(u), M, F_, d, st) == 0
+    t = x.float() @ w1.float().t() + b1
+    a, sg = t[:, :F_], torch.sigmoid(t[:, F_:])
+    assert rel(h[:, :F_].float(), a) < 1e-2 and rel(h[:, F_:].float(), sg) < 1e-2 and rel(u.float(), a * sg) < 1e-2
+    # backward on the saved (a | sigmoid(b))
+    dy = rnd(M, d, seed=64).to(bf)
+    w2t = (rnd(F_, d, seed=65) / math.sqrt(F_)).to(bf)            # [F, d] = w_2^T
+    dh = torch.zeros_like(h)
+    cap = (M + 63) // 64
+    part = torch.zeros(cap, 2 * F_, device=DEV)
+    rows = C.c_int32(0)
+    assert lib.otr_ffn_glu_bwd(p(dy), 1, d, p(w2t), d, p(h), 1, p(dh), p(part), cap, C.byref(rows), M, F_, d, st) == 0
+    du = (dy.float() @ w2t.float().t()).to(bf).float()
+    hs, hg = h[:, :F_].float(), h[:, F_:].float()
+    ra, rb = du * hg, du * hs * hg * (1 - hg)
+    assert rel(dh[:, :F_].float(), ra) < 1.5e-2 and rel(dh[:, F_:].float(), rb) < 1.5e-2
+    assert 0 < rows.value <= cap
+    got = part[:rows.value].sum(0)
+    assert rel(got[:F_], dh[:, :F_].float().sum(0)) < 1e-2 and rel(got[F_:], dh[:, F_:].float().sum(0)) < 1e-2
+    # F not a multiple of the tile's value width: refused, nothing written
+    h2 = torch.full((M, 80), 7.0, device=DEV, dtype=bf)
+    assert lib.otr_ffn_glu_fwd(p(x), d, p(w1), d, p(b1), p(h2), p(u), M, 40, d, st) == 1
+    torch.cuda.synchronize()
+    assert bool((h2 == 7.0).all())
