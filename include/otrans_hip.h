@@ -293,6 +293,11 @@ int32_t otr_beam_prune(const float* k_score, const int64_t* k_idx, const float* 
 int32_t otr_transpose_batched(const void* src, void* dst, const int64_t* table, int32_t n_mats, int64_t total_tiles,
                               int32_t elem_bytes, void* stream);
 
+/* ---- SpecAugment on the device (data/augment.py:9-41): zero x[b,t,f] (f32 [B,T,F]) inside NR
+ *      rectangles per utterance, ranges int32 [B,NR,4] = {t0,t1,f0,f1} half-open.  The rectangles are drawn on the host
+ *      with the reference's own random calls (opentransformer_amd/data.py), so the masks are bit-identical. */
+int32_t otr_spec_mask(float* x, const int32_t* ranges, int32_t B, int32_t NR, int32_t T, int32_t F, void* stream);
+
 /* ---- incremental (KV-cached) decoding, SURVEY.md 8f rank 1.  The reference threads a `cache` argument through
  *      decoder.inference / attention.inference but never fills it (decoder/transformer.py:185-208,
  *      module/attention.py:86-104, README.md:13 TODO) and re-runs the decoder over the whole prefix each step.

@@ -5,6 +5,7 @@ kwargs, forward signatures and state_dict keys, with every kernel a hand-written
 the C ABI of include/otrans_hip.h (opentransformer_amd/lib/libotrans_hip.so).  No CPU fallback.
 """
 from . import synthetic                                   # noqa: F401  (numpy/torch host helpers only)
+from . import data, tools                                # noqa: F401  (batch assembly / SpecAugment; checkpoint + WER tooling)
 from .ops import set_compute_dtype, get_compute_dtype     # noqa: F401
 from .model import (BuildFrontEnd, BuildEncoder, BuildDecoder, End2EndModel, SpeechToText,   # noqa: F401
                     CTCAssistor)

@@ -377,3 +377,29 @@ extern "C" int32_t otr_transpose_batched(const void* src, void* dst, const int64
                        (const uint32_t*)src, (uint32_t*)dst, table, n_mats);
   return otr_check_launch("transpose_batched");
 }
+
+// ------------------------------------------------------------------------------------------------ SpecAugment masks
+// x[b, t, f] = 0 wherever (t, f) falls into one of the NR rectangles of utterance b.  ranges: int32 [B, NR, 4] =
+// {t0, t1, f0, f1} half-open (a frequency mask covers all t, a time mask all f).  data/augment.py:9-41 draws the
+// rectangles on the host with numpy / random; drawing them there with the same calls keeps the masks bit-identical.
+__global__ void spec_mask_kernel(float* x, const int32_t* ranges, int NR, int T, int F) {
+  const int b = blockIdx.y;
+  const int32_t* r = ranges + (int64_t)b * NR * 4;
+  float* xb = x + (int64_t)b * T * F;
+  const int64_t total = (int64_t)T * F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i / F), f = (int)(i - (int64_t)t * F);
+    bool hit = false;
+    for (int k = 0; k < NR; ++k) hit = hit || (t >= r[4 * k] && t < r[4 * k + 1] && f >= r[4 * k + 2] && f < r[4 * k + 3]);
+    if (hit) xb[i] = 0.f;
+  }
+}
+extern "C" int32_t otr_spec_mask(float* x, const int32_t* ranges, int32_t B, int32_t NR, int32_t T, int32_t F, void* stream) {
+  OTR_REQUIRE(x && ranges, "spec_mask: null pointer");
+  OTR_REQUIRE(B >= 0 && NR >= 0 && NR <= 64 && T > 0 && F > 0, "spec_mask: bad shape B=%d NR=%d T=%d F=%d", B, NR, T, F);
+  if (B == 0 || NR == 0) return 0;
+  unsigned gx = (unsigned)(((int64_t)T * F + 255) / 256);
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(spec_mask_kernel, dim3(gx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ranges, NR, T, F);
+  return otr_check_launch("spec_mask");
+}

@@ -222,6 +222,37 @@ def golden_tools():
     print('tools_average.npz', sorted(arrs))
 
 
+def golden_data():
+    """tests/golden/data_collate.npz: the reference's collate_fn_with_eos_bos (data/loader.py:66-108) and spec_augment
+    (data/augment.py:9-41) on seeded toy utterances.  otrans.data.loader imports torchaudio / kaldiio /
+    python_speech_features (absent here): stub modules stand in for them, the two functions do not use them."""
+    import random
+    import types
+    for name in ('torchaudio', 'kaldiio', 'python_speech_features', 'prefetch_generator'):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.BackgroundGenerator = object
+            sys.modules[name] = m
+    from otrans.data.loader import collate_fn_with_eos_bos
+    from otrans.data.augment import spec_augment
+    from tests.test_data import toy_batch
+    batch = toy_batch()
+    ids, inputs, targets = collate_fn_with_eos_bos(batch)
+    arrs = {'inputs': inputs['inputs'].numpy(), 'inputs_length': inputs['inputs_length'].numpy(), 'mask': inputs['mask'].numpy(),
+            'targets': targets['targets'].numpy(), 'targets_length': targets['targets_length'].numpy(),
+            'targets_mask': targets['mask'].numpy()}
+    np.random.seed(11)
+    random.seed(12)
+    aug = []
+    for _, feat, flen, _, _ in toy_batch():
+        aug.append(spec_augment(feat[:flen].numpy().copy(), freq_mask_num=2, time_mask_num=2, freq_mask_rate=0.3,
+                                time_mask_rate=0.2, max_mask_time_len=100))
+    for i, a in enumerate(aug):
+        arrs['aug%d' % i] = a
+    np.savez(os.path.join(OUT, 'data_collate.npz'), **arrs)
+    print('data_collate.npz', ids, [a.shape for a in aug])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -251,6 +282,9 @@ def main():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'tools':
         golden_tools()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'data':
+        golden_data()
     else:
         main()
         golden_tools()
+        golden_data()
