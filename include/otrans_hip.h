@@ -158,7 +158,11 @@ int32_t otr_add_layernorm_fwd(const otr_ln_desc_t* d, const float* x, const void
  * branch (module/attention.py:43 output_proj, module/ffn.py:41 w_2) without a separate reduction launch. */
 int32_t otr_add_layernorm_bwd(const otr_ln_desc_t* d, const float* dy, const float* z, const float* mean,
                               const float* rstd, const float* gamma, const uint64_t* seed, float* dx, void* da,
-                              float* dgamma, float* dbeta, float* da_colsum, void* stream);
+                              float* dgamma, float* dbeta, float* da_colsum, float* partial, void* stream);
+/* partial (may be NULL): f32 [otr_add_layernorm_bwd_partial_rows(M), 3, d].  When given, NOTHING is added to dgamma / dbeta /
+ * da_colsum (they may be NULL); each workgroup writes its own sums (dgamma | dbeta | da column sums) to its row and the
+ * caller column-sums the rows (otr_colsum / otr_colsum_grouped): no atomics, deterministic. */
+int64_t otr_add_layernorm_bwd_partial_rows(int64_t M);
 
 /* ---- F.glu / F.relu on the FFN hidden (module/ffn.py:15-21,40): u[M,F] = h[:, :F]*sigmoid(h[:, F:]) */
 /* row_mask (uint8 [M], may be NULL): rows with mask 0 produce u = 0 / dh = 0 (module/conformer.py:46) */

@@ -72,7 +72,8 @@ SIGNATURES = {
     'otr_attention_bias_fwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P],
     'otr_attention_bias_bwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_add_layernorm_fwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    'otr_add_layernorm_bwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    'otr_add_layernorm_bwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    'otr_add_layernorm_bwd_partial_rows': [_I64],
     'otr_debug_trace': [_P],
     'otr_spec_mask': [_P, _P, _I32, _I32, _I32, _I32, _P],
     'otr_transpose_batched': [_P, _P, _P, _I32, _I64, _I32, _P],
@@ -109,7 +110,7 @@ SIGNATURES = {
     'otr_bn_swish_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _F32, _F32, _I32, _P],
     'otr_bn_swish_bwd': [_P, _P, _I32, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
 }
-_RESTYPE = {'otr_last_error_string': C.c_char_p}
+_RESTYPE = {'otr_last_error_string': C.c_char_p, 'otr_add_layernorm_bwd_partial_rows': C.c_int64}
 
 _lib = None
 

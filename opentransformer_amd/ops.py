@@ -525,14 +525,26 @@ class AddLayerNormFn(torch.autograd.Function):
             dgb = torch.zeros((2, d), dtype=torch.float32, device=dy.device)
             gg, gb = dgb[0], dgb[1]
         gab, dab = None, None
-        if ctx.ab_ref is not None and da is not None and ctx.needs_input_grad[6]:
+        want_ab = ctx.ab_ref is not None and da is not None and ctx.needs_input_grad[6]
+        if want_ab:
             gab = grad_target(ctx.ab_ref)
             if gab is None:
                 gab = dab = torch.zeros((d,), dtype=torch.float32, device=dy.device)
         desc = L.LnDesc(M, d, _code(adt) if adt is not None else L.OTR_F32, eps, p_drop, off)
+        part = None
+        if inplace and dab is None and _wq['on'] and _in_backward() and d % 4 == 0:
+            # in-place gradient buffers + deferred reductions: the kernel writes per-workgroup partial sums and the
+            # three column sums join the grouped launch at the end of backward (no atomics, deterministic)
+            nrow = L.load().otr_add_layernorm_bwd_partial_rows(M)
+            part = torch.empty((nrow, 3 * d), dtype=torch.float32, device=dy.device)
         L.check(L.load().otr_add_layernorm_bwd(C.byref(desc), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed),
-                                               _p(dx), _p(da), _p(gg), _p(gb), _p(gab), _stream()),
+                                               _p(dx), _p(da), _p(gg), _p(gb), _p(gab), _p(part), _stream()),
                 'otr_add_layernorm_bwd')
+        if part is not None:
+            colsum_raw(part[:, :d], out=gg)
+            colsum_raw(part[:, d:2 * d], out=gb)
+            if want_ab:
+                colsum_raw(part[:, 2 * d:], out=gab)
         dx_ret = dx.view(xshape)
         if ctx.link is not None and ctx.link.armed and ctx.needs_input_grad[0]:
             ctx.link.buf = dx           # the branch's first Linear adds its input gradient into this and returns the sum
