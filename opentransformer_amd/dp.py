@@ -105,6 +105,9 @@ class FlatDataParallel:
 
     def zero_grad(self):
         self.flat_grad.zero_()
+        if self.flat_grad.is_cuda:
+            from . import ops
+            ops.discard_pending_weight_grads()      # nothing queued survives into a new step (e.g. after an exception)
 
     def broadcast_parameters(self, src=0):
         """one-time replica sync at start-up (the reference re-broadcasts every step)."""

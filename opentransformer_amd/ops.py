@@ -228,6 +228,12 @@ def defer_weight_grads(on):
     _wq['on'] = bool(on)
 
 
+def discard_pending_weight_grads():
+    """Drop queued (never launched) weight-gradient work, e.g. left behind by a backward pass that raised.  Called by
+    FlatDataParallel.zero_grad(): a stale queue must not leak into the next step's gradients."""
+    _wq['w'], _wq['b'], _wq['armed'] = [], [], False
+
+
 def _arm_flush():
     if not _wq['armed']:
         _wq['armed'] = True

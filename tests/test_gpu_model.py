@@ -235,6 +235,40 @@ def test_inplace_flat_gradients_match_autograd_gradients():
         ops.set_compute_dtype('bf16')
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_gradient_accumulation_and_stale_queue(mode):
+    """accum_steps > 1 (transformer_baseline.yaml:96): two backward passes without zero_grad sum their gradients in the
+    flat buffer (each pass flushes its own deferred weight-gradient queue); work queued by a pass that never finished
+    is dropped by zero_grad instead of leaking into the next step."""
+    from opentransformer_amd import ops
+    from opentransformer_amd.dp import FlatDataParallel
+    ops.set_compute_dtype(mode)
+    try:
+        cfg = syn.c1_model(0.0, ctc_weight=0.3)
+        i1, t1 = syn.synthetic_batch(**C1_BATCH)
+        i2, t2 = syn.synthetic_batch(**dict(C1_BATCH, seed=5))
+        i1, t1, i2, t2 = to_dev(i1), to_dev(t1), to_dev(i2), to_dev(t2)
+        dp = FlatDataParallel(build(cfg))
+        grads = []
+        for batch in ((i1, t1), (i2, t2)):
+            dp.zero_grad()
+            dp(*batch)[0].backward()
+            grads.append(dp.flat_grad.clone())
+        dp.zero_grad()
+        dp(i1, t1)[0].backward()
+        dp(i2, t2)[0].backward()
+        tol = 1e-5 if mode == 'fp32' else 2e-2
+        assert rel(dp.flat_grad.cpu().numpy(), (grads[0] + grads[1]).cpu().numpy()) < tol
+        # a queue left behind (simulated) must not survive zero_grad
+        ops._wq['w'].append((torch.ones(8, 8, device=DEV), torch.ones(8, 8, device=DEV), dp.flat_grad[:64].view(8, 8)))
+        dp.zero_grad()
+        assert not ops._wq['w'] and not ops._wq['b']
+        dp(i1, t1)[0].backward()
+        assert rel(dp.flat_grad.cpu().numpy(), grads[0].cpu().numpy()) < tol
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
 def test_c4_conformer_full_size_matches_cpu_oracle():
     """conformer_baseline.yaml dimensions (d=384, dk=96, 256-channel frontend, 12 blocks, 50.4 M parameters) on a
     small ragged batch against the CPU oracle (which is pinned to the reference on the small conformer fixture)."""
