@@ -40,6 +40,30 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.otr_add_layernorm_fwd(C.byref(ln), None, None, None, None, None, None, None, None, None, None, None) < 0
 
 
+def test_argument_errors_of_the_fused_and_grouped_entries():
+    """the entries added for fusion / grouping / decoding validate before they launch (no GPU here)"""
+    lib = _lib.load()
+    one = C.c_void_p(16)                        # non-null, 16-byte "aligned" dummy: must never be dereferenced
+    assert lib.otr_ffn_glu_fwd(None, 8, None, 8, None, None, None, 4, 64, 8, None) < 0
+    assert b'ffn_glu_fwd' in lib.otr_last_error_string()
+    rows = C.c_int32(7)
+    assert lib.otr_ffn_glu_bwd(one, 1, 4, one, 4, one, 1, one, one, 1, C.byref(rows), 4, 64, 8, None) < 0   # ldy < d_model
+    assert lib.otr_linear_wgrad_grouped(None, -1, 1, None, 0, None) < 0
+    assert lib.otr_linear_wgrad_grouped(None, 0, 1, None, 0, None) == 0          # empty group: nothing to do
+    assert lib.otr_linear_wgrad_grouped(None, 0, 7, None, 0, None) < 0           # bad compute type
+    it = (_lib.ColsumItem * 1)()
+    it[0].a, it[0].out, it[0].M, it[0].N, it[0].lda, it[0].dtype = 16, 16, 4, 8, 8, 5
+    assert lib.otr_colsum_grouped(it, 1, None) < 0                               # bad dtype
+    assert lib.otr_colsum_grouped(None, 0, None) == 0
+    assert lib.otr_transpose_batched(one, one, one, 1, 1, 2, None) < 0           # in place
+    assert lib.otr_spec_mask(one, one, 1, 65, 4, 4, None) < 0                    # too many rectangles
+    assert lib.otr_decode_embed(None, 4, None, None, None, None, 2, 8, 10, 1.0, None) < 0
+    assert lib.otr_decode_self_attention(one, one, one, one, one, one, 1, 2, 4, 256, 8, 1.0, None) < 0      # dk > 128
+    assert lib.otr_beam_prune_cached(one, one, one, one, one, 8, 1, 2, 1, one, one, one, one, 4, one, one, one, one,
+                                     None) < 0                                   # in/out buffers must differ
+    assert lib.otr_add_layernorm_bwd_partial_rows(7968) == 249
+
+
 def test_product_refuses_cpu_tensors():
     import opentransformer_amd as ota
     from opentransformer_amd import synthetic as syn
