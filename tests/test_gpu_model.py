@@ -269,6 +269,41 @@ def test_gradient_accumulation_and_stale_queue(mode):
         ops.set_compute_dtype('bf16')
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('shape', [dict(batch=1, frames=50, tgt_len=2), dict(batch=3, frames=131, tgt_len=1, lengths=[131, 64, 23]),
+                                   dict(batch=2, frames=23, tgt_len=3)])
+def test_tiny_and_ragged_shapes_match_cpu_oracle(mode, shape):
+    """Edge sizes: one utterance, T' = 11 / 4 frames after subsampling (less than any tile), single-token targets, an
+    utterance that is almost all padding -- through the flat / deferred / fused training path, against the oracle."""
+    from opentransformer_amd import ops
+    from opentransformer_amd.dp import FlatDataParallel
+    from oracle import otrans_oracle as orc
+    cfg = syn.c1_model(0.0, ctc_weight=0.3)
+    kw = dict(feat_dim=80, vocab=100, seed=9)
+    kw.update(shape)
+    inputs, targets = syn.synthetic_batch(**kw)
+    parts = H.require_grad(H.filled_state(cfg, seed=77))
+    ref, _ = orc.speech2text_forward(parts, cfg, inputs, targets)
+    ref.backward()
+    flat = H.flat_named(parts)
+    ops.set_compute_dtype(mode)
+    try:
+        model = build(cfg, seed=77)
+        dp = FlatDataParallel(model)
+        dp.zero_grad()
+        loss, _ = dp(to_dev(inputs), to_dev(targets))
+        loss.backward()
+        tl, tg = (1e-4, 5e-3) if mode == 'fp32' else (3e-3, 1e-1)
+        assert abs(loss.item() - ref.item()) < tl * abs(ref.item()), (loss.item(), ref.item())
+        worst = 0.0
+        for k, p in model.named_parameters():
+            gr, gg = flat[k].grad.numpy(), p.grad.cpu().numpy()
+            worst = max(worst, float(np.linalg.norm(gg - gr) / max(np.linalg.norm(gr), 1e-2)))
+        assert worst < tg, worst
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
 def test_c4_conformer_full_size_matches_cpu_oracle():
     """conformer_baseline.yaml dimensions (d=384, dk=96, 256-channel frontend, 12 blocks, 50.4 M parameters) on a
     small ragged batch against the CPU oracle (which is pinned to the reference on the small conformer fixture)."""
