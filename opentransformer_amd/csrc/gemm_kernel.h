@@ -12,14 +12,17 @@
 //   MODE_IM2K    rows = conv2 output pixels, k = (kh,kw,c1) gathered from channel-last act1
 //   MODE_IM2M    rows = (kh,kw,c1), contraction = output pixels   (conv2 wgrad B operand)
 //
-// Pipeline: double-buffered LDS, global loads for stage t+1 are issued before the MFMAs of stage t
-// and written to the other buffer afterwards -> one barrier per BK = KCH*CE contraction elements
-// (64 for bf16).  Workgroup = 4 waves in a 2x2 grid; wave tile (BM/2)x(BN/2) of 16x16 MFMA tiles.
-// The accumulator is kept TRANSPOSED (mma(B-frag, A-frag)): lane holds row m = lane&15 and four
-// consecutive columns n = (lane>>4)*4.., so the epilogue stores 8-16 contiguous bytes per lane.
+// Pipeline: double-buffered LDS; raw (same-type) operands additionally keep a 2-slot register ring, so the global
+// loads of stage t+2 are in flight while stage t is multiplied and stage t+1 is written to the other LDS buffer
+// -> one barrier per BK = KCH*CE contraction elements (64 for bf16).  Workgroup = 4 waves in a 2x2 grid; wave tile
+// (BM/2)x(BN/2) of 16x16 MFMA tiles.  The accumulator is kept TRANSPOSED (mma(B-frag, A-frag)): lane holds row
+// m = lane&15 and four consecutive columns n = (lane>>4)*4..; FAST kernels stage the finished tile through the idle
+// operand LDS and write whole rows (16 B per lane), with optional fused GLU forward / backward epilogues (EPI).
 //
-// Split-K (blockIdx.y): contraction-heavy / output-small problems (all weight gradients) are cut
-// into k-slices whose partial tiles are reduced with fp32 atomics into a pre-zeroed C.
+// Persistent tile loop (no split-K, <= OTR_RESIDENT_WG workgroups): the next tile's operands are prefetched across the
+// epilogue.  Split-K (blockIdx.y): k-slices write fp32 partial tiles to the caller's workspace and
+// splitk_reduce_kernel sums them in a fixed order (deterministic; no atomics).  Weight gradients do not come through
+// here one by one: gemm_grouped_kernel runs all of a backward pass's dW problems from a device-side descriptor table.
 #pragma once
 #include <type_traits>
 
@@ -45,7 +48,7 @@ struct GemmArgs {
   int64_t lda, ldb, ldc;
   int act, accumulate;
   int a_vec, b_vec;  // operand base/ld satisfy the vector-load alignment
-  int ksplit;        // number of k-slices (grid.y); > 1 => atomic fp32 reduction
+  int ksplit;        // number of k-slices (grid.y); > 1 => partial tiles to ws + splitk_reduce_kernel
   int allow_split;   // caller permits split-K (needs a workspace)
   float* ws;         // split-K workspace: ksplit partial [M,N] fp32 slabs, reduced in a fixed order
   int64_t ws_bytes;
