@@ -4,6 +4,8 @@ built directly in device memory.
 * `collate_fn_with_eos_bos(batch, device)`: otrans/data/loader.py:66-108 -- pad features with zeros, bool masks,
   targets `[BOS] tokens [EOS] PAD*`, `targets_length` counting the EOS.  Features may already live on the device (they are
   copied into ONE preallocated [B,Tmax,F] buffer; no per-utterance F.pad + cat).
+* `BySequenceLengthSampler`: otrans/data/bucket.py:14-170 -- length-bucketed batches (same batches as the reference under
+  the same `random` seed), which bound the padding of those device batches.
 * `spec_augment_ranges` + `spec_augment_batch`: otrans/data/augment.py:9-41.  The mask rectangles are drawn on the host
   with the reference's exact sequence of `np.random.uniform` / `random.randint` calls (so a seeded run produces the same
   masks), then applied to the whole batch by one kernel (otr_spec_mask) instead of per-utterance numpy slicing.
@@ -13,6 +15,7 @@ import random
 
 import numpy as np
 import torch
+import torch.utils.data
 
 from . import _lib as L
 
@@ -79,3 +82,118 @@ def spec_augment_batch(inputs, lengths=None, **kw):
     if x is not inputs:
         inputs.copy_(x)
     return inputs
+
+
+class BySequenceLengthSampler(torch.utils.data.Sampler):
+    """Length-bucketed batch sampler with the reference's semantics (otrans/data/bucket.py:14-170), so that a seeded
+    `random` yields the very same batches: utterances go to the bucket whose (lower, upper] frame range holds them, each
+    bucket is shuffled and cut into batches -- of `bucket_batch_size[min(id, last)]` utterances, or (the default,
+    `audo_set_batch_size`, spelled as in the reference) greedily up to `max_frames_one_batch` frames -- and the batches of
+    all buckets are shuffled together at the start of every epoch.  Padding per batch is bounded by the bucket width,
+    which is what keeps the padded [B, Tmax, F] device batches of `collate_fn_with_eos_bos` dense.
+
+    Reference quirks kept on purpose (they change which batches come out):
+      * `short_first` is accepted and ignored (bucket.py:28 overwrites it with False);
+      * in frame-budget mode an utterance longer than the budget that comes first in its bucket emits an EMPTY batch
+        before it (bucket.py:139-142), and `drop_last` drops the last partial batch of every bucket;
+      * the per-bucket lists are shuffled in place, so `shuffle_batch_in_bucket()` (called between epochs) reshuffles the
+        previous epoch's order rather than the dataset order.
+    Bucket lookup is one `np.searchsorted` over all lengths instead of a numpy round trip per utterance."""
+    INT32_MAX = int(np.iinfo(np.int32).max)
+
+    def __init__(self, dataset, bucket_boundaries, bucket_batch_size=[], rm_the_long_sents=True,
+                 audo_set_batch_size=True, max_frames_one_batch=20000, drop_last=False, short_first=False):
+        assert isinstance(bucket_boundaries, list) and isinstance(bucket_batch_size, list)
+        self.index_length_pair = list(dataset.index_length_pair())
+        self.bucket_boundaries = bucket_boundaries
+        self.bucket_batch_size = bucket_batch_size
+        self.rm_the_long_sents = rm_the_long_sents
+        self.audo_set_batch_size = audo_set_batch_size
+        self.max_frames_one_batch = max_frames_one_batch
+        self.drop_last = drop_last
+        self.short_first = False
+        if audo_set_batch_size:
+            assert max_frames_one_batch > 0
+        self.max_length = bucket_boundaries[-1] if rm_the_long_sents else self.INT32_MAX
+        self.num_of_buckets = len(bucket_boundaries) + (0 if rm_the_long_sents else 1)
+        self.buckets = {}
+        for b in range(self.num_of_buckets):
+            lo = 0 if b == 0 else bucket_boundaries[b - 1]
+            hi = self.INT32_MAX if b == len(bucket_boundaries) else bucket_boundaries[b]
+            size = 0 if audo_set_batch_size else bucket_batch_size[min(b, len(bucket_batch_size) - 1)]
+            self.buckets[str(b)] = {'index_length_pair': [], 'batch_size': size, 'boundary': [lo, hi]}
+        self.batch_list = []
+        self.put_data_pair_into_buckets()
+        self.split_the_bucket_into_batch()
+
+    def element_to_bucket_id(self, seq_length):
+        if seq_length <= 0 or seq_length > self.INT32_MAX:
+            raise ValueError('no bucket holds a sequence of length %r' % (seq_length,))
+        return int(np.searchsorted(np.asarray(self.bucket_boundaries), seq_length, side='left'))
+
+    def put_data_pair_into_buckets(self):
+        pairs = self.index_length_pair
+        if not pairs:
+            return
+        lengths = np.asarray([p[1] for p in pairs])
+        keep = lengths <= self.max_length if self.rm_the_long_sents else np.ones(len(pairs), bool)
+        if np.any(lengths[keep] <= 0):
+            raise ValueError('no bucket holds a sequence of length <= 0')
+        ids = np.searchsorted(np.asarray(self.bucket_boundaries), lengths, side='left')
+        for (index, length), b, k in zip(pairs, ids, keep):
+            if k:
+                self.buckets[str(int(b))]['index_length_pair'].append((index, length))
+        self.removed = int(len(pairs) - keep.sum())
+
+    def split_the_bucket_into_batch(self):
+        self.batch_list = []
+        for bucket_id, bucket in self.buckets.items():
+            pairs = bucket['index_length_pair']
+            if not pairs:
+                continue
+            random.shuffle(pairs)
+            if self.audo_set_batch_size:
+                self.batch_list.extend(self.generate_batches_based_length(bucket_id, pairs))
+            else:
+                self.batch_list.extend(self.generate_batches(bucket_id, pairs, bucket['batch_size']))
+
+    def generate_batches(self, bucket_id, pairs, batch_size):
+        n = len(pairs)
+        nb = n // batch_size if self.drop_last else -(-n // batch_size)
+        return [(int(bucket_id), [i for i, _ in pairs[s * batch_size:min((s + 1) * batch_size, n)]]) for s in range(nb)]
+
+    def generate_batches_based_length(self, bucket_id, pairs):
+        out, cur, frames = [], [], 0
+        for index, length in pairs:
+            if frames + length > self.max_frames_one_batch:
+                out.append((int(bucket_id), cur))
+                cur, frames = [], 0
+            cur.append(index)
+            frames += length
+        if cur and not self.drop_last:
+            out.append((int(bucket_id), cur))
+        return out
+
+    def shuffle_batch_in_bucket(self):
+        if not self.short_first:
+            self.split_the_bucket_into_batch()
+
+    def padding_waste(self):
+        """fraction of padded frames over all current batches (what bucketing is for): 1 - sum(len) / sum(B * Tmax)"""
+        length = dict(self.index_length_pair)
+        real = padded = 0
+        for _, idx in self.batch_list:
+            if idx:
+                ls = [length[i] for i in idx]
+                real += sum(ls)
+                padded += len(ls) * max(ls)
+        return 1.0 - real / max(padded, 1)
+
+    def __iter__(self):
+        if not self.short_first:
+            random.shuffle(self.batch_list)
+        for _, index_list in self.batch_list:
+            yield index_list
+
+    def __len__(self):
+        return len(self.batch_list)

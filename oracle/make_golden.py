@@ -253,6 +253,32 @@ def golden_data():
     print('data_collate.npz', ids, [a.shape for a in aug])
 
 
+def golden_bucket():
+    """tests/golden/data_bucket.npz: the reference's BySequenceLengthSampler (data/bucket.py:14-170) on a seeded toy
+    length table, in its four modes; per case the batches of the constructor split, of two epochs of __iter__, and of a
+    shuffle_batch_in_bucket() re-split, flattened as (values, offsets)."""
+    import random
+    import types
+    for name in ('torchaudio', 'kaldiio', 'python_speech_features', 'prefetch_generator'):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.BackgroundGenerator = object
+            sys.modules[name] = m
+    from otrans.data.bucket import BySequenceLengthSampler
+    from tests.test_data import ToyLengths, BUCKET_CASES, flatten_batches
+    arrs = {}
+    for name, kw in BUCKET_CASES.items():
+        random.seed(21)
+        s = BySequenceLengthSampler(ToyLengths(), **kw)
+        seqs = [[b for _, b in s.batch_list], list(s), list(s)]
+        s.shuffle_batch_in_bucket()
+        seqs.append(list(s))
+        for i, seq in enumerate(seqs):
+            arrs['%s_%d_v' % (name, i)], arrs['%s_%d_o' % (name, i)] = flatten_batches(seq)
+        print('data_bucket', name, [len(q) for q in seqs])
+    np.savez(os.path.join(OUT, 'data_bucket.npz'), **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -284,7 +310,10 @@ if __name__ == '__main__':
         golden_tools()
     elif len(sys.argv) > 1 and sys.argv[1] == 'data':
         golden_data()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'bucket':
+        golden_bucket()
     else:
         main()
         golden_tools()
         golden_data()
+        golden_bucket()

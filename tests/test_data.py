@@ -18,6 +18,60 @@ def toy_batch():
     return out
 
 
+class ToyLengths:
+    """what the sampler needs from a dataset: (index, number of frames) pairs; a few utterances beyond the last boundary"""
+    def index_length_pair(self):
+        rng = np.random.default_rng(9)
+        return [(i, int(v)) for i, v in enumerate(rng.integers(30, 1300, 400))]
+
+
+BUCKET_CASES = {
+    'frames': dict(bucket_boundaries=[200, 400, 600, 800, 1000], max_frames_one_batch=6000),
+    'frames_keep_long_drop_last': dict(bucket_boundaries=[300, 600, 900], rm_the_long_sents=False, max_frames_one_batch=5000,
+                                       drop_last=True, short_first=True),
+    'fixed': dict(bucket_boundaries=[250, 500, 750, 1000], bucket_batch_size=[16, 12, 8], audo_set_batch_size=False),
+    'fixed_drop_last_keep_long': dict(bucket_boundaries=[400, 800], bucket_batch_size=[10, 6, 3], audo_set_batch_size=False,
+                                      rm_the_long_sents=False, drop_last=True),
+    'frames_budget_below_one_utterance': dict(bucket_boundaries=[500, 1000], max_frames_one_batch=700),
+}
+
+
+def flatten_batches(seq):
+    vals = np.asarray([i for b in seq for i in b], dtype=np.int64)
+    offs = np.cumsum([0] + [len(b) for b in seq]).astype(np.int64)
+    return vals, offs
+
+
+def test_bucket_sampler_matches_reference(golden):
+    """same `random` seed -> the same batches as data/bucket.py, through construction, two epochs and a re-split"""
+    from opentransformer_amd.data import BySequenceLengthSampler
+    g = golden('data_bucket.npz')
+    for name, kw in BUCKET_CASES.items():
+        random.seed(21)
+        s = BySequenceLengthSampler(ToyLengths(), **kw)
+        seqs = [[b for _, b in s.batch_list], list(s), list(s)]
+        s.shuffle_batch_in_bucket()
+        seqs.append(list(s))
+        for i, seq in enumerate(seqs):
+            v, o = flatten_batches(seq)
+            assert np.array_equal(o, g['%s_%d_o' % (name, i)]), (name, i)
+            assert np.array_equal(v, g['%s_%d_v' % (name, i)]), (name, i)
+        assert len(s) == len(seqs[-1])
+
+
+def test_bucket_sampler_bounds_padding():
+    from opentransformer_amd.data import BySequenceLengthSampler
+    random.seed(3)
+    ds = ToyLengths()
+    bucketed = BySequenceLengthSampler(ds, [200, 400, 600, 800, 1000, 1300], max_frames_one_batch=8000)
+    one = BySequenceLengthSampler(ds, [1300], max_frames_one_batch=8000)
+    assert bucketed.padding_waste() < 0.15 < one.padding_waste()
+    seen = sorted(i for b in bucketed for i in b)
+    assert seen == list(range(400))                      # every utterance exactly once
+    with pytest.raises(ValueError):
+        bucketed.element_to_bucket_id(0)
+
+
 def test_collate_matches_reference(golden):
     from opentransformer_amd.data import collate_fn_with_eos_bos
     g = golden('data_collate.npz')
