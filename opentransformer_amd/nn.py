@@ -7,9 +7,13 @@ Embedding objects are used only as *parameter containers* (identical shapes, nam
 initialisation); their forward() is never called -- all math goes through opentransformer_amd.ops,
 i.e. through libotrans_hip.so.
 
-Not built yet (constructor raises NotImplementedError): normalize_before=True, concat_after=True,
-relative_positional=True (transformer encoder), FFN activations other than 'glu'/'relu',
-front_end_layer_norm=True, in_channel != 1.  The shipped AISHELL yamls use none of these.
+Transformer layers come in the reference's four variants: post-norm (the shipped yamls) or its non-standard pre-norm
+(`normalize_before=True`: the residual is taken AFTER the norm, encoder/transformer.py:42-44), each with or without
+`concat_after` (a Linear over cat(x, attention) instead of dropout(attention)).
+
+Not built yet (constructor raises NotImplementedError): relative_positional=True (transformer encoder), FFN
+activations other than 'glu'/'relu', front_end_layer_norm=True, in_channel != 1, dropout inside attention / FFN /
+frontend.  The shipped AISHELL yamls use none of these.
 """
 import math
 
@@ -207,32 +211,60 @@ def _post_norm(norm, x, branch, p, training, a_bias=None, link=None):
     return ops.add_layernorm(x, branch, norm.weight, norm.bias, p if training else 0.0, norm.eps, a_bias=a_bias, link=link)
 
 
+def _norm(norm, x):
+    return ops.add_layernorm(x, None, norm.weight, norm.bias, 0.0, norm.eps)
+
+
+def _attention_branch(layer, concat_linear, x, p, run):
+    """The residual branch of an attention sub-layer, bias left to the LayerNorm that closes it: (branch, bias, dropout
+    rate, link).  `run(**kw)` calls the attention module.  concat_after (encoder/transformer.py:51-52,
+    decoder/transformer.py:63-64,73-74): Linear(cat(x, attention)) and NO dropout on that path."""
+    if layer.concat_after:
+        att, _ = run()
+        cat = torch.cat((x, att.to(x.dtype)), dim=-1)
+        return (ops.linear(cat, concat_linear.weight, concat_linear.bias, defer_bias=True, out_dtype=ops.act_dtype()),
+                concat_linear.bias, 0.0, None)
+    link = ops.new_link()                     # skip-connection gradients are summed in GEMM epilogues
+    att, bias = run(defer_bias=True, link=link)
+    return att, bias, p, link
+
+
 # ------------------------------------------------------------------------------------- encoder
 class TransformerEncoderLayer(nn.Module):
-    """encoder/transformer.py:16-90 (post-norm)."""
+    """encoder/transformer.py:16-90.  Post-norm: x = LN1(x + drop(SA(x))); x = LN2(x + drop(FFN(x))).  Pre-norm as the
+    reference wrote it: x = LN1(x); x = x + drop(SA(x)); x = LN2(x); x = x + drop(FFN(x)) -- so "norm_k+1 of (x + branch_k)"
+    is the same fused add+LayerNorm kernel in both variants, shifted by one sub-layer."""
 
     def __init__(self, n_heads, d_model, d_ff, slf_attn_dropout, ffn_dropout, residual_dropout,
                  normalize_before=False, concat_after=False, relative_positional=False, activation='relu'):
         super().__init__()
-        if normalize_before:
-            _unsupported('normalize_before=True')
-        if concat_after:
-            _unsupported('concat_after=True')
         if relative_positional:
             _unsupported('relative_positional=True')
-        self.relative_positional, self.normalize_before, self.concat_after = False, False, False
+        self.relative_positional, self.normalize_before, self.concat_after = False, normalize_before, concat_after
         self.slf_attn = MultiHeadedSelfAttention(n_heads, d_model, slf_attn_dropout)
         self.feed_forward = PositionwiseFeedForward(d_model, d_ff, ffn_dropout, activation)
         self.norm1 = nn.LayerNorm(d_model)
         self.norm2 = nn.LayerNorm(d_model)
         self.residual_dropout = residual_dropout
+        if concat_after:
+            self.concat_linear = nn.Linear(d_model * 2, d_model)
 
     def forward(self, x, mask, pos=None, causal=False):
-        l1, l2 = ops.new_link(), ops.new_link()          # skip-connection gradients are summed in GEMM epilogues
-        attn, _ = self.slf_attn(x, mask, causal, defer_bias=True, link=l1)
-        x = _post_norm(self.norm1, x, attn, self.residual_dropout, self.training, self.slf_attn.output_proj.bias, l1)
-        x = _post_norm(self.norm2, x, self.feed_forward(x, defer_bias=True, link=l2), self.residual_dropout, self.training,
-                       self.feed_forward.w_2.bias, l2)
+        p = self.residual_dropout if self.training else 0.0
+        pre = self.normalize_before
+        if pre:
+            x = _norm(self.norm1, x)
+
+        def run(**kw):
+            att, _ = self.slf_attn(x, mask, causal, **kw)
+            return att, self.slf_attn.output_proj.bias
+        branch, bias, p1, link = _attention_branch(self, getattr(self, 'concat_linear', None), x, p, run)
+        x = _post_norm(self.norm2 if pre else self.norm1, x, branch, p1, True, bias, link)
+        if pre:
+            x = ops.residual_add(x, self.feed_forward(x), 1.0, p)
+        else:
+            l2 = ops.new_link()
+            x = _post_norm(self.norm2, x, self.feed_forward(x, defer_bias=True, link=l2), p, True, self.feed_forward.w_2.bias, l2)
         return x, {'slf_attn_weights': None}
 
     def inference(self, x, mask, pos=None, cache=None):
@@ -258,12 +290,16 @@ class TransformerEncoder(nn.Module):
             TransformerEncoderLayer(n_heads, d_model, d_ff, slf_attn_dropout, ffn_dropout, residual_dropout,
                                     normalize_before, concat_after, relative_positional, activation)
             for _ in range(n_blocks)])
+        if normalize_before:
+            self.norm = nn.LayerNorm(d_model)               # encoder/transformer.py:111-112
 
     def forward(self, inputs, mask):
         x, _ = self.pos_emb(inputs)
         km = mask.to(torch.uint8).unsqueeze(1)              # cast once; every layer's key mask is this uint8 view
         for block in self.blocks:
             x, _ = block(x, km)
+        if self.normalize_before:
+            x = _norm(self.norm, x)
         # the reference returns every layer's [B,h,T,T] weights; nothing reads them
         return x, mask, {}
 
@@ -420,19 +456,15 @@ class ConformerEncoder(nn.Module):
 
 # ------------------------------------------------------------------------------------- decoder
 class TransformerDecoderLayer(nn.Module):
-    """decoder/transformer.py:18-126 (post-norm)."""
+    """decoder/transformer.py:18-126; the same four variants as TransformerEncoderLayer."""
 
     def __init__(self, n_heads, d_model, d_ff, memory_dim, slf_attn_dropout=0.0, src_attn_dropout=0.0,
                  ffn_dropout=0.0, residual_dropout=0.1, normalize_before=False, concat_after=False,
                  relative_positional=False, activation='relu'):
         super().__init__()
-        if normalize_before:
-            _unsupported('normalize_before=True')
-        if concat_after:
-            _unsupported('concat_after=True')
         if relative_positional:
             _unsupported('relative_positional=True')
-        self.relative_positional, self.normalize_before, self.concat_after = False, False, False
+        self.relative_positional, self.normalize_before, self.concat_after = False, normalize_before, concat_after
         self.slf_attn = MultiHeadedSelfAttention(n_heads, d_model, slf_attn_dropout)
         self.src_attn = MultiHeadedCrossAttention(n_heads, d_model, memory_dim, src_attn_dropout)
         self.feed_forward = PositionwiseFeedForward(d_model, d_ff, ffn_dropout, activation)
@@ -440,19 +472,33 @@ class TransformerDecoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
         self.norm3 = nn.LayerNorm(d_model)
         self.residual_dropout = residual_dropout
+        if concat_after:
+            self.concat_linear1 = nn.Linear(d_model * 2, d_model)
+            self.concat_linear2 = nn.Linear(d_model * 2, d_model)
 
     def forward(self, tgt, tgt_mask, memory, memory_mask, pos=None):
         """tgt_mask: the causal [B,L,L] tril mask of decoder/utils.py:7-11, or None meaning causal."""
-        p, tr = self.residual_dropout, self.training
-        l1, l2, l3 = ops.new_link(), ops.new_link(), ops.new_link()
-        if tgt_mask is None:
-            attn, _ = self.slf_attn(tgt, None, causal=True, defer_bias=True, link=l1)
+        p = self.residual_dropout if self.training else 0.0
+        pre = self.normalize_before
+        norms = (self.norm2, self.norm3) if pre else (self.norm1, self.norm2)      # the norm that closes sub-layer 1, 2
+        x = _norm(self.norm1, tgt) if pre else tgt
+
+        def run_self(**kw):
+            att, _ = self.slf_attn(x, tgt_mask, causal=tgt_mask is None, **kw)
+            return att, self.slf_attn.output_proj.bias
+        branch, bias, p1, link = _attention_branch(self, getattr(self, 'concat_linear1', None), x, p, run_self)
+        x = _post_norm(norms[0], x, branch, p1, True, bias, link)
+
+        def run_src(**kw):
+            att, _ = self.src_attn(x, memory, memory_mask, **kw)
+            return att, self.src_attn.output_proj.bias
+        branch, bias, p2, link = _attention_branch(self, getattr(self, 'concat_linear2', None), x, p, run_src)
+        x = _post_norm(norms[1], x, branch, p2, True, bias, link)
+        if pre:
+            x = ops.residual_add(x, self.feed_forward(x), 1.0, p)
         else:
-            attn, _ = self.slf_attn(tgt, tgt_mask, defer_bias=True, link=l1)
-        x = _post_norm(self.norm1, tgt, attn, p, tr, self.slf_attn.output_proj.bias, l1)
-        src, _ = self.src_attn(x, memory, memory_mask, defer_bias=True, link=l2)
-        x = _post_norm(self.norm2, x, src, p, tr, self.src_attn.output_proj.bias, l2)
-        x = _post_norm(self.norm3, x, self.feed_forward(x, defer_bias=True, link=l3), p, tr, self.feed_forward.w_2.bias, l3)
+            l3 = ops.new_link()
+            x = _post_norm(self.norm3, x, self.feed_forward(x, defer_bias=True, link=l3), p, True, self.feed_forward.w_2.bias, l3)
         return x, {'slf_attn_weights': None, 'src_attn_weights': None}
 
 
@@ -472,6 +518,8 @@ class TransformerDecoder(nn.Module):
                                     ffn_dropout, residual_dropout, normalize_before=normalize_before,
                                     concat_after=concat_after, relative_positional=False, activation=activation)
             for _ in range(n_blocks)])
+        if normalize_before:
+            self.after_norm = nn.LayerNorm(d_model)              # decoder/transformer.py:150-151
         self.output_layer = nn.Linear(d_model, vocab_size)
         if share_embedding:
             self.output_layer.weight = self.embedding.weight      # decoder/transformer.py:156-158
@@ -481,6 +529,8 @@ class TransformerDecoder(nn.Module):
         mm = memory_mask.to(torch.uint8).unsqueeze(1)
         for block in self.blocks:
             x, _ = block(x, None, memory, mm)                    # None -> causal self-attention
+        if self.normalize_before:
+            x = _norm(self.after_norm, x)
         logits = ops.linear(x, self.output_layer.weight, self.output_layer.bias)
         return logits, {}
 

@@ -249,14 +249,31 @@ class CachedBeamState:
         self.flags[0].zero_()
         self.pos[0].zero_()
 
-    def _stack_step(self, x, blk, cache, cur):
-        """self-attention sub-layer of one post-norm layer for the new position (encoder/transformer.py:54-56,
-        decoder/transformer.py:66-68)"""
+    @staticmethod
+    def _close(blk, concat_linear, norm, x, a, ctx):
+        """output projection (+ the concat_after Linear) and the add+LayerNorm that closes an attention sub-layer: norm_k of
+        a post-norm layer, norm_k+1 of a pre-norm one (nn.TransformerEncoderLayer)"""
+        att = ops.linear(ctx, a.output_proj.weight, a.output_proj.bias)
+        if blk.concat_after:
+            att = ops.linear(torch.cat((x, att), dim=-1), concat_linear.weight, concat_linear.bias)
+        return ops.add_layernorm(x, att, norm.weight, norm.bias, 0.0, norm.eps)
+
+    @staticmethod
+    def _ffn(blk, norm, x):
+        ff = blk.feed_forward(x)
+        if blk.normalize_before:
+            return ops.residual_add(x, ff, 1.0, 0.0)
+        return ops.add_layernorm(x, ff, norm.weight, norm.bias, 0.0, norm.eps)
+
+    def _stack_step(self, x, blk, cache, cur, concat_linear=None):
+        """self-attention sub-layer of one layer for the new position (encoder/transformer.py:41-56,
+        decoder/transformer.py:56-68)"""
         a = blk.slf_attn
+        if blk.normalize_before:
+            x = ops.add_layernorm(x, None, blk.norm1.weight, blk.norm1.bias, 0.0, blk.norm1.eps)
         qkv = ops.linear(x, a.qvk_proj.weight, a.qvk_proj.bias, out_dtype=ops.act_dtype())
         ctx = ops.decode_self_attention(qkv, cache[0], cache[1], self.anc[cur], self.pos[cur], a.nheads)
-        att = ops.linear(ctx, a.output_proj.weight, a.output_proj.bias)
-        return ops.add_layernorm(x, att, blk.norm1.weight, blk.norm1.bias, 0.0, blk.norm1.eps)
+        return self._close(blk, concat_linear, blk.norm2 if blk.normalize_before else blk.norm1, x, a, ctx)
 
     def step(self, cur):
         """One beam-search step (recognize/speech2text.py:95-146) reading phase `cur`, writing phase cur^1."""
@@ -266,22 +283,24 @@ class CachedBeamState:
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         x = ops.decode_embed(self.preds[cur], self.pos[cur], dec.embedding.weight)
         for blk, cache, kv in zip(dec.blocks, self.dec_cache, self.mem_kv):
-            x = self._stack_step(x, blk, cache, cur)
+            x = self._stack_step(x, blk, cache, cur, getattr(blk, 'concat_linear1', None))
             a = blk.src_attn
             q = ops.linear(x, a.q_proj.weight, a.q_proj.bias, out_dtype=adt)
             # the beam hypotheses of an utterance are the query rows of ONE attention problem over its memory
             ctx = ops.CrossAttentionFn.apply(q.view(self.b, beam, -1), kv, self.mem_mask, a.nheads)
-            att = ops.linear(ctx.view(self.R, -1), a.output_proj.weight, a.output_proj.bias)
-            x = ops.add_layernorm(x, att, blk.norm2.weight, blk.norm2.bias, 0.0, blk.norm2.eps)
-            x = ops.add_layernorm(x, blk.feed_forward(x), blk.norm3.weight, blk.norm3.bias, 0.0, blk.norm3.eps)
+            x = self._close(blk, getattr(blk, 'concat_linear2', None), blk.norm3 if blk.normalize_before else blk.norm2,
+                            x, a, ctx.view(self.R, -1))
+            x = self._ffn(blk, blk.norm3, x)
+        if dec.normalize_before:
+            x = ops.add_layernorm(x, None, dec.after_norm.weight, dec.after_norm.bias, 0.0, dec.after_norm.eps)
         logits = ops.linear(x, dec.output_layer.weight, dec.output_layer.bias)
         V = logits.size(-1)
         lm_logits = None
         if lm is not None:
             y = ops.decode_embed(self.preds[cur], self.pos[cur], lm.embedding.weight)
             for blk, cache in zip(lm.blocks, self.lm_cache):
-                y = self._stack_step(y, blk, cache, cur)
-                y = ops.add_layernorm(y, blk.feed_forward(y), blk.norm2.weight, blk.norm2.bias, 0.0, blk.norm2.eps)
+                y = self._stack_step(y, blk, cache, cur, getattr(blk, 'concat_linear', None))
+                y = self._ffn(blk, blk.norm2, y)
             lm_logits = ops.linear(y, lm.output_project.weight, lm.output_project.bias)
         L.check(lib.otr_beam_topk(_ptr(logits), V, _ptr(lm_logits), V, float(rec.lm_weight or 0.0), self.R, V, beam,
                                   _ptr(self.k_score), _ptr(self.k_idx), stream), 'otr_beam_topk')

@@ -58,6 +58,14 @@ def c1_model(residual_dropout=0.0, ctc_weight=0.0):
     return m
 
 
+def c1_variant(normalize_before, concat_after, ctc_weight=0.3):
+    """C1 with the layer variants the shipped yamls leave off (encoder/transformer.py:16-65, decoder/transformer.py:18-90)"""
+    m = c1_model(0.0, ctc_weight)
+    for part in ('encoder', 'decoder'):
+        m[part].update(normalize_before=normalize_before, concat_after=concat_after)
+    return m
+
+
 def conformer_model(small=False, residual_dropout=0.0):
     """egs/aishell/conf/conformer_baseline.yaml model section (80-d); small=True is a plumbing-size variant."""
     m = copy.deepcopy(C2_MODEL)

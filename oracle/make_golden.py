@@ -279,6 +279,23 @@ def golden_bucket():
     np.savez(os.path.join(OUT, 'data_bucket.npz'), **arrs)
 
 
+VARIANTS = {'prenorm': (True, False), 'concat': (False, True), 'prenorm_concat': (True, True)}
+
+
+def golden_variants(c1_batch=None):
+    """tests/golden/c1_<variant>.npz: the reference's pre-norm / concat_after layer variants (encoder/transformer.py:41-65,
+    decoder/transformer.py:47-90) at plumbing size -- no shipped yaml turns them on, the constructors accept them."""
+    c1_batch = c1_batch or dict(batch=4, frames=200, feat_dim=80, vocab=100, tgt_len=10, seed=0,
+                                lengths=[200, 180, 150, 97], tgt_lengths=[10, 8, 10, 5])
+    for name, (pre, cat) in VARIANTS.items():
+        full = ['encoder.blocks.1.norm1.weight', 'decoder.blocks.0.norm3.bias']
+        if pre:
+            full += ['encoder.norm.weight', 'decoder.after_norm.bias']
+        if cat:
+            full += ['encoder.blocks.0.concat_linear.weight', 'decoder.blocks.1.concat_linear2.bias']
+        golden_train('c1_%s.npz' % name, syn.c1_variant(pre, cat), c1_batch, store_full_grads=full)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -291,6 +308,7 @@ def main():
                                    'encoder.blocks.1.norm2.weight', 'assistor.output_layer.bias'))
     c1d = syn.c1_model(residual_dropout=0.0, ctc_weight=0.3)
     golden_decode('c1_decode.npz', c1d)
+    golden_variants(c1_batch)
     # full-size transformer_baseline (+80-d), tiny batch, ragged, dropout 0: pins C2 numerics
     c2 = syn.c2_model(residual_dropout=0.0)
     c2_batch = dict(batch=2, frames=1000, feat_dim=80, vocab=4234, tgt_len=15, seed=0,
@@ -312,6 +330,8 @@ if __name__ == '__main__':
         golden_data()
     elif len(sys.argv) > 1 and sys.argv[1] == 'bucket':
         golden_bucket()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'variants':
+        golden_variants()
     else:
         main()
         golden_tools()

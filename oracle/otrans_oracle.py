@@ -140,13 +140,21 @@ def _ln(sd, name, x):
 
 
 # --------------------------------------------------------------------------- encoder
+def _attn_residual(sd, concat_name, x, att):
+    """x + att, or with concat_after x + concat_linear(cat(x, att)) (encoder/transformer.py:51-54; no dropout there)"""
+    if concat_name + '.weight' in sd:
+        return x + F.linear(torch.cat((x, att), dim=-1), sd[concat_name + '.weight'], sd[concat_name + '.bias'])
+    return x + att
+
+
 def encoder_layer(sd, x, mask, h, activation, normalize_before=False):
     """TransformerEncoderLayer.forward: otrans/encoder/transformer.py:41-65 (dropout off).
 
-    The pre-norm variant takes the residual AFTER the norm (transformer.py:42-44)."""
+    The pre-norm variant takes the residual AFTER the norm (transformer.py:42-44); concat_after is on when the state
+    holds a `concat_linear`."""
     if normalize_before:
         x = _ln(sd, 'norm1', x)
-    x = x + self_attention(_sub(sd, 'slf_attn.'), x, mask, h)
+    x = _attn_residual(sd, 'concat_linear', x, self_attention(_sub(sd, 'slf_attn.'), x, mask, h))
     if not normalize_before:
         x = _ln(sd, 'norm1', x)
     if normalize_before:
@@ -236,15 +244,16 @@ def conformer_encoder(sd, x, mask, cfg, training=True):
 
 # --------------------------------------------------------------------------- decoder
 def decoder_layer(sd, x, tgt_mask, memory, memory_mask, h, activation, normalize_before=False):
-    """TransformerDecoderLayer.forward: otrans/decoder/transformer.py:47-90 (dropout off)."""
+    """TransformerDecoderLayer.forward: otrans/decoder/transformer.py:47-90 (dropout off; concat_after when the state
+    holds concat_linear1/2)."""
     if normalize_before:
         x = _ln(sd, 'norm1', x)
-    x = x + self_attention(_sub(sd, 'slf_attn.'), x, tgt_mask, h)
+    x = _attn_residual(sd, 'concat_linear1', x, self_attention(_sub(sd, 'slf_attn.'), x, tgt_mask, h))
     if not normalize_before:
         x = _ln(sd, 'norm1', x)
     if normalize_before:
         x = _ln(sd, 'norm2', x)
-    x = x + cross_attention(_sub(sd, 'src_attn.'), x, memory, memory_mask, h)
+    x = _attn_residual(sd, 'concat_linear2', x, cross_attention(_sub(sd, 'src_attn.'), x, memory, memory_mask, h))
     if not normalize_before:
         x = _ln(sd, 'norm2', x)
     if normalize_before:

@@ -70,6 +70,8 @@ def empty_state(cfg, with_ctc=None):
         ffn(e, p, d, en['d_ff'], en['activation'])
         _ln(e, p + 'norm1', d)
         _ln(e, p + 'norm2', d)
+        if en.get('concat_after', False):
+            _linear(e, p + 'concat_linear', d, 2 * d)
     if en.get('normalize_before', False):
         _ln(e, 'norm', d)
     dd = {}
@@ -85,6 +87,9 @@ def empty_state(cfg, with_ctc=None):
         ffn(dd, p, d, de['d_ff'], de['activation'])
         for n in ('norm1', 'norm2', 'norm3'):
             _ln(dd, p + n, d)
+        if de.get('concat_after', False):
+            _linear(dd, p + 'concat_linear1', d, 2 * d)
+            _linear(dd, p + 'concat_linear2', d, 2 * d)
     if de.get('normalize_before', True):
         _ln(dd, 'after_norm', d)
     if de.get('share_embedding', False):

@@ -200,6 +200,33 @@ def test_cached_decode_full_size_c5(mode):
         ops.set_compute_dtype('bf16')
 
 
+@pytest.mark.parametrize('variant', [(True, False), (False, True), (True, True)])
+def test_cached_decode_layer_variants(variant):
+    """pre-norm / concat_after decoders: the cached one-token step agrees with the re-forward loop, which itself runs the
+    training forward that tests/test_gpu_model.py pins against the reference fixture."""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops
+    from opentransformer_amd.recognize import SpeechToTextRecognizer
+    ops.set_compute_dtype('fp32')
+    try:
+        model = ota.SpeechToText(syn.c1_variant(*variant, ctc_weight=0.0))
+        syn.fill_state_dict_(model.state_dict(), 17)
+        with torch.no_grad():
+            model.decoder.output_layer.bias[1] = -30.0          # EOS never wins: decode runs max_len steps
+        model = model.to(DEV).eval()
+        inputs, _ = syn.synthetic_batch(batch=3, frames=160, feat_dim=80, vocab=100, tgt_len=5, seed=4, lengths=[160, 121, 90])
+        x, m = inputs['inputs'].to(DEV), inputs['mask'].to(DEV)
+        kw = dict(beam_width=4, nbest=4, max_len=9, penalty=0.6, lamda=5, idx2unit={i: str(i) for i in range(100)})
+        ref_h, ref_s = SpeechToTextRecognizer(model, apply_cache=False, **kw).recognize(x, m)
+        rec = SpeechToTextRecognizer(model, apply_cache=True, **kw)
+        for _ in range(2):
+            got_h, got_s = rec.recognize(x, m)
+            assert got_h == ref_h
+            np.testing.assert_allclose(got_s.numpy(), ref_s.numpy(), rtol=1e-4, atol=1e-4)
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_decode_self_attention_kernel(dtype):
     """One new query per hypothesis against a tree-structured cache (ancestor table), positions beyond one

@@ -105,6 +105,15 @@ def test_c1_bf16_matches_reference_golden(golden, report):
     run_train_case(golden('c1_train.npz'), syn.c1_model(0.0, ctc_weight=0.3), C1_BATCH, 'bf16', 1e-3, 2e-2, 5e-2, report)
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('variant', ['prenorm', 'concat', 'prenorm_concat'])
+def test_c1_layer_variants_match_reference_golden(golden, report, variant, mode):
+    """normalize_before (the reference's residual-after-norm flavour) and concat_after, encoder and decoder"""
+    pre, cat = {'prenorm': (True, False), 'concat': (False, True), 'prenorm_concat': (True, True)}[variant]
+    tol = (1e-4, 1e-4, 2e-3) if mode == 'fp32' else (1e-3, 2e-2, 5e-2)
+    run_train_case(golden('c1_%s.npz' % variant), syn.c1_variant(pre, cat), C1_BATCH, mode, *tol, report)
+
+
 def test_c2_fp32_matches_reference_golden(golden, report):
     run_train_case(golden('c2_train_b2.npz'), syn.c2_model(0.0), C2_BATCH, 'fp32', 1e-4, 2e-4, 2e-3, report)
 

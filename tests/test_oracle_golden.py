@@ -1,6 +1,7 @@
 """CPU (-m "not gpu"): pin the oracle restatement against fixtures produced by the REAL reference
 (oracle/make_golden.py).  fp32 CPU torch on both sides => tolerances are roundoff-level."""
 import numpy as np
+import pytest
 import torch
 
 from opentransformer_amd import synthetic as syn
@@ -44,6 +45,13 @@ def _check_train(g, cfg, batch_kw, rtol):
 
 def test_c1_train_matches_reference(golden):
     _check_train(golden('c1_train.npz'), syn.c1_model(0.0, ctc_weight=0.3), C1_BATCH, 2e-5)
+
+
+@pytest.mark.parametrize('variant', ['prenorm', 'concat', 'prenorm_concat'])
+def test_c1_layer_variants_match_reference(golden, variant):
+    """pre-norm (residual taken after the norm) and concat_after, encoder and decoder"""
+    pre, cat = {'prenorm': (True, False), 'concat': (False, True), 'prenorm_concat': (True, True)}[variant]
+    _check_train(golden('c1_%s.npz' % variant), syn.c1_variant(pre, cat), C1_BATCH, 2e-5)
 
 
 def test_c2_train_matches_reference(golden):
