@@ -11,7 +11,7 @@ Transformer layers come in the reference's four variants: post-norm (the shipped
 (`normalize_before=True`: the residual is taken AFTER the norm, encoder/transformer.py:42-44), each with or without
 `concat_after` (a Linear over cat(x, attention) instead of dropout(attention)).
 
-Not built yet (constructor raises NotImplementedError): relative_positional=True (transformer encoder), FFN
+Not built yet (constructor raises NotImplementedError): FFN
 activations other than 'glu'/'relu', front_end_layer_norm=True, in_channel != 1, dropout inside attention / FFN /
 frontend.  The shipped AISHELL yamls use none of these.
 """
@@ -238,10 +238,11 @@ class TransformerEncoderLayer(nn.Module):
     def __init__(self, n_heads, d_model, d_ff, slf_attn_dropout, ffn_dropout, residual_dropout,
                  normalize_before=False, concat_after=False, relative_positional=False, activation='relu'):
         super().__init__()
-        if relative_positional:
-            _unsupported('relative_positional=True')
-        self.relative_positional, self.normalize_before, self.concat_after = False, normalize_before, concat_after
-        self.slf_attn = MultiHeadedSelfAttention(n_heads, d_model, slf_attn_dropout)
+        self.relative_positional, self.normalize_before, self.concat_after = relative_positional, normalize_before, concat_after
+        if relative_positional:       # Transformer-XL style scores; as shipped this module has no output projection (a19)
+            self.slf_attn = MultiHeadedSelfAttentionWithRelPos(n_heads, d_model, slf_attn_dropout)
+        else:
+            self.slf_attn = MultiHeadedSelfAttention(n_heads, d_model, slf_attn_dropout)
         self.feed_forward = PositionwiseFeedForward(d_model, d_ff, ffn_dropout, activation)
         self.norm1 = nn.LayerNorm(d_model)
         self.norm2 = nn.LayerNorm(d_model)
@@ -256,6 +257,10 @@ class TransformerEncoderLayer(nn.Module):
             x = _norm(self.norm1, x)
 
         def run(**kw):
+            if self.relative_positional:
+                if causal:
+                    _unsupported('causal relative-positional self-attention')
+                return self.slf_attn(x, mask, pos)[0], None
             att, _ = self.slf_attn(x, mask, causal, **kw)
             return att, self.slf_attn.output_proj.bias
         branch, bias, p1, link = _attention_branch(self, getattr(self, 'concat_linear', None), x, p, run)
@@ -294,10 +299,13 @@ class TransformerEncoder(nn.Module):
             self.norm = nn.LayerNorm(d_model)               # encoder/transformer.py:111-112
 
     def forward(self, inputs, mask):
-        x, _ = self.pos_emb(inputs)
+        if self.relative_positional:                        # encoder/transformer.py:116-120: no sqrt(d) scaling, no absolute PE
+            x, pos = inputs.float(), relative_sinusoid(inputs.size(1), inputs.size(2), inputs.device)
+        else:
+            (x, _), pos = self.pos_emb(inputs), None
         km = mask.to(torch.uint8).unsqueeze(1)              # cast once; every layer's key mask is this uint8 view
         for block in self.blocks:
-            x, _ = block(x, km)
+            x, _ = block(x, km, pos)
         if self.normalize_before:
             x = _norm(self.norm, x)
         # the reference returns every layer's [B,h,T,T] weights; nothing reads them

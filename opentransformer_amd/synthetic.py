@@ -58,11 +58,12 @@ def c1_model(residual_dropout=0.0, ctc_weight=0.0):
     return m
 
 
-def c1_variant(normalize_before, concat_after, ctc_weight=0.3):
+def c1_variant(normalize_before, concat_after, ctc_weight=0.3, relative_positional=False):
     """C1 with the layer variants the shipped yamls leave off (encoder/transformer.py:16-65, decoder/transformer.py:18-90)"""
     m = c1_model(0.0, ctc_weight)
     for part in ('encoder', 'decoder'):
         m[part].update(normalize_before=normalize_before, concat_after=concat_after)
+    m['encoder']['relative_positional'] = relative_positional      # the decoder hard-wires False (decoder/transformer.py:144)
     return m
 
 

@@ -279,7 +279,8 @@ def golden_bucket():
     np.savez(os.path.join(OUT, 'data_bucket.npz'), **arrs)
 
 
-VARIANTS = {'prenorm': (True, False), 'concat': (False, True), 'prenorm_concat': (True, True)}
+VARIANTS = {'prenorm': (True, False, False), 'concat': (False, True, False), 'prenorm_concat': (True, True, False),
+            'relpos': (False, False, True), 'relpos_prenorm_concat': (True, True, True)}
 
 
 def golden_variants(c1_batch=None):
@@ -287,13 +288,15 @@ def golden_variants(c1_batch=None):
     decoder/transformer.py:47-90) at plumbing size -- no shipped yaml turns them on, the constructors accept them."""
     c1_batch = c1_batch or dict(batch=4, frames=200, feat_dim=80, vocab=100, tgt_len=10, seed=0,
                                 lengths=[200, 180, 150, 97], tgt_lengths=[10, 8, 10, 5])
-    for name, (pre, cat) in VARIANTS.items():
+    for name, (pre, cat, rel) in VARIANTS.items():
         full = ['encoder.blocks.1.norm1.weight', 'decoder.blocks.0.norm3.bias']
         if pre:
             full += ['encoder.norm.weight', 'decoder.after_norm.bias']
         if cat:
             full += ['encoder.blocks.0.concat_linear.weight', 'decoder.blocks.1.concat_linear2.bias']
-        golden_train('c1_%s.npz' % name, syn.c1_variant(pre, cat), c1_batch, store_full_grads=full)
+        if rel:
+            full += ['encoder.blocks.0.slf_attn.posu', 'encoder.blocks.1.slf_attn.pos_proj.weight']
+        golden_train('c1_%s.npz' % name, syn.c1_variant(pre, cat, relative_positional=rel), c1_batch, store_full_grads=full)
 
 
 def main():

@@ -147,14 +147,18 @@ def _attn_residual(sd, concat_name, x, att):
     return x + att
 
 
-def encoder_layer(sd, x, mask, h, activation, normalize_before=False):
+def encoder_layer(sd, x, mask, h, activation, normalize_before=False, pos=None):
     """TransformerEncoderLayer.forward: otrans/encoder/transformer.py:41-65 (dropout off).
 
     The pre-norm variant takes the residual AFTER the norm (transformer.py:42-44); concat_after is on when the state
     holds a `concat_linear`."""
     if normalize_before:
         x = _ln(sd, 'norm1', x)
-    x = _attn_residual(sd, 'concat_linear', x, self_attention(_sub(sd, 'slf_attn.'), x, mask, h))
+    if 'slf_attn.posu' in sd:       # relative_positional=True (transformer.py:23-24,47-48)
+        att = relpos_self_attention(_sub(sd, 'slf_attn.'), x, mask, pos, h)
+    else:
+        att = self_attention(_sub(sd, 'slf_attn.'), x, mask, h)
+    x = _attn_residual(sd, 'concat_linear', x, att)
     if not normalize_before:
         x = _ln(sd, 'norm1', x)
     if normalize_before:
@@ -167,11 +171,16 @@ def encoder_layer(sd, x, mask, h, activation, normalize_before=False):
 
 def transformer_encoder(sd, x, mask, cfg):
     """TransformerEncoder.forward: otrans/encoder/transformer.py:114-134."""
-    x = add_posenc(x)
+    pos = None
+    if cfg.get('relative_positional', False):       # transformer.py:116-120: raw inputs + relative sinusoid table
+        T = x.size(1)
+        pos = sinusoid(torch.arange(-(T - 1), T).reshape(1, -1), x.size(-1))
+    else:
+        x = add_posenc(x)
     nb = cfg.get('normalize_before', False)
     for i in range(cfg['n_blocks']):
         x = encoder_layer(_sub(sd, 'blocks.%d.' % i), x, mask.unsqueeze(1), cfg['n_heads'],
-                          cfg.get('activation', 'relu'), nb)
+                          cfg.get('activation', 'relu'), nb, pos)
     if nb:
         x = _ln(sd, 'norm', x)
     return x, mask

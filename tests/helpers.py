@@ -65,7 +65,13 @@ def empty_state(cfg, with_ctc=None):
             _linear(e, p + 'conv.pointwise_conv2', d, d)
     for i in range(en.get('n_blocks', 0) if cfg.get('encoder_type', 'transformer') != 'conformer' else 0):
         p = 'blocks.%d.' % i
-        _linear(e, p + 'slf_attn.output_proj', d, d)
+        if en.get('relative_positional', False):      # no output_proj: the shipped constructor bug
+            hh = en['n_heads']
+            e[p + 'slf_attn.posu'] = torch.empty(1, 1, hh, d // hh)
+            e[p + 'slf_attn.posv'] = torch.empty(1, 1, hh, d // hh)
+            _linear(e, p + 'slf_attn.pos_proj', d, d, bias=False)
+        else:
+            _linear(e, p + 'slf_attn.output_proj', d, d)
         _linear(e, p + 'slf_attn.qvk_proj', 3 * d, d)
         ffn(e, p, d, en['d_ff'], en['activation'])
         _ln(e, p + 'norm1', d)

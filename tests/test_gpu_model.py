@@ -106,12 +106,13 @@ def test_c1_bf16_matches_reference_golden(golden, report):
 
 
 @pytest.mark.parametrize('mode', ['fp32', 'bf16'])
-@pytest.mark.parametrize('variant', ['prenorm', 'concat', 'prenorm_concat'])
+@pytest.mark.parametrize('variant', ['prenorm', 'concat', 'prenorm_concat', 'relpos', 'relpos_prenorm_concat'])
 def test_c1_layer_variants_match_reference_golden(golden, report, variant, mode):
     """normalize_before (the reference's residual-after-norm flavour) and concat_after, encoder and decoder"""
-    pre, cat = {'prenorm': (True, False), 'concat': (False, True), 'prenorm_concat': (True, True)}[variant]
+    pre, cat, rel = {'prenorm': (True, False, False), 'concat': (False, True, False), 'prenorm_concat': (True, True, False),
+                     'relpos': (False, False, True), 'relpos_prenorm_concat': (True, True, True)}[variant]
     tol = (1e-4, 1e-4, 2e-3) if mode == 'fp32' else (1e-3, 2e-2, 5e-2)
-    run_train_case(golden('c1_%s.npz' % variant), syn.c1_variant(pre, cat), C1_BATCH, mode, *tol, report)
+    run_train_case(golden('c1_%s.npz' % variant), syn.c1_variant(pre, cat, relative_positional=rel), C1_BATCH, mode, *tol, report)
 
 
 def test_c2_fp32_matches_reference_golden(golden, report):

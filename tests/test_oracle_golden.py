@@ -47,11 +47,12 @@ def test_c1_train_matches_reference(golden):
     _check_train(golden('c1_train.npz'), syn.c1_model(0.0, ctc_weight=0.3), C1_BATCH, 2e-5)
 
 
-@pytest.mark.parametrize('variant', ['prenorm', 'concat', 'prenorm_concat'])
+@pytest.mark.parametrize('variant', ['prenorm', 'concat', 'prenorm_concat', 'relpos', 'relpos_prenorm_concat'])
 def test_c1_layer_variants_match_reference(golden, variant):
     """pre-norm (residual taken after the norm) and concat_after, encoder and decoder"""
-    pre, cat = {'prenorm': (True, False), 'concat': (False, True), 'prenorm_concat': (True, True)}[variant]
-    _check_train(golden('c1_%s.npz' % variant), syn.c1_variant(pre, cat), C1_BATCH, 2e-5)
+    pre, cat, rel = {'prenorm': (True, False, False), 'concat': (False, True, False), 'prenorm_concat': (True, True, False),
+                     'relpos': (False, False, True), 'relpos_prenorm_concat': (True, True, True)}[variant]
+    _check_train(golden('c1_%s.npz' % variant), syn.c1_variant(pre, cat, relative_positional=rel), C1_BATCH, 2e-5)
 
 
 def test_c2_train_matches_reference(golden):
