@@ -217,6 +217,12 @@ int32_t otr_conv2_wgrad(const otr_conv_desc_t* d, const void* dact2, const void*
 /* g = g * (y > 0) elementwise (ReLU backward through a stored post-ReLU activation); g may alias out */
 int32_t otr_relu_bwd(const void* y, const void* g, void* out, int32_t dtype, int64_t n, void* stream);
 
+/* The other FFN activations of module/ffn.py:15-21 (relu runs in the GEMM epilogue, glu has otr_glu_* / otr_ffn_glu_*):
+ * kind 1 = gelu (erf form, F.gelu's default), 2 = tanh, 3 = swish (x * sigmoid(x)).  y = act(x);  dx = dy * act'(x) from
+ * the saved pre-activation x.  f32 or bf16, n elements, 16-byte aligned buffers; dx may alias dy. */
+int32_t otr_act_fwd(const void* x, void* y, int32_t dtype, int64_t n, int32_t kind, void* stream);
+int32_t otr_act_bwd(const void* x, const void* dy, void* dx, int32_t dtype, int64_t n, int32_t kind, void* stream);
+
 /* ---- LabelSmoothingLoss (module/loss.py:21-48): logits f32 [R,V], target int64 [R].
  *      loss (f32 scalar) = sum_nonpad KL(conf || softmax) / #nonpad ; dlogits = d loss / d logits.
  *      scratch: f32[R+2] workspace (per-row losses are reduced in a fixed order: deterministic). */

@@ -109,6 +109,75 @@ extern "C" int32_t otr_relu_bwd(const void* y, const void* g, void* out, int32_t
   return otr_check_launch("relu_bwd");
 }
 
+// ------------------------------------------------------------------------------------------------ FFN activations
+// module/ffn.py:15-21 besides relu (GEMM epilogue) and glu (own kernels): gelu (erf form, F.gelu's default), tanh, swish.
+// HBM-bound: 16 bytes per lane per access; the backward recomputes from the saved pre-activation.
+enum { ACT_GELU = 1, ACT_TANH = 2, ACT_SWISH = 3 };
+template <int KIND> __device__ __forceinline__ float act_f(float x) {
+  if constexpr (KIND == ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+  else if constexpr (KIND == ACT_TANH) return tanhf(x);
+  else return x / (1.f + __expf(-x));
+}
+template <int KIND> __device__ __forceinline__ float act_df(float x) {
+  if constexpr (KIND == ACT_GELU) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+  } else if constexpr (KIND == ACT_TANH) {
+    const float t = tanhf(x);
+    return 1.f - t * t;
+  } else {
+    const float sg = 1.f / (1.f + __expf(-x));
+    return sg * (1.f + x * (1.f - sg));
+  }
+}
+template <class T, int KIND, bool BWD> __global__ void act_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, int64_t n) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const int64_t nv = n / V;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    float xv[V], gv[V], ov[V];
+    load_row<T, V>(x + i * V, V, true, xv);
+    if constexpr (BWD) load_row<T, V>(dy + i * V, V, true, gv);
+#pragma unroll
+    for (int e = 0; e < V; ++e) ov[e] = BWD ? gv[e] * act_df<KIND>(xv[e]) : act_f<KIND>(xv[e]);
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(out + i * V) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    else *reinterpret_cast<uint4*>(out + i * V) = MMA<bf16_t>::pack(ov);
+  }
+  if (blockIdx.x == 0)   // tail (n not a multiple of the vector width)
+    for (int64_t i = nv * V + threadIdx.x; i < n; i += blockDim.x) {
+      const float xe = ElemIO<T>::ld(x + i);
+      ElemIO<T>::st(out + i, BWD ? ElemIO<T>::ld(dy + i) * act_df<KIND>(xe) : act_f<KIND>(xe));
+    }
+}
+template <class T, bool BWD> static void act_launch(int kind, const void* x, const void* dy, void* out, int64_t n, hipStream_t s) {
+  const unsigned g = grid_for(n / (16 / (int)sizeof(T)) + 1);
+#define OTR_ACT(K) hipLaunchKernelGGL((act_kernel<T, K, BWD>), dim3(g), dim3(256), 0, s, (const T*)x, (const T*)dy, (T*)out, n)
+  if (kind == ACT_GELU) OTR_ACT(ACT_GELU);
+  else if (kind == ACT_TANH) OTR_ACT(ACT_TANH);
+  else OTR_ACT(ACT_SWISH);
+#undef OTR_ACT
+}
+static int32_t act_check(const char* what, const void* x, const void* out, int32_t dtype, int64_t n, int32_t kind) {
+  OTR_REQUIRE(x && out, "%s: null pointer", what);
+  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_BF16, "%s: bad dtype", what);
+  OTR_REQUIRE(kind >= ACT_GELU && kind <= ACT_SWISH, "%s: kind must be 1 (gelu), 2 (tanh) or 3 (swish)", what);
+  OTR_REQUIRE(n >= 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0, "%s: buffers must be 16-byte aligned", what);
+  return 0;
+}
+extern "C" int32_t otr_act_fwd(const void* x, void* y, int32_t dtype, int64_t n, int32_t kind, void* stream) {
+  if (int32_t e = act_check("act_fwd", x, y, dtype, n, kind)) return e;
+  if (n == 0) return 0;
+  if (dtype == OTR_F32) act_launch<float, false>(kind, x, nullptr, y, n, (hipStream_t)stream);
+  else act_launch<bf16_t, false>(kind, x, nullptr, y, n, (hipStream_t)stream);
+  return otr_check_launch("act_fwd");
+}
+extern "C" int32_t otr_act_bwd(const void* x, const void* dy, void* dx, int32_t dtype, int64_t n, int32_t kind, void* stream) {
+  if (int32_t e = act_check("act_bwd", x, dx, dtype, n, kind)) return e;
+  OTR_REQUIRE(dy && (uintptr_t)dy % 16 == 0, "act_bwd: dy must be a 16-byte aligned pointer");
+  if (n == 0) return 0;
+  if (dtype == OTR_F32) act_launch<float, true>(kind, x, dy, dx, n, (hipStream_t)stream);
+  else act_launch<bf16_t, true>(kind, x, dy, dx, n, (hipStream_t)stream);
+  return otr_check_launch("act_bwd");
+}
+
 // ------------------------------------------------------------------------------------------------ posenc / embedding
 // PE[t, 2i] = sin(t * exp(-2i ln(1e4)/d)), PE[t, 2i+1] = cos(same)        (module/pos.py:30-42)
 // (pe_value lives in common.h: the incremental decoder must produce the same bits)

@@ -11,8 +11,7 @@ Transformer layers come in the reference's four variants: post-norm (the shipped
 (`normalize_before=True`: the residual is taken AFTER the norm, encoder/transformer.py:42-44), each with or without
 `concat_after` (a Linear over cat(x, attention) instead of dropout(attention)).
 
-Not built yet (constructor raises NotImplementedError): FFN
-activations other than 'glu'/'relu', front_end_layer_norm=True, in_channel != 1, dropout inside attention / FFN /
+Not built yet (constructor raises NotImplementedError): front_end_layer_norm=True, in_channel != 1, dropout inside attention / FFN /
 frontend.  The shipped AISHELL yamls use none of these.
 """
 import math
@@ -188,8 +187,7 @@ class PositionwiseFeedForward(nn.Module):
 
     def __init__(self, d_model, d_ff, dropout, activation='relu'):
         super().__init__()
-        if activation not in ('glu', 'relu'):
-            _unsupported("FFN activation '%s' (only 'glu' and 'relu')" % activation)
+        assert activation in ('relu', 'gelu', 'glu', 'tanh', 'swish')
         if dropout:
             _unsupported('ffn_dropout > 0')
         self.activation = activation
@@ -200,7 +198,9 @@ class PositionwiseFeedForward(nn.Module):
         if self.activation == 'glu':
             return ops.FeedForwardGLUFn.apply(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias,
                                               defer_bias, ops.act_dtype() if defer_bias else torch.float32, link)
-        h = ops.linear(x, self.w_1.weight, self.w_1.bias, relu=True, out_dtype=ops.act_dtype())
+        h = ops.linear(x, self.w_1.weight, self.w_1.bias, relu=self.activation == 'relu', out_dtype=ops.act_dtype(), link=link)
+        if self.activation != 'relu':
+            h = ops.activation(h, self.activation)
         return ops.linear(h, self.w_2.weight, self.w_2.bias, defer_bias=defer_bias,
                           out_dtype=ops.act_dtype() if defer_bias else None)
 

@@ -389,6 +389,36 @@ def relu_bwd_raw(y, g):
     return out
 
 
+ACT_KINDS = {'gelu': 1, 'tanh': 2, 'swish': 3}       # otr_act_fwd / otr_act_bwd
+
+
+class ActivationFn(torch.autograd.Function):
+    """gelu / tanh / swish of module/ffn.py:15-21 on the pre-activation (relu lives in the GEMM epilogue, glu has its own path)."""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        _cuda(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        L.check(L.load().otr_act_fwd(_p(x), _p(y), _code(x.dtype), x.numel(), ACT_KINDS[kind], _stream()), 'otr_act_fwd')
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        dy = dy.contiguous().to(x.dtype)
+        dx = torch.empty_like(x)
+        L.check(L.load().otr_act_bwd(_p(x), _p(dy), _p(dx), _code(x.dtype), x.numel(), ACT_KINDS[ctx.kind], _stream()),
+                'otr_act_bwd')
+        return dx, None
+
+
+def activation(x, kind):
+    return ActivationFn.apply(x, kind)
+
+
 # ---------------------------------------------------------------------------------------- attention
 def _attn_desc(B, H, Tq, Tk, dk, dt, qs, ks, vs, os_, causal):
     return L.AttnDesc(B, H, Tq, Tk, dk, _code(dt), qs[0], qs[1], ks[0], ks[1], vs[0], vs[1], os_[0], os_[1],

@@ -67,6 +67,13 @@ def c1_variant(normalize_before, concat_after, ctc_weight=0.3, relative_position
     return m
 
 
+def c1_activations(enc_act, dec_act, ctc_weight=0.3):
+    """C1 with the FFN activations of module/ffn.py:15-21 other than the yamls' glu"""
+    m = c1_model(0.0, ctc_weight)
+    m['encoder']['activation'], m['decoder']['activation'] = enc_act, dec_act
+    return m
+
+
 def conformer_model(small=False, residual_dropout=0.0):
     """egs/aishell/conf/conformer_baseline.yaml model section (80-d); small=True is a plumbing-size variant."""
     m = copy.deepcopy(C2_MODEL)

@@ -283,6 +283,9 @@ VARIANTS = {'prenorm': (True, False, False), 'concat': (False, True, False), 'pr
             'relpos': (False, False, True), 'relpos_prenorm_concat': (True, True, True)}
 
 
+ACTIVATION_CASES = [('gelu', 'swish'), ('tanh', 'relu')]
+
+
 def golden_variants(c1_batch=None):
     """tests/golden/c1_<variant>.npz: the reference's pre-norm / concat_after layer variants (encoder/transformer.py:41-65,
     decoder/transformer.py:47-90) at plumbing size -- no shipped yaml turns them on, the constructors accept them."""
@@ -297,6 +300,9 @@ def golden_variants(c1_batch=None):
         if rel:
             full += ['encoder.blocks.0.slf_attn.posu', 'encoder.blocks.1.slf_attn.pos_proj.weight']
         golden_train('c1_%s.npz' % name, syn.c1_variant(pre, cat, relative_positional=rel), c1_batch, store_full_grads=full)
+    for enc_act, dec_act in ACTIVATION_CASES:
+        golden_train('c1_act_%s_%s.npz' % (enc_act, dec_act), syn.c1_activations(enc_act, dec_act), c1_batch,
+                     store_full_grads=['encoder.blocks.0.feed_forward.w_1.weight', 'decoder.blocks.1.feed_forward.w_1.bias'])
 
 
 def main():

@@ -115,6 +115,14 @@ def test_c1_layer_variants_match_reference_golden(golden, report, variant, mode)
     run_train_case(golden('c1_%s.npz' % variant), syn.c1_variant(pre, cat, relative_positional=rel), C1_BATCH, mode, *tol, report)
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('acts', [('gelu', 'swish'), ('tanh', 'relu')])
+def test_c1_ffn_activations_match_reference_golden(golden, report, acts, mode):
+    """module/ffn.py:15-21: gelu / tanh / swish through otr_act_fwd/bwd, relu in the GEMM epilogue"""
+    tol = (1e-4, 1e-4, 2e-3) if mode == 'fp32' else (1e-3, 2e-2, 5e-2)
+    run_train_case(golden('c1_act_%s_%s.npz' % acts), syn.c1_activations(*acts), C1_BATCH, mode, *tol, report)
+
+
 def test_c2_fp32_matches_reference_golden(golden, report):
     run_train_case(golden('c2_train_b2.npz'), syn.c2_model(0.0), C2_BATCH, 'fp32', 1e-4, 2e-4, 2e-3, report)
 

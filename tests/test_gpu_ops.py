@@ -412,6 +412,26 @@ def test_residual_add_dropout():
     assert bool(((da != 0) == kept).all())
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('kind', ['gelu', 'tanh', 'swish'])
+def test_ffn_activation_kernels(kind, dtype):
+    """otr_act_fwd / otr_act_bwd vs torch (erf gelu, tanh, x*sigmoid(x)); n = 8k + 3 exercises the scalar tail"""
+    from opentransformer_amd import ops
+    ref = {'gelu': torch.nn.functional.gelu, 'tanh': torch.tanh, 'swish': lambda t: t * torch.sigmoid(t)}[kind]
+    torch.manual_seed(0)
+    x = (3 * torch.randn(37, 1003, device=DEV)).to(dtype).requires_grad_(True)
+    dy = torch.randn(37, 1003, device=DEV).to(dtype)
+    y = ops.activation(x, kind)
+    y.backward(dy)
+    xr = x.detach().float().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(dy.float())
+    tol = 2e-6 if dtype == torch.float32 else 1e-2
+    assert y.dtype == dtype and x.grad.dtype == dtype
+    assert (y.float() - yr).abs().max().item() <= tol * max(1.0, yr.abs().max().item())
+    assert (x.grad.float() - xr.grad).abs().max().item() <= tol * max(1.0, xr.grad.abs().max().item())
+
+
 def test_transpose_batched():
     """one launch transposes a list of ragged 2-D matrices packed in a flat buffer (bf16 weight shadows)"""
     import ctypes as C

@@ -55,6 +55,11 @@ def test_c1_layer_variants_match_reference(golden, variant):
     _check_train(golden('c1_%s.npz' % variant), syn.c1_variant(pre, cat, relative_positional=rel), C1_BATCH, 2e-5)
 
 
+@pytest.mark.parametrize('acts', [('gelu', 'swish'), ('tanh', 'relu')])
+def test_c1_ffn_activations_match_reference(golden, acts):
+    _check_train(golden('c1_act_%s_%s.npz' % acts), syn.c1_activations(*acts), C1_BATCH, 2e-5)
+
+
 def test_c2_train_matches_reference(golden):
     _check_train(golden('c2_train_b2.npz'), syn.c2_model(0.0), C2_BATCH, 5e-5)
 
