@@ -11,7 +11,7 @@ Transformer layers come in the reference's four variants: post-norm (the shipped
 (`normalize_before=True`: the residual is taken AFTER the norm, encoder/transformer.py:42-44), each with or without
 `concat_after` (a Linear over cat(x, attention) instead of dropout(attention)).
 
-Not built yet (constructor raises NotImplementedError): front_end_layer_norm=True, in_channel != 1, dropout inside attention / FFN /
+Not built yet (constructor raises NotImplementedError): in_channel != 1, dropout inside attention / FFN /
 frontend.  The shipped AISHELL yamls use none of these.
 """
 import math
@@ -60,8 +60,6 @@ class ConvFrontEnd(nn.Module):
         super().__init__()
         if in_channel != 1:
             _unsupported('ConvFrontEnd in_channel != 1')
-        if front_end_layer_norm:
-            _unsupported('front_end_layer_norm')
         if dropout != 0.0:
             _unsupported('ConvFrontEnd dropout > 0')
         self.kernel_size, self.stride, self.output_size = kernel_size, stride, output_size
@@ -70,6 +68,8 @@ class ConvFrontEnd(nn.Module):
         self.conv2 = Conv2dLayer(self.conv1.output_size, mid_channel, out_channel, kernel_size[1], stride[1], dropout)
         self.conv_output_size = self.conv2.output_size * out_channel
         self.output_layer = nn.Linear(self.conv_output_size, output_size)
+        if front_end_layer_norm:
+            self.layer_norm = nn.LayerNorm(output_size)           # frontend/conv.py:128-129,150-151
 
     def forward(self, x, mask):
         c1, c2 = self.conv1.conv_layer, self.conv2.conv_layer
@@ -79,6 +79,8 @@ class ConvFrontEnd(nn.Module):
         t1 = (x.size(1) - 3) // 2 + 1
         mask = Conv2dLayer.return_output_mask(mask, t1)
         mask = Conv2dLayer.return_output_mask(mask, act2.size(1))
+        if self.front_end_layer_norm:
+            y = ops.add_layernorm(y, None, self.layer_norm.weight, self.layer_norm.bias, 0.0, self.layer_norm.eps)
         return y, mask
 
     def inference(self, x, mask, cache):
@@ -120,14 +122,12 @@ class MultiHeadedSelfAttention(nn.Module):
 
     def __init__(self, n_heads, d_model, dropout_rate=0.0, share_qvk_proj=False):
         super().__init__()
-        if share_qvk_proj:
-            _unsupported('share_qvk_proj')
         if dropout_rate:
             _unsupported('attention dropout > 0')
         self.d_model, self.nheads, self.d_k = d_model, n_heads, d_model // n_heads
         self.share_qvk_proj = share_qvk_proj
         self.output_proj = nn.Linear(d_model, d_model)
-        self.qvk_proj = nn.Linear(d_model, d_model * 3)
+        self.qvk_proj = nn.Linear(d_model, d_model if share_qvk_proj else d_model * 3)
 
     def context(self, x, mask, causal=False, link=None):
         """softmax(QK^T/sqrt(dk)) V merged over heads, before output_proj (act dtype)."""
@@ -138,6 +138,8 @@ class MultiHeadedSelfAttention(nn.Module):
                 _unsupported('arbitrary [B,T,T] attention masks (only key masks and the causal mask)')
             mask, causal = None, True
         qkv = ops.linear(x, self.qvk_proj.weight, self.qvk_proj.bias, out_dtype=ops.act_dtype(), link=link)
+        if self.share_qvk_proj:          # query = key = value = the one projection (module/attention.py:71-72); rare: packed by copy
+            qkv = torch.cat((qkv, qkv, qkv), dim=-1)
         return ops.SelfAttentionFn.apply(qkv, _key_mask(mask, B, T), self.nheads, causal)
 
     def forward(self, x, mask, causal=False, defer_bias=False, link=None):
@@ -159,20 +161,21 @@ class MultiHeadedCrossAttention(nn.Module):
 
     def __init__(self, n_heads, d_model, memory_dim, dropout_rate=0.0, share_vk_proj=False):
         super().__init__()
-        if share_vk_proj:
-            _unsupported('share_vk_proj')
         if dropout_rate:
             _unsupported('attention dropout > 0')
         self.d_model, self.nheads, self.d_k = d_model, n_heads, d_model // n_heads
+        self.share_vk_proj = share_vk_proj
         self.output_proj = nn.Linear(d_model, d_model)
         self.q_proj = nn.Linear(d_model, d_model)
-        self.vk_proj = nn.Linear(memory_dim, d_model * 2)
+        self.vk_proj = nn.Linear(memory_dim, d_model if share_vk_proj else d_model * 2)
 
     def forward(self, query, memory, memory_mask, defer_bias=False, link=None):
         B, T, _ = memory.shape
         adt = ops.act_dtype()
         q = ops.linear(query, self.q_proj.weight, self.q_proj.bias, out_dtype=adt, link=link)
         kv = ops.linear(memory, self.vk_proj.weight, self.vk_proj.bias, out_dtype=adt)
+        if self.share_vk_proj:           # key = value (module/attention.py:131-132)
+            kv = torch.cat((kv, kv), dim=-1)
         ctx = ops.CrossAttentionFn.apply(q, kv, _key_mask(memory_mask, B, T), self.nheads)
         return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, defer_bias=defer_bias,
                           out_dtype=ops.act_dtype() if defer_bias else None), None

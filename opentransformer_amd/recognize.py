@@ -241,7 +241,8 @@ class CachedBeamState:
         adt = ops.act_dtype()
         for blk, kv in zip(self.rec.model.decoder.blocks, self.mem_kv):
             a = blk.src_attn
-            kv.copy_(ops.linear(memory, a.vk_proj.weight, a.vk_proj.bias, out_dtype=adt))
+            m_kv = ops.linear(memory, a.vk_proj.weight, a.vk_proj.bias, out_dtype=adt)
+            kv.copy_(torch.cat((m_kv, m_kv), dim=-1) if a.share_vk_proj else m_kv)
         self.mem_mask.copy_(memory_mask.reshape(self.b, self.Tm))
         self.preds[0].fill_(EOS)
         self.preds[0][:, 0] = BOS
@@ -272,6 +273,8 @@ class CachedBeamState:
         if blk.normalize_before:
             x = ops.add_layernorm(x, None, blk.norm1.weight, blk.norm1.bias, 0.0, blk.norm1.eps)
         qkv = ops.linear(x, a.qvk_proj.weight, a.qvk_proj.bias, out_dtype=ops.act_dtype())
+        if a.share_qvk_proj:
+            qkv = torch.cat((qkv, qkv, qkv), dim=-1)
         ctx = ops.decode_self_attention(qkv, cache[0], cache[1], self.anc[cur], self.pos[cur], a.nheads)
         return self._close(blk, concat_linear, blk.norm2 if blk.normalize_before else blk.norm1, x, a, ctx)
 

@@ -67,6 +67,13 @@ def c1_variant(normalize_before, concat_after, ctc_weight=0.3, relative_position
     return m
 
 
+def c1_frontend_ln(ctc_weight=0.3):
+    """C1 with front_end_layer_norm=True (frontend/conv.py:128-129)"""
+    m = c1_model(0.0, ctc_weight)
+    m['frontend']['front_end_layer_norm'] = True
+    return m
+
+
 def c1_activations(enc_act, dec_act, ctc_weight=0.3):
     """C1 with the FFN activations of module/ffn.py:15-21 other than the yamls' glu"""
     m = c1_model(0.0, ctc_weight)

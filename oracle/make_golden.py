@@ -283,6 +283,34 @@ VARIANTS = {'prenorm': (True, False, False), 'concat': (False, True, False), 'pr
             'relpos': (False, False, True), 'relpos_prenorm_concat': (True, True, True)}
 
 
+def golden_shared_projections():
+    """tests/golden/modules_shared.npz: MultiHeadedSelfAttention(share_qvk_proj=True) and
+    MultiHeadedCrossAttention(share_vk_proj=True) (module/attention.py:49-145) -- options no encoder/decoder constructor passes
+    on, so they are pinned at module level: seeded weights and inputs, outputs and all gradients."""
+    from otrans.module.attention import MultiHeadedSelfAttention, MultiHeadedCrossAttention
+    from tests.test_gpu_ops import shared_projection_inputs
+    x, mem, xmask, mmask, dy = shared_projection_inputs()
+    out = {}
+    sa = MultiHeadedSelfAttention(4, 64, 0.0, share_qvk_proj=True)
+    ca = MultiHeadedCrossAttention(4, 64, 48, 0.0, share_vk_proj=True)
+    syn.fill_state_dict_(sa.state_dict(), 31)
+    syn.fill_state_dict_(ca.state_dict(), 32)
+    xs = x.clone().requires_grad_(True)
+    y, _ = sa(xs, xmask.unsqueeze(1))
+    y.backward(dy)
+    out['sa_y'], out['sa_dx'] = y.detach().numpy(), xs.grad.numpy()
+    for k, p in sa.named_parameters():
+        out['sa_grad:' + k] = p.grad.numpy()
+    xq, ms = x.clone().requires_grad_(True), mem.clone().requires_grad_(True)
+    y, _ = ca(xq, ms, mmask.unsqueeze(1))
+    y.backward(dy)
+    out['ca_y'], out['ca_dq'], out['ca_dmem'] = y.detach().numpy(), xq.grad.numpy(), ms.grad.numpy()
+    for k, p in ca.named_parameters():
+        out['ca_grad:' + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'modules_shared.npz'), **out)
+    print('modules_shared.npz', {k: v.shape for k, v in out.items() if not k.startswith(('sa_grad', 'ca_grad'))})
+
+
 ACTIVATION_CASES = [('gelu', 'swish'), ('tanh', 'relu')]
 
 
@@ -300,6 +328,9 @@ def golden_variants(c1_batch=None):
         if rel:
             full += ['encoder.blocks.0.slf_attn.posu', 'encoder.blocks.1.slf_attn.pos_proj.weight']
         golden_train('c1_%s.npz' % name, syn.c1_variant(pre, cat, relative_positional=rel), c1_batch, store_full_grads=full)
+    golden_train('c1_frontend_ln.npz', syn.c1_frontend_ln(), c1_batch,
+                 store_full_grads=['frontend.layer_norm.weight', 'frontend.output_layer.bias'])
+    golden_shared_projections()
     for enc_act, dec_act in ACTIVATION_CASES:
         golden_train('c1_act_%s_%s.npz' % (enc_act, dec_act), syn.c1_activations(enc_act, dec_act), c1_batch,
                      store_full_grads=['encoder.blocks.0.feed_forward.w_1.weight', 'decoder.blocks.1.feed_forward.w_1.bias'])

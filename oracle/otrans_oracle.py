@@ -57,6 +57,8 @@ def conv_frontend(sd, x, mask):
     b, c, t, f = x.shape
     x = x.permute(0, 2, 1, 3).reshape(b, t, c * f)
     x = F.linear(x, sd['output_layer.weight'], sd['output_layer.bias'])
+    if 'layer_norm.weight' in sd:            # front_end_layer_norm=True (conv.py:128-129,150-151)
+        x = F.layer_norm(x, (x.size(-1),), sd['layer_norm.weight'], sd['layer_norm.bias'], 1e-5)
     return x, mask
 
 
@@ -99,7 +101,8 @@ def self_attention(sd, x, mask, h):
 
     qvk_proj rows are ordered q,k,v (attention.py:73); mask [B,1|T,T]."""
     d = x.size(-1)
-    q, k, v = torch.split(F.linear(x, sd['qvk_proj.weight'], sd['qvk_proj.bias']), d, dim=-1)
+    y = F.linear(x, sd['qvk_proj.weight'], sd['qvk_proj.bias'])
+    q, k, v = (y, y, y) if y.size(-1) == d else torch.split(y, d, dim=-1)      # share_qvk_proj (attention.py:71-72)
     q, k, v = _heads(q, h), _heads(k, h), _heads(v, h)
     scores = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(d // h)
     return _context(sd, v, scores, mask.unsqueeze(1) if mask is not None else None)
@@ -111,7 +114,8 @@ def cross_attention(sd, x, memory, memory_mask, h):
     vk_proj rows are ordered k,v (attention.py:134)."""
     d = x.size(-1)
     q = F.linear(x, sd['q_proj.weight'], sd['q_proj.bias'])
-    k, v = torch.split(F.linear(memory, sd['vk_proj.weight'], sd['vk_proj.bias']), d, dim=-1)
+    m = F.linear(memory, sd['vk_proj.weight'], sd['vk_proj.bias'])
+    k, v = (m, m) if m.size(-1) == d else torch.split(m, d, dim=-1)              # share_vk_proj (attention.py:131-132)
     q, k, v = _heads(q, h), _heads(k, h), _heads(v, h)
     scores = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(d // h)
     return _context(sd, v, scores, memory_mask.unsqueeze(1))

@@ -35,6 +35,8 @@ def empty_state(cfg, with_ctc=None):
          'conv2.conv_layer.weight': torch.empty(fe['out_channel'], fe['mid_channel'], 3, 3),
          'conv2.conv_layer.bias': torch.empty(fe['out_channel'])}
     _linear(f, 'output_layer', fe['output_size'], fe['out_channel'] * F2)
+    if fe.get('front_end_layer_norm', False):
+        _ln(f, 'layer_norm', fe['output_size'])
 
     def ffn(sd, p, d, dff, act):
         _linear(sd, p + 'feed_forward.w_1', dff * 2 if act == 'glu' else dff, d)

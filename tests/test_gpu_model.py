@@ -123,6 +123,12 @@ def test_c1_ffn_activations_match_reference_golden(golden, report, acts, mode):
     run_train_case(golden('c1_act_%s_%s.npz' % acts), syn.c1_activations(*acts), C1_BATCH, mode, *tol, report)
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_c1_frontend_layer_norm_matches_reference_golden(golden, report, mode):
+    tol = (1e-4, 1e-4, 2e-3) if mode == 'fp32' else (1e-3, 2e-2, 5e-2)
+    run_train_case(golden('c1_frontend_ln.npz'), syn.c1_frontend_ln(), C1_BATCH, mode, *tol, report)
+
+
 def test_c2_fp32_matches_reference_golden(golden, report):
     run_train_case(golden('c2_train_b2.npz'), syn.c2_model(0.0), C2_BATCH, 'fp32', 1e-4, 2e-4, 2e-3, report)
 

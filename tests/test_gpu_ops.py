@@ -432,6 +432,53 @@ def test_ffn_activation_kernels(kind, dtype):
     assert (x.grad.float() - xr.grad).abs().max().item() <= tol * max(1.0, xr.grad.abs().max().item())
 
 
+def shared_projection_inputs():
+    """seeded CPU inputs shared with oracle/make_golden.py:golden_shared_projections"""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(3, 21, 64, generator=g)
+    mem = torch.randn(3, 50, 48, generator=g)
+    xmask = torch.arange(21).unsqueeze(0) < torch.tensor([21, 17, 9]).unsqueeze(1)
+    mmask = torch.arange(50).unsqueeze(0) < torch.tensor([50, 33, 41]).unsqueeze(1)
+    dy = torch.randn(3, 21, 64, generator=g)
+    return x, mem, xmask, mmask, dy
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_shared_qvk_and_vk_projections_match_reference(golden, mode):
+    """share_qvk_proj / share_vk_proj (module/attention.py:71-72,131-132): query = key = value = one projection"""
+    from opentransformer_amd import ops, nn as onn
+    from opentransformer_amd import synthetic as syn
+    gz = golden('modules_shared.npz')
+    g = {k: torch.from_numpy(gz[k]) for k in gz.files}
+    x, mem, xmask, mmask, dy = shared_projection_inputs()
+    tol = 2e-4 if mode == 'fp32' else 4e-2
+    ops.set_compute_dtype(mode)
+    try:
+        sa = onn.MultiHeadedSelfAttention(4, 64, 0.0, share_qvk_proj=True)
+        ca = onn.MultiHeadedCrossAttention(4, 64, 48, 0.0, share_vk_proj=True)
+        syn.fill_state_dict_(sa.state_dict(), 31)
+        syn.fill_state_dict_(ca.state_dict(), 32)
+        sa, ca = sa.to(DEV), ca.to(DEV)
+        valid = xmask
+        xs = x.to(DEV).requires_grad_(True)
+        y, _ = sa(xs, xmask.to(DEV).unsqueeze(1))
+        y.float().backward(dy.to(DEV))
+        assert rel(y.detach().float().cpu()[valid], g['sa_y'][valid]) < tol
+        # padded query rows see real keys: their dy flows into dk/dv in the reference as well
+        assert rel(xs.grad.cpu(), g['sa_dx']) < tol
+        for k, p in sa.named_parameters():
+            assert rel(p.grad.cpu(), g['sa_grad:' + k]) < tol, k
+        xq, ms = x.to(DEV).requires_grad_(True), mem.to(DEV).requires_grad_(True)
+        y, _ = ca(xq, ms, mmask.to(DEV).unsqueeze(1))
+        y.float().backward(dy.to(DEV))
+        assert rel(y.detach().float().cpu(), g['ca_y']) < tol
+        assert rel(xq.grad.cpu(), g['ca_dq']) < tol and rel(ms.grad.cpu(), g['ca_dmem']) < tol
+        for k, p in ca.named_parameters():
+            assert rel(p.grad.cpu(), g['ca_grad:' + k]) < tol, k
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
 def test_transpose_batched():
     """one launch transposes a list of ragged 2-D matrices packed in a flat buffer (bf16 weight shadows)"""
     import ctypes as C

@@ -60,6 +60,40 @@ def test_c1_ffn_activations_match_reference(golden, acts):
     _check_train(golden('c1_act_%s_%s.npz' % acts), syn.c1_activations(*acts), C1_BATCH, 2e-5)
 
 
+def test_c1_frontend_layer_norm_matches_reference(golden):
+    _check_train(golden('c1_frontend_ln.npz'), syn.c1_frontend_ln(), C1_BATCH, 2e-5)
+
+
+def test_shared_projection_modules_match_reference(golden):
+    """share_qvk_proj / share_vk_proj restated in the oracle (module/attention.py:71-72,131-132)"""
+    from tests.test_gpu_ops import shared_projection_inputs
+    g = golden('modules_shared.npz')
+    x, mem, xmask, mmask, dy = shared_projection_inputs()
+    sa = {'qvk_proj.weight': torch.empty(64, 64), 'qvk_proj.bias': torch.empty(64),
+          'output_proj.weight': torch.empty(64, 64), 'output_proj.bias': torch.empty(64)}
+    ca = {'q_proj.weight': torch.empty(64, 64), 'q_proj.bias': torch.empty(64), 'vk_proj.weight': torch.empty(64, 48),
+          'vk_proj.bias': torch.empty(64), 'output_proj.weight': torch.empty(64, 64), 'output_proj.bias': torch.empty(64)}
+    syn.fill_state_dict_(sa, 31)
+    syn.fill_state_dict_(ca, 32)
+    for sd in (sa, ca):
+        for v in sd.values():
+            v.requires_grad_(True)
+    xs = x.clone().requires_grad_(True)
+    y = orc.self_attention(sa, xs, xmask.unsqueeze(1), 4)
+    y.backward(dy)
+    np.testing.assert_allclose(y.detach().numpy(), g['sa_y'], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(xs.grad.numpy(), g['sa_dx'], rtol=2e-4, atol=2e-5)
+    for k, v in sa.items():
+        np.testing.assert_allclose(v.grad.numpy(), g['sa_grad:' + k], rtol=2e-4, atol=2e-4)
+    xq, ms = x.clone().requires_grad_(True), mem.clone().requires_grad_(True)
+    y = orc.cross_attention(ca, xq, ms, mmask.unsqueeze(1), 4)
+    y.backward(dy)
+    np.testing.assert_allclose(y.detach().numpy(), g['ca_y'], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(ms.grad.numpy(), g['ca_dmem'], rtol=2e-4, atol=2e-5)
+    for k, v in ca.items():
+        np.testing.assert_allclose(v.grad.numpy(), g['ca_grad:' + k], rtol=2e-4, atol=2e-4)
+
+
 def test_c2_train_matches_reference(golden):
     _check_train(golden('c2_train_b2.npz'), syn.c2_model(0.0), C2_BATCH, 5e-5)
 
