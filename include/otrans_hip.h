@@ -247,13 +247,16 @@ int32_t otr_add2_strided(const void* a, int64_t lda, const void* b, int64_t ldb,
                          int64_t M, int32_t cols, void* stream);
 /* out = x where mask[row] else 0 (f32) */
 int32_t otr_row_mask(const float* x, const uint8_t* mask, float* out, int64_t M, int32_t C, void* stream);
-/* depthwise Conv1d over time (k odd <= 7, zero pad (k-1)/2), channel-last: y f32 [B,T,C]; stats f32 [2C] (may be
- * NULL) receives per-channel sum / sum of squares of y over all B*T rows (BatchNorm batch statistics) */
+/* depthwise Conv1d over time, channel-last, per utterance, zero padded:
+ *   y[b,t,c] = bias[c] + sum_{j<k} w[c,j] * g[b, t + j - pad, c]          k <= 7, 0 <= pad < k
+ * pad = (k-1)/2 is the Conformer's 'same' convolution (module/conformer.py:26-28); pad = 0 with k = lookahead_steps + 1 is
+ * the CTC head's look-ahead convolution (model/ctc.py:17-24,35-39: right-padded, no bias).  y f32 [B,T,C]; stats f32 [2C]
+ * (may be NULL) receives per-channel sum / sum of squares of y over all B*T rows (BatchNorm batch statistics) */
 int32_t otr_dwconv_fwd(const void* g, int32_t dtype, const float* w, const float* bias, float* y, float* stats,
-                       int32_t B, int32_t T, int32_t C, int32_t k, void* stream);
+                       int32_t B, int32_t T, int32_t C, int32_t k, int32_t pad, void* stream);
 /* dg (dtype), dw f32 [C,k] +=, db f32 [C] += (may be NULL) */
 int32_t otr_dwconv_bwd(const float* dy, const void* g, int32_t dtype, const float* w, void* dg, float* dw, float* db,
-                       int32_t B, int32_t T, int32_t C, int32_t k, void* stream);
+                       int32_t B, int32_t T, int32_t C, int32_t k, int32_t pad, void* stream);
 /* BatchNorm1d (training: batch statistics from `stats`, running stats updated in place; eval: running stats) fused
  * with swish; saved f32 [2C] = mean | rstd for backward */
 int32_t otr_bn_swish_fwd(const float* y, const float* stats, const float* gamma, const float* beta, float* running_mean,

@@ -107,8 +107,8 @@ SIGNATURES = {
     'otr_head_bias_add': [_P, _I64, _P, _P, _P, _I32, _I64, _I32, _P],
     'otr_add2_strided': [_P, _I64, _P, _I64, _P, _I64, _I32, _I64, _I32, _P],
     'otr_row_mask': [_P, _P, _P, _I64, _I32, _P],
-    'otr_dwconv_fwd': [_P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
-    'otr_dwconv_bwd': [_P, _P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
+    'otr_dwconv_fwd': [_P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
+    'otr_dwconv_bwd': [_P, _P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
     'otr_bn_swish_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _F32, _F32, _I32, _P],
     'otr_bn_swish_bwd': [_P, _P, _I32, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
 }

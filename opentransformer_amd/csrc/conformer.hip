@@ -159,7 +159,7 @@ extern "C" int32_t otr_row_mask(const float* x, const uint8_t* mask, float* out,
 struct DwArgs {
   const void* g; const float* w; const float* b; float* y; float* stats;
   const float* dy; void* dg; float* dw; float* db;
-  int B, T, C, k;
+  int B, T, C, k, pad;   // pad = taps left of the output position ((k-1)/2: 'same' conv; 0: look-ahead conv)
 };
 
 // Thread layout of the depthwise-conv kernels: 256 threads = DW_NY row phases x (C/4 <= 256/DW_NY) channel groups;
@@ -174,7 +174,7 @@ constexpr int DW_RPB = 64;
 // stats[c] += sum y, stats[C + c] += sum y^2   over ALL B*T positions (the reference's BatchNorm1d sees padded frames)
 template <class T, int KT> __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwArgs p, int NY) {
   extern __shared__ float dw_red[];                       // [NY][C][2]
-  const int C4 = p.C / 4, pad = (p.k - 1) / 2;
+  const int C4 = p.C / 4, pad = p.pad;
   const int64_t M = (int64_t)p.B * p.T;
   const int64_t r0 = (int64_t)blockIdx.x * DW_RPB, r1 = min(M, r0 + DW_RPB);
   const T* g = reinterpret_cast<const T*>(p.g);
@@ -229,7 +229,7 @@ template <class T, int KT> __global__ __launch_bounds__(256) void dwconv_fwd_ker
 // dg[b,t,c] = sum_j w[c,j] * dy[b, t - j + pad, c];  dw[c,j] += sum dy[b,t,c] g[b,t+j-pad,c];  db[c] += sum dy
 template <class T, int KT> __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwArgs p, int NY) {
   extern __shared__ float dw_red[];                       // [NY][C][k+1]
-  const int C4 = p.C / 4, pad = (p.k - 1) / 2, K1 = p.k + 1;
+  const int C4 = p.C / 4, pad = p.pad, K1 = p.k + 1;
   const int64_t M = (int64_t)p.B * p.T;
   const int64_t r0 = (int64_t)blockIdx.x * DW_RPB, r1 = min(M, r0 + DW_RPB);
   const T* g = reinterpret_cast<const T*>(p.g);
@@ -287,16 +287,17 @@ template <class T, int KT> __global__ __launch_bounds__(256) void dwconv_bwd_ker
   }
 }
 
-static int32_t dw_check(int B, int T, int C, int k) {
+static int32_t dw_check(int B, int T, int C, int k, int pad) {
   OTR_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 1024, "dwconv: bad shape B=%d T=%d C=%d (C % 4 == 0, C <= 1024)", B, T, C);
-  OTR_REQUIRE(k >= 1 && k <= 7 && (k & 1), "dwconv: kernel size %d must be odd and <= 7", k);
+  OTR_REQUIRE(k >= 1 && k <= 7, "dwconv: kernel size %d must be in 1..7", k);
+  OTR_REQUIRE(pad >= 0 && pad < k, "dwconv: pad %d must be in [0, k)", pad);
   return 0;
 }
 extern "C" int32_t otr_dwconv_fwd(const void* g, int32_t dtype, const float* w, const float* bias, float* y, float* stats,
-                                  int32_t B, int32_t T, int32_t C, int32_t k, void* stream) {
-  if (int32_t e = dw_check(B, T, C, k)) return e;
+                                  int32_t B, int32_t T, int32_t C, int32_t k, int32_t pad, void* stream) {
+  if (int32_t e = dw_check(B, T, C, k, pad)) return e;
   OTR_REQUIRE(g && w && y, "dwconv_fwd: null pointer");
-  DwArgs p{}; p.g = g; p.w = w; p.b = bias; p.y = y; p.stats = stats; p.B = B; p.T = T; p.C = C; p.k = k;
+  DwArgs p{}; p.g = g; p.w = w; p.b = bias; p.y = y; p.stats = stats; p.B = B; p.T = T; p.C = C; p.k = k; p.pad = pad;
   hipStream_t s = (hipStream_t)stream;
   if (stats) otr_zero_f32(stats, 2 * C, s);
   const int NY = 256 / (C / 4);
@@ -311,10 +312,10 @@ extern "C" int32_t otr_dwconv_fwd(const void* g, int32_t dtype, const float* w, 
   return otr_check_launch("dwconv_fwd");
 }
 extern "C" int32_t otr_dwconv_bwd(const float* dy, const void* g, int32_t dtype, const float* w, void* dg, float* dw, float* db,
-                                  int32_t B, int32_t T, int32_t C, int32_t k, void* stream) {
-  if (int32_t e = dw_check(B, T, C, k)) return e;
+                                  int32_t B, int32_t T, int32_t C, int32_t k, int32_t pad, void* stream) {
+  if (int32_t e = dw_check(B, T, C, k, pad)) return e;
   OTR_REQUIRE(dy && g && w && dg && dw, "dwconv_bwd: null pointer");
-  DwArgs p{}; p.dy = dy; p.g = g; p.w = w; p.dg = dg; p.dw = dw; p.db = db; p.B = B; p.T = T; p.C = C; p.k = k;
+  DwArgs p{}; p.dy = dy; p.g = g; p.w = w; p.dg = dg; p.dw = dw; p.db = db; p.B = B; p.T = T; p.C = C; p.k = k; p.pad = pad;
   hipStream_t s = (hipStream_t)stream;
   const int NY = 256 / (C / 4);
   const dim3 grid((unsigned)(((int64_t)B * T + DW_RPB - 1) / DW_RPB));

@@ -17,16 +17,22 @@ class CTCAssistor(nn.Module):
 
     def __init__(self, hidden_size, vocab_size, blank=BLK, lookahead_steps=-1):
         super().__init__()
-        if lookahead_steps > 0:
-            _unsupported('CTCAssistor lookahead_steps > 0')
-        self.lookahead_steps, self.apply_look_ahead, self.blank = lookahead_steps, False, blank
+        self.lookahead_steps, self.apply_look_ahead, self.blank = lookahead_steps, lookahead_steps > 0, blank
+        if self.apply_look_ahead:
+            if lookahead_steps > 6 or hidden_size % 4:
+                _unsupported('CTCAssistor lookahead_steps > 6 (the depthwise-conv kernels hold at most 7 taps)')
+            self.lookahead_conv = nn.Conv1d(hidden_size, hidden_size, lookahead_steps + 1, padding=0, stride=1, bias=False,
+                                            groups=hidden_size)         # parameter container only (model/ctc.py:17-24)
         self.output_layer = nn.Linear(hidden_size, vocab_size)
+
+    def _look_ahead(self, memory):
+        return ops.LookaheadConvFn.apply(memory, self.lookahead_conv.weight) if self.apply_look_ahead else memory
 
     def compute_logits(self, enc_states):
         return ops.linear(enc_states, self.output_layer.weight, self.output_layer.bias)
 
     def forward(self, memory, memory_length=None, targets=None, tgt_length=None, return_logits=False):
-        logits = self.compute_logits(memory)
+        logits = self.compute_logits(self._look_ahead(memory))
         if return_logits:
             return logits
         return self.compute_loss(logits, memory_length, targets, tgt_length)
@@ -35,7 +41,7 @@ class CTCAssistor(nn.Module):
         return ops.CTCLossFn.apply(logits, targets, enc_length, targets_length, self.blank)
 
     def inference(self, memory, memory_mask):
-        logits = self.compute_logits(memory)
+        logits = self.compute_logits(self._look_ahead(memory))
         memory_length = torch.sum(memory_mask.squeeze(1) if memory_mask.dim() == 3 else memory_mask, dim=-1)
         return ops.log_softmax(logits), memory_length
 

@@ -1006,7 +1006,7 @@ class ConformerConvFn(torch.autograd.Function):
         wk = wdw.reshape(Cc, k).contiguous()
         y = torch.empty((M, Cc), dtype=torch.float32, device=x.device)
         stats = torch.empty((2 * Cc,), dtype=torch.float32, device=x.device) if training else None
-        L.check(lib.otr_dwconv_fwd(_p(g), _code(adt), _p(wk), _p(bdw), _p(y), _p(stats), B, T, Cc, k, _stream()),
+        L.check(lib.otr_dwconv_fwd(_p(g), _code(adt), _p(wk), _p(bdw), _p(y), _p(stats), B, T, Cc, k, (k - 1) // 2, _stream()),
                 'otr_dwconv_fwd')
         saved = torch.empty((2 * Cc,), dtype=torch.float32, device=x.device)
         s = torch.empty((M, Cc), dtype=adt, device=x.device)
@@ -1040,7 +1040,7 @@ class ConformerConvFn(torch.autograd.Function):
         dg = torch.empty((M, Cc), dtype=adt, device=dout.device)
         dwk = torch.zeros((Cc * k + Cc,), dtype=torch.float32, device=dout.device)
         L.check(lib.otr_dwconv_bwd(_p(dy), _p(g), _code(adt), _p(wk), _p(dg), _p(dwk), _p(dwk, Cc * k), B, T, Cc, k,
-                                   _stream()), 'otr_dwconv_bwd')
+                                   (k - 1) // 2, _stream()), 'otr_dwconv_bwd')
         dh = torch.empty_like(h)
         nblk = (M + GLU_RPB - 1) // GLU_RPB
         part = torch.empty((nblk, 2 * Cc), dtype=torch.float32, device=dout.device)
@@ -1051,6 +1051,37 @@ class ConformerConvFn(torch.autograd.Function):
         return (dx, None, None if gw1 is not None else dw1, None if gb1 is not None else db1, dwk[:Cc * k].view(wdw_shape),
                 dwk[Cc * k:] if has_dwb else None, red[Cc:], red[:Cc], None, None, None if gw2 is not None else dw2,
                 None if gb2 is not None else db2, None, None, None)
+
+
+class LookaheadConvFn(torch.autograd.Function):
+    """The CTC head's look-ahead convolution (model/ctc.py:35-39): y[b,t,c] = sum_{j<=L} w[c,0,j] x[b,t+j,c], zeros past
+    the end of the (padded) batch, no bias -- the depthwise-conv kernels with pad = 0."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _cuda(x, w)
+        B, T, Cc = x.shape
+        k = w.shape[-1]
+        x2 = x.contiguous()
+        wk = w.reshape(Cc, k).contiguous().float()
+        y = torch.empty((B, T, Cc), dtype=torch.float32, device=x.device)
+        L.check(L.load().otr_dwconv_fwd(_p(x2), _code(x2.dtype), _p(wk), None, _p(y), None, B, T, Cc, k, 0, _stream()),
+                'otr_dwconv_fwd')
+        ctx.save_for_backward(x2, wk)
+        ctx.wshape = w.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wk = ctx.saved_tensors
+        B, T, Cc = x2.shape
+        k = wk.shape[1]
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(x2)
+        dw = torch.zeros((Cc * k,), dtype=torch.float32, device=dy.device)
+        L.check(L.load().otr_dwconv_bwd(_p(dy), _p(x2), _code(x2.dtype), _p(wk), _p(dx), _p(dw), None, B, T, Cc, k, 0,
+                                        _stream()), 'otr_dwconv_bwd')
+        return dx, dw.view(ctx.wshape)
 
 
 # ---------------------------------------------------------------------------------------- losses

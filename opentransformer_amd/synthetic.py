@@ -67,6 +67,13 @@ def c1_variant(normalize_before, concat_after, ctc_weight=0.3, relative_position
     return m
 
 
+def c1_lookahead(steps, ctc_weight=0.3):
+    """C1 with the CTC head's look-ahead convolution (model/ctc.py:17-24; yaml key `lookahead_steps`)"""
+    m = c1_model(0.0, ctc_weight)
+    m['lookahead_steps'] = steps
+    return m
+
+
 def c1_frontend_ln(ctc_weight=0.3):
     """C1 with front_end_layer_norm=True (frontend/conv.py:128-129)"""
     m = c1_model(0.0, ctc_weight)

@@ -330,6 +330,9 @@ def golden_variants(c1_batch=None):
         golden_train('c1_%s.npz' % name, syn.c1_variant(pre, cat, relative_positional=rel), c1_batch, store_full_grads=full)
     golden_train('c1_frontend_ln.npz', syn.c1_frontend_ln(), c1_batch,
                  store_full_grads=['frontend.layer_norm.weight', 'frontend.output_layer.bias'])
+    for steps in (2, 5):
+        golden_train('c1_lookahead%d.npz' % steps, syn.c1_lookahead(steps), c1_batch,
+                     store_full_grads=['assistor.lookahead_conv.weight', 'assistor.output_layer.bias'])
     golden_shared_projections()
     for enc_act, dec_act in ACTIVATION_CASES:
         golden_train('c1_act_%s_%s.npz' % (enc_act, dec_act), syn.c1_activations(enc_act, dec_act), c1_batch,

@@ -348,6 +348,16 @@ def ctc_nll(log_probs, targets, in_len, tgt_len, blank=BLK):
     return torch.stack(out)
 
 
+def ctc_look_ahead(sd_ctc, memory):
+    """CTCAssistor look-ahead (model/ctc.py:17-24,35-39): right-pad lookahead_steps zero frames, depthwise Conv1d with
+    kernel lookahead_steps + 1, no bias.  Identity when the head has no lookahead_conv."""
+    if 'lookahead_conv.weight' not in sd_ctc:
+        return memory
+    w = sd_ctc['lookahead_conv.weight']                    # [C, 1, L+1]
+    x = F.pad(memory, (0, 0, 0, w.size(-1) - 1)).transpose(1, 2)
+    return F.conv1d(x, w, None, 1, 0, 1, w.size(0)).transpose(1, 2)
+
+
 def ctc_loss(logits, in_len, targets, tgt_len):
     """CTCAssistor.compute_loss: otrans/model/ctc.py:50-53 with nn.CTCLoss(blank=0,
     zero_infinity=True), default reduction 'mean' = mean_b(nll_b / clamp(tgt_len_b,1))."""
@@ -374,7 +384,7 @@ def speech2text_forward(sd, params, inputs, targets):
     aux = {'logits': logits, 'memory': memory, 'memory_mask': memory_mask}
     w = params.get('ctc_weight', 0.0)
     if w > 0:
-        ctc_logits = F.linear(memory, sd['ctc']['output_layer.weight'], sd['ctc']['output_layer.bias'])
+        ctc_logits = F.linear(ctc_look_ahead(sd['ctc'], memory), sd['ctc']['output_layer.weight'], sd['ctc']['output_layer.bias'])
         lctc = ctc_loss(ctc_logits, memory_mask.sum(-1), target_out, targets['targets_length'])
         aux['ctc_loss'] = lctc
         loss = (1 - w) * loss + w * lctc
@@ -383,7 +393,7 @@ def speech2text_forward(sd, params, inputs, targets):
 
 def ctc_inference(sd_ctc, memory, memory_mask):
     """CTCAssistor.inference (no look-ahead): otrans/model/ctc.py:55-66."""
-    logits = F.linear(memory, sd_ctc['output_layer.weight'], sd_ctc['output_layer.bias'])
+    logits = F.linear(ctc_look_ahead(sd_ctc, memory), sd_ctc['output_layer.weight'], sd_ctc['output_layer.bias'])
     return F.log_softmax(logits, dim=-1), memory_mask.sum(-1)
 
 

@@ -109,6 +109,8 @@ def empty_state(cfg, with_ctc=None):
     if with_ctc or (with_ctc is None and cfg.get('ctc_weight', 0.0) > 0):
         c = {}
         _linear(c, 'output_layer', de['vocab_size'], cfg['encoder_output_size'])
+        if cfg.get('lookahead_steps', 0) > 0:
+            c['lookahead_conv.weight'] = torch.empty(cfg['encoder_output_size'], 1, cfg['lookahead_steps'] + 1)
         out['ctc'] = c
     return out
 

@@ -124,6 +124,25 @@ def test_c1_ffn_activations_match_reference_golden(golden, report, acts, mode):
 
 
 @pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('steps', [2, 5])
+def test_c1_ctc_lookahead_matches_reference_golden(golden, report, steps, mode):
+    """model/ctc.py:17-24,35-39: the look-ahead depthwise convolution in front of the CTC projection (train + inference)"""
+    from opentransformer_amd import ops
+    g = golden('c1_lookahead%d.npz' % steps)
+    tol = (1e-4, 1e-4, 2e-3) if mode == 'fp32' else (1e-3, 2e-2, 5e-2)
+    run_train_case(g, syn.c1_lookahead(steps), C1_BATCH, mode, *tol, report)
+    ops.set_compute_dtype(mode)
+    try:
+        model = build(syn.c1_lookahead(steps))
+        lp, ln = model.assistor.inference(torch.from_numpy(g['memory']).to(DEV), torch.from_numpy(g['fe_mask']).to(DEV))
+        assert np.array_equal(ln.cpu().numpy(), g['ctc_len'])
+        valid = g['fe_mask'].astype(bool)
+        assert rel(lp.float().cpu().numpy()[valid], g['ctc_log_probs'][valid]) < (1e-4 if mode == 'fp32' else 2e-2)
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
 def test_c1_frontend_layer_norm_matches_reference_golden(golden, report, mode):
     tol = (1e-4, 1e-4, 2e-3) if mode == 'fp32' else (1e-3, 2e-2, 5e-2)
     run_train_case(golden('c1_frontend_ln.npz'), syn.c1_frontend_ln(), C1_BATCH, mode, *tol, report)

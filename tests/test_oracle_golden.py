@@ -60,6 +60,17 @@ def test_c1_ffn_activations_match_reference(golden, acts):
     _check_train(golden('c1_act_%s_%s.npz' % acts), syn.c1_activations(*acts), C1_BATCH, 2e-5)
 
 
+@pytest.mark.parametrize('steps', [2, 5])
+def test_c1_ctc_lookahead_matches_reference(golden, steps):
+    g = golden('c1_lookahead%d.npz' % steps)
+    cfg = syn.c1_lookahead(steps)
+    _check_train(g, cfg, C1_BATCH, 2e-5)
+    parts = H.filled_state(cfg)
+    lp, ln = orc.ctc_inference(parts['ctc'], torch.from_numpy(g['memory']), torch.from_numpy(g['fe_mask']))
+    np.testing.assert_allclose(lp.numpy(), g['ctc_log_probs'], rtol=2e-5, atol=2e-5)
+    assert np.array_equal(ln.numpy(), g['ctc_len'])
+
+
 def test_c1_frontend_layer_norm_matches_reference(golden):
     _check_train(golden('c1_frontend_ln.npz'), syn.c1_frontend_ln(), C1_BATCH, 2e-5)
 
