@@ -555,16 +555,19 @@ class TransformerDecoder(nn.Module):
 
 # ------------------------------------------------------------------------------------- losses / heads
 class LabelSmoothingLoss(nn.Module):
-    """module/loss.py:12-48 (mask argument of the reference is never passed by the model)."""
+    """module/loss.py:12-48.  `mask` (True = leave the position out, on top of target == PAD) and normalize_length=False
+    (divide by all B*L positions instead of the counted ones) are folded into the one kernel's inputs / result."""
 
     def __init__(self, size, smoothing=0.1, padding_idx=PAD, normalize_length=True):
         super().__init__()
-        if not normalize_length:
-            _unsupported('normalize_length=False')
-        self.size, self.smoothing, self.padding_idx, self.normalize_length = size, smoothing, padding_idx, True
+        self.size, self.smoothing, self.padding_idx, self.normalize_length = size, smoothing, padding_idx, normalize_length
 
     def forward(self, logits, target, mask=None):
-        if mask is not None:
-            _unsupported('LabelSmoothingLoss extra mask')
         assert logits.dim() == 3 and logits.size(-1) == self.size
+        if mask is not None:          # a masked row contributes nothing, exactly like a PAD row (loss.py:31-35,45-46)
+            target = target.masked_fill(mask.bool(), self.padding_idx)
+        if not self.normalize_length:
+            loss = ops.LabelSmoothingLossFn.apply(logits.float(), target, float(self.smoothing), int(self.padding_idx))
+            kept = (target != self.padding_idx).sum().to(loss.dtype)
+            return loss * (kept / target.numel())
         return ops.LabelSmoothingLossFn.apply(logits.float(), target, float(self.smoothing), int(self.padding_idx))

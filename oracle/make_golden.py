@@ -311,6 +311,23 @@ def golden_shared_projections():
     print('modules_shared.npz', {k: v.shape for k, v in out.items() if not k.startswith(('sa_grad', 'ca_grad'))})
 
 
+def golden_loss_options():
+    """tests/golden/module_loss.npz: LabelSmoothingLoss (module/loss.py:12-48) with its `mask` argument and
+    normalize_length=False -- options the model never uses, pinned at module level."""
+    from otrans.module.loss import LabelSmoothingLoss
+    from tests.test_gpu_ops import loss_option_inputs
+    logits, target, mask = loss_option_inputs()
+    out = {}
+    for name, (use_mask, norm) in LOSS_CASES.items():
+        lg = logits.clone().requires_grad_(True)
+        loss = LabelSmoothingLoss(logits.size(-1), 0.1, normalize_length=norm)(lg, target, mask if use_mask else None)
+        loss.backward()
+        out[name + '_loss'], out[name + '_grad'] = loss.detach().numpy(), lg.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'module_loss.npz'), **out)
+    print('module_loss.npz', {k: float(v) for k, v in out.items() if k.endswith('_loss')})
+
+
+LOSS_CASES = {'mask': (True, True), 'sum': (False, False), 'mask_sum': (True, False)}
 ACTIVATION_CASES = [('gelu', 'swish'), ('tanh', 'relu')]
 
 
@@ -334,6 +351,7 @@ def golden_variants(c1_batch=None):
         golden_train('c1_lookahead%d.npz' % steps, syn.c1_lookahead(steps), c1_batch,
                      store_full_grads=['assistor.lookahead_conv.weight', 'assistor.output_layer.bias'])
     golden_shared_projections()
+    golden_loss_options()
     for enc_act, dec_act in ACTIVATION_CASES:
         golden_train('c1_act_%s_%s.npz' % (enc_act, dec_act), syn.c1_activations(enc_act, dec_act), c1_batch,
                      store_full_grads=['encoder.blocks.0.feed_forward.w_1.weight', 'decoder.blocks.1.feed_forward.w_1.bias'])

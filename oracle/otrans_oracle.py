@@ -300,10 +300,11 @@ def decoder_inference(sd, preds, memory, memory_mask, cfg):
 
 
 # --------------------------------------------------------------------------- losses
-def label_smoothing_loss(logits, target, smoothing, padding_idx=PAD):
+def label_smoothing_loss(logits, target, smoothing, padding_idx=PAD, mask=None, normalize_length=True):
     """LabelSmoothingLoss.forward: otrans/module/loss.py:21-48.
 
-    Off-target mass eps/(V-1); rows with target==PAD zeroed; divided by #non-pad."""
+    Off-target mass eps/(V-1); rows with target==PAD (or mask True) zeroed; divided by the number of rows kept, or by all
+    rows when normalize_length is False."""
     V = logits.size(-1)
     logits = logits.reshape(-1, V)
     tgt = target.reshape(-1)
@@ -312,7 +313,10 @@ def label_smoothing_loss(logits, target, smoothing, padding_idx=PAD):
     logp = F.log_softmax(logits, dim=-1)
     row = torch.sum(conf * (torch.log(conf) - logp), dim=-1)
     pad = tgt == padding_idx
-    return torch.sum(row.masked_fill(pad, 0.0)) / torch.sum(~pad)
+    if mask is not None:
+        pad = pad | mask.reshape(-1).bool()
+    denom = torch.sum(~pad) if normalize_length else logits.size(0)
+    return torch.sum(row.masked_fill(pad, 0.0)) / denom
 
 
 def ctc_nll(log_probs, targets, in_len, tgt_len, blank=BLK):

@@ -479,6 +479,30 @@ def test_shared_qvk_and_vk_projections_match_reference(golden, mode):
         ops.set_compute_dtype('bf16')
 
 
+def loss_option_inputs():
+    """seeded CPU inputs shared with oracle/make_golden.py:golden_loss_options"""
+    g = torch.Generator().manual_seed(91)
+    logits = 2 * torch.randn(3, 9, 57, generator=g)
+    target = torch.randint(1, 57, (3, 9), generator=g)
+    target[0, 7:] = 0
+    target[2, 4:] = 0
+    mask = torch.rand(3, 9, generator=g) < 0.3
+    return logits, target, mask
+
+
+def test_label_smoothing_mask_and_sum_normalisation(golden):
+    """LabelSmoothingLoss(mask=..., normalize_length=False): module/loss.py:31-35,43-46"""
+    from opentransformer_amd import nn as onn
+    g = golden('module_loss.npz')
+    logits, target, mask = loss_option_inputs()
+    for name, (use_mask, norm) in {'mask': (True, True), 'sum': (False, False), 'mask_sum': (True, False)}.items():
+        lg = logits.to(DEV).requires_grad_(True)
+        loss = onn.LabelSmoothingLoss(57, 0.1, normalize_length=norm)(lg, target.to(DEV), mask.to(DEV) if use_mask else None)
+        loss.backward()
+        assert abs(loss.item() - float(g[name + '_loss'])) < 1e-5 * abs(float(g[name + '_loss'])), name
+        assert rel(lg.grad.cpu(), torch.from_numpy(g[name + '_grad'])) < 1e-5, name
+
+
 def test_transpose_batched():
     """one launch transposes a list of ragged 2-D matrices packed in a flat buffer (bf16 weight shadows)"""
     import ctypes as C

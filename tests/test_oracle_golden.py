@@ -71,6 +71,18 @@ def test_c1_ctc_lookahead_matches_reference(golden, steps):
     assert np.array_equal(ln.numpy(), g['ctc_len'])
 
 
+def test_label_smoothing_options_match_reference(golden):
+    from tests.test_gpu_ops import loss_option_inputs
+    g = golden('module_loss.npz')
+    logits, target, mask = loss_option_inputs()
+    for name, (use_mask, norm) in {'mask': (True, True), 'sum': (False, False), 'mask_sum': (True, False)}.items():
+        lg = logits.clone().requires_grad_(True)
+        loss = orc.label_smoothing_loss(lg, target, 0.1, mask=mask if use_mask else None, normalize_length=norm)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), float(g[name + '_loss']), rtol=2e-6)
+        np.testing.assert_allclose(lg.grad.numpy(), g[name + '_grad'], rtol=2e-5, atol=1e-7)
+
+
 def test_c1_frontend_layer_norm_matches_reference(golden):
     _check_train(golden('c1_frontend_ln.npz'), syn.c1_frontend_ln(), C1_BATCH, 2e-5)
 
