@@ -311,6 +311,42 @@ def golden_shared_projections():
     print('modules_shared.npz', {k: v.shape for k, v in out.items() if not k.startswith(('sa_grad', 'ca_grad'))})
 
 
+def golden_optimizer():
+    """tests/golden/optimizer_steps.npz: the trainer's update (train/trainer.py:221-234: clip_grad_norm_(5.0), NaN guard,
+    scheduler.step(), optimizer.step(), zero_grad) with the reference's TransformerScheduler (train/scheduler.py:16-53,
+    129-138) driving torch.optim.Adam(betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6) (transformer_baseline.yaml:82-88),
+    on seeded parameters and gradients.  Step 2 has a huge gradient (clipped), step 4 a NaN gradient (skipped)."""
+    import importlib.util
+    import math
+    spec = importlib.util.spec_from_file_location('ref_scheduler', '/root/reference/otrans/train/scheduler.py')
+    sch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sch)
+    from tests.test_gpu_ops import optimizer_inputs
+    shapes, params, grads, hp = optimizer_inputs()
+    ps = [torch.nn.Parameter(p.clone()) for p in params]
+    opt = sch.BuildOptimizer['adam'](ps, lr=hp['lr'], betas=hp['betas'], eps=hp['eps'], weight_decay=hp['weight_decay'])
+    scheduler = sch.TransformerScheduler(opt, hp['model_size'], hp['warmup_steps'], hp['factor'])
+    out = {'lr0': np.float64(scheduler.lr if scheduler.lr is not None else np.nan), 'global_step0': scheduler.global_step}
+    lrs, norms, skipped = [], [], []
+    for step, gs in enumerate(grads):
+        for p, g in zip(ps, gs):
+            p.grad = g.clone()
+        grad_norm = torch.nn.utils.clip_grad_norm_(ps, hp['clip'])
+        if math.isnan(grad_norm):
+            skipped.append(1)
+        else:
+            skipped.append(0)
+            scheduler.step()
+            opt.step()
+        opt.zero_grad()
+        lrs.append(opt.param_groups[0]['lr'])
+        norms.append(float(grad_norm))
+        out['params_%d' % step] = np.concatenate([p.detach().reshape(-1).numpy() for p in ps])
+    out.update(lr=np.asarray(lrs, np.float64), grad_norm=np.asarray(norms, np.float64), skipped=np.asarray(skipped))
+    np.savez_compressed(os.path.join(OUT, 'optimizer_steps.npz'), **out)
+    print('optimizer_steps.npz lr', lrs, 'norm', norms, 'skipped', skipped, 'init', out['lr0'], out['global_step0'])
+
+
 def golden_loss_options():
     """tests/golden/module_loss.npz: LabelSmoothingLoss (module/loss.py:12-48) with its `mask` argument and
     normalize_length=False -- options the model never uses, pinned at module level."""
@@ -352,6 +388,7 @@ def golden_variants(c1_batch=None):
                      store_full_grads=['assistor.lookahead_conv.weight', 'assistor.output_layer.bias'])
     golden_shared_projections()
     golden_loss_options()
+    golden_optimizer()
     for enc_act, dec_act in ACTIVATION_CASES:
         golden_train('c1_act_%s_%s.npz' % (enc_act, dec_act), syn.c1_activations(enc_act, dec_act), c1_batch,
                      store_full_grads=['encoder.blocks.0.feed_forward.w_1.weight', 'decoder.blocks.1.feed_forward.w_1.bias'])
@@ -393,6 +430,8 @@ if __name__ == '__main__':
         golden_bucket()
     elif len(sys.argv) > 1 and sys.argv[1] == 'variants':
         golden_variants()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'optimizer':
+        golden_optimizer()
     else:
         main()
         golden_tools()

@@ -508,3 +508,45 @@ def dp_mean_loss_grads(sd_flat_params, loss_fn, shards):
                                          for a, b in zip(grads, g)]
     n = len(shards)
     return torch.stack(losses).mean(), [None if g is None else g / n for g in grads]
+
+
+# --------------------------------------------------------------------------- optimizer update (trainer core)
+def noam_lr(step, model_size, warmup_steps, factor=1.0):
+    """TransformerScheduler.get_step_lr: otrans/train/scheduler.py:137-138."""
+    return factor * model_size ** (-0.5) * min(step ** (-0.5), step * warmup_steps ** (-1.5))
+
+
+class TrainerUpdate:
+    """One parameter update of Trainer.train_one_epoch (otrans/train/trainer.py:221-234) with the baseline's Adam + Noam
+    schedule (transformer_baseline.yaml:82-93): grad_norm = clip_grad_norm_(params, clip); a NaN norm skips BOTH
+    scheduler.step() and optimizer.step(); Adam is torch.optim.Adam with L2 weight decay (added to the gradient).
+
+    Scheduler quirk (scheduler.py:16-53): BaseScheduler starts at global_step 1 and initial_lr() already calls step()
+    once, so the first real update is evaluated at global_step 3."""
+
+    def __init__(self, params, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6, clip=5.0, model_size=256, warmup_steps=12000,
+                 factor=1.0):
+        self.params = params
+        self.b1, self.b2, self.eps, self.wd, self.clip = betas[0], betas[1], eps, weight_decay, clip
+        self.noam = (model_size, warmup_steps, factor)
+        self.global_step, self.t, self.lr = 2, 0, None
+        self.m = [torch.zeros_like(p) for p in params]
+        self.v = [torch.zeros_like(p) for p in params]
+
+    def step(self, grads):
+        """grads: one tensor per parameter.  Returns (grad_norm, skipped)."""
+        norm = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+        if torch.isnan(norm):
+            return float(norm), True
+        coef = torch.clamp(self.clip / (norm + 1e-6), max=1.0)
+        self.global_step += 1
+        self.lr = noam_lr(self.global_step, *self.noam)
+        self.t += 1
+        bc1, bc2 = 1 - self.b1 ** self.t, 1 - self.b2 ** self.t
+        with torch.no_grad():
+            for p, g, m, v in zip(self.params, grads, self.m, self.v):
+                g = g * coef + self.wd * p
+                m.mul_(self.b1).add_(g, alpha=1 - self.b1)
+                v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+                p.addcdiv_(m, v.sqrt() / math.sqrt(bc2) + self.eps, value=-self.lr / bc1)
+        return float(norm), False

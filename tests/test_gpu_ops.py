@@ -503,6 +503,60 @@ def test_label_smoothing_mask_and_sum_normalisation(golden):
         assert rel(lg.grad.cpu(), torch.from_numpy(g[name + '_grad'])) < 1e-5, name
 
 
+def optimizer_inputs():
+    """seeded parameters / per-step gradients shared with oracle/make_golden.py:golden_optimizer.  Step 2 carries a huge
+    gradient (clipped to norm 5), step 4 a NaN (the update is skipped and the schedule does not advance)."""
+    g = torch.Generator().manual_seed(123)
+    shapes = [(37, 64), (64,), (5, 3, 3), (130,)]
+    params = [0.3 * torch.randn(*sh, generator=g) for sh in shapes]
+    grads = []
+    for step in range(7):
+        scale = 400.0 if step == 2 else 0.05
+        gs = [scale * torch.randn(*sh, generator=g) for sh in shapes]
+        if step == 4:
+            gs[1][7] = float('nan')
+        grads.append(gs)
+    hp = dict(lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6, clip=5.0, model_size=256, warmup_steps=4, factor=1.0)
+    return shapes, params, grads, hp
+
+
+@pytest.mark.parametrize('world', [1, 4])
+def test_fused_optimizer_step_matches_reference(golden, world):
+    """otr_optimizer_step (clip + NaN guard + Noam + Adam with L2 decay over the flat buffers) against the reference's
+    TransformerScheduler + torch.optim.Adam loop (train/trainer.py:221-234); world > 1: gradients arrive as a sum over
+    ranks and 1/world is folded into the update (grad_scale)."""
+    from opentransformer_amd import ops
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+    g = golden('optimizer_steps.npz')
+    shapes, params, grads, hp = optimizer_inputs()
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ps = torch.nn.ParameterList([torch.nn.Parameter(p.clone().to(DEV)) for p in params])
+
+    try:
+        dp = FlatDataParallel(Holder())
+        opt = FusedAdam(dp, lr=hp['lr'], betas=hp['betas'], eps=hp['eps'], weight_decay=hp['weight_decay'], clip_grad=hp['clip'],
+                        noam=dict(model_size=hp['model_size'], warmup_steps=hp['warmup_steps'], factor=hp['factor']))
+        for step, gs in enumerate(grads):
+            for p, gr in zip(dp.params, gs):
+                p.grad.copy_(gr.to(DEV) * world)
+            opt.step(grad_scale=1.0 / world)
+            st = opt.stats()
+            got = torch.cat([p.detach().reshape(-1) for p in dp.params]).cpu()
+            want = torch.from_numpy(g['params_%d' % step])
+            assert rel(got, want) < 5e-6, (step, rel(got, want))
+            assert abs(st['lr'] - float(g['lr'][step])) <= 1e-6 * float(g['lr'][step]), (step, st['lr'], g['lr'][step])
+            assert int(st['skipped']) == int(g['skipped'][:step + 1].sum()), (step, st)
+            if not g['skipped'][step]:
+                assert abs(st['grad_sqnorm'] ** 0.5 / world - float(g['grad_norm'][step])) <= 2e-5 * float(g['grad_norm'][step])
+            if dp.flat_param_lp is not None:      # the bf16 shadow is refreshed in the same pass
+                assert torch.equal(dp.flat_param_lp.float().cpu(), dp.flat_param.to(torch.bfloat16).float().cpu())
+    finally:
+        ops.defer_weight_grads(False)
+
+
 def test_transpose_batched():
     """one launch transposes a list of ragged 2-D matrices packed in a flat buffer (bf16 weight shadows)"""
     import ctypes as C

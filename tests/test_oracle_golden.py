@@ -71,6 +71,24 @@ def test_c1_ctc_lookahead_matches_reference(golden, steps):
     assert np.array_equal(ln.numpy(), g['ctc_len'])
 
 
+def test_trainer_update_matches_reference(golden):
+    """clip + NaN guard + Noam + Adam restated in the oracle vs the reference's scheduler + torch.optim.Adam loop"""
+    from tests.test_gpu_ops import optimizer_inputs
+    g = golden('optimizer_steps.npz')
+    shapes, params, grads, hp = optimizer_inputs()
+    assert int(g['global_step0']) == 2 and np.isnan(float(g['lr0']))       # the constructor quirk the oracle hard-codes
+    ps = [p.clone() for p in params]
+    upd = orc.TrainerUpdate(ps, hp['betas'], hp['eps'], hp['weight_decay'], hp['clip'], hp['model_size'], hp['warmup_steps'],
+                            hp['factor'])
+    for step, gs in enumerate(grads):
+        norm, skipped = upd.step(gs)
+        assert skipped == bool(g['skipped'][step])
+        if not skipped:
+            np.testing.assert_allclose(norm, g['grad_norm'][step], rtol=1e-6)
+        np.testing.assert_allclose(upd.lr, g['lr'][step], rtol=1e-12)
+        np.testing.assert_allclose(torch.cat([p.reshape(-1) for p in ps]).numpy(), g['params_%d' % step], rtol=2e-5, atol=2e-7)
+
+
 def test_label_smoothing_options_match_reference(golden):
     from tests.test_gpu_ops import loss_option_inputs
     g = golden('module_loss.npz')
