@@ -535,6 +535,7 @@ def test_fused_optimizer_step_matches_reference(golden, world):
             super().__init__()
             self.ps = torch.nn.ParameterList([torch.nn.Parameter(p.clone().to(DEV)) for p in params])
 
+    deferral = ops._wq['on']
     try:
         dp = FlatDataParallel(Holder())
         opt = FusedAdam(dp, lr=hp['lr'], betas=hp['betas'], eps=hp['eps'], weight_decay=hp['weight_decay'], clip_grad=hp['clip'],
@@ -554,7 +555,7 @@ def test_fused_optimizer_step_matches_reference(golden, world):
             if dp.flat_param_lp is not None:      # the bf16 shadow is refreshed in the same pass
                 assert torch.equal(dp.flat_param_lp.float().cpu(), dp.flat_param.to(torch.bfloat16).float().cpu())
     finally:
-        ops.defer_weight_grads(False)
+        ops.defer_weight_grads(deferral)
 
 
 def test_transpose_batched():
