@@ -188,7 +188,7 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with ops.graph_capture(graph):
                 fwd_bwd()
         except Exception as e:                                # noqa: BLE001
             if rank == 0:

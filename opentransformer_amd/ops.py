@@ -10,7 +10,9 @@ Precision policy (set_compute_dtype):
           activations and the FFN hidden are stored bf16.
   'fp32': exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) everywhere, all activations fp32 -- parity mode.
 """
+import contextlib
 import ctypes as C
+import gc
 import os
 import math
 
@@ -19,6 +21,24 @@ import torch
 from . import _lib as L
 
 _state = {'compute': 'bf16', 'rng_offset': 0, 'seed': None}
+
+
+@contextlib.contextmanager
+def graph_capture(graph, **kw):
+    """`torch.cuda.graph(graph)` with Python's cyclic garbage collector parked.  A collection that fires while a stream
+    is capturing can finalize ANOTHER CUDAGraph (or tensors of its private pool) that sat in a dead reference cycle; the
+    hipGraphExecDestroy / hipFree inside that finalizer is illegal during capture and aborts the process (seen in a
+    sequential pytest run; torch >= 2.10 no longer collects on entry).  So: collect first, keep the collector off until
+    the capture has ended."""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, **kw):
+            yield graph
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def set_compute_dtype(name):

@@ -14,6 +14,7 @@ Same constructor arguments and return values as the reference recognizers.  Two 
   (decoder + LM + scoring + pruning).  Hypotheses are identical to the re-forward loop.
 """
 import ctypes as C
+import weakref
 
 import torch
 import torch.nn as nn
@@ -207,7 +208,7 @@ class CachedBeamState:
     cross-attention K/V, and the two captured step graphs (even / odd ping-pong phase)."""
 
     def __init__(self, rec, b, Tm, dev):
-        self.rec, self.b, self.Tm, self.dev = rec, b, Tm, dev
+        self.rec, self.b, self.Tm, self.dev = weakref.proxy(rec), b, Tm, dev     # no rec <-> state cycle: graphs die with rec
         dec, lm = rec.model.decoder, rec.lm
         beam = rec.beam_width
         R = self.R = b * beam
@@ -323,7 +324,7 @@ class CachedBeamState:
             self.warm[cur] = True
             return self.step(cur)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with ops.graph_capture(g):
             self.step(cur)
         self.graphs[cur] = g
         g.replay()

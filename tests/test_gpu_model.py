@@ -245,7 +245,7 @@ def test_hipgraph_replay_matches_eager():
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with ops.graph_capture(g):
         fwd_bwd()
     for _ in range(3):
         dp.flat_grad.fill_(float('nan'))
