@@ -82,6 +82,33 @@ int32_t otr_ffn_glu_bwd(const void* dy, int32_t dy_dtype, int64_t ldy, const voi
                         int32_t h_has_sigmoid, void* dh, float* dbias_partial, int32_t partial_rows_cap,
                         int32_t* partial_rows, int32_t M, int32_t F, int32_t d_model, void* stream);
 
+/* ---- row-block fused FFN sub-layer of the post-norm layers (encoder/transformer.py:58-63, decoder/transformer.py:82-86,
+ *      module/ffn.py:38-41 with activation 'glu'; SURVEY.md K7 + K8), d_model = 256, d_ff % 256 == 0, 16-bit operands.
+ *      A workgroup owns 32 rows and streams the PACKED weights (otr_pack_frags) from L2 into registers; the d_ff-wide
+ *      hidden lives in MFMA accumulators only.
+ * otr_pack_frags: fragment-major copies of 16-bit matrices, many per launch.  table: DEVICE int64 [n_items][8] rows of
+ *   {src element offset, row stride, col stride, rows (%32), cols (%16), perm, dst element offset, first block}; item i
+ *   views src+offset as A[r][c] = src[r*rs + c*cs] (r = output index, c = contraction index) and writes one 1 KiB MFMA
+ *   A-operand per (32 rows, 16 contraction indices) in (row tile, k-step) order; perm = 1 orders the contraction
+ *   indices the way an accumulator tile presents them when it is fed back as an operand.  A block packs 4 fragments;
+ *   total_blocks = sum of ceil(rows/32 * cols/16 / 4).
+ * otr_ffn_ln_fwd:  y = LayerNorm(x + dropout(w_2(glu(w_1 x + b_1)) + b_2)) in ONE launch.  x f32 [M,256] and its 16-bit
+ *   twin x16; w1_pack = pack(w_1 [2F,256] as A[f][k], perm 0); w2_pack = pack(w_2 [256,F] as A[n][f], perm 1).
+ *   Outputs as otr_add_layernorm_fwd: y, y16 (may be NULL), z = x + dropout(branch) (may be NULL), mean, rstd; the
+ *   dropout mask is the one otr_add_layernorm_bwd regenerates from (seed, rng_offset).
+ * otr_ffn_bwd:  recomputes the pre-activations from x16, then dh[M,2F] = GLU'(.) * (dy16 . w_2), u[M,F] = glu(.)
+ *   (row-major, the operands of the two weight gradients) and dx[M,256] f32 = skip + dh . w_1 in ONE launch.
+ *   w2t_pack = pack(w_2 as A[f][n], perm 0); w1t_pack = pack(w_1 as A[k][f'], perm 1); skip may be NULL or alias dx. */
+int32_t otr_pack_frags(const void* src, void* dst, const int64_t* table, int32_t n_items, int64_t total_blocks,
+                       void* stream);
+int32_t otr_ffn_ln_fwd(const float* x, const void* x16, const void* w1_pack, const float* b1, const void* w2_pack,
+                       const float* b2, const float* gamma, const float* beta, const uint64_t* seed, float p_drop,
+                       uint64_t rng_offset, float eps, float* y, void* y16, float* z, float* mean, float* rstd, int64_t M,
+                       int32_t F, int32_t d_model, void* stream);
+int32_t otr_ffn_bwd(const void* x16, const void* dy16, const void* w1_pack, const float* b1, const void* w2t_pack,
+                    const void* w1t_pack, void* dh, void* u, const float* skip, float* dx, int64_t M, int32_t F,
+                    int32_t d_model, void* stream);
+
 /* ---- grouped weight / bias gradients: every dw_i[N,K] += dy_i[M,N]^T x_i[M,K] of a backward pass in a few launches
  *      (one per operand-type group), likewise every bias gradient out_i[N] += column sums of a_i[M,N].  The per-layer
  *      launches they replace are latency bound (a 4-k-step GEMM workgroup lives ~10 us, every launch costs 2-3 us);

@@ -68,6 +68,20 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, h);
 }
 
+// half-type-neutral names (the 16-bit storage type is a build parameter, see the top of this file)
+__device__ __forceinline__ float h2f(bf16_t v) { return bf2f(v); }
+__device__ __forceinline__ bf16_t f2h(float f) { return f2bf(f); }
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) { return pack2bf(lo, hi); }
+__device__ __forceinline__ float h2f_lo(uint32_t w) { return bf2f((bf16_t)(w & 0xffffu)); }   // low / high half of a packed pair
+__device__ __forceinline__ float h2f_hi(uint32_t w) { return bf2f((bf16_t)(w >> 16)); }
+
+// 32x32x16 MFMA on the 16-bit storage type.  A: lane l holds row (l&31), k = (l>>5)*8 + 0..7; B: col (l&31), same k;
+// D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)  (MI355X_MICROARCH / cdna_hip_programming.md section 3)
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__device__ __forceinline__ void mma32(f32x16& acc, const uint4& a, const uint4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
 template <class T> struct ElemIO;
 template <> struct ElemIO<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }

@@ -1,0 +1,461 @@
+// Row-block fused FFN sub-layer for the post-norm Transformer layers (encoder/transformer.py:58-63,
+// decoder/transformer.py:82-86, module/ffn.py:38-41 with activation 'glu'):
+//
+//   forward :  y  = LayerNorm(x + dropout(w_2(glu(w_1 x + b_1)) + b_2))                      ONE launch
+//   backward:  dh = GLU'(w_1 x + b_1) * (dy . w_2),  u = glu(w_1 x + b_1),  dx = skip + dh . w_1   ONE launch
+//
+// The 4096-wide FFN hidden never reaches HBM in the forward pass and is RECOMPUTED in the backward pass (SURVEY.md K7 +
+// K8): forward traffic per layer is x (fp32 + 16-bit twin) in, y out; the backward pass writes only what the
+// weight-gradient GEMMs consume (dh, u).
+//
+// Design (d_model = 256 makes every GEMM of this model skinny, so the classic big-tile GEMM is the wrong tool):
+//  * a workgroup owns RB = 32 rows of the residual stream (249 workgroups for B=32 x 249 frames: one per CU);
+//  * the hidden dimension is cut into chunks of 32 units; the 4 waves of a workgroup own DIFFERENT chunks and never
+//    synchronise inside the chunk loop: each wave computes h^T[32 hidden, 32 rows] with v_mfma_f32_32x32x16 (A = weight
+//    fragment, B = activation fragment), applies the GLU on the accumulator registers, and feeds the result straight
+//    back as the B operand of the next GEMM -- the accumulator layout (lane = row m, registers = hidden units) IS an
+//    operand layout once the contraction index is permuted, and the permutation is applied to the WEIGHTS when they
+//    are packed (otr_pack_frags, perm = 1);
+//  * weights are pre-packed "fragment-major" (1 KiB = one MFMA A operand = 64 lanes x 16 B, in consumption order), so
+//    the weight stream is L2 -> VGPR with fully coalesced 16-byte loads through a PD-deep register ring: no LDS, no
+//    barrier in the main loop.  Each weight fragment is used exactly once per wave, so LDS staging would buy nothing;
+//  * the waves' partial outputs (sums over their chunks) meet in LDS once, at the end, where the bias / dropout /
+//    residual / LayerNorm epilogue (forward) or the skip-connection add (backward) runs on whole rows.
+// Bound: the 3 MB (forward) / 5 MB (backward) of packed weights stream from L2 into every CU: 64 B/clk/CU ->
+// ~20 us / ~33 us per layer at B=32, i.e. ~50 % of the MFMA rate; HBM traffic is a few MB.
+#include "common.h"
+
+constexpr int FF_RB = 32;   // rows per workgroup
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// Fragment (rt, ks) of a logical matrix A[r][c] (r = free index, c = contraction index), element (r, c) at
+// src[off + r*rs + c*cs]:  1 KiB at dst[dst_off + (rt*(cols/16) + ks)*512 + lane*8 + j]  holding
+//   A[rt*32 + (lane&31)][ks*16 + kmap(lane>>5, j)],   kmap(hi, j) = hi*8 + j                       (perm = 0)
+//                                                      kmap(hi, j) = 4*hi + j (j<4), 8 + 4*hi + j-4  (perm = 1)
+// perm = 1 matches an accumulator tile that is fed back as the B operand (its lane holds contraction indices
+// {4hi..4hi+3, 8+4hi..8+4hi+3} of each group of 16).  table (device, int64 [n][8]):
+//   {src_off, rs, cs, rows, cols, perm, dst_off, first_block}; a block packs 4 fragments.
+__global__ __launch_bounds__(256) void pack_frags_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
+                                                        const int64_t* __restrict__ table, int n) {
+  const int64_t b = blockIdx.x;
+  int lo = 0, hi_ = n - 1;
+  while (lo < hi_) {
+    const int mid = (lo + hi_ + 1) >> 1;
+    if (table[mid * 8 + 7] <= b) lo = mid; else hi_ = mid - 1;
+  }
+  const int64_t* t = table + lo * 8;
+  const int64_t src_off = t[0], rs = t[1], cs = t[2], rows = t[3], cols = t[4], perm = t[5], dst_off = t[6];
+  const int64_t nks = cols >> 4, nfrag = (rows >> 5) * nks;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t frag = (b - t[7]) * 4 + wid;
+  if (frag >= nfrag) return;
+  const int64_t rt = frag / nks, ks = frag - rt * nks;
+  const int64_t r = rt * 32 + (lane & 31);
+  const int hi = lane >> 5;
+  const uint16_t* s = src + src_off + r * rs;
+  uint16_t v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int kk = perm ? (j < 4 ? 4 * hi + j : 8 + 4 * hi + (j - 4)) : hi * 8 + j;
+    v[j] = s[(ks * 16 + kk) * cs];
+  }
+  uint4 q;
+  q.x = v[0] | ((uint32_t)v[1] << 16); q.y = v[2] | ((uint32_t)v[3] << 16);
+  q.z = v[4] | ((uint32_t)v[5] << 16); q.w = v[6] | ((uint32_t)v[7] << 16);
+  *reinterpret_cast<uint4*>(dst + dst_off + frag * 512 + lane * 8) = q;
+}
+
+extern "C" int32_t otr_pack_frags(const void* src, void* dst, const int64_t* table, int32_t n_items, int64_t total_blocks,
+                                  void* stream) {
+  OTR_REQUIRE(src && dst && table, "pack_frags: null pointer");
+  OTR_REQUIRE(n_items >= 0 && total_blocks >= 0 && total_blocks < (1ll << 31), "pack_frags: bad sizes");
+  if (n_items == 0 || total_blocks == 0) return 0;
+  hipLaunchKernelGGL(pack_frags_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)src, (uint16_t*)dst, table, n_items);
+  return otr_check_launch("pack_frags");
+}
+
+// ------------------------------------------------------------------------------------------------ shared pieces
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
+// 32 rows x D 16-bit activations -> LDS as 16-byte chunks, chunk index XOR (row & 15): the B-operand read of lane
+// (m = lane&31, hi) -- chunk (2*ks + hi) of row m -- is then bank-conflict free for ds_read_b128
+template <int D>
+__device__ __forceinline__ void stage_rows(uint4* dst, const uint16_t* src, int row0, int M, int tid) {
+  constexpr int CPR = D / 8;
+#pragma unroll
+  for (int i = tid; i < FF_RB * CPR; i += 256) {
+    const int r = i / CPR, ch = i % CPR;
+    const int gr = min(row0 + r, M - 1);
+    dst[r * CPR + (ch ^ (r & 15))] = ld_global_b128(src + (int64_t)gr * D + ch * 8);
+  }
+}
+template <int D> __device__ __forceinline__ uint4 frag_b(const uint4* rows, int m, int hi, int ks) {
+  return rows[m * (D / 8) + ((2 * ks + hi) ^ (m & 15))];
+}
+
+// accumulator tile (16 floats: hidden units 8q + 4hi + (r&3), q = r>>2, of row m = lane&31) -> two B-operand fragments
+__device__ __forceinline__ void tile_to_frags(const float* v, uint4& f0, uint4& f1) {
+  f0 = make_uint4(pack2h(v[0], v[1]), pack2h(v[2], v[3]), pack2h(v[4], v[5]), pack2h(v[6], v[7]));
+  f1 = make_uint4(pack2h(v[8], v[9]), pack2h(v[10], v[11]), pack2h(v[12], v[13]), pack2h(v[14], v[15]));
+}
+
+// store an accumulator tile as 32 consecutive 16-bit elements of row m (row-major consumer: the weight-gradient GEMM).
+// The row's 64 bytes are split over lanes m and m+32 in 8-byte pieces; one v_permlane32_swap per dword turns them into
+// 16-byte pieces (cdna_hip_programming.md T21): lane (m, hi) then owns elements [8(q0+hi), 8(q0+hi)+8) for q0 = 0, 2.
+__device__ __forceinline__ void store_tile_row(uint16_t* rowp, const uint4& f0, const uint4& f1, int hi, bool live) {
+  uint32_t w[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+  for (int q0 = 0; q0 < 4; q0 += 2) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      auto r = __builtin_amdgcn_permlane32_swap(w[2 * q0 + e], w[2 * q0 + 2 + e], false, false);
+      w[2 * q0 + e] = r[0];
+      w[2 * q0 + 2 + e] = r[1];
+    }
+    if (live) st_global_b128(rowp + 8 * (q0 + hi), make_uint4(w[2 * q0], w[2 * q0 + 1], w[2 * q0 + 2], w[2 * q0 + 3]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+struct FfnFwdArgs {
+  const float* x;          // residual stream [M, D] f32
+  const uint16_t* x16;     // its 16-bit twin [M, D] (the GEMM operand form)
+  const uint4* p1;         // w_1 packed: rows = 2F hidden pre-activations (value rows then gate rows), contraction = D, perm 0
+  const float* b1;         // [2F]
+  const uint4* p2;         // w_2 packed: rows = D outputs, contraction = F hidden units, perm 1
+  const float* b2;         // [D]
+  const float* gamma; const float* beta; const uint64_t* seed;
+  float* y; uint16_t* y16; float* z; float* mean; float* rstd;
+  int M, F;
+  float eps, p_drop;
+  uint64_t rng_offset;
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 1) void ffn_ln_fwd_kernel(FfnFwdArgs p) {
+  static_assert(D == 256, "the LayerNorm epilogue maps one float4 per lane: d_model = 256");
+  constexpr int NKS = D / 16, NT = D / 32, YP = D + 4;
+  constexpr int STEPS = 2 * NKS + 2 * NT;          // weight fragments (= MFMAs) per chunk: 32 + 16
+  constexpr int PD = 24;                           // fragments in flight per wave (24 KiB)
+  static_assert(STEPS % PD == 0, "ring slots must be compile-time constants");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[FF_RB * D * 2 + 4 * FF_RB * YP * 4];
+  uint4* xs = reinterpret_cast<uint4*>(smem);
+  float* red = reinterpret_cast<float*>(smem + FF_RB * D * 2);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, hi = lane >> 5;
+  const int row0 = blockIdx.x * FF_RB;
+  stage_rows<D>(xs, p.x16, row0, p.M, tid);
+  __syncthreads();
+
+  const int nchunk = p.F / 32, npair = nchunk / 8, nit = nchunk / 4;
+  const int rot = (int)(blockIdx.x % (unsigned)npair);      // workgroups walk the weights from different starting points
+  auto chunk_of = [&](int it) {
+    int j = (it >> 1) + rot;
+    if (j >= npair) j -= npair;
+    return 8 * j + 2 * wid + (it & 1);                       // a wave's consecutive chunks are adjacent
+  };
+  const uint4* P1 = p.p1 + lane;
+  const uint4* P2 = p.p2 + lane;
+  auto fptr = [&](int c, int s) -> const uint4* {
+    if (s < 2 * NKS) return P1 + (int64_t)(((s & 1) ? nchunk + c : c) * NKS + (s >> 1)) * 64;
+    const int t = s - 2 * NKS;
+    return P2 + (int64_t)((t >> 1) * (2 * nchunk) + 2 * c + (t & 1)) * 64;
+  };
+
+  f32x16 yacc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) yacc[i][r] = 0.f;
+
+  uint4 ring[PD];
+  int c = chunk_of(0);
+#pragma unroll
+  for (int s = 0; s < PD; ++s) ring[s] = ld_global_b128(fptr(c, s));
+
+  for (int it = 0; it < nit; ++it) {
+    const int cn = chunk_of(min(it + 1, nit - 1));          // last round: re-loads its own chunk (valid, unused)
+    float4 bv[4], bg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bv[q] = *reinterpret_cast<const float4*>(p.b1 + c * 32 + 8 * q + 4 * hi);
+      bg[q] = *reinterpret_cast<const float4*>(p.b1 + p.F + c * 32 + 8 * q + 4 * hi);
+    }
+    f32x16 av, ag;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { av[r] = 0.f; ag[r] = 0.f; }
+    uint4 xb, uf0, uf1;
+#pragma clang loop unroll(full)
+    for (int s = 0; s < STEPS; ++s) {
+      const uint4 w = ring[s % PD];
+      if (s < 2 * NKS) {
+        if ((s & 1) == 0) xb = frag_b<D>(xs, m, hi, s >> 1);
+        if (s & 1) mma32(ag, w, xb); else mma32(av, w, xb);
+      } else {
+        const int t = s - 2 * NKS;
+        mma32(yacc[t >> 1], w, (t & 1) ? uf1 : uf0);
+      }
+      ring[s % PD] = ld_global_b128(s + PD < STEPS ? fptr(c, s + PD) : fptr(cn, s + PD - STEPS));
+      if (s == 2 * NKS - 1) {                               // GLU on the accumulators: u = (a + b_a) * sigmoid(g + b_g)
+        float u[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float a = av[r] + reinterpret_cast<const float*>(&bv[r >> 2])[r & 3];
+          const float g = ag[r] + reinterpret_cast<const float*>(&bg[r >> 2])[r & 3];
+          u[r] = a * fast_sigmoid(g);
+        }
+        tile_to_frags(u, uf0, uf1);
+      }
+    }
+    c = cn;
+  }
+
+  // the four waves' partial y^T tiles meet in LDS: red[wave][m][n], n = nt*32 + 8q + 4hi + (r&3)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(red + (wid * FF_RB + m) * YP + nt * 32 + 8 * q + 4 * hi) =
+          make_float4(yacc[nt][4 * q], yacc[nt][4 * q + 1], yacc[nt][4 * q + 2], yacc[nt][4 * q + 3]);
+  __syncthreads();
+
+  // bias + dropout + residual + LayerNorm on whole rows: wave w owns rows 8w..8w+7, lane owns columns 4*lane..+3
+  const bool drop = p.p_drop > 0.f;
+  const uint64_t seed = drop ? *p.seed : 0;
+  const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
+  const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+  const int col = lane * 4;
+  const float4 b2 = *reinterpret_cast<const float4*>(p.b2 + col);
+  const float4 gm = *reinterpret_cast<const float4*>(p.gamma + col);
+  const float4 bt = *reinterpret_cast<const float4*>(p.beta + col);
+  float4 xr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t row = min((int64_t)row0 + wid * 8 + i, (int64_t)p.M - 1);
+    xr[i] = *reinterpret_cast<const float4*>(p.x + row * D + col);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = wid * 8 + i;
+    const int64_t row = (int64_t)row0 + r;
+    float v[4] = {b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float4 t = *reinterpret_cast<const float4*>(red + (w * FF_RB + r) * YP + col);
+      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+    if (row >= p.M) continue;                               // wave-uniform
+    const float xv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float sc = 1.f;
+      if (drop) sc = otr_rand32(seed, p.rng_offset + (uint64_t)(row * D + col + e)) >= thr ? inv_keep : 0.f;
+      v[e] = xv[e] + v[e] * sc;
+      s += v[e];
+    }
+    if (p.z) *reinterpret_cast<float4*>(p.z + row * D + col) = make_float4(v[0], v[1], v[2], v[3]);
+    const float mean = wave_sum(s) * (1.f / D);
+    float qq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float t = v[e] - mean; qq += t * t; }
+    const float rstd = rsqrtf(wave_sum(qq) * (1.f / D) + p.eps);
+    const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * g4[e] + b4[e];
+    *reinterpret_cast<float4*>(p.y + row * D + col) = make_float4(o[0], o[1], o[2], o[3]);
+    if (p.y16) *reinterpret_cast<uint2*>(p.y16 + row * D + col) = make_uint2(pack2h(o[0], o[1]), pack2h(o[2], o[3]));
+    if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+struct FfnBwdArgs {
+  const uint16_t* x16;     // FFN input [M, D] (16-bit twin of the residual stream)
+  const uint16_t* dy16;    // gradient of the FFN output [M, D] (branch gradient of the LayerNorm backward)
+  const uint4* p1;         // w_1 packed as in the forward pass (recompute of the pre-activations)
+  const float* b1;
+  const uint4* p3;         // w_2^T packed: rows = F hidden units, contraction = D, perm 0       (du = dy . w_2)
+  const uint4* p4;         // w_1^T packed: rows = D, contraction = 2F (value then gate), perm 1  (dx = dh . w_1)
+  uint16_t* dh;            // [M, 2F] out: gradient of the pre-activations (operand of the w_1 weight gradient)
+  uint16_t* u;             // [M, F] out: glu output (operand of the w_2 weight gradient)
+  const float* skip;       // [M, D] f32 or NULL, added to dx (the skip-connection gradient of y = LN(x + f(x)))
+  float* dx;               // [M, D] f32 out (may alias skip)
+  int M, F;
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(FfnBwdArgs p) {
+  static_assert(D == 256, "row epilogue maps one float4 per lane: d_model = 256");
+  constexpr int NKS = D / 16, NT = D / 32, YP = D + 4;
+  constexpr int S1 = 2 * NKS, S2 = S1 + NKS, STEPS = S2 + 4 * NT;   // 32 + 16 + 32 weight fragments per chunk
+  constexpr int PD = 20;
+  static_assert(STEPS % PD == 0, "ring slots must be compile-time constants");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * FF_RB * YP * 4];   // operands first, partial sums after
+  uint4* xs = reinterpret_cast<uint4*>(smem);
+  uint4* ds = reinterpret_cast<uint4*>(smem + FF_RB * D * 2);
+  float* red = reinterpret_cast<float*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, hi = lane >> 5;
+  const int row0 = blockIdx.x * FF_RB;
+  stage_rows<D>(xs, p.x16, row0, p.M, tid);
+  stage_rows<D>(ds, p.dy16, row0, p.M, tid);
+  __syncthreads();
+
+  const int nchunk = p.F / 32, npair = nchunk / 8, nit = nchunk / 4;
+  const int rot = (int)(blockIdx.x % (unsigned)npair);
+  auto chunk_of = [&](int it) {
+    int j = (it >> 1) + rot;
+    if (j >= npair) j -= npair;
+    return 8 * j + 2 * wid + (it & 1);
+  };
+  const uint4* P1 = p.p1 + lane;
+  const uint4* P3 = p.p3 + lane;
+  const uint4* P4 = p.p4 + lane;
+  auto fptr = [&](int c, int s) -> const uint4* {
+    if (s < S1) return P1 + (int64_t)(((s & 1) ? nchunk + c : c) * NKS + (s >> 1)) * 64;
+    if (s < S2) return P3 + (int64_t)(c * NKS + (s - S1)) * 64;
+    const int t = s - S2, j4 = t & 3;
+    const int ksf = (j4 < 2) ? 2 * c + j4 : 2 * nchunk + 2 * c + (j4 - 2);
+    return P4 + (int64_t)((t >> 2) * (4 * nchunk) + ksf) * 64;
+  };
+
+  f32x16 xacc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xacc[i][r] = 0.f;
+
+  uint4 ring[PD];
+  int c = chunk_of(0);
+#pragma unroll
+  for (int s = 0; s < PD; ++s) ring[s] = ld_global_b128(fptr(c, s));
+  const int64_t grow = (int64_t)row0 + m;
+  const bool live = grow < p.M;
+  const int64_t crow = min(grow, (int64_t)p.M - 1);
+
+  for (int it = 0; it < nit; ++it) {
+    const int cn = chunk_of(min(it + 1, nit - 1));
+    float4 bv[4], bg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bv[q] = *reinterpret_cast<const float4*>(p.b1 + c * 32 + 8 * q + 4 * hi);
+      bg[q] = *reinterpret_cast<const float4*>(p.b1 + p.F + c * 32 + 8 * q + 4 * hi);
+    }
+    f32x16 av, ag, du;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { av[r] = 0.f; ag[r] = 0.f; du[r] = 0.f; }
+    uint4 ob, hf[4];
+#pragma clang loop unroll(full)
+    for (int s = 0; s < STEPS; ++s) {
+      const uint4 w = ring[s % PD];
+      if (s < S1) {
+        if ((s & 1) == 0) ob = frag_b<D>(xs, m, hi, s >> 1);
+        if (s & 1) mma32(ag, w, ob); else mma32(av, w, ob);
+      } else if (s < S2) {
+        ob = frag_b<D>(ds, m, hi, s - S1);
+        mma32(du, w, ob);
+      } else {
+        const int t = s - S2;
+        mma32(xacc[t >> 2], w, hf[t & 3]);
+      }
+      ring[s % PD] = ld_global_b128(s + PD < STEPS ? fptr(c, s + PD) : fptr(cn, s + PD - STEPS));
+      if (s == S2 - 1) {
+        // GLU backward on the accumulators: a = value, sg = sigmoid(gate);  u = a*sg;  d a = du*sg;  d gate = du*a*sg*(1-sg)
+        float uu[16], da_[16], dg_[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float a = av[r] + reinterpret_cast<const float*>(&bv[r >> 2])[r & 3];
+          const float sg = fast_sigmoid(ag[r] + reinterpret_cast<const float*>(&bg[r >> 2])[r & 3]);
+          uu[r] = a * sg;
+          da_[r] = du[r] * sg;
+          dg_[r] = du[r] * uu[r] * (1.f - sg);
+        }
+        uint4 u0, u1;
+        tile_to_frags(uu, u0, u1);
+        tile_to_frags(da_, hf[0], hf[1]);
+        tile_to_frags(dg_, hf[2], hf[3]);
+        store_tile_row(p.u + crow * p.F + c * 32, u0, u1, hi, live);
+        store_tile_row(p.dh + crow * (2 * (int64_t)p.F) + c * 32, hf[0], hf[1], hi, live);
+        store_tile_row(p.dh + crow * (2 * (int64_t)p.F) + p.F + c * 32, hf[2], hf[3], hi, live);
+      }
+    }
+    c = cn;
+  }
+
+  __syncthreads();                                          // every wave is done with the staged operands
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(red + (wid * FF_RB + m) * YP + nt * 32 + 8 * q + 4 * hi) =
+          make_float4(xacc[nt][4 * q], xacc[nt][4 * q + 1], xacc[nt][4 * q + 2], xacc[nt][4 * q + 3]);
+  __syncthreads();
+  const int col = lane * 4;
+  float4 sk[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t row = min((int64_t)row0 + wid * 8 + i, (int64_t)p.M - 1);
+    sk[i] = p.skip ? *reinterpret_cast<const float4*>(p.skip + row * D + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = wid * 8 + i;
+    const int64_t row = (int64_t)row0 + r;
+    float4 v = sk[i];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float4 t = *reinterpret_cast<const float4*>(red + (w * FF_RB + r) * YP + col);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (row < p.M) *reinterpret_cast<float4*>(p.dx + row * D + col) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static int32_t ffn_shape_check(const char* who, int64_t M, int32_t F, int32_t d_model) {
+  OTR_REQUIRE(M >= 0 && M < (1ll << 31), "%s: bad M", who);
+  OTR_REQUIRE(d_model == 256, "%s: built for d_model = 256 (got %d); use the unfused path", who, d_model);
+  OTR_REQUIRE(F > 0 && F % 256 == 0, "%s: d_ff = %d must be a multiple of 256", who, F);
+  return 0;
+}
+
+extern "C" int32_t otr_ffn_ln_fwd(const float* x, const void* x16, const void* w1_pack, const float* b1, const void* w2_pack,
+                                  const float* b2, const float* gamma, const float* beta, const uint64_t* seed, float p_drop,
+                                  uint64_t rng_offset, float eps, float* y, void* y16, float* z, float* mean, float* rstd,
+                                  int64_t M, int32_t F, int32_t d_model, void* stream) {
+  if (int32_t e = ffn_shape_check("ffn_ln_fwd", M, F, d_model)) return e;
+  OTR_REQUIRE(x && x16 && w1_pack && b1 && w2_pack && b2 && gamma && beta && y && mean && rstd, "ffn_ln_fwd: null pointer");
+  OTR_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed), "ffn_ln_fwd: bad dropout arguments");
+  OTR_REQUIRE(((uintptr_t)x16 | (uintptr_t)w1_pack | (uintptr_t)w2_pack | (uintptr_t)x | (uintptr_t)y | (uintptr_t)b1 | (uintptr_t)b2) % 16 == 0,
+              "ffn_ln_fwd: buffers must be 16-byte aligned");
+  if (M == 0) return 0;
+  FfnFwdArgs p{};
+  p.x = x; p.x16 = (const uint16_t*)x16; p.p1 = (const uint4*)w1_pack; p.b1 = b1; p.p2 = (const uint4*)w2_pack; p.b2 = b2;
+  p.gamma = gamma; p.beta = beta; p.seed = seed; p.y = y; p.y16 = (uint16_t*)y16; p.z = z; p.mean = mean; p.rstd = rstd;
+  p.M = (int)M; p.F = F; p.eps = eps; p.p_drop = p_drop; p.rng_offset = rng_offset;
+  hipLaunchKernelGGL(ffn_ln_fwd_kernel<256>, dim3((unsigned)((M + FF_RB - 1) / FF_RB)), dim3(256), 0, (hipStream_t)stream, p);
+  return otr_check_launch("ffn_ln_fwd");
+}
+
+extern "C" int32_t otr_ffn_bwd(const void* x16, const void* dy16, const void* w1_pack, const float* b1, const void* w2t_pack,
+                               const void* w1t_pack, void* dh, void* u, const float* skip, float* dx, int64_t M, int32_t F,
+                               int32_t d_model, void* stream) {
+  if (int32_t e = ffn_shape_check("ffn_bwd", M, F, d_model)) return e;
+  OTR_REQUIRE(x16 && dy16 && w1_pack && b1 && w2t_pack && w1t_pack && dh && u && dx, "ffn_bwd: null pointer");
+  OTR_REQUIRE(((uintptr_t)x16 | (uintptr_t)dy16 | (uintptr_t)w1_pack | (uintptr_t)w2t_pack | (uintptr_t)w1t_pack | (uintptr_t)dh |
+               (uintptr_t)u | (uintptr_t)dx | (uintptr_t)skip | (uintptr_t)b1) % 16 == 0, "ffn_bwd: buffers must be 16-byte aligned");
+  if (M == 0) return 0;
+  FfnBwdArgs p{};
+  p.x16 = (const uint16_t*)x16; p.dy16 = (const uint16_t*)dy16; p.p1 = (const uint4*)w1_pack; p.b1 = b1;
+  p.p3 = (const uint4*)w2t_pack; p.p4 = (const uint4*)w1t_pack; p.dh = (uint16_t*)dh; p.u = (uint16_t*)u; p.skip = skip; p.dx = dx;
+  p.M = (int)M; p.F = F;
+  hipLaunchKernelGGL(ffn_bwd_kernel<256>, dim3((unsigned)((M + FF_RB - 1) / FF_RB)), dim3(256), 0, (hipStream_t)stream, p);
+  return otr_check_launch("ffn_bwd");
+}

@@ -72,25 +72,62 @@ class FlatDataParallel:
                 # one launch transposes every 2-D shadow (include/otrans_hip.h: otr_transpose_batched)
                 self._lpt_table = torch.tensor(table, dtype=torch.int64, device=dev).reshape(-1, 4)
                 self._lpt_tiles = tiles
+                self._build_ffn_packs(module, dev)
                 self.refresh_lp()
         if dev.type == 'cuda':
             from . import ops
             ops.defer_weight_grads(True)    # weight / bias gradients run as grouped launches at the end of backward
 
+    def _build_ffn_packs(self, module, dev):
+        """Fragment-major copies of every GLU FFN's weights for the row-block fused FFN kernels (ops.FfnLnFn): one flat
+        buffer, one device table, ONE otr_pack_frags launch per optimizer step (csrc/ffn_fused.hip)."""
+        from . import ops
+        self.flat_pack, self._pack_table, self._pack_blocks = None, None, 0
+        off_of = {id(p): o for p, o in zip(self.params, self.offsets)}
+        rows, total, views = [], 0, []
+        for mod in module.modules():
+            w1, w2 = getattr(getattr(mod, 'w_1', None), 'weight', None), getattr(getattr(mod, 'w_2', None), 'weight', None)
+            if w1 is None or w2 is None or getattr(mod, 'activation', None) != 'glu':
+                continue
+            if id(w1) not in off_of or id(w2) not in off_of or w1.shape[1] != 256 or (w1.shape[0] // 2) % 256 != 0:
+                continue
+            F2, d = w1.shape
+            r, offs, n = ops.ffn_pack_items(off_of[id(w1)], off_of[id(w2)], F2, d, F2 // 2, total)
+            rows += r
+            views.append((w1, offs, F2 * d, d * (F2 // 2)))
+            total += n
+        if not rows:
+            return
+        self.flat_pack = torch.empty(total, device=dev, dtype=self.flat_param_lp.dtype)
+        table, blocks = [], 0
+        for r in rows:
+            table.append(list(r) + [blocks])
+            blocks += ((r[3] // 32) * (r[4] // 16) + 3) // 4
+        self._pack_table = torch.tensor(table, dtype=torch.int64, device=dev)
+        self._pack_blocks = blocks
+        for w1, offs, n1, n2 in views:
+            w1._otr_ffn_packs = (self.flat_pack[offs[0]:offs[0] + n1], self.flat_pack[offs[1]:offs[1] + n2],
+                                 self.flat_pack[offs[2]:offs[2] + n2], self.flat_pack[offs[3]:offs[3] + n1])
+
     def refresh_lp(self):
-        """re-cast the bf16 shadows after any out-of-band parameter change (load_state_dict, ...)."""
+        """re-cast the 16-bit shadows after any out-of-band parameter change (load_state_dict, broadcast, ...)."""
         if self.flat_param_lp is not None:
             from . import ops
             ops.cast_bf16(self.flat_param, self.flat_param_lp)
             self.refresh_transposed()
 
     def refresh_transposed(self):
-        """W^T shadows follow the bf16 shadows (call after every optimizer step)."""
+        """W^T shadows and the packed FFN weights follow the 16-bit shadows (call after every optimizer step)."""
         if self.flat_param_lp is not None and self._lpt_tiles:
             L.check(L.load().otr_transpose_batched(
                 C.c_void_p(self.flat_param_lp.data_ptr()), C.c_void_p(self.flat_param_lpt.data_ptr()),
                 C.c_void_p(self._lpt_table.data_ptr()), self._lpt_table.shape[0], self._lpt_tiles, 2,
                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'otr_transpose_batched')
+        if self.flat_param_lp is not None and getattr(self, '_pack_blocks', 0):
+            L.check(L.load().otr_pack_frags(
+                C.c_void_p(self.flat_param_lp.data_ptr()), C.c_void_p(self.flat_pack.data_ptr()),
+                C.c_void_p(self._pack_table.data_ptr()), self._pack_table.shape[0], self._pack_blocks,
+                C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'otr_pack_frags')
 
     def packed_grads(self):
         """gradients without the alignment gaps, in parameter order (tests / checkpointing)"""
@@ -112,8 +149,12 @@ class FlatDataParallel:
     def broadcast_parameters(self, src=0):
         """one-time replica sync at start-up (the reference re-broadcasts every step)."""
         if self.world_size > 1:
-            dist.broadcast(self.flat_param if self.flat_param is not None else self._pack_params(), src,
-                           group=self.group)
+            if self.flat_param is not None:
+                dist.broadcast(self.flat_param, src, group=self.group)
+            else:                       # per-parameter storage: broadcast each tensor in place
+                for p in self.params:
+                    dist.broadcast(p.data, src, group=self.group)
+            self.refresh_lp()           # the GEMMs read the 16-bit shadows: they must follow the broadcast masters
 
     def all_reduce_gradients(self, async_op=False):
         """single collective over the flat buffer; returns 1/world_size for the optimizer to fold in."""

@@ -214,6 +214,16 @@ def _post_norm(norm, x, branch, p, training, a_bias=None, link=None):
     return ops.add_layernorm(x, branch, norm.weight, norm.bias, p if training else 0.0, norm.eps, a_bias=a_bias, link=link)
 
 
+def _ffn_post_norm(ff, norm, x, p):
+    """LN(x + dropout(FFN(x))): one row-block fused launch (ops.FfnLnFn) for GLU FFNs on enough rows, else GEMMs + add+LN."""
+    if ff.activation == 'glu':
+        y = ops.ffn_add_layernorm(x, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias, norm.weight, norm.bias, p, norm.eps)
+        if y is not None:
+            return y
+    link = ops.new_link()
+    return _post_norm(norm, x, ff(x, defer_bias=True, link=link), p, True, ff.w_2.bias, link)
+
+
 def _norm(norm, x):
     return ops.add_layernorm(x, None, norm.weight, norm.bias, 0.0, norm.eps)
 
@@ -271,8 +281,7 @@ class TransformerEncoderLayer(nn.Module):
         if pre:
             x = ops.residual_add(x, self.feed_forward(x), 1.0, p)
         else:
-            l2 = ops.new_link()
-            x = _post_norm(self.norm2, x, self.feed_forward(x, defer_bias=True, link=l2), p, True, self.feed_forward.w_2.bias, l2)
+            x = _ffn_post_norm(self.feed_forward, self.norm2, x, p)
         return x, {'slf_attn_weights': None}
 
     def inference(self, x, mask, pos=None, cache=None):
@@ -508,8 +517,7 @@ class TransformerDecoderLayer(nn.Module):
         if pre:
             x = ops.residual_add(x, self.feed_forward(x), 1.0, p)
         else:
-            l3 = ops.new_link()
-            x = _post_norm(self.norm3, x, self.feed_forward(x, defer_bias=True, link=l3), p, True, self.feed_forward.w_2.bias, l3)
+            x = _ffn_post_norm(self.feed_forward, self.norm3, x, p)
         return x, {'slf_attn_weights': None, 'src_attn_weights': None}
 
 

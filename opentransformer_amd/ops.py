@@ -699,6 +699,163 @@ class FeedForwardGLUFn(torch.autograd.Function):
                 None if gw2 is not None else dw2, None if (gb2 is not None or ctx.defer_b2) else db2, None, None, None)
 
 
+# ---------------------------------------------------------------------------------------- row-block fused FFN sub-layer
+# y = LN(x + dropout(FFN(x))) in ONE launch forward and ONE launch (+ the LayerNorm backward) backward; the d_ff-wide hidden
+# is never stored: the backward pass recomputes it (csrc/ffn_fused.hip).  Weights are consumed "fragment-major": four packed
+# copies per FFN (w_1, w_2, w_2^T, w_1^T in MFMA-operand order) that FlatDataParallel refreshes after every optimizer step
+# (one otr_pack_frags launch for the whole model) or, for stand-alone modules, a cache keyed by the parameter versions.
+_FUSED_FFN = os.environ.get('OTR_NO_FUSED_FFN', '0') != '1'
+_FUSED_FFN_MIN_ROWS = int(os.environ.get('OTR_FUSED_FFN_MIN_ROWS', '1024'))   # below: too few 32-row workgroups to fill the chip
+
+
+def ffn_pack_items(w1_off, w2_off, F2, d, F, dst_off):
+    """otr_pack_frags table rows {src_off, rs, cs, rows, cols, perm, dst_off} for one FFN (w_1 [2F,d], w_2 [d,F]) and the
+    element offsets of its four packs inside the destination buffer."""
+    n1, n2 = F2 * d, d * F
+    o1, o2, o3, o4 = dst_off, dst_off + n1, dst_off + n1 + n2, dst_off + n1 + 2 * n2
+    rows = [[w1_off, d, 1, F2, d, 0, o1],        # P1: A[f'][k]  = w_1[f'][k]          (h = w_1 x)
+            [w2_off, F, 1, d, F, 1, o2],         # P2: A[n][f]   = w_2[n][f], perm     (y = w_2 u, u from accumulators)
+            [w2_off, 1, F, F, d, 0, o3],         # P3: A[f][n]   = w_2[n][f]           (du = dy . w_2)
+            [w1_off, 1, d, d, F2, 1, o4]]        # P4: A[k][f']  = w_1[f'][k], perm    (dx = dh . w_1, dh from accumulators)
+    return rows, (o1, o2, o3, o4), 2 * (n1 + n2)
+
+
+def pack_frags(src, dst, rows):
+    """run otr_pack_frags for table rows built by ffn_pack_items (first-block column appended here)"""
+    table, blocks = [], 0
+    for r in rows:
+        table.append(list(r) + [blocks])
+        blocks += ((r[3] // 32) * (r[4] // 16) + 3) // 4
+    t = torch.tensor(table, dtype=torch.int64, device=src.device)
+    L.check(L.load().otr_pack_frags(_p(src), _p(dst), _p(t), len(table), blocks, _stream()), 'otr_pack_frags')
+    return t, blocks
+
+
+def ffn_packs(w1, w2):
+    """(P1, P2, P3, P4) 16-bit packed weights of one FFN, or None when the fused kernels do not apply."""
+    if not _FUSED_FFN or _state['compute'] == 'fp32' or w1.dim() != 2 or w2.dim() != 2:
+        return None
+    F2, d = w1.shape
+    F = F2 // 2
+    if d != 256 or F % 256 != 0 or tuple(w2.shape) != (d, F) or not w1.is_cuda:
+        return None
+    views = getattr(w1, '_otr_ffn_packs', None)
+    if views is not None:                      # slices of FlatDataParallel's pack buffer (kept fresh by the optimizer)
+        return views
+    key = (w1._version, w1.data_ptr(), w2._version, w2.data_ptr(), _state['compute'])
+    cache = getattr(w1, '_otr_ffn_pack_cache', None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    l1, l2 = weight_lp(w1), weight_lp(w2)
+    src = torch.cat((l1.reshape(-1), l2.reshape(-1)))
+    rows, offs, total = ffn_pack_items(0, l1.numel(), F2, d, F, 0)
+    dst = torch.empty(total, dtype=src.dtype, device=src.device)
+    pack_frags(src, dst, rows)
+    n1, n2 = F2 * d, d * F
+    packs = (dst[offs[0]:offs[0] + n1], dst[offs[1]:offs[1] + n2], dst[offs[2]:offs[2] + n2], dst[offs[3]:offs[3] + n1])
+    w1._otr_ffn_pack_cache = (key, packs)
+    return packs
+
+
+class FfnLnFn(torch.autograd.Function):
+    """LN(x + dropout(w_2(glu(w_1 x + b_1)) + b_2)): the FFN sub-layer of a post-norm layer (encoder/transformer.py:58-63,
+    decoder/transformer.py:82-86) on the row-block fused kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, p_drop, eps, packs):
+        _cuda(x, w1, b1, w2, b2, gamma, beta)
+        ctx.set_materialize_grads(False)
+        d = x.shape[-1]
+        x2 = x.reshape(-1, d)
+        x16 = lp_of(x).reshape(-1, d)
+        M, F = x2.shape[0], w2.shape[1]
+        need_grad = any(ctx.needs_input_grad)
+        y = torch.empty_like(x2)
+        y16 = torch.empty(x2.shape, dtype=x16.dtype, device=x.device)
+        z = torch.empty_like(x2) if need_grad else None
+        mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        seed = rng_seed_tensor(x.device) if p_drop > 0 else None
+        off = _next_rng_offset(M * d) if p_drop > 0 else 0
+        L.check(L.load().otr_ffn_ln_fwd(_p(x2), _p(x16), _p(packs[0]), _p(b1), _p(packs[1]), _p(b2), _p(gamma), _p(beta),
+                                        _p(seed), p_drop, off, eps, _p(y), _p(y16), _p(z), _p(mean), _p(rstd), M, F, d,
+                                        _stream()), 'otr_ffn_ln_fwd')
+        ctx.save_for_backward(x16, z, mean, rstd, gamma, seed, b1)
+        ctx.packs = packs
+        ctx.refs = (w1, b1, w2, b2, gamma, beta)
+        ctx.cfg = (M, d, F, eps, p_drop, off, x.shape)
+        y16 = y16.view(x.shape)
+        ctx.mark_non_differentiable(y16)
+        return y.view(x.shape), y16
+
+    @staticmethod
+    def backward(ctx, dy, _dy16=None):
+        if dy is None:
+            return (None,) * 10
+        x16, z, mean, rstd, gamma, seed, b1 = ctx.saved_tensors
+        M, d, F, eps, p_drop, off, xshape = ctx.cfg
+        w1p, b1p, w2p, b2p, gp, bp = ctx.refs
+        P1, _, P3, P4 = ctx.packs
+        lib = L.load()
+        dy2 = dy.reshape(-1, d).contiguous()
+        dx = torch.empty_like(dy2)
+        da = torch.empty((M, d), dtype=x16.dtype, device=dy.device)
+        # LayerNorm backward: dx = skip-connection gradient, da = gradient of the FFN output (dropout mask regenerated)
+        gg, gb, gb2 = grad_target(gp), grad_target(bp), grad_target(b2p)
+        inplace = gg is not None and gb is not None and gb2 is not None
+        desc = L.LnDesc(M, d, _code(da.dtype), eps, p_drop, off)
+        part, dgb = None, None
+        if inplace and _wq['on'] and _in_backward():
+            part = torch.empty((lib.otr_add_layernorm_bwd_partial_rows(M), 3 * d), dtype=torch.float32, device=dy.device)
+        else:
+            dgb = torch.zeros((3, d), dtype=torch.float32, device=dy.device)
+        L.check(lib.otr_add_layernorm_bwd(C.byref(desc), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed), _p(dx), _p(da),
+                                          _p(dgb[0]) if dgb is not None else None, _p(dgb[1]) if dgb is not None else None,
+                                          _p(dgb[2]) if dgb is not None else None, _p(part), _stream()), 'otr_add_layernorm_bwd')
+        ret_g = ret_b = ret_b2 = None
+        if part is not None:
+            colsum_raw(part[:, :d], out=gg)
+            colsum_raw(part[:, d:2 * d], out=gb)
+            colsum_raw(part[:, 2 * d:], out=gb2)
+        else:
+            if gg is not None:
+                gg.add_(dgb[0])
+            else:
+                ret_g = dgb[0]
+            if gb is not None:
+                gb.add_(dgb[1])
+            else:
+                ret_b = dgb[1]
+            if gb2 is not None:
+                gb2.add_(dgb[2])
+            else:
+                ret_b2 = dgb[2]
+        # FFN backward with recompute: dh, u for the weight gradients; dx += dh . w_1
+        dh = torch.empty((M, 2 * F), dtype=x16.dtype, device=dy.device)
+        u = torch.empty((M, F), dtype=x16.dtype, device=dy.device)
+        L.check(lib.otr_ffn_bwd(_p(x16), _p(da), _p(P1), _p(b1), _p(P3), _p(P4), _p(dh), _p(u), _p(dx), _p(dx), M, F, d,
+                                _stream()), 'otr_ffn_bwd')
+        gw1, gb1, gw2 = grad_target(w1p), grad_target(b1p), grad_target(w2p)
+        dw1 = linear_wgrad_raw(dh, x16, None, out=gw1)
+        dw2 = linear_wgrad_raw(da, u, None, out=gw2)
+        db1 = colsum_raw(dh, out=gb1)
+        return (dx.view(xshape), None if gw1 is not None else dw1, None if gb1 is not None else db1,
+                None if gw2 is not None else dw2, ret_b2, ret_g, ret_b, None, None, None)
+
+
+def ffn_add_layernorm(x, w1, b1, w2, b2, gamma, beta, p_drop=0.0, eps=1e-5):
+    """Fused FFN sub-layer when it applies (GLU, d_model 256, a 16-bit twin of x, enough rows); else None."""
+    if lp_of(x) is None or x.dtype != torch.float32 or x.shape[-1] != 256:
+        return None
+    if x.numel() // 256 < _FUSED_FFN_MIN_ROWS:
+        return None
+    packs = ffn_packs(w1, w2)
+    if packs is None or b1 is None or b2 is None:
+        return None
+    y, y16 = FfnLnFn.apply(x, w1, b1, w2, b2, gamma, beta, float(p_drop), float(eps), packs)
+    return attach_lp(y, y16)
+
+
 GLU_RPB = 32        # rows per workgroup of otr_glu_bwd (csrc/elementwise.hip)
 _FUSED_GLU_BWD = os.environ.get('OTR_NO_FUSED_GLU_BWD', '0') != '1'     # A/B switches for tuning runs
 _FUSED_GLU_FWD = os.environ.get('OTR_NO_FUSED_GLU_FWD', '0') != '1'

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Time the row-block fused FFN kernels (csrc/ffn_fused.hip) at the benchmark shape: M = 32 x 249 rows, d 256, d_ff 2048."""
+import argparse
+import json
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from opentransformer_amd import ops, _lib as L     # noqa: E402
+import ctypes as C                                  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rows', type=int, default=7968)
+    ap.add_argument('--dff', type=int, default=2048)
+    ap.add_argument('--mode', default='bf16')
+    ap.add_argument('--iters', type=int, default=50)
+    a = ap.parse_args()
+    ops.set_compute_dtype(a.mode)
+    dev = 'cuda'
+    M, d, F = a.rows, 256, a.dff
+    hdt = ops.act_dtype()
+    w1 = torch.randn(2 * F, d, device=dev) / math.sqrt(d)
+    w2 = torch.randn(d, F, device=dev) / math.sqrt(F)
+    b1, b2 = torch.randn(2 * F, device=dev) * 0.1, torch.randn(d, device=dev) * 0.1
+    gamma, beta = torch.ones(d, device=dev), torch.zeros(d, device=dev)
+    x = torch.randn(M, d, device=dev)
+    x16 = x.to(hdt)
+    P = ops.ffn_packs(w1, w2)
+    y, y16, z = torch.empty_like(x), torch.empty_like(x16), torch.empty_like(x)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    seed = ops.rng_seed_tensor(dev)
+    lib = L.load()
+    p, st = ops._p, ops._stream
+
+    def fwd(pd):
+        L.check(lib.otr_ffn_ln_fwd(p(x), p(x16), p(P[0]), p(b1), p(P[1]), p(b2), p(gamma), p(beta), p(seed), pd, 0, 1e-5,
+                                   p(y), p(y16), p(z), p(mean), p(rstd), M, F, d, st()), 'fwd')
+    da = (torch.randn(M, d, device=dev) * 0.01).to(hdt)
+    dh = torch.empty(M, 2 * F, dtype=hdt, device=dev)
+    u = torch.empty(M, F, dtype=hdt, device=dev)
+    dx = torch.zeros(M, d, device=dev)
+
+    def bwd():
+        L.check(lib.otr_ffn_bwd(p(x16), p(da), p(P[0]), p(b1), p(P[2]), p(P[3]), p(dh), p(u), p(dx), p(dx), M, F, d, st()), 'bwd')
+
+    def wgrad():
+        ops.linear_wgrad_raw(dh, x16, None)
+        ops.linear_wgrad_raw(da, u, None)
+
+    def old_fwd():
+        h = torch.empty(M, 2 * F, dtype=hdt, device=dev)
+        uu = torch.empty(M, F, dtype=hdt, device=dev)
+        L.check(lib.otr_ffn_glu_fwd(p(x16), d, p(ops.weight_lp(w1)), d, p(b1), p(h), p(uu), M, F, d, st()), 'glu')
+        a_ = ops.linear_fwd_raw(uu, ops.weight_lp(w2), b2, hdt)
+        return a_
+
+    def timeit(fn, n):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3
+    res = {'rows': M, 'dff': F, 'mode': a.mode}
+    res['fwd_us'] = timeit(lambda: fwd(0.0), a.iters)
+    res['fwd_drop_us'] = timeit(lambda: fwd(0.1), a.iters)
+    res['bwd_us'] = timeit(bwd, a.iters)
+    res['wgrad_pair_us'] = timeit(wgrad, 10)
+    try:
+        res['old_fwd_us'] = timeit(old_fwd, 20)
+    except Exception as e:                                # noqa: BLE001
+        res['old_fwd_us'] = str(e)
+    fl_f = 2.0 * M * (2 * F * d + F * d)
+    fl_b = 2.0 * M * (2 * F * d + F * d + 2 * F * d)
+    res['fwd_tflops'] = fl_f / res['fwd_us'] / 1e6
+    res['bwd_tflops'] = fl_b / res['bwd_us'] / 1e6
+    print(json.dumps(res))
+
+
+if __name__ == '__main__':
+    main()
