@@ -12,9 +12,14 @@
  *    entries are legal inside hipGraph stream capture.
  *  - return 0 = OK, negative = bad argument (nothing launched), positive = hipError_t.
  *    otr_last_error_string() describes the last failure on the calling thread.
- *  - dtype codes: OTR_F32 = 0, OTR_BF16 = 1 (raw bf16 bits).  `compute` selects the MFMA type:
- *    OTR_BF16 -> v_mfma_f32_16x16x32_bf16 (fp32 accumulate), OTR_F32 -> v_mfma_f32_16x16x4_f32
- *    (exact fp32, the parity mode).
+ *  - dtype codes: OTR_F32 = 0, OTR_BF16 = 1 (raw bf16 bits), OTR_F16 = 2 (IEEE binary16 bits).  The library is built
+ *    twice from one source: libotrans_hip.so has bf16 as its 16-bit storage / MFMA-input type and accepts OTR_BF16,
+ *    libotrans_hip_f16.so has fp16 and accepts OTR_F16 (otr_half_type() says which; the other code is rejected).
+ *    Below, "bf16" in a parameter name or comment means "the 16-bit type of the build".  fp16 carries 3 more mantissa
+ *    bits (logits 5e-4 from the fp32 reference instead of 3.9e-3, tools/precision_study.py) at the same MFMA rate;
+ *    its gradients need loss scaling (see otr_optimizer_step).  `compute` selects the MFMA type: the 16-bit code ->
+ *    v_mfma_f32_{16x16x32,32x32x16}_{bf16,f16} (fp32 accumulate), OTR_F32 -> v_mfma_f32_16x16x4_f32 (exact fp32,
+ *    the parity mode).
  */
 #ifndef OTRANS_HIP_H
 #define OTRANS_HIP_H
@@ -26,10 +31,13 @@ extern "C" {
 
 #define OTR_F32 0
 #define OTR_BF16 1
+#define OTR_F16 2
 #define OTR_ACT_NONE 0
 #define OTR_ACT_RELU 1
 
 int32_t otr_version(void);
+/* OTR_BF16 or OTR_F16: the 16-bit type this library was built for */
+int32_t otr_half_type(void);
 /* tuning hook for benchmarks: key 0 = force GEMM tile (0 auto / 64 / 128), key 1 = force split-K (0 auto),
  * key 2 = 1: generic (bounds-checked) loaders only, key 3 = 1: no persistent tile loop */
 int32_t otr_debug_set(int32_t key, int32_t value);
@@ -302,16 +310,22 @@ int32_t otr_ctc_loss(const float* log_probs, const int64_t* targets, int64_t ldt
                      const int32_t* tgt_len, int32_t B, int32_t T, int32_t V, int32_t max_tgt, int32_t blank,
                      float* alpha_ws, float* nll, float* loss, float* dlogits, void* stream);
 
-/* ---- one optimizer update over a replica's FLAT buffers (train/trainer.py:221-234 clip_grad_norm_(5) +
+/* ---- one optimizer update over a replica's FLAT buffers (train/trainer.py:221-234 clip_grad_norm_(5) + gradient noise +
  *      NaN guard + scheduler.step + optimizer.step; train/scheduler.py:129-138 Noam lr; torch Adam with
  *      L2 weight decay, train/scheduler.py:10-13).  grad_scale (1/world_size after the all-reduce-sum)
- *      is folded into clip + update.  state: f32[8] device block {step, lr, bc1, bc2, sqnorm, skipped},
- *      zero-initialised by the caller once.  noam_warmup <= 0 selects the constant base_lr. */
+ *      is folded into clip + update.  state: f32[16] device block, zero-initialised by the caller once:
+ *        [0] step  [1] lr  [2] bc1  [3] bc2  [4] sqnorm  [5] skipped  [6] loss_scale  [7] good_steps  [8] unscale
+ *        [9] growth_interval  [10..15] reserved.
+ *      Loss scaling (fp16 builds): when state[6] > 0 the gradients in `grad` are state[6] times too large (the caller
+ *      seeded its backward pass with that device scalar); the update divides it out, HALVES it and skips the update when
+ *      the gradient norm is not finite, and doubles it after state[9] consecutive finite updates (0 = never) -- all on
+ *      the device, so the step stays hipGraph-replayable.  grad_noise_std > 0 adds N(0, std) to every gradient element
+ *      after clipping (trainer.py:223-227; pass train.grad_noise / accum_steps).  noam_warmup <= 0 selects base_lr. */
 int32_t otr_optimizer_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                           float* state, void* param_bf16 /* NULL or bf16 shadow[n] refreshed in the same pass */,
+                           float* state, void* param_bf16 /* NULL or 16-bit shadow[n] refreshed in the same pass */,
                            float base_lr, float beta1, float beta2, float eps, float weight_decay,
                            float grad_scale, float clip_norm, float noam_model_size, float noam_warmup,
-                           float noam_factor, float noam_step_offset, void* stream);
+                           float noam_factor, float noam_step_offset, float grad_noise_std, void* stream);
 
 /* ---- batch beam search step (recognize/speech2text.py:95-192).
  * beam_topk: rows = batch*beam hypotheses; logits f32 [rows, V] (row stride ld) are the decoder logits of

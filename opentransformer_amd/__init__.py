@@ -7,7 +7,7 @@ the C ABI of include/otrans_hip.h (opentransformer_amd/lib/libotrans_hip.so).  N
 from . import synthetic                                   # noqa: F401  (numpy/torch host helpers only)
 from . import data, tools                                # noqa: F401  (batch assembly / SpecAugment; checkpoint + WER tooling)
 from .ops import set_compute_dtype, get_compute_dtype     # noqa: F401
-from .model import (BuildFrontEnd, BuildEncoder, BuildDecoder, End2EndModel, SpeechToText,   # noqa: F401
+from .model import (BuildFrontEnd, BuildEncoder, BuildDecoder, End2EndModel, SpeechToText, CTCModel,   # noqa: F401
                     CTCAssistor)
 from .nn import (ConvFrontEnd, ConformerEncoder, ConformerEncoderBlock, ConformerConvolutionModule,   # noqa: F401
                  MultiHeadedSelfAttentionWithRelPos)

@@ -7,9 +7,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libotrans_hip.so')
+# One source, two builds: the 16-bit storage / MFMA-input type is bf16 in libotrans_hip.so and IEEE fp16 in
+# libotrans_hip_f16.so (csrc/common.h).  select() picks the build every later load() returns; ops.set_compute_dtype calls it.
+LIB_PATHS = {'bf16': os.path.join(_HERE, 'lib', 'libotrans_hip.so'), 'fp16': os.path.join(_HERE, 'lib', 'libotrans_hip_f16.so')}
+LIB_PATH = LIB_PATHS['bf16']
 
-OTR_F32, OTR_BF16 = 0, 1
+OTR_F32, OTR_BF16, OTR_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU = 0, 1
 
 
@@ -57,6 +60,7 @@ _I32, _I64, _F32 = C.c_int32, C.c_int64, C.c_float
 # include/otrans_hip.h declares; tests/test_cabi.py cross-checks the two.
 SIGNATURES = {
     'otr_version': [],
+    'otr_half_type': [],
     'otr_debug_set': [_I32, _I32],
     'otr_last_error_string': [],
     'otr_linear_fwd': [C.POINTER(LinearDesc), _P, _P, _P, _P, _P, _I64, _P],
@@ -99,7 +103,7 @@ SIGNATURES = {
     'otr_label_smoothing_loss': [_P, _P, _I64, _I32, _F32, _I32, _P, _P, _P, _P],
     'otr_log_softmax': [_P, _P, _I64, _I32, _P],
     'otr_ctc_loss': [_P, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
-    'otr_optimizer_step': [_P, _P, _P, _P, _I64, _P, _P] + [_F32] * 11 + [_P],
+    'otr_optimizer_step': [_P, _P, _P, _P, _I64, _P, _P] + [_F32] * 12 + [_P],
     'otr_beam_topk': [_P, _I64, _P, _I64, _F32, _I64, _I32, _I32, _P, _P, _P],
     'otr_beam_prune': [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     'otr_beam_prune_cached': [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P],
@@ -117,28 +121,39 @@ SIGNATURES = {
 }
 _RESTYPE = {'otr_last_error_string': C.c_char_p, 'otr_add_layernorm_bwd_partial_rows': C.c_int64}
 
-_lib = None
+_libs = {}
+_kind = 'bf16'
 
 
 class OtransHipError(RuntimeError):
     pass
 
 
-def load():
-    """Load the HIP library or raise -- never falls back to anything else."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def select(kind):
+    """choose the build (16-bit type 'bf16' or 'fp16') that load() returns from now on"""
+    global _kind
+    assert kind in LIB_PATHS
+    _kind = kind
+
+
+def load(kind=None):
+    """Load the HIP library (the selected build) or raise -- never falls back to anything else."""
+    kind = kind or _kind
+    lib = _libs.get(kind)
+    if lib is not None:
+        return lib
+    path = LIB_PATHS[kind]
+    if not os.path.exists(path):
         raise OtransHipError(
-            'libotrans_hip.so not found at %s. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
-            '(or `make -C opentransformer_amd/csrc`). There is no CPU/PyTorch fallback.' % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+            '%s not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(or `make -C opentransformer_amd/csrc`). There is no CPU/PyTorch fallback.' % path)
+    lib = C.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, C.c_int32)
-    _lib = lib
+    assert lib.otr_half_type() == (OTR_F16 if kind == 'fp16' else OTR_BF16), 'library / 16-bit type mismatch'
+    _libs[kind] = lib
     return lib
 
 

@@ -49,18 +49,19 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   return 0;
 }
 
-extern "C" int32_t otr_version(void) { return 100; }
+extern "C" int32_t otr_version(void) { return 200; }
+extern "C" int32_t otr_half_type(void) { return OTR_H16; }
 extern "C" const char* otr_last_error_string(void) { return g_err; }
 
 static inline int esize(int dtype) { return dtype == OTR_F32 ? 4 : 2; }
-static inline bool dtype_ok(int d) { return d == OTR_F32 || d == OTR_BF16; }
+static inline bool dtype_ok(int d) { return d == OTR_F32 || d == OTR_H16; }
 // vector path of the row-major loaders: 16-byte aligned base and rows
 static inline int kc_vec(const void* p, int64_t ld, int dtype) {
   return ((uintptr_t)p % 16 == 0) && (ld % (16 / esize(dtype)) == 0);
 }
 // PM-element vector path of the transposing loaders (PM = 4 rows for bf16 compute, 2 for fp32)
 static inline int mc_vec(const void* p, int64_t ld, int dtype, int compute) {
-  int pm = compute == OTR_BF16 ? 4 : 2;
+  int pm = compute == OTR_H16 ? 4 : 2;
   return ((uintptr_t)p % (pm * esize(dtype)) == 0) && (ld % pm == 0);
 }
 
@@ -68,7 +69,7 @@ static int32_t run_gemm(const GemmArgs& a, int compute, int ad, int bd, int cd, 
   if (a.M <= 0 || a.N <= 0) return 0;
   OTR_REQUIRE(a.K > 0, "gemm: K must be positive (got %d)", a.K);
   hipStream_t s = (hipStream_t)stream;
-  if (compute == OTR_BF16) return gemm_dispatch_bf16(a, ad, bd, cd, amode, bmode, s);
+  if (compute == OTR_H16) return gemm_dispatch_bf16(a, ad, bd, cd, amode, bmode, s);
   if (compute == OTR_F32) return gemm_dispatch_f32(a, ad, bd, cd, amode, bmode, s);
   otr_set_error("gemm: bad compute type %d", compute);
   return -1;
@@ -139,7 +140,7 @@ extern "C" int32_t otr_ffn_glu_fwd(const void* x, int64_t ldx, const void* w1, i
   const int64_t t128 = (int64_t)((M + 127) / 128) * ((2 * F + 127) / 128);
   const bool big = M >= 128 && F >= 128 && t128 >= 256 && g_otr_force_tile != 64;
   const int half = big ? 64 : 32;                          // value columns per tile
-  const bool ok = kc_vec(x, ldx, OTR_BF16) && kc_vec(w1, ldw, OTR_BF16) && d_model % 8 == 0 && F % half == 0 &&
+  const bool ok = kc_vec(x, ldx, OTR_H16) && kc_vec(w1, ldw, OTR_H16) && d_model % 8 == 0 && F % half == 0 &&
                   (uintptr_t)h % 16 == 0 && (uintptr_t)u % 16 == 0 && g_otr_force_generic == 0;
   if (!ok) return 1;
   GemmArgs a{};
@@ -152,7 +153,7 @@ extern "C" int32_t otr_ffn_glu_fwd(const void* x, int64_t ldx, const void* w1, i
   a.aux_out = u;
   const int keep = g_otr_force_tile;
   g_otr_force_tile = big ? 128 : 64;                       // F % (tile/2) == 0 was checked for this tile width
-  const int32_t e = run_gemm(a, OTR_BF16, OTR_BF16, OTR_BF16, OTR_BF16, MODE_KC, MODE_KC, stream);
+  const int32_t e = run_gemm(a, OTR_H16, OTR_H16, OTR_H16, OTR_H16, MODE_KC, MODE_KC, stream);
   g_otr_force_tile = keep;
   return e;
 }
@@ -168,7 +169,7 @@ extern "C" int32_t otr_ffn_glu_bwd(const void* dy, int32_t dy_dtype, int64_t ldy
   OTR_REQUIRE(M >= 0 && F > 0 && d_model > 0 && ldy >= d_model && ldw >= d_model, "ffn_glu_bwd: bad shape");
   *partial_rows = 0;
   if (M == 0) return 0;
-  const bool ok = dy_dtype == OTR_BF16 && kc_vec(dy, ldy, OTR_BF16) && kc_vec(w2t, ldw, OTR_BF16) && d_model % 8 == 0 &&
+  const bool ok = dy_dtype == OTR_H16 && kc_vec(dy, ldy, OTR_H16) && kc_vec(w2t, ldw, OTR_H16) && d_model % 8 == 0 &&
                   F % 8 == 0 && (uintptr_t)h % 16 == 0 && (uintptr_t)dh % 16 == 0 && g_otr_force_generic == 0;
   const int64_t t128 = (int64_t)((M + 127) / 128) * ((F + 127) / 128);
   const bool big = M >= 128 && F >= 128 && t128 >= 256 && g_otr_force_tile != 64;   // few tiles: 64x64 fills the chip better
@@ -184,7 +185,7 @@ extern "C" int32_t otr_ffn_glu_bwd(const void* dy, int32_t dy_dtype, int64_t ldy
   a.aux_in = h; a.aux_out = dh; a.aux_part = dbias_partial;
   const int keep = g_otr_force_tile;
   g_otr_force_tile = big ? 128 : 64;                  // the partial layout depends on the tile height: pin it
-  const int32_t e = run_gemm(a, OTR_BF16, OTR_BF16, OTR_BF16, OTR_BF16, MODE_KC, MODE_KC, stream);
+  const int32_t e = run_gemm(a, OTR_H16, OTR_H16, OTR_H16, OTR_H16, MODE_KC, MODE_KC, stream);
   g_otr_force_tile = keep;
   if (e) return e;
   *partial_rows = rows;
@@ -196,8 +197,8 @@ extern "C" int32_t otr_ffn_glu_bwd(const void* dy, int32_t dy_dtype, int64_t ldy
 extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32_t n, int32_t compute, void* workspace,
                                             int64_t workspace_bytes, void* stream) {
   OTR_REQUIRE(n >= 0 && (items || n == 0), "linear_wgrad_grouped: null items");
-  OTR_REQUIRE(compute == OTR_BF16 || compute == OTR_F32, "linear_wgrad_grouped: bad compute type");
-  const int pm = compute == OTR_BF16 ? 4 : 2;
+  OTR_REQUIRE(compute == OTR_H16 || compute == OTR_F32, "linear_wgrad_grouped: bad compute type");
+  const int pm = compute == OTR_H16 ? 4 : 2;
   std::vector<int> order[16];   // key = big(1) | dy dtype(1) | x dtype(1)
   for (int i = 0; i < n; ++i) {
     const otr_wgrad_item_t& it = items[i];
@@ -207,7 +208,7 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
     OTR_REQUIRE(dtype_ok(it.dy_dtype) && dtype_ok(it.x_dtype), "linear_wgrad_grouped: item %d has a bad dtype", i);
     if (it.M == 0) continue;
     const bool fast = mc_vec(it.dy, it.ldy, it.dy_dtype, compute) && mc_vec(it.x, it.ldx, it.x_dtype, compute) &&
-                      it.N % pm == 0 && it.K % pm == 0 && it.M % (compute == OTR_BF16 ? 8 : 4) == 0 &&
+                      it.N % pm == 0 && it.K % pm == 0 && it.M % (compute == OTR_H16 ? 8 : 4) == 0 &&
                       (uintptr_t)it.dw % 16 == 0 && it.ldw % 4 == 0 &&
                       it.ldy < (1ll << 31) && it.ldx < (1ll << 31) && it.ldw < (1ll << 31);
     if (!fast) {   // odd alignment: the stand-alone path (generic loaders, split-K through the workspace)
@@ -219,7 +220,7 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
       continue;
     }
     const int big = (it.N >= 128 && it.K >= 128) ? 1 : 0;
-    order[(big << 2) | (it.dy_dtype << 1) | it.x_dtype].push_back(i);
+    order[(big << 2) | ((it.dy_dtype != OTR_F32) << 1) | (it.x_dtype != OTR_F32)].push_back(i);   // dtype codes -> 0 / 1
   }
   hipStream_t s = (hipStream_t)stream;
   for (int key = 0; key < 8; ++key) {
@@ -235,9 +236,9 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
       d[c].lda = (int)it.ldy; d[c].ldb = (int)it.ldx; d[c].ldc = (int)it.ldw;
       d[c].a_vec = 1; d[c].b_vec = 1;
     }
-    const int ad = (key >> 1) & 1, bd = key & 1, big = key >> 2;
+    const int ad = ((key >> 1) & 1) ? OTR_H16 : OTR_F32, bd = (key & 1) ? OTR_H16 : OTR_F32, big = key >> 2;
     OTR_REQUIRE(workspace && workspace_bytes >= 4096, "linear_wgrad_grouped: needs a workspace (descriptor table)");
-    int32_t e = compute == OTR_BF16 ? gemm_grouped_wgrad_bf16(d.data(), (int)d.size(), ad, bd, big, workspace, workspace_bytes, s)
+    int32_t e = compute == OTR_H16 ? gemm_grouped_wgrad_bf16(d.data(), (int)d.size(), ad, bd, big, workspace, workspace_bytes, s)
                                     : gemm_grouped_wgrad_f32(d.data(), (int)d.size(), ad, bd, big, workspace, workspace_bytes, s);
     if (e) return e;
   }

@@ -105,7 +105,7 @@ __device__ __forceinline__ void load_tile_tr(unsigned char* lds, const CT* g, in
             v0[j] = t.x; v1[j] = t.y;
           } else {
             uint32_t t = *reinterpret_cast<const uint32_t*>(p);
-            v0[j] = __uint_as_float(t << 16); v1[j] = __uint_as_float(t & 0xffff0000u);
+            v0[j] = h2f_lo(t); v1[j] = h2f_hi(t);
           }
         } else {
           v0[j] = ElemIO<CT>::ld(p); v1[j] = ElemIO<CT>::ld(p + 1);
@@ -575,8 +575,8 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
         if constexpr (sizeof(CT) == 4) {
           acc_d += __uint_as_float(aw[e]) * __uint_as_float(bw[e]);
         } else {
-          acc_d += __uint_as_float(aw[e] << 16) * __uint_as_float(bw[e] << 16);
-          acc_d += __uint_as_float(aw[e] & 0xffff0000u) * __uint_as_float(bw[e] & 0xffff0000u);
+          acc_d += h2f_lo(aw[e]) * h2f_lo(bw[e]);
+          acc_d += h2f_hi(aw[e]) * h2f_hi(bw[e]);
         }
       }
     }
@@ -667,7 +667,7 @@ static int32_t fill_args(const otr_attn_desc_t* d, AttnArgs& a) {
   OTR_REQUIRE(d != nullptr, "attention: null descriptor");
   OTR_REQUIRE(d->B > 0 && d->H > 0 && d->Tq > 0 && d->Tk > 0, "attention: bad shape B=%d H=%d Tq=%d Tk=%d", d->B, d->H,
               d->Tq, d->Tk);
-  OTR_REQUIRE(d->dtype == OTR_F32 || d->dtype == OTR_BF16, "attention: bad dtype %d", d->dtype);
+  OTR_REQUIRE(d->dtype == OTR_F32 || d->dtype == OTR_H16, "attention: bad dtype %d", d->dtype);
   OTR_REQUIRE(d->dk == 16 || d->dk == 32 || d->dk == 64 || d->dk == 96 || d->dk == 128,
               "attention: head dim %d not built (16/32/64/96/128)", d->dk);
   a.B = d->B; a.H = d->H; a.Tq = d->Tq; a.Tk = d->Tk;
@@ -709,7 +709,7 @@ extern "C" int32_t otr_attention_fwd(const otr_attn_desc_t* d, const void* q, co
   a.vec = vec_ok(d, {q, k, v, o});
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((d->Tq + 63) / 64, d->H, d->B);
-  if (d->dtype == OTR_BF16) { DK_SWITCH(bf16_t, attn_fwd_kernel, grid) } else { DK_SWITCH(float, attn_fwd_kernel, grid) }
+  if (d->dtype == OTR_H16) { DK_SWITCH(bf16_t, attn_fwd_kernel, grid) } else { DK_SWITCH(float, attn_fwd_kernel, grid) }
   return otr_check_launch("attention_fwd");
 }
 
@@ -729,7 +729,7 @@ extern "C" int32_t otr_attention_bias_fwd(const otr_attn_desc_t* d, const void* 
   set_bias(a, bias, nullptr, bias_bs, bias_hs, bias_rs, rel_shift);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((d->Tq + 63) / 64, d->H, d->B);
-  if (d->dtype == OTR_BF16) { DK_SWITCH(bf16_t, attn_fwd_kernel, grid) } else { DK_SWITCH(float, attn_fwd_kernel, grid) }
+  if (d->dtype == OTR_H16) { DK_SWITCH(bf16_t, attn_fwd_kernel, grid) } else { DK_SWITCH(float, attn_fwd_kernel, grid) }
   return otr_check_launch("attention_bias_fwd");
 }
 
@@ -766,7 +766,7 @@ static int32_t attention_bwd_impl(const otr_attn_desc_t* d, AttnArgs& a, void* s
   hipStream_t s = (hipStream_t)stream;
   // dQ first: it also produces delta = rowsum(dO * O), which the dK/dV kernel reads
   dim3 gk((d->Tk + 63) / 64, d->H, d->B), gq((d->Tq + 63) / 64, d->H, d->B);
-  if (d->dtype == OTR_BF16) {
+  if (d->dtype == OTR_H16) {
     DK_SWITCH(bf16_t, attn_bwd_dq_kernel, gq)
     DK_SWITCH(bf16_t, attn_bwd_dkdv_kernel, gk)
   } else {

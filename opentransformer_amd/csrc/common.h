@@ -16,8 +16,20 @@
 
 #include "../../include/otrans_hip.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// The 16-bit storage / MFMA-input type is a BUILD parameter: bf16 (libotrans_hip.so, dtype code OTR_BF16) or IEEE fp16
+// (-DOTR_HALF_FP16: libotrans_hip_f16.so, dtype code OTR_F16).  fp16 has 3 more mantissa bits -- the full model's
+// logits land 5e-4 from the fp32 reference instead of 3.9e-3 (tools/precision_study.py) at the same MFMA rate -- and
+// needs loss scaling for the gradients (ops.ScaleGradFn + otr_optimizer_step).  Kernels call the 16-bit type "bf16_t"
+// (raw bits) throughout; only the conversions and the MFMA opcode below differ.
+#ifdef OTR_HALF_FP16
+typedef _Float16 otr_hreal;
+#define OTR_H16 OTR_F16
+#else
+typedef __bf16 otr_hreal;
+#define OTR_H16 OTR_BF16
+#endif
+typedef __attribute__((ext_vector_type(8))) otr_hreal bf16x8;
+typedef __attribute__((ext_vector_type(2))) otr_hreal bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef uint16_t bf16_t;  // raw bf16 bits in memory
@@ -57,9 +69,17 @@ __device__ __forceinline__ void st_global_b128(void* p, uint4 v) {
 }
 
 // ---------------------------------------------------------------- scalar conversions
+#ifdef OTR_HALF_FP16
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ float h2f_lo(uint32_t w) { return bf2f((bf16_t)(w & 0xffffu)); }   // low / high half of a packed pair
+__device__ __forceinline__ float h2f_hi(uint32_t w) { return bf2f((bf16_t)(w >> 16)); }
+#else
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // RNE, lowers to v_cvt_pk_bf16_f32
-  __bf16 h = (__bf16)f;
+__device__ __forceinline__ float h2f_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float h2f_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+#endif
+__device__ __forceinline__ bf16_t f2bf(float f) {  // RNE (v_cvt_pk_bf16_f32 / v_cvt_f16_f32)
+  otr_hreal h = (otr_hreal)f;
   return __builtin_bit_cast(bf16_t, h);
 }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
@@ -72,14 +92,16 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 __device__ __forceinline__ float h2f(bf16_t v) { return bf2f(v); }
 __device__ __forceinline__ bf16_t f2h(float f) { return f2bf(f); }
 __device__ __forceinline__ uint32_t pack2h(float lo, float hi) { return pack2bf(lo, hi); }
-__device__ __forceinline__ float h2f_lo(uint32_t w) { return bf2f((bf16_t)(w & 0xffffu)); }   // low / high half of a packed pair
-__device__ __forceinline__ float h2f_hi(uint32_t w) { return bf2f((bf16_t)(w >> 16)); }
 
 // 32x32x16 MFMA on the 16-bit storage type.  A: lane l holds row (l&31), k = (l>>5)*8 + 0..7; B: col (l&31), same k;
 // D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)  (MI355X_MICROARCH / cdna_hip_programming.md section 3)
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 __device__ __forceinline__ void mma32(f32x16& acc, const uint4& a, const uint4& b) {
+#ifdef OTR_HALF_FP16
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+#else
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+#endif
 }
 
 template <class T> struct ElemIO;
@@ -100,8 +122,11 @@ template <> struct MMA<bf16_t> {
   static constexpr int KSTEP = 32;   // contraction length of one mma() call
   static constexpr int TPC = 2;      // 16-wide C tiles that make up one contraction chunk
   static __device__ __forceinline__ void mma(f32x4& acc, const uint4& a, const uint4& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
-                                                  acc, 0, 0, 0);
+#ifdef OTR_HALF_FP16
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+#else
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+#endif
   }
   // pack CE floats into a chunk
   static __device__ __forceinline__ uint4 pack(const float* f) {
@@ -156,15 +181,15 @@ __device__ __forceinline__ void load_row(const ST* p, int nvalid, bool vec, floa
     } else {
       if constexpr (N == 8) {
         uint4 v = *reinterpret_cast<const uint4*>(p);
-        out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xffff0000u);
-        out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xffff0000u);
-        out[4] = __uint_as_float(v.z << 16); out[5] = __uint_as_float(v.z & 0xffff0000u);
-        out[6] = __uint_as_float(v.w << 16); out[7] = __uint_as_float(v.w & 0xffff0000u);
+        out[0] = h2f_lo(v.x); out[1] = h2f_hi(v.x);
+        out[2] = h2f_lo(v.y); out[3] = h2f_hi(v.y);
+        out[4] = h2f_lo(v.z); out[5] = h2f_hi(v.z);
+        out[6] = h2f_lo(v.w); out[7] = h2f_hi(v.w);
       } else {
         static_assert(N == 4, "bf16 rows are read 4 or 8 at a time");
         uint2 v = *reinterpret_cast<const uint2*>(p);
-        out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xffff0000u);
-        out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xffff0000u);
+        out[0] = h2f_lo(v.x); out[1] = h2f_hi(v.x);
+        out[2] = h2f_lo(v.y); out[3] = h2f_hi(v.y);
       }
     }
   } else {

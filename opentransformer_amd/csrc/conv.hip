@@ -173,7 +173,7 @@ static int32_t conv_check(const otr_conv_desc_t* d, ConvArgs& a) {
   OTR_REQUIRE(d->F1 == (d->F - 1) / 2 + 1 && d->F2 == (d->F1 - 1) / 2 + 1, "conv: F1/F2 inconsistent with F");
   OTR_REQUIRE(d->C1 >= 8 && d->C1 % 8 == 0 && d->C1 <= 256 && 256 % (d->C1 / 8) == 0,
               "conv: C1=%d must be a multiple of 8 with C1/8 dividing 256", d->C1);
-  OTR_REQUIRE(d->act_dtype == OTR_F32 || d->act_dtype == OTR_BF16, "conv: bad act dtype");
+  OTR_REQUIRE(d->act_dtype == OTR_F32 || d->act_dtype == OTR_H16, "conv: bad act dtype");
   a.B = d->B; a.T = d->T; a.F = d->F; a.C1 = d->C1; a.C2 = d->C2;
   a.T1 = d->T1; a.F1 = d->F1; a.T2 = d->T2; a.F2 = d->F2;
   return 0;

@@ -106,7 +106,7 @@ extern "C" int32_t otr_decode_self_attention(const void* qkv, void* kcache, void
                                              const int32_t* pos, void* out, int32_t dtype, int64_t rows, int32_t H,
                                              int32_t dk, int32_t maxlen, float scale, void* stream) {
   OTR_REQUIRE(qkv && kcache && vcache && anc && pos && out, "decode_self_attention: null pointer");
-  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_BF16, "decode_self_attention: dtype must be f32 or bf16");
+  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_H16, "decode_self_attention: dtype must be f32 or bf16");
   OTR_REQUIRE(H > 0 && dk > 0 && dk <= 128 && maxlen > 0 && rows >= 0, "decode_self_attention: bad shape (dk <= 128)");
   OTR_REQUIRE(rows * H < (1ll << 31), "decode_self_attention: too many rows");
   if (rows == 0) return 0;

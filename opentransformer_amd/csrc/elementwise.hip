@@ -71,7 +71,7 @@ template <class T> __global__ void glu_bwd_kernel(const T* h, const T* du, T* dh
 extern "C" int32_t otr_glu_fwd(const void* h, void* u, int32_t dtype, int64_t M, int64_t F, const uint8_t* row_mask,
                                void* stream) {
   OTR_REQUIRE(h && u, "glu_fwd: null pointer");
-  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_BF16, "glu_fwd: bad dtype");
+  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_H16, "glu_fwd: bad dtype");
   OTR_REQUIRE(F > 0 && F % 8 == 0 && M >= 0, "glu_fwd: F=%lld must be a positive multiple of 8", (long long)F);
   if (M == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
@@ -83,7 +83,7 @@ extern "C" int32_t otr_glu_fwd(const void* h, void* u, int32_t dtype, int64_t M,
 extern "C" int32_t otr_glu_bwd(const void* h, const void* du, void* dh, float* dbias, int32_t dtype, int64_t M,
                                int64_t F, const uint8_t* row_mask, int32_t h_has_sigmoid, void* stream) {
   OTR_REQUIRE(h && du && dh, "glu_bwd: null pointer");
-  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_BF16, "glu_bwd: bad dtype");
+  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_H16, "glu_bwd: bad dtype");
   OTR_REQUIRE(F > 0 && F % 8 == 0 && M >= 0, "glu_bwd: F=%lld must be a positive multiple of 8", (long long)F);
   if (M == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
@@ -101,7 +101,7 @@ template <class T> __global__ void relu_bwd_kernel(const T* y, const T* g, T* ou
 }
 extern "C" int32_t otr_relu_bwd(const void* y, const void* g, void* out, int32_t dtype, int64_t n, void* stream) {
   OTR_REQUIRE(y && g && out, "relu_bwd: null pointer");
-  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_BF16, "relu_bwd: bad dtype");
+  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_H16, "relu_bwd: bad dtype");
   if (n <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == OTR_F32) hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)y, (const float*)g, (float*)out, n);
@@ -157,7 +157,7 @@ template <class T, bool BWD> static void act_launch(int kind, const void* x, con
 }
 static int32_t act_check(const char* what, const void* x, const void* out, int32_t dtype, int64_t n, int32_t kind) {
   OTR_REQUIRE(x && out, "%s: null pointer", what);
-  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_BF16, "%s: bad dtype", what);
+  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_H16, "%s: bad dtype", what);
   OTR_REQUIRE(kind >= ACT_GELU && kind <= ACT_SWISH, "%s: kind must be 1 (gelu), 2 (tanh) or 3 (swish)", what);
   OTR_REQUIRE(n >= 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0, "%s: buffers must be 16-byte aligned", what);
   return 0;
@@ -301,7 +301,7 @@ template <class T> __global__ void colsum_kernel(const T* a, int64_t M, int64_t 
 extern "C" int32_t otr_colsum(const void* a, int32_t dtype, int64_t M, int64_t N, int64_t lda, float* out,
                               int32_t accumulate, void* stream) {
   OTR_REQUIRE(a && out, "colsum: null pointer");
-  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_BF16, "colsum: bad dtype");
+  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_H16, "colsum: bad dtype");
   OTR_REQUIRE(N > 0 && M >= 0 && lda >= N, "colsum: bad shape");
   OTR_REQUIRE((uintptr_t)a % 16 == 0, "colsum: input must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
@@ -371,7 +371,8 @@ template <class T> __global__ void colsum_grouped_kernel(ColsumGroup g) {
 extern "C" int32_t otr_colsum_grouped(const otr_colsum_item_t* items, int32_t n, void* stream) {
   OTR_REQUIRE(n >= 0 && (items || n == 0), "colsum_grouped: null items");
   hipStream_t s = (hipStream_t)stream;
-  for (int dt = 0; dt < 2; ++dt) {
+  for (int pass = 0; pass < 2; ++pass) {
+    const int dt = pass == 0 ? OTR_F32 : OTR_H16;
     ColsumGroup g{};
     int blocks = 0;
     auto flush = [&]() -> int32_t {
@@ -386,7 +387,7 @@ extern "C" int32_t otr_colsum_grouped(const otr_colsum_item_t* items, int32_t n,
     for (int i = 0; i < n; ++i) {
       const otr_colsum_item_t& it = items[i];
       OTR_REQUIRE(it.a && it.out, "colsum_grouped: item %d has a null pointer", i);
-      OTR_REQUIRE(it.dtype == OTR_F32 || it.dtype == OTR_BF16, "colsum_grouped: item %d has a bad dtype", i);
+      OTR_REQUIRE(it.dtype == OTR_F32 || it.dtype == OTR_H16, "colsum_grouped: item %d has a bad dtype", i);
       OTR_REQUIRE(it.N > 0 && it.M >= 0 && it.lda >= it.N && it.lda < (1ll << 31) && it.M < (1ll << 31),
                   "colsum_grouped: item %d has a bad shape", i);
       OTR_REQUIRE((uintptr_t)it.a % 16 == 0, "colsum_grouped: item %d input must be 16-byte aligned", i);

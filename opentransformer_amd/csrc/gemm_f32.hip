@@ -25,8 +25,8 @@ int32_t gemm_grouped_wgrad_f32(const GroupDesc* d, int n, int ad, int bd, int bi
 #define GCASE(AT, BT)                                                                  \
   return big ? gemm_grouped_launch<float, AT, BT, 128, 128>(d, n, tm, tb, s) : gemm_grouped_launch<float, AT, BT, 64, 64>(d, n, tm, tb, s)
   if (ad == OTR_F32 && bd == OTR_F32) { GCASE(float, float); }
-  if (ad == OTR_F32 && bd == OTR_BF16) { GCASE(float, bf16_t); }
-  if (ad == OTR_BF16 && bd == OTR_F32) { GCASE(bf16_t, float); }
+  if (ad == OTR_F32 && bd == OTR_H16) { GCASE(float, bf16_t); }
+  if (ad == OTR_H16 && bd == OTR_F32) { GCASE(bf16_t, float); }
   GCASE(bf16_t, bf16_t);
 #undef GCASE
 }

@@ -92,11 +92,11 @@ template <class ST, int N> __device__ __forceinline__ void load_vec(const ST* p,
   } else {
     if constexpr (N == 4) {
       uint2 v = *reinterpret_cast<const uint2*>(p);
-      out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xffff0000u);
-      out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xffff0000u);
+      out[0] = h2f_lo(v.x); out[1] = h2f_hi(v.x);
+      out[2] = h2f_lo(v.y); out[3] = h2f_hi(v.y);
     } else {
       uint32_t v = *reinterpret_cast<const uint32_t*>(p);
-      out[0] = __uint_as_float(v << 16); out[1] = __uint_as_float(v & 0xffff0000u);
+      out[0] = h2f_lo(v); out[1] = h2f_hi(v);
     }
   }
 }
@@ -729,8 +729,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
               float o[EPC], sg[EPC];
 #pragma unroll
               for (int e = 0; e < EPC; ++e) {
-                const float a = __uint_as_float((e & 1) ? (aw[e >> 1] & 0xffff0000u) : (aw[e >> 1] << 16));
-                const float b = __uint_as_float((e & 1) ? (bw[e >> 1] & 0xffff0000u) : (bw[e >> 1] << 16));
+                const float a = ((e & 1) ? h2f_hi(aw[e >> 1]) : h2f_lo(aw[e >> 1]));
+                const float b = ((e & 1) ? h2f_hi(bw[e >> 1]) : h2f_lo(bw[e >> 1]));
                 sg[e] = 1.f / (1.f + __expf(-b));
                 o[e] = a * sg[e];
               }
@@ -776,9 +776,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
               const int sh = (e & 1) ? 0 : 16;               // element e of a packed pair: low half first
-              const float d = __uint_as_float((e & 1) ? (dw[e >> 1] & 0xffff0000u) : (dw[e >> 1] << 16));
-              const float a = __uint_as_float((e & 1) ? (aw[e >> 1] & 0xffff0000u) : (aw[e >> 1] << 16));
-              const float b = __uint_as_float((e & 1) ? (bw[e >> 1] & 0xffff0000u) : (bw[e >> 1] << 16));
+              const float d = ((e & 1) ? h2f_hi(dw[e >> 1]) : h2f_lo(dw[e >> 1]));
+              const float a = ((e & 1) ? h2f_hi(aw[e >> 1]) : h2f_lo(aw[e >> 1]));
+              const float b = ((e & 1) ? h2f_hi(bw[e >> 1]) : h2f_lo(bw[e >> 1]));
               (void)sh;
               const float sg = p.aux_flag ? b : 1.f / (1.f + __expf(-b));
               oa[e] = live ? d * sg : 0.f;

@@ -21,8 +21,8 @@ template <class AT> __device__ __forceinline__ void ld4(const AT* p, float* o) {
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
   } else {
     uint2 v = *reinterpret_cast<const uint2*>(p);
-    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[0] = h2f_lo(v.x); o[1] = h2f_hi(v.x);
+    o[2] = h2f_lo(v.y); o[3] = h2f_hi(v.y);
   }
 }
 template <class AT> __device__ __forceinline__ void st4(AT* p, const float* o) {
@@ -216,7 +216,7 @@ static int32_t ln_check(const otr_ln_desc_t* d) {
   OTR_REQUIRE(d->M >= 0 && d->d > 0 && d->d % 4 == 0 && d->d <= LN_MAXV * 256,
               "layernorm: d=%d must be a multiple of 4 and <= %d", d->d, LN_MAXV * 256);
   OTR_REQUIRE(d->p_drop >= 0.f && d->p_drop < 1.f, "layernorm: p_drop=%f out of [0,1)", (double)d->p_drop);
-  OTR_REQUIRE(d->a_dtype == OTR_F32 || d->a_dtype == OTR_BF16, "layernorm: bad a_dtype");
+  OTR_REQUIRE(d->a_dtype == OTR_F32 || d->a_dtype == OTR_H16, "layernorm: bad a_dtype");
   return 0;
 }
 

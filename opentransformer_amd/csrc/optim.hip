@@ -7,11 +7,17 @@
 #include "common.h"
 
 struct OptState {
-  float step;        // number of optimizer updates applied so far (Adam's t)
-  float lr;          // learning rate used by the last update
-  float bc1, bc2;    // 1 - beta^t
-  float sqnorm;      // sum of squares of the (unscaled) flat gradient
-  float skipped;     // count of updates skipped by the NaN guard
+  float step;            // [0] number of optimizer updates applied so far (Adam's t)
+  float lr;              // [1] learning rate used by the last update
+  float bc1, bc2;        // [2,3] 1 - beta^t
+  float sqnorm;          // [4] sum of squares of the flat gradient as it sits in memory (loss-scaled, not yet / world)
+  float skipped;         // [5] count of updates skipped by the NaN guard
+  float loss_scale;      // [6] 0 = loss scaling off; else the factor the backward pass was seeded with (fp16 builds:
+                         //     ops.ScaleGradFn multiplies the loss gradient by this device scalar)
+  float good_steps;      // [7] consecutive finite updates since loss_scale last changed
+  float unscale;         // [8] grad_scale / loss_scale of THIS update (tick kernel -> adam kernel)
+  float growth_interval; // [9] double loss_scale after this many finite updates (0 = never); set by the caller
+  float reserved[6];
 };
 
 __global__ void sqnorm_kernel(const float* g, int64_t n, OptState* st) {
@@ -30,11 +36,26 @@ __global__ void sqnorm_kernel(const float* g, int64_t n, OptState* st) {
   if (threadIdx.x == 0) atomicAdd(&st->sqnorm, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
-// one thread: advance the step counter, evaluate the schedule (Noam if warmup > 0, else constant lr)
+// one thread: NaN guard + dynamic loss scale, then advance the step counter and evaluate the schedule (Noam if
+// warmup > 0, else constant lr)
 __global__ void opt_tick_kernel(OptState* st, float base_lr, float model_size, float warmup, float factor,
                                 float step_offset, float beta1, float beta2, float grad_scale) {
-  float norm = sqrtf(st->sqnorm) * grad_scale;
-  if (!isfinite(norm)) { st->skipped += 1.f; return; }     // trainer.py:229: skip the update
+  const float ls = st->loss_scale > 0.f ? st->loss_scale : 1.f;
+  const float us = grad_scale / ls;
+  st->unscale = us;
+  float norm = sqrtf(st->sqnorm) * us;
+  if (!isfinite(norm)) {                                   // trainer.py:229: skip the update
+    st->skipped += 1.f;
+    if (st->loss_scale > 0.f) { st->loss_scale = fmaxf(ls * 0.5f, 1.f); st->good_steps = 0.f; }   // fp16 overflow: back off
+    return;
+  }
+  if (st->loss_scale > 0.f) {
+    st->good_steps += 1.f;
+    if (st->growth_interval > 0.f && st->good_steps >= st->growth_interval) {
+      st->loss_scale = fminf(ls * 2.f, 65536.f);
+      st->good_steps = 0.f;
+    }
+  }
   float t = st->step + 1.f;
   st->step = t;
   st->bc1 = 1.f - powf(beta1, t);
@@ -47,15 +68,26 @@ __global__ void opt_tick_kernel(OptState* st, float base_lr, float model_size, f
   }
 }
 
+// N(0,1) from the counter RNG (Box-Muller): gradient noise of train/trainer.py:223-227
+__device__ __forceinline__ float otr_gauss(uint64_t seed, uint64_t idx) {
+  const float u1 = ((float)otr_rand32(seed, 2 * idx) + 1.f) * (1.f / 4294967296.f);
+  const float u2 = (float)otr_rand32(seed, 2 * idx + 1) * (1.f / 4294967296.f);
+  return sqrtf(-2.f * __logf(u1)) * __cosf(6.2831853f * u2);
+}
+
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, const OptState* st, bf16_t* p_lp,
-                            float beta1, float beta2, float eps, float wd, float grad_scale, float clip) {
-  const float norm = sqrtf(st->sqnorm) * grad_scale;
+                            float beta1, float beta2, float eps, float wd, float clip, float noise_std) {
+  const float us = st->unscale;
+  const float norm = sqrtf(st->sqnorm) * us;
   if (!isfinite(norm)) return;
-  const float coef = grad_scale * (clip > 0.f ? fminf(1.f, clip / (norm + 1e-6f)) : 1.f);
+  const float coef = us * (clip > 0.f ? fminf(1.f, clip / (norm + 1e-6f)) : 1.f);
   const float lr = st->lr, bc1 = st->bc1, rbc2 = rsqrtf(st->bc2);
+  const uint64_t nseed = 0x6E015Eull + (uint64_t)st->step * 0x9E3779B97F4A7C15ull;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float pi = p[i];
-    float gi = g[i] * coef + wd * pi;
+    float gi = g[i] * coef;
+    if (noise_std > 0.f) gi += noise_std * otr_gauss(nseed, (uint64_t)i);   // added after clipping, as the reference does
+    gi += wd * pi;
     float mi = beta1 * m[i] + (1.f - beta1) * gi;
     float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
     m[i] = mi;
@@ -69,9 +101,11 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_
 extern "C" int32_t otr_optimizer_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                       float* state, void* param_bf16, float base_lr, float beta1, float beta2, float eps,
                                       float weight_decay, float grad_scale, float clip_norm, float noam_model_size,
-                                      float noam_warmup, float noam_factor, float noam_step_offset, void* stream) {
+                                      float noam_warmup, float noam_factor, float noam_step_offset, float grad_noise_std,
+                                      void* stream) {
   OTR_REQUIRE(param && grad && exp_avg && exp_avg_sq && state, "optimizer_step: null pointer");
   OTR_REQUIRE(n > 0, "optimizer_step: empty parameter buffer");
+  OTR_REQUIRE(grad_noise_std >= 0.f, "optimizer_step: grad_noise_std must be >= 0");
   OTR_REQUIRE((uintptr_t)grad % 16 == 0, "optimizer_step: grad buffer must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   OptState* st = reinterpret_cast<OptState*>(state);
@@ -83,6 +117,6 @@ extern "C" int32_t otr_optimizer_step(float* param, const float* grad, float* ex
                      noam_step_offset, beta1, beta2, grad_scale);
   unsigned g2 = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
   hipLaunchKernelGGL(adam_kernel, dim3(g2), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, st, (bf16_t*)param_bf16, beta1, beta2, eps,
-                     weight_decay, grad_scale, clip_norm);
+                     weight_decay, clip_norm, grad_noise_std);
   return otr_check_launch("optimizer_step");
 }

@@ -55,13 +55,13 @@ class FlatDataParallel:
         self.flat_param_lp = None
         if flatten_params and dev.type == 'cuda' and dt == torch.float32:
             from . import ops
-            if ops.get_compute_dtype() == 'bf16':
-                self.flat_param_lp = torch.empty(padded, device=dev, dtype=torch.bfloat16)
+            if ops.is_half():
+                self.flat_param_lp = torch.empty(padded, device=dev, dtype=ops.half_dtype())
                 for p, off in zip(params, offs):
                     n = p.numel()
                     p._otr_lp_view = self.flat_param_lp[off:off + n].view(p.shape)
                 # transposed bf16 shadows of the 2-D weights ([K,N]: dgrad becomes a forward-type GEMM)
-                self.flat_param_lpt = torch.empty(padded, device=dev, dtype=torch.bfloat16)
+                self.flat_param_lpt = torch.empty(padded, device=dev, dtype=ops.half_dtype())
                 table, tiles = [], 0
                 for p, off in zip(params, offs):
                     n = p.numel()
@@ -170,15 +170,29 @@ class FusedAdam:
     buffers (include/otrans_hip.h: otr_optimizer_step).  State tensors are caller-owned."""
 
     def __init__(self, dp, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6, clip_grad=5.0,
-                 noam=None):
-        """noam: dict(model_size, warmup_steps, factor) of train/scheduler.py:129-138, or None."""
+                 noam=None, grad_noise=0.0, loss_scale=None, loss_scale_growth=2000):
+        """noam: dict(model_size, warmup_steps, factor) of train/scheduler.py:129-138, or None.
+        grad_noise: std of the Gaussian gradient noise (train.grad_noise / accum_steps, trainer.py:223-227).
+        loss_scale: initial dynamic loss scale; None = 4096 in fp16 mode, off otherwise (bf16 / fp32 need none).  The
+        scale lives in the device state block; the model's backward pass is seeded with it (ops.ScaleGradFn)."""
         assert dp.flat_param is not None, 'FusedAdam needs FlatDataParallel(flatten_params=True)'
         self.dp = dp
         self.lr, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip_grad
         self.noam = noam
         self.exp_avg = torch.zeros_like(dp.flat_param)
         self.exp_avg_sq = torch.zeros_like(dp.flat_param)
-        self.state = torch.zeros(8, dtype=torch.float32, device=dp.flat_param.device)
+        self.state = torch.zeros(16, dtype=torch.float32, device=dp.flat_param.device)
+        self.grad_noise = float(grad_noise)
+        if dp.flat_param.is_cuda:
+            from . import ops
+            if loss_scale is None:
+                loss_scale = 4096.0 if ops.get_compute_dtype() == 'fp16' else 0.0
+            if loss_scale:
+                self.state[6] = float(loss_scale)
+                self.state[9] = float(loss_scale_growth)
+                ops.set_loss_scale_tensor(self.state[6:7])
+            else:
+                ops.set_loss_scale_tensor(None)
 
     def step(self, grad_scale=1.0):
         if not self.dp.flat_param.is_cuda:
@@ -193,10 +207,12 @@ class FusedAdam:
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
             grad_scale, self.clip, float(nm.get('model_size', 1.0)), float(nm.get('warmup_steps', 0.0)),
             float(nm.get('factor', 1.0)), 2.0,   # scheduler.py:41-53: the first update sees global_step 3
+            self.grad_noise,
             C.c_void_p(torch.cuda.current_stream().cuda_stream))
         L.check(ret, 'otr_optimizer_step')
         self.dp.refresh_transposed()
 
     def stats(self):
         s = self.state.tolist()
-        return {'step': s[0], 'lr': s[1], 'grad_sqnorm': s[4], 'skipped': s[5]}
+        ls = s[6] if s[6] > 0 else 1.0
+        return {'step': s[0], 'lr': s[1], 'grad_sqnorm': s[4] / (ls * ls), 'skipped': s[5], 'loss_scale': s[6]}

@@ -72,8 +72,9 @@ class SpeechToText(nn.Module):
         if self.ctc_weight > 0:
             loss_ctc = self.compute_ctc_loss(memory, memory_mask, target_out, truth_length)
             # the reference returns {'CTCLoss': loss_ctc.item()} (a host sync per step); we keep the tensor
-            return (1 - self.ctc_weight) * loss + self.ctc_weight * loss_ctc, {'CTCLoss': loss_ctc.detach()}
-        return loss, None
+            total = (1 - self.ctc_weight) * loss + self.ctc_weight * loss_ctc
+            return ops.scale_loss_grad(total), {'CTCLoss': loss_ctc.detach()}
+        return ops.scale_loss_grad(loss), None      # identity unless a loss scale is registered (fp16 training)
 
     def compute_ctc_loss(self, memory, memory_mask, targets_out, targets_length):
         memory_length = torch.sum(memory_mask, dim=-1)
@@ -97,4 +98,46 @@ class SpeechToText(nn.Module):
         pass
 
 
-End2EndModel = {'speech2text': SpeechToText}           # otrans/model/__init__.py:6-9
+class CTCModel(nn.Module):
+    """model/ctc.py:69-140: frontend + encoder + CTC head.  forward(inputs, targets) -> (loss, None) with the labels
+    truth[:, 1:-1] and lengths targets_length - 1 (:95; SpeechToText's joint CTC term keeps the EOS instead).  The
+    reference's inference / recognize / ts_forward call the encoder without the frontend and with a length where a mask
+    belongs (:98-121, broken as shipped); inference() here is the working form: frontend -> encoder ->
+    CTCAssistor.inference, which is what recognize.CTCRecognizer consumes."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.frontend = BuildFrontEnd[params['frontend_type']](**params['frontend'])
+        self.encoder = BuildEncoder[params['encoder_type']](**params['encoder'])
+        self.assistor = CTCAssistor(hidden_size=params['encoder_output_size'], vocab_size=params['vocab_size'],
+                                    lookahead_steps=params['lookahead_steps'] if 'lookahead_steps' in params else -1)
+
+    def forward(self, inputs, targets):
+        truth, truth_length = targets['targets'], targets['targets_length']
+        enc_inputs, enc_mask = self.frontend(inputs['inputs'], inputs['mask'])
+        memory, memory_mask, _ = self.encoder(enc_inputs, enc_mask)
+        memory_length = torch.sum(memory_mask, dim=-1)
+        loss = self.assistor(memory, memory_length, truth[:, 1:-1].contiguous(), truth_length.add(-1))
+        return ops.scale_loss_grad(loss), None
+
+    def inference(self, inputs, inputs_mask):
+        enc_inputs, enc_mask = self.frontend(inputs, inputs_mask)
+        memory, memory_mask, _ = self.encoder(enc_inputs, enc_mask)
+        return self.assistor.inference(memory, memory_mask)
+
+    recognize = inference
+
+    def save_checkpoint(self, params, name):
+        torch.save({'params': params, 'frontend': self.frontend.state_dict(), 'encoder': self.encoder.state_dict(),
+                    'ctc': self.assistor.state_dict()}, name)
+
+    def load_model(self, chkpt):
+        self.frontend.load_state_dict(chkpt['frontend'])
+        self.encoder.load_state_dict(chkpt['encoder'])
+        self.assistor.load_state_dict(chkpt['ctc'])
+
+    def set_epoch(self, epoch):
+        pass
+
+
+End2EndModel = {'ctc': CTCModel, 'speech2text': SpeechToText}           # otrans/model/__init__.py:6-9

@@ -5,9 +5,12 @@ below hands raw data_ptr()s and torch's *current stream* to libotrans_hip.so.  T
 a non-CUDA tensor raises.
 
 Precision policy (set_compute_dtype):
-  'bf16' (default): MFMA inputs bf16, fp32 accumulate; the residual stream, LayerNorm/softmax
+  'bf16' / 'fp16': MFMA inputs in that 16-bit type, fp32 accumulate; the residual stream, LayerNorm/softmax
           statistics, losses and every parameter/gradient stay fp32; q/k/v, attention context, conv
-          activations and the FFN hidden are stored bf16.
+          activations and the FFN hidden are stored 16-bit.  The two modes run the same kernels built for the
+          other 16-bit type (libotrans_hip.so / libotrans_hip_f16.so).  fp16 has 3 more mantissa bits -- the
+          full-size model's logits land 5e-4 from the fp32 reference instead of 3.9e-3 in bf16
+          (tools/precision_study.py; the north-star bar is 1e-3) -- and needs the loss scaling below.
   'fp32': exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) everywhere, all activations fp32 -- parity mode.
 """
 import contextlib
@@ -42,8 +45,18 @@ def graph_capture(graph, **kw):
 
 
 def set_compute_dtype(name):
-    assert name in ('bf16', 'fp32')
+    assert name in ('bf16', 'fp16', 'fp32')
     _state['compute'] = name
+    L.select('fp16' if name == 'fp16' else 'bf16')      # fp32 mode lives in both builds; keep the bf16 one
+
+
+def is_half():
+    return _state['compute'] != 'fp32'
+
+
+def half_dtype():
+    """the 16-bit tensor dtype of the current mode (GEMM-operand form of activations and weights)"""
+    return torch.float16 if _state['compute'] == 'fp16' else torch.bfloat16
 
 
 def get_compute_dtype():
@@ -51,11 +64,11 @@ def get_compute_dtype():
 
 
 def act_dtype():
-    return torch.bfloat16 if _state['compute'] == 'bf16' else torch.float32
+    return half_dtype() if is_half() else torch.float32
 
 
 def _compute_code():
-    return L.OTR_BF16 if _state['compute'] == 'bf16' else L.OTR_F32
+    return {'bf16': L.OTR_BF16, 'fp16': L.OTR_F16, 'fp32': L.OTR_F32}[_state['compute']]
 
 
 def _code(dt):
@@ -63,6 +76,8 @@ def _code(dt):
         return L.OTR_F32
     if dt == torch.bfloat16:
         return L.OTR_BF16
+    if dt == torch.float16:
+        return L.OTR_F16
     raise TypeError('opentransformer_amd: unsupported dtype %s' % dt)
 
 
@@ -105,6 +120,45 @@ def _next_rng_offset(n):
     return off
 
 
+# ---------------------------------------------------------------------------------------- loss scaling (fp16)
+# fp16 activation gradients underflow without it (d loss / d logit is ~1e-7 for most of a 4234-way softmax).  The scale
+# is a DEVICE scalar owned by the optimizer (slot 6 of otr_optimizer_step's state block): the model multiplies the
+# gradient that enters its backward pass by it (ScaleGradFn, one otr_scale launch), every gradient in the flat buffer
+# comes out that much too large, and the optimizer divides it out, halves it on overflow and grows it back -- all on the
+# device, so a captured hipGraph stays valid.  No scale registered (reference-style use, bf16 / fp32 modes) = identity.
+def set_loss_scale_tensor(t):
+    """t: 1-element fp32 device tensor (a view of the optimizer state) or None."""
+    _state['loss_scale'] = t
+
+
+def loss_scale_tensor():
+    return _state.get('loss_scale')
+
+
+class ScaleGradFn(torch.autograd.Function):
+    """identity forward; backward multiplies the incoming gradient by the registered device-side loss scale"""
+
+    @staticmethod
+    def forward(ctx, loss, scale):
+        ctx.save_for_backward(scale)
+        return loss.view_as(loss)
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        g = g.contiguous().float()
+        out = torch.empty_like(g)
+        L.check(L.load().otr_scale(_p(g), _p(out), g.numel(), _p(scale), 1.0, _stream()), 'otr_scale')
+        return out, None
+
+
+def scale_loss_grad(loss):
+    s = _state.get('loss_scale')
+    if s is None or not loss.requires_grad:
+        return loss
+    return ScaleGradFn.apply(loss, s)
+
+
 # ---------------------------------------------------------------------------------------- bf16 shadows
 # In bf16 mode every GEMM operand is read as bf16 from memory:
 #  * activations of the fp32 residual stream carry a bf16 twin produced by the kernel that wrote them
@@ -116,7 +170,7 @@ _LP_ATTR = '_otr_bf16'
 
 
 def lp_of(t):
-    if _state['compute'] != 'bf16' or t is None:
+    if not is_half() or t is None:
         return None
     return getattr(t, _LP_ATTR, None)
 
@@ -130,14 +184,14 @@ def attach_lp(t, lp):
 def cast_bf16(src, dst=None):
     src = src.contiguous()
     if dst is None:
-        dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+        dst = torch.empty(src.shape, dtype=half_dtype(), device=src.device)
     L.check(L.load().otr_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()), 'otr_cast_f32_to_bf16')
     return dst
 
 
 def weight_lp(w):
     """bf16 shadow of an fp32 weight (None in fp32 mode)."""
-    if _state['compute'] != 'bf16' or w.dtype != torch.float32:
+    if not is_half() or w.dtype != torch.float32:
         return None
     view = getattr(w, '_otr_lp_view', None)
     if view is not None:
@@ -177,7 +231,7 @@ def _workspace(device):
 def weight_lpt(w):
     """TRANSPOSED bf16 shadow [K, N] of an fp32 weight [N, K] (None in fp32 mode): with it the input
     gradient dx = dy . w becomes a forward-type GEMM (both operands k-contiguous)."""
-    if _state['compute'] != 'bf16' or w.dtype != torch.float32 or w.dim() != 2:
+    if not is_half() or w.dtype != torch.float32 or w.dim() != 2:
         return None
     view = getattr(w, '_otr_lpt_view', None)
     if view is not None:
@@ -547,7 +601,7 @@ class AddLayerNormFn(torch.autograd.Function):
         M = x2.shape[0]
         need_grad = any(ctx.needs_input_grad)
         y = torch.empty_like(x2)
-        ylp = torch.empty(x2.shape, dtype=torch.bfloat16, device=x.device) if _state['compute'] == 'bf16' else None
+        ylp = torch.empty(x2.shape, dtype=half_dtype(), device=x.device) if is_half() else None
         z = torch.empty_like(x2) if need_grad else None
         mean = torch.empty((M,), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
@@ -640,7 +694,7 @@ class FeedForwardGLUFn(torch.autograd.Function):
         F = F2 // 2
         h = None
         u = torch.empty((M, F), dtype=adt, device=x.device)
-        if adt == torch.bfloat16 and x2.dtype == adt and w1.dtype == adt and _FUSED_GLU_FWD:
+        if adt != torch.float32 and x2.dtype == adt and w1.dtype == adt and _FUSED_GLU_FWD:
             h = torch.empty((M, F2), dtype=adt, device=x.device)
             rc = L.load().otr_ffn_glu_fwd(_p(x2), x2.stride(0), _p(w1), w1.stride(0), _p(b1), _p(h), _p(u), M, F,
                                           x2.shape[1], _stream())
@@ -668,7 +722,7 @@ class FeedForwardGLUFn(torch.autograd.Function):
         db2 = None if ctx.defer_b2 else colsum_raw(dy2, out=gb2)
         dh = torch.empty_like(h)
         part = None
-        if ctx.w2t is not None and dy2.dtype == torch.bfloat16 and h.dtype == torch.bfloat16 and _FUSED_GLU_BWD:
+        if ctx.w2t is not None and dy2.dtype == half_dtype() and h.dtype == dy2.dtype and is_half() and _FUSED_GLU_BWD:
             # one launch: du = dy . w2 stays in registers / LDS, GLU backward and the bias partials in the GEMM epilogue
             cap = (M + 63) // 64
             part = torch.empty((cap, 2 * F), dtype=torch.float32, device=dy.device)
@@ -872,7 +926,7 @@ class PosEncFn(torch.autograd.Function):
         B, T, d = x.shape
         x = x.contiguous().float()
         y = torch.empty_like(x)
-        ylp = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if _state['compute'] == 'bf16' else None
+        ylp = torch.empty(x.shape, dtype=half_dtype(), device=x.device) if is_half() else None
         ctx.scale = math.sqrt(d)
         L.check(L.load().otr_posenc_fwd(_p(x), _p(y), _p(ylp), B * T, T, d, ctx.scale, _stream()), 'otr_posenc_fwd')
         if ylp is not None:
@@ -900,7 +954,7 @@ class EmbedPosEncFn(torch.autograd.Function):
         V, d = E.shape
         tokens = tokens.contiguous()
         y = torch.empty((B, Lq, d), dtype=torch.float32, device=E.device)
-        ylp = torch.empty((B, Lq, d), dtype=torch.bfloat16, device=E.device) if _state['compute'] == 'bf16' else None
+        ylp = torch.empty((B, Lq, d), dtype=half_dtype(), device=E.device) if is_half() else None
         ctx.scale = math.sqrt(d)
         L.check(L.load().otr_embed_posenc_fwd(_p(tokens), _p(E), _p(y), _p(ylp), B * Lq, Lq, d, V, ctx.scale, _stream()),
                 'otr_embed_posenc_fwd')
@@ -942,7 +996,7 @@ def decode_embed(preds, pos, E):
     R, ldp = preds.shape
     V, d = E.shape
     y = torch.empty((R, d), dtype=torch.float32, device=E.device)
-    ylp = torch.empty((R, d), dtype=torch.bfloat16, device=E.device) if _state['compute'] == 'bf16' else None
+    ylp = torch.empty((R, d), dtype=half_dtype(), device=E.device) if is_half() else None
     L.check(L.load().otr_decode_embed(_p(preds), ldp, _p(pos), _p(E), _p(y), _p(ylp), R, d, V, math.sqrt(d), _stream()),
             'otr_decode_embed')
     return attach_lp(y, ylp)

@@ -157,3 +157,35 @@ def require_grad(parts):
             if v.is_floating_point() and not k.endswith(('running_mean', 'running_var')):
                 v.requires_grad_(True)
     return parts
+
+
+# ---------------------------------------------------------------------------------------------- fp16 parity runs
+LOSS_SCALE = 1024.0     # static loss scale for fp16 parity runs without an optimizer (FusedAdam scales dynamically)
+
+
+class loss_scaled:
+    """with loss_scaled(mode, device): ... registers a static device-side loss scale in fp16 mode (ops.ScaleGradFn seeds
+    the backward pass with it); unscale(model_or_tensor) divides it back out."""
+
+    def __init__(self, mode, device='cuda'):
+        self.on, self.device = mode == 'fp16', device
+
+    def __enter__(self):
+        from opentransformer_amd import ops
+        if self.on:
+            ops.set_loss_scale_tensor(torch.full((1,), LOSS_SCALE, device=self.device))
+        return self
+
+    def __exit__(self, *a):
+        from opentransformer_amd import ops
+        ops.set_loss_scale_tensor(None)
+
+    def unscale(self, obj):
+        if not self.on:
+            return obj
+        if isinstance(obj, torch.Tensor):
+            return obj.div_(LOSS_SCALE)
+        for p in obj.parameters():
+            if p.grad is not None:
+                p.grad.div_(LOSS_SCALE)
+        return obj

@@ -32,7 +32,7 @@ def hyp_arr(nbest, like):
     return a
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'fp16'])
 def test_beam_search_matches_reference(golden, mode):
     from opentransformer_amd import ops
     from opentransformer_amd.recognize import SpeechToTextRecognizer
@@ -162,7 +162,7 @@ def test_cached_beam_search_bf16_matches_uncached(golden):
         ops.set_compute_dtype('bf16')
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'fp16'])
 def test_cached_decode_full_size_c5(mode):
     """C5 shape (transformer_baseline dims, beam 10, 4-block LM fusion, V=4234): with EOS suppressed so every
     hypothesis runs the full max_len, the cached loop and the reference-style re-forward loop agree."""

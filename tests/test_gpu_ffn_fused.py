@@ -34,7 +34,7 @@ def test_pack_frags_layout():
     ops.set_compute_dtype('bf16')
     R, Cc = 64, 48
     a = torch.arange(R * Cc, dtype=torch.int16, device=DEV).view(R, Cc)
-    src = a.view(torch.bfloat16).reshape(-1)
+    src = a.view(torch.bfloat16).reshape(-1)       # raw 16-bit payloads: the packer never interprets them
     for perm in (0, 1):
         for transposed in (False, True):
             rows, cols = (Cc, R) if transposed else (R, Cc)
@@ -54,10 +54,17 @@ def test_pack_frags_layout():
                             assert got[rt, ks, lane, j] == A[rt * 32 + (lane & 31), ks * 16 + kk], (perm, transposed, rt, ks, lane, j)
 
 
-@pytest.mark.parametrize('M,dff,p_drop', [(2048, 2048, 0.0), (1504, 512, 0.0), (1024 + 17, 256, 0.1)])
-def test_ffn_ln_fused_matches_reference(M, dff, p_drop):
+@pytest.fixture(params=['bf16', 'fp16'])
+def mode(request):
     from opentransformer_amd import ops
+    ops.set_compute_dtype(request.param)
+    yield request.param
     ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('M,dff,p_drop', [(2048, 2048, 0.0), (1504, 512, 0.0), (1024 + 17, 256, 0.1)])
+def test_ffn_ln_fused_matches_reference(mode, M, dff, p_drop):
+    from opentransformer_amd import ops
     d = 256
     w1, b1, w2, b2, gamma, beta = _params(d, dff, 3)
     g = torch.Generator().manual_seed(5)
@@ -93,10 +100,11 @@ def test_ffn_ln_fused_matches_reference(M, dff, p_drop):
         return
     yr = F.layer_norm(xr + a, (d,), gr, br, 1e-5)
     ref = torch.autograd.grad(yr, (xr, w1r, b1r, w2r, b2r, gr, br), gy)
-    assert rel(y, yr) < 3e-3, rel(y, yr)
+    ty, tg = (3e-3, 1.5e-2) if mode == 'bf16' else (5e-4, 2e-3)     # u / dh are rounded to 16 bits between the GEMMs
+    assert rel(y, yr) < ty, rel(y, yr)
     names = ('dx', 'dw1', 'db1', 'dw2', 'db2', 'dgamma', 'dbeta')
     for n, a_, b_ in zip(names, grads, ref):
-        assert rel(a_, b_) < 1.5e-2, (n, rel(a_, b_))
+        assert rel(a_, b_) < tg, (n, rel(a_, b_))
 
 
 def test_ffn_ln_fused_dropout_mask_consistent_fwd_bwd():
@@ -117,11 +125,10 @@ def test_ffn_ln_fused_dropout_mask_consistent_fwd_bwd():
     assert torch.isfinite(db2).all() and float(db2.abs().sum()) > 0
 
 
-def test_ffn_fused_matches_unfused_model_path():
+def test_ffn_fused_matches_unfused_model_path(mode):
     """encoder layer forward/backward: fused FFN sub-layer == GEMM + GLU + GEMM + add+LN path (same 16-bit operands)"""
     import opentransformer_amd.nn as onn
     from opentransformer_amd import ops
-    ops.set_compute_dtype('bf16')
     torch.manual_seed(11)
     layer = onn.TransformerEncoderLayer(4, 256, 2048, 0.0, 0.0, 0.0, activation='glu').to(DEV)
     B, T = 8, 160
@@ -139,6 +146,7 @@ def test_ffn_fused_matches_unfused_model_path():
         finally:
             ops._FUSED_FFN = True
     (y1, g1), (y0, g0) = outs
-    assert rel(y1, y0) < 3e-3, rel(y1, y0)
+    ty, tg = (3e-3, 2e-2) if mode == 'bf16' else (5e-4, 3e-3)
+    assert rel(y1, y0) < ty, rel(y1, y0)
     for (n, _), a_, b_ in zip([('x', None)] + list(layer.named_parameters()), g1, g0):
-        assert rel(a_, b_) < 2e-2, (n, rel(a_, b_))
+        assert rel(a_, b_) < tg, (n, rel(a_, b_))

@@ -38,10 +38,19 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
+# (loss, activations incl. logits, worst parameter gradient) relative bars per compute mode, <= 2x the drift measured on
+# MI355X (gpurun_out/parity_report.json).  The north-star bar is 1e-3 on loss and logits: fp32 and
+# fp16 meet it; bf16 (8 mantissa bits) cannot -- tools/precision_study.py reproduces its 3.9e-3 on the CPU.
+TOL16 = {'bf16': (1e-3, 8e-3, 2e-2), 'fp16': (5e-4, 1e-3, 4e-3)}
+LOSS_SCALE = 1024.0           # fp16 gradients: static loss scale for the parity runs (the optimizer path scales dynamically)
+
+
 def run_train_case(g, cfg, batch_kw, mode, tol_loss, tol_act, tol_grad, report):
     from opentransformer_amd import ops
     ops.set_compute_dtype(mode)
     try:
+        if mode == 'fp16':
+            ops.set_loss_scale_tensor(torch.full((1,), LOSS_SCALE, device=DEV))
         model = build(cfg)
         inputs, targets = syn.synthetic_batch(**batch_kw)
         inputs, targets = to_dev(inputs), to_dev(targets)
@@ -50,6 +59,10 @@ def run_train_case(g, cfg, batch_kw, mode, tol_loss, tol_act, tol_grad, report):
         logits, _ = model.decoder(targets['targets'][:, :-1].contiguous(), memory, mem_mask)
         loss, aux = model(inputs, targets)
         loss.backward()
+        if mode == 'fp16':
+            for p_ in model.parameters():
+                if p_.grad is not None:
+                    p_.grad.div_(LOSS_SCALE)
         valid = g['fe_mask'].astype(bool)
         assert np.array_equal(fe_mask.cpu().numpy(), g['fe_mask'])
         r = {'mode': mode,
@@ -84,6 +97,7 @@ def run_train_case(g, cfg, batch_kw, mode, tol_loss, tol_act, tol_grad, report):
         if 'ctc_rel' in r:
             assert r['ctc_rel'] < tol_loss, r
     finally:
+        ops.set_loss_scale_tensor(None)
         ops.set_compute_dtype('bf16')
 
 
@@ -101,35 +115,36 @@ def test_c1_fp32_matches_reference_golden(golden, report):
     run_train_case(golden('c1_train.npz'), syn.c1_model(0.0, ctc_weight=0.3), C1_BATCH, 'fp32', 1e-4, 1e-4, 2e-3, report)
 
 
-def test_c1_bf16_matches_reference_golden(golden, report):
-    run_train_case(golden('c1_train.npz'), syn.c1_model(0.0, ctc_weight=0.3), C1_BATCH, 'bf16', 1e-3, 2e-2, 5e-2, report)
+@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
+def test_c1_16bit_matches_reference_golden(golden, report, mode):
+    run_train_case(golden('c1_train.npz'), syn.c1_model(0.0, ctc_weight=0.3), C1_BATCH, mode, *TOL16[mode], report)
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'fp16'])
 @pytest.mark.parametrize('variant', ['prenorm', 'concat', 'prenorm_concat', 'relpos', 'relpos_prenorm_concat'])
 def test_c1_layer_variants_match_reference_golden(golden, report, variant, mode):
     """normalize_before (the reference's residual-after-norm flavour) and concat_after, encoder and decoder"""
     pre, cat, rel = {'prenorm': (True, False, False), 'concat': (False, True, False), 'prenorm_concat': (True, True, False),
                      'relpos': (False, False, True), 'relpos_prenorm_concat': (True, True, True)}[variant]
-    tol = (1e-4, 1e-4, 2e-3) if mode == 'fp32' else (1e-3, 2e-2, 5e-2)
+    tol = (1e-4, 1e-4, 2e-3) if mode == 'fp32' else TOL16[mode]
     run_train_case(golden('c1_%s.npz' % variant), syn.c1_variant(pre, cat, relative_positional=rel), C1_BATCH, mode, *tol, report)
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'fp16'])
 @pytest.mark.parametrize('acts', [('gelu', 'swish'), ('tanh', 'relu')])
 def test_c1_ffn_activations_match_reference_golden(golden, report, acts, mode):
     """module/ffn.py:15-21: gelu / tanh / swish through otr_act_fwd/bwd, relu in the GEMM epilogue"""
-    tol = (1e-4, 1e-4, 2e-3) if mode == 'fp32' else (1e-3, 2e-2, 5e-2)
+    tol = (1e-4, 1e-4, 2e-3) if mode == 'fp32' else TOL16[mode]
     run_train_case(golden('c1_act_%s_%s.npz' % acts), syn.c1_activations(*acts), C1_BATCH, mode, *tol, report)
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'fp16'])
 @pytest.mark.parametrize('steps', [2, 5])
 def test_c1_ctc_lookahead_matches_reference_golden(golden, report, steps, mode):
     """model/ctc.py:17-24,35-39: the look-ahead depthwise convolution in front of the CTC projection (train + inference)"""
     from opentransformer_amd import ops
     g = golden('c1_lookahead%d.npz' % steps)
-    tol = (1e-4, 1e-4, 2e-3) if mode == 'fp32' else (1e-3, 2e-2, 5e-2)
+    tol = (1e-4, 1e-4, 2e-3) if mode == 'fp32' else TOL16[mode]
     run_train_case(g, syn.c1_lookahead(steps), C1_BATCH, mode, *tol, report)
     ops.set_compute_dtype(mode)
     try:
@@ -137,14 +152,14 @@ def test_c1_ctc_lookahead_matches_reference_golden(golden, report, steps, mode):
         lp, ln = model.assistor.inference(torch.from_numpy(g['memory']).to(DEV), torch.from_numpy(g['fe_mask']).to(DEV))
         assert np.array_equal(ln.cpu().numpy(), g['ctc_len'])
         valid = g['fe_mask'].astype(bool)
-        assert rel(lp.float().cpu().numpy()[valid], g['ctc_log_probs'][valid]) < (1e-4 if mode == 'fp32' else 2e-2)
+        assert rel(lp.float().cpu().numpy()[valid], g['ctc_log_probs'][valid]) < (1e-4 if mode == 'fp32' else TOL16[mode][1])
     finally:
         ops.set_compute_dtype('bf16')
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'fp16'])
 def test_c1_frontend_layer_norm_matches_reference_golden(golden, report, mode):
-    tol = (1e-4, 1e-4, 2e-3) if mode == 'fp32' else (1e-3, 2e-2, 5e-2)
+    tol = (1e-4, 1e-4, 2e-3) if mode == 'fp32' else TOL16[mode]
     run_train_case(golden('c1_frontend_ln.npz'), syn.c1_frontend_ln(), C1_BATCH, mode, *tol, report)
 
 
@@ -152,8 +167,9 @@ def test_c2_fp32_matches_reference_golden(golden, report):
     run_train_case(golden('c2_train_b2.npz'), syn.c2_model(0.0), C2_BATCH, 'fp32', 1e-4, 2e-4, 2e-3, report)
 
 
-def test_c2_bf16_matches_reference_golden(golden, report):
-    run_train_case(golden('c2_train_b2.npz'), syn.c2_model(0.0), C2_BATCH, 'bf16', 1e-3, 2e-2, 5e-2, report)
+@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
+def test_c2_16bit_matches_reference_golden(golden, report, mode):
+    run_train_case(golden('c2_train_b2.npz'), syn.c2_model(0.0), C2_BATCH, mode, *TOL16[mode], report)
 
 
 def test_c4_conformer_fp32_matches_reference_golden(golden, report):
@@ -161,9 +177,11 @@ def test_c4_conformer_fp32_matches_reference_golden(golden, report):
                    report)
 
 
-def test_c4_conformer_bf16_matches_reference_golden(golden, report):
-    run_train_case(golden('c4_conformer_small.npz'), syn.conformer_model(small=True), C1_BATCH, 'bf16', 2e-3, 3e-2, 8e-2,
-                   report)
+@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
+def test_c4_conformer_16bit_matches_reference_golden(golden, report, mode):
+    # BatchNorm batch statistics + swish amplify operand rounding: wider bars than the Transformer (measured 2.9e-3 / 1.1e-2 in bf16)
+    tol = {'bf16': (1e-3, 1.6e-2, 2.5e-2), 'fp16': (5e-4, 2.5e-3, 6e-3)}[mode]      # measured bf16: memory 8.7e-3, grad 1.1e-2
+    run_train_case(golden('c4_conformer_small.npz'), syn.conformer_model(small=True), C1_BATCH, mode, *tol, report)
 
 
 def test_c1_fp32_matches_cpu_oracle_on_fresh_inputs():
@@ -278,7 +296,7 @@ def test_inplace_flat_gradients_match_autograd_gradients():
         ops.set_compute_dtype('bf16')
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'fp16'])
 def test_gradient_accumulation_and_stale_queue(mode):
     """accum_steps > 1 (transformer_baseline.yaml:96): two backward passes without zero_grad sum their gradients in the
     flat buffer (each pass flushes its own deferred weight-gradient queue); work queued by a pass that never finished
@@ -312,7 +330,7 @@ def test_gradient_accumulation_and_stale_queue(mode):
         ops.set_compute_dtype('bf16')
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'fp16'])
 @pytest.mark.parametrize('shape', [dict(batch=1, frames=50, tgt_len=2), dict(batch=3, frames=131, tgt_len=1, lengths=[131, 64, 23]),
                                    dict(batch=2, frames=23, tgt_len=3)])
 def test_tiny_and_ragged_shapes_match_cpu_oracle(mode, shape):
@@ -334,8 +352,10 @@ def test_tiny_and_ragged_shapes_match_cpu_oracle(mode, shape):
         model = build(cfg, seed=77)
         dp = FlatDataParallel(model)
         dp.zero_grad()
-        loss, _ = dp(to_dev(inputs), to_dev(targets))
-        loss.backward()
+        with H.loss_scaled(mode) as ls:
+            loss, _ = dp(to_dev(inputs), to_dev(targets))
+            loss.backward()
+            ls.unscale(dp.flat_grad)
         tl, tg = (1e-4, 5e-3) if mode == 'fp32' else (3e-3, 1e-1)
         assert abs(loss.item() - ref.item()) < tl * abs(ref.item()), (loss.item(), ref.item())
         worst = 0.0
@@ -359,13 +379,15 @@ def test_c4_conformer_full_size_matches_cpu_oracle():
     ref, _ = orc.speech2text_forward(parts, cfg, inputs, targets)
     ref.backward()
     flat = H.flat_named(parts)
-    for mode, tl, tg in (('fp32', 1e-4, 5e-3), ('bf16', 2e-3, 1e-1)):
+    for mode, tl, tg in (('fp32', 1e-4, 5e-3), ('bf16', 2e-3, 1e-1), ('fp16', 5e-4, 3e-2)):
         ops.set_compute_dtype(mode)
         try:
             model = build(cfg, seed=31)
             assert sum(p.numel() for p in model.parameters()) == 50405130
-            loss, _ = model(to_dev(inputs), to_dev(targets))
-            loss.backward()
+            with H.loss_scaled(mode) as ls:
+                loss, _ = model(to_dev(inputs), to_dev(targets))
+                loss.backward()
+                ls.unscale(model)
             assert abs(loss.item() - ref.item()) < tl * abs(ref.item()), (mode, loss.item(), ref.item())
             worst = 0.0
             for k, p in model.named_parameters():

@@ -12,8 +12,9 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 DEV = 'cuda'
-MODES = ['fp32', 'bf16']
-TOL = {'fp32': 2e-5, 'bf16': 1.5e-2}
+MODES = ['fp32', 'bf16', 'fp16']
+TOL = {'fp32': 2e-5, 'bf16': 1.5e-2, 'fp16': 2e-3}
+HALF = {'bf16': torch.bfloat16, 'fp16': torch.float16}
 
 
 def rel(a, b):
@@ -35,7 +36,7 @@ def mode(request):
 
 
 def adt(mode):
-    return torch.float32 if mode == 'fp32' else torch.bfloat16
+    return torch.float32 if mode == 'fp32' else HALF[mode]
 
 
 # ------------------------------------------------------------------------------------------ linear
@@ -43,11 +44,11 @@ def adt(mode):
                                    (480, 4234, 256), (1000, 64, 2560)])
 def test_linear_fwd_bwd(mode, M, N, K):
     from opentransformer_amd import ops
-    for xdt in ([torch.float32] if mode == 'fp32' else [torch.float32, torch.bfloat16]):
+    for xdt in ([torch.float32] if mode == 'fp32' else [torch.float32, HALF[mode]]):
         x = rnd(M, K, seed=1).to(xdt).requires_grad_(True)
         w = (rnd(N, K, seed=2) / math.sqrt(K)).requires_grad_(True)
         b = rnd(N, seed=3).requires_grad_(True)
-        for odt in ([torch.float32] if mode == 'fp32' else [torch.float32, torch.bfloat16]):
+        for odt in ([torch.float32] if mode == 'fp32' else [torch.float32, HALF[mode]]):
             y = ops.linear(x, w, b, out_dtype=odt)
             yr = F.linear(x.float(), w, b)
             assert rel(y.float(), yr) < TOL[mode], ('fwd', xdt, odt)
@@ -282,7 +283,11 @@ def test_conv_subsample(mode, B, T, Fdim, C1, C2):
     grads = torch.autograd.grad(act2, (w1, b1, w2, b2), g)
     gref = torch.autograd.grad(ref, (w1, b1, w2, b2), g.float())
     for nm, u, v in zip(('dw1', 'db1', 'dw2', 'db2'), grads, gref):
-        assert rel(u, v) < 3 * TOL[mode], nm
+        # every gradient here passes through the ReLU mask of act2, which the reference takes from UNROUNDED pre-activations:
+        # operand rounding eps flips a fraction ~eps of the mask bits and each flip moves an O(1) random upstream element,
+        # so the error goes like sqrt(eps) (measured 1.3e-2 in fp16 here; 1.5e-3 inside the real model, whose upstream
+        # gradient is smooth)
+        assert rel(u, v) < (10 if mode == 'fp16' else 3) * TOL[mode], nm
 
 
 # ------------------------------------------------------------------------------------------ losses
@@ -443,7 +448,7 @@ def shared_projection_inputs():
     return x, mem, xmask, mmask, dy
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'fp16'])
 def test_shared_qvk_and_vk_projections_match_reference(golden, mode):
     """share_qvk_proj / share_vk_proj (module/attention.py:71-72,131-132): query = key = value = one projection"""
     from opentransformer_amd import ops, nn as onn
@@ -580,7 +585,7 @@ def test_transpose_batched():
     assert float(dst[:2].abs().sum()) == 0.0 and float(dst[off:].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'fp16'])
 def test_deferred_bias_gradient_through_layernorm(mode):
     """linear(defer_bias=True) + add_layernorm(a_bias=b): the bias gradient comes out of the LayerNorm backward
     (with dropout) and equals the plain path's, both as a returned tensor and accumulated in place."""
@@ -615,7 +620,7 @@ def test_deferred_bias_gradient_through_layernorm(mode):
         ops.set_compute_dtype('bf16')
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'fp16'])
 def test_grouped_weight_and_bias_gradients(mode):
     """otr_linear_wgrad_grouped / otr_colsum_grouped == the per-layer launches they replace (accumulating), over
     ragged shapes: long and short contractions, small and large outputs, both dy dtypes, one misaligned item."""
