@@ -3,17 +3,30 @@
 
 Workload (BASELINE.json configs[1]): egs/aishell/conf/transformer_baseline.yaml with
 frontend.input_size 80, residual_dropout 0.1, synthetic 80-d fbank x 1000 frames, 15 decoder rows,
-B = 32 utterances per GPU, bf16 MFMA / fp32 accumulate.  One step = zero grads, forward, backward,
+B = 32 utterances per GPU, 16-bit MFMA operands / fp32 accumulate.  One step = zero grads, forward, backward,
 ONE gradient all-reduce (N>1), clip + Adam + Noam update: nothing is skipped in the timed region.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0) following the driver's contract, plus `roofline` (dominant kernel,
-timed live with events on the launch stream) and `cpu_baseline` (the CPU oracle on the host cores).
+N > 1 without a torchrun environment re-launches itself as `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` (one rank per GPU over RCCL); under
+torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.
+
+Prints ONE JSON line (rank 0) following the driver's contract, plus
+  roofline      the kernel that is largest by time IN the training step (today: the grouped weight-gradient launch),
+                timed inside a real step with events on the launch stream (ops.set_kernel_timer); `roofline_kernels`
+                lists the other hot launches of the same instrumented step;
+  cpu_baseline  the CPU oracle (a port: /root/reference does not exist on the GPU box) on the host cores, B=4 and B=32.
+
+Compute mode: fp16 MFMA operands by default.  bf16 operands (8 mantissa bits) put the logits 4.2e-3 from the fp32
+reference, fp16 (11 bits) 5.4e-4 -- inside the north-star's 1e-3 -- at the same MFMA rate (tests/test_gpu_headline.py,
+tools/precision_study.py); gradients are loss-scaled on the device (dynamic, inside otr_optimizer_step).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 from opentransformer_amd import synthetic as syn          # noqa: E402
 
-PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_16BIT_TFLOPS = 2500.0    # MI355X dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
@@ -38,121 +51,154 @@ def parse():
     ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
     ap.add_argument('--frames', type=int, default=1000)
     ap.add_argument('--mode', default='fp16', choices=['fp16', 'bf16', 'fp32'],
-                    help='16-bit MFMA operand type: fp16 (default; logits within 1e-3 of the fp32 reference) or bf16; fp32 = exact-fp32 MFMA')
+                    help='MFMA operand type: fp16 (default; logits within 1e-3 of the fp32 reference), bf16, or fp32 (exact-fp32 MFMA)')
     ap.add_argument('--model', default='transformer', choices=['transformer', 'conformer'],
                     help='transformer = BASELINE configs[1] (the metric); conformer = configs[3] (informative)')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=4)
-    ap.add_argument('--cpu-iters', type=int, default=8)
+    ap.add_argument('--cpu-threads', type=int, default=0, help='torch threads of the CPU baseline (0 = min(16, host cores))')
     return ap.parse_args()
 
 
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: become N ranks on this node."""
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        print('bench.py: --gpus %d requested but only %d GPU(s) are visible' % (args.gpus, n_dev), file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def cpu_baseline(args):
-    """The CPU oracle (a port of the reference path, oracle/otrans_oracle.py) timed on the host
-    cores: train fwd+bwd, fp32, same model config, bounded sample."""
+    """The CPU oracle (oracle/otrans_oracle.py: a restatement of the reference path, pinned to the real reference by
+    tests/test_oracle_golden.py; kind 'port' because /root/reference is not present on the GPU box) timed on the host
+    cores: train fwd+bwd, fp32, same model config, bounded samples at B=4 and B=32."""
     from oracle import otrans_oracle as orc
     from tests import helpers as H
-    # torch CPU kernels stop scaling long before the host's 256 hardware threads (measured on the GPU
-    # box: 0.24 s/iter at 16 threads, 0.80 s at 64, 173 s at 256), so the baseline uses 16 threads.
-    cores = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
+    host = os.cpu_count() or 1
+    # torch's CPU kernels stop scaling long before a 256-thread host is full (measured on the GPU box: 0.24 s/iter at
+    # 16 threads, 0.80 s at 64, 173 s at 256 for B=4), so the baseline runs min(16, host cores) threads and says so
+    threads = args.cpu_threads or min(16, host)
+    torch.set_num_threads(threads)
     cfg = syn.c2_model(0.0)
     parts = H.require_grad(H.filled_state(cfg))
-    B = args.cpu_batch
-    inputs, targets = syn.synthetic_batch(B, args.frames, 80, 4234, 15, seed=0)
     flat = [t for sd in parts.values() for t in sd.values()]
-    times = []
-    for it in range(2 + args.cpu_iters):
-        for t in flat:
-            t.grad = None
-        t0 = time.perf_counter()
-        loss, _ = orc.speech2text_forward(parts, cfg, inputs, targets)
-        loss.backward()
-        times.append(time.perf_counter() - t0)
-    times = sorted(times[2:])
-    med = times[len(times) // 2]
-    return {'value': B / med, 'unit': 'utterances/s', 'cores': cores, 'kind': 'port',
-            'sample': 'CPU oracle fwd+bwd fp32, B=%d x %d frames, median of %d iters (2 warm-up), %d torch threads'
-                      % (B, args.frames, args.cpu_iters, cores)}
+    res = {}
+    for B, iters in ((4, 6), (32, 3)):
+        inputs, targets = syn.synthetic_batch(B, args.frames, 80, 4234, 15, seed=0)
+        times = []
+        for it in range(1 + iters):
+            for t in flat:
+                t.grad = None
+            t0 = time.perf_counter()
+            loss, _ = orc.speech2text_forward(parts, cfg, inputs, targets)
+            loss.backward()
+            times.append(time.perf_counter() - t0)
+        times = sorted(times[1:])
+        res[B] = B / times[len(times) // 2]
+    return {'value': res[32], 'unit': 'utterances/s', 'cores': threads, 'host_cores': host, 'kind': 'port',
+            'value_b4': res[4], 'value_b32': res[32],
+            'sample': 'CPU oracle (port of the reference path; the reference tree is absent on the GPU box) fwd+bwd fp32, '
+                      '%d frames, median of 6 iters at B=4 and of 3 iters at B=32 (1 warm-up each), %d torch threads on a '
+                      '%d-core host' % (args.frames, threads, host)}
 
 
-def time_dominant_kernel(model, mode):
-    """Dominant kernel = the FFN w_1 GEMM (52%% of encoder FLOPs incl. bwd twins): time the forward
-    instance [M=B*T', N=2*d_ff, K=d] live with events on the launch stream."""
-    from opentransformer_amd import ops
-    w1 = model.encoder.blocks[0].feed_forward.w_1
-    M = time_dominant_kernel.rows
-    adt = ops.act_dtype()
-    x = torch.randn(M, w1.in_features, device=w1.weight.device).to(adt)      # the model feeds the bf16 twin
-    wq = ops.weight_lp(w1.weight)
-    wq = wq if wq is not None else w1.weight
-    for _ in range(5):
-        ops.linear_fwd_raw(x, wq, w1.bias, adt)
-    n = 50
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        ops.linear_fwd_raw(x, wq, w1.bias, adt)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
-    flops = 2.0 * M * w1.out_features * w1.in_features
-    peak = PEAK_F32_TFLOPS if mode == 'fp32' else PEAK_BF16_TFLOPS
-    ach = flops / (ms * 1e-3) / 1e12
-    traffic = None
-    try:     # HBM bytes per launch measured offline with rocprofv3 PMC passes (profiles/r01_pmc_traffic.json)
-        key = 'gemm_fwd_%dx%dx%d_%s' % (M, w1.out_features, w1.in_features, mode)
-        traffic = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))[key]['hbm_bytes']
-    except Exception:                                          # noqa: BLE001
-        pass
-    return {'bound': 'mfma', 'kernel': 'gemm_kernel (FFN w_1 forward, M=%d N=%d K=%d)' % (M, w1.out_features, w1.in_features),
-            'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
-            'avg_launch_ms': ms}
-
-
-def time_grouped_wgrad(ops, mode):
-    """Largest single kernel of the step: the grouped weight-gradient launch (every dW of the backward pass).  Re-run
-    it on the operands of the last backward pass (accumulating into the already-consumed gradient buffer)."""
-    w, b = ops._wq.get('last', ([], []))
+def replay_dominant(ops, name, mode):
+    """Accurate launch duration of the dominant kernel: its launch is re-issued 10x back to back on the operands of the
+    last step inside ONE hipGraph (no host gaps between launches) and timed with events on the launch stream."""
+    if name != 'linear_wgrad_grouped':
+        return None
+    w, _ = ops._wq.get('last', ([], []))
     if not w:
         return None
-    flops = sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _ in w)
-    byts = sum(dy.numel() * dy.element_size() + x.numel() * x.element_size() + 2 * out.numel() * 4 for dy, x, out in w)
 
     def run():
         ops._wq['w'], ops._wq['b'] = list(w), []
         ops.flush_weight_grads()
     ops._wq['keep_last'] = False
-    for _ in range(2):
-        run()
     n = 10
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
-    peak = PEAK_F32_TFLOPS if mode == 'fp32' else PEAK_BF16_TFLOPS
-    ach = flops / (ms * 1e-3) / 1e12
-    return {'bound': 'mfma', 'kernel': 'gemm_grouped_kernel (all %d weight gradients of one backward pass, one launch per '
-                                       'operand-type group)' % len(w),
-            'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
-            'algorithmic_bytes': byts, 'avg_launch_ms': ms}
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with ops.graph_capture(g):
+            for _ in range(n):
+                run()
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    except Exception:                                          # noqa: BLE001
+        return None
+
+
+def instrumented_step(ops, fwd_bwd, mode):
+    """One EAGER training step with ops' kernel timer installed: every hot launch is bracketed by events on the launch
+    stream.  Returns {kernel name: {avg_launch_ms, launches, total_ms, achieved, frac, ...}} for this step."""
+    rec = []
+    ops._wq['keep_last'] = True            # keep the grouped weight-gradient operands of the pass for replay_dominant()
+    for _ in range(2):                    # the first pass warms caches / allocator, the second is kept
+        rec.clear()
+        ops.set_kernel_timer(rec)
+        try:
+            fwd_bwd()
+            torch.cuda.synchronize()
+        finally:
+            ops.set_kernel_timer(None)
+    peak = PEAK_F32_TFLOPS if mode == 'fp32' else PEAK_16BIT_TFLOPS
+    agg = {}
+    for name, meta, e0, e1 in rec:
+        a = agg.setdefault(name, {'launches': 0, 'total_ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+        a['launches'] += 1
+        a['total_ms'] += e0.elapsed_time(e1)
+        a['flops'] += (meta or {}).get('flops', 0.0)
+        a['bytes'] += (meta or {}).get('bytes', 0.0)
+        if meta and 'problems' in meta:
+            a['problems'] = meta['problems']
+    for a in agg.values():
+        a['avg_launch_ms'] = a['total_ms'] / a['launches']
+        a['achieved'] = a['flops'] / (a['total_ms'] * 1e-3) / 1e12 if a['total_ms'] > 0 else 0.0    # TFLOP/s
+        a['frac'] = a['achieved'] / peak
+        a['algorithmic_bytes_per_launch'] = a.pop('bytes') / a['launches']
+        a['flops_per_launch'] = a.pop('flops') / a['launches']
+    return agg
+
+
+KERNEL_LABEL = {
+    'linear_wgrad_grouped': 'gemm_grouped_kernel (every weight gradient of the backward pass, one launch per operand-type group)',
+    'ffn_ln_fwd': 'ffn_ln_fwd_kernel (w_1 + GLU + w_2 + bias + dropout + residual + LayerNorm, row-block fused)',
+    'ffn_bwd': 'ffn_bwd_kernel (FFN backward with recompute: dh, u, dx; row-block fused)',
+}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        relaunch_under_torchrun(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', init_method='env://')
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the product has no CPU path)'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', init_method='env://', device_id=dev)
 
     import opentransformer_amd as ota
     from opentransformer_amd import ops
@@ -164,6 +210,7 @@ def main():
     syn.fill_state_dict_(model.state_dict(), 1234)           # identical replicas on every rank
     model = model.to(dev).train()
     dp = FlatDataParallel(model)
+    dp.broadcast_parameters()
     opt = FusedAdam(dp, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6, clip_grad=5.0,
                     noam=dict(model_size=cfg['encoder']['d_model'], warmup_steps=12000, factor=1.0))   # *_baseline.yaml train section
     inputs, targets = syn.synthetic_batch(args.batch, args.frames, 80, 4234, 15, seed=rank)
@@ -224,30 +271,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # untimed extras (rank 0): where the step time goes, and the operands of one backward pass for the wgrad roofline
+    # ---- untimed extras: where the step time goes (every rank: the collectives must match)
     final_loss, final_stats = float(loss_buf.item()), opt.stats()      # state at the end of the timed region
-    parts = None
-    if True:                                                 # every rank: the collectives must match
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        acc = [0.0, 0.0]
-        for _ in range(5):
-            ev[0].record()
-            if graph is not None:
-                graph.replay()
-            else:
-                fwd_bwd()
-            ev[1].record()
-            scale, _ = dp.all_reduce_gradients()
-            opt.step(scale)
-            ev[2].record()
-            torch.cuda.synchronize()
-            acc[0] += ev[0].elapsed_time(ev[1])
-            acc[1] += ev[1].elapsed_time(ev[2])
-        parts = {'fwd_bwd_ms': acc[0] / 5, 'allreduce_optimizer_ms': acc[1] / 5}
-    if rank == 0:
-        ops._wq['keep_last'] = True
-        fwd_bwd()                                            # eager pass: queues and flushes once, keeping the items
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    acc = [0.0, 0.0]
+    for _ in range(5):
+        ev[0].record()
+        if graph is not None:
+            graph.replay()
+        else:
+            fwd_bwd()
+        ev[1].record()
+        scale, _ = dp.all_reduce_gradients()
+        opt.step(scale)
+        ev[2].record()
         torch.cuda.synchronize()
+        acc[0] += ev[0].elapsed_time(ev[1])
+        acc[1] += ev[1].elapsed_time(ev[2])
+    parts = {'fwd_bwd_ms': acc[0] / 5, 'allreduce_optimizer_ms': acc[1] / 5}
+    kern = instrumented_step(ops, fwd_bwd, args.mode) if rank == 0 else None
     if world > 1:
         dist.barrier()
 
@@ -255,7 +297,7 @@ def main():
         global_batch = args.batch * world
         utt_s = global_batch * args.steps / elapsed
         flops_utt = syn.flops_per_utt(cfg, args.frames, 15) if args.model == 'transformer' else 63207.57e6
-        time_dominant_kernel.rows = args.batch * (((args.frames - 3) // 2 + 1 - 3) // 2 + 1)
+        peak = PEAK_F32_TFLOPS if args.mode == 'fp32' else PEAK_16BIT_TFLOPS
         out = {
             'metric': 'utterances/sec (80-d fbank, ~1000 frames) train fwd+bwd', 'value': utt_s,
             'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -268,18 +310,43 @@ def main():
                        'hipgraph': graph is not None},
             'loss': final_loss, 'optimizer': final_stats,
             'model_tflops_per_s': utt_s * flops_utt / 1e12,
-            'model_mfma_frac': utt_s * flops_utt / 1e12 / world / (PEAK_F32_TFLOPS if args.mode == 'fp32' else PEAK_BF16_TFLOPS),
+            'model_mfma_frac': utt_s * flops_utt / 1e12 / world / peak,
         }
         st = final_stats
         if st['skipped'] != 0 or not (st['grad_sqnorm'] == st['grad_sqnorm'] and st['grad_sqnorm'] < float('inf')):
             out['INVALID'] = 'non-finite gradient norm: %d optimizer updates were skipped' % int(st['skipped'])
         out['step_breakdown'] = parts
-        if args.model == 'transformer':
-            out['roofline'] = time_dominant_kernel(model, args.mode)
-            rw = time_grouped_wgrad(ops, args.mode)
-            if rw is not None:
-                out['roofline_wgrad_grouped'] = rw
-        else:
+        if kern:
+            traffic_db = {}
+            try:     # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (profiles/r02_pmc_traffic.json)
+                traffic_db = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))
+            except Exception:                                          # noqa: BLE001
+                pass
+            lines = {}
+            for name, a in kern.items():
+                if a['flops_per_launch'] <= 0:
+                    continue
+                lines[name] = {'bound': 'mfma', 'kernel': KERNEL_LABEL.get(name, name), 'achieved': a['achieved'], 'peak': peak,
+                               'unit': 'TFLOP/s', 'frac': a['frac'],
+                               'traffic': (traffic_db.get(name, {}) or {}).get('hbm_bytes_per_launch'),
+                               'algorithmic_bytes': a['algorithmic_bytes_per_launch'] or None,
+                               'avg_launch_ms': a['avg_launch_ms'], 'launches_per_step': a['launches'],
+                               'ms_per_step': a['total_ms'], 'timed': 'events around every launch inside one eager training step'}
+            if lines:
+                dom = max(lines, key=lambda k: lines[k]['avg_launch_ms'])          # largest single kernel of the step
+                ms = replay_dominant(ops, dom, args.mode)
+                if ms:                    # the eager bracket also holds the launch gap and the descriptor-table writers
+                    d = lines[dom]
+                    d['avg_launch_ms_eager_bracket'] = d['avg_launch_ms']
+                    d['avg_launch_ms'] = ms
+                    d['achieved'] = kern[dom]['flops_per_launch'] / (ms * 1e-3) / 1e12
+                    d['frac'] = d['achieved'] / peak
+                    d['timed'] = ('10 back-to-back launches on the operands of the step inside one hipGraph, events on the launch '
+                                  'stream (rocprofv3 --kernel-trace of this command: profiles/r02_kernel_trace_graph.txt)')
+                out['roofline'] = lines.pop(dom)
+                keep = sorted(lines, key=lambda k: -lines[k]['ms_per_step'])[:8]
+                out['roofline_kernels'] = {k: lines[k] for k in keep}
+        if args.model != 'transformer':
             out['config']['workload'] = out['config']['workload'].replace('transformer_baseline.yaml (+input_size 80), 12 enc / 6 dec layers', 'conformer_baseline.yaml, 12 conformer blocks / 6 dec layers')
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)

@@ -327,6 +327,17 @@ int32_t otr_optimizer_step(float* param, const float* grad, float* exp_avg, floa
                            float grad_scale, float clip_norm, float noam_model_size, float noam_warmup,
                            float noam_factor, float noam_step_offset, float grad_noise_std, void* stream);
 
+/* ---- gradient all-reduce over RCCL / xGMI (replaces nn.DataParallel's per-step scatter / replicate / gather /
+ *      reduce-add, train/trainer.py:56-66).  One in-place sum over the replica's flat gradient buffer,
+ *      issued on the stream passed in (the compute stream: nothing to synchronise before the optimizer).  librccl is
+ *      opened lazily (dlopen); the communicator is the one object the library owns.
+ *      Rendezvous: rank 0 calls otr_allreduce_unique_id, the HOST ships the 128 bytes to every rank, every rank (having
+ *      selected its GPU with hipSetDevice) calls otr_allreduce_init; dtype is OTR_F32 / OTR_BF16 / OTR_F16 of `buf`. */
+int32_t otr_allreduce_unique_id(void* id128);
+int32_t otr_allreduce_init(void** handle, const void* id128, int32_t rank, int32_t world);
+int32_t otr_allreduce_run(void* handle, void* buf, int64_t count, int32_t dtype, void* stream);
+int32_t otr_allreduce_destroy(void* handle);
+
 /* ---- batch beam search step (recognize/speech2text.py:95-192).
  * beam_topk: rows = batch*beam hypotheses; logits f32 [rows, V] (row stride ld) are the decoder logits of
  *   the last position; optional LM logits are fused as log_softmax(dec) + lm_weight*log_softmax(lm)

@@ -104,6 +104,10 @@ SIGNATURES = {
     'otr_log_softmax': [_P, _P, _I64, _I32, _P],
     'otr_ctc_loss': [_P, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     'otr_optimizer_step': [_P, _P, _P, _P, _I64, _P, _P] + [_F32] * 12 + [_P],
+    'otr_allreduce_unique_id': [_P],
+    'otr_allreduce_init': [C.POINTER(C.c_void_p), _P, _I32, _I32],
+    'otr_allreduce_run': [_P, _P, _I64, _I32, _P],
+    'otr_allreduce_destroy': [_P],
     'otr_beam_topk': [_P, _I64, _P, _I64, _F32, _I64, _I32, _I32, _P, _P, _P],
     'otr_beam_prune': [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     'otr_beam_prune_cached': [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P],

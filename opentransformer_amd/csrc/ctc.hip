@@ -36,7 +36,12 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* lp, co
   __shared__ float sh[2][256];
   __shared__ float s_ll;
   const int b = blockIdx.x, s = threadIdx.x;
-  const int Tb = min(in_len[b], T), L = tgt_len[b], S = 2 * L + 1;
+  // a target length beyond the caller's bound (Smax = 2*max_tgt + 1 alpha slots per frame, `targets` rows of at least
+  // max_tgt labels) would read `targets` out of bounds and write alpha rows over neighbouring (t, b) slots: such an
+  // utterance is treated like an infeasible alignment (nll 0, zero gradient: zero_infinity semantics), never computed
+  const int Lraw = tgt_len[b];
+  const bool bad_len = Lraw < 0 || 2 * Lraw + 1 > Smax;
+  const int Tb = max(min(in_len[b], T), 0), L = bad_len ? 0 : Lraw, S = 2 * L + 1;
   const float* lpb = lp + (int64_t)b * T * V;
   float* aw = alpha_ws + (int64_t)b * T * Smax;
   const int64_t* tg = targets + (int64_t)b * ldt;
@@ -73,6 +78,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const float* lp, co
       const float* fin = sh[(Tb - 1) & 1];
       ll = lse3(fin[S - 1], S > 1 ? fin[S - 2] : NEG_INF, NEG_INF);
     }
+    if (bad_len) ll = NEG_INF;
     s_ll = ll;
     bool ok = ll != NEG_INF;                      // zero_infinity=True
     nll_out[b] = ok ? -ll : 0.f;

@@ -19,9 +19,20 @@ from . import _lib as L
 
 
 class FlatDataParallel:
-    def __init__(self, module, process_group=None, flatten_params=True):
+    def __init__(self, module, process_group=None, flatten_params=True, comm='torch', grad_comm_dtype=None):
+        """comm: 'torch' = torch.distributed all_reduce (backend "nccl" IS RCCL on ROCm; gloo in the CPU tests), or
+        'rccl' = the library's own communicator (otr_allreduce_*, include/otrans_hip.h): the collective is issued on the
+        compute stream through the C ABI, torch.distributed only ships the 128-byte unique id at start-up.
+        grad_comm_dtype: None = all-reduce the fp32 flat buffer (bit-exact sum order aside); torch.bfloat16 / torch.float16
+        = all-reduce a 16-bit copy (half the xGMI bytes: 73 MB instead of 146 MB for the AISHELL transformer) and widen the
+        sum back into the fp32 buffer -- bf16 keeps fp32's exponent range, so loss-scaled fp16-mode gradients cannot
+        overflow in the payload."""
         self.module = module
         self.group = process_group
+        assert comm in ('torch', 'rccl')
+        self.comm, self.grad_comm_dtype = comm, grad_comm_dtype
+        self._rccl = None
+        self._payload = None
         seen, params = set(), []
         for p in module.parameters():
             if p.requires_grad and id(p) not in seen:      # tied weights appear once
@@ -140,7 +151,26 @@ class FlatDataParallel:
     def __call__(self, *args, **kw):
         return self.module(*args, **kw)
 
+    def _check_grad_views(self, reinstall=False):
+        """Every parameter's .grad must still be its view of the flat buffer: the backward kernels write there
+        (ops.grad_target) and the all-reduce / optimizer read there.  torch's default `module.zero_grad()` /
+        `optimizer.zero_grad(set_to_none=True)` drop the views (.grad = None; the next backward would then allocate
+        ordinary gradients OUTSIDE the flat buffer and training would silently become weight decay only)."""
+        es = self.flat_grad.element_size()
+        base = self.flat_grad.data_ptr()
+        for p, off in zip(self.params, self.offsets):
+            g = p.grad
+            if g is not None and g.data_ptr() == base + off * es:
+                continue
+            if g is None and reinstall:
+                p.grad = self.flat_grad[off:off + p.numel()].view_as(p.data)
+                continue
+            raise RuntimeError('FlatDataParallel: the .grad of a parameter of shape %s is no longer its view of the flat '
+                               'gradient buffer (was module.zero_grad() / optimizer.zero_grad(set_to_none=True) called?). '
+                               'Use FlatDataParallel.zero_grad().' % (tuple(p.shape),))
+
     def zero_grad(self):
+        self._check_grad_views(reinstall=True)      # a view dropped by set_to_none is put back; a foreign .grad raises
         self.flat_grad.zero_()
         if self.flat_grad.is_cuda:
             from . import ops
@@ -156,12 +186,49 @@ class FlatDataParallel:
                     dist.broadcast(p.data, src, group=self.group)
             self.refresh_lp()           # the GEMMs read the 16-bit shadows: they must follow the broadcast masters
 
-    def all_reduce_gradients(self, async_op=False):
-        """single collective over the flat buffer; returns 1/world_size for the optimizer to fold in."""
+    def _rccl_handle(self):
+        """lazily build the library-owned RCCL communicator (rank 0's unique id travels through torch.distributed)"""
+        if self._rccl is None:
+            lib = L.load()
+            rank, ws = (dist.get_rank(self.group), self.world_size) if dist.is_available() and dist.is_initialized() else (0, 1)
+            uid = C.create_string_buffer(128)
+            if rank == 0:
+                L.check(lib.otr_allreduce_unique_id(uid), 'otr_allreduce_unique_id')
+            if ws > 1:
+                box = [uid.raw]
+                dist.broadcast_object_list(box, src=0, group=self.group)
+                uid = C.create_string_buffer(box[0], 128)
+            h = C.c_void_p()
+            L.check(lib.otr_allreduce_init(C.byref(h), uid, rank, ws), 'otr_allreduce_init')
+            self._rccl = h
+        return self._rccl
+
+    def close(self):
+        if self._rccl is not None:
+            L.check(L.load().otr_allreduce_destroy(self._rccl), 'otr_allreduce_destroy')
+            self._rccl = None
+
+    def all_reduce_gradients(self, async_op=False, force=False):
+        """single collective over the flat buffer; returns 1/world_size for the optimizer to fold in.
+        force: run the collective even at world_size 1 (self-test of the RCCL path on a one-GPU box)."""
         ws = self.world_size
         work = None
-        if ws > 1:
-            work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        self._check_grad_views()
+        if ws > 1 or force:
+            buf = self.flat_grad
+            if self.grad_comm_dtype is not None:            # 16-bit payload: half the bytes over xGMI
+                if self._payload is None:
+                    self._payload = torch.empty_like(self.flat_grad, dtype=self.grad_comm_dtype)
+                self._payload.copy_(self.flat_grad)
+                buf = self._payload
+            if self.comm == 'rccl':
+                code = {torch.float32: L.OTR_F32, torch.bfloat16: L.OTR_BF16, torch.float16: L.OTR_F16}[buf.dtype]
+                L.check(L.load().otr_allreduce_run(self._rccl_handle(), C.c_void_p(buf.data_ptr()), buf.numel(), code,
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'otr_allreduce_run')
+            elif ws > 1:
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op and buf is self.flat_grad)
+            if buf is not self.flat_grad:
+                self.flat_grad.copy_(buf)
         return 1.0 / ws, work
 
 
@@ -190,9 +257,9 @@ class FusedAdam:
             if loss_scale:
                 self.state[6] = float(loss_scale)
                 self.state[9] = float(loss_scale_growth)
-                ops.set_loss_scale_tensor(self.state[6:7])
+                dp.module._otr_loss_scale = self.state[6:7]     # the model seeds its backward pass with this device scalar
             else:
-                ops.set_loss_scale_tensor(None)
+                dp.module._otr_loss_scale = None
 
     def step(self, grad_scale=1.0):
         if not self.dp.flat_param.is_cuda:

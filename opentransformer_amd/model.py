@@ -73,8 +73,8 @@ class SpeechToText(nn.Module):
             loss_ctc = self.compute_ctc_loss(memory, memory_mask, target_out, truth_length)
             # the reference returns {'CTCLoss': loss_ctc.item()} (a host sync per step); we keep the tensor
             total = (1 - self.ctc_weight) * loss + self.ctc_weight * loss_ctc
-            return ops.scale_loss_grad(total), {'CTCLoss': loss_ctc.detach()}
-        return ops.scale_loss_grad(loss), None      # identity unless a loss scale is registered (fp16 training)
+            return ops.scale_loss_grad(total, self), {'CTCLoss': loss_ctc.detach()}
+        return ops.scale_loss_grad(loss, self), None      # identity unless a loss scale is registered (fp16 training)
 
     def compute_ctc_loss(self, memory, memory_mask, targets_out, targets_length):
         memory_length = torch.sum(memory_mask, dim=-1)
@@ -118,7 +118,7 @@ class CTCModel(nn.Module):
         memory, memory_mask, _ = self.encoder(enc_inputs, enc_mask)
         memory_length = torch.sum(memory_mask, dim=-1)
         loss = self.assistor(memory, memory_length, truth[:, 1:-1].contiguous(), truth_length.add(-1))
-        return ops.scale_loss_grad(loss), None
+        return ops.scale_loss_grad(loss, self), None
 
     def inference(self, inputs, inputs_mask):
         enc_inputs, enc_mask = self.frontend(inputs, inputs_mask)

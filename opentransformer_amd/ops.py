@@ -44,6 +44,27 @@ def graph_capture(graph, **kw):
             gc.enable()
 
 
+# ---------------------------------------------------------------------------------------- kernel timing hook (bench.py)
+# bench.py's `roofline` times the dominant kernels INSIDE a real training step: with a timer installed the wrappers of
+# the hot launches bracket them with events on the launch stream (torch's current stream is the stream handed to the
+# library).  Off (None) in production: one dict lookup per launch.
+def set_kernel_timer(records):
+    """records: a list that receives (name, meta, start_event, end_event) tuples, or None to switch timing off"""
+    _state['ktimer'] = records
+
+
+def _timed(name, meta, call):
+    rec = _state.get('ktimer')
+    if rec is None:
+        return call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = call()
+    e1.record()
+    rec.append((name, meta, e0, e1))
+    return r
+
+
 def set_compute_dtype(name):
     assert name in ('bf16', 'fp16', 'fp32')
     _state['compute'] = name
@@ -152,8 +173,12 @@ class ScaleGradFn(torch.autograd.Function):
         return out, None
 
 
-def scale_loss_grad(loss):
-    s = _state.get('loss_scale')
+def scale_loss_grad(loss, owner=None):
+    """owner: the model whose optimizer registered a scale on it (FusedAdam sets `_otr_loss_scale` on the wrapped module, so
+    two models trained in one process keep separate scales); the process-wide tensor is the fallback (parity tests)."""
+    s = getattr(owner, '_otr_loss_scale', None) if owner is not None else None
+    if s is None:
+        s = _state.get('loss_scale')
     if s is None or not loss.requires_grad:
         return loss
     return ScaleGradFn.apply(loss, s)
@@ -275,7 +300,9 @@ def linear_fwd_raw(x2, w, b, out_dtype, act=L.ACT_NONE, out=None):
     d = _linear_desc(M, N, K, x2.dtype, w.dtype, y.dtype, x2.stride(0), w.stride(0), y.stride(0), act,
                      accumulate=int(out is not None))
     ws = _workspace(x2.device)
-    L.check(L.load().otr_linear_fwd(C.byref(d), _p(x2), _p(w), _p(b), _p(y), _p(ws), _WS_BYTES, _stream()), 'otr_linear_fwd')
+    L.check(_timed('linear_fwd %dx%dx%d' % (M, N, K), {'flops': 2.0 * M * N * K},
+                   lambda: L.load().otr_linear_fwd(C.byref(d), _p(x2), _p(w), _p(b), _p(y), _p(ws), _WS_BYTES, _stream())),
+            'otr_linear_fwd')
     return y
 
 
@@ -295,7 +322,11 @@ def linear_dgrad_raw(dy2, w, dx_dtype, out=None):
 # be launched where autograd reaches them: nothing downstream reads them before the optimizer.  They are queued
 # and, when the autograd engine finishes, run as a few GROUPED launches (otr_linear_wgrad_grouped /
 # otr_colsum_grouped): ~150 latency-bound GEMM + split-K-reduce + column-sum launches per step become ~6.
-_wq = {'on': False, 'w': [], 'b': [], 'armed': False}
+# The queue belongs to ONE backward pass: it is filled and flushed inside a single autograd-engine run (the flush is an
+# engine callback of that run), so two models trained in one process -- an ASR model and an LM, say -- never see each
+# other's items as long as their backward passes do not interleave on one thread; a pass that dies half way leaves its
+# items behind, which the owner's zero_grad() / the next pass's first enqueue (different graph-task id) discards.
+_wq = {'on': False, 'w': [], 'b': [], 'armed': False, 'task': None}
 
 
 def defer_weight_grads(on):
@@ -305,10 +336,14 @@ def defer_weight_grads(on):
 def discard_pending_weight_grads():
     """Drop queued (never launched) weight-gradient work, e.g. left behind by a backward pass that raised.  Called by
     FlatDataParallel.zero_grad(): a stale queue must not leak into the next step's gradients."""
-    _wq['w'], _wq['b'], _wq['armed'] = [], [], False
+    _wq['w'], _wq['b'], _wq['armed'], _wq['task'] = [], [], False, None
 
 
 def _arm_flush():
+    task = torch._C._current_graph_task_id()
+    if _wq['task'] is not None and _wq['task'] != task:      # leftovers of a backward pass that never finished
+        discard_pending_weight_grads()
+    _wq['task'] = task
     if not _wq['armed']:
         _wq['armed'] = True
         torch.autograd.Variable._execution_engine.queue_callback(flush_weight_grads)
@@ -317,7 +352,7 @@ def _arm_flush():
 def flush_weight_grads():
     """Launch everything queued by linear_wgrad_raw / colsum_raw (called by the autograd engine at the end of
     backward; safe to call by hand)."""
-    _wq['armed'] = False
+    _wq['armed'], _wq['task'] = False, None
     w, b = _wq['w'], _wq['b']
     _wq['w'], _wq['b'] = [], []
     if _wq.get('keep_last'):            # bench.py re-times the grouped launch on the items of the last backward
@@ -331,8 +366,13 @@ def flush_weight_grads():
             it.ldy, it.ldx, it.ldw = dy2.stride(0), x2.stride(0), out.stride(0)
             it.dy_dtype, it.x_dtype = _code(dy2.dtype), _code(x2.dtype)
         ws = _workspace(w[0][0].device)
-        L.check(lib.otr_linear_wgrad_grouped(items, len(w), _compute_code(), _p(ws), _WS_BYTES, _stream()),
-                'otr_linear_wgrad_grouped')
+        meta = None
+        if _state.get('ktimer') is not None:
+            meta = {'problems': len(w),
+                    'flops': sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _ in w),
+                    'bytes': sum(dy.numel() * dy.element_size() + x.numel() * x.element_size() + 2 * o.numel() * 4 for dy, x, o in w)}
+        L.check(_timed('linear_wgrad_grouped', meta, lambda: lib.otr_linear_wgrad_grouped(
+            items, len(w), _compute_code(), _p(ws), _WS_BYTES, _stream())), 'otr_linear_wgrad_grouped')
     if b:
         items = (L.ColsumItem * len(b))()
         for it, (a2, out) in zip(items, b):
@@ -831,9 +871,10 @@ class FfnLnFn(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         seed = rng_seed_tensor(x.device) if p_drop > 0 else None
         off = _next_rng_offset(M * d) if p_drop > 0 else 0
-        L.check(L.load().otr_ffn_ln_fwd(_p(x2), _p(x16), _p(packs[0]), _p(b1), _p(packs[1]), _p(b2), _p(gamma), _p(beta),
-                                        _p(seed), p_drop, off, eps, _p(y), _p(y16), _p(z), _p(mean), _p(rstd), M, F, d,
-                                        _stream()), 'otr_ffn_ln_fwd')
+        L.check(_timed('ffn_ln_fwd', {'flops': 6.0 * M * F * d, 'bytes': M * d * (4 + 2 + 4 + 2 + 4) + 6 * F * d},
+                       lambda: L.load().otr_ffn_ln_fwd(_p(x2), _p(x16), _p(packs[0]), _p(b1), _p(packs[1]), _p(b2), _p(gamma),
+                                                       _p(beta), _p(seed), p_drop, off, eps, _p(y), _p(y16), _p(z), _p(mean),
+                                                       _p(rstd), M, F, d, _stream())), 'otr_ffn_ln_fwd')
         ctx.save_for_backward(x16, z, mean, rstd, gamma, seed, b1)
         ctx.packs = packs
         ctx.refs = (w1, b1, w2, b2, gamma, beta)
@@ -887,8 +928,9 @@ class FfnLnFn(torch.autograd.Function):
         # FFN backward with recompute: dh, u for the weight gradients; dx += dh . w_1
         dh = torch.empty((M, 2 * F), dtype=x16.dtype, device=dy.device)
         u = torch.empty((M, F), dtype=x16.dtype, device=dy.device)
-        L.check(lib.otr_ffn_bwd(_p(x16), _p(da), _p(P1), _p(b1), _p(P3), _p(P4), _p(dh), _p(u), _p(dx), _p(dx), M, F, d,
-                                _stream()), 'otr_ffn_bwd')
+        L.check(_timed('ffn_bwd', {'flops': 10.0 * M * F * d, 'bytes': M * d * (2 + 2 + 4 + 4) + M * F * 6 + 10 * F * d},
+                       lambda: lib.otr_ffn_bwd(_p(x16), _p(da), _p(P1), _p(b1), _p(P3), _p(P4), _p(dh), _p(u), _p(dx), _p(dx),
+                                               M, F, d, _stream())), 'otr_ffn_bwd')
         gw1, gb1, gw2 = grad_target(w1p), grad_target(b1p), grad_target(w2p)
         dw1 = linear_wgrad_raw(dh, x16, None, out=gw1)
         dw2 = linear_wgrad_raw(da, u, None, out=gw2)

@@ -148,8 +148,16 @@ class SpeechToTextRecognizer(Recognizer):
     def recognize_cached(self, inputs, inputs_mask):
         memory, memory_mask, _, _ = self.encode(inputs, inputs_mask)
         b, t, _ = memory.size()
+        # the captured graphs bake in the device pointers of the stand-alone 16-bit weight shadows (ops.weight_lp caches a
+        # cast per parameter version): a checkpoint loaded into the same modules, averaging, ... re-allocates them, so the
+        # weights' (version, pointer) fingerprint is part of the key -- stale graphs are dropped, never replayed
+        fp = 0
+        for mod in (self.model.decoder, self.lm):
+            if mod is not None:
+                for p_ in mod.parameters():
+                    fp = (fp * 1000003 + p_._version * 31 + p_.data_ptr()) & 0xFFFFFFFFFFFF
         key = (b, t, self.beam_width, self.max_len, ops.get_compute_dtype(), str(memory.device),
-               self.lm is not None, bool(self.use_hipgraph))
+               self.lm is not None, bool(self.use_hipgraph), fp)
         st = self._cached_states.get(key)
         if st is None:
             if len(self._cached_states) >= 4:                # a few shapes; each holds caches + two graphs

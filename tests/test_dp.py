@@ -110,3 +110,62 @@ def test_flat_buffers_alias_parameters():
     dp(tok, tgt).backward()
     assert float(dp.flat_grad.abs().sum()) > 0              # autograd accumulated into the flat views
     assert model.emb.weight.grad.data_ptr() == model.out2.weight.grad.data_ptr()
+
+
+def _worker_lp(rank, world, port, out):
+    """same as _worker with a bf16 gradient payload and non-flattened parameters (the per-tensor broadcast path)"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model = Tiny()
+    if rank == 1:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    dp = FlatDataParallel(model, flatten_params=False, grad_comm_dtype=torch.bfloat16)
+    dp.broadcast_parameters(0)                       # ADVICE r01: this path used to call a method that did not exist
+    tok, tgt = _data()
+    shard = slice(rank * 4, rank * 4 + 4)
+    dp.zero_grad()
+    dp(tok[shard], tgt[shard]).backward()
+    scale, _ = dp.all_reduce_gradients()
+    if rank == 1:
+        torch.save({'grad': (dp.packed_grads() * scale).clone(),
+                    'params': torch.cat([p.detach().reshape(-1) for p in dp.params])}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_payload_and_per_tensor_broadcast(tmp_path):
+    out = str(tmp_path / 'r1.pt')
+    mp.spawn(_worker_lp, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    model = Tiny()
+    tok, tgt = _data()
+    loss = 0.5 * (model(tok[:4], tgt[:4]) + model(tok[4:], tgt[4:]))
+    params, seen = [], set()
+    for p in model.parameters():
+        if id(p) not in seen:
+            seen.add(id(p))
+            params.append(p)
+    ref = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, params)])
+    assert torch.equal(got['params'], torch.cat([p.detach().reshape(-1) for p in params]))     # rank 1 received rank 0's weights
+    # each rank's gradient is rounded to bf16 before the sum: 2^-9 relative per element
+    assert float((got['grad'] - ref).norm() / ref.norm()) < 6e-3
+
+
+def test_dropped_gradient_views_are_detected():
+    """torch's default zero_grad(set_to_none=True) drops the flat views; the engine must notice instead of
+    training on an all-zero flat buffer."""
+    model = Tiny()
+    dp = FlatDataParallel(model)
+    tok, tgt = _data()
+    model.zero_grad()                                        # torch default: .grad = None
+    assert all(p.grad is None for p in model.parameters())
+    dp.zero_grad()                                           # puts the views back
+    dp(tok, tgt).backward()
+    assert float(dp.flat_grad.abs().sum()) > 0
+    dp.all_reduce_gradients()
+    model.l1.weight.grad = torch.zeros_like(model.l1.weight)  # a foreign gradient tensor
+    with pytest.raises(RuntimeError, match='flat'):
+        dp.all_reduce_gradients()
