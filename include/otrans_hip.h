@@ -106,7 +106,9 @@ int32_t otr_ffn_glu_bwd(const void* dy, int32_t dy_dtype, int64_t ldy, const voi
  *   dropout mask is the one otr_add_layernorm_bwd regenerates from (seed, rng_offset).
  * otr_ffn_bwd:  recomputes the pre-activations from x16, then dh[M,2F] = GLU'(.) * (dy16 . w_2), u[M,F] = glu(.)
  *   (row-major, the operands of the two weight gradients) and dx[M,256] f32 = skip + dh . w_1 in ONE launch.
- *   w2t_pack = pack(w_2 as A[f][n], perm 0); w1t_pack = pack(w_1 as A[k][f'], perm 1); skip may be NULL or alias dx. */
+ *   w2t_pack = pack(w_2 as A[f][n], perm 0); w1t_pack = pack(w_1 as A[k][f'], perm 1); skip may be NULL or alias dx.
+ *   db1_part f32 [ceil(M/32)][2F]: column sums of dh per 32-row block (column-sum them for the w_1 bias gradient; the
+ *   reduction over each block's rows happens on the accumulator registers, dh is not read again). */
 int32_t otr_pack_frags(const void* src, void* dst, const int64_t* table, int32_t n_items, int64_t total_blocks,
                        void* stream);
 int32_t otr_ffn_ln_fwd(const float* x, const void* x16, const void* w1_pack, const float* b1, const void* w2_pack,
@@ -114,8 +116,22 @@ int32_t otr_ffn_ln_fwd(const float* x, const void* x16, const void* w1_pack, con
                        uint64_t rng_offset, float eps, float* y, void* y16, float* z, float* mean, float* rstd, int64_t M,
                        int32_t F, int32_t d_model, void* stream);
 int32_t otr_ffn_bwd(const void* x16, const void* dy16, const void* w1_pack, const float* b1, const void* w2t_pack,
-                    const void* w1t_pack, void* dh, void* u, const float* skip, float* dx, int64_t M, int32_t F,
-                    int32_t d_model, void* stream);
+                    const void* w1t_pack, void* dh, void* u, float* db1_part, const float* skip, float* dx, int64_t M,
+                    int32_t F, int32_t d_model, void* stream);
+
+/* ---- the same sub-layer with the weight stream SHARED by 128 rows (v2, experimental: OTR_FFN_V2=1): a workgroup owns
+ *      128 rows x 1/n_slabs of the hidden units, fetches every packed weight fragment once (global -> LDS, direct DMA)
+ *      for its four waves, and leaves fp32 partial sums: slabs [n_slabs][M][256].
+ * otr_ffn_fwd_slabs:  slabs = partial w_2(glu(w_1 x + b_1)) (b_2 not included); finish with otr_add_layernorm_fwd_slabs.
+ * otr_ffn_bwd_slabs:  dh, u, db1_part as otr_ffn_bwd; slabs = partial dh . w_1; finish with otr_slab_sum(slabs, skip) -> dx.
+ * otr_slab_sum:  out[n] = skip[n] (or 0) + sum over n_slabs of slabs[s*n + i], f32, n % 4 == 0; out may alias skip.
+ * (d_ff / 32) % n_slabs == 0; 4 slabs fill the 256 CUs at 63 row blocks (B = 32 x 249 frames). */
+int32_t otr_ffn_fwd_slabs(const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, float* slabs,
+                          int32_t n_slabs, int64_t M, int32_t F, int32_t d_model, void* stream);
+int32_t otr_ffn_bwd_slabs(const void* x16, const void* dy16, const void* w1_pack, const float* b1, const void* w2t_pack,
+                          const void* w1t_pack, void* dh, void* u, float* db1_part, float* slabs, int32_t n_slabs, int64_t M,
+                          int32_t F, int32_t d_model, void* stream);
+int32_t otr_slab_sum(const float* slabs, int32_t n_slabs, int64_t n, const float* skip, float* out, void* stream);
 
 /* ---- grouped weight / bias gradients: every dw_i[N,K] += dy_i[M,N]^T x_i[M,K] of a backward pass in a few launches
  *      (one per operand-type group), likewise every bias gradient out_i[N] += column sums of a_i[M,N].  The per-layer
@@ -188,6 +204,12 @@ typedef struct {
 int32_t otr_add_layernorm_fwd(const otr_ln_desc_t* d, const float* x, const void* a, const float* gamma,
                               const float* beta, const uint64_t* seed, float* y, void* y_bf16, float* z, float* mean,
                               float* rstd, void* stream);
+/* the branch given as n_slabs f32 partial sums [n_slabs][slab_stride >= M*d] plus an optional bias a_bias f32[d]
+ * (otr_ffn_fwd_slabs): y = LayerNorm(x + dropout(a_bias + sum of slabs)); outputs as otr_add_layernorm_fwd */
+int32_t otr_add_layernorm_fwd_slabs(const otr_ln_desc_t* d, const float* x, const float* slabs, int32_t n_slabs,
+                                    int64_t slab_stride, const float* a_bias, const float* gamma, const float* beta,
+                                    const uint64_t* seed, float* y, void* y_bf16, float* z, float* mean, float* rstd,
+                                    void* stream);
 /* dx f32 [M,d] (residual grad), da [M,d] a_dtype (branch grad, may be NULL), dgamma/dbeta f32[d] +=.
  * da_colsum (f32[d] +=, may be NULL): column sums of da, i.e. the bias gradient of the Linear that produced the
  * branch (module/attention.py:43 output_proj, module/ffn.py:41 w_2) without a separate reduction launch. */

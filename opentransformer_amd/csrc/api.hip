@@ -38,6 +38,8 @@ int g_otr_force_tile = 0;
 int g_otr_force_ksplit = 0;
 int g_otr_force_generic = 0;
 int g_otr_no_persist = 0;
+int g_otr_ffn_waves = 4;   // 8 measured SLOWER (85 vs 61 us forward): see DESIGN.md
+int g_otr_ffn2_ablate = 0;   // tuning hook (otr_debug_set(4, v)): bit 0 = no weight DMA after the first chunk, bit 1 = no MFMA work
 unsigned long long* g_otr_trace = nullptr;
 extern "C" int32_t otr_debug_trace(void* buf) { g_otr_trace = (unsigned long long*)buf; return 0; }
 extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
@@ -45,6 +47,8 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   else if (key == 1) g_otr_force_ksplit = value;
   else if (key == 2) g_otr_force_generic = value;
   else if (key == 3) g_otr_no_persist = value;
+  else if (key == 4) g_otr_ffn2_ablate = value;
+  else if (key == 5) g_otr_ffn_waves = value;
   else { otr_set_error("debug_set: unknown key %d", key); return -1; }
   return 0;
 }

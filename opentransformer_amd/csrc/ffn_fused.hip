@@ -80,11 +80,11 @@ __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn
 
 // 32 rows x D 16-bit activations -> LDS as 16-byte chunks, chunk index XOR (row & 15): the B-operand read of lane
 // (m = lane&31, hi) -- chunk (2*ks + hi) of row m -- is then bank-conflict free for ds_read_b128
-template <int D>
+template <int D, int NTHR = 256>
 __device__ __forceinline__ void stage_rows(uint4* dst, const uint16_t* src, int row0, int M, int tid) {
   constexpr int CPR = D / 8;
 #pragma unroll
-  for (int i = tid; i < FF_RB * CPR; i += 256) {
+  for (int i = tid; i < FF_RB * CPR; i += NTHR) {
     const int r = i / CPR, ch = i % CPR;
     const int gr = min(row0 + r, M - 1);
     dst[r * CPR + (ch ^ (r & 15))] = ld_global_b128(src + (int64_t)gr * D + ch * 8);
@@ -117,6 +117,29 @@ __device__ __forceinline__ void store_tile_row(uint16_t* rowp, const uint4& f0, 
   }
 }
 
+// column sums of an accumulator tile over its 32 rows: the 16 registers of lane (m, hi) are hidden units 8q + 4hi + (r&3) of
+// row m.  Reduce-scatter butterfly over the 32 lanes of a half-wave (xor 16, 8, 4, 2 halve the register set each step, xor 1
+// finishes): 16 shuffles per tile instead of 80 for sixteen independent butterflies; lane m ends up with the total of
+// register r = (m4 m3 m2 m1) and the even lanes store it.  dst = the 32 floats of this tile in the partial-sum row.
+__device__ __forceinline__ void tile_colsum_store(const float* v, float* dst, int lane, int hi, bool rows_live) {
+  const int m = lane & 31;
+  const bool b4 = m & 16, b3 = m & 8, b2 = m & 4, b1 = m & 2;
+  float a[8], b[4], c[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float lo = rows_live ? v[i] : 0.f, hi_ = rows_live ? v[8 + i] : 0.f;
+    a[i] = (b4 ? hi_ : lo) + __shfl_xor(b4 ? lo : hi_, 16);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b[i] = (b3 ? a[4 + i] : a[i]) + __shfl_xor(b3 ? a[i] : a[4 + i], 8);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) c[i] = (b2 ? b[2 + i] : b[i]) + __shfl_xor(b2 ? b[i] : b[2 + i], 4);
+  float d = (b1 ? c[1] : c[0]) + __shfl_xor(b1 ? c[0] : c[1], 2);
+  d += __shfl_xor(d, 1);
+  const int r = ((m >> 4) & 1) * 8 + ((m >> 3) & 1) * 4 + ((m >> 2) & 1) * 2 + ((m >> 1) & 1);
+  if ((m & 1) == 0) dst[8 * (r >> 2) + 4 * hi + (r & 3)] = d;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 struct FfnFwdArgs {
   const float* x;          // residual stream [M, D] f32
@@ -132,12 +155,17 @@ struct FfnFwdArgs {
   uint64_t rng_offset;
 };
 
-template <int D>
-__global__ __launch_bounds__(256, 1) void ffn_ln_fwd_kernel(FfnFwdArgs p) {
+// NW = waves per workgroup.  A pure streaming kernel ingests ~22 B/clk per CU with 4 waves and ~33 B/clk with 8
+// (tools/ubench/l2stream.hip), and this kernel sits on the 4-wave figure -- but its 8-wave form (two waves per SIMD, <= 256
+// registers each, a 12-deep ring per wave) measured 85 us against 61 us: the shallower rings and the shared matrix pipe cost
+// more than the extra load issue slots bring.  NW = 4 is the production form; NW = 8 stays selectable (otr_debug_set(5, 8)).
+template <int D, int NW, int PD>
+__global__ __launch_bounds__(NW * 64, NW / 4) void ffn_ln_fwd_kernel(FfnFwdArgs p) {
   static_assert(D == 256, "the LayerNorm epilogue maps one float4 per lane: d_model = 256");
   constexpr int NKS = D / 16, NT = D / 32, YP = D + 4;
   constexpr int STEPS = 2 * NKS + 2 * NT;          // weight fragments (= MFMAs) per chunk: 32 + 16
-  constexpr int PD = 24;                           // fragments in flight per wave (24 KiB)
+  constexpr int NTHR = NW * 64, RPW = FF_RB / NW;  // PD = fragments in flight per wave (1 KiB each)
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   static_assert(STEPS % PD == 0, "ring slots must be compile-time constants");
   __shared__ __attribute__((aligned(16))) unsigned char smem[FF_RB * D * 2 + 4 * FF_RB * YP * 4];
   uint4* xs = reinterpret_cast<uint4*>(smem);
@@ -147,15 +175,15 @@ __global__ __launch_bounds__(256, 1) void ffn_ln_fwd_kernel(FfnFwdArgs p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, hi = lane >> 5;
   const int row0 = blockIdx.x * FF_RB;
-  stage_rows<D>(xs, p.x16, row0, p.M, tid);
+  stage_rows<D, NTHR>(xs, p.x16, row0, p.M, tid);
   __syncthreads();
 
-  const int nchunk = p.F / 32, npair = nchunk / 8, nit = nchunk / 4;
+  const int nchunk = p.F / 32, npair = nchunk / (2 * NW), nit = nchunk / NW;
   const int rot = (int)(blockIdx.x % (unsigned)npair);      // workgroups walk the weights from different starting points
   auto chunk_of = [&](int it) {
     int j = (it >> 1) + rot;
     if (j >= npair) j -= npair;
-    return 8 * j + 2 * wid + (it & 1);                       // a wave's consecutive chunks are adjacent
+    return 2 * NW * j + 2 * wid + (it & 1);                  // a wave's consecutive chunks are adjacent
   };
   const uint4* P1 = p.p1 + lane;
   const uint4* P2 = p.p2 + lane;
@@ -213,16 +241,34 @@ __global__ __launch_bounds__(256, 1) void ffn_ln_fwd_kernel(FfnFwdArgs p) {
     c = cn;
   }
 
-  // the four waves' partial y^T tiles meet in LDS: red[wave][m][n], n = nt*32 + 8q + 4hi + (r&3)
+  // the waves' partial y^T tiles meet in LDS: red[slot][m][n], n = nt*32 + 8q + 4hi + (r&3); four slots -- with 8 waves
+  // the upper four first hand their tiles to the lower four, which fold them into their accumulators
+  auto put = [&](int slot) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<float4*>(red + (wid * FF_RB + m) * YP + nt * 32 + 8 * q + 4 * hi) =
-          make_float4(yacc[nt][4 * q], yacc[nt][4 * q + 1], yacc[nt][4 * q + 2], yacc[nt][4 * q + 3]);
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(red + (slot * FF_RB + m) * YP + nt * 32 + 8 * q + 4 * hi) =
+            make_float4(yacc[nt][4 * q], yacc[nt][4 * q + 1], yacc[nt][4 * q + 2], yacc[nt][4 * q + 3]);
+  };
+  if constexpr (NW == 8) {
+    if (wid >= 4) put(wid - 4);
+    __syncthreads();
+    if (wid < 4) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(red + (wid * FF_RB + m) * YP + nt * 32 + 8 * q + 4 * hi);
+          yacc[nt][4 * q] += t.x; yacc[nt][4 * q + 1] += t.y; yacc[nt][4 * q + 2] += t.z; yacc[nt][4 * q + 3] += t.w;
+        }
+    }
+    __syncthreads();
+  }
+  if (wid < 4) put(wid);
   __syncthreads();
 
-  // bias + dropout + residual + LayerNorm on whole rows: wave w owns rows 8w..8w+7, lane owns columns 4*lane..+3
+  // bias + dropout + residual + LayerNorm on whole rows: wave w owns rows RPW*w .. +RPW-1, lane owns columns 4*lane..+3
   const bool drop = p.p_drop > 0.f;
   const uint64_t seed = drop ? *p.seed : 0;
   const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
@@ -231,15 +277,15 @@ __global__ __launch_bounds__(256, 1) void ffn_ln_fwd_kernel(FfnFwdArgs p) {
   const float4 b2 = *reinterpret_cast<const float4*>(p.b2 + col);
   const float4 gm = *reinterpret_cast<const float4*>(p.gamma + col);
   const float4 bt = *reinterpret_cast<const float4*>(p.beta + col);
-  float4 xr[8];
+  float4 xr[RPW];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int64_t row = min((int64_t)row0 + wid * 8 + i, (int64_t)p.M - 1);
+  for (int i = 0; i < RPW; ++i) {
+    const int64_t row = min((int64_t)row0 + wid * RPW + i, (int64_t)p.M - 1);
     xr[i] = *reinterpret_cast<const float4*>(p.x + row * D + col);
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int r = wid * 8 + i;
+  for (int i = 0; i < RPW; ++i) {
+    const int r = wid * RPW + i;
     const int64_t row = (int64_t)row0 + r;
     float v[4] = {b2.x, b2.y, b2.z, b2.w};
 #pragma unroll
@@ -283,6 +329,7 @@ struct FfnBwdArgs {
   const uint4* p4;         // w_1^T packed: rows = D, contraction = 2F (value then gate), perm 1  (dx = dh . w_1)
   uint16_t* dh;            // [M, 2F] out: gradient of the pre-activations (operand of the w_1 weight gradient)
   uint16_t* u;             // [M, F] out: glu output (operand of the w_2 weight gradient)
+  float* bpart;            // [gridDim.x][2F] out: column sums of dh over this workgroup's rows (the w_1 bias gradient, partial)
   const float* skip;       // [M, D] f32 or NULL, added to dx (the skip-connection gradient of y = LN(x + f(x)))
   float* dx;               // [M, D] f32 out (may alias skip)
   int M, F;
@@ -384,6 +431,9 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(FfnBwdArgs p) {
         store_tile_row(p.u + crow * p.F + c * 32, u0, u1, hi, live);
         store_tile_row(p.dh + crow * (2 * (int64_t)p.F) + c * 32, hf[0], hf[1], hi, live);
         store_tile_row(p.dh + crow * (2 * (int64_t)p.F) + p.F + c * 32, hf[2], hf[3], hi, live);
+        float* bp = p.bpart + (int64_t)blockIdx.x * (2 * p.F) + c * 32;      // this wave owns chunk c of the block's row
+        tile_colsum_store(da_, bp, lane, hi, live);
+        tile_colsum_store(dg_, bp + p.F, lane, hi, live);
       }
     }
     c = cn;
@@ -419,6 +469,7 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(FfnBwdArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
+extern int g_otr_ffn_waves;   // tuning hook (otr_debug_set(5, v)): 8 = the 8-wave form of the forward kernel, anything else = 4 waves
 static int32_t ffn_shape_check(const char* who, int64_t M, int32_t F, int32_t d_model) {
   OTR_REQUIRE(M >= 0 && M < (1ll << 31), "%s: bad M", who);
   OTR_REQUIRE(d_model == 256, "%s: built for d_model = 256 (got %d); use the unfused path", who, d_model);
@@ -440,22 +491,435 @@ extern "C" int32_t otr_ffn_ln_fwd(const float* x, const void* x16, const void* w
   p.x = x; p.x16 = (const uint16_t*)x16; p.p1 = (const uint4*)w1_pack; p.b1 = b1; p.p2 = (const uint4*)w2_pack; p.b2 = b2;
   p.gamma = gamma; p.beta = beta; p.seed = seed; p.y = y; p.y16 = (uint16_t*)y16; p.z = z; p.mean = mean; p.rstd = rstd;
   p.M = (int)M; p.F = F; p.eps = eps; p.p_drop = p_drop; p.rng_offset = rng_offset;
-  hipLaunchKernelGGL(ffn_ln_fwd_kernel<256>, dim3((unsigned)((M + FF_RB - 1) / FF_RB)), dim3(256), 0, (hipStream_t)stream, p);
+  const unsigned nblk = (unsigned)((M + FF_RB - 1) / FF_RB);
+  if (g_otr_ffn_waves != 8 || F % 512 != 0)
+    hipLaunchKernelGGL((ffn_ln_fwd_kernel<256, 4, 24>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL((ffn_ln_fwd_kernel<256, 8, 12>), dim3(nblk), dim3(512), 0, (hipStream_t)stream, p);
   return otr_check_launch("ffn_ln_fwd");
 }
 
 extern "C" int32_t otr_ffn_bwd(const void* x16, const void* dy16, const void* w1_pack, const float* b1, const void* w2t_pack,
-                               const void* w1t_pack, void* dh, void* u, const float* skip, float* dx, int64_t M, int32_t F,
-                               int32_t d_model, void* stream) {
+                               const void* w1t_pack, void* dh, void* u, float* db1_part, const float* skip, float* dx, int64_t M,
+                               int32_t F, int32_t d_model, void* stream) {
   if (int32_t e = ffn_shape_check("ffn_bwd", M, F, d_model)) return e;
-  OTR_REQUIRE(x16 && dy16 && w1_pack && b1 && w2t_pack && w1t_pack && dh && u && dx, "ffn_bwd: null pointer");
+  OTR_REQUIRE(x16 && dy16 && w1_pack && b1 && w2t_pack && w1t_pack && dh && u && dx && db1_part, "ffn_bwd: null pointer");
+  OTR_REQUIRE((uintptr_t)db1_part % 16 == 0, "ffn_bwd: db1_part must be 16-byte aligned");
   OTR_REQUIRE(((uintptr_t)x16 | (uintptr_t)dy16 | (uintptr_t)w1_pack | (uintptr_t)w2t_pack | (uintptr_t)w1t_pack | (uintptr_t)dh |
                (uintptr_t)u | (uintptr_t)dx | (uintptr_t)skip | (uintptr_t)b1) % 16 == 0, "ffn_bwd: buffers must be 16-byte aligned");
   if (M == 0) return 0;
   FfnBwdArgs p{};
   p.x16 = (const uint16_t*)x16; p.dy16 = (const uint16_t*)dy16; p.p1 = (const uint4*)w1_pack; p.b1 = b1;
-  p.p3 = (const uint4*)w2t_pack; p.p4 = (const uint4*)w1t_pack; p.dh = (uint16_t*)dh; p.u = (uint16_t*)u; p.skip = skip; p.dx = dx;
+  p.p3 = (const uint4*)w2t_pack; p.p4 = (const uint4*)w1t_pack; p.dh = (uint16_t*)dh; p.u = (uint16_t*)u; p.bpart = db1_part; p.skip = skip; p.dx = dx;
   p.M = (int)M; p.F = F;
   hipLaunchKernelGGL(ffn_bwd_kernel<256>, dim3((unsigned)((M + FF_RB - 1) / FF_RB)), dim3(256), 0, (hipStream_t)stream, p);
   return otr_check_launch("ffn_bwd");
+}
+
+// ================================================================================================ v2: shared weight stream
+// Measured on MI355X (tools/ubench/l2stream.hip, profiles/r02_l2stream.txt): a CU ingests global memory at ~22 B/clk
+// with 4 waves (33 B/clk with 8), whether the lines come from L2, MALL or even L1 -- the v1 kernels above, whose waves
+// each stream their own weight fragments into registers, sit exactly on that ceiling (3 MB per CU -> 60 us forward).
+// v2 cuts the ingest per CU by 4: a workgroup owns 128 rows (wave w: rows 32w..32w+31) and 1/S of the hidden units
+// (grid = row blocks x S = 63 x 4 at B=32); every weight fragment is fetched ONCE per workgroup, global -> LDS by
+// direct-to-LDS loads (global_load_lds_dwordx4: the fragment-major packs are exactly the lane-linear image those
+// need), and read from LDS by all four waves (ds_read_b128, conflict-free).  Chunk c+1 streams in while chunk c is
+// multiplied: one barrier per chunk of 48 (forward) / 80 (backward) MFMAs per wave.  The hidden-dimension split leaves S
+// partial fp32 output slabs; the LayerNorm kernel (otr_add_layernorm_fwd_slabs) / a small reduce kernel sums them.
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+typedef __attribute__((address_space(1))) const unsigned char gbl_byte;
+
+// one 1 KiB fragment: 64 lanes x 16 B, global (fragment-major pack) -> LDS, asynchronous (vmcnt)
+// Inline asm, not __builtin_amdgcn_global_load_lds: with the builtin hipcc tracks the pending LDS write and puts
+// `s_waitcnt vmcnt(0)` in front of the next ds_read of ANY address -- i.e. it waited for the chunk it had just started to
+// fetch before multiplying the current one (seen in the ISA: the whole DMA latency exposed per chunk).  The asm form is
+// invisible to that bookkeeping; the kernels below wait themselves (vmcnt(0) + barrier right before a buffer is read).
+// M0 carries the wave-uniform LDS byte address and is restored afterwards (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void dma_frag(const uint4* src_frag, unsigned char* lds_frag, int lane) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_byte*)lds_frag);
+  const uint4* src = src_frag + lane;
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+
+struct Ffn2FwdArgs {
+  const uint16_t* x16;     // [M, D]
+  const uint4* p1; const float* b1; const uint4* p2;
+  float* slabs;            // [S][M][D] f32 partial outputs (bias b_2 NOT included)
+  int M, F, S;
+  int ablate;              // tuning hook (otr_debug_set(4, v)); 0 in production
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 1) void ffn2_fwd_kernel(Ffn2FwdArgs p) {
+  constexpr int NKS = D / 16, NT = D / 32;
+  constexpr int FR = 2 * NKS + 2 * NT;             // fragments per chunk: 32 (w_1 value+gate) + 16 (w_2)
+  constexpr int BUF = FR * 1024;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + 8192];
+  float* bias_s = reinterpret_cast<float*>(smem + 2 * BUF);      // b_1 of this workgroup's hidden units: [chunk][value 32 | gate 32]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, hi = lane >> 5;
+  const int row0 = blockIdx.x * 128 + wid * 32;
+  const int nchunk = p.F / 32, per = nchunk / p.S;               // chunks of this workgroup: [c0, c0 + per)
+  const int c0 = blockIdx.y * per;
+
+  for (int i = tid; i < per * 64; i += 256) {
+    const int c = i >> 6, j = i & 63;
+    bias_s[i] = p.b1[(j < 32 ? 0 : p.F) + (c0 + c) * 32 + (j & 31)];
+  }
+  // this wave's activation rows as MFMA B operands, held in registers for the whole kernel
+  uint4 xf[NKS];
+  {
+    const int64_t row = min(row0 + m, p.M - 1);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) xf[ks] = ld_global_b128(p.x16 + row * D + ks * 16 + hi * 8);
+  }
+  // fragment f of chunk c -> source fragment; every wave DMAs FR/4 of them
+  auto issue = [&](int c, int buf) {
+#pragma unroll
+    for (int j = 0; j < FR / 4; ++j) {
+      const int f = wid * (FR / 4) + j;              // wave-uniform
+      const uint4* src;
+      if (f < 2 * NKS) src = p.p1 + (int64_t)(((f & 1) ? nchunk + c : c) * NKS + (f >> 1)) * 64;
+      else { const int t = f - 2 * NKS; src = p.p2 + (int64_t)((t >> 1) * (2 * nchunk) + 2 * c + (t & 1)) * 64; }
+      dma_frag(src, smem + buf * BUF + f * 1024, lane);
+    }
+  };
+
+  f32x16 yacc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) yacc[i][r] = 0.f;
+
+  // Software pipeline across chunks: the second GEMM of chunk i-1 (y += w_2 . u) is issued together with the GLU of
+  // chunk i, so the matrix pipe has work while the VALU computes sigmoid / products / packs of the chunk just
+  // multiplied (measured: with GEMM1 -> GLU -> GEMM2 in sequence a chunk took 4.2 k cycles for 1.5 k cycles of MFMAs).
+  // The w_2 fragments of a chunk are therefore copied LDS -> registers while that chunk's first GEMM runs (its buffer
+  // is refilled during the next iteration) and used one iteration later.
+  constexpr int G = 8, NG1 = 2 * NKS / G;           // first GEMM: 32 fragments in groups of 8 (LDS -> register prefetch)
+  static_assert((2 * NKS) % G == 0, "whole prefetch groups");
+  uint4 w2r[2 * NT], uf0, uf1;
+
+  // GEMM1 of chunk i (weights in LDS buffer i&1) into av / ag, with the chunk's bias and w_2 fragments fetched alongside
+#define FFN2_GEMM1(I)                                                                                  \
+  {                                                                                                     \
+    const uint4* wb = reinterpret_cast<const uint4*>(smem + ((I) & 1) * BUF) + lane;                    \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                     \
+      bv[q] = *reinterpret_cast<const float4*>(bias_s + (I) * 64 + 8 * q + 4 * hi);                     \
+      bg[q] = *reinterpret_cast<const float4*>(bias_s + (I) * 64 + 32 + 8 * q + 4 * hi);                \
+    }                                                                                                   \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) { av[r] = 0.f; ag[r] = 0.f; }                        \
+    uint4 fr[2][G];                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < G; ++j) fr[0][j] = wb[j * 64];                                \
+    _Pragma("unroll") for (int g = 0; g < NG1; ++g) {                                                   \
+      if (g + 1 < NG1) {                                                                                \
+        _Pragma("unroll") for (int j = 0; j < G; ++j) fr[(g + 1) & 1][j] = wb[((g + 1) * G + j) * 64];  \
+      } else {                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2 * NT; ++j) nw[j] = wb[(2 * NKS + j) * 64];              \
+      }                                                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                \
+      _Pragma("unroll") for (int j = 0; j < G; ++j) {                                                   \
+        const int f = g * G + j;                                                                        \
+        if (f & 1) mma32(ag, fr[g & 1][j], xf[f >> 1]); else mma32(av, fr[g & 1][j], xf[f >> 1]);       \
+      }                                                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                \
+    }                                                                                                   \
+  }
+#define FFN2_GLU()                                                                                      \
+  {                                                                                                     \
+    float u[16];                                                                                        \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
+      const float a = av[r] + reinterpret_cast<const float*>(&bv[r >> 2])[r & 3];                       \
+      const float gt = ag[r] + reinterpret_cast<const float*>(&bg[r >> 2])[r & 3];                      \
+      u[r] = a * fast_sigmoid(gt);                                                                      \
+    }                                                                                                   \
+    tile_to_frags(u, n0, n1);                                                                           \
+  }
+#define FFN2_GEMM2()                                                                                    \
+  _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                   \
+    mma32(yacc[nt], w2r[2 * nt], uf0);                                                                  \
+    mma32(yacc[nt], w2r[2 * nt + 1], uf1);                                                              \
+  }
+#define FFN2_ROTATE()                                                                                   \
+  {                                                                                                     \
+    uf0 = n0; uf1 = n1;                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 2 * NT; ++j) w2r[j] = nw[j];                                  \
+  }
+#define FFN2_ARRIVE(I)                                                                                  \
+  {                                                                                                     \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
+    __syncthreads(); /* chunk I has landed for every wave; buffer (I+1)&1 is free */                    \
+    if ((I) + 1 < per && !(p.ablate & 1)) issue(c0 + (I) + 1, ((I) + 1) & 1);                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  }
+  f32x16 av, ag;
+  float4 bv[4], bg[4];
+  uint4 nw[2 * NT], n0, n1;
+  issue(c0, 0);
+  // The activation fragments must be KNOWN complete before the loop: hipcc's waitcnt pass otherwise carries "up to 16
+  // loads may be pending" around the back edge and guards every xf use with vmcnt(15) ... vmcnt(0) -- which, since the
+  // counter also holds the DMA just issued for the next chunk, waits for that DMA in the middle of the current chunk.
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) asm volatile("" :: "v"(xf[ks].x), "v"(xf[ks].y), "v"(xf[ks].z), "v"(xf[ks].w));
+  FFN2_ARRIVE(0)
+  if (!(p.ablate & 2)) {
+    FFN2_GEMM1(0)
+    FFN2_GLU()
+    FFN2_ROTATE()
+  }
+  for (int i = 1; i < per; ++i) {
+    FFN2_ARRIVE(i)
+    if (p.ablate & 2) continue;
+    FFN2_GEMM1(i)
+    FFN2_GEMM2()                                      // chunk i-1, registers only: runs beside the GLU of chunk i
+    FFN2_GLU()
+    __builtin_amdgcn_sched_barrier(0);
+    FFN2_ROTATE()
+  }
+  if (!(p.ablate & 2)) { FFN2_GEMM2() }
+#undef FFN2_GEMM1
+#undef FFN2_GLU
+#undef FFN2_GEMM2
+#undef FFN2_ROTATE
+#undef FFN2_ARRIVE
+  // partial output rows -> slab blockIdx.y, staged through the (now idle) buffer (per & 1) so that memory sees whole
+  // 256-byte row segments: each wave uses a private 8 KiB slice, 64 columns at a time (no workgroup barrier needed)
+  float* st = reinterpret_cast<float*>(smem + (per & 1) * BUF + wid * 8192);      // [32 rows][64 cols]
+  float* out = p.slabs + ((int64_t)blockIdx.y * p.M) * D;
+#pragma unroll
+  for (int h = 0; h < NT / 2; ++h) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(st + m * 64 + t * 32 + 8 * q + 4 * hi) =
+            make_float4(yacc[2 * h + t][4 * q], yacc[2 * h + t][4 * q + 1], yacc[2 * h + t][4 * q + 2], yacc[2 * h + t][4 * q + 3]);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {                 // 4 rows x 16 lanes x float4 per pass
+      const int r = rr * 4 + (lane >> 4);
+      const int64_t row = (int64_t)row0 + r;
+      const float4 v = *reinterpret_cast<const float4*>(st + r * 64 + (lane & 15) * 4);
+      if (row < p.M) *reinterpret_cast<float4*>(out + row * D + h * 64 + (lane & 15) * 4) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+struct Ffn2BwdArgs {
+  const uint16_t* x16; const uint16_t* dy16;
+  const uint4* p1; const float* b1; const uint4* p3; const uint4* p4;
+  uint16_t* dh; uint16_t* u;
+  float* bpart;            // [ceil(M/32)][2F]: column sums of dh per 32-row block (= per wave)
+  float* slabs;            // [S][M][D] f32 partial input gradients
+  int M, F, S;
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 1) void ffn2_bwd_kernel(Ffn2BwdArgs p) {
+  constexpr int NKS = D / 16, NT = D / 32;
+  constexpr int S1 = 2 * NKS, S2 = S1 + NKS, FR = S2 + 4 * NT;    // 32 + 16 + 32 fragments per chunk
+  constexpr int BUF = FR * 1024;                                  // 80 KiB: two of them are the whole LDS
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, hi = lane >> 5;
+  const int row0 = blockIdx.x * 128 + wid * 32;
+  const int nchunk = p.F / 32, per = nchunk / p.S;
+  const int c0 = blockIdx.y * per;
+  const int64_t grow = (int64_t)row0 + m;
+  const bool live = grow < p.M;
+  const int64_t crow = min(grow, (int64_t)p.M - 1);
+
+  uint4 xf[NKS], df[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    xf[ks] = ld_global_b128(p.x16 + crow * D + ks * 16 + hi * 8);
+    df[ks] = ld_global_b128(p.dy16 + crow * D + ks * 16 + hi * 8);
+  }
+  auto issue = [&](int c, int buf) {
+#pragma unroll
+    for (int j = 0; j < FR / 4; ++j) {
+      const int f = wid * (FR / 4) + j;
+      const uint4* src;
+      if (f < S1) src = p.p1 + (int64_t)(((f & 1) ? nchunk + c : c) * NKS + (f >> 1)) * 64;
+      else if (f < S2) src = p.p3 + (int64_t)(c * NKS + (f - S1)) * 64;
+      else {
+        const int t = f - S2, j4 = t & 3;
+        const int ksf = (j4 < 2) ? 2 * c + j4 : 2 * nchunk + 2 * c + (j4 - 2);
+        src = p.p4 + (int64_t)((t >> 2) * (4 * nchunk) + ksf) * 64;
+      }
+      dma_frag(src, smem + buf * BUF + f * 1024, lane);
+    }
+  };
+
+  f32x16 xacc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xacc[i][r] = 0.f;
+
+  issue(c0, 0);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {                 // see ffn2_fwd_kernel: the operand fragments are complete before the loop
+    asm volatile("" :: "v"(xf[ks].x), "v"(xf[ks].y), "v"(xf[ks].z), "v"(xf[ks].w));
+    asm volatile("" :: "v"(df[ks].x), "v"(df[ks].y), "v"(df[ks].z), "v"(df[ks].w));
+  }
+  for (int i = 0; i < per; ++i) {
+    const int c = c0 + i;
+    // b_1 of this chunk: plain loads BEFORE the wait below (they retire with it; nothing else is in flight then)
+    float4 bv[4], bg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bv[q] = *reinterpret_cast<const float4*>(p.b1 + c * 32 + 8 * q + 4 * hi);
+      bg[q] = *reinterpret_cast<const float4*>(p.b1 + p.F + c * 32 + 8 * q + 4 * hi);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (i + 1 < per) issue(c + 1, (i + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const uint4* wb = reinterpret_cast<const uint4*>(smem + (i & 1) * BUF) + lane;
+    f32x16 av, ag, du;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { av[r] = 0.f; ag[r] = 0.f; du[r] = 0.f; }
+    constexpr int G = 8, NG = FR / G;               // LDS -> register prefetch groups (see ffn2_fwd_kernel)
+    static_assert(FR % G == 0 && S2 % G == 0, "group boundary must fall in front of the dx GEMM");
+    uint4 fr[2][G], hf[4];
+#pragma unroll
+    for (int j = 0; j < G; ++j) fr[0][j] = wb[j * 64];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) fr[(g + 1) & 1][j] = wb[((g + 1) * G + j) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (g * G == S2) {
+        float uu[16], da_[16], dg_[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float a = av[r] + reinterpret_cast<const float*>(&bv[r >> 2])[r & 3];
+          const float sg = fast_sigmoid(ag[r] + reinterpret_cast<const float*>(&bg[r >> 2])[r & 3]);
+          uu[r] = a * sg;
+          da_[r] = du[r] * sg;
+          dg_[r] = du[r] * uu[r] * (1.f - sg);
+        }
+        uint4 u0, u1;
+        tile_to_frags(uu, u0, u1);
+        tile_to_frags(da_, hf[0], hf[1]);
+        tile_to_frags(dg_, hf[2], hf[3]);
+        store_tile_row(p.u + crow * p.F + c * 32, u0, u1, hi, live);
+        store_tile_row(p.dh + crow * (2 * (int64_t)p.F) + c * 32, hf[0], hf[1], hi, live);
+        store_tile_row(p.dh + crow * (2 * (int64_t)p.F) + p.F + c * 32, hf[2], hf[3], hi, live);
+        float* bp = p.bpart + ((int64_t)blockIdx.x * 4 + wid) * (2 * p.F) + c * 32;
+        tile_colsum_store(da_, bp, lane, hi, live);
+        tile_colsum_store(dg_, bp + p.F, lane, hi, live);
+      }
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int f = g * G + j;
+        const uint4 w = fr[g & 1][j];
+        if (f < S1) {
+          if (f & 1) mma32(ag, w, xf[f >> 1]); else mma32(av, w, xf[f >> 1]);
+        } else if (f < S2) {
+          mma32(du, w, df[f - S1]);
+        } else {
+          const int t = f - S2;
+          mma32(xacc[t >> 2], w, hf[t & 3]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();                                   // every wave is done with both weight buffers (the stores above are global)
+  float* st = reinterpret_cast<float*>(smem + wid * 8192);
+  float* out = p.slabs + ((int64_t)blockIdx.y * p.M) * D;
+#pragma unroll
+  for (int h = 0; h < NT / 2; ++h) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(st + m * 64 + t * 32 + 8 * q + 4 * hi) =
+            make_float4(xacc[2 * h + t][4 * q], xacc[2 * h + t][4 * q + 1], xacc[2 * h + t][4 * q + 2], xacc[2 * h + t][4 * q + 3]);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = rr * 4 + (lane >> 4);
+      const int64_t row = (int64_t)row0 + r;
+      const float4 v = *reinterpret_cast<const float4*>(st + r * 64 + (lane & 15) * 4);
+      if (row < p.M) *reinterpret_cast<float4*>(out + row * D + h * 64 + (lane & 15) * 4) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// out[M, D] = sum of S slabs (+ skip): the input gradient of the FFN sub-layer after the hidden-dimension split
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int S, int64_t n4, const float* skip, float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 a = skip ? reinterpret_cast<const float4*>(skip)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < S; ++s) {
+      const float4 v = reinterpret_cast<const float4*>(slabs)[(int64_t)s * n4 + i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
+  }
+}
+
+extern int g_otr_ffn2_ablate;
+static int32_t ffn2_split_check(const char* who, int32_t F, int32_t S) {
+  OTR_REQUIRE(S >= 1 && S <= 16 && (F / 32) % S == 0, "%s: d_ff / 32 = %d chunks do not split into %d parts", who, F / 32, S);
+  return 0;
+}
+
+extern "C" int32_t otr_ffn_fwd_slabs(const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, float* slabs,
+                                     int32_t n_slabs, int64_t M, int32_t F, int32_t d_model, void* stream) {
+  if (int32_t e = ffn_shape_check("ffn_fwd_slabs", M, F, d_model)) return e;
+  if (int32_t e = ffn2_split_check("ffn_fwd_slabs", F, n_slabs)) return e;
+  OTR_REQUIRE(x16 && w1_pack && b1 && w2_pack && slabs, "ffn_fwd_slabs: null pointer");
+  OTR_REQUIRE(((uintptr_t)x16 | (uintptr_t)w1_pack | (uintptr_t)w2_pack | (uintptr_t)slabs) % 16 == 0, "ffn_fwd_slabs: buffers must be 16-byte aligned");
+  OTR_REQUIRE((F / 32 / n_slabs) * 64 * 4 <= 8192, "ffn_fwd_slabs: too many hidden units per workgroup for the bias staging");
+  if (M == 0) return 0;
+  Ffn2FwdArgs p{};
+  p.x16 = (const uint16_t*)x16; p.p1 = (const uint4*)w1_pack; p.b1 = b1; p.p2 = (const uint4*)w2_pack; p.slabs = slabs;
+  p.M = (int)M; p.F = F; p.S = n_slabs; p.ablate = g_otr_ffn2_ablate;
+  hipLaunchKernelGGL(ffn2_fwd_kernel<256>, dim3((unsigned)((M + 127) / 128), (unsigned)n_slabs), dim3(256), 0, (hipStream_t)stream, p);
+  return otr_check_launch("ffn_fwd_slabs");
+}
+
+extern "C" int32_t otr_ffn_bwd_slabs(const void* x16, const void* dy16, const void* w1_pack, const float* b1, const void* w2t_pack,
+                                     const void* w1t_pack, void* dh, void* u, float* db1_part, float* slabs, int32_t n_slabs,
+                                     int64_t M, int32_t F, int32_t d_model, void* stream) {
+  if (int32_t e = ffn_shape_check("ffn_bwd_slabs", M, F, d_model)) return e;
+  if (int32_t e = ffn2_split_check("ffn_bwd_slabs", F, n_slabs)) return e;
+  OTR_REQUIRE(x16 && dy16 && w1_pack && b1 && w2t_pack && w1t_pack && dh && u && slabs && db1_part, "ffn_bwd_slabs: null pointer");
+  OTR_REQUIRE((uintptr_t)db1_part % 16 == 0, "ffn_bwd_slabs: db1_part must be 16-byte aligned");
+  OTR_REQUIRE(((uintptr_t)x16 | (uintptr_t)dy16 | (uintptr_t)w1_pack | (uintptr_t)w2t_pack | (uintptr_t)w1t_pack | (uintptr_t)dh |
+               (uintptr_t)u | (uintptr_t)slabs | (uintptr_t)b1) % 16 == 0, "ffn_bwd_slabs: buffers must be 16-byte aligned");
+  if (M == 0) return 0;
+  Ffn2BwdArgs p{};
+  p.x16 = (const uint16_t*)x16; p.dy16 = (const uint16_t*)dy16; p.p1 = (const uint4*)w1_pack; p.b1 = b1;
+  p.p3 = (const uint4*)w2t_pack; p.p4 = (const uint4*)w1t_pack; p.dh = (uint16_t*)dh; p.u = (uint16_t*)u; p.bpart = db1_part; p.slabs = slabs;
+  p.M = (int)M; p.F = F; p.S = n_slabs;
+  hipLaunchKernelGGL(ffn2_bwd_kernel<256>, dim3((unsigned)((M + 127) / 128), (unsigned)n_slabs), dim3(256), 0, (hipStream_t)stream, p);
+  return otr_check_launch("ffn_bwd_slabs");
+}
+
+extern "C" int32_t otr_slab_sum(const float* slabs, int32_t n_slabs, int64_t n, const float* skip, float* out, void* stream) {
+  OTR_REQUIRE(slabs && out && n_slabs >= 1 && n >= 0 && n % 4 == 0, "slab_sum: bad arguments");
+  OTR_REQUIRE(((uintptr_t)slabs | (uintptr_t)out | (uintptr_t)skip) % 16 == 0, "slab_sum: buffers must be 16-byte aligned");
+  if (n == 0) return 0;
+  const int64_t n4 = n / 4;
+  unsigned g = (unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs, n4, skip, out);
+  return otr_check_launch("slab_sum");
 }

@@ -369,8 +369,8 @@ def flush_weight_grads():
         meta = None
         if _state.get('ktimer') is not None:
             meta = {'problems': len(w),
-                    'flops': sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _ in w),
-                    'bytes': sum(dy.numel() * dy.element_size() + x.numel() * x.element_size() + 2 * o.numel() * 4 for dy, x, o in w)}
+                    'flops': sum(2.0 * wi[0].shape[0] * wi[0].shape[1] * wi[1].shape[1] for wi in w),
+                    'bytes': sum(wi[0].numel() * wi[0].element_size() + wi[1].numel() * wi[1].element_size() + 2 * wi[2].numel() * 4 for wi in w)}
         L.check(_timed('linear_wgrad_grouped', meta, lambda: lib.otr_linear_wgrad_grouped(
             items, len(w), _compute_code(), _p(ws), _WS_BYTES, _stream())), 'otr_linear_wgrad_grouped')
     if b:
@@ -802,6 +802,25 @@ _FUSED_FFN = os.environ.get('OTR_NO_FUSED_FFN', '0') != '1'
 _FUSED_FFN_MIN_ROWS = int(os.environ.get('OTR_FUSED_FFN_MIN_ROWS', '1024'))   # below: too few 32-row workgroups to fill the chip
 
 
+_FFN_V2 = os.environ.get('OTR_FFN_V2', '0') == '1'      # measured equal to v1 at B=32 (LDS-read bound): v1 is the default
+_FFN_V2_MIN_ROWS = 2048
+
+
+def _ffn_slabs(M, F):
+    """hidden-dimension split of the v2 fused FFN kernels (0 = use v1): enough (row block, split) workgroups to fill the
+    256 CUs once, at most 8 slabs"""
+    if not _FFN_V2 or M < _FFN_V2_MIN_ROWS:
+        return 0
+    blocks = (M + 127) // 128
+    chunks = F // 32
+    S = 1
+    while chunks // S > 32 and chunks % (S * 2) == 0:          # at most 32 chunks per workgroup (bias staging in LDS)
+        S *= 2
+    while S < 8 and blocks * S * 2 <= 256 + 32 and chunks % (S * 2) == 0:
+        S *= 2
+    return S if chunks % S == 0 and chunks // S <= 32 else 0
+
+
 def ffn_pack_items(w1_off, w2_off, F2, d, F, dst_off):
     """otr_pack_frags table rows {src_off, rs, cs, rows, cols, perm, dst_off} for one FFN (w_1 [2F,d], w_2 [d,F]) and the
     element offsets of its four packs inside the destination buffer."""
@@ -871,10 +890,23 @@ class FfnLnFn(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         seed = rng_seed_tensor(x.device) if p_drop > 0 else None
         off = _next_rng_offset(M * d) if p_drop > 0 else 0
-        L.check(_timed('ffn_ln_fwd', {'flops': 6.0 * M * F * d, 'bytes': M * d * (4 + 2 + 4 + 2 + 4) + 6 * F * d},
-                       lambda: L.load().otr_ffn_ln_fwd(_p(x2), _p(x16), _p(packs[0]), _p(b1), _p(packs[1]), _p(b2), _p(gamma),
-                                                       _p(beta), _p(seed), p_drop, off, eps, _p(y), _p(y16), _p(z), _p(mean),
-                                                       _p(rstd), M, F, d, _stream())), 'otr_ffn_ln_fwd')
+        S = _ffn_slabs(M, F)
+        ctx.S = S
+        if S:       # v2: weight stream shared by 128 rows through LDS, hidden units split over S workgroups, LayerNorm sums the slabs
+            lib = L.load()
+            slabs = torch.empty((S, M, d), dtype=torch.float32, device=x.device)
+            L.check(_timed('ffn_fwd_slabs', {'flops': 6.0 * M * F * d, 'bytes': M * d * 2 + 6 * F * d + S * M * d * 4},
+                           lambda: lib.otr_ffn_fwd_slabs(_p(x16), _p(packs[0]), _p(b1), _p(packs[1]), _p(slabs), S, M, F, d,
+                                                         _stream())), 'otr_ffn_fwd_slabs')
+            desc = L.LnDesc(M, d, L.OTR_F32, eps, p_drop, off)
+            L.check(lib.otr_add_layernorm_fwd_slabs(C.byref(desc), _p(x2), _p(slabs), S, M * d, _p(b2), _p(gamma), _p(beta),
+                                                    _p(seed), _p(y), _p(y16), _p(z), _p(mean), _p(rstd), _stream()),
+                    'otr_add_layernorm_fwd_slabs')
+        else:
+            L.check(_timed('ffn_ln_fwd', {'flops': 6.0 * M * F * d, 'bytes': M * d * (4 + 2 + 4 + 2 + 4) + 6 * F * d},
+                           lambda: L.load().otr_ffn_ln_fwd(_p(x2), _p(x16), _p(packs[0]), _p(b1), _p(packs[1]), _p(b2), _p(gamma),
+                                                           _p(beta), _p(seed), p_drop, off, eps, _p(y), _p(y16), _p(z), _p(mean),
+                                                           _p(rstd), M, F, d, _stream())), 'otr_ffn_ln_fwd')
         ctx.save_for_backward(x16, z, mean, rstd, gamma, seed, b1)
         ctx.packs = packs
         ctx.refs = (w1, b1, w2, b2, gamma, beta)
@@ -928,13 +960,22 @@ class FfnLnFn(torch.autograd.Function):
         # FFN backward with recompute: dh, u for the weight gradients; dx += dh . w_1
         dh = torch.empty((M, 2 * F), dtype=x16.dtype, device=dy.device)
         u = torch.empty((M, F), dtype=x16.dtype, device=dy.device)
-        L.check(_timed('ffn_bwd', {'flops': 10.0 * M * F * d, 'bytes': M * d * (2 + 2 + 4 + 4) + M * F * 6 + 10 * F * d},
-                       lambda: lib.otr_ffn_bwd(_p(x16), _p(da), _p(P1), _p(b1), _p(P3), _p(P4), _p(dh), _p(u), _p(dx), _p(dx),
-                                               M, F, d, _stream())), 'otr_ffn_bwd')
+        bpart = torch.empty(((M + 31) // 32, 2 * F), dtype=torch.float32, device=dy.device)    # d b_1 per 32-row block
+        if ctx.S:
+            S = ctx.S
+            slabs = torch.empty((S, M, d), dtype=torch.float32, device=dy.device)
+            L.check(_timed('ffn_bwd_slabs', {'flops': 10.0 * M * F * d, 'bytes': M * d * 4 + M * F * 6 + 10 * F * d + S * M * d * 4},
+                           lambda: lib.otr_ffn_bwd_slabs(_p(x16), _p(da), _p(P1), _p(b1), _p(P3), _p(P4), _p(dh), _p(u), _p(bpart),
+                                                         _p(slabs), S, M, F, d, _stream())), 'otr_ffn_bwd_slabs')
+            L.check(lib.otr_slab_sum(_p(slabs), S, M * d, _p(dx), _p(dx), _stream()), 'otr_slab_sum')
+        else:
+            L.check(_timed('ffn_bwd', {'flops': 10.0 * M * F * d, 'bytes': M * d * (2 + 2 + 4 + 4) + M * F * 6 + 10 * F * d},
+                           lambda: lib.otr_ffn_bwd(_p(x16), _p(da), _p(P1), _p(b1), _p(P3), _p(P4), _p(dh), _p(u), _p(bpart), _p(dx),
+                                                   _p(dx), M, F, d, _stream())), 'otr_ffn_bwd')
         gw1, gb1, gw2 = grad_target(w1p), grad_target(b1p), grad_target(w2p)
         dw1 = linear_wgrad_raw(dh, x16, None, out=gw1)
         dw2 = linear_wgrad_raw(da, u, None, out=gw2)
-        db1 = colsum_raw(dh, out=gb1)
+        db1 = colsum_raw(bpart, out=gb1)             # per-workgroup column sums of dh, written by the backward kernel
         return (dx.view(xshape), None if gw1 is not None else dw1, None if gb1 is not None else db1,
                 None if gw2 is not None else dw2, ret_b2, ret_g, ret_b, None, None, None)
 

@@ -62,8 +62,19 @@ def mode(request):
     ops.set_compute_dtype('bf16')
 
 
-@pytest.mark.parametrize('M,dff,p_drop', [(2048, 2048, 0.0), (1504, 512, 0.0), (1024 + 17, 256, 0.1)])
-def test_ffn_ln_fused_matches_reference(mode, M, dff, p_drop):
+@pytest.fixture(params=['v1', 'v2'])
+def variant(request):
+    """v1: every wave streams its own weight fragments into registers (the default); v2: 128-row workgroups share the
+    stream through LDS and split the hidden units (rows >= 2048 only)"""
+    from opentransformer_amd import ops
+    was = ops._FFN_V2
+    ops._FFN_V2 = request.param == 'v2'
+    yield request.param
+    ops._FFN_V2 = was
+
+
+@pytest.mark.parametrize('M,dff,p_drop', [(2048, 2048, 0.0), (2048 + 40, 512, 0.0), (1504, 512, 0.0), (1024 + 17, 256, 0.1)])
+def test_ffn_ln_fused_matches_reference(mode, variant, M, dff, p_drop):
     from opentransformer_amd import ops
     d = 256
     w1, b1, w2, b2, gamma, beta = _params(d, dff, 3)

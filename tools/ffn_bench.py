@@ -44,9 +44,28 @@ def main():
     dh = torch.empty(M, 2 * F, dtype=hdt, device=dev)
     u = torch.empty(M, F, dtype=hdt, device=dev)
     dx = torch.zeros(M, d, device=dev)
+    bpart = torch.empty((M + 31) // 32, 2 * F, device=dev)
 
     def bwd():
-        L.check(lib.otr_ffn_bwd(p(x16), p(da), p(P[0]), p(b1), p(P[2]), p(P[3]), p(dh), p(u), p(dx), p(dx), M, F, d, st()), 'bwd')
+        L.check(lib.otr_ffn_bwd(p(x16), p(da), p(P[0]), p(b1), p(P[2]), p(P[3]), p(dh), p(u), p(bpart), p(dx), p(dx), M, F, d, st()), 'bwd')
+
+    ops._FFN_V2 = True
+    S = ops._ffn_slabs(M, F)
+    slabs = torch.empty(max(S, 1), M, d, device=dev)
+    desc = L.LnDesc(M, d, L.OTR_F32, 1e-5, 0.1, 0)
+
+    def fwd2():
+        L.check(lib.otr_ffn_fwd_slabs(p(x16), p(P[0]), p(b1), p(P[1]), p(slabs), S, M, F, d, st()), 'fwd2')
+
+    def ln2():
+        L.check(lib.otr_add_layernorm_fwd_slabs(C.byref(desc), p(x), p(slabs), S, M * d, p(b2), p(gamma), p(beta), p(seed), p(y), p(y16),
+                                                p(z), p(mean), p(rstd), st()), 'ln2')
+
+    def bwd2():
+        L.check(lib.otr_ffn_bwd_slabs(p(x16), p(da), p(P[0]), p(b1), p(P[2]), p(P[3]), p(dh), p(u), p(bpart), p(slabs), S, M, F, d, st()), 'bwd2')
+
+    def sum2():
+        L.check(lib.otr_slab_sum(p(slabs), S, M * d, p(dx), p(dx), st()), 'sum')
 
     def wgrad():
         ops.linear_wgrad_raw(dh, x16, None)
@@ -71,9 +90,24 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e3
     res = {'rows': M, 'dff': F, 'mode': a.mode}
+    lib.otr_debug_set(5, 4)
+    res['fwd_4waves_us'] = timeit(lambda: fwd(0.0), a.iters)
+    lib.otr_debug_set(5, 8)
     res['fwd_us'] = timeit(lambda: fwd(0.0), a.iters)
     res['fwd_drop_us'] = timeit(lambda: fwd(0.1), a.iters)
     res['bwd_us'] = timeit(bwd, a.iters)
+    if S:
+        res['slabs'] = S
+        res['v2_fwd_us'] = timeit(fwd2, a.iters)
+        res['v2_ln_slabs_us'] = timeit(ln2, a.iters)
+        res['v2_bwd_us'] = timeit(bwd2, a.iters)
+        res['v2_slab_sum_us'] = timeit(sum2, a.iters)
+        for ab in (1, 2, 3):          # ablations: 1 = no weight DMA, 2 = no MFMA work, 3 = neither (launch + x load + epilogue)
+            lib.otr_debug_set(4, ab)
+            res['v2_fwd_ablate%d_us' % ab] = timeit(fwd2, a.iters)
+        lib.otr_debug_set(4, 0)
+        res['v2_fwd_tflops'] = 2.0 * M * 3 * F * d / res['v2_fwd_us'] / 1e6
+        res['v2_bwd_tflops'] = 2.0 * M * 5 * F * d / res['v2_bwd_us'] / 1e6
     res['wgrad_pair_us'] = timeit(wgrad, 10)
     try:
         res['old_fwd_us'] = timeit(old_fwd, 20)
