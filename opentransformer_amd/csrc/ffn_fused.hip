@@ -53,15 +53,23 @@ __global__ __launch_bounds__(256) void pack_frags_kernel(const uint16_t* __restr
   const int64_t r = rt * 32 + (lane & 31);
   const int hi = lane >> 5;
   const uint16_t* s = src + src_off + r * rs;
-  uint16_t v[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int kk = perm ? (j < 4 ? 4 * hi + j : 8 + 4 * hi + (j - 4)) : hi * 8 + j;
-    v[j] = s[(ks * 16 + kk) * cs];
-  }
   uint4 q;
-  q.x = v[0] | ((uint32_t)v[1] << 16); q.y = v[2] | ((uint32_t)v[3] << 16);
-  q.z = v[4] | ((uint32_t)v[5] << 16); q.w = v[6] | ((uint32_t)v[7] << 16);
+  if (cs == 1 && perm == 0 && ((src_off + r * rs) % 8 == 0)) {        // contraction index contiguous: one 16-byte load
+    q = *reinterpret_cast<const uint4*>(s + ks * 16 + hi * 8);
+  } else if (cs == 1 && ((src_off + r * rs) % 4 == 0)) {                // perm = 1 on a contiguous source: two 8-byte loads
+    const uint2 a = *reinterpret_cast<const uint2*>(s + ks * 16 + 4 * hi);
+    const uint2 b = *reinterpret_cast<const uint2*>(s + ks * 16 + 8 + 4 * hi);
+    q = make_uint4(a.x, a.y, b.x, b.y);
+  } else {
+    uint16_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kk = perm ? (j < 4 ? 4 * hi + j : 8 + 4 * hi + (j - 4)) : hi * 8 + j;
+      v[j] = s[(ks * 16 + kk) * cs];
+    }
+    q.x = v[0] | ((uint32_t)v[1] << 16); q.y = v[2] | ((uint32_t)v[3] << 16);
+    q.z = v[4] | ((uint32_t)v[5] << 16); q.w = v[6] | ((uint32_t)v[7] << 16);
+  }
   *reinterpret_cast<uint4*>(dst + dst_off + frag * 512 + lane * 8) = q;
 }
 

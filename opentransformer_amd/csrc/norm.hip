@@ -105,7 +105,8 @@ template <class AT, bool HAS_A, bool SLABS = false> __global__ __launch_bounds__
   if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
 }
 
-constexpr int LN_BWD_ROWS = 8;  // rows per wave -> 32 rows per block (4 rows per wave was no faster: twice the atomics)
+constexpr int LN_BWD_ROWS = 4;  // rows per wave -> 16 rows per block: 498 blocks at M = 7968 (8 rows per wave left one 4-wave block per CU:
+                                // too few loads in flight for an HBM-bound kernel; the affine-gradient partials are summed by the grouped column sums)
 
 // NV = ceil(d / 256): float4 slots per lane actually used (d = 256 -> 1).  Each wave owns LN_BWD_ROWS rows; the loads of
 // ALL of them (dy, z, mean, rstd) are issued back to back before any arithmetic (rows clamped, tails masked), so a

@@ -169,10 +169,16 @@ class MultiHeadedCrossAttention(nn.Module):
         self.q_proj = nn.Linear(d_model, d_model)
         self.vk_proj = nn.Linear(memory_dim, d_model if share_vk_proj else d_model * 2)
 
-    def forward(self, query, memory, memory_mask, defer_bias=False, link=None):
+    def forward(self, query, memory, memory_mask, defer_bias=False, link=None, kv_all=None):
+        """kv_all = (projection of the memory by ALL decoder layers' vk_proj in one GEMM, this layer's slice index, shared
+        bookkeeping): TransformerDecoder.forward builds it once per pass (ops.CrossKVAllFn)."""
         B, T, _ = memory.shape
         adt = ops.act_dtype()
         q = ops.linear(query, self.q_proj.weight, self.q_proj.bias, out_dtype=adt, link=link)
+        if kv_all is not None:
+            ctx = ops.CrossAttentionSliceFn.apply(q, kv_all[0], _key_mask(memory_mask, B, T), self.nheads, kv_all[1], kv_all[2])
+            return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, defer_bias=defer_bias,
+                              out_dtype=ops.act_dtype() if defer_bias else None), None
         kv = ops.linear(memory, self.vk_proj.weight, self.vk_proj.bias, out_dtype=adt)
         if self.share_vk_proj:           # key = value (module/attention.py:131-132)
             kv = torch.cat((kv, kv), dim=-1)
@@ -496,7 +502,7 @@ class TransformerDecoderLayer(nn.Module):
             self.concat_linear1 = nn.Linear(d_model * 2, d_model)
             self.concat_linear2 = nn.Linear(d_model * 2, d_model)
 
-    def forward(self, tgt, tgt_mask, memory, memory_mask, pos=None):
+    def forward(self, tgt, tgt_mask, memory, memory_mask, pos=None, kv_all=None):
         """tgt_mask: the causal [B,L,L] tril mask of decoder/utils.py:7-11, or None meaning causal."""
         p = self.residual_dropout if self.training else 0.0
         pre = self.normalize_before
@@ -510,7 +516,7 @@ class TransformerDecoderLayer(nn.Module):
         x = _post_norm(norms[0], x, branch, p1, True, bias, link)
 
         def run_src(**kw):
-            att, _ = self.src_attn(x, memory, memory_mask, **kw)
+            att, _ = self.src_attn(x, memory, memory_mask, kv_all=kv_all, **kw)
             return att, self.src_attn.output_proj.bias
         branch, bias, p2, link = _attention_branch(self, getattr(self, 'concat_linear2', None), x, p, run_src)
         x = _post_norm(norms[1], x, branch, p2, True, bias, link)
@@ -546,8 +552,15 @@ class TransformerDecoder(nn.Module):
     def forward(self, targets, memory, memory_mask):
         x = ops.embed_posenc(targets, self.embedding.weight)
         mm = memory_mask.to(torch.uint8).unsqueeze(1)
-        for block in self.blocks:
-            x, _ = block(x, None, memory, mm)                    # None -> causal self-attention
+        kv = None
+        if (len(self.blocks) > 1 and memory.is_cuda and torch.is_grad_enabled()
+                and not any(b.src_attn.share_vk_proj for b in self.blocks)):
+            # keys / values of every layer from ONE GEMM over the shared memory (ops.CrossKVAllFn)
+            shared = ops.CrossKVShared(len(self.blocks))
+            wb = [t for b in self.blocks for t in (b.src_attn.vk_proj.weight, b.src_attn.vk_proj.bias)]
+            kv = (ops.CrossKVAllFn.apply(memory, shared, *wb), shared)
+        for i, block in enumerate(self.blocks):
+            x, _ = block(x, None, memory, mm, kv_all=(kv[0], i, kv[1]) if kv is not None else None)   # None -> causal self-attention
         if self.normalize_before:
             x = _norm(self.after_norm, x)
         logits = ops.linear(x, self.output_layer.weight, self.output_layer.bias)

@@ -625,6 +625,110 @@ class CrossAttentionFn(torch.autograd.Function):
         return dq, dkv, None, None
 
 
+# ---------------------------------------------------------------------------------------- batched cross-attention K/V
+# The decoder's cross-attention projects the SAME encoder memory to keys / values in every layer (module/attention.py:
+# 128-134 `vk_proj`, six times per step at [B*T', 256] x [512, 256]^T).  One 512-wide GEMM on 7968 rows runs at 65 TFLOP/s
+# (32 us); all layers at once -- [B*T', 256] x [L*512, 256]^T -- is one well-filled GEMM, and the backward pass needs ONE
+# input-gradient GEMM (K = L*512) instead of L plus L-1 adds of [B*T', 256] fp32 tensors.
+class CrossKVShared:
+    """bookkeeping shared by the L cross-attention slices of one decoder pass: the gradient buffer [B,T,L*2d] every slice's
+    backward writes its columns into, and how many have done so"""
+    __slots__ = ('n', 'dkv', 'done')
+
+    def __init__(self, n):
+        self.n, self.dkv, self.done = n, None, 0
+
+
+class CrossKVAllFn(torch.autograd.Function):
+    """kv_all[B,T,L*2d] = memory . cat_l(vk_proj_l.weight)^T + cat_l(bias): columns [l*2d, l*2d+d) are layer l's keys, the
+    next d its values (split order k, v: module/attention.py:134)."""
+
+    @staticmethod
+    def forward(ctx, memory, shared, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        _cuda(memory, *ws)
+        ctx.shared, ctx.refs = shared, (ws, bs)
+        mc = lp_of(memory)
+        m2 = _rows(mc if mc is not None else memory)
+        adt = act_dtype()
+        wl = [weight_lp(w) if weight_lp(w) is not None else w for w in ws]
+        wcat = torch.cat(wl, dim=0)                                   # [L*2d, dm]
+        bcat = torch.cat([b for b in bs], dim=0)
+        y = linear_fwd_raw(m2, wcat, bcat, adt)
+        wt = [weight_lpt(w) for w in ws]
+        ctx.wcat_t = torch.cat(wt, dim=1) if all(t is not None for t in wt) else None      # [dm, L*2d]
+        ctx.save_for_backward(m2, wcat)
+        ctx.mshape, ctx.mdtype = memory.shape, memory.dtype
+        return y.view(*memory.shape[:-1], wcat.shape[0])
+
+    @staticmethod
+    def backward(ctx, dkv):
+        m2, wcat = ctx.saved_tensors
+        ws, bs = ctx.refs
+        d2 = _rows(dkv)
+        if ctx.wcat_t is not None:
+            dmem = linear_fwd_raw(d2, ctx.wcat_t, None, ctx.mdtype)
+        else:
+            dmem = linear_dgrad_raw(d2, wcat, ctx.mdtype)
+        grads = []
+        n2 = ws[0].shape[0]
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            sl = d2[:, i * n2:(i + 1) * n2]
+            gw, gb = grad_target(w), grad_target(b)
+            dw = linear_wgrad_raw(sl, m2, None, out=gw)
+            db = colsum_raw(sl, out=gb)
+            grads += [None if gw is not None else dw, None if gb is not None else db]
+        return (dmem.view(ctx.mshape), None, *grads)
+
+
+class CrossAttentionSliceFn(torch.autograd.Function):
+    """CrossAttentionFn on slice `idx` of a CrossKVAllFn output: keys / values are read in place by stride, and the backward
+    pass writes d k | d v into the shared [B,T,L*2d] gradient buffer; the last slice to finish hands that buffer to autograd
+    (the others return None), so no per-layer gradient tensors are allocated or added."""
+
+    @staticmethod
+    def forward(ctx, q, kv_all, key_mask_u8, n_heads, idx, shared):
+        _cuda(q, kv_all)
+        B, Lq, d = q.shape
+        T, W = kv_all.shape[1], kv_all.shape[2]
+        dk = d // n_heads
+        q = q.contiguous()
+        assert kv_all.is_contiguous() and W == shared.n * 2 * d
+        out = torch.empty((B, Lq, d), dtype=q.dtype, device=q.device)
+        lse = torch.empty((B, n_heads, Lq), dtype=torch.float32, device=q.device)
+        sq, skv = (Lq * d, d), (T * W, W)
+        desc = _attn_desc(B, n_heads, Lq, T, dk, q.dtype, sq, skv, skv, sq, False)
+        L.check(L.load().otr_attention_fwd(C.byref(desc), _p(q), _p(kv_all, idx * 2 * d), _p(kv_all, idx * 2 * d + d),
+                                           _p(key_mask_u8), _p(out), _p(lse), _stream()), 'otr_attention_fwd')
+        ctx.save_for_backward(q, kv_all, out, lse, key_mask_u8)
+        ctx.cfg = (n_heads, idx, shared)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv_all, out, lse, km = ctx.saved_tensors
+        n_heads, idx, shared = ctx.cfg
+        B, Lq, d = q.shape
+        T, W = kv_all.shape[1], kv_all.shape[2]
+        dk = d // n_heads
+        dout = dout.contiguous()
+        dq = torch.empty_like(q)
+        if shared.dkv is None:
+            shared.dkv = torch.empty_like(kv_all)
+        dkv = shared.dkv
+        delta = torch.empty_like(lse)
+        sq, skv = (Lq * d, d), (T * W, W)
+        desc = _attn_desc(B, n_heads, Lq, T, dk, q.dtype, sq, skv, skv, sq, False)
+        L.check(L.load().otr_attention_bwd(C.byref(desc), _p(q), _p(kv_all, idx * 2 * d), _p(kv_all, idx * 2 * d + d), _p(km),
+                                           _p(out), _p(dout), _p(lse), _p(delta), _p(dq), _p(dkv, idx * 2 * d),
+                                           _p(dkv, idx * 2 * d + d), _stream()), 'otr_attention_bwd')
+        shared.done += 1
+        if shared.done == shared.n:                    # every slice is written: release the whole gradient to the projection
+            shared.dkv, shared.done = None, 0
+            return dq, dkv, None, None, None, None
+        return dq, None, None, None, None, None
+
+
 # ---------------------------------------------------------------------------------------- add + LayerNorm
 class AddLayerNormFn(torch.autograd.Function):
     """y = LayerNorm(x + dropout(a)) (post-norm residual: encoder/transformer.py:54-56,61-63)."""

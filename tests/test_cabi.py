@@ -61,7 +61,7 @@ def test_argument_errors_of_the_fused_and_grouped_entries():
     assert lib.otr_decode_self_attention(one, one, one, one, one, one, 1, 2, 4, 256, 8, 1.0, None) < 0      # dk > 128
     assert lib.otr_beam_prune_cached(one, one, one, one, one, 8, 1, 2, 1, one, one, one, one, 4, one, one, one, one,
                                      None) < 0                                   # in/out buffers must differ
-    assert lib.otr_add_layernorm_bwd_partial_rows(7968) == 249
+    assert lib.otr_add_layernorm_bwd_partial_rows(7968) == 498            # 16 rows per workgroup
     assert lib.otr_act_fwd(one, one, 0, 64, 4, None) < 0                         # kind must be gelu / tanh / swish
     assert b'act_fwd' in lib.otr_last_error_string()
     assert lib.otr_act_bwd(one, None, one, 1, 64, 1, None) < 0                   # dy missing
