@@ -296,6 +296,11 @@ int32_t otr_residual_add_fwd(const float* x, const void* a, int32_t a_dtype, flo
                              float p_drop, const uint64_t* seed, uint64_t rng_offset, void* stream);
 int32_t otr_residual_add_bwd(const float* dy, void* da, int32_t a_dtype, int64_t n, float scale, float p_drop,
                              const uint64_t* seed, uint64_t rng_offset, void* stream);
+/* y = dropout(x): x * mask / (1 - p), mask from the counter RNG keyed by (*seed, rng_offset + element index); applied to dy
+ * with the same (seed, offset) it is the backward pass.  nn.Dropout of module/attention.py:46 (projected context),
+ * module/ffn.py:40 (hidden), frontend/conv.py:66, module/conformer.py (end of the convolution module).  n % 4 == 0. */
+int32_t otr_dropout(const void* x, void* y, int32_t dtype, int64_t n, float p_drop, const uint64_t* seed,
+                    uint64_t rng_offset, void* stream);
 /* out[M, 2d] = [q + u | q + v] (pos_bias_u / pos_bias_v flattened to [d]); q has leading dimension ldq */
 int32_t otr_head_bias_add(const void* q, int64_t ldq, const float* u, const float* v, void* out, int32_t dtype,
                           int64_t M, int32_t d, void* stream);

@@ -81,6 +81,36 @@ extern "C" int32_t otr_residual_add_bwd(const float* dy, void* da, int32_t a_dty
   return otr_check_launch("residual_add_bwd");
 }
 
+// ------------------------------------------------------------------------------------------------ stand-alone dropout
+// y = dropout(x) = x * mask / (1 - p) with the library's counter RNG (mask regenerated, never stored): nn.Dropout on the
+// projected attention context (module/attention.py:46), on the FFN hidden (module/ffn.py:40), behind the frontend's
+// Conv2dLayers (frontend/conv.py:66) and at the end of the Conformer convolution module.  The backward pass is the same
+// map applied to dy, so one kernel serves both.
+template <class T> __global__ void dropout_kernel(const T* x, T* y, int64_t n4, float p_drop, const uint64_t* seed, uint64_t off) {
+  const uint64_t sd = *seed;
+  const uint32_t thr = (uint32_t)fminf(p_drop * 4294967296.f, 4294967295.f);
+  const float keep = 1.f / (1.f - p_drop);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[4];
+    ldc4<T>(x + i * 4, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= otr_rand32(sd, off + (uint64_t)(i * 4 + e)) >= thr ? keep : 0.f;
+    stc4<T>(y + i * 4, v);
+  }
+}
+extern "C" int32_t otr_dropout(const void* x, void* y, int32_t dtype, int64_t n, float p_drop, const uint64_t* seed,
+                               uint64_t rng_offset, void* stream) {
+  OTR_REQUIRE(x && y && seed, "dropout: null pointer");
+  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_H16, "dropout: bad dtype");
+  OTR_REQUIRE(n % 4 == 0 && n >= 0, "dropout: n must be a multiple of 4");
+  OTR_REQUIRE(p_drop > 0.f && p_drop < 1.f, "dropout: p_drop=%f out of (0,1)", (double)p_drop);
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OTR_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, s, (const float*)x, (float*)y, n / 4, p_drop, seed, rng_offset);
+  else hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(ew_grid(n / 4)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n / 4, p_drop, seed, rng_offset);
+  return otr_check_launch("dropout");
+}
+
 // ------------------------------------------------------------------------------------------------ q + u | q + v
 template <class T> __global__ void head_bias_add_kernel(const T* q, int64_t ldq, const float* u, const float* v, T* out, int64_t M,
                                                         int d) {

@@ -341,6 +341,7 @@ struct FfnBwdArgs {
   const float* skip;       // [M, D] f32 or NULL, added to dx (the skip-connection gradient of y = LN(x + f(x)))
   float* dx;               // [M, D] f32 out (may alias skip)
   int M, F;
+  int ablate;              // tuning hook (otr_debug_set(4, v)): bit 2 = no bias-gradient reduction; 0 in production
 };
 
 template <int D>
@@ -439,9 +440,11 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(FfnBwdArgs p) {
         store_tile_row(p.u + crow * p.F + c * 32, u0, u1, hi, live);
         store_tile_row(p.dh + crow * (2 * (int64_t)p.F) + c * 32, hf[0], hf[1], hi, live);
         store_tile_row(p.dh + crow * (2 * (int64_t)p.F) + p.F + c * 32, hf[2], hf[3], hi, live);
-        float* bp = p.bpart + (int64_t)blockIdx.x * (2 * p.F) + c * 32;      // this wave owns chunk c of the block's row
-        tile_colsum_store(da_, bp, lane, hi, live);
-        tile_colsum_store(dg_, bp + p.F, lane, hi, live);
+        if (!(p.ablate & 4)) {
+          float* bp = p.bpart + (int64_t)blockIdx.x * (2 * p.F) + c * 32;    // this wave owns chunk c of the block's row
+          tile_colsum_store(da_, bp, lane, hi, live);
+          tile_colsum_store(dg_, bp + p.F, lane, hi, live);
+        }
       }
     }
     c = cn;
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(FfnBwdArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
+extern int g_otr_ffn2_ablate;
 extern int g_otr_ffn_waves;   // tuning hook (otr_debug_set(5, v)): 8 = the 8-wave form of the forward kernel, anything else = 4 waves
 static int32_t ffn_shape_check(const char* who, int64_t M, int32_t F, int32_t d_model) {
   OTR_REQUIRE(M >= 0 && M < (1ll << 31), "%s: bad M", who);
@@ -519,7 +523,7 @@ extern "C" int32_t otr_ffn_bwd(const void* x16, const void* dy16, const void* w1
   FfnBwdArgs p{};
   p.x16 = (const uint16_t*)x16; p.dy16 = (const uint16_t*)dy16; p.p1 = (const uint4*)w1_pack; p.b1 = b1;
   p.p3 = (const uint4*)w2t_pack; p.p4 = (const uint4*)w1t_pack; p.dh = (uint16_t*)dh; p.u = (uint16_t*)u; p.bpart = db1_part; p.skip = skip; p.dx = dx;
-  p.M = (int)M; p.F = F;
+  p.M = (int)M; p.F = F; p.ablate = g_otr_ffn2_ablate;
   hipLaunchKernelGGL(ffn_bwd_kernel<256>, dim3((unsigned)((M + FF_RB - 1) / FF_RB)), dim3(256), 0, (hipStream_t)stream, p);
   return otr_check_launch("ffn_bwd");
 }
@@ -883,7 +887,6 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
   }
 }
 
-extern int g_otr_ffn2_ablate;
 static int32_t ffn2_split_check(const char* who, int32_t F, int32_t S) {
   OTR_REQUIRE(S >= 1 && S <= 16 && (F / 32) % S == 0, "%s: d_ff / 32 = %d chunks do not split into %d parts", who, F / 32, S);
   return 0;

@@ -11,8 +11,10 @@ Transformer layers come in the reference's four variants: post-norm (the shipped
 (`normalize_before=True`: the residual is taken AFTER the norm, encoder/transformer.py:42-44), each with or without
 `concat_after` (a Linear over cat(x, attention) instead of dropout(attention)).
 
-Not built yet (constructor raises NotImplementedError): in_channel != 1, dropout inside attention / FFN /
-frontend.  The shipped AISHELL yamls use none of these.
+Dropout inside attention (on the projected context, module/attention.py:46), the FFN hidden (module/ffn.py:40), the
+frontend's conv layers (frontend/conv.py:66) and the Conformer convolution module runs through ops.dropout (counter RNG,
+mask regenerated in backward); with p = 0 (the shipped AISHELL yamls) nothing is launched.  Not built (constructor
+raises NotImplementedError): in_channel != 1, pos_dropout > 0 (which in the reference silently switches the formula).
 """
 import math
 
@@ -60,8 +62,7 @@ class ConvFrontEnd(nn.Module):
         super().__init__()
         if in_channel != 1:
             _unsupported('ConvFrontEnd in_channel != 1')
-        if dropout != 0.0:
-            _unsupported('ConvFrontEnd dropout > 0')
+        self.dropout = dropout
         self.kernel_size, self.stride, self.output_size = kernel_size, stride, output_size
         self.act_func_type, self.front_end_layer_norm = act_func_type, front_end_layer_norm
         self.conv1 = Conv2dLayer(input_size, in_channel, mid_channel, kernel_size[0], stride[0], dropout)
@@ -74,7 +75,12 @@ class ConvFrontEnd(nn.Module):
     def forward(self, x, mask):
         c1, c2 = self.conv1.conv_layer, self.conv2.conv_layer
         C2, F2 = c2.out_channels, self.conv2.output_size
-        act2 = ops.ConvSubsampleFn.apply(x, c1.weight, c1.bias, c2.weight, c2.bias)     # [B,T2,F2*C2] channel-last
+        if self.dropout and self.training:
+            # Conv2dLayer = dropout(relu(conv(x))) (frontend/conv.py:63-66): a mask between the two convolutions breaks their
+            # fused chain, so this (never shipped) configuration runs them one at a time
+            act2 = ops.conv_subsample_with_dropout(x, c1.weight, c1.bias, c2.weight, c2.bias, self.dropout)
+        else:
+            act2 = ops.ConvSubsampleFn.apply(x, c1.weight, c1.bias, c2.weight, c2.bias)     # [B,T2,F2*C2] channel-last
         y = ops.linear(act2, self.output_layer.weight, self.output_layer.bias, perm=(C2, F2))
         t1 = (x.size(1) - 3) // 2 + 1
         mask = Conv2dLayer.return_output_mask(mask, t1)
@@ -122,8 +128,7 @@ class MultiHeadedSelfAttention(nn.Module):
 
     def __init__(self, n_heads, d_model, dropout_rate=0.0, share_qvk_proj=False):
         super().__init__()
-        if dropout_rate:
-            _unsupported('attention dropout > 0')
+        self.dropout_rate = dropout_rate          # on the projected context (module/attention.py:46)
         self.d_model, self.nheads, self.d_k = d_model, n_heads, d_model // n_heads
         self.share_qvk_proj = share_qvk_proj
         self.output_proj = nn.Linear(d_model, d_model)
@@ -146,6 +151,9 @@ class MultiHeadedSelfAttention(nn.Module):
         """defer_bias: the caller feeds the result to _post_norm(..., a_bias=self.output_proj.bias); link: ops.ResidualLink
         shared with that _post_norm."""
         ctx = self.context(x, mask, causal, link)
+        if self.dropout_rate and self.training:   # dropout(output_proj(ctx)): the bias is inside the mask, so it cannot be deferred
+            out = ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, out_dtype=ops.act_dtype() if defer_bias else None)
+            return ops.dropout(out, self.dropout_rate), None
         # a branch that feeds the fused add+LayerNorm is written in the activation dtype (bf16 in bf16 mode, like every
         # other GEMM output; the fp32 residual stream adds it in fp32): its gradient then comes back in bf16 too
         return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, defer_bias=defer_bias,
@@ -161,8 +169,7 @@ class MultiHeadedCrossAttention(nn.Module):
 
     def __init__(self, n_heads, d_model, memory_dim, dropout_rate=0.0, share_vk_proj=False):
         super().__init__()
-        if dropout_rate:
-            _unsupported('attention dropout > 0')
+        self.dropout_rate = dropout_rate
         self.d_model, self.nheads, self.d_k = d_model, n_heads, d_model // n_heads
         self.share_vk_proj = share_vk_proj
         self.output_proj = nn.Linear(d_model, d_model)
@@ -177,12 +184,14 @@ class MultiHeadedCrossAttention(nn.Module):
         q = ops.linear(query, self.q_proj.weight, self.q_proj.bias, out_dtype=adt, link=link)
         if kv_all is not None:
             ctx = ops.CrossAttentionSliceFn.apply(q, kv_all[0], _key_mask(memory_mask, B, T), self.nheads, kv_all[1], kv_all[2])
-            return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, defer_bias=defer_bias,
-                              out_dtype=ops.act_dtype() if defer_bias else None), None
-        kv = ops.linear(memory, self.vk_proj.weight, self.vk_proj.bias, out_dtype=adt)
-        if self.share_vk_proj:           # key = value (module/attention.py:131-132)
-            kv = torch.cat((kv, kv), dim=-1)
-        ctx = ops.CrossAttentionFn.apply(q, kv, _key_mask(memory_mask, B, T), self.nheads)
+        else:
+            kv = ops.linear(memory, self.vk_proj.weight, self.vk_proj.bias, out_dtype=adt)
+            if self.share_vk_proj:           # key = value (module/attention.py:131-132)
+                kv = torch.cat((kv, kv), dim=-1)
+            ctx = ops.CrossAttentionFn.apply(q, kv, _key_mask(memory_mask, B, T), self.nheads)
+        if self.dropout_rate and self.training:   # dropout(output_proj(ctx)): bias inside the mask, not deferrable
+            out = ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, out_dtype=ops.act_dtype() if defer_bias else None)
+            return ops.dropout(out, self.dropout_rate), None
         return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, defer_bias=defer_bias,
                           out_dtype=ops.act_dtype() if defer_bias else None), None
 
@@ -197,13 +206,21 @@ class PositionwiseFeedForward(nn.Module):
     def __init__(self, d_model, d_ff, dropout, activation='relu'):
         super().__init__()
         assert activation in ('relu', 'gelu', 'glu', 'tanh', 'swish')
-        if dropout:
-            _unsupported('ffn_dropout > 0')
+        self.dropout = dropout                    # on the hidden, between the activation and w_2 (module/ffn.py:40)
         self.activation = activation
         self.w_1 = nn.Linear(d_model, d_ff * 2 if activation == 'glu' else d_ff)
         self.w_2 = nn.Linear(d_ff, d_model)
 
     def forward(self, x, defer_bias=False, link=None):
+        if self.dropout and self.training:        # w_2(dropout(act(w_1 x))): the mask sits between the two GEMMs -> unfused chain
+            h = ops.linear(x, self.w_1.weight, self.w_1.bias, relu=self.activation == 'relu', out_dtype=ops.act_dtype(), link=link)
+            if self.activation == 'glu':
+                h = ops.GLUFn.apply(h)
+            elif self.activation != 'relu':
+                h = ops.activation(h, self.activation)
+            h = ops.dropout(h, self.dropout)
+            return ops.linear(h, self.w_2.weight, self.w_2.bias, defer_bias=defer_bias,
+                              out_dtype=ops.act_dtype() if defer_bias else None)
         if self.activation == 'glu':
             return ops.FeedForwardGLUFn.apply(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias,
                                               defer_bias, ops.act_dtype() if defer_bias else torch.float32, link)
@@ -222,7 +239,7 @@ def _post_norm(norm, x, branch, p, training, a_bias=None, link=None):
 
 def _ffn_post_norm(ff, norm, x, p):
     """LN(x + dropout(FFN(x))): one row-block fused launch (ops.FfnLnFn) for GLU FFNs on enough rows, else GEMMs + add+LN."""
-    if ff.activation == 'glu':
+    if ff.activation == 'glu' and not (ff.dropout and ff.training):
         y = ops.ffn_add_layernorm(x, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias, norm.weight, norm.bias, p, norm.eps)
         if y is not None:
             return y
@@ -232,6 +249,12 @@ def _ffn_post_norm(ff, norm, x, p):
 
 def _norm(norm, x):
     return ops.add_layernorm(x, None, norm.weight, norm.bias, 0.0, norm.eps)
+
+
+def _deferred_bias(attn):
+    """the output_proj bias the closing add+LayerNorm must add (and differentiate) -- None when the attention module applied
+    it itself because its own dropout sits behind the projection"""
+    return None if (attn.dropout_rate and attn.training) else attn.output_proj.bias
 
 
 def _attention_branch(layer, concat_linear, x, p, run):
@@ -281,7 +304,7 @@ class TransformerEncoderLayer(nn.Module):
                     _unsupported('causal relative-positional self-attention')
                 return self.slf_attn(x, mask, pos)[0], None
             att, _ = self.slf_attn(x, mask, causal, **kw)
-            return att, self.slf_attn.output_proj.bias
+            return att, _deferred_bias(self.slf_attn)
         branch, bias, p1, link = _attention_branch(self, getattr(self, 'concat_linear', None), x, p, run)
         x = _post_norm(self.norm2 if pre else self.norm1, x, branch, p1, True, bias, link)
         if pre:
@@ -367,8 +390,7 @@ class ConformerConvolutionModule(nn.Module):
     def __init__(self, channels, kernel_size, bias=True, dropout=0.0):
         super().__init__()
         assert kernel_size % 2 == 1
-        if dropout:
-            _unsupported('conv_dropout > 0')
+        self.dropout = dropout                    # the reference builds nn.Dropout(dropout) here and never applies it (module/conformer.py:34-57)
         self.pointwise_conv1 = nn.Linear(channels, 2 * channels, bias=bias)
         self.depthwise_conv = nn.Conv1d(channels, channels, kernel_size, stride=1, padding=(kernel_size - 1) // 2,
                                         groups=channels, bias=bias)
@@ -511,13 +533,13 @@ class TransformerDecoderLayer(nn.Module):
 
         def run_self(**kw):
             att, _ = self.slf_attn(x, tgt_mask, causal=tgt_mask is None, **kw)
-            return att, self.slf_attn.output_proj.bias
+            return att, _deferred_bias(self.slf_attn)
         branch, bias, p1, link = _attention_branch(self, getattr(self, 'concat_linear1', None), x, p, run_self)
         x = _post_norm(norms[0], x, branch, p1, True, bias, link)
 
         def run_src(**kw):
             att, _ = self.src_attn(x, memory, memory_mask, kv_all=kv_all, **kw)
-            return att, self.src_attn.output_proj.bias
+            return att, _deferred_bias(self.src_attn)
         branch, bias, p2, link = _attention_branch(self, getattr(self, 'concat_linear2', None), x, p, run_src)
         x = _post_norm(norms[1], x, branch, p2, True, bias, link)
         if pre:

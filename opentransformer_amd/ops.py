@@ -1097,6 +1097,30 @@ def ffn_add_layernorm(x, w1, b1, w2, b2, gamma, beta, p_drop=0.0, eps=1e-5):
     return attach_lp(y, y16)
 
 
+class GLUFn(torch.autograd.Function):
+    """F.glu(h, -1) as its own autograd node (ffn_dropout > 0 puts a dropout between the GLU and w_2, module/ffn.py:40)"""
+
+    @staticmethod
+    def forward(ctx, h):
+        _cuda(h)
+        F2 = h.shape[-1]
+        h2 = h.reshape(-1, F2).contiguous()
+        u = torch.empty((h2.shape[0], F2 // 2), dtype=h2.dtype, device=h.device)
+        L.check(L.load().otr_glu_fwd(_p(h2), _p(u), _code(h2.dtype), h2.shape[0], F2 // 2, None, _stream()), 'otr_glu_fwd')
+        ctx.save_for_backward(h2)
+        ctx.hshape = h.shape
+        return u.view(*h.shape[:-1], F2 // 2)
+
+    @staticmethod
+    def backward(ctx, du):
+        (h2,) = ctx.saved_tensors
+        du2 = du.reshape(-1, du.shape[-1]).contiguous().to(h2.dtype)
+        dh = torch.empty_like(h2)
+        L.check(L.load().otr_glu_bwd(_p(h2), _p(du2), _p(dh), None, _code(h2.dtype), h2.shape[0], du2.shape[1], None, 0, _stream()),
+                'otr_glu_bwd')
+        return dh.view(ctx.hshape)
+
+
 GLU_RPB = 32        # rows per workgroup of otr_glu_bwd (csrc/elementwise.hip)
 _FUSED_GLU_BWD = os.environ.get('OTR_NO_FUSED_GLU_BWD', '0') != '1'     # A/B switches for tuning runs
 _FUSED_GLU_FWD = os.environ.get('OTR_NO_FUSED_GLU_FWD', '0') != '1'
@@ -1222,7 +1246,10 @@ class ConvSubsampleFn(torch.autograd.Function):
     (column index f*C2 + c)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, p_drop=0.0):
+        """p_drop > 0: each Conv2dLayer is dropout(relu(conv(x))) (frontend/conv.py:63-66).  The masks are applied in place
+        on act1 / act2 (which are saved MASKED: their > 0 pattern is then relu' AND mask) and, in backward, on the incoming
+        gradients with the same (seed, offset) -- zeros stay zero, kept elements pick up the 1/(1-p)."""
         _cuda(x, w1, b1, w2, b2)
         B, T, F = x.shape
         C1, C2 = w1.shape[0], w2.shape[0]
@@ -1238,7 +1265,15 @@ class ConvSubsampleFn(torch.autograd.Function):
         act2 = torch.empty((B, T2, F2 * C2), dtype=adt, device=x.device)
         lib = L.load()
         L.check(lib.otr_conv1_fwd(C.byref(desc), _p(x), _p(w1), _p(b1), _p(act1), _stream()), 'otr_conv1_fwd')
+        seed, offs = None, (0, 0)
+        if p_drop > 0:
+            seed = rng_seed_tensor(x.device)
+            offs = (_next_rng_offset(act1.numel()), _next_rng_offset(act2.numel()))
+            L.check(lib.otr_dropout(_p(act1), _p(act1), _code(adt), act1.numel(), p_drop, _p(seed), offs[0], _stream()), 'otr_dropout')
         L.check(lib.otr_conv2_fwd(C.byref(desc), _p(act1), _p(w2r), _p(b2), _p(act2), _stream()), 'otr_conv2_fwd')
+        if p_drop > 0:
+            L.check(lib.otr_dropout(_p(act2), _p(act2), _code(adt), act2.numel(), p_drop, _p(seed), offs[1], _stream()), 'otr_dropout')
+        ctx.drop = (p_drop, seed, offs)
         ctx.save_for_backward(x, w2r, act1, act2)
         ctx.desc_args = (B, T, F, C1, C2, T1, F1, T2, F2)
         ctx.refs = (w1_param, b1, b2)
@@ -1251,7 +1286,13 @@ class ConvSubsampleFn(torch.autograd.Function):
         adt = act2.dtype
         desc = L.ConvDesc(B, T, F, C1, C2, T1, F1, T2, F2, _code(adt), _compute_code(), _code(w2r.dtype))
         lib = L.load()
-        g2 = relu_bwd_raw(act2, dact2.contiguous())
+        p_drop, seed, offs = ctx.drop
+        dact2 = dact2.contiguous()
+        if p_drop > 0:
+            gm = torch.empty_like(dact2)
+            L.check(lib.otr_dropout(_p(dact2), _p(gm), _code(adt), dact2.numel(), p_drop, _p(seed), offs[1], _stream()), 'otr_dropout')
+            dact2 = gm
+        g2 = relu_bwd_raw(act2, dact2)
         M2 = B * T2 * F2
         w1p, b1p, b2p = ctx.refs
         gw1, gb1, gb2 = grad_target(w1p), grad_target(b1p), grad_target(b2p)
@@ -1263,6 +1304,8 @@ class ConvSubsampleFn(torch.autograd.Function):
         L.check(lib.otr_conv2_dgrad_cols(C.byref(desc), _p(g2), _p(w2r), _p(dcol), _stream()), 'otr_conv2_dgrad_cols')
         dact1 = torch.empty_like(act1)
         L.check(lib.otr_conv2_col2im(C.byref(desc), _p(dcol), _p(act1), _p(dact1), _stream()), 'otr_conv2_col2im')
+        if p_drop > 0:
+            L.check(lib.otr_dropout(_p(dact1), _p(dact1), _code(adt), dact1.numel(), p_drop, _p(seed), offs[0], _stream()), 'otr_dropout')
         if gw1 is not None and gb1 is not None:
             dw1, db1 = gw1, gb1
         else:
@@ -1271,7 +1314,11 @@ class ConvSubsampleFn(torch.autograd.Function):
         L.check(lib.otr_conv1_wgrad(C.byref(desc), _p(x), _p(dact1), _p(dw1), _p(db1), _stream()), 'otr_conv1_wgrad')
         inpl = gw1 is not None and gb1 is not None
         return (None, None if inpl else dw1.view(C1, 1, 3, 3), None if inpl else db1, dw2r.permute(0, 3, 1, 2),
-                None if gb2 is not None else db2)
+                None if gb2 is not None else db2, None)
+
+
+def conv_subsample_with_dropout(x, w1, b1, w2, b2, p_drop):
+    return ConvSubsampleFn.apply(x, w1, b1, w2, b2, float(p_drop))
 
 
 # ---------------------------------------------------------------------------------------- conformer pieces
@@ -1324,6 +1371,40 @@ class ResidualAddFn(torch.autograd.Function):
 
 def residual_add(x, a, scale=1.0, p_drop=0.0):
     return ResidualAddFn.apply(x, a, float(scale), float(p_drop))
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout(p) on the HIP path (otr_dropout): the mask is regenerated from (seed, offset) in the backward pass"""
+
+    @staticmethod
+    def forward(ctx, x, p_drop):
+        _cuda(x)
+        x2 = x.contiguous()
+        y = torch.empty_like(x2)
+        seed = rng_seed_tensor(x.device)
+        off = _next_rng_offset(x2.numel())
+        L.check(L.load().otr_dropout(_p(x2), _p(y), _code(x2.dtype), x2.numel(), p_drop, _p(seed), off, _stream()), 'otr_dropout')
+        ctx.save_for_backward(seed)
+        ctx.cfg = (p_drop, off)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (seed,) = ctx.saved_tensors
+        p_drop, off = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        L.check(L.load().otr_dropout(_p(dy), _p(dx), _code(dy.dtype), dy.numel(), p_drop, _p(seed), off, _stream()), 'otr_dropout')
+        return dx, None
+
+
+def dropout(x, p, training=True):
+    """F.dropout(x, p, training) through the library's counter RNG; identity for p == 0 or eval"""
+    if p <= 0.0 or not training or x.numel() == 0:
+        return x
+    if x.numel() % 4:
+        raise L.OtransHipError('dropout: tensor size must be a multiple of 4')
+    return DropoutFn.apply(x, float(p))
 
 
 class RelPosAttentionFn(torch.autograd.Function):

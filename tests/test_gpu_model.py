@@ -398,3 +398,44 @@ def test_c4_conformer_full_size_matches_cpu_oracle():
             assert worst < tg, (mode, worst)
         finally:
             ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'fp16'])
+def test_ctc_model_matches_cpu_oracle(mode):
+    """End2EndModel['ctc'] (model/ctc.py:69-96): frontend + encoder + CTC head on the labels truth[:, 1:-1] with lengths
+    targets_length - 1, against the oracle's pieces assembled the same way"""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops
+    from oracle import otrans_oracle as orc
+    assert ota.End2EndModel['ctc'] is ota.CTCModel
+    cfg = syn.c1_model(0.0, ctc_weight=0.3)
+    params = dict(cfg, vocab_size=cfg['decoder']['vocab_size'], lookahead_steps=2)
+    inputs, targets = syn.synthetic_batch(**C1_BATCH)
+    parts = H.require_grad(H.filled_state(dict(cfg, lookahead_steps=2), seed=21, with_ctc=True))
+    x, mask = orc.conv_frontend(parts['frontend'], inputs['inputs'], inputs['mask'])
+    memory, mmask = orc.transformer_encoder(parts['encoder'], x, mask, cfg['encoder'])
+    logits = torch.nn.functional.linear(orc.ctc_look_ahead(parts['ctc'], memory), parts['ctc']['output_layer.weight'],
+                                        parts['ctc']['output_layer.bias'])
+    ref = orc.ctc_loss(logits, mmask.sum(-1), targets['targets'][:, 1:-1], targets['targets_length'] - 1)
+    ref.backward()
+    ops.set_compute_dtype(mode)
+    try:
+        model = ota.CTCModel(params)
+        for name, mod in (('frontend', model.frontend), ('encoder', model.encoder), ('ctc', model.assistor)):
+            mod.load_state_dict({k: v.detach() for k, v in parts[name].items()}, strict=True)
+        model = model.to(DEV).train()
+        with H.loss_scaled(mode) as ls:
+            loss, aux = model(to_dev(inputs), to_dev(targets))
+            loss.backward()
+            ls.unscale(model)
+        assert aux is None
+        assert abs(loss.item() - ref.item()) < (1e-5 if mode == 'fp32' else 5e-4) * abs(ref.item())
+        flat = {'frontend.' + k: v for k, v in parts['frontend'].items()}
+        flat.update({'encoder.' + k: v for k, v in parts['encoder'].items()})
+        flat.update({'assistor.' + k: v for k, v in parts['ctc'].items()})
+        for k, p in model.named_parameters():
+            assert rel(p.grad.cpu().numpy(), flat[k].grad.numpy()) < (2e-3 if mode == 'fp32' else 1e-2), k
+        lp, ln = model.inference(inputs['inputs'].to(DEV), inputs['mask'].to(DEV))
+        assert lp.shape[:2] == memory.shape[:2] and torch.equal(ln.cpu(), mmask.sum(-1))
+    finally:
+        ops.set_compute_dtype('bf16')

@@ -699,3 +699,44 @@ def test_ffn_glu_fused_entries_direct(M, d, F_):
     assert lib.otr_ffn_glu_fwd(p(x), d, p(w1), d, p(b1), p(h2), p(u), M, 40, d, st) == 1
     torch.cuda.synchronize()
     assert bool((h2 == 7.0).all())
+
+
+def test_optimizer_gradient_noise_and_loss_scale():
+    """otr_optimizer_step extras: Gaussian gradient noise added after clipping (train/trainer.py:223-227) and the device-side
+    dynamic loss scale (divide out, halve + skip on a non-finite norm, grow after `growth_interval` finite updates)"""
+    from opentransformer_amd import ops
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1 << 18, device=DEV))
+
+    deferral = ops._wq['on']
+    try:
+        # noise: zero gradients, so exp_avg = (1 - beta1) * noise
+        dp = FlatDataParallel(Holder())
+        opt = FusedAdam(dp, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.0, clip_grad=5.0, grad_noise=0.05, loss_scale=0.0)
+        dp.zero_grad()
+        opt.step()
+        m = opt.exp_avg[:1 << 18] / 0.1
+        assert abs(float(m.mean())) < 1e-3 and abs(float(m.std()) - 0.05) < 1e-3
+        # loss scale: gradients arrive 1024x too large
+        dp = FlatDataParallel(Holder())
+        opt = FusedAdam(dp, lr=1e-3, weight_decay=0.0, clip_grad=0.0, loss_scale=1024.0, loss_scale_growth=2)
+        g = torch.randn(1 << 18, device=DEV) * 0.01
+        dp.params[0].grad.copy_(g * 1024.0)
+        opt.step()
+        st = opt.stats()
+        assert st['skipped'] == 0 and abs(st['grad_sqnorm'] - float((g * g).sum())) < 1e-3 * float((g * g).sum())
+        assert rel(opt.exp_avg[:1 << 18], 0.1 * g) < 1e-5                       # scale divided out
+        dp.params[0].grad.copy_(g * 1024.0)
+        opt.step()                                                               # second finite update: growth_interval reached
+        assert opt.stats()['loss_scale'] == 2048.0
+        before = dp.flat_param.clone()
+        dp.params[0].grad.fill_(float('inf'))                                    # overflow: skip, halve
+        opt.step()
+        st = opt.stats()
+        assert st['skipped'] == 1 and st['loss_scale'] == 1024.0 and torch.equal(dp.flat_param, before)
+    finally:
+        ops.defer_weight_grads(deferral)

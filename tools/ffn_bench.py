@@ -96,6 +96,9 @@ def main():
     res['fwd_us'] = timeit(lambda: fwd(0.0), a.iters)
     res['fwd_drop_us'] = timeit(lambda: fwd(0.1), a.iters)
     res['bwd_us'] = timeit(bwd, a.iters)
+    lib.otr_debug_set(4, 4)
+    res['bwd_no_db1_us'] = timeit(bwd, a.iters)
+    lib.otr_debug_set(4, 0)
     if S:
         res['slabs'] = S
         res['v2_fwd_us'] = timeit(fwd2, a.iters)
