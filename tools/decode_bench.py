@@ -2,9 +2,9 @@
 transformer_baseline dims, T=1000 frames, max_len 60, EOS suppressed so every hypothesis runs all 60 steps
 (random-init weights would stop at step 1).  Prints one JSON line: utterances/s and ms per decode step for the
 reference-style re-forward loop, the KV-cached loop (eager launches) and the KV-cached loop under hipGraph replay,
-plus (optional) the CPU oracle on a bounded sample.
+plus `roofline` (bytes one cached step must stream / step time / 8 TB/s) and the CPU oracle on a bounded sample.
 
-    python tools/decode_bench.py [--batch 8] [--beam 10] [--max-len 60] [--mode bf16] [--cpu-baseline]
+    python tools/decode_bench.py [--batch 8] [--beam 10] [--max-len 60] [--mode fp16] [--no-cpu-baseline]
 """
 import argparse
 import json
@@ -48,9 +48,9 @@ def main():
     ap.add_argument('--frames', type=int, default=1000)
     ap.add_argument('--beam', type=int, default=10)
     ap.add_argument('--max-len', type=int, default=60)
-    ap.add_argument('--mode', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--mode', default='fp16', choices=['fp16', 'bf16', 'fp32'])
     ap.add_argument('--iters', type=int, default=3)
-    ap.add_argument('--cpu-baseline', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
     from opentransformer_amd.recognize import SpeechToTextRecognizer
     dev = torch.device('cuda:0')
@@ -80,7 +80,18 @@ def main():
            'speedup_vs_reforward': res['reforward']['s_per_batch'] / res['cached_hipgraph']['s_per_batch'],
            'identical_1best': '%d/%d' % (same, args.batch),
            'tokens_per_hyp': len(hyps['cached_hipgraph'][0].split())}
-    if args.cpu_baseline:
+    # roofline of the cached step: it is a weight stream -- every decoder + LM weight (16-bit shadows) and the cross-attention
+    # keys / values of the batch are read once per step for ~0.4 GFLOP of work -- so the bound is HBM bandwidth
+    esz = 4 if args.mode == 'fp32' else 2
+    wbytes = sum(p.numel() for p in model.decoder.parameters()) * esz + sum(p.numel() for p in lm.parameters()) * esz
+    Tm = ((args.frames - 3) // 2 + 1 - 3) // 2 + 1
+    kv_bytes = args.batch * Tm * 2 * 256 * esz * len(model.decoder.blocks)
+    step_s = res['cached_hipgraph']['ms_per_step'] * 1e-3
+    ach = (wbytes + kv_bytes) / step_s / 1e9
+    out['roofline'] = {'bound': 'hbm', 'kernel': 'one KV-cached decode step (decoder + LM, ~170 launches under one hipGraph)',
+                       'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0, 'traffic': None,
+                       'algorithmic_bytes': wbytes + kv_bytes, 'avg_launch_ms': res['cached_hipgraph']['ms_per_step']}
+    if not args.no_cpu_baseline:
         from oracle import otrans_oracle as orc
         from tests import helpers as H
         torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -94,7 +105,8 @@ def main():
         orc.beam_search(parts, cfg, inputs['inputs'][:nb], inputs['mask'][:nb], beam=args.beam, nbest=1, max_len=ml,
                         penalty=0.6, lamda=5, lm=(lmp, lm_cfg), lm_weight=0.1)
         dt = time.perf_counter() - t0
-        out['cpu_baseline'] = {'s_per_utt_at_max_len_%d' % ml: dt / nb, 'cores': torch.get_num_threads(), 'kind': 'port',
+        out['cpu_baseline'] = {'value': nb / dt, 'unit': 'utterances/s at max_len %d' % ml, 's_per_utt_at_max_len_%d' % ml: dt / nb,
+                               'cores': torch.get_num_threads(), 'host_cores': os.cpu_count(), 'kind': 'port',
                                'sample': 'CPU oracle beam search (re-forward, like the reference), %d utterance, '
                                          'max_len %d' % (nb, ml)}
     print(json.dumps(out))
