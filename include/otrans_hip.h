@@ -257,9 +257,13 @@ typedef struct {
 /* conv1: 1->C1, 3x3, stride 2, pad (0,1), +bias, ReLU.  w1 f32 [C1,1,3,3] */
 int32_t otr_conv1_fwd(const otr_conv_desc_t* d, const float* x, const float* w1, const float* b1, void* act1,
                       void* stream);
-/* dw1 [C1,9] f32 +=, db1 [C1] f32 += ; dact1 already masked by ReLU */
+/* dw1 [C1,9] f32 +=, db1 [C1] f32 += ; dact1 already masked by ReLU.  partial (may be NULL): f32
+ * [otr_conv1_wgrad_partial_rows()][10*C1]; when given NOTHING is added to dw1 / db1 (they may be NULL): every workgroup
+ * writes its own sums (9*C1 weight-gradient values in dw1's layout, then C1 bias-gradient values) and the caller
+ * column-sums the rows (otr_colsum / otr_colsum_grouped): no atomics, deterministic, 4x the workgroups. */
 int32_t otr_conv1_wgrad(const otr_conv_desc_t* d, const float* x, const void* dact1, float* dw1, float* db1,
-                        void* stream);
+                        float* partial, void* stream);
+int32_t otr_conv1_wgrad_partial_rows(void);
 /* conv2 as implicit GEMM on MFMA: w2r = w2 permuted to [C2,3,3,C1] (f32). +bias, ReLU */
 int32_t otr_conv2_fwd(const otr_conv_desc_t* d, const void* act1, const void* w2r, const float* b2, void* act2,
                       void* stream);

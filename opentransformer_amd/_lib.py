@@ -96,7 +96,8 @@ SIGNATURES = {
     'otr_scale': [_P, _P, _I64, _P, _F32, _P],
     'otr_cast_f32_to_bf16': [_P, _P, _I64, _P],
     'otr_conv1_fwd': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
-    'otr_conv1_wgrad': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
+    'otr_conv1_wgrad': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P],
+    'otr_conv1_wgrad_partial_rows': [],
     'otr_conv2_fwd': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
     'otr_conv2_dgrad_cols': [C.POINTER(ConvDesc), _P, _P, _P, _P],
     'otr_conv2_col2im': [C.POINTER(ConvDesc), _P, _P, _P, _P],

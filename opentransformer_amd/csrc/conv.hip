@@ -9,7 +9,7 @@
 
 struct ConvArgs {
   const float* x; const float* w1; const float* b1;
-  void* act1; const void* dact1_in; float* dw1; float* db1;
+  void* act1; const void* dact1_in; float* dw1; float* db1; float* partial;
   const void* dcol; const void* act1_in; void* dact1_out;
   int B, T, F, C1, C2, T1, F1, T2, F2;
 };
@@ -114,7 +114,10 @@ template <class T> __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Con
       float s = 0.f;
       for (int t = g2; t < 256; t += CG) s += red[t][v];
       int ch = g2 * 8 + c;
-      if (v < 9) atomicAdd(p.dw1 + ch * 9 + v, s);
+      if (p.partial) {             // per-workgroup sums, reduced by the caller's column sum: no atomics, 4x the workgroups
+        float* row = p.partial + (int64_t)blockIdx.x * (p.C1 * 10);
+        if (v < 9) row[ch * 9 + v] = s; else row[p.C1 * 9 + ch] = s;
+      } else if (v < 9) atomicAdd(p.dw1 + ch * 9 + v, s);
       else atomicAdd(p.db1 + ch, s);
     }
   }
@@ -197,15 +200,20 @@ extern "C" int32_t otr_conv1_fwd(const otr_conv_desc_t* d, const float* x, const
   return otr_check_launch("conv1_fwd");
 }
 
+constexpr int CONV1_WGRAD_PARTIAL_BLOCKS = 1024;
+extern "C" int32_t otr_conv1_wgrad_partial_rows(void) { return CONV1_WGRAD_PARTIAL_BLOCKS; }
 extern "C" int32_t otr_conv1_wgrad(const otr_conv_desc_t* d, const float* x, const void* dact1, float* dw1, float* db1,
-                                   void* stream) {
+                                   float* partial, void* stream) {
   ConvArgs a{};
   if (int32_t e = conv_check(d, a)) return e;
-  OTR_REQUIRE(x && dact1 && dw1 && db1, "conv1_wgrad: null pointer");
-  a.x = x; a.dact1_in = dact1; a.dw1 = dw1; a.db1 = db1;
+  OTR_REQUIRE(x && dact1 && (partial || (dw1 && db1)), "conv1_wgrad: null pointer");
+  a.x = x; a.dact1_in = dact1; a.dw1 = dw1; a.db1 = db1; a.partial = partial;
   hipStream_t s = (hipStream_t)stream;
   unsigned g = conv_grid(a);
-  if (g > 256) g = 256;   // every block ends with 10*C1 atomics on the same addresses: 1024 blocks spent ~75 % of the kernel there
+  // atomics: every block ends with 10*C1 atomics on the same addresses (1024 blocks spent ~75 % of the kernel there) -> 256
+  // blocks; with `partial` every block writes its own row and the chip can be filled (4 waves per CU left the 80-accumulator
+  // reduction latency-bound at 124 us)
+  if (partial) g = CONV1_WGRAD_PARTIAL_BLOCKS; else if (g > 256) g = 256;
   if (d->act_dtype == OTR_F32) hipLaunchKernelGGL(conv1_wgrad_kernel<float>, dim3(g), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(conv1_wgrad_kernel<bf16_t>, dim3(g), dim3(256), 0, s, a);
   return otr_check_launch("conv1_wgrad");

@@ -322,10 +322,10 @@ struct ColsumGroup {
   float* out[CSG_MAX];
   int M[CSG_MAX], N[CSG_MAX], lda[CSG_MAX], rblocks[CSG_MAX];
 };
-// EPT elements (16 bytes) per thread and row: 4 floats or 8 sixteen-bit values -- 8-byte loads of 16-bit rows left the
-// kernel at 1.1 TB/s on the [M, 768] / [M, 512] gradient matrices of a backward pass
+// EPT = 4 columns per thread for both element types: the matrices of a backward pass are mostly [M, 256], which 8 columns
+// per thread (16-byte loads of 16-bit rows) would cover with half a wave -- measured 169 -> 300 us per training step
 template <class T> __global__ void colsum_grouped_kernel(ColsumGroup g) {
-  constexpr int EPT = 16 / (int)sizeof(T);
+  constexpr int EPT = 4;
   __shared__ float red[4][64][EPT];
   const int b = (int)blockIdx.x;
   int i = 0;
@@ -397,7 +397,7 @@ extern "C" int32_t otr_colsum_grouped(const otr_colsum_item_t* items, int32_t n,
                   "colsum_grouped: item %d has a bad shape", i);
       OTR_REQUIRE((uintptr_t)it.a % 16 == 0, "colsum_grouped: item %d input must be 16-byte aligned", i);
       if (it.dtype != dt || it.M == 0) continue;
-      const int cpb = 64 * (dt == OTR_F32 ? 4 : 8);          // columns per block: 16 bytes per thread
+      const int cpb = 64 * 4;                                // columns per block: 4 per thread
       const int rb = (int)((it.M + CS_RPB - 1) / CS_RPB), cb = (int)((it.N + cpb - 1) / cpb);
       const int k = g.n++;
       g.first[k] = blocks;
@@ -427,9 +427,35 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const T* __restr
   const int64_t t = b - table[lo * 4 + 3];
   const int64_t tc = (cols + 63) >> 6;
   const int64_t r0 = (t / tc) << 6, c0 = (t % tc) << 6;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const T* s = src + off;
   T* d = dst + off;
+  if constexpr (sizeof(T) == 2) {
+    // full 64x64 tiles of 16-bit matrices with 16-byte aligned rows: 16-byte loads and stores (the element-wise form ran at
+    // 1.9 TB/s on the 73 MB of weight shadows refreshed after every optimizer step)
+    const bool fast = r0 + 64 <= rows && c0 + 64 <= cols && cols % 8 == 0 && rows % 8 == 0 && off % 8 == 0;
+    if (fast) {
+      const int tid = threadIdx.x;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int id = tid + 256 * u, r = id >> 3, ch = id & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(s + (r0 + r) * cols + c0 + ch * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[r][ch * 8 + e] = (T)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int id = tid + 256 * u, c = id >> 3, ch = id & 7;      // output row c (a source column), 8 source rows per chunk
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (uint32_t)tile[ch * 8 + 2 * e][c] | ((uint32_t)tile[ch * 8 + 2 * e + 1][c] << 16);
+        *reinterpret_cast<uint4*>(d + (c0 + c) * rows + r0 + ch * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      return;
+    }
+  }
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int r = ty; r < 64; r += 4)
     if (r0 + r < rows && c0 + tx < cols) tile[r][tx] = s[(r0 + r) * cols + c0 + tx];
   __syncthreads();

@@ -405,10 +405,12 @@ def linear_wgrad_raw(dy2, x2, w_like, out=None):
     return dw
 
 
-def colsum_raw(a2, out=None):
+def colsum_raw(a2, out=None, defer=True):
+    """out[N] (+)= column sums of a2[M, N].  With `out` (a gradient buffer that outlives the backward pass) the sum may be
+    queued for the grouped launch at the end of backward; defer=False forces it now (out is a temporary autograd returns)."""
     M, N = a2.shape
     acc = out is not None
-    if acc and _wq['on'] and a2.stride(1) == 1 and a2.data_ptr() % 16 == 0 and _in_backward():
+    if acc and defer and _wq['on'] and a2.stride(1) == 1 and a2.data_ptr() % 16 == 0 and _in_backward():
         _wq['b'].append((a2, out))
         _arm_flush()
         return out
@@ -1311,8 +1313,12 @@ class ConvSubsampleFn(torch.autograd.Function):
         else:
             dwb = torch.zeros((C1 * 10,), dtype=torch.float32, device=x.device)
             dw1, db1 = dwb[:C1 * 9], dwb[C1 * 9:]
-        L.check(lib.otr_conv1_wgrad(C.byref(desc), _p(x), _p(dact1), _p(dw1), _p(db1), _stream()), 'otr_conv1_wgrad')
+        nrow = lib.otr_conv1_wgrad_partial_rows()
+        part = torch.empty((nrow, C1 * 10), dtype=torch.float32, device=x.device)      # per-workgroup sums: no atomics
+        L.check(lib.otr_conv1_wgrad(C.byref(desc), _p(x), _p(dact1), None, None, _p(part), _stream()), 'otr_conv1_wgrad')
         inpl = gw1 is not None and gb1 is not None
+        colsum_raw(part[:, :C1 * 9], out=dw1.view(-1), defer=inpl)
+        colsum_raw(part[:, C1 * 9:], out=db1, defer=inpl)
         return (None, None if inpl else dw1.view(C1, 1, 3, 3), None if inpl else db1, dw2r.permute(0, 3, 1, 2),
                 None if gb2 is not None else db2, None)
 
