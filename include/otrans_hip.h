@@ -39,8 +39,12 @@ int32_t otr_version(void);
 /* OTR_BF16 or OTR_F16: the 16-bit type this library was built for */
 int32_t otr_half_type(void);
 /* tuning hook for benchmarks: key 0 = force GEMM tile (0 auto / 64 / 128), key 1 = force split-K (0 auto),
- * key 2 = 1: generic (bounds-checked) loaders only, key 3 = 1: no persistent tile loop */
+ * key 2 = 1: generic (bounds-checked) loaders only, key 3 = 1: no persistent tile loop, key 6 = 0/1: 256-wide
+ * weight-gradient launch off / on (-1: environment OTR_WGRAD256), key 7 = its workgroup count (0 = one per CU) */
 int32_t otr_debug_set(int32_t key, int32_t value);
+/* hardware probe used by the tests of the 256-wide weight-gradient kernel: one wave copies image[2048] (16-bit words)
+ * to LDS and issues ONE ds_read_b64_tr_b16 with lane l at byte address addr[l]; out[l*4 + j] = element j lane l got. */
+int32_t otr_debug_trread(const void* image, const int32_t* addr, void* out, void* stream);
 /* tuning hook: when buf != NULL every GEMM workgroup writes 4 shader-clock timestamps (start, operands staged,
  * k-loop done, stores issued) to buf[(blockIdx.y*gridDim.x + blockIdx.x)*4 ..]; NULL disables.  Not for production. */
 int32_t otr_debug_trace(void* buf);

@@ -86,6 +86,7 @@ SIGNATURES = {
     'otr_add_layernorm_bwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_add_layernorm_bwd_partial_rows': [_I64],
     'otr_debug_trace': [_P],
+    'otr_debug_trread': [_P, _P, _P, _P],
     'otr_spec_mask': [_P, _P, _I32, _I32, _I32, _I32, _P],
     'otr_transpose_batched': [_P, _P, _P, _I32, _I64, _I32, _P],
     'otr_glu_fwd': [_P, _P, _I32, _I64, _I64, _P, _P],

@@ -1,11 +1,13 @@
 // C-ABI entry points: error plumbing, nn.Linear family (on the GEMM core), conv2 implicit GEMMs.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <vector>
 
 #include "gemm_kernel.h"
+#include "wgrad256.h"
 
 static thread_local char g_err[512] = "";
 
@@ -40,6 +42,9 @@ int g_otr_force_generic = 0;
 int g_otr_no_persist = 0;
 int g_otr_ffn_waves = 4;   // 8 measured SLOWER (85 vs 61 us forward): see DESIGN.md
 int g_otr_ffn2_ablate = 0;   // tuning hook (otr_debug_set(4, v)): bit 0 = no weight DMA after the first chunk, bit 1 = no MFMA work
+int g_otr_wgrad256 = -1;     // 256x256-tile weight-gradient launch (wgrad256.hip): -1 = environment OTR_WGRAD256 (default off until measured), 0 / 1 (otr_debug_set(6, v))
+int g_otr_wgrad256_ablate = 0;   // tuning hook (otr_debug_set(8, v)), see wgrad256.h
+int g_otr_wgrad256_grid = 0; // workgroups of that launch; 0 = one per CU (otr_debug_set(7, v))
 unsigned long long* g_otr_trace = nullptr;
 extern "C" int32_t otr_debug_trace(void* buf) { g_otr_trace = (unsigned long long*)buf; return 0; }
 extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
@@ -49,6 +54,9 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   else if (key == 3) g_otr_no_persist = value;
   else if (key == 4) g_otr_ffn2_ablate = value;
   else if (key == 5) g_otr_ffn_waves = value;
+  else if (key == 6) g_otr_wgrad256 = value;
+  else if (key == 7) g_otr_wgrad256_grid = value;
+  else if (key == 8) g_otr_wgrad256_ablate = value;
   else { otr_set_error("debug_set: unknown key %d", key); return -1; }
   return 0;
 }
@@ -203,8 +211,43 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
   OTR_REQUIRE(n >= 0 && (items || n == 0), "linear_wgrad_grouped: null items");
   OTR_REQUIRE(compute == OTR_H16 || compute == OTR_F32, "linear_wgrad_grouped: bad compute type");
   const int pm = compute == OTR_H16 ? 4 : 2;
+  if (g_otr_wgrad256 < 0) {
+    const char* e = getenv("OTR_WGRAD256");
+    g_otr_wgrad256 = (e && e[0] == '1') ? 1 : 0;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  // Long-contraction 16-bit problems whose output is made of whole 256 x 256 tiles: ONE persistent launch with 256-wide
+  // tiles fed by direct-to-LDS DMA (wgrad256.hip); everything else stays on the 128 / 64-wide grouped kernel below.
+  std::vector<char> taken((size_t)n, 0);
+  if (g_otr_wgrad256 && compute == OTR_H16) {
+    std::vector<W256Item> big;
+    std::vector<int> idx;
+    for (int i = 0; i < n; ++i) {
+      const otr_wgrad_item_t& it = items[i];
+      if (!(it.dy && it.x && it.dw)) continue;                        // reported below
+      const bool ok = it.dy_dtype == OTR_H16 && it.x_dtype == OTR_H16 && it.M >= 1024 && it.N >= 128 && it.K >= 128 && it.N % 8 == 0 &&
+                      it.K % 8 == 0 && it.ldy >= it.N && it.ldx >= it.K && it.ldw >= it.K && it.ldy % 8 == 0 && it.ldx % 8 == 0 &&
+                      it.ldw % 4 == 0 && (uintptr_t)it.dy % 16 == 0 && (uintptr_t)it.x % 16 == 0 && (uintptr_t)it.dw % 16 == 0 &&
+                      it.ldy < (1ll << 24) && it.ldx < (1ll << 24) && (int64_t)(it.N + 256) * it.ldw * 4 < (1ll << 31);
+      if (ok) idx.push_back(i);
+    }
+    // longest contraction first (equal row counts stay together: their chunks can be phase-aligned)
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return items[a].M > items[b].M; });
+    for (size_t c0 = 0; c0 < idx.size(); c0 += W256_MAX_PROBS) {
+      const size_t c1 = std::min(idx.size(), c0 + (size_t)W256_MAX_PROBS);
+      big.clear();
+      for (size_t c = c0; c < c1; ++c) {
+        const otr_wgrad_item_t& it = items[idx[c]];
+        big.push_back(W256Item{it.dy, it.x, it.dw, it.M, it.N, it.K, it.ldy, it.ldx, it.ldw});
+      }
+      if (!workspace || wgrad256_workspace_bytes(big.data(), (int)big.size()) > workspace_bytes) break;   // the grouped kernel takes them
+      if (int32_t e = wgrad256_launch(big.data(), (int)big.size(), workspace, workspace_bytes, g_otr_wgrad256_grid, g_otr_wgrad256_ablate, s)) return e;
+      for (size_t c = c0; c < c1; ++c) taken[(size_t)idx[c]] = 1;
+    }
+  }
   std::vector<int> order[16];   // key = big(1) | dy dtype(1) | x dtype(1)
   for (int i = 0; i < n; ++i) {
+    if (taken[(size_t)i]) continue;
     const otr_wgrad_item_t& it = items[i];
     OTR_REQUIRE(it.dy && it.x && it.dw, "linear_wgrad_grouped: item %d has a null pointer", i);
     OTR_REQUIRE(it.M >= 0 && it.N > 0 && it.K > 0 && it.ldy >= it.N && it.ldx >= it.K && it.ldw >= it.K,
@@ -226,7 +269,6 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
     const int big = (it.N >= 128 && it.K >= 128) ? 1 : 0;
     order[(big << 2) | ((it.dy_dtype != OTR_F32) << 1) | (it.x_dtype != OTR_F32)].push_back(i);   // dtype codes -> 0 / 1
   }
-  hipStream_t s = (hipStream_t)stream;
   for (int key = 0; key < 8; ++key) {
     std::vector<int>& v = order[key];
     if (v.empty()) continue;

@@ -1,0 +1,36 @@
+// Host <-> kernel types of the 256 x 256-tile weight-gradient launch (wgrad256.hip), used by api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+constexpr int W256_MAX_PROBS = 64;      // the table travels in the kernel-argument segment (< 4 KB): hipGraph-capturable by value
+
+struct W256Item {                       // dw[N,K] += dy[M,N]^T x[M,K]; 16-bit operands, N % 8 == 0, K % 8 == 0
+  const void* dy;
+  const void* x;
+  float* dw;
+  int M, N, K;
+  int64_t ldy, ldx, ldw;
+};
+
+struct W256Prob {
+  const uint16_t* dy;
+  const uint16_t* x;
+  float* dw;
+  int start;                            // first slab of this problem in the launch's (tile, slab) space
+  int M, N, K, ldy, ldx, ldw;           // tiles: ceil(N/256) x ceil(K/256), each ceil(M/16) slabs long
+  int flag0;                            // first turnstile flag of this problem (one per tile)
+};                                      // 56 bytes: 64 of them + the scalars below stay under the 4 KB argument segment
+
+struct W256Args {
+  W256Prob p[W256_MAX_PROBS];
+  int total, chunk;                     // slabs in the launch; slabs per workgroup
+  int nprob, spin_limit;
+  int ablate, pad;                      // tuning hook (otr_debug_set(8, v)): 1 = no MFMA, 2 = no DMA after the prologue, 4 = no accumulation into dw
+  int* flags;
+  const void* zeros;                    // >= 64 zero bytes: source of rows past M
+};
+
+// Eligibility is the caller's business (api.hip); workspace holds 64 zero bytes + one int per tile.
+int32_t wgrad256_launch(const W256Item* items, int n, void* workspace, int64_t workspace_bytes, int grid_cap, int ablate, hipStream_t s);
+int64_t wgrad256_workspace_bytes(const W256Item* items, int n);

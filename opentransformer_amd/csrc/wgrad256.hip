@@ -1,0 +1,375 @@
+// Weight gradients of the wide 16-bit Linears, dw[N,K] += dy[M,N]^T x[M,K]  (train/trainer.py:208 loss.backward(): the
+// aten mm_backward of module/ffn.py:38-41, module/attention.py:62-75), as ONE persistent launch over every qualifying
+// problem of a backward pass.  Reached through otr_linear_wgrad_grouped (api.hip).
+//
+// Why a second kernel next to gemm_grouped_kernel: these problems have a long contraction (M = batch x frames = 7968)
+// and a small output, both operands are contraction-major ([m][cols] row-major), and together they stream 2 GB for
+// 377 GFLOP -- 189 flop/B, below the 312 flop/B ridge of the chip: the launch is HBM-bound (floor 250 us at 8 TB/s).
+// The 128x128-tile kernel needs 64 flop per byte a CU ingests and tops out on the CU's vector-memory return path
+// (22-33 B/clk) at 550 TFLOP/s = 690 us.  Here:
+//  * 256 x 256 output tile per workgroup of 8 waves (2 x 4, 128 x 64 each: 4 x 2 accumulators of v_mfma_f32_32x32x16):
+//    128 flop per ingested byte.
+//  * operands go global -> LDS by direct-to-LDS DMA (global_load_lds_dwordx4, 8 rows x 128 B per wave instruction), as a
+//    ring of eight 16-row slabs, staged six slabs ahead; waits are counted (vmcnt(8)), never zero, in the steady state.
+//  * the LDS image of a slab is made of [8 rows][32 columns] subtiles (512 B, exactly what ONE ds_read_b64_tr_b16 of a
+//    wave covers): the transposing read hands every lane 4 consecutive contraction rows of one column, two reads make
+//    one MFMA operand, both operands are read the same way so the contraction order agrees; no swizzle, no VALU.
+//  * fragments of slab q+1 are read while the MFMAs of slab q run (two register sets); one barrier per slab.
+//  * work is cut stream-K style: the (tile, row) space of all problems is divided into gridDim.x equal chunks of whole
+//    16-row slabs; a tile that straddles chunks is accumulated by its pieces one after the other (a turnstile per tile:
+//    flag == my slice index; payload and flag travel with sc0 sc1 accesses, cdna_hip_programming.md G16 valid forms).
+//    The piece that finishes first in time (the head of the later chunk) goes first, so nobody waits for work that has
+//    not started; the order is fixed, the sum is deterministic.
+#include "common.h"
+#include "wgrad256.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s lds_v4s;
+
+constexpr int SLAB_ROWS = 16;
+constexpr int SLAB_BYTES = 16384;                 // 16 rows x 256 columns x 2 B, dy part then x part
+constexpr int RING = 8, AHEAD = 6;
+constexpr int SCRATCH = RING * SLAB_BYTES;        // 4 KB per wave behind the ring: epilogue transposition
+constexpr int LDS_BYTES = SCRATCH + 8 * 4096;     // 163840 = all of a CU's LDS
+
+// one wave instruction: 64 lanes x 16 B, per-lane global source -> LDS [dst, dst + 1024) lane-linear.  Inline asm so
+// that hipcc does not see a pending LDS write (it would wait vmcnt(0) before the next ds_read, ffn_fused.hip).
+__device__ __forceinline__ void dma16(const void* src, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ uint2 tr_read(uint32_t lds_addr) {
+  v4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(uintptr_t)lds_addr);
+  return __builtin_bit_cast(uint2, r);
+}
+
+struct Frags {
+  uint4 a[4], b[2];
+};
+
+// the wave's operands of one slab: 4 dy fragments (32 columns each) + 2 x fragments, 12 transposing reads, in two
+// halves so that they can be spread between the MFMAs of the slab before
+__device__ __forceinline__ void read_frags_lo(Frags& f, uint32_t slab_addr, uint32_t a_off, uint32_t b_off) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const uint2 lo = tr_read(slab_addr + b_off + i * 512), hi = tr_read(slab_addr + b_off + 4096 + i * 512);
+    f.b[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const uint2 lo = tr_read(slab_addr + a_off + i * 512), hi = tr_read(slab_addr + a_off + 4096 + i * 512);
+    f.a[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  }
+}
+__device__ __forceinline__ void read_frags_hi(Frags& f, uint32_t slab_addr, uint32_t a_off, uint32_t b_off) {
+#pragma unroll
+  for (int i = 2; i < 4; ++i) {
+    const uint2 lo = tr_read(slab_addr + a_off + i * 512), hi = tr_read(slab_addr + a_off + 4096 + i * 512);
+    f.a[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  }
+}
+
+struct Stager {                 // this lane's share of the two DMA instructions its wave issues per slab
+  const unsigned char* pa;      // dy: row (first row of the slab + lane row), this lane's 16 bytes
+  const unsigned char* pb;      // x
+  int64_t step_a, step_b;       // bytes per 16 rows
+  int row, M;                   // global row of this lane in the NEXT slab to stage
+  bool col_a, col_b;            // this lane's 8 columns exist (ragged last tile of N / K)
+  const unsigned char* zeros;
+  uint32_t dst;                 // wave's byte offset inside a slab's dy part (the x part is + 8192)
+  __device__ __forceinline__ void issue(int slot) {
+    const bool ok = row < M;
+    dma16(ok && col_a ? pa : zeros, (uint32_t)(slot * SLAB_BYTES) + dst);
+    dma16(ok && col_b ? pb : zeros, (uint32_t)(slot * SLAB_BYTES) + 8192u + dst);
+    pa += step_a; pb += step_b; row += SLAB_ROWS;
+  }
+};
+
+template <bool COH>
+__device__ __forceinline__ void flush_tile(f32x16 (&acc)[4][2], float* dw, int ldw, int N, int K, int n_base, int k_base,
+                                           unsigned char* scr, int lane) {
+  // acc[a][b]: rows n_base + 32a + (r&3) + 8(r>>2) + 4(lane>>5), column k_base + 32b + (lane&31).  Through the wave's 4 KB
+  // of LDS a 32 x 32 tile becomes 8 rows x 128 B per instruction: 16-byte read-modify-write of dw.  dw came out of a
+  // table (no known address space): buffer accesses, which also carry the cache policy.  COH: sc0 sc1 -- loads are
+  // served by memory and not by an L2 line another XCD has since rewritten, stores write through and drop the line.
+  constexpr int AUX = COH ? 17 : 0;
+  const int rr = lane >> 3, cq = lane & 7;
+  float* sw = reinterpret_cast<float*>(scr);
+  // the descriptor ends with the matrix: rows >= N fall outside (loads give 0, stores are dropped); columns >= K of a
+  // ragged last tile are sent outside by their offset
+  auto rs = __builtin_amdgcn_make_buffer_rsrc(dw, 0, ((N - 1) * ldw + K) * 4, 0x00020000);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      otr_u32x4 old[4];
+      uint32_t off[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        off[j] = k_base + 32 * b + 4 * cq < K ? (uint32_t)(((n_base + 32 * a + 8 * j + rr) * ldw + k_base + 32 * b + 4 * cq) * 4)
+                                              : 0xfffffff0u;
+        old[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j], 0, AUX);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sw[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[a][b][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(sw + (8 * j + rr) * 32 + 4 * cq);
+        otr_u32x4 v = {__float_as_uint(__uint_as_float(old[j].x) + t.x), __float_as_uint(__uint_as_float(old[j].y) + t.y),
+                       __float_as_uint(__uint_as_float(old[j].z) + t.z), __float_as_uint(__uint_as_float(old[j].w) + t.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off[j], 0, AUX);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next tile overwrites the scratch: reads above first
+    }
+  }
+}
+
+__global__ void trread_probe_kernel(const uint16_t* image, const int* addr, uint16_t* out) {
+  __shared__ __attribute__((aligned(16))) uint16_t img[2048];
+  for (int i = threadIdx.x; i < 2048; i += 64) img[i] = image[i];
+  __syncthreads();
+  const uint2 r = tr_read((uint32_t)(uintptr_t)(lds_byte*)reinterpret_cast<unsigned char*>(img) + (uint32_t)addr[threadIdx.x]);
+  out[threadIdx.x * 4 + 0] = (uint16_t)(r.x & 0xffffu); out[threadIdx.x * 4 + 1] = (uint16_t)(r.x >> 16);
+  out[threadIdx.x * 4 + 2] = (uint16_t)(r.y & 0xffffu); out[threadIdx.x * 4 + 3] = (uint16_t)(r.y >> 16);
+}
+
+__global__ void wgrad256_init_kernel(int* flags, int n, uint32_t* zeros) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) flags[i] = 0;
+  if (threadIdx.x < 16) zeros[threadIdx.x] = 0u;
+}
+
+__global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  const uint32_t smem0 = (uint32_t)(uintptr_t)(lds_byte*)smem;
+
+  // transposing read: lane p of 16-lane group gq supplies the 8-byte piece (row 4(gq>>1) + (p>>2), columns 16(gq&1) + 4(p&3)..)
+  // of the [8][32] subtile and receives column 16(gq&1) + p of rows 4(gq>>1) .. +3
+  const int gq = lane >> 4, p16 = lane & 15;
+  const uint32_t lane_off = (uint32_t)((4 * (gq >> 1) + (p16 >> 2)) * 64 + (gq & 1) * 32 + (p16 & 3) * 8);
+  const uint32_t a_off = smem0 + lane_off + (uint32_t)(4 * wr) * 512u;             // dy subtiles (mb, 4wr + i)
+  const uint32_t b_off = smem0 + lane_off + 8192u + (uint32_t)(2 * wc) * 512u;     // x subtiles (mb, 2wc + i)
+
+  // staging: wave w fills subtiles (mb = w>>2, columns 64(w&3) .. +63) of both parts; lane -> (subtile, row, 16-byte unit)
+  const int st_row = 8 * (wid >> 2) + ((lane >> 2) & 7);
+  const int st_col = 64 * (wid & 3) + 32 * (lane >> 5) + 8 * (lane & 3);
+
+  // this workgroup's chunk of the (tile, row) space, in slabs
+  // Chunk <-> block: consecutive chunks (tiles that share an operand panel, read at the same row phase when the chunk
+  // length is a multiple of half a tile) go to ONE XCD (block b runs on XCD b % 8: observed placement, speed only), so the
+  // shared panel is fetched into that L2 once instead of once per tile.  Inside an XCD's group the order is reversed:
+  // a piece only waits for a piece of the NEXT chunk, i.e. (except at the 7 group seams) of a LOWER block index, which
+  // the dispatcher starts no later than this one; the spin is bounded in any case.
+  const int G = (int)gridDim.x, gx = G >> 3, bid = (int)blockIdx.x;
+  const int my_chunk = (G & 7) == 0 ? (bid & 7) * gx + (gx - 1 - (bid >> 3)) : G - 1 - bid;
+  const int c_begin = my_chunk * g.chunk;
+  int pos = c_begin;
+  const int c_end = c_begin + g.chunk < g.total ? c_begin + g.chunk : g.total;
+
+  while (pos < c_end) {
+    // ---- decode the piece [pos, pe) of one tile
+    int pi = 0;
+    while (pi + 1 < g.nprob && g.p[pi + 1].start <= pos) ++pi;
+    const W256Prob& pr = g.p[pi];
+    const int slabs_per_tile = (pr.M + SLAB_ROWS - 1) / SLAB_ROWS, tiles_k = (pr.K + 255) >> 8;
+    const int rel = pos - pr.start;
+    const int tile = rel / slabs_per_tile;
+    const int s0 = rel - tile * slabs_per_tile;
+    const int tile_begin = pr.start + tile * slabs_per_tile, tile_end = tile_begin + slabs_per_tile;
+    const int pe = tile_end < c_end ? tile_end : c_end;
+    const int P = pe - pos;                                          // slabs of this piece
+    const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
+    const int n0 = tn * 256, k0 = tk * 256;
+    const int first_chunk = tile_begin / g.chunk, last_chunk = (tile_end - 1) / g.chunk;
+    const int nslices = last_chunk - first_chunk + 1, slice = last_chunk - my_chunk;
+    const int M = pr.M;
+    const uint16_t* dy = pr.dy;
+    const uint16_t* x = pr.x;
+
+    Stager sg;
+    sg.M = M; sg.row = s0 * SLAB_ROWS + st_row; sg.zeros = reinterpret_cast<const unsigned char*>(g.zeros);
+    sg.col_a = n0 + st_col < pr.N; sg.col_b = k0 + st_col < pr.K;
+    sg.pa = reinterpret_cast<const unsigned char*>(dy + (int64_t)sg.row * pr.ldy + n0 + st_col);
+    sg.pb = reinterpret_cast<const unsigned char*>(x + (int64_t)sg.row * pr.ldx + k0 + st_col);
+    sg.step_a = (int64_t)pr.ldy * SLAB_ROWS * 2; sg.step_b = (int64_t)pr.ldx * SLAB_ROWS * 2;
+    sg.dst = smem0 + (uint32_t)wid * 1024u;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // ---- prologue: slabs 0 .. AHEAD-1 in flight, slabs 0 and 1 landed, fragments of slab 0 in registers
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j)
+      if (j < P) sg.issue(j);
+    if (P >= AHEAD) wait_vm<2 * (AHEAD - 2)>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    Frags f0, f1;
+    read_frags_lo(f0, 0u, a_off, b_off);
+    read_frags_hi(f0, 0u, a_off, b_off);
+
+    // ---- main loop: two slabs per trip (static register sets).  Per slab and wave: 8 MFMAs of the current fragments with
+    // the two DMA instructions of slab q+6 and the 12 reads of slab q+1 spread between them, then the counted wait that
+    // retires slab q+2 and the barrier that publishes it.
+#define W256_PHASE(Q, CUR, NXT, ST)                                                                            \
+  {                                                                                                          \
+    const int q_ = (Q);                                                                                      \
+    const bool more_ = ((ST) || q_ + AHEAD < P) && !no_dma, next_ = (ST) || q_ + 1 < P;                      \
+    const uint32_t nslab_ = (uint32_t)(((q_ + 1) & (RING - 1)) * SLAB_BYTES);                                \
+    if (!no_mma) {                                                                                           \
+    mma32(acc[0][0], CUR.a[0], CUR.b[0]);                                                                    \
+    mma32(acc[0][1], CUR.a[0], CUR.b[1]);                                                                    \
+    }                                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (more_) sg.issue((q_ + AHEAD) & (RING - 1));                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (!no_mma) {                                                                                           \
+    mma32(acc[1][0], CUR.a[1], CUR.b[0]);                                                                    \
+    mma32(acc[1][1], CUR.a[1], CUR.b[1]);                                                                    \
+    } else { asm volatile("" :: "v"(CUR.a[1].x), "v"(CUR.b[0].x), "v"(CUR.b[1].w), "v"(CUR.a[1].w)); }        \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (next_) read_frags_lo(NXT, nslab_, a_off, b_off);                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (!no_mma) {                                                                                           \
+    mma32(acc[2][0], CUR.a[2], CUR.b[0]);                                                                    \
+    mma32(acc[2][1], CUR.a[2], CUR.b[1]);                                                                    \
+    } else { asm volatile("" :: "v"(CUR.a[2].x), "v"(CUR.b[0].x), "v"(CUR.b[1].w), "v"(CUR.a[2].w)); }        \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (next_) read_frags_hi(NXT, nslab_, a_off, b_off);                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (!no_mma) {                                                                                           \
+    mma32(acc[3][0], CUR.a[3], CUR.b[0]);                                                                    \
+    mma32(acc[3][1], CUR.a[3], CUR.b[1]);                                                                    \
+    } else { asm volatile("" :: "v"(CUR.a[3].x), "v"(CUR.b[0].x), "v"(CUR.b[1].w), "v"(CUR.a[3].w)); }        \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (more_) wait_vm<2 * (AHEAD - 2)>(); else wait_vm<0>();                                                \
+    __builtin_amdgcn_s_barrier();                                                                            \
+    asm volatile("" ::: "memory");                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  }
+    const bool no_mma = g.ablate & 1, no_dma = g.ablate & 2;
+    int q = 0;
+    for (; q + AHEAD + 1 < P; q += 2) {     // steady state: no conditionals inside a slab
+      W256_PHASE(q, f0, f1, true)
+      W256_PHASE(q + 1, f1, f0, true)
+    }
+    for (; q + 1 < P; q += 2) {             // the last AHEAD slabs: nothing left to stage
+      W256_PHASE(q, f0, f1, false)
+      W256_PHASE(q + 1, f1, f0, false)
+    }
+    if (q < P) W256_PHASE(q, f0, f1, false)
+#undef W256_PHASE
+
+    // ---- accumulate into dw (every DMA has landed and every wave has passed the last barrier: the ring is idle)
+    float* dw = pr.dw;
+    const int n_base = n0 + 128 * wr, k_base = k0 + 64 * wc;
+    unsigned char* scr = smem + SCRATCH + wid * 4096;
+    if (g.ablate & 4) {
+    } else if (nslices == 1) {
+      flush_tile<false>(acc, dw, pr.ldw, pr.N, pr.K, n_base, k_base, scr, lane);
+    } else {
+      int* flag = g.flags + pr.flag0 + tile;
+      if (slice > 0) {
+        if (tid == 0) {
+          int spins = 0;                                               // bounded: a lost piece gives a wrong sum, never a hang
+          while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != slice && spins < g.spin_limit) {
+            __builtin_amdgcn_s_sleep(8);
+            ++spins;
+          }
+        }
+        __syncthreads();
+      }
+      flush_tile<true>(acc, dw, pr.ldw, pr.N, pr.K, n_base, k_base, scr, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's write-through stores are at memory
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flag, slice + 1 == nslices ? 0 : slice + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                                 // scratch / ring reuse by the next piece
+    pos = pe;
+  }
+}
+
+}  // namespace
+
+// Host side: lay the problems out in the (tile, slab) space, cut it into one chunk per workgroup, launch.
+static inline int w256_tiles(const W256Item& it) { return ((it.N + 255) / 256) * ((it.K + 255) / 256); }
+
+int32_t wgrad256_launch(const W256Item* it, int n, void* workspace, int64_t workspace_bytes, int grid_cap, int ablate, hipStream_t s) {
+  if (n <= 0) return 0;
+  if (n > W256_MAX_PROBS) {
+    otr_set_error("wgrad256: %d problems exceed the table of %d", n, W256_MAX_PROBS);
+    return -1;
+  }
+  W256Args g{};
+  int64_t total = 0;
+  int flags = 0;
+  bool same_rows = true;
+  for (int i = 0; i < n; ++i) {
+    W256Prob& p = g.p[i];
+    p.dy = reinterpret_cast<const uint16_t*>(it[i].dy); p.x = reinterpret_cast<const uint16_t*>(it[i].x); p.dw = it[i].dw;
+    p.M = it[i].M; p.N = it[i].N; p.K = it[i].K; p.ldy = (int)it[i].ldy; p.ldx = (int)it[i].ldx; p.ldw = (int)it[i].ldw;
+    p.start = (int)total;
+    p.flag0 = flags;
+    const int tiles = w256_tiles(it[i]), slabs = (it[i].M + SLAB_ROWS - 1) / SLAB_ROWS;
+    same_rows = same_rows && it[i].M == it[0].M;
+    total += (int64_t)tiles * slabs;
+    flags += tiles;
+  }
+  const int64_t need = 64 + (int64_t)flags * 4;   // (== wgrad256_workspace_bytes)
+  if (!workspace || workspace_bytes < need) {
+    otr_set_error("wgrad256: workspace of %lld bytes, need %lld", (long long)workspace_bytes, (long long)need);
+    return -1;
+  }
+  if (total >= (1ll << 30)) {
+    otr_set_error("wgrad256: %lld slabs do not fit the 32-bit work index", (long long)total);
+    return -1;
+  }
+  int cap = grid_cap > 0 ? grid_cap : (grid_cap < 0 ? -grid_cap : 256);    // < 0: that many workgroups, plain equal chunks
+  // short chunks make pieces whose epilogue outweighs their work: at least 64 slabs (1024 rows) per workgroup
+  while (cap > 1 && total / cap < 64) cap /= 2;
+  int64_t chunk = (total + cap - 1) / cap;
+  if (same_rows && grid_cap >= 0) {
+    // every tile is R slabs long: make the chunk a whole number of HALF tiles, so that workgroups walk their tiles at one
+    // of two row phases and the tiles of a problem (which share an operand panel) read the same rows at the same time
+    const int64_t R = (it[0].M + SLAB_ROWS - 1) / SLAB_ROWS;
+    const int64_t halves = (2 * (int64_t)flags + cap - 1) / cap;              // half tiles per chunk
+    chunk = (R * halves + 1) / 2;
+  }
+  int grid = (int)((total + chunk - 1) / chunk);
+  if (grid >= 8) grid = (grid + 7) / 8 * 8;       // whole XCD groups; the extra chunks are empty
+  g.nprob = n; g.total = (int)total; g.spin_limit = 1 << 22; g.ablate = ablate;
+  g.chunk = (int)chunk;
+  g.zeros = workspace;
+  g.flags = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(workspace) + 64);
+  hipLaunchKernelGGL(wgrad256_init_kernel, dim3(1), dim3(256), 0, s, g.flags, flags, reinterpret_cast<uint32_t*>(workspace));
+  hipLaunchKernelGGL(wgrad256_kernel, dim3((unsigned)grid), dim3(512), 0, s, g);
+  return otr_check_launch("wgrad256");
+}
+
+int64_t wgrad256_workspace_bytes(const W256Item* it, int n) {
+  int64_t flags = 0;
+  for (int i = 0; i < n; ++i) flags += w256_tiles(it[i]);
+  return 64 + flags * 4;
+}
+
+extern "C" int32_t otr_debug_trread(const void* image, const int32_t* addr, void* out, void* stream) {
+  OTR_REQUIRE(image && addr && out, "debug_trread: null pointer");
+  hipLaunchKernelGGL(trread_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const uint16_t*>(image), addr,
+                     reinterpret_cast<uint16_t*>(out));
+  return otr_check_launch("debug_trread");
+}
