@@ -24,9 +24,10 @@ struct W256Prob {
 
 struct W256Args {
   W256Prob p[W256_MAX_PROBS];
-  int total, chunk;                     // slabs in the launch; slabs per workgroup
+  int total, chunk;                     // slabs in the launch; slabs per workgroup (stream-K) / per tile (rounds)
+  int mode, nfull, rem_tiles, parts;    // 1 = rounds schedule: full rounds, tiles left for the last round, row ranges per tile there
   int nprob, spin_limit;
-  int ablate, pad;                      // tuning hook (otr_debug_set(8, v)): 1 = no MFMA, 2 = no DMA after the prologue, 4 = no accumulation into dw
+  int ablate, policy;                      // tuning hook (otr_debug_set(8, v)): 1 = no MFMA, 2 = no DMA after the prologue, 4 = no accumulation into dw; v >> 3: 0 = default policy, 1 = no non-temporal loads, 2 = non-temporal loads of unshared operand strips
   int* flags;
   const void* zeros;                    // >= 64 zero bytes: source of rows past M
 };

@@ -23,6 +23,8 @@
 #include "common.h"
 #include "wgrad256.h"
 
+#include <algorithm>
+
 namespace {
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -32,14 +34,18 @@ typedef __attribute__((address_space(3))) v4s lds_v4s;
 constexpr int SLAB_ROWS = 16;
 constexpr int SLAB_BYTES = 16384;                 // 16 rows x 256 columns x 2 B, dy part then x part
 constexpr int RING = 8, AHEAD = 6;
-constexpr int SCRATCH = RING * SLAB_BYTES;        // 4 KB per wave behind the ring: epilogue transposition
-constexpr int LDS_BYTES = SCRATCH + 8 * 4096;     // 163840 = all of a CU's LDS
+constexpr int LDS_BYTES = RING * SLAB_BYTES;      // 128 KB; after a piece's last slab the ring doubles as the epilogue's scratch (16 KB per wave)
 
 // one wave instruction: 64 lanes x 16 B, per-lane global source -> LDS [dst, dst + 1024) lane-linear.  Inline asm so
 // that hipcc does not see a pending LDS write (it would wait vmcnt(0) before the next ds_read, ffn_fused.hip).
 __device__ __forceinline__ void dma16(const void* src, uint32_t lds_dst) {
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma16_nt(const void* src, uint32_t lds_dst) {     // non-temporal: a stream no other tile reads
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -76,58 +82,141 @@ __device__ __forceinline__ void read_frags_hi(Frags& f, uint32_t slab_addr, uint
 }
 
 struct Stager {                 // this lane's share of the two DMA instructions its wave issues per slab
-  const unsigned char* pa;      // dy: row (first row of the slab + lane row), this lane's 16 bytes
-  const unsigned char* pb;      // x
+  const unsigned char* base_a;  // dy: (row = lane row of slab 0, this lane's 16 bytes)
+  const unsigned char* base_b;  // x
   int64_t step_a, step_b;       // bytes per 16 rows
-  int row, M;                   // global row of this lane in the NEXT slab to stage
+  int row0, M;                  // lane row inside a slab; rows of the problem
   bool col_a, col_b;            // this lane's 8 columns exist (ragged last tile of N / K)
   const unsigned char* zeros;
   uint32_t dst;                 // wave's byte offset inside a slab's dy part (the x part is + 8192)
-  __device__ __forceinline__ void issue(int slot) {
-    const bool ok = row < M;
-    dma16(ok && col_a ? pa : zeros, (uint32_t)(slot * SLAB_BYTES) + dst);
-    dma16(ok && col_b ? pb : zeros, (uint32_t)(slot * SLAB_BYTES) + 8192u + dst);
-    pa += step_a; pb += step_b; row += SLAB_ROWS;
+  // NTA / NTB: the operand strip is read by this tile only -> non-temporal, it stays out of the L2 the shared strips live in
+  template <bool NTA, bool NTB> __device__ __forceinline__ void issue(int slab, int slot) {
+    const bool ok = slab * SLAB_ROWS + row0 < M;
+    const unsigned char* pa = ok && col_a ? base_a + slab * step_a : zeros;
+    const unsigned char* pb = ok && col_b ? base_b + slab * step_b : zeros;
+    if constexpr (NTA) dma16_nt(pa, (uint32_t)(slot * SLAB_BYTES) + dst); else dma16(pa, (uint32_t)(slot * SLAB_BYTES) + dst);
+    if constexpr (NTB) dma16_nt(pb, (uint32_t)(slot * SLAB_BYTES) + 8192u + dst); else dma16(pb, (uint32_t)(slot * SLAB_BYTES) + 8192u + dst);
   }
 };
+
+// One piece = slabs [sb, sb + P) of one tile, walked in the rotated order sb + (i + rot) % P (a sum: any order is right;
+// the rotation staggers the problems of a launch so that their pipeline fills and epilogues do not coincide).
+// Per slab and wave: 8 MFMAs of the current fragments with the two DMA instructions of slab i+6 and the 12 reads of slab
+// i+1 spread between them, then the counted wait that retires slab i+2 and the barrier that publishes it.  Two slabs per
+// trip (static register sets); the steady-state trips carry no conditionals.
+template <bool NTA, bool NTB, int ABL>
+__device__ __forceinline__ void stream_piece(Stager& sg, f32x16 (&acc)[4][2], int sb, int P, int rot, uint32_t a_off, uint32_t b_off) {
+  constexpr bool no_mma = ABL & 1, no_dma = ABL & 2;
+  int stage = rot;                                     // next slab to stage, relative to sb, walks rot .. P-1, 0 .. rot-1
+  auto issue_next = [&](int slot) {
+    sg.issue<NTA, NTB>(sb + stage, slot);
+    stage = stage + 1 == P ? 0 : stage + 1;
+  };
+  // ---- prologue: slabs 0 .. AHEAD-1 in flight, slabs 0 and 1 landed, fragments of slab 0 in registers
+#pragma unroll
+  for (int j = 0; j < AHEAD; ++j)
+    if (j < P) issue_next(j);
+  if (P >= AHEAD) wait_vm<2 * (AHEAD - 2)>(); else wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" ::: "memory");
+  Frags f0, f1;
+  read_frags_lo(f0, 0u, a_off, b_off);
+  read_frags_hi(f0, 0u, a_off, b_off);
+#define W256_MMA(A, CUR)                                                                                     \
+  if constexpr (!no_mma) {                                                                                   \
+    mma32(acc[A][0], CUR.a[A], CUR.b[0]);                                                                    \
+    mma32(acc[A][1], CUR.a[A], CUR.b[1]);                                                                    \
+  } else {                                                                                                   \
+    asm volatile("" ::"v"(CUR.a[A].x), "v"(CUR.b[0].x), "v"(CUR.b[1].w), "v"(CUR.a[A].w));                   \
+  }                                                                                                          \
+  __builtin_amdgcn_sched_barrier(0);
+#define W256_PHASE(Q, CUR, NXT, ST)                                                                          \
+  {                                                                                                          \
+    const int q_ = (Q);                                                                                      \
+    const bool more_ = ((ST) || q_ + AHEAD < P) && !no_dma, next_ = (ST) || q_ + 1 < P;                      \
+    const uint32_t nslab_ = (uint32_t)(((q_ + 1) & (RING - 1)) * SLAB_BYTES);                                \
+    W256_MMA(0, CUR)                                                                                         \
+    if (more_) issue_next((q_ + AHEAD) & (RING - 1));                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    W256_MMA(1, CUR)                                                                                         \
+    if (next_) read_frags_lo(NXT, nslab_, a_off, b_off);                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    W256_MMA(2, CUR)                                                                                         \
+    if (next_) read_frags_hi(NXT, nslab_, a_off, b_off);                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    W256_MMA(3, CUR)                                                                                         \
+    if (more_) wait_vm<2 * (AHEAD - 2)>(); else wait_vm<0>();                                                \
+    __builtin_amdgcn_s_barrier();                                                                            \
+    asm volatile("" ::: "memory");                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  }
+  int q = 0;
+  for (; q + AHEAD + 1 < P; q += 2) {     // steady state
+    W256_PHASE(q, f0, f1, true)
+    W256_PHASE(q + 1, f1, f0, true)
+  }
+  for (; q + 1 < P; q += 2) {             // the last AHEAD slabs: nothing left to stage
+    W256_PHASE(q, f0, f1, false)
+    W256_PHASE(q + 1, f1, f0, false)
+  }
+  if (q < P) W256_PHASE(q, f0, f1, false)
+#undef W256_PHASE
+#undef W256_MMA
+}
 
 template <bool COH>
 __device__ __forceinline__ void flush_tile(f32x16 (&acc)[4][2], float* dw, int ldw, int N, int K, int n_base, int k_base,
                                            unsigned char* scr, int lane) {
-  // acc[a][b]: rows n_base + 32a + (r&3) + 8(r>>2) + 4(lane>>5), column k_base + 32b + (lane&31).  Through the wave's 4 KB
-  // of LDS a 32 x 32 tile becomes 8 rows x 128 B per instruction: 16-byte read-modify-write of dw.  dw came out of a
-  // table (no known address space): buffer accesses, which also carry the cache policy.  COH: sc0 sc1 -- loads are
-  // served by memory and not by an L2 line another XCD has since rewritten, stores write through and drop the line.
+  // acc[a][b]: rows n_base + 32a + (r&3) + 8(r>>2) + 4(lane>>5), column k_base + 32b + (lane&31).  Through 4 KB of the
+  // (now idle) ring a 32 x 32 tile becomes 8 rows x 128 B per instruction: 16-byte read-modify-write of dw, in two rounds of
+  // four tiles with all 16 loads of a round in flight at once (one round per tile cost 8 memory latencies per piece:
+  // 0.13 ms of the launch).  dw came out of a table (no known address space): buffer accesses, which also carry the
+  // cache policy.  COH: sc0 sc1 -- loads are served by memory and not by an L2 line another XCD has since rewritten,
+  // stores write through and drop the line.
   constexpr int AUX = COH ? 17 : 0;
   const int rr = lane >> 3, cq = lane & 7;
-  float* sw = reinterpret_cast<float*>(scr);
   // the descriptor ends with the matrix: rows >= N fall outside (loads give 0, stores are dropped); columns >= K of a
   // ragged last tile are sent outside by their offset
   auto rs = __builtin_amdgcn_make_buffer_rsrc(dw, 0, ((N - 1) * ldw + K) * 4, 0x00020000);
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
+  for (int h = 0; h < 2; ++h) {
+    otr_u32x4 old[2][2][4];
+    uint32_t off[2][2][4];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      otr_u32x4 old[4];
-      uint32_t off[4];
+    for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        off[j] = k_base + 32 * b + 4 * cq < K ? (uint32_t)(((n_base + 32 * a + 8 * j + rr) * ldw + k_base + 32 * b + 4 * cq) * 4)
-                                              : 0xfffffff0u;
-        old[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j], 0, AUX);
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = n_base + 32 * (2 * h + a2) + 8 * j + rr, col = k_base + 32 * b + 4 * cq;
+          off[a2][b][j] = col < K ? (uint32_t)((row * ldw + col) * 4) : 0xfffffff0u;
+          old[a2][b][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[a2][b][j], 0, AUX);
+        }
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float* sw = reinterpret_cast<float*>(scr + (a2 * 2 + b) * 4096);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sw[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[2 * h + a2][b][r];
       }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sw[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[a][b][r];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 t = *reinterpret_cast<const float4*>(sw + (8 * j + rr) * 32 + 4 * cq);
-        otr_u32x4 v = {__float_as_uint(__uint_as_float(old[j].x) + t.x), __float_as_uint(__uint_as_float(old[j].y) + t.y),
-                       __float_as_uint(__uint_as_float(old[j].z) + t.z), __float_as_uint(__uint_as_float(old[j].w) + t.w)};
-        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off[j], 0, AUX);
+      for (int b = 0; b < 2; ++b) {
+        const float* sw = reinterpret_cast<const float*>(scr + (a2 * 2 + b) * 4096);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 t = *reinterpret_cast<const float4*>(sw + (8 * j + rr) * 32 + 4 * cq);
+          const otr_u32x4 o = old[a2][b][j];
+          otr_u32x4 v = {__float_as_uint(__uint_as_float(o.x) + t.x), __float_as_uint(__uint_as_float(o.y) + t.y),
+                         __float_as_uint(__uint_as_float(o.z) + t.z), __float_as_uint(__uint_as_float(o.w) + t.w)};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, off[a2][b][j], 0, AUX);
+        }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next tile overwrites the scratch: reads above first
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the second round overwrites the scratch: reads above first
   }
 }
 
@@ -145,6 +234,7 @@ __global__ void wgrad256_init_kernel(int* flags, int n, uint32_t* zeros) {
   if (threadIdx.x < 16) zeros[threadIdx.x] = 0u;
 }
 
+template <int ABL>
 __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -163,43 +253,67 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
   const int st_row = 8 * (wid >> 2) + ((lane >> 2) & 7);
   const int st_col = 64 * (wid & 3) + 32 * (lane >> 5) + 8 * (lane & 3);
 
-  // this workgroup's chunk of the (tile, row) space, in slabs
-  // Chunk <-> block: consecutive chunks (tiles that share an operand panel, read at the same row phase when the chunk
-  // length is a multiple of half a tile) go to ONE XCD (block b runs on XCD b % 8: observed placement, speed only), so the
-  // shared panel is fetched into that L2 once instead of once per tile.  Inside an XCD's group the order is reversed:
-  // a piece only waits for a piece of the NEXT chunk, i.e. (except at the 7 group seams) of a LOWER block index, which
-  // the dispatcher starts no later than this one; the spin is bounded in any case.
+  // Slot <-> block: consecutive slots (tiles that share an operand panel and walk it in step) go to ONE XCD (block b runs on
+  // XCD b % 8: observed placement, used for speed only), so a shared panel is fetched into that L2 once instead of once
+  // per tile.  In the stream-K schedule the order inside an XCD's group is reversed: a piece only waits for a piece of the
+  // NEXT chunk, i.e. (except at the 7 group seams) of a LOWER block index, which the dispatcher starts no later than
+  // this one; every spin is bounded in any case.
   const int G = (int)gridDim.x, gx = G >> 3, bid = (int)blockIdx.x;
-  const int my_chunk = (G & 7) == 0 ? (bid & 7) * gx + (gx - 1 - (bid >> 3)) : G - 1 - bid;
-  const int c_begin = my_chunk * g.chunk;
-  int pos = c_begin;
-  const int c_end = c_begin + g.chunk < g.total ? c_begin + g.chunk : g.total;
+  const bool rounds = g.mode == 1;
+  const int slot = (G & 7) == 0 ? (bid & 7) * gx + (rounds ? (bid >> 3) : gx - 1 - (bid >> 3)) : (rounds ? bid : G - 1 - bid);
+  // stream-K: this workgroup's chunk of the (tile, slab) space
+  int pos = slot * g.chunk;
+  const int c_end = pos + g.chunk < g.total ? pos + g.chunk : g.total;
+  int round = 0;
 
-  while (pos < c_end) {
-    // ---- decode the piece [pos, pe) of one tile
-    int pi = 0;
-    while (pi + 1 < g.nprob && g.p[pi + 1].start <= pos) ++pi;
+  for (;;) {
+    // ---- next piece: slabs [sb, sb + P) of tile `tile` of problem pi; `slice` of `nslices` pieces of that tile
+    int pi = 0, tile, sb, P, rot = 0, slice = 0, nslices = 1;
+    if (rounds) {
+      // every tile is R slabs long.  Rounds 0 .. nfull-1: slot s walks the whole tile round*G + s; last round: the remaining
+      // tiles cut into `parts` row ranges each, the parts of a tile in neighbouring slots
+      const int R = g.chunk;
+      int t;
+      if (round < g.nfull) {
+        t = round * G + slot; sb = 0; P = R;
+      } else if (round == g.nfull && slot < g.rem_tiles * g.parts) {
+        const int part = slot % g.parts;
+        t = g.nfull * G + slot / g.parts;
+        sb = (int)((int64_t)R * part / g.parts);
+        P = (int)((int64_t)R * (part + 1) / g.parts) - sb;
+        slice = part; nslices = g.parts;
+      } else {
+        break;
+      }
+      ++round;
+      const int tpos = t * R;
+      while (pi + 1 < g.nprob && g.p[pi + 1].start <= tpos) ++pi;
+      tile = (tpos - g.p[pi].start) / R;
+      if (nslices == 1) rot = (int)(((unsigned)pi * 40503u & 0xffu) * (unsigned)P >> 8);       // stagger the problems
+    } else {
+      if (pos >= c_end) break;
+      while (pi + 1 < g.nprob && g.p[pi + 1].start <= pos) ++pi;
+      const int R = (g.p[pi].M + SLAB_ROWS - 1) / SLAB_ROWS;
+      const int rel = pos - g.p[pi].start;
+      tile = rel / R;
+      sb = rel - tile * R;
+      const int tile_begin = g.p[pi].start + tile * R, tile_end = tile_begin + R;
+      const int pe = tile_end < c_end ? tile_end : c_end;
+      P = pe - pos;
+      const int first_chunk = tile_begin / g.chunk, last_chunk = (tile_end - 1) / g.chunk;
+      nslices = last_chunk - first_chunk + 1; slice = last_chunk - slot;      // the piece that finishes first goes first
+      pos = pe;
+    }
     const W256Prob& pr = g.p[pi];
-    const int slabs_per_tile = (pr.M + SLAB_ROWS - 1) / SLAB_ROWS, tiles_k = (pr.K + 255) >> 8;
-    const int rel = pos - pr.start;
-    const int tile = rel / slabs_per_tile;
-    const int s0 = rel - tile * slabs_per_tile;
-    const int tile_begin = pr.start + tile * slabs_per_tile, tile_end = tile_begin + slabs_per_tile;
-    const int pe = tile_end < c_end ? tile_end : c_end;
-    const int P = pe - pos;                                          // slabs of this piece
+    const int tiles_k = (pr.K + 255) >> 8;
     const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
     const int n0 = tn * 256, k0 = tk * 256;
-    const int first_chunk = tile_begin / g.chunk, last_chunk = (tile_end - 1) / g.chunk;
-    const int nslices = last_chunk - first_chunk + 1, slice = last_chunk - my_chunk;
-    const int M = pr.M;
-    const uint16_t* dy = pr.dy;
-    const uint16_t* x = pr.x;
 
     Stager sg;
-    sg.M = M; sg.row = s0 * SLAB_ROWS + st_row; sg.zeros = reinterpret_cast<const unsigned char*>(g.zeros);
+    sg.M = pr.M; sg.row0 = st_row; sg.zeros = reinterpret_cast<const unsigned char*>(g.zeros);
     sg.col_a = n0 + st_col < pr.N; sg.col_b = k0 + st_col < pr.K;
-    sg.pa = reinterpret_cast<const unsigned char*>(dy + (int64_t)sg.row * pr.ldy + n0 + st_col);
-    sg.pb = reinterpret_cast<const unsigned char*>(x + (int64_t)sg.row * pr.ldx + k0 + st_col);
+    sg.base_a = reinterpret_cast<const unsigned char*>(pr.dy + (int64_t)st_row * pr.ldy + n0 + st_col);
+    sg.base_b = reinterpret_cast<const unsigned char*>(pr.x + (int64_t)st_row * pr.ldx + k0 + st_col);
     sg.step_a = (int64_t)pr.ldy * SLAB_ROWS * 2; sg.step_b = (int64_t)pr.ldx * SLAB_ROWS * 2;
     sg.dst = smem0 + (uint32_t)wid * 1024u;
 
@@ -211,75 +325,18 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // ---- prologue: slabs 0 .. AHEAD-1 in flight, slabs 0 and 1 landed, fragments of slab 0 in registers
-#pragma unroll
-    for (int j = 0; j < AHEAD; ++j)
-      if (j < P) sg.issue(j);
-    if (P >= AHEAD) wait_vm<2 * (AHEAD - 2)>(); else wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::: "memory");
-    Frags f0, f1;
-    read_frags_lo(f0, 0u, a_off, b_off);
-    read_frags_hi(f0, 0u, a_off, b_off);
-
-    // ---- main loop: two slabs per trip (static register sets).  Per slab and wave: 8 MFMAs of the current fragments with
-    // the two DMA instructions of slab q+6 and the 12 reads of slab q+1 spread between them, then the counted wait that
-    // retires slab q+2 and the barrier that publishes it.
-#define W256_PHASE(Q, CUR, NXT, ST)                                                                            \
-  {                                                                                                          \
-    const int q_ = (Q);                                                                                      \
-    const bool more_ = ((ST) || q_ + AHEAD < P) && !no_dma, next_ = (ST) || q_ + 1 < P;                      \
-    const uint32_t nslab_ = (uint32_t)(((q_ + 1) & (RING - 1)) * SLAB_BYTES);                                \
-    if (!no_mma) {                                                                                           \
-    mma32(acc[0][0], CUR.a[0], CUR.b[0]);                                                                    \
-    mma32(acc[0][1], CUR.a[0], CUR.b[1]);                                                                    \
-    }                                                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if (more_) sg.issue((q_ + AHEAD) & (RING - 1));                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if (!no_mma) {                                                                                           \
-    mma32(acc[1][0], CUR.a[1], CUR.b[0]);                                                                    \
-    mma32(acc[1][1], CUR.a[1], CUR.b[1]);                                                                    \
-    } else { asm volatile("" :: "v"(CUR.a[1].x), "v"(CUR.b[0].x), "v"(CUR.b[1].w), "v"(CUR.a[1].w)); }        \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if (next_) read_frags_lo(NXT, nslab_, a_off, b_off);                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if (!no_mma) {                                                                                           \
-    mma32(acc[2][0], CUR.a[2], CUR.b[0]);                                                                    \
-    mma32(acc[2][1], CUR.a[2], CUR.b[1]);                                                                    \
-    } else { asm volatile("" :: "v"(CUR.a[2].x), "v"(CUR.b[0].x), "v"(CUR.b[1].w), "v"(CUR.a[2].w)); }        \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if (next_) read_frags_hi(NXT, nslab_, a_off, b_off);                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if (!no_mma) {                                                                                           \
-    mma32(acc[3][0], CUR.a[3], CUR.b[0]);                                                                    \
-    mma32(acc[3][1], CUR.a[3], CUR.b[1]);                                                                    \
-    } else { asm volatile("" :: "v"(CUR.a[3].x), "v"(CUR.b[0].x), "v"(CUR.b[1].w), "v"(CUR.a[3].w)); }        \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if (more_) wait_vm<2 * (AHEAD - 2)>(); else wait_vm<0>();                                                \
-    __builtin_amdgcn_s_barrier();                                                                            \
-    asm volatile("" ::: "memory");                                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-  }
-    const bool no_mma = g.ablate & 1, no_dma = g.ablate & 2;
-    int q = 0;
-    for (; q + AHEAD + 1 < P; q += 2) {     // steady state: no conditionals inside a slab
-      W256_PHASE(q, f0, f1, true)
-      W256_PHASE(q + 1, f1, f0, true)
-    }
-    for (; q + 1 < P; q += 2) {             // the last AHEAD slabs: nothing left to stage
-      W256_PHASE(q, f0, f1, false)
-      W256_PHASE(q + 1, f1, f0, false)
-    }
-    if (q < P) W256_PHASE(q, f0, f1, false)
-#undef W256_PHASE
+    // the dy strip of this tile is shared with the other tk tiles of its problem, the x strip with the other tn tiles
+    const bool nt_a = (g.policy & 1) && tiles_k == 1, nt_b = (g.policy & 1) && pr.N <= 256;
+    if (nt_a && nt_b) stream_piece<true, true, ABL>(sg, acc, sb, P, rot, a_off, b_off);
+    else if (nt_a) stream_piece<true, false, ABL>(sg, acc, sb, P, rot, a_off, b_off);
+    else if (nt_b) stream_piece<false, true, ABL>(sg, acc, sb, P, rot, a_off, b_off);
+    else stream_piece<false, false, ABL>(sg, acc, sb, P, rot, a_off, b_off);
 
     // ---- accumulate into dw (every DMA has landed and every wave has passed the last barrier: the ring is idle)
     float* dw = pr.dw;
     const int n_base = n0 + 128 * wr, k_base = k0 + 64 * wc;
-    unsigned char* scr = smem + SCRATCH + wid * 4096;
-    if (g.ablate & 4) {
+    unsigned char* scr = smem + wid * 16384;
+    if constexpr ((ABL & 4) != 0) {
     } else if (nslices == 1) {
       flush_tile<false>(acc, dw, pr.ldw, pr.N, pr.K, n_base, k_base, scr, lane);
     } else {
@@ -299,8 +356,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
       __syncthreads();
       if (tid == 0) __hip_atomic_store(flag, slice + 1 == nslices ? 0 : slice + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();                                                 // scratch / ring reuse by the next piece
-    pos = pe;
+    __syncthreads();                                                 // the ring (epilogue scratch) is reused by the next piece
   }
 }
 
@@ -339,25 +395,45 @@ int32_t wgrad256_launch(const W256Item* it, int n, void* workspace, int64_t work
     otr_set_error("wgrad256: %lld slabs do not fit the 32-bit work index", (long long)total);
     return -1;
   }
-  int cap = grid_cap > 0 ? grid_cap : (grid_cap < 0 ? -grid_cap : 256);    // < 0: that many workgroups, plain equal chunks
-  // short chunks make pieces whose epilogue outweighs their work: at least 64 slabs (1024 rows) per workgroup
-  while (cap > 1 && total / cap < 64) cap /= 2;
-  int64_t chunk = (total + cap - 1) / cap;
-  if (same_rows && grid_cap >= 0) {
-    // every tile is R slabs long: make the chunk a whole number of HALF tiles, so that workgroups walk their tiles at one
-    // of two row phases and the tiles of a problem (which share an operand panel) read the same rows at the same time
-    const int64_t R = (it[0].M + SLAB_ROWS - 1) / SLAB_ROWS;
-    const int64_t halves = (2 * (int64_t)flags + cap - 1) / cap;              // half tiles per chunk
-    chunk = (R * halves + 1) / 2;
+  int cap = grid_cap > 0 ? grid_cap : (grid_cap < 0 ? -grid_cap : 248);    // < 0: that many workgroups, stream-K schedule
+  int grid;
+  g.nprob = n; g.total = (int)total; g.spin_limit = 1 << 22; g.ablate = ablate & 7; g.policy = ablate >> 3 ? (ablate >> 3) - 1 : 1;
+  if (same_rows && grid_cap >= 0 && flags >= 8) {
+    // Rounds: every tile is R slabs long.  G slots (whole XCD groups) each walk one whole tile per round -- the tiles of a
+    // problem sit in neighbouring slots of one XCD and read their shared operand panel in step -- and the tiles left over
+    // after the full rounds are cut into `parts` row ranges so that they fill the slots once more.
+    const int R = (it[0].M + SLAB_ROWS - 1) / SLAB_ROWS, T = flags;
+    double best = 1e30;
+    int bestG = 8;
+    for (int G = cap / 8 * 8; G >= 8 && G >= cap / 2; G -= 8) {
+      const int nfull = T / G, rem = T - nfull * G, parts = rem ? std::min(G / rem, 8) : 1;
+      const double cost = nfull + (rem ? 1.0 / parts + 0.02 : 0.0);           // + a piece's fill / drain
+      if (cost < best - 1e-9) { best = cost; bestG = G; }
+    }
+    grid = bestG;
+    g.mode = 1; g.chunk = R;
+    g.nfull = T / grid; g.rem_tiles = T - g.nfull * grid; g.parts = g.rem_tiles ? std::min(grid / g.rem_tiles, 8) : 1;
+  } else {
+    // Stream-K: short chunks make pieces whose epilogue outweighs their work: at least 64 slabs (1024 rows) per workgroup
+    while (cap > 1 && total / cap < 64) cap /= 2;
+    const int64_t chunk = (total + cap - 1) / cap;
+    grid = (int)((total + chunk - 1) / chunk);
+    if (grid >= 8) grid = (grid + 7) / 8 * 8;       // whole XCD groups; the extra chunks are empty
+    g.mode = 0; g.chunk = (int)chunk;
   }
-  int grid = (int)((total + chunk - 1) / chunk);
-  if (grid >= 8) grid = (grid + 7) / 8 * 8;       // whole XCD groups; the extra chunks are empty
-  g.nprob = n; g.total = (int)total; g.spin_limit = 1 << 22; g.ablate = ablate;
-  g.chunk = (int)chunk;
   g.zeros = workspace;
   g.flags = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(workspace) + 64);
   hipLaunchKernelGGL(wgrad256_init_kernel, dim3(1), dim3(256), 0, s, g.flags, flags, reinterpret_cast<uint32_t*>(workspace));
-  hipLaunchKernelGGL(wgrad256_kernel, dim3((unsigned)grid), dim3(512), 0, s, g);
+  switch (ablate & 7) {
+    case 0: hipLaunchKernelGGL(wgrad256_kernel<0>, dim3((unsigned)grid), dim3(512), 0, s, g); break;
+    case 1: hipLaunchKernelGGL(wgrad256_kernel<1>, dim3((unsigned)grid), dim3(512), 0, s, g); break;
+    case 2: hipLaunchKernelGGL(wgrad256_kernel<2>, dim3((unsigned)grid), dim3(512), 0, s, g); break;
+    case 3: hipLaunchKernelGGL(wgrad256_kernel<3>, dim3((unsigned)grid), dim3(512), 0, s, g); break;
+    case 4: hipLaunchKernelGGL(wgrad256_kernel<4>, dim3((unsigned)grid), dim3(512), 0, s, g); break;
+    case 5: hipLaunchKernelGGL(wgrad256_kernel<5>, dim3((unsigned)grid), dim3(512), 0, s, g); break;
+    case 6: hipLaunchKernelGGL(wgrad256_kernel<6>, dim3((unsigned)grid), dim3(512), 0, s, g); break;
+    default: hipLaunchKernelGGL(wgrad256_kernel<7>, dim3((unsigned)grid), dim3(512), 0, s, g); break;
+  }
   return otr_check_launch("wgrad256");
 }
 

@@ -83,6 +83,8 @@ def main():
     for ab in [int(v) for v in a.ablate.split(',') if v]:
         lib.otr_debug_set(8, ab)
         out['ablate%d_grid-248_ms' % ab] = timed(1, -248)
+        if ab >= 8:
+            out['ablate%d_grid0_ms' % ab] = timed(1, 0)
     lib.otr_debug_set(8, 0)
     lib.otr_debug_set(6, -1)
     lib.otr_debug_set(7, 0)
