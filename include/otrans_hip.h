@@ -123,6 +123,27 @@ int32_t otr_ffn_bwd(const void* x16, const void* dy16, const void* w1_pack, cons
                     const void* w1t_pack, void* dh, void* u, float* db1_part, const float* skip, float* dx, int64_t M,
                     int32_t F, int32_t d_model, void* stream);
 
+/* ---- row-block projections of the attention sub-layers (module/attention.py:62-75 qvk_proj / output_proj, :120-140 q_proj /
+ *      output_proj with the residual + LayerNorm of encoder/transformer.py:47-56, decoder/transformer.py:58-80), d_model = 256,
+ *      16-bit operands.  Same structure as the fused FFN: 32 rows per workgroup, packed weights (otr_pack_frags, perm 0)
+ *      streamed from L2, whole-row epilogues.
+ * otr_rb_linear:  out[M,N] = x16[M,K] . W^T (+ bias) (+ skip), (N,K) in {(256,256), (768,256), (256,768)}; w_pack =
+ *   pack(W as A[n][k]); for an input gradient pass dy16 as x16 and pack(W as A[k][n]) (rows = K inputs).  out f32 or 16-bit.
+ * otr_proj_ln_fwd:  y = LayerNorm(x + dropout(c16 . W^T + bias)); outputs as otr_add_layernorm_fwd (y16, z may be NULL).
+ * otr_ln_bwd_proj:  the LayerNorm backward of that sub-layer -- dx[M,256] f32 (may be NULL), da16 = dropout-masked gradient
+ *   of the projection output (16-bit, the weight-gradient operand; may be NULL), partial f32
+ *   [otr_ln_bwd_proj_partial_rows(M)][3][256] = per-workgroup sums of dgamma | dbeta | da (may be NULL) -- followed in
+ *   the same launch by dc16 = da . W (16-bit, row stride ldc).  wt_pack = pack(W as A[k][n]). */
+int32_t otr_rb_linear(const void* x16, int64_t ldx, const void* w_pack, const float* bias, const float* skip, int64_t lds,
+                      void* out, int32_t out_dtype, int64_t ldo, int64_t M, int32_t N, int32_t K, void* stream);
+int32_t otr_proj_ln_fwd(const float* x, const void* c16, int64_t ldc, const void* w_pack, const float* bias, const float* gamma,
+                        const float* beta, const uint64_t* seed, float* y, void* y16, float* z, float* mean, float* rstd,
+                        int64_t M, int32_t d_model, float eps, float p_drop, uint64_t rng_offset, void* stream);
+int64_t otr_ln_bwd_proj_partial_rows(int64_t M);
+int32_t otr_ln_bwd_proj(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                        const uint64_t* seed, const void* wt_pack, float* dx, void* da16, void* dc16, int64_t ldc,
+                        float* partial, int64_t M, int32_t d_model, float p_drop, uint64_t rng_offset, void* stream);
+
 /* ---- the same sub-layer with the weight stream SHARED by 128 rows (v2, experimental: OTR_FFN_V2=1): a workgroup owns
  *      128 rows x 1/n_slabs of the hidden units, fetches every packed weight fragment once (global -> LDS, direct DMA)
  *      for its four waves, and leaves fp32 partial sums: slabs [n_slabs][M][256].

@@ -85,6 +85,10 @@ SIGNATURES = {
     'otr_add_layernorm_fwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_add_layernorm_bwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_add_layernorm_bwd_partial_rows': [_I64],
+    'otr_rb_linear': [_P, _I64, _P, _P, _P, _I64, _P, _I32, _I64, _I64, _I32, _I32, _P],
+    'otr_proj_ln_fwd': [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F32, _F32, C.c_uint64, _P],
+    'otr_ln_bwd_proj_partial_rows': [_I64],
+    'otr_ln_bwd_proj': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I32, _F32, C.c_uint64, _P],
     'otr_debug_trace': [_P],
     'otr_debug_trread': [_P, _P, _P, _P],
     'otr_spec_mask': [_P, _P, _I32, _I32, _I32, _I32, _P],
@@ -130,7 +134,8 @@ SIGNATURES = {
     'otr_bn_swish_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _F32, _F32, _I32, _P],
     'otr_bn_swish_bwd': [_P, _P, _I32, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
 }
-_RESTYPE = {'otr_last_error_string': C.c_char_p, 'otr_add_layernorm_bwd_partial_rows': C.c_int64}
+_RESTYPE = {'otr_last_error_string': C.c_char_p, 'otr_add_layernorm_bwd_partial_rows': C.c_int64,
+            'otr_ln_bwd_proj_partial_rows': C.c_int64}
 
 _libs = {}
 _kind = 'bf16'

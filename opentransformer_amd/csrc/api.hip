@@ -42,7 +42,7 @@ int g_otr_force_generic = 0;
 int g_otr_no_persist = 0;
 int g_otr_ffn_waves = 4;   // 8 measured SLOWER (85 vs 61 us forward): see DESIGN.md
 int g_otr_ffn2_ablate = 0;   // tuning hook (otr_debug_set(4, v)): bit 0 = no weight DMA after the first chunk, bit 1 = no MFMA work
-int g_otr_wgrad256 = -1;     // 256x256-tile weight-gradient launch (wgrad256.hip): -1 = environment OTR_WGRAD256 (default off until measured), 0 / 1 (otr_debug_set(6, v))
+int g_otr_wgrad256 = -1;     // 256x256-tile weight-gradient launch (wgrad256.hip): -1 = environment OTR_WGRAD256 (default on), 0 / 1 (otr_debug_set(6, v))
 int g_otr_wgrad256_ablate = 0;   // tuning hook (otr_debug_set(8, v)), see wgrad256.h
 int g_otr_wgrad256_grid = 0; // workgroups of that launch; 0 = one per CU (otr_debug_set(7, v))
 unsigned long long* g_otr_trace = nullptr;
@@ -213,7 +213,7 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
   const int pm = compute == OTR_H16 ? 4 : 2;
   if (g_otr_wgrad256 < 0) {
     const char* e = getenv("OTR_WGRAD256");
-    g_otr_wgrad256 = (e && e[0] == '1') ? 1 : 0;
+    g_otr_wgrad256 = (e && e[0] == '0') ? 0 : 1;
   }
   hipStream_t s = (hipStream_t)stream;
   // Long-contraction 16-bit problems whose output is made of whole 256 x 256 tiles: ONE persistent launch with 256-wide

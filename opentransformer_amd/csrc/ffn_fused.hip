@@ -291,36 +291,54 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void ffn_ln_fwd_kernel(FfnFwdArgs 
     const int64_t row = min((int64_t)row0 + wid * RPW + i, (int64_t)p.M - 1);
     xr[i] = *reinterpret_cast<const float4*>(p.x + row * D + col);
   }
+  // the wave's rows are normalised TOGETHER: their butterfly steps are independent, so the cross-lane latency is paid
+  // 12 times per wave instead of 12 x RPW (rowblock.hip: one row after the other it was ~5 us of a launch)
+  float v[RPW][4], sm[RPW], qq[RPW];
 #pragma unroll
   for (int i = 0; i < RPW; ++i) {
     const int r = wid * RPW + i;
-    const int64_t row = (int64_t)row0 + r;
-    float v[4] = {b2.x, b2.y, b2.z, b2.w};
+    const int64_t row = min((int64_t)row0 + r, (int64_t)p.M - 1);
+    float t4[4] = {b2.x, b2.y, b2.z, b2.w};
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const float4 t = *reinterpret_cast<const float4*>(red + (w * FF_RB + r) * YP + col);
-      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+      t4[0] += t.x; t4[1] += t.y; t4[2] += t.z; t4[3] += t.w;
     }
-    if (row >= p.M) continue;                               // wave-uniform
     const float xv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
-    float s = 0.f;
+    sm[i] = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float sc = 1.f;
       if (drop) sc = otr_rand32(seed, p.rng_offset + (uint64_t)(row * D + col + e)) >= thr ? inv_keep : 0.f;
-      v[e] = xv[e] + v[e] * sc;
-      s += v[e];
+      v[i][e] = xv[e] + t4[e] * sc;
+      sm[i] += v[i][e];
     }
-    if (p.z) *reinterpret_cast<float4*>(p.z + row * D + col) = make_float4(v[0], v[1], v[2], v[3]);
-    const float mean = wave_sum(s) * (1.f / D);
-    float qq = 0.f;
+  }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const float t = v[e] - mean; qq += t * t; }
-    const float rstd = rsqrtf(wave_sum(qq) * (1.f / D) + p.eps);
-    const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) sm[i] += __shfl_xor(sm[i], o);
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    sm[i] *= (1.f / D);
+    qq[i] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float t = v[i][e] - sm[i]; qq[i] += t * t; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) qq[i] += __shfl_xor(qq[i], o);
+  const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int64_t row = (int64_t)row0 + wid * RPW + i;
+    if (row >= p.M) break;                                  // wave-uniform
+    const float mean = sm[i], rstd = rsqrtf(qq[i] * (1.f / D) + p.eps);
+    if (p.z) *reinterpret_cast<float4*>(p.z + row * D + col) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
     float o[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * g4[e] + b4[e];
+    for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
     *reinterpret_cast<float4*>(p.y + row * D + col) = make_float4(o[0], o[1], o[2], o[3]);
     if (p.y16) *reinterpret_cast<uint2*>(p.y16 + row * D + col) = make_uint2(pack2h(o[0], o[1]), pack2h(o[2], o[3]));
     if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }

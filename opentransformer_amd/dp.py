@@ -107,6 +107,19 @@ class FlatDataParallel:
             rows += r
             views.append((w1, offs, F2 * d, d * (F2 // 2)))
             total += n
+        # the attention projections the row-block kernels take (ops.lin_packs): forward + input-gradient pack each
+        lin_views = []
+        for mod in module.modules():
+            for name in ('qvk_proj', 'q_proj', 'output_proj'):
+                w = getattr(getattr(mod, name, None), 'weight', None)
+                if w is None or id(w) not in off_of or w.dim() != 2 or tuple(w.shape) not in ops._RB_SHAPES or not ops._RB:
+                    continue
+                if any(w is v[0] for v in lin_views):
+                    continue
+                r, n = ops.lin_pack_items(off_of[id(w)], w.shape[0], w.shape[1], total)
+                rows += r
+                lin_views.append((w, total, w.numel()))
+                total += n
         if not rows:
             return
         self.flat_pack = torch.empty(total, device=dev, dtype=self.flat_param_lp.dtype)
@@ -119,6 +132,8 @@ class FlatDataParallel:
         for w1, offs, n1, n2 in views:
             w1._otr_ffn_packs = (self.flat_pack[offs[0]:offs[0] + n1], self.flat_pack[offs[1]:offs[1] + n2],
                                  self.flat_pack[offs[2]:offs[2] + n2], self.flat_pack[offs[3]:offs[3] + n1])
+        for w, o, n in lin_views:
+            w._otr_lin_packs = (self.flat_pack[o:o + n], self.flat_pack[o + n:o + 2 * n])
 
     def refresh_lp(self):
         """re-cast the 16-bit shadows after any out-of-band parameter change (load_state_dict, broadcast, ...)."""

@@ -179,6 +179,15 @@ class MultiHeadedCrossAttention(nn.Module):
     def forward(self, query, memory, memory_mask, defer_bias=False, link=None, kv_all=None):
         """kv_all = (projection of the memory by ALL decoder layers' vk_proj in one GEMM, this layer's slice index, shared
         bookkeeping): TransformerDecoder.forward builds it once per pass (ops.CrossKVAllFn)."""
+        ctx = self.context(query, memory, memory_mask, link, kv_all)
+        if self.dropout_rate and self.training:   # dropout(output_proj(ctx)): bias inside the mask, not deferrable
+            out = ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, out_dtype=ops.act_dtype() if defer_bias else None)
+            return ops.dropout(out, self.dropout_rate), None
+        return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, defer_bias=defer_bias,
+                          out_dtype=ops.act_dtype() if defer_bias else None), None
+
+    def context(self, query, memory, memory_mask, link=None, kv_all=None):
+        """merged-head attention context before output_proj (act dtype)"""
         B, T, _ = memory.shape
         adt = ops.act_dtype()
         q = ops.linear(query, self.q_proj.weight, self.q_proj.bias, out_dtype=adt, link=link)
@@ -189,11 +198,7 @@ class MultiHeadedCrossAttention(nn.Module):
             if self.share_vk_proj:           # key = value (module/attention.py:131-132)
                 kv = torch.cat((kv, kv), dim=-1)
             ctx = ops.CrossAttentionFn.apply(q, kv, _key_mask(memory_mask, B, T), self.nheads)
-        if self.dropout_rate and self.training:   # dropout(output_proj(ctx)): bias inside the mask, not deferrable
-            out = ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, out_dtype=ops.act_dtype() if defer_bias else None)
-            return ops.dropout(out, self.dropout_rate), None
-        return ops.linear(ctx, self.output_proj.weight, self.output_proj.bias, defer_bias=defer_bias,
-                          out_dtype=ops.act_dtype() if defer_bias else None), None
+        return ctx
 
     def inference(self, query, memory, memory_mask, cache=None):
         out, w = self.forward(query, memory, memory_mask)
@@ -271,6 +276,23 @@ def _attention_branch(layer, concat_linear, x, p, run):
     return att, bias, p, link
 
 
+def _attn_sublayer(layer, concat_linear, norm, attn, x, p, run, run_ctx):
+    """LN(x + dropout(attention branch)).  When the row-block kernels apply (16-bit mode, d_model 256, no concat_after, no
+    dropout inside the attention module) output_proj + residual + LayerNorm are ONE launch (ops.ProjLnFn); `run_ctx(link)`
+    returns the attention context before output_proj, `run(**kw)` the projected branch of the generic path."""
+    if not layer.concat_after and run_ctx is not None and not (attn.dropout_rate and attn.training) and x.is_cuda:
+        link = ops.new_link()
+        c = run_ctx(link)
+        packs = ops.proj_ln_packs(x, c, attn.output_proj.weight, norm.weight)
+        if packs is not None:
+            return ops.proj_add_layernorm(x, c, attn.output_proj.weight, attn.output_proj.bias, norm.weight, norm.bias, p, norm.eps,
+                                          packs, link)
+        branch = ops.linear(c, attn.output_proj.weight, attn.output_proj.bias, defer_bias=True, out_dtype=ops.act_dtype())
+        return _post_norm(norm, x, branch, p, True, attn.output_proj.bias, link)
+    branch, bias, p1, link = _attention_branch(layer, concat_linear, x, p, run)
+    return _post_norm(norm, x, branch, p1, True, bias, link)
+
+
 # ------------------------------------------------------------------------------------- encoder
 class TransformerEncoderLayer(nn.Module):
     """encoder/transformer.py:16-90.  Post-norm: x = LN1(x + drop(SA(x))); x = LN2(x + drop(FFN(x))).  Pre-norm as the
@@ -305,8 +327,9 @@ class TransformerEncoderLayer(nn.Module):
                 return self.slf_attn(x, mask, pos)[0], None
             att, _ = self.slf_attn(x, mask, causal, **kw)
             return att, _deferred_bias(self.slf_attn)
-        branch, bias, p1, link = _attention_branch(self, getattr(self, 'concat_linear', None), x, p, run)
-        x = _post_norm(self.norm2 if pre else self.norm1, x, branch, p1, True, bias, link)
+        run_ctx = None if self.relative_positional else (lambda link: self.slf_attn.context(x, mask, causal, link))
+        x = _attn_sublayer(self, getattr(self, 'concat_linear', None), self.norm2 if pre else self.norm1, self.slf_attn, x, p, run,
+                           run_ctx)
         if pre:
             x = ops.residual_add(x, self.feed_forward(x), 1.0, p)
         else:
@@ -534,14 +557,16 @@ class TransformerDecoderLayer(nn.Module):
         def run_self(**kw):
             att, _ = self.slf_attn(x, tgt_mask, causal=tgt_mask is None, **kw)
             return att, _deferred_bias(self.slf_attn)
-        branch, bias, p1, link = _attention_branch(self, getattr(self, 'concat_linear1', None), x, p, run_self)
-        x = _post_norm(norms[0], x, branch, p1, True, bias, link)
+        x0 = x
+        x = _attn_sublayer(self, getattr(self, 'concat_linear1', None), norms[0], self.slf_attn, x0, p, run_self,
+                           lambda link: self.slf_attn.context(x0, tgt_mask, tgt_mask is None, link))
 
         def run_src(**kw):
             att, _ = self.src_attn(x, memory, memory_mask, kv_all=kv_all, **kw)
             return att, _deferred_bias(self.src_attn)
-        branch, bias, p2, link = _attention_branch(self, getattr(self, 'concat_linear2', None), x, p, run_src)
-        x = _post_norm(norms[1], x, branch, p2, True, bias, link)
+        x1 = x
+        x = _attn_sublayer(self, getattr(self, 'concat_linear2', None), norms[1], self.src_attn, x1, p, run_src,
+                           lambda link: self.src_attn.context(x1, memory, memory_mask, link, kv_all))
         if pre:
             x = ops.residual_add(x, self.feed_forward(x), 1.0, p)
         else:

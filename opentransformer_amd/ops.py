@@ -428,6 +428,58 @@ def _rows(x):
     return x2
 
 
+# ---------------------------------------------------------------------------------------- row-block projections
+# The skinny projections of the attention sub-layers (q|k|v, q, output_proj; N, K in {256, 768}) run as row-block kernels
+# (csrc/rowblock.hip) on fragment-major packs of the weight: `fwd` = pack(W as A[n][k]) and `dgrad` = pack(W as A[k][n]),
+# slices of FlatDataParallel's pack buffer (refreshed with the FFN packs after every optimizer step) or, for stand-alone
+# modules, a cache keyed by the parameter version.
+_RB = os.environ.get('OTR_NO_ROWBLOCK', '0') != '1'
+_RB_SHAPES = ((256, 256), (768, 256))          # (N, K) of the Linear
+
+
+def lin_pack_items(w_off, N, K, dst_off):
+    """otr_pack_frags table rows for one Linear weight [N, K]: forward pack, input-gradient pack; elements used"""
+    return [[w_off, K, 1, N, K, 0, dst_off], [w_off, 1, K, K, N, 0, dst_off + N * K]], 2 * N * K
+
+
+def lin_packs(w):
+    """(fwd_pack, dgrad_pack) of a Linear weight, or None when the row-block kernels do not apply"""
+    if not _RB or _state['compute'] == 'fp32' or w is None or w.dim() != 2 or not w.is_cuda or tuple(w.shape) not in _RB_SHAPES:
+        return None
+    views = getattr(w, '_otr_lin_packs', None)
+    if views is not None:
+        return views
+    key = (w._version, w.data_ptr(), _state['compute'])
+    cache = getattr(w, '_otr_lin_pack_cache', None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    N, K = w.shape
+    src = weight_lp(w).reshape(-1)
+    rows, total = lin_pack_items(0, N, K, 0)
+    dst = torch.empty(total, dtype=src.dtype, device=src.device)
+    pack_frags(src, dst, rows)
+    packs = (dst[:N * K], dst[N * K:])
+    w._otr_lin_pack_cache = (key, packs)
+    return packs
+
+
+def _rb_rows_ok(t2):
+    """[M, C] 16-bit rows the row-block kernels can read: unit column stride, 16-byte aligned rows"""
+    return (t2 is not None and t2.dtype == half_dtype() and t2.dim() == 2 and t2.stride(1) == 1 and t2.stride(0) % 8 == 0
+            and t2.data_ptr() % 16 == 0)
+
+
+def rb_linear_raw(x2, pack, N, bias, out_dtype, skip=None):
+    """out[M,N] = x2 . W^T (+ bias) (+ skip, which may be the output buffer itself) through otr_rb_linear"""
+    M, K = x2.shape
+    out = skip if (skip is not None and skip.dtype == out_dtype) else torch.empty((M, N), dtype=out_dtype, device=x2.device)
+    L.check(_timed('rb_linear %dx%dx%d' % (M, N, K), {'flops': 2.0 * M * N * K},
+                   lambda: L.load().otr_rb_linear(_p(x2), x2.stride(0), _p(pack), _p(bias), _p(skip),
+                                                  skip.stride(0) if skip is not None else 0, _p(out), _code(out_dtype), out.stride(0),
+                                                  M, N, K, _stream())), 'otr_rb_linear')
+    return out
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x w^T + b): nn.Linear of the reference (e.g. module/attention.py:43,68).
 
@@ -448,7 +500,13 @@ class LinearFn(torch.autograd.Function):
         if perm is not None:
             C_, F_ = perm
             wc = wc.view(-1, C_, F_).permute(0, 2, 1).reshape(w.shape[0], F_ * C_).contiguous()
-        y = linear_fwd_raw(x2, wc, b, out_dtype, L.ACT_RELU if relu else L.ACT_NONE)
+        packs = lin_packs(w) if (perm is None and not relu and _rb_rows_ok(x2) and x2.shape[0] > 0
+                                 and (b is None or b.data_ptr() % 16 == 0)) else None
+        ctx.rb = packs
+        if packs is not None:
+            y = rb_linear_raw(x2, packs[0], w.shape[0], b, out_dtype)
+        else:
+            y = linear_fwd_raw(x2, wc, b, out_dtype, L.ACT_RELU if relu else L.ACT_NONE)
         ctx.relu = relu
         ctx.has_bias = b is not None
         ctx.perm = perm
@@ -469,7 +527,9 @@ class LinearFn(torch.autograd.Function):
             skip = None
             if ctx.link is not None and ctx.link.buf is not None:      # skip-connection gradient handed over by the LN
                 skip, ctx.link.buf = ctx.link.buf, None
-            if ctx.wt is not None:      # dx = dy . w as a forward-type GEMM on the transposed shadow
+            if ctx.rb is not None and _rb_rows_ok(dy2) and (skip is None or (skip.dtype == ctx.xdtype and skip.stride(0) % 4 == 0)):
+                dx = rb_linear_raw(dy2, ctx.rb[1], wc.shape[1], None, ctx.xdtype, skip=skip).view(ctx.xshape)
+            elif ctx.wt is not None:      # dx = dy . w as a forward-type GEMM on the transposed shadow
                 dx = linear_fwd_raw(dy2, ctx.wt, None, ctx.xdtype, out=skip).view(ctx.xshape)
             else:
                 dx = linear_dgrad_raw(dy2, wc, ctx.xdtype, out=skip).view(ctx.xshape)
@@ -813,6 +873,95 @@ def add_layernorm(x, a, gamma, beta, p_drop=0.0, eps=1e-5, a_bias=None, link=Non
     """a_bias: the bias parameter of the Linear that produced `a` (called with defer_bias=True); its gradient
     (column sums of d loss / d a) is then reduced inside the LayerNorm backward kernel."""
     y, ylp = AddLayerNormFn.apply(x, a, gamma, beta, float(p_drop), float(eps), a_bias, link)
+    return attach_lp(y, ylp)
+
+
+class ProjLnFn(torch.autograd.Function):
+    """y = LayerNorm(x + dropout(c . W^T + b)): output projection + residual + LayerNorm of an attention sub-layer
+    (module/attention.py:75,140 + encoder/transformer.py:54-56, decoder/transformer.py:66-80) in ONE launch forward;
+    backward = LayerNorm backward + the projection's input gradient in one launch (csrc/rowblock.hip), the weight / bias /
+    affine gradients join the grouped launches at the end of the pass."""
+
+    @staticmethod
+    def forward(ctx, x, c, w, b, gamma, beta, p_drop, eps, packs, link):
+        _cuda(x, c, w, gamma, beta)
+        ctx.set_materialize_grads(False)
+        ctx.link = link
+        if link is not None:
+            link.armed = bool(ctx.needs_input_grad[0])
+        d = x.shape[-1]
+        x2 = x.reshape(-1, d).contiguous()
+        c2 = _rows(c)
+        M = x2.shape[0]
+        need_grad = any(ctx.needs_input_grad)
+        y = torch.empty_like(x2)
+        ylp = torch.empty(x2.shape, dtype=half_dtype(), device=x.device)
+        z = torch.empty_like(x2) if need_grad else None
+        mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        seed = rng_seed_tensor(x.device) if p_drop > 0 else None
+        off = _next_rng_offset(M * d) if p_drop > 0 else 0
+        L.check(_timed('proj_ln_fwd', {'flops': 2.0 * M * d * d},
+                       lambda: L.load().otr_proj_ln_fwd(_p(x2), _p(c2), c2.stride(0), _p(packs[0]), _p(b), _p(gamma), _p(beta), _p(seed),
+                                                        _p(y), _p(ylp), _p(z), _p(mean), _p(rstd), M, d, eps, p_drop, off, _stream())),
+                'otr_proj_ln_fwd')
+        ctx.save_for_backward(z, mean, rstd, gamma, seed, c2)
+        ctx.refs = (w, b, gamma, beta)
+        ctx.cfg = (M, d, p_drop, off, x.shape, c.shape, packs)
+        ylp = ylp.view(x.shape)
+        ctx.mark_non_differentiable(ylp)
+        return y.view(x.shape), ylp
+
+    @staticmethod
+    def backward(ctx, dy, _dylp=None):
+        if dy is None:
+            return (None,) * 10
+        z, mean, rstd, gamma, seed, c2 = ctx.saved_tensors
+        w, b, g_ref, b_ref = ctx.refs
+        M, d, p_drop, off, xshape, cshape, packs = ctx.cfg
+        dy2 = dy.reshape(-1, d).contiguous()
+        dx = torch.empty_like(dy2)
+        da = torch.empty((M, d), dtype=half_dtype(), device=dy.device)
+        dc = torch.empty((M, d), dtype=half_dtype(), device=dy.device)
+        nrow = L.load().otr_ln_bwd_proj_partial_rows(M)
+        part = torch.empty((nrow, 3 * d), dtype=torch.float32, device=dy.device)
+        L.check(_timed('ln_bwd_proj', {'flops': 2.0 * M * d * d},
+                       lambda: L.load().otr_ln_bwd_proj(_p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed), _p(packs[1]), _p(dx),
+                                                        _p(da), _p(dc), dc.stride(0), _p(part), M, d, p_drop, off, _stream())),
+                'otr_ln_bwd_proj')
+        outs = []
+        for k, ref in ((0, g_ref), (1, b_ref), (2, b)):
+            if ref is None:
+                outs.append(None)
+                continue
+            gt = grad_target(ref)
+            sl = part[:, k * d:(k + 1) * d]
+            if gt is not None:
+                colsum_raw(sl, out=gt)
+                outs.append(None)
+            else:
+                outs.append(colsum_raw(sl))
+        dgamma, dbeta, dbias = outs
+        gw = grad_target(w)
+        dw = linear_wgrad_raw(da, c2, w, out=gw)
+        dx_ret = dx.view(xshape)
+        if ctx.link is not None and ctx.link.armed and ctx.needs_input_grad[0]:
+            ctx.link.buf = dx           # the branch's first Linear adds its input gradient into this and returns the sum
+            dx_ret = None
+        return (dx_ret, dc.view(cshape), None if gw is not None else dw, dbias, dgamma, dbeta, None, None, None, None)
+
+
+def proj_ln_packs(x, c, w, gamma):
+    """packs of `w` when LN(x + drop(c . w^T + b)) can run as the row-block kernels, else None"""
+    if not is_half() or x.dtype != torch.float32 or x.shape[-1] != 256 or tuple(w.shape) != (256, 256) or gamma is None:
+        return None
+    if c.dtype != half_dtype() or not _rb_rows_ok(_rows(c)):
+        return None
+    return lin_packs(w)
+
+
+def proj_add_layernorm(x, c, w, b, gamma, beta, p_drop, eps, packs, link=None):
+    y, ylp = ProjLnFn.apply(x, c, w, b, gamma, beta, float(p_drop), float(eps), packs, link)
     return attach_lp(y, ylp)
 
 

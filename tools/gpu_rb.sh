@@ -1,0 +1,15 @@
+#!/bin/bash
+TAG=${1:-rb}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 300 python -m pytest tests/test_gpu_rowblock.py -q --timeout 120 -p no:cacheprovider > $OUT/pytest_rb.log 2>&1
+echo "pytest rowblock exit $?"; grep -E "^(FAILED|ERROR)|passed|failed|^E  " $OUT/pytest_rb.log | cut -c1-250 | head -30
+timeout 900 python -m pytest tests -m gpu -q -n 2 --timeout 300 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
+echo "pytest all exit $?"; grep -E "^(FAILED|ERROR)|passed|failed|^E  " $OUT/pytest_gpu.log | sed -e 's/ - .*//' | cut -c1-250 | head -30
+for v in 1 0; do
+OTR_NO_ROWBLOCK=$v timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_norb$v.log 2>&1; echo "bench OTR_NO_ROWBLOCK=$v exit $?"; grep -v amdgpu.ids $OUT/bench_norb$v.log | tail -1 | cut -c1-330
+done
+R=$PWD
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_rb -o graph -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $R/$OUT/rocprof.log 2>&1; echo "rocprof exit $?")
+python tools/prof_summary.py /tmp/prof_rb/graph_results.db 6 > $OUT/kernel_summary_graph.txt 2>&1; head -36 $OUT/kernel_summary_graph.txt | cut -c1-170
