@@ -171,7 +171,11 @@ typedef struct {
   int32_t M, N, K;
   int64_t ldy, ldx, ldw;
   int32_t dy_dtype, x_dtype;
+  float* dbias;          /* NULL, or [N]: dbias += column sums of dy (the bias gradient of the same Linear), folded into the
+                          * 256-wide launch -- allowed only on items for which otr_wgrad256_takes() returns 1 */
 } otr_wgrad_item_t;
+/* 1 when otr_linear_wgrad_grouped would run this item on the 256-wide kernel (csrc/wgrad256.hip), else 0 */
+int32_t otr_wgrad256_takes(const otr_wgrad_item_t* item, int32_t compute);
 int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32_t n, int32_t compute, void* workspace,
                                  int64_t workspace_bytes, void* stream);
 typedef struct {

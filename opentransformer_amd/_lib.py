@@ -26,7 +26,7 @@ class LinearDesc(C.Structure):
 class WgradItem(C.Structure):               # otr_wgrad_item_t
     _fields_ = [('dy', C.c_void_p), ('x', C.c_void_p), ('dw', C.c_void_p), ('M', C.c_int32), ('N', C.c_int32),
                 ('K', C.c_int32), ('ldy', C.c_int64), ('ldx', C.c_int64), ('ldw', C.c_int64),
-                ('dy_dtype', C.c_int32), ('x_dtype', C.c_int32)]
+                ('dy_dtype', C.c_int32), ('x_dtype', C.c_int32), ('dbias', C.c_void_p)]
 
 
 class ColsumItem(C.Structure):              # otr_colsum_item_t
@@ -90,6 +90,7 @@ SIGNATURES = {
     'otr_ln_bwd_proj_partial_rows': [_I64],
     'otr_ln_bwd_proj': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I32, _F32, C.c_uint64, _P],
     'otr_debug_trace': [_P],
+    'otr_wgrad256_takes': [C.POINTER(WgradItem), _I32],
     'otr_debug_trread': [_P, _P, _P, _P],
     'otr_spec_mask': [_P, _P, _I32, _I32, _I32, _I32, _P],
     'otr_transpose_batched': [_P, _P, _P, _I32, _I64, _I32, _P],

@@ -206,15 +206,31 @@ extern "C" int32_t otr_ffn_glu_bwd(const void* dy, int32_t dy_dtype, int64_t ldy
 
 // ------------------------------------------------------------------------------------------------
 // All weight gradients of a backward pass in (a few) grouped launches: dw_i[N,K] += dy_i[M,N]^T x_i[M,K].
+// the problems the 256-wide launch takes: long contraction, 16-bit operands in 16-byte aligned rows, a few tiles at least
+static bool wgrad256_ok(const otr_wgrad_item_t& it, int compute) {
+  return compute == OTR_H16 && it.dy && it.x && it.dw && it.dy_dtype == OTR_H16 && it.x_dtype == OTR_H16 && it.M >= 1024 && it.N >= 128 &&
+         it.K >= 128 && it.N % 8 == 0 && it.K % 8 == 0 && it.ldy >= it.N && it.ldx >= it.K && it.ldw >= it.K && it.ldy % 8 == 0 &&
+         it.ldx % 8 == 0 && it.ldw % 4 == 0 && (uintptr_t)it.dy % 16 == 0 && (uintptr_t)it.x % 16 == 0 && (uintptr_t)it.dw % 16 == 0 &&
+         it.ldy < (1ll << 24) && it.ldx < (1ll << 24) && (int64_t)(it.N + 256) * it.ldw * 4 < (1ll << 31) &&
+         (!it.dbias || (uintptr_t)it.dbias % 4 == 0);
+}
+static void wgrad256_env() {
+  if (g_otr_wgrad256 < 0) {
+    const char* e = getenv("OTR_WGRAD256");
+    g_otr_wgrad256 = (e && e[0] == '0') ? 0 : 1;
+  }
+}
+extern "C" int32_t otr_wgrad256_takes(const otr_wgrad_item_t* item, int32_t compute) {
+  wgrad256_env();
+  return (item && g_otr_wgrad256 && wgrad256_ok(*item, compute)) ? 1 : 0;
+}
+
 extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32_t n, int32_t compute, void* workspace,
                                             int64_t workspace_bytes, void* stream) {
   OTR_REQUIRE(n >= 0 && (items || n == 0), "linear_wgrad_grouped: null items");
   OTR_REQUIRE(compute == OTR_H16 || compute == OTR_F32, "linear_wgrad_grouped: bad compute type");
   const int pm = compute == OTR_H16 ? 4 : 2;
-  if (g_otr_wgrad256 < 0) {
-    const char* e = getenv("OTR_WGRAD256");
-    g_otr_wgrad256 = (e && e[0] == '0') ? 0 : 1;
-  }
+  wgrad256_env();
   hipStream_t s = (hipStream_t)stream;
   // Long-contraction 16-bit problems whose output is made of whole 256 x 256 tiles: ONE persistent launch with 256-wide
   // tiles fed by direct-to-LDS DMA (wgrad256.hip); everything else stays on the 128 / 64-wide grouped kernel below.
@@ -225,10 +241,7 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
     for (int i = 0; i < n; ++i) {
       const otr_wgrad_item_t& it = items[i];
       if (!(it.dy && it.x && it.dw)) continue;                        // reported below
-      const bool ok = it.dy_dtype == OTR_H16 && it.x_dtype == OTR_H16 && it.M >= 1024 && it.N >= 128 && it.K >= 128 && it.N % 8 == 0 &&
-                      it.K % 8 == 0 && it.ldy >= it.N && it.ldx >= it.K && it.ldw >= it.K && it.ldy % 8 == 0 && it.ldx % 8 == 0 &&
-                      it.ldw % 4 == 0 && (uintptr_t)it.dy % 16 == 0 && (uintptr_t)it.x % 16 == 0 && (uintptr_t)it.dw % 16 == 0 &&
-                      it.ldy < (1ll << 24) && it.ldx < (1ll << 24) && (int64_t)(it.N + 256) * it.ldw * 4 < (1ll << 31);
+      const bool ok = wgrad256_ok(it, compute);
       if (ok) idx.push_back(i);
     }
     // longest contraction first (equal row counts stay together: their chunks can be phase-aligned)
@@ -238,7 +251,7 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
       big.clear();
       for (size_t c = c0; c < c1; ++c) {
         const otr_wgrad_item_t& it = items[idx[c]];
-        big.push_back(W256Item{it.dy, it.x, it.dw, it.M, it.N, it.K, it.ldy, it.ldx, it.ldw});
+        big.push_back(W256Item{it.dy, it.x, it.dw, it.dbias, it.M, it.N, it.K, it.ldy, it.ldx, it.ldw});
       }
       if (!workspace || wgrad256_workspace_bytes(big.data(), (int)big.size()) > workspace_bytes) break;   // the grouped kernel takes them
       if (int32_t e = wgrad256_launch(big.data(), (int)big.size(), workspace, workspace_bytes, g_otr_wgrad256_grid, g_otr_wgrad256_ablate, s)) return e;
@@ -249,6 +262,8 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
   for (int i = 0; i < n; ++i) {
     if (taken[(size_t)i]) continue;
     const otr_wgrad_item_t& it = items[i];
+    OTR_REQUIRE(!it.dbias, "linear_wgrad_grouped: item %d carries a bias gradient but does not run on the 256-wide kernel "
+                "(check otr_wgrad256_takes first)", i);
     OTR_REQUIRE(it.dy && it.x && it.dw, "linear_wgrad_grouped: item %d has a null pointer", i);
     OTR_REQUIRE(it.M >= 0 && it.N > 0 && it.K > 0 && it.ldy >= it.N && it.ldx >= it.K && it.ldw >= it.K,
                 "linear_wgrad_grouped: item %d has a bad shape", i);

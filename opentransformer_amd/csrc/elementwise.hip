@@ -321,42 +321,49 @@ struct ColsumGroup {
   const void* a[CSG_MAX];
   float* out[CSG_MAX];
   int M[CSG_MAX], N[CSG_MAX], lda[CSG_MAX], rblocks[CSG_MAX];
+  int tpr[CSG_MAX];   // threads per row: a thread owns 4 columns, a block min(N, 256) columns -> 256 / tpr rows per pass
+  int rpb[CSG_MAX];   // rows per block: >= 128, and few enough blocks per column (<= ~192) that their atomics do not pile up
 };
 // EPT = 4 columns per thread for both element types: the matrices of a backward pass are mostly [M, 256], which 8 columns
-// per thread (16-byte loads of 16-bit rows) would cover with half a wave -- measured 169 -> 300 us per training step
+// per thread (16-byte loads of 16-bit rows) would cover with half a wave -- measured 169 -> 300 us per training step.
+// Narrow matrices (the conv2 bias gradient is [151392, 32]) fold their rows into the idle lanes: 8 threads per row, 32 rows
+// per pass (with 64 threads per row 7/8 of every wave idled: 128 us of a training step for 10 MB).
 template <class T> __global__ void colsum_grouped_kernel(ColsumGroup g) {
-  constexpr int EPT = 4;
-  __shared__ float red[4][64][EPT];
+  constexpr int EPT = 4, UN = 8;
+  __shared__ float red[256][EPT];
   const int b = (int)blockIdx.x;
   int i = 0;
   for (int j = 1; j < g.n; ++j) i = (g.first[j] <= b) ? j : i;
   const T* a = reinterpret_cast<const T*>(g.a[i]);
   float* out = g.out[i];
   const int64_t M = g.M[i], N = g.N[i], lda = g.lda[i];
+  const int tpr = g.tpr[i], nrl = 256 / tpr;                 // row lanes of the block
+  const int rpb = g.rpb[i];
   const int lb = b - g.first[i], by = lb % g.rblocks[i], bx = lb / g.rblocks[i];
-  const int tx = threadIdx.x, ty = threadIdx.y;
-  const int64_t c = ((int64_t)bx * 64 + tx) * EPT;
+  const int t = (int)(threadIdx.y * 64 + threadIdx.x);
+  const int tx = t % tpr, ty = t / tpr;
+  const int64_t c = ((int64_t)bx * tpr + tx) * EPT;
   float s[EPT];
 #pragma unroll
   for (int e = 0; e < EPT; ++e) s[e] = 0.f;
-  if (c < N) {
-    const int64_t r0 = (int64_t)by * CS_RPB, r1 = min(M, r0 + CS_RPB);
+  if (c < N && ty < nrl) {
+    const int64_t r0 = (int64_t)by * rpb, r1 = min(M, r0 + rpb);
     const bool full = c + EPT <= N && (lda % EPT == 0);
     int64_t r = r0 + ty;
-    if (full) {   // 8 rows in flight per thread (rows clamped, tail rows weighted 0): the serial loop was latency bound
-      for (; r < r1; r += 32) {
-        float v[8][EPT];
+    if (full) {   // UN rows in flight per thread (rows clamped, tail rows weighted 0): the serial loop was latency bound
+      for (; r < r1; r += (int64_t)UN * nrl) {
+        float v[UN][EPT];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) load_row<T, EPT>(a + min(r + 4 * u, M - 1) * lda + c, EPT, true, v[u]);
+        for (int u = 0; u < UN; ++u) load_row<T, EPT>(a + min(r + (int64_t)nrl * u, M - 1) * lda + c, EPT, true, v[u]);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float w = (r + 4 * u < r1) ? 1.f : 0.f;
+        for (int u = 0; u < UN; ++u) {
+          const float w = (r + (int64_t)nrl * u < r1) ? 1.f : 0.f;
 #pragma unroll
           for (int e = 0; e < EPT; ++e) s[e] += w * v[u][e];
         }
       }
     } else {
-      for (; r < r1; r += 4) {
+      for (; r < r1; r += nrl) {
         float v[EPT];
         load_row<T, EPT>(a + r * lda + c, (int)min((int64_t)EPT, N - c), false, v);
 #pragma unroll
@@ -365,12 +372,15 @@ template <class T> __global__ void colsum_grouped_kernel(ColsumGroup g) {
     }
   }
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) red[ty][tx][e] = s[e];
+  for (int e = 0; e < EPT; ++e) red[t][e] = s[e];
   __syncthreads();
   if (ty == 0 && c < N) {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e)
-      if (c + e < N) atomicAdd(out + c + e, red[0][tx][e] + red[1][tx][e] + red[2][tx][e] + red[3][tx][e]);
+    for (int e = 0; e < EPT; ++e) {
+      float v = 0.f;
+      for (int q = 0; q < nrl; ++q) v += red[q * tpr + tx][e];
+      if (c + e < N) atomicAdd(out + c + e, v);
+    }
   }
 }
 extern "C" int32_t otr_colsum_grouped(const otr_colsum_item_t* items, int32_t n, void* stream) {
@@ -397,11 +407,18 @@ extern "C" int32_t otr_colsum_grouped(const otr_colsum_item_t* items, int32_t n,
                   "colsum_grouped: item %d has a bad shape", i);
       OTR_REQUIRE((uintptr_t)it.a % 16 == 0, "colsum_grouped: item %d input must be 16-byte aligned", i);
       if (it.dtype != dt || it.M == 0) continue;
-      const int cpb = 64 * 4;                                // columns per block: 4 per thread
-      const int rb = (int)((it.M + CS_RPB - 1) / CS_RPB), cb = (int)((it.N + cpb - 1) / cpb);
+      int tpr = 64;                                           // threads per row: the power of two >= N / 4, at most 64
+      while (tpr > 8 && (int64_t)(tpr / 2) * 4 >= it.N) tpr /= 2;
+      // every block ends with one atomic per column: 1245 blocks of a [159360, 128] matrix queued 20 k atomics on each of its 8
+      // cache lines -- 100 of that launch's 127 us.  At most ~192 row blocks per matrix.
+      const int nrl = 256 / tpr, pass_rows = nrl * 8 > 128 ? nrl * 8 : 128;
+      int rpb = pass_rows;
+      if ((it.M + rpb - 1) / rpb > 192) rpb = (int)(((it.M + 191) / 192 + pass_rows - 1) / pass_rows) * pass_rows;
+      const int cpb = tpr * 4;                                // columns per block
+      const int rb = (int)((it.M + rpb - 1) / rpb), cb = (int)((it.N + cpb - 1) / cpb);
       const int k = g.n++;
       g.first[k] = blocks;
-      g.a[k] = it.a; g.out[k] = it.out; g.M[k] = (int)it.M; g.N[k] = (int)it.N; g.lda[k] = (int)it.lda; g.rblocks[k] = rb;
+      g.a[k] = it.a; g.out[k] = it.out; g.M[k] = (int)it.M; g.N[k] = (int)it.N; g.lda[k] = (int)it.lda; g.rblocks[k] = rb; g.tpr[k] = tpr; g.rpb[k] = rpb;
       blocks += rb * cb;
       if (g.n == CSG_MAX)
         if (int32_t e = flush()) return e;

@@ -3,12 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-constexpr int W256_MAX_PROBS = 64;      // the table travels in the kernel-argument segment (< 4 KB): hipGraph-capturable by value
+constexpr int W256_MAX_PROBS = 56;      // the table travels in the kernel-argument segment (< 4 KB): hipGraph-capturable by value
 
 struct W256Item {                       // dw[N,K] += dy[M,N]^T x[M,K]; 16-bit operands, N % 8 == 0, K % 8 == 0
   const void* dy;
   const void* x;
   float* dw;
+  float* dbias;                         // NULL or [N]: dbias += column sums of dy (the bias gradient of the same Linear)
   int M, N, K;
   int64_t ldy, ldx, ldw;
 };
@@ -17,10 +18,11 @@ struct W256Prob {
   const uint16_t* dy;
   const uint16_t* x;
   float* dw;
+  float* dbias;
   int start;                            // first slab of this problem in the launch's (tile, slab) space
   int M, N, K, ldy, ldx, ldw;           // tiles: ceil(N/256) x ceil(K/256), each ceil(M/16) slabs long
   int flag0;                            // first turnstile flag of this problem (one per tile)
-};                                      // 56 bytes: 64 of them + the scalars below stay under the 4 KB argument segment
+};                                      // 64 bytes: 56 of them + the scalars below stay under the 4 KB argument segment
 
 struct W256Args {
   W256Prob p[W256_MAX_PROBS];

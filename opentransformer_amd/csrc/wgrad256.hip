@@ -81,6 +81,28 @@ __device__ __forceinline__ void read_frags_hi(Frags& f, uint32_t slab_addr, uint
   }
 }
 
+// column sums of the dy operand for the bias gradient: lane (column l & 31, rows 8 (l >> 5) ..) adds the 8 values of each of
+// its 4 fragments with v_dot2c against ones (16 VALU per slab, on the two waves of a workgroup that own wc == 0)
+__device__ __forceinline__ void frag_colsum(float (&cs)[4], const Frags& f) {
+#ifdef OTR_HALF_FP16
+  typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
+  const hv2 one = {(_Float16)1.f, (_Float16)1.f};
+#define W256_DOT(w, c) __builtin_amdgcn_fdot2(__builtin_bit_cast(hv2, w), one, c, false)
+#else
+  typedef __bf16 hv2 __attribute__((ext_vector_type(2)));
+  const hv2 one = {(__bf16)1.f, (__bf16)1.f};
+#define W256_DOT(w, c) __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hv2, w), one, c, false)
+#endif
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    cs[a] = W256_DOT(f.a[a].x, cs[a]);
+    cs[a] = W256_DOT(f.a[a].y, cs[a]);
+    cs[a] = W256_DOT(f.a[a].z, cs[a]);
+    cs[a] = W256_DOT(f.a[a].w, cs[a]);
+  }
+#undef W256_DOT
+}
+
 struct Stager {                 // this lane's share of the two DMA instructions its wave issues per slab
   const unsigned char* base_a;  // dy: (row = lane row of slab 0, this lane's 16 bytes)
   const unsigned char* base_b;  // x
@@ -105,7 +127,8 @@ struct Stager {                 // this lane's share of the two DMA instructions
 // i+1 spread between them, then the counted wait that retires slab i+2 and the barrier that publishes it.  Two slabs per
 // trip (static register sets); the steady-state trips carry no conditionals.
 template <bool NTA, bool NTB, int ABL>
-__device__ __forceinline__ void stream_piece(Stager& sg, f32x16 (&acc)[4][2], int sb, int P, int rot, uint32_t a_off, uint32_t b_off) {
+__device__ __forceinline__ void stream_piece(Stager& sg, f32x16 (&acc)[4][2], float (&cs)[4], int sb, int P, int rot,
+                                             uint32_t a_off, uint32_t b_off) {
   constexpr bool no_mma = ABL & 1, no_dma = ABL & 2;
   int stage = rot;                                     // next slab to stage, relative to sb, walks rot .. P-1, 0 .. rot-1
   auto issue_next = [&](int slot) {
@@ -146,6 +169,7 @@ __device__ __forceinline__ void stream_piece(Stager& sg, f32x16 (&acc)[4][2], in
     if (next_) read_frags_hi(NXT, nslab_, a_off, b_off);                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     W256_MMA(3, CUR)                                                                                         \
+    frag_colsum(cs, CUR);   /* unconditional: 16 VALU in the shadow of the MFMAs cost less than a branch per slab */ \
     if (more_) wait_vm<2 * (AHEAD - 2)>(); else wait_vm<0>();                                                \
     __builtin_amdgcn_s_barrier();                                                                            \
     asm volatile("" ::: "memory");                                                                           \
@@ -217,6 +241,18 @@ __device__ __forceinline__ void flush_tile(f32x16 (&acc)[4][2], float* dw, int l
         }
       }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the second round overwrites the scratch: reads above first
+  }
+}
+
+// dbias[n_base + 32a + lane] += cs[a] (lanes 0..31), same cache policy and the same turnstile as the tile it belongs to
+template <bool COH> __device__ __forceinline__ void flush_bias(const float (&cs)[4], float* dbias, int N, int n_base, int lane) {
+  constexpr int AUX = COH ? 17 : 0;
+  auto rs = __builtin_amdgcn_make_buffer_rsrc(dbias, 0, N * 4, 0x00020000);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const uint32_t off = (uint32_t)((n_base + 32 * a + lane) * 4);
+    const float old = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, AUX));
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(old + cs[a]), rs, off, 0, AUX);
   }
 }
 
@@ -325,12 +361,19 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // bias gradient: column sums of the dy strip, taken by the tk == 0 tile of each strip on its two wc == 0 waves
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool bias = pr.dbias != nullptr && tk == 0 && wc == 0;
     // the dy strip of this tile is shared with the other tk tiles of its problem, the x strip with the other tn tiles
     const bool nt_a = (g.policy & 1) && tiles_k == 1, nt_b = (g.policy & 1) && pr.N <= 256;
-    if (nt_a && nt_b) stream_piece<true, true, ABL>(sg, acc, sb, P, rot, a_off, b_off);
-    else if (nt_a) stream_piece<true, false, ABL>(sg, acc, sb, P, rot, a_off, b_off);
-    else if (nt_b) stream_piece<false, true, ABL>(sg, acc, sb, P, rot, a_off, b_off);
-    else stream_piece<false, false, ABL>(sg, acc, sb, P, rot, a_off, b_off);
+    if (nt_a && nt_b) stream_piece<true, true, ABL>(sg, acc, cs, sb, P, rot, a_off, b_off);
+    else if (nt_a) stream_piece<true, false, ABL>(sg, acc, cs, sb, P, rot, a_off, b_off);
+    else if (nt_b) stream_piece<false, true, ABL>(sg, acc, cs, sb, P, rot, a_off, b_off);
+    else stream_piece<false, false, ABL>(sg, acc, cs, sb, P, rot, a_off, b_off);
+    if (bias) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) cs[a] += __shfl_xor(cs[a], 32);       // the two row halves of a column
+    }
 
     // ---- accumulate into dw (every DMA has landed and every wave has passed the last barrier: the ring is idle)
     float* dw = pr.dw;
@@ -339,6 +382,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
     if constexpr ((ABL & 4) != 0) {
     } else if (nslices == 1) {
       flush_tile<false>(acc, dw, pr.ldw, pr.N, pr.K, n_base, k_base, scr, lane);
+      if (bias && lane < 32) flush_bias<false>(cs, pr.dbias, pr.N, n_base, lane);
     } else {
       int* flag = g.flags + pr.flag0 + tile;
       if (slice > 0) {
@@ -352,6 +396,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
         __syncthreads();
       }
       flush_tile<true>(acc, dw, pr.ldw, pr.N, pr.K, n_base, k_base, scr, lane);
+      if (bias && lane < 32) flush_bias<true>(cs, pr.dbias, pr.N, n_base, lane);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's write-through stores are at memory
       __syncthreads();
       if (tid == 0) __hip_atomic_store(flag, slice + 1 == nslices ? 0 : slice + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -378,6 +423,7 @@ int32_t wgrad256_launch(const W256Item* it, int n, void* workspace, int64_t work
   for (int i = 0; i < n; ++i) {
     W256Prob& p = g.p[i];
     p.dy = reinterpret_cast<const uint16_t*>(it[i].dy); p.x = reinterpret_cast<const uint16_t*>(it[i].x); p.dw = it[i].dw;
+    p.dbias = it[i].dbias;
     p.M = it[i].M; p.N = it[i].N; p.K = it[i].K; p.ldy = (int)it[i].ldy; p.ldx = (int)it[i].ldx; p.ldw = (int)it[i].ldw;
     p.start = (int)total;
     p.flag0 = flags;

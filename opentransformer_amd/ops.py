@@ -327,6 +327,8 @@ def linear_dgrad_raw(dy2, w, dx_dtype, out=None):
 # other's items as long as their backward passes do not interleave on one thread; a pass that dies half way leaves its
 # items behind, which the owner's zero_grad() / the next pass's first enqueue (different graph-task id) discards.
 _wq = {'on': False, 'w': [], 'b': [], 'armed': False, 'task': None}
+_FUSE_BIAS_COLSUM = os.environ.get('OTR_NO_FUSED_BIAS_COLSUM', '0') != '1'
+_DEBUG_WQ = os.environ.get('OTR_DEBUG_WQ', '0') == '1'
 
 
 def defer_weight_grads(on):
@@ -358,6 +360,12 @@ def flush_weight_grads():
     if _wq.get('keep_last'):            # bench.py re-times the grouped launch on the items of the last backward
         _wq['last'] = (list(w), list(b))
     lib = L.load()
+    if _DEBUG_WQ and (w or b) and not _wq.get('dumped'):      # one-off listing of a backward pass's deferred work (tuning aid)
+        _wq['dumped'] = True
+        for dy2, x2, out in w:
+            print('wq w', tuple(dy2.shape), dy2.dtype, dy2.stride(0), tuple(x2.shape), x2.dtype, flush=True)
+        for a2, out in b:
+            print('wq b', tuple(a2.shape), a2.dtype, a2.stride(0), flush=True)
     if w:
         items = (L.WgradItem * len(w))()
         for it, (dy2, x2, out) in zip(items, w):
@@ -365,6 +373,22 @@ def flush_weight_grads():
             it.M, it.N, it.K = dy2.shape[0], dy2.shape[1], x2.shape[1]
             it.ldy, it.ldx, it.ldw = dy2.stride(0), x2.stride(0), out.stride(0)
             it.dy_dtype, it.x_dtype = _code(dy2.dtype), _code(x2.dtype)
+            it.dbias = None
+        if b and _FUSE_BIAS_COLSUM:
+            # a bias gradient whose matrix is the dy operand of a weight gradient the 256-wide kernel takes rides along with
+            # it (the kernel reads that matrix anyway): one less pass over it by the column-sum launch
+            by_dy = {}
+            for i, (dy2, x2, out) in enumerate(w):
+                by_dy.setdefault((dy2.data_ptr(), dy2.shape[0], dy2.shape[1], dy2.stride(0)), i)
+            rest = []
+            for a2, out in b:
+                i = by_dy.get((a2.data_ptr(), a2.shape[0], a2.shape[1], a2.stride(0)))
+                if (i is not None and not items[i].dbias and a2.dtype == w[i][0].dtype and out.dtype == torch.float32
+                        and out.is_contiguous() and lib.otr_wgrad256_takes(C.byref(items[i]), _compute_code())):
+                    items[i].dbias = out.data_ptr()
+                else:
+                    rest.append((a2, out))
+            b = rest
         ws = _workspace(w[0][0].device)
         meta = None
         if _state.get('ktimer') is not None:

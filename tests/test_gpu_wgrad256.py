@@ -121,3 +121,42 @@ def test_wgrad256_mixed_with_unqualified_items():
     for (dy, x, out), ref in zip(items, refs):
         tol = 2e-5 if dy.dtype == adt else 1e-2           # an fp32 dy is rounded to the 16-bit type by the grouped kernel
         assert float((out - ref).abs().max()) / float(ref.abs().max()) < tol, tuple(dy.shape)
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
+@pytest.mark.parametrize('grid', [0, 5, -7])
+def test_wgrad256_bias_gradient_rides_along(mode, grid):
+    """a bias gradient (column sums of dy) queued next to the weight gradient of the same Linear is folded into the 256-wide
+    launch (otr_wgrad_item_t.dbias); one whose matrix is not a weight-gradient operand stays on the column-sum kernel"""
+    from opentransformer_amd import ops
+    L, lib = _lib()
+    ops.set_compute_dtype(mode)
+    try:
+        adt = ops.act_dtype()
+        gen = torch.Generator().manual_seed(8)
+        items, biases, refs = [], [], []
+        for (m, n, k) in [(2048, 768, 256), (2048, 256, 512), (1544, 136, 392), (2048, 512, 256)]:
+            wide = torch.randn(m, n + 8, generator=gen).to(DEV, adt)
+            dy = wide[:, :n]
+            x = torch.randn(m, k, generator=gen).to(DEV, adt)
+            out, bias = torch.zeros(n, k, device=DEV), torch.full((n,), 2.0, device=DEV)
+            items.append((dy, x, out))
+            biases.append((dy, bias))
+            refs.append((dy.float().t() @ x.float(), 2.0 + dy.float().sum(0)))
+        lone = torch.randn(1000, 96, generator=gen).to(DEV, adt)
+        lone_b = torch.zeros(96, device=DEV)
+        L.check(lib.otr_debug_set(6, 1), 'debug_set')
+        L.check(lib.otr_debug_set(7, grid), 'debug_set')
+        try:
+            ops._wq['w'], ops._wq['b'] = list(items), list(biases) + [(lone, lone_b)]
+            ops.flush_weight_grads()
+            torch.cuda.synchronize()
+        finally:
+            lib.otr_debug_set(6, -1)
+            lib.otr_debug_set(7, 0)
+        for (dy, x, out), (_, bias), (rw, rb) in zip(items, biases, refs):
+            assert float((out - rw).abs().max()) / float(rw.abs().max()) < 2e-5
+            assert float((bias - rb).abs().max()) / float(rb.abs().max()) < 2e-5, tuple(dy.shape)
+        assert float((lone_b - lone.float().sum(0)).abs().max()) < 1e-3
+    finally:
+        ops.set_compute_dtype('bf16')
