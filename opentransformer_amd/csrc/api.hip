@@ -44,6 +44,7 @@ int g_otr_ffn_waves = 4;   // 8 measured SLOWER (85 vs 61 us forward): see DESIG
 int g_otr_ffn2_ablate = 0;   // tuning hook (otr_debug_set(4, v)): bit 0 = no weight DMA after the first chunk, bit 1 = no MFMA work
 int g_otr_wgrad256 = -1;     // 256x256-tile weight-gradient launch (wgrad256.hip): -1 = environment OTR_WGRAD256 (default on), 0 / 1 (otr_debug_set(6, v))
 int g_otr_wgrad256_ablate = 0;   // tuning hook (otr_debug_set(8, v)), see wgrad256.h
+int g_otr_wgrad256_min_rows = 256;   // shortest contraction the 256-wide launch takes (otr_debug_set(9, v))
 int g_otr_wgrad256_grid = 0; // workgroups of that launch; 0 = one per CU (otr_debug_set(7, v))
 unsigned long long* g_otr_trace = nullptr;
 extern "C" int32_t otr_debug_trace(void* buf) { g_otr_trace = (unsigned long long*)buf; return 0; }
@@ -57,6 +58,7 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   else if (key == 6) g_otr_wgrad256 = value;
   else if (key == 7) g_otr_wgrad256_grid = value;
   else if (key == 8) g_otr_wgrad256_ablate = value;
+  else if (key == 9) g_otr_wgrad256_min_rows = value;
   else { otr_set_error("debug_set: unknown key %d", key); return -1; }
   return 0;
 }
@@ -208,7 +210,7 @@ extern "C" int32_t otr_ffn_glu_bwd(const void* dy, int32_t dy_dtype, int64_t ldy
 // All weight gradients of a backward pass in (a few) grouped launches: dw_i[N,K] += dy_i[M,N]^T x_i[M,K].
 // the problems the 256-wide launch takes: long contraction, 16-bit operands in 16-byte aligned rows, a few tiles at least
 static bool wgrad256_ok(const otr_wgrad_item_t& it, int compute) {
-  return compute == OTR_H16 && it.dy && it.x && it.dw && it.dy_dtype == OTR_H16 && it.x_dtype == OTR_H16 && it.M >= 1024 && it.N >= 128 &&
+  return compute == OTR_H16 && it.dy && it.x && it.dw && it.dy_dtype == OTR_H16 && it.x_dtype == OTR_H16 && it.M >= g_otr_wgrad256_min_rows && it.N >= 128 &&
          it.K >= 128 && it.N % 8 == 0 && it.K % 8 == 0 && it.ldy >= it.N && it.ldx >= it.K && it.ldw >= it.K && it.ldy % 8 == 0 &&
          it.ldx % 8 == 0 && it.ldw % 4 == 0 && (uintptr_t)it.dy % 16 == 0 && (uintptr_t)it.x % 16 == 0 && (uintptr_t)it.dw % 16 == 0 &&
          it.ldy < (1ll << 24) && it.ldx < (1ll << 24) && (int64_t)(it.N + 256) * it.ldw * 4 < (1ll << 31) &&
@@ -244,10 +246,12 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
       const bool ok = wgrad256_ok(it, compute);
       if (ok) idx.push_back(i);
     }
-    // longest contraction first (equal row counts stay together: their chunks can be phase-aligned)
+    // longest contraction first; problems of equal row count share a launch (its rounds schedule needs tiles of one length)
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return items[a].M > items[b].M; });
-    for (size_t c0 = 0; c0 < idx.size(); c0 += W256_MAX_PROBS) {
-      const size_t c1 = std::min(idx.size(), c0 + (size_t)W256_MAX_PROBS);
+    size_t c0 = 0;
+    while (c0 < idx.size()) {
+      size_t c1 = c0;
+      while (c1 < idx.size() && c1 - c0 < (size_t)W256_MAX_PROBS && items[idx[c1]].M == items[idx[c0]].M) ++c1;
       big.clear();
       for (size_t c = c0; c < c1; ++c) {
         const otr_wgrad_item_t& it = items[idx[c]];
@@ -256,6 +260,7 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
       if (!workspace || wgrad256_workspace_bytes(big.data(), (int)big.size()) > workspace_bytes) break;   // the grouped kernel takes them
       if (int32_t e = wgrad256_launch(big.data(), (int)big.size(), workspace, workspace_bytes, g_otr_wgrad256_grid, g_otr_wgrad256_ablate, s)) return e;
       for (size_t c = c0; c < c1; ++c) taken[(size_t)idx[c]] = 1;
+      c0 = c1;
     }
   }
   std::vector<int> order[16];   // key = big(1) | dy dtype(1) | x dtype(1)

@@ -459,6 +459,7 @@ def _rows(x):
 # modules, a cache keyed by the parameter version.
 _RB = os.environ.get('OTR_NO_ROWBLOCK', '0') != '1'
 _RB_SHAPES = ((256, 256), (768, 256))          # (N, K) of the Linear
+_RB_LINEAR_MIN_ROWS = int(os.environ.get('OTR_RB_LINEAR_MIN_ROWS', '1024'))   # below: 16 workgroups each streaming the whole weight lose to the 64-wide tile GEMM
 
 
 def lin_pack_items(w_off, N, K, dst_off):
@@ -524,7 +525,7 @@ class LinearFn(torch.autograd.Function):
         if perm is not None:
             C_, F_ = perm
             wc = wc.view(-1, C_, F_).permute(0, 2, 1).reshape(w.shape[0], F_ * C_).contiguous()
-        packs = lin_packs(w) if (perm is None and not relu and _rb_rows_ok(x2) and x2.shape[0] > 0
+        packs = lin_packs(w) if (perm is None and not relu and _rb_rows_ok(x2) and x2.shape[0] >= _RB_LINEAR_MIN_ROWS
                                  and (b is None or b.data_ptr() % 16 == 0)) else None
         ctx.rb = packs
         if packs is not None:
