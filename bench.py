@@ -118,6 +118,16 @@ def replay_dominant(ops, name, mode):
     w, _ = ops._wq.get('last', ([], []))
     if not w:
         return None
+    # the dominant LAUNCH is the 256-wide kernel over the longest-contraction group (the encoder's 48 wide problems, the
+    # decoder's cross-attention key/value slices and the frontend Linear: M = B x T'); the short decoder problems run in a
+    # second, much smaller launch of the same kernel
+    m_max = max(wi[0].shape[0] for wi in w)
+    w = [wi for wi in w if wi[0].shape[0] == m_max and wi[0].dtype == wi[1].dtype and wi[0].dtype != torch.float32]
+    if not w:
+        return None
+    flops = sum(2.0 * wi[0].shape[0] * wi[0].shape[1] * wi[1].shape[1] for wi in w)
+    nbytes = sum(wi[0].shape[0] * wi[0].shape[1] * wi[0].element_size() + wi[1].numel() * wi[1].element_size() + 2 * wi[2].numel() * 4
+                 for wi in w)
 
     def run():
         ops._wq['w'], ops._wq['b'] = list(w), []
@@ -141,7 +151,7 @@ def replay_dominant(ops, name, mode):
         g.replay()
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n
+        return {'ms': e0.elapsed_time(e1) / n, 'flops': flops, 'bytes': nbytes, 'problems': len(w), 'rows': m_max}
     except Exception:                                          # noqa: BLE001
         return None
 
@@ -179,7 +189,9 @@ def instrumented_step(ops, fwd_bwd, mode):
 
 
 KERNEL_LABEL = {
-    'linear_wgrad_grouped': 'gemm_grouped_kernel (every weight gradient of the backward pass, one launch per operand-type group)',
+    'linear_wgrad_grouped': 'wgrad256_kernel (weight + bias gradients of every wide Linear of the backward pass: one persistent 256x256-tile launch per row count; the rest on gemm_grouped_kernel)',
+    'proj_ln_fwd': 'proj_ln_fwd_kernel (attention output projection + bias + dropout + residual + LayerNorm, row-block fused)',
+    'ln_bwd_proj': 'ln_bwd_proj_kernel (LayerNorm backward + input gradient of the output projection, row-block fused)',
     'ffn_ln_fwd': 'ffn_ln_fwd_kernel (w_1 + GLU + w_2 + bias + dropout + residual + LayerNorm, row-block fused)',
     'ffn_bwd': 'ffn_bwd_kernel (FFN backward with recompute: dh, u, dx; row-block fused)',
 }
@@ -334,15 +346,27 @@ def main():
                                'ms_per_step': a['total_ms'], 'timed': 'events around every launch inside one eager training step'}
             if lines:
                 dom = max(lines, key=lambda k: lines[k]['avg_launch_ms'])          # largest single kernel of the step
-                ms = replay_dominant(ops, dom, args.mode)
-                if ms:                    # the eager bracket also holds the launch gap and the descriptor-table writers
+                rep = replay_dominant(ops, dom, args.mode)
+                if rep:                   # the eager bracket also holds the launch gaps, the init kernels and the small launches
                     d = lines[dom]
                     d['avg_launch_ms_eager_bracket'] = d['avg_launch_ms']
-                    d['avg_launch_ms'] = ms
-                    d['achieved'] = kern[dom]['flops_per_launch'] / (ms * 1e-3) / 1e12
-                    d['frac'] = d['achieved'] / peak
-                    d['timed'] = ('10 back-to-back launches on the operands of the step inside one hipGraph, events on the launch '
-                                  'stream (rocprofv3 --kernel-trace of this command: profiles/r02_kernel_trace_graph.txt)')
+                    d['avg_launch_ms'] = rep['ms']
+                    # 189 flop per algorithmic byte, below the 312 flop/B ridge of the chip: this launch is HBM-bound
+                    # (DESIGN.md section 5.2); its MFMA rate is reported next to it
+                    d['bound'] = 'hbm'
+                    d['algorithmic_bytes'] = rep['bytes']
+                    d['achieved'] = rep['bytes'] / (rep['ms'] * 1e-3) / 1e9
+                    d['peak'] = PEAK_HBM_GBS
+                    d['unit'] = 'GB/s'
+                    d['frac'] = d['achieved'] / PEAK_HBM_GBS
+                    d['tflops'] = rep['flops'] / (rep['ms'] * 1e-3) / 1e12
+                    d['mfma_frac'] = d['tflops'] / peak
+                    d['problems'] = rep['problems']
+                    d['rows'] = rep['rows']
+                    d['timed'] = ('10 back-to-back launches of the longest-contraction group on the operands of the step inside one '
+                                  'hipGraph, events on the launch stream (rocprofv3 --kernel-trace of this command: '
+                                  'profiles/r02_kernel_trace_graph.txt; traffic = FETCH_SIZE x 2 + WRITE_SIZE of separate --pmc passes: '
+                                  'profiles/r02_pmc_traffic.json)')
                 out['roofline'] = lines.pop(dom)
                 keep = sorted(lines, key=lambda k: -lines[k]['ms_per_step'])[:8]
                 out['roofline_kernels'] = {k: lines[k] for k in keep}
