@@ -1016,6 +1016,9 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
     if (!can_split) return 1;
     // measured (tools/gemm_sweep.py): with >= 64 output tiles one k-slice per CU is enough (w_2 forward 7968x256x2048:
     // 35 us at 5 slices, 28 us at 2); tiny outputs need the second resident workgroup per CU as well
+    // a short contraction (K <= 768: <= 24 stages) is over in a few microseconds whether split or not, and the reduce
+    // launch that a split needs costs 5-7 us: 23 of them per training step bought nothing (r02 kernel trace)
+    if (nk <= 24 && g_otr_force_ksplit == 0) return 1;
     int64_t want = tiles >= 64 ? (256 + tiles / 2) / tiles : (512 + tiles - 1) / tiles;   // >= 64 tiles: ~one wave of CUs
     int64_t cap = nk / 4 > 0 ? nk / 4 : 1;
     if (cap > max_by_ws) cap = max_by_ws;

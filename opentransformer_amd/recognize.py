@@ -263,6 +263,12 @@ class CachedBeamState:
     def _close(blk, concat_linear, norm, x, a, ctx):
         """output projection (+ the concat_after Linear) and the add+LayerNorm that closes an attention sub-layer: norm_k of
         a post-norm layer, norm_k+1 of a pre-norm one (nn.TransformerEncoderLayer)"""
+        if not blk.concat_after and x.dtype == torch.float32:
+            # output projection + residual + LayerNorm as ONE row-block launch (csrc/rowblock.hip), as in training
+            packs = ops.proj_ln_packs(x, ctx, a.output_proj.weight, norm.weight)
+            if packs is not None:
+                return ops.proj_add_layernorm(x, ctx, a.output_proj.weight, a.output_proj.bias, norm.weight, norm.bias, 0.0,
+                                              norm.eps, packs)
         att = ops.linear(ctx, a.output_proj.weight, a.output_proj.bias)
         if blk.concat_after:
             att = ops.linear(torch.cat((x, att), dim=-1), concat_linear.weight, concat_linear.bias)
