@@ -163,6 +163,79 @@ struct FfnFwdArgs {
   uint64_t rng_offset;
 };
 
+// bias + dropout + residual + LayerNorm on whole rows (shared by the forward kernels): red[slot][row][YP] holds the four
+// waves' partial outputs
+template <int D, int RPW, int YP>
+__device__ __forceinline__ void ffn_fwd_row_epilogue(const FfnFwdArgs& p, const float* red, int row0, int wid, int lane) {
+  // wave w owns rows RPW*w .. +RPW-1, lane owns columns 4*lane..+3
+  const bool drop = p.p_drop > 0.f;
+  const uint64_t seed = drop ? *p.seed : 0;
+  const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
+  const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+  const int col = lane * 4;
+  const float4 b2 = *reinterpret_cast<const float4*>(p.b2 + col);
+  const float4 gm = *reinterpret_cast<const float4*>(p.gamma + col);
+  const float4 bt = *reinterpret_cast<const float4*>(p.beta + col);
+  float4 xr[RPW];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int64_t row = min((int64_t)row0 + wid * RPW + i, (int64_t)p.M - 1);
+    xr[i] = *reinterpret_cast<const float4*>(p.x + row * D + col);
+  }
+  // the wave's rows are normalised TOGETHER: their butterfly steps are independent, so the cross-lane latency is paid
+  // 12 times per wave instead of 12 x RPW (rowblock.hip: one row after the other it was ~5 us of a launch)
+  float v[RPW][4], sm[RPW], qq[RPW];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int r = wid * RPW + i;
+    const int64_t row = min((int64_t)row0 + r, (int64_t)p.M - 1);
+    float t4[4] = {b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float4 t = *reinterpret_cast<const float4*>(red + (w * FF_RB + r) * YP + col);
+      t4[0] += t.x; t4[1] += t.y; t4[2] += t.z; t4[3] += t.w;
+    }
+    const float xv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+    sm[i] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float sc = 1.f;
+      if (drop) sc = otr_rand32(seed, p.rng_offset + (uint64_t)(row * D + col + e)) >= thr ? inv_keep : 0.f;
+      v[i][e] = xv[e] + t4[e] * sc;
+      sm[i] += v[i][e];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) sm[i] += __shfl_xor(sm[i], o);
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    sm[i] *= (1.f / D);
+    qq[i] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float t = v[i][e] - sm[i]; qq[i] += t * t; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) qq[i] += __shfl_xor(qq[i], o);
+  const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int64_t row = (int64_t)row0 + wid * RPW + i;
+    if (row >= p.M) break;                                  // wave-uniform
+    const float mean = sm[i], rstd = rsqrtf(qq[i] * (1.f / D) + p.eps);
+    if (p.z) *reinterpret_cast<float4*>(p.z + row * D + col) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
+    *reinterpret_cast<float4*>(p.y + row * D + col) = make_float4(o[0], o[1], o[2], o[3]);
+    if (p.y16) *reinterpret_cast<uint2*>(p.y16 + row * D + col) = make_uint2(pack2h(o[0], o[1]), pack2h(o[2], o[3]));
+    if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
+  }
+}
+
 // NW = waves per workgroup.  A pure streaming kernel ingests ~22 B/clk per CU with 4 waves and ~33 B/clk with 8
 // (tools/ubench/l2stream.hip), and this kernel sits on the 4-wave figure -- but its 8-wave form (two waves per SIMD, <= 256
 // registers each, a 12-deep ring per wave) measured 85 us against 61 us: the shallower rings and the shared matrix pipe cost
@@ -276,73 +349,129 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void ffn_ln_fwd_kernel(FfnFwdArgs 
   if (wid < 4) put(wid);
   __syncthreads();
 
-  // bias + dropout + residual + LayerNorm on whole rows: wave w owns rows RPW*w .. +RPW-1, lane owns columns 4*lane..+3
-  const bool drop = p.p_drop > 0.f;
-  const uint64_t seed = drop ? *p.seed : 0;
-  const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
-  const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
-  const int col = lane * 4;
-  const float4 b2 = *reinterpret_cast<const float4*>(p.b2 + col);
-  const float4 gm = *reinterpret_cast<const float4*>(p.gamma + col);
-  const float4 bt = *reinterpret_cast<const float4*>(p.beta + col);
-  float4 xr[RPW];
+  ffn_fwd_row_epilogue<D, RPW, YP>(p, red, row0, wid, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ forward, weights through LDS-DMA
+// Same structure as ffn_ln_fwd_kernel (32 rows per workgroup, a wave owns hidden chunks, no barrier in the loop), but the
+// weight fragments travel global -> LDS by direct-to-LDS DMA into a wave-PRIVATE ring (PD x 1 KiB) and reach the MFMA by one
+// ds_read_b128: the DMA path ingests ~33 B/clk per CU where global -> VGPR loads stop at ~22 (the v2 kernels
+// measured 10.7 us for 0.75 MB).  The fragment address is wave-uniform (SGPR base + lane * 16), so a DMA costs scalar
+// instructions only; the wave waits for its own DMAs with counted vmcnt (nothing else in the loop is a vector-memory
+// operation: the biases are staged in LDS up front).  The rings live where the partial outputs meet after the loop.
+typedef __attribute__((address_space(3))) unsigned char ffn_lds_byte;
+__device__ __forceinline__ void ffn_dma(const void* uniform_src, uint32_t lane_off, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_off), "s"(uniform_src), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void ffn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int D, int PD>
+__global__ __launch_bounds__(256, 1) void ffn_ln_fwd_dma_kernel(FfnFwdArgs p) {
+  static_assert(D == 256, "the LayerNorm epilogue maps one float4 per lane: d_model = 256");
+  constexpr int NKS = D / 16, NT = D / 32, YP = D + 4, NW = 4;
+  constexpr int STEPS = 2 * NKS + 2 * NT;          // weight fragments (= MFMAs) per chunk: 32 + 16
+  constexpr int RPW = FF_RB / NW;
+  static_assert(STEPS % PD == 0, "ring slots must be compile-time constants");
+  static_assert(NW * PD * 1024 + 16384 <= 4 * FF_RB * YP * 4, "rings + staged biases fit where the partial outputs meet");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * FF_RB * YP * 4 + FF_RB * D * 2];
+  float* red = reinterpret_cast<float*>(smem);                       // after the loop; before it: rings | biases
+  uint4* xs = reinterpret_cast<uint4*>(smem + 4 * FF_RB * YP * 4);
+  float* bias_s = reinterpret_cast<float*>(smem + NW * PD * 1024);   // b_1 [2F] (F <= 2048)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, hi = lane >> 5;
+  const int row0 = blockIdx.x * FF_RB;
+  stage_rows<D, 256>(xs, p.x16, row0, p.M, tid);
+  for (int i = tid * 4; i < 2 * p.F; i += 1024) *reinterpret_cast<float4*>(bias_s + i) = *reinterpret_cast<const float4*>(p.b1 + i);
+  __syncthreads();
+
+  const int nchunk = p.F / 32, npair = nchunk / (2 * NW), nit = nchunk / NW;
+  const int rot = (int)(blockIdx.x % (unsigned)npair);      // workgroups walk the weights from different starting points
+  auto chunk_of = [&](int it) {
+    int j = (it >> 1) + rot;
+    if (j >= npair) j -= npair;
+    return 2 * NW * j + 2 * wid + (it & 1);                  // a wave's consecutive chunks are adjacent
+  };
+  const unsigned char* P1 = reinterpret_cast<const unsigned char*>(p.p1);
+  const unsigned char* P2 = reinterpret_cast<const unsigned char*>(p.p2);
+  auto fptr = [&](int c, int s) -> const unsigned char* {   // wave-uniform address of fragment s of chunk c
+    if (s < 2 * NKS) return P1 + ((int64_t)(((s & 1) ? nchunk + c : c) * NKS + (s >> 1)) << 10);
+    const int t = s - 2 * NKS;
+    return P2 + ((int64_t)((t >> 1) * (2 * nchunk) + 2 * c + (t & 1)) << 10);
+  };
+  const uint32_t ring0 = (uint32_t)(uintptr_t)(ffn_lds_byte*)smem + (uint32_t)wid * (PD * 1024);
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  const uint4* ring = reinterpret_cast<const uint4*>(smem + wid * (PD * 1024)) + lane;
+
+  f32x16 yacc[NT];
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int64_t row = min((int64_t)row0 + wid * RPW + i, (int64_t)p.M - 1);
-    xr[i] = *reinterpret_cast<const float4*>(p.x + row * D + col);
-  }
-  // the wave's rows are normalised TOGETHER: their butterfly steps are independent, so the cross-lane latency is paid
-  // 12 times per wave instead of 12 x RPW (rowblock.hip: one row after the other it was ~5 us of a launch)
-  float v[RPW][4], sm[RPW], qq[RPW];
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int r = wid * RPW + i;
-    const int64_t row = min((int64_t)row0 + r, (int64_t)p.M - 1);
-    float t4[4] = {b2.x, b2.y, b2.z, b2.w};
+    for (int r = 0; r < 16; ++r) yacc[i][r] = 0.f;
+
+  int c = chunk_of(0);
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float4 t = *reinterpret_cast<const float4*>(red + (w * FF_RB + r) * YP + col);
-      t4[0] += t.x; t4[1] += t.y; t4[2] += t.z; t4[3] += t.w;
+  for (int s = 0; s < PD; ++s) ffn_dma(fptr(c, s), lane_off, ring0 + s * 1024);
+  ffn_wait_vm<PD - 1>();
+  uint4 w = ring[0];
+
+  for (int it = 0; it < nit; ++it) {
+    const int cn = chunk_of(min(it + 1, nit - 1));          // last round: re-loads its own chunk (valid, unused)
+    float4 bv[4], bg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bv[q] = *reinterpret_cast<const float4*>(bias_s + c * 32 + 8 * q + 4 * hi);
+      bg[q] = *reinterpret_cast<const float4*>(bias_s + p.F + c * 32 + 8 * q + 4 * hi);
     }
-    const float xv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
-    sm[i] = 0.f;
+    f32x16 av, ag;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float sc = 1.f;
-      if (drop) sc = otr_rand32(seed, p.rng_offset + (uint64_t)(row * D + col + e)) >= thr ? inv_keep : 0.f;
-      v[i][e] = xv[e] + t4[e] * sc;
-      sm[i] += v[i][e];
+    for (int r = 0; r < 16; ++r) { av[r] = 0.f; ag[r] = 0.f; }
+    uint4 xb, uf0, uf1;
+#pragma clang loop unroll(full)
+    for (int s = 0; s < STEPS; ++s) {
+      // fragment s is in `w`; fragment s+1 has landed once at most PD-2 DMAs are outstanding (PD were in flight)
+      ffn_wait_vm<PD - 2>();
+      const uint4 wn = ring[((s + 1) % PD) * 64];
+      if (s < 2 * NKS) {
+        if ((s & 1) == 0) xb = frag_b<D>(xs, m, hi, s >> 1);
+        if (s & 1) mma32(ag, w, xb); else mma32(av, w, xb);
+      } else {
+        const int t = s - 2 * NKS;
+        mma32(yacc[t >> 1], w, (t & 1) ? uf1 : uf0);
+      }
+      // slot s % PD is free (its fragment sits in `w`, read one step ago): fetch the fragment PD steps ahead into it
+      ffn_dma(s + PD < STEPS ? fptr(c, s + PD) : fptr(cn, s + PD - STEPS), lane_off, ring0 + (s % PD) * 1024);
+      w = wn;
+      if (s == 2 * NKS - 1) {                               // GLU on the accumulators: u = (a + b_a) * sigmoid(g + b_g)
+        float u[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float a = av[r] + reinterpret_cast<const float*>(&bv[r >> 2])[r & 3];
+          const float g = ag[r] + reinterpret_cast<const float*>(&bg[r >> 2])[r & 3];
+          u[r] = a * fast_sigmoid(g);
+        }
+        tile_to_frags(u, uf0, uf1);
+      }
     }
+    c = cn;
   }
+  ffn_wait_vm<0>();                                          // the trailing (unused) DMAs must land before the rings become `red`
+  __syncthreads();
+
+  auto put = [&](int slot) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) sm[i] += __shfl_xor(sm[i], o);
-#pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    sm[i] *= (1.f / D);
-    qq[i] = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { const float t = v[i][e] - sm[i]; qq[i] += t * t; }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) qq[i] += __shfl_xor(qq[i], o);
-  const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
-#pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int64_t row = (int64_t)row0 + wid * RPW + i;
-    if (row >= p.M) break;                                  // wave-uniform
-    const float mean = sm[i], rstd = rsqrtf(qq[i] * (1.f / D) + p.eps);
-    if (p.z) *reinterpret_cast<float4*>(p.z + row * D + col) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
-    float o[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
-    *reinterpret_cast<float4*>(p.y + row * D + col) = make_float4(o[0], o[1], o[2], o[3]);
-    if (p.y16) *reinterpret_cast<uint2*>(p.y16 + row * D + col) = make_uint2(pack2h(o[0], o[1]), pack2h(o[2], o[3]));
-    if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
-  }
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(red + (slot * FF_RB + m) * YP + nt * 32 + 8 * q + 4 * hi) =
+            make_float4(yacc[nt][4 * q], yacc[nt][4 * q + 1], yacc[nt][4 * q + 2], yacc[nt][4 * q + 3]);
+  };
+  put(wid);
+  __syncthreads();
+  ffn_fwd_row_epilogue<D, RPW, YP>(p, red, row0, wid, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -522,7 +651,9 @@ extern "C" int32_t otr_ffn_ln_fwd(const float* x, const void* x16, const void* w
   p.gamma = gamma; p.beta = beta; p.seed = seed; p.y = y; p.y16 = (uint16_t*)y16; p.z = z; p.mean = mean; p.rstd = rstd;
   p.M = (int)M; p.F = F; p.eps = eps; p.p_drop = p_drop; p.rng_offset = rng_offset;
   const unsigned nblk = (unsigned)((M + FF_RB - 1) / FF_RB);
-  if (g_otr_ffn_waves != 8 || F % 512 != 0)
+  if (g_otr_ffn_waves == 16 && F <= 2048)       // weights through LDS-DMA rings (otr_debug_set(5, 16))
+    hipLaunchKernelGGL((ffn_ln_fwd_dma_kernel<256, 24>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
+  else if (g_otr_ffn_waves != 8 || F % 512 != 0)
     hipLaunchKernelGGL((ffn_ln_fwd_kernel<256, 4, 24>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL((ffn_ln_fwd_kernel<256, 8, 12>), dim3(nblk), dim3(512), 0, (hipStream_t)stream, p);

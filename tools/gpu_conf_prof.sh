@@ -4,11 +4,11 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 R=$PWD
-(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o graph -- python $R/bench.py --model conformer --steps 4 --warmup 2 --no-cpu-baseline > $R/$OUT/rocprof.log 2>&1; echo "rocprof exit $?")
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_cp -o graph -- python $R/bench.py --model conformer --steps 4 --warmup 2 --no-cpu-baseline > $R/$OUT/rocprof.log 2>&1; echo "rocprof exit $?")
 python - <<PY
 import sqlite3,re
 from collections import Counter, defaultdict
-db=sqlite3.connect('$OUT/prof/graph_results.db')
+db=sqlite3.connect('/tmp/prof_cp/graph_results.db')
 rows=db.execute("select name,start,end from kernels order by start").fetchall()
 idx=[i for i,r in enumerate(rows) if r[0].startswith('adam_kernel')]
 a,b=idx[-2],idx[-1]
