@@ -126,8 +126,8 @@ struct Stager {                 // this lane's share of the two DMA instructions
 // Per slab and wave: 8 MFMAs of the current fragments with the two DMA instructions of slab i+6 and the 12 reads of slab
 // i+1 spread between them, then the counted wait that retires slab i+2 and the barrier that publishes it.  Two slabs per
 // trip (static register sets); the steady-state trips carry no conditionals.
-template <bool NTA, bool NTB, int ABL>
-__device__ __forceinline__ void stream_piece(Stager& sg, f32x16 (&acc)[4][2], float (&cs)[4], int sb, int P, int rot,
+template <bool NTA, bool NTB, int ABL, bool BIAS>
+__device__ __forceinline__ void stream_piece(Stager& sg, f32x16 (&acc)[4][2], float (&cs)[4], int wc, int sb, int P, int rot,
                                              uint32_t a_off, uint32_t b_off) {
   constexpr bool no_mma = ABL & 1, no_dma = ABL & 2;
   int stage = rot;                                     // next slab to stage, relative to sb, walks rot .. P-1, 0 .. rot-1
@@ -169,7 +169,7 @@ __device__ __forceinline__ void stream_piece(Stager& sg, f32x16 (&acc)[4][2], fl
     if (next_) read_frags_hi(NXT, nslab_, a_off, b_off);                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     W256_MMA(3, CUR)                                                                                         \
-    frag_colsum(cs, CUR);   /* unconditional: 16 VALU in the shadow of the MFMAs cost less than a branch per slab */ \
+    if constexpr (BIAS) { if ((q_ & 3) == wc) frag_colsum(cs, CUR); }   /* the four waves of a row half take turns */  \
     if (more_) wait_vm<2 * (AHEAD - 2)>(); else wait_vm<0>();                                                \
     __builtin_amdgcn_s_barrier();                                                                            \
     asm volatile("" ::: "memory");                                                                           \
@@ -361,20 +361,39 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // bias gradient: column sums of the dy strip, taken by the tk == 0 tile of each strip on its two wc == 0 waves
+    // bias gradient: column sums of the dy strip, taken by the tk == 0 tile of each strip.  The four waves of a row half hold
+    // the same dy fragments: they take the slabs in turns (16 v_dot2c on every 4th slab; on every slab for all waves it cost
+    // 0.05 ms of the launch) and meet in LDS before the epilogue.
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool bias = pr.dbias != nullptr && tk == 0 && wc == 0;
+    const bool bias = pr.dbias != nullptr && tk == 0;
     // the dy strip of this tile is shared with the other tk tiles of its problem, the x strip with the other tn tiles
     const bool nt_a = (g.policy & 1) && tiles_k == 1, nt_b = (g.policy & 1) && pr.N <= 256;
-    if (nt_a && nt_b) stream_piece<true, true, ABL>(sg, acc, cs, sb, P, rot, a_off, b_off);
-    else if (nt_a) stream_piece<true, false, ABL>(sg, acc, cs, sb, P, rot, a_off, b_off);
-    else if (nt_b) stream_piece<false, true, ABL>(sg, acc, cs, sb, P, rot, a_off, b_off);
-    else stream_piece<false, false, ABL>(sg, acc, cs, sb, P, rot, a_off, b_off);
-    if (bias) {
+#define W256_RUN(A, B)                                                                                       \
+  {                                                                                                          \
+    if (bias) stream_piece<A, B, ABL, true>(sg, acc, cs, wc, sb, P, rot, a_off, b_off);                     \
+    else stream_piece<A, B, ABL, false>(sg, acc, cs, wc, sb, P, rot, a_off, b_off);                          \
+  }
+    if (nt_a && nt_b) W256_RUN(true, true)
+    else if (nt_a) W256_RUN(true, false)
+    else if (nt_b) W256_RUN(false, true)
+    else W256_RUN(false, false)
+#undef W256_RUN
+    if (bias) {                                                      // workgroup-uniform
+      float* bx = reinterpret_cast<float*>(smem);                    // [8 waves][4 fragments][32 columns] (the ring is idle)
 #pragma unroll
-      for (int a = 0; a < 4; ++a) cs[a] += __shfl_xor(cs[a], 32);       // the two row halves of a column
+      for (int a = 0; a < 4; ++a) {
+        cs[a] += __shfl_xor(cs[a], 32);                              // the two row halves of a column
+        if (lane < 32) bx[(wid * 4 + a) * 32 + lane] = cs[a];
+      }
+      __syncthreads();
+      if (wc == 0 && lane < 32) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          cs[a] = bx[((wr * 4 + 0) * 4 + a) * 32 + lane] + bx[((wr * 4 + 1) * 4 + a) * 32 + lane] +
+                  bx[((wr * 4 + 2) * 4 + a) * 32 + lane] + bx[((wr * 4 + 3) * 4 + a) * 32 + lane];
+      }
+      __syncthreads();                                               // the epilogue reuses this LDS
     }
-
     // ---- accumulate into dw (every DMA has landed and every wave has passed the last barrier: the ring is idle)
     float* dw = pr.dw;
     const int n_base = n0 + 128 * wr, k_base = k0 + 64 * wc;
@@ -382,7 +401,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
     if constexpr ((ABL & 4) != 0) {
     } else if (nslices == 1) {
       flush_tile<false>(acc, dw, pr.ldw, pr.N, pr.K, n_base, k_base, scr, lane);
-      if (bias && lane < 32) flush_bias<false>(cs, pr.dbias, pr.N, n_base, lane);
+      if (bias && wc == 0 && lane < 32) flush_bias<false>(cs, pr.dbias, pr.N, n_base, lane);
     } else {
       int* flag = g.flags + pr.flag0 + tile;
       if (slice > 0) {
@@ -396,7 +415,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
         __syncthreads();
       }
       flush_tile<true>(acc, dw, pr.ldw, pr.N, pr.K, n_base, k_base, scr, lane);
-      if (bias && lane < 32) flush_bias<true>(cs, pr.dbias, pr.N, n_base, lane);
+      if (bias && wc == 0 && lane < 32) flush_bias<true>(cs, pr.dbias, pr.N, n_base, lane);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's write-through stores are at memory
       __syncthreads();
       if (tid == 0) __hip_atomic_store(flag, slice + 1 == nslices ? 0 : slice + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
