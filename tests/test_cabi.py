@@ -103,3 +103,37 @@ def test_reference_trained_checkpoint_loads(golden):
     sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('w:')}
     missing, unexpected = model.load_state_dict(sd, strict=True)
     assert not missing and not unexpected
+
+
+def test_wgrad256_eligibility_rule_is_host_logic():
+    """otr_wgrad256_takes (no GPU needed): the 256-wide weight-gradient launch takes long-contraction 16-bit problems in
+    16-byte aligned rows and nothing else; otr_linear_wgrad_grouped refuses a bias gradient on an item it would not take."""
+    import ctypes as C
+    from opentransformer_amd import _lib as L
+    for kind, code in (('bf16', L.OTR_BF16), ('fp16', L.OTR_F16)):
+        lib = L.load(kind)
+        lib.otr_debug_set(6, 1)
+        try:
+            def item(M, N, K, ldy=None, ldx=None, dy_dtype=code, x_dtype=code, base=0x10000):
+                it = L.WgradItem()
+                it.dy, it.x, it.dw = base, base + 0x100000, base + 0x200000
+                it.M, it.N, it.K = M, N, K
+                it.ldy, it.ldx, it.ldw = ldy or N, ldx or K, K
+                it.dy_dtype, it.x_dtype = dy_dtype, x_dtype
+                it.dbias = None
+                return it
+            takes = lambda it: lib.otr_wgrad256_takes(C.byref(it), code)        # noqa: E731
+            assert takes(item(7968, 768, 256)) == 1
+            assert takes(item(7968, 256, 608)) == 1                      # ragged last tile of K
+            assert takes(item(512, 4096, 256)) == 1                      # the decoder's rows
+            assert takes(item(7968, 512, 256, ldy=3072)) == 1            # a slice of a wider matrix
+            assert takes(item(128, 768, 256)) == 0                       # short contraction
+            assert takes(item(7968, 100, 256)) == 0 and takes(item(7968, 256, 68)) == 0    # narrow / not whole 16-byte units
+            assert takes(item(7968, 768, 256, ldy=772)) == 0             # rows not 16-byte aligned
+            assert takes(item(7968, 768, 256, dy_dtype=L.OTR_F32)) == 0  # fp32 operand
+            assert takes(item(7968, 768, 256, base=0x10004)) == 0        # misaligned base
+            assert lib.otr_wgrad256_takes(C.byref(item(7968, 768, 256)), L.OTR_F32) == 0   # fp32 compute mode
+            lib.otr_debug_set(6, 0)
+            assert takes(item(7968, 768, 256)) == 0                      # switched off
+        finally:
+            lib.otr_debug_set(6, -1)
