@@ -29,7 +29,7 @@ struct W256Args {
   int total, chunk;                     // slabs in the launch; slabs per workgroup (stream-K) / per tile (rounds)
   int mode, nfull, rem_tiles, parts;    // 1 = rounds schedule: full rounds, tiles left for the last round, row ranges per tile there
   int nprob, spin_limit;
-  int ablate, policy;                      // tuning hook (otr_debug_set(8, v)): 1 = no MFMA, 2 = no DMA after the prologue, 4 = no accumulation into dw; v >> 3: 0 = default policy, 1 = no non-temporal loads, 2 = non-temporal loads of unshared operand strips
+  int ablate, policy;                      // tuning hook (otr_debug_set(8, v)): 1 = no MFMA, 2 = no DMA after the prologue, 4 = no accumulation into dw; v >> 3: 0 = default policy (non-temporal unshared strips); else (v >> 3) - 1 = bit 0 non-temporal strips.  Ablation 6 = the x part is not fetched (its DMA reads one zero line)
   int* flags;
   const void* zeros;                    // >= 64 zero bytes: source of rows past M
 };

@@ -112,12 +112,14 @@ struct Stager {                 // this lane's share of the two DMA instructions
   const unsigned char* zeros;
   uint32_t dst;                 // wave's byte offset inside a slab's dy part (the x part is + 8192)
   // NTA / NTB: the operand strip is read by this tile only -> non-temporal, it stays out of the L2 the shared strips live in
-  template <bool NTA, bool NTB> __device__ __forceinline__ void issue(int slab, int slot) {
+  template <bool NTA, bool NTB, bool SKIPB = false> __device__ __forceinline__ void issue(int slab, int slot) {
     const bool ok = slab * SLAB_ROWS + row0 < M;
     const unsigned char* pa = ok && col_a ? base_a + slab * step_a : zeros;
     const unsigned char* pb = ok && col_b ? base_b + slab * step_b : zeros;
     if constexpr (NTA) dma16_nt(pa, (uint32_t)(slot * SLAB_BYTES) + dst); else dma16(pa, (uint32_t)(slot * SLAB_BYTES) + dst);
-    if constexpr (NTB) dma16_nt(pb, (uint32_t)(slot * SLAB_BYTES) + 8192u + dst); else dma16(pb, (uint32_t)(slot * SLAB_BYTES) + 8192u + dst);
+    if constexpr (SKIPB) dma16(zeros, (uint32_t)(slot * SLAB_BYTES) + 8192u + dst);        // ablation 6: the x part is not fetched (one line, L1-hot)
+    else if constexpr (NTB) dma16_nt(pb, (uint32_t)(slot * SLAB_BYTES) + 8192u + dst);
+    else dma16(pb, (uint32_t)(slot * SLAB_BYTES) + 8192u + dst);
   }
 };
 
@@ -129,10 +131,10 @@ struct Stager {                 // this lane's share of the two DMA instructions
 template <bool NTA, bool NTB, int ABL, bool BIAS>
 __device__ __forceinline__ void stream_piece(Stager& sg, f32x16 (&acc)[4][2], float (&cs)[4], int wc, int sb, int P, int rot,
                                              uint32_t a_off, uint32_t b_off) {
-  constexpr bool no_mma = ABL & 1, no_dma = ABL & 2;
+  constexpr bool no_mma = (ABL & 1) && ABL != 6, no_dma = (ABL & 2) && ABL != 6;
   int stage = rot;                                     // next slab to stage, relative to sb, walks rot .. P-1, 0 .. rot-1
   auto issue_next = [&](int slot) {
-    sg.issue<NTA, NTB>(sb + stage, slot);
+    sg.issue<NTA, NTB, ABL == 6>(sb + stage, slot);
     stage = stage + 1 == P ? 0 : stage + 1;
   };
   // ---- prologue: slabs 0 .. AHEAD-1 in flight, slabs 0 and 1 landed, fragments of slab 0 in registers
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
     float* dw = pr.dw;
     const int n_base = n0 + 128 * wr, k_base = k0 + 64 * wc;
     unsigned char* scr = smem + wid * 16384;
-    if constexpr ((ABL & 4) != 0) {
+    if constexpr ((ABL & 4) != 0 && ABL != 6) {
     } else if (nslices == 1) {
       flush_tile<false>(acc, dw, pr.ldw, pr.N, pr.K, n_base, k_base, scr, lane);
       if (bias && wc == 0 && lane < 32) flush_bias<false>(cs, pr.dbias, pr.N, n_base, lane);
@@ -462,7 +464,7 @@ int32_t wgrad256_launch(const W256Item* it, int n, void* workspace, int64_t work
   }
   int cap = grid_cap > 0 ? grid_cap : (grid_cap < 0 ? -grid_cap : 248);    // < 0: that many workgroups, stream-K schedule
   int grid;
-  g.nprob = n; g.total = (int)total; g.spin_limit = 1 << 22; g.ablate = ablate & 7; g.policy = ablate >> 3 ? (ablate >> 3) - 1 : 1;
+  g.nprob = n; g.total = (int)total; g.spin_limit = 1 << 22; g.ablate = ablate & 7; g.policy = ablate >> 3 ? (ablate >> 3) - 1 : 1;   // (ablate >> 3) - 1: bit 0 non-temporal strips
   if (same_rows && grid_cap >= 0 && flags >= 8) {
     // Rounds: every tile is R slabs long.  G slots (whole XCD groups) each walk one whole tile per round -- the tiles of a
     // problem sit in neighbouring slots of one XCD and read their shared operand panel in step -- and the tiles left over

@@ -20,9 +20,12 @@ def main():
     ap.add_argument('--layers', type=int, default=12)
     ap.add_argument('--rows', type=int, default=7968)
     ap.add_argument('--ablate', default='')
+    ap.add_argument('--base', type=int, default=0, help='otr_debug_set(8, v) for the main runs (0 = shipped policy)')
+    ap.add_argument('--alias', action='store_true', help='every layer reads the SAME operand tensors (cache-resident working set)')
     a = ap.parse_args()
     ops.set_compute_dtype(a.mode)
     lib = L.load()
+    lib.otr_debug_set(8, a.base)
     dev = 'cuda:0'
     adt = ops.act_dtype()
     M = a.rows
@@ -31,9 +34,11 @@ def main():
     def rnd(*s):
         return torch.randn(*s, device=dev, generator=g).to(adt)
     items = []
+    shared = None
     for _ in range(a.layers):
-        x, dqkv, ctx, dout = rnd(M, 256), rnd(M, 768), rnd(M, 256), rnd(M, 256)
-        x1, dh, u, dy2 = rnd(M, 256), rnd(M, 4096), rnd(M, 2048), rnd(M, 256)
+        if shared is None or not a.alias:
+            shared = (rnd(M, 256), rnd(M, 768), rnd(M, 256), rnd(M, 256), rnd(M, 256), rnd(M, 4096), rnd(M, 2048), rnd(M, 256))
+        x, dqkv, ctx, dout, x1, dh, u, dy2 = shared
         for dy, xx in ((dqkv, x), (dout, ctx), (dh, x1), (dy2, u)):
             items.append((dy, xx, torch.zeros(dy.shape[1], xx.shape[1], device=dev)))
     if a.layers == 12:       # the other wide problems of the step: the decoder's cross-attention key/value slices, the frontend's Linear
@@ -85,6 +90,7 @@ def main():
         out['ablate%d_grid-248_ms' % ab] = timed(1, -248)
         if ab >= 8:
             out['ablate%d_grid0_ms' % ab] = timed(1, 0)
+    lib.otr_debug_set(8, a.base)
     lib.otr_debug_set(8, 0)
     lib.otr_debug_set(6, -1)
     lib.otr_debug_set(7, 0)
