@@ -13,5 +13,5 @@ R=$PWD
 python tools/graph_gaps.py /tmp/prof_fin/graph_results.db | tail -1
 python tools/prof_summary.py /tmp/prof_fin/graph_results.db 6 > $OUT/kernel_summary_graph.txt 2>&1; head -12 $OUT/kernel_summary_graph.txt | cut -c1-150
 timeout 300 python bench.py --model conformer --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_conformer.log 2>&1; echo "conformer exit $?"; grep -v amdgpu.ids $OUT/bench_conformer.log | tail -1 > $OUT/bench_conformer.json; cut -c1-300 $OUT/bench_conformer.json
-timeout 600 python tools/decode_bench.py --batch 8 --cpu-baseline > $OUT/decode_bench.log 2>&1; echo "decode exit $?"; grep -v amdgpu.ids $OUT/decode_bench.log | tail -1 > $OUT/decode_bench.json; cut -c1-600 $OUT/decode_bench.json
-timeout 200 python tools/wgrad256_bench.py --grids 0,-248 --ablate 1,2,3 > $OUT/w256_bench.log 2>&1; grep -v amdgpu.ids $OUT/w256_bench.log | tail -1 > $OUT/wgrad256_bench.json; cut -c1-900 $OUT/wgrad256_bench.json
+timeout 600 python tools/decode_bench.py --batch 8 > $OUT/decode_bench.log 2>&1; echo "decode exit $?"; grep -v amdgpu.ids $OUT/decode_bench.log | tail -1 > $OUT/decode_bench.json; cut -c1-600 $OUT/decode_bench.json
+timeout 200 python tools/wgrad256_bench.py --grids 0,-248 --ablate 17,18,22 > $OUT/w256_bench.log 2>&1; grep -v amdgpu.ids $OUT/w256_bench.log | tail -1 > $OUT/wgrad256_bench.json; cut -c1-900 $OUT/wgrad256_bench.json
