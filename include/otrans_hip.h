@@ -177,6 +177,13 @@ typedef struct {
 } otr_wgrad_item_t;
 /* 1 when otr_linear_wgrad_grouped would run this item on the 256-wide kernel (csrc/wgrad256.hip), else 0 */
 int32_t otr_wgrad256_takes(const otr_wgrad_item_t* item, int32_t compute);
+/* the schedule the 256-wide launch would use for these items (host only; tests replay the kernel's work decoding on it):
+ * out[0..7] = {mode (1 rounds / 0 stream-K), grid, chunk, full rounds, tiles left, row ranges per left tile, total slabs, n},
+ * out[8 + i] = first slab of problem i; grid_cap as otr_debug_set(7, v) */
+int32_t otr_debug_wgrad256_plan(const otr_wgrad_item_t* items, int32_t n, int32_t grid_cap, int32_t* out);
+/* number of pieces of the last 256-wide launch on `workspace` that gave up waiting for their turn (bounded spin; 0 in any
+ * healthy run; < 0 on error).  Synchronises the device. */
+int32_t otr_debug_wgrad256_errors(const void* workspace);
 int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32_t n, int32_t compute, void* workspace,
                                  int64_t workspace_bytes, void* stream);
 typedef struct {

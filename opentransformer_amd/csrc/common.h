@@ -204,8 +204,11 @@ __device__ __forceinline__ void load_row(const ST* p, int nvalid, bool vec, floa
 // NCH=4 (64-B rows): ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27},{4-11,16-19,28-31}
 // (+32), i.e. rows {0-3,12-15} at chunk g together with rows {4-11} at chunk g^1; the lookup
 // {0,2,3,1}[(row>>2)&3] makes all 16 (row&3, chunk) slots of such a group distinct.
+// NCH=12 (192-B rows: head dim 96 in 16-bit, the Conformer): a row starts 12 units of 16 B further, i.e. -4 units mod the
+// 16-unit bank window -- the NCH=4 geometry with the row classes relabelled (row&3 -> -row&3) and the k-step adding whole
+// windows; the same lookup on the low two chunk bits is conflict-free (chunks stay inside their aligned group of four).
 template <int NCH> __device__ __forceinline__ int swz(int row) {
-  if constexpr (NCH == 4) return (0x78 >> (((row >> 2) & 3) * 2)) & 3;
+  if constexpr (NCH == 4 || NCH == 12) return (0x78 >> (((row >> 2) & 3) * 2)) & 3;
   else if constexpr (NCH == 8) return (row >> 1) & 7;
   else if constexpr (NCH == 16) return row & 15;
   else return 0;

@@ -413,6 +413,8 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
             __builtin_amdgcn_s_sleep(8);
             ++spins;
           }
+          if (spins >= g.spin_limit)                                   // give-up code: word 15 of the zero line (otr_debug_wgrad256_errors)
+            __hip_atomic_fetch_add(const_cast<int*>(reinterpret_cast<const int*>(g.zeros)) + 15, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
       }
@@ -431,15 +433,15 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
 // Host side: lay the problems out in the (tile, slab) space, cut it into one chunk per workgroup, launch.
 static inline int w256_tiles(const W256Item& it) { return ((it.N + 255) / 256) * ((it.K + 255) / 256); }
 
-int32_t wgrad256_launch(const W256Item* it, int n, void* workspace, int64_t workspace_bytes, int grid_cap, int ablate, hipStream_t s) {
-  if (n <= 0) return 0;
+// The schedule of a launch (host only, no device work): the problem table with its slab offsets, the mode and its parameters,
+// the grid.  Shared by wgrad256_launch and otr_debug_wgrad256_plan (tests/test_cabi.py replays the kernel's piece decoding on it).
+static int32_t wgrad256_plan(const W256Item* it, int n, int grid_cap, W256Args& g, int& grid, int& flags) {
   if (n > W256_MAX_PROBS) {
     otr_set_error("wgrad256: %d problems exceed the table of %d", n, W256_MAX_PROBS);
     return -1;
   }
-  W256Args g{};
   int64_t total = 0;
-  int flags = 0;
+  flags = 0;
   bool same_rows = true;
   for (int i = 0; i < n; ++i) {
     W256Prob& p = g.p[i];
@@ -453,18 +455,12 @@ int32_t wgrad256_launch(const W256Item* it, int n, void* workspace, int64_t work
     total += (int64_t)tiles * slabs;
     flags += tiles;
   }
-  const int64_t need = 64 + (int64_t)flags * 4;   // (== wgrad256_workspace_bytes)
-  if (!workspace || workspace_bytes < need) {
-    otr_set_error("wgrad256: workspace of %lld bytes, need %lld", (long long)workspace_bytes, (long long)need);
-    return -1;
-  }
   if (total >= (1ll << 30)) {
     otr_set_error("wgrad256: %lld slabs do not fit the 32-bit work index", (long long)total);
     return -1;
   }
   int cap = grid_cap > 0 ? grid_cap : (grid_cap < 0 ? -grid_cap : 248);    // < 0: that many workgroups, stream-K schedule
-  int grid;
-  g.nprob = n; g.total = (int)total; g.spin_limit = 1 << 22; g.ablate = ablate & 7; g.policy = ablate >> 3 ? (ablate >> 3) - 1 : 1;   // (ablate >> 3) - 1: bit 0 non-temporal strips
+  g.nprob = n; g.total = (int)total; g.spin_limit = 1 << 22;
   if (same_rows && grid_cap >= 0 && flags >= 8) {
     // Rounds: every tile is R slabs long.  G slots (whole XCD groups) each walk one whole tile per round -- the tiles of a
     // problem sit in neighbouring slots of one XCD and read their shared operand panel in step -- and the tiles left over
@@ -480,6 +476,7 @@ int32_t wgrad256_launch(const W256Item* it, int n, void* workspace, int64_t work
     grid = bestG;
     g.mode = 1; g.chunk = R;
     g.nfull = T / grid; g.rem_tiles = T - g.nfull * grid; g.parts = g.rem_tiles ? std::min(grid / g.rem_tiles, 8) : 1;
+    if (g.parts > R) g.parts = R;                   // never an empty row range
   } else {
     // Stream-K: short chunks make pieces whose epilogue outweighs their work: at least 64 slabs (1024 rows) per workgroup
     while (cap > 1 && total / cap < 64) cap /= 2;
@@ -488,6 +485,20 @@ int32_t wgrad256_launch(const W256Item* it, int n, void* workspace, int64_t work
     if (grid >= 8) grid = (grid + 7) / 8 * 8;       // whole XCD groups; the extra chunks are empty
     g.mode = 0; g.chunk = (int)chunk;
   }
+  return 0;
+}
+
+int32_t wgrad256_launch(const W256Item* it, int n, void* workspace, int64_t workspace_bytes, int grid_cap, int ablate, hipStream_t s) {
+  if (n <= 0) return 0;
+  W256Args g{};
+  int grid = 0, flags = 0;
+  if (int32_t e = wgrad256_plan(it, n, grid_cap, g, grid, flags)) return e;
+  const int64_t need = 64 + (int64_t)flags * 4;   // (== wgrad256_workspace_bytes)
+  if (!workspace || workspace_bytes < need) {
+    otr_set_error("wgrad256: workspace of %lld bytes, need %lld", (long long)workspace_bytes, (long long)need);
+    return -1;
+  }
+  g.ablate = ablate & 7; g.policy = ablate >> 3 ? (ablate >> 3) - 1 : 1;   // (ablate >> 3) - 1: bit 0 non-temporal strips
   g.zeros = workspace;
   g.flags = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(workspace) + 64);
   hipLaunchKernelGGL(wgrad256_init_kernel, dim3(1), dim3(256), 0, s, g.flags, flags, reinterpret_cast<uint32_t*>(workspace));
@@ -515,4 +526,30 @@ extern "C" int32_t otr_debug_trread(const void* image, const int32_t* addr, void
   hipLaunchKernelGGL(trread_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const uint16_t*>(image), addr,
                      reinterpret_cast<uint16_t*>(out));
   return otr_check_launch("debug_trread");
+}
+
+// out: {mode, grid, chunk, nfull, rem_tiles, parts, total slabs, problems} then the first slab of every problem
+extern "C" int32_t otr_debug_wgrad256_plan(const otr_wgrad_item_t* items, int32_t n, int32_t grid_cap, int32_t* out) {
+  OTR_REQUIRE(items && out && n > 0 && n <= W256_MAX_PROBS, "debug_wgrad256_plan: bad arguments");
+  W256Item it[W256_MAX_PROBS];
+  for (int i = 0; i < n; ++i) it[i] = W256Item{items[i].dy, items[i].x, items[i].dw, items[i].dbias, items[i].M, items[i].N, items[i].K,
+                                                items[i].ldy, items[i].ldx, items[i].ldw};
+  W256Args g{};
+  int grid = 0, flags = 0;
+  if (int32_t e = wgrad256_plan(it, n, grid_cap, g, grid, flags)) return e;
+  out[0] = g.mode; out[1] = grid; out[2] = g.chunk; out[3] = g.nfull; out[4] = g.rem_tiles; out[5] = g.parts; out[6] = g.total; out[7] = n;
+  for (int i = 0; i < n; ++i) out[8 + i] = g.p[i].start;
+  return 0;
+}
+
+// pieces of the LAST launch on this workspace that gave up waiting at a turnstile (0 unless workgroups could not be
+// co-resident); synchronises the device
+extern "C" int32_t otr_debug_wgrad256_errors(const void* workspace) {
+  OTR_REQUIRE(workspace, "debug_wgrad256_errors: null workspace");
+  int v = -1;
+  if (hipMemcpy(&v, reinterpret_cast<const int*>(workspace) + 15, 4, hipMemcpyDeviceToHost) != hipSuccess) {
+    otr_set_error("debug_wgrad256_errors: copy failed");
+    return -1;
+  }
+  return v;
 }

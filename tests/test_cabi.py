@@ -137,3 +137,88 @@ def test_wgrad256_eligibility_rule_is_host_logic():
             assert takes(item(7968, 768, 256)) == 0                      # switched off
         finally:
             lib.otr_debug_set(6, -1)
+
+
+def _wgrad256_pieces(plan, starts, Ms):
+    """tests' replay of wgrad256_kernel's work decoding (csrc/wgrad256.hip: slot <- block, pieces of a slot)"""
+    mode, G, chunk, nfull, rem, parts, total, n = plan
+    pieces = []
+    prob_of = lambda pos: max(i for i in range(n) if starts[i] <= pos)      # noqa: E731
+    for bid in range(G):
+        gx, rounds = G >> 3, mode == 1
+        if G & 7 == 0:
+            slot = (bid & 7) * gx + ((bid >> 3) if rounds else gx - 1 - (bid >> 3))
+        else:
+            slot = bid if rounds else G - 1 - bid
+        if rounds:
+            R, rnd = chunk, 0
+            while True:
+                if rnd < nfull:
+                    t, sb, P, sl, ns = rnd * G + slot, 0, R, 0, 1
+                elif rnd == nfull and slot < rem * parts:
+                    part = slot % parts
+                    t, sb = nfull * G + slot // parts, R * part // parts
+                    P, sl, ns = R * (part + 1) // parts - sb, part, parts
+                else:
+                    break
+                rnd += 1
+                pi = prob_of(t * R)
+                pieces.append((pi, (t * R - starts[pi]) // R, sb, P, sl, ns))
+        else:
+            pos, c_end = slot * chunk, min(slot * chunk + chunk, total)
+            while pos < c_end:
+                pi = prob_of(pos)
+                R = (Ms[pi] + 15) // 16
+                rel = pos - starts[pi]
+                tile = rel // R
+                sb = rel - tile * R
+                tb = starts[pi] + tile * R
+                te = tb + R
+                pe = min(te, c_end)
+                first, last = tb // chunk, (te - 1) // chunk
+                pieces.append((pi, tile, sb, pe - pos, last - slot, last - first + 1))
+                pos = pe
+    return pieces
+
+
+def test_wgrad256_schedule_covers_every_slab_once():
+    """otr_debug_wgrad256_plan (host only) + the kernel's decoding replayed here: for the rounds schedule (equal row counts) and
+    the stream-K schedule (mixed row counts, forced), every (problem, tile, 16-row slab) is worked on exactly once, no piece is
+    empty, and the pieces of a tile carry the slice indices 0 .. n-1 of the turnstile exactly once"""
+    import ctypes as C
+    from opentransformer_amd import _lib as L
+    lib = L.load('bf16')
+
+    def items_of(shapes):
+        arr = (L.WgradItem * len(shapes))()
+        for it, (M, N, K) in zip(arr, shapes):
+            it.dy, it.x, it.dw = 0x10000, 0x20000, 0x30000
+            it.M, it.N, it.K, it.ldy, it.ldx, it.ldw = M, N, K, N, K, K
+            it.dy_dtype = it.x_dtype = L.OTR_BF16
+            it.dbias = None
+        return arr
+    layer = [(7968, 768, 256), (7968, 256, 256), (7968, 4096, 256), (7968, 256, 2048)]
+    cases = [(layer * 12 + [(7968, 512, 256)] * 6 + [(7968, 256, 608)], 0),      # the training step: rounds, 1 full round + halves
+             (layer * 12, -248), (layer * 12, 96), (layer, 0), (layer, 3),
+             ([(512, 768, 256), (512, 256, 256), (512, 4096, 256), (512, 256, 2048)] * 6, 0),           # the decoder group
+             ([(1032, 256, 256), (2048, 512, 256), (1544, 256, 768)], 0), ([(1032, 384, 136), (7968, 256, 608)], 7)]
+    for shapes, cap in cases:
+        out = (C.c_int32 * (8 + len(shapes)))()
+        assert lib.otr_debug_wgrad256_plan(items_of(shapes), len(shapes), cap, out) == 0
+        plan, starts = list(out[:8]), list(out[8:])
+        Ms = [s[0] for s in shapes]
+        assert plan[1] >= 1 and (plan[0] == 1) == (len(set(Ms)) == 1 and cap >= 0 and sum(-(-n // 256) * -(-k // 256) for _, n, k in shapes) >= 8)
+        seen, slices = {}, {}
+        for pi, tile, sb, P, sl, ns in _wgrad256_pieces(plan, starts, Ms):
+            R = (Ms[pi] + 15) // 16
+            tiles = -(-shapes[pi][1] // 256) * -(-shapes[pi][2] // 256)
+            assert 0 <= tile < tiles and P >= 1 and 0 <= sb and sb + P <= R and 0 <= sl < ns, (shapes[pi], tile, sb, P, sl, ns)
+            for sidx in range(sb, sb + P):
+                assert (pi, tile, sidx) not in seen
+                seen[(pi, tile, sidx)] = 1
+            slices.setdefault((pi, tile), []).append((sl, ns))
+        want = sum(-(-n // 256) * -(-k // 256) * ((m + 15) // 16) for m, n, k in shapes)
+        assert len(seen) == want == plan[6], (len(seen), want, plan)
+        for key, lst in slices.items():
+            ns = lst[0][1]
+            assert all(n == ns for _, n in lst) and sorted(s for s, _ in lst) == list(range(ns)), (key, lst)

@@ -42,7 +42,7 @@ def test_trread_lane_mapping():
         assert np.array_equal(got, want), (trial, got[:20], want[:20])
 
 
-def _run(items, mode, grid, on=1):
+def _run(items, mode, grid, on=1, all_taken=True):
     """items: list of (dy, x, out).  Runs otr_linear_wgrad_grouped with the 256-wide launch forced on / off."""
     from opentransformer_amd import ops
     L, lib = _lib()
@@ -52,6 +52,8 @@ def _run(items, mode, grid, on=1):
         ops._wq['w'], ops._wq['b'] = list(items), []
         ops.flush_weight_grads()
         torch.cuda.synchronize()
+        if on and all_taken:   # no piece gave up at a turnstile (the grouped kernel's table would overwrite the counter)
+            assert lib.otr_debug_wgrad256_errors(ops._p(ops._workspace(items[0][0].device))) == 0
     finally:
         lib.otr_debug_set(6, -1)
         lib.otr_debug_set(7, 0)
@@ -117,7 +119,7 @@ def test_wgrad256_mixed_with_unqualified_items():
         out = torch.zeros(n, k, device=DEV)
         items.append((dy, x, out))
         refs.append(dy.float().t() @ x.float())
-    _run(items, 'bf16', 0)
+    _run(items, 'bf16', 0, all_taken=False)
     for (dy, x, out), ref in zip(items, refs):
         tol = 2e-5 if dy.dtype == adt else 1e-2           # an fp32 dy is rounded to the 16-bit type by the grouped kernel
         assert float((out - ref).abs().max()) / float(ref.abs().max()) < tol, tuple(dy.shape)
