@@ -257,6 +257,12 @@ int32_t otr_add_layernorm_bwd(const otr_ln_desc_t* d, const float* dy, const flo
  * da_colsum (they may be NULL); each workgroup writes its own sums (dgamma | dbeta | da column sums) to its row and the
  * caller column-sums the rows (otr_colsum / otr_colsum_grouped): no atomics, deterministic. */
 int64_t otr_add_layernorm_bwd_partial_rows(int64_t M);
+/* the same with dx = skip + (gradient w.r.t. the LayerNorm input), skip f32 [M,d] or NULL: a pre-norm residual
+ * x + f(LN(x)) (encoder/conformer.py:50-73; normalize_before layers) hands x two gradients, and this saves the elementwise
+ * add autograd would launch to join them.  skip may alias dx. */
+int32_t otr_add_layernorm_bwd_skip(const otr_ln_desc_t* d, const float* dy, const float* z, const float* mean,
+                                   const float* rstd, const float* gamma, const uint64_t* seed, const float* skip, float* dx,
+                                   void* da, float* dgamma, float* dbeta, float* da_colsum, float* partial, void* stream);
 
 /* ---- F.glu / F.relu on the FFN hidden (module/ffn.py:15-21,40): u[M,F] = h[:, :F]*sigmoid(h[:, F:]) */
 /* row_mask (uint8 [M], may be NULL): rows with mask 0 produce u = 0 / dh = 0 (module/conformer.py:46) */
@@ -314,6 +320,13 @@ int32_t otr_conv2_wgrad(const otr_conv_desc_t* d, const void* dact2, const void*
                         int64_t workspace_bytes, void* stream);
 /* g = g * (y > 0) elementwise (ReLU backward through a stored post-ReLU activation); g may alias out */
 int32_t otr_relu_bwd(const void* y, const void* g, void* out, int32_t dtype, int64_t n, void* stream);
+/* The same over a [rows, cols] matrix plus the bias gradient of the layer that produced y (column sums of out) in one pass:
+ * partial [otr_relu_bwd_colsum_partial_rows(rows, cols, dtype)][cols] f32 receives per-workgroup sums (no atomics) for the
+ * caller's column sum.  The second Conv2dLayer of frontend/conv.py:63-66 (relu then bias, C2 channels) is the user.
+ * partial_rows returns 0 when the shape is not served (cols must be a multiple of the 16-byte vector, cols / vector dividing 256). */
+int32_t otr_relu_bwd_colsum_partial_rows(int64_t rows, int32_t cols, int32_t dtype);
+int32_t otr_relu_bwd_colsum(const void* y, const void* g, void* out, float* partial, int32_t dtype, int64_t rows, int32_t cols,
+                            void* stream);
 
 /* The other FFN activations of module/ffn.py:15-21 (relu runs in the GEMM epilogue, glu has otr_glu_* / otr_ffn_glu_*):
  * kind 1 = gelu (erf form, F.gelu's default), 2 = tanh, 3 = swish (x * sigmoid(x)).  y = act(x);  dx = dy * act'(x) from
@@ -350,6 +363,10 @@ int32_t otr_add2_strided(const void* a, int64_t lda, const void* b, int64_t ldb,
                          int64_t M, int32_t cols, void* stream);
 /* out = x where mask[row] else 0 (f32) */
 int32_t otr_row_mask(const float* x, const uint8_t* mask, float* out, int64_t M, int32_t C, void* stream);
+/* the same with a type change on the way (OTR_F32 / OTR_H16 either side): the Conformer convolution module hands its
+ * branch to the residual add, and takes the gradient back, in the activation type (module/conformer.py:56) */
+int32_t otr_row_mask_cast(const void* x, int32_t x_dtype, const uint8_t* mask, void* out, int32_t out_dtype, int64_t M,
+                          int32_t C, void* stream);
 /* depthwise Conv1d over time, channel-last, per utterance, zero padded:
  *   y[b,t,c] = bias[c] + sum_{j<k} w[c,j] * g[b, t + j - pad, c]          k <= 7, 0 <= pad < k
  * pad = (k-1)/2 is the Conformer's 'same' convolution (module/conformer.py:26-28); pad = 0 with k = lookahead_steps + 1 is
@@ -365,9 +382,13 @@ int32_t otr_dwconv_bwd(const float* dy, const void* g, int32_t dtype, const floa
 int32_t otr_bn_swish_fwd(const float* y, const float* stats, const float* gamma, const float* beta, float* running_mean,
                          float* running_var, float* saved, void* out, int32_t out_dtype, int64_t M, int32_t C, float eps,
                          float momentum, int32_t training, void* stream);
-/* red f32 [2C]: on return d beta | d gamma; dy f32 [M,C] = gradient w.r.t. the BatchNorm input */
+/* red f32 [2C]: on return d beta | d gamma of THIS call; dy f32 [M,C] = gradient w.r.t. the BatchNorm input.
+ * partial: f32 scratch [otr_bn_swish_bwd_partial_rows(M)][2C] (per-strip sums: no atomics, deterministic).
+ * dgamma_acc / dbeta_acc (f32 [C], may be NULL): the parameter gradients, += the same sums in the reduction launch. */
+int32_t otr_bn_swish_bwd_partial_rows(int64_t M);
 int32_t otr_bn_swish_bwd(const float* y, const void* ds, int32_t ds_dtype, const float* saved, const float* gamma,
-                         const float* beta, float* red, float* dy, int64_t M, int32_t C, int32_t training, void* stream);
+                         const float* beta, float* red, float* partial, float* dgamma_acc, float* dbeta_acc, float* dy,
+                         int64_t M, int32_t C, int32_t training, void* stream);
 
 /* ---- CTC loss with gradient w.r.t. the logits (nn.CTCLoss(blank, zero_infinity=True), reduction
  *      'mean', as built at model/ctc.py:30 and called at :50-53).  log_probs f32 [B,T,V] (already

@@ -84,6 +84,7 @@ SIGNATURES = {
     'otr_attention_bias_bwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_add_layernorm_fwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_add_layernorm_bwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    'otr_add_layernorm_bwd_skip': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_add_layernorm_bwd_partial_rows': [_I64],
     'otr_rb_linear': [_P, _I64, _P, _P, _P, _I64, _P, _I32, _I64, _I64, _I32, _I32, _P],
     'otr_proj_ln_fwd': [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F32, _F32, C.c_uint64, _P],
@@ -111,6 +112,8 @@ SIGNATURES = {
     'otr_conv2_col2im': [C.POINTER(ConvDesc), _P, _P, _P, _P],
     'otr_conv2_wgrad': [C.POINTER(ConvDesc), _P, _P, _P, _P, _I64, _P],
     'otr_relu_bwd': [_P, _P, _P, _I32, _I64, _P],
+    'otr_relu_bwd_colsum_partial_rows': [_I64, _I32, _I32],
+    'otr_relu_bwd_colsum': [_P, _P, _P, _P, _I32, _I64, _I32, _P],
     'otr_act_fwd': [_P, _P, _I32, _I64, _I32, _P],
     'otr_act_bwd': [_P, _P, _P, _I32, _I64, _I32, _P],
     'otr_label_smoothing_loss': [_P, _P, _I64, _I32, _F32, _I32, _P, _P, _P, _P],
@@ -132,10 +135,12 @@ SIGNATURES = {
     'otr_head_bias_add': [_P, _I64, _P, _P, _P, _I32, _I64, _I32, _P],
     'otr_add2_strided': [_P, _I64, _P, _I64, _P, _I64, _I32, _I64, _I32, _P],
     'otr_row_mask': [_P, _P, _P, _I64, _I32, _P],
+    'otr_row_mask_cast': [_P, _I32, _P, _P, _I32, _I64, _I32, _P],
     'otr_dwconv_fwd': [_P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
     'otr_dwconv_bwd': [_P, _P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
     'otr_bn_swish_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _F32, _F32, _I32, _P],
-    'otr_bn_swish_bwd': [_P, _P, _I32, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
+    'otr_bn_swish_bwd_partial_rows': [_I64],
+    'otr_bn_swish_bwd': [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
 }
 _RESTYPE = {'otr_last_error_string': C.c_char_p, 'otr_add_layernorm_bwd_partial_rows': C.c_int64,
             'otr_ln_bwd_proj_partial_rows': C.c_int64}

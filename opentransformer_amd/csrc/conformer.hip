@@ -10,8 +10,6 @@
 // thread over a strip of rows and merged with one fp32 atomic per (workgroup, channel).
 #include "common.h"
 
-constexpr int CF_BLOCK = 128;  // threads: channel groups of 4
-constexpr int CF_RPB = 16;     // rows per workgroup strip
 
 template <class T> __device__ __forceinline__ void ldc4(const T* p, float* o) { load_row<T, 4>(p, 4, true, o); }
 template <class T> __device__ __forceinline__ void stc4(T* p, const float* o) {
@@ -19,7 +17,6 @@ template <class T> __device__ __forceinline__ void stc4(T* p, const float* o) {
   else *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
 }
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
-static inline dim3 strip_grid(int64_t M) { return dim3((unsigned)((M + CF_RPB - 1) / CF_RPB)); }
 
 // ------------------------------------------------------------------------------------------------ residual add
 template <class AT> __global__ void residual_add_fwd_kernel(const float* x, const AT* a, float* y, int64_t n4, float scale,
@@ -167,22 +164,33 @@ extern "C" int32_t otr_add2_strided(const void* a, int64_t lda, const void* b, i
 }
 
 // ------------------------------------------------------------------------------------------------ row mask
-__global__ void row_mask_kernel(const float* x, const uint8_t* mask, float* out, int64_t M, int C) {
+template <class TI, class TO> __global__ void row_mask_kernel(const TI* x, const uint8_t* mask, TO* out, int64_t M, int C) {
   const int c4 = C / 4;
   const int64_t total = M * c4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t row = i / c4;
-    float4 v = reinterpret_cast<const float4*>(x)[i];
-    if (!mask[row]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-    reinterpret_cast<float4*>(out)[i] = v;
+    float v[4];
+    ldc4<TI>(x + i * 4, v);
+    if (!mask[row]) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+    stc4<TO>(out + i * 4, v);
   }
 }
-extern "C" int32_t otr_row_mask(const float* x, const uint8_t* mask, float* out, int64_t M, int32_t C, void* stream) {
+extern "C" int32_t otr_row_mask_cast(const void* x, int32_t x_dtype, const uint8_t* mask, void* out, int32_t out_dtype, int64_t M,
+                                     int32_t C, void* stream) {
   OTR_REQUIRE(x && mask && out, "row_mask: null pointer");
   OTR_REQUIRE(C % 4 == 0, "row_mask: C must be a multiple of 4");
+  OTR_REQUIRE((x_dtype == OTR_F32 || x_dtype == OTR_H16) && (out_dtype == OTR_F32 || out_dtype == OTR_H16), "row_mask: bad dtype");
   if (M <= 0) return 0;
-  hipLaunchKernelGGL(row_mask_kernel, dim3(ew_grid(M * C / 4)), dim3(256), 0, (hipStream_t)stream, x, mask, out, M, C);
+  const dim3 g(ew_grid(M * C / 4));
+  hipStream_t s = (hipStream_t)stream;
+  if (x_dtype == OTR_F32 && out_dtype == OTR_F32) hipLaunchKernelGGL((row_mask_kernel<float, float>), g, dim3(256), 0, s, (const float*)x, mask, (float*)out, M, C);
+  else if (x_dtype == OTR_F32) hipLaunchKernelGGL((row_mask_kernel<float, bf16_t>), g, dim3(256), 0, s, (const float*)x, mask, (bf16_t*)out, M, C);
+  else if (out_dtype == OTR_F32) hipLaunchKernelGGL((row_mask_kernel<bf16_t, float>), g, dim3(256), 0, s, (const bf16_t*)x, mask, (float*)out, M, C);
+  else hipLaunchKernelGGL((row_mask_kernel<bf16_t, bf16_t>), g, dim3(256), 0, s, (const bf16_t*)x, mask, (bf16_t*)out, M, C);
   return otr_check_launch("row_mask");
+}
+extern "C" int32_t otr_row_mask(const float* x, const uint8_t* mask, float* out, int64_t M, int32_t C, void* stream) {
+  return otr_row_mask_cast(x, OTR_F32, mask, out, OTR_F32, M, C, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise conv + BN stats
@@ -395,41 +403,87 @@ template <class T> __global__ void bn_swish_fwd_kernel(const float* y, const flo
   }
 }
 
-// MODE 0: red[c] += sum dz, red[C+c] += sum dz*xhat      MODE 1: dy = gamma*rstd*(dz - red0/N - xhat*red1/N)
-template <class T, int MODE> __global__ __launch_bounds__(CF_BLOCK) void bn_swish_bwd_kernel(const float* y, const T* ds, const float* saved,
-                                                                                          const float* gamma, const float* beta, float* red,
-                                                                                          float* dy, int64_t M, int C, float n, int training) {
-  const int C4 = C / 4;
-  const int64_t r0 = (int64_t)blockIdx.x * CF_RPB, r1 = min(M, r0 + CF_RPB);
-  for (int cg = threadIdx.x; cg < C4; cg += CF_BLOCK) {
-    const int c = cg * 4;
-    float mean[4], rstd[4], gam[4], bet[4], a0[4], a1[4];
+// MODE 0: partial[strip][c] = sum dz, partial[strip][C+c] = sum dz*xhat over the strip's rows (no atomics; bn_reduce_kernel
+// sums the strips)      MODE 1: dy = gamma*rstd*(dz - red0/N - xhat*red1/N)
+// Block = TX channel groups (4 channels each; TX = largest power of two dividing C/4) x 256/TX row lanes on a BN_RPB-row
+// strip, four rows per lane in flight.  (First version: 16-row strips walked serially by 96 of 128 threads, then 2C atomics
+// per workgroup onto the same 2C addresses: 61 us of which most was the atomics.)
+constexpr int BN_RPB = 32;
+template <class T, int MODE> __global__ __launch_bounds__(256) void bn_swish_bwd_kernel(const float* y, const T* ds, const float* saved,
+                                                                                      const float* gamma, const float* beta, const float* red,
+                                                                                      float* partial, float* dy, int64_t M, int C, float n,
+                                                                                      int training, int TX) {
+  __shared__ float sh[256][9];
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
+  const int c = (blockIdx.x * TX + tx) * 4;
+  const int64_t r0 = (int64_t)blockIdx.y * BN_RPB, r1 = min(M, r0 + BN_RPB);
+  float mean[4], rstd[4], gam[4], bet[4], a0[4], a1[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      mean[e] = saved[c + e]; rstd[e] = saved[C + c + e]; gam[e] = gamma[c + e]; bet[e] = beta[c + e];
-      a0[e] = 0.f; a1[e] = 0.f;
-      if (MODE == 1) { a0[e] = red[c + e] / n; a1[e] = red[C + c + e] / n; }
+  for (int e = 0; e < 4; ++e) {
+    mean[e] = saved[c + e]; rstd[e] = saved[C + c + e]; gam[e] = gamma[c + e]; bet[e] = beta[c + e];
+    a0[e] = 0.f; a1[e] = 0.f;
+    if (MODE == 1) { a0[e] = red[c + e] / n; a1[e] = red[C + c + e] / n; }
+  }
+  constexpr int UNR = 4;
+  for (int64_t base = r0 + ty; base < r1; base += (int64_t)TY * UNR) {
+    float yv[UNR][4], dsv[UNR][4];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t row = min(base + (int64_t)u * TY, r1 - 1);
+      ldc4<float>(y + row * C + c, yv[u]);
+      ldc4<T>(ds + row * C + c, dsv[u]);
     }
-    for (int64_t row = r0; row < r1; ++row) {
-      float yv[4], dsv[4], o[4];
-      ldc4<float>(y + row * C + c, yv);
-      ldc4<T>(ds + row * C + c, dsv);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t row = base + (int64_t)u * TY;
+      if (row >= r1) break;
+      float o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float xh = (yv[e] - mean[e]) * rstd[e];
+        float xh = (yv[u][e] - mean[e]) * rstd[e];
         float z = xh * gam[e] + bet[e];
         float sg = sigm(z);
-        float dz = dsv[e] * (sg + z * sg * (1.f - sg));
+        float dz = dsv[u][e] * (sg + z * sg * (1.f - sg));
         if (MODE == 0) { a0[e] += dz; a1[e] += dz * xh; }
         else o[e] = training ? gam[e] * rstd[e] * (dz - a0[e] - xh * a1[e]) : gam[e] * rstd[e] * dz;
       }
       if (MODE == 1) stc4<float>(dy + row * C + c, o);
     }
-    if (MODE == 0) {
+  }
+  if (MODE == 0) {
+    if (TY > 1) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { atomicAdd(red + c + e, a0[e]); atomicAdd(red + C + c + e, a1[e]); }
+      for (int e = 0; e < 4; ++e) { sh[threadIdx.x][e] = a0[e]; sh[threadIdx.x][4 + e] = a1[e]; }
+      __syncthreads();
+      if (ty == 0)
+        for (int k = 1; k < TY; ++k) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a0[e] += sh[k * TX + tx][e]; a1[e] += sh[k * TX + tx][4 + e]; }
+        }
+    }
+    if (ty == 0) {
+      float* dst = partial + (int64_t)blockIdx.y * 2 * C;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { dst[c + e] = a0[e]; dst[C + c + e] = a1[e]; }
     }
   }
+}
+// red[j] = sum over strips of partial[strip][j] (j < 2C); optionally the same sums are added to the parameter gradients
+// (dbeta += red[:C], dgamma += red[C:]) so the caller has no elementwise add to launch
+__global__ void bn_reduce_kernel(const float* partial, int nstrip, int C, float* red, float* dgamma, float* dbeta) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= 2 * C) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < nstrip; k += 4) {
+    s0 += partial[(int64_t)k * 2 * C + j]; s1 += partial[(int64_t)(k + 1) * 2 * C + j];
+    s2 += partial[(int64_t)(k + 2) * 2 * C + j]; s3 += partial[(int64_t)(k + 3) * 2 * C + j];
+  }
+  for (; k < nstrip; ++k) s0 += partial[(int64_t)k * 2 * C + j];
+  const float t = (s0 + s1) + (s2 + s3);
+  red[j] = t;
+  if (j < C) { if (dbeta) dbeta[j] += t; }
+  else if (dgamma) dgamma[j - C] += t;
 }
 
 extern "C" int32_t otr_bn_swish_fwd(const float* y, const float* stats, const float* gamma, const float* beta,
@@ -446,20 +500,25 @@ extern "C" int32_t otr_bn_swish_fwd(const float* y, const float* stats, const fl
   return otr_check_launch("bn_swish_fwd");
 }
 
-// red: f32 [2C] zeroed here; on return red[c] = d beta, red[C + c] = d gamma.  dy: f32 [M, C].
+// red: f32 [2C]; on return red[c] = d beta, red[C + c] = d gamma (this call's sums; also the input of the second pass).
+// partial: f32 [otr_bn_swish_bwd_partial_rows(M)][2C] scratch.  dgamma_acc / dbeta_acc (f32 [C], may be NULL): += the same sums.
+// dy: f32 [M, C].
+extern "C" int32_t otr_bn_swish_bwd_partial_rows(int64_t M) { return (int32_t)((M + BN_RPB - 1) / BN_RPB); }
 extern "C" int32_t otr_bn_swish_bwd(const float* y, const void* ds, int32_t ds_dtype, const float* saved, const float* gamma,
-                                    const float* beta, float* red, float* dy, int64_t M, int32_t C, int32_t training,
-                                    void* stream) {
-  OTR_REQUIRE(y && ds && saved && gamma && beta && red && dy, "bn_swish_bwd: null pointer");
+                                    const float* beta, float* red, float* partial, float* dgamma_acc, float* dbeta_acc, float* dy,
+                                    int64_t M, int32_t C, int32_t training, void* stream) {
+  OTR_REQUIRE(y && ds && saved && gamma && beta && red && partial && dy, "bn_swish_bwd: null pointer");
   OTR_REQUIRE(C % 4 == 0 && M > 0, "bn_swish_bwd: bad shape");
   hipStream_t s = (hipStream_t)stream;
-  otr_zero_f32(red, 2 * C, s);
-  if (ds_dtype == OTR_F32) {
-    hipLaunchKernelGGL((bn_swish_bwd_kernel<float, 0>), strip_grid(M), dim3(CF_BLOCK), 0, s, y, (const float*)ds, saved, gamma, beta, red, dy, M, C, (float)M, training);
-    hipLaunchKernelGGL((bn_swish_bwd_kernel<float, 1>), strip_grid(M), dim3(CF_BLOCK), 0, s, y, (const float*)ds, saved, gamma, beta, red, dy, M, C, (float)M, training);
-  } else {
-    hipLaunchKernelGGL((bn_swish_bwd_kernel<bf16_t, 0>), strip_grid(M), dim3(CF_BLOCK), 0, s, y, (const bf16_t*)ds, saved, gamma, beta, red, dy, M, C, (float)M, training);
-    hipLaunchKernelGGL((bn_swish_bwd_kernel<bf16_t, 1>), strip_grid(M), dim3(CF_BLOCK), 0, s, y, (const bf16_t*)ds, saved, gamma, beta, red, dy, M, C, (float)M, training);
-  }
+  const int C4 = C / 4;
+  int TX = 1;
+  while (TX < 256 && C4 % (2 * TX) == 0) TX *= 2;
+  const int nstrip = (int)((M + BN_RPB - 1) / BN_RPB);
+  const dim3 grid((unsigned)(C4 / TX), (unsigned)nstrip);
+#define BN_BWD(T, MODE) hipLaunchKernelGGL((bn_swish_bwd_kernel<T, MODE>), grid, dim3(256), 0, s, y, (const T*)ds, saved, gamma, beta, red, partial, dy, M, C, (float)M, training, TX)
+  if (ds_dtype == OTR_F32) BN_BWD(float, 0); else BN_BWD(bf16_t, 0);
+  hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, s, partial, nstrip, C, red, dgamma_acc, dbeta_acc);
+  if (ds_dtype == OTR_F32) BN_BWD(float, 1); else BN_BWD(bf16_t, 1);
+#undef BN_BWD
   return otr_check_launch("bn_swish_bwd");
 }

@@ -31,40 +31,70 @@ template <class T> __global__ void glu_fwd_kernel(const T* h, T* u, int64_t M, i
 
 // dh[:, :F] = du * sig(g);  dh[:, F:] = du * a * sig(g) * (1 - sig(g));  optional bias-gradient partials
 constexpr int GLU_RPB = 32;  // rows per block in the backward (each thread owns V columns)
-template <class T> __global__ void glu_bwd_kernel(const T* h, const T* du, T* dh, float* dbias, int64_t M, int64_t F,
-                                                  const uint8_t* row_mask, int has_sig) {
+// Block = TX column threads (16 bytes of a row each) x 256/TX row lanes; gridDim.x * TX covers F exactly (TX is the largest
+// power of two dividing F / V, so narrow matrices -- the conformer's F = 384 gate -- still fill their 256 threads), blockIdx.y
+// picks the GLU_RPB-row strip.  Four rows per lane are in flight (a serial 32-row walk per thread left the 120 MB pass of the
+// conformer FFN latency-bound at 43 us).
+template <class T> __global__ __launch_bounds__(256) void glu_bwd_kernel(const T* h, const T* du, T* dh, float* dbias, int64_t M, int64_t F,
+                                                                         const uint8_t* row_mask, int has_sig, int TX) {
   constexpr int V = 16 / sizeof(T);
-  const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
-  if (c >= F) return;
+  __shared__ float red[256][2 * V + 1];
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
+  const int64_t c = ((int64_t)blockIdx.x * TX + tx) * V;
   float sa[V], sg[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) { sa[e] = 0.f; sg[e] = 0.f; }
   const int64_t r0 = (int64_t)blockIdx.y * GLU_RPB, r1 = min(M, r0 + GLU_RPB);
-  for (int64_t row = r0; row < r1; ++row) {
-    float a[V], g[V], d[V], oa[V], og[V];
-    load_row<T, V>(h + row * 2 * F + c, V, true, a);
-    load_row<T, V>(h + row * 2 * F + F + c, V, true, g);
-    load_row<T, V>(du + row * F + c, V, true, d);
+  constexpr int UNR = 4;
+  for (int64_t base = r0 + ty; base < r1; base += (int64_t)TY * UNR) {
+    float a[UNR][V], g[UNR][V], d[UNR][V];
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-      float s = has_sig ? g[e] : sigmoidf_(g[e]);       // h[:, F:] may already hold sigmoid(gate) (otr_ffn_glu_fwd)
-      float dd = (!row_mask || row_mask[row]) ? d[e] : 0.f;     // masked_fill_(~mask, 0) after the GLU
-      oa[e] = dd * s;
-      og[e] = dd * a[e] * s * (1.f - s);
-      sa[e] += oa[e]; sg[e] += og[e];
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t row = min(base + (int64_t)u * TY, r1 - 1);        // clamped duplicates are not stored or summed
+      load_row<T, V>(h + row * 2 * F + c, V, true, a[u]);
+      load_row<T, V>(h + row * 2 * F + F + c, V, true, g[u]);
+      load_row<T, V>(du + row * F + c, V, true, d[u]);
     }
-    if constexpr (sizeof(T) == 4) {
-      *reinterpret_cast<float4*>(dh + row * 2 * F + c) = make_float4(oa[0], oa[1], oa[2], oa[3]);
-      *reinterpret_cast<float4*>(dh + row * 2 * F + F + c) = make_float4(og[0], og[1], og[2], og[3]);
-    } else {
-      *reinterpret_cast<uint4*>(dh + row * 2 * F + c) = MMA<bf16_t>::pack(oa);
-      *reinterpret_cast<uint4*>(dh + row * 2 * F + F + c) = MMA<bf16_t>::pack(og);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t row = base + (int64_t)u * TY;
+      if (row >= r1) break;
+      const bool keep = !row_mask || row_mask[row];                   // masked_fill_(~mask, 0) after the GLU
+      float oa[V], og[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        float sgm = has_sig ? g[u][e] : sigmoidf_(g[u][e]);           // h[:, F:] may already hold sigmoid(gate) (otr_ffn_glu_fwd)
+        float dd = keep ? d[u][e] : 0.f;
+        oa[e] = dd * sgm;
+        og[e] = dd * a[u][e] * sgm * (1.f - sgm);
+        sa[e] += oa[e]; sg[e] += og[e];
+      }
+      if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(dh + row * 2 * F + c) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+        *reinterpret_cast<float4*>(dh + row * 2 * F + F + c) = make_float4(og[0], og[1], og[2], og[3]);
+      } else {
+        *reinterpret_cast<uint4*>(dh + row * 2 * F + c) = MMA<bf16_t>::pack(oa);
+        *reinterpret_cast<uint4*>(dh + row * 2 * F + F + c) = MMA<bf16_t>::pack(og);
+      }
     }
   }
   if (dbias) {  // per-row-block partial column sums [gridDim.y][2F] (no atomics); the caller column-sums them
-    float* dst = dbias + (int64_t)blockIdx.y * 2 * F;
+    if (TY > 1) {
 #pragma unroll
-    for (int e = 0; e < V; ++e) { dst[c + e] = sa[e]; dst[F + c + e] = sg[e]; }
+      for (int e = 0; e < V; ++e) { red[threadIdx.x][e] = sa[e]; red[threadIdx.x][V + e] = sg[e]; }
+      __syncthreads();
+      if (ty == 0) {
+        for (int k = 1; k < TY; ++k) {
+#pragma unroll
+          for (int e = 0; e < V; ++e) { sa[e] += red[k * TX + tx][e]; sg[e] += red[k * TX + tx][V + e]; }
+        }
+      }
+    }
+    if (ty == 0) {
+      float* dst = dbias + (int64_t)blockIdx.y * 2 * F;
+#pragma unroll
+      for (int e = 0; e < V; ++e) { dst[c + e] = sa[e]; dst[F + c + e] = sg[e]; }
+    }
   }
 }
 
@@ -88,9 +118,12 @@ extern "C" int32_t otr_glu_bwd(const void* h, const void* du, void* dh, float* d
   if (M == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   int V = dtype == OTR_F32 ? 4 : 8;
-  dim3 grid((unsigned)((F / V + 255) / 256), (unsigned)((M + GLU_RPB - 1) / GLU_RPB));
-  if (dtype == OTR_F32) hipLaunchKernelGGL(glu_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)h, (const float*)du, (float*)dh, dbias, M, F, row_mask, h_has_sigmoid);
-  else hipLaunchKernelGGL(glu_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)h, (const bf16_t*)du, (bf16_t*)dh, dbias, M, F, row_mask, h_has_sigmoid);
+  const int64_t cols = F / V;                    // 16-byte column groups per row
+  int TX = 1;
+  while (TX < 256 && cols % (2 * TX) == 0) TX *= 2;
+  dim3 grid((unsigned)(cols / TX), (unsigned)((M + GLU_RPB - 1) / GLU_RPB));
+  if (dtype == OTR_F32) hipLaunchKernelGGL(glu_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)h, (const float*)du, (float*)dh, dbias, M, F, row_mask, h_has_sigmoid, TX);
+  else hipLaunchKernelGGL(glu_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)h, (const bf16_t*)du, (bf16_t*)dh, dbias, M, F, row_mask, h_has_sigmoid, TX);
   return otr_check_launch("glu_bwd");
 }
 
@@ -107,6 +140,83 @@ extern "C" int32_t otr_relu_bwd(const void* y, const void* g, void* out, int32_t
   if (dtype == OTR_F32) hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)y, (const float*)g, (float*)out, n);
   else hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)y, (const bf16_t*)g, (bf16_t*)out, n);
   return otr_check_launch("relu_bwd");
+}
+
+// ReLU backward of a [rows, cols] matrix with the bias gradient (column sums of the result) in the same pass: the conv2 layer of
+// the frontend (frontend/conv.py:63-66) needs both, and the separate column-sum launch re-read the 41 MB it had just written.
+// A thread owns 16 bytes of a row; blocks stride over the rows, four rows in flight per lane; every block leaves one row of
+// per-block sums in `partial` [gridDim.x][cols] for the caller's (deferred, grouped) column sum -- no atomics.
+constexpr int RBC_MAX_BLOCKS = 1024;
+template <class T> __global__ __launch_bounds__(256) void relu_bwd_colsum_kernel(const T* __restrict__ y, const T* __restrict__ g,
+                                                                                 T* __restrict__ out, float* __restrict__ partial,
+                                                                                 int64_t rows, int cols) {
+  constexpr int V = 16 / (int)sizeof(T);
+  __shared__ float red[256][V + 1];
+  const int tpr = cols / V;                    // threads per row (divides 256)
+  const int cg = threadIdx.x % tpr, rpi = 256 / tpr;
+  float s[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) s[e] = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * rpi;
+  int64_t r = (int64_t)blockIdx.x * rpi + threadIdx.x / tpr;
+  auto one = [&](const float* yv, const float* gv, int64_t row) {
+    float o[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { o[e] = yv[e] > 0.f ? gv[e] : 0.f; s[e] += o[e]; }
+    T* dst = out + row * cols + cg * V;
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    else *reinterpret_cast<uint4*>(dst) = MMA<bf16_t>::pack(o);
+  };
+  for (; r + 3 * stride < rows; r += 4 * stride) {
+    float yv[4][V], gv[4][V];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      load_row<T, V>(y + (r + u * stride) * cols + cg * V, V, true, yv[u]);
+      load_row<T, V>(g + (r + u * stride) * cols + cg * V, V, true, gv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(yv[u], gv[u], r + u * stride);
+  }
+  for (; r < rows; r += stride) {
+    float yv[V], gv[V];
+    load_row<T, V>(y + r * cols + cg * V, V, true, yv);
+    load_row<T, V>(g + r * cols + cg * V, V, true, gv);
+    one(yv, gv, r);
+  }
+#pragma unroll
+  for (int e = 0; e < V; ++e) red[threadIdx.x][e] = s[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const int t0 = c / V, e = c % V;
+    float a = 0.f;
+    for (int k = 0; k < rpi; ++k) a += red[k * tpr + t0][e];
+    partial[(int64_t)blockIdx.x * cols + c] = a;
+  }
+}
+static inline int rbc_blocks(int64_t rows, int cols, int dtype) {
+  const int V = dtype == OTR_F32 ? 4 : 8, rpi = 256 / (cols / V);
+  const int64_t need = (rows + rpi - 1) / rpi;
+  return (int)(need < 1 ? 1 : (need > RBC_MAX_BLOCKS ? RBC_MAX_BLOCKS : need));
+}
+static inline bool rbc_shape_ok(int64_t rows, int cols, int dtype) {
+  const int V = dtype == OTR_F32 ? 4 : 8;
+  return rows > 0 && cols > 0 && cols % V == 0 && cols / V <= 256 && 256 % (cols / V) == 0;
+}
+extern "C" int32_t otr_relu_bwd_colsum_partial_rows(int64_t rows, int32_t cols, int32_t dtype) {
+  if ((dtype != OTR_F32 && dtype != OTR_H16) || !rbc_shape_ok(rows, cols, dtype)) return 0;     // 0: shape not served
+  return rbc_blocks(rows, cols, dtype);
+}
+extern "C" int32_t otr_relu_bwd_colsum(const void* y, const void* g, void* out, float* partial, int32_t dtype, int64_t rows,
+                                       int32_t cols, void* stream) {
+  OTR_REQUIRE(y && g && out && partial, "relu_bwd_colsum: null pointer");
+  OTR_REQUIRE(dtype == OTR_F32 || dtype == OTR_H16, "relu_bwd_colsum: bad dtype");
+  OTR_REQUIRE(rbc_shape_ok(rows, cols, dtype), "relu_bwd_colsum: cols=%d must be a multiple of the 16-byte vector with cols/vector dividing 256", cols);
+  OTR_REQUIRE(((uintptr_t)y | (uintptr_t)g | (uintptr_t)out) % 16 == 0, "relu_bwd_colsum: operands must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)rbc_blocks(rows, cols, dtype));
+  if (dtype == OTR_F32) hipLaunchKernelGGL(relu_bwd_colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)y, (const float*)g, (float*)out, partial, rows, cols);
+  else hipLaunchKernelGGL(relu_bwd_colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)y, (const bf16_t*)g, (bf16_t*)out, partial, rows, cols);
+  return otr_check_launch("relu_bwd_colsum");
 }
 
 // ------------------------------------------------------------------------------------------------ FFN activations

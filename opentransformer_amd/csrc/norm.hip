@@ -11,6 +11,7 @@ struct LnArgs {
   int64_t M; int d;
   float eps, p_drop;
   uint64_t rng_offset;
+  const float* skip;                                      // backward: dx = skip + LayerNorm input gradient (pre-norm residual)
   int nslab; int64_t slab_stride; const float* a_bias;   // SLABS: a = a_bias + sum of nslab f32 slabs (slab_stride elements apart)
 };
 
@@ -173,7 +174,15 @@ template <class AT, bool HAS_A, int NV> __global__ __launch_bounds__(256) void a
           float dz[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) dz[e] = rstd[rr] * (dyv[rr][i][e] * gam[i][e] - s1 - zh[rr][i][e] * s2);
-          st4<float>(p.dx + row * d + col, dz);
+          if (p.skip) {
+            float sk[4];
+            ld4<float>(p.skip + row * d + col, sk);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sk[e] += dz[e];
+            st4<float>(p.dx + row * d + col, sk);
+          } else {
+            st4<float>(p.dx + row * d + col, dz);
+          }
           if constexpr (HAS_A) {
             if (p.da) {
               float o[4];
@@ -275,13 +284,19 @@ extern "C" int32_t otr_add_layernorm_bwd(const otr_ln_desc_t* d, const float* dy
                                          const float* rstd, const float* gamma, const uint64_t* seed, float* dx,
                                          void* da, float* dgamma, float* dbeta, float* da_colsum, float* partial,
                                          void* stream) {
+  return otr_add_layernorm_bwd_skip(d, dy, z, mean, rstd, gamma, seed, nullptr, dx, da, dgamma, dbeta, da_colsum, partial, stream);
+}
+extern "C" int32_t otr_add_layernorm_bwd_skip(const otr_ln_desc_t* d, const float* dy, const float* z, const float* mean,
+                                              const float* rstd, const float* gamma, const uint64_t* seed, const float* skip,
+                                              float* dx, void* da, float* dgamma, float* dbeta, float* da_colsum, float* partial,
+                                              void* stream) {
   if (int32_t e = ln_check(d)) return e;
   OTR_REQUIRE(dy && z && mean && rstd && gamma && dx && (partial || (dgamma && dbeta)), "add_layernorm_bwd: null pointer");
   OTR_REQUIRE(d->p_drop == 0.f || seed, "add_layernorm_bwd: dropout needs seed");
   if (d->M == 0) return 0;
   LnArgs p{};
   p.dy = dy; p.zin = z; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd); p.gamma = gamma;
-  p.seed = seed; p.dx = dx; p.da = da; p.dgamma = dgamma; p.dbeta = dbeta; p.da_colsum = da ? da_colsum : nullptr; p.partial = partial;
+  p.seed = seed; p.skip = skip; p.dx = dx; p.da = da; p.dgamma = dgamma; p.dbeta = dbeta; p.da_colsum = da ? da_colsum : nullptr; p.partial = partial;
   p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
   dim3 grid((unsigned)((d->M + 4 * LN_BWD_ROWS - 1) / (4 * LN_BWD_ROWS)));
   hipStream_t s = (hipStream_t)stream;

@@ -25,7 +25,16 @@ __global__ void sqnorm_kernel(const float* g, int64_t n, OptState* st) {
   float s = 0.f;
   const int64_t n4 = n / 4;
   const float4* g4 = reinterpret_cast<const float4*>(g);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {          // four 16-byte loads in flight per lane (one was latency-bound: 45 us for 150 MB)
+    float4 v0 = g4[i], v1 = g4[i + stride], v2 = g4[i + 2 * stride], v3 = g4[i + 3 * stride];
+    s += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w;
+    s += v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+    s += v2.x * v2.x + v2.y * v2.y + v2.z * v2.z + v2.w * v2.w;
+    s += v3.x * v3.x + v3.y * v3.y + v3.z * v3.z + v3.w * v3.w;
+  }
+  for (; i < n4; i += stride) {
     float4 v = g4[i];
     s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   }

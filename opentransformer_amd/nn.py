@@ -216,7 +216,10 @@ class PositionwiseFeedForward(nn.Module):
         self.w_1 = nn.Linear(d_model, d_ff * 2 if activation == 'glu' else d_ff)
         self.w_2 = nn.Linear(d_ff, d_model)
 
-    def forward(self, x, defer_bias=False, link=None):
+    def forward(self, x, defer_bias=False, link=None, branch=False):
+        """branch=True: the result feeds a residual add that takes the branch in the activation type (its gradient then comes
+        back in that type too: the w_2 weight gradient joins the deferred launch and the GLU backward runs in the GEMM epilogue)"""
+        odt = ops.act_dtype() if (defer_bias or branch) else None
         if self.dropout and self.training:        # w_2(dropout(act(w_1 x))): the mask sits between the two GEMMs -> unfused chain
             h = ops.linear(x, self.w_1.weight, self.w_1.bias, relu=self.activation == 'relu', out_dtype=ops.act_dtype(), link=link)
             if self.activation == 'glu':
@@ -224,16 +227,14 @@ class PositionwiseFeedForward(nn.Module):
             elif self.activation != 'relu':
                 h = ops.activation(h, self.activation)
             h = ops.dropout(h, self.dropout)
-            return ops.linear(h, self.w_2.weight, self.w_2.bias, defer_bias=defer_bias,
-                              out_dtype=ops.act_dtype() if defer_bias else None)
+            return ops.linear(h, self.w_2.weight, self.w_2.bias, defer_bias=defer_bias, out_dtype=odt)
         if self.activation == 'glu':
             return ops.FeedForwardGLUFn.apply(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias,
-                                              defer_bias, ops.act_dtype() if defer_bias else torch.float32, link)
+                                              defer_bias, odt if odt is not None else torch.float32, link)
         h = ops.linear(x, self.w_1.weight, self.w_1.bias, relu=self.activation == 'relu', out_dtype=ops.act_dtype(), link=link)
         if self.activation != 'relu':
             h = ops.activation(h, self.activation)
-        return ops.linear(h, self.w_2.weight, self.w_2.bias, defer_bias=defer_bias,
-                          out_dtype=ops.act_dtype() if defer_bias else None)
+        return ops.linear(h, self.w_2.weight, self.w_2.bias, defer_bias=defer_bias, out_dtype=odt)
 
 
 def _post_norm(norm, x, branch, p, training, a_bias=None, link=None):
@@ -457,21 +458,24 @@ class ConformerEncoderBlock(nn.Module):
         self.final_norm = nn.LayerNorm(d_model)
 
     @staticmethod
-    def _ln(norm, x):
-        return ops.add_layernorm(x, None, norm.weight, norm.bias, 0.0, norm.eps)
+    def _ln(norm, x, link=None):
+        return ops.add_layernorm(x, None, norm.weight, norm.bias, 0.0, norm.eps, link=link)
 
     def _attn(self, x, mask, pos, p):
-        h = self._ln(self.mha_norm, x)
+        link = ops.new_prenorm_link()                  # x + f(LN(x)): the two gradients of x meet in the LayerNorm backward
+        h = self._ln(self.mha_norm, x, link)
         out = self.mha(h, mask.unsqueeze(1), pos)[0] if self.relative_positional else self.mha(h, mask.unsqueeze(1))[0]
-        return ops.residual_add(x, out, 1.0, p)
+        return ops.residual_add(x, out, 1.0, p, link)
 
     def _conv(self, x, mask, p):
-        return ops.residual_add(x, self.conv(self._ln(self.conv_norm, x), mask), 1.0, p)
+        link = ops.new_prenorm_link()
+        return ops.residual_add(x, self.conv(self._ln(self.conv_norm, x, link), mask), 1.0, p, link)
 
     def forward(self, x, mask, pos=None):
         p = self.residual_dropout                      # F.dropout(..., p): active in train AND eval in the reference
         if self.macaron_style:
-            x = ops.residual_add(x, self.pre_ffn(self._ln(self.macaron_ffn_norm, x)), self.ffn_scale, p)
+            link = ops.new_prenorm_link()
+            x = ops.residual_add(x, self.pre_ffn(self._ln(self.macaron_ffn_norm, x, link), branch=True), self.ffn_scale, p, link)
         if self.conv_first:
             x = self._attn(self._conv(x, mask, p), mask, pos, p)
         else:

@@ -292,6 +292,22 @@ def new_link():
     return ResidualLink() if torch.is_grad_enabled() else None
 
 
+class PreNormLink:
+    """The mirror image for a pre-norm residual y = x + f(LN(x)) (encoder/conformer.py:50-73): the residual add's backward
+    runs first and parks dy (the gradient through the skip connection) here instead of returning it for x; the LayerNorm's
+    backward -- which always runs later, it is reached through f -- adds it to its input gradient in the same kernel
+    (otr_add_layernorm_bwd_skip).  armed: set by the LayerNorm when its input wants a gradient."""
+    __slots__ = ('armed', 'buf')
+
+    def __init__(self):
+        self.armed = False
+        self.buf = None
+
+
+def new_prenorm_link():
+    return PreNormLink() if torch.is_grad_enabled() else None
+
+
 def linear_fwd_raw(x2, w, b, out_dtype, act=L.ACT_NONE, out=None):
     """y = act(x w^T + b); with `out` the product is ACCUMULATED into that [M,N] buffer."""
     M, K = x2.shape
@@ -590,6 +606,19 @@ def relu_bwd_raw(y, g):
     return out
 
 
+def relu_bwd_colsum_raw(y2, g2):
+    """(g2 * (y2 > 0), per-workgroup column sums of it [nblk, cols] f32) in one pass; None when the shape is not served"""
+    rows, cols = y2.shape
+    lib = L.load()
+    nblk = lib.otr_relu_bwd_colsum_partial_rows(rows, cols, _code(g2.dtype))
+    if nblk <= 0 or not (y2.is_contiguous() and g2.is_contiguous()) or (y2.data_ptr() | g2.data_ptr()) % 16:
+        return None
+    out = torch.empty_like(g2)
+    part = torch.empty((nblk, cols), dtype=torch.float32, device=g2.device)
+    L.check(lib.otr_relu_bwd_colsum(_p(y2), _p(g2), _p(out), _p(part), _code(g2.dtype), rows, cols, _stream()), 'otr_relu_bwd_colsum')
+    return out, part
+
+
 ACT_KINDS = {'gelu': 1, 'tanh': 2, 'swish': 3}       # otr_act_fwd / otr_act_bwd
 
 
@@ -824,6 +853,8 @@ class AddLayerNormFn(torch.autograd.Function):
     def forward(ctx, x, a, gamma, beta, p_drop, eps, a_bias=None, link=None):
         _cuda(x, a, gamma, beta)
         ctx.link = link
+        if isinstance(link, PreNormLink):
+            link.armed = bool(ctx.needs_input_grad[0]) and a is None and x.dtype == torch.float32
         ctx.set_materialize_grads(False)      # no zero-filled bf16 'gradient' for the non-differentiable twin
         ctx.ab_ref = a_bias
         d = x.shape[-1]
@@ -854,6 +885,9 @@ class AddLayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dylp=None):
         if dy is None:
+            if isinstance(ctx.link, PreNormLink) and ctx.link.buf is not None:     # nothing came back through the branch
+                skip, ctx.link.buf = ctx.link.buf, None
+                return (skip.view(ctx.cfg[6]),) + (None,) * 7
             return (None,) * 8
         z, mean, rstd, gamma, seed = ctx.saved_tensors
         M, d, adt, eps, p_drop, off, xshape, ashape = ctx.cfg
@@ -878,8 +912,11 @@ class AddLayerNormFn(torch.autograd.Function):
             # three column sums join the grouped launch at the end of backward (no atomics, deterministic)
             nrow = L.load().otr_add_layernorm_bwd_partial_rows(M)
             part = torch.empty((nrow, 3 * d), dtype=torch.float32, device=dy.device)
-        L.check(L.load().otr_add_layernorm_bwd(C.byref(desc), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed),
-                                               _p(dx), _p(da), _p(gg), _p(gb), _p(gab), _p(part), _stream()),
+        skip = None
+        if isinstance(ctx.link, PreNormLink) and ctx.link.buf is not None:     # gradient through the skip connection of x + f(LN(x))
+            skip, ctx.link.buf = ctx.link.buf, None
+        L.check(L.load().otr_add_layernorm_bwd_skip(C.byref(desc), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed),
+                                                    _p(skip), _p(dx), _p(da), _p(gg), _p(gb), _p(gab), _p(part), _stream()),
                 'otr_add_layernorm_bwd')
         if part is not None:
             colsum_raw(part[:, :d], out=gg)
@@ -887,7 +924,7 @@ class AddLayerNormFn(torch.autograd.Function):
             if want_ab:
                 colsum_raw(part[:, 2 * d:], out=gab)
         dx_ret = dx.view(xshape)
-        if ctx.link is not None and ctx.link.armed and ctx.needs_input_grad[0]:
+        if isinstance(ctx.link, ResidualLink) and ctx.link.armed and ctx.needs_input_grad[0]:
             ctx.link.buf = dx           # the branch's first Linear adds its input gradient into this and returns the sum
             dx_ret = None
         return (dx_ret, (da.view(ashape) if da is not None else None),
@@ -970,7 +1007,7 @@ class ProjLnFn(torch.autograd.Function):
         gw = grad_target(w)
         dw = linear_wgrad_raw(da, c2, w, out=gw)
         dx_ret = dx.view(xshape)
-        if ctx.link is not None and ctx.link.armed and ctx.needs_input_grad[0]:
+        if isinstance(ctx.link, ResidualLink) and ctx.link.armed and ctx.needs_input_grad[0]:
             ctx.link.buf = dx           # the branch's first Linear adds its input gradient into this and returns the sum
             dx_ret = None
         return (dx_ret, dc.view(cshape), None if gw is not None else dw, dbias, dgamma, dbeta, None, None, None, None)
@@ -1468,11 +1505,15 @@ class ConvSubsampleFn(torch.autograd.Function):
             gm = torch.empty_like(dact2)
             L.check(lib.otr_dropout(_p(dact2), _p(gm), _code(adt), dact2.numel(), p_drop, _p(seed), offs[1], _stream()), 'otr_dropout')
             dact2 = gm
-        g2 = relu_bwd_raw(act2, dact2)
         M2 = B * T2 * F2
         w1p, b1p, b2p = ctx.refs
         gw1, gb1, gb2 = grad_target(w1p), grad_target(b1p), grad_target(b2p)
-        db2 = colsum_raw(g2.view(M2, C2), out=gb2)
+        fused = relu_bwd_colsum_raw(act2.view(M2, C2), dact2.view(M2, C2))       # ReLU mask + the bias-gradient partial sums
+        if fused is not None:
+            g2, db2 = fused[0].view(dact2.shape), colsum_raw(fused[1], out=gb2)
+        else:
+            g2 = relu_bwd_raw(act2, dact2)
+            db2 = colsum_raw(g2.view(M2, C2), out=gb2)
         dw2r = torch.empty((C2, 3, 3, C1), dtype=torch.float32, device=x.device)
         L.check(lib.otr_conv2_wgrad(C.byref(desc), _p(g2), _p(act1), _p(dw2r), _p(_workspace(x.device)), _WS_BYTES, _stream()),
                 'otr_conv2_wgrad')
@@ -1525,8 +1566,10 @@ class ResidualAddFn(torch.autograd.Function):
     """y = x + scale * dropout(a): the pre-norm residual branches of encoder/conformer.py:50-73."""
 
     @staticmethod
-    def forward(ctx, x, a, scale, p_drop):
+    def forward(ctx, x, a, scale, p_drop, link=None):
         _cuda(x, a)
+        # PreNormLink: x's gradient through the skip connection is handed to the LayerNorm at the head of the branch
+        ctx.link = link if (link is not None and link.armed and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]) else None
         x2 = x.contiguous()
         a2 = a.contiguous()
         y = torch.empty_like(x2)
@@ -1546,11 +1589,14 @@ class ResidualAddFn(torch.autograd.Function):
         da = torch.empty(ashape, dtype=adt, device=dy.device)
         L.check(L.load().otr_residual_add_bwd(_p(dy), _p(da), _code(adt), dy.numel(), scale, p_drop, _p(seed), off,
                                               _stream()), 'otr_residual_add_bwd')
-        return dy, da, None, None
+        if ctx.link is not None:
+            ctx.link.buf = dy.view(-1, dy.shape[-1])
+            return None, da, None, None, None
+        return dy, da, None, None, None
 
 
-def residual_add(x, a, scale=1.0, p_drop=0.0):
-    return ResidualAddFn.apply(x, a, float(scale), float(p_drop))
+def residual_add(x, a, scale=1.0, p_drop=0.0, link=None):
+    return ResidualAddFn.apply(x, a, float(scale), float(p_drop), link)
 
 
 class DropoutFn(torch.autograd.Function):
@@ -1675,6 +1721,8 @@ class ConformerConvFn(torch.autograd.Function):
         x2 = _rows(xc if xc is not None else x)
         w1l, w2l = weight_lp(w1), weight_lp(w2)
         ctx.refs = (w1, b1, w2, b2)                    # in-place / deferred weight gradients (grad_target)
+        ctx.bn_refs = (gamma, beta)
+        ctx.dw_refs = (wdw, bdw)
         ctx.w1t, ctx.w2t = weight_lpt(w1), weight_lpt(w2)
         w1c = w1l if w1l is not None else w1
         w2c = w2l if w2l is not None else w2
@@ -1691,9 +1739,11 @@ class ConformerConvFn(torch.autograd.Function):
         s = torch.empty((M, Cc), dtype=adt, device=x.device)
         L.check(lib.otr_bn_swish_fwd(_p(y), _p(stats), _p(gamma), _p(beta), _p(run_mean), _p(run_var), _p(saved), _p(s),
                                      _code(adt), M, Cc, eps, momentum, int(training), _stream()), 'otr_bn_swish_fwd')
-        o = linear_fwd_raw(s, w2c, b2, torch.float32)
+        # the branch leaves in the activation type (the residual add takes it as such): its gradient then arrives in that
+        # type too, so the w_2 weight / bias gradients join the deferred 256-wide launch instead of an fp32-operand GEMM each
+        o = linear_fwd_raw(s, w2c, b2, adt)
         out = torch.empty_like(o)
-        L.check(lib.otr_row_mask(_p(o), _p(mask_u8), _p(out), M, Cc, _stream()), 'otr_row_mask')
+        L.check(lib.otr_row_mask_cast(_p(o), _code(adt), _p(mask_u8), _p(out), _code(adt), M, Cc, _stream()), 'otr_row_mask_cast')
         ctx.save_for_backward(x2, mask_u8, w1c, wk, gamma, beta, w2c, h, g, y, saved, s)
         ctx.cfg = (B, T, Cc, k, training, x.shape, x.dtype, bdw is not None, wdw.shape)
         return out.view(B, T, Cc)
@@ -1705,8 +1755,9 @@ class ConformerConvFn(torch.autograd.Function):
         M = B * T
         adt = s.dtype
         lib = L.load()
-        dm = torch.empty((M, Cc), dtype=torch.float32, device=dout.device)
-        L.check(lib.otr_row_mask(_p(dout.contiguous()), _p(mask_u8), _p(dm), M, Cc, _stream()), 'otr_row_mask')
+        dout = dout.contiguous()
+        dm = torch.empty((M, Cc), dtype=adt, device=dout.device)
+        L.check(lib.otr_row_mask_cast(_p(dout), _code(dout.dtype), _p(mask_u8), _p(dm), _code(adt), M, Cc, _stream()), 'otr_row_mask_cast')
         w1p, b1p, w2p, b2p = ctx.refs
         gw1, gb1, gw2, gb2 = grad_target(w1p), grad_target(b1p), grad_target(w2p), grad_target(b2p)
         ds = linear_fwd_raw(dm, ctx.w2t, None, adt) if ctx.w2t is not None else linear_dgrad_raw(dm, w2c, adt)
@@ -1714,11 +1765,20 @@ class ConformerConvFn(torch.autograd.Function):
         db2 = colsum_raw(dm, out=gb2) if b2p is not None else None
         red = torch.empty((2 * Cc,), dtype=torch.float32, device=dout.device)
         dy = torch.empty((M, Cc), dtype=torch.float32, device=dout.device)
-        L.check(lib.otr_bn_swish_bwd(_p(y), _p(ds), _code(adt), _p(saved), _p(gamma), _p(beta), _p(red), _p(dy), M, Cc,
+        bn_part = torch.empty((lib.otr_bn_swish_bwd_partial_rows(M), 2 * Cc), dtype=torch.float32, device=dout.device)
+        gp, bp = ctx.bn_refs
+        gg, gbt = grad_target(gp), grad_target(bp)
+        bn_inplace = gg is not None and gbt is not None        # the reduction launch adds d gamma / d beta where they live
+        L.check(lib.otr_bn_swish_bwd(_p(y), _p(ds), _code(adt), _p(saved), _p(gamma), _p(beta), _p(red), _p(bn_part),
+                                     _p(gg) if bn_inplace else None, _p(gbt) if bn_inplace else None, _p(dy), M, Cc,
                                      int(training), _stream()), 'otr_bn_swish_bwd')
         dg = torch.empty((M, Cc), dtype=adt, device=dout.device)
-        dwk = torch.zeros((Cc * k + Cc,), dtype=torch.float32, device=dout.device)
-        L.check(lib.otr_dwconv_bwd(_p(dy), _p(g), _code(adt), _p(wk), _p(dg), _p(dwk), _p(dwk, Cc * k), B, T, Cc, k,
+        wdwp, bdwp = ctx.dw_refs
+        gwd, gbd = grad_target(wdwp), (grad_target(bdwp) if has_dwb else None)
+        dw_inplace = gwd is not None and gwd.is_contiguous() and (not has_dwb or gbd is not None)   # the kernel's sums are += already
+        dwk = None if dw_inplace else torch.zeros((Cc * k + Cc,), dtype=torch.float32, device=dout.device)
+        L.check(lib.otr_dwconv_bwd(_p(dy), _p(g), _code(adt), _p(wk), _p(dg), _p(gwd) if dw_inplace else _p(dwk),
+                                   (_p(gbd) if has_dwb else None) if dw_inplace else _p(dwk, Cc * k), B, T, Cc, k,
                                    (k - 1) // 2, _stream()), 'otr_dwconv_bwd')
         dh = torch.empty_like(h)
         nblk = (M + GLU_RPB - 1) // GLU_RPB
@@ -1727,8 +1787,10 @@ class ConformerConvFn(torch.autograd.Function):
         db1 = colsum_raw(part, out=gb1) if b1p is not None else None
         dx = (linear_fwd_raw(dh, ctx.w1t, None, xdtype) if ctx.w1t is not None else linear_dgrad_raw(dh, w1c, xdtype)).view(xshape)
         dw1 = linear_wgrad_raw(dh, x2, w1c, out=gw1)
-        return (dx, None, None if gw1 is not None else dw1, None if gb1 is not None else db1, dwk[:Cc * k].view(wdw_shape),
-                dwk[Cc * k:] if has_dwb else None, red[Cc:], red[:Cc], None, None, None if gw2 is not None else dw2,
+        return (dx, None, None if gw1 is not None else dw1, None if gb1 is not None else db1,
+                None if dw_inplace else dwk[:Cc * k].view(wdw_shape), dwk[Cc * k:] if (has_dwb and not dw_inplace) else None,
+                None if bn_inplace else red[Cc:], None if bn_inplace else red[:Cc], None, None,
+                None if gw2 is not None else dw2,
                 None if gb2 is not None else db2, None, None, None)
 
 

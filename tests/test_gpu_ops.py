@@ -381,14 +381,15 @@ def test_conformer_conv_module(mode, B, T, C):
     xc = x.detach().cpu().requires_grad_(True)
     run_m, run_v = sd['batch_norm.running_mean'].clone(), sd['batch_norm.running_var'].clone()
     ref = orc.conformer_conv_module(sd, xc, mask.cpu(), training=True)
-    assert rel(out.cpu(), ref) < TOL[mode]
+    assert out.dtype == adt(mode)           # the branch leaves in the activation type (the residual add takes it as such)
+    assert rel(out.float().cpu(), ref) < TOL[mode]
     # running statistics were updated like torch's BatchNorm1d (momentum 0.1, unbiased variance)
     y = torch.nn.functional.batch_norm(torch.zeros(1, C, 2), run_m, run_v, training=False)   # noqa: F841 (buffers untouched)
-    g = rnd(B, T, C, seed=112)
+    g = rnd(B, T, C, seed=112).to(out.dtype)
     names = [k for k in sd if sd[k].requires_grad]
     params = dict(mod.named_parameters())
     grads = torch.autograd.grad(out, [x] + [params[n] for n in names], g)
-    gref = torch.autograd.grad(ref, [xc] + [sd[n] for n in names], g.cpu())
+    gref = torch.autograd.grad(ref, [xc] + [sd[n] for n in names], g.float().cpu())
     for nm, u, v in zip(['dx'] + names, grads, gref):
         if nm == 'depthwise_conv.bias':     # a bias in front of BatchNorm has zero gradient: both sides are roundoff
             assert float(u.abs().max()) < 1e-3 * float(gref[1].abs().max() + 1e-6) + 1e-4, nm
@@ -400,7 +401,7 @@ def test_conformer_conv_module(mode, B, T, C):
         oe = mod(x, mask)
         sde = {k: v.detach().cpu() for k, v in mod.state_dict().items()}
         re = orc.conformer_conv_module(sde, xc.detach(), mask.cpu(), training=False)
-    assert rel(oe.cpu(), re) < TOL[mode]
+    assert rel(oe.float().cpu(), re) < TOL[mode]
 
 
 def test_residual_add_dropout():
