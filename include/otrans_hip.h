@@ -315,6 +315,12 @@ int32_t otr_conv2_dgrad_cols(const otr_conv_desc_t* d, const void* dact2, const 
                              void* stream);
 /* dact1 = col2im(dcol) * (act1 > 0) */
 int32_t otr_conv2_col2im(const otr_conv_desc_t* d, const void* dcol, const void* act1, void* dact1, void* stream);
+/* The two above in ONE launch, implicitly (no column matrix): dact1 = [act1 > 0] * conv2's input gradient of dact2.  The
+ * stride-2 output pixels fall into four parity classes with 4 / 2 / 2 / 1 taps; each is a GEMM whose B operand is read
+ * straight from dact2's channel rows (csrc/conv.hip).  16-bit operands, (C1, C2) = (64, 128) or (32, 64).
+ * Returns 1 without launching anything when the operands do not qualify: use otr_conv2_dgrad_cols + otr_conv2_col2im then. */
+int32_t otr_conv2_dgrad(const otr_conv_desc_t* d, const void* dact2, const void* w2r, const void* act1, void* dact1,
+                        void* stream);
 /* dw2r [C2, 9*C1] f32 = dact2^T * im2col(act1) */
 int32_t otr_conv2_wgrad(const otr_conv_desc_t* d, const void* dact2, const void* act1, float* dw2r, void* workspace,
                         int64_t workspace_bytes, void* stream);

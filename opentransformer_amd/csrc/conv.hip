@@ -61,15 +61,9 @@ template <class T> __global__ __launch_bounds__(256) void conv1_fwd_kernel(ConvA
     }
     store8<T>(out + pix * p.C1 + cg * 8, o);
   };
-  int64_t pix = (int64_t)blockIdx.x * pix_per_iter + threadIdx.x / CG;
-  for (; pix + 3 * stride < npix; pix += 4 * stride) {      // four pixels per lane in flight: one left the 9 taps' latency exposed (49 us for 92 MB)
-    float in[4][9];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) gather(pix + u * stride, in[u]);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) emit(pix + u * stride, in[u]);
-  }
-  for (; pix < npix; pix += stride) {
+  // (four pixels per lane in flight were tried: 47.5 us against 48.7 -- the kernel is bound by its ~100 VALU instructions per
+  //  pixel and channel group, not by the latency of the nine taps)
+  for (int64_t pix = (int64_t)blockIdx.x * pix_per_iter + threadIdx.x / CG; pix < npix; pix += stride) {
     float in[9];
     gather(pix, in);
     emit(pix, in);
@@ -113,15 +107,7 @@ template <class T> __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Con
       for (int t = 0; t < 9; ++t) dw[c][t] = fmaf(gv[c], in[t], dw[c][t]);
     }
   };
-  int64_t pix = (int64_t)blockIdx.x * pix_per_iter + threadIdx.x / CG;
-  for (; pix + 1 * stride < npix; pix += 2 * stride) {      // two pixels per lane in flight (80 accumulators leave room for no more)
-    float in[2][9], gv[2][8];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) gather(pix + u * stride, in[u], gv[u]);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) accum(in[u], gv[u]);
-  }
-  for (; pix < npix; pix += stride) {
+  for (int64_t pix = (int64_t)blockIdx.x * pix_per_iter + threadIdx.x / CG; pix < npix; pix += stride) {
     float in[9], gv[8];
     gather(pix, in, gv);
     accum(in, gv);
@@ -254,4 +240,190 @@ extern "C" int32_t otr_conv2_col2im(const otr_conv_desc_t* d, const void* dcol, 
   if (d->act_dtype == OTR_F32) hipLaunchKernelGGL(col2im_kernel<float>, dim3(conv_grid(a)), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(col2im_kernel<bf16_t>, dim3(conv_grid(a)), dim3(256), 0, s, a);
   return otr_check_launch("conv2_col2im");
+}
+
+// ------------------------------------------------------------------------------------------------ conv2 input gradient, implicit
+// dact1[b,t1,f1,:] = [act1 > 0] * sum over the taps (kh,kw) that reach it of  W[:,kh,kw,:]^T g2[b,t2,f2,:],
+//   t2 = (t1-kh)/2, f2 = (f1+1-kw)/2 (both exact and in range).
+// Stride 2 splits the output pixels into four parity classes (t1 & 1, f1 & 1) with 4 / 2 / 2 / 1 taps; inside a class every
+// pixel sees the same taps, so the class is a plain GEMM  D[c1, pixel] = sum_tap A_tap[c1, c2] B_tap[c2, pixel]  with
+//   A_tap = W[:,kh,kw,:]^T (at most 4 x 16 KB, built once per workgroup in LDS as MFMA A-fragments),
+//   B_tap = rows of g2: lane (pixel, hi) reads 16 contiguous bytes of its pixel's channel row -- straight from global memory into
+//           the B operand, no staging (a pixel row is read by one wave only).
+// D comes out with 4 consecutive c1 per lane and register group, i.e. 8-byte pieces of the channel-last dact1 rows, where the
+// ReLU mask of act1 is applied.  Nothing like the [pixels, 9*C1] column matrix of the explicit form is written or read
+// (184 MB each way at the AISHELL shapes: the GEMM + col2im pair took 77 + 70 us).  Workgroups are persistent, belong to one
+// class (their A fragments never change) and the classes get workgroups in proportion to pixels x taps.
+struct Conv2DgArgs {
+  const uint16_t* g2; const uint16_t* w2r; const uint16_t* act1; uint16_t* dact1;
+  int B, T1, F1, T2, F2;
+  int wg0[5];                       // class c = 2*(t1&1) + (f1&1) owns workgroups [wg0[c], wg0[c+1])
+};
+
+// one parity class (PT = t1 & 1, PF = f1 & 1): the tap count is a compile-time constant, so a tile is straight-line code --
+// every load is unconditional (the last tile prefetches its own first tap again) and hipcc can count vmcnt exactly instead
+// of draining the prefetch before the MFMAs that do not need it
+template <int RT, int KS, int PT, int PF>
+__device__ __forceinline__ void conv2_dgrad_class(const Conv2DgArgs& p, uint4* afrag, int w, int nwg) {
+  constexpr int C1 = RT * 32, C2 = KS * 16, NKW = PF ? 2 : 1, NT = (PT ? 1 : 2) * NKW;
+  // local tap tt = a * NKW + b2:  kh = PT ? 1 : 2a,  kw = PF ? 2 b2 : 1
+  constexpr int NENT = NT * RT * KS * 64;
+#pragma unroll
+  for (int it = 0; it < (NENT + 511) / 512; ++it) {            // unrolled: the loads of all entries are in flight together
+    const int e = it * 512 + (int)threadIdx.x;
+    if (NENT % 512 != 0 && e >= NENT) break;
+    const int ln = e & 63, f = e >> 6, ks = f % KS, rt = (f / KS) % RT, tt = f / (KS * RT);
+    const int a = tt / NKW, b2 = tt - a * NKW;
+    const int tap = (PT ? 1 : 2 * a) * 3 + (PF ? 2 * b2 : 1);
+    const uint16_t* src = p.w2r + ((int64_t)(ks * 16 + (ln >> 5) * 8) * 9 + tap) * C1 + rt * 32 + (ln & 31);
+    uint32_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)j * 9 * C1];
+    afrag[e] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, hi = lane >> 5, pl = lane & 31;
+  const int nT = PT ? p.T1 / 2 : (p.T1 + 1) / 2, nF = PF ? p.F1 / 2 : (p.F1 + 1) / 2;
+  const int Mc = p.B * nT * nF;
+  const int ntile = (Mc + 255) / 256;
+  if (w >= ntile) return;
+
+  struct Pix { int b, i, j, live; };
+  auto pix_of = [&](int tl) {
+    const int m = tl * 256 + wid * 32 + pl;
+    const uint32_t mc = (uint32_t)min(m, Mc - 1), bi = mc / (uint32_t)nF, b = bi / (uint32_t)nT;
+    return Pix{(int)b, (int)(bi - b * (uint32_t)nT), (int)(mc - bi * (uint32_t)nF), m < Mc};
+  };
+  // address of lane (pixel, hi)'s 16-byte pieces of tap tt; false = the tap falls outside g2 for this pixel (operand = 0)
+  auto src_of = [&](const Pix& px, int tt, const uint16_t*& src) {
+    const int a = tt / NKW, b2 = tt - a * NKW;
+    const int t2 = PT ? px.i : px.i - a, f2 = PF ? px.j + 1 - b2 : px.j;
+    const int t2c = min(max(t2, 0), p.T2 - 1), f2c = min(max(f2, 0), p.F2 - 1);
+    src = p.g2 + ((int64_t)((px.b * p.T2 + t2c) * p.F2 + f2c)) * C2 + hi * 8;
+    return t2 >= 0 && t2 < p.T2 && f2 >= 0 && f2 < p.F2;
+  };
+
+  f32x16 acc[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+  Pix px = pix_of(w);
+  uint4 cur[KS];
+  const uint16_t* srcc;
+  bool okc = src_of(px, 0, srcc);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) cur[ks] = ld_global_b128(srcc + ks * 16);
+  for (int tile = w; tile < ntile; tile += nwg) {
+    const Pix npx = tile + nwg < ntile ? pix_of(tile + nwg) : px;
+    const int64_t obase = ((int64_t)((px.b * p.T1 + 2 * px.i + PT) * p.F1) + 2 * px.j + PF) * C1 + 4 * hi;
+    uint2 am[RT * 4];
+    // the A fragments do not depend on the tile: without this opaque zero hipcc hoists all NT*RT*KS LDS reads out of the
+    // tile loop (256 registers at the AISHELL shape, 455 spilled)
+    int opq = 0;
+    asm volatile("" : "+v"(opq));
+    const uint4* af = afrag + opq + lane;
+    uint4 ac[RT], an[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) ac[rt] = af[rt * KS * 64];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      const uint16_t* srcn;
+      const bool okn = tt + 1 < NT ? src_of(px, tt + 1, srcn) : src_of(npx, 0, srcn);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (tt == NT - 1 && ks == (KS > 4 ? 4 : 0)) {          // ReLU mask of this tile's pixels: in flight under the last MFMAs
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) am[rt * 4 + q] = ld_global_b64(p.act1 + obase + rt * 32 + 8 * q);
+        }
+        const uint4 bq = okc ? cur[ks] : make_uint4(0u, 0u, 0u, 0u);
+        {                                                      // next step's A fragments: their LDS latency under this step's MFMAs
+          const int nt = ks + 1 < KS ? tt : (tt + 1 < NT ? tt + 1 : 0), nk = ks + 1 < KS ? ks + 1 : 0;
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) an[rt] = af[((nt * RT + rt) * KS + nk) * 64];
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) mma32(acc[rt], ac[rt], bq);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) ac[rt] = an[rt];
+        // the registers just consumed take the same pieces of the next tap (or of the next tile's first tap): the operand set
+        // stays in flight under the MFMAs without a second buffer.  Four at a time = one 128-byte line of every pixel row:
+        // issued one by one between the MFMAs, the four touches of a line were a whole tap apart and the 16 waves of a CU
+        // (128 KB of rows in flight, 32 KB of L1) evicted it in between -- every line came from L2 four times (116 us)
+        if ((ks & 3) == 3) {
+#pragma unroll
+          for (int k2 = ks - 3; k2 <= ks; ++k2) cur[k2] = ld_global_b128(srcn + k2 * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);                     // keep the loads here: hipcc otherwise sinks them to just before their use
+      }
+      okc = okn;
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint2 a = am[rt * 4 + q];
+        const float v0 = (int16_t)(a.x & 0xffffu) > 0 ? acc[rt][4 * q] : 0.f, v1 = (int16_t)(a.x >> 16) > 0 ? acc[rt][4 * q + 1] : 0.f;
+        const float v2 = (int16_t)(a.y & 0xffffu) > 0 ? acc[rt][4 * q + 2] : 0.f, v3 = (int16_t)(a.y >> 16) > 0 ? acc[rt][4 * q + 3] : 0.f;
+        if (px.live) {
+          otr_u32x2 o = {pack2h(v0, v1), pack2h(v2, v3)};
+          *(OTR_GLOBAL otr_u32x2*)(p.dact1 + obase + rt * 32 + 8 * q) = o;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[rt][4 * q + r] = 0.f;
+      }
+    px = npx;
+  }
+}
+
+template <int RT, int KS> __global__ __launch_bounds__(512, 4) void conv2_dgrad_kernel(Conv2DgArgs p) {
+  __shared__ uint4 afrag[4 * RT * KS * 64];
+  int cls = 0;
+  while (cls < 3 && (int)blockIdx.x >= p.wg0[cls + 1]) ++cls;
+  const int w = (int)blockIdx.x - p.wg0[cls], nwg = p.wg0[cls + 1] - p.wg0[cls];
+  if (cls == 0) conv2_dgrad_class<RT, KS, 0, 0>(p, afrag, w, nwg);
+  else if (cls == 1) conv2_dgrad_class<RT, KS, 0, 1>(p, afrag, w, nwg);
+  else if (cls == 2) conv2_dgrad_class<RT, KS, 1, 0>(p, afrag, w, nwg);
+  else conv2_dgrad_class<RT, KS, 1, 1>(p, afrag, w, nwg);
+}
+
+// 0 = launched, 1 = shape not served (the caller uses otr_conv2_dgrad_cols + otr_conv2_col2im), < 0 = bad argument
+extern "C" int32_t otr_conv2_dgrad(const otr_conv_desc_t* d, const void* dact2, const void* w2r, const void* act1, void* dact1,
+                                   void* stream) {
+  ConvArgs chk{};
+  if (int32_t e = conv_check(d, chk)) return e;
+  OTR_REQUIRE(dact2 && w2r && act1 && dact1, "conv2_dgrad: null pointer");
+  const bool big = d->C1 == 64 && d->C2 == 128, small = d->C1 == 32 && d->C2 == 64;
+  if (d->act_dtype != OTR_H16 || d->w_dtype != OTR_H16 || !(big || small)) return 1;
+  if (((uintptr_t)dact2 | (uintptr_t)act1 | (uintptr_t)dact1) % 16 != 0) return 1;
+  OTR_REQUIRE((int64_t)d->B * d->T2 * d->F2 * d->C2 < (1ll << 31), "conv2_dgrad: act2 too large for 32-bit pixel index");
+  Conv2DgArgs a{};
+  a.g2 = (const uint16_t*)dact2; a.w2r = (const uint16_t*)w2r; a.act1 = (const uint16_t*)act1; a.dact1 = (uint16_t*)dact1;
+  a.B = d->B; a.T1 = d->T1; a.F1 = d->F1; a.T2 = d->T2; a.F2 = d->F2;
+  // workgroups per class in proportion to pixels x taps, at least one each, never more than the class has tiles
+  const int G = 512;
+  int64_t work[4], total = 0;
+  int tiles[4], n[4];
+  for (int c = 0; c < 4; ++c) {
+    const int pt = c >> 1, pf = c & 1;
+    const int64_t nT = pt ? d->T1 / 2 : (d->T1 + 1) / 2, nF = pf ? d->F1 / 2 : (d->F1 + 1) / 2;
+    const int64_t Mc = (int64_t)d->B * nT * nF;
+    tiles[c] = (int)((Mc + 255) / 256);
+    work[c] = Mc * ((pt ? 1 : 2) * (pf ? 2 : 1));
+    total += work[c];
+  }
+  for (int c = 0; c < 4; ++c) {
+    n[c] = total > 0 ? (int)((work[c] * G + total / 2) / total) : 0;
+    if (n[c] > tiles[c]) n[c] = tiles[c];
+    if (n[c] < 1 && tiles[c] > 0) n[c] = 1;
+  }
+  a.wg0[0] = 0;
+  for (int c = 0; c < 4; ++c) a.wg0[c + 1] = a.wg0[c] + n[c];
+  if (a.wg0[4] == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (big) hipLaunchKernelGGL((conv2_dgrad_kernel<2, 8>), dim3((unsigned)a.wg0[4]), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((conv2_dgrad_kernel<1, 4>), dim3((unsigned)a.wg0[4]), dim3(512), 0, s, a);
+  return otr_check_launch("conv2_dgrad");
 }

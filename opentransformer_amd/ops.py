@@ -1451,6 +1451,9 @@ def conv_geometry(T, F):
     return T1, F1, T2, F2
 
 
+_CONV2_IMPLICIT_DGRAD = True       # tests switch it off to compare with the explicit (column matrix) path
+
+
 class ConvSubsampleFn(torch.autograd.Function):
     """Two Conv2dLayers of frontend/conv.py:141-142 (3x3, stride 2, pad (0,1), ReLU).
 
@@ -1517,10 +1520,14 @@ class ConvSubsampleFn(torch.autograd.Function):
         dw2r = torch.empty((C2, 3, 3, C1), dtype=torch.float32, device=x.device)
         L.check(lib.otr_conv2_wgrad(C.byref(desc), _p(g2), _p(act1), _p(dw2r), _p(_workspace(x.device)), _WS_BYTES, _stream()),
                 'otr_conv2_wgrad')
-        dcol = torch.empty((M2, 9 * C1), dtype=adt, device=x.device)
-        L.check(lib.otr_conv2_dgrad_cols(C.byref(desc), _p(g2), _p(w2r), _p(dcol), _stream()), 'otr_conv2_dgrad_cols')
         dact1 = torch.empty_like(act1)
-        L.check(lib.otr_conv2_col2im(C.byref(desc), _p(dcol), _p(act1), _p(dact1), _stream()), 'otr_conv2_col2im')
+        rc = lib.otr_conv2_dgrad(C.byref(desc), _p(g2), _p(w2r), _p(act1), _p(dact1), _stream()) if _CONV2_IMPLICIT_DGRAD else 1
+        if rc == 1:                          # operands do not qualify for the implicit kernel: column matrix + col2im
+            dcol = torch.empty((M2, 9 * C1), dtype=adt, device=x.device)
+            L.check(lib.otr_conv2_dgrad_cols(C.byref(desc), _p(g2), _p(w2r), _p(dcol), _stream()), 'otr_conv2_dgrad_cols')
+            L.check(lib.otr_conv2_col2im(C.byref(desc), _p(dcol), _p(act1), _p(dact1), _stream()), 'otr_conv2_col2im')
+        else:
+            L.check(rc, 'otr_conv2_dgrad')
         if p_drop > 0:
             L.check(lib.otr_dropout(_p(dact1), _p(dact1), _code(adt), dact1.numel(), p_drop, _p(seed), offs[0], _stream()), 'otr_dropout')
         if gw1 is not None and gb1 is not None:
