@@ -264,7 +264,7 @@ struct Conv2DgArgs {
 // every load is unconditional (the last tile prefetches its own first tap again) and hipcc can count vmcnt exactly instead
 // of draining the prefetch before the MFMAs that do not need it
 template <int RT, int KS, int PT, int PF>
-__device__ __forceinline__ void conv2_dgrad_class(const Conv2DgArgs& p, uint4* afrag, int w, int nwg) {
+__device__ __forceinline__ void conv2_dgrad_class(const Conv2DgArgs& p, uint4* afrag, uint4* ebuf_all, int w, int nwg) {
   constexpr int C1 = RT * 32, C2 = KS * 16, NKW = PF ? 2 : 1, NT = (PT ? 1 : 2) * NKW;
   // local tap tt = a * NKW + b2:  kh = PT ? 1 : 2a,  kw = PF ? 2 b2 : 1
   constexpr int NENT = NT * RT * KS * 64;
@@ -314,10 +314,25 @@ __device__ __forceinline__ void conv2_dgrad_class(const Conv2DgArgs& p, uint4* a
   bool okc = src_of(px, 0, srcc);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) cur[ks] = ld_global_b128(srcc + ks * 16);
+  // epilogue layout: the accumulators hold 8-byte pieces of 32 different pixel rows per lane group, and a store of such
+  // pieces costs the address path of the CU one cycle per LANE (every lane a different 128-byte line; so did the ReLU-mask
+  // loads: 16 such instructions per tile were most of the kernel's first 116 us).  Each 16-channel slab goes through 1 KB
+  // of LDS per wave instead and leaves as 16 bytes per lane, lanes 2i / 2i+1 on the same row.
+  uint4* ebuf = ebuf_all + wid * 64;
+  unsigned char* ebytes = reinterpret_cast<unsigned char*>(ebuf);
+  const int erow = lane >> 1, ehalf = lane & 1;               // the pixel row / 8-channel half this lane stores
+  auto ebase_of = [&](int tl, bool& live) {
+    const int m = tl * 256 + wid * 32 + erow;
+    live = m < Mc;
+    const uint32_t mc = (uint32_t)min(m, Mc - 1), bi = mc / (uint32_t)nF, b = bi / (uint32_t)nT;
+    const int i = (int)(bi - b * (uint32_t)nT), j = (int)(mc - bi * (uint32_t)nF);
+    return ((int64_t)(((int)b * p.T1 + 2 * i + PT) * p.F1) + 2 * j + PF) * C1 + 8 * ehalf;
+  };
   for (int tile = w; tile < ntile; tile += nwg) {
     const Pix npx = tile + nwg < ntile ? pix_of(tile + nwg) : px;
-    const int64_t obase = ((int64_t)((px.b * p.T1 + 2 * px.i + PT) * p.F1) + 2 * px.j + PF) * C1 + 4 * hi;
-    uint2 am[RT * 4];
+    bool elive;
+    const int64_t obase = ebase_of(tile, elive);
+    uint4 am[RT * 2];
     // the A fragments do not depend on the tile: without this opaque zero hipcc hoists all NT*RT*KS LDS reads out of the
     // tile loop (256 registers at the AISHELL shape, 455 spilled)
     int opq = 0;
@@ -334,9 +349,7 @@ __device__ __forceinline__ void conv2_dgrad_class(const Conv2DgArgs& p, uint4* a
       for (int ks = 0; ks < KS; ++ks) {
         if (tt == NT - 1 && ks == (KS > 4 ? 4 : 0)) {          // ReLU mask of this tile's pixels: in flight under the last MFMAs
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) am[rt * 4 + q] = ld_global_b64(p.act1 + obase + rt * 32 + 8 * q);
+          for (int g = 0; g < RT * 2; ++g) am[g] = ld_global_b128(p.act1 + obase + g * 16);
         }
         const uint4 bq = okc ? cur[ks] : make_uint4(0u, 0u, 0u, 0u);
         {                                                      // next step's A fragments: their LDS latency under this step's MFMAs
@@ -361,34 +374,45 @@ __device__ __forceinline__ void conv2_dgrad_class(const Conv2DgArgs& p, uint4* a
       okc = okn;
     }
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int g = 0; g < RT * 2; ++g) {                       // 16-channel slab g: c1 in [16g, 16g + 16)
+      const int rt = g >> 1, q0 = 2 * (g & 1);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint2 a = am[rt * 4 + q];
-        const float v0 = (int16_t)(a.x & 0xffffu) > 0 ? acc[rt][4 * q] : 0.f, v1 = (int16_t)(a.x >> 16) > 0 ? acc[rt][4 * q + 1] : 0.f;
-        const float v2 = (int16_t)(a.y & 0xffffu) > 0 ? acc[rt][4 * q + 2] : 0.f, v3 = (int16_t)(a.y >> 16) > 0 ? acc[rt][4 * q + 3] : 0.f;
-        if (px.live) {
-          otr_u32x2 o = {pack2h(v0, v1), pack2h(v2, v3)};
-          *(OTR_GLOBAL otr_u32x2*)(p.dact1 + obase + rt * 32 + 8 * q) = o;
-        }
+      for (int qq = 0; qq < 2; ++qq) {
+        const int q = q0 + qq;
+        otr_u32x2 w = {pack2h(acc[rt][4 * q], acc[rt][4 * q + 1]), pack2h(acc[rt][4 * q + 2], acc[rt][4 * q + 3])};
+        *reinterpret_cast<otr_u32x2*>(ebytes + pl * 32 + qq * 16 + hi * 8) = w;
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[rt][4 * q + r] = 0.f;
       }
+      asm volatile("" ::: "memory");                           // the pieces above are read back by other lanes of this wave
+      const uint4 v = ebuf[lane];                              // (LDS operations of a wave complete in order: no barrier)
+      asm volatile("" ::: "memory");
+      const uint4 a = am[g];
+      auto keep = [](uint32_t act, uint32_t val) {
+        return ((int16_t)(act & 0xffffu) > 0 ? (val & 0xffffu) : 0u) | ((int16_t)(act >> 16) > 0 ? (val & 0xffff0000u) : 0u);
+      };
+      if (elive) st_global_b128(p.dact1 + obase + g * 16, make_uint4(keep(a.x, v.x), keep(a.y, v.y), keep(a.z, v.z), keep(a.w, v.w)));
+    }
     px = npx;
   }
 }
 
 template <int RT, int KS> __global__ __launch_bounds__(512, 4) void conv2_dgrad_kernel(Conv2DgArgs p) {
   __shared__ uint4 afrag[4 * RT * KS * 64];
+  __shared__ uint4 ebuf[8 * 64];                              // 1 KB per wave: epilogue transposition
   int cls = 0;
   while (cls < 3 && (int)blockIdx.x >= p.wg0[cls + 1]) ++cls;
   const int w = (int)blockIdx.x - p.wg0[cls], nwg = p.wg0[cls + 1] - p.wg0[cls];
-  if (cls == 0) conv2_dgrad_class<RT, KS, 0, 0>(p, afrag, w, nwg);
-  else if (cls == 1) conv2_dgrad_class<RT, KS, 0, 1>(p, afrag, w, nwg);
-  else if (cls == 2) conv2_dgrad_class<RT, KS, 1, 0>(p, afrag, w, nwg);
-  else conv2_dgrad_class<RT, KS, 1, 1>(p, afrag, w, nwg);
+  if (cls == 0) conv2_dgrad_class<RT, KS, 0, 0>(p, afrag, ebuf, w, nwg);
+  else if (cls == 1) conv2_dgrad_class<RT, KS, 0, 1>(p, afrag, ebuf, w, nwg);
+  else if (cls == 2) conv2_dgrad_class<RT, KS, 1, 0>(p, afrag, ebuf, w, nwg);
+  else conv2_dgrad_class<RT, KS, 1, 1>(p, afrag, ebuf, w, nwg);
 }
 
+// (Tried and removed: the B operand staged through LDS -- rows fetched line by line, 8 lanes per 128-byte line, XOR-swizzled
+//  chunks, 16 waves sharing the A fragments -- to spare the address path the one-lane-per-line loads above: 82 us against 78,
+//  bit-identical results.  What bounds this kernel is the latency of a wave's serial tile chain (a tile is 16-64 MFMAs, its
+//  ReLU-mask rows come from HBM every time), not the load instructions; profiles/r02_conv2_dgrad_bench.json.)
 // 0 = launched, 1 = shape not served (the caller uses otr_conv2_dgrad_cols + otr_conv2_col2im), < 0 = bad argument
 extern "C" int32_t otr_conv2_dgrad(const otr_conv_desc_t* d, const void* dact2, const void* w2r, const void* act1, void* dact1,
                                    void* stream) {
@@ -403,14 +427,15 @@ extern "C" int32_t otr_conv2_dgrad(const otr_conv_desc_t* d, const void* dact2, 
   a.g2 = (const uint16_t*)dact2; a.w2r = (const uint16_t*)w2r; a.act1 = (const uint16_t*)act1; a.dact1 = (uint16_t*)dact1;
   a.B = d->B; a.T1 = d->T1; a.F1 = d->F1; a.T2 = d->T2; a.F2 = d->F2;
   // workgroups per class in proportion to pixels x taps, at least one each, never more than the class has tiles
-  const int G = 512;
+  // (a class with no pixels -- T1 or F1 of 1 -- gets none)
+  const int G = 512, TILE = 256;
   int64_t work[4], total = 0;
   int tiles[4], n[4];
   for (int c = 0; c < 4; ++c) {
     const int pt = c >> 1, pf = c & 1;
     const int64_t nT = pt ? d->T1 / 2 : (d->T1 + 1) / 2, nF = pf ? d->F1 / 2 : (d->F1 + 1) / 2;
     const int64_t Mc = (int64_t)d->B * nT * nF;
-    tiles[c] = (int)((Mc + 255) / 256);
+    tiles[c] = (int)((Mc + TILE - 1) / TILE);
     work[c] = Mc * ((pt ? 1 : 2) * (pf ? 2 : 1));
     total += work[c];
   }

@@ -114,8 +114,11 @@ def test_conformer_block_prenorm_link_equals_autograd_sum(mode, monkeypatch):
             y, _ = blk(x, mask, pos)
             y.square().mean().backward()
             res.append([y.detach().clone(), x.grad.clone()] + [prm.grad.clone() for prm in blk.parameters() if prm.grad is not None])   # (post_ffn is never applied, as shipped)
+        scale = max(float(t.abs().max()) for t in res[1][2:])
         for a, b in zip(*res):
-            assert _rel(a, b) < 5e-4, _rel(a, b)       # (the rel-pos attention backward accumulates with atomics: runs differ at 1e-5)
+            # (the rel-pos attention backward accumulates with atomics: runs differ at 1e-5; gradients that are analytically zero --
+            #  a bias in front of BatchNorm -- are rounding noise on both sides and are compared on the absolute scale)
+            assert float((a - b).abs().max()) < 5e-4 * max(float(b.abs().max()), 1e-3 * scale), _rel(a, b)
     finally:
         ops.set_compute_dtype('bf16')
 
@@ -178,7 +181,7 @@ def test_conv2_implicit_input_gradient_equals_column_path(mode, B, T, Fdim, C1, 
         for name, a, b in zip(('dw1', 'db1', 'dw2', 'db2'), *res):
             # (the column path rounds every tap's contribution to 16 bits before col2im sums them; the implicit kernel rounds once)
             assert _rel(a, b) < (6e-3 if mode == 'bf16' else 8e-4), (name, _rel(a, b))
-            if name in ('dw2', 'db2'):
+            if name == 'dw2':                                  # (db2 goes through the atomics of the stand-alone column sum here)
                 assert torch.equal(a, b), name
     finally:
         ops.set_compute_dtype('bf16')
@@ -193,7 +196,7 @@ def test_conv2_implicit_input_gradient_elementwise(mode):
     ops.set_compute_dtype(mode)
     try:
         adt = ops.act_dtype()
-        for (B, T, Fd, C1, C2) in [(2, 61, 30, 64, 128), (3, 40, 17, 32, 64), (1, 250, 80, 64, 128)]:
+        for (B, T, Fd, C1, C2) in [(2, 61, 30, 64, 128), (3, 40, 17, 32, 64), (1, 250, 80, 64, 128), (9, 333, 80, 64, 128), (1, 7, 3, 32, 64)]:
             T1, F1, T2, F2 = ops.conv_geometry(T, Fd)
             gen = torch.Generator().manual_seed(T)
             g2 = torch.randn(B, T2, F2, C2, generator=gen).to(DEV, adt)
