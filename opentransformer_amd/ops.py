@@ -1640,6 +1640,24 @@ def dropout(x, p, training=True):
     return DropoutFn.apply(x, float(p))
 
 
+_PADDED_ROWS = {}
+
+
+def _zero_padded_rows(t2, rows):
+    """t2 [r, c] -> [rows, c] with zero rows appended; cached by storage (constant tables only)"""
+    if t2.shape[0] == rows:
+        return t2
+    key = (t2.data_ptr(), t2._version, tuple(t2.shape), rows, t2.dtype, str(t2.device))
+    hit = _PADDED_ROWS.get(key)
+    if hit is None:
+        if len(_PADDED_ROWS) > 16:
+            _PADDED_ROWS.clear()
+        out = torch.zeros((rows, t2.shape[1]), dtype=t2.dtype, device=t2.device)
+        out[:t2.shape[0]].copy_(t2)
+        hit = _PADDED_ROWS[key] = (out, t2)              # (keeps the source alive: the key is its address)
+    return hit[0]
+
+
 class RelPosAttentionFn(torch.autograd.Function):
     """MultiHeadedSelfAttentionWithRelPos.forward after the qvk projection (module/attention.py:217-253):
     softmax(((q+u) k^T + shift((q+v) p^T)) / sqrt(dk)) v with p = pos_proj(sinusoid[-(T-1)..T-1]).
@@ -1660,8 +1678,8 @@ class RelPosAttentionFn(torch.autograd.Function):
         # 16-byte aligned operands / outputs and whole contraction chunks, i.e. takes the fast kernels (the unpadded
         # layout ran the generic bounds-checked ones: 96 launches of 33-42 us per step)
         Pp = (P + 7) // 8 * 8
-        p = torch.zeros((Pp, d), dtype=adt, device=qkv.device)
-        p[:P].copy_(linear_fwd_raw(pe, wl if wl is not None else pos_w, None, adt))         # [P, d] (+ zero rows)
+        pe = _zero_padded_rows(pe, Pp)                   # the sinusoid table is a constant: padded once per (T, d)
+        p = linear_fwd_raw(pe, wl if wl is not None else pos_w, None, adt)                  # [Pp, d], rows >= P are zero
         pt = p.t().contiguous()                                                             # [d, Pp]: dgrad as a forward GEMM
         u, v = posu.reshape(d).contiguous(), posv.reshape(d).contiguous()
         quv = torch.empty((B, T, 2 * d), dtype=adt, device=qkv.device)
@@ -1677,6 +1695,7 @@ class RelPosAttentionFn(torch.autograd.Function):
                                            T * H * Pp, Pp, H * Pp, 1, _p(out), _p(lse), _stream()), 'otr_attention_bias_fwd')
         ctx.save_for_backward(qkv, quv, pt, pe, bd, out, lse, key_mask_u8, pos_w)
         ctx.H = H
+        ctx.uv_refs = (posu, posv)                     # in-place / deferred parameter gradients (grad_target)
         return out
 
     @staticmethod
@@ -1706,10 +1725,17 @@ class RelPosAttentionFn(torch.autograd.Function):
         L.check(lib.otr_add2_strided(_p(dquv), 2 * d, _p(dquv, d), 2 * d, _p(dqkv), d3, _code(adt), M, d, _stream()),
                 'otr_add2_strided')
         dq2 = dquv.view(M, 2 * d)
-        du = colsum_raw(dq2[:, :d])
-        dv = colsum_raw(dq2[:, d:])
-        dw = linear_wgrad_raw(dp[:P], pe, pos_w)
-        return dqkv, None, dw, du.view(1, 1, H, dk), dv.view(1, 1, H, dk), None, None
+        pu, pv = ctx.uv_refs
+        gu, gv, gw = grad_target(pu), grad_target(pv), grad_target(pos_w)
+        if gu is not None and gv is not None and gu.is_contiguous() and gv.is_contiguous():
+            # the two column sums join the grouped launch at the end of backward (they were 2 launches + 2 gradient adds per block)
+            colsum_raw(dq2[:, :d], out=gu.view(-1))
+            colsum_raw(dq2[:, d:], out=gv.view(-1))
+            du = dv = None
+        else:
+            du, dv = colsum_raw(dq2[:, :d]).view(1, 1, H, dk), colsum_raw(dq2[:, d:]).view(1, 1, H, dk)
+        dw = linear_wgrad_raw(dp, pe, pos_w, out=gw)     # contraction over the padded axis (zero rows): the fast grouped kernel takes it
+        return dqkv, None, None if gw is not None else dw, du, dv, None, None
 
 
 class ConformerConvFn(torch.autograd.Function):
