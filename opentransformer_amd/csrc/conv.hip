@@ -347,7 +347,7 @@ __device__ __forceinline__ void conv2_dgrad_class(const Conv2DgArgs& p, uint4* a
       const bool okn = tt + 1 < NT ? src_of(px, tt + 1, srcn) : src_of(npx, 0, srcn);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        if (tt == NT - 1 && ks == (KS > 4 ? 4 : 0)) {          // ReLU mask of this tile's pixels: in flight under the last MFMAs
+        if (tt == 0 && ks == 0) {                              // ReLU mask of this tile's pixels (HBM every time): in flight under the whole tile
 #pragma unroll
           for (int g = 0; g < RT * 2; ++g) am[g] = ld_global_b128(p.act1 + obase + g * 16);
         }
@@ -426,23 +426,29 @@ extern "C" int32_t otr_conv2_dgrad(const otr_conv_desc_t* d, const void* dact2, 
   Conv2DgArgs a{};
   a.g2 = (const uint16_t*)dact2; a.w2r = (const uint16_t*)w2r; a.act1 = (const uint16_t*)act1; a.dact1 = (uint16_t*)dact1;
   a.B = d->B; a.T1 = d->T1; a.F1 = d->F1; a.T2 = d->T2; a.F2 = d->F2;
-  // workgroups per class in proportion to pixels x taps, at least one each, never more than the class has tiles
-  // (a class with no pixels -- T1 or F1 of 1 -- gets none)
+  // Workgroups per class: a tile is modelled as a fixed part (mask rows, the epilogue's LDS round trips, the header wait) plus
+  // one part per tap, 3.7 : 1.  Every class gets one workgroup, the rest go one by one to the class whose workgroups
+  // currently run longest (exact for this min-max problem).  (Splitting by pixels x taps instead gave the same 75 us at the
+  // AISHELL shape: the launch is not bound by the balance between the classes -- profiles/r02_conv2_dgrad_pmc.txt.)
   const int G = 512, TILE = 256;
-  int64_t work[4], total = 0;
-  int tiles[4], n[4];
+  int tiles[4], n[4], taps[4];
   for (int c = 0; c < 4; ++c) {
     const int pt = c >> 1, pf = c & 1;
     const int64_t nT = pt ? d->T1 / 2 : (d->T1 + 1) / 2, nF = pf ? d->F1 / 2 : (d->F1 + 1) / 2;
     const int64_t Mc = (int64_t)d->B * nT * nF;
     tiles[c] = (int)((Mc + TILE - 1) / TILE);
-    work[c] = Mc * ((pt ? 1 : 2) * (pf ? 2 : 1));
-    total += work[c];
+    taps[c] = (pt ? 1 : 2) * (pf ? 2 : 1);
+    n[c] = tiles[c] > 0 ? 1 : 0;
   }
-  for (int c = 0; c < 4; ++c) {
-    n[c] = total > 0 ? (int)((work[c] * G + total / 2) / total) : 0;
-    if (n[c] > tiles[c]) n[c] = tiles[c];
-    if (n[c] < 1 && tiles[c] > 0) n[c] = 1;
+  auto span = [&](int c) {                       // time of the class's longest workgroup, in units of 0.1 tap
+    return n[c] > 0 ? (int64_t)((tiles[c] + n[c] - 1) / n[c]) * (37 + 10 * taps[c]) : 0;
+  };
+  for (int left = G - (n[0] + n[1] + n[2] + n[3]); left > 0; --left) {
+    int best = -1;
+    for (int c = 0; c < 4; ++c)
+      if (n[c] > 0 && n[c] < tiles[c] && (best < 0 || span(c) > span(best))) best = c;
+    if (best < 0) break;
+    ++n[best];
   }
   a.wg0[0] = 0;
   for (int c = 0; c < 4; ++c) a.wg0[c + 1] = a.wg0[c] + n[c];
