@@ -47,7 +47,8 @@ int32_t otr_debug_set(int32_t key, int32_t value);
  * to LDS and issues ONE ds_read_b64_tr_b16 with lane l at byte address addr[l]; out[l*4 + j] = element j lane l got. */
 int32_t otr_debug_trread(const void* image, const int32_t* addr, void* out, void* stream);
 /* tuning hook: when buf != NULL every GEMM workgroup writes 4 shader-clock timestamps (start, operands staged,
- * k-loop done, stores issued) to buf[(blockIdx.y*gridDim.x + blockIdx.x)*4 ..]; NULL disables.  Not for production. */
+ * k-loop done, stores issued) to buf[(blockIdx.y*gridDim.x + blockIdx.x)*4 ..]; otr_conv2_dgrad writes, per workgroup, the 100 MHz
+ * real time at start / operand fragments built / end and its parity class; NULL disables.  Not for production. */
 int32_t otr_debug_trace(void* buf);
 const char* otr_last_error_string(void);
 

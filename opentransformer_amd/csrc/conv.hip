@@ -254,10 +254,13 @@ extern "C" int32_t otr_conv2_col2im(const otr_conv_desc_t* d, const void* dcol, 
 // ReLU mask of act1 is applied.  Nothing like the [pixels, 9*C1] column matrix of the explicit form is written or read
 // (184 MB each way at the AISHELL shapes: the GEMM + col2im pair took 77 + 70 us).  Workgroups are persistent, belong to one
 // class (their A fragments never change) and the classes get workgroups in proportion to pixels x taps.
+extern unsigned long long* g_otr_trace;   // api.hip (otr_debug_trace)
 struct Conv2DgArgs {
   const uint16_t* g2; const uint16_t* w2r; const uint16_t* act1; uint16_t* dact1;
   int B, T1, F1, T2, F2;
   int wg0[5];                       // class c = 2*(t1&1) + (f1&1) owns workgroups [wg0[c], wg0[c+1])
+  unsigned long long* trace;        // tuning hook (otr_debug_trace): [workgroup][4] = 100 MHz real-time at start, after the A
+                                    // fragments are built, at the end, and the class; or NULL
 };
 
 // one parity class (PT = t1 & 1, PF = f1 & 1): the tap count is a compile-time constant, so a tile is straight-line code --
@@ -282,6 +285,7 @@ __device__ __forceinline__ void conv2_dgrad_class(const Conv2DgArgs& p, uint4* a
     afrag[e] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
   }
   __syncthreads();
+  if (p.trace && threadIdx.x == 0) p.trace[(int64_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, hi = lane >> 5, pl = lane & 31;
   const int nT = PT ? p.T1 / 2 : (p.T1 + 1) / 2, nF = PF ? p.F1 / 2 : (p.F1 + 1) / 2;
   const int Mc = p.B * nT * nF;
@@ -403,10 +407,16 @@ template <int RT, int KS> __global__ __launch_bounds__(512, 4) void conv2_dgrad_
   int cls = 0;
   while (cls < 3 && (int)blockIdx.x >= p.wg0[cls + 1]) ++cls;
   const int w = (int)blockIdx.x - p.wg0[cls], nwg = p.wg0[cls + 1] - p.wg0[cls];
+  if (p.trace && threadIdx.x == 0) {
+    p.trace[(int64_t)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+    p.trace[(int64_t)blockIdx.x * 4 + 3] = (unsigned long long)cls;
+  }
   if (cls == 0) conv2_dgrad_class<RT, KS, 0, 0>(p, afrag, ebuf, w, nwg);
   else if (cls == 1) conv2_dgrad_class<RT, KS, 0, 1>(p, afrag, ebuf, w, nwg);
   else if (cls == 2) conv2_dgrad_class<RT, KS, 1, 0>(p, afrag, ebuf, w, nwg);
   else conv2_dgrad_class<RT, KS, 1, 1>(p, afrag, ebuf, w, nwg);
+  __syncthreads();
+  if (p.trace && threadIdx.x == 0) p.trace[(int64_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 }
 
 // (Tried and removed: the B operand staged through LDS -- rows fetched line by line, 8 lanes per 128-byte line, XOR-swizzled
@@ -426,6 +436,7 @@ extern "C" int32_t otr_conv2_dgrad(const otr_conv_desc_t* d, const void* dact2, 
   Conv2DgArgs a{};
   a.g2 = (const uint16_t*)dact2; a.w2r = (const uint16_t*)w2r; a.act1 = (const uint16_t*)act1; a.dact1 = (uint16_t*)dact1;
   a.B = d->B; a.T1 = d->T1; a.F1 = d->F1; a.T2 = d->T2; a.F2 = d->F2;
+  a.trace = g_otr_trace;
   // Workgroups per class: a tile is modelled as a fixed part (mask rows, the epilogue's LDS round trips, the header wait) plus
   // one part per tap, 3.7 : 1.  Every class gets one workgroup, the rest go one by one to the class whose workgroups
   // currently run longest (exact for this min-max problem).  (Splitting by pixels x taps instead gave the same 75 us at the

@@ -55,4 +55,25 @@ res['max_abs_diff_vs_column_pair'] = float((a.float() - dact1.float()).abs().max
 res['hbm_bytes_min'] = g2.numel() * 2 + act1.numel() * 2 * 2
 res['tflops'] = res['flops'] / res['implicit_us'] / 1e6
 res['hbm_gbps_min_traffic'] = res['hbm_bytes_min'] / res['implicit_us'] / 1e3
+# per-workgroup timeline of one launch (otr_debug_trace: 100 MHz real-time stamps at start / fragments built / end, class)
+tr = torch.zeros(512 * 4, dtype=torch.int64, device=dev)
+lib.otr_debug_trace(C.c_void_p(tr.data_ptr()))
+implicit()
+torch.cuda.synchronize()
+lib.otr_debug_trace(None)
+t = tr.view(512, 4).cpu()
+t = t[t[:, 0] > 0]
+t0 = int(t[:, 0].min())
+tl = {}
+for c in range(4):
+    m = t[t[:, 3] == c]
+    if len(m) == 0:
+        continue
+    us = lambda x: round(float(x) / 100.0, 2)                      # noqa: E731
+    tl['class%d' % c] = {'workgroups': int(len(m)),
+                         'start_us_min_max': [us(m[:, 0].min() - t0), us(m[:, 0].max() - t0)],
+                         'fragments_built_us_median': us((m[:, 1] - m[:, 0]).median()),
+                         'tiles_us_min_median_max': [us((m[:, 2] - m[:, 1]).min()), us((m[:, 2] - m[:, 1]).median()), us((m[:, 2] - m[:, 1]).max())],
+                         'end_us_min_max': [us(m[:, 2].min() - t0), us(m[:, 2].max() - t0)]}
+res['timeline'] = tl
 print(json.dumps(res))
