@@ -41,7 +41,8 @@ int32_t otr_half_type(void);
 /* tuning hook for benchmarks: key 0 = force GEMM tile (0 auto / 64 / 128), key 1 = force split-K (0 auto),
  * key 2 = 1: generic (bounds-checked) loaders only, key 3 = 1: no persistent tile loop, key 6 = 0/1: 256-wide
  * weight-gradient launch off / on (-1: environment OTR_WGRAD256), key 7 = its workgroup count (0 = one per CU), key 8 = its ablation / cache
- * policy switches (wgrad256.h), key 9 = the shortest contraction it takes */
+ * policy switches (wgrad256.h), key 9 = the shortest contraction it takes, key 10 = ablations of otr_conv2_dgrad (1 = no mask loads /
+ * result stores, 2 = every operand load from one line: timing only, results are garbage) */
 int32_t otr_debug_set(int32_t key, int32_t value);
 /* hardware probe used by the tests of the 256-wide weight-gradient kernel: one wave copies image[2048] (16-bit words)
  * to LDS and issues ONE ds_read_b64_tr_b16 with lane l at byte address addr[l]; out[l*4 + j] = element j lane l got. */

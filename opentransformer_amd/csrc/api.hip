@@ -45,6 +45,7 @@ int g_otr_ffn2_ablate = 0;   // tuning hook (otr_debug_set(4, v)): bit 0 = no we
 int g_otr_wgrad256 = -1;     // 256x256-tile weight-gradient launch (wgrad256.hip): -1 = environment OTR_WGRAD256 (default on), 0 / 1 (otr_debug_set(6, v))
 int g_otr_wgrad256_ablate = 0;   // tuning hook (otr_debug_set(8, v)), see wgrad256.h
 int g_otr_wgrad256_min_rows = 256;   // shortest contraction the 256-wide launch takes (otr_debug_set(9, v))
+extern int g_otr_conv2_dgrad_ablate;   // conv.hip (otr_debug_set(10, v))
 int g_otr_wgrad256_grid = 0; // workgroups of that launch; 0 = one per CU (otr_debug_set(7, v))
 unsigned long long* g_otr_trace = nullptr;
 extern "C" int32_t otr_debug_trace(void* buf) { g_otr_trace = (unsigned long long*)buf; return 0; }
@@ -59,6 +60,7 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   else if (key == 7) g_otr_wgrad256_grid = value;
   else if (key == 8) g_otr_wgrad256_ablate = value;
   else if (key == 9) g_otr_wgrad256_min_rows = value;
+  else if (key == 10) g_otr_conv2_dgrad_ablate = value;
   else { otr_set_error("debug_set: unknown key %d", key); return -1; }
   return 0;
 }

@@ -255,10 +255,12 @@ extern "C" int32_t otr_conv2_col2im(const otr_conv_desc_t* d, const void* dcol, 
 // (184 MB each way at the AISHELL shapes: the GEMM + col2im pair took 77 + 70 us).  Workgroups are persistent, belong to one
 // class (their A fragments never change) and the classes get workgroups in proportion to pixels x taps.
 extern unsigned long long* g_otr_trace;   // api.hip (otr_debug_trace)
+int g_otr_conv2_dgrad_ablate = 0;         // tuning hook (otr_debug_set(10, v)), see Conv2DgArgs
 struct Conv2DgArgs {
   const uint16_t* g2; const uint16_t* w2r; const uint16_t* act1; uint16_t* dact1;
   int B, T1, F1, T2, F2;
   int wg0[5];                       // class c = 2*(t1&1) + (f1&1) owns workgroups [wg0[c], wg0[c+1])
+  int ablate;                       // tuning hook (otr_debug_set(10, v)): 1 = no mask loads / result stores, 2 = every operand load from one line
   unsigned long long* trace;        // tuning hook (otr_debug_trace): [workgroup][4] = 100 MHz real-time at start, after the A
                                     // fragments are built, at the end, and the class; or NULL
 };
@@ -349,11 +351,12 @@ __device__ __forceinline__ void conv2_dgrad_class(const Conv2DgArgs& p, uint4* a
     for (int tt = 0; tt < NT; ++tt) {
       const uint16_t* srcn;
       const bool okn = tt + 1 < NT ? src_of(px, tt + 1, srcn) : src_of(npx, 0, srcn);
+      if (p.ablate & 2) srcn = p.g2 + hi * 8;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         if (tt == 0 && ks == 0) {                              // ReLU mask of this tile's pixels (HBM every time): in flight under the whole tile
 #pragma unroll
-          for (int g = 0; g < RT * 2; ++g) am[g] = ld_global_b128(p.act1 + obase + g * 16);
+          for (int g = 0; g < RT * 2; ++g) am[g] = (p.ablate & 1) ? make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u) : ld_global_b128(p.act1 + obase + g * 16);
         }
         const uint4 bq = okc ? cur[ks] : make_uint4(0u, 0u, 0u, 0u);
         {                                                      // next step's A fragments: their LDS latency under this step's MFMAs
@@ -395,7 +398,7 @@ __device__ __forceinline__ void conv2_dgrad_class(const Conv2DgArgs& p, uint4* a
       auto keep = [](uint32_t act, uint32_t val) {
         return ((int16_t)(act & 0xffffu) > 0 ? (val & 0xffffu) : 0u) | ((int16_t)(act >> 16) > 0 ? (val & 0xffff0000u) : 0u);
       };
-      if (elive) st_global_b128(p.dact1 + obase + g * 16, make_uint4(keep(a.x, v.x), keep(a.y, v.y), keep(a.z, v.z), keep(a.w, v.w)));
+      if (elive && !(p.ablate & 1)) st_global_b128(p.dact1 + obase + g * 16, make_uint4(keep(a.x, v.x), keep(a.y, v.y), keep(a.z, v.z), keep(a.w, v.w)));
     }
     px = npx;
   }
@@ -437,6 +440,7 @@ extern "C" int32_t otr_conv2_dgrad(const otr_conv_desc_t* d, const void* dact2, 
   a.g2 = (const uint16_t*)dact2; a.w2r = (const uint16_t*)w2r; a.act1 = (const uint16_t*)act1; a.dact1 = (uint16_t*)dact1;
   a.B = d->B; a.T1 = d->T1; a.F1 = d->F1; a.T2 = d->T2; a.F2 = d->F2;
   a.trace = g_otr_trace;
+  a.ablate = g_otr_conv2_dgrad_ablate;
   // Workgroups per class: a tile is modelled as a fixed part (mask rows, the epilogue's LDS round trips, the header wait) plus
   // one part per tap, 3.7 : 1.  Every class gets one workgroup, the rest go one by one to the class whose workgroups
   // currently run longest (exact for this min-max problem).  (Splitting by pixels x taps instead gave the same 75 us at the

@@ -55,6 +55,13 @@ res['max_abs_diff_vs_column_pair'] = float((a.float() - dact1.float()).abs().max
 res['hbm_bytes_min'] = g2.numel() * 2 + act1.numel() * 2 * 2
 res['tflops'] = res['flops'] / res['implicit_us'] / 1e6
 res['hbm_gbps_min_traffic'] = res['hbm_bytes_min'] / res['implicit_us'] / 1e3
+# ablations (otr_debug_set(10, v)): results are garbage, only the time counts
+res['ablations_us'] = {}
+for v, name in ((1, 'no mask loads / result stores'), (2, 'operand loads from one line'), (3, 'both')):
+    lib.otr_debug_set(10, v)
+    res['ablations_us'][name] = timed(implicit, 10)
+lib.otr_debug_set(10, 0)
+res['implicit_us_again'] = timed(implicit, 10)
 # per-workgroup timeline of one launch (otr_debug_trace: 100 MHz real-time stamps at start / fragments built / end, class)
 tr = torch.zeros(512 * 4, dtype=torch.int64, device=dev)
 lib.otr_debug_trace(C.c_void_p(tr.data_ptr()))
