@@ -323,6 +323,9 @@ int32_t otr_conv2_col2im(const otr_conv_desc_t* d, const void* dcol, const void*
  * Returns 1 without launching anything when the operands do not qualify: use otr_conv2_dgrad_cols + otr_conv2_col2im then. */
 int32_t otr_conv2_dgrad(const otr_conv_desc_t* d, const void* dact2, const void* w2r, const void* act1, void* dact1,
                         void* stream);
+/* host-side plan of that launch, no device work (tests): out[10] = {served 0/1, first workgroup of the parity classes
+ * c = 2*(t1&1) + (f1&1) and the total (5 values), 256-pixel tiles per class (4 values)} */
+int32_t otr_debug_conv2_dgrad_plan(const otr_conv_desc_t* d, int32_t* out);
 /* dw2r [C2, 9*C1] f32 = dact2^T * im2col(act1) */
 int32_t otr_conv2_wgrad(const otr_conv_desc_t* d, const void* dact2, const void* act1, float* dw2r, void* workspace,
                         int64_t workspace_bytes, void* stream);

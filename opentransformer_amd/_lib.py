@@ -111,6 +111,7 @@ SIGNATURES = {
     'otr_conv2_dgrad_cols': [C.POINTER(ConvDesc), _P, _P, _P, _P],
     'otr_conv2_col2im': [C.POINTER(ConvDesc), _P, _P, _P, _P],
     'otr_conv2_dgrad': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
+    'otr_debug_conv2_dgrad_plan': [C.POINTER(ConvDesc), _P],
     'otr_conv2_wgrad': [C.POINTER(ConvDesc), _P, _P, _P, _P, _I64, _P],
     'otr_relu_bwd': [_P, _P, _P, _I32, _I64, _P],
     'otr_relu_bwd_colsum_partial_rows': [_I64, _I32, _I32],

@@ -426,27 +426,16 @@ template <int RT, int KS> __global__ __launch_bounds__(512, 4) void conv2_dgrad_
 //  chunks, 16 waves sharing the A fragments -- to spare the address path the one-lane-per-line loads above: 82 us against 78,
 //  bit-identical results.  What bounds this kernel is the latency of a wave's serial tile chain (a tile is 16-64 MFMAs, its
 //  ReLU-mask rows come from HBM every time), not the load instructions; profiles/r02_conv2_dgrad_bench.json.)
-// 0 = launched, 1 = shape not served (the caller uses otr_conv2_dgrad_cols + otr_conv2_col2im), < 0 = bad argument
-extern "C" int32_t otr_conv2_dgrad(const otr_conv_desc_t* d, const void* dact2, const void* w2r, const void* act1, void* dact1,
-                                   void* stream) {
-  ConvArgs chk{};
-  if (int32_t e = conv_check(d, chk)) return e;
-  OTR_REQUIRE(dact2 && w2r && act1 && dact1, "conv2_dgrad: null pointer");
-  const bool big = d->C1 == 64 && d->C2 == 128, small = d->C1 == 32 && d->C2 == 64;
-  if (d->act_dtype != OTR_H16 || d->w_dtype != OTR_H16 || !(big || small)) return 1;
-  if (((uintptr_t)dact2 | (uintptr_t)act1 | (uintptr_t)dact1) % 16 != 0) return 1;
-  OTR_REQUIRE((int64_t)d->B * d->T2 * d->F2 * d->C2 < (1ll << 31), "conv2_dgrad: act2 too large for 32-bit pixel index");
-  Conv2DgArgs a{};
-  a.g2 = (const uint16_t*)dact2; a.w2r = (const uint16_t*)w2r; a.act1 = (const uint16_t*)act1; a.dact1 = (uint16_t*)dact1;
-  a.B = d->B; a.T1 = d->T1; a.F1 = d->F1; a.T2 = d->T2; a.F2 = d->F2;
-  a.trace = g_otr_trace;
-  a.ablate = g_otr_conv2_dgrad_ablate;
+// The launch's split into parity classes (host only): wg0[c..c+1) = the workgroups of class c = 2*(t1&1) + (f1&1), tiles[c] =
+// its 256-pixel tiles.  Shared by otr_conv2_dgrad and otr_debug_conv2_dgrad_plan (tests/test_cabi.py replays the kernel's pixel
+// and tap arithmetic on it).
+static void conv2_dgrad_plan(const otr_conv_desc_t* d, int* wg0, int* tiles) {
   // Workgroups per class: a tile is modelled as a fixed part (mask rows, the epilogue's LDS round trips, the header wait) plus
   // one part per tap, 3.7 : 1.  Every class gets one workgroup, the rest go one by one to the class whose workgroups
   // currently run longest (exact for this min-max problem).  (Splitting by pixels x taps instead gave the same 75 us at the
   // AISHELL shape: the launch is not bound by the balance between the classes -- profiles/r02_conv2_dgrad_pmc.txt.)
   const int G = 512, TILE = 256;
-  int tiles[4], n[4], taps[4];
+  int n[4], taps[4];
   for (int c = 0; c < 4; ++c) {
     const int pt = c >> 1, pf = c & 1;
     const int64_t nT = pt ? d->T1 / 2 : (d->T1 + 1) / 2, nF = pf ? d->F1 / 2 : (d->F1 + 1) / 2;
@@ -465,8 +454,43 @@ extern "C" int32_t otr_conv2_dgrad(const otr_conv_desc_t* d, const void* dact2, 
     if (best < 0) break;
     ++n[best];
   }
-  a.wg0[0] = 0;
-  for (int c = 0; c < 4; ++c) a.wg0[c + 1] = a.wg0[c] + n[c];
+  wg0[0] = 0;
+  for (int c = 0; c < 4; ++c) wg0[c + 1] = wg0[c] + n[c];
+}
+static bool conv2_dgrad_serves(const otr_conv_desc_t* d) {
+  const bool big = d->C1 == 64 && d->C2 == 128, small = d->C1 == 32 && d->C2 == 64;
+  return d->act_dtype == OTR_H16 && d->w_dtype == OTR_H16 && (big || small);
+}
+// out: {served (0 / 1), wg0[0..4], tiles[0..3]}
+extern "C" int32_t otr_debug_conv2_dgrad_plan(const otr_conv_desc_t* d, int32_t* out) {
+  ConvArgs chk{};
+  if (int32_t e = conv_check(d, chk)) return e;
+  OTR_REQUIRE(out != nullptr, "debug_conv2_dgrad_plan: null pointer");
+  int wg0[5], tiles[4];
+  conv2_dgrad_plan(d, wg0, tiles);
+  out[0] = conv2_dgrad_serves(d) ? 1 : 0;
+  for (int c = 0; c < 5; ++c) out[1 + c] = wg0[c];
+  for (int c = 0; c < 4; ++c) out[6 + c] = tiles[c];
+  return 0;
+}
+
+// 0 = launched, 1 = shape not served (the caller uses otr_conv2_dgrad_cols + otr_conv2_col2im), < 0 = bad argument
+extern "C" int32_t otr_conv2_dgrad(const otr_conv_desc_t* d, const void* dact2, const void* w2r, const void* act1, void* dact1,
+                                   void* stream) {
+  ConvArgs chk{};
+  if (int32_t e = conv_check(d, chk)) return e;
+  OTR_REQUIRE(dact2 && w2r && act1 && dact1, "conv2_dgrad: null pointer");
+  const bool big = d->C1 == 64 && d->C2 == 128;
+  if (!conv2_dgrad_serves(d)) return 1;
+  if (((uintptr_t)dact2 | (uintptr_t)act1 | (uintptr_t)dact1) % 16 != 0) return 1;
+  OTR_REQUIRE((int64_t)d->B * d->T2 * d->F2 * d->C2 < (1ll << 31), "conv2_dgrad: act2 too large for 32-bit pixel index");
+  Conv2DgArgs a{};
+  a.g2 = (const uint16_t*)dact2; a.w2r = (const uint16_t*)w2r; a.act1 = (const uint16_t*)act1; a.dact1 = (uint16_t*)dact1;
+  a.B = d->B; a.T1 = d->T1; a.F1 = d->F1; a.T2 = d->T2; a.F2 = d->F2;
+  a.trace = g_otr_trace;
+  a.ablate = g_otr_conv2_dgrad_ablate;
+  int tiles[4];
+  conv2_dgrad_plan(d, a.wg0, tiles);
   if (a.wg0[4] == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (big) hipLaunchKernelGGL((conv2_dgrad_kernel<2, 8>), dim3((unsigned)a.wg0[4]), dim3(512), 0, s, a);

@@ -222,3 +222,57 @@ def test_wgrad256_schedule_covers_every_slab_once():
         for key, lst in slices.items():
             ns = lst[0][1]
             assert all(n == ns for _, n in lst) and sorted(s for s, _ in lst) == list(range(ns)), (key, lst)
+
+
+def test_conv2_dgrad_plan_and_index_arithmetic():
+    """otr_debug_conv2_dgrad_plan (host only) + the implicit conv2 input-gradient kernel's pixel / tap arithmetic replayed here
+    (csrc/conv.hip conv2_dgrad_class): the four parity classes with their workgroup ranges cover every act1 pixel exactly once,
+    and the taps a class uses -- (kh, kw) -> g2 pixel (t2, f2), dropped when out of range -- are exactly the (t2, f2, kh, kw) for
+    which the forward convolution (3x3, stride 2, pad (0, 1): frontend/conv.py:63) reads that pixel."""
+    import ctypes as C
+    import numpy as np
+    from opentransformer_amd import _lib as L
+    from opentransformer_amd.ops import conv_geometry
+    lib = L.load('bf16')
+    for (B, T, Fd, C1, C2) in [(32, 1000, 80, 64, 128), (3, 97, 40, 64, 128), (2, 200, 83, 32, 64), (1, 7, 3, 64, 128), (5, 331, 80, 128, 128)]:
+        T1, F1, T2, F2 = conv_geometry(T, Fd)
+        desc = L.ConvDesc(B, T, Fd, C1, C2, T1, F1, T2, F2, L.OTR_BF16, L.OTR_BF16, L.OTR_BF16)
+        out = (C.c_int32 * 10)()
+        assert lib.otr_debug_conv2_dgrad_plan(C.byref(desc), out) == 0
+        served, wg0, tiles = out[0], list(out[1:6]), list(out[6:10])
+        assert served == int((C1, C2) in ((64, 128), (32, 64)))
+        assert wg0[0] == 0 and wg0[4] <= 512
+        cover = np.zeros((B, T1, F1), np.int32)
+        small = B * T1 * F1 <= 40000                      # the tap relation is checked exhaustively on the small shapes
+        for c in range(4):
+            pt, pf = c >> 1, c & 1
+            nT, nF = (T1 // 2 if pt else (T1 + 1) // 2), (F1 // 2 if pf else (F1 + 1) // 2)
+            Mc = B * nT * nF
+            assert tiles[c] == -(-Mc // 256)
+            nwg = wg0[c + 1] - wg0[c]
+            assert (nwg >= 1) == (tiles[c] > 0) and nwg <= max(tiles[c], 0)
+            # workgroup w of the class walks tiles w, w + nwg, ...: every tile once
+            walked = sorted(t for w in range(nwg) for t in range(w, tiles[c], nwg))
+            assert walked == list(range(tiles[c]))
+            m = np.arange(Mc)
+            bi, j = m // nF, m % nF
+            b, i = bi // nT, bi % nT
+            t1, f1 = 2 * i + pt, 2 * j + pf
+            np.add.at(cover, (b, t1, f1), 1)
+            nkw = 2 if pf else 1
+            ntaps = (1 if pt else 2) * nkw
+            if not small:
+                continue
+            for mm in range(Mc):
+                got = set()
+                for tt in range(ntaps):
+                    a, b2 = tt // nkw, tt % nkw
+                    kh, kw = (1 if pt else 2 * a), (2 * b2 if pf else 1)
+                    t2, f2 = (i[mm] if pt else i[mm] - a), (j[mm] + 1 - b2 if pf else j[mm])
+                    if 0 <= t2 < T2 and 0 <= f2 < F2:
+                        got.add((int(t2), int(f2), kh, kw))
+                want = {(t2, f2, kh, kw) for kh in range(3) for kw in range(3)
+                        for t2 in [(t1[mm] - kh) // 2] if (t1[mm] - kh) % 2 == 0 and 0 <= t2 < T2
+                        for f2 in [(f1[mm] + 1 - kw) // 2] if (f1[mm] + 1 - kw) % 2 == 0 and 0 <= f2 < F2}
+                assert got == want, (c, mm, got, want)
+        assert int(cover.min()) == 1 and int(cover.max()) == 1
