@@ -42,8 +42,15 @@ int32_t otr_half_type(void);
  * key 2 = 1: generic (bounds-checked) loaders only, key 3 = 1: no persistent tile loop, key 6 = 0/1: 256-wide
  * weight-gradient launch off / on (-1: environment OTR_WGRAD256), key 7 = its workgroup count (0 = one per CU), key 8 = its ablation / cache
  * policy switches (wgrad256.h), key 9 = the shortest contraction it takes, key 10 = ablations of otr_conv2_dgrad (1 = no mask loads /
- * result stores, 2 = every operand load from one line: timing only, results are garbage) */
+ * result stores, 2 = every operand load from one line: timing only, results are garbage), key 11 = bound of every in-kernel
+ * turnstile / arrival spin (<= 0: the default 2^22; tests force a give-up with 1) */
 int32_t otr_debug_set(int32_t key, int32_t value);
+/* Register the caller-owned, zero-initialised DEVICE word that spin-bounded kernels (the turnstile of the 256-wide
+ * weight-gradient launch; NULL = none) add 1 to whenever a wait gives up -- the results of such a launch may be wrong sums.
+ * otr_optimizer_step reads and clears it: a non-zero count skips the update exactly like a non-finite gradient norm and is
+ * accumulated in state[10].  Process-wide like the compute type; the pointer is baked into captured graphs, so register it
+ * before capturing and keep the word alive.  Replaces nothing in the reference (train/trainer.py:229 only guards NaNs). */
+int32_t otr_set_fault_counter(void* device_word);
 /* hardware probe used by the tests of the 256-wide weight-gradient kernel: one wave copies image[2048] (16-bit words)
  * to LDS and issues ONE ds_read_b64_tr_b16 with lane l at byte address addr[l]; out[l*4 + j] = element j lane l got. */
 int32_t otr_debug_trread(const void* image, const int32_t* addr, void* out, void* stream);
@@ -415,7 +422,8 @@ int32_t otr_ctc_loss(const float* log_probs, const int64_t* targets, int64_t ldt
  *      L2 weight decay, train/scheduler.py:10-13).  grad_scale (1/world_size after the all-reduce-sum)
  *      is folded into clip + update.  state: f32[16] device block, zero-initialised by the caller once:
  *        [0] step  [1] lr  [2] bc1  [3] bc2  [4] sqnorm  [5] skipped  [6] loss_scale  [7] good_steps  [8] unscale
- *        [9] growth_interval  [10..15] reserved.
+ *        [9] growth_interval  [10] faults (give-ups reported through otr_set_fault_counter; each skipped its update)
+ *        [11..15] reserved.
  *      Loss scaling (fp16 builds): when state[6] > 0 the gradients in `grad` are state[6] times too large (the caller
  *      seeded its backward pass with that device scalar); the update divides it out, HALVES it and skips the update when
  *      the gradient norm is not finite, and doubles it after state[9] consecutive finite updates (0 = never) -- all on

@@ -62,6 +62,7 @@ SIGNATURES = {
     'otr_version': [],
     'otr_half_type': [],
     'otr_debug_set': [_I32, _I32],
+    'otr_set_fault_counter': [_P],
     'otr_last_error_string': [],
     'otr_linear_fwd': [C.POINTER(LinearDesc), _P, _P, _P, _P, _P, _I64, _P],
     'otr_linear_dgrad': [C.POINTER(LinearDesc), _P, _P, _P, _P, _I64, _P],

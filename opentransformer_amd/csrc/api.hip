@@ -47,6 +47,8 @@ int g_otr_wgrad256_ablate = 0;   // tuning hook (otr_debug_set(8, v)), see wgrad
 int g_otr_wgrad256_min_rows = 256;   // shortest contraction the 256-wide launch takes (otr_debug_set(9, v))
 extern int g_otr_conv2_dgrad_ablate;   // conv.hip (otr_debug_set(10, v))
 int g_otr_wgrad256_grid = 0; // workgroups of that launch; 0 = one per CU (otr_debug_set(7, v))
+int g_otr_spin_limit = 1 << 22;  // bound of every in-kernel turnstile / arrival spin (otr_debug_set(11, v): tests force a give-up with 1)
+int32_t* g_otr_fault = nullptr;  // device word the spin-bounded kernels add 1 to when they give up (otr_set_fault_counter)
 unsigned long long* g_otr_trace = nullptr;
 extern "C" int32_t otr_debug_trace(void* buf) { g_otr_trace = (unsigned long long*)buf; return 0; }
 extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
@@ -61,11 +63,14 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   else if (key == 8) g_otr_wgrad256_ablate = value;
   else if (key == 9) g_otr_wgrad256_min_rows = value;
   else if (key == 10) g_otr_conv2_dgrad_ablate = value;
+  else if (key == 11) g_otr_spin_limit = value > 0 ? value : 1 << 22;
   else { otr_set_error("debug_set: unknown key %d", key); return -1; }
   return 0;
 }
 
-extern "C" int32_t otr_version(void) { return 200; }
+extern "C" int32_t otr_set_fault_counter(void* device_word) { g_otr_fault = (int32_t*)device_word; return 0; }
+
+extern "C" int32_t otr_version(void) { return 300; }
 extern "C" int32_t otr_half_type(void) { return OTR_H16; }
 extern "C" const char* otr_last_error_string(void) { return g_err; }
 

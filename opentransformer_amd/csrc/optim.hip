@@ -6,6 +6,8 @@
 // is hipGraph-replayable:  state = {step, lr, bias_corr1, bias_corr2, sqnorm, skipped}.
 #include "common.h"
 
+extern int32_t* g_otr_fault;   // api.hip: sticky device fault word (otr_set_fault_counter) or NULL
+
 struct OptState {
   float step;            // [0] number of optimizer updates applied so far (Adam's t)
   float lr;              // [1] learning rate used by the last update
@@ -17,7 +19,9 @@ struct OptState {
   float good_steps;      // [7] consecutive finite updates since loss_scale last changed
   float unscale;         // [8] grad_scale / loss_scale of THIS update (tick kernel -> adam kernel)
   float growth_interval; // [9] double loss_scale after this many finite updates (0 = never); set by the caller
-  float reserved[6];
+  float faults;          // [10] total give-ups of spin-bounded kernels (otr_set_fault_counter) seen by the updates so far: each
+                         //      such update was skipped like a non-finite one -- its gradients may be wrong sums
+  float reserved[5];
 };
 
 __global__ void sqnorm_kernel(const float* g, int64_t n, OptState* st) {
@@ -48,10 +52,21 @@ __global__ void sqnorm_kernel(const float* g, int64_t n, OptState* st) {
 // one thread: NaN guard + dynamic loss scale, then advance the step counter and evaluate the schedule (Noam if
 // warmup > 0, else constant lr)
 __global__ void opt_tick_kernel(OptState* st, float base_lr, float model_size, float warmup, float factor,
-                                float step_offset, float beta1, float beta2, float grad_scale) {
+                                float step_offset, float beta1, float beta2, float grad_scale, int32_t* fault) {
   const float ls = st->loss_scale > 0.f ? st->loss_scale : 1.f;
   const float us = grad_scale / ls;
   st->unscale = us;
+  if (fault) {
+    // a kernel of this step gave up a bounded wait (wgrad256 turnstile, fused-FFN arrival): a finite but WRONG gradient would
+    // pass the NaN guard below, so the update is skipped here and the adam kernel is told through a NaN unscale factor
+    const int32_t nf = __hip_atomic_exchange(fault, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nf != 0) {
+      st->faults += (float)nf;
+      st->skipped += 1.f;
+      st->unscale = __builtin_nanf("");
+      return;
+    }
+  }
   float norm = sqrtf(st->sqnorm) * us;
   if (!isfinite(norm)) {                                   // trainer.py:229: skip the update
     st->skipped += 1.f;
@@ -124,7 +139,7 @@ extern "C" int32_t otr_optimizer_step(float* param, const float* grad, float* ex
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(256), 0, s, grad, n, st);
   hipLaunchKernelGGL(opt_tick_kernel, dim3(1), dim3(1), 0, s, st, base_lr, noam_model_size, noam_warmup, noam_factor,
-                     noam_step_offset, beta1, beta2, grad_scale);
+                     noam_step_offset, beta1, beta2, grad_scale, g_otr_fault);
   unsigned g2 = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
   hipLaunchKernelGGL(adam_kernel, dim3(g2), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, st, (bf16_t*)param_bf16, beta1, beta2, eps,
                      weight_decay, clip_norm, grad_noise_std);

@@ -32,6 +32,7 @@ struct W256Args {
   int ablate, policy;                      // tuning hook (otr_debug_set(8, v)): 1 = no MFMA, 2 = no DMA after the prologue, 4 = no accumulation into dw; v >> 3: 0 = default policy (non-temporal unshared strips); else (v >> 3) - 1 = bit 0 non-temporal strips.  Ablation 6 = the x part is not fetched (its DMA reads one zero line)
   int* flags;
   const void* zeros;                    // >= 64 zero bytes: source of rows past M
+  int* fault;                           // NULL or the sticky device fault word (otr_set_fault_counter): +1 per piece that gave up
 };
 
 // Eligibility is the caller's business (api.hip); workspace holds 64 zero bytes + one int per tile.

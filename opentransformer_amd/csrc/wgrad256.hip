@@ -25,6 +25,9 @@
 
 #include <algorithm>
 
+extern int g_otr_spin_limit;       // api.hip: bound of the turnstile spin (otr_debug_set(11, v))
+extern int32_t* g_otr_fault;       // api.hip: sticky device fault word (otr_set_fault_counter) or NULL
+
 namespace {
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -413,8 +416,11 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
             __builtin_amdgcn_s_sleep(8);
             ++spins;
           }
-          if (spins >= g.spin_limit)                                   // give-up code: word 15 of the zero line (otr_debug_wgrad256_errors)
+          if (spins >= g.spin_limit) {                                 // give-up code: word 15 of the zero line (otr_debug_wgrad256_errors)
             __hip_atomic_fetch_add(const_cast<int*>(reinterpret_cast<const int*>(g.zeros)) + 15, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ... and the caller's sticky fault word: otr_optimizer_step skips the update of a step whose gradients may be wrong
+            if (g.fault) __hip_atomic_fetch_add(g.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
         __syncthreads();
       }
@@ -460,7 +466,7 @@ static int32_t wgrad256_plan(const W256Item* it, int n, int grid_cap, W256Args& 
     return -1;
   }
   int cap = grid_cap > 0 ? grid_cap : (grid_cap < 0 ? -grid_cap : 248);    // < 0: that many workgroups, stream-K schedule
-  g.nprob = n; g.total = (int)total; g.spin_limit = 1 << 22;
+  g.nprob = n; g.total = (int)total; g.spin_limit = g_otr_spin_limit; g.fault = g_otr_fault;
   if (same_rows && grid_cap >= 0 && flags >= 8) {
     // Rounds: every tile is R slabs long.  G slots (whole XCD groups) each walk one whole tile per round -- the tiles of a
     // problem sit in neighbouring slots of one XCD and read their shared operand panel in step -- and the tiles left over

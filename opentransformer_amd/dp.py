@@ -107,19 +107,17 @@ class FlatDataParallel:
             rows += r
             views.append((w1, offs, F2 * d, d * (F2 // 2)))
             total += n
-        # the attention projections the row-block kernels take (ops.lin_packs): forward + input-gradient pack each
+        # every Linear weight the row-block kernels can take (ops.lin_packs / ops._RB_SHAPES): forward + input-gradient pack
+        # each.  By SHAPE, not by attribute name: any such weight that reached ops.LinearFn without registered packs would
+        # otherwise be served from a cache keyed by (_version, data_ptr), which FusedAdam's raw-pointer update never changes
         lin_views = []
-        for mod in module.modules():
-            for name in ('qvk_proj', 'q_proj', 'output_proj'):
-                w = getattr(getattr(mod, name, None), 'weight', None)
-                if w is None or id(w) not in off_of or w.dim() != 2 or tuple(w.shape) not in ops._RB_SHAPES or not ops._RB:
-                    continue
-                if any(w is v[0] for v in lin_views):
-                    continue
-                r, n = ops.lin_pack_items(off_of[id(w)], w.shape[0], w.shape[1], total)
-                rows += r
-                lin_views.append((w, total, w.numel()))
-                total += n
+        for w in self.params:
+            if w.dim() != 2 or tuple(w.shape) not in ops._RB_SHAPES or not ops._RB:
+                continue
+            r, n = ops.lin_pack_items(off_of[id(w)], w.shape[0], w.shape[1], total)
+            rows += r
+            lin_views.append((w, total, w.numel()))
+            total += n
         if not rows:
             return
         self.flat_pack = torch.empty(total, device=dev, dtype=self.flat_param_lp.dtype)
@@ -211,7 +209,9 @@ class FlatDataParallel:
                 L.check(lib.otr_allreduce_unique_id(uid), 'otr_allreduce_unique_id')
             if ws > 1:
                 box = [uid.raw]
-                dist.broadcast_object_list(box, src=0, group=self.group)
+                # `src` of a collective is a GLOBAL rank: group rank 0 of a sub-group need not be global rank 0
+                src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+                dist.broadcast_object_list(box, src=src, group=self.group)
                 uid = C.create_string_buffer(box[0], 128)
             h = C.c_void_p()
             L.check(lib.otr_allreduce_init(C.byref(h), uid, rank, ws), 'otr_allreduce_init')
@@ -222,6 +222,12 @@ class FlatDataParallel:
         if self._rccl is not None:
             L.check(L.load().otr_allreduce_destroy(self._rccl), 'otr_allreduce_destroy')
             self._rccl = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                   # noqa: BLE001  (interpreter shutdown: the library may be gone)
+            pass
 
     def all_reduce_gradients(self, async_op=False, force=False):
         """single collective over the flat buffer; returns 1/world_size for the optimizer to fold in.
@@ -267,6 +273,7 @@ class FusedAdam:
         self.grad_noise = float(grad_noise)
         if dp.flat_param.is_cuda:
             from . import ops
+            ops.fault_counter(dp.flat_param.device)     # the update skips when a spin-bounded kernel of the step gave up
             if loss_scale is None:
                 loss_scale = 4096.0 if ops.get_compute_dtype() == 'fp16' else 0.0
             if loss_scale:
@@ -281,6 +288,7 @@ class FusedAdam:
             raise L.OtransHipError('FusedAdam runs on the GPU only')
         n = self.dp.flat_param.numel()
         nm = self.noam or {}
+        self._last_grad_scale = float(grad_scale)
         ret = L.load().otr_optimizer_step(
             C.c_void_p(self.dp.flat_param.data_ptr()), C.c_void_p(self.dp.flat_grad.data_ptr()),
             C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()), n,
@@ -296,5 +304,9 @@ class FusedAdam:
 
     def stats(self):
         s = self.state.tolist()
-        ls = s[6] if s[6] > 0 else 1.0
-        return {'step': s[0], 'lr': s[1], 'grad_sqnorm': s[4] / (ls * ls), 'skipped': s[5], 'loss_scale': s[6]}
+        # state[4] is the squared norm of the gradients as they sat in memory (loss-scaled, summed over ranks); state[8] is
+        # the grad_scale / loss_scale of THAT update -- not the current state[6], which the same update may have halved or
+        # doubled.  A skipped update (NaN unscale after a fault, non-finite norm) reports the raw value over the current scale.
+        us, gs = s[8], getattr(self, '_last_grad_scale', 1.0)
+        ls = gs / us if (us == us and 0 < us < float('inf')) else (s[6] if s[6] > 0 else 1.0)
+        return {'step': s[0], 'lr': s[1], 'grad_sqnorm': s[4] / (ls * ls), 'skipped': s[5], 'loss_scale': s[6], 'faults': s[10]}

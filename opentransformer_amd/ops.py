@@ -61,7 +61,7 @@ def _timed(name, meta, call):
     e0.record()
     r = call()
     e1.record()
-    rec.append((name, meta, e0, e1))
+    rec.append((name, meta, e0, e1, call))
     return r
 
 
@@ -69,6 +69,26 @@ def set_compute_dtype(name):
     assert name in ('bf16', 'fp16', 'fp32')
     _state['compute'] = name
     L.select('fp16' if name == 'fp16' else 'bf16')      # fp32 mode lives in both builds; keep the bf16 one
+    _register_fault_counter()                           # each build keeps its own pointer to the one device word
+
+
+def fault_counter(device):
+    """The sticky device fault word (include/otrans_hip.h: otr_set_fault_counter): int32[1], one per process, registered with
+    the library build in use.  Kernels whose inter-workgroup waits are bounded (the turnstile of the 256-wide weight-gradient
+    launch) add 1 when a wait gives up; FusedAdam's update reads and clears it and skips the update -- a wrong-but-finite
+    gradient never reaches the parameters."""
+    f = _state.get('fault')
+    if f is None or f.device != device:
+        f = torch.zeros(1, dtype=torch.int32, device=device)
+        _state['fault'] = f
+        _register_fault_counter()
+    return f
+
+
+def _register_fault_counter():
+    f = _state.get('fault')
+    if f is not None:
+        L.check(L.load().otr_set_fault_counter(C.c_void_p(f.data_ptr())), 'otr_set_fault_counter')
 
 
 def is_half():
@@ -250,6 +270,7 @@ def _workspace(device):
     if ws is None or ws.device != device:
         ws = torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
         _state['ws'] = ws
+        fault_counter(device)           # registered before the first launch that could report through it (and before any capture)
     return ws
 
 
@@ -490,6 +511,10 @@ def lin_packs(w):
     views = getattr(w, '_otr_lin_packs', None)
     if views is not None:
         return views
+    if getattr(w, '_otr_grad_inplace', False):
+        # a parameter of a FlatDataParallel replica without registered packs: FusedAdam rewrites it through raw pointers
+        # (neither _version nor data_ptr changes), so a version-keyed cache would go stale after the first update
+        return None
     key = (w._version, w.data_ptr(), _state['compute'])
     cache = getattr(w, '_otr_lin_pack_cache', None)
     if cache is not None and cache[0] == key:
@@ -1172,6 +1197,8 @@ def ffn_packs(w1, w2):
     views = getattr(w1, '_otr_ffn_packs', None)
     if views is not None:                      # slices of FlatDataParallel's pack buffer (kept fresh by the optimizer)
         return views
+    if getattr(w1, '_otr_grad_inplace', False) or getattr(w2, '_otr_grad_inplace', False):
+        return None                            # replica parameters without registered packs: no version-keyed cache (see lin_packs)
     key = (w1._version, w1.data_ptr(), w2._version, w2.data_ptr(), _state['compute'])
     cache = getattr(w1, '_otr_ffn_pack_cache', None)
     if cache is not None and cache[0] == key:

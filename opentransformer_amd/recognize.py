@@ -124,6 +124,7 @@ class SpeechToTextRecognizer(Recognizer):
         self.apply_cache = bool(apply_cache)
         self.use_hipgraph = True
         self._cached_states = {}
+        self.trace = None       # test hook: a list collects (prefixes [B*beam, step+1], cumulative scores [B*beam]) after every step
 
     def encode(self, inputs, inputs_mask, cache=None):
         x, mask, fe_cache = self.model.frontend.inference(inputs, inputs_mask, None)
@@ -205,6 +206,8 @@ class SpeechToTextRecognizer(Recognizer):
                                        _ptr(preds[cur ^ 1]), _ptr(n_fin), stream()), 'otr_beam_prune')
             cur ^= 1
             steps = step
+            if self.trace is not None:
+                self.trace.append((preds[cur][:, :step + 1].clone(), scores[cur].clone()))
             if int(n_fin.item()) == R:           # the reference syncs here every step too (speech2text.py:67)
                 break
         return self._nbest(scores[cur], preds[cur], steps, b)
@@ -349,6 +352,8 @@ class CachedBeamState:
             self._launch(cur)
             cur ^= 1
             steps = step
+            if self.rec.trace is not None:
+                self.rec.trace.append((self.preds[cur][:, :step + 1].clone(), self.scores[cur].clone()))
             if int(self.n_fin.item()) == self.R:      # the reference syncs here every step too (speech2text.py:67)
                 break
         return cur, steps

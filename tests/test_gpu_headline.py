@@ -6,7 +6,13 @@
    compute modes.  North-star bar: 1e-3 relative on loss and logits; bench.py's mode (fp16) must meet it.
  * configs[4] (C5) at full size -- 12+6 layers, beam 10, 4-block TransformerLM shallow fusion, V = 4234 -- hypotheses and
    scores of the KV-cached hipGraph decoder against the ORACLE's beam search (recognize/speech2text.py:39-192 restated),
-   not against the product's own re-forward loop."""
+   not against the product's own re-forward loop.  In the 16-bit modes rounding may flip a near-tie inside the search, so
+   the product's per-step beams (SpeechToTextRecognizer.trace) are checked to be a VALID beam search under the oracle's
+   own scores: at every step the kept candidates are a top-`beam` set of the ORACLE's candidate scores up to twice the
+   measured score drift, and the product's cumulative scores sit within the drift of the oracle's.
+ * (r03) configs[3] (C4, conformer_baseline.yaml) at the bench batch -- B = 32 x 1000 frames, ragged lengths -- and
+   configs[1] with the joint CTC term (ctc_weight 0.3) at the same size: loss (+ the CTC term), logits, encoder memory and
+   every parameter gradient against the oracle in all three modes."""
 import json
 import os
 
@@ -45,15 +51,25 @@ def c2_oracle():
 HEADLINE_TOL = {'fp32': (1e-5, 5e-6, 1e-4), 'fp16': (1e-4, 1e-3, 8e-3), 'bf16': (1e-3, 8e-3, 5e-2)}
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'fp16', 'bf16'])
-def test_c2_batch32_matches_oracle(c2_oracle, mode):
+def _oracle_run(cfg, inputs, targets, seed=1234):
+    from oracle import otrans_oracle as orc
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    parts = H.require_grad(H.filled_state(cfg, seed=seed))
+    loss, aux = orc.speech2text_forward(parts, cfg, inputs, targets)
+    loss.backward()
+    return loss.detach(), {k: v.detach() for k, v in aux.items()}, H.flat_named(parts)
+
+
+def _compare_with_oracle(cfg, inputs, targets, ref_loss, ref_aux, ref_flat, mode, tag, label, tol, seed=1234):
+    """product forward + backward on the GPU in `mode`; relative errors of loss (+ CTC term), logits, encoder memory and every
+    parameter gradient against the oracle's; written to gpurun_out/parity_<tag>_<mode>.json and asserted against tol =
+    (loss, logits / memory, worst gradient)"""
     import opentransformer_amd as ota
     from opentransformer_amd import ops
-    cfg, inputs, targets, ref_loss, ref_aux, ref_flat = c2_oracle
     ops.set_compute_dtype(mode)
     try:
         model = ota.SpeechToText(cfg)
-        syn.fill_state_dict_(model.state_dict(), 1234)
+        syn.fill_state_dict_(model.state_dict(), seed)
         model = model.to(DEV).train()
         di = {k: v.to(DEV) for k, v in inputs.items()}
         dt = {k: v.to(DEV) for k, v in targets.items()}
@@ -61,15 +77,23 @@ def test_c2_batch32_matches_oracle(c2_oracle, mode):
             fe, fm = model.frontend(di['inputs'], di['mask'])
             memory, mm, _ = model.encoder(fe, fm)
             logits, _ = model.decoder(dt['targets'][:, :-1].contiguous(), memory, mm)
-            loss, _ = model(di, dt)
+            loss, aux = model(di, dt)
             loss.backward()
             ls.unscale(model)
-        r = {'config': 'C2 B=32 x 1000 frames (bench batch)', 'mode': mode,
+        r = {'config': label, 'mode': mode,
              'loss_rel': abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()),
              'logits_rel': rel(logits.detach(), ref_aux['logits']), 'memory_rel': rel(memory.detach(), ref_aux['memory'])}
+        if 'ctc_loss' in ref_aux:
+            r['ctc_loss_rel'] = abs(float(aux['CTCLoss']) - float(ref_aux['ctc_loss'])) / abs(float(ref_aux['ctc_loss']))
         worst, wkey, rels = 0.0, None, {}
         for k, p in model.named_parameters():
-            e = rel(p.grad, ref_flat[k].grad)
+            if p.grad is None:
+                assert ref_flat[k].grad is None or float(ref_flat[k].grad.abs().max()) == 0.0, k
+                continue
+            g_ref = ref_flat[k].grad
+            # a gradient that is analytically zero (a bias in front of a batch-statistics BatchNorm) has no scale of its own:
+            # measure it against the typical gradient magnitude of the model instead of against rounding noise
+            e = float((p.grad.double().cpu() - g_ref.double()).norm() / max(float(g_ref.double().norm()), 1e-6 * g_ref.numel() ** 0.5))
             rels[k] = e
             if e > worst:
                 worst, wkey = e, k
@@ -78,14 +102,117 @@ def test_c2_batch32_matches_oracle(c2_oracle, mode):
         r['grad_conv1_weight'] = rels.get('frontend.conv1.conv_layer.weight')
         out = os.path.join(ROOT, 'gpurun_out')
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, 'parity_headline_%s.json' % mode), 'w') as f:
+        with open(os.path.join(out, 'parity_%s_%s.json' % (tag, mode)), 'w') as f:
             json.dump(r, f, indent=1)
         print(json.dumps(r))
-        tl, ta, tg = HEADLINE_TOL[mode]
+        tl, ta, tg = tol
         assert r['loss_rel'] < tl and r['logits_rel'] < ta and r['memory_rel'] < ta, r
+        assert r.get('ctc_loss_rel', 0.0) < tl, r
         assert worst < tg, r
     finally:
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'fp16', 'bf16'])
+def test_c2_batch32_matches_oracle(c2_oracle, mode):
+    cfg, inputs, targets, ref_loss, ref_aux, ref_flat = c2_oracle
+    _compare_with_oracle(cfg, inputs, targets, ref_loss, ref_aux, ref_flat, mode, 'headline', 'C2 B=32 x 1000 frames (bench batch)',
+                         HEADLINE_TOL[mode])
+
+
+def _ragged(batch, lo, hi, seed):
+    """utterance lengths in frames: the longest fills the batch, the rest are drawn from [lo, hi]"""
+    rng = np.random.default_rng(seed)
+    n = [int(v) for v in rng.integers(lo, hi + 1, batch)]
+    n[int(rng.integers(0, batch))] = hi
+    return n
+
+
+@pytest.fixture(scope='module')
+def c2_ctc_oracle():
+    """configs[1] with the joint CTC term of model/speech2text.py:59-64 (ctc_weight 0.3) on a RAGGED bench-size batch: CTC log-probs
+    [249, 32, 4234], up to 16 labels per utterance"""
+    cfg = syn.c2_model(0.0, ctc_weight=0.3)
+    rng = np.random.default_rng(11)
+    inputs, targets = syn.synthetic_batch(32, 1000, 80, 4234, 15, seed=5, lengths=_ragged(32, 520, 1000, 6),
+                                          tgt_lengths=[int(v) for v in rng.integers(4, 16, 32)])
+    return (cfg, inputs, targets) + _oracle_run(cfg, inputs, targets)
+
+
+# measured r03 on MI355X (profiles/r03_parity_c2ctc_*.json): see the table in DESIGN.md section 2; tolerances <= 2x measured
+C2CTC_TOL = {'fp32': (1e-5, 5e-6, 1e-4), 'fp16': (1e-4, 1e-3, 8e-3), 'bf16': (1e-3, 8e-3, 5e-2)}
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'fp16', 'bf16'])
+def test_c2_ctc_batch32_matches_oracle(c2_ctc_oracle, mode):
+    cfg, inputs, targets, ref_loss, ref_aux, ref_flat = c2_ctc_oracle
+    _compare_with_oracle(cfg, inputs, targets, ref_loss, ref_aux, ref_flat, mode, 'c2ctc',
+                         'C2 + CTC 0.3, B=32 x 1000 frames, ragged', C2CTC_TOL[mode])
+
+
+@pytest.fixture(scope='module')
+def c4_oracle():
+    """configs[3]: conformer_baseline.yaml (d = 384, 12 blocks, BatchNorm on batch statistics) at the bench batch, ragged"""
+    cfg = syn.conformer_model(False, 0.0)
+    rng = np.random.default_rng(12)
+    inputs, targets = syn.synthetic_batch(32, 1000, 80, 4234, 15, seed=7, lengths=_ragged(32, 520, 1000, 8),
+                                          tgt_lengths=[int(v) for v in rng.integers(4, 16, 32)])
+    return (cfg, inputs, targets) + _oracle_run(cfg, inputs, targets, seed=31)
+
+
+# measured r03 on MI355X (profiles/r03_parity_c4_*.json); tolerances <= 2x measured
+C4_TOL = {'fp32': (1e-5, 1e-5, 5e-4), 'fp16': (2e-4, 2e-3, 2e-2), 'bf16': (2e-3, 1.6e-2, 1e-1)}
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'fp16', 'bf16'])
+def test_c4_batch32_matches_oracle(c4_oracle, mode):
+    cfg, inputs, targets, ref_loss, ref_aux, ref_flat = c4_oracle
+    _compare_with_oracle(cfg, inputs, targets, ref_loss, ref_aux, ref_flat, mode, 'c4', 'C4 conformer_baseline B=32 x 1000 frames, ragged',
+                         C4_TOL[mode], seed=31)
+
+
+def _beam_search_validity(orc, parts, cfg, inputs, lm, lm_weight, beam, trace, tol):
+    """Replay the product's per-step beams (trace: [(prefixes [B*beam, t+1], scores [B*beam])] after step t = 1, 2, ...) on the
+    ORACLE's log-probabilities (recognize/speech2text.py:95-146 restated: decoder.inference + lm_weight * lm.predict on the
+    product's own prefixes).  Returns
+      worst_kept_below_cut  max over steps / utterances of (oracle's beam-th best candidate score - oracle score of a candidate
+                            the product kept): <= 0 when the product kept a true top-beam set, positive by the margin it
+                            mis-ranked otherwise
+      worst_score_drift     max |product cumulative score - oracle cumulative score of the same prefix|
+      min_cut_margin[b]     min over steps of (oracle beam-th best - (beam+1)-th best candidate score): how close the ORACLE's
+                            own search came to a tie at its cut"""
+    with torch.no_grad():
+        x, mask = orc.conv_frontend(parts['frontend'], inputs['inputs'], inputs['mask'])
+        memory, mmask = orc.transformer_encoder(parts['encoder'], x, mask, cfg['encoder'])
+        B, T, D = memory.shape
+        R = B * beam
+        bm = memory.unsqueeze(1).repeat(1, beam, 1, 1).view(R, T, D)
+        bmask = mmask.unsqueeze(1).repeat(1, beam, 1).view(R, T)
+        prev = torch.full((R, 1), 1, dtype=torch.long)                        # BOS
+        cum = torch.tensor([0.0] + [-float('inf')] * (beam - 1), dtype=torch.float64).repeat(B)
+        worst_cut, worst_drift, min_margin = -float('inf'), 0.0, [float('inf')] * B
+        for pref, sc in trace:
+            pref, sc = pref.cpu(), sc.double().cpu()
+            lp = orc.decoder_inference(parts['decoder'], prev, bm, bmask, cfg['decoder'])
+            if lm is not None:
+                lp = lp + lm_weight * orc.transformer_lm_predict(lm[0], lm[1], prev)
+            cand = (cum.view(R, 1) + lp.double()).view(B, -1)                  # every (beam, token) expansion of the product's beams
+            V = lp.size(1)
+            top = torch.topk(cand, beam + 1, dim=-1).values
+            new_cum = torch.empty(R, dtype=torch.float64)
+            for r in range(R):
+                b = r // beam
+                # the parent of the kept prefix: the beam of this utterance whose prefix it extends (first match; duplicates
+                # carry identical scores)
+                par = [q for q in range(b * beam, (b + 1) * beam) if torch.equal(prev[q], pref[r, :-1]) and cum[q] > -float('inf')]
+                assert par, ('kept prefix does not extend a beam of the previous step', r)
+                new_cum[r] = max(float(cum[q] + lp[q, int(pref[r, -1])].double()) for q in par)
+                worst_cut = max(worst_cut, float(top[b, beam - 1] - new_cum[r]))
+                worst_drift = max(worst_drift, abs(float(sc[r]) - float(new_cum[r])))
+            for b in range(B):
+                min_margin[b] = min(min_margin[b], float(top[b, beam - 1] - top[b, beam]))
+            prev, cum = pref, new_cum
+    return {'worst_kept_below_cut': worst_cut, 'worst_score_drift': worst_drift, 'min_cut_margin': min_margin, 'steps': len(trace)}
 
 
 @pytest.mark.parametrize('mode', ['fp32', 'fp16', 'bf16'])
@@ -114,6 +241,7 @@ def test_c5_full_size_decode_matches_oracle_beam_search(mode):
                                        lamda=5, nbest=beam, lm=(lm_sd, lm_cfg), lm_weight=0.1)
         rec = SpeechToTextRecognizer(model, apply_cache=True, beam_width=beam, nbest=beam, max_len=max_len, penalty=0.6, lamda=5,
                                      lm=lm, lm_weight=0.1, idx2unit={i: str(i) for i in range(4234)})
+        rec.trace = rec_trace = []
         got_h, got_s = rec.recognize(inputs['inputs'].to(DEV), inputs['mask'].to(DEV))
         got_tok = [[[int(t) for t in s.split()] for s in utt] for utt in got_h]
         ref_s, got_s = ref_s.numpy(), got_s.numpy()
@@ -121,20 +249,34 @@ def test_c5_full_size_decode_matches_oracle_beam_search(mode):
             assert got_tok == ref_h
             np.testing.assert_allclose(got_s, ref_s, rtol=1e-4, atol=1e-4)
             return
-        # 16-bit operands: rounding can flip a near-tie INSIDE the search (a hypothesis pruned at some step in one run
-        # survives in the other), which inserts / drops whole hypotheses further down the n-best list.  So: the 1-best
-        # must be token-identical unless the oracle's own 1-best / 2-best margin is within the score drift; every
-        # hypothesis both lists contain must carry the same score to the drift; most of the n-best must be shared.
+        # 16-bit operands: rounding can flip a near-tie INSIDE the search (a candidate pruned at some step in one run survives
+        # in the other), which inserts / drops whole hypotheses further down the n-best list.  "Identical hypotheses" is
+        # therefore asserted in the only form rounding leaves meaningful: the product's search, replayed step by step on
+        # the ORACLE's scores, never keeps a candidate the oracle scores more than 2 x drift below its own cut, never
+        # reports a cumulative score further than the drift from the oracle's, and ends in the oracle's ranking wherever
+        # the oracle's final scores are further apart than 2 x drift.  drift = measured worst |score - oracle score| x 2
+        # (profiles/r03_decode_validity_*.json: fp16 0.008, bf16 0.035 nat over 10 steps)
         tol = 0.02 if mode == 'fp16' else 0.08
+        rep = _beam_search_validity(orc, parts, cfg, inputs, (lm_sd, lm_cfg), 0.1, beam, rec_trace, tol)
+        rep.update(mode=mode, tol=tol, nbest_identical=[got_tok[b] == ref_h[b] for b in range(len(ref_h))],
+                   nbest_shared=[len(set(map(tuple, got_tok[b])) & set(map(tuple, ref_h[b]))) for b in range(len(ref_h))])
+        with open(os.path.join(ROOT, 'gpurun_out', 'decode_validity_%s.json' % mode), 'w') as f:
+            json.dump(rep, f, indent=1)
+        print(json.dumps(rep))
+        assert rep['worst_kept_below_cut'] < 2 * tol, rep
+        assert rep['worst_score_drift'] < tol, rep
         for b in range(len(ref_h)):
-            assert got_tok[b][0] == ref_h[b][0] or ref_s[b, 0] - ref_s[b, 1] < 2 * tol, (mode, b)
+            # final ranking (length penalty is a constant here: EOS never wins): same order as the oracle's own scores of the
+            # product's hypotheses wherever those are separated by more than 2 x drift
             assert abs(got_s[b, 0] - ref_s[b, 0]) < tol, (mode, b, got_s[b, 0], ref_s[b, 0])
-            ref_map = {tuple(h): ref_s[b, n] for n, h in enumerate(ref_h[b])}
-            shared = 0
-            for n, h in enumerate(got_tok[b]):
+            assert got_tok[b][0] == ref_h[b][0] or ref_s[b, 0] - ref_s[b, 1] < 2 * tol, (mode, b)
+            ref_map = {tuple(h): float(ref_s[b, n]) for n, h in enumerate(ref_h[b])}
+            if rep['min_cut_margin'][b] > 2 * tol:         # no near-tie at any cut of this utterance's search: the same n-best set
+                assert set(map(tuple, got_tok[b])) == set(ref_map), (mode, b)
+            for n, h in enumerate(got_tok[b]):             # shared hypotheses: same score, and in the oracle's order up to the drift
                 if tuple(h) in ref_map:
-                    shared += 1
-                    assert abs(got_s[b, n] - ref_map[tuple(h)]) < tol, (mode, b, n, got_s[b, n], ref_map[tuple(h)])
-            assert shared >= (8 if mode == 'fp16' else 6), (mode, b, shared)
+                    assert abs(got_s[b, n] - ref_map[tuple(h)]) < tol, (mode, b, n)
+                    later = [ref_map[tuple(g)] for g in got_tok[b][n + 1:] if tuple(g) in ref_map]
+                    assert all(ref_map[tuple(h)] > v - 2 * tol for v in later), (mode, b, n)
     finally:
         ops.set_compute_dtype('bf16')

@@ -146,3 +146,48 @@ def test_encoder_layer_rowblock_equals_generic_path(mode, monkeypatch):
             assert err < 4 * TOL[mode], err
     finally:
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
+def test_packs_follow_the_optimizer_for_every_row_block_linear(mode):
+    """a (256,256) Linear that FlatDataParallel's NAME list did not cover -- vk_proj with
+    share_vk_proj=True (module/attention.py:128-132) -- reached the row-block path in ops.LinearFn through a cache keyed by
+    (_version, data_ptr), which FusedAdam's raw-pointer update never changes: forward and input gradient kept using the
+    INITIAL weights.  Packs are now registered by shape; two optimizer steps on the row-block path must track the same two
+    steps on the generic GEMM path (OTR_NO_ROWBLOCK)."""
+    from opentransformer_amd import ops
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+    from opentransformer_amd.nn import MultiHeadedCrossAttention
+    ops.set_compute_dtype(mode)
+    was = ops._RB
+    try:
+        gen = torch.Generator().manual_seed(12)
+        B, T, Lq, d = 8, 160, 12, 256                       # 1280 memory rows: above the row-block threshold
+        memory = torch.randn(B, T, d, generator=gen).to(DEV)
+        query = torch.randn(B, Lq, d, generator=gen).to(DEV)
+        mask = torch.ones(B, T, dtype=torch.bool, device=DEV)
+        outs = {}
+        for rb in (True, False):
+            ops._RB = rb
+            torch.manual_seed(5)
+            att = MultiHeadedCrossAttention(4, d, d, 0.0, share_vk_proj=True).to(DEV)
+            dp = FlatDataParallel(att)
+            opt = FusedAdam(dp, lr=5e-2, clip_grad=0.0, weight_decay=0.0, loss_scale=0.0)     # big steps: a stale operand shows
+            if rb:
+                assert getattr(att.vk_proj.weight, '_otr_lin_packs', None) is not None, 'vk_proj packs not registered by shape'
+            trace = []
+            for _ in range(3):
+                dp.zero_grad()
+                y, _ = dp(ops.attach_lp(query, query.to(ops.act_dtype())), ops.attach_lp(memory, memory.to(ops.act_dtype())), mask)
+                trace.append(y.detach().float().clone())
+                (y.float() ** 2).mean().backward()
+                opt.step(1.0)
+            outs[rb] = trace
+        assert _rel(outs[True][0], outs[False][0]) < TOL[mode]
+        moved = _rel(outs[False][2], outs[False][0])
+        assert moved > 20 * TOL[mode], ('the optimizer did not move the output enough for this test to see a stale pack', moved)
+        for i in (1, 2):                                      # after the updates the two paths still agree
+            assert _rel(outs[True][i], outs[False][i]) < 4 * TOL[mode], (i, _rel(outs[True][i], outs[False][i]), moved)
+    finally:
+        ops._RB = was
+        ops.set_compute_dtype('bf16')

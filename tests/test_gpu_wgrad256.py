@@ -162,3 +162,47 @@ def test_wgrad256_bias_gradient_rides_along(mode, grid):
         assert float((lone_b - lone.float().sum(0)).abs().max()) < 1e-3
     finally:
         ops.set_compute_dtype('bf16')
+
+
+def test_turnstile_give_up_reaches_the_optimizer():
+    """a turnstile wait that gives up leaves a finite but WRONG sum, which passes the NaN guard.  With the
+    spin bound forced to 1 (otr_debug_set(11, 1)) pieces of split tiles give up; the sticky fault word
+    (otr_set_fault_counter) must then make FusedAdam skip the update and count the event, and a healthy step afterwards must
+    go through."""
+    from opentransformer_amd import ops
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+    L, lib = _lib()
+    ops.set_compute_dtype('bf16')
+    adt = ops.act_dtype()
+    lin = torch.nn.Linear(256, 256).to(DEV)
+    dp = FlatDataParallel(lin)
+    opt = FusedAdam(dp, lr=1e-3, clip_grad=5.0)
+    fault = ops.fault_counter(torch.device(DEV))
+    gen = torch.Generator().manual_seed(8)
+    items = []
+    for (m, n, k) in SHAPES_SMALL:                      # grid 7 cuts the few tiles into row ranges that meet at turnstiles
+        dy = torch.randn(m, n, generator=gen).to(DEV, adt)
+        x = torch.randn(m, k, generator=gen).to(DEV, adt)
+        items.append((dy, x, torch.zeros(n, k, device=DEV)))
+    w0 = dp.flat_param.clone()
+    try:
+        L.check(lib.otr_debug_set(11, 1), 'debug_set')
+        dp.zero_grad()
+        dp.flat_grad.fill_(1e-3)
+        _run(items, 'bf16', 7, all_taken=False)
+        torch.cuda.synchronize()
+        assert int(fault.item()) > 0, 'no piece gave up with a spin bound of 1: the test does not exercise the give-up path'
+        opt.step(1.0)
+        st = opt.stats()
+        assert st['skipped'] == 1 and st['faults'] > 0 and st['step'] == 0, st
+        assert int(fault.item()) == 0                   # read and cleared by the update
+        assert torch.equal(dp.flat_param, w0)           # nothing was applied
+    finally:
+        lib.otr_debug_set(11, 0)
+    for _, _, o in items:
+        o.zero_()
+    _run(items, 'bf16', 7)
+    assert int(fault.item()) == 0
+    opt.step(1.0)
+    st = opt.stats()
+    assert st['skipped'] == 1 and st['step'] == 1 and not torch.equal(dp.flat_param, w0), st
