@@ -180,7 +180,7 @@ def test_turnstile_give_up_reaches_the_optimizer():
     fault = ops.fault_counter(torch.device(DEV))
     gen = torch.Generator().manual_seed(8)
     items = []
-    for (m, n, k) in SHAPES_SMALL:                      # grid 7 cuts the few tiles into row ranges that meet at turnstiles
+    for (m, n, k) in SHAPES_HEAD:                       # 28 tiles of equal row count on 96 workgroups: 3 concurrent row ranges per tile
         dy = torch.randn(m, n, generator=gen).to(DEV, adt)
         x = torch.randn(m, k, generator=gen).to(DEV, adt)
         items.append((dy, x, torch.zeros(n, k, device=DEV)))
@@ -189,7 +189,7 @@ def test_turnstile_give_up_reaches_the_optimizer():
         L.check(lib.otr_debug_set(11, 1), 'debug_set')
         dp.zero_grad()
         dp.flat_grad.fill_(1e-3)
-        _run(items, 'bf16', 7, all_taken=False)
+        _run(items, 'bf16', 96, all_taken=False)
         torch.cuda.synchronize()
         assert int(fault.item()) > 0, 'no piece gave up with a spin bound of 1: the test does not exercise the give-up path'
         opt.step(1.0)
@@ -201,7 +201,7 @@ def test_turnstile_give_up_reaches_the_optimizer():
         lib.otr_debug_set(11, 0)
     for _, _, o in items:
         o.zero_()
-    _run(items, 'bf16', 7)
+    _run(items, 'bf16', 96)
     assert int(fault.item()) == 0
     opt.step(1.0)
     st = opt.stats()
