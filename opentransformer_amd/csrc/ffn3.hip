@@ -1,0 +1,549 @@
+// Fused FFN sub-layer, third form: 128-row workgroups, weights through an LDS-DMA ring, 64 rows per wave
+// (encoder/transformer.py:58-63, decoder/transformer.py:82-86, module/ffn.py:38-41 with activation 'glu').
+//
+//   forward :  partial y_s = w_2[:, slice s] glu(w_1[slice s] x + b_1[slice s])        (S hidden slices -> S fp32 slabs; the
+//              bias b_2 / dropout / residual / LayerNorm epilogue sums the slabs: otr_add_layernorm_fwd_slabs)
+//   backward:  dh, u for the weight gradients, partial dx_s = dh[slice s] . w_1[slice s]  (summed by otr_slab_sum)
+//
+// Why a third form: the 32-row kernels (ffn_fused.hip) stream ALL packed weights into every CU and sit on the
+// CU's ~22 B/clk vector-memory ingest (60 us forward for 3 MB per CU).  A workgroup here owns 128 rows x 1/S of the hidden
+// units, so a CU ingests 1/S of the weights (0.75 MB at S = 4), once, by direct-to-LDS DMA, and the four waves share every
+// fragment.  What the second form (32 rows per wave) ran into was the LDS READ rate: every 32-cycle MFMA consumed a fresh
+// 1 KiB fragment.  Here the waves form a 2 x 2 grid -- wave (wr, wc) owns rows 64 wr .. +63 (two 32-row B-operand tiles, kept in
+// REGISTERS for the whole kernel: 128 VGPRs) -- so every weight fragment read from LDS feeds TWO MFMAs:
+//   GEMM1  h^T[32 hidden of sub-chunk wc, 64 rows] = w_1 frags (LDS) x x^T frags (registers)          64 MFMAs / 32 KiB read
+//   GLU    on the accumulators; u (16-bit) stays in registers as B operands (the accumulator layout IS an operand layout once
+//          the contraction index is permuted, and the permutation is applied to w_2 when it is packed, perm = 1) and is also
+//          handed to the partner wave (same rows, other sub-chunk) through 4 KiB of LDS
+//   GEMM2  y^T[128 output columns of half wc, 64 rows] += w_2 frags (LDS) x u^T frags (own: registers, partner's: LDS)
+//                                                                                                    32 MFMAs / 20 KiB read
+// i.e. 0.54 KiB of LDS reads per MFMA instead of 1, on the 512-register budget of one wave per SIMD (y accumulators 128 +
+// x 128 + h 64 + u 48 + fragment staging 32).
+//
+// The hidden slice is walked in chunks of 64 units = 3 phases of 32 fragments (32 KiB) each -- A: w_1, contraction steps 0-7;
+// B: steps 8-15; G: w_2 of the PREVIOUS chunk (its GEMM2 runs beside the GLU of this chunk, so the matrix pipe has work
+// during the VALU phase) -- through a ring of four 32 KiB slots: phase p's barrier releases its slot for phase p+4, whose 8
+// DMAs per wave are issued two at a time between the MFMA groups of phase p+1 (scalar instructions only: wave-uniform source,
+// SGPR base + lane offset) and waited for with a counted vmcnt(16) at the end of phase p+3's predecessor, so a phase's data
+// has two whole phases (> 2000 cycles) to land.  One barrier per phase (32 MFMAs per wave).
+#include "ffn_frag.h"
+
+namespace {
+
+constexpr int F3_PHASE = 32 * 1024;      // one phase = 32 fragments
+constexpr int F3_SLOTS = 4;
+constexpr int F3_RING = F3_SLOTS * F3_PHASE;
+constexpr int F3_UBUF = 16 * 1024;       // u hand-over: [wr][wc][row tile][k-step] fragments of 1 KiB
+constexpr int F3_BIAS = 8 * 1024;        // b_1 of the slice: [v1 chunk][value 32 | gate 32] floats (<= 32 chunks)
+
+template <int N> __device__ __forceinline__ void f3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void f3_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void f3_barrier() {
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" ::: "memory");
+}
+
+// GEMM1's MFMA with the register classes spelled out: accumulator in VGPRs (the GLU's VALU code reads it without
+// v_accvgpr_read), weight fragment in VGPRs (fresh from ds_read), activation fragment in the ACCUMULATOR half of the register
+// file ("a": it is an MFMA operand only).  With the builtin hipcc keeps both operands in VGPRs; the 128 registers of x then
+// overflow the 256 architectural VGPRs and are shuttled through AGPRs (160 v_accvgpr moves per 32 MFMAs in the first build).
+// Hazards (hipcc pads nothing inside asm, cdna_hip_programming.md 5.7): the accumulate chain D -> C of the next MFMA needs no
+// wait states; the VALU readers of the result sit behind a barrier and an explicit s_nop (F3_MFMA_DRAIN).
+#ifdef OTR_HALF_FP16
+#define F3_MFMA_OP "v_mfma_f32_32x32x16_f16"
+#else
+#define F3_MFMA_OP "v_mfma_f32_32x32x16_bf16"
+#endif
+__device__ __forceinline__ void f3_mma_xa(f32x16& acc, const otr_u32x4& w, const otr_u32x4& x_acc) {
+  asm volatile(F3_MFMA_OP " %0, %1, %2, %0" : "+v"(acc) : "v"(w), "a"(x_acc));
+}
+#define F3_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")   /* >= 12 wait states: MFMA result -> VALU reader */
+
+struct Ffn3FwdArgs {
+  const uint16_t* x16;     // [M, D]
+  const uint4* p1; const float* b1; const uint4* p2;
+  float* slabs;            // slab form: [S][M][D] f32 partial outputs (bias b_2 NOT included); fused form: exchange scratch
+                           // [row block][sender slice][quarter][32 KiB of accumulator tiles]
+  int M, F, S;
+  // ---- fused form only (in-kernel reduction of the S = 4 partial sums + bias + dropout + residual + LayerNorm)
+  const float* x; const float* b2; const float* gamma; const float* beta; const uint64_t* seed;
+  float* y; uint16_t* y16; float* z; float* mean; float* rstd;
+  int* sync;               // [2 * row blocks] zero on entry, zero again on exit: arrivals / readers done per row block
+  int* fault;              // NULL or the sticky fault word (otr_set_fault_counter)
+  int spin_limit;
+  float eps, p_drop;
+  uint64_t rng_offset;
+};
+
+// workgroup -> (row block, hidden slice).  Consecutive workgroup ids go to consecutive XCDs (observed, not promised: used for
+// locality only): the S slices of a row block share an XCD (their x rows are fetched into that L2 once), and an XCD's 32 / S
+// row blocks walk the same slice order.
+__device__ __forceinline__ void f3_block_map(int b, int S, int& rb, int& s) {
+  const int xcd = b & 7, j = b >> 3;
+  s = j % S;
+  rb = (j / S) * 8 + xcd;
+}
+
+template <int D, int ABL, bool FUSE>
+__global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
+  static_assert(D == 256, "two 128-column halves, 16 contraction steps");
+  constexpr int NKS = D / 16;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[F3_RING + F3_UBUF + F3_BIAS];
+  unsigned char* ring = smem;
+  unsigned char* ubuf = smem + F3_RING;
+  float* bias_s = reinterpret_cast<float*>(smem + F3_RING + F3_UBUF);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  const int m = lane & 31, hi = lane >> 5;
+  int rb, sl;
+  f3_block_map((int)blockIdx.x, p.S, rb, sl);
+  if (rb * 128 >= p.M) return;                                   // whole workgroup: the grid is padded to 8 x S x ceil(blocks / 8)
+  const int row0 = rb * 128 + wr * 64;
+  const int nchunk = p.F / 32, per = nchunk / p.S, NC = per >> 1; // v1 chunks (32 units) of the layer / of this slice; 64-unit chunks
+  const int c_base = sl * per;
+
+  // ---- DMA schedule.  Phase p = 3C + k (k = 0: A(C), 1: B(C), 2: G(C) = w_2 of chunk C-1), the closing phase 3 NC = w_2 of the
+  // last chunk; anything later is a placeholder (valid addresses, never read) that keeps the counted waits uniform.  A wave
+  // owns fragments wid*8 .. wid*8 + 7 of every phase; fragment j of them sits at source offset
+  // (pa (j >> 2) + pb ((j >> 1) & 1) + pc (j & 1)) KiB from `psrc`: w_1 phases (f = (ksl*2 + wcc)*2 + vg): pa = 1 (next
+  // contraction step), pb = NKS (the other sub-chunk), pc = nchunk NKS (gate rows); w_2 phases (f = ct*4 + k): pa = 2 nchunk
+  // (next column tile), pb = 2, pc = 1 (contraction steps).
+  const unsigned char* psrc = nullptr;
+  uint32_t pa = 0, pb = 0, pc = 0, pdst = 0;
+  int pC = 0, pk = 0;                                            // the next phase to schedule
+  const uint32_t ring0 = (uint32_t)(uintptr_t)(ffn_lds_byte*)ring;
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  auto schedule = [&](int slot) {
+    const bool w2 = pk == 2 || pC >= NC;
+    if (!w2) {
+      const int c0 = c_base + 2 * pC;
+      psrc = reinterpret_cast<const unsigned char*>(p.p1) + ((int64_t)(c0 * NKS + pk * 8 + wid * 2) << 10);
+      pa = 1; pb = NKS; pc = (uint32_t)(nchunk * NKS);
+    } else {
+      const int cp = pC >= NC ? NC - 1 : (pC > 0 ? pC - 1 : 0);
+      psrc = reinterpret_cast<const unsigned char*>(p.p2) + ((int64_t)(wid * 2 * (2 * nchunk) + 2 * (c_base + 2 * cp)) << 10);
+      pa = (uint32_t)(2 * nchunk); pb = 2; pc = 1;
+    }
+    pdst = ring0 + (uint32_t)(slot * F3_PHASE + wid * 8192);
+    if (++pk == 3) { pk = 0; ++pC; }
+  };
+  auto issue2 = [&](int i) {                                     // fragments 2i, 2i + 1 of the scheduled phase
+    const uint32_t o = pa * (uint32_t)(i >> 1) + pb * (uint32_t)(i & 1);
+    ffn_dma(psrc + ((uint64_t)o << 10), lane_off, pdst + (uint32_t)(2 * i) * 1024u);
+    ffn_dma(psrc + ((uint64_t)(o + pc) << 10), lane_off, pdst + (uint32_t)(2 * i + 1) * 1024u);
+  };
+
+  schedule(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue2(i);
+  // this wave's 64 activation rows as MFMA B operands, in registers for the whole kernel
+  otr_u32x4 xf[2][NKS];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int64_t row = min(row0 + 32 * rt + m, p.M - 1);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) xf[rt][ks] = *(const OTR_GLOBAL otr_u32x4*)(p.x16 + row * D + ks * 16 + hi * 8);
+  }
+  for (int i = tid; i < per * 64; i += 256) {
+    const int c = i >> 6, j = i & 63;
+    bias_s[i] = p.b1[(j < 32 ? 0 : p.F) + (c_base + c) * 32 + (j & 31)];
+  }
+  // The operand fragments must be KNOWN complete before the loop (ffn_fused.hip, lesson 2): otherwise the waitcnt pass guards
+  // every later use with vmcnt(n) and waits for the DMAs in flight.  This wait also covers phase 0's DMAs.
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)     // "+a": the activation fragments are MFMA operands only -> the accumulator half of the register file
+      asm volatile("" : "+a"(xf[rt][ks]));
+  f3_wait_vm<0>();
+  schedule(1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue2(i);
+  schedule(2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue2(i);
+  schedule(3);                                                   // issued between the MFMA groups of phase 0
+  f3_wait_lds();
+  f3_barrier();
+
+  f32x16 yacc[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yacc[rt][ct][r] = 0.f;
+  f32x16 hv[2], hg[2];
+  uint4 uown[2][2], upart[2][2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) uown[rt][j] = upart[rt][j] = make_uint4(0u, 0u, 0u, 0u);
+
+  constexpr bool no_dma = (ABL & 1) != 0, no_mma = (ABL & 2) != 0;   // ablations are compile-time: a run-time flag would split
+  // the G phase into basic blocks, and hipcc interleaves the GLU's VALU code with the MFMAs only inside one block
+  uint4* my_u = reinterpret_cast<uint4*>(ubuf) + ((wr * 2 + wc) * 4) * 64 + lane;
+  const uint4* partner_u = reinterpret_cast<const uint4*>(ubuf) + ((wr * 2 + (wc ^ 1)) * 4) * 64 + lane;
+  const int k_own = 2 * wc, k_par = 2 * (wc ^ 1);
+
+#define F3_ISSUE2(I) if constexpr (!no_dma) issue2(I);
+  // accumulators of GEMM1 start from the biases (register r of lane (m, hi) is hidden unit 8 (r >> 2) + 4 hi + (r & 3) of the
+  // sub-chunk, for both row tiles), so the GLU adds nothing
+#define F3_BIAS_INIT(CL)                                                                                       \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
+    const float4 bv = *reinterpret_cast<const float4*>(bias_s + (CL) * 64 + 8 * q + 4 * hi);                   \
+    const float4 bg = *reinterpret_cast<const float4*>(bias_s + (CL) * 64 + 32 + 8 * q + 4 * hi);              \
+    _Pragma("unroll") for (int rt = 0; rt < 2; ++rt) {                                                         \
+      hv[rt][4 * q] = bv.x; hv[rt][4 * q + 1] = bv.y; hv[rt][4 * q + 2] = bv.z; hv[rt][4 * q + 3] = bv.w;       \
+      hg[rt][4 * q] = bg.x; hg[rt][4 * q + 1] = bg.y; hg[rt][4 * q + 2] = bg.z; hg[rt][4 * q + 3] = bg.w;       \
+    }                                                                                                          \
+  }                                                                                                            \
+  asm volatile("s_nop 3" ::: "memory");     /* VALU / LDS write of an accumulator -> asm MFMA reading it as C */
+  // GEMM1 over 8 contraction steps (HALF = 0: steps 0-7, 1: steps 8-15) of the phase in ring slot SLOT; the two DMAs of the
+  // scheduled phase ride behind every group of 8 MFMAs
+#define F3_GEMM1(HALF, SLOT)                                                                                   \
+  if constexpr (!no_mma) {                                                                                     \
+    const otr_u32x4* wb = reinterpret_cast<const otr_u32x4*>(ring + (SLOT) * F3_PHASE) + (wc * 2) * 64 + lane; \
+    otr_u32x4 fr[2][4];                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) fr[0][j] = wb[(((j >> 1)) * 4 + (j & 1)) * 64];               \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                            \
+      if (g + 1 < 4) {                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
+          fr[(g + 1) & 1][j] = wb[((2 * (g + 1) + (j >> 1)) * 4 + (j & 1)) * 64];                              \
+      }                                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
+        const int ks = (HALF) * 8 + 2 * g + (j >> 1);                                                          \
+        if (j & 1) { f3_mma_xa(hg[0], fr[g & 1][j], xf[0][ks]); f3_mma_xa(hg[1], fr[g & 1][j], xf[1][ks]); }   \
+        else       { f3_mma_xa(hv[0], fr[g & 1][j], xf[0][ks]); f3_mma_xa(hv[1], fr[g & 1][j], xf[1][ks]); }   \
+      }                                                                                                        \
+      F3_ISSUE2(g)                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+  } else {                                                                                                     \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) { F3_ISSUE2(g) }                                             \
+  }
+  // end of a phase: this wave's DMAs of the NEXT phase have landed (the 16 of the two phases after it may still fly), its LDS
+  // traffic is done; after the barrier the slot just consumed is free for the phase four ahead, which is scheduled here and
+  // issued during the next phase
+#define F3_PHASE_END()                                                                                         \
+  if constexpr (no_dma) f3_wait_vm<0>(); else f3_wait_vm<16>();                                                \
+  f3_wait_lds();                                                                                               \
+  f3_barrier();                                                                                                \
+  schedule(slot);                                                                                              \
+  slot = (slot + 1) & 3;
+  // Phase G of chunk C.  G2: GEMM2 of chunk C-1 -- w_2 fragment (ct, k) at ring[(ct*4 + k) KiB]; this wave's column tiles are
+  // 4 wc .. 4 wc + 3; contraction steps k_own, k_own + 1 take u from registers (uown), k_par, k_par + 1 the partner's (upart,
+  // read from the hand-over buffer during phase B).  GLU: the GLU of chunk C in quarters; quarter kk REPLACES
+  // uown[kk >> 1][kk & 1], which step (kk & 1) <= kk of GEMM2 has already consumed.  One basic block; per step 8 MFMAs with the
+  // quarter's ~45 VALU instructions pinned between them (sched_group_barrier: 1 MFMA, then 6 VALU), so the matrix pipe runs
+  // during the VALU phase.
+#define F3_PHASE_G(G2, GLU, SLOT)                                                                              \
+  if constexpr (!no_mma) {                                                                                     \
+    const uint4* wb = reinterpret_cast<const uint4*>(ring + (SLOT) * F3_PHASE) + (wc * 16) * 64 + lane;        \
+    uint4 fr[2][4];                                                                                            \
+    if constexpr (GLU) F3_MFMA_DRAIN();      /* GEMM1's asm MFMAs -> the GLU's VALU reads (also behind the barrier) */ \
+    if constexpr (G2) {                                                                                        \
+      _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) fr[0][ct] = wb[(ct * 4 + k_own) * 64];                  \
+    }                                                                                                          \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                         \
+      if constexpr (G2) {                                                                                      \
+        if (kk + 1 < 4) {                                                                                      \
+          const int kn = (kk + 1 < 2 ? k_own : k_par) + ((kk + 1) & 1);                                        \
+          _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) fr[(kk + 1) & 1][ct] = wb[(ct * 4 + kn) * 64];      \
+        }                                                                                                      \
+      }                                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      if constexpr (G2) {                                                                                      \
+        const uint4 u0 = kk < 2 ? uown[0][kk & 1] : upart[0][kk & 1], u1 = kk < 2 ? uown[1][kk & 1] : upart[1][kk & 1]; \
+        _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) {                                                     \
+          mma32(yacc[0][ct], fr[kk & 1][ct], u0);                                                              \
+          mma32(yacc[1][ct], fr[kk & 1][ct], u1);                                                              \
+        }                                                                                                      \
+      }                                                                                                        \
+      if constexpr (GLU) {                   /* quarter kk: row tile kk >> 1, registers 8 (kk & 1) .. + 7 */       \
+        const int rt = kk >> 1, j0 = (kk & 1) * 8;                                                             \
+        float u[8];                                                                                            \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) u[e] = hv[rt][j0 + e] * fast_sigmoid(hg[rt][j0 + e]);    \
+        const uint4 nu = make_uint4(pack2h(u[0], u[1]), pack2h(u[2], u[3]), pack2h(u[4], u[5]), pack2h(u[6], u[7])); \
+        uown[rt][kk & 1] = nu;               /* kept for GEMM2 of this chunk one iteration later ... */            \
+        my_u[(rt * 2 + (kk & 1)) * 64] = nu; /* ... and handed to the partner wave */                            \
+      }                                                                                                        \
+      if constexpr (G2 && GLU) {                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                        \
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     /* one MFMA */                                \
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);     /* six VALU */                                \
+        }                                                                                                      \
+      }                                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      if constexpr (GLU) { F3_ISSUE2(kk) }   /* the closing phase (no GLU) schedules nothing */                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+  } else if constexpr (GLU) {                                                                                  \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) { F3_ISSUE2(kk) }                                         \
+  }
+  // the partner's u of the previous chunk: written before the barrier that closed G(C-1), rewritten in G(C) behind the
+  // barrier that closes this phase B(C)
+#define F3_READ_PARTNER()                                                                                      \
+  _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                             \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) upart[rt][j] = partner_u[(rt * 2 + j) * 64];
+
+  int slot = 0;                                                  // ring slot of the current phase (phase index mod 4)
+  // ---- chunk 0: A, B, GLU only
+  F3_BIAS_INIT(wc)
+  F3_GEMM1(0, slot)
+  F3_PHASE_END()
+  F3_GEMM1(1, slot)
+  F3_PHASE_END()
+  F3_PHASE_G(false, true, slot)
+  F3_PHASE_END()
+  // ---- chunks 1 .. NC-1: A, B, GLU beside the previous chunk's GEMM2
+  for (int C = 1; C < NC; ++C) {
+    F3_BIAS_INIT(2 * C + wc)
+    F3_GEMM1(0, slot)
+    F3_PHASE_END()
+    F3_READ_PARTNER()
+    F3_GEMM1(1, slot)
+    F3_PHASE_END()
+    F3_PHASE_G(true, true, slot)
+    F3_PHASE_END()
+  }
+  // ---- closing phase: GEMM2 of chunk NC-1 (its w_2 took the place of a phase A(NC))
+  F3_READ_PARTNER()
+  F3_PHASE_G(true, false, slot)
+#undef F3_ISSUE2
+#undef F3_BIAS_INIT
+#undef F3_GEMM1
+#undef F3_PHASE_END
+#undef F3_PHASE_G
+#undef F3_READ_PARTNER
+  f3_wait_vm<0>();                                               // the placeholder DMAs have landed: the ring becomes scratch
+  f3_wait_lds();
+  f3_barrier();
+
+  if constexpr (!FUSE) {
+  // ---- partial output rows -> slab `sl`, staged through the idle ring so that memory sees whole 256-byte row segments: each
+  // wave uses a private 8 KiB slice, 32 rows x 64 columns at a time (no workgroup barrier needed)
+  float* st = reinterpret_cast<float*>(ring + wid * 8192);       // [32 rows][64 cols]
+  float* out = p.slabs + ((int64_t)sl * p.M) * D;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(st + m * 64 + t * 32 + 8 * q + 4 * hi) =
+              make_float4(yacc[rt][2 * h + t][4 * q], yacc[rt][2 * h + t][4 * q + 1], yacc[rt][2 * h + t][4 * q + 2],
+                          yacc[rt][2 * h + t][4 * q + 3]);
+      __builtin_amdgcn_wave_barrier();
+      f3_wait_lds();
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {                           // 4 rows x 16 lanes x float4 per pass
+        const int r = rr * 4 + (lane >> 4);
+        const int64_t row = (int64_t)row0 + 32 * rt + r;
+        const float4 v = *reinterpret_cast<const float4*>(st + r * 64 + (lane & 15) * 4);
+        if (row < p.M) *reinterpret_cast<float4*>(out + row * D + 128 * wc + 64 * h + (lane & 15) * 4) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      f3_wait_lds();
+    }
+  }
+  } else {
+  // ---- fused form (S = 4): the four workgroups of a row block exchange their partial sums and each finishes ONE quarter of
+  // the rows (32 rows: quarter `sl`): y = LayerNorm(x + dropout(sum of the four partials + b_2)).  Everything stays in the
+  // accumulator layout -- tile (ct, q): lane (m, hi) holds columns 32 ct + 8 q + 4 hi .. + 3 of row m as one float4 -- so the
+  // exchange is lane-linear 1 KiB pieces (coalesced both ways) and a row's statistics need one cross-lane step (hi) plus the
+  // four waves' column shares meeting in LDS.
+  //   1. own quarter -> LDS, the three foreign quarters -> scratch[row block][sl][quarter] with write-through stores
+  //      (sc0 sc1: at memory when vmcnt drains, whatever XCD the reader sits on)
+  //   2. arrive (one atomic per workgroup), wait for all four (bounded spin; a give-up is reported through the fault word)
+  //   3. wave w sums column tiles 2w, 2w+1 of its quarter: own (LDS) + three partners (sc1 loads: served past the L1)
+  //   4. bias, dropout (the mask otr_add_layernorm_bwd regenerates), residual, LayerNorm; y / y16 / z / mean / rstd
+  constexpr int AUX = 17;                                        // sc0 | sc1
+  float* own = reinterpret_cast<float*>(ring);                   // [8 column tiles][4 q][64 lanes] float4 = 32 KiB
+  float* red = reinterpret_cast<float*>(ring + 32768);           // [2 passes][4 waves][32 rows]
+  auto rs = __builtin_amdgcn_make_buffer_rsrc(p.slabs + (int64_t)rb * (4 * 4 * 8192), 0, 4 * 4 * 32768, 0x00020000);
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int qt = 2 * wr + rt;                                  // the quarter these 32 rows belong to (wave-uniform)
+    if (qt == sl) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(own + (((4 * wc + ct) * 4 + q) * 64 + lane) * 4) =
+              make_float4(yacc[rt][ct][4 * q], yacc[rt][ct][4 * q + 1], yacc[rt][ct][4 * q + 2], yacc[rt][ct][4 * q + 3]);
+    } else {
+      const uint32_t base = (uint32_t)((sl * 4 + qt) * 32768 + (4 * wc) * 4096 + lane * 16);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const otr_u32x4 v = {__float_as_uint(yacc[rt][ct][4 * q]), __float_as_uint(yacc[rt][ct][4 * q + 1]),
+                               __float_as_uint(yacc[rt][ct][4 * q + 2]), __float_as_uint(yacc[rt][ct][4 * q + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, base + (uint32_t)((ct * 4 + q) * 1024), 0, AUX);
+        }
+    }
+  }
+  f3_wait_vm<0>();                                               // this wave's write-through stores are at memory
+  f3_wait_lds();
+  f3_barrier();
+  if (tid == 0) {
+    int* arrive = p.sync + 2 * rb;
+    __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4 && spins < p.spin_limit) {
+      __builtin_amdgcn_s_sleep(4);
+      ++spins;
+    }
+    if (spins >= p.spin_limit && p.fault) __hip_atomic_fetch_add(p.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  f3_barrier();
+  // ---- the quarter's rows: lane (m, hi) of wave `wid` owns row m, columns 32 ct + 8 q + 4 hi .. + 3 for ct = 2 wid, 2 wid + 1
+  const int64_t row = (int64_t)rb * 128 + 32 * sl + m;
+  const bool live = row < p.M;
+  const int64_t crow = live ? row : (int64_t)p.M - 1;
+  otr_u32x4 part[3][2][4];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    const int s2 = n + (n >= sl ? 1 : 0);                        // the three other slices (wave-uniform)
+    const uint32_t base = (uint32_t)((s2 * 4 + sl) * 32768 + (2 * wid) * 4096 + lane * 16);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        part[n][t][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (uint32_t)((t * 4 + q) * 1024), 0, AUX);
+  }
+  float4 xr[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      xr[t][q] = *reinterpret_cast<const float4*>(p.x + crow * D + 32 * (2 * wid + t) + 8 * q + 4 * hi);
+  const bool drop = p.p_drop > 0.f;
+  const uint64_t seed = drop ? *p.seed : 0;
+  const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
+  const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+  float v[2][16];
+  float sm = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = 32 * (2 * wid + t) + 8 * q + 4 * hi;
+      const float4 o = *reinterpret_cast<const float4*>(own + (((2 * wid + t) * 4 + q) * 64 + lane) * 4);
+      const float4 b2 = *reinterpret_cast<const float4*>(p.b2 + col);
+      float a4[4] = {o.x + b2.x, o.y + b2.y, o.z + b2.z, o.w + b2.w};
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        a4[0] += __uint_as_float(part[n][t][q].x); a4[1] += __uint_as_float(part[n][t][q].y);
+        a4[2] += __uint_as_float(part[n][t][q].z); a4[3] += __uint_as_float(part[n][t][q].w);
+      }
+      const float x4[4] = {xr[t][q].x, xr[t][q].y, xr[t][q].z, xr[t][q].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float sc = 1.f;
+        if (drop) sc = otr_rand32(seed, p.rng_offset + (uint64_t)(crow * D + col + e)) >= thr ? inv_keep : 0.f;
+        const float zz = x4[e] + a4[e] * sc;
+        v[t][4 * q + e] = zz;
+        sm += zz;
+      }
+    }
+  sm += __shfl_xor(sm, 32);
+  if (hi == 0) red[wid * 32 + m] = sm;
+  f3_wait_lds();
+  f3_barrier();
+  const float mean = (red[m] + red[32 + m] + red[64 + m] + red[96 + m]) * (1.f / D);
+  float qq = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float d_ = v[t][r] - mean; qq += d_ * d_; }
+  qq += __shfl_xor(qq, 32);
+  if (hi == 0) red[128 + wid * 32 + m] = qq;
+  f3_wait_lds();
+  f3_barrier();
+  const float rstd = rsqrtf((red[128 + m] + red[160 + m] + red[192 + m] + red[224 + m]) * (1.f / D) + p.eps);
+  if (live) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = 32 * (2 * wid + t) + 8 * q + 4 * hi;
+        const float4 gm = *reinterpret_cast<const float4*>(p.gamma + col);
+        const float4 bt = *reinterpret_cast<const float4*>(p.beta + col);
+        const float* vv = &v[t][4 * q];
+        if (p.z) *reinterpret_cast<float4*>(p.z + row * D + col) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        const float o0 = (vv[0] - mean) * rstd * gm.x + bt.x, o1 = (vv[1] - mean) * rstd * gm.y + bt.y;
+        const float o2 = (vv[2] - mean) * rstd * gm.z + bt.z, o3 = (vv[3] - mean) * rstd * gm.w + bt.w;
+        *reinterpret_cast<float4*>(p.y + row * D + col) = make_float4(o0, o1, o2, o3);
+        if (p.y16) *reinterpret_cast<uint2*>(p.y16 + row * D + col) = make_uint2(pack2h(o0, o1), pack2h(o2, o3));
+      }
+    if (wid == 0 && hi == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
+  }
+  // every partial this workgroup needed has been read: the last of the four readers re-arms the row block's counters
+  if (tid == 0) {
+    int* arrive = p.sync + 2 * rb;
+    if (__hip_atomic_fetch_add(arrive + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3) {
+      __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(arrive + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  }
+}
+
+}  // namespace
+
+extern int g_otr_ffn2_ablate;
+
+// hidden slices x row blocks, padded to whole XCD groups (f3_block_map)
+static inline unsigned f3_grid(int64_t M, int S) {
+  const int64_t blocks = (M + 127) / 128;
+  return (unsigned)(8 * S * ((blocks + 7) / 8));
+}
+
+extern int g_otr_spin_limit;
+extern int32_t* g_otr_fault;
+
+#define F3_LAUNCH_FWD(FUSE)                                                                                              \
+  switch (g_otr_ffn2_ablate & 3) {                                                                                       \
+    case 0: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 0, FUSE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
+    case 1: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 1, FUSE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
+    case 2: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 2, FUSE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
+    default: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 3, FUSE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;  \
+  }
+
+int32_t ffn3_fwd_launch(const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, float* slabs, int32_t S, int64_t M,
+                        int32_t F, hipStream_t stream) {
+  Ffn3FwdArgs p{};
+  p.x16 = (const uint16_t*)x16; p.p1 = (const uint4*)w1_pack; p.b1 = b1; p.p2 = (const uint4*)w2_pack; p.slabs = slabs;
+  p.M = (int)M; p.F = F; p.S = S;
+  F3_LAUNCH_FWD(false)
+  return otr_check_launch("ffn3_fwd");
+}
+
+// scratch bytes / sync ints of the fused form for M rows (S = 4)
+int64_t ffn3_scratch_bytes(int64_t M) { return ((M + 127) / 128) * (int64_t)(4 * 4 * 32768); }
+int64_t ffn3_sync_ints(int64_t M) { return 2 * ((M + 127) / 128); }
+
+int32_t ffn3_ln_fwd_launch(const float* x, const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, const float* b2,
+                           const float* gamma, const float* beta, const uint64_t* seed, float p_drop, uint64_t rng_offset, float eps,
+                           float* y, void* y16, float* z, float* mean, float* rstd, float* scratch, int32_t* sync, int64_t M, int32_t F,
+                           hipStream_t stream) {
+  constexpr int S = 4;
+  Ffn3FwdArgs p{};
+  p.x16 = (const uint16_t*)x16; p.p1 = (const uint4*)w1_pack; p.b1 = b1; p.p2 = (const uint4*)w2_pack; p.slabs = scratch;
+  p.M = (int)M; p.F = F; p.S = S;
+  p.x = x; p.b2 = b2; p.gamma = gamma; p.beta = beta; p.seed = seed; p.y = y; p.y16 = (uint16_t*)y16; p.z = z; p.mean = mean; p.rstd = rstd;
+  p.sync = sync; p.fault = g_otr_fault; p.spin_limit = g_otr_spin_limit; p.eps = eps; p.p_drop = p_drop; p.rng_offset = rng_offset;
+  F3_LAUNCH_FWD(true)
+  return otr_check_launch("ffn3_ln_fwd");
+}
+
+// 1 when the 128-row kernels take this (hidden size, split): whole 64-unit chunks per slice, biases fit their LDS staging
+int32_t ffn3_takes(int32_t F, int32_t S) { return S >= 1 && (F / 32) % S == 0 && ((F / 32) / S) % 2 == 0 && (F / 32) / S <= 32; }

@@ -23,9 +23,7 @@
 //    residual / LayerNorm epilogue (forward) or the skip-connection add (backward) runs on whole rows.
 // Bound: the 3 MB (forward) / 5 MB (backward) of packed weights stream from L2 into every CU: 64 B/clk/CU ->
 // ~20 us / ~33 us per layer at B=32, i.e. ~50 % of the MFMA rate; HBM traffic is a few MB.
-#include "common.h"
-
-constexpr int FF_RB = 32;   // rows per workgroup
+#include "ffn_frag.h"
 
 // ------------------------------------------------------------------------------------------------ weight packing
 // Fragment (rt, ks) of a logical matrix A[r][c] (r = free index, c = contraction index), element (r, c) at
@@ -81,71 +79,6 @@ extern "C" int32_t otr_pack_frags(const void* src, void* dst, const int64_t* tab
   hipLaunchKernelGGL(pack_frags_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
                      (const uint16_t*)src, (uint16_t*)dst, table, n_items);
   return otr_check_launch("pack_frags");
-}
-
-// ------------------------------------------------------------------------------------------------ shared pieces
-__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
-
-// 32 rows x D 16-bit activations -> LDS as 16-byte chunks, chunk index XOR (row & 15): the B-operand read of lane
-// (m = lane&31, hi) -- chunk (2*ks + hi) of row m -- is then bank-conflict free for ds_read_b128
-template <int D, int NTHR = 256>
-__device__ __forceinline__ void stage_rows(uint4* dst, const uint16_t* src, int row0, int M, int tid) {
-  constexpr int CPR = D / 8;
-#pragma unroll
-  for (int i = tid; i < FF_RB * CPR; i += NTHR) {
-    const int r = i / CPR, ch = i % CPR;
-    const int gr = min(row0 + r, M - 1);
-    dst[r * CPR + (ch ^ (r & 15))] = ld_global_b128(src + (int64_t)gr * D + ch * 8);
-  }
-}
-template <int D> __device__ __forceinline__ uint4 frag_b(const uint4* rows, int m, int hi, int ks) {
-  return rows[m * (D / 8) + ((2 * ks + hi) ^ (m & 15))];
-}
-
-// accumulator tile (16 floats: hidden units 8q + 4hi + (r&3), q = r>>2, of row m = lane&31) -> two B-operand fragments
-__device__ __forceinline__ void tile_to_frags(const float* v, uint4& f0, uint4& f1) {
-  f0 = make_uint4(pack2h(v[0], v[1]), pack2h(v[2], v[3]), pack2h(v[4], v[5]), pack2h(v[6], v[7]));
-  f1 = make_uint4(pack2h(v[8], v[9]), pack2h(v[10], v[11]), pack2h(v[12], v[13]), pack2h(v[14], v[15]));
-}
-
-// store an accumulator tile as 32 consecutive 16-bit elements of row m (row-major consumer: the weight-gradient GEMM).
-// The row's 64 bytes are split over lanes m and m+32 in 8-byte pieces; one v_permlane32_swap per dword turns them into
-// 16-byte pieces (cdna_hip_programming.md T21): lane (m, hi) then owns elements [8(q0+hi), 8(q0+hi)+8) for q0 = 0, 2.
-__device__ __forceinline__ void store_tile_row(uint16_t* rowp, const uint4& f0, const uint4& f1, int hi, bool live) {
-  uint32_t w[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-#pragma unroll
-  for (int q0 = 0; q0 < 4; q0 += 2) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      auto r = __builtin_amdgcn_permlane32_swap(w[2 * q0 + e], w[2 * q0 + 2 + e], false, false);
-      w[2 * q0 + e] = r[0];
-      w[2 * q0 + 2 + e] = r[1];
-    }
-    if (live) st_global_b128(rowp + 8 * (q0 + hi), make_uint4(w[2 * q0], w[2 * q0 + 1], w[2 * q0 + 2], w[2 * q0 + 3]));
-  }
-}
-
-// column sums of an accumulator tile over its 32 rows: the 16 registers of lane (m, hi) are hidden units 8q + 4hi + (r&3) of
-// row m.  Reduce-scatter butterfly over the 32 lanes of a half-wave (xor 16, 8, 4, 2 halve the register set each step, xor 1
-// finishes): 16 shuffles per tile instead of 80 for sixteen independent butterflies; lane m ends up with the total of
-// register r = (m4 m3 m2 m1) and the even lanes store it.  dst = the 32 floats of this tile in the partial-sum row.
-__device__ __forceinline__ void tile_colsum_store(const float* v, float* dst, int lane, int hi, bool rows_live) {
-  const int m = lane & 31;
-  const bool b4 = m & 16, b3 = m & 8, b2 = m & 4, b1 = m & 2;
-  float a[8], b[4], c[2];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float lo = rows_live ? v[i] : 0.f, hi_ = rows_live ? v[8 + i] : 0.f;
-    a[i] = (b4 ? hi_ : lo) + __shfl_xor(b4 ? lo : hi_, 16);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) b[i] = (b3 ? a[4 + i] : a[i]) + __shfl_xor(b3 ? a[i] : a[4 + i], 8);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) c[i] = (b2 ? b[2 + i] : b[i]) + __shfl_xor(b2 ? b[i] : b[2 + i], 4);
-  float d = (b1 ? c[1] : c[0]) + __shfl_xor(b1 ? c[0] : c[1], 2);
-  d += __shfl_xor(d, 1);
-  const int r = ((m >> 4) & 1) * 8 + ((m >> 3) & 1) * 4 + ((m >> 2) & 1) * 2 + ((m >> 1) & 1);
-  if ((m & 1) == 0) dst[8 * (r >> 2) + 4 * hi + (r & 3)] = d;
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -359,12 +292,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void ffn_ln_fwd_kernel(FfnFwdArgs 
 // measured 10.7 us for 0.75 MB).  The fragment address is wave-uniform (SGPR base + lane * 16), so a DMA costs scalar
 // instructions only; the wave waits for its own DMAs with counted vmcnt (nothing else in the loop is a vector-memory
 // operation: the biases are staged in LDS up front).  The rings live where the partial outputs meet after the loop.
-typedef __attribute__((address_space(3))) unsigned char ffn_lds_byte;
-__device__ __forceinline__ void ffn_dma(const void* uniform_src, uint32_t lane_off, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(lane_off), "s"(uniform_src), "s"(lds_dst) : "memory");
-}
 template <int N> __device__ __forceinline__ void ffn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int D, int PD>
@@ -628,6 +555,15 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(FfnBwdArgs p) {
 
 // ------------------------------------------------------------------------------------------------ C ABI
 extern int g_otr_ffn2_ablate;
+int32_t ffn3_takes(int32_t F, int32_t S);                // ffn3.hip
+int32_t ffn3_fwd_launch(const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, float* slabs, int32_t S, int64_t M,
+                        int32_t F, hipStream_t stream);
+int64_t ffn3_scratch_bytes(int64_t M);
+int64_t ffn3_sync_ints(int64_t M);
+int32_t ffn3_ln_fwd_launch(const float* x, const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, const float* b2,
+                           const float* gamma, const float* beta, const uint64_t* seed, float p_drop, uint64_t rng_offset, float eps,
+                           float* y, void* y16, float* z, float* mean, float* rstd, float* scratch, int32_t* sync, int64_t M, int32_t F,
+                           hipStream_t stream);
 extern int g_otr_ffn_waves;   // tuning hook (otr_debug_set(5, v)): 8 = the 8-wave form of the forward kernel, anything else = 4 waves
 static int32_t ffn_shape_check(const char* who, int64_t M, int32_t F, int32_t d_model) {
   OTR_REQUIRE(M >= 0 && M < (1ll << 31), "%s: bad M", who);
@@ -660,6 +596,27 @@ extern "C" int32_t otr_ffn_ln_fwd(const float* x, const void* x16, const void* w
   return otr_check_launch("ffn_ln_fwd");
 }
 
+extern "C" int64_t otr_ffn_split_scratch_bytes(int64_t M) { return M > 0 ? ffn3_scratch_bytes(M) : 0; }
+extern "C" int64_t otr_ffn_split_sync_ints(int64_t M) { return M > 0 ? ffn3_sync_ints(M) : 0; }
+
+extern "C" int32_t otr_ffn_ln_fwd_split(const float* x, const void* x16, const void* w1_pack, const float* b1, const void* w2_pack,
+                                        const float* b2, const float* gamma, const float* beta, const uint64_t* seed, float p_drop,
+                                        uint64_t rng_offset, float eps, float* y, void* y16, float* z, float* mean, float* rstd,
+                                        void* scratch, int64_t scratch_bytes, int32_t* sync, int64_t sync_ints, int64_t M, int32_t F,
+                                        int32_t d_model, void* stream) {
+  if (int32_t e = ffn_shape_check("ffn_ln_fwd_split", M, F, d_model)) return e;
+  OTR_REQUIRE(ffn3_takes(F, 4), "ffn_ln_fwd_split: d_ff = %d does not split into 4 slices of whole 64-unit chunks", F);
+  OTR_REQUIRE(x && x16 && w1_pack && b1 && w2_pack && b2 && gamma && beta && y && mean && rstd && scratch && sync, "ffn_ln_fwd_split: null pointer");
+  OTR_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed), "ffn_ln_fwd_split: bad dropout arguments");
+  OTR_REQUIRE(((uintptr_t)x16 | (uintptr_t)w1_pack | (uintptr_t)w2_pack | (uintptr_t)x | (uintptr_t)y | (uintptr_t)b1 | (uintptr_t)b2 |
+               (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)scratch | (uintptr_t)z | (uintptr_t)y16) % 16 == 0,
+              "ffn_ln_fwd_split: buffers must be 16-byte aligned");
+  OTR_REQUIRE(scratch_bytes >= ffn3_scratch_bytes(M) && sync_ints >= ffn3_sync_ints(M), "ffn_ln_fwd_split: scratch / sync too small");
+  if (M == 0) return 0;
+  return ffn3_ln_fwd_launch(x, x16, w1_pack, b1, w2_pack, b2, gamma, beta, seed, p_drop, rng_offset, eps, y, y16, z, mean, rstd,
+                            (float*)scratch, sync, M, F, (hipStream_t)stream);
+}
+
 extern "C" int32_t otr_ffn_bwd(const void* x16, const void* dy16, const void* w1_pack, const float* b1, const void* w2t_pack,
                                const void* w1t_pack, void* dh, void* u, float* db1_part, const float* skip, float* dx, int64_t M,
                                int32_t F, int32_t d_model, void* stream) {
@@ -687,23 +644,6 @@ extern "C" int32_t otr_ffn_bwd(const void* x16, const void* dy16, const void* w1
 // need), and read from LDS by all four waves (ds_read_b128, conflict-free).  Chunk c+1 streams in while chunk c is
 // multiplied: one barrier per chunk of 48 (forward) / 80 (backward) MFMAs per wave.  The hidden-dimension split leaves S
 // partial fp32 output slabs; the LayerNorm kernel (otr_add_layernorm_fwd_slabs) / a small reduce kernel sums them.
-typedef __attribute__((address_space(3))) unsigned char lds_byte;
-typedef __attribute__((address_space(1))) const unsigned char gbl_byte;
-
-// one 1 KiB fragment: 64 lanes x 16 B, global (fragment-major pack) -> LDS, asynchronous (vmcnt)
-// Inline asm, not __builtin_amdgcn_global_load_lds: with the builtin hipcc tracks the pending LDS write and puts
-// `s_waitcnt vmcnt(0)` in front of the next ds_read of ANY address -- i.e. it waited for the chunk it had just started to
-// fetch before multiplying the current one (seen in the ISA: the whole DMA latency exposed per chunk).  The asm form is
-// invisible to that bookkeeping; the kernels below wait themselves (vmcnt(0) + barrier right before a buffer is read).
-// M0 carries the wave-uniform LDS byte address and is restored afterwards (cdna_hip_programming.md 5.7).
-__device__ __forceinline__ void dma_frag(const uint4* src_frag, unsigned char* lds_frag, int lane) {
-  const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_byte*)lds_frag);
-  const uint4* src = src_frag + lane;
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-}
-
 struct Ffn2FwdArgs {
   const uint16_t* x16;     // [M, D]
   const uint4* p1; const float* b1; const uint4* p2;
@@ -1049,6 +989,8 @@ extern "C" int32_t otr_ffn_fwd_slabs(const void* x16, const void* w1_pack, const
   OTR_REQUIRE(((uintptr_t)x16 | (uintptr_t)w1_pack | (uintptr_t)w2_pack | (uintptr_t)slabs) % 16 == 0, "ffn_fwd_slabs: buffers must be 16-byte aligned");
   OTR_REQUIRE((F / 32 / n_slabs) * 64 * 4 <= 8192, "ffn_fwd_slabs: too many hidden units per workgroup for the bias staging");
   if (M == 0) return 0;
+  if (g_otr_ffn_waves != 2 && ffn3_takes(F, n_slabs))     // third form (ffn3.hip); otr_debug_set(5, 2) keeps the second for A/B runs
+    return ffn3_fwd_launch(x16, w1_pack, b1, w2_pack, slabs, n_slabs, M, F, (hipStream_t)stream);
   Ffn2FwdArgs p{};
   p.x16 = (const uint16_t*)x16; p.p1 = (const uint4*)w1_pack; p.b1 = b1; p.p2 = (const uint4*)w2_pack; p.slabs = slabs;
   p.M = (int)M; p.F = F; p.S = n_slabs; p.ablate = g_otr_ffn2_ablate;

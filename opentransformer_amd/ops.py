@@ -1144,8 +1144,27 @@ _FUSED_FFN = os.environ.get('OTR_NO_FUSED_FFN', '0') != '1'
 _FUSED_FFN_MIN_ROWS = int(os.environ.get('OTR_FUSED_FFN_MIN_ROWS', '1024'))   # below: too few 32-row workgroups to fill the chip
 
 
-_FFN_V2 = os.environ.get('OTR_FFN_V2', '0') == '1'      # measured equal to v1 at B=32 (LDS-read bound): v1 is the default
+_FFN_V2 = os.environ.get('OTR_FFN_V2', '0') == '1'      # slab form (partial sums through HBM + a LayerNorm / sum launch): A/B runs
 _FFN_V2_MIN_ROWS = 2048
+# 128-row workgroups with the hidden units split four ways and the partial sums exchanged inside the launch (csrc/ffn3.hip):
+# the default from 2048 rows up; OTR_FFN_SPLIT=0 keeps the 32-row kernels
+_FFN_SPLIT = os.environ.get('OTR_FFN_SPLIT', '1') == '1'
+_FFN_SPLIT_MIN_ROWS = 2048
+_FFN_SYNC_INTS = 1 << 14
+
+
+def _ffn_sync(device):
+    """arrival counters of the split FFN kernels: zero once, every launch leaves them zero (include/otrans_hip.h)"""
+    t = _state.get('ffn_sync')
+    if t is None or t.device != device:
+        t = torch.zeros(_FFN_SYNC_INTS, dtype=torch.int32, device=device)
+        _state['ffn_sync'] = t
+    return t
+
+
+def _ffn_split(M, F):
+    return (_FFN_SPLIT and not _FFN_V2 and M >= _FFN_SPLIT_MIN_ROWS and F % 256 == 0 and F // 32 // 4 <= 32
+            and 2 * ((M + 127) // 128) <= _FFN_SYNC_INTS)
 
 
 def _ffn_slabs(M, F):
@@ -1236,7 +1255,18 @@ class FfnLnFn(torch.autograd.Function):
         off = _next_rng_offset(M * d) if p_drop > 0 else 0
         S = _ffn_slabs(M, F)
         ctx.S = S
-        if S:       # v2: weight stream shared by 128 rows through LDS, hidden units split over S workgroups, LayerNorm sums the slabs
+        ctx.split = _ffn_split(M, F)
+        if ctx.split:
+            lib = L.load()
+            nb = lib.otr_ffn_split_scratch_bytes(M)
+            scratch = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
+            sync = _ffn_sync(x.device)
+            L.check(_timed('ffn_ln_fwd_split', {'flops': 6.0 * M * F * d, 'bytes': M * d * (4 + 2 + 4 + 2 + 4) + 6 * F * d},
+                           lambda: lib.otr_ffn_ln_fwd_split(_p(x2), _p(x16), _p(packs[0]), _p(b1), _p(packs[1]), _p(b2), _p(gamma),
+                                                            _p(beta), _p(seed), p_drop, off, eps, _p(y), _p(y16), _p(z), _p(mean),
+                                                            _p(rstd), _p(scratch), nb, _p(sync), sync.numel(), M, F, d, _stream())),
+                    'otr_ffn_ln_fwd_split')
+        elif S:     # v2: weight stream shared by 128 rows through LDS, hidden units split over S workgroups, LayerNorm sums the slabs
             lib = L.load()
             slabs = torch.empty((S, M, d), dtype=torch.float32, device=x.device)
             L.check(_timed('ffn_fwd_slabs', {'flops': 6.0 * M * F * d, 'bytes': M * d * 2 + 6 * F * d + S * M * d * 4},

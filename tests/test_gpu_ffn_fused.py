@@ -62,18 +62,20 @@ def mode(request):
     ops.set_compute_dtype('bf16')
 
 
-@pytest.fixture(params=['v1', 'v2'])
+@pytest.fixture(params=['v1', 'slabs', 'split'])
 def variant(request):
-    """v1: every wave streams its own weight fragments into registers (the default); v2: 128-row workgroups share the
-    stream through LDS and split the hidden units (rows >= 2048 only)"""
+    """v1: 32-row workgroups, every wave streams its own weight fragments into registers; slabs: 128-row workgroups share the
+    weight stream through LDS, split the hidden units and leave fp32 partial slabs to a LayerNorm / sum launch; split (the
+    default from 2048 rows): the same workgroups exchange their partial sums inside the launch (csrc/ffn3.hip)"""
     from opentransformer_amd import ops
-    was = ops._FFN_V2
-    ops._FFN_V2 = request.param == 'v2'
+    was = ops._FFN_V2, ops._FFN_SPLIT
+    ops._FFN_V2, ops._FFN_SPLIT = request.param == 'slabs', request.param == 'split'
     yield request.param
-    ops._FFN_V2 = was
+    ops._FFN_V2, ops._FFN_SPLIT = was
 
 
-@pytest.mark.parametrize('M,dff,p_drop', [(2048, 2048, 0.0), (2048 + 40, 512, 0.0), (1504, 512, 0.0), (1024 + 17, 256, 0.1)])
+@pytest.mark.parametrize('M,dff,p_drop', [(2048, 2048, 0.0), (2048 + 40, 512, 0.0), (1504, 512, 0.0), (1024 + 17, 256, 0.1), (7968, 2048, 0.0),
+                                          (4000 + 33, 1024, 0.1)])
 def test_ffn_ln_fused_matches_reference(mode, variant, M, dff, p_drop):
     from opentransformer_amd import ops
     d = 256

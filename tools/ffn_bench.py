@@ -61,6 +61,14 @@ def main():
         L.check(lib.otr_add_layernorm_fwd_slabs(C.byref(desc), p(x), p(slabs), S, M * d, p(b2), p(gamma), p(beta), p(seed), p(y), p(y16),
                                                 p(z), p(mean), p(rstd), st()), 'ln2')
 
+    nb = lib.otr_ffn_split_scratch_bytes(M)
+    scratch = torch.empty(nb // 4, device=dev)
+    sync = ops._ffn_sync(torch.device('cuda', torch.cuda.current_device()))
+
+    def fwd3(pd):
+        L.check(lib.otr_ffn_ln_fwd_split(p(x), p(x16), p(P[0]), p(b1), p(P[1]), p(b2), p(gamma), p(beta), p(seed), pd, 0, 1e-5, p(y), p(y16),
+                                         p(z), p(mean), p(rstd), p(scratch), nb, p(sync), sync.numel(), M, F, d, st()), 'fwd3')
+
     def bwd2():
         L.check(lib.otr_ffn_bwd_slabs(p(x16), p(da), p(P[0]), p(b1), p(P[2]), p(P[3]), p(dh), p(u), p(bpart), p(slabs), S, M, F, d, st()), 'bwd2')
 
@@ -91,26 +99,45 @@ def main():
         return e0.elapsed_time(e1) / n * 1e3
     res = {'rows': M, 'dff': F, 'mode': a.mode}
     lib.otr_debug_set(5, 4)
-    res['fwd_4waves_us'] = timeit(lambda: fwd(0.0), a.iters)
-    lib.otr_debug_set(5, 8)
-    res['fwd_us'] = timeit(lambda: fwd(0.0), a.iters)
-    res['fwd_drop_us'] = timeit(lambda: fwd(0.1), a.iters)
-    res['bwd_us'] = timeit(bwd, a.iters)
-    lib.otr_debug_set(4, 4)
-    res['bwd_no_db1_us'] = timeit(bwd, a.iters)
+    res['v1_fwd_us'] = timeit(lambda: fwd(0.0), a.iters)
+    res['v1_fwd_drop_us'] = timeit(lambda: fwd(0.1), a.iters)
+    res['v1_bwd_us'] = timeit(bwd, a.iters)
+    fwd(0.0)
+    y1 = y.clone()
+    res['split_fwd_us'] = timeit(lambda: fwd3(0.0), a.iters)
+    res['split_fwd_drop_us'] = timeit(lambda: fwd3(0.1), a.iters)
+    fwd3(0.0)
+    res['split_vs_v1_y_rel'] = float((y - y1).norm() / y1.norm())
+    res['split_sync_left'] = int(sync.abs().sum().item())
+    for ab in (1, 2, 3):
+        lib.otr_debug_set(4, ab)
+        res['split_fwd_ablate%d_us' % ab] = timeit(lambda: fwd3(0.0), a.iters)
     lib.otr_debug_set(4, 0)
+    res['split_fwd_tflops'] = 2.0 * M * 3 * F * d / res['split_fwd_us'] / 1e6
     if S:
         res['slabs'] = S
-        res['v2_fwd_us'] = timeit(fwd2, a.iters)
-        res['v2_ln_slabs_us'] = timeit(ln2, a.iters)
-        res['v2_bwd_us'] = timeit(bwd2, a.iters)
-        res['v2_slab_sum_us'] = timeit(sum2, a.iters)
-        for ab in (1, 2, 3):          # ablations: 1 = no weight DMA, 2 = no MFMA work, 3 = neither (launch + x load + epilogue)
-            lib.otr_debug_set(4, ab)
-            res['v2_fwd_ablate%d_us' % ab] = timeit(fwd2, a.iters)
-        lib.otr_debug_set(4, 0)
-        res['v2_fwd_tflops'] = 2.0 * M * 3 * F * d / res['v2_fwd_us'] / 1e6
-        res['v2_bwd_tflops'] = 2.0 * M * 5 * F * d / res['v2_bwd_us'] / 1e6
+        res['ln_slabs_us'] = timeit(ln2, a.iters)
+        res['slab_sum_us'] = timeit(sum2, a.iters)
+        for tag, key in (('v3', 4), ('v2', 2)):          # otr_debug_set(5, 2): the second form (32 rows per wave) for A/B runs
+            lib.otr_debug_set(5, key)
+            res[tag + '_fwd_us'] = timeit(fwd2, a.iters)
+            res[tag + '_bwd_us'] = timeit(bwd2, a.iters)
+            for ab in (1, 2, 3):      # ablations: 1 = no weight DMA after the prologue, 2 = no MFMA / GLU work, 3 = neither
+                lib.otr_debug_set(4, ab)
+                res['%s_fwd_ablate%d_us' % (tag, ab)] = timeit(fwd2, a.iters)
+                res['%s_bwd_ablate%d_us' % (tag, ab)] = timeit(bwd2, a.iters)
+            lib.otr_debug_set(4, 0)
+            res[tag + '_fwd_tflops'] = 2.0 * M * 3 * F * d / res[tag + '_fwd_us'] / 1e6
+            res[tag + '_bwd_tflops'] = 2.0 * M * 5 * F * d / res[tag + '_bwd_us'] / 1e6
+        lib.otr_debug_set(5, 4)
+        # parity of the two slab kernels on this shape: same partial sums up to the order of accumulation
+        fwd2()
+        s3 = slabs.sum(0).clone()
+        lib.otr_debug_set(5, 2)
+        fwd2()
+        lib.otr_debug_set(5, 4)
+        s2 = slabs.sum(0)
+        res['v3_vs_v2_fwd_rel'] = float((s3 - s2).norm() / s2.norm())
     res['wgrad_pair_us'] = timeit(wgrad, 10)
     try:
         res['old_fwd_us'] = timeit(old_fwd, 20)
@@ -118,8 +145,8 @@ def main():
         res['old_fwd_us'] = str(e)
     fl_f = 2.0 * M * (2 * F * d + F * d)
     fl_b = 2.0 * M * (2 * F * d + F * d + 2 * F * d)
-    res['fwd_tflops'] = fl_f / res['fwd_us'] / 1e6
-    res['bwd_tflops'] = fl_b / res['bwd_us'] / 1e6
+    res['v1_fwd_tflops'] = fl_f / res['v1_fwd_us'] / 1e6
+    res['v1_bwd_tflops'] = fl_b / res['v1_bwd_us'] / 1e6
     print(json.dumps(res))
 
 
