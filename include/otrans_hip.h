@@ -155,21 +155,33 @@ int32_t otr_ln_bwd_proj(const float* dy, const float* z, const float* mean, cons
                         float* partial, int64_t M, int32_t d_model, float p_drop, uint64_t rng_offset, void* stream);
 
 /* ---- the same sub-layer on 128-row workgroups (csrc/ffn3.hip): a workgroup owns 128 rows x 1/4 of the hidden units, the
- *      packed weights reach it ONCE through an LDS-DMA ring shared by its four waves (64 rows per wave), and the four
- *      workgroups of a row block exchange their fp32 partial sums through `scratch` (write-through stores, one arrival counter
- *      per row block in `sync`) and finish a quarter of the rows each: bias + dropout + residual + LayerNorm as in
- *      otr_ffn_ln_fwd.  scratch: >= otr_ffn_split_scratch_bytes(M) bytes, contents don't care; sync: >=
- *      otr_ffn_split_sync_ints(M) ints, ZERO before the first call -- every call leaves them zero again.  The arrival wait is
- *      bounded (otr_debug_set(11, v)); a give-up is reported through otr_set_fault_counter and leaves wrong rows behind.
- *      Needs the four workgroups of a row block co-resident: any grid on an otherwise idle GPU (they sit next to each other in
- *      dispatch order).  d_ff % 256 == 0, d_model 256. */
+ *      packed weights reach it ONCE through an LDS-DMA ring shared by its four waves (64 rows per wave, activations in the
+ *      accumulator half of the register file), and the four workgroups of a row block exchange their fp32 partial sums
+ *      through `scratch` (write-through stores, one arrival counter per row block in `sync`) and finish a quarter of the rows
+ *      each.  d_ff % 256 == 0, d_model 256.
+ *      scratch: >= otr_ffn_split_scratch_bytes(M) bytes, contents don't care; sync: >= otr_ffn_split_sync_ints(M) ints, ZERO
+ *      before the first call -- every call leaves them zero again.  The arrival wait is bounded (otr_debug_set(11, v)); a
+ *      give-up is reported through otr_set_fault_counter and leaves wrong rows behind.  Needs the four workgroups of a row
+ *      block co-resident: any grid on an otherwise idle GPU (they sit next to each other in dispatch order).
+ * otr_ffn_ln_fwd_split: y = LayerNorm(x + dropout(w_2 glu(w_1 x + b_1) + b_2)), outputs as otr_ffn_ln_fwd.  With hsave / usave
+ *      (both or neither) the pass also leaves what otr_ffn_bwd_split needs instead of recomputing it: hsave
+ *      [otr_ffn_split_hsave_bytes(M, F) bytes] = (value + bias, sigmoid(gate)) of every hidden unit, 16-bit, in accumulator-tile
+ *      order (opaque); usave [otr_ffn_split_padded_rows(M), F] 16-bit row-major = the glu output (operand of the w_2 weight
+ *      gradient; rows past M are scratch).
+ * otr_ffn_bwd_split: dh [otr_ffn_split_padded_rows(M), 2F] 16-bit row-major = GLU'(saved tiles, dy . w_2) (operand of the w_1
+ *      weight gradient; its column sums are the w_1 bias gradient); dx = skip (or 0) + dh . w_1, f32 [M, 256], may alias skip. */
 int64_t otr_ffn_split_scratch_bytes(int64_t M);
 int64_t otr_ffn_split_sync_ints(int64_t M);
+int64_t otr_ffn_split_hsave_bytes(int64_t M, int32_t F);
+int64_t otr_ffn_split_padded_rows(int64_t M);
 int32_t otr_ffn_ln_fwd_split(const float* x, const void* x16, const void* w1_pack, const float* b1, const void* w2_pack,
                              const float* b2, const float* gamma, const float* beta, const uint64_t* seed, float p_drop,
                              uint64_t rng_offset, float eps, float* y, void* y16, float* z, float* mean, float* rstd,
-                             void* scratch, int64_t scratch_bytes, int32_t* sync, int64_t sync_ints, int64_t M, int32_t F,
-                             int32_t d_model, void* stream);
+                             void* hsave, void* usave, void* scratch, int64_t scratch_bytes, int32_t* sync, int64_t sync_ints,
+                             int64_t M, int32_t F, int32_t d_model, void* stream);
+int32_t otr_ffn_bwd_split(const void* dy16, const void* hsave, const void* w2t_pack, const void* w1t_pack, void* dh,
+                          const float* skip, float* dx, void* scratch, int64_t scratch_bytes, int32_t* sync, int64_t sync_ints,
+                          int64_t M, int32_t F, int32_t d_model, void* stream);
 /* ---- the same sub-layer with the weight stream SHARED by 128 rows (v2, experimental: OTR_FFN_V2=1): a workgroup owns
  *      128 rows x 1/n_slabs of the hidden units, fetches every packed weight fragment once (global -> LDS, direct DMA)
  *      for its four waves, and leaves fp32 partial sums: slabs [n_slabs][M][256].

@@ -74,7 +74,10 @@ SIGNATURES = {
     'otr_ffn_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
     'otr_ffn_split_scratch_bytes': [_I64],
     'otr_ffn_split_sync_ints': [_I64],
-    'otr_ffn_ln_fwd_split': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F32, C.c_uint64, _F32, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _P],
+    'otr_ffn_split_hsave_bytes': [_I64, _I32],
+    'otr_ffn_split_padded_rows': [_I64],
+    'otr_ffn_ln_fwd_split': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F32, C.c_uint64, _F32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _P],
+    'otr_ffn_bwd_split': [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _P],
     'otr_ffn_fwd_slabs': [_P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _P],
     'otr_ffn_bwd_slabs': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _P],
     'otr_slab_sum': [_P, _I32, _I64, _P, _P, _P],
@@ -148,7 +151,8 @@ SIGNATURES = {
     'otr_bn_swish_bwd_partial_rows': [_I64],
     'otr_bn_swish_bwd': [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
 }
-_RESTYPE = {'otr_last_error_string': C.c_char_p, 'otr_ffn_split_scratch_bytes': C.c_int64, 'otr_ffn_split_sync_ints': C.c_int64, 'otr_add_layernorm_bwd_partial_rows': C.c_int64,
+_RESTYPE = {'otr_last_error_string': C.c_char_p, 'otr_ffn_split_scratch_bytes': C.c_int64, 'otr_ffn_split_sync_ints': C.c_int64, 'otr_ffn_split_hsave_bytes': C.c_int64,
+            'otr_ffn_split_padded_rows': C.c_int64, 'otr_add_layernorm_bwd_partial_rows': C.c_int64,
             'otr_ln_bwd_proj_partial_rows': C.c_int64}
 
 _libs = {}

@@ -60,6 +60,69 @@ __device__ __forceinline__ void f3_mma_xa(f32x16& acc, const otr_u32x4& w, const
 }
 #define F3_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")   /* >= 12 wait states: MFMA result -> VALU reader */
 
+// ---- partial-sum exchange between the four workgroups of a row block (fused forms).  Accumulator layout throughout: tile
+// (ct, q): lane (m, hi) holds columns 32 ct + 8 q + 4 hi .. + 3 of row m as one float4, so every piece is 1 KiB lane-linear.
+constexpr int F3_AUX_COH = 17;           // sc0 | sc1: stores write through to memory, loads are served by memory
+typedef decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0)) f3_rsrc_t;
+
+// wave (wr, wc) holds acc[rt][ct]: rows 64 wr + 32 rt .., columns 128 wc + 32 ct ..; the row tile that belongs to quarter `sl`
+// (this workgroup finishes it) goes to LDS `own` [8 column tiles][4 q][64 lanes] float4, the others to
+// scratch[sender sl][quarter] of the row block with write-through stores
+__device__ __forceinline__ void f3_send_partials(const f32x16 (&acc)[2][4], f3_rsrc_t rs, float* own, int sl, int wr, int wc, int lane) {
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int qt = 2 * wr + rt;                                  // the quarter these 32 rows belong to (wave-uniform)
+    if (qt == sl) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(own + (((4 * wc + ct) * 4 + q) * 64 + lane) * 4) =
+              make_float4(acc[rt][ct][4 * q], acc[rt][ct][4 * q + 1], acc[rt][ct][4 * q + 2], acc[rt][ct][4 * q + 3]);
+    } else {
+      const uint32_t base = (uint32_t)((sl * 4 + qt) * 32768 + (4 * wc) * 4096 + lane * 16);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const otr_u32x4 v = {__float_as_uint(acc[rt][ct][4 * q]), __float_as_uint(acc[rt][ct][4 * q + 1]),
+                               __float_as_uint(acc[rt][ct][4 * q + 2]), __float_as_uint(acc[rt][ct][4 * q + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, base + (uint32_t)((ct * 4 + q) * 1024), 0, F3_AUX_COH);
+        }
+    }
+  }
+}
+// one lane: arrive, then wait for all four workgroups of the row block (bounded; a give-up bumps the fault word)
+__device__ __forceinline__ void f3_arrive_wait(int* arrive, int spin_limit, int* fault) {
+  __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int spins = 0;
+  while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4 && spins < spin_limit) {
+    __builtin_amdgcn_s_sleep(4);
+    ++spins;
+  }
+  if (spins >= spin_limit && fault) __hip_atomic_fetch_add(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the three partners' partials of quarter `sl`, column tiles 2 wid, 2 wid + 1
+__device__ __forceinline__ void f3_recv_partials(otr_u32x4 (&part)[3][2][4], f3_rsrc_t rs, int sl, int wid, int lane) {
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    const int s2 = n + (n >= sl ? 1 : 0);                        // the three other slices (wave-uniform)
+    const uint32_t base = (uint32_t)((s2 * 4 + sl) * 32768 + (2 * wid) * 4096 + lane * 16);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        part[n][t][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (uint32_t)((t * 4 + q) * 1024), 0, F3_AUX_COH);
+  }
+}
+// one lane, after this workgroup has read everything it needed: the last of the four readers re-arms the counters
+__device__ __forceinline__ void f3_done(int* arrive) {
+  if (__hip_atomic_fetch_add(arrive + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3) {
+    __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(arrive + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 struct Ffn3FwdArgs {
   const uint16_t* x16;     // [M, D]
   const uint4* p1; const float* b1; const uint4* p2;
@@ -69,6 +132,10 @@ struct Ffn3FwdArgs {
   // ---- fused form only (in-kernel reduction of the S = 4 partial sums + bias + dropout + residual + LayerNorm)
   const float* x; const float* b2; const float* gamma; const float* beta; const uint64_t* seed;
   float* y; uint16_t* y16; float* z; float* mean; float* rstd;
+  uint4* hsave;            // SAVE: (value + bias, sigmoid(gate)) of every hidden unit, 16-bit, in ACCUMULATOR-TILE order for the
+                           // backward kernel: [row block][slice][64-unit chunk][wave][8 pieces][64 lanes] x 16 B; piece
+                           // rt*2 + j = value registers 8j .. 8j+7 of row tile rt, piece 4 + rt*2 + j = the sigmoids
+  uint16_t* usave;         // SAVE: u = glu output [128 * row blocks, F] row-major (operand of the w_2 weight gradient)
   int* sync;               // [2 * row blocks] zero on entry, zero again on exit: arrivals / readers done per row block
   int* fault;              // NULL or the sticky fault word (otr_set_fault_counter)
   int spin_limit;
@@ -85,7 +152,7 @@ __device__ __forceinline__ void f3_block_map(int b, int S, int& rb, int& s) {
   rb = (j / S) * 8 + xcd;
 }
 
-template <int D, int ABL, bool FUSE>
+template <int D, int ABL, bool FUSE, bool SAVE>
 __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   static_assert(D == 256, "two 128-column halves, 16 contraction steps");
   constexpr int NKS = D / 16;
@@ -226,11 +293,13 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   } else {                                                                                                     \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) { F3_ISSUE2(g) }                                             \
   }
-  // end of a phase: this wave's DMAs of the NEXT phase have landed (the 16 of the two phases after it may still fly), its LDS
-  // traffic is done; after the barrier the slot just consumed is free for the phase four ahead, which is scheduled here and
-  // issued during the next phase
-#define F3_PHASE_END()                                                                                         \
-  if constexpr (no_dma) f3_wait_vm<0>(); else f3_wait_vm<16>();                                                \
+  // end of a phase: this wave's DMAs of the NEXT phase have landed, its LDS traffic is done; after the barrier the slot just
+  // consumed is free for the phase four ahead, which is scheduled here and issued during the next phase.  The wait is COUNTED
+  // (vmcnt retires in issue order, stores included): everything this wave issued after the last DMA of the next phase's
+  // group may still fly -- the 16 DMAs of the two phases after it plus EXTRA = the global stores of those two phases (SAVE: 12
+  // per G phase, unconditional so that the count is exact)
+#define F3_PHASE_END(EXTRA)                                                                                    \
+  if constexpr (no_dma) f3_wait_vm<0>(); else f3_wait_vm<16 + (EXTRA)>();                                      \
   f3_wait_lds();                                                                                               \
   f3_barrier();                                                                                                \
   schedule(slot);                                                                                              \
@@ -241,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   // uown[kk >> 1][kk & 1], which step (kk & 1) <= kk of GEMM2 has already consumed.  One basic block; per step 8 MFMAs with the
   // quarter's ~45 VALU instructions pinned between them (sched_group_barrier: 1 MFMA, then 6 VALU), so the matrix pipe runs
   // during the VALU phase.
-#define F3_PHASE_G(G2, GLU, SLOT)                                                                              \
+#define F3_PHASE_G(G2, GLU, SLOT, CHUNK)                                                                              \
   if constexpr (!no_mma) {                                                                                     \
     const uint4* wb = reinterpret_cast<const uint4*>(ring + (SLOT) * F3_PHASE) + (wc * 16) * 64 + lane;        \
     uint4 fr[2][4];                                                                                            \
@@ -266,11 +335,22 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
       }                                                                                                        \
       if constexpr (GLU) {                   /* quarter kk: row tile kk >> 1, registers 8 (kk & 1) .. + 7 */       \
         const int rt = kk >> 1, j0 = (kk & 1) * 8;                                                             \
-        float u[8];                                                                                            \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) u[e] = hv[rt][j0 + e] * fast_sigmoid(hg[rt][j0 + e]);    \
+        float u[8], sg[8];                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) { sg[e] = fast_sigmoid(hg[rt][j0 + e]); u[e] = hv[rt][j0 + e] * sg[e]; } \
         const uint4 nu = make_uint4(pack2h(u[0], u[1]), pack2h(u[2], u[3]), pack2h(u[4], u[5]), pack2h(u[6], u[7])); \
         uown[rt][kk & 1] = nu;               /* kept for GEMM2 of this chunk one iteration later ... */            \
         my_u[(rt * 2 + (kk & 1)) * 64] = nu; /* ... and handed to the partner wave */                            \
+        if constexpr (SAVE) {                /* 2 (+ 2 on odd quarters) global stores: F3_SAVE_STORES per G phase */ \
+          uint4* hs = p.hsave + ((int64_t)(((rb * 4 + sl) * NC + (CHUNK)) * 4 + wid) * 8) * 64 + lane;         \
+          st_global_b128(hs + (rt * 2 + (kk & 1)) * 64,                                                        \
+                         make_uint4(pack2h(hv[rt][j0], hv[rt][j0 + 1]), pack2h(hv[rt][j0 + 2], hv[rt][j0 + 3]), \
+                                    pack2h(hv[rt][j0 + 4], hv[rt][j0 + 5]), pack2h(hv[rt][j0 + 6], hv[rt][j0 + 7]))); \
+          st_global_b128(hs + (4 + rt * 2 + (kk & 1)) * 64,                                                    \
+                         make_uint4(pack2h(sg[0], sg[1]), pack2h(sg[2], sg[3]), pack2h(sg[4], sg[5]), pack2h(sg[6], sg[7]))); \
+          if (kk & 1)                        /* both halves of row tile rt are new: its 32 u values, row-major */   \
+            store_tile_row(p.usave + ((int64_t)row0 + 32 * rt + m) * p.F + (c_base + 2 * (CHUNK) + wc) * 32,     \
+                           uown[rt][0], uown[rt][1], hi, true);                                                \
+        }                                                                                                      \
       }                                                                                                        \
       if constexpr (G2 && GLU) {                                                                               \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                        \
@@ -291,29 +371,30 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                             \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) upart[rt][j] = partner_u[(rt * 2 + j) * 64];
 
+  constexpr int KG = SAVE ? 12 : 0;                              // global stores of a G phase (F3_PHASE_G: 8 h pieces + 4 u pieces)
   int slot = 0;                                                  // ring slot of the current phase (phase index mod 4)
   // ---- chunk 0: A, B, GLU only
   F3_BIAS_INIT(wc)
   F3_GEMM1(0, slot)
-  F3_PHASE_END()
+  F3_PHASE_END(0)
   F3_GEMM1(1, slot)
-  F3_PHASE_END()
-  F3_PHASE_G(false, true, slot)
-  F3_PHASE_END()
+  F3_PHASE_END(0)
+  F3_PHASE_G(false, true, slot, 0)
+  F3_PHASE_END(KG)
   // ---- chunks 1 .. NC-1: A, B, GLU beside the previous chunk's GEMM2
   for (int C = 1; C < NC; ++C) {
     F3_BIAS_INIT(2 * C + wc)
     F3_GEMM1(0, slot)
-    F3_PHASE_END()
+    F3_PHASE_END(KG)                                             // the G phase before this one
     F3_READ_PARTNER()
     F3_GEMM1(1, slot)
-    F3_PHASE_END()
-    F3_PHASE_G(true, true, slot)
-    F3_PHASE_END()
+    F3_PHASE_END(0)
+    F3_PHASE_G(true, true, slot, C)
+    F3_PHASE_END(KG)
   }
   // ---- closing phase: GEMM2 of chunk NC-1 (its w_2 took the place of a phase A(NC))
   F3_READ_PARTNER()
-  F3_PHASE_G(true, false, slot)
+  F3_PHASE_G(true, false, slot, 0)
 #undef F3_ISSUE2
 #undef F3_BIAS_INIT
 #undef F3_GEMM1
@@ -364,67 +445,33 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   //   2. arrive (one atomic per workgroup), wait for all four (bounded spin; a give-up is reported through the fault word)
   //   3. wave w sums column tiles 2w, 2w+1 of its quarter: own (LDS) + three partners (sc1 loads: served past the L1)
   //   4. bias, dropout (the mask otr_add_layernorm_bwd regenerates), residual, LayerNorm; y / y16 / z / mean / rstd
-  constexpr int AUX = 17;                                        // sc0 | sc1
   float* own = reinterpret_cast<float*>(ring);                   // [8 column tiles][4 q][64 lanes] float4 = 32 KiB
   float* red = reinterpret_cast<float*>(ring + 32768);           // [2 passes][4 waves][32 rows]
   auto rs = __builtin_amdgcn_make_buffer_rsrc(p.slabs + (int64_t)rb * (4 * 4 * 8192), 0, 4 * 4 * 32768, 0x00020000);
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-    const int qt = 2 * wr + rt;                                  // the quarter these 32 rows belong to (wave-uniform)
-    if (qt == sl) {
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float4*>(own + (((4 * wc + ct) * 4 + q) * 64 + lane) * 4) =
-              make_float4(yacc[rt][ct][4 * q], yacc[rt][ct][4 * q + 1], yacc[rt][ct][4 * q + 2], yacc[rt][ct][4 * q + 3]);
-    } else {
-      const uint32_t base = (uint32_t)((sl * 4 + qt) * 32768 + (4 * wc) * 4096 + lane * 16);
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const otr_u32x4 v = {__float_as_uint(yacc[rt][ct][4 * q]), __float_as_uint(yacc[rt][ct][4 * q + 1]),
-                               __float_as_uint(yacc[rt][ct][4 * q + 2]), __float_as_uint(yacc[rt][ct][4 * q + 3])};
-          __builtin_amdgcn_raw_buffer_store_b128(v, rs, base + (uint32_t)((ct * 4 + q) * 1024), 0, AUX);
-        }
-    }
-  }
-  f3_wait_vm<0>();                                               // this wave's write-through stores are at memory
-  f3_wait_lds();
-  f3_barrier();
-  if (tid == 0) {
-    int* arrive = p.sync + 2 * rb;
-    __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int spins = 0;
-    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4 && spins < p.spin_limit) {
-      __builtin_amdgcn_s_sleep(4);
-      ++spins;
-    }
-    if (spins >= p.spin_limit && p.fault) __hip_atomic_fetch_add(p.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  f3_barrier();
-  // ---- the quarter's rows: lane (m, hi) of wave `wid` owns row m, columns 32 ct + 8 q + 4 hi .. + 3 for ct = 2 wid, 2 wid + 1
+  f3_send_partials(yacc, rs, own, sl, wr, wc, lane);
+  // everything the quarter's epilogue reads besides the partials is fetched before the arrival wait
   const int64_t row = (int64_t)rb * 128 + 32 * sl + m;
   const bool live = row < p.M;
   const int64_t crow = live ? row : (int64_t)p.M - 1;
-  otr_u32x4 part[3][2][4];
-#pragma unroll
-  for (int n = 0; n < 3; ++n) {
-    const int s2 = n + (n >= sl ? 1 : 0);                        // the three other slices (wave-uniform)
-    const uint32_t base = (uint32_t)((s2 * 4 + sl) * 32768 + (2 * wid) * 4096 + lane * 16);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        part[n][t][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (uint32_t)((t * 4 + q) * 1024), 0, AUX);
-  }
-  float4 xr[2][4];
+  float4 xr[2][4], b2r[2][4], gmr[2][4], btr[2][4];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      xr[t][q] = *reinterpret_cast<const float4*>(p.x + crow * D + 32 * (2 * wid + t) + 8 * q + 4 * hi);
+    for (int q = 0; q < 4; ++q) {
+      const int col = 32 * (2 * wid + t) + 8 * q + 4 * hi;
+      xr[t][q] = *reinterpret_cast<const float4*>(p.x + crow * D + col);
+      b2r[t][q] = *reinterpret_cast<const float4*>(p.b2 + col);
+      gmr[t][q] = *reinterpret_cast<const float4*>(p.gamma + col);
+      btr[t][q] = *reinterpret_cast<const float4*>(p.beta + col);
+    }
+  f3_wait_vm<0>();                                               // this wave's write-through stores are at memory
+  f3_wait_lds();
+  f3_barrier();
+  if (tid == 0) f3_arrive_wait(p.sync + 2 * rb, p.spin_limit, p.fault);
+  f3_barrier();
+  // ---- the quarter's rows: lane (m, hi) of wave `wid` owns row m, columns 32 ct + 8 q + 4 hi .. + 3 for ct = 2 wid, 2 wid + 1
+  otr_u32x4 part[3][2][4];
+  f3_recv_partials(part, rs, sl, wid, lane);
   const bool drop = p.p_drop > 0.f;
   const uint64_t seed = drop ? *p.seed : 0;
   const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
@@ -437,7 +484,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
     for (int q = 0; q < 4; ++q) {
       const int col = 32 * (2 * wid + t) + 8 * q + 4 * hi;
       const float4 o = *reinterpret_cast<const float4*>(own + (((2 * wid + t) * 4 + q) * 64 + lane) * 4);
-      const float4 b2 = *reinterpret_cast<const float4*>(p.b2 + col);
+      const float4 b2 = b2r[t][q];
       float a4[4] = {o.x + b2.x, o.y + b2.y, o.z + b2.z, o.w + b2.w};
 #pragma unroll
       for (int n = 0; n < 3; ++n) {
@@ -470,31 +517,379 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   f3_barrier();
   const float rstd = rsqrtf((red[128 + m] + red[160 + m] + red[192 + m] + red[224 + m]) * (1.f / D) + p.eps);
   if (live) {
+    if (p.z) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(p.z + row * D + 32 * (2 * wid + t) + 8 * q + 4 * hi) =
+              make_float4(v[t][4 * q], v[t][4 * q + 1], v[t][4 * q + 2], v[t][4 * q + 3]);
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int col = 32 * (2 * wid + t) + 8 * q + 4 * hi;
-        const float4 gm = *reinterpret_cast<const float4*>(p.gamma + col);
-        const float4 bt = *reinterpret_cast<const float4*>(p.beta + col);
-        const float* vv = &v[t][4 * q];
-        if (p.z) *reinterpret_cast<float4*>(p.z + row * D + col) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-        const float o0 = (vv[0] - mean) * rstd * gm.x + bt.x, o1 = (vv[1] - mean) * rstd * gm.y + bt.y;
-        const float o2 = (vv[2] - mean) * rstd * gm.z + bt.z, o3 = (vv[3] - mean) * rstd * gm.w + bt.w;
-        *reinterpret_cast<float4*>(p.y + row * D + col) = make_float4(o0, o1, o2, o3);
-        if (p.y16) *reinterpret_cast<uint2*>(p.y16 + row * D + col) = make_uint2(pack2h(o0, o1), pack2h(o2, o3));
+        const float4 gm = gmr[t][q], bt = btr[t][q];
+        float* vv = &v[t][4 * q];
+        vv[0] = (vv[0] - mean) * rstd * gm.x + bt.x; vv[1] = (vv[1] - mean) * rstd * gm.y + bt.y;
+        vv[2] = (vv[2] - mean) * rstd * gm.z + bt.z; vv[3] = (vv[3] - mean) * rstd * gm.w + bt.w;
+        *reinterpret_cast<float4*>(p.y + row * D + 32 * (2 * wid + t) + 8 * q + 4 * hi) = make_float4(vv[0], vv[1], vv[2], vv[3]);
       }
+    if (p.y16) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<uint2*>(p.y16 + row * D + 32 * (2 * wid + t) + 8 * q + 4 * hi) =
+              make_uint2(pack2h(v[t][4 * q], v[t][4 * q + 1]), pack2h(v[t][4 * q + 2], v[t][4 * q + 3]));
+    }
     if (wid == 0 && hi == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
   }
   // every partial this workgroup needed has been read: the last of the four readers re-arms the row block's counters
-  if (tid == 0) {
-    int* arrive = p.sync + 2 * rb;
-    if (__hip_atomic_fetch_add(arrive + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3) {
-      __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(arrive + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) f3_done(p.sync + 2 * rb);
+  }
+}
+
+
+// ================================================================================================ backward
+// dx = skip + dh . w_1 with dh = GLU'(saved (value, sigmoid), du), du = dy . w_2; dh (16-bit, row-major) is the operand of the
+// w_1 weight gradient (its column sums = the w_1 bias gradient ride along in that launch).  The hidden pre-activations are
+// NOT recomputed: the forward kernel left (value + bias, sigmoid(gate)) in accumulator-tile order (Ffn3FwdArgs::hsave), which
+// this kernel reads back piece by piece (1 KiB coalesced loads) -- the backward pass is then the forward pass mirrored:
+//   D   du^T[32 hidden of sub-chunk wc, 64 rows] = w_2^T frags (LDS) x dy^T frags (ACCUMULATOR registers, 128)   32 MFMAs
+//   GLU' on the accumulators (du) and the saved tiles -> dvalue, dgate: 16-bit B-operand fragments (registers + hand-over to
+//       the partner wave) and row-major dh (global)
+//   XA  dx^T[128 columns of half wc, 64 rows] += w_1^T frags x OWN dh frags                                         32 MFMAs
+//   XB  ... += w_1^T frags x the PARTNER's dh frags (read from the hand-over buffer during the next D phase)           32 MFMAs
+// software-pipelined like the forward kernel: iteration C = D(C), XA(C-1) beside the first half of GLU'(C), XB(C-1) beside
+// the second half.  Same ring, same counted waits; the global traffic of an X phase -- 4 dh stores and 4 loads of the NEXT
+// chunk's saved tiles (two phases ahead of their use) -- sits in front of the phase's last DMA pair, so the counts are exact.
+struct Ffn3BwdArgs {
+  const uint16_t* dy16;    // [M, D]
+  const uint4* hsave;      // forward's (value, sigmoid) tiles
+  const uint4* p3;         // w_2^T packed: rows = F hidden units, contraction = D, perm 0
+  const uint4* p4;         // w_1^T packed: rows = D, contraction = 2F (value then gate), perm 1
+  uint16_t* dh;            // [128 * row blocks, 2F] row-major out
+  const float* skip;       // [M, D] or NULL
+  float* dx;               // [M, D] out (may alias skip)
+  float* scratch; int* sync; int* fault; int spin_limit;
+  int M, F;
+};
+
+// a global load hipcc does not count (its own s_waitcnt would drain the DMAs in flight): 16 B per lane from a wave-uniform base.
+// Form (ii) of cdna_hip_programming.md 5.7: the load, and before the first consumer a counted wait that names the destination.
+// The destination is "+v", not "=v": it lives across the loop back-edge, and with a plain output hipcc may give the loop-carried
+// value another register and copy the "defined" one there while the load is still in flight; read-modify-write
+// ties the asm to the ONE register the loop carries.
+__device__ __forceinline__ void f3_gload(otr_u32x4& dst, const void* uniform_src, uint32_t lane_off) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(lane_off), "s"(uniform_src) : "memory");
+}
+template <int N> __device__ __forceinline__ void f3_wait_vm_for(otr_u32x4& a, otr_u32x4& b, otr_u32x4& c, otr_u32x4& d) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+__device__ __forceinline__ void f3_mma_acc(f32x16& acc, const otr_u32x4& w, const otr_u32x4& b_acc) {
+  asm volatile(F3_MFMA_OP " %0, %1, %2, %0" : "+v"(acc) : "v"(w), "a"(b_acc));
+}
+__device__ __forceinline__ float f3_h2f_lo(uint32_t w) { return h2f_lo(w); }
+
+template <int D, int ABL>
+__global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
+  static_assert(D == 256, "two 128-column halves, 16 contraction steps");
+  constexpr int NKS = D / 16;
+  constexpr int HAND = 32 * 1024;        // dh hand-over: [wave][row tile][k: dvalue 0, 1, dgate 0, 1] fragments of 1 KiB
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[F3_RING + HAND];
+  unsigned char* ring = smem;
+  unsigned char* hand = smem + F3_RING;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  const int m = lane & 31, hi = lane >> 5;
+  int rb, sl;
+  f3_block_map((int)blockIdx.x, 4, rb, sl);
+  if (rb * 128 >= p.M) return;
+  const int row0 = rb * 128 + wr * 64;
+  const int nchunk = p.F / 32, per = nchunk / 4, NC = per >> 1;
+  const int c_base = sl * per;
+  constexpr bool no_dma = (ABL & 1) != 0, no_mma = (ABL & 2) != 0;
+
+  // ---- DMA schedule (see ffn3_fwd_kernel).  Phase 3C + k: k = 0: D(C) = w_2^T of chunk C (fragment f = ks*2 + wcc); k = 1 / 2:
+  // XA / XB of chunk C-1 = w_1^T fragments for the OWN / PARTNER step: f = (wcc*4 + ctl)*4 + j4 -- column tile 4 wcc + ctl,
+  // contraction steps j4 = {value 0, 1, gate 0, 1} of sub-chunk wcc (own step) or 1 - wcc (partner step); phases 3 NC and
+  // 3 NC + 1 close with XA / XB of the last chunk.  This wave's fragments are wid*8 + j; source offset of fragment j:
+  // (pa (j >> 2) + pb ((j >> 1) & 1) + pc (j & 1)) KiB.
+  const unsigned char* psrc = nullptr;
+  uint32_t pa = 0, pb = 0, pc = 0, pdst = 0;
+  int pC = 0, pk = 0;
+  const uint32_t ring0 = (uint32_t)(uintptr_t)(ffn_lds_byte*)ring;
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  auto schedule = [&](int slot) {
+    int kind, ch;                                                // kind 0: w_2^T, 1: own step, 2: partner step
+    if (pC < NC) { kind = pk; ch = pk == 0 ? pC : (pC > 0 ? pC - 1 : 0); }
+    else { kind = (pC == NC && pk == 0) ? 1 : 2; ch = NC - 1; }
+    if (kind == 0) {
+      psrc = reinterpret_cast<const unsigned char*>(p.p3) + ((int64_t)((c_base + 2 * ch) * NKS + wid * 4) << 10);
+      pa = 2; pb = 1; pc = NKS;                                  // f = wid*8 + j: ks = wid*4 + (j >> 1), wcc = j & 1
+    } else {
+      const int wcc = wid >> 1, sc = kind == 1 ? wcc : (wcc ^ 1);
+      const int c = c_base + 2 * ch + sc;
+      psrc = reinterpret_cast<const unsigned char*>(p.p4) + ((int64_t)((4 * wcc + (wid & 1) * 2) * (4 * nchunk) + 2 * c) << 10);
+      pa = (uint32_t)(4 * nchunk); pb = (uint32_t)(2 * nchunk); pc = 1;   // f = wid*8 + j: ctl = (wid & 1)*2 + (j >> 2), j4 = j & 3
     }
+    pdst = ring0 + (uint32_t)(slot * F3_PHASE + wid * 8192);
+    if (++pk == 3) { pk = 0; ++pC; }
+  };
+  auto issue2 = [&](int i) {
+    const uint32_t o = pa * (uint32_t)(i >> 1) + pb * (uint32_t)(i & 1);
+    ffn_dma(psrc + ((uint64_t)o << 10), lane_off, pdst + (uint32_t)(2 * i) * 1024u);
+    ffn_dma(psrc + ((uint64_t)(o + pc) << 10), lane_off, pdst + (uint32_t)(2 * i + 1) * 1024u);
+  };
+#define F3B_ISSUE2(I) if constexpr (!no_dma) issue2(I);
+
+  schedule(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue2(i);
+  // this wave's 64 rows of dy as MFMA B operands, in (accumulator) registers for the whole kernel
+  otr_u32x4 dyf[2][NKS];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int64_t row = min(row0 + 32 * rt + m, p.M - 1);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) dyf[rt][ks] = *(const OTR_GLOBAL otr_u32x4*)(p.dy16 + row * D + ks * 16 + hi * 8);
   }
+  // the saved (value, sigmoid) tiles of chunk C for this wave: 8 pieces; hp[0..3] = row tile 0 (value 0, 1, sigmoid 0, 1),
+  // hp[4..7] = row tile 1
+  const unsigned char* hbase = reinterpret_cast<const unsigned char*>(p.hsave) + ((int64_t)((rb * 4 + sl) * NC) * 4 + wid) * 8192;
+  otr_u32x4 hp[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) hp[i] = otr_u32x4{0u, 0u, 0u, 0u};
+  auto hload = [&](int C, int half) {                            // 4 pieces of row tile `half`
+    const unsigned char* b = hbase + (int64_t)C * (4 * 8192);
+    f3_gload(hp[4 * half + 0], b + (half * 2 + 0) * 1024, lane_off);
+    f3_gload(hp[4 * half + 1], b + (half * 2 + 1) * 1024, lane_off);
+    f3_gload(hp[4 * half + 2], b + (4 + half * 2 + 0) * 1024, lane_off);
+    f3_gload(hp[4 * half + 3], b + (4 + half * 2 + 1) * 1024, lane_off);
+  };
+  hload(0, 0);
+  hload(0, 1);
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+a"(dyf[rt][ks]));
+  f3_wait_vm_for<0>(hp[0], hp[1], hp[2], hp[3]);
+  f3_wait_vm_for<0>(hp[4], hp[5], hp[6], hp[7]);
+  schedule(1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue2(i);
+  schedule(2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue2(i);
+  schedule(3);
+  f3_wait_lds();
+  f3_barrier();
+
+  f32x16 xacc[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xacc[rt][ct][r] = 0.f;
+  f32x16 du[2];
+  uint4 dho[2][4], dhp[2][4];                                    // own / partner dh fragments of the previous chunk
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dho[rt][k] = dhp[rt][k] = make_uint4(0u, 0u, 0u, 0u);
+  uint4* my_h = reinterpret_cast<uint4*>(hand) + (wid * 8) * 64 + lane;
+  const uint4* partner_h = reinterpret_cast<const uint4*>(hand) + ((wid ^ 1) * 8) * 64 + lane;
+
+  // D: du = w_2^T . dy over 16 contraction steps, 8 MFMAs per group of 4 fragments, two DMAs behind every group
+#define F3B_PHASE_D(SLOT)                                                                                      \
+  if constexpr (!no_mma) {                                                                                     \
+    _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                           \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) du[rt][r] = 0.f;                                          \
+    asm volatile("s_nop 3" ::: "memory");                                                                      \
+    const otr_u32x4* wb = reinterpret_cast<const otr_u32x4*>(ring + (SLOT) * F3_PHASE) + wc * 64 + lane;       \
+    otr_u32x4 fr[2][4];                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) fr[0][j] = wb[(j * 2) * 64];                                 \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                            \
+      if (g + 1 < 4) {                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) fr[(g + 1) & 1][j] = wb[((4 * (g + 1) + j) * 2) * 64];   \
+      }                                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
+        f3_mma_acc(du[0], fr[g & 1][j], dyf[0][4 * g + j]);                                                    \
+        f3_mma_acc(du[1], fr[g & 1][j], dyf[1][4 * g + j]);                                                    \
+      }                                                                                                        \
+      F3B_ISSUE2(g)                                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+  } else {                                                                                                     \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) { F3B_ISSUE2(g) }                                            \
   }
+#define F3B_PHASE_END(KEEP)                                                                                    \
+  if constexpr (no_dma) f3_wait_vm<0>(); else f3_wait_vm<(KEEP)>();                                            \
+  f3_wait_lds();                                                                                               \
+  f3_barrier();                                                                                                \
+  schedule(slot);                                                                                              \
+  slot = (slot + 1) & 3;
+  // GLU' of quarter (RT, J) of chunk CH: registers 8J .. 8J+7 of row tile RT.  value a, sigmoid s (saved), d = du:
+  //   dvalue = d s,  dgate = d a s (1 - s);  fragments: dvalue -> contraction step J, dgate -> step 2 + J of this sub-chunk
+#define F3B_GLU(RT, J, NDH)                                                                                    \
+  {                                                                                                            \
+    const otr_u32x4 pa_ = hp[4 * (RT) + (J)], ps_ = hp[4 * (RT) + 2 + (J)];                                    \
+    const uint32_t aw[4] = {pa_.x, pa_.y, pa_.z, pa_.w}, sw[4] = {ps_.x, ps_.y, ps_.z, ps_.w};                 \
+    float da[8], dg[8];                                                                                        \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                            \
+      const float a = (e & 1) ? h2f_hi(aw[e >> 1]) : h2f_lo(aw[e >> 1]);                                       \
+      const float sg = (e & 1) ? h2f_hi(sw[e >> 1]) : h2f_lo(sw[e >> 1]);                                      \
+      const float d_ = du[RT][8 * (J) + e];                                                                    \
+      da[e] = d_ * sg;                                                                                         \
+      const float t_ = d_ * a * sg;                                                                            \
+      dg[e] = t_ - t_ * sg;                                                                                    \
+    }                                                                                                          \
+    NDH[RT][J] = make_uint4(pack2h(da[0], da[1]), pack2h(da[2], da[3]), pack2h(da[4], da[5]), pack2h(da[6], da[7])); \
+    NDH[RT][2 + (J)] = make_uint4(pack2h(dg[0], dg[1]), pack2h(dg[2], dg[3]), pack2h(dg[4], dg[5]), pack2h(dg[6], dg[7])); \
+    my_h[((RT) * 4 + (J)) * 64] = NDH[RT][J];                                                                  \
+    my_h[((RT) * 4 + 2 + (J)) * 64] = NDH[RT][2 + (J)];                                                        \
+  }
+  // row tile RT of chunk CH complete: its 32 dvalue and 32 dgate values per row, row-major (4 global stores), then the loads of
+  // the NEXT chunk's saved tiles for this row tile (4 global loads) -- both in front of the phase's last DMA pair
+#define F3B_STORE_LOAD(RT, CH, NDH)                                                                            \
+  {                                                                                                            \
+    uint16_t* dr = p.dh + ((int64_t)row0 + 32 * (RT) + m) * (2 * (int64_t)p.F) + (c_base + 2 * (CH) + wc) * 32; \
+    store_tile_row(dr, NDH[RT][0], NDH[RT][1], hi, true);                                                      \
+    store_tile_row(dr + p.F, NDH[RT][2], NDH[RT][3], hi, true);                                                \
+    hload((CH) + 1 < NC ? (CH) + 1 : (CH), RT);          /* past the end: a reload of valid tiles, never used */  \
+  }
+  // X phase: 32 MFMAs in 4 steps (j4) of 8 over w_1^T fragments [(wc*4 + ctl)*4 + j4] with the dh fragments DHF[rt][j4], the GLU'
+  // quarters Q0 / Q1 (row tile RTQ) of chunk CH beside steps 0-1 / 2-3
+#define F3B_PHASE_X(X, GLUQ, SLOT, DHF, RTQ, CH, NDH)                                                          \
+  if constexpr (!no_mma) {                                                                                     \
+    const uint4* wb = reinterpret_cast<const uint4*>(ring + (SLOT) * F3_PHASE) + (wc * 16) * 64 + lane;        \
+    uint4 fr[2][4];                                                                                            \
+    if constexpr (GLUQ) {                                                                                      \
+      F3_MFMA_DRAIN();                                                                                         \
+      if constexpr (!no_dma) { f3_wait_vm_for<26>(hp[4 * (RTQ)], hp[4 * (RTQ) + 1], hp[4 * (RTQ) + 2], hp[4 * (RTQ) + 3]); } \
+      else { f3_wait_vm_for<0>(hp[4 * (RTQ)], hp[4 * (RTQ) + 1], hp[4 * (RTQ) + 2], hp[4 * (RTQ) + 3]); }      \
+    }                                                                                                          \
+    if constexpr (X) {                                                                                         \
+      _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) fr[0][ct] = wb[(ct * 4 + 0) * 64];                      \
+    }                                                                                                          \
+    _Pragma("unroll") for (int j4 = 0; j4 < 4; ++j4) {                                                         \
+      if constexpr (X) {                                                                                       \
+        if (j4 + 1 < 4) {                                                                                      \
+          _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) fr[(j4 + 1) & 1][ct] = wb[(ct * 4 + j4 + 1) * 64];  \
+        }                                                                                                      \
+      }                                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      if constexpr (X) {                                                                                       \
+        _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) {                                                     \
+          mma32(xacc[0][ct], fr[j4 & 1][ct], DHF[0][j4]);                                                      \
+          mma32(xacc[1][ct], fr[j4 & 1][ct], DHF[1][j4]);                                                      \
+        }                                                                                                      \
+      }                                                                                                        \
+      if constexpr (GLUQ) {                                                                                    \
+        if (j4 == 0) F3B_GLU(RTQ, 0, NDH)                                                                      \
+        if (j4 == 2) F3B_GLU(RTQ, 1, NDH)                                                                      \
+        if (j4 == 3) F3B_STORE_LOAD(RTQ, CH, NDH)                                                              \
+      }                                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      if constexpr (GLUQ) { F3B_ISSUE2(j4) }                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+  } else if constexpr (GLUQ) {                                                                                 \
+    _Pragma("unroll") for (int j4 = 0; j4 < 4; ++j4) { F3B_ISSUE2(j4) }                                        \
+  }
+#define F3B_READ_PARTNER()                                                                                     \
+  _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                             \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) dhp[rt][k] = partner_h[(rt * 4 + k) * 64];
+
+  // per-phase global traffic (DMAs + dh stores + tile loads): D 8, X 16.  A phase end keeps what was issued after the last DMA
+  // of the next phase's group = the two phases in between (ffn3_fwd_kernel); the very first one sees the prologue's groups
+  int slot = 0;
+  uint4 dhn[2][4];                                               // the fragments the GLU' of this iteration produces
+  // ---- chunk 0: D, then GLU' only
+  F3B_PHASE_D(slot)
+  F3B_PHASE_END(16)
+  F3B_PHASE_X(false, true, slot, dho, 0, 0, dhn)
+  F3B_PHASE_END(24)
+  F3B_PHASE_X(false, true, slot, dhp, 1, 0, dhn)
+  F3B_PHASE_END(32)
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dho[rt][k] = dhn[rt][k];
+  // ---- chunks 1 .. NC-1
+  for (int C = 1; C < NC; ++C) {
+    F3B_READ_PARTNER()                                           // dh of chunk C-1 (written before the barriers of its X phases)
+    F3B_PHASE_D(slot)
+    F3B_PHASE_END(24)
+    F3B_PHASE_X(true, true, slot, dho, 0, C, dhn)
+    F3B_PHASE_END(24)
+    F3B_PHASE_X(true, true, slot, dhp, 1, C, dhn)
+    F3B_PHASE_END(32)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dho[rt][k] = dhn[rt][k];
+  }
+  // ---- closing phases: XA, XB of the last chunk (no DMA, no global traffic: only the last X phase's 16 may still fly)
+  F3B_READ_PARTNER()
+  F3B_PHASE_X(true, false, slot, dho, 0, 0, dhn)
+  if constexpr (no_dma) f3_wait_vm<0>(); else f3_wait_vm<16>();
+  f3_wait_lds();
+  f3_barrier();
+  slot = (slot + 1) & 3;
+  F3B_PHASE_X(true, false, slot, dhp, 1, 0, dhn)
+#undef F3B_ISSUE2
+#undef F3B_PHASE_D
+#undef F3B_PHASE_END
+#undef F3B_GLU
+#undef F3B_STORE_LOAD
+#undef F3B_PHASE_X
+#undef F3B_READ_PARTNER
+  f3_wait_vm_for<0>(hp[0], hp[1], hp[2], hp[3]);                 // the last (unused) tile reloads land in registers that stay
+  f3_wait_vm_for<0>(hp[4], hp[5], hp[6], hp[7]);                 // theirs until here; everything else has drained too
+  f3_wait_lds();
+  f3_barrier();
+
+  // ---- exchange the four partial input gradients of the row block; this workgroup finishes quarter `sl`: dx = skip + sum
+  float* own = reinterpret_cast<float*>(ring);
+  auto rs = __builtin_amdgcn_make_buffer_rsrc(p.scratch + (int64_t)rb * (4 * 4 * 8192), 0, 4 * 4 * 32768, 0x00020000);
+  f3_send_partials(xacc, rs, own, sl, wr, wc, lane);
+  const int64_t row = (int64_t)rb * 128 + 32 * sl + m;
+  const bool live = row < p.M;
+  const int64_t crow = live ? row : (int64_t)p.M - 1;
+  float4 sk[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      sk[t][q] = p.skip ? *reinterpret_cast<const float4*>(p.skip + crow * D + 32 * (2 * wid + t) + 8 * q + 4 * hi)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+  f3_wait_vm<0>();
+  f3_wait_lds();
+  f3_barrier();
+  if (tid == 0) f3_arrive_wait(p.sync + 2 * rb, p.spin_limit, p.fault);
+  f3_barrier();
+  otr_u32x4 part[3][2][4];
+  f3_recv_partials(part, rs, sl, wid, lane);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 o = *reinterpret_cast<const float4*>(own + (((2 * wid + t) * 4 + q) * 64 + lane) * 4);
+      float4 v = make_float4(sk[t][q].x + o.x, sk[t][q].y + o.y, sk[t][q].z + o.z, sk[t][q].w + o.w);
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        v.x += __uint_as_float(part[n][t][q].x); v.y += __uint_as_float(part[n][t][q].y);
+        v.z += __uint_as_float(part[n][t][q].z); v.w += __uint_as_float(part[n][t][q].w);
+      }
+      if (live) *reinterpret_cast<float4*>(p.dx + row * D + 32 * (2 * wid + t) + 8 * q + 4 * hi) = v;
+    }
+  if (tid == 0) f3_done(p.sync + 2 * rb);
 }
 
 }  // namespace
@@ -510,12 +905,12 @@ static inline unsigned f3_grid(int64_t M, int S) {
 extern int g_otr_spin_limit;
 extern int32_t* g_otr_fault;
 
-#define F3_LAUNCH_FWD(FUSE)                                                                                              \
+#define F3_LAUNCH_FWD(FUSE, SAVE)                                                                                        \
   switch (g_otr_ffn2_ablate & 3) {                                                                                       \
-    case 0: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 0, FUSE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
-    case 1: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 1, FUSE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
-    case 2: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 2, FUSE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
-    default: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 3, FUSE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;  \
+    case 0: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 0, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
+    case 1: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 1, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
+    case 2: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 2, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
+    default: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 3, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;  \
   }
 
 int32_t ffn3_fwd_launch(const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, float* slabs, int32_t S, int64_t M,
@@ -523,26 +918,44 @@ int32_t ffn3_fwd_launch(const void* x16, const void* w1_pack, const float* b1, c
   Ffn3FwdArgs p{};
   p.x16 = (const uint16_t*)x16; p.p1 = (const uint4*)w1_pack; p.b1 = b1; p.p2 = (const uint4*)w2_pack; p.slabs = slabs;
   p.M = (int)M; p.F = F; p.S = S;
-  F3_LAUNCH_FWD(false)
+  F3_LAUNCH_FWD(false, false)
   return otr_check_launch("ffn3_fwd");
 }
 
-// scratch bytes / sync ints of the fused form for M rows (S = 4)
+// scratch bytes / sync ints of the fused form for M rows (S = 4); bytes of the saved (value, sigmoid) tiles; padded rows of u / dh
 int64_t ffn3_scratch_bytes(int64_t M) { return ((M + 127) / 128) * (int64_t)(4 * 4 * 32768); }
+int64_t ffn3_hsave_bytes(int64_t M, int32_t F) { return ((M + 127) / 128) * 128 * (int64_t)F * 4; }
+int64_t ffn3_padded_rows(int64_t M) { return ((M + 127) / 128) * 128; }
 int64_t ffn3_sync_ints(int64_t M) { return 2 * ((M + 127) / 128); }
 
 int32_t ffn3_ln_fwd_launch(const float* x, const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, const float* b2,
                            const float* gamma, const float* beta, const uint64_t* seed, float p_drop, uint64_t rng_offset, float eps,
-                           float* y, void* y16, float* z, float* mean, float* rstd, float* scratch, int32_t* sync, int64_t M, int32_t F,
-                           hipStream_t stream) {
+                           float* y, void* y16, float* z, float* mean, float* rstd, void* hsave, void* usave, float* scratch,
+                           int32_t* sync, int64_t M, int32_t F, hipStream_t stream) {
   constexpr int S = 4;
   Ffn3FwdArgs p{};
   p.x16 = (const uint16_t*)x16; p.p1 = (const uint4*)w1_pack; p.b1 = b1; p.p2 = (const uint4*)w2_pack; p.slabs = scratch;
   p.M = (int)M; p.F = F; p.S = S;
   p.x = x; p.b2 = b2; p.gamma = gamma; p.beta = beta; p.seed = seed; p.y = y; p.y16 = (uint16_t*)y16; p.z = z; p.mean = mean; p.rstd = rstd;
   p.sync = sync; p.fault = g_otr_fault; p.spin_limit = g_otr_spin_limit; p.eps = eps; p.p_drop = p_drop; p.rng_offset = rng_offset;
-  F3_LAUNCH_FWD(true)
+  p.hsave = (uint4*)hsave; p.usave = (uint16_t*)usave;
+  if (hsave) { F3_LAUNCH_FWD(true, true) } else { F3_LAUNCH_FWD(true, false) }
   return otr_check_launch("ffn3_ln_fwd");
+}
+
+int32_t ffn3_bwd_launch(const void* dy16, const void* hsave, const void* w2t_pack, const void* w1t_pack, void* dh, const float* skip,
+                        float* dx, float* scratch, int32_t* sync, int64_t M, int32_t F, hipStream_t stream) {
+  Ffn3BwdArgs p{};
+  p.dy16 = (const uint16_t*)dy16; p.hsave = (const uint4*)hsave; p.p3 = (const uint4*)w2t_pack; p.p4 = (const uint4*)w1t_pack;
+  p.dh = (uint16_t*)dh; p.skip = skip; p.dx = dx; p.scratch = scratch; p.sync = sync; p.fault = g_otr_fault;
+  p.spin_limit = g_otr_spin_limit; p.M = (int)M; p.F = F;
+  switch (g_otr_ffn2_ablate & 3) {
+    case 0: hipLaunchKernelGGL((ffn3_bwd_kernel<256, 0>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p); break;
+    case 1: hipLaunchKernelGGL((ffn3_bwd_kernel<256, 1>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((ffn3_bwd_kernel<256, 2>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p); break;
+    default: hipLaunchKernelGGL((ffn3_bwd_kernel<256, 3>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p); break;
+  }
+  return otr_check_launch("ffn3_bwd");
 }
 
 // 1 when the 128-row kernels take this (hidden size, split): whole 64-unit chunks per slice, biases fit their LDS staging

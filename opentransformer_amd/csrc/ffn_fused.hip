@@ -560,10 +560,14 @@ int32_t ffn3_fwd_launch(const void* x16, const void* w1_pack, const float* b1, c
                         int32_t F, hipStream_t stream);
 int64_t ffn3_scratch_bytes(int64_t M);
 int64_t ffn3_sync_ints(int64_t M);
+int64_t ffn3_hsave_bytes(int64_t M, int32_t F);
+int64_t ffn3_padded_rows(int64_t M);
 int32_t ffn3_ln_fwd_launch(const float* x, const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, const float* b2,
                            const float* gamma, const float* beta, const uint64_t* seed, float p_drop, uint64_t rng_offset, float eps,
-                           float* y, void* y16, float* z, float* mean, float* rstd, float* scratch, int32_t* sync, int64_t M, int32_t F,
-                           hipStream_t stream);
+                           float* y, void* y16, float* z, float* mean, float* rstd, void* hsave, void* usave, float* scratch,
+                           int32_t* sync, int64_t M, int32_t F, hipStream_t stream);
+int32_t ffn3_bwd_launch(const void* dy16, const void* hsave, const void* w2t_pack, const void* w1t_pack, void* dh, const float* skip,
+                        float* dx, float* scratch, int32_t* sync, int64_t M, int32_t F, hipStream_t stream);
 extern int g_otr_ffn_waves;   // tuning hook (otr_debug_set(5, v)): 8 = the 8-wave form of the forward kernel, anything else = 4 waves
 static int32_t ffn_shape_check(const char* who, int64_t M, int32_t F, int32_t d_model) {
   OTR_REQUIRE(M >= 0 && M < (1ll << 31), "%s: bad M", who);
@@ -599,22 +603,39 @@ extern "C" int32_t otr_ffn_ln_fwd(const float* x, const void* x16, const void* w
 extern "C" int64_t otr_ffn_split_scratch_bytes(int64_t M) { return M > 0 ? ffn3_scratch_bytes(M) : 0; }
 extern "C" int64_t otr_ffn_split_sync_ints(int64_t M) { return M > 0 ? ffn3_sync_ints(M) : 0; }
 
+extern "C" int64_t otr_ffn_split_hsave_bytes(int64_t M, int32_t F) { return M > 0 && F > 0 ? ffn3_hsave_bytes(M, F) : 0; }
+extern "C" int64_t otr_ffn_split_padded_rows(int64_t M) { return M > 0 ? ffn3_padded_rows(M) : 0; }
+
 extern "C" int32_t otr_ffn_ln_fwd_split(const float* x, const void* x16, const void* w1_pack, const float* b1, const void* w2_pack,
                                         const float* b2, const float* gamma, const float* beta, const uint64_t* seed, float p_drop,
                                         uint64_t rng_offset, float eps, float* y, void* y16, float* z, float* mean, float* rstd,
-                                        void* scratch, int64_t scratch_bytes, int32_t* sync, int64_t sync_ints, int64_t M, int32_t F,
-                                        int32_t d_model, void* stream) {
+                                        void* hsave, void* usave, void* scratch, int64_t scratch_bytes, int32_t* sync,
+                                        int64_t sync_ints, int64_t M, int32_t F, int32_t d_model, void* stream) {
   if (int32_t e = ffn_shape_check("ffn_ln_fwd_split", M, F, d_model)) return e;
   OTR_REQUIRE(ffn3_takes(F, 4), "ffn_ln_fwd_split: d_ff = %d does not split into 4 slices of whole 64-unit chunks", F);
   OTR_REQUIRE(x && x16 && w1_pack && b1 && w2_pack && b2 && gamma && beta && y && mean && rstd && scratch && sync, "ffn_ln_fwd_split: null pointer");
+  OTR_REQUIRE((hsave == nullptr) == (usave == nullptr), "ffn_ln_fwd_split: hsave and usave come together");
   OTR_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed), "ffn_ln_fwd_split: bad dropout arguments");
   OTR_REQUIRE(((uintptr_t)x16 | (uintptr_t)w1_pack | (uintptr_t)w2_pack | (uintptr_t)x | (uintptr_t)y | (uintptr_t)b1 | (uintptr_t)b2 |
-               (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)scratch | (uintptr_t)z | (uintptr_t)y16) % 16 == 0,
+               (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)scratch | (uintptr_t)z | (uintptr_t)y16 | (uintptr_t)hsave | (uintptr_t)usave) % 16 == 0,
               "ffn_ln_fwd_split: buffers must be 16-byte aligned");
   OTR_REQUIRE(scratch_bytes >= ffn3_scratch_bytes(M) && sync_ints >= ffn3_sync_ints(M), "ffn_ln_fwd_split: scratch / sync too small");
   if (M == 0) return 0;
   return ffn3_ln_fwd_launch(x, x16, w1_pack, b1, w2_pack, b2, gamma, beta, seed, p_drop, rng_offset, eps, y, y16, z, mean, rstd,
-                            (float*)scratch, sync, M, F, (hipStream_t)stream);
+                            hsave, usave, (float*)scratch, sync, M, F, (hipStream_t)stream);
+}
+
+extern "C" int32_t otr_ffn_bwd_split(const void* dy16, const void* hsave, const void* w2t_pack, const void* w1t_pack, void* dh,
+                                     const float* skip, float* dx, void* scratch, int64_t scratch_bytes, int32_t* sync,
+                                     int64_t sync_ints, int64_t M, int32_t F, int32_t d_model, void* stream) {
+  if (int32_t e = ffn_shape_check("ffn_bwd_split", M, F, d_model)) return e;
+  OTR_REQUIRE(ffn3_takes(F, 4), "ffn_bwd_split: d_ff = %d does not split into 4 slices of whole 64-unit chunks", F);
+  OTR_REQUIRE(dy16 && hsave && w2t_pack && w1t_pack && dh && dx && scratch && sync, "ffn_bwd_split: null pointer");
+  OTR_REQUIRE(((uintptr_t)dy16 | (uintptr_t)hsave | (uintptr_t)w2t_pack | (uintptr_t)w1t_pack | (uintptr_t)dh | (uintptr_t)skip |
+               (uintptr_t)dx | (uintptr_t)scratch) % 16 == 0, "ffn_bwd_split: buffers must be 16-byte aligned");
+  OTR_REQUIRE(scratch_bytes >= ffn3_scratch_bytes(M) && sync_ints >= ffn3_sync_ints(M), "ffn_bwd_split: scratch / sync too small");
+  if (M == 0) return 0;
+  return ffn3_bwd_launch(dy16, hsave, w2t_pack, w1t_pack, dh, skip, dx, (float*)scratch, sync, M, F, (hipStream_t)stream);
 }
 
 extern "C" int32_t otr_ffn_bwd(const void* x16, const void* dy16, const void* w1_pack, const float* b1, const void* w2t_pack,

@@ -1256,15 +1256,21 @@ class FfnLnFn(torch.autograd.Function):
         S = _ffn_slabs(M, F)
         ctx.S = S
         ctx.split = _ffn_split(M, F)
+        hsave = usave = None
         if ctx.split:
             lib = L.load()
             nb = lib.otr_ffn_split_scratch_bytes(M)
             scratch = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
             sync = _ffn_sync(x.device)
-            L.check(_timed('ffn_ln_fwd_split', {'flops': 6.0 * M * F * d, 'bytes': M * d * (4 + 2 + 4 + 2 + 4) + 6 * F * d},
+            if need_grad:       # what the backward kernel reads back instead of recomputing the hidden (csrc/ffn3.hip)
+                hsave = torch.empty(lib.otr_ffn_split_hsave_bytes(M, F) // 2, dtype=x16.dtype, device=x.device)
+                usave = torch.empty((lib.otr_ffn_split_padded_rows(M), F), dtype=x16.dtype, device=x.device)
+            L.check(_timed('ffn_ln_fwd_split', {'flops': 6.0 * M * F * d,
+                                                'bytes': M * d * (4 + 2 + 4 + 2 + 4) + 6 * F * d + (M * F * 6 if need_grad else 0)},
                            lambda: lib.otr_ffn_ln_fwd_split(_p(x2), _p(x16), _p(packs[0]), _p(b1), _p(packs[1]), _p(b2), _p(gamma),
                                                             _p(beta), _p(seed), p_drop, off, eps, _p(y), _p(y16), _p(z), _p(mean),
-                                                            _p(rstd), _p(scratch), nb, _p(sync), sync.numel(), M, F, d, _stream())),
+                                                            _p(rstd), _p(hsave), _p(usave), _p(scratch), nb, _p(sync), sync.numel(),
+                                                            M, F, d, _stream())),
                     'otr_ffn_ln_fwd_split')
         elif S:     # v2: weight stream shared by 128 rows through LDS, hidden units split over S workgroups, LayerNorm sums the slabs
             lib = L.load()
@@ -1281,7 +1287,7 @@ class FfnLnFn(torch.autograd.Function):
                            lambda: L.load().otr_ffn_ln_fwd(_p(x2), _p(x16), _p(packs[0]), _p(b1), _p(packs[1]), _p(b2), _p(gamma),
                                                            _p(beta), _p(seed), p_drop, off, eps, _p(y), _p(y16), _p(z), _p(mean),
                                                            _p(rstd), M, F, d, _stream())), 'otr_ffn_ln_fwd')
-        ctx.save_for_backward(x16, z, mean, rstd, gamma, seed, b1)
+        ctx.save_for_backward(x16, z, mean, rstd, gamma, seed, b1, hsave, usave)
         ctx.packs = packs
         ctx.refs = (w1, b1, w2, b2, gamma, beta)
         ctx.cfg = (M, d, F, eps, p_drop, off, x.shape)
@@ -1293,7 +1299,7 @@ class FfnLnFn(torch.autograd.Function):
     def backward(ctx, dy, _dy16=None):
         if dy is None:
             return (None,) * 10
-        x16, z, mean, rstd, gamma, seed, b1 = ctx.saved_tensors
+        x16, z, mean, rstd, gamma, seed, b1, hsave, usave = ctx.saved_tensors
         M, d, F, eps, p_drop, off, xshape = ctx.cfg
         w1p, b1p, w2p, b2p, gp, bp = ctx.refs
         P1, _, P3, P4 = ctx.packs
@@ -1331,6 +1337,21 @@ class FfnLnFn(torch.autograd.Function):
                 gb2.add_(dgb[2])
             else:
                 ret_b2 = dgb[2]
+        if ctx.split and hsave is not None:
+            # 128-row workgroups, the hidden read back from the forward pass's tiles: dh for the w_1 weight gradient; dx += dh . w_1
+            nb = lib.otr_ffn_split_scratch_bytes(M)
+            scratch = torch.empty(nb // 4, dtype=torch.float32, device=dy.device)
+            sync = _ffn_sync(dy.device)
+            dh = torch.empty((usave.shape[0], 2 * F), dtype=x16.dtype, device=dy.device)[:M]
+            L.check(_timed('ffn_bwd_split', {'flops': 6.0 * M * F * d, 'bytes': M * d * (2 + 4 + 4) + M * F * 8 + 6 * F * d},
+                           lambda: lib.otr_ffn_bwd_split(_p(da), _p(hsave), _p(P3), _p(P4), _p(dh), _p(dx), _p(dx), _p(scratch), nb,
+                                                         _p(sync), sync.numel(), M, F, d, _stream())), 'otr_ffn_bwd_split')
+            gw1, gb1, gw2 = grad_target(w1p), grad_target(b1p), grad_target(w2p)
+            dw1 = linear_wgrad_raw(dh, x16, None, out=gw1)
+            dw2 = linear_wgrad_raw(da, usave[:M], None, out=gw2)
+            db1 = colsum_raw(dh, out=gb1)               # rides along with the w_1 weight-gradient launch (same matrix)
+            return (dx.view(xshape), None if gw1 is not None else dw1, None if gb1 is not None else db1,
+                    None if gw2 is not None else dw2, ret_b2, ret_g, ret_b, None, None, None)
         # FFN backward with recompute: dh, u for the weight gradients; dx += dh . w_1
         dh = torch.empty((M, 2 * F), dtype=x16.dtype, device=dy.device)
         u = torch.empty((M, F), dtype=x16.dtype, device=dy.device)

@@ -65,9 +65,20 @@ def main():
     scratch = torch.empty(nb // 4, device=dev)
     sync = ops._ffn_sync(torch.device('cuda', torch.cuda.current_device()))
 
-    def fwd3(pd):
+    hsave = torch.empty(lib.otr_ffn_split_hsave_bytes(M, F) // 2, dtype=hdt, device=dev)
+    mp = lib.otr_ffn_split_padded_rows(M)
+    usave = torch.empty(mp, F, dtype=hdt, device=dev)
+    dh3 = torch.empty(mp, 2 * F, dtype=hdt, device=dev)
+    dx3 = torch.zeros(M, d, device=dev)
+
+    def fwd3(pd, save=False):
         L.check(lib.otr_ffn_ln_fwd_split(p(x), p(x16), p(P[0]), p(b1), p(P[1]), p(b2), p(gamma), p(beta), p(seed), pd, 0, 1e-5, p(y), p(y16),
-                                         p(z), p(mean), p(rstd), p(scratch), nb, p(sync), sync.numel(), M, F, d, st()), 'fwd3')
+                                         p(z), p(mean), p(rstd), p(hsave) if save else None, p(usave) if save else None, p(scratch), nb,
+                                         p(sync), sync.numel(), M, F, d, st()), 'fwd3')
+
+    def bwd3():
+        L.check(lib.otr_ffn_bwd_split(p(da), p(hsave), p(P[2]), p(P[3]), p(dh3), None, p(dx3), p(scratch), nb, p(sync), sync.numel(),
+                                      M, F, d, st()), 'bwd3')
 
     def bwd2():
         L.check(lib.otr_ffn_bwd_slabs(p(x16), p(da), p(P[0]), p(b1), p(P[2]), p(P[3]), p(dh), p(u), p(bpart), p(slabs), S, M, F, d, st()), 'bwd2')
@@ -109,11 +120,24 @@ def main():
     fwd3(0.0)
     res['split_vs_v1_y_rel'] = float((y - y1).norm() / y1.norm())
     res['split_sync_left'] = int(sync.abs().sum().item())
+    res['split_fwd_save_us'] = timeit(lambda: fwd3(0.0, True), a.iters)
+    res['split_bwd_us'] = timeit(bwd3, a.iters)
+    # parity of the split backward (saved tiles) against the 32-row kernel (recompute): dx without skip, dh, u
+    dxz = torch.zeros(M, d, device=dev)
+    L.check(lib.otr_ffn_bwd(p(x16), p(da), p(P[0]), p(b1), p(P[2]), p(P[3]), p(dh), p(u), p(bpart), None, p(dxz), M, F, d, st()), 'bwd')
+    fwd3(0.0, True)
+    bwd3()
+    res['split_vs_v1_dx_rel'] = float((dx3 - dxz).norm() / dxz.norm())
+    res['split_vs_v1_dh_rel'] = float((dh3[:M].float() - dh.float()).norm() / dh.float().norm())
+    res['split_vs_v1_u_rel'] = float((usave[:M].float() - u.float()).norm() / u.float().norm())
+    res['split_sync_left'] = int(sync.abs().sum().item())
     for ab in (1, 2, 3):
         lib.otr_debug_set(4, ab)
         res['split_fwd_ablate%d_us' % ab] = timeit(lambda: fwd3(0.0), a.iters)
+        res['split_bwd_ablate%d_us' % ab] = timeit(bwd3, a.iters)
     lib.otr_debug_set(4, 0)
     res['split_fwd_tflops'] = 2.0 * M * 3 * F * d / res['split_fwd_us'] / 1e6
+    res['split_bwd_tflops'] = 2.0 * M * 3 * F * d / res['split_bwd_us'] / 1e6
     if S:
         res['slabs'] = S
         res['ln_slabs_us'] = timeit(ln2, a.iters)
