@@ -371,7 +371,11 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                             \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) upart[rt][j] = partner_u[(rt * 2 + j) * 64];
 
-  constexpr int KG = SAVE ? 12 : 0;                              // global stores of a G phase (F3_PHASE_G: 8 h pieces + 4 u pieces)
+  // Stores do NOT retire in issue order with loads (measured: with the 12 stores of a G phase added to the count, ring slots were
+  // read before their DMA had landed -- 0.5 % wrong outputs): a store is acknowledged by the L2 long before an older LDS-DMA
+  // returns.  Loads retire in order among themselves, so the count keeps the 16 YOUNGER LOADS only; the stores in flight merely
+  // make the wait a little longer than needed.
+  constexpr int KG = 0;
   int slot = 0;                                                  // ring slot of the current phase (phase index mod 4)
   // ---- chunk 0: A, B, GLU only
   F3_BIAS_INIT(wc)
@@ -771,7 +775,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
     uint4 fr[2][4];                                                                                            \
     if constexpr (GLUQ) {                                                                                      \
       F3_MFMA_DRAIN();                                                                                         \
-      if constexpr (!no_dma) { f3_wait_vm_for<26>(hp[4 * (RTQ)], hp[4 * (RTQ) + 1], hp[4 * (RTQ) + 2], hp[4 * (RTQ) + 3]); } \
+      if constexpr (!no_dma) { f3_wait_vm_for<22>(hp[4 * (RTQ)], hp[4 * (RTQ) + 1], hp[4 * (RTQ) + 2], hp[4 * (RTQ) + 3]); } \
       else { f3_wait_vm_for<0>(hp[4 * (RTQ)], hp[4 * (RTQ) + 1], hp[4 * (RTQ) + 2], hp[4 * (RTQ) + 3]); }      \
     }                                                                                                          \
     if constexpr (X) {                                                                                         \
@@ -806,17 +810,19 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                             \
     _Pragma("unroll") for (int k = 0; k < 4; ++k) dhp[rt][k] = partner_h[(rt * 4 + k) * 64];
 
-  // per-phase global traffic (DMAs + dh stores + tile loads): D 8, X 16.  A phase end keeps what was issued after the last DMA
-  // of the next phase's group = the two phases in between (ffn3_fwd_kernel); the very first one sees the prologue's groups
+  // Counted waits (ffn3_fwd_kernel: loads retire in issue order, stores do not count on).  A phase end keeps 16: the DMAs of
+  // the two phases after the next phase's group -- also right if the tile loads (4 per X phase, HBM) retired late or early.
+  // The tile loads themselves are waited for at the start of the X phase that consumes them with the 22 loads issued after
+  // them kept (2 + 12 + 8: the rest of their phase, an X phase, a D phase)
   int slot = 0;
   uint4 dhn[2][4];                                               // the fragments the GLU' of this iteration produces
   // ---- chunk 0: D, then GLU' only
   F3B_PHASE_D(slot)
   F3B_PHASE_END(16)
   F3B_PHASE_X(false, true, slot, dho, 0, 0, dhn)
-  F3B_PHASE_END(24)
+  F3B_PHASE_END(16)
   F3B_PHASE_X(false, true, slot, dhp, 1, 0, dhn)
-  F3B_PHASE_END(32)
+  F3B_PHASE_END(16)
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -825,11 +831,11 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   for (int C = 1; C < NC; ++C) {
     F3B_READ_PARTNER()                                           // dh of chunk C-1 (written before the barriers of its X phases)
     F3B_PHASE_D(slot)
-    F3B_PHASE_END(24)
+    F3B_PHASE_END(16)
     F3B_PHASE_X(true, true, slot, dho, 0, C, dhn)
-    F3B_PHASE_END(24)
+    F3B_PHASE_END(16)
     F3B_PHASE_X(true, true, slot, dhp, 1, C, dhn)
-    F3B_PHASE_END(32)
+    F3B_PHASE_END(16)
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -838,7 +844,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   // ---- closing phases: XA, XB of the last chunk (no DMA, no global traffic: only the last X phase's 16 may still fly)
   F3B_READ_PARTNER()
   F3B_PHASE_X(true, false, slot, dho, 0, 0, dhn)
-  if constexpr (no_dma) f3_wait_vm<0>(); else f3_wait_vm<16>();
+  if constexpr (no_dma) f3_wait_vm<0>(); else f3_wait_vm<8>();    // of the last X phase: its 4 tile reloads + 4 of its DMAs at most
   f3_wait_lds();
   f3_barrier();
   slot = (slot + 1) & 3;
