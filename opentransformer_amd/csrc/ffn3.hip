@@ -49,14 +49,17 @@ __device__ __forceinline__ void f3_barrier() {
 // file ("a": it is an MFMA operand only).  With the builtin hipcc keeps both operands in VGPRs; the 128 registers of x then
 // overflow the 256 architectural VGPRs and are shuttled through AGPRs (160 v_accvgpr moves per 32 MFMAs in the first build).
 // Hazards (hipcc pads nothing inside asm, cdna_hip_programming.md 5.7): the accumulate chain D -> C of the next MFMA needs no
-// wait states; the VALU readers of the result sit behind a barrier and an explicit s_nop (F3_MFMA_DRAIN).
+// wait states; the VALU readers of the result sit behind a barrier and an explicit s_nop (F3_MFMA_DRAIN); and every statement
+// opens with `s_nop 1`: hipcc is free to place a VALU write of an operand (a register copy of the bias-initialised
+// accumulator, seen in one build: the first chunk's row tile 0 came out wrong) directly in front of the statement, and a VALU
+// write -> MFMA read needs two wait states.  Inside a back-to-back MFMA stream the two states hide behind the busy pipe.
 #ifdef OTR_HALF_FP16
 #define F3_MFMA_OP "v_mfma_f32_32x32x16_f16"
 #else
 #define F3_MFMA_OP "v_mfma_f32_32x32x16_bf16"
 #endif
 __device__ __forceinline__ void f3_mma_xa(f32x16& acc, const otr_u32x4& w, const otr_u32x4& x_acc) {
-  asm volatile(F3_MFMA_OP " %0, %1, %2, %0" : "+v"(acc) : "v"(w), "a"(x_acc));
+  asm volatile("s_nop 1\n\t" F3_MFMA_OP " %0, %1, %2, %0" : "+v"(acc) : "v"(w), "a"(x_acc));
 }
 #define F3_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")   /* >= 12 wait states: MFMA result -> VALU reader */
 
@@ -592,7 +595,7 @@ template <int N> __device__ __forceinline__ void f3_wait_vm_for(otr_u32x4& a, ot
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
 __device__ __forceinline__ void f3_mma_acc(f32x16& acc, const otr_u32x4& w, const otr_u32x4& b_acc) {
-  asm volatile(F3_MFMA_OP " %0, %1, %2, %0" : "+v"(acc) : "v"(w), "a"(b_acc));
+  asm volatile("s_nop 1\n\t" F3_MFMA_OP " %0, %1, %2, %0" : "+v"(acc) : "v"(w), "a"(b_acc));
 }
 __device__ __forceinline__ float f3_h2f_lo(uint32_t w) { return h2f_lo(w); }
 
