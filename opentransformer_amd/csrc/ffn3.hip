@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) uown[rt][j] = upart[rt][j] = make_uint4(0u, 0u, 0u, 0u);
 
-  constexpr bool no_dma = (ABL & 1) != 0, no_mma = (ABL & 2) != 0;   // ablations are compile-time: a run-time flag would split
+  constexpr bool no_dma = (ABL & 1) != 0, no_mma = (ABL & 2) != 0, no_st = (ABL & 4) != 0;   // ablations are compile-time: a run-time flag would split
   // the G phase into basic blocks, and hipcc interleaves the GLU's VALU code with the MFMAs only inside one block
   uint4* my_u = reinterpret_cast<uint4*>(ubuf) + ((wr * 2 + wc) * 4) * 64 + lane;
   const uint4* partner_u = reinterpret_cast<const uint4*>(ubuf) + ((wr * 2 + (wc ^ 1)) * 4) * 64 + lane;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
         const uint4 nu = make_uint4(pack2h(u[0], u[1]), pack2h(u[2], u[3]), pack2h(u[4], u[5]), pack2h(u[6], u[7])); \
         uown[rt][kk & 1] = nu;               /* kept for GEMM2 of this chunk one iteration later ... */            \
         my_u[(rt * 2 + (kk & 1)) * 64] = nu; /* ... and handed to the partner wave */                            \
-        if constexpr (SAVE) {                /* 2 (+ 2 on odd quarters) global stores: F3_SAVE_STORES per G phase */ \
+        if constexpr (SAVE && !no_st) {      /* 2 (+ 2 on odd quarters) global stores per quarter */               \
           uint4* hs = p.hsave + ((int64_t)(((rb * 4 + sl) * NC + (CHUNK)) * 4 + wid) * 8) * 64 + lane;         \
           st_global_b128(hs + (rt * 2 + (kk & 1)) * 64,                                                        \
                          make_uint4(pack2h(hv[rt][j0], hv[rt][j0 + 1]), pack2h(hv[rt][j0 + 2], hv[rt][j0 + 3]), \
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   const int row0 = rb * 128 + wr * 64;
   const int nchunk = p.F / 32, per = nchunk / 4, NC = per >> 1;
   const int c_base = sl * per;
-  constexpr bool no_dma = (ABL & 1) != 0, no_mma = (ABL & 2) != 0;
+  constexpr bool no_dma = (ABL & 1) != 0, no_mma = (ABL & 2) != 0, no_st = (ABL & 4) != 0, no_hl = (ABL & 8) != 0;
 
   // ---- DMA schedule (see ffn3_fwd_kernel).  Phase 3C + k: k = 0: D(C) = w_2^T of chunk C (fragment f = ks*2 + wcc); k = 1 / 2:
   // XA / XB of chunk C-1 = w_1^T fragments for the OWN / PARTNER step: f = (wcc*4 + ctl)*4 + j4 -- column tile 4 wcc + ctl,
@@ -766,9 +766,11 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
 #define F3B_STORE_LOAD(RT, CH, NDH)                                                                            \
   {                                                                                                            \
     uint16_t* dr = p.dh + ((int64_t)row0 + 32 * (RT) + m) * (2 * (int64_t)p.F) + (c_base + 2 * (CH) + wc) * 32; \
-    store_tile_row(dr, NDH[RT][0], NDH[RT][1], hi, true);                                                      \
-    store_tile_row(dr + p.F, NDH[RT][2], NDH[RT][3], hi, true);                                                \
-    hload((CH) + 1 < NC ? (CH) + 1 : (CH), RT);          /* past the end: a reload of valid tiles, never used */  \
+    if constexpr (!no_st) {                                                                                    \
+      store_tile_row(dr, NDH[RT][0], NDH[RT][1], hi, true);                                                    \
+      store_tile_row(dr + p.F, NDH[RT][2], NDH[RT][3], hi, true);                                              \
+    }                                                                                                          \
+    if constexpr (!no_hl) hload((CH) + 1 < NC ? (CH) + 1 : (CH), RT);   /* past the end: a reload of valid tiles, never used */ \
   }
   // X phase: 32 MFMAs in 4 steps (j4) of 8 over w_1^T fragments [(wc*4 + ctl)*4 + j4] with the dh fragments DHF[rt][j4], the GLU'
   // quarters Q0 / Q1 (row tile RTQ) of chunk CH beside steps 0-1 / 2-3
@@ -778,7 +780,8 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
     uint4 fr[2][4];                                                                                            \
     if constexpr (GLUQ) {                                                                                      \
       F3_MFMA_DRAIN();                                                                                         \
-      if constexpr (!no_dma) { f3_wait_vm_for<22>(hp[4 * (RTQ)], hp[4 * (RTQ) + 1], hp[4 * (RTQ) + 2], hp[4 * (RTQ) + 3]); } \
+      if constexpr (!no_dma && !no_hl) { f3_wait_vm_for<22>(hp[4 * (RTQ)], hp[4 * (RTQ) + 1], hp[4 * (RTQ) + 2], hp[4 * (RTQ) + 3]); } \
+      else if constexpr (no_hl) { }                                                                            \
       else { f3_wait_vm_for<0>(hp[4 * (RTQ)], hp[4 * (RTQ) + 1], hp[4 * (RTQ) + 2], hp[4 * (RTQ) + 3]); }      \
     }                                                                                                          \
     if constexpr (X) {                                                                                         \
@@ -915,10 +918,11 @@ extern int g_otr_spin_limit;
 extern int32_t* g_otr_fault;
 
 #define F3_LAUNCH_FWD(FUSE, SAVE)                                                                                        \
-  switch (g_otr_ffn2_ablate & 3) {                                                                                       \
+  switch (g_otr_ffn2_ablate & 7) {                                                                                       \
     case 0: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 0, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
     case 1: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 1, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
     case 2: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 2, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
+    case 4: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 4, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
     default: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 3, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;  \
   }
 
@@ -958,10 +962,13 @@ int32_t ffn3_bwd_launch(const void* dy16, const void* hsave, const void* w2t_pac
   p.dy16 = (const uint16_t*)dy16; p.hsave = (const uint4*)hsave; p.p3 = (const uint4*)w2t_pack; p.p4 = (const uint4*)w1t_pack;
   p.dh = (uint16_t*)dh; p.skip = skip; p.dx = dx; p.scratch = scratch; p.sync = sync; p.fault = g_otr_fault;
   p.spin_limit = g_otr_spin_limit; p.M = (int)M; p.F = F;
-  switch (g_otr_ffn2_ablate & 3) {
+  switch (g_otr_ffn2_ablate & 15) {
     case 0: hipLaunchKernelGGL((ffn3_bwd_kernel<256, 0>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p); break;
     case 1: hipLaunchKernelGGL((ffn3_bwd_kernel<256, 1>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p); break;
     case 2: hipLaunchKernelGGL((ffn3_bwd_kernel<256, 2>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((ffn3_bwd_kernel<256, 4>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p); break;
+    case 8: hipLaunchKernelGGL((ffn3_bwd_kernel<256, 8>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p); break;
+    case 12: hipLaunchKernelGGL((ffn3_bwd_kernel<256, 12>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p); break;
     default: hipLaunchKernelGGL((ffn3_bwd_kernel<256, 3>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p); break;
   }
   return otr_check_launch("ffn3_bwd");

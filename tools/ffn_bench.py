@@ -135,6 +135,11 @@ def main():
         lib.otr_debug_set(4, ab)
         res['split_fwd_ablate%d_us' % ab] = timeit(lambda: fwd3(0.0), a.iters)
         res['split_bwd_ablate%d_us' % ab] = timeit(bwd3, a.iters)
+    for ab in (4, 8, 12):     # 4 = no global stores of the saved tiles / dh, 8 = no tile loads (backward), 12 = neither
+        lib.otr_debug_set(4, ab)
+        if ab == 4:
+            res['split_fwd_save_ablate4_us'] = timeit(lambda: fwd3(0.0, True), a.iters)
+        res['split_bwd_ablate%d_us' % ab] = timeit(bwd3, a.iters)
     lib.otr_debug_set(4, 0)
     res['split_fwd_tflops'] = 2.0 * M * 3 * F * d / res['split_fwd_us'] / 1e6
     res['split_bwd_tflops'] = 2.0 * M * 3 * F * d / res['split_bwd_us'] / 1e6
