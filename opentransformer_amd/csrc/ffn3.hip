@@ -68,10 +68,38 @@ __device__ __forceinline__ void f3_mma_xa(f32x16& acc, const otr_u32x4& w, const
 constexpr int F3_AUX_COH = 17;           // sc0 | sc1: stores write through to memory, loads are served by memory
 typedef decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0)) f3_rsrc_t;
 
+// Cache policy of a transfer.  The XCDs' L2s are not coherent with each other, so in general the sender writes THROUGH
+// (sc0 sc1) and the receiver reads past its L2 (sc0 sc1).  But the four workgroups of a row block are neighbours in dispatch
+// order and in practice share an XCD; each publishes its XCC id (+1) in the row block's sync record at kernel entry, and a
+// transfer whose two ends read EQUAL ids uses the shared L2: plain stores (at the L2 when vmcnt drains) and sc1 loads (past
+// the L1, served by the L2).  Mixed decisions stay correct: an id not yet published or different -> write-through; a
+// write-through store on the same XCD drops the line from that L2, so an L2-served load refetches it; the ids are cleared
+// with the counters, so a stale id of an earlier launch never vouches for a placement.
+//   sync record of a row block (8 ints): [0] arrivals, [1] readers done, [2 + s] XCC id + 1 of slice s
+__device__ __forceinline__ int f3_xcc_id() {
+  int v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xf;
+}
+__device__ __forceinline__ void f3_publish_xcc(int* rec, int sl, int xcc) {
+  __hip_atomic_store(rec + 2 + sl, xcc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int AUX>
+__device__ __forceinline__ void f3_store_tile4(const f32x16 (&acc)[4], f3_rsrc_t rs, uint32_t base) {
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const otr_u32x4 v = {__float_as_uint(acc[ct][4 * q]), __float_as_uint(acc[ct][4 * q + 1]),
+                           __float_as_uint(acc[ct][4 * q + 2]), __float_as_uint(acc[ct][4 * q + 3])};
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs, base + (uint32_t)((ct * 4 + q) * 1024), 0, AUX);
+    }
+}
 // wave (wr, wc) holds acc[rt][ct]: rows 64 wr + 32 rt .., columns 128 wc + 32 ct ..; the row tile that belongs to quarter `sl`
 // (this workgroup finishes it) goes to LDS `own` [8 column tiles][4 q][64 lanes] float4, the others to
-// scratch[sender sl][quarter] of the row block with write-through stores
-__device__ __forceinline__ void f3_send_partials(const f32x16 (&acc)[2][4], f3_rsrc_t rs, float* own, int sl, int wr, int wc, int lane) {
+// scratch[sender sl][quarter] of the row block
+__device__ __forceinline__ void f3_send_partials(const f32x16 (&acc)[2][4], f3_rsrc_t rs, float* own, const int* rec, int xcc, int sl, int wr,
+                                                 int wc, int lane) {
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
     const int qt = 2 * wr + rt;                                  // the quarter these 32 rows belong to (wave-uniform)
@@ -84,14 +112,8 @@ __device__ __forceinline__ void f3_send_partials(const f32x16 (&acc)[2][4], f3_r
               make_float4(acc[rt][ct][4 * q], acc[rt][ct][4 * q + 1], acc[rt][ct][4 * q + 2], acc[rt][ct][4 * q + 3]);
     } else {
       const uint32_t base = (uint32_t)((sl * 4 + qt) * 32768 + (4 * wc) * 4096 + lane * 16);
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const otr_u32x4 v = {__float_as_uint(acc[rt][ct][4 * q]), __float_as_uint(acc[rt][ct][4 * q + 1]),
-                               __float_as_uint(acc[rt][ct][4 * q + 2]), __float_as_uint(acc[rt][ct][4 * q + 3])};
-          __builtin_amdgcn_raw_buffer_store_b128(v, rs, base + (uint32_t)((ct * 4 + q) * 1024), 0, F3_AUX_COH);
-        }
+      const bool same = __builtin_amdgcn_readfirstlane(__hip_atomic_load(rec + 2 + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == xcc + 1;
+      if (same) f3_store_tile4<0>(acc[rt], rs, base); else f3_store_tile4<F3_AUX_COH>(acc[rt], rs, base);
     }
   }
 }
@@ -105,24 +127,28 @@ __device__ __forceinline__ void f3_arrive_wait(int* arrive, int spin_limit, int*
   }
   if (spins >= spin_limit && fault) __hip_atomic_fetch_add(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// the three partners' partials of quarter `sl`, column tiles 2 wid, 2 wid + 1
-__device__ __forceinline__ void f3_recv_partials(otr_u32x4 (&part)[3][2][4], f3_rsrc_t rs, int sl, int wid, int lane) {
+template <int AUX>
+__device__ __forceinline__ void f3_load_tile2(otr_u32x4 (&part)[2][4], f3_rsrc_t rs, uint32_t base) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part[t][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (uint32_t)((t * 4 + q) * 1024), 0, AUX);
+}
+// the three partners' partials of quarter `sl`, column tiles 2 wid, 2 wid + 1 (after the arrival wait: every id is published)
+__device__ __forceinline__ void f3_recv_partials(otr_u32x4 (&part)[3][2][4], f3_rsrc_t rs, const int* rec, int xcc, int sl, int wid, int lane) {
 #pragma unroll
   for (int n = 0; n < 3; ++n) {
     const int s2 = n + (n >= sl ? 1 : 0);                        // the three other slices (wave-uniform)
     const uint32_t base = (uint32_t)((s2 * 4 + sl) * 32768 + (2 * wid) * 4096 + lane * 16);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        part[n][t][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (uint32_t)((t * 4 + q) * 1024), 0, F3_AUX_COH);
+    const bool same = __builtin_amdgcn_readfirstlane(__hip_atomic_load(rec + 2 + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == xcc + 1;
+    if (same) f3_load_tile2<16>(part[n], rs, base); else f3_load_tile2<F3_AUX_COH>(part[n], rs, base);
   }
 }
-// one lane, after this workgroup has read everything it needed: the last of the four readers re-arms the counters
-__device__ __forceinline__ void f3_done(int* arrive) {
-  if (__hip_atomic_fetch_add(arrive + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3) {
-    __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(arrive + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// one lane, after this workgroup has read everything it needed: the last of the four readers re-arms the record
+__device__ __forceinline__ void f3_done(int* rec) {
+  if (__hip_atomic_fetch_add(rec + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) __hip_atomic_store(rec + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -139,9 +165,9 @@ struct Ffn3FwdArgs {
                            // backward kernel: [row block][slice][64-unit chunk][wave][8 pieces][64 lanes] x 16 B; piece
                            // rt*2 + j = value registers 8j .. 8j+7 of row tile rt, piece 4 + rt*2 + j = the sigmoids
   uint16_t* usave;         // SAVE: u = glu output [128 * row blocks, F] row-major (operand of the w_2 weight gradient)
-  int* sync;               // [2 * row blocks] zero on entry, zero again on exit: arrivals / readers done per row block
+  int* sync;               // [8 * row blocks] zero on entry, zero again on exit: the row blocks' sync records (f3_send_partials)
   int* fault;              // NULL or the sticky fault word (otr_set_fault_counter)
-  int spin_limit;
+  int spin_limit, coh_only;
   float eps, p_drop;
   uint64_t rng_offset;
 };
@@ -172,6 +198,8 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   f3_block_map((int)blockIdx.x, p.S, rb, sl);
   if (rb * 128 >= p.M) return;                                   // whole workgroup: the grid is padded to 8 x S x ceil(blocks / 8)
   const int row0 = rb * 128 + wr * 64;
+  const int xcc = p.coh_only ? 16 + sl : f3_xcc_id();            // coh_only (otr_debug_set(12, 1)): no two ids match -> every transfer writes through
+  if constexpr (FUSE) { if (tid == 0) f3_publish_xcc(p.sync + 8 * rb, sl, xcc); }
   const int nchunk = p.F / 32, per = nchunk / p.S, NC = per >> 1; // v1 chunks (32 units) of the layer / of this slice; 64-unit chunks
   const int c_base = sl * per;
 
@@ -455,7 +483,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   float* own = reinterpret_cast<float*>(ring);                   // [8 column tiles][4 q][64 lanes] float4 = 32 KiB
   float* red = reinterpret_cast<float*>(ring + 32768);           // [2 passes][4 waves][32 rows]
   auto rs = __builtin_amdgcn_make_buffer_rsrc(p.slabs + (int64_t)rb * (4 * 4 * 8192), 0, 4 * 4 * 32768, 0x00020000);
-  f3_send_partials(yacc, rs, own, sl, wr, wc, lane);
+  f3_send_partials(yacc, rs, own, p.sync + 8 * rb, xcc, sl, wr, wc, lane);
   // everything the quarter's epilogue reads besides the partials is fetched before the arrival wait
   const int64_t row = (int64_t)rb * 128 + 32 * sl + m;
   const bool live = row < p.M;
@@ -474,11 +502,11 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   f3_wait_vm<0>();                                               // this wave's write-through stores are at memory
   f3_wait_lds();
   f3_barrier();
-  if (tid == 0) f3_arrive_wait(p.sync + 2 * rb, p.spin_limit, p.fault);
+  if (tid == 0) f3_arrive_wait(p.sync + 8 * rb, p.spin_limit, p.fault);
   f3_barrier();
   // ---- the quarter's rows: lane (m, hi) of wave `wid` owns row m, columns 32 ct + 8 q + 4 hi .. + 3 for ct = 2 wid, 2 wid + 1
   otr_u32x4 part[3][2][4];
-  f3_recv_partials(part, rs, sl, wid, lane);
+  f3_recv_partials(part, rs, p.sync + 8 * rb, xcc, sl, wid, lane);
   const bool drop = p.p_drop > 0.f;
   const uint64_t seed = drop ? *p.seed : 0;
   const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
@@ -553,7 +581,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
     if (wid == 0 && hi == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
   }
   // every partial this workgroup needed has been read: the last of the four readers re-arms the row block's counters
-  if (tid == 0) f3_done(p.sync + 2 * rb);
+  if (tid == 0) f3_done(p.sync + 8 * rb);
   }
 }
 
@@ -579,7 +607,7 @@ struct Ffn3BwdArgs {
   uint16_t* dh;            // [128 * row blocks, 2F] row-major out
   const float* skip;       // [M, D] or NULL
   float* dx;               // [M, D] out (may alias skip)
-  float* scratch; int* sync; int* fault; int spin_limit;
+  float* scratch; int* sync; int* fault; int spin_limit, coh_only;
   int M, F;
 };
 
@@ -616,6 +644,8 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   f3_block_map((int)blockIdx.x, 4, rb, sl);
   if (rb * 128 >= p.M) return;
   const int row0 = rb * 128 + wr * 64;
+  const int xcc = p.coh_only ? 16 + sl : f3_xcc_id();
+  if (tid == 0) f3_publish_xcc(p.sync + 8 * rb, sl, xcc);
   const int nchunk = p.F / 32, per = nchunk / 4, NC = per >> 1;
   const int c_base = sl * per;
   constexpr bool no_dma = (ABL & 1) != 0, no_mma = (ABL & 2) != 0, no_st = (ABL & 4) != 0, no_hl = (ABL & 8) != 0;
@@ -870,7 +900,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   // ---- exchange the four partial input gradients of the row block; this workgroup finishes quarter `sl`: dx = skip + sum
   float* own = reinterpret_cast<float*>(ring);
   auto rs = __builtin_amdgcn_make_buffer_rsrc(p.scratch + (int64_t)rb * (4 * 4 * 8192), 0, 4 * 4 * 32768, 0x00020000);
-  f3_send_partials(xacc, rs, own, sl, wr, wc, lane);
+  f3_send_partials(xacc, rs, own, p.sync + 8 * rb, xcc, sl, wr, wc, lane);
   const int64_t row = (int64_t)rb * 128 + 32 * sl + m;
   const bool live = row < p.M;
   const int64_t crow = live ? row : (int64_t)p.M - 1;
@@ -884,10 +914,10 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   f3_wait_vm<0>();
   f3_wait_lds();
   f3_barrier();
-  if (tid == 0) f3_arrive_wait(p.sync + 2 * rb, p.spin_limit, p.fault);
+  if (tid == 0) f3_arrive_wait(p.sync + 8 * rb, p.spin_limit, p.fault);
   f3_barrier();
   otr_u32x4 part[3][2][4];
-  f3_recv_partials(part, rs, sl, wid, lane);
+  f3_recv_partials(part, rs, p.sync + 8 * rb, xcc, sl, wid, lane);
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -901,7 +931,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
       }
       if (live) *reinterpret_cast<float4*>(p.dx + row * D + 32 * (2 * wid + t) + 8 * q + 4 * hi) = v;
     }
-  if (tid == 0) f3_done(p.sync + 2 * rb);
+  if (tid == 0) f3_done(p.sync + 8 * rb);
 }
 
 }  // namespace
@@ -916,6 +946,7 @@ static inline unsigned f3_grid(int64_t M, int S) {
 
 extern int g_otr_spin_limit;
 extern int32_t* g_otr_fault;
+extern int g_otr_ffn_coh_only;
 
 #define F3_LAUNCH_FWD(FUSE, SAVE)                                                                                        \
   switch (g_otr_ffn2_ablate & 7) {                                                                                       \
@@ -939,7 +970,7 @@ int32_t ffn3_fwd_launch(const void* x16, const void* w1_pack, const float* b1, c
 int64_t ffn3_scratch_bytes(int64_t M) { return ((M + 127) / 128) * (int64_t)(4 * 4 * 32768); }
 int64_t ffn3_hsave_bytes(int64_t M, int32_t F) { return ((M + 127) / 128) * 128 * (int64_t)F * 4; }
 int64_t ffn3_padded_rows(int64_t M) { return ((M + 127) / 128) * 128; }
-int64_t ffn3_sync_ints(int64_t M) { return 2 * ((M + 127) / 128); }
+int64_t ffn3_sync_ints(int64_t M) { return 8 * ((M + 127) / 128); }
 
 int32_t ffn3_ln_fwd_launch(const float* x, const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, const float* b2,
                            const float* gamma, const float* beta, const uint64_t* seed, float p_drop, uint64_t rng_offset, float eps,
@@ -950,7 +981,7 @@ int32_t ffn3_ln_fwd_launch(const float* x, const void* x16, const void* w1_pack,
   p.x16 = (const uint16_t*)x16; p.p1 = (const uint4*)w1_pack; p.b1 = b1; p.p2 = (const uint4*)w2_pack; p.slabs = scratch;
   p.M = (int)M; p.F = F; p.S = S;
   p.x = x; p.b2 = b2; p.gamma = gamma; p.beta = beta; p.seed = seed; p.y = y; p.y16 = (uint16_t*)y16; p.z = z; p.mean = mean; p.rstd = rstd;
-  p.sync = sync; p.fault = g_otr_fault; p.spin_limit = g_otr_spin_limit; p.eps = eps; p.p_drop = p_drop; p.rng_offset = rng_offset;
+  p.sync = sync; p.fault = g_otr_fault; p.spin_limit = g_otr_spin_limit; p.coh_only = g_otr_ffn_coh_only; p.eps = eps; p.p_drop = p_drop; p.rng_offset = rng_offset;
   p.hsave = (uint4*)hsave; p.usave = (uint16_t*)usave;
   if (hsave) { F3_LAUNCH_FWD(true, true) } else { F3_LAUNCH_FWD(true, false) }
   return otr_check_launch("ffn3_ln_fwd");
@@ -961,7 +992,7 @@ int32_t ffn3_bwd_launch(const void* dy16, const void* hsave, const void* w2t_pac
   Ffn3BwdArgs p{};
   p.dy16 = (const uint16_t*)dy16; p.hsave = (const uint4*)hsave; p.p3 = (const uint4*)w2t_pack; p.p4 = (const uint4*)w1t_pack;
   p.dh = (uint16_t*)dh; p.skip = skip; p.dx = dx; p.scratch = scratch; p.sync = sync; p.fault = g_otr_fault;
-  p.spin_limit = g_otr_spin_limit; p.M = (int)M; p.F = F;
+  p.spin_limit = g_otr_spin_limit; p.coh_only = g_otr_ffn_coh_only; p.M = (int)M; p.F = F;
   switch (g_otr_ffn2_ablate & 15) {
     case 0: hipLaunchKernelGGL((ffn3_bwd_kernel<256, 0>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p); break;
     case 1: hipLaunchKernelGGL((ffn3_bwd_kernel<256, 1>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p); break;

@@ -1164,7 +1164,7 @@ def _ffn_sync(device):
 
 def _ffn_split(M, F):
     return (_FFN_SPLIT and not _FFN_V2 and M >= _FFN_SPLIT_MIN_ROWS and F % 256 == 0 and F // 32 // 4 <= 32
-            and 2 * ((M + 127) // 128) <= _FFN_SYNC_INTS)
+            and 8 * ((M + 127) // 128) <= _FFN_SYNC_INTS)
 
 
 def _ffn_slabs(M, F):

@@ -163,3 +163,35 @@ def test_ffn_fused_matches_unfused_model_path(mode):
     assert rel(y1, y0) < ty, rel(y1, y0)
     for (n, _), a_, b_ in zip([('x', None)] + list(layer.named_parameters()), g1, g0):
         assert rel(a_, b_) < tg, (n, rel(a_, b_))
+
+
+@pytest.mark.parametrize('coh_only', [0, 1])
+def test_split_exchange_paths_agree(coh_only):
+    """The four workgroups of a row block exchange partial sums through the shared L2 when their published XCC ids match and with
+    write-through stores / memory-served loads otherwise (csrc/ffn3.hip); otr_debug_set(12, 1) forces the second path for every
+    transfer.  Both must give the 32-row kernels' result, forward and backward, and leave the sync records zero."""
+    from opentransformer_amd import ops, _lib as L
+    ops.set_compute_dtype('fp16')
+    was = ops._FFN_V2, ops._FFN_SPLIT
+    lib = L.load()
+    try:
+        d, dff, M = 256, 1024, 4000 + 33
+        w1, b1, w2, b2, gamma, beta = _params(d, dff, 7)
+        g = torch.Generator().manual_seed(9)
+        xv = torch.randn(M, d, generator=g).to(DEV)
+        gy = torch.randn(M, d, generator=g).to(DEV)
+        outs = {}
+        for name, split in (('v1', False), ('split', True)):
+            ops._FFN_V2, ops._FFN_SPLIT = False, split
+            L.check(lib.otr_debug_set(12, coh_only if split else 0), 'debug_set')
+            x = xv.clone().requires_grad_(True)
+            y = ops.ffn_add_layernorm(ops.attach_lp(x, x.detach().to(ops.act_dtype())), w1, b1, w2, b2, gamma, beta, 0.0, 1e-5)
+            grads = torch.autograd.grad(y, (x, w1, b1, w2), gy)
+            outs[name] = (y.detach(),) + tuple(t.detach() for t in grads)
+        for a_, b_, n, tol in zip(outs['split'], outs['v1'], ('y', 'dx', 'dw1', 'db1', 'dw2'), (1e-5, 2e-3, 2e-3, 2e-3, 2e-3)):
+            assert rel(a_, b_) < tol, (n, rel(a_, b_))
+        assert int(ops._ffn_sync(torch.device(DEV, torch.cuda.current_device())).abs().sum()) == 0
+    finally:
+        lib.otr_debug_set(12, 0)
+        ops._FFN_V2, ops._FFN_SPLIT = was
+        ops.set_compute_dtype('bf16')
