@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes over one harness; profiler output stays in /tmp on the GPU box, only the per-kernel sums come back.
-# usage: gpu_pmc3.sh TAG 'kernel name LIKE pattern' tools/xxx.py args...
+# usage: gpu_pmc4.sh TAG 'kernel name LIKE pattern' tools/xxx.py args...
 TAG=$1; PAT=$2; shift 2
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -15,14 +15,16 @@ import sqlite3, glob
 for f in glob.glob('/tmp/pmc_$1/**/*.db', recursive=True):
     db = sqlite3.connect(f)
     try:
-        rows = db.execute("select counter_name, count(distinct dispatch_id), sum(value) from counters_collection where kernel_name like '$PAT' group by counter_name").fetchall()
-        for r in rows: print('  $1', r[0], 'dispatches=%d' % r[1], 'per_dispatch=%.6g' % (r[2] / max(r[1], 1)))
+        for kn, in db.execute("select distinct kernel_name from counters_collection where kernel_name like '$PAT'").fetchall():
+            dur = db.execute("select avg(end-start), count(*) from kernels where name = ?", (kn,)).fetchone()
+            print('== %s  avg %.1f us over %d launches' % (kn[:90], (dur[0] or 0) / 1e3, dur[1]))
+            rows = db.execute("select counter_name, count(distinct dispatch_id), sum(value) from counters_collection where kernel_name = ? group by counter_name", (kn,)).fetchall()
+            for r in rows: print('  $1 %-28s per_dispatch=%.6g' % (r[0], r[2] / max(r[1], 1)))
     except Exception as e:
-        print('query failed', e, [r[0] for r in db.execute("select name from sqlite_master").fetchall()][:40])
+        print('query failed', e)
 PY
 }
 run p1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES"
-
+run p2 "SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
 run p3 "FETCH_SIZE"
 run p4 "WRITE_SIZE"
-
