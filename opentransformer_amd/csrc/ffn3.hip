@@ -274,6 +274,12 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
       for (int r = 0; r < 16; ++r) yacc[rt][ct][r] = 0.f;
+  f32x16 hv[2], hg[2];
+  uint4 uown[2][2], upart[2][2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) uown[rt][j] = upart[rt][j] = make_uint4(0u, 0u, 0u, 0u);
 
   constexpr bool no_dma = (ABL & 1) != 0, no_mma = (ABL & 2) != 0, no_st = (ABL & 4) != 0;   // ablations are compile-time: a run-time flag would split
   // the G phase into basic blocks, and hipcc interleaves the GLU's VALU code with the MFMAs only inside one block
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
 #define F3_ISSUE2(I) if constexpr (!no_dma) issue2(I);
   // accumulators of GEMM1 start from the biases (register r of lane (m, hi) is hidden unit 8 (r >> 2) + 4 hi + (r & 3) of the
   // sub-chunk, for both row tiles), so the GLU adds nothing
-#define F3_BIAS_INIT(CL)                                                                               \
+#define F3_BIAS_INIT(CL)                                                                                       \
   _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
     const float4 bv = *reinterpret_cast<const float4*>(bias_s + (CL) * 64 + 8 * q + 4 * hi);                   \
     const float4 bg = *reinterpret_cast<const float4*>(bias_s + (CL) * 64 + 32 + 8 * q + 4 * hi);              \
@@ -292,45 +298,14 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
       hv[rt][4 * q] = bv.x; hv[rt][4 * q + 1] = bv.y; hv[rt][4 * q + 2] = bv.z; hv[rt][4 * q + 3] = bv.w;       \
       hg[rt][4 * q] = bg.x; hg[rt][4 * q + 1] = bg.y; hg[rt][4 * q + 2] = bg.z; hg[rt][4 * q + 3] = bg.w;       \
     }                                                                                                          \
-  }
-  // One quarter (J = 0 / 1: registers 8J .. 8J+7) of row tile RT of chunk CH is complete in ue / sge: pack, keep for GEMM2, hand
-  // to the partner wave, and (SAVE) leave the tiles the backward kernel reads + the row-major u of the w_2 weight gradient
-#define F3_GLU_PACK(RT, J, CH)                                                                                 \
-  {                                                                                                            \
-    const uint4 nu = make_uint4(upk[0], upk[1], upk[2], upk[3]);                                               \
-    my_u[((RT) * 2 + (J)) * 64] = nu;        /* read back by this wave's and the partner's GEMM2 */               \
-    if constexpr (SAVE && !no_st) {                                                                            \
-      uint4* hs = p.hsave + ((int64_t)(((rb * 4 + sl) * NC + (CH)) * 4 + wid) * 8) * 64 + lane;                \
-      st_global_b128(hs + ((RT) * 2 + (J)) * 64, make_uint4(apk[0], apk[1], apk[2], apk[3]));                  \
-      st_global_b128(hs + (4 + (RT) * 2 + (J)) * 64, make_uint4(spk[0], spk[1], spk[2], spk[3]));              \
-      if ((J) == 0) uq0 = nu;                                                                                  \
-      else store_tile_row(p.usave + ((int64_t)row0 + 32 * (RT) + m) * p.F + (c_base + 2 * (CH) + wc) * 32, uq0, nu, hi, true); \
-    }                                                                                                          \
-  }
-  // GLU of elements E0, E0 + 1 of row tile RT of the chunk whose accumulators are (PV, PG): packed at once (16-bit pairs), so a
-  // quarter in flight holds 4 (+ 8 with SAVE) registers
-#define F3_GLU_PAIR(RT, E0, CH, PV, PG)                                                                        \
-  {                                                                                                            \
-    const float s0_ = fast_sigmoid(PG[RT][E0]), s1_ = fast_sigmoid(PG[RT][(E0) + 1]);                          \
-    upk[((E0) >> 1) & 3] = pack2h(PV[RT][E0] * s0_, PV[RT][(E0) + 1] * s1_);                                   \
-    if constexpr (SAVE && !no_st) {                                                                            \
-      apk[((E0) >> 1) & 3] = pack2h(PV[RT][E0], PV[RT][(E0) + 1]);                                             \
-      spk[((E0) >> 1) & 3] = pack2h(s0_, s1_);                                                                 \
-    }                                                                                                          \
-    if ((((E0) >> 1) & 3) == 3) F3_GLU_PACK(RT, (E0) >> 3, CH)                                                 \
-  }
-  // GEMM1 over 8 contraction steps (HALF = 0: steps 0-7, 1: steps 8-15) of the phase in ring slot SLOT into (hv, hg).  DOGLU: the
-  // GLU of row tile HALF of the PREVIOUS chunk CH (its pre-activations were copied to (pv, pg) during the G phase) rides between
-  // the MFMAs, two elements (~12 VALU instructions) behind every second pair -- the matrix pipe never waits for a VALU phase.
-  // Two DMAs of the scheduled phase behind every group of 8 MFMAs.
-#define F3_GEMM1(HALF, SLOT, DOGLU, CH)                                                        \
+  }                                                                                                            \
+  asm volatile("s_nop 3" ::: "memory");     /* VALU / LDS write of an accumulator -> asm MFMA reading it as C */
+  // GEMM1 over 8 contraction steps (HALF = 0: steps 0-7, 1: steps 8-15) of the phase in ring slot SLOT; the two DMAs of the
+  // scheduled phase ride behind every group of 8 MFMAs
+#define F3_GEMM1(HALF, SLOT)                                                                                   \
   if constexpr (!no_mma) {                                                                                     \
     const otr_u32x4* wb = reinterpret_cast<const otr_u32x4*>(ring + (SLOT) * F3_PHASE) + (wc * 2) * 64 + lane; \
     otr_u32x4 fr[2][4];                                                                                        \
-    uint32_t upk[4], apk[4], spk[4];                                                                           \
-    uint4 uq0 = make_uint4(0u, 0u, 0u, 0u);                                                                    \
-    if constexpr (DOGLU) F3_MFMA_DRAIN();                                                                      \
-    asm volatile("s_nop 3" ::: "memory");     /* VALU / LDS write of an accumulator -> asm MFMA reading it as C */ \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) fr[0][j] = wb[(((j >> 1)) * 4 + (j & 1)) * 64];               \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                            \
       if (g + 1 < 4) {                                                                                         \
@@ -342,12 +317,6 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
         const int ks = (HALF) * 8 + 2 * g + (j >> 1);                                                          \
         if (j & 1) { f3_mma_xa(hg[0], fr[g & 1][j], xf[0][ks]); f3_mma_xa(hg[1], fr[g & 1][j], xf[1][ks]); }   \
         else       { f3_mma_xa(hv[0], fr[g & 1][j], xf[0][ks]); f3_mma_xa(hv[1], fr[g & 1][j], xf[1][ks]); }   \
-        if constexpr (DOGLU) {                                                                                 \
-          if (j & 1) {                                 /* elements 4g + j - 1, 4g + j of row tile HALF */        \
-            F3_GLU_PAIR(HALF, 4 * g + j - 1, CH, pv, pg)                                                       \
-            __builtin_amdgcn_sched_barrier(0);                                                                 \
-          }                                                                                                    \
-        }                                                                                                      \
       }                                                                                                        \
       F3_ISSUE2(g)                                                                                             \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
@@ -356,93 +325,117 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
     _Pragma("unroll") for (int g = 0; g < 4; ++g) { F3_ISSUE2(g) }                                             \
   }
   // end of a phase: this wave's DMAs of the NEXT phase have landed, its LDS traffic is done; after the barrier the slot just
-  // consumed is free for the phase four ahead, which is scheduled here and issued during the next phase.  The wait is COUNTED:
-  // loads retire in issue order, so with at most the 16 DMAs of the two phases after it outstanding the next phase's group
-  // has landed.  Stores do NOT retire in issue order with loads (measured: with the stores of the phases added to the count,
-  // ring slots were read before their DMA had landed -- 0.5 % wrong outputs: a store is acknowledged by the L2 long before an
-  // older LDS-DMA returns), so the count keeps the younger LOADS only and stores in flight merely lengthen the wait a little.
-#define F3_PHASE_END()                                                                                         \
-  if constexpr (no_dma) f3_wait_vm<0>(); else f3_wait_vm<16>();                                                \
+  // consumed is free for the phase four ahead, which is scheduled here and issued during the next phase.  The wait is COUNTED
+  // (vmcnt retires in issue order, stores included): everything this wave issued after the last DMA of the next phase's
+  // group may still fly -- the 16 DMAs of the two phases after it plus EXTRA = the global stores of those two phases (SAVE: 12
+  // per G phase, unconditional so that the count is exact)
+#define F3_PHASE_END(EXTRA)                                                                                    \
+  if constexpr (no_dma) f3_wait_vm<0>(); else f3_wait_vm<16 + (EXTRA)>();                                      \
   f3_wait_lds();                                                                                               \
   f3_barrier();                                                                                                \
   schedule(slot);                                                                                              \
   slot = (slot + 1) & 3;
-  // Phase G: GEMM2 of the previous chunk -- w_2 fragment (ct, k) at ring[(ct*4 + k) KiB]; this wave's column tiles are
-  // 4 wc .. 4 wc + 3; contraction steps k_own, k_own + 1 take this wave's u, k_par, k_par + 1 the partner's, both from the
-  // hand-over buffer (fragment rt*2 + j: written during the two phases before, rewritten after this one)
-#define F3_PHASE_G(G2, SLOT, DMA, COPY)                                                                        \
-  if constexpr (!no_mma && COPY) F3_MFMA_DRAIN();                                                              \
-  if constexpr (!no_mma && G2) {                                                                               \
+  // Phase G of chunk C.  G2: GEMM2 of chunk C-1 -- w_2 fragment (ct, k) at ring[(ct*4 + k) KiB]; this wave's column tiles are
+  // 4 wc .. 4 wc + 3; contraction steps k_own, k_own + 1 take u from registers (uown), k_par, k_par + 1 the partner's (upart,
+  // read from the hand-over buffer during phase B).  GLU: the GLU of chunk C in quarters; quarter kk REPLACES
+  // uown[kk >> 1][kk & 1], which step (kk & 1) <= kk of GEMM2 has already consumed.  One basic block; per step 8 MFMAs with the
+  // quarter's ~45 VALU instructions pinned between them (sched_group_barrier: 1 MFMA, then 6 VALU), so the matrix pipe runs
+  // during the VALU phase.
+#define F3_PHASE_G(G2, GLU, SLOT, CHUNK)                                                                              \
+  if constexpr (!no_mma) {                                                                                     \
     const uint4* wb = reinterpret_cast<const uint4*>(ring + (SLOT) * F3_PHASE) + (wc * 16) * 64 + lane;        \
-    uint4 fr[2][6];                          /* 4 w_2 fragments + the u fragments of the two row tiles */         \
-    _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) fr[0][ct] = wb[(ct * 4 + k_own) * 64];                    \
-    fr[0][4] = my_u[0]; fr[0][5] = my_u[2 * 64];                                                               \
+    uint4 fr[2][4];                                                                                            \
+    if constexpr (GLU) F3_MFMA_DRAIN();      /* GEMM1's asm MFMAs -> the GLU's VALU reads (also behind the barrier) */ \
+    if constexpr (G2) {                                                                                        \
+      _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) fr[0][ct] = wb[(ct * 4 + k_own) * 64];                  \
+    }                                                                                                          \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                         \
-      if (kk + 1 < 4) {                                                                                        \
-        const int kn = (kk + 1 < 2 ? k_own : k_par) + ((kk + 1) & 1);                                          \
-        const uint4* ub = kk + 1 < 2 ? my_u : partner_u;                                                       \
-        _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) fr[(kk + 1) & 1][ct] = wb[(ct * 4 + kn) * 64];        \
-        fr[(kk + 1) & 1][4] = ub[((kk + 1) & 1) * 64]; fr[(kk + 1) & 1][5] = ub[(2 + ((kk + 1) & 1)) * 64];    \
+      if constexpr (G2) {                                                                                      \
+        if (kk + 1 < 4) {                                                                                      \
+          const int kn = (kk + 1 < 2 ? k_own : k_par) + ((kk + 1) & 1);                                        \
+          _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) fr[(kk + 1) & 1][ct] = wb[(ct * 4 + kn) * 64];      \
+        }                                                                                                      \
       }                                                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
-      _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) {                                                       \
-        mma32(yacc[0][ct], fr[kk & 1][ct], fr[kk & 1][4]);                                                     \
-        mma32(yacc[1][ct], fr[kk & 1][ct], fr[kk & 1][5]);                                                     \
+      if constexpr (G2) {                                                                                      \
+        const uint4 u0 = kk < 2 ? uown[0][kk & 1] : upart[0][kk & 1], u1 = kk < 2 ? uown[1][kk & 1] : upart[1][kk & 1]; \
+        _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) {                                                     \
+          mma32(yacc[0][ct], fr[kk & 1][ct], u0);                                                              \
+          mma32(yacc[1][ct], fr[kk & 1][ct], u1);                                                              \
+        }                                                                                                      \
       }                                                                                                        \
-      if constexpr (COPY) {                  /* this chunk's pre-activations move aside: GEMM1 of the next chunk reuses (hv, hg) */ \
-        if (kk & 1) pg[kk >> 1] = hg[kk >> 1]; else pv[kk >> 1] = hv[kk >> 1];                                 \
+      if constexpr (GLU) {                   /* quarter kk: row tile kk >> 1, registers 8 (kk & 1) .. + 7 */       \
+        const int rt = kk >> 1, j0 = (kk & 1) * 8;                                                             \
+        float u[8], sg[8];                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) { sg[e] = fast_sigmoid(hg[rt][j0 + e]); u[e] = hv[rt][j0 + e] * sg[e]; } \
+        const uint4 nu = make_uint4(pack2h(u[0], u[1]), pack2h(u[2], u[3]), pack2h(u[4], u[5]), pack2h(u[6], u[7])); \
+        uown[rt][kk & 1] = nu;               /* kept for GEMM2 of this chunk one iteration later ... */            \
+        my_u[(rt * 2 + (kk & 1)) * 64] = nu; /* ... and handed to the partner wave */                            \
+        if constexpr (SAVE && !no_st) {      /* 2 (+ 2 on odd quarters) global stores per quarter */               \
+          uint4* hs = p.hsave + ((int64_t)(((rb * 4 + sl) * NC + (CHUNK)) * 4 + wid) * 8) * 64 + lane;         \
+          st_global_b128(hs + (rt * 2 + (kk & 1)) * 64,                                                        \
+                         make_uint4(pack2h(hv[rt][j0], hv[rt][j0 + 1]), pack2h(hv[rt][j0 + 2], hv[rt][j0 + 3]), \
+                                    pack2h(hv[rt][j0 + 4], hv[rt][j0 + 5]), pack2h(hv[rt][j0 + 6], hv[rt][j0 + 7]))); \
+          st_global_b128(hs + (4 + rt * 2 + (kk & 1)) * 64,                                                    \
+                         make_uint4(pack2h(sg[0], sg[1]), pack2h(sg[2], sg[3]), pack2h(sg[4], sg[5]), pack2h(sg[6], sg[7]))); \
+          if (kk & 1)                        /* both halves of row tile rt are new: its 32 u values, row-major */   \
+            store_tile_row(p.usave + ((int64_t)row0 + 32 * rt + m) * p.F + (c_base + 2 * (CHUNK) + wc) * 32,     \
+                           uown[rt][0], uown[rt][1], hi, true);                                                \
+        }                                                                                                      \
+      }                                                                                                        \
+      if constexpr (G2 && GLU) {                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                        \
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     /* one MFMA */                                \
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);     /* six VALU */                                \
+        }                                                                                                      \
       }                                                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
-      if constexpr (DMA) { F3_ISSUE2(kk) }   /* the closing phase schedules nothing */                          \
+      if constexpr (GLU) { F3_ISSUE2(kk) }   /* the closing phase (no GLU) schedules nothing */                  \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
     }                                                                                                          \
-  } else {                                                                                                     \
-    if constexpr (!no_mma && COPY) { pv[0] = hv[0]; pv[1] = hv[1]; pg[0] = hg[0]; pg[1] = hg[1]; }             \
-    if constexpr (DMA) { _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) { F3_ISSUE2(kk) } }                  \
+  } else if constexpr (GLU) {                                                                                  \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) { F3_ISSUE2(kk) }                                         \
   }
-  // chunk C beside the GLU of chunk C-1, then GEMM2 of chunk C-1 beside the copy of chunk C's pre-activations
-#define F3_ITER(C_)                                                                                            \
-  F3_BIAS_INIT(2 * (C_) + wc)                                                                                  \
-  F3_GEMM1(0, slot, true, (C_) - 1)                                                                            \
-  F3_PHASE_END()                                                                                               \
-  F3_GEMM1(1, slot, true, (C_) - 1)                                                                            \
-  F3_PHASE_END()                                                                                               \
-  F3_PHASE_G(true, slot, true, true)                                                                           \
-  F3_PHASE_END()
+  // the partner's u of the previous chunk: written before the barrier that closed G(C-1), rewritten in G(C) behind the
+  // barrier that closes this phase B(C)
+#define F3_READ_PARTNER()                                                                                      \
+  _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                             \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) upart[rt][j] = partner_u[(rt * 2 + j) * 64];
 
-  f32x16 hv[2], hg[2], pv[2], pg[2];                             // GEMM1 accumulators; the previous chunk's, awaiting their GLU
+  // Stores do NOT retire in issue order with loads (measured: with the 12 stores of a G phase added to the count, ring slots were
+  // read before their DMA had landed -- 0.5 % wrong outputs): a store is acknowledged by the L2 long before an older LDS-DMA
+  // returns.  Loads retire in order among themselves, so the count keeps the 16 YOUNGER LOADS only; the stores in flight merely
+  // make the wait a little longer than needed.
+  constexpr int KG = 0;
   int slot = 0;                                                  // ring slot of the current phase (phase index mod 4)
-  // ---- chunk 0: A, B; its G phase has nothing to multiply yet (placeholder payload)
+  // ---- chunk 0: A, B, GLU only
   F3_BIAS_INIT(wc)
-  F3_GEMM1(0, slot, false, 0)
-  F3_PHASE_END()
-  F3_GEMM1(1, slot, false, 0)
-  F3_PHASE_END()
-  F3_PHASE_G(false, slot, true, true)
-  F3_PHASE_END()
+  F3_GEMM1(0, slot)
+  F3_PHASE_END(0)
+  F3_GEMM1(1, slot)
+  F3_PHASE_END(0)
+  F3_PHASE_G(false, true, slot, 0)
+  F3_PHASE_END(KG)
+  // ---- chunks 1 .. NC-1: A, B, GLU beside the previous chunk's GEMM2
   for (int C = 1; C < NC; ++C) {
-    F3_ITER(C)
+    F3_BIAS_INIT(2 * C + wc)
+    F3_GEMM1(0, slot)
+    F3_PHASE_END(KG)                                             // the G phase before this one
+    F3_READ_PARTNER()
+    F3_GEMM1(1, slot)
+    F3_PHASE_END(0)
+    F3_PHASE_G(true, true, slot, C)
+    F3_PHASE_END(KG)
   }
-  // ---- the GLU of the last chunk has no MFMAs to ride with; then its GEMM2 closes (its w_2 took the place of a phase A(NC))
-  if constexpr (!no_mma) {
-    uint32_t upk[4], apk[4], spk[4];
-    uint4 uq0 = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int e = 0; e < 16; e += 2) F3_GLU_PAIR(rt, e, NC - 1, pv, pg)
-  }
-  f3_wait_lds();
-  f3_barrier();
-  F3_PHASE_G(true, slot, false, false)
+  // ---- closing phase: GEMM2 of chunk NC-1 (its w_2 took the place of a phase A(NC))
+  F3_READ_PARTNER()
+  F3_PHASE_G(true, false, slot, 0)
 #undef F3_ISSUE2
 #undef F3_BIAS_INIT
-#undef F3_GLU_PACK
-#undef F3_GLU_PAIR
 #undef F3_GEMM1
 #undef F3_PHASE_END
 #undef F3_PHASE_G
-#undef F3_ITER
+#undef F3_READ_PARTNER
   f3_wait_vm<0>();                                               // the placeholder DMAs have landed: the ring becomes scratch
   f3_wait_lds();
   f3_barrier();
