@@ -152,6 +152,29 @@ __device__ __forceinline__ void f3_done(int* rec) {
   }
 }
 
+// The workgroup's 128 activation rows (16-bit, D = 256) -> LDS, then this wave's 64 rows as MFMA B-operand fragments.  Loading
+// the fragments straight from global memory (lane (m, hi) fetches 16 bytes of ITS row per contraction step) touches 64
+// different 128-byte lines per instruction, and the 32 KiB of a row tile thrash the L1: the forward prologue took 11.9 k
+// cycles (5.7 us of a 45 us kernel, per-workgroup clock stamps).  Coalesced loads (a wave instruction covers two whole rows)
+// into an XOR-swizzled row-major image (chunk index ^ (row & 15): conflict-free for the fragment reads, ffn_frag.h), two
+// barriers, 32 ds_read_b128 per lane.
+template <int D>
+__device__ __forceinline__ void f3_stage_rows128(uint4* xs, const uint16_t* src, int rb, int M, int tid) {
+  constexpr int CPR = D / 8;                                     // 16-byte chunks per row
+  uint4 v[128 * CPR / 256];
+#pragma unroll
+  for (int k = 0; k < 128 * CPR / 256; ++k) {
+    const int pi = tid + 256 * k, r = pi / CPR, ch = pi % CPR;
+    const int64_t gr = min((int64_t)rb * 128 + r, (int64_t)M - 1);
+    v[k] = ld_global_b128(src + gr * D + ch * 8);
+  }
+#pragma unroll
+  for (int k = 0; k < 128 * CPR / 256; ++k) {
+    const int pi = tid + 256 * k, r = pi / CPR, ch = pi % CPR;
+    xs[r * CPR + (ch ^ (r & 15))] = v[k];
+  }
+}
+
 struct Ffn3FwdArgs {
   const uint16_t* x16;     // [M, D]
   const uint4* p1; const float* b1; const uint4* p2;
@@ -168,6 +191,7 @@ struct Ffn3FwdArgs {
   int* sync;               // [8 * row blocks] zero on entry, zero again on exit: the row blocks' sync records (f3_send_partials)
   int* fault;              // NULL or the sticky fault word (otr_set_fault_counter)
   int spin_limit, coh_only;
+  unsigned long long* trace;   // tuning hook (otr_debug_trace): wave 0 of every workgroup stamps the shader clock: [48 per workgroup]
   float eps, p_drop;
   uint64_t rng_offset;
 };
@@ -198,6 +222,9 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   f3_block_map((int)blockIdx.x, p.S, rb, sl);
   if (rb * 128 >= p.M) return;                                   // whole workgroup: the grid is padded to 8 x S x ceil(blocks / 8)
   const int row0 = rb * 128 + wr * 64;
+  int stamp_i = 0;
+#define F3_STAMP() if constexpr ((ABL & 16) != 0) { if (p.trace && tid == 0 && stamp_i < 48) p.trace[(int64_t)blockIdx.x * 48 + stamp_i++] = __builtin_amdgcn_s_memtime(); }
+  F3_STAMP()
   const int xcc = p.coh_only ? 16 + sl : f3_xcc_id();            // coh_only (otr_debug_set(12, 1)): no two ids match -> every transfer writes through
   if constexpr (FUSE) { if (tid == 0) f3_publish_xcc(p.sync + 8 * rb, sl, xcc); }
   const int nchunk = p.F / 32, per = nchunk / p.S, NC = per >> 1; // v1 chunks (32 units) of the layer / of this slice; 64-unit chunks
@@ -237,35 +264,42 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   schedule(0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) issue2(i);
-  // this wave's 64 activation rows as MFMA B operands, in registers for the whole kernel
-  otr_u32x4 xf[2][NKS];
+  schedule(1);
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-    const int64_t row = min(row0 + 32 * rt + m, p.M - 1);
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) xf[rt][ks] = *(const OTR_GLOBAL otr_u32x4*)(p.x16 + row * D + ks * 16 + hi * 8);
-  }
+  for (int i = 0; i < 4; ++i) issue2(i);
+  // this wave's 64 activation rows as MFMA B operands, in registers for the whole kernel; staged through ring slots 2 and 3
+  // (64 KiB), which receive their first DMAs only after the second barrier below
+  uint4* xs = reinterpret_cast<uint4*>(ring + 2 * F3_PHASE);
+  f3_stage_rows128<D>(xs, p.x16, rb, p.M, tid);
   for (int i = tid; i < per * 64; i += 256) {
     const int c = i >> 6, j = i & 63;
     bias_s[i] = p.b1[(j < 32 ? 0 : p.F) + (c_base + c) * 32 + (j & 31)];
   }
-  // The operand fragments must be KNOWN complete before the loop (ffn_fused.hip, lesson 2): otherwise the waitcnt pass guards
-  // every later use with vmcnt(n) and waits for the DMAs in flight.  This wait also covers phase 0's DMAs.
+  f3_wait_lds();
+  f3_barrier();
+  otr_u32x4 xf[2][NKS];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)     // "+a": the activation fragments are MFMA operands only -> the accumulator half of the register file
-      asm volatile("" : "+a"(xf[rt][ks]));
-  f3_wait_vm<0>();
-  schedule(1);
+    for (int ks = 0; ks < NKS; ++ks) {
+      const uint4 t = xs[(wr * 64 + 32 * rt + m) * (D / 8) + ((2 * ks + hi) ^ (m & 15))];
+      xf[rt][ks] = otr_u32x4{t.x, t.y, t.z, t.w};
+    }
+  // The operand fragments must be KNOWN complete before the loop (ffn_fused.hip, lesson 2); "+a": they are MFMA operands only
+  // -> the accumulator half of the register file
 #pragma unroll
-  for (int i = 0; i < 4; ++i) issue2(i);
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+a"(xf[rt][ks]));
+  f3_wait_lds();
+  f3_barrier();                                                  // every wave has its fragments: slots 2 and 3 may be filled
   schedule(2);
 #pragma unroll
   for (int i = 0; i < 4; ++i) issue2(i);
   schedule(3);                                                   // issued between the MFMA groups of phase 0
-  f3_wait_lds();
+  f3_wait_vm<16>();                                              // phase 0 has landed (phases 1, 2 may fly)
   f3_barrier();
+  F3_STAMP()
 
   f32x16 yacc[2][4];
 #pragma unroll
@@ -334,7 +368,8 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   f3_wait_lds();                                                                                               \
   f3_barrier();                                                                                                \
   schedule(slot);                                                                                              \
-  slot = (slot + 1) & 3;
+  slot = (slot + 1) & 3;                                                                                       \
+  F3_STAMP()
   // Phase G of chunk C.  G2: GEMM2 of chunk C-1 -- w_2 fragment (ct, k) at ring[(ct*4 + k) KiB]; this wave's column tiles are
   // 4 wc .. 4 wc + 3; contraction steps k_own, k_own + 1 take u from registers (uown), k_par, k_par + 1 the partner's (upart,
   // read from the hand-over buffer during phase B).  GLU: the GLU of chunk C in quarters; quarter kk REPLACES
@@ -436,9 +471,11 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
 #undef F3_PHASE_END
 #undef F3_PHASE_G
 #undef F3_READ_PARTNER
+  F3_STAMP()
   f3_wait_vm<0>();                                               // the placeholder DMAs have landed: the ring becomes scratch
   f3_wait_lds();
   f3_barrier();
+  F3_STAMP()
 
   if constexpr (!FUSE) {
   // ---- partial output rows -> slab `sl`, staged through the idle ring so that memory sees whole 256-byte row segments: each
@@ -499,11 +536,14 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
       gmr[t][q] = *reinterpret_cast<const float4*>(p.gamma + col);
       btr[t][q] = *reinterpret_cast<const float4*>(p.beta + col);
     }
+  F3_STAMP()
   f3_wait_vm<0>();                                               // this wave's write-through stores are at memory
   f3_wait_lds();
   f3_barrier();
+  F3_STAMP()
   if (tid == 0) f3_arrive_wait(p.sync + 8 * rb, p.spin_limit, p.fault);
   f3_barrier();
+  F3_STAMP()
   // ---- the quarter's rows: lane (m, hi) of wave `wid` owns row m, columns 32 ct + 8 q + 4 hi .. + 3 for ct = 2 wid, 2 wid + 1
   otr_u32x4 part[3][2][4];
   f3_recv_partials(part, rs, p.sync + 8 * rb, xcc, sl, wid, lane);
@@ -536,6 +576,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
         sm += zz;
       }
     }
+  F3_STAMP()
   sm += __shfl_xor(sm, 32);
   if (hi == 0) red[wid * 32 + m] = sm;
   f3_wait_lds();
@@ -582,7 +623,9 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   }
   // every partial this workgroup needed has been read: the last of the four readers re-arms the row block's counters
   if (tid == 0) f3_done(p.sync + 8 * rb);
+  F3_STAMP()
   }
+#undef F3_STAMP
 }
 
 
@@ -686,14 +729,29 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   schedule(0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) issue2(i);
-  // this wave's 64 rows of dy as MFMA B operands, in (accumulator) registers for the whole kernel
+  schedule(1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue2(i);
+  // this wave's 64 rows of dy as MFMA B operands, in (accumulator) registers for the whole kernel; staged through ring slots 2
+  // and 3 (f3_stage_rows128)
+  uint4* xs = reinterpret_cast<uint4*>(ring + 2 * F3_PHASE);
+  f3_stage_rows128<D>(xs, p.dy16, rb, p.M, tid);
+  f3_wait_lds();
+  f3_barrier();
   otr_u32x4 dyf[2][NKS];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-    const int64_t row = min(row0 + 32 * rt + m, p.M - 1);
+  for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) dyf[rt][ks] = *(const OTR_GLOBAL otr_u32x4*)(p.dy16 + row * D + ks * 16 + hi * 8);
-  }
+    for (int ks = 0; ks < NKS; ++ks) {
+      const uint4 t = xs[(wr * 64 + 32 * rt + m) * (D / 8) + ((2 * ks + hi) ^ (m & 15))];
+      dyf[rt][ks] = otr_u32x4{t.x, t.y, t.z, t.w};
+    }
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+a"(dyf[rt][ks]));
+  f3_wait_lds();
+  f3_barrier();                                                  // every wave has its fragments: slots 2 and 3 may be filled
   // the saved (value, sigmoid) tiles of chunk C for this wave: 8 pieces; hp[0..3] = row tile 0 (value 0, 1, sigmoid 0, 1),
   // hp[4..7] = row tile 1
   const unsigned char* hbase = reinterpret_cast<const unsigned char*>(p.hsave) + ((int64_t)((rb * 4 + sl) * NC) * 4 + wid) * 8192;
@@ -709,20 +767,12 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   };
   hload(0, 0);
   hload(0, 1);
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+a"(dyf[rt][ks]));
-  f3_wait_vm_for<0>(hp[0], hp[1], hp[2], hp[3]);
-  f3_wait_vm_for<0>(hp[4], hp[5], hp[6], hp[7]);
-  schedule(1);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) issue2(i);
   schedule(2);
 #pragma unroll
   for (int i = 0; i < 4; ++i) issue2(i);
   schedule(3);
-  f3_wait_lds();
+  f3_wait_vm_for<8>(hp[0], hp[1], hp[2], hp[3]);                 // phases 0, 1 and the first tiles have landed (phase 2 may fly)
+  f3_wait_vm_for<8>(hp[4], hp[5], hp[6], hp[7]);
   f3_barrier();
 
   f32x16 xacc[2][4];
@@ -947,9 +997,11 @@ static inline unsigned f3_grid(int64_t M, int S) {
 extern int g_otr_spin_limit;
 extern int32_t* g_otr_fault;
 extern int g_otr_ffn_coh_only;
+extern unsigned long long* g_otr_trace;
 
 #define F3_LAUNCH_FWD(FUSE, SAVE)                                                                                        \
-  switch (g_otr_ffn2_ablate & 7) {                                                                                       \
+  switch (g_otr_ffn2_ablate & 31) {                                                                                      \
+    case 16: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 16, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break; \
     case 0: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 0, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
     case 1: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 1, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
     case 2: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 2, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
@@ -982,7 +1034,7 @@ int32_t ffn3_ln_fwd_launch(const float* x, const void* x16, const void* w1_pack,
   p.M = (int)M; p.F = F; p.S = S;
   p.x = x; p.b2 = b2; p.gamma = gamma; p.beta = beta; p.seed = seed; p.y = y; p.y16 = (uint16_t*)y16; p.z = z; p.mean = mean; p.rstd = rstd;
   p.sync = sync; p.fault = g_otr_fault; p.spin_limit = g_otr_spin_limit; p.coh_only = g_otr_ffn_coh_only; p.eps = eps; p.p_drop = p_drop; p.rng_offset = rng_offset;
-  p.hsave = (uint4*)hsave; p.usave = (uint16_t*)usave;
+  p.hsave = (uint4*)hsave; p.usave = (uint16_t*)usave; p.trace = g_otr_trace;
   if (hsave) { F3_LAUNCH_FWD(true, true) } else { F3_LAUNCH_FWD(true, false) }
   return otr_check_launch("ffn3_ln_fwd");
 }
