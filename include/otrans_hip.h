@@ -161,7 +161,8 @@ int32_t otr_ln_bwd_proj(const float* dy, const float* z, const float* mean, cons
  *      through `scratch` (write-through stores, one arrival counter per row block in `sync`) and finish a quarter of the rows
  *      each.  d_ff % 256 == 0, d_model 256.
  *      scratch: >= otr_ffn_split_scratch_bytes(M) bytes, contents don't care; sync: >= otr_ffn_split_sync_ints(M) ints, ZERO
- *      before the first call -- every call leaves them zero again.  The arrival wait is bounded (otr_debug_set(11, v)); a
+ *      before the first call and owned by these kernels afterwards (monotonic arrival counters: launches on one buffer must
+ *      be stream-ordered).  The arrival wait is bounded (otr_debug_set(11, v)); a
  *      give-up is reported through otr_set_fault_counter and leaves wrong rows behind.  Needs the four workgroups of a row
  *      block co-resident: any grid on an otherwise idle GPU (they sit next to each other in dispatch order).
  * otr_ffn_ln_fwd_split: y = LayerNorm(x + dropout(w_2 glu(w_1 x + b_1) + b_2)), outputs as otr_ffn_ln_fwd.  With hsave / usave

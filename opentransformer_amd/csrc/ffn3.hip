@@ -70,20 +70,45 @@ typedef decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 
 
 // Cache policy of a transfer.  The XCDs' L2s are not coherent with each other, so in general the sender writes THROUGH
 // (sc0 sc1) and the receiver reads past its L2 (sc0 sc1).  But the four workgroups of a row block are neighbours in dispatch
-// order and in practice share an XCD; each publishes its XCC id (+1) in the row block's sync record at kernel entry, and a
-// transfer whose two ends read EQUAL ids uses the shared L2: plain stores (at the L2 when vmcnt drains) and sc1 loads (past
-// the L1, served by the L2).  Mixed decisions stay correct: an id not yet published or different -> write-through; a
-// write-through store on the same XCD drops the line from that L2, so an L2-served load refetches it; the ids are cleared
-// with the counters, so a stale id of an earlier launch never vouches for a placement.
-//   sync record of a row block (8 ints): [0] arrivals, [1] readers done, [2 + s] XCC id + 1 of slice s
+// order and in practice share an XCD; each publishes its XCC id in the row block's sync record at kernel entry, and a transfer
+// whose two ends read EQUAL ids uses the shared L2: plain stores (at the L2 when vmcnt drains) and sc1 loads (past the L1,
+// served by the L2).  Mixed decisions stay correct: an id not (yet) valid or different -> write-through; a write-through
+// store on the same XCD drops the line from that L2, so an L2-served load refetches it.
+//   sync record of a row block (8 ints): [0] arrivals, MONOTONIC: launches are stream-ordered, so launch n finds 4n and a
+//   workgroup waits for 4n + 4 -- nothing is reset, nobody is the "last reader"; [2 + s] = (n << 6) | (XCC id of slice s + 1),
+//   valid only with this launch's n (a stale id of an earlier launch never vouches for a placement).
+// Every agent-scope load is a round trip of 1-2 us, so the record is read TWICE per workgroup, both off the critical path: the
+// generation at kernel entry, the four ids while the closing MFMAs run (ids still invalid then are re-read after the arrival
+// wait, when they are certain to be there).
 __device__ __forceinline__ int f3_xcc_id() {
   int v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
   return v & 0xf;
 }
-__device__ __forceinline__ void f3_publish_xcc(int* rec, int sl, int xcc) {
-  __hip_atomic_store(rec + 2 + sl, xcc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+struct F3Sync {
+  int* rec;
+  int gen;                 // arrivals at this launch's start (a multiple of 4)
+  int xcc;
+  int ids[4];              // the slices' entries as read early (f3_sync_read_ids)
+};
+__device__ __forceinline__ int f3_agent_load(const int* p) {
+  return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+// kernel entry: the load only (its round trip hides behind the prologue); f3_sync_publish after the prologue's first barrier
+__device__ __forceinline__ void f3_sync_begin(F3Sync& y, int* rec, int xcc) {
+  y.rec = rec; y.xcc = xcc;
+  y.gen = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void f3_sync_publish(F3Sync& y, int sl, int tid) {
+  y.gen = __builtin_amdgcn_readfirstlane(y.gen) & ~3;           // a late starter may see partners' arrivals of THIS launch: < 4
+  if (tid == 0) __hip_atomic_store(y.rec + 2 + sl, ((y.gen >> 2) << 6) | (y.xcc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void f3_sync_read_ids(F3Sync& y) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) y.ids[i] = __hip_atomic_load(y.rec + 2 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool f3_same_xcd(const F3Sync& y, int entry) { return entry == (((y.gen >> 2) << 6) | (y.xcc + 1)); }
+__device__ __forceinline__ bool f3_entry_valid(const F3Sync& y, int entry) { return (entry >> 6) == (y.gen >> 2) && (entry & 63) != 0; }
 template <int AUX>
 __device__ __forceinline__ void f3_store_tile4(const f32x16 (&acc)[4], f3_rsrc_t rs, uint32_t base) {
 #pragma unroll
@@ -98,8 +123,8 @@ __device__ __forceinline__ void f3_store_tile4(const f32x16 (&acc)[4], f3_rsrc_t
 // wave (wr, wc) holds acc[rt][ct]: rows 64 wr + 32 rt .., columns 128 wc + 32 ct ..; the row tile that belongs to quarter `sl`
 // (this workgroup finishes it) goes to LDS `own` [8 column tiles][4 q][64 lanes] float4, the others to
 // scratch[sender sl][quarter] of the row block
-__device__ __forceinline__ void f3_send_partials(const f32x16 (&acc)[2][4], f3_rsrc_t rs, float* own, const int* rec, int xcc, int sl, int wr,
-                                                 int wc, int lane) {
+__device__ __forceinline__ void f3_send_partials(const f32x16 (&acc)[2][4], f3_rsrc_t rs, float* own, const F3Sync& y, int sl, int wr, int wc,
+                                                 int lane) {
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
     const int qt = 2 * wr + rt;                                  // the quarter these 32 rows belong to (wave-uniform)
@@ -112,17 +137,18 @@ __device__ __forceinline__ void f3_send_partials(const f32x16 (&acc)[2][4], f3_r
               make_float4(acc[rt][ct][4 * q], acc[rt][ct][4 * q + 1], acc[rt][ct][4 * q + 2], acc[rt][ct][4 * q + 3]);
     } else {
       const uint32_t base = (uint32_t)((sl * 4 + qt) * 32768 + (4 * wc) * 4096 + lane * 16);
-      const bool same = __builtin_amdgcn_readfirstlane(__hip_atomic_load(rec + 2 + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == xcc + 1;
-      if (same) f3_store_tile4<0>(acc[rt], rs, base); else f3_store_tile4<F3_AUX_COH>(acc[rt], rs, base);
+      const int e = __builtin_amdgcn_readfirstlane(qt == 0 ? y.ids[0] : qt == 1 ? y.ids[1] : qt == 2 ? y.ids[2] : y.ids[3]);
+      if (f3_same_xcd(y, e)) f3_store_tile4<0>(acc[rt], rs, base); else f3_store_tile4<F3_AUX_COH>(acc[rt], rs, base);
     }
   }
 }
 // one lane: arrive, then wait for all four workgroups of the row block (bounded; a give-up bumps the fault word)
-__device__ __forceinline__ void f3_arrive_wait(int* arrive, int spin_limit, int* fault) {
-  __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void f3_arrive_wait(const F3Sync& y, int spin_limit, int* fault) {
+  __hip_atomic_fetch_add(y.rec, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int target = y.gen + 4;
   int spins = 0;
-  while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4 && spins < spin_limit) {
-    __builtin_amdgcn_s_sleep(4);
+  while (__hip_atomic_load(y.rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0 && spins < spin_limit) {
+    __builtin_amdgcn_s_sleep(2);
     ++spins;
   }
   if (spins >= spin_limit && fault) __hip_atomic_fetch_add(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -135,20 +161,14 @@ __device__ __forceinline__ void f3_load_tile2(otr_u32x4 (&part)[2][4], f3_rsrc_t
     for (int q = 0; q < 4; ++q) part[t][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (uint32_t)((t * 4 + q) * 1024), 0, AUX);
 }
 // the three partners' partials of quarter `sl`, column tiles 2 wid, 2 wid + 1 (after the arrival wait: every id is published)
-__device__ __forceinline__ void f3_recv_partials(otr_u32x4 (&part)[3][2][4], f3_rsrc_t rs, const int* rec, int xcc, int sl, int wid, int lane) {
+__device__ __forceinline__ void f3_recv_partials(otr_u32x4 (&part)[3][2][4], f3_rsrc_t rs, const F3Sync& y, int sl, int wid, int lane) {
 #pragma unroll
   for (int n = 0; n < 3; ++n) {
     const int s2 = n + (n >= sl ? 1 : 0);                        // the three other slices (wave-uniform)
     const uint32_t base = (uint32_t)((s2 * 4 + sl) * 32768 + (2 * wid) * 4096 + lane * 16);
-    const bool same = __builtin_amdgcn_readfirstlane(__hip_atomic_load(rec + 2 + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == xcc + 1;
-    if (same) f3_load_tile2<16>(part[n], rs, base); else f3_load_tile2<F3_AUX_COH>(part[n], rs, base);
-  }
-}
-// one lane, after this workgroup has read everything it needed: the last of the four readers re-arms the record
-__device__ __forceinline__ void f3_done(int* rec) {
-  if (__hip_atomic_fetch_add(rec + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) __hip_atomic_store(rec + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int e = __builtin_amdgcn_readfirstlane(s2 == 0 ? y.ids[0] : s2 == 1 ? y.ids[1] : s2 == 2 ? y.ids[2] : y.ids[3]);
+    if (!f3_entry_valid(y, e)) e = f3_agent_load(y.rec + 2 + s2);   // read too early (rare): the sender may have seen OUR id
+    if (f3_same_xcd(y, e)) f3_load_tile2<16>(part[n], rs, base); else f3_load_tile2<F3_AUX_COH>(part[n], rs, base);
   }
 }
 
@@ -188,7 +208,7 @@ struct Ffn3FwdArgs {
                            // backward kernel: [row block][slice][64-unit chunk][wave][8 pieces][64 lanes] x 16 B; piece
                            // rt*2 + j = value registers 8j .. 8j+7 of row tile rt, piece 4 + rt*2 + j = the sigmoids
   uint16_t* usave;         // SAVE: u = glu output [128 * row blocks, F] row-major (operand of the w_2 weight gradient)
-  int* sync;               // [8 * row blocks] zero on entry, zero again on exit: the row blocks' sync records (f3_send_partials)
+  int* sync;               // [8 * row blocks] zero before the first launch: the row blocks' sync records (F3Sync)
   int* fault;              // NULL or the sticky fault word (otr_set_fault_counter)
   int spin_limit, coh_only;
   unsigned long long* trace;   // tuning hook (otr_debug_trace): wave 0 of every workgroup stamps the shader clock: [48 per workgroup]
@@ -225,8 +245,9 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   int stamp_i = 0;
 #define F3_STAMP() if constexpr ((ABL & 16) != 0) { if (p.trace && tid == 0 && stamp_i < 48) p.trace[(int64_t)blockIdx.x * 48 + stamp_i++] = __builtin_amdgcn_s_memtime(); }
   F3_STAMP()
-  const int xcc = p.coh_only ? 16 + sl : f3_xcc_id();            // coh_only (otr_debug_set(12, 1)): no two ids match -> every transfer writes through
-  if constexpr (FUSE) { if (tid == 0) f3_publish_xcc(p.sync + 8 * rb, sl, xcc); }
+  F3Sync sy{};
+  if constexpr (FUSE)                                          // coh_only (otr_debug_set(12, 1)): no two ids match -> every transfer writes through
+    f3_sync_begin(sy, p.sync + 8 * rb, p.coh_only ? 16 + sl : f3_xcc_id());
   const int nchunk = p.F / 32, per = nchunk / p.S, NC = per >> 1; // v1 chunks (32 units) of the layer / of this slice; 64-unit chunks
   const int c_base = sl * per;
 
@@ -277,6 +298,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   }
   f3_wait_lds();
   f3_barrier();
+  if constexpr (FUSE) f3_sync_publish(sy, sl, tid);
   otr_u32x4 xf[2][NKS];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
@@ -462,7 +484,8 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
     F3_PHASE_G(true, true, slot, C)
     F3_PHASE_END(KG)
   }
-  // ---- closing phase: GEMM2 of chunk NC-1 (its w_2 took the place of a phase A(NC))
+  // ---- closing phase: GEMM2 of chunk NC-1 (its w_2 took the place of a phase A(NC)); the partners' ids travel meanwhile
+  if constexpr (FUSE) f3_sync_read_ids(sy);
   F3_READ_PARTNER()
   F3_PHASE_G(true, false, slot, 0)
 #undef F3_ISSUE2
@@ -520,7 +543,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   float* own = reinterpret_cast<float*>(ring);                   // [8 column tiles][4 q][64 lanes] float4 = 32 KiB
   float* red = reinterpret_cast<float*>(ring + 32768);           // [2 passes][4 waves][32 rows]
   auto rs = __builtin_amdgcn_make_buffer_rsrc(p.slabs + (int64_t)rb * (4 * 4 * 8192), 0, 4 * 4 * 32768, 0x00020000);
-  f3_send_partials(yacc, rs, own, p.sync + 8 * rb, xcc, sl, wr, wc, lane);
+  f3_send_partials(yacc, rs, own, sy, sl, wr, wc, lane);
   // everything the quarter's epilogue reads besides the partials is fetched before the arrival wait
   const int64_t row = (int64_t)rb * 128 + 32 * sl + m;
   const bool live = row < p.M;
@@ -541,12 +564,12 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   f3_wait_lds();
   f3_barrier();
   F3_STAMP()
-  if (tid == 0) f3_arrive_wait(p.sync + 8 * rb, p.spin_limit, p.fault);
+  if (tid == 0) f3_arrive_wait(sy, p.spin_limit, p.fault);
   f3_barrier();
   F3_STAMP()
   // ---- the quarter's rows: lane (m, hi) of wave `wid` owns row m, columns 32 ct + 8 q + 4 hi .. + 3 for ct = 2 wid, 2 wid + 1
   otr_u32x4 part[3][2][4];
-  f3_recv_partials(part, rs, p.sync + 8 * rb, xcc, sl, wid, lane);
+  f3_recv_partials(part, rs, sy, sl, wid, lane);
   const bool drop = p.p_drop > 0.f;
   const uint64_t seed = drop ? *p.seed : 0;
   const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
@@ -621,8 +644,6 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
     }
     if (wid == 0 && hi == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
   }
-  // every partial this workgroup needed has been read: the last of the four readers re-arms the row block's counters
-  if (tid == 0) f3_done(p.sync + 8 * rb);
   F3_STAMP()
   }
 #undef F3_STAMP
@@ -687,8 +708,8 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   f3_block_map((int)blockIdx.x, 4, rb, sl);
   if (rb * 128 >= p.M) return;
   const int row0 = rb * 128 + wr * 64;
-  const int xcc = p.coh_only ? 16 + sl : f3_xcc_id();
-  if (tid == 0) f3_publish_xcc(p.sync + 8 * rb, sl, xcc);
+  F3Sync sy{};
+  f3_sync_begin(sy, p.sync + 8 * rb, p.coh_only ? 16 + sl : f3_xcc_id());
   const int nchunk = p.F / 32, per = nchunk / 4, NC = per >> 1;
   const int c_base = sl * per;
   constexpr bool no_dma = (ABL & 1) != 0, no_mma = (ABL & 2) != 0, no_st = (ABL & 4) != 0, no_hl = (ABL & 8) != 0;
@@ -738,6 +759,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   f3_stage_rows128<D>(xs, p.dy16, rb, p.M, tid);
   f3_wait_lds();
   f3_barrier();
+  f3_sync_publish(sy, sl, tid);
   otr_u32x4 dyf[2][NKS];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
@@ -927,7 +949,9 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) dho[rt][k] = dhn[rt][k];
   }
-  // ---- closing phases: XA, XB of the last chunk (no DMA, no global traffic: only the last X phase's 16 may still fly)
+  // ---- closing phases: XA, XB of the last chunk (no DMA, no global traffic: only the last X phase's 16 may still fly); the
+  // partners' ids travel meanwhile
+  f3_sync_read_ids(sy);
   F3B_READ_PARTNER()
   F3B_PHASE_X(true, false, slot, dho, 0, 0, dhn)
   if constexpr (no_dma) f3_wait_vm<0>(); else f3_wait_vm<8>();    // of the last X phase: its 4 tile reloads + 4 of its DMAs at most
@@ -950,7 +974,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   // ---- exchange the four partial input gradients of the row block; this workgroup finishes quarter `sl`: dx = skip + sum
   float* own = reinterpret_cast<float*>(ring);
   auto rs = __builtin_amdgcn_make_buffer_rsrc(p.scratch + (int64_t)rb * (4 * 4 * 8192), 0, 4 * 4 * 32768, 0x00020000);
-  f3_send_partials(xacc, rs, own, p.sync + 8 * rb, xcc, sl, wr, wc, lane);
+  f3_send_partials(xacc, rs, own, sy, sl, wr, wc, lane);
   const int64_t row = (int64_t)rb * 128 + 32 * sl + m;
   const bool live = row < p.M;
   const int64_t crow = live ? row : (int64_t)p.M - 1;
@@ -964,10 +988,10 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   f3_wait_vm<0>();
   f3_wait_lds();
   f3_barrier();
-  if (tid == 0) f3_arrive_wait(p.sync + 8 * rb, p.spin_limit, p.fault);
+  if (tid == 0) f3_arrive_wait(sy, p.spin_limit, p.fault);
   f3_barrier();
   otr_u32x4 part[3][2][4];
-  f3_recv_partials(part, rs, p.sync + 8 * rb, xcc, sl, wid, lane);
+  f3_recv_partials(part, rs, sy, sl, wid, lane);
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -981,7 +1005,6 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
       }
       if (live) *reinterpret_cast<float4*>(p.dx + row * D + 32 * (2 * wid + t) + 8 * q + 4 * hi) = v;
     }
-  if (tid == 0) f3_done(p.sync + 8 * rb);
 }
 
 }  // namespace

@@ -119,7 +119,7 @@ def main():
     res['split_fwd_drop_us'] = timeit(lambda: fwd3(0.1), a.iters)
     fwd3(0.0)
     res['split_vs_v1_y_rel'] = float((y - y1).norm() / y1.norm())
-    res['split_sync_left'] = int(sync.abs().sum().item())
+    res['split_arrivals_mod4'] = int((sync.view(-1, 8)[:, 0] % 4).abs().sum().item())
     res['split_fwd_save_us'] = timeit(lambda: fwd3(0.0, True), a.iters)
     res['split_bwd_us'] = timeit(bwd3, a.iters)
     # parity of the split backward (saved tiles) against the 32-row kernel (recompute): dx without skip, dh, u
@@ -130,7 +130,6 @@ def main():
     res['split_vs_v1_dx_rel'] = float((dx3 - dxz).norm() / dxz.norm())
     res['split_vs_v1_dh_rel'] = float((dh3[:M].float() - dh.float()).norm() / dh.float().norm())
     res['split_vs_v1_u_rel'] = float((usave[:M].float() - u.float()).norm() / u.float().norm())
-    res['split_sync_left'] = int(sync.abs().sum().item())
     for ab in (1, 2, 3):
         lib.otr_debug_set(4, ab)
         res['split_fwd_ablate%d_us' % ab] = timeit(lambda: fwd3(0.0), a.iters)
