@@ -544,6 +544,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   float* red = reinterpret_cast<float*>(ring + 32768);           // [2 passes][4 waves][32 rows]
   auto rs = __builtin_amdgcn_make_buffer_rsrc(p.slabs + (int64_t)rb * (4 * 4 * 8192), 0, 4 * 4 * 32768, 0x00020000);
   f3_send_partials(yacc, rs, own, sy, sl, wr, wc, lane);
+  F3_STAMP()
   // everything the quarter's epilogue reads besides the partials is fetched before the arrival wait
   const int64_t row = (int64_t)rb * 128 + 32 * sl + m;
   const bool live = row < p.M;

@@ -36,7 +36,7 @@ live = t[:, 0] > 0
 t = t[live]
 n = int((t[0] > 0).sum())
 dt = np.diff(t[:, :n], axis=1).astype(np.float64)
-names = ['prologue'] + ['ph%d%s' % (i // 3, 'ABG'[i % 3]) for i in range(24)] + ['closing', 'drain+bar', 'send+loads', 'store drain+bar', 'arrive wait', 'recv+sum', 'LN+out']
+names = ['prologue'] + ['ph%d%s' % (i // 3, 'ABG'[i % 3]) for i in range(24)] + ['closing', 'drain+bar', 'send', 'hoisted loads', 'store drain+bar', 'arrive wait', 'recv+sum', 'LN+out']
 print('workgroups', t.shape[0], 'stamps', n, 'total cycles median', np.median(t[:, n - 1] - t[:, 0]), '(100 MHz s_memtime ticks?)')
 for i in range(min(n - 1, len(names))):
     print('%-16s median %8.0f  p10 %8.0f  p90 %8.0f' % (names[i], np.median(dt[:, i]), np.percentile(dt[:, i], 10), np.percentile(dt[:, i], 90)))
