@@ -32,8 +32,9 @@ def build(mode, dev):
     return model.to(dev).eval(), lm.to(dev).eval()
 
 
-def timed(fn, iters):
-    fn()
+def timed(fn, iters, warmup=1):
+    for _ in range(max(1, warmup)):
+        fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
@@ -42,7 +43,7 @@ def timed(fn, iters):
     return (time.perf_counter() - t0) / iters, out
 
 
-def main():
+def main(argv=None, emit=True):
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--frames', type=int, default=1000)
@@ -51,7 +52,8 @@ def main():
     ap.add_argument('--mode', default='fp16', choices=['fp16', 'bf16', 'fp32'])
     ap.add_argument('--iters', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
+    ap.add_argument('--warmup', type=int, default=1)
+    args = ap.parse_args(argv)
     from opentransformer_amd.recognize import SpeechToTextRecognizer
     dev = torch.device('cuda:0')
     model, lm = build(args.mode, dev)
@@ -64,11 +66,11 @@ def main():
     hyps = {}
     with torch.no_grad():
         enc = SpeechToTextRecognizer(model, **kw)
-        t_enc, _ = timed(lambda: enc.encode(x, m), args.iters)
+        t_enc, _ = timed(lambda: enc.encode(x, m), args.iters, args.warmup)
     for tag, cache, graph in (('reforward', False, False), ('cached_eager', True, False), ('cached_hipgraph', True, True)):
         rec = SpeechToTextRecognizer(model, apply_cache=cache, **kw)
         rec.use_hipgraph = graph
-        t, (h, s) = timed(lambda: rec.recognize(x, m), args.iters)
+        t, (h, s) = timed(lambda: rec.recognize(x, m), args.iters, args.warmup)
         hyps[tag] = [u[0] for u in h]
         res[tag] = {'s_per_batch': t, 'utt_per_s': args.batch / t,
                     'ms_per_step': (t - t_enc) * 1e3 / args.max_len}
@@ -109,7 +111,15 @@ def main():
                                'cores': torch.get_num_threads(), 'host_cores': os.cpu_count(), 'kind': 'port',
                                'sample': 'CPU oracle beam search (re-forward, like the reference), %d utterance, '
                                          'max_len %d' % (nb, ml)}
-    print(json.dumps(out))
+    # the driver's contract keys (bench.py --task decode): a step = one batch of utterances decoded end to end
+    out.update(n_gpus=1, steps=args.iters, warmup=args.warmup, ms_per_step=res['cached_hipgraph']['s_per_batch'] * 1e3,
+               higher_is_better=True, scaling='weak', vs_baseline=None, data='synthetic',
+               config={'workload': 'C5: transformer_baseline dims (12 enc / 6 dec), batch %d x %d frames, beam %d, 4-block TransformerLM '
+                                   'shallow fusion (weight 0.1), max_len %d, EOS suppressed; KV-cached decoder step replayed as one hipGraph'
+                                   % (args.batch, args.frames, args.beam, args.max_len), 'global_batch': args.batch})
+    if emit:
+        print(json.dumps(out))
+    return out
 
 
 if __name__ == '__main__':
