@@ -215,9 +215,8 @@ KERNEL_LABEL = {
 
 
 PMC_KERNEL = {'linear_wgrad_grouped': 'wgrad256_kernel', 'proj_ln_fwd': 'proj_ln_fwd_kernel', 'ln_bwd_proj': 'ln_bwd_proj_kernel',
-              'ffn_ln_fwd': 'ffn_ln_fwd_kernel', 'ffn_bwd': 'ffn_bwd_kernel', 'ffn_fwd_slabs': 'ffn3_fwd_kernel', 'ffn_ln_fwd_split': 'ffn3_fwd_kernel',
-              'ffn_bwd_split': 'ffn3_bwd_kernel',
-              'ffn_bwd_slabs': 'ffn3_bwd_kernel', 'rb_linear': 'rb_linear_kernel'}
+              'ffn_ln_fwd': 'ffn_ln_fwd_kernel', 'ffn_bwd': 'ffn_bwd_kernel', 'ffn_ln_fwd_split': 'ffn3_fwd_kernel',
+              'ffn_bwd_split': 'ffn3_bwd_kernel', 'rb_linear': 'rb_linear_kernel'}
 
 
 def replay_call(ops, call, n=10):

@@ -39,7 +39,9 @@ int32_t otr_version(void);
 /* OTR_BF16 or OTR_F16: the 16-bit type this library was built for */
 int32_t otr_half_type(void);
 /* tuning hook for benchmarks: key 0 = force GEMM tile (0 auto / 64 / 128), key 1 = force split-K (0 auto),
- * key 2 = 1: generic (bounds-checked) loaders only, key 3 = 1: no persistent tile loop, key 6 = 0/1: 256-wide
+ * key 2 = 1: generic (bounds-checked) loaders only, key 3 = 1: no persistent tile loop, key 4 = ablation bits of the split FFN
+ * kernels (ffn3.hip: 1 no weight DMA, 2 no MFMA, 4 no tile stores, 8 no tile loads, 16 clock stamps into otr_debug_trace's buffer;
+ * timing only), key 5 retired, key 6 = 0/1: 256-wide
  * weight-gradient launch off / on (-1: environment OTR_WGRAD256), key 7 = its workgroup count (0 = one per CU), key 8 = its ablation / cache
  * policy switches (wgrad256.h), key 9 = the shortest contraction it takes, key 10 = ablations of otr_conv2_dgrad (1 = no mask loads /
  * result stores, 2 = every operand load from one line: timing only, results are garbage), key 11 = bound of every in-kernel
@@ -184,20 +186,6 @@ int32_t otr_ffn_ln_fwd_split(const float* x, const void* x16, const void* w1_pac
 int32_t otr_ffn_bwd_split(const void* dy16, const void* hsave, const void* w2t_pack, const void* w1t_pack, void* dh,
                           const float* skip, float* dx, void* scratch, int64_t scratch_bytes, int32_t* sync, int64_t sync_ints,
                           int64_t M, int32_t F, int32_t d_model, void* stream);
-/* ---- the same sub-layer with the weight stream SHARED by 128 rows (v2, experimental: OTR_FFN_V2=1): a workgroup owns
- *      128 rows x 1/n_slabs of the hidden units, fetches every packed weight fragment once (global -> LDS, direct DMA)
- *      for its four waves, and leaves fp32 partial sums: slabs [n_slabs][M][256].
- * otr_ffn_fwd_slabs:  slabs = partial w_2(glu(w_1 x + b_1)) (b_2 not included); finish with otr_add_layernorm_fwd_slabs.
- * otr_ffn_bwd_slabs:  dh, u, db1_part as otr_ffn_bwd; slabs = partial dh . w_1; finish with otr_slab_sum(slabs, skip) -> dx.
- * otr_slab_sum:  out[n] = skip[n] (or 0) + sum over n_slabs of slabs[s*n + i], f32, n % 4 == 0; out may alias skip.
- * (d_ff / 32) % n_slabs == 0; 4 slabs fill the 256 CUs at 63 row blocks (B = 32 x 249 frames). */
-int32_t otr_ffn_fwd_slabs(const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, float* slabs,
-                          int32_t n_slabs, int64_t M, int32_t F, int32_t d_model, void* stream);
-int32_t otr_ffn_bwd_slabs(const void* x16, const void* dy16, const void* w1_pack, const float* b1, const void* w2t_pack,
-                          const void* w1t_pack, void* dh, void* u, float* db1_part, float* slabs, int32_t n_slabs, int64_t M,
-                          int32_t F, int32_t d_model, void* stream);
-int32_t otr_slab_sum(const float* slabs, int32_t n_slabs, int64_t n, const float* skip, float* out, void* stream);
-
 /* ---- grouped weight / bias gradients: every dw_i[N,K] += dy_i[M,N]^T x_i[M,K] of a backward pass in a few launches
  *      (one per operand-type group), likewise every bias gradient out_i[N] += column sums of a_i[M,N].  The per-layer
  *      launches they replace are latency bound (a 4-k-step GEMM workgroup lives ~10 us, every launch costs 2-3 us);
@@ -280,12 +268,6 @@ typedef struct {
 int32_t otr_add_layernorm_fwd(const otr_ln_desc_t* d, const float* x, const void* a, const float* gamma,
                               const float* beta, const uint64_t* seed, float* y, void* y_bf16, float* z, float* mean,
                               float* rstd, void* stream);
-/* the branch given as n_slabs f32 partial sums [n_slabs][slab_stride >= M*d] plus an optional bias a_bias f32[d]
- * (otr_ffn_fwd_slabs): y = LayerNorm(x + dropout(a_bias + sum of slabs)); outputs as otr_add_layernorm_fwd */
-int32_t otr_add_layernorm_fwd_slabs(const otr_ln_desc_t* d, const float* x, const float* slabs, int32_t n_slabs,
-                                    int64_t slab_stride, const float* a_bias, const float* gamma, const float* beta,
-                                    const uint64_t* seed, float* y, void* y_bf16, float* z, float* mean, float* rstd,
-                                    void* stream);
 /* dx f32 [M,d] (residual grad), da [M,d] a_dtype (branch grad, may be NULL), dgamma/dbeta f32[d] +=.
  * da_colsum (f32[d] +=, may be NULL): column sums of da, i.e. the bias gradient of the Linear that produced the
  * branch (module/attention.py:43 output_proj, module/ffn.py:41 w_2) without a separate reduction launch. */

@@ -78,10 +78,6 @@ SIGNATURES = {
     'otr_ffn_split_padded_rows': [_I64],
     'otr_ffn_ln_fwd_split': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F32, C.c_uint64, _F32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _P],
     'otr_ffn_bwd_split': [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _P],
-    'otr_ffn_fwd_slabs': [_P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _P],
-    'otr_ffn_bwd_slabs': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _P],
-    'otr_slab_sum': [_P, _I32, _I64, _P, _P, _P],
-    'otr_add_layernorm_fwd_slabs': [C.POINTER(LnDesc), _P, _P, _I32, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_linear_wgrad_grouped': [_P, _I32, _I32, _P, _I64, _P],
     'otr_colsum_grouped': [_P, _I32, _P],
     'otr_colsum': [_P, _I32, _I64, _I64, _I64, _P, _I32, _P],

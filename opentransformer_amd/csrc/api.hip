@@ -40,7 +40,6 @@ int g_otr_force_tile = 0;
 int g_otr_force_ksplit = 0;
 int g_otr_force_generic = 0;
 int g_otr_no_persist = 0;
-int g_otr_ffn_waves = 4;   // 8 measured SLOWER (85 vs 61 us forward): see DESIGN.md
 int g_otr_ffn2_ablate = 0;   // tuning hook (otr_debug_set(4, v)): bit 0 = no weight DMA after the first chunk, bit 1 = no MFMA work
 int g_otr_wgrad256 = -1;     // 256x256-tile weight-gradient launch (wgrad256.hip): -1 = environment OTR_WGRAD256 (default on), 0 / 1 (otr_debug_set(6, v))
 int g_otr_wgrad256_ablate = 0;   // tuning hook (otr_debug_set(8, v)), see wgrad256.h
@@ -58,7 +57,7 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   else if (key == 2) g_otr_force_generic = value;
   else if (key == 3) g_otr_no_persist = value;
   else if (key == 4) g_otr_ffn2_ablate = value;
-  else if (key == 5) g_otr_ffn_waves = value;
+  else if (key == 5) { /* retired (8-wave form of the 32-row FFN kernel) */ }
   else if (key == 6) g_otr_wgrad256 = value;
   else if (key == 7) g_otr_wgrad256_grid = value;
   else if (key == 8) g_otr_wgrad256_ablate = value;

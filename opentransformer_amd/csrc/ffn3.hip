@@ -1,9 +1,10 @@
 // Fused FFN sub-layer, third form: 128-row workgroups, weights through an LDS-DMA ring, 64 rows per wave
 // (encoder/transformer.py:58-63, decoder/transformer.py:82-86, module/ffn.py:38-41 with activation 'glu').
 //
-//   forward :  partial y_s = w_2[:, slice s] glu(w_1[slice s] x + b_1[slice s])        (S hidden slices -> S fp32 slabs; the
-//              bias b_2 / dropout / residual / LayerNorm epilogue sums the slabs: otr_add_layernorm_fwd_slabs)
-//   backward:  dh, u for the weight gradients, partial dx_s = dh[slice s] . w_1[slice s]  (summed by otr_slab_sum)
+//   forward :  partial y_s = w_2[:, slice s] glu(w_1[slice s] x + b_1[slice s]) for S = 4 hidden slices; the four workgroups of a
+//              row block exchange their partial sums and each finishes 32 rows: + b_2, dropout, residual, LayerNorm
+//   backward:  dh for the weight gradients from the SAVED (value, sigmoid) tiles, partial dx_s = dh[slice s] . w_1[slice s],
+//              exchanged the same way (+ skip)
 //
 // Why a third form: the 32-row kernels (ffn_fused.hip) stream ALL packed weights into every CU and sit on the
 // CU's ~22 B/clk vector-memory ingest (60 us forward for 3 MB per CU).  A workgroup here owns 128 rows x 1/S of the hidden
@@ -198,10 +199,9 @@ __device__ __forceinline__ void f3_stage_rows128(uint4* xs, const uint16_t* src,
 struct Ffn3FwdArgs {
   const uint16_t* x16;     // [M, D]
   const uint4* p1; const float* b1; const uint4* p2;
-  float* slabs;            // slab form: [S][M][D] f32 partial outputs (bias b_2 NOT included); fused form: exchange scratch
-                           // [row block][sender slice][quarter][32 KiB of accumulator tiles]
+  float* scratch;          // exchange of the partial sums: [row block][sender slice][quarter][32 KiB of accumulator tiles]
   int M, F, S;
-  // ---- fused form only (in-kernel reduction of the S = 4 partial sums + bias + dropout + residual + LayerNorm)
+  // ---- epilogue (in-kernel reduction of the S = 4 partial sums + bias + dropout + residual + LayerNorm)
   const float* x; const float* b2; const float* gamma; const float* beta; const uint64_t* seed;
   float* y; uint16_t* y16; float* z; float* mean; float* rstd;
   uint4* hsave;            // SAVE: (value + bias, sigmoid(gate)) of every hidden unit, 16-bit, in ACCUMULATOR-TILE order for the
@@ -225,7 +225,7 @@ __device__ __forceinline__ void f3_block_map(int b, int S, int& rb, int& s) {
   rb = (j / S) * 8 + xcd;
 }
 
-template <int D, int ABL, bool FUSE, bool SAVE>
+template <int D, int ABL, bool SAVE>
 __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   static_assert(D == 256, "two 128-column halves, 16 contraction steps");
   constexpr int NKS = D / 16;
@@ -246,8 +246,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
 #define F3_STAMP() if constexpr ((ABL & 16) != 0) { if (p.trace && tid == 0 && stamp_i < 48) p.trace[(int64_t)blockIdx.x * 48 + stamp_i++] = __builtin_amdgcn_s_memtime(); }
   F3_STAMP()
   F3Sync sy{};
-  if constexpr (FUSE)                                          // coh_only (otr_debug_set(12, 1)): no two ids match -> every transfer writes through
-    f3_sync_begin(sy, p.sync + 8 * rb, p.coh_only ? 16 + sl : f3_xcc_id());
+  f3_sync_begin(sy, p.sync + 8 * rb, p.coh_only ? 16 + sl : f3_xcc_id());
   const int nchunk = p.F / 32, per = nchunk / p.S, NC = per >> 1; // v1 chunks (32 units) of the layer / of this slice; 64-unit chunks
   const int c_base = sl * per;
 
@@ -298,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   }
   f3_wait_lds();
   f3_barrier();
-  if constexpr (FUSE) f3_sync_publish(sy, sl, tid);
+  f3_sync_publish(sy, sl, tid);
   otr_u32x4 xf[2][NKS];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
@@ -485,7 +484,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
     F3_PHASE_END(KG)
   }
   // ---- closing phase: GEMM2 of chunk NC-1 (its w_2 took the place of a phase A(NC)); the partners' ids travel meanwhile
-  if constexpr (FUSE) f3_sync_read_ids(sy);
+  f3_sync_read_ids(sy);
   F3_READ_PARTNER()
   F3_PHASE_G(true, false, slot, 0)
 #undef F3_ISSUE2
@@ -500,36 +499,6 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   f3_barrier();
   F3_STAMP()
 
-  if constexpr (!FUSE) {
-  // ---- partial output rows -> slab `sl`, staged through the idle ring so that memory sees whole 256-byte row segments: each
-  // wave uses a private 8 KiB slice, 32 rows x 64 columns at a time (no workgroup barrier needed)
-  float* st = reinterpret_cast<float*>(ring + wid * 8192);       // [32 rows][64 cols]
-  float* out = p.slabs + ((int64_t)sl * p.M) * D;
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float4*>(st + m * 64 + t * 32 + 8 * q + 4 * hi) =
-              make_float4(yacc[rt][2 * h + t][4 * q], yacc[rt][2 * h + t][4 * q + 1], yacc[rt][2 * h + t][4 * q + 2],
-                          yacc[rt][2 * h + t][4 * q + 3]);
-      __builtin_amdgcn_wave_barrier();
-      f3_wait_lds();
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {                           // 4 rows x 16 lanes x float4 per pass
-        const int r = rr * 4 + (lane >> 4);
-        const int64_t row = (int64_t)row0 + 32 * rt + r;
-        const float4 v = *reinterpret_cast<const float4*>(st + r * 64 + (lane & 15) * 4);
-        if (row < p.M) *reinterpret_cast<float4*>(out + row * D + 128 * wc + 64 * h + (lane & 15) * 4) = v;
-      }
-      __builtin_amdgcn_wave_barrier();
-      f3_wait_lds();
-    }
-  }
-  } else {
   // ---- fused form (S = 4): the four workgroups of a row block exchange their partial sums and each finishes ONE quarter of
   // the rows (32 rows: quarter `sl`): y = LayerNorm(x + dropout(sum of the four partials + b_2)).  Everything stays in the
   // accumulator layout -- tile (ct, q): lane (m, hi) holds columns 32 ct + 8 q + 4 hi .. + 3 of row m as one float4 -- so the
@@ -542,7 +511,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   //   4. bias, dropout (the mask otr_add_layernorm_bwd regenerates), residual, LayerNorm; y / y16 / z / mean / rstd
   float* own = reinterpret_cast<float*>(ring);                   // [8 column tiles][4 q][64 lanes] float4 = 32 KiB
   float* red = reinterpret_cast<float*>(ring + 32768);           // [2 passes][4 waves][32 rows]
-  auto rs = __builtin_amdgcn_make_buffer_rsrc(p.slabs + (int64_t)rb * (4 * 4 * 8192), 0, 4 * 4 * 32768, 0x00020000);
+  auto rs = __builtin_amdgcn_make_buffer_rsrc(p.scratch + (int64_t)rb * (4 * 4 * 8192), 0, 4 * 4 * 32768, 0x00020000);
   f3_send_partials(yacc, rs, own, sy, sl, wr, wc, lane);
   F3_STAMP()
   // everything the quarter's epilogue reads besides the partials is fetched before the arrival wait
@@ -646,7 +615,6 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
     if (wid == 0 && hi == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
   }
   F3_STAMP()
-  }
 #undef F3_STAMP
 }
 
@@ -1023,24 +991,15 @@ extern int32_t* g_otr_fault;
 extern int g_otr_ffn_coh_only;
 extern unsigned long long* g_otr_trace;
 
-#define F3_LAUNCH_FWD(FUSE, SAVE)                                                                                        \
+#define F3_LAUNCH_FWD(SAVE)                                                                                        \
   switch (g_otr_ffn2_ablate & 31) {                                                                                      \
-    case 16: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 16, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break; \
-    case 0: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 0, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
-    case 1: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 1, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
-    case 2: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 2, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
-    case 4: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 4, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
-    default: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 3, FUSE, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;  \
+    case 16: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 16, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break; \
+    case 0: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 0, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
+    case 1: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 1, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
+    case 2: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 2, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
+    case 4: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 4, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;   \
+    default: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 3, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;  \
   }
-
-int32_t ffn3_fwd_launch(const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, float* slabs, int32_t S, int64_t M,
-                        int32_t F, hipStream_t stream) {
-  Ffn3FwdArgs p{};
-  p.x16 = (const uint16_t*)x16; p.p1 = (const uint4*)w1_pack; p.b1 = b1; p.p2 = (const uint4*)w2_pack; p.slabs = slabs;
-  p.M = (int)M; p.F = F; p.S = S;
-  F3_LAUNCH_FWD(false, false)
-  return otr_check_launch("ffn3_fwd");
-}
 
 // scratch bytes / sync ints of the fused form for M rows (S = 4); bytes of the saved (value, sigmoid) tiles; padded rows of u / dh
 int64_t ffn3_scratch_bytes(int64_t M) { return ((M + 127) / 128) * (int64_t)(4 * 4 * 32768); }
@@ -1054,12 +1013,12 @@ int32_t ffn3_ln_fwd_launch(const float* x, const void* x16, const void* w1_pack,
                            int32_t* sync, int64_t M, int32_t F, hipStream_t stream) {
   constexpr int S = 4;
   Ffn3FwdArgs p{};
-  p.x16 = (const uint16_t*)x16; p.p1 = (const uint4*)w1_pack; p.b1 = b1; p.p2 = (const uint4*)w2_pack; p.slabs = scratch;
+  p.x16 = (const uint16_t*)x16; p.p1 = (const uint4*)w1_pack; p.b1 = b1; p.p2 = (const uint4*)w2_pack; p.scratch = scratch;
   p.M = (int)M; p.F = F; p.S = S;
   p.x = x; p.b2 = b2; p.gamma = gamma; p.beta = beta; p.seed = seed; p.y = y; p.y16 = (uint16_t*)y16; p.z = z; p.mean = mean; p.rstd = rstd;
   p.sync = sync; p.fault = g_otr_fault; p.spin_limit = g_otr_spin_limit; p.coh_only = g_otr_ffn_coh_only; p.eps = eps; p.p_drop = p_drop; p.rng_offset = rng_offset;
   p.hsave = (uint4*)hsave; p.usave = (uint16_t*)usave; p.trace = g_otr_trace;
-  if (hsave) { F3_LAUNCH_FWD(true, true) } else { F3_LAUNCH_FWD(true, false) }
+  if (hsave) { F3_LAUNCH_FWD(true) } else { F3_LAUNCH_FWD(false) }
   return otr_check_launch("ffn3_ln_fwd");
 }
 

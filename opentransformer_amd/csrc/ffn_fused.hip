@@ -169,17 +169,15 @@ __device__ __forceinline__ void ffn_fwd_row_epilogue(const FfnFwdArgs& p, const 
   }
 }
 
-// NW = waves per workgroup.  A pure streaming kernel ingests ~22 B/clk per CU with 4 waves and ~33 B/clk with 8
-// (tools/ubench/l2stream.hip), and this kernel sits on the 4-wave figure -- but its 8-wave form (two waves per SIMD, <= 256
-// registers each, a 12-deep ring per wave) measured 85 us against 61 us: the shallower rings and the shared matrix pipe cost
-// more than the extra load issue slots bring.  NW = 4 is the production form; NW = 8 stays selectable (otr_debug_set(5, 8)).
+// NW = waves per workgroup (4: an 8-wave form -- two waves per SIMD, <= 256 registers each, 12-deep rings -- measured 85 us against
+// 61 us in round 2 and was removed).
 template <int D, int NW, int PD>
 __global__ __launch_bounds__(NW * 64, NW / 4) void ffn_ln_fwd_kernel(FfnFwdArgs p) {
   static_assert(D == 256, "the LayerNorm epilogue maps one float4 per lane: d_model = 256");
   constexpr int NKS = D / 16, NT = D / 32, YP = D + 4;
   constexpr int STEPS = 2 * NKS + 2 * NT;          // weight fragments (= MFMAs) per chunk: 32 + 16
   constexpr int NTHR = NW * 64, RPW = FF_RB / NW;  // PD = fragments in flight per wave (1 KiB each)
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert(NW == 4, "one wave per SIMD");
   static_assert(STEPS % PD == 0, "ring slots must be compile-time constants");
   __shared__ __attribute__((aligned(16))) unsigned char smem[FF_RB * D * 2 + 4 * FF_RB * YP * 4];
   uint4* xs = reinterpret_cast<uint4*>(smem);
@@ -255,139 +253,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void ffn_ln_fwd_kernel(FfnFwdArgs 
     c = cn;
   }
 
-  // the waves' partial y^T tiles meet in LDS: red[slot][m][n], n = nt*32 + 8q + 4hi + (r&3); four slots -- with 8 waves
-  // the upper four first hand their tiles to the lower four, which fold them into their accumulators
-  auto put = [&](int slot) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(red + (slot * FF_RB + m) * YP + nt * 32 + 8 * q + 4 * hi) =
-            make_float4(yacc[nt][4 * q], yacc[nt][4 * q + 1], yacc[nt][4 * q + 2], yacc[nt][4 * q + 3]);
-  };
-  if constexpr (NW == 8) {
-    if (wid >= 4) put(wid - 4);
-    __syncthreads();
-    if (wid < 4) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 t = *reinterpret_cast<const float4*>(red + (wid * FF_RB + m) * YP + nt * 32 + 8 * q + 4 * hi);
-          yacc[nt][4 * q] += t.x; yacc[nt][4 * q + 1] += t.y; yacc[nt][4 * q + 2] += t.z; yacc[nt][4 * q + 3] += t.w;
-        }
-    }
-    __syncthreads();
-  }
-  if (wid < 4) put(wid);
-  __syncthreads();
-
-  ffn_fwd_row_epilogue<D, RPW, YP>(p, red, row0, wid, lane);
-}
-
-// ------------------------------------------------------------------------------------------------ forward, weights through LDS-DMA
-// Same structure as ffn_ln_fwd_kernel (32 rows per workgroup, a wave owns hidden chunks, no barrier in the loop), but the
-// weight fragments travel global -> LDS by direct-to-LDS DMA into a wave-PRIVATE ring (PD x 1 KiB) and reach the MFMA by one
-// ds_read_b128: the DMA path ingests ~33 B/clk per CU where global -> VGPR loads stop at ~22 (the v2 kernels
-// measured 10.7 us for 0.75 MB).  The fragment address is wave-uniform (SGPR base + lane * 16), so a DMA costs scalar
-// instructions only; the wave waits for its own DMAs with counted vmcnt (nothing else in the loop is a vector-memory
-// operation: the biases are staged in LDS up front).  The rings live where the partial outputs meet after the loop.
-template <int N> __device__ __forceinline__ void ffn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <int D, int PD>
-__global__ __launch_bounds__(256, 1) void ffn_ln_fwd_dma_kernel(FfnFwdArgs p) {
-  static_assert(D == 256, "the LayerNorm epilogue maps one float4 per lane: d_model = 256");
-  constexpr int NKS = D / 16, NT = D / 32, YP = D + 4, NW = 4;
-  constexpr int STEPS = 2 * NKS + 2 * NT;          // weight fragments (= MFMAs) per chunk: 32 + 16
-  constexpr int RPW = FF_RB / NW;
-  static_assert(STEPS % PD == 0, "ring slots must be compile-time constants");
-  static_assert(NW * PD * 1024 + 16384 <= 4 * FF_RB * YP * 4, "rings + staged biases fit where the partial outputs meet");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * FF_RB * YP * 4 + FF_RB * D * 2];
-  float* red = reinterpret_cast<float*>(smem);                       // after the loop; before it: rings | biases
-  uint4* xs = reinterpret_cast<uint4*>(smem + 4 * FF_RB * YP * 4);
-  float* bias_s = reinterpret_cast<float*>(smem + NW * PD * 1024);   // b_1 [2F] (F <= 2048)
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m = lane & 31, hi = lane >> 5;
-  const int row0 = blockIdx.x * FF_RB;
-  stage_rows<D, 256>(xs, p.x16, row0, p.M, tid);
-  for (int i = tid * 4; i < 2 * p.F; i += 1024) *reinterpret_cast<float4*>(bias_s + i) = *reinterpret_cast<const float4*>(p.b1 + i);
-  __syncthreads();
-
-  const int nchunk = p.F / 32, npair = nchunk / (2 * NW), nit = nchunk / NW;
-  const int rot = (int)(blockIdx.x % (unsigned)npair);      // workgroups walk the weights from different starting points
-  auto chunk_of = [&](int it) {
-    int j = (it >> 1) + rot;
-    if (j >= npair) j -= npair;
-    return 2 * NW * j + 2 * wid + (it & 1);                  // a wave's consecutive chunks are adjacent
-  };
-  const unsigned char* P1 = reinterpret_cast<const unsigned char*>(p.p1);
-  const unsigned char* P2 = reinterpret_cast<const unsigned char*>(p.p2);
-  auto fptr = [&](int c, int s) -> const unsigned char* {   // wave-uniform address of fragment s of chunk c
-    if (s < 2 * NKS) return P1 + ((int64_t)(((s & 1) ? nchunk + c : c) * NKS + (s >> 1)) << 10);
-    const int t = s - 2 * NKS;
-    return P2 + ((int64_t)((t >> 1) * (2 * nchunk) + 2 * c + (t & 1)) << 10);
-  };
-  const uint32_t ring0 = (uint32_t)(uintptr_t)(ffn_lds_byte*)smem + (uint32_t)wid * (PD * 1024);
-  const uint32_t lane_off = (uint32_t)lane * 16u;
-  const uint4* ring = reinterpret_cast<const uint4*>(smem + wid * (PD * 1024)) + lane;
-
-  f32x16 yacc[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) yacc[i][r] = 0.f;
-
-  int c = chunk_of(0);
-#pragma unroll
-  for (int s = 0; s < PD; ++s) ffn_dma(fptr(c, s), lane_off, ring0 + s * 1024);
-  ffn_wait_vm<PD - 1>();
-  uint4 w = ring[0];
-
-  for (int it = 0; it < nit; ++it) {
-    const int cn = chunk_of(min(it + 1, nit - 1));          // last round: re-loads its own chunk (valid, unused)
-    float4 bv[4], bg[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      bv[q] = *reinterpret_cast<const float4*>(bias_s + c * 32 + 8 * q + 4 * hi);
-      bg[q] = *reinterpret_cast<const float4*>(bias_s + p.F + c * 32 + 8 * q + 4 * hi);
-    }
-    f32x16 av, ag;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { av[r] = 0.f; ag[r] = 0.f; }
-    uint4 xb, uf0, uf1;
-#pragma clang loop unroll(full)
-    for (int s = 0; s < STEPS; ++s) {
-      // fragment s is in `w`; fragment s+1 has landed once at most PD-2 DMAs are outstanding (PD were in flight)
-      ffn_wait_vm<PD - 2>();
-      const uint4 wn = ring[((s + 1) % PD) * 64];
-      if (s < 2 * NKS) {
-        if ((s & 1) == 0) xb = frag_b<D>(xs, m, hi, s >> 1);
-        if (s & 1) mma32(ag, w, xb); else mma32(av, w, xb);
-      } else {
-        const int t = s - 2 * NKS;
-        mma32(yacc[t >> 1], w, (t & 1) ? uf1 : uf0);
-      }
-      // slot s % PD is free (its fragment sits in `w`, read one step ago): fetch the fragment PD steps ahead into it
-      ffn_dma(s + PD < STEPS ? fptr(c, s + PD) : fptr(cn, s + PD - STEPS), lane_off, ring0 + (s % PD) * 1024);
-      w = wn;
-      if (s == 2 * NKS - 1) {                               // GLU on the accumulators: u = (a + b_a) * sigmoid(g + b_g)
-        float u[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float a = av[r] + reinterpret_cast<const float*>(&bv[r >> 2])[r & 3];
-          const float g = ag[r] + reinterpret_cast<const float*>(&bg[r >> 2])[r & 3];
-          u[r] = a * fast_sigmoid(g);
-        }
-        tile_to_frags(u, uf0, uf1);
-      }
-    }
-    c = cn;
-  }
-  ffn_wait_vm<0>();                                          // the trailing (unused) DMAs must land before the rings become `red`
-  __syncthreads();
-
+  // the waves' partial y^T tiles meet in LDS: red[slot][m][n], n = nt*32 + 8q + 4hi + (r&3); four slots
   auto put = [&](int slot) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -398,6 +264,7 @@ __global__ __launch_bounds__(256, 1) void ffn_ln_fwd_dma_kernel(FfnFwdArgs p) {
   };
   put(wid);
   __syncthreads();
+
   ffn_fwd_row_epilogue<D, RPW, YP>(p, red, row0, wid, lane);
 }
 
@@ -556,8 +423,6 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(FfnBwdArgs p) {
 // ------------------------------------------------------------------------------------------------ C ABI
 extern int g_otr_ffn2_ablate;
 int32_t ffn3_takes(int32_t F, int32_t S);                // ffn3.hip
-int32_t ffn3_fwd_launch(const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, float* slabs, int32_t S, int64_t M,
-                        int32_t F, hipStream_t stream);
 int64_t ffn3_scratch_bytes(int64_t M);
 int64_t ffn3_sync_ints(int64_t M);
 int64_t ffn3_hsave_bytes(int64_t M, int32_t F);
@@ -568,7 +433,6 @@ int32_t ffn3_ln_fwd_launch(const float* x, const void* x16, const void* w1_pack,
                            int32_t* sync, int64_t M, int32_t F, hipStream_t stream);
 int32_t ffn3_bwd_launch(const void* dy16, const void* hsave, const void* w2t_pack, const void* w1t_pack, void* dh, const float* skip,
                         float* dx, float* scratch, int32_t* sync, int64_t M, int32_t F, hipStream_t stream);
-extern int g_otr_ffn_waves;   // tuning hook (otr_debug_set(5, v)): 8 = the 8-wave form of the forward kernel, anything else = 4 waves
 static int32_t ffn_shape_check(const char* who, int64_t M, int32_t F, int32_t d_model) {
   OTR_REQUIRE(M >= 0 && M < (1ll << 31), "%s: bad M", who);
   OTR_REQUIRE(d_model == 256, "%s: built for d_model = 256 (got %d); use the unfused path", who, d_model);
@@ -591,12 +455,7 @@ extern "C" int32_t otr_ffn_ln_fwd(const float* x, const void* x16, const void* w
   p.gamma = gamma; p.beta = beta; p.seed = seed; p.y = y; p.y16 = (uint16_t*)y16; p.z = z; p.mean = mean; p.rstd = rstd;
   p.M = (int)M; p.F = F; p.eps = eps; p.p_drop = p_drop; p.rng_offset = rng_offset;
   const unsigned nblk = (unsigned)((M + FF_RB - 1) / FF_RB);
-  if (g_otr_ffn_waves == 16 && F <= 2048)       // weights through LDS-DMA rings (otr_debug_set(5, 16))
-    hipLaunchKernelGGL((ffn_ln_fwd_dma_kernel<256, 24>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
-  else if (g_otr_ffn_waves != 8 || F % 512 != 0)
-    hipLaunchKernelGGL((ffn_ln_fwd_kernel<256, 4, 24>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL((ffn_ln_fwd_kernel<256, 8, 12>), dim3(nblk), dim3(512), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL((ffn_ln_fwd_kernel<256, 4, 24>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
   return otr_check_launch("ffn_ln_fwd");
 }
 
@@ -653,396 +512,4 @@ extern "C" int32_t otr_ffn_bwd(const void* x16, const void* dy16, const void* w1
   p.M = (int)M; p.F = F; p.ablate = g_otr_ffn2_ablate;
   hipLaunchKernelGGL(ffn_bwd_kernel<256>, dim3((unsigned)((M + FF_RB - 1) / FF_RB)), dim3(256), 0, (hipStream_t)stream, p);
   return otr_check_launch("ffn_bwd");
-}
-
-// ================================================================================================ v2: shared weight stream
-// Measured on MI355X (tools/ubench/l2stream.hip, profiles/r02_l2stream.txt): a CU ingests global memory at ~22 B/clk
-// with 4 waves (33 B/clk with 8), whether the lines come from L2, MALL or even L1 -- the v1 kernels above, whose waves
-// each stream their own weight fragments into registers, sit exactly on that ceiling (3 MB per CU -> 60 us forward).
-// v2 cuts the ingest per CU by 4: a workgroup owns 128 rows (wave w: rows 32w..32w+31) and 1/S of the hidden units
-// (grid = row blocks x S = 63 x 4 at B=32); every weight fragment is fetched ONCE per workgroup, global -> LDS by
-// direct-to-LDS loads (global_load_lds_dwordx4: the fragment-major packs are exactly the lane-linear image those
-// need), and read from LDS by all four waves (ds_read_b128, conflict-free).  Chunk c+1 streams in while chunk c is
-// multiplied: one barrier per chunk of 48 (forward) / 80 (backward) MFMAs per wave.  The hidden-dimension split leaves S
-// partial fp32 output slabs; the LayerNorm kernel (otr_add_layernorm_fwd_slabs) / a small reduce kernel sums them.
-struct Ffn2FwdArgs {
-  const uint16_t* x16;     // [M, D]
-  const uint4* p1; const float* b1; const uint4* p2;
-  float* slabs;            // [S][M][D] f32 partial outputs (bias b_2 NOT included)
-  int M, F, S;
-  int ablate;              // tuning hook (otr_debug_set(4, v)); 0 in production
-};
-
-template <int D>
-__global__ __launch_bounds__(256, 1) void ffn2_fwd_kernel(Ffn2FwdArgs p) {
-  constexpr int NKS = D / 16, NT = D / 32;
-  constexpr int FR = 2 * NKS + 2 * NT;             // fragments per chunk: 32 (w_1 value+gate) + 16 (w_2)
-  constexpr int BUF = FR * 1024;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + 8192];
-  float* bias_s = reinterpret_cast<float*>(smem + 2 * BUF);      // b_1 of this workgroup's hidden units: [chunk][value 32 | gate 32]
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m = lane & 31, hi = lane >> 5;
-  const int row0 = blockIdx.x * 128 + wid * 32;
-  const int nchunk = p.F / 32, per = nchunk / p.S;               // chunks of this workgroup: [c0, c0 + per)
-  const int c0 = blockIdx.y * per;
-
-  for (int i = tid; i < per * 64; i += 256) {
-    const int c = i >> 6, j = i & 63;
-    bias_s[i] = p.b1[(j < 32 ? 0 : p.F) + (c0 + c) * 32 + (j & 31)];
-  }
-  // this wave's activation rows as MFMA B operands, held in registers for the whole kernel
-  uint4 xf[NKS];
-  {
-    const int64_t row = min(row0 + m, p.M - 1);
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) xf[ks] = ld_global_b128(p.x16 + row * D + ks * 16 + hi * 8);
-  }
-  // fragment f of chunk c -> source fragment; every wave DMAs FR/4 of them
-  auto issue = [&](int c, int buf) {
-#pragma unroll
-    for (int j = 0; j < FR / 4; ++j) {
-      const int f = wid * (FR / 4) + j;              // wave-uniform
-      const uint4* src;
-      if (f < 2 * NKS) src = p.p1 + (int64_t)(((f & 1) ? nchunk + c : c) * NKS + (f >> 1)) * 64;
-      else { const int t = f - 2 * NKS; src = p.p2 + (int64_t)((t >> 1) * (2 * nchunk) + 2 * c + (t & 1)) * 64; }
-      dma_frag(src, smem + buf * BUF + f * 1024, lane);
-    }
-  };
-
-  f32x16 yacc[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) yacc[i][r] = 0.f;
-
-  // Software pipeline across chunks: the second GEMM of chunk i-1 (y += w_2 . u) is issued together with the GLU of
-  // chunk i, so the matrix pipe has work while the VALU computes sigmoid / products / packs of the chunk just
-  // multiplied (measured: with GEMM1 -> GLU -> GEMM2 in sequence a chunk took 4.2 k cycles for 1.5 k cycles of MFMAs).
-  // The w_2 fragments of a chunk are therefore copied LDS -> registers while that chunk's first GEMM runs (its buffer
-  // is refilled during the next iteration) and used one iteration later.
-  constexpr int G = 8, NG1 = 2 * NKS / G;           // first GEMM: 32 fragments in groups of 8 (LDS -> register prefetch)
-  static_assert((2 * NKS) % G == 0, "whole prefetch groups");
-  uint4 w2r[2 * NT], uf0, uf1;
-
-  // GEMM1 of chunk i (weights in LDS buffer i&1) into av / ag, with the chunk's bias and w_2 fragments fetched alongside
-#define FFN2_GEMM1(I)                                                                                  \
-  {                                                                                                     \
-    const uint4* wb = reinterpret_cast<const uint4*>(smem + ((I) & 1) * BUF) + lane;                    \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                     \
-      bv[q] = *reinterpret_cast<const float4*>(bias_s + (I) * 64 + 8 * q + 4 * hi);                     \
-      bg[q] = *reinterpret_cast<const float4*>(bias_s + (I) * 64 + 32 + 8 * q + 4 * hi);                \
-    }                                                                                                   \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) { av[r] = 0.f; ag[r] = 0.f; }                        \
-    uint4 fr[2][G];                                                                                     \
-    _Pragma("unroll") for (int j = 0; j < G; ++j) fr[0][j] = wb[j * 64];                                \
-    _Pragma("unroll") for (int g = 0; g < NG1; ++g) {                                                   \
-      if (g + 1 < NG1) {                                                                                \
-        _Pragma("unroll") for (int j = 0; j < G; ++j) fr[(g + 1) & 1][j] = wb[((g + 1) * G + j) * 64];  \
-      } else {                                                                                          \
-        _Pragma("unroll") for (int j = 0; j < 2 * NT; ++j) nw[j] = wb[(2 * NKS + j) * 64];              \
-      }                                                                                                 \
-      __builtin_amdgcn_sched_barrier(0);                                                                \
-      _Pragma("unroll") for (int j = 0; j < G; ++j) {                                                   \
-        const int f = g * G + j;                                                                        \
-        if (f & 1) mma32(ag, fr[g & 1][j], xf[f >> 1]); else mma32(av, fr[g & 1][j], xf[f >> 1]);       \
-      }                                                                                                 \
-      __builtin_amdgcn_sched_barrier(0);                                                                \
-    }                                                                                                   \
-  }
-#define FFN2_GLU()                                                                                      \
-  {                                                                                                     \
-    float u[16];                                                                                        \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
-      const float a = av[r] + reinterpret_cast<const float*>(&bv[r >> 2])[r & 3];                       \
-      const float gt = ag[r] + reinterpret_cast<const float*>(&bg[r >> 2])[r & 3];                      \
-      u[r] = a * fast_sigmoid(gt);                                                                      \
-    }                                                                                                   \
-    tile_to_frags(u, n0, n1);                                                                           \
-  }
-#define FFN2_GEMM2()                                                                                    \
-  _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                   \
-    mma32(yacc[nt], w2r[2 * nt], uf0);                                                                  \
-    mma32(yacc[nt], w2r[2 * nt + 1], uf1);                                                              \
-  }
-#define FFN2_ROTATE()                                                                                   \
-  {                                                                                                     \
-    uf0 = n0; uf1 = n1;                                                                                 \
-    _Pragma("unroll") for (int j = 0; j < 2 * NT; ++j) w2r[j] = nw[j];                                  \
-  }
-#define FFN2_ARRIVE(I)                                                                                  \
-  {                                                                                                     \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
-    __syncthreads(); /* chunk I has landed for every wave; buffer (I+1)&1 is free */                    \
-    if ((I) + 1 < per && !(p.ablate & 1)) issue(c0 + (I) + 1, ((I) + 1) & 1);                           \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
-  }
-  f32x16 av, ag;
-  float4 bv[4], bg[4];
-  uint4 nw[2 * NT], n0, n1;
-  issue(c0, 0);
-  // The activation fragments must be KNOWN complete before the loop: hipcc's waitcnt pass otherwise carries "up to 16
-  // loads may be pending" around the back edge and guards every xf use with vmcnt(15) ... vmcnt(0) -- which, since the
-  // counter also holds the DMA just issued for the next chunk, waits for that DMA in the middle of the current chunk.
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) asm volatile("" :: "v"(xf[ks].x), "v"(xf[ks].y), "v"(xf[ks].z), "v"(xf[ks].w));
-  FFN2_ARRIVE(0)
-  if (!(p.ablate & 2)) {
-    FFN2_GEMM1(0)
-    FFN2_GLU()
-    FFN2_ROTATE()
-  }
-  for (int i = 1; i < per; ++i) {
-    FFN2_ARRIVE(i)
-    if (p.ablate & 2) continue;
-    FFN2_GEMM1(i)
-    FFN2_GEMM2()                                      // chunk i-1, registers only: runs beside the GLU of chunk i
-    FFN2_GLU()
-    __builtin_amdgcn_sched_barrier(0);
-    FFN2_ROTATE()
-  }
-  if (!(p.ablate & 2)) { FFN2_GEMM2() }
-#undef FFN2_GEMM1
-#undef FFN2_GLU
-#undef FFN2_GEMM2
-#undef FFN2_ROTATE
-#undef FFN2_ARRIVE
-  // partial output rows -> slab blockIdx.y, staged through the (now idle) buffer (per & 1) so that memory sees whole
-  // 256-byte row segments: each wave uses a private 8 KiB slice, 64 columns at a time (no workgroup barrier needed)
-  float* st = reinterpret_cast<float*>(smem + (per & 1) * BUF + wid * 8192);      // [32 rows][64 cols]
-  float* out = p.slabs + ((int64_t)blockIdx.y * p.M) * D;
-#pragma unroll
-  for (int h = 0; h < NT / 2; ++h) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(st + m * 64 + t * 32 + 8 * q + 4 * hi) =
-            make_float4(yacc[2 * h + t][4 * q], yacc[2 * h + t][4 * q + 1], yacc[2 * h + t][4 * q + 2], yacc[2 * h + t][4 * q + 3]);
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {                 // 4 rows x 16 lanes x float4 per pass
-      const int r = rr * 4 + (lane >> 4);
-      const int64_t row = (int64_t)row0 + r;
-      const float4 v = *reinterpret_cast<const float4*>(st + r * 64 + (lane & 15) * 4);
-      if (row < p.M) *reinterpret_cast<float4*>(out + row * D + h * 64 + (lane & 15) * 4) = v;
-    }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-}
-
-struct Ffn2BwdArgs {
-  const uint16_t* x16; const uint16_t* dy16;
-  const uint4* p1; const float* b1; const uint4* p3; const uint4* p4;
-  uint16_t* dh; uint16_t* u;
-  float* bpart;            // [ceil(M/32)][2F]: column sums of dh per 32-row block (= per wave)
-  float* slabs;            // [S][M][D] f32 partial input gradients
-  int M, F, S;
-};
-
-template <int D>
-__global__ __launch_bounds__(256, 1) void ffn2_bwd_kernel(Ffn2BwdArgs p) {
-  constexpr int NKS = D / 16, NT = D / 32;
-  constexpr int S1 = 2 * NKS, S2 = S1 + NKS, FR = S2 + 4 * NT;    // 32 + 16 + 32 fragments per chunk
-  constexpr int BUF = FR * 1024;                                  // 80 KiB: two of them are the whole LDS
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m = lane & 31, hi = lane >> 5;
-  const int row0 = blockIdx.x * 128 + wid * 32;
-  const int nchunk = p.F / 32, per = nchunk / p.S;
-  const int c0 = blockIdx.y * per;
-  const int64_t grow = (int64_t)row0 + m;
-  const bool live = grow < p.M;
-  const int64_t crow = min(grow, (int64_t)p.M - 1);
-
-  uint4 xf[NKS], df[NKS];
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    xf[ks] = ld_global_b128(p.x16 + crow * D + ks * 16 + hi * 8);
-    df[ks] = ld_global_b128(p.dy16 + crow * D + ks * 16 + hi * 8);
-  }
-  auto issue = [&](int c, int buf) {
-#pragma unroll
-    for (int j = 0; j < FR / 4; ++j) {
-      const int f = wid * (FR / 4) + j;
-      const uint4* src;
-      if (f < S1) src = p.p1 + (int64_t)(((f & 1) ? nchunk + c : c) * NKS + (f >> 1)) * 64;
-      else if (f < S2) src = p.p3 + (int64_t)(c * NKS + (f - S1)) * 64;
-      else {
-        const int t = f - S2, j4 = t & 3;
-        const int ksf = (j4 < 2) ? 2 * c + j4 : 2 * nchunk + 2 * c + (j4 - 2);
-        src = p.p4 + (int64_t)((t >> 2) * (4 * nchunk) + ksf) * 64;
-      }
-      dma_frag(src, smem + buf * BUF + f * 1024, lane);
-    }
-  };
-
-  f32x16 xacc[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) xacc[i][r] = 0.f;
-
-  issue(c0, 0);
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {                 // see ffn2_fwd_kernel: the operand fragments are complete before the loop
-    asm volatile("" :: "v"(xf[ks].x), "v"(xf[ks].y), "v"(xf[ks].z), "v"(xf[ks].w));
-    asm volatile("" :: "v"(df[ks].x), "v"(df[ks].y), "v"(df[ks].z), "v"(df[ks].w));
-  }
-  for (int i = 0; i < per; ++i) {
-    const int c = c0 + i;
-    // b_1 of this chunk: plain loads BEFORE the wait below (they retire with it; nothing else is in flight then)
-    float4 bv[4], bg[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      bv[q] = *reinterpret_cast<const float4*>(p.b1 + c * 32 + 8 * q + 4 * hi);
-      bg[q] = *reinterpret_cast<const float4*>(p.b1 + p.F + c * 32 + 8 * q + 4 * hi);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (i + 1 < per) issue(c + 1, (i + 1) & 1);
-    __builtin_amdgcn_sched_barrier(0);
-    const uint4* wb = reinterpret_cast<const uint4*>(smem + (i & 1) * BUF) + lane;
-    f32x16 av, ag, du;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { av[r] = 0.f; ag[r] = 0.f; du[r] = 0.f; }
-    constexpr int G = 8, NG = FR / G;               // LDS -> register prefetch groups (see ffn2_fwd_kernel)
-    static_assert(FR % G == 0 && S2 % G == 0, "group boundary must fall in front of the dx GEMM");
-    uint4 fr[2][G], hf[4];
-#pragma unroll
-    for (int j = 0; j < G; ++j) fr[0][j] = wb[j * 64];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      if (g + 1 < NG) {
-#pragma unroll
-        for (int j = 0; j < G; ++j) fr[(g + 1) & 1][j] = wb[((g + 1) * G + j) * 64];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (g * G == S2) {
-        float uu[16], da_[16], dg_[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float a = av[r] + reinterpret_cast<const float*>(&bv[r >> 2])[r & 3];
-          const float sg = fast_sigmoid(ag[r] + reinterpret_cast<const float*>(&bg[r >> 2])[r & 3]);
-          uu[r] = a * sg;
-          da_[r] = du[r] * sg;
-          dg_[r] = du[r] * uu[r] * (1.f - sg);
-        }
-        uint4 u0, u1;
-        tile_to_frags(uu, u0, u1);
-        tile_to_frags(da_, hf[0], hf[1]);
-        tile_to_frags(dg_, hf[2], hf[3]);
-        store_tile_row(p.u + crow * p.F + c * 32, u0, u1, hi, live);
-        store_tile_row(p.dh + crow * (2 * (int64_t)p.F) + c * 32, hf[0], hf[1], hi, live);
-        store_tile_row(p.dh + crow * (2 * (int64_t)p.F) + p.F + c * 32, hf[2], hf[3], hi, live);
-        float* bp = p.bpart + ((int64_t)blockIdx.x * 4 + wid) * (2 * p.F) + c * 32;
-        tile_colsum_store(da_, bp, lane, hi, live);
-        tile_colsum_store(dg_, bp + p.F, lane, hi, live);
-      }
-#pragma unroll
-      for (int j = 0; j < G; ++j) {
-        const int f = g * G + j;
-        const uint4 w = fr[g & 1][j];
-        if (f < S1) {
-          if (f & 1) mma32(ag, w, xf[f >> 1]); else mma32(av, w, xf[f >> 1]);
-        } else if (f < S2) {
-          mma32(du, w, df[f - S1]);
-        } else {
-          const int t = f - S2;
-          mma32(xacc[t >> 2], w, hf[t & 3]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  __syncthreads();                                   // every wave is done with both weight buffers (the stores above are global)
-  float* st = reinterpret_cast<float*>(smem + wid * 8192);
-  float* out = p.slabs + ((int64_t)blockIdx.y * p.M) * D;
-#pragma unroll
-  for (int h = 0; h < NT / 2; ++h) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(st + m * 64 + t * 32 + 8 * q + 4 * hi) =
-            make_float4(xacc[2 * h + t][4 * q], xacc[2 * h + t][4 * q + 1], xacc[2 * h + t][4 * q + 2], xacc[2 * h + t][4 * q + 3]);
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int r = rr * 4 + (lane >> 4);
-      const int64_t row = (int64_t)row0 + r;
-      const float4 v = *reinterpret_cast<const float4*>(st + r * 64 + (lane & 15) * 4);
-      if (row < p.M) *reinterpret_cast<float4*>(out + row * D + h * 64 + (lane & 15) * 4) = v;
-    }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-}
-
-// out[M, D] = sum of S slabs (+ skip): the input gradient of the FFN sub-layer after the hidden-dimension split
-__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int S, int64_t n4, const float* skip, float* out) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    float4 a = skip ? reinterpret_cast<const float4*>(skip)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < S; ++s) {
-      const float4 v = reinterpret_cast<const float4*>(slabs)[(int64_t)s * n4 + i];
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-    }
-    reinterpret_cast<float4*>(out)[i] = a;
-  }
-}
-
-static int32_t ffn2_split_check(const char* who, int32_t F, int32_t S) {
-  OTR_REQUIRE(S >= 1 && S <= 16 && (F / 32) % S == 0, "%s: d_ff / 32 = %d chunks do not split into %d parts", who, F / 32, S);
-  return 0;
-}
-
-extern "C" int32_t otr_ffn_fwd_slabs(const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, float* slabs,
-                                     int32_t n_slabs, int64_t M, int32_t F, int32_t d_model, void* stream) {
-  if (int32_t e = ffn_shape_check("ffn_fwd_slabs", M, F, d_model)) return e;
-  if (int32_t e = ffn2_split_check("ffn_fwd_slabs", F, n_slabs)) return e;
-  OTR_REQUIRE(x16 && w1_pack && b1 && w2_pack && slabs, "ffn_fwd_slabs: null pointer");
-  OTR_REQUIRE(((uintptr_t)x16 | (uintptr_t)w1_pack | (uintptr_t)w2_pack | (uintptr_t)slabs) % 16 == 0, "ffn_fwd_slabs: buffers must be 16-byte aligned");
-  OTR_REQUIRE((F / 32 / n_slabs) * 64 * 4 <= 8192, "ffn_fwd_slabs: too many hidden units per workgroup for the bias staging");
-  if (M == 0) return 0;
-  if (g_otr_ffn_waves != 2 && ffn3_takes(F, n_slabs))     // third form (ffn3.hip); otr_debug_set(5, 2) keeps the second for A/B runs
-    return ffn3_fwd_launch(x16, w1_pack, b1, w2_pack, slabs, n_slabs, M, F, (hipStream_t)stream);
-  Ffn2FwdArgs p{};
-  p.x16 = (const uint16_t*)x16; p.p1 = (const uint4*)w1_pack; p.b1 = b1; p.p2 = (const uint4*)w2_pack; p.slabs = slabs;
-  p.M = (int)M; p.F = F; p.S = n_slabs; p.ablate = g_otr_ffn2_ablate;
-  hipLaunchKernelGGL(ffn2_fwd_kernel<256>, dim3((unsigned)((M + 127) / 128), (unsigned)n_slabs), dim3(256), 0, (hipStream_t)stream, p);
-  return otr_check_launch("ffn_fwd_slabs");
-}
-
-extern "C" int32_t otr_ffn_bwd_slabs(const void* x16, const void* dy16, const void* w1_pack, const float* b1, const void* w2t_pack,
-                                     const void* w1t_pack, void* dh, void* u, float* db1_part, float* slabs, int32_t n_slabs,
-                                     int64_t M, int32_t F, int32_t d_model, void* stream) {
-  if (int32_t e = ffn_shape_check("ffn_bwd_slabs", M, F, d_model)) return e;
-  if (int32_t e = ffn2_split_check("ffn_bwd_slabs", F, n_slabs)) return e;
-  OTR_REQUIRE(x16 && dy16 && w1_pack && b1 && w2t_pack && w1t_pack && dh && u && slabs && db1_part, "ffn_bwd_slabs: null pointer");
-  OTR_REQUIRE((uintptr_t)db1_part % 16 == 0, "ffn_bwd_slabs: db1_part must be 16-byte aligned");
-  OTR_REQUIRE(((uintptr_t)x16 | (uintptr_t)dy16 | (uintptr_t)w1_pack | (uintptr_t)w2t_pack | (uintptr_t)w1t_pack | (uintptr_t)dh |
-               (uintptr_t)u | (uintptr_t)slabs | (uintptr_t)b1) % 16 == 0, "ffn_bwd_slabs: buffers must be 16-byte aligned");
-  if (M == 0) return 0;
-  Ffn2BwdArgs p{};
-  p.x16 = (const uint16_t*)x16; p.dy16 = (const uint16_t*)dy16; p.p1 = (const uint4*)w1_pack; p.b1 = b1;
-  p.p3 = (const uint4*)w2t_pack; p.p4 = (const uint4*)w1t_pack; p.dh = (uint16_t*)dh; p.u = (uint16_t*)u; p.bpart = db1_part; p.slabs = slabs;
-  p.M = (int)M; p.F = F; p.S = n_slabs;
-  hipLaunchKernelGGL(ffn2_bwd_kernel<256>, dim3((unsigned)((M + 127) / 128), (unsigned)n_slabs), dim3(256), 0, (hipStream_t)stream, p);
-  return otr_check_launch("ffn_bwd_slabs");
-}
-
-extern "C" int32_t otr_slab_sum(const float* slabs, int32_t n_slabs, int64_t n, const float* skip, float* out, void* stream) {
-  OTR_REQUIRE(slabs && out && n_slabs >= 1 && n >= 0 && n % 4 == 0, "slab_sum: bad arguments");
-  OTR_REQUIRE(((uintptr_t)slabs | (uintptr_t)out | (uintptr_t)skip) % 16 == 0, "slab_sum: buffers must be 16-byte aligned");
-  if (n == 0) return 0;
-  const int64_t n4 = n / 4;
-  unsigned g = (unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
-  hipLaunchKernelGGL(slab_sum_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs, n4, skip, out);
-  return otr_check_launch("slab_sum");
 }

@@ -12,7 +12,6 @@ struct LnArgs {
   float eps, p_drop;
   uint64_t rng_offset;
   const float* skip;                                      // backward: dx = skip + LayerNorm input gradient (pre-norm residual)
-  int nslab; int64_t slab_stride; const float* a_bias;   // SLABS: a = a_bias + sum of nslab f32 slabs (slab_stride elements apart)
 };
 
 constexpr int LN_MAXV = 4;  // float4 per lane -> d <= 1024
@@ -36,7 +35,7 @@ __device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, uint32_
   return otr_rand32(seed, idx) >= thr ? inv_keep : 0.f;
 }
 
-template <class AT, bool HAS_A, bool SLABS = false> __global__ __launch_bounds__(256) void add_ln_fwd_kernel(LnArgs p) {
+template <class AT, bool HAS_A> __global__ __launch_bounds__(256) void add_ln_fwd_kernel(LnArgs p) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wid;
   if (row >= p.M) return;
@@ -55,20 +54,6 @@ template <class AT, bool HAS_A, bool SLABS = false> __global__ __launch_bounds__
       if constexpr (HAS_A) {
         float a[4];
         ld4<AT>(reinterpret_cast<const AT*>(p.a) + row * d + col, a);
-        if constexpr (SLABS) {          // the branch arrives as partial sums (hidden-dimension split of the fused FFN) + its bias
-          for (int sl = 1; sl < p.nslab; ++sl) {
-            float t[4];
-            ld4<float>(reinterpret_cast<const float*>(p.a) + sl * p.slab_stride + row * d + col, t);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] += t[e];
-          }
-          if (p.a_bias) {
-            float t[4];
-            ld4<float>(p.a_bias + col, t);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] += t[e];
-          }
-        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float sc = drop ? drop_scale(seed, p.rng_offset + (uint64_t)(row * d + col + e), thr, inv_keep) : 1.f;
@@ -261,23 +246,6 @@ extern "C" int32_t otr_add_layernorm_fwd(const otr_ln_desc_t* d, const float* x,
   else if (d->a_dtype == OTR_F32) hipLaunchKernelGGL((add_ln_fwd_kernel<float, true>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, p);
   return otr_check_launch("add_layernorm_fwd");
-}
-
-extern "C" int32_t otr_add_layernorm_fwd_slabs(const otr_ln_desc_t* d, const float* x, const float* slabs, int32_t n_slabs,
-                                               int64_t slab_stride, const float* a_bias, const float* gamma, const float* beta,
-                                               const uint64_t* seed, float* y, void* y_bf16, float* z, float* mean, float* rstd,
-                                               void* stream) {
-  if (int32_t e = ln_check(d)) return e;
-  OTR_REQUIRE(x && slabs && gamma && beta && y && mean && rstd, "add_layernorm_fwd_slabs: null pointer");
-  OTR_REQUIRE(n_slabs >= 1 && slab_stride >= d->M * d->d, "add_layernorm_fwd_slabs: bad slab geometry");
-  OTR_REQUIRE(d->p_drop == 0.f || seed, "add_layernorm_fwd_slabs: dropout needs seed");
-  if (d->M == 0) return 0;
-  LnArgs p{};
-  p.x = x; p.a = slabs; p.gamma = gamma; p.beta = beta; p.seed = seed; p.y = y; p.z = z; p.mean = mean; p.rstd = rstd; p.y_lp = (bf16_t*)y_bf16;
-  p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
-  p.nslab = n_slabs; p.slab_stride = slab_stride; p.a_bias = a_bias;
-  hipLaunchKernelGGL((add_ln_fwd_kernel<float, true, true>), dim3((unsigned)((d->M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
-  return otr_check_launch("add_layernorm_fwd_slabs");
 }
 
 extern "C" int32_t otr_add_layernorm_bwd(const otr_ln_desc_t* d, const float* dy, const float* z, const float* mean,

@@ -1144,8 +1144,6 @@ _FUSED_FFN = os.environ.get('OTR_NO_FUSED_FFN', '0') != '1'
 _FUSED_FFN_MIN_ROWS = int(os.environ.get('OTR_FUSED_FFN_MIN_ROWS', '1024'))   # below: too few 32-row workgroups to fill the chip
 
 
-_FFN_V2 = os.environ.get('OTR_FFN_V2', '0') == '1'      # slab form (partial sums through HBM + a LayerNorm / sum launch): A/B runs
-_FFN_V2_MIN_ROWS = 2048
 # 128-row workgroups with the hidden units split four ways and the partial sums exchanged inside the launch (csrc/ffn3.hip):
 # the default from 2048 rows up; OTR_FFN_SPLIT=0 keeps the 32-row kernels
 _FFN_SPLIT = os.environ.get('OTR_FFN_SPLIT', '1') == '1'
@@ -1163,23 +1161,8 @@ def _ffn_sync(device):
 
 
 def _ffn_split(M, F):
-    return (_FFN_SPLIT and not _FFN_V2 and M >= _FFN_SPLIT_MIN_ROWS and F % 256 == 0 and F // 32 // 4 <= 32
+    return (_FFN_SPLIT and M >= _FFN_SPLIT_MIN_ROWS and F % 256 == 0 and F // 32 // 4 <= 32
             and 8 * ((M + 127) // 128) <= _FFN_SYNC_INTS)
-
-
-def _ffn_slabs(M, F):
-    """hidden-dimension split of the v2 fused FFN kernels (0 = use v1): enough (row block, split) workgroups to fill the
-    256 CUs once, at most 8 slabs"""
-    if not _FFN_V2 or M < _FFN_V2_MIN_ROWS:
-        return 0
-    blocks = (M + 127) // 128
-    chunks = F // 32
-    S = 1
-    while chunks // S > 32 and chunks % (S * 2) == 0:          # at most 32 chunks per workgroup (bias staging in LDS)
-        S *= 2
-    while S < 8 and blocks * S * 2 <= 256 + 32 and chunks % (S * 2) == 0:
-        S *= 2
-    return S if chunks % S == 0 and chunks // S <= 32 else 0
 
 
 def ffn_pack_items(w1_off, w2_off, F2, d, F, dst_off):
@@ -1253,8 +1236,6 @@ class FfnLnFn(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         seed = rng_seed_tensor(x.device) if p_drop > 0 else None
         off = _next_rng_offset(M * d) if p_drop > 0 else 0
-        S = _ffn_slabs(M, F)
-        ctx.S = S
         ctx.split = _ffn_split(M, F)
         hsave = usave = None
         if ctx.split:
@@ -1272,16 +1253,6 @@ class FfnLnFn(torch.autograd.Function):
                                                             _p(rstd), _p(hsave), _p(usave), _p(scratch), nb, _p(sync), sync.numel(),
                                                             M, F, d, _stream())),
                     'otr_ffn_ln_fwd_split')
-        elif S:     # v2: weight stream shared by 128 rows through LDS, hidden units split over S workgroups, LayerNorm sums the slabs
-            lib = L.load()
-            slabs = torch.empty((S, M, d), dtype=torch.float32, device=x.device)
-            L.check(_timed('ffn_fwd_slabs', {'flops': 6.0 * M * F * d, 'bytes': M * d * 2 + 6 * F * d + S * M * d * 4},
-                           lambda: lib.otr_ffn_fwd_slabs(_p(x16), _p(packs[0]), _p(b1), _p(packs[1]), _p(slabs), S, M, F, d,
-                                                         _stream())), 'otr_ffn_fwd_slabs')
-            desc = L.LnDesc(M, d, L.OTR_F32, eps, p_drop, off)
-            L.check(lib.otr_add_layernorm_fwd_slabs(C.byref(desc), _p(x2), _p(slabs), S, M * d, _p(b2), _p(gamma), _p(beta),
-                                                    _p(seed), _p(y), _p(y16), _p(z), _p(mean), _p(rstd), _stream()),
-                    'otr_add_layernorm_fwd_slabs')
         else:
             L.check(_timed('ffn_ln_fwd', {'flops': 6.0 * M * F * d, 'bytes': M * d * (4 + 2 + 4 + 2 + 4) + 6 * F * d},
                            lambda: L.load().otr_ffn_ln_fwd(_p(x2), _p(x16), _p(packs[0]), _p(b1), _p(packs[1]), _p(b2), _p(gamma),
@@ -1356,17 +1327,9 @@ class FfnLnFn(torch.autograd.Function):
         dh = torch.empty((M, 2 * F), dtype=x16.dtype, device=dy.device)
         u = torch.empty((M, F), dtype=x16.dtype, device=dy.device)
         bpart = torch.empty(((M + 31) // 32, 2 * F), dtype=torch.float32, device=dy.device)    # d b_1 per 32-row block
-        if ctx.S:
-            S = ctx.S
-            slabs = torch.empty((S, M, d), dtype=torch.float32, device=dy.device)
-            L.check(_timed('ffn_bwd_slabs', {'flops': 10.0 * M * F * d, 'bytes': M * d * 4 + M * F * 6 + 10 * F * d + S * M * d * 4},
-                           lambda: lib.otr_ffn_bwd_slabs(_p(x16), _p(da), _p(P1), _p(b1), _p(P3), _p(P4), _p(dh), _p(u), _p(bpart),
-                                                         _p(slabs), S, M, F, d, _stream())), 'otr_ffn_bwd_slabs')
-            L.check(lib.otr_slab_sum(_p(slabs), S, M * d, _p(dx), _p(dx), _stream()), 'otr_slab_sum')
-        else:
-            L.check(_timed('ffn_bwd', {'flops': 10.0 * M * F * d, 'bytes': M * d * (2 + 2 + 4 + 4) + M * F * 6 + 10 * F * d},
-                           lambda: lib.otr_ffn_bwd(_p(x16), _p(da), _p(P1), _p(b1), _p(P3), _p(P4), _p(dh), _p(u), _p(bpart), _p(dx),
-                                                   _p(dx), M, F, d, _stream())), 'otr_ffn_bwd')
+        L.check(_timed('ffn_bwd', {'flops': 10.0 * M * F * d, 'bytes': M * d * (2 + 2 + 4 + 4) + M * F * 6 + 10 * F * d},
+                       lambda: lib.otr_ffn_bwd(_p(x16), _p(da), _p(P1), _p(b1), _p(P3), _p(P4), _p(dh), _p(u), _p(bpart), _p(dx),
+                                               _p(dx), M, F, d, _stream())), 'otr_ffn_bwd')
         gw1, gb1, gw2 = grad_target(w1p), grad_target(b1p), grad_target(w2p)
         dw1 = linear_wgrad_raw(dh, x16, None, out=gw1)
         dw2 = linear_wgrad_raw(da, u, None, out=gw2)

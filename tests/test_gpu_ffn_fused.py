@@ -62,16 +62,16 @@ def mode(request):
     ops.set_compute_dtype('bf16')
 
 
-@pytest.fixture(params=['v1', 'slabs', 'split'])
+@pytest.fixture(params=['v1', 'split'])
 def variant(request):
-    """v1: 32-row workgroups, every wave streams its own weight fragments into registers; slabs: 128-row workgroups share the
-    weight stream through LDS, split the hidden units and leave fp32 partial slabs to a LayerNorm / sum launch; split (the
-    default from 2048 rows): the same workgroups exchange their partial sums inside the launch (csrc/ffn3.hip)"""
+    """v1: 32-row workgroups, every wave streams its own weight fragments into registers; split (the default from 2048 rows):
+    128-row workgroups share the weight stream through LDS, split the hidden units four ways and exchange their partial sums
+    inside the launch (csrc/ffn3.hip)"""
     from opentransformer_amd import ops
-    was = ops._FFN_V2, ops._FFN_SPLIT
-    ops._FFN_V2, ops._FFN_SPLIT = request.param == 'slabs', request.param == 'split'
+    was = ops._FFN_SPLIT
+    ops._FFN_SPLIT = request.param == 'split'
     yield request.param
-    ops._FFN_V2, ops._FFN_SPLIT = was
+    ops._FFN_SPLIT = was
 
 
 @pytest.mark.parametrize('M,dff,p_drop', [(2048, 2048, 0.0), (2048 + 40, 512, 0.0), (1504, 512, 0.0), (1024 + 17, 256, 0.1), (7968, 2048, 0.0),
@@ -173,7 +173,7 @@ def test_split_exchange_paths_agree(coh_only):
     launches (4 per row block)."""
     from opentransformer_amd import ops, _lib as L
     ops.set_compute_dtype('fp16')
-    was = ops._FFN_V2, ops._FFN_SPLIT
+    was = ops._FFN_SPLIT
     lib = L.load()
     try:
         d, dff, M = 256, 1024, 4000 + 33
@@ -183,7 +183,7 @@ def test_split_exchange_paths_agree(coh_only):
         gy = torch.randn(M, d, generator=g).to(DEV)
         outs = {}
         for name, split in (('v1', False), ('split', True)):
-            ops._FFN_V2, ops._FFN_SPLIT = False, split
+            ops._FFN_SPLIT = split
             L.check(lib.otr_debug_set(12, coh_only if split else 0), 'debug_set')
             x = xv.clone().requires_grad_(True)
             y = ops.ffn_add_layernorm(ops.attach_lp(x, x.detach().to(ops.act_dtype())), w1, b1, w2, b2, gamma, beta, 0.0, 1e-5)
@@ -195,5 +195,5 @@ def test_split_exchange_paths_agree(coh_only):
         assert int((rec[:, 0] % 4).abs().sum()) == 0 and int(rec[:, 1].abs().sum()) == 0
     finally:
         lib.otr_debug_set(12, 0)
-        ops._FFN_V2, ops._FFN_SPLIT = was
+        ops._FFN_SPLIT = was
         ops.set_compute_dtype('bf16')

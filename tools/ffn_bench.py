@@ -10,7 +10,6 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from opentransformer_amd import ops, _lib as L     # noqa: E402
-import ctypes as C                                  # noqa: E402
 
 
 def main():
@@ -49,18 +48,6 @@ def main():
     def bwd():
         L.check(lib.otr_ffn_bwd(p(x16), p(da), p(P[0]), p(b1), p(P[2]), p(P[3]), p(dh), p(u), p(bpart), p(dx), p(dx), M, F, d, st()), 'bwd')
 
-    ops._FFN_V2 = True
-    S = ops._ffn_slabs(M, F)
-    slabs = torch.empty(max(S, 1), M, d, device=dev)
-    desc = L.LnDesc(M, d, L.OTR_F32, 1e-5, 0.1, 0)
-
-    def fwd2():
-        L.check(lib.otr_ffn_fwd_slabs(p(x16), p(P[0]), p(b1), p(P[1]), p(slabs), S, M, F, d, st()), 'fwd2')
-
-    def ln2():
-        L.check(lib.otr_add_layernorm_fwd_slabs(C.byref(desc), p(x), p(slabs), S, M * d, p(b2), p(gamma), p(beta), p(seed), p(y), p(y16),
-                                                p(z), p(mean), p(rstd), st()), 'ln2')
-
     nb = lib.otr_ffn_split_scratch_bytes(M)
     scratch = torch.empty(nb // 4, device=dev)
     sync = ops._ffn_sync(torch.device('cuda', torch.cuda.current_device()))
@@ -79,12 +66,6 @@ def main():
     def bwd3():
         L.check(lib.otr_ffn_bwd_split(p(da), p(hsave), p(P[2]), p(P[3]), p(dh3), None, p(dx3), p(scratch), nb, p(sync), sync.numel(),
                                       M, F, d, st()), 'bwd3')
-
-    def bwd2():
-        L.check(lib.otr_ffn_bwd_slabs(p(x16), p(da), p(P[0]), p(b1), p(P[2]), p(P[3]), p(dh), p(u), p(bpart), p(slabs), S, M, F, d, st()), 'bwd2')
-
-    def sum2():
-        L.check(lib.otr_slab_sum(p(slabs), S, M * d, p(dx), p(dx), st()), 'sum')
 
     def wgrad():
         ops.linear_wgrad_raw(dh, x16, None)
@@ -109,7 +90,6 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e3
     res = {'rows': M, 'dff': F, 'mode': a.mode}
-    lib.otr_debug_set(5, 4)
     res['v1_fwd_us'] = timeit(lambda: fwd(0.0), a.iters)
     res['v1_fwd_drop_us'] = timeit(lambda: fwd(0.1), a.iters)
     res['v1_bwd_us'] = timeit(bwd, a.iters)
@@ -142,30 +122,6 @@ def main():
     lib.otr_debug_set(4, 0)
     res['split_fwd_tflops'] = 2.0 * M * 3 * F * d / res['split_fwd_us'] / 1e6
     res['split_bwd_tflops'] = 2.0 * M * 3 * F * d / res['split_bwd_us'] / 1e6
-    if S:
-        res['slabs'] = S
-        res['ln_slabs_us'] = timeit(ln2, a.iters)
-        res['slab_sum_us'] = timeit(sum2, a.iters)
-        for tag, key in (('v3', 4), ('v2', 2)):          # otr_debug_set(5, 2): the second form (32 rows per wave) for A/B runs
-            lib.otr_debug_set(5, key)
-            res[tag + '_fwd_us'] = timeit(fwd2, a.iters)
-            res[tag + '_bwd_us'] = timeit(bwd2, a.iters)
-            for ab in (1, 2, 3):      # ablations: 1 = no weight DMA after the prologue, 2 = no MFMA / GLU work, 3 = neither
-                lib.otr_debug_set(4, ab)
-                res['%s_fwd_ablate%d_us' % (tag, ab)] = timeit(fwd2, a.iters)
-                res['%s_bwd_ablate%d_us' % (tag, ab)] = timeit(bwd2, a.iters)
-            lib.otr_debug_set(4, 0)
-            res[tag + '_fwd_tflops'] = 2.0 * M * 3 * F * d / res[tag + '_fwd_us'] / 1e6
-            res[tag + '_bwd_tflops'] = 2.0 * M * 5 * F * d / res[tag + '_bwd_us'] / 1e6
-        lib.otr_debug_set(5, 4)
-        # parity of the two slab kernels on this shape: same partial sums up to the order of accumulation
-        fwd2()
-        s3 = slabs.sum(0).clone()
-        lib.otr_debug_set(5, 2)
-        fwd2()
-        lib.otr_debug_set(5, 4)
-        s2 = slabs.sum(0)
-        res['v3_vs_v2_fwd_rel'] = float((s3 - s2).norm() / s2.norm())
     res['wgrad_pair_us'] = timeit(wgrad, 10)
     try:
         res['old_fwd_us'] = timeit(old_fwd, 20)
