@@ -340,6 +340,17 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   // the G phase into basic blocks, and hipcc interleaves the GLU's VALU code with the MFMAs only inside one block
   uint4* my_u = reinterpret_cast<uint4*>(ubuf) + ((wr * 2 + wc) * 4) * 64 + lane;
   const uint4* partner_u = reinterpret_cast<const uint4*>(ubuf) + ((wr * 2 + (wc ^ 1)) * 4) * 64 + lane;
+  // SAVE: row-major u leaves as whole 128-byte lines, one chunk late, from the hand-over buffer (ffn3_bwd_kernel: dh_store): a
+  // row's 64 elements of a chunk = 8 pieces (sub-chunk w, step j, half h); this wave takes rows 32 wid .. + 31 of the row block,
+  // instruction g rows 8g .. 8g + 7
+  const int st_r = lane >> 3, st_q = lane & 7;
+  const unsigned char* st_src = ubuf + ((((wid >> 1) * 2 + (st_q >> 2)) * 4 + (wid & 1) * 2 + ((st_q >> 1) & 1)) * 64 + st_r) * 16 + 8 * (st_q & 1);
+  uint16_t* st_dst = SAVE ? p.usave + ((int64_t)rb * 128 + 32 * wid + st_r) * (int64_t)p.F + c_base * 32 + 8 * st_q : nullptr;
+  auto u_store = [&](int CH, int g) {
+    const unsigned char* sp = st_src + g * 128;
+    const uint2 lo = *reinterpret_cast<const uint2*>(sp), up = *reinterpret_cast<const uint2*>(sp + 512);
+    st_global_b128(st_dst + (int64_t)(8 * g) * (int64_t)p.F + CH * 64, make_uint4(lo.x, lo.y, up.x, up.y));
+  };
   const int k_own = 2 * wc, k_par = 2 * (wc ^ 1);
 
 #define F3_ISSUE2(I) if constexpr (!no_dma) issue2(I);
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   asm volatile("s_nop 3" ::: "memory");     /* VALU / LDS write of an accumulator -> asm MFMA reading it as C */
   // GEMM1 over 8 contraction steps (HALF = 0: steps 0-7, 1: steps 8-15) of the phase in ring slot SLOT; the two DMAs of the
   // scheduled phase ride behind every group of 8 MFMAs
-#define F3_GEMM1(HALF, SLOT)                                                                                   \
+#define F3_GEMM1(HALF, SLOT, STP, CHP)                                                                         \
   if constexpr (!no_mma) {                                                                                     \
     const otr_u32x4* wb = reinterpret_cast<const otr_u32x4*>(ring + (SLOT) * F3_PHASE) + (wc * 2) * 64 + lane; \
     otr_u32x4 fr[2][4];                                                                                        \
@@ -373,11 +384,15 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
         if (j & 1) { f3_mma_xa(hg[0], fr[g & 1][j], xf[0][ks]); f3_mma_xa(hg[1], fr[g & 1][j], xf[1][ks]); }   \
         else       { f3_mma_xa(hv[0], fr[g & 1][j], xf[0][ks]); f3_mma_xa(hv[1], fr[g & 1][j], xf[1][ks]); }   \
       }                                                                                                        \
+      if constexpr (SAVE && (STP) && !no_st) u_store(CHP, g);    /* the previous chunk's u */                    \
       F3_ISSUE2(g)                                                                                             \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
     }                                                                                                          \
   } else {                                                                                                     \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g) { F3_ISSUE2(g) }                                             \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                            \
+      if constexpr (SAVE && (STP) && !no_st) u_store(CHP, g);                                                  \
+      F3_ISSUE2(g)                                                                                             \
+    }                                                                                                          \
   }
   // end of a phase: this wave's DMAs of the NEXT phase have landed, its LDS traffic is done; after the barrier the slot just
   // consumed is free for the phase four ahead, which is scheduled here and issued during the next phase.  The wait is COUNTED
@@ -427,16 +442,13 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
         const uint4 nu = make_uint4(pack2h(u[0], u[1]), pack2h(u[2], u[3]), pack2h(u[4], u[5]), pack2h(u[6], u[7])); \
         uown[rt][kk & 1] = nu;               /* kept for GEMM2 of this chunk one iteration later ... */            \
         my_u[(rt * 2 + (kk & 1)) * 64] = nu; /* ... and handed to the partner wave */                            \
-        if constexpr (SAVE && !no_st) {      /* 2 (+ 2 on odd quarters) global stores per quarter */               \
+        if constexpr (SAVE && !no_st) {      /* 2 global stores per quarter (row-major u: u_store) */              \
           uint4* hs = p.hsave + ((int64_t)(((rb * 4 + sl) * NC + (CHUNK)) * 4 + wid) * 8) * 64 + lane;         \
           st_global_b128(hs + (rt * 2 + (kk & 1)) * 64,                                                        \
                          make_uint4(pack2h(hv[rt][j0], hv[rt][j0 + 1]), pack2h(hv[rt][j0 + 2], hv[rt][j0 + 3]), \
                                     pack2h(hv[rt][j0 + 4], hv[rt][j0 + 5]), pack2h(hv[rt][j0 + 6], hv[rt][j0 + 7]))); \
           st_global_b128(hs + (4 + rt * 2 + (kk & 1)) * 64,                                                    \
                          make_uint4(pack2h(sg[0], sg[1]), pack2h(sg[2], sg[3]), pack2h(sg[4], sg[5]), pack2h(sg[6], sg[7]))); \
-          if (kk & 1)                        /* both halves of row tile rt are new: its 32 u values, row-major */   \
-            store_tile_row(p.usave + ((int64_t)row0 + 32 * rt + m) * p.F + (c_base + 2 * (CHUNK) + wc) * 32,     \
-                           uown[rt][0], uown[rt][1], hi, true);                                                \
         }                                                                                                      \
       }                                                                                                        \
       if constexpr (G2 && GLU) {                                                                               \
@@ -466,19 +478,19 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   int slot = 0;                                                  // ring slot of the current phase (phase index mod 4)
   // ---- chunk 0: A, B, GLU only
   F3_BIAS_INIT(wc)
-  F3_GEMM1(0, slot)
+  F3_GEMM1(0, slot, false, 0)
   F3_PHASE_END(0)
-  F3_GEMM1(1, slot)
+  F3_GEMM1(1, slot, false, 0)
   F3_PHASE_END(0)
   F3_PHASE_G(false, true, slot, 0)
   F3_PHASE_END(KG)
   // ---- chunks 1 .. NC-1: A, B, GLU beside the previous chunk's GEMM2
   for (int C = 1; C < NC; ++C) {
     F3_BIAS_INIT(2 * C + wc)
-    F3_GEMM1(0, slot)
+    F3_GEMM1(0, slot, true, C - 1)
     F3_PHASE_END(KG)                                             // the G phase before this one
     F3_READ_PARTNER()
-    F3_GEMM1(1, slot)
+    F3_GEMM1(1, slot, false, 0)
     F3_PHASE_END(0)
     F3_PHASE_G(true, true, slot, C)
     F3_PHASE_END(KG)
@@ -486,6 +498,10 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   // ---- closing phase: GEMM2 of chunk NC-1 (its w_2 took the place of a phase A(NC)); the partners' ids travel meanwhile
   f3_sync_read_ids(sy);
   F3_READ_PARTNER()
+  if constexpr (SAVE && !no_st) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) u_store(NC - 1, g);              // the last chunk's u
+  }
   F3_PHASE_G(true, false, slot, 0)
 #undef F3_ISSUE2
 #undef F3_BIAS_INIT
@@ -630,8 +646,9 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
 //   XA  dx^T[128 columns of half wc, 64 rows] += w_1^T frags x OWN dh frags                                         32 MFMAs
 //   XB  ... += w_1^T frags x the PARTNER's dh frags (read from the hand-over buffer during the next D phase)           32 MFMAs
 // software-pipelined like the forward kernel: iteration C = D(C), XA(C-1) beside the first half of GLU'(C), XB(C-1) beside
-// the second half.  Same ring, same counted waits; the global traffic of an X phase -- 4 dh stores and 4 loads of the NEXT
-// chunk's saved tiles (two phases ahead of their use) -- sits in front of the phase's last DMA pair, so the counts are exact.
+// the second half.  Same ring, same counted waits; the 4 loads of the NEXT chunk's saved tiles an X phase issues (two phases ahead
+// of their use) sit in front of the phase's last DMA pair, so the counts are exact; row-major dh leaves one chunk late, during
+// the D phase, as whole lines (dh_store).
 struct Ffn3BwdArgs {
   const uint16_t* dy16;    // [M, D]
   const uint4* hsave;      // forward's (value, sigmoid) tiles
@@ -781,9 +798,24 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
     for (int k = 0; k < 4; ++k) dho[rt][k] = dhp[rt][k] = make_uint4(0u, 0u, 0u, 0u);
   uint4* my_h = reinterpret_cast<uint4*>(hand) + (wid * 8) * 64 + lane;
   const uint4* partner_h = reinterpret_cast<const uint4*>(hand) + ((wid ^ 1) * 8) * 64 + lane;
+  // Row-major dh leaves as WHOLE 128-byte lines, one chunk late, from the hand-over buffer (where both partner waves' fragments
+  // of a chunk meet anyway): a row's 64 dvalue (64 dgate) elements of a chunk are 8 pieces of 16 B = (sub-chunk w, contraction
+  // step k, half h), and piece (w, k, h) is the 8-byte half h of lanes (row, hi = 0) and (row, hi = 1) of fragment (wave (wr, w),
+  // row tile, k).  This wave takes rows 32 wid .. + 31 of the row block (row tile wid & 1 of wave row wid >> 1); instruction
+  // t = 4 seg + g covers rows 8g .. 8g + 7 of segment seg (0 dvalue, 1 dgate), 8 lanes per row.  (Stored straight from the
+  // accumulator layout -- 32-byte pieces of 32 different rows per instruction -- the stores cost 20 us of a 63 us launch and
+  // held up the tile loads behind them: the CU's address path takes about a cycle per line touched.)
+  const int st_r = lane >> 3, st_q = lane & 7;
+  const unsigned char* st_src = hand + ((((wid >> 1) * 2 + (st_q >> 2)) * 8 + (wid & 1) * 4 + ((st_q >> 1) & 1)) * 64 + st_r) * 16 + 8 * (st_q & 1);
+  uint16_t* st_dst = p.dh + ((int64_t)rb * 128 + 32 * wid + st_r) * (2 * (int64_t)p.F) + c_base * 32 + 8 * st_q;
+  auto dh_store = [&](int CH, int t) {
+    const unsigned char* sp = st_src + (t >> 2) * 2048 + (t & 3) * 128;
+    const uint2 lo = *reinterpret_cast<const uint2*>(sp), up = *reinterpret_cast<const uint2*>(sp + 512);
+    st_global_b128(st_dst + (int64_t)(8 * (t & 3)) * (2 * (int64_t)p.F) + (t >> 2) * (int64_t)p.F + CH * 64, make_uint4(lo.x, lo.y, up.x, up.y));
+  };
 
   // D: du = w_2^T . dy over 16 contraction steps, 8 MFMAs per group of 4 fragments, two DMAs behind every group
-#define F3B_PHASE_D(SLOT)                                                                                      \
+#define F3B_PHASE_D(SLOT, STP, CHP)                                                                            \
   if constexpr (!no_mma) {                                                                                     \
     _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                           \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) du[rt][r] = 0.f;                                          \
@@ -800,11 +832,15 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
         f3_mma_acc(du[0], fr[g & 1][j], dyf[0][4 * g + j]);                                                    \
         f3_mma_acc(du[1], fr[g & 1][j], dyf[1][4 * g + j]);                                                    \
       }                                                                                                        \
+      if constexpr ((STP) && !no_st) { dh_store(CHP, 2 * g); dh_store(CHP, 2 * g + 1); }   /* the previous chunk's dh */ \
       F3B_ISSUE2(g)                                                                                            \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
     }                                                                                                          \
   } else {                                                                                                     \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g) { F3B_ISSUE2(g) }                                            \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                            \
+      if constexpr ((STP) && !no_st) { dh_store(CHP, 2 * g); dh_store(CHP, 2 * g + 1); }                       \
+      F3B_ISSUE2(g)                                                                                            \
+    }                                                                                                          \
   }
 #define F3B_PHASE_END(KEEP)                                                                                    \
   if constexpr (no_dma) f3_wait_vm<0>(); else f3_wait_vm<(KEEP)>();                                            \
@@ -832,15 +868,10 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
     my_h[((RT) * 4 + (J)) * 64] = NDH[RT][J];                                                                  \
     my_h[((RT) * 4 + 2 + (J)) * 64] = NDH[RT][2 + (J)];                                                        \
   }
-  // row tile RT of chunk CH complete: its 32 dvalue and 32 dgate values per row, row-major (4 global stores), then the loads of
-  // the NEXT chunk's saved tiles for this row tile (4 global loads) -- both in front of the phase's last DMA pair
+  // row tile RT of chunk CH complete: the loads of the NEXT chunk's saved tiles for this row tile (4 global loads), in front of
+  // the phase's last DMA pair
 #define F3B_STORE_LOAD(RT, CH, NDH)                                                                            \
   {                                                                                                            \
-    uint16_t* dr = p.dh + ((int64_t)row0 + 32 * (RT) + m) * (2 * (int64_t)p.F) + (c_base + 2 * (CH) + wc) * 32; \
-    if constexpr (!no_st) {                                                                                    \
-      store_tile_row(dr, NDH[RT][0], NDH[RT][1], hi, true);                                                    \
-      store_tile_row(dr + p.F, NDH[RT][2], NDH[RT][3], hi, true);                                              \
-    }                                                                                                          \
     if constexpr (!no_hl) hload((CH) + 1 < NC ? (CH) + 1 : (CH), RT);   /* past the end: a reload of valid tiles, never used */ \
   }
   // X phase: 32 MFMAs in 4 steps (j4) of 8 over w_1^T fragments [(wc*4 + ctl)*4 + j4] with the dh fragments DHF[rt][j4], the GLU'
@@ -894,7 +925,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   int slot = 0;
   uint4 dhn[2][4];                                               // the fragments the GLU' of this iteration produces
   // ---- chunk 0: D, then GLU' only
-  F3B_PHASE_D(slot)
+  F3B_PHASE_D(slot, false, 0)
   F3B_PHASE_END(16)
   F3B_PHASE_X(false, true, slot, dho, 0, 0, dhn)
   F3B_PHASE_END(16)
@@ -907,7 +938,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   // ---- chunks 1 .. NC-1
   for (int C = 1; C < NC; ++C) {
     F3B_READ_PARTNER()                                           // dh of chunk C-1 (written before the barriers of its X phases)
-    F3B_PHASE_D(slot)
+    F3B_PHASE_D(slot, true, C - 1)
     F3B_PHASE_END(16)
     F3B_PHASE_X(true, true, slot, dho, 0, C, dhn)
     F3B_PHASE_END(16)
@@ -922,6 +953,10 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   // partners' ids travel meanwhile
   f3_sync_read_ids(sy);
   F3B_READ_PARTNER()
+  if constexpr (!no_st) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) dh_store(NC - 1, t);             // the last chunk's dh
+  }
   F3B_PHASE_X(true, false, slot, dho, 0, 0, dhn)
   if constexpr (no_dma) f3_wait_vm<0>(); else f3_wait_vm<8>();    // of the last X phase: its 4 tile reloads + 4 of its DMAs at most
   f3_wait_lds();
