@@ -183,6 +183,10 @@ def load(kind=None):
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, C.c_int32)
     assert lib.otr_half_type() == (OTR_F16 if kind == 'fp16' else OTR_BF16), 'library / 16-bit type mismatch'
+    for kv in filter(None, os.environ.get('OTR_DEBUG_SET', '').split(',')):   # tuning hook for A/B runs: "key=value,..."
+        k, v = kv.split('=')
+        if lib.otr_debug_set(int(k), int(v)) != 0:
+            raise OtransHipError('OTR_DEBUG_SET: bad entry %r' % kv)
     _libs[kind] = lib
     return lib
 

@@ -393,10 +393,34 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
 }
 
 // ================================================================================================ dK, dV
-// wave owns 16 keys (columns); streams 64-query blocks.
-template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
+// wave owns 16 keys (columns); streams 64-query blocks.  OWN_DELTA: delta = rowsum(dO * O) of every query block is formed here,
+// from the dO rows on their way to LDS and the matching O rows (two more 16-byte loads per thread and block), so that this body
+// does not depend on the dQ body's output and both can share ONE launch (attn_bwd_kernel).
+template <class CT, int DK> struct BwdSmem {
   using C = ACfg<CT, DK>;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C::RM_BYTES + 2 * C::TR_BYTES + 512];
+  static constexpr int DKDV = 2 * C::RM_BYTES + 2 * C::TR_BYTES + 512;
+  static constexpr int DQ = 2 * C::RM_BYTES + C::TR_BYTES;
+  static constexpr int BOTH = DKDV > DQ ? DKDV : DQ;
+};
+// partial dot product of two 16-byte chunks of CT
+template <class CT> __device__ __forceinline__ float chunk_dot(const uint4& a, const uint4& b) {
+  const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+  float acc = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if constexpr (sizeof(CT) == 4) {
+      acc += __uint_as_float(aw[e]) * __uint_as_float(bw[e]);
+    } else {
+      acc += h2f_lo(aw[e]) * h2f_lo(bw[e]);
+      acc += h2f_hi(aw[e]) * h2f_hi(bw[e]);
+    }
+  }
+  return acc;
+}
+template <class CT, int DK, bool PIPE, bool OWN_DELTA>
+__device__ __forceinline__ void attn_bwd_dkdv_body(const AttnArgs& p, const int bx, unsigned char* smem) {
+  using C = ACfg<CT, DK>;
+  static_assert(!OWN_DELTA || (PIPE && (C::NCH & (C::NCH - 1)) == 0 && C::NCH <= 64), "own delta: aligned rows, 2^n chunks per row");
   unsigned char* sQ = smem;
   unsigned char* sdO = smem + C::RM_BYTES;
   unsigned char* sQt = smem + 2 * C::RM_BYTES;
@@ -405,13 +429,14 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
   float* sDel = sLse + 64;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lg = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int k0 = blockIdx.x * 64 + wid * 16;
+  const int k0 = bx * 64 + wid * 16;
   const bool vec = p.vec != 0;
   const float sc2 = p.scale * ExpDom<CT>::K;
   const CT* Q = reinterpret_cast<const CT*>(p.q) + b * p.q_bs + h * DK;
   const CT* K = reinterpret_cast<const CT*>(p.k) + b * p.k_bs + h * DK;
   const CT* V = reinterpret_cast<const CT*>(p.v) + b * p.v_bs + h * DK;
   const CT* dO = reinterpret_cast<const CT*>(p.do_) + b * p.o_bs + h * DK;
+  const CT* Og = reinterpret_cast<const CT*>(p.o) + b * p.o_bs + h * DK;
   const float* lse = p.lse + ((int64_t)b * p.H + h) * p.Tq;
   const float* del = p.delta + ((int64_t)b * p.H + h) * p.Tq;
   const int key = k0 + lr;
@@ -426,17 +451,18 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
   for (int i = 0; i < C::DT; ++i) { dk_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const int nqb = (p.Tq + 63) / 64;
-  RmRegs<CT, DK> qreg, doreg;
+  RmRegs<CT, DK> qreg, doreg, oreg;
   TrRegs<CT, DK> qtreg, dotreg;
   float lreg = 0.f, dreg = 0.f;
   if constexpr (PIPE) {
     const int nv0 = min(64, p.Tq);
     ld_rm<CT, DK>(qreg, Q, p.q_ts, nv0, tid);
     ld_rm<CT, DK>(doreg, dO, p.o_ts, nv0, tid);
+    if constexpr (OWN_DELTA) ld_rm<CT, DK>(oreg, Og, p.o_ts, nv0, tid);
     ld_tr<CT, DK>(qtreg, Q, p.q_ts, nv0, tid);
     ld_tr<CT, DK>(dotreg, dO, p.o_ts, nv0, tid);
     lreg = lse[min(tid & 63, p.Tq - 1)];
-    dreg = del[min(tid & 63, p.Tq - 1)];
+    if constexpr (!OWN_DELTA) dreg = del[min(tid & 63, p.Tq - 1)];
   }
   for (int qb = 0; qb < nqb; ++qb) {
     __syncthreads();
@@ -446,7 +472,17 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
       st_rm<CT, DK>(sdO, doreg, nvalid, tid);
       st_tr<CT, DK>(sQt, qtreg, nvalid, tid);
       st_tr<CT, DK>(sdOt, dotreg, nvalid, tid);
-      if (tid < 64) {
+      if constexpr (OWN_DELTA) {             // thread (u, tid) holds chunk id % NCH of row id / NCH: the row's chunks sit in NCH neighbouring lanes
+#pragma unroll
+        for (int u = 0; u < RmRegs<CT, DK>::NU; ++u) {
+          const int id = tid + 256 * u, row = id / C::NCH, c = id - row * C::NCH;
+          float part = (c * C::CE < DK) ? chunk_dot<CT>(doreg.v[u], oreg.v[u]) : 0.f;
+#pragma unroll
+          for (int sh = 1; sh < C::NCH; sh <<= 1) part += __shfl_xor(part, sh);
+          if (c == 0) sDel[row] = (row < nvalid) ? part : 0.f;
+        }
+        if (tid < 64) sLse[tid] = (tid < nvalid) ? lreg * ExpDom<CT>::K : 0.f;
+      } else if (tid < 64) {
         sLse[tid] = (tid < nvalid) ? lreg * ExpDom<CT>::K : 0.f;
         sDel[tid] = (tid < nvalid) ? dreg : 0.f;
       }
@@ -465,10 +501,11 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
       const int qn = min(qb + 1, nqb - 1), nv2 = min(64, p.Tq - qn * 64);
       ld_rm<CT, DK>(qreg, Q + (int64_t)qn * 64 * p.q_ts, p.q_ts, nv2, tid);
       ld_rm<CT, DK>(doreg, dO + (int64_t)qn * 64 * p.o_ts, p.o_ts, nv2, tid);
+      if constexpr (OWN_DELTA) ld_rm<CT, DK>(oreg, Og + (int64_t)qn * 64 * p.o_ts, p.o_ts, nv2, tid);
       ld_tr<CT, DK>(qtreg, Q + (int64_t)qn * 64 * p.q_ts, p.q_ts, nv2, tid);
       ld_tr<CT, DK>(dotreg, dO + (int64_t)qn * 64 * p.o_ts, p.o_ts, nv2, tid);
       lreg = lse[min(qn * 64 + (tid & 63), p.Tq - 1)];
-      dreg = del[min(qn * 64 + (tid & 63), p.Tq - 1)];
+      if constexpr (!OWN_DELTA) dreg = del[min(qn * 64 + (tid & 63), p.Tq - 1)];
       __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -532,18 +569,22 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
     }
   }
 }
+template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BwdSmem<CT, DK>::DKDV];
+  attn_bwd_dkdv_body<CT, DK, PIPE, false>(p, (int)blockIdx.x, smem);
+}
 
 // ================================================================================================ dQ
 // wave owns 16 queries (columns); streams 64-key blocks.
-template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+template <class CT, int DK, bool PIPE>
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int bx, unsigned char* smem) {
   using C = ACfg<CT, DK>;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C::RM_BYTES + C::TR_BYTES];
   unsigned char* sK = smem;
   unsigned char* sV = smem + C::RM_BYTES;
   unsigned char* sKt = smem + 2 * C::RM_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lg = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 64 + wid * 16;
+  const int q0 = bx * 64 + wid * 16;
   const bool vec = p.vec != 0;
   const float sc2 = p.scale * ExpDom<CT>::K;
   const CT* Q = reinterpret_cast<const CT*>(p.q) + b * p.q_bs + h * DK;
@@ -661,6 +702,19 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
     }
   }
 }
+template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BwdSmem<CT, DK>::DQ];
+  attn_bwd_dq_body<CT, DK, PIPE>(p, (int)blockIdx.x, smem);
+}
+// dQ and dK/dV in ONE launch: workgroups 0 .. nqb-1 of a (head, utterance) own 64 queries each, the rest 64 keys each.  The two
+// halves share nothing but the launch -- no ordering between them (the dK/dV half forms its own delta) -- so a CU holds twice
+// the waves to hide latency behind and the step has one dependent launch less per attention (24 per step at the benchmark).
+template <class CT, int DK> __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p, int nqb) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BwdSmem<CT, DK>::BOTH];
+  const int bx = (int)blockIdx.x;
+  if (bx < nqb) attn_bwd_dq_body<CT, DK, true>(p, bx, smem);
+  else attn_bwd_dkdv_body<CT, DK, true, true>(p, bx - nqb, smem);
+}
 
 // ================================================================================================ host side
 static int32_t fill_args(const otr_attn_desc_t* d, AttnArgs& a) {
@@ -762,8 +816,26 @@ extern "C" int32_t otr_attention_bwd(const otr_attn_desc_t* d, const void* q, co
   return attention_bwd_impl(d, a, stream);
 }
 
+extern int g_otr_attn_bwd_split;   // api.hip (otr_debug_set(13, 1)): the two-launch form, for A/B runs
+#define ATTN_BWD_MERGED(CTYPE, DKV) \
+  hipLaunchKernelGGL((attn_bwd_kernel<CTYPE, DKV>), dim3(nqb + nkb, d->H, d->B), dim3(256), 0, s, a, nqb)
 static int32_t attention_bwd_impl(const otr_attn_desc_t* d, AttnArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  const int nqb = (d->Tq + 63) / 64, nkb = (d->Tk + 63) / 64;
+  // one launch where both halves fit the 256-register budget of two waves per SIMD without spilling (16-bit: head dims up to 64,
+  // fp32: up to 32; aligned operands)
+  if (a.vec && !g_otr_attn_bwd_split && (d->dtype == OTR_H16 ? d->dk <= 64 : d->dk <= 32)) {
+    if (d->dtype == OTR_H16) {
+      switch (d->dk) {
+        case 16: ATTN_BWD_MERGED(bf16_t, 16); break;
+        case 32: ATTN_BWD_MERGED(bf16_t, 32); break;
+        default: ATTN_BWD_MERGED(bf16_t, 64); break;
+      }
+    } else {
+      if (d->dk == 16) ATTN_BWD_MERGED(float, 16); else ATTN_BWD_MERGED(float, 32);
+    }
+    return otr_check_launch("attention_bwd");
+  }
   // dQ first: it also produces delta = rowsum(dO * O), which the dK/dV kernel reads
   dim3 gk((d->Tk + 63) / 64, d->H, d->B), gq((d->Tq + 63) / 64, d->H, d->B);
   if (d->dtype == OTR_H16) {

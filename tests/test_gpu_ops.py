@@ -120,6 +120,32 @@ def test_self_attention(mode, B, T, H, dk, ragged, causal):
         assert rel(dqkv[..., sl].float(), dref[..., sl]) < 2 * TOL[mode], nm
 
 
+@pytest.mark.parametrize('B,T,H,dk,causal', [(3, 249, 4, 64, False), (2, 15, 4, 64, True), (2, 130, 2, 32, False), (2, 70, 4, 16, True)])
+def test_attention_bwd_one_launch_equals_two(mode, B, T, H, dk, causal):
+    """The backward pass is ONE launch (dQ workgroups + dK/dV workgroups, the dK/dV half forming its own delta = rowsum(dO * O));
+    otr_debug_set(13, 1) brings back the two-launch form (dQ writes delta, dK/dV reads it).  Same results: dQ bit for bit, dK / dV
+    up to the summation order of delta."""
+    from opentransformer_amd import ops, _lib as L
+    d = H * dk
+    qkv = (rnd(B, T, 3 * d, seed=31) * 0.7).to(adt(mode)).requires_grad_(True)
+    km = torch.zeros(B, T, dtype=torch.bool, device=DEV)
+    for i in range(B):
+        km[i, :T - 11 * i] = True
+    g = rnd(B, T, d, seed=32).to(adt(mode))
+    lib = L.load()
+    res = []
+    try:
+        for two in (0, 1):
+            L.check(lib.otr_debug_set(13, two), 'debug_set')
+            out = ops.SelfAttentionFn.apply(qkv, km.to(torch.uint8), H, causal)
+            (dqkv,) = torch.autograd.grad(out, qkv, g)
+            res.append(dqkv.float())
+    finally:
+        lib.otr_debug_set(13, 0)
+    assert torch.equal(res[0][..., :d], res[1][..., :d])
+    assert rel(res[0][..., d:], res[1][..., d:]) < (1e-5 if mode == 'fp32' else 2e-3)
+
+
 @pytest.mark.parametrize('B,L,T,H,dk', [(3, 15, 249, 4, 64), (2, 1, 49, 4, 16), (2, 70, 100, 4, 16)])
 def test_cross_attention(mode, B, L, T, H, dk):
     from opentransformer_amd import ops

@@ -57,6 +57,24 @@ for e in prof.events():
     key = (' <- '.join(chain), str(e.input_shapes)[:80], frame[-90:], ks[0].name[:40])
     groups[key] += len(ks)
     total[ks[0].name[:40]] += len(ks)
+# device-to-device copies are runtime calls (hipMemcpyAsync -> a memcpy node = __amd_rocclr_copyBuffer under hipGraph), not kernels
+# of an op: walk up from the runtime event to the aten op / autograd node that made it
+mem = collections.Counter()
+for e in prof.events():
+    if 'hipMemcpy' not in e.name and 'Memcpy' not in e.name:
+        continue
+    chain, p, frame, shapes = [], e, '?', ''
+    while p is not None and len(chain) < 7:
+        chain.append(p.name[:48])
+        if frame == '?' and p.stack:
+            frame = next((f for f in p.stack if 'opentransformer_amd' in f or 'bench' in f), '?')
+        if not shapes and getattr(p, 'input_shapes', None):
+            shapes = str(p.input_shapes)[:80]
+        p = p.cpu_parent
+    mem[(' <- '.join(chain), shapes, frame[-100:])] += 1
+print('memcpy runtime calls in one step:', sum(mem.values()))
+for (chain, shapes, frame), n in mem.most_common(40):
+    print('%3d  %s\n       shapes %s\n       at %s' % (n, chain, shapes, frame))
 print('device kernels of interest in one step:', dict(total))
 for (chain, shapes, frame, kn), n in groups.most_common(60):
     print('%3d  %-38s %s\n       shapes %s\n       at %s' % (n, kn, chain, shapes, frame))

@@ -22,3 +22,11 @@ for a, b in zip(idx[-4:-1], idx[-3:]):
     gaps = sorted((seg[i + 1][1] - seg[i][2]) for i in range(len(seg) - 1))
     print('step: %d kernels, wall %.2f ms, sum of durations %.2f ms, covered %.2f ms, idle %.2f ms; gap median %.2f us, p90 %.2f us'
           % (len(seg), wall / 1e6, busy / 1e6, union / 1e6, (wall - union) / 1e6, gaps[len(gaps) // 2] / 1e3, gaps[int(len(gaps) * .9)] / 1e3))
+# the launch sequence of the last whole step (which kernels sit next to the copy / fill nodes, what runs concurrently)
+if len(idx) >= 2:
+    seg = rows[idx[-2] + 1:idx[-1] + 1]
+    t0 = seg[0][1]
+    print('--- sequence of the last step: index, start us, duration us, name')
+    for i, (n, s, e) in enumerate(seg):
+        short = n.replace('(anonymous namespace)::', '').replace('at::native::', '')[:90]
+        print('%4d %9.1f %7.1f  %s' % (i, (s - t0) / 1e3, (e - s) / 1e3, short))
