@@ -9,7 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # One source, two builds: the 16-bit storage / MFMA-input type is bf16 in libotrans_hip.so and IEEE fp16 in
 # libotrans_hip_f16.so (csrc/common.h).  select() picks the build every later load() returns; ops.set_compute_dtype calls it.
-LIB_PATHS = {'bf16': os.path.join(_HERE, 'lib', 'libotrans_hip.so'), 'fp16': os.path.join(_HERE, 'lib', 'libotrans_hip_f16.so')}
+_LIB_DIR = os.environ.get('OTR_LIB_DIR') or os.path.join(_HERE, 'lib')     # OTR_LIB_DIR: a second build for A/B runs (csrc/Makefile)
+LIB_PATHS = {'bf16': os.path.join(_LIB_DIR, 'libotrans_hip.so'), 'fp16': os.path.join(_LIB_DIR, 'libotrans_hip_f16.so')}
 LIB_PATH = LIB_PATHS['bf16']
 
 OTR_F32, OTR_BF16, OTR_F16 = 0, 1, 2

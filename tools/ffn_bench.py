@@ -119,7 +119,58 @@ def main():
         if ab == 4:
             res['split_fwd_save_ablate4_us'] = timeit(lambda: fwd3(0.0, True), a.iters)
         res['split_bwd_ablate%d_us' % ab] = timeit(bwd3, a.iters)
+    # in the step every layer saves into its own buffers (12 x 98 MB) and the backward kernels read them back much later: the
+    # same launches cycling through N distinct (hsave, usave / dh) sets
+    for ncyc in (2, 12):
+        hs = [torch.empty_like(hsave) for _ in range(ncyc)]
+        us = [torch.empty_like(usave) for _ in range(ncyc)]
+        ds = [torch.empty_like(dh3) for _ in range(ncyc)]
+        cnt = [0]
+
+        def fwd_c():
+            i = cnt[0] % ncyc
+            cnt[0] += 1
+            L.check(lib.otr_ffn_ln_fwd_split(p(x), p(x16), p(P[0]), p(b1), p(P[1]), p(b2), p(gamma), p(beta), p(seed), 0.0, 0, 1e-5, p(y),
+                                             p(y16), p(z), p(mean), p(rstd), p(hs[i]), p(us[i]), p(scratch), nb, p(sync), sync.numel(),
+                                             M, F, d, st()), 'fwd3')
+
+        def bwd_c():
+            i = cnt[0] % ncyc
+            cnt[0] += 1
+            L.check(lib.otr_ffn_bwd_split(p(da), p(hs[i]), p(P[2]), p(P[3]), p(ds[i]), None, p(dx3), p(scratch), nb, p(sync),
+                                          sync.numel(), M, F, d, st()), 'bwd3')
+        res['split_fwd_save_cycle%d_us' % ncyc] = timeit(fwd_c, 48)
+        res['split_bwd_cycle%d_us' % ncyc] = timeit(bwd_c, 48)
+        del hs, us, ds
+    # ... and through 12 distinct weight sets as well (in the step no layer finds its packed weights in the L2)
+    Ps = [ops.ffn_packs(torch.randn(2 * F, d, device=dev) / math.sqrt(d), torch.randn(d, F, device=dev) / math.sqrt(F)) for _ in range(12)]
+    Ps = [[t.clone() for t in q] for q in Ps]
+    hs = [torch.empty_like(hsave) for _ in range(12)]
+    us = [torch.empty_like(usave) for _ in range(12)]
+    ds = [torch.empty_like(dh3) for _ in range(12)]
+    xs = [(torch.randn(M, d, device=dev), ) for _ in range(12)]
+    xs = [(t[0], t[0].to(hdt)) for t in xs]
+    cnt = [0]
+
+    def fwd_w():
+        i = cnt[0] % 12
+        cnt[0] += 1
+        L.check(lib.otr_ffn_ln_fwd_split(p(xs[i][0]), p(xs[i][1]), p(Ps[i][0]), p(b1), p(Ps[i][1]), p(b2), p(gamma), p(beta), p(seed), 0.0, 0,
+                                         1e-5, p(y), p(y16), p(z), p(mean), p(rstd), p(hs[i]), p(us[i]), p(scratch), nb, p(sync),
+                                         sync.numel(), M, F, d, st()), 'fwd3')
+
+    def bwd_w():
+        i = cnt[0] % 12
+        cnt[0] += 1
+        L.check(lib.otr_ffn_bwd_split(p(xs[i][1]), p(hs[i]), p(Ps[i][2]), p(Ps[i][3]), p(ds[i]), None, p(dx3), p(scratch), nb, p(sync),
+                                      sync.numel(), M, F, d, st()), 'bwd3')
+    res['split_fwd_save_cold_us'] = timeit(fwd_w, 48)
+    res['split_bwd_cold_us'] = timeit(bwd_w, 48)
+    lib.otr_debug_set(4, 1)
+    res['split_fwd_save_cold_nodma_us'] = timeit(fwd_w, 48)
+    res['split_bwd_cold_nodma_us'] = timeit(bwd_w, 48)
     lib.otr_debug_set(4, 0)
+    del Ps, hs, us, ds, xs
     res['split_fwd_tflops'] = 2.0 * M * 3 * F * d / res['split_fwd_us'] / 1e6
     res['split_bwd_tflops'] = 2.0 * M * 3 * F * d / res['split_bwd_us'] / 1e6
     res['wgrad_pair_us'] = timeit(wgrad, 10)

@@ -7,7 +7,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 for i in 1 2 3; do
   for v in "$VA" "$VB"; do
-    env $VAR=$v timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras > $OUT/bench_${v}_$i.log 2>&1
-    echo "$VAR=$v run $i: $(grep '^{' $OUT/bench_${v}_$i.log | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), "utt/s", round(d["ms_per_step"],3), "ms")')"
+    f=$OUT/bench_$(echo "$v" | tr '/=' '__')_$i.log
+    env $VAR=$v timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras > $f 2>&1
+    echo "$VAR=$v run $i: $(grep '^{' $f | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), "utt/s", round(d["ms_per_step"],3), "ms")')"
   done
 done
