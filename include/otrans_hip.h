@@ -154,6 +154,15 @@ int32_t otr_proj_ln_fwd(const float* x, const void* c16, int64_t ldc, const void
                         const float* beta, const uint64_t* seed, float* y, void* y16, float* z, float* mean, float* rstd,
                         int64_t M, int32_t d_model, float eps, float p_drop, uint64_t rng_offset, void* stream);
 int64_t otr_ln_bwd_proj_partial_rows(int64_t M);
+/* otr_rb_linear_ln_bwd:  the input gradient of a projection whose INPUT is the output of a LayerNorm y = LN(z), z = x + dropout(a)
+ *   (layer l's q|k|v projection reads layer l-1's FFN sub-layer: encoder/transformer.py:47-63), followed in the same launch by
+ *   that LayerNorm's backward: dy = skip + g16[M,K] . W stays on chip; dx = d z f32 [M,256], da16 = dropout-masked branch
+ *   gradient, partial as otr_ln_bwd_proj ([otr_ln_bwd_proj_partial_rows(M)][3][256]).  wt_pack = pack(W as A[k][n]); N = 256,
+ *   K in {256, 768}. */
+int32_t otr_rb_linear_ln_bwd(const void* g16, int64_t ldg, const void* wt_pack, const float* skip, int64_t lds, const float* z,
+                             const float* mean, const float* rstd, const float* gamma, const uint64_t* seed, float p_drop,
+                             uint64_t rng_offset, float* dx, void* da16, float* partial, int64_t M, int32_t N, int32_t K,
+                             void* stream);
 int32_t otr_ln_bwd_proj(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                         const uint64_t* seed, const void* wt_pack, float* dx, void* da16, void* dc16, int64_t ldc,
                         float* partial, int64_t M, int32_t d_model, float p_drop, uint64_t rng_offset, void* stream);

@@ -363,6 +363,121 @@ __global__ __launch_bounds__(256, 1) void ln_bwd_proj_kernel(LnBwdProjArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ input gradient of a projection + the LayerNorm backward it feeds
+// dy = skip + g16 . W is the gradient of a LayerNorm OUTPUT y = LN(z), z = x + dropout(a) (the q|k|v projection of layer l reads
+// the output of layer l-1's FFN sub-layer: encoder/transformer.py:47-63): the rows are complete in this workgroup, so the
+// LayerNorm backward runs in the epilogue instead of a launch of its own that would read dy back -- dy itself is never stored.
+// Outputs as otr_ln_bwd_proj: dx = d z (the skip-connection gradient of that sub-layer), da16 = the dropout-masked branch gradient,
+// partial = this workgroup's sums of dgamma | dbeta | da.
+struct RbLinLnBwdArgs {
+  const uint16_t* g16;     // [M, K] 16-bit rows (row stride ldg): gradient of the projection's output
+  const uint4* pw;         // W^T packed: rows = 256 inputs of the projection, contraction = K
+  const float* skip;       // f32 [M, 256] (row stride lds) or NULL
+  const float* z; const float* mean; const float* rstd; const float* gamma; const uint64_t* seed;
+  float* dx; uint16_t* da16; float* partial;
+  int64_t ldg, lds;
+  int M;
+  float p_drop;
+  uint64_t rng_offset;
+};
+
+template <int K>
+__global__ __launch_bounds__(256, 1) void rb_linear_ln_bwd_kernel(RbLinLnBwdArgs p) {
+  constexpr int D = 256, RS = D + 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RB * K * 2 + RB * RS * 4];
+  uint4* xs = reinterpret_cast<uint4*>(smem);
+  float* red = reinterpret_cast<float*>(smem + RB * K * 2);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * RB;
+  const int col = lane * 4;
+  RbStream<K, 2> ws;
+  ws.fill(p.pw, wid * 2, lane);
+  rb_stage_rows<K>(xs, p.g16, p.ldg, row0, p.M, tid);
+  // everything of the LayerNorm backward that does not depend on the product travels under the GEMM
+  const bool drop = p.p_drop > 0.f;
+  const uint64_t seed = drop ? *p.seed : 0;
+  const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
+  const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+  const float4 gm4 = *reinterpret_cast<const float4*>(p.gamma + col);
+  const float gam[4] = {gm4.x, gm4.y, gm4.z, gm4.w};
+  float4 skv[8], zv[8];
+  float mean[8], rstd[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t row = min((int64_t)row0 + wid * 8 + i, (int64_t)p.M - 1);
+    skv[i] = p.skip ? *reinterpret_cast<const float4*>(p.skip + row * p.lds + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    zv[i] = *reinterpret_cast<const float4*>(p.z + row * D + col);
+    mean[i] = p.mean[row]; rstd[i] = p.rstd[row];
+  }
+  __syncthreads();
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  ws.run(acc, xs, lane);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) rb_put_tile<RS>(red, acc[i], (wid * 2 + i) * 32, lane);
+  __syncthreads();
+  // ---- LayerNorm backward on this wave's 8 rows (ln_bwd_proj_kernel), dy = the product + skip
+  float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dab[4] = {0.f, 0.f, 0.f, 0.f};
+  float d4[8][4], z4[8][4], s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = wid * 8 + i;
+    const float live = (int64_t)row0 + r < p.M ? 1.f : 0.f;
+    const float4 v = *reinterpret_cast<const float4*>(red + r * RS + col);
+    const float dd[4] = {(v.x + skv[i].x) * live, (v.y + skv[i].y) * live, (v.z + skv[i].z) * live, (v.w + skv[i].w) * live};
+    const float zz[4] = {zv[i].x, zv[i].y, zv[i].z, zv[i].w};
+    s1[i] = 0.f; s2[i] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      d4[i][e] = dd[e];
+      z4[i][e] = (zz[e] - mean[i]) * rstd[i];
+      const float g = dd[e] * gam[e];
+      s1[i] += g; s2[i] += g * z4[i][e];
+      dg[e] += dd[e] * z4[i][e];
+      db[e] += dd[e];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t row = (int64_t)row0 + wid * 8 + i;
+    const float m1 = s1[i] * (1.f / D), m2 = s2[i] * (1.f / D);
+    float dz[4], da[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dz[e] = rstd[i] * (d4[i][e] * gam[e] - m1 - z4[i][e] * m2);
+      const float sc = drop ? (otr_rand32(seed, p.rng_offset + (uint64_t)(row * D + col + e)) >= thr ? inv_keep : 0.f) : 1.f;
+      da[e] = dz[e] * sc;
+      dab[e] += da[e];
+    }
+    if (row < p.M) {
+      *reinterpret_cast<float4*>(p.dx + row * D + col) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+      *reinterpret_cast<uint2*>(p.da16 + row * D + col) = make_uint2(pack2h(da[0], da[1]), pack2h(da[2], da[3]));
+    }
+  }
+  __syncthreads();                                                  // every wave has read its rows: `red` becomes the partial sums
+  float* part = red;                                                // [3][4 waves][256]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    part[(0 * 4 + wid) * D + col + e] = dg[e];
+    part[(1 * 4 + wid) * D + col + e] = db[e];
+    part[(2 * 4 + wid) * D + col + e] = dab[e];
+  }
+  __syncthreads();
+  float* prow = p.partial + (int64_t)blockIdx.x * 3 * D;
+  for (int c = tid; c < 3 * D; c += 256) {
+    const int k = c >> 8, cc = c & 255;
+    prow[c] = part[(k * 4 + 0) * D + cc] + part[(k * 4 + 1) * D + cc] + part[(k * 4 + 2) * D + cc] + part[(k * 4 + 3) * D + cc];
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -420,4 +535,25 @@ extern "C" int32_t otr_ln_bwd_proj(const float* dy, const float* z, const float*
   p.ldc = ldc; p.M = (int)M; p.p_drop = p_drop; p.rng_offset = rng_offset;
   hipLaunchKernelGGL(ln_bwd_proj_kernel, dim3((unsigned)((M + RB - 1) / RB)), dim3(256), 0, (hipStream_t)stream, p);
   return otr_check_launch("ln_bwd_proj");
+}
+
+extern "C" int32_t otr_rb_linear_ln_bwd(const void* g16, int64_t ldg, const void* wt_pack, const float* skip, int64_t lds, const float* z,
+                                        const float* mean, const float* rstd, const float* gamma, const uint64_t* seed, float p_drop,
+                                        uint64_t rng_offset, float* dx, void* da16, float* partial, int64_t M, int32_t N, int32_t K,
+                                        void* stream) {
+  OTR_REQUIRE(g16 && wt_pack && z && mean && rstd && gamma && dx && da16 && partial, "rb_linear_ln_bwd: null pointer");
+  OTR_REQUIRE(N == 256 && (K == 256 || K == 768), "rb_linear_ln_bwd: built for N = 256, K in {256, 768} (got %d, %d)", N, K);
+  OTR_REQUIRE(M >= 0 && M < (1ll << 31) && ldg >= K && ldg % 8 == 0 && (uintptr_t)g16 % 16 == 0 && (uintptr_t)wt_pack % 16 == 0,
+              "rb_linear_ln_bwd: bad shape / alignment");
+  OTR_REQUIRE(!skip || (lds >= N && lds % 4 == 0 && (uintptr_t)skip % 16 == 0), "rb_linear_ln_bwd: skip alignment");
+  OTR_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed), "rb_linear_ln_bwd: bad dropout");
+  if (M == 0) return 0;
+  RbLinLnBwdArgs p{};
+  p.g16 = reinterpret_cast<const uint16_t*>(g16); p.pw = reinterpret_cast<const uint4*>(wt_pack); p.skip = skip; p.z = z; p.mean = mean;
+  p.rstd = rstd; p.gamma = gamma; p.seed = seed; p.dx = dx; p.da16 = reinterpret_cast<uint16_t*>(da16); p.partial = partial;
+  p.ldg = ldg; p.lds = lds; p.M = (int)M; p.p_drop = p_drop; p.rng_offset = rng_offset;
+  const dim3 grid((unsigned)((M + RB - 1) / RB));
+  if (K == 768) hipLaunchKernelGGL((rb_linear_ln_bwd_kernel<768>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((rb_linear_ln_bwd_kernel<256>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  return otr_check_launch("rb_linear_ln_bwd");
 }

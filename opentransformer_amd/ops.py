@@ -329,6 +329,35 @@ def new_prenorm_link():
     return PreNormLink() if torch.is_grad_enabled() else None
 
 
+class LnOutLink:
+    """Pairs the LayerNorm that closes a post-norm FFN sub-layer, y = LN(z), with the first Linear that reads y (the q|k|v
+    projection of the next layer).  That Linear's input-gradient launch produces dy row by row, complete, so the LayerNorm backward
+    runs in its epilogue (otr_rb_linear_ln_bwd) instead of a launch of its own that would read dy back: the Linear's backward
+    leaves (d z, d a 16-bit, partial affine / bias sums) in `result` and returns a zero PLACEHOLDER for y (a stride-0 view of one
+    device scalar); the FFN sub-layer's backward recognises the placeholder and takes `result`.  Any other gradient that reaches
+    y is added to the placeholder by autograd, arrives as a real tensor and goes through the ordinary LayerNorm backward on top
+    (the operation is linear in dy).  saved = what the LayerNorm backward needs, params = the parameters whose gradients it sums."""
+    __slots__ = ('armed', 'saved', 'params', 'result')
+
+    def __init__(self):
+        self.armed, self.saved, self.params, self.result = False, None, None, None
+
+
+_LNOUT = os.environ.get('OTR_LNOUT_LINK', '1') == '1'
+
+
+def _zero_placeholder(device, shape):
+    z = _state.setdefault('zero_scalar', {}).get(device)
+    if z is None:
+        z = _state['zero_scalar'][device] = torch.zeros((), dtype=torch.float32, device=device)
+    return z.expand(shape)
+
+
+def _is_zero_placeholder(t):
+    z = _state.get('zero_scalar', {}).get(t.device)
+    return z is not None and t.data_ptr() == z.data_ptr() and all(st == 0 for st in t.stride())
+
+
 def linear_fwd_raw(x2, w, b, out_dtype, act=L.ACT_NONE, out=None):
     """y = act(x w^T + b); with `out` the product is ACCUMULATED into that [M,N] buffer."""
     M, K = x2.shape
@@ -546,6 +575,22 @@ def rb_linear_raw(x2, pack, N, bias, out_dtype, skip=None):
     return out
 
 
+def rb_linear_ln_bwd_raw(g2, wt_pack, skip, saved):
+    """(d z f32, d a 16-bit, partial [blocks, 3*256]) of the LayerNorm y = LN(z) whose output gradient is skip + g2 . W"""
+    z, mean, rstd, gamma, seed, p_drop, off = saved
+    M, K = g2.shape
+    d = 256
+    lib = L.load()
+    dx = torch.empty((M, d), dtype=torch.float32, device=g2.device)
+    da = torch.empty((M, d), dtype=g2.dtype, device=g2.device)
+    part = torch.empty((lib.otr_ln_bwd_proj_partial_rows(M), 3 * d), dtype=torch.float32, device=g2.device)
+    L.check(_timed('rb_linear_ln_bwd %dx%dx%d' % (M, d, K), {'flops': 2.0 * M * d * K},
+                   lambda: lib.otr_rb_linear_ln_bwd(_p(g2), g2.stride(0), _p(wt_pack), _p(skip), skip.stride(0) if skip is not None else 0,
+                                                    _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed), p_drop, off, _p(dx), _p(da), _p(part),
+                                                    M, d, K, _stream())), 'otr_rb_linear_ln_bwd')
+    return dx, da, part
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x w^T + b): nn.Linear of the reference (e.g. module/attention.py:43,68).
 
@@ -569,6 +614,9 @@ class LinearFn(torch.autograd.Function):
         packs = lin_packs(w) if (perm is None and not relu and _rb_rows_ok(x2) and x2.shape[0] >= _RB_LINEAR_MIN_ROWS
                                  and (b is None or b.data_ptr() % 16 == 0)) else None
         ctx.rb = packs
+        lo = getattr(x, '_otr_lnout', None)      # x is the output of a LayerNorm whose backward can run in this Linear's dgrad launch
+        ctx.lnout = lo if (lo is not None and lo.armed and packs is not None and ctx.needs_input_grad[0] and x.dtype == torch.float32
+                           and w.shape[1] == 256 and w.shape[0] in (256, 768)) else None
         if packs is not None:
             y = rb_linear_raw(x2, packs[0], w.shape[0], b, out_dtype)
         else:
@@ -593,7 +641,13 @@ class LinearFn(torch.autograd.Function):
             skip = None
             if ctx.link is not None and ctx.link.buf is not None:      # skip-connection gradient handed over by the LN
                 skip, ctx.link.buf = ctx.link.buf, None
-            if ctx.rb is not None and _rb_rows_ok(dy2) and (skip is None or (skip.dtype == ctx.xdtype and skip.stride(0) % 4 == 0)):
+            rb_ok = ctx.rb is not None and _rb_rows_ok(dy2) and (skip is None or (skip.dtype == ctx.xdtype and skip.stride(0) % 4 == 0))
+            lo = ctx.lnout
+            if (rb_ok and lo is not None and lo.result is None and dy2.dtype == half_dtype() and _wq['on'] and _in_backward()
+                    and all(grad_target(q) is not None for q in lo.params)):
+                lo.result = rb_linear_ln_bwd_raw(dy2, ctx.rb[1], skip, lo.saved)
+                dx = _zero_placeholder(dy2.device, ctx.xshape)
+            elif rb_ok:
                 dx = rb_linear_raw(dy2, ctx.rb[1], wc.shape[1], None, ctx.xdtype, skip=skip).view(ctx.xshape)
             elif ctx.wt is not None:      # dx = dy . w as a forward-type GEMM on the transposed shadow
                 dx = linear_fwd_raw(dy2, ctx.wt, None, ctx.xdtype, out=skip).view(ctx.xshape)
@@ -1221,7 +1275,7 @@ class FfnLnFn(torch.autograd.Function):
     decoder/transformer.py:82-86) on the row-block fused kernels."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, p_drop, eps, packs):
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, p_drop, eps, packs, olink=None):
         _cuda(x, w1, b1, w2, b2, gamma, beta)
         ctx.set_materialize_grads(False)
         d = x.shape[-1]
@@ -1262,6 +1316,9 @@ class FfnLnFn(torch.autograd.Function):
         ctx.packs = packs
         ctx.refs = (w1, b1, w2, b2, gamma, beta)
         ctx.cfg = (M, d, F, eps, p_drop, off, x.shape)
+        ctx.olink = olink
+        if olink is not None and need_grad:        # see LnOutLink: the next layer's first Linear may run this LayerNorm's backward
+            olink.saved, olink.params, olink.armed = (z, mean, rstd, gamma, seed, p_drop, off), (gamma, beta, b2), True
         y16 = y16.view(x.shape)
         ctx.mark_non_differentiable(y16)
         return y.view(x.shape), y16
@@ -1269,27 +1326,41 @@ class FfnLnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dy16=None):
         if dy is None:
-            return (None,) * 10
+            return (None,) * 11
         x16, z, mean, rstd, gamma, seed, b1, hsave, usave = ctx.saved_tensors
         M, d, F, eps, p_drop, off, xshape = ctx.cfg
         w1p, b1p, w2p, b2p, gp, bp = ctx.refs
         P1, _, P3, P4 = ctx.packs
         lib = L.load()
-        dy2 = dy.reshape(-1, d).contiguous()
-        dx = torch.empty_like(dy2)
-        da = torch.empty((M, d), dtype=x16.dtype, device=dy.device)
-        # LayerNorm backward: dx = skip-connection gradient, da = gradient of the FFN output (dropout mask regenerated)
         gg, gb, gb2 = grad_target(gp), grad_target(bp), grad_target(b2p)
-        inplace = gg is not None and gb is not None and gb2 is not None
-        desc = L.LnDesc(M, d, _code(da.dtype), eps, p_drop, off)
+        stash = None
+        if ctx.olink is not None:
+            stash, ctx.olink.result, ctx.olink.saved = ctx.olink.result, None, None
         part, dgb = None, None
-        if inplace and _wq['on'] and _in_backward():
-            part = torch.empty((lib.otr_add_layernorm_bwd_partial_rows(M), 3 * d), dtype=torch.float32, device=dy.device)
+        if stash is not None and _is_zero_placeholder(dy):
+            # the LayerNorm backward already ran in the epilogue of the next layer's q|k|v input-gradient launch (LnOutLink)
+            dx, da, part = stash
+            stash = None
         else:
-            dgb = torch.zeros((3, d), dtype=torch.float32, device=dy.device)
-        L.check(lib.otr_add_layernorm_bwd(C.byref(desc), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed), _p(dx), _p(da),
-                                          _p(dgb[0]) if dgb is not None else None, _p(dgb[1]) if dgb is not None else None,
-                                          _p(dgb[2]) if dgb is not None else None, _p(part), _stream()), 'otr_add_layernorm_bwd')
+            dy2 = dy.reshape(-1, d).contiguous()
+            dx = torch.empty_like(dy2)
+            da = torch.empty((M, d), dtype=x16.dtype, device=dy.device)
+            # LayerNorm backward: dx = skip-connection gradient, da = gradient of the FFN output (dropout mask regenerated)
+            inplace = gg is not None and gb is not None and gb2 is not None
+            desc = L.LnDesc(M, d, _code(da.dtype), eps, p_drop, off)
+            if inplace and _wq['on'] and _in_backward():
+                part = torch.empty((lib.otr_add_layernorm_bwd_partial_rows(M), 3 * d), dtype=torch.float32, device=dy.device)
+            else:
+                dgb = torch.zeros((3, d), dtype=torch.float32, device=dy.device)
+            L.check(lib.otr_add_layernorm_bwd(C.byref(desc), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed), _p(dx), _p(da),
+                                              _p(dgb[0]) if dgb is not None else None, _p(dgb[1]) if dgb is not None else None,
+                                              _p(dgb[2]) if dgb is not None else None, _p(part), _stream()), 'otr_add_layernorm_bwd')
+            if stash is not None:       # y had another consumer besides the linked Linear: add the part that Linear's launch produced
+                dx.add_(stash[0])
+                da = (da.float() + stash[1].float()).to(da.dtype)
+                colsum_raw(stash[2][:, :d], out=gg)
+                colsum_raw(stash[2][:, d:2 * d], out=gb)
+                colsum_raw(stash[2][:, 2 * d:], out=gb2)
         ret_g = ret_b = ret_b2 = None
         if part is not None:
             colsum_raw(part[:, :d], out=gg)
@@ -1322,7 +1393,7 @@ class FfnLnFn(torch.autograd.Function):
             dw2 = linear_wgrad_raw(da, usave[:M], None, out=gw2)
             db1 = colsum_raw(dh, out=gb1)               # rides along with the w_1 weight-gradient launch (same matrix)
             return (dx.view(xshape), None if gw1 is not None else dw1, None if gb1 is not None else db1,
-                    None if gw2 is not None else dw2, ret_b2, ret_g, ret_b, None, None, None)
+                    None if gw2 is not None else dw2, ret_b2, ret_g, ret_b, None, None, None, None)
         # FFN backward with recompute: dh, u for the weight gradients; dx += dh . w_1
         dh = torch.empty((M, 2 * F), dtype=x16.dtype, device=dy.device)
         u = torch.empty((M, F), dtype=x16.dtype, device=dy.device)
@@ -1335,7 +1406,7 @@ class FfnLnFn(torch.autograd.Function):
         dw2 = linear_wgrad_raw(da, u, None, out=gw2)
         db1 = colsum_raw(bpart, out=gb1)             # per-workgroup column sums of dh, written by the backward kernel
         return (dx.view(xshape), None if gw1 is not None else dw1, None if gb1 is not None else db1,
-                None if gw2 is not None else dw2, ret_b2, ret_g, ret_b, None, None, None)
+                None if gw2 is not None else dw2, ret_b2, ret_g, ret_b, None, None, None, None)
 
 
 def ffn_add_layernorm(x, w1, b1, w2, b2, gamma, beta, p_drop=0.0, eps=1e-5):
@@ -1347,7 +1418,10 @@ def ffn_add_layernorm(x, w1, b1, w2, b2, gamma, beta, p_drop=0.0, eps=1e-5):
     packs = ffn_packs(w1, w2)
     if packs is None or b1 is None or b2 is None:
         return None
-    y, y16 = FfnLnFn.apply(x, w1, b1, w2, b2, gamma, beta, float(p_drop), float(eps), packs)
+    olink = LnOutLink() if (_LNOUT and torch.is_grad_enabled()) else None
+    y, y16 = FfnLnFn.apply(x, w1, b1, w2, b2, gamma, beta, float(p_drop), float(eps), packs, olink)
+    if olink is not None and olink.armed:
+        y._otr_lnout = olink
     return attach_lp(y, y16)
 
 

@@ -192,3 +192,54 @@ def test_packs_follow_the_optimizer_for_every_row_block_linear(mode):
     finally:
         ops._RB = was
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode,p_drop', [('fp16', 0.0), ('fp16', 0.1), ('bf16', 0.1)])
+def test_ffn_layernorm_backward_in_the_next_projections_launch(mode, p_drop, monkeypatch):
+    """Two post-norm encoder layers under FlatDataParallel (in-place flat gradients, deferred weight gradients): layer 2's q|k|v
+    input-gradient launch runs the backward of layer 1's closing LayerNorm in its epilogue (ops.LnOutLink, otr_rb_linear_ln_bwd)
+    -- same gradients as with the separate LayerNorm-backward launch (OTR_LNOUT_LINK=0), dropout masks included, and the fused
+    launch is really taken (once: layer 2 has no successor)."""
+    from opentransformer_amd import nn as onn, ops
+    from opentransformer_amd.dp import FlatDataParallel
+
+    class Two(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l1 = onn.TransformerEncoderLayer(4, 256, 2048, 0.0, 0.0, p_drop, activation='glu')
+            self.l2 = onn.TransformerEncoderLayer(4, 256, 2048, 0.0, 0.0, p_drop, activation='glu')
+            self.g = torch.nn.Parameter(torch.ones(256))
+            self.b = torch.nn.Parameter(torch.zeros(256))
+
+        def forward(self, x, mask):
+            h = ops.add_layernorm(ops.attach_lp(x, None), None, self.g, self.b, 0.0, 1e-5)     # gives the stream its 16-bit twin
+            h, _ = self.l1(h, mask)
+            h, _ = self.l2(h, mask)
+            return h
+
+    ops.set_compute_dtype(mode)
+    try:
+        torch.manual_seed(5)
+        model = Two().to(DEV).train()
+        dp = FlatDataParallel(model)
+        x0 = torch.randn(9, 250, 256, device=DEV)
+        mask = torch.ones(9, 250, dtype=torch.bool, device=DEV)
+        mask[2, 180:] = False
+        gy = torch.randn(9, 250, 256, device=DEV)
+        calls = []
+        raw = ops.rb_linear_ln_bwd_raw
+        monkeypatch.setattr(ops, 'rb_linear_ln_bwd_raw', lambda *a: (calls.append(1), raw(*a))[1])
+        res = []
+        for fused in (True, False):
+            monkeypatch.setattr(ops, '_LNOUT', fused)
+            dp.zero_grad()
+            ops._state['rng_offset'] = 0                     # same dropout masks in both passes
+            x = x0.clone().requires_grad_(True)
+            y = dp(x, mask)
+            y.backward(gy)
+            res.append((y.detach().clone(), x.grad.clone(), dp.flat_grad.clone()))
+        assert len(calls) == 1
+        for a, b, name in zip(res[0], res[1], ('y', 'dx', 'flat gradient')):
+            assert _rel(a, b) < 1e-5, (name, _rel(a, b))      # the affine / bias sums are grouped by 32 instead of 16 rows
+    finally:
+        ops.set_compute_dtype('bf16')
