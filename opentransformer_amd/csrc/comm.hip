@@ -11,7 +11,19 @@
 // the HOST side ships its 128 bytes to the other ranks (opentransformer_amd/dp.py uses the torch.distributed store).
 #include <dlfcn.h>
 #include <string.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// a build box without the RCCL headers: the few NCCL types / values this file uses (nccl.h 2.x ABI), so that the library still
+// compiles; the entry points are looked up at run time either way
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat16 = 6, ncclFloat32 = 7, ncclBfloat16 = 9 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+}
+#endif
 
 #include "common.h"
 

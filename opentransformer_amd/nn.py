@@ -11,9 +11,10 @@ Transformer layers come in the reference's four variants: post-norm (the shipped
 (`normalize_before=True`: the residual is taken AFTER the norm, encoder/transformer.py:42-44), each with or without
 `concat_after` (a Linear over cat(x, attention) instead of dropout(attention)).
 
-Dropout inside attention (on the projected context, module/attention.py:46), the FFN hidden (module/ffn.py:40), the
-frontend's conv layers (frontend/conv.py:66) and the Conformer convolution module runs through ops.dropout (counter RNG,
-mask regenerated in backward); with p = 0 (the shipped AISHELL yamls) nothing is launched.  Not built (constructor
+Dropout inside attention (on the projected context, module/attention.py:46), the FFN hidden (module/ffn.py:40) and the
+frontend's conv layers (frontend/conv.py:66) runs through ops.dropout (counter RNG, mask regenerated in backward); with p = 0
+(the shipped AISHELL yamls) nothing is launched.  The Conformer convolution module takes a dropout rate but, like the reference
+(module/conformer.py:58-123), never applies it.  Not built (constructor
 raises NotImplementedError): in_channel != 1, pos_dropout > 0 (which in the reference silently switches the formula).
 """
 import math

@@ -1028,8 +1028,8 @@ class ProjLnFn(torch.autograd.Function):
         _cuda(x, c, w, gamma, beta)
         ctx.set_materialize_grads(False)
         ctx.link = link
-        if link is not None:
-            link.armed = bool(ctx.needs_input_grad[0])
+        if link is not None:            # the branch's first Linear armed it under ITS conditions (fp32 x, no perm, no relu): keep them
+            link.armed = link.armed and bool(ctx.needs_input_grad[0])
         d = x.shape[-1]
         x2 = x.reshape(-1, d).contiguous()
         c2 = _rows(c)
