@@ -471,6 +471,34 @@ def flush_weight_grads():
         L.check(lib.otr_colsum_grouped(items, len(b), _stream()), 'otr_colsum_grouped')
 
 
+# Links (ResidualLink, PreNormLink, LnOutLink) hand a gradient from one autograd node to a later one OUTSIDE autograd's own
+# bookkeeping.  If the receiving node never runs in that pass (its branch detached or frozen after the forward pass), the gradient
+# would be dropped without a trace: every hand-over is registered, and the engine's end-of-pass callback raises if one is left.
+_parked = []
+
+
+def _park(link):
+    if not _in_backward():
+        return
+    if not _parked:
+        torch.autograd.Variable._execution_engine.queue_callback(_check_parked)
+    _parked.append(link)
+
+
+def _check_parked():
+    left = [k for k in _parked if getattr(k, 'buf', None) is not None or getattr(k, 'result', None) is not None]
+    del _parked[:]
+    for k in left:
+        if hasattr(k, 'buf'):
+            k.buf = None
+        if hasattr(k, 'result'):
+            k.result = None
+    if left:
+        raise RuntimeError('%d gradient hand-over(s) between linked autograd nodes (%s) were never picked up: the receiving node did '
+                           'not run in this backward pass; results of the pass are incomplete'
+                           % (len(left), ', '.join(sorted({type(k).__name__ for k in left}))))
+
+
 def _in_backward():
     """True while the autograd engine is executing a backward pass on this thread (queue_callback needs it)."""
     try:
@@ -646,6 +674,7 @@ class LinearFn(torch.autograd.Function):
             if (rb_ok and lo is not None and lo.result is None and dy2.dtype == half_dtype() and _wq['on'] and _in_backward()
                     and all(grad_target(q) is not None for q in lo.params)):
                 lo.result = rb_linear_ln_bwd_raw(dy2, ctx.rb[1], skip, lo.saved)
+                _park(lo)
                 dx = _zero_placeholder(dy2.device, ctx.xshape)
             elif rb_ok:
                 dx = rb_linear_raw(dy2, ctx.rb[1], wc.shape[1], None, ctx.xdtype, skip=skip).view(ctx.xshape)
@@ -1005,6 +1034,7 @@ class AddLayerNormFn(torch.autograd.Function):
         dx_ret = dx.view(xshape)
         if isinstance(ctx.link, ResidualLink) and ctx.link.armed and ctx.needs_input_grad[0]:
             ctx.link.buf = dx           # the branch's first Linear adds its input gradient into this and returns the sum
+            _park(ctx.link)
             dx_ret = None
         return (dx_ret, (da.view(ashape) if da is not None else None),
                 None if inplace else gg, None if inplace else gb, None, None, dab, None)
@@ -1088,6 +1118,7 @@ class ProjLnFn(torch.autograd.Function):
         dx_ret = dx.view(xshape)
         if isinstance(ctx.link, ResidualLink) and ctx.link.armed and ctx.needs_input_grad[0]:
             ctx.link.buf = dx           # the branch's first Linear adds its input gradient into this and returns the sum
+            _park(ctx.link)
             dx_ret = None
         return (dx_ret, dc.view(cshape), None if gw is not None else dw, dbias, dgamma, dbeta, None, None, None, None)
 
@@ -1713,6 +1744,7 @@ class ResidualAddFn(torch.autograd.Function):
                                               _stream()), 'otr_residual_add_bwd')
         if ctx.link is not None:
             ctx.link.buf = dy.view(-1, dy.shape[-1])
+            _park(ctx.link)
             return None, da, None, None, None
         return dy, da, None, None, None
 

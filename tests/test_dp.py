@@ -169,3 +169,19 @@ def test_dropped_gradient_views_are_detected():
     model.l1.weight.grad = torch.zeros_like(model.l1.weight)  # a foreign gradient tensor
     with pytest.raises(RuntimeError, match='flat'):
         dp.all_reduce_gradients()
+
+
+def test_gradient_hand_over_left_behind_is_an_error():
+    """ops links (ResidualLink / PreNormLink / LnOutLink) pass gradients between autograd nodes outside autograd's bookkeeping; a
+    hand-over nobody picked up by the end of the backward pass must raise, not vanish (ops._park / ops._check_parked)."""
+    import pytest
+    from opentransformer_amd import ops
+    link, lo = ops.ResidualLink(), ops.LnOutLink()
+    link.buf, lo.result = torch.zeros(1), (torch.zeros(1),)
+    done = ops.ResidualLink()                     # picked up: buf is None again
+    ops._parked.extend([link, lo, done])
+    with pytest.raises(RuntimeError, match='never picked up'):
+        ops._check_parked()
+    assert link.buf is None and lo.result is None and not ops._parked
+    ops._parked.append(done)
+    ops._check_parked()                           # nothing left: no error
