@@ -243,3 +243,39 @@ def test_ffn_layernorm_backward_in_the_next_projections_launch(mode, p_drop, mon
             assert _rel(a, b) < 1e-5, (name, _rel(a, b))      # the affine / bias sums are grouped by 32 instead of 16 rows
     finally:
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
+@pytest.mark.parametrize('M,K,with_skip', [(7968, 768, True), (1000, 768, False), (45, 256, True)])
+def test_rb_linear_ln_bwd_matches_reference(mode, M, K, with_skip):
+    """otr_rb_linear_ln_bwd against torch autograd in fp32 on the same 16-bit operands: for y = LN(z) (affine gamma, beta) and
+    dy = skip + g . W, the launch returns dz, the 16-bit branch gradient (= dz, dropout 0) and per-workgroup sums whose totals
+    are dgamma, dbeta and the column sums of the branch gradient."""
+    from opentransformer_amd import ops
+    ops.set_compute_dtype(mode)
+    try:
+        adt, d = ops.act_dtype(), 256
+        gen = torch.Generator().manual_seed(6)
+        w = torch.nn.Parameter((torch.randn(K, d, generator=gen) / d ** 0.5).to(DEV))       # y_next = x W^T: W is [K outputs, 256 inputs]
+        packs = ops.lin_packs(w)
+        assert packs is not None
+        wl = ops.weight_lp(w).float()
+        g = torch.randn(M, K, generator=gen).to(DEV, adt)
+        skip = torch.randn(M, d, generator=gen).to(DEV) if with_skip else None
+        z = torch.randn(M, d, generator=gen).to(DEV) * 1.5 + 0.3
+        gamma = (1 + 0.1 * torch.randn(d, generator=gen)).to(DEV)
+        beta = (0.1 * torch.randn(d, generator=gen)).to(DEV)
+        mean = z.mean(1)
+        rstd = (z.var(1, unbiased=False) + 1e-5).rsqrt()
+        dx, da, part = ops.rb_linear_ln_bwd_raw(g, packs[1], skip, (z, mean, rstd, gamma, None, 0.0, 0))
+        # reference
+        dy = g.float() @ wl + (skip if skip is not None else 0.0)
+        z2, g2, b2 = z.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        F.layer_norm(z2, (d,), g2, b2, 1e-5).backward(dy)
+        assert _rel(dx, z2.grad) < 2e-5, _rel(dx, z2.grad)
+        assert _rel(da, z2.grad) < TOL[mode] / 4
+        sums = part.sum(0)
+        assert _rel(sums[:d], g2.grad) < 2e-5 and _rel(sums[d:2 * d], b2.grad) < 2e-5
+        assert _rel(sums[2 * d:], z2.grad.sum(0)) < 1e-4
+    finally:
+        ops.set_compute_dtype('bf16')
