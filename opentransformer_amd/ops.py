@@ -271,6 +271,7 @@ def _workspace(device):
         ws = torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
         _state['ws'] = ws
         fault_counter(device)           # registered before the first launch that could report through it (and before any capture)
+        _zero_placeholder(device, ())   # likewise allocated outside any capture's private pool (LnOutLink)
     return ws
 
 
