@@ -24,9 +24,9 @@
 // The hidden slice is walked in chunks of 64 units = 3 phases of 32 fragments (32 KiB) each -- A: w_1, contraction steps 0-7;
 // B: steps 8-15; G: w_2 of the PREVIOUS chunk (its GEMM2 runs beside the GLU of this chunk, so the matrix pipe has work
 // during the VALU phase) -- through a ring of four 32 KiB slots: phase p's barrier releases its slot for phase p+4, whose 8
-// DMAs per wave are issued two at a time between the MFMA groups of phase p+1 (scalar instructions only: wave-uniform source,
+// DMAs per wave are issued behind the first MFMA group of phase p+1 (scalar instructions only: wave-uniform source,
 // SGPR base + lane offset) and waited for with a counted vmcnt(16) at the end of phase p+3's predecessor, so a phase's data
-// has two whole phases (> 2000 cycles) to land.  One barrier per phase (32 MFMAs per wave).
+// has nearly three whole phases (> 3000 cycles) to land.  One barrier per phase (32 MFMAs per wave).
 #include "ffn_frag.h"
 
 namespace {
@@ -353,7 +353,9 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   };
   const int k_own = 2 * wc, k_par = 2 * (wc ^ 1);
 
-#define F3_ISSUE2(I) if constexpr (!no_dma) issue2(I);
+  // all eight DMAs of the scheduled phase go out right behind the FIRST MFMA group of a phase (not two behind every group): every
+  // fragment then has three phases to land, which matters when the weights come from beyond the L2 (5.41 -> 5.39 ms per step)
+#define F3_ISSUE2(I) if constexpr (!no_dma) { if ((I) == 0) { issue2(0); issue2(1); issue2(2); issue2(3); } }
   // accumulators of GEMM1 start from the biases (register r of lane (m, hi) is hidden unit 8 (r >> 2) + 4 hi + (r & 3) of the
   // sub-chunk, for both row tiles), so the GLU adds nothing
 #define F3_BIAS_INIT(CL)                                                                                       \
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
 //   XB  ... += w_1^T frags x the PARTNER's dh frags (read from the hand-over buffer during the next D phase)           32 MFMAs
 // software-pipelined like the forward kernel: iteration C = D(C), XA(C-1) beside the first half of GLU'(C), XB(C-1) beside
 // the second half.  Same ring, same counted waits; the 4 loads of the NEXT chunk's saved tiles an X phase issues (two phases ahead
-// of their use) sit in front of the phase's last DMA pair, so the counts are exact; row-major dh leaves one chunk late, during
+// of their use) sit behind the phase's eight DMAs, so the counts are exact; row-major dh leaves one chunk late, during
 // the D phase, as whole lines (dh_store).
 struct Ffn3BwdArgs {
   const uint16_t* dy16;    // [M, D]
@@ -731,7 +733,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
     ffn_dma(psrc + ((uint64_t)o << 10), lane_off, pdst + (uint32_t)(2 * i) * 1024u);
     ffn_dma(psrc + ((uint64_t)(o + pc) << 10), lane_off, pdst + (uint32_t)(2 * i + 1) * 1024u);
   };
-#define F3B_ISSUE2(I) if constexpr (!no_dma) issue2(I);
+#define F3B_ISSUE2(I) if constexpr (!no_dma) { if ((I) == 0) { issue2(0); issue2(1); issue2(2); issue2(3); } }   /* see ffn3_fwd_kernel */
 
   schedule(0);
 #pragma unroll
@@ -882,7 +884,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
     uint4 fr[2][4];                                                                                            \
     if constexpr (GLUQ) {                                                                                      \
       F3_MFMA_DRAIN();                                                                                         \
-      if constexpr (!no_dma && !no_hl) { f3_wait_vm_for<22>(hp[4 * (RTQ)], hp[4 * (RTQ) + 1], hp[4 * (RTQ) + 2], hp[4 * (RTQ) + 3]); } \
+      if constexpr (!no_dma && !no_hl) { f3_wait_vm_for<20>(hp[4 * (RTQ)], hp[4 * (RTQ) + 1], hp[4 * (RTQ) + 2], hp[4 * (RTQ) + 3]); } \
       else if constexpr (no_hl) { }                                                                            \
       else { f3_wait_vm_for<0>(hp[4 * (RTQ)], hp[4 * (RTQ) + 1], hp[4 * (RTQ) + 2], hp[4 * (RTQ) + 3]); }      \
     }                                                                                                          \
@@ -920,8 +922,8 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
 
   // Counted waits (ffn3_fwd_kernel: loads retire in issue order, stores do not count on).  A phase end keeps 16: the DMAs of
   // the two phases after the next phase's group -- also right if the tile loads (4 per X phase, HBM) retired late or early.
-  // The tile loads themselves are waited for at the start of the X phase that consumes them with the 22 loads issued after
-  // them kept (2 + 12 + 8: the rest of their phase, an X phase, a D phase)
+  // The tile loads themselves are waited for at the start of the X phase that consumes them with the 20 loads issued after
+  // them kept (12 + 8: an X phase -- 8 DMAs and 4 tile loads --, a D phase)
   int slot = 0;
   uint4 dhn[2][4];                                               // the fragments the GLU' of this iteration produces
   // ---- chunk 0: D, then GLU' only

@@ -119,6 +119,7 @@ def main():
         if ab == 4:
             res['split_fwd_save_ablate4_us'] = timeit(lambda: fwd3(0.0, True), a.iters)
         res['split_bwd_ablate%d_us' % ab] = timeit(bwd3, a.iters)
+    lib.otr_debug_set(4, 0)
     # in the step every layer saves into its own buffers (12 x 98 MB) and the backward kernels read them back much later: the
     # same launches cycling through N distinct (hsave, usave / dh) sets
     for ncyc in (2, 12):
