@@ -210,19 +210,27 @@ struct Ffn3FwdArgs {
   uint16_t* usave;         // SAVE: u = glu output [128 * row blocks, F] row-major (operand of the w_2 weight gradient)
   int* sync;               // [8 * row blocks] zero before the first launch: the row blocks' sync records (F3Sync)
   int* fault;              // NULL or the sticky fault word (otr_set_fault_counter)
-  int spin_limit, coh_only;
+  int spin_limit, coh_only, map;
   unsigned long long* trace;   // tuning hook (otr_debug_trace): wave 0 of every workgroup stamps the shader clock: [48 per workgroup]
   float eps, p_drop;
   uint64_t rng_offset;
 };
 
 // workgroup -> (row block, hidden slice).  Consecutive workgroup ids go to consecutive XCDs (observed, not promised: used for
-// locality only): the S slices of a row block share an XCD (their x rows are fetched into that L2 once), and an XCD's 32 / S
-// row blocks walk the same slice order.
-__device__ __forceinline__ void f3_block_map(int b, int S, int& rb, int& s) {
+// locality only).  map 0: the four slices of a row block share an XCD (their x rows are fetched into that L2 once, the partial
+// sums meet in it) and every XCD streams all four weight slices.  map 1: an XCD owns ONE slice (XCDs s and s + 4 share slice s,
+// the row blocks alternate between them): its 32 workgroups re-read 0.75 MB of weights instead of 3 MB, which survive the store
+// stream of the saved tiles in the 4 MB L2 -- the four slices of a row block then sit on four XCDs (consecutive workgroup ids), their
+// exchange takes the write-through path (measured: no slower) and x is fetched by four L2s.
+__device__ __forceinline__ void f3_block_map(int b, int map, int& rb, int& s) {
   const int xcd = b & 7, j = b >> 3;
-  s = j % S;
-  rb = (j / S) * 8 + xcd;
+  if (map) {
+    s = xcd & 3;
+    rb = 2 * j + (xcd >> 2);
+  } else {
+    s = j & 3;
+    rb = (j >> 2) * 8 + xcd;
+  }
 }
 
 template <int D, int ABL, bool SAVE>
@@ -239,8 +247,8 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   const int wr = wid >> 1, wc = wid & 1;
   const int m = lane & 31, hi = lane >> 5;
   int rb, sl;
-  f3_block_map((int)blockIdx.x, p.S, rb, sl);
-  if (rb * 128 >= p.M) return;                                   // whole workgroup: the grid is padded to 8 x S x ceil(blocks / 8)
+  f3_block_map((int)blockIdx.x, p.map, rb, sl);
+  if (rb * 128 >= p.M) return;                                   // whole workgroup: the grid is padded to whole XCD groups
   const int row0 = rb * 128 + wr * 64;
   int stamp_i = 0;
 #define F3_STAMP() if constexpr ((ABL & 16) != 0) { if (p.trace && tid == 0 && stamp_i < 48) p.trace[(int64_t)blockIdx.x * 48 + stamp_i++] = __builtin_amdgcn_s_memtime(); }
@@ -659,7 +667,7 @@ struct Ffn3BwdArgs {
   uint16_t* dh;            // [128 * row blocks, 2F] row-major out
   const float* skip;       // [M, D] or NULL
   float* dx;               // [M, D] out (may alias skip)
-  float* scratch; int* sync; int* fault; int spin_limit, coh_only;
+  float* scratch; int* sync; int* fault; int spin_limit, coh_only, map;
   int M, F;
 };
 
@@ -693,7 +701,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   const int wr = wid >> 1, wc = wid & 1;
   const int m = lane & 31, hi = lane >> 5;
   int rb, sl;
-  f3_block_map((int)blockIdx.x, 4, rb, sl);
+  f3_block_map((int)blockIdx.x, p.map, rb, sl);
   if (rb * 128 >= p.M) return;
   const int row0 = rb * 128 + wr * 64;
   F3Sync sy{};
@@ -1018,9 +1026,10 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
 extern int g_otr_ffn2_ablate;
 
 // hidden slices x row blocks, padded to whole XCD groups (f3_block_map)
+extern int g_otr_ffn_map;   // api.hip (otr_debug_set(15, v))
 static inline unsigned f3_grid(int64_t M, int S) {
   const int64_t blocks = (M + 127) / 128;
-  return (unsigned)(8 * S * ((blocks + 7) / 8));
+  return g_otr_ffn_map ? (unsigned)(8 * ((blocks + 1) / 2)) : (unsigned)(8 * S * ((blocks + 7) / 8));
 }
 
 extern int g_otr_spin_limit;
@@ -1053,7 +1062,7 @@ int32_t ffn3_ln_fwd_launch(const float* x, const void* x16, const void* w1_pack,
   p.x16 = (const uint16_t*)x16; p.p1 = (const uint4*)w1_pack; p.b1 = b1; p.p2 = (const uint4*)w2_pack; p.scratch = scratch;
   p.M = (int)M; p.F = F; p.S = S;
   p.x = x; p.b2 = b2; p.gamma = gamma; p.beta = beta; p.seed = seed; p.y = y; p.y16 = (uint16_t*)y16; p.z = z; p.mean = mean; p.rstd = rstd;
-  p.sync = sync; p.fault = g_otr_fault; p.spin_limit = g_otr_spin_limit; p.coh_only = g_otr_ffn_coh_only; p.eps = eps; p.p_drop = p_drop; p.rng_offset = rng_offset;
+  p.sync = sync; p.fault = g_otr_fault; p.spin_limit = g_otr_spin_limit; p.coh_only = g_otr_ffn_coh_only; p.map = g_otr_ffn_map; p.eps = eps; p.p_drop = p_drop; p.rng_offset = rng_offset;
   p.hsave = (uint4*)hsave; p.usave = (uint16_t*)usave; p.trace = g_otr_trace;
   if (hsave) { F3_LAUNCH_FWD(true) } else { F3_LAUNCH_FWD(false) }
   return otr_check_launch("ffn3_ln_fwd");
@@ -1064,7 +1073,7 @@ int32_t ffn3_bwd_launch(const void* dy16, const void* hsave, const void* w2t_pac
   Ffn3BwdArgs p{};
   p.dy16 = (const uint16_t*)dy16; p.hsave = (const uint4*)hsave; p.p3 = (const uint4*)w2t_pack; p.p4 = (const uint4*)w1t_pack;
   p.dh = (uint16_t*)dh; p.skip = skip; p.dx = dx; p.scratch = scratch; p.sync = sync; p.fault = g_otr_fault;
-  p.spin_limit = g_otr_spin_limit; p.coh_only = g_otr_ffn_coh_only; p.M = (int)M; p.F = F;
+  p.spin_limit = g_otr_spin_limit; p.coh_only = g_otr_ffn_coh_only; p.map = g_otr_ffn_map; p.M = (int)M; p.F = F;
   switch (g_otr_ffn2_ablate & 15) {
     case 0: hipLaunchKernelGGL((ffn3_bwd_kernel<256, 0>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p); break;
     case 1: hipLaunchKernelGGL((ffn3_bwd_kernel<256, 1>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p); break;

@@ -165,12 +165,14 @@ def test_ffn_fused_matches_unfused_model_path(mode):
         assert rel(a_, b_) < tg, (n, rel(a_, b_))
 
 
-@pytest.mark.parametrize('coh_only', [0, 1])
-def test_split_exchange_paths_agree(coh_only):
+@pytest.mark.parametrize('coh_only,wg_map', [(0, 1), (1, 1), (0, 0), (1, 0)])
+def test_split_exchange_paths_agree(coh_only, wg_map):
     """The four workgroups of a row block exchange partial sums through the shared L2 when their published XCC ids match and with
     write-through stores / memory-served loads otherwise (csrc/ffn3.hip); otr_debug_set(12, 1) forces the second path for every
-    transfer.  Both must give the 32-row kernels' result, forward and backward; the arrival counters only ever advance by whole
-    launches (4 per row block)."""
+    transfer.  The workgroup -> (row block, slice) mapping decides which one is taken in practice: map 1 (the default: an XCD owns
+    one weight slice, the four slices of a row block sit on four XCDs) always writes through, map 0 (otr_debug_set(15, 0): the four
+    slices of a row block on one XCD) meets in the L2.  All must give the 32-row kernels' result, forward and backward; the arrival
+    counters only ever advance by whole launches (4 per row block)."""
     from opentransformer_amd import ops, _lib as L
     ops.set_compute_dtype('fp16')
     was = ops._FFN_SPLIT
@@ -185,6 +187,7 @@ def test_split_exchange_paths_agree(coh_only):
         for name, split in (('v1', False), ('split', True)):
             ops._FFN_SPLIT = split
             L.check(lib.otr_debug_set(12, coh_only if split else 0), 'debug_set')
+            L.check(lib.otr_debug_set(15, wg_map), 'debug_set')
             x = xv.clone().requires_grad_(True)
             y = ops.ffn_add_layernorm(ops.attach_lp(x, x.detach().to(ops.act_dtype())), w1, b1, w2, b2, gamma, beta, 0.0, 1e-5)
             grads = torch.autograd.grad(y, (x, w1, b1, w2), gy)
@@ -195,5 +198,6 @@ def test_split_exchange_paths_agree(coh_only):
         assert int((rec[:, 0] % 4).abs().sum()) == 0 and int(rec[:, 1].abs().sum()) == 0
     finally:
         lib.otr_debug_set(12, 0)
+        lib.otr_debug_set(15, 1)
         ops._FFN_SPLIT = was
         ops.set_compute_dtype('bf16')

@@ -167,6 +167,22 @@ def main():
                                       sync.numel(), M, F, d, st()), 'bwd3')
     res['split_fwd_save_cold_us'] = timeit(fwd_w, 48)
     res['split_bwd_cold_us'] = timeit(bwd_w, 48)
+
+    def fwd_wn():           # cold weights, nothing saved: is it the saves' store stream that pushes the weights out of the L2?
+        i = cnt[0] % 12
+        cnt[0] += 1
+        L.check(lib.otr_ffn_ln_fwd_split(p(xs[i][0]), p(xs[i][1]), p(Ps[i][0]), p(b1), p(Ps[i][1]), p(b2), p(gamma), p(beta), p(seed), 0.0, 0,
+                                         1e-5, p(y), p(y16), p(z), p(mean), p(rstd), None, None, p(scratch), nb, p(sync),
+                                         sync.numel(), M, F, d, st()), 'fwd3')
+
+    def fwd_xn():           # warm weights (one set), cold x, nothing saved
+        i = cnt[0] % 12
+        cnt[0] += 1
+        L.check(lib.otr_ffn_ln_fwd_split(p(xs[i][0]), p(xs[i][1]), p(P[0]), p(b1), p(P[1]), p(b2), p(gamma), p(beta), p(seed), 0.0, 0,
+                                         1e-5, p(y), p(y16), p(z), p(mean), p(rstd), None, None, p(scratch), nb, p(sync),
+                                         sync.numel(), M, F, d, st()), 'fwd3')
+    res['split_fwd_nosave_cold_us'] = timeit(fwd_wn, 48)
+    res['split_fwd_nosave_coldx_warmw_us'] = timeit(fwd_xn, 48)
     lib.otr_debug_set(4, 1)
     res['split_fwd_save_cold_nodma_us'] = timeit(fwd_w, 48)
     res['split_bwd_cold_nodma_us'] = timeit(bwd_w, 48)
