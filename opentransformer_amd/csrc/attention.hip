@@ -29,6 +29,7 @@ struct AttnArgs {
   int causal;
   float scale;
   int vec;  // all strides/base pointers allow 16-byte row chunks
+  int xmap; // 1: 1-D grid, the blocks of one (head, utterance) share an XCD (attn_block)
   // optional additive score bias (pre-scale): S = (q.k + bias[b,h,i,col]) * scale, col = j (+ Tq-1-i if rel_shift):
   // rel_shift turns a [.., i, 2T-1] relative-position term into the Transformer-XL shifted matrix by index
   // arithmetic (module/attention.py:209-215 materialises and gathers it).
@@ -40,6 +41,20 @@ struct AttnArgs {
 
 __device__ __forceinline__ int64_t bias_index(const AttnArgs& p, int b, int h, int i, int j) {
   return (int64_t)b * p.bias_bs + (int64_t)h * p.bias_hs + (int64_t)i * p.bias_rs + j + (p.rel_shift ? (p.Tq - 1 - i) : 0);
+}
+
+// Which (block of queries / keys, head, utterance) a workgroup works on.  xmap = 0: the 3-D grid as launched.  xmap = 1: a 1-D grid
+// in which the nx blocks of one (head, utterance) get workgroup ids that are EQUAL modulo 8 -- consecutive ids go to consecutive
+// XCDs (observed placement, used for locality only), so the blocks that stream the same K / V (or Q / dO) rows meet in ONE L2
+// instead of four.  Groups past H * B (the grid is padded to whole XCD rounds) return false: the workgroup leaves.
+__device__ __forceinline__ bool attn_block(const AttnArgs& p, int nx, int& bx, int& h, int& b) {
+  if (!p.xmap) { bx = blockIdx.x; h = blockIdx.y; b = blockIdx.z; return true; }
+  const int lid = blockIdx.x, xcd = lid & 7, k = lid >> 3;
+  bx = k % nx;
+  const int g = (k / nx) * 8 + xcd;
+  if (g >= p.H * p.B) return false;
+  h = g % p.H; b = g / p.H;
+  return true;
 }
 
 template <class CT, int DK> struct ACfg {
@@ -280,8 +295,9 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
   unsigned char* sK = smem;
   unsigned char* sVt = smem + C::RM_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lg = lane >> 4;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 64 + wid * 16;
+  int bx, h, b;
+  if (!attn_block(p, (p.Tq + 63) / 64, bx, h, b)) return;
+  const int q0 = bx * 64 + wid * 16;
   const bool vec = p.vec != 0;
   const CT* Q = reinterpret_cast<const CT*>(p.q) + b * p.q_bs + h * DK;
   const CT* K = reinterpret_cast<const CT*>(p.k) + b * p.k_bs + h * DK;
@@ -418,7 +434,7 @@ template <class CT> __device__ __forceinline__ float chunk_dot(const uint4& a, c
   return acc;
 }
 template <class CT, int DK, bool PIPE, bool OWN_DELTA>
-__device__ __forceinline__ void attn_bwd_dkdv_body(const AttnArgs& p, const int bx, unsigned char* smem) {
+__device__ __forceinline__ void attn_bwd_dkdv_body(const AttnArgs& p, const int bx, const int h, const int b, unsigned char* smem) {
   using C = ACfg<CT, DK>;
   static_assert(!OWN_DELTA || (PIPE && (C::NCH & (C::NCH - 1)) == 0 && C::NCH <= 64), "own delta: aligned rows, 2^n chunks per row");
   unsigned char* sQ = smem;
@@ -428,7 +444,6 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnArgs& p, const int 
   float* sLse = reinterpret_cast<float*>(sdOt + C::TR_BYTES);
   float* sDel = sLse + 64;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lg = lane >> 4;
-  const int h = blockIdx.y, b = blockIdx.z;
   const int k0 = bx * 64 + wid * 16;
   const bool vec = p.vec != 0;
   const float sc2 = p.scale * ExpDom<CT>::K;
@@ -571,19 +586,18 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnArgs& p, const int 
 }
 template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[BwdSmem<CT, DK>::DKDV];
-  attn_bwd_dkdv_body<CT, DK, PIPE, false>(p, (int)blockIdx.x, smem);
+  attn_bwd_dkdv_body<CT, DK, PIPE, false>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);
 }
 
 // ================================================================================================ dQ
 // wave owns 16 queries (columns); streams 64-key blocks.
 template <class CT, int DK, bool PIPE>
-__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int bx, unsigned char* smem) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int bx, const int h, const int b, unsigned char* smem) {
   using C = ACfg<CT, DK>;
   unsigned char* sK = smem;
   unsigned char* sV = smem + C::RM_BYTES;
   unsigned char* sKt = smem + 2 * C::RM_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lg = lane >> 4;
-  const int h = blockIdx.y, b = blockIdx.z;
   const int q0 = bx * 64 + wid * 16;
   const bool vec = p.vec != 0;
   const float sc2 = p.scale * ExpDom<CT>::K;
@@ -704,16 +718,17 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int bx
 }
 template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[BwdSmem<CT, DK>::DQ];
-  attn_bwd_dq_body<CT, DK, PIPE>(p, (int)blockIdx.x, smem);
+  attn_bwd_dq_body<CT, DK, PIPE>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);
 }
 // dQ and dK/dV in ONE launch: workgroups 0 .. nqb-1 of a (head, utterance) own 64 queries each, the rest 64 keys each.  The two
 // halves share nothing but the launch -- no ordering between them (the dK/dV half forms its own delta) -- so a CU holds twice
 // the waves to hide latency behind and the step has one dependent launch less per attention (24 per step at the benchmark).
 template <class CT, int DK> __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p, int nqb) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[BwdSmem<CT, DK>::BOTH];
-  const int bx = (int)blockIdx.x;
-  if (bx < nqb) attn_bwd_dq_body<CT, DK, true>(p, bx, smem);
-  else attn_bwd_dkdv_body<CT, DK, true, true>(p, bx - nqb, smem);
+  int bx, h, b;
+  if (!attn_block(p, nqb + (p.Tk + 63) / 64, bx, h, b)) return;
+  if (bx < nqb) attn_bwd_dq_body<CT, DK, true>(p, bx, h, b, smem);
+  else attn_bwd_dkdv_body<CT, DK, true, true>(p, bx - nqb, h, b, smem);
 }
 
 // ================================================================================================ host side
@@ -729,6 +744,11 @@ static int32_t fill_args(const otr_attn_desc_t* d, AttnArgs& a) {
   a.v_bs = d->v_bs; a.v_ts = d->v_ts; a.o_bs = d->o_bs; a.o_ts = d->o_ts;
   a.causal = d->causal; a.scale = d->scale;
   return 0;
+}
+extern int g_otr_attn_xmap;        // api.hip (otr_debug_set(16, v)): XCD-aware workgroup mapping of the attention launches
+static dim3 attn_grid(AttnArgs& a, const otr_attn_desc_t* d, int nx) {
+  a.xmap = g_otr_attn_xmap;
+  return a.xmap ? dim3((unsigned)(8 * nx * ((d->H * d->B + 7) / 8))) : dim3((unsigned)nx, d->H, d->B);
 }
 static int vec_ok(const otr_attn_desc_t* d, std::initializer_list<const void*> ptrs) {
   int ce = d->dtype == OTR_F32 ? 4 : 8;
@@ -762,7 +782,7 @@ extern "C" int32_t otr_attention_fwd(const otr_attn_desc_t* d, const void* q, co
   a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse; a.key_mask = key_mask;
   a.vec = vec_ok(d, {q, k, v, o});
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((d->Tq + 63) / 64, d->H, d->B);
+  dim3 grid = attn_grid(a, d, (d->Tq + 63) / 64);
   if (d->dtype == OTR_H16) { DK_SWITCH(bf16_t, attn_fwd_kernel, grid) } else { DK_SWITCH(float, attn_fwd_kernel, grid) }
   return otr_check_launch("attention_fwd");
 }
@@ -782,7 +802,7 @@ extern "C" int32_t otr_attention_bias_fwd(const otr_attn_desc_t* d, const void* 
   a.vec = vec_ok(d, {q, k, v, o});
   set_bias(a, bias, nullptr, bias_bs, bias_hs, bias_rs, rel_shift);
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((d->Tq + 63) / 64, d->H, d->B);
+  dim3 grid = attn_grid(a, d, (d->Tq + 63) / 64);
   if (d->dtype == OTR_H16) { DK_SWITCH(bf16_t, attn_fwd_kernel, grid) } else { DK_SWITCH(float, attn_fwd_kernel, grid) }
   return otr_check_launch("attention_bias_fwd");
 }
@@ -818,7 +838,7 @@ extern "C" int32_t otr_attention_bwd(const otr_attn_desc_t* d, const void* q, co
 
 extern int g_otr_attn_bwd_split;   // api.hip (otr_debug_set(13, 1)): the two-launch form, for A/B runs
 #define ATTN_BWD_MERGED(CTYPE, DKV) \
-  hipLaunchKernelGGL((attn_bwd_kernel<CTYPE, DKV>), dim3(nqb + nkb, d->H, d->B), dim3(256), 0, s, a, nqb)
+  hipLaunchKernelGGL((attn_bwd_kernel<CTYPE, DKV>), attn_grid(a, d, nqb + nkb), dim3(256), 0, s, a, nqb)
 static int32_t attention_bwd_impl(const otr_attn_desc_t* d, AttnArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int nqb = (d->Tq + 63) / 64, nkb = (d->Tk + 63) / 64;

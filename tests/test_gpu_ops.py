@@ -146,6 +146,31 @@ def test_attention_bwd_one_launch_equals_two(mode, B, T, H, dk, causal):
     assert rel(res[0][..., d:], res[1][..., d:]) < (1e-5 if mode == 'fp32' else 2e-3)
 
 
+@pytest.mark.parametrize('B,T,H,dk,causal', [(3, 249, 4, 64, False), (5, 15, 4, 64, True), (2, 130, 2, 32, False)])
+def test_attention_workgroup_mapping_does_not_change_results(mode, B, T, H, dk, causal):
+    """The attention launches place the blocks of one (head, utterance) on one XCD (a 1-D grid decoded in the kernel; H * B not a
+    multiple of 8 leaves padding workgroups that exit); otr_debug_set(16, 0) brings back the 3-D grid.  Same blocks, same
+    arithmetic: bit-identical outputs and gradients."""
+    from opentransformer_amd import ops, _lib as L
+    d = H * dk
+    qkv = (rnd(B, T, 3 * d, seed=41) * 0.7).to(adt(mode)).requires_grad_(True)
+    km = torch.zeros(B, T, dtype=torch.bool, device=DEV)
+    for i in range(B):
+        km[i, :T - 3 * i] = True
+    g = rnd(B, T, d, seed=42).to(adt(mode))
+    lib = L.load()
+    res = []
+    try:
+        for xmap in (1, 0):
+            L.check(lib.otr_debug_set(16, xmap), 'debug_set')
+            out = ops.SelfAttentionFn.apply(qkv, km.to(torch.uint8), H, causal)
+            (dqkv,) = torch.autograd.grad(out, qkv, g)
+            res.append((out.detach().clone(), dqkv.clone()))
+    finally:
+        lib.otr_debug_set(16, 1)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize('B,L,T,H,dk', [(3, 15, 249, 4, 64), (2, 1, 49, 4, 16), (2, 70, 100, 4, 16)])
 def test_cross_attention(mode, B, L, T, H, dk):
     from opentransformer_amd import ops
