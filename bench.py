@@ -187,7 +187,7 @@ def instrumented_step(ops, fwd_bwd, mode):
     agg = {}
     for name, meta, e0, e1, call in rec:
         a = agg.setdefault(name, {'launches': 0, 'total_ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
-        a['call'] = call                   # the last launch of this name: replay_call() re-times it without host gaps
+        a.setdefault('calls', []).append(call)    # every launch of this name in the step: replay_call() re-times them without host gaps
         a['launches'] += 1
         a['total_ms'] += e0.elapsed_time(e1)
         a['flops'] += (meta or {}).get('flops', 0.0)
@@ -219,29 +219,34 @@ PMC_KERNEL = {'linear_wgrad_grouped': 'wgrad256_kernel', 'proj_ln_fwd': 'proj_ln
               'ffn_bwd_split': 'ffn3_bwd_kernel', 'rb_linear': 'rb_linear_kernel'}
 
 
-def replay_call(ops, call, n=10):
-    """launch duration of one kernel: its last launch of the instrumented step re-issued n times back to back inside ONE
-    hipGraph (no host gaps), events on the launch stream"""
-    if call is None:
+def replay_call(ops, calls, n=10):
+    """launch duration of one kernel: ALL its launches of the instrumented step (each on its own operands -- in the step no layer
+    finds its weights in a cache, a loop on one operand set flatters or penalises a kernel depending on what it shares through the
+    L2) re-issued back to back inside ONE hipGraph, at least n launches, events on the launch stream"""
+    calls = [c for c in (calls or []) if c is not None][:16]
+    if not calls:
         return None
+    reps = max(1, (n + len(calls) - 1) // len(calls))
     try:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            call()
+            for c in calls:
+                c()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with ops.graph_capture(g):
-            for _ in range(n):
-                call()
+            for _ in range(reps):
+                for c in calls:
+                    c()
         g.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         g.replay()
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n
+        return e0.elapsed_time(e1) / (reps * len(calls))
     except Exception:                                          # noqa: BLE001
         return None
 
@@ -466,14 +471,14 @@ def main():
                             d['timed'] = ('10 back-to-back launches of the longest-contraction group on the operands of the step inside '
                                           'one hipGraph, events on the launch stream')
                     else:
-                        ms = replay_call(ops, kern[name].get('call'))
+                        ms = replay_call(ops, kern[name].get('calls'))
                         if ms:
                             d.update(avg_launch_ms_eager_bracket=d['avg_launch_ms'], avg_launch_ms=ms,
                                      achieved=kern[name]['flops_per_launch'] / (ms * 1e-3) / 1e12)
                             d['frac'] = d['achieved'] / peak
                             d['ms_per_step'] = ms * d['launches_per_step']
-                            d['timed'] = ('10 back-to-back launches on the operands of the last such launch of the step inside one '
-                                          'hipGraph, events on the launch stream')
+                            d['timed'] = ('the launches of this kernel in the step, each on its own operands, re-issued back to back (>= 10) '
+                                          'inside one hipGraph, events on the launch stream')
                 # the split FFN kernels trade the recompute for saved tiles: 187 / 161 flop per algorithmic byte, below the 312 flop/B
                 # ridge -> their roofline is HBM; the MFMA rate is reported next to it
                 for name in ('ffn_ln_fwd_split', 'ffn_bwd_split'):
