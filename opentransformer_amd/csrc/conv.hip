@@ -70,6 +70,74 @@ template <class T> __global__ __launch_bounds__(256) void conv1_fwd_kernel(ConvA
   }
 }
 
+// ------------------------------------------------------------------------------------------------ conv1 forward on the fp32 matrix pipe
+// 64 output channels, 16-bit activations.  The stencil kernel above spends ~100 VALU instructions per (pixel, 8 channels) and is
+// bound by them (46 us for 0.7 GFLOP).  As a GEMM the layer is out[pixel][c] = sum_tap patch[pixel][tap] w[c][tap] with 9 taps:
+// v_mfma_f32_32x32x2_f32 -- fp32 products and sums, exactly the arithmetic of the stencil up to the order of the nine additions --
+// takes taps in pairs: A = w (lane (channel, tap parity)), B = the patches (lane (pixel, tap parity)): FIVE loads per lane give 32
+// pixels x 64 channels (10 MFMAs).  The accumulators start from the bias; ReLU and the 16-bit conversion run on them; a tile of 32
+// consecutive pixels is one contiguous 4 KiB block of the channel-last output, written through LDS as whole lines.
+constexpr int C1M_PITCH = 144;                   // bytes per pixel row of the LDS image (128 + 16: the 8-byte pieces of a tile spread over the banks)
+__global__ __launch_bounds__(256) void conv1_fwd_mfma_kernel(ConvArgs p) {
+  typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 32 * C1M_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, m = lane & 31, hi = lane >> 5;
+  unsigned char* img = smem + wid * (32 * C1M_PITCH);
+  // A operands: step s covers taps 2s, 2s + 1; lane (channel 32 ct + m, tap 2s + hi); tap 9 does not exist
+  float wa[2][5], bias[2][16];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) wa[ct][s5] = (2 * s5 + hi < 9) ? p.w1[(32 * ct + m) * 9 + 2 * s5 + hi] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias[ct][r] = p.b1[32 * ct + 8 * (r >> 2) + 4 * hi + (r & 3)];
+  }
+  const int64_t npix = (int64_t)p.B * p.T1 * p.F1;
+  const int64_t ntile = (npix + 31) / 32;
+  uint16_t* out = reinterpret_cast<uint16_t*>(p.act1);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wid; tile < ntile; tile += (int64_t)gridDim.x * 4) {
+    const int64_t pix = tile * 32 + m;
+    const uint32_t pu = (uint32_t)(pix < npix ? pix : npix - 1), bt = pu / (uint32_t)p.F1;       // 32-bit: conv_check bounds the pixel count
+    const int f1 = (int)(pu - bt * (uint32_t)p.F1), b = (int)(bt / (uint32_t)p.T1), t1 = (int)(bt - (uint32_t)b * (uint32_t)p.T1);
+    const float* xin = p.x + ((int64_t)b * p.T + 2 * t1) * p.F;
+    float xb[5];
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) {
+      const int tap = 2 * s5 + hi, kh = tap / 3, kw = tap - 3 * kh, f = 2 * f1 + kw - 1;
+      const bool ok = tap < 9 && f >= 0 && f < p.F;
+      const float v = xin[(ok ? kh : 0) * p.F + (ok ? f : 0)];
+      xb[s5] = ok ? v : 0.f;
+    }
+    f32x16_t acc[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] = bias[ct][r];
+#pragma unroll
+      for (int s5 = 0; s5 < 5; ++s5) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ct][s5], xb[s5], acc[ct], 0, 0, 0);
+    }
+    // D: lane (pixel m, hi) holds channels 32 ct + 8 q + 4 hi + (0..3) for q = r >> 2: 8-byte pieces of the pixel's 128-byte row
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint2 v = make_uint2(pack2h(fmaxf(acc[ct][4 * q], 0.f), fmaxf(acc[ct][4 * q + 1], 0.f)),
+                                   pack2h(fmaxf(acc[ct][4 * q + 2], 0.f), fmaxf(acc[ct][4 * q + 3], 0.f)));
+        *reinterpret_cast<uint2*>(img + m * C1M_PITCH + (32 * ct + 8 * q + 4 * hi) * 2) = v;
+      }
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes (the image is wave-private: no barrier)
+    const int64_t pix0 = tile * 32;
+    const int nvalid = (int)(npix - pix0 < 32 ? npix - pix0 : 32);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pr = 8 * i + (lane >> 3), piece = lane & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(img + pr * C1M_PITCH + piece * 16);
+      if (pr < nvalid) *reinterpret_cast<uint4*>(out + (pix0 + pr) * 64 + piece * 8) = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // reads done before the next tile overwrites the image
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ conv1 wgrad
 template <class T> __global__ __launch_bounds__(256) void conv1_wgrad_kernel(ConvArgs p) {
   __shared__ float red[256][10];                 // one tap-vector (or bias) at a time, padded
@@ -192,6 +260,7 @@ static int32_t conv_check(const otr_conv_desc_t* d, ConvArgs& a) {
   a.T1 = d->T1; a.F1 = d->F1; a.T2 = d->T2; a.F2 = d->F2;
   return 0;
 }
+extern int g_otr_conv1_stencil;    // api.hip (otr_debug_set(17, 1)): the VALU stencil for every shape, for A/B runs
 static unsigned conv_grid(const ConvArgs& a) {
   int64_t npix = (int64_t)a.B * a.T1 * a.F1;
   int ppi = 256 / (a.C1 / 8);
@@ -207,7 +276,11 @@ extern "C" int32_t otr_conv1_fwd(const otr_conv_desc_t* d, const float* x, const
   a.x = x; a.w1 = w1; a.b1 = b1; a.act1 = act1;
   hipStream_t s = (hipStream_t)stream;
   if (d->act_dtype == OTR_F32) hipLaunchKernelGGL(conv1_fwd_kernel<float>, dim3(conv_grid(a)), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(conv1_fwd_kernel<bf16_t>, dim3(conv_grid(a)), dim3(256), 0, s, a);
+  else if (a.C1 == 64 && !g_otr_conv1_stencil && (uintptr_t)act1 % 16 == 0) {
+    const int64_t ntile = ((int64_t)a.B * a.T1 * a.F1 + 31) / 32;
+    const int64_t g = (ntile + 3) / 4;
+    hipLaunchKernelGGL(conv1_fwd_mfma_kernel, dim3((unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g))), dim3(256), 0, s, a);
+  } else hipLaunchKernelGGL(conv1_fwd_kernel<bf16_t>, dim3(conv_grid(a)), dim3(256), 0, s, a);
   return otr_check_launch("conv1_fwd");
 }
 
