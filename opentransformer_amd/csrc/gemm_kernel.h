@@ -962,8 +962,16 @@ static __global__ void splitk_reduce_kernel(const float* ws, int ks, int M, int 
   if (v4) {
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * blockDim.x * 4) {
       float4 a = *reinterpret_cast<const float4*>(ws + i);
-      for (int s = 1; s < ks; ++s) {
-        float4 b = *reinterpret_cast<const float4*>(ws + s * slab + i);
+      int s = 1;
+      for (; s + 8 <= ks; s += 8) {       // eight slabs in flight (one at a time the loop was a chain of memory latencies: 26 us for
+        float4 b[8];                      // the 64 slabs of the conv2 weight gradient); the additions keep their fixed order
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = *reinterpret_cast<const float4*>(ws + (int64_t)(s + j) * slab + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a.x += b[j].x; a.y += b[j].y; a.z += b[j].z; a.w += b[j].w; }
+      }
+      for (; s < ks; ++s) {
+        float4 b = *reinterpret_cast<const float4*>(ws + (int64_t)s * slab + i);
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
       }
       int64_t r = i / N;
