@@ -93,9 +93,12 @@ struct RbLinArgs {
   int M, N, out_h16;
 };
 
-template <int K, int TPW>
-__global__ __launch_bounds__(256, 1) void rb_linear_kernel(RbLinArgs p) {
+// NSPLIT workgroups share a row block, each takes N / NSPLIT output columns (blockIdx.y): with two resident workgroups a CU has 8
+// waves in flight and ingests ~33 B/clk instead of ~22 for the same weight bytes
+template <int K, int TPW, int NSPLIT = 1>
+__global__ __launch_bounds__(256, NSPLIT) void rb_linear_kernel(RbLinArgs p) {
   constexpr int N = 128 * TPW, RS = N + 4;
+  const int cbase = (int)blockIdx.y * N;                         // first output column of this workgroup
   __shared__ __attribute__((aligned(16))) unsigned char smem[RB * K * 2 + RB * RS * 4];
   uint4* xs = reinterpret_cast<uint4*>(smem);
   float* red = reinterpret_cast<float*>(smem + RB * K * 2);
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256, 1) void rb_linear_kernel(RbLinArgs p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row0 = blockIdx.x * RB;
   RbStream<K, TPW> ws;
-  ws.fill(p.pw, wid * TPW, lane);
+  ws.fill(p.pw, (int)blockIdx.y * 4 * TPW + wid * TPW, lane);
   rb_stage_rows<K>(xs, p.x16, p.ldx, row0, p.M, tid);
   __syncthreads();
   f32x16 acc[TPW];
@@ -123,8 +126,10 @@ __global__ __launch_bounds__(256, 1) void rb_linear_kernel(RbLinArgs p) {
     if (row >= p.M) break;                                          // wave-uniform
 #pragma unroll
     for (int c0 = 0; c0 < N; c0 += 256) {
-      const int col = c0 + lane * 4;
-      float4 v = *reinterpret_cast<const float4*>(red + r * RS + col);
+      const int lc = c0 + lane * 4;
+      if (N % 256 != 0 && lc >= N) break;
+      const int col = cbase + lc;
+      float4 v = *reinterpret_cast<const float4*>(red + r * RS + lc);
       if (p.bias) {
         const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
         v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
@@ -481,6 +486,7 @@ __global__ __launch_bounds__(256, 1) void rb_linear_ln_bwd_kernel(RbLinLnBwdArgs
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ C ABI
+extern int g_otr_rb_nsplit;        // api.hip (otr_debug_set(18, v)): the 768-column projection on two workgroups per row block
 extern "C" int32_t otr_rb_linear(const void* x16, int64_t ldx, const void* w_pack, const float* bias, const float* skip, int64_t lds,
                                  void* out, int32_t out_dtype, int64_t ldo, int64_t M, int32_t N, int32_t K, void* stream) {
   OTR_REQUIRE(x16 && w_pack && out, "rb_linear: null pointer");
@@ -498,6 +504,7 @@ extern "C" int32_t otr_rb_linear(const void* x16, int64_t ldx, const void* w_pac
   const dim3 grid((unsigned)((M + RB - 1) / RB));
   hipStream_t s = (hipStream_t)stream;
   if (K == 256 && N == 256) hipLaunchKernelGGL((rb_linear_kernel<256, 2>), grid, dim3(256), 0, s, p);
+  else if (K == 256 && g_otr_rb_nsplit) hipLaunchKernelGGL((rb_linear_kernel<256, 3, 2>), dim3(grid.x, 2), dim3(256), 0, s, p);
   else if (K == 256) hipLaunchKernelGGL((rb_linear_kernel<256, 6>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((rb_linear_kernel<768, 2>), grid, dim3(256), 0, s, p);
   return otr_check_launch("rb_linear");
