@@ -21,17 +21,17 @@ constexpr int RB_PD = 16;     // weight fragments in flight per wave (1 KiB each
 
 // 32 rows x K 16-bit activations -> LDS as 16-byte chunks, chunk index XOR (row & 15): the B-operand read of lane
 // (m = lane&31, hi) -- chunk (2*ks + hi) of row m -- is then bank-conflict free for ds_read_b128 (as ffn_fused.hip)
-template <int K> __device__ __forceinline__ void rb_stage_rows(uint4* dst, const uint16_t* src, int64_t ld, int row0, int M, int tid) {
-  constexpr int CPR = K / 8, PER = RB * CPR / 256;       // chunks per thread: 4 (K = 256) / 12 (K = 768), all loads before any store
+template <int K, int NTHR = 256> __device__ __forceinline__ void rb_stage_rows(uint4* dst, const uint16_t* src, int64_t ld, int row0, int M, int tid) {
+  constexpr int CPR = K / 8, PER = RB * CPR / NTHR;       // chunks per thread: 4 (K = 256) / 12 (K = 768), all loads before any store
   uint4 v[PER];
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
-    const int i = tid + j * 256, r = i / CPR, ch = i % CPR;
+    const int i = tid + j * NTHR, r = i / CPR, ch = i % CPR;
     v[j] = ld_global_b128(src + (int64_t)min(row0 + r, M - 1) * ld + ch * 8);
   }
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
-    const int i = tid + j * 256, r = i / CPR, ch = i % CPR;
+    const int i = tid + j * NTHR, r = i / CPR, ch = i % CPR;
     dst[r * CPR + (ch ^ (r & 15))] = v[j];
   }
 }
@@ -157,29 +157,32 @@ struct ProjLnArgs {
   uint64_t rng_offset;
 };
 
-__global__ __launch_bounds__(256, 1) void proj_ln_fwd_kernel(ProjLnArgs p) {
-  constexpr int D = 256, RS = D + 4;
+// NW = 4 or 8 waves: with 8 (two per SIMD) the CU has twice the loads in flight and ingests the 128 KB of packed weights at ~33
+// instead of ~22 B/clk; a wave then owns one column tile and four rows of the epilogue
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void proj_ln_fwd_kernel(ProjLnArgs p) {
+  constexpr int D = 256, RS = D + 4, TPW = 8 / NW, RPW = RB / NW;
   __shared__ __attribute__((aligned(16))) unsigned char smem[RB * D * 2 + RB * RS * 4];
   uint4* xs = reinterpret_cast<uint4*>(smem);
   float* red = reinterpret_cast<float*>(smem + RB * D * 2);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row0 = blockIdx.x * RB;
-  RbStream<D, 2> ws;
-  ws.fill(p.pw, wid * 2, lane);
-  rb_stage_rows<D>(xs, p.c16, p.ldc, row0, p.M, tid);
+  RbStream<D, TPW> ws;
+  ws.fill(p.pw, wid * TPW, lane);
+  rb_stage_rows<D, 64 * NW>(xs, p.c16, p.ldc, row0, p.M, tid);
   __syncthreads();
-  f32x16 acc[2];
+  f32x16 acc[TPW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TPW; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   // the residual rows of this wave travel while the GEMM runs
   const int col = lane * 4;
-  float4 xr[8];
+  float4 xr[RPW];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int64_t row = min((int64_t)row0 + wid * 8 + i, (int64_t)p.M - 1);
+  for (int i = 0; i < RPW; ++i) {
+    const int64_t row = min((int64_t)row0 + wid * RPW + i, (int64_t)p.M - 1);
     xr[i] = *reinterpret_cast<const float4*>(p.x + row * D + col);
   }
   const bool drop = p.p_drop > 0.f;
@@ -192,14 +195,14 @@ __global__ __launch_bounds__(256, 1) void proj_ln_fwd_kernel(ProjLnArgs p) {
   const float4 bt = *reinterpret_cast<const float4*>(p.beta + col);
   ws.run(acc, xs, lane);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) rb_put_tile<RS>(red, acc[i], (wid * 2 + i) * 32, lane);
+  for (int i = 0; i < TPW; ++i) rb_put_tile<RS>(red, acc[i], (wid * TPW + i) * 32, lane);
   __syncthreads();
   // the 8 rows of a wave are normalised TOGETHER: their 2 x 6 butterfly steps are independent, so the cross-lane latency
   // is paid 12 times per wave instead of 96 (one row after the other it was ~5 us of this kernel)
-  float v[8][4], sm[8], qq[8];
+  float v[RPW][4], sm[RPW], qq[RPW];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int r = wid * 8 + i;
+  for (int i = 0; i < RPW; ++i) {
+    const int r = wid * RPW + i;
     const int64_t row = min((int64_t)row0 + r, (int64_t)p.M - 1);
     const float4 t = *reinterpret_cast<const float4*>(red + r * RS + col);
     const float bv[4] = {t.x + bb.x, t.y + bb.y, t.z + bb.z, t.w + bb.w};
@@ -216,9 +219,9 @@ __global__ __launch_bounds__(256, 1) void proj_ln_fwd_kernel(ProjLnArgs p) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sm[i] += __shfl_xor(sm[i], o);
+    for (int i = 0; i < RPW; ++i) sm[i] += __shfl_xor(sm[i], o);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < RPW; ++i) {
     sm[i] *= (1.f / D);
     qq[i] = 0.f;
 #pragma unroll
@@ -227,11 +230,11 @@ __global__ __launch_bounds__(256, 1) void proj_ln_fwd_kernel(ProjLnArgs p) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) qq[i] += __shfl_xor(qq[i], o);
+    for (int i = 0; i < RPW; ++i) qq[i] += __shfl_xor(qq[i], o);
   const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int64_t row = (int64_t)row0 + wid * 8 + i;
+  for (int i = 0; i < RPW; ++i) {
+    const int64_t row = (int64_t)row0 + wid * RPW + i;
     if (row >= p.M) break;                                          // wave-uniform
     const float mean = sm[i], rstd = rsqrtf(qq[i] * (1.f / D) + p.eps);
     if (p.z) *reinterpret_cast<float4*>(p.z + row * D + col) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
@@ -260,8 +263,9 @@ struct LnBwdProjArgs {
   uint64_t rng_offset;
 };
 
-__global__ __launch_bounds__(256, 1) void ln_bwd_proj_kernel(LnBwdProjArgs p) {
-  constexpr int D = 256, RS = D + 4, CPR = D / 8;
+template <int NW>     // 4 or 8 waves (proj_ln_fwd_kernel)
+__global__ __launch_bounds__(64 * NW, NW / 4) void ln_bwd_proj_kernel(LnBwdProjArgs p) {
+  constexpr int D = 256, RS = D + 4, CPR = D / 8, TPW = 8 / NW, RPW = RB / NW;
   __shared__ __attribute__((aligned(16))) unsigned char smem[RB * D * 2 + RB * RS * 4];
   uint4* xs = reinterpret_cast<uint4*>(smem);
   float* red = reinterpret_cast<float*>(smem + RB * D * 2);
@@ -273,25 +277,25 @@ __global__ __launch_bounds__(256, 1) void ln_bwd_proj_kernel(LnBwdProjArgs p) {
   const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
   const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
   const int col = lane * 4;
-  RbStream<D, 2> ws;
-  ws.fill(p.pwt, wid * 2, lane);                                   // W^T starts to travel under the LayerNorm arithmetic
+  RbStream<D, TPW> ws;
+  ws.fill(p.pwt, wid * TPW, lane);                                   // W^T starts to travel under the LayerNorm arithmetic
   const float4 gm4 = *reinterpret_cast<const float4*>(p.gamma + col);
   const float gam[4] = {gm4.x, gm4.y, gm4.z, gm4.w};
   // ---- LayerNorm backward on this wave's 8 rows (all loads first)
-  float4 dyv[8], zv[8];
-  float mean[8], rstd[8];
+  float4 dyv[RPW], zv[RPW];
+  float mean[RPW], rstd[RPW];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int64_t row = min((int64_t)row0 + wid * 8 + i, (int64_t)p.M - 1);
+  for (int i = 0; i < RPW; ++i) {
+    const int64_t row = min((int64_t)row0 + wid * RPW + i, (int64_t)p.M - 1);
     dyv[i] = *reinterpret_cast<const float4*>(p.dy + row * D + col);
     zv[i] = *reinterpret_cast<const float4*>(p.z + row * D + col);
     mean[i] = p.mean[row]; rstd[i] = p.rstd[row];
   }
   float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dab[4] = {0.f, 0.f, 0.f, 0.f};
-  float d4[8][4], z4[8][4], s1[8], s2[8];
+  float d4[RPW][4], z4[RPW][4], s1[RPW], s2[RPW];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float live = (int64_t)row0 + wid * 8 + i < p.M ? 1.f : 0.f;
+  for (int i = 0; i < RPW; ++i) {
+    const float live = (int64_t)row0 + wid * RPW + i < p.M ? 1.f : 0.f;
     const float dd[4] = {dyv[i].x * live, dyv[i].y * live, dyv[i].z * live, dyv[i].w * live};
     const float zz[4] = {zv[i].x, zv[i].y, zv[i].z, zv[i].w};
     s1[i] = 0.f; s2[i] = 0.f;
@@ -309,10 +313,10 @@ __global__ __launch_bounds__(256, 1) void ln_bwd_proj_kernel(LnBwdProjArgs p) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
+    for (int i = 0; i < RPW; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int r = wid * 8 + i;
+  for (int i = 0; i < RPW; ++i) {
+    const int r = wid * RPW + i;
     const int64_t row = (int64_t)row0 + r;
     const float m1 = s1[i] * (1.f / D), m2 = s2[i] * (1.f / D);
     float dz[4], da[4];
@@ -335,32 +339,35 @@ __global__ __launch_bounds__(256, 1) void ln_bwd_proj_kernel(LnBwdProjArgs p) {
   float* part = reinterpret_cast<float*>(red);                      // [3][4 waves][256]
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    part[(0 * 4 + wid) * D + col + e] = dg[e];
-    part[(1 * 4 + wid) * D + col + e] = db[e];
-    part[(2 * 4 + wid) * D + col + e] = dab[e];
+    part[(0 * NW + wid) * D + col + e] = dg[e];
+    part[(1 * NW + wid) * D + col + e] = db[e];
+    part[(2 * NW + wid) * D + col + e] = dab[e];
   }
   __syncthreads();
   if (p.partial) {
     float* prow = p.partial + (int64_t)blockIdx.x * 3 * D;
-    for (int c = tid; c < 3 * D; c += 256) {
+    for (int c = tid; c < 3 * D; c += 64 * NW) {
       const int k = c >> 8, cc = c & 255;
-      prow[c] = part[(k * 4 + 0) * D + cc] + part[(k * 4 + 1) * D + cc] + part[(k * 4 + 2) * D + cc] + part[(k * 4 + 3) * D + cc];
+      float t_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t_ += part[(k * NW + w) * D + cc];
+      prow[c] = t_;
     }
   }
   __syncthreads();                                                  // `red` is reused for the output tiles
   // ---- dc = da . W: output column = input feature of the projection
-  f32x16 acc[2];
+  f32x16 acc[TPW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TPW; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   ws.run(acc, xs, lane);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) rb_put_tile<RS>(red, acc[i], (wid * 2 + i) * 32, lane);
+  for (int i = 0; i < TPW; ++i) rb_put_tile<RS>(red, acc[i], (wid * TPW + i) * 32, lane);
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int r = wid * 8 + i;
+  for (int i = 0; i < RPW; ++i) {
+    const int r = wid * RPW + i;
     const int64_t row = (int64_t)row0 + r;
     if (row >= p.M) break;
     const float4 v = *reinterpret_cast<const float4*>(red + r * RS + col);
@@ -386,9 +393,9 @@ struct RbLinLnBwdArgs {
   uint64_t rng_offset;
 };
 
-template <int K>
-__global__ __launch_bounds__(256, 1) void rb_linear_ln_bwd_kernel(RbLinLnBwdArgs p) {
-  constexpr int D = 256, RS = D + 4;
+template <int K, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void rb_linear_ln_bwd_kernel(RbLinLnBwdArgs p) {
+  constexpr int D = 256, RS = D + 4, TPW = 8 / NW, RPW = RB / NW;
   __shared__ __attribute__((aligned(16))) unsigned char smem[RB * K * 2 + RB * RS * 4];
   uint4* xs = reinterpret_cast<uint4*>(smem);
   float* red = reinterpret_cast<float*>(smem + RB * K * 2);
@@ -396,9 +403,9 @@ __global__ __launch_bounds__(256, 1) void rb_linear_ln_bwd_kernel(RbLinLnBwdArgs
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row0 = blockIdx.x * RB;
   const int col = lane * 4;
-  RbStream<K, 2> ws;
-  ws.fill(p.pw, wid * 2, lane);
-  rb_stage_rows<K>(xs, p.g16, p.ldg, row0, p.M, tid);
+  RbStream<K, TPW> ws;
+  ws.fill(p.pw, wid * TPW, lane);
+  rb_stage_rows<K, 64 * NW>(xs, p.g16, p.ldg, row0, p.M, tid);
   // everything of the LayerNorm backward that does not depend on the product travels under the GEMM
   const bool drop = p.p_drop > 0.f;
   const uint64_t seed = drop ? *p.seed : 0;
@@ -406,31 +413,31 @@ __global__ __launch_bounds__(256, 1) void rb_linear_ln_bwd_kernel(RbLinLnBwdArgs
   const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
   const float4 gm4 = *reinterpret_cast<const float4*>(p.gamma + col);
   const float gam[4] = {gm4.x, gm4.y, gm4.z, gm4.w};
-  float4 skv[8], zv[8];
-  float mean[8], rstd[8];
+  float4 skv[RPW], zv[RPW];
+  float mean[RPW], rstd[RPW];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int64_t row = min((int64_t)row0 + wid * 8 + i, (int64_t)p.M - 1);
+  for (int i = 0; i < RPW; ++i) {
+    const int64_t row = min((int64_t)row0 + wid * RPW + i, (int64_t)p.M - 1);
     skv[i] = p.skip ? *reinterpret_cast<const float4*>(p.skip + row * p.lds + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     zv[i] = *reinterpret_cast<const float4*>(p.z + row * D + col);
     mean[i] = p.mean[row]; rstd[i] = p.rstd[row];
   }
   __syncthreads();
-  f32x16 acc[2];
+  f32x16 acc[TPW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TPW; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   ws.run(acc, xs, lane);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) rb_put_tile<RS>(red, acc[i], (wid * 2 + i) * 32, lane);
+  for (int i = 0; i < TPW; ++i) rb_put_tile<RS>(red, acc[i], (wid * TPW + i) * 32, lane);
   __syncthreads();
   // ---- LayerNorm backward on this wave's 8 rows (ln_bwd_proj_kernel), dy = the product + skip
   float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dab[4] = {0.f, 0.f, 0.f, 0.f};
-  float d4[8][4], z4[8][4], s1[8], s2[8];
+  float d4[RPW][4], z4[RPW][4], s1[RPW], s2[RPW];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int r = wid * 8 + i;
+  for (int i = 0; i < RPW; ++i) {
+    const int r = wid * RPW + i;
     const float live = (int64_t)row0 + r < p.M ? 1.f : 0.f;
     const float4 v = *reinterpret_cast<const float4*>(red + r * RS + col);
     const float dd[4] = {(v.x + skv[i].x) * live, (v.y + skv[i].y) * live, (v.z + skv[i].z) * live, (v.w + skv[i].w) * live};
@@ -449,10 +456,10 @@ __global__ __launch_bounds__(256, 1) void rb_linear_ln_bwd_kernel(RbLinLnBwdArgs
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
+    for (int i = 0; i < RPW; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int64_t row = (int64_t)row0 + wid * 8 + i;
+  for (int i = 0; i < RPW; ++i) {
+    const int64_t row = (int64_t)row0 + wid * RPW + i;
     const float m1 = s1[i] * (1.f / D), m2 = s2[i] * (1.f / D);
     float dz[4], da[4];
 #pragma unroll
@@ -471,21 +478,25 @@ __global__ __launch_bounds__(256, 1) void rb_linear_ln_bwd_kernel(RbLinLnBwdArgs
   float* part = red;                                                // [3][4 waves][256]
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    part[(0 * 4 + wid) * D + col + e] = dg[e];
-    part[(1 * 4 + wid) * D + col + e] = db[e];
-    part[(2 * 4 + wid) * D + col + e] = dab[e];
+    part[(0 * NW + wid) * D + col + e] = dg[e];
+    part[(1 * NW + wid) * D + col + e] = db[e];
+    part[(2 * NW + wid) * D + col + e] = dab[e];
   }
   __syncthreads();
   float* prow = p.partial + (int64_t)blockIdx.x * 3 * D;
-  for (int c = tid; c < 3 * D; c += 256) {
+  for (int c = tid; c < 3 * D; c += 64 * NW) {
     const int k = c >> 8, cc = c & 255;
-    prow[c] = part[(k * 4 + 0) * D + cc] + part[(k * 4 + 1) * D + cc] + part[(k * 4 + 2) * D + cc] + part[(k * 4 + 3) * D + cc];
+    float t_ = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t_ += part[(k * NW + w) * D + cc];
+    prow[c] = t_;
   }
 }
 
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ C ABI
+extern int g_otr_rb_waves8;        // api.hip (otr_debug_set(19, v)): 8-wave workgroups for the 256-column row-block kernels
 extern int g_otr_rb_nsplit;        // api.hip (otr_debug_set(18, v)): the 768-column projection on two workgroups per row block
 extern "C" int32_t otr_rb_linear(const void* x16, int64_t ldx, const void* w_pack, const float* bias, const float* skip, int64_t lds,
                                  void* out, int32_t out_dtype, int64_t ldo, int64_t M, int32_t N, int32_t K, void* stream) {
@@ -522,7 +533,8 @@ extern "C" int32_t otr_proj_ln_fwd(const float* x, const void* c16, int64_t ldc,
   p.x = x; p.c16 = reinterpret_cast<const uint16_t*>(c16); p.pw = reinterpret_cast<const uint4*>(w_pack); p.bias = bias; p.gamma = gamma;
   p.beta = beta; p.seed = seed; p.y = y; p.y16 = reinterpret_cast<uint16_t*>(y16); p.z = z; p.mean = mean; p.rstd = rstd;
   p.ldc = ldc; p.M = (int)M; p.eps = eps; p.p_drop = p_drop; p.rng_offset = rng_offset;
-  hipLaunchKernelGGL(proj_ln_fwd_kernel, dim3((unsigned)((M + RB - 1) / RB)), dim3(256), 0, (hipStream_t)stream, p);
+  if (g_otr_rb_waves8) hipLaunchKernelGGL(proj_ln_fwd_kernel<8>, dim3((unsigned)((M + RB - 1) / RB)), dim3(512), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(proj_ln_fwd_kernel<4>, dim3((unsigned)((M + RB - 1) / RB)), dim3(256), 0, (hipStream_t)stream, p);
   return otr_check_launch("proj_ln_fwd");
 }
 
@@ -540,7 +552,8 @@ extern "C" int32_t otr_ln_bwd_proj(const float* dy, const float* z, const float*
   p.dy = dy; p.z = z; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.seed = seed; p.pwt = reinterpret_cast<const uint4*>(wt_pack);
   p.dx = dx; p.da16 = reinterpret_cast<uint16_t*>(da16); p.dc16 = reinterpret_cast<uint16_t*>(dc16); p.partial = partial;
   p.ldc = ldc; p.M = (int)M; p.p_drop = p_drop; p.rng_offset = rng_offset;
-  hipLaunchKernelGGL(ln_bwd_proj_kernel, dim3((unsigned)((M + RB - 1) / RB)), dim3(256), 0, (hipStream_t)stream, p);
+  if (g_otr_rb_waves8) hipLaunchKernelGGL(ln_bwd_proj_kernel<8>, dim3((unsigned)((M + RB - 1) / RB)), dim3(512), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(ln_bwd_proj_kernel<4>, dim3((unsigned)((M + RB - 1) / RB)), dim3(256), 0, (hipStream_t)stream, p);
   return otr_check_launch("ln_bwd_proj");
 }
 
@@ -560,7 +573,13 @@ extern "C" int32_t otr_rb_linear_ln_bwd(const void* g16, int64_t ldg, const void
   p.rstd = rstd; p.gamma = gamma; p.seed = seed; p.dx = dx; p.da16 = reinterpret_cast<uint16_t*>(da16); p.partial = partial;
   p.ldg = ldg; p.lds = lds; p.M = (int)M; p.p_drop = p_drop; p.rng_offset = rng_offset;
   const dim3 grid((unsigned)((M + RB - 1) / RB));
-  if (K == 768) hipLaunchKernelGGL((rb_linear_ln_bwd_kernel<768>), grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((rb_linear_ln_bwd_kernel<256>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  hipStream_t s = (hipStream_t)stream;
+  if (g_otr_rb_waves8) {
+    if (K == 768) hipLaunchKernelGGL((rb_linear_ln_bwd_kernel<768, 8>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((rb_linear_ln_bwd_kernel<256, 8>), grid, dim3(512), 0, s, p);
+  } else {
+    if (K == 768) hipLaunchKernelGGL((rb_linear_ln_bwd_kernel<768, 4>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((rb_linear_ln_bwd_kernel<256, 4>), grid, dim3(256), 0, s, p);
+  }
   return otr_check_launch("rb_linear_ln_bwd");
 }
