@@ -70,11 +70,12 @@ constexpr int F3_AUX_COH = 17;           // sc0 | sc1: stores write through to m
 typedef decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0)) f3_rsrc_t;
 
 // Cache policy of a transfer.  The XCDs' L2s are not coherent with each other, so in general the sender writes THROUGH
-// (sc0 sc1) and the receiver reads past its L2 (sc0 sc1).  But the four workgroups of a row block are neighbours in dispatch
-// order and in practice share an XCD; each publishes its XCC id in the row block's sync record at kernel entry, and a transfer
-// whose two ends read EQUAL ids uses the shared L2: plain stores (at the L2 when vmcnt drains) and sc1 loads (past the L1,
-// served by the L2).  Mixed decisions stay correct: an id not (yet) valid or different -> write-through; a write-through
-// store on the same XCD drops the line from that L2, so an L2-served load refetches it.
+// (sc0 sc1) and the receiver reads past its L2 (sc0 sc1) -- with the default workgroup mapping (f3_block_map, map 1: the four
+// slices of a row block on four XCDs) that is what every transfer does, and it was measured no slower.  Under map 0 the four
+// workgroups of a row block share an XCD in practice; each publishes its XCC id in the row block's sync record at kernel
+// entry, and a transfer whose two ends read EQUAL ids uses the shared L2: plain stores (at the L2 when vmcnt drains) and sc1
+// loads (past the L1, served by the L2).  Mixed decisions stay correct: an id not (yet) valid or different -> write-through; a
+// write-through store on the same XCD drops the line from that L2, so an L2-served load refetches it.
 //   sync record of a row block (8 ints): [0] arrivals, MONOTONIC: launches are stream-ordered, so launch n finds 4n and a
 //   workgroup waits for 4n + 4 -- nothing is reset, nobody is the "last reader"; [2 + s] = (n << 6) | (XCC id of slice s + 1),
 //   valid only with this launch's n (a stale id of an earlier launch never vouches for a placement).
