@@ -52,7 +52,8 @@ int32_t otr_half_type(void);
  * attention launches (1, the default: the blocks of one (head, utterance) on one XCD; 0: the plain 3-D grid), key 17 = 1: conv1
  * forward on the VALU stencil for every shape (default: the fp32 matrix pipe for 64 channels and 16-bit activations), key 18 = 0:
  * the 768-column row-block projection on one workgroup per row block (default: two, 384 columns each), key 19 = 0: 4-wave workgroups
- * for the 256-column row-block kernels (default: 8 waves) */
+ * for the 256-column row-block kernels (default: 8 waves), key 20 = 0: 4-wave (64 queries / keys) workgroups for the attention launches
+ * (default: 8 waves, 128 queries / keys, for aligned 16-bit operands with head dim 64) */
 int32_t otr_debug_set(int32_t key, int32_t value);
 /* Register the caller-owned, zero-initialised DEVICE word that spin-bounded kernels (the turnstile of the 256-wide
  * weight-gradient launch; NULL = none) add 1 to whenever a wait gives up -- the results of such a launch may be wrong sums.

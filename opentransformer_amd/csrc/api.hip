@@ -49,6 +49,7 @@ int g_otr_wgrad256_grid = 0; // workgroups of that launch; 0 = one per CU (otr_d
 int g_otr_rb_waves8 = 1;         // 256-column row-block kernels on 8-wave workgroups (otr_debug_set(19, v))
 int g_otr_rb_nsplit = 1;         // q|k|v row-block projection: 1 = two workgroups per row block, 384 columns each (otr_debug_set(18, v))
 int g_otr_conv1_stencil = 0;     // 1: conv1 forward on the VALU stencil instead of the fp32 matrix pipe (otr_debug_set(17, v))
+int g_otr_attn_waves8 = 1;       // merged attention backward on 8-wave workgroups (128 queries / keys each; otr_debug_set(20, v))
 int g_otr_attn_xmap = 1;         // attention launches: the blocks of one (head, utterance) on one XCD (otr_debug_set(16, v))
 int g_otr_attn_bwd_split = 0;    // attention backward as two launches (dQ, then dK/dV) instead of one (otr_debug_set(13, v))
 int g_otr_ffn_map = 1;           // split FFN kernels: workgroup -> (row block, slice) mapping, ffn3.hip f3_block_map (otr_debug_set(15, v))
@@ -73,6 +74,7 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   else if (key == 12) g_otr_ffn_coh_only = value;
   else if (key == 13) g_otr_attn_bwd_split = value;
   else if (key == 16) g_otr_attn_xmap = value;
+  else if (key == 20) g_otr_attn_waves8 = value;
   else if (key == 17) g_otr_conv1_stencil = value;
   else if (key == 18) g_otr_rb_nsplit = value;
   else if (key == 19) g_otr_rb_waves8 = value;

@@ -158,44 +158,44 @@ __device__ __forceinline__ uint4 read_tr(const unsigned char* lds, int row, int 
 // before the MFMAs of block i, so the HBM/L2 latency of the streamed operand hides behind compute instead of being
 // paid once per block between two barriers.  All loads are unconditional (rows clamped, invalid rows zeroed with a
 // mask at store time): a load inside a branch gets its own vmcnt(0) from hipcc.
-template <class CT, int DK> struct RmRegs {
-  static constexpr int NU = (64 * ACfg<CT, DK>::NCH) / 256;
-  static_assert((64 * ACfg<CT, DK>::NCH) % 256 == 0, "row-major tile must divide evenly over 256 threads");
+template <class CT, int DK, int NT = 256> struct RmRegs {      // NT = threads of the workgroup
+  static constexpr int NU = (64 * ACfg<CT, DK>::NCH) / NT;
+  static_assert((64 * ACfg<CT, DK>::NCH) % NT == 0, "row-major tile must divide evenly over the workgroup's threads");
   uint4 v[NU];
 };
-template <class CT, int DK>
-__device__ __forceinline__ void ld_rm(RmRegs<CT, DK>& r, const CT* g, int64_t ts, int nvalid, int tid) {
+template <class CT, int DK, int NT>
+__device__ __forceinline__ void ld_rm(RmRegs<CT, DK, NT>& r, const CT* g, int64_t ts, int nvalid, int tid) {
   using C = ACfg<CT, DK>;
 #pragma unroll
-  for (int u = 0; u < RmRegs<CT, DK>::NU; ++u) {
-    const int id = tid + 256 * u, row = id / C::NCH, c = id - row * C::NCH;
+  for (int u = 0; u < RmRegs<CT, DK, NT>::NU; ++u) {
+    const int id = tid + NT * u, row = id / C::NCH, c = id - row * C::NCH;
     const int rr = min(row, nvalid - 1), cc = (c * C::CE < DK) ? c * C::CE : 0;
     r.v[u] = *reinterpret_cast<const uint4*>(g + (int64_t)rr * ts + cc);
   }
 }
-template <class CT, int DK>
-__device__ __forceinline__ void st_rm(unsigned char* lds, const RmRegs<CT, DK>& r, int nvalid, int tid) {
+template <class CT, int DK, int NT>
+__device__ __forceinline__ void st_rm(unsigned char* lds, const RmRegs<CT, DK, NT>& r, int nvalid, int tid) {
   using C = ACfg<CT, DK>;
 #pragma unroll
-  for (int u = 0; u < RmRegs<CT, DK>::NU; ++u) {
-    const int id = tid + 256 * u, row = id / C::NCH, c = id - row * C::NCH;
+  for (int u = 0; u < RmRegs<CT, DK, NT>::NU; ++u) {
+    const int id = tid + NT * u, row = id / C::NCH, c = id - row * C::NCH;
     const uint32_t m = (uint32_t)0 - (uint32_t)(row < nvalid && c * C::CE < DK);
     uint4 q = r.v[u];
     q.x &= m; q.y &= m; q.z &= m; q.w &= m;
     *reinterpret_cast<uint4*>(lds + row * C::ROWB + ((c ^ swz<C::NCH>(row)) << 4)) = q;
   }
 }
-template <class CT, int DK> struct TrRegs {
+template <class CT, int DK, int NT = 256> struct TrRegs {
   static constexpr int DP = DK / 2;
-  static constexpr int NI = (DP * 16 + 255) / 256;
+  static constexpr int NI = (DP * 16 + NT - 1) / NT;
   uint2 w[NI][4];   // two adjacent head-dim elements of 4 consecutive streamed rows (bf16 uses .x only)
 };
-template <class CT, int DK>
-__device__ __forceinline__ void ld_tr(TrRegs<CT, DK>& r, const CT* g, int64_t ts, int nvalid, int tid) {
+template <class CT, int DK, int NT>
+__device__ __forceinline__ void ld_tr(TrRegs<CT, DK, NT>& r, const CT* g, int64_t ts, int nvalid, int tid) {
   constexpr int DP = DK / 2;
 #pragma unroll
-  for (int it = 0; it < TrRegs<CT, DK>::NI; ++it) {
-    const int id = min(tid + 256 * it, DP * 16 - 1), dp = id % DP, kg = id / DP;
+  for (int it = 0; it < TrRegs<CT, DK, NT>::NI; ++it) {
+    const int id = min(tid + NT * it, DP * 16 - 1), dp = id % DP, kg = id / DP;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int rr = min(kg * 4 + j, nvalid - 1);
@@ -205,13 +205,13 @@ __device__ __forceinline__ void ld_tr(TrRegs<CT, DK>& r, const CT* g, int64_t ts
     }
   }
 }
-template <class CT, int DK>
-__device__ __forceinline__ void st_tr(unsigned char* lds, const TrRegs<CT, DK>& r, int nvalid, int tid) {
+template <class CT, int DK, int NT>
+__device__ __forceinline__ void st_tr(unsigned char* lds, const TrRegs<CT, DK, NT>& r, int nvalid, int tid) {
   using C = ACfg<CT, DK>;
   constexpr int DP = DK / 2;
 #pragma unroll
-  for (int it = 0; it < TrRegs<CT, DK>::NI; ++it) {
-    const int id = tid + 256 * it;
+  for (int it = 0; it < TrRegs<CT, DK, NT>::NI; ++it) {
+    const int id = tid + NT * it;
     if (id < DP * 16) {                 // LDS-only branch (DK = 16: half of the threads have no patch)
       const int dp = id % DP, kg = id / DP;
       uint32_t lo[4], hi[4];            // element 2dp / 2dp+1 of rows kg*4..+3, as raw bits
@@ -289,15 +289,19 @@ template <class CT> __device__ __forceinline__ void store4(CT* p, float a, float
 #define NEG_INF (-__builtin_huge_valf())
 
 // ================================================================================================ forward
-template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+// NW waves per workgroup (16 queries each).  NW = 8 (aligned 16-bit operands, head dim 64): every streamed key / value block is
+// staged once for eight waves instead of four (attn_bwd_kernel)
+template <class CT, int DK, bool PIPE, int NW = 4> __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
   using C = ACfg<CT, DK>;
+  constexpr int NT = 64 * NW;
+  static_assert(NW == 4 || PIPE, "more than four waves: aligned operands only");
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::RM_BYTES + C::TR_BYTES];
   unsigned char* sK = smem;
   unsigned char* sVt = smem + C::RM_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lg = lane >> 4;
   int bx, h, b;
-  if (!attn_block(p, (p.Tq + 63) / 64, bx, h, b)) return;
-  const int q0 = bx * 64 + wid * 16;
+  if (!attn_block(p, (p.Tq + 16 * NW - 1) / (16 * NW), bx, h, b)) return;
+  const int q0 = bx * (16 * NW) + wid * 16;
   const bool vec = p.vec != 0;
   const CT* Q = reinterpret_cast<const CT*>(p.q) + b * p.q_bs + h * DK;
   const CT* K = reinterpret_cast<const CT*>(p.k) + b * p.k_bs + h * DK;
@@ -315,8 +319,8 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
   const float sc2 = p.scale * ExpDom<CT>::K;
 
   const int nkb = (p.Tk + 63) / 64;
-  RmRegs<CT, DK> kreg;
-  TrRegs<CT, DK> vreg;
+  RmRegs<CT, DK, NT> kreg;
+  TrRegs<CT, DK, NT> vreg;
   if constexpr (PIPE) {
     ld_rm<CT, DK>(kreg, K, p.k_ts, min(64, p.Tk), tid);
     ld_tr<CT, DK>(vreg, V, p.v_ts, min(64, p.Tk), tid);
@@ -433,7 +437,7 @@ template <class CT> __device__ __forceinline__ float chunk_dot(const uint4& a, c
   }
   return acc;
 }
-template <class CT, int DK, bool PIPE, bool OWN_DELTA>
+template <class CT, int DK, bool PIPE, bool OWN_DELTA, int NW = 4>     // NW waves: the workgroup owns 16 NW keys
 __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnArgs& p, const int bx, const int h, const int b, unsigned char* smem) {
   using C = ACfg<CT, DK>;
   static_assert(!OWN_DELTA || (PIPE && (C::NCH & (C::NCH - 1)) == 0 && C::NCH <= 64), "own delta: aligned rows, 2^n chunks per row");
@@ -444,7 +448,9 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnArgs& p, const int 
   float* sLse = reinterpret_cast<float*>(sdOt + C::TR_BYTES);
   float* sDel = sLse + 64;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lg = lane >> 4;
-  const int k0 = bx * 64 + wid * 16;
+  constexpr int NT = 64 * NW;
+  static_assert(NW == 4 || PIPE, "more than four waves: aligned operands only");
+  const int k0 = bx * (16 * NW) + wid * 16;
   const bool vec = p.vec != 0;
   const float sc2 = p.scale * ExpDom<CT>::K;
   const CT* Q = reinterpret_cast<const CT*>(p.q) + b * p.q_bs + h * DK;
@@ -466,8 +472,8 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnArgs& p, const int 
   for (int i = 0; i < C::DT; ++i) { dk_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const int nqb = (p.Tq + 63) / 64;
-  RmRegs<CT, DK> qreg, doreg, oreg;
-  TrRegs<CT, DK> qtreg, dotreg;
+  RmRegs<CT, DK, NT> qreg, doreg, oreg;
+  TrRegs<CT, DK, NT> qtreg, dotreg;
   float lreg = 0.f, dreg = 0.f;
   if constexpr (PIPE) {
     const int nv0 = min(64, p.Tq);
@@ -489,8 +495,8 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnArgs& p, const int 
       st_tr<CT, DK>(sdOt, dotreg, nvalid, tid);
       if constexpr (OWN_DELTA) {             // thread (u, tid) holds chunk id % NCH of row id / NCH: the row's chunks sit in NCH neighbouring lanes
 #pragma unroll
-        for (int u = 0; u < RmRegs<CT, DK>::NU; ++u) {
-          const int id = tid + 256 * u, row = id / C::NCH, c = id - row * C::NCH;
+        for (int u = 0; u < RmRegs<CT, DK, NT>::NU; ++u) {
+          const int id = tid + NT * u, row = id / C::NCH, c = id - row * C::NCH;
           float part = (c * C::CE < DK) ? chunk_dot<CT>(doreg.v[u], oreg.v[u]) : 0.f;
 #pragma unroll
           for (int sh = 1; sh < C::NCH; sh <<= 1) part += __shfl_xor(part, sh);
@@ -591,14 +597,16 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
 
 // ================================================================================================ dQ
 // wave owns 16 queries (columns); streams 64-key blocks.
-template <class CT, int DK, bool PIPE>
+template <class CT, int DK, bool PIPE, int NW = 4>     // NW waves: the workgroup owns 16 NW queries
 __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int bx, const int h, const int b, unsigned char* smem) {
   using C = ACfg<CT, DK>;
   unsigned char* sK = smem;
   unsigned char* sV = smem + C::RM_BYTES;
   unsigned char* sKt = smem + 2 * C::RM_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lg = lane >> 4;
-  const int q0 = bx * 64 + wid * 16;
+  constexpr int NT = 64 * NW;
+  static_assert(NW == 4 || PIPE, "more than four waves: aligned operands only");
+  const int q0 = bx * (16 * NW) + wid * 16;
   const bool vec = p.vec != 0;
   const float sc2 = p.scale * ExpDom<CT>::K;
   const CT* Q = reinterpret_cast<const CT*>(p.q) + b * p.q_bs + h * DK;
@@ -646,8 +654,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int bx
   for (int i = 0; i < C::DT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkb = (p.Tk + 63) / 64;
-  RmRegs<CT, DK> kreg, vreg;
-  TrRegs<CT, DK> ktreg;
+  RmRegs<CT, DK, NT> kreg, vreg;
+  TrRegs<CT, DK, NT> ktreg;
   if constexpr (PIPE) {
     const int nv0 = min(64, p.Tk);
     ld_rm<CT, DK>(kreg, K, p.k_ts, nv0, tid);
@@ -723,12 +731,15 @@ template <class CT, int DK, bool PIPE> __global__ __launch_bounds__(256) void at
 // dQ and dK/dV in ONE launch: workgroups 0 .. nqb-1 of a (head, utterance) own 64 queries each, the rest 64 keys each.  The two
 // halves share nothing but the launch -- no ordering between them (the dK/dV half forms its own delta) -- so a CU holds twice
 // the waves to hide latency behind and the step has one dependent launch less per attention (24 per step at the benchmark).
-template <class CT, int DK> __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p, int nqb) {
+// NW = 8: 128 queries / keys per workgroup -- every streamed 64-row block is staged ONCE for eight waves instead of four, which
+// halves the L2 -> LDS staging traffic of the launch (five tile images per block and workgroup; at 32 x 249 frames that traffic
+// was ~0.6 MB per CU per launch, a quarter of the launch at the CU's ingest rate)
+template <class CT, int DK, int NW> __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kernel(AttnArgs p, int nqb) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[BwdSmem<CT, DK>::BOTH];
   int bx, h, b;
-  if (!attn_block(p, nqb + (p.Tk + 63) / 64, bx, h, b)) return;
-  if (bx < nqb) attn_bwd_dq_body<CT, DK, true>(p, bx, h, b, smem);
-  else attn_bwd_dkdv_body<CT, DK, true, true>(p, bx - nqb, h, b, smem);
+  if (!attn_block(p, nqb + (p.Tk + 16 * NW - 1) / (16 * NW), bx, h, b)) return;
+  if (bx < nqb) attn_bwd_dq_body<CT, DK, true, NW>(p, bx, h, b, smem);
+  else attn_bwd_dkdv_body<CT, DK, true, true, NW>(p, bx - nqb, h, b, smem);
 }
 
 // ================================================================================================ host side
@@ -745,6 +756,7 @@ static int32_t fill_args(const otr_attn_desc_t* d, AttnArgs& a) {
   a.causal = d->causal; a.scale = d->scale;
   return 0;
 }
+extern int g_otr_attn_waves8;      // api.hip (otr_debug_set(20, v)): 8-wave workgroups (128 queries / keys) for 16-bit operands, head dim 64
 extern int g_otr_attn_xmap;        // api.hip (otr_debug_set(16, v)): XCD-aware workgroup mapping of the attention launches
 static dim3 attn_grid(AttnArgs& a, const otr_attn_desc_t* d, int nx) {
   a.xmap = g_otr_attn_xmap;
@@ -782,6 +794,10 @@ extern "C" int32_t otr_attention_fwd(const otr_attn_desc_t* d, const void* q, co
   a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse; a.key_mask = key_mask;
   a.vec = vec_ok(d, {q, k, v, o});
   hipStream_t s = (hipStream_t)stream;
+  if (g_otr_attn_waves8 && a.vec && d->dtype == OTR_H16 && d->dk == 64) {
+    hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 64, true, 8>), attn_grid(a, d, (d->Tq + 127) / 128), dim3(512), 0, s, a);
+    return otr_check_launch("attention_fwd");
+  }
   dim3 grid = attn_grid(a, d, (d->Tq + 63) / 64);
   if (d->dtype == OTR_H16) { DK_SWITCH(bf16_t, attn_fwd_kernel, grid) } else { DK_SWITCH(float, attn_fwd_kernel, grid) }
   return otr_check_launch("attention_fwd");
@@ -802,6 +818,10 @@ extern "C" int32_t otr_attention_bias_fwd(const otr_attn_desc_t* d, const void* 
   a.vec = vec_ok(d, {q, k, v, o});
   set_bias(a, bias, nullptr, bias_bs, bias_hs, bias_rs, rel_shift);
   hipStream_t s = (hipStream_t)stream;
+  if (g_otr_attn_waves8 && a.vec && d->dtype == OTR_H16 && d->dk == 64) {
+    hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 64, true, 8>), attn_grid(a, d, (d->Tq + 127) / 128), dim3(512), 0, s, a);
+    return otr_check_launch("attention_bias_fwd");
+  }
   dim3 grid = attn_grid(a, d, (d->Tq + 63) / 64);
   if (d->dtype == OTR_H16) { DK_SWITCH(bf16_t, attn_fwd_kernel, grid) } else { DK_SWITCH(float, attn_fwd_kernel, grid) }
   return otr_check_launch("attention_bias_fwd");
@@ -837,8 +857,18 @@ extern "C" int32_t otr_attention_bwd(const otr_attn_desc_t* d, const void* q, co
 }
 
 extern int g_otr_attn_bwd_split;   // api.hip (otr_debug_set(13, 1)): the two-launch form, for A/B runs
-#define ATTN_BWD_MERGED(CTYPE, DKV) \
-  hipLaunchKernelGGL((attn_bwd_kernel<CTYPE, DKV>), attn_grid(a, d, nqb + nkb), dim3(256), 0, s, a, nqb)
+template <class CT, int DK> static void attn_bwd_merged_launch(const otr_attn_desc_t* d, AttnArgs& a, hipStream_t s) {
+  if constexpr (DK == 64 && sizeof(CT) == 2) {
+    if (g_otr_attn_waves8) {
+      const int nq8 = (d->Tq + 127) / 128, nk8 = (d->Tk + 127) / 128;
+      hipLaunchKernelGGL((attn_bwd_kernel<CT, DK, 8>), attn_grid(a, d, nq8 + nk8), dim3(512), 0, s, a, nq8);
+      return;
+    }
+  }
+  const int nqb = (d->Tq + 63) / 64, nkb = (d->Tk + 63) / 64;
+  hipLaunchKernelGGL((attn_bwd_kernel<CT, DK, 4>), attn_grid(a, d, nqb + nkb), dim3(256), 0, s, a, nqb);
+}
+#define ATTN_BWD_MERGED(CTYPE, DKV) attn_bwd_merged_launch<CTYPE, DKV>(d, a, s)
 static int32_t attention_bwd_impl(const otr_attn_desc_t* d, AttnArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int nqb = (d->Tq + 63) / 64, nkb = (d->Tk + 63) / 64;
