@@ -223,6 +223,11 @@ int32_t otr_wgrad256_takes(const otr_wgrad_item_t* item, int32_t compute);
 /* the schedule the 256-wide launch would use for these items (host only; tests replay the kernel's work decoding on it):
  * out[0..7] = {mode (1 rounds / 0 stream-K), grid, chunk, full rounds, tiles left, row ranges per left tile, total slabs, n},
  * out[8 + i] = first slab of problem i; grid_cap as otr_debug_set(7, v) */
+/* host-only views of two launch geometries, for tests (no device work): the (row block, slice) of every workgroup of the split FFN
+ * kernels under mapping `map` (otr_debug_set(15, .)) -- out[2 b], out[2 b + 1], returns the grid size (out may be NULL) -- and the
+ * (block, head, utterance) of every workgroup of the XCD-aware attention grid (-1 for padding workgroups), out[3 i ..] */
+int32_t otr_debug_ffn_split_map(int64_t M, int32_t map, int32_t* out, int32_t cap);
+int32_t otr_debug_attention_grid(int32_t nx, int32_t H, int32_t B, int32_t* out, int32_t cap);
 int32_t otr_debug_wgrad256_plan(const otr_wgrad_item_t* items, int32_t n, int32_t grid_cap, int32_t* out);
 /* number of pieces of the last 256-wide launch on `workspace` that gave up waiting for their turn (bounded spin; 0 in any
  * healthy run; < 0 on error).  Synchronises the device. */

@@ -97,6 +97,8 @@ SIGNATURES = {
     'otr_ln_bwd_proj': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I32, _F32, C.c_uint64, _P],
     'otr_debug_trace': [_P],
     'otr_wgrad256_takes': [C.POINTER(WgradItem), _I32],
+    'otr_debug_ffn_split_map': [_I64, _I32, _P, _I32],
+    'otr_debug_attention_grid': [_I32, _I32, _I32, _P, _I32],
     'otr_debug_wgrad256_plan': [C.POINTER(WgradItem), _I32, _I32, _P],
     'otr_debug_wgrad256_errors': [_P],
     'otr_debug_trread': [_P, _P, _P, _P],

@@ -47,14 +47,17 @@ __device__ __forceinline__ int64_t bias_index(const AttnArgs& p, int b, int h, i
 // in which the nx blocks of one (head, utterance) get workgroup ids that are EQUAL modulo 8 -- consecutive ids go to consecutive
 // XCDs (observed placement, used for locality only), so the blocks that stream the same K / V (or Q / dO) rows meet in ONE L2
 // instead of four.  Groups past H * B (the grid is padded to whole XCD rounds) return false: the workgroup leaves.
-__device__ __forceinline__ bool attn_block(const AttnArgs& p, int nx, int& bx, int& h, int& b) {
-  if (!p.xmap) { bx = blockIdx.x; h = blockIdx.y; b = blockIdx.z; return true; }
-  const int lid = blockIdx.x, xcd = lid & 7, k = lid >> 3;
+__host__ __device__ __forceinline__ bool attn_block_of(int lid, int nx, int H, int B, int& bx, int& h, int& b) {
+  const int xcd = lid & 7, k = lid >> 3;
   bx = k % nx;
   const int g = (k / nx) * 8 + xcd;
-  if (g >= p.H * p.B) return false;
-  h = g % p.H; b = g / p.H;
+  if (g >= H * B) return false;
+  h = g % H; b = g / H;
   return true;
+}
+__device__ __forceinline__ bool attn_block(const AttnArgs& p, int nx, int& bx, int& h, int& b) {
+  if (!p.xmap) { bx = blockIdx.x; h = blockIdx.y; b = blockIdx.z; return true; }
+  return attn_block_of((int)blockIdx.x, nx, p.H, p.B, bx, h, b);
 }
 
 template <class CT, int DK> struct ACfg {
@@ -896,4 +899,18 @@ static int32_t attention_bwd_impl(const otr_attn_desc_t* d, AttnArgs& a, void* s
     DK_SWITCH(float, attn_bwd_dkdv_kernel, gk)
   }
   return otr_check_launch("attention_bwd");
+}
+
+// host-side view of the XCD-aware 1-D grid (tests): returns its size for nx blocks per (head, utterance); out[3 i ..] = (block, head,
+// utterance) of workgroup i, or (-1, -1, -1) for a padding workgroup
+extern "C" int32_t otr_debug_attention_grid(int32_t nx, int32_t H, int32_t B, int32_t* out, int32_t cap) {
+  OTR_REQUIRE(nx > 0 && H > 0 && B > 0 && cap >= 0, "debug_attention_grid: bad arguments");
+  const int32_t grid = 8 * nx * ((H * B + 7) / 8);
+  if (!out) return grid;
+  for (int i = 0; i < grid && i < cap; ++i) {
+    int bx, h, b;
+    if (!attn_block_of(i, nx, H, B, bx, h, b)) bx = h = b = -1;
+    out[3 * i] = bx; out[3 * i + 1] = h; out[3 * i + 2] = b;
+  }
+  return grid;
 }

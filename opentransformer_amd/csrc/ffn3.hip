@@ -223,7 +223,7 @@ struct Ffn3FwdArgs {
 // the row blocks alternate between them): its 32 workgroups re-read 0.75 MB of weights instead of 3 MB, which survive the store
 // stream of the saved tiles in the 4 MB L2 -- the four slices of a row block then sit on four XCDs (consecutive workgroup ids), their
 // exchange takes the write-through path (measured: no slower) and x is fetched by four L2s.
-__device__ __forceinline__ void f3_block_map(int b, int map, int& rb, int& s) {
+__host__ __device__ __forceinline__ void f3_block_map(int b, int map, int& rb, int& s) {
   const int xcd = b & 7, j = b >> 3;
   if (map) {
     s = xcd & 3;
@@ -1089,3 +1089,17 @@ int32_t ffn3_bwd_launch(const void* dy16, const void* hsave, const void* w2t_pac
 
 // 1 when the 128-row kernels take this (hidden size, split): whole 64-unit chunks per slice, biases fit their LDS staging
 int32_t ffn3_takes(int32_t F, int32_t S) { return S >= 1 && (F / 32) % S == 0 && ((F / 32) / S) % 2 == 0 && (F / 32) / S <= 32; }
+
+// host-side view of the launch geometry, for tests: grid size of the split kernels for M rows under mapping `map`, and
+// out[2 b], out[2 b + 1] = (row block, slice) of workgroup b (row blocks >= ceil(M / 128) are padding that exits at once)
+int32_t ffn3_debug_block_map(int64_t M, int32_t map, int32_t* out, int32_t cap) {
+  const int64_t blocks = (M + 127) / 128;
+  const int32_t grid = map ? (int32_t)(8 * ((blocks + 1) / 2)) : (int32_t)(8 * 4 * ((blocks + 7) / 8));
+  if (!out) return grid;
+  for (int b = 0; b < grid && b < cap; ++b) {
+    int rb, sl;
+    f3_block_map(b, map, rb, sl);
+    out[2 * b] = rb; out[2 * b + 1] = sl;
+  }
+  return grid;
+}

@@ -423,6 +423,7 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(FfnBwdArgs p) {
 // ------------------------------------------------------------------------------------------------ C ABI
 extern int g_otr_ffn2_ablate;
 int32_t ffn3_takes(int32_t F, int32_t S);                // ffn3.hip
+int32_t ffn3_debug_block_map(int64_t M, int32_t map, int32_t* out, int32_t cap);
 int64_t ffn3_scratch_bytes(int64_t M);
 int64_t ffn3_sync_ints(int64_t M);
 int64_t ffn3_hsave_bytes(int64_t M, int32_t F);
@@ -459,6 +460,10 @@ extern "C" int32_t otr_ffn_ln_fwd(const float* x, const void* x16, const void* w
   return otr_check_launch("ffn_ln_fwd");
 }
 
+extern "C" int32_t otr_debug_ffn_split_map(int64_t M, int32_t map, int32_t* out, int32_t cap) {
+  OTR_REQUIRE(M > 0 && (map == 0 || map == 1) && cap >= 0, "debug_ffn_split_map: bad arguments");
+  return ffn3_debug_block_map(M, map, out, cap);
+}
 extern "C" int64_t otr_ffn_split_scratch_bytes(int64_t M) { return M > 0 ? ffn3_scratch_bytes(M) : 0; }
 extern "C" int64_t otr_ffn_split_sync_ints(int64_t M) { return M > 0 ? ffn3_sync_ints(M) : 0; }
 

@@ -276,3 +276,43 @@ def test_conv2_dgrad_plan_and_index_arithmetic():
                         for f2 in [(f1[mm] + 1 - kw) // 2] if (f1[mm] + 1 - kw) % 2 == 0 and 0 <= f2 < F2}
                 assert got == want, (c, mm, got, want)
         assert int(cover.min()) == 1 and int(cover.max()) == 1
+
+
+def test_split_ffn_and_attention_grids_cover_every_unit_once():
+    """Host-only views of two launch geometries whose decoding happens inside the kernels: under both workgroup mappings of the
+    split FFN kernels every (row block, slice) pair is taken by exactly one workgroup, the four workgroups of a row block are
+    within 32 ids of each other (co-resident on an idle GPU) and -- mapping 1 -- an XCD (id mod 8) sees one slice only; the
+    XCD-aware attention grid gives every (block, head, utterance) exactly one workgroup and puts the blocks of a (head, utterance)
+    on ids that are equal modulo 8."""
+    import numpy as np
+    from opentransformer_amd import _lib as L
+    lib = L.load('bf16')
+    for M in (128, 2048, 7968, 8000, 100000):
+        nblk = (M + 127) // 128
+        for wg_map in (0, 1):
+            grid = lib.otr_debug_ffn_split_map(M, wg_map, None, 0)
+            out = np.zeros(2 * grid, dtype=np.int32)
+            assert lib.otr_debug_ffn_split_map(M, wg_map, out.ctypes.data_as(C.c_void_p), grid) == grid
+            rb, sl = out[0::2], out[1::2]
+            live = rb < nblk
+            pairs = sorted(zip(rb[live].tolist(), sl[live].tolist()))
+            assert pairs == [(r, s) for r in range(nblk) for s in range(4)], (M, wg_map)
+            ids = np.arange(grid)[live]
+            for r in (0, nblk // 2, nblk - 1):
+                mine = ids[rb[live] == r]
+                assert mine.max() - mine.min() < 32
+            if wg_map == 1:
+                for x in range(8):
+                    assert len(set(sl[live][ids % 8 == x].tolist())) <= 1
+    for nx, H, B in ((4, 4, 32), (8, 4, 32), (1, 4, 32), (2, 6, 5), (3, 1, 1)):
+        grid = lib.otr_debug_attention_grid(nx, H, B, None, 0)
+        out = np.zeros(3 * grid, dtype=np.int32)
+        assert lib.otr_debug_attention_grid(nx, H, B, out.ctypes.data_as(C.c_void_p), grid) == grid
+        trip = out.reshape(-1, 3)
+        live = trip[:, 0] >= 0
+        got = sorted(map(tuple, trip[live].tolist()))
+        assert got == sorted((x, h, b) for b in range(B) for h in range(H) for x in range(nx)), (nx, H, B)
+        ids = np.arange(grid)[live]
+        for h, b in ((0, 0), (H - 1, B - 1)):
+            sel = (trip[live][:, 1] == h) & (trip[live][:, 2] == b)
+            assert len(set((ids[sel] % 8).tolist())) == 1
