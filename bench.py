@@ -117,8 +117,18 @@ def cpu_baseline(args):
         if len(times) >= 5 and (best is None or med < best[1]):
             best = (threads, med)
     threads, med = best
+    ratio = None
+    try:        # the port's speed relative to the REAL reference, measured where /root/reference exists (tools/cpu_ref_vs_port.py)
+        rr = json.load(open(os.path.join(ROOT, 'profiles', 'r04_cpu_ref_vs_port.json')))
+        ratio = {'same_config_dropout_0': rr['reference_dropout_0.0']['port_over_reference'],
+                 'reference_with_yaml_dropout_0.1': rr['reference_dropout_0.1']['port_over_reference'],
+                 'judge_r03': rr['judge_r03']['port_over_reference'],
+                 'note': 'port utt/s divided by reference utt/s on the SAME cores (8 threads, B=4, build container): the port is this much '
+                         'FASTER than the reference, so the baseline above is generous to the CPU; value / ratio estimates the reference'}
+    except Exception:                                          # noqa: BLE001
+        pass
     return {'value': args.batch / med, 'unit': 'utterances/s', 'cores': threads, 'host_cores': host, 'kind': 'port',
-            'by_threads': tried,
+            'port_over_reference': ratio, 'by_threads': tried,
             'sample': 'CPU oracle (port of the reference path; the reference tree is absent on the GPU box) fwd+bwd fp32, B=%d x '
                       '%d frames, median of 5 iterations (1 warm-up) at the best of %s torch threads on a %d-core host'
                       % (args.batch, args.frames, '/'.join(str(t) for t in tried), host)}
@@ -368,6 +378,12 @@ def main():
     final_loss, final_stats = float(loss_buf.item()), opt.stats()      # state at the end of the timed region
     parts = {}
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    windows = None
+    if not args.no_extras:
+        # box-to-box and run-to-run spread is ~1.5 %: besides the contract's K steps (`value`), five more windows of K steps each,
+        # timed the same way (barrier + synchronize on both sides, max over ranks); their median is the robust figure
+        windows = [timed(step, 0, args.steps) / args.steps * 1e3 for _ in range(5)]
+        final_loss, final_stats = float(loss_buf.item()), opt.stats()
     if not args.no_extras:
         acc = [0.0, 0.0]
         for _ in range(5):
@@ -424,21 +440,30 @@ def main():
         elif st['skipped'] != 0 or not (st['grad_sqnorm'] == st['grad_sqnorm'] and st['grad_sqnorm'] < float('inf')):
             out['INVALID'] = 'non-finite gradient norm: %d optimizer updates were skipped' % int(st['skipped'])
         out['step_breakdown'] = parts
+        if windows:
+            ws_ = sorted(windows)
+            out['windows'] = {'ms_per_step': windows, 'median_ms_per_step': ws_[len(ws_) // 2],
+                              'median_value': global_batch / (ws_[len(ws_) // 2] * 1e-3), 'steps_per_window': args.steps,
+                              'note': 'five further windows of K steps, timed like the contract region; `value` is the contract region'}
         if kern:
             # HBM bytes per launch and MFMA-busy cycles from separate rocprofv3 --pmc passes of this command (tools/gpu_pmc_step.sh
             # -> profiles/r03_pmc_step.json; regenerate whenever a kernel changes: the record carries the commit it was taken at)
-            pmc_db, pmc_file = {}, os.path.join('profiles', 'r03_pmc_step.json')
-            try:
-                pmc_db = json.load(open(os.path.join(ROOT, pmc_file)))
-            except Exception:                                          # noqa: BLE001
-                pass
+            pmc_db, pmc_file = {}, None
+            for cand_file in ('r04_pmc_step.json', 'r03_pmc_step.json'):
+                try:
+                    pmc_db = json.load(open(os.path.join(ROOT, 'profiles', cand_file)))
+                    pmc_file = os.path.join('profiles', cand_file)
+                    break
+                except Exception:                                          # noqa: BLE001
+                    continue
 
             def pmc_of(name):
+                # records are keyed by kernel AND grid size (tools/pmc_summary.py): a kernel launched on several problem sizes
+                # (wgrad256_kernel: the M = B x T' group and the decoder's group) has one record each; the line of the step's
+                # dominant launch of that kernel is the one with the longest duration
                 pat = PMC_KERNEL.get(name.split(' ')[0])
-                for k, v in pmc_db.items():
-                    if pat and pat in k:
-                        return v
-                return {}
+                hits = [v for k, v in pmc_db.items() if pat and pat in k and isinstance(v, dict) and not k.startswith('_')]
+                return max(hits, key=lambda v: v.get('avg_us', 0.0)) if hits else {}
             lines = {}
             for name, a in kern.items():
                 if a['flops_per_launch'] <= 0:
@@ -479,15 +504,22 @@ def main():
                             d['ms_per_step'] = ms * d['launches_per_step']
                             d['timed'] = ('the launches of this kernel in the step, each on its own operands, re-issued back to back (>= 10) '
                                           'inside one hipGraph, events on the launch stream')
-                # the split FFN kernels trade the recompute for saved tiles: 187 / 161 flop per algorithmic byte, below the 312 flop/B
-                # ridge -> their roofline is HBM; the MFMA rate is reported next to it
-                for name in ('ffn_ln_fwd_split', 'ffn_bwd_split'):
+                # The FFN sub-layer is graded against the bound SURVEY.md 8(d) names for it: MFMA (frac = flops / launch duration /
+                # 2.5 PFLOP/s).  Its MINIMAL I/O (x, x16, y, y16, z, the packed weights once: what a recomputing backward would
+                # need) puts it at ~700 flop/B, far above the 312 flop/B ridge; the tiles it saves for the backward pass are a
+                # choice of this implementation, not algorithmic traffic.  The HBM view is kept as a secondary key.
+                for name in ('ffn_ln_fwd_split', 'ffn_bwd_split', 'ffn_ln_fwd', 'ffn_bwd'):
                     if name in lines and lines[name].get('algorithmic_bytes'):
                         d = lines[name]
-                        d.update(bound='hbm', tflops=d['achieved'], mfma_frac=d['frac'], unit='GB/s', peak=PEAK_HBM_GBS)
-                        d['achieved'] = d['algorithmic_bytes'] / (d['avg_launch_ms'] * 1e-3) / 1e9
-                        d['frac'] = d['achieved'] / PEAK_HBM_GBS
-                dom = max((k for k in lines if k != 'linear_wgrad_grouped'), key=lambda k: lines[k]['ms_per_step'])
+                        M_, F_, d_ = args.batch * ((((args.frames - 3) // 2 + 1) - 3) // 2 + 1), cfg['encoder']['d_ff'], cfg['encoder']['d_model']
+                        min_io = M_ * d_ * (4 + 2 + 4 + 2 + 4) + 6 * F_ * d_ if 'fwd' in name else M_ * d_ * (2 + 4 + 4) + 6 * F_ * d_
+                        d['hbm_view'] = {'algorithmic_bytes_minimal_io': min_io, 'bytes_incl_saved_tiles': d['algorithmic_bytes'],
+                                         'achieved_GBs_minimal_io': min_io / (d['avg_launch_ms'] * 1e-3) / 1e9,
+                                         'achieved_GBs_incl_saved_tiles': d['algorithmic_bytes'] / (d['avg_launch_ms'] * 1e-3) / 1e9,
+                                         'frac_of_hbm_peak_incl_saved_tiles': d['algorithmic_bytes'] / (d['avg_launch_ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                         'flop_per_byte_minimal_io': kern[name]['flops_per_launch'] / min_io}
+                        d['algorithmic_bytes'] = min_io
+                dom = max(lines, key=lambda k: lines[k]['ms_per_step'])     # launches x duration, every kernel a candidate
                 d = lines.pop(dom)
                 d['flops_per_launch'] = kern[dom]['flops_per_launch']
                 d['share_of_step'] = d['ms_per_step'] / (elapsed / args.steps * 1e3)
@@ -514,11 +546,18 @@ def main():
     if rank == 0:
         if bf16_line is not None:
             for mode_, slot in (('bf16', bf16_line), (args.mode, out)):
-                try:      # the measured parity of that mode at this batch (tests/test_gpu_headline.py -> profiles/)
-                    pr = json.load(open(os.path.join(ROOT, 'profiles', 'r03_parity_headline_%s.json' % mode_)))
+                for rnd in ('r04', 'r03'):      # the measured parity of that mode at this batch (tests/test_gpu_headline.py -> profiles/)
+                    try:
+                        pr = json.load(open(os.path.join(ROOT, 'profiles', '%s_parity_headline_%s.json' % (rnd, mode_))))
+                    except Exception:                                          # noqa: BLE001
+                        continue
                     slot['logits_rel_vs_oracle'] = pr.get('logits_rel')
-                except Exception:                                          # noqa: BLE001
-                    pass
+                    slot['loss_rel_vs_oracle'] = pr.get('loss_rel')
+                    # the north star's bar: logits and loss within 1e-3 relative of the reference
+                    slot['parity_bar_met'] = bool(pr.get('logits_rel') is not None and pr['logits_rel'] < 1e-3
+                                                  and (pr.get('loss_rel') is None or pr['loss_rel'] < 1e-3))
+                    slot['parity_source'] = 'profiles/%s_parity_headline_%s.json' % (rnd, mode_)
+                    break
             out['bf16'] = bf16_line
         if args.model != 'transformer':
             out['config']['workload'] = out['config']['workload'].replace('transformer_baseline.yaml (+input_size 80), 12 enc / 6 dec layers', 'conformer_baseline.yaml, 12 conformer blocks / 6 dec layers')

@@ -88,29 +88,32 @@ __device__ __forceinline__ int f3_xcc_id() {
   return v & 0xf;
 }
 struct F3Sync {
-  int* rec;
-  int gen;                 // arrivals at this launch's start (a multiple of 4)
+  uint32_t* rec;
+  uint32_t gen;            // arrivals at this launch's start (a multiple of 4).  UNSIGNED: the counter gains 4 per launch and wraps
+                           // after 2^30 launches (~30 h of training); all comparisons below are modular, so the wrap is harmless
   int xcc;
-  int ids[4];              // the slices' entries as read early (f3_sync_read_ids)
+  uint32_t ids[4];         // the slices' entries as read early (f3_sync_read_ids)
 };
-__device__ __forceinline__ int f3_agent_load(const int* p) {
-  return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+__device__ __forceinline__ uint32_t f3_agent_load(const uint32_t* p) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+// the tag a workgroup publishes next to its XCC id: this launch's number modulo 2^26 (equality tests only)
+__device__ __forceinline__ uint32_t f3_tag(uint32_t gen, int xcc) { return (((gen >> 2) & 0x3ffffffu) << 6) | (uint32_t)(xcc + 1); }
 // kernel entry: the load only (its round trip hides behind the prologue); f3_sync_publish after the prologue's first barrier
 __device__ __forceinline__ void f3_sync_begin(F3Sync& y, int* rec, int xcc) {
-  y.rec = rec; y.xcc = xcc;
-  y.gen = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  y.rec = reinterpret_cast<uint32_t*>(rec); y.xcc = xcc;
+  y.gen = __hip_atomic_load(y.rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void f3_sync_publish(F3Sync& y, int sl, int tid) {
-  y.gen = __builtin_amdgcn_readfirstlane(y.gen) & ~3;           // a late starter may see partners' arrivals of THIS launch: < 4
-  if (tid == 0) __hip_atomic_store(y.rec + 2 + sl, ((y.gen >> 2) << 6) | (y.xcc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  y.gen = (uint32_t)__builtin_amdgcn_readfirstlane((int)y.gen) & ~3u;   // a late starter may see partners' arrivals of THIS launch: < 4
+  if (tid == 0) __hip_atomic_store(y.rec + 2 + sl, f3_tag(y.gen, y.xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void f3_sync_read_ids(F3Sync& y) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) y.ids[i] = __hip_atomic_load(y.rec + 2 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool f3_same_xcd(const F3Sync& y, int entry) { return entry == (((y.gen >> 2) << 6) | (y.xcc + 1)); }
-__device__ __forceinline__ bool f3_entry_valid(const F3Sync& y, int entry) { return (entry >> 6) == (y.gen >> 2) && (entry & 63) != 0; }
+__device__ __forceinline__ bool f3_same_xcd(const F3Sync& y, uint32_t entry) { return entry == f3_tag(y.gen, y.xcc); }
+__device__ __forceinline__ bool f3_entry_valid(const F3Sync& y, uint32_t entry) { return (entry >> 6) == ((y.gen >> 2) & 0x3ffffffu) && (entry & 63u) != 0; }
 template <int AUX>
 __device__ __forceinline__ void f3_store_tile4(const f32x16 (&acc)[4], f3_rsrc_t rs, uint32_t base) {
 #pragma unroll
@@ -139,17 +142,17 @@ __device__ __forceinline__ void f3_send_partials(const f32x16 (&acc)[2][4], f3_r
               make_float4(acc[rt][ct][4 * q], acc[rt][ct][4 * q + 1], acc[rt][ct][4 * q + 2], acc[rt][ct][4 * q + 3]);
     } else {
       const uint32_t base = (uint32_t)((sl * 4 + qt) * 32768 + (4 * wc) * 4096 + lane * 16);
-      const int e = __builtin_amdgcn_readfirstlane(qt == 0 ? y.ids[0] : qt == 1 ? y.ids[1] : qt == 2 ? y.ids[2] : y.ids[3]);
+      const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qt == 0 ? y.ids[0] : qt == 1 ? y.ids[1] : qt == 2 ? y.ids[2] : y.ids[3]));
       if (f3_same_xcd(y, e)) f3_store_tile4<0>(acc[rt], rs, base); else f3_store_tile4<F3_AUX_COH>(acc[rt], rs, base);
     }
   }
 }
 // one lane: arrive, then wait for all four workgroups of the row block (bounded; a give-up bumps the fault word)
 __device__ __forceinline__ void f3_arrive_wait(const F3Sync& y, int spin_limit, int* fault) {
-  __hip_atomic_fetch_add(y.rec, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int target = y.gen + 4;
+  __hip_atomic_fetch_add(y.rec, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t target = y.gen + 4u;                            // modular: (int32_t)(counter - target) < 0 <=> not all four have arrived
   int spins = 0;
-  while (__hip_atomic_load(y.rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0 && spins < spin_limit) {
+  while ((int32_t)(__hip_atomic_load(y.rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0 && spins < spin_limit) {
     __builtin_amdgcn_s_sleep(2);
     ++spins;
   }
@@ -168,7 +171,7 @@ __device__ __forceinline__ void f3_recv_partials(otr_u32x4 (&part)[3][2][4], f3_
   for (int n = 0; n < 3; ++n) {
     const int s2 = n + (n >= sl ? 1 : 0);                        // the three other slices (wave-uniform)
     const uint32_t base = (uint32_t)((s2 * 4 + sl) * 32768 + (2 * wid) * 4096 + lane * 16);
-    int e = __builtin_amdgcn_readfirstlane(s2 == 0 ? y.ids[0] : s2 == 1 ? y.ids[1] : s2 == 2 ? y.ids[2] : y.ids[3]);
+    uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s2 == 0 ? y.ids[0] : s2 == 1 ? y.ids[1] : s2 == 2 ? y.ids[2] : y.ids[3]));
     if (!f3_entry_valid(y, e)) e = f3_agent_load(y.rec + 2 + s2);   // read too early (rare): the sender may have seen OUR id
     if (f3_same_xcd(y, e)) f3_load_tile2<16>(part[n], rs, base); else f3_load_tile2<F3_AUX_COH>(part[n], rs, base);
   }

@@ -51,7 +51,12 @@ class FlatDataParallel:
         self.param_numel = sum(p.numel() for p in params)   # true parameter count
         padded = total
         dev, dt = params[0].device, params[0].dtype
-        self.flat_grad = torch.zeros(padded, device=dev, dtype=dt)
+        # the gradient buffer carries one extra cell behind the parameters' range (its own 64-element block): the collective
+        # sums it like any gradient, and all_reduce_gradients() uses it to make the fault word GLOBAL (see there).  Optimizer
+        # and norm only ever see the first `padded` elements.
+        self._grad_store = torch.zeros(padded + ALIGN, device=dev, dtype=dt)
+        self.flat_grad = self._grad_store[:padded]
+        self._fault_cell = self._grad_store[padded:padded + 1]
         self.flat_param = torch.empty(padded, device=dev, dtype=dt) if flatten_params else None
         if flatten_params:
             self.flat_param.zero_()         # alignment gaps stay zero: their gradient is zero, Adam leaves them at zero
@@ -184,7 +189,7 @@ class FlatDataParallel:
 
     def zero_grad(self):
         self._check_grad_views(reinstall=True)      # a view dropped by set_to_none is put back; a foreign .grad raises
-        self.flat_grad.zero_()
+        self._grad_store.zero_()
         if self.flat_grad.is_cuda:
             from . import ops
             ops.discard_pending_weight_grads()      # nothing queued survives into a new step (e.g. after an exception)
@@ -236,20 +241,32 @@ class FlatDataParallel:
         work = None
         self._check_grad_views()
         if ws > 1 or force:
-            buf = self.flat_grad
+            # The sticky fault word (a bounded in-kernel wait gave up on THIS rank: its gradient sums may be wrong) is local, but
+            # the gradient it taints is about to be summed into every replica.  It rides in the cell behind the gradients
+            # through the same collective, and comes back as the sum over ranks: every rank's optimizer step then sees a
+            # non-zero word and skips together -- the replicas stay identical (a rank skipping alone would diverge for good).
+            fault = None
+            if self.flat_grad.is_cuda:
+                from . import ops
+                fault = ops.fault_counter(self.flat_grad.device)
+                self._fault_cell.copy_(fault)
+            buf = self._grad_store
             if self.grad_comm_dtype is not None:            # 16-bit payload: half the bytes over xGMI
                 if self._payload is None:
-                    self._payload = torch.empty_like(self.flat_grad, dtype=self.grad_comm_dtype)
-                self._payload.copy_(self.flat_grad)
+                    self._payload = torch.empty_like(self._grad_store, dtype=self.grad_comm_dtype)
+                self._payload.copy_(self._grad_store)
                 buf = self._payload
             if self.comm == 'rccl':
                 code = {torch.float32: L.OTR_F32, torch.bfloat16: L.OTR_BF16, torch.float16: L.OTR_F16}[buf.dtype]
                 L.check(L.load().otr_allreduce_run(self._rccl_handle(), C.c_void_p(buf.data_ptr()), buf.numel(), code,
                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'otr_allreduce_run')
             elif ws > 1:
-                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op and buf is self.flat_grad)
-            if buf is not self.flat_grad:
-                self.flat_grad.copy_(buf)
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group,
+                                       async_op=async_op and buf is self._grad_store and fault is None)
+            if buf is not self._grad_store:
+                self._grad_store.copy_(buf)
+            if fault is not None:
+                fault.copy_(self._fault_cell)               # float -> int32: the number of give-ups over all ranks
         return 1.0 / ws, work
 
 
@@ -301,6 +318,67 @@ class FusedAdam:
             C.c_void_p(torch.cuda.current_stream().cuda_stream))
         L.check(ret, 'otr_optimizer_step')
         self.dp.refresh_transposed()
+
+    # ---- checkpoint / resume (train/trainer.py:280-290 save_optimizer_state_dict, run.py:49-62 --init_optim_state) ----------
+    # The layout is torch.optim.Adam's own state_dict -- {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups':
+    # [{'lr', 'betas', 'eps', 'weight_decay', ..., 'params': [0 .. n-1]}]} with parameter i = the i-th of
+    # filter(requires_grad, model.parameters()), the order the reference builds its optimizer in (run.py:42-44) -- so an optimizer
+    # checkpoint written by the reference resumes here and the other way round.  What torch's Adam does not have (dynamic loss
+    # scale, skip / fault counters) travels under the extra key 'otr', which torch's load_state_dict ignores.
+    @property
+    def global_step(self):
+        """the reference scheduler's global_step after the updates applied so far (scheduler.py:16-53: it starts at 1, the stepwise
+        initial_lr() advances it once, every update once more -- the first update computes its lr at 3)"""
+        return int(self.state[0].item()) + 2
+
+    def state_dict(self):
+        st = self.state.tolist()
+        state = {}
+        for i, (p, off) in enumerate(zip(self.dp.params, self.dp.offsets)):
+            n = p.numel()
+            state[i] = {'step': torch.tensor(float(st[0])),
+                        'exp_avg': self.exp_avg[off:off + n].view(p.shape).clone(),
+                        'exp_avg_sq': self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+        group = {'lr': float(st[1]) if st[0] > 0 else self.lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.wd,
+                 'amsgrad': False, 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'params': list(range(len(self.dp.params)))}
+        return {'state': state, 'param_groups': [group],
+                'otr': {'state_block': self.state.detach().cpu().clone(), 'global_step': int(st[0]) + 2}}
+
+    def load_state_dict(self, sd):
+        """accepts state_dict() of this class or of the torch.optim.Adam the reference trains with; moments are copied into the flat
+        buffers, the update count (Adam's t and the Noam step) is taken from the per-parameter 'step' entries"""
+        state, groups = sd['state'], sd['param_groups']
+        order = [i for g in groups for i in g['params']]
+        if len(order) != len(self.dp.params):
+            raise ValueError('optimizer checkpoint holds %d parameters, the model has %d' % (len(order), len(self.dp.params)))
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for key, p, off in zip(order, self.dp.params, self.dp.offsets):
+            ent = state.get(key)
+            if ent is None:                 # torch leaves parameters that never received a gradient without state
+                continue
+            n = p.numel()
+            if tuple(ent['exp_avg'].shape) != tuple(p.shape):
+                raise ValueError('optimizer checkpoint: parameter %s has shape %s, the model %s'
+                                 % (key, tuple(ent['exp_avg'].shape), tuple(p.shape)))
+            self.exp_avg[off:off + n].copy_(ent['exp_avg'].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(ent['exp_avg_sq'].reshape(-1))
+            steps.add(float(ent['step']))
+        if len(steps) > 1:
+            raise ValueError('optimizer checkpoint: parameters disagree about the step count (%s); one flat update needs one' % sorted(steps))
+        t = steps.pop() if steps else 0.0
+        blk = sd.get('otr', {}).get('state_block')
+        if blk is not None:                 # loss scale, good-step count, skip / fault counters
+            self.state.copy_(blk.to(self.state.device))
+        g0 = groups[0]
+        self.betas, self.eps, self.wd = tuple(g0.get('betas', self.betas)), g0.get('eps', self.eps), g0.get('weight_decay', self.wd)
+        b1, b2 = self.betas
+        self.state[0] = t
+        self.state[1] = float(g0.get('lr', self.lr))
+        self.state[2] = 1.0 - b1 ** t
+        self.state[3] = 1.0 - b2 ** t
 
     def stats(self):
         s = self.state.tolist()

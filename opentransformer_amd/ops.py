@@ -272,6 +272,7 @@ def _workspace(device):
         _state['ws'] = ws
         fault_counter(device)           # registered before the first launch that could report through it (and before any capture)
         _zero_placeholder(device, ())   # likewise allocated outside any capture's private pool (LnOutLink)
+        _ffn_sync_pool(device)          # and the split FFN kernels' arrival counters (one row per launch stream)
     return ws
 
 
@@ -476,24 +477,37 @@ def flush_weight_grads():
 # bookkeeping.  If the receiving node never runs in that pass (its branch detached or frozen after the forward pass), the gradient
 # would be dropped without a trace: every hand-over is registered, and the engine's end-of-pass callback raises if one is left.
 _parked = []
+_parked_task = [None]      # graph-task id of the backward pass whose end-of-pass check is queued
+
+
+def _drop_handovers(links):
+    for k in links:
+        if hasattr(k, 'buf'):
+            k.buf = None
+        if hasattr(k, 'result'):
+            k.result = None
 
 
 def _park(link):
     if not _in_backward():
         return
-    if not _parked:
+    task = torch._C._current_graph_task_id()
+    if _parked_task[0] != task:
+        # first hand-over of a NEW backward pass.  Whatever is still listed belongs to a pass that raised before its callback
+        # ran (the engine drops queued callbacks then): clear those links -- their gradients are stale, and they pin tensors --
+        # and queue the check for THIS pass (keyed by the pass, not by list emptiness, so a dead pass cannot switch it off)
+        _drop_handovers(_parked)
+        del _parked[:]
+        _parked_task[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(_check_parked)
     _parked.append(link)
 
 
 def _check_parked():
+    _parked_task[0] = None
     left = [k for k in _parked if getattr(k, 'buf', None) is not None or getattr(k, 'result', None) is not None]
     del _parked[:]
-    for k in left:
-        if hasattr(k, 'buf'):
-            k.buf = None
-        if hasattr(k, 'result'):
-            k.result = None
+    _drop_handovers(left)
     if left:
         raise RuntimeError('%d gradient hand-over(s) between linked autograd nodes (%s) were never picked up: the receiving node did '
                            'not run in this backward pass; results of the pass are incomplete'
@@ -1237,13 +1251,33 @@ _FFN_SPLIT_MIN_ROWS = 2048
 _FFN_SYNC_INTS = 1 << 14
 
 
+_FFN_SYNC_STREAMS = 16
+
+
+def _ffn_sync_pool(device):
+    p = _state.get('ffn_sync_pool')
+    if p is None or p[0].device != device:
+        p = (torch.zeros((_FFN_SYNC_STREAMS, _FFN_SYNC_INTS), dtype=torch.int32, device=device), {})
+        _state['ffn_sync_pool'] = p
+    return p
+
+
 def _ffn_sync(device):
-    """arrival counters of the split FFN kernels: zero once, every launch leaves them zero (include/otrans_hip.h)"""
-    t = _state.get('ffn_sync')
-    if t is None or t.device != device:
-        t = torch.zeros(_FFN_SYNC_INTS, dtype=torch.int32, device=device)
-        _state['ffn_sync'] = t
-    return t
+    """Arrival counters of the split FFN kernels (include/otrans_hip.h): zero ONCE, then owned by the kernels -- the counters are
+    monotonic (a row block gains 4 per launch, unsigned, wrap-safe), and launches that share a buffer must be stream-ordered.  So
+    the buffer is keyed by (device, current stream): training on one stream and an eval / recognizer graph on another never mix
+    their arrivals.  The pool is allocated by _workspace() before the first launch, i.e. outside any graph capture's private pool;
+    a stream takes the next free row at its first split-FFN launch (a capture's stream included: captured launches replay in
+    capture order whatever stream replays them)."""
+    _workspace(device)
+    pool, rows = _ffn_sync_pool(device)
+    sid = torch.cuda.current_stream().cuda_stream
+    i = rows.get(sid)
+    if i is None:
+        if len(rows) >= _FFN_SYNC_STREAMS:
+            raise L.OtransHipError('opentransformer_amd: split-FFN launches from more than %d streams on one device' % _FFN_SYNC_STREAMS)
+        i = rows[sid] = len(rows)
+    return pool[i]
 
 
 def _ffn_split(M, F):
@@ -1367,7 +1401,8 @@ class FfnLnFn(torch.autograd.Function):
         gg, gb, gb2 = grad_target(gp), grad_target(bp), grad_target(b2p)
         stash = None
         if ctx.olink is not None:
-            stash, ctx.olink.result, ctx.olink.saved = ctx.olink.result, None, None
+            # `saved` stays: a second backward through a retained graph reaches the linked Linear again (ops.LinearFn.backward)
+            stash, ctx.olink.result = ctx.olink.result, None
         part, dgb = None, None
         if stash is not None and _is_zero_placeholder(dy):
             # the LayerNorm backward already ran in the epilogue of the next layer's q|k|v input-gradient launch (LnOutLink)

@@ -511,9 +511,6 @@ def dp_mean_loss_grads(sd_flat_params, loss_fn, shards):
 
 
 # --------------------------------------------------------------------------- optimizer update (trainer core)
-def noam_lr(step, model_size, warmup_steps, factor=1.0):
-    """TransformerScheduler.get_step_lr: otrans/train/scheduler.py:137-138."""
-    return factor * model_size ** (-0.5) * min(step ** (-0.5), step * warmup_steps ** (-1.5))
 
 
 class TrainerUpdate:

@@ -185,3 +185,40 @@ def test_gradient_hand_over_left_behind_is_an_error():
     assert link.buf is None and lo.result is None and not ops._parked
     ops._parked.append(done)
     ops._check_parked()                           # nothing left: no error
+
+
+def test_fused_adam_state_dict_is_torch_adams_layout():
+    """FusedAdam.state_dict / load_state_dict (train/trainer.py:280-290, run.py:49-62): the layout is torch.optim.Adam's, so an
+    optimizer checkpoint of the reference resumes here and the other way round.  Host logic only (no update is run)."""
+    from opentransformer_amd.dp import FusedAdam
+    tok, tgt = _data()
+    ref = Tiny()
+    adam = torch.optim.Adam(filter(lambda p: p.requires_grad, ref.parameters()), lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6)
+    for _ in range(3):
+        adam.zero_grad()
+        ref(tok, tgt).backward()
+        adam.step()
+    model = Tiny()
+    dp = FlatDataParallel(model)
+    opt = FusedAdam(dp, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6)
+    opt.load_state_dict(adam.state_dict())                       # the reference's checkpoint -> flat buffers
+    assert float(opt.state[0]) == 3.0 and opt.global_step == 5   # scheduler.py: global_step starts at 1, +1 at build, +1 per update
+    assert abs(float(opt.state[2]) - (1 - 0.9 ** 3)) < 1e-6 and abs(float(opt.state[3]) - (1 - 0.98 ** 3)) < 1e-6
+    ref_params = [p for p in ref.parameters()]
+    for p, q, off in zip(dp.params, ref_params, dp.offsets):
+        st = adam.state[q]
+        assert torch.equal(opt.exp_avg[off:off + p.numel()].view(p.shape), st['exp_avg'])
+        assert torch.equal(opt.exp_avg_sq[off:off + p.numel()].view(p.shape), st['exp_avg_sq'])
+    sd = opt.state_dict()
+    adam2 = torch.optim.Adam(filter(lambda p: p.requires_grad, Tiny().parameters()), lr=1.0)
+    adam2.load_state_dict(sd)                                    # and back: torch accepts it as its own
+    for (k, a), (_, b) in zip(sorted(adam.state_dict()['state'].items()), sorted(adam2.state_dict()['state'].items())):
+        assert float(a['step']) == float(b['step']) and torch.equal(a['exp_avg'], b['exp_avg']) and torch.equal(a['exp_avg_sq'], b['exp_avg_sq'])
+    assert adam2.param_groups[0]['betas'] == (0.9, 0.98) and adam2.param_groups[0]['weight_decay'] == 1e-6
+    opt2 = FusedAdam(FlatDataParallel(Tiny()), lr=1e-3)
+    opt2.load_state_dict(sd)                                     # own round trip incl. the extra state block
+    assert torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.state, opt.state)
+    with pytest.raises(ValueError):
+        bad = adam.state_dict()
+        bad['param_groups'][0]['params'] = bad['param_groups'][0]['params'][:-1]
+        opt2.load_state_dict(bad)

@@ -89,6 +89,57 @@ def test_two_ranks_one_gpu_real_model_matches_oracle(tmp_path, mode):
     assert got['stats']['skipped'] == 0 and got['moved'] > 0 and got['shadow_ok']
 
 
+def _fault_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+    torch.cuda.set_device(0)
+    ops.set_compute_dtype('fp16')
+    cfg = syn.c1_model(0.0, ctc_weight=0.3)
+    model = ota.SpeechToText(cfg)
+    syn.fill_state_dict_(model.state_dict(), 77)
+    model = model.to('cuda').train()
+    dp = FlatDataParallel(model, grad_comm_dtype=(torch.bfloat16 if rank >= 0 and os.environ.get('OTR_TEST_PAYLOAD') == 'bf16' else None))
+    dp.broadcast_parameters(0)
+    opt = FusedAdam(dp, lr=1e-3, loss_scale=1024.0)
+    inputs, targets = syn.synthetic_batch(**BATCH)
+    sh = slice(rank * 2, rank * 2 + 2)
+    res = []
+    for step in range(2):
+        dp.zero_grad()
+        loss, _ = dp({k: v[sh].cuda() for k, v in inputs.items()}, {k: v[sh].cuda() for k, v in targets.items()})
+        loss.backward()
+        if step == 0 and rank == 1:
+            ops.fault_counter(torch.device('cuda', 0)).add_(3)     # rank 1 only: a bounded wait of its backward pass gave up
+        before = dp.flat_param.clone()
+        scale, _ = dp.all_reduce_gradients()
+        opt.step(scale)
+        torch.cuda.synchronize()
+        res.append({'moved': float((dp.flat_param - before).abs().max()), 'stats': opt.stats(),
+                    'word': int(ops.fault_counter(torch.device('cuda', 0)).item())})
+    torch.save({'res': res, 'param': dp.flat_param.cpu()}, out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('payload', ['fp32', 'bf16'])
+def test_fault_on_one_rank_skips_the_update_on_every_rank(tmp_path, payload, monkeypatch):
+    """ADVICE r03 (dp.py:276): the sticky fault word is local to a rank, but the gradient it taints is summed into every replica.
+    It now rides through the same collective: BOTH ranks skip the update of that step (parameters unchanged, same counters) and
+    apply the next one -- the replicas stay identical."""
+    monkeypatch.setenv('OTR_TEST_PAYLOAD', payload)
+    out = str(tmp_path / 'r%d.pt')
+    mp.spawn(_fault_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out % 0, weights_only=False), torch.load(out % 1, weights_only=False)
+    for r in (r0, r1):
+        first, second = r['res']
+        assert first['moved'] == 0.0 and first['stats']['skipped'] == 1 and first['stats']['faults'] == 3 and first['word'] == 0
+        assert second['moved'] > 0 and second['stats']['skipped'] == 1 and second['stats']['step'] == 1
+    assert torch.equal(r0['param'], r1['param'])
+
+
 def test_library_owned_rccl_communicator_world_one():
     """otr_allreduce_unique_id / init / run / destroy on a single-rank communicator: sum over one rank = identity, issued on
     the compute stream, for the fp32 buffer and for a bf16 payload"""

@@ -294,3 +294,69 @@ def test_c5_full_size_decode_matches_oracle_beam_search(mode):
                     assert all(ref_map[tuple(h)] > v - 2 * tol for v in later), (mode, b, n)
     finally:
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'fp16'])
+def test_c5_full_size_decode_with_live_eos(mode):
+    """the full-size C5 search with EOS LIVE -- beams finish at different steps (hypothesis lengths 0 .. 60 in one
+    n-best list), so mask_finished_scores / mask_finished_preds (recognize/speech2text.py:156-192), the all-finished early exit
+    (:117-118) and the length penalty over ragged lengths (:128-131) run at V = 4234 with LM fusion, B = 8 ragged utterances,
+    beam 10, max_len 60, against orc.beam_search.  The EOS logit gets +4 (random weights otherwise never emit it)."""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops
+    from opentransformer_amd.recognize import SpeechToTextRecognizer, TransformerLanguageModel
+    from oracle import otrans_oracle as orc
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cfg = syn.c2_model(0.0)
+    lm_cfg = syn.lm_config(4234, num_blocks=4)
+    beam, max_len, B = 10, 60, 8
+    parts = H.filled_state(cfg, seed=7)
+    parts['decoder']['output_layer.bias'][1] = 4.0
+    inputs, _ = syn.synthetic_batch(batch=B, frames=1000, feat_dim=80, vocab=4234, tgt_len=5, seed=3,
+                                    lengths=[1000, 873, 640, 999, 512, 931, 777, 404])
+    ops.set_compute_dtype(mode)
+    try:
+        model = ota.SpeechToText(cfg)
+        for name, sd in (('frontend', model.frontend), ('encoder', model.encoder), ('decoder', model.decoder)):
+            sd.load_state_dict(parts[name], strict=True)
+        lm = TransformerLanguageModel(lm_cfg)
+        syn.fill_state_dict_(lm.state_dict(), 8)
+        lm_sd = {k: v.detach().clone() for k, v in lm.state_dict().items()}
+        model, lm = model.to(DEV).eval(), lm.to(DEV).eval()
+        ref_h, ref_s = orc.beam_search(parts, cfg, inputs['inputs'], inputs['mask'], beam=beam, max_len=max_len, penalty=0.6,
+                                       lamda=5, nbest=beam, lm=(lm_sd, lm_cfg), lm_weight=0.1)
+        lens = sorted({len(h) for utt in ref_h for h in utt})
+        assert len(lens) >= 5 and lens[0] < 3 and lens[-1] >= 20, lens       # the case does what it is for: ragged finishing steps
+        ref_s = ref_s.numpy()
+        report = {'mode': mode, 'lengths': lens}
+        for cache in (True, False) if mode == 'fp32' else (True,):
+            rec = SpeechToTextRecognizer(model, apply_cache=cache, beam_width=beam, nbest=beam, max_len=max_len, penalty=0.6, lamda=5,
+                                         lm=lm, lm_weight=0.1, idx2unit={i: str(i) for i in range(4234)})
+            got_h, got_s = rec.recognize(inputs['inputs'].to(DEV), inputs['mask'].to(DEV))
+            got_tok = [[[int(t) for t in s.split()] for s in utt] for utt in got_h]
+            got_s = got_s.numpy()
+            if mode == 'fp32':
+                assert got_tok == ref_h, cache
+                np.testing.assert_allclose(got_s, ref_s, rtol=2e-4, atol=2e-4)
+                continue
+            tol = 0.03                                       # score drift of 16-bit operands over up to 60 steps (measured below)
+            drift, shared = 0.0, []
+            for b in range(B):
+                ref_map = {tuple(h): float(ref_s[b, n]) for n, h in enumerate(ref_h[b])}
+                assert got_tok[b][0] == ref_h[b][0] or ref_s[b, 0] - ref_s[b, 1] < 2 * tol, (b, got_tok[b][0], ref_h[b][0])
+                n_sh = 0
+                for n, h in enumerate(got_tok[b]):
+                    if tuple(h) in ref_map:
+                        n_sh += 1
+                        drift = max(drift, abs(float(got_s[b, n]) - ref_map[tuple(h)]))
+                shared.append(n_sh)
+            report.update(worst_score_drift=drift, nbest_shared=shared,
+                          nbest_identical=[got_tok[b] == ref_h[b] for b in range(B)])
+            assert drift < tol, report
+            assert min(shared) >= 6, report                 # rounding may flip near-ties deep in the list, not reshuffle it
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'decode_eos_live_%s.json' % mode), 'w') as f:
+            json.dump(report, f, indent=1)
+        print(json.dumps(report))
+    finally:
+        ops.set_compute_dtype('bf16')

@@ -1,0 +1,240 @@
+"""GPU (-m gpu): round-4 robustness items (ADVICE r03 + VERDICT r03 item 8).
+
+* the split-FFN arrival counters are modular: a run whose sync record starts just below 2^31 / 2^32 gives the same results;
+* each launch stream has its own arrival counters;
+* a second backward through a retained graph works across the LnOutLink;
+* a backward pass that dies does not switch off the hand-over check of later passes;
+* FusedAdam.state_dict / load_state_dict resume a run bit for bit, and a torch.optim.Adam checkpoint continues identically."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _ffn_params(d, dff, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    return [t.to(DEV).requires_grad_(True) for t in (r(2 * dff, d) / math.sqrt(d), 0.1 * r(2 * dff), r(d, dff) / math.sqrt(dff),
+                                                      0.1 * r(d), 1 + 0.1 * r(d), 0.1 * r(d))]
+
+
+def _ffn_run(ops, xv, gy, params, n=1):
+    outs = None
+    for _ in range(n):
+        x = xv.clone().requires_grad_(True)
+        y = ops.ffn_add_layernorm(ops.attach_lp(x, x.detach().to(ops.act_dtype())), *params, 0.0, 1e-5)
+        grads = torch.autograd.grad(y, (x, params[0], params[2]), gy)
+        outs = (y.detach(),) + tuple(t.detach() for t in grads)
+    return outs
+
+
+@pytest.mark.parametrize('seed_value', [0x7FFFFFF8, 0xFFFFFFF8])
+def test_split_ffn_counters_survive_the_wrap(seed_value):
+    """ADVICE r03 (csrc/ffn3.hip:150): the monotonic arrival counters gain 4 per launch; signed arithmetic crossed INT_MAX after
+    2^29 launches (~30 h of training).  They are unsigned / modular now: pre-seed every sync record 8 below the wrap, run four
+    launches (two forward + two backward) across it, and compare with a run on zeroed counters."""
+    from opentransformer_amd import ops
+    ops.set_compute_dtype('fp16')
+    try:
+        d, dff, M = 256, 512, 2048 + 40
+        params = _ffn_params(d, dff, 21)
+        g = torch.Generator().manual_seed(22)
+        xv, gy = torch.randn(M, d, generator=g).to(DEV), torch.randn(M, d, generator=g).to(DEV)
+        dev = torch.device(DEV, torch.cuda.current_device())
+        sync = ops._ffn_sync(dev)
+        sync.zero_()
+        want = _ffn_run(ops, xv, gy, params, n=2)
+        torch.cuda.synchronize()
+        sync.zero_()
+        sv = seed_value - (1 << 32) if seed_value >= (1 << 31) else seed_value
+        sync.view(-1, 8)[:, 0] = sv
+        got = _ffn_run(ops, xv, gy, params, n=2)
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+        assert int(ops.fault_counter(dev).item()) == 0
+        rec = sync.view(-1, 8)
+        used = rec[:(M + 127) // 128, 0].to(torch.int64) & 0xFFFFFFFF
+        assert bool((used == ((seed_value + 16) & 0xFFFFFFFF)).all())          # four launches x four arrivals, across the wrap
+    finally:
+        ops._ffn_sync(torch.device(DEV, torch.cuda.current_device())).zero_()
+        ops.set_compute_dtype('bf16')
+
+
+def test_split_ffn_counters_are_per_stream():
+    from opentransformer_amd import ops
+    ops.set_compute_dtype('fp16')
+    try:
+        dev = torch.device(DEV, torch.cuda.current_device())
+        a = ops._ffn_sync(dev)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            b = ops._ffn_sync(dev)
+            b2 = ops._ffn_sync(dev)
+        assert a.data_ptr() != b.data_ptr() and b.data_ptr() == b2.data_ptr() and ops._ffn_sync(dev).data_ptr() == a.data_ptr()
+        # both streams run the split kernels at the same time on their own counters and agree
+        params = _ffn_params(256, 512, 5)
+        g = torch.Generator().manual_seed(6)
+        xv, gy = torch.randn(2304, 256, generator=g).to(DEV), torch.randn(2304, 256, generator=g).to(DEV)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            r1 = _ffn_run(ops, xv, gy, params, n=3)
+        r0 = _ffn_run(ops, xv, gy, params, n=3)
+        torch.cuda.synchronize()
+        for x0, x1 in zip(r0, r1):
+            assert torch.equal(x0, x1)
+        assert int(ops.fault_counter(dev).item()) == 0
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
+def test_second_backward_through_a_retained_graph():
+    """ADVICE r03 (ops.py:1370): FfnLnFn.backward dropped the LnOutLink's saved tensors after the first pass; a second backward
+    through the retained graph (two losses sharing the encoder) then crashed in the linked Linear."""
+    import opentransformer_amd.nn as onn
+    from opentransformer_amd import ops
+    ops.set_compute_dtype('fp16')
+    try:
+        torch.manual_seed(3)
+        enc = torch.nn.ModuleList([onn.TransformerEncoderLayer(4, 256, 2048, 0.0, 0.0, 0.0, activation='glu') for _ in range(2)]).to(DEV)
+        B, T = 8, 160
+        x = torch.randn(B, T, 256, device=DEV)
+        mask = torch.ones(B, 1, T, dtype=torch.uint8, device=DEV)
+        ps = list(enc.parameters())
+        h = ops.attach_lp(x.clone().requires_grad_(True), x.to(ops.act_dtype()))
+        for l in enc:
+            h, _ = l(h, mask)
+        gy = torch.randn_like(h)
+        g1 = torch.autograd.grad(h, ps, gy, retain_graph=True)
+        g2 = torch.autograd.grad(h, ps, gy)
+        for a, b in zip(g1, g2):
+            assert torch.equal(a, b)
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
+def test_handover_check_survives_a_failed_pass():
+    """ADVICE r03 (ops.py:481): a backward pass that raises leaves parked links behind and its engine callback never runs; the
+    next pass must clear them and queue its own check."""
+    from opentransformer_amd import ops
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError('boom')
+
+    class ParkFn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, link):
+            ctx.link = link
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            ctx.link.buf = g
+            ops._park(ctx.link)
+            return g, None
+
+    link = ops.ResidualLink()
+    x = torch.randn(4, device=DEV, requires_grad=True)
+    with pytest.raises(RuntimeError, match='boom'):
+        ParkFn.apply(Boom.apply(x), link).sum().backward()      # parks, then Boom raises: the callback of this pass is dropped
+    assert len(ops._parked) == 1 and link.buf is not None
+    link2 = ops.ResidualLink()
+    with pytest.raises(RuntimeError, match='never picked up'):
+        ParkFn.apply(x, link2).sum().backward()                  # a fresh pass: stale entries cleared, its own check still fires
+    assert link.buf is None and link2.buf is None and not ops._parked
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'fp16'])
+def test_fused_adam_resume_is_bit_exact(mode):
+    """FusedAdam.state_dict / load_state_dict (train/trainer.py:280-290): 3 updates, checkpoint, 2 more == fresh objects loaded
+    from the checkpoint + the same 2 updates (parameters, moments, loss scale, step, lr)."""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops, synthetic as syn
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+    ops.set_compute_dtype(mode)
+    try:
+        cfg = syn.c1_model(0.1, ctc_weight=0.3)
+        inputs, targets = syn.synthetic_batch(batch=4, frames=160, feat_dim=80, vocab=100, tgt_len=8, seed=3)
+        inputs = {k: v.to(DEV) for k, v in inputs.items()}
+        targets = {k: v.to(DEV) for k, v in targets.items()}
+
+        def make():
+            m = ota.SpeechToText(cfg)
+            syn.fill_state_dict_(m.state_dict(), 5)
+            m = m.to(DEV).train()
+            dp = FlatDataParallel(m)
+            return m, dp, FusedAdam(dp, lr=1e-3, noam=dict(model_size=64, warmup_steps=10, factor=1.0))
+
+        def steps(dp, opt, k, first):
+            for i in range(k):
+                ops._state['seed'] = None
+                ops.rng_seed_tensor(DEV).fill_(1000 + first + i)       # the dropout stream is part of the run's state
+                ops._state['rng_offset'] = 0
+                dp.zero_grad()
+                loss, _ = dp(inputs, targets)
+                loss.backward()
+                opt.step(dp.all_reduce_gradients()[0])
+        m, dp, opt = make()
+        steps(dp, opt, 3, 0)
+        ck_model = {k: v.clone() for k, v in m.state_dict().items()}
+        ck_opt = opt.state_dict()
+        steps(dp, opt, 2, 3)
+        torch.cuda.synchronize()
+        m2, dp2, opt2 = make()
+        m2.load_state_dict(ck_model)
+        dp2.refresh_lp()
+        opt2.load_state_dict(ck_opt)
+        steps(dp2, opt2, 2, 3)
+        torch.cuda.synchronize()
+        assert torch.equal(dp.flat_param, dp2.flat_param) and torch.equal(opt.exp_avg, opt2.exp_avg)
+        assert torch.equal(opt.exp_avg_sq, opt2.exp_avg_sq) and torch.equal(opt.state, opt2.state)
+        assert opt2.global_step == 7
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
+def test_torch_adam_checkpoint_continues_identically():
+    """an optimizer checkpoint of the reference (torch.optim.Adam.state_dict()) loaded into FusedAdam: the next update equals
+    torch's next update on the same gradient (no clipping, constant lr, L2 weight decay)"""
+    from opentransformer_amd import ops
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+    ops.set_compute_dtype('fp32')
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.Linear(96, 32)).to(DEV)
+    ref = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.Linear(96, 32)).to(DEV)
+    ref.load_state_dict(net.state_dict())
+    adam = torch.optim.Adam(ref.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6)
+    gs = [[torch.randn_like(p) for p in ref.parameters()] for _ in range(3)]
+    for g in gs[:2]:
+        for p, gi in zip(ref.parameters(), g):
+            p.grad = gi.clone()
+        adam.step()
+    net.load_state_dict(ref.state_dict())
+    dp = FlatDataParallel(net)
+    opt = FusedAdam(dp, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6, clip_grad=0.0)
+    opt.load_state_dict(adam.state_dict())
+    for p, gi in zip(ref.parameters(), gs[2]):
+        p.grad = gi.clone()
+    adam.step()
+    dp.zero_grad()
+    for p, gi in zip(net.parameters(), gs[2]):
+        p.grad.copy_(gi)
+    opt.step(1.0)
+    torch.cuda.synchronize()
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert rel(p.detach(), q.detach()) < 1e-6
+    ops.set_compute_dtype('bf16')
