@@ -54,6 +54,20 @@ class ConvDesc(C.Structure):
                 ('act_dtype', C.c_int32), ('compute', C.c_int32), ('w_dtype', C.c_int32)]
 
 
+class DecLn(C.Structure):                   # otr_dec_ln_t
+    _fields_ = [('xres', C.c_void_p), ('x16', C.c_void_p), ('slabs', C.c_void_p), ('nslab', C.c_int32),
+                ('bias', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('seed', C.c_void_p),
+                ('p_drop', C.c_float), ('eps', C.c_float), ('rng_offset', C.c_uint64),
+                ('y', C.c_void_p), ('y16', C.c_void_p), ('z', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p)]
+
+
+class DecLnB(C.Structure):                  # otr_dec_lnb_t
+    _fields_ = [('dskip', C.c_void_p), ('slabs', C.c_void_p), ('nslab', C.c_int32),
+                ('z', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('gamma', C.c_void_p), ('seed', C.c_void_p),
+                ('p_drop', C.c_float), ('rng_offset', C.c_uint64),
+                ('dz', C.c_void_p), ('da16', C.c_void_p), ('partial', C.c_void_p)]
+
+
 _P = C.c_void_p
 _I32, _I64, _F32 = C.c_int32, C.c_int64, C.c_float
 
@@ -128,6 +142,14 @@ SIGNATURES = {
     'otr_label_smoothing_loss': [_P, _P, _I64, _I32, _F32, _I32, _P, _P, _P, _P],
     'otr_log_softmax': [_P, _P, _I64, _I32, _P],
     'otr_ctc_loss': [_P, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    'otr_dec_self_fwd': [C.POINTER(DecLn), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
+    'otr_dec_cross_fwd': [C.POINTER(DecLn), _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P],
+    'otr_dec_ffn_fwd': [C.POINTER(DecLn), _I64, _P, _P, _P, _I32, _I32, _P, _P],
+    'otr_dec_ln': [C.POINTER(DecLn), _I64, _P],
+    'otr_dec_ffn_bwd': [C.POINTER(DecLnB), _I64, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P],
+    'otr_dec_cross_bwd': [C.POINTER(DecLnB), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _I32, _P, _P, _P],
+    'otr_dec_self_bwd': [C.POINTER(DecLnB), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
+    'otr_dec_sum': [_P, _P, _I32, _I64, _P, _P],
     'otr_optimizer_step': [_P, _P, _P, _P, _I64, _P, _P] + [_F32] * 12 + [_P],
     'otr_allreduce_unique_id': [_P],
     'otr_allreduce_init': [C.POINTER(C.c_void_p), _P, _I32, _I32],

@@ -22,7 +22,12 @@ struct OptState {
   float faults;          // [10] total give-ups of spin-bounded kernels (otr_set_fault_counter) seen by the updates so far: each
                          //      such update was skipped like a non-finite one -- its gradients may be wrong sums
   float reserved[5];
+  float norm_part[512];  // [16 .. 527] scratch: per-workgroup sums of squares of the gradient, summed by the tick kernel in a FIXED
+                         //      order -- every rank of a data-parallel job then derives bit-identical clip factors from its
+                         //      (bit-identical, all-reduced) gradients; an atomic sum over 512 workgroups differed in the last
+                         //      bits from rank to rank and let the replicas drift apart
 };
+constexpr int OPT_NORM_WG = 512;
 
 __global__ void sqnorm_kernel(const float* g, int64_t n, OptState* st) {
   __shared__ float sh[4];
@@ -46,13 +51,19 @@ __global__ void sqnorm_kernel(const float* g, int64_t n, OptState* st) {
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&st->sqnorm, sh[0] + sh[1] + sh[2] + sh[3]);
+  if (threadIdx.x == 0) st->norm_part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
 // one thread: NaN guard + dynamic loss scale, then advance the step counter and evaluate the schedule (Noam if
 // warmup > 0, else constant lr)
 __global__ void opt_tick_kernel(OptState* st, float base_lr, float model_size, float warmup, float factor,
-                                float step_offset, float beta1, float beta2, float grad_scale, int32_t* fault) {
+                                float step_offset, float beta1, float beta2, float grad_scale, int32_t* fault, int nparts) {
+  // one wave: the partial sums in a fixed order (lane l takes parts l, l + 64, ...; then the butterfly)
+  float part = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 64) part += st->norm_part[i];
+  part = wave_sum(part);
+  if (threadIdx.x != 0) return;
+  st->sqnorm = part;
   const float ls = st->loss_scale > 0.f ? st->loss_scale : 1.f;
   const float us = grad_scale / ls;
   st->unscale = us;
@@ -133,13 +144,12 @@ extern "C" int32_t otr_optimizer_step(float* param, const float* grad, float* ex
   OTR_REQUIRE((uintptr_t)grad % 16 == 0, "optimizer_step: grad buffer must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   OptState* st = reinterpret_cast<OptState*>(state);
-  otr_zero_f32(&st->sqnorm, 1, s);
-  // 512 workgroups: each ends with one atomic on the same word (2048 of them cost ~20 us of the kernel's 40)
-  unsigned grid = (unsigned)((n / 4 + 255) / 256 > 512 ? 512 : (n / 4 + 255) / 256);
+  // <= 512 workgroups, each leaves ONE partial sum in the state block (no atomics: the sum order is fixed, see OptState)
+  unsigned grid = (unsigned)((n / 4 + 255) / 256 > OPT_NORM_WG ? OPT_NORM_WG : (n / 4 + 255) / 256);
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(256), 0, s, grad, n, st);
-  hipLaunchKernelGGL(opt_tick_kernel, dim3(1), dim3(1), 0, s, st, base_lr, noam_model_size, noam_warmup, noam_factor,
-                     noam_step_offset, beta1, beta2, grad_scale, g_otr_fault);
+  hipLaunchKernelGGL(opt_tick_kernel, dim3(1), dim3(64), 0, s, st, base_lr, noam_model_size, noam_warmup, noam_factor,
+                     noam_step_offset, beta1, beta2, grad_scale, g_otr_fault, (int)grid);
   unsigned g2 = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
   hipLaunchKernelGGL(adam_kernel, dim3(g2), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, st, (bf16_t*)param_bf16, beta1, beta2, eps,
                      weight_decay, clip_norm, grad_noise_std);

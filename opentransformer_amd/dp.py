@@ -286,7 +286,9 @@ class FusedAdam:
         self.noam = noam
         self.exp_avg = torch.zeros_like(dp.flat_param)
         self.exp_avg_sq = torch.zeros_like(dp.flat_param)
-        self.state = torch.zeros(16, dtype=torch.float32, device=dp.flat_param.device)
+        # include/otrans_hip.h: f32[OTR_OPT_STATE_FLOATS]; [0..15] is the state proper, the rest the norm kernel's scratch
+        self._state_store = torch.zeros(528, dtype=torch.float32, device=dp.flat_param.device)
+        self.state = self._state_store[:16]
         self.grad_noise = float(grad_noise)
         if dp.flat_param.is_cuda:
             from . import ops

@@ -605,14 +605,19 @@ class TransformerDecoder(nn.Module):
         x = ops.embed_posenc(targets, self.embedding.weight)
         mm = memory_mask.to(torch.uint8).unsqueeze(1)
         kv = None
-        if (len(self.blocks) > 1 and memory.is_cuda and torch.is_grad_enabled()
-                and not any(b.src_attn.share_vk_proj for b in self.blocks)):
+        if (len(self.blocks) > 1 and memory.is_cuda and not any(b.src_attn.share_vk_proj for b in self.blocks)):
             # keys / values of every layer from ONE GEMM over the shared memory (ops.CrossKVAllFn)
             shared = ops.CrossKVShared(len(self.blocks))
             wb = [t for b in self.blocks for t in (b.src_attn.vk_proj.weight, b.src_attn.vk_proj.bias)]
             kv = (ops.CrossKVAllFn.apply(memory, shared, *wb), shared)
-        for i, block in enumerate(self.blocks):
-            x, _ = block(x, None, memory, mm, kv_all=(kv[0], i, kv[1]) if kv is not None else None)   # None -> causal self-attention
+        S = ops.decoder_stack_applies(x, memory, self.blocks, self.normalize_before) if kv is not None else 0
+        if S and all(b.residual_dropout == self.blocks[0].residual_dropout and b.norm1.eps == self.blocks[0].norm1.eps
+                     and b.norm2.eps == b.norm1.eps and b.norm3.eps == b.norm1.eps for b in self.blocks):
+            # the whole stack as three launches per layer (csrc/declayer.hip): cut along (utterance group, head) / (rows, hidden slice)
+            x = ops.decoder_stack(x, kv[0], ops._mask_u8(memory_mask, memory.size(0), memory.size(1)), self.blocks, S)
+        else:
+            for i, block in enumerate(self.blocks):
+                x, _ = block(x, None, memory, mm, kv_all=(kv[0], i, kv[1]) if kv is not None else None)   # None -> causal self-attention
         if self.normalize_before:
             x = _norm(self.after_norm, x)
         logits = ops.linear(x, self.output_layer.weight, self.output_layer.bias)

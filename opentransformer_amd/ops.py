@@ -1521,6 +1521,206 @@ _FUSED_GLU_BWD = os.environ.get('OTR_NO_FUSED_GLU_BWD', '0') != '1'     # A/B sw
 _FUSED_GLU_FWD = os.environ.get('OTR_NO_FUSED_GLU_FWD', '0') != '1'
 
 
+# ---------------------------------------------------------------------------------------- fused decoder stack
+# The post-norm Transformer decoder on few rows (B x L = 480 at the AISHELL batch; decoder/transformer.py:47-90,161-183) as three
+# launches per layer and direction, cut along (utterance group, head) / (row block, hidden slice) instead of along operators
+# (csrc/declayer.hip).  A sub-layer leaves PARTIAL sums ("slabs") and the next launch finishes the LayerNorm in its prologue.
+_DEC_FUSED = os.environ.get('OTR_NO_FUSED_DECODER', '0') != '1'
+_DEC_FFN_SLICES = int(os.environ.get('OTR_DEC_FFN_SLICES', '8'))
+DEC_LAYER_PARAMS = 18      # qvk w,b | out w,b | norm1 w,b | q w,b | out w,b | norm2 w,b | w_1 w,b | w_2 w,b | norm3 w,b
+
+
+def dec_ffn_slices(F):
+    """hidden slices of the fused decoder's FFN launches: the largest S <= OTR_DEC_FFN_SLICES with F % (128 S) == 0 (0: none)"""
+    for s in range(min(_DEC_FFN_SLICES, 64), 0, -1):
+        if F % (128 * s) == 0:
+            return s
+    return 0
+
+
+def _dec_ln(xres=None, x16=None, slabs=None, nslab=0, bias=None, gamma=None, beta=None, seed=None, p_drop=0.0, eps=1e-5, off=0,
+            y=None, y16=None, z=None, mean=None, rstd=None):
+    pv = lambda t: t.data_ptr() if t is not None else None
+    return L.DecLn(pv(xres), pv(x16), pv(slabs), nslab, pv(bias), pv(gamma), pv(beta), pv(seed), p_drop, eps, off,
+                   pv(y), pv(y16), pv(z), pv(mean), pv(rstd))
+
+
+def _dec_lnb(dskip, slabs, nslab, saved, gamma, seed, p_drop, dz, da16, partial):
+    z, mean, rstd, off = saved
+    pv = lambda t: t.data_ptr() if t is not None else None
+    return L.DecLnB(pv(dskip), pv(slabs), nslab, pv(z), pv(mean), pv(rstd), pv(gamma), pv(seed), p_drop, off, pv(dz), pv(da16), pv(partial))
+
+
+def _grad_w(dy2, x2, w):
+    gt = grad_target(w)
+    r = linear_wgrad_raw(dy2, x2, None, out=gt)
+    return None if gt is not None else r
+
+
+def _grad_b(a2, b):
+    gt = grad_target(b)
+    r = colsum_raw(a2, out=gt)
+    return None if gt is not None else r
+
+
+class DecoderStackFn(torch.autograd.Function):
+    """TransformerDecoder.forward between the embedding and the output layer (decoder/transformer.py:172-176): n post-norm layers of
+    [causal self-attention, cross-attention over the encoder memory, GLU feed-forward], each closed by dropout + residual + LayerNorm.
+    x0 [B,L,256] f32 with its 16-bit twin; kv_all [B,T,n*512] 16-bit = every layer's keys | values of the memory (CrossKVAllFn)."""
+
+    @staticmethod
+    def forward(ctx, x0, kv_all, kmask, n_layers, p_drop, eps, S, *params):
+        _cuda(x0, kv_all)
+        ctx.set_materialize_grads(False)
+        lib = L.load()
+        B, Lq, d = x0.shape
+        R, H = B * Lq, 4
+        T, W = kv_all.shape[1], kv_all.shape[2]
+        dev, hdt = x0.device, half_dtype()
+        assert d == 256 and kv_all.is_contiguous() and kv_all.dtype == hdt and W == n_layers * 512 and len(params) == DEC_LAYER_PARAMS * n_layers
+        xres, x16 = x0.reshape(R, d).contiguous(), lp_of(x0).reshape(R, d).contiguous()
+        seed = rng_seed_tensor(dev) if p_drop > 0 else None
+        f32 = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        h16 = lambda *sh: torch.empty(sh, dtype=hdt, device=dev)
+        slA, slB, slC = f32(4, R, d), f32(4, R, d), f32(S, R, d)
+        st = _stream()
+
+        def ln_out(xres_, slabs, nslab, bias, gamma, beta):
+            """descriptor + outputs of one LayerNorm finished in a prologue"""
+            y, y16, z, mean, rstd = f32(R, d), h16(R, d), f32(R, d), f32(R), f32(R)
+            off = _next_rng_offset(R * d) if p_drop > 0 else 0
+            desc = _dec_ln(xres_, None, slabs, nslab, bias, gamma, beta, seed, p_drop, eps, off, y, y16, z, mean, rstd)
+            return desc, y, y16, (z, mean, rstd, off)
+
+        layers, packs_all = [], []
+        y_in, y_in16, pending = xres, x16, None          # pending = (slabs, nslab, bias, gamma, beta) of the FFN sub-layer below
+        F = params[12].shape[0] // 2
+        for l in range(n_layers):
+            (wqkv, bqkv, wo, bo, g1, be1, wq, bq, wo2, bo2, g2, be2, w1, b1, w2, b2, g3, be3) = params[DEC_LAYER_PARAMS * l:DEC_LAYER_PARAMS * (l + 1)]
+            pk = (lin_packs(wqkv), lin_packs(wo), lin_packs(wq), lin_packs(wo2), ffn_packs(w1, w2))
+            packs_all.append(pk)
+            rec = {}
+            if pending is None:
+                lnA, y0, y016 = _dec_ln(None, x16, None, 0), xres, x16
+            else:
+                lnA, y0, y016, rec_prev = ln_out(y_in, *pending)
+                layers[-1]['ln3'] = rec_prev
+            qkv16, ctx1, lse1 = h16(R, 3 * d), h16(R, d), f32(B, H, Lq)
+            L.check(lib.otr_dec_self_fwd(C.byref(lnA), B, Lq, _p(pk[0][0]), _p(bqkv), _p(pk[1][0]), _p(qkv16), _p(ctx1), _p(lse1), _p(slA), st),
+                    'otr_dec_self_fwd')
+            lnB, y1, y116, rec['ln1'] = ln_out(y0, slA, 4, bo, g1, be1)
+            q16, ctx2, lse2 = h16(R, d), h16(R, d), f32(B, H, Lq)
+            L.check(lib.otr_dec_cross_fwd(C.byref(lnB), B, Lq, _p(pk[2][0]), _p(bq), _p(pk[3][0]), _p(kv_all), T * W, W, l * 512, l * 512 + 256,
+                                          _p(kmask), T, _p(q16), _p(ctx2), _p(lse2), _p(slB), st), 'otr_dec_cross_fwd')
+            lnC, y2, y216, rec['ln2'] = ln_out(y1, slB, 4, bo2, g2, be2)
+            L.check(lib.otr_dec_ffn_fwd(C.byref(lnC), R, _p(pk[4][0]), _p(b1), _p(pk[4][1]), F, S, _p(slC), st), 'otr_dec_ffn_fwd')
+            rec.update(y016=y016, qkv16=qkv16, ctx1=ctx1, lse1=lse1, y116=y116, q16=q16, ctx2=ctx2, lse2=lse2, y216=y216)
+            layers.append(rec)
+            y_in, pending = y2, (slC, S, b2, g3, be3)
+        lnF, y3, y316, rec_last = ln_out(y_in, *pending)
+        layers[-1]['ln3'] = rec_last
+        L.check(lib.otr_dec_ln(C.byref(lnF), R, st), 'otr_dec_ln')
+        ctx.layers, ctx.packs, ctx.params = layers, packs_all, params
+        ctx.cfg = (B, Lq, d, T, W, n_layers, p_drop, S, F, seed)
+        ctx.kv, ctx.kmask = kv_all, kmask
+        y3, y316 = y3.view(B, Lq, d), y316.view(B, Lq, d)
+        ctx.mark_non_differentiable(y316)
+        return y3, y316
+
+    @staticmethod
+    def backward(ctx, dy, _dy16=None):
+        n_in = 7
+        if dy is None:
+            return (None,) * (n_in + len(ctx.params))
+        lib = L.load()
+        B, Lq, d, T, W, n_layers, p_drop, S, F, seed = ctx.cfg
+        R, G = B * Lq, 32 // Lq
+        ngrp, nblk = (B + G - 1) // G, (R + 31) // 32
+        dev, hdt = dy.device, half_dtype()
+        f32 = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        h16 = lambda *sh: torch.empty(sh, dtype=hdt, device=dev)
+        kv_all, kmask = ctx.kv, ctx.kmask
+        dkv = torch.empty_like(kv_all) if ctx.needs_input_grad[1] else None
+        st = _stream()
+        dskip, slabs, nslab = dy.reshape(R, d).contiguous().float(), None, 0
+        grads = [None] * len(ctx.params)
+        for l in reversed(range(n_layers)):
+            (wqkv, bqkv, wo, bo, g1, be1, wq, bq, wo2, bo2, g2, be2, w1, b1, w2, b2, g3, be3) = ctx.params[DEC_LAYER_PARAMS * l:DEC_LAYER_PARAMS * (l + 1)]
+            pk, rec, o = ctx.packs[l], ctx.layers[l], DEC_LAYER_PARAMS * l
+            # ---- FFN sub-layer
+            dz3, da3, part3 = f32(R, d), h16(R, d), f32(nblk, 3 * d)
+            dh, u, bpart, slCb = h16(R, 2 * F), h16(R, F), f32(nblk, 2 * F), f32(S, R, d)
+            lnb = _dec_lnb(dskip, slabs, nslab, rec['ln3'], g3, seed, p_drop, dz3, da3, part3)
+            P1, _, P3, P4 = pk[4]
+            L.check(lib.otr_dec_ffn_bwd(C.byref(lnb), R, _p(rec['y216']), _p(P1), _p(b1), _p(P3), _p(P4), F, S, _p(dh), _p(u), _p(bpart),
+                                        _p(slCb), st), 'otr_dec_ffn_bwd')
+            grads[o + 16], grads[o + 17], grads[o + 15] = _grad_b(part3[:, :d], g3), _grad_b(part3[:, d:2 * d], be3), _grad_b(part3[:, 2 * d:], b2)
+            grads[o + 12], grads[o + 13], grads[o + 14] = _grad_w(dh, rec['y216'], w1), _grad_b(bpart, b1), _grad_w(da3, u, w2)
+            # ---- cross-attention sub-layer
+            dz2, da2, part2, dq16, slBb = f32(R, d), h16(R, d), f32(ngrp, 3 * d), h16(R, d), f32(4, R, d)
+            if dkv is None:
+                dkv = torch.empty_like(kv_all)
+            lnb = _dec_lnb(dz3, slCb, S, rec['ln2'], g2, seed, p_drop, dz2, da2, part2)
+            L.check(lib.otr_dec_cross_bwd(C.byref(lnb), B, Lq, _p(pk[3][1]), _p(pk[2][1]), _p(rec['q16']), _p(rec['ctx2']), _p(rec['lse2']),
+                                          _p(kv_all), _p(dkv), T * W, W, l * 512, l * 512 + 256, _p(kmask), T, _p(dq16), _p(slBb), st),
+                    'otr_dec_cross_bwd')
+            grads[o + 10], grads[o + 11], grads[o + 9] = _grad_b(part2[:, :d], g2), _grad_b(part2[:, d:2 * d], be2), _grad_b(part2[:, 2 * d:], bo2)
+            grads[o + 8], grads[o + 6], grads[o + 7] = _grad_w(da2, rec['ctx2'], wo2), _grad_w(dq16, rec['y116'], wq), _grad_b(dq16, bq)
+            # ---- self-attention sub-layer
+            dz1, da1, part1, dqkv16, slAb = f32(R, d), h16(R, d), f32(ngrp, 3 * d), h16(R, 3 * d), f32(4, R, d)
+            lnb = _dec_lnb(dz2, slBb, 4, rec['ln1'], g1, seed, p_drop, dz1, da1, part1)
+            L.check(lib.otr_dec_self_bwd(C.byref(lnb), B, Lq, _p(pk[1][1]), _p(pk[0][1]), _p(rec['qkv16']), _p(rec['ctx1']), _p(rec['lse1']),
+                                         _p(dqkv16), _p(slAb), st), 'otr_dec_self_bwd')
+            grads[o + 4], grads[o + 5], grads[o + 3] = _grad_b(part1[:, :d], g1), _grad_b(part1[:, d:2 * d], be1), _grad_b(part1[:, 2 * d:], bo)
+            grads[o + 2], grads[o + 0], grads[o + 1] = _grad_w(da1, rec['ctx1'], wo), _grad_w(dqkv16, rec['y016'], wqkv), _grad_b(dqkv16, bqkv)
+            dskip, slabs, nslab = dz1, slAb, 4
+        dx0 = None
+        if ctx.needs_input_grad[0]:
+            dx0 = f32(R, d)
+            L.check(lib.otr_dec_sum(_p(dskip), _p(slabs), nslab, R, _p(dx0), st), 'otr_dec_sum')
+            dx0 = dx0.view(B, Lq, d)
+        return (dx0, dkv if ctx.needs_input_grad[1] else None, None, None, None, None, None, *grads)
+
+
+def decoder_stack_applies(x0, memory, blocks, normalize_before):
+    """S (the FFN launches' hidden slices) when the fused decoder stack can run this forward pass, else 0"""
+    if not _DEC_FUSED or not is_half() or not x0.is_cuda or normalize_before or lp_of(x0) is None or x0.dim() != 3:
+        return 0
+    B, Lq, d = x0.shape
+    if d != 256 or Lq > 32 or Lq < 1 or len(blocks) < 1:
+        return 0
+    F = None
+    for b in blocks:
+        sa, ca, ff = b.slf_attn, b.src_attn, b.feed_forward
+        if (b.concat_after or b.normalize_before or sa.nheads != 4 or ca.nheads != 4 or sa.share_qvk_proj or ca.share_vk_proj
+                or ff.activation != 'glu' or (b.training and (sa.dropout_rate or ca.dropout_rate or ff.dropout))):
+            return 0
+        if ff.w_1.bias is None or ff.w_2.bias is None or tuple(ff.w_2.weight.shape) != (256, ff.w_1.weight.shape[0] // 2):
+            return 0
+        if F is None:
+            F = ff.w_2.weight.shape[1]
+        if ff.w_2.weight.shape[1] != F or tuple(ca.vk_proj.weight.shape) != (512, memory.shape[-1]):
+            return 0
+        for w in (sa.qvk_proj.weight, sa.output_proj.weight, ca.q_proj.weight, ca.output_proj.weight):
+            if lin_packs(w) is None:
+                return 0
+        if ffn_packs(ff.w_1.weight, ff.w_2.weight) is None:
+            return 0
+    return dec_ffn_slices(F)
+
+
+def decoder_stack(x0, kv_all, kmask_u8, blocks, S):
+    p = blocks[0].residual_dropout if blocks[0].training else 0.0
+    params = []
+    for b in blocks:
+        sa, ca, ff = b.slf_attn, b.src_attn, b.feed_forward
+        params += [sa.qvk_proj.weight, sa.qvk_proj.bias, sa.output_proj.weight, sa.output_proj.bias, b.norm1.weight, b.norm1.bias,
+                   ca.q_proj.weight, ca.q_proj.bias, ca.output_proj.weight, ca.output_proj.bias, b.norm2.weight, b.norm2.bias,
+                   ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias, b.norm3.weight, b.norm3.bias]
+    y, y16 = DecoderStackFn.apply(x0, kv_all, kmask_u8, len(blocks), float(p), float(blocks[0].norm1.eps), S, *params)
+    return attach_lp(y, y16)
+
+
 # ---------------------------------------------------------------------------------------- positional encoding
 class PosEncFn(torch.autograd.Function):
     """x*sqrt(d) + PE (module/pos.py:44-57, scale_learnable=False)."""
