@@ -533,29 +533,33 @@ int32_t otr_beam_prune_cached(const float* k_score, const int64_t* k_idx, const 
 /* ---- fused decoder layer for few rows (decoder/transformer.py:47-90 TransformerDecoderLayer.forward, post-norm, and :161-183
  *      the stack around it; module/attention.py:60-84,120-145; module/ffn.py:38-41 'glu'), csrc/declayer.hip.  d_model 256, 4 heads
  *      of 64, 16-bit operands, L <= 32 decoder rows per utterance.  Three launches per layer, cut along (utterance group, head) /
- *      (32-row block, hidden slice); a sub-layer leaves PARTIAL sums of its branch in `slabs` f32 [n][R][256] (R = B * L rows) and the
+ *      (32-row block, hidden slice); a sub-layer leaves PARTIAL sums of its branch in `slabs` 16-BIT [n][R][256] (R = B * L rows) and the
  *      next launch finishes  y = LayerNorm(xres + dropout(sum_n slabs[n] + bias))  in its prologue -- described by otr_dec_ln_t --
  *      writing y / y16 / z / mean / rstd (each may be NULL) once per row.  nslab == 0: nothing to finish, the rows are taken from x16.
  *      Weight packs are otr_pack_frags packs with perm 0, rows = outputs (the forward packs of otr_rb_linear / otr_ffn_ln_fwd).
  * otr_dec_self_fwd:  q|k|v of every head (qkv16 [R,768], columns q | k | v), causal self-attention inside each utterance (ctx16 [R,256],
- *      lse f32 [B,4,L]), slabs [4][R][256] = per-head shares of ctx . W_o^T (no bias).
+ *      lse f32 [B,4,L]), slabs [4][R][256] = per-head shares of ctx . W_o^T (no bias), 16-bit.
  * otr_dec_cross_fwd: q (q16 [R,256]) against the utterance's encoder keys / values, element (b, t, c) at kv[b*kv_bs + t*kv_ts + c], keys
  *      from column koff, values from voff (head h adds 64 h); key_mask uint8 [B,Tk] or NULL; ctx16, lse, slabs as above.
- * otr_dec_ffn_fwd:   slabs [S][R][256] = w_2 glu(w_1 y + b_1) over 1/S of the hidden units each (no b_2); F % (128 S) == 0.
+ * otr_dec_ffn_fwd:   slabs [S][R][256] = w_2 glu(w_1 y + b_1) over 1/S of the hidden units each (no b_2); F % (128 S) == 0.  hsave
+ *      (may be NULL; otr_dec_ffn_hsave_bytes(R, F) bytes, opaque) receives (value + bias, sigmoid(gate)) of every hidden unit for
+ *      otr_dec_ffn_bwd.  Every slab is 16-bit (the shares are rounded once and added up in fp32 by the consumer): the prologues are
+ *      bound by what a CU can ingest, and the slabs were most of it.
  * otr_dec_ln:        the LayerNorm alone (closes the last layer). */
 typedef struct {
-  const float* xres; const void* x16; const float* slabs; int32_t nslab;
+  const float* xres; const void* x16; const void* slabs; int32_t nslab;
   const float* bias; const float* gamma; const float* beta; const uint64_t* seed;
   float p_drop, eps; uint64_t rng_offset;
   float* y; void* y16; float* z; float* mean; float* rstd;
 } otr_dec_ln_t;
 int32_t otr_dec_self_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t L, const void* wqkv_pack, const float* bqkv, const void* wo_pack,
-                         void* qkv16, void* ctx16, float* lse, float* slabs, void* stream);
+                         void* qkv16, void* ctx16, float* lse, void* slabs, void* stream);
 int32_t otr_dec_cross_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t L, const void* wq_pack, const float* bq, const void* wo_pack,
                           const void* kv, int64_t kv_bs, int64_t kv_ts, int32_t koff, int32_t voff, const uint8_t* key_mask, int32_t Tk,
-                          void* q16, void* ctx16, float* lse, float* slabs, void* stream);
+                          void* q16, void* ctx16, float* lse, void* slabs, void* stream);
+int64_t otr_dec_ffn_hsave_bytes(int64_t R, int32_t F);
 int32_t otr_dec_ffn_fwd(const otr_dec_ln_t* ln, int64_t R, const void* w1_pack, const float* b1, const void* w2_pack, int32_t F, int32_t S,
-                        float* slabs, void* stream);
+                        void* slabs, void* hsave, void* stream);
 int32_t otr_dec_ln(const otr_dec_ln_t* ln, int64_t R, void* stream);
 /* Backward, the same cut mirrored (csrc/declayer.hip).  The gradient of a sub-layer's LayerNorm output arrives as dskip f32 [R,256]
  * (may be NULL) plus nslab partial slabs; every launch finishes it and runs that LayerNorm's backward in its prologue
@@ -563,27 +567,28 @@ int32_t otr_dec_ln(const otr_dec_ln_t* ln, int64_t R, void* stream);
  * the skip part for the launch below), da16 (the dropout-masked branch gradient: weight-gradient operand of output_proj / w_2) and
  * partial f32 [row blocks][3][256] = per-block sums of dgamma | dbeta | d branch-bias (column-sum them; a row block is a group for the
  * attention launches (ceil(B / (32 / L)) of them), 32 rows for the FFN launch).
- * otr_dec_ffn_bwd:   hidden recomputed from x16 (the FFN input, 16-bit); dh [R,2F], u [R,F] (weight-gradient operands), db1_part
- *      [ceil(R/32)][2F] (column-sum for the w_1 bias gradient), slabs [S][R][256] = shares of dh . w_1.  Packs as otr_ffn_bwd.
+ * otr_dec_ffn_bwd:   the hidden comes from hsave (otr_dec_ffn_fwd); dh [R,2F], u [R,F] (weight-gradient operands), db1_part
+ *      [ceil(R/32)][2F] (column-sum for the w_1 bias gradient), slabs 16-BIT [S][R][256] = shares of dh . w_1.  Packs as otr_ffn_bwd.
+ *      (all slabs 16-bit, as in the forward launches)
  * otr_dec_cross_bwd: wo / wq input-gradient packs (otr_pack_frags of W as A[k][n]); q16, ctx16, lse as the forward left them; dkv has kv's
  *      geometry and receives d keys / d values of this layer's columns (every (utterance, key) once); dq16 [R,256]; slabs [4][R][256] =
  *      per-head shares of dq . W_q.
  * otr_dec_self_bwd:  dqkv16 [R,768]; slabs [4][R][256] = per-head shares of dqkv . W_qkv.
  * otr_dec_sum:       out = skip + sum of slabs (the gradient that leaves the stack). */
 typedef struct {
-  const float* dskip; const float* slabs; int32_t nslab;
+  const float* dskip; const void* slabs; int32_t nslab;
   const float* z; const float* mean; const float* rstd; const float* gamma; const uint64_t* seed;
   float p_drop; uint64_t rng_offset;
   float* dz; void* da16; float* partial;
 } otr_dec_lnb_t;
-int32_t otr_dec_ffn_bwd(const otr_dec_lnb_t* ln, int64_t R, const void* x16, const void* w1_pack, const float* b1, const void* w2t_pack,
-                        const void* w1t_pack, int32_t F, int32_t S, void* dh, void* u, float* db1_part, float* slabs, void* stream);
+int32_t otr_dec_ffn_bwd(const otr_dec_lnb_t* ln, int64_t R, const void* hsave, const void* w2t_pack, const void* w1t_pack, int32_t F,
+                        int32_t S, void* dh, void* u, float* db1_part, void* slabs, void* stream);
 int32_t otr_dec_cross_bwd(const otr_dec_lnb_t* ln, int32_t B, int32_t L, const void* wo_dgrad_pack, const void* wq_dgrad_pack, const void* q16,
                           const void* ctx16, const float* lse, const void* kv, void* dkv, int64_t kv_bs, int64_t kv_ts, int32_t koff,
-                          int32_t voff, const uint8_t* key_mask, int32_t Tk, void* dq16, float* slabs, void* stream);
+                          int32_t voff, const uint8_t* key_mask, int32_t Tk, void* dq16, void* slabs, void* stream);
 int32_t otr_dec_self_bwd(const otr_dec_lnb_t* ln, int32_t B, int32_t L, const void* wo_dgrad_pack, const void* wqkv_dgrad_pack,
-                         const void* qkv16, const void* ctx16, const float* lse, void* dqkv16, float* slabs, void* stream);
-int32_t otr_dec_sum(const float* skip, const float* slabs, int32_t nslab, int64_t R, float* out, void* stream);
+                         const void* qkv16, const void* ctx16, const float* lse, void* dqkv16, void* slabs, void* stream);
+int32_t otr_dec_sum(const float* skip, const void* slabs, int32_t nslab, int64_t R, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -144,9 +144,10 @@ SIGNATURES = {
     'otr_ctc_loss': [_P, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     'otr_dec_self_fwd': [C.POINTER(DecLn), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_dec_cross_fwd': [C.POINTER(DecLn), _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P],
-    'otr_dec_ffn_fwd': [C.POINTER(DecLn), _I64, _P, _P, _P, _I32, _I32, _P, _P],
+    'otr_dec_ffn_hsave_bytes': [_I64, _I32],
+    'otr_dec_ffn_fwd': [C.POINTER(DecLn), _I64, _P, _P, _P, _I32, _I32, _P, _P, _P],
     'otr_dec_ln': [C.POINTER(DecLn), _I64, _P],
-    'otr_dec_ffn_bwd': [C.POINTER(DecLnB), _I64, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P],
+    'otr_dec_ffn_bwd': [C.POINTER(DecLnB), _I64, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P],
     'otr_dec_cross_bwd': [C.POINTER(DecLnB), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _I32, _P, _P, _P],
     'otr_dec_self_bwd': [C.POINTER(DecLnB), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_dec_sum': [_P, _P, _I32, _I64, _P, _P],
@@ -173,7 +174,7 @@ SIGNATURES = {
     'otr_bn_swish_bwd_partial_rows': [_I64],
     'otr_bn_swish_bwd': [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
 }
-_RESTYPE = {'otr_last_error_string': C.c_char_p, 'otr_ffn_split_scratch_bytes': C.c_int64, 'otr_ffn_split_sync_ints': C.c_int64, 'otr_ffn_split_hsave_bytes': C.c_int64,
+_RESTYPE = {'otr_last_error_string': C.c_char_p, 'otr_dec_ffn_hsave_bytes': C.c_int64, 'otr_ffn_split_scratch_bytes': C.c_int64, 'otr_ffn_split_sync_ints': C.c_int64, 'otr_ffn_split_hsave_bytes': C.c_int64,
             'otr_ffn_split_padded_rows': C.c_int64, 'otr_add_layernorm_bwd_partial_rows': C.c_int64,
             'otr_ln_bwd_proj_partial_rows': C.c_int64}
 

@@ -24,6 +24,8 @@
 // z / mean / rstd for the backward pass.  Weights are the fragment-major packs the row-block kernels use (otr_pack_frags):
 // a head's columns are whole 32-row tiles of the q|k|v pack, and its share of the output projection is 4 of the 16 contraction
 // steps of that pack.  d_model = 256, 4 heads of 64, 16-bit operands.
+#include <type_traits>
+
 #include "ffn_frag.h"
 
 namespace {
@@ -33,11 +35,14 @@ constexpr int DL_YS = DL_D * 2 + 16;      // bytes per row of the [32][256] 16-b
 constexpr int DL_HS = DL_DK * 2 + 16;     // bytes per row of a [32][64] 16-bit head image (q, k, context)
 constexpr int DL_VT = DL_RB * 2 + 8;      // bytes per row of a transposed [64][32] value image
 constexpr int DL_RS = DL_D + 4;           // floats per row of the fp32 output staging tile
+// tuning hook (otr_debug_trace): thread 0 of every workgroup stamps the shader clock into trace[16384 + (kernel id * 256 + workgroup) * 16 + k]
+// (the first 16384 entries are the GEMM kernels' region of the same buffer)
+#define DL_STAMP(KID, K) do { if (p.trace && threadIdx.x == 0) p.trace[16384 + ((KID) * 256 + (int)blockIdx.x) * 16 + (K)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 struct DlLn {              // the LayerNorm a launch finishes in its prologue: y = LN(xres + dropout(sum_s slabs[s] + bias))
   const float* xres;       // [R, 256] residual input
   const uint16_t* x16;     // nslab == 0: there is nothing to finish, the rows pass through (their 16-bit twin is given)
-  const float* slabs;      // [nslab][R][256] partial sums of the branch
+  const void* slabs;       // [nslab][R][256] partial sums of the branch: fp32 (attention head shares) or 16-bit (FFN slices), fixed per launch type
   int nslab;
   const float* bias; const float* gamma; const float* beta; const uint64_t* seed;
   float p_drop, eps;
@@ -50,104 +55,145 @@ __device__ __forceinline__ uint4 dl_frag(const unsigned char* img, int stride, i
   return *reinterpret_cast<const uint4*>(img + m * stride + (2 * ks + hi) * 16);
 }
 
-// rows row0 .. row0 + 31 (clamped to nrows): finish the LayerNorm, leave the 16-bit rows in `img` ([32][DL_YS bytes]); wave w owns
-// rows RPW w .., lane 4 consecutive columns.  The rows of a wave are normalised together (independent butterflies).
-template <int NW>
-__device__ __forceinline__ void dl_prologue(const DlLn& p, int64_t row0, int nrows, bool write, unsigned char* img, int tid) {
-  constexpr int RPW = DL_RB / NW, D = DL_D;
-  const int lane = tid & 63, wid = tid >> 6, col = lane * 4;
-  if (p.nslab == 0) {
-    for (int i = tid; i < DL_RB * 32; i += NW * 64) {
-      const int r = i >> 5, ch = i & 31;
-      const int64_t row = row0 + min(r, nrows - 1);
-      *reinterpret_cast<uint4*>(img + r * DL_YS + ch * 16) = ld_global_b128(p.x16 + row * D + ch * 8);
-    }
-    return;
-  }
-  const bool drop = p.p_drop > 0.f;
-  const uint64_t seed = drop ? *p.seed : 0;
-  const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
-  const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
-  float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + col);
-  const float4 gm = *reinterpret_cast<const float4*>(p.gamma + col);
-  const float4 bt = *reinterpret_cast<const float4*>(p.beta + col);
+// The LayerNorm prologue of a forward launch, in two steps.  issue() starts EVERY global load it needs (the residual rows and all
+// slabs of the workgroup's 32 rows) before the caller starts its prefetches (weights, keys / values): vmcnt retires in order, and
+// with the prefetches issued first the LayerNorm waited for ~200 KiB it did not need (7-10 us of a 17-21 us launch, clock stamps).
+// finish() normalises and leaves the 16-bit rows in `img` ([32][DL_YS bytes]); wave w owns rows RPW w .., lane 4 consecutive columns;
+// the rows of a wave are normalised together (independent butterflies).  H16: the slabs are 16-bit (the FFN launches' partial sums:
+// up to 8 of them in flight), else fp32 (the attention launches' four head shares).
+template <int NW, bool H16> struct DlPro {
+  static constexpr int RPW = DL_RB / NW, NS = H16 ? 8 : 4, D = DL_D, PT = DL_RB * 32 / (NW * 64);
+  typedef typename std::conditional<H16, uint2, float4>::type slab_t;
   int64_t rows[RPW];
   float4 xr[RPW];
-  float a[RPW][4];
+  slab_t t[NS][RPW];
+  uint4 px[PT];
+  float4 bb, gm, bt;
+  uint64_t seed;
+  __device__ __forceinline__ void issue(const DlLn& p, int64_t row0, int nrows, int tid) {
+    const int lane = tid & 63, wid = tid >> 6, col = lane * 4;
+    // EVERY load of the prologue goes out here, the small ones included: one issued later queues behind the caller's prefetches
+    bb = make_float4(0.f, 0.f, 0.f, 0.f);
+    seed = 0;
+    if (p.nslab != 0) {
+      if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + col);
+      gm = *reinterpret_cast<const float4*>(p.gamma + col);
+      bt = *reinterpret_cast<const float4*>(p.beta + col);
+      if (p.p_drop > 0.f) seed = *p.seed;
+    }
+    if (p.nslab == 0) {
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    rows[i] = row0 + min(wid * RPW + i, nrows - 1);
-    xr[i] = *reinterpret_cast<const float4*>(p.xres + rows[i] * D + col);
-    a[i][0] = bb.x; a[i][1] = bb.y; a[i][2] = bb.z; a[i][3] = bb.w;
-  }
-  for (int s0 = 0; s0 < p.nslab; s0 += 4) {            // four slabs in flight per pass
-    float4 t[4][RPW];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int ss = min(s0 + s, p.nslab - 1);
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) t[s][i] = *reinterpret_cast<const float4*>(p.slabs + ((int64_t)ss * p.R + rows[i]) * D + col);
+      for (int k = 0; k < PT; ++k) {
+        const int i = tid + k * NW * 64, r = i >> 5, ch = i & 31;
+        px[k] = ld_global_b128(p.x16 + (row0 + min(r, nrows - 1)) * D + ch * 8);
+      }
+      return;
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float live = s0 + s < p.nslab ? 1.f : 0.f;
+    for (int i = 0; i < RPW; ++i) {
+      rows[i] = row0 + min(wid * RPW + i, nrows - 1);
+      xr[i] = *reinterpret_cast<const float4*>(p.xres + rows[i] * D + col);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int ss = min(s, p.nslab - 1);
 #pragma unroll
       for (int i = 0; i < RPW; ++i) {
-        a[i][0] += live * t[s][i].x; a[i][1] += live * t[s][i].y; a[i][2] += live * t[s][i].z; a[i][3] += live * t[s][i].w;
+        if constexpr (H16) t[s][i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.slabs) + ((int64_t)ss * p.R + rows[i]) * D + col);
+        else t[s][i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.slabs) + ((int64_t)ss * p.R + rows[i]) * D + col);
       }
     }
   }
-  float v[RPW][4], sm[RPW], qq[RPW];
+  __device__ __forceinline__ void finish(const DlLn& p, int nrows, bool write, unsigned char* img, int tid) {
+    const int lane = tid & 63, wid = tid >> 6, col = lane * 4;
+    if (p.nslab == 0) {
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const float xv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
-    sm[i] = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float sc = 1.f;
-      if (drop) sc = otr_rand32(seed, p.rng_offset + (uint64_t)(rows[i] * D + col + e)) >= thr ? inv_keep : 0.f;
-      v[i][e] = xv[e] + a[i][e] * sc;
-      sm[i] += v[i][e];
+      for (int k = 0; k < PT; ++k) {
+        const int i = tid + k * NW * 64, r = i >> 5, ch = i & 31;
+        *reinterpret_cast<uint4*>(img + r * DL_YS + ch * 16) = px[k];
+      }
+      return;
     }
-  }
+    const bool drop = p.p_drop > 0.f;
+    const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
+    const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+    float a[RPW][4];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
+    for (int i = 0; i < RPW; ++i) { a[i][0] = bb.x; a[i][1] = bb.y; a[i][2] = bb.z; a[i][3] = bb.w; }
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) sm[i] += __shfl_xor(sm[i], o);
+    for (int s = 0; s < NS; ++s) {
+      const float live = s < p.nslab ? 1.f : 0.f;
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    sm[i] *= (1.f / D);
-    qq[i] = 0.f;
+      for (int i = 0; i < RPW; ++i) {
+        if constexpr (H16) {
+          a[i][0] += live * h2f_lo(t[s][i].x); a[i][1] += live * h2f_hi(t[s][i].x); a[i][2] += live * h2f_lo(t[s][i].y); a[i][3] += live * h2f_hi(t[s][i].y);
+        } else {
+          a[i][0] += live * t[s][i].x; a[i][1] += live * t[s][i].y; a[i][2] += live * t[s][i].z; a[i][3] += live * t[s][i].w;
+        }
+      }
+    }
+    for (int s = NS; s < p.nslab; ++s)                   // more slabs than fit in flight (not the shipped shapes): one after the other
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const float d = v[i][e] - sm[i]; qq[i] += d * d; }
-  }
+      for (int i = 0; i < RPW; ++i) {
+        if constexpr (H16) {
+          const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.slabs) + ((int64_t)s * p.R + rows[i]) * D + col);
+          a[i][0] += h2f_lo(q.x); a[i][1] += h2f_hi(q.x); a[i][2] += h2f_lo(q.y); a[i][3] += h2f_hi(q.y);
+        } else {
+          const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.slabs) + ((int64_t)s * p.R + rows[i]) * D + col);
+          a[i][0] += q.x; a[i][1] += q.y; a[i][2] += q.z; a[i][3] += q.w;
+        }
+      }
+    float v[RPW][4], sm[RPW], qq[RPW];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
+    for (int i = 0; i < RPW; ++i) {
+      const float xv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+      sm[i] = 0.f;
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) qq[i] += __shfl_xor(qq[i], o);
-  const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
+      for (int e = 0; e < 4; ++e) {
+        float sc = 1.f;
+        if (drop) sc = otr_rand32(seed, p.rng_offset + (uint64_t)(rows[i] * D + col + e)) >= thr ? inv_keep : 0.f;
+        v[i][e] = xv[e] + a[i][e] * sc;
+        sm[i] += v[i][e];
+      }
+    }
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int r = wid * RPW + i;
-    const float mean = sm[i], rstd = rsqrtf(qq[i] * (1.f / D) + p.eps);
-    float o[4];
+    for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
-    const uint2 h = make_uint2(pack2h(o[0], o[1]), pack2h(o[2], o[3]));
-    if (img) *reinterpret_cast<uint2*>(img + r * DL_YS + col * 2) = h;
-    if (write && r < nrows) {
-      const int64_t row = rows[i];
-      if (p.z) *reinterpret_cast<float4*>(p.z + row * D + col) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
-      if (p.y) *reinterpret_cast<float4*>(p.y + row * D + col) = make_float4(o[0], o[1], o[2], o[3]);
-      if (p.y16) *reinterpret_cast<uint2*>(p.y16 + row * D + col) = h;
-      if (lane == 0) {
-        if (p.mean) p.mean[row] = mean;
-        if (p.rstd) p.rstd[row] = rstd;
+      for (int i = 0; i < RPW; ++i) sm[i] += __shfl_xor(sm[i], o);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      sm[i] *= (1.f / D);
+      qq[i] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - sm[i]; qq[i] += d * d; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) qq[i] += __shfl_xor(qq[i], o);
+    const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = wid * RPW + i;
+      const float mean = sm[i], rstd = rsqrtf(qq[i] * (1.f / D) + p.eps);
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
+      const uint2 h = make_uint2(pack2h(o[0], o[1]), pack2h(o[2], o[3]));
+      *reinterpret_cast<uint2*>(img + r * DL_YS + col * 2) = h;
+      if (write && r < nrows) {
+        const int64_t row = rows[i];
+        if (p.z) *reinterpret_cast<float4*>(p.z + row * D + col) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+        if (p.y) *reinterpret_cast<float4*>(p.y + row * D + col) = make_float4(o[0], o[1], o[2], o[3]);
+        if (p.y16) *reinterpret_cast<uint2*>(p.y16 + row * D + col) = h;
+        if (lane == 0) {
+          if (p.mean) p.mean[row] = mean;
+          if (p.rstd) p.rstd[row] = rstd;
+        }
       }
     }
   }
-}
+};
 
 // acc[i] += W[tile t0 + i tstep][contraction steps ks0 .. ks0 + NK) . (the 32 rows of `img`)^T; fragment (tile, ks) of the pack sits at
 // ((tile nks + ks) 64 + lane) uint4.  fill() starts the stream (the first PD fragments travel under whatever the caller does
@@ -195,15 +241,19 @@ __device__ __forceinline__ void dl_put_tile(float* red, const f32x16& a, int col
     *reinterpret_cast<float4*>(red + m * DL_RS + col0 + 8 * q + 4 * hi) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
 }
 
-// red[32][256] -> slab rows (whole 1 KiB rows per wave instruction)
+// red[32][256] -> slab rows, rounded to 16 bits (whole 512-byte rows per wave instruction).  Every slab of this file is 16-bit: a
+// launch's prologue is bound by what its CU can ingest (~22 B/clk: the slabs + residual rows of 32 rows were 160 KiB of a 256 KiB
+// prologue, 20 k cycles of a 30 k cycle launch by clock stamps); the shares are rounded once, like every other branch of this model
+// that feeds an add + LayerNorm, and added up in fp32 by the consumer.
 template <int NW>
-__device__ __forceinline__ void dl_store_slab(float* slab, const float* red, int64_t row0, int nrows, int tid) {
+__device__ __forceinline__ void dl_store_slab(uint16_t* slab, const float* red, int64_t row0, int nrows, int tid) {
   constexpr int RPW = DL_RB / NW;
   const int lane = tid & 63, wid = tid >> 6, col = lane * 4;
 #pragma unroll
   for (int i = 0; i < RPW; ++i) {
     const int r = wid * RPW + i;
-    if (r < nrows) *reinterpret_cast<float4*>(slab + (row0 + r) * DL_D + col) = *reinterpret_cast<const float4*>(red + r * DL_RS + col);
+    const float4 v = *reinterpret_cast<const float4*>(red + r * DL_RS + col);
+    if (r < nrows) *reinterpret_cast<uint2*>(slab + (row0 + r) * DL_D + col) = make_uint2(pack2h(v.x, v.y), pack2h(v.z, v.w));
   }
 }
 
@@ -213,9 +263,21 @@ __device__ __forceinline__ void dl_group(const DlGeom& g, int gi, int& u0, int64
   row0 = (int64_t)u0 * g.L;
   nrows = min(g.G, g.B - u0) * g.L;
 }
+// Workgroup id -> (row block or group, part), part = head or hidden slice, nparts of them.  The nparts workgroups of one row block
+// read the SAME slabs / residual rows in their prologue (every one of them finishes the LayerNorm): with ids that are equal modulo
+// 8 they sit on one XCD (consecutive ids go to consecutive XCDs: observed placement, used for locality only) and the rows cross the
+// fabric once instead of nparts times.  Launch 8 * nparts * ceil(nblocks / 8) workgroups; returns false for the padding ones.
+__host__ __device__ __forceinline__ bool dl_block_of(int id, int nparts, int nblocks, int& blk, int& part) {
+  const int xcd = id & 7, k = id >> 3;
+  part = k % nparts;
+  blk = (k / nparts) * 8 + xcd;
+  return blk < nblocks;
+}
+static inline unsigned dl_grid(int nparts, int nblocks) { return (unsigned)(8 * nparts * ((nblocks + 7) / 8)); }
 
 // ------------------------------------------------------------------------------------------------ self-attention launch
 struct DlSelfArgs {
+  unsigned long long* trace;
   DlLn ln;
   DlGeom g;
   const uint4* wqkv; const float* bqkv;      // forward pack of qvk_proj.weight [768, 256] (q | k | v rows), bias [768]
@@ -223,7 +285,7 @@ struct DlSelfArgs {
   uint16_t* qkv16;                           // [R, 768] out (saved for the backward pass)
   uint16_t* ctx16;                           // [R, 256] out: merged-head attention context (operand of the output projection)
   float* lse;                                // [B, H, L] out
-  float* slabs;                              // [H][R][256] out: this head's share of context . W_o^T
+  uint16_t* slabs;                           // [H][R][256] 16-bit out: this head's share of context . W_o^T
   float scale;
 };
 
@@ -238,14 +300,26 @@ __global__ __launch_bounds__(256, 1) void dec_self_fwd_kernel(DlSelfArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y;
+  int gi, h;
+  if (!dl_block_of((int)blockIdx.x, DL_H, (p.g.B + p.g.G - 1) / p.g.G, gi, h)) return;
   int u0, nrows;
   int64_t row0;
-  dl_group(p.g, blockIdx.x, u0, row0, nrows);
-  DlStream<2, 16, 16> sq;
-  if (wid < 3) sq.fill(p.wqkv, 16, wid * 8 + 2 * h, 1, 0, lane);      // wave 0: q tiles of this head, 1: k, 2: v
-  dl_prologue<4>(p.ln, row0, nrows, h == 0, ys, tid);
+  dl_group(p.g, gi, u0, row0, nrows);
+  DL_STAMP(0, 0);
+  DlPro<4, true> pro;                                                  // its loads go out first: vmcnt retires in order
+  pro.issue(p.ln, row0, nrows, tid);
+  DlStream<2, 16, 32> sq;                                             // all 32 fragments of a wave in flight: one round trip
+  float4 bq4[2][4];
+  if (wid < 3) {
+    sq.fill(p.wqkv, 16, wid * 8 + 2 * h, 1, 0, lane);                  // wave 0: q tiles of this head, 1: k, 2: v
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bq4[t][q] = *reinterpret_cast<const float4*>(p.bqkv + wid * DL_D + DL_DK * h + 32 * t + 8 * q + 4 * (lane >> 5));
+  }
+  pro.finish(p.ln, nrows, h == 0, ys, tid);
   __syncthreads();
+  DL_STAMP(0, 1);
   if (wid < 3) {
     f32x16 acc[2];
     dl_zero(acc);
@@ -255,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void dec_self_fwd_kernel(DlSelfArgs p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = 32 * t + 8 * q + 4 * hi;                       // column of the head
-        const float4 b = *reinterpret_cast<const float4*>(p.bqkv + wid * DL_D + DL_DK * h + c);
+        const float4 b = bq4[t][q];
         const float v0 = acc[t][4 * q] + b.x, v1 = acc[t][4 * q + 1] + b.y, v2 = acc[t][4 * q + 2] + b.z, v3 = acc[t][4 * q + 3] + b.w;
         const uint2 pk = make_uint2(pack2h(v0, v1), pack2h(v2, v3));
         if (wid == 0) *reinterpret_cast<uint2*>(qs + m * DL_HS + c * 2) = pk;
@@ -271,6 +345,7 @@ __global__ __launch_bounds__(256, 1) void dec_self_fwd_kernel(DlSelfArgs p) {
   DlStream<2, 4, 8> so;
   so.fill(p.wo, 16, 2 * wid, 1, 4 * h, lane);                         // this head's 4 contraction steps of the output projection
   __syncthreads();
+  DL_STAMP(0, 2);
   if (wid == 0) {
     // S^T = K Q^T for the 32 rows of the group: rows = keys j, columns = queries i; lane (i, hi) holds j = 8q + 4hi + (r & 3)
     f32x16 st[1];
@@ -282,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void dec_self_fwd_kernel(DlSelfArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = 8 * (r >> 2) + 4 * hi + (r & 3);
-      const bool ok = j <= i && i < nrows && (j / p.g.L) == ui;      // causal inside the utterance (decoder/utils.py:7-11)
+      const bool ok = j <= i && i < nrows && j >= ui * p.g.L;        // causal inside the utterance (decoder/utils.py:7-11)
       s[r] = ok ? st[0][r] * p.scale : -INFINITY;
       mx = fmaxf(mx, s[r]);
     }
@@ -321,17 +396,21 @@ __global__ __launch_bounds__(256, 1) void dec_self_fwd_kernel(DlSelfArgs p) {
       }
   }
   __syncthreads();
+  DL_STAMP(0, 3);
   f32x16 acc[2];
   dl_zero(acc);
   so.run(acc, cs, DL_HS, 0, lane);
   dl_put_tile(red, acc[0], (2 * wid) * 32, lane);
   dl_put_tile(red, acc[1], (2 * wid + 1) * 32, lane);
   __syncthreads();
+  DL_STAMP(0, 4);
   dl_store_slab<4>(p.slabs + (int64_t)h * p.ln.R * DL_D, red, row0, nrows, tid);
+  DL_STAMP(0, 5);
 }
 
 // ------------------------------------------------------------------------------------------------ cross-attention launch
 struct DlCrossArgs {
+  unsigned long long* trace;
   DlLn ln;
   DlGeom g;
   const uint4* wq; const float* bq;          // forward pack of q_proj.weight [256, 256], bias
@@ -343,7 +422,7 @@ struct DlCrossArgs {
   int Tk;
   uint16_t* q16; uint16_t* ctx16;            // [R, 256] out
   float* lse;                                // [B, H, L] out
-  float* slabs;                              // [H][R][256] out
+  uint16_t* slabs;                           // [H][R][256] 16-bit out
   float scale;
 };
 
@@ -379,11 +458,15 @@ __global__ __launch_bounds__(512, 1) void dec_cross_fwd_kernel(DlCrossArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y;
+  int gi, h;
+  if (!dl_block_of((int)blockIdx.x, DL_H, (p.g.B + p.g.G - 1) / p.g.G, gi, h)) return;
   int u0, nrows;
   int64_t row0;
-  dl_group(p.g, blockIdx.x, u0, row0, nrows);
+  dl_group(p.g, gi, u0, row0, nrows);
   const int nutt = nrows / p.g.L, ntile = (p.Tk + 31) >> 5, nit = nutt * ntile;
+  DL_STAMP(1, 0);
+  DlPro<8, true> pro;
+  pro.issue(p.ln, row0, nrows, tid);
   // the first key / value tile of this wave travels under the prologue and the q projection (it does not depend on them)
   DlKvTile cur;
   {
@@ -394,8 +477,14 @@ __global__ __launch_bounds__(512, 1) void dec_cross_fwd_kernel(DlCrossArgs p) {
   if (wid < 2) sq.fill(p.wq, 16, 2 * h + wid, 1, 0, lane);
   DlStream<1, 4, 4> so;
   so.fill(p.wo, 16, wid, 1, 4 * h, lane);
-  dl_prologue<8>(p.ln, row0, nrows, h == 0, ys, tid);
+  pro.finish(p.ln, nrows, h == 0, ys, tid);
+  DlKvTile alt;
+  {
+    const int it = min(wid + 8, nit - 1);                             // this wave's second tile lands under the q projection
+    dl_load_kv(alt, p, u0 + it / ntile, (it % ntile) * 32, h, lane);
+  }
   __syncthreads();
+  DL_STAMP(1, 1);
   if (wid < 2) {
     f32x16 acc[1];
     dl_zero(acc);
@@ -410,8 +499,10 @@ __global__ __launch_bounds__(512, 1) void dec_cross_fwd_kernel(DlCrossArgs p) {
     }
   }
   __syncthreads();
+  DL_STAMP(1, 2);
   // ---- flash attention: this wave takes (utterance, key tile) pairs wid, wid + 8, ...; the queries are the group's 32 rows, of which
-  // only the rows of that utterance take part (the others see -inf scores and keep their state)
+  // only the rows of that utterance take part (the others see -inf scores and keep their state).  Two tile register sets take
+  // turns (no copies: a copy of registers that a load still has to fill waits for the load, which serialised the loop)
   uint4 qf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qf[ks] = dl_frag(qs, DL_HS, m, hi, ks);
@@ -420,18 +511,17 @@ __global__ __launch_bounds__(512, 1) void dec_cross_fwd_kernel(DlCrossArgs p) {
   f32x16 o[2];
   dl_zero(o);
   unsigned char* vt = vtw + wid * (DL_DK * DL_VT);
-  for (int it = wid; it < nit; it += 8) {
+  auto load_tile = [&](DlKvTile& t, int it) {
+    const int itc = min(it, nit - 1);                                   // past the end: a valid tile, loaded and never used
+    dl_load_kv(t, p, u0 + itc / ntile, (itc % ntile) * 32, h, lane);
+  };
+  auto consume = [&](const DlKvTile& t, int it) {
     const int u = it / ntile;
-    DlKvTile nxt;
-    {
-      const int itn = min(it + 8, nit - 1);                           // the last round re-loads a valid tile (unused)
-      dl_load_kv(nxt, p, u0 + itn / ntile, (itn % ntile) * 32, h, lane);
-    }
     // values -> transposed image of this wave (rows = the head's 64 columns, 32 keys each)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int j = 8 * q + (lane >> 3), c0 = 8 * (lane & 7);
-      const uint32_t w[4] = {cur.v[q].x, cur.v[q].y, cur.v[q].z, cur.v[q].w};
+      const uint32_t w[4] = {t.v[q].x, t.v[q].y, t.v[q].z, t.v[q].w};
 #pragma unroll
       for (int e = 0; e < 8; ++e)
         *reinterpret_cast<uint16_t*>(vt + (c0 + e) * DL_VT + j * 2) = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
@@ -439,13 +529,13 @@ __global__ __launch_bounds__(512, 1) void dec_cross_fwd_kernel(DlCrossArgs p) {
     f32x16 st[1];
     dl_zero(st);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) mma32(st[0], cur.k[ks], qf[ks]);
+    for (int ks = 0; ks < 4; ++ks) mma32(st[0], t.k[ks], qf[ks]);
     float s[16], tmax = -INFINITY;
     const bool mine = ui == u && i < nrows;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = 8 * (r >> 2) + 4 * hi + (r & 3);
-      const bool ok = mine && ((cur.valid >> j) & 1u);
+      const bool ok = mine && ((t.valid >> j) & 1u);
       s[r] = ok ? st[0][r] * p.scale : -INFINITY;
       tmax = fmaxf(tmax, s[r]);
     }
@@ -477,8 +567,16 @@ __global__ __launch_bounds__(512, 1) void dec_cross_fwd_kernel(DlCrossArgs p) {
         mma32(o[ct], make_uint4(lo.x, lo.y, up.x, up.y), pb[k2]);
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the tile is read before the next round overwrites it
-    cur = nxt;
+  };
+  for (int it = wid; it < nit; it += 16) {
+    consume(cur, it);
+    if (it + 8 < nit) {
+      load_tile(cur, it + 16);
+      consume(alt, it + 8);
+      load_tile(alt, it + 24);
+    }
   }
+  DL_STAMP(1, 3);
   // ---- the eight waves' partial results meet in LDS
   if (hi == 0) { mb[wid * DL_RB + i] = mrun; lb[wid * DL_RB + i] = lrun; }
 #pragma unroll
@@ -488,6 +586,7 @@ __global__ __launch_bounds__(512, 1) void dec_cross_fwd_kernel(DlCrossArgs p) {
       *reinterpret_cast<float4*>(ob + (wid * DL_RB + i) * OS + 32 * ct + 8 * q + 4 * hi) =
           make_float4(o[ct][4 * q], o[ct][4 * q + 1], o[ct][4 * q + 2], o[ct][4 * q + 3]);
   __syncthreads();
+  DL_STAMP(1, 4);
   {
     const int r = tid >> 4, c = (tid & 15) * 4;                        // 512 threads: row r, four columns of the head
     float M = -INFINITY;
@@ -514,21 +613,44 @@ __global__ __launch_bounds__(512, 1) void dec_cross_fwd_kernel(DlCrossArgs p) {
     }
   }
   __syncthreads();
+  DL_STAMP(1, 5);
   f32x16 acc[1];
   dl_zero(acc);
   so.run(acc, cs, DL_HS, 0, lane);
   dl_put_tile(red, acc[0], wid * 32, lane);
   __syncthreads();
   dl_store_slab<8>(p.slabs + (int64_t)h * p.ln.R * DL_D, red, row0, nrows, tid);
+  DL_STAMP(1, 6);
 }
 
 // ------------------------------------------------------------------------------------------------ FFN launch
 struct DlFfnArgs {
+  unsigned long long* trace;
   DlLn ln;
   const uint4* p1; const float* b1; const uint4* p2;   // packs of w_1 [2F, 256] (perm 0) and w_2 [256, F] (perm 1), as otr_ffn_ln_fwd
-  float* slabs;                                         // [S][R][256] out: w_2 glu(w_1 y + b_1) over this slice's hidden units (no b_2)
+  uint16_t* slabs;                                      // [S][R][256] 16-bit out: w_2 glu(w_1 y + b_1) over this slice's hidden units (no b_2)
+  uint4* hsave;                                         // NULL, or [row blocks][F / 32 chunks][4][64 lanes] x 16 B out: (value + bias, sigmoid(gate)) of
+                                                        // every hidden unit in accumulator order (pieces 0, 1 = values, 2, 3 = sigmoids): what the
+                                                        // backward launch reads instead of recomputing the hidden (1/3 less weight traffic there)
   int F, S;
 };
+
+// red[4 waves][32][256] fp32 partial tiles -> one 16-bit slab (the partial sums of a slice are rounded once, like every other
+// branch of this model that feeds an add + LayerNorm; the consumer adds the S slabs in fp32)
+__device__ __forceinline__ void dl_store_slab16(uint16_t* slab, const float* red, int64_t row0, int nrows, int wid, int lane) {
+  const int col = lane * 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = wid * 8 + i;
+    float4 v = *reinterpret_cast<const float4*>(red + r * DL_RS + col);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 t = *reinterpret_cast<const float4*>(red + (w * DL_RB + r) * DL_RS + col);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (r < nrows) *reinterpret_cast<uint2*>(slab + (row0 + r) * DL_D + col) = make_uint2(pack2h(v.x, v.y), pack2h(v.z, v.w));
+  }
+}
 
 __global__ __launch_bounds__(256, 1) void dec_ffn_fwd_kernel(DlFfnArgs p) {
   constexpr int D = DL_D, NKS = D / 16, NT = D / 32, STEPS = 2 * NKS + 2 * NT, PD = 24;
@@ -539,9 +661,10 @@ __global__ __launch_bounds__(256, 1) void dec_ffn_fwd_kernel(DlFfnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, hi = lane >> 5;
-  const int64_t row0 = (int64_t)blockIdx.x * DL_RB;
+  int rb, sl;
+  if (!dl_block_of((int)blockIdx.x, p.S, (int)((p.ln.R + DL_RB - 1) / DL_RB), rb, sl)) return;
+  const int64_t row0 = (int64_t)rb * DL_RB;
   const int nrows = (int)min((int64_t)DL_RB, p.ln.R - row0);
-  const int sl = blockIdx.y;
   const int nchunk = p.F / 32, cps = nchunk / p.S, nit = cps / 4;     // chunks (32 hidden units) of the layer / of a slice / of a wave
   auto chunk_of = [&](int it) { return sl * cps + 4 * it + wid; };
   const uint4* P1 = p.p1 + lane;
@@ -551,13 +674,17 @@ __global__ __launch_bounds__(256, 1) void dec_ffn_fwd_kernel(DlFfnArgs p) {
     const int t = s - 2 * NKS;
     return P2 + (int64_t)((t >> 1) * (2 * nchunk) + 2 * c + (t & 1)) * 64;
   };
+  DL_STAMP(2, 0);
+  DlPro<4, true> pro;
+  pro.issue(p.ln, row0, nrows, tid);
   uint4 ring[PD];
   int c = chunk_of(0);
 #pragma unroll
   for (int s = 0; s < PD; ++s) ring[s] = ld_global_b128(fptr(c, s));
   __builtin_amdgcn_sched_barrier(0);
-  dl_prologue<4>(p.ln, row0, nrows, sl == 0, ys, tid);
+  pro.finish(p.ln, nrows, sl == 0, ys, tid);
   __syncthreads();
+  DL_STAMP(2, 1);
   f32x16 yacc[NT];
   dl_zero(yacc);
   for (int it = 0; it < nit; ++it) {
@@ -584,36 +711,31 @@ __global__ __launch_bounds__(256, 1) void dec_ffn_fwd_kernel(DlFfnArgs p) {
       }
       ring[s % PD] = ld_global_b128(s + PD < STEPS ? fptr(c, s + PD) : fptr(cn, s + PD - STEPS));
       if (s == 2 * NKS - 1) {
-        float u[16];
+        float u[16], a[16], sg[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float a = av[r] + reinterpret_cast<const float*>(&bv[r >> 2])[r & 3];
-          const float g = ag[r] + reinterpret_cast<const float*>(&bg[r >> 2])[r & 3];
-          u[r] = a * fast_sigmoid(g);
+          a[r] = av[r] + reinterpret_cast<const float*>(&bv[r >> 2])[r & 3];
+          sg[r] = fast_sigmoid(ag[r] + reinterpret_cast<const float*>(&bg[r >> 2])[r & 3]);
+          u[r] = a[r] * sg[r];
         }
         tile_to_frags(u, uf0, uf1);
+        if (p.hsave) {
+          uint4 a0, a1, s0, s1;
+          tile_to_frags(a, a0, a1);
+          tile_to_frags(sg, s0, s1);
+          uint4* hs = p.hsave + (((int64_t)rb * nchunk + c) * 4) * 64 + lane;
+          st_global_b128(hs, a0); st_global_b128(hs + 64, a1); st_global_b128(hs + 128, s0); st_global_b128(hs + 192, s1);
+        }
       }
     }
     c = cn;
   }
+  DL_STAMP(2, 2);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) dl_put_tile(red + wid * DL_RB * DL_RS, yacc[nt], nt * 32, lane);
   __syncthreads();
-  {
-    const int col = lane * 4;
-    float* slab = p.slabs + (int64_t)sl * p.ln.R * D;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = wid * 8 + i;
-      float4 v = *reinterpret_cast<const float4*>(red + r * DL_RS + col);
-#pragma unroll
-      for (int w = 1; w < 4; ++w) {
-        const float4 t = *reinterpret_cast<const float4*>(red + (w * DL_RB + r) * DL_RS + col);
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-      }
-      if (r < nrows) *reinterpret_cast<float4*>(slab + (row0 + r) * D + col) = v;
-    }
-  }
+  DL_STAMP(2, 3);
+  dl_store_slab16(p.slabs + (int64_t)sl * p.ln.R * D, red, row0, nrows, wid, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ closing LayerNorm
@@ -642,13 +764,14 @@ __global__ __launch_bounds__(256) void dec_ln_kernel(DlLnArgs p) {
     const float4 xr = *reinterpret_cast<const float4*>(q.xres + row * DL_D + col);
     float a[4] = {bb.x, bb.y, bb.z, bb.w};
     for (int s0 = 0; s0 < q.nslab; s0 += 4) {                         // four slabs in flight
-      float4 t[4];
+      uint2 t[4];                                                      // the FFN launches' slabs are 16-bit
 #pragma unroll
-      for (int s = 0; s < 4; ++s) t[s] = *reinterpret_cast<const float4*>(q.slabs + ((int64_t)min(s0 + s, q.nslab - 1) * q.R + row) * DL_D + col);
+      for (int s = 0; s < 4; ++s)
+        t[s] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(q.slabs) + ((int64_t)min(s0 + s, q.nslab - 1) * q.R + row) * DL_D + col);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const float live = s0 + s < q.nslab ? 1.f : 0.f;
-        a[0] += live * t[s].x; a[1] += live * t[s].y; a[2] += live * t[s].z; a[3] += live * t[s].w;
+        a[0] += live * h2f_lo(t[s].x); a[1] += live * h2f_hi(t[s].x); a[2] += live * h2f_lo(t[s].y); a[3] += live * h2f_hi(t[s].y);
       }
     }
     const float xv[4] = {xr.x, xr.y, xr.z, xr.w};
@@ -696,7 +819,7 @@ __global__ __launch_bounds__(256) void dec_ln_kernel(DlLnArgs p) {
 // weight-gradient operand of the output projection / w_2) and its sums of dgamma | dbeta | d bias.
 struct DlLnB {
   const float* dskip;      // [R,256] or NULL: skip-path part of the gradient of the LayerNorm output
-  const float* slabs;      // [nslab][R][256]: the rest of it, in shares (nslab may be 0)
+  const void* slabs;       // [nslab][R][256]: the rest of it, in shares (nslab may be 0); fp32 or 16-bit, fixed per launch type
   int nslab;
   const float* z; const float* mean; const float* rstd; const float* gamma; const uint64_t* seed;
   float p_drop;
@@ -707,182 +830,204 @@ struct DlLnB {
   int64_t R;
 };
 
-// LayerNorm backward of rows row0 .. (clamped to nrows); the 16-bit branch gradient lands in `img` ([32][DL_YS]) as MFMA B operands.
-// stage: [3][NW][256] floats of LDS scratch.  Contains two __syncthreads when `write` (block-uniform).
-template <int NW>
-__device__ __forceinline__ void dl_ln_bwd(const DlLnB& p, int64_t row0, int nrows, int block, bool write, unsigned char* img, float* stage, int tid) {
-  constexpr int RPW = DL_RB / NW, D = DL_D;
-  const int lane = tid & 63, wid = tid >> 6, col = lane * 4;
-  const bool drop = p.p_drop > 0.f;
-  const uint64_t seed = drop ? *p.seed : 0;
-  const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
-  const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
-  const float4 gm4 = *reinterpret_cast<const float4*>(p.gamma + col);
-  const float gam[4] = {gm4.x, gm4.y, gm4.z, gm4.w};
+// LayerNorm backward of rows row0 .. (clamped to nrows), in two steps like DlPro: issue() starts every global load, finish() leaves
+// the 16-bit branch gradient in `img` ([32][DL_YS]) as MFMA B operands.  stage: [3][NW][256] floats of LDS scratch; finish() contains
+// two __syncthreads when `write` (block-uniform).  H16: the slabs are 16-bit (the FFN backward launch's shares).
+template <int NW, bool H16> struct DlProB {
+  static constexpr int RPW = DL_RB / NW, NS = H16 ? 8 : 4, D = DL_D;
+  typedef typename std::conditional<H16, uint2, float4>::type slab_t;
   int64_t rows[RPW];
-  float4 zv[RPW];
-  float mean[RPW], rstd[RPW], d4[RPW][4];
+  float4 zv[RPW], dk[RPW];
+  float mean[RPW], rstd[RPW];
+  slab_t t[NS][RPW];
+  float4 gm4;
+  uint64_t seed;
+  __device__ __forceinline__ void issue(const DlLnB& p, int64_t row0, int nrows, int tid) {
+    const int lane = tid & 63, wid = tid >> 6, col = lane * 4;
+    gm4 = *reinterpret_cast<const float4*>(p.gamma + col);
+    seed = p.p_drop > 0.f ? *p.seed : 0;
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    rows[i] = row0 + min(wid * RPW + i, nrows - 1);
-    zv[i] = *reinterpret_cast<const float4*>(p.z + rows[i] * D + col);
-    mean[i] = p.mean[rows[i]]; rstd[i] = p.rstd[rows[i]];
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.dskip) t = *reinterpret_cast<const float4*>(p.dskip + rows[i] * D + col);
-    d4[i][0] = t.x; d4[i][1] = t.y; d4[i][2] = t.z; d4[i][3] = t.w;
-  }
-  for (int s0 = 0; s0 < p.nslab; s0 += 4) {
-    float4 t[4][RPW];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int ss = min(s0 + s, p.nslab - 1);
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) t[s][i] = *reinterpret_cast<const float4*>(p.slabs + ((int64_t)ss * p.R + rows[i]) * D + col);
+    for (int i = 0; i < RPW; ++i) {
+      rows[i] = row0 + min(wid * RPW + i, nrows - 1);
+      zv[i] = *reinterpret_cast<const float4*>(p.z + rows[i] * D + col);
+      mean[i] = p.mean[rows[i]]; rstd[i] = p.rstd[rows[i]];
+      dk[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.dskip) dk[i] = *reinterpret_cast<const float4*>(p.dskip + rows[i] * D + col);
     }
+    if (p.nslab > 0) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float live = s0 + s < p.nslab ? 1.f : 0.f;
+      for (int s = 0; s < NS; ++s) {
+        const int ss = min(s, p.nslab - 1);
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        d4[i][0] += live * t[s][i].x; d4[i][1] += live * t[s][i].y; d4[i][2] += live * t[s][i].z; d4[i][3] += live * t[s][i].w;
+        for (int i = 0; i < RPW; ++i) {
+          if constexpr (H16) t[s][i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.slabs) + ((int64_t)ss * p.R + rows[i]) * D + col);
+          else t[s][i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.slabs) + ((int64_t)ss * p.R + rows[i]) * D + col);
+        }
       }
     }
   }
-  float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dab[4] = {0.f, 0.f, 0.f, 0.f};
-  float z4[RPW][4], s1[RPW], s2[RPW];
+  __device__ __forceinline__ void finish(const DlLnB& p, int nrows, int block, bool write, unsigned char* img, float* stage, int tid) {
+    const int lane = tid & 63, wid = tid >> 6, col = lane * 4;
+    const bool drop = p.p_drop > 0.f;
+    const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
+    const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+    const float gam[4] = {gm4.x, gm4.y, gm4.z, gm4.w};
+    float d4[RPW][4];
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const float live = wid * RPW + i < nrows ? 1.f : 0.f;
-    const float zz[4] = {zv[i].x, zv[i].y, zv[i].z, zv[i].w};
-    s1[i] = 0.f; s2[i] = 0.f;
+    for (int i = 0; i < RPW; ++i) { d4[i][0] = dk[i].x; d4[i][1] = dk[i].y; d4[i][2] = dk[i].z; d4[i][3] = dk[i].w; }
+    if (p.nslab > 0) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      d4[i][e] *= live;
-      z4[i][e] = (zz[e] - mean[i]) * rstd[i];
-      const float g = d4[i][e] * gam[e];
-      s1[i] += g; s2[i] += g * z4[i][e];
-      dg[e] += d4[i][e] * z4[i][e];
-      db[e] += d4[i][e];
+      for (int s = 0; s < NS; ++s) {
+        const float live = s < p.nslab ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+          if constexpr (H16) {
+            d4[i][0] += live * h2f_lo(t[s][i].x); d4[i][1] += live * h2f_hi(t[s][i].x); d4[i][2] += live * h2f_lo(t[s][i].y); d4[i][3] += live * h2f_hi(t[s][i].y);
+          } else {
+            d4[i][0] += live * t[s][i].x; d4[i][1] += live * t[s][i].y; d4[i][2] += live * t[s][i].z; d4[i][3] += live * t[s][i].w;
+          }
+        }
+      }
+      for (int s = NS; s < p.nslab; ++s)
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+          if constexpr (H16) {
+            const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.slabs) + ((int64_t)s * p.R + rows[i]) * D + col);
+            d4[i][0] += h2f_lo(q.x); d4[i][1] += h2f_hi(q.x); d4[i][2] += h2f_lo(q.y); d4[i][3] += h2f_hi(q.y);
+          } else {
+            const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.slabs) + ((int64_t)s * p.R + rows[i]) * D + col);
+            d4[i][0] += q.x; d4[i][1] += q.y; d4[i][2] += q.z; d4[i][3] += q.w;
+          }
+        }
+    }
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dab[4] = {0.f, 0.f, 0.f, 0.f};
+    float z4[RPW][4], s1[RPW], s2[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const float live = wid * RPW + i < nrows ? 1.f : 0.f;
+      const float zz[4] = {zv[i].x, zv[i].y, zv[i].z, zv[i].w};
+      s1[i] = 0.f; s2[i] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        d4[i][e] *= live;
+        z4[i][e] = (zz[e] - mean[i]) * rstd[i];
+        const float g = d4[i][e] * gam[e];
+        s1[i] += g; s2[i] += g * z4[i][e];
+        dg[e] += d4[i][e] * z4[i][e];
+        db[e] += d4[i][e];
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = wid * RPW + i;
+      const float m1 = s1[i] * (1.f / D), m2 = s2[i] * (1.f / D);
+      float dz[4], da[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dz[e] = rstd[i] * (d4[i][e] * gam[e] - m1 - z4[i][e] * m2);
+        const float sc = drop ? (otr_rand32(seed, p.rng_offset + (uint64_t)(rows[i] * D + col + e)) >= thr ? inv_keep : 0.f) : 1.f;
+        da[e] = dz[e] * sc;
+        dab[e] += da[e];
+      }
+      const uint2 h = make_uint2(pack2h(da[0], da[1]), pack2h(da[2], da[3]));
+      *reinterpret_cast<uint2*>(img + r * DL_YS + col * 2) = h;
+      if (write && r < nrows) {
+        if (p.dz) *reinterpret_cast<float4*>(p.dz + rows[i] * D + col) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+        if (p.da16) *reinterpret_cast<uint2*>(p.da16 + rows[i] * D + col) = h;
+      }
+    }
+    if (write && p.partial) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        stage[(0 * NW + wid) * D + col + e] = dg[e];
+        stage[(1 * NW + wid) * D + col + e] = db[e];
+        stage[(2 * NW + wid) * D + col + e] = dab[e];
+      }
+      __syncthreads();
+      float* prow = p.partial + (int64_t)block * 3 * D;
+      for (int c = tid; c < 3 * D; c += 64 * NW) {
+        const int k = c >> 8, cc = c & 255;
+        float t_ = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t_ += stage[(k * NW + w) * D + cc];
+        prow[c] = t_;
+      }
+      __syncthreads();
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
-#pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int r = wid * RPW + i;
-    const float m1 = s1[i] * (1.f / D), m2 = s2[i] * (1.f / D);
-    float dz[4], da[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      dz[e] = rstd[i] * (d4[i][e] * gam[e] - m1 - z4[i][e] * m2);
-      const float sc = drop ? (otr_rand32(seed, p.rng_offset + (uint64_t)(rows[i] * D + col + e)) >= thr ? inv_keep : 0.f) : 1.f;
-      da[e] = dz[e] * sc;
-      dab[e] += da[e];
-    }
-    const uint2 h = make_uint2(pack2h(da[0], da[1]), pack2h(da[2], da[3]));
-    *reinterpret_cast<uint2*>(img + r * DL_YS + col * 2) = h;
-    if (write && r < nrows) {
-      if (p.dz) *reinterpret_cast<float4*>(p.dz + rows[i] * D + col) = make_float4(dz[0], dz[1], dz[2], dz[3]);
-      if (p.da16) *reinterpret_cast<uint2*>(p.da16 + rows[i] * D + col) = h;
-    }
-  }
-  if (write && p.partial) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      stage[(0 * NW + wid) * D + col + e] = dg[e];
-      stage[(1 * NW + wid) * D + col + e] = db[e];
-      stage[(2 * NW + wid) * D + col + e] = dab[e];
-    }
-    __syncthreads();
-    float* prow = p.partial + (int64_t)block * 3 * D;
-    for (int c = tid; c < 3 * D; c += 64 * NW) {
-      const int k = c >> 8, cc = c & 255;
-      float t_ = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) t_ += stage[(k * NW + w) * D + cc];
-      prow[c] = t_;
-    }
-    __syncthreads();
-  }
-}
+};
 
 // ------------------------------------------------------------------------------------------------ FFN backward launch
 struct DlFfnBwdArgs {
+  unsigned long long* trace;
   DlLnB ln;
-  const uint16_t* x16;     // FFN input (y2, 16-bit) [R,256]: the hidden is recomputed from it
-  const uint4* p1; const float* b1; const uint4* p3; const uint4* p4;   // packs as otr_ffn_bwd
+  const uint4* hsave;      // (value + bias, sigmoid) tiles the forward launch left (DlFfnArgs::hsave)
+  const uint4* p3; const uint4* p4;   // packs of w_2^T (rows = F hidden units, perm 0) and w_1^T (rows = 256, contraction 2F, perm 1), as otr_ffn_bwd
   uint16_t* dh;            // [R, 2F] out
   uint16_t* u;             // [R, F] out
   float* bpart;            // [row blocks][2F] out: column sums of dh over the block's rows
-  float* slabs;            // [S][R][256] out: dh[slice] . w_1[slice]
+  uint16_t* slabs;         // [S][R][256] 16-bit out: dh[slice] . w_1[slice]
   int F, S;
 };
 
 __global__ __launch_bounds__(256, 1) void dec_ffn_bwd_kernel(DlFfnBwdArgs p) {
   constexpr int D = DL_D, NKS = D / 16, NT = D / 32;
-  constexpr int S1 = 2 * NKS, S2 = S1 + NKS, STEPS = S2 + 4 * NT, PD = 20;
+  constexpr int S2 = NKS, STEPS = S2 + 4 * NT, PD = 24;            // 16 + 32 weight fragments per chunk
   static_assert(STEPS % PD == 0, "ring slots must be compile-time constants");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * DL_RB * DL_RS * 4];   // operand images first, partial sums after
-  unsigned char* xs = smem;
-  unsigned char* ds = smem + DL_RB * DL_YS;
-  float* stage = reinterpret_cast<float*>(smem + 2 * DL_RB * DL_YS);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * DL_RB * DL_RS * 4];   // operand image first, partial sums after
+  unsigned char* ds = smem;
+  float* stage = reinterpret_cast<float*>(smem + DL_RB * DL_YS);
   float* red = reinterpret_cast<float*>(smem);
-  static_assert(2 * DL_RB * DL_YS + 3 * 4 * DL_D * 4 <= 4 * DL_RB * DL_RS * 4, "LDS layout");
+  static_assert(DL_RB * DL_YS + 3 * 4 * DL_D * 4 <= 4 * DL_RB * DL_RS * 4, "LDS layout");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, hi = lane >> 5;
-  const int64_t row0 = (int64_t)blockIdx.x * DL_RB;
+  int rb, sl;
+  if (!dl_block_of((int)blockIdx.x, p.S, (int)((p.ln.R + DL_RB - 1) / DL_RB), rb, sl)) return;
+  const int64_t row0 = (int64_t)rb * DL_RB;
   const int nrows = (int)min((int64_t)DL_RB, p.ln.R - row0);
-  const int sl = blockIdx.y;
   const int nchunk = p.F / 32, cps = nchunk / p.S, nit = cps / 4;
   auto chunk_of = [&](int it) { return sl * cps + 4 * it + wid; };
-  const uint4* P1 = p.p1 + lane;
   const uint4* P3 = p.p3 + lane;
   const uint4* P4 = p.p4 + lane;
   auto fptr = [&](int c, int s) -> const uint4* {
-    if (s < S1) return P1 + (int64_t)(((s & 1) ? nchunk + c : c) * NKS + (s >> 1)) * 64;
-    if (s < S2) return P3 + (int64_t)(c * NKS + (s - S1)) * 64;
+    if (s < S2) return P3 + (int64_t)(c * NKS + s) * 64;
     const int t = s - S2, j4 = t & 3;
     const int ksf = (j4 < 2) ? 2 * c + j4 : 2 * nchunk + 2 * c + (j4 - 2);
     return P4 + (int64_t)((t >> 2) * (4 * nchunk) + ksf) * 64;
   };
-  for (int i = tid; i < DL_RB * 32; i += 256) {
-    const int r = i >> 5, ch = i & 31;
-    *reinterpret_cast<uint4*>(xs + r * DL_YS + ch * 16) = ld_global_b128(p.x16 + (row0 + min(r, nrows - 1)) * D + ch * 8);
-  }
-  dl_ln_bwd<4>(p.ln, row0, nrows, blockIdx.x, sl == 0, ds, stage, tid);
-  uint4 ring[PD];                                           // (filled after the prologue: its 80 registers on top of the LayerNorm's spilled)
+  DL_STAMP(3, 0);
+  DlProB<4, true> pro;
+  pro.issue(p.ln, row0, nrows, tid);
+  uint4 ring[PD];
   int c = chunk_of(0);
 #pragma unroll
   for (int s = 0; s < PD; ++s) ring[s] = ld_global_b128(fptr(c, s));
   __builtin_amdgcn_sched_barrier(0);
+  pro.finish(p.ln, nrows, rb, sl == 0, ds, stage, tid);
   __syncthreads();
+  DL_STAMP(3, 1);
   f32x16 xacc[NT];
   dl_zero(xacc);
   const bool live = m < nrows;
   const int64_t crow = row0 + min(m, nrows - 1);
   for (int it = 0; it < nit; ++it) {
     const int cn = chunk_of(min(it + 1, nit - 1));
-    float4 bv[4], bg[4];
+    const uint4* hs = p.hsave + (((int64_t)rb * nchunk + c) * 4) * 64 + lane;
+    const uint4 a0 = ld_global_b128(hs), a1 = ld_global_b128(hs + 64), g0 = ld_global_b128(hs + 128), g1 = ld_global_b128(hs + 192);
+    f32x16 du;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      bv[q] = *reinterpret_cast<const float4*>(p.b1 + c * 32 + 8 * q + 4 * hi);
-      bg[q] = *reinterpret_cast<const float4*>(p.b1 + p.F + c * 32 + 8 * q + 4 * hi);
-    }
-    f32x16 av, ag, du;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { av[r] = 0.f; ag[r] = 0.f; du[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) du[r] = 0.f;
     uint4 ob, hf[4];
 #pragma clang loop unroll(full)
     for (int s = 0; s < STEPS; ++s) {
       const uint4 w = ring[s % PD];
-      if (s < S1) {
-        if ((s & 1) == 0) ob = dl_frag(xs, DL_YS, m, hi, s >> 1);
-        if (s & 1) mma32(ag, w, ob); else mma32(av, w, ob);
-      } else if (s < S2) {
-        ob = dl_frag(ds, DL_YS, m, hi, s - S1);
+      if (s < S2) {
+        ob = dl_frag(ds, DL_YS, m, hi, s);
         mma32(du, w, ob);
       } else {
         const int t = s - S2;
@@ -890,11 +1035,13 @@ __global__ __launch_bounds__(256, 1) void dec_ffn_bwd_kernel(DlFfnBwdArgs p) {
       }
       ring[s % PD] = ld_global_b128(s + PD < STEPS ? fptr(c, s + PD) : fptr(cn, s + PD - STEPS));
       if (s == S2 - 1) {
+        // GLU backward on the accumulators against the SAVED (value, sigmoid): u = a sg; d a = du sg; d gate = du a sg (1 - sg)
+        const uint32_t aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, gw[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
         float uu[16], da_[16], dg_[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float a = av[r] + reinterpret_cast<const float*>(&bv[r >> 2])[r & 3];
-          const float sg = fast_sigmoid(ag[r] + reinterpret_cast<const float*>(&bg[r >> 2])[r & 3]);
+          const float a = (r & 1) ? h2f_hi(aw[r >> 1]) : h2f_lo(aw[r >> 1]);
+          const float sg = (r & 1) ? h2f_hi(gw[r >> 1]) : h2f_lo(gw[r >> 1]);
           uu[r] = a * sg;
           da_[r] = du[r] * sg;
           dg_[r] = du[r] * uu[r] * (1.f - sg);
@@ -906,32 +1053,20 @@ __global__ __launch_bounds__(256, 1) void dec_ffn_bwd_kernel(DlFfnBwdArgs p) {
         store_tile_row(p.u + crow * p.F + c * 32, u0, u1, hi, live);
         store_tile_row(p.dh + crow * (2 * (int64_t)p.F) + c * 32, hf[0], hf[1], hi, live);
         store_tile_row(p.dh + crow * (2 * (int64_t)p.F) + p.F + c * 32, hf[2], hf[3], hi, live);
-        float* bp = p.bpart + (int64_t)blockIdx.x * (2 * p.F) + c * 32;
+        float* bp = p.bpart + (int64_t)rb * (2 * p.F) + c * 32;
         tile_colsum_store(da_, bp, lane, hi, live);
         tile_colsum_store(dg_, bp + p.F, lane, hi, live);
       }
     }
     c = cn;
   }
-  __syncthreads();                                          // every wave is done with the operand images
+  DL_STAMP(3, 2);
+  __syncthreads();                                          // every wave is done with the operand image
+  DL_STAMP(3, 3);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) dl_put_tile(red + wid * DL_RB * DL_RS, xacc[nt], nt * 32, lane);
   __syncthreads();
-  {
-    const int col = lane * 4;
-    float* slab = p.slabs + (int64_t)sl * p.ln.R * D;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = wid * 8 + i;
-      float4 v = *reinterpret_cast<const float4*>(red + r * DL_RS + col);
-#pragma unroll
-      for (int w = 1; w < 4; ++w) {
-        const float4 t = *reinterpret_cast<const float4*>(red + (w * DL_RB + r) * DL_RS + col);
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-      }
-      if (r < nrows) *reinterpret_cast<float4*>(slab + (row0 + r) * D + col) = v;
-    }
-  }
+  dl_store_slab16(p.slabs + (int64_t)sl * p.ln.R * D, red, row0, nrows, wid, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ attention backward, shared pieces
@@ -974,6 +1109,7 @@ __device__ __forceinline__ uint4 dl_pack8(const float* v) {
 
 // ------------------------------------------------------------------------------------------------ cross-attention backward launch
 struct DlCrossBwdArgs {
+  unsigned long long* trace;
   DlLnB ln;
   DlGeom g;
   const uint4* wo_t;       // input-gradient pack of output_proj.weight (rows = its 256 inputs)
@@ -985,7 +1121,7 @@ struct DlCrossBwdArgs {
   const uint8_t* kmask;
   int Tk;
   uint16_t* dq16;          // [R,256] out: gradient of the projected queries (weight-gradient operand of q_proj)
-  float* slabs;            // [H][R][256] out: dq_h . W_q[head rows]
+  uint16_t* slabs;         // [H][R][256] 16-bit out: dq_h . W_q[head rows]
   float scale;
 };
 
@@ -1001,45 +1137,56 @@ __device__ __forceinline__ void dl_load_kv_rows(DlKvRows& t, const uint16_t* kv,
   t.valid = (uint32_t)__ballot(ok != 0);
 }
 
-__global__ __launch_bounds__(256, 1) void dec_cross_bwd_kernel(DlCrossBwdArgs p) {
+// 8 waves: wave w takes the (utterance, key tile) pairs slot, slot + 4, ... with slot = w & 3, and ONE of the two orientations of the
+// score tile (w >> 2): 0 = lane per query (-> dq, summed over the tiles), 1 = lane per key (-> dk, dv of the tile, complete).  A wave
+// is a chain of dependent MFMA / LDS / exp steps with nothing to overlap them (10 k cycles per tile for both orientations in one
+// wave, clock stamps): two waves per tile halve it.
+__global__ __launch_bounds__(512, 1) void dec_cross_bwd_kernel(DlCrossBwdArgs p) {
   constexpr int OS = DL_DK;
   constexpr int SM_IMG = DL_RB * DL_YS, SM_H = DL_RB * DL_HS, SM_T = DL_DK * DL_VT;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SM_IMG + 3 * SM_H + 2 * SM_T + 4 * SM_T + 4 * DL_RB * 4 + DL_RB * DL_RS * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SM_IMG + 3 * SM_H + 2 * SM_T + 4 * SM_T + 8 * SM_H + 4 * DL_RB * 4 + DL_RB * DL_RS * 4];
   unsigned char* ys = smem;                       // branch gradient image (LayerNorm backward output)
   unsigned char* dos = ys + SM_IMG;               // dO [32][64]
   unsigned char* qs = dos + SM_H;                 // Q  [32][64]
   unsigned char* dqs = qs + SM_H;                 // dq [32][64]
   unsigned char* dot = dqs + SM_H;                // dO^T [64][32]
   unsigned char* qt = dot + SM_T;                 // Q^T
-  unsigned char* ktw = qt + SM_T;                 // per wave: K^T of the current key tile
-  float* lses = reinterpret_cast<float*>(ktw + 4 * SM_T);   // [32]
+  unsigned char* ktw = qt + SM_T;                 // per orientation-0 wave: K^T of the current key tile
+  unsigned char* ogw = ktw + 4 * SM_T;            // per orientation-1 wave: dk | dv tiles staged for whole-row stores
+  float* lses = reinterpret_cast<float*>(ogw + 8 * SM_H);   // [32]
   float* dels = lses + DL_RB;                               // [32]
   float* dpart = dels + DL_RB;                              // [2][32]
   float* red = dpart + 2 * DL_RB;                           // [32][DL_RS]: LayerNorm staging, then the waves' dq partials, then the output tile
-  static_assert(3 * 4 * DL_D <= DL_RB * DL_RS && 4 * DL_RB * OS <= DL_RB * DL_RS, "LDS layout");
+  static_assert(3 * 8 * DL_D <= DL_RB * DL_RS && 4 * DL_RB * OS <= DL_RB * DL_RS, "LDS layout");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = wid & 3, orient = wid >> 2;
   const int m = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y;
+  int gi, h;
+  if (!dl_block_of((int)blockIdx.x, DL_H, (p.g.B + p.g.G - 1) / p.g.G, gi, h)) return;
   int u0, nrows;
   int64_t row0;
-  dl_group(p.g, blockIdx.x, u0, row0, nrows);
+  dl_group(p.g, gi, u0, row0, nrows);
   const int nutt = nrows / p.g.L, ntile = (p.Tk + 31) >> 5, nit = nutt * ntile;
-  DlKvRows cur;
-  {
-    const int it = min(wid, nit - 1);
-    dl_load_kv_rows(cur, p.kv, p.kv_bs, p.kv_ts, p.koff, p.voff, p.kmask, p.Tk, u0 + it / ntile, (it % ntile) * 32, h, lane);
-  }
+  DL_STAMP(4, 0);
+  DlProB<8, true> pro;
+  pro.issue(p.ln, row0, nrows, tid);
+  auto load_tile = [&](DlKvRows& t, int it) {
+    const int itc = min(it, nit - 1);                                   // past the end: a valid tile, loaded and never used
+    dl_load_kv_rows(t, p.kv, p.kv_bs, p.kv_ts, p.koff, p.voff, p.kmask, p.Tk, u0 + itc / ntile, (itc % ntile) * 32, h, lane);
+  };
   DlStream<1, 16, 16> sdo;
   if (wid < 2) sdo.fill(p.wo_t, 16, 2 * h + wid, 1, 0, lane);
-  DlStream<2, 4, 8> sdy;
-  sdy.fill(p.wq_t, 16, 2 * wid, 1, 4 * h, lane);
-  dl_ln_bwd<4>(p.ln, row0, nrows, blockIdx.x, h == 0, ys, red, tid);
+  pro.finish(p.ln, nrows, gi, h == 0, ys, red, tid);
+  DlKvRows cur, alt;                                                    // issued here (the prologue's registers are free again): they land
+  load_tile(cur, slot);                                                 // under the d-context GEMM
+  load_tile(alt, slot + 4);
   __syncthreads();
+  DL_STAMP(4, 1);
   if (wid < 2) {
     dl_dctx(sdo, ys, dos, dot, dpart, p.ctx16, row0, nrows, h, wid, lane);
   } else if (wid == 2) {
-    // the head's queries: row-major and transposed images; lane -> (row lane / 2 [+ 0], 64-byte half)
+    // the head's queries: row-major and transposed images; lane -> (row lane / 2, 64-byte half)
     const int r = lane >> 1, half = lane & 1;
     const uint16_t* src = p.q16 + (row0 + min(r, nrows - 1)) * DL_D + DL_DK * h + 32 * half;
     uint4 v[4];
@@ -1053,50 +1200,46 @@ __global__ __launch_bounds__(256, 1) void dec_cross_bwd_kernel(DlCrossBwdArgs p)
       for (int e = 0; e < 8; ++e)
         *reinterpret_cast<uint16_t*>(qt + (32 * half + 8 * j + e) * DL_VT + r * 2) = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
     }
-  } else {
+  } else if (wid == 3) {
     if (lane < DL_RB) {
       const int r = min(lane, nrows - 1), ur = r / p.g.L;
       lses[lane] = p.lse[((int64_t)(u0 + ur) * DL_H + h) * p.g.L + (r - ur * p.g.L)];
     }
   }
   __syncthreads();
+  DL_STAMP(4, 2);
   if (tid < DL_RB) dels[tid] = dpart[tid] + dpart[DL_RB + tid];
   __syncthreads();
-  uint4 qf[4], dof[4];
+  // (the Q / dO operand fragments are re-read from LDS for every tile: held in registers across the loops they pushed the wave
+  // past its 256 registers, and the spills' scratch round trips cost more than 8 LDS reads)
+  float* ob = red;                                                     // [4][32][OS]: the orientation-0 waves' dq partials
+  if (orient == 0) {
+    // ---- lane = query i, registers = keys j -> dq
+    f32x16 dq[2];
+    dl_zero(dq);
+    const float my_lse = lses[m], my_del = dels[m];
+    const int my_u = m / p.g.L;
+    unsigned char* kt = ktw + slot * SM_T;
+    auto consume = [&](const DlKvRows& t, int it) {
+      const int u = it / ntile;
+      // K^T image of this tile (this wave's own): lane (j, hi) holds K[j][16 ks + 8 hi + e]
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) { qf[ks] = dl_frag(qs, DL_HS, m, hi, ks); dof[ks] = dl_frag(dos, DL_HS, m, hi, ks); }
-  const float my_lse = lses[m], my_del = dels[m];
-  const int my_u = m / p.g.L;
-  f32x16 dq[2];
-  dl_zero(dq);
-  unsigned char* kt = ktw + wid * SM_T;
-  for (int it = wid; it < nit; it += 4) {
-    const int u = it / ntile, b = u0 + u, j0 = (it % ntile) * 32;
-    DlKvRows nxt;
-    {
-      const int itn = min(it + 4, nit - 1);
-      dl_load_kv_rows(nxt, p.kv, p.kv_bs, p.kv_ts, p.koff, p.voff, p.kmask, p.Tk, u0 + itn / ntile, (itn % ntile) * 32, h, lane);
-    }
-    // K^T image of this tile (this wave's own): lane (j, hi) holds K[j][16 ks + 8 hi + e]
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint32_t w[4] = {t.k[ks].x, t.k[ks].y, t.k[ks].z, t.k[ks].w};
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const uint32_t w[4] = {cur.k[ks].x, cur.k[ks].y, cur.k[ks].z, cur.k[ks].w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        *reinterpret_cast<uint16_t*>(kt + (16 * ks + 8 * hi + e) * DL_VT + m * 2) = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
-    }
-    // ---- orientation 1: lane = query i, registers = keys j -> dq
-    {
+        for (int e = 0; e < 8; ++e)
+          *reinterpret_cast<uint16_t*>(kt + (16 * ks + 8 * hi + e) * DL_VT + m * 2) = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+      }
       f32x16 st[1], dp[1];
       dl_zero(st); dl_zero(dp);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) { mma32(st[0], cur.k[ks], qf[ks]); mma32(dp[0], cur.v[ks], dof[ks]); }
+      for (int ks = 0; ks < 4; ++ks) { mma32(st[0], t.k[ks], dl_frag(qs, DL_HS, m, hi, ks)); mma32(dp[0], t.v[ks], dl_frag(dos, DL_HS, m, hi, ks)); }
       const bool mine = my_u == u && m < nrows;
       float dsv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = 8 * (r >> 2) + 4 * hi + (r & 3);
-        const bool ok = mine && ((cur.valid >> j) & 1u);
+        const bool ok = mine && ((t.valid >> j) & 1u);
         const float pr = ok ? __expf(st[0][r] * p.scale - my_lse) : 0.f;
         dsv[r] = pr * (dp[0][r] - my_del);
       }
@@ -1107,59 +1250,98 @@ __global__ __launch_bounds__(256, 1) void dec_cross_bwd_kernel(DlCrossBwdArgs p)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) mma32(dq[ct], dl_tfrag(kt, 32 * ct + m, hi, k2), pb);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    for (int it = slot; it < nit; it += 8) {
+      consume(cur, it);
+      if (it + 4 < nit) {
+        load_tile(cur, it + 8);
+        consume(alt, it + 4);
+        load_tile(alt, it + 12);
+      }
     }
-    // ---- orientation 2: lane = key j, registers = queries i -> dk, dv of this tile (complete: one wave owns (utterance, tile))
-    {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(ob + (slot * DL_RB + m) * OS + 32 * ct + 8 * q + 4 * hi) =
+            make_float4(dq[ct][4 * q], dq[ct][4 * q + 1], dq[ct][4 * q + 2], dq[ct][4 * q + 3]);
+  } else {
+    // ---- lane = key j, registers = queries i -> dk, dv of this tile (complete: one wave owns (utterance, tile))
+    unsigned char* og = ogw + slot * (2 * SM_H);                       // this wave's dk | dv tiles on their way out ([32][64] 16-bit each)
+    auto consume = [&](const DlKvRows& t, int it) {
+      const int u = it / ntile, b = u0 + u, j0 = (it % ntile) * 32, ulo = u * p.g.L;      // the utterance's rows: ulo .. ulo + L - 1
       f32x16 st[1], dp[1];
       dl_zero(st); dl_zero(dp);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) { mma32(st[0], qf[ks], cur.k[ks]); mma32(dp[0], dof[ks], cur.v[ks]); }
-      const bool keyok = (cur.valid >> m) & 1u;
+      for (int ks = 0; ks < 4; ++ks) { mma32(st[0], dl_frag(qs, DL_HS, m, hi, ks), t.k[ks]); mma32(dp[0], dl_frag(dos, DL_HS, m, hi, ks), t.v[ks]); }
+      const bool keyok = (t.valid >> m) & 1u;
       float pv[16], dsv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = 8 * (r >> 2) + 4 * hi + (r & 3);
-        const bool ok = keyok && i < nrows && (i / p.g.L) == u;
+        const bool ok = keyok && i < nrows && i >= ulo && i < ulo + p.g.L;
         pv[r] = ok ? __expf(st[0][r] * p.scale - lses[i]) : 0.f;
         dsv[r] = pv[r] * (dp[0][r] - dels[i]) * p.scale;
       }
-      f32x16 dv[2], dk[2];
-      dl_zero(dv); dl_zero(dk);
+      // out through this wave's LDS tile: the accumulator layout gives every lane 8-byte pieces of 32 different rows (32 partial
+      // lines per store instruction); staged, an instruction writes 8 whole 128-byte rows.  dv first, then dk: one pair of
+      // accumulator tiles live at a time (the wave has 256 registers)
+      {
+        const uint4 pb0 = dl_pack8(pv), pb1 = dl_pack8(pv + 8);
+        f32x16 dv[2];
+        dl_zero(dv);
 #pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        const uint4 pb = dl_pack8(pv + 8 * k2), sb = dl_pack8(dsv + 8 * k2);
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          mma32(dv[ct], dl_tfrag(dot, 32 * ct + m, hi, k2), pb);
-          mma32(dk[ct], dl_tfrag(qt, 32 * ct + m, hi, k2), sb);
-        }
-      }
-      if (j0 + m < p.Tk) {
-        uint16_t* orow = p.dkv + (int64_t)b * p.kv_bs + (int64_t)(j0 + m) * p.kv_ts + DL_DK * h;
+        for (int ct = 0; ct < 2; ++ct) { mma32(dv[ct], dl_tfrag(dot, 32 * ct + m, hi, 0), pb0); mma32(dv[ct], dl_tfrag(dot, 32 * ct + m, hi, 1), pb1); }
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int cc = 32 * ct + 8 * q + 4 * hi;
-            *reinterpret_cast<uint2*>(orow + p.koff + cc) = make_uint2(pack2h(dk[ct][4 * q], dk[ct][4 * q + 1]), pack2h(dk[ct][4 * q + 2], dk[ct][4 * q + 3]));
-            *reinterpret_cast<uint2*>(orow + p.voff + cc) = make_uint2(pack2h(dv[ct][4 * q], dv[ct][4 * q + 1]), pack2h(dv[ct][4 * q + 2], dv[ct][4 * q + 3]));
-          }
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<uint2*>(og + SM_H + m * DL_HS + (32 * ct + 8 * q + 4 * hi) * 2) =
+                make_uint2(pack2h(dv[ct][4 * q], dv[ct][4 * q + 1]), pack2h(dv[ct][4 * q + 2], dv[ct][4 * q + 3]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const uint4 sb0 = dl_pack8(dsv), sb1 = dl_pack8(dsv + 8);
+        f32x16 dk[2];
+        dl_zero(dk);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) { mma32(dk[ct], dl_tfrag(qt, 32 * ct + m, hi, 0), sb0); mma32(dk[ct], dl_tfrag(qt, 32 * ct + m, hi, 1), sb1); }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<uint2*>(og + m * DL_HS + (32 * ct + 8 * q + 4 * hi) * 2) =
+                make_uint2(pack2h(dk[ct][4 * q], dk[ct][4 * q + 1]), pack2h(dk[ct][4 * q + 2], dk[ct][4 * q + 3]));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = 8 * q + (lane >> 3), ch = lane & 7;
+        if (j0 + j < p.Tk) {
+          uint16_t* orow = p.dkv + (int64_t)b * p.kv_bs + (int64_t)(j0 + j) * p.kv_ts + DL_DK * h + 8 * ch;
+          st_global_b128(orow + p.koff, *reinterpret_cast<const uint4*>(og + j * DL_HS + ch * 16));
+          st_global_b128(orow + p.voff, *reinterpret_cast<const uint4*>(og + SM_H + j * DL_HS + ch * 16));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    for (int it = slot; it < nit; it += 8) {
+      consume(cur, it);
+      if (it + 4 < nit) {
+        load_tile(cur, it + 8);
+        consume(alt, it + 4);
+        load_tile(alt, it + 12);
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    cur = nxt;
   }
-  // ---- the four waves' dq partials: sum -> 16-bit image + memory
-  float* ob = red;                                                     // [4][32][OS]
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<float4*>(ob + (wid * DL_RB + m) * OS + 32 * ct + 8 * q + 4 * hi) =
-          make_float4(dq[ct][4 * q], dq[ct][4 * q + 1], dq[ct][4 * q + 2], dq[ct][4 * q + 3]);
+  DL_STAMP(4, 3);
+  // ---- the four orientation-0 waves' dq partials: sum -> 16-bit image + memory
+  DlStream<1, 4, 4> sdy;                                                // (filled here: inside the loops its 16 registers spilled)
+  sdy.fill(p.wq_t, 16, wid, 1, 4 * h, lane);
   __syncthreads();
-  for (int e = tid; e < DL_RB * 16; e += 256) {
-    const int r = e >> 4, c = (e & 15) * 4;
+  {
+    const int r = tid >> 4, c = (tid & 15) * 4;                        // 512 threads: row r, four columns of the head
     float a4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -1171,24 +1353,26 @@ __global__ __launch_bounds__(256, 1) void dec_cross_bwd_kernel(DlCrossBwdArgs p)
     if (r < nrows) *reinterpret_cast<uint2*>(p.dq16 + (row0 + r) * DL_D + DL_DK * h + c) = pk;
   }
   __syncthreads();
-  f32x16 acc[2];
+  DL_STAMP(4, 4);
+  f32x16 acc[1];
   dl_zero(acc);
   sdy.run(acc, dqs, DL_HS, 0, lane);
-  dl_put_tile(red, acc[0], (2 * wid) * 32, lane);
-  dl_put_tile(red, acc[1], (2 * wid + 1) * 32, lane);
+  dl_put_tile(red, acc[0], wid * 32, lane);
   __syncthreads();
-  dl_store_slab<4>(p.slabs + (int64_t)h * p.ln.R * DL_D, red, row0, nrows, tid);
+  dl_store_slab<8>(p.slabs + (int64_t)h * p.ln.R * DL_D, red, row0, nrows, tid);
+  DL_STAMP(4, 5);
 }
 
 // ------------------------------------------------------------------------------------------------ self-attention backward launch
 struct DlSelfBwdArgs {
+  unsigned long long* trace;
   DlLnB ln;
   DlGeom g;
   const uint4* wo_t;       // input-gradient pack of output_proj.weight
   const uint4* wqkv_t;     // input-gradient pack of qvk_proj.weight: rows = 256 inputs, contraction = 768 (q | k | v)
   const uint16_t* qkv16; const uint16_t* ctx16; const float* lse;
   uint16_t* dqkv16;        // [R,768] out
-  float* slabs;            // [H][R][256] out: dqkv_h . W_qkv[head rows]
+  uint16_t* slabs;         // [H][R][256] 16-bit out: dqkv_h . W_qkv[head rows]
   float scale;
 };
 
@@ -1211,16 +1395,20 @@ __global__ __launch_bounds__(256, 1) void dec_self_bwd_kernel(DlSelfBwdArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y;
+  int gi, h;
+  if (!dl_block_of((int)blockIdx.x, DL_H, (p.g.B + p.g.G - 1) / p.g.G, gi, h)) return;
   int u0, nrows;
   int64_t row0;
-  dl_group(p.g, blockIdx.x, u0, row0, nrows);
+  dl_group(p.g, gi, u0, row0, nrows);
+  DL_STAMP(5, 0);
+  DlProB<4, true> pro;
+  pro.issue(p.ln, row0, nrows, tid);
   DlStream<1, 16, 16> sdo;
   if (wid < 2) sdo.fill(p.wo_t, 16, 2 * h + wid, 1, 0, lane);
   DlStream<2, 4, 8> sg[3];                        // the head's q, k, v columns = contraction steps 4h.., 16 + 4h.., 32 + 4h.. of the 48
 #pragma unroll
   for (int j = 0; j < 3; ++j) sg[j].fill(p.wqkv_t, 48, 2 * wid, 1, 16 * j + 4 * h, lane);
-  dl_ln_bwd<4>(p.ln, row0, nrows, blockIdx.x, h == 0, ys, red, tid);
+  pro.finish(p.ln, nrows, gi, h == 0, ys, red, tid);
   // the head's q, k, v rows: row-major images (all three), transposed images of q and k
   {
     const int part = tid >> 6;                    // wave 0: q, 1: k, 2: v, 3: the softmax statistics
@@ -1248,8 +1436,10 @@ __global__ __launch_bounds__(256, 1) void dec_self_bwd_kernel(DlSelfBwdArgs p) {
     }
   }
   __syncthreads();
+  DL_STAMP(5, 1);
   if (wid < 2) dl_dctx(sdo, ys, dos, dot, dpart, p.ctx16, row0, nrows, h, wid, lane);
   __syncthreads();
+  DL_STAMP(5, 2);
   if (tid < DL_RB) dels[tid] = dpart[tid] + dpart[DL_RB + tid];
   __syncthreads();
   if (wid == 0) {
@@ -1268,7 +1458,7 @@ __global__ __launch_bounds__(256, 1) void dec_self_bwd_kernel(DlSelfBwdArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = 8 * (r >> 2) + 4 * hi + (r & 3);
-      const bool ok = j <= i && i < nrows && (j / p.g.L) == ui;
+      const bool ok = j <= i && i < nrows && j >= ui * p.g.L;
       const float pr = ok ? __expf(st[0][r] * p.scale - my_lse) : 0.f;
       dsv[r] = pr * (dp[0][r] - my_del) * p.scale;
     }
@@ -1304,7 +1494,7 @@ __global__ __launch_bounds__(256, 1) void dec_self_bwd_kernel(DlSelfBwdArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = 8 * (r >> 2) + 4 * hi + (r & 3);
-      const bool ok = j <= i && i < nrows && (i / p.g.L) == uj;
+      const bool ok = j <= i && i < nrows && i < (uj + 1) * p.g.L;
       pv[r] = ok ? __expf(st[0][r] * p.scale - lses[i]) : 0.f;
       dsv[r] = pv[r] * (dp[0][r] - dels[i]) * p.scale;
     }
@@ -1335,6 +1525,7 @@ __global__ __launch_bounds__(256, 1) void dec_self_bwd_kernel(DlSelfBwdArgs p) {
       }
   }
   __syncthreads();
+  DL_STAMP(5, 3);
   f32x16 acc[2];
   dl_zero(acc);
 #pragma unroll
@@ -1343,16 +1534,17 @@ __global__ __launch_bounds__(256, 1) void dec_self_bwd_kernel(DlSelfBwdArgs p) {
   dl_put_tile(red, acc[1], (2 * wid + 1) * 32, lane);
   __syncthreads();
   dl_store_slab<4>(p.slabs + (int64_t)h * p.ln.R * DL_D, red, row0, nrows, tid);
+  DL_STAMP(5, 4);
 }
 
 // dx = skip + sum of slabs
-__global__ __launch_bounds__(256) void dec_sum_kernel(const float* skip, const float* slabs, int nslab, int64_t R, float* out) {
+__global__ __launch_bounds__(256) void dec_sum_kernel(const float* skip, const uint16_t* slabs, int nslab, int64_t R, float* out) {
   const int64_t n4 = R * (DL_D / 4);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     float4 a = skip ? reinterpret_cast<const float4*>(skip)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < nslab; ++s) {
-      const float4 t = reinterpret_cast<const float4*>(slabs + (int64_t)s * R * DL_D)[i];
-      a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      const uint2 t = reinterpret_cast<const uint2*>(slabs + (int64_t)s * R * DL_D)[i];
+      a.x += h2f_lo(t.x); a.y += h2f_hi(t.x); a.z += h2f_lo(t.y); a.w += h2f_hi(t.y);
     }
     reinterpret_cast<float4*>(out)[i] = a;
   }
@@ -1395,9 +1587,10 @@ int32_t dl_check_geom(const char* who, int32_t B, int32_t L, DlGeom& g) {
 }
 
 }  // namespace
+extern unsigned long long* g_otr_trace;   // api.hip (otr_debug_trace)
 
 extern "C" int32_t otr_dec_self_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t L, const void* wqkv_pack, const float* bqkv,
-                                    const void* wo_pack, void* qkv16, void* ctx16, float* lse, float* slabs, void* stream) {
+                                    const void* wo_pack, void* qkv16, void* ctx16, float* lse, void* slabs, void* stream) {
   DlSelfArgs a{};
   if (int32_t e = dl_check_geom("dec_self_fwd", B, L, a.g)) return e;
   if (int32_t e = dl_check_ln("dec_self_fwd", ln, (int64_t)B * L, a.ln)) return e;
@@ -1405,14 +1598,15 @@ extern "C" int32_t otr_dec_self_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t L
   OTR_REQUIRE(((uintptr_t)wqkv_pack | (uintptr_t)bqkv | (uintptr_t)wo_pack | (uintptr_t)qkv16 | (uintptr_t)ctx16 | (uintptr_t)slabs) % 16 == 0,
               "dec_self_fwd: buffers must be 16-byte aligned");
   a.wqkv = (const uint4*)wqkv_pack; a.bqkv = bqkv; a.wo = (const uint4*)wo_pack; a.qkv16 = (uint16_t*)qkv16; a.ctx16 = (uint16_t*)ctx16;
-  a.lse = lse; a.slabs = slabs; a.scale = 0.125f;                     // 1 / sqrt(64)
-  hipLaunchKernelGGL(dec_self_fwd_kernel, dim3((unsigned)((B + a.g.G - 1) / a.g.G), DL_H), dim3(256), 0, (hipStream_t)stream, a);
+  a.lse = lse; a.slabs = (uint16_t*)slabs; a.scale = 0.125f;          // 1 / sqrt(64)
+  a.trace = g_otr_trace;
+  hipLaunchKernelGGL(dec_self_fwd_kernel, dim3(dl_grid(DL_H, (B + a.g.G - 1) / a.g.G)), dim3(256), 0, (hipStream_t)stream, a);
   return otr_check_launch("dec_self_fwd");
 }
 
 extern "C" int32_t otr_dec_cross_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t L, const void* wq_pack, const float* bq, const void* wo_pack,
                                      const void* kv, int64_t kv_bs, int64_t kv_ts, int32_t koff, int32_t voff, const uint8_t* key_mask,
-                                     int32_t Tk, void* q16, void* ctx16, float* lse, float* slabs, void* stream) {
+                                     int32_t Tk, void* q16, void* ctx16, float* lse, void* slabs, void* stream) {
   DlCrossArgs a{};
   if (int32_t e = dl_check_geom("dec_cross_fwd", B, L, a.g)) return e;
   if (int32_t e = dl_check_ln("dec_cross_fwd", ln, (int64_t)B * L, a.ln)) return e;
@@ -1421,22 +1615,24 @@ extern "C" int32_t otr_dec_cross_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t 
   OTR_REQUIRE(((uintptr_t)wq_pack | (uintptr_t)bq | (uintptr_t)wo_pack | (uintptr_t)kv | (uintptr_t)q16 | (uintptr_t)ctx16 | (uintptr_t)slabs) % 16 == 0,
               "dec_cross_fwd: buffers must be 16-byte aligned");
   a.wq = (const uint4*)wq_pack; a.bq = bq; a.wo = (const uint4*)wo_pack; a.kv = (const uint16_t*)kv; a.kv_bs = kv_bs; a.kv_ts = kv_ts;
-  a.koff = koff; a.voff = voff; a.kmask = key_mask; a.Tk = Tk; a.q16 = (uint16_t*)q16; a.ctx16 = (uint16_t*)ctx16; a.lse = lse; a.slabs = slabs;
-  a.scale = 0.125f;
-  hipLaunchKernelGGL(dec_cross_fwd_kernel, dim3((unsigned)((B + a.g.G - 1) / a.g.G), DL_H), dim3(512), 0, (hipStream_t)stream, a);
+  a.koff = koff; a.voff = voff; a.kmask = key_mask; a.Tk = Tk; a.q16 = (uint16_t*)q16; a.ctx16 = (uint16_t*)ctx16; a.lse = lse; a.slabs = (uint16_t*)slabs;
+  a.scale = 0.125f; a.trace = g_otr_trace;
+  hipLaunchKernelGGL(dec_cross_fwd_kernel, dim3(dl_grid(DL_H, (B + a.g.G - 1) / a.g.G)), dim3(512), 0, (hipStream_t)stream, a);
   return otr_check_launch("dec_cross_fwd");
 }
 
+extern "C" int64_t otr_dec_ffn_hsave_bytes(int64_t R, int32_t F) { return R > 0 && F > 0 ? ((R + DL_RB - 1) / DL_RB) * (int64_t)(F / 32) * 4096 : 0; }
+
 extern "C" int32_t otr_dec_ffn_fwd(const otr_dec_ln_t* ln, int64_t R, const void* w1_pack, const float* b1, const void* w2_pack, int32_t F,
-                                   int32_t S, float* slabs, void* stream) {
+                                   int32_t S, void* slabs, void* hsave, void* stream) {
   DlFfnArgs a{};
   OTR_REQUIRE(R > 0 && R < (1ll << 31), "dec_ffn_fwd: bad row count");
   if (int32_t e = dl_check_ln("dec_ffn_fwd", ln, R, a.ln)) return e;
   OTR_REQUIRE(w1_pack && b1 && w2_pack && slabs, "dec_ffn_fwd: null pointer");
   OTR_REQUIRE(F > 0 && S > 0 && F % (128 * S) == 0, "dec_ffn_fwd: d_ff = %d does not split into %d slices of whole 128-unit wave rounds", F, S);
-  OTR_REQUIRE(((uintptr_t)w1_pack | (uintptr_t)b1 | (uintptr_t)w2_pack | (uintptr_t)slabs) % 16 == 0, "dec_ffn_fwd: buffers must be 16-byte aligned");
-  a.p1 = (const uint4*)w1_pack; a.b1 = b1; a.p2 = (const uint4*)w2_pack; a.slabs = slabs; a.F = F; a.S = S;
-  hipLaunchKernelGGL(dec_ffn_fwd_kernel, dim3((unsigned)((R + DL_RB - 1) / DL_RB), (unsigned)S), dim3(256), 0, (hipStream_t)stream, a);
+  OTR_REQUIRE(((uintptr_t)w1_pack | (uintptr_t)b1 | (uintptr_t)w2_pack | (uintptr_t)slabs | (uintptr_t)hsave) % 16 == 0, "dec_ffn_fwd: buffers must be 16-byte aligned");
+  a.p1 = (const uint4*)w1_pack; a.b1 = b1; a.p2 = (const uint4*)w2_pack; a.slabs = (uint16_t*)slabs; a.hsave = (uint4*)hsave; a.F = F; a.S = S; a.trace = g_otr_trace;
+  hipLaunchKernelGGL(dec_ffn_fwd_kernel, dim3(dl_grid(S, (int)((R + DL_RB - 1) / DL_RB))), dim3(256), 0, (hipStream_t)stream, a);
   return otr_check_launch("dec_ffn_fwd");
 }
 
@@ -1449,25 +1645,24 @@ extern "C" int32_t otr_dec_ln(const otr_dec_ln_t* ln, int64_t R, void* stream) {
   return otr_check_launch("dec_ln");
 }
 
-extern "C" int32_t otr_dec_ffn_bwd(const otr_dec_lnb_t* ln, int64_t R, const void* x16, const void* w1_pack, const float* b1,
-                                   const void* w2t_pack, const void* w1t_pack, int32_t F, int32_t S, void* dh, void* u, float* db1_part,
-                                   float* slabs, void* stream) {
+extern "C" int32_t otr_dec_ffn_bwd(const otr_dec_lnb_t* ln, int64_t R, const void* hsave, const void* w2t_pack, const void* w1t_pack,
+                                   int32_t F, int32_t S, void* dh, void* u, float* db1_part, void* slabs, void* stream) {
   DlFfnBwdArgs a{};
   OTR_REQUIRE(R > 0 && R < (1ll << 31), "dec_ffn_bwd: bad row count");
   if (int32_t e = dl_check_lnb("dec_ffn_bwd", ln, R, a.ln)) return e;
-  OTR_REQUIRE(x16 && w1_pack && b1 && w2t_pack && w1t_pack && dh && u && db1_part && slabs, "dec_ffn_bwd: null pointer");
+  OTR_REQUIRE(hsave && w2t_pack && w1t_pack && dh && u && db1_part && slabs, "dec_ffn_bwd: null pointer");
   OTR_REQUIRE(F > 0 && S > 0 && F % (128 * S) == 0, "dec_ffn_bwd: d_ff = %d does not split into %d slices of whole 128-unit wave rounds", F, S);
-  OTR_REQUIRE(((uintptr_t)x16 | (uintptr_t)w1_pack | (uintptr_t)b1 | (uintptr_t)w2t_pack | (uintptr_t)w1t_pack | (uintptr_t)dh | (uintptr_t)u |
+  OTR_REQUIRE(((uintptr_t)hsave | (uintptr_t)w2t_pack | (uintptr_t)w1t_pack | (uintptr_t)dh | (uintptr_t)u |
                (uintptr_t)db1_part | (uintptr_t)slabs) % 16 == 0, "dec_ffn_bwd: buffers must be 16-byte aligned");
-  a.x16 = (const uint16_t*)x16; a.p1 = (const uint4*)w1_pack; a.b1 = b1; a.p3 = (const uint4*)w2t_pack; a.p4 = (const uint4*)w1t_pack;
-  a.dh = (uint16_t*)dh; a.u = (uint16_t*)u; a.bpart = db1_part; a.slabs = slabs; a.F = F; a.S = S;
-  hipLaunchKernelGGL(dec_ffn_bwd_kernel, dim3((unsigned)((R + DL_RB - 1) / DL_RB), (unsigned)S), dim3(256), 0, (hipStream_t)stream, a);
+  a.hsave = (const uint4*)hsave; a.p3 = (const uint4*)w2t_pack; a.p4 = (const uint4*)w1t_pack;
+  a.dh = (uint16_t*)dh; a.u = (uint16_t*)u; a.bpart = db1_part; a.slabs = (uint16_t*)slabs; a.F = F; a.S = S; a.trace = g_otr_trace;
+  hipLaunchKernelGGL(dec_ffn_bwd_kernel, dim3(dl_grid(S, (int)((R + DL_RB - 1) / DL_RB))), dim3(256), 0, (hipStream_t)stream, a);
   return otr_check_launch("dec_ffn_bwd");
 }
 
 extern "C" int32_t otr_dec_cross_bwd(const otr_dec_lnb_t* ln, int32_t B, int32_t L, const void* wo_dgrad_pack, const void* wq_dgrad_pack,
                                      const void* q16, const void* ctx16, const float* lse, const void* kv, void* dkv, int64_t kv_bs,
-                                     int64_t kv_ts, int32_t koff, int32_t voff, const uint8_t* key_mask, int32_t Tk, void* dq16, float* slabs,
+                                     int64_t kv_ts, int32_t koff, int32_t voff, const uint8_t* key_mask, int32_t Tk, void* dq16, void* slabs,
                                      void* stream) {
   DlCrossBwdArgs a{};
   if (int32_t e = dl_check_geom("dec_cross_bwd", B, L, a.g)) return e;
@@ -1478,13 +1673,13 @@ extern "C" int32_t otr_dec_cross_bwd(const otr_dec_lnb_t* ln, int32_t B, int32_t
                (uintptr_t)dq16 | (uintptr_t)slabs) % 16 == 0, "dec_cross_bwd: buffers must be 16-byte aligned");
   a.wo_t = (const uint4*)wo_dgrad_pack; a.wq_t = (const uint4*)wq_dgrad_pack; a.q16 = (const uint16_t*)q16; a.ctx16 = (const uint16_t*)ctx16;
   a.lse = lse; a.kv = (const uint16_t*)kv; a.dkv = (uint16_t*)dkv; a.kv_bs = kv_bs; a.kv_ts = kv_ts; a.koff = koff; a.voff = voff;
-  a.kmask = key_mask; a.Tk = Tk; a.dq16 = (uint16_t*)dq16; a.slabs = slabs; a.scale = 0.125f;
-  hipLaunchKernelGGL(dec_cross_bwd_kernel, dim3((unsigned)((B + a.g.G - 1) / a.g.G), DL_H), dim3(256), 0, (hipStream_t)stream, a);
+  a.kmask = key_mask; a.Tk = Tk; a.dq16 = (uint16_t*)dq16; a.slabs = (uint16_t*)slabs; a.scale = 0.125f; a.trace = g_otr_trace;
+  hipLaunchKernelGGL(dec_cross_bwd_kernel, dim3(dl_grid(DL_H, (B + a.g.G - 1) / a.g.G)), dim3(512), 0, (hipStream_t)stream, a);
   return otr_check_launch("dec_cross_bwd");
 }
 
 extern "C" int32_t otr_dec_self_bwd(const otr_dec_lnb_t* ln, int32_t B, int32_t L, const void* wo_dgrad_pack, const void* wqkv_dgrad_pack,
-                                    const void* qkv16, const void* ctx16, const float* lse, void* dqkv16, float* slabs, void* stream) {
+                                    const void* qkv16, const void* ctx16, const float* lse, void* dqkv16, void* slabs, void* stream) {
   DlSelfBwdArgs a{};
   if (int32_t e = dl_check_geom("dec_self_bwd", B, L, a.g)) return e;
   if (int32_t e = dl_check_lnb("dec_self_bwd", ln, (int64_t)B * L, a.ln)) return e;
@@ -1492,16 +1687,16 @@ extern "C" int32_t otr_dec_self_bwd(const otr_dec_lnb_t* ln, int32_t B, int32_t 
   OTR_REQUIRE(((uintptr_t)wo_dgrad_pack | (uintptr_t)wqkv_dgrad_pack | (uintptr_t)qkv16 | (uintptr_t)ctx16 | (uintptr_t)dqkv16 | (uintptr_t)slabs) % 16 == 0,
               "dec_self_bwd: buffers must be 16-byte aligned");
   a.wo_t = (const uint4*)wo_dgrad_pack; a.wqkv_t = (const uint4*)wqkv_dgrad_pack; a.qkv16 = (const uint16_t*)qkv16; a.ctx16 = (const uint16_t*)ctx16;
-  a.lse = lse; a.dqkv16 = (uint16_t*)dqkv16; a.slabs = slabs; a.scale = 0.125f;
-  hipLaunchKernelGGL(dec_self_bwd_kernel, dim3((unsigned)((B + a.g.G - 1) / a.g.G), DL_H), dim3(256), 0, (hipStream_t)stream, a);
+  a.lse = lse; a.dqkv16 = (uint16_t*)dqkv16; a.slabs = (uint16_t*)slabs; a.scale = 0.125f; a.trace = g_otr_trace;
+  hipLaunchKernelGGL(dec_self_bwd_kernel, dim3(dl_grid(DL_H, (B + a.g.G - 1) / a.g.G)), dim3(256), 0, (hipStream_t)stream, a);
   return otr_check_launch("dec_self_bwd");
 }
 
-extern "C" int32_t otr_dec_sum(const float* skip, const float* slabs, int32_t nslab, int64_t R, float* out, void* stream) {
+extern "C" int32_t otr_dec_sum(const float* skip, const void* slabs, int32_t nslab, int64_t R, float* out, void* stream) {
   OTR_REQUIRE(out && R > 0 && nslab >= 0 && (nslab == 0 || slabs), "dec_sum: bad arguments");
   OTR_REQUIRE(((uintptr_t)skip | (uintptr_t)slabs | (uintptr_t)out) % 16 == 0, "dec_sum: buffers must be 16-byte aligned");
   const int64_t n4 = R * (DL_D / 4);
   hipLaunchKernelGGL(dec_sum_kernel, dim3((unsigned)((n4 + 255) / 256 > 1024 ? 1024 : (n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, skip,
-                     slabs, nslab, R, out);
+                     (const uint16_t*)slabs, nslab, R, out);
   return otr_check_launch("dec_sum");
 }

@@ -603,7 +603,6 @@ class TransformerDecoder(nn.Module):
 
     def forward(self, targets, memory, memory_mask):
         x = ops.embed_posenc(targets, self.embedding.weight)
-        mm = memory_mask.to(torch.uint8).unsqueeze(1)
         kv = None
         if (len(self.blocks) > 1 and memory.is_cuda and not any(b.src_attn.share_vk_proj for b in self.blocks)):
             # keys / values of every layer from ONE GEMM over the shared memory (ops.CrossKVAllFn)
@@ -616,6 +615,7 @@ class TransformerDecoder(nn.Module):
             # the whole stack as three launches per layer (csrc/declayer.hip): cut along (utterance group, head) / (rows, hidden slice)
             x = ops.decoder_stack(x, kv[0], ops._mask_u8(memory_mask, memory.size(0), memory.size(1)), self.blocks, S)
         else:
+            mm = memory_mask.to(torch.uint8).unsqueeze(1)
             for i, block in enumerate(self.blocks):
                 x, _ = block(x, None, memory, mm, kv_all=(kv[0], i, kv[1]) if kv is not None else None)   # None -> causal self-attention
         if self.normalize_before:

@@ -1582,7 +1582,8 @@ class DecoderStackFn(torch.autograd.Function):
         seed = rng_seed_tensor(dev) if p_drop > 0 else None
         f32 = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
         h16 = lambda *sh: torch.empty(sh, dtype=hdt, device=dev)
-        slA, slB, slC = f32(4, R, d), f32(4, R, d), f32(S, R, d)
+        slA, slB, slC = h16(4, R, d), h16(4, R, d), h16(S, R, d)       # partial sums travel 16-bit (csrc/declayer.hip: dl_store_slab)
+        need = any(ctx.needs_input_grad)
         st = _stream()
 
         def ln_out(xres_, slabs, nslab, bias, gamma, beta):
@@ -1613,8 +1614,9 @@ class DecoderStackFn(torch.autograd.Function):
             L.check(lib.otr_dec_cross_fwd(C.byref(lnB), B, Lq, _p(pk[2][0]), _p(bq), _p(pk[3][0]), _p(kv_all), T * W, W, l * 512, l * 512 + 256,
                                           _p(kmask), T, _p(q16), _p(ctx2), _p(lse2), _p(slB), st), 'otr_dec_cross_fwd')
             lnC, y2, y216, rec['ln2'] = ln_out(y1, slB, 4, bo2, g2, be2)
-            L.check(lib.otr_dec_ffn_fwd(C.byref(lnC), R, _p(pk[4][0]), _p(b1), _p(pk[4][1]), F, S, _p(slC), st), 'otr_dec_ffn_fwd')
-            rec.update(y016=y016, qkv16=qkv16, ctx1=ctx1, lse1=lse1, y116=y116, q16=q16, ctx2=ctx2, lse2=lse2, y216=y216)
+            hsave = torch.empty(lib.otr_dec_ffn_hsave_bytes(R, F) // 2, dtype=hdt, device=dev) if need else None
+            L.check(lib.otr_dec_ffn_fwd(C.byref(lnC), R, _p(pk[4][0]), _p(b1), _p(pk[4][1]), F, S, _p(slC), _p(hsave), st), 'otr_dec_ffn_fwd')
+            rec.update(hsave=hsave, y016=y016, qkv16=qkv16, ctx1=ctx1, lse1=lse1, y116=y116, q16=q16, ctx2=ctx2, lse2=lse2, y216=y216)
             layers.append(rec)
             y_in, pending = y2, (slC, S, b2, g3, be3)
         lnF, y3, y316, rec_last = ln_out(y_in, *pending)
@@ -1649,15 +1651,15 @@ class DecoderStackFn(torch.autograd.Function):
             pk, rec, o = ctx.packs[l], ctx.layers[l], DEC_LAYER_PARAMS * l
             # ---- FFN sub-layer
             dz3, da3, part3 = f32(R, d), h16(R, d), f32(nblk, 3 * d)
-            dh, u, bpart, slCb = h16(R, 2 * F), h16(R, F), f32(nblk, 2 * F), f32(S, R, d)
+            dh, u, bpart, slCb = h16(R, 2 * F), h16(R, F), f32(nblk, 2 * F), h16(S, R, d)
             lnb = _dec_lnb(dskip, slabs, nslab, rec['ln3'], g3, seed, p_drop, dz3, da3, part3)
-            P1, _, P3, P4 = pk[4]
-            L.check(lib.otr_dec_ffn_bwd(C.byref(lnb), R, _p(rec['y216']), _p(P1), _p(b1), _p(P3), _p(P4), F, S, _p(dh), _p(u), _p(bpart),
-                                        _p(slCb), st), 'otr_dec_ffn_bwd')
+            _, _, P3, P4 = pk[4]
+            L.check(lib.otr_dec_ffn_bwd(C.byref(lnb), R, _p(rec['hsave']), _p(P3), _p(P4), F, S, _p(dh), _p(u), _p(bpart), _p(slCb), st),
+                    'otr_dec_ffn_bwd')
             grads[o + 16], grads[o + 17], grads[o + 15] = _grad_b(part3[:, :d], g3), _grad_b(part3[:, d:2 * d], be3), _grad_b(part3[:, 2 * d:], b2)
             grads[o + 12], grads[o + 13], grads[o + 14] = _grad_w(dh, rec['y216'], w1), _grad_b(bpart, b1), _grad_w(da3, u, w2)
             # ---- cross-attention sub-layer
-            dz2, da2, part2, dq16, slBb = f32(R, d), h16(R, d), f32(ngrp, 3 * d), h16(R, d), f32(4, R, d)
+            dz2, da2, part2, dq16, slBb = f32(R, d), h16(R, d), f32(ngrp, 3 * d), h16(R, d), h16(4, R, d)
             if dkv is None:
                 dkv = torch.empty_like(kv_all)
             lnb = _dec_lnb(dz3, slCb, S, rec['ln2'], g2, seed, p_drop, dz2, da2, part2)
@@ -1667,7 +1669,7 @@ class DecoderStackFn(torch.autograd.Function):
             grads[o + 10], grads[o + 11], grads[o + 9] = _grad_b(part2[:, :d], g2), _grad_b(part2[:, d:2 * d], be2), _grad_b(part2[:, 2 * d:], bo2)
             grads[o + 8], grads[o + 6], grads[o + 7] = _grad_w(da2, rec['ctx2'], wo2), _grad_w(dq16, rec['y116'], wq), _grad_b(dq16, bq)
             # ---- self-attention sub-layer
-            dz1, da1, part1, dqkv16, slAb = f32(R, d), h16(R, d), f32(ngrp, 3 * d), h16(R, 3 * d), f32(4, R, d)
+            dz1, da1, part1, dqkv16, slAb = f32(R, d), h16(R, d), f32(ngrp, 3 * d), h16(R, 3 * d), h16(4, R, d)
             lnb = _dec_lnb(dz2, slBb, 4, rec['ln1'], g1, seed, p_drop, dz1, da1, part1)
             L.check(lib.otr_dec_self_bwd(C.byref(lnb), B, Lq, _p(pk[1][1]), _p(pk[0][1]), _p(rec['qkv16']), _p(rec['ctx1']), _p(rec['lse1']),
                                          _p(dqkv16), _p(slAb), st), 'otr_dec_self_bwd')
