@@ -59,28 +59,21 @@ __device__ __forceinline__ uint4 dl_frag(const unsigned char* img, int stride, i
 // slabs of the workgroup's 32 rows) before the caller starts its prefetches (weights, keys / values): vmcnt retires in order, and
 // with the prefetches issued first the LayerNorm waited for ~200 KiB it did not need (7-10 us of a 17-21 us launch, clock stamps).
 // finish() normalises and leaves the 16-bit rows in `img` ([32][DL_YS bytes]); wave w owns rows RPW w .., lane 4 consecutive columns;
-// the rows of a wave are normalised together (independent butterflies).  H16: the slabs are 16-bit (the FFN launches' partial sums:
-// up to 8 of them in flight), else fp32 (the attention launches' four head shares).
-template <int NW, bool H16> struct DlPro {
-  static constexpr int RPW = DL_RB / NW, NS = H16 ? 8 : 4, D = DL_D, PT = DL_RB * 32 / (NW * 64);
-  typedef typename std::conditional<H16, uint2, float4>::type slab_t;
-  int64_t rows[RPW];
-  float4 xr[RPW];
-  slab_t t[NS][RPW];
+// the rows of a wave are normalised together (independent butterflies).  Every slab is 16-bit.
+template <int NW, int NS> struct DlPro {
+  // NS = slabs in flight (4: the head shares, 8: the FFN slices).  Lane (hw, l32) owns columns 8 l32 .. + 7 of row 2k + hw of its
+  // wave's rows: 16-byte loads, two whole 512-byte slab rows per instruction -- the prologue's time went with the NUMBER of load
+  // instructions (63 outstanding per wave x their size is all that hides the ~2 us a row written by the previous launch is away):
+  // 8-byte pieces of one row per instruction took 20 k cycles for 8 slabs, clock stamps.
+  static constexpr int RPW = DL_RB / NW, NP = RPW / 2, D = DL_D, PT = DL_RB * 32 / (NW * 64);
+  int64_t rows[NP];
+  float4 x0[NP], x1[NP];
+  otr_u32x4 t[NS][NP];
   uint4 px[PT];
-  float4 bb, gm, bt;
+  float4 bb0, bb1, gm0, gm1, bt0, bt1;
   uint64_t seed;
   __device__ __forceinline__ void issue(const DlLn& p, int64_t row0, int nrows, int tid) {
-    const int lane = tid & 63, wid = tid >> 6, col = lane * 4;
-    // EVERY load of the prologue goes out here, the small ones included: one issued later queues behind the caller's prefetches
-    bb = make_float4(0.f, 0.f, 0.f, 0.f);
-    seed = 0;
-    if (p.nslab != 0) {
-      if (p.bias) bb = *reinterpret_cast<const float4*>(p.bias + col);
-      gm = *reinterpret_cast<const float4*>(p.gamma + col);
-      bt = *reinterpret_cast<const float4*>(p.beta + col);
-      if (p.p_drop > 0.f) seed = *p.seed;
-    }
+    const int lane = tid & 63, wid = tid >> 6, hw = lane >> 5, col = (lane & 31) * 8;
     if (p.nslab == 0) {
 #pragma unroll
       for (int k = 0; k < PT; ++k) {
@@ -89,23 +82,30 @@ template <int NW, bool H16> struct DlPro {
       }
       return;
     }
+    // EVERY load of the prologue goes out here, the small ones included: one issued later queues behind the caller's prefetches
+    bb0 = bb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) { bb0 = *reinterpret_cast<const float4*>(p.bias + col); bb1 = *reinterpret_cast<const float4*>(p.bias + col + 4); }
+    gm0 = *reinterpret_cast<const float4*>(p.gamma + col); gm1 = *reinterpret_cast<const float4*>(p.gamma + col + 4);
+    bt0 = *reinterpret_cast<const float4*>(p.beta + col); bt1 = *reinterpret_cast<const float4*>(p.beta + col + 4);
+    seed = p.p_drop > 0.f ? *p.seed : 0;
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      rows[i] = row0 + min(wid * RPW + i, nrows - 1);
-      xr[i] = *reinterpret_cast<const float4*>(p.xres + rows[i] * D + col);
+    for (int k = 0; k < NP; ++k) {
+      rows[k] = row0 + min(wid * RPW + 2 * k + hw, nrows - 1);
+      x0[k] = *reinterpret_cast<const float4*>(p.xres + rows[k] * D + col);
+      x1[k] = *reinterpret_cast<const float4*>(p.xres + rows[k] * D + col + 4);
     }
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int ss = min(s, p.nslab - 1);
+    for (int s = 0; s < NS; ++s)
+      if (s < p.nslab) {
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        if constexpr (H16) t[s][i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.slabs) + ((int64_t)ss * p.R + rows[i]) * D + col);
-        else t[s][i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.slabs) + ((int64_t)ss * p.R + rows[i]) * D + col);
+        for (int k = 0; k < NP; ++k) {
+          const uint4 q = ld_global_b128(reinterpret_cast<const uint16_t*>(p.slabs) + ((int64_t)s * p.R + rows[k]) * D + col);
+          t[s][k] = otr_u32x4{q.x, q.y, q.z, q.w};
+        }
       }
-    }
   }
   __device__ __forceinline__ void finish(const DlLn& p, int nrows, bool write, unsigned char* img, int tid) {
-    const int lane = tid & 63, wid = tid >> 6, col = lane * 4;
+    const int lane = tid & 63, wid = tid >> 6, hw = lane >> 5, col = (lane & 31) * 8;
     if (p.nslab == 0) {
 #pragma unroll
       for (int k = 0; k < PT; ++k) {
@@ -117,76 +117,74 @@ template <int NW, bool H16> struct DlPro {
     const bool drop = p.p_drop > 0.f;
     const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
     const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
-    float a[RPW][4];
+    const float bb[8] = {bb0.x, bb0.y, bb0.z, bb0.w, bb1.x, bb1.y, bb1.z, bb1.w};
+    const float g8[8] = {gm0.x, gm0.y, gm0.z, gm0.w, gm1.x, gm1.y, gm1.z, gm1.w};
+    const float b8[8] = {bt0.x, bt0.y, bt0.z, bt0.w, bt1.x, bt1.y, bt1.z, bt1.w};
+    float v[NP][8], sm[NP], qq[NP];
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) { a[i][0] = bb.x; a[i][1] = bb.y; a[i][2] = bb.z; a[i][3] = bb.w; }
+    for (int k = 0; k < NP; ++k) {
+      float a[8];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const float live = s < p.nslab ? 1.f : 0.f;
+      for (int e = 0; e < 8; ++e) a[e] = bb[e];
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        if constexpr (H16) {
-          a[i][0] += live * h2f_lo(t[s][i].x); a[i][1] += live * h2f_hi(t[s][i].x); a[i][2] += live * h2f_lo(t[s][i].y); a[i][3] += live * h2f_hi(t[s][i].y);
-        } else {
-          a[i][0] += live * t[s][i].x; a[i][1] += live * t[s][i].y; a[i][2] += live * t[s][i].z; a[i][3] += live * t[s][i].w;
+      for (int s = 0; s < NS; ++s)
+        if (s < p.nslab) {
+          const uint32_t w[4] = {t[s][k].x, t[s][k].y, t[s][k].z, t[s][k].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a[2 * e] += h2f_lo(w[e]); a[2 * e + 1] += h2f_hi(w[e]); }
         }
+      for (int s = NS; s < p.nslab; ++s) {               // more slabs than fit in flight (not the shipped shapes): one after the other
+        const uint4 q = ld_global_b128(reinterpret_cast<const uint16_t*>(p.slabs) + ((int64_t)s * p.R + rows[k]) * D + col);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[2 * e] += h2f_lo(w[e]); a[2 * e + 1] += h2f_hi(w[e]); }
       }
-    }
-    for (int s = NS; s < p.nslab; ++s)                   // more slabs than fit in flight (not the shipped shapes): one after the other
+      const float xv[8] = {x0[k].x, x0[k].y, x0[k].z, x0[k].w, x1[k].x, x1[k].y, x1[k].z, x1[k].w};
+      sm[k] = 0.f;
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        if constexpr (H16) {
-          const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.slabs) + ((int64_t)s * p.R + rows[i]) * D + col);
-          a[i][0] += h2f_lo(q.x); a[i][1] += h2f_hi(q.x); a[i][2] += h2f_lo(q.y); a[i][3] += h2f_hi(q.y);
-        } else {
-          const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.slabs) + ((int64_t)s * p.R + rows[i]) * D + col);
-          a[i][0] += q.x; a[i][1] += q.y; a[i][2] += q.z; a[i][3] += q.w;
-        }
-      }
-    float v[RPW][4], sm[RPW], qq[RPW];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const float xv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
-      sm[i] = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < 8; ++e) {
         float sc = 1.f;
-        if (drop) sc = otr_rand32(seed, p.rng_offset + (uint64_t)(rows[i] * D + col + e)) >= thr ? inv_keep : 0.f;
-        v[i][e] = xv[e] + a[i][e] * sc;
-        sm[i] += v[i][e];
+        if (drop) sc = otr_rand32(seed, p.rng_offset + (uint64_t)(rows[k] * D + col + e)) >= thr ? inv_keep : 0.f;
+        v[k][e] = xv[e] + a[e] * sc;
+        sm[k] += v[k][e];
       }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
+    for (int o = 16; o > 0; o >>= 1)
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) sm[i] += __shfl_xor(sm[i], o);
+      for (int k = 0; k < NP; ++k) sm[k] += __shfl_xor(sm[k], o);
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      sm[i] *= (1.f / D);
-      qq[i] = 0.f;
+    for (int k = 0; k < NP; ++k) {
+      sm[k] *= (1.f / D);
+      qq[k] = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - sm[i]; qq[i] += d * d; }
+      for (int e = 0; e < 8; ++e) { const float d = v[k][e] - sm[k]; qq[k] += d * d; }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
+    for (int o = 16; o > 0; o >>= 1)
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) qq[i] += __shfl_xor(qq[i], o);
-    const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
+      for (int k = 0; k < NP; ++k) qq[k] += __shfl_xor(qq[k], o);
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int r = wid * RPW + i;
-      const float mean = sm[i], rstd = rsqrtf(qq[i] * (1.f / D) + p.eps);
-      float o[4];
+    for (int k = 0; k < NP; ++k) {
+      const int r = wid * RPW + 2 * k + hw;
+      const int64_t row = rows[k];
+      const float mean = sm[k], rstd = rsqrtf(qq[k] * (1.f / D) + p.eps);
+      float o[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
-      const uint2 h = make_uint2(pack2h(o[0], o[1]), pack2h(o[2], o[3]));
-      *reinterpret_cast<uint2*>(img + r * DL_YS + col * 2) = h;
+      for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mean) * rstd * g8[e] + b8[e];
+      const uint4 h = make_uint4(pack2h(o[0], o[1]), pack2h(o[2], o[3]), pack2h(o[4], o[5]), pack2h(o[6], o[7]));
+      *reinterpret_cast<uint4*>(img + r * DL_YS + col * 2) = h;
       if (write && r < nrows) {
-        const int64_t row = rows[i];
-        if (p.z) *reinterpret_cast<float4*>(p.z + row * D + col) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
-        if (p.y) *reinterpret_cast<float4*>(p.y + row * D + col) = make_float4(o[0], o[1], o[2], o[3]);
-        if (p.y16) *reinterpret_cast<uint2*>(p.y16 + row * D + col) = h;
-        if (lane == 0) {
+        if (p.z) {
+          *reinterpret_cast<float4*>(p.z + row * D + col) = make_float4(v[k][0], v[k][1], v[k][2], v[k][3]);
+          *reinterpret_cast<float4*>(p.z + row * D + col + 4) = make_float4(v[k][4], v[k][5], v[k][6], v[k][7]);
+        }
+        if (p.y) {
+          *reinterpret_cast<float4*>(p.y + row * D + col) = make_float4(o[0], o[1], o[2], o[3]);
+          *reinterpret_cast<float4*>(p.y + row * D + col + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        if (p.y16) *reinterpret_cast<uint4*>(p.y16 + row * D + col) = h;
+        if ((lane & 31) == 0) {
           if (p.mean) p.mean[row] = mean;
           if (p.rstd) p.rstd[row] = rstd;
         }
@@ -306,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void dec_self_fwd_kernel(DlSelfArgs p) {
   int64_t row0;
   dl_group(p.g, gi, u0, row0, nrows);
   DL_STAMP(0, 0);
-  DlPro<4, true> pro;                                                  // its loads go out first: vmcnt retires in order
+  DlPro<4, 8> pro;                                                     // its loads go out first: vmcnt retires in order
   pro.issue(p.ln, row0, nrows, tid);
   DlStream<2, 16, 32> sq;                                             // all 32 fragments of a wave in flight: one round trip
   float4 bq4[2][4];
@@ -465,7 +463,7 @@ __global__ __launch_bounds__(512, 1) void dec_cross_fwd_kernel(DlCrossArgs p) {
   dl_group(p.g, gi, u0, row0, nrows);
   const int nutt = nrows / p.g.L, ntile = (p.Tk + 31) >> 5, nit = nutt * ntile;
   DL_STAMP(1, 0);
-  DlPro<8, true> pro;
+  DlPro<8, 4> pro;
   pro.issue(p.ln, row0, nrows, tid);
   // the first key / value tile of this wave travels under the prologue and the q projection (it does not depend on them)
   DlKvTile cur;
@@ -675,7 +673,7 @@ __global__ __launch_bounds__(256, 1) void dec_ffn_fwd_kernel(DlFfnArgs p) {
     return P2 + (int64_t)((t >> 1) * (2 * nchunk) + 2 * c + (t & 1)) * 64;
   };
   DL_STAMP(2, 0);
-  DlPro<4, true> pro;
+  DlPro<4, 4> pro;
   pro.issue(p.ln, row0, nrows, tid);
   uint4 ring[PD];
   int c = chunk_of(0);
@@ -832,120 +830,118 @@ struct DlLnB {
 
 // LayerNorm backward of rows row0 .. (clamped to nrows), in two steps like DlPro: issue() starts every global load, finish() leaves
 // the 16-bit branch gradient in `img` ([32][DL_YS]) as MFMA B operands.  stage: [3][NW][256] floats of LDS scratch; finish() contains
-// two __syncthreads when `write` (block-uniform).  H16: the slabs are 16-bit (the FFN backward launch's shares).
-template <int NW, bool H16> struct DlProB {
-  static constexpr int RPW = DL_RB / NW, NS = H16 ? 8 : 4, D = DL_D;
-  typedef typename std::conditional<H16, uint2, float4>::type slab_t;
-  int64_t rows[RPW];
-  float4 zv[RPW], dk[RPW];
-  float mean[RPW], rstd[RPW];
-  slab_t t[NS][RPW];
-  float4 gm4;
+// two __syncthreads when `write` (block-uniform).  NS = slabs in flight.
+template <int NW, int NS> struct DlProB {
+  static constexpr int RPW = DL_RB / NW, NP = RPW / 2, D = DL_D;
+  int64_t rows[NP];
+  float4 z0[NP], z1[NP], k0[NP], k1[NP];
+  float mean[NP], rstd[NP];
+  otr_u32x4 t[NS][NP];
+  float4 gm0, gm1;
   uint64_t seed;
   __device__ __forceinline__ void issue(const DlLnB& p, int64_t row0, int nrows, int tid) {
-    const int lane = tid & 63, wid = tid >> 6, col = lane * 4;
-    gm4 = *reinterpret_cast<const float4*>(p.gamma + col);
+    const int lane = tid & 63, wid = tid >> 6, hw = lane >> 5, col = (lane & 31) * 8;
+    gm0 = *reinterpret_cast<const float4*>(p.gamma + col); gm1 = *reinterpret_cast<const float4*>(p.gamma + col + 4);
     seed = p.p_drop > 0.f ? *p.seed : 0;
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      rows[i] = row0 + min(wid * RPW + i, nrows - 1);
-      zv[i] = *reinterpret_cast<const float4*>(p.z + rows[i] * D + col);
-      mean[i] = p.mean[rows[i]]; rstd[i] = p.rstd[rows[i]];
-      dk[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.dskip) dk[i] = *reinterpret_cast<const float4*>(p.dskip + rows[i] * D + col);
+    for (int k = 0; k < NP; ++k) {
+      rows[k] = row0 + min(wid * RPW + 2 * k + hw, nrows - 1);
+      z0[k] = *reinterpret_cast<const float4*>(p.z + rows[k] * D + col);
+      z1[k] = *reinterpret_cast<const float4*>(p.z + rows[k] * D + col + 4);
+      mean[k] = p.mean[rows[k]]; rstd[k] = p.rstd[rows[k]];
+      k0[k] = k1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.dskip) { k0[k] = *reinterpret_cast<const float4*>(p.dskip + rows[k] * D + col); k1[k] = *reinterpret_cast<const float4*>(p.dskip + rows[k] * D + col + 4); }
     }
-    if (p.nslab > 0) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const int ss = min(s, p.nslab - 1);
+    for (int s = 0; s < NS; ++s)
+      if (s < p.nslab) {
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-          if constexpr (H16) t[s][i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.slabs) + ((int64_t)ss * p.R + rows[i]) * D + col);
-          else t[s][i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.slabs) + ((int64_t)ss * p.R + rows[i]) * D + col);
+        for (int k = 0; k < NP; ++k) {
+          const uint4 q = ld_global_b128(reinterpret_cast<const uint16_t*>(p.slabs) + ((int64_t)s * p.R + rows[k]) * D + col);
+          t[s][k] = otr_u32x4{q.x, q.y, q.z, q.w};
         }
       }
-    }
   }
   __device__ __forceinline__ void finish(const DlLnB& p, int nrows, int block, bool write, unsigned char* img, float* stage, int tid) {
-    const int lane = tid & 63, wid = tid >> 6, col = lane * 4;
+    const int lane = tid & 63, wid = tid >> 6, hw = lane >> 5, col = (lane & 31) * 8;
     const bool drop = p.p_drop > 0.f;
     const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
     const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
-    const float gam[4] = {gm4.x, gm4.y, gm4.z, gm4.w};
-    float d4[RPW][4];
+    const float gam[8] = {gm0.x, gm0.y, gm0.z, gm0.w, gm1.x, gm1.y, gm1.z, gm1.w};
+    float d8[NP][8];
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) { d4[i][0] = dk[i].x; d4[i][1] = dk[i].y; d4[i][2] = dk[i].z; d4[i][3] = dk[i].w; }
-    if (p.nslab > 0) {
+    for (int k = 0; k < NP; ++k) {
+      d8[k][0] = k0[k].x; d8[k][1] = k0[k].y; d8[k][2] = k0[k].z; d8[k][3] = k0[k].w; d8[k][4] = k1[k].x; d8[k][5] = k1[k].y; d8[k][6] = k1[k].z; d8[k][7] = k1[k].w;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const float live = s < p.nslab ? 1.f : 0.f;
+      for (int s = 0; s < NS; ++s)
+        if (s < p.nslab) {
+          const uint32_t w[4] = {t[s][k].x, t[s][k].y, t[s][k].z, t[s][k].w};
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-          if constexpr (H16) {
-            d4[i][0] += live * h2f_lo(t[s][i].x); d4[i][1] += live * h2f_hi(t[s][i].x); d4[i][2] += live * h2f_lo(t[s][i].y); d4[i][3] += live * h2f_hi(t[s][i].y);
-          } else {
-            d4[i][0] += live * t[s][i].x; d4[i][1] += live * t[s][i].y; d4[i][2] += live * t[s][i].z; d4[i][3] += live * t[s][i].w;
-          }
+          for (int e = 0; e < 4; ++e) { d8[k][2 * e] += h2f_lo(w[e]); d8[k][2 * e + 1] += h2f_hi(w[e]); }
         }
+      for (int s = NS; s < p.nslab; ++s) {
+        const uint4 q = ld_global_b128(reinterpret_cast<const uint16_t*>(p.slabs) + ((int64_t)s * p.R + rows[k]) * D + col);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { d8[k][2 * e] += h2f_lo(w[e]); d8[k][2 * e + 1] += h2f_hi(w[e]); }
       }
-      for (int s = NS; s < p.nslab; ++s)
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-          if constexpr (H16) {
-            const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.slabs) + ((int64_t)s * p.R + rows[i]) * D + col);
-            d4[i][0] += h2f_lo(q.x); d4[i][1] += h2f_hi(q.x); d4[i][2] += h2f_lo(q.y); d4[i][3] += h2f_hi(q.y);
-          } else {
-            const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.slabs) + ((int64_t)s * p.R + rows[i]) * D + col);
-            d4[i][0] += q.x; d4[i][1] += q.y; d4[i][2] += q.z; d4[i][3] += q.w;
-          }
-        }
     }
-    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dab[4] = {0.f, 0.f, 0.f, 0.f};
-    float z4[RPW][4], s1[RPW], s2[RPW];
+    float dg[8], db[8], dab[8], z8[NP][8], s1[NP], s2[NP];
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const float live = wid * RPW + i < nrows ? 1.f : 0.f;
-      const float zz[4] = {zv[i].x, zv[i].y, zv[i].z, zv[i].w};
-      s1[i] = 0.f; s2[i] = 0.f;
+    for (int e = 0; e < 8; ++e) { dg[e] = 0.f; db[e] = 0.f; dab[e] = 0.f; }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        d4[i][e] *= live;
-        z4[i][e] = (zz[e] - mean[i]) * rstd[i];
-        const float g = d4[i][e] * gam[e];
-        s1[i] += g; s2[i] += g * z4[i][e];
-        dg[e] += d4[i][e] * z4[i][e];
-        db[e] += d4[i][e];
+    for (int k = 0; k < NP; ++k) {
+      const float live = wid * RPW + 2 * k + hw < nrows ? 1.f : 0.f;
+      const float zz[8] = {z0[k].x, z0[k].y, z0[k].z, z0[k].w, z1[k].x, z1[k].y, z1[k].z, z1[k].w};
+      s1[k] = 0.f; s2[k] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        d8[k][e] *= live;
+        z8[k][e] = (zz[e] - mean[k]) * rstd[k];
+        const float g = d8[k][e] * gam[e];
+        s1[k] += g; s2[k] += g * z8[k][e];
+        dg[e] += d8[k][e] * z8[k][e];
+        db[e] += d8[k][e];
       }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
+    for (int o = 16; o > 0; o >>= 1)
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
+      for (int k = 0; k < NP; ++k) { s1[k] += __shfl_xor(s1[k], o); s2[k] += __shfl_xor(s2[k], o); }
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int r = wid * RPW + i;
-      const float m1 = s1[i] * (1.f / D), m2 = s2[i] * (1.f / D);
-      float dz[4], da[4];
+    for (int k = 0; k < NP; ++k) {
+      const int r = wid * RPW + 2 * k + hw;
+      const float m1 = s1[k] * (1.f / D), m2 = s2[k] * (1.f / D);
+      float dz[8], da[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        dz[e] = rstd[i] * (d4[i][e] * gam[e] - m1 - z4[i][e] * m2);
-        const float sc = drop ? (otr_rand32(seed, p.rng_offset + (uint64_t)(rows[i] * D + col + e)) >= thr ? inv_keep : 0.f) : 1.f;
+      for (int e = 0; e < 8; ++e) {
+        dz[e] = rstd[k] * (d8[k][e] * gam[e] - m1 - z8[k][e] * m2);
+        const float sc = drop ? (otr_rand32(seed, p.rng_offset + (uint64_t)(rows[k] * D + col + e)) >= thr ? inv_keep : 0.f) : 1.f;
         da[e] = dz[e] * sc;
         dab[e] += da[e];
       }
-      const uint2 h = make_uint2(pack2h(da[0], da[1]), pack2h(da[2], da[3]));
-      *reinterpret_cast<uint2*>(img + r * DL_YS + col * 2) = h;
+      const uint4 h = make_uint4(pack2h(da[0], da[1]), pack2h(da[2], da[3]), pack2h(da[4], da[5]), pack2h(da[6], da[7]));
+      *reinterpret_cast<uint4*>(img + r * DL_YS + col * 2) = h;
       if (write && r < nrows) {
-        if (p.dz) *reinterpret_cast<float4*>(p.dz + rows[i] * D + col) = make_float4(dz[0], dz[1], dz[2], dz[3]);
-        if (p.da16) *reinterpret_cast<uint2*>(p.da16 + rows[i] * D + col) = h;
+        if (p.dz) {
+          *reinterpret_cast<float4*>(p.dz + rows[k] * D + col) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+          *reinterpret_cast<float4*>(p.dz + rows[k] * D + col + 4) = make_float4(dz[4], dz[5], dz[6], dz[7]);
+        }
+        if (p.da16) *reinterpret_cast<uint4*>(p.da16 + rows[k] * D + col) = h;
       }
     }
     if (write && p.partial) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        stage[(0 * NW + wid) * D + col + e] = dg[e];
-        stage[(1 * NW + wid) * D + col + e] = db[e];
-        stage[(2 * NW + wid) * D + col + e] = dab[e];
+      for (int e = 0; e < 8; ++e) {                     // the two half-waves hold different rows of the same columns
+        dg[e] += __shfl_xor(dg[e], 32); db[e] += __shfl_xor(db[e], 32); dab[e] += __shfl_xor(dab[e], 32);
+      }
+      if (hw == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          stage[(0 * NW + wid) * D + col + e] = dg[e];
+          stage[(1 * NW + wid) * D + col + e] = db[e];
+          stage[(2 * NW + wid) * D + col + e] = dab[e];
+        }
       }
       __syncthreads();
       float* prow = p.partial + (int64_t)block * 3 * D;
@@ -1001,7 +997,7 @@ __global__ __launch_bounds__(256, 1) void dec_ffn_bwd_kernel(DlFfnBwdArgs p) {
     return P4 + (int64_t)((t >> 2) * (4 * nchunk) + ksf) * 64;
   };
   DL_STAMP(3, 0);
-  DlProB<4, true> pro;
+  DlProB<4, 4> pro;
   pro.issue(p.ln, row0, nrows, tid);
   uint4 ring[PD];
   int c = chunk_of(0);
@@ -1169,7 +1165,7 @@ __global__ __launch_bounds__(512, 1) void dec_cross_bwd_kernel(DlCrossBwdArgs p)
   dl_group(p.g, gi, u0, row0, nrows);
   const int nutt = nrows / p.g.L, ntile = (p.Tk + 31) >> 5, nit = nutt * ntile;
   DL_STAMP(4, 0);
-  DlProB<8, true> pro;
+  DlProB<8, 8> pro;
   pro.issue(p.ln, row0, nrows, tid);
   auto load_tile = [&](DlKvRows& t, int it) {
     const int itc = min(it, nit - 1);                                   // past the end: a valid tile, loaded and never used
@@ -1401,7 +1397,7 @@ __global__ __launch_bounds__(256, 1) void dec_self_bwd_kernel(DlSelfBwdArgs p) {
   int64_t row0;
   dl_group(p.g, gi, u0, row0, nrows);
   DL_STAMP(5, 0);
-  DlProB<4, true> pro;
+  DlProB<4, 4> pro;
   pro.issue(p.ln, row0, nrows, tid);
   DlStream<1, 16, 16> sdo;
   if (wid < 2) sdo.fill(p.wo_t, 16, 2 * h + wid, 1, 0, lane);
