@@ -63,6 +63,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='timed region only (profiler runs): no breakdown, no roofline, no bf16 line')
     ap.add_argument('--no-bf16-line', action='store_true', help='skip the secondary bf16 measurement of the same workload')
+    ap.add_argument('--overlap', action='store_true',
+                    help='N > 1: reduce the decoder group on a side stream while the encoder backward runs (two collectives; the step '
+                         'then launches eagerly: a collective inside a captured graph is not used)')
     ap.add_argument('--cpu-threads', type=int, default=0, help='torch threads of the CPU baseline (0 = best of 16 / 32 / 64)')
     return ap.parse_args()
 
@@ -312,7 +315,8 @@ def main():
         model = ota.SpeechToText(cfg)
         syn.fill_state_dict_(model.state_dict(), 1234)           # identical replicas on every rank
         model = model.to(dev).train()
-        dp = FlatDataParallel(model)
+        overlap = args.overlap and world > 1
+        dp = FlatDataParallel(model, early_modules=([model.decoder] + ([model.assistor] if hasattr(model, 'assistor') else [])) if overlap else None)
         dp.broadcast_parameters()
         opt = FusedAdam(dp, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6, clip_grad=5.0,
                         noam=dict(model_size=cfg['encoder']['d_model'], warmup_steps=12000, factor=1.0))   # *_baseline.yaml train section
@@ -326,7 +330,7 @@ def main():
             loss_buf.copy_(loss.detach())
 
         graph = None
-        if not args.no_graph:
+        if not args.no_graph and not overlap:
             try:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
@@ -407,6 +411,13 @@ def main():
         ev[1].record()
         torch.cuda.synchronize()
         parts['allreduce_ms'] = ev[0].elapsed_time(ev[1]) / 5
+        # what the step pays for it: the same steps with every collective skipped (gradients are then wrong: timing only)
+        dp.skip_collectives = True
+        t_skip = timed(step, 2, args.steps) / args.steps * 1e3
+        dp.skip_collectives = False
+        parts['ms_per_step_without_collectives'] = t_skip
+        parts['exposed_allreduce_ms'] = elapsed / args.steps * 1e3 - t_skip
+        parts['overlap'] = bool(args.overlap)
         parts['allreduce_bytes'] = dp.flat_grad.numel() * dp.flat_grad.element_size()
         parts['nranks'] = dist.get_world_size()
     kern = instrumented_step(ops, fwd_bwd, args.mode) if (rank == 0 and not args.no_extras) else None

@@ -19,14 +19,20 @@ from . import _lib as L
 
 
 class FlatDataParallel:
-    def __init__(self, module, process_group=None, flatten_params=True, comm='torch', grad_comm_dtype=None):
+    def __init__(self, module, process_group=None, flatten_params=True, comm='torch', grad_comm_dtype=None, early_modules=None):
         """comm: 'torch' = torch.distributed all_reduce (backend "nccl" IS RCCL on ROCm; gloo in the CPU tests), or
         'rccl' = the library's own communicator (otr_allreduce_*, include/otrans_hip.h): the collective is issued on the
         compute stream through the C ABI, torch.distributed only ships the 128-byte unique id at start-up.
         grad_comm_dtype: None = all-reduce the fp32 flat buffer (bit-exact sum order aside); torch.bfloat16 / torch.float16
         = all-reduce a 16-bit copy (half the xGMI bytes: 73 MB instead of 146 MB for the AISHELL transformer) and widen the
         sum back into the fp32 buffer -- bf16 keeps fp32's exponent range, so loss-scaled fp16-mode gradients cannot
-        overflow in the payload."""
+        overflow in the payload.
+        early_modules: sub-modules whose gradients are COMPLETE before the rest of the backward pass runs -- for SpeechToText the
+        decoder (+ the CTC head): their backward precedes the encoder's.  Their parameters take the front of the flat buffers, and
+        when the model signals that point (ops.early_mark on the encoder output, see model.SpeechToText.forward) their slice is
+        all-reduced on a side stream WHILE the encoder / frontend backward runs; all_reduce_gradients() then reduces only the rest
+        and joins.  Two collectives instead of one; same sums (the reference's nn.DataParallel reduces per parameter,
+        train/trainer.py:56-66).  None = one collective at the end."""
         self.module = module
         self.group = process_group
         assert comm in ('torch', 'rccl')
@@ -42,11 +48,21 @@ class FlatDataParallel:
         # every parameter starts on a 64-element (256-byte) boundary of the flat buffers: gradient kernels then see
         # 16-byte aligned outputs whatever the sizes before them (a 4234-wide bias would misalign everything after it)
         ALIGN = 64
-        offs, total = [], 0
-        for p in params:
-            offs.append(total)
-            total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        early_ids = set()
+        for m in (early_modules or []):
+            early_ids.update(id(p) for p in m.parameters())
+        offs, total = [None] * len(params), 0
+        for want_early in (True, False):            # the early group first: [0, early_end), then everything else
+            for i, p in enumerate(params):
+                if (id(p) in early_ids) == want_early:
+                    offs[i] = total
+                    total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            if want_early:
+                self.early_end = total
         self.offsets = offs
+        self._early_state = None                    # None: not issued this step; else (work handle or None, payload slice or None)
+        self._side = None
+        self.skip_collectives = False               # measurement only (bench.py: exposed all-reduce time = step - step without)
         self.numel = total                                  # flat length incl. alignment gaps
         self.param_numel = sum(p.numel() for p in params)   # true parameter count
         padded = total
@@ -76,29 +92,36 @@ class FlatDataParallel:
                 for p, off in zip(params, offs):
                     n = p.numel()
                     p._otr_lp_view = self.flat_param_lp[off:off + n].view(p.shape)
-                # transposed bf16 shadows of the 2-D weights ([K,N]: dgrad becomes a forward-type GEMM)
+                self._build_ffn_packs(module, dev)
+                # transposed bf16 shadows of the 2-D weights ([K,N]: dgrad becomes a forward-type GEMM) -- except the weights that
+                # have fragment-major packs (the FFNs' w_1 / w_2, the 256- and 768-wide projections: 33 of the 36.5 M parameters
+                # of the AISHELL model): their input gradients run on the packs, and refreshing 66 MB of transposes nobody reads
+                # cost 35 us of every step.  A path that does not take the packs (fewer than 1024 rows) finds no transposed
+                # shadow for them and uses the plain input-gradient GEMM (ops.weight_lpt returns None).
                 self.flat_param_lpt = torch.empty(padded, device=dev, dtype=ops.half_dtype())
                 table, tiles = [], 0
                 for p, off in zip(params, offs):
                     n = p.numel()
-                    if p.dim() == 2:
+                    if p.dim() == 2 and getattr(p, '_otr_lin_packs', None) is None and id(p) not in self._ffn_packed:
                         p._otr_lpt_view = self.flat_param_lpt[off:off + n].view(p.shape[1], p.shape[0])
                         table.append([off, p.shape[0], p.shape[1], tiles])
                         tiles += ((p.shape[0] + 63) // 64) * ((p.shape[1] + 63) // 64)
-                # one launch transposes every 2-D shadow (include/otrans_hip.h: otr_transpose_batched)
+                # one launch transposes every such shadow (include/otrans_hip.h: otr_transpose_batched)
                 self._lpt_table = torch.tensor(table, dtype=torch.int64, device=dev).reshape(-1, 4)
                 self._lpt_tiles = tiles
-                self._build_ffn_packs(module, dev)
                 self.refresh_lp()
         if dev.type == 'cuda':
             from . import ops
             ops.defer_weight_grads(True)    # weight / bias gradients run as grouped launches at the end of backward
+        if self.early_end > 0:
+            from . import ops
+            ops.set_early_callback(self._on_early_ready)
 
     def _build_ffn_packs(self, module, dev):
         """Fragment-major copies of every GLU FFN's weights for the row-block fused FFN kernels (ops.FfnLnFn): one flat
         buffer, one device table, ONE otr_pack_frags launch per optimizer step (csrc/ffn_fused.hip)."""
         from . import ops
-        self.flat_pack, self._pack_table, self._pack_blocks = None, None, 0
+        self.flat_pack, self._pack_table, self._pack_blocks, self._ffn_packed = None, None, 0, set()
         off_of = {id(p): o for p, o in zip(self.params, self.offsets)}
         rows, total, views = [], 0, []
         for mod in module.modules():
@@ -132,6 +155,10 @@ class FlatDataParallel:
             blocks += ((r[3] // 32) * (r[4] // 16) + 3) // 4
         self._pack_table = torch.tensor(table, dtype=torch.int64, device=dev)
         self._pack_blocks = blocks
+        for mod in module.modules():
+            w1, w2 = getattr(getattr(mod, 'w_1', None), 'weight', None), getattr(getattr(mod, 'w_2', None), 'weight', None)
+            if w1 is not None and w2 is not None and any(v[0] is w1 for v in views):
+                self._ffn_packed.update((id(w1), id(w2)))
         for w1, offs, n1, n2 in views:
             w1._otr_ffn_packs = (self.flat_pack[offs[0]:offs[0] + n1], self.flat_pack[offs[1]:offs[1] + n2],
                                  self.flat_pack[offs[2]:offs[2] + n2], self.flat_pack[offs[3]:offs[3] + n1])
@@ -189,6 +216,7 @@ class FlatDataParallel:
 
     def zero_grad(self):
         self._check_grad_views(reinstall=True)      # a view dropped by set_to_none is put back; a foreign .grad raises
+        self._early_state = None
         self._grad_store.zero_()
         if self.flat_grad.is_cuda:
             from . import ops
@@ -234,12 +262,49 @@ class FlatDataParallel:
         except Exception:                   # noqa: BLE001  (interpreter shutdown: the library may be gone)
             pass
 
+    def _reduce_slice(self, lo, hi, stream=None):
+        """in-place sum over ranks of _grad_store[lo:hi] (through the 16-bit payload if configured); returns a work handle or None"""
+        buf = self._grad_store[lo:hi]
+        if self.grad_comm_dtype is not None:
+            if self._payload is None:
+                self._payload = torch.empty_like(self._grad_store, dtype=self.grad_comm_dtype)
+            pay = self._payload[lo:hi]
+            pay.copy_(buf)
+            buf = pay
+        work = None
+        if self.comm == 'rccl':
+            code = {torch.float32: L.OTR_F32, torch.bfloat16: L.OTR_BF16, torch.float16: L.OTR_F16}[buf.dtype]
+            L.check(L.load().otr_allreduce_run(self._rccl_handle(), C.c_void_p(buf.data_ptr()), buf.numel(), code,
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'otr_allreduce_run')
+        elif self.world_size > 1:
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return work, (buf if buf is not self._grad_store[lo:hi] and self.grad_comm_dtype is not None else None)
+
+    def _on_early_ready(self, force=False):
+        """called from inside the backward pass (ops.EarlyMarkFn) once the early group's gradients are final and their deferred
+        weight-gradient launches are queued on the compute stream: start their all-reduce on a side stream"""
+        if self.early_end <= 0 or self._early_state is not None or not (self.world_size > 1 or force) or self.skip_collectives:
+            return
+        if torch.cuda.is_available() and self._grad_store.is_cuda and torch.cuda.is_current_stream_capturing():
+            return                                   # a captured step keeps the single collective after the graph (DESIGN.md section 7)
+        if self._grad_store.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                work, pay = self._reduce_slice(0, self.early_end)
+        else:
+            work, pay = self._reduce_slice(0, self.early_end)
+        self._early_state = (work, pay)
+
     def all_reduce_gradients(self, async_op=False, force=False):
         """single collective over the flat buffer; returns 1/world_size for the optimizer to fold in.
         force: run the collective even at world_size 1 (self-test of the RCCL path on a one-GPU box)."""
         ws = self.world_size
         work = None
         self._check_grad_views()
+        if self.skip_collectives:
+            return 1.0 / ws, None
         if ws > 1 or force:
             # The sticky fault word (a bounded in-kernel wait gave up on THIS rank: its gradient sums may be wrong) is local, but
             # the gradient it taints is about to be summed into every replica.  It rides in the cell behind the gradients
@@ -250,6 +315,25 @@ class FlatDataParallel:
                 from . import ops
                 fault = ops.fault_counter(self.flat_grad.device)
                 self._fault_cell.copy_(fault)
+            if self._early_state is not None:
+                # the early group is already on its way (side stream): reduce the rest [early_end, end) incl. the fault cell here,
+                # then join
+                work_e, pay_e = self._early_state
+                self._early_state = None
+                work_l, pay_l = self._reduce_slice(self.early_end, self._grad_store.numel())
+                if work_l is not None:
+                    work_l.wait()
+                if pay_l is not None:
+                    self._grad_store[self.early_end:].copy_(pay_l)
+                if work_e is not None:
+                    work_e.wait()
+                if self._side is not None:
+                    torch.cuda.current_stream().wait_stream(self._side)
+                if pay_e is not None:
+                    self._grad_store[:self.early_end].copy_(pay_e)
+                if fault is not None:
+                    fault.copy_(self._fault_cell)
+                return 1.0 / ws, None
             buf = self._grad_store
             if self.grad_comm_dtype is not None:            # 16-bit payload: half the bytes over xGMI
                 if self._payload is None:

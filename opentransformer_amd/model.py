@@ -66,6 +66,7 @@ class SpeechToText(nn.Module):
         truth, truth_length = targets['targets'], targets['targets_length']
         enc_inputs, enc_mask = self.frontend(enc_inputs, enc_mask)
         memory, memory_mask, _ = self.encoder(enc_inputs, enc_mask)
+        memory = ops.early_mark(memory)       # everything behind this point finishes its backward before the encoder's starts (dp.py)
         logits, _ = self.decoder(truth[:, :-1].contiguous(), memory, memory_mask)
         target_out = truth[:, 1:].contiguous()
         loss = self.crit(logits, target_out)

@@ -284,6 +284,10 @@ def weight_lpt(w):
     view = getattr(w, '_otr_lpt_view', None)
     if view is not None:
         return view
+    if getattr(w, '_otr_grad_inplace', False):
+        # a replica parameter without a registered transposed shadow (FlatDataParallel keeps none for weights that have packs):
+        # FusedAdam rewrites it through raw pointers, so a version-keyed cache would go stale after the first update
+        return None
     cache = getattr(w, '_otr_lpt_cache', None)
     if cache is not None and cache[0] == w._version and cache[1] == w.data_ptr():
         return cache[2]
@@ -471,6 +475,45 @@ def flush_weight_grads():
             it.a, it.out = a2.data_ptr(), out.data_ptr()
             it.M, it.N, it.lda, it.dtype = a2.shape[0], a2.shape[1], a2.stride(0), _code(a2.dtype)
         L.check(lib.otr_colsum_grouped(items, len(b), _stream()), 'otr_colsum_grouped')
+
+
+# ---------------------------------------------------------------------------------------- early gradient groups
+# The decoder's (and the CTC head's) backward runs BEFORE the encoder's: their gradients are final long before the pass ends, and a
+# data-parallel engine can start reducing them while the encoder backward runs (dp.FlatDataParallel(early_modules=...)).  The
+# model marks the point on the encoder output: every autograd node created after the mark (decoder, embedding, heads) has a higher
+# sequence number than the mark, so the engine runs their backward first; the mark's backward then (i) launches the weight / bias
+# gradients queued so far -- all of them belong to modules behind the mark -- and (ii) tells the engine.
+def set_early_callback(fn):
+    """fn: a bound method (kept by weak reference) or None"""
+    import weakref
+    _state['early_cb'] = weakref.WeakMethod(fn) if fn is not None else None
+
+
+class EarlyMarkFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ref = _state.get('early_cb')
+        cb = ref() if ref is not None else None          # a weak reference: a dead engine leaves nothing behind
+        if cb is not None:
+            if _wq['w'] or _wq['b']:
+                flush_weight_grads()         # re-arms itself at the next enqueue (the encoder's items)
+            cb()
+        return g
+
+
+def early_mark(x):
+    """identity; see EarlyMarkFn (keeps the 16-bit twin of x)"""
+    if _state.get('early_cb') is None or not x.requires_grad or not torch.is_grad_enabled():
+        return x
+    y = EarlyMarkFn.apply(x)
+    lp = getattr(x, _LP_ATTR, None)
+    if lp is not None:
+        setattr(y, _LP_ATTR, lp)
+    return y
 
 
 # Links (ResidualLink, PreNormLink, LnOutLink) hand a gradient from one autograd node to a later one OUTSIDE autograd's own

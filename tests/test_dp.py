@@ -222,3 +222,52 @@ def test_fused_adam_state_dict_is_torch_adams_layout():
         bad = adam.state_dict()
         bad['param_groups'][0]['params'] = bad['param_groups'][0]['params'][:-1]
         opt2.load_state_dict(bad)
+
+
+class TinySplit(Tiny):
+    """Tiny with the early-group mark between the trunk (emb, l1) and the head (out)"""
+
+    def forward(self, tok, tgt):
+        from opentransformer_amd import ops
+        h = torch.relu(self.l1(self.emb(tok)))
+        h = ops.early_mark(h)
+        logits = self.out(h) + self.out2(self.emb(tok))
+        keep = tgt != 0
+        nll = torch.nn.functional.cross_entropy(logits.view(-1, 11), tgt.view(-1), reduction='none')
+        return (nll * keep.view(-1)).sum() / keep.sum()
+
+
+def _split_worker(rank, world, port, out, payload):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    tok, tgt = _data()
+    shard = slice(rank * 4, rank * 4 + 4)
+    res = {}
+    for name, early in (('single', False), ('split', True)):
+        model = TinySplit()
+        dp = FlatDataParallel(model, early_modules=[model.out] if early else None, grad_comm_dtype=payload)
+        dp.zero_grad()
+        dp(tok[shard], tgt[shard]).backward()
+        res[name + '_early_issued'] = dp._early_state is not None
+        scale, _ = dp.all_reduce_gradients()
+        res[name] = (dp.packed_grads() * scale).clone()
+        res[name + '_early_end'] = dp.early_end
+    from opentransformer_amd import ops
+    ops.set_early_callback(None)
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('payload', [None, torch.bfloat16])
+def test_two_group_allreduce_equals_the_single_collective(tmp_path, payload):
+    """the gradient all-reduce split into an EARLY group (the modules behind ops.early_mark: reduced while the
+    rest of the backward pass still runs) and the rest gives the same reduced gradient as one collective -- world size 2, gloo."""
+    out = str(tmp_path / 'r0.pt')
+    mp.spawn(_split_worker, args=(2, _free_port(), out, payload), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got['split_early_end'] > 0 and got['single_early_end'] == 0
+    assert got['split_early_issued'] and not got['single_early_issued']        # the early collective was started INSIDE backward
+    torch.testing.assert_close(got['split'], got['single'], rtol=0, atol=0)

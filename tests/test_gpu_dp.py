@@ -140,6 +140,53 @@ def test_fault_on_one_rank_skips_the_update_on_every_rank(tmp_path, payload, mon
     assert torch.equal(r0['param'], r1['param'])
 
 
+def _split_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops
+    from opentransformer_amd.dp import FlatDataParallel
+    torch.cuda.set_device(0)
+    ops.set_compute_dtype('fp16')
+    cfg = syn.c1_model(0.0, ctc_weight=0.3)
+    inputs, targets = syn.synthetic_batch(**BATCH)
+    sh = slice(rank * 2, rank * 2 + 2)
+    res = {}
+    for name in ('single', 'split'):
+        model = ota.SpeechToText(cfg)
+        syn.fill_state_dict_(model.state_dict(), 77)
+        model = model.to('cuda').train()
+        dp = FlatDataParallel(model, early_modules=[model.decoder, model.assistor] if name == 'split' else None)
+        dp.zero_grad()
+        loss, _ = dp({k: v[sh].cuda() for k, v in inputs.items()}, {k: v[sh].cuda() for k, v in targets.items()})
+        loss.backward()
+        res[name + '_issued'] = dp._early_state is not None
+        scale, _ = dp.all_reduce_gradients()
+        torch.cuda.synchronize()
+        res[name] = {k: (p.grad.detach().float() * scale).cpu() for k, p in model.named_parameters()}
+        res[name + '_early'] = dp.early_end
+        ops.set_early_callback(None)
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_group_allreduce_with_the_real_model(tmp_path):
+    """decoder + CTC head reduced on a side stream as soon as their backward is done (ops.early_mark on the
+    encoder output fires inside the pass, after their deferred weight-gradient launches), the rest at the end: the same reduced
+    gradient as the single collective.  Two ranks on one GPU over gloo."""
+    out = str(tmp_path / 'r0.pt')
+    mp.spawn(_split_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=False)
+    assert got['split_issued'] and not got['single_issued'] and got['split_early'] > 0 and got['single_early'] == 0
+    worst = 0.0
+    for k, g in got['split'].items():
+        ref = got['single'][k]
+        worst = max(worst, float((g - ref).norm() / max(float(ref.norm()), 1e-6)))
+    assert worst < 1e-5, worst            # two runs of one backward pass differ in the last bits (float atomics), nothing more
+
+
 def test_library_owned_rccl_communicator_world_one():
     """otr_allreduce_unique_id / init / run / destroy on a single-rank communicator: sum over one rank = identity, issued on
     the compute stream, for the fp32 buffer and for a bf16 payload"""
