@@ -51,12 +51,37 @@ class FlatDataParallel:
         early_ids = set()
         for m in (early_modules or []):
             early_ids.update(id(p) for p in m.parameters())
+        # parameters that one GEMM reads as ONE matrix sit next to each other: the decoder layers' cross-attention key / value
+        # projections (module/attention.py:128-134 `vk_proj`, all applied to the same encoder memory: ops.CrossKVAllFn) -- their
+        # concatenation is then a VIEW of the flat buffers instead of three torch.cat launches per step
+        name_of = {id(p): n for n, p in module.named_parameters()}
+        def group_key(p):
+            n = name_of.get(id(p), '')
+            for suffix in ('src_attn.vk_proj.weight', 'src_attn.vk_proj.bias'):
+                if n.endswith(suffix) and p.numel() % ALIGN == 0:
+                    return suffix
+            return None
         offs, total = [None] * len(params), 0
+        self._row_groups = []                       # [(indices of params stacked along dim 0)]
         for want_early in (True, False):            # the early group first: [0, early_end), then everything else
-            for i, p in enumerate(params):
-                if (id(p) in early_ids) == want_early:
-                    offs[i] = total
-                    total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            todo = [i for i, p in enumerate(params) if (id(p) in early_ids) == want_early]
+            groups = {}
+            for i in todo:
+                k = group_key(params[i])
+                if k is not None:
+                    groups.setdefault((k, tuple(params[i].shape)), []).append(i)
+            done = set()
+            for i in todo:
+                if i in done:
+                    continue
+                k = group_key(params[i])
+                members = groups.get((k, tuple(params[i].shape)), [i]) if k is not None else [i]
+                if len(members) > 1:
+                    self._row_groups.append(list(members))
+                for j in members:
+                    offs[j] = total
+                    total += (params[j].numel() + ALIGN - 1) // ALIGN * ALIGN
+                    done.add(j)
             if want_early:
                 self.early_end = total
         self.offsets = offs
@@ -100,8 +125,24 @@ class FlatDataParallel:
                 # shadow for them and uses the plain input-gradient GEMM (ops.weight_lpt returns None).
                 self.flat_param_lpt = torch.empty(padded, device=dev, dtype=ops.half_dtype())
                 table, tiles = [], 0
+                grouped = set()
+                for members in self._row_groups:     # a stacked group is transposed as ONE matrix: its members' shadows are column slices
+                    ps = [params[j] for j in members]
+                    if ps[0].dim() != 2:
+                        continue
+                    rows, cols, o0 = sum(q.shape[0] for q in ps), ps[0].shape[1], offs[members[0]]
+                    big = self.flat_param_lpt[o0:o0 + rows * cols].view(cols, rows)
+                    r0 = 0
+                    for q in ps:
+                        q._otr_lpt_view = big[:, r0:r0 + q.shape[0]]
+                        r0 += q.shape[0]
+                        grouped.add(id(q))
+                    table.append([o0, rows, cols, tiles])
+                    tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
                 for p, off in zip(params, offs):
                     n = p.numel()
+                    if id(p) in grouped:
+                        continue
                     if p.dim() == 2 and getattr(p, '_otr_lin_packs', None) is None and id(p) not in self._ffn_packed:
                         p._otr_lpt_view = self.flat_param_lpt[off:off + n].view(p.shape[1], p.shape[0])
                         table.append([off, p.shape[0], p.shape[1], tiles])

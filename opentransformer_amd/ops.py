@@ -921,6 +921,34 @@ class CrossKVShared:
         self.n, self.dkv, self.done = n, None, 0
 
 
+def stack_rows(ts):
+    """torch.cat(ts, 0) -- as a VIEW when the tensors already sit one after the other in memory (FlatDataParallel lays the decoder
+    layers' vk_proj parameters out that way): no launch"""
+    t0 = t0_ = ts[0]
+    if all(t.is_contiguous() and t.dtype == t0.dtype and t.shape[1:] == t0.shape[1:] for t in ts):
+        nb, ok, p = t0.element_size(), True, t0.data_ptr()
+        for t in ts:
+            ok = ok and t.data_ptr() == p
+            p += t.numel() * nb
+        if ok and t0._base is not None or ok and len(ts) == 1:
+            rows = sum(t.shape[0] for t in ts)
+            return t0.as_strided((rows,) + tuple(t0.shape[1:]), t0.stride())
+    return torch.cat(ts, dim=0)
+
+
+def stack_cols(ts):
+    """torch.cat(ts, 1) of 2-D tensors -- as a view when they are adjacent column slices of one row-major matrix"""
+    t0 = ts[0]
+    if all(t.dim() == 2 and t.stride() == t0.stride() and t.stride(1) == 1 and t.shape[0] == t0.shape[0] and t.dtype == t0.dtype for t in ts):
+        nb, ok, p, cols = t0.element_size(), True, t0.data_ptr(), sum(t.shape[1] for t in ts)
+        for t in ts:
+            ok = ok and t.data_ptr() == p
+            p += t.shape[1] * nb
+        if ok and cols <= t0.stride(0) and t0._base is not None:
+            return t0.as_strided((t0.shape[0], cols), t0.stride())
+    return torch.cat(ts, dim=1)
+
+
 class CrossKVAllFn(torch.autograd.Function):
     """kv_all[B,T,L*2d] = memory . cat_l(vk_proj_l.weight)^T + cat_l(bias): columns [l*2d, l*2d+d) are layer l's keys, the
     next d its values (split order k, v: module/attention.py:134)."""
@@ -934,11 +962,11 @@ class CrossKVAllFn(torch.autograd.Function):
         m2 = _rows(mc if mc is not None else memory)
         adt = act_dtype()
         wl = [weight_lp(w) if weight_lp(w) is not None else w for w in ws]
-        wcat = torch.cat(wl, dim=0)                                   # [L*2d, dm]
-        bcat = torch.cat([b for b in bs], dim=0)
+        wcat = stack_rows(wl)                                         # [L*2d, dm]
+        bcat = stack_rows([b for b in bs])
         y = linear_fwd_raw(m2, wcat, bcat, adt)
         wt = [weight_lpt(w) for w in ws]
-        ctx.wcat_t = torch.cat(wt, dim=1) if all(t is not None for t in wt) else None      # [dm, L*2d]
+        ctx.wcat_t = stack_cols(wt) if all(t is not None for t in wt) else None      # [dm, L*2d]
         ctx.save_for_backward(m2, wcat)
         ctx.mshape, ctx.mdtype = memory.shape, memory.dtype
         return y.view(*memory.shape[:-1], wcat.shape[0])
@@ -1650,15 +1678,19 @@ class DecoderStackFn(torch.autograd.Function):
                 lnA, y0, y016, rec_prev = ln_out(y_in, *pending)
                 layers[-1]['ln3'] = rec_prev
             qkv16, ctx1, lse1 = h16(R, 3 * d), h16(R, d), f32(B, H, Lq)
-            L.check(lib.otr_dec_self_fwd(C.byref(lnA), B, Lq, _p(pk[0][0]), _p(bqkv), _p(pk[1][0]), _p(qkv16), _p(ctx1), _p(lse1), _p(slA), st),
-                    'otr_dec_self_fwd')
+            fl_self = 2.0 * R * d * (3 * d + d) + 4.0 * R * Lq * d
+            L.check(_timed('dec_self_fwd', {'flops': fl_self}, lambda lnA=lnA, pk=pk, bqkv=bqkv, qkv16=qkv16, ctx1=ctx1, lse1=lse1: lib.otr_dec_self_fwd(
+                C.byref(lnA), B, Lq, _p(pk[0][0]), _p(bqkv), _p(pk[1][0]), _p(qkv16), _p(ctx1), _p(lse1), _p(slA), st)), 'otr_dec_self_fwd')
             lnB, y1, y116, rec['ln1'] = ln_out(y0, slA, 4, bo, g1, be1)
             q16, ctx2, lse2 = h16(R, d), h16(R, d), f32(B, H, Lq)
-            L.check(lib.otr_dec_cross_fwd(C.byref(lnB), B, Lq, _p(pk[2][0]), _p(bq), _p(pk[3][0]), _p(kv_all), T * W, W, l * 512, l * 512 + 256,
-                                          _p(kmask), T, _p(q16), _p(ctx2), _p(lse2), _p(slB), st), 'otr_dec_cross_fwd')
+            fl_cross = 2.0 * R * d * (d + d) + 4.0 * R * T * d
+            L.check(_timed('dec_cross_fwd', {'flops': fl_cross}, lambda lnB=lnB, pk=pk, bq=bq, q16=q16, ctx2=ctx2, lse2=lse2, l=l: lib.otr_dec_cross_fwd(
+                C.byref(lnB), B, Lq, _p(pk[2][0]), _p(bq), _p(pk[3][0]), _p(kv_all), T * W, W, l * 512, l * 512 + 256, _p(kmask), T, _p(q16), _p(ctx2),
+                _p(lse2), _p(slB), st)), 'otr_dec_cross_fwd')
             lnC, y2, y216, rec['ln2'] = ln_out(y1, slB, 4, bo2, g2, be2)
             hsave = torch.empty(lib.otr_dec_ffn_hsave_bytes(R, F) // 2, dtype=hdt, device=dev) if need else None
-            L.check(lib.otr_dec_ffn_fwd(C.byref(lnC), R, _p(pk[4][0]), _p(b1), _p(pk[4][1]), F, S, _p(slC), _p(hsave), st), 'otr_dec_ffn_fwd')
+            L.check(_timed('dec_ffn_fwd', {'flops': 6.0 * R * F * d}, lambda lnC=lnC, pk=pk, b1=b1, hsave=hsave: lib.otr_dec_ffn_fwd(
+                C.byref(lnC), R, _p(pk[4][0]), _p(b1), _p(pk[4][1]), F, S, _p(slC), _p(hsave), st)), 'otr_dec_ffn_fwd')
             rec.update(hsave=hsave, y016=y016, qkv16=qkv16, ctx1=ctx1, lse1=lse1, y116=y116, q16=q16, ctx2=ctx2, lse2=lse2, y216=y216)
             layers.append(rec)
             y_in, pending = y2, (slC, S, b2, g3, be3)
@@ -1697,7 +1729,8 @@ class DecoderStackFn(torch.autograd.Function):
             dh, u, bpart, slCb = h16(R, 2 * F), h16(R, F), f32(nblk, 2 * F), h16(S, R, d)
             lnb = _dec_lnb(dskip, slabs, nslab, rec['ln3'], g3, seed, p_drop, dz3, da3, part3)
             _, _, P3, P4 = pk[4]
-            L.check(lib.otr_dec_ffn_bwd(C.byref(lnb), R, _p(rec['hsave']), _p(P3), _p(P4), F, S, _p(dh), _p(u), _p(bpart), _p(slCb), st),
+            L.check(_timed('dec_ffn_bwd', {'flops': 6.0 * R * F * d}, lambda lnb=lnb, rec=rec, P3=P3, P4=P4, dh=dh, u=u, bpart=bpart, slCb=slCb:
+                           lib.otr_dec_ffn_bwd(C.byref(lnb), R, _p(rec['hsave']), _p(P3), _p(P4), F, S, _p(dh), _p(u), _p(bpart), _p(slCb), st)),
                     'otr_dec_ffn_bwd')
             grads[o + 16], grads[o + 17], grads[o + 15] = _grad_b(part3[:, :d], g3), _grad_b(part3[:, d:2 * d], be3), _grad_b(part3[:, 2 * d:], b2)
             grads[o + 12], grads[o + 13], grads[o + 14] = _grad_w(dh, rec['y216'], w1), _grad_b(bpart, b1), _grad_w(da3, u, w2)
@@ -1706,16 +1739,19 @@ class DecoderStackFn(torch.autograd.Function):
             if dkv is None:
                 dkv = torch.empty_like(kv_all)
             lnb = _dec_lnb(dz3, slCb, S, rec['ln2'], g2, seed, p_drop, dz2, da2, part2)
-            L.check(lib.otr_dec_cross_bwd(C.byref(lnb), B, Lq, _p(pk[3][1]), _p(pk[2][1]), _p(rec['q16']), _p(rec['ctx2']), _p(rec['lse2']),
-                                          _p(kv_all), _p(dkv), T * W, W, l * 512, l * 512 + 256, _p(kmask), T, _p(dq16), _p(slBb), st),
-                    'otr_dec_cross_bwd')
+            L.check(_timed('dec_cross_bwd', {'flops': 2.0 * R * d * (d + d) + 10.0 * R * T * d},
+                           lambda lnb=lnb, pk=pk, rec=rec, l=l, dq16=dq16, slBb=slBb: lib.otr_dec_cross_bwd(
+                               C.byref(lnb), B, Lq, _p(pk[3][1]), _p(pk[2][1]), _p(rec['q16']), _p(rec['ctx2']), _p(rec['lse2']), _p(kv_all), _p(dkv),
+                               T * W, W, l * 512, l * 512 + 256, _p(kmask), T, _p(dq16), _p(slBb), st)), 'otr_dec_cross_bwd')
             grads[o + 10], grads[o + 11], grads[o + 9] = _grad_b(part2[:, :d], g2), _grad_b(part2[:, d:2 * d], be2), _grad_b(part2[:, 2 * d:], bo2)
             grads[o + 8], grads[o + 6], grads[o + 7] = _grad_w(da2, rec['ctx2'], wo2), _grad_w(dq16, rec['y116'], wq), _grad_b(dq16, bq)
             # ---- self-attention sub-layer
             dz1, da1, part1, dqkv16, slAb = f32(R, d), h16(R, d), f32(ngrp, 3 * d), h16(R, 3 * d), h16(4, R, d)
             lnb = _dec_lnb(dz2, slBb, 4, rec['ln1'], g1, seed, p_drop, dz1, da1, part1)
-            L.check(lib.otr_dec_self_bwd(C.byref(lnb), B, Lq, _p(pk[1][1]), _p(pk[0][1]), _p(rec['qkv16']), _p(rec['ctx1']), _p(rec['lse1']),
-                                         _p(dqkv16), _p(slAb), st), 'otr_dec_self_bwd')
+            L.check(_timed('dec_self_bwd', {'flops': 2.0 * R * d * (3 * d + d) + 10.0 * R * Lq * d},
+                           lambda lnb=lnb, pk=pk, rec=rec, dqkv16=dqkv16, slAb=slAb: lib.otr_dec_self_bwd(
+                               C.byref(lnb), B, Lq, _p(pk[1][1]), _p(pk[0][1]), _p(rec['qkv16']), _p(rec['ctx1']), _p(rec['lse1']), _p(dqkv16),
+                               _p(slAb), st)), 'otr_dec_self_bwd')
             grads[o + 4], grads[o + 5], grads[o + 3] = _grad_b(part1[:, :d], g1), _grad_b(part1[:, d:2 * d], be1), _grad_b(part1[:, 2 * d:], bo)
             grads[o + 2], grads[o + 0], grads[o + 1] = _grad_w(da1, rec['ctx1'], wo), _grad_w(dqkv16, rec['y016'], wqkv), _grad_b(dqkv16, bqkv)
             dskip, slabs, nslab = dz1, slAb, 4
