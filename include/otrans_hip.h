@@ -202,6 +202,23 @@ int32_t otr_ffn_ln_fwd_split(const float* x, const void* x16, const void* w1_pac
 int32_t otr_ffn_bwd_split(const void* dy16, const void* hsave, const void* w2t_pack, const void* w1t_pack, void* dh,
                           const float* skip, float* dx, void* scratch, int64_t scratch_bytes, int32_t* sync, int64_t sync_ints,
                           int64_t M, int32_t F, int32_t d_model, void* stream);
+/* ---- the same split FFN kernels in SLAB mode: no partial-sum exchange, no LayerNorm inside the launch.  The four hidden slices of
+ *      a row block leave their shares as 16-bit slabs [4][M][256] and the launch that reads the sub-layer's output finishes
+ *      y = LayerNorm(x + dropout(sum of slabs + b_2))  in its prologue (the in-launch exchange is a chain of far round trips: a third
+ *      of the forward kernel's cycles; a launch boundary is cheaper).
+ * otr_ffn_fwd_split_slab:  slabs = w_2[:, slice] glu(w_1[slice] x + b_1[slice]); hsave / usave as otr_ffn_ln_fwd_split.
+ * otr_rb_linear_ln:        the q|k|v projection of the NEXT layer with that LayerNorm in its prologue: out[M,768] = y16 . W^T + bias,
+ *      y and the LayerNorm's saved z / mean / rstd written on the way (otr_dec_ln_t, nslab <= 4).
+ * otr_dec_ln (declared with the fused decoder below) is the LayerNorm alone, for an output nobody projects (the last encoder layer).
+ * otr_ffn_bwd_split_slab:  dh as otr_ffn_bwd_split; slabs = the slices' shares dh[slice] . w_1[slice] of the input gradient.
+ * otr_ln_bwd_proj_slabs:   otr_ln_bwd_proj with the LayerNorm's output gradient given as dskip f32 [M,256] + nslab (<= 4) such slabs. */
+int32_t otr_ffn_fwd_split_slab(const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, void* hsave, void* usave,
+                               void* slabs, int64_t M, int32_t F, int32_t d_model, void* stream);
+int32_t otr_ffn_bwd_split_slab(const void* dy16, const void* hsave, const void* w2t_pack, const void* w1t_pack, void* dh, void* slabs,
+                               int64_t M, int32_t F, int32_t d_model, void* stream);
+int32_t otr_ln_bwd_proj_slabs(const float* dskip, const void* slabs, int32_t nslab, const float* z, const float* mean, const float* rstd,
+                              const float* gamma, const uint64_t* seed, const void* wt_pack, float* dx, void* da16, void* dc16, int64_t ldc,
+                              float* partial, int64_t M, int32_t d_model, float p_drop, uint64_t rng_offset, void* stream);
 /* ---- grouped weight / bias gradients: every dw_i[N,K] += dy_i[M,N]^T x_i[M,K] of a backward pass in a few launches
  *      (one per operand-type group), likewise every bias gradient out_i[N] += column sums of a_i[M,N].  The per-layer
  *      launches they replace are latency bound (a 4-k-step GEMM workgroup lives ~10 us, every launch costs 2-3 us);
@@ -552,6 +569,8 @@ typedef struct {
   float p_drop, eps; uint64_t rng_offset;
   float* y; void* y16; float* z; float* mean; float* rstd;
 } otr_dec_ln_t;
+int32_t otr_rb_linear_ln(const otr_dec_ln_t* ln, const void* w_pack, const float* bias, void* out, int32_t out_dtype, int64_t ldo, int64_t M,
+                         int32_t N, int32_t K, void* stream);
 int32_t otr_dec_self_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t L, const void* wqkv_pack, const float* bqkv, const void* wo_pack,
                          void* qkv16, void* ctx16, float* lse, void* slabs, void* stream);
 int32_t otr_dec_cross_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t L, const void* wq_pack, const float* bq, const void* wo_pack,

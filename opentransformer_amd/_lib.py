@@ -142,6 +142,10 @@ SIGNATURES = {
     'otr_label_smoothing_loss': [_P, _P, _I64, _I32, _F32, _I32, _P, _P, _P, _P],
     'otr_log_softmax': [_P, _P, _I64, _I32, _P],
     'otr_ctc_loss': [_P, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    'otr_ffn_fwd_split_slab': [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
+    'otr_ffn_bwd_split_slab': [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
+    'otr_ln_bwd_proj_slabs': [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I32, _F32, C.c_uint64, _P],
+    'otr_rb_linear_ln': [C.POINTER(DecLn), _P, _P, _P, _I32, _I64, _I64, _I32, _I32, _P],
     'otr_dec_self_fwd': [C.POINTER(DecLn), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_dec_cross_fwd': [C.POINTER(DecLn), _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P],
     'otr_dec_ffn_hsave_bytes': [_I64, _I32],

@@ -212,6 +212,9 @@ struct Ffn3FwdArgs {
                            // backward kernel: [row block][slice][64-unit chunk][wave][8 pieces][64 lanes] x 16 B; piece
                            // rt*2 + j = value registers 8j .. 8j+7 of row tile rt, piece 4 + rt*2 + j = the sigmoids
   uint16_t* usave;         // SAVE: u = glu output [128 * row blocks, F] row-major (operand of the w_2 weight gradient)
+  uint16_t* slab;          // SLAB: [4 slices][M][256] 16-bit out -- this slice's partial sums w_2[:, slice] glu(...) (no bias): the launch that
+                           // consumes them finishes the LayerNorm in its prologue (ln_pro.h); nothing of the exchange / epilogue fields
+                           // below is touched then
   int* sync;               // [8 * row blocks] zero before the first launch: the row blocks' sync records (F3Sync)
   int* fault;              // NULL or the sticky fault word (otr_set_fault_counter)
   int spin_limit, coh_only, map;
@@ -237,7 +240,34 @@ __host__ __device__ __forceinline__ void f3_block_map(int b, int map, int& rb, i
   }
 }
 
-template <int D, int ABL, bool SAVE>
+// accumulator tiles acc[rt][ct] of wave (wr, wc) (rows 64 wr + 32 rt .., columns 128 wc + 32 ct ..) -> the slice's 16-bit slab rows:
+// through LDS (the ring, free after the main loop) as a row-major [128][256] tile, then whole 512-byte rows, two per wave
+// instruction.  (Straight from the accumulator layout an instruction would touch 32 rows with 8 bytes each: the CU's address path
+// takes about a cycle per line touched.)
+__device__ __forceinline__ void f3_store_slab(const f32x16 (&acc)[2][4], unsigned char* lds, uint16_t* slab_rows, int rb, int M, int wid, int wr, int wc,
+                                              int lane) {
+  constexpr int TS = 256 * 2 + 16;                                 // bytes per tile row
+  const int m = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<uint2*>(lds + (64 * wr + 32 * rt + m) * TS + (128 * wc + 32 * ct + 8 * q + 4 * hi) * 2) =
+            make_uint2(pack2h(acc[rt][ct][4 * q], acc[rt][ct][4 * q + 1]), pack2h(acc[rt][ct][4 * q + 2], acc[rt][ct][4 * q + 3]));
+  f3_wait_lds();
+  f3_barrier();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int r = 32 * wid + 2 * k + hi;
+    const int64_t row = (int64_t)rb * 128 + r;
+    const uint4 v = *reinterpret_cast<const uint4*>(lds + r * TS + m * 16);
+    if (row < M) st_global_b128(slab_rows + row * 256 + m * 8, v);
+  }
+}
+
+template <int D, int ABL, bool SAVE, bool SLAB = false>
 __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   static_assert(D == 256, "two 128-column halves, 16 contraction steps");
   constexpr int NKS = D / 16;
@@ -258,7 +288,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
 #define F3_STAMP() if constexpr ((ABL & 16) != 0) { if (p.trace && tid == 0 && stamp_i < 48) p.trace[(int64_t)blockIdx.x * 48 + stamp_i++] = __builtin_amdgcn_s_memtime(); }
   F3_STAMP()
   F3Sync sy{};
-  f3_sync_begin(sy, p.sync + 8 * rb, p.coh_only ? 16 + sl : f3_xcc_id());
+  if constexpr (!SLAB) f3_sync_begin(sy, p.sync + 8 * rb, p.coh_only ? 16 + sl : f3_xcc_id());
   const int nchunk = p.F / 32, per = nchunk / p.S, NC = per >> 1; // v1 chunks (32 units) of the layer / of this slice; 64-unit chunks
   const int c_base = sl * per;
 
@@ -309,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   }
   f3_wait_lds();
   f3_barrier();
-  f3_sync_publish(sy, sl, tid);
+  if constexpr (!SLAB) f3_sync_publish(sy, sl, tid);
   otr_u32x4 xf[2][NKS];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
@@ -510,7 +540,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
     F3_PHASE_END(KG)
   }
   // ---- closing phase: GEMM2 of chunk NC-1 (its w_2 took the place of a phase A(NC)); the partners' ids travel meanwhile
-  f3_sync_read_ids(sy);
+  if constexpr (!SLAB) f3_sync_read_ids(sy);
   F3_READ_PARTNER()
   if constexpr (SAVE && !no_st) {
 #pragma unroll
@@ -528,6 +558,14 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   f3_wait_lds();
   f3_barrier();
   F3_STAMP()
+  if constexpr (SLAB) {
+    // ---- slab form: no exchange, no LayerNorm here.  The exchange below is a chain of far round trips (write-through drain,
+    // arrival atomic, partners' data, LayerNorm: 36 k of this kernel's 108 k cycles by clock stamps); a launch boundary is cheaper,
+    // and the q|k|v projection that reads this sub-layer's output finishes the LayerNorm in its prologue (rowblock.hip)
+    f3_store_slab(yacc, ring, p.slab + (int64_t)sl * p.M * 256, rb, p.M, wid, wr, wc, lane);
+    F3_STAMP()
+    return;
+  }
 
   // ---- fused form (S = 4): the four workgroups of a row block exchange their partial sums and each finishes ONE quarter of
   // the rows (32 rows: quarter `sl`): y = LayerNorm(x + dropout(sum of the four partials + b_2)).  Everything stays in the
@@ -673,6 +711,8 @@ struct Ffn3BwdArgs {
   float* dx;               // [M, D] out (may alias skip)
   float* scratch; int* sync; int* fault; int spin_limit, coh_only, map;
   int M, F;
+  uint16_t* slab;          // SLAB: [4 slices][M][256] 16-bit out -- this slice's share dh[slice] . w_1[slice] of the input gradient (skip, dx,
+                           // scratch, sync are not touched then: the consumer adds the shares to the skip gradient, rowblock.hip)
 };
 
 // a global load hipcc does not count (its own s_waitcnt would drain the DMAs in flight): 16 B per lane from a wave-uniform base.
@@ -691,7 +731,7 @@ __device__ __forceinline__ void f3_mma_acc(f32x16& acc, const otr_u32x4& w, cons
 }
 __device__ __forceinline__ float f3_h2f_lo(uint32_t w) { return h2f_lo(w); }
 
-template <int D, int ABL>
+template <int D, int ABL, bool SLAB = false>
 __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   static_assert(D == 256, "two 128-column halves, 16 contraction steps");
   constexpr int NKS = D / 16;
@@ -709,7 +749,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   if (rb * 128 >= p.M) return;
   const int row0 = rb * 128 + wr * 64;
   F3Sync sy{};
-  f3_sync_begin(sy, p.sync + 8 * rb, p.coh_only ? 16 + sl : f3_xcc_id());
+  if constexpr (!SLAB) f3_sync_begin(sy, p.sync + 8 * rb, p.coh_only ? 16 + sl : f3_xcc_id());
   const int nchunk = p.F / 32, per = nchunk / 4, NC = per >> 1;
   const int c_base = sl * per;
   constexpr bool no_dma = (ABL & 1) != 0, no_mma = (ABL & 2) != 0, no_st = (ABL & 4) != 0, no_hl = (ABL & 8) != 0;
@@ -759,7 +799,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   f3_stage_rows128<D>(xs, p.dy16, rb, p.M, tid);
   f3_wait_lds();
   f3_barrier();
-  f3_sync_publish(sy, sl, tid);
+  if constexpr (!SLAB) f3_sync_publish(sy, sl, tid);
   otr_u32x4 dyf[2][NKS];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
@@ -965,7 +1005,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   }
   // ---- closing phases: XA, XB of the last chunk (no DMA, no global traffic: only the last X phase's 16 may still fly); the
   // partners' ids travel meanwhile
-  f3_sync_read_ids(sy);
+  if constexpr (!SLAB) f3_sync_read_ids(sy);
   F3B_READ_PARTNER()
   if constexpr (!no_st) {
 #pragma unroll
@@ -988,6 +1028,10 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   f3_wait_vm_for<0>(hp[4], hp[5], hp[6], hp[7]);                 // theirs until here; everything else has drained too
   f3_wait_lds();
   f3_barrier();
+  if constexpr (SLAB) {
+    f3_store_slab(xacc, ring, p.slab + (int64_t)sl * p.M * 256, rb, p.M, wid, wr, wc, lane);    // see ffn3_fwd_kernel
+    return;
+  }
 
   // ---- exchange the four partial input gradients of the row block; this workgroup finishes quarter `sl`: dx = skip + sum
   float* own = reinterpret_cast<float*>(ring);
@@ -1041,6 +1085,11 @@ extern int32_t* g_otr_fault;
 extern int g_otr_ffn_coh_only;
 extern unsigned long long* g_otr_trace;
 
+#define F3_LAUNCH_FWD_SLAB(SAVE)                                                                                   \
+  switch (g_otr_ffn2_ablate & 31) {                                                                                      \
+    case 16: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 16, SAVE, true>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break; \
+    default: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 0, SAVE, true>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break;  \
+  }
 #define F3_LAUNCH_FWD(SAVE)                                                                                        \
   switch (g_otr_ffn2_ablate & 31) {                                                                                      \
     case 16: hipLaunchKernelGGL((ffn3_fwd_kernel<256, 16, SAVE>), dim3(f3_grid(M, S)), dim3(256), 0, stream, p); break; \
@@ -1072,6 +1121,18 @@ int32_t ffn3_ln_fwd_launch(const float* x, const void* x16, const void* w1_pack,
   return otr_check_launch("ffn3_ln_fwd");
 }
 
+// slab form: the slices' partial sums leave as 16-bit slabs [4][M][256]; the consumer finishes the LayerNorm
+int32_t ffn3_fwd_slab_launch(const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, void* hsave, void* usave, void* slab,
+                             int64_t M, int32_t F, hipStream_t stream) {
+  constexpr int S = 4;
+  Ffn3FwdArgs p{};
+  p.x16 = (const uint16_t*)x16; p.p1 = (const uint4*)w1_pack; p.b1 = b1; p.p2 = (const uint4*)w2_pack;
+  p.M = (int)M; p.F = F; p.S = S; p.map = g_otr_ffn_map;
+  p.hsave = (uint4*)hsave; p.usave = (uint16_t*)usave; p.slab = (uint16_t*)slab; p.trace = g_otr_trace;
+  if (hsave) { F3_LAUNCH_FWD_SLAB(true) } else { F3_LAUNCH_FWD_SLAB(false) }
+  return otr_check_launch("ffn3_fwd_slab");
+}
+
 int32_t ffn3_bwd_launch(const void* dy16, const void* hsave, const void* w2t_pack, const void* w1t_pack, void* dh, const float* skip,
                         float* dx, float* scratch, int32_t* sync, int64_t M, int32_t F, hipStream_t stream) {
   Ffn3BwdArgs p{};
@@ -1088,6 +1149,15 @@ int32_t ffn3_bwd_launch(const void* dy16, const void* hsave, const void* w2t_pac
     default: hipLaunchKernelGGL((ffn3_bwd_kernel<256, 3>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p); break;
   }
   return otr_check_launch("ffn3_bwd");
+}
+
+int32_t ffn3_bwd_slab_launch(const void* dy16, const void* hsave, const void* w2t_pack, const void* w1t_pack, void* dh, void* slab, int64_t M,
+                             int32_t F, hipStream_t stream) {
+  Ffn3BwdArgs p{};
+  p.dy16 = (const uint16_t*)dy16; p.hsave = (const uint4*)hsave; p.p3 = (const uint4*)w2t_pack; p.p4 = (const uint4*)w1t_pack;
+  p.dh = (uint16_t*)dh; p.slab = (uint16_t*)slab; p.map = g_otr_ffn_map; p.M = (int)M; p.F = F;
+  hipLaunchKernelGGL((ffn3_bwd_kernel<256, 0, true>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p);
+  return otr_check_launch("ffn3_bwd_slab");
 }
 
 // 1 when the 128-row kernels take this (hidden size, split): whole 64-unit chunks per slice, biases fit their LDS staging

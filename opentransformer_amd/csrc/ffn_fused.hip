@@ -434,6 +434,10 @@ int32_t ffn3_ln_fwd_launch(const float* x, const void* x16, const void* w1_pack,
                            int32_t* sync, int64_t M, int32_t F, hipStream_t stream);
 int32_t ffn3_bwd_launch(const void* dy16, const void* hsave, const void* w2t_pack, const void* w1t_pack, void* dh, const float* skip,
                         float* dx, float* scratch, int32_t* sync, int64_t M, int32_t F, hipStream_t stream);
+int32_t ffn3_fwd_slab_launch(const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, void* hsave, void* usave, void* slab,
+                             int64_t M, int32_t F, hipStream_t stream);
+int32_t ffn3_bwd_slab_launch(const void* dy16, const void* hsave, const void* w2t_pack, const void* w1t_pack, void* dh, void* slab, int64_t M,
+                             int32_t F, hipStream_t stream);
 static int32_t ffn_shape_check(const char* who, int64_t M, int32_t F, int32_t d_model) {
   OTR_REQUIRE(M >= 0 && M < (1ll << 31), "%s: bad M", who);
   OTR_REQUIRE(d_model == 256, "%s: built for d_model = 256 (got %d); use the unfused path", who, d_model);
@@ -517,4 +521,27 @@ extern "C" int32_t otr_ffn_bwd(const void* x16, const void* dy16, const void* w1
   p.M = (int)M; p.F = F; p.ablate = g_otr_ffn2_ablate;
   hipLaunchKernelGGL(ffn_bwd_kernel<256>, dim3((unsigned)((M + FF_RB - 1) / FF_RB)), dim3(256), 0, (hipStream_t)stream, p);
   return otr_check_launch("ffn_bwd");
+}
+
+extern "C" int32_t otr_ffn_fwd_split_slab(const void* x16, const void* w1_pack, const float* b1, const void* w2_pack, void* hsave, void* usave,
+                                          void* slabs, int64_t M, int32_t F, int32_t d_model, void* stream) {
+  if (int32_t e = ffn_shape_check("ffn_fwd_split_slab", M, F, d_model)) return e;
+  OTR_REQUIRE(ffn3_takes(F, 4), "ffn_fwd_split_slab: d_ff = %d does not split into 4 slices of whole 64-unit chunks", F);
+  OTR_REQUIRE(x16 && w1_pack && b1 && w2_pack && slabs, "ffn_fwd_split_slab: null pointer");
+  OTR_REQUIRE((hsave == nullptr) == (usave == nullptr), "ffn_fwd_split_slab: hsave and usave come together");
+  OTR_REQUIRE(((uintptr_t)x16 | (uintptr_t)w1_pack | (uintptr_t)w2_pack | (uintptr_t)b1 | (uintptr_t)hsave | (uintptr_t)usave | (uintptr_t)slabs) % 16 == 0,
+              "ffn_fwd_split_slab: buffers must be 16-byte aligned");
+  if (M == 0) return 0;
+  return ffn3_fwd_slab_launch(x16, w1_pack, b1, w2_pack, hsave, usave, slabs, M, F, (hipStream_t)stream);
+}
+
+extern "C" int32_t otr_ffn_bwd_split_slab(const void* dy16, const void* hsave, const void* w2t_pack, const void* w1t_pack, void* dh, void* slabs,
+                                          int64_t M, int32_t F, int32_t d_model, void* stream) {
+  if (int32_t e = ffn_shape_check("ffn_bwd_split_slab", M, F, d_model)) return e;
+  OTR_REQUIRE(ffn3_takes(F, 4), "ffn_bwd_split_slab: d_ff = %d does not split into 4 slices of whole 64-unit chunks", F);
+  OTR_REQUIRE(dy16 && hsave && w2t_pack && w1t_pack && dh && slabs, "ffn_bwd_split_slab: null pointer");
+  OTR_REQUIRE(((uintptr_t)dy16 | (uintptr_t)hsave | (uintptr_t)w2t_pack | (uintptr_t)w1t_pack | (uintptr_t)dh | (uintptr_t)slabs) % 16 == 0,
+              "ffn_bwd_split_slab: buffers must be 16-byte aligned");
+  if (M == 0) return 0;
+  return ffn3_bwd_slab_launch(dy16, hsave, w2t_pack, w1t_pack, dh, slabs, M, F, (hipStream_t)stream);
 }

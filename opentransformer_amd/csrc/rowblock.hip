@@ -13,6 +13,7 @@
 // epilogue (bias / dropout / residual / LayerNorm, or the 16-bit store) runs on whole rows.  Bound: the packed weight
 // (128 KB for 256 x 256, 384 KB for 768 x 256) into every CU at ~22 B/clk: 3 / 8 us.
 #include "common.h"
+#include "ln_pro.h"
 
 namespace {
 
@@ -144,6 +145,64 @@ __global__ __launch_bounds__(256, NSPLIT) void rb_linear_kernel(RbLinArgs p) {
   }
 }
 
+// The q|k|v projection behind a split FFN in SLAB mode (ffn3.hip): the FFN launch leaves four 16-bit partial slabs instead of
+// exchanging them, and this launch finishes  y = LayerNorm(xres + dropout(sum of the slabs + b_2))  for its 32 rows in its prologue
+// (ln_pro.h; both column-half workgroups of a row block do, the first one writes y / y16 / z / mean / rstd), then projects.
+struct RbLinLnArgs {
+  DlLn ln;
+  const uint4* pw; const float* bias;
+  void* out; int64_t ldo;
+  int M, out_h16;
+};
+// NW = 8, NSPLIT = 1: one 8-wave workgroup per row block takes all 768 columns -- the prologue's ~100 KiB (residual rows + four slabs)
+// travel once per row block instead of once per column half (per-CU ingest is what bounds these launches).
+template <int TPW, int NSPLIT, int NW>
+__global__ __launch_bounds__(NW * 64, NSPLIT) void rb_linear_ln_kernel(RbLinLnArgs p) {
+  constexpr int K = 256, N = 32 * NW * TPW, RS = N + 4, RPW = RB / NW;
+  const int cbase = (int)blockIdx.y * N;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RB * K * 2 + RB * RS * 4];
+  uint4* xs = reinterpret_cast<uint4*>(smem);
+  float* red = reinterpret_cast<float*>(smem + RB * K * 2);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * RB;
+  const int nrows = min(RB, p.M - row0);
+  DlPro<NW, 4> pro;                                                // its loads first (vmcnt retires in order), then the weight stream
+  pro.issue(p.ln, row0, nrows, tid);
+  RbStream<K, TPW> ws;
+  ws.fill(p.pw, (int)blockIdx.y * NW * TPW + wid * TPW, lane);
+  pro.finish(p.ln, nrows, blockIdx.y == 0, [&](int r, int ch, const uint4& v) { xs[r * (K / 8) + (ch ^ (r & 15))] = v; }, tid);
+  __syncthreads();
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  ws.run(acc, xs, lane);
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) rb_put_tile<RS>(red, acc[i], (wid * TPW + i) * 32, lane);
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int r = wid * RPW + rr;
+    const int64_t row = (int64_t)row0 + r;
+    if (row >= p.M) break;                                          // wave-uniform
+#pragma unroll
+    for (int c0 = 0; c0 < N; c0 += 256) {
+      const int lc = c0 + lane * 4;
+      if (N % 256 != 0 && lc >= N) break;
+      const int col = cbase + lc;
+      float4 v = *reinterpret_cast<const float4*>(red + r * RS + lc);
+      if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      if (p.out_h16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + row * p.ldo + col) = make_uint2(pack2h(v.x, v.y), pack2h(v.z, v.w));
+      else *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + row * p.ldo + col) = v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ projection + residual + LayerNorm
 struct ProjLnArgs {
   const float* x;          // residual stream [M, 256] f32
@@ -249,6 +308,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void proj_ln_fwd_kernel(ProjLnArgs
 
 // ------------------------------------------------------------------------------------------------ LayerNorm backward + input gradient of the projection
 struct LnBwdProjArgs {
+  const uint16_t* slabs;   // NULL, or [nslab][M][256] 16-bit: shares of the gradient ON TOP of dy (the split FFN's backward launch in slab
+  int nslab;               // mode leaves its four input-gradient shares; dy is then the skip-path part)
   const float* dy;         // [M, 256] f32: gradient of the LayerNorm output
   const float* z;          // saved pre-norm sum x + dropout(branch)
   const float* mean; const float* rstd; const float* gamma; const uint64_t* seed;
@@ -290,6 +351,25 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ln_bwd_proj_kernel(LnBwdProjA
     dyv[i] = *reinterpret_cast<const float4*>(p.dy + row * D + col);
     zv[i] = *reinterpret_cast<const float4*>(p.z + row * D + col);
     mean[i] = p.mean[row]; rstd[i] = p.rstd[row];
+  }
+  if (p.nslab > 0) {
+    uint2 sl[4][RPW];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int64_t row = min((int64_t)row0 + wid * RPW + i, (int64_t)p.M - 1);
+        sl[s_][i] = *reinterpret_cast<const uint2*>(p.slabs + ((int64_t)min(s_, p.nslab - 1) * p.M + row) * D + col);
+      }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      const float live = s_ < p.nslab ? 1.f : 0.f;
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        dyv[i].x += live * h2f_lo(sl[s_][i].x); dyv[i].y += live * h2f_hi(sl[s_][i].x);
+        dyv[i].z += live * h2f_lo(sl[s_][i].y); dyv[i].w += live * h2f_hi(sl[s_][i].y);
+      }
+    }
   }
   float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dab[4] = {0.f, 0.f, 0.f, 0.f};
   float d4[RPW][4], z4[RPW][4], s1[RPW], s2[RPW];
@@ -521,6 +601,26 @@ extern "C" int32_t otr_rb_linear(const void* x16, int64_t ldx, const void* w_pac
   return otr_check_launch("rb_linear");
 }
 
+extern "C" int32_t otr_rb_linear_ln(const otr_dec_ln_t* ln, const void* w_pack, const float* bias, void* out, int32_t out_dtype, int64_t ldo,
+                                    int64_t M, int32_t N, int32_t K, void* stream) {
+  OTR_REQUIRE(ln && w_pack && out, "rb_linear_ln: null pointer");
+  OTR_REQUIRE(M > 0 && M < (1ll << 31) && N == 768 && K == 256, "rb_linear_ln: built for the q|k|v projection (N, K) = (768, 256), got (%d, %d)", N, K);
+  OTR_REQUIRE(ln->nslab > 0 && ln->nslab <= 4 && ln->xres && ln->slabs && ln->gamma && ln->beta, "rb_linear_ln: bad LayerNorm descriptor");
+  OTR_REQUIRE(ln->p_drop >= 0.f && ln->p_drop < 1.f && (ln->p_drop == 0.f || ln->seed), "rb_linear_ln: bad dropout arguments");
+  OTR_REQUIRE(out_dtype == OTR_F32 || out_dtype == OTR_H16, "rb_linear_ln: bad out dtype");
+  OTR_REQUIRE(ldo >= N && ldo % 4 == 0 && ((uintptr_t)out | (uintptr_t)w_pack | (uintptr_t)bias | (uintptr_t)ln->xres | (uintptr_t)ln->slabs |
+                                           (uintptr_t)ln->bias | (uintptr_t)ln->gamma | (uintptr_t)ln->beta | (uintptr_t)ln->y | (uintptr_t)ln->y16 |
+                                           (uintptr_t)ln->z) % 16 == 0, "rb_linear_ln: alignment");
+  RbLinLnArgs p{};
+  p.ln.xres = ln->xres; p.ln.x16 = nullptr; p.ln.slabs = ln->slabs; p.ln.nslab = ln->nslab; p.ln.bias = ln->bias; p.ln.gamma = ln->gamma;
+  p.ln.beta = ln->beta; p.ln.seed = ln->seed; p.ln.p_drop = ln->p_drop; p.ln.eps = ln->eps; p.ln.rng_offset = ln->rng_offset;
+  p.ln.y = ln->y; p.ln.y16 = (uint16_t*)ln->y16; p.ln.z = ln->z; p.ln.mean = ln->mean; p.ln.rstd = ln->rstd; p.ln.R = M;
+  p.pw = reinterpret_cast<const uint4*>(w_pack); p.bias = bias; p.out = out; p.ldo = ldo; p.M = (int)M; p.out_h16 = out_dtype == OTR_H16;
+  if (g_otr_rb_waves8) hipLaunchKernelGGL((rb_linear_ln_kernel<3, 1, 8>), dim3((unsigned)((M + RB - 1) / RB), 1), dim3(512), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((rb_linear_ln_kernel<3, 2, 4>), dim3((unsigned)((M + RB - 1) / RB), 2), dim3(256), 0, (hipStream_t)stream, p);
+  return otr_check_launch("rb_linear_ln");
+}
+
 extern "C" int32_t otr_proj_ln_fwd(const float* x, const void* c16, int64_t ldc, const void* w_pack, const float* bias, const float* gamma,
                                    const float* beta, const uint64_t* seed, float* y, void* y16, float* z, float* mean, float* rstd,
                                    int64_t M, int32_t d_model, float eps, float p_drop, uint64_t rng_offset, void* stream) {
@@ -555,6 +655,26 @@ extern "C" int32_t otr_ln_bwd_proj(const float* dy, const float* z, const float*
   if (g_otr_rb_waves8) hipLaunchKernelGGL(ln_bwd_proj_kernel<8>, dim3((unsigned)((M + RB - 1) / RB)), dim3(512), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(ln_bwd_proj_kernel<4>, dim3((unsigned)((M + RB - 1) / RB)), dim3(256), 0, (hipStream_t)stream, p);
   return otr_check_launch("ln_bwd_proj");
+}
+
+extern "C" int32_t otr_ln_bwd_proj_slabs(const float* dskip, const void* slabs, int32_t nslab, const float* z, const float* mean, const float* rstd,
+                                         const float* gamma, const uint64_t* seed, const void* wt_pack, float* dx, void* da16, void* dc16,
+                                         int64_t ldc, float* partial, int64_t M, int32_t d_model, float p_drop, uint64_t rng_offset,
+                                         void* stream) {
+  OTR_REQUIRE(dskip && slabs && z && mean && rstd && gamma && wt_pack && dc16, "ln_bwd_proj_slabs: null pointer");
+  OTR_REQUIRE(nslab > 0 && nslab <= 4 && (uintptr_t)slabs % 8 == 0, "ln_bwd_proj_slabs: 1 .. 4 slabs");
+  OTR_REQUIRE(d_model == 256, "ln_bwd_proj_slabs: built for d_model = 256 (got %d)", d_model);
+  OTR_REQUIRE(M >= 0 && M < (1ll << 31) && ldc >= 256 && ldc % 4 == 0 && (uintptr_t)dc16 % 8 == 0, "ln_bwd_proj_slabs: bad shape / alignment");
+  OTR_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed), "ln_bwd_proj_slabs: bad dropout");
+  if (M == 0) return 0;
+  LnBwdProjArgs p{};
+  p.slabs = reinterpret_cast<const uint16_t*>(slabs); p.nslab = nslab;
+  p.dy = dskip; p.z = z; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.seed = seed; p.pwt = reinterpret_cast<const uint4*>(wt_pack);
+  p.dx = dx; p.da16 = reinterpret_cast<uint16_t*>(da16); p.dc16 = reinterpret_cast<uint16_t*>(dc16); p.partial = partial;
+  p.ldc = ldc; p.M = (int)M; p.p_drop = p_drop; p.rng_offset = rng_offset;
+  if (g_otr_rb_waves8) hipLaunchKernelGGL(ln_bwd_proj_kernel<8>, dim3((unsigned)((M + RB - 1) / RB)), dim3(512), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(ln_bwd_proj_kernel<4>, dim3((unsigned)((M + RB - 1) / RB)), dim3(256), 0, (hipStream_t)stream, p);
+  return otr_check_launch("ln_bwd_proj_slabs");
 }
 
 extern "C" int32_t otr_rb_linear_ln_bwd(const void* g16, int64_t ldg, const void* wt_pack, const float* skip, int64_t lds, const float* z,

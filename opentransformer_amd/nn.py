@@ -244,10 +244,12 @@ def _post_norm(norm, x, branch, p, training, a_bias=None, link=None):
     return ops.add_layernorm(x, branch, norm.weight, norm.bias, p if training else 0.0, norm.eps, a_bias=a_bias, link=link)
 
 
-def _ffn_post_norm(ff, norm, x, p):
-    """LN(x + dropout(FFN(x))): one row-block fused launch (ops.FfnLnFn) for GLU FFNs on enough rows, else GEMMs + add+LN."""
+def _ffn_post_norm(ff, norm, x, p, defer_ln=False):
+    """LN(x + dropout(FFN(x))): one row-block fused launch (ops.FfnLnFn) for GLU FFNs on enough rows, else GEMMs + add+LN.
+    defer_ln: see ops.ffn_add_layernorm (the LayerNorm may be left to the launch that reads the result)."""
     if ff.activation == 'glu' and not (ff.dropout and ff.training):
-        y = ops.ffn_add_layernorm(x, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias, norm.weight, norm.bias, p, norm.eps)
+        y = ops.ffn_add_layernorm(x, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias, norm.weight, norm.bias, p, norm.eps,
+                                  defer_ln=defer_ln)
         if y is not None:
             return y
     link = ops.new_link()
@@ -316,7 +318,13 @@ class TransformerEncoderLayer(nn.Module):
         if concat_after:
             self.concat_linear = nn.Linear(d_model * 2, d_model)
 
+    # set by TransformerEncoder.forward around its calls: the block's closing LayerNorm may stay pending (ops.PendingLn) -- the caller
+    # hands the result to another block of this kind, whose first read is the q|k|v projection, or to ops.materialize.  (An attribute,
+    # not an argument: forward keeps the reference's signature.)
+    _defer_ln = False
+
     def forward(self, x, mask, pos=None, causal=False):
+        defer_ln = self._defer_ln
         p = self.residual_dropout if self.training else 0.0
         pre = self.normalize_before
         if pre:
@@ -335,7 +343,7 @@ class TransformerEncoderLayer(nn.Module):
         if pre:
             x = ops.residual_add(x, self.feed_forward(x), 1.0, p)
         else:
-            x = _ffn_post_norm(self.feed_forward, self.norm2, x, p)
+            x = _ffn_post_norm(self.feed_forward, self.norm2, x, p, defer_ln and not self.relative_positional)
         return x, {'slf_attn_weights': None}
 
     def inference(self, x, mask, pos=None, cache=None):
@@ -370,8 +378,14 @@ class TransformerEncoder(nn.Module):
         else:
             (x, _), pos = self.pos_emb(inputs), None
         km = mask.to(torch.uint8).unsqueeze(1)              # cast once; every layer's key mask is this uint8 view
+        defer = not self.normalize_before and not self.relative_positional
         for block in self.blocks:
-            x, _ = block(x, km, pos)
+            block._defer_ln = defer
+            try:
+                x, _ = block(x, km, pos)
+            finally:
+                block._defer_ln = False
+        x = ops.materialize(x)
         if self.normalize_before:
             x = _norm(self.norm, x)
         # the reference returns every layer's [B,h,T,T] weights; nothing reads them

@@ -352,6 +352,45 @@ class LnOutLink:
 _LNOUT = os.environ.get('OTR_LNOUT_LINK', '1') == '1'
 
 
+class LnInLink:
+    """Pairs the attention sub-layer's closing launch, y1 = LN(x + proj(c)) (ProjLnFn), with the split FFN that reads y1 in SLAB mode:
+    the FFN's backward launch leaves the four hidden slices' shares of d y1 as 16-bit slabs instead of summing them, so FfnLnFn.backward
+    leaves (skip-path gradient f32, slabs) in `result` and returns the zero placeholder; ProjLnFn.backward sums them while it loads
+    its rows (otr_ln_bwd_proj_slabs).  A gradient from any other consumer of y1 arrives as a real tensor and is added on top."""
+    __slots__ = ('armed', 'result')
+
+    def __init__(self):
+        self.armed, self.result = False, None
+
+
+class PendingLn:
+    """A LayerNorm output nobody has computed yet: the split FFN in slab mode returns y / y16 / z / mean / rstd as ALLOCATED buffers
+    plus this record; the first Linear that reads y (the next layer's q|k|v projection) finishes the LayerNorm in its prologue and
+    fills them (otr_rb_linear_ln), anything else calls materialize() first (otr_dec_ln: the LayerNorm alone).  Only callers that
+    control who reads y next ask for this (nn.TransformerEncoder)."""
+    __slots__ = ('kw', 'M', 'done')
+
+    def __init__(self):
+        self.kw, self.M, self.done = None, 0, True
+
+    def desc(self):
+        return _dec_ln(**self.kw)
+
+    def finish(self):
+        self.done, self.kw = True, None      # the slabs go back to the allocator
+
+
+def materialize(x):
+    """x with its pending LayerNorm (if any) computed"""
+    pend = getattr(x, '_otr_pending', None)
+    if pend is not None and not pend.done:
+        M = pend.M
+        d = pend.desc()
+        L.check(_timed('dec_ln', {'bytes': M * 256 * (4 + 8 + 4 + 2 + 4)}, lambda: L.load().otr_dec_ln(C.byref(d), M, _stream())), 'otr_dec_ln')
+        pend.finish()
+    return x
+
+
 def _zero_placeholder(device, shape):
     z = _state.setdefault('zero_scalar', {}).get(device)
     if z is None:
@@ -661,6 +700,18 @@ def rb_linear_raw(x2, pack, N, bias, out_dtype, skip=None):
     return out
 
 
+def rb_linear_pending_raw(pend, pack, N, bias, out_dtype):
+    """out[M,N] = LN(...) . W^T + bias with the pending LayerNorm finished in the launch's prologue (otr_rb_linear_ln)"""
+    M = pend.M
+    out = torch.empty((M, N), dtype=out_dtype, device=bias.device if bias is not None else pack.device)
+    d = pend.desc()
+    L.check(_timed('rb_linear_ln %dx%dx256' % (M, N), {'flops': 2.0 * M * N * 256},
+                   lambda: L.load().otr_rb_linear_ln(C.byref(d), _p(pack), _p(bias), _p(out), _code(out_dtype), out.stride(0), M, N, 256,
+                                                     _stream())), 'otr_rb_linear_ln')
+    pend.finish()
+    return out
+
+
 def rb_linear_ln_bwd_raw(g2, wt_pack, skip, saved):
     """(d z f32, d a 16-bit, partial [blocks, 3*256]) of the LayerNorm y = LN(z) whose output gradient is skip + g2 . W"""
     z, mean, rstd, gamma, seed, p_drop, off = saved
@@ -700,10 +751,18 @@ class LinearFn(torch.autograd.Function):
         packs = lin_packs(w) if (perm is None and not relu and _rb_rows_ok(x2) and x2.shape[0] >= _RB_LINEAR_MIN_ROWS
                                  and (b is None or b.data_ptr() % 16 == 0)) else None
         ctx.rb = packs
+        pend = getattr(x, '_otr_pending', None)
+        if pend is not None and pend.done:
+            pend = None
+        if pend is not None and not (packs is not None and tuple(w.shape) == (768, 256) and out_dtype in (torch.float32, half_dtype())):
+            materialize(x)
+            pend = None
         lo = getattr(x, '_otr_lnout', None)      # x is the output of a LayerNorm whose backward can run in this Linear's dgrad launch
         ctx.lnout = lo if (lo is not None and lo.armed and packs is not None and ctx.needs_input_grad[0] and x.dtype == torch.float32
                            and w.shape[1] == 256 and w.shape[0] in (256, 768)) else None
-        if packs is not None:
+        if pend is not None:
+            y = rb_linear_pending_raw(pend, packs[0], w.shape[0], b, out_dtype)
+        elif packs is not None:
             y = rb_linear_raw(x2, packs[0], w.shape[0], b, out_dtype)
         else:
             y = linear_fwd_raw(x2, wc, b, out_dtype, L.ACT_RELU if relu else L.ACT_NONE)
@@ -1140,10 +1199,14 @@ class ProjLnFn(torch.autograd.Function):
     affine gradients join the grouped launches at the end of the pass."""
 
     @staticmethod
-    def forward(ctx, x, c, w, b, gamma, beta, p_drop, eps, packs, link):
+    def forward(ctx, x, c, w, b, gamma, beta, p_drop, eps, packs, link, ilink=None):
         _cuda(x, c, w, gamma, beta)
         ctx.set_materialize_grads(False)
+        materialize(x)
         ctx.link = link
+        ctx.ilink = ilink
+        if ilink is not None:
+            ilink.armed = any(ctx.needs_input_grad)
         if link is not None:            # the branch's first Linear armed it under ITS conditions (fp32 x, no perm, no relu): keep them
             link.armed = link.armed and bool(ctx.needs_input_grad[0])
         d = x.shape[-1]
@@ -1171,21 +1234,34 @@ class ProjLnFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dylp=None):
-        if dy is None:
-            return (None,) * 10
+        stash = None
+        if ctx.ilink is not None:
+            stash, ctx.ilink.result = ctx.ilink.result, None
+        if dy is None and stash is None:
+            return (None,) * 11
         z, mean, rstd, gamma, seed, c2 = ctx.saved_tensors
         w, b, g_ref, b_ref = ctx.refs
         M, d, p_drop, off, xshape, cshape, packs = ctx.cfg
-        dy2 = dy.reshape(-1, d).contiguous()
-        dx = torch.empty_like(dy2)
-        da = torch.empty((M, d), dtype=half_dtype(), device=dy.device)
-        dc = torch.empty((M, d), dtype=half_dtype(), device=dy.device)
+        dev = z.device
+        dx = torch.empty((M, d), dtype=torch.float32, device=dev)
+        da = torch.empty((M, d), dtype=half_dtype(), device=dev)
+        dc = torch.empty((M, d), dtype=half_dtype(), device=dev)
         nrow = L.load().otr_ln_bwd_proj_partial_rows(M)
-        part = torch.empty((nrow, 3 * d), dtype=torch.float32, device=dy.device)
-        L.check(_timed('ln_bwd_proj', {'flops': 2.0 * M * d * d},
-                       lambda: L.load().otr_ln_bwd_proj(_p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed), _p(packs[1]), _p(dx),
-                                                        _p(da), _p(dc), dc.stride(0), _p(part), M, d, p_drop, off, _stream())),
-                'otr_ln_bwd_proj')
+        part = torch.empty((nrow, 3 * d), dtype=torch.float32, device=dev)
+        if stash is not None:           # see LnInLink: the FFN's backward launch left (skip-path gradient, four slabs)
+            dskip, bslabs = stash
+            if dy is not None and not _is_zero_placeholder(dy):
+                dskip = dskip + dy.reshape(-1, d)
+            L.check(_timed('ln_bwd_proj', {'flops': 2.0 * M * d * d},
+                           lambda: L.load().otr_ln_bwd_proj_slabs(_p(dskip), _p(bslabs), bslabs.shape[0], _p(z), _p(mean), _p(rstd),
+                                                                  _p(gamma), _p(seed), _p(packs[1]), _p(dx), _p(da), _p(dc), dc.stride(0),
+                                                                  _p(part), M, d, p_drop, off, _stream())), 'otr_ln_bwd_proj_slabs')
+        else:
+            dy2 = dy.reshape(-1, d).contiguous()
+            L.check(_timed('ln_bwd_proj', {'flops': 2.0 * M * d * d},
+                           lambda: L.load().otr_ln_bwd_proj(_p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed), _p(packs[1]), _p(dx),
+                                                            _p(da), _p(dc), dc.stride(0), _p(part), M, d, p_drop, off, _stream())),
+                    'otr_ln_bwd_proj')
         outs = []
         for k, ref in ((0, g_ref), (1, b_ref), (2, b)):
             if ref is None:
@@ -1206,7 +1282,7 @@ class ProjLnFn(torch.autograd.Function):
             ctx.link.buf = dx           # the branch's first Linear adds its input gradient into this and returns the sum
             _park(ctx.link)
             dx_ret = None
-        return (dx_ret, dc.view(cshape), None if gw is not None else dw, dbias, dgamma, dbeta, None, None, None, None)
+        return (dx_ret, dc.view(cshape), None if gw is not None else dw, dbias, dgamma, dbeta, None, None, None, None, None)
 
 
 def proj_ln_packs(x, c, w, gamma):
@@ -1219,7 +1295,10 @@ def proj_ln_packs(x, c, w, gamma):
 
 
 def proj_add_layernorm(x, c, w, b, gamma, beta, p_drop, eps, packs, link=None):
-    y, ylp = ProjLnFn.apply(x, c, w, b, gamma, beta, float(p_drop), float(eps), packs, link)
+    ilink = LnInLink() if (_FFN_SLAB and torch.is_grad_enabled()) else None
+    y, ylp = ProjLnFn.apply(x, c, w, b, gamma, beta, float(p_drop), float(eps), packs, link, ilink)
+    if ilink is not None and ilink.armed:
+        y._otr_inlink = ilink
     return attach_lp(y, ylp)
 
 
@@ -1318,6 +1397,8 @@ _FUSED_FFN_MIN_ROWS = int(os.environ.get('OTR_FUSED_FFN_MIN_ROWS', '1024'))   # 
 # 128-row workgroups with the hidden units split four ways and the partial sums exchanged inside the launch (csrc/ffn3.hip):
 # the default from 2048 rows up; OTR_FFN_SPLIT=0 keeps the 32-row kernels
 _FFN_SPLIT = os.environ.get('OTR_FFN_SPLIT', '1') == '1'
+# the split kernels in slab mode (no in-launch exchange; the LayerNorm moves into the next launch's prologue) where the caller allows it
+_FFN_SLAB = os.environ.get('OTR_FFN_SLAB', '1') == '1'
 _FFN_SPLIT_MIN_ROWS = 2048
 _FFN_SYNC_INTS = 1 << 14
 
@@ -1412,9 +1493,10 @@ class FfnLnFn(torch.autograd.Function):
     decoder/transformer.py:82-86) on the row-block fused kernels."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, p_drop, eps, packs, olink=None):
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, p_drop, eps, packs, olink=None, pend=None, ilink=None):
         _cuda(x, w1, b1, w2, b2, gamma, beta)
         ctx.set_materialize_grads(False)
+        materialize(x)
         d = x.shape[-1]
         x2 = x.reshape(-1, d)
         x16 = lp_of(x).reshape(-1, d)
@@ -1428,8 +1510,23 @@ class FfnLnFn(torch.autograd.Function):
         seed = rng_seed_tensor(x.device) if p_drop > 0 else None
         off = _next_rng_offset(M * d) if p_drop > 0 else 0
         ctx.split = _ffn_split(M, F)
+        ctx.slab = ctx.split and pend is not None and x2.is_contiguous()
+        ctx.ilink = ilink if ctx.slab else None
         hsave = usave = None
-        if ctx.split:
+        if ctx.slab:
+            # slab mode: the four hidden slices leave 16-bit partial sums, whoever reads y finishes the LayerNorm (PendingLn)
+            lib = L.load()
+            if need_grad:
+                hsave = torch.empty(lib.otr_ffn_split_hsave_bytes(M, F) // 2, dtype=x16.dtype, device=x.device)
+                usave = torch.empty((lib.otr_ffn_split_padded_rows(M), F), dtype=x16.dtype, device=x.device)
+            slabs = torch.empty((4, M, d), dtype=x16.dtype, device=x.device)
+            L.check(_timed('ffn_fwd_slab', {'flops': 6.0 * M * F * d, 'bytes': M * d * (2 + 8) + 6 * F * d + (M * F * 6 if need_grad else 0)},
+                           lambda: lib.otr_ffn_fwd_split_slab(_p(x16), _p(packs[0]), _p(b1), _p(packs[1]), _p(hsave), _p(usave), _p(slabs),
+                                                              M, F, d, _stream())), 'otr_ffn_fwd_split_slab')
+            pend.kw = dict(xres=x2, slabs=slabs, nslab=4, bias=b2, gamma=gamma, beta=beta, seed=seed, p_drop=p_drop, eps=eps, off=off,
+                           y=y, y16=y16, z=z, mean=mean, rstd=rstd)
+            pend.M, pend.done = M, False
+        elif ctx.split:
             lib = L.load()
             nb = lib.otr_ffn_split_scratch_bytes(M)
             scratch = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
@@ -1463,7 +1560,7 @@ class FfnLnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dy16=None):
         if dy is None:
-            return (None,) * 11
+            return (None,) * 13
         x16, z, mean, rstd, gamma, seed, b1, hsave, usave = ctx.saved_tensors
         M, d, F, eps, p_drop, off, xshape = ctx.cfg
         w1p, b1p, w2p, b2p, gp, bp = ctx.refs
@@ -1519,19 +1616,34 @@ class FfnLnFn(torch.autograd.Function):
                 ret_b2 = dgb[2]
         if ctx.split and hsave is not None:
             # 128-row workgroups, the hidden read back from the forward pass's tiles: dh for the w_1 weight gradient; dx += dh . w_1
-            nb = lib.otr_ffn_split_scratch_bytes(M)
-            scratch = torch.empty(nb // 4, dtype=torch.float32, device=dy.device)
-            sync = _ffn_sync(dy.device)
             dh = torch.empty((usave.shape[0], 2 * F), dtype=x16.dtype, device=dy.device)[:M]
-            L.check(_timed('ffn_bwd_split', {'flops': 6.0 * M * F * d, 'bytes': M * d * (2 + 4 + 4) + M * F * 8 + 6 * F * d},
-                           lambda: lib.otr_ffn_bwd_split(_p(da), _p(hsave), _p(P3), _p(P4), _p(dh), _p(dx), _p(dx), _p(scratch), nb,
-                                                         _p(sync), sync.numel(), M, F, d, _stream())), 'otr_ffn_bwd_split')
+            if ctx.slab:
+                bslabs = torch.empty((4, M, d), dtype=x16.dtype, device=dy.device)
+                L.check(_timed('ffn_bwd_slab', {'flops': 6.0 * M * F * d, 'bytes': M * d * (2 + 8) + M * F * 8 + 6 * F * d},
+                               lambda: lib.otr_ffn_bwd_split_slab(_p(da), _p(hsave), _p(P3), _p(P4), _p(dh), _p(bslabs), M, F, d,
+                                                                  _stream())), 'otr_ffn_bwd_split_slab')
+                il = ctx.ilink
+                if il is not None and il.armed and il.result is None and _in_backward():
+                    il.result = (dx, bslabs)          # see LnInLink: the attention sub-layer's closing launch sums them
+                    _park(il)
+                    dx = _zero_placeholder(dy.device, xshape)
+                else:
+                    tot = torch.empty_like(dx)
+                    L.check(lib.otr_dec_sum(_p(dx), _p(bslabs), 4, M, _p(tot), _stream()), 'otr_dec_sum')
+                    dx = tot
+            else:
+                nb = lib.otr_ffn_split_scratch_bytes(M)
+                scratch = torch.empty(nb // 4, dtype=torch.float32, device=dy.device)
+                sync = _ffn_sync(dy.device)
+                L.check(_timed('ffn_bwd_split', {'flops': 6.0 * M * F * d, 'bytes': M * d * (2 + 4 + 4) + M * F * 8 + 6 * F * d},
+                               lambda: lib.otr_ffn_bwd_split(_p(da), _p(hsave), _p(P3), _p(P4), _p(dh), _p(dx), _p(dx), _p(scratch), nb,
+                                                             _p(sync), sync.numel(), M, F, d, _stream())), 'otr_ffn_bwd_split')
             gw1, gb1, gw2 = grad_target(w1p), grad_target(b1p), grad_target(w2p)
             dw1 = linear_wgrad_raw(dh, x16, None, out=gw1)
             dw2 = linear_wgrad_raw(da, usave[:M], None, out=gw2)
             db1 = colsum_raw(dh, out=gb1)               # rides along with the w_1 weight-gradient launch (same matrix)
             return (dx.view(xshape), None if gw1 is not None else dw1, None if gb1 is not None else db1,
-                    None if gw2 is not None else dw2, ret_b2, ret_g, ret_b, None, None, None, None)
+                    None if gw2 is not None else dw2, ret_b2, ret_g, ret_b, None, None, None, None, None, None)
         # FFN backward with recompute: dh, u for the weight gradients; dx += dh . w_1
         dh = torch.empty((M, 2 * F), dtype=x16.dtype, device=dy.device)
         u = torch.empty((M, F), dtype=x16.dtype, device=dy.device)
@@ -1544,11 +1656,12 @@ class FfnLnFn(torch.autograd.Function):
         dw2 = linear_wgrad_raw(da, u, None, out=gw2)
         db1 = colsum_raw(bpart, out=gb1)             # per-workgroup column sums of dh, written by the backward kernel
         return (dx.view(xshape), None if gw1 is not None else dw1, None if gb1 is not None else db1,
-                None if gw2 is not None else dw2, ret_b2, ret_g, ret_b, None, None, None, None)
+                None if gw2 is not None else dw2, ret_b2, ret_g, ret_b, None, None, None, None, None, None)
 
 
-def ffn_add_layernorm(x, w1, b1, w2, b2, gamma, beta, p_drop=0.0, eps=1e-5):
-    """Fused FFN sub-layer when it applies (GLU, d_model 256, a 16-bit twin of x, enough rows); else None."""
+def ffn_add_layernorm(x, w1, b1, w2, b2, gamma, beta, p_drop=0.0, eps=1e-5, defer_ln=False):
+    """Fused FFN sub-layer when it applies (GLU, d_model 256, a 16-bit twin of x, enough rows); else None.
+    defer_ln: the caller guarantees that whoever reads the result next goes through ops.linear / ops.materialize (PendingLn)."""
     if lp_of(x) is None or x.dtype != torch.float32 or x.shape[-1] != 256:
         return None
     if x.numel() // 256 < _FUSED_FFN_MIN_ROWS:
@@ -1557,9 +1670,13 @@ def ffn_add_layernorm(x, w1, b1, w2, b2, gamma, beta, p_drop=0.0, eps=1e-5):
     if packs is None or b1 is None or b2 is None:
         return None
     olink = LnOutLink() if (_LNOUT and torch.is_grad_enabled()) else None
-    y, y16 = FfnLnFn.apply(x, w1, b1, w2, b2, gamma, beta, float(p_drop), float(eps), packs, olink)
+    pend = PendingLn() if (defer_ln and _FFN_SLAB) else None
+    y, y16 = FfnLnFn.apply(x, w1, b1, w2, b2, gamma, beta, float(p_drop), float(eps), packs, olink, pend,
+                           getattr(x, '_otr_inlink', None))
     if olink is not None and olink.armed:
         y._otr_lnout = olink
+    if pend is not None and not pend.done:
+        y._otr_pending = pend
     return attach_lp(y, y16)
 
 

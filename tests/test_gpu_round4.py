@@ -200,8 +200,11 @@ def test_fused_adam_resume_continues_the_run(mode):
         opt2.load_state_dict(ck_opt)
         steps(dp2, opt2, 2, 3)
         torch.cuda.synchronize()
-        # not bitwise: two runs of one backward pass differ in the last bits (float atomics in the embedding gradient)
-        assert rel(dp2.flat_param, dp.flat_param) < 1e-6 and rel(opt2.exp_avg, opt.exp_avg) < 1e-4
+        # not bitwise: two runs of one backward pass differ in the last bits (float atomics in the embedding gradient).  Parameters whose
+        # gradient is zero in exact arithmetic (the key third of every q|k|v bias) carry only that noise, and Adam (eps 1e-9) turns noise
+        # into steps of +-lr: a few hundred elements may differ by lr between two otherwise identical runs -- seen in fp32 mode, one
+        # run in three, 6e-5 .. 9e-5 of the parameter norm
+        assert rel(dp2.flat_param, dp.flat_param) < (5e-4 if mode == 'fp32' else 1e-6) and rel(opt2.exp_avg, opt.exp_avg) < 1e-4
         assert rel(opt2.exp_avg_sq, opt.exp_avg_sq) < 1e-4
         s1, s2 = opt.stats(), opt2.stats()
         assert s1['step'] == s2['step'] == 5 and s1['lr'] == s2['lr'] and s1['loss_scale'] == s2['loss_scale'] and s2['skipped'] == 0
