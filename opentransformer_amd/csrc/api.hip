@@ -46,6 +46,7 @@ int g_otr_wgrad256_ablate = 0;   // tuning hook (otr_debug_set(8, v)), see wgrad
 int g_otr_wgrad256_min_rows = 256;   // shortest contraction the 256-wide launch takes (otr_debug_set(9, v))
 extern int g_otr_conv2_dgrad_ablate;   // conv.hip (otr_debug_set(10, v))
 int g_otr_wgrad256_grid = 0; // workgroups of that launch; 0 = one per CU (otr_debug_set(7, v))
+int g_otr_attn_enc = 1;          // encoder-shape attention backward with the whole (utterance, head) in LDS (otr_debug_set(21, v))
 int g_otr_rb_waves8 = 1;         // 256-column row-block kernels on 8-wave workgroups (otr_debug_set(19, v))
 int g_otr_rb_nsplit = 1;         // q|k|v row-block projection: 1 = two workgroups per row block, 384 columns each (otr_debug_set(18, v))
 int g_otr_conv1_stencil = 0;     // 1: conv1 forward on the VALU stencil instead of the fp32 matrix pipe (otr_debug_set(17, v))
@@ -78,6 +79,7 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   else if (key == 17) g_otr_conv1_stencil = value;
   else if (key == 18) g_otr_rb_nsplit = value;
   else if (key == 19) g_otr_rb_waves8 = value;
+  else if (key == 21) g_otr_attn_enc = value;
   else if (key == 15) g_otr_ffn_map = value;
   else { otr_set_error("debug_set: unknown key %d", key); return -1; }
   return 0;

@@ -1,0 +1,298 @@
+// Encoder self-attention backward for the shipped shape class (module/attention.py:23-46 under autograd; encoder/transformer.py:47-49):
+// 16-bit operands, head dim 64, no causal mask, no score bias, T <= 256 frames after the frontend (AISHELL: 249).
+//
+// Why a second kernel beside attention.hip: that one is generic (any T, head dim, fp32) -- 16-row MFMA tiles, the streamed side
+// re-staged block by block behind two barriers each, every 16-cycle MFMA fed by a fresh 1 KiB LDS operand.  At 32 x 4 x 249 x 64 it
+// took 34 us for 7 GFLOP (LDS-read and barrier bound: ~770 KiB of operand reads per CU and block step against 128 B/clk).
+// Here one (utterance, head) is small enough to live in LDS WHOLE:
+//   * 2 workgroups per (utterance, head) -- one per ORIENTATION, 8 waves each, 256 workgroups for 32 x 4: one per CU, the pair on
+//     one XCD (they read the same rows);
+//       orientation 0: lane = query, registers = keys   -> dQ       (wave w owns queries 32 w .. + 31)
+//       orientation 1: lane = key,   registers = queries -> dK, dV  (wave w owns keys 32 w .. + 31)
+//   * the streamed side is staged ONCE (row-major image for the products contracted over the head dim, transposed image for the ones
+//     contracted over the streamed index), then every wave walks the 32-row tiles on its own: no barrier, no global load in the loop;
+//   * 32 x 32 x 16 MFMAs: half the operand bytes per flop of the 16-row tiles; the owned side's fragments stay in registers;
+//   * P and dS go from the accumulators straight back into MFMA operands (the accumulator layout is an operand layout once the
+//     contraction slots are taken in accumulator order -- the transposed images are read in that order, dl_tfrag in declayer.hip);
+//   * delta = rowsum(dO . O) is formed on the way in (no separate pass), outputs leave through LDS as whole 128-byte rows.
+// Work per (utterance, head): 7 products of T x T x 64 (S and dP are formed in both orientations) -- the same recompute as before.
+#include "common.h"
+
+namespace {
+
+constexpr int EA_T = 256;                 // most frames served
+constexpr int EA_DK = 64;
+constexpr int EA_HS = EA_DK * 2 + 16;     // bytes per row of a row-major [T][64] 16-bit image
+constexpr int EA_TS = EA_T * 2 + 8;       // bytes per row of a transposed [64][T] 16-bit image
+constexpr int EA_RM = EA_T * EA_HS;       // 36864
+constexpr int EA_TR = EA_DK * EA_TS;      // 33280
+constexpr float EA_LOG2E = 1.4426950408889634f;
+
+struct EaArgs {
+  const uint16_t *q, *k, *v, *o, *do_;
+  uint16_t *dq, *dk, *dv;
+  const uint8_t* key_mask;
+  const float* lse;
+  int B, H, T;
+  int64_t q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
+  float scale;
+};
+
+__device__ __forceinline__ uint4 ea_frag(const unsigned char* img, int row, int hi, int ks) {
+  return *reinterpret_cast<const uint4*>(img + row * EA_HS + (2 * ks + hi) * 16);
+}
+// contraction slots of step k2 (16 streamed rows from `col0`) in accumulator order: rows col0 + 16 k2 + 4 hi + e, then + 8
+__device__ __forceinline__ uint4 ea_tfrag(const unsigned char* timg, int row, int col0, int hi, int k2) {
+  const unsigned char* vr = timg + row * EA_TS + (col0 + 16 * k2 + 4 * hi) * 2;
+  const uint2 lo = *reinterpret_cast<const uint2*>(vr), up = *reinterpret_cast<const uint2*>(vr + 16);
+  return make_uint4(lo.x, lo.y, up.x, up.y);
+}
+__device__ __forceinline__ uint4 ea_pack8(const float* v) {
+  return make_uint4(pack2h(v[0], v[1]), pack2h(v[2], v[3]), pack2h(v[4], v[5]), pack2h(v[6], v[7]));
+}
+__device__ __forceinline__ void ea_zero(f32x16& a) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// rows 0 .. T-1 of a [T][64] matrix (row stride ts elements) -> row-major image, rows T .. nt 32 - 1 zero.  512 threads, 16-byte pieces.
+// DOT: the same pieces of a second matrix are loaded beside them and sdot[row] = sum_d a[row][d] b[row][d] is left in LDS.
+template <bool DOT>
+__device__ __forceinline__ void ea_stage_rm(unsigned char* img, const uint16_t* src, int64_t ts, const uint16_t* src2, int64_t ts2, float* sdot, int T,
+                                            int nrows, int tid) {
+  uint4 v[4], w[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int id = tid + 512 * k, row = id >> 3, c = id & 7, rr = min(row, T - 1);
+    v[k] = ld_global_b128(src + (int64_t)rr * ts + 8 * c);
+    if constexpr (DOT) w[k] = ld_global_b128(src2 + (int64_t)rr * ts2 + 8 * c);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int id = tid + 512 * k, row = id >> 3, c = id & 7;
+    if (row >= nrows) continue;
+    const uint32_t live = (uint32_t)0 - (uint32_t)(row < T);
+    uint4 q = v[k];
+    q.x &= live; q.y &= live; q.z &= live; q.w &= live;
+    *reinterpret_cast<uint4*>(img + row * EA_HS + c * 16) = q;
+    if constexpr (DOT) {
+      const uint32_t a[4] = {q.x, q.y, q.z, q.w}, b[4] = {w[k].x, w[k].y, w[k].z, w[k].w};
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part += h2f_lo(a[e]) * h2f_lo(b[e]) + h2f_hi(a[e]) * h2f_hi(b[e]);
+      part += __shfl_xor(part, 1);
+      part += __shfl_xor(part, 2);
+      part += __shfl_xor(part, 4);
+      if (c == 0) sdot[row] = part;
+    }
+  }
+}
+// transposed image of a staged row-major image: timg[d][row] (two rows per 32-bit store).  Call between two barriers.
+__device__ __forceinline__ void ea_transpose(unsigned char* timg, const unsigned char* img, int nrows, int tid) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int id = tid + 512 * k, rp = id & 127, c = id >> 7;
+    if (2 * rp >= nrows) continue;
+    const uint4 a = *reinterpret_cast<const uint4*>(img + (2 * rp) * EA_HS + c * 16);
+    const uint4 b = *reinterpret_cast<const uint4*>(img + (2 * rp + 1) * EA_HS + c * 16);
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      *reinterpret_cast<uint32_t*>(timg + (8 * c + 2 * e) * EA_TS + 4 * rp) = (aw[e] & 0xffffu) | (bw[e] << 16);
+      *reinterpret_cast<uint32_t*>(timg + (8 * c + 2 * e + 1) * EA_TS + 4 * rp) = (aw[e] >> 16) | (bw[e] & 0xffff0000u);
+    }
+  }
+}
+
+// own side: the four contraction-step fragments of row `row` (lane (m, hi) holds elements 16 ks + 8 hi .. + 7)
+__device__ __forceinline__ void ea_load_frags(uint4 (&f)[4], const uint16_t* src, int64_t ts, int row, int hi) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) f[ks] = ld_global_b128(src + (int64_t)row * ts + 16 * ks + 8 * hi);
+}
+
+// accumulator tiles (lane = own row m, registers = head dim 32 ct + 8 q + 4 hi + (r & 3)) x scale -> this wave's 32 rows of a row-major
+// image -> memory as whole 128-byte rows
+__device__ __forceinline__ void ea_store_rows(const f32x16 (&acc)[2], float scale, unsigned char* og, uint16_t* dst, int64_t ts, int row0, int T,
+                                              int lane) {
+  const int m = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<uint2*>(og + m * EA_HS + (32 * ct + 8 * q + 4 * hi) * 2) =
+          make_uint2(pack2h(acc[ct][4 * q] * scale, acc[ct][4 * q + 1] * scale), pack2h(acc[ct][4 * q + 2] * scale, acc[ct][4 * q + 3] * scale));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int j = 8 * q + (lane >> 3), ch = lane & 7;
+    if (row0 + j < T) st_global_b128(dst + (int64_t)(row0 + j) * ts + 8 * ch, *reinterpret_cast<const uint4*>(og + j * EA_HS + ch * 16));
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+constexpr int EA_SMEM = 2 * EA_RM + 2 * EA_TR + 2 * EA_T * 4;
+
+__global__ __launch_bounds__(512, 1) void encattn_bwd_kernel(EaArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[EA_SMEM];
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, hi = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // the two orientations of one (utterance, head) get workgroup ids equal modulo 8: one XCD (placement observed, used for locality only)
+  const int xcd = (int)blockIdx.x & 7, kk = (int)blockIdx.x >> 3;
+  const int orient = kk & 1, g = (kk >> 1) * 8 + xcd;
+  if (g >= p.H * p.B) return;
+  const int h = g % p.H, b = g / p.H;
+  const int T = p.T, nt = (T + 31) >> 5, nrows = nt * 32;
+  const float sc2 = p.scale * EA_LOG2E;
+  const uint16_t* Q = p.q + (int64_t)b * p.q_bs + h * EA_DK;
+  const uint16_t* K = p.k + (int64_t)b * p.k_bs + h * EA_DK;
+  const uint16_t* V = p.v + (int64_t)b * p.v_bs + h * EA_DK;
+  const uint16_t* O = p.o + (int64_t)b * p.o_bs + h * EA_DK;
+  const uint16_t* dO = p.do_ + (int64_t)b * p.o_bs + h * EA_DK;
+  const float* lse = p.lse + ((int64_t)b * p.H + h) * T;
+  const uint8_t* km = p.key_mask ? p.key_mask + (int64_t)b * T : nullptr;
+  const int own = 32 * wid + m;                                  // this lane's own row (query or key)
+  const int ownc = min(own, T - 1);
+
+  if (orient == 0) {
+    // ------------------------------------------------------------------ lane = query: dQ = scale . dS K
+    unsigned char* krm = smem;
+    unsigned char* vrm = smem + EA_RM;
+    unsigned char* kt = smem + 2 * EA_RM;
+    float* kbias = reinterpret_cast<float*>(smem + 2 * EA_RM + EA_TR);          // 0 for a live key, -inf for a masked one / past T
+    ea_stage_rm<false>(krm, K, p.k_ts, nullptr, 0, nullptr, T, nrows, tid);
+    ea_stage_rm<false>(vrm, V, p.v_ts, nullptr, 0, nullptr, T, nrows, tid);
+    uint4 qf[4], dof[4], of[4];
+    ea_load_frags(qf, Q, p.q_ts, ownc, hi);
+    ea_load_frags(dof, dO, p.o_ts, ownc, hi);
+    ea_load_frags(of, O, p.o_ts, ownc, hi);
+    const float l0 = lse[ownc];
+    if (tid < EA_T) kbias[tid] = (tid < T && (!km || km[min(tid, T - 1)])) ? 0.f : -__builtin_huge_valf();
+    __syncthreads();
+    ea_transpose(kt, krm, nrows, tid);
+    float del = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const uint32_t a[4] = {dof[ks].x, dof[ks].y, dof[ks].z, dof[ks].w}, c[4] = {of[ks].x, of[ks].y, of[ks].z, of[ks].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) del += h2f_lo(a[e]) * h2f_lo(c[e]) + h2f_hi(a[e]) * h2f_hi(c[e]);
+    }
+    del += __shfl_xor(del, 32);
+    // a query row with no live key at all (lse = -inf) has P = 0 everywhere; rows past T contribute nothing and are not stored
+    const float nl = (own < T && l0 != -__builtin_huge_valf()) ? -l0 * EA_LOG2E : -__builtin_huge_valf();
+    __syncthreads();
+    f32x16 dq[2];
+    ea_zero(dq[0]); ea_zero(dq[1]);
+    if (32 * wid < T) {
+      for (int jt = 0; jt < nt; ++jt) {
+        const unsigned char* kr = krm + jt * 32 * EA_HS;
+        const unsigned char* vr = vrm + jt * 32 * EA_HS;
+        f32x16 st, dp;
+        ea_zero(st); ea_zero(dp);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { mma32(st, ea_frag(kr, m, hi, ks), qf[ks]); mma32(dp, ea_frag(vr, m, hi, ks), dof[ks]); }
+        float dsv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 kb = *reinterpret_cast<const float4*>(kbias + jt * 32 + 8 * q + 4 * hi);
+          const float kb4[4] = {kb.x, kb.y, kb.z, kb.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e;
+            const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc2, nl) + kb4[e]);
+            dsv[r] = pe * (dp[r] - del);
+          }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const uint4 pb = ea_pack8(dsv + 8 * k2);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) mma32(dq[ct], ea_tfrag(kt, 32 * ct + m, jt * 32, hi, k2), pb);
+        }
+      }
+    }
+    __syncthreads();                                               // every wave is done with the images: they become staging space
+    if (32 * wid < T) ea_store_rows(dq, p.scale, krm + 32 * wid * EA_HS, p.dq + (int64_t)b * p.q_bs + h * EA_DK, p.q_ts, 32 * wid, T, lane);
+  } else {
+    // ------------------------------------------------------------------ lane = key: dV = P^T dO, dK = scale . dS^T Q
+    unsigned char* qrm = smem;
+    unsigned char* dorm = smem + EA_RM;
+    unsigned char* qt = smem + 2 * EA_RM;
+    unsigned char* dot = smem + 2 * EA_RM + EA_TR;
+    float* nls = reinterpret_cast<float*>(smem + 2 * EA_RM + 2 * EA_TR);       // -lse log2(e) per query (-inf: no live key / past T)
+    float* dels = nls + EA_T;
+    ea_stage_rm<false>(qrm, Q, p.q_ts, nullptr, 0, nullptr, T, nrows, tid);
+    ea_stage_rm<true>(dorm, dO, p.o_ts, O, p.o_ts, dels, T, nrows, tid);
+    uint4 kf[4], vf[4];
+    ea_load_frags(kf, K, p.k_ts, ownc, hi);
+    ea_load_frags(vf, V, p.v_ts, ownc, hi);
+    if (tid < EA_T) {
+      const float l0 = lse[min(tid, T - 1)];
+      nls[tid] = (tid < T && l0 != -__builtin_huge_valf()) ? -l0 * EA_LOG2E : -__builtin_huge_valf();
+    }
+    const bool keyok = own < T && (!km || km[ownc]);
+    const float kb = keyok ? 0.f : -__builtin_huge_valf();
+    __syncthreads();
+    ea_transpose(qt, qrm, nrows, tid);
+    ea_transpose(dot, dorm, nrows, tid);
+    __syncthreads();
+    f32x16 dk[2], dv[2];
+    ea_zero(dk[0]); ea_zero(dk[1]); ea_zero(dv[0]); ea_zero(dv[1]);
+    if (32 * wid < T) {
+      for (int it = 0; it < nt; ++it) {
+        const unsigned char* qr = qrm + it * 32 * EA_HS;
+        const unsigned char* dr = dorm + it * 32 * EA_HS;
+        f32x16 st, dp;
+        ea_zero(st); ea_zero(dp);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { mma32(st, ea_frag(qr, m, hi, ks), kf[ks]); mma32(dp, ea_frag(dr, m, hi, ks), vf[ks]); }
+        float pv[16], dsv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 nl = *reinterpret_cast<const float4*>(nls + it * 32 + 8 * q + 4 * hi);
+          const float4 de = *reinterpret_cast<const float4*>(dels + it * 32 + 8 * q + 4 * hi);
+          const float nl4[4] = {nl.x, nl.y, nl.z, nl.w}, de4[4] = {de.x, de.y, de.z, de.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e;
+            pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc2, nl4[e]) + kb);
+            dsv[r] = pv[r] * (dp[r] - de4[e]);
+          }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const uint4 pb = ea_pack8(pv + 8 * k2), sb = ea_pack8(dsv + 8 * k2);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            mma32(dv[ct], ea_tfrag(dot, 32 * ct + m, it * 32, hi, k2), pb);
+            mma32(dk[ct], ea_tfrag(qt, 32 * ct + m, it * 32, hi, k2), sb);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (32 * wid < T) {
+      ea_store_rows(dk, p.scale, qrm + 32 * wid * EA_HS, p.dk + (int64_t)b * p.k_bs + h * EA_DK, p.k_ts, 32 * wid, T, lane);
+      ea_store_rows(dv, 1.f, dorm + 32 * wid * EA_HS, p.dv + (int64_t)b * p.v_bs + h * EA_DK, p.v_ts, 32 * wid, T, lane);
+    }
+  }
+}
+
+}  // namespace
+
+// shapes this kernel serves (attention.hip asks before it takes its own path)
+bool encattn_bwd_takes(int dtype_is_h16, int dk, int Tq, int Tk, int causal, int has_bias, int vec) {
+  return dtype_is_h16 && dk == EA_DK && Tq == Tk && Tq >= 1 && Tq <= EA_T && !causal && !has_bias && vec;
+}
+
+int32_t encattn_bwd_launch(const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse, const uint8_t* key_mask,
+                           void* dq, void* dk, void* dv, int B, int H, int T, int64_t q_bs, int64_t q_ts, int64_t k_bs, int64_t k_ts, int64_t v_bs,
+                           int64_t v_ts, int64_t o_bs, int64_t o_ts, float scale, hipStream_t stream) {
+  EaArgs p{};
+  p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.v = (const uint16_t*)v; p.o = (const uint16_t*)o; p.do_ = (const uint16_t*)do_;
+  p.dq = (uint16_t*)dq; p.dk = (uint16_t*)dk; p.dv = (uint16_t*)dv; p.key_mask = key_mask; p.lse = lse;
+  p.B = B; p.H = H; p.T = T; p.q_bs = q_bs; p.q_ts = q_ts; p.k_bs = k_bs; p.k_ts = k_ts; p.v_bs = v_bs; p.v_ts = v_ts; p.o_bs = o_bs; p.o_ts = o_ts;
+  p.scale = scale;
+  const unsigned grid = 8u * 2u * (unsigned)((H * B + 7) / 8);
+  hipLaunchKernelGGL(encattn_bwd_kernel, dim3(grid), dim3(512), 0, stream, p);
+  return otr_check_launch("encattn_bwd");
+}

@@ -135,6 +135,7 @@ def test_attention_bwd_one_launch_equals_two(mode, B, T, H, dk, causal):
     lib = L.load()
     res = []
     try:
+        L.check(lib.otr_debug_set(21, 0), 'debug_set')        # the generic kernels (the encoder-shape kernel has its own tests)
         for two in (0, 1):
             L.check(lib.otr_debug_set(13, two), 'debug_set')
             out = ops.SelfAttentionFn.apply(qkv, km.to(torch.uint8), H, causal)
@@ -142,6 +143,7 @@ def test_attention_bwd_one_launch_equals_two(mode, B, T, H, dk, causal):
             res.append(dqkv.float())
     finally:
         lib.otr_debug_set(13, 0)
+        lib.otr_debug_set(21, 1)
     assert torch.equal(res[0][..., :d], res[1][..., :d])
     assert rel(res[0][..., d:], res[1][..., d:]) < (1e-5 if mode == 'fp32' else 2e-3)
 
@@ -161,6 +163,7 @@ def test_attention_workgroup_mapping_does_not_change_results(mode, B, T, H, dk, 
     lib = L.load()
     res = []
     try:
+        L.check(lib.otr_debug_set(21, 0), 'debug_set')        # the generic kernels (the encoder-shape kernel's grid is fixed)
         for xmap in (1, 0):
             L.check(lib.otr_debug_set(16, xmap), 'debug_set')
             out = ops.SelfAttentionFn.apply(qkv, km.to(torch.uint8), H, causal)
@@ -168,6 +171,7 @@ def test_attention_workgroup_mapping_does_not_change_results(mode, B, T, H, dk, 
             res.append((out.detach().clone(), dqkv.clone()))
     finally:
         lib.otr_debug_set(16, 1)
+        lib.otr_debug_set(21, 1)
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
