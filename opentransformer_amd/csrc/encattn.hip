@@ -28,7 +28,11 @@ constexpr int EA_RM = EA_T * EA_HS;       // 36864
 constexpr int EA_TR = EA_DK * EA_TS;      // 33280
 constexpr float EA_LOG2E = 1.4426950408889634f;
 
+// tuning hook (otr_debug_trace): thread 0 stamps the shader clock into trace[16384 + ((6 + orientation) * 256 + unit) * 16 + k]
+#define EA_STAMP(K) do { if (p.trace && threadIdx.x == 0 && g < 256) p.trace[16384 + ((6 + orient) * 256 + g) * 16 + (K)] = __builtin_amdgcn_s_memtime(); } while (0)
+
 struct EaArgs {
+  unsigned long long* trace;
   const uint16_t *q, *k, *v, *o, *do_;
   uint16_t *dq, *dk, *dv;
   const uint8_t* key_mask;
@@ -55,52 +59,45 @@ __device__ __forceinline__ void ea_zero(f32x16& a) {
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 
-// rows 0 .. T-1 of a [T][64] matrix (row stride ts elements) -> row-major image, rows T .. nt 32 - 1 zero.  512 threads, 16-byte pieces.
-// DOT: the same pieces of a second matrix are loaded beside them and sdot[row] = sum_d a[row][d] b[row][d] is left in LDS.
+// The streamed side is staged in CHUNKS of 64 rows (two tiles): the workgroup issues every global load of its set-up at once, chunk by
+// chunk (vmcnt retires in order), and starts on the tiles of chunk c while chunks c+1.. are still travelling -- the set-up is bound by
+// the CU's ingest (~160 KiB per workgroup, ~10 k cycles when it was waited for in one piece, a third of the launch).
+// piece (row 64 c + tid / 8, 16 bytes tid % 8) of chunk c of a [T][64] matrix (row stride ts elements); rows past T are clamped here and
+// zeroed when they are written
+__device__ __forceinline__ uint4 ea_issue(const uint16_t* src, int64_t ts, int T, int tid, int c) {
+  const int row = 64 * c + (tid >> 3);
+  return ld_global_b128(src + (int64_t)min(row, T - 1) * ts + 8 * (tid & 7));
+}
+// -> row-major image.  DOT: w is the same piece of a second matrix and sdot[row] = sum_d a[row][d] b[row][d] is left in LDS.
 template <bool DOT>
-__device__ __forceinline__ void ea_stage_rm(unsigned char* img, const uint16_t* src, int64_t ts, const uint16_t* src2, int64_t ts2, float* sdot, int T,
-                                            int nrows, int tid) {
-  uint4 v[4], w[4];
+__device__ __forceinline__ void ea_stage_rm(unsigned char* img, uint4 q, uint4 w, float* sdot, int T, int tid, int c) {
+  const int row = 64 * c + (tid >> 3), ch = tid & 7;
+  const uint32_t live = (uint32_t)0 - (uint32_t)(row < T);
+  q.x &= live; q.y &= live; q.z &= live; q.w &= live;
+  *reinterpret_cast<uint4*>(img + row * EA_HS + ch * 16) = q;
+  if constexpr (DOT) {
+    const uint32_t a[4] = {q.x, q.y, q.z, q.w}, b[4] = {w.x, w.y, w.z, w.w};
+    float part = 0.f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int id = tid + 512 * k, row = id >> 3, c = id & 7, rr = min(row, T - 1);
-    v[k] = ld_global_b128(src + (int64_t)rr * ts + 8 * c);
-    if constexpr (DOT) w[k] = ld_global_b128(src2 + (int64_t)rr * ts2 + 8 * c);
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int id = tid + 512 * k, row = id >> 3, c = id & 7;
-    if (row >= nrows) continue;
-    const uint32_t live = (uint32_t)0 - (uint32_t)(row < T);
-    uint4 q = v[k];
-    q.x &= live; q.y &= live; q.z &= live; q.w &= live;
-    *reinterpret_cast<uint4*>(img + row * EA_HS + c * 16) = q;
-    if constexpr (DOT) {
-      const uint32_t a[4] = {q.x, q.y, q.z, q.w}, b[4] = {w[k].x, w[k].y, w[k].z, w[k].w};
-      float part = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) part += h2f_lo(a[e]) * h2f_lo(b[e]) + h2f_hi(a[e]) * h2f_hi(b[e]);
-      part += __shfl_xor(part, 1);
-      part += __shfl_xor(part, 2);
-      part += __shfl_xor(part, 4);
-      if (c == 0) sdot[row] = part;
-    }
+    for (int e = 0; e < 4; ++e) part += h2f_lo(a[e]) * h2f_lo(b[e]) + h2f_hi(a[e]) * h2f_hi(b[e]);
+    part += __shfl_xor(part, 1);
+    part += __shfl_xor(part, 2);
+    part += __shfl_xor(part, 4);
+    if (ch == 0) sdot[row] = part;
   }
 }
-// transposed image of a staged row-major image: timg[d][row] (two rows per 32-bit store).  Call between two barriers.
-__device__ __forceinline__ void ea_transpose(unsigned char* timg, const unsigned char* img, int nrows, int tid) {
+// transposed image of chunk c of a staged row-major image: timg[d][row], two rows per 32-bit store; thread t (0 .. 255) takes the row pair
+// 32 c + t % 32 and the 16-byte piece t / 32, elements 2 e0 .. 2 e0 + 2 ne - 1 of it.  Call between two barriers.
+__device__ __forceinline__ void ea_transpose(unsigned char* timg, const unsigned char* img, int c, int t, int e0, int ne) {
+  const int rp = 32 * c + (t & 31), ch = (t >> 5) & 7;
+  const uint4 a = *reinterpret_cast<const uint4*>(img + (2 * rp) * EA_HS + ch * 16);
+  const uint4 b = *reinterpret_cast<const uint4*>(img + (2 * rp + 1) * EA_HS + ch * 16);
+  const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int id = tid + 512 * k, rp = id & 127, c = id >> 7;
-    if (2 * rp >= nrows) continue;
-    const uint4 a = *reinterpret_cast<const uint4*>(img + (2 * rp) * EA_HS + c * 16);
-    const uint4 b = *reinterpret_cast<const uint4*>(img + (2 * rp + 1) * EA_HS + c * 16);
-    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      *reinterpret_cast<uint32_t*>(timg + (8 * c + 2 * e) * EA_TS + 4 * rp) = (aw[e] & 0xffffu) | (bw[e] << 16);
-      *reinterpret_cast<uint32_t*>(timg + (8 * c + 2 * e + 1) * EA_TS + 4 * rp) = (aw[e] >> 16) | (bw[e] & 0xffff0000u);
-    }
+  for (int e = 0; e < 4; ++e) {
+    if (e < e0 || e >= e0 + ne) continue;
+    *reinterpret_cast<uint32_t*>(timg + (8 * ch + 2 * e) * EA_TS + 4 * rp) = (aw[e] & 0xffffu) | (bw[e] << 16);
+    *reinterpret_cast<uint32_t*>(timg + (8 * ch + 2 * e + 1) * EA_TS + 4 * rp) = (aw[e] >> 16) | (bw[e] & 0xffff0000u);
   }
 }
 
@@ -112,15 +109,21 @@ __device__ __forceinline__ void ea_load_frags(uint4 (&f)[4], const uint16_t* src
 
 // accumulator tiles (lane = own row m, registers = head dim 32 ct + 8 q + 4 hi + (r & 3)) x scale -> this wave's 32 rows of a row-major
 // image -> memory as whole 128-byte rows
-__device__ __forceinline__ void ea_store_rows(const f32x16 (&acc)[2], float scale, unsigned char* og, uint16_t* dst, int64_t ts, int row0, int T,
-                                              int lane) {
+// live = false: the lane's row is written as zeros (whatever the accumulators hold, NaN included)
+__device__ __forceinline__ void ea_put_rows(const f32x16 (&acc)[2], float scale, bool live, unsigned char* og, int lane) {
   const int m = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<uint2*>(og + m * EA_HS + (32 * ct + 8 * q + 4 * hi) * 2) =
-          make_uint2(pack2h(acc[ct][4 * q] * scale, acc[ct][4 * q + 1] * scale), pack2h(acc[ct][4 * q + 2] * scale, acc[ct][4 * q + 3] * scale));
+    for (int q = 0; q < 4; ++q) {
+      uint2 v = make_uint2(pack2h(acc[ct][4 * q] * scale, acc[ct][4 * q + 1] * scale), pack2h(acc[ct][4 * q + 2] * scale, acc[ct][4 * q + 3] * scale));
+      if (!live) v = make_uint2(0u, 0u);
+      *reinterpret_cast<uint2*>(og + m * EA_HS + (32 * ct + 8 * q + 4 * hi) * 2) = v;
+    }
+}
+__device__ __forceinline__ void ea_store_rows(const f32x16 (&acc)[2], float scale, bool live, unsigned char* og, uint16_t* dst, int64_t ts, int row0,
+                                              int T, int lane) {
+  ea_put_rows(acc, scale, live, og, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(512, 1) void encattn_bwd_kernel(EaArgs p) {
   const uint8_t* km = p.key_mask ? p.key_mask + (int64_t)b * T : nullptr;
   const int own = 32 * wid + m;                                  // this lane's own row (query or key)
   const int ownc = min(own, T - 1);
+  EA_STAMP(0);
 
   if (orient == 0) {
     // ------------------------------------------------------------------ lane = query: dQ = scale . dS K
@@ -159,16 +163,20 @@ __global__ __launch_bounds__(512, 1) void encattn_bwd_kernel(EaArgs p) {
     unsigned char* vrm = smem + EA_RM;
     unsigned char* kt = smem + 2 * EA_RM;
     float* kbias = reinterpret_cast<float*>(smem + 2 * EA_RM + EA_TR);          // 0 for a live key, -inf for a masked one / past T
-    ea_stage_rm<false>(krm, K, p.k_ts, nullptr, 0, nullptr, T, nrows, tid);
-    ea_stage_rm<false>(vrm, V, p.v_ts, nullptr, 0, nullptr, T, nrows, tid);
-    uint4 qf[4], dof[4], of[4];
-    ea_load_frags(qf, Q, p.q_ts, ownc, hi);
+    uint4 gk[4], gv[4], qf[4], dof[4], of[4];
+    ea_load_frags(qf, Q, p.q_ts, ownc, hi);                                      // the own side first: the first tile needs it
     ea_load_frags(dof, dO, p.o_ts, ownc, hi);
     ea_load_frags(of, O, p.o_ts, ownc, hi);
     const float l0 = lse[ownc];
-    if (tid < EA_T) kbias[tid] = (tid < T && (!km || km[min(tid, T - 1)])) ? 0.f : -__builtin_huge_valf();
-    __syncthreads();
-    ea_transpose(kt, krm, nrows, tid);
+    const uint8_t kmb = km ? km[min(tid, T - 1)] : (uint8_t)1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      gk[c] = ea_issue(K, p.k_ts, T, tid, c);
+      gv[c] = ea_issue(V, p.v_ts, T, tid, c);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    EA_STAMP(1);
+    if (tid < EA_T) kbias[tid] = (tid < T && kmb) ? 0.f : -__builtin_huge_valf();
     float del = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -179,39 +187,53 @@ __global__ __launch_bounds__(512, 1) void encattn_bwd_kernel(EaArgs p) {
     del += __shfl_xor(del, 32);
     // a query row with no live key at all (lse = -inf) has P = 0 everywhere; rows past T contribute nothing and are not stored
     const float nl = (own < T && l0 != -__builtin_huge_valf()) ? -l0 * EA_LOG2E : -__builtin_huge_valf();
-    __syncthreads();
     f32x16 dq[2];
     ea_zero(dq[0]); ea_zero(dq[1]);
-    if (32 * wid < T) {
-      for (int jt = 0; jt < nt; ++jt) {
-        const unsigned char* kr = krm + jt * 32 * EA_HS;
-        const unsigned char* vr = vrm + jt * 32 * EA_HS;
-        f32x16 st, dp;
-        ea_zero(st); ea_zero(dp);
+    auto tile = [&](int jt) {
+      const unsigned char* kr = krm + jt * 32 * EA_HS;
+      const unsigned char* vr = vrm + jt * 32 * EA_HS;
+      f32x16 st, dp;
+      ea_zero(st); ea_zero(dp);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { mma32(st, ea_frag(kr, m, hi, ks), qf[ks]); mma32(dp, ea_frag(vr, m, hi, ks), dof[ks]); }
-        float dsv[16];
+      for (int ks = 0; ks < 4; ++ks) { mma32(st, ea_frag(kr, m, hi, ks), qf[ks]); mma32(dp, ea_frag(vr, m, hi, ks), dof[ks]); }
+      float dsv[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 kb = *reinterpret_cast<const float4*>(kbias + jt * 32 + 8 * q + 4 * hi);
-          const float kb4[4] = {kb.x, kb.y, kb.z, kb.w};
+      for (int q = 0; q < 4; ++q) {
+        const float4 kb = *reinterpret_cast<const float4*>(kbias + jt * 32 + 8 * q + 4 * hi);
+        const float kb4[4] = {kb.x, kb.y, kb.z, kb.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * q + e;
-            const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc2, nl) + kb4[e]);
-            dsv[r] = pe * (dp[r] - del);
-          }
-        }
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-          const uint4 pb = ea_pack8(dsv + 8 * k2);
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct) mma32(dq[ct], ea_tfrag(kt, 32 * ct + m, jt * 32, hi, k2), pb);
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q + e;
+          const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc2, nl) + kb4[e]);
+          dsv[r] = pe * (dp[r] - del);
         }
       }
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const uint4 pb = ea_pack8(dsv + 8 * k2);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) mma32(dq[ct], ea_tfrag(kt, 32 * ct + m, jt * 32, hi, k2), pb);
+      }
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (2 * c >= nt) break;                                       // uniform over the workgroup
+      ea_stage_rm<false>(krm, gk[c], gk[c], nullptr, T, tid, c);
+      ea_stage_rm<false>(vrm, gv[c], gv[c], nullptr, T, tid, c);
+      __syncthreads();
+      ea_transpose(kt, krm, c, tid & 255, 2 * (tid >> 8), 2);
+      __syncthreads();
+      if (c == 0) EA_STAMP(2);
+      if (32 * wid < T) {
+        tile(2 * c);
+        if (2 * c + 1 < nt) tile(2 * c + 1);
+      }
     }
+    EA_STAMP(3);
     __syncthreads();                                               // every wave is done with the images: they become staging space
-    if (32 * wid < T) ea_store_rows(dq, p.scale, krm + 32 * wid * EA_HS, p.dq + (int64_t)b * p.q_bs + h * EA_DK, p.q_ts, 32 * wid, T, lane);
+    EA_STAMP(4);
+    if (32 * wid < T) ea_store_rows(dq, p.scale, true, krm + 32 * wid * EA_HS, p.dq + (int64_t)b * p.q_bs + h * EA_DK, p.q_ts, 32 * wid, T, lane);
+    EA_STAMP(5);
   } else {
     // ------------------------------------------------------------------ lane = key: dV = P^T dO, dK = scale . dS^T Q
     unsigned char* qrm = smem;
@@ -220,64 +242,84 @@ __global__ __launch_bounds__(512, 1) void encattn_bwd_kernel(EaArgs p) {
     unsigned char* dot = smem + 2 * EA_RM + EA_TR;
     float* nls = reinterpret_cast<float*>(smem + 2 * EA_RM + 2 * EA_TR);       // -lse log2(e) per query (-inf: no live key / past T)
     float* dels = nls + EA_T;
-    ea_stage_rm<false>(qrm, Q, p.q_ts, nullptr, 0, nullptr, T, nrows, tid);
-    ea_stage_rm<true>(dorm, dO, p.o_ts, O, p.o_ts, dels, T, nrows, tid);
-    uint4 kf[4], vf[4];
-    ea_load_frags(kf, K, p.k_ts, ownc, hi);
+    uint4 gq[4], gdo[4], go[4], kf[4], vf[4];
+    ea_load_frags(kf, K, p.k_ts, ownc, hi);                                      // the own side first: the first tile needs it
     ea_load_frags(vf, V, p.v_ts, ownc, hi);
-    if (tid < EA_T) {
-      const float l0 = lse[min(tid, T - 1)];
-      nls[tid] = (tid < T && l0 != -__builtin_huge_valf()) ? -l0 * EA_LOG2E : -__builtin_huge_valf();
+    const float l0 = lse[min(tid, T - 1)];
+    const uint8_t kmb = km ? km[ownc] : (uint8_t)1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      gq[c] = ea_issue(Q, p.q_ts, T, tid, c);
+      gdo[c] = ea_issue(dO, p.o_ts, T, tid, c);
+      go[c] = ea_issue(O, p.o_ts, T, tid, c);
     }
-    const bool keyok = own < T && (!km || km[ownc]);
-    const float kb = keyok ? 0.f : -__builtin_huge_valf();
-    __syncthreads();
-    ea_transpose(qt, qrm, nrows, tid);
-    ea_transpose(dot, dorm, nrows, tid);
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    EA_STAMP(1);
+    if (tid < EA_T) nls[tid] = (tid < T && l0 != -__builtin_huge_valf()) ? -l0 * EA_LOG2E : -__builtin_huge_valf();
+    // a masked key (or one past T) only pollutes ITS OWN dk / dv rows -- the lane is a column of every product here -- so the loop
+    // carries no mask at all and the rows are zeroed on their way out
+    const bool keyok = own < T && kmb;
     f32x16 dk[2], dv[2];
     ea_zero(dk[0]); ea_zero(dk[1]); ea_zero(dv[0]); ea_zero(dv[1]);
-    if (32 * wid < T) {
-      for (int it = 0; it < nt; ++it) {
-        const unsigned char* qr = qrm + it * 32 * EA_HS;
-        const unsigned char* dr = dorm + it * 32 * EA_HS;
-        f32x16 st, dp;
-        ea_zero(st); ea_zero(dp);
+    auto tile = [&](int it) {
+      const unsigned char* qr = qrm + it * 32 * EA_HS;
+      const unsigned char* dr = dorm + it * 32 * EA_HS;
+      f32x16 st, dp;
+      ea_zero(st); ea_zero(dp);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { mma32(st, ea_frag(qr, m, hi, ks), kf[ks]); mma32(dp, ea_frag(dr, m, hi, ks), vf[ks]); }
-        float pv[16], dsv[16];
+      for (int ks = 0; ks < 4; ++ks) { mma32(st, ea_frag(qr, m, hi, ks), kf[ks]); mma32(dp, ea_frag(dr, m, hi, ks), vf[ks]); }
+      float pv[16], dsv[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 nl = *reinterpret_cast<const float4*>(nls + it * 32 + 8 * q + 4 * hi);
-          const float4 de = *reinterpret_cast<const float4*>(dels + it * 32 + 8 * q + 4 * hi);
-          const float nl4[4] = {nl.x, nl.y, nl.z, nl.w}, de4[4] = {de.x, de.y, de.z, de.w};
+      for (int q = 0; q < 4; ++q) {
+        const float4 nl = *reinterpret_cast<const float4*>(nls + it * 32 + 8 * q + 4 * hi);
+        const float4 de = *reinterpret_cast<const float4*>(dels + it * 32 + 8 * q + 4 * hi);
+        const float nl4[4] = {nl.x, nl.y, nl.z, nl.w}, de4[4] = {de.x, de.y, de.z, de.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * q + e;
-            pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc2, nl4[e]) + kb);
-            dsv[r] = pv[r] * (dp[r] - de4[e]);
-          }
-        }
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-          const uint4 pb = ea_pack8(pv + 8 * k2), sb = ea_pack8(dsv + 8 * k2);
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct) {
-            mma32(dv[ct], ea_tfrag(dot, 32 * ct + m, it * 32, hi, k2), pb);
-            mma32(dk[ct], ea_tfrag(qt, 32 * ct + m, it * 32, hi, k2), sb);
-          }
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q + e;
+          pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc2, nl4[e]));
+          dsv[r] = pv[r] * (dp[r] - de4[e]);
         }
       }
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const uint4 pb = ea_pack8(pv + 8 * k2), sb = ea_pack8(dsv + 8 * k2);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          mma32(dv[ct], ea_tfrag(dot, 32 * ct + m, it * 32, hi, k2), pb);
+          mma32(dk[ct], ea_tfrag(qt, 32 * ct + m, it * 32, hi, k2), sb);
+        }
+      }
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (2 * c >= nt) break;                                       // uniform over the workgroup
+      ea_stage_rm<false>(qrm, gq[c], gq[c], nullptr, T, tid, c);
+      ea_stage_rm<true>(dorm, gdo[c], go[c], dels, T, tid, c);
+      __syncthreads();
+      if (tid < 256) ea_transpose(qt, qrm, c, tid, 0, 4);           // wave-uniform split: four waves per image
+      else ea_transpose(dot, dorm, c, tid - 256, 0, 4);
+      __syncthreads();
+      if (c == 0) EA_STAMP(2);
+      if (32 * wid < T) {
+        tile(2 * c);
+        if (2 * c + 1 < nt) tile(2 * c + 1);
+      }
     }
+    EA_STAMP(3);
     __syncthreads();
+    EA_STAMP(4);
     if (32 * wid < T) {
-      ea_store_rows(dk, p.scale, qrm + 32 * wid * EA_HS, p.dk + (int64_t)b * p.k_bs + h * EA_DK, p.k_ts, 32 * wid, T, lane);
-      ea_store_rows(dv, 1.f, dorm + 32 * wid * EA_HS, p.dv + (int64_t)b * p.v_bs + h * EA_DK, p.v_ts, 32 * wid, T, lane);
+      ea_store_rows(dk, p.scale, keyok, qrm + 32 * wid * EA_HS, p.dk + (int64_t)b * p.k_bs + h * EA_DK, p.k_ts, 32 * wid, T, lane);
+      ea_store_rows(dv, 1.f, keyok, dorm + 32 * wid * EA_HS, p.dv + (int64_t)b * p.v_bs + h * EA_DK, p.v_ts, 32 * wid, T, lane);
     }
+    EA_STAMP(5);
   }
 }
 
 }  // namespace
+
+extern unsigned long long* g_otr_trace;
 
 // shapes this kernel serves (attention.hip asks before it takes its own path)
 bool encattn_bwd_takes(int dtype_is_h16, int dk, int Tq, int Tk, int causal, int has_bias, int vec) {
@@ -288,6 +330,7 @@ int32_t encattn_bwd_launch(const void* q, const void* k, const void* v, const vo
                            void* dq, void* dk, void* dv, int B, int H, int T, int64_t q_bs, int64_t q_ts, int64_t k_bs, int64_t k_ts, int64_t v_bs,
                            int64_t v_ts, int64_t o_bs, int64_t o_ts, float scale, hipStream_t stream) {
   EaArgs p{};
+  p.trace = g_otr_trace;
   p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.v = (const uint16_t*)v; p.o = (const uint16_t*)o; p.do_ = (const uint16_t*)do_;
   p.dq = (uint16_t*)dq; p.dk = (uint16_t*)dk; p.dv = (uint16_t*)dv; p.key_mask = key_mask; p.lse = lse;
   p.B = B; p.H = H; p.T = T; p.q_bs = q_bs; p.q_ts = q_ts; p.k_bs = k_bs; p.k_ts = k_ts; p.v_bs = v_bs; p.v_ts = v_ts; p.o_bs = o_bs; p.o_ts = o_ts;

@@ -54,10 +54,29 @@ __global__ __launch_bounds__(256) void pack_frags_kernel(const uint16_t* __restr
   uint4 q;
   if (cs == 1 && perm == 0 && ((src_off + r * rs) % 8 == 0)) {        // contraction index contiguous: one 16-byte load
     q = *reinterpret_cast<const uint4*>(s + ks * 16 + hi * 8);
-  } else if (cs == 1 && ((src_off + r * rs) % 4 == 0)) {                // perm = 1 on a contiguous source: two 8-byte loads
-    const uint2 a = *reinterpret_cast<const uint2*>(s + ks * 16 + 4 * hi);
-    const uint2 b = *reinterpret_cast<const uint2*>(s + ks * 16 + 8 + 4 * hi);
+  } else if (cs == 1 && ((src_off + r * rs) % 4 == 0)) {                // contiguous source, 8-byte aligned: two 8-byte loads
+    const uint2 a = *reinterpret_cast<const uint2*>(s + ks * 16 + (perm ? 4 * hi : 8 * hi));
+    const uint2 b = *reinterpret_cast<const uint2*>(s + ks * 16 + (perm ? 8 + 4 * hi : 8 * hi + 4));
     q = make_uint4(a.x, a.y, b.x, b.y);
+  } else if (rs == 1 && ((src_off + rt * 32) % 8 == 0) && (cs % 8 == 0)) {
+    // the FREE index is the contiguous one (a transposed pack: the input-gradient form of a weight).  The fragment is 16 contraction
+    // rows of 64 contiguous bytes: every lane fetches ONE 16-byte piece (row lane / 4, piece lane % 4) and the wave turns the tile
+    // through its own 1 KiB of LDS -- read element by element it was 8 two-byte loads per lane, each instruction touching 64 bytes
+    // per half wave (the step's weight packing took 64 us, most of it here)
+    __shared__ __attribute__((aligned(16))) uint16_t tile[4][16][32 + 8];
+    const int c = lane >> 2, pc = lane & 3;
+    *reinterpret_cast<uint4*>(&tile[wid][c][pc * 8]) =
+        *reinterpret_cast<const uint4*>(src + src_off + (ks * 16 + c) * cs + rt * 32 + pc * 8);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    uint16_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kk = perm ? (j < 4 ? 4 * hi + j : 8 + 4 * hi + (j - 4)) : hi * 8 + j;
+      v[j] = tile[wid][kk][lane & 31];
+    }
+    q.x = v[0] | ((uint32_t)v[1] << 16); q.y = v[2] | ((uint32_t)v[3] << 16);
+    q.z = v[4] | ((uint32_t)v[5] << 16); q.w = v[6] | ((uint32_t)v[7] << 16);
   } else {
     uint16_t v[8];
 #pragma unroll

@@ -32,26 +32,27 @@ def test_pack_frags_layout():
     """the packed image is exactly the documented (row tile, k-step, lane, j) order for both contraction orders"""
     from opentransformer_amd import ops
     ops.set_compute_dtype('bf16')
-    R, Cc = 64, 48
-    a = torch.arange(R * Cc, dtype=torch.int16, device=DEV).view(R, Cc)
-    src = a.view(torch.bfloat16).reshape(-1)       # raw 16-bit payloads: the packer never interprets them
-    for perm in (0, 1):
-        for transposed in (False, True):
-            rows, cols = (Cc, R) if transposed else (R, Cc)
-            rs, cs = (1, Cc) if transposed else (Cc, 1)
-            if rows % 32 or cols % 16:
-                continue
-            dst = torch.empty(rows * cols, dtype=torch.bfloat16, device=DEV)
-            ops.pack_frags(src, dst, [[0, rs, cs, rows, cols, perm, 0]])
-            got = dst.view(torch.int16).view(rows // 32, cols // 16, 64, 8).cpu()
-            A = (a.t() if transposed else a).cpu()
-            for rt in range(rows // 32):
-                for ks in range(cols // 16):
-                    for lane in (0, 7, 31, 32, 45, 63):
-                        hi = lane >> 5
-                        for j in range(8):
-                            kk = (4 * hi + j if j < 4 else 8 + 4 * hi + j - 4) if perm else hi * 8 + j
-                            assert got[rt, ks, lane, j] == A[rt * 32 + (lane & 31), ks * 16 + kk], (perm, transposed, rt, ks, lane, j)
+    R, Cc = 64, 96
+    for off in (0, 4):                              # 4: rows not 16-byte aligned -> the element-wise paths
+        flat = torch.arange(off + R * Cc, dtype=torch.int16, device=DEV)
+        a = flat[off:].view(R, Cc)
+        src = flat.view(torch.bfloat16)             # raw 16-bit payloads: the packer never interprets them
+        for perm in (0, 1):
+            for transposed in (False, True):        # transposed: the free index is the contiguous one (input-gradient packs)
+                rows, cols = (Cc, R) if transposed else (R, Cc)
+                rs, cs = (1, Cc) if transposed else (Cc, 1)
+                assert rows % 32 == 0 and cols % 16 == 0
+                dst = torch.empty(rows * cols, dtype=torch.bfloat16, device=DEV)
+                ops.pack_frags(src, dst, [[off, rs, cs, rows, cols, perm, 0]])
+                got = dst.view(torch.int16).view(rows // 32, cols // 16, 64, 8).cpu()
+                A = (a.t() if transposed else a).cpu()
+                for rt in range(rows // 32):
+                    for ks in range(cols // 16):
+                        for lane in (0, 3, 7, 31, 32, 45, 63):
+                            hi = lane >> 5
+                            for j in range(8):
+                                kk = (4 * hi + j if j < 4 else 8 + 4 * hi + j - 4) if perm else hi * 8 + j
+                                assert got[rt, ks, lane, j] == A[rt * 32 + (lane & 31), ks * 16 + kk], (off, perm, transposed, rt, ks, lane, j)
 
 
 @pytest.fixture(params=['bf16', 'fp16'])

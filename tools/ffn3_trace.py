@@ -24,8 +24,14 @@ scratch = torch.empty(nb // 4, device=dev)
 sync = ops._ffn_sync(torch.device('cuda', torch.cuda.current_device()))
 hsave = torch.zeros(lib.otr_ffn_split_hsave_bytes(M, F) // 2, dtype=hdt, device=dev)
 usave = torch.zeros(lib.otr_ffn_split_padded_rows(M), F, dtype=hdt, device=dev)
-save = len(sys.argv) > 1 and sys.argv[1] == 'save'
+save = 'save' in sys.argv[1:]
+slab = 'slab' in sys.argv[1:]
+slabs = torch.empty(4, M, d, dtype=hdt, device=dev)
 def run():
+    if slab:
+        L.check(lib.otr_ffn_fwd_split_slab(p(x16), p(P[0]), p(b1), p(P[1]), p(hsave) if save else None, p(usave) if save else None, p(slabs),
+                                           M, F, d, st()), 'fwd3 slab')
+        return
     L.check(lib.otr_ffn_ln_fwd_split(p(x), p(x16), p(P[0]), p(b1), p(P[1]), p(b2), p(gamma), p(beta), p(seed), 0.0, 0, 1e-5, p(y), p(y16),
                                      p(z), p(mean), p(rstd), p(hsave) if save else None, p(usave) if save else None, p(scratch), nb, p(sync), sync.numel(), M, F, d, st()), 'fwd3')
 for _ in range(3): run()
@@ -36,7 +42,7 @@ live = t[:, 0] > 0
 t = t[live]
 n = int((t[0] > 0).sum())
 dt = np.diff(t[:, :n], axis=1).astype(np.float64)
-names = ['prologue'] + ['ph%d%s' % (i // 3, 'ABG'[i % 3]) for i in range(24)] + ['closing', 'drain+bar', 'send', 'hoisted loads', 'store drain+bar', 'arrive wait', 'recv+sum', 'LN+out']
+names = ['prologue'] + ['ph%d%s' % (i // 3, 'ABG'[i % 3]) for i in range(24)] + (['closing', 'drain+bar', 'slab store'] if slab else []) + ['closing', 'drain+bar', 'send', 'hoisted loads', 'store drain+bar', 'arrive wait', 'recv+sum', 'LN+out']
 print('workgroups', t.shape[0], 'stamps', n, 'total cycles median', np.median(t[:, n - 1] - t[:, 0]), '(100 MHz s_memtime ticks?)')
 for i in range(min(n - 1, len(names))):
     print('%-16s median %8.0f  p10 %8.0f  p90 %8.0f' % (names[i], np.median(dt[:, i]), np.percentile(dt[:, i], 10), np.percentile(dt[:, i], 90)))
