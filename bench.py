@@ -224,6 +224,12 @@ KERNEL_LABEL = {
     'ffn_bwd': 'ffn_bwd_kernel (FFN backward with recompute: dh, u, dx; row-block fused)',
     'ffn_ln_fwd_split': 'ffn3_fwd_kernel (csrc/ffn3.hip: w_1 + GLU + w_2 on 128-row workgroups sharing the weights through an LDS-DMA ring, hidden units split 4 ways, partial sums exchanged in the launch, bias + dropout + residual + LayerNorm; saves (value, sigmoid) tiles + u for backward)',
     'ffn_bwd_split': 'ffn3_bwd_kernel (csrc/ffn3.hip: du = dy . w_2, GLU backward on the saved tiles, dx = skip + dh . w_1, dh for the weight gradient; same structure)',
+    'ffn_fwd_slab': 'ffn3_fwd_kernel<SLAB> (csrc/ffn3.hip: w_1 + GLU + w_2 on 128-row workgroups sharing the weights through an LDS-DMA ring, hidden units split 4 ways; the four slices leave 16-bit partial slabs, the next q|k|v projection finishes bias + dropout + residual + LayerNorm in its prologue; saves (value, sigmoid) tiles + u for backward)',
+    'ffn_bwd_slab': 'ffn3_bwd_kernel<SLAB> (csrc/ffn3.hip: du = dy . w_2, GLU backward on the saved tiles, dh for the weight gradient, the slices\' shares of dh . w_1 as 16-bit slabs summed by the attention sub-layer\'s backward launch)',
+    'rb_linear_ln': 'rb_linear_ln_kernel (csrc/rowblock.hip: the q|k|v projection with the previous FFN sub-layer\'s bias + dropout + residual + LayerNorm finished in its prologue from the four slabs)',
+    'rb_linear_ln_bwd': 'rb_linear_ln_bwd_kernel (input gradient of the q|k|v projection + skip + the LayerNorm backward of the FFN sub-layer below in its epilogue)',
+    'self_attention_fwd': 'attn_fwd_kernel (csrc/attention.hip: streaming-softmax attention, 128 queries per workgroup)',
+    'self_attention_bwd': 'encattn_bwd_kernel (csrc/encattn.hip: one (utterance, head) staged whole in LDS, one workgroup per orientation; flops = the 5 products of the backward pass, 7 are run)',
     'dec_self_fwd': 'dec_self_fwd_kernel (csrc/declayer.hip: previous LayerNorm + q|k|v of one head + causal self-attention + its share of the output projection; grid (utterance groups, heads))',
     'dec_cross_fwd': 'dec_cross_fwd_kernel (LayerNorm + q of one head + cross-attention over the utterance memory + its share of the output projection)',
     'dec_ffn_fwd': 'dec_ffn_fwd_kernel (LayerNorm + w_1 + GLU + w_2 on 1/8 of the hidden units; grid (32-row blocks, slices))',
@@ -235,7 +241,9 @@ KERNEL_LABEL = {
 
 PMC_KERNEL = {'linear_wgrad_grouped': 'wgrad256_kernel', 'proj_ln_fwd': 'proj_ln_fwd_kernel', 'ln_bwd_proj': 'ln_bwd_proj_kernel',
               'ffn_ln_fwd': 'ffn_ln_fwd_kernel', 'ffn_bwd': 'ffn_bwd_kernel', 'ffn_ln_fwd_split': 'ffn3_fwd_kernel',
-              'ffn_bwd_split': 'ffn3_bwd_kernel', 'rb_linear': 'rb_linear_kernel', 'dec_self_fwd': 'dec_self_fwd_kernel',
+              'ffn_bwd_split': 'ffn3_bwd_kernel', 'ffn_fwd_slab': 'ffn3_fwd_kernel', 'ffn_bwd_slab': 'ffn3_bwd_kernel',
+              'rb_linear_ln': 'rb_linear_ln_kernel', 'rb_linear_ln_bwd': 'rb_linear_ln_bwd_kernel', 'self_attention_fwd': 'attn_fwd_kernel',
+              'self_attention_bwd': 'encattn_bwd_kernel', 'rb_linear': 'rb_linear_kernel', 'dec_self_fwd': 'dec_self_fwd_kernel',
               'dec_cross_fwd': 'dec_cross_fwd_kernel', 'dec_ffn_fwd': 'dec_ffn_fwd_kernel', 'dec_ffn_bwd': 'dec_ffn_bwd_kernel',
               'dec_cross_bwd': 'dec_cross_bwd_kernel', 'dec_self_bwd': 'dec_self_bwd_kernel'}
 
@@ -527,7 +535,7 @@ def main():
                 # 2.5 PFLOP/s).  Its MINIMAL I/O (x, x16, y, y16, z, the packed weights once: what a recomputing backward would
                 # need) puts it at ~700 flop/B, far above the 312 flop/B ridge; the tiles it saves for the backward pass are a
                 # choice of this implementation, not algorithmic traffic.  The HBM view is kept as a secondary key.
-                for name in ('ffn_ln_fwd_split', 'ffn_bwd_split', 'ffn_ln_fwd', 'ffn_bwd'):
+                for name in ('ffn_fwd_slab', 'ffn_bwd_slab', 'ffn_ln_fwd_split', 'ffn_bwd_split', 'ffn_ln_fwd', 'ffn_bwd'):
                     if name in lines and lines[name].get('algorithmic_bytes'):
                         d = lines[name]
                         M_, F_, d_ = args.batch * ((((args.frames - 3) // 2 + 1) - 3) // 2 + 1), cfg['encoder']['d_ff'], cfg['encoder']['d_model']

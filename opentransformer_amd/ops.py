@@ -903,8 +903,9 @@ class SelfAttentionFn(torch.autograd.Function):
         lse = torch.empty((B, n_heads, T), dtype=torch.float32, device=qkv.device)
         s3 = (T * d3, d3)
         desc = _attn_desc(B, n_heads, T, T, dk, qkv.dtype, s3, s3, s3, (T * d, d), causal)
-        L.check(L.load().otr_attention_fwd(C.byref(desc), _p(qkv), _p(qkv, d), _p(qkv, 2 * d), _p(key_mask_u8),
-                                           _p(out), _p(lse), _stream()), 'otr_attention_fwd')
+        L.check(_timed('self_attention_fwd', {'flops': 4.0 * B * T * T * d * (0.5 if causal else 1.0), 'bytes': B * T * d * 2 * 4},
+                       lambda: L.load().otr_attention_fwd(C.byref(desc), _p(qkv), _p(qkv, d), _p(qkv, 2 * d), _p(key_mask_u8),
+                                                          _p(out), _p(lse), _stream())), 'otr_attention_fwd')
         ctx.save_for_backward(qkv, out, lse, key_mask_u8)
         ctx.cfg = (n_heads, causal)
         return out
@@ -921,9 +922,11 @@ class SelfAttentionFn(torch.autograd.Function):
         delta = torch.empty_like(lse)
         s3 = (T * d3, d3)
         desc = _attn_desc(B, n_heads, T, T, dk, qkv.dtype, s3, s3, s3, (T * d, d), causal)
-        L.check(L.load().otr_attention_bwd(C.byref(desc), _p(qkv), _p(qkv, d), _p(qkv, 2 * d), _p(km), _p(out),
-                                           _p(dout), _p(lse), _p(delta), _p(dqkv), _p(dqkv, d), _p(dqkv, 2 * d),
-                                           _stream()), 'otr_attention_bwd')
+        # flops: the five products of the backward pass (S, dP, dQ, dK, dV); both orientations of the kernel form S and dP (7 products run)
+        L.check(_timed('self_attention_bwd', {'flops': 10.0 * B * T * T * d * (0.5 if causal else 1.0), 'bytes': B * T * d * 2 * 8},
+                       lambda: L.load().otr_attention_bwd(C.byref(desc), _p(qkv), _p(qkv, d), _p(qkv, 2 * d), _p(km), _p(out),
+                                                          _p(dout), _p(lse), _p(delta), _p(dqkv), _p(dqkv, d), _p(dqkv, 2 * d),
+                                                          _stream())), 'otr_attention_bwd')
         return dqkv, None, None, None
 
 
