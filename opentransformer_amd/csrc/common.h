@@ -68,6 +68,14 @@ __device__ __forceinline__ void st_global_b128(void* p, uint4 v) {
   *(OTR_GLOBAL otr_u32x4*)(p) = t;
 }
 
+// streaming store: data nobody reads soon (tiles saved for the backward pass).  A launch that leaves tens of MB dirty in the L2s pays
+// for their write-back when it ENDS (the L2s of the XCDs are not coherent: kernel end flushes them); marked non-temporal the lines
+// leave while the launch still computes
+__device__ __forceinline__ void st_global_b128_nt(void* p, uint4 v) {
+  otr_u32x4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, (OTR_GLOBAL otr_u32x4*)(p));
+}
+
 // ---------------------------------------------------------------- scalar conversions
 #ifdef OTR_HALF_FP16
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }

@@ -37,6 +37,15 @@ constexpr int F3_RING = F3_SLOTS * F3_PHASE;
 constexpr int F3_UBUF = 16 * 1024;       // u hand-over: [wr][wc][row tile][k-step] fragments of 1 KiB
 constexpr int F3_BIAS = 8 * 1024;        // b_1 of the slice: [v1 chunk][value 32 | gate 32] floats (<= 32 chunks)
 
+// stores of what only the backward pass / the weight-gradient launch reads (OTR_F3_NT=0 at build time: plain stores, for A/B runs)
+#ifndef OTR_F3_NT
+#define OTR_F3_NT 1
+#endif
+#if OTR_F3_NT
+#define F3_ST_SAVE(P, V) st_global_b128_nt((P), (V))
+#else
+#define F3_ST_SAVE(P, V) st_global_b128((P), (V))
+#endif
 template <int N> __device__ __forceinline__ void f3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void f3_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void f3_barrier() {
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   auto u_store = [&](int CH, int g) {
     const unsigned char* sp = st_src + g * 128;
     const uint2 lo = *reinterpret_cast<const uint2*>(sp), up = *reinterpret_cast<const uint2*>(sp + 512);
-    st_global_b128(st_dst + (int64_t)(8 * g) * (int64_t)p.F + CH * 64, make_uint4(lo.x, lo.y, up.x, up.y));
+    F3_ST_SAVE(st_dst + (int64_t)(8 * g) * (int64_t)p.F + CH * 64, make_uint4(lo.x, lo.y, up.x, up.y));
   };
   const int k_own = 2 * wc, k_par = 2 * (wc ^ 1);
 
@@ -488,10 +497,10 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
         my_u[(rt * 2 + (kk & 1)) * 64] = nu; /* ... and handed to the partner wave */                            \
         if constexpr (SAVE && !no_st) {      /* 2 global stores per quarter (row-major u: u_store) */              \
           uint4* hs = p.hsave + ((int64_t)(((rb * 4 + sl) * NC + (CHUNK)) * 4 + wid) * 8) * 64 + lane;         \
-          st_global_b128(hs + (rt * 2 + (kk & 1)) * 64,                                                        \
+          F3_ST_SAVE(hs + (rt * 2 + (kk & 1)) * 64,                                                            \
                          make_uint4(pack2h(hv[rt][j0], hv[rt][j0 + 1]), pack2h(hv[rt][j0 + 2], hv[rt][j0 + 3]), \
                                     pack2h(hv[rt][j0 + 4], hv[rt][j0 + 5]), pack2h(hv[rt][j0 + 6], hv[rt][j0 + 7]))); \
-          st_global_b128(hs + (4 + rt * 2 + (kk & 1)) * 64,                                                    \
+          F3_ST_SAVE(hs + (4 + rt * 2 + (kk & 1)) * 64,                                                        \
                          make_uint4(pack2h(sg[0], sg[1]), pack2h(sg[2], sg[3]), pack2h(sg[4], sg[5]), pack2h(sg[6], sg[7]))); \
         }                                                                                                      \
       }                                                                                                        \
@@ -865,7 +874,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   auto dh_store = [&](int CH, int t) {
     const unsigned char* sp = st_src + (t >> 2) * 2048 + (t & 3) * 128;
     const uint2 lo = *reinterpret_cast<const uint2*>(sp), up = *reinterpret_cast<const uint2*>(sp + 512);
-    st_global_b128(st_dst + (int64_t)(8 * (t & 3)) * (2 * (int64_t)p.F) + (t >> 2) * (int64_t)p.F + CH * 64, make_uint4(lo.x, lo.y, up.x, up.y));
+    F3_ST_SAVE(st_dst + (int64_t)(8 * (t & 3)) * (2 * (int64_t)p.F) + (t >> 2) * (int64_t)p.F + CH * 64, make_uint4(lo.x, lo.y, up.x, up.y));
   };
 
   // D: du = w_2^T . dy over 16 contraction steps, 8 MFMAs per group of 4 fragments, two DMAs behind every group

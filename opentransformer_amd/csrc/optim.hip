@@ -110,25 +110,51 @@ __device__ __forceinline__ float otr_gauss(uint64_t seed, uint64_t idx) {
   return sqrtf(-2.f * __logf(u1)) * __cosf(6.2831853f * u2);
 }
 
-__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, const OptState* st, bf16_t* p_lp,
-                            float beta1, float beta2, float eps, float wd, float clip, float noise_std) {
+// One element of the update (torch.optim.Adam with L2 weight decay, train/trainer.py:221-234)
+__device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& vi, int64_t i, float coef, float wd, float beta1, float beta2,
+                                         float step_size, float rbc2, float eps, float noise_std, uint64_t nseed) {
+  gi *= coef;
+  if (noise_std > 0.f) gi += noise_std * otr_gauss(nseed, (uint64_t)i);   // added after clipping, as the reference does
+  gi += wd * pi;
+  mi = beta1 * mi + (1.f - beta1) * gi;
+  vi = beta2 * vi + (1.f - beta2) * gi * gi;
+  pi = pi - step_size * mi / (sqrtf(vi) * rbc2 + eps);
+}
+// 16 bytes per lane and stream; p / m / v are read once and written once per step and nobody reads them before the next step's
+// optimizer: non-temporal both ways, so 0.58 GB of state does not push the 16-bit weights (written here, read by the next step's
+// first launches) and the packs out of the caches.  n4 = whole float4s, the tail (< 4 elements) is done by workgroup 0.
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, const OptState* st, bf16_t* p_lp,
+                                                   float beta1, float beta2, float eps, float wd, float clip, float noise_std) {
   const float us = st->unscale;
   const float norm = sqrtf(st->sqnorm) * us;
   if (!isfinite(norm)) return;
   const float coef = us * (clip > 0.f ? fminf(1.f, clip / (norm + 1e-6f)) : 1.f);
   const float lr = st->lr, bc1 = st->bc1, rbc2 = rsqrtf(st->bc2);
+  const float step_size = lr / bc1;
   const uint64_t nseed = 0x6E015Eull + (uint64_t)st->step * 0x9E3779B97F4A7C15ull;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float pi = p[i];
-    float gi = g[i] * coef;
-    if (noise_std > 0.f) gi += noise_std * otr_gauss(nseed, (uint64_t)i);   // added after clipping, as the reference does
-    gi += wd * pi;
-    float mi = beta1 * m[i] + (1.f - beta1) * gi;
-    float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    pi = pi - (lr / bc1) * mi / (sqrtf(vi) * rbc2 + eps);
-    p[i] = pi;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f4 pv = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p) + i);
+    const f4 gv = *(reinterpret_cast<const f4*>(g) + i);
+    f4 mv = __builtin_nontemporal_load(reinterpret_cast<const f4*>(m) + i);
+    f4 vv = __builtin_nontemporal_load(reinterpret_cast<const f4*>(v) + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float pi = pv[e], mi = mv[e], vi = vv[e];
+      adam_one(pi, gv[e], mi, vi, 4 * i + e, coef, wd, beta1, beta2, step_size, rbc2, eps, noise_std, nseed);
+      pv[e] = pi; mv[e] = mi; vv[e] = vi;
+    }
+    __builtin_nontemporal_store(mv, reinterpret_cast<f4*>(m) + i);
+    __builtin_nontemporal_store(vv, reinterpret_cast<f4*>(v) + i);
+    __builtin_nontemporal_store(pv, reinterpret_cast<f4*>(p) + i);
+    if (p_lp) *reinterpret_cast<uint2*>(p_lp + 4 * i) = make_uint2((uint32_t)f2bf(pv[0]) | ((uint32_t)f2bf(pv[1]) << 16), (uint32_t)f2bf(pv[2]) | ((uint32_t)f2bf(pv[3]) << 16));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = 4 * n4 + threadIdx.x;
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_one(pi, g[i], mi, vi, i, coef, wd, beta1, beta2, step_size, rbc2, eps, noise_std, nseed);
+    p[i] = pi; m[i] = mi; v[i] = vi;
     if (p_lp) p_lp[i] = f2bf(pi);
   }
 }
@@ -150,7 +176,10 @@ extern "C" int32_t otr_optimizer_step(float* param, const float* grad, float* ex
   hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(256), 0, s, grad, n, st);
   hipLaunchKernelGGL(opt_tick_kernel, dim3(1), dim3(64), 0, s, st, base_lr, noam_model_size, noam_warmup, noam_factor,
                      noam_step_offset, beta1, beta2, grad_scale, g_otr_fault, (int)grid);
-  unsigned g2 = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  OTR_REQUIRE(((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0 && (!param_bf16 || (uintptr_t)param_bf16 % 8 == 0),
+              "optimizer_step: parameter / moment buffers must be 16-byte aligned (the 16-bit shadow 8-byte)");
+  unsigned g2 = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256);
+  if (g2 < 1) g2 = 1;
   hipLaunchKernelGGL(adam_kernel, dim3(g2), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, st, (bf16_t*)param_bf16, beta1, beta2, eps,
                      weight_decay, clip_norm, grad_noise_std);
   return otr_check_launch("optimizer_step");
