@@ -46,6 +46,7 @@ int g_otr_wgrad256_ablate = 0;   // tuning hook (otr_debug_set(8, v)), see wgrad
 int g_otr_wgrad256_min_rows = 256;   // shortest contraction the 256-wide launch takes (otr_debug_set(9, v))
 extern int g_otr_conv2_dgrad_ablate;   // conv.hip (otr_debug_set(10, v))
 int g_otr_wgrad256_grid = 0; // workgroups of that launch; 0 = one per CU (otr_debug_set(7, v))
+int g_otr_conv2_fwd_direct = 1;  // conv2 forward on the weight-stationary kernel where it serves (otr_debug_set(22, v))
 int g_otr_attn_enc = 1;          // encoder-shape attention backward with the whole (utterance, head) in LDS (otr_debug_set(21, v))
 int g_otr_rb_waves8 = 1;         // 256-column row-block kernels on 8-wave workgroups (otr_debug_set(19, v))
 int g_otr_rb_nsplit = 1;         // q|k|v row-block projection: 1 = two workgroups per row block, 384 columns each (otr_debug_set(18, v))
@@ -80,6 +81,7 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   else if (key == 18) g_otr_rb_nsplit = value;
   else if (key == 19) g_otr_rb_waves8 = value;
   else if (key == 21) g_otr_attn_enc = value;
+  else if (key == 22) g_otr_conv2_fwd_direct = value;
   else if (key == 15) g_otr_ffn_map = value;
   else { otr_set_error("debug_set: unknown key %d", key); return -1; }
   return 0;
@@ -353,11 +355,19 @@ static int32_t conv_geom(const otr_conv_desc_t* d, ConvGeom& g) {
   return 0;
 }
 
+int32_t conv2_fwd_direct(const void* act1, const void* w2r, const float* b2, void* act2, int B, int T1, int F1, int T2, int F2, int C1, int C2,
+                         int act_is_h16, int w_is_h16, hipStream_t stream);      // conv2fwd.hip: weight-stationary kernel (64 -> 128 channels)
+
 extern "C" int32_t otr_conv2_fwd(const otr_conv_desc_t* d, const void* act1, const void* w2r, const float* b2,
                                  void* act2, void* stream) {
   GemmArgs a{};
   if (int32_t e = conv_geom(d, a.cg)) return e;
   OTR_REQUIRE(act1 && w2r && act2, "conv2_fwd: null pointer");
+  if (b2) {
+    const int32_t rc = conv2_fwd_direct(act1, w2r, b2, act2, d->B, d->T1, d->F1, d->T2, d->F2, d->C1, d->C2, d->act_dtype == OTR_H16,
+                                        d->w_dtype == OTR_H16, (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
   a.A = act1; a.B = w2r; a.C = act2; a.bias = b2;
   a.M = d->B * d->T2 * d->F2; a.N = d->C2; a.K = 9 * d->C1;
   a.lda = 0; a.ldb = a.K; a.ldc = d->C2;
