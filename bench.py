@@ -63,9 +63,10 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='timed region only (profiler runs): no breakdown, no roofline, no bf16 line')
     ap.add_argument('--no-bf16-line', action='store_true', help='skip the secondary bf16 measurement of the same workload')
-    ap.add_argument('--overlap', action='store_true',
-                    help='N > 1: reduce the decoder group on a side stream while the encoder backward runs (two collectives; the step '
-                         'then launches eagerly: a collective inside a captured graph is not used)')
+    ap.add_argument('--overlap', default='auto', choices=['auto', 'on', 'off'],
+                    help='staged step: the backward pass is cut at the encoder / decoder boundary into two hipGraphs, and between their '
+                         'replays the all-reduce of the decoder group (37 %% of the gradient bytes) starts on a side stream and runs '
+                         'beside the encoder backward; the collectives themselves are never captured.  auto = on when N > 1')
     ap.add_argument('--cpu-threads', type=int, default=0, help='torch threads of the CPU baseline (0 = best of 16 / 32 / 64)')
     return ap.parse_args()
 
@@ -331,47 +332,76 @@ def main():
         model = ota.SpeechToText(cfg)
         syn.fill_state_dict_(model.state_dict(), 1234)           # identical replicas on every rank
         model = model.to(dev).train()
-        overlap = args.overlap and world > 1
+        overlap = args.overlap == 'on' or (args.overlap == 'auto' and world > 1)
+        ops.set_stage_split(overlap)
         dp = FlatDataParallel(model, early_modules=([model.decoder] + ([model.assistor] if hasattr(model, 'assistor') else [])) if overlap else None)
         dp.broadcast_parameters()
         opt = FusedAdam(dp, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6, clip_grad=5.0,
                         noam=dict(model_size=cfg['encoder']['d_model'], warmup_steps=12000, factor=1.0))   # *_baseline.yaml train section
         loss_buf = torch.zeros((), device=dev)
 
-        def fwd_bwd():
+        stages = []
+
+        def stage1():
             dp.zero_grad()
             ops.next_dropout_step(dev)
             loss, _ = dp(inputs, targets)
-            loss.backward()
+            loss.backward()                       # staged: stops at the encoder / decoder cut (ops.early_mark); else the whole pass
             loss_buf.copy_(loss.detach())
+            stages[:] = ops.take_stages()
 
-        graph = None
-        if not args.no_graph and not overlap:
+        def stage2():
+            for x, leaf in reversed(stages):
+                x.backward(leaf.grad)
+
+        def fwd_bwd():
+            stage1()
+            if overlap:
+                dp.start_early_reduce()
+                stage2()
+
+        graph, graph2 = None, None
+        if not args.no_graph:
             try:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     for _ in range(3):
                         fwd_bwd()
+                        if overlap:
+                            dp.all_reduce_gradients()     # consumes the early collective of the warm-up passes
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with ops.graph_capture(graph):
-                    fwd_bwd()
+                    stage1()
+                if overlap:
+                    graph2 = torch.cuda.CUDAGraph()
+                    with ops.graph_capture(graph2, pool=graph.pool()):
+                        stage2()
             except Exception as e:                                # noqa: BLE001
                 if rank == 0:
                     print('hipGraph capture failed (%s: %s); running eagerly' % (type(e).__name__, e), file=sys.stderr)
-                graph = None
+                graph, graph2 = None, None
                 torch.cuda.synchronize()
 
-        def step():
-            if graph is not None:
-                graph.replay()
-            else:
+        def run_fwd_bwd():
+            if graph is None:
                 fwd_bwd()
+                return
+            graph.replay()
+            if overlap:
+                # (a second graph launch costs ~0.2 ms on this stack -- measured at N = 1 with forward / backward as two graphs and
+                # with this staged step: 4.40 -> 4.62 ms, the host calls take 0.05 + 0.18 ms and never block -- which the early
+                # group's 37 % of the all-reduce has to buy back: break-even near 0.55 ms of all-reduce time)
+                dp.start_early_reduce()                   # eager, on the side stream: beside the second graph
+                graph2.replay()
+
+        def step():
+            run_fwd_bwd()
             scale, _ = dp.all_reduce_gradients()
             opt.step(scale)
-        return dict(dp=dp, opt=opt, fwd_bwd=fwd_bwd, step=step, graph=graph, loss_buf=loss_buf)
+        return dict(dp=dp, opt=opt, fwd_bwd=fwd_bwd, run_fwd_bwd=run_fwd_bwd, step=step, graph=graph, loss_buf=loss_buf, overlap=overlap)
 
     def timed(step, warmup, steps):
         """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; max over ranks"""
@@ -391,6 +421,7 @@ def main():
 
     run = build(args.mode)
     dp, opt, fwd_bwd, step, graph, loss_buf = (run[k] for k in ('dp', 'opt', 'fwd_bwd', 'step', 'graph', 'loss_buf'))
+    run_fwd_bwd = run['run_fwd_bwd']
     used_graph = graph is not None
     elapsed = timed(step, args.warmup, args.steps)
 
@@ -408,10 +439,7 @@ def main():
         acc = [0.0, 0.0]
         for _ in range(5):
             ev[0].record()
-            if graph is not None:
-                graph.replay()
-            else:
-                fwd_bwd()
+            run_fwd_bwd()
             ev[1].record()
             scale, _ = dp.all_reduce_gradients()
             opt.step(scale)
@@ -433,10 +461,16 @@ def main():
         dp.skip_collectives = False
         parts['ms_per_step_without_collectives'] = t_skip
         parts['exposed_allreduce_ms'] = elapsed / args.steps * 1e3 - t_skip
-        parts['overlap'] = bool(args.overlap)
+        parts['overlap'] = bool(run['overlap'])
         parts['allreduce_bytes'] = dp.flat_grad.numel() * dp.flat_grad.element_size()
         parts['nranks'] = dist.get_world_size()
-    kern = instrumented_step(ops, fwd_bwd, args.mode) if (rank == 0 and not args.no_extras) else None
+    kern = None
+    if rank == 0 and not args.no_extras:
+        dp.skip_collectives = True            # rank 0 alone runs this pass: it must not start a collective (staged step: the early group's)
+        try:
+            kern = instrumented_step(ops, fwd_bwd, args.mode)
+        finally:
+            dp.skip_collectives = False
     if world > 1:
         dist.barrier()
 
@@ -559,7 +593,7 @@ def main():
     #      takes part (the step holds the collective); after the replays above, which need the primary mode's operands
     bf16_line = None
     if args.mode != 'bf16' and args.model == 'transformer' and not (args.no_extras or args.no_bf16_line):
-        del run, dp, opt, fwd_bwd, step, graph, kern    # free the primary replica (graph pool, 2.2 GB of saved activations)
+        del run, dp, opt, fwd_bwd, run_fwd_bwd, step, graph, kern    # free the primary replica (graph pool, 2.2 GB of saved activations)
         torch.cuda.empty_cache()
         run2 = build('bf16')
         el2 = timed(run2['step'], args.warmup, args.steps)

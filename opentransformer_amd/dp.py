@@ -338,6 +338,25 @@ class FlatDataParallel:
             work, pay = self._reduce_slice(0, self.early_end)
         self._early_state = (work, pay)
 
+    def start_early_reduce(self, force=False):
+        """Staged step (ops.set_stage_split): call between stage 1 (forward + the backward of everything behind ops.early_mark, whose
+        deferred weight gradients are flushed when that backward ends) and stage 2 (the rest of the backward pass): the early group's
+        all-reduce starts on the side stream, ordered behind whatever the compute stream holds now, and runs beside stage 2;
+        all_reduce_gradients() reduces the rest and joins.  Nothing happens at world size 1 (unless forced), with no early group,
+        or when it was already started this step."""
+        self._on_early_ready(force)
+
+    def backward_staged(self, loss, between=None):
+        """loss.backward() cut at the marks of ops.set_stage_split(True); `between` (default: start_early_reduce) runs after stage 1"""
+        from . import ops
+        loss.backward()
+        stages = ops.take_stages()
+        (between or self.start_early_reduce)()
+        for x, leaf in reversed(stages):
+            if leaf.grad is not None:
+                x.backward(leaf.grad)
+        return stages
+
     def all_reduce_gradients(self, async_op=False, force=False):
         """single collective over the flat buffer; returns 1/world_size for the optimizer to fold in.
         force: run the collective even at world_size 1 (self-test of the RCCL path on a one-GPU box)."""

@@ -544,8 +544,32 @@ class EarlyMarkFn(torch.autograd.Function):
         return g
 
 
+def set_stage_split(on):
+    """Staged backward (dp.py, bench.py): with the switch on, ops.early_mark CUTS the autograd graph -- it returns a detached leaf
+    that shares x's storage and records (x, leaf).  `loss.backward()` then stops at the leaf (stage 1: everything behind the mark);
+    `for x, leaf in reversed(ops.take_stages()): x.backward(leaf.grad)` runs the rest (stage 2).  Each stage can be captured as its
+    own hipGraph, and between two replays the host can start the all-reduce of the gradients that are already final (the
+    collective itself is never captured)."""
+    _state['stage_split'] = bool(on)
+    _state['stages'] = []
+
+
+def take_stages():
+    st = _state.get('stages') or []
+    _state['stages'] = []
+    return st
+
+
 def early_mark(x):
-    """identity; see EarlyMarkFn (keeps the 16-bit twin of x)"""
+    """identity; see EarlyMarkFn (keeps the 16-bit twin of x).  In stage-split mode: a graph cut (set_stage_split)."""
+    if _state.get('stage_split') and x.requires_grad and torch.is_grad_enabled():
+        x = materialize(x)
+        leaf = x.detach().requires_grad_(True)
+        lp = getattr(x, _LP_ATTR, None)
+        if lp is not None:
+            setattr(leaf, _LP_ATTR, lp)
+        _state['stages'].append((x, leaf))
+        return leaf
     if _state.get('early_cb') is None or not x.requires_grad or not torch.is_grad_enabled():
         return x
     y = EarlyMarkFn.apply(x)

@@ -152,20 +152,62 @@ def _split_worker(rank, world, port, out):
     inputs, targets = syn.synthetic_batch(**BATCH)
     sh = slice(rank * 2, rank * 2 + 2)
     res = {}
-    for name in ('single', 'split'):
+    ins, tgs = {k: v[sh].cuda() for k, v in inputs.items()}, {k: v[sh].cuda() for k, v in targets.items()}
+    for name in ('single', 'split', 'staged', 'staged_graphs'):
         model = ota.SpeechToText(cfg)
         syn.fill_state_dict_(model.state_dict(), 77)
         model = model.to('cuda').train()
-        dp = FlatDataParallel(model, early_modules=[model.decoder, model.assistor] if name == 'split' else None)
-        dp.zero_grad()
-        loss, _ = dp({k: v[sh].cuda() for k, v in inputs.items()}, {k: v[sh].cuda() for k, v in targets.items()})
-        loss.backward()
-        res[name + '_issued'] = dp._early_state is not None
-        scale, _ = dp.all_reduce_gradients()
-        torch.cuda.synchronize()
-        res[name] = {k: (p.grad.detach().float() * scale).cpu() for k, p in model.named_parameters()}
-        res[name + '_early'] = dp.early_end
-        ops.set_early_callback(None)
+        dp = FlatDataParallel(model, early_modules=[model.decoder, model.assistor] if name != 'single' else None)
+        ops.set_stage_split(name.startswith('staged'))
+        try:
+            if name == 'staged_graphs':
+                # bench.py's N > 1 step: stage 1 and stage 2 as two hipGraphs, the early collective issued between their replays
+                stages = []
+
+                def stage1():
+                    dp.zero_grad()
+                    loss, _ = dp(ins, tgs)
+                    loss.backward()
+                    stages[:] = ops.take_stages()
+
+                def stage2():
+                    for x, leaf in reversed(stages):
+                        x.backward(leaf.grad)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        stage1(); dp.start_early_reduce(); stage2(); dp.all_reduce_gradients()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with ops.graph_capture(g1):
+                    stage1()
+                with ops.graph_capture(g2, pool=g1.pool()):
+                    stage2()
+                for _ in range(2):                      # replayed twice: nothing of a replay may leak into the next
+                    g1.replay()
+                    dp.start_early_reduce()
+                    res[name + '_issued'] = dp._early_state is not None
+                    g2.replay()
+                    scale, _ = dp.all_reduce_gradients()
+            else:
+                dp.zero_grad()
+                loss, _ = dp(ins, tgs)
+                if name == 'staged':
+                    n_st = len(dp.backward_staged(loss))
+                    assert n_st == 1
+                    res[name + '_issued'] = True
+                else:
+                    loss.backward()
+                    res[name + '_issued'] = dp._early_state is not None
+                scale, _ = dp.all_reduce_gradients()
+            torch.cuda.synchronize()
+            res[name] = {k: (p.grad.detach().float() * scale).cpu() for k, p in model.named_parameters()}
+            res[name + '_early'] = dp.early_end
+        finally:
+            ops.set_early_callback(None)
+            ops.set_stage_split(False)
     if rank == 0:
         torch.save(res, out)
     dist.barrier()
@@ -180,11 +222,15 @@ def test_two_group_allreduce_with_the_real_model(tmp_path):
     mp.spawn(_split_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     got = torch.load(out, weights_only=False)
     assert got['split_issued'] and not got['single_issued'] and got['split_early'] > 0 and got['single_early'] == 0
-    worst = 0.0
-    for k, g in got['split'].items():
-        ref = got['single'][k]
-        worst = max(worst, float((g - ref).norm() / max(float(ref.norm()), 1e-6)))
-    assert worst < 1e-5, worst            # two runs of one backward pass differ in the last bits (float atomics), nothing more
+    assert got['staged_issued'] and got['staged_graphs_issued']
+    # 'staged': the graph-cut backward of ops.set_stage_split (loss.backward() stops at the encoder output, the early group's
+    # collective starts, the encoder's backward follows); 'staged_graphs': the same as two replayed hipGraphs (bench.py at N > 1)
+    for name in ('split', 'staged', 'staged_graphs'):
+        worst = 0.0
+        for k, g in got[name].items():
+            ref = got['single'][k]
+            worst = max(worst, float((g - ref).norm() / max(float(ref.norm()), 1e-6)))
+        assert worst < 1e-5, (name, worst)   # two runs of one backward pass differ in the last bits (float atomics), nothing more
 
 
 def test_library_owned_rccl_communicator_world_one():
