@@ -306,10 +306,18 @@ def main():
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the product has no CPU path)'
+    # OTR_BENCH_ONE_GPU=1 (tests on a one-GPU box only): every rank on cuda:0, collectives over gloo -- exercises the N > 1 control
+    # flow (staged step, collectives between the graphs, breakdown passes) end to end; the numbers mean nothing
+    one_gpu = os.environ.get('OTR_BENCH_ONE_GPU') == '1'
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', init_method='env://', device_id=dev)
+        if one_gpu:
+            dist.init_process_group('gloo', init_method='env://')
+        else:
+            dist.init_process_group('nccl', init_method='env://', device_id=dev)
 
     import opentransformer_amd as ota
     from opentransformer_amd import ops
