@@ -296,6 +296,63 @@ class CachedBeamState:
         ctx = ops.decode_self_attention(qkv, cache[0], cache[1], self.anc[cur], self.pos[cur], a.nheads)
         return self._close(blk, concat_linear, blk.norm2 if blk.normalize_before else blk.norm1, x, a, ctx)
 
+    def _fused_tail_ok(self, blk, with_cross):
+        """can the cross-attention + FFN sub-layers (decoder) / the FFN sub-layer (LM) of this post-norm layer run on the fused decoder
+        launches of training (csrc/declayer.hip)?  16-bit mode, d_model 256, 4 heads, GLU, no concat_after, beam <= 32"""
+        ff = blk.feed_forward
+        if (not ops._DEC_FUSED or not ops.is_half() or blk.normalize_before or blk.concat_after or ff.activation != 'glu'
+                or ff.w_1.bias is None or ff.w_2.bias is None or ff.w_1.weight.shape[1] != 256
+                or tuple(ff.w_2.weight.shape) != (256, ff.w_1.weight.shape[0] // 2) or self.rec.beam_width > 32):
+            return False
+        if ops.dec_ffn_slices(ff.w_2.weight.shape[1]) == 0 or ops.ffn_packs(ff.w_1.weight, ff.w_2.weight) is None:
+            return False
+        if with_cross:
+            ca = blk.src_attn
+            if ca.nheads != 4 or tuple(ca.q_proj.weight.shape) != (256, 256) or ca.q_proj.bias is None or ca.output_proj.bias is None:
+                return False
+            if ops.lin_packs(ca.q_proj.weight) is None or ops.lin_packs(ca.output_proj.weight) is None:
+                return False
+        return True
+
+    def _fused_tail(self, blk, x1, kv, norm_cross, norm_ffn):
+        """x1 = the layer's state after the self-attention sub-layer.  kv given (decoder): [q projection + cross-attention over the
+        utterance memory + output projection] as ONE launch per layer cut along (group of 32 // beam utterances, head) -- the beam
+        hypotheses of an utterance are the query rows of one attention problem, exactly the training launch with L = beam -- then
+        [LayerNorm + w_1 + GLU + w_2] cut along (32-row block, hidden slice), then the closing LayerNorm (otr_dec_ln): 3 launches
+        for what took 8-9 (decoder/transformer.py:70-86).  kv None (LM layer, model/lm.py:94-140): the FFN sub-layer alone, 2 launches."""
+        lib, R, d = L.load(), self.R, 256
+        dev, hdt, st = x1.device, ops.half_dtype(), ops._stream()
+        ff = blk.feed_forward
+        F = ff.w_2.weight.shape[1]
+        S = ops.dec_ffn_slices(F)
+        h16 = lambda *sh: torch.empty(sh, dtype=hdt, device=dev)          # noqa: E731
+        f32 = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)  # noqa: E731
+        xr, x16 = x1.reshape(R, d), ops.lp_of(x1).reshape(R, d)
+        if kv is not None:
+            ca = blk.src_attn
+            beam = self.rec.beam_width
+            slB, q16, ctx2, lse2 = h16(4, R, d), h16(R, d), h16(R, d), f32(self.b, 4, beam)
+            lnB = ops._dec_ln(None, x16, None, 0)                          # the rows are normalised already: nothing to finish
+            W = kv.shape[2]
+            L.check(lib.otr_dec_cross_fwd(C.byref(lnB), self.b, beam, ops._p(ops.lin_packs(ca.q_proj.weight)[0]), ops._p(ca.q_proj.bias),
+                                          ops._p(ops.lin_packs(ca.output_proj.weight)[0]), ops._p(kv), self.Tm * W, W, 0, W // 2,
+                                          ops._p(self.mem_mask), self.Tm, ops._p(q16), ops._p(ctx2), ops._p(lse2), ops._p(slB), st),
+                    'otr_dec_cross_fwd')
+            y2, y216 = f32(R, d), h16(R, d)
+            lnC = ops._dec_ln(xr, None, slB, 4, ca.output_proj.bias, norm_cross.weight, norm_cross.bias, None, 0.0, norm_cross.eps, 0,
+                              y2, y216)
+        else:
+            y2 = xr
+            lnC = ops._dec_ln(None, x16, None, 0)
+        packs = ops.ffn_packs(ff.w_1.weight, ff.w_2.weight)
+        slC = h16(S, R, d)
+        L.check(lib.otr_dec_ffn_fwd(C.byref(lnC), R, ops._p(packs[0]), ops._p(ff.w_1.bias), ops._p(packs[1]), F, S, ops._p(slC), None, st),
+                'otr_dec_ffn_fwd')
+        y3, y316 = f32(R, d), h16(R, d)
+        lnF = ops._dec_ln(y2, None, slC, S, ff.w_2.bias, norm_ffn.weight, norm_ffn.bias, None, 0.0, norm_ffn.eps, 0, y3, y316)
+        L.check(lib.otr_dec_ln(C.byref(lnF), R, st), 'otr_dec_ln')
+        return ops.attach_lp(y3, y316)
+
     def step(self, cur):
         """One beam-search step (recognize/speech2text.py:95-146) reading phase `cur`, writing phase cur^1."""
         rec, lib = self.rec, L.load()
@@ -306,6 +363,9 @@ class CachedBeamState:
         for blk, cache, kv in zip(dec.blocks, self.dec_cache, self.mem_kv):
             x = self._stack_step(x, blk, cache, cur, getattr(blk, 'concat_linear1', None))
             a = blk.src_attn
+            if ops.lp_of(x) is not None and x.dtype == torch.float32 and self._fused_tail_ok(blk, True) and kv.shape[2] == 512:
+                x = self._fused_tail(blk, x, kv, blk.norm2, blk.norm3)
+                continue
             q = ops.linear(x, a.q_proj.weight, a.q_proj.bias, out_dtype=adt)
             # the beam hypotheses of an utterance are the query rows of ONE attention problem over its memory
             ctx = ops.CrossAttentionFn.apply(q.view(self.b, beam, -1), kv, self.mem_mask, a.nheads)
@@ -321,6 +381,9 @@ class CachedBeamState:
             y = ops.decode_embed(self.preds[cur], self.pos[cur], lm.embedding.weight)
             for blk, cache in zip(lm.blocks, self.lm_cache):
                 y = self._stack_step(y, blk, cache, cur, getattr(blk, 'concat_linear', None))
+                if ops.lp_of(y) is not None and y.dtype == torch.float32 and self._fused_tail_ok(blk, False):
+                    y = self._fused_tail(blk, y, None, None, blk.norm2)
+                    continue
                 y = self._ffn(blk, blk.norm2, y)
             lm_logits = ops.linear(y, lm.output_project.weight, lm.output_project.bias)
         L.check(lib.otr_beam_topk(_ptr(logits), V, _ptr(lm_logits), V, float(rec.lm_weight or 0.0), self.R, V, beam,
