@@ -67,6 +67,8 @@ def parse():
                     help='staged step: the backward pass is cut at the encoder / decoder boundary into two hipGraphs, and between their '
                          'replays the all-reduce of the decoder group (37 %% of the gradient bytes) starts on a side stream and runs '
                          'beside the encoder backward; the collectives themselves are never captured.  auto = on when N > 1')
+    ap.add_argument('--opt-in-graph', default='on', choices=['on', 'off'],
+                    help='N = 1: capture the optimizer launches in the step graph too (on) or issue them eagerly behind the replay (off)')
     ap.add_argument('--cpu-threads', type=int, default=0, help='torch threads of the CPU baseline (0 = best of 16 / 32 / 64)')
     return ap.parse_args()
 
@@ -349,6 +351,9 @@ def main():
         loss_buf = torch.zeros((), device=dev)
 
         stages = []
+        # N = 1: nothing sits between the backward pass and the optimizer, so the WHOLE step is one hipGraph (--opt-in-graph off: the
+        # optimizer's launches follow the replay eagerly, as they must at N > 1 where the all-reduce sits in between)
+        whole = world == 1 and not overlap and args.opt_in_graph == 'on' and not args.no_graph
 
         def stage1():
             dp.zero_grad()
@@ -383,6 +388,8 @@ def main():
                 graph = torch.cuda.CUDAGraph()
                 with ops.graph_capture(graph):
                     stage1()
+                    if whole:
+                        opt.step(1.0)
                 if overlap:
                     graph2 = torch.cuda.CUDAGraph()
                     with ops.graph_capture(graph2, pool=graph.pool()):
@@ -407,9 +414,11 @@ def main():
 
         def step():
             run_fwd_bwd()
+            if whole and graph is not None:
+                return
             scale, _ = dp.all_reduce_gradients()
             opt.step(scale)
-        return dict(dp=dp, opt=opt, fwd_bwd=fwd_bwd, run_fwd_bwd=run_fwd_bwd, step=step, graph=graph, loss_buf=loss_buf, overlap=overlap)
+        return dict(whole=whole, dp=dp, opt=opt, fwd_bwd=fwd_bwd, run_fwd_bwd=run_fwd_bwd, step=step, graph=graph, loss_buf=loss_buf, overlap=overlap)
 
     def timed(step, warmup, steps):
         """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; max over ranks"""
@@ -430,6 +439,7 @@ def main():
     run = build(args.mode)
     dp, opt, fwd_bwd, step, graph, loss_buf = (run[k] for k in ('dp', 'opt', 'fwd_bwd', 'step', 'graph', 'loss_buf'))
     run_fwd_bwd = run['run_fwd_bwd']
+
     used_graph = graph is not None
     elapsed = timed(step, args.warmup, args.steps)
 
@@ -449,13 +459,17 @@ def main():
             ev[0].record()
             run_fwd_bwd()
             ev[1].record()
-            scale, _ = dp.all_reduce_gradients()
-            opt.step(scale)
+            if not (run['whole'] and graph is not None):
+                scale, _ = dp.all_reduce_gradients()
+                opt.step(scale)
             ev[2].record()
             torch.cuda.synchronize()
             acc[0] += ev[0].elapsed_time(ev[1])
             acc[1] += ev[1].elapsed_time(ev[2])
         parts = {'fwd_bwd_ms': acc[0] / 5, 'allreduce_optimizer_ms': acc[1] / 5}
+        if run['whole'] and graph is not None:
+            parts = {'whole_step_graph_ms': acc[0] / 5,
+                     'note': 'N = 1: forward, backward and the optimizer launches are ONE hipGraph (--opt-in-graph off separates them)'}
     if world > 1 and not args.no_extras:     # the collective on its own: 5 all-reduces of the flat gradient buffer, events on the stream
         ev[0].record()
         for _ in range(5):
