@@ -244,16 +244,29 @@ def _split_worker(rank, world, port, out, payload):
     tok, tgt = _data()
     shard = slice(rank * 4, rank * 4 + 4)
     res = {}
-    for name, early in (('single', False), ('split', True)):
+    from opentransformer_amd import ops
+    for name, early in (('single', False), ('split', True), ('staged', True)):
         model = TinySplit()
         dp = FlatDataParallel(model, early_modules=[model.out] if early else None, grad_comm_dtype=payload)
         dp.zero_grad()
-        dp(tok[shard], tgt[shard]).backward()
-        res[name + '_early_issued'] = dp._early_state is not None
+        ops.set_stage_split(name == 'staged')
+        try:
+            loss = dp(tok[shard], tgt[shard])
+            if name == 'staged':
+                # the graph-cut form (bench.py at N > 1): loss.backward() stops at the mark, the early group's collective starts,
+                # the trunk's backward follows as a second pass
+                issued = []
+                stages = dp.backward_staged(loss, between=lambda: (dp.start_early_reduce(), issued.append(dp._early_state is not None)))
+                res[name + '_stages'] = len(stages)
+                res[name + '_early_issued'] = issued[0]
+            else:
+                loss.backward()
+                res[name + '_early_issued'] = dp._early_state is not None
+        finally:
+            ops.set_stage_split(False)
         scale, _ = dp.all_reduce_gradients()
         res[name] = (dp.packed_grads() * scale).clone()
         res[name + '_early_end'] = dp.early_end
-    from opentransformer_amd import ops
     ops.set_early_callback(None)
     if rank == 0:
         torch.save(res, out)
@@ -271,3 +284,5 @@ def test_two_group_allreduce_equals_the_single_collective(tmp_path, payload):
     assert got['split_early_end'] > 0 and got['single_early_end'] == 0
     assert got['split_early_issued'] and not got['single_early_issued']        # the early collective was started INSIDE backward
     torch.testing.assert_close(got['split'], got['single'], rtol=0, atol=0)
+    assert got['staged_stages'] == 1 and got['staged_early_issued']            # ... and BETWEEN the two passes of the staged form
+    torch.testing.assert_close(got['staged'], got['single'], rtol=0, atol=0)
