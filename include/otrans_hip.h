@@ -369,6 +369,12 @@ int32_t otr_conv1_wgrad_partial_rows(void);
 /* conv2 as implicit GEMM on MFMA: w2r = w2 permuted to [C2,3,3,C1] (f32). +bias, ReLU */
 int32_t otr_conv2_fwd(const otr_conv_desc_t* d, const void* act1, const void* w2r, const float* b2, void* act2,
                       void* stream);
+/* Both Conv2dLayers of frontend/conv.py:141-142 in ONE launch (csrc/conv2fwd.hip): conv2 on a weight-stationary kernel whose input
+ * rows are computed from the filterbank frames in place (conv1's arithmetic, bit for bit); act1 is written for the backward pass.
+ * 16-bit activations and w2r, (C1, C2) = (64, 128), F1 = 40 or 20.  Returns 1 without launching anything when the operands do not
+ * qualify: call otr_conv1_fwd + otr_conv2_fwd then.  otr_debug_set(22, 0 | 1 | 2): 0 = the generic paths, 2 = conv2 alone on the new kernel. */
+int32_t otr_conv12_fwd(const otr_conv_desc_t* d, const float* x, const float* w1, const float* b1, void* act1, const void* w2r,
+                       const float* b2, void* act2, void* stream);
 /* dcol[B*T2*F2, 9*C1] (act dtype) = dact2 * w2r  (dact2 already masked by ReLU) */
 int32_t otr_conv2_dgrad_cols(const otr_conv_desc_t* d, const void* dact2, const void* w2r, void* dcol,
                              void* stream);

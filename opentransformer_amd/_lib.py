@@ -129,6 +129,7 @@ SIGNATURES = {
     'otr_conv1_wgrad': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P],
     'otr_conv1_wgrad_partial_rows': [],
     'otr_conv2_fwd': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
+    'otr_conv12_fwd': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_conv2_dgrad_cols': [C.POINTER(ConvDesc), _P, _P, _P, _P],
     'otr_conv2_col2im': [C.POINTER(ConvDesc), _P, _P, _P, _P],
     'otr_conv2_dgrad': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],

@@ -378,6 +378,18 @@ extern "C" int32_t otr_conv2_fwd(const otr_conv_desc_t* d, const void* act1, con
   return run_gemm(a, d->compute, d->act_dtype, d->w_dtype, d->act_dtype, MODE_IM2K, MODE_KC, stream);
 }
 
+int32_t conv12_fwd_direct(const float* x, const float* w1, const float* b1, void* act1, const void* w2r, const float* b2, void* act2, int B, int T,
+                          int F, int T1, int F1, int T2, int F2, int C1, int C2, int act_is_h16, int w_is_h16, hipStream_t stream);
+
+extern "C" int32_t otr_conv12_fwd(const otr_conv_desc_t* d, const float* x, const float* w1, const float* b1, void* act1, const void* w2r,
+                                  const float* b2, void* act2, void* stream) {
+  ConvGeom g{};
+  if (int32_t e = conv_geom(d, g)) return e;
+  OTR_REQUIRE(x && w1 && b1 && act1 && w2r && b2 && act2, "conv12_fwd: null pointer");
+  return conv12_fwd_direct(x, w1, b1, act1, w2r, b2, act2, d->B, d->T, d->F, d->T1, d->F1, d->T2, d->F2, d->C1, d->C2, d->act_dtype == OTR_H16,
+                           d->w_dtype == OTR_H16, (hipStream_t)stream);
+}
+
 extern "C" int32_t otr_conv2_dgrad_cols(const otr_conv_desc_t* d, const void* dact2, const void* w2r, void* dcol,
                                         void* stream) {
   GemmArgs a{};

@@ -2087,13 +2087,20 @@ class ConvSubsampleFn(torch.autograd.Function):
         act1 = torch.empty((B, T1, F1, C1), dtype=adt, device=x.device)
         act2 = torch.empty((B, T2, F2 * C2), dtype=adt, device=x.device)
         lib = L.load()
-        L.check(lib.otr_conv1_fwd(C.byref(desc), _p(x), _p(w1), _p(b1), _p(act1), _stream()), 'otr_conv1_fwd')
         seed, offs = None, (0, 0)
-        if p_drop > 0:
-            seed = rng_seed_tensor(x.device)
-            offs = (_next_rng_offset(act1.numel()), _next_rng_offset(act2.numel()))
-            L.check(lib.otr_dropout(_p(act1), _p(act1), _code(adt), act1.numel(), p_drop, _p(seed), offs[0], _stream()), 'otr_dropout')
-        L.check(lib.otr_conv2_fwd(C.byref(desc), _p(act1), _p(w2r), _p(b2), _p(act2), _stream()), 'otr_conv2_fwd')
+        fused = 1
+        if p_drop == 0 and b2 is not None and x.dtype == torch.float32 and w1.dtype == torch.float32:
+            # both layers in one launch where the shapes are served (csrc/conv2fwd.hip); 1 = not served
+            fused = lib.otr_conv12_fwd(C.byref(desc), _p(x), _p(w1), _p(b1), _p(act1), _p(w2r), _p(b2), _p(act2), _stream())
+            if fused != 1:
+                L.check(fused, 'otr_conv12_fwd')
+        if fused == 1:
+            L.check(lib.otr_conv1_fwd(C.byref(desc), _p(x), _p(w1), _p(b1), _p(act1), _stream()), 'otr_conv1_fwd')
+            if p_drop > 0:
+                seed = rng_seed_tensor(x.device)
+                offs = (_next_rng_offset(act1.numel()), _next_rng_offset(act2.numel()))
+                L.check(lib.otr_dropout(_p(act1), _p(act1), _code(adt), act1.numel(), p_drop, _p(seed), offs[0], _stream()), 'otr_dropout')
+            L.check(lib.otr_conv2_fwd(C.byref(desc), _p(act1), _p(w2r), _p(b2), _p(act2), _stream()), 'otr_conv2_fwd')
         if p_drop > 0:
             L.check(lib.otr_dropout(_p(act2), _p(act2), _code(adt), act2.numel(), p_drop, _p(seed), offs[1], _stream()), 'otr_dropout')
         ctx.drop = (p_drop, seed, offs)

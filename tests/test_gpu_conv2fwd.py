@@ -18,7 +18,7 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize('mode', ['fp16', 'bf16'])
-@pytest.mark.parametrize('B,T,Fdim', [(32, 1000, 80), (3, 97, 40), (1, 7, 80), (5, 331, 80), (2, 1023, 80), (4, 643, 40), (3, 35, 80)])
+@pytest.mark.parametrize('B,T,Fdim', [(32, 1000, 80), (3, 97, 40), (1, 7, 80), (5, 331, 80), (2, 1023, 80), (4, 643, 40), (3, 35, 80), (2, 71, 80), (2, 75, 80), (1, 139, 40)])
 def test_conv2_forward_direct_kernel(mode, B, T, Fdim):
     from opentransformer_amd import ops, _lib as L
     ops.set_compute_dtype(mode)
@@ -31,13 +31,19 @@ def test_conv2_forward_direct_kernel(mode, B, T, Fdim):
         b1 = (0.1 * torch.randn(C1, generator=gen)).to(DEV)
         w2 = (torch.randn(C2, C1, 3, 3, generator=gen) / math.sqrt(9 * C1)).to(DEV)
         b2 = (0.1 * torch.randn(C2, generator=gen)).to(DEV)
-        outs = []
-        for direct in (1, 0):
+        outs, a1s = [], []
+        w1g = w1.clone().requires_grad_(True)
+        for direct in (1, 2, 0):                 # 1: both layers in one launch, 2: conv2 alone on the new kernel, 0: the generic paths
             L.check(lib.otr_debug_set(22, direct), 'debug_set')
-            with torch.no_grad():
-                outs.append(ops.ConvSubsampleFn.apply(x, w1, b1, w2, b2).float())
-        a, g = outs
+            y = ops.ConvSubsampleFn.apply(x, w1g, b1, w2, b2)
+            outs.append(y.detach().float())
+            a1s.append(y.grad_fn.saved_tensors[2].clone())
+        a, a2, g = outs
         assert a.shape == g.shape and torch.isfinite(a).all()
+        # act1 (saved for the backward pass) is the same tensor bit for bit whoever computed it, hence also conv2's output of the two
+        # forms of the new kernel
+        assert torch.equal(a1s[0], a1s[2]) and torch.equal(a1s[1], a1s[2])
+        assert torch.equal(a, a2)
         # same 16-bit operands, fp32 accumulation in a different order, one rounding at the end on both sides
         assert rel(a, g) < (3e-3 if mode == 'bf16' else 4e-4), rel(a, g)
         assert float((a - g).abs().max()) < (0.1 if mode == 'bf16' else 0.02)
