@@ -362,6 +362,8 @@ class FlatDataParallel:
         force: run the collective even at world_size 1 (self-test of the RCCL path on a one-GPU box)."""
         ws = self.world_size
         work = None
+        from . import ops as _ops
+        _ops.check_no_pending_stages('all_reduce_gradients')
         self._check_grad_views()
         if self.skip_collectives:
             return 1.0 / ws, None
@@ -451,6 +453,8 @@ class FusedAdam:
             raise L.OtransHipError('FusedAdam runs on the GPU only')
         n = self.dp.flat_param.numel()
         nm = self.noam or {}
+        from . import ops as _ops
+        _ops.check_no_pending_stages('FusedAdam.step')
         self._last_grad_scale = float(grad_scale)
         ret = L.load().otr_optimizer_step(
             C.c_void_p(self.dp.flat_param.data_ptr()), C.c_void_p(self.dp.flat_grad.data_ptr()),

@@ -560,6 +560,18 @@ def take_stages():
     return st
 
 
+def check_no_pending_stages(who):
+    """With the graph cut on, `loss.backward()` alone leaves everything in front of the cut WITHOUT gradients.  The consumers of the
+    gradients (dp.all_reduce_gradients, FusedAdam.step) call this: cuts recorded by a forward pass that nobody took (ops.take_stages /
+    dp.backward_staged) mean stage 2 never ran."""
+    st = _state.get('stages') or []
+    if st:
+        _state['stages'] = []
+        raise RuntimeError('%s: ops.set_stage_split(True) is on and %d graph cut(s) of the last forward pass were never taken -- '
+                           'loss.backward() stopped at ops.early_mark and the rest of the backward pass did not run; use '
+                           'dp.backward_staged(loss) (or ops.take_stages() + x.backward(leaf.grad)), or switch the split off' % (who, len(st)))
+
+
 def early_mark(x):
     """identity; see EarlyMarkFn (keeps the 16-bit twin of x).  In stage-split mode: a graph cut (set_stage_split)."""
     if _state.get('stage_split') and x.requires_grad and torch.is_grad_enabled():

@@ -286,3 +286,24 @@ def test_two_group_allreduce_equals_the_single_collective(tmp_path, payload):
     torch.testing.assert_close(got['split'], got['single'], rtol=0, atol=0)
     assert got['staged_stages'] == 1 and got['staged_early_issued']            # ... and BETWEEN the two passes of the staged form
     torch.testing.assert_close(got['staged'], got['single'], rtol=0, atol=0)
+
+
+def test_staged_backward_left_half_done_is_an_error():
+    """ops.set_stage_split(True) + a plain loss.backward(): the trunk in front of the cut gets no gradient -- the gradient consumers refuse"""
+    from opentransformer_amd import ops
+    tok, tgt = _data()
+    model = TinySplit()
+    dp = FlatDataParallel(model)
+    ops.set_stage_split(True)
+    try:
+        dp.zero_grad()
+        dp(tok[:4], tgt[:4]).backward()
+        with pytest.raises(RuntimeError, match='never taken'):
+            dp.all_reduce_gradients()
+        dp.zero_grad()
+        dp.backward_staged(dp(tok[:4], tgt[:4]))          # the supported form leaves nothing behind
+        dp.all_reduce_gradients()
+        assert float(model.l1.weight.grad.abs().sum()) > 0
+    finally:
+        ops.set_stage_split(False)
+        ops.set_early_callback(None)
