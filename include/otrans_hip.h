@@ -169,6 +169,14 @@ int32_t otr_rb_linear_ln_bwd(const void* g16, int64_t ldg, const void* wt_pack, 
                              const float* mean, const float* rstd, const float* gamma, const uint64_t* seed, float p_drop,
                              uint64_t rng_offset, float* dx, void* da16, float* partial, int64_t M, int32_t N, int32_t K,
                              void* stream);
+/* The same with a PREFETCH range: while the epilogue runs every workgroup touches its share of [prefetch, prefetch + prefetch_bytes)
+ * (one dword per 64 bytes, no consumer) so that the NEXT launch finds those lines in the memory-side cache -- used for the two
+ * input-gradient packs of the split FFN's backward launch that follows this one in the backward pass (3 MB it would otherwise
+ * fetch from HBM in scattered 1 KiB pieces).  prefetch may be NULL (then exactly otr_rb_linear_ln_bwd). */
+int32_t otr_rb_linear_ln_bwd_pf(const void* g16, int64_t ldg, const void* wt_pack, const float* skip, int64_t lds, const float* z,
+                                const float* mean, const float* rstd, const float* gamma, const uint64_t* seed, float p_drop,
+                                uint64_t rng_offset, float* dx, void* da16, float* partial, int64_t M, int32_t N, int32_t K,
+                                const void* prefetch, int64_t prefetch_bytes, void* stream);
 int32_t otr_ln_bwd_proj(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                         const uint64_t* seed, const void* wt_pack, float* dx, void* da16, void* dc16, int64_t ldc,
                         float* partial, int64_t M, int32_t d_model, float p_drop, uint64_t rng_offset, void* stream);

@@ -73,7 +73,13 @@ __device__ __forceinline__ void st_global_b128(void* p, uint4 v) {
 // leave while the launch still computes
 __device__ __forceinline__ void st_global_b128_nt(void* p, uint4 v) {
   otr_u32x4 t = {v.x, v.y, v.z, v.w};
+#if defined(OTR_ST_WT) && OTR_ST_WT
+  // experiment: system-scope write-through (sc0 sc1) + nt: the line goes to memory now instead of lingering dirty in the L2 until the
+  // end-of-kernel release writes it back
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#else
   __builtin_nontemporal_store(t, (OTR_GLOBAL otr_u32x4*)(p));
+#endif
 }
 
 // ---------------------------------------------------------------- scalar conversions

@@ -295,6 +295,9 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
   const int row0 = rb * 128 + wr * 64;
   int stamp_i = 0;
 #define F3_STAMP() if constexpr ((ABL & 16) != 0) { if (p.trace && tid == 0 && stamp_i < 48) p.trace[(int64_t)blockIdx.x * 48 + stamp_i++] = __builtin_amdgcn_s_memtime(); }
+  // the constant-rate clock all XCDs share (100 MHz): when each workgroup starts / ends, at [256 * 48 + 2 workgroup + 0 / 1]
+#define F3_REALTIME(K) if constexpr ((ABL & 16) != 0) { if (p.trace && tid == 0) p.trace[256 * 48 + 2 * (int64_t)blockIdx.x + (K)] = __builtin_amdgcn_s_memrealtime(); }
+  F3_REALTIME(0)
   F3_STAMP()
   F3Sync sy{};
   if constexpr (!SLAB) f3_sync_begin(sy, p.sync + 8 * rb, p.coh_only ? 16 + sl : f3_xcc_id());
@@ -573,6 +576,7 @@ __global__ __launch_bounds__(256, 1) void ffn3_fwd_kernel(Ffn3FwdArgs p) {
     // and the q|k|v projection that reads this sub-layer's output finishes the LayerNorm in its prologue (rowblock.hip)
     f3_store_slab(yacc, ring, p.slab + (int64_t)sl * p.M * 256, rb, p.M, wid, wr, wc, lane);
     F3_STAMP()
+    F3_REALTIME(1)
     return;
   }
 
@@ -722,6 +726,7 @@ struct Ffn3BwdArgs {
   int M, F;
   uint16_t* slab;          // SLAB: [4 slices][M][256] 16-bit out -- this slice's share dh[slice] . w_1[slice] of the input gradient (skip, dx,
                            // scratch, sync are not touched then: the consumer adds the shares to the skip gradient, rowblock.hip)
+  unsigned long long* trace;   // tuning hook (otr_debug_trace), as Ffn3FwdArgs::trace
 };
 
 // a global load hipcc does not count (its own s_waitcnt would drain the DMAs in flight): 16 B per lane from a wave-uniform base.
@@ -757,6 +762,9 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   f3_block_map((int)blockIdx.x, p.map, rb, sl);
   if (rb * 128 >= p.M) return;
   const int row0 = rb * 128 + wr * 64;
+  int stamp_i = 0;
+#define F3B_STAMP() if constexpr ((ABL & 16) != 0) { if (p.trace && tid == 0 && stamp_i < 48) p.trace[(int64_t)blockIdx.x * 48 + stamp_i++] = __builtin_amdgcn_s_memtime(); }
+  F3B_STAMP()
   F3Sync sy{};
   if constexpr (!SLAB) f3_sync_begin(sy, p.sync + 8 * rb, p.coh_only ? 16 + sl : f3_xcc_id());
   const int nchunk = p.F / 32, per = nchunk / 4, NC = per >> 1;
@@ -988,12 +996,16 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   int slot = 0;
   uint4 dhn[2][4];                                               // the fragments the GLU' of this iteration produces
   // ---- chunk 0: D, then GLU' only
+  F3B_STAMP()
   F3B_PHASE_D(slot, false, 0)
   F3B_PHASE_END(16)
+  F3B_STAMP()
   F3B_PHASE_X(false, true, slot, dho, 0, 0, dhn)
   F3B_PHASE_END(16)
+  F3B_STAMP()
   F3B_PHASE_X(false, true, slot, dhp, 1, 0, dhn)
   F3B_PHASE_END(16)
+  F3B_STAMP()
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -1003,10 +1015,13 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
     F3B_READ_PARTNER()                                           // dh of chunk C-1 (written before the barriers of its X phases)
     F3B_PHASE_D(slot, true, C - 1)
     F3B_PHASE_END(16)
+    F3B_STAMP()
     F3B_PHASE_X(true, true, slot, dho, 0, C, dhn)
     F3B_PHASE_END(16)
+    F3B_STAMP()
     F3B_PHASE_X(true, true, slot, dhp, 1, C, dhn)
     F3B_PHASE_END(16)
+    F3B_STAMP()
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -1037,8 +1052,10 @@ __global__ __launch_bounds__(256, 1) void ffn3_bwd_kernel(Ffn3BwdArgs p) {
   f3_wait_vm_for<0>(hp[4], hp[5], hp[6], hp[7]);                 // theirs until here; everything else has drained too
   f3_wait_lds();
   f3_barrier();
+  F3B_STAMP()
   if constexpr (SLAB) {
     f3_store_slab(xacc, ring, p.slab + (int64_t)sl * p.M * 256, rb, p.M, wid, wr, wc, lane);    // see ffn3_fwd_kernel
+    F3B_STAMP()
     return;
   }
 
@@ -1165,7 +1182,9 @@ int32_t ffn3_bwd_slab_launch(const void* dy16, const void* hsave, const void* w2
   Ffn3BwdArgs p{};
   p.dy16 = (const uint16_t*)dy16; p.hsave = (const uint4*)hsave; p.p3 = (const uint4*)w2t_pack; p.p4 = (const uint4*)w1t_pack;
   p.dh = (uint16_t*)dh; p.slab = (uint16_t*)slab; p.map = g_otr_ffn_map; p.M = (int)M; p.F = F;
-  hipLaunchKernelGGL((ffn3_bwd_kernel<256, 0, true>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p);
+  p.trace = g_otr_trace;
+  if ((g_otr_ffn2_ablate & 31) == 16) hipLaunchKernelGGL((ffn3_bwd_kernel<256, 16, true>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((ffn3_bwd_kernel<256, 0, true>), dim3(f3_grid(M, 4)), dim3(256), 0, stream, p);
   return otr_check_launch("ffn3_bwd_slab");
 }
 

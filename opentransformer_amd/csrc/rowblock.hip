@@ -471,6 +471,11 @@ struct RbLinLnBwdArgs {
   int M;
   float p_drop;
   uint64_t rng_offset;
+  // What the NEXT launch streams first and would otherwise find nowhere but in HBM (the split FFN's backward launch: its two
+  // input-gradient packs, 3 MB, the second read in 1 KiB pieces 128 KiB apart): every workgroup touches its share -- one dword per
+  // 64 bytes, no consumer -- while its epilogue runs, so the lines sit in the memory-side cache when that launch asks for them
+  // (tools/ffn3_prefetch_probe.py: 50.8 -> 47.0 us for the backward launch on cold operands).
+  const unsigned char* pf; int64_t pf_lines;
 };
 
 template <int K, int NW>
@@ -509,6 +514,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rb_linear_ln_bwd_kernel(RbLin
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   ws.run(acc, xs, lane);
+  // see RbLinLnBwdArgs::pf.  The destination registers stay OWNED until the closing wait (hipcc does not know the asm is a load: a
+  // register it believed dead after the statement was reused, and the returning load overwrote a live value -- 1 % wrong dx).
+  uint32_t sink[4] = {0u, 0u, 0u, 0u};
+  if (p.pf) {
+    const int64_t per = min((p.pf_lines + gridDim.x - 1) / gridDim.x, (int64_t)(4 * 64 * NW)), l0 = (int64_t)blockIdx.x * per;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t l = l0 + tid + k * 64 * NW;
+      if (l < l0 + per && l < p.pf_lines) asm volatile("global_load_dword %0, %1, off" : "+v"(sink[k]) : "v"(p.pf + l * 64) : "memory");
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TPW; ++i) rb_put_tile<RS>(red, acc[i], (wid * TPW + i) * 32, lane);
   __syncthreads();
@@ -571,6 +587,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rb_linear_ln_bwd_kernel(RbLin
     for (int w = 0; w < NW; ++w) t_ += part[(k * NW + w) * D + cc];
     prow[c] = t_;
   }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink[0]), "+v"(sink[1]), "+v"(sink[2]), "+v"(sink[3])::"memory");   // the touches have come back
 }
 
 }  // namespace
@@ -677,10 +694,23 @@ extern "C" int32_t otr_ln_bwd_proj_slabs(const float* dskip, const void* slabs, 
   return otr_check_launch("ln_bwd_proj_slabs");
 }
 
+extern "C" int32_t otr_rb_linear_ln_bwd_pf(const void* g16, int64_t ldg, const void* wt_pack, const float* skip, int64_t lds, const float* z,
+                                           const float* mean, const float* rstd, const float* gamma, const uint64_t* seed, float p_drop,
+                                           uint64_t rng_offset, float* dx, void* da16, float* partial, int64_t M, int32_t N, int32_t K,
+                                           const void* prefetch, int64_t prefetch_bytes, void* stream);
 extern "C" int32_t otr_rb_linear_ln_bwd(const void* g16, int64_t ldg, const void* wt_pack, const float* skip, int64_t lds, const float* z,
                                         const float* mean, const float* rstd, const float* gamma, const uint64_t* seed, float p_drop,
                                         uint64_t rng_offset, float* dx, void* da16, float* partial, int64_t M, int32_t N, int32_t K,
                                         void* stream) {
+  return otr_rb_linear_ln_bwd_pf(g16, ldg, wt_pack, skip, lds, z, mean, rstd, gamma, seed, p_drop, rng_offset, dx, da16, partial, M, N, K, nullptr,
+                                 0, stream);
+}
+
+extern "C" int32_t otr_rb_linear_ln_bwd_pf(const void* g16, int64_t ldg, const void* wt_pack, const float* skip, int64_t lds, const float* z,
+                                           const float* mean, const float* rstd, const float* gamma, const uint64_t* seed, float p_drop,
+                                           uint64_t rng_offset, float* dx, void* da16, float* partial, int64_t M, int32_t N, int32_t K,
+                                           const void* prefetch, int64_t prefetch_bytes, void* stream) {
+  OTR_REQUIRE(prefetch_bytes >= 0 && (prefetch || prefetch_bytes == 0), "rb_linear_ln_bwd: bad prefetch range");
   OTR_REQUIRE(g16 && wt_pack && z && mean && rstd && gamma && dx && da16 && partial, "rb_linear_ln_bwd: null pointer");
   OTR_REQUIRE(N == 256 && (K == 256 || K == 768), "rb_linear_ln_bwd: built for N = 256, K in {256, 768} (got %d, %d)", N, K);
   OTR_REQUIRE(M >= 0 && M < (1ll << 31) && ldg >= K && ldg % 8 == 0 && (uintptr_t)g16 % 16 == 0 && (uintptr_t)wt_pack % 16 == 0,
@@ -692,6 +722,7 @@ extern "C" int32_t otr_rb_linear_ln_bwd(const void* g16, int64_t ldg, const void
   p.g16 = reinterpret_cast<const uint16_t*>(g16); p.pw = reinterpret_cast<const uint4*>(wt_pack); p.skip = skip; p.z = z; p.mean = mean;
   p.rstd = rstd; p.gamma = gamma; p.seed = seed; p.dx = dx; p.da16 = reinterpret_cast<uint16_t*>(da16); p.partial = partial;
   p.ldg = ldg; p.lds = lds; p.M = (int)M; p.p_drop = p_drop; p.rng_offset = rng_offset;
+  p.pf = prefetch_bytes >= 64 ? reinterpret_cast<const unsigned char*>(prefetch) : nullptr; p.pf_lines = prefetch_bytes / 64;
   const dim3 grid((unsigned)((M + RB - 1) / RB));
   hipStream_t s = (hipStream_t)stream;
   if (g_otr_rb_waves8) {

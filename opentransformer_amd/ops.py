@@ -343,10 +343,11 @@ class LnOutLink:
     device scalar); the FFN sub-layer's backward recognises the placeholder and takes `result`.  Any other gradient that reaches
     y is added to the placeholder by autograd, arrives as a real tensor and goes through the ordinary LayerNorm backward on top
     (the operation is linear in dy).  saved = what the LayerNorm backward needs, params = the parameters whose gradients it sums."""
-    __slots__ = ('armed', 'saved', 'params', 'result')
+    __slots__ = ('armed', 'saved', 'params', 'result', 'prefetch')
 
     def __init__(self):
         self.armed, self.saved, self.params, self.result = False, None, None, None
+        self.prefetch = None       # (tensor, bytes): what the launch AFTER the linked Linear's backward streams first (otr_rb_linear_ln_bwd_pf)
 
 
 _LNOUT = os.environ.get('OTR_LNOUT_LINK', '1') == '1'
@@ -748,9 +749,10 @@ def rb_linear_pending_raw(pend, pack, N, bias, out_dtype):
     return out
 
 
-def rb_linear_ln_bwd_raw(g2, wt_pack, skip, saved):
+def rb_linear_ln_bwd_raw(g2, wt_pack, skip, saved, prefetch=None):
     """(d z f32, d a 16-bit, partial [blocks, 3*256]) of the LayerNorm y = LN(z) whose output gradient is skip + g2 . W"""
     z, mean, rstd, gamma, seed, p_drop, off = saved
+    pf_t, pf_n = prefetch if prefetch is not None else (None, 0)
     M, K = g2.shape
     d = 256
     lib = L.load()
@@ -758,9 +760,9 @@ def rb_linear_ln_bwd_raw(g2, wt_pack, skip, saved):
     da = torch.empty((M, d), dtype=g2.dtype, device=g2.device)
     part = torch.empty((lib.otr_ln_bwd_proj_partial_rows(M), 3 * d), dtype=torch.float32, device=g2.device)
     L.check(_timed('rb_linear_ln_bwd %dx%dx%d' % (M, d, K), {'flops': 2.0 * M * d * K},
-                   lambda: lib.otr_rb_linear_ln_bwd(_p(g2), g2.stride(0), _p(wt_pack), _p(skip), skip.stride(0) if skip is not None else 0,
-                                                    _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed), p_drop, off, _p(dx), _p(da), _p(part),
-                                                    M, d, K, _stream())), 'otr_rb_linear_ln_bwd')
+                   lambda: lib.otr_rb_linear_ln_bwd_pf(_p(g2), g2.stride(0), _p(wt_pack), _p(skip), skip.stride(0) if skip is not None else 0,
+                                                       _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed), p_drop, off, _p(dx), _p(da), _p(part),
+                                                       M, d, K, _p(pf_t), pf_n, _stream())), 'otr_rb_linear_ln_bwd')
     return dx, da, part
 
 
@@ -826,7 +828,7 @@ class LinearFn(torch.autograd.Function):
             lo = ctx.lnout
             if (rb_ok and lo is not None and lo.result is None and dy2.dtype == half_dtype() and _wq['on'] and _in_backward()
                     and all(grad_target(q) is not None for q in lo.params)):
-                lo.result = rb_linear_ln_bwd_raw(dy2, ctx.rb[1], skip, lo.saved)
+                lo.result = rb_linear_ln_bwd_raw(dy2, ctx.rb[1], skip, lo.saved, lo.prefetch)
                 _park(lo)
                 dx = _zero_placeholder(dy2.device, ctx.xshape)
             elif rb_ok:
@@ -1438,6 +1440,7 @@ _FUSED_FFN_MIN_ROWS = int(os.environ.get('OTR_FUSED_FFN_MIN_ROWS', '1024'))   # 
 _FFN_SPLIT = os.environ.get('OTR_FFN_SPLIT', '1') == '1'
 # the split kernels in slab mode (no in-launch exchange; the LayerNorm moves into the next launch's prologue) where the caller allows it
 _FFN_SLAB = os.environ.get('OTR_FFN_SLAB', '1') == '1'
+_FFN_PREFETCH = os.environ.get('OTR_FFN_PREFETCH', '1') == '1'
 _FFN_SPLIT_MIN_ROWS = 2048
 _FFN_SYNC_INTS = 1 << 14
 
@@ -1592,6 +1595,10 @@ class FfnLnFn(torch.autograd.Function):
         ctx.olink = olink
         if olink is not None and need_grad:        # see LnOutLink: the next layer's first Linear may run this LayerNorm's backward
             olink.saved, olink.params, olink.armed = (z, mean, rstd, gamma, seed, p_drop, off), (gamma, beta, b2), True
+            if ctx.split and _FFN_PREFETCH and packs[3].data_ptr() == packs[2].data_ptr() + packs[2].numel() * packs[2].element_size():
+                # that launch is followed by THIS sub-layer's backward launch, whose two packs (adjacent in the pack buffer) it
+                # would fetch cold: have them touched on the way (otr_rb_linear_ln_bwd_pf)
+                olink.prefetch = (packs[2], (packs[2].numel() + packs[3].numel()) * packs[2].element_size())
         y16 = y16.view(x.shape)
         ctx.mark_non_differentiable(y16)
         return y.view(x.shape), y16

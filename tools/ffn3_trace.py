@@ -35,9 +35,10 @@ def run():
     L.check(lib.otr_ffn_ln_fwd_split(p(x), p(x16), p(P[0]), p(b1), p(P[1]), p(b2), p(gamma), p(beta), p(seed), 0.0, 0, 1e-5, p(y), p(y16),
                                      p(z), p(mean), p(rstd), p(hsave) if save else None, p(usave) if save else None, p(scratch), nb, p(sync), sync.numel(), M, F, d, st()), 'fwd3')
 for _ in range(3): run()
-tr = torch.zeros(256 * 48, dtype=torch.int64, device=dev)
+tr = torch.zeros(256 * 48 + 512, dtype=torch.int64, device=dev)
 lib.otr_debug_set(4, 16); lib.otr_debug_trace(p(tr)); run(); torch.cuda.synchronize(); lib.otr_debug_trace(None); lib.otr_debug_set(4, 0)
-t = tr.cpu().numpy().reshape(256, 48)
+rt = tr.cpu().numpy()[256 * 48:].reshape(256, 2)
+t = tr.cpu().numpy()[:256 * 48].reshape(256, 48)
 live = t[:, 0] > 0
 t = t[live]
 n = int((t[0] > 0).sum())
@@ -47,3 +48,9 @@ print('workgroups', t.shape[0], 'stamps', n, 'total cycles median', np.median(t[
 for i in range(min(n - 1, len(names))):
     print('%-16s median %8.0f  p10 %8.0f  p90 %8.0f' % (names[i], np.median(dt[:, i]), np.percentile(dt[:, i], 10), np.percentile(dt[:, i], 90)))
 print('start spread (first stamp max-min):', t[:, 0].max() - t[:, 0].min())
+
+if slab:
+    r = rt[rt[:, 0] > 0].astype(np.float64)
+    s0, e0 = r[:, 0].min(), r[:, 1].max()
+    print('100 MHz clock: first workgroup starts at 0, the last one starts %.2f us later (median start %.2f us); ends: first %.2f us, median %.2f us, last %.2f us'
+          % ((r[:, 0].max() - s0) / 100, (np.median(r[:, 0]) - s0) / 100, (r[:, 1].min() - s0) / 100, (np.median(r[:, 1]) - s0) / 100, (e0 - s0) / 100))
