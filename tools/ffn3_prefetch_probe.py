@@ -53,3 +53,5 @@ print('bwd  12 sets (cold)            %.1f us' % measure(bwd, allsets, None))
 print('bwd  12 sets, weights touched  %.1f us' % measure(bwd, allsets, lambda i: touch(Ps[i][2:])))
 print('bwd  12 sets, dy rows touched  %.1f us' % measure(bwd, allsets, lambda i: touch([das[i]])))
 print('bwd  12 sets, weights + dy     %.1f us' % measure(bwd, allsets, lambda i: touch(Ps[i][2:] + [das[i]])))
+print('bwd  12 sets, weights + saved tiles touched  %.1f us' % measure(bwd, allsets, lambda i: touch(Ps[i][2:] + [hs[i]])))
+print('bwd  12 sets, saved tiles touched  %.1f us' % measure(bwd, allsets, lambda i: touch([hs[i]])))
