@@ -173,6 +173,9 @@ int32_t otr_rb_linear_ln_bwd(const void* g16, int64_t ldg, const void* wt_pack, 
  * (one dword per 64 bytes, no consumer) so that the NEXT launch finds those lines in the memory-side cache -- used for the two
  * input-gradient packs of the split FFN's backward launch that follows this one in the backward pass (3 MB it would otherwise
  * fetch from HBM in scattered 1 KiB pieces).  prefetch may be NULL (then exactly otr_rb_linear_ln_bwd). */
+/* Ranges the NEXT otr_ln_bwd_proj / otr_ln_bwd_proj_slabs call of the calling thread has its kernel touch the same way (then the hint
+ * is forgotten): the saved q|k|v and context the attention backward launch that follows it would otherwise fetch cold. */
+int32_t otr_touch_hint(const void* p0, int64_t bytes0, const void* p1, int64_t bytes1);
 int32_t otr_rb_linear_ln_bwd_pf(const void* g16, int64_t ldg, const void* wt_pack, const float* skip, int64_t lds, const float* z,
                                 const float* mean, const float* rstd, const float* gamma, const uint64_t* seed, float p_drop,
                                 uint64_t rng_offset, float* dx, void* da16, float* partial, int64_t M, int32_t N, int32_t K,

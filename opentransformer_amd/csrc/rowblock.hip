@@ -83,6 +83,31 @@ template <int RS> __device__ __forceinline__ void rb_put_tile(float* red, const 
     *reinterpret_cast<float4*>(red + m * RS + col0 + 8 * q + 4 * hi) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
 }
 
+// ------------------------------------------------------------------------------------------------ a touch for the launch that follows
+// Inside the step every launch finds its operands in HBM only.  Where that hurts the NEXT launch (scattered or latency-critical first
+// reads: the FFN backward launch's packs, the attention backward launch's saved q|k|v and context) the launch before it touches
+// those ranges -- one dword per 64 bytes, issued behind its main loop, never consumed -- so the lines sit in the memory-side cache
+// in time.  The destination registers stay OWNED until the closing wait: hipcc does not know the asm is a load (a register it
+// believed dead was reused and the returning load overwrote a live value: 1 % wrong dx in the first build).
+struct RbTouch { const unsigned char* p[2]; int64_t lines[2]; };
+constexpr int RB_TOUCH_PER = 6;                                      // loads per thread at most (grid x threads x 6 x 64 B >= 16 MB + 3 MB here)
+__device__ __forceinline__ void rb_touch_issue(const RbTouch& t, uint32_t (&sink)[RB_TOUCH_PER], int tid, int nthr) {
+  if (!t.p[0]) return;
+  const int64_t total = t.lines[0] + t.lines[1];
+  const int64_t per = min((total + gridDim.x - 1) / gridDim.x, (int64_t)RB_TOUCH_PER * nthr), l0 = (int64_t)blockIdx.x * per;
+#pragma unroll
+  for (int k = 0; k < RB_TOUCH_PER; ++k) {
+    const int64_t l = l0 + tid + (int64_t)k * nthr;
+    if (l < l0 + per && l < total) {
+      const unsigned char* a = l < t.lines[0] ? t.p[0] + l * 64 : t.p[1] + (l - t.lines[0]) * 64;
+      asm volatile("global_load_dword %0, %1, off" : "+v"(sink[k]) : "v"(a) : "memory");
+    }
+  }
+}
+__device__ __forceinline__ void rb_touch_wait(uint32_t (&sink)[RB_TOUCH_PER]) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink[0]), "+v"(sink[1]), "+v"(sink[2]), "+v"(sink[3]), "+v"(sink[4]), "+v"(sink[5])::"memory");
+}
+
 // ------------------------------------------------------------------------------------------------ plain projection
 struct RbLinArgs {
   const uint16_t* x16;     // [M, K] 16-bit rows, row stride ldx
@@ -322,6 +347,7 @@ struct LnBwdProjArgs {
   int M;
   float p_drop;
   uint64_t rng_offset;
+  RbTouch touch;           // see RbTouch: the attention backward launch's saved q|k|v and context (otr_touch_hint)
 };
 
 template <int NW>     // 4 or 8 waves (proj_ln_fwd_kernel)
@@ -442,6 +468,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ln_bwd_proj_kernel(LnBwdProjA
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   ws.run(acc, xs, lane);
+  uint32_t sink[RB_TOUCH_PER] = {0u, 0u, 0u, 0u, 0u, 0u};
+  rb_touch_issue(p.touch, sink, tid, 64 * NW);                       // nothing below loads anything
 #pragma unroll
   for (int i = 0; i < TPW; ++i) rb_put_tile<RS>(red, acc[i], (wid * TPW + i) * 32, lane);
   __syncthreads();
@@ -453,6 +481,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ln_bwd_proj_kernel(LnBwdProjA
     const float4 v = *reinterpret_cast<const float4*>(red + r * RS + col);
     *reinterpret_cast<uint2*>(p.dc16 + row * p.ldc + col) = make_uint2(pack2h(v.x, v.y), pack2h(v.z, v.w));
   }
+  rb_touch_wait(sink);
 }
 
 // ------------------------------------------------------------------------------------------------ input gradient of a projection + the LayerNorm backward it feeds
@@ -472,10 +501,9 @@ struct RbLinLnBwdArgs {
   float p_drop;
   uint64_t rng_offset;
   // What the NEXT launch streams first and would otherwise find nowhere but in HBM (the split FFN's backward launch: its two
-  // input-gradient packs, 3 MB, the second read in 1 KiB pieces 128 KiB apart): every workgroup touches its share -- one dword per
-  // 64 bytes, no consumer -- while its epilogue runs, so the lines sit in the memory-side cache when that launch asks for them
-  // (tools/ffn3_prefetch_probe.py: 50.8 -> 47.0 us for the backward launch on cold operands).
-  const unsigned char* pf; int64_t pf_lines;
+  // input-gradient packs, 3 MB, the second read in 8 KiB runs 256 KiB apart): see RbTouch (tools/ffn3_prefetch_probe.py: 50.8 -> 47.0
+  // us for the backward launch on cold operands).
+  RbTouch touch;
 };
 
 template <int K, int NW>
@@ -514,17 +542,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rb_linear_ln_bwd_kernel(RbLin
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   ws.run(acc, xs, lane);
-  // see RbLinLnBwdArgs::pf.  The destination registers stay OWNED until the closing wait (hipcc does not know the asm is a load: a
-  // register it believed dead after the statement was reused, and the returning load overwrote a live value -- 1 % wrong dx).
-  uint32_t sink[4] = {0u, 0u, 0u, 0u};
-  if (p.pf) {
-    const int64_t per = min((p.pf_lines + gridDim.x - 1) / gridDim.x, (int64_t)(4 * 64 * NW)), l0 = (int64_t)blockIdx.x * per;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int64_t l = l0 + tid + k * 64 * NW;
-      if (l < l0 + per && l < p.pf_lines) asm volatile("global_load_dword %0, %1, off" : "+v"(sink[k]) : "v"(p.pf + l * 64) : "memory");
-    }
-  }
+  uint32_t sink[RB_TOUCH_PER] = {0u, 0u, 0u, 0u, 0u, 0u};
+  rb_touch_issue(p.touch, sink, tid, 64 * NW);                       // nothing below loads anything
 #pragma unroll
   for (int i = 0; i < TPW; ++i) rb_put_tile<RS>(red, acc[i], (wid * TPW + i) * 32, lane);
   __syncthreads();
@@ -587,7 +606,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rb_linear_ln_bwd_kernel(RbLin
     for (int w = 0; w < NW; ++w) t_ += part[(k * NW + w) * D + cc];
     prow[c] = t_;
   }
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink[0]), "+v"(sink[1]), "+v"(sink[2]), "+v"(sink[3])::"memory");   // the touches have come back
+  rb_touch_wait(sink);
 }
 
 }  // namespace
@@ -657,6 +676,18 @@ extern "C" int32_t otr_proj_ln_fwd(const float* x, const void* c16, int64_t ldc,
 
 extern "C" int64_t otr_ln_bwd_proj_partial_rows(int64_t M) { return (M + RB - 1) / RB; }
 
+// otr_touch_hint: ranges the NEXT otr_ln_bwd_proj / otr_ln_bwd_proj_slabs call of this thread passes to its kernel (RbTouch), then forgotten
+static thread_local RbTouch g_touch_hint{};
+extern "C" int32_t otr_touch_hint(const void* p0, int64_t bytes0, const void* p1, int64_t bytes1) {
+  OTR_REQUIRE(bytes0 >= 0 && bytes1 >= 0 && (p0 || bytes0 == 0) && (p1 || bytes1 == 0), "touch_hint: bad range");
+  g_touch_hint = RbTouch{};
+  int n = 0;
+  if (bytes0 >= 64) { g_touch_hint.p[n] = reinterpret_cast<const unsigned char*>(p0); g_touch_hint.lines[n] = bytes0 / 64; ++n; }
+  if (bytes1 >= 64) { g_touch_hint.p[n] = reinterpret_cast<const unsigned char*>(p1); g_touch_hint.lines[n] = bytes1 / 64; ++n; }
+  return 0;
+}
+static RbTouch take_touch_hint() { RbTouch t = g_touch_hint; g_touch_hint = RbTouch{}; return t; }
+
 extern "C" int32_t otr_ln_bwd_proj(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                                    const uint64_t* seed, const void* wt_pack, float* dx, void* da16, void* dc16, int64_t ldc,
                                    float* partial, int64_t M, int32_t d_model, float p_drop, uint64_t rng_offset, void* stream) {
@@ -669,6 +700,7 @@ extern "C" int32_t otr_ln_bwd_proj(const float* dy, const float* z, const float*
   p.dy = dy; p.z = z; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.seed = seed; p.pwt = reinterpret_cast<const uint4*>(wt_pack);
   p.dx = dx; p.da16 = reinterpret_cast<uint16_t*>(da16); p.dc16 = reinterpret_cast<uint16_t*>(dc16); p.partial = partial;
   p.ldc = ldc; p.M = (int)M; p.p_drop = p_drop; p.rng_offset = rng_offset;
+  p.touch = take_touch_hint();
   if (g_otr_rb_waves8) hipLaunchKernelGGL(ln_bwd_proj_kernel<8>, dim3((unsigned)((M + RB - 1) / RB)), dim3(512), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(ln_bwd_proj_kernel<4>, dim3((unsigned)((M + RB - 1) / RB)), dim3(256), 0, (hipStream_t)stream, p);
   return otr_check_launch("ln_bwd_proj");
@@ -689,6 +721,7 @@ extern "C" int32_t otr_ln_bwd_proj_slabs(const float* dskip, const void* slabs, 
   p.dy = dskip; p.z = z; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.seed = seed; p.pwt = reinterpret_cast<const uint4*>(wt_pack);
   p.dx = dx; p.da16 = reinterpret_cast<uint16_t*>(da16); p.dc16 = reinterpret_cast<uint16_t*>(dc16); p.partial = partial;
   p.ldc = ldc; p.M = (int)M; p.p_drop = p_drop; p.rng_offset = rng_offset;
+  p.touch = take_touch_hint();
   if (g_otr_rb_waves8) hipLaunchKernelGGL(ln_bwd_proj_kernel<8>, dim3((unsigned)((M + RB - 1) / RB)), dim3(512), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(ln_bwd_proj_kernel<4>, dim3((unsigned)((M + RB - 1) / RB)), dim3(256), 0, (hipStream_t)stream, p);
   return otr_check_launch("ln_bwd_proj_slabs");
@@ -722,7 +755,7 @@ extern "C" int32_t otr_rb_linear_ln_bwd_pf(const void* g16, int64_t ldg, const v
   p.g16 = reinterpret_cast<const uint16_t*>(g16); p.pw = reinterpret_cast<const uint4*>(wt_pack); p.skip = skip; p.z = z; p.mean = mean;
   p.rstd = rstd; p.gamma = gamma; p.seed = seed; p.dx = dx; p.da16 = reinterpret_cast<uint16_t*>(da16); p.partial = partial;
   p.ldg = ldg; p.lds = lds; p.M = (int)M; p.p_drop = p_drop; p.rng_offset = rng_offset;
-  p.pf = prefetch_bytes >= 64 ? reinterpret_cast<const unsigned char*>(prefetch) : nullptr; p.pf_lines = prefetch_bytes / 64;
+  if (prefetch_bytes >= 64) { p.touch.p[0] = reinterpret_cast<const unsigned char*>(prefetch); p.touch.lines[0] = prefetch_bytes / 64; }
   const dim3 grid((unsigned)((M + RB - 1) / RB));
   hipStream_t s = (hipStream_t)stream;
   if (g_otr_rb_waves8) {

@@ -146,7 +146,10 @@ class MultiHeadedSelfAttention(nn.Module):
         qkv = ops.linear(x, self.qvk_proj.weight, self.qvk_proj.bias, out_dtype=ops.act_dtype(), link=link)
         if self.share_qvk_proj:          # query = key = value = the one projection (module/attention.py:71-72); rare: packed by copy
             qkv = torch.cat((qkv, qkv, qkv), dim=-1)
-        return ops.SelfAttentionFn.apply(qkv, _key_mask(mask, B, T), self.nheads, causal)
+        ctx = ops.SelfAttentionFn.apply(qkv, _key_mask(mask, B, T), self.nheads, causal)
+        if qkv.is_contiguous() and ctx.requires_grad:
+            ctx._otr_touch = qkv          # what the attention's backward launch reads first (ops.ProjLnFn has the launch before it touch it)
+        return ctx
 
     def forward(self, x, mask, causal=False, defer_bias=False, link=None):
         """defer_bias: the caller feeds the result to _post_norm(..., a_bias=self.output_proj.bias); link: ops.ResidualLink

@@ -1240,12 +1240,13 @@ class ProjLnFn(torch.autograd.Function):
     affine gradients join the grouped launches at the end of the pass."""
 
     @staticmethod
-    def forward(ctx, x, c, w, b, gamma, beta, p_drop, eps, packs, link, ilink=None):
+    def forward(ctx, x, c, w, b, gamma, beta, p_drop, eps, packs, link, ilink=None, touch=None):
         _cuda(x, c, w, gamma, beta)
         ctx.set_materialize_grads(False)
         materialize(x)
         ctx.link = link
         ctx.ilink = ilink
+        ctx.touch = touch           # the attention launch's saved q|k|v: this Function's backward launch touches it for the one that follows
         if ilink is not None:
             ilink.armed = any(ctx.needs_input_grad)
         if link is not None:            # the branch's first Linear armed it under ITS conditions (fp32 x, no perm, no relu): keep them
@@ -1279,7 +1280,7 @@ class ProjLnFn(torch.autograd.Function):
         if ctx.ilink is not None:
             stash, ctx.ilink.result = ctx.ilink.result, None
         if dy is None and stash is None:
-            return (None,) * 11
+            return (None,) * 12
         z, mean, rstd, gamma, seed, c2 = ctx.saved_tensors
         w, b, g_ref, b_ref = ctx.refs
         M, d, p_drop, off, xshape, cshape, packs = ctx.cfg
@@ -1289,6 +1290,10 @@ class ProjLnFn(torch.autograd.Function):
         dc = torch.empty((M, d), dtype=half_dtype(), device=dev)
         nrow = L.load().otr_ln_bwd_proj_partial_rows(M)
         part = torch.empty((nrow, 3 * d), dtype=torch.float32, device=dev)
+        if ctx.touch is not None and _ATTN_PREFETCH:
+            # the attention backward launch runs next and would fetch its saved q|k|v and context (c2) cold: csrc/rowblock.hip RbTouch
+            t = ctx.touch
+            L.check(L.load().otr_touch_hint(_p(t), t.numel() * t.element_size(), _p(c2), c2.numel() * c2.element_size()), 'otr_touch_hint')
         if stash is not None:           # see LnInLink: the FFN's backward launch left (skip-path gradient, four slabs)
             dskip, bslabs = stash
             if dy is not None and not _is_zero_placeholder(dy):
@@ -1323,7 +1328,7 @@ class ProjLnFn(torch.autograd.Function):
             ctx.link.buf = dx           # the branch's first Linear adds its input gradient into this and returns the sum
             _park(ctx.link)
             dx_ret = None
-        return (dx_ret, dc.view(cshape), None if gw is not None else dw, dbias, dgamma, dbeta, None, None, None, None, None)
+        return (dx_ret, dc.view(cshape), None if gw is not None else dw, dbias, dgamma, dbeta, None, None, None, None, None, None)
 
 
 def proj_ln_packs(x, c, w, gamma):
@@ -1337,7 +1342,7 @@ def proj_ln_packs(x, c, w, gamma):
 
 def proj_add_layernorm(x, c, w, b, gamma, beta, p_drop, eps, packs, link=None):
     ilink = LnInLink() if (_FFN_SLAB and torch.is_grad_enabled()) else None
-    y, ylp = ProjLnFn.apply(x, c, w, b, gamma, beta, float(p_drop), float(eps), packs, link, ilink)
+    y, ylp = ProjLnFn.apply(x, c, w, b, gamma, beta, float(p_drop), float(eps), packs, link, ilink, getattr(c, '_otr_touch', None))
     if ilink is not None and ilink.armed:
         y._otr_inlink = ilink
     return attach_lp(y, ylp)
@@ -1441,6 +1446,9 @@ _FFN_SPLIT = os.environ.get('OTR_FFN_SPLIT', '1') == '1'
 # the split kernels in slab mode (no in-launch exchange; the LayerNorm moves into the next launch's prologue) where the caller allows it
 _FFN_SLAB = os.environ.get('OTR_FFN_SLAB', '1') == '1'
 _FFN_PREFETCH = os.environ.get('OTR_FFN_PREFETCH', '1') == '1'
+# the same for the attention backward launch's saved q|k|v + context, touched by the LayerNorm-backward launch before it (otr_touch_hint):
+# -3.6 us per launch in tools/encattn_prefetch_probe.py, nothing measurable in the step (4.478 vs 4.471 / 4.500 ms on one box): off
+_ATTN_PREFETCH = os.environ.get('OTR_ATTN_PREFETCH', '0') == '1'
 _FFN_SPLIT_MIN_ROWS = 2048
 _FFN_SYNC_INTS = 1 << 14
 
