@@ -175,6 +175,9 @@ int32_t otr_rb_linear_ln_bwd(const void* g16, int64_t ldg, const void* wt_pack, 
  * fetch from HBM in scattered 1 KiB pieces).  prefetch may be NULL (then exactly otr_rb_linear_ln_bwd). */
 /* Ranges the NEXT otr_ln_bwd_proj / otr_ln_bwd_proj_slabs call of the calling thread has its kernel touch the same way (then the hint
  * is forgotten): the saved q|k|v and context the attention backward launch that follows it would otherwise fetch cold. */
+/* Read [p, p + bytes) once and consume nothing: the lines are then in the memory-side cache for the launches that follow (the fused
+ * decoder's packed weights, touched once before the stack's forward pass). */
+int32_t otr_touch(const void* p, int64_t bytes, void* stream);
 int32_t otr_touch_hint(const void* p0, int64_t bytes0, const void* p1, int64_t bytes1);
 int32_t otr_rb_linear_ln_bwd_pf(const void* g16, int64_t ldg, const void* wt_pack, const float* skip, int64_t lds, const float* z,
                                 const float* mean, const float* rstd, const float* gamma, const uint64_t* seed, float p_drop,

@@ -108,6 +108,7 @@ SIGNATURES = {
     'otr_proj_ln_fwd': [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F32, _F32, C.c_uint64, _P],
     'otr_ln_bwd_proj_partial_rows': [_I64],
     'otr_rb_linear_ln_bwd': [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _F32, C.c_uint64, _P, _P, _P, _I64, _I32, _I32, _P],
+    'otr_touch': [_P, _I64, _P],
     'otr_touch_hint': [_P, _I64, _P, _I64],
     'otr_rb_linear_ln_bwd_pf': [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _F32, C.c_uint64, _P, _P, _P, _I64, _I32, _I32, _P, _I64, _P],
     'otr_ln_bwd_proj': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I32, _F32, C.c_uint64, _P],

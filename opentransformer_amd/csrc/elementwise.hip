@@ -381,6 +381,26 @@ extern "C" int32_t otr_scale(const float* x, float* y, int64_t n, const float* s
   return otr_check_launch("scale");
 }
 
+// ------------------------------------------------------------------------------------------------ touch
+// Read a range once, consume nothing: the lines are then in the memory-side cache (256 MB, shared by the XCDs, not flushed between
+// launches) for the launches that follow.  The fused decoder uses it for its packed weights: 64-120 workgroups per launch stream
+// 1/4 .. 1/8 of a layer's weights each and wait for every cold line (csrc/declayer.hip; profiles/r04_dec_trace.txt is 6 us per FFN
+// launch faster on warm weights than the same launches inside the step).  One dword per 64 bytes.
+__global__ __launch_bounds__(256) void touch_kernel(const unsigned char* p, int64_t lines) {
+  uint32_t acc = 0;
+  for (int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x; l < lines; l += (int64_t)gridDim.x * 256)
+    acc |= *reinterpret_cast<const volatile uint32_t*>(p + l * 64);
+  if (acc == 0x9e3779b9u && lines < 0) const_cast<unsigned char*>(p)[0] = 0;      // never true: keeps the loads
+}
+extern "C" int32_t otr_touch(const void* p, int64_t bytes, void* stream) {
+  OTR_REQUIRE(bytes >= 0 && (p || bytes == 0), "touch: bad range");
+  const int64_t lines = bytes / 64;
+  if (lines == 0) return 0;
+  const int64_t g = (lines + 255) / 256;
+  hipLaunchKernelGGL(touch_kernel, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)p, lines);
+  return otr_check_launch("touch");
+}
+
 // ------------------------------------------------------------------------------------------------ column sums
 // out[n] (+)= sum_m a[m, n].  block (64 x 4): x -> 4 consecutive columns per lane, y -> row lanes.
 constexpr int CS_RPB = 128;

@@ -1768,6 +1768,7 @@ _FUSED_GLU_FWD = os.environ.get('OTR_NO_FUSED_GLU_FWD', '0') != '1'
 # launches per layer and direction, cut along (utterance group, head) / (row block, hidden slice) instead of along operators
 # (csrc/declayer.hip).  A sub-layer leaves PARTIAL sums ("slabs") and the next launch finishes the LayerNorm in its prologue.
 _DEC_FUSED = os.environ.get('OTR_NO_FUSED_DECODER', '0') != '1'
+_DEC_TOUCH = os.environ.get('OTR_DEC_TOUCH', '1') == '1'
 _DEC_FFN_SLICES = int(os.environ.get('OTR_DEC_FFN_SLICES', '8'))
 DEC_LAYER_PARAMS = 18      # qvk w,b | out w,b | norm1 w,b | q w,b | out w,b | norm2 w,b | w_1 w,b | w_2 w,b | norm3 w,b
 
@@ -1838,6 +1839,23 @@ class DecoderStackFn(torch.autograd.Function):
         layers, packs_all = [], []
         y_in, y_in16, pending = xres, x16, None          # pending = (slabs, nslab, bias, gamma, beta) of the FFN sub-layer below
         F = params[12].shape[0] // 2
+        if _DEC_TOUCH and need:
+            # every packed weight of the stack (forward and input-gradient packs, ~40 MB) read once: the 36 launches of the forward and
+            # backward pass then find them in the memory-side cache instead of HBM (csrc/elementwise.hip: otr_touch)
+            rng = []
+            for l in range(n_layers):
+                pr = params[DEC_LAYER_PARAMS * l:DEC_LAYER_PARAMS * (l + 1)]
+                for t in (*lin_packs(pr[0]), *lin_packs(pr[2]), *lin_packs(pr[6]), *lin_packs(pr[8]), *ffn_packs(pr[12], pr[14])):
+                    rng.append((t.data_ptr(), t.numel() * t.element_size()))
+            rng.sort()
+            merged = [list(rng[0])]
+            for a, n in rng[1:]:
+                if a <= merged[-1][0] + merged[-1][1] + 4096:
+                    merged[-1][1] = max(merged[-1][1], a + n - merged[-1][0])
+                else:
+                    merged.append([a, n])
+            for a, n in merged:
+                L.check(lib.otr_touch(C.c_void_p(a), n, st), 'otr_touch')
         for l in range(n_layers):
             (wqkv, bqkv, wo, bo, g1, be1, wq, bq, wo2, bo2, g2, be2, w1, b1, w2, b2, g3, be3) = params[DEC_LAYER_PARAMS * l:DEC_LAYER_PARAMS * (l + 1)]
             pk = (lin_packs(wqkv), lin_packs(wo), lin_packs(wq), lin_packs(wo2), ffn_packs(w1, w2))
