@@ -90,7 +90,7 @@ template <int RS> __device__ __forceinline__ void rb_put_tile(float* red, const 
 // in time.  The destination registers stay OWNED until the closing wait: hipcc does not know the asm is a load (a register it
 // believed dead was reused and the returning load overwrote a live value: 1 % wrong dx in the first build).
 struct RbTouch { const unsigned char* p[2]; int64_t lines[2]; };
-constexpr int RB_TOUCH_PER = 6;                                      // loads per thread at most (grid x threads x 6 x 64 B >= 16 MB + 3 MB here)
+constexpr int RB_TOUCH_PER = 10;                                      // loads per thread at most (grid x threads x 6 x 64 B >= 16 MB + 3 MB here)
 __device__ __forceinline__ void rb_touch_issue(const RbTouch& t, uint32_t (&sink)[RB_TOUCH_PER], int tid, int nthr) {
   if (!t.p[0]) return;
   const int64_t total = t.lines[0] + t.lines[1];
@@ -105,7 +105,8 @@ __device__ __forceinline__ void rb_touch_issue(const RbTouch& t, uint32_t (&sink
   }
 }
 __device__ __forceinline__ void rb_touch_wait(uint32_t (&sink)[RB_TOUCH_PER]) {
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink[0]), "+v"(sink[1]), "+v"(sink[2]), "+v"(sink[3]), "+v"(sink[4]), "+v"(sink[5])::"memory");
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink[0]), "+v"(sink[1]), "+v"(sink[2]), "+v"(sink[3]), "+v"(sink[4]), "+v"(sink[5]), "+v"(sink[6]), "+v"(sink[7]),
+               "+v"(sink[8]), "+v"(sink[9])::"memory");
 }
 
 // ------------------------------------------------------------------------------------------------ plain projection
@@ -239,6 +240,7 @@ struct ProjLnArgs {
   int M;
   float eps, p_drop;
   uint64_t rng_offset;
+  RbTouch touch;           // see RbTouch: the packs of the FFN launch that follows (otr_touch_hint)
 };
 
 // NW = 4 or 8 waves: with 8 (two per SIMD) the CU has twice the loads in flight and ingests the 128 KB of packed weights at ~33
@@ -278,6 +280,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void proj_ln_fwd_kernel(ProjLnArgs
   const float4 gm = *reinterpret_cast<const float4*>(p.gamma + col);
   const float4 bt = *reinterpret_cast<const float4*>(p.beta + col);
   ws.run(acc, xs, lane);
+  uint32_t sink[RB_TOUCH_PER] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  rb_touch_issue(p.touch, sink, tid, 64 * NW);
 #pragma unroll
   for (int i = 0; i < TPW; ++i) rb_put_tile<RS>(red, acc[i], (wid * TPW + i) * 32, lane);
   __syncthreads();
@@ -329,6 +333,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void proj_ln_fwd_kernel(ProjLnArgs
     if (p.y16) *reinterpret_cast<uint2*>(p.y16 + row * D + col) = make_uint2(pack2h(o[0], o[1]), pack2h(o[2], o[3]));
     if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
   }
+  rb_touch_wait(sink);
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm backward + input gradient of the projection
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ln_bwd_proj_kernel(LnBwdProjA
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   ws.run(acc, xs, lane);
-  uint32_t sink[RB_TOUCH_PER] = {0u, 0u, 0u, 0u, 0u, 0u};
+  uint32_t sink[RB_TOUCH_PER] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
   rb_touch_issue(p.touch, sink, tid, 64 * NW);                       // nothing below loads anything
 #pragma unroll
   for (int i = 0; i < TPW; ++i) rb_put_tile<RS>(red, acc[i], (wid * TPW + i) * 32, lane);
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rb_linear_ln_bwd_kernel(RbLin
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   ws.run(acc, xs, lane);
-  uint32_t sink[RB_TOUCH_PER] = {0u, 0u, 0u, 0u, 0u, 0u};
+  uint32_t sink[RB_TOUCH_PER] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
   rb_touch_issue(p.touch, sink, tid, 64 * NW);                       // nothing below loads anything
 #pragma unroll
   for (int i = 0; i < TPW; ++i) rb_put_tile<RS>(red, acc[i], (wid * TPW + i) * 32, lane);
@@ -657,6 +662,18 @@ extern "C" int32_t otr_rb_linear_ln(const otr_dec_ln_t* ln, const void* w_pack, 
   return otr_check_launch("rb_linear_ln");
 }
 
+// otr_touch_hint: ranges the NEXT otr_proj_ln_fwd / otr_ln_bwd_proj / otr_ln_bwd_proj_slabs call of this thread passes to its kernel (RbTouch), then forgotten
+static thread_local RbTouch g_touch_hint{};
+extern "C" int32_t otr_touch_hint(const void* p0, int64_t bytes0, const void* p1, int64_t bytes1) {
+  OTR_REQUIRE(bytes0 >= 0 && bytes1 >= 0 && (p0 || bytes0 == 0) && (p1 || bytes1 == 0), "touch_hint: bad range");
+  g_touch_hint = RbTouch{};
+  int n = 0;
+  if (bytes0 >= 64) { g_touch_hint.p[n] = reinterpret_cast<const unsigned char*>(p0); g_touch_hint.lines[n] = bytes0 / 64; ++n; }
+  if (bytes1 >= 64) { g_touch_hint.p[n] = reinterpret_cast<const unsigned char*>(p1); g_touch_hint.lines[n] = bytes1 / 64; ++n; }
+  return 0;
+}
+static RbTouch take_touch_hint() { RbTouch t = g_touch_hint; g_touch_hint = RbTouch{}; return t; }
+
 extern "C" int32_t otr_proj_ln_fwd(const float* x, const void* c16, int64_t ldc, const void* w_pack, const float* bias, const float* gamma,
                                    const float* beta, const uint64_t* seed, float* y, void* y16, float* z, float* mean, float* rstd,
                                    int64_t M, int32_t d_model, float eps, float p_drop, uint64_t rng_offset, void* stream) {
@@ -669,6 +686,7 @@ extern "C" int32_t otr_proj_ln_fwd(const float* x, const void* c16, int64_t ldc,
   p.x = x; p.c16 = reinterpret_cast<const uint16_t*>(c16); p.pw = reinterpret_cast<const uint4*>(w_pack); p.bias = bias; p.gamma = gamma;
   p.beta = beta; p.seed = seed; p.y = y; p.y16 = reinterpret_cast<uint16_t*>(y16); p.z = z; p.mean = mean; p.rstd = rstd;
   p.ldc = ldc; p.M = (int)M; p.eps = eps; p.p_drop = p_drop; p.rng_offset = rng_offset;
+  p.touch = take_touch_hint();
   if (g_otr_rb_waves8) hipLaunchKernelGGL(proj_ln_fwd_kernel<8>, dim3((unsigned)((M + RB - 1) / RB)), dim3(512), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(proj_ln_fwd_kernel<4>, dim3((unsigned)((M + RB - 1) / RB)), dim3(256), 0, (hipStream_t)stream, p);
   return otr_check_launch("proj_ln_fwd");
@@ -676,17 +694,6 @@ extern "C" int32_t otr_proj_ln_fwd(const float* x, const void* c16, int64_t ldc,
 
 extern "C" int64_t otr_ln_bwd_proj_partial_rows(int64_t M) { return (M + RB - 1) / RB; }
 
-// otr_touch_hint: ranges the NEXT otr_ln_bwd_proj / otr_ln_bwd_proj_slabs call of this thread passes to its kernel (RbTouch), then forgotten
-static thread_local RbTouch g_touch_hint{};
-extern "C" int32_t otr_touch_hint(const void* p0, int64_t bytes0, const void* p1, int64_t bytes1) {
-  OTR_REQUIRE(bytes0 >= 0 && bytes1 >= 0 && (p0 || bytes0 == 0) && (p1 || bytes1 == 0), "touch_hint: bad range");
-  g_touch_hint = RbTouch{};
-  int n = 0;
-  if (bytes0 >= 64) { g_touch_hint.p[n] = reinterpret_cast<const unsigned char*>(p0); g_touch_hint.lines[n] = bytes0 / 64; ++n; }
-  if (bytes1 >= 64) { g_touch_hint.p[n] = reinterpret_cast<const unsigned char*>(p1); g_touch_hint.lines[n] = bytes1 / 64; ++n; }
-  return 0;
-}
-static RbTouch take_touch_hint() { RbTouch t = g_touch_hint; g_touch_hint = RbTouch{}; return t; }
 
 extern "C" int32_t otr_ln_bwd_proj(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                                    const uint64_t* seed, const void* wt_pack, float* dx, void* da16, void* dc16, int64_t ldc,
@@ -756,6 +763,13 @@ extern "C" int32_t otr_rb_linear_ln_bwd_pf(const void* g16, int64_t ldg, const v
   p.rstd = rstd; p.gamma = gamma; p.seed = seed; p.dx = dx; p.da16 = reinterpret_cast<uint16_t*>(da16); p.partial = partial;
   p.ldg = ldg; p.lds = lds; p.M = (int)M; p.p_drop = p_drop; p.rng_offset = rng_offset;
   if (prefetch_bytes >= 64) { p.touch.p[0] = reinterpret_cast<const unsigned char*>(prefetch); p.touch.lines[0] = prefetch_bytes / 64; }
+  {                                        // a pending otr_touch_hint rides along as the second range
+    const RbTouch h = take_touch_hint();
+    if (h.p[0]) {
+      const int k = p.touch.p[0] ? 1 : 0;
+      p.touch.p[k] = h.p[0]; p.touch.lines[k] = h.lines[0];
+    }
+  }
   const dim3 grid((unsigned)((M + RB - 1) / RB));
   hipStream_t s = (hipStream_t)stream;
   if (g_otr_rb_waves8) {

@@ -292,6 +292,7 @@ def _attn_sublayer(layer, concat_linear, norm, attn, x, p, run, run_ctx):
         c = run_ctx(link)
         packs = ops.proj_ln_packs(x, c, attn.output_proj.weight, norm.weight)
         if packs is not None:
+            ops.touch_ffn_packs_next(getattr(layer, 'feed_forward', None), x)
             return ops.proj_add_layernorm(x, c, attn.output_proj.weight, attn.output_proj.bias, norm.weight, norm.bias, p, norm.eps,
                                           packs, link)
         branch = ops.linear(c, attn.output_proj.weight, attn.output_proj.bias, defer_bias=True, out_dtype=ops.act_dtype())

@@ -752,7 +752,9 @@ def rb_linear_pending_raw(pend, pack, N, bias, out_dtype):
 def rb_linear_ln_bwd_raw(g2, wt_pack, skip, saved, prefetch=None):
     """(d z f32, d a 16-bit, partial [blocks, 3*256]) of the LayerNorm y = LN(z) whose output gradient is skip + g2 . W"""
     z, mean, rstd, gamma, seed, p_drop, off = saved
-    pf_t, pf_n = prefetch if prefetch is not None else (None, 0)
+    pf_t, pf_n, pf_h = prefetch if prefetch is not None else (None, 0, None)
+    if pf_h is not None:
+        L.check(L.load().otr_touch_hint(_p(pf_h), pf_h.numel() * pf_h.element_size(), None, 0), 'otr_touch_hint')
     M, K = g2.shape
     d = 256
     lib = L.load()
@@ -1340,6 +1342,20 @@ def proj_ln_packs(x, c, w, gamma):
     return lin_packs(w)
 
 
+_FFN_FWD_TOUCH = os.environ.get('OTR_FFN_FWD_TOUCH', '1') == '1'
+
+
+def touch_ffn_packs_next(ff, x):
+    """the next otr_proj_ln_fwd launch (the attention sub-layer's closing launch) touches the two forward packs of the split FFN that
+    follows it (3 MB the FFN launch's 252 workgroups would all wait for, cold, at their first phases): 4.43 -> 4.37 ms per step"""
+    if not _FFN_FWD_TOUCH or ff is None or getattr(ff, 'activation', None) != 'glu' or x.numel() // 256 < _FFN_SPLIT_MIN_ROWS:
+        return
+    packs = ffn_packs(ff.w_1.weight, ff.w_2.weight)
+    if packs is None or packs[1].data_ptr() != packs[0].data_ptr() + packs[0].numel() * packs[0].element_size():
+        return
+    L.check(L.load().otr_touch_hint(_p(packs[0]), (packs[0].numel() + packs[1].numel()) * packs[0].element_size(), None, 0), 'otr_touch_hint')
+
+
 def proj_add_layernorm(x, c, w, b, gamma, beta, p_drop, eps, packs, link=None):
     ilink = LnInLink() if (_FFN_SLAB and torch.is_grad_enabled()) else None
     y, ylp = ProjLnFn.apply(x, c, w, b, gamma, beta, float(p_drop), float(eps), packs, link, ilink, getattr(c, '_otr_touch', None))
@@ -1446,6 +1462,7 @@ _FFN_SPLIT = os.environ.get('OTR_FFN_SPLIT', '1') == '1'
 # the split kernels in slab mode (no in-launch exchange; the LayerNorm moves into the next launch's prologue) where the caller allows it
 _FFN_SLAB = os.environ.get('OTR_FFN_SLAB', '1') == '1'
 _FFN_PREFETCH = os.environ.get('OTR_FFN_PREFETCH', '1') == '1'
+_FFN_HSAVE_TOUCH = os.environ.get('OTR_FFN_HSAVE_TOUCH', '0') == '1'      # experiment: the saved tiles (65 MB) as well
 # the same for the attention backward launch's saved q|k|v + context, touched by the LayerNorm-backward launch before it (otr_touch_hint):
 # -3.6 us per launch in tools/encattn_prefetch_probe.py, nothing measurable in the step (4.478 vs 4.471 / 4.500 ms on one box): off
 _ATTN_PREFETCH = os.environ.get('OTR_ATTN_PREFETCH', '0') == '1'
@@ -1606,7 +1623,8 @@ class FfnLnFn(torch.autograd.Function):
             if ctx.split and _FFN_PREFETCH and packs[3].data_ptr() == packs[2].data_ptr() + packs[2].numel() * packs[2].element_size():
                 # that launch is followed by THIS sub-layer's backward launch, whose two packs (adjacent in the pack buffer) it
                 # would fetch cold: have them touched on the way (otr_rb_linear_ln_bwd_pf)
-                olink.prefetch = (packs[2], (packs[2].numel() + packs[3].numel()) * packs[2].element_size())
+                olink.prefetch = (packs[2], (packs[2].numel() + packs[3].numel()) * packs[2].element_size(),
+                                  hsave if (_FFN_HSAVE_TOUCH and hsave is not None) else None)
         y16 = y16.view(x.shape)
         ctx.mark_non_differentiable(y16)
         return y.view(x.shape), y16
