@@ -149,6 +149,8 @@ class MultiHeadedSelfAttention(nn.Module):
         ctx = ops.SelfAttentionFn.apply(qkv, _key_mask(mask, B, T), self.nheads, causal)
         if qkv.is_contiguous() and ctx.requires_grad:
             ctx._otr_touch = qkv          # what the attention's backward launch reads first (ops.ProjLnFn has the launch before it touch it)
+            wp = ops.lin_packs(self.qvk_proj.weight) if not self.share_qvk_proj else None
+            ctx._otr_touch_w = wp[1] if wp is not None else None      # the input-gradient pack the launch after that one streams
         return ctx
 
     def forward(self, x, mask, causal=False, defer_bias=False, link=None):

@@ -1242,13 +1242,14 @@ class ProjLnFn(torch.autograd.Function):
     affine gradients join the grouped launches at the end of the pass."""
 
     @staticmethod
-    def forward(ctx, x, c, w, b, gamma, beta, p_drop, eps, packs, link, ilink=None, touch=None):
+    def forward(ctx, x, c, w, b, gamma, beta, p_drop, eps, packs, link, ilink=None, touch=None, touch_w=None):
         _cuda(x, c, w, gamma, beta)
         ctx.set_materialize_grads(False)
         materialize(x)
         ctx.link = link
         ctx.ilink = ilink
         ctx.touch = touch           # the attention launch's saved q|k|v: this Function's backward launch touches it for the one that follows
+        ctx.touch_w = touch_w       # the q|k|v projection's input-gradient pack (read two launches later)
         if ilink is not None:
             ilink.armed = any(ctx.needs_input_grad)
         if link is not None:            # the branch's first Linear armed it under ITS conditions (fp32 x, no perm, no relu): keep them
@@ -1282,7 +1283,7 @@ class ProjLnFn(torch.autograd.Function):
         if ctx.ilink is not None:
             stash, ctx.ilink.result = ctx.ilink.result, None
         if dy is None and stash is None:
-            return (None,) * 12
+            return (None,) * 13
         z, mean, rstd, gamma, seed, c2 = ctx.saved_tensors
         w, b, g_ref, b_ref = ctx.refs
         M, d, p_drop, off, xshape, cshape, packs = ctx.cfg
@@ -1292,6 +1293,9 @@ class ProjLnFn(torch.autograd.Function):
         dc = torch.empty((M, d), dtype=half_dtype(), device=dev)
         nrow = L.load().otr_ln_bwd_proj_partial_rows(M)
         part = torch.empty((nrow, 3 * d), dtype=torch.float32, device=dev)
+        if ctx.touch_w is not None and _QKV_W_TOUCH and not (ctx.touch is not None and _ATTN_PREFETCH):
+            tw = ctx.touch_w
+            L.check(L.load().otr_touch_hint(_p(tw), tw.numel() * tw.element_size(), None, 0), 'otr_touch_hint')
         if ctx.touch is not None and _ATTN_PREFETCH:
             # the attention backward launch runs next and would fetch its saved q|k|v and context (c2) cold: csrc/rowblock.hip RbTouch
             t = ctx.touch
@@ -1330,7 +1334,7 @@ class ProjLnFn(torch.autograd.Function):
             ctx.link.buf = dx           # the branch's first Linear adds its input gradient into this and returns the sum
             _park(ctx.link)
             dx_ret = None
-        return (dx_ret, dc.view(cshape), None if gw is not None else dw, dbias, dgamma, dbeta, None, None, None, None, None, None)
+        return (dx_ret, dc.view(cshape), None if gw is not None else dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None)
 
 
 def proj_ln_packs(x, c, w, gamma):
@@ -1358,7 +1362,8 @@ def touch_ffn_packs_next(ff, x):
 
 def proj_add_layernorm(x, c, w, b, gamma, beta, p_drop, eps, packs, link=None):
     ilink = LnInLink() if (_FFN_SLAB and torch.is_grad_enabled()) else None
-    y, ylp = ProjLnFn.apply(x, c, w, b, gamma, beta, float(p_drop), float(eps), packs, link, ilink, getattr(c, '_otr_touch', None))
+    y, ylp = ProjLnFn.apply(x, c, w, b, gamma, beta, float(p_drop), float(eps), packs, link, ilink, getattr(c, '_otr_touch', None),
+                            getattr(c, '_otr_touch_w', None))
     if ilink is not None and ilink.armed:
         y._otr_inlink = ilink
     return attach_lp(y, ylp)
@@ -1462,6 +1467,7 @@ _FFN_SPLIT = os.environ.get('OTR_FFN_SPLIT', '1') == '1'
 # the split kernels in slab mode (no in-launch exchange; the LayerNorm moves into the next launch's prologue) where the caller allows it
 _FFN_SLAB = os.environ.get('OTR_FFN_SLAB', '1') == '1'
 _FFN_PREFETCH = os.environ.get('OTR_FFN_PREFETCH', '1') == '1'
+_QKV_W_TOUCH = os.environ.get('OTR_QKV_W_TOUCH', '0') == '1'              # experiment: ln_bwd_proj touches the q|k|v input-gradient pack
 _FFN_HSAVE_TOUCH = os.environ.get('OTR_FFN_HSAVE_TOUCH', '0') == '1'      # experiment: the saved tiles (65 MB) as well
 # the same for the attention backward launch's saved q|k|v + context, touched by the LayerNorm-backward launch before it (otr_touch_hint):
 # -3.6 us per launch in tools/encattn_prefetch_probe.py, nothing measurable in the step (4.478 vs 4.471 / 4.500 ms on one box): off
