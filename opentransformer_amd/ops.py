@@ -358,10 +358,10 @@ class LnInLink:
     the FFN's backward launch leaves the four hidden slices' shares of d y1 as 16-bit slabs instead of summing them, so FfnLnFn.backward
     leaves (skip-path gradient f32, slabs) in `result` and returns the zero placeholder; ProjLnFn.backward sums them while it loads
     its rows (otr_ln_bwd_proj_slabs).  A gradient from any other consumer of y1 arrives as a real tensor and is added on top."""
-    __slots__ = ('armed', 'result')
+    __slots__ = ('armed', 'result', 'z')
 
     def __init__(self):
-        self.armed, self.result = False, None
+        self.armed, self.result, self.z = False, None, None
 
 
 class PendingLn:
@@ -1271,6 +1271,8 @@ class ProjLnFn(torch.autograd.Function):
                                                         _p(y), _p(ylp), _p(z), _p(mean), _p(rstd), M, d, eps, p_drop, off, _stream())),
                 'otr_proj_ln_fwd')
         ctx.save_for_backward(z, mean, rstd, gamma, seed, c2)
+        if ilink is not None:
+            ilink.z = z
         ctx.refs = (w, b, gamma, beta)
         ctx.cfg = (M, d, p_drop, off, x.shape, c.shape, packs)
         ylp = ylp.view(x.shape)
@@ -1467,6 +1469,7 @@ _FFN_SPLIT = os.environ.get('OTR_FFN_SPLIT', '1') == '1'
 # the split kernels in slab mode (no in-launch exchange; the LayerNorm moves into the next launch's prologue) where the caller allows it
 _FFN_SLAB = os.environ.get('OTR_FFN_SLAB', '1') == '1'
 _FFN_PREFETCH = os.environ.get('OTR_FFN_PREFETCH', '1') == '1'
+_Z_TOUCH = os.environ.get('OTR_Z_TOUCH', '0') == '1'
 _QKV_W_TOUCH = os.environ.get('OTR_QKV_W_TOUCH', '0') == '1'              # experiment: ln_bwd_proj touches the q|k|v input-gradient pack
 _FFN_HSAVE_TOUCH = os.environ.get('OTR_FFN_HSAVE_TOUCH', '0') == '1'      # experiment: the saved tiles (65 MB) as well
 # the same for the attention backward launch's saved q|k|v + context, touched by the LayerNorm-backward launch before it (otr_touch_hint):
@@ -1629,8 +1632,10 @@ class FfnLnFn(torch.autograd.Function):
             if ctx.split and _FFN_PREFETCH and packs[3].data_ptr() == packs[2].data_ptr() + packs[2].numel() * packs[2].element_size():
                 # that launch is followed by THIS sub-layer's backward launch, whose two packs (adjacent in the pack buffer) it
                 # would fetch cold: have them touched on the way (otr_rb_linear_ln_bwd_pf)
-                olink.prefetch = (packs[2], (packs[2].numel() + packs[3].numel()) * packs[2].element_size(),
-                                  hsave if (_FFN_HSAVE_TOUCH and hsave is not None) else None)
+                extra = hsave if (_FFN_HSAVE_TOUCH and hsave is not None) else None
+                if extra is None and _Z_TOUCH and ilink is not None:
+                    extra = ilink.z          # experiment: the saved pre-norm sums of the attention sub-layer's LayerNorm (read two launches later)
+                olink.prefetch = (packs[2], (packs[2].numel() + packs[3].numel()) * packs[2].element_size(), extra)
         y16 = y16.view(x.shape)
         ctx.mark_non_differentiable(y16)
         return y.view(x.shape), y16
