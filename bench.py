@@ -348,7 +348,14 @@ def main():
         dp.broadcast_parameters()
         opt = FusedAdam(dp, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6, clip_grad=5.0,
                         noam=dict(model_size=cfg['encoder']['d_model'], warmup_steps=12000, factor=1.0))   # *_baseline.yaml train section
-        loss_buf = torch.zeros((), device=dev)
+        class _LossRef:
+            """the loss of the last step: the tensor the step itself wrote (under a hipGraph that is static memory of the graph's
+            pool, rewritten by every replay), so reading it out costs no copy launch inside the step"""
+            t = torch.zeros((), device=dev)
+
+            def item(self):
+                return self.t.item()
+        loss_buf = _LossRef()
 
         stages = []
         # N = 1: nothing sits between the backward pass and the optimizer, so the WHOLE step is one hipGraph (--opt-in-graph off: the
@@ -359,8 +366,8 @@ def main():
             dp.zero_grad()
             ops.next_dropout_step(dev)
             loss, _ = dp(inputs, targets)
-            loss.backward()                       # staged: stops at the encoder / decoder cut (ops.early_mark); else the whole pass
-            loss_buf.copy_(loss.detach())
+            ops.backward(loss)                    # staged: stops at the encoder / decoder cut (ops.early_mark); else the whole pass
+            loss_buf.t = loss.detach()
             stages[:] = ops.take_stages()
 
         def stage2():

@@ -139,6 +139,20 @@ class FlatDataParallel:
                         grouped.add(id(q))
                     table.append([o0, rows, cols, tiles])
                     tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
+                # weights a kernel reads with two axes swapped (nn.ConvFrontEnd.regrouped_weights): [A, R, S] -> [A, S, R] is A
+                # small transposes, done in the same launch instead of a copy per forward pass
+                off_of = {id(p): o for p, o in zip(params, offs)}
+                for mod in module.modules():
+                    regroup = getattr(mod, 'regrouped_weights', None)
+                    for p, (A, R, S) in (regroup() if callable(regroup) else []):
+                        if id(p) not in off_of or id(p) in grouped or p.numel() != A * R * S or not p.is_contiguous():
+                            continue
+                        o0 = off_of[id(p)]
+                        p._otr_regroup_view = self.flat_param_lpt[o0:o0 + A * R * S].view(A, S, R)
+                        for a in range(A):
+                            table.append([o0 + a * R * S, R, S, tiles])
+                            tiles += ((R + 63) // 64) * ((S + 63) // 64)
+                        grouped.add(id(p))
                 for p, off in zip(params, offs):
                     n = p.numel()
                     if id(p) in grouped:
@@ -349,7 +363,7 @@ class FlatDataParallel:
     def backward_staged(self, loss, between=None):
         """loss.backward() cut at the marks of ops.set_stage_split(True); `between` (default: start_early_reduce) runs after stage 1"""
         from . import ops
-        loss.backward()
+        ops.backward(loss)
         stages = ops.take_stages()
         (between or self.start_early_reduce)()
         for x, leaf in reversed(stages):

@@ -67,8 +67,9 @@ class SpeechToText(nn.Module):
         enc_inputs, enc_mask = self.frontend(enc_inputs, enc_mask)
         memory, memory_mask, _ = self.encoder(enc_inputs, enc_mask)
         memory = ops.early_mark(memory)       # everything behind this point finishes its backward before the encoder's starts (dp.py)
-        logits, _ = self.decoder(truth[:, :-1].contiguous(), memory, memory_mask)
-        target_out = truth[:, 1:].contiguous()
+        shifted = torch.stack((truth[:, :-1], truth[:, 1:]))     # decoder input | loss target (speech2text.py:53,57 clones each) in one launch
+        logits, _ = self.decoder(shifted[0], memory, memory_mask)
+        target_out = shifted[1]
         loss = self.crit(logits, target_out)
         if self.ctc_weight > 0:
             loss_ctc = self.compute_ctc_loss(memory, memory_mask, target_out, truth_length)

@@ -73,6 +73,15 @@ class ConvFrontEnd(nn.Module):
         if front_end_layer_norm:
             self.layer_norm = nn.LayerNorm(output_size)           # frontend/conv.py:128-129,150-151
 
+    def regrouped_weights(self):
+        """[(parameter, (A, R, S))]: the kernels read these weights as [A, S, R] (channel-last) where the reference stores
+        [A, R, S]: conv2's taps [C2, C1, 3*3] -> [C2, 3*3, C1], and the output Linear's columns from c*F2+f (the reference's
+        channel-first flatten, frontend/conv.py:145) to f*C2+c.  dp.FlatDataParallel keeps such 16-bit shadows fresh in its
+        one transpose launch per optimizer step; without it ops regroups on every forward."""
+        c2 = self.conv2.conv_layer
+        C2, C1, F2 = c2.out_channels, c2.in_channels, self.conv2.output_size
+        return [(c2.weight, (C2, C1, 9)), (self.output_layer.weight, (self.output_layer.out_features, C2, F2))]
+
     def forward(self, x, mask):
         c1, c2 = self.conv1.conv_layer, self.conv2.conv_layer
         C2, F2 = c2.out_channels, self.conv2.output_size
@@ -383,7 +392,8 @@ class TransformerEncoder(nn.Module):
             x, pos = inputs.float(), relative_sinusoid(inputs.size(1), inputs.size(2), inputs.device)
         else:
             (x, _), pos = self.pos_emb(inputs), None
-        km = mask.to(torch.uint8).unsqueeze(1)              # cast once; every layer's key mask is this uint8 view
+        # cast once; every layer's key mask is this uint8 view (and the decoder's memory mask: ops._mask_u8 remembers it on the tensor)
+        km = (ops._mask_u8(mask, mask.size(0), mask.size(1)) if mask.dim() == 2 else mask.to(torch.uint8)).unsqueeze(1)
         defer = not self.normalize_before and not self.relative_positional
         for block in self.blocks:
             block._defer_ln = defer

@@ -204,6 +204,19 @@ def scale_loss_grad(loss, owner=None):
     return ScaleGradFn.apply(loss, s)
 
 
+def backward(loss):
+    """loss.backward() for a scalar loss, seeded with a cached device-side 1.0 instead of the ones_like(loss) the autograd engine
+    would fill on every call (one launch per step; the cached scalar is allocated by the first eager call, so a capture only
+    ever reads it)."""
+    seed = None
+    if loss.dim() == 0 and loss.is_cuda:
+        key = ('unit_grad', loss.device, loss.dtype)
+        seed = _state.get(key)
+        if seed is None and not torch.cuda.is_current_stream_capturing():
+            seed = _state[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    torch.autograd.backward(loss, grad_tensors=seed)
+
+
 # ---------------------------------------------------------------------------------------- bf16 shadows
 # In bf16 mode every GEMM operand is read as bf16 from memory:
 #  * activations of the fp32 residual stream carry a bf16 twin produced by the kernel that wrote them
@@ -274,6 +287,15 @@ def _workspace(device):
         _zero_placeholder(device, ())   # likewise allocated outside any capture's private pool (LnOutLink)
         _ffn_sync_pool(device)          # and the split FFN kernels' arrival counters (one row per launch stream)
     return ws
+
+
+def regrouped_lp(w, shape):
+    """the 16-bit shadow of w with its two inner axes swapped ([A, R, S] kept as [A, S, R] = `shape`), where FlatDataParallel
+    registered one (it refreshes it after every optimizer step, dp.refresh_transposed); None otherwise"""
+    v = getattr(w, '_otr_regroup_view', None) if is_half() else None
+    if v is None or tuple(v.shape) != tuple(shape) or v.dtype != half_dtype():
+        return None
+    return v
 
 
 def weight_lpt(w):
@@ -787,7 +809,8 @@ class LinearFn(torch.autograd.Function):
         wc = wl if wl is not None else w
         if perm is not None:
             C_, F_ = perm
-            wc = wc.view(-1, C_, F_).permute(0, 2, 1).reshape(w.shape[0], F_ * C_).contiguous()
+            rg = regrouped_lp(w, (w.shape[0], F_, C_))
+            wc = rg.view(w.shape[0], F_ * C_) if rg is not None else wc.view(-1, C_, F_).permute(0, 2, 1).reshape(w.shape[0], F_ * C_).contiguous()
         packs = lin_packs(w) if (perm is None and not relu and _rb_rows_ok(x2) and x2.shape[0] >= _RB_LINEAR_MIN_ROWS
                                  and (b is None or b.data_ptr() % 16 == 0)) else None
         ctx.rb = packs
@@ -848,7 +871,13 @@ class LinearFn(torch.autograd.Function):
                 dw = linear_wgrad_raw(dy2, x2, wc)
                 if ctx.perm is not None:
                     C_, F_ = ctx.perm
-                    dw = dw.view(-1, F_, C_).permute(0, 2, 1).reshape(dw.shape[0], C_ * F_)
+                    dw = dw.view(-1, F_, C_).permute(0, 2, 1)
+                    gt = grad_target(ctx.w_ref)
+                    if gt is not None:       # regrouped back while it is added to the gradient buffer: one launch, not copy + add
+                        gt.view(-1, C_, F_).add_(dw)
+                        dw = None
+                    else:
+                        dw = dw.reshape(dw.shape[0], C_ * F_)
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2] and not ctx.defer_bias:
             gt = grad_target(ctx.b_ref)
@@ -921,11 +950,19 @@ def _attn_desc(B, H, Tq, Tk, dk, dt, qs, ks, vs, os_, causal):
 
 
 def _mask_u8(mask, B, Tk):
-    """[B,Tk] bool key mask -> uint8 (None if there is no mask)."""
+    """[B,Tk] bool key mask -> uint8 (None if there is no mask).  The cast is remembered ON the mask tensor (with its version
+    counter): the encoder's key mask and the decoder's memory mask are one tensor (model/speech2text.py:50-54), a strided
+    view of the batch's frame mask, and each cast of it is a launch."""
     if mask is None:
         return None
-    m = mask.reshape(B, Tk)
-    return m.to(torch.uint8).contiguous()
+    if mask.dtype == torch.uint8 and mask.dim() == 2 and mask.is_contiguous() and tuple(mask.shape) == (B, Tk):
+        return mask
+    hit = getattr(mask, '_otr_u8', None)
+    if hit is not None and hit[0] == mask._version and tuple(hit[1].shape) == (B, Tk):
+        return hit[1]
+    u8 = mask.reshape(B, Tk).to(torch.uint8).contiguous()
+    mask._otr_u8 = (mask._version, u8)
+    return u8
 
 
 class SelfAttentionFn(torch.autograd.Function):
@@ -1023,18 +1060,24 @@ class CrossKVShared:
         self.n, self.dkv, self.done = n, None, 0
 
 
+def _same_storage(ts):
+    """the tensors are windows of ONE allocation (a flat buffer): a view may then span them"""
+    s0 = ts[0].untyped_storage()
+    return all(t.untyped_storage().data_ptr() == s0.data_ptr() for t in ts)
+
+
 def stack_rows(ts):
-    """torch.cat(ts, 0) -- as a VIEW when the tensors already sit one after the other in memory (FlatDataParallel lays the decoder
-    layers' vk_proj parameters out that way): no launch"""
-    t0 = t0_ = ts[0]
+    """torch.cat(ts, 0) -- as a VIEW when the tensors already sit one after the other in one allocation (FlatDataParallel lays the
+    decoder layers' vk_proj parameters out that way): no launch"""
+    t0 = ts[0]
     if all(t.is_contiguous() and t.dtype == t0.dtype and t.shape[1:] == t0.shape[1:] for t in ts):
         nb, ok, p = t0.element_size(), True, t0.data_ptr()
         for t in ts:
             ok = ok and t.data_ptr() == p
             p += t.numel() * nb
-        if ok and t0._base is not None or ok and len(ts) == 1:
+        if ok and (len(ts) == 1 or _same_storage(ts)):
             rows = sum(t.shape[0] for t in ts)
-            return t0.as_strided((rows,) + tuple(t0.shape[1:]), t0.stride())
+            return t0.detach().as_strided((rows,) + tuple(t0.shape[1:]), t0.stride())
     return torch.cat(ts, dim=0)
 
 
@@ -1046,8 +1089,8 @@ def stack_cols(ts):
         for t in ts:
             ok = ok and t.data_ptr() == p
             p += t.shape[1] * nb
-        if ok and cols <= t0.stride(0) and t0._base is not None:
-            return t0.as_strided((t0.shape[0], cols), t0.stride())
+        if ok and cols <= t0.stride(0) and _same_storage(ts):
+            return t0.detach().as_strided((t0.shape[0], cols), t0.stride())
     return torch.cat(ts, dim=1)
 
 
@@ -2156,7 +2199,8 @@ class ConvSubsampleFn(torch.autograd.Function):
         w1_param = w1
         w1 = w1.contiguous()
         w2l = weight_lp(w2)
-        w2r = (w2l if w2l is not None else w2).view(C2, C1, 3, 3).permute(0, 2, 3, 1).contiguous()
+        w2r = regrouped_lp(w2, (C2, 9, C1))
+        w2r = w2r.view(C2, 3, 3, C1) if w2r is not None else (w2l if w2l is not None else w2).view(C2, C1, 3, 3).permute(0, 2, 3, 1).contiguous()
         desc = L.ConvDesc(B, T, F, C1, C2, T1, F1, T2, F2, _code(adt), _compute_code(), _code(w2r.dtype))
         act1 = torch.empty((B, T1, F1, C1), dtype=adt, device=x.device)
         act2 = torch.empty((B, T2, F2 * C2), dtype=adt, device=x.device)

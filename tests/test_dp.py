@@ -307,3 +307,43 @@ def test_staged_backward_left_half_done_is_an_error():
     finally:
         ops.set_stage_split(False)
         ops.set_early_callback(None)
+
+
+def test_stacked_views_of_a_flat_buffer_launch_nothing():
+    """ops.stack_rows / stack_cols (the decoder layers' vk_proj weights and biases, ops.CrossKVAllFn): a VIEW when the pieces sit one
+    after the other in ONE allocation -- also for parameters whose .data was pointed into the flat buffer (they are not autograd
+    views: `_base` is None) -- and a real concatenation otherwise."""
+    from opentransformer_amd import ops
+    flat = torch.arange(64, dtype=torch.float32)
+    ps = [torch.nn.Parameter(torch.empty(2, 4)) for _ in range(3)]
+    for i, p in enumerate(ps):
+        p.data = flat[8 * i:8 * i + 8].view(2, 4)
+    v = ops.stack_rows(ps)
+    assert v.data_ptr() == flat.data_ptr() and v.shape == (6, 4) and not v.requires_grad
+    assert torch.equal(v, flat[:24].view(6, 4))
+    bs = [torch.nn.Parameter(torch.empty(4)) for _ in range(2)]
+    for i, b in enumerate(bs):
+        b.data = flat[32 + 4 * i:36 + 4 * i]
+    vb = ops.stack_rows(bs)
+    assert vb.data_ptr() == bs[0].data_ptr() and torch.equal(vb, flat[32:40])
+    gap = ops.stack_rows([ps[0], ps[2]])                     # not adjacent: a copy
+    assert gap.data_ptr() != flat.data_ptr() and torch.equal(gap, torch.cat([ps[0], ps[2]]))
+    other = ops.stack_rows([flat[:8].view(2, 4), torch.zeros(2, 4)])        # different allocations: a copy
+    assert other.shape == (4, 4) and other.data_ptr() != flat.data_ptr()
+    big = flat[:48].view(4, 12)
+    cols = ops.stack_cols([big[:, 0:4], big[:, 4:8], big[:, 8:12]])
+    assert cols.data_ptr() == flat.data_ptr() and torch.equal(cols, big)
+    assert torch.equal(ops.stack_cols([big[:, 0:4], big[:, 8:12]]), torch.cat([big[:, 0:4], big[:, 8:12]], 1))
+
+
+def test_mask_cast_is_remembered_on_the_tensor():
+    from opentransformer_amd import ops
+    frames = torch.rand(3, 40) > 0.3
+    m = frames[:, 1::2][:, :19][:, 1::2][:, :9]              # frontend/conv.py:78-83, twice
+    a = ops._mask_u8(m, 3, 9)
+    assert a.dtype == torch.uint8 and a.is_contiguous() and torch.equal(a.bool(), m)
+    assert ops._mask_u8(m, 3, 9) is a                        # the decoder's memory mask: same tensor, no second cast
+    frames.fill_(False)                                      # in-place change of the base: the version counter moves
+    b = ops._mask_u8(m, 3, 9)
+    assert b is not a and not b.any()
+    assert ops._mask_u8(b, 3, 9) is b and ops._mask_u8(None, 3, 9) is None

@@ -253,3 +253,59 @@ def test_library_owned_rccl_communicator_world_one():
             dp.close()
     finally:
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp16', 'bf16'])
+def test_regrouped_frontend_shadows_follow_the_optimizer(mode):
+    """The frontend's channel-last weight images (nn.ConvFrontEnd.regrouped_weights: conv2's taps, the output Linear's columns,
+    frontend/conv.py:141-145) are kept by FlatDataParallel's one transpose launch per optimizer step instead of a copy per forward
+    pass: same loss and gradients as the stand-alone module that regroups on the fly, and still right after an update."""
+    import copy
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+    ops.set_compute_dtype(mode)
+    try:
+        cfg = syn.c1_model(0.0)
+        plain = ota.SpeechToText(cfg)
+        syn.fill_state_dict_(plain.state_dict(), 5)
+        plain = plain.to('cuda').train()
+        model = copy.deepcopy(plain)
+        dp = FlatDataParallel(model)
+        opt = FusedAdam(dp, lr=1e-2, loss_scale=(256.0 if mode == 'fp16' else None))
+        fe = model.frontend
+
+        def check_views():
+            seen = 0
+            for w, (A, R, S) in fe.regrouped_weights():
+                v = ops.regrouped_lp(w, (A, S, R))
+                assert v is not None, 'no regrouped shadow registered'
+                assert torch.equal(v, ops.weight_lp(w).reshape(A, R, S).transpose(1, 2))
+                seen += 1
+            assert seen == 2
+        check_views()
+        inputs, targets = syn.synthetic_batch(**BATCH)
+        inputs, targets = {k: v.cuda() for k, v in inputs.items()}, {k: v.cuda() for k, v in targets.items()}
+        recs = []
+        ops.set_kernel_timer(recs)
+        try:
+            dp.zero_grad()
+            loss, _ = dp(inputs, targets)
+        finally:
+            ops.set_kernel_timer(None)
+        ops.backward(loss)
+        plain._otr_loss_scale = getattr(model, '_otr_loss_scale', None)     # the same seed scale for both backward passes
+        ref, _ = plain(inputs, targets)
+        ref.backward()
+        ls = float(opt.state[6]) or 1.0
+        assert abs(loss.item() - ref.item()) < 1e-3 * abs(ref.item())
+        for (n, p), (_, q) in zip(model.named_parameters(), plain.named_parameters()):
+            if n.startswith('frontend'):
+                a, b = p.grad.double() / ls, q.grad.double() / ls
+                assert float((a - b).norm() / (b.norm() + 1e-30)) < 2e-2, n
+        dp.all_reduce_gradients()
+        opt.step(1.0)
+        torch.cuda.synchronize()
+        check_views()                                   # refreshed behind the update
+    finally:
+        ops.set_compute_dtype('bf16')
