@@ -392,14 +392,17 @@ def main():
                             dp.all_reduce_gradients()     # consumes the early collective of the warm-up passes
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
+                # N > 1: the process group's watchdog thread polls its events while this thread captures; only THIS thread's calls
+                # are policed then (the default, global, mode lets a foreign thread's call invalidate the capture)
+                cap = {'capture_error_mode': 'thread_local'} if world > 1 else {}
                 graph = torch.cuda.CUDAGraph()
-                with ops.graph_capture(graph):
+                with ops.graph_capture(graph, **cap):
                     stage1()
                     if whole:
                         opt.step(1.0)
                 if overlap:
                     graph2 = torch.cuda.CUDAGraph()
-                    with ops.graph_capture(graph2, pool=graph.pool()):
+                    with ops.graph_capture(graph2, pool=graph.pool(), **cap):
                         stage2()
             except Exception as e:                                # noqa: BLE001
                 if rank == 0:

@@ -181,9 +181,9 @@ def _split_worker(rank, world, port, out):
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with ops.graph_capture(g1):
+                with ops.graph_capture(g1, capture_error_mode='thread_local'):        # as bench.py captures at N > 1
                     stage1()
-                with ops.graph_capture(g2, pool=g1.pool()):
+                with ops.graph_capture(g2, pool=g1.pool(), capture_error_mode='thread_local'):
                     stage2()
                 for _ in range(2):                      # replayed twice: nothing of a replay may leak into the next
                     g1.replay()
