@@ -427,6 +427,13 @@ int32_t otr_act_bwd(const void* x, const void* dy, void* dx, int32_t dtype, int6
  *      scratch: f32[R+2] workspace (per-row losses are reduced in a fixed order: deterministic). */
 int32_t otr_label_smoothing_loss(const float* logits, const int64_t* target, int64_t R, int32_t V, float smoothing,
                                  int32_t pad_idx, float* loss, float* dlogits, float* scratch, void* stream);
+/* The same on rows longer than V (leading dimensions ld_logits, ld_dlogits >= V, in elements): the logits of an output layer
+ * whose width is not a multiple of 8 (decoder/transformer.py:153, 4234 tokens) arrive as the head of a [R, V8] product and the
+ * gradient leaves the same way, its columns V .. ld_dlogits-1 written as zeros, so that the layer's backward GEMMs read aligned
+ * rows at the padded width. */
+int32_t otr_label_smoothing_loss_ld(const float* logits, int64_t ld_logits, const int64_t* target, int64_t R, int32_t V,
+                                    float smoothing, int32_t pad_idx, float* loss, float* dlogits, int64_t ld_dlogits,
+                                    float* scratch, void* stream);
 
 /* ---- log_softmax over the last dim, f32 [R,V] (model/ctc.py:51,66; decoder/transformer.py:206) */
 int32_t otr_log_softmax(const float* x, float* y, int64_t R, int32_t V, void* stream);

@@ -37,13 +37,16 @@ __global__ void ls_finalize_kernel(const float* row_loss, int64_t R, float* loss
 //   row_loss = C - [ (1-eps) logp_t + eps/(V-1) (sum_v logp_v - logp_t) ],
 //   C = (1-eps) log(1-eps) + eps log(eps/(V-1))        (0 log 0 := 0, as torch's kl_div)
 //   d row_loss / d logit_v = softmax_v - conf_v
-__global__ __launch_bounds__(256) void ls_rows_kernel(const float* logits, const int64_t* target, int V, float eps,
-                                                     int pad_idx, const float* scratch, float* row_loss, float* dlogits) {
+// Rows of logits / dlogits may be longer than V (ld_x, ld_dx >= V: the head of a row-padded product, ops.padded_rows): the
+// columns of dlogits behind V are written as zeros, so that the buffer can be read at its full width.
+__global__ __launch_bounds__(256) void ls_rows_kernel(const float* logits, int64_t ld_x, const int64_t* target, int V, float eps,
+                                                     int pad_idx, const float* scratch, float* row_loss, float* dlogits, int64_t ld_dx) {
   __shared__ float sh[4];
   const int64_t row = blockIdx.x;
-  const float* x = logits + row * V;
-  float* dx = dlogits ? dlogits + row * V : nullptr;
+  const float* x = logits + row * ld_x;
+  float* dx = dlogits ? dlogits + row * ld_dx : nullptr;
   const int64_t t = target[row];
+  if (dx) for (int64_t v = V + threadIdx.x; v < ld_dx; v += blockDim.x) dx[v] = 0.f;
   if (t == pad_idx) {
     if (dx) for (int v = threadIdx.x; v < V; v += blockDim.x) dx[v] = 0.f;
     if (threadIdx.x == 0) row_loss[row] = 0.f;
@@ -74,17 +77,26 @@ __global__ __launch_bounds__(256) void ls_rows_kernel(const float* logits, const
   }
 }
 
-extern "C" int32_t otr_label_smoothing_loss(const float* logits, const int64_t* target, int64_t R, int32_t V,
-                                            float smoothing, int32_t pad_idx, float* loss, float* dlogits,
-                                            float* scratch, void* stream) {
+extern "C" int32_t otr_label_smoothing_loss_ld(const float* logits, int64_t ld_logits, const int64_t* target, int64_t R, int32_t V,
+                                               float smoothing, int32_t pad_idx, float* loss, float* dlogits, int64_t ld_dlogits,
+                                               float* scratch, void* stream) {
   OTR_REQUIRE(logits && target && loss && scratch, "label_smoothing_loss: null pointer");
   OTR_REQUIRE(R > 0 && V > 1, "label_smoothing_loss: bad shape R=%lld V=%d", (long long)R, V);
+  OTR_REQUIRE(ld_logits >= V && (!dlogits || ld_dlogits >= V), "label_smoothing_loss: leading dimensions %lld / %lld shorter than V=%d",
+              (long long)ld_logits, (long long)ld_dlogits, V);
   OTR_REQUIRE(smoothing >= 0.f && smoothing < 1.f, "label_smoothing_loss: smoothing out of [0,1)");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(ls_count_kernel, dim3(1), dim3(256), 0, s, target, R, pad_idx, scratch);
-  hipLaunchKernelGGL(ls_rows_kernel, dim3((unsigned)R), dim3(256), 0, s, logits, target, V, smoothing, pad_idx, scratch, scratch + 2, dlogits);
+  hipLaunchKernelGGL(ls_rows_kernel, dim3((unsigned)R), dim3(256), 0, s, logits, ld_logits, target, V, smoothing, pad_idx, scratch, scratch + 2,
+                     dlogits, ld_dlogits);
   hipLaunchKernelGGL(ls_finalize_kernel, dim3(1), dim3(256), 0, s, scratch + 2, R, loss);
   return otr_check_launch("label_smoothing_loss");
+}
+
+extern "C" int32_t otr_label_smoothing_loss(const float* logits, const int64_t* target, int64_t R, int32_t V,
+                                            float smoothing, int32_t pad_idx, float* loss, float* dlogits,
+                                            float* scratch, void* stream) {
+  return otr_label_smoothing_loss_ld(logits, V, target, R, V, smoothing, pad_idx, loss, dlogits, V, scratch, stream);
 }
 
 __global__ __launch_bounds__(256) void log_softmax_kernel(const float* x, float* y, int V) {

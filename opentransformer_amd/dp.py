@@ -61,6 +61,15 @@ class FlatDataParallel:
                 if n.endswith(suffix) and p.numel() % ALIGN == 0:
                     return suffix
             return None
+        # A Linear whose row count is not a multiple of 8 (the 4234-token output layer, decoder/transformer.py:153) gets the missing
+        # rows as part of its slot: the GEMMs of that layer then see [rows8, K] operands with aligned rows everywhere (weight,
+        # transposed shadow, gradient; the logits / their gradient with a leading dimension of rows8) and run on the branch-free
+        # kernels.  The extra rows are zero and stay zero (zero gradient, zero weight: Adam and the decay leave them alone); the
+        # parameter itself is the [rows, K] head of the slot.  A bias finds its 8-padding inside the alignment gap it has anyway.
+        def slot_numel(q):
+            if q.dim() == 2 and q.shape[0] % 8 != 0 and q.shape[1] % 8 == 0 and q.shape[0] > 8:
+                return (q.shape[0] + 7) // 8 * 8 * q.shape[1]
+            return q.numel()
         offs, total = [None] * len(params), 0
         self._row_groups = []                       # [(indices of params stacked along dim 0)]
         for want_early in (True, False):            # the early group first: [0, early_end), then everything else
@@ -80,7 +89,7 @@ class FlatDataParallel:
                     self._row_groups.append(list(members))
                 for j in members:
                     offs[j] = total
-                    total += (params[j].numel() + ALIGN - 1) // ALIGN * ALIGN
+                    total += (slot_numel(params[j]) + ALIGN - 1) // ALIGN * ALIGN
                     done.add(j)
             if want_early:
                 self.early_end = total
@@ -108,6 +117,12 @@ class FlatDataParallel:
                 p.data = self.flat_param[off:off + n].view_as(p.data)
             p.grad = self.flat_grad[off:off + n].view_as(p.data)
             p._otr_grad_inplace = True      # ops.grad_target(): backward kernels accumulate straight into the view
+            if flatten_params and dev.type == 'cuda' and n % 8 != 0 and (p.dim() == 1 or slot_numel(p) != n):
+                # the row-padded images of this parameter and of its gradient (ops.padded_rows): [rows8, K] / [n8]
+                shape8 = ((p.shape[0] + 7) // 8 * 8,) + tuple(p.shape[1:])
+                n8 = shape8[0] * (p.shape[1] if p.dim() == 2 else 1)
+                if p.dim() <= 2 and n8 <= (slot_numel(p) + ALIGN - 1) // ALIGN * ALIGN:
+                    p._otr_pad = {'param': self.flat_param[off:off + n8].view(shape8), 'grad': self.flat_grad[off:off + n8].view(shape8)}
         # bf16 shadow of every parameter (GEMM operand form), kept fresh by FusedAdam in the same pass
         self.flat_param_lp = None
         if flatten_params and dev.type == 'cuda' and dt == torch.float32:
@@ -117,6 +132,9 @@ class FlatDataParallel:
                 for p, off in zip(params, offs):
                     n = p.numel()
                     p._otr_lp_view = self.flat_param_lp[off:off + n].view(p.shape)
+                    pad = getattr(p, '_otr_pad', None)
+                    if pad is not None:
+                        pad['lp'] = self.flat_param_lp[off:off + pad['param'].numel()].view(pad['param'].shape)
                 self._build_ffn_packs(module, dev)
                 # transposed bf16 shadows of the 2-D weights ([K,N]: dgrad becomes a forward-type GEMM) -- except the weights that
                 # have fragment-major packs (the FFNs' w_1 / w_2, the 256- and 768-wide projections: 33 of the 36.5 M parameters
@@ -158,9 +176,14 @@ class FlatDataParallel:
                     if id(p) in grouped:
                         continue
                     if p.dim() == 2 and getattr(p, '_otr_lin_packs', None) is None and id(p) not in self._ffn_packed:
-                        p._otr_lpt_view = self.flat_param_lpt[off:off + n].view(p.shape[1], p.shape[0])
-                        table.append([off, p.shape[0], p.shape[1], tiles])
-                        tiles += ((p.shape[0] + 63) // 64) * ((p.shape[1] + 63) // 64)
+                        pad = getattr(p, '_otr_pad', None)
+                        rows = pad['param'].shape[0] if pad is not None else p.shape[0]       # the padded matrix: [K, rows8], zero tail columns
+                        full = self.flat_param_lpt[off:off + rows * p.shape[1]].view(p.shape[1], rows)
+                        p._otr_lpt_view = full[:, :p.shape[0]]
+                        if pad is not None:
+                            pad['lpt'] = full
+                        table.append([off, rows, p.shape[1], tiles])
+                        tiles += ((rows + 63) // 64) * ((p.shape[1] + 63) // 64)
                 # one launch transposes every such shadow (include/otrans_hip.h: otr_transpose_batched)
                 self._lpt_table = torch.tensor(table, dtype=torch.int64, device=dev).reshape(-1, 4)
                 self._lpt_tiles = tiles

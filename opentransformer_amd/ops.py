@@ -225,6 +225,7 @@ def backward(loss):
 #    refreshes in the same pass as the fp32 master, or (stand-alone modules) a cached cast keyed by
 #    the parameter's version counter.
 _LP_ATTR = '_otr_bf16'
+_PAD_ROWS = os.environ.get('OTR_PAD_ROWS', '1') != '0'      # A/B switch of ops.padded_rows
 
 
 def lp_of(t):
@@ -287,6 +288,28 @@ def _workspace(device):
         _zero_placeholder(device, ())   # likewise allocated outside any capture's private pool (LnOutLink)
         _ffn_sync_pool(device)          # and the split FFN kernels' arrival counters (one row per launch stream)
     return ws
+
+
+def padded_rows(w, b=None):
+    """FlatDataParallel's row-padded images of a Linear whose output width is not a multiple of 8 (dp.py `slot_numel`): dicts
+    {'param', 'grad', 'lp', 'lpt'} for the weight and {'param', 'grad'} for the bias, or None when this weight has none (or the
+    bias lacks its own).  The GEMMs of such a layer run on [rows8, K] operands: aligned rows, branch-free loaders."""
+    if not is_half() or not _PAD_ROWS:
+        return None
+    pw = getattr(w, '_otr_pad', None)
+    if pw is None or 'lp' not in pw or 'lpt' not in pw or pw['lp'].dtype != half_dtype():
+        return None
+    pb = None
+    if b is not None:
+        pb = getattr(b, '_otr_pad', None)
+        if pb is None or pb['param'].shape[0] != pw['param'].shape[0]:
+            return None
+    return pw, pb
+
+
+# gradient buffers whose columns behind the logical width are known to be zero (written by the loss kernel that made them):
+# data_ptr -> (rows, width8).  LinearFn.backward widens exactly these to their padded width.
+_zero_tailed = {}
 
 
 def regrouped_lp(w, shape):
@@ -823,10 +846,18 @@ class LinearFn(torch.autograd.Function):
         lo = getattr(x, '_otr_lnout', None)      # x is the output of a LayerNorm whose backward can run in this Linear's dgrad launch
         ctx.lnout = lo if (lo is not None and lo.armed and packs is not None and ctx.needs_input_grad[0] and x.dtype == torch.float32
                            and w.shape[1] == 256 and w.shape[0] in (256, 768)) else None
+        ctx.pad = None
+        pad = padded_rows(w, b) if (packs is None and pend is None and perm is None and not relu and out_dtype == torch.float32) else None
         if pend is not None:
             y = rb_linear_pending_raw(pend, packs[0], w.shape[0], b, out_dtype)
         elif packs is not None:
             y = rb_linear_raw(x2, packs[0], w.shape[0], b, out_dtype)
+        elif pad is not None:
+            # output width not a multiple of 8: the product is taken against the row-padded weight into a [M, rows8] buffer (the
+            # tail columns come out 0) and the result is its [M, N] head -- rows start 16-byte aligned, whoever reads them
+            pw, pb = pad
+            y = linear_fwd_raw(x2, pw['lp'], pb['param'] if pb is not None else None, out_dtype)[:, :w.shape[0]]
+            ctx.pad = pad
         else:
             y = linear_fwd_raw(x2, wc, b, out_dtype, L.ACT_RELU if relu else L.ACT_NONE)
         ctx.relu = relu
@@ -844,6 +875,26 @@ class LinearFn(torch.autograd.Function):
         dy2 = _rows(dy)
         if ctx.relu:
             dy2 = relu_bwd_raw(y, dy2.contiguous())
+        if ctx.pad is not None:
+            # the gradient of a row-padded product: when it arrives as the head of a zero-tailed [M, rows8] buffer (the loss
+            # kernel wrote it that way), all three GEMMs of this layer run on the padded operands
+            pw, pb = ctx.pad
+            N8 = pw['param'].shape[0]
+            tail = _zero_tailed.pop(dy2.data_ptr(), None)
+            if (tail == (dy2.shape[0], N8) and dy2.dim() == 2 and dy2.stride() == (N8, 1) and dy2.dtype == torch.float32
+                    and dy2.data_ptr() % 16 == 0):
+                dyp = dy2.as_strided((dy2.shape[0], N8), (N8, 1))
+                dx = None
+                if ctx.needs_input_grad[0]:
+                    skip = None
+                    if ctx.link is not None and ctx.link.buf is not None:
+                        skip, ctx.link.buf = ctx.link.buf, None
+                    dx = linear_fwd_raw(dyp, pw['lpt'], None, ctx.xdtype, out=skip).view(ctx.xshape)
+                if ctx.needs_input_grad[1]:
+                    linear_wgrad_raw(dyp, x2, pw['lp'], out=pw['grad'])
+                if ctx.has_bias and ctx.needs_input_grad[2] and not ctx.defer_bias:
+                    colsum_raw(dyp, out=pb['grad'])
+                return dx, None, None, None, None, None, None, None
         dx = None
         if ctx.needs_input_grad[0]:
             skip = None
@@ -2599,15 +2650,22 @@ class LabelSmoothingLossFn(torch.autograd.Function):
     def forward(ctx, logits, target, smoothing, pad_idx):
         _cuda(logits, target)
         V = logits.shape[-1]
-        lg = logits.reshape(-1, V).contiguous()
+        lg = logits.reshape(-1, V)
+        # the head of a row-padded product (ops.padded_rows: rows of V8 = ceil8(V) floats) is read in place, and the gradient
+        # leaves as the head of a zero-tailed [R, V8] buffer
+        ld = lg.stride(0) if (lg.dim() == 2 and lg.shape[0] > 1 and lg.stride(1) == 1 and lg.dtype == torch.float32) else V
+        if not (V < ld < V + 8 and ld % 8 == 0 and lg.data_ptr() % 16 == 0):
+            lg, ld = lg.contiguous(), V
+        R = lg.shape[0]
         tg = target.reshape(-1).contiguous()
         loss = torch.empty((), dtype=torch.float32, device=lg.device)
-        dlogits = torch.empty_like(lg) if ctx.needs_input_grad[0] else None
-        scratch = torch.empty((lg.shape[0] + 2,), dtype=torch.float32, device=lg.device)
-        L.check(L.load().otr_label_smoothing_loss(_p(lg), _p(tg), lg.shape[0], V, smoothing, pad_idx, _p(loss),
-                                                  _p(dlogits), _p(scratch), _stream()), 'otr_label_smoothing_loss')
+        dlogits = torch.empty((R, ld), dtype=torch.float32, device=lg.device) if ctx.needs_input_grad[0] else None
+        scratch = torch.empty((R + 2,), dtype=torch.float32, device=lg.device)
+        L.check(L.load().otr_label_smoothing_loss_ld(_p(lg), ld, _p(tg), R, V, smoothing, pad_idx, _p(loss), _p(dlogits), ld,
+                                                     _p(scratch), _stream()), 'otr_label_smoothing_loss_ld')
+        _zero_tailed.clear()
         ctx.save_for_backward(dlogits)
-        ctx.shape = logits.shape
+        ctx.shape, ctx.V = logits.shape, V
         return loss
 
     @staticmethod
@@ -2616,6 +2674,9 @@ class LabelSmoothingLossFn(torch.autograd.Function):
         out = torch.empty_like(dlogits)
         g = g.contiguous().float()
         L.check(L.load().otr_scale(_p(dlogits), _p(out), dlogits.numel(), _p(g), 1.0, _stream()), 'otr_scale')
+        if out.shape[1] != ctx.V:
+            _zero_tailed[out.data_ptr()] = tuple(out.shape)        # LinearFn.backward may read it at its full width
+            out = out[:, :ctx.V]
         return out.view(ctx.shape), None, None, None
 
 

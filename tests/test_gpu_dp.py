@@ -309,3 +309,75 @@ def test_regrouped_frontend_shadows_follow_the_optimizer(mode):
         check_views()                                   # refreshed behind the update
     finally:
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('V', [4234, 100])
+def test_output_layer_on_row_padded_operands(V):
+    """A Linear whose width is not a multiple of 8 (the 4234-token output layer, decoder/transformer.py:153) under
+    FlatDataParallel: weight, transposed shadow and gradient carry zero rows up to the next multiple of 8 inside the layer's slot of
+    the flat buffers, logits and their gradient travel as heads of [R, V8] buffers (otr_label_smoothing_loss_ld), and the three
+    GEMMs of the layer run at the padded width.  Same loss and gradients as the unpadded path; the padding stays zero."""
+    import copy
+    import opentransformer_amd.nn as onn
+    from opentransformer_amd import ops
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+
+    class Head(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(V)
+            self.output_layer = torch.nn.Linear(256, V)
+            self.crit = onn.LabelSmoothingLoss(V, 0.1)
+
+        def forward(self, x, tgt):
+            return self.crit(ops.linear(x, self.output_layer.weight, self.output_layer.bias), tgt)
+
+    ops.set_compute_dtype('fp16')
+    try:
+        g = torch.Generator().manual_seed(1)
+        x0 = torch.randn(32, 15, 256, generator=g).cuda()
+        tgt = torch.randint(1, V, (32, 15), generator=g).cuda()
+        tgt[3, 9:] = 0                                         # PAD rows
+        V8 = (V + 7) // 8 * 8
+        res = {}
+        for name, on in (('padded', True), ('plain', False)):
+            m = Head().cuda().train()
+            dp = FlatDataParallel(m)
+            w, b = m.output_layer.weight, m.output_layer.bias
+            assert tuple(w._otr_pad['param'].shape) == (V8, 256) and tuple(b._otr_pad['param'].shape) == (V8,)
+            assert w._otr_pad['param'].data_ptr() == w.data_ptr() and not w._otr_pad['param'][V:].any()
+            was = ops._PAD_ROWS
+            ops._PAD_ROWS = on
+            recs = []
+            try:
+                x = x0.clone().requires_grad_(True)
+                dp.zero_grad()
+                ops.set_kernel_timer(recs)
+                loss = dp(x, tgt)
+                ops.set_kernel_timer(None)
+                ops.backward(loss)
+                torch.cuda.synchronize()
+            finally:
+                ops.set_kernel_timer(None)
+                ops._PAD_ROWS = was
+            names = ' '.join(str(r[0] if isinstance(r, (tuple, list)) else r) for r in recs)
+            assert ('linear_fwd 480x%dx256' % (V8 if on else V)) in names, names
+            res[name] = (loss.item(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+            assert not w._otr_pad['grad'][V:].any() and not b._otr_pad['grad'][V:].any()
+            assert not w._otr_pad['lpt'][:, V:].any()
+            assert torch.equal(w._otr_pad['lpt'][:, :V], ops.weight_lp(w).t())
+            if on:                                              # an update leaves the padding at zero and the shadows in step
+                opt = FusedAdam(dp, lr=1e-2, loss_scale=None)
+                dp.all_reduce_gradients()
+                opt.step(1.0)
+                torch.cuda.synchronize()
+                assert not w._otr_pad['param'][V:].any() and not b._otr_pad['param'][V:].any()
+                assert torch.equal(w._otr_pad['lpt'][:, :V], ops.weight_lp(w).t()) and not w._otr_pad['lpt'][:, V:].any()
+        (la, xa, wa, ba), (lb, xb, wb, bb) = res['padded'], res['plain']
+        assert abs(la - lb) < 1e-5 * abs(lb)
+
+        def rel(a, b):
+            return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+        assert rel(xa, xb) < 2e-3 and rel(wa, wb) < 2e-3 and rel(ba, bb) < 1e-4, (rel(xa, xb), rel(wa, wb), rel(ba, bb))
+    finally:
+        ops.set_compute_dtype('bf16')
