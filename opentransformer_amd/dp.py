@@ -117,7 +117,7 @@ class FlatDataParallel:
                 p.data = self.flat_param[off:off + n].view_as(p.data)
             p.grad = self.flat_grad[off:off + n].view_as(p.data)
             p._otr_grad_inplace = True      # ops.grad_target(): backward kernels accumulate straight into the view
-            if flatten_params and dev.type == 'cuda' and n % 8 != 0 and (p.dim() == 1 or slot_numel(p) != n):
+            if flatten_params and dev.type == 'cuda' and ((p.dim() == 1 and n % 8 != 0) or slot_numel(p) != n):
                 # the row-padded images of this parameter and of its gradient (ops.padded_rows): [rows8, K] / [n8]
                 shape8 = ((p.shape[0] + 7) // 8 * 8,) + tuple(p.shape[1:])
                 n8 = shape8[0] * (p.shape[1] if p.dim() == 2 else 1)
