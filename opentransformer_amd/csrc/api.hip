@@ -315,6 +315,16 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
     const int big = (it.N >= 128 && it.K >= 128) ? 1 : 0;
     order[(big << 2) | ((it.dy_dtype != OTR_F32) << 1) | (it.x_dtype != OTR_F32)].push_back(i);   // dtype codes -> 0 / 1
   }
+  for (int key = 4; key < 8; ++key) {
+    // a group whose 128 x 128 tiles would not cover half the chip (the 4240 x 256 output layer over 480 rows: 68 tiles) runs on
+    // 64 x 64 tiles instead: four times the workgroups
+    int64_t t128 = 0;
+    for (int i : order[key]) t128 += (int64_t)((items[i].N + 127) / 128) * ((items[i].K + 127) / 128);
+    if (!order[key].empty() && t128 < 128) {
+      order[key & 3].insert(order[key & 3].end(), order[key].begin(), order[key].end());
+      order[key].clear();
+    }
+  }
   for (int key = 0; key < 8; ++key) {
     std::vector<int>& v = order[key];
     if (v.empty()) continue;

@@ -15,12 +15,18 @@ __device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
   return r;
 }
 
-// scratch[0] = number of non-pad rows
-__global__ void ls_count_kernel(const int64_t* target, int64_t R, int pad_idx, float* scratch) {
-  __shared__ float sh[4];
+// number of non-pad rows: every row's block counts them itself (R targets, a few loads per thread, an exact integer-valued sum in a
+// fixed order: the same value in every block) -- a counting launch of its own was 5 us in front of the rows kernel
+// (beyond LS_COUNT_INLINE rows the R^2 / 256 loads stop being free: the counting launch is kept for those)
+constexpr int64_t LS_COUNT_INLINE = 8192;
+__device__ __forceinline__ float ls_count(const int64_t* target, int64_t R, int pad_idx, float* sh) {
   float c = 0.f;
   for (int64_t i = threadIdx.x; i < R; i += blockDim.x) c += (target[i] != pad_idx) ? 1.f : 0.f;
-  c = block_reduce(c, sh, false);
+  return block_reduce(c, sh, false);
+}
+__global__ void ls_count_kernel(const int64_t* target, int64_t R, int pad_idx, float* scratch) {      // scratch[0] = number of non-pad rows
+  __shared__ float sh[4];
+  const float c = ls_count(target, R, pad_idx, sh);
   if (threadIdx.x == 0) scratch[0] = c;
 }
 
@@ -39,8 +45,8 @@ __global__ void ls_finalize_kernel(const float* row_loss, int64_t R, float* loss
 //   d row_loss / d logit_v = softmax_v - conf_v
 // Rows of logits / dlogits may be longer than V (ld_x, ld_dx >= V: the head of a row-padded product, ops.padded_rows): the
 // columns of dlogits behind V are written as zeros, so that the buffer can be read at its full width.
-__global__ __launch_bounds__(256) void ls_rows_kernel(const float* logits, int64_t ld_x, const int64_t* target, int V, float eps,
-                                                     int pad_idx, const float* scratch, float* row_loss, float* dlogits, int64_t ld_dx) {
+__global__ __launch_bounds__(256) void ls_rows_kernel(const float* logits, int64_t ld_x, const int64_t* target, int64_t R, int V, float eps,
+                                                     int pad_idx, const float* count, float* row_loss, float* dlogits, int64_t ld_dx) {
   __shared__ float sh[4];
   const int64_t row = blockIdx.x;
   const float* x = logits + row * ld_x;
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(256) void ls_rows_kernel(const float* logits, int64
   se = block_reduce(se, sh, false);
   sx = block_reduce(sx, sh, false);
   const float lse = mx + logf(se);
-  const float inv_cnt = 1.f / scratch[0];
+  const float inv_cnt = 1.f / (count ? count[0] : ls_count(target, R, pad_idx, sh));
   const float off = eps / (float)(V - 1), on = 1.f - eps;
   if (dx) {
     for (int v = threadIdx.x; v < V; v += blockDim.x) {
@@ -86,8 +92,12 @@ extern "C" int32_t otr_label_smoothing_loss_ld(const float* logits, int64_t ld_l
               (long long)ld_logits, (long long)ld_dlogits, V);
   OTR_REQUIRE(smoothing >= 0.f && smoothing < 1.f, "label_smoothing_loss: smoothing out of [0,1)");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(ls_count_kernel, dim3(1), dim3(256), 0, s, target, R, pad_idx, scratch);
-  hipLaunchKernelGGL(ls_rows_kernel, dim3((unsigned)R), dim3(256), 0, s, logits, ld_logits, target, V, smoothing, pad_idx, scratch, scratch + 2,
+  const float* count = nullptr;
+  if (R > LS_COUNT_INLINE) {
+    hipLaunchKernelGGL(ls_count_kernel, dim3(1), dim3(256), 0, s, target, R, pad_idx, scratch);
+    count = scratch;
+  }
+  hipLaunchKernelGGL(ls_rows_kernel, dim3((unsigned)R), dim3(256), 0, s, logits, ld_logits, target, R, V, smoothing, pad_idx, count, scratch + 2,
                      dlogits, ld_dlogits);
   hipLaunchKernelGGL(ls_finalize_kernel, dim3(1), dim3(256), 0, s, scratch + 2, R, loss);
   return otr_check_launch("label_smoothing_loss");
