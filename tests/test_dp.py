@@ -347,3 +347,39 @@ def test_mask_cast_is_remembered_on_the_tensor():
     b = ops._mask_u8(m, 3, 9)
     assert b is not a and not b.any()
     assert ops._mask_u8(b, 3, 9) is b and ops._mask_u8(None, 3, 9) is None
+
+
+def test_row_padded_slots_in_the_flat_layout():
+    """dp.py `slot_numel`: a 2-D parameter whose row count is not a multiple of 8 (the 4234-token output layer,
+    decoder/transformer.py:153) owns the rows up to the next multiple of 8 inside its slot of the flat buffers; the parameter and
+    its gradient stay the [rows, K] head of the slot, everything behind starts 64-element aligned, the extra rows are zero and take
+    no gradient (host layout only here: the padded operand images themselves are device-side, tests/test_gpu_dp.py)."""
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            self.a = torch.nn.Linear(16, 11)         # 11 rows -> 16 in the slot
+            self.b = torch.nn.Linear(16, 8)          # already a multiple of 8
+            self.c = torch.nn.Linear(12, 13)         # 12 columns: not a multiple of 8, left alone
+
+        def forward(self, x):
+            return (self.a(x).sum() + self.b(x).sum() + self.c(x[:, :12]).sum())
+    m = M()
+    ref = {n: p.detach().clone() for n, p in m.named_parameters()}
+    dp = FlatDataParallel(m)
+    off = {id(p): o for p, o in zip(dp.params, dp.offsets)}
+    order = sorted(dp.params, key=lambda p: off[id(p)])
+    assert all(off[id(p)] % 64 == 0 for p in order)
+    for p, q in zip(order, order[1:]):
+        room = off[id(q)] - off[id(p)]
+        want = 16 * 16 if p is m.a.weight else p.numel()
+        assert room == (want + 63) // 64 * 64, (tuple(p.shape), room)
+    for n, p in m.named_parameters():
+        assert torch.equal(p.detach(), ref[n]) and p.data_ptr() == dp.flat_param[off[id(p)]:].data_ptr()
+        assert p.grad.data_ptr() == dp.flat_grad[off[id(p)]:].data_ptr() and p.grad.shape == p.shape
+    o = off[id(m.a.weight)]
+    assert not dp.flat_param[o + 11 * 16:o + 16 * 16].any()
+    dp.zero_grad()
+    m(torch.randn(5, 16)).backward()
+    assert m.a.weight.grad.abs().sum() > 0 and not dp.flat_grad[o + 11 * 16:o + 16 * 16].any()
+    assert dp.packed_grads().numel() == sum(p.numel() for p in m.parameters())
