@@ -507,10 +507,13 @@ int32_t otr_ctc_loss(const float* log_probs, const int64_t* targets, int64_t ldt
  *      seeded its backward pass with that device scalar); the update divides it out, HALVES it and skips the update when
  *      the gradient norm is not finite, and doubles it after state[9] consecutive finite updates (0 = never) -- all on
  *      the device, so the step stays hipGraph-replayable.  grad_noise_std > 0 adds N(0, std) to every gradient element
- *      after clipping (trainer.py:223-227; pass train.grad_noise / accum_steps).  noam_warmup <= 0 selects base_lr. */
+ *      after clipping (trainer.py:223-227; pass train.grad_noise / accum_steps) -- except where gradient AND parameter are
+ *      exactly zero (padding cells of the flat buffers stay zero).  noam_warmup <= 0 selects base_lr.  All arguments are
+ *      checked before the first launch: a refused call leaves the device state untouched. */
 #define OTR_OPT_STATE_FLOATS 528
 int32_t otr_optimizer_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                           float* state, void* param_bf16 /* NULL or 16-bit shadow[n] refreshed in the same pass */,
+                           float* state, int32_t state_floats /* floats the caller allocated for `state`: refused below OTR_OPT_STATE_FLOATS */,
+                           void* param_bf16 /* NULL or 16-bit shadow[n] refreshed in the same pass */,
                            float base_lr, float beta1, float beta2, float eps, float weight_decay,
                            float grad_scale, float clip_norm, float noam_model_size, float noam_warmup,
                            float noam_factor, float noam_step_offset, float grad_noise_std, void* stream);

@@ -14,6 +14,7 @@ LIB_PATHS = {'bf16': os.path.join(_LIB_DIR, 'libotrans_hip.so'), 'fp16': os.path
 LIB_PATH = LIB_PATHS['bf16']
 
 OTR_F32, OTR_BF16, OTR_F16 = 0, 1, 2
+OTR_OPT_STATE_FLOATS = 528      # include/otrans_hip.h: floats of otr_optimizer_step's device state block
 ACT_NONE, ACT_RELU = 0, 1
 
 
@@ -160,7 +161,7 @@ SIGNATURES = {
     'otr_dec_cross_bwd': [C.POINTER(DecLnB), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _I32, _P, _P, _P],
     'otr_dec_self_bwd': [C.POINTER(DecLnB), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_dec_sum': [_P, _P, _I32, _I64, _P, _P],
-    'otr_optimizer_step': [_P, _P, _P, _P, _I64, _P, _P] + [_F32] * 12 + [_P],
+    'otr_optimizer_step': [_P, _P, _P, _P, _I64, _P, _I32, _P] + [_F32] * 12 + [_P],
     'otr_allreduce_unique_id': [_P],
     'otr_allreduce_init': [C.POINTER(C.c_void_p), _P, _I32, _I32],
     'otr_allreduce_run': [_P, _P, _I64, _I32, _P],

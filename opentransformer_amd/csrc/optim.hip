@@ -113,8 +113,12 @@ __device__ __forceinline__ float otr_gauss(uint64_t seed, uint64_t idx) {
 // One element of the update (torch.optim.Adam with L2 weight decay, train/trainer.py:221-234)
 __device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& vi, int64_t i, float coef, float wd, float beta1, float beta2,
                                          float step_size, float rbc2, float eps, float noise_std, uint64_t nseed) {
+  // Cells where BOTH the gradient and the parameter are exactly zero are structural padding of the flat buffers (alignment gaps, the
+  // extra rows of a row-padded Linear: include/otrans_hip.h): they get no noise, so they stay zero -- the invariant the padded
+  // GEMMs rely on.  (A real parameter that is exactly 0 with an exactly 0 gradient is skipped too: measure zero.)
+  const bool pad = gi == 0.f && pi == 0.f;
   gi *= coef;
-  if (noise_std > 0.f) gi += noise_std * otr_gauss(nseed, (uint64_t)i);   // added after clipping, as the reference does
+  if (noise_std > 0.f && !pad) gi += noise_std * otr_gauss(nseed, (uint64_t)i);   // added after clipping, as the reference does
   gi += wd * pi;
   mi = beta1 * mi + (1.f - beta1) * gi;
   vi = beta2 * vi + (1.f - beta2) * gi * gi;
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
 }
 
 extern "C" int32_t otr_optimizer_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                                      float* state, void* param_bf16, float base_lr, float beta1, float beta2, float eps,
+                                      float* state, int32_t state_floats, void* param_bf16, float base_lr, float beta1, float beta2, float eps,
                                       float weight_decay, float grad_scale, float clip_norm, float noam_model_size,
                                       float noam_warmup, float noam_factor, float noam_step_offset, float grad_noise_std,
                                       void* stream) {
@@ -168,6 +172,12 @@ extern "C" int32_t otr_optimizer_step(float* param, const float* grad, float* ex
   OTR_REQUIRE(n > 0, "optimizer_step: empty parameter buffer");
   OTR_REQUIRE(grad_noise_std >= 0.f, "optimizer_step: grad_noise_std must be >= 0");
   OTR_REQUIRE((uintptr_t)grad % 16 == 0, "optimizer_step: grad buffer must be 16-byte aligned");
+  // every argument check sits in front of the FIRST launch: a refused call must not have advanced the device state (step count,
+  // loss scale, the consumed fault word) without applying an update
+  OTR_REQUIRE(state_floats >= OTR_OPT_STATE_FLOATS, "optimizer_step: the state block must hold OTR_OPT_STATE_FLOATS floats "
+              "(the gradient-norm partial sums live behind the 16 state slots)");
+  OTR_REQUIRE(((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0 && (!param_bf16 || (uintptr_t)param_bf16 % 8 == 0),
+              "optimizer_step: parameter / moment buffers must be 16-byte aligned (the 16-bit shadow 8-byte)");
   hipStream_t s = (hipStream_t)stream;
   OptState* st = reinterpret_cast<OptState*>(state);
   // <= 512 workgroups, each leaves ONE partial sum in the state block (no atomics: the sum order is fixed, see OptState)
@@ -176,8 +186,6 @@ extern "C" int32_t otr_optimizer_step(float* param, const float* grad, float* ex
   hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(256), 0, s, grad, n, st);
   hipLaunchKernelGGL(opt_tick_kernel, dim3(1), dim3(64), 0, s, st, base_lr, noam_model_size, noam_warmup, noam_factor,
                      noam_step_offset, beta1, beta2, grad_scale, g_otr_fault, (int)grid);
-  OTR_REQUIRE(((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0 && (!param_bf16 || (uintptr_t)param_bf16 % 8 == 0),
-              "optimizer_step: parameter / moment buffers must be 16-byte aligned (the 16-bit shadow 8-byte)");
   unsigned g2 = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256);
   if (g2 < 1) g2 = 1;
   hipLaunchKernelGGL(adam_kernel, dim3(g2), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, st, (bf16_t*)param_bf16, beta1, beta2, eps,

@@ -10,6 +10,7 @@ folded into the clip/Adam step.
 The engine is model-agnostic host logic (it only touches .grad/.data of nn.Parameters), so the
 gloo/CPU tests in tests/test_dp.py exercise exactly this code with world_size 2.
 """
+import contextlib
 import ctypes as C
 
 import torch
@@ -191,9 +192,10 @@ class FlatDataParallel:
         if dev.type == 'cuda':
             from . import ops
             ops.defer_weight_grads(True)    # weight / bias gradients run as grouped launches at the end of backward
+        self._accumulating = False                  # inside no_sync(): backward passes accumulate, no collective may start
         if self.early_end > 0:
             from . import ops
-            ops.set_early_callback(self._on_early_ready)
+            ops.set_early_callback(self._on_early_mark, modules=list(module.modules()))
 
     def _build_ffn_packs(self, module, dev):
         """Fragment-major copies of every GLU FFN's weights for the row-block fused FFN kernels (ops.FfnLnFn): one flat
@@ -292,9 +294,21 @@ class FlatDataParallel:
                                'gradient buffer (was module.zero_grad() / optimizer.zero_grad(set_to_none=True) called?). '
                                'Use FlatDataParallel.zero_grad().' % (tuple(p.shape),))
 
+    def _join_early(self):
+        """wait for an early collective that is still in flight (work handle + side stream) and forget it"""
+        st, self._early_state = self._early_state, None
+        if st is not None:
+            work, _ = st
+            if work is not None:
+                work.wait()
+            if self._side is not None:
+                torch.cuda.current_stream().wait_stream(self._side)
+
     def zero_grad(self):
         self._check_grad_views(reinstall=True)      # a view dropped by set_to_none is put back; a foreign .grad raises
-        self._early_state = None
+        # a step that is abandoned (NaN loss -> zero_grad without all_reduce_gradients) may still have the early group's collective
+        # in flight on the side stream: zeroing the buffer under it would race (ADVICE r04)
+        self._join_early()
         self._grad_store.zero_()
         if self.flat_grad.is_cuda:
             from . import ops
@@ -342,7 +356,7 @@ class FlatDataParallel:
 
     def _reduce_slice(self, lo, hi, stream=None):
         """in-place sum over ranks of _grad_store[lo:hi] (through the 16-bit payload if configured); returns a work handle or None"""
-        buf = self._grad_store[lo:hi]
+        buf, pay = self._grad_store[lo:hi], None
         if self.grad_comm_dtype is not None:
             if self._payload is None:
                 self._payload = torch.empty_like(self._grad_store, dtype=self.grad_comm_dtype)
@@ -356,11 +370,34 @@ class FlatDataParallel:
                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'otr_allreduce_run')
         elif self.world_size > 1:
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        return work, (buf if buf is not self._grad_store[lo:hi] and self.grad_comm_dtype is not None else None)
+        return work, (pay if self.grad_comm_dtype is not None else None)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation (the reference's accum_steps, train/trainer.py:206-221): wrap every backward pass of a step EXCEPT
+        the last one.  Inside, the gradients accumulate in the flat buffer and the early group's all-reduce does not start; the
+        last backward (outside) starts it.  A backward pass that crosses the mark AFTER the early collective of this step has
+        started would write into a buffer that is being reduced: that raises instead of racing."""
+        was, self._accumulating = self._accumulating, True
+        try:
+            yield self
+        finally:
+            self._accumulating = was
+
+    def _on_early_mark(self):
+        """ops.EarlyMarkFn's callback: the backward pass crossed the mark"""
+        if self._accumulating or self.early_end <= 0 or self.skip_collectives or self.world_size <= 1:
+            return
+        if self._early_state is not None:
+            raise RuntimeError('FlatDataParallel: a backward pass crossed ops.early_mark after the early group\'s all-reduce of this step '
+                               'had started (gradient accumulation / a second backward()).  Its gradients would be written into a '
+                               'buffer that is being reduced.  Wrap every backward pass of the step except the last in dp.no_sync().')
+        self._on_early_ready()
 
     def _on_early_ready(self, force=False):
-        """called from inside the backward pass (ops.EarlyMarkFn) once the early group's gradients are final and their deferred
-        weight-gradient launches are queued on the compute stream: start their all-reduce on a side stream"""
+        """called once per step, when the early group's gradients are final and their deferred weight-gradient launches are queued on
+        the compute stream (from inside the LAST backward pass: _on_early_mark; or by hand: start_early_reduce): start their
+        all-reduce on a side stream"""
         if self.early_end <= 0 or self._early_state is not None or not (self.world_size > 1 or force) or self.skip_collectives:
             return
         if torch.cuda.is_available() and self._grad_store.is_cuda and torch.cuda.is_current_stream_capturing():
@@ -470,9 +507,10 @@ class FusedAdam:
         self.exp_avg = torch.zeros_like(dp.flat_param)
         self.exp_avg_sq = torch.zeros_like(dp.flat_param)
         # include/otrans_hip.h: f32[OTR_OPT_STATE_FLOATS]; [0..15] is the state proper, the rest the norm kernel's scratch
-        self._state_store = torch.zeros(528, dtype=torch.float32, device=dp.flat_param.device)
+        self._state_store = torch.zeros(L.OTR_OPT_STATE_FLOATS, dtype=torch.float32, device=dp.flat_param.device)
         self.state = self._state_store[:16]
         self.grad_noise = float(grad_noise)
+        self.step_offset = 2.0          # Noam step of update t+1 = t + 1 + step_offset (scheduler.py:16-53); load_state_dict may move it
         if dp.flat_param.is_cuda:
             from . import ops
             ops.fault_counter(dp.flat_param.device)     # the update skips when a spin-bounded kernel of the step gave up
@@ -496,11 +534,11 @@ class FusedAdam:
         ret = L.load().otr_optimizer_step(
             C.c_void_p(self.dp.flat_param.data_ptr()), C.c_void_p(self.dp.flat_grad.data_ptr()),
             C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()), n,
-            C.c_void_p(self.state.data_ptr()),
+            C.c_void_p(self.state.data_ptr()), self._state_store.numel(),
             C.c_void_p(self.dp.flat_param_lp.data_ptr()) if self.dp.flat_param_lp is not None else None,
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
             grad_scale, self.clip, float(nm.get('model_size', 1.0)), float(nm.get('warmup_steps', 0.0)),
-            float(nm.get('factor', 1.0)), 2.0,   # scheduler.py:41-53: the first update sees global_step 3
+            float(nm.get('factor', 1.0)), self.step_offset,   # scheduler.py:41-53: the first update sees global_step 3
             self.grad_noise,
             C.c_void_p(torch.cuda.current_stream().cuda_stream))
         L.check(ret, 'otr_optimizer_step')
@@ -516,7 +554,7 @@ class FusedAdam:
     def global_step(self):
         """the reference scheduler's global_step after the updates applied so far (scheduler.py:16-53: it starts at 1, the stepwise
         initial_lr() advances it once, every update once more -- the first update computes its lr at 3)"""
-        return int(self.state[0].item()) + 2
+        return int(self.state[0].item() + self.step_offset)
 
     def state_dict(self):
         st = self.state.tolist()
@@ -530,11 +568,14 @@ class FusedAdam:
                  'amsgrad': False, 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
                  'params': list(range(len(self.dp.params)))}
         return {'state': state, 'param_groups': [group],
-                'otr': {'state_block': self.state.detach().cpu().clone(), 'global_step': int(st[0]) + 2}}
+                'otr': {'state_block': self.state.detach().cpu().clone(), 'global_step': int(st[0] + self.step_offset)}}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, global_step=None):
         """accepts state_dict() of this class or of the torch.optim.Adam the reference trains with; moments are copied into the flat
-        buffers, the update count (Adam's t and the Noam step) is taken from the per-parameter 'step' entries"""
+        buffers, Adam's update count t is taken from the per-parameter 'step' entries.
+        global_step: the reference checkpoint's separate scheduler counter (train/trainer.py:284 'global_step', run.py:59-60); it
+        legitimately differs from t + 2 after --from_step or a mismatched resume.  Given (or found under sd['otr']), the Noam step
+        of the next update is global_step + 1 instead of t + 3: the difference is kept in `self.step_offset`."""
         state, groups = sd['state'], sd['param_groups']
         order = [i for g in groups for i in g['params']]
         if len(order) != len(self.dp.params):
@@ -564,6 +605,11 @@ class FusedAdam:
         b1, b2 = self.betas
         self.state[0] = t
         self.state[1] = float(g0.get('lr', self.lr))
+        if self.noam is None:               # constant-lr runs: the checkpoint's lr IS the lr of the next update
+            self.lr = float(g0.get('lr', self.lr))
+        if global_step is None:
+            global_step = sd.get('otr', {}).get('global_step')
+        self.step_offset = 2.0 if global_step is None else float(global_step) - t
         self.state[2] = 1.0 - b1 ** t
         self.state[3] = 1.0 - b2 ** t
 

@@ -66,7 +66,7 @@ class SpeechToText(nn.Module):
         truth, truth_length = targets['targets'], targets['targets_length']
         enc_inputs, enc_mask = self.frontend(enc_inputs, enc_mask)
         memory, memory_mask, _ = self.encoder(enc_inputs, enc_mask)
-        memory = ops.early_mark(memory)       # everything behind this point finishes its backward before the encoder's starts (dp.py)
+        memory = ops.early_mark(memory, self) # everything behind this point finishes its backward before the encoder's starts (dp.py)
         shifted = torch.stack((truth[:, :-1], truth[:, 1:]))     # decoder input | loss target (speech2text.py:53,57 clones each) in one launch
         logits, _ = self.decoder(shifted[0], memory, memory_mask)
         target_out = shifted[1]

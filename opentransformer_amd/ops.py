@@ -307,9 +307,17 @@ def padded_rows(w, b=None):
     return pw, pb
 
 
-# gradient buffers whose columns behind the logical width are known to be zero (written by the loss kernel that made them):
-# data_ptr -> (rows, width8).  LinearFn.backward widens exactly these to their padded width.
-_zero_tailed = {}
+# Gradient buffers whose columns behind the logical width are known to be zero (written by the loss kernel that made them) carry
+# that fact ON the buffer: `_otr_zero_tail = (rows, width8)` on the padded [rows, width8] tensor whose head the gradient is a view
+# of.  LinearFn.backward widens exactly these -- found through `dy._base` -- to their padded width.  (Not a process-wide map keyed
+# by data_ptr: a recycled allocation with the same address would have been read at the padded width with an unverified tail, and
+# two models trained in one process cleared each other's entries: ADVICE r04.)
+def _zero_tail_of(t):
+    base = t._base if t._base is not None else t
+    tail = getattr(base, '_otr_zero_tail', None)
+    if tail is None or base.data_ptr() != t.data_ptr() or tuple(base.shape) != tuple(tail):
+        return None
+    return tail
 
 
 def regrouped_lp(w, shape):
@@ -568,26 +576,39 @@ def flush_weight_grads():
 # model marks the point on the encoder output: every autograd node created after the mark (decoder, embedding, heads) has a higher
 # sequence number than the mark, so the engine runs their backward first; the mark's backward then (i) launches the weight / bias
 # gradients queued so far -- all of them belong to modules behind the mark -- and (ii) tells the engine.
-def set_early_callback(fn):
-    """fn: a bound method (kept by weak reference) or None"""
+def set_early_callback(fn, modules=None):
+    """fn: a bound method (kept by weak reference) or None.  `modules`: the modules of the engine that registers -- the callback is
+    stored ON them (`_otr_early_cb`), and a mark placed with `early_mark(x, owner)` resolves it through its owner, so two engines
+    in one process (an ASR model and an LM) each get their own marks.  The process-wide slot written as well is only the fallback
+    of marks placed WITHOUT an owner: it belongs to whichever engine registered last."""
     import weakref
-    _state['early_cb'] = weakref.WeakMethod(fn) if fn is not None else None
+    ref = weakref.WeakMethod(fn) if fn is not None else None
+    _state['early_cb'] = ref
+    for m in (modules or []):
+        object.__setattr__(m, '_otr_early_cb', ref)
+
+
+def _early_cb_of(owner):
+    if owner is not None:                    # a model without an engine of its own never borrows another model's
+        return getattr(owner, '_otr_early_cb', None)
+    return _state.get('early_cb')
 
 
 class EarlyMarkFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, ref):
+        ctx.cb_ref = ref                     # the engine of the model that placed THIS mark (resolved at forward time)
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
-        ref = _state.get('early_cb')
+        ref = ctx.cb_ref
         cb = ref() if ref is not None else None          # a weak reference: a dead engine leaves nothing behind
         if cb is not None:
             if _wq['w'] or _wq['b']:
                 flush_weight_grads()         # re-arms itself at the next enqueue (the encoder's items)
             cb()
-        return g
+        return g, None
 
 
 def set_stage_split(on):
@@ -618,8 +639,9 @@ def check_no_pending_stages(who):
                            'dp.backward_staged(loss) (or ops.take_stages() + x.backward(leaf.grad)), or switch the split off' % (who, len(st)))
 
 
-def early_mark(x):
-    """identity; see EarlyMarkFn (keeps the 16-bit twin of x).  In stage-split mode: a graph cut (set_stage_split)."""
+def early_mark(x, owner=None):
+    """identity; see EarlyMarkFn (keeps the 16-bit twin of x).  In stage-split mode: a graph cut (set_stage_split).
+    owner: the module that places the mark (the model); its engine's callback fires in backward, nobody else's."""
     if _state.get('stage_split') and x.requires_grad and torch.is_grad_enabled():
         x = materialize(x)
         leaf = x.detach().requires_grad_(True)
@@ -628,9 +650,10 @@ def early_mark(x):
             setattr(leaf, _LP_ATTR, lp)
         _state['stages'].append((x, leaf))
         return leaf
-    if _state.get('early_cb') is None or not x.requires_grad or not torch.is_grad_enabled():
+    ref = _early_cb_of(owner)
+    if ref is None or not x.requires_grad or not torch.is_grad_enabled():
         return x
-    y = EarlyMarkFn.apply(x)
+    y = EarlyMarkFn.apply(x, ref)
     lp = getattr(x, _LP_ATTR, None)
     if lp is not None:
         setattr(y, _LP_ATTR, lp)
@@ -880,7 +903,7 @@ class LinearFn(torch.autograd.Function):
             # kernel wrote it that way), all three GEMMs of this layer run on the padded operands
             pw, pb = ctx.pad
             N8 = pw['param'].shape[0]
-            tail = _zero_tailed.pop(dy2.data_ptr(), None)
+            tail = _zero_tail_of(dy2)
             if (tail == (dy2.shape[0], N8) and dy2.dim() == 2 and dy2.stride() == (N8, 1) and dy2.dtype == torch.float32
                     and dy2.data_ptr() % 16 == 0):
                 dyp = dy2.as_strided((dy2.shape[0], N8), (N8, 1))
@@ -2663,7 +2686,6 @@ class LabelSmoothingLossFn(torch.autograd.Function):
         scratch = torch.empty((R + 2,), dtype=torch.float32, device=lg.device)
         L.check(L.load().otr_label_smoothing_loss_ld(_p(lg), ld, _p(tg), R, V, smoothing, pad_idx, _p(loss), _p(dlogits), ld,
                                                      _p(scratch), _stream()), 'otr_label_smoothing_loss_ld')
-        _zero_tailed.clear()
         ctx.save_for_backward(dlogits)
         ctx.shape, ctx.V = logits.shape, V
         return loss
@@ -2675,7 +2697,7 @@ class LabelSmoothingLossFn(torch.autograd.Function):
         g = g.contiguous().float()
         L.check(L.load().otr_scale(_p(dlogits), _p(out), dlogits.numel(), _p(g), 1.0, _stream()), 'otr_scale')
         if out.shape[1] != ctx.V:
-            _zero_tailed[out.data_ptr()] = tuple(out.shape)        # LinearFn.backward may read it at its full width
+            out._otr_zero_tail = tuple(out.shape)                  # LinearFn.backward may read it at its full width (_zero_tail_of)
             out = out[:, :ctx.V]
         return out.view(ctx.shape), None, None, None
 

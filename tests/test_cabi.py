@@ -40,6 +40,21 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.otr_add_layernorm_fwd(C.byref(ln), None, None, None, None, None, None, None, None, None, None, None) < 0
 
 
+def test_optimizer_step_validates_before_it_launches():
+    """every check of otr_optimizer_step sits in front of its first launch (a refused call must not advance the device
+    state), and a caller that allocated the old 16-float state block is refused instead of being written out of bounds"""
+    lib = _lib.load()
+    al, odd = C.c_void_p(4096), C.c_void_p(4096 + 4)
+
+    def call(param=al, grad=al, m=al, v=al, state_floats=_lib.OTR_OPT_STATE_FLOATS, lp=None, noise=0.0):
+        return lib.otr_optimizer_step(param, grad, m, v, 1024, al, state_floats, lp, 1e-3, 0.9, 0.98, 1e-9, 0.0, 1.0, 5.0, 256.0, 100.0,
+                                      1.0, 2.0, noise, None)
+    assert call(state_floats=16) < 0 and b'OTR_OPT_STATE_FLOATS' in lib.otr_last_error_string()
+    assert call(param=odd) < 0 and b'aligned' in lib.otr_last_error_string()
+    assert call(m=odd) < 0 and call(grad=odd) < 0 and call(lp=C.c_void_p(4096 + 2)) < 0
+    assert call(noise=-1.0) < 0
+
+
 def test_argument_errors_of_the_fused_and_grouped_entries():
     """the entries added for fusion / grouping / decoding validate before they launch (no GPU here)"""
     lib = _lib.load()

@@ -218,6 +218,19 @@ def test_fused_adam_state_dict_is_torch_adams_layout():
     opt2 = FusedAdam(FlatDataParallel(Tiny()), lr=1e-3)
     opt2.load_state_dict(sd)                                     # own round trip incl. the extra state block
     assert torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.state, opt.state)
+    # the reference checkpoint's scheduler counter ('global_step', trainer.py:284) is separate from Adam's t
+    opt3 = FusedAdam(FlatDataParallel(Tiny()), lr=1e-3)
+    opt3.load_state_dict(adam.state_dict(), global_step=100)     # e.g. resumed with --from_step
+    assert float(opt3.state[0]) == 3.0 and opt3.global_step == 100 and opt3.step_offset == 97.0
+    assert opt3.state_dict()['otr']['global_step'] == 100
+    opt4 = FusedAdam(FlatDataParallel(Tiny()), lr=1e-3)
+    opt4.load_state_dict(opt3.state_dict())                      # ... and it survives the own round trip
+    assert opt4.global_step == 100
+    sd_c = adam.state_dict()
+    sd_c['param_groups'][0]['lr'] = 0.25
+    opt5 = FusedAdam(FlatDataParallel(Tiny()), lr=1e-3, noam=None)
+    opt5.load_state_dict(sd_c)
+    assert opt5.lr == 0.25                                       # constant-lr run: the next tick must not fall back to the constructor lr
     with pytest.raises(ValueError):
         bad = adam.state_dict()
         bad['param_groups'][0]['params'] = bad['param_groups'][0]['params'][:-1]
@@ -230,7 +243,7 @@ class TinySplit(Tiny):
     def forward(self, tok, tgt):
         from opentransformer_amd import ops
         h = torch.relu(self.l1(self.emb(tok)))
-        h = ops.early_mark(h)
+        h = ops.early_mark(h, self)
         logits = self.out(h) + self.out2(self.emb(tok))
         keep = tgt != 0
         nll = torch.nn.functional.cross_entropy(logits.view(-1, 11), tgt.view(-1), reduction='none')
@@ -272,6 +285,71 @@ def _split_worker(rank, world, port, out, payload):
         torch.save(res, out)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _accum_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    tok, tgt = _data()
+    res = {}
+    from opentransformer_amd import ops
+    micro = [slice(rank * 4, rank * 4 + 2), slice(rank * 4 + 2, rank * 4 + 4)]
+    for name, early in (('single', False), ('split', True)):
+        model = TinySplit()
+        dp = FlatDataParallel(model, early_modules=[model.out] if early else None)
+        dp.zero_grad()
+        with dp.no_sync():                                   # every backward pass of the step except the last
+            dp(tok[micro[0]], tgt[micro[0]]).backward()
+            res[name + '_issued_inside_no_sync'] = dp._early_state is not None
+        dp(tok[micro[1]], tgt[micro[1]]).backward()
+        res[name + '_issued_by_last'] = dp._early_state is not None
+        scale, _ = dp.all_reduce_gradients()
+        res[name] = (dp.packed_grads() * scale).clone()
+        if early:
+            # a further backward pass of a step whose early collective has started would write into the buffer that is being
+            # reduced: refused, not raced (its own step here: the refused pass leaves the head's gradients half accumulated)
+            dp.zero_grad()
+            dp(tok[micro[0]], tgt[micro[0]]).backward()
+            try:
+                dp(tok[micro[1]], tgt[micro[1]]).backward()
+                res['second_backward'] = 'ran'
+            except RuntimeError as e:
+                res['second_backward'] = 'refused' if 'no_sync' in str(e) else repr(e)
+            dp.all_reduce_gradients()
+        # an abandoned step: the early collective is in flight, zero_grad() joins it before it clears the buffer
+        if early:
+            dp.zero_grad()
+            dp(tok[micro[1]], tgt[micro[1]]).backward()
+            assert dp._early_state is not None
+            dp.zero_grad()
+            res['abandoned_left'] = (dp._early_state is not None, float(dp._grad_store.abs().sum()))
+    # two engines in one process (an ASR model and an LM): each mark fires ITS engine
+    a, b = TinySplit(), TinySplit()
+    dpa, dpb = FlatDataParallel(a, early_modules=[a.out]), FlatDataParallel(b, early_modules=[b.out])   # b registered last
+    dpa.zero_grad(); dpb.zero_grad()
+    dpa(tok[micro[0]], tgt[micro[0]]).backward()
+    res['two_engines'] = (dpa._early_state is not None, dpb._early_state is not None)
+    dpa.all_reduce_gradients(); dpb.all_reduce_gradients()
+    ops.set_early_callback(None)
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_early_group_with_gradient_accumulation_and_two_engines(tmp_path):
+    """ADVICE r04 (dp.py early reduce): (1) with accumulation the early collective starts in the LAST backward pass only
+    (dp.no_sync() around the others) and a backward pass after it has started is refused; (2) the callback belongs to the model
+    that placed the mark, not to the engine that registered last; (3) zero_grad() joins a collective still in flight."""
+    out = str(tmp_path / 'r0.pt')
+    mp.spawn(_accum_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert not got['split_issued_inside_no_sync'] and got['split_issued_by_last'] and not got['single_issued_by_last']
+    assert got['second_backward'] == 'refused', got['second_backward']
+    torch.testing.assert_close(got['split'], got['single'], rtol=0, atol=0)
+    assert got['abandoned_left'] == (False, 0.0)
+    assert got['two_engines'] == (True, False)
 
 
 @pytest.mark.parametrize('payload', [None, torch.bfloat16])

@@ -15,8 +15,16 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from tests import helpers as H
+
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
+
+# gradients allowed over the flat bound tg, by name pattern, each with its own bound per mode and the reason (none needed so far:
+# the cases that used to fall back to 'as far off as the unfused HIP path' were the key-bias slices, now measured apart)
+OVER_TG = {}
+# residue the 16-bit paths leave in the analytically-zero key-bias gradient, relative to the live slices of the same bias
+KEY_RESIDUE = {'fp16': 6e-2, 'bf16': 2.4e-1}
 
 
 def rel(a, b):
@@ -131,12 +139,18 @@ def test_fused_decoder_matches_fp32_torch(mode, B, Lq, T, nl, dff):
         assert rel(got, ref) < ty, rel(got, ref)
         assert row_rel(got, ref) < 8 * ty, row_rel(got, ref)             # no single (utterance, position) is off
         names = ['memory'] + [n for n, _ in dec.named_parameters()]
-        errs = {n: rel(a, b) for n, a, b in zip(names, ggot, gref) if float(b.norm()) > 1e-6}
+        # no tensor is judged against the HIP path itself any more.  The key-bias slices (zero in exact arithmetic)
+        # are measured apart (tests/helpers.py: key_aware_grad_errors); every other gradient meets the flat bound tg, except the
+        # tensors NAMED in OVER_TG with their own measured bound
+        errs, key_errs = H.key_aware_grad_errors(names, ggot, gref)
         worst = max((e, n) for n, e in errs.items())
-        if worst[0] >= tg:       # 16-bit rounding of P / dS can exceed the flat bound on one tensor: then the per-operator HIP path, which
-            old, gold = run_hip(dec, tokens, memory, key_mask, gy, fused=False)      # rounds at the same places, must be as far off
-            eold = {n: rel(a, b) for n, a, b in zip(names, gold, gref) if float(b.norm()) > 1e-6}
-            assert worst[0] < 1.5 * eold[worst[1]] and worst[0] < 3 * tg, (worst, eold[worst[1]])
+        over = {n: e for n, e in errs.items() if e >= tg}
+        H.log_tolerance_cases('decoder_fused', {'mode': mode, 'shape': [B, Lq, T, nl, dff], 'tg': tg, 'worst': worst, 'over_tg': over,
+                                                'key_bias_residue': key_errs})
+        for n, e in over.items():
+            bound = next((b for pat, b in OVER_TG.items() if pat in n), None)
+            assert bound is not None and e < bound[mode], ('gradient over the flat bound and not a named exception', n, e, tg)
+        assert all(e < KEY_RESIDUE[mode] for e in key_errs.values()), key_errs
         print('decoder parity', mode, (B, Lq, T), 'logits %.2e rows %.2e worst grad %.2e %s' % (rel(got, ref), row_rel(got, ref), worst[0], worst[1]))
         # keys beyond an utterance's length receive no gradient
         assert float(ggot[0][~key_mask].abs().max()) < 1e-3 * float(ggot[0].abs().max())

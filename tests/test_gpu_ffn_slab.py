@@ -15,6 +15,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from tests import helpers as H
+
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
@@ -132,12 +134,15 @@ def test_slab_mode_matches_fp32_torch(mode):
         ty, tg = (2e-3, 2e-2) if mode == 'fp16' else (1.5e-2, 8e-2)
         assert rel(got, ref) < ty, rel(got, ref)
         names = ['x'] + [n for n, _ in enc.named_parameters()]
-        errs = {n: rel(u, v) for n, u, v in zip(names, ggot, gref) if float(v.norm()) > 1e-6}
+        # the key third of the q|k|v bias gradient is zero in exact arithmetic and is measured apart
+        # (tests/helpers.py: key_aware_grad_errors); every other gradient meets the flat bound -- no comparison against the HIP
+        # path's own exchange form any more
+        errs, key_errs = H.key_aware_grad_errors(names, ggot, gref)
         worst = max((e, n) for n, e in errs.items())
-        if worst[0] >= tg:       # 16-bit rounding of P / dS can exceed the flat bound on one tensor (the q|k|v bias: its key third is
-            old, gold = run_hip(enc, x, mask, gy, slab=False)     # zero in exact arithmetic): the exchange form must be as far off
-            eold = {n: rel(u, v) for n, u, v in zip(names, gold, gref) if float(v.norm()) > 1e-6}
-            assert worst[0] < 1.5 * eold[worst[1]] and worst[0] < 3 * tg, (worst, eold[worst[1]])
+        over = {n: e for n, e in errs.items() if e >= tg}
+        H.log_tolerance_cases('ffn_slab', {'mode': mode, 'tg': tg, 'worst': worst, 'over_tg': over, 'key_bias_residue': key_errs})
+        assert not over, ('gradients over the flat bound', over, tg)
+        assert all(e < (6e-2 if mode == 'fp16' else 2.4e-1) for e in key_errs.values()), key_errs
         print('encoder slab parity', mode, 'out %.2e worst grad %.2e %s' % (rel(got, ref), worst[0], worst[1]))
     finally:
         ops.set_compute_dtype('bf16')

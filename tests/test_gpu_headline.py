@@ -205,12 +205,21 @@ def _beam_search_validity(orc, parts, cfg, inputs, lm, lm_weight, beam, trace, t
         prev = torch.full((R, 1), 1, dtype=torch.long)                        # BOS
         cum = torch.tensor([0.0] + [-float('inf')] * (beam - 1), dtype=torch.float64).repeat(B)
         worst_cut, worst_drift, min_margin = -float('inf'), 0.0, [float('inf')] * B
-        for pref, sc in trace:
-            pref, sc = pref.cpu(), sc.double().cpu()
+        for step, (pref, sc) in enumerate(trace):
+            pref, sc = pref.cpu(), sc.double().cpu().view(-1)
             lp = orc.decoder_inference(parts['decoder'], prev, bm, bmask, cfg['decoder'])
             if lm is not None:
                 lp = lp + lm_weight * orc.transformer_lm_predict(lm[0], lm[1], prev)
-            cand = (cum.view(R, 1) + lp.double()).view(B, -1)                  # every (beam, token) expansion of the product's beams
+            lp = lp.double()
+            if step > 0:
+                # finished beams (last token EOS; BOS shares the id, hence not at step 0) have ONE live branch: EOS at score 0
+                # (mask_finished_scores / mask_finished_preds, recognize/speech2text.py:156-192)
+                fin = prev[:, -1] == orc.EOS
+                if bool(fin.any()):
+                    lp = lp.clone()
+                    lp[fin] = -float('inf')
+                    lp[fin, orc.EOS] = 0.0
+            cand = (cum.view(R, 1) + lp).view(B, -1)                           # every (beam, token) expansion of the product's beams
             V = lp.size(1)
             top = torch.topk(cand, beam + 1, dim=-1).values
             new_cum = torch.empty(R, dtype=torch.float64)
@@ -220,7 +229,7 @@ def _beam_search_validity(orc, parts, cfg, inputs, lm, lm_weight, beam, trace, t
                 # carry identical scores)
                 par = [q for q in range(b * beam, (b + 1) * beam) if torch.equal(prev[q], pref[r, :-1]) and cum[q] > -float('inf')]
                 assert par, ('kept prefix does not extend a beam of the previous step', r)
-                new_cum[r] = max(float(cum[q] + lp[q, int(pref[r, -1])].double()) for q in par)
+                new_cum[r] = max(float(cum[q] + lp[q, int(pref[r, -1])]) for q in par)
                 worst_cut = max(worst_cut, float(top[b, beam - 1] - new_cum[r]))
                 worst_drift = max(worst_drift, abs(float(sc[r]) - float(new_cum[r])))
             for b in range(B):
@@ -296,12 +305,21 @@ def test_c5_full_size_decode_matches_oracle_beam_search(mode):
         ops.set_compute_dtype('bf16')
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'fp16'])
+# worst cumulative-score drift of the 16-bit modes over the 60-step search, x 2 (measured: profiles/r05_decode_eos_live_*.json)
+LIVE_EOS_TOL = {'fp16': 0.03, 'bf16': 0.25}
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'fp16', 'bf16'])
 def test_c5_full_size_decode_with_live_eos(mode):
     """the full-size C5 search with EOS LIVE -- beams finish at different steps (hypothesis lengths 0 .. 60 in one
     n-best list), so mask_finished_scores / mask_finished_preds (recognize/speech2text.py:156-192), the all-finished early exit
     (:117-118) and the length penalty over ragged lengths (:128-131) run at V = 4234 with LM fusion, B = 8 ragged utterances,
-    beam 10, max_len 60, against orc.beam_search.  The EOS logit gets +4 (random weights otherwise never emit it)."""
+    beam 10, max_len 60, against orc.beam_search.  The EOS logit gets +4 (random weights otherwise never emit it).
+    16-bit modes: no count of shared hypotheses is asserted -- a rounding flip of a near-tie deep in the search
+    reshuffles the tail of an n-best list without being wrong.  The product's per-step beams are REPLAYED on the oracle's scores
+    (_beam_search_validity, with the finished-beam masking): every kept candidate lies within 2 x tol of the oracle's cut at
+    that step, every cumulative score within tol of the oracle's, and the final (length-normalised) ranking agrees wherever the
+    oracle's own search never came closer than 2 x tol to a tie at a cut."""
     import opentransformer_amd as ota
     from opentransformer_amd import ops
     from opentransformer_amd.recognize import SpeechToTextRecognizer, TransformerLanguageModel
@@ -332,28 +350,38 @@ def test_c5_full_size_decode_with_live_eos(mode):
         for cache in (True, False) if mode == 'fp32' else (True,):
             rec = SpeechToTextRecognizer(model, apply_cache=cache, beam_width=beam, nbest=beam, max_len=max_len, penalty=0.6, lamda=5,
                                          lm=lm, lm_weight=0.1, idx2unit={i: str(i) for i in range(4234)})
+            rec.trace = rec_trace = []
             got_h, got_s = rec.recognize(inputs['inputs'].to(DEV), inputs['mask'].to(DEV))
             got_tok = [[[int(t) for t in s.split()] for s in utt] for utt in got_h]
             got_s = got_s.numpy()
             if mode == 'fp32':
                 assert got_tok == ref_h, cache
                 np.testing.assert_allclose(got_s, ref_s, rtol=2e-4, atol=2e-4)
+                if cache:      # the replay criterion itself, where the answer is known: an exact search is a valid search
+                    rep = _beam_search_validity(orc, parts, cfg, inputs, (lm_sd, lm_cfg), 0.1, beam, rec_trace, 1e-3)
+                    report.update(rep)
+                    assert rep['worst_kept_below_cut'] < 1e-3 and rep['worst_score_drift'] < 1e-3, rep
                 continue
-            tol = 0.03                                       # score drift of 16-bit operands over up to 60 steps (measured below)
-            drift, shared = 0.0, []
+            # tol: <= 2 x the measured worst cumulative-score drift over up to 60 steps (profiles/r05_decode_eos_live_*.json)
+            tol = LIVE_EOS_TOL[mode]
+            rep = _beam_search_validity(orc, parts, cfg, inputs, (lm_sd, lm_cfg), 0.1, beam, rec_trace, tol)
+            drift_final, shared = 0.0, []
             for b in range(B):
                 ref_map = {tuple(h): float(ref_s[b, n]) for n, h in enumerate(ref_h[b])}
                 assert got_tok[b][0] == ref_h[b][0] or ref_s[b, 0] - ref_s[b, 1] < 2 * tol, (b, got_tok[b][0], ref_h[b][0])
+                if rep['min_cut_margin'][b] > 2 * tol:     # no near-tie at any cut of this utterance's search: the same n-best set
+                    assert set(map(tuple, got_tok[b])) == set(ref_map), (mode, b)
                 n_sh = 0
                 for n, h in enumerate(got_tok[b]):
                     if tuple(h) in ref_map:
                         n_sh += 1
-                        drift = max(drift, abs(float(got_s[b, n]) - ref_map[tuple(h)]))
+                        drift_final = max(drift_final, abs(float(got_s[b, n]) - ref_map[tuple(h)]))
                 shared.append(n_sh)
-            report.update(worst_score_drift=drift, nbest_shared=shared,
+            report.update(rep, tol=tol, worst_final_score_drift=drift_final, nbest_shared=shared,
                           nbest_identical=[got_tok[b] == ref_h[b] for b in range(B)])
-            assert drift < tol, report
-            assert min(shared) >= 6, report                 # rounding may flip near-ties deep in the list, not reshuffle it
+            assert rep['worst_kept_below_cut'] < 2 * tol, report
+            assert rep['worst_score_drift'] < tol, report
+            assert drift_final < tol, report
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
         with open(os.path.join(ROOT, 'gpurun_out', 'decode_eos_live_%s.json' % mode), 'w') as f:
             json.dump(report, f, indent=1)

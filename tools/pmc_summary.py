@@ -7,8 +7,10 @@ launches, median duration, the counter sums per launch, and the derived figures
                    (what 2.5 PFLOP/s is quoted at); mfma_busy_of_sq_busy relates it to SQ_BUSY_CYCLES x 4 SIMDs x (CUs per SE)
   hbm_bytes      = 2 x FETCH_SIZE KB + WRITE_SIZE KB (FETCH_SIZE counts 128-byte requests at 64 bytes on gfx950 for wide loads)
 
-A kernel that is launched with several grid sizes (wgrad256_kernel: one launch per row count) gets one record per grid size,
-keyed "<kernel> [grid N]".
+A kernel that is launched with several grid sizes gets one record per grid size, keyed "<kernel> [grid N]"; launches of ONE
+grid whose durations fall into separate classes (wgrad256_kernel: the M = B x T' group and the decoder's M = 480 group run on
+the same persistent grid, 420 us against 47 us) get one record per class, keyed "<kernel> [grid N, duration class k: T us]",
+with the counters of exactly those dispatches (joined on dispatch_id).
 
 usage: pmc_summary.py OUT.json DIR [DIR ...]"""
 import glob
@@ -16,6 +18,8 @@ import json
 import re
 import sqlite3
 import sys
+
+CLASS_RATIO = 2.5     # launches of one (kernel, grid) whose durations differ by more than this are different problems
 
 
 def short(name):
@@ -53,44 +57,66 @@ def main():
             kc, cc = cols(db, 'kernels'), cols(db, 'counters_collection')
             schema_note = {'kernels': kc, 'counters_collection': cc}
             kg = grid_expr(kc)
+            if kg is None or 'dispatch_id' not in kc:
+                print('kernels view without grid / dispatch_id columns in', f)
+                continue
             try:
-                dur = db.execute("select name, %s, count(*), sum(end-start) from kernels group by 1, 2" % (kg or '0')).fetchall()
+                disp = db.execute("select dispatch_id, name, %s, end - start from kernels" % kg).fetchall()
             except Exception as e:                                         # noqa: BLE001
                 print('no kernel table in', f, e)
                 continue
-            tot = sum(r[3] for r in dur) or 1
-            for name, grid, n, t in dur:
-                k = res.setdefault((short(name), int(grid or 0)), {})
-                k.setdefault('launches', n)
-                k.setdefault('avg_us', t / n / 1e3)
-                k.setdefault('share_of_kernel_time', t / tot)
-            # counters keyed by (kernel, grid) as well: a kernel launched on two problem sizes (wgrad256_kernel: the M = 7968 group
-            # and the decoder's M = 480 group) must not have its FETCH / WRITE averaged over both
-            cg = grid_expr(cc)
+            # A kernel launched on several PROBLEM sizes with the SAME grid (wgrad256_kernel: the M = B x T' group and the decoder's
+            # M = 480 group both run on the persistent 256-workgroup grid) must not have its counters averaged over both
+            # (VERDICT r03 / r04): launches of one (kernel, grid) are split into duration classes -- sorted durations are cut where
+            # two neighbours differ by more than CLASS_RATIO -- and every record is keyed by (kernel, grid, class), class 0 = longest.
+            # The classes are formed per pass from that pass's own durations; the program is deterministic, so class k of the SQ
+            # pass and class k of the FETCH / WRITE passes are the same launches (the launch counts are compared below).
+            by_kg = {}
+            for did, name, grid, t in disp:
+                by_kg.setdefault((short(name), int(grid or 0)), []).append((t, did))
+            cls_of = {}
+            tot = sum(r[3] for r in disp) or 1
+            for (name, grid), lst in by_kg.items():
+                lst.sort(reverse=True)
+                c = 0
+                groups = [[lst[0]]]
+                for prev, cur in zip(lst, lst[1:]):
+                    if prev[0] > CLASS_RATIO * max(cur[0], 1):
+                        groups.append([])
+                    groups[-1].append(cur)
+                for c, g in enumerate(groups):
+                    k = res.setdefault((name, grid, c), {})
+                    n, t = len(g), sum(x[0] for x in g)
+                    if 'launches' in k and k['launches'] != n:
+                        k.setdefault('class_count_mismatch', []).append(n)
+                    k.setdefault('launches', n)
+                    k.setdefault('avg_us', t / n / 1e3)
+                    k.setdefault('share_of_kernel_time', t / tot)
+                    k.setdefault('n_classes', len(groups))
+                    for _, did in g:
+                        cls_of[did] = (name, grid, c)
             try:
-                if cg is not None:
-                    rows = db.execute("select kernel_name, %s, counter_name, count(distinct dispatch_id), sum(value) from "
-                                      "counters_collection group by 1, 2, 3" % cg).fetchall()
-                elif kg is not None and 'dispatch_id' in kc and 'dispatch_id' in cc:
-                    rows = db.execute("select c.kernel_name, %s, c.counter_name, count(distinct c.dispatch_id), sum(c.value) from "
-                                      "counters_collection c join kernels k on k.dispatch_id = c.dispatch_id group by 1, 2, 3"
-                                      % grid_expr(kc, 'k.')).fetchall()
-                else:
-                    rows = [(a, 0, b, c, d_) for a, b, c, d_ in db.execute(
-                        "select kernel_name, counter_name, count(distinct dispatch_id), sum(value) from counters_collection "
-                        "group by 1, 2").fetchall()]
+                rows = db.execute("select dispatch_id, counter_name, sum(value) from counters_collection group by 1, 2").fetchall()
             except Exception as e:                                         # noqa: BLE001
                 print('no counters in', f, e)
                 continue
-            for name, grid, c, nd, v in rows:
-                k = res.setdefault((short(name), int(grid or 0)), {})
-                k[c] = v / max(nd, 1)
-                k['dispatches_' + c] = nd
+            acc = {}
+            for did, cname, v in rows:
+                key = cls_of.get(did)
+                if key is None:
+                    continue
+                a = acc.setdefault((key, cname), [0.0, 0])
+                a[0] += v
+                a[1] += 1
+            for (key, cname), (v, nd) in acc.items():
+                k = res[key]
+                k[cname] = v / max(nd, 1)
+                k['dispatches_' + cname] = nd
     names = {}
-    for (name, grid) in res:
-        names.setdefault(name, set()).add(grid)
+    for (name, grid, c) in res:
+        names.setdefault(name, set()).add((grid, c))
     keep = {}
-    for (name, grid), k in res.items():
+    for (name, grid, c), k in res.items():
         if k.get('share_of_kernel_time', 0) < 0.004:
             continue
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in k and 'avg_us' in k:
@@ -100,7 +126,14 @@ def main():
         if 'FETCH_SIZE' in k and 'WRITE_SIZE' in k:
             k['hbm_bytes_per_launch'] = int(2 * k['FETCH_SIZE'] * 1024 + k['WRITE_SIZE'] * 1024)
         k['grid_work_items'] = grid
-        keep[name if len(names[name]) == 1 else '%s [grid %d]' % (name, grid)] = k
+        k['duration_class'] = c
+        if len(names[name]) == 1:
+            key = name
+        elif k.get('n_classes', 1) == 1:
+            key = '%s [grid %d]' % (name, grid)
+        else:
+            key = '%s [grid %d, duration class %d: %.0f us]' % (name, grid, c, k.get('avg_us', 0.0))
+        keep[key] = k
     keep = dict(sorted(keep.items(), key=lambda kv: -kv[1].get('share_of_kernel_time', 0)))
     keep['_schema'] = schema_note
     json.dump(keep, open(out, 'w'), indent=1)
