@@ -64,9 +64,12 @@ def parse():
     ap.add_argument('--no-extras', action='store_true', help='timed region only (profiler runs): no breakdown, no roofline, no bf16 line')
     ap.add_argument('--no-bf16-line', action='store_true', help='skip the secondary bf16 measurement of the same workload')
     ap.add_argument('--overlap', default='auto', choices=['auto', 'on', 'off'],
-                    help='staged step: the backward pass is cut at the encoder / decoder boundary into two hipGraphs, and between their '
-                         'replays the all-reduce of the decoder group (37 %% of the gradient bytes) starts on a side stream and runs '
-                         'beside the encoder backward; the collectives themselves are never captured.  auto = on when N > 1')
+                    help='off = ONE gradient all-reduce per step behind the backward pass (what north_star states; the form at N = 1).  '
+                         'on = staged step: the backward pass is cut at the encoder / decoder boundary into two hipGraphs, and between '
+                         'their replays the all-reduce of the decoder group (37 %% of the gradient bytes) starts on a side stream and runs '
+                         'beside the encoder backward; the collectives themselves are never captured.  auto (N > 1) = MEASURE both forms '
+                         'for a few untimed steps in this invocation and run the contract region on the faster one; off when N = 1')
+    ap.add_argument('--calib-steps', type=int, default=8, help='steps per form of the --overlap auto measurement (N > 1)')
     ap.add_argument('--opt-in-graph', default='on', choices=['on', 'off'],
                     help='N = 1: capture the optimizer launches in the step graph too (on) or issue them eagerly behind the replay (off)')
     ap.add_argument('--cpu-threads', type=int, default=0, help='torch threads of the CPU baseline (0 = best of 16 / 32 / 64)')
@@ -336,15 +339,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def build(mode):
-        """model + replica engine + optimizer + (captured) step of the workload in compute mode `mode`"""
+    def build(mode, overlap=False, payload=None):
+        """model + replica engine + optimizer + (captured) step of the workload in compute mode `mode`; overlap: the staged
+        two-collective step; payload: None = the fp32 gradient buffer travels, torch.bfloat16 = a 16-bit copy of it"""
         ops.set_compute_dtype(mode)
         model = ota.SpeechToText(cfg)
         syn.fill_state_dict_(model.state_dict(), 1234)           # identical replicas on every rank
         model = model.to(dev).train()
-        overlap = args.overlap == 'on' or (args.overlap == 'auto' and world > 1)
         ops.set_stage_split(overlap)
-        dp = FlatDataParallel(model, early_modules=([model.decoder] + ([model.assistor] if hasattr(model, 'assistor') else [])) if overlap else None)
+        dp = FlatDataParallel(model, early_modules=([model.decoder] + ([model.assistor] if hasattr(model, 'assistor') else [])) if overlap else None,
+                              grad_comm_dtype=payload)
         dp.broadcast_parameters()
         opt = FusedAdam(dp, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6, clip_grad=5.0,
                         noam=dict(model_size=cfg['encoder']['d_model'], warmup_steps=12000, factor=1.0))   # *_baseline.yaml train section
@@ -375,6 +379,7 @@ def main():
                 x.backward(leaf.grad)
 
         def fwd_bwd():
+            ops.set_stage_split(overlap)          # process-wide switch, read by the forward pass: several runs may be alive
             stage1()
             if overlap:
                 dp.start_early_reduce()
@@ -446,7 +451,22 @@ def main():
             el = float(t.item())
         return el
 
-    run = build(args.mode)
+    # N > 1: which form of the step?  `off` = the single collective north_star states; `on` = the staged two-collective step; `auto` =
+    # both are built and MEASURED here (a few untimed steps each, max over ranks, so every rank takes the same decision) and the
+    # contract region runs on the faster one.  N = 1: no collective, one graph.
+    forms = None
+    if world > 1 and args.overlap == 'auto':
+        cands = {'single_collective': build(args.mode, overlap=False), 'staged_two_collectives': build(args.mode, overlap=True)}
+        forms = {k: timed(r['step'], 3, args.calib_steps) / args.calib_steps * 1e3 for k, r in cands.items()}
+        chosen = min(forms, key=lambda k: forms[k])
+        run = cands.pop(chosen)
+        cands.clear()
+        torch.cuda.empty_cache()
+        forms = {'ms_per_step_calibration': forms, 'chosen': chosen, 'calib_steps': args.calib_steps,
+                 'note': 'both forms of the N > 1 step measured in this invocation before the contract region (untimed, max over ranks)'}
+    else:
+        run = build(args.mode, overlap=(args.overlap == 'on'))      # N = 1 / explicit choice; --overlap on at N = 1 is the A/B of DESIGN.md section 7
+    ops.set_stage_split(run['overlap'])
     dp, opt, fwd_bwd, step, graph, loss_buf = (run[k] for k in ('dp', 'opt', 'fwd_bwd', 'step', 'graph', 'loss_buf'))
     run_fwd_bwd = run['run_fwd_bwd']
 
@@ -494,8 +514,24 @@ def main():
         parts['ms_per_step_without_collectives'] = t_skip
         parts['exposed_allreduce_ms'] = elapsed / args.steps * 1e3 - t_skip
         parts['overlap'] = bool(run['overlap'])
+        parts['form'] = 'staged_two_collectives' if run['overlap'] else 'single_collective'
+        parts['forms_measured'] = forms
         parts['allreduce_bytes'] = dp.flat_grad.numel() * dp.flat_grad.element_size()
         parts['nranks'] = dist.get_world_size()
+        parts['backend'] = dist.get_backend()
+        # the same step with a bf16 gradient payload (half the xGMI bytes; the sum is rounded to bf16: NOT the parity mode, reported
+        # beside the contract value, never as it)
+        try:
+            run_p = build(args.mode, overlap=run['overlap'], payload=torch.bfloat16)
+            t_p = timed(run_p['step'], 3, args.steps) / args.steps * 1e3
+            parts['bf16_payload'] = {'ms_per_step': t_p, 'value': args.batch * world / (t_p * 1e-3), 'allreduce_bytes': dp.flat_grad.numel() * 2,
+                                     'skipped': run_p['opt'].stats()['skipped']}
+            del run_p
+            torch.cuda.empty_cache()
+        except Exception as e:                                     # noqa: BLE001  (every rank fails alike: same code, same sizes)
+            parts['bf16_payload'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        ops.set_stage_split(run['overlap'])
+        ops.set_compute_dtype(args.mode)
     kern = None
     if rank == 0 and not args.no_extras:
         dp.skip_collectives = True            # rank 0 alone runs this pass: it must not start a collective (staged step: the early group's)
@@ -643,9 +679,10 @@ def main():
     #      takes part (the step holds the collective); after the replays above, which need the primary mode's operands
     bf16_line = None
     if args.mode != 'bf16' and args.model == 'transformer' and not (args.no_extras or args.no_bf16_line):
+        overlap_primary = run['overlap']
         del run, dp, opt, fwd_bwd, run_fwd_bwd, step, graph, kern    # free the primary replica (graph pool, 2.2 GB of saved activations)
         torch.cuda.empty_cache()
-        run2 = build('bf16')
+        run2 = build('bf16', overlap=overlap_primary)
         el2 = timed(run2['step'], args.warmup, args.steps)
         st2 = run2['opt'].stats()
         bf16_line = {'value': args.batch * world * args.steps / el2, 'unit': 'utterances/s', 'ms_per_step': el2 / args.steps * 1e3,

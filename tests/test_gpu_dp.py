@@ -255,6 +255,81 @@ def test_library_owned_rccl_communicator_world_one():
         ops.set_compute_dtype('bf16')
 
 
+def _rccl2_worker(rank, world, port, out):
+    import threading
+    # RCCL's rendezvous is host-side sockets: a refusal is an error code, but a hang must not take the test run with it
+    def give_up():
+        torch.save({'rank': rank, 'init': 'timeout', 'uid': b'', 'uid_nonzero': False}, out % rank)
+        os._exit(0)
+    threading.Timer(90.0, give_up).start()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import ctypes as C
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops, _lib
+    from opentransformer_amd.dp import FlatDataParallel
+    torch.cuda.set_device(0)
+    ops.set_compute_dtype('fp16')
+    model = ota.SpeechToText(syn.c1_model(0.0, ctc_weight=0.3))
+    syn.fill_state_dict_(model.state_dict(), 3)
+    dp = FlatDataParallel(model.to('cuda').train(), comm='rccl')
+    res = {'rank': rank}
+    # (i) the plumbing of dp._rccl_handle, step by step: rank 0's unique id reaches every rank through the torch.distributed store
+    lib = _lib.load()
+    uid = C.create_string_buffer(128)
+    if rank == 0:
+        _lib.check(lib.otr_allreduce_unique_id(uid), 'otr_allreduce_unique_id')
+    box = [uid.raw]
+    dist.broadcast_object_list(box, src=0)
+    res['uid'] = bytes(box[0])
+    res['uid_nonzero'] = any(box[0])
+    # (ii) the engine's own path: init with (rank, world) = (rank, 2).  Two ranks on ONE device: RCCL may refuse ("duplicate GPU");
+    # then the refusal must arrive as an error of the C ABI with a message, on both ranks, not as a hang or a crash
+    try:
+        dp._rccl_handle()
+        res['init'] = 'ok'
+    except _lib.OtransHipError as e:
+        res['init'] = 'refused: %s' % e
+    if res['init'] == 'ok':
+        dp.flat_grad.fill_(float(rank + 1))
+        scale, _ = dp.all_reduce_gradients()
+        torch.cuda.synchronize()
+        res['sum_ok'] = bool(scale == 0.5 and torch.equal(dp.flat_grad, torch.full_like(dp.flat_grad, 3.0)))
+        dp.close()
+    torch.save(res, out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+    os._exit(0)
+
+
+def test_library_owned_rccl_communicator_two_processes(tmp_path):
+    """comm='rccl' across TWO processes -- otr_allreduce_unique_id on rank 0, the 128 bytes shipped through the
+    gloo-bootstrapped torch.distributed group, otr_allreduce_init(rank, 2) on both.  A box with one GPU puts both ranks on one
+    device, which RCCL may refuse: the test then checks that the refusal is an error of the C ABI on both ranks (and skips the sum);
+    where RCCL accepts it, the in-place sum over the two ranks is checked."""
+    out = str(tmp_path / 'r%d.pt')
+    ctx = mp.spawn(_rccl2_worker, args=(2, _free_port(), out), nprocs=2, join=False)
+    deadline = 150
+    import time
+    t0 = time.time()
+    while not ctx.join(timeout=5):
+        if time.time() - t0 > deadline:
+            for p in ctx.processes:
+                p.kill()
+            pytest.fail('RCCL rendezvous of two processes did not return')
+    got = [torch.load(out % r, weights_only=False) for r in range(2)]
+    if any(g['init'] == 'timeout' for g in got):
+        pytest.skip('RCCL rendezvous of two ranks on one device did not return within 90 s on this box: %s' % [g['init'] for g in got])
+    assert got[0]['uid'] == got[1]['uid'] and got[0]['uid_nonzero']          # the id travelled
+    assert (got[0]['init'] == 'ok') == (got[1]['init'] == 'ok'), got           # both ranks see the same outcome
+    if got[0]['init'] == 'ok':
+        assert got[0]['sum_ok'] and got[1]['sum_ok']
+    else:
+        assert all('RCCL error' in g['init'] or 'allreduce' in g['init'] for g in got), got
+        print('RCCL refused two ranks on one device:', got[0]['init'])
+
+
 @pytest.mark.parametrize('mode', ['fp16', 'bf16'])
 def test_regrouped_frontend_shadows_follow_the_optimizer(mode):
     """The frontend's channel-last weight images (nn.ConvFrontEnd.regrouped_weights: conv2's taps, the output Linear's columns,
