@@ -672,7 +672,7 @@ def main():
                 d['share_of_step'] = d['ms_per_step'] / (elapsed / args.steps * 1e3)
                 d['pmc_source'] = '%s (%s)' % (pmc_file, pmc_db.get('_meta', {}).get('commit', 'absent')) if pmc_db else None
                 out['roofline'] = d
-                keep = sorted(lines, key=lambda k: -lines[k]['ms_per_step'])[:14]
+                keep = sorted(lines, key=lambda k: -lines[k]['ms_per_step'])[:24]
                 out['roofline_kernels'] = {k: lines[k] for k in keep}
     # ---- BASELINE.json configs[1] names bf16: the same workload, steps and timing in bf16 mode (8 mantissa bits: logits
     #      4e-3 from the fp32 reference, outside the north star's 1e-3 -- why the headline value is the fp16 line).  Every rank

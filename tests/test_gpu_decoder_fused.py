@@ -20,9 +20,13 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
-# gradients allowed over the flat bound tg, by name pattern, each with its own bound per mode and the reason (none needed so far:
-# the cases that used to fall back to 'as far off as the unfused HIP path' were the key-bias slices, now measured apart)
-OVER_TG = {}
+# Gradients allowed over the flat bound tg, by name pattern, each with its own bound per mode (<= 1.5 x the worst value measured over
+# SHAPES on MI355X, profiles/r05_tolerance_cases.jsonl: fp16 0.027, bf16 0.22).  They are ONE error, seen three times: the q|k|v
+# gradient of the FIRST layer's self-attention and what it feeds (the embedding).  Layer 0 attends over sqrt(d) x embedding + PE
+# rows (|x| ~ 16 x a later layer's LayerNorm output): its softmax saturates, P is close to one-hot, and dS = P o (dP - rowsum(dO o O))
+# cancels to the rounding of the 16-bit O / dO / P operands.  Every other tensor of every shape meets tg; the per-operator HIP path
+# shows the same three values (what the old "as far off as the unfused path" branch compared against).
+OVER_TG = {'blocks.0.slf_attn.qvk_proj.': {'fp16': 4e-2, 'bf16': 3e-1}, 'embedding.weight': {'fp16': 4e-2, 'bf16': 3e-1}}
 # residue the 16-bit paths leave in the analytically-zero key-bias gradient, relative to the live slices of the same bias
 KEY_RESIDUE = {'fp16': 6e-2, 'bf16': 2.4e-1}
 

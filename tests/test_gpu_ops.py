@@ -764,19 +764,28 @@ def test_optimizer_gradient_noise_and_loss_scale():
     from opentransformer_amd.dp import FlatDataParallel, FusedAdam
 
     class Holder(torch.nn.Module):
-        def __init__(self):
+        def __init__(self, value=0.0):
             super().__init__()
-            self.w = torch.nn.Parameter(torch.zeros(1 << 18, device=DEV))
+            self.w = torch.nn.Parameter(torch.full((1 << 18,), value, device=DEV))
 
     deferral = ops._wq['on']
     try:
         # noise: zero gradients, so exp_avg = (1 - beta1) * noise
-        dp = FlatDataParallel(Holder())
+        dp = FlatDataParallel(Holder(1.0))
         opt = FusedAdam(dp, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.0, clip_grad=5.0, grad_noise=0.05, loss_scale=0.0)
         dp.zero_grad()
         opt.step()
         m = opt.exp_avg[:1 << 18] / 0.1
         assert abs(float(m.mean())) < 1e-3 and abs(float(m.std()) - 0.05) < 1e-3
+        # cells whose parameter AND gradient are exactly zero are padding of the flat buffers (alignment gaps, the extra rows of a
+        # row-padded Linear): no noise there, they stay zero (include/otrans_hip.h)
+        dp = FlatDataParallel(Holder(0.0))
+        opt = FusedAdam(dp, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.0, clip_grad=5.0, grad_noise=0.05, loss_scale=0.0)
+        dp.zero_grad()
+        dp.params[0].grad[:1024].fill_(1e-3)            # the first 1024 cells are live (non-zero gradient): they do get noise
+        opt.step()
+        assert float(dp.flat_param[1024:].abs().max()) == 0.0 and float(opt.exp_avg[1024:].abs().max()) == 0.0
+        assert float(opt.exp_avg[:1024].std()) > 1e-3
         # loss scale: gradients arrive 1024x too large
         dp = FlatDataParallel(Holder())
         opt = FusedAdam(dp, lr=1e-3, weight_decay=0.0, clip_grad=0.0, loss_scale=1024.0, loss_scale_growth=2)
