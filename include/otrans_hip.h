@@ -355,6 +355,13 @@ int32_t otr_embed_posenc_fwd(const int64_t* tok, const float* E, float* y, void*
 /* dE[tok[r],:] += scale * dy[r,:]  (atomic f32) */
 int32_t otr_embed_bwd(const int64_t* tok, const float* dy, float* dE, int64_t rows, int32_t d, int32_t vocab,
                       float scale, void* stream);
+/* The two above on a token VIEW: tok is addressed as tok[(r / L) * ld_tok + r % L] (`truth[:, :-1]` of the [B, L + 1] target matrix,
+ * model/speech2text.py:53: no copy).  otr_embed_bwd_ld also takes the gradient as partial sums: dE[tok[r],:] += scale * (dy[r,:] +
+ * sum_s slabs[s][r,:]) with dy f32 [rows, d] or NULL and slabs 16-bit [nslab][rows][d] or NULL (what otr_dec_self_bwd leaves). */
+int32_t otr_embed_posenc_fwd_ld(const int64_t* tok, int64_t ld_tok, const float* E, float* y, void* y_bf16, int64_t rows, int32_t L,
+                                int32_t d, int32_t vocab, float scale, void* stream);
+int32_t otr_embed_bwd_ld(const int64_t* tok, int64_t ld_tok, int32_t L, const float* dy, const void* slabs, int32_t nslab, float* dE,
+                         int64_t rows, int32_t d, int32_t vocab, float scale, void* stream);
 /* dst (bf16) = src (f32), n elements: bf16 shadows of weights / activations */
 int32_t otr_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* y = x * (*s_dev) * s_host, elementwise f32 (n elements); x may alias y; s_dev may be NULL */
@@ -434,6 +441,17 @@ int32_t otr_label_smoothing_loss(const float* logits, const int64_t* target, int
 int32_t otr_label_smoothing_loss_ld(const float* logits, int64_t ld_logits, const int64_t* target, int64_t R, int32_t V,
                                     float smoothing, int32_t pad_idx, float* loss, float* dlogits, int64_t ld_dlogits,
                                     float* scratch, void* stream);
+
+/* The whole loss in ONE launch, for the training step (module/loss.py:21-48 + the two scalar multiplications around it): every row
+ * is read once (16-byte loads: logits and dlogits rows 16-byte aligned, ld % 4 == 0, V <= 8192, R <= 8192), the block that finishes
+ * last adds up the row losses in the fixed order of otr_label_smoothing_loss (deterministic), and dlogits leaves already multiplied
+ * by the device scalar *grad_scale (NULL = 1: the factor the caller's backward pass will be seeded with, e.g. the dynamic loss
+ * scale of otr_optimizer_step's state block).  target: int64, addressed as target[(r / L) * ld_target + r % L] for r in [0, R): a
+ * [B, L] view with row stride ld_target (model/speech2text.py:57 `truth[:, 1:]`) needs no copy; R % L == 0.
+ * scratch: f32[R+2]; ticket: one uint32 the caller zero-initialises ONCE (the launch leaves it at zero again). */
+int32_t otr_label_smoothing_loss_fused(const float* logits, int64_t ld_logits, const int64_t* target, int64_t ld_target, int32_t L,
+                                       int64_t R, int32_t V, float smoothing, int32_t pad_idx, const float* grad_scale, float* loss,
+                                       float* dlogits, int64_t ld_dlogits, float* scratch, uint32_t* ticket, void* stream);
 
 /* ---- log_softmax over the last dim, f32 [R,V] (model/ctc.py:51,66; decoder/transformer.py:206) */
 int32_t otr_log_softmax(const float* x, float* y, int64_t R, int32_t V, void* stream);

@@ -312,44 +312,67 @@ extern "C" int32_t otr_posenc_fwd(const float* x, float* y, void* y_bf16, int64_
   return otr_check_launch("posenc_fwd");
 }
 
-__global__ void embed_posenc_kernel(const int64_t* tok, const float* E, float* y, bf16_t* y_lp, int64_t rows, int L, int d,
+// tokens are addressed as tok[(row / L) * ldt + row % L]: a [B, L] view with row stride ldt (truth[:, :-1] of a [B, L + 1] matrix,
+// model/speech2text.py:53) needs no copy
+__global__ void embed_posenc_kernel(const int64_t* tok, int64_t ldt, const float* E, float* y, bf16_t* y_lp, int64_t rows, int L, int d,
                                     int vocab, float scale) {
   const float nl = -logf(10000.f) / (float)d;
   const int64_t total = rows * d;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t row = i / d;
     int col = (int)(i - row * d);
-    int64_t t = tok[row];
+    int64_t t = tok[(row / L) * ldt + (row % L)];
     float e = (t >= 0 && t < vocab) ? E[t * d + col] : 0.f;
     float v = e * scale + pe_value((int)(row % L), col, nl);
     y[i] = v;
     if (y_lp) y_lp[i] = f2bf(v);
   }
 }
-extern "C" int32_t otr_embed_posenc_fwd(const int64_t* tok, const float* E, float* y, void* y_bf16, int64_t rows, int32_t L,
-                                        int32_t d, int32_t vocab, float scale, void* stream) {
+extern "C" int32_t otr_embed_posenc_fwd_ld(const int64_t* tok, int64_t ld_tok, const float* E, float* y, void* y_bf16, int64_t rows,
+                                           int32_t L, int32_t d, int32_t vocab, float scale, void* stream) {
   OTR_REQUIRE(tok && E && y, "embed_posenc_fwd: null pointer");
-  OTR_REQUIRE(L > 0 && d > 0 && vocab > 0 && rows >= 0, "embed_posenc_fwd: bad shape");
+  OTR_REQUIRE(L > 0 && d > 0 && vocab > 0 && rows >= 0 && ld_tok >= L, "embed_posenc_fwd: bad shape");
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(embed_posenc_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, tok, E, y, (bf16_t*)y_bf16, rows, L, d, vocab, scale);
+  hipLaunchKernelGGL(embed_posenc_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, tok, ld_tok, E, y, (bf16_t*)y_bf16, rows, L, d,
+                     vocab, scale);
   return otr_check_launch("embed_posenc_fwd");
 }
+extern "C" int32_t otr_embed_posenc_fwd(const int64_t* tok, const float* E, float* y, void* y_bf16, int64_t rows, int32_t L,
+                                        int32_t d, int32_t vocab, float scale, void* stream) {
+  return otr_embed_posenc_fwd_ld(tok, L, E, y, y_bf16, rows, L, d, vocab, scale, stream);
+}
 
-__global__ void embed_bwd_kernel(const int64_t* tok, const float* dy, float* dE, int64_t rows, int d, int vocab, float scale) {
+// dE[tok[r],:] += scale * (dy[r,:] + sum_s slabs[s][r,:]): `slabs` (16-bit partial sums [nslab][rows][d], the fused decoder stack's
+// last launch leaves its input gradient that way: csrc/declayer.hip) may be NULL / nslab 0
+__global__ void embed_bwd_kernel(const int64_t* tok, int64_t ldt, int L, const float* dy, const bf16_t* slabs, int nslab, float* dE, int64_t rows,
+                                 int d, int vocab, float scale) {
   const int64_t total = rows * d;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t row = i / d;
     int col = (int)(i - row * d);
-    int64_t t = tok[row];
-    if (t >= 0 && t < vocab) atomicAdd(dE + t * d + col, dy[i] * scale);
+    int64_t t = tok[(row / L) * ldt + (row % L)];
+    if (t >= 0 && t < vocab) {
+      float g = dy ? dy[i] : 0.f;
+      for (int s = 0; s < nslab; ++s) g += bf2f(slabs[(int64_t)s * total + i]);
+      atomicAdd(dE + t * d + col, g * scale);
+    }
   }
+}
+extern "C" int32_t otr_embed_bwd_ld(const int64_t* tok, int64_t ld_tok, int32_t L, const float* dy, const void* slabs, int32_t nslab, float* dE,
+                                    int64_t rows, int32_t d, int32_t vocab, float scale, void* stream) {
+  OTR_REQUIRE(tok && dE && (dy || (slabs && nslab > 0)), "embed_bwd: null pointer");
+  OTR_REQUIRE(L > 0 && ld_tok >= L && nslab >= 0 && (nslab == 0 || slabs), "embed_bwd: bad shape");
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, tok, ld_tok, L, dy, (const bf16_t*)slabs, nslab, dE,
+                     rows, d, vocab, scale);
+  return otr_check_launch("embed_bwd");
 }
 extern "C" int32_t otr_embed_bwd(const int64_t* tok, const float* dy, float* dE, int64_t rows, int32_t d, int32_t vocab,
                                  float scale, void* stream) {
   OTR_REQUIRE(tok && dy && dE, "embed_bwd: null pointer");
   if (rows <= 0) return 0;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, tok, dy, dE, rows, d, vocab, scale);
-  return otr_check_launch("embed_bwd");
+  OTR_REQUIRE(rows <= 0x7fffffff, "embed_bwd: too many rows");
+  return otr_embed_bwd_ld(tok, rows, (int32_t)rows, dy, nullptr, 0, dE, rows, d, vocab, scale, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ cast

@@ -24,6 +24,12 @@ __device__ __forceinline__ float ls_count(const int64_t* target, int64_t R, int 
   for (int64_t i = threadIdx.x; i < R; i += blockDim.x) c += (target[i] != pad_idx) ? 1.f : 0.f;
   return block_reduce(c, sh, false);
 }
+// the same over a [B, L] view with row stride ldt (elements): target[(i / L) * ldt + i % L]
+__device__ __forceinline__ float ls_count_ld(const int64_t* target, int64_t ldt, int L, int64_t R, int pad_idx, float* sh) {
+  float c = 0.f;
+  for (int64_t i = threadIdx.x; i < R; i += blockDim.x) c += (target[(i / L) * ldt + (i % L)] != pad_idx) ? 1.f : 0.f;
+  return block_reduce(c, sh, false);
+}
 __global__ void ls_count_kernel(const int64_t* target, int64_t R, int pad_idx, float* scratch) {      // scratch[0] = number of non-pad rows
   __shared__ float sh[4];
   const float c = ls_count(target, R, pad_idx, sh);
@@ -101,6 +107,126 @@ extern "C" int32_t otr_label_smoothing_loss_ld(const float* logits, int64_t ld_l
                      dlogits, ld_dlogits);
   hipLaunchKernelGGL(ls_finalize_kernel, dim3(1), dim3(256), 0, s, scratch + 2, R, loss);
   return otr_check_launch("label_smoothing_loss");
+}
+
+// ---- the whole loss in ONE launch (round 5).  What the three-kernel form above spends around its 8 MB of logits at the AISHELL
+// shape (480 rows x 4234): three passes over every row with 4-byte loads (17 us), a finalize launch (5 us), and -- in the training
+// step -- two launches that only multiply by a scalar (the loss scale seeding the backward pass, 5 us; the gradient of the loss
+// times it, 6 us).  Here a row is read ONCE into registers (16-byte loads: NV4 float4 per thread), its gradient leaves already
+// multiplied by the device scalar *gscale (the factor the backward pass will be seeded with), and the block that finishes LAST adds
+// up the per-row losses in a fixed order (the order of ls_finalize_kernel: the result is bit-identical to the three-kernel form's
+// reduction of the same row losses).  Inter-block hand-off: row losses travel as agent-scope relaxed atomic stores / loads
+// (global_store / load sc1: write-through, served past the L1), the arrival count is one agent-scope atomic add behind an
+// explicit vmcnt(0) (cdna_hip_programming.md G16, "sc1 stores and loads both sides"); the last block puts the ticket back to 0.
+// Targets are addressed as target[(row / L) * ldt + row % L]: the [B, L] view truth[:, 1:] of a [B, L + 1] matrix needs no copy.
+template <int NV4>
+__global__ __launch_bounds__(256) void ls_rows_fused_kernel(const float* logits, int64_t ld_x, const int64_t* target, int64_t ldt, int L,
+                                                           int64_t R, int V, float eps, int pad_idx, const float* gscale, float* row_loss,
+                                                           float* dlogits, int64_t ld_dx, float* loss, unsigned int* ticket) {
+  __shared__ float sh[4];
+  __shared__ int last_flag;
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const float* x = logits + row * ld_x;
+  float* dx = dlogits ? dlogits + row * ld_dx : nullptr;
+  const int64_t t = target[(row / L) * ldt + (row % L)];
+  float rl = 0.f;
+  if (t == pad_idx) {
+    if (dx) for (int64_t v = 4 * tid; v < ld_dx; v += 1024) *reinterpret_cast<float4*>(dx + v) = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    float4 xv[NV4];
+    const float ninf = -__builtin_huge_valf();
+    float mx = ninf;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+      const int v = 4 * (tid + 256 * k);
+      float4 q = make_float4(ninf, ninf, ninf, ninf);
+      if (v + 3 < V) {
+        q = *reinterpret_cast<const float4*>(x + v);
+      } else if (v < V) {              // the row's last, partial quad: element loads (ld_x may equal V: nothing behind the row is touched)
+        q.x = x[v];
+        if (v + 1 < V) q.y = x[v + 1];
+        if (v + 2 < V) q.z = x[v + 2];
+      }
+      xv[k] = q;
+      mx = fmaxf(mx, fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
+    }
+    mx = block_reduce(mx, sh, true);
+    float se = 0.f, sx = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+      const int v = 4 * (tid + 256 * k);
+      const float e[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (v + j < V) { se += expf(e[j] - mx); sx += e[j]; }
+    }
+    se = block_reduce(se, sh, false);
+    sx = block_reduce(sx, sh, false);
+    const float lse = mx + logf(se);
+    const float inv_cnt = 1.f / ls_count_ld(target, ldt, L, R, pad_idx, sh);
+    const float off = eps / (float)(V - 1), on = 1.f - eps;
+    if (dx) {
+      const float g = inv_cnt * (gscale ? gscale[0] : 1.f);
+#pragma unroll
+      for (int k = 0; k < NV4; ++k) {
+        const int v = 4 * (tid + 256 * k);
+        if (v < ld_dx) {
+          const float e[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (v + j < V) ? (expf(e[j] - lse) - ((int64_t)(v + j) == t ? on : off)) * g : 0.f;
+          *reinterpret_cast<float4*>(dx + v) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      }
+    }
+    if (tid == 0) {
+      const float logp_t = x[t] - lse;
+      const float sum_logp = sx - (float)V * lse;
+      const float Cc = (on > 0.f ? on * logf(on) : 0.f) + (eps > 0.f ? eps * logf(off) : 0.f);
+      rl = (Cc - (on * logp_t + off * (sum_logp - logp_t))) * inv_cnt;
+    }
+  }
+  if (tid == 0) {
+    __hip_atomic_store(row_loss + row, rl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = (arrived == (unsigned int)(R - 1));
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  float c = 0.f;
+  for (int64_t i = tid; i < R; i += 256) c += __hip_atomic_load(row_loss + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  c = block_reduce(c, sh, false);
+  if (tid == 0) {
+    *loss = c;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+extern "C" int32_t otr_label_smoothing_loss_fused(const float* logits, int64_t ld_logits, const int64_t* target, int64_t ld_target,
+                                                  int32_t L, int64_t R, int32_t V, float smoothing, int32_t pad_idx,
+                                                  const float* grad_scale, float* loss, float* dlogits, int64_t ld_dlogits,
+                                                  float* scratch, uint32_t* ticket, void* stream) {
+  OTR_REQUIRE(logits && target && loss && scratch && ticket, "label_smoothing_loss_fused: null pointer");
+  OTR_REQUIRE(R > 0 && V > 1 && L > 0 && R % L == 0 && ld_target >= L, "label_smoothing_loss_fused: bad shape R=%lld L=%d ld_target=%lld V=%d",
+              (long long)R, L, (long long)ld_target, V);
+  OTR_REQUIRE(R <= LS_COUNT_INLINE, "label_smoothing_loss_fused: more than %lld rows (use otr_label_smoothing_loss_ld)", (long long)LS_COUNT_INLINE);
+  OTR_REQUIRE(V <= 8192, "label_smoothing_loss_fused: V = %d > 8192 does not fit a row in registers (use otr_label_smoothing_loss_ld)", V);
+  OTR_REQUIRE(ld_logits >= V && ld_logits % 4 == 0 && (uintptr_t)logits % 16 == 0, "label_smoothing_loss_fused: logits rows must be 16-byte aligned (ld %% 4 == 0)");
+  OTR_REQUIRE(!dlogits || (ld_dlogits >= V && ld_dlogits % 4 == 0 && ld_dlogits <= 8192 && (uintptr_t)dlogits % 16 == 0),
+              "label_smoothing_loss_fused: dlogits rows must be 16-byte aligned (ld %% 4 == 0, ld <= 8192)");
+  OTR_REQUIRE(smoothing >= 0.f && smoothing < 1.f, "label_smoothing_loss_fused: smoothing out of [0,1)");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t width = dlogits && ld_dlogits > V ? ld_dlogits : V;
+#define OTR_LS_LAUNCH(NV4)                                                                                                            \
+  hipLaunchKernelGGL(ls_rows_fused_kernel<NV4>, dim3((unsigned)R), dim3(256), 0, s, logits, ld_logits, target, ld_target, L, R, V, smoothing, \
+                     pad_idx, grad_scale, scratch + 2, dlogits, ld_dlogits, loss, ticket)
+  if (width <= 2048) OTR_LS_LAUNCH(2);
+  else if (width <= 5120) OTR_LS_LAUNCH(5);
+  else OTR_LS_LAUNCH(8);
+#undef OTR_LS_LAUNCH
+  return otr_check_launch("label_smoothing_loss_fused");
 }
 
 extern "C" int32_t otr_label_smoothing_loss(const float* logits, const int64_t* target, int64_t R, int32_t V,

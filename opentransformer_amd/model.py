@@ -67,9 +67,21 @@ class SpeechToText(nn.Module):
         enc_inputs, enc_mask = self.frontend(enc_inputs, enc_mask)
         memory, memory_mask, _ = self.encoder(enc_inputs, enc_mask)
         memory = ops.early_mark(memory, self) # everything behind this point finishes its backward before the encoder's starts (dp.py)
-        shifted = torch.stack((truth[:, :-1], truth[:, 1:]))     # decoder input | loss target (speech2text.py:53,57 clones each) in one launch
-        logits, _ = self.decoder(shifted[0], memory, memory_mask)
-        target_out = shifted[1]
+        if self.ctc_weight > 0 or not truth.is_cuda or truth.stride(-1) != 1:
+            shifted = torch.stack((truth[:, :-1], truth[:, 1:]))     # decoder input | loss target (speech2text.py:53,57 clones each) in one launch
+            dec_in, target_out = shifted[0], shifted[1]
+        else:
+            # the embedding and the loss kernels read the two shifted VIEWS of the target matrix in place (row stride L + 1): no launch
+            dec_in, target_out = truth[:, :-1], truth[:, 1:]
+        logits, _ = self.decoder(dec_in, memory, memory_mask)
+        if self.ctc_weight <= 0 and isinstance(self.crit, LabelSmoothingLoss):
+            # the loss is the root of the backward pass: the factor it is seeded with (fp16 loss scale, ops.scale_loss_grad) rides in
+            # the loss launch's gradient instead of two scalar-multiply launches
+            self.crit._otr_grad_scale = ops.loss_scale_of(self)
+            try:
+                return self.crit(logits, target_out), None
+            finally:
+                self.crit._otr_grad_scale = None
         loss = self.crit(logits, target_out)
         if self.ctc_weight > 0:
             loss_ctc = self.compute_ctc_loss(memory, memory_mask, target_out, truth_length)

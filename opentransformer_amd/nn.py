@@ -670,6 +670,8 @@ class LabelSmoothingLoss(nn.Module):
         super().__init__()
         self.size, self.smoothing, self.padding_idx, self.normalize_length = size, smoothing, padding_idx, normalize_length
 
+    _otr_grad_scale = None
+
     def forward(self, logits, target, mask=None):
         assert logits.dim() == 3 and logits.size(-1) == self.size
         if mask is not None:          # a masked row contributes nothing, exactly like a PAD row (loss.py:31-35,45-46)
@@ -677,5 +679,9 @@ class LabelSmoothingLoss(nn.Module):
         if not self.normalize_length:
             loss = ops.LabelSmoothingLossFn.apply(logits.float(), target, float(self.smoothing), int(self.padding_idx))
             kept = (target != self.padding_idx).sum().to(loss.dtype)
-            return loss * (kept / target.numel())
-        return ops.LabelSmoothingLossFn.apply(logits.float(), target, float(self.smoothing), int(self.padding_idx))
+            loss = loss * (kept / target.numel())
+            return ops.ScaleGradFn.apply(loss, self._otr_grad_scale) if self._otr_grad_scale is not None and loss.requires_grad else loss
+        # _otr_grad_scale: set by the model around its call (an attribute, not an argument: forward keeps the reference's signature) --
+        # the device scalar its backward pass is seeded with (fp16 loss scale); the fused loss launch folds it into the gradient
+        return ops.label_smoothing_loss(logits.float(), target, float(self.smoothing), int(self.padding_idx),
+                                        grad_scale=self._otr_grad_scale)

@@ -193,6 +193,12 @@ class ScaleGradFn(torch.autograd.Function):
         return out, None
 
 
+def loss_scale_of(owner=None):
+    """the device scalar the backward pass of `owner`'s loss is seeded with, or None (see scale_loss_grad)"""
+    s = getattr(owner, '_otr_loss_scale', None) if owner is not None else None
+    return s if s is not None else _state.get('loss_scale')
+
+
 def scale_loss_grad(loss, owner=None):
     """owner: the model whose optimizer registered a scale on it (FusedAdam sets `_otr_loss_scale` on the wrapped module, so
     two models trained in one process keep separate scales); the process-wide tensor is the fallback (parity tests)."""
@@ -1916,6 +1922,7 @@ _FUSED_GLU_FWD = os.environ.get('OTR_NO_FUSED_GLU_FWD', '0') != '1'
 _DEC_FUSED = os.environ.get('OTR_NO_FUSED_DECODER', '0') != '1'
 _DEC_TOUCH = os.environ.get('OTR_DEC_TOUCH', '1') == '1'
 _DEC_FFN_SLICES = int(os.environ.get('OTR_DEC_FFN_SLICES', '8'))
+_EMBED_SINK = os.environ.get('OTR_EMBED_SINK', '1') == '1'     # A/B: the decoder stack's input gradient summed by the embedding's backward
 DEC_LAYER_PARAMS = 18      # qvk w,b | out w,b | norm1 w,b | q w,b | out w,b | norm2 w,b | w_1 w,b | w_2 w,b | norm3 w,b
 
 
@@ -2035,6 +2042,7 @@ class DecoderStackFn(torch.autograd.Function):
         ctx.layers, ctx.packs, ctx.params = layers, packs_all, params
         ctx.cfg = (B, Lq, d, T, W, n_layers, p_drop, S, F, seed)
         ctx.kv, ctx.kmask = kv_all, kmask
+        ctx.sink = getattr(x0, '_otr_embed_sink', None) if _EMBED_SINK else None
         y3, y316 = y3.view(B, Lq, d), y316.view(B, Lq, d)
         ctx.mark_non_differentiable(y316)
         return y3, y316
@@ -2092,9 +2100,16 @@ class DecoderStackFn(torch.autograd.Function):
             dskip, slabs, nslab = dz1, slAb, 4
         dx0 = None
         if ctx.needs_input_grad[0]:
-            dx0 = f32(R, d)
-            L.check(lib.otr_dec_sum(_p(dskip), _p(slabs), nslab, R, _p(dx0), st), 'otr_dec_sum')
-            dx0 = dx0.view(B, Lq, d)
+            sink = ctx.sink
+            if sink is not None and sink.buf is None and _in_backward() and slabs is not None:
+                # x0 is the embedding's output and nothing else reads its gradient: the embedding's backward adds skip + slabs itself
+                sink.buf = (dskip, slabs, nslab)
+                _park(sink)
+                dx0 = _zero_placeholder(dev, (B, Lq, d))
+            else:
+                dx0 = f32(R, d)
+                L.check(lib.otr_dec_sum(_p(dskip), _p(slabs), nslab, R, _p(dx0), st), 'otr_dec_sum')
+                dx0 = dx0.view(B, Lq, d)
         return (dx0, dkv if ctx.needs_input_grad[1] else None, None, None, None, None, None, *grads)
 
 
@@ -2165,40 +2180,63 @@ class PosEncFn(torch.autograd.Function):
         return dx
 
 
+class _EmbedSink:
+    """hand-over from the fused decoder stack to the embedding's backward: the stack's input gradient as (skip, slabs, nslab) -- the
+    embedding adds the partial sums itself (otr_embed_bwd_ld) instead of a launch that only sums them (otr_dec_sum)"""
+    buf = None
+
+
+def _token_view(tokens):
+    """(tokens as the kernels read them, row stride, L): a [B, L] view with unit inner stride is passed through (no copy launch)"""
+    if tokens.dim() == 2 and tokens.stride(1) == 1 and tokens.stride(0) >= tokens.shape[1]:
+        return tokens, tokens.stride(0), tokens.shape[1]
+    tokens = tokens.contiguous()
+    return tokens, tokens.shape[-1], tokens.shape[-1]
+
+
 class EmbedPosEncFn(torch.autograd.Function):
     """embedding(tokens)*sqrt(d) + PE (decoder/transformer.py:163-169)."""
 
     @staticmethod
-    def forward(ctx, tokens, E):
+    def forward(ctx, tokens, E, sink=None):
         _cuda(tokens, E)
         ctx.set_materialize_grads(False)
         B, Lq = tokens.shape
         V, d = E.shape
-        tokens = tokens.contiguous()
+        tokens, ldt, _ = _token_view(tokens)
         y = torch.empty((B, Lq, d), dtype=torch.float32, device=E.device)
         ylp = torch.empty((B, Lq, d), dtype=half_dtype(), device=E.device) if is_half() else None
         ctx.scale = math.sqrt(d)
-        L.check(L.load().otr_embed_posenc_fwd(_p(tokens), _p(E), _p(y), _p(ylp), B * Lq, Lq, d, V, ctx.scale, _stream()),
-                'otr_embed_posenc_fwd')
+        L.check(L.load().otr_embed_posenc_fwd_ld(_p(tokens), ldt, _p(E), _p(y), _p(ylp), B * Lq, Lq, d, V, ctx.scale, _stream()),
+                'otr_embed_posenc_fwd_ld')
         ctx.save_for_backward(tokens)
-        ctx.eshape = (V, d)
-        ctx.e_ref = E
+        ctx.eshape, ctx.ldt, ctx.Lq = (V, d), ldt, Lq
+        ctx.e_ref, ctx.sink = E, sink
         if ylp is not None:
             ctx.mark_non_differentiable(ylp)
         return y, ylp
 
     @staticmethod
     def backward(ctx, dy, _dylp=None):
-        if dy is None:
-            return None, None
+        sink = ctx.sink
+        parked = sink.buf if sink is not None else None
+        if dy is None and parked is None:
+            return None, None, None
         (tokens,) = ctx.saved_tensors
         V, d = ctx.eshape
-        dy = dy.contiguous()
         gt = grad_target(ctx.e_ref)
-        dE = gt if gt is not None else torch.zeros((V, d), dtype=torch.float32, device=dy.device)
-        L.check(L.load().otr_embed_bwd(_p(tokens), _p(dy), _p(dE), tokens.numel(), d, V, ctx.scale, _stream()),
-                'otr_embed_bwd')
-        return None, (None if gt is not None else dE)
+        dev = tokens.device
+        dE = gt if gt is not None else torch.zeros((V, d), dtype=torch.float32, device=dev)
+        if parked is not None:            # the decoder stack's input gradient arrives as skip + 16-bit partial sums (DecoderStackFn.backward)
+            sink.buf = None
+            dskip, slabs, nslab = parked
+            L.check(L.load().otr_embed_bwd_ld(_p(tokens), ctx.ldt, ctx.Lq, _p(dskip), _p(slabs), nslab, _p(dE), tokens.shape[0] * ctx.Lq, d, V,
+                                              ctx.scale, _stream()), 'otr_embed_bwd_ld')
+        else:
+            dy = dy.contiguous()
+            L.check(L.load().otr_embed_bwd_ld(_p(tokens), ctx.ldt, ctx.Lq, _p(dy), None, 0, _p(dE), tokens.shape[0] * ctx.Lq, d, V, ctx.scale,
+                                              _stream()), 'otr_embed_bwd_ld')
+        return None, (None if gt is not None else dE), None
 
 
 def posenc(x):
@@ -2207,7 +2245,9 @@ def posenc(x):
 
 
 def embed_posenc(tokens, E):
-    y, ylp = EmbedPosEncFn.apply(tokens, E)
+    sink = _EmbedSink()
+    y, ylp = EmbedPosEncFn.apply(tokens, E, sink)
+    y._otr_embed_sink = sink              # read by DecoderStackFn when y is its input (and only then)
     return attach_lp(y, ylp)
 
 
@@ -2700,6 +2740,78 @@ class LabelSmoothingLossFn(torch.autograd.Function):
             out._otr_zero_tail = tuple(out.shape)                  # LinearFn.backward may read it at its full width (_zero_tail_of)
             out = out[:, :ctx.V]
         return out.view(ctx.shape), None, None, None
+
+
+class LabelSmoothingLossFusedFn(torch.autograd.Function):
+    """LabelSmoothingLoss.forward + its gradient + the scalar factor of the backward seed in ONE launch (otr_label_smoothing_loss_fused).
+    Semantics: loss = LabelSmoothingLossFn(...), d loss / d logits multiplied by `gscale` (a device scalar; None = 1) -- i.e.
+    ScaleGradFn o LabelSmoothingLossFn.  The kernel writes gscale x d loss / d logits; backward multiplies by the incoming gradient,
+    unless that is the cached unit seed of ops.backward (then the buffer leaves as it is: no launch)."""
+
+    @staticmethod
+    def forward(ctx, logits, ld, target, ldt, Lt, V, smoothing, pad_idx, gscale, ticket):
+        lg = logits.reshape(-1, V)              # a view (label_smoothing_loss checked the strides)
+        R = lg.shape[0]
+        loss = torch.empty((), dtype=torch.float32, device=lg.device)
+        need = ctx.needs_input_grad[0]
+        dlogits = torch.empty((R, ld), dtype=torch.float32, device=lg.device) if need else None
+        scratch = torch.empty((R + 2,), dtype=torch.float32, device=lg.device)
+        L.check(L.load().otr_label_smoothing_loss_fused(_p(lg), ld, _p(target), ldt, Lt, R, V, smoothing, pad_idx, _p(gscale), _p(loss),
+                                                        _p(dlogits), ld, _p(scratch), _p(ticket), _stream()), 'otr_label_smoothing_loss_fused')
+        ctx.save_for_backward(dlogits)
+        ctx.shape, ctx.V = logits.shape, V
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        seed = _state.get(('unit_grad', g.device, g.dtype))
+        if seed is not None and g.data_ptr() == seed.data_ptr():
+            out = dlogits                                          # g == 1: the saved buffer IS the gradient
+        else:
+            out = torch.empty_like(dlogits)
+            g = g.contiguous().float()
+            L.check(L.load().otr_scale(_p(dlogits), _p(out), dlogits.numel(), _p(g), 1.0, _stream()), 'otr_scale')
+        if out.shape[1] != ctx.V:
+            out._otr_zero_tail = tuple(out.shape)                  # LinearFn.backward may read it at its full width (_zero_tail_of)
+            out = out[:, :ctx.V]
+        return (out.view(ctx.shape),) + (None,) * 9
+
+
+_LS_FUSED = os.environ.get('OTR_LS_FUSED', '1') == '1'
+
+
+def _ls_ticket(device):
+    """the arrival counter of otr_label_smoothing_loss_fused: one zeroed uint32 per device, allocated outside any capture"""
+    t = _state.setdefault('ls_ticket', {}).get(device)
+    if t is None and not torch.cuda.is_current_stream_capturing():
+        t = _state['ls_ticket'][device] = torch.zeros(4, dtype=torch.int32, device=device)
+    return t
+
+
+def label_smoothing_loss(logits, target, smoothing, pad_idx, grad_scale=None):
+    """LabelSmoothingLoss (module/loss.py:21-48) of logits [..., V] against target [...]; with grad_scale (a device scalar, the loss
+    scale) the gradient that flows back into the logits carries that factor (= ops.ScaleGradFn applied to the loss).  One launch where
+    the fused kernel's alignment rules hold (fp32 logits with 16-byte aligned rows -- the row-padded output layer's are -- V <= 8192,
+    <= 8192 rows), the three-kernel form + ScaleGradFn otherwise."""
+    V = logits.shape[-1]
+    lg = logits.reshape(-1, V)
+    ok = (_LS_FUSED and lg.is_cuda and lg.dtype == torch.float32 and lg.dim() == 2 and lg.stride(1) == 1 and V <= 8192 and 0 < lg.shape[0] <= 8192
+          and lg.data_ptr() % 16 == 0 and target.dtype == torch.int64)
+    if ok:
+        ld = lg.stride(0) if lg.shape[0] > 1 else (V + 3) // 4 * 4
+        ok = ld % 4 == 0 and V <= ld < V + 8
+    ticket = _ls_ticket(lg.device) if ok else None
+    if ok and ticket is not None:
+        if target.dim() == 2 and target.stride(1) == 1 and target.stride(0) >= target.shape[1] and target.numel() == lg.shape[0]:
+            tg, ldt, Lt = target, target.stride(0), target.shape[1]
+        else:
+            tg = target.reshape(-1).contiguous()
+            ldt = Lt = tg.numel()
+        if Lt <= 0x7fffffff and tg.numel() == lg.shape[0] and (lg.shape[0] == 1 or lg.shape[0] % Lt == 0):
+            return LabelSmoothingLossFusedFn.apply(logits, ld, tg, ldt, Lt, V, smoothing, pad_idx, grad_scale, ticket)
+    loss = LabelSmoothingLossFn.apply(logits, target, smoothing, pad_idx)
+    return ScaleGradFn.apply(loss, grad_scale) if (grad_scale is not None and loss.requires_grad) else loss
 
 
 class CTCLossFn(torch.autograd.Function):

@@ -1,0 +1,186 @@
+"""GPU (-m gpu): round-5 launches.
+
+* otr_label_smoothing_loss_fused (module/loss.py:21-48 in ONE launch: rows read once, the last block sums the row losses in the
+  three-kernel form's order, the gradient pre-multiplied by a device scalar, targets as a strided view) against the three-kernel
+  form and against plain fp32 torch; deterministic; replayable from a hipGraph (the arrival ticket returns to zero);
+* the embedding on token VIEWS (truth[:, :-1]) and the fused decoder stack's input gradient summed by the embedding's backward
+  (otr_embed_bwd_ld) against the otr_dec_sum form;
+* the whole model: views + fused loss + folded loss scale give the loss / gradients of the round-4 forms."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def torch_ls_loss(logits, target, smoothing, pad):
+    """module/loss.py:21-48 restated with torch ops (fp64)"""
+    V = logits.shape[-1]
+    x = logits.reshape(-1, V).double()
+    t = target.reshape(-1)
+    keep = t != pad
+    true = torch.full_like(x, smoothing / (V - 1))
+    true.scatter_(1, t.clamp(min=0).unsqueeze(1), 1.0 - smoothing)
+    kl = F.kl_div(torch.log_softmax(x, dim=1), true, reduction='none')
+    return kl.masked_fill(~keep.unsqueeze(1), 0.0).sum() / keep.sum()
+
+
+CASES = [  # B, L, V, padded rows (ld), pad positions, strided target view
+    (32, 15, 4234, True, True, True),       # the AISHELL output layer: head of a [480, 4240] product, truth[:, 1:] view
+    (32, 15, 4234, True, False, False),
+    (4, 7, 100, False, True, True),         # V % 4 == 0: contiguous rows are aligned
+    (3, 5, 2048, False, True, False),       # the 2-quad instantiation's upper edge
+    (2, 9, 5120, False, False, True),       # the 5-quad instantiation's upper edge
+    (2, 3, 8192, False, True, False),       # 8 quads
+    (1, 1, 36, False, False, False),        # one row
+]
+
+
+@pytest.mark.parametrize('B,L,V,padded,with_pad,view', CASES)
+def test_fused_loss_matches_three_kernel_form_and_torch(B, L, V, padded, with_pad, view):
+    from opentransformer_amd import ops
+    g = torch.Generator().manual_seed(B * 131 + L * 7 + V)
+    R = B * L
+    ld = (V + 7) // 8 * 8 if padded else V
+    buf = (3.0 * torch.randn(R, ld, generator=g)).to(DEV)
+    truth = torch.randint(1, V, (B, L + 1), generator=g).to(DEV)
+    if with_pad:
+        truth[0, L // 2 + 1:] = 0
+        truth[-1, -1] = 0
+    target = truth[:, 1:] if view else truth[:, 1:].contiguous()
+    scale = torch.tensor([1024.0], device=DEV)
+
+    def run(fused, gs):
+        was = ops._LS_FUSED
+        ops._LS_FUSED = fused
+        try:
+            base = buf.clone().requires_grad_(True)
+            logits = base[:, :V].view(B, L, V)
+            loss = ops.label_smoothing_loss(logits, target, 0.1, 0, grad_scale=gs)
+            ops.backward(loss)
+            return loss.detach().clone(), base.grad.clone()
+        finally:
+            ops._LS_FUSED = was
+    l1, g1 = run(True, scale)
+    l0, g0 = run(False, scale)
+    assert float(g1[:, V:].abs().max()) == 0.0 if ld > V else True            # the zero tail of a padded row
+    assert abs(float(l1) - float(l0)) <= 2e-6 * abs(float(l0)), (float(l1), float(l0))
+    assert rel(g1, g0) < 2e-6, rel(g1, g0)
+    ref_in = buf[:, :V].double().clone().requires_grad_(True)
+    ref = torch_ls_loss(ref_in.view(B, L, V), target, 0.1, 0)
+    ref.backward()
+    assert abs(float(l1) - float(ref)) < 2e-6 * abs(float(ref))
+    assert rel(g1[:, :V], 1024.0 * ref_in.grad) < 5e-6
+    l2, g2 = run(True, scale)                                                     # deterministic: bit-equal on a second run
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)
+    l3, g3 = run(True, None)                                                      # no scale: the plain gradient
+    assert rel(g3 * 1024.0, g1) < 1e-6 and torch.equal(l3, l1)
+    # a gradient that is NOT the unit seed of ops.backward takes the general path
+    base = buf.clone().requires_grad_(True)
+    loss = ops.label_smoothing_loss(base[:, :V].view(B, L, V), target, 0.1, 0, grad_scale=scale)
+    (2.5 * loss).backward()
+    assert rel(base.grad, 2.5 * g1) < 1e-6
+
+
+def test_fused_loss_replays_from_a_hipgraph():
+    """the arrival ticket is left at zero by every launch: a captured loss launch replays any number of times"""
+    from opentransformer_amd import ops
+    B, L, V = 32, 15, 4234
+    g = torch.Generator().manual_seed(5)
+    buf = torch.randn(B * L, 4240, generator=g).to(DEV)
+    target = torch.randint(1, V, (B, L), generator=g).to(DEV)
+    logits = buf[:, :V].view(B, L, V)
+    want = ops.label_smoothing_loss(logits, target, 0.1, 0).clone()            # eager first: allocates the ticket outside the capture
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.label_smoothing_loss(logits, target, 0.1, 0)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with ops.graph_capture(graph):
+        out = ops.label_smoothing_loss(logits, target, 0.1, 0)
+    for _ in range(4):
+        out.fill_(-1.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), (float(out), float(want))
+    assert int(ops._ls_ticket(buf.device)[0]) == 0
+
+
+def test_embedding_reads_token_views_and_takes_the_decoder_slabs():
+    from opentransformer_amd import ops
+    from tests.test_gpu_decoder_fused import make_decoder, inputs, run_hip
+    ops.set_compute_dtype('fp16')
+    try:
+        B, Lq, T, vocab = 5, 15, 70, 200
+        dec = make_decoder(2, 1024, vocab, 0.0, seed=3)
+        dec.train()
+        tokens, memory, key_mask, gy = inputs(B, Lq, T, vocab, seed=11)
+        truth = torch.cat([tokens, tokens[:, :1]], dim=1)                         # [B, L + 1]: tokens = truth[:, :-1] as a VIEW
+        view = truth[:, :-1]
+        assert not view.is_contiguous()
+        names = ['memory'] + [n for n, _ in dec.named_parameters()]
+        res = {}
+        for label, sink, tok in (('sink+view', True, view), ('sum+contiguous', False, tokens)):
+            was = ops._EMBED_SINK
+            ops._EMBED_SINK = sink
+            try:
+                recs = []
+                ops.set_kernel_timer(recs)
+                try:
+                    res[label] = run_hip(dec, tok, memory, key_mask, gy, fused=True)
+                finally:
+                    ops.set_kernel_timer(None)
+            finally:
+                ops._EMBED_SINK = was
+        (ya, ga), (yb, gb) = res['sink+view'], res['sum+contiguous']
+        assert torch.equal(ya, yb)
+        for n, a, b in zip(names, ga, gb):
+            assert rel(a, b) < (2e-6 if n != 'embedding.weight' else 2e-5), (n, rel(a, b))   # embedding: float atomics, fp32 vs 16-bit-rounded sums
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp16', 'fp32'])
+def test_model_step_with_views_and_fused_loss_matches_the_round4_forms(mode):
+    """SpeechToText.forward (model/speech2text.py:44-62): the shifted target VIEWS + the one-launch loss with the loss scale folded in
+    against torch.stack + three-kernel loss + ScaleGradFn, same parameters, same batch: same loss, same gradients"""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops, synthetic as syn
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+    ops.set_compute_dtype(mode)
+    try:
+        cfg = syn.c1_model(0.0)
+        inputs, targets = syn.synthetic_batch(batch=4, frames=200, feat_dim=80, vocab=100, tgt_len=10, seed=0, lengths=[200, 180, 150, 97],
+                                              tgt_lengths=[10, 8, 10, 5])
+        inputs, targets = {k: v.to(DEV) for k, v in inputs.items()}, {k: v.to(DEV) for k, v in targets.items()}
+        out = {}
+        for label, fused in (('new', True), ('old', False)):
+            was = (ops._LS_FUSED, ops._EMBED_SINK)
+            ops._LS_FUSED = ops._EMBED_SINK = fused
+            try:
+                model = ota.SpeechToText(cfg)
+                syn.fill_state_dict_(model.state_dict(), 21)
+                model = model.to(DEV).train()
+                dp = FlatDataParallel(model)
+                opt = FusedAdam(dp, lr=1e-3, loss_scale=(512.0 if mode == 'fp16' else None))
+                dp.zero_grad()
+                loss, _ = dp(inputs, targets)
+                ops.backward(loss)
+                torch.cuda.synchronize()
+                out[label] = (loss.detach().clone(), dp.flat_grad.clone())
+            finally:
+                ops._LS_FUSED, ops._EMBED_SINK = was
+        assert abs(float(out['new'][0]) - float(out['old'][0])) < 2e-6 * abs(float(out['old'][0]))
+        assert rel(out['new'][1], out['old'][1]) < (1e-5 if mode == 'fp32' else 1e-3), rel(out['new'][1], out['old'][1])
+    finally:
+        ops.set_compute_dtype('bf16')
