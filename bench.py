@@ -367,8 +367,7 @@ def main():
         whole = world == 1 and not overlap and args.opt_in_graph == 'on' and not args.no_graph
 
         def stage1():
-            dp.zero_grad()
-            ops.next_dropout_step(dev)
+            dp.zero_grad(next_dropout_step=True)   # the gradient fill and the dropout seed's step in one launch
             loss, _ = dp(inputs, targets)
             ops.backward(loss)                    # staged: stops at the encoder / decoder cut (ops.early_mark); else the whole pass
             loss_buf.t = loss.detach()

@@ -178,6 +178,10 @@ int32_t otr_rb_linear_ln_bwd(const void* g16, int64_t ldg, const void* wt_pack, 
 /* Read [p, p + bytes) once and consume nothing: the lines are then in the memory-side cache for the launches that follow (the fused
  * decoder's packed weights, touched once before the stack's forward pass). */
 int32_t otr_touch(const void* p, int64_t bytes, void* stream);
+/* The start of a training step in one launch: buf[0..n) = 0 (the flat gradient buffer; f32, 16-byte aligned) and, when counter is not
+ * NULL, counter[0] += inc (the device-resident dropout seed, advanced once per step so that forward and backward of one step draw
+ * the same masks).  Replaces a fill launch + an 8-byte add launch (train/trainer.py:206-208 optimizer.zero_grad()). */
+int32_t otr_zero_tick(float* buf, int64_t n, int64_t* counter, int64_t inc, void* stream);
 int32_t otr_touch_hint(const void* p0, int64_t bytes0, const void* p1, int64_t bytes1);
 int32_t otr_rb_linear_ln_bwd_pf(const void* g16, int64_t ldg, const void* wt_pack, const float* skip, int64_t lds, const float* z,
                                 const float* mean, const float* rstd, const float* gamma, const uint64_t* seed, float p_drop,
@@ -349,6 +353,11 @@ int32_t otr_glu_bwd(const void* h, const void* du, void* dh, float* dbias, int32
  *      x may alias y. */
 int32_t otr_posenc_fwd(const float* x, float* y, void* y_bf16, int64_t rows, int32_t T, int32_t d, float scale,
                        void* stream);
+/* the same launch also casts the encoder's key mask: mask_out[r] (uint8 [rows]) = mask_in[(r / T) * mask_bs + (r % T) * mask_ts] != 0,
+ * mask_in = the bytes of a bool / uint8 mask read through its strides (the frame mask behind the two stride-2 convolutions is a
+ * strided view, frontend/conv.py:78-83); both NULL = otr_posenc_fwd.  d % 4 == 0, x / y 16-byte aligned. */
+int32_t otr_posenc_mask_fwd(const float* x, float* y, void* y_bf16, int64_t rows, int32_t T, int32_t d, float scale,
+                            const uint8_t* mask_in, int64_t mask_bs, int64_t mask_ts, uint8_t* mask_out, void* stream);
 /* decoder embedding + posenc (decoder/transformer.py:163-169): y[r,:] = E[tok[r],:]*scale + PE[r % L] */
 int32_t otr_embed_posenc_fwd(const int64_t* tok, const float* E, float* y, void* y_bf16, int64_t rows, int32_t L,
                              int32_t d, int32_t vocab, float scale, void* stream);

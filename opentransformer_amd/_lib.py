@@ -110,6 +110,7 @@ SIGNATURES = {
     'otr_ln_bwd_proj_partial_rows': [_I64],
     'otr_rb_linear_ln_bwd': [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _F32, C.c_uint64, _P, _P, _P, _I64, _I32, _I32, _P],
     'otr_touch': [_P, _I64, _P],
+    'otr_zero_tick': [_P, _I64, _P, _I64, _P],
     'otr_touch_hint': [_P, _I64, _P, _I64],
     'otr_rb_linear_ln_bwd_pf': [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _F32, C.c_uint64, _P, _P, _P, _I64, _I32, _I32, _P, _I64, _P],
     'otr_ln_bwd_proj': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I32, _F32, C.c_uint64, _P],
@@ -125,6 +126,7 @@ SIGNATURES = {
     'otr_glu_fwd': [_P, _P, _I32, _I64, _I64, _P, _P],
     'otr_glu_bwd': [_P, _P, _P, _P, _I32, _I64, _I64, _P, _I32, _P],
     'otr_posenc_fwd': [_P, _P, _P, _I64, _I32, _I32, _F32, _P],
+    'otr_posenc_mask_fwd': [_P, _P, _P, _I64, _I32, _I32, _F32, _P, _I64, _I64, _P, _P],
     'otr_embed_posenc_fwd': [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _F32, _P],
     'otr_embed_posenc_fwd_ld': [_P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _F32, _P],
     'otr_embed_bwd_ld': [_P, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _I32, _F32, _P],

@@ -292,24 +292,45 @@ extern "C" int32_t otr_act_bwd(const void* x, const void* dy, void* dx, int32_t 
 // PE[t, 2i] = sin(t * exp(-2i ln(1e4)/d)), PE[t, 2i+1] = cos(same)        (module/pos.py:30-42)
 // (pe_value lives in common.h: the incremental decoder must produce the same bits)
 
-__global__ void posenc_kernel(const float* x, float* y, bf16_t* y_lp, int64_t rows, int T, int d, float scale) {
+// Four columns per thread (16-byte loads / stores; the table entry is still pe_value, element by element: the decoder's incremental
+// step must produce the same bits).  Optionally the launch also leaves the encoder's key mask as bytes: mask_out[row] =
+// mask_in[(row / T) * mask_bs + (row % T) * mask_ts] != 0 -- the frame mask after the two stride-2 convolutions is the strided view
+// mask[:, 1::2][:, :t1][:, 1::2][:, :t2] of the batch's bool mask (frontend/conv.py:78-83), and casting it was a launch of its own
+// (9 us in the AISHELL step) in front of the first attention kernel.
+__global__ void posenc_kernel(const float* x, float* y, bf16_t* y_lp, int64_t rows, int T, int d, float scale, const uint8_t* mask_in,
+                              int64_t mask_bs, int64_t mask_ts, uint8_t* mask_out) {
   const float nl = -logf(10000.f) / (float)d;
-  const int64_t total = rows * d;
+  const int d4 = d >> 2;
+  const int64_t total = rows * d4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t row = i / d;
-    int col = (int)(i - row * d);
-    float v = x[i] * scale + pe_value((int)(row % T), col, nl);
-    y[i] = v;
-    if (y_lp) y_lp[i] = f2bf(v);
+    const int64_t row = i / d4;
+    const int col = (int)(i - row * d4) * 4;
+    const int t = (int)(row % T);
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    float4 v;
+    v.x = xv.x * scale + pe_value(t, col, nl);
+    v.y = xv.y * scale + pe_value(t, col + 1, nl);
+    v.z = xv.z * scale + pe_value(t, col + 2, nl);
+    v.w = xv.w * scale + pe_value(t, col + 3, nl);
+    reinterpret_cast<float4*>(y)[i] = v;
+    if (y_lp) reinterpret_cast<uint2*>(y_lp)[i] = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w));
+    if (mask_out && col == 0) mask_out[row] = mask_in[(row / T) * mask_bs + (int64_t)t * mask_ts] != 0 ? 1 : 0;
   }
+}
+extern "C" int32_t otr_posenc_mask_fwd(const float* x, float* y, void* y_bf16, int64_t rows, int32_t T, int32_t d, float scale,
+                                       const uint8_t* mask_in, int64_t mask_bs, int64_t mask_ts, uint8_t* mask_out, void* stream) {
+  OTR_REQUIRE(x && y, "posenc_fwd: null pointer");
+  OTR_REQUIRE(T > 0 && d > 0 && d % 4 == 0 && rows >= 0, "posenc_fwd: bad shape (d %% 4 == 0)");
+  OTR_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0 && (uintptr_t)y_bf16 % 8 == 0, "posenc_fwd: unaligned buffers");
+  OTR_REQUIRE((mask_in == nullptr) == (mask_out == nullptr), "posenc_mask_fwd: mask_in and mask_out go together");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(posenc_kernel, dim3(grid_for(rows * (d / 4))), dim3(256), 0, (hipStream_t)stream, x, y, (bf16_t*)y_bf16, rows, T, d, scale,
+                     mask_in, mask_bs, mask_ts, mask_out);
+  return otr_check_launch("posenc_fwd");
 }
 extern "C" int32_t otr_posenc_fwd(const float* x, float* y, void* y_bf16, int64_t rows, int32_t T, int32_t d,
                                   float scale, void* stream) {
-  OTR_REQUIRE(x && y, "posenc_fwd: null pointer");
-  OTR_REQUIRE(T > 0 && d > 0 && rows >= 0, "posenc_fwd: bad shape");
-  if (rows == 0) return 0;
-  hipLaunchKernelGGL(posenc_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, x, y, (bf16_t*)y_bf16, rows, T, d, scale);
-  return otr_check_launch("posenc_fwd");
+  return otr_posenc_mask_fwd(x, y, y_bf16, rows, T, d, scale, nullptr, 0, 0, nullptr, stream);
 }
 
 // tokens are addressed as tok[(row / L) * ldt + row % L]: a [B, L] view with row stride ldt (truth[:, :-1] of a [B, L + 1] matrix,
@@ -402,6 +423,26 @@ extern "C" int32_t otr_scale(const float* x, float* y, int64_t n, const float* s
   if (n <= 0) return 0;
   hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, s_dev, s_host);
   return otr_check_launch("scale");
+}
+
+// ------------------------------------------------------------------------------------------------ start of a training step
+// The two launches every step begins with -- zero the flat gradient buffer (146 MB at the AISHELL model: 19.6 us), advance the
+// dropout seed (an 8-byte add: 5 us of launch) -- as one: thread 0 of workgroup 0 bumps the counter, everybody clears.  16-byte
+// stores; n = floats, the buffer 16-byte aligned; counter may be NULL.
+__global__ __launch_bounds__(256) void zero_tick_kernel(float* buf, int64_t n, int64_t* counter, int64_t inc) {
+  if (counter && blockIdx.x == 0 && threadIdx.x == 0) counter[0] += inc;
+  const int64_t n4 = n >> 2;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) reinterpret_cast<float4*>(buf)[i] = z;
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) buf[4 * n4 + threadIdx.x] = 0.f;
+}
+extern "C" int32_t otr_zero_tick(float* buf, int64_t n, int64_t* counter, int64_t inc, void* stream) {
+  OTR_REQUIRE(n >= 0 && (buf || n == 0), "zero_tick: bad buffer");
+  OTR_REQUIRE((uintptr_t)buf % 16 == 0 && (uintptr_t)counter % 8 == 0, "zero_tick: buffer must be 16-byte, counter 8-byte aligned");
+  if (n == 0 && !counter) return 0;
+  const int64_t g = ((n >> 2) + 255) / 256;
+  hipLaunchKernelGGL(zero_tick_kernel, dim3((unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g))), dim3(256), 0, (hipStream_t)stream, buf, n, counter, inc);
+  return otr_check_launch("zero_tick");
 }
 
 // ------------------------------------------------------------------------------------------------ touch

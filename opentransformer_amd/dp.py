@@ -304,15 +304,23 @@ class FlatDataParallel:
             if self._side is not None:
                 torch.cuda.current_stream().wait_stream(self._side)
 
-    def zero_grad(self):
+    def zero_grad(self, next_dropout_step=False):
+        """next_dropout_step: also advance the dropout seed (ops.next_dropout_step) -- on the GPU in the same launch as the fill"""
         self._check_grad_views(reinstall=True)      # a view dropped by set_to_none is put back; a foreign .grad raises
         # a step that is abandoned (NaN loss -> zero_grad without all_reduce_gradients) may still have the early group's collective
         # in flight on the side stream: zeroing the buffer under it would race (ADVICE r04)
         self._join_early()
-        self._grad_store.zero_()
         if self.flat_grad.is_cuda:
             from . import ops
+            if next_dropout_step and self._grad_store.dtype == torch.float32:
+                ops.zero_and_next_dropout_step(self._grad_store)
+            else:
+                self._grad_store.zero_()
+                if next_dropout_step:
+                    ops.next_dropout_step(self._grad_store.device)
             ops.discard_pending_weight_grads()      # nothing queued survives into a new step (e.g. after an exception)
+        else:
+            self._grad_store.zero_()
 
     def broadcast_parameters(self, src=0):
         """one-time replica sync at start-up (the reference re-broadcasts every step)."""

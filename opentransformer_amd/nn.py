@@ -118,8 +118,10 @@ class PositionalEncoding(nn.Module):
         self.emb_dim = emb_dim
         self.xscale = math.sqrt(emb_dim)
 
-    def forward(self, x):
-        return ops.posenc(x), None
+    def forward(self, x, mask=None):
+        """mask (an extra keyword the reference's callers never pass): the [B, T] key mask of the rows; its uint8 cast leaves the same
+        launch (ops.PosEncFn) instead of one of its own"""
+        return ops.posenc(x, mask), None
 
 
 def _key_mask(mask, B, Tk):
@@ -391,7 +393,8 @@ class TransformerEncoder(nn.Module):
         if self.relative_positional:                        # encoder/transformer.py:116-120: no sqrt(d) scaling, no absolute PE
             x, pos = inputs.float(), relative_sinusoid(inputs.size(1), inputs.size(2), inputs.device)
         else:
-            (x, _), pos = self.pos_emb(inputs), None
+            # the positional-encoding launch also leaves the key mask as bytes (ops.PosEncFn: no cast launch)
+            (x, _), pos = self.pos_emb(inputs, mask=mask if mask.dim() == 2 else None), None
         # cast once; every layer's key mask is this uint8 view (and the decoder's memory mask: ops._mask_u8 remembers it on the tensor)
         km = (ops._mask_u8(mask, mask.size(0), mask.size(1)) if mask.dim() == 2 else mask.to(torch.uint8)).unsqueeze(1)
         defer = not self.normalize_before and not self.relative_positional

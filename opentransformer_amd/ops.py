@@ -150,8 +150,21 @@ def rng_seed_tensor(device):
     return s
 
 
+_DROPOUT_STEP_INC = 0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF
+
+
 def next_dropout_step(device):
-    rng_seed_tensor(device).add_(0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF)
+    rng_seed_tensor(device).add_(_DROPOUT_STEP_INC)
+    _state['rng_offset'] = 0
+
+
+def zero_and_next_dropout_step(buf):
+    """the start of a training step in ONE launch (otr_zero_tick): clear the flat gradient buffer `buf` (fp32, CUDA) and advance the
+    dropout seed like next_dropout_step -- a fill launch + an 8-byte add launch otherwise"""
+    _cuda(buf)
+    assert buf.dtype == torch.float32 and buf.is_contiguous()
+    seed = rng_seed_tensor(buf.device)
+    L.check(L.load().otr_zero_tick(_p(buf), buf.numel(), _p(seed), _DROPOUT_STEP_INC, _stream()), 'otr_zero_tick')
     _state['rng_offset'] = 0
 
 
@@ -2157,7 +2170,9 @@ class PosEncFn(torch.autograd.Function):
     """x*sqrt(d) + PE (module/pos.py:44-57, scale_learnable=False)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, mask=None):
+        """mask: optional [B, T] bool / uint8 key mask (any strides): its uint8 cast leaves the same launch and is remembered on the
+        mask tensor, where ops._mask_u8 finds it (the encoder's attention launches and the decoder's memory mask read that)"""
         _cuda(x)
         ctx.set_materialize_grads(False)
         B, T, d = x.shape
@@ -2165,7 +2180,15 @@ class PosEncFn(torch.autograd.Function):
         y = torch.empty_like(x)
         ylp = torch.empty(x.shape, dtype=half_dtype(), device=x.device) if is_half() else None
         ctx.scale = math.sqrt(d)
-        L.check(L.load().otr_posenc_fwd(_p(x), _p(y), _p(ylp), B * T, T, d, ctx.scale, _stream()), 'otr_posenc_fwd')
+        u8 = None
+        if (mask is not None and d % 4 == 0 and mask.is_cuda and mask.dim() == 2 and tuple(mask.shape) == (B, T)
+                and mask.dtype in (torch.bool, torch.uint8) and getattr(mask, '_otr_u8', (None,))[0] != mask._version):
+            u8 = torch.empty((B, T), dtype=torch.uint8, device=x.device)
+            L.check(L.load().otr_posenc_mask_fwd(_p(x), _p(y), _p(ylp), B * T, T, d, ctx.scale, _p(mask), mask.stride(0), mask.stride(1),
+                                                 _p(u8), _stream()), 'otr_posenc_mask_fwd')
+            mask._otr_u8 = (mask._version, u8)
+        else:
+            L.check(L.load().otr_posenc_fwd(_p(x), _p(y), _p(ylp), B * T, T, d, ctx.scale, _stream()), 'otr_posenc_fwd')
         if ylp is not None:
             ctx.mark_non_differentiable(ylp)
         return y, ylp
@@ -2173,11 +2196,11 @@ class PosEncFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dylp=None):
         if dy is None:
-            return None
+            return None, None
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
         L.check(L.load().otr_scale(_p(dy), _p(dx), dy.numel(), None, ctx.scale, _stream()), 'otr_scale')
-        return dx
+        return dx, None
 
 
 class _EmbedSink:
@@ -2239,8 +2262,8 @@ class EmbedPosEncFn(torch.autograd.Function):
         return None, (None if gt is not None else dE), None
 
 
-def posenc(x):
-    y, ylp = PosEncFn.apply(x)
+def posenc(x, mask=None):
+    y, ylp = PosEncFn.apply(x, mask)
     return attach_lp(y, ylp)
 
 
