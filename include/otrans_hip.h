@@ -375,6 +375,9 @@ int32_t otr_embed_bwd_ld(const int64_t* tok, int64_t ld_tok, int32_t L, const fl
 int32_t otr_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* y = x * (*s_dev) * s_host, elementwise f32 (n elements); x may alias y; s_dev may be NULL */
 int32_t otr_scale(const float* x, float* y, int64_t n, const float* s_dev, float s_host, void* stream);
+/* y16 (the library's 16-bit type) = x * s, n elements; x 16-byte, y16 8-byte aligned.  The positional encoding's backward
+ * (module/pos.py:44-57) when its gradient goes on as a GEMM operand. */
+int32_t otr_scale_cast(const float* x, void* y16, int64_t n, float s, void* stream);
 
 /* ---- Conv2d-subsampling frontend (frontend/conv.py:50-83 Conv2dLayer, :131-153 ConvFrontEnd).
  *      Activations are channel-last: act1 [B,T1,F1,C1], act2 [B,T2,F2,C2] == [B*T2, F2*C2] rows

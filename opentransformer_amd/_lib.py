@@ -132,6 +132,7 @@ SIGNATURES = {
     'otr_embed_bwd_ld': [_P, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _I32, _F32, _P],
     'otr_embed_bwd': [_P, _P, _P, _I64, _I32, _I32, _F32, _P],
     'otr_scale': [_P, _P, _I64, _P, _F32, _P],
+    'otr_scale_cast': [_P, _P, _I64, _F32, _P],
     'otr_cast_f32_to_bf16': [_P, _P, _I64, _P],
     'otr_conv1_fwd': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
     'otr_conv1_wgrad': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P],

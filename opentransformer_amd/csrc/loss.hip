@@ -109,6 +109,18 @@ extern "C" int32_t otr_label_smoothing_loss_ld(const float* logits, int64_t ld_l
   return otr_check_launch("label_smoothing_loss");
 }
 
+// three sums in one exchange (the waves' partials in a fixed order, like block_reduce)
+__device__ __forceinline__ void block_reduce3(float& a, float& b, float& c, float* sh3) {
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { sh3[wid] = a; sh3[4 + wid] = b; sh3[8 + wid] = c; }
+  __syncthreads();
+  a = sh3[0] + sh3[1] + sh3[2] + sh3[3];
+  b = sh3[4] + sh3[5] + sh3[6] + sh3[7];
+  c = sh3[8] + sh3[9] + sh3[10] + sh3[11];
+}
+
 // ---- the whole loss in ONE launch (round 5).  What the three-kernel form above spends around its 8 MB of logits at the AISHELL
 // shape (480 rows x 4234): three passes over every row with 4-byte loads (17 us), a finalize launch (5 us), and -- in the training
 // step -- two launches that only multiply by a scalar (the loss scale seeding the backward pass, 5 us; the gradient of the loss
@@ -124,6 +136,7 @@ __global__ __launch_bounds__(256) void ls_rows_fused_kernel(const float* logits,
                                                            int64_t R, int V, float eps, int pad_idx, const float* gscale, float* row_loss,
                                                            float* dlogits, int64_t ld_dx, float* loss, unsigned int* ticket) {
   __shared__ float sh[4];
+  __shared__ float sh3[12];
   __shared__ int last_flag;
   const int tid = threadIdx.x;
   const int64_t row = blockIdx.x;
@@ -151,6 +164,9 @@ __global__ __launch_bounds__(256) void ls_rows_fused_kernel(const float* logits,
       xv[k] = q;
       mx = fmaxf(mx, fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
     }
+    // the non-pad count rides in the same reductions (its target loads were issued beside the row's): two block exchanges in all
+    float cnt = 0.f;
+    for (int64_t i = tid; i < R; i += 256) cnt += (target[(i / L) * ldt + (i % L)] != pad_idx) ? 1.f : 0.f;
     mx = block_reduce(mx, sh, true);
     float se = 0.f, sx = 0.f;
 #pragma unroll
@@ -161,10 +177,9 @@ __global__ __launch_bounds__(256) void ls_rows_fused_kernel(const float* logits,
       for (int j = 0; j < 4; ++j)
         if (v + j < V) { se += expf(e[j] - mx); sx += e[j]; }
     }
-    se = block_reduce(se, sh, false);
-    sx = block_reduce(sx, sh, false);
+    block_reduce3(se, sx, cnt, sh3);
     const float lse = mx + logf(se);
-    const float inv_cnt = 1.f / ls_count_ld(target, ldt, L, R, pad_idx, sh);
+    const float inv_cnt = 1.f / cnt;
     const float off = eps / (float)(V - 1), on = 1.f - eps;
     if (dx) {
       const float g = inv_cnt * (gscale ? gscale[0] : 1.f);

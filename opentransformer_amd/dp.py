@@ -105,7 +105,26 @@ class FlatDataParallel:
         # the gradient buffer carries one extra cell behind the parameters' range (its own 64-element block): the collective
         # sums it like any gradient, and all_reduce_gradients() uses it to make the fault word GLOBAL (see there).  Optimizer
         # and norm only ever see the first `padded` elements.
-        self._grad_store = torch.zeros(padded + ALIGN, device=dev, dtype=dt)
+        # ... and behind that, staging images for the gradients of weights a kernel reads with two axes swapped
+        # (nn.ConvFrontEnd.regrouped_weights): the weight-gradient launch accumulates there in the kernel's order, one strided add
+        # regroups it into the parameter's layout (ops.LinearFn.backward).  Part of the one allocation zero_grad() clears; NOT part of
+        # the buffer the collectives move.
+        stage_of, stage_total = {}, 0
+        if dev.type == 'cuda' and dt == torch.float32:
+            for mod in module.modules():
+                regroup = getattr(mod, 'regrouped_weights', None)
+                for p, (A, R, S) in (regroup() if callable(regroup) else []):
+                    if any(p is q for q in params) and p.dim() == 2 and p.numel() == A * R * S and id(p) not in stage_of:
+                        stage_of[id(p)] = (stage_total, (A, S, R))
+                        stage_total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self._store_all = torch.zeros(padded + ALIGN + stage_total, device=dev, dtype=dt)
+        self._grad_store = self._store_all[:padded + ALIGN]
+        for p in params:
+            if id(p) in stage_of:
+                o, shp = stage_of[id(p)]
+                p._otr_regroup_grad = self._store_all[padded + ALIGN + o:padded + ALIGN + o + p.numel()].view(shp)
+                p._otr_regroup_state = {'dirty': False}      # True once a backward pass has added the image to the gradient
+        self._staged = [p for p in params if id(p) in stage_of]
         self.flat_grad = self._grad_store[:padded]
         self._fault_cell = self._grad_store[padded:padded + 1]
         self.flat_param = torch.empty(padded, device=dev, dtype=dt) if flatten_params else None
@@ -310,17 +329,19 @@ class FlatDataParallel:
         # a step that is abandoned (NaN loss -> zero_grad without all_reduce_gradients) may still have the early group's collective
         # in flight on the side stream: zeroing the buffer under it would race
         self._join_early()
+        for p in self._staged:
+            p._otr_regroup_state['dirty'] = False
         if self.flat_grad.is_cuda:
             from . import ops
-            if next_dropout_step and self._grad_store.dtype == torch.float32:
-                ops.zero_and_next_dropout_step(self._grad_store)
+            if next_dropout_step and self._store_all.dtype == torch.float32:
+                ops.zero_and_next_dropout_step(self._store_all)
             else:
-                self._grad_store.zero_()
+                self._store_all.zero_()
                 if next_dropout_step:
-                    ops.next_dropout_step(self._grad_store.device)
+                    ops.next_dropout_step(self._store_all.device)
             ops.discard_pending_weight_grads()      # nothing queued survives into a new step (e.g. after an exception)
         else:
-            self._grad_store.zero_()
+            self._store_all.zero_()
 
     def broadcast_parameters(self, src=0):
         """one-time replica sync at start-up (the reference re-broadcasts every step)."""

@@ -510,7 +510,7 @@ def linear_dgrad_raw(dy2, w, dx_dtype, out=None):
 # engine callback of that run), so two models trained in one process -- an ASR model and an LM, say -- never see each
 # other's items as long as their backward passes do not interleave on one thread; a pass that dies half way leaves its
 # items behind, which the owner's zero_grad() / the next pass's first enqueue (different graph-task id) discards.
-_wq = {'on': False, 'w': [], 'b': [], 'armed': False, 'task': None}
+_wq = {'on': False, 'w': [], 'b': [], 'post': [], 'armed': False, 'task': None}    # post: callables run behind the grouped launches
 _FUSE_BIAS_COLSUM = os.environ.get('OTR_NO_FUSED_BIAS_COLSUM', '0') != '1'
 _DEBUG_WQ = os.environ.get('OTR_DEBUG_WQ', '0') == '1'
 
@@ -522,7 +522,7 @@ def defer_weight_grads(on):
 def discard_pending_weight_grads():
     """Drop queued (never launched) weight-gradient work, e.g. left behind by a backward pass that raised.  Called by
     FlatDataParallel.zero_grad(): a stale queue must not leak into the next step's gradients."""
-    _wq['w'], _wq['b'], _wq['armed'], _wq['task'] = [], [], False, None
+    _wq['w'], _wq['b'], _wq['post'], _wq['armed'], _wq['task'] = [], [], [], False, None
 
 
 def _arm_flush():
@@ -539,8 +539,8 @@ def flush_weight_grads():
     """Launch everything queued by linear_wgrad_raw / colsum_raw (called by the autograd engine at the end of
     backward; safe to call by hand)."""
     _wq['armed'], _wq['task'] = False, None
-    w, b = _wq['w'], _wq['b']
-    _wq['w'], _wq['b'] = [], []
+    w, b, post = _wq['w'], _wq['b'], _wq['post']
+    _wq['w'], _wq['b'], _wq['post'] = [], [], []
     if _wq.get('keep_last'):            # bench.py re-times the grouped launch on the items of the last backward
         _wq['last'] = (list(w), list(b))
     lib = L.load()
@@ -587,6 +587,8 @@ def flush_weight_grads():
             it.a, it.out = a2.data_ptr(), out.data_ptr()
             it.M, it.N, it.lda, it.dtype = a2.shape[0], a2.shape[1], a2.stride(0), _code(a2.dtype)
         L.check(lib.otr_colsum_grouped(items, len(b), _stream()), 'otr_colsum_grouped')
+    for fn in post:                      # work that reads what the grouped launches just wrote (LinearFn: a regrouped weight gradient)
+        fn()
 
 
 # ---------------------------------------------------------------------------------------- early gradient groups
@@ -862,7 +864,7 @@ class LinearFn(torch.autograd.Function):
     channel-last flatten of the conv frontend, frontend/conv.py:145); dw is regrouped back."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu, out_dtype, perm, defer_bias=False, link=None):
+    def forward(ctx, x, w, b, relu, out_dtype, perm, defer_bias=False, link=None, g16=None):
         _cuda(x, w, b)
         ctx.defer_bias = defer_bias      # the consumer (AddLayerNormFn, a_bias=b) produces the bias gradient
         ctx.link = link
@@ -905,6 +907,12 @@ class LinearFn(torch.autograd.Function):
         ctx.relu = relu
         ctx.has_bias = b is not None
         ctx.perm = perm
+        # 16-bit output-gradient hand-over (_Grad16Link): the Linear with regrouped columns (the frontend's output layer), fp32 output,
+        # in-place gradient buffers with a kernel-order staging image of this weight's gradient (dp.FlatDataParallel), 16-bit operands
+        ctx.g16 = None
+        if g16 is not None and xc is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[0]):
+            ctx.g16 = g16
+            g16.armed = True
         ctx.wt = weight_lpt(w) if (perm is None and ctx.needs_input_grad[0]) else None
         ctx.w_ref, ctx.b_ref = w, b
         ctx.save_for_backward(x2, wc, y if relu else None)
@@ -914,6 +922,9 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, wc, y = ctx.saved_tensors
+        g16 = ctx.g16
+        if g16 is not None and g16.buf is not None and _is_zero_placeholder(dy):
+            dy, g16.buf = g16.buf, None              # the gradient as the 16-bit operand PosEncFn.backward wrote
         dy2 = _rows(dy)
         if ctx.relu:
             dy2 = relu_bwd_raw(y, dy2.contiguous())
@@ -936,7 +947,7 @@ class LinearFn(torch.autograd.Function):
                     linear_wgrad_raw(dyp, x2, pw['lp'], out=pw['grad'])
                 if ctx.has_bias and ctx.needs_input_grad[2] and not ctx.defer_bias:
                     colsum_raw(dyp, out=pb['grad'])
-                return dx, None, None, None, None, None, None, None
+                return dx, None, None, None, None, None, None, None, None
         dx = None
         if ctx.needs_input_grad[0]:
             skip = None
@@ -960,6 +971,20 @@ class LinearFn(torch.autograd.Function):
             gt = grad_target(ctx.w_ref) if ctx.perm is None else None
             if gt is not None:
                 linear_wgrad_raw(dy2, x2, wc, out=gt)
+            elif (ctx.perm is not None and dy2.dtype == half_dtype() and x2.dtype == half_dtype() and _wq['on'] and _in_backward()
+                  and getattr(ctx.w_ref, '_otr_regroup_grad', None) is not None and grad_target(ctx.w_ref) is not None):
+                # 16-bit operands: the product joins the grouped 256-wide launch, accumulating into the KERNEL-order staging image of
+                # this weight's gradient (zeroed with the gradient buffer); behind that launch one strided add regroups it into the
+                # parameter's layout (flush_weight_grads runs the hook)
+                C_, F_ = ctx.perm
+                stage = ctx.w_ref._otr_regroup_grad.view(wc.shape[0], F_ * C_)
+                st = ctx.w_ref._otr_regroup_state
+                if st['dirty']:                  # a second backward pass before the next zero_grad() (gradient accumulation): the image
+                    stage.zero_()                # of the first was already added to the gradient
+                st['dirty'] = True
+                linear_wgrad_raw(dy2, x2, wc, out=stage)
+                gt_w = grad_target(ctx.w_ref)
+                _wq['post'].append(lambda gt_w=gt_w, stage=stage, C_=C_, F_=F_: gt_w.view(-1, C_, F_).add_(stage.view(-1, F_, C_).permute(0, 2, 1)))
             else:
                 dw = linear_wgrad_raw(dy2, x2, wc)
                 if ctx.perm is not None:
@@ -978,13 +1003,21 @@ class LinearFn(torch.autograd.Function):
                 colsum_raw(dy2, out=gt)
             else:
                 db = colsum_raw(dy2)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 def linear(x, w, b=None, relu=False, out_dtype=None, perm=None, defer_bias=False, link=None):
     """defer_bias=True: the caller hands `b` to add_layernorm(..., a_bias=b), whose backward reduces the bias
     gradient in the same pass that produces the branch gradient."""
-    return LinearFn.apply(x, w, b, relu, out_dtype if out_dtype is not None else torch.float32, perm, defer_bias, link)
+    out_dtype = out_dtype if out_dtype is not None else torch.float32
+    g16 = None
+    if (_G16 and perm is not None and not relu and out_dtype == torch.float32 and is_half() and _wq['on'] and torch.is_grad_enabled()
+            and getattr(w, '_otr_regroup_grad', None) is not None):
+        g16 = _Grad16Link()
+    y = LinearFn.apply(x, w, b, relu, out_dtype, perm, defer_bias, link, g16)
+    if g16 is not None and g16.armed:
+        y._otr_g16 = g16                 # read by PosEncFn.forward when y is its input
+    return y
 
 
 def relu_bwd_raw(y, g):
@@ -2166,6 +2199,19 @@ def decoder_stack(x0, kv_all, kmask_u8, blocks, S):
 
 
 # ---------------------------------------------------------------------------------------- positional encoding
+class _Grad16Link:
+    """The gradient of a Linear's fp32 OUTPUT handed to that Linear's backward as a 16-bit tensor, outside autograd's own bookkeeping
+    (which would cast it back to the output's dtype).  The Linear in front of the encoder's positional encoding (frontend/conv.py:146)
+    reads its output gradient only as a GEMM operand -- dx, dw and db are all products with it -- so PosEncFn.backward writes
+    sqrt(d) dy straight in the 16-bit operand type, parks it here and returns a stride-0 zero placeholder; LinearFn.backward picks it
+    up.  With 16-bit operands the weight gradient joins the 256-wide grouped launch instead of a split-K GEMM of its own."""
+    buf = None
+    armed = False
+
+
+_G16 = os.environ.get('OTR_GRAD16_LINK', '1') == '1'
+
+
 class PosEncFn(torch.autograd.Function):
     """x*sqrt(d) + PE (module/pos.py:44-57, scale_learnable=False)."""
 
@@ -2180,6 +2226,7 @@ class PosEncFn(torch.autograd.Function):
         y = torch.empty_like(x)
         ylp = torch.empty(x.shape, dtype=half_dtype(), device=x.device) if is_half() else None
         ctx.scale = math.sqrt(d)
+        ctx.g16 = getattr(x, '_otr_g16', None)         # x is the output of a LinearFn that takes its gradient as a 16-bit operand
         u8 = None
         if (mask is not None and d % 4 == 0 and mask.is_cuda and mask.dim() == 2 and tuple(mask.shape) == (B, T)
                 and mask.dtype in (torch.bool, torch.uint8) and getattr(mask, '_otr_u8', (None,))[0] != mask._version):
@@ -2198,6 +2245,14 @@ class PosEncFn(torch.autograd.Function):
         if dy is None:
             return None, None
         dy = dy.contiguous()
+        link = ctx.g16
+        if (link is not None and link.armed and link.buf is None and dy.dtype == torch.float32 and is_half() and _in_backward()
+                and dy.data_ptr() % 16 == 0):
+            g16 = torch.empty(dy.shape, dtype=half_dtype(), device=dy.device)
+            L.check(L.load().otr_scale_cast(_p(dy), _p(g16), dy.numel(), ctx.scale, _stream()), 'otr_scale_cast')
+            link.buf = g16
+            _park(link)
+            return _zero_placeholder(dy.device, dy.shape), None
         dx = torch.empty_like(dy)
         L.check(L.load().otr_scale(_p(dy), _p(dx), dy.numel(), None, ctx.scale, _stream()), 'otr_scale')
         return dx, None

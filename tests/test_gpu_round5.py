@@ -235,3 +235,55 @@ def test_posenc_launch_also_casts_the_key_mask():
         assert rel(y1, ref + pe) < 1e-6
     finally:
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('accumulate', [False, True])
+def test_frontend_linear_takes_its_gradient_as_a_16bit_operand(accumulate):
+    """ops._Grad16Link: the positional encoding's backward hands sqrt(d) dy to the frontend's output Linear as a 16-bit operand (its
+    weight gradient then joins the grouped 256-wide launch through a kernel-order staging image + one regrouping add).  Against the
+    fp32-gradient path on the same model and batch: every gradient behind the hand-over (frontend) agrees to 16-bit rounding, every
+    other gradient exactly; with two backward passes per step (accumulation) the staging image is not counted twice."""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops, synthetic as syn
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+    ops.set_compute_dtype('fp16')
+    try:
+        cfg = syn.c2_model(0.0)
+        cfg['encoder']['n_blocks'] = 2
+        cfg['decoder']['n_blocks'] = 1
+        inputs, targets = syn.synthetic_batch(batch=4, frames=400, feat_dim=80, vocab=4234, tgt_len=8, seed=2, lengths=[400, 333, 280, 395])
+        inputs, targets = {k: v.to(DEV) for k, v in inputs.items()}, {k: v.to(DEV) for k, v in targets.items()}
+        out = {}
+        for label, on in (('g16', True), ('fp32', False)):
+            was = ops._G16
+            ops._G16 = on
+            try:
+                model = ota.SpeechToText(cfg)
+                syn.fill_state_dict_(model.state_dict(), 5)
+                model = model.to(DEV).train()
+                dp = FlatDataParallel(model)
+                FusedAdam(dp, lr=1e-3, loss_scale=256.0)
+                names = recs = []
+                ops.set_kernel_timer(recs)
+                try:
+                    dp.zero_grad()
+                    for _ in range(2 if accumulate else 1):
+                        loss, _ = dp(inputs, targets)
+                        ops.backward(loss)
+                finally:
+                    ops.set_kernel_timer(None)
+                torch.cuda.synchronize()
+                out[label] = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+                out[label + '_staged'] = getattr(model.frontend.output_layer.weight, '_otr_regroup_state', {'dirty': None})['dirty']
+            finally:
+                ops._G16 = was
+        assert out['g16_staged'] is True and out['fp32_staged'] is False          # the hand-over really ran / really did not
+        for n, g in out['g16'].items():
+            r = rel(g, out['fp32'][n])
+            if n.startswith('frontend.'):
+                assert r < 4e-3, (n, r)          # the output gradient rounded to fp16 once (eps 4.9e-4) before three GEMMs
+            else:
+                assert r < 1e-5, (n, r)          # nothing in front of the hand-over changes (float atomics aside)
+        assert float(out['g16']['frontend.output_layer.weight'].abs().sum()) > 0
+    finally:
+        ops.set_compute_dtype('bf16')
