@@ -910,7 +910,7 @@ class LinearFn(torch.autograd.Function):
         # 16-bit output-gradient hand-over (_Grad16Link): the Linear with regrouped columns (the frontend's output layer), fp32 output,
         # in-place gradient buffers with a kernel-order staging image of this weight's gradient (dp.FlatDataParallel), 16-bit operands
         ctx.g16 = None
-        if g16 is not None and xc is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[0]):
+        if g16 is not None and x2.dtype == half_dtype() and (ctx.needs_input_grad[1] or ctx.needs_input_grad[0]):
             ctx.g16 = g16
             g16.armed = True
         ctx.wt = weight_lpt(w) if (perm is None and ctx.needs_input_grad[0]) else None

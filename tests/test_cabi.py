@@ -55,6 +55,31 @@ def test_optimizer_step_validates_before_it_launches():
     assert call(noise=-1.0) < 0
 
 
+def test_argument_errors_of_the_round5_entries():
+    """the entries added in round 5 validate before they launch (no GPU here): the one-launch loss, the token-view embedding, the
+    step-start fill, the scaled cast, the positional encoding with the mask cast"""
+    lib = _lib.load()
+    al, odd = C.c_void_p(4096), C.c_void_p(4096 + 4)
+
+    def loss(logits=al, ld=4240, ldt=16, L=15, R=480, V=4234, dl=al, ldd=4240, ticket=al, scratch=al):
+        return lib.otr_label_smoothing_loss_fused(logits, ld, al, ldt, L, R, V, 0.1, 0, None, al, dl, ldd, scratch, ticket, None)
+    assert loss(ticket=None) < 0 and b'label_smoothing_loss_fused' in lib.otr_last_error_string()
+    assert loss(ld=4234) < 0            # rows not 16-byte aligned (ld % 4 != 0): the three-kernel form serves those
+    assert loss(logits=odd) < 0
+    assert loss(R=481) < 0              # R % L != 0
+    assert loss(ldt=14) < 0             # row stride of the target view shorter than L
+    assert loss(V=9000, ld=9000, ldd=9000) < 0
+    assert loss(R=480 * 32, L=15) < 0   # > 8192 rows
+    assert lib.otr_embed_posenc_fwd_ld(al, 14, al, al, None, 480, 15, 256, 4234, 16.0, None) < 0       # ld_tok < L
+    assert lib.otr_embed_bwd_ld(al, 16, 15, None, None, 0, al, 480, 256, 4234, 16.0, None) < 0         # neither dy nor slabs
+    assert lib.otr_embed_bwd_ld(al, 16, 15, None, None, 4, al, 480, 256, 4234, 16.0, None) < 0         # nslab without slabs
+    assert lib.otr_zero_tick(odd, 1024, None, 0, None) < 0 and b'zero_tick' in lib.otr_last_error_string()
+    assert lib.otr_zero_tick(None, 0, None, 0, None) == 0                                                # nothing to do
+    assert lib.otr_scale_cast(odd, al, 1024, 16.0, None) < 0 and lib.otr_scale_cast(None, al, 8, 1.0, None) < 0
+    assert lib.otr_posenc_mask_fwd(al, al, None, 64, 8, 254, 16.0, None, 0, 0, None, None) < 0           # d % 4 != 0
+    assert lib.otr_posenc_mask_fwd(al, al, None, 64, 8, 256, 16.0, al, 8, 1, None, None) < 0             # mask_in without mask_out
+
+
 def test_argument_errors_of_the_fused_and_grouped_entries():
     """the entries added for fusion / grouping / decoding validate before they launch (no GPU here)"""
     lib = _lib.load()
