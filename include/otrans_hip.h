@@ -598,6 +598,16 @@ int32_t otr_spec_mask(float* x, const int32_t* ranges, int32_t B, int32_t NR, in
  *   *pos_out = *pos_in + 1 (in/out buffers must be distinct). */
 int32_t otr_decode_embed(const int64_t* preds, int64_t ldp, const int32_t* pos, const float* E, float* y, void* y_bf16,
                          int64_t rows, int32_t d, int32_t vocab, float scale, void* stream);
+/* ---- the recurrent language model of the shallow fusion (model/lm.py:33-91: nn.Embedding -> nn.LSTM -> Linear; reached through
+ *      recognize/base.py:26-37, which feeds it the LAST token of every hypothesis).
+ * otr_decode_lookup: y[r,:] = E[preds[r, *pos],:] (f32 + optional 16-bit twin), pos a device scalar or NULL (= column 0).
+ * otr_lstm_cell:     one cell update in torch.nn.LSTM's gate order i | f | g | o: gates = gates_a [rows,4H] + gates_b [rows,4H] (NULL)
+ *                    + bias_b [4H] (NULL);  c = sigmoid(f) c_prev + sigmoid(i) tanh(g) (c_prev NULL = zeros);  h = sigmoid(o) tanh(c).
+ *                    The two GEMMs (W_ih x + b_ih, W_hh h + b_hh) are otr_linear_fwd calls. */
+int32_t otr_decode_lookup(const int64_t* preds, int64_t ldp, const int32_t* pos, const float* E, float* y, void* y_bf16, int64_t rows,
+                          int32_t d, int32_t vocab, void* stream);
+int32_t otr_lstm_cell(const float* gates_a, const float* gates_b, const float* bias_b, const float* c_prev, float* h, void* h_bf16,
+                      float* c, int64_t rows, int32_t hidden, void* stream);
 int32_t otr_decode_self_attention(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const int32_t* pos,
                                   void* out, int32_t dtype, int64_t rows, int32_t H, int32_t dk, int32_t maxlen,
                                   float scale, void* stream);

@@ -176,6 +176,8 @@ SIGNATURES = {
     'otr_beam_prune': [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     'otr_beam_prune_cached': [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P],
     'otr_decode_embed': [_P, _I64, _P, _P, _P, _P, _I64, _I32, _I32, _F32, _P],
+    'otr_decode_lookup': [_P, _I64, _P, _P, _P, _P, _I64, _I32, _I32, _P],
+    'otr_lstm_cell': [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P],
     'otr_decode_self_attention': [_P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _I32, _F32, _P],
     'otr_residual_add_fwd': [_P, _P, _I32, _P, _I64, _F32, _F32, _P, C.c_uint64, _P],
     'otr_residual_add_bwd': [_P, _P, _I32, _I64, _F32, _F32, _P, C.c_uint64, _P],

@@ -40,6 +40,67 @@ extern "C" int32_t otr_decode_embed(const int64_t* preds, int64_t ldp, const int
   return otr_check_launch("decode_embed");
 }
 
+// ---- recurrent language model in the fused search (model/lm.py:72-79 through recognize/base.py:26-37)
+// y[r] = E[preds[r, *pos]]: the plain nn.Embedding row of each hypothesis' LAST token (no scale, no positional term), position read
+// from device memory like decode_embed (pos == NULL: column 0 of preds).
+__global__ void decode_lookup_kernel(const int64_t* preds, int64_t ldp, const int32_t* pos, const float* E, float* y, bf16_t* y_lp, int d,
+                                     int vocab) {
+  const int64_t r = blockIdx.x;
+  const int64_t t = preds[r * ldp + (pos ? *pos : 0)];
+  const bool ok = t >= 0 && t < vocab;
+  for (int col = threadIdx.x; col < d; col += blockDim.x) {
+    const float v = ok ? E[t * d + col] : 0.f;
+    y[r * d + col] = v;
+    if (y_lp) y_lp[r * d + col] = f2bf(v);
+  }
+}
+extern "C" int32_t otr_decode_lookup(const int64_t* preds, int64_t ldp, const int32_t* pos, const float* E, float* y, void* y_bf16,
+                                     int64_t rows, int32_t d, int32_t vocab, void* stream) {
+  OTR_REQUIRE(preds && E && y, "decode_lookup: null pointer");
+  OTR_REQUIRE(rows >= 0 && d > 0 && vocab > 0 && ldp > 0, "decode_lookup: bad shape");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(decode_lookup_kernel, dim3((unsigned)rows), dim3(d >= 256 ? 256 : 64), 0, (hipStream_t)stream, preds, ldp, pos, E, y,
+                     (bf16_t*)y_bf16, d, vocab);
+  return otr_check_launch("decode_lookup");
+}
+
+// One LSTM cell update (torch.nn.LSTM's equations, gate order i | f | g | o): gates = ga + gb + bias_b with ga = W_ih x + b_ih the
+// caller's first GEMM, gb = W_hh h + b_hh its second (NULL when the previous state is zero: then bias_b = b_hh is all that is left
+// of that term), c_prev NULL = zeros.
+//   c = sigmoid(f) c_prev + sigmoid(i) tanh(g);  h = sigmoid(o) tanh(c)        -> h (f32 + 16-bit twin for the next GEMM), c (f32)
+__global__ void lstm_cell_kernel(const float* ga, const float* gb, const float* bias_b, const float* c_prev, float* h, bf16_t* h_lp, float* c,
+                                 int64_t rows, int H) {
+  const int64_t total = rows * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / H;
+    const int j = (int)(i - r * H);
+    float g4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v = ga[r * 4 * H + q * H + j];
+      if (gb) v += gb[r * 4 * H + q * H + j];
+      if (bias_b) v += bias_b[q * H + j];
+      g4[q] = v;
+    }
+    const float si = 1.f / (1.f + expf(-g4[0])), sf = 1.f / (1.f + expf(-g4[1])), so = 1.f / (1.f + expf(-g4[3]));
+    const float cn = sf * (c_prev ? c_prev[i] : 0.f) + si * tanhf(g4[2]);
+    const float hn = so * tanhf(cn);
+    c[i] = cn;
+    h[i] = hn;
+    if (h_lp) h_lp[i] = f2bf(hn);
+  }
+}
+extern "C" int32_t otr_lstm_cell(const float* gates_a, const float* gates_b, const float* bias_b, const float* c_prev, float* h, void* h_bf16,
+                                 float* c, int64_t rows, int32_t hidden, void* stream) {
+  OTR_REQUIRE(gates_a && h && c, "lstm_cell: null pointer");
+  OTR_REQUIRE(rows >= 0 && hidden > 0, "lstm_cell: bad shape");
+  if (rows == 0) return 0;
+  const int64_t n = rows * hidden, g = (n + 255) / 256;
+  hipLaunchKernelGGL(lstm_cell_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, (hipStream_t)stream, gates_a, gates_b, bias_b, c_prev, h,
+                     (bf16_t*)h_bf16, c, rows, hidden);
+  return otr_check_launch("lstm_cell");
+}
+
 // One wave per (hypothesis row, head).  qkv: [R, 3d] of the new position (columns q|k|v, module/attention.py:73).
 // Phase 0 stores the new k,v into cache[r, p]; phase 1: lane = key position (chunks of 64, online softmax),
 // each lane dots its ancestor's cached key with q (q staged in LDS); phase 2: lane = head dimension, the

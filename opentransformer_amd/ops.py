@@ -2342,6 +2342,34 @@ def decode_embed(preds, pos, E):
     return attach_lp(y, ylp)
 
 
+def decode_lookup(preds, pos, E):
+    """y[r] = E[preds[r, *pos]] (plain embedding rows of the hypotheses' last tokens; pos a DEVICE int32 scalar, or None = column 0)"""
+    _cuda(preds, E)
+    R, ldp = preds.shape[0], preds.stride(0)
+    V, d = E.shape
+    y = torch.empty((R, d), dtype=torch.float32, device=E.device)
+    ylp = torch.empty((R, d), dtype=half_dtype(), device=E.device) if is_half() else None
+    L.check(L.load().otr_decode_lookup(_p(preds), ldp, _p(pos), _p(E), _p(y), _p(ylp), R, d, V, _stream()), 'otr_decode_lookup')
+    return attach_lp(y, ylp)
+
+
+def lstm_cell(gates_a, gates_b, bias_b, c_prev):
+    """one torch.nn.LSTM cell update on [R, 4H] gate pre-activations (see include/otrans_hip.h: otr_lstm_cell) -> (h with its 16-bit
+    twin, c); no autograd (the recurrent LM is an inference-time component here)"""
+    _cuda(gates_a)
+    R, H4 = gates_a.shape
+    H = H4 // 4
+    ga = gates_a.contiguous().float()
+    gb = gates_b.contiguous().float() if gates_b is not None else None
+    h = torch.empty((R, H), dtype=torch.float32, device=ga.device)
+    c = torch.empty((R, H), dtype=torch.float32, device=ga.device)
+    hlp = torch.empty((R, H), dtype=half_dtype(), device=ga.device) if is_half() else None
+    L.check(L.load().otr_lstm_cell(_p(ga), _p(gb), _p(bias_b.contiguous().float() if bias_b is not None else None),
+                                   _p(c_prev.contiguous() if c_prev is not None else None), _p(h), _p(hlp), _p(c), R, H, _stream()),
+            'otr_lstm_cell')
+    return attach_lp(h, hlp), c
+
+
 def decode_self_attention(qkv, kcache, vcache, anc, pos, n_heads):
     """New-position query against the ancestors' cached keys/values (include/otrans_hip.h)."""
     _cuda(qkv, kcache, vcache, anc, pos)

@@ -66,7 +66,97 @@ class TransformerLanguageModel(nn.Module):
         pass
 
 
-LanguageModel = {'transformer_lm': TransformerLanguageModel}     # otrans/model/__init__.py:11-14 (rnn_lm not built)
+class RecurrentLanguageModel(nn.Module):
+    """model/lm.py:33-91: nn.Embedding -> nn.LSTM(hidden, hidden, num_layers, batch_first) -> tied Linear, same constructor dict,
+    attribute names and state_dict keys (`embedding.weight`, `rnn.weight_ih_l0` ...: a reference checkpoint loads strict).  On the hot
+    path it is an INFERENCE component: the recognizers fuse its log-probabilities into the beam search (recognize/base.py:26-37), and
+    the reference hands it the LAST token of every hypothesis with no carried state (recognize/speech2text.py:102-105 passes
+    cache['lm'], which is never set) -- `logits_last`.  `predict` is the reference's general form (any prefix length, optional
+    state).  The cell runs as two otr_linear_fwd GEMMs + otr_lstm_cell per layer and step; `self.rnn` only holds the parameters.
+    Training this LM (model/lm.py:63-70 through nn.LSTM's backward) is not part of the speech path: forward()
+    evaluates the loss without building a graph."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.params = params
+        self.model_type = 'recurrent_lm'
+        self.vocab_size = params['vocab_size']
+        self.share_embedding = params['share_embedding']
+        self.smoothing = params['smoothing']
+        self.num_layers = params['num_layers']
+        self.hidden_size = params['hidden_size']
+        self.embedding = nn.Embedding(params['vocab_size'], params['hidden_size'])
+        self.rnn = nn.LSTM(input_size=params['hidden_size'], hidden_size=params['hidden_size'], num_layers=params['num_layers'],
+                           batch_first=True, dropout=params['dropout'], bidirectional=False)
+        self.output_project = nn.Linear(params['hidden_size'], params['vocab_size'])
+        if self.share_embedding:
+            assert self.embedding.weight.size() == self.output_project.weight.size()
+            self.output_project.weight = self.embedding.weight
+        self.crit = LabelSmoothingLoss(size=self.vocab_size, smoothing=self.smoothing, padding_idx=PAD)
+
+    def _layer_params(self, k):
+        r = self.rnn
+        return (getattr(r, 'weight_ih_l%d' % k), getattr(r, 'weight_hh_l%d' % k), getattr(r, 'bias_ih_l%d' % k), getattr(r, 'bias_hh_l%d' % k))
+
+    def _step(self, x, h, c):
+        """one time step through all layers; h / c: lists per layer (entries None = zero state)"""
+        for k in range(self.num_layers):
+            w_ih, w_hh, b_ih, b_hh = self._layer_params(k)
+            ga = ops.linear(x, w_ih, b_ih)
+            gb = ops.linear(h[k], w_hh, b_hh) if h[k] is not None else None          # W_hh . 0 = 0: the GEMM is skipped, b_hh stays
+            h[k], c[k] = ops.lstm_cell(ga, gb, b_hh if gb is None else None, c[k])
+            x = h[k]
+        return x
+
+    @torch.no_grad()
+    def _run(self, tokens, hidden):
+        B, T = tokens.shape
+        nl = self.num_layers
+        h = [None] * nl if hidden is None else [ops.attach_lp(hidden[0][k].contiguous().float(), hidden[0][k].to(ops.act_dtype()).contiguous())
+                                                 if ops.is_half() else hidden[0][k].contiguous().float() for k in range(nl)]
+        c = [None] * nl if hidden is None else [hidden[1][k].contiguous().float() for k in range(nl)]
+        tokens = tokens.contiguous()
+        outs = []
+        for t in range(T):
+            outs.append(self._step(ops.decode_lookup(tokens[:, t:t + 1], None, self.embedding.weight), h, c))
+        y = torch.stack(outs, dim=1)
+        return y, (torch.stack(h), torch.stack(c))
+
+    def predict(self, pred, hidden=None):
+        """model/lm.py:72-79: (log_probs [B, t, V], (h_n, c_n))"""
+        y, hidden = self._run(pred, hidden)
+        logits = ops.linear(y, self.output_project.weight, self.output_project.bias)
+        return ops.log_softmax(logits), hidden
+
+    @torch.no_grad()
+    def logits_last(self, preds, pos=None):
+        """un-normalised scores [R, V] of the token after preds[:, *pos] from the ZERO state: what the fused beam search adds at every
+        step (recognize/base.py:35-36 with hidden = None); pos: device int32 scalar (cached search) or None = the last column"""
+        if pos is None:
+            preds, pos = preds[:, -1:], None
+        x = ops.decode_lookup(preds, pos, self.embedding.weight)
+        y = self._step(x, [None] * self.num_layers, [None] * self.num_layers)
+        return ops.linear(y, self.output_project.weight, self.output_project.bias)
+
+    def forward(self, inputs, targets):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError('opentransformer_amd: training the recurrent LM (nn.LSTM backward) is outside the speech hot path '
+                                      '(SURVEY.md section 8); evaluate it under torch.no_grad()')
+        y, _ = self._run(inputs['inputs'], None)
+        logits = ops.linear(y, self.output_project.weight, self.output_project.bias)
+        return self.crit(logits, targets['targets']), None
+
+    def save_checkpoint(self, params, name):
+        torch.save({'params': params, 'model': self.state_dict()}, name)
+
+    def init_hidden_states(self, batch_size, device):
+        return torch.zeros([self.num_layers, batch_size, self.hidden_size]).to(device)
+
+    def set_epoch(self, epoch):
+        pass
+
+
+LanguageModel = {'rnn_lm': RecurrentLanguageModel, 'transformer_lm': TransformerLanguageModel}     # otrans/model/__init__.py:11-14
 
 
 class Recognizer:
@@ -196,9 +286,13 @@ class SpeechToTextRecognizer(Recognizer):
             prefix = preds[cur][:, :step].contiguous()
             logits, _ = self.model.decoder(prefix, beam_memory, beam_mask)       # [R, step, V] fp32
             V = logits.size(-1)
-            lm_logits = self.lm.logits(prefix) if self.lm is not None else None
+            lm_logits, lm_off, lm_ld = None, 0, step * V
+            if self.lm is not None and getattr(self.lm, 'model_type', '') == 'recurrent_lm':
+                lm_logits, lm_off, lm_ld = self.lm.logits_last(prefix), 0, V        # the last token, no state (recognize/base.py:35-36)
+            elif self.lm is not None:
+                lm_logits, lm_off = self.lm.logits(prefix), (step - 1) * V
             L.check(lib.otr_beam_topk(_ptr(logits, (step - 1) * V), step * V,
-                                      _ptr(lm_logits, (step - 1) * V) if lm_logits is not None else None, step * V,
+                                      _ptr(lm_logits, lm_off) if lm_logits is not None else None, lm_ld,
                                       float(self.lm_weight or 0.0), R, V, beam, _ptr(k_score), _ptr(k_idx), stream()),
                     'otr_beam_topk')
             L.check(lib.otr_beam_prune(_ptr(k_score), _ptr(k_idx), _ptr(scores[cur]), _ptr(flags[cur]), _ptr(preds[cur]),
@@ -241,7 +335,8 @@ class CachedBeamState:
         self.mem_mask = new((b, Tm), torch.uint8)
         self.dec_cache = [(new((R, self.maxlen, d), adt), new((R, self.maxlen, d), adt)) for _ in dec.blocks]
         self.lm_cache = None
-        if lm is not None:
+        self.lm_recurrent = lm is not None and getattr(lm, 'model_type', '') == 'recurrent_lm'
+        if lm is not None and not self.lm_recurrent:
             dl = lm.embedding.weight.shape[1]
             self.lm_cache = [(new((R, self.maxlen, dl), adt), new((R, self.maxlen, dl), adt)) for _ in lm.blocks]
         self.graphs = [None, None]
@@ -377,7 +472,9 @@ class CachedBeamState:
         logits = ops.linear(x, dec.output_layer.weight, dec.output_layer.bias)
         V = logits.size(-1)
         lm_logits = None
-        if lm is not None:
+        if self.lm_recurrent:
+            lm_logits = lm.logits_last(self.preds[cur], self.pos[cur])     # one LSTM step from zeros on the last token (base.py:35-36)
+        elif lm is not None:
             y = ops.decode_embed(self.preds[cur], self.pos[cur], lm.embedding.weight)
             for blk, cache in zip(lm.blocks, self.lm_cache):
                 y = self._stack_step(y, blk, cache, cur, getattr(blk, 'concat_linear', None))

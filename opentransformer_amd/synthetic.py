@@ -118,6 +118,13 @@ def lm_config(vocab_size, d_model=256, n_heads=4, d_ff=2048, num_blocks=4):
                 smoothing=0.1)
 
 
+def rnn_lm_config(vocab_size, hidden_size=256, num_layers=2):
+    """a `rnn_lm` model section (model/lm.py:33-60: vocab_size, hidden_size, num_layers, dropout, share_embedding, smoothing); the
+    reference ships no yaml for it -- sizes follow transformer_lm.yaml's width"""
+    return dict(type='recurrent_lm', vocab_size=vocab_size, hidden_size=hidden_size, num_layers=num_layers, dropout=0.0,
+                share_embedding=True, smoothing=0.1)
+
+
 def fill_state_dict_(sd, seed=1234):
     """Deterministic, machine-independent weight fill.  Each tensor gets its own numpy
     Generator seeded by crc32(key)^seed.  Matrices ~ U(-1/sqrt(fan_in), +); biases small;

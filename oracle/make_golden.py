@@ -204,6 +204,53 @@ def golden_decode(name, cfg):
     np.savez_compressed(os.path.join(OUT, name), **out)
 
 
+def golden_decode_rnnlm(name='c1_decode_rnnlm.npz', base='c1_decode.npz'):
+    """Shallow fusion with the RECURRENT language model (model/lm.py:33-91 through recognize/base.py:26-37): the trained C1 weights
+    of c1_decode.npz (not re-trained), a seeded 2-layer LSTM LM, the reference's beam search; plus RecurrentLanguageModel.predict on
+    a token batch with and without a carried state."""
+    g = np.load(os.path.join(OUT, base))
+    cfg = syn.c1_model(residual_dropout=0.0, ctc_weight=0.3)
+    torch.manual_seed(1234)
+    model = End2EndModel[cfg['type']](cfg)
+    model.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('w:')}, strict=True)
+    model.eval()
+    V = cfg['decoder']['vocab_size']
+    idx2unit = {i: str(i) for i in range(V)}
+    inputs = {'inputs': torch.from_numpy(g['inputs']), 'mask': torch.from_numpy(g['mask'])}
+    lm_cfg = syn.rnn_lm_config(V, hidden_size=cfg['decoder']['d_model'], num_layers=2)
+    torch.manual_seed(7)
+    lm = LanguageModel['rnn_lm'](lm_cfg)
+    syn.fill_state_dict_(lm.state_dict(), 4321)
+    lm.eval()
+    out = {}
+
+    def to_arr(nbest):
+        rows = [[[int(t) for t in s.split()] for s in utt] for utt in nbest]
+        L = max(1, max(len(h) for u in rows for h in u))
+        a = -np.ones((len(rows), len(rows[0]), L), dtype=np.int64)
+        for i, u in enumerate(rows):
+            for j, h in enumerate(u):
+                a[i, j, :len(h)] = h
+        return a
+    rec = SpeechToTextRecognizer(model, idx2unit=idx2unit, ngpu=0, beam_width=5, nbest=3, max_len=12, penalty=0.6, lamda=5, lm=lm,
+                                 lm_weight=0.3)
+    with torch.no_grad():
+        nbest, scores = rec.recognize(inputs['inputs'], inputs['mask'])
+    out['beam5_rnnlm_hyp'] = to_arr(nbest)
+    out['beam5_rnnlm_score'] = scores.numpy()
+    print(name, [u[0] for u in nbest], scores[:, 0].tolist())
+    with torch.no_grad():
+        toks = torch.tensor([[1, 5, 9, 33, 2], [1, 7, 3, 98, 64], [1, 4, 4, 4, 4]])
+        lp, hid = lm.predict(toks)                                  # whole sequences from the zero state
+        out['predict_tokens'] = toks.numpy()
+        out['predict_logp'] = lp.numpy()
+        out['predict_h'], out['predict_c'] = hid[0].numpy(), hid[1].numpy()
+        lp2, hid2 = lm.predict(toks[:, :2], hid)                    # ... and two more steps carried on from that state
+        out['predict2_logp'] = lp2.numpy()
+        out['predict2_h'], out['predict2_c'] = hid2[0].numpy(), hid2[1].numpy()
+    np.savez_compressed(os.path.join(OUT, name), **out)
+
+
 def golden_tools():
     """tests/golden/tools_average.npz: the reference's own average_parameters (otrans/utils.py:46-102) on the toy
     checkpoints of tests/test_tools.py:make_checkpoints."""
@@ -432,6 +479,8 @@ if __name__ == '__main__':
         golden_variants()
     elif len(sys.argv) > 1 and sys.argv[1] == 'optimizer':
         golden_optimizer()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'rnnlm':
+        golden_decode_rnnlm()
     else:
         main()
         golden_tools()

@@ -431,6 +431,48 @@ def transformer_lm_predict(sd, cfg, tokens):
     return F.log_softmax(logits[:, -1, :], dim=-1)
 
 
+def rnn_lm_predict(sd, cfg, tokens, hidden=None):
+    """RecurrentLanguageModel.predict: otrans/model/lm.py:72-79 -- embedding, nn.LSTM(hidden_size, hidden_size, num_layers,
+    batch_first, unidirectional), output_project, log_softmax.  nn.LSTM restated cell by cell (torch's documented equations, gate
+    order i | f | g | o in weight_ih_l{k} / weight_hh_l{k} / bias_ih_l{k} / bias_hh_l{k}; inter-layer dropout is off in eval):
+        i, f, g, o = split(W_ih x_t + b_ih + W_hh h_{t-1} + b_hh);  c_t = sigmoid(f) c_{t-1} + sigmoid(i) tanh(g);
+        h_t = sigmoid(o) tanh(c_t)
+    tokens [B, t]; hidden None (zeros) or (h [layers, B, H], c [layers, B, H]).  Returns (log_probs [B, t, V], (h_n, c_n))."""
+    nl, H = cfg['num_layers'], cfg['hidden_size']
+    B, T = tokens.shape
+    x = F.embedding(tokens, sd['embedding.weight'])
+    if hidden is None:
+        h = [torch.zeros(B, H) for _ in range(nl)]
+        c = [torch.zeros(B, H) for _ in range(nl)]
+    else:
+        h, c = [hidden[0][k] for k in range(nl)], [hidden[1][k] for k in range(nl)]
+    outs = []
+    for t in range(T):
+        inp = x[:, t]
+        for k in range(nl):
+            gates = (F.linear(inp, sd['rnn.weight_ih_l%d' % k], sd['rnn.bias_ih_l%d' % k])
+                     + F.linear(h[k], sd['rnn.weight_hh_l%d' % k], sd['rnn.bias_hh_l%d' % k]))
+            gi, gf, gg, go = gates.chunk(4, dim=-1)
+            c[k] = torch.sigmoid(gf) * c[k] + torch.sigmoid(gi) * torch.tanh(gg)
+            h[k] = torch.sigmoid(go) * torch.tanh(c[k])
+            inp = h[k]
+        outs.append(inp)
+    y = torch.stack(outs, dim=1)
+    logits = F.linear(y, sd['output_project.weight'], sd['output_project.bias'])
+    return F.log_softmax(logits, dim=-1), (torch.stack(h), torch.stack(c))
+
+
+def lm_step_log_probs(lm, preds):
+    """Recognizer.lm_decode as decode_step calls it (recognize/base.py:26-37 from recognize/speech2text.py:102-105): a transformer LM
+    re-reads the whole prefix; a recurrent LM sees ONLY the last token and NO state -- decode_step passes cache['lm'], which is never
+    set (the lines that would carry the hidden state forward are commented out, speech2text.py:143-150) -- so every step is one LSTM
+    step from zeros."""
+    sd, cfg = lm
+    if cfg.get('type', 'transformer_lm') == 'recurrent_lm':
+        return rnn_lm_predict(sd, cfg, preds[:, -1:], None)[0][:, 0]
+    return transformer_lm_predict(sd, cfg, preds)
+
+
 def beam_search(sd, params, inputs, inputs_mask, beam=5, max_len=50, penalty=0.0, lamda=5,
                 nbest=1, lm=None, lm_weight=0.1):
     """SpeechToTextRecognizer.recognize/decode_step + mask_finished_*:
@@ -449,7 +491,7 @@ def beam_search(sd, params, inputs, inputs_mask, beam=5, max_len=50, penalty=0.0
         for _ in range(max_len):
             lp = decoder_inference(sd['decoder'], preds, bm, bmask, params['decoder'])
             if lm is not None:
-                lp = lp + lm_weight * transformer_lm_predict(lm[0], lm[1], preds)
+                lp = lp + lm_weight * lm_step_log_probs(lm, preds)
             k_scores, k_preds = lp.topk(beam)
             # finished beams: one live branch with score 0 that emits EOS (speech2text.py:156-192)
             fin = flag.expand(-1, beam)

@@ -151,6 +151,22 @@ def lm_state(cfg, seed=4321):
     return sd
 
 
+def rnn_lm_state(cfg, seed=4321):
+    """state_dict of the reference's RecurrentLanguageModel (model/lm.py:46-60: embedding, nn.LSTM `rnn`, tied output_project),
+    filled like oracle/make_golden.py fills the reference module"""
+    H_, V, nl = cfg['hidden_size'], cfg['vocab_size'], cfg['num_layers']
+    sd = {'embedding.weight': torch.empty(V, H_)}
+    for k in range(nl):
+        sd['rnn.weight_ih_l%d' % k] = torch.empty(4 * H_, H_)
+        sd['rnn.weight_hh_l%d' % k] = torch.empty(4 * H_, H_)
+        sd['rnn.bias_ih_l%d' % k] = torch.empty(4 * H_)
+        sd['rnn.bias_hh_l%d' % k] = torch.empty(4 * H_)
+    sd['output_project.weight'] = sd['embedding.weight'] if cfg.get('share_embedding', True) else torch.empty(V, H_)
+    sd['output_project.bias'] = torch.empty(V)
+    syn.fill_state_dict_(sd, seed)
+    return sd
+
+
 def require_grad(parts):
     for sd in parts.values():
         for k, v in sd.items():

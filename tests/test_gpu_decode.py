@@ -88,6 +88,53 @@ def test_decoder_inference_lm_and_ctc_greedy_match_reference(golden):
         ops.set_compute_dtype('bf16')
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'fp16'])
+def test_recurrent_lm_and_its_shallow_fusion_match_reference(golden, mode):
+    """model/lm.py:33-91 + recognize/base.py:26-37 against the fixture the REAL reference produced (tests/golden/c1_decode_rnnlm.npz,
+    oracle/make_golden.py:golden_decode_rnnlm): RecurrentLanguageModel.predict from zeros and from a carried state, and the beam
+    search fused with it -- re-forward loop, KV-cached eager and KV-cached under hipGraph replay all give the reference's n-best."""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops
+    from opentransformer_amd.recognize import LanguageModel, SpeechToTextRecognizer
+    g, base = golden('c1_decode_rnnlm.npz'), golden('c1_decode.npz')
+    ops.set_compute_dtype(mode)
+    try:
+        model = ota.SpeechToText(syn.c1_model(0.0, ctc_weight=0.3))
+        model.load_state_dict({k[2:]: torch.from_numpy(base[k]) for k in base.files if k.startswith('w:')}, strict=True)
+        model = model.to(DEV).eval()
+        lm = LanguageModel['rnn_lm'](syn.rnn_lm_config(100, hidden_size=64, num_layers=2))
+        syn.fill_state_dict_(lm.state_dict(), 4321)
+        lm = lm.to(DEV).eval()
+        tol = dict(rtol=1e-4, atol=1e-4) if mode == 'fp32' else dict(rtol=3e-2, atol=3e-2)
+        toks = torch.from_numpy(g['predict_tokens']).to(DEV)
+        lp, (h, c) = lm.predict(toks)
+        np.testing.assert_allclose(lp.cpu().numpy(), g['predict_logp'], **tol)
+        np.testing.assert_allclose(h.cpu().numpy(), g['predict_h'], **tol)
+        np.testing.assert_allclose(c.cpu().numpy(), g['predict_c'], **tol)
+        lp2, (h2, c2) = lm.predict(toks[:, :2], (h, c))
+        np.testing.assert_allclose(lp2.cpu().numpy(), g['predict2_logp'], **tol)
+        np.testing.assert_allclose(c2.cpu().numpy(), g['predict2_c'], **tol)
+        x, m = torch.from_numpy(base['inputs']).to(DEV), torch.from_numpy(base['mask']).to(DEV)
+        want, ref_s = g['beam5_rnnlm_hyp'], g['beam5_rnnlm_score']
+        for cache, graph in ((False, False), (True, False), (True, True)):
+            rec = SpeechToTextRecognizer(model, idx2unit={i: str(i) for i in range(100)}, ngpu=1, beam_width=5, nbest=3, max_len=12, penalty=0.6,
+                                         lamda=5, lm=lm, lm_weight=0.3, apply_cache=cache)
+            rec.use_hipgraph = graph
+            for _ in range(2 if graph else 1):          # the second call replays the captured step graphs
+                nbest, scores = rec.recognize(x, m)
+            got = hyp_arr(nbest, want)
+            if mode == 'fp32':
+                assert np.array_equal(got, want), (cache, graph)
+                np.testing.assert_allclose(scores.numpy(), ref_s, rtol=2e-4, atol=2e-4)
+            else:
+                clear = (ref_s[:, 0] - ref_s[:, 1]) > 0.1     # the reference's own 1-best / 2-best margin (as test_beam_search_matches_reference)
+                assert clear.sum() >= 2
+                assert np.array_equal(got[clear, 0], want[clear, 0]), (cache, graph)
+                np.testing.assert_allclose(scores.numpy()[clear, 0], ref_s[clear, 0], rtol=5e-2, atol=5e-2)
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
 def test_beam_kernels_against_torch():
     """otr_beam_topk / otr_beam_prune vs the reference's own torch formulation on random scores."""
     import ctypes as C

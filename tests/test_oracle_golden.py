@@ -192,6 +192,31 @@ def test_beam_search_hypotheses_match_reference(golden):
         np.testing.assert_allclose(scores.numpy(), g[tag + '_score'], rtol=1e-4, atol=1e-4)
 
 
+def test_recurrent_lm_and_its_shallow_fusion_match_reference(golden):
+    """model/lm.py:33-91 + recognize/base.py:26-37: the LSTM language model's predict (from zeros and from a carried state) and the beam
+    search fused with it -- which feeds the LM the LAST token and NO state at every step (oracle.lm_step_log_probs)"""
+    g = golden('c1_decode_rnnlm.npz')
+    base = golden('c1_decode.npz')
+    cfg = syn.c1_model(0.0, ctc_weight=0.3)
+    lm_cfg = syn.rnn_lm_config(100, hidden_size=64, num_layers=2)
+    sd = H.rnn_lm_state(lm_cfg)
+    with torch.no_grad():
+        toks = torch.from_numpy(g['predict_tokens'])
+        lp, (h, c) = orc.rnn_lm_predict(sd, lm_cfg, toks)
+        np.testing.assert_allclose(lp.numpy(), g['predict_logp'], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(h.numpy(), g['predict_h'], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(c.numpy(), g['predict_c'], rtol=1e-4, atol=1e-6)
+        lp2, (h2, c2) = orc.rnn_lm_predict(sd, lm_cfg, toks[:, :2], (h, c))
+        np.testing.assert_allclose(lp2.numpy(), g['predict2_logp'], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(h2.numpy(), g['predict2_h'], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(c2.numpy(), g['predict2_c'], rtol=1e-4, atol=1e-6)
+    parts = _decode_state(base)
+    x, m = torch.from_numpy(base['inputs']), torch.from_numpy(base['mask'])
+    hyps, scores = orc.beam_search(parts, cfg, x, m, beam=5, nbest=3, max_len=12, penalty=0.6, lamda=5, lm=(sd, lm_cfg), lm_weight=0.3)
+    assert np.array_equal(_hyp_arr(hyps, g['beam5_rnnlm_hyp']), g['beam5_rnnlm_hyp'])
+    np.testing.assert_allclose(scores.numpy(), g['beam5_rnnlm_score'], rtol=1e-4, atol=1e-4)
+
+
 def test_decoder_inference_lm_and_ctc_greedy_match_reference(golden):
     g = golden('c1_decode.npz')
     cfg = syn.c1_model(0.0, ctc_weight=0.3)
