@@ -460,10 +460,13 @@ int32_t otr_label_smoothing_loss_ld(const float* logits, int64_t ld_logits, cons
  * by the device scalar *grad_scale (NULL = 1: the factor the caller's backward pass will be seeded with, e.g. the dynamic loss
  * scale of otr_optimizer_step's state block).  target: int64, addressed as target[(r / L) * ld_target + r % L] for r in [0, R): a
  * [B, L] view with row stride ld_target (model/speech2text.py:57 `truth[:, 1:]`) needs no copy; R % L == 0.
- * scratch: f32[R+2]; ticket: one uint32 the caller zero-initialises ONCE (the launch leaves it at zero again). */
+ * dlogits_dtype OTR_F32, or OTR_H16: the gradient in the library's 16-bit type (ld_dlogits % 8 == 0) -- the operand type of the output
+ * layer's three backward GEMMs.  scratch: f32[R+2]; ticket: one uint32 the caller zero-initialises ONCE (the launch leaves it at
+ * zero again). */
 int32_t otr_label_smoothing_loss_fused(const float* logits, int64_t ld_logits, const int64_t* target, int64_t ld_target, int32_t L,
                                        int64_t R, int32_t V, float smoothing, int32_t pad_idx, const float* grad_scale, float* loss,
-                                       float* dlogits, int64_t ld_dlogits, float* scratch, uint32_t* ticket, void* stream);
+                                       void* dlogits, int32_t dlogits_dtype, int64_t ld_dlogits, float* scratch, uint32_t* ticket,
+                                       void* stream);
 
 /* ---- log_softmax over the last dim, f32 [R,V] (model/ctc.py:51,66; decoder/transformer.py:206) */
 int32_t otr_log_softmax(const float* x, float* y, int64_t R, int32_t V, void* stream);

@@ -151,7 +151,7 @@ SIGNATURES = {
     'otr_act_bwd': [_P, _P, _P, _I32, _I64, _I32, _P],
     'otr_label_smoothing_loss': [_P, _P, _I64, _I32, _F32, _I32, _P, _P, _P, _P],
     'otr_label_smoothing_loss_ld': [_P, _I64, _P, _I64, _I32, _F32, _I32, _P, _P, _I64, _P, _P],
-    'otr_label_smoothing_loss_fused': [_P, _I64, _P, _I64, _I32, _I64, _I32, _F32, _I32, _P, _P, _P, _I64, _P, _P, _P],
+    'otr_label_smoothing_loss_fused': [_P, _I64, _P, _I64, _I32, _I64, _I32, _F32, _I32, _P, _P, _P, _I32, _I64, _P, _P, _P],
     'otr_log_softmax': [_P, _P, _I64, _I32, _P],
     'otr_ctc_loss': [_P, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     'otr_ffn_fwd_split_slab': [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],

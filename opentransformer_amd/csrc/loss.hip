@@ -131,21 +131,28 @@ __device__ __forceinline__ void block_reduce3(float& a, float& b, float& c, floa
 // (global_store / load sc1: write-through, served past the L1), the arrival count is one agent-scope atomic add behind an
 // explicit vmcnt(0) (cdna_hip_programming.md G16, "sc1 stores and loads both sides"); the last block puts the ticket back to 0.
 // Targets are addressed as target[(row / L) * ldt + row % L]: the [B, L] view truth[:, 1:] of a [B, L + 1] matrix needs no copy.
-template <int NV4>
+// H16: the gradient leaves in the library's 16-bit type (8 bytes per quad) -- the operand type of the three GEMMs of the output layer
+// behind it (decoder/transformer.py:153), which then run on the 16-bit paths (its weight gradient in the grouped 256-wide launch).
+template <int NV4, bool H16>
 __global__ __launch_bounds__(256) void ls_rows_fused_kernel(const float* logits, int64_t ld_x, const int64_t* target, int64_t ldt, int L,
                                                            int64_t R, int V, float eps, int pad_idx, const float* gscale, float* row_loss,
-                                                           float* dlogits, int64_t ld_dx, float* loss, unsigned int* ticket) {
+                                                           void* dlogits, int64_t ld_dx, float* loss, unsigned int* ticket) {
   __shared__ float sh[4];
   __shared__ float sh3[12];
   __shared__ int last_flag;
   const int tid = threadIdx.x;
   const int64_t row = blockIdx.x;
   const float* x = logits + row * ld_x;
-  float* dx = dlogits ? dlogits + row * ld_dx : nullptr;
+  float* dx = dlogits ? reinterpret_cast<float*>(dlogits) + row * ld_dx : nullptr;                     // !H16
+  bf16_t* dxh = dlogits ? reinterpret_cast<bf16_t*>(dlogits) + row * ld_dx : nullptr;                  //  H16
+  auto put4 = [&](int64_t v, float a, float b, float c, float d) {
+    if constexpr (H16) *reinterpret_cast<uint2*>(dxh + v) = make_uint2(pack2bf(a, b), pack2bf(c, d));
+    else *reinterpret_cast<float4*>(dx + v) = make_float4(a, b, c, d);
+  };
   const int64_t t = target[(row / L) * ldt + (row % L)];
   float rl = 0.f;
   if (t == pad_idx) {
-    if (dx) for (int64_t v = 4 * tid; v < ld_dx; v += 1024) *reinterpret_cast<float4*>(dx + v) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dlogits) for (int64_t v = 4 * tid; v < ld_dx; v += 1024) put4(v, 0.f, 0.f, 0.f, 0.f);
   } else {
     float4 xv[NV4];
     const float ninf = -__builtin_huge_valf();
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(256) void ls_rows_fused_kernel(const float* logits,
     const float lse = mx + logf(se);
     const float inv_cnt = 1.f / cnt;
     const float off = eps / (float)(V - 1), on = 1.f - eps;
-    if (dx) {
+    if (dlogits) {
       const float g = inv_cnt * (gscale ? gscale[0] : 1.f);
 #pragma unroll
       for (int k = 0; k < NV4; ++k) {
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(256) void ls_rows_fused_kernel(const float* logits,
           float o[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = (v + j < V) ? (expf(e[j] - lse) - ((int64_t)(v + j) == t ? on : off)) * g : 0.f;
-          *reinterpret_cast<float4*>(dx + v) = make_float4(o[0], o[1], o[2], o[3]);
+          put4(v, o[0], o[1], o[2], o[3]);
         }
       }
     }
@@ -221,25 +228,28 @@ __global__ __launch_bounds__(256) void ls_rows_fused_kernel(const float* logits,
 
 extern "C" int32_t otr_label_smoothing_loss_fused(const float* logits, int64_t ld_logits, const int64_t* target, int64_t ld_target,
                                                   int32_t L, int64_t R, int32_t V, float smoothing, int32_t pad_idx,
-                                                  const float* grad_scale, float* loss, float* dlogits, int64_t ld_dlogits,
-                                                  float* scratch, uint32_t* ticket, void* stream) {
+                                                  const float* grad_scale, float* loss, void* dlogits, int32_t dlogits_dtype,
+                                                  int64_t ld_dlogits, float* scratch, uint32_t* ticket, void* stream) {
   OTR_REQUIRE(logits && target && loss && scratch && ticket, "label_smoothing_loss_fused: null pointer");
   OTR_REQUIRE(R > 0 && V > 1 && L > 0 && R % L == 0 && ld_target >= L, "label_smoothing_loss_fused: bad shape R=%lld L=%d ld_target=%lld V=%d",
               (long long)R, L, (long long)ld_target, V);
   OTR_REQUIRE(R <= LS_COUNT_INLINE, "label_smoothing_loss_fused: more than %lld rows (use otr_label_smoothing_loss_ld)", (long long)LS_COUNT_INLINE);
   OTR_REQUIRE(V <= 8192, "label_smoothing_loss_fused: V = %d > 8192 does not fit a row in registers (use otr_label_smoothing_loss_ld)", V);
   OTR_REQUIRE(ld_logits >= V && ld_logits % 4 == 0 && (uintptr_t)logits % 16 == 0, "label_smoothing_loss_fused: logits rows must be 16-byte aligned (ld %% 4 == 0)");
-  OTR_REQUIRE(!dlogits || (ld_dlogits >= V && ld_dlogits % 4 == 0 && ld_dlogits <= 8192 && (uintptr_t)dlogits % 16 == 0),
-              "label_smoothing_loss_fused: dlogits rows must be 16-byte aligned (ld %% 4 == 0, ld <= 8192)");
+  OTR_REQUIRE(dlogits_dtype == OTR_F32 || dlogits_dtype == OTR_H16, "label_smoothing_loss_fused: bad dlogits dtype %d", dlogits_dtype);
+  OTR_REQUIRE(!dlogits || (ld_dlogits >= V && ld_dlogits % 4 == 0 && ld_dlogits <= 8192 && (uintptr_t)dlogits % 16 == 0 &&
+                           (dlogits_dtype == OTR_F32 || ld_dlogits % 8 == 0)),
+              "label_smoothing_loss_fused: dlogits rows must be 16-byte aligned (ld %% 4 == 0 for f32, %% 8 for 16-bit; ld <= 8192)");
   OTR_REQUIRE(smoothing >= 0.f && smoothing < 1.f, "label_smoothing_loss_fused: smoothing out of [0,1)");
   hipStream_t s = (hipStream_t)stream;
   const int64_t width = dlogits && ld_dlogits > V ? ld_dlogits : V;
-#define OTR_LS_LAUNCH(NV4)                                                                                                            \
-  hipLaunchKernelGGL(ls_rows_fused_kernel<NV4>, dim3((unsigned)R), dim3(256), 0, s, logits, ld_logits, target, ld_target, L, R, V, smoothing, \
+#define OTR_LS_LAUNCH(NV4, H)                                                                                                            \
+  hipLaunchKernelGGL((ls_rows_fused_kernel<NV4, H>), dim3((unsigned)R), dim3(256), 0, s, logits, ld_logits, target, ld_target, L, R, V, smoothing, \
                      pad_idx, grad_scale, scratch + 2, dlogits, ld_dlogits, loss, ticket)
-  if (width <= 2048) OTR_LS_LAUNCH(2);
-  else if (width <= 5120) OTR_LS_LAUNCH(5);
-  else OTR_LS_LAUNCH(8);
+  const bool h16 = dlogits_dtype == OTR_H16;
+  if (width <= 2048) { if (h16) OTR_LS_LAUNCH(2, true); else OTR_LS_LAUNCH(2, false); }
+  else if (width <= 5120) { if (h16) OTR_LS_LAUNCH(5, true); else OTR_LS_LAUNCH(5, false); }
+  else { if (h16) OTR_LS_LAUNCH(8, true); else OTR_LS_LAUNCH(8, false); }
 #undef OTR_LS_LAUNCH
   return otr_check_launch("label_smoothing_loss_fused");
 }

@@ -910,7 +910,8 @@ class LinearFn(torch.autograd.Function):
         # 16-bit output-gradient hand-over (_Grad16Link): the Linear with regrouped columns (the frontend's output layer), fp32 output,
         # in-place gradient buffers with a kernel-order staging image of this weight's gradient (dp.FlatDataParallel), 16-bit operands
         ctx.g16 = None
-        if g16 is not None and x2.dtype == half_dtype() and (ctx.needs_input_grad[1] or ctx.needs_input_grad[0]):
+        if (g16 is not None and x2.dtype == half_dtype() and (ctx.needs_input_grad[1] or ctx.needs_input_grad[0])
+                and (perm is not None or ctx.pad is not None)):
             ctx.g16 = g16
             g16.armed = True
         ctx.wt = weight_lpt(w) if (perm is None and ctx.needs_input_grad[0]) else None
@@ -923,9 +924,13 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, wc, y = ctx.saved_tensors
         g16 = ctx.g16
+        dyp16 = None
         if g16 is not None and g16.buf is not None and _is_zero_placeholder(dy):
-            dy, g16.buf = g16.buf, None              # the gradient as the 16-bit operand PosEncFn.backward wrote
-        dy2 = _rows(dy)
+            if ctx.pad is not None:
+                dyp16, g16.buf = g16.buf, None       # the loss launch's [M, rows8] 16-bit gradient, zero behind column N
+            else:
+                dy, g16.buf = g16.buf, None          # the gradient as the 16-bit operand PosEncFn.backward wrote
+        dy2 = _rows(dy) if dyp16 is None else dyp16
         if ctx.relu:
             dy2 = relu_bwd_raw(y, dy2.contiguous())
         if ctx.pad is not None:
@@ -933,10 +938,12 @@ class LinearFn(torch.autograd.Function):
             # kernel wrote it that way), all three GEMMs of this layer run on the padded operands
             pw, pb = ctx.pad
             N8 = pw['param'].shape[0]
-            tail = _zero_tail_of(dy2)
-            if (tail == (dy2.shape[0], N8) and dy2.dim() == 2 and dy2.stride() == (N8, 1) and dy2.dtype == torch.float32
-                    and dy2.data_ptr() % 16 == 0):
-                dyp = dy2.as_strided((dy2.shape[0], N8), (N8, 1))
+            tail = _zero_tail_of(dy2) if dyp16 is None else None
+            if dyp16 is not None and tuple(dyp16.shape) != (x2.shape[0], N8):
+                raise RuntimeError('LinearFn.backward: the parked 16-bit gradient has shape %s, expected %s' % (tuple(dyp16.shape), (x2.shape[0], N8)))
+            if dyp16 is not None or (tail == (dy2.shape[0], N8) and dy2.dim() == 2 and dy2.stride() == (N8, 1) and dy2.dtype == torch.float32
+                                     and dy2.data_ptr() % 16 == 0):
+                dyp = dyp16 if dyp16 is not None else dy2.as_strided((dy2.shape[0], N8), (N8, 1))
                 dx = None
                 if ctx.needs_input_grad[0]:
                     skip = None
@@ -1011,9 +1018,11 @@ def linear(x, w, b=None, relu=False, out_dtype=None, perm=None, defer_bias=False
     gradient in the same pass that produces the branch gradient."""
     out_dtype = out_dtype if out_dtype is not None else torch.float32
     g16 = None
-    if (_G16 and perm is not None and not relu and out_dtype == torch.float32 and is_half() and _wq['on'] and torch.is_grad_enabled()
-            and getattr(w, '_otr_regroup_grad', None) is not None):
-        g16 = _Grad16Link()
+    if _G16 and not relu and out_dtype == torch.float32 and is_half() and _wq['on'] and torch.is_grad_enabled():
+        if perm is not None and getattr(w, '_otr_regroup_grad', None) is not None:
+            g16 = _Grad16Link()                       # the frontend's output layer <- PosEncFn.backward
+        elif perm is None and _G16_LOSS and getattr(w, '_otr_pad', None) is not None:
+            g16 = _Grad16Link()                       # the row-padded output layer <- LabelSmoothingLossFusedFn.backward
     y = LinearFn.apply(x, w, b, relu, out_dtype, perm, defer_bias, link, g16)
     if g16 is not None and g16.armed:
         y._otr_g16 = g16                 # read by PosEncFn.forward when y is its input
@@ -2210,6 +2219,7 @@ class _Grad16Link:
 
 
 _G16 = os.environ.get('OTR_GRAD16_LINK', '1') == '1'
+_G16_LOSS = os.environ.get('OTR_GRAD16_LOSS', '1') == '1'      # A/B: the loss launch's gradient as a 16-bit operand of the output layer
 
 
 class PosEncFn(torch.autograd.Function):
@@ -2860,10 +2870,16 @@ class LabelSmoothingLossFusedFn(torch.autograd.Function):
         R = lg.shape[0]
         loss = torch.empty((), dtype=torch.float32, device=lg.device)
         need = ctx.needs_input_grad[0]
-        dlogits = torch.empty((R, ld), dtype=torch.float32, device=lg.device) if need else None
+        # the logits' producer takes its output gradient as a 16-bit operand (_Grad16Link: the row-padded output layer): the
+        # gradient is written in that type, one rounding where every other branch gradient of the model already has one
+        g16 = getattr(logits, '_otr_g16', None)
+        ctx.g16 = g16 if (need and g16 is not None and g16.armed and is_half() and ld % 8 == 0) else None
+        ddt = half_dtype() if ctx.g16 is not None else torch.float32
+        dlogits = torch.empty((R, ld), dtype=ddt, device=lg.device) if need else None
         scratch = torch.empty((R + 2,), dtype=torch.float32, device=lg.device)
         L.check(L.load().otr_label_smoothing_loss_fused(_p(lg), ld, _p(target), ldt, Lt, R, V, smoothing, pad_idx, _p(gscale), _p(loss),
-                                                        _p(dlogits), ld, _p(scratch), _p(ticket), _stream()), 'otr_label_smoothing_loss_fused')
+                                                        _p(dlogits), _code(ddt), ld, _p(scratch), _p(ticket), _stream()),
+                'otr_label_smoothing_loss_fused')
         ctx.save_for_backward(dlogits)
         ctx.shape, ctx.V = logits.shape, V
         return loss
@@ -2872,7 +2888,16 @@ class LabelSmoothingLossFusedFn(torch.autograd.Function):
     def backward(ctx, g):
         (dlogits,) = ctx.saved_tensors
         seed = _state.get(('unit_grad', g.device, g.dtype))
-        if seed is not None and g.data_ptr() == seed.data_ptr():
+        unit = seed is not None and g.data_ptr() == seed.data_ptr()
+        if ctx.g16 is not None:
+            link = ctx.g16
+            if unit and link.buf is None and _in_backward():
+                link.buf = dlogits                                 # [R, ld] 16-bit, zero behind column V: LinearFn.backward's operand
+                _park(link)
+                return (_zero_placeholder(dlogits.device, ctx.shape),) + (None,) * 9
+            dlogits = dlogits.float()                              # a gradient other than the unit seed: the general (fp32) route
+            unit = False if not unit else unit
+        if unit:
             out = dlogits                                          # g == 1: the saved buffer IS the gradient
         else:
             out = torch.empty_like(dlogits)

@@ -61,8 +61,8 @@ def test_argument_errors_of_the_round5_entries():
     lib = _lib.load()
     al, odd = C.c_void_p(4096), C.c_void_p(4096 + 4)
 
-    def loss(logits=al, ld=4240, ldt=16, L=15, R=480, V=4234, dl=al, ldd=4240, ticket=al, scratch=al):
-        return lib.otr_label_smoothing_loss_fused(logits, ld, al, ldt, L, R, V, 0.1, 0, None, al, dl, ldd, scratch, ticket, None)
+    def loss(logits=al, ld=4240, ldt=16, L=15, R=480, V=4234, dl=al, ldd=4240, ticket=al, scratch=al, dt=_lib.OTR_F32):
+        return lib.otr_label_smoothing_loss_fused(logits, ld, al, ldt, L, R, V, 0.1, 0, None, al, dl, dt, ldd, scratch, ticket, None)
     assert loss(ticket=None) < 0 and b'label_smoothing_loss_fused' in lib.otr_last_error_string()
     assert loss(ld=4234) < 0            # rows not 16-byte aligned (ld % 4 != 0): the three-kernel form serves those
     assert loss(logits=odd) < 0
@@ -70,6 +70,7 @@ def test_argument_errors_of_the_round5_entries():
     assert loss(ldt=14) < 0             # row stride of the target view shorter than L
     assert loss(V=9000, ld=9000, ldd=9000) < 0
     assert loss(R=480 * 32, L=15) < 0   # > 8192 rows
+    assert loss(dt=7) < 0 and loss(dt=_lib.OTR_BF16, ldd=4236, ld=4236) < 0      # 16-bit gradient rows need ld % 8 == 0
     assert lib.otr_embed_posenc_fwd_ld(al, 14, al, al, None, 480, 15, 256, 4234, 16.0, None) < 0       # ld_tok < L
     assert lib.otr_embed_bwd_ld(al, 16, 15, None, None, 0, al, 480, 256, 4234, 16.0, None) < 0         # neither dy nor slabs
     assert lib.otr_embed_bwd_ld(al, 16, 15, None, None, 4, al, 480, 256, 4234, 16.0, None) < 0         # nslab without slabs

@@ -278,12 +278,11 @@ def test_frontend_linear_takes_its_gradient_as_a_16bit_operand(accumulate):
             finally:
                 ops._G16 = was
         assert out['g16_staged'] is True and out['fp32_staged'] is False          # the hand-over really ran / really did not
-        for n, g in out['g16'].items():
-            r = rel(g, out['fp32'][n])
-            if n.startswith('frontend.'):
-                assert r < 4e-3, (n, r)          # the output gradient rounded to fp16 once (eps 4.9e-4) before three GEMMs
-            else:
-                assert r < 1e-5, (n, r)          # nothing in front of the hand-over changes (float atomics aside)
+        worst = max((rel(g, out['fp32'][n]), n) for n, g in out['g16'].items())
+        # two hand-overs are on: the loss launch's gradient (16-bit operand of the output layer: one fp16 rounding, eps 4.9e-4, at the
+        # top of the backward pass -- every gradient moves by about that much) and the positional encoding's (the frontend's Linear)
+        assert worst[0] < 1e-2, worst
         assert float(out['g16']['frontend.output_layer.weight'].abs().sum()) > 0
+        assert float(out['g16']['decoder.output_layer.weight'].abs().sum()) > 0
     finally:
         ops.set_compute_dtype('bf16')
