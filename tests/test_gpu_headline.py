@@ -130,6 +130,58 @@ def test_c2_batch32_matches_oracle(c2_oracle, mode):
                          HEADLINE_TOL[mode])
 
 
+@pytest.mark.parametrize('mode', ['fp16', 'bf16'])
+def test_c2_batch32_through_the_bench_engine_matches_oracle(c2_oracle, mode):
+    """The TIMED configuration, not only the bare model: bench.py's construction -- FlatDataParallel (flat in-place gradients, deferred
+    grouped weight gradients in the 256-wide launch, the row-padded output layer, the 16-bit gradient hand-overs, the staged frontend
+    weight gradient) + FusedAdam's device-side loss scale, `dp.zero_grad(next_dropout_step=True)`, `ops.backward(loss)` -- at the bench
+    batch against the oracle: loss and every parameter gradient (read from the flat buffer, loss scale divided out)."""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+    cfg, inputs, targets, ref_loss, ref_aux, ref_flat = c2_oracle
+    ops.set_compute_dtype(mode)
+    try:
+        model = ota.SpeechToText(cfg)
+        syn.fill_state_dict_(model.state_dict(), 1234)
+        model = model.to(DEV).train()
+        dp = FlatDataParallel(model)
+        opt = FusedAdam(dp, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6, clip_grad=5.0,
+                        noam=dict(model_size=256, warmup_steps=12000, factor=1.0))
+        di = {k: v.to(DEV) for k, v in inputs.items()}
+        dt = {k: v.to(DEV) for k, v in targets.items()}
+        dp.zero_grad(next_dropout_step=True)
+        loss, _ = dp(di, dt)
+        ops.backward(loss)
+        torch.cuda.synchronize()
+        ls = float(opt.state[6]) or 1.0
+        worst, wkey, rels = 0.0, None, {}
+        for k, p in model.named_parameters():
+            g_ref = ref_flat[k].grad
+            if g_ref is None:
+                continue
+            e = rel(p.grad.detach() / ls, g_ref)
+            rels[k] = e
+            if e > worst:
+                worst, wkey = e, k
+        staged = getattr(model.frontend.output_layer.weight, '_otr_regroup_state', {'dirty': None})['dirty']
+        r = {'config': 'C2 B=32 x 1000 frames through bench.py\'s engine (FlatDataParallel + FusedAdam loss scale)', 'mode': mode,
+             'loss_rel': abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()), 'loss_scale': ls, 'grad_worst': worst,
+             'grad_worst_key': wkey, 'grad_median': float(np.median(list(rels.values()))),
+             'grad_frontend_output_layer': rels.get('frontend.output_layer.weight'),
+             'grad_conv1_weight': rels.get('frontend.conv1.conv_layer.weight'),
+             'grad_output_layer': rels.get('decoder.output_layer.weight', rels.get('decoder.embedding.weight')),
+             'frontend_weight_gradient_staged': staged, 'faults': opt.stats()['faults']}
+        with open(os.path.join(ROOT, 'gpurun_out', 'parity_headline_engine_%s.json' % mode), 'w') as f:
+            json.dump(r, f, indent=1)
+        print(json.dumps(r))
+        tl, _, tg = HEADLINE_TOL[mode]
+        assert r['loss_rel'] < tl and worst < tg, r
+        assert staged is True and r['faults'] == 0, r
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
 def _ragged(batch, lo, hi, seed):
     """utterance lengths in frames: the longest fills the batch, the rest are drawn from [lo, hi]"""
     rng = np.random.default_rng(seed)
