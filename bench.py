@@ -592,6 +592,20 @@ def main():
                 pat = PMC_KERNEL.get(name.split(' ')[0])
                 hits = [v for k, v in pmc_db.items() if pat and pat in k and isinstance(v, dict) and not k.startswith('_')]
                 return max(hits, key=lambda v: v.get('share_of_kernel_time', 0.0)) if hits else {}
+            # in-step durations of the same kernels from the committed rocprofv3 trace of the replayed step (tools/graph_gaps.py):
+            # printed beside the live timings, not instead of them
+            try:
+                step_db = json.load(open(os.path.join(ROOT, 'profiles', 'r05_step_kernels.json')))
+            except Exception:                                          # noqa: BLE001
+                step_db = {}
+
+            def in_step_us(name):
+                pat = PMC_KERNEL.get(name.split(' ')[0])
+                hits = [v for k, v in step_db.items() if pat and k.startswith(pat) and isinstance(v, dict) and not k.startswith('_')]
+                if not hits:
+                    return None
+                h = max(hits, key=lambda v: v['avg_us'] * v['launches_per_step'])
+                return h['max_us'] if name == 'linear_wgrad_grouped' else h['avg_us']    # the M = B x T' launch is the longest of its name
             lines = {}
             for name, a in kern.items():
                 if a['flops_per_launch'] <= 0:
@@ -603,7 +617,8 @@ def main():
                                'algorithmic_bytes': a['algorithmic_bytes_per_launch'] or None,
                                'mfma_busy_frac_pmc': pm.get('mfma_busy_frac'),
                                'avg_launch_ms': a['avg_launch_ms'], 'launches_per_step': a['launches'],
-                               'ms_per_step': a['total_ms'], 'timed': 'events around every launch inside one eager training step'}
+                               'ms_per_step': a['total_ms'], 'timed': 'events around every launch inside one eager training step',
+                               'avg_launch_us_in_step_rocprof': in_step_us(name)}
             if lines:
                 # EVERY line is re-timed before it is graded (no duration from the eager brackets, which also hold the
                 # host's launch gap): the launches of that kernel in the step, each on its own operands, re-issued back to back inside

@@ -252,6 +252,10 @@ typedef struct {
   int32_t dy_dtype, x_dtype;
   float* dbias;          /* NULL, or [N]: dbias += column sums of dy (the bias gradient of the same Linear), folded into the
                           * 256-wide launch -- allowed only on items for which otr_wgrad256_takes() returns 1 */
+  int32_t overwrite;     /* != 0: the caller guarantees that dw holds ZEROS which nothing else has written in this backward pass (a
+                          * gradient buffer cleared at the start of the step, this item its only writer): the 256-wide launch then
+                          * STORES the first partial sum of every tile instead of reading the zeros back (7 % of that launch's
+                          * bytes).  The result is the same sum; other paths ignore the flag and accumulate. */
 } otr_wgrad_item_t;
 /* 1 when otr_linear_wgrad_grouped would run this item on the 256-wide kernel (csrc/wgrad256.hip), else 0 */
 int32_t otr_wgrad256_takes(const otr_wgrad_item_t* item, int32_t compute);

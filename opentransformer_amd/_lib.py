@@ -28,7 +28,7 @@ class LinearDesc(C.Structure):
 class WgradItem(C.Structure):               # otr_wgrad_item_t
     _fields_ = [('dy', C.c_void_p), ('x', C.c_void_p), ('dw', C.c_void_p), ('M', C.c_int32), ('N', C.c_int32),
                 ('K', C.c_int32), ('ldy', C.c_int64), ('ldx', C.c_int64), ('ldw', C.c_int64),
-                ('dy_dtype', C.c_int32), ('x_dtype', C.c_int32), ('dbias', C.c_void_p)]
+                ('dy_dtype', C.c_int32), ('x_dtype', C.c_int32), ('dbias', C.c_void_p), ('overwrite', C.c_int32)]
 
 
 class ColsumItem(C.Structure):              # otr_colsum_item_t

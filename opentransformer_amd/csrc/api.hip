@@ -281,7 +281,7 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
       big.clear();
       for (size_t c = c0; c < c1; ++c) {
         const otr_wgrad_item_t& it = items[idx[c]];
-        big.push_back(W256Item{it.dy, it.x, it.dw, it.dbias, it.M, it.N, it.K, it.ldy, it.ldx, it.ldw});
+        big.push_back(W256Item{it.dy, it.x, it.dw, it.dbias, it.M, it.N, it.K, it.ldy, it.ldx, it.ldw, it.overwrite != 0});
       }
       if (!workspace || wgrad256_workspace_bytes(big.data(), (int)big.size()) > workspace_bytes) break;   // the grouped kernel takes them
       if (int32_t e = wgrad256_launch(big.data(), (int)big.size(), workspace, workspace_bytes, g_otr_wgrad256_grid, g_otr_wgrad256_ablate, s)) return e;

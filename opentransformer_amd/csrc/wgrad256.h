@@ -12,6 +12,7 @@ struct W256Item {                       // dw[N,K] += dy[M,N]^T x[M,K]; 16-bit o
   float* dbias;                         // NULL or [N]: dbias += column sums of dy (the bias gradient of the same Linear)
   int M, N, K;
   int64_t ldy, ldx, ldw;
+  int overwrite;                        // != 0: dw holds zeros nobody else has written in this pass: the first partial sum is STORED
 };
 
 struct W256Prob {
@@ -21,7 +22,7 @@ struct W256Prob {
   float* dbias;
   int start;                            // first slab of this problem in the launch's (tile, slab) space
   int M, N, K, ldy, ldx, ldw;           // tiles: ceil(N/256) x ceil(K/256), each ceil(M/16) slabs long
-  int flag0;                            // first turnstile flag of this problem (one per tile)
+  int flag0;                            // first turnstile flag of this problem (one per tile); bit 30: overwrite (W256Item)
 };                                      // 64 bytes: 56 of them + the scalars below stay under the 4 KB argument segment
 
 struct W256Args {

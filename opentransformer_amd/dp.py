@@ -143,6 +143,19 @@ class FlatDataParallel:
                 n8 = shape8[0] * (p.shape[1] if p.dim() == 2 else 1)
                 if p.dim() <= 2 and n8 <= (slot_numel(p) + ALIGN - 1) // ALIGN * ALIGN:
                     p._otr_pad = {'param': self.flat_param[off:off + n8].view(shape8), 'grad': self.flat_grad[off:off + n8].view(shape8)}
+        # gradient buffers with ONE writer per backward pass (ops.register_single_writer_grads): the 2-D weights whose gradient is a
+        # deferred Linear weight-gradient product and nothing else -- not an embedding matrix (its scatter-add, and with
+        # share_embedding the output layer's product, land in one buffer) -- plus the staging images above
+        self._single_writer = set()
+        if dev.type == 'cuda' and flatten_params:
+            emb = {id(m.weight) for m in module.modules() if isinstance(m, torch.nn.Embedding)}
+            for p in params:
+                if p.dim() == 2 and id(p) not in emb:
+                    self._single_writer.add(p.grad.data_ptr())
+                if id(p) in stage_of:
+                    self._single_writer.add(p._otr_regroup_grad.data_ptr())
+            from . import ops
+            ops.register_single_writer_grads(self._single_writer)
         # bf16 shadow of every parameter (GEMM operand form), kept fresh by FusedAdam in the same pass
         self.flat_param_lp = None
         if flatten_params and dev.type == 'cuda' and dt == torch.float32:
@@ -340,6 +353,7 @@ class FlatDataParallel:
                 if next_dropout_step:
                     ops.next_dropout_step(self._store_all.device)
             ops.discard_pending_weight_grads()      # nothing queued survives into a new step (e.g. after an exception)
+            ops.gradients_cleared(self._single_writer)
         else:
             self._store_all.zero_()
 
@@ -373,6 +387,10 @@ class FlatDataParallel:
         return self._rccl
 
     def close(self):
+        if getattr(self, '_single_writer', None):
+            from . import ops
+            ops.unregister_single_writer_grads(self._single_writer)
+            self._single_writer = set()
         if self._rccl is not None:
             L.check(L.load().otr_allreduce_destroy(self._rccl), 'otr_allreduce_destroy')
             self._rccl = None

@@ -511,6 +511,28 @@ def linear_dgrad_raw(dy2, w, dx_dtype, out=None):
 # other's items as long as their backward passes do not interleave on one thread; a pass that dies half way leaves its
 # items behind, which the owner's zero_grad() / the next pass's first enqueue (different graph-task id) discards.
 _wq = {'on': False, 'w': [], 'b': [], 'post': [], 'armed': False, 'task': None}    # post: callables run behind the grouped launches
+# Store instead of accumulate (otr_wgrad_item_t.overwrite): a replica engine registers the gradient buffers that have exactly ONE
+# writer per backward pass -- the deferred weight-gradient product of a Linear (not: an embedding that is also an output layer, whose
+# scatter-add lands in the same buffer) -- and tells when it has cleared them.  The first grouped launch that writes such a buffer
+# after a clear may store its sums; every write is recorded, so a second backward pass before the next clear (gradient accumulation)
+# accumulates as before.  Addresses, not tensors: a gradient view and its row-padded image are the same buffer.
+_wq_excl = {'single_writer': set(), 'written': set()}
+_WG_OVERWRITE = os.environ.get('OTR_WGRAD_OVERWRITE', '1') == '1'
+
+
+def register_single_writer_grads(ptrs):
+    _wq_excl['single_writer'].update(ptrs)
+
+
+def unregister_single_writer_grads(ptrs):
+    _wq_excl['single_writer'].difference_update(ptrs)
+    _wq_excl['written'].difference_update(ptrs)
+
+
+def gradients_cleared(ptrs):
+    """the buffers at these addresses were just zeroed by their owner (FlatDataParallel.zero_grad)"""
+    _wq_excl['written'].difference_update(ptrs)
+
 _FUSE_BIAS_COLSUM = os.environ.get('OTR_NO_FUSED_BIAS_COLSUM', '0') != '1'
 _DEBUG_WQ = os.environ.get('OTR_DEBUG_WQ', '0') == '1'
 
@@ -552,12 +574,19 @@ def flush_weight_grads():
             print('wq b', tuple(a2.shape), a2.dtype, a2.stride(0), flush=True)
     if w:
         items = (L.WgradItem * len(w))()
+        seen = {}
+        for _, _, out in w:
+            seen[out.data_ptr()] = seen.get(out.data_ptr(), 0) + 1
+        sw, written = _wq_excl['single_writer'], _wq_excl['written']
         for it, (dy2, x2, out) in zip(items, w):
             it.dy, it.x, it.dw = dy2.data_ptr(), x2.data_ptr(), out.data_ptr()
             it.M, it.N, it.K = dy2.shape[0], dy2.shape[1], x2.shape[1]
             it.ldy, it.ldx, it.ldw = dy2.stride(0), x2.stride(0), out.stride(0)
             it.dy_dtype, it.x_dtype = _code(dy2.dtype), _code(x2.dtype)
             it.dbias = None
+            ptr = out.data_ptr()
+            it.overwrite = int(_WG_OVERWRITE and ptr in sw and ptr not in written and seen[ptr] == 1)
+        written.update(seen)
         if b and _FUSE_BIAS_COLSUM:
             # a bias gradient whose matrix is the dy operand of a weight gradient the 256-wide kernel takes rides along with
             # it (the kernel reads that matrix anyway): one less pass over it by the column-sum launch
@@ -739,6 +768,8 @@ def linear_wgrad_raw(dy2, x2, w_like, out=None):
         _arm_flush()
         return out
     dw = out if out is not None else torch.empty((N, K), dtype=torch.float32, device=dy2.device)
+    if out is not None:
+        _wq_excl['written'].add(out.data_ptr())          # written outside the grouped launches: whoever comes next accumulates
     d = _linear_desc(M, N, K, x2.dtype, torch.float32, dy2.dtype, x2.stride(0), K, dy2.stride(0),
                      accumulate=int(out is not None))
     ws = _workspace(dy2.device)
@@ -2077,17 +2108,17 @@ class DecoderStackFn(torch.autograd.Function):
             qkv16, ctx1, lse1 = h16(R, 3 * d), h16(R, d), f32(B, H, Lq)
             fl_self = 2.0 * R * d * (3 * d + d) + 4.0 * R * Lq * d
             L.check(_timed('dec_self_fwd', {'flops': fl_self}, lambda lnA=lnA, pk=pk, bqkv=bqkv, qkv16=qkv16, ctx1=ctx1, lse1=lse1: lib.otr_dec_self_fwd(
-                C.byref(lnA), B, Lq, _p(pk[0][0]), _p(bqkv), _p(pk[1][0]), _p(qkv16), _p(ctx1), _p(lse1), _p(slA), st)), 'otr_dec_self_fwd')
+                C.byref(lnA), B, Lq, _p(pk[0][0]), _p(bqkv), _p(pk[1][0]), _p(qkv16), _p(ctx1), _p(lse1), _p(slA), _stream())), 'otr_dec_self_fwd')
             lnB, y1, y116, rec['ln1'] = ln_out(y0, slA, 4, bo, g1, be1)
             q16, ctx2, lse2 = h16(R, d), h16(R, d), f32(B, H, Lq)
             fl_cross = 2.0 * R * d * (d + d) + 4.0 * R * T * d
             L.check(_timed('dec_cross_fwd', {'flops': fl_cross}, lambda lnB=lnB, pk=pk, bq=bq, q16=q16, ctx2=ctx2, lse2=lse2, l=l: lib.otr_dec_cross_fwd(
                 C.byref(lnB), B, Lq, _p(pk[2][0]), _p(bq), _p(pk[3][0]), _p(kv_all), T * W, W, l * 512, l * 512 + 256, _p(kmask), T, _p(q16), _p(ctx2),
-                _p(lse2), _p(slB), st)), 'otr_dec_cross_fwd')
+                _p(lse2), _p(slB), _stream())), 'otr_dec_cross_fwd')
             lnC, y2, y216, rec['ln2'] = ln_out(y1, slB, 4, bo2, g2, be2)
             hsave = torch.empty(lib.otr_dec_ffn_hsave_bytes(R, F) // 2, dtype=hdt, device=dev) if need else None
             L.check(_timed('dec_ffn_fwd', {'flops': 6.0 * R * F * d}, lambda lnC=lnC, pk=pk, b1=b1, hsave=hsave: lib.otr_dec_ffn_fwd(
-                C.byref(lnC), R, _p(pk[4][0]), _p(b1), _p(pk[4][1]), F, S, _p(slC), _p(hsave), st)), 'otr_dec_ffn_fwd')
+                C.byref(lnC), R, _p(pk[4][0]), _p(b1), _p(pk[4][1]), F, S, _p(slC), _p(hsave), _stream())), 'otr_dec_ffn_fwd')
             rec.update(hsave=hsave, y016=y016, qkv16=qkv16, ctx1=ctx1, lse1=lse1, y116=y116, q16=q16, ctx2=ctx2, lse2=lse2, y216=y216)
             layers.append(rec)
             y_in, pending = y2, (slC, S, b2, g3, be3)
@@ -2128,7 +2159,7 @@ class DecoderStackFn(torch.autograd.Function):
             lnb = _dec_lnb(dskip, slabs, nslab, rec['ln3'], g3, seed, p_drop, dz3, da3, part3)
             _, _, P3, P4 = pk[4]
             L.check(_timed('dec_ffn_bwd', {'flops': 6.0 * R * F * d}, lambda lnb=lnb, rec=rec, P3=P3, P4=P4, dh=dh, u=u, bpart=bpart, slCb=slCb:
-                           lib.otr_dec_ffn_bwd(C.byref(lnb), R, _p(rec['hsave']), _p(P3), _p(P4), F, S, _p(dh), _p(u), _p(bpart), _p(slCb), st)),
+                           lib.otr_dec_ffn_bwd(C.byref(lnb), R, _p(rec['hsave']), _p(P3), _p(P4), F, S, _p(dh), _p(u), _p(bpart), _p(slCb), _stream())),
                     'otr_dec_ffn_bwd')
             grads[o + 16], grads[o + 17], grads[o + 15] = _grad_b(part3[:, :d], g3), _grad_b(part3[:, d:2 * d], be3), _grad_b(part3[:, 2 * d:], b2)
             grads[o + 12], grads[o + 13], grads[o + 14] = _grad_w(dh, rec['y216'], w1), _grad_b(bpart, b1), _grad_w(da3, u, w2)
@@ -2140,7 +2171,7 @@ class DecoderStackFn(torch.autograd.Function):
             L.check(_timed('dec_cross_bwd', {'flops': 2.0 * R * d * (d + d) + 10.0 * R * T * d},
                            lambda lnb=lnb, pk=pk, rec=rec, l=l, dq16=dq16, slBb=slBb: lib.otr_dec_cross_bwd(
                                C.byref(lnb), B, Lq, _p(pk[3][1]), _p(pk[2][1]), _p(rec['q16']), _p(rec['ctx2']), _p(rec['lse2']), _p(kv_all), _p(dkv),
-                               T * W, W, l * 512, l * 512 + 256, _p(kmask), T, _p(dq16), _p(slBb), st)), 'otr_dec_cross_bwd')
+                               T * W, W, l * 512, l * 512 + 256, _p(kmask), T, _p(dq16), _p(slBb), _stream())), 'otr_dec_cross_bwd')
             grads[o + 10], grads[o + 11], grads[o + 9] = _grad_b(part2[:, :d], g2), _grad_b(part2[:, d:2 * d], be2), _grad_b(part2[:, 2 * d:], bo2)
             grads[o + 8], grads[o + 6], grads[o + 7] = _grad_w(da2, rec['ctx2'], wo2), _grad_w(dq16, rec['y116'], wq), _grad_b(dq16, bq)
             # ---- self-attention sub-layer
@@ -2149,7 +2180,7 @@ class DecoderStackFn(torch.autograd.Function):
             L.check(_timed('dec_self_bwd', {'flops': 2.0 * R * d * (3 * d + d) + 10.0 * R * Lq * d},
                            lambda lnb=lnb, pk=pk, rec=rec, dqkv16=dqkv16, slAb=slAb: lib.otr_dec_self_bwd(
                                C.byref(lnb), B, Lq, _p(pk[1][1]), _p(pk[0][1]), _p(rec['qkv16']), _p(rec['ctx1']), _p(rec['lse1']), _p(dqkv16),
-                               _p(slAb), st)), 'otr_dec_self_bwd')
+                               _p(slAb), _stream())), 'otr_dec_self_bwd')
             grads[o + 4], grads[o + 5], grads[o + 3] = _grad_b(part1[:, :d], g1), _grad_b(part1[:, d:2 * d], be1), _grad_b(part1[:, 2 * d:], bo)
             grads[o + 2], grads[o + 0], grads[o + 1] = _grad_w(da1, rec['ctx1'], wo), _grad_w(dqkv16, rec['y016'], wqkv), _grad_b(dqkv16, bqkv)
             dskip, slabs, nslab = dz1, slAb, 4

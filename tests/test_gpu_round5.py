@@ -286,3 +286,44 @@ def test_frontend_linear_takes_its_gradient_as_a_16bit_operand(accumulate):
         assert float(out['g16'].get('decoder.output_layer.weight', out['g16']['decoder.embedding.weight']).abs().sum()) > 0
     finally:
         ops.set_compute_dtype('bf16')
+
+
+def test_gradient_accumulation_with_store_first_weight_gradients():
+    """two backward passes into one cleared gradient buffer (dp.no_sync-style accumulation at world size 1) give twice the gradient of
+    one: the first pass's weight-gradient launch STORES into the cleared buffers (ops.gradients_cleared), the second accumulates"""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops, synthetic as syn
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+    ops.set_compute_dtype('fp16')
+    try:
+        cfg = syn.c2_model(0.0)
+        cfg['encoder']['n_blocks'] = 1
+        cfg['decoder']['n_blocks'] = 1
+        inputs, targets = syn.synthetic_batch(batch=8, frames=1000, feat_dim=80, vocab=4234, tgt_len=15, seed=4)
+        inputs, targets = {k: v.to(DEV) for k, v in inputs.items()}, {k: v.to(DEV) for k, v in targets.items()}
+        model = ota.SpeechToText(cfg)
+        syn.fill_state_dict_(model.state_dict(), 9)
+        model = model.to(DEV).train()
+        dp = FlatDataParallel(model)
+        FusedAdam(dp, lr=1e-3, loss_scale=256.0)
+        res = []
+        for passes in (1, 2):
+            dp.zero_grad()
+            for _ in range(passes):
+                loss, _ = dp(inputs, targets)
+                ops.backward(loss)
+            torch.cuda.synchronize()
+            res.append(dp.flat_grad.clone())
+        assert rel(res[1], 2 * res[0]) < 1e-5, rel(res[1], 2 * res[0])
+        was = ops._WG_OVERWRITE
+        ops._WG_OVERWRITE = False                                      # and the same gradient with the switch off
+        try:
+            dp.zero_grad()
+            loss, _ = dp(inputs, targets)
+            ops.backward(loss)
+            torch.cuda.synchronize()
+            assert rel(dp.flat_grad, res[0]) < 1e-5
+        finally:
+            ops._WG_OVERWRITE = was
+    finally:
+        ops.set_compute_dtype('bf16')

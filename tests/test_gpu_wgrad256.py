@@ -103,6 +103,56 @@ def test_wgrad256_matches_reference(mode, shapes, grid):
         ops.set_compute_dtype('bf16')
 
 
+@pytest.mark.parametrize('shapes,grid', [(SHAPES_SMALL, 0), (SHAPES_SMALL, 7), (SHAPES_RAGGED, 5), (SHAPES_HEAD, 0), (SHAPES_HEAD, -250)])
+def test_wgrad256_stores_into_cleared_single_writer_buffers(shapes, grid):
+    """otr_wgrad_item_t.overwrite (ops.register_single_writer_grads / gradients_cleared): a registered buffer that was just cleared
+    receives the first partial sum of every tile as a STORE (through the turnstile too: piece 0 stores, the others accumulate);
+    the result is bit-identical to the accumulating launch on zeros.  A second launch before the next clear accumulates.  That the
+    store path really runs is shown on a buffer that is NOT zero when it is declared cleared: the old content is gone."""
+    from opentransformer_amd import ops
+    ops.set_compute_dtype('fp16')
+    try:
+        adt = ops.act_dtype()
+        gen = torch.Generator().manual_seed(11)
+        items, refs = [], []
+        for (m, n, k) in shapes:
+            dy = torch.randn(m, n, generator=gen).to(DEV, adt)
+            x = torch.randn(m, k, generator=gen).to(DEV, adt)
+            items.append((dy, x, torch.zeros(n, k, device=DEV)))
+            refs.append(dy.float().t() @ x.float())
+        ptrs = {o.data_ptr() for _, _, o in items}
+        _run(items, 'fp16', grid)                                   # unregistered buffers: read-modify-write on zeros
+        base = [o.clone() for _, _, o in items]
+        ops.register_single_writer_grads(ptrs)
+        try:
+            for _, _, o in items:
+                o.zero_()
+            ops.gradients_cleared(ptrs)
+            _run(items, 'fp16', grid)                               # cleared + registered: the store path
+            for a, (_, _, o), ref in zip(base, items, refs):
+                assert torch.equal(a, o)
+                assert float((o - ref).abs().max()) / float(ref.abs().max()) < 2e-5
+            _run(items, 'fp16', grid)                               # not cleared in between: accumulates
+            for a, (_, _, o) in zip(base, items):
+                assert float((o - 2 * a).abs().max()) / float(a.abs().max()) < 1e-6
+            for _, _, o in items:
+                o.fill_(7.0)
+            ops.gradients_cleared(ptrs)                             # (a lie, to see the store: nothing of the 7.0 survives)
+            _run(items, 'fp16', grid)
+            for a, (_, _, o) in zip(base, items):
+                assert torch.equal(a, o)
+            # the same buffer twice in one launch: never stored
+            for _, _, o in items:
+                o.zero_()
+            ops.gradients_cleared(ptrs)
+            _run(items + [items[0]], 'fp16', grid)
+            assert float((items[0][2] - 2 * base[0]).abs().max()) / float(base[0].abs().max()) < 1e-6
+        finally:
+            ops.unregister_single_writer_grads(ptrs)
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
 def test_wgrad256_mixed_with_unqualified_items():
     """Items the 256-wide launch cannot take (short contraction, odd sizes, fp32 operand) stay on the grouped kernel in
     the same call; results of both groups are right."""

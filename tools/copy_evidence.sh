@@ -7,6 +7,7 @@ c $T/bench.json $P/${R}_bench.json
 c $T/decode.json $P/${R}_decode_bench_c5.json
 c $T/kernel_summary_graph.txt $P/${R}_kernel_trace_graph.txt
 c $T/graph_gaps.txt $P/${R}_step_sequence.txt
+c $T/step_kernels.json $P/${R}_step_kernels.json
 c $T/pmc_step.json $P/${R}_pmc_step.json; c $T/pmc_step.txt $P/${R}_pmc_step.txt
 c $T/ffn_bench.json $P/${R}_ffn_bench.json
 c $T/tolerance_cases.jsonl $P/${R}_tolerance_cases.jsonl

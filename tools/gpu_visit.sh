@@ -29,7 +29,7 @@ pmc)
 trace)
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o graph -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extras > $R/$OUT/rocprof.log 2>&1; echo "rocprof exit $?")
   DB=$(ls /tmp/prof_$TAG/*.db /tmp/prof_$TAG/*/*.db 2>/dev/null | head -1)
-  python tools/graph_gaps.py $DB > $OUT/graph_gaps.txt 2>&1
+  python tools/graph_gaps.py $DB $OUT/step_kernels.json > $OUT/graph_gaps.txt 2>&1
   python tools/prof_summary.py $DB 9 > $OUT/kernel_summary_graph.txt 2>&1; head -45 $OUT/kernel_summary_graph.txt | cut -c1-180 ;;
 ffn)
   timeout 600 python -m pytest tests/test_gpu_ffn_fused.py -x -q -p no:cacheprovider > $OUT/ffn_test.log 2>&1; echo "ffn pytest exit $?"

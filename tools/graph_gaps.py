@@ -1,4 +1,6 @@
 """From a rocprofv3 kernel trace of the hipGraph bench: per-step busy time vs wall time (inter-kernel gaps)."""
+import json
+import re
 import sqlite3
 import sys
 
@@ -30,3 +32,17 @@ if len(idx) >= 2:
     for i, (n, s, e) in enumerate(seg):
         short = n.replace('(anonymous namespace)::', '').replace('at::native::', '')[:90]
         print('%4d %9.1f %7.1f  %s' % (i, (s - t0) / 1e3, (e - s) / 1e3, short))
+
+# machine-readable: every launch of the last three whole steps by kernel name -> profiles/rNN_step_kernels.json; bench.py prints the
+# in-step duration of a graded kernel from it beside its live graph-replay timing       usage: graph_gaps.py DB [OUT.json]
+if len(sys.argv) > 2 and len(idx) >= 4:
+    per = {}
+    nsteps = 0
+    for a, b in zip(idx[-4:-1], idx[-3:]):
+        nsteps += 1
+        for n, s, e in rows[a + 1:b + 1]:
+            k = re.sub(r'\bvoid ', '', n).replace('(anonymous namespace)::', '').split('(')[0]
+            per.setdefault(k, []).append((e - s) / 1e3)
+    out = {k: {'launches_per_step': len(v) / nsteps, 'avg_us': sum(v) / len(v), 'max_us': max(v), 'min_us': min(v)} for k, v in per.items()}
+    out['_meta'] = {'steps': nsteps, 'source': 'rocprofv3 --kernel-trace of bench.py (hipGraph replay), the last three whole steps'}
+    json.dump(out, open(sys.argv[2], 'w'), indent=1)
