@@ -563,6 +563,17 @@ def flush_weight_grads():
     _wq['armed'], _wq['task'] = False, None
     w, b, post = _wq['w'], _wq['b'], _wq['post']
     _wq['w'], _wq['b'], _wq['post'] = [], [], []
+    # a gradient buffer that appears twice (one Linear applied twice in the forward pass): the problems of ONE grouped launch run
+    # side by side and would read-modify-write the same tiles unordered -- the repeats go to a flush of their own behind this one
+    if w:
+        first, again, seen_ptr = [], [], set()
+        for item in w:
+            (again if item[2].data_ptr() in seen_ptr else first).append(item)
+            seen_ptr.add(item[2].data_ptr())
+        if again:
+            w = first
+            _wq['w'] = again
+            post = post + [flush_weight_grads]
     if _wq.get('keep_last'):            # bench.py re-times the grouped launch on the items of the last backward
         _wq['last'] = (list(w), list(b))
     lib = L.load()

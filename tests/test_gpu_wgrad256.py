@@ -141,7 +141,8 @@ def test_wgrad256_stores_into_cleared_single_writer_buffers(shapes, grid):
             _run(items, 'fp16', grid)
             for a, (_, _, o) in zip(base, items):
                 assert torch.equal(a, o)
-            # the same buffer twice in one launch: never stored
+            # the same buffer twice in one flush (a Linear applied twice): never stored, and the second product runs in a launch of
+            # its own behind the first (two problems of ONE launch read-modify-write the same tiles unordered)
             for _, _, o in items:
                 o.zero_()
             ops.gradients_cleared(ptrs)
