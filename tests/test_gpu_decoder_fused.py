@@ -28,7 +28,7 @@ DEV = 'cuda'
 # shows the same three values (what the old "as far off as the unfused path" branch compared against).
 OVER_TG = {'blocks.0.slf_attn.qvk_proj.': {'fp16': 4e-2, 'bf16': 3e-1}, 'embedding.weight': {'fp16': 4e-2, 'bf16': 3e-1}}
 # residue the 16-bit paths leave in the analytically-zero key-bias gradient, relative to the live slices of the same bias
-KEY_RESIDUE = {'fp16': 6e-2, 'bf16': 2.4e-1}
+KEY_RESIDUE = {'fp16': 8e-3, 'bf16': 4.5e-2}        # <= 2.2 x measured (profiles/r05_tolerance_cases.jsonl: 3.7e-3 / 2.1e-2)
 
 
 def rel(a, b):

@@ -147,7 +147,7 @@ def test_slab_mode_matches_fp32_torch(mode):
         named = {'x': (4e-2, 3e-1), 'blocks.0.slf_attn.qvk_proj.weight': (4e-2, 3e-1), 'blocks.0.slf_attn.qvk_proj.bias': (4e-2, 3e-1)}
         for n, e in over.items():
             assert n in named and e < named[n][0 if mode == 'fp16' else 1], ('gradient over the flat bound and not a named exception', n, e, tg)
-        assert all(e < (6e-2 if mode == 'fp16' else 2.4e-1) for e in key_errs.values()), key_errs
+        assert all(e < (8e-3 if mode == 'fp16' else 4.5e-2) for e in key_errs.values()), key_errs      # measured 1.0e-3 / 7.5e-3
         print('encoder slab parity', mode, 'out %.2e worst grad %.2e %s' % (rel(got, ref), worst[0], worst[1]))
     finally:
         ops.set_compute_dtype('bf16')
