@@ -648,6 +648,9 @@ typedef struct {
 } otr_dec_ln_t;
 int32_t otr_rb_linear_ln(const otr_dec_ln_t* ln, const void* w_pack, const float* bias, void* out, int32_t out_dtype, int64_t ldo, int64_t M,
                          int32_t N, int32_t K, void* stream);
+/* utterances per (group, head) workgroup of the four attention launches for a batch of B utterances x L decoder rows (host only): the
+ * per-group partial buffers of otr_dec_cross_bwd / otr_dec_self_bwd have ceil(B / this) rows.  0 for shapes the launches refuse. */
+int32_t otr_dec_group_size(int32_t B, int32_t L);
 int32_t otr_dec_self_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t L, const void* wqkv_pack, const float* bqkv, const void* wo_pack,
                          void* qkv16, void* ctx16, float* lse, void* slabs, void* stream);
 int32_t otr_dec_cross_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t L, const void* wq_pack, const float* bq, const void* wo_pack,

@@ -167,6 +167,7 @@ SIGNATURES = {
     'otr_dec_cross_bwd': [C.POINTER(DecLnB), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _I32, _P, _P, _P],
     'otr_dec_self_bwd': [C.POINTER(DecLnB), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_dec_sum': [_P, _P, _I32, _I64, _P, _P],
+    'otr_dec_group_size': [_I32, _I32],
     'otr_optimizer_step': [_P, _P, _P, _P, _I64, _P, _I32, _P] + [_F32] * 12 + [_P],
     'otr_allreduce_unique_id': [_P],
     'otr_allreduce_init': [C.POINTER(C.c_void_p), _P, _I32, _I32],

@@ -27,6 +27,8 @@
 #include "ffn_frag.h"
 #include "ln_pro.h"
 
+extern int g_otr_dec_group;     // api.hip (otr_debug_set(23, v)): cap on the utterances per attention workgroup, 0 = dl_group_size's choice
+
 namespace {
 
 constexpr int DL_H = 4, DL_DK = 64;        // DL_D = 256, DL_RB = 32: ln_pro.h
@@ -1425,14 +1427,33 @@ int32_t dl_check_ln(const char* who, const otr_dec_ln_t* ln, int64_t R, DlLn& o)
   return 0;
 }
 
+// Utterances per (group, head) workgroup of the attention launches.  A 32-row tile holds 32 / L whole utterances, but the launch is
+// a grid of (groups x 4 heads) latency chains on 256 CUs: at the AISHELL batch (B = 32, L = 15) full tiles make 64 workgroups, each
+// walking 16 (utterance, key tile) pairs in its flash loops; ONE utterance per group makes 128 with 8 pairs each -- the padding rows of
+// the tile cost MFMA work nobody waits for (mfma_busy 0.01), the loops are what the launch waits for.  So: the largest group that
+// still leaves >= 256 workgroups, else one utterance per group.  otr_debug_set(23, v) caps it by hand (v >= 32 / L = full tiles, the
+// round-4 geometry).  The kernels never assumed full groups (the last group of a batch is ragged anyway).
+static inline int dl_group_size(int B, int L) {
+  const int gmax = DL_RB / L;
+  if (g_otr_dec_group > 0) return g_otr_dec_group < gmax ? g_otr_dec_group : gmax;
+  int G = gmax;
+  while (G > 1 && ((B + G - 1) / G) * DL_H < 256) --G;
+  return G;
+}
+
 int32_t dl_check_geom(const char* who, int32_t B, int32_t L, DlGeom& g) {
   OTR_REQUIRE(B > 0 && L > 0 && L <= DL_RB, "%s: %d utterances x %d decoder rows: a group is 32 / L whole utterances, L <= 32", who, B, L);
-  g.B = B; g.L = L; g.G = DL_RB / L;
+  g.B = B; g.L = L; g.G = dl_group_size(B, L);
   return 0;
 }
 
 }  // namespace
 extern unsigned long long* g_otr_trace;   // api.hip (otr_debug_trace)
+
+extern "C" int32_t otr_dec_group_size(int32_t B, int32_t L) {
+  if (B <= 0 || L <= 0 || L > DL_RB) return 0;
+  return dl_group_size(B, L);
+}
 
 extern "C" int32_t otr_dec_self_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t L, const void* wqkv_pack, const float* bqkv,
                                     const void* wo_pack, void* qkv16, void* ctx16, float* lse, void* slabs, void* stream) {

@@ -2151,7 +2151,7 @@ class DecoderStackFn(torch.autograd.Function):
             return (None,) * (n_in + len(ctx.params))
         lib = L.load()
         B, Lq, d, T, W, n_layers, p_drop, S, F, seed = ctx.cfg
-        R, G = B * Lq, 32 // Lq
+        R, G = B * Lq, max(1, lib.otr_dec_group_size(B, Lq))     # utterances per (group, head) workgroup: the library's choice
         ngrp, nblk = (B + G - 1) // G, (R + 31) // 32
         dev, hdt = dy.device, half_dtype()
         f32 = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)

@@ -123,11 +123,13 @@ SHAPES = [  # B, L, T', layers, d_ff
 ]
 
 
-@pytest.mark.parametrize('mode', ['fp16', 'bf16'])
+@pytest.mark.parametrize('group', [0, 32])          # utterances per attention workgroup: 0 = the library's choice (round 5: smaller groups
+@pytest.mark.parametrize('mode', ['fp16', 'bf16'])   # when the grid would be thin), 32 = full 32-row tiles (the round-4 geometry)
 @pytest.mark.parametrize('B,Lq,T,nl,dff', SHAPES)
-def test_fused_decoder_matches_fp32_torch(mode, B, Lq, T, nl, dff):
-    from opentransformer_amd import ops
+def test_fused_decoder_matches_fp32_torch(mode, B, Lq, T, nl, dff, group):
+    from opentransformer_amd import ops, _lib
     ops.set_compute_dtype(mode)
+    _lib.check(_lib.load().otr_debug_set(23, group), 'otr_debug_set')
     try:
         vocab = 200
         dec = make_decoder(nl, dff, vocab, 0.0, seed=B + Lq)
@@ -149,7 +151,7 @@ def test_fused_decoder_matches_fp32_torch(mode, B, Lq, T, nl, dff):
         errs, key_errs = H.key_aware_grad_errors(names, ggot, gref)
         worst = max((e, n) for n, e in errs.items())
         over = {n: e for n, e in errs.items() if e >= tg}
-        H.log_tolerance_cases('decoder_fused', {'mode': mode, 'shape': [B, Lq, T, nl, dff], 'tg': tg, 'worst': worst, 'over_tg': over,
+        H.log_tolerance_cases('decoder_fused', {'mode': mode, 'shape': [B, Lq, T, nl, dff], 'group': group, 'tg': tg, 'worst': worst, 'over_tg': over,
                                                 'key_bias_residue': key_errs})
         for n, e in over.items():
             bound = next((b for pat, b in OVER_TG.items() if pat in n), None)
@@ -159,6 +161,7 @@ def test_fused_decoder_matches_fp32_torch(mode, B, Lq, T, nl, dff):
         # keys beyond an utterance's length receive no gradient
         assert float(ggot[0][~key_mask].abs().max()) < 1e-3 * float(ggot[0].abs().max())
     finally:
+        _lib.load().otr_debug_set(23, 0)
         ops.set_compute_dtype('bf16')
 
 
