@@ -69,6 +69,7 @@ def parse():
                          'their replays the all-reduce of the decoder group (37 %% of the gradient bytes) starts on a side stream and runs '
                          'beside the encoder backward; the collectives themselves are never captured.  auto (N > 1) = MEASURE both forms '
                          'for a few untimed steps in this invocation and run the contract region on the faster one; off when N = 1')
+    ap.add_argument('--dropout', type=float, default=0.1, help='residual_dropout of the workload (the shipped yaml: 0.1; other values are experiments, not the metric)')
     ap.add_argument('--calib-steps', type=int, default=8, help='steps per form of the --overlap auto measurement (N > 1)')
     ap.add_argument('--opt-in-graph', default='on', choices=['on', 'off'],
                     help='N = 1: capture the optimizer launches in the step graph too (on) or issue them eagerly behind the replay (off)')
@@ -328,7 +329,7 @@ def main():
     from opentransformer_amd import ops
     from opentransformer_amd.dp import FlatDataParallel, FusedAdam
 
-    cfg = syn.c2_model(residual_dropout=0.1) if args.model == 'transformer' else syn.conformer_model(False, 0.1)
+    cfg = syn.c2_model(residual_dropout=args.dropout) if args.model == 'transformer' else syn.conformer_model(False, args.dropout)
     inputs, targets = syn.synthetic_batch(args.batch, args.frames, 80, 4234, 15, seed=rank)
     inputs = {k: v.to(dev) for k, v in inputs.items()}
     targets = {k: v.to(dev) for k, v in targets.items()}
@@ -553,8 +554,8 @@ def main():
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.mode, 'data': 'synthetic',
             'config': {'workload': 'AISHELL-1 transformer_baseline.yaml (+input_size 80), 12 enc / 6 dec layers, '
-                                   'B=%d/GPU x %d frames x 80-d fbank, 15 decoder rows, V=4234, residual_dropout 0.1; '
-                                   'step = fwd + bwd + grad all-reduce + clip/Adam/Noam' % (args.batch, args.frames),
+                                   'B=%d/GPU x %d frames x 80-d fbank, 15 decoder rows, V=4234, residual_dropout %s; '
+                                   'step = fwd + bwd + grad all-reduce + clip/Adam/Noam' % (args.batch, args.frames, args.dropout),
                        'global_batch': global_batch, 'frames': args.frames, 'parallelism': 'dp%d' % world,
                        'hipgraph': used_graph},
             'loss': final_loss, 'optimizer': final_stats,
