@@ -247,13 +247,32 @@ __device__ __forceinline__ float pe_value(int t, int col, float neg_ln_over_d) {
   return (col & 1) ? cosf(ang) : sinf(ang);
 }
 
-// counter-based RNG for dropout: one 32-bit draw per element index (SplitMix64 finaliser)
-__device__ __forceinline__ uint32_t otr_rand32(uint64_t seed, uint64_t idx) {
+// counter-based RNG: one 32-bit draw per (seed, element index), SplitMix64 finaliser -- the optimizer's gradient noise
+__device__ __forceinline__ uint32_t otr_rand32_sm64(uint64_t seed, uint64_t idx) {
   uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z = z ^ (z >> 31);
   return (uint32_t)(z >> 32);
+}
+// The DROPOUT masks' draw (every kernel that applies or regenerates a mask calls this with the element's index: forward and backward
+// agree by construction).  Round 5: a 32-bit keyed mixer instead of SplitMix64.  Three 64-bit multiplies per ELEMENT were ~60 VALU
+// issue slots; with residual_dropout 0.1 the 60 LayerNorm-bearing launches of a training step draw ~100 M masks, and the step ran
+// 0.13 ms (3 %) slower than with dropout off (same box, tools/gpu_dropout_ab.sh).  Here: the index is xor-ed with a key, two rounds
+// of the `lowbias32` finaliser (xorshift-multiply, constants 0x7FEB352D / 0x846CA68B) with a second key between them -- for a fixed
+// seed a bijection of the low 32 index bits (exactly uniform over a full period), both keys wave-uniform functions of the seed
+// (scalar ALU).  Keep rate, lag-1 / lag-256 / cross-step / cross-site correlations and row / column means of 2 M-element masks match
+// an i.i.d. source to sampling noise (tools/dropout_hash_check.py); tests/test_gpu_dropout.py measures the kernels themselves.
+__device__ __forceinline__ uint32_t otr_rand32(uint64_t seed, uint64_t idx) {
+  const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+  const uint32_t k0 = (s0 * 0x9E3779B1u) ^ s1;
+  const uint32_t k1 = (s1 * 0x85EBCA77u) ^ (s0 >> 15) ^ 0xC2B2AE3Du;
+  uint32_t x = (uint32_t)idx ^ k0;
+  x += (uint32_t)(idx >> 32) * 0x27D4EB2Fu;        // indices past 2^32 (a step's offsets never get there; kept for totality)
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15; x ^= k1; x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
 }
 
 // fast unsigned division by a runtime constant (host-computed magic), valid for n < 2^31

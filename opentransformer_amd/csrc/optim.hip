@@ -105,8 +105,8 @@ __global__ void opt_tick_kernel(OptState* st, float base_lr, float model_size, f
 
 // N(0,1) from the counter RNG (Box-Muller): gradient noise of train/trainer.py:223-227
 __device__ __forceinline__ float otr_gauss(uint64_t seed, uint64_t idx) {
-  const float u1 = ((float)otr_rand32(seed, 2 * idx) + 1.f) * (1.f / 4294967296.f);
-  const float u2 = (float)otr_rand32(seed, 2 * idx + 1) * (1.f / 4294967296.f);
+  const float u1 = ((float)otr_rand32_sm64(seed, 2 * idx) + 1.f) * (1.f / 4294967296.f);
+  const float u2 = (float)otr_rand32_sm64(seed, 2 * idx + 1) * (1.f / 4294967296.f);
   return sqrtf(-2.f * __logf(u1)) * __cosf(6.2831853f * u2);
 }
 
