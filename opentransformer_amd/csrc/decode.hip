@@ -14,6 +14,7 @@
 #include "common.h"
 
 #define NEG_INF (-__builtin_huge_valf())
+extern int g_otr_decode_attn64;    // api.hip (otr_debug_set(24, v)): the vector-load form of the cached self-attention step
 
 __global__ void decode_embed_kernel(const int64_t* preds, int64_t ldp, const int32_t* pos, const float* E, float* y,
                                     bf16_t* y_lp, int d, int vocab, float scale) {
@@ -163,6 +164,97 @@ __global__ __launch_bounds__(64) void decode_self_attn_kernel(const T* __restric
   if (lane + 64 < dk) ElemIO<T>::st(o + lane + 64, acc1 * inv);
 }
 
+// The same for 16-bit operands and head dim 64 (the shipped models), without the two serial loops: the kernel above dots a key with
+// 64 two-byte loads per lane and then walks the positions one value row at a time, a dependent global load per position -- 14 us
+// per launch at 30 cached positions, 25 us at 60, ten launches per decode step (rocprofv3, profiles/r05_decode_kernels.txt).  Here a
+// lane fetches its key as eight 16-byte loads in flight, and the value rows of a 64-position chunk are read as (row, 16-byte piece)
+// pairs, eight per lane, all in flight: lane -> piece lane & 7 of rows (lane >> 3) + 8 t; the eight row groups meet in a 3-step
+// butterfly.  Probabilities and ancestor rows travel through LDS.  Same arithmetic per score; the context sums in a different order.
+__global__ __launch_bounds__(64) void decode_self_attn64_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+                                                               const int32_t* __restrict__ anc, const int32_t* __restrict__ pos,
+                                                               bf16_t* __restrict__ out, int H, int maxlen, float scale) {
+  constexpr int DK = 64;
+  __shared__ float qs[DK];
+  __shared__ float ps[64];
+  __shared__ int rws[64];
+  const int r = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+  const int d = H * DK;
+  const int p = *pos;
+  const bf16_t* q = qkv + (int64_t)r * 3 * d + h * DK;
+  const bf16_t* kn = q + d;
+  const bf16_t* vn = q + 2 * d;
+  qs[lane] = bf2f(q[lane]);
+  if (lane < 16) {                                      // the new position's key / value into the caches: 16 bytes per lane
+    const int64_t o = ((int64_t)r * maxlen + p) * d + h * DK + 8 * (lane & 7);
+    if (lane < 8) st_global_b128(kc + o, ld_global_b128(kn + 8 * lane));
+    else st_global_b128(vc + o, ld_global_b128(vn + 8 * (lane & 7)));
+  }
+  __syncthreads();
+  float m = NEG_INF, l = 0.f, acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const int ch = lane & 7, g = lane >> 3;
+  for (int c0 = 0; c0 <= p; c0 += 64) {
+    const int j = c0 + lane, jc = min(j, p);            // lanes past the last position fetch a valid row and are masked
+    int row = r;
+    const bf16_t* kp = kn;
+    if (jc != p) {
+      row = anc[(int64_t)r * maxlen + jc];
+      kp = kc + ((int64_t)row * maxlen + jc) * d + h * DK;
+    }
+    uint4 kk[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kk[i] = ld_global_b128(kp + 8 * i);
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t w[4] = {kk[i].x, kk[i].y, kk[i].z, kk[i].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a += qs[8 * i + 2 * e] * h2f_lo(w[e]); a += qs[8 * i + 2 * e + 1] * h2f_hi(w[e]); }
+    }
+    const float s = (j <= p) ? a * scale : NEG_INF;
+    const float mn = fmaxf(m, wave_max(s));
+    const float pj = (j <= p) ? expf(s - mn) : 0.f;
+    const float corr = expf(m - mn);                    // m = -inf on the first chunk -> 0
+    l = l * corr + wave_sum(pj);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= corr;
+    m = mn;
+    __syncthreads();                                    // the previous chunk's readers are done with ps / rws
+    ps[lane] = pj;
+    rws[lane] = row;
+    __syncthreads();
+    const int n = min(64, p + 1 - c0);
+    uint4 vv[8];
+    float pw[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int jj = g + 8 * t, jv = min(jj, n - 1), jabs = c0 + jv;
+      const bf16_t* vp = (jabs == p) ? vn : vc + ((int64_t)rws[jv] * maxlen + jabs) * d + h * DK;
+      vv[t] = ld_global_b128(vp + 8 * ch);
+      pw[t] = jj < n ? ps[jv] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const uint32_t w[4] = {vv[t].x, vv[t].y, vv[t].z, vv[t].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] += pw[t] * h2f_lo(w[e]); acc[2 * e + 1] += pw[t] * h2f_hi(w[e]); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    acc[e] += __shfl_xor(acc[e], 8);
+    acc[e] += __shfl_xor(acc[e], 16);
+    acc[e] += __shfl_xor(acc[e], 32);
+  }
+  if (lane < 8) {
+    const float inv = 1.f / l;
+    st_global_b128(out + (int64_t)r * d + h * DK + 8 * lane,
+                   make_uint4(pack2h(acc[0] * inv, acc[1] * inv), pack2h(acc[2] * inv, acc[3] * inv), pack2h(acc[4] * inv, acc[5] * inv),
+                              pack2h(acc[6] * inv, acc[7] * inv)));
+  }
+}
+
 extern "C" int32_t otr_decode_self_attention(const void* qkv, void* kcache, void* vcache, const int32_t* anc,
                                              const int32_t* pos, void* out, int32_t dtype, int64_t rows, int32_t H,
                                              int32_t dk, int32_t maxlen, float scale, void* stream) {
@@ -175,6 +267,9 @@ extern "C" int32_t otr_decode_self_attention(const void* qkv, void* kcache, void
   if (dtype == OTR_F32)
     hipLaunchKernelGGL(decode_self_attn_kernel<float>, dim3((unsigned)(rows * H)), dim3(64), 0, s, (const float*)qkv,
                        (float*)kcache, (float*)vcache, anc, pos, (float*)out, H, dk, maxlen, scale);
+  else if (dk == 64 && g_otr_decode_attn64 && (((uintptr_t)qkv | (uintptr_t)kcache | (uintptr_t)vcache | (uintptr_t)out) % 16) == 0)
+    hipLaunchKernelGGL(decode_self_attn64_kernel, dim3((unsigned)(rows * H)), dim3(64), 0, s, (const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache,
+                       anc, pos, (bf16_t*)out, H, maxlen, scale);
   else
     hipLaunchKernelGGL(decode_self_attn_kernel<bf16_t>, dim3((unsigned)(rows * H)), dim3(64), 0, s, (const bf16_t*)qkv,
                        (bf16_t*)kcache, (bf16_t*)vcache, anc, pos, (bf16_t*)out, H, dk, maxlen, scale);

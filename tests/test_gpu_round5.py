@@ -327,3 +327,44 @@ def test_gradient_accumulation_with_store_first_weight_gradients():
             ops._WG_OVERWRITE = was
     finally:
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp16', 'bf16'])
+@pytest.mark.parametrize('R,pos,maxlen', [(80, 0, 61), (80, 1, 61), (80, 29, 61), (80, 60, 61), (20, 63, 130), (20, 64, 130), (20, 127, 130), (7, 5, 13)])
+def test_cached_self_attention_vector_form_matches_plain_torch_and_the_serial_kernel(mode, R, pos, maxlen):
+    """otr_decode_self_attention on 16-bit operands with head dim 64 (csrc/decode.hip: 16-byte loads, a chunk's value rows all in
+    flight) against plain fp32 torch on the same caches and ancestor table, and against the serial kernel it replaces
+    (otr_debug_set(24, 0)); the new key / value land in the caches at [r, pos]; positions past 64 take the second chunk."""
+    from opentransformer_amd import ops, _lib
+    ops.set_compute_dtype(mode)
+    try:
+        H, dk = 4, 64
+        d = H * dk
+        adt = ops.act_dtype()
+        g = torch.Generator().manual_seed(R * 1000 + pos)
+        qkv = torch.randn(R, 3 * d, generator=g).to(DEV, adt)
+        kc0 = torch.randn(R, maxlen, d, generator=g).to(DEV, adt)
+        vc0 = torch.randn(R, maxlen, d, generator=g).to(DEV, adt)
+        anc = torch.randint(0, R, (R, maxlen), generator=g).to(torch.int32).to(DEV)
+        p = torch.tensor([pos], dtype=torch.int32, device=DEV)
+        outs = {}
+        for form in (1, 0):
+            _lib.check(_lib.load().otr_debug_set(24, form), 'otr_debug_set')
+            kc, vc = kc0.clone(), vc0.clone()
+            outs[form] = (ops.decode_self_attention(qkv, kc, vc, anc, p, H), kc, vc)
+        _lib.load().otr_debug_set(24, 1)
+        (o1, k1, v1), (o0, k0, v0) = outs[1], outs[0]
+        assert torch.equal(k1, k0) and torch.equal(v1, v0)
+        assert torch.equal(k1[:, pos], qkv[:, d:2 * d]) and torch.equal(v1[:, pos], qkv[:, 2 * d:])
+        # plain torch on the same numbers
+        q = qkv[:, :d].float().view(R, H, dk)
+        rows = torch.arange(R, device=DEV)
+        keys = torch.stack([kc0[anc[:, j].long(), j] for j in range(pos)] + [qkv[:, d:2 * d]], dim=1).float().view(R, pos + 1, H, dk)
+        vals = torch.stack([vc0[anc[:, j].long(), j] for j in range(pos)] + [qkv[:, 2 * d:]], dim=1).float().view(R, pos + 1, H, dk)
+        sc = torch.einsum('rhd,rjhd->rhj', q, keys) / 8.0
+        ref = torch.einsum('rhj,rjhd->rhd', torch.softmax(sc, dim=-1), vals).reshape(R, d)
+        tol = 4e-3 if mode == 'fp16' else 2e-2              # the 16-bit rounding of the output
+        assert rel(o1.float(), ref) < tol, rel(o1.float(), ref)
+        assert rel(o1.float(), o0.float()) < tol
+    finally:
+        ops.set_compute_dtype('bf16')
