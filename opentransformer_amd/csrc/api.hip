@@ -54,6 +54,7 @@ int g_otr_conv1_stencil = 0;     // 1: conv1 forward on the VALU stencil instead
 int g_otr_attn_waves8 = 1;       // merged attention backward on 8-wave workgroups (128 queries / keys each; otr_debug_set(20, v))
 int g_otr_attn_xmap = 1;         // attention launches: the blocks of one (head, utterance) on one XCD (otr_debug_set(16, v))
 int g_otr_attn_bwd_split = 0;    // attention backward as two launches (dQ, then dK/dV) instead of one (otr_debug_set(13, v))
+int g_otr_beam_reg = 1;          // beam_topk with the row in registers and wave-level arg-max rounds (beam.hip; otr_debug_set(25, v))
 int g_otr_decode_attn64 = 1;     // cached decode self-attention: 16-byte loads, all value rows of a chunk in flight (decode.hip; otr_debug_set(24, v))
 int g_otr_dec_group = 0;         // fused decoder: utterances per (group, head) workgroup; 0 = declayer.hip's choice, > 0 = at most that many (otr_debug_set(23, v))
 int g_otr_ffn_map = 1;           // split FFN kernels: workgroup -> (row block, slice) mapping, ffn3.hip f3_block_map (otr_debug_set(15, v))
@@ -87,6 +88,7 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   else if (key == 15) g_otr_ffn_map = value;
   else if (key == 23) g_otr_dec_group = value;
   else if (key == 24) g_otr_decode_attn64 = value;
+  else if (key == 25) g_otr_beam_reg = value;
   else { otr_set_error("debug_set: unknown key %d", key); return -1; }
   return 0;
 }

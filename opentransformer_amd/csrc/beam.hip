@@ -10,6 +10,7 @@
 
 #define NEG_INF (-__builtin_huge_valf())
 constexpr int MAXK = 16;
+extern int g_otr_beam_reg;     // api.hip (otr_debug_set(25, v)): 1 = the register-resident top-k kernel where the vocabulary fits
 
 __device__ __forceinline__ void block_lse(const float* x, int V, float* sh, float& mx, float& lse) {
   float m = NEG_INF;
@@ -88,14 +89,111 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* logits, int
   }
 }
 
+// The same for V <= 256 * BT_NV (the shipped vocabularies), r05: the row (and the LM's row) is read ONCE into registers -- the kernel
+// above reads each five times with 4-byte loads -- and a round of the block-wide arg-max is a 6-step wave butterfly + one exchange
+// of the four waves' winners (2 barriers) instead of an 8-level shared-memory tree (18 barriers): 53 -> ~15 us per decode step at
+// 80 rows x 4234 (profiles/r05_decode_kernels.txt).  Same scores, same tie rule (lower index first): same selection.
+constexpr int BT_NV = 20;
+__device__ __forceinline__ bool bt_better(float s, int i, float t, int j) { return s > t || (s == t && i < j); }
+__global__ __launch_bounds__(256) void beam_topk_reg_kernel(const float* logits, int64_t ld, const float* lm_logits, int64_t ld_lm, float lm_weight,
+                                                           int V, int k, float* out_score, int64_t* out_idx) {
+  __shared__ float shf[8];
+  __shared__ float ws_s[4];
+  __shared__ int ws_i[4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t row = blockIdx.x;
+  const float* x = logits + row * ld;
+  const float* y = lm_logits ? lm_logits + row * ld_lm : nullptr;
+  float xs[BT_NV], ys[BT_NV];
+  float mx = NEG_INF, my = NEG_INF;
+#pragma unroll
+  for (int j = 0; j < BT_NV; ++j) {
+    const int v = tid + 256 * j;
+    xs[j] = v < V ? x[v] : NEG_INF;
+    ys[j] = (y && v < V) ? y[v] : NEG_INF;
+    mx = fmaxf(mx, xs[j]);
+    my = fmaxf(my, ys[j]);
+  }
+  mx = wave_max(mx); my = wave_max(my);
+  if (lane == 0) { shf[wid] = mx; shf[4 + wid] = my; }
+  __syncthreads();
+  mx = fmaxf(fmaxf(shf[0], shf[1]), fmaxf(shf[2], shf[3]));
+  my = fmaxf(fmaxf(shf[4], shf[5]), fmaxf(shf[6], shf[7]));
+  float sx = 0.f, sy = 0.f;
+#pragma unroll
+  for (int j = 0; j < BT_NV; ++j) {
+    const int v = tid + 256 * j;
+    if (v < V) { sx += expf(xs[j] - mx); if (y) sy += expf(ys[j] - my); }
+  }
+  sx = wave_sum(sx); sy = wave_sum(sy);
+  __syncthreads();
+  if (lane == 0) { shf[wid] = sx; shf[4 + wid] = sy; }
+  __syncthreads();
+  const float lse = mx + logf(shf[0] + shf[1] + shf[2] + shf[3]);
+  const float llse = y ? my + logf(shf[4] + shf[5] + shf[6] + shf[7]) : 0.f;
+  // per-thread sorted top-k over its strided slice (descending, ties -> lower index first)
+  float ts[MAXK];
+  int ti[MAXK];
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) { ts[j] = NEG_INF; ti[j] = 0x7fffffff; }
+#pragma unroll
+  for (int jj = 0; jj < BT_NV; ++jj) {
+    const int v = tid + 256 * jj;
+    if (v < V) {
+      float sc = xs[jj] - lse;
+      if (y) sc += lm_weight * (ys[jj] - llse);
+      if (bt_better(sc, v, ts[k - 1], ti[k - 1])) {
+        ts[k - 1] = sc; ti[k - 1] = v;
+#pragma unroll
+        for (int j = MAXK - 1; j > 0; --j) {
+          if (j < k && bt_better(ts[j], ti[j], ts[j - 1], ti[j - 1])) {
+            float a = ts[j]; ts[j] = ts[j - 1]; ts[j - 1] = a;
+            int b = ti[j]; ti[j] = ti[j - 1]; ti[j - 1] = b;
+          }
+        }
+      }
+    }
+  }
+  int head = 0;
+  for (int r = 0; r < k; ++r) {
+    float hs = NEG_INF;
+    int hi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j)
+      if (j == head) { hs = ts[j]; hi = ti[j]; }
+    float bs = hs;
+    int bi = hi;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float os = __shfl_xor(bs, off);
+      const int oi = __shfl_xor(bi, off);
+      if (bt_better(os, oi, bs, bi)) { bs = os; bi = oi; }
+    }
+    __syncthreads();                                  // the previous round's readers are done with ws_*
+    if (lane == 0) { ws_s[wid] = bs; ws_i[wid] = bi; }
+    __syncthreads();
+    float wsc = ws_s[0];
+    int wi = ws_i[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (bt_better(ws_s[w], ws_i[w], wsc, wi)) { wsc = ws_s[w]; wi = ws_i[w]; }
+    if (tid == 0) { out_score[row * k + r] = wsc; out_idx[row * k + r] = wi; }
+    if (hi == wi && hs == wsc && head < k) ++head;   // the owner pops its head
+  }
+}
+
 extern "C" int32_t otr_beam_topk(const float* logits, int64_t ld, const float* lm_logits, int64_t ld_lm, float lm_weight,
                                  int64_t rows, int32_t V, int32_t k, float* out_score, int64_t* out_idx, void* stream) {
   OTR_REQUIRE(logits && out_score && out_idx, "beam_topk: null pointer");
   OTR_REQUIRE(k >= 1 && k <= MAXK && k <= V, "beam_topk: k=%d must be in [1, %d] and <= V", k, MAXK);
   OTR_REQUIRE(rows >= 0 && V > 0 && ld >= V, "beam_topk: bad shape");
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(beam_topk_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, ld, lm_logits,
-                     ld_lm, lm_weight, V, k, out_score, out_idx);
+  if (V <= 256 * BT_NV && g_otr_beam_reg)
+    hipLaunchKernelGGL(beam_topk_reg_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, ld, lm_logits, ld_lm, lm_weight, V,
+                       k, out_score, out_idx);
+  else
+    hipLaunchKernelGGL(beam_topk_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, ld, lm_logits,
+                       ld_lm, lm_weight, V, k, out_score, out_idx);
   return otr_check_launch("beam_topk");
 }
 
@@ -120,27 +218,33 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(const float* k_score, c
     if (fin) ks = (br == 0) ? 0.f : NEG_INF;        // mask_finished_scores
     s = scores_in[hyp] + ks;
   }
-  c0[tid] = s;
-  __syncthreads();
+  // beam rounds of a block-wide arg-max over the candidates, one per thread (ties -> lower candidate index): a 6-step wave butterfly
+  // + one exchange of the four waves' winners per round (r05; it was an 8-level shared-memory tree: 22.9 us per decode step)
+  const int lane = tid & 63, wid = tid >> 6;
   for (int r = 0; r < beam; ++r) {
-    cs[tid] = c0[tid];
-    ci[tid] = tid;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if (tid < off) {
-        float a = cs[tid], bb = cs[tid + off];
-        int ia = ci[tid], ib = ci[tid + off];
-        if (bb > a || (bb == a && ib < ia)) { cs[tid] = bb; ci[tid] = ib; }
-      }
-      __syncthreads();
+    float bs = s;
+    int bi = tid;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float os = __shfl_xor(bs, off);
+      const int oi = __shfl_xor(bi, off);
+      if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
     }
+    __syncthreads();                                // the previous round's readers are done with cs / ci
+    if (lane == 0) { cs[wid] = bs; ci[wid] = bi; }
+    __syncthreads();
+    float wsc = cs[0];
+    int wi = ci[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (cs[w] > wsc || (cs[w] == wsc && ci[w] < wi)) { wsc = cs[w]; wi = ci[w]; }
     if (tid == 0) {
-      win[r] = ci[0];
-      scores_out[b * beam + r] = cs[0];
-      c0[ci[0]] = NEG_INF;                          // remove the winner (NaN-free: -inf stays -inf)
+      win[r] = wi;
+      scores_out[b * beam + r] = wsc;
     }
-    __syncthreads();
+    if (tid == wi) s = NEG_INF;                     // remove the winner (NaN-free: -inf stays -inf)
   }
+  __syncthreads();
   // gather prefixes + append tokens: thread j < beam handles output hypothesis j
   for (int r = 0; r < beam; ++r) {
     int w = win[r];

@@ -129,13 +129,15 @@ class RecurrentLanguageModel(nn.Module):
         return ops.log_softmax(logits), hidden
 
     @torch.no_grad()
-    def logits_last(self, preds, pos=None):
+    def logits_last(self, preds, pos=None, out=None):
         """un-normalised scores [R, V] of the token after preds[:, *pos] from the ZERO state: what the fused beam search adds at every
         step (recognize/base.py:35-36 with hidden = None); pos: device int32 scalar (cached search) or None = the last column"""
         if pos is None:
             preds, pos = preds[:, -1:], None
         x = ops.decode_lookup(preds, pos, self.embedding.weight)
         y = self._step(x, [None] * self.num_layers, [None] * self.num_layers)
+        if out is not None:                   # recognize._PaddedOutput of output_project: [R, rows8] logits
+            return out(y)
         return ops.linear(y, self.output_project.weight, self.output_project.bias)
 
     def forward(self, inputs, targets):
@@ -200,6 +202,41 @@ class Recognizer:
 
 def _ptr(t, off=0):
     return C.c_void_p(t.data_ptr() + off * t.element_size()) if t is not None else None
+
+
+class _PaddedOutput:
+    """The vocabulary projection of a decode step on ROW-PADDED operands (decoder/transformer.py:153, model/lm.py:60; the training
+    path gets the same from dp.FlatDataParallel's padded slots): a 4234-row weight puts the rows of the [R, 4234] logits at odd
+    addresses and the product on the generic loaders -- 87 + 41 us of a 0.6 ms decode step for the decoder's and the LM's output layers
+    (rocprofv3, profiles/r05_decode_kernels.txt).  Here: a 16-bit copy of the weight with the rows padded to a multiple of 8 (zeros),
+    the bias likewise, the logits come out as [R, rows8] and otr_beam_topk reads them through their leading dimension.  Built once per
+    (weights' version, pointer) fingerprint by the owners below: a changed checkpoint rebuilds it."""
+
+    def __init__(self, weight, bias):
+        N, K = weight.shape
+        self.N, self.N8 = N, (N + 7) // 8 * 8
+        hdt = ops.half_dtype()
+        self.w = torch.zeros((self.N8, K), dtype=hdt, device=weight.device)
+        self.w[:N].copy_(weight.detach())
+        self.b = None
+        if bias is not None:
+            self.b = torch.zeros((self.N8,), dtype=torch.float32, device=weight.device)
+            self.b[:N].copy_(bias.detach())
+
+    def __call__(self, x):
+        """x [R, K] fp32 with its 16-bit twin (or 16-bit) -> logits [R, N8] fp32 (columns >= N are zero-weight products: ignored)"""
+        x16 = ops.lp_of(x)
+        x2 = (x16 if x16 is not None else x).reshape(-1, self.w.shape[1])
+        if x2.dtype != self.w.dtype:
+            x2 = x2.to(self.w.dtype)
+        return ops.linear_fwd_raw(x2.contiguous(), self.w, self.b, torch.float32)
+
+
+def _padded_output(weight, bias):
+    """a _PaddedOutput where it pays (16-bit mode, CUDA, output width not a multiple of 8), else None"""
+    if ops.is_half() and weight.is_cuda and weight.dim() == 2 and weight.shape[0] % 8 != 0 and weight.shape[1] % 8 == 0:
+        return _PaddedOutput(weight, bias)
+    return None
 
 
 class SpeechToTextRecognizer(Recognizer):
@@ -339,6 +376,8 @@ class CachedBeamState:
         if lm is not None and not self.lm_recurrent:
             dl = lm.embedding.weight.shape[1]
             self.lm_cache = [(new((R, self.maxlen, dl), adt), new((R, self.maxlen, dl), adt)) for _ in lm.blocks]
+        self.out_dec = _padded_output(dec.output_layer.weight, dec.output_layer.bias)
+        self.out_lm = _padded_output(lm.output_project.weight, lm.output_project.bias) if lm is not None else None
         self.graphs = [None, None]
         self.warm = [False, False]
 
@@ -469,11 +508,13 @@ class CachedBeamState:
             x = self._ffn(blk, blk.norm3, x)
         if dec.normalize_before:
             x = ops.add_layernorm(x, None, dec.after_norm.weight, dec.after_norm.bias, 0.0, dec.after_norm.eps)
-        logits = ops.linear(x, dec.output_layer.weight, dec.output_layer.bias)
-        V = logits.size(-1)
-        lm_logits = None
+        V = dec.output_layer.weight.shape[0]
+        logits = self.out_dec(x) if self.out_dec is not None else ops.linear(x, dec.output_layer.weight, dec.output_layer.bias)
+        ld = logits.size(-1)                             # V, or V padded to a multiple of 8 (_PaddedOutput)
+        lm_logits, ld_lm = None, V
         if self.lm_recurrent:
-            lm_logits = lm.logits_last(self.preds[cur], self.pos[cur])     # one LSTM step from zeros on the last token (base.py:35-36)
+            lm_logits = lm.logits_last(self.preds[cur], self.pos[cur], out=self.out_lm)     # one LSTM step from zeros on the last token (base.py:35-36)
+            ld_lm = lm_logits.size(-1)
         elif lm is not None:
             y = ops.decode_embed(self.preds[cur], self.pos[cur], lm.embedding.weight)
             for blk, cache in zip(lm.blocks, self.lm_cache):
@@ -482,8 +523,9 @@ class CachedBeamState:
                     y = self._fused_tail(blk, y, None, None, blk.norm2)
                     continue
                 y = self._ffn(blk, blk.norm2, y)
-            lm_logits = ops.linear(y, lm.output_project.weight, lm.output_project.bias)
-        L.check(lib.otr_beam_topk(_ptr(logits), V, _ptr(lm_logits), V, float(rec.lm_weight or 0.0), self.R, V, beam,
+            lm_logits = self.out_lm(y) if self.out_lm is not None else ops.linear(y, lm.output_project.weight, lm.output_project.bias)
+            ld_lm = lm_logits.size(-1)
+        L.check(lib.otr_beam_topk(_ptr(logits), ld, _ptr(lm_logits), ld_lm, float(rec.lm_weight or 0.0), self.R, V, beam,
                                   _ptr(self.k_score), _ptr(self.k_idx), stream), 'otr_beam_topk')
         nxt = cur ^ 1
         L.check(lib.otr_beam_prune_cached(_ptr(self.k_score), _ptr(self.k_idx), _ptr(self.scores[cur]),
