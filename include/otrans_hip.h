@@ -618,6 +618,8 @@ int32_t otr_lstm_cell(const float* gates_a, const float* gates_b, const float* b
 int32_t otr_decode_self_attention(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const int32_t* pos,
                                   void* out, int32_t dtype, int64_t rows, int32_t H, int32_t dk, int32_t maxlen,
                                   float scale, void* stream);
+/* otr_beam_prune_cached: n_finished is int32[2] here -- [0] receives the number of finished hypotheses, [1] is the kernel's arrival
+ * word: zero it once when the buffer is made, the launch leaves it zero (no zeroing launch per step, r05).  batch * beam < 65536. */
 int32_t otr_beam_prune_cached(const float* k_score, const int64_t* k_idx, const float* scores_in, const uint8_t* flag_in,
                               const int64_t* preds_in, int64_t ldp, int32_t batch, int32_t beam, int32_t eos,
                               const int32_t* pos_in, int32_t* pos_out, const int32_t* anc_in, int32_t* anc_out,

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* logits, int
 
 // The same for V <= 256 * BT_NV (the shipped vocabularies), r05: the row (and the LM's row) is read ONCE into registers -- the kernel
 // above reads each five times with 4-byte loads -- and a round of the block-wide arg-max is a 6-step wave butterfly + one exchange
-// of the four waves' winners (2 barriers) instead of an 8-level shared-memory tree (18 barriers): 53 -> ~15 us per decode step at
+// of the four waves' winners (2 barriers) instead of an 8-level shared-memory tree (18 barriers): 53 us per decode step before; the number now is in DESIGN.md 5.7 at
 // 80 rows x 4234 (profiles/r05_decode_kernels.txt).  Same scores, same tie rule (lower index first): same selection.
 constexpr int BT_NV = 20;
 __device__ __forceinline__ bool bt_better(float s, int i, float t, int j) { return s > t || (s == t && i < j); }
@@ -131,36 +131,24 @@ __global__ __launch_bounds__(256) void beam_topk_reg_kernel(const float* logits,
   __syncthreads();
   const float lse = mx + logf(shf[0] + shf[1] + shf[2] + shf[3]);
   const float llse = y ? my + logf(shf[4] + shf[5] + shf[6] + shf[7]) : 0.f;
-  // per-thread sorted top-k over its strided slice (descending, ties -> lower index first)
-  float ts[MAXK];
-  int ti[MAXK];
+  // k rounds of a block-wide arg-max over the live elements (ties -> lower index first).  Each thread keeps the best of ITS live
+  // elements; only the thread that owned a round's winner retires it and rescans its 20 registers.  (The first r05 form kept a
+  // sorted k-list per thread: 19k instructions once unrolled, larger than the instruction cache -- 40 us; this is ~1k.)
+  float sc[BT_NV];
+  uint32_t alive = 0;
 #pragma unroll
-  for (int j = 0; j < MAXK; ++j) { ts[j] = NEG_INF; ti[j] = 0x7fffffff; }
-#pragma unroll
-  for (int jj = 0; jj < BT_NV; ++jj) {
-    const int v = tid + 256 * jj;
-    if (v < V) {
-      float sc = xs[jj] - lse;
-      if (y) sc += lm_weight * (ys[jj] - llse);
-      if (bt_better(sc, v, ts[k - 1], ti[k - 1])) {
-        ts[k - 1] = sc; ti[k - 1] = v;
-#pragma unroll
-        for (int j = MAXK - 1; j > 0; --j) {
-          if (j < k && bt_better(ts[j], ti[j], ts[j - 1], ti[j - 1])) {
-            float a = ts[j]; ts[j] = ts[j - 1]; ts[j - 1] = a;
-            int b = ti[j]; ti[j] = ti[j - 1]; ti[j - 1] = b;
-          }
-        }
-      }
-    }
+  for (int j = 0; j < BT_NV; ++j) {
+    const int v = tid + 256 * j;
+    sc[j] = xs[j] - lse;
+    if (y) sc[j] += lm_weight * (ys[j] - llse);
+    if (v < V) alive |= 1u << j;
   }
-  int head = 0;
-  for (int r = 0; r < k; ++r) {
-    float hs = NEG_INF;
-    int hi = 0x7fffffff;
+  float hs = NEG_INF;
+  int hi = 0x7fffffff;
 #pragma unroll
-    for (int j = 0; j < MAXK; ++j)
-      if (j == head) { hs = ts[j]; hi = ti[j]; }
+  for (int j = 0; j < BT_NV; ++j)
+    if ((alive >> j & 1u) && bt_better(sc[j], tid + 256 * j, hs, hi)) { hs = sc[j]; hi = tid + 256 * j; }
+  for (int r = 0; r < k; ++r) {
     float bs = hs;
     int bi = hi;
 #pragma unroll
@@ -178,7 +166,13 @@ __global__ __launch_bounds__(256) void beam_topk_reg_kernel(const float* logits,
     for (int w = 1; w < 4; ++w)
       if (bt_better(ws_s[w], ws_i[w], wsc, wi)) { wsc = ws_s[w]; wi = ws_i[w]; }
     if (tid == 0) { out_score[row * k + r] = wsc; out_idx[row * k + r] = wi; }
-    if (hi == wi && hs == wsc && head < k) ++head;   // the owner pops its head
+    if (hi == wi) {                                   // the owner retires the winner and rescans
+      alive &= ~(1u << ((wi - tid) >> 8));
+      hs = NEG_INF; hi = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < BT_NV; ++j)
+        if ((alive >> j & 1u) && bt_better(sc[j], tid + 256 * j, hs, hi)) { hs = sc[j]; hi = tid + 256 * j; }
+    }
   }
 }
 
@@ -203,7 +197,7 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(const float* k_score, c
                                                         int beam, int t, int eos, float* scores_out, uint8_t* flag_out,
                                                         int64_t* preds_out, int32_t* n_finished, const int32_t* pos_in,
                                                         int32_t* pos_out, const int32_t* anc_in, int32_t* anc_out,
-                                                        int ld_anc) {
+                                                        int ld_anc, int32_t* arrive) {
   __shared__ float cs[256];
   __shared__ int ci[256];
   __shared__ float c0[256];
@@ -245,26 +239,40 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(const float* k_score, c
     if (tid == wi) s = NEG_INF;                     // remove the winner (NaN-free: -inf stays -inf)
   }
   __syncthreads();
-  // gather prefixes + append tokens: thread j < beam handles output hypothesis j
-  for (int r = 0; r < beam; ++r) {
-    int w = win[r];
-    int src = b * beam + w / beam;
-    bool fin = flag_in[src] != 0;
-    int64_t tok = fin ? (int64_t)eos : k_idx[(int64_t)src * beam + (w % beam)];   // mask_finished_preds
-    int64_t* dst = preds_out + (int64_t)(b * beam + r) * ldp;
-    const int64_t* sp = preds_in + (int64_t)src * ldp;
-    for (int i = tid; i < t; i += 256) dst[i] = sp[i];
-    if (anc_in) {                                   // re-parent the KV-cache ancestor table (decode.hip)
-      int32_t* ad = anc_out + (int64_t)(b * beam + r) * ld_anc;
-      const int32_t* as = anc_in + (int64_t)src * ld_anc;
-      for (int i = tid; i < t - 1; i += 256) ad[i] = as[i];
-      if (tid == 0) ad[t - 1] = src;
+  // gather prefixes (+ re-parent the KV-cache ancestor table, decode.hip): every (output hypothesis, position) pair at once -- one
+  // level of dependent loads; it was a serial loop over the beam, 10 x [winner -> flag -> token -> copy]: 20.6 us per decode step
+  const int64_t ob = (int64_t)b * beam;
+  for (int e = tid; e < beam * t; e += 256) {
+    const int r = e / t, i = e - r * t;
+    const int64_t src = ob + win[r] / beam;
+    preds_out[(ob + r) * ldp + i] = preds_in[src * ldp + i];
+    if (anc_in && i < t - 1) anc_out[(ob + r) * ld_anc + i] = anc_in[src * ld_anc + i];
+  }
+  if (tid < 64) {                                   // wave 0: lane r < beam appends output hypothesis r's token
+    bool f = false;
+    if (tid < beam) {
+      const int w = win[tid];
+      const int64_t src = ob + w / beam;
+      const bool fin = flag_in[src] != 0;
+      const int64_t tok = fin ? (int64_t)eos : k_idx[src * beam + (w % beam)];   // mask_finished_preds
+      preds_out[(ob + tid) * ldp + t] = tok;
+      if (anc_in) anc_out[(ob + tid) * ld_anc + t - 1] = (int32_t)src;
+      f = tok == eos;
+      flag_out[ob + tid] = f ? 1 : 0;
     }
+    const int cnt = __popcll(__ballot(f));
     if (tid == 0) {
-      dst[t] = tok;
-      bool f = tok == eos;
-      flag_out[b * beam + r] = f ? 1 : 0;
-      if (f) atomicAdd(n_finished, 1);
+      if (!arrive) {
+        if (cnt) atomicAdd(n_finished, cnt);        // n_finished zeroed by the launch before this one
+      } else {
+        // cached loop: no zeroing launch.  *arrive packs (blocks arrived << 16 | finished so far); the last block to arrive publishes
+        // the total and resets the word for the next step (which is a later launch on the same stream / graph branch)
+        const int old = atomicAdd(arrive, (1 << 16) | cnt);
+        if ((old >> 16) == (int)gridDim.x - 1) {
+          *n_finished = (old & 0xffff) + cnt;
+          *arrive = 0;
+        }
+      }
     }
   }
   if (pos_out && b == 0 && tid == 0) *pos_out = t;
@@ -282,7 +290,7 @@ extern "C" int32_t otr_beam_prune(const float* k_score, const int64_t* k_idx, co
   otr_zero_f32(reinterpret_cast<float*>(n_finished), 1, s);   // int32 0 == float 0 bit pattern
   hipLaunchKernelGGL(beam_prune_kernel, dim3(batch), dim3(256), 0, s, k_score, k_idx, scores_in, flag_in, preds_in, ldp,
                      beam, t, eos, scores_out, flag_out, preds_out, n_finished, (const int32_t*)nullptr, (int32_t*)nullptr,
-                     (const int32_t*)nullptr, (int32_t*)nullptr, 0);
+                     (const int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr);
   return otr_check_launch("beam_prune");
 }
 
@@ -299,9 +307,11 @@ extern "C" int32_t otr_beam_prune_cached(const float* k_score, const int64_t* k_
   OTR_REQUIRE(beam >= 1 && beam <= MAXK && beam * beam <= 256, "beam_prune_cached: beam=%d must be in [1, 16]", beam);
   OTR_REQUIRE(batch > 0 && ld_anc > 0 && ld_anc < ldp, "beam_prune_cached: bad shape batch=%d ld_anc=%d ldp=%lld", batch,
               ld_anc, (long long)ldp);
+  OTR_REQUIRE(batch < 32768 && (int64_t)batch * beam < 65536, "beam_prune_cached: batch=%d x beam=%d too large for the packed arrival word",
+              batch, beam);
   hipStream_t s = (hipStream_t)stream;
-  otr_zero_f32(reinterpret_cast<float*>(n_finished), 1, s);
   hipLaunchKernelGGL(beam_prune_kernel, dim3(batch), dim3(256), 0, s, k_score, k_idx, scores_in, flag_in, preds_in, ldp,
-                     beam, 0, eos, scores_out, flag_out, preds_out, n_finished, pos_in, pos_out, anc_in, anc_out, ld_anc);
+                     beam, 0, eos, scores_out, flag_out, preds_out, n_finished, pos_in, pos_out, anc_in, anc_out, ld_anc,
+                     n_finished + 1);
   return otr_check_launch("beam_prune_cached");
 }

@@ -306,7 +306,26 @@ def _workspace(device):
         fault_counter(device)           # registered before the first launch that could report through it (and before any capture)
         _zero_placeholder(device, ())   # likewise allocated outside any capture's private pool (LnOutLink)
         _ffn_sync_pool(device)          # and the split FFN kernels' arrival counters (one row per launch stream)
-    return ws
+    lane = _state.get('ws_lane')
+    return lane if lane is not None and lane.device == device else ws
+
+
+def new_workspace(device):
+    """a second split-K workspace, for launches that run on ANOTHER stream concurrently with the default lane (workspace_lane)"""
+    _workspace(device)
+    return torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
+
+
+@contextlib.contextmanager
+def workspace_lane(ws):
+    """GEMM launches issued inside take `ws` (from new_workspace) as their split-K workspace: the shared one is only safe for
+    launches ordered on one stream (recognize.CachedBeamState runs the LM branch of a beam step on a side stream)."""
+    prev = _state.get('ws_lane')
+    _state['ws_lane'] = ws
+    try:
+        yield
+    finally:
+        _state['ws_lane'] = prev
 
 
 def padded_rows(w, b=None):

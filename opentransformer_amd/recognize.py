@@ -14,6 +14,7 @@ Same constructor arguments and return values as the reference recognizers.  Two 
   (decoder + LM + scoring + pruning).  Hypotheses are identical to the re-forward loop.
 """
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -22,6 +23,8 @@ import torch.nn as nn
 from . import _lib as L
 from . import ops
 from .nn import (BOS, EOS, PAD, LabelSmoothingLoss, PositionalEncoding, TransformerEncoderLayer)
+
+_DECODE_FORK = os.environ.get('OTR_DECODE_FORK', '1') != '0'   # cached beam step: the LM chain on a side stream (CachedBeamState)
 
 
 class TransformerLanguageModel(nn.Module):
@@ -365,7 +368,7 @@ class CachedBeamState:
         self.anc = [new((R, self.maxlen), torch.int32) for _ in range(2)]
         self.k_score = new((R, beam), torch.float32)
         self.k_idx = new((R, beam), torch.long)
-        self.n_fin = new((1,), torch.int32)
+        self.n_fin = new((2,), torch.int32)           # [finished hypotheses, the prune kernel's arrival word]
         self.score0 = torch.tensor([0.0] + [-float('inf')] * (beam - 1), device=dev).repeat([b]).contiguous()
         d = dec.d_model
         self.mem_kv = [new((b, Tm, 2 * d), adt) for _ in dec.blocks]
@@ -380,6 +383,11 @@ class CachedBeamState:
         self.out_lm = _padded_output(lm.output_project.weight, lm.output_project.bias) if lm is not None else None
         self.graphs = [None, None]
         self.warm = [False, False]
+        # The LM's layers and the decoder's are two independent chains of small launches (24-80 workgroups on 256 CUs) that only
+        # meet at the top-k: the LM chain runs on a side stream, forked at the start of the step and joined before the top-k
+        # (in the captured graph: two parallel branches).  Its GEMMs get their own split-K workspace.
+        self.side = torch.cuda.Stream(device=dev) if (lm is not None and _DECODE_FORK and dev.type == 'cuda') else None
+        self.side_ws = ops.new_workspace(dev) if self.side is not None else None
 
     def load_memory(self, memory, memory_mask):
         """Project the encoder memory to cross-attention K|V once per utterance and layer
@@ -487,12 +495,34 @@ class CachedBeamState:
         L.check(lib.otr_dec_ln(C.byref(lnF), R, st), 'otr_dec_ln')
         return ops.attach_lp(y3, y316)
 
+    def _lm_logits(self, cur):
+        """the LM's scores of the next token for every hypothesis, [R, V or V padded to 8] (speech2text.py:108-113)"""
+        lm = self.rec.lm
+        if self.lm_recurrent:
+            return lm.logits_last(self.preds[cur], self.pos[cur], out=self.out_lm)     # one LSTM step from zeros on the last token (base.py:35-36)
+        y = ops.decode_embed(self.preds[cur], self.pos[cur], lm.embedding.weight)
+        for blk, cache in zip(lm.blocks, self.lm_cache):
+            y = self._stack_step(y, blk, cache, cur, getattr(blk, 'concat_linear', None))
+            if ops.lp_of(y) is not None and y.dtype == torch.float32 and self._fused_tail_ok(blk, False):
+                y = self._fused_tail(blk, y, None, None, blk.norm2)
+                continue
+            y = self._ffn(blk, blk.norm2, y)
+        return self.out_lm(y) if self.out_lm is not None else ops.linear(y, lm.output_project.weight, lm.output_project.bias)
+
     def step(self, cur):
         """One beam-search step (recognize/speech2text.py:95-146) reading phase `cur`, writing phase cur^1."""
         rec, lib = self.rec, L.load()
         dec, lm, beam = rec.model.decoder, rec.lm, rec.beam_width
         adt = ops.act_dtype()
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        main = torch.cuda.current_stream()
+        stream = C.c_void_p(main.cuda_stream)
+        lm_logits = None
+        if self.side is not None:
+            self.side.wait_stream(main)                   # fork
+            with torch.cuda.stream(self.side), ops.workspace_lane(self.side_ws):
+                lm_logits = self._lm_logits(cur)
+        elif lm is not None:
+            lm_logits = self._lm_logits(cur)
         x = ops.decode_embed(self.preds[cur], self.pos[cur], dec.embedding.weight)
         for blk, cache, kv in zip(dec.blocks, self.dec_cache, self.mem_kv):
             x = self._stack_step(x, blk, cache, cur, getattr(blk, 'concat_linear1', None))
@@ -511,20 +541,9 @@ class CachedBeamState:
         V = dec.output_layer.weight.shape[0]
         logits = self.out_dec(x) if self.out_dec is not None else ops.linear(x, dec.output_layer.weight, dec.output_layer.bias)
         ld = logits.size(-1)                             # V, or V padded to a multiple of 8 (_PaddedOutput)
-        lm_logits, ld_lm = None, V
-        if self.lm_recurrent:
-            lm_logits = lm.logits_last(self.preds[cur], self.pos[cur], out=self.out_lm)     # one LSTM step from zeros on the last token (base.py:35-36)
-            ld_lm = lm_logits.size(-1)
-        elif lm is not None:
-            y = ops.decode_embed(self.preds[cur], self.pos[cur], lm.embedding.weight)
-            for blk, cache in zip(lm.blocks, self.lm_cache):
-                y = self._stack_step(y, blk, cache, cur, getattr(blk, 'concat_linear', None))
-                if ops.lp_of(y) is not None and y.dtype == torch.float32 and self._fused_tail_ok(blk, False):
-                    y = self._fused_tail(blk, y, None, None, blk.norm2)
-                    continue
-                y = self._ffn(blk, blk.norm2, y)
-            lm_logits = self.out_lm(y) if self.out_lm is not None else ops.linear(y, lm.output_project.weight, lm.output_project.bias)
-            ld_lm = lm_logits.size(-1)
+        if self.side is not None:
+            main.wait_stream(self.side)                   # join: the LM's logits are ready
+        ld_lm = lm_logits.size(-1) if lm_logits is not None else V
         L.check(lib.otr_beam_topk(_ptr(logits), ld, _ptr(lm_logits), ld_lm, float(rec.lm_weight or 0.0), self.R, V, beam,
                                   _ptr(self.k_score), _ptr(self.k_idx), stream), 'otr_beam_topk')
         nxt = cur ^ 1
@@ -556,7 +575,7 @@ class CachedBeamState:
             steps = step
             if self.rec.trace is not None:
                 self.rec.trace.append((self.preds[cur][:, :step + 1].clone(), self.scores[cur].clone()))
-            if int(self.n_fin.item()) == self.R:      # the reference syncs here every step too (speech2text.py:67)
+            if int(self.n_fin[0].item()) == self.R:      # the reference syncs here every step too (speech2text.py:67)
                 break
         return cur, steps
 

@@ -332,14 +332,19 @@ def test_decode_embed_and_prune_cached_kernels():
     o = dict(s=torch.empty_like(sc), f=torch.empty_like(fl), p=torch.zeros_like(pr), n=torch.zeros(1, dtype=torch.int32, device=DEV))
     L.check(lib.otr_beam_prune(p(ks), p(ki), p(sc), p(fl), p(pr), ldp, batch, beam, t, 1, p(o['s']), p(o['f']), p(o['p']),
                                p(o['n']), st), 'prune')
-    c = dict(s=torch.empty_like(sc), f=torch.empty_like(fl), p=torch.zeros_like(pr), n=torch.zeros(1, dtype=torch.int32, device=DEV))
+    c = dict(s=torch.empty_like(sc), f=torch.empty_like(fl), p=torch.zeros_like(pr), n=torch.zeros(2, dtype=torch.int32, device=DEV))
     pin = torch.tensor([t - 1], dtype=torch.int32, device=DEV)
     pout = torch.zeros(1, dtype=torch.int32, device=DEV)
     anc2 = torch.full_like(anc, -1)
     L.check(lib.otr_beam_prune_cached(p(ks), p(ki), p(sc), p(fl), p(pr), ldp, batch, beam, 1, p(pin), p(pout), p(anc), p(anc2),
                                       maxlen, p(c['s']), p(c['f']), p(c['p']), p(c['n']), st), 'prune_cached')
-    for k in o:
-        assert torch.equal(o[k], c[k]), k
+    for rep in range(2):                 # the arrival word resets itself: a second launch on the same buffer counts from zero again
+        for k in o:
+            assert torch.equal(o[k], c[k][:o[k].shape[0]] if k == 'n' else c[k]), k
+        assert int(c['n'][1]) == 0
+        if rep == 0:
+            L.check(lib.otr_beam_prune_cached(p(ks), p(ki), p(sc), p(fl), p(pr), ldp, batch, beam, 1, p(pin), p(pout), p(anc), p(anc2),
+                                              maxlen, p(c['s']), p(c['f']), p(c['p']), p(c['n']), st), 'prune_cached')
     assert int(pout) == t
     # parent of each surviving hypothesis = the row whose prefix it inherited
     for r in range(Rb):
