@@ -655,6 +655,14 @@ int32_t otr_rb_linear_ln(const otr_dec_ln_t* ln, const void* w_pack, const float
 int32_t otr_dec_group_size(int32_t B, int32_t L);
 int32_t otr_dec_self_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t L, const void* wqkv_pack, const float* bqkv, const void* wo_pack,
                          void* qkv16, void* ctx16, float* lse, void* slabs, void* stream);
+/* otr_dec_self_step: the self-attention sub-layer of ONE cached beam-search step (recognize/speech2text.py:95-146 with the KV cache the
+ *      reference leaves as a TODO, README.md:13): R hypothesis rows, one new position *pos each.  Finishes `ln` (the layer below), projects
+ *      q | k | v, appends k, v to kcache / vcache [R, maxlen, 256] at position *pos, attends over positions 0..*pos of the row's ancestors
+ *      (anc int32 [R, maxlen]: anc[r][j] = the row whose cache holds position j of r's prefix; as otr_decode_self_attention), and leaves
+ *      slabs [4][R][256] = per-head shares of ctx . W_o^T for the next launch's prologue.  Replaces otr_dec_ln + otr_linear_fwd +
+ *      otr_decode_self_attention + otr_proj_ln_fwd of the step. */
+int32_t otr_dec_self_step(const otr_dec_ln_t* ln, int64_t R, const void* wqkv_pack, const float* bqkv, const void* wo_pack, void* kcache,
+                          void* vcache, const int32_t* anc, const int32_t* pos, int32_t maxlen, void* slabs, void* stream);
 int32_t otr_dec_cross_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t L, const void* wq_pack, const float* bq, const void* wo_pack,
                           const void* kv, int64_t kv_bs, int64_t kv_ts, int32_t koff, int32_t voff, const uint8_t* key_mask, int32_t Tk,
                           void* q16, void* ctx16, float* lse, void* slabs, void* stream);

@@ -159,6 +159,7 @@ SIGNATURES = {
     'otr_ln_bwd_proj_slabs': [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I32, _F32, C.c_uint64, _P],
     'otr_rb_linear_ln': [C.POINTER(DecLn), _P, _P, _P, _I32, _I64, _I64, _I32, _I32, _P],
     'otr_dec_self_fwd': [C.POINTER(DecLn), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
+    'otr_dec_self_step': [C.POINTER(DecLn), _I64, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P],
     'otr_dec_cross_fwd': [C.POINTER(DecLn), _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P],
     'otr_dec_ffn_hsave_bytes': [_I64, _I32],
     'otr_dec_ffn_fwd': [C.POINTER(DecLn), _I64, _P, _P, _P, _I32, _I32, _P, _P, _P],

@@ -257,6 +257,159 @@ __global__ __launch_bounds__(256, 1) void dec_self_fwd_kernel(DlSelfArgs p) {
   DL_STAMP(0, 5);
 }
 
+// ------------------------------------------------------------------------------------------------ self-attention launch, cached decoding
+// One beam-search step with a KV cache (recognize.py CachedBeamState) sees ONE new position per hypothesis: R = batch x beam rows
+// (80 at C5), every row its own attention problem over the cached positions of its ancestors (decode.hip).  The step spent four
+// launches on the sub-layer -- closing LayerNorm of the layer below, q|k|v GEMM, cached attention, output projection + LayerNorm: 23 us
+// of dependent 5-7 us launches for 0.1 GFLOP.  Here it is one launch cut along (block of 8 rows, head), 512 threads:
+//   LN of the layer below in the prologue (DlPro, as above) -> q | k | v of the head, one 32-column tile per wave (waves 0-5) ->
+//   k, v appended to the caches -> wave w = row w: scores against the ancestors' cached keys (lane = position, eight 16-byte loads in
+//   flight), softmax, context from (position, 16-byte piece) pairs -- the loops of decode_self_attn64_kernel, probabilities and
+//   ancestor rows handed over by shuffles -> the head's share of the output projection, one tile per wave -> slab [head][rows][256].
+// The NEXT launch (dec_cross_fwd for a decoder layer, dec_ffn_fwd for an LM layer) finishes the sub-layer's add + LayerNorm in its
+// prologue, as in training.  The 32-row MFMA tile holds 8 live rows: the MFMA work is noise, the launch is a chain of round trips.
+constexpr int DL_SB = 8;                     // rows per workgroup = waves per workgroup
+struct DlStepArgs {
+  unsigned long long* trace;
+  DlLn ln;
+  const uint4* wqkv; const float* bqkv;      // forward pack of qvk_proj.weight [768, 256], bias [768]
+  const uint4* wo;                           // forward pack of output_proj.weight [256, 256]
+  uint16_t* kc; uint16_t* vc;                // [R, maxlen, 256] write-once caches
+  const int32_t* anc;                        // [R, maxlen]: anc[r][j] = the row whose cache holds position j of hypothesis r's prefix
+  const int32_t* pos;                        // device scalar: the new position p (keys 0..p)
+  int maxlen;
+  uint16_t* slabs;                           // [H][R][256] 16-bit out
+  float scale;
+};
+
+__global__ __launch_bounds__(512, 1) void dec_self_step_kernel(DlStepArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DL_RB * DL_YS + 4 * DL_RB * DL_HS + DL_RB * DL_RS * 4];
+  unsigned char* ys = smem;
+  unsigned char* qs = ys + DL_RB * DL_YS;
+  unsigned char* ks_ = qs + DL_RB * DL_HS;
+  unsigned char* vs = ks_ + DL_RB * DL_HS;
+  unsigned char* cs = vs + DL_RB * DL_HS;
+  float* red = reinterpret_cast<float*>(cs + DL_RB * DL_HS);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, hi = lane >> 5;
+  int rb, h;
+  if (!dl_block_of((int)blockIdx.x, DL_H, (int)((p.ln.R + DL_SB - 1) / DL_SB), rb, h)) return;
+  const int64_t row0 = (int64_t)rb * DL_SB;
+  const int nrows = (int)min((int64_t)DL_SB, p.ln.R - row0);
+  DlPro<8, 8> pro;
+  pro.issue(p.ln, row0, nrows, tid);
+  const int pp = *p.pos;
+  const int part = wid >> 1, half = wid & 1;                           // waves 0-5: (q | k | v, 32-column half of the head)
+  DlStream<1, 16, 16> sq;
+  float4 bq4[4];
+  if (wid < 6) {
+    sq.fill(p.wqkv, 16, part * 8 + 2 * h + half, 1, 0, lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq4[q] = *reinterpret_cast<const float4*>(p.bqkv + part * DL_D + DL_DK * h + 32 * half + 8 * q + 4 * hi);
+  }
+  pro.finish(p.ln, nrows, h == 0, [&](int r, int ch, const uint4& v) { *reinterpret_cast<uint4*>(ys + r * DL_YS + ch * 16) = v; }, tid);
+  __syncthreads();
+  if (wid < 6) {
+    f32x16 acc[1];
+    dl_zero(acc);
+    sq.run(acc, ys, DL_YS, 0, lane);
+    unsigned char* img = part == 0 ? qs : part == 1 ? ks_ : vs;
+    uint16_t* cache = part == 1 ? p.kc : p.vc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 32 * half + 8 * q + 4 * hi;                        // column of the head
+      const float4 b = bq4[q];
+      const uint2 pk = make_uint2(pack2h(acc[0][4 * q] + b.x, acc[0][4 * q + 1] + b.y), pack2h(acc[0][4 * q + 2] + b.z, acc[0][4 * q + 3] + b.w));
+      *reinterpret_cast<uint2*>(img + m * DL_HS + c * 2) = pk;
+      if (part > 0 && m < nrows) *reinterpret_cast<uint2*>(cache + ((row0 + m) * p.maxlen + pp) * DL_D + DL_DK * h + c) = pk;
+    }
+  }
+  DlStream<1, 4, 4> so;
+  so.fill(p.wo, 16, wid, 1, 4 * h, lane);                              // this head's 4 contraction steps, output columns 32 wid ..
+  __syncthreads();
+  if (wid < nrows) {
+    const int64_t r = row0 + wid;
+    const unsigned char* qrow = qs + wid * DL_HS;
+    const unsigned char* krow = ks_ + wid * DL_HS;
+    const unsigned char* vrow = vs + wid * DL_HS;
+    float mrun = -INFINITY, l = 0.f, acc8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc8[e] = 0.f;
+    const int ch = lane & 7, g = lane >> 3;
+    for (int c0 = 0; c0 <= pp; c0 += 64) {
+      const int j = c0 + lane, jc = min(j, pp);                        // lanes past the last position fetch a valid row and are masked
+      int row = (int)r;
+      uint4 kk[8];
+      if (jc != pp) {
+        row = p.anc[r * p.maxlen + jc];
+        const uint16_t* kp = p.kc + ((int64_t)row * p.maxlen + jc) * DL_D + DL_DK * h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kk[i] = ld_global_b128(kp + 8 * i);
+      } else {                                                          // the new position: from LDS, not back through the cache
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kk[i] = *reinterpret_cast<const uint4*>(krow + 16 * i);
+      }
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint4 qv = *reinterpret_cast<const uint4*>(qrow + 16 * i);
+        const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
+        const uint32_t w[4] = {kk[i].x, kk[i].y, kk[i].z, kk[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a += h2f_lo(qw[e]) * h2f_lo(w[e]); a += h2f_hi(qw[e]) * h2f_hi(w[e]); }
+      }
+      const float s = (j <= pp) ? a * p.scale : -INFINITY;
+      const float mn = fmaxf(mrun, wave_max(s));
+      const float pj = (j <= pp) ? expf(s - mn) : 0.f;
+      const float corr = expf(mrun - mn);                              // -inf on the first chunk -> 0
+      l = l * corr + wave_sum(pj);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc8[e] *= corr;
+      mrun = mn;
+      const int n = min(64, pp + 1 - c0);
+      uint4 vv[8];
+      float pw[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int jj = g + 8 * t, jv = min(jj, n - 1), jabs = c0 + jv;
+        const int rw = __shfl(row, jv);
+        const float pv = __shfl(pj, jv);
+        pw[t] = jj < n ? pv : 0.f;
+        if (jabs == pp) vv[t] = *reinterpret_cast<const uint4*>(vrow + 16 * ch);
+        else vv[t] = ld_global_b128(p.vc + ((int64_t)rw * p.maxlen + jabs) * DL_D + DL_DK * h + 8 * ch);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const uint32_t w[4] = {vv[t].x, vv[t].y, vv[t].z, vv[t].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc8[2 * e] += pw[t] * h2f_lo(w[e]); acc8[2 * e + 1] += pw[t] * h2f_hi(w[e]); }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      acc8[e] += __shfl_xor(acc8[e], 8);
+      acc8[e] += __shfl_xor(acc8[e], 16);
+      acc8[e] += __shfl_xor(acc8[e], 32);
+    }
+    if (lane < 8) {
+      const float inv = 1.f / l;
+      *reinterpret_cast<uint4*>(cs + wid * DL_HS + 16 * lane) =
+          make_uint4(pack2h(acc8[0] * inv, acc8[1] * inv), pack2h(acc8[2] * inv, acc8[3] * inv), pack2h(acc8[4] * inv, acc8[5] * inv),
+                     pack2h(acc8[6] * inv, acc8[7] * inv));
+    }
+  } else {                                                              // a dead row of the tile: finite operands for the MFMA below
+    for (int i = lane; i < DL_HS / 4; i += 64) reinterpret_cast<uint32_t*>(cs + wid * DL_HS)[i] = 0u;
+  }
+  __syncthreads();
+  f32x16 acc[1];
+  dl_zero(acc);
+  so.run(acc, cs, DL_HS, 0, lane);
+  dl_put_tile(red, acc[0], wid * 32, lane);
+  __syncthreads();
+  dl_store_slab<8>(p.slabs + (int64_t)h * p.ln.R * DL_D, red, row0, nrows, tid);
+}
+
 // ------------------------------------------------------------------------------------------------ cross-attention launch
 struct DlCrossArgs {
   unsigned long long* trace;
@@ -1468,6 +1621,22 @@ extern "C" int32_t otr_dec_self_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t L
   a.trace = g_otr_trace;
   hipLaunchKernelGGL(dec_self_fwd_kernel, dim3(dl_grid(DL_H, (B + a.g.G - 1) / a.g.G)), dim3(256), 0, (hipStream_t)stream, a);
   return otr_check_launch("dec_self_fwd");
+}
+
+extern "C" int32_t otr_dec_self_step(const otr_dec_ln_t* ln, int64_t R, const void* wqkv_pack, const float* bqkv, const void* wo_pack,
+                                     void* kcache, void* vcache, const int32_t* anc, const int32_t* pos, int32_t maxlen, void* slabs,
+                                     void* stream) {
+  DlStepArgs a{};
+  OTR_REQUIRE(R > 0 && R < (1ll << 31) / 4, "dec_self_step: bad row count");
+  if (int32_t e = dl_check_ln("dec_self_step", ln, R, a.ln)) return e;
+  OTR_REQUIRE(wqkv_pack && bqkv && wo_pack && kcache && vcache && anc && pos && slabs, "dec_self_step: null pointer");
+  OTR_REQUIRE(maxlen > 0, "dec_self_step: bad cache length %d", maxlen);
+  OTR_REQUIRE(((uintptr_t)wqkv_pack | (uintptr_t)bqkv | (uintptr_t)wo_pack | (uintptr_t)kcache | (uintptr_t)vcache | (uintptr_t)slabs) % 16 == 0,
+              "dec_self_step: buffers must be 16-byte aligned");
+  a.wqkv = (const uint4*)wqkv_pack; a.bqkv = bqkv; a.wo = (const uint4*)wo_pack; a.kc = (uint16_t*)kcache; a.vc = (uint16_t*)vcache;
+  a.anc = anc; a.pos = pos; a.maxlen = maxlen; a.slabs = (uint16_t*)slabs; a.scale = 0.125f; a.trace = g_otr_trace;
+  hipLaunchKernelGGL(dec_self_step_kernel, dim3(dl_grid(DL_H, (int)((R + DL_SB - 1) / DL_SB))), dim3(512), 0, (hipStream_t)stream, a);
+  return otr_check_launch("dec_self_step");
 }
 
 extern "C" int32_t otr_dec_cross_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t L, const void* wq_pack, const float* bq, const void* wo_pack,

@@ -24,6 +24,7 @@ from . import _lib as L
 from . import ops
 from .nn import (BOS, EOS, PAD, LabelSmoothingLoss, PositionalEncoding, TransformerEncoderLayer)
 
+_DECODE_STEP_FUSED = os.environ.get('OTR_DECODE_STEP_FUSED', '1') != '0'   # cached beam step on otr_dec_self_step + the fused tail
 _DECODE_FORK = os.environ.get('OTR_DECODE_FORK', '1') != '0'   # cached beam step: the LM chain on a side stream (CachedBeamState)
 
 
@@ -383,6 +384,10 @@ class CachedBeamState:
         self.out_lm = _padded_output(lm.output_project.weight, lm.output_project.bias) if lm is not None else None
         self.graphs = [None, None]
         self.warm = [False, False]
+        self.fused_dec = (not dec.normalize_before and adt == ops.half_dtype() and all(kv.shape[2] == 512 for kv in self.mem_kv)
+                          and self._fused_stack_ok(dec.blocks, True))
+        self.fused_lm = (self.lm_cache is not None and not getattr(lm, 'normalize_before', False) and adt == ops.half_dtype()
+                         and self._fused_stack_ok(lm.blocks, False))
         # The LM's layers and the decoder's are two independent chains of small launches (24-80 workgroups on 256 CUs) that only
         # meet at the top-k: the LM chain runs on a side stream, forked at the start of the step and joined before the top-k
         # (in the captured graph: two parallel branches).  Its GEMMs get their own split-K workspace.
@@ -495,12 +500,74 @@ class CachedBeamState:
         L.check(lib.otr_dec_ln(C.byref(lnF), R, st), 'otr_dec_ln')
         return ops.attach_lp(y3, y316)
 
+    def _fused_stack_ok(self, blocks, with_cross):
+        """can every layer of this stack run the step on the fused launches (otr_dec_self_step + the fused tail)?"""
+        if not _DECODE_STEP_FUSED:
+            return False
+        for blk in blocks:
+            a = blk.slf_attn
+            if (not self._fused_tail_ok(blk, with_cross) or a.nheads != 4 or a.share_qvk_proj or tuple(a.qvk_proj.weight.shape) != (768, 256)
+                    or tuple(a.output_proj.weight.shape) != (256, 256) or a.qvk_proj.bias is None or a.output_proj.bias is None
+                    or ops.lin_packs(a.qvk_proj.weight) is None or ops.lin_packs(a.output_proj.weight) is None):
+                return False
+        return True
+
+    def _fused_stack(self, x, blocks, caches, kvs, cur):
+        """Every layer of a post-norm stack for the new position on the fused launches of csrc/declayer.hip: per layer
+        [LayerNorm of the layer below + q|k|v + cached self-attention + output projection] (otr_dec_self_step), for a decoder layer
+        [LayerNorm + q + cross-attention + output projection] (otr_dec_cross_fwd, kvs given), [LayerNorm + w_1 + GLU + w_2]
+        (otr_dec_ffn_fwd); the LayerNorm that closes the stack is otr_dec_ln.  3 launches per decoder layer, 2 per LM layer (it was 6
+        and 5: decoder/transformer.py:56-86, encoder/transformer.py:41-63)."""
+        lib, R, d = L.load(), self.R, 256
+        dev, hdt, st = x.device, ops.half_dtype(), ops._stream()
+        h16 = lambda *sh: torch.empty(sh, dtype=hdt, device=dev)          # noqa: E731
+        f32 = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)  # noqa: E731
+        beam = self.rec.beam_width
+        yres = x.reshape(R, d)
+        ln = ops._dec_ln(None, ops.lp_of(x).reshape(R, d), None, 0)       # the embedded rows: nothing to finish
+        out = None
+
+        def closes(slabs, nslab, bias, norm):
+            """descriptor of the add + LayerNorm the NEXT launch finishes in its prologue, and its outputs"""
+            y, y16 = f32(R, d), h16(R, d)
+            return ops._dec_ln(yres, None, slabs, nslab, bias, norm.weight, norm.bias, None, 0.0, norm.eps, 0, y, y16), y, y16
+
+        for li, blk in enumerate(blocks):
+            a, ff = blk.slf_attn, blk.feed_forward
+            slA = h16(4, R, d)
+            L.check(lib.otr_dec_self_step(C.byref(ln), R, ops._p(ops.lin_packs(a.qvk_proj.weight)[0]), ops._p(a.qvk_proj.bias),
+                                          ops._p(ops.lin_packs(a.output_proj.weight)[0]), ops._p(caches[li][0]), ops._p(caches[li][1]),
+                                          ops._p(self.anc[cur]), ops._p(self.pos[cur]), self.maxlen, ops._p(slA), st), 'otr_dec_self_step')
+            ln, yres, _ = closes(slA, 4, a.output_proj.bias, blk.norm1)
+            if kvs is not None:
+                ca, kv = blk.src_attn, kvs[li]
+                slB, q16, ctx2, lse2 = h16(4, R, d), h16(R, d), h16(R, d), f32(self.b, 4, beam)
+                W = kv.shape[2]
+                L.check(lib.otr_dec_cross_fwd(C.byref(ln), self.b, beam, ops._p(ops.lin_packs(ca.q_proj.weight)[0]), ops._p(ca.q_proj.bias),
+                                              ops._p(ops.lin_packs(ca.output_proj.weight)[0]), ops._p(kv), self.Tm * W, W, 0, W // 2,
+                                              ops._p(self.mem_mask), self.Tm, ops._p(q16), ops._p(ctx2), ops._p(lse2), ops._p(slB), st),
+                        'otr_dec_cross_fwd')
+                ln, yres, _ = closes(slB, 4, ca.output_proj.bias, blk.norm2)
+            F = ff.w_2.weight.shape[1]
+            S = ops.dec_ffn_slices(F)
+            packs = ops.ffn_packs(ff.w_1.weight, ff.w_2.weight)
+            slC = h16(S, R, d)
+            L.check(lib.otr_dec_ffn_fwd(C.byref(ln), R, ops._p(packs[0]), ops._p(ff.w_1.bias), ops._p(packs[1]), F, S, ops._p(slC), None, st),
+                    'otr_dec_ffn_fwd')
+            ln, yres, y16 = closes(slC, S, ff.w_2.bias, blk.norm3 if kvs is not None else blk.norm2)
+            out = (yres, y16)
+        L.check(lib.otr_dec_ln(C.byref(ln), R, st), 'otr_dec_ln')
+        return ops.attach_lp(*out)
+
     def _lm_logits(self, cur):
         """the LM's scores of the next token for every hypothesis, [R, V or V padded to 8] (speech2text.py:108-113)"""
         lm = self.rec.lm
         if self.lm_recurrent:
             return lm.logits_last(self.preds[cur], self.pos[cur], out=self.out_lm)     # one LSTM step from zeros on the last token (base.py:35-36)
         y = ops.decode_embed(self.preds[cur], self.pos[cur], lm.embedding.weight)
+        if self.fused_lm and ops.lp_of(y) is not None:
+            y = self._fused_stack(y, lm.blocks, self.lm_cache, None, cur)
+            return self.out_lm(y) if self.out_lm is not None else ops.linear(y, lm.output_project.weight, lm.output_project.bias)
         for blk, cache in zip(lm.blocks, self.lm_cache):
             y = self._stack_step(y, blk, cache, cur, getattr(blk, 'concat_linear', None))
             if ops.lp_of(y) is not None and y.dtype == torch.float32 and self._fused_tail_ok(blk, False):
@@ -524,7 +591,10 @@ class CachedBeamState:
         elif lm is not None:
             lm_logits = self._lm_logits(cur)
         x = ops.decode_embed(self.preds[cur], self.pos[cur], dec.embedding.weight)
-        for blk, cache, kv in zip(dec.blocks, self.dec_cache, self.mem_kv):
+        fused_dec = self.fused_dec and ops.lp_of(x) is not None
+        if fused_dec:
+            x = self._fused_stack(x, dec.blocks, self.dec_cache, self.mem_kv, cur)
+        for blk, cache, kv in (() if fused_dec else zip(dec.blocks, self.dec_cache, self.mem_kv)):
             x = self._stack_step(x, blk, cache, cur, getattr(blk, 'concat_linear1', None))
             a = blk.src_attn
             if ops.lp_of(x) is not None and x.dtype == torch.float32 and self._fused_tail_ok(blk, True) and kv.shape[2] == 512:

@@ -368,3 +368,106 @@ def test_cached_self_attention_vector_form_matches_plain_torch_and_the_serial_ke
         assert rel(o1.float(), o0.float()) < tol
     finally:
         ops.set_compute_dtype('bf16')
+
+
+# ----------------------------------------------------------------------------------- cached decode step: fused self-attention launch
+@pytest.mark.parametrize('mode', ['fp16', 'bf16'])
+@pytest.mark.parametrize('R,pos,nslab', [(13, 0, 0), (13, 5, 8), (80, 37, 8), (21, 70, 4), (8, 63, 0)])
+def test_dec_self_step_against_torch(mode, R, pos, nslab):
+    """otr_dec_self_step (csrc/declayer.hip) = LayerNorm of the layer below + q|k|v + attention over the ancestors' cached positions
+    + the heads' shares of the output projection, checked against the same arithmetic in torch fp32 on the 16-bit rounded operands
+    (module/attention.py:60-84 for one new position; the cache addressing of otr_decode_self_attention).  Ragged last block
+    (R % 8 != 0), first step (pos 0), more than one 64-position chunk (pos 70), chunk boundary (pos 63)."""
+    import ctypes as C
+    from opentransformer_amd import _lib as L, ops
+    ops.set_compute_dtype(mode)
+    try:
+        lib, hdt, d, H = L.load(), ops.half_dtype(), 256, 4
+        maxlen = pos + 3
+        gen = torch.Generator().manual_seed(100 * R + pos)
+        rnd = lambda *sh, s=1.0: (torch.randn(*sh, generator=gen) * s).to(DEV)      # noqa: E731
+        wqkv, bqkv, wo = torch.nn.Parameter(rnd(768, d, s=0.06)), rnd(768, s=0.1), torch.nn.Parameter(rnd(d, d, s=0.06))
+        kc, vc = rnd(R, maxlen, d, s=0.7).to(hdt), rnd(R, maxlen, d, s=0.7).to(hdt)
+        kc0, vc0 = kc.clone(), vc.clone()
+        anc = torch.randint(0, R, (R, maxlen), generator=gen).to(DEV, torch.int32)
+        post = torch.tensor([pos], dtype=torch.int32, device=DEV)
+        xres = rnd(R, d)
+        y, y16 = torch.zeros(R, d, device=DEV), torch.zeros(R, d, dtype=hdt, device=DEV)
+        if nslab:
+            sl_in = rnd(nslab, R, d, s=0.3).to(hdt)
+            bias, gamma, beta = rnd(d, s=0.1), 1 + rnd(d, s=0.1), rnd(d, s=0.1)
+            ln = ops._dec_ln(xres, None, sl_in, nslab, bias, gamma, beta, None, 0.0, 1e-5, 0, y, y16)
+            want_y = torch.nn.functional.layer_norm(xres + sl_in.float().sum(0) + bias, (d,), gamma, beta, 1e-5)
+            xin = want_y.to(hdt).float()
+        else:
+            x16 = xres.to(hdt)
+            ln = ops._dec_ln(None, x16, None, 0)
+            xin = x16.float()
+        slabs = torch.full((H, R, d), float('nan'), dtype=hdt, device=DEV)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        pq, po = ops.lin_packs(wqkv)[0], ops.lin_packs(wo)[0]
+        L.check(lib.otr_dec_self_step(C.byref(ln), R, ops._p(pq), ops._p(bqkv), ops._p(po), ops._p(kc), ops._p(vc), ops._p(anc), ops._p(post),
+                                      maxlen, ops._p(slabs), st), 'otr_dec_self_step')
+        torch.cuda.synchronize()
+        tol = dict(rtol=2e-2, atol=2e-2) if mode == 'bf16' else dict(rtol=3e-3, atol=3e-3)
+        if nslab:
+            torch.testing.assert_close(y, want_y, rtol=1e-4, atol=1e-4)
+            torch.testing.assert_close(y16.float(), want_y, **tol)
+        w16 = wqkv.detach().to(hdt).float()
+        qkv = (xin @ w16.T + bqkv).to(hdt).float()
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        # the caches: position `pos` of every row appended, everything else untouched
+        torch.testing.assert_close(kc[:, pos].float(), k, **tol)
+        torch.testing.assert_close(vc[:, pos].float(), v, **tol)
+        keep = torch.ones(maxlen, dtype=torch.bool, device=DEV)
+        keep[pos] = False
+        assert torch.equal(kc[:, keep], kc0[:, keep]) and torch.equal(vc[:, keep], vc0[:, keep])
+        rows = anc[:, :pos].long()                                          # [R, pos]
+        jj = torch.arange(pos, device=DEV)
+        K = torch.cat((kc0[rows, jj].float(), k[:, None]), 1).view(R, pos + 1, H, 64)
+        V = torch.cat((vc0[rows, jj].float(), v[:, None]), 1).view(R, pos + 1, H, 64)
+        s = torch.einsum('rhd,rjhd->rhj', q.view(R, H, 64), K) * 0.125
+        ctx = torch.einsum('rhj,rjhd->rhd', torch.softmax(s, -1), V).to(hdt).float()        # [R, H, 64]
+        wo16 = wo.detach().to(hdt).float()
+        for h in range(H):
+            want = ctx[:, h] @ wo16[:, 64 * h:64 * (h + 1)].T
+            torch.testing.assert_close(slabs[h].float(), want, **tol)
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp16', 'bf16'])
+def test_cached_search_fused_step_matches_unfused_step(mode):
+    """the cached beam search at the C5 shapes on otr_dec_self_step + the fused tail vs the same search on the per-operator launches
+    (qkv GEMM, otr_decode_self_attention, output projection + LayerNorm): same hypotheses wherever the margin is clear, close scores"""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops, recognize, synthetic as syn
+    ops.set_compute_dtype(mode)
+    try:
+        model = ota.SpeechToText(syn.c2_model(0.0, n_enc=2))
+        syn.fill_state_dict_(model.state_dict(), 7)
+        lm = recognize.TransformerLanguageModel(syn.lm_config(4234, num_blocks=2))
+        syn.fill_state_dict_(lm.state_dict(), 8)
+        with torch.no_grad():
+            model.decoder.output_layer.bias[1] = -30.0          # EOS never wins: every hypothesis runs max_len steps
+        model, lm = model.to(DEV).eval(), lm.to(DEV).eval()
+        inputs, _ = syn.synthetic_batch(batch=3, frames=400, feat_dim=80, vocab=4234, tgt_len=5, seed=3, lengths=[400, 333, 250])
+        x, m = inputs['inputs'].to(DEV), inputs['mask'].to(DEV)
+        kw = dict(beam_width=10, nbest=10, max_len=20, penalty=0.6, lamda=5, lm=lm, lm_weight=0.1, idx2unit={i: str(i) for i in range(4234)})
+        res = {}
+        for fused in (True, False):
+            recognize._DECODE_STEP_FUSED = fused
+            rec = recognize.SpeechToTextRecognizer(model, apply_cache=True, **kw)
+            res[fused] = rec.recognize(x, m)
+            stt = next(iter(rec._cached_states.values()))
+            assert stt.fused_dec == fused and stt.fused_lm == fused
+        (h1, s1), (h0, s0) = res[True], res[False]
+        s1, s0 = s1.numpy(), s0.numpy()
+        tol = 0.15 if mode == 'bf16' else 0.03
+        assert abs(s1[:, 0] - s0[:, 0]).max() < tol, (s1[:, 0], s0[:, 0])
+        for i in range(len(h0)):
+            if s0[i, 0] - s0[i, 1] > 2 * tol:
+                assert h1[i][0] == h0[i][0], i
+    finally:
+        recognize._DECODE_STEP_FUSED = True
+        ops.set_compute_dtype('bf16')
