@@ -262,10 +262,10 @@ __global__ __launch_bounds__(256, 1) void dec_self_fwd_kernel(DlSelfArgs p) {
 // (80 at C5), every row its own attention problem over the cached positions of its ancestors (decode.hip).  The step spent four
 // launches on the sub-layer -- closing LayerNorm of the layer below, q|k|v GEMM, cached attention, output projection + LayerNorm: 23 us
 // of dependent 5-7 us launches for 0.1 GFLOP.  Here it is one launch cut along (block of 8 rows, head), 512 threads:
-//   LN of the layer below in the prologue (DlPro, as above) -> q | k | v of the head, one 32-column tile per wave (waves 0-5) ->
-//   k, v appended to the caches -> wave w = row w: scores against the ancestors' cached keys (lane = position, eight 16-byte loads in
-//   flight), softmax, context from (position, 16-byte piece) pairs -- the loops of decode_self_attn64_kernel, probabilities and
-//   ancestor rows handed over by shuffles -> the head's share of the output projection, one tile per wave -> slab [head][rows][256].
+//   LN of the layer below in the prologue (wave w = row w) -> q | k | v of the head, one 32-column tile per wave (waves 0-5) ->
+//   k, v appended to the caches -> wave w = row w: scores against the ancestors' cached keys, softmax, context, all on (position,
+//   16-byte piece) pairs whose loads were issued before the projection -> the head's share of the output projection, one tile per
+//   wave -> slab [head][rows][256].
 // The NEXT launch (dec_cross_fwd for a decoder layer, dec_ffn_fwd for an LM layer) finishes the sub-layer's add + LayerNorm in its
 // prologue, as in training.  The 32-row MFMA tile holds 8 live rows: the MFMA work is noise, the launch is a chain of round trips.
 constexpr int DL_SB = 8;                     // rows per workgroup = waves per workgroup
@@ -280,6 +280,50 @@ struct DlStepArgs {
   int maxlen;
   uint16_t* slabs;                           // [H][R][256] 16-bit out
   float scale;
+};
+
+// The LayerNorm prologue for ONE row per wave (lane = 4 columns, 8-byte loads): DlPro finishes 32-row tiles, 3/4 of them copies of
+// the last live row when a block has 8.  Up to 16 slabs in flight (the FFN launch of a decode step cuts the hidden units 16 ways).
+// No dropout (decoding).
+struct DlProRow {
+  static constexpr int NS = 16;
+  float4 x, bb, gm, bt;
+  uint2 t[NS];
+  uint2 px;
+  __device__ __forceinline__ void issue(const DlLn& p, int64_t row, int lane) {
+    const int col = lane * 4;
+    if (p.nslab == 0) { px = *reinterpret_cast<const uint2*>(p.x16 + row * DL_D + col); return; }
+    bb = p.bias ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    gm = *reinterpret_cast<const float4*>(p.gamma + col);
+    bt = *reinterpret_cast<const float4*>(p.beta + col);
+    x = *reinterpret_cast<const float4*>(p.xres + row * DL_D + col);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      if (s < p.nslab) t[s] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.slabs) + ((int64_t)s * p.R + row) * DL_D + col);
+  }
+  // leaves the row's 16-bit image at img (512 bytes); write: also y / y16 of the row
+  __device__ __forceinline__ void finish(const DlLn& p, int64_t row, bool write, unsigned char* img, int lane) {
+    const int col = lane * 4;
+    if (p.nslab == 0) { *reinterpret_cast<uint2*>(img + col * 2) = px; return; }
+    float v[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      if (s < p.nslab) { v[0] += h2f_lo(t[s].x); v[1] += h2f_hi(t[s].x); v[2] += h2f_lo(t[s].y); v[3] += h2f_hi(t[s].y); }
+    v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+    const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / DL_D);
+    float qq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; qq += d * d; }
+    const float rstd = rsqrtf(wave_sum(qq) * (1.f / DL_D) + p.eps);
+    const float o0 = (v[0] - mean) * rstd * gm.x + bt.x, o1 = (v[1] - mean) * rstd * gm.y + bt.y;
+    const float o2 = (v[2] - mean) * rstd * gm.z + bt.z, o3 = (v[3] - mean) * rstd * gm.w + bt.w;
+    const uint2 h = make_uint2(pack2h(o0, o1), pack2h(o2, o3));
+    *reinterpret_cast<uint2*>(img + col * 2) = h;
+    if (write) {
+      if (p.y) *reinterpret_cast<float4*>(p.y + row * DL_D + col) = make_float4(o0, o1, o2, o3);
+      if (p.y16) *reinterpret_cast<uint2*>(p.y16 + row * DL_D + col) = h;
+    }
+  }
 };
 
 __global__ __launch_bounds__(512, 1) void dec_self_step_kernel(DlStepArgs p) {
@@ -297,8 +341,17 @@ __global__ __launch_bounds__(512, 1) void dec_self_step_kernel(DlStepArgs p) {
   if (!dl_block_of((int)blockIdx.x, DL_H, (int)((p.ln.R + DL_SB - 1) / DL_SB), rb, h)) return;
   const int64_t row0 = (int64_t)rb * DL_SB;
   const int nrows = (int)min((int64_t)DL_SB, p.ln.R - row0);
-  DlPro<8, 8> pro;
-  pro.issue(p.ln, row0, nrows, tid);
+  const bool live = wid < nrows;                                       // wave w = row w of the block, here and in the attention below
+  const int64_t r = row0 + min(wid, nrows - 1);
+  // Attention works on (position, 16-byte piece) pairs: lane (g, ch) = (lane >> 3, lane & 7) holds piece ch of positions g + 8t,
+  // t < 8, of a 64-position chunk -- a wave instruction touches 8 cache lines (a lane per position touched 64, and the launch
+  // grew from 7 to 17 us over 60 positions).  The ancestors of chunk 0 are the first loads of the launch.
+  const int g = lane >> 3, ch = lane & 7;
+  int rowt[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) rowt[t] = p.anc[r * p.maxlen + min(g + 8 * t, p.maxlen - 1)];
+  DlProRow pro;
+  pro.issue(p.ln, r, lane);
   const int pp = *p.pos;
   const int part = wid >> 1, half = wid & 1;                           // waves 0-5: (q | k | v, 32-column half of the head)
   DlStream<1, 16, 16> sq;
@@ -308,7 +361,21 @@ __global__ __launch_bounds__(512, 1) void dec_self_step_kernel(DlStepArgs p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) bq4[q] = *reinterpret_cast<const float4*>(p.bqkv + part * DL_D + DL_DK * h + 32 * half + 8 * q + 4 * hi);
   }
-  pro.finish(p.ln, nrows, h == 0, [&](int r, int ch, const uint4& v) { *reinterpret_cast<uint4*>(ys + r * DL_YS + ch * 16) = v; }, tid);
+  pro.finish(p.ln, r, h == 0 && live, ys + wid * DL_YS, lane);
+  uint4 kk[8], vv[8];
+  auto fetch = [&](int c0) {                                           // cached keys / values of a chunk: every load in flight at once
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int j = c0 + g + 8 * t;
+      kk[t] = vv[t] = make_uint4(0u, 0u, 0u, 0u);
+      if (live && j < pp) {
+        const int64_t o = ((int64_t)rowt[t] * p.maxlen + j) * DL_D + DL_DK * h + 8 * ch;
+        kk[t] = ld_global_b128(p.kc + o);
+        vv[t] = ld_global_b128(p.vc + o);
+      }
+    }
+  };
+  fetch(0);                                                            // travels under the q | k | v projection
   __syncthreads();
   if (wid < 6) {
     f32x16 acc[1];
@@ -328,63 +395,62 @@ __global__ __launch_bounds__(512, 1) void dec_self_step_kernel(DlStepArgs p) {
   DlStream<1, 4, 4> so;
   so.fill(p.wo, 16, wid, 1, 4 * h, lane);                              // this head's 4 contraction steps, output columns 32 wid ..
   __syncthreads();
-  if (wid < nrows) {
-    const int64_t r = row0 + wid;
-    const unsigned char* qrow = qs + wid * DL_HS;
-    const unsigned char* krow = ks_ + wid * DL_HS;
-    const unsigned char* vrow = vs + wid * DL_HS;
+  if (live) {
+    const uint4 qv = *reinterpret_cast<const uint4*>(qs + wid * DL_HS + 16 * ch);
+    const uint4 knew = *reinterpret_cast<const uint4*>(ks_ + wid * DL_HS + 16 * ch);   // the new position: from LDS, not back through the cache
+    const uint4 vnew = *reinterpret_cast<const uint4*>(vs + wid * DL_HS + 16 * ch);
+    const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
     float mrun = -INFINITY, l = 0.f, acc8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc8[e] = 0.f;
-    const int ch = lane & 7, g = lane >> 3;
-    for (int c0 = 0; c0 <= pp; c0 += 64) {
-      const int j = c0 + lane, jc = min(j, pp);                        // lanes past the last position fetch a valid row and are masked
-      int row = (int)r;
-      uint4 kk[8];
-      if (jc != pp) {
-        row = p.anc[r * p.maxlen + jc];
-        const uint16_t* kp = p.kc + ((int64_t)row * p.maxlen + jc) * DL_D + DL_DK * h;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) kk[i] = ld_global_b128(kp + 8 * i);
-      } else {                                                          // the new position: from LDS, not back through the cache
-#pragma unroll
-        for (int i = 0; i < 8; ++i) kk[i] = *reinterpret_cast<const uint4*>(krow + 16 * i);
-      }
-      float a = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const uint4 qv = *reinterpret_cast<const uint4*>(qrow + 16 * i);
-        const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
-        const uint32_t w[4] = {kk[i].x, kk[i].y, kk[i].z, kk[i].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { a += h2f_lo(qw[e]) * h2f_lo(w[e]); a += h2f_hi(qw[e]) * h2f_hi(w[e]); }
-      }
-      const float s = (j <= pp) ? a * p.scale : -INFINITY;
-      const float mn = fmaxf(mrun, wave_max(s));
-      const float pj = (j <= pp) ? expf(s - mn) : 0.f;
-      const float corr = expf(mrun - mn);                              // -inf on the first chunk -> 0
-      l = l * corr + wave_sum(pj);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc8[e] *= corr;
-      mrun = mn;
-      const int n = min(64, pp + 1 - c0);
-      uint4 vv[8];
-      float pw[8];
+    for (int c0 = 0;;) {
+      float sc[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        const int jj = g + 8 * t, jv = min(jj, n - 1), jabs = c0 + jv;
-        const int rw = __shfl(row, jv);
-        const float pv = __shfl(pj, jv);
-        pw[t] = jj < n ? pv : 0.f;
-        if (jabs == pp) vv[t] = *reinterpret_cast<const uint4*>(vrow + 16 * ch);
-        else vv[t] = ld_global_b128(p.vc + ((int64_t)rw * p.maxlen + jabs) * DL_D + DL_DK * h + 8 * ch);
+        if (c0 + g + 8 * t == pp) { kk[t] = knew; vv[t] = vnew; }
+        const uint32_t w[4] = {kk[t].x, kk[t].y, kk[t].z, kk[t].w};
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a += h2f_lo(qw[e]) * h2f_lo(w[e]); a += h2f_hi(qw[e]) * h2f_hi(w[e]); }
+        sc[t] = a;
       }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) sc[t] += __shfl_xor(sc[t], o);     // the 8 pieces of a position
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        sc[t] = (c0 + g + 8 * t <= pp) ? sc[t] * p.scale : -INFINITY;
+        mx = fmaxf(mx, sc[t]);
+      }
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      const float mn = fmaxf(mrun, mx);
+      const float corr = expf(mrun - mn);                              // -inf on the first chunk -> 0
+      float ls = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        sc[t] = (c0 + g + 8 * t <= pp) ? expf(sc[t] - mn) : 0.f;
+        ls += sc[t];
+      }
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) ls += __shfl_xor(ls, o);
+      l = l * corr + ls;
+      mrun = mn;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc8[e] *= corr;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const uint32_t w[4] = {vv[t].x, vv[t].y, vv[t].z, vv[t].w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { acc8[2 * e] += pw[t] * h2f_lo(w[e]); acc8[2 * e + 1] += pw[t] * h2f_hi(w[e]); }
+        for (int e = 0; e < 4; ++e) { acc8[2 * e] += sc[t] * h2f_lo(w[e]); acc8[2 * e + 1] += sc[t] * h2f_hi(w[e]); }
       }
+      c0 += 64;
+      if (c0 > pp) break;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) rowt[t] = p.anc[r * p.maxlen + min(c0 + g + 8 * t, p.maxlen - 1)];
+      fetch(c0);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -398,8 +464,6 @@ __global__ __launch_bounds__(512, 1) void dec_self_step_kernel(DlStepArgs p) {
           make_uint4(pack2h(acc8[0] * inv, acc8[1] * inv), pack2h(acc8[2] * inv, acc8[3] * inv), pack2h(acc8[4] * inv, acc8[5] * inv),
                      pack2h(acc8[6] * inv, acc8[7] * inv));
     }
-  } else {                                                              // a dead row of the tile: finite operands for the MFMA below
-    for (int i = lane; i < DL_HS / 4; i += 64) reinterpret_cast<uint32_t*>(cs + wid * DL_HS)[i] = 0u;
   }
   __syncthreads();
   f32x16 acc[1];
@@ -1631,6 +1695,8 @@ extern "C" int32_t otr_dec_self_step(const otr_dec_ln_t* ln, int64_t R, const vo
   if (int32_t e = dl_check_ln("dec_self_step", ln, R, a.ln)) return e;
   OTR_REQUIRE(wqkv_pack && bqkv && wo_pack && kcache && vcache && anc && pos && slabs, "dec_self_step: null pointer");
   OTR_REQUIRE(maxlen > 0, "dec_self_step: bad cache length %d", maxlen);
+  OTR_REQUIRE(ln->nslab <= 16 && (ln->nslab == 0 || ln->p_drop == 0.f), "dec_self_step: at most 16 slabs, no dropout (nslab=%d p_drop=%g)",
+              ln->nslab, (double)ln->p_drop);
   OTR_REQUIRE(((uintptr_t)wqkv_pack | (uintptr_t)bqkv | (uintptr_t)wo_pack | (uintptr_t)kcache | (uintptr_t)vcache | (uintptr_t)slabs) % 16 == 0,
               "dec_self_step: buffers must be 16-byte aligned");
   a.wqkv = (const uint4*)wqkv_pack; a.bqkv = bqkv; a.wo = (const uint4*)wo_pack; a.kc = (uint16_t*)kcache; a.vc = (uint16_t*)vcache;

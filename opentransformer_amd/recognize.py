@@ -25,6 +25,7 @@ from . import ops
 from .nn import (BOS, EOS, PAD, LabelSmoothingLoss, PositionalEncoding, TransformerEncoderLayer)
 
 _DECODE_STEP_FUSED = os.environ.get('OTR_DECODE_STEP_FUSED', '1') != '0'   # cached beam step on otr_dec_self_step + the fused tail
+_DECODE_FFN16 = os.environ.get('OTR_DECODE_FFN16', '1') != '0'
 _DECODE_FORK = os.environ.get('OTR_DECODE_FORK', '1') != '0'   # cached beam step: the LM chain on a side stream (CachedBeamState)
 
 
@@ -549,7 +550,9 @@ class CachedBeamState:
                         'otr_dec_cross_fwd')
                 ln, yres, _ = closes(slB, 4, ca.output_proj.bias, blk.norm2)
             F = ff.w_2.weight.shape[1]
-            S = ops.dec_ffn_slices(F)
+            # a few row blocks only: cut the hidden units 16 ways (a workgroup streams its slice of w_1 / w_2 at what ONE CU ingests,
+            # 24 workgroups of 393 KB at S = 8); otr_dec_self_step and otr_dec_ln take up to 16 slabs
+            S = 16 if (_DECODE_FFN16 and F % 2048 == 0 and R <= 128) else ops.dec_ffn_slices(F)
             packs = ops.ffn_packs(ff.w_1.weight, ff.w_2.weight)
             slC = h16(S, R, d)
             L.check(lib.otr_dec_ffn_fwd(C.byref(ln), R, ops._p(packs[0]), ops._p(ff.w_1.bias), ops._p(packs[1]), F, S, ops._p(slC), None, st),

@@ -372,7 +372,7 @@ def test_cached_self_attention_vector_form_matches_plain_torch_and_the_serial_ke
 
 # ----------------------------------------------------------------------------------- cached decode step: fused self-attention launch
 @pytest.mark.parametrize('mode', ['fp16', 'bf16'])
-@pytest.mark.parametrize('R,pos,nslab', [(13, 0, 0), (13, 5, 8), (80, 37, 8), (21, 70, 4), (8, 63, 0)])
+@pytest.mark.parametrize('R,pos,nslab', [(13, 0, 0), (13, 5, 8), (80, 37, 16), (21, 70, 4), (8, 63, 0), (30, 64, 16)])
 def test_dec_self_step_against_torch(mode, R, pos, nslab):
     """otr_dec_self_step (csrc/declayer.hip) = LayerNorm of the layer below + q|k|v + attention over the ancestors' cached positions
     + the heads' shares of the output projection, checked against the same arithmetic in torch fp32 on the 16-bit rounded operands
