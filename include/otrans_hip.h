@@ -87,6 +87,13 @@ typedef struct {
 int32_t otr_linear_fwd(const otr_linear_desc_t* d, const void* x, const void* w, const float* bias, void* y,
                        void* workspace, int64_t workspace_bytes, void* stream);
 /* dx[M,K] (dtype x_dtype, ld ldx) = dy[M,N] (dtype y_dtype, ld ldy) * w[N,K] */
+/* otr_linear_fwd_batched: nbatch products of ONE shape in one launch, y_b = x_b w_b^T with x_b = x + b*bsx, w_b = w + b*bsw,
+ * y_b = y + b*bsy (ELEMENT strides): the per-head products of module/attention.py:217-253 (MultiHeadedSelfAttentionWithRelPos:
+ * (q+v) p^T per head, and its input gradient).  No bias, activation, accumulation or split-K.  Returns 1 WITHOUT launching when
+ * the operands do not qualify (fp32 compute, unaligned rows / strides, operand types other than 16-bit x 16-bit -> f32 and
+ * f32 x 16-bit -> 16-bit): the caller then loops over otr_linear_fwd. */
+int32_t otr_linear_fwd_batched(const otr_linear_desc_t* d, const void* x, const void* w, void* y, int32_t nbatch, int64_t bsx, int64_t bsw,
+                               int64_t bsy, void* stream);
 int32_t otr_linear_dgrad(const otr_linear_desc_t* d, const void* dy, const void* w, void* dx, void* workspace,
                          int64_t workspace_bytes, void* stream);
 /* dw[N,K] (dtype w_dtype, ld ldw) = dy[M,N]^T * x[M,K] */

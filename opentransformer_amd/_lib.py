@@ -81,6 +81,7 @@ SIGNATURES = {
     'otr_set_fault_counter': [_P],
     'otr_last_error_string': [],
     'otr_linear_fwd': [C.POINTER(LinearDesc), _P, _P, _P, _P, _P, _I64, _P],
+    'otr_linear_fwd_batched': [C.POINTER(LinearDesc), _P, _P, _P, _I32, _I64, _I64, _I64, _P],
     'otr_linear_dgrad': [C.POINTER(LinearDesc), _P, _P, _P, _P, _I64, _P],
     'otr_linear_wgrad': [C.POINTER(LinearDesc), _P, _P, _P, _P, _I64, _P],
     'otr_ffn_glu_fwd': [_P, _I64, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _P],

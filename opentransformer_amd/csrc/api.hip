@@ -144,6 +144,26 @@ extern "C" int32_t otr_linear_fwd(const otr_linear_desc_t* d, const void* x, con
   return run_gemm(a, d->compute, d->x_dtype, d->w_dtype, d->y_dtype, MODE_KC, MODE_KC, stream);
 }
 
+extern "C" int32_t otr_linear_fwd_batched(const otr_linear_desc_t* d, const void* x, const void* w, void* y, int32_t nbatch, int64_t bsx,
+                                          int64_t bsw, int64_t bsy, void* stream) {
+  if (int32_t e = check_linear(d)) return e;
+  OTR_REQUIRE(x && w && y, "linear_fwd_batched: null pointer");
+  OTR_REQUIRE(nbatch >= 1 && nbatch <= 65535 && bsx >= 0 && bsw >= 0 && bsy > 0, "linear_fwd_batched: bad batch (n=%d)", nbatch);
+  OTR_REQUIRE(d->act == OTR_ACT_NONE && !d->accumulate, "linear_fwd_batched: plain products only");
+  if (nbatch == 1) return 1;
+  GemmArgs a{};
+  a.A = x; a.B = w; a.C = y; a.bias = nullptr;
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.lda = d->ldx; a.ldb = d->ldw; a.ldc = d->ldy;
+  a.act = OTR_ACT_NONE; a.accumulate = 0;
+  a.a_vec = kc_vec(x, d->ldx, d->x_dtype);
+  a.b_vec = kc_vec(w, d->ldw, d->w_dtype);
+  a.allow_split = 0; a.ws = nullptr; a.ws_bytes = 0; a.trace = nullptr;
+  a.nbatch = nbatch; a.bsa = bsx * esize(d->x_dtype); a.bsb = bsw * esize(d->w_dtype); a.bsc = bsy * esize(d->y_dtype);
+  if (d->compute != OTR_H16) return 1;                                 // 16-bit compute only; 1 = not served
+  return run_gemm(a, d->compute, d->x_dtype, d->w_dtype, d->y_dtype, MODE_KC, MODE_KC, stream);
+}
+
 extern "C" int32_t otr_linear_dgrad(const otr_linear_desc_t* d, const void* dy, const void* w, void* dx,
                                     void* workspace, int64_t workspace_bytes, void* stream) {
   if (int32_t e = check_linear(d)) return e;

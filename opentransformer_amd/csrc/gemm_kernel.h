@@ -60,6 +60,9 @@ struct GemmArgs {
   int aux_flag;               // GLU_BWD: 1 = the second half of aux_in already holds sigmoid(gate)
   unsigned long long* trace;  // tuning hook (otr_debug_trace): per-workgroup phase timestamps, or NULL
   ConvGeom cg;
+  // batched launch (otr_linear_fwd_batched): problem z = blockIdx.z uses A + z bsa, B + z bsb, C + z bsc (BYTE strides); no split-K
+  int nbatch;
+  int64_t bsa, bsb, bsc;
 };
 
 template <class CT> struct GemmCfg {
@@ -1002,6 +1005,18 @@ static __global__ void splitk_reduce_kernel(const float* ws, int ks, int M, int 
   }
 }
 
+// nbatch problems of one shape side by side (the per-head GEMMs of the relative-position attention, module/attention.py:217-253:
+// four launches of 11-16 us each were four dependent launch boundaries for one head's worth of work each)
+template <class CT, class AT, class BT, class OT, int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_batched_kernel(GemmArgs p) {
+  GemmArgs q = p;
+  const int64_t z = blockIdx.z;
+  q.A = reinterpret_cast<const char*>(p.A) + z * p.bsa;
+  q.B = reinterpret_cast<const char*>(p.B) + z * p.bsb;
+  q.C = reinterpret_cast<char*>(p.C) + z * p.bsc;
+  gemm_body<CT, AT, BT, OT, MODE_KC, MODE_KC, BM, BN, true, false, 0>(q, (int)blockIdx.x, (int)gridDim.x, 0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Tile / split-K selection.  Goal: >= ~512 workgroups (2 per CU) whenever the problem allows it; split-K
 // only when the output grid alone cannot fill the chip and a workspace was provided.
@@ -1020,6 +1035,25 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
   const bool can_split = a.allow_split && max_by_ws >= 2;
   const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
   const int64_t t64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
+  if (a.nbatch > 1) {
+    // batched: FAST KC/KC operands, plain epilogue, no split-K, for the operand types the callers use
+    constexpr bool BUILT = AMODE == MODE_KC && BMODE == MODE_KC && std::is_same<CT, bf16_t>::value && std::is_same<BT, bf16_t>::value &&
+                           ((std::is_same<AT, bf16_t>::value && std::is_same<OT, float>::value) ||
+                            (std::is_same<AT, float>::value && std::is_same<OT, bf16_t>::value));
+    if constexpr (BUILT) {
+      constexpr int CE = GemmCfg<CT>::CE;
+      const bool fast = a.a_vec && a.b_vec && (a.K % CE == 0) && ((uintptr_t)a.C % 16 == 0) && (a.ldc % (16 / (int)sizeof(OT)) == 0) &&
+                        (a.bsa % 16 == 0) && (a.bsb % 16 == 0) && (a.bsc % 16 == 0) && !a.accumulate && !a.bias && a.act == OTR_ACT_NONE;
+      if (!fast) return 1;                                            // not served: the caller loops over otr_linear_fwd
+      const bool big = a.M >= 128 && a.N >= 128 && t128 * a.nbatch >= 256;
+      a.ksplit = 1;
+      if (big) hipLaunchKernelGGL((gemm_batched_kernel<CT, AT, BT, OT, 128, 128>), dim3((unsigned)t128, 1, (unsigned)a.nbatch), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gemm_batched_kernel<CT, AT, BT, OT, 64, 64>), dim3((unsigned)t64, 1, (unsigned)a.nbatch), dim3(256), 0, s, a);
+      return otr_check_launch("gemm(batched)");
+    } else {
+      return 1;
+    }
+  }
   auto splits_for = [&](int64_t tiles) {
     if (!can_split) return 1;
     // measured (tools/gemm_sweep.py): with >= 64 output tiles one k-slice per CU is enough (w_2 forward 7968x256x2048:

@@ -648,6 +648,12 @@ def flush_weight_grads():
         L.check(lib.otr_colsum_grouped(items, len(b), _stream()), 'otr_colsum_grouped')
     for fn in post:                      # work that reads what the grouped launches just wrote (LinearFn: a regrouped weight gradient)
         fn()
+    if post and (_wq['w'] or _wq['b']):  # ... and may queue weight gradients of its own (RelPosAttentionFn: dW_pos from the finished dp)
+        keep, _wq['keep_last'] = _wq.get('keep_last'), False      # bench.py re-times the MAIN grouped launch, not this tail
+        try:
+            flush_weight_grads()
+        finally:
+            _wq['keep_last'] = keep
 
 
 # ---------------------------------------------------------------------------------------- early gradient groups
@@ -2592,6 +2598,25 @@ def _gemm_ptr(kind, M, N, K, x, w, y, bias=None, accumulate=0):
                 'otr_linear_wgrad')
 
 
+_GEMM_BATCHED = os.environ.get('OTR_GEMM_BATCHED', '1') != '0'
+_POS_DEFER = os.environ.get('OTR_POS_DEFER', '1') != '0'      # RelPosAttentionFn: the per-head dp products join the grouped weight-gradient launch
+
+
+def _gemm_heads(M, N, K, x, w, y, nb, bsx, bsw, bsy):
+    """y_b[M,N] = x_b[M,K] w_b[N,K]^T for b < nb on (tensor, element offset, leading dim) triples whose heads are bs* elements
+    apart: ONE launch (otr_linear_fwd_batched) where the operands qualify, else nb launches of otr_linear_fwd."""
+    (xt, xo, ldx), (wt, wo, ldw), (yt, yo, ldy) = x, w, y
+    if _GEMM_BATCHED and nb > 1:
+        d = L.LinearDesc(M, N, K, _code(xt.dtype), _code(wt.dtype), _code(yt.dtype), _compute_code(), ldx, ldw, ldy, 0, 0)
+        rc = L.load().otr_linear_fwd_batched(C.byref(d), _p(xt, xo), _p(wt, wo), _p(yt, yo), nb, bsx, bsw, bsy, _stream())
+        if rc == 0:
+            return
+        if rc < 0:
+            L.check(rc, 'otr_linear_fwd_batched')
+    for b in range(nb):
+        _gemm_ptr('fwd', M, N, K, (xt, xo + b * bsx, ldx), (wt, wo + b * bsw, ldw), (yt, yo + b * bsy, ldy))
+
+
 class ResidualAddFn(torch.autograd.Function):
     """y = x + scale * dropout(a): the pre-norm residual branches of encoder/conformer.py:50-73."""
 
@@ -2710,8 +2735,7 @@ class RelPosAttentionFn(torch.autograd.Function):
         lib = L.load()
         L.check(lib.otr_head_bias_add(_p(qkv), d3, _p(u), _p(v), _p(quv), _code(adt), M, d, _stream()), 'otr_head_bias_add')
         bd = torch.empty((B, T, H, Pp), dtype=torch.float32, device=qkv.device)
-        for h in range(H):
-            _gemm_ptr('fwd', M, Pp, dk, (quv, d + h * dk, 2 * d), (p, h * dk, d), (bd, h * Pp, H * Pp))
+        _gemm_heads(M, Pp, dk, (quv, d, 2 * d), (p, 0, d), (bd, 0, H * Pp), H, dk, dk, Pp)     # bd_h = (q+v)_h p_h^T
         out = torch.empty((B, T, d), dtype=adt, device=qkv.device)
         lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
         desc = _attn_desc(B, H, T, T, dk, adt, (T * 2 * d, 2 * d), (T * d3, d3), (T * d3, d3), (T * d, d), False)
@@ -2741,16 +2765,28 @@ class RelPosAttentionFn(torch.autograd.Function):
         L.check(lib.otr_attention_bias_bwd(C.byref(desc), _p(quv), _p(qkv, d), _p(qkv, 2 * d), _p(km), _p(bd), _p(dbd),
                                            T * H * Pp, Pp, H * Pp, 1, _p(out), _p(dout), _p(lse), _p(delta), _p(dquv),
                                            _p(dqkv, d), _p(dqkv, 2 * d), _stream()), 'otr_attention_bias_bwd')
-        dp = torch.empty((Pp, d), dtype=torch.float32, device=qkv.device)
-        for h in range(H):
-            # d(q+v)_h = dbd_h . p_h  as a forward-type GEMM on the transposed p (contraction over the padded axis)
-            _gemm_ptr('fwd', M, dk, Pp, (dbd, h * Pp, H * Pp), (pt, h * dk * Pp, Pp), (dquv, d + h * dk, 2 * d))
-            _gemm_ptr('wgrad', M, Pp, dk, (quv, d + h * dk, 2 * d), (dp, h * dk, d), (dbd, h * Pp, H * Pp))
+        # d(q+v)_h = dbd_h . p_h  as forward-type GEMMs on the transposed p (contraction over the padded axis), the four heads in one launch
+        _gemm_heads(M, dk, Pp, (dbd, 0, H * Pp), (pt, 0, Pp), (dquv, d, 2 * d), H, Pp, dk * Pp, dk)
+        pu, pv = ctx.uv_refs
+        gu, gv, gw = grad_target(pu), grad_target(pv), grad_target(pos_w)
+        # dp_h = dbd_h^T (q+v)_h feeds nothing but pos_proj's weight gradient: with an in-place gradient buffer the four products join
+        # the grouped weight-gradient launch at the end of backward (they were 4 x [split-K GEMM + reduce] = 84 us per block in the
+        # chain), and dW_pos = dp^T pe follows it (flush_weight_grads: post)
+        dbd2, quv2 = dbd.view(M, H * Pp), quv.view(M, 2 * d)
+        n0 = len(_wq['w'])
+        if gw is not None and _wq['on'] and _in_backward() and _POS_DEFER:
+            dp = torch.zeros((Pp, d), dtype=torch.float32, device=qkv.device)
+            for h in range(H):
+                linear_wgrad_raw(dbd2[:, h * Pp:(h + 1) * Pp], quv2[:, d + h * dk:d + (h + 1) * dk], None, out=dp[:, h * dk:(h + 1) * dk])
+        deferred = len(_wq['w']) == n0 + H
+        if not deferred:
+            assert len(_wq['w']) == n0
+            dp = torch.empty((Pp, d), dtype=torch.float32, device=qkv.device)
+            for h in range(H):
+                _gemm_ptr('wgrad', M, Pp, dk, (quv, d + h * dk, 2 * d), (dp, h * dk, d), (dbd, h * Pp, H * Pp))
         L.check(lib.otr_add2_strided(_p(dquv), 2 * d, _p(dquv, d), 2 * d, _p(dqkv), d3, _code(adt), M, d, _stream()),
                 'otr_add2_strided')
         dq2 = dquv.view(M, 2 * d)
-        pu, pv = ctx.uv_refs
-        gu, gv, gw = grad_target(pu), grad_target(pv), grad_target(pos_w)
         if gu is not None and gv is not None and gu.is_contiguous() and gv.is_contiguous():
             # the two column sums join the grouped launch at the end of backward (they were 2 launches + 2 gradient adds per block)
             colsum_raw(dq2[:, :d], out=gu.view(-1))
@@ -2758,7 +2794,11 @@ class RelPosAttentionFn(torch.autograd.Function):
             du = dv = None
         else:
             du, dv = colsum_raw(dq2[:, :d]).view(1, 1, H, dk), colsum_raw(dq2[:, d:]).view(1, 1, H, dk)
-        dw = linear_wgrad_raw(dp, pe, pos_w, out=gw)     # contraction over the padded axis (zero rows): the fast grouped kernel takes it
+        if deferred:
+            _wq['post'].append(lambda: linear_wgrad_raw(dp, pe, pos_w, out=gw))      # queued again: one more grouped launch for all blocks
+            dw = None
+        else:
+            dw = linear_wgrad_raw(dp, pe, pos_w, out=gw)     # contraction over the padded axis (zero rows): the fast grouped kernel takes it
         return dqkv, None, None if gw is not None else dw, du, dv, None, None
 
 

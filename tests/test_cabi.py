@@ -102,6 +102,11 @@ def test_argument_errors_of_the_fused_and_grouped_entries():
     assert lib.otr_decode_self_attention(one, one, one, one, one, one, 1, 2, 4, 256, 8, 1.0, None) < 0      # dk > 128
     assert lib.otr_beam_prune_cached(one, one, one, one, one, 8, 1, 2, 1, one, one, one, one, 4, one, one, one, one,
                                      None) < 0                                   # in/out buffers must differ
+    hcode = lib.otr_half_type()
+    ld0 = _lib.LinearDesc(8, 8, 8, hcode, hcode, 0, hcode, 8, 8, 8, 0, 0)
+    assert lib.otr_linear_fwd_batched(C.byref(ld0), one, one, None, 4, 8, 8, 8, None) < 0                 # null output
+    assert lib.otr_linear_fwd_batched(C.byref(ld0), one, one, one, 0, 8, 8, 8, None) < 0                  # no batches
+    assert b'linear_fwd_batched' in lib.otr_last_error_string()
     ln0 = _lib.DecLn(None, 16, None, 0, None, None, None, None, 0.0, 1e-5, 0, None, None, None, None, None)
     assert lib.otr_dec_self_step(C.byref(ln0), 8, one, one, one, one, one, None, one, 4, one, None) < 0     # ancestor table missing
     assert b'dec_self_step' in lib.otr_last_error_string()

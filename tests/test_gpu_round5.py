@@ -471,3 +471,48 @@ def test_cached_search_fused_step_matches_unfused_step(mode):
     finally:
         recognize._DECODE_STEP_FUSED = True
         ops.set_compute_dtype('bf16')
+
+
+# ----------------------------------------------------------------------------------- Conformer: per-head GEMMs in one launch, dp products deferred
+@pytest.mark.parametrize('mode', ['fp16', 'fp32'])
+def test_conformer_through_the_engine_matches_bare_model(mode):
+    """MultiHeadedSelfAttentionWithRelPos (module/attention.py:217-253) on the batched per-head GEMM launch, and -- through
+    FlatDataParallel's in-place gradients -- its dp_h = dbd_h^T (q+v)_h products in the grouped weight-gradient launch with dW_pos behind it
+    (ops.RelPosAttentionFn.backward): every parameter gradient of the small Conformer equals the bare model's (per-operator launches,
+    OTR_GEMM_BATCHED / OTR_POS_DEFER off) up to summation order."""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops, synthetic as syn
+    from opentransformer_amd.dp import FlatDataParallel
+    ops.set_compute_dtype(mode)
+    try:
+        cfg = syn.conformer_model(small=True)
+        inputs, targets = syn.synthetic_batch(batch=4, frames=120, feat_dim=80, vocab=100, tgt_len=6, seed=11, lengths=[120, 97, 80, 111])
+        di = {k: v.to(DEV) for k, v in inputs.items()}
+        dt = {k: v.to(DEV) for k, v in targets.items()}
+
+        def grads(engine, batched):
+            ops._GEMM_BATCHED, ops._POS_DEFER = batched, batched
+            model = ota.SpeechToText(cfg)
+            syn.fill_state_dict_(model.state_dict(), 77)
+            model = model.to(DEV).train()
+            if engine:
+                dp = FlatDataParallel(model)
+                dp.zero_grad()
+                loss, _ = dp(di, dt)
+                ops.backward(loss)
+            else:
+                loss, _ = model(di, dt)
+                loss.backward()
+            torch.cuda.synchronize()
+            return float(loss), {k: p.grad.detach().float().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+        l0, g0 = grads(False, False)
+        l1, g1 = grads(True, True)
+        assert abs(l0 - l1) <= (2e-3 if mode == 'fp16' else 1e-5) * abs(l0), (l0, l1)
+        tol = 2e-2 if mode == 'fp16' else 2e-4
+        worst = max((float((g1[k] - g0[k]).norm() / (g0[k].norm() + 1e-12)), k) for k in g0)
+        assert worst[0] < tol, worst
+        assert any('pos_proj' in k for k in g0)
+    finally:
+        ops._GEMM_BATCHED, ops._POS_DEFER = True, True
+        ops.set_compute_dtype('bf16')
