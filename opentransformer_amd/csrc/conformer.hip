@@ -205,7 +205,11 @@ struct DwArgs {
 // (time index clamped into the utterance, contribution masked); the per-channel sums are reduced through LDS so each
 // workgroup issues one set of atomics.  (The first version: 16-row strips, 96 active threads, every tap load behind
 // its own bounds branch, 498 x 2304 atomics: 271 us for the backward at C=384.)
-constexpr int DW_RPB = 64;
+// r05: a thread walks a SEGMENT of consecutive rows and keeps the taps' rows in registers (a sliding window over the flat row index:
+// one load per row and operand instead of KT; neighbours across an utterance boundary are loaded and masked), and a workgroup owns 32
+// rows: 249 workgroups at the bench batch instead of 125 walking 32 rows per thread behind 5-11 loads each (forward 30 -> , backward
+// 46 -> us at 7968 x 384, rocprofv3).
+constexpr int DW_RPB = 32;
 // KT = compile-time tap count (3 / 5 / 7: the smallest >= k), so only real taps are loaded
 
 // y[b,t,c] = bias[c] + sum_j w[c,j] * g[b, t + j - pad, c]   (zero padded in time, per utterance)
@@ -218,7 +222,7 @@ template <class T, int KT> __global__ __launch_bounds__(256) void dwconv_fwd_ker
   const T* g = reinterpret_cast<const T*>(p.g);
   const int cg = threadIdx.x % C4, ty = threadIdx.x / C4;
   const bool active = ty < NY;
-  const int c = cg * 4;
+  const int c = cg * 4, seg = (DW_RPB + NY - 1) / NY;
   float w[4][KT], bias[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -227,26 +231,31 @@ template <class T, int KT> __global__ __launch_bounds__(256) void dwconv_fwd_ker
     for (int j = 0; j < KT; ++j) w[e][j] = (j < p.k) ? p.w[(c + e) * p.k + j] : 0.f;
   }
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (active) {
-    for (int64_t row = r0 + ty; row < r1; row += NY) {
-      const int t = (int)(row % p.T);
-      float acc[4] = {bias[0], bias[1], bias[2], bias[3]};
-      float gv[KT][4];
+  const int64_t rs = r0 + (int64_t)ty * seg, re = min(r1, rs + seg);
+  if (active && rs < re) {
+    auto flat = [&](int64_t r) { return min(max(r, (int64_t)0), M - 1); };
+    int t = (int)(rs % p.T);
+    float gw[KT][4];                                      // gw[j] = g[row + j - pad] (flat rows; taps outside the utterance are masked)
 #pragma unroll
-      for (int j = 0; j < KT; ++j) {
-        const int tt = min(max(t + j - pad, 0), p.T - 1);    // clamped inside the utterance (tap masked below)
-        ldc4<T>(g + (row - t + tt) * p.C + c, gv[j]);
-      }
+    for (int j = 0; j < KT - 1; ++j) ldc4<T>(g + flat(rs + j - pad) * p.C + c, gw[j]);
+    for (int64_t row = rs; row < re; ++row) {
+      ldc4<T>(g + flat(row + KT - 1 - pad) * p.C + c, gw[KT - 1]);
+      float acc[4] = {bias[0], bias[1], bias[2], bias[3]};
 #pragma unroll
       for (int j = 0; j < KT; ++j) {
         const int tt = t + j - pad;
         const float m = (j < p.k && tt >= 0 && tt < p.T) ? 1.f : 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fmaf(w[e][j] * m, gv[j][e], acc[e]);
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(w[e][j] * m, gw[j][e], acc[e]);
       }
       stc4<float>(p.y + row * p.C + c, acc);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s1[e] += acc[e]; s2[e] += acc[e] * acc[e]; }
+#pragma unroll
+      for (int j = 0; j < KT - 1; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gw[j][e] = gw[j + 1][e];
+      if (++t == p.T) t = 0;
     }
   }
   if (p.stats) {
@@ -274,38 +283,58 @@ template <class T, int KT> __global__ __launch_bounds__(256) void dwconv_bwd_ker
   T* dg = reinterpret_cast<T*>(p.dg);
   const int cg = threadIdx.x % C4, ty = threadIdx.x / C4;
   const bool active = ty < NY;
-  const int c = cg * 4;
+  const int c = cg * 4, seg = (DW_RPB + NY - 1) / NY;
   float w[4][KT], dw[4][KT], db[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
     for (int j = 0; j < KT; ++j) { w[e][j] = (j < p.k) ? p.w[(c + e) * p.k + j] : 0.f; dw[e][j] = 0.f; }
+  const int64_t rs = r0 + (int64_t)ty * seg, re = min(r1, rs + seg);
   if (active) {
-    for (int64_t row = r0 + ty; row < r1; row += NY) {
-      const int t = (int)(row % p.T);
-      float dyv[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
-      float gv[KT][4], yv[KT][4];
-      ldc4<float>(p.dy + row * p.C + c, dyv);
+    if (rs < re) {
+      auto flat = [&](int64_t r) { return min(max(r, (int64_t)0), M - 1); };
+      int t = (int)(rs % p.T);
+      float gw[KT][4], yw[KT][4];                         // gw[j] = g[row + j - pad], yw[j] = dy[row - j + pad] (flat rows, masked by t)
 #pragma unroll
-      for (int j = 0; j < KT; ++j) {
-        const int tg = min(max(t + j - pad, 0), p.T - 1), tyy = min(max(t - j + pad, 0), p.T - 1);
-        ldc4<T>(g + (row - t + tg) * p.C + c, gv[j]);
-        ldc4<float>(p.dy + (row - t + tyy) * p.C + c, yv[j]);
-      }
+      for (int j = 0; j < KT - 1; ++j) ldc4<T>(g + flat(rs + j - pad) * p.C + c, gw[j]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) db[e] += dyv[e];
+      for (int j = 1; j < KT; ++j) ldc4<float>(p.dy + flat(rs - j + pad) * p.C + c, yw[j]);
+      for (int64_t row = rs; row < re; ++row) {
+        ldc4<T>(g + flat(row + KT - 1 - pad) * p.C + c, gw[KT - 1]);
+        ldc4<float>(p.dy + flat(row + pad) * p.C + c, yw[0]);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f}, dyv[4];
 #pragma unroll
-      for (int j = 0; j < KT; ++j) {
-        const int tg = t + j - pad, tyy = t - j + pad;
-        const float mg = (j < p.k && tg >= 0 && tg < p.T) ? 1.f : 0.f;       // forward tap: y[t] used g[t + j - pad]
-        const float my = (j < p.k && tyy >= 0 && tyy < p.T) ? 1.f : 0.f;     // dg[t] collects dy[t - j + pad] * w[j]
+        for (int e = 0; e < 4; ++e) dyv[e] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          dw[e][j] = fmaf(dyv[e] * mg, gv[j][e], dw[e][j]);
-          acc[e] = fmaf(w[e][j] * my, yv[j][e], acc[e]);
+        for (int j = 0; j < KT; ++j)
+          if (j == pad) {                                  // dy[row] sits in the window (pad < KT)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dyv[e] = yw[j][e];
+          }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) db[e] += dyv[e];
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+          const int tg = t + j - pad, tyy = t - j + pad;
+          const float mg = (j < p.k && tg >= 0 && tg < p.T) ? 1.f : 0.f;       // forward tap: y[t] used g[t + j - pad]
+          const float my = (j < p.k && tyy >= 0 && tyy < p.T) ? 1.f : 0.f;     // dg[t] collects dy[t - j + pad] * w[j]
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            dw[e][j] = fmaf(dyv[e] * mg, gw[j][e], dw[e][j]);
+            acc[e] = fmaf(w[e][j] * my, yw[j][e], acc[e]);
+          }
         }
+        stc4<T>(dg + row * p.C + c, acc);
+#pragma unroll
+        for (int j = 0; j < KT - 1; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gw[j][e] = gw[j + 1][e];
+#pragma unroll
+        for (int j = KT - 1; j > 0; --j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) yw[j][e] = yw[j - 1][e];
+        if (++t == p.T) t = 0;
       }
-      stc4<T>(dg + row * p.C + c, acc);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
