@@ -516,6 +516,12 @@ int32_t otr_dwconv_fwd(const void* g, int32_t dtype, const float* w, const float
 /* dg (dtype), dw f32 [C,k] +=, db f32 [C] += (may be NULL) */
 int32_t otr_dwconv_bwd(const float* dy, const void* g, int32_t dtype, const float* w, void* dg, float* dw, float* db,
                        int32_t B, int32_t T, int32_t C, int32_t k, int32_t pad, void* stream);
+/* otr_dwconv_bwd_part: the same with the weight / bias gradient sums left PER WORKGROUP in part [otr_dwconv_bwd_partial_rows(B*T)][C*k + C]
+ * (columns: dw as [C][k], then db) instead of atomic adds on dw / db: the caller column-sums them (otr_colsum_grouped at the end of the
+ * backward pass): 249 workgroups x 2304 atomics on 2304 addresses were half of the launch at the bench batch. */
+int64_t otr_dwconv_bwd_partial_rows(int64_t M);
+int32_t otr_dwconv_bwd_part(const float* dy, const void* g, int32_t dtype, const float* w, void* dg, float* part, int32_t B, int32_t T,
+                            int32_t C, int32_t k, int32_t pad, void* stream);
 /* BatchNorm1d (training: batch statistics from `stats`, running stats updated in place; eval: running stats) fused
  * with swish; saved f32 [2C] = mean | rstd for backward */
 int32_t otr_bn_swish_fwd(const float* y, const float* stats, const float* gamma, const float* beta, float* running_mean,

@@ -197,6 +197,7 @@ extern "C" int32_t otr_row_mask(const float* x, const uint8_t* mask, float* out,
 struct DwArgs {
   const void* g; const float* w; const float* b; float* y; float* stats;
   const float* dy; void* dg; float* dw; float* db;
+  float* part;           // backward: per-workgroup sums [blocks][C*k | C] instead of atomics on dw / db (the caller column-sums them)
   int B, T, C, k, pad;   // pad = taps left of the output position ((k-1)/2: 'same' conv; 0: look-ahead conv)
 };
 
@@ -349,7 +350,8 @@ template <class T, int KT> __global__ __launch_bounds__(256) void dwconv_bwd_ker
     float a = 0.f;
     for (int y = 0; y < NY; ++y) a += dw_red[y * p.C * K1 + i];
     const int ch = i / K1, j = i - ch * K1;
-    if (j < p.k) atomicAdd(p.dw + ch * p.k + j, a);
+    if (p.part) p.part[(int64_t)blockIdx.x * (p.C * K1) + (j < p.k ? ch * p.k + j : p.C * p.k + ch)] = a;
+    else if (j < p.k) atomicAdd(p.dw + ch * p.k + j, a);
     else if (p.db) atomicAdd(p.db + ch, a);
   }
 }
@@ -378,11 +380,28 @@ extern "C" int32_t otr_dwconv_fwd(const void* g, int32_t dtype, const float* w, 
   if (k <= 3) DW_LAUNCH(dwconv_fwd_kernel, 3) else if (k <= 5) DW_LAUNCH(dwconv_fwd_kernel, 5) else DW_LAUNCH(dwconv_fwd_kernel, 7)
   return otr_check_launch("dwconv_fwd");
 }
+extern "C" int64_t otr_dwconv_bwd_partial_rows(int64_t M) { return (M + DW_RPB - 1) / DW_RPB; }
+
+static int32_t dwconv_bwd_launch(const float* dy, const void* g, int32_t dtype, const float* w, void* dg, float* dw, float* db, float* part,
+                                 int32_t B, int32_t T, int32_t C, int32_t k, int32_t pad, void* stream);
+
+extern "C" int32_t otr_dwconv_bwd_part(const float* dy, const void* g, int32_t dtype, const float* w, void* dg, float* part,
+                                       int32_t B, int32_t T, int32_t C, int32_t k, int32_t pad, void* stream) {
+  OTR_REQUIRE(part && (uintptr_t)part % 16 == 0, "dwconv_bwd_part: null / unaligned partial buffer");
+  return dwconv_bwd_launch(dy, g, dtype, w, dg, nullptr, nullptr, part, B, T, C, k, pad, stream);
+}
+
 extern "C" int32_t otr_dwconv_bwd(const float* dy, const void* g, int32_t dtype, const float* w, void* dg, float* dw, float* db,
                                   int32_t B, int32_t T, int32_t C, int32_t k, int32_t pad, void* stream) {
+  OTR_REQUIRE(dw, "dwconv_bwd: null pointer");
+  return dwconv_bwd_launch(dy, g, dtype, w, dg, dw, db, nullptr, B, T, C, k, pad, stream);
+}
+
+static int32_t dwconv_bwd_launch(const float* dy, const void* g, int32_t dtype, const float* w, void* dg, float* dw, float* db, float* part,
+                                 int32_t B, int32_t T, int32_t C, int32_t k, int32_t pad, void* stream) {
   if (int32_t e = dw_check(B, T, C, k, pad)) return e;
-  OTR_REQUIRE(dy && g && w && dg && dw, "dwconv_bwd: null pointer");
-  DwArgs p{}; p.dy = dy; p.g = g; p.w = w; p.dg = dg; p.dw = dw; p.db = db; p.B = B; p.T = T; p.C = C; p.k = k; p.pad = pad;
+  OTR_REQUIRE(dy && g && w && dg, "dwconv_bwd: null pointer");
+  DwArgs p{}; p.dy = dy; p.g = g; p.w = w; p.dg = dg; p.dw = dw; p.db = db; p.part = part; p.B = B; p.T = T; p.C = C; p.k = k; p.pad = pad;
   hipStream_t s = (hipStream_t)stream;
   const int NY = 256 / (C / 4);
   const dim3 grid((unsigned)(((int64_t)B * T + DW_RPB - 1) / DW_RPB));

@@ -2599,6 +2599,7 @@ def _gemm_ptr(kind, M, N, K, x, w, y, bias=None, accumulate=0):
 
 
 _GEMM_BATCHED = os.environ.get('OTR_GEMM_BATCHED', '1') != '0'
+_DW_PART = os.environ.get('OTR_DWCONV_PART', '1') != '0'      # ConformerConvFn: depthwise-conv parameter gradients through per-workgroup sums
 _POS_DEFER = os.environ.get('OTR_POS_DEFER', '1') != '0'      # RelPosAttentionFn: the per-head dp products join the grouped weight-gradient launch
 
 
@@ -2874,9 +2875,19 @@ class ConformerConvFn(torch.autograd.Function):
         gwd, gbd = grad_target(wdwp), (grad_target(bdwp) if has_dwb else None)
         dw_inplace = gwd is not None and gwd.is_contiguous() and (not has_dwb or gbd is not None)   # the kernel's sums are += already
         dwk = None if dw_inplace else torch.zeros((Cc * k + Cc,), dtype=torch.float32, device=dout.device)
-        L.check(lib.otr_dwconv_bwd(_p(dy), _p(g), _code(adt), _p(wk), _p(dg), _p(gwd) if dw_inplace else _p(dwk),
-                                   (_p(gbd) if has_dwb else None) if dw_inplace else _p(dwk, Cc * k), B, T, Cc, k,
-                                   (k - 1) // 2, _stream()), 'otr_dwconv_bwd')
+        if dw_inplace and _DW_PART and _wq['on'] and _in_backward():
+            # the kernel leaves per-workgroup sums; the grouped column-sum launch at the end of backward adds them where the gradients
+            # live (otr_dwconv_bwd_part: no atomics)
+            dpart = torch.empty((lib.otr_dwconv_bwd_partial_rows(M), Cc * k + Cc), dtype=torch.float32, device=dout.device)
+            L.check(lib.otr_dwconv_bwd_part(_p(dy), _p(g), _code(adt), _p(wk), _p(dg), _p(dpart), B, T, Cc, k, (k - 1) // 2, _stream()),
+                    'otr_dwconv_bwd_part')
+            colsum_raw(dpart[:, :Cc * k], out=gwd.view(-1))
+            if has_dwb:
+                colsum_raw(dpart[:, Cc * k:], out=gbd)
+        else:
+            L.check(lib.otr_dwconv_bwd(_p(dy), _p(g), _code(adt), _p(wk), _p(dg), _p(gwd) if dw_inplace else _p(dwk),
+                                       (_p(gbd) if has_dwb else None) if dw_inplace else _p(dwk, Cc * k), B, T, Cc, k,
+                                       (k - 1) // 2, _stream()), 'otr_dwconv_bwd')
         dh = torch.empty_like(h)
         nblk = (M + GLU_RPB - 1) // GLU_RPB
         part = torch.empty((nblk, 2 * Cc), dtype=torch.float32, device=dout.device)

@@ -491,7 +491,7 @@ def test_conformer_through_the_engine_matches_bare_model(mode):
         dt = {k: v.to(DEV) for k, v in targets.items()}
 
         def grads(engine, batched):
-            ops._GEMM_BATCHED, ops._POS_DEFER = batched, batched
+            ops._GEMM_BATCHED, ops._POS_DEFER, ops._DW_PART = batched, batched, batched
             model = ota.SpeechToText(cfg)
             syn.fill_state_dict_(model.state_dict(), 77)
             model = model.to(DEV).train()
@@ -510,9 +510,12 @@ def test_conformer_through_the_engine_matches_bare_model(mode):
         l1, g1 = grads(True, True)
         assert abs(l0 - l1) <= (2e-3 if mode == 'fp16' else 1e-5) * abs(l0), (l0, l1)
         tol = 2e-2 if mode == 'fp16' else 2e-4
-        worst = max((float((g1[k] - g0[k]).norm() / (g0[k].norm() + 1e-12)), k) for k in g0)
+        # (a bias in front of a BatchNorm on batch statistics has an analytically zero gradient, module/conformer.py:103-110: what the two
+        #  runs hold there is rounding noise of different summation orders -- measured against the largest gradient instead of itself)
+        gmax = max(float(v.norm()) for v in g0.values())
+        worst = max((float((g1[k] - g0[k]).norm() / (g0[k].norm() + 1e-3 * gmax)), k) for k in g0)
         assert worst[0] < tol, worst
         assert any('pos_proj' in k for k in g0)
     finally:
-        ops._GEMM_BATCHED, ops._POS_DEFER = True, True
+        ops._GEMM_BATCHED, ops._POS_DEFER, ops._DW_PART = True, True, True
         ops.set_compute_dtype('bf16')
