@@ -346,6 +346,19 @@ template <class CT, int DK, bool PIPE, int NW = 4> __global__ __launch_bounds__(
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    // score bias (relative-position term): the block's 16 values per lane go out BEFORE the MFMAs, unconditionally (indices clamped
+    // into the tensor, masked at use) -- read at the point of use, each behind its own predicate, they were 16 exposed round trips
+    // per key block (attention forward 38 us, backward 139 us per Conformer block; r05)
+    float bv[4][4];
+    if (p.bias) {
+      const int qc = min(qrow, p.Tq - 1);
+      const float* brow = p.bias + bias_index(p, b, h, qc, 0);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[kt][r] = brow[min(kb * 64 + kt * 16 + lg * 4 + r, p.Tk - 1)];
+      __builtin_amdgcn_sched_barrier(0);
+    }
     f32x4 st[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -371,7 +384,7 @@ template <class CT, int DK, bool PIPE, int NW = 4> __global__ __launch_bounds__(
           const int kl = kt * 16 + lg * 4 + r, key = kb * 64 + kl;
           bool ok = ((kmask >> kl) & 1) && (!p.causal || key <= qrow);
           float raw = st[kt][r];
-          if (p.bias && ok && qrow < p.Tq) raw += p.bias[bias_index(p, b, h, qrow, key)];
+          if (p.bias && ok && qrow < p.Tq) raw += bv[kt][r];
           float s = ok ? raw * sc2 : NEG_INF;
           st[kt][r] = s;
           bm = fmaxf(bm, s);
@@ -533,6 +546,15 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnArgs& p, const int 
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    float bv[4][4];      // score bias of the block, loaded ahead of the MFMAs (see attn_fwd_kernel)
+    if (p.bias) {
+      const int kc = min(key, p.Tk - 1);
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[qt][r] = p.bias[bias_index(p, b, h, min(qb * 64 + qt * 16 + lg * 4 + r, p.Tq - 1), kc)];
+      __builtin_amdgcn_sched_barrier(0);
+    }
     f32x4 pt[4], ds[4];  // tiles over q (rows), cols = keys
     // whole query block valid with finite lse, no causal mask, no bias: no per-element predicate (masked KEYS only
     // pollute their own dK/dV columns, which are zeroed at the store)
@@ -561,7 +583,7 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnArgs& p, const int 
         float ls = sLse[ql];                               // pre-multiplied by ExpDom<CT>::K when it was staged
         bool ok = key_ok && qg < p.Tq && (!p.causal || key <= qg) && ls != NEG_INF;
         float raw = s[r];
-        if (p.bias && ok) raw += p.bias[bias_index(p, b, h, qg, key)];
+        if (p.bias && ok) raw += bv[qt][r];
         float pe = ok ? attn_exp<CT>(raw * sc2 - ls) : 0.f;
         pt[qt][r] = pe;
         float dsv = pe * (dp[r] - sDel[ql]) * p.scale;
@@ -687,6 +709,15 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int bx
     }
 
     const uint64_t kmask = key_block_mask(km, kb, p.Tk, lane);
+    float bv[4][4];      // score bias of the block, loaded ahead of the MFMAs (see attn_fwd_kernel)
+    if (p.bias) {
+      const float* brow = p.bias + bias_index(p, b, h, min(qrow, p.Tq - 1), 0);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[kt][r] = brow[min(kb * 64 + kt * 16 + lg * 4 + r, p.Tk - 1)];
+      __builtin_amdgcn_sched_barrier(0);
+    }
     f32x4 ds[4];  // tiles over keys (rows), cols = queries
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -706,7 +737,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int bx
         const int kl = kt * 16 + lg * 4 + r, key = kb * 64 + kl;
         bool ok = q_ok && ls != NEG_INF && ((kmask >> kl) & 1) && (!p.causal || key <= qrow);
         float raw = s[r];
-        if (p.bias && ok) raw += p.bias[bias_index(p, b, h, qrow, key)];
+        if (p.bias && ok) raw += bv[kt][r];
         float pe = ok ? attn_exp<CT>(raw * sc2 - ls) : 0.f;
         ds[kt][r] = pe * (dp[r] - dl) * p.scale;
       }
