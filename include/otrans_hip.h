@@ -330,6 +330,7 @@ typedef struct {
   int32_t a_dtype;
   float eps, p_drop;            /* p_drop = 0 -> no dropout */
   uint64_t rng_offset;
+  float a_scale;                /* r05: y = LN(x + a_scale * dropout(a)), da = a_scale * dropout'(dz); 0 means 1 (older callers) */
 } otr_ln_desc_t;
 /* y_bf16 (may be NULL): bf16 copy of y, the GEMM-operand form of the residual stream */
 int32_t otr_add_layernorm_fwd(const otr_ln_desc_t* d, const float* x, const void* a, const float* gamma,

@@ -12,6 +12,7 @@ struct LnArgs {
   float eps, p_drop;
   uint64_t rng_offset;
   const float* skip;                                      // backward: dx = skip + LayerNorm input gradient (pre-norm residual)
+  float a_scale;                                          // the branch enters as a_scale * dropout(a) (encoder/conformer.py:56: 0.5 * ffn)
 };
 
 constexpr int LN_MAXV = 4;  // float4 per lane -> d <= 1024
@@ -43,7 +44,7 @@ template <class AT, bool HAS_A> __global__ __launch_bounds__(256) void add_ln_fw
   const bool drop = HAS_A && p.p_drop > 0.f;
   const uint64_t seed = drop ? *p.seed : 0;
   const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
-  const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+  const float inv_keep = (drop ? 1.f / (1.f - p.p_drop) : 1.f) * p.a_scale;
   float v[LN_MAXV][4];
   float s = 0.f;
 #pragma unroll
@@ -56,7 +57,7 @@ template <class AT, bool HAS_A> __global__ __launch_bounds__(256) void add_ln_fw
         ld4<AT>(reinterpret_cast<const AT*>(p.a) + row * d + col, a);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float sc = drop ? drop_scale(seed, p.rng_offset + (uint64_t)(row * d + col + e), thr, inv_keep) : 1.f;
+          float sc = drop ? drop_scale(seed, p.rng_offset + (uint64_t)(row * d + col + e), thr, inv_keep) : inv_keep;
           v[i][e] += a[e] * sc;
         }
       }
@@ -104,7 +105,7 @@ template <class AT, bool HAS_A, int NV> __global__ __launch_bounds__(256) void a
   const bool drop = HAS_A && p.p_drop > 0.f;
   const uint64_t seed = drop ? *p.seed : 0;
   const uint32_t thr = drop ? (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) : 0;
-  const float inv_keep = drop ? 1.f / (1.f - p.p_drop) : 1.f;
+  const float inv_keep = (drop ? 1.f / (1.f - p.p_drop) : 1.f) * p.a_scale;
   const bool want_ab = HAS_A && p.da_colsum != nullptr;
   float gam[NV][4], dg[NV][4], db[NV][4], dab[NV][4];
   int colv[NV];
@@ -173,7 +174,7 @@ template <class AT, bool HAS_A, int NV> __global__ __launch_bounds__(256) void a
               float o[4];
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                float sc = drop ? drop_scale(seed, p.rng_offset + (uint64_t)(row * d + col + e), thr, inv_keep) : 1.f;
+                float sc = drop ? drop_scale(seed, p.rng_offset + (uint64_t)(row * d + col + e), thr, inv_keep) : inv_keep;
                 o[e] = dz[e] * sc;
                 dab[i][e] += o[e];
               }
@@ -240,6 +241,7 @@ extern "C" int32_t otr_add_layernorm_fwd(const otr_ln_desc_t* d, const float* x,
   LnArgs p{};
   p.x = x; p.a = a; p.gamma = gamma; p.beta = beta; p.seed = seed; p.y = y; p.z = z; p.mean = mean; p.rstd = rstd; p.y_lp = (bf16_t*)y_bf16;
   p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
+  p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale;
   dim3 grid((unsigned)((d->M + 3) / 4));
   hipStream_t s = (hipStream_t)stream;
   if (!a) hipLaunchKernelGGL((add_ln_fwd_kernel<float, false>), grid, dim3(256), 0, s, p);
@@ -266,6 +268,7 @@ extern "C" int32_t otr_add_layernorm_bwd_skip(const otr_ln_desc_t* d, const floa
   p.dy = dy; p.zin = z; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd); p.gamma = gamma;
   p.seed = seed; p.skip = skip; p.dx = dx; p.da = da; p.dgamma = dgamma; p.dbeta = dbeta; p.da_colsum = da ? da_colsum : nullptr; p.partial = partial;
   p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
+  p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale;
   dim3 grid((unsigned)((d->M + 4 * LN_BWD_ROWS - 1) / (4 * LN_BWD_ROWS)));
   hipStream_t s = (hipStream_t)stream;
 #define LN_BWD_LAUNCH(NV)                                                                                   \

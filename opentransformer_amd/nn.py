@@ -18,11 +18,14 @@ frontend's conv layers (frontend/conv.py:66) runs through ops.dropout (counter R
 raises NotImplementedError): in_channel != 1, pos_dropout > 0 (which in the reference silently switches the formula).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 
 from . import ops
+
+_RES_LN = os.environ.get('OTR_RESIDUAL_LN', '1') != '0'     # ConformerEncoderBlock: residual adds fused into the LayerNorms that follow them
 
 PAD, BLK, BOS, EOS = 0, 0, 1, 1       # otrans/data/__init__.py:7-12
 
@@ -512,8 +515,28 @@ class ConformerEncoderBlock(nn.Module):
         link = ops.new_prenorm_link()
         return ops.residual_add(x, self.conv(self._ln(self.conv_norm, x, link), mask), 1.0, p, link)
 
+    def _forward_fused(self, x, mask, pos):
+        """the shipped layout (macaron FFN, attention, convolution) with every residual add fused into the LayerNorm that reads its
+        result (ops.ResidualLnFn): encoder/conformer.py:50-89"""
+        p = self.residual_dropout
+        link = ops.new_prenorm_link()
+        a = self.pre_ffn(self._ln(self.macaron_ffn_norm, x, link), branch=True)
+        n = self.mha_norm
+        x, h = ops.residual_layernorm(x, a, self.ffn_scale, p, n.weight, n.bias, n.eps, link)
+        km = ops._mask_u8(mask, mask.shape[0], mask.shape[1]).unsqueeze(1)
+        a = self.mha(h, km, pos)[0] if self.relative_positional else self.mha(h, km)[0]
+        n = self.conv_norm
+        x, h = ops.residual_layernorm(x, a, 1.0, p, n.weight, n.bias, n.eps)
+        a = self.conv(h, mask)
+        n = self.post_ffn_norm
+        _, y = ops.residual_layernorm(x, a, 1.0, p, n.weight, n.bias, n.eps)
+        return self._ln(self.final_norm, y), {'slf_attn_weights': None}
+
     def forward(self, x, mask, pos=None):
         p = self.residual_dropout                      # F.dropout(..., p): active in train AND eval in the reference
+        if (_RES_LN and self.macaron_style and not self.conv_first and x.is_cuda and x.dtype == torch.float32 and mask is not None
+                and mask.dim() == 2 and x.shape[-1] % 4 == 0):
+            return self._forward_fused(x, mask, pos)
         if self.macaron_style:
             link = ops.new_prenorm_link()
             x = ops.residual_add(x, self.pre_ffn(self._ln(self.macaron_ffn_norm, x, link), branch=True), self.ffn_scale, p, link)

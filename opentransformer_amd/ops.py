@@ -1473,6 +1473,79 @@ class AddLayerNormFn(torch.autograd.Function):
                 None if inplace else gg, None if inplace else gb, None, None, dab, None)
 
 
+class ResidualLnFn(torch.autograd.Function):
+    """(z, y) = (x + scale * dropout(a), LayerNorm(z)): a pre-norm residual add (encoder/conformer.py:53-72) together with the LayerNorm
+    that reads its result -- the norm at the head of the NEXT branch, or post_ffn_norm (:87) -- in one launch forward
+    (otr_add_layernorm_fwd with a_scale, z is the launch's saved pre-norm sum) and one backward (otr_add_layernorm_bwd_skip: the
+    gradient that reaches z from the residual stream is the `skip` operand; dx = skip + LayerNorm input gradient, da = scale *
+    dropout'(dx)).  It was residual_add + add_layernorm: 36 + 36 launches of 5-7 us per Conformer step more.  `link`: x is also
+    the input of the LayerNorm at the head of the branch that produced a (PreNormLink); its gradient goes there, as in ResidualAddFn."""
+
+    @staticmethod
+    def forward(ctx, x, a, scale, p_drop, gamma, beta, eps, link=None):
+        _cuda(x, a, gamma, beta)
+        ctx.set_materialize_grads(False)
+        ctx.link = link if (link is not None and link.armed and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]) else None
+        d = x.shape[-1]
+        x2 = x.reshape(-1, d).contiguous()
+        a2 = a.reshape(-1, d).contiguous()
+        M = x2.shape[0]
+        z, y = torch.empty_like(x2), torch.empty_like(x2)
+        ylp = torch.empty(x2.shape, dtype=half_dtype(), device=x.device) if is_half() else None
+        mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        seed = rng_seed_tensor(x.device) if p_drop > 0 else None
+        off = _next_rng_offset(M * d) if p_drop > 0 else 0
+        desc = L.LnDesc(M, d, _code(a2.dtype), eps, p_drop, off, scale)
+        L.check(L.load().otr_add_layernorm_fwd(C.byref(desc), _p(x2), _p(a2), _p(gamma), _p(beta), _p(seed), _p(y), _p(ylp), _p(z),
+                                               _p(mean), _p(rstd), _stream()), 'otr_add_layernorm_fwd')
+        ctx.save_for_backward(z, mean, rstd, gamma, seed)
+        ctx.g_ref, ctx.b_ref = gamma, beta
+        ctx.cfg = (M, d, a2.dtype, eps, p_drop, off, scale, x.shape, a.shape)
+        if ylp is None:
+            return z.view(x.shape), y.view(x.shape), None
+        ylp = ylp.view(x.shape)
+        ctx.mark_non_differentiable(ylp)
+        return z.view(x.shape), y.view(x.shape), ylp
+
+    @staticmethod
+    def backward(ctx, dz, dy, _dylp=None):
+        if dz is None and dy is None:
+            return (None,) * 8
+        z, mean, rstd, gamma, seed = ctx.saved_tensors
+        M, d, adt, eps, p_drop, off, scale, xshape, ashape = ctx.cfg
+        dy2 = dy.reshape(-1, d).contiguous() if dy is not None else torch.zeros((M, d), dtype=torch.float32, device=z.device)
+        skip = dz.reshape(-1, d).contiguous() if dz is not None else None
+        dx = torch.empty_like(dy2)
+        da = torch.empty((M, d), dtype=adt, device=z.device)
+        gg, gb = grad_target(ctx.g_ref), grad_target(ctx.b_ref)
+        inplace = gg is not None and gb is not None
+        if not inplace:
+            dgb = torch.zeros((2, d), dtype=torch.float32, device=z.device)
+            gg, gb = dgb[0], dgb[1]
+        part = None
+        if inplace and _wq['on'] and _in_backward() and d % 4 == 0:
+            part = torch.empty((L.load().otr_add_layernorm_bwd_partial_rows(M), 3 * d), dtype=torch.float32, device=z.device)
+        desc = L.LnDesc(M, d, _code(adt), eps, p_drop, off, scale)
+        L.check(L.load().otr_add_layernorm_bwd_skip(C.byref(desc), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed), _p(skip),
+                                                    _p(dx), _p(da), _p(gg), _p(gb), None, _p(part), _stream()), 'otr_add_layernorm_bwd')
+        if part is not None:
+            colsum_raw(part[:, :d], out=gg)
+            colsum_raw(part[:, d:2 * d], out=gb)
+        dx_ret = dx.view(xshape)
+        if ctx.link is not None:
+            ctx.link.buf = dx
+            _park(ctx.link)
+            dx_ret = None
+        return dx_ret, da.view(ashape), None, None, None if inplace else gg, None if inplace else gb, None, None
+
+
+def residual_layernorm(x, a, scale, p_drop, gamma, beta, eps=1e-5, link=None):
+    """(x + scale * dropout(a), LayerNorm of that sum [with its 16-bit twin]) in one launch: ResidualLnFn"""
+    z, y, ylp = ResidualLnFn.apply(x, a, float(scale), float(p_drop), gamma, beta, float(eps), link)
+    return z, attach_lp(y, ylp)
+
+
 def add_layernorm(x, a, gamma, beta, p_drop=0.0, eps=1e-5, a_bias=None, link=None):
     """a_bias: the bias parameter of the Linear that produced `a` (called with defer_bias=True); its gradient
     (column sums of d loss / d a) is then reduced inside the LayerNorm backward kernel."""

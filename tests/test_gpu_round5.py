@@ -481,7 +481,7 @@ def test_conformer_through_the_engine_matches_bare_model(mode):
     (ops.RelPosAttentionFn.backward): every parameter gradient of the small Conformer equals the bare model's (per-operator launches,
     OTR_GEMM_BATCHED / OTR_POS_DEFER off) up to summation order."""
     import opentransformer_amd as ota
-    from opentransformer_amd import ops, synthetic as syn
+    from opentransformer_amd import ops, synthetic as syn, nn as nn_mod
     from opentransformer_amd.dp import FlatDataParallel
     ops.set_compute_dtype(mode)
     try:
@@ -492,6 +492,7 @@ def test_conformer_through_the_engine_matches_bare_model(mode):
 
         def grads(engine, batched):
             ops._GEMM_BATCHED, ops._POS_DEFER, ops._DW_PART = batched, batched, batched
+            nn_mod._RES_LN = batched
             model = ota.SpeechToText(cfg)
             syn.fill_state_dict_(model.state_dict(), 77)
             model = model.to(DEV).train()
@@ -518,4 +519,56 @@ def test_conformer_through_the_engine_matches_bare_model(mode):
         assert any('pos_proj' in k for k in g0)
     finally:
         ops._GEMM_BATCHED, ops._POS_DEFER, ops._DW_PART = True, True, True
+        nn_mod._RES_LN = True
+        ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp16', 'fp32'])
+@pytest.mark.parametrize('p_drop', [0.0, 0.3])
+def test_residual_layernorm_fn_against_torch(mode, p_drop):
+    """ops.ResidualLnFn: (z, y) = (x + scale dropout(a), LN(z)) and its backward with gradients arriving on BOTH outputs, against torch
+    autograd on the same maths; with dropout the mask is read back from z and must be the one the backward pass regenerates."""
+    from opentransformer_amd import ops
+    ops.set_compute_dtype(mode)
+    try:
+        M, d, scale = 333, 384, 0.5
+        gen = torch.Generator().manual_seed(5)
+        rnd = lambda *sh: torch.randn(*sh, generator=gen).to(DEV)      # noqa: E731
+        adt = ops.act_dtype()
+        x = rnd(M, d).requires_grad_(True)
+        a = rnd(M, d).to(adt).requires_grad_(True)
+        gamma, beta = (1 + 0.1 * rnd(d)).requires_grad_(True), (0.1 * rnd(d)).requires_grad_(True)
+        gz, gy = rnd(M, d), rnd(M, d)
+        z, y = ops.residual_layernorm(x, a, scale, p_drop, gamma, beta, 1e-5)
+        if mode == 'fp16':
+            assert ops.lp_of(y) is not None and torch.equal(ops.lp_of(y).float(), y.to(adt).float())
+        ((z * gz).sum() + (y * gy).sum()).backward()
+        af = a.detach().float()
+        if p_drop > 0:
+            m = ((z.detach() - x.detach()).abs() > 0).float()
+            keep = float(m[af.abs() > 1e-3].mean())
+            assert abs(keep - (1 - p_drop)) < 0.01, keep
+            m = m / (1 - p_drop)
+        else:
+            m = torch.ones_like(af)
+        xr, ar = x.detach().clone().requires_grad_(True), af.clone().requires_grad_(True)
+        gr, br = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+        zr = xr + scale * m * ar
+        yr = F.layer_norm(zr, (d,), gr, br, 1e-5)
+        ((zr * gz).sum() + (yr * gy).sum()).backward()
+        tol = dict(rtol=2e-3, atol=2e-3) if mode == 'fp16' else dict(rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(z.detach(), zr.detach(), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(y.detach(), yr.detach(), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(x.grad, xr.grad, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(a.grad.float(), ar.grad, **tol)
+        torch.testing.assert_close(gamma.grad, gr.grad, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(beta.grad, br.grad, rtol=1e-3, atol=1e-3)
+        # only one of the two outputs used
+        x.grad = None
+        z2, y2 = ops.residual_layernorm(x, a, scale, 0.0, gamma, beta, 1e-5)
+        (y2 * gy).sum().backward()
+        xr.grad = None
+        F.layer_norm(xr + scale * ar, (d,), gr, br, 1e-5).mul(gy).sum().backward()
+        torch.testing.assert_close(x.grad, xr.grad, rtol=1e-4, atol=1e-4)
+    finally:
         ops.set_compute_dtype('bf16')
