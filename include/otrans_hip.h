@@ -348,7 +348,8 @@ int32_t otr_add_layernorm_bwd(const otr_ln_desc_t* d, const float* dy, const flo
 int64_t otr_add_layernorm_bwd_partial_rows(int64_t M);
 /* the same with dx = skip + (gradient w.r.t. the LayerNorm input), skip f32 [M,d] or NULL: a pre-norm residual
  * x + f(LN(x)) (encoder/conformer.py:50-73; normalize_before layers) hands x two gradients, and this saves the elementwise
- * add autograd would launch to join them.  skip may alias dx. */
+ * add autograd would launch to join them.  skip may alias dx.  With a branch (da != NULL) the skip gradient is part of the
+ * gradient of the sum x + a_scale * dropout(a): da = a_scale * dropout'(skip + LayerNorm input gradient) (r05, ops.ResidualLnFn). */
 int32_t otr_add_layernorm_bwd_skip(const otr_ln_desc_t* d, const float* dy, const float* z, const float* mean,
                                    const float* rstd, const float* gamma, const uint64_t* seed, const float* skip, float* dx,
                                    void* da, float* dgamma, float* dbeta, float* da_colsum, float* partial, void* stream);

@@ -160,15 +160,13 @@ template <class AT, bool HAS_A, int NV> __global__ __launch_bounds__(256) void a
           float dz[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) dz[e] = rstd[rr] * (dyv[rr][i][e] * gam[i][e] - s1 - zh[rr][i][e] * s2);
-          if (p.skip) {
+          if (p.skip) {                                   // the gradient that reaches z from the residual stream: part of dz for dx AND da
             float sk[4];
             ld4<float>(p.skip + row * d + col, sk);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sk[e] += dz[e];
-            st4<float>(p.dx + row * d + col, sk);
-          } else {
-            st4<float>(p.dx + row * d + col, dz);
+            for (int e = 0; e < 4; ++e) dz[e] += sk[e];
           }
+          st4<float>(p.dx + row * d + col, dz);
           if constexpr (HAS_A) {
             if (p.da) {
               float o[4];
