@@ -10,6 +10,8 @@ c $T/graph_gaps.txt $P/${R}_step_sequence.txt
 c $T/step_kernels.json $P/${R}_step_kernels.json
 c $T/pmc_step.json $P/${R}_pmc_step.json; c $T/pmc_step.txt $P/${R}_pmc_step.txt
 c $T/ffn_bench.json $P/${R}_ffn_bench.json
+c $T/conformer_kernels.txt $P/${R}_conformer_kernels.txt; c $T/conformer_step_sequence.txt $P/${R}_conformer_step_sequence.txt
+c $T/decode_kernels.txt $P/${R}_decode_kernels.txt
 c $T/tolerance_cases.jsonl $P/${R}_tolerance_cases.jsonl
 c $T/bench_2rank_onegpu_gloo.log $P/${R}_bench_2rank_onegpu_gloo.log
 [ -f $T/pytest_gpu.log ] && grep -E "passed|failed" $T/pytest_gpu.log | tail -1 > $P/${R}_pytest_gpu.txt

@@ -31,6 +31,15 @@ import json,sys
 d=json.loads(sys.stdin.read()); print(json.dumps({k:d.get(k) for k in ('value','n_gpus','ms_per_step','step_breakdown','INVALID')})[:1500])" ;;
 decode)
   timeout 300 python bench.py --task decode --no-cpu-baseline > $OUT/decode.log 2>&1; grep '^{' $OUT/decode.log | tail -1 > $OUT/decode.json; cut -c1-300 $OUT/decode.json ;;
+ctrace)
+  bash tools/gpu_conformer_trace.sh ${TAG}_c > $OUT/ctrace_stdout.txt 2>&1; cp gpurun_out/${TAG}_c/conformer_kernels.txt gpurun_out/${TAG}_c/graph_gaps.txt $OUT/ 2>/dev/null
+  mv $OUT/graph_gaps.txt $OUT/conformer_step_sequence.txt 2>/dev/null; cp gpurun_out/${TAG}_c/bench_conformer.log $OUT/ 2>/dev/null; head -12 $OUT/conformer_kernels.txt | cut -c1-160 ;;
+dtrace)
+  bash tools/gpu_decode_trace.sh ${TAG}_d > $OUT/dtrace_stdout.txt 2>&1; cp gpurun_out/${TAG}_d/decode_kernels.txt gpurun_out/${TAG}_d/decode.json $OUT/ 2>/dev/null; cut -c1-300 $OUT/decode.json; head -14 $OUT/decode_kernels.txt | cut -c1-160 ;;
+seqtests)
+  # exactly what the driver runs at round end: sequential, stop at the first failure
+  timeout 1500 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest(sequential) exit $?"; tail -3 $OUT/pytest_gpu.log | cut -c1-200
+  cp gpurun_out/parity_*.json gpurun_out/decode_validity_*.json gpurun_out/tolerance_cases.jsonl gpurun_out/decode_eos_live_*.json $OUT/ 2>/dev/null ;;
 ffn)
   timeout 300 python tools/ffn_bench.py --mode fp16 > $OUT/ffn_bench.log 2>&1; grep '^{' $OUT/ffn_bench.log | tail -1 > $OUT/ffn_bench.json; cut -c1-300 $OUT/ffn_bench.json ;;
 esac
