@@ -1070,7 +1070,8 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
   int ks = 1;
   if (big && t128 >= 256) {
     ks = 1;
-  } else if (big && t128 * splits_for(t128) >= 192) {   // (126 tiles x 2 slices = 252 workgroups is a full wave of CUs)
+  } else if (big && t128 * splits_for(t128) >= 180) {   // (126 tiles x 2 slices = 252 workgroups is a full wave of CUs; r05: 189 -- the
+    // Conformer's input-gradient GEMMs, 7968 x 384 -- is enough too: 64-wide tiles stream twice the operand bytes per flop)
     ks = splits_for(t128);
   } else {
     big = false;
