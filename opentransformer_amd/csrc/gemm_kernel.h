@@ -1070,8 +1070,8 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
   int ks = 1;
   if (big && t128 >= 256) {
     ks = 1;
-  } else if (big && t128 * splits_for(t128) >= 180) {   // (126 tiles x 2 slices = 252 workgroups is a full wave of CUs; r05: 189 -- the
-    // Conformer's input-gradient GEMMs, 7968 x 384 -- is enough too: 64-wide tiles stream twice the operand bytes per flop)
+  } else if (big && t128 * splits_for(t128) >= 192) {   // (126 tiles x 2 slices = 252 workgroups is a full wave of CUs; r05: with 189
+    // -- the Conformer's 7968 x 384 outputs -- on 128-wide tiles the fp32-writing GEMMs gain what the 16-bit-writing ones lose: 12.67 vs 12.59 ms)
     ks = splits_for(t128);
   } else {
     big = false;
