@@ -311,9 +311,14 @@ def _workspace(device):
 
 
 def new_workspace(device):
-    """a second split-K workspace, for launches that run on ANOTHER stream concurrently with the default lane (workspace_lane)"""
+    """the second split-K workspace of this device, for launches that run on ANOTHER stream concurrently with the default lane
+    (workspace_lane).  One per device, shared by everything that forks ONE side stream at a time (recognize.CachedBeamState: the
+    states of different batch shapes never run concurrently)."""
     _workspace(device)
-    return torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
+    side = _state.get('ws_side')
+    if side is None or side.device != device:
+        side = _state['ws_side'] = torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
+    return side
 
 
 @contextlib.contextmanager
