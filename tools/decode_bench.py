@@ -90,7 +90,8 @@ def main(argv=None, emit=True):
     kv_bytes = args.batch * Tm * 2 * 256 * esz * len(model.decoder.blocks)
     step_s = res['cached_hipgraph']['ms_per_step'] * 1e-3
     ach = (wbytes + kv_bytes) / step_s / 1e9
-    out['roofline'] = {'bound': 'hbm', 'kernel': 'one KV-cached decode step (decoder + LM, ~170 launches under one hipGraph)',
+    out['roofline'] = {'bound': 'hbm', 'kernel': 'one KV-cached decode step (decoder + LM: 34 launches under one hipGraph, 23 on the decoder chain; r04: ~140)',
+                       'note': 'a chain of dependent launches over <= 80 workgroups: the bound that binds is the launch chain (DESIGN.md 5.7), the HBM figure is the weight stream once per step',
                        'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0, 'traffic': None,
                        'algorithmic_bytes': wbytes + kv_bytes, 'avg_launch_ms': res['cached_hipgraph']['ms_per_step']}
     if not args.no_cpu_baseline:
