@@ -354,6 +354,18 @@ int32_t otr_add_layernorm_bwd_skip(const otr_ln_desc_t* d, const float* dy, cons
                                    const float* rstd, const float* gamma, const uint64_t* seed, const float* skip, float* dx,
                                    void* da, float* dgamma, float* dbeta, float* da_colsum, float* partial, void* stream);
 
+/* Two LayerNorms back to back, y2 = LN2(LN1(x + a_scale * dropout(a))) -- encoder/conformer.py:87-89 (post_ffn_norm, then final_norm, on
+ * the result of the convolution branch's residual add) -- in one launch each way (r05).  Forward writes y2 (+ 16-bit twin), the pre-norm
+ * sum z and both LayerNorms' row statistics; backward takes d y2, recomputes y1 = LN1(z) from z / mean / rstd, and leaves
+ * partial f32 [otr_add_layernorm_bwd_partial_rows(M)][5 d] = per-workgroup sums of dgamma | dbeta | da | dgamma2 | dbeta2 (the
+ * caller column-sums them).  skip / dx / da as otr_add_layernorm_bwd_skip. */
+int32_t otr_add_layernorm2_fwd(const otr_ln_desc_t* d, const float* x, const void* a, const float* gamma, const float* beta,
+                               const float* gamma2, const float* beta2, const uint64_t* seed, float* y2, void* y2_bf16, float* z,
+                               float* mean, float* rstd, float* mean2, float* rstd2, void* stream);
+int32_t otr_add_layernorm2_bwd(const otr_ln_desc_t* d, const float* dy2, const float* z, const float* mean, const float* rstd,
+                               const float* gamma, const float* beta, const float* mean2, const float* rstd2, const float* gamma2,
+                               const uint64_t* seed, const float* skip, float* dx, void* da, float* partial, void* stream);
+
 /* ---- F.glu / F.relu on the FFN hidden (module/ffn.py:15-21,40): u[M,F] = h[:, :F]*sigmoid(h[:, F:]) */
 /* row_mask (uint8 [M], may be NULL): rows with mask 0 produce u = 0 / dh = 0 (module/conformer.py:46) */
 int32_t otr_glu_fwd(const void* h, void* u, int32_t dtype, int64_t M, int64_t F, const uint8_t* row_mask, void* stream);

@@ -13,6 +13,9 @@ struct LnArgs {
   uint64_t rng_offset;
   const float* skip;                                      // backward: dx = skip + LayerNorm input gradient (pre-norm residual)
   float a_scale;                                          // the branch enters as a_scale * dropout(a) (encoder/conformer.py:56: 0.5 * ffn)
+  // a SECOND LayerNorm on the first one's output, y2 = LN2(LN1(z)) (encoder/conformer.py:87-89: post_ffn_norm, then final_norm), r05:
+  // forward writes y2 (and its twin) instead of y1 plus mean2 / rstd2; backward takes d y2 and recomputes y1 from z / mean / rstd
+  const float* gamma2; const float* beta2; float* mean2; float* rstd2;
 };
 
 constexpr int LN_MAXV = 4;  // float4 per lane -> d <= 1024
@@ -36,7 +39,7 @@ __device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, uint32_
   return otr_rand32(seed, idx) >= thr ? inv_keep : 0.f;
 }
 
-template <class AT, bool HAS_A> __global__ __launch_bounds__(256) void add_ln_fwd_kernel(LnArgs p) {
+template <class AT, bool HAS_A, bool LN2 = false> __global__ __launch_bounds__(256) void add_ln_fwd_kernel(LnArgs p) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wid;
   if (row >= p.M) return;
@@ -76,6 +79,46 @@ template <class AT, bool HAS_A> __global__ __launch_bounds__(256) void add_ln_fw
     }
   }
   const float rstd = rsqrtf(wave_sum(q) / d + p.eps);
+  if constexpr (LN2) {
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      int col = (i * 64 + lane) * 4;
+      if (col < d) {
+        float g[4], bta[4];
+        ld4<float>(p.gamma + col, g);
+        ld4<float>(p.beta + col, bta);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][e] = (v[i][e] - mean) * rstd * g[e] + bta[e]; s2 += v[i][e]; }   // y1, in place
+      }
+    }
+    const float mean2 = wave_sum(s2) / d;
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      int col = (i * 64 + lane) * 4;
+      if (col < d) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float t = v[i][e] - mean2; q2 += t * t; }
+      }
+    }
+    const float rstd2 = rsqrtf(wave_sum(q2) / d + p.eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      int col = (i * 64 + lane) * 4;
+      if (col < d) {
+        float g[4], bta[4], o[4];
+        ld4<float>(p.gamma2 + col, g);
+        ld4<float>(p.beta2 + col, bta);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean2) * rstd2 * g[e] + bta[e];
+        st4<float>(p.y + row * d + col, o);
+        if (p.y_lp) st4<bf16_t>(p.y_lp + row * d + col, o);
+      }
+    }
+    if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; p.mean2[row] = mean2; p.rstd2[row] = rstd2; }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     int col = (i * 64 + lane) * 4;
@@ -98,7 +141,7 @@ constexpr int LN_BWD_ROWS = 4;  // rows per wave -> 16 rows per block: 498 block
 // NV = ceil(d / 256): float4 slots per lane actually used (d = 256 -> 1).  Each wave owns LN_BWD_ROWS rows; the loads of
 // ALL of them (dy, z, mean, rstd) are issued back to back before any arithmetic (rows clamped, tails masked), so a
 // wave has 2*LN_BWD_ROWS*NV 16-byte loads in flight instead of walking the rows one dependent round trip at a time.
-template <class AT, bool HAS_A, int NV> __global__ __launch_bounds__(256) void add_ln_bwd_kernel(LnArgs p) {
+template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bounds__(256) void add_ln_bwd_kernel(LnArgs p) {
   __shared__ float red[2][4][NV * 256];  // [gamma|beta][wave][column]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int d = p.d;
@@ -119,17 +162,60 @@ template <class AT, bool HAS_A, int NV> __global__ __launch_bounds__(256) void a
     for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; dab[i][e] = 0.f; }
     ld4<float>(p.gamma + colv[i], gam[i]);
   }
+  // LN2: p.dy is d y2; gam2 / bet1 and the second LayerNorm's saved statistics turn it into d y1 below, its affine sums go to
+  // partial[...][3d .. 5d) (dgamma2 | dbeta2)
+  float gam2[NV][4], bet1[NV][4], dg2[NV][4], db2[NV][4];
+  if constexpr (LN2) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      ld4<float>(p.gamma2 + colv[i], gam2[i]);
+      ld4<float>(p.beta + colv[i], bet1[i]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { dg2[i][e] = 0.f; db2[i][e] = 0.f; }
+    }
+  }
   const int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * LN_BWD_ROWS;
   float dyv[LN_BWD_ROWS][NV][4], zh[LN_BWD_ROWS][NV][4], mean[LN_BWD_ROWS], rstd[LN_BWD_ROWS];
+  float mean2[LN_BWD_ROWS], rstd2[LN_BWD_ROWS];
 #pragma unroll
   for (int rr = 0; rr < LN_BWD_ROWS; ++rr) {
     const int64_t row = min(row0 + rr, p.M - 1);
     mean[rr] = p.mean[row];
     rstd[rr] = p.rstd[row];
+    if constexpr (LN2) { mean2[rr] = p.mean2[row]; rstd2[rr] = p.rstd2[row]; }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       ld4<float>(p.dy + row * d + colv[i], dyv[rr][i]);
       ld4<float>(p.zin + row * d + colv[i], zh[rr][i]);
+    }
+  }
+  if constexpr (LN2) {
+    // d y2 -> d y1 through the second LayerNorm: y1 = zhat gamma + beta (recomputed), yhat = (y1 - mean2) rstd2
+#pragma unroll
+    for (int rr = 0; rr < LN_BWD_ROWS; ++rr) {
+      const float rmask = row0 + rr < p.M ? 1.f : 0.f;
+      float yh[NV][4], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const float w = rmask * cmask[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float y1 = (zh[rr][i][e] - mean[rr]) * rstd[rr] * gam[i][e] + bet1[i][e];
+          yh[i][e] = (y1 - mean2[rr]) * rstd2[rr];
+          const float dy2 = dyv[rr][i][e] * w;
+          const float g = dy2 * gam2[i][e];
+          t1 += g; t2 += g * yh[i][e];
+          dg2[i][e] += dy2 * yh[i][e];
+          db2[i][e] += dy2;
+          dyv[rr][i][e] = g;                                 // d y2 . gamma2, finished below
+        }
+      }
+      t1 = wave_sum(t1) / d;
+      t2 = wave_sum(t2) / d;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dyv[rr][i][e] = rstd2[rr] * (dyv[rr][i][e] - t1 - yh[i][e] * t2);   // d y1
     }
   }
 #pragma unroll
@@ -195,12 +281,27 @@ template <class AT, bool HAS_A, int NV> __global__ __launch_bounds__(256) void a
   // partial != NULL: this workgroup's sums go to partial[blockIdx.x][0|1|2][d] (dgamma | dbeta | da column sums) and the
   // caller column-sums the blocks (with everything else, in the grouped launch at the end of backward): no atomics --
   // they were 2.7 of this kernel's 14 us -- and a deterministic result
-  float* prow = p.partial ? p.partial + (int64_t)blockIdx.x * 3 * d : nullptr;
+  float* prow = p.partial ? p.partial + (int64_t)blockIdx.x * (LN2 ? 5 : 3) * d : nullptr;
   for (int c = threadIdx.x; c < d; c += 256) {
     float a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
     float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
     if (prow) { prow[c] = a; prow[d + c] = b; }
     else { atomicAdd(p.dgamma + c, a); atomicAdd(p.dbeta + c, b); }
+  }
+  if constexpr (LN2) {                                     // dgamma2 | dbeta2 -> partial columns [3d, 5d) (partial is required here)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[0][wid][(i * 64 + lane) * 4 + e] = dg2[i][e];
+        red[1][wid][(i * 64 + lane) * 4 + e] = db2[i][e];
+      }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+      prow[3 * d + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+      prow[4 * d + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    }
   }
   if constexpr (HAS_A) {
     // column sums of da = the bias gradient of the Linear that produced the branch (saves its colsum launch)
@@ -279,6 +380,56 @@ extern "C" int32_t otr_add_layernorm_bwd_skip(const otr_ln_desc_t* d, const floa
   if (nv == 1) LN_BWD_LAUNCH(1) else if (nv == 2) LN_BWD_LAUNCH(2) else if (nv == 3) LN_BWD_LAUNCH(3) else LN_BWD_LAUNCH(4)
 #undef LN_BWD_LAUNCH
   return otr_check_launch("add_layernorm_bwd");
+}
+
+// y2 = LN2(LN1(x + a_scale dropout(a))): two LayerNorms back to back in one launch each way (encoder/conformer.py:87-89)
+extern "C" int32_t otr_add_layernorm2_fwd(const otr_ln_desc_t* d, const float* x, const void* a, const float* gamma, const float* beta,
+                                          const float* gamma2, const float* beta2, const uint64_t* seed, float* y2, void* y2_bf16,
+                                          float* z, float* mean, float* rstd, float* mean2, float* rstd2, void* stream) {
+  if (int32_t e = ln_check(d)) return e;
+  OTR_REQUIRE(x && gamma && beta && gamma2 && beta2 && y2 && mean && rstd && mean2 && rstd2, "add_layernorm2_fwd: null pointer");
+  OTR_REQUIRE(d->p_drop == 0.f || (a && seed), "add_layernorm2_fwd: dropout needs a and seed");
+  if (d->M == 0) return 0;
+  LnArgs p{};
+  p.x = x; p.a = a; p.gamma = gamma; p.beta = beta; p.gamma2 = gamma2; p.beta2 = beta2; p.seed = seed; p.y = y2; p.z = z;
+  p.mean = mean; p.rstd = rstd; p.mean2 = mean2; p.rstd2 = rstd2; p.y_lp = (bf16_t*)y2_bf16;
+  p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
+  p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale;
+  dim3 grid((unsigned)((d->M + 3) / 4));
+  hipStream_t s = (hipStream_t)stream;
+  if (!a) hipLaunchKernelGGL((add_ln_fwd_kernel<float, false, true>), grid, dim3(256), 0, s, p);
+  else if (d->a_dtype == OTR_F32) hipLaunchKernelGGL((add_ln_fwd_kernel<float, true, true>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t, true, true>), grid, dim3(256), 0, s, p);
+  return otr_check_launch("add_layernorm2_fwd");
+}
+
+// dy2 -> dx (= skip + d z), da; partial f32 [otr_add_layernorm_bwd_partial_rows(M)][5 d]: dgamma | dbeta | da column sums | dgamma2 | dbeta2
+extern "C" int32_t otr_add_layernorm2_bwd(const otr_ln_desc_t* d, const float* dy2, const float* z, const float* mean, const float* rstd,
+                                          const float* gamma, const float* beta, const float* mean2, const float* rstd2,
+                                          const float* gamma2, const uint64_t* seed, const float* skip, float* dx, void* da,
+                                          float* partial, void* stream) {
+  if (int32_t e = ln_check(d)) return e;
+  OTR_REQUIRE(dy2 && z && mean && rstd && gamma && beta && mean2 && rstd2 && gamma2 && dx && partial, "add_layernorm2_bwd: null pointer");
+  OTR_REQUIRE(d->p_drop == 0.f || seed, "add_layernorm2_bwd: dropout needs seed");
+  if (d->M == 0) return 0;
+  LnArgs p{};
+  p.dy = dy2; p.zin = z; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd); p.gamma = gamma; p.beta = beta;
+  p.mean2 = const_cast<float*>(mean2); p.rstd2 = const_cast<float*>(rstd2); p.gamma2 = gamma2;
+  p.seed = seed; p.skip = skip; p.dx = dx; p.da = da; p.partial = partial;
+  p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
+  p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale;
+  dim3 grid((unsigned)((d->M + 4 * LN_BWD_ROWS - 1) / (4 * LN_BWD_ROWS)));
+  hipStream_t s = (hipStream_t)stream;
+#define LN2_BWD_LAUNCH(NV)                                                                                        \
+  {                                                                                                               \
+    if (!da) hipLaunchKernelGGL((add_ln_bwd_kernel<float, false, NV, true>), grid, dim3(256), 0, s, p);           \
+    else if (d->a_dtype == OTR_F32) hipLaunchKernelGGL((add_ln_bwd_kernel<float, true, NV, true>), grid, dim3(256), 0, s, p); \
+    else hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t, true, NV, true>), grid, dim3(256), 0, s, p);               \
+  }
+  const int nv = (d->d + 255) / 256;
+  if (nv == 1) LN2_BWD_LAUNCH(1) else if (nv == 2) LN2_BWD_LAUNCH(2) else if (nv == 3) LN2_BWD_LAUNCH(3) else LN2_BWD_LAUNCH(4)
+#undef LN2_BWD_LAUNCH
+  return otr_check_launch("add_layernorm2_bwd");
 }
 
 // rows of the `partial` buffer of otr_add_layernorm_bwd for M input rows

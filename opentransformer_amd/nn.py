@@ -25,6 +25,7 @@ import torch.nn as nn
 
 from . import ops
 
+_LN2 = os.environ.get('OTR_LN2', '1') != '0'                   # ... and post_ffn_norm + final_norm in one launch each way
 _RES_LN = os.environ.get('OTR_RESIDUAL_LN', '1') != '0'     # ConformerEncoderBlock: residual adds fused into the LayerNorms that follow them
 
 PAD, BLK, BOS, EOS = 0, 0, 1, 1       # otrans/data/__init__.py:7-12
@@ -528,7 +529,10 @@ class ConformerEncoderBlock(nn.Module):
         n = self.conv_norm
         x, h = ops.residual_layernorm(x, a, 1.0, p, n.weight, n.bias, n.eps)
         a = self.conv(h, mask)
-        n = self.post_ffn_norm
+        n, n2 = self.post_ffn_norm, self.final_norm
+        if _LN2 and n.eps == n2.eps:                    # the two closing LayerNorms in the same launches (otr_add_layernorm2_*)
+            _, y = ops.residual_layernorm(x, a, 1.0, p, n.weight, n.bias, n.eps, None, n2.weight, n2.bias)
+            return y, {'slf_attn_weights': None}
         _, y = ops.residual_layernorm(x, a, 1.0, p, n.weight, n.bias, n.eps)
         return self._ln(self.final_norm, y), {'slf_attn_weights': None}
 

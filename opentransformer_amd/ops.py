@@ -1484,10 +1484,12 @@ class ResidualLnFn(torch.autograd.Function):
     (otr_add_layernorm_fwd with a_scale, z is the launch's saved pre-norm sum) and one backward (otr_add_layernorm_bwd_skip: the
     gradient that reaches z from the residual stream is the `skip` operand; dx = skip + LayerNorm input gradient, da = scale *
     dropout'(dx)).  It was residual_add + add_layernorm: 36 + 36 launches of 5-7 us per Conformer step more.  `link`: x is also
-    the input of the LayerNorm at the head of the branch that produced a (PreNormLink); its gradient goes there, as in ResidualAddFn."""
+    the input of the LayerNorm at the head of the branch that produced a (PreNormLink); its gradient goes there, as in ResidualAddFn.
+    gamma2 / beta2: a SECOND LayerNorm on the first one's output in the same launches, y = LN2(LN1(z)) (encoder/conformer.py:87-89:
+    post_ffn_norm, then final_norm; otr_add_layernorm2_fwd / _bwd)."""
 
     @staticmethod
-    def forward(ctx, x, a, scale, p_drop, gamma, beta, eps, link=None):
+    def forward(ctx, x, a, scale, p_drop, gamma, beta, eps, link=None, gamma2=None, beta2=None):
         _cuda(x, a, gamma, beta)
         ctx.set_materialize_grads(False)
         ctx.link = link if (link is not None and link.armed and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]) else None
@@ -1502,11 +1504,19 @@ class ResidualLnFn(torch.autograd.Function):
         seed = rng_seed_tensor(x.device) if p_drop > 0 else None
         off = _next_rng_offset(M * d) if p_drop > 0 else 0
         desc = L.LnDesc(M, d, _code(a2.dtype), eps, p_drop, off, scale)
-        L.check(L.load().otr_add_layernorm_fwd(C.byref(desc), _p(x2), _p(a2), _p(gamma), _p(beta), _p(seed), _p(y), _p(ylp), _p(z),
-                                               _p(mean), _p(rstd), _stream()), 'otr_add_layernorm_fwd')
-        ctx.save_for_backward(z, mean, rstd, gamma, seed)
-        ctx.g_ref, ctx.b_ref = gamma, beta
-        ctx.cfg = (M, d, a2.dtype, eps, p_drop, off, scale, x.shape, a.shape)
+        two = gamma2 is not None
+        if two:
+            mean2, rstd2 = torch.empty_like(mean), torch.empty_like(mean)
+            L.check(L.load().otr_add_layernorm2_fwd(C.byref(desc), _p(x2), _p(a2), _p(gamma), _p(beta), _p(gamma2), _p(beta2), _p(seed), _p(y),
+                                                    _p(ylp), _p(z), _p(mean), _p(rstd), _p(mean2), _p(rstd2), _stream()),
+                    'otr_add_layernorm2_fwd')
+            ctx.save_for_backward(z, mean, rstd, gamma, seed, beta, mean2, rstd2, gamma2)
+        else:
+            L.check(L.load().otr_add_layernorm_fwd(C.byref(desc), _p(x2), _p(a2), _p(gamma), _p(beta), _p(seed), _p(y), _p(ylp), _p(z),
+                                                   _p(mean), _p(rstd), _stream()), 'otr_add_layernorm_fwd')
+            ctx.save_for_backward(z, mean, rstd, gamma, seed)
+        ctx.g_ref, ctx.b_ref, ctx.g2_ref, ctx.b2_ref = gamma, beta, gamma2, beta2
+        ctx.cfg = (M, d, a2.dtype, eps, p_drop, off, scale, x.shape, a.shape, two)
         if ylp is None:
             return z.view(x.shape), y.view(x.shape), None
         ylp = ylp.view(x.shape)
@@ -1516,38 +1526,64 @@ class ResidualLnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz, dy, _dylp=None):
         if dz is None and dy is None:
-            return (None,) * 8
-        z, mean, rstd, gamma, seed = ctx.saved_tensors
-        M, d, adt, eps, p_drop, off, scale, xshape, ashape = ctx.cfg
+            return (None,) * 10
+        M, d, adt, eps, p_drop, off, scale, xshape, ashape, two = ctx.cfg
+        if two:
+            z, mean, rstd, gamma, seed, beta, mean2, rstd2, gamma2 = ctx.saved_tensors
+        else:
+            z, mean, rstd, gamma, seed = ctx.saved_tensors
         dy2 = dy.reshape(-1, d).contiguous() if dy is not None else torch.zeros((M, d), dtype=torch.float32, device=z.device)
         skip = dz.reshape(-1, d).contiguous() if dz is not None else None
         dx = torch.empty_like(dy2)
         da = torch.empty((M, d), dtype=adt, device=z.device)
-        gg, gb = grad_target(ctx.g_ref), grad_target(ctx.b_ref)
-        inplace = gg is not None and gb is not None
-        if not inplace:
-            dgb = torch.zeros((2, d), dtype=torch.float32, device=z.device)
-            gg, gb = dgb[0], dgb[1]
-        part = None
-        if inplace and _wq['on'] and _in_backward() and d % 4 == 0:
-            part = torch.empty((L.load().otr_add_layernorm_bwd_partial_rows(M), 3 * d), dtype=torch.float32, device=z.device)
+        refs = (ctx.g_ref, ctx.b_ref) + ((ctx.g2_ref, ctx.b2_ref) if two else ())
+        targets = [grad_target(r) for r in refs]
+        inplace = all(t is not None for t in targets)
+        lib = L.load()
         desc = L.LnDesc(M, d, _code(adt), eps, p_drop, off, scale)
-        L.check(L.load().otr_add_layernorm_bwd_skip(C.byref(desc), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed), _p(skip),
-                                                    _p(dx), _p(da), _p(gg), _p(gb), None, _p(part), _stream()), 'otr_add_layernorm_bwd')
-        if part is not None:
-            colsum_raw(part[:, :d], out=gg)
-            colsum_raw(part[:, d:2 * d], out=gb)
+        ret = [None] * len(refs)
+        if two:
+            part = torch.empty((lib.otr_add_layernorm_bwd_partial_rows(M), 5 * d), dtype=torch.float32, device=z.device)
+            L.check(lib.otr_add_layernorm2_bwd(C.byref(desc), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(mean2), _p(rstd2),
+                                               _p(gamma2), _p(seed), _p(skip), _p(dx), _p(da), _p(part), _stream()), 'otr_add_layernorm2_bwd')
+            cols = (0, 1, 3, 4)                       # dgamma | dbeta | (da sums) | dgamma2 | dbeta2
+            if inplace and _wq['on'] and _in_backward() and d % 4 == 0:
+                for t, c in zip(targets, cols):
+                    colsum_raw(part[:, c * d:(c + 1) * d], out=t)
+            else:
+                sums = part.sum(0)
+                for i, (t, c) in enumerate(zip(targets, cols)):
+                    if inplace:
+                        t.add_(sums[c * d:(c + 1) * d])
+                    else:
+                        ret[i] = sums[c * d:(c + 1) * d]
+        else:
+            gg, gb = targets
+            if not inplace:
+                dgb = torch.zeros((2, d), dtype=torch.float32, device=z.device)
+                gg, gb = dgb[0], dgb[1]
+                ret = [gg, gb]
+            part = None
+            if inplace and _wq['on'] and _in_backward() and d % 4 == 0:
+                part = torch.empty((lib.otr_add_layernorm_bwd_partial_rows(M), 3 * d), dtype=torch.float32, device=z.device)
+            L.check(lib.otr_add_layernorm_bwd_skip(C.byref(desc), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(seed), _p(skip),
+                                                   _p(dx), _p(da), _p(gg), _p(gb), None, _p(part), _stream()), 'otr_add_layernorm_bwd')
+            if part is not None:
+                colsum_raw(part[:, :d], out=gg)
+                colsum_raw(part[:, d:2 * d], out=gb)
         dx_ret = dx.view(xshape)
         if ctx.link is not None:
             ctx.link.buf = dx
             _park(ctx.link)
             dx_ret = None
-        return dx_ret, da.view(ashape), None, None, None if inplace else gg, None if inplace else gb, None, None
+        g2 = (ret[2], ret[3]) if two else (None, None)
+        return dx_ret, da.view(ashape), None, None, ret[0], ret[1], None, None, g2[0], g2[1]
 
 
-def residual_layernorm(x, a, scale, p_drop, gamma, beta, eps=1e-5, link=None):
-    """(x + scale * dropout(a), LayerNorm of that sum [with its 16-bit twin]) in one launch: ResidualLnFn"""
-    z, y, ylp = ResidualLnFn.apply(x, a, float(scale), float(p_drop), gamma, beta, float(eps), link)
+def residual_layernorm(x, a, scale, p_drop, gamma, beta, eps=1e-5, link=None, gamma2=None, beta2=None):
+    """(x + scale * dropout(a), LayerNorm of that sum [with its 16-bit twin]) in one launch: ResidualLnFn; with gamma2 / beta2 the
+    second value is LN2(LN1(sum))"""
+    z, y, ylp = ResidualLnFn.apply(x, a, float(scale), float(p_drop), gamma, beta, float(eps), link, gamma2, beta2)
     return z, attach_lp(y, ylp)
 
 

@@ -492,7 +492,7 @@ def test_conformer_through_the_engine_matches_bare_model(mode):
 
         def grads(engine, batched):
             ops._GEMM_BATCHED, ops._POS_DEFER, ops._DW_PART = batched, batched, batched
-            nn_mod._RES_LN = batched
+            nn_mod._RES_LN = nn_mod._LN2 = batched
             model = ota.SpeechToText(cfg)
             syn.fill_state_dict_(model.state_dict(), 77)
             model = model.to(DEV).train()
@@ -519,7 +519,7 @@ def test_conformer_through_the_engine_matches_bare_model(mode):
         assert any('pos_proj' in k for k in g0)
     finally:
         ops._GEMM_BATCHED, ops._POS_DEFER, ops._DW_PART = True, True, True
-        nn_mod._RES_LN = True
+        nn_mod._RES_LN = nn_mod._LN2 = True
         ops.set_compute_dtype('bf16')
 
 
@@ -570,5 +570,39 @@ def test_residual_layernorm_fn_against_torch(mode, p_drop):
         xr.grad = None
         F.layer_norm(xr + scale * ar, (d,), gr, br, 1e-5).mul(gy).sum().backward()
         torch.testing.assert_close(x.grad, xr.grad, rtol=1e-4, atol=1e-4)
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp16', 'fp32'])
+@pytest.mark.parametrize('d,M', [(384, 333), (256, 50), (640, 77)])
+def test_residual_double_layernorm_against_torch(mode, d, M):
+    """ops.ResidualLnFn with a second LayerNorm, y = LN2(LN1(x + scale a)) (encoder/conformer.py:87-89 post_ffn_norm + final_norm):
+    otr_add_layernorm2_fwd / _bwd against torch autograd, gradients on both outputs, all four affine gradients."""
+    from opentransformer_amd import ops
+    ops.set_compute_dtype(mode)
+    try:
+        scale = 1.0
+        gen = torch.Generator().manual_seed(d + M)
+        rnd = lambda *sh: torch.randn(*sh, generator=gen).to(DEV)      # noqa: E731
+        adt = ops.act_dtype()
+        x = rnd(M, d).requires_grad_(True)
+        a = rnd(M, d).to(adt).requires_grad_(True)
+        g1, b1 = (1 + 0.2 * rnd(d)).requires_grad_(True), (0.3 * rnd(d)).requires_grad_(True)
+        g2, b2 = (1 + 0.2 * rnd(d)).requires_grad_(True), (0.3 * rnd(d)).requires_grad_(True)
+        gz, gy = rnd(M, d), rnd(M, d)
+        z, y = ops.residual_layernorm(x, a, scale, 0.0, g1, b1, 1e-5, None, g2, b2)
+        ((z * gz).sum() + (y * gy).sum()).backward()
+        ref = [t.detach().float().clone().requires_grad_(True) for t in (x, a, g1, b1, g2, b2)]
+        zr = ref[0] + scale * ref[1]
+        yr = F.layer_norm(F.layer_norm(zr, (d,), ref[2], ref[3], 1e-5), (d,), ref[4], ref[5], 1e-5)
+        ((zr * gz).sum() + (yr * gy).sum()).backward()
+        torch.testing.assert_close(z.detach(), zr.detach(), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(y.detach(), yr.detach(), rtol=2e-4, atol=2e-4)
+        torch.testing.assert_close(x.grad, ref[0].grad, rtol=5e-4, atol=5e-4)
+        tol = dict(rtol=3e-3, atol=3e-3) if mode == 'fp16' else dict(rtol=5e-4, atol=5e-4)
+        torch.testing.assert_close(a.grad.float(), ref[1].grad, **tol)
+        for got, want, nm in zip((g1, b1, g2, b2), ref[2:], ('gamma', 'beta', 'gamma2', 'beta2')):
+            torch.testing.assert_close(got.grad, want.grad, rtol=2e-3, atol=2e-3, msg=lambda m, nm=nm: nm + ': ' + m)
     finally:
         ops.set_compute_dtype('bf16')
