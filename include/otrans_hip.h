@@ -331,6 +331,8 @@ typedef struct {
   float eps, p_drop;            /* p_drop = 0 -> no dropout */
   uint64_t rng_offset;
   float a_scale;                /* r05: y = LN(x + a_scale * dropout(a)), da = a_scale * dropout'(dz); 0 means 1 (older callers) */
+  const uint8_t* a_row_mask;    /* r05: [M] or NULL; rows with 0 take no branch: a row := 0 forward, da row := 0 backward (the
+                                 * masked_fill of module/conformer.py:109 folded into the residual add that consumes the branch) */
 } otr_ln_desc_t;
 /* y_bf16 (may be NULL): bf16 copy of y, the GEMM-operand form of the residual stream */
 int32_t otr_add_layernorm_fwd(const otr_ln_desc_t* d, const float* x, const void* a, const float* gamma,

@@ -16,6 +16,7 @@ struct LnArgs {
   // a SECOND LayerNorm on the first one's output, y2 = LN2(LN1(z)) (encoder/conformer.py:87-89: post_ffn_norm, then final_norm), r05:
   // forward writes y2 (and its twin) instead of y1 plus mean2 / rstd2; backward takes d y2 and recomputes y1 from z / mean / rstd
   const float* gamma2; const float* beta2; float* mean2; float* rstd2;
+  const uint8_t* amask;                                   // [M] or NULL: rows with 0 take no branch (a row := 0; da row := 0): module/conformer.py:109
 };
 
 constexpr int LN_MAXV = 4;  // float4 per lane -> d <= 1024
@@ -50,6 +51,7 @@ template <class AT, bool HAS_A, bool LN2 = false> __global__ __launch_bounds__(2
   const float inv_keep = (drop ? 1.f / (1.f - p.p_drop) : 1.f) * p.a_scale;
   float v[LN_MAXV][4];
   float s = 0.f;
+  const float am = (HAS_A && p.amask) ? (p.amask[row] ? 1.f : 0.f) : 1.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     int col = (i * 64 + lane) * 4;
@@ -61,7 +63,7 @@ template <class AT, bool HAS_A, bool LN2 = false> __global__ __launch_bounds__(2
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float sc = drop ? drop_scale(seed, p.rng_offset + (uint64_t)(row * d + col + e), thr, inv_keep) : inv_keep;
-          v[i][e] += a[e] * sc;
+          v[i][e] += a[e] * sc * am;
         }
       }
       if (p.z) st4<float>(p.z + row * d + col, v[i]);
@@ -255,11 +257,12 @@ template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bo
           st4<float>(p.dx + row * d + col, dz);
           if constexpr (HAS_A) {
             if (p.da) {
+              const float am = p.amask ? (p.amask[row] ? 1.f : 0.f) : 1.f;
               float o[4];
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 float sc = drop ? drop_scale(seed, p.rng_offset + (uint64_t)(row * d + col + e), thr, inv_keep) : inv_keep;
-                o[e] = dz[e] * sc;
+                o[e] = dz[e] * sc * am;
                 dab[i][e] += o[e];
               }
               st4<AT>(reinterpret_cast<AT*>(p.da) + row * d + col, o);
@@ -340,7 +343,7 @@ extern "C" int32_t otr_add_layernorm_fwd(const otr_ln_desc_t* d, const float* x,
   LnArgs p{};
   p.x = x; p.a = a; p.gamma = gamma; p.beta = beta; p.seed = seed; p.y = y; p.z = z; p.mean = mean; p.rstd = rstd; p.y_lp = (bf16_t*)y_bf16;
   p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
-  p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale;
+  p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale; p.amask = d->a_row_mask;
   dim3 grid((unsigned)((d->M + 3) / 4));
   hipStream_t s = (hipStream_t)stream;
   if (!a) hipLaunchKernelGGL((add_ln_fwd_kernel<float, false>), grid, dim3(256), 0, s, p);
@@ -367,7 +370,7 @@ extern "C" int32_t otr_add_layernorm_bwd_skip(const otr_ln_desc_t* d, const floa
   p.dy = dy; p.zin = z; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd); p.gamma = gamma;
   p.seed = seed; p.skip = skip; p.dx = dx; p.da = da; p.dgamma = dgamma; p.dbeta = dbeta; p.da_colsum = da ? da_colsum : nullptr; p.partial = partial;
   p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
-  p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale;
+  p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale; p.amask = d->a_row_mask;
   dim3 grid((unsigned)((d->M + 4 * LN_BWD_ROWS - 1) / (4 * LN_BWD_ROWS)));
   hipStream_t s = (hipStream_t)stream;
 #define LN_BWD_LAUNCH(NV)                                                                                   \
@@ -394,7 +397,7 @@ extern "C" int32_t otr_add_layernorm2_fwd(const otr_ln_desc_t* d, const float* x
   p.x = x; p.a = a; p.gamma = gamma; p.beta = beta; p.gamma2 = gamma2; p.beta2 = beta2; p.seed = seed; p.y = y2; p.z = z;
   p.mean = mean; p.rstd = rstd; p.mean2 = mean2; p.rstd2 = rstd2; p.y_lp = (bf16_t*)y2_bf16;
   p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
-  p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale;
+  p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale; p.amask = d->a_row_mask;
   dim3 grid((unsigned)((d->M + 3) / 4));
   hipStream_t s = (hipStream_t)stream;
   if (!a) hipLaunchKernelGGL((add_ln_fwd_kernel<float, false, true>), grid, dim3(256), 0, s, p);
@@ -417,7 +420,7 @@ extern "C" int32_t otr_add_layernorm2_bwd(const otr_ln_desc_t* d, const float* d
   p.mean2 = const_cast<float*>(mean2); p.rstd2 = const_cast<float*>(rstd2); p.gamma2 = gamma2;
   p.seed = seed; p.skip = skip; p.dx = dx; p.da = da; p.partial = partial;
   p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
-  p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale;
+  p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale; p.amask = d->a_row_mask;
   dim3 grid((unsigned)((d->M + 4 * LN_BWD_ROWS - 1) / (4 * LN_BWD_ROWS)));
   hipStream_t s = (hipStream_t)stream;
 #define LN2_BWD_LAUNCH(NV)                                                                                        \

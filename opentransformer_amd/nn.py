@@ -25,6 +25,7 @@ import torch.nn as nn
 
 from . import ops
 
+_MASK_FOLD = os.environ.get('OTR_CONV_MASK_FOLD', '1') != '0'  # ... and the convolution branch's row mask applied by that launch
 _LN2 = os.environ.get('OTR_LN2', '1') != '0'                   # ... and post_ffn_norm + final_norm in one launch each way
 _RES_LN = os.environ.get('OTR_RESIDUAL_LN', '1') != '0'     # ConformerEncoderBlock: residual adds fused into the LayerNorms that follow them
 
@@ -460,13 +461,14 @@ class ConformerConvolutionModule(nn.Module):
         self.pointwise_conv2 = nn.Linear(channels, channels, bias=bias)
         self.tick_later = None                    # a list (not a module attribute of tensors): see ConformerEncoder.forward
 
-    def forward(self, x, mask):
+    def forward(self, x, mask, mask_out=True):
+        """mask_out False: the caller zeroes the padded frames' rows of the result (and of its gradient) itself -- ops.ResidualLnFn(a_mask)"""
         bn = self.batch_norm
         B, T, _ = x.shape
         out = ops.ConformerConvFn.apply(x, ops._mask_u8(mask, B, T).reshape(-1), self.pointwise_conv1.weight,
                                         self.pointwise_conv1.bias, self.depthwise_conv.weight, self.depthwise_conv.bias,
                                         bn.weight, bn.bias, bn.running_mean, bn.running_var, self.pointwise_conv2.weight,
-                                        self.pointwise_conv2.bias, self.training, bn.eps, bn.momentum)
+                                        self.pointwise_conv2.bias, self.training, bn.eps, bn.momentum, mask_out)
         if self.training:
             if self.tick_later is not None:
                 self.tick_later.append(bn.num_batches_tracked)     # ConformerEncoder adds 1 to all of them in one launch
@@ -528,12 +530,13 @@ class ConformerEncoderBlock(nn.Module):
         a = self.mha(h, km, pos)[0] if self.relative_positional else self.mha(h, km)[0]
         n = self.conv_norm
         x, h = ops.residual_layernorm(x, a, 1.0, p, n.weight, n.bias, n.eps)
-        a = self.conv(h, mask)
+        am = ops._mask_u8(mask, mask.shape[0], mask.shape[1]).reshape(-1) if _MASK_FOLD else None
+        a = self.conv(h, mask, mask_out=am is None)      # the padded frames' rows are zeroed by the residual launch below
         n, n2 = self.post_ffn_norm, self.final_norm
         if _LN2 and n.eps == n2.eps:                    # the two closing LayerNorms in the same launches (otr_add_layernorm2_*)
-            _, y = ops.residual_layernorm(x, a, 1.0, p, n.weight, n.bias, n.eps, None, n2.weight, n2.bias)
+            _, y = ops.residual_layernorm(x, a, 1.0, p, n.weight, n.bias, n.eps, None, n2.weight, n2.bias, a_mask=am)
             return y, {'slf_attn_weights': None}
-        _, y = ops.residual_layernorm(x, a, 1.0, p, n.weight, n.bias, n.eps)
+        _, y = ops.residual_layernorm(x, a, 1.0, p, n.weight, n.bias, n.eps, a_mask=am)
         return self._ln(self.final_norm, y), {'slf_attn_weights': None}
 
     def forward(self, x, mask, pos=None):

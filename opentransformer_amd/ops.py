@@ -1489,9 +1489,10 @@ class ResidualLnFn(torch.autograd.Function):
     post_ffn_norm, then final_norm; otr_add_layernorm2_fwd / _bwd)."""
 
     @staticmethod
-    def forward(ctx, x, a, scale, p_drop, gamma, beta, eps, link=None, gamma2=None, beta2=None):
+    def forward(ctx, x, a, scale, p_drop, gamma, beta, eps, link=None, gamma2=None, beta2=None, a_mask=None):
         _cuda(x, a, gamma, beta)
         ctx.set_materialize_grads(False)
+        ctx.a_mask = a_mask                # uint8 [M]: rows with 0 take no branch (module/conformer.py:109), forward and backward
         ctx.link = link if (link is not None and link.armed and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]) else None
         d = x.shape[-1]
         x2 = x.reshape(-1, d).contiguous()
@@ -1503,7 +1504,7 @@ class ResidualLnFn(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         seed = rng_seed_tensor(x.device) if p_drop > 0 else None
         off = _next_rng_offset(M * d) if p_drop > 0 else 0
-        desc = L.LnDesc(M, d, _code(a2.dtype), eps, p_drop, off, scale)
+        desc = L.LnDesc(M, d, _code(a2.dtype), eps, p_drop, off, scale, a_mask.data_ptr() if a_mask is not None else None)
         two = gamma2 is not None
         if two:
             mean2, rstd2 = torch.empty_like(mean), torch.empty_like(mean)
@@ -1526,7 +1527,7 @@ class ResidualLnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz, dy, _dylp=None):
         if dz is None and dy is None:
-            return (None,) * 10
+            return (None,) * 11
         M, d, adt, eps, p_drop, off, scale, xshape, ashape, two = ctx.cfg
         if two:
             z, mean, rstd, gamma, seed, beta, mean2, rstd2, gamma2 = ctx.saved_tensors
@@ -1540,7 +1541,7 @@ class ResidualLnFn(torch.autograd.Function):
         targets = [grad_target(r) for r in refs]
         inplace = all(t is not None for t in targets)
         lib = L.load()
-        desc = L.LnDesc(M, d, _code(adt), eps, p_drop, off, scale)
+        desc = L.LnDesc(M, d, _code(adt), eps, p_drop, off, scale, ctx.a_mask.data_ptr() if ctx.a_mask is not None else None)
         ret = [None] * len(refs)
         if two:
             part = torch.empty((lib.otr_add_layernorm_bwd_partial_rows(M), 5 * d), dtype=torch.float32, device=z.device)
@@ -1577,13 +1578,13 @@ class ResidualLnFn(torch.autograd.Function):
             _park(ctx.link)
             dx_ret = None
         g2 = (ret[2], ret[3]) if two else (None, None)
-        return dx_ret, da.view(ashape), None, None, ret[0], ret[1], None, None, g2[0], g2[1]
+        return dx_ret, da.view(ashape), None, None, ret[0], ret[1], None, None, g2[0], g2[1], None
 
 
-def residual_layernorm(x, a, scale, p_drop, gamma, beta, eps=1e-5, link=None, gamma2=None, beta2=None):
+def residual_layernorm(x, a, scale, p_drop, gamma, beta, eps=1e-5, link=None, gamma2=None, beta2=None, a_mask=None):
     """(x + scale * dropout(a), LayerNorm of that sum [with its 16-bit twin]) in one launch: ResidualLnFn; with gamma2 / beta2 the
-    second value is LN2(LN1(sum))"""
-    z, y, ylp = ResidualLnFn.apply(x, a, float(scale), float(p_drop), gamma, beta, float(eps), link, gamma2, beta2)
+    second value is LN2(LN1(sum)); a_mask (uint8, one per row): rows with 0 take no branch"""
+    z, y, ylp = ResidualLnFn.apply(x, a, float(scale), float(p_drop), gamma, beta, float(eps), link, gamma2, beta2, a_mask)
     return z, attach_lp(y, ylp)
 
 
@@ -2923,7 +2924,7 @@ class ConformerConvFn(torch.autograd.Function):
     zero padded frames."""
 
     @staticmethod
-    def forward(ctx, x, mask_u8, w1, b1, wdw, bdw, gamma, beta, run_mean, run_var, w2, b2, training, eps, momentum):
+    def forward(ctx, x, mask_u8, w1, b1, wdw, bdw, gamma, beta, run_mean, run_var, w2, b2, training, eps, momentum, mask_out=True):
         _cuda(x, w1, wdw, gamma, beta, w2)
         B, T, Cc = x.shape
         M = B * T
@@ -2954,8 +2955,14 @@ class ConformerConvFn(torch.autograd.Function):
         # the branch leaves in the activation type (the residual add takes it as such): its gradient then arrives in that
         # type too, so the w_2 weight / bias gradients join the deferred 256-wide launch instead of an fp32-operand GEMM each
         o = linear_fwd_raw(s, w2c, b2, adt)
-        out = torch.empty_like(o)
-        L.check(lib.otr_row_mask_cast(_p(o), _code(adt), _p(mask_u8), _p(out), _code(adt), M, Cc, _stream()), 'otr_row_mask_cast')
+        # mask_out False: the consumer zeroes the padded frames' rows of this branch and of its gradient itself (ResidualLnFn a_mask:
+        # the masked_fill of module/conformer.py:109 and its mirror in backward were a launch each)
+        ctx.mask_out = bool(mask_out)
+        if mask_out:
+            out = torch.empty_like(o)
+            L.check(lib.otr_row_mask_cast(_p(o), _code(adt), _p(mask_u8), _p(out), _code(adt), M, Cc, _stream()), 'otr_row_mask_cast')
+        else:
+            out = o
         ctx.save_for_backward(x2, mask_u8, w1c, wk, gamma, beta, w2c, h, g, y, saved, s)
         ctx.cfg = (B, T, Cc, k, training, x.shape, x.dtype, bdw is not None, wdw.shape)
         return out.view(B, T, Cc)
@@ -2968,8 +2975,11 @@ class ConformerConvFn(torch.autograd.Function):
         adt = s.dtype
         lib = L.load()
         dout = dout.contiguous()
-        dm = torch.empty((M, Cc), dtype=adt, device=dout.device)
-        L.check(lib.otr_row_mask_cast(_p(dout), _code(dout.dtype), _p(mask_u8), _p(dm), _code(adt), M, Cc, _stream()), 'otr_row_mask_cast')
+        if not ctx.mask_out and dout.dtype == adt:
+            dm = dout.view(M, Cc)                           # masked by the producer of this gradient (ResidualLnFn a_mask)
+        else:
+            dm = torch.empty((M, Cc), dtype=adt, device=dout.device)
+            L.check(lib.otr_row_mask_cast(_p(dout), _code(dout.dtype), _p(mask_u8), _p(dm), _code(adt), M, Cc, _stream()), 'otr_row_mask_cast')
         w1p, b1p, w2p, b2p = ctx.refs
         gw1, gb1, gw2, gb2 = grad_target(w1p), grad_target(b1p), grad_target(w2p), grad_target(b2p)
         ds = linear_fwd_raw(dm, ctx.w2t, None, adt) if ctx.w2t is not None else linear_dgrad_raw(dm, w2c, adt)
@@ -3013,7 +3023,7 @@ class ConformerConvFn(torch.autograd.Function):
                 None if dw_inplace else dwk[:Cc * k].view(wdw_shape), dwk[Cc * k:] if (has_dwb and not dw_inplace) else None,
                 None if bn_inplace else red[Cc:], None if bn_inplace else red[:Cc], None, None,
                 None if gw2 is not None else dw2,
-                None if gb2 is not None else db2, None, None, None)
+                None if gb2 is not None else db2, None, None, None, None)
 
 
 class LookaheadConvFn(torch.autograd.Function):

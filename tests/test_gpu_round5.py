@@ -492,7 +492,7 @@ def test_conformer_through_the_engine_matches_bare_model(mode):
 
         def grads(engine, batched):
             ops._GEMM_BATCHED, ops._POS_DEFER, ops._DW_PART = batched, batched, batched
-            nn_mod._RES_LN = nn_mod._LN2 = batched
+            nn_mod._RES_LN = nn_mod._LN2 = nn_mod._MASK_FOLD = batched
             model = ota.SpeechToText(cfg)
             syn.fill_state_dict_(model.state_dict(), 77)
             model = model.to(DEV).train()
@@ -519,7 +519,7 @@ def test_conformer_through_the_engine_matches_bare_model(mode):
         assert any('pos_proj' in k for k in g0)
     finally:
         ops._GEMM_BATCHED, ops._POS_DEFER, ops._DW_PART = True, True, True
-        nn_mod._RES_LN = nn_mod._LN2 = True
+        nn_mod._RES_LN = nn_mod._LN2 = nn_mod._MASK_FOLD = True
         ops.set_compute_dtype('bf16')
 
 
@@ -591,10 +591,11 @@ def test_residual_double_layernorm_against_torch(mode, d, M):
         g1, b1 = (1 + 0.2 * rnd(d)).requires_grad_(True), (0.3 * rnd(d)).requires_grad_(True)
         g2, b2 = (1 + 0.2 * rnd(d)).requires_grad_(True), (0.3 * rnd(d)).requires_grad_(True)
         gz, gy = rnd(M, d), rnd(M, d)
-        z, y = ops.residual_layernorm(x, a, scale, 0.0, g1, b1, 1e-5, None, g2, b2)
+        am = (torch.rand(M, generator=gen) > 0.3).to(DEV, torch.uint8)      # rows that take no branch (a_mask)
+        z, y = ops.residual_layernorm(x, a, scale, 0.0, g1, b1, 1e-5, None, g2, b2, a_mask=am)
         ((z * gz).sum() + (y * gy).sum()).backward()
         ref = [t.detach().float().clone().requires_grad_(True) for t in (x, a, g1, b1, g2, b2)]
-        zr = ref[0] + scale * ref[1]
+        zr = ref[0] + scale * ref[1] * am.float()[:, None]
         yr = F.layer_norm(F.layer_norm(zr, (d,), ref[2], ref[3], 1e-5), (d,), ref[4], ref[5], 1e-5)
         ((zr * gz).sum() + (yr * gy).sum()).backward()
         torch.testing.assert_close(z.detach(), zr.detach(), rtol=1e-6, atol=1e-6)
