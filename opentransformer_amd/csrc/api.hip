@@ -338,7 +338,9 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
       if (int32_t e = otr_linear_wgrad(&d, it.dy, it.x, it.dw, workspace, workspace_bytes, stream)) return e;
       continue;
     }
-    const int big = (it.N >= 128 && it.K >= 128) ? 1 : 0;
+    // (K >= 96: the relative-position attention's dp products, 504 x 96 over 7968 rows of an fp32 operand, are bound by reading that
+    //  operand -- twice on 64-wide tiles, once on 128-wide ones, a quarter of whose MFMA columns then idle: r05)
+    const int big = (it.N >= 128 && it.K >= 96) ? 1 : 0;
     order[(big << 2) | ((it.dy_dtype != OTR_F32) << 1) | (it.x_dtype != OTR_F32)].push_back(i);   // dtype codes -> 0 / 1
   }
   for (int key = 4; key < 8; ++key) {
