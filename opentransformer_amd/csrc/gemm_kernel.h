@@ -1045,7 +1045,8 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
       const bool fast = a.a_vec && a.b_vec && (a.K % CE == 0) && ((uintptr_t)a.C % 16 == 0) && (a.ldc % (16 / (int)sizeof(OT)) == 0) &&
                         (a.bsa % 16 == 0) && (a.bsb % 16 == 0) && (a.bsc % 16 == 0) && !a.accumulate && !a.bias && a.act == OTR_ACT_NONE;
       if (!fast) return 1;                                            // not served: the caller loops over otr_linear_fwd
-      const bool big = a.M >= 128 && a.N >= 128 && t128 * a.nbatch >= 256;
+      // (N >= 96: d(q+v)_h = dbd_h p_h reads its fp32 operand once per column tile -- 96 columns are one 128-wide tile or two 64-wide ones)
+      const bool big = a.M >= 128 && a.N >= 96 && t128 * a.nbatch >= 240;
       a.ksplit = 1;
       if (big) hipLaunchKernelGGL((gemm_batched_kernel<CT, AT, BT, OT, 128, 128>), dim3((unsigned)t128, 1, (unsigned)a.nbatch), dim3(256), 0, s, a);
       else hipLaunchKernelGGL((gemm_batched_kernel<CT, AT, BT, OT, 64, 64>), dim3((unsigned)t64, 1, (unsigned)a.nbatch), dim3(256), 0, s, a);
