@@ -588,7 +588,9 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnArgs& p, const int 
         pt[qt][r] = pe;
         float dsv = pe * (dp[r] - sDel[ql]) * p.scale;
         ds[qt][r] = dsv;
-        if (p.dbias && ok) p.dbias[bias_index(p, b, h, qg, key)] = dsv;   // unique (i, col): plain store
+        // unique (i, col): plain store.  EVERY in-range (query, key) pair is written, masked ones with 0: a caller that keeps the
+        // gradient tensor across steps (ops.RelPosAttentionFn: zeroed once, not per step) never finds a stale entry in the band
+        if (p.dbias && key < p.Tk && qg < p.Tq) p.dbias[bias_index(p, b, h, qg, key)] = ok ? dsv : 0.f;
       }
     }
 #pragma unroll

@@ -2823,6 +2823,27 @@ def _zero_padded_rows(t2, rows):
     return hit[0]
 
 
+_DBD_PERSIST = os.environ.get('OTR_DBD_PERSIST', '1') != '0'
+_DBD_CACHE = {}
+
+
+def _persistent_dbd(owner, like):
+    """The gradient tensor of the relative-position score term, [B, T, H, Pp] fp32 (64 MB per Conformer block at the bench batch).  Only its
+    band (column j - i + T - 1 of row i) is ever non-zero, and the attention backward rewrites EVERY in-range band entry (masked pairs
+    with 0), so the tensor is zeroed ONCE per (layer, shape) and kept: the per-step zero fill was 10.5 us x 12 blocks.  Keyed by the
+    layer's pos_proj weight; a few shapes per layer are kept (ragged batches), the oldest dropped."""
+    if not _DBD_PERSIST:
+        return torch.zeros_like(like)
+    key = (owner.data_ptr(), tuple(like.shape), str(like.device))
+    hit = _DBD_CACHE.get(key)
+    if hit is None:
+        mine = [k for k in _DBD_CACHE if k[0] == key[0]]
+        if len(mine) >= 2:
+            _DBD_CACHE.pop(mine[0])
+        hit = _DBD_CACHE[key] = torch.zeros_like(like)
+    return hit
+
+
 class RelPosAttentionFn(torch.autograd.Function):
     """MultiHeadedSelfAttentionWithRelPos.forward after the qvk projection (module/attention.py:217-253):
     softmax(((q+u) k^T + shift((q+v) p^T)) / sqrt(dk)) v with p = pos_proj(sinusoid[-(T-1)..T-1]).
@@ -2873,7 +2894,7 @@ class RelPosAttentionFn(torch.autograd.Function):
         adt = qkv.dtype
         lib = L.load()
         dout = dout.contiguous()
-        dbd = torch.zeros_like(bd)
+        dbd = _persistent_dbd(pos_w, bd)
         dquv = torch.empty_like(quv)
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)

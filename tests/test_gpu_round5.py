@@ -607,3 +607,44 @@ def test_residual_double_layernorm_against_torch(mode, d, M):
             torch.testing.assert_close(got.grad, want.grad, rtol=2e-3, atol=2e-3, msg=lambda m, nm=nm: nm + ': ' + m)
     finally:
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp16', 'fp32'])
+def test_relpos_attention_gradient_tensor_kept_across_steps(mode):
+    """ops.RelPosAttentionFn keeps the gradient tensor of the score term across steps (zeroed once: `_persistent_dbd`); the attention
+    backward rewrites every in-range band entry, so a second pass with a DIFFERENT key mask (and different data) on the same module
+    gives the gradients a fresh tensor gives (OTR_DBD_PERSIST off)."""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops, synthetic as syn
+    from opentransformer_amd.nn import relative_sinusoid
+    ops.set_compute_dtype(mode)
+    try:
+        B, T, H, dk = 3, 70, 4, 96
+        d = H * dk
+        mod = ota.MultiHeadedSelfAttentionWithRelPos(H, d).to(DEV)
+        syn.fill_state_dict_(mod.state_dict(), 5)
+        pos = relative_sinusoid(T, d, DEV)
+        gen = torch.Generator().manual_seed(3)
+
+        def run(seed, valid, persist):
+            ops._DBD_PERSIST = persist
+            x = (torch.randn(B, T, d, generator=torch.Generator().manual_seed(seed)) * 0.5).to(DEV).requires_grad_(True)
+            mask = torch.zeros(B, 1, T, dtype=torch.bool, device=DEV)
+            for b, n in enumerate(valid):
+                mask[b, 0, :n] = True
+            out, _ = mod(x, mask, pos)
+            g = torch.randn(B, T, d, generator=torch.Generator().manual_seed(seed + 1)).to(DEV).to(out.dtype)
+            names = ['qvk_proj.weight', 'pos_proj.weight', 'posu', 'posv']
+            params = dict(mod.named_parameters())
+            return [t.float().clone() for t in torch.autograd.grad(out, [x] + [params[n] for n in names], g)]
+
+        ops._DBD_CACHE.clear()
+        run(11, [70, 70, 70], True)                     # fills the whole band of the kept tensor
+        second = run(12, [70, 41, 9], True)             # most of it masked now: stale entries would show up in every gradient
+        assert len(ops._DBD_CACHE) == 1
+        fresh = run(12, [70, 41, 9], False)
+        for a, b in zip(second, fresh):
+            assert torch.equal(a, b)
+    finally:
+        ops._DBD_PERSIST = True
+        ops.set_compute_dtype('bf16')
