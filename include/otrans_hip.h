@@ -543,6 +543,15 @@ int32_t otr_dwconv_bwd_part(const float* dy, const void* g, int32_t dtype, const
 int32_t otr_bn_swish_fwd(const float* y, const float* stats, const float* gamma, const float* beta, float* running_mean,
                          float* running_var, float* saved, void* out, int32_t out_dtype, int64_t M, int32_t C, float eps,
                          float momentum, int32_t training, void* stream);
+/* r05: the BatchNorm batch statistics without a zeroing launch and without atomics: otr_dwconv_fwd_part leaves the depthwise
+ * convolution's per-workgroup sums in spart [otr_dwconv_fwd_partial_rows(B*T)][sum y (C) | sum y^2 (C)], otr_bn_swish_fwd_part adds
+ * them up in its statistics launch (training mode; module/conformer.py:40-46,103-110). */
+int64_t otr_dwconv_fwd_partial_rows(int64_t M);
+int32_t otr_dwconv_fwd_part(const void* g, int32_t dtype, const float* w, const float* bias, float* y, float* spart, int32_t B, int32_t T,
+                            int32_t C, int32_t k, int32_t pad, void* stream);
+int32_t otr_bn_swish_fwd_part(const float* y, const float* spart, int32_t nblk, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, float* saved, void* out, int32_t out_dtype, int64_t M, int32_t C, float eps,
+                              float momentum, void* stream);
 /* red f32 [2C]: on return d beta | d gamma of THIS call; dy f32 [M,C] = gradient w.r.t. the BatchNorm input.
  * partial: f32 scratch [otr_bn_swish_bwd_partial_rows(M)][2C] (per-strip sums: no atomics, deterministic).
  * dgamma_acc / dbeta_acc (f32 [C], may be NULL): the parameter gradients, += the same sums in the reduction launch. */

@@ -198,6 +198,7 @@ struct DwArgs {
   const void* g; const float* w; const float* b; float* y; float* stats;
   const float* dy; void* dg; float* dw; float* db;
   float* part;           // backward: per-workgroup sums [blocks][C*k | C] instead of atomics on dw / db (the caller column-sums them)
+  float* spart;          // forward: per-workgroup BatchNorm sums [blocks][sum y (C) | sum y^2 (C)] instead of atomics on stats
   int B, T, C, k, pad;   // pad = taps left of the output position ((k-1)/2: 'same' conv; 0: look-ahead conv)
 };
 
@@ -259,7 +260,7 @@ template <class T, int KT> __global__ __launch_bounds__(256) void dwconv_fwd_ker
       if (++t == p.T) t = 0;
     }
   }
-  if (p.stats) {
+  if (p.stats || p.spart) {
     if (active) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { dw_red[(ty * p.C + c + e) * 2] = s1[e]; dw_red[(ty * p.C + c + e) * 2 + 1] = s2[e]; }
@@ -269,7 +270,8 @@ template <class T, int KT> __global__ __launch_bounds__(256) void dwconv_fwd_ker
       const int ch = i >> 1, which = i & 1;
       float a = 0.f;
       for (int y = 0; y < NY; ++y) a += dw_red[(y * p.C + ch) * 2 + which];
-      atomicAdd(p.stats + which * p.C + ch, a);
+      if (p.spart) p.spart[(int64_t)blockIdx.x * 2 * p.C + which * p.C + ch] = a;
+      else atomicAdd(p.stats + which * p.C + ch, a);
     }
   }
 }
@@ -362,11 +364,27 @@ static int32_t dw_check(int B, int T, int C, int k, int pad) {
   OTR_REQUIRE(pad >= 0 && pad < k, "dwconv: pad %d must be in [0, k)", pad);
   return 0;
 }
+extern "C" int64_t otr_dwconv_fwd_partial_rows(int64_t M) { return (M + DW_RPB - 1) / DW_RPB; }
+
+static int32_t dwconv_fwd_launch(const void* g, int32_t dtype, const float* w, const float* bias, float* y, float* stats, float* spart,
+                                 int32_t B, int32_t T, int32_t C, int32_t k, int32_t pad, void* stream);
+
 extern "C" int32_t otr_dwconv_fwd(const void* g, int32_t dtype, const float* w, const float* bias, float* y, float* stats,
                                   int32_t B, int32_t T, int32_t C, int32_t k, int32_t pad, void* stream) {
+  return dwconv_fwd_launch(g, dtype, w, bias, y, stats, nullptr, B, T, C, k, pad, stream);
+}
+
+extern "C" int32_t otr_dwconv_fwd_part(const void* g, int32_t dtype, const float* w, const float* bias, float* y, float* spart,
+                                       int32_t B, int32_t T, int32_t C, int32_t k, int32_t pad, void* stream) {
+  OTR_REQUIRE(spart, "dwconv_fwd_part: null partial buffer");
+  return dwconv_fwd_launch(g, dtype, w, bias, y, nullptr, spart, B, T, C, k, pad, stream);
+}
+
+static int32_t dwconv_fwd_launch(const void* g, int32_t dtype, const float* w, const float* bias, float* y, float* stats, float* spart,
+                                 int32_t B, int32_t T, int32_t C, int32_t k, int32_t pad, void* stream) {
   if (int32_t e = dw_check(B, T, C, k, pad)) return e;
   OTR_REQUIRE(g && w && y, "dwconv_fwd: null pointer");
-  DwArgs p{}; p.g = g; p.w = w; p.b = bias; p.y = y; p.stats = stats; p.B = B; p.T = T; p.C = C; p.k = k; p.pad = pad;
+  DwArgs p{}; p.g = g; p.w = w; p.b = bias; p.y = y; p.stats = stats; p.spart = spart; p.B = B; p.T = T; p.C = C; p.k = k; p.pad = pad;
   hipStream_t s = (hipStream_t)stream;
   if (stats) otr_zero_f32(stats, 2 * C, s);
   const int NY = 256 / (C / 4);
@@ -432,6 +450,31 @@ __global__ void bn_prepare_kernel(const float* stats, float* run_mean, float* ru
   }
   saved[c] = mean;
   saved[C + c] = rsqrtf(var + eps);
+}
+
+// the same from the depthwise convolution's per-workgroup sums spart [nblk][2C] (otr_dwconv_fwd_part: no zeroing launch, no atomics):
+// block = 64 channels x 4 row lanes
+__global__ __launch_bounds__(256) void bn_prepare_part_kernel(const float* spart, int nblk, float* run_mean, float* run_var, float* saved,
+                                                             int C, float n, float eps, float momentum) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C)
+    for (int r = rl; r < nblk; r += 4) { s1 += spart[(int64_t)r * 2 * C + c]; s2 += spart[(int64_t)r * 2 * C + C + c]; }
+  red[0][rl][cl] = s1; red[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    const float mean = s1 / n, var = fmaxf(s2 / n - mean * mean, 0.f);
+    if (run_mean) {
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (n > 1.f ? n / (n - 1.f) : 1.f);
+    }
+    saved[c] = mean;
+    saved[C + c] = rsqrtf(var + eps);
+  }
 }
 
 template <class T> __global__ void bn_swish_fwd_kernel(const float* y, const float* saved, const float* gamma, const float* beta, T* out,
@@ -556,6 +599,21 @@ extern "C" int32_t otr_bn_swish_fwd(const float* y, const float* stats, const fl
   if (out_dtype == OTR_F32) hipLaunchKernelGGL(bn_swish_fwd_kernel<float>, dim3(ew_grid(M * C / 4)), dim3(256), 0, s, y, saved, gamma, beta, (float*)out, M, C);
   else hipLaunchKernelGGL(bn_swish_fwd_kernel<bf16_t>, dim3(ew_grid(M * C / 4)), dim3(256), 0, s, y, saved, gamma, beta, (bf16_t*)out, M, C);
   return otr_check_launch("bn_swish_fwd");
+}
+
+// training only: the batch statistics come as the depthwise convolution's per-workgroup sums (otr_dwconv_fwd_part)
+extern "C" int32_t otr_bn_swish_fwd_part(const float* y, const float* spart, int32_t nblk, const float* gamma, const float* beta,
+                                         float* running_mean, float* running_var, float* saved, void* out, int32_t out_dtype, int64_t M,
+                                         int32_t C, float eps, float momentum, void* stream) {
+  OTR_REQUIRE(y && spart && gamma && beta && saved && out && nblk > 0, "bn_swish_fwd_part: null pointer");
+  OTR_REQUIRE(C % 4 == 0 && M > 0, "bn_swish_fwd_part: bad shape");
+  OTR_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_swish_fwd_part: running statistics come in pairs");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_prepare_part_kernel, dim3((C + 63) / 64), dim3(256), 0, s, spart, nblk, running_mean, running_var, saved, C, (float)M, eps,
+                     momentum);
+  if (out_dtype == OTR_F32) hipLaunchKernelGGL(bn_swish_fwd_kernel<float>, dim3(ew_grid(M * C / 4)), dim3(256), 0, s, y, saved, gamma, beta, (float*)out, M, C);
+  else hipLaunchKernelGGL(bn_swish_fwd_kernel<bf16_t>, dim3(ew_grid(M * C / 4)), dim3(256), 0, s, y, saved, gamma, beta, (bf16_t*)out, M, C);
+  return otr_check_launch("bn_swish_fwd_part");
 }
 
 // red: f32 [2C]; on return red[c] = d beta, red[C + c] = d gamma (this call's sums; also the input of the second pass).

@@ -585,6 +585,7 @@ def flush_weight_grads():
     """Launch everything queued by linear_wgrad_raw / colsum_raw (called by the autograd engine at the end of
     backward; safe to call by hand)."""
     _wq['armed'], _wq['task'] = False, None
+    _wq['dp_pool'] = None                # (the queued items and post hooks keep their slices alive)
     w, b, post = _wq['w'], _wq['b'], _wq['post']
     _wq['w'], _wq['b'], _wq['post'] = [], [], []
     # a gradient buffer that appears twice (one Linear applied twice in the forward pass): the problems of ONE grouped launch run
@@ -2714,6 +2715,7 @@ def _gemm_ptr(kind, M, N, K, x, w, y, bias=None, accumulate=0):
 
 
 _GEMM_BATCHED = os.environ.get('OTR_GEMM_BATCHED', '1') != '0'
+_BN_PART = os.environ.get('OTR_BN_PART', '1') != '0'          # ConformerConvFn: BatchNorm batch statistics through per-workgroup sums
 _DW_PART = os.environ.get('OTR_DWCONV_PART', '1') != '0'      # ConformerConvFn: depthwise-conv parameter gradients through per-workgroup sums
 _POS_DEFER = os.environ.get('OTR_POS_DEFER', '1') != '0'      # RelPosAttentionFn: the per-head dp products join the grouped weight-gradient launch
 
@@ -2823,6 +2825,18 @@ def _zero_padded_rows(t2, rows):
     return hit[0]
 
 
+def _dp_from_pool(Pp, d, device):
+    """a zeroed fp32 [Pp, d] accumulator for RelPosAttentionFn's deferred dp products: slices of one buffer zeroed ONCE per backward pass
+    (16 blocks' worth; the pool belongs to the pass -- flush_weight_grads drops it -- and a second one is made if it runs out)"""
+    task = torch._C._current_graph_task_id()
+    pool = _wq.get('dp_pool')
+    if pool is None or pool[0] != task or pool[2] >= pool[1].shape[0] or tuple(pool[1].shape[1:]) != (Pp, d) or pool[1].device != device:
+        pool = _wq['dp_pool'] = [task, torch.zeros((16, Pp, d), dtype=torch.float32, device=device), 0]
+    i = pool[2]
+    pool[2] += 1
+    return pool[1][i]
+
+
 _DBD_PERSIST = os.environ.get('OTR_DBD_PERSIST', '1') != '0'
 _DBD_CACHE = {}
 
@@ -2912,7 +2926,7 @@ class RelPosAttentionFn(torch.autograd.Function):
         dbd2, quv2 = dbd.view(M, H * Pp), quv.view(M, 2 * d)
         n0 = len(_wq['w'])
         if gw is not None and _wq['on'] and _in_backward() and _POS_DEFER:
-            dp = torch.zeros((Pp, d), dtype=torch.float32, device=qkv.device)
+            dp = _dp_from_pool(Pp, d, qkv.device)       # zeros; one fill per backward pass for all blocks, not one per block
             for h in range(H):
                 linear_wgrad_raw(dbd2[:, h * Pp:(h + 1) * Pp], quv2[:, d + h * dk:d + (h + 1) * dk], None, out=dp[:, h * dk:(h + 1) * dk])
         deferred = len(_wq['w']) == n0 + H
@@ -2966,13 +2980,22 @@ class ConformerConvFn(torch.autograd.Function):
         k = wdw.shape[-1]
         wk = wdw.reshape(Cc, k).contiguous()
         y = torch.empty((M, Cc), dtype=torch.float32, device=x.device)
-        stats = torch.empty((2 * Cc,), dtype=torch.float32, device=x.device) if training else None
-        L.check(lib.otr_dwconv_fwd(_p(g), _code(adt), _p(wk), _p(bdw), _p(y), _p(stats), B, T, Cc, k, (k - 1) // 2, _stream()),
-                'otr_dwconv_fwd')
         saved = torch.empty((2 * Cc,), dtype=torch.float32, device=x.device)
         s = torch.empty((M, Cc), dtype=adt, device=x.device)
-        L.check(lib.otr_bn_swish_fwd(_p(y), _p(stats), _p(gamma), _p(beta), _p(run_mean), _p(run_var), _p(saved), _p(s),
-                                     _code(adt), M, Cc, eps, momentum, int(training), _stream()), 'otr_bn_swish_fwd')
+        if training and _BN_PART:
+            # batch statistics through per-workgroup sums: no zeroing launch, no atomics (otr_dwconv_fwd_part / otr_bn_swish_fwd_part)
+            nblk = lib.otr_dwconv_fwd_partial_rows(M)
+            spart = torch.empty((nblk, 2 * Cc), dtype=torch.float32, device=x.device)
+            L.check(lib.otr_dwconv_fwd_part(_p(g), _code(adt), _p(wk), _p(bdw), _p(y), _p(spart), B, T, Cc, k, (k - 1) // 2, _stream()),
+                    'otr_dwconv_fwd_part')
+            L.check(lib.otr_bn_swish_fwd_part(_p(y), _p(spart), nblk, _p(gamma), _p(beta), _p(run_mean), _p(run_var), _p(saved), _p(s),
+                                              _code(adt), M, Cc, eps, momentum, _stream()), 'otr_bn_swish_fwd_part')
+        else:
+            stats = torch.empty((2 * Cc,), dtype=torch.float32, device=x.device) if training else None
+            L.check(lib.otr_dwconv_fwd(_p(g), _code(adt), _p(wk), _p(bdw), _p(y), _p(stats), B, T, Cc, k, (k - 1) // 2, _stream()),
+                    'otr_dwconv_fwd')
+            L.check(lib.otr_bn_swish_fwd(_p(y), _p(stats), _p(gamma), _p(beta), _p(run_mean), _p(run_var), _p(saved), _p(s),
+                                         _code(adt), M, Cc, eps, momentum, int(training), _stream()), 'otr_bn_swish_fwd')
         # the branch leaves in the activation type (the residual add takes it as such): its gradient then arrives in that
         # type too, so the w_2 weight / bias gradients join the deferred 256-wide launch instead of an fp32-operand GEMM each
         o = linear_fwd_raw(s, w2c, b2, adt)

@@ -113,6 +113,9 @@ def test_argument_errors_of_the_fused_and_grouped_entries():
     assert lib.otr_add_layernorm2_fwd(C.byref(lnd), one, one, one, one, None, one, None, one, None, one, one, one, one, one, None) < 0   # gamma2 missing
     assert lib.otr_add_layernorm2_bwd(C.byref(lnd), one, one, one, one, one, one, one, one, one, None, None, one, one, None, None) < 0   # no partial buffer
     assert b'add_layernorm2_bwd' in lib.otr_last_error_string()
+    assert lib.otr_dwconv_fwd_part(one, hcode, one, None, one, None, 2, 8, 16, 5, 2, None) < 0                 # no partial buffer
+    assert lib.otr_bn_swish_fwd_part(one, one, 0, one, one, None, None, one, one, hcode, 16, 16, 1e-5, 0.1, None) < 0   # no partial rows
+    assert lib.otr_dwconv_fwd_partial_rows(7968) == 249
     ln0 = _lib.DecLn(None, 16, None, 0, None, None, None, None, 0.0, 1e-5, 0, None, None, None, None, None)
     assert lib.otr_dec_self_step(C.byref(ln0), 8, one, one, one, one, one, None, one, 4, one, None) < 0     # ancestor table missing
     assert b'dec_self_step' in lib.otr_last_error_string()

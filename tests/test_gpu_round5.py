@@ -491,7 +491,7 @@ def test_conformer_through_the_engine_matches_bare_model(mode):
         dt = {k: v.to(DEV) for k, v in targets.items()}
 
         def grads(engine, batched):
-            ops._GEMM_BATCHED, ops._POS_DEFER, ops._DW_PART = batched, batched, batched
+            ops._GEMM_BATCHED, ops._POS_DEFER, ops._DW_PART, ops._BN_PART, ops._DBD_PERSIST = batched, batched, batched, batched, batched
             nn_mod._RES_LN = nn_mod._LN2 = nn_mod._MASK_FOLD = batched
             model = ota.SpeechToText(cfg)
             syn.fill_state_dict_(model.state_dict(), 77)
@@ -518,7 +518,7 @@ def test_conformer_through_the_engine_matches_bare_model(mode):
         assert worst[0] < tol, worst
         assert any('pos_proj' in k for k in g0)
     finally:
-        ops._GEMM_BATCHED, ops._POS_DEFER, ops._DW_PART = True, True, True
+        ops._GEMM_BATCHED, ops._POS_DEFER, ops._DW_PART, ops._BN_PART, ops._DBD_PERSIST = True, True, True, True, True
         nn_mod._RES_LN = nn_mod._LN2 = nn_mod._MASK_FOLD = True
         ops.set_compute_dtype('bf16')
 
