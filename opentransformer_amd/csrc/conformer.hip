@@ -453,20 +453,32 @@ __global__ void bn_prepare_kernel(const float* stats, float* run_mean, float* ru
 }
 
 // the same from the depthwise convolution's per-workgroup sums spart [nblk][2C] (otr_dwconv_fwd_part: no zeroing launch, no atomics):
-// block = 64 channels x 4 row lanes
+// block = 16 channels x 16 row lanes, four independent loads in flight per lane (6 blocks of 64 channels x 4 lanes walked 62 rows
+// each, one dependent load after the other: 20 us)
 __global__ __launch_bounds__(256) void bn_prepare_part_kernel(const float* spart, int nblk, float* run_mean, float* run_var, float* saved,
                                                              int C, float n, float eps, float momentum) {
-  __shared__ float red[2][4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  __shared__ float red[2][16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl, cc = min(c, C - 1);
   float s1 = 0.f, s2 = 0.f;
-  if (c < C)
-    for (int r = rl; r < nblk; r += 4) { s1 += spart[(int64_t)r * 2 * C + c]; s2 += spart[(int64_t)r * 2 * C + C + c]; }
+  for (int r0 = rl; r0 < nblk; r0 += 64) {
+    float a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = min(r0 + 16 * u, nblk - 1);
+      a[u] = spart[(int64_t)r * 2 * C + cc];
+      b[u] = spart[(int64_t)r * 2 * C + C + cc];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (r0 + 16 * u < nblk) { s1 += a[u]; s2 += b[u]; }
+  }
   red[0][rl][cl] = s1; red[1][rl][cl] = s2;
   __syncthreads();
   if (rl == 0 && c < C) {
-    s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-    s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { s1 += red[0][q][cl]; s2 += red[1][q][cl]; }
     const float mean = s1 / n, var = fmaxf(s2 / n - mean * mean, 0.f);
     if (run_mean) {
       run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
@@ -609,7 +621,7 @@ extern "C" int32_t otr_bn_swish_fwd_part(const float* y, const float* spart, int
   OTR_REQUIRE(C % 4 == 0 && M > 0, "bn_swish_fwd_part: bad shape");
   OTR_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_swish_fwd_part: running statistics come in pairs");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_prepare_part_kernel, dim3((C + 63) / 64), dim3(256), 0, s, spart, nblk, running_mean, running_var, saved, C, (float)M, eps,
+  hipLaunchKernelGGL(bn_prepare_part_kernel, dim3((C + 15) / 16), dim3(256), 0, s, spart, nblk, running_mean, running_var, saved, C, (float)M, eps,
                      momentum);
   if (out_dtype == OTR_F32) hipLaunchKernelGGL(bn_swish_fwd_kernel<float>, dim3(ew_grid(M * C / 4)), dim3(256), 0, s, y, saved, gamma, beta, (float*)out, M, C);
   else hipLaunchKernelGGL(bn_swish_fwd_kernel<bf16_t>, dim3(ew_grid(M * C / 4)), dim3(256), 0, s, y, saved, gamma, beta, (bf16_t*)out, M, C);
