@@ -63,6 +63,7 @@ struct GemmArgs {
   // batched launch (otr_linear_fwd_batched): problem z = blockIdx.z uses A + z bsa, B + z bsb, C + z bsc (BYTE strides); no split-K
   int nbatch;
   int64_t bsa, bsb, bsc;
+  int xcd_map;       // gemm_tile_of: positions equal modulo 8 share their row blocks of A (set by the launcher)
 };
 
 template <class CT> struct GemmCfg {
@@ -457,6 +458,27 @@ template <class OT> __device__ __noinline__ void store_tail_acc(OT* dst, const O
 // Shared by the plain kernel (blockIdx -> tile) and the grouped kernel (blockIdx -> problem -> tile).
 // EPI: 0 = plain epilogue (bias / ReLU / accumulate), 1 = GLU forward, 2 = GLU backward (own instantiations: their
 // registers must not weigh on the plain kernel -- folded into it they made it spill)
+// Position in the launch -> output tile.  Consecutive workgroup ids go to consecutive XCDs (observed placement, used for locality
+// only), and every XCD has its own L2: in the natural order (column tile fastest) the tiles_n workgroups that read ONE row block of A sit
+// on tiles_n different XCDs and that block crosses the fabric tiles_n times -- the Conformer's 7968 x 384 input-gradient GEMMs moved
+// 127 MB per launch for 24 MB of operands and results (rocprofv3 FETCH_SIZE / WRITE_SIZE, profiles/r05_pmc_conformer.txt), i.e. they
+// were HBM-bound on re-reads.  Here positions that are EQUAL modulo 8 walk the column tiles of the same row blocks: row blocks
+// 8g + (position % 8), column tile fastest.  A bijection of [0, tiles_m * tiles_n) (the last tiles_m % 8 row blocks keep the natural
+// order), so the persistent loop (stride = a multiple of 8) and split-K are untouched.
+extern int g_otr_gemm_xcd_map;   // api.hip (otr_debug_set(26, v)): 0 = the natural order
+__device__ __forceinline__ void gemm_tile_of(int t, int tiles_m, int tiles_n, bool xmap, int& tm, int& tn) {
+  const int full = xmap ? (tiles_m >> 3) * 8 * tiles_n : 0;
+  if (t < full) {
+    const int idx = t >> 3, g = idx / tiles_n;
+    tm = g * 8 + (t & 7);
+    tn = idx - g * tiles_n;
+  } else {
+    const int r = t - full, q = r / tiles_n;
+    tm = (xmap ? (tiles_m & ~7) : 0) + q;
+    tn = r - q * tiles_n;
+  }
+}
+
 template <class CT, class AT, class BT, class OT, int AMODE, int BMODE, int BM, int BN, bool FAST, bool PERSIST, int EPI = 0>
 __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, const int tile_stride, const int kslice) {
   using G = GemmCfg<CT>;
@@ -468,12 +490,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int ntiles = tiles_n * ((p.M + BM - 1) / BM);
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int ntiles = tiles_n * tiles_m;
+  const bool xmap = p.xcd_map != 0;
   // PERSIST (ksplit == 1 only): the grid is capped at the number of resident workgroups and each one walks tiles
   // tile0, +tile_stride, ...; the operand loads of the next tile are issued before the epilogue of the current
   // one, so the ~3 k-cycle stage-in latency and the epilogue overlap instead of adding up per tile.
   int tile = tile0;
-  int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+  int tile_m, tile_n;
+  gemm_tile_of(tile, tiles_m, tiles_n, xmap, tile_m, tile_n);
 
   // k-slice of this workgroup
   const int nk_total = (p.K + BK - 1) / BK;
@@ -659,8 +684,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
     // operands of this workgroup's next tile (clamped: the last round re-loads a valid tile and drops it); issued
     // AFTER the bias loads so that waiting for the bias does not wait for them (vmcnt retires in order)
     const int nxt = min(tile + tile_stride, ntiles - 1);
-    tile_m = nxt / tiles_n;
-    tile_n = nxt - tile_m * tiles_n;
+    gemm_tile_of(nxt, tiles_m, tiles_n, xmap, tile_m, tile_n);
     la.init(p.A, p.lda, p.M, p.K, tile_m * BM, p.a_vec != 0, p.cg, tid);
     lb.init(p.B, p.ldb, p.N, p.K, tile_n * bstep, p.b_vec != 0, p.cg, tid, pairF);
     la.template load<0>(kt0 * BK, p.cg, tid);
@@ -888,8 +912,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
     tile += tile_stride;
     if (tile >= ntiles) break;
     if constexpr (D != 2) {
-      tile_m = tile / tiles_n;
-      tile_n = tile - tile_m * tiles_n;
+      gemm_tile_of(tile, tiles_m, tiles_n, xmap, tile_m, tile_n);
       la.init(p.A, p.lda, p.M, p.K, tile_m * BM, p.a_vec != 0, p.cg, tid);
       lb.init(p.B, p.ldb, p.N, p.K, tile_n * bstep, p.b_vec != 0, p.cg, tid, pairF);
     }
@@ -1091,6 +1114,7 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
     ks = (nk + per - 1) / per;
   }
   a.ksplit = ks;
+  a.xcd_map = g_otr_gemm_xcd_map;
   // branch-free loaders need aligned rows and whole chunks / whole row groups (see TileLoader)
   constexpr int CE = GemmCfg<CT>::CE, PM = GemmCfg<CT>::PM;
   auto side_fast = [&](int mode, int vec, int rows) {

@@ -376,3 +376,28 @@ def test_split_ffn_and_attention_grids_cover_every_unit_once():
         for h, b in ((0, 0), (H - 1, B - 1)):
             sel = (trip[live][:, 1] == h) & (trip[live][:, 2] == b)
             assert len(set((ids[sel] % 8).tolist())) == 1
+
+
+def test_gemm_tile_order_is_a_permutation():
+    """csrc/gemm_kernel.h gemm_tile_of (the XCD-aware position -> tile map of the tile GEMM), emulated: a bijection of
+    [0, tiles_m * tiles_n) for every shape, and positions that are equal modulo 8 walk the column tiles of the same row blocks."""
+    def tile_of(t, tiles_m, tiles_n):
+        full = (tiles_m >> 3) * 8 * tiles_n
+        if t < full:
+            idx = t >> 3
+            g = idx // tiles_n
+            return g * 8 + (t & 7), idx - g * tiles_n
+        r = t - full
+        q = r // tiles_n
+        return (tiles_m & ~7) + q, r - q * tiles_n
+
+    for tiles_m in (1, 7, 8, 9, 16, 63, 125, 189):
+        for tiles_n in (1, 2, 3, 6, 67):
+            seen = {tile_of(t, tiles_m, tiles_n) for t in range(tiles_m * tiles_n)}
+            assert seen == {(m, n) for m in range(tiles_m) for n in range(tiles_n)}, (tiles_m, tiles_n)
+    # 125 row blocks x 6 column tiles (7968 x 384 on 64-wide tiles): the six column tiles of a row block sit on ONE position class
+    cls = {}
+    for t in range(125 * 6):
+        m, n = tile_of(t, 125, 6)
+        cls.setdefault(m, set()).add(t % 8)
+    assert all(len(v) == 1 for m, v in cls.items() if m < 120)
