@@ -461,8 +461,8 @@ template <class OT> __device__ __noinline__ void store_tail_acc(OT* dst, const O
 // Position in the launch -> output tile.  Consecutive workgroup ids go to consecutive XCDs (observed placement, used for locality
 // only), and every XCD has its own L2: in the natural order (column tile fastest) the tiles_n workgroups that read ONE row block of A sit
 // on tiles_n different XCDs and that block crosses the fabric tiles_n times -- the Conformer's 7968 x 384 input-gradient GEMMs moved
-// 127 MB per launch for 24 MB of operands and results (rocprofv3 FETCH_SIZE / WRITE_SIZE, profiles/r05_pmc_conformer.txt), i.e. they
-// were HBM-bound on re-reads.  Here positions that are EQUAL modulo 8 walk the column tiles of the same row blocks: row blocks
+// 127 MB per launch for 24 MB of operands and results (rocprofv3 FETCH_SIZE / WRITE_SIZE, profiles/r05_pmc_conformer_before_xcdmap.txt;
+// 42 MB with this map, profiles/r05_pmc_conformer.txt).  Here positions that are EQUAL modulo 8 walk the column tiles of the same row blocks: row blocks
 // 8g + (position % 8), column tile fastest.  A bijection of [0, tiles_m * tiles_n) (the last tiles_m % 8 row blocks keep the natural
 // order), so the persistent loop (stride = a multiple of 8) and split-K are untouched.
 extern int g_otr_gemm_xcd_map;   // api.hip (otr_debug_set(26, v)): 0 = the natural order
