@@ -925,7 +925,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int tile0, co
 
 template <class CT, class AT, class BT, class OT, int AMODE, int BMODE, int BM, int BN, bool FAST, bool PERSIST = false, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {   // <= 256 VGPRs: two workgroups per CU
-  gemm_body<CT, AT, BT, OT, AMODE, BMODE, BM, BN, FAST, PERSIST, EPI>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
+  int tile0 = (int)blockIdx.x, kslice = (int)blockIdx.y;
+  if (!PERSIST && p.xcd_map && gridDim.y >= 8) {
+    // split-K: the tiles of ONE k-slice read the same slices of both operands (the frontend's weight gradient: 5 column tiles x 48
+    // pixel slices moved 418 MB for 119 MB of operands) -- launched as (tile, k-slice) with the tile fastest they sat on consecutive
+    // XCDs.  Same bijection as gemm_tile_of with the k-slices in the role of the row blocks: ids equal modulo 8 share their k-slices.
+    gemm_tile_of((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.y, (int)gridDim.x, true, kslice, tile0);
+  }
+  gemm_body<CT, AT, BT, OT, AMODE, BMODE, BM, BN, FAST, PERSIST, EPI>(p, tile0, (int)gridDim.x, kslice);
 }
 
 // ------------------------------------------------------------------------------------------------
