@@ -35,6 +35,11 @@ extern "C" {
 #define OTR_ACT_NONE 0
 #define OTR_ACT_RELU 1
 
+/* ABI version of THIS header: bumped whenever a signature, a descriptor struct or the meaning of an argument changes (600: round 6;
+ * 300 was rounds 3-5, during which otr_optimizer_step, otr_ln_desc_t, otr_wgrad_item_t and otr_beam_prune_cached changed without a
+ * bump).  A binding compares otr_version() with the OTR_ABI_VERSION it was written against BEFORE its first call and refuses a
+ * library that answers anything else: descriptors are passed by pointer and read at the library's idea of their size. */
+#define OTR_ABI_VERSION 600
 int32_t otr_version(void);
 /* OTR_BF16 or OTR_F16: the 16-bit type this library was built for */
 int32_t otr_half_type(void);

@@ -14,6 +14,7 @@ LIB_PATHS = {'bf16': os.path.join(_LIB_DIR, 'libotrans_hip.so'), 'fp16': os.path
 LIB_PATH = LIB_PATHS['bf16']
 
 OTR_F32, OTR_BF16, OTR_F16 = 0, 1, 2
+OTR_ABI_VERSION = 600           # include/otrans_hip.h: the header this binding's structures and SIGNATURES were written against
 OTR_OPT_STATE_FLOATS = 528      # include/otrans_hip.h: floats of otr_optimizer_step's device state block
 ACT_NONE, ACT_RELU = 0, 1
 
@@ -233,6 +234,10 @@ def load(kind=None):
             '%s not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
             '(or `make -C opentransformer_amd/csrc`). There is no CPU/PyTorch fallback.' % path)
     lib = C.CDLL(path)
+    lib.otr_version.restype = C.c_int32
+    if lib.otr_version() != OTR_ABI_VERSION:      # a stale build: structures would be read at the wrong size (no call is safe)
+        raise OtransHipError('%s answers ABI version %d, this binding was written against %d (include/otrans_hip.h): rebuild it with '
+                             '`make -C opentransformer_amd/csrc`' % (path, lib.otr_version(), OTR_ABI_VERSION))
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.argtypes = argtypes

@@ -97,7 +97,7 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
 
 extern "C" int32_t otr_set_fault_counter(void* device_word) { g_otr_fault = (int32_t*)device_word; return 0; }
 
-extern "C" int32_t otr_version(void) { return 300; }
+extern "C" int32_t otr_version(void) { return OTR_ABI_VERSION; }
 extern "C" int32_t otr_half_type(void) { return OTR_H16; }
 extern "C" const char* otr_last_error_string(void) { return g_err; }
 

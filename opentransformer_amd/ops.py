@@ -36,12 +36,30 @@ def graph_capture(graph, **kw):
     gc.collect()
     was_enabled = gc.isenabled()
     gc.disable()
+    _capture['serial'] += 1
+    _capture['active'] = _capture['serial']
     try:
         with torch.cuda.graph(graph, **kw):
             yield graph
     finally:
+        _capture['active'] = None
         if was_enabled:
             gc.enable()
+
+
+# Which recording are we in?  Host-side facts about device memory ("this gradient buffer was just cleared") are only true for the
+# launches issued in the SAME context: eagerly, or inside the same capture -- a captured launch is replayed later, any number of
+# times, whatever the host knew when it was recorded.  ('eager',) outside a capture, ('capture', n) inside the n-th graph_capture of
+# this process, None inside a capture somebody else started (torch.cuda.graph used directly): nothing can be assumed there.
+_capture = {'serial': 0, 'active': None}
+
+
+def capture_context():
+    if _capture['active'] is not None:
+        return ('capture', _capture['active'])
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return None
+    return ('eager',)
 
 
 # ---------------------------------------------------------------------------------------- kernel timing hook (bench.py)
@@ -540,8 +558,14 @@ _wq = {'on': False, 'w': [], 'b': [], 'post': [], 'armed': False, 'task': None} 
 # scatter-add lands in the same buffer) -- and tells when it has cleared them.  The first grouped launch that writes such a buffer
 # after a clear may store its sums; every write is recorded, so a second backward pass before the next clear (gradient accumulation)
 # accumulates as before.  Addresses, not tensors: a gradient view and its row-padded image are the same buffer.
-_wq_excl = {'single_writer': set(), 'written': set()}
-_WG_OVERWRITE = os.environ.get('OTR_WGRAD_OVERWRITE', '1') == '1'
+# The store is safe by construction, not by convention: it is taken only when the clear and the launch were issued in the SAME
+# context (capture_context(): both eagerly, or both inside one captured graph).  A launch captured WITHOUT its clear always
+# accumulates -- replaying a captured forward + backward twice between two eager zero_grad() calls (graph-based gradient accumulation)
+# therefore adds up, like the biases and LayerNorm gradients do.  Anything else that adds into a registered buffer between the clear and
+# the first grouped launch (an autograd AccumulateGrad of a torch-native use of the weight, a hook, user code) must say so with
+# gradients_written(ptrs); FlatDataParallel registers only buffers whose gradient never passes through AccumulateGrad.
+_wq_excl = {'single_writer': set(), 'written': set(), 'cleared_in': {}}
+_WG_OVERWRITE = True        # tests flip it to compare the store with accumulation on zeros
 
 
 def register_single_writer_grads(ptrs):
@@ -551,11 +575,21 @@ def register_single_writer_grads(ptrs):
 def unregister_single_writer_grads(ptrs):
     _wq_excl['single_writer'].difference_update(ptrs)
     _wq_excl['written'].difference_update(ptrs)
+    for q in ptrs:
+        _wq_excl['cleared_in'].pop(q, None)
 
 
 def gradients_cleared(ptrs):
-    """the buffers at these addresses were just zeroed by their owner (FlatDataParallel.zero_grad)"""
+    """the buffers at these addresses were just zeroed by their owner (FlatDataParallel.zero_grad), in the current context"""
     _wq_excl['written'].difference_update(ptrs)
+    ctx = capture_context()
+    _wq_excl['cleared_in'].update((q, ctx) for q in ptrs)
+
+
+def gradients_written(ptrs):
+    """somebody other than the grouped weight-gradient launch added into the buffers at these addresses: the next grouped launch
+    accumulates instead of storing"""
+    _wq_excl['written'].update(ptrs)
 
 _FUSE_BIAS_COLSUM = os.environ.get('OTR_NO_FUSED_BIAS_COLSUM', '0') != '1'
 _DEBUG_WQ = os.environ.get('OTR_DEBUG_WQ', '0') == '1'
@@ -613,7 +647,7 @@ def flush_weight_grads():
         seen = {}
         for _, _, out in w:
             seen[out.data_ptr()] = seen.get(out.data_ptr(), 0) + 1
-        sw, written = _wq_excl['single_writer'], _wq_excl['written']
+        sw, written, cleared_in, here = _wq_excl['single_writer'], _wq_excl['written'], _wq_excl['cleared_in'], capture_context()
         for it, (dy2, x2, out) in zip(items, w):
             it.dy, it.x, it.dw = dy2.data_ptr(), x2.data_ptr(), out.data_ptr()
             it.M, it.N, it.K = dy2.shape[0], dy2.shape[1], x2.shape[1]
@@ -621,7 +655,8 @@ def flush_weight_grads():
             it.dy_dtype, it.x_dtype = _code(dy2.dtype), _code(x2.dtype)
             it.dbias = None
             ptr = out.data_ptr()
-            it.overwrite = int(_WG_OVERWRITE and ptr in sw and ptr not in written and seen[ptr] == 1)
+            it.overwrite = int(_WG_OVERWRITE and ptr in sw and ptr not in written and seen[ptr] == 1
+                               and here is not None and cleared_in.get(ptr) == here)
         written.update(seen)
         if b and _FUSE_BIAS_COLSUM:
             # a bias gradient whose matrix is the dy operand of a weight gradient the 256-wide kernel takes rides along with

@@ -26,7 +26,10 @@ def test_header_binding_and_library_agree():
     assert sorted(_lib.SIGNATURES) == decl          # the ctypes stub binds exactly the header
     for name in decl:
         assert hasattr(lib, name), name             # and the .so exports every one of them
-    assert lib.otr_version() >= 100
+    # the ABI version: header constant == library answer == what the binding was written against (breaking changes of
+    # descriptors / signatures must bump it, and _lib.load refuses a library that answers anything else)
+    hdr = int(re.search(r'#define\s+OTR_ABI_VERSION\s+(\d+)', open(os.path.join(ROOT, 'include', 'otrans_hip.h')).read()).group(1))
+    assert lib.otr_version() == hdr == _lib.OTR_ABI_VERSION
 
 
 def test_argument_errors_are_reported_without_a_gpu():
