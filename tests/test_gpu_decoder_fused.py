@@ -53,8 +53,9 @@ def make_decoder(n_blocks, d_ff, vocab, p_drop, seed):
     return dec
 
 
-def torch_decoder(dec, tokens, memory, key_mask):
-    """fp32 restatement with torch ops only (dropout off)"""
+def torch_decoder(dec, tokens, memory, key_mask, round_qkv=None):
+    """fp32 restatement with torch ops only (dropout off); round_qkv = a 16-bit dtype: the FIRST layer's projected self-attention
+    q | k | v are rounded to it (straight-through gradient) -- the reference that shares the HIP path's attention operands"""
     d, H = 256, 4
     B, Lq = tokens.shape
     x = dec.embedding.weight[tokens] * math.sqrt(d)
@@ -73,9 +74,12 @@ def torch_decoder(dec, tokens, memory, key_mask):
         s = s.masked_fill(~mask, float('-inf'))
         p = torch.softmax(s, dim=-1).masked_fill(~mask, 0.0)
         return (p @ heads(v)).transpose(1, 2).reshape(q.shape[0], q.shape[1], d)
-    for b in dec.blocks:
+    for li, b in enumerate(dec.blocks):
         sa, ca, ff = b.slf_attn, b.src_attn, b.feed_forward
-        q, k, v = F.linear(x, sa.qvk_proj.weight, sa.qvk_proj.bias).split(d, dim=-1)
+        qkv = F.linear(x, sa.qvk_proj.weight, sa.qvk_proj.bias)
+        if round_qkv is not None and li == 0:
+            qkv = qkv + (qkv.to(round_qkv).float() - qkv).detach()
+        q, k, v = qkv.split(d, dim=-1)
         x = F.layer_norm(x + F.linear(attend(q, k, v, causal.view(1, 1, Lq, Lq)), sa.output_proj.weight, sa.output_proj.bias), (d,),
                          b.norm1.weight, b.norm1.bias, b.norm1.eps)
         q = F.linear(x, ca.q_proj.weight, ca.q_proj.bias)
@@ -156,6 +160,18 @@ def test_fused_decoder_matches_fp32_torch(mode, B, Lq, T, nl, dff, group):
         for n, e in over.items():
             bound = next((b for pat, b in OVER_TG.items() if pat in n), None)
             assert bound is not None and e < bound[mode], ('gradient over the flat bound and not a named exception', n, e, tg)
+        if over:
+            # r06: the cause is MEASURED, not only named: against an fp32 reference whose layer-0 q|k|v are rounded to the compute type
+            # (everything else fp32) the same gradients meet the flat bound -- the gap to the plain fp32 reference is the rounding of the
+            # attention OPERANDS in front of a saturated softmax, not the backward arithmetic (tools/delta_study.py)
+            memr2 = memory.clone().requires_grad_(True)
+            ref2 = torch_decoder(dec, tokens, memr2, key_mask, round_qkv=ops.act_dtype())
+            gref2 = torch.autograd.grad(ref2, [memr2] + list(dec.parameters()), gy)
+            errs2, _ = H.key_aware_grad_errors(names, ggot, gref2)
+            same_operands = {n: errs2[n] for n in over}
+            H.log_tolerance_cases('decoder_fused_same_operands', {'mode': mode, 'shape': [B, Lq, T, nl, dff], 'group': group, 'tg': tg,
+                                                                  'vs_fp32': over, 'vs_fp32_on_rounded_qkv': same_operands})
+            assert all(e < tg for e in same_operands.values()), (same_operands, tg)
         assert all(e < KEY_RESIDUE[mode] for e in key_errs.values()), key_errs
         print('decoder parity', mode, (B, Lq, T), 'logits %.2e rows %.2e worst grad %.2e %s' % (rel(got, ref), row_rel(got, ref), worst[0], worst[1]))
         # keys beyond an utterance's length receive no gradient

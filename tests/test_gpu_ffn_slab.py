@@ -69,7 +69,9 @@ def run_hip(enc, x, mask, gy, slab, count=None):
         ops._FFN_SLAB = was
 
 
-def torch_encoder(enc, x, mask):
+def torch_encoder(enc, x, mask, round_qkv=None):
+    """fp32 torch restatement of the encoder stack; round_qkv = a 16-bit dtype: the FIRST layer's projected q | k | v are rounded to it
+    (straight-through gradient), every other operation stays fp32 -- the reference that shares the HIP path's attention OPERANDS"""
     d, H = 256, 4
     B, T, _ = x.shape
     pos = torch.arange(T, device=x.device, dtype=torch.float32).unsqueeze(1)
@@ -81,9 +83,12 @@ def torch_encoder(enc, x, mask):
 
     def heads(t):
         return t.view(B, T, H, d // H).transpose(1, 2)
-    for b in enc.blocks:
+    for li, b in enumerate(enc.blocks):
         sa, ff = b.slf_attn, b.feed_forward
-        q, k, v = F.linear(x, sa.qvk_proj.weight, sa.qvk_proj.bias).split(d, dim=-1)
+        qkv = F.linear(x, sa.qvk_proj.weight, sa.qvk_proj.bias)
+        if round_qkv is not None and li == 0:
+            qkv = qkv + (qkv.to(round_qkv).float() - qkv).detach()
+        q, k, v = qkv.split(d, dim=-1)
         s = (heads(q) @ heads(k).transpose(-1, -2) / math.sqrt(d // H)).masked_fill(~km, float('-inf'))
         c = (torch.softmax(s, dim=-1).masked_fill(~km, 0.0) @ heads(v)).transpose(1, 2).reshape(B, T, d)
         x = F.layer_norm(x + F.linear(c, sa.output_proj.weight, sa.output_proj.bias), (d,), b.norm1.weight, b.norm1.bias, b.norm1.eps)
@@ -141,12 +146,24 @@ def test_slab_mode_matches_fp32_torch(mode):
         worst = max((e, n) for n, e in errs.items())
         over = {n: e for n, e in errs.items() if e >= tg}
         H.log_tolerance_cases('ffn_slab', {'mode': mode, 'tg': tg, 'worst': worst, 'over_tg': over, 'key_bias_residue': key_errs})
-        # the named exception (measured 0.026 / 0.20, bound <= 1.5 x; same cause as tests/test_gpu_decoder_fused.py OVER_TG): the q|k|v
-        # gradient of the FIRST layer's self-attention and the input gradient it feeds -- layer 0 attends over sqrt(d)-scaled inputs,
-        # its softmax saturates and dS cancels to the rounding of the 16-bit operands; layer 1's, and every other tensor, meet tg
-        named = {'x': (4e-2, 3e-1), 'blocks.0.slf_attn.qvk_proj.weight': (4e-2, 3e-1), 'blocks.0.slf_attn.qvk_proj.bias': (4e-2, 3e-1)}
-        for n, e in over.items():
-            assert n in named and e < named[n][0 if mode == 'fp16' else 1], ('gradient over the flat bound and not a named exception', n, e, tg)
+        # The named tensors (measured 0.026 / 0.20 against the fp32 reference): the q|k|v gradient of the FIRST layer's self-attention and
+        # the input gradient it feeds.  Layer 0 attends over sqrt(d)-scaled inputs: its scores have a standard deviation of ~85, the
+        # softmax saturates, and the 16-bit rounding of the projected q and k (2^-11 / 2^-8 of values ~ 9) moves the few unsaturated
+        # probabilities by percents -- BEFORE any backward arithmetic runs.  r06: this is now MEASURED instead of asserted by name
+        # (tools/delta_study.py: with exact arithmetic on the rounded operands the error is the same 1.6e-2; delta from P . dP instead
+        # of dO . O changes the third digit): the same gradients are compared with an fp32 reference whose layer-0 q|k|v are rounded to
+        # the compute type and whose every other operation is fp32, and against THAT reference they must meet the flat bound.
+        named = ('x', 'blocks.0.slf_attn.qvk_proj.weight', 'blocks.0.slf_attn.qvk_proj.bias')
+        if over:
+            assert all(n in named for n in over), ('gradient over the flat bound and not a named exception', over, tg)
+            xr2 = x.clone().requires_grad_(True)
+            ref2 = torch_encoder(enc, xr2, mask, round_qkv=ops.act_dtype())
+            gref2 = torch.autograd.grad(ref2, [xr2] + list(enc.parameters()), gy)
+            errs2, _ = H.key_aware_grad_errors(names, ggot, gref2)
+            same_operands = {n: errs2[n] for n in over}
+            H.log_tolerance_cases('ffn_slab_same_operands', {'mode': mode, 'tg': tg, 'vs_fp32': over, 'vs_fp32_on_rounded_qkv': same_operands})
+            print('encoder slab parity', mode, 'named tensors against the reference on rounded q|k|v:', same_operands)
+            assert all(e < tg for e in same_operands.values()), (same_operands, tg)
         assert all(e < (8e-3 if mode == 'fp16' else 4.5e-2) for e in key_errs.values()), key_errs      # measured 1.0e-3 / 7.5e-3
         print('encoder slab parity', mode, 'out %.2e worst grad %.2e %s' % (rel(got, ref), worst[0], worst[1]))
     finally:

@@ -420,7 +420,6 @@ def test_c5_full_size_decode_with_live_eos(mode):
             drift_final, shared = 0.0, []
             for b in range(B):
                 ref_map = {tuple(h): float(ref_s[b, n]) for n, h in enumerate(ref_h[b])}
-                assert got_tok[b][0] == ref_h[b][0] or ref_s[b, 0] - ref_s[b, 1] < 2 * tol, (b, got_tok[b][0], ref_h[b][0])
                 if rep['min_cut_margin'][b] > 2 * tol:     # no near-tie at any cut of this utterance's search: the same n-best set
                     assert set(map(tuple, got_tok[b])) == set(ref_map), (mode, b)
                 n_sh = 0
@@ -429,8 +428,18 @@ def test_c5_full_size_decode_with_live_eos(mode):
                         n_sh += 1
                         drift_final = max(drift_final, abs(float(got_s[b, n]) - ref_map[tuple(h)]))
                 shared.append(n_sh)
+            # The 1-best, per utterance: identical to the oracle's OUTRIGHT unless one of two MEASURED quantities of this
+            # very run says a rounding flip was possible -- the oracle's own final 1-best / 2-best gap is within twice the final score
+            # drift measured above (both scores may move by the drift), or the oracle's search came closer to a tie at some cut than twice
+            # the depth below the cut at which this run is MEASURED to keep candidates (worst_kept_below_cut: the winner's prefix may have
+            # been pruned there).  No 2 x tol escape any more.
+            one_best = [got_tok[b][0] == ref_h[b][0] for b in range(B)]
+            gap12 = [float(ref_s[b, 0] - ref_s[b, 1]) for b in range(B)]
+            excused = [gap12[b] <= 2 * drift_final or rep['min_cut_margin'][b] <= 2 * rep['worst_kept_below_cut'] for b in range(B)]
             report.update(rep, tol=tol, worst_final_score_drift=drift_final, nbest_shared=shared,
-                          nbest_identical=[got_tok[b] == ref_h[b] for b in range(B)])
+                          nbest_identical=[got_tok[b] == ref_h[b] for b in range(B)], one_best_identical=one_best,
+                          oracle_gap_1best_2best=gap12, one_best_flip_possible=excused)
+            assert all(one_best[b] or excused[b] for b in range(B)), report
             assert rep['worst_kept_below_cut'] < 2 * tol, report
             assert rep['worst_score_drift'] < tol, report
             assert drift_final < tol, report
