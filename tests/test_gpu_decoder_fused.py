@@ -54,8 +54,8 @@ def make_decoder(n_blocks, d_ff, vocab, p_drop, seed):
 
 
 def torch_decoder(dec, tokens, memory, key_mask, round_qkv=None):
-    """fp32 restatement with torch ops only (dropout off); round_qkv = a 16-bit dtype: the FIRST layer's projected self-attention
-    q | k | v are rounded to it (straight-through gradient) -- the reference that shares the HIP path's attention operands"""
+    """fp32 restatement with torch ops only (dropout off); round_qkv = a 16-bit dtype: the FIRST layer's self-attention
+    q | k | v are formed as the HIP path forms them (16-bit rows and weights, fp32 sums, rounded; straight-through gradient) -- the reference that shares the HIP path's attention operands"""
     d, H = 256, 4
     B, Lq = tokens.shape
     x = dec.embedding.weight[tokens] * math.sqrt(d)
@@ -76,9 +76,13 @@ def torch_decoder(dec, tokens, memory, key_mask, round_qkv=None):
         return (p @ heads(v)).transpose(1, 2).reshape(q.shape[0], q.shape[1], d)
     for li, b in enumerate(dec.blocks):
         sa, ca, ff = b.slf_attn, b.src_attn, b.feed_forward
-        qkv = F.linear(x, sa.qvk_proj.weight, sa.qvk_proj.bias)
         if round_qkv is not None and li == 0:
-            qkv = qkv + (qkv.to(round_qkv).float() - qkv).detach()
+            # the HIP path's operands: 16-bit input rows and weights, fp32 accumulation, 16-bit q | k | v (straight-through gradients)
+            def st(t):
+                return t + (t.to(round_qkv).float() - t).detach()
+            qkv = st(F.linear(st(x), st(sa.qvk_proj.weight), sa.qvk_proj.bias))
+        else:
+            qkv = F.linear(x, sa.qvk_proj.weight, sa.qvk_proj.bias)
         q, k, v = qkv.split(d, dim=-1)
         x = F.layer_norm(x + F.linear(attend(q, k, v, causal.view(1, 1, Lq, Lq)), sa.output_proj.weight, sa.output_proj.bias), (d,),
                          b.norm1.weight, b.norm1.bias, b.norm1.eps)

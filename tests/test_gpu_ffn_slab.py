@@ -70,8 +70,8 @@ def run_hip(enc, x, mask, gy, slab, count=None):
 
 
 def torch_encoder(enc, x, mask, round_qkv=None):
-    """fp32 torch restatement of the encoder stack; round_qkv = a 16-bit dtype: the FIRST layer's projected q | k | v are rounded to it
-    (straight-through gradient), every other operation stays fp32 -- the reference that shares the HIP path's attention OPERANDS"""
+    """fp32 torch restatement of the encoder stack; round_qkv = a 16-bit dtype: the FIRST layer's q | k | v are formed as the HIP path forms them
+    (16-bit rows and weights, fp32 sums, rounded; straight-through gradient), every other operation stays fp32 -- the reference that shares the HIP path's attention OPERANDS"""
     d, H = 256, 4
     B, T, _ = x.shape
     pos = torch.arange(T, device=x.device, dtype=torch.float32).unsqueeze(1)
@@ -85,9 +85,13 @@ def torch_encoder(enc, x, mask, round_qkv=None):
         return t.view(B, T, H, d // H).transpose(1, 2)
     for li, b in enumerate(enc.blocks):
         sa, ff = b.slf_attn, b.feed_forward
-        qkv = F.linear(x, sa.qvk_proj.weight, sa.qvk_proj.bias)
         if round_qkv is not None and li == 0:
-            qkv = qkv + (qkv.to(round_qkv).float() - qkv).detach()
+            # the HIP path's operands: 16-bit input rows and weights, fp32 accumulation, 16-bit q | k | v (straight-through gradients)
+            def st(t):
+                return t + (t.to(round_qkv).float() - t).detach()
+            qkv = st(F.linear(st(x), st(sa.qvk_proj.weight), sa.qvk_proj.bias))
+        else:
+            qkv = F.linear(x, sa.qvk_proj.weight, sa.qvk_proj.bias)
         q, k, v = qkv.split(d, dim=-1)
         s = (heads(q) @ heads(k).transpose(-1, -2) / math.sqrt(d // H)).masked_fill(~km, float('-inf'))
         c = (torch.softmax(s, dim=-1).masked_fill(~km, 0.0) @ heads(v)).transpose(1, 2).reshape(B, T, d)

@@ -237,6 +237,64 @@ def test_c4_batch32_matches_oracle(c4_oracle, mode):
                          C4_TOL[mode], seed=31)
 
 
+@pytest.mark.parametrize('mode', ['fp16', 'bf16'])
+def test_c4_batch32_through_the_bench_engine_matches_oracle(c4_oracle, mode):
+    """VERDICT r05 "missing 4": the Conformer through bench.py's construction -- FlatDataParallel (flat in-place gradients, grouped weight
+    gradients incl. the DEFERRED dp products of the relative-position attention and dW_pos behind them, the persistent score-gradient
+    tensor, BatchNorm partial sums, the residual + double-LayerNorm launches) + FusedAdam's device-side loss scale -- at the bench batch
+    against the ORACLE (not against the bare HIP model): loss and every parameter gradient, read from the flat buffer."""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+    cfg, inputs, targets, ref_loss, ref_aux, ref_flat = c4_oracle
+    ops.set_compute_dtype(mode)
+    try:
+        model = ota.SpeechToText(cfg)
+        syn.fill_state_dict_(model.state_dict(), 31)
+        model = model.to(DEV).train()
+        dp = FlatDataParallel(model)
+        opt = FusedAdam(dp, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6, clip_grad=5.0,
+                        noam=dict(model_size=cfg['encoder']['d_model'], warmup_steps=12000, factor=1.0))
+        di = {k: v.to(DEV) for k, v in inputs.items()}
+        dt = {k: v.to(DEV) for k, v in targets.items()}
+        g_rms = None
+        for rep_ in range(2):                        # twice: the second pass runs on the persistent score-gradient tensors of the first
+            dp.zero_grad(next_dropout_step=True)
+            loss, _ = dp(di, dt)
+            ops.backward(loss)
+        torch.cuda.synchronize()
+        ls = float(opt.state[6]) or 1.0
+        n_el = sum(v.grad.numel() for v in ref_flat.values() if v.grad is not None)
+        g_rms = (sum(float(v.grad.double().pow(2).sum()) for v in ref_flat.values() if v.grad is not None) / n_el) ** 0.5
+        worst, wkey, rels, zero_worst = 0.0, None, {}, 0.0
+        for k, p in model.named_parameters():
+            g_ref = ref_flat[k].grad
+            if g_ref is None:
+                continue
+            if k.endswith('conv.depthwise_conv.bias'):           # analytically zero (see _compare_with_oracle)
+                zero_worst = max(zero_worst, float((p.grad.detach() / ls).double().pow(2).mean().sqrt()) / g_rms)
+                continue
+            e = rel(p.grad.detach() / ls, g_ref)
+            rels[k] = e
+            if e > worst:
+                worst, wkey = e, k
+        r = {'config': 'C4 conformer_baseline B=32 x 1000 frames, ragged, through bench.py\'s engine (FlatDataParallel + FusedAdam loss scale), second of two passes',
+             'mode': mode, 'loss_rel': abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()), 'loss_scale': ls, 'grad_worst': worst,
+             'grad_worst_key': wkey, 'grad_median': float(np.median(list(rels.values()))),
+             'grad_pos_proj_worst': max(v for k, v in rels.items() if 'pos_proj' in k),
+             'grad_posu_posv_worst': max(v for k, v in rels.items() if k.endswith('posu') or k.endswith('posv')),
+             'zero_grad_rms_over_model_rms': zero_worst, 'faults': opt.stats()['faults']}
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'parity_c4_engine_%s.json' % mode), 'w') as f:
+            json.dump(r, f, indent=1)
+        print(json.dumps(r))
+        tl, _, _, tg = C4_TOL[mode]
+        assert r['loss_rel'] < tl and worst < tg, r
+        assert zero_worst < 5e-2 and r['faults'] == 0, r
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
 def _beam_search_validity(orc, parts, cfg, inputs, lm, lm_weight, beam, trace, tol):
     """Replay the product's per-step beams (trace: [(prefixes [B*beam, t+1], scores [B*beam])] after step t = 1, 2, ...) on the
     ORACLE's log-probabilities (recognize/speech2text.py:95-146 restated: decoder.inference + lm_weight * lm.predict on the
@@ -428,18 +486,19 @@ def test_c5_full_size_decode_with_live_eos(mode):
                         n_sh += 1
                         drift_final = max(drift_final, abs(float(got_s[b, n]) - ref_map[tuple(h)]))
                 shared.append(n_sh)
-            # The 1-best, per utterance: identical to the oracle's OUTRIGHT unless one of two MEASURED quantities of this
-            # very run says a rounding flip was possible -- the oracle's own final 1-best / 2-best gap is within twice the final score
-            # drift measured above (both scores may move by the drift), or the oracle's search came closer to a tie at some cut than twice
-            # the depth below the cut at which this run is MEASURED to keep candidates (worst_kept_below_cut: the winner's prefix may have
-            # been pruned there).  No 2 x tol escape any more.
+            # The 1-best, per utterance: identical to the oracle's OUTRIGHT wherever the oracle's own final 1-best / 2-best
+            # gap exceeds twice the final score drift MEASURED in this run (each of the two scores may move by the drift) -- no 2 x tol
+            # escape, no appeal to near-ties at cuts.  (r06 on MI355X: 8 / 8 identical in fp16 and bf16; the gaps are 9.3-9.8 nat
+            # against a drift of 3.3e-3 / 3.4e-2.)  one_best_flip_possible records the other MEASURED way a 1-best could differ
+            # legitimately -- the oracle's search came closer to a tie at some cut than the depth below the cut at which this run is
+            # measured to keep candidates -- for the report only.
             one_best = [got_tok[b][0] == ref_h[b][0] for b in range(B)]
             gap12 = [float(ref_s[b, 0] - ref_s[b, 1]) for b in range(B)]
-            excused = [gap12[b] <= 2 * drift_final or rep['min_cut_margin'][b] <= 2 * rep['worst_kept_below_cut'] for b in range(B)]
+            near_cut = [rep['min_cut_margin'][b] <= 2 * rep['worst_kept_below_cut'] for b in range(B)]
             report.update(rep, tol=tol, worst_final_score_drift=drift_final, nbest_shared=shared,
                           nbest_identical=[got_tok[b] == ref_h[b] for b in range(B)], one_best_identical=one_best,
-                          oracle_gap_1best_2best=gap12, one_best_flip_possible=excused)
-            assert all(one_best[b] or excused[b] for b in range(B)), report
+                          oracle_gap_1best_2best=gap12, one_best_flip_possible=near_cut)
+            assert all(one_best[b] or gap12[b] <= 2 * drift_final for b in range(B)), report
             assert rep['worst_kept_below_cut'] < 2 * tol, report
             assert rep['worst_score_drift'] < tol, report
             assert drift_final < tol, report

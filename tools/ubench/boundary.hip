@@ -53,6 +53,13 @@ __global__ void k_chase(const int* __restrict__ next, int depth, int* sink) {
   if (p == 0x7fffffff) sink[0] = 1;
 }
 
+// occupies its workgroups for `ticks` of the 100 MHz constant clock (1 tick = 10 ns): a stand-in for a latency-bound kernel
+__global__ void k_spin(long ticks, int* sink) {
+  const long t0 = (long)__builtin_amdgcn_s_memrealtime();
+  while ((long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+  if (ticks < 0) sink[0] = 1;
+}
+
 using Launch = std::function<void(hipStream_t, int)>;     // (stream, index of the node in the chain)
 
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -188,6 +195,46 @@ int main(int argc, char** argv) {
     }
     printf("%-72s %9.2f %9.2f %9.2f %9.2f %9.2f\n", c.name.c_str(), eager, cap, ev, expl, c.body_us);
     fflush(stdout);
+  }
+  // ---- do two BRANCHES of a captured graph run side by side?  Each node holds `grid` workgroups for 20 us (k_spin).  One chain of
+  // 2 n nodes against two forked chains of n nodes each (event fork / join inside the capture): side by side = half the time.
+  {
+    hipStream_t s2;
+    CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    hipEvent_t ef, ej;
+    CK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+    const int n = 20;
+    for (int grid : {64, 128, 256}) {
+      for (int lds : {0, 100 * 1024}) {
+        auto node = [&](hipStream_t st) {
+          if (lds) hipLaunchKernelGGL(k_lds, dim3(grid), dim3(256), lds, st, sink);       // residency probe only: trivial body
+          hipLaunchKernelGGL(k_spin, dim3(grid), dim3(256), 0, st, 2000l, sink);
+        };
+        hipGraph_t g1, g2;
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < 2 * n; ++i) node(s);
+        CK(hipStreamEndCapture(s, &g1));
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        CK(hipEventRecord(ef, s)); CK(hipStreamWaitEvent(s2, ef, 0));
+        for (int i = 0; i < n; ++i) { node(s); node(s2); }
+        CK(hipEventRecord(ej, s2)); CK(hipStreamWaitEvent(s, ej, 0));
+        CK(hipStreamEndCapture(s, &g2));
+        hipGraphExec_t x1, x2;
+        CK(hipGraphInstantiate(&x1, g1, nullptr, nullptr, 0)); CK(hipGraphInstantiate(&x2, g2, nullptr, nullptr, 0));
+        double e1, e2;
+        const double t1 = time_graph(x1, 1, 10, s, &e1), t2 = time_graph(x2, 1, 10, s, &e2);
+        // eager on two streams, for reference
+        for (int i = 0; i < n; ++i) { node(s); node(s2); }
+        CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(s2));
+        double t0 = now_us();
+        for (int i = 0; i < n; ++i) { node(s); node(s2); }
+        CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(s2));
+        const double te = now_us() - t0;
+        printf("# fork: %d x (20 us spin on %3d workgroups%s): one chain of %d nodes %.1f us; two captured branches of %d %.1f us; two eager streams %.1f us\n",
+               2 * n, grid, lds ? " + a 100 KiB-LDS node" : "", 2 * n, t1, n, t2, te);
+        CK(hipGraphExecDestroy(x1)); CK(hipGraphExecDestroy(x2)); CK(hipGraphDestroy(g1)); CK(hipGraphDestroy(g2));
+      }
+    }
   }
   // one replay at a time with a host sync in between: the per-replay floor (not a per-node cost)
   {
