@@ -518,6 +518,11 @@ int32_t otr_dropout(const void* x, void* y, int32_t dtype, int64_t n, float p_dr
 /* out[M, 2d] = [q + u | q + v] (pos_bias_u / pos_bias_v flattened to [d]); q has leading dimension ldq */
 int32_t otr_head_bias_add(const void* q, int64_t ldq, const float* u, const float* v, void* out, int32_t dtype,
                           int64_t M, int32_t d, void* stream);
+/* dst[r, c, f] += src[r, f, c] (fp32; dst [rows, C, F], src [rows, F, C], both dense); clear_src != 0 leaves src ZERO.  Regroups a
+ * weight gradient produced in a kernel's column order into the parameter's layout in one launch: the frontend Linear's staging image
+ * (frontend/conv.py:145-146: flatten c*F+f, kernel order f*C+c) and conv2's channel-last taps (frontend/conv.py:56).  Replaces
+ * torch's strided add (AccumulateGrad / add_) in the step. */
+int32_t otr_regroup_add(float* dst, float* src, int64_t rows, int32_t C, int32_t F, int32_t clear_src, void* stream);
 /* out[r, :cols] = a[r, :cols] + b[r, :cols] with independent leading dimensions */
 int32_t otr_add2_strided(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int32_t dtype,
                          int64_t M, int32_t cols, void* stream);

@@ -190,6 +190,7 @@ SIGNATURES = {
     'otr_dropout': [_P, _P, _I32, _I64, _F32, _P, C.c_uint64, _P],
     'otr_head_bias_add': [_P, _I64, _P, _P, _P, _I32, _I64, _I32, _P],
     'otr_add2_strided': [_P, _I64, _P, _I64, _P, _I64, _I32, _I64, _I32, _P],
+    'otr_regroup_add': [_P, _P, _I64, _I32, _I32, _I32, _P],
     'otr_row_mask': [_P, _P, _P, _I64, _I32, _P],
     'otr_row_mask_cast': [_P, _I32, _P, _P, _I32, _I64, _I32, _P],
     'otr_dwconv_fwd': [_P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],

@@ -141,6 +141,10 @@ __global__ __launch_bounds__(256) void beam_topk_reg_kernel(const float* logits,
     const int v = tid + 256 * j;
     sc[j] = xs[j] - lse;
     if (y) sc[j] += lm_weight * (ys[j] - llse);
+    // a NaN never compares (bt_better is false both ways): a row of NaNs left the winner index at its 0x7fffffff sentinel, the shift
+    // below undefined and a sentinel as a token id.  NaN ranks as -inf: such a row yields its lowest indices, like the
+    // shared-memory kernel
+    if (!(sc[j] == sc[j])) sc[j] = NEG_INF;
     if (v < V) alive |= 1u << j;
   }
   float hs = NEG_INF;
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(256) void beam_topk_reg_kernel(const float* logits,
     for (int w = 1; w < 4; ++w)
       if (bt_better(ws_s[w], ws_i[w], wsc, wi)) { wsc = ws_s[w]; wi = ws_i[w]; }
     if (tid == 0) { out_score[row * k + r] = wsc; out_idx[row * k + r] = wi; }
-    if (hi == wi) {                                   // the owner retires the winner and rescans
+    if (hi == wi && wi < V) {                         // the owner retires the winner and rescans (wi < V: never shift by a sentinel)
       alive &= ~(1u << ((wi - tid) >> 8));
       hs = NEG_INF; hi = 0x7fffffff;
 #pragma unroll

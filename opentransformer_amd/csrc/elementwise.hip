@@ -317,15 +317,35 @@ __global__ void posenc_kernel(const float* x, float* y, bf16_t* y_lp, int64_t ro
     if (mask_out && col == 0) mask_out[row] = mask_in[(row / T) * mask_bs + (int64_t)t * mask_ts] != 0 ? 1 : 0;
   }
 }
+// any d, any alignment: one element per thread (the four-column kernel above must not be the only form -- a model with
+// d_model % 4 != 0, or a contiguous view at an odd storage offset, ran before round 5 and runs again)
+__global__ void posenc_scalar_kernel(const float* x, float* y, bf16_t* y_lp, int64_t rows, int T, int d, float scale, const uint8_t* mask_in,
+                                     int64_t mask_bs, int64_t mask_ts, uint8_t* mask_out) {
+  const float nl = -logf(10000.f) / (float)d;
+  const int64_t total = rows * d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / d;
+    const int col = (int)(i - row * d);
+    const int t = (int)(row % T);
+    const float v = x[i] * scale + pe_value(t, col, nl);
+    y[i] = v;
+    if (y_lp) y_lp[i] = f2bf(v);
+    if (mask_out && col == 0) mask_out[row] = mask_in[(row / T) * mask_bs + (int64_t)t * mask_ts] != 0 ? 1 : 0;
+  }
+}
 extern "C" int32_t otr_posenc_mask_fwd(const float* x, float* y, void* y_bf16, int64_t rows, int32_t T, int32_t d, float scale,
                                        const uint8_t* mask_in, int64_t mask_bs, int64_t mask_ts, uint8_t* mask_out, void* stream) {
   OTR_REQUIRE(x && y, "posenc_fwd: null pointer");
-  OTR_REQUIRE(T > 0 && d > 0 && d % 4 == 0 && rows >= 0, "posenc_fwd: bad shape (d %% 4 == 0)");
-  OTR_REQUIRE(((uintptr_t)x | (uintptr_t)y) % 16 == 0 && (uintptr_t)y_bf16 % 8 == 0, "posenc_fwd: unaligned buffers");
+  OTR_REQUIRE(T > 0 && d > 0 && rows >= 0, "posenc_fwd: bad shape");
   OTR_REQUIRE((mask_in == nullptr) == (mask_out == nullptr), "posenc_mask_fwd: mask_in and mask_out go together");
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(posenc_kernel, dim3(grid_for(rows * (d / 4))), dim3(256), 0, (hipStream_t)stream, x, y, (bf16_t*)y_bf16, rows, T, d, scale,
-                     mask_in, mask_bs, mask_ts, mask_out);
+  const bool vec = d % 4 == 0 && ((uintptr_t)x | (uintptr_t)y) % 16 == 0 && (uintptr_t)y_bf16 % 8 == 0;
+  if (vec)
+    hipLaunchKernelGGL(posenc_kernel, dim3(grid_for(rows * (d / 4))), dim3(256), 0, (hipStream_t)stream, x, y, (bf16_t*)y_bf16, rows, T, d, scale,
+                       mask_in, mask_bs, mask_ts, mask_out);
+  else
+    hipLaunchKernelGGL(posenc_scalar_kernel, dim3(grid_for(rows * (int64_t)d)), dim3(256), 0, (hipStream_t)stream, x, y, (bf16_t*)y_bf16, rows, T,
+                       d, scale, mask_in, mask_bs, mask_ts, mask_out);
   return otr_check_launch("posenc_fwd");
 }
 extern "C" int32_t otr_posenc_fwd(const float* x, float* y, void* y_bf16, int64_t rows, int32_t T, int32_t d,
@@ -483,6 +503,43 @@ extern "C" int32_t otr_touch(const void* p, int64_t bytes, void* stream) {
   const int64_t g = (lines + 255) / 256;
   hipLaunchKernelGGL(touch_kernel, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)p, lines);
   return otr_check_launch("touch");
+}
+
+// ------------------------------------------------------------------------------------------------ regrouping add
+// dst[r, c, f] += src[r, f, c] (fp32), optionally leaving src ZERO: a weight gradient that a kernel produced in ITS column order
+// (the frontend Linear's f*C+c columns, conv2's channel-last taps) lands in the parameter's layout.  With `clear` the staging image is
+// zero again when the launch ends -- the next backward pass, whenever and however it is issued (eager, or a replay of a graph that
+// was captured without the gradient clear), starts from zeros without anybody on the host having to know (r06: a captured forward +
+// backward replayed twice left 3 x the frontend Linear's gradient; the host-side "dirty" flag had been baked into the graph).
+// One 32 x 32 tile of (f, c) per workgroup and row: both sides move as 128-byte row pieces.
+__global__ __launch_bounds__(256) void regroup_add_kernel(float* __restrict__ dst, float* __restrict__ src, int C, int F, int clear) {
+  __shared__ float tile[32][33];
+  const int r = blockIdx.z, f0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 8 rows of 32 per pass
+  float* s = src + (int64_t)r * F * C;
+  float* d = dst + (int64_t)r * C * F;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = f0 + ty + 8 * i, c = c0 + tx;
+    if (f < F && c < C) {
+      tile[ty + 8 * i][tx] = s[(int64_t)f * C + c];
+      if (clear) s[(int64_t)f * C + c] = 0.f;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, f = f0 + tx;
+    if (f < F && c < C) d[(int64_t)c * F + f] += tile[tx][ty + 8 * i];
+  }
+}
+extern "C" int32_t otr_regroup_add(float* dst, float* src, int64_t rows, int32_t C, int32_t F, int32_t clear_src, void* stream) {
+  OTR_REQUIRE(dst && src, "regroup_add: null pointer");
+  OTR_REQUIRE(rows >= 0 && rows < 65536 && C > 0 && F > 0, "regroup_add: bad shape");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(regroup_add_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((F + 31) / 32), (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                     dst, src, C, F, clear_src);
+  return otr_check_launch("regroup_add");
 }
 
 // ------------------------------------------------------------------------------------------------ column sums

@@ -1093,13 +1093,12 @@ class LinearFn(torch.autograd.Function):
                 # parameter's layout (flush_weight_grads runs the hook)
                 C_, F_ = ctx.perm
                 stage = ctx.w_ref._otr_regroup_grad.view(wc.shape[0], F_ * C_)
-                st = ctx.w_ref._otr_regroup_state
-                if st['dirty']:                  # a second backward pass before the next zero_grad() (gradient accumulation): the image
-                    stage.zero_()                # of the first was already added to the gradient
-                st['dirty'] = True
+                ctx.w_ref._otr_regroup_state['dirty'] = True        # (tests read it: "the hand-over really ran")
                 linear_wgrad_raw(dy2, x2, wc, out=stage)
                 gt_w = grad_target(ctx.w_ref)
-                _wq['post'].append(lambda gt_w=gt_w, stage=stage, C_=C_, F_=F_: gt_w.view(-1, C_, F_).add_(stage.view(-1, F_, C_).permute(0, 2, 1)))
+                # the regrouping launch leaves the image ZERO: every pass starts from zeros whoever issues it (a second eager pass, a
+                # replay of a graph captured without the clear), with no host-side state baked into anything
+                _wq['post'].append(lambda gt_w=gt_w, stage=stage, C_=C_, F_=F_: regroup_add(gt_w, stage, stage.shape[0], C_, F_, True))
             else:
                 dw = linear_wgrad_raw(dy2, x2, wc)
                 if ctx.perm is not None:
@@ -1119,6 +1118,13 @@ class LinearFn(torch.autograd.Function):
             else:
                 db = colsum_raw(dy2)
         return dx, dw, db, None, None, None, None, None, None
+
+
+def regroup_add(dst, src, rows, C_, F_, clear):
+    """dst[r, c, f] += src[r, f, c] in one launch (otr_regroup_add); clear: src is left zero"""
+    assert dst.dtype == torch.float32 and src.dtype == torch.float32 and dst.is_contiguous() and src.is_contiguous()
+    assert dst.numel() == src.numel() == rows * C_ * F_
+    L.check(L.load().otr_regroup_add(_p(dst), _p(src), rows, C_, F_, int(bool(clear)), _stream()), 'otr_regroup_add')
 
 
 def linear(x, w, b=None, relu=False, out_dtype=None, perm=None, defer_bias=False, link=None):
@@ -2673,6 +2679,7 @@ class ConvSubsampleFn(torch.autograd.Function):
         ctx.save_for_backward(x, w2r, act1, act2)
         ctx.desc_args = (B, T, F, C1, C2, T1, F1, T2, F2)
         ctx.refs = (w1_param, b1, b2)
+        ctx.w2_ref = w2
         return act2
 
     @staticmethod
@@ -2698,9 +2705,13 @@ class ConvSubsampleFn(torch.autograd.Function):
             g2 = relu_bwd_raw(act2, dact2)
             db2 = colsum_raw(g2.view(M2, C2), out=gb2)
         dw2r = torch.empty((C2, 3, 3, C1), dtype=torch.float32, device=x.device)
+        dact1 = torch.empty_like(act1)
+        # (r06, measured and removed: this weight gradient on a side stream -- a BRANCH of the captured step beside the input gradient
+        #  and conv1's weight gradient, which are independent of it -- made the step 0.065 ms SLOWER (3.99 -> 4.06 ms).  Branches do run
+        #  side by side on this stack, but ONE fork anywhere in a hipGraph takes the whole graph off the runtime's batched-packet path:
+        #  200 trivial nodes 318 -> 621 us, 200 streaming nodes 442 -> 611 us; tools/ubench/boundary.hip, profiles/r06_boundary_probe.txt)
         L.check(lib.otr_conv2_wgrad(C.byref(desc), _p(g2), _p(act1), _p(dw2r), _p(_workspace(x.device)), _WS_BYTES, _stream()),
                 'otr_conv2_wgrad')
-        dact1 = torch.empty_like(act1)
         rc = lib.otr_conv2_dgrad(C.byref(desc), _p(g2), _p(w2r), _p(act1), _p(dact1), _stream()) if _CONV2_IMPLICIT_DGRAD else 1
         if rc == 1:                          # operands do not qualify for the implicit kernel: column matrix + col2im
             dcol = torch.empty((M2, 9 * C1), dtype=adt, device=x.device)
@@ -2721,8 +2732,13 @@ class ConvSubsampleFn(torch.autograd.Function):
         inpl = gw1 is not None and gb1 is not None
         colsum_raw(part[:, :C1 * 9], out=dw1.view(-1), defer=inpl)
         colsum_raw(part[:, C1 * 9:], out=db1, defer=inpl)
-        return (None, None if inpl else dw1.view(C1, 1, 3, 3), None if inpl else db1, dw2r.permute(0, 3, 1, 2),
-                None if gb2 is not None else db2, None)
+        gw2 = grad_target(ctx.w2_ref)
+        if gw2 is not None and gw2.is_contiguous() and gw2.dtype == torch.float32:
+            regroup_add(gw2, dw2r, C2, C1, 9, False)                 # [C2, 9, C1] -> += [C2, C1, 3, 3] in one launch (it was AccumulateGrad's strided add)
+            dw2 = None
+        else:
+            dw2 = dw2r.permute(0, 3, 1, 2)
+        return (None, None if inpl else dw1.view(C1, 1, 3, 3), None if inpl else db1, dw2, None if gb2 is not None else db2, None)
 
 
 def conv_subsample_with_dropout(x, w1, b1, w2, b2, p_drop):
@@ -2872,25 +2888,29 @@ def _dp_from_pool(Pp, d, device):
     return pool[1][i]
 
 
-_DBD_PERSIST = os.environ.get('OTR_DBD_PERSIST', '1') != '0'
-_DBD_CACHE = {}
+_DBD_PERSIST = True        # tests flip it to compare with a fresh tensor per backward pass
 
 
 def _persistent_dbd(owner, like):
     """The gradient tensor of the relative-position score term, [B, T, H, Pp] fp32 (64 MB per Conformer block at the bench batch).  Only its
     band (column j - i + T - 1 of row i) is ever non-zero, and the attention backward rewrites EVERY in-range band entry (masked pairs
-    with 0), so the tensor is zeroed ONCE per (layer, shape) and kept: the per-step zero fill was 10.5 us x 12 blocks.  Keyed by the
-    layer's pos_proj weight; a few shapes per layer are kept (ragged batches), the oldest dropped."""
+    with 0), so the tensor is zeroed ONCE per (layer, shape) and kept: the per-step zero fill was 10.5 us x 12 blocks.
+    The buffer lives ON the layer's pos_proj weight (`owner._otr_dbd`), so it dies with the model; only the LAST shape is kept (a
+    ragged batch with a new T replaces it: no stale 64 MB buffers pinned per layer); and a second request for the same layer inside
+    ONE backward pass (a weight-shared layer applied twice: the deferred dp products of the first application still read the
+    buffer at flush time) gets a fresh tensor instead of the shared one."""
     if not _DBD_PERSIST:
         return torch.zeros_like(like)
-    key = (owner.data_ptr(), tuple(like.shape), str(like.device))
-    hit = _DBD_CACHE.get(key)
-    if hit is None:
-        mine = [k for k in _DBD_CACHE if k[0] == key[0]]
-        if len(mine) >= 2:
-            _DBD_CACHE.pop(mine[0])
-        hit = _DBD_CACHE[key] = torch.zeros_like(like)
-    return hit
+    task = torch._C._current_graph_task_id()
+    st = getattr(owner, '_otr_dbd', None)
+    if st is not None and st['buf'].shape == like.shape and st['buf'].device == like.device and st['buf'].dtype == like.dtype:
+        if task != -1 and st['task'] == task:
+            return torch.zeros_like(like)
+        st['task'] = task
+        return st['buf']
+    buf = torch.zeros_like(like)
+    owner._otr_dbd = {'buf': buf, 'task': task}
+    return buf
 
 
 class RelPosAttentionFn(torch.autograd.Function):

@@ -409,6 +409,7 @@ class CachedBeamState:
         self.scores[0].copy_(self.score0)
         self.flags[0].zero_()
         self.pos[0].zero_()
+        self.n_fin.zero_()       # incl. the prune kernel's arrival word: a launch aborted mid-step would leave it poisoned for every later batch
 
     @staticmethod
     def _close(blk, concat_linear, norm, x, a, ctx):

@@ -80,7 +80,7 @@ def test_argument_errors_of_the_round5_entries():
     assert lib.otr_zero_tick(odd, 1024, None, 0, None) < 0 and b'zero_tick' in lib.otr_last_error_string()
     assert lib.otr_zero_tick(None, 0, None, 0, None) == 0                                                # nothing to do
     assert lib.otr_scale_cast(odd, al, 1024, 16.0, None) < 0 and lib.otr_scale_cast(None, al, 8, 1.0, None) < 0
-    assert lib.otr_posenc_mask_fwd(al, al, None, 64, 8, 254, 16.0, None, 0, 0, None, None) < 0           # d % 4 != 0
+    assert lib.otr_posenc_mask_fwd(al, al, None, 64, 0, 256, 16.0, None, 0, 0, None, None) < 0             # T = 0 (r06: d % 4 != 0 is served again)
     assert lib.otr_posenc_mask_fwd(al, al, None, 64, 8, 256, 16.0, al, 8, 1, None, None) < 0             # mask_in without mask_out
 
 

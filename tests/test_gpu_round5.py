@@ -613,7 +613,7 @@ def test_residual_double_layernorm_against_torch(mode, d, M):
 def test_relpos_attention_gradient_tensor_kept_across_steps(mode):
     """ops.RelPosAttentionFn keeps the gradient tensor of the score term across steps (zeroed once: `_persistent_dbd`); the attention
     backward rewrites every in-range band entry, so a second pass with a DIFFERENT key mask (and different data) on the same module
-    gives the gradients a fresh tensor gives (OTR_DBD_PERSIST off)."""
+    gives the gradients a fresh tensor gives (ops._DBD_PERSIST off)."""
     import opentransformer_amd as ota
     from opentransformer_amd import ops, synthetic as syn
     from opentransformer_amd.nn import relative_sinusoid
@@ -638,10 +638,13 @@ def test_relpos_attention_gradient_tensor_kept_across_steps(mode):
             params = dict(mod.named_parameters())
             return [t.float().clone() for t in torch.autograd.grad(out, [x] + [params[n] for n in names], g)]
 
-        ops._DBD_CACHE.clear()
+        pw = mod.pos_proj.weight
+        if hasattr(pw, '_otr_dbd'):
+            del pw._otr_dbd
         run(11, [70, 70, 70], True)                     # fills the whole band of the kept tensor
+        kept = pw._otr_dbd['buf']
         second = run(12, [70, 41, 9], True)             # most of it masked now: stale entries would show up in every gradient
-        assert len(ops._DBD_CACHE) == 1
+        assert pw._otr_dbd['buf'] is kept               # the SAME tensor served the second pass (it lives on the layer: dies with the model)
         fresh = run(12, [70, 41, 9], False)
         for a, b in zip(second, fresh):
             assert torch.equal(a, b)

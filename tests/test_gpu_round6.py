@@ -1,0 +1,151 @@
+"""GPU (-m gpu): round-6 changes.
+
+* otr_posenc_fwd serves any d and any alignment again (the four-column kernel had become the only form);
+* store-first weight gradients are taken only when the clear and the launch share a capture context: a captured forward + backward
+  replayed twice between two eager zero_grad() calls ACCUMULATES, a capture that contains its own zero_grad stores;
+* otr_beam_topk on a row of NaNs returns in-range indices."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def torch_posenc(x):
+    B, T, d = x.shape
+    pos = torch.arange(T, device=x.device, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d, 2, device=x.device, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe = torch.zeros(T, d, device=x.device)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)[:, :d // 2]
+    return x * math.sqrt(d) + pe
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'fp16'])
+@pytest.mark.parametrize('d,odd_offset', [(254, False), (256, True), (30, True), (256, False)])
+def test_posenc_any_width_any_alignment(mode, d, odd_offset):
+    from opentransformer_amd import ops
+    ops.set_compute_dtype(mode)
+    try:
+        B, T = 3, 37
+        base = torch.randn(B * T * d + 1, device=DEV)
+        x = (base[1:] if odd_offset else base[:-1]).view(B, T, d)       # contiguous, but 4 bytes off a 16-byte boundary when odd_offset
+        assert x.is_contiguous() and (x.data_ptr() % 16 != 0) == odd_offset
+        xr = x.clone().requires_grad_(True)
+        y = ops.posenc(x.requires_grad_(True))
+        y = y[0] if isinstance(y, tuple) else y
+        ref = torch_posenc(xr)
+        assert rel(y.float(), ref) < 1e-5, rel(y.float(), ref)
+        g = torch.randn_like(ref)
+        gx, = torch.autograd.grad(y, x, g)
+        gr, = torch.autograd.grad(ref, xr, g)
+        assert rel(gx, gr) < 1e-5
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
+def _small_model():
+    import opentransformer_amd as ota
+    from opentransformer_amd import synthetic as syn
+    cfg = syn.c2_model(0.0)
+    cfg['encoder']['n_blocks'] = 1
+    cfg['decoder']['n_blocks'] = 1
+    inputs, targets = syn.synthetic_batch(batch=8, frames=1000, feat_dim=80, vocab=4234, tgt_len=15, seed=4)
+    inputs, targets = {k: v.to(DEV) for k, v in inputs.items()}, {k: v.to(DEV) for k, v in targets.items()}
+    model = ota.SpeechToText(cfg)
+    syn.fill_state_dict_(model.state_dict(), 9)
+    return model.to(DEV).train(), inputs, targets
+
+
+def test_store_first_weight_gradients_only_within_one_capture_context():
+    """the overwrite decision is baked into a captured graph.  (a) forward + backward captured WITHOUT the clear,
+    replayed twice after an eager zero_grad(): the weight gradients are twice one replay's (they accumulate like every other
+    gradient); (b) a capture that contains zero_grad + forward + backward stores: replayed twice it still holds ONE pass's gradient,
+    bit-equal to the eager pass."""
+    from opentransformer_amd import ops
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+    ops.set_compute_dtype('fp16')
+    try:
+        model, inputs, targets = _small_model()
+        dp = FlatDataParallel(model)
+        FusedAdam(dp, lr=1e-3, loss_scale=256.0)
+
+        def fwd_bwd():
+            loss, _ = dp(inputs, targets)
+            ops.backward(loss)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                dp.zero_grad()
+                fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        one = dp.flat_grad.clone()                                     # eager: clear and launch in the same (eager) context -> stored
+        assert float(one.abs().sum()) > 0
+        # (a) the clear is NOT part of the graph
+        dp.zero_grad()
+        g = torch.cuda.CUDAGraph()
+        with ops.graph_capture(g):
+            fwd_bwd()
+        dp.zero_grad()
+        g.replay(); g.replay()
+        torch.cuda.synchronize()
+        assert rel(dp.flat_grad, 2 * one) < 1e-5, rel(dp.flat_grad, 2 * one)
+        # (b) the clear is part of the graph
+        g2 = torch.cuda.CUDAGraph()
+        with ops.graph_capture(g2):
+            dp.zero_grad()
+            fwd_bwd()
+        g2.replay(); g2.replay()
+        torch.cuda.synchronize()
+        assert rel(dp.flat_grad, one) < 1e-6, rel(dp.flat_grad, one)
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
+def test_foreign_writer_of_a_registered_gradient_is_not_overwritten():
+    from opentransformer_amd import ops
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+    ops.set_compute_dtype('fp16')
+    try:
+        model, inputs, targets = _small_model()
+        dp = FlatDataParallel(model)
+        FusedAdam(dp, lr=1e-3, loss_scale=256.0)
+        w = model.encoder.blocks[0].slf_attn.qvk_proj.weight
+        dp.zero_grad()
+        loss, _ = dp(inputs, targets); ops.backward(loss); torch.cuda.synchronize()
+        plain = w.grad.clone()
+        dp.zero_grad()
+        w.grad.add_(3.0)                                               # e.g. a hook, or an AccumulateGrad of a torch-native use
+        ops.gradients_written([w.grad.data_ptr()])
+        loss, _ = dp(inputs, targets); ops.backward(loss); torch.cuda.synchronize()
+        assert rel(w.grad, plain + 3.0) < 1e-5
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
+def test_beam_topk_on_a_row_of_nans_returns_in_range_indices():
+    from opentransformer_amd import _lib as L
+    lib = L.load()
+    V, k = 4234, 10
+    logits = torch.randn(3, V, device=DEV)
+    logits[1] = float('nan')
+    score = torch.empty(3, k, device=DEV)
+    idx = torch.full((3, k), -7, dtype=torch.int64, device=DEV)
+    L.check(lib.otr_beam_topk(C.c_void_p(logits.data_ptr()), V, None, 0, 0.0, 3, V, k, C.c_void_p(score.data_ptr()), C.c_void_p(idx.data_ptr()),
+                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'otr_beam_topk')
+    torch.cuda.synchronize()
+    assert int(idx.min()) >= 0 and int(idx.max()) < V, idx
+    assert idx[1].tolist() == list(range(k))                          # a row that cannot be ranked yields its lowest indices, in order
+    lp = torch.log_softmax(logits[[0, 2]], dim=-1)
+    ref = torch.topk(lp, k, dim=-1)
+    assert torch.equal(idx[[0, 2]], ref.indices) and rel(score[[0, 2]], ref.values) < 1e-6

@@ -236,6 +236,48 @@ int main(int argc, char** argv) {
       }
     }
   }
+  // ---- what does ONE fork / join pair cost a long chain?  200 trivial nodes; in the forked variant nodes 100..109 have a 2-node side
+  // branch beside them.  If only the fork's neighbourhood pays, the difference is a few us; if the runtime executes a graph with a
+  // branch differently as a whole, every node pays.
+  {
+    hipStream_t s2;
+    CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    hipEvent_t ef, ej;
+    CK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+    for (int body = 0; body < 2; ++body) {
+      auto node = [&](hipStream_t st) {
+        if (body) hipLaunchKernelGGL(k_stream, dim3(1024), dim3(256), 0, st, a, b, (4l << 20) / 16);
+        else hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st);
+      };
+      auto side_node = [&](hipStream_t st) { hipLaunchKernelGGL(k_read, dim3(256), dim3(256), 0, st, a + (16l << 20) / 16, (1l << 20) / 16, sink); };
+      hipGraph_t g1, g2, g3;
+      CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      for (int i = 0; i < 200; ++i) node(s);
+      side_node(s); side_node(s);
+      CK(hipStreamEndCapture(s, &g1));
+      CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      for (int i = 0; i < 200; ++i) {
+        if (i == 100) { CK(hipEventRecord(ef, s)); CK(hipStreamWaitEvent(s2, ef, 0)); side_node(s2); side_node(s2); CK(hipEventRecord(ej, s2)); }
+        if (i == 110) CK(hipStreamWaitEvent(s, ej, 0));
+        node(s);
+      }
+      CK(hipStreamEndCapture(s, &g2));
+      // fork at the very start, join at the very end
+      CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      CK(hipEventRecord(ef, s)); CK(hipStreamWaitEvent(s2, ef, 0)); side_node(s2); side_node(s2); CK(hipEventRecord(ej, s2));
+      for (int i = 0; i < 200; ++i) node(s);
+      CK(hipStreamWaitEvent(s, ej, 0));
+      CK(hipStreamEndCapture(s, &g3));
+      hipGraphExec_t x1, x2, x3;
+      CK(hipGraphInstantiate(&x1, g1, nullptr, nullptr, 0)); CK(hipGraphInstantiate(&x2, g2, nullptr, nullptr, 0)); CK(hipGraphInstantiate(&x3, g3, nullptr, nullptr, 0));
+      double e1, e2, e3;
+      const double t1 = time_graph(x1, 1, 20, s, &e1), t2 = time_graph(x2, 1, 20, s, &e2), t3 = time_graph(x3, 1, 20, s, &e3);
+      printf("# one fork in a chain of 200 %s nodes (+ 2 side nodes): all in one chain %.1f us; side nodes as a branch beside nodes 100..109 %.1f us; "
+             "branch forked at the start, joined at the end %.1f us\n", body ? "4 MiB-stream" : "trivial", t1, t2, t3);
+      CK(hipGraphExecDestroy(x1)); CK(hipGraphExecDestroy(x2)); CK(hipGraphExecDestroy(x3));
+      CK(hipGraphDestroy(g1)); CK(hipGraphDestroy(g2)); CK(hipGraphDestroy(g3));
+    }
+  }
   // one replay at a time with a host sync in between: the per-replay floor (not a per-node cost)
   {
     Launch f = cases[1].f;
