@@ -1,5 +1,7 @@
 // Encoder self-attention backward for the shipped shape class (module/attention.py:23-46 under autograd; encoder/transformer.py:47-49):
-// 16-bit operands, head dim 64, no causal mask, no score bias, T <= 256 frames after the frontend (AISHELL: 249).
+// 16-bit operands, head dim 64, no causal mask, no score bias, T <= 512 frames after the frontend (AISHELL's 10 s bench utterances: 249; its longest,
+// ~14.5 s: 363).  Up to 256 frames one (utterance, head) lives in LDS whole (below); beyond (r06, MULTI) the SAME code walks the streamed side in
+// super-chunks of 256 rows, restaging the images between them, and the owned side is cut into blocks of 256 rows, one workgroup each.
 //
 // Why a second kernel beside attention.hip: that one is generic (any T, head dim, fp32) -- 16-row MFMA tiles, the streamed side
 // re-staged block by block behind two barriers each, every 16-cycle MFMA fed by a fresh 1 KiB LDS operand.  At 32 x 4 x 249 x 64 it
@@ -20,7 +22,8 @@
 
 namespace {
 
-constexpr int EA_T = 256;                 // most frames served
+constexpr int EA_T = 256;                 // rows of one LDS image: most frames served in ONE pass
+constexpr int EA_TMAX = 512;              // most frames served at all (own blocks x streamed super-chunks of EA_T)
 constexpr int EA_DK = 64;
 constexpr int EA_HS = EA_DK * 2 + 16;     // bytes per row of a row-major [T][64] 16-bit image
 constexpr int EA_TS = EA_T * 2 + 8;       // bytes per row of a transposed [64][T] 16-bit image
@@ -135,16 +138,22 @@ __device__ __forceinline__ void ea_store_rows(const f32x16 (&acc)[2], float scal
 
 constexpr int EA_SMEM = 2 * EA_RM + 2 * EA_TR + 2 * EA_T * 4;
 
+// MULTI = false: T <= 256, one own block, one super-chunk -- every `s0` / `o0` below folds to 0 and the code is the round-4 kernel.
+// MULTI = true: own block ob = rows 256 ob .. (one workgroup per block, orientation and (utterance, head)), streamed super-chunks
+// s0 = 0, 256, ...: the accumulators of the own rows live across them, the images are restaged behind a barrier.
+template <bool MULTI>
 __global__ __launch_bounds__(512, 1) void encattn_bwd_kernel(EaArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[EA_SMEM];
   const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, hi = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   // the two orientations of one (utterance, head) get workgroup ids equal modulo 8: one XCD (placement observed, used for locality only)
   const int xcd = (int)blockIdx.x & 7, kk = (int)blockIdx.x >> 3;
-  const int orient = kk & 1, g = (kk >> 1) * 8 + xcd;
+  const int T = p.T;
+  const int nob = MULTI ? (T + EA_T - 1) / EA_T : 1;               // own blocks
+  const int orient = kk & 1, ob = MULTI ? (kk >> 1) % nob : 0, g = (MULTI ? (kk >> 1) / nob : (kk >> 1)) * 8 + xcd;
   if (g >= p.H * p.B) return;
   const int h = g % p.H, b = g / p.H;
-  const int T = p.T, nt = (T + 31) >> 5, nrows = nt * 32;
+  const int o0 = ob * EA_T;                                        // first own row of this workgroup
   const float sc2 = p.scale * EA_LOG2E;
   const uint16_t* Q = p.q + (int64_t)b * p.q_bs + h * EA_DK;
   const uint16_t* K = p.k + (int64_t)b * p.k_bs + h * EA_DK;
@@ -153,8 +162,9 @@ __global__ __launch_bounds__(512, 1) void encattn_bwd_kernel(EaArgs p) {
   const uint16_t* dO = p.do_ + (int64_t)b * p.o_bs + h * EA_DK;
   const float* lse = p.lse + ((int64_t)b * p.H + h) * T;
   const uint8_t* km = p.key_mask ? p.key_mask + (int64_t)b * T : nullptr;
-  const int own = 32 * wid + m;                                  // this lane's own row (query or key)
+  const int own = o0 + 32 * wid + m;                             // this lane's own row (query or key)
   const int ownc = min(own, T - 1);
+  const bool wave_live = o0 + 32 * wid < T;                      // this wave owns at least one real row
   EA_STAMP(0);
 
   if (orient == 0) {
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(512, 1) void encattn_bwd_kernel(EaArgs p) {
     ea_load_frags(dof, dO, p.o_ts, ownc, hi);
     ea_load_frags(of, O, p.o_ts, ownc, hi);
     const float l0 = lse[ownc];
-    const uint8_t kmb = km ? km[min(tid, T - 1)] : (uint8_t)1;
+    uint8_t kmb = km ? km[min(tid, T - 1)] : (uint8_t)1;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       gk[c] = ea_issue(K, p.k_ts, T, tid, c);
@@ -176,7 +186,6 @@ __global__ __launch_bounds__(512, 1) void encattn_bwd_kernel(EaArgs p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     EA_STAMP(1);
-    if (tid < EA_T) kbias[tid] = (tid < T && kmb) ? 0.f : -__builtin_huge_valf();
     float del = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -215,24 +224,37 @@ __global__ __launch_bounds__(512, 1) void encattn_bwd_kernel(EaArgs p) {
         for (int ct = 0; ct < 2; ++ct) mma32(dq[ct], ea_tfrag(kt, 32 * ct + m, jt * 32, hi, k2), pb);
       }
     };
+    for (int s0 = 0; s0 < (MULTI ? T : 1); s0 += EA_T) {           // streamed super-chunks (one when T <= 256)
+      const int Ts = MULTI ? min(EA_T, T - s0) : T, nt = (Ts + 31) >> 5;
+      if (MULTI && s0 > 0) {
+        __syncthreads();                                           // every wave is done with the previous super-chunk's images
+        kmb = km ? km[min(s0 + tid, T - 1)] : (uint8_t)1;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (2 * c >= nt) break;                                       // uniform over the workgroup
-      ea_stage_rm<false>(krm, gk[c], gk[c], nullptr, T, tid, c);
-      ea_stage_rm<false>(vrm, gv[c], gv[c], nullptr, T, tid, c);
-      __syncthreads();
-      ea_transpose(kt, krm, c, tid & 255, 2 * (tid >> 8), 2);
-      __syncthreads();
-      if (c == 0) EA_STAMP(2);
-      if (32 * wid < T) {
-        tile(2 * c);
-        if (2 * c + 1 < nt) tile(2 * c + 1);
+        for (int c = 0; c < 4; ++c) {
+          gk[c] = ea_issue(K + (int64_t)s0 * p.k_ts, p.k_ts, Ts, tid, c);
+          gv[c] = ea_issue(V + (int64_t)s0 * p.v_ts, p.v_ts, Ts, tid, c);
+        }
+      }
+      if (tid < EA_T) kbias[tid] = (tid < Ts && kmb) ? 0.f : -__builtin_huge_valf();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (2 * c >= nt) break;                                     // uniform over the workgroup
+        ea_stage_rm<false>(krm, gk[c], gk[c], nullptr, Ts, tid, c);
+        ea_stage_rm<false>(vrm, gv[c], gv[c], nullptr, Ts, tid, c);
+        __syncthreads();
+        ea_transpose(kt, krm, c, tid & 255, 2 * (tid >> 8), 2);
+        __syncthreads();
+        if (c == 0) EA_STAMP(2);
+        if (wave_live) {
+          tile(2 * c);
+          if (2 * c + 1 < nt) tile(2 * c + 1);
+        }
       }
     }
     EA_STAMP(3);
     __syncthreads();                                               // every wave is done with the images: they become staging space
     EA_STAMP(4);
-    if (32 * wid < T) ea_store_rows(dq, p.scale, true, krm + 32 * wid * EA_HS, p.dq + (int64_t)b * p.q_bs + h * EA_DK, p.q_ts, 32 * wid, T, lane);
+    if (wave_live) ea_store_rows(dq, p.scale, true, krm + 32 * wid * EA_HS, p.dq + (int64_t)b * p.q_bs + h * EA_DK, p.q_ts, o0 + 32 * wid, T, lane);
     EA_STAMP(5);
   } else {
     // ------------------------------------------------------------------ lane = key: dV = P^T dO, dK = scale . dS^T Q
@@ -245,7 +267,7 @@ __global__ __launch_bounds__(512, 1) void encattn_bwd_kernel(EaArgs p) {
     uint4 gq[4], gdo[4], go[4], kf[4], vf[4];
     ea_load_frags(kf, K, p.k_ts, ownc, hi);                                      // the own side first: the first tile needs it
     ea_load_frags(vf, V, p.v_ts, ownc, hi);
-    const float l0 = lse[min(tid, T - 1)];
+    float l0 = lse[min(tid, T - 1)];
     const uint8_t kmb = km ? km[ownc] : (uint8_t)1;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -255,7 +277,6 @@ __global__ __launch_bounds__(512, 1) void encattn_bwd_kernel(EaArgs p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     EA_STAMP(1);
-    if (tid < EA_T) nls[tid] = (tid < T && l0 != -__builtin_huge_valf()) ? -l0 * EA_LOG2E : -__builtin_huge_valf();
     // a masked key (or one past T) only pollutes ITS OWN dk / dv rows -- the lane is a column of every product here -- so the loop
     // carries no mask at all and the rows are zeroed on their way out
     const bool keyok = own < T && kmb;
@@ -291,27 +312,41 @@ __global__ __launch_bounds__(512, 1) void encattn_bwd_kernel(EaArgs p) {
         }
       }
     };
+    for (int s0 = 0; s0 < (MULTI ? T : 1); s0 += EA_T) {           // streamed super-chunks of queries (one when T <= 256)
+      const int Ts = MULTI ? min(EA_T, T - s0) : T, nt = (Ts + 31) >> 5;
+      if (MULTI && s0 > 0) {
+        __syncthreads();                                           // every wave is done with the previous super-chunk's images
+        l0 = lse[min(s0 + tid, T - 1)];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (2 * c >= nt) break;                                       // uniform over the workgroup
-      ea_stage_rm<false>(qrm, gq[c], gq[c], nullptr, T, tid, c);
-      ea_stage_rm<true>(dorm, gdo[c], go[c], dels, T, tid, c);
-      __syncthreads();
-      if (tid < 256) ea_transpose(qt, qrm, c, tid, 0, 4);           // wave-uniform split: four waves per image
-      else ea_transpose(dot, dorm, c, tid - 256, 0, 4);
-      __syncthreads();
-      if (c == 0) EA_STAMP(2);
-      if (32 * wid < T) {
-        tile(2 * c);
-        if (2 * c + 1 < nt) tile(2 * c + 1);
+        for (int c = 0; c < 4; ++c) {
+          gq[c] = ea_issue(Q + (int64_t)s0 * p.q_ts, p.q_ts, Ts, tid, c);
+          gdo[c] = ea_issue(dO + (int64_t)s0 * p.o_ts, p.o_ts, Ts, tid, c);
+          go[c] = ea_issue(O + (int64_t)s0 * p.o_ts, p.o_ts, Ts, tid, c);
+        }
+      }
+      if (tid < EA_T) nls[tid] = (tid < Ts && l0 != -__builtin_huge_valf()) ? -l0 * EA_LOG2E : -__builtin_huge_valf();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (2 * c >= nt) break;                                     // uniform over the workgroup
+        ea_stage_rm<false>(qrm, gq[c], gq[c], nullptr, Ts, tid, c);
+        ea_stage_rm<true>(dorm, gdo[c], go[c], dels, Ts, tid, c);
+        __syncthreads();
+        if (tid < 256) ea_transpose(qt, qrm, c, tid, 0, 4);         // wave-uniform split: four waves per image
+        else ea_transpose(dot, dorm, c, tid - 256, 0, 4);
+        __syncthreads();
+        if (c == 0) EA_STAMP(2);
+        if (wave_live) {
+          tile(2 * c);
+          if (2 * c + 1 < nt) tile(2 * c + 1);
+        }
       }
     }
     EA_STAMP(3);
     __syncthreads();
     EA_STAMP(4);
-    if (32 * wid < T) {
-      ea_store_rows(dk, p.scale, keyok, qrm + 32 * wid * EA_HS, p.dk + (int64_t)b * p.k_bs + h * EA_DK, p.k_ts, 32 * wid, T, lane);
-      ea_store_rows(dv, 1.f, keyok, dorm + 32 * wid * EA_HS, p.dv + (int64_t)b * p.v_bs + h * EA_DK, p.v_ts, 32 * wid, T, lane);
+    if (wave_live) {
+      ea_store_rows(dk, p.scale, keyok, qrm + 32 * wid * EA_HS, p.dk + (int64_t)b * p.k_bs + h * EA_DK, p.k_ts, o0 + 32 * wid, T, lane);
+      ea_store_rows(dv, 1.f, keyok, dorm + 32 * wid * EA_HS, p.dv + (int64_t)b * p.v_bs + h * EA_DK, p.v_ts, o0 + 32 * wid, T, lane);
     }
     EA_STAMP(5);
   }
@@ -323,7 +358,7 @@ extern unsigned long long* g_otr_trace;
 
 // shapes this kernel serves (attention.hip asks before it takes its own path)
 bool encattn_bwd_takes(int dtype_is_h16, int dk, int Tq, int Tk, int causal, int has_bias, int vec) {
-  return dtype_is_h16 && dk == EA_DK && Tq == Tk && Tq >= 1 && Tq <= EA_T && !causal && !has_bias && vec;
+  return dtype_is_h16 && dk == EA_DK && Tq == Tk && Tq >= 1 && Tq <= EA_TMAX && !causal && !has_bias && vec;
 }
 
 int32_t encattn_bwd_launch(const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse, const uint8_t* key_mask,
@@ -335,7 +370,13 @@ int32_t encattn_bwd_launch(const void* q, const void* k, const void* v, const vo
   p.dq = (uint16_t*)dq; p.dk = (uint16_t*)dk; p.dv = (uint16_t*)dv; p.key_mask = key_mask; p.lse = lse;
   p.B = B; p.H = H; p.T = T; p.q_bs = q_bs; p.q_ts = q_ts; p.k_bs = k_bs; p.k_ts = k_ts; p.v_bs = v_bs; p.v_ts = v_ts; p.o_bs = o_bs; p.o_ts = o_ts;
   p.scale = scale;
-  const unsigned grid = 8u * 2u * (unsigned)((H * B + 7) / 8);
-  hipLaunchKernelGGL(encattn_bwd_kernel, dim3(grid), dim3(512), 0, stream, p);
+  if (T <= EA_T) {
+    const unsigned grid = 8u * 2u * (unsigned)((H * B + 7) / 8);
+    hipLaunchKernelGGL(encattn_bwd_kernel<false>, dim3(grid), dim3(512), 0, stream, p);
+  } else {
+    const unsigned nob = (unsigned)((T + EA_T - 1) / EA_T);
+    const unsigned grid = 8u * 2u * nob * (unsigned)((H * B + 7) / 8);
+    hipLaunchKernelGGL(encattn_bwd_kernel<true>, dim3(grid), dim3(512), 0, stream, p);
+  }
   return otr_check_launch("encattn_bwd");
 }

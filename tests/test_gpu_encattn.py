@@ -5,8 +5,9 @@
  * the generic streamed kernels of attention.hip (otr_debug_set(21, 0)), which round at the same places.
 
 Shapes: the AISHELL one (249 frames), exact tile multiples, one frame, a partial last tile, head counts that leave padding workgroups in
-the XCD-aware grid, ragged key masks (an utterance with ONE live key included), and T = 256 (every wave busy); T = 257 must fall
-back to the generic kernels."""
+the XCD-aware grid, ragged key masks (an utterance with ONE live key included), and T = 256 (every wave busy).  r06: 257 <= T <= 512 run
+on the same kernel (own blocks of 256 rows x streamed super-chunks of 256 rows: 257 = a second block of ONE row, 349 / 363 = AISHELL's
+longest utterances, 384, 512 = every wave of both blocks busy); T = 513 falls back to the generic kernels."""
 import math
 
 import pytest
@@ -48,7 +49,10 @@ def run(qkv, km, H, g, enc):
 
 @pytest.mark.parametrize('mode', ['fp16', 'bf16'])
 @pytest.mark.parametrize('B,T,H,ragged', [(3, 249, 4, True), (32, 249, 4, True), (5, 32, 4, False), (2, 33, 3, True), (9, 256, 1, True),
-                                          (2, 1, 4, False), (4, 100, 2, True), (1, 64, 4, False), (3, 257, 4, True)])
+                                          (2, 1, 4, False), (4, 100, 2, True), (1, 64, 4, False), (3, 257, 4, True),
+                                          # r06: beyond 256 frames -- own blocks x streamed super-chunks (AISHELL's longest utterances: T' ~ 349-363)
+                                          (4, 349, 4, True), (32, 349, 4, True), (3, 363, 4, True), (2, 384, 2, True), (2, 512, 1, True), (5, 289, 3, True),
+                                          (1, 513, 2, False)])
 def test_encoder_attention_backward(mode, B, T, H, ragged):
     from opentransformer_amd import ops
     ops.set_compute_dtype(mode)
