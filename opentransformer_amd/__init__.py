@@ -15,5 +15,28 @@ from .nn import (ConvFrontEnd, TransformerEncoder, TransformerEncoderLayer, Tran
                  TransformerDecoderLayer, MultiHeadedSelfAttention, MultiHeadedCrossAttention,
                  PositionwiseFeedForward, PositionalEncoding, LabelSmoothingLoss)
 
+
+
+def _apply_switch_overrides():
+    """The ONE environment hook of the Python side (r06: the 39 `OTR_*` reads scattered over ops / nn / recognize are module constants
+    now): OTR_SWITCHES="ops._FFN_SLAB=0,nn._LN2=0,recognize._DECODE_FORK=0" sets module-level switches for an A/B run
+    (tools/gpu_ab.sh TAG OTR_SWITCHES ops._X=1 ops._X=0).  Values are integers; a switch that is a bool stays a bool.  An unknown
+    name is an error: a typo must not silently measure the default twice.  The C side has the same single hook: OTR_DEBUG_SET."""
+    import os
+    spec = os.environ.get('OTR_SWITCHES', '')
+    if not spec:
+        return
+    from . import nn as _nn, ops as _ops, recognize as _rec
+    mods = {'ops': _ops, 'nn': _nn, 'recognize': _rec}
+    for item in filter(None, spec.split(',')):
+        name, val = item.split('=')
+        mod, attr = name.split('.')
+        cur = getattr(mods[mod], attr)            # AttributeError / KeyError on an unknown switch
+        assert attr.startswith('_') and isinstance(cur, (bool, int)), 'OTR_SWITCHES: %s is not a switch' % name
+        setattr(mods[mod], attr, bool(int(val)) if isinstance(cur, bool) else int(val))
+
+
+_apply_switch_overrides()
+
 __all__ = ['BuildFrontEnd', 'BuildEncoder', 'BuildDecoder', 'End2EndModel', 'SpeechToText', 'CTCAssistor',
            'set_compute_dtype', 'get_compute_dtype']

@@ -18,16 +18,15 @@ frontend's conv layers (frontend/conv.py:66) runs through ops.dropout (counter R
 raises NotImplementedError): in_channel != 1, pos_dropout > 0 (which in the reference silently switches the formula).
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
 
 from . import ops
 
-_MASK_FOLD = os.environ.get('OTR_CONV_MASK_FOLD', '1') != '0'  # ... and the convolution branch's row mask applied by that launch
-_LN2 = os.environ.get('OTR_LN2', '1') != '0'                   # ... and post_ffn_norm + final_norm in one launch each way
-_RES_LN = os.environ.get('OTR_RESIDUAL_LN', '1') != '0'     # ConformerEncoderBlock: residual adds fused into the LayerNorms that follow them
+_MASK_FOLD = True  # ... and the convolution branch's row mask applied by that launch
+_LN2 = True                   # ... and post_ffn_norm + final_norm in one launch each way
+_RES_LN = True     # ConformerEncoderBlock: residual adds fused into the LayerNorms that follow them
 
 PAD, BLK, BOS, EOS = 0, 0, 1, 1       # otrans/data/__init__.py:7-12
 

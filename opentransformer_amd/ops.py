@@ -262,7 +262,7 @@ def backward(loss):
 #    refreshes in the same pass as the fp32 master, or (stand-alone modules) a cached cast keyed by
 #    the parameter's version counter.
 _LP_ATTR = '_otr_bf16'
-_PAD_ROWS = os.environ.get('OTR_PAD_ROWS', '1') != '0'      # A/B switch of ops.padded_rows
+_PAD_ROWS = True      # A/B switch of ops.padded_rows
 
 
 def lp_of(t):
@@ -464,7 +464,7 @@ class LnOutLink:
         self.prefetch = None       # (tensor, bytes): what the launch AFTER the linked Linear's backward streams first (otr_rb_linear_ln_bwd_pf)
 
 
-_LNOUT = os.environ.get('OTR_LNOUT_LINK', '1') == '1'
+_LNOUT = True
 
 
 class LnInLink:
@@ -591,8 +591,8 @@ def gradients_written(ptrs):
     accumulates instead of storing"""
     _wq_excl['written'].update(ptrs)
 
-_FUSE_BIAS_COLSUM = os.environ.get('OTR_NO_FUSED_BIAS_COLSUM', '0') != '1'
-_DEBUG_WQ = os.environ.get('OTR_DEBUG_WQ', '0') == '1'
+_FUSE_BIAS_COLSUM = True
+_DEBUG_WQ = False
 
 
 def defer_weight_grads(on):
@@ -882,9 +882,9 @@ def _rows(x):
 # (csrc/rowblock.hip) on fragment-major packs of the weight: `fwd` = pack(W as A[n][k]) and `dgrad` = pack(W as A[k][n]),
 # slices of FlatDataParallel's pack buffer (refreshed with the FFN packs after every optimizer step) or, for stand-alone
 # modules, a cache keyed by the parameter version.
-_RB = os.environ.get('OTR_NO_ROWBLOCK', '0') != '1'
+_RB = True
 _RB_SHAPES = ((256, 256), (768, 256))          # (N, K) of the Linear
-_RB_LINEAR_MIN_ROWS = int(os.environ.get('OTR_RB_LINEAR_MIN_ROWS', '1024'))   # below: 16 workgroups each streaming the whole weight lose to the 64-wide tile GEMM
+_RB_LINEAR_MIN_ROWS = 1024   # below: 16 workgroups each streaming the whole weight lose to the 64-wide tile GEMM
 
 
 def lin_pack_items(w_off, N, K, dst_off):
@@ -1750,7 +1750,7 @@ def proj_ln_packs(x, c, w, gamma):
     return lin_packs(w)
 
 
-_FFN_FWD_TOUCH = os.environ.get('OTR_FFN_FWD_TOUCH', '1') == '1'
+_FFN_FWD_TOUCH = True
 
 
 def touch_ffn_packs_next(ff, x):
@@ -1861,22 +1861,22 @@ class FeedForwardGLUFn(torch.autograd.Function):
 # is never stored: the backward pass recomputes it (csrc/ffn_fused.hip).  Weights are consumed "fragment-major": four packed
 # copies per FFN (w_1, w_2, w_2^T, w_1^T in MFMA-operand order) that FlatDataParallel refreshes after every optimizer step
 # (one otr_pack_frags launch for the whole model) or, for stand-alone modules, a cache keyed by the parameter versions.
-_FUSED_FFN = os.environ.get('OTR_NO_FUSED_FFN', '0') != '1'
-_FUSED_FFN_MIN_ROWS = int(os.environ.get('OTR_FUSED_FFN_MIN_ROWS', '1024'))   # below: too few 32-row workgroups to fill the chip
+_FUSED_FFN = True
+_FUSED_FFN_MIN_ROWS = 1024   # below: too few 32-row workgroups to fill the chip
 
 
 # 128-row workgroups with the hidden units split four ways and the partial sums exchanged inside the launch (csrc/ffn3.hip):
 # the default from 2048 rows up; OTR_FFN_SPLIT=0 keeps the 32-row kernels
-_FFN_SPLIT = os.environ.get('OTR_FFN_SPLIT', '1') == '1'
+_FFN_SPLIT = True
 # the split kernels in slab mode (no in-launch exchange; the LayerNorm moves into the next launch's prologue) where the caller allows it
-_FFN_SLAB = os.environ.get('OTR_FFN_SLAB', '1') == '1'
-_FFN_PREFETCH = os.environ.get('OTR_FFN_PREFETCH', '1') == '1'
-_Z_TOUCH = os.environ.get('OTR_Z_TOUCH', '0') == '1'
-_QKV_W_TOUCH = os.environ.get('OTR_QKV_W_TOUCH', '0') == '1'              # experiment: ln_bwd_proj touches the q|k|v input-gradient pack
-_FFN_HSAVE_TOUCH = os.environ.get('OTR_FFN_HSAVE_TOUCH', '0') == '1'      # experiment: the saved tiles (65 MB) as well
+_FFN_SLAB = True
+_FFN_PREFETCH = True
+_Z_TOUCH = False
+_QKV_W_TOUCH = False              # experiment: ln_bwd_proj touches the q|k|v input-gradient pack
+_FFN_HSAVE_TOUCH = False      # experiment: the saved tiles (65 MB) as well
 # the same for the attention backward launch's saved q|k|v + context, touched by the LayerNorm-backward launch before it (otr_touch_hint):
 # -3.6 us per launch in tools/encattn_prefetch_probe.py, nothing measurable in the step (4.478 vs 4.471 / 4.500 ms on one box): off
-_ATTN_PREFETCH = os.environ.get('OTR_ATTN_PREFETCH', '0') == '1'
+_ATTN_PREFETCH = False
 _FFN_SPLIT_MIN_ROWS = 2048
 _FFN_SYNC_INTS = 1 << 14
 
@@ -2190,18 +2190,18 @@ class GLUFn(torch.autograd.Function):
 
 
 GLU_RPB = 32        # rows per workgroup of otr_glu_bwd (csrc/elementwise.hip)
-_FUSED_GLU_BWD = os.environ.get('OTR_NO_FUSED_GLU_BWD', '0') != '1'     # A/B switches for tuning runs
-_FUSED_GLU_FWD = os.environ.get('OTR_NO_FUSED_GLU_FWD', '0') != '1'
+_FUSED_GLU_BWD = True     # A/B switches for tuning runs
+_FUSED_GLU_FWD = True
 
 
 # ---------------------------------------------------------------------------------------- fused decoder stack
 # The post-norm Transformer decoder on few rows (B x L = 480 at the AISHELL batch; decoder/transformer.py:47-90,161-183) as three
 # launches per layer and direction, cut along (utterance group, head) / (row block, hidden slice) instead of along operators
 # (csrc/declayer.hip).  A sub-layer leaves PARTIAL sums ("slabs") and the next launch finishes the LayerNorm in its prologue.
-_DEC_FUSED = os.environ.get('OTR_NO_FUSED_DECODER', '0') != '1'
-_DEC_TOUCH = os.environ.get('OTR_DEC_TOUCH', '1') == '1'
-_DEC_FFN_SLICES = int(os.environ.get('OTR_DEC_FFN_SLICES', '8'))
-_EMBED_SINK = os.environ.get('OTR_EMBED_SINK', '1') == '1'     # A/B: the decoder stack's input gradient summed by the embedding's backward
+_DEC_FUSED = True
+_DEC_TOUCH = True
+_DEC_FFN_SLICES = 8
+_EMBED_SINK = True     # A/B: the decoder stack's input gradient summed by the embedding's backward
 DEC_LAYER_PARAMS = 18      # qvk w,b | out w,b | norm1 w,b | q w,b | out w,b | norm2 w,b | w_1 w,b | w_2 w,b | norm3 w,b
 
 
@@ -2442,8 +2442,8 @@ class _Grad16Link:
     armed = False
 
 
-_G16 = os.environ.get('OTR_GRAD16_LINK', '1') == '1'
-_G16_LOSS = os.environ.get('OTR_GRAD16_LOSS', '1') == '1'      # A/B: the loss launch's gradient as a 16-bit operand of the output layer
+_G16 = True
+_G16_LOSS = True      # A/B: the loss launch's gradient as a 16-bit operand of the output layer
 
 
 class PosEncFn(torch.autograd.Function):
@@ -2765,10 +2765,10 @@ def _gemm_ptr(kind, M, N, K, x, w, y, bias=None, accumulate=0):
                 'otr_linear_wgrad')
 
 
-_GEMM_BATCHED = os.environ.get('OTR_GEMM_BATCHED', '1') != '0'
-_BN_PART = os.environ.get('OTR_BN_PART', '1') != '0'          # ConformerConvFn: BatchNorm batch statistics through per-workgroup sums
-_DW_PART = os.environ.get('OTR_DWCONV_PART', '1') != '0'      # ConformerConvFn: depthwise-conv parameter gradients through per-workgroup sums
-_POS_DEFER = os.environ.get('OTR_POS_DEFER', '1') != '0'      # RelPosAttentionFn: the per-head dp products join the grouped weight-gradient launch
+_GEMM_BATCHED = True
+_BN_PART = True          # ConformerConvFn: BatchNorm batch statistics through per-workgroup sums
+_DW_PART = True      # ConformerConvFn: depthwise-conv parameter gradients through per-workgroup sums
+_POS_DEFER = True      # RelPosAttentionFn: the per-head dp products join the grouped weight-gradient launch
 
 
 def _gemm_heads(M, N, K, x, w, y, nb, bsx, bsw, bsy):
@@ -3244,7 +3244,7 @@ class LabelSmoothingLossFusedFn(torch.autograd.Function):
         return (out.view(ctx.shape),) + (None,) * 9
 
 
-_LS_FUSED = os.environ.get('OTR_LS_FUSED', '1') == '1'
+_LS_FUSED = True
 
 
 def _ls_ticket(device):

@@ -14,7 +14,6 @@ Same constructor arguments and return values as the reference recognizers.  Two 
   (decoder + LM + scoring + pruning).  Hypotheses are identical to the re-forward loop.
 """
 import ctypes as C
-import os
 import weakref
 
 import torch
@@ -24,9 +23,9 @@ from . import _lib as L
 from . import ops
 from .nn import (BOS, EOS, PAD, LabelSmoothingLoss, PositionalEncoding, TransformerEncoderLayer)
 
-_DECODE_STEP_FUSED = os.environ.get('OTR_DECODE_STEP_FUSED', '1') != '0'   # cached beam step on otr_dec_self_step + the fused tail
-_DECODE_FFN16 = os.environ.get('OTR_DECODE_FFN16', '1') != '0'
-_DECODE_FORK = os.environ.get('OTR_DECODE_FORK', '1') != '0'   # cached beam step: the LM chain on a side stream (CachedBeamState)
+_DECODE_STEP_FUSED = True   # cached beam step on otr_dec_self_step + the fused tail
+_DECODE_FFN16 = True
+_DECODE_FORK = True   # cached beam step: the LM chain on a side stream (CachedBeamState)
 
 
 class TransformerLanguageModel(nn.Module):

@@ -9,10 +9,10 @@ run() { # name, env...
 }
 : > $OUT/ablation.txt
 run "all_on(1)" X=1
-run "encoder_ffn_exchange_form(slab_off)" OTR_FFN_SLAB=0
+run "encoder_ffn_exchange_form(slab_off)" OTR_SWITCHES=ops._FFN_SLAB=0
 run "generic_attention_backward" OTR_DEBUG_SET=21=0
 run "conv2_only_on_new_kernel" OTR_DEBUG_SET=22=2
 run "conv_generic_paths" OTR_DEBUG_SET=22=0
-run "per_operator_decoder" OTR_NO_FUSED_DECODER=1
+run "per_operator_decoder" OTR_SWITCHES=ops._DEC_FUSED=0
 run "all_on(2)" X=1
-run "all_round4_switches_off" OTR_FFN_SLAB=0 OTR_DEBUG_SET=21=0,22=0 OTR_NO_FUSED_DECODER=1
+run "all_round4_switches_off" OTR_SWITCHES=ops._FFN_SLAB=0,ops._DEC_FUSED=0 OTR_DEBUG_SET=21=0,22=0

@@ -9,9 +9,9 @@ run() { # name, env...
 }
 : > $OUT/ablation.txt
 run "all_on(1)" X=1
-run "frontend_linear_fp32_gradient(g16_off)" OTR_GRAD16_LINK=0
-run "three_kernel_loss+scale_launches(ls_fused_off)" OTR_LS_FUSED=0
-run "dec_sum_launch(embed_sink_off)" OTR_EMBED_SINK=0
+run "frontend_linear_fp32_gradient(g16_off)" OTR_SWITCHES=ops._G16=0
+run "three_kernel_loss+scale_launches(ls_fused_off)" OTR_SWITCHES=ops._LS_FUSED=0
+run "dec_sum_launch(embed_sink_off)" OTR_SWITCHES=ops._EMBED_SINK=0
 run "all_on(2)" X=1
-run "all_three_off" OTR_GRAD16_LINK=0 OTR_LS_FUSED=0 OTR_EMBED_SINK=0
+run "all_three_off" OTR_SWITCHES=ops._G16=0,ops._LS_FUSED=0,ops._EMBED_SINK=0
 run "all_on(3)" X=1
