@@ -16,7 +16,6 @@ Precision policy (set_compute_dtype):
 import contextlib
 import ctypes as C
 import gc
-import os
 import math
 
 import torch
