@@ -578,7 +578,7 @@ def main():
             # HBM bytes per launch and MFMA-busy cycles from separate rocprofv3 --pmc passes of this command (tools/gpu_pmc_step.sh
             # -> profiles/r03_pmc_step.json; regenerate whenever a kernel changes: the record carries the commit it was taken at)
             pmc_db, pmc_file = {}, None
-            for cand_file in ('r05_pmc_step.json', 'r04_pmc_step.json', 'r03_pmc_step.json'):
+            for cand_file in ('r06_pmc_step.json', 'r05_pmc_step.json', 'r04_pmc_step.json', 'r03_pmc_step.json'):
                 try:
                     pmc_db = json.load(open(os.path.join(ROOT, 'profiles', cand_file)))
                     pmc_file = os.path.join('profiles', cand_file)
@@ -595,10 +595,13 @@ def main():
                 return max(hits, key=lambda v: v.get('share_of_kernel_time', 0.0)) if hits else {}
             # in-step durations of the same kernels from the committed rocprofv3 trace of the replayed step (tools/graph_gaps.py):
             # printed beside the live timings, not instead of them
-            try:
-                step_db = json.load(open(os.path.join(ROOT, 'profiles', 'r05_step_kernels.json')))
-            except Exception:                                          # noqa: BLE001
-                step_db = {}
+            step_db = {}
+            for cand_file in ('r06_step_kernels.json', 'r05_step_kernels.json'):
+                try:
+                    step_db = json.load(open(os.path.join(ROOT, 'profiles', cand_file)))
+                    break
+                except Exception:                                      # noqa: BLE001
+                    continue
 
             def in_step_us(name):
                 pat = PMC_KERNEL.get(name.split(' ')[0])
@@ -709,7 +712,7 @@ def main():
     if rank == 0:
         if bf16_line is not None:
             for mode_, slot in (('bf16', bf16_line), (args.mode, out)):
-                for rnd in ('r05', 'r04', 'r03'):      # the measured parity of that mode at this batch (tests/test_gpu_headline.py -> profiles/)
+                for rnd in ('r06', 'r05', 'r04', 'r03'):      # the measured parity of that mode at this batch (tests/test_gpu_headline.py -> profiles/)
                     try:
                         pr = json.load(open(os.path.join(ROOT, 'profiles', '%s_parity_headline_%s.json' % (rnd, mode_))))
                     except Exception:                                          # noqa: BLE001

@@ -718,6 +718,20 @@ int64_t otr_dec_ffn_hsave_bytes(int64_t R, int32_t F);
 int32_t otr_dec_ffn_fwd(const otr_dec_ln_t* ln, int64_t R, const void* w1_pack, const float* b1, const void* w2_pack, int32_t F, int32_t S,
                         void* slabs, void* hsave, void* stream);
 int32_t otr_dec_ln(const otr_dec_ln_t* ln, int64_t R, void* stream);
+/* PAIR launches (r06): two independent problems of the same launch in ONE grid -- the decoder's and the language model's layer of a
+ * beam-search step (recognize/speech2text.py:100-113 runs them one after the other; they only meet in the top-k).  Block ids
+ * 0 .. n_a - 1 work on problem a, the rest on b; each descriptor holds exactly the arguments of the single entry.  The LM chain then
+ * rides in the decoder's launches: no second stream, no branch in the captured step. */
+typedef struct {
+  otr_dec_ln_t ln; int64_t R; const void* wqkv_pack; const float* bqkv; const void* wo_pack; void* kcache; void* vcache;
+  const int32_t* anc; const int32_t* pos; int32_t maxlen; void* slabs;
+} otr_dec_self_step_t;
+typedef struct {
+  otr_dec_ln_t ln; int64_t R; const void* w1_pack; const float* b1; const void* w2_pack; int32_t F, S; void* slabs; void* hsave;
+} otr_dec_ffn_fwd_t;
+int32_t otr_dec_self_step_pair(const otr_dec_self_step_t* a, const otr_dec_self_step_t* b, void* stream);
+int32_t otr_dec_ffn_fwd_pair(const otr_dec_ffn_fwd_t* a, const otr_dec_ffn_fwd_t* b, void* stream);
+int32_t otr_dec_ln_pair(const otr_dec_ln_t* a, int64_t Ra, const otr_dec_ln_t* b, int64_t Rb, void* stream);
 /* Backward, the same cut mirrored (csrc/declayer.hip).  The gradient of a sub-layer's LayerNorm output arrives as dskip f32 [R,256]
  * (may be NULL) plus nslab partial slabs; every launch finishes it and runs that LayerNorm's backward in its prologue
  * (otr_dec_lnb_t; z / mean / rstd as saved by the forward prologue), writing -- once per row -- dz (the gradient of the residual input =

@@ -63,6 +63,17 @@ class DecLn(C.Structure):                   # otr_dec_ln_t
                 ('y', C.c_void_p), ('y16', C.c_void_p), ('z', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p)]
 
 
+class DecSelfStep(C.Structure):             # otr_dec_self_step_t
+    _fields_ = [('ln', DecLn), ('R', C.c_int64), ('wqkv_pack', C.c_void_p), ('bqkv', C.c_void_p), ('wo_pack', C.c_void_p),
+                ('kcache', C.c_void_p), ('vcache', C.c_void_p), ('anc', C.c_void_p), ('pos', C.c_void_p), ('maxlen', C.c_int32),
+                ('slabs', C.c_void_p)]
+
+
+class DecFfnFwd(C.Structure):               # otr_dec_ffn_fwd_t
+    _fields_ = [('ln', DecLn), ('R', C.c_int64), ('w1_pack', C.c_void_p), ('b1', C.c_void_p), ('w2_pack', C.c_void_p),
+                ('F', C.c_int32), ('S', C.c_int32), ('slabs', C.c_void_p), ('hsave', C.c_void_p)]
+
+
 class DecLnB(C.Structure):                  # otr_dec_lnb_t
     _fields_ = [('dskip', C.c_void_p), ('slabs', C.c_void_p), ('nslab', C.c_int32),
                 ('z', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('gamma', C.c_void_p), ('seed', C.c_void_p),
@@ -168,6 +179,9 @@ SIGNATURES = {
     'otr_dec_ffn_hsave_bytes': [_I64, _I32],
     'otr_dec_ffn_fwd': [C.POINTER(DecLn), _I64, _P, _P, _P, _I32, _I32, _P, _P, _P],
     'otr_dec_ln': [C.POINTER(DecLn), _I64, _P],
+    'otr_dec_self_step_pair': [C.POINTER(DecSelfStep), C.POINTER(DecSelfStep), _P],
+    'otr_dec_ffn_fwd_pair': [C.POINTER(DecFfnFwd), C.POINTER(DecFfnFwd), _P],
+    'otr_dec_ln_pair': [C.POINTER(DecLn), _I64, C.POINTER(DecLn), _I64, _P],
     'otr_dec_ffn_bwd': [C.POINTER(DecLnB), _I64, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P],
     'otr_dec_cross_bwd': [C.POINTER(DecLnB), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _P, _I32, _P, _P, _P],
     'otr_dec_self_bwd': [C.POINTER(DecLnB), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -94,12 +94,19 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* logits, int
 // of the four waves' winners (2 barriers) instead of an 8-level shared-memory tree (18 barriers): 53 us per decode step before; the number now is in DESIGN.md 5.7 at
 // 80 rows x 4234 (profiles/r05_decode_kernels.txt).  Same scores, same tie rule (lower index first): same selection.
 constexpr int BT_NV = 20;
+constexpr int BT_CAP = 16 * BT_NV;       // the counting selection's candidates: only the <= k threads whose maximum is at least tau hold any, BT_NV each
 __device__ __forceinline__ bool bt_better(float s, int i, float t, int j) { return s > t || (s == t && i < j); }
 __global__ __launch_bounds__(256) void beam_topk_reg_kernel(const float* logits, int64_t ld, const float* lm_logits, int64_t ld_lm, float lm_weight,
-                                                           int V, int k, float* out_score, int64_t* out_idx) {
+                                                           int V, int k, float* out_score, int64_t* out_idx, int g_rank) {
   __shared__ float shf[8];
   __shared__ float ws_s[4];
   __shared__ int ws_i[4];
+  __shared__ __attribute__((aligned(16))) float tm_s[256];
+  __shared__ __attribute__((aligned(16))) int tm_i[256];
+  __shared__ float cand_s[BT_CAP];
+  __shared__ int cand_i[BT_CAP];
+  __shared__ float thr_s;
+  __shared__ int thr_i, ncand;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int64_t row = blockIdx.x;
   const float* x = logits + row * ld;
@@ -152,6 +159,51 @@ __global__ __launch_bounds__(256) void beam_topk_reg_kernel(const float* logits,
 #pragma unroll
   for (int j = 0; j < BT_NV; ++j)
     if ((alive >> j & 1u) && bt_better(sc[j], tid + 256 * j, hs, hi)) { hs = sc[j]; hi = tid + 256 * j; }
+  // ---- r06: selection by COUNTING instead of k serial arg-max rounds (2 barriers + a butterfly each: 22 us at k = 10).
+  //  1. tau = the k-th best of the 256 thread maxima (each thread ranks its own maximum against all: keys (score, index) are
+  //     distinct, so exactly one thread finds rank k - 1).  Every element of the true top-k is at least tau: k distinct elements --
+  //     the k best thread maxima -- are at least tau, so anything below tau has k elements above it.
+  //  2. the candidates = all elements at least tau (k of them when every thread holds at most one, a few more otherwise) are
+  //     compacted into LDS; a candidate's rank among the candidates is its rank in the row, and ranks 0 .. k-1 write the output.
+  // Same keys, same tie rule (lower index first): the same selection as the rounds.  At most k threads have a maximum >= tau and only
+  // they hold candidates: nc <= k * BT_NV <= BT_CAP always; the rounds below stay as a guarded fall-back (and as otr_debug_set(25, 2)).
+  if (g_rank) {
+    tm_s[tid] = hs; tm_i[tid] = hi;
+    if (tid == 0) { ncand = 0; thr_i = 0x7fffffff; thr_s = NEG_INF; }
+    __syncthreads();
+    int rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < 256; j += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(tm_s + j);
+      const int4 b = *reinterpret_cast<const int4*>(tm_i + j);
+      rank += (int)bt_better(a.x, b.x, hs, hi) + (int)bt_better(a.y, b.y, hs, hi) + (int)bt_better(a.z, b.z, hs, hi) + (int)bt_better(a.w, b.w, hs, hi);
+    }
+    if (rank == k - 1 && hi != 0x7fffffff) { thr_s = hs; thr_i = hi; }
+    __syncthreads();
+    const float ts_ = thr_s;
+    const int ti_ = thr_i;
+#pragma unroll
+    for (int j = 0; j < BT_NV; ++j) {
+      const int v = tid + 256 * j;
+      if ((alive >> j & 1u) && !bt_better(ts_, ti_, sc[j], v)) {           // at least tau
+        const int pos = atomicAdd(&ncand, 1);
+        if (pos < BT_CAP) { cand_s[pos] = sc[j]; cand_i[pos] = v; }
+      }
+    }
+    __syncthreads();
+    const int nc = ncand;
+    if (nc >= k && nc <= BT_CAP && ti_ != 0x7fffffff) {                    // (uniform over the workgroup)
+      for (int c = tid; c < nc; c += 256) {
+        const float ms = cand_s[c];
+        const int mi = cand_i[c];
+        int r = 0;
+        for (int q = 0; q < nc; ++q) r += (int)bt_better(cand_s[q], cand_i[q], ms, mi);
+        if (r < k) { out_score[row * k + r] = ms; out_idx[row * k + r] = mi; }
+      }
+      return;
+    }
+    __syncthreads();                                                        // fall back: the rounds below
+  }
   for (int r = 0; r < k; ++r) {
     float bs = hs;
     int bi = hi;
@@ -188,7 +240,7 @@ extern "C" int32_t otr_beam_topk(const float* logits, int64_t ld, const float* l
   if (rows == 0) return 0;
   if (V <= 256 * BT_NV && g_otr_beam_reg)
     hipLaunchKernelGGL(beam_topk_reg_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, ld, lm_logits, ld_lm, lm_weight, V,
-                       k, out_score, out_idx);
+                       k, out_score, out_idx, g_otr_beam_reg == 1 ? 1 : 0);     // otr_debug_set(25, 2): the register kernel with the serial rounds
   else
     hipLaunchKernelGGL(beam_topk_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, ld, lm_logits,
                        ld_lm, lm_weight, V, k, out_score, out_idx);

@@ -38,7 +38,7 @@ constexpr int DL_VT = DL_RB * 2 + 8;      // bytes per row of a transposed [64][
 constexpr int DL_RS = DL_D + 4;           // floats per row of the fp32 output staging tile
 // tuning hook (otr_debug_trace): thread 0 of every workgroup stamps the shader clock into trace[16384 + (kernel id * 256 + workgroup) * 16 + k]
 // (the first 16384 entries are the GEMM kernels' region of the same buffer)
-#define DL_STAMP(KID, K) do { if (p.trace && threadIdx.x == 0) p.trace[16384 + ((KID) * 256 + (int)blockIdx.x) * 16 + (K)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DL_STAMP(KID, K) do { if (p.trace && threadIdx.x == 0) p.trace[16384 + ((KID) * 256 + ((int)blockIdx.x & 255)) * 16 + (K)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 __device__ __forceinline__ uint4 dl_frag(const unsigned char* img, int stride, int m, int hi, int ks) {
   return *reinterpret_cast<const uint4*>(img + m * stride + (2 * ks + hi) * 16);
@@ -326,7 +326,11 @@ struct DlProRow {
   }
 };
 
-__global__ __launch_bounds__(512, 1) void dec_self_step_kernel(DlStepArgs p) {
+// (body + two kernels: alone, and as a PAIR -- r06: the decoder's and the language model's layers of one beam-search step are
+// independent chains of the SAME launches; a pair launch runs both problems' workgroups side by side (block ids 0 .. n0-1 = problem a,
+// the rest = problem b), so the LM chain rides in the decoder's launches instead of a forked stream: a branch anywhere in a hipGraph takes
+// the whole graph off the runtime's fast path, profiles/r06_boundary_probe.txt)
+__device__ __forceinline__ void dec_self_step_body(const DlStepArgs& p, const int bid) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[DL_RB * DL_YS + 4 * DL_RB * DL_HS + DL_RB * DL_RS * 4];
   unsigned char* ys = smem;
   unsigned char* qs = ys + DL_RB * DL_YS;
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(512, 1) void dec_self_step_kernel(DlStepArgs p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, hi = lane >> 5;
   int rb, h;
-  if (!dl_block_of((int)blockIdx.x, DL_H, (int)((p.ln.R + DL_SB - 1) / DL_SB), rb, h)) return;
+  if (!dl_block_of(bid, DL_H, (int)((p.ln.R + DL_SB - 1) / DL_SB), rb, h)) return;
   const int64_t row0 = (int64_t)rb * DL_SB;
   const int nrows = (int)min((int64_t)DL_SB, p.ln.R - row0);
   const bool live = wid < nrows;                                       // wave w = row w of the block, here and in the attention below
@@ -472,6 +476,13 @@ __global__ __launch_bounds__(512, 1) void dec_self_step_kernel(DlStepArgs p) {
   dl_put_tile(red, acc[0], wid * 32, lane);
   __syncthreads();
   dl_store_slab<8>(p.slabs + (int64_t)h * p.ln.R * DL_D, red, row0, nrows, tid);
+}
+
+__global__ __launch_bounds__(512, 1) void dec_self_step_kernel(DlStepArgs p) { dec_self_step_body(p, (int)blockIdx.x); }
+struct DlStepPair { DlStepArgs a, b; int n0; };
+__global__ __launch_bounds__(512, 1) void dec_self_step_pair_kernel(DlStepPair pp) {
+  if ((int)blockIdx.x < pp.n0) dec_self_step_body(pp.a, (int)blockIdx.x);
+  else dec_self_step_body(pp.b, (int)blockIdx.x - pp.n0);
 }
 
 // ------------------------------------------------------------------------------------------------ cross-attention launch
@@ -718,7 +729,7 @@ __device__ __forceinline__ void dl_store_slab16(uint16_t* slab, const float* red
   }
 }
 
-__global__ __launch_bounds__(256, 1) void dec_ffn_fwd_kernel(DlFfnArgs p) {
+__device__ __forceinline__ void dec_ffn_fwd_body(const DlFfnArgs& p, const int bid) {
   constexpr int D = DL_D, NKS = D / 16, NT = D / 32, STEPS = 2 * NKS + 2 * NT, PD = 24;
   static_assert(STEPS % PD == 0, "ring slots must be compile-time constants");
   __shared__ __attribute__((aligned(16))) unsigned char smem[DL_RB * DL_YS + 4 * DL_RB * DL_RS * 4];
@@ -728,7 +739,7 @@ __global__ __launch_bounds__(256, 1) void dec_ffn_fwd_kernel(DlFfnArgs p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, hi = lane >> 5;
   int rb, sl;
-  if (!dl_block_of((int)blockIdx.x, p.S, (int)((p.ln.R + DL_RB - 1) / DL_RB), rb, sl)) return;
+  if (!dl_block_of(bid, p.S, (int)((p.ln.R + DL_RB - 1) / DL_RB), rb, sl)) return;
   const int64_t row0 = (int64_t)rb * DL_RB;
   const int nrows = (int)min((int64_t)DL_RB, p.ln.R - row0);
   const int nchunk = p.F / 32, cps = nchunk / p.S, nit = cps / 4;     // chunks (32 hidden units) of the layer / of a slice / of a wave
@@ -804,13 +815,20 @@ __global__ __launch_bounds__(256, 1) void dec_ffn_fwd_kernel(DlFfnArgs p) {
   dl_store_slab16(p.slabs + (int64_t)sl * p.ln.R * D, red, row0, nrows, wid, lane);
 }
 
+__global__ __launch_bounds__(256, 1) void dec_ffn_fwd_kernel(DlFfnArgs p) { dec_ffn_fwd_body(p, (int)blockIdx.x); }
+struct DlFfnPair { DlFfnArgs a, b; int n0; };
+__global__ __launch_bounds__(256, 1) void dec_ffn_fwd_pair_kernel(DlFfnPair pp) {
+  if ((int)blockIdx.x < pp.n0) dec_ffn_fwd_body(pp.a, (int)blockIdx.x);
+  else dec_ffn_fwd_body(pp.b, (int)blockIdx.x - pp.n0);
+}
+
 // ------------------------------------------------------------------------------------------------ closing LayerNorm
 struct DlLnArgs { DlLn ln; };
-__global__ __launch_bounds__(256) void dec_ln_kernel(DlLnArgs p) {
+__device__ __forceinline__ void dec_ln_body(const DlLnArgs& p, const int bid) {
   // 8 rows per workgroup (2 per wave): 60 workgroups at 480 rows instead of 15, each reading S x 8 KiB of slabs
   constexpr int RPB = 8;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, col = lane * 4;
-  const int64_t row0 = (int64_t)blockIdx.x * RPB;
+  const int64_t row0 = (int64_t)bid * RPB;
   const int nrows = (int)min((int64_t)RPB, p.ln.R - row0);
   const DlLn& q = p.ln;
   const bool drop = q.p_drop > 0.f;
@@ -866,6 +884,12 @@ __global__ __launch_bounds__(256) void dec_ln_kernel(DlLnArgs p) {
       if (q.rstd) q.rstd[row] = rstd;
     }
   }
+}
+__global__ __launch_bounds__(256) void dec_ln_kernel(DlLnArgs p) { dec_ln_body(p, (int)blockIdx.x); }
+struct DlLnPair { DlLnArgs a, b; int n0; };
+__global__ __launch_bounds__(256) void dec_ln_pair_kernel(DlLnPair pp) {
+  if ((int)blockIdx.x < pp.n0) dec_ln_body(pp.a, (int)blockIdx.x);
+  else dec_ln_body(pp.b, (int)blockIdx.x - pp.n0);
 }
 
 // ================================================================================================ backward
@@ -1687,10 +1711,8 @@ extern "C" int32_t otr_dec_self_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t L
   return otr_check_launch("dec_self_fwd");
 }
 
-extern "C" int32_t otr_dec_self_step(const otr_dec_ln_t* ln, int64_t R, const void* wqkv_pack, const float* bqkv, const void* wo_pack,
-                                     void* kcache, void* vcache, const int32_t* anc, const int32_t* pos, int32_t maxlen, void* slabs,
-                                     void* stream) {
-  DlStepArgs a{};
+static int32_t dl_fill_self_step(DlStepArgs& a, const otr_dec_ln_t* ln, int64_t R, const void* wqkv_pack, const float* bqkv, const void* wo_pack,
+                                 void* kcache, void* vcache, const int32_t* anc, const int32_t* pos, int32_t maxlen, void* slabs) {
   OTR_REQUIRE(R > 0 && R < (1ll << 31) / 4, "dec_self_step: bad row count");
   if (int32_t e = dl_check_ln("dec_self_step", ln, R, a.ln)) return e;
   OTR_REQUIRE(wqkv_pack && bqkv && wo_pack && kcache && vcache && anc && pos && slabs, "dec_self_step: null pointer");
@@ -1701,8 +1723,25 @@ extern "C" int32_t otr_dec_self_step(const otr_dec_ln_t* ln, int64_t R, const vo
               "dec_self_step: buffers must be 16-byte aligned");
   a.wqkv = (const uint4*)wqkv_pack; a.bqkv = bqkv; a.wo = (const uint4*)wo_pack; a.kc = (uint16_t*)kcache; a.vc = (uint16_t*)vcache;
   a.anc = anc; a.pos = pos; a.maxlen = maxlen; a.slabs = (uint16_t*)slabs; a.scale = 0.125f; a.trace = g_otr_trace;
+  return 0;
+}
+extern "C" int32_t otr_dec_self_step(const otr_dec_ln_t* ln, int64_t R, const void* wqkv_pack, const float* bqkv, const void* wo_pack,
+                                     void* kcache, void* vcache, const int32_t* anc, const int32_t* pos, int32_t maxlen, void* slabs,
+                                     void* stream) {
+  DlStepArgs a{};
+  if (int32_t e = dl_fill_self_step(a, ln, R, wqkv_pack, bqkv, wo_pack, kcache, vcache, anc, pos, maxlen, slabs)) return e;
   hipLaunchKernelGGL(dec_self_step_kernel, dim3(dl_grid(DL_H, (int)((R + DL_SB - 1) / DL_SB))), dim3(512), 0, (hipStream_t)stream, a);
   return otr_check_launch("dec_self_step");
+}
+extern "C" int32_t otr_dec_self_step_pair(const otr_dec_self_step_t* x, const otr_dec_self_step_t* y, void* stream) {
+  OTR_REQUIRE(x && y, "dec_self_step_pair: null descriptor");
+  DlStepPair pp{};
+  if (int32_t e = dl_fill_self_step(pp.a, &x->ln, x->R, x->wqkv_pack, x->bqkv, x->wo_pack, x->kcache, x->vcache, x->anc, x->pos, x->maxlen, x->slabs)) return e;
+  if (int32_t e = dl_fill_self_step(pp.b, &y->ln, y->R, y->wqkv_pack, y->bqkv, y->wo_pack, y->kcache, y->vcache, y->anc, y->pos, y->maxlen, y->slabs)) return e;
+  pp.n0 = (int)dl_grid(DL_H, (int)((x->R + DL_SB - 1) / DL_SB));
+  const unsigned n1 = dl_grid(DL_H, (int)((y->R + DL_SB - 1) / DL_SB));
+  hipLaunchKernelGGL(dec_self_step_pair_kernel, dim3((unsigned)pp.n0 + n1), dim3(512), 0, (hipStream_t)stream, pp);
+  return otr_check_launch("dec_self_step_pair");
 }
 
 extern "C" int32_t otr_dec_cross_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t L, const void* wq_pack, const float* bq, const void* wo_pack,
@@ -1724,17 +1763,32 @@ extern "C" int32_t otr_dec_cross_fwd(const otr_dec_ln_t* ln, int32_t B, int32_t 
 
 extern "C" int64_t otr_dec_ffn_hsave_bytes(int64_t R, int32_t F) { return R > 0 && F > 0 ? ((R + DL_RB - 1) / DL_RB) * (int64_t)(F / 32) * 4096 : 0; }
 
-extern "C" int32_t otr_dec_ffn_fwd(const otr_dec_ln_t* ln, int64_t R, const void* w1_pack, const float* b1, const void* w2_pack, int32_t F,
-                                   int32_t S, void* slabs, void* hsave, void* stream) {
-  DlFfnArgs a{};
+static int32_t dl_fill_ffn_fwd(DlFfnArgs& a, const otr_dec_ln_t* ln, int64_t R, const void* w1_pack, const float* b1, const void* w2_pack, int32_t F,
+                               int32_t S, void* slabs, void* hsave) {
   OTR_REQUIRE(R > 0 && R < (1ll << 31), "dec_ffn_fwd: bad row count");
   if (int32_t e = dl_check_ln("dec_ffn_fwd", ln, R, a.ln)) return e;
   OTR_REQUIRE(w1_pack && b1 && w2_pack && slabs, "dec_ffn_fwd: null pointer");
   OTR_REQUIRE(F > 0 && S > 0 && F % (128 * S) == 0, "dec_ffn_fwd: d_ff = %d does not split into %d slices of whole 128-unit wave rounds", F, S);
   OTR_REQUIRE(((uintptr_t)w1_pack | (uintptr_t)b1 | (uintptr_t)w2_pack | (uintptr_t)slabs | (uintptr_t)hsave) % 16 == 0, "dec_ffn_fwd: buffers must be 16-byte aligned");
   a.p1 = (const uint4*)w1_pack; a.b1 = b1; a.p2 = (const uint4*)w2_pack; a.slabs = (uint16_t*)slabs; a.hsave = (uint4*)hsave; a.F = F; a.S = S; a.trace = g_otr_trace;
+  return 0;
+}
+extern "C" int32_t otr_dec_ffn_fwd(const otr_dec_ln_t* ln, int64_t R, const void* w1_pack, const float* b1, const void* w2_pack, int32_t F,
+                                   int32_t S, void* slabs, void* hsave, void* stream) {
+  DlFfnArgs a{};
+  if (int32_t e = dl_fill_ffn_fwd(a, ln, R, w1_pack, b1, w2_pack, F, S, slabs, hsave)) return e;
   hipLaunchKernelGGL(dec_ffn_fwd_kernel, dim3(dl_grid(S, (int)((R + DL_RB - 1) / DL_RB))), dim3(256), 0, (hipStream_t)stream, a);
   return otr_check_launch("dec_ffn_fwd");
+}
+extern "C" int32_t otr_dec_ffn_fwd_pair(const otr_dec_ffn_fwd_t* x, const otr_dec_ffn_fwd_t* y, void* stream) {
+  OTR_REQUIRE(x && y, "dec_ffn_fwd_pair: null descriptor");
+  DlFfnPair pp{};
+  if (int32_t e = dl_fill_ffn_fwd(pp.a, &x->ln, x->R, x->w1_pack, x->b1, x->w2_pack, x->F, x->S, x->slabs, x->hsave)) return e;
+  if (int32_t e = dl_fill_ffn_fwd(pp.b, &y->ln, y->R, y->w1_pack, y->b1, y->w2_pack, y->F, y->S, y->slabs, y->hsave)) return e;
+  pp.n0 = (int)dl_grid(x->S, (int)((x->R + DL_RB - 1) / DL_RB));
+  const unsigned n1 = dl_grid(y->S, (int)((y->R + DL_RB - 1) / DL_RB));
+  hipLaunchKernelGGL(dec_ffn_fwd_pair_kernel, dim3((unsigned)pp.n0 + n1), dim3(256), 0, (hipStream_t)stream, pp);
+  return otr_check_launch("dec_ffn_fwd_pair");
 }
 
 extern "C" int32_t otr_dec_ln(const otr_dec_ln_t* ln, int64_t R, void* stream) {
@@ -1744,6 +1798,17 @@ extern "C" int32_t otr_dec_ln(const otr_dec_ln_t* ln, int64_t R, void* stream) {
   OTR_REQUIRE(ln->nslab > 0, "dec_ln: nothing to normalise");
   hipLaunchKernelGGL(dec_ln_kernel, dim3((unsigned)((R + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);
   return otr_check_launch("dec_ln");
+}
+
+extern "C" int32_t otr_dec_ln_pair(const otr_dec_ln_t* lx, int64_t Rx, const otr_dec_ln_t* ly, int64_t Ry, void* stream) {
+  DlLnPair pp{};
+  OTR_REQUIRE(Rx > 0 && Rx < (1ll << 31) && Ry > 0 && Ry < (1ll << 31), "dec_ln_pair: bad row count");
+  if (int32_t e = dl_check_ln("dec_ln_pair", lx, Rx, pp.a.ln)) return e;
+  if (int32_t e = dl_check_ln("dec_ln_pair", ly, Ry, pp.b.ln)) return e;
+  OTR_REQUIRE(lx->nslab > 0 && ly->nslab > 0, "dec_ln_pair: nothing to normalise");
+  pp.n0 = (int)((Rx + 7) / 8);
+  hipLaunchKernelGGL(dec_ln_pair_kernel, dim3((unsigned)(pp.n0 + (int)((Ry + 7) / 8))), dim3(256), 0, (hipStream_t)stream, pp);
+  return otr_check_launch("dec_ln_pair");
 }
 
 extern "C" int32_t otr_dec_ffn_bwd(const otr_dec_lnb_t* ln, int64_t R, const void* hsave, const void* w2t_pack, const void* w1t_pack,

@@ -25,7 +25,8 @@ from .nn import (BOS, EOS, PAD, LabelSmoothingLoss, PositionalEncoding, Transfor
 
 _DECODE_STEP_FUSED = True   # cached beam step on otr_dec_self_step + the fused tail
 _DECODE_FFN16 = True
-_DECODE_FORK = True   # cached beam step: the LM chain on a side stream (CachedBeamState)
+_DECODE_FORK = True   # cached beam step: the LM chain on a side stream (CachedBeamState) -- only where the pair launches below do not apply
+_DECODE_PAIR = True   # cached beam step: the LM's layers ride in the decoder's launches (otr_dec_*_pair): one chain, no branch in the graph
 
 
 class TransformerLanguageModel(nn.Module):
@@ -391,7 +392,12 @@ class CachedBeamState:
         # The LM's layers and the decoder's are two independent chains of small launches (24-80 workgroups on 256 CUs) that only
         # meet at the top-k: the LM chain runs on a side stream, forked at the start of the step and joined before the top-k
         # (in the captured graph: two parallel branches).  Its GEMMs get their own split-K workspace.
-        self.side = torch.cuda.Stream(device=dev) if (lm is not None and _DECODE_FORK and dev.type == 'cuda') else None
+        # r06: ONE fork anywhere in a hipGraph takes the whole graph off the runtime's fast per-node path (1.6 -> ~3 us per node,
+        # profiles/r06_boundary_probe.txt), which cost this 34-node step about as much as the overlap returned.  Where both stacks run on
+        # the fused launches, the LM's layers are the SECOND problem of the decoder's own launches instead (otr_dec_self_step_pair,
+        # otr_dec_ffn_fwd_pair, otr_dec_ln_pair: _fused_stacks_paired): the same concurrency, one chain, 23 nodes.
+        self.paired = bool(_DECODE_PAIR and self.fused_dec and self.fused_lm and not self.lm_recurrent)
+        self.side = torch.cuda.Stream(device=dev) if (lm is not None and _DECODE_FORK and dev.type == 'cuda' and not self.paired) else None
         self.side_ws = ops.new_workspace(dev) if self.side is not None else None
 
     def load_memory(self, memory, memory_mask):
@@ -562,6 +568,105 @@ class CachedBeamState:
         L.check(lib.otr_dec_ln(C.byref(ln), R, st), 'otr_dec_ln')
         return ops.attach_lp(*out)
 
+    def _fused_stacks_paired(self, xd, xl, cur):
+        """The decoder stack and the LM stack of one step in LOCKSTEP on pair launches: layer i of both in one otr_dec_self_step_pair and
+        one otr_dec_ffn_fwd_pair (the decoder's cross-attention launch between them is its own), the two closing LayerNorms in one
+        otr_dec_ln_pair.  The same launches on the same operands as two _fused_stack calls: bit-identical results."""
+        lib, R, d = L.load(), self.R, 256
+        dev, hdt, st = xd.device, ops.half_dtype(), ops._stream()
+        h16 = lambda *sh: torch.empty(sh, dtype=hdt, device=dev)          # noqa: E731
+        f32 = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)  # noqa: E731
+        beam = self.rec.beam_width
+        dec, lm = self.rec.model.decoder, self.rec.lm
+        state = self
+
+        class Walk:
+            """one stack's position in the chain: the descriptor of the add + LayerNorm the NEXT launch finishes, the residual rows"""
+
+            def __init__(self, x, blocks, caches, kvs):
+                self.blocks, self.caches, self.kvs, self.li = blocks, caches, kvs, 0
+                self.yres = x.reshape(R, d)
+                self.keep = [x, ops.lp_of(x)]                                     # tensors the pending descriptor points at
+                self.ln = ops._dec_ln(None, ops.lp_of(x).reshape(R, d), None, 0)
+
+            def done(self):
+                return self.li >= len(self.blocks)
+
+            def closes(self, slabs, nslab, bias, norm):
+                y, y16 = f32(R, d), h16(R, d)
+                self.ln = ops._dec_ln(self.yres, None, slabs, nslab, bias, norm.weight, norm.bias, None, 0.0, norm.eps, 0, y, y16)
+                self.keep = [self.yres, slabs, y, y16]
+                self.yres, self.y16 = y, y16
+
+            def self_item(self):
+                a = self.blocks[self.li].slf_attn
+                self.slA = h16(4, R, d)
+                it = L.DecSelfStep()
+                it.ln, it.R = self.ln, R
+                it.wqkv_pack, it.bqkv = ops.lin_packs(a.qvk_proj.weight)[0].data_ptr(), a.qvk_proj.bias.data_ptr()
+                it.wo_pack = ops.lin_packs(a.output_proj.weight)[0].data_ptr()
+                it.kcache, it.vcache = self.caches[self.li][0].data_ptr(), self.caches[self.li][1].data_ptr()
+                it.anc, it.pos, it.maxlen, it.slabs = state.anc[cur].data_ptr(), state.pos[cur].data_ptr(), state.maxlen, self.slA.data_ptr()
+                return it
+
+            def after_self(self):
+                blk = self.blocks[self.li]
+                self.closes(self.slA, 4, blk.slf_attn.output_proj.bias, blk.norm1)
+
+            def cross(self):
+                if self.kvs is None:
+                    return
+                blk = self.blocks[self.li]
+                ca, kv = blk.src_attn, self.kvs[self.li]
+                slB, q16, ctx2, lse2 = h16(4, R, d), h16(R, d), h16(R, d), f32(state.b, 4, beam)
+                W = kv.shape[2]
+                L.check(lib.otr_dec_cross_fwd(C.byref(self.ln), state.b, beam, ops._p(ops.lin_packs(ca.q_proj.weight)[0]), ops._p(ca.q_proj.bias),
+                                              ops._p(ops.lin_packs(ca.output_proj.weight)[0]), ops._p(kv), state.Tm * W, W, 0, W // 2,
+                                              ops._p(state.mem_mask), state.Tm, ops._p(q16), ops._p(ctx2), ops._p(lse2), ops._p(slB), st),
+                        'otr_dec_cross_fwd')
+                self.closes(slB, 4, ca.output_proj.bias, blk.norm2)
+
+            def ffn_item(self):
+                ff = self.blocks[self.li].feed_forward
+                F = ff.w_2.weight.shape[1]
+                self.S = 16 if (_DECODE_FFN16 and F % 2048 == 0 and R <= 128) else ops.dec_ffn_slices(F)
+                packs = ops.ffn_packs(ff.w_1.weight, ff.w_2.weight)
+                self.slC = h16(self.S, R, d)
+                it = L.DecFfnFwd()
+                it.ln, it.R = self.ln, R
+                it.w1_pack, it.b1, it.w2_pack = packs[0].data_ptr(), ff.w_1.bias.data_ptr(), packs[1].data_ptr()
+                it.F, it.S, it.slabs, it.hsave = F, self.S, self.slC.data_ptr(), None
+                return it
+
+            def after_ffn(self):
+                blk = self.blocks[self.li]
+                self.closes(self.slC, self.S, blk.feed_forward.w_2.bias, blk.norm3 if self.kvs is not None else blk.norm2)
+                self.li += 1
+
+        wd, wl = Walk(xd, dec.blocks, self.dec_cache, self.mem_kv), Walk(xl, lm.blocks, self.lm_cache, None)
+        while not (wd.done() and wl.done()):
+            live = [w for w in (wd, wl) if not w.done()]
+            items = [w.self_item() for w in live]
+            if len(items) == 2:
+                L.check(lib.otr_dec_self_step_pair(C.byref(items[0]), C.byref(items[1]), st), 'otr_dec_self_step_pair')
+            else:
+                i = items[0]
+                L.check(lib.otr_dec_self_step(C.byref(i.ln), R, i.wqkv_pack, i.bqkv, i.wo_pack, i.kcache, i.vcache, i.anc, i.pos, i.maxlen, i.slabs, st),
+                        'otr_dec_self_step')
+            for w in live:
+                w.after_self()
+                w.cross()
+            items = [w.ffn_item() for w in live]
+            if len(items) == 2:
+                L.check(lib.otr_dec_ffn_fwd_pair(C.byref(items[0]), C.byref(items[1]), st), 'otr_dec_ffn_fwd_pair')
+            else:
+                i = items[0]
+                L.check(lib.otr_dec_ffn_fwd(C.byref(i.ln), R, i.w1_pack, i.b1, i.w2_pack, i.F, i.S, i.slabs, None, st), 'otr_dec_ffn_fwd')
+            for w in live:
+                w.after_ffn()
+        L.check(lib.otr_dec_ln_pair(C.byref(wd.ln), R, C.byref(wl.ln), R, st), 'otr_dec_ln_pair')
+        return ops.attach_lp(wd.yres, wd.y16), ops.attach_lp(wl.yres, wl.y16)
+
     def _lm_logits(self, cur):
         """the LM's scores of the next token for every hypothesis, [R, V or V padded to 8] (speech2text.py:108-113)"""
         lm = self.rec.lm
@@ -587,15 +692,26 @@ class CachedBeamState:
         main = torch.cuda.current_stream()
         stream = C.c_void_p(main.cuda_stream)
         lm_logits = None
-        if self.side is not None:
+        paired = False
+        if self.paired:
+            x = ops.decode_embed(self.preds[cur], self.pos[cur], dec.embedding.weight)
+            xl = ops.decode_embed(self.preds[cur], self.pos[cur], lm.embedding.weight)
+            if ops.lp_of(x) is not None and ops.lp_of(xl) is not None:
+                x, yl = self._fused_stacks_paired(x, xl, cur)
+                lm_logits = self.out_lm(yl) if self.out_lm is not None else ops.linear(yl, lm.output_project.weight, lm.output_project.bias)
+                paired = True
+        if paired:
+            pass
+        elif self.side is not None:
             self.side.wait_stream(main)                   # fork
             with torch.cuda.stream(self.side), ops.workspace_lane(self.side_ws):
                 lm_logits = self._lm_logits(cur)
         elif lm is not None:
             lm_logits = self._lm_logits(cur)
-        x = ops.decode_embed(self.preds[cur], self.pos[cur], dec.embedding.weight)
-        fused_dec = self.fused_dec and ops.lp_of(x) is not None
-        if fused_dec:
+        if not paired:
+            x = ops.decode_embed(self.preds[cur], self.pos[cur], dec.embedding.weight)
+        fused_dec = (self.fused_dec and ops.lp_of(x) is not None) or paired
+        if fused_dec and not paired:
             x = self._fused_stack(x, dec.blocks, self.dec_cache, self.mem_kv, cur)
         for blk, cache, kv in (() if fused_dec else zip(dec.blocks, self.dec_cache, self.mem_kv)):
             x = self._stack_step(x, blk, cache, cur, getattr(blk, 'concat_linear1', None))

@@ -149,3 +149,95 @@ def test_beam_topk_on_a_row_of_nans_returns_in_range_indices():
     lp = torch.log_softmax(logits[[0, 2]], dim=-1)
     ref = torch.topk(lp, k, dim=-1)
     assert torch.equal(idx[[0, 2]], ref.indices) and rel(score[[0, 2]], ref.values) < 1e-6
+
+
+@pytest.mark.parametrize('V,k', [(4234, 10), (4234, 1), (4240, 16), (300, 10), (100, 10), (5120, 5)])
+@pytest.mark.parametrize('case', ['random', 'clustered', 'equal', 'lm'])
+def test_beam_topk_selection_by_counting(V, k, case):
+    """r06: beam_topk_reg_kernel selects by COUNTING (threshold = k-th best thread maximum, candidates ranked among themselves) instead
+    of k serial arg-max rounds: against torch.topk of the fused log-probabilities, and bit-equal to the rounds form
+    (otr_debug_set(25, 2)).  clustered: the whole top-k in ONE thread's stride (index = 5 mod 256); equal: a row of equal scores (ties
+    -> lower index first)."""
+    from opentransformer_amd import _lib as L
+    lib = L.load()
+    R = 7
+    g = torch.Generator().manual_seed(V + k)
+    logits = torch.randn(R, V, generator=g)
+    lm = torch.randn(R, V, generator=g) if case == 'lm' else None
+    if case == 'clustered':
+        logits[:, 5::256] += 20.0
+    if case == 'equal':
+        logits[2] = 0.25
+        logits[3, : V // 2] = 1.0
+        logits[3, V // 2:] = -1.0
+    logits = logits.to(DEV)
+    lm = lm.to(DEV) if lm is not None else None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = {}
+    for form in (1, 2):
+        L.check(lib.otr_debug_set(25, form), 'debug_set')
+        try:
+            score = torch.empty(R, k, device=DEV)
+            idx = torch.full((R, k), -1, dtype=torch.int64, device=DEV)
+            L.check(lib.otr_beam_topk(C.c_void_p(logits.data_ptr()), V, C.c_void_p(lm.data_ptr()) if lm is not None else None, V if lm is not None else 0,
+                                      0.3 if lm is not None else 0.0, R, V, k, C.c_void_p(score.data_ptr()), C.c_void_p(idx.data_ptr()), st), 'otr_beam_topk')
+            torch.cuda.synchronize()
+            outs[form] = (score.clone(), idx.clone())
+        finally:
+            lib.otr_debug_set(25, 1)
+    assert torch.equal(outs[1][1], outs[2][1]) and torch.equal(outs[1][0], outs[2][0])
+    lp = torch.log_softmax(logits.double(), dim=-1)
+    if lm is not None:
+        lp = lp + 0.3 * torch.log_softmax(lm.double(), dim=-1)
+    # ties -> lower index first: a stable descending sort of the fp64 scores
+    order = torch.sort(lp, dim=-1, descending=True, stable=True).indices[:, :k]
+    score, idx = outs[1]
+    got_lp = torch.gather(lp, 1, idx)
+    ref_lp = torch.gather(lp, 1, order)
+    assert rel(score, ref_lp) < 1e-5
+    assert float((got_lp - ref_lp).abs().max()) < 1e-5                  # the same scores in the same order (fp32 near-ties may swap indices)
+    if case in ('equal', 'clustered') or lm is None:
+        same = (idx == order) | ((got_lp - ref_lp).abs() < 1e-6)
+        assert bool(same.all())
+    if case == 'equal':
+        assert idx[2].tolist() == list(range(k))                        # all equal: the lowest indices, in order
+
+
+@pytest.mark.parametrize('mode', ['fp16', 'bf16'])
+@pytest.mark.parametrize('lm_blocks,dec_blocks', [(2, 3), (4, 2), (3, 3)])
+def test_cached_search_on_pair_launches_is_the_forked_search(mode, lm_blocks, dec_blocks):
+    """r06: the LM's layers as the second problem of the decoder's launches (otr_dec_self_step_pair / otr_dec_ffn_fwd_pair /
+    otr_dec_ln_pair, recognize._fused_stacks_paired) run the same kernels on the same operands as the two separate chains (the LM on a
+    forked stream): token-identical n-best lists and bit-equal scores, also when one stack is deeper than the other (the tail of the
+    deeper one runs on single launches), eagerly and under hipGraph replay."""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops, recognize, synthetic as syn
+    ops.set_compute_dtype(mode)
+    try:
+        cfg = syn.c2_model(0.0, n_enc=2)
+        cfg['decoder']['n_blocks'] = dec_blocks
+        model = ota.SpeechToText(cfg)
+        syn.fill_state_dict_(model.state_dict(), 7)
+        lm = recognize.TransformerLanguageModel(syn.lm_config(4234, num_blocks=lm_blocks))
+        syn.fill_state_dict_(lm.state_dict(), 8)
+        with torch.no_grad():
+            model.decoder.output_layer.bias[1] = 2.0            # EOS live: beams finish at different steps
+        model, lm = model.to(DEV).eval(), lm.to(DEV).eval()
+        inputs, _ = syn.synthetic_batch(batch=3, frames=400, feat_dim=80, vocab=4234, tgt_len=5, seed=3, lengths=[400, 333, 250])
+        x, m = inputs['inputs'].to(DEV), inputs['mask'].to(DEV)
+        kw = dict(beam_width=10, nbest=10, max_len=16, penalty=0.6, lamda=5, lm=lm, lm_weight=0.1, idx2unit={i: str(i) for i in range(4234)})
+        res = {}
+        for pair in (True, False):
+            recognize._DECODE_PAIR = pair
+            rec = recognize.SpeechToTextRecognizer(model, apply_cache=True, **kw)
+            res[pair] = rec.recognize(x, m)
+            stt = next(iter(rec._cached_states.values()))
+            assert stt.paired == pair and (stt.side is None) == pair
+            if pair:
+                assert all(g is not None for g in stt.graphs)      # the paired step was captured and replayed
+        (h1, s1), (h0, s0) = res[True], res[False]
+        assert h1 == h0
+        assert torch.equal(s1, s0)
+    finally:
+        recognize._DECODE_PAIR = True
+        ops.set_compute_dtype('bf16')
