@@ -1069,6 +1069,7 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
     // batched: FAST KC/KC operands, plain epilogue, no split-K, for the operand types the callers use
     constexpr bool BUILT = AMODE == MODE_KC && BMODE == MODE_KC && std::is_same<CT, bf16_t>::value && std::is_same<BT, bf16_t>::value &&
                            ((std::is_same<AT, bf16_t>::value && std::is_same<OT, float>::value) ||
+                            (std::is_same<AT, bf16_t>::value && std::is_same<OT, bf16_t>::value) ||      // r06: pt_i = W_i pe^T of all Conformer blocks
                             (std::is_same<AT, float>::value && std::is_same<OT, bf16_t>::value));
     if constexpr (BUILT) {
       constexpr int CE = GemmCfg<CT>::CE;

@@ -26,6 +26,7 @@ from . import ops
 
 _MASK_FOLD = True  # ... and the convolution branch's row mask applied by that launch
 _LN2 = True                   # ... and post_ffn_norm + final_norm in one launch each way
+_POS_TABLES = True    # ConformerEncoder: the relative-position tables of all blocks in two batched launches (ops.relpos_tables)
 _RES_LN = True     # ConformerEncoderBlock: residual adds fused into the LayerNorms that follow them
 
 PAD, BLK, BOS, EOS = 0, 0, 1, 1       # otrans/data/__init__.py:7-12
@@ -438,7 +439,7 @@ class MultiHeadedSelfAttentionWithRelPos(nn.Module):
         B, T, _ = x.shape
         qkv = ops.linear(x, self.qvk_proj.weight, self.qvk_proj.bias, out_dtype=ops.act_dtype())
         ctx = ops.RelPosAttentionFn.apply(qkv, pos, self.pos_proj.weight, self.posu, self.posv, _key_mask(mask, B, T),
-                                          self.nheads)
+                                          self.nheads, getattr(self, 'pos_tables', None))
         return ctx, None
 
     def inference(self, inputs, mask, pos, cache=None):
@@ -595,12 +596,18 @@ class ConformerEncoder(nn.Module):
             x = inputs.float()
             pos = relative_sinusoid(inputs.size(1), inputs.size(2), inputs.device) if self.relative_positional else None
         ticks = [] if self.training else None           # BatchNorm1d.num_batches_tracked += 1 (module/conformer.py:33) of every block: one launch
-        for block in self.blocks:
+        # r06: pos_proj(sinusoid) of EVERY block (and its transpose) in two batched launches instead of a GEMM + a transposing copy per block
+        tables = None
+        if self.relative_positional and _POS_TABLES and x.is_cuda:
+            tables = ops.relpos_tables(pos, [block.mha.pos_proj.weight for block in self.blocks])
+        for bi, block in enumerate(self.blocks):
             block.conv.tick_later = ticks
+            block.mha.pos_tables = tables[bi] if tables is not None else None
             try:
                 x, _ = block(x, mask, pos)
             finally:
                 block.conv.tick_later = None
+                block.mha.pos_tables = None
         if ticks:
             torch._foreach_add_(ticks, 1)
         return x, mask, {}

@@ -2912,6 +2912,45 @@ def _persistent_dbd(owner, like):
     return buf
 
 
+_PE16 = {}
+
+
+def relpos_tables(pos_emb, weights):
+    """p_i = pos_proj_i(sinusoid) and its transpose for EVERY layer of a Conformer stack (module/attention.py:217-221 computes them layer by
+    layer: a [2T-1, d] x [d, d] GEMM and a transposing copy in each of 12 blocks, ~15 us of launches per block for a table that depends on
+    nothing but the weights) in TWO batched launches: p_i = pe W_i^T and pt_i = W_i pe^T (the transpose is the same product with the
+    operands swapped).  The layers' 16-bit weight shadows must sit at one constant stride (FlatDataParallel lays a stack's blocks out
+    that way); anything else returns None and every layer computes its own.  Returns [(pe padded, p_i [Pp, d], pt_i [d, Pp])]."""
+    if not is_half() or len(weights) < 2 or not pos_emb.is_cuda:
+        return None
+    wl = [weight_lp(w) for w in weights]
+    if any(t is None or not t.is_contiguous() or t.shape != wl[0].shape or t.dtype != half_dtype() for t in wl):
+        return None
+    d = wl[0].shape[1]
+    if wl[0].shape[0] != d:
+        return None
+    es = wl[0].element_size()
+    step = wl[1].data_ptr() - wl[0].data_ptr()
+    if step <= 0 or step % 16 != 0 or any(wl[i + 1].data_ptr() - wl[i].data_ptr() != step for i in range(len(wl) - 1)):
+        return None
+    P = pos_emb.numel() // d
+    Pp = (P + 7) // 8 * 8
+    pe = _zero_padded_rows(pos_emb.reshape(P, d).contiguous(), Pp)          # fp32 constant table, padded once per (T, d)
+    key = (pe.data_ptr(), pe._version, half_dtype())
+    hit = _PE16.get(key)
+    if hit is None:
+        if len(_PE16) > 8:
+            _PE16.clear()
+        hit = _PE16[key] = (pe.to(half_dtype()), pe)                       # its 16-bit twin (what the GEMM's loader makes of it), once
+    pe16 = hit[0]
+    n = len(wl)
+    p_all = torch.empty((n, Pp, d), dtype=half_dtype(), device=pe.device)
+    pt_all = torch.empty((n, d, Pp), dtype=half_dtype(), device=pe.device)
+    _gemm_heads(Pp, d, d, (pe, 0, d), (wl[0], 0, d), (p_all, 0, d), n, 0, step // es, Pp * d)        # p_i = pe . W_i^T
+    _gemm_heads(d, Pp, d, (wl[0], 0, d), (pe16, 0, d), (pt_all, 0, Pp), n, step // es, 0, d * Pp)    # pt_i = W_i . pe^T
+    return [(pe, p_all[i], pt_all[i]) for i in range(n)]
+
+
 class RelPosAttentionFn(torch.autograd.Function):
     """MultiHeadedSelfAttentionWithRelPos.forward after the qvk projection (module/attention.py:217-253):
     softmax(((q+u) k^T + shift((q+v) p^T)) / sqrt(dk)) v with p = pos_proj(sinusoid[-(T-1)..T-1]).
@@ -2919,7 +2958,9 @@ class RelPosAttentionFn(torch.autograd.Function):
     (q+v) p^T term at column j - i + T - 1."""
 
     @staticmethod
-    def forward(ctx, qkv, pos_emb, pos_w, posu, posv, key_mask_u8, n_heads):
+    def forward(ctx, qkv, pos_emb, pos_w, posu, posv, key_mask_u8, n_heads, tables=None):
+        """tables: (pe padded [Pp, d], p [Pp, d], pt [d, Pp]) of this layer, precomputed for all layers of the stack in two batched launches
+        (relpos_tables) -- or None: computed here"""
         _cuda(qkv, pos_emb, pos_w, posu, posv)
         B, T, d3 = qkv.shape
         d = d3 // 3
@@ -2932,9 +2973,12 @@ class RelPosAttentionFn(torch.autograd.Function):
         # 16-byte aligned operands / outputs and whole contraction chunks, i.e. takes the fast kernels (the unpadded
         # layout ran the generic bounds-checked ones: 96 launches of 33-42 us per step)
         Pp = (P + 7) // 8 * 8
-        pe = _zero_padded_rows(pe, Pp)                   # the sinusoid table is a constant: padded once per (T, d)
-        p = linear_fwd_raw(pe, wl if wl is not None else pos_w, None, adt)                  # [Pp, d], rows >= P are zero
-        pt = p.t().contiguous()                                                             # [d, Pp]: dgrad as a forward GEMM
+        if tables is not None and tables[1].dtype == adt and tuple(tables[1].shape) == (Pp, d):
+            pe, p, pt = tables
+        else:
+            pe = _zero_padded_rows(pe, Pp)               # the sinusoid table is a constant: padded once per (T, d)
+            p = linear_fwd_raw(pe, wl if wl is not None else pos_w, None, adt)              # [Pp, d], rows >= P are zero
+            pt = p.t().contiguous()                                                         # [d, Pp]: dgrad as a forward GEMM
         u, v = posu.reshape(d).contiguous(), posv.reshape(d).contiguous()
         quv = torch.empty((B, T, 2 * d), dtype=adt, device=qkv.device)
         lib = L.load()
@@ -3004,7 +3048,7 @@ class RelPosAttentionFn(torch.autograd.Function):
             dw = None
         else:
             dw = linear_wgrad_raw(dp, pe, pos_w, out=gw)     # contraction over the padded axis (zero rows): the fast grouped kernel takes it
-        return dqkv, None, None if gw is not None else dw, du, dv, None, None
+        return dqkv, None, None if gw is not None else dw, du, dv, None, None, None
 
 
 class ConformerConvFn(torch.autograd.Function):

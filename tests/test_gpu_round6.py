@@ -241,3 +241,45 @@ def test_cached_search_on_pair_launches_is_the_forked_search(mode, lm_blocks, de
     finally:
         recognize._DECODE_PAIR = True
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp16', 'bf16'])
+def test_conformer_relpos_tables_of_all_blocks_in_two_batched_launches(mode):
+    """r06 (nn._POS_TABLES / ops.relpos_tables): pos_proj(sinusoid) of every Conformer block and its transpose come from two batched
+    GEMM launches under FlatDataParallel (the blocks' weight shadows sit at one stride) instead of a GEMM + a transposing copy per
+    block: the same loss and gradients as the per-block form, and the tables really were batched."""
+    import opentransformer_amd as ota
+    import opentransformer_amd.nn as onn
+    from opentransformer_amd import ops, synthetic as syn
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+    ops.set_compute_dtype(mode)
+    try:
+        cfg = syn.conformer_model(True, 0.0)                       # the small Conformer (d = 64, 2 blocks)
+        inputs, targets = syn.synthetic_batch(batch=4, frames=200, feat_dim=80, vocab=100, tgt_len=6, seed=2, lengths=[200, 161, 120, 88])
+        inputs, targets = {k: v.to(DEV) for k, v in inputs.items()}, {k: v.to(DEV) for k, v in targets.items()}
+        res = {}
+        for batched in (True, False):
+            onn._POS_TABLES = batched
+            model = ota.SpeechToText(cfg)
+            syn.fill_state_dict_(model.state_dict(), 3)
+            model = model.to(DEV).train()
+            dp = FlatDataParallel(model)
+            FusedAdam(dp, lr=1e-3, loss_scale=64.0)
+            if batched:
+                pos = onn.relative_sinusoid(13, cfg['encoder']['d_model'], torch.device(DEV))
+                tabs = ops.relpos_tables(pos, [b.mha.pos_proj.weight for b in model.encoder.blocks])
+                assert tabs is not None and len(tabs) == len(model.encoder.blocks)
+                pe, p0, pt0 = tabs[0]
+                assert rel(pt0.float(), p0.float().t()) < 1e-3        # the transpose is the swapped product
+                w16 = ops.weight_lp(model.encoder.blocks[1].mha.pos_proj.weight).float()
+                assert rel(tabs[1][1].float(), pe.to(ops.half_dtype()).float() @ w16.t()) < 5e-3
+            dp.zero_grad()
+            loss, _ = dp(inputs, targets)
+            ops.backward(loss)
+            torch.cuda.synchronize()
+            res[batched] = (float(loss), dp.flat_grad.clone())
+        assert abs(res[True][0] - res[False][0]) < 2e-3 * abs(res[False][0])
+        assert rel(res[True][1], res[False][1]) < (2e-2 if mode == 'bf16' else 3e-3), rel(res[True][1], res[False][1])
+    finally:
+        onn._POS_TABLES = True
+        ops.set_compute_dtype('bf16')
