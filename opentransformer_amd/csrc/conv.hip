@@ -83,14 +83,17 @@ __global__ __launch_bounds__(256) void conv1_fwd_mfma_kernel(ConvArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 32 * C1M_PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, m = lane & 31, hi = lane >> 5;
   unsigned char* img = smem + wid * (32 * C1M_PITCH);
+  // r06: blockIdx.y = the group of 64 output channels this workgroup produces (C1 = 64: one group; the Conformer's 256: four -- the
+  // VALU stencil took 138 us there); the input patches are re-read per group (they are 1/C1 of the output's bytes)
+  const int c0 = (int)blockIdx.y * 64;
   // A operands: step s covers taps 2s, 2s + 1; lane (channel 32 ct + m, tap 2s + hi); tap 9 does not exist
   float wa[2][5], bias[2][16];
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
-    for (int s5 = 0; s5 < 5; ++s5) wa[ct][s5] = (2 * s5 + hi < 9) ? p.w1[(32 * ct + m) * 9 + 2 * s5 + hi] : 0.f;
+    for (int s5 = 0; s5 < 5; ++s5) wa[ct][s5] = (2 * s5 + hi < 9) ? p.w1[(c0 + 32 * ct + m) * 9 + 2 * s5 + hi] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bias[ct][r] = p.b1[32 * ct + 8 * (r >> 2) + 4 * hi + (r & 3)];
+    for (int r = 0; r < 16; ++r) bias[ct][r] = p.b1[c0 + 32 * ct + 8 * (r >> 2) + 4 * hi + (r & 3)];
   }
   const int64_t npix = (int64_t)p.B * p.T1 * p.F1;
   const int64_t ntile = (npix + 31) / 32;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_mfma_kernel(ConvArgs p) {
     for (int i = 0; i < 4; ++i) {
       const int pr = 8 * i + (lane >> 3), piece = lane & 7;
       const uint4 v = *reinterpret_cast<const uint4*>(img + pr * C1M_PITCH + piece * 16);
-      if (pr < nvalid) *reinterpret_cast<uint4*>(out + (pix0 + pr) * 64 + piece * 8) = v;
+      if (pr < nvalid) *reinterpret_cast<uint4*>(out + (pix0 + pr) * p.C1 + c0 + piece * 8) = v;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);          // reads done before the next tile overwrites the image
   }
@@ -276,10 +279,10 @@ extern "C" int32_t otr_conv1_fwd(const otr_conv_desc_t* d, const float* x, const
   a.x = x; a.w1 = w1; a.b1 = b1; a.act1 = act1;
   hipStream_t s = (hipStream_t)stream;
   if (d->act_dtype == OTR_F32) hipLaunchKernelGGL(conv1_fwd_kernel<float>, dim3(conv_grid(a)), dim3(256), 0, s, a);
-  else if (a.C1 == 64 && !g_otr_conv1_stencil && (uintptr_t)act1 % 16 == 0) {
+  else if (a.C1 % 64 == 0 && !g_otr_conv1_stencil && (uintptr_t)act1 % 16 == 0) {
     const int64_t ntile = ((int64_t)a.B * a.T1 * a.F1 + 31) / 32;
     const int64_t g = (ntile + 3) / 4;
-    hipLaunchKernelGGL(conv1_fwd_mfma_kernel, dim3((unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g))), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(conv1_fwd_mfma_kernel, dim3((unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g)), (unsigned)(a.C1 / 64)), dim3(256), 0, s, a);
   } else hipLaunchKernelGGL(conv1_fwd_kernel<bf16_t>, dim3(conv_grid(a)), dim3(256), 0, s, a);
   return otr_check_launch("conv1_fwd");
 }

@@ -320,7 +320,8 @@ def test_colsum_unaligned(mode):
 
 
 # ------------------------------------------------------------------------------------------ conv frontend
-@pytest.mark.parametrize('B,T,Fdim,C1,C2', [(2, 200, 80, 32, 64), (3, 97, 40, 64, 128), (1, 1000, 80, 64, 128)])
+@pytest.mark.parametrize('B,T,Fdim,C1,C2', [(2, 200, 80, 32, 64), (3, 97, 40, 64, 128), (1, 1000, 80, 64, 128),
+                                            (2, 120, 80, 256, 256), (1, 77, 80, 128, 64)])      # r06: conv1 on the matrix pipe for any multiple of 64 channels
 def test_conv_subsample(mode, B, T, Fdim, C1, C2):
     from opentransformer_amd import ops
     x = rnd(B, T, Fdim, seed=71)
