@@ -166,7 +166,15 @@ __global__ __launch_bounds__(256, 1) void dec_self_fwd_kernel(DlSelfArgs p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) bq4[t][q] = *reinterpret_cast<const float4*>(p.bqkv + wid * DL_D + DL_DK * h + 32 * t + 8 * q + 4 * (lane >> 5));
   }
+#ifdef DL_PROBE      // tuning build only (make DEFS=-DDL_PROBE): where the prologue's cycles go -- loads issued / everything landed / LayerNorm done
+  DL_STAMP(0, 8);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DL_STAMP(0, 9);
+#endif
   pro.finish(p.ln, nrows, h == 0, [&](int r, int ch, const uint4& v) { *reinterpret_cast<uint4*>(ys + r * DL_YS + ch * 16) = v; }, tid);
+#ifdef DL_PROBE
+  DL_STAMP(0, 10);
+#endif
   __syncthreads();
   DL_STAMP(0, 1);
   if (wid < 3) {

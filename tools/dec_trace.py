@@ -38,3 +38,12 @@ for k, (nm, ph) in names.items():
     print('%-10s workgroups %3d  total cycles median %7.0f (p90 %7.0f); start spread %d' % (nm, a.shape[0], np.median(tot), np.percentile(tot, 90), a[:, 0].max() - a[:, 0].min()))
     for i, p_ in enumerate(ph):
         print('    %-26s median %7.0f   p90 %7.0f' % (p_, np.median(d[:, i]), np.percentile(d[:, i], 90)))
+
+# tuning build (make DEFS=-DDL_PROBE LIBDIR=../lib_probe, OTR_LIB_DIR=...): the self-attention forward launch's prologue in pieces
+a = t[0]
+a = a[a[:, 0] > 0]
+if a.shape[0] and (a[:, 8] > 0).all():
+    for nm, lo, hi in (('entry -> loads issued (LN rows + slabs, q|k|v weight stream)', 0, 8), ('-> everything landed (vmcnt 0)', 8, 9),
+                       ('-> LayerNorm arithmetic + LDS image', 9, 10), ('-> barrier', 10, 1)):
+        d = (a[:, hi] - a[:, lo]).astype(np.float64)
+        print('    probe %-62s median %7.0f   p90 %7.0f' % (nm, np.median(d), np.percentile(d, 90)))
