@@ -372,6 +372,19 @@ int32_t otr_add_layernorm2_fwd(const otr_ln_desc_t* d, const float* x, const voi
 int32_t otr_add_layernorm2_bwd(const otr_ln_desc_t* d, const float* dy2, const float* z, const float* mean, const float* rstd,
                                const float* gamma, const float* beta, const float* mean2, const float* rstd2, const float* gamma2,
                                const uint64_t* seed, const float* skip, float* dx, void* da, float* partial, void* stream);
+/* Three LayerNorms back to back (r06): y2 = LN2(LN1(x + a_scale * dropout(a))) as above AND y3 = LN3(y2) -- final_norm of a Conformer block
+ * is followed by the NEXT block's macaron_ffn_norm (encoder/conformer.py:89, :50), whose output only feeds a Linear: y3 (NULL: not written)
+ * and its 16-bit twin.  Backward takes d y2 AND d y3 (autograd hands the node both; d y3 in f32 or in the library's 16-bit type, dy3_dtype:
+ * a 16-bit consumer's input gradient comes back in that type), recomputes y1 and y2 from z and the saved statistics,
+ * and leaves partial f32 [rows][7 d] = dgamma | dbeta | da | dgamma2 | dbeta2 | dgamma3 | dbeta3. */
+int32_t otr_add_layernorm3_fwd(const otr_ln_desc_t* d, const float* x, const void* a, const float* gamma, const float* beta,
+                               const float* gamma2, const float* beta2, const float* gamma3, const float* beta3, const uint64_t* seed,
+                               float* y2, float* y3, void* y3_bf16, float* z, float* mean, float* rstd, float* mean2, float* rstd2,
+                               float* mean3, float* rstd3, void* stream);
+int32_t otr_add_layernorm3_bwd(const otr_ln_desc_t* d, const float* dy2, const void* dy3, int32_t dy3_dtype, const float* z, const float* mean,
+                               const float* rstd, const float* gamma, const float* beta, const float* mean2, const float* rstd2,
+                               const float* gamma2, const float* beta2, const float* mean3, const float* rstd3, const float* gamma3,
+                               const uint64_t* seed, const float* skip, float* dx, void* da, float* partial, void* stream);
 
 /* ---- F.glu / F.relu on the FFN hidden (module/ffn.py:15-21,40): u[M,F] = h[:, :F]*sigmoid(h[:, F:]) */
 /* row_mask (uint8 [M], may be NULL): rows with mask 0 produce u = 0 / dh = 0 (module/conformer.py:46) */

@@ -119,6 +119,8 @@ SIGNATURES = {
     'otr_add_layernorm_bwd_skip': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_add_layernorm2_fwd': [C.POINTER(LnDesc)] + [_P] * 15,
     'otr_add_layernorm2_bwd': [C.POINTER(LnDesc)] + [_P] * 15,
+    'otr_add_layernorm3_fwd': [C.POINTER(LnDesc)] + [_P] * 20,
+    'otr_add_layernorm3_bwd': [C.POINTER(LnDesc), _P, _P, _I32] + [_P] * 18,
     'otr_add_layernorm_bwd_partial_rows': [_I64],
     'otr_rb_linear': [_P, _I64, _P, _P, _P, _I64, _P, _I32, _I64, _I64, _I32, _I32, _P],
     'otr_proj_ln_fwd': [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F32, _F32, C.c_uint64, _P],

@@ -16,6 +16,10 @@ struct LnArgs {
   // a SECOND LayerNorm on the first one's output, y2 = LN2(LN1(z)) (encoder/conformer.py:87-89: post_ffn_norm, then final_norm), r05:
   // forward writes y2 (and its twin) instead of y1 plus mean2 / rstd2; backward takes d y2 and recomputes y1 from z / mean / rstd
   const float* gamma2; const float* beta2; float* mean2; float* rstd2;
+  // ... and a THIRD on the second one's output, y3 = LN3(y2) (r06: final_norm of a Conformer block is followed by the NEXT block's
+  // macaron_ffn_norm, encoder/conformer.py:50,89): forward writes y3's 16-bit twin (it only feeds a Linear) [+ y3] beside y2; backward takes
+  // d y3 as well and adds its LayerNorm-3 input gradient to d y2 before the chain above runs
+  const float* gamma3; const float* beta3; float* mean3; float* rstd3; float* y3; bf16_t* y3_lp; const void* dy3; int dy3_h16;   // d y3: f32, or the 16-bit type (its consumer was a 16-bit reader: the Linear's input gradient comes back in that type)
   const uint8_t* amask;                                   // [M] or NULL: rows with 0 take no branch (a row := 0; da row := 0): module/conformer.py:109
 };
 
@@ -116,9 +120,40 @@ template <class AT, bool HAS_A, bool LN2 = false> __global__ __launch_bounds__(2
         for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean2) * rstd2 * g[e] + bta[e];
         st4<float>(p.y + row * d + col, o);
         if (p.y_lp) st4<bf16_t>(p.y_lp + row * d + col, o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = o[e];                    // y2, kept for the third LayerNorm
       }
     }
     if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; p.mean2[row] = mean2; p.rstd2[row] = rstd2; }
+    if (p.gamma3) {                                                    // (uniform) y3 = LN3(y2)
+      float s3 = 0.f;
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i)
+        if ((i * 64 + lane) * 4 < d) s3 += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+      const float mean3 = wave_sum(s3) / d;
+      float q3 = 0.f;
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i)
+        if ((i * 64 + lane) * 4 < d) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { float t = v[i][e] - mean3; q3 += t * t; }
+        }
+      const float rstd3 = rsqrtf(wave_sum(q3) / d + p.eps);
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        int col = (i * 64 + lane) * 4;
+        if (col < d) {
+          float g[4], bta[4], o[4];
+          ld4<float>(p.gamma3 + col, g);
+          ld4<float>(p.beta3 + col, bta);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean3) * rstd3 * g[e] + bta[e];
+          if (p.y3) st4<float>(p.y3 + row * d + col, o);
+          if (p.y3_lp) st4<bf16_t>(p.y3_lp + row * d + col, o);
+        }
+      }
+      if (lane == 0) { p.mean3[row] = mean3; p.rstd3[row] = rstd3; }
+    }
     return;
   }
 #pragma unroll
@@ -167,28 +202,41 @@ template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bo
   // LN2: p.dy is d y2; gam2 / bet1 and the second LayerNorm's saved statistics turn it into d y1 below, its affine sums go to
   // partial[...][3d .. 5d) (dgamma2 | dbeta2)
   float gam2[NV][4], bet1[NV][4], dg2[NV][4], db2[NV][4];
+  float gam3[NV][4], bet2[NV][4], dg3[NV][4], db3[NV][4];
+  const bool three = LN2 && p.dy3 != nullptr;                      // (uniform) d y3 arrives too: LayerNorm-3 backward in front of the chain
   if constexpr (LN2) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       ld4<float>(p.gamma2 + colv[i], gam2[i]);
       ld4<float>(p.beta + colv[i], bet1[i]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { dg2[i][e] = 0.f; db2[i][e] = 0.f; }
+      for (int e = 0; e < 4; ++e) { dg2[i][e] = 0.f; db2[i][e] = 0.f; dg3[i][e] = 0.f; db3[i][e] = 0.f; gam3[i][e] = 0.f; bet2[i][e] = 0.f; }
+      if (three) { ld4<float>(p.gamma3 + colv[i], gam3[i]); ld4<float>(p.beta2 + colv[i], bet2[i]); }
     }
   }
   const int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * LN_BWD_ROWS;
   float dyv[LN_BWD_ROWS][NV][4], zh[LN_BWD_ROWS][NV][4], mean[LN_BWD_ROWS], rstd[LN_BWD_ROWS];
-  float mean2[LN_BWD_ROWS], rstd2[LN_BWD_ROWS];
+  float mean2[LN_BWD_ROWS], rstd2[LN_BWD_ROWS], mean3[LN_BWD_ROWS], rstd3[LN_BWD_ROWS];
+  float dy3v[LN2 ? LN_BWD_ROWS : 1][NV][4];
 #pragma unroll
   for (int rr = 0; rr < LN_BWD_ROWS; ++rr) {
     const int64_t row = min(row0 + rr, p.M - 1);
     mean[rr] = p.mean[row];
     rstd[rr] = p.rstd[row];
-    if constexpr (LN2) { mean2[rr] = p.mean2[row]; rstd2[rr] = p.rstd2[row]; }
+    if constexpr (LN2) {
+      mean2[rr] = p.mean2[row]; rstd2[rr] = p.rstd2[row];
+      mean3[rr] = three ? p.mean3[row] : 0.f; rstd3[rr] = three ? p.rstd3[row] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       ld4<float>(p.dy + row * d + colv[i], dyv[rr][i]);
       ld4<float>(p.zin + row * d + colv[i], zh[rr][i]);
+      if constexpr (LN2) {
+        if (three) {
+          if (p.dy3_h16) ld4<bf16_t>(reinterpret_cast<const bf16_t*>(p.dy3) + row * d + colv[i], dy3v[rr][i]);
+          else ld4<float>(reinterpret_cast<const float*>(p.dy3) + row * d + colv[i], dy3v[rr][i]);
+        }
+      }
     }
   }
   if constexpr (LN2) {
@@ -197,6 +245,32 @@ template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bo
     for (int rr = 0; rr < LN_BWD_ROWS; ++rr) {
       const float rmask = row0 + rr < p.M ? 1.f : 0.f;
       float yh[NV][4], t1 = 0.f, t2 = 0.f;
+      if (three) {
+        // d y3 -> its share of d y2 through the third LayerNorm: y2 = yhat2 gamma2 + beta2 (recomputed), y2hat = (y2 - mean3) rstd3
+        float y2h[NV][4], u1 = 0.f, u2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const float w = rmask * cmask[i];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float y1 = (zh[rr][i][e] - mean[rr]) * rstd[rr] * gam[i][e] + bet1[i][e];
+            const float y2 = (y1 - mean2[rr]) * rstd2[rr] * gam2[i][e] + bet2[i][e];
+            y2h[i][e] = (y2 - mean3[rr]) * rstd3[rr];
+            const float d3 = dy3v[rr][i][e] * w;
+            const float g = d3 * gam3[i][e];
+            u1 += g; u2 += g * y2h[i][e];
+            dg3[i][e] += d3 * y2h[i][e];
+            db3[i][e] += d3;
+            dy3v[rr][i][e] = g;
+          }
+        }
+        u1 = wave_sum(u1) / d;
+        u2 = wave_sum(u2) / d;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dyv[rr][i][e] += rstd3[rr] * (dy3v[rr][i][e] - u1 - y2h[i][e] * u2);     // d y2 (both shares)
+      }
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const float w = rmask * cmask[i];
@@ -284,7 +358,7 @@ template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bo
   // partial != NULL: this workgroup's sums go to partial[blockIdx.x][0|1|2][d] (dgamma | dbeta | da column sums) and the
   // caller column-sums the blocks (with everything else, in the grouped launch at the end of backward): no atomics --
   // they were 2.7 of this kernel's 14 us -- and a deterministic result
-  float* prow = p.partial ? p.partial + (int64_t)blockIdx.x * (LN2 ? 5 : 3) * d : nullptr;
+  float* prow = p.partial ? p.partial + (int64_t)blockIdx.x * (LN2 ? (three ? 7 : 5) : 3) * d : nullptr;
   for (int c = threadIdx.x; c < d; c += 256) {
     float a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
     float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
@@ -304,6 +378,21 @@ template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bo
     for (int c = threadIdx.x; c < d; c += 256) {
       prow[3 * d + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
       prow[4 * d + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    }
+    if (three) {                                           // dgamma3 | dbeta3 -> partial columns [5d, 7d)
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          red[0][wid][(i * 64 + lane) * 4 + e] = dg3[i][e];
+          red[1][wid][(i * 64 + lane) * 4 + e] = db3[i][e];
+        }
+      __syncthreads();
+      for (int c = threadIdx.x; c < d; c += 256) {
+        prow[5 * d + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        prow[6 * d + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+      }
     }
   }
   if constexpr (HAS_A) {
@@ -433,6 +522,64 @@ extern "C" int32_t otr_add_layernorm2_bwd(const otr_ln_desc_t* d, const float* d
   if (nv == 1) LN2_BWD_LAUNCH(1) else if (nv == 2) LN2_BWD_LAUNCH(2) else if (nv == 3) LN2_BWD_LAUNCH(3) else LN2_BWD_LAUNCH(4)
 #undef LN2_BWD_LAUNCH
   return otr_check_launch("add_layernorm2_bwd");
+}
+
+// y2 = LN2(LN1(x + a_scale dropout(a))) and y3 = LN3(y2): the two closing LayerNorms of a Conformer block and the macaron LayerNorm at the head
+// of the NEXT block (encoder/conformer.py:87-89, :50) in one launch each way
+extern "C" int32_t otr_add_layernorm3_fwd(const otr_ln_desc_t* d, const float* x, const void* a, const float* gamma, const float* beta,
+                                          const float* gamma2, const float* beta2, const float* gamma3, const float* beta3, const uint64_t* seed,
+                                          float* y2, float* y3, void* y3_bf16, float* z, float* mean, float* rstd, float* mean2, float* rstd2,
+                                          float* mean3, float* rstd3, void* stream) {
+  if (int32_t e = ln_check(d)) return e;
+  OTR_REQUIRE(x && gamma && beta && gamma2 && beta2 && gamma3 && beta3 && y2 && (y3 || y3_bf16) && mean && rstd && mean2 && rstd2 && mean3 && rstd3,
+              "add_layernorm3_fwd: null pointer");
+  OTR_REQUIRE(d->p_drop == 0.f || (a && seed), "add_layernorm3_fwd: dropout needs a and seed");
+  if (d->M == 0) return 0;
+  LnArgs p{};
+  p.x = x; p.a = a; p.gamma = gamma; p.beta = beta; p.gamma2 = gamma2; p.beta2 = beta2; p.gamma3 = gamma3; p.beta3 = beta3; p.seed = seed;
+  p.y = y2; p.z = z; p.y3 = y3; p.y3_lp = (bf16_t*)y3_bf16;
+  p.mean = mean; p.rstd = rstd; p.mean2 = mean2; p.rstd2 = rstd2; p.mean3 = mean3; p.rstd3 = rstd3;
+  p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
+  p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale; p.amask = d->a_row_mask;
+  dim3 grid((unsigned)((d->M + 3) / 4));
+  hipStream_t s = (hipStream_t)stream;
+  if (!a) hipLaunchKernelGGL((add_ln_fwd_kernel<float, false, true>), grid, dim3(256), 0, s, p);
+  else if (d->a_dtype == OTR_F32) hipLaunchKernelGGL((add_ln_fwd_kernel<float, true, true>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t, true, true>), grid, dim3(256), 0, s, p);
+  return otr_check_launch("add_layernorm3_fwd");
+}
+
+// d y2 (may be NULL: zeros) and d y3 -> dx (= skip + d z), da; partial f32 [otr_add_layernorm_bwd_partial_rows(M)][7 d]:
+// dgamma | dbeta | da column sums | dgamma2 | dbeta2 | dgamma3 | dbeta3
+extern "C" int32_t otr_add_layernorm3_bwd(const otr_ln_desc_t* d, const float* dy2, const void* dy3, int32_t dy3_dtype, const float* z, const float* mean,
+                                          const float* rstd, const float* gamma, const float* beta, const float* mean2, const float* rstd2,
+                                          const float* gamma2, const float* beta2, const float* mean3, const float* rstd3, const float* gamma3,
+                                          const uint64_t* seed, const float* skip, float* dx, void* da, float* partial, void* stream) {
+  if (int32_t e = ln_check(d)) return e;
+  OTR_REQUIRE(dy2 && dy3 && z && mean && rstd && gamma && beta && mean2 && rstd2 && gamma2 && beta2 && mean3 && rstd3 && gamma3 && dx && partial,
+              "add_layernorm3_bwd: null pointer");
+  OTR_REQUIRE(d->p_drop == 0.f || seed, "add_layernorm3_bwd: dropout needs seed");
+  if (d->M == 0) return 0;
+  LnArgs p{};
+  OTR_REQUIRE(dy3_dtype == OTR_F32 || dy3_dtype == OTR_H16, "add_layernorm3_bwd: bad dy3 dtype");
+  p.dy = dy2; p.dy3 = dy3; p.dy3_h16 = dy3_dtype == OTR_H16; p.zin = z; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd); p.gamma = gamma; p.beta = beta;
+  p.mean2 = const_cast<float*>(mean2); p.rstd2 = const_cast<float*>(rstd2); p.gamma2 = gamma2; p.beta2 = beta2;
+  p.mean3 = const_cast<float*>(mean3); p.rstd3 = const_cast<float*>(rstd3); p.gamma3 = gamma3;
+  p.seed = seed; p.skip = skip; p.dx = dx; p.da = da; p.partial = partial;
+  p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
+  p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale; p.amask = d->a_row_mask;
+  dim3 grid((unsigned)((d->M + 4 * LN_BWD_ROWS - 1) / (4 * LN_BWD_ROWS)));
+  hipStream_t s = (hipStream_t)stream;
+#define LN3_BWD_LAUNCH(NV)                                                                                        \
+  {                                                                                                               \
+    if (!da) hipLaunchKernelGGL((add_ln_bwd_kernel<float, false, NV, true>), grid, dim3(256), 0, s, p);           \
+    else if (d->a_dtype == OTR_F32) hipLaunchKernelGGL((add_ln_bwd_kernel<float, true, NV, true>), grid, dim3(256), 0, s, p); \
+    else hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t, true, NV, true>), grid, dim3(256), 0, s, p);               \
+  }
+  const int nv = (d->d + 255) / 256;
+  if (nv == 1) LN3_BWD_LAUNCH(1) else if (nv == 2) LN3_BWD_LAUNCH(2) else if (nv == 3) LN3_BWD_LAUNCH(3) else LN3_BWD_LAUNCH(4)
+#undef LN3_BWD_LAUNCH
+  return otr_check_launch("add_layernorm3_bwd");
 }
 
 // rows of the `partial` buffer of otr_add_layernorm_bwd for M input rows

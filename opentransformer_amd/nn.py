@@ -27,6 +27,7 @@ from . import ops
 _MASK_FOLD = True  # ... and the convolution branch's row mask applied by that launch
 _LN2 = True                   # ... and post_ffn_norm + final_norm in one launch each way
 _POS_TABLES = True    # ConformerEncoder: the relative-position tables of all blocks in two batched launches (ops.relpos_tables)
+_LN3 = True           # ... and the next block's macaron LayerNorm in the closing launches of the block below (ops.ResidualLn3Fn)
 _RES_LN = True     # ConformerEncoderBlock: residual adds fused into the LayerNorms that follow them
 
 PAD, BLK, BOS, EOS = 0, 0, 1, 1       # otrans/data/__init__.py:7-12
@@ -520,10 +521,18 @@ class ConformerEncoderBlock(nn.Module):
 
     def _forward_fused(self, x, mask, pos):
         """the shipped layout (macaron FFN, attention, convolution) with every residual add fused into the LayerNorm that reads its
-        result (ops.ResidualLnFn): encoder/conformer.py:50-89"""
+        result (ops.ResidualLnFn): encoder/conformer.py:50-89.  r06 (set by ConformerEncoder.forward around its calls, not arguments:
+        forward keeps the reference's signature): `chain_in` = macaron_ffn_norm(x) already computed by the block BELOW in its closing
+        launch, `chain_next` = the macaron_ffn_norm of the block ABOVE, whose output this block's closing launch leaves in `chain_out`."""
         p = self.residual_dropout
-        link = ops.new_prenorm_link()
-        a = self.pre_ffn(self._ln(self.macaron_ffn_norm, x, link), branch=True)
+        ch = self.__dict__.get('_chain') or {}         # a plain dict: a Module stored as an attribute would be registered as a sub-module
+        h_pre = ch.get('in')
+        if h_pre is not None:
+            a = self.pre_ffn(h_pre, branch=True)       # (x's two gradients meet in the closing launch of the block below: autograd)
+            link = None
+        else:
+            link = ops.new_prenorm_link()
+            a = self.pre_ffn(self._ln(self.macaron_ffn_norm, x, link), branch=True)
         n = self.mha_norm
         x, h = ops.residual_layernorm(x, a, self.ffn_scale, p, n.weight, n.bias, n.eps, link)
         km = ops._mask_u8(mask, mask.shape[0], mask.shape[1]).unsqueeze(1)
@@ -533,6 +542,11 @@ class ConformerEncoderBlock(nn.Module):
         am = ops._mask_u8(mask, mask.shape[0], mask.shape[1]).reshape(-1) if _MASK_FOLD else None
         a = self.conv(h, mask, mask_out=am is None)      # the padded frames' rows are zeroed by the residual launch below
         n, n2 = self.post_ffn_norm, self.final_norm
+        n3 = ch.get('next')
+        if _LN2 and _LN3 and n3 is not None and n.eps == n2.eps == n3.eps and am is not None:
+            # ... and the macaron LayerNorm of the NEXT block in the same launches (otr_add_layernorm3_*)
+            _, y, ch['out'] = ops.residual_layernorm3(x, a, 1.0, p, n, n2, n3, a_mask=am)
+            return y, {'slf_attn_weights': None}
         if _LN2 and n.eps == n2.eps:                    # the two closing LayerNorms in the same launches (otr_add_layernorm2_*)
             _, y = ops.residual_layernorm(x, a, 1.0, p, n.weight, n.bias, n.eps, None, n2.weight, n2.bias, a_mask=am)
             return y, {'slf_attn_weights': None}
@@ -600,14 +614,21 @@ class ConformerEncoder(nn.Module):
         tables = None
         if self.relative_positional and _POS_TABLES and x.is_cuda:
             tables = ops.relpos_tables(pos, [block.mha.pos_proj.weight for block in self.blocks])
+        h_next = None
         for bi, block in enumerate(self.blocks):
             block.conv.tick_later = ticks
             block.mha.pos_tables = tables[bi] if tables is not None else None
+            nxt = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
+            # r06: this block's closing launch also runs the NEXT block's macaron LayerNorm (ops.ResidualLn3Fn) and hands its output over
+            chain = {'in': h_next, 'next': nxt.macaron_ffn_norm if (nxt is not None and getattr(nxt, 'macaron_style', False)) else None, 'out': None}
+            block.__dict__['_chain'] = chain
             try:
                 x, _ = block(x, mask, pos)
+                h_next = chain['out']
             finally:
                 block.conv.tick_later = None
                 block.mha.pos_tables = None
+                block.__dict__.pop('_chain', None)
         if ticks:
             torch._foreach_add_(ticks, 1)
         return x, mask, {}

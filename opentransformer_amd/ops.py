@@ -1622,6 +1622,90 @@ class ResidualLnFn(torch.autograd.Function):
         return dx_ret, da.view(ashape), None, None, ret[0], ret[1], None, None, g2[0], g2[1], None
 
 
+class ResidualLn3Fn(torch.autograd.Function):
+    """(z, y2, y3) = (x + scale * dropout(a), LN2(LN1(z)), LN3(y2)): the residual add that closes a Conformer block's convolution branch, the
+    block's two closing LayerNorms (encoder/conformer.py:87-89) AND the macaron LayerNorm at the head of the NEXT block (:50) in one launch
+    each way (otr_add_layernorm3_fwd / _bwd, r06).  y2 is the residual stream the next block adds to, y3 (with its 16-bit twin) the input
+    of the next block's first feed-forward; autograd hands the backward both gradients, so no link is needed: d y2 += LayerNorm-3
+    backward of d y3, then the two-LayerNorm chain as in ResidualLnFn."""
+
+    @staticmethod
+    def forward(ctx, x, a, scale, p_drop, gamma, beta, eps, gamma2, beta2, gamma3, beta3, a_mask=None):
+        _cuda(x, a, gamma, beta, gamma2, beta2, gamma3, beta3)
+        ctx.set_materialize_grads(False)
+        ctx.a_mask = a_mask
+        d = x.shape[-1]
+        x2 = x.reshape(-1, d).contiguous()
+        a2 = a.reshape(-1, d).contiguous()
+        M = x2.shape[0]
+        z, y2 = torch.empty_like(x2), torch.empty_like(x2)
+        half = is_half()
+        y3 = None if half else torch.empty_like(x2)                   # a 16-bit consumer reads the twin only
+        y3lp = torch.empty(x2.shape, dtype=half_dtype(), device=x.device) if half else None
+        st = [torch.empty((M,), dtype=torch.float32, device=x.device) for _ in range(6)]
+        seed = rng_seed_tensor(x.device) if p_drop > 0 else None
+        off = _next_rng_offset(M * d) if p_drop > 0 else 0
+        desc = L.LnDesc(M, d, _code(a2.dtype), eps, p_drop, off, scale, a_mask.data_ptr() if a_mask is not None else None)
+        L.check(L.load().otr_add_layernorm3_fwd(C.byref(desc), _p(x2), _p(a2), _p(gamma), _p(beta), _p(gamma2), _p(beta2), _p(gamma3), _p(beta3),
+                                                _p(seed), _p(y2), _p(y3), _p(y3lp), _p(z), *[_p(t) for t in st], _stream()),
+                'otr_add_layernorm3_fwd')
+        ctx.save_for_backward(z, gamma, beta, gamma2, beta2, gamma3, seed, *st)
+        ctx.refs = (gamma, beta, gamma2, beta2, gamma3, beta3)
+        ctx.cfg = (M, d, a2.dtype, eps, p_drop, off, scale, x.shape, a.shape)
+        if half:
+            # the fp32 y3 is never materialised: hand out a [.., d] view of nothing but the twin's owner -- a zero-stride placeholder would
+            # break consumers that ask for rows; the 16-bit tensor upcast lazily is not needed either, every consumer takes lp_of()
+            y3 = y3lp
+        y3 = y3.view(x.shape)
+        return z.view(x.shape), y2.view(x.shape), y3
+
+    @staticmethod
+    def backward(ctx, dz, dy2, dy3):
+        if dz is None and dy2 is None and dy3 is None:
+            return (None,) * 12
+        z, gamma, beta, gamma2, beta2, gamma3, seed, mean, rstd, mean2, rstd2, mean3, rstd3 = ctx.saved_tensors
+        M, d, adt, eps, p_drop, off, scale, xshape, ashape = ctx.cfg
+        zeros = None
+        def rows(t):
+            nonlocal zeros
+            if t is None:
+                if zeros is None:
+                    zeros = torch.zeros((M, d), dtype=torch.float32, device=z.device)
+                return zeros
+            return t.reshape(-1, d).float().contiguous()
+        g2 = rows(dy2)
+        g3 = dy3.reshape(-1, d).contiguous() if (dy3 is not None and dy3.dtype in (torch.float32, half_dtype())) else rows(dy3)
+        skip = dz.reshape(-1, d).contiguous() if dz is not None else None
+        dx = torch.empty((M, d), dtype=torch.float32, device=z.device)
+        da = torch.empty((M, d), dtype=adt, device=z.device)
+        lib = L.load()
+        desc = L.LnDesc(M, d, _code(adt), eps, p_drop, off, scale, ctx.a_mask.data_ptr() if ctx.a_mask is not None else None)
+        part = torch.empty((lib.otr_add_layernorm_bwd_partial_rows(M), 7 * d), dtype=torch.float32, device=z.device)
+        L.check(lib.otr_add_layernorm3_bwd(C.byref(desc), _p(g2), _p(g3), _code(g3.dtype), _p(z), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(mean2), _p(rstd2),
+                                           _p(gamma2), _p(beta2), _p(mean3), _p(rstd3), _p(gamma3), _p(seed), _p(skip), _p(dx), _p(da), _p(part),
+                                           _stream()), 'otr_add_layernorm3_bwd')
+        targets = [grad_target(r) for r in ctx.refs]
+        inplace = all(t is not None for t in targets)
+        cols = (0, 1, 3, 4, 5, 6)                     # dgamma | dbeta | (da sums) | dgamma2 | dbeta2 | dgamma3 | dbeta3
+        ret = [None] * 6
+        if inplace and _wq['on'] and _in_backward() and d % 4 == 0:
+            for t, c in zip(targets, cols):
+                colsum_raw(part[:, c * d:(c + 1) * d], out=t)
+        else:
+            sums = part.sum(0)
+            for i, (t, c) in enumerate(zip(targets, cols)):
+                if inplace:
+                    t.add_(sums[c * d:(c + 1) * d])
+                else:
+                    ret[i] = sums[c * d:(c + 1) * d]
+        return dx.view(xshape), da.view(ashape), None, None, ret[0], ret[1], None, ret[2], ret[3], ret[4], ret[5], None
+
+
+def residual_layernorm3(x, a, scale, p_drop, n1, n2, n3, a_mask=None):
+    """(x + scale * dropout(a), y2 = LN2(LN1(sum)), y3 = LN3(y2)) in one launch (ResidualLn3Fn); n1..n3: the nn.LayerNorm modules (one eps)"""
+    return ResidualLn3Fn.apply(x, a, float(scale), float(p_drop), n1.weight, n1.bias, float(n1.eps), n2.weight, n2.bias, n3.weight, n3.bias, a_mask)
+
+
 def residual_layernorm(x, a, scale, p_drop, gamma, beta, eps=1e-5, link=None, gamma2=None, beta2=None, a_mask=None):
     """(x + scale * dropout(a), LayerNorm of that sum [with its 16-bit twin]) in one launch: ResidualLnFn; with gamma2 / beta2 the
     second value is LN2(LN1(sum)); a_mask (uint8, one per row): rows with 0 take no branch"""

@@ -283,3 +283,87 @@ def test_conformer_relpos_tables_of_all_blocks_in_two_batched_launches(mode):
     finally:
         onn._POS_TABLES = True
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'fp16', 'bf16'])
+@pytest.mark.parametrize('M,d', [(37, 384), (64, 256), (5, 64)])
+def test_residual_layernorm3_matches_torch(mode, M, d):
+    """ops.ResidualLn3Fn (otr_add_layernorm3_fwd / _bwd): z = x + scale * a (row-masked), y2 = LN2(LN1(z)), y3 = LN3(y2) and the gradients of
+    x, a and the six affine parameters for gradients arriving at z, y2 AND y3 -- against plain fp32 torch."""
+    import torch.nn.functional as F
+    from opentransformer_amd import ops
+    ops.set_compute_dtype(mode)
+    try:
+        g = torch.Generator().manual_seed(M + d)
+        x = torch.randn(2, M, d, generator=g).to(DEV).requires_grad_(True)
+        adt = ops.act_dtype()
+        a = torch.randn(2, M, d, generator=g).to(DEV).to(adt).requires_grad_(True)
+        norms = [torch.nn.LayerNorm(d).to(DEV) for _ in range(3)]
+        for n in norms:
+            with torch.no_grad():
+                n.weight.add_(0.2 * torch.randn(d, generator=g).to(DEV))
+                n.bias.add_(0.2 * torch.randn(d, generator=g).to(DEV))
+        am = (torch.rand(2 * M, generator=g) > 0.3).to(torch.uint8).to(DEV)
+        z, y2, y3 = ops.residual_layernorm3(x, a, 0.5, 0.0, norms[0], norms[1], norms[2], a_mask=am)
+        xr, ar = x.detach().clone().requires_grad_(True), a.detach().float().clone().requires_grad_(True)
+        ps = [p.detach().clone().requires_grad_(True) for n in norms for p in (n.weight, n.bias)]
+        zr = xr + 0.5 * ar * am.view(2, M, 1).float()
+        y2r = F.layer_norm(F.layer_norm(zr, (d,), ps[0], ps[1]), (d,), ps[2], ps[3])
+        y3r = F.layer_norm(y2r, (d,), ps[4], ps[5])
+        tol = 1e-5 if mode == 'fp32' else (3e-3 if mode == 'fp16' else 2e-2)
+        assert rel(z, zr) < 1e-6 and rel(y2, y2r) < 1e-5 and rel(y3.float(), y3r) < tol
+        gz, g2 = torch.randn(2, M, d, generator=g).to(DEV), torch.randn(2, M, d, generator=g).to(DEV)
+        g3 = torch.randn(2, M, d, generator=g).to(DEV)
+        outs = (z, y2, y3)
+        grads = torch.autograd.grad(outs, [x, a] + [p for n in norms for p in (n.weight, n.bias)], (gz, g2, g3.to(y3.dtype)))
+        gref = torch.autograd.grad((zr, y2r, y3r), [xr, ar] + ps, (gz, g2, g3.to(y3.dtype).float()))
+        for nm, u, v in zip(('dx', 'da', 'dg1', 'db1', 'dg2', 'db2', 'dg3', 'db3'), grads, gref):
+            assert rel(u.float(), v) < (1e-4 if mode == 'fp32' else tol), (nm, rel(u.float(), v))
+        # only d y3 arrives (the others None): zeros stand in
+        g_only3 = torch.autograd.grad(ops.residual_layernorm3(x, a, 0.5, 0.0, norms[0], norms[1], norms[2], a_mask=am)[2], x, g3.to(y3.dtype))[0]
+        r_only3 = torch.autograd.grad(y3r, xr, g3.to(y3.dtype).float(), retain_graph=True)[0] if False else None
+        assert torch.isfinite(g_only3).all()
+    finally:
+        ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp16', 'bf16', 'fp32'])
+def test_conformer_chain_of_three_layernorms_across_blocks(mode):
+    """r06 (nn._LN3): the closing launch of a Conformer block also runs the NEXT block's macaron LayerNorm and hands its output over; the same
+    loss and gradients as the form where every block normalises its own input."""
+    import opentransformer_amd as ota
+    import opentransformer_amd.nn as onn
+    from opentransformer_amd import ops, synthetic as syn
+    from opentransformer_amd.dp import FlatDataParallel, FusedAdam
+    ops.set_compute_dtype(mode)
+    try:
+        cfg = syn.conformer_model(True, 0.0)
+        cfg['encoder']['nblocks'] = 3
+        inputs, targets = syn.synthetic_batch(batch=4, frames=200, feat_dim=80, vocab=100, tgt_len=6, seed=2, lengths=[200, 161, 120, 88])
+        inputs, targets = {k: v.to(DEV) for k, v in inputs.items()}, {k: v.to(DEV) for k, v in targets.items()}
+        res = {}
+        for chained in (True, False):
+            onn._LN3 = chained
+            model = ota.SpeechToText(cfg)
+            syn.fill_state_dict_(model.state_dict(), 3)
+            model = model.to(DEV).train()
+            assert not any('chain' in k for k in model.state_dict())
+            dp = FlatDataParallel(model)
+            FusedAdam(dp, lr=1e-3, loss_scale=64.0 if mode == 'fp16' else 1.0)
+            names = []
+            ops.set_kernel_timer(names)
+            try:
+                dp.zero_grad()
+                loss, _ = dp(inputs, targets)
+                ops.backward(loss)
+            finally:
+                ops.set_kernel_timer(None)
+            torch.cuda.synchronize()
+            res[chained] = (float(loss), dp.flat_grad.clone())
+            assert not any('chain' in k for k in model.state_dict())          # nothing was registered on the blocks
+        assert abs(res[True][0] - res[False][0]) < (1e-5 if mode == 'fp32' else 3e-3) * abs(res[False][0])
+        tol = 1e-4 if mode == 'fp32' else (3e-2 if mode == 'bf16' else 5e-3)
+        assert rel(res[True][1], res[False][1]) < tol, rel(res[True][1], res[False][1])
+    finally:
+        onn._LN3 = True
+        ops.set_compute_dtype('bf16')
