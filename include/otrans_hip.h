@@ -338,6 +338,9 @@ typedef struct {
   float a_scale;                /* r05: y = LN(x + a_scale * dropout(a)), da = a_scale * dropout'(dz); 0 means 1 (older callers) */
   const uint8_t* a_row_mask;    /* r05: [M] or NULL; rows with 0 take no branch: a row := 0 forward, da row := 0 backward (the
                                  * masked_fill of module/conformer.py:109 folded into the residual add that consumes the branch) */
+  int32_t dy_dtype;             /* r06, backward entries: OTR_F32 (0) or the library's 16-bit type -- the LayerNorm's output fed a 16-bit
+                                 * reader only (a Linear), whose input gradient then comes back in that type (half the bytes of the
+                                 * input-gradient GEMM's output); forward entries may pass y = NULL then and write the 16-bit twin alone */
 } otr_ln_desc_t;
 /* y_bf16 (may be NULL): bf16 copy of y, the GEMM-operand form of the residual stream */
 int32_t otr_add_layernorm_fwd(const otr_ln_desc_t* d, const float* x, const void* a, const float* gamma,

@@ -47,7 +47,8 @@ class AttnDesc(C.Structure):
 
 class LnDesc(C.Structure):
     _fields_ = [('M', C.c_int64), ('d', C.c_int32), ('a_dtype', C.c_int32),
-                ('eps', C.c_float), ('p_drop', C.c_float), ('rng_offset', C.c_uint64), ('a_scale', C.c_float), ('a_row_mask', C.c_void_p)]
+                ('eps', C.c_float), ('p_drop', C.c_float), ('rng_offset', C.c_uint64), ('a_scale', C.c_float), ('a_row_mask', C.c_void_p),
+                ('dy_dtype', C.c_int32)]
 
 
 class ConvDesc(C.Structure):

@@ -20,6 +20,7 @@ struct LnArgs {
   // macaron_ffn_norm, encoder/conformer.py:50,89): forward writes y3's 16-bit twin (it only feeds a Linear) [+ y3] beside y2; backward takes
   // d y3 as well and adds its LayerNorm-3 input gradient to d y2 before the chain above runs
   const float* gamma3; const float* beta3; float* mean3; float* rstd3; float* y3; bf16_t* y3_lp; const void* dy3; int dy3_h16;   // d y3: f32, or the 16-bit type (its consumer was a 16-bit reader: the Linear's input gradient comes back in that type)
+  int dy_h16;                                             // backward: dy is 16-bit (otr_ln_desc_t.dy_dtype)
   const uint8_t* amask;                                   // [M] or NULL: rows with 0 take no branch (a row := 0; da row := 0): module/conformer.py:109
 };
 
@@ -165,7 +166,7 @@ template <class AT, bool HAS_A, bool LN2 = false> __global__ __launch_bounds__(2
       ld4<float>(p.beta + col, bta);
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + bta[e];
-      st4<float>(p.y + row * d + col, o);
+      if (p.y) st4<float>(p.y + row * d + col, o);
       if (p.y_lp) st4<bf16_t>(p.y_lp + row * d + col, o);
     }
   }
@@ -229,7 +230,8 @@ template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bo
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      ld4<float>(p.dy + row * d + colv[i], dyv[rr][i]);
+      if (p.dy_h16) ld4<bf16_t>(reinterpret_cast<const bf16_t*>(p.dy) + row * d + colv[i], dyv[rr][i]);
+      else ld4<float>(p.dy + row * d + colv[i], dyv[rr][i]);
       ld4<float>(p.zin + row * d + colv[i], zh[rr][i]);
       if constexpr (LN2) {
         if (three) {
@@ -426,7 +428,7 @@ extern "C" int32_t otr_add_layernorm_fwd(const otr_ln_desc_t* d, const float* x,
                                          const float* beta, const uint64_t* seed, float* y, void* y_bf16, float* z,
                                          float* mean, float* rstd, void* stream) {
   if (int32_t e = ln_check(d)) return e;
-  OTR_REQUIRE(x && gamma && beta && y && mean && rstd, "add_layernorm_fwd: null pointer");
+  OTR_REQUIRE(x && gamma && beta && (y || y_bf16) && mean && rstd, "add_layernorm_fwd: null pointer");
   OTR_REQUIRE(d->p_drop == 0.f || (a && seed), "add_layernorm_fwd: dropout needs a and seed");
   if (d->M == 0) return 0;
   LnArgs p{};
@@ -457,6 +459,8 @@ extern "C" int32_t otr_add_layernorm_bwd_skip(const otr_ln_desc_t* d, const floa
   if (d->M == 0) return 0;
   LnArgs p{};
   p.dy = dy; p.zin = z; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd); p.gamma = gamma;
+  OTR_REQUIRE(d->dy_dtype == OTR_F32 || d->dy_dtype == OTR_H16, "add_layernorm_bwd: bad dy_dtype %d", d->dy_dtype);
+  p.dy_h16 = d->dy_dtype == OTR_H16;
   p.seed = seed; p.skip = skip; p.dx = dx; p.da = da; p.dgamma = dgamma; p.dbeta = dbeta; p.da_colsum = da ? da_colsum : nullptr; p.partial = partial;
   p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
   p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale; p.amask = d->a_row_mask;

@@ -27,6 +27,7 @@ from . import ops
 _MASK_FOLD = True  # ... and the convolution branch's row mask applied by that launch
 _LN2 = True                   # ... and post_ffn_norm + final_norm in one launch each way
 _POS_TABLES = True    # ConformerEncoder: the relative-position tables of all blocks in two batched launches (ops.relpos_tables)
+_LN16 = True          # ... the inner LayerNorms' outputs leave as the 16-bit tensor alone (ops.ResidualLnFn lp_only): 16-bit input gradients back
 _LN3 = True           # ... and the next block's macaron LayerNorm in the closing launches of the block below (ops.ResidualLn3Fn)
 _RES_LN = True     # ConformerEncoderBlock: residual adds fused into the LayerNorms that follow them
 
@@ -534,11 +535,11 @@ class ConformerEncoderBlock(nn.Module):
             link = ops.new_prenorm_link()
             a = self.pre_ffn(self._ln(self.macaron_ffn_norm, x, link), branch=True)
         n = self.mha_norm
-        x, h = ops.residual_layernorm(x, a, self.ffn_scale, p, n.weight, n.bias, n.eps, link)
+        x, h = ops.residual_layernorm(x, a, self.ffn_scale, p, n.weight, n.bias, n.eps, link, lp_only=_LN16)
         km = ops._mask_u8(mask, mask.shape[0], mask.shape[1]).unsqueeze(1)
         a = self.mha(h, km, pos)[0] if self.relative_positional else self.mha(h, km)[0]
         n = self.conv_norm
-        x, h = ops.residual_layernorm(x, a, 1.0, p, n.weight, n.bias, n.eps)
+        x, h = ops.residual_layernorm(x, a, 1.0, p, n.weight, n.bias, n.eps, lp_only=_LN16)
         am = ops._mask_u8(mask, mask.shape[0], mask.shape[1]).reshape(-1) if _MASK_FOLD else None
         a = self.conv(h, mask, mask_out=am is None)      # the padded frames' rows are zeroed by the residual launch below
         n, n2 = self.post_ffn_norm, self.final_norm

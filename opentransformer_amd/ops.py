@@ -1530,7 +1530,10 @@ class ResidualLnFn(torch.autograd.Function):
     post_ffn_norm, then final_norm; otr_add_layernorm2_fwd / _bwd)."""
 
     @staticmethod
-    def forward(ctx, x, a, scale, p_drop, gamma, beta, eps, link=None, gamma2=None, beta2=None, a_mask=None):
+    def forward(ctx, x, a, scale, p_drop, gamma, beta, eps, link=None, gamma2=None, beta2=None, a_mask=None, lp_only=False):
+        """lp_only (r06, 16-bit modes, one LayerNorm): the normalised rows leave as the 16-bit tensor ALONE and that tensor is the
+        differentiable output -- its only reader is a Linear (q|k|v, pointwise_conv1), whose input gradient then comes back 16-bit: the
+        input-gradient GEMM writes half the bytes and this launch's backward reads half (otr_ln_desc_t.dy_dtype)"""
         _cuda(x, a, gamma, beta)
         ctx.set_materialize_grads(False)
         ctx.a_mask = a_mask                # uint8 [M]: rows with 0 take no branch (module/conformer.py:109), forward and backward
@@ -1539,7 +1542,9 @@ class ResidualLnFn(torch.autograd.Function):
         x2 = x.reshape(-1, d).contiguous()
         a2 = a.reshape(-1, d).contiguous()
         M = x2.shape[0]
-        z, y = torch.empty_like(x2), torch.empty_like(x2)
+        lp_only = bool(lp_only and is_half() and gamma2 is None)
+        z = torch.empty_like(x2)
+        y = None if lp_only else torch.empty_like(x2)
         ylp = torch.empty(x2.shape, dtype=half_dtype(), device=x.device) if is_half() else None
         mean = torch.empty((M,), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
@@ -1559,6 +1564,8 @@ class ResidualLnFn(torch.autograd.Function):
             ctx.save_for_backward(z, mean, rstd, gamma, seed)
         ctx.g_ref, ctx.b_ref, ctx.g2_ref, ctx.b2_ref = gamma, beta, gamma2, beta2
         ctx.cfg = (M, d, a2.dtype, eps, p_drop, off, scale, x.shape, a.shape, two)
+        if lp_only:
+            return z.view(x.shape), ylp.view(x.shape), None
         if ylp is None:
             return z.view(x.shape), y.view(x.shape), None
         ylp = ylp.view(x.shape)
@@ -1568,21 +1575,23 @@ class ResidualLnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz, dy, _dylp=None):
         if dz is None and dy is None:
-            return (None,) * 11
+            return (None,) * 12
         M, d, adt, eps, p_drop, off, scale, xshape, ashape, two = ctx.cfg
         if two:
             z, mean, rstd, gamma, seed, beta, mean2, rstd2, gamma2 = ctx.saved_tensors
         else:
             z, mean, rstd, gamma, seed = ctx.saved_tensors
         dy2 = dy.reshape(-1, d).contiguous() if dy is not None else torch.zeros((M, d), dtype=torch.float32, device=z.device)
+        if dy2.dtype not in (torch.float32, half_dtype()) or (dy2.dtype != torch.float32 and two):
+            dy2 = dy2.float()
         skip = dz.reshape(-1, d).contiguous() if dz is not None else None
-        dx = torch.empty_like(dy2)
+        dx = torch.empty((M, d), dtype=torch.float32, device=z.device)
         da = torch.empty((M, d), dtype=adt, device=z.device)
         refs = (ctx.g_ref, ctx.b_ref) + ((ctx.g2_ref, ctx.b2_ref) if two else ())
         targets = [grad_target(r) for r in refs]
         inplace = all(t is not None for t in targets)
         lib = L.load()
-        desc = L.LnDesc(M, d, _code(adt), eps, p_drop, off, scale, ctx.a_mask.data_ptr() if ctx.a_mask is not None else None)
+        desc = L.LnDesc(M, d, _code(adt), eps, p_drop, off, scale, ctx.a_mask.data_ptr() if ctx.a_mask is not None else None, _code(dy2.dtype))
         ret = [None] * len(refs)
         if two:
             part = torch.empty((lib.otr_add_layernorm_bwd_partial_rows(M), 5 * d), dtype=torch.float32, device=z.device)
@@ -1619,7 +1628,7 @@ class ResidualLnFn(torch.autograd.Function):
             _park(ctx.link)
             dx_ret = None
         g2 = (ret[2], ret[3]) if two else (None, None)
-        return dx_ret, da.view(ashape), None, None, ret[0], ret[1], None, None, g2[0], g2[1], None
+        return dx_ret, da.view(ashape), None, None, ret[0], ret[1], None, None, g2[0], g2[1], None, None
 
 
 class ResidualLn3Fn(torch.autograd.Function):
@@ -1706,11 +1715,12 @@ def residual_layernorm3(x, a, scale, p_drop, n1, n2, n3, a_mask=None):
     return ResidualLn3Fn.apply(x, a, float(scale), float(p_drop), n1.weight, n1.bias, float(n1.eps), n2.weight, n2.bias, n3.weight, n3.bias, a_mask)
 
 
-def residual_layernorm(x, a, scale, p_drop, gamma, beta, eps=1e-5, link=None, gamma2=None, beta2=None, a_mask=None):
+def residual_layernorm(x, a, scale, p_drop, gamma, beta, eps=1e-5, link=None, gamma2=None, beta2=None, a_mask=None, lp_only=False):
     """(x + scale * dropout(a), LayerNorm of that sum [with its 16-bit twin]) in one launch: ResidualLnFn; with gamma2 / beta2 the
-    second value is LN2(LN1(sum)); a_mask (uint8, one per row): rows with 0 take no branch"""
-    z, y, ylp = ResidualLnFn.apply(x, a, float(scale), float(p_drop), gamma, beta, float(eps), link, gamma2, beta2, a_mask)
-    return z, attach_lp(y, ylp)
+    second value is LN2(LN1(sum)); a_mask (uint8, one per row): rows with 0 take no branch; lp_only: the second value is the 16-bit
+    tensor alone (its reader is a Linear)"""
+    z, y, ylp = ResidualLnFn.apply(x, a, float(scale), float(p_drop), gamma, beta, float(eps), link, gamma2, beta2, a_mask, lp_only)
+    return z, (attach_lp(y, ylp) if ylp is not None else y)
 
 
 def add_layernorm(x, a, gamma, beta, p_drop=0.0, eps=1e-5, a_bias=None, link=None):

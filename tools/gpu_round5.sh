@@ -32,8 +32,9 @@ d=json.loads(sys.stdin.read()); print(json.dumps({k:d.get(k) for k in ('value','
 decode)
   timeout 300 python bench.py --task decode --no-cpu-baseline > $OUT/decode.log 2>&1; grep '^{' $OUT/decode.log | tail -1 > $OUT/decode.json; cut -c1-300 $OUT/decode.json ;;
 ctrace)
-  bash tools/gpu_conformer_trace.sh ${TAG}_c > $OUT/ctrace_stdout.txt 2>&1; cp gpurun_out/${TAG}_c/conformer_kernels.txt gpurun_out/${TAG}_c/graph_gaps.txt $OUT/ 2>/dev/null
-  mv $OUT/graph_gaps.txt $OUT/conformer_step_sequence.txt 2>/dev/null; cp gpurun_out/${TAG}_c/bench_conformer.log $OUT/ 2>/dev/null; head -12 $OUT/conformer_kernels.txt | cut -c1-160 ;;
+  bash tools/gpu_conformer_trace.sh ${TAG}_c > $OUT/ctrace_stdout.txt 2>&1; cp gpurun_out/${TAG}_c/conformer_kernels.txt $OUT/ 2>/dev/null
+  # (r06: straight to its own name -- copied as graph_gaps.txt first it replaced the TRAIN step's sequence of the `trace` step of the same visit)
+  cp gpurun_out/${TAG}_c/graph_gaps.txt $OUT/conformer_step_sequence.txt 2>/dev/null; cp gpurun_out/${TAG}_c/bench_conformer.log $OUT/ 2>/dev/null; head -12 $OUT/conformer_kernels.txt | cut -c1-160 ;;
 dtrace)
   bash tools/gpu_decode_trace.sh ${TAG}_d > $OUT/dtrace_stdout.txt 2>&1; cp gpurun_out/${TAG}_d/decode_kernels.txt gpurun_out/${TAG}_d/decode.json $OUT/ 2>/dev/null; cut -c1-300 $OUT/decode.json; head -14 $OUT/decode_kernels.txt | cut -c1-160 ;;
 seqtests)
