@@ -254,8 +254,6 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(const float* k_score, c
                                                         int64_t* preds_out, int32_t* n_finished, const int32_t* pos_in,
                                                         int32_t* pos_out, const int32_t* anc_in, int32_t* anc_out,
                                                         int ld_anc, int32_t* arrive) {
-  __shared__ float cs[256];
-  __shared__ int ci[256];
   __shared__ float c0[256];
   __shared__ int win[MAXK];
   const int b = blockIdx.x, tid = threadIdx.x, nc = beam * beam;
@@ -268,31 +266,22 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(const float* k_score, c
     if (fin) ks = (br == 0) ? 0.f : NEG_INF;        // mask_finished_scores
     s = scores_in[hyp] + ks;
   }
-  // beam rounds of a block-wide arg-max over the candidates, one per thread (ties -> lower candidate index): a 6-step wave butterfly
-  // + one exchange of the four waves' winners per round (r05; it was an 8-level shared-memory tree: 22.9 us per decode step)
-  const int lane = tid & 63, wid = tid >> 6;
-  for (int r = 0; r < beam; ++r) {
-    float bs = s;
-    int bi = tid;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const float os = __shfl_xor(bs, off);
-      const int oi = __shfl_xor(bi, off);
-      if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+  // r06: selection by COUNTING (it was `beam` rounds of a block-wide arg-max, two barriers each: 12.8 us per decode step): every
+  // candidate's rank = the number of candidates that beat it (ties -> lower candidate index; keys are distinct), ranks 0 .. beam-1 are the
+  // winners in order.  A NaN score ranks as -inf (it never compares).
+  if (!(s == s)) s = NEG_INF;
+  c0[tid] = s;
+  __syncthreads();
+  if (tid < nc) {
+    int rank = 0;
+    for (int q = 0; q < nc; ++q) {
+      const float o = c0[q];
+      rank += (o > s || (o == s && q < tid)) ? 1 : 0;
     }
-    __syncthreads();                                // the previous round's readers are done with cs / ci
-    if (lane == 0) { cs[wid] = bs; ci[wid] = bi; }
-    __syncthreads();
-    float wsc = cs[0];
-    int wi = ci[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w)
-      if (cs[w] > wsc || (cs[w] == wsc && ci[w] < wi)) { wsc = cs[w]; wi = ci[w]; }
-    if (tid == 0) {
-      win[r] = wi;
-      scores_out[b * beam + r] = wsc;
+    if (rank < beam) {
+      win[rank] = tid;
+      scores_out[b * beam + rank] = s;
     }
-    if (tid == wi) s = NEG_INF;                     // remove the winner (NaN-free: -inf stays -inf)
   }
   __syncthreads();
   // gather prefixes (+ re-parent the KV-cache ancestor table, decode.hip): every (output hypothesis, position) pair at once -- one
