@@ -316,12 +316,13 @@ int32_t otr_attention_bwd(const otr_attn_desc_t* d, const void* q, const void* k
  * bias[b*bias_bs + h*bias_hs + i*bias_rs + col], col = j, or col = j - i + Tq - 1 when rel_shift != 0: the
  * Transformer-XL relative-position term of MultiHeadedSelfAttentionWithRelPos (module/attention.py:196-253; the
  * reference materialises [B,h,T,2T-1] and gathers it at :209-215).  dbias (same addressing, caller pre-zeroed when
- * rel_shift) receives d loss / d bias. */
+ * rel_shift) receives d loss / d bias, in f32 or (r06, dbias_dtype) in the library's 16-bit type: the band tensor of one Conformer block is
+ * 64 MB in f32, written once and read by two GEMMs. */
 int32_t otr_attention_bias_fwd(const otr_attn_desc_t* d, const void* q, const void* k, const void* v,
                                const uint8_t* key_mask, const float* bias, int64_t bias_bs, int64_t bias_hs,
                                int64_t bias_rs, int32_t rel_shift, void* o, float* lse, void* stream);
 int32_t otr_attention_bias_bwd(const otr_attn_desc_t* d, const void* q, const void* k, const void* v,
-                               const uint8_t* key_mask, const float* bias, float* dbias, int64_t bias_bs,
+                               const uint8_t* key_mask, const float* bias, void* dbias, int32_t dbias_dtype, int64_t bias_bs,
                                int64_t bias_hs, int64_t bias_rs, int32_t rel_shift, const void* o, const void* do_,
                                const float* lse, float* delta, void* dq, void* dk, void* dv, void* stream);
 

@@ -114,7 +114,7 @@ SIGNATURES = {
     'otr_attention_fwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P],
     'otr_attention_bwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_attention_bias_fwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P],
-    'otr_attention_bias_bwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
+    'otr_attention_bias_bwd': [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P, _I32, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_add_layernorm_fwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_add_layernorm_bwd': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'otr_add_layernorm_bwd_skip': [C.POINTER(LnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -34,7 +34,7 @@ struct AttnArgs {
   // rel_shift turns a [.., i, 2T-1] relative-position term into the Transformer-XL shifted matrix by index
   // arithmetic (module/attention.py:209-215 materialises and gathers it).
   const float* bias;
-  float* dbias;
+  float* dbias; int dbias_h16;     // dbias_h16: the gradient tensor is 16-bit (r06: half the bytes of a 64 MB band tensor written once and read twice)
   int64_t bias_bs, bias_hs, bias_rs;
   int rel_shift;
 };
@@ -590,7 +590,11 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnArgs& p, const int 
         ds[qt][r] = dsv;
         // unique (i, col): plain store.  EVERY in-range (query, key) pair is written, masked ones with 0: a caller that keeps the
         // gradient tensor across steps (ops.RelPosAttentionFn: zeroed once, not per step) never finds a stale entry in the band
-        if (p.dbias && key < p.Tk && qg < p.Tq) p.dbias[bias_index(p, b, h, qg, key)] = ok ? dsv : 0.f;
+        if (p.dbias && key < p.Tk && qg < p.Tq) {
+          const float gv = ok ? dsv : 0.f;
+          if (p.dbias_h16) reinterpret_cast<bf16_t*>(p.dbias)[bias_index(p, b, h, qg, key)] = f2bf(gv);
+          else p.dbias[bias_index(p, b, h, qg, key)] = gv;
+        }
       }
     }
 #pragma unroll
@@ -866,17 +870,19 @@ extern "C" int32_t otr_attention_bias_fwd(const otr_attn_desc_t* d, const void* 
 static int32_t attention_bwd_impl(const otr_attn_desc_t* d, AttnArgs& a, void* stream);
 
 extern "C" int32_t otr_attention_bias_bwd(const otr_attn_desc_t* d, const void* q, const void* k, const void* v,
-                                          const uint8_t* key_mask, const float* bias, float* dbias, int64_t bias_bs,
+                                          const uint8_t* key_mask, const float* bias, void* dbias, int32_t dbias_dtype, int64_t bias_bs,
                                           int64_t bias_hs, int64_t bias_rs, int32_t rel_shift, const void* o,
                                           const void* do_, const float* lse, float* delta, void* dq, void* dk, void* dv,
                                           void* stream) {
   AttnArgs a{};
   if (int32_t e = fill_args(d, a)) return e;
   OTR_REQUIRE(q && k && v && o && do_ && lse && delta && dq && dk && dv && bias, "attention_bias_bwd: null pointer");
+  OTR_REQUIRE(dbias_dtype == OTR_F32 || dbias_dtype == OTR_H16, "attention_bias_bwd: bad dbias dtype %d", dbias_dtype);
+  a.dbias_h16 = dbias_dtype == OTR_H16;
   a.q = q; a.k = k; a.v = v; a.o = o; a.do_ = do_; a.lse = const_cast<float*>(lse); a.delta = delta;
   a.dq = dq; a.dk = dk; a.dv = dv; a.key_mask = key_mask;
   a.vec = vec_ok(d, {q, k, v, o, do_, dq, dk, dv});
-  set_bias(a, bias, dbias, bias_bs, bias_hs, bias_rs, rel_shift);
+  set_bias(a, bias, reinterpret_cast<float*>(dbias), bias_bs, bias_hs, bias_rs, rel_shift);
   return attention_bwd_impl(d, a, stream);
 }
 

@@ -2984,7 +2984,10 @@ def _dp_from_pool(Pp, d, device):
 _DBD_PERSIST = True        # tests flip it to compare with a fresh tensor per backward pass
 
 
-def _persistent_dbd(owner, like):
+_DBD16 = True              # RelPosAttentionFn: the score term's gradient tensor in the 16-bit type (16-bit modes)
+
+
+def _persistent_dbd(owner, like, dtype=None):
     """The gradient tensor of the relative-position score term, [B, T, H, Pp] fp32 (64 MB per Conformer block at the bench batch).  Only its
     band (column j - i + T - 1 of row i) is ever non-zero, and the attention backward rewrites EVERY in-range band entry (masked pairs
     with 0), so the tensor is zeroed ONCE per (layer, shape) and kept: the per-step zero fill was 10.5 us x 12 blocks.
@@ -2992,16 +2995,17 @@ def _persistent_dbd(owner, like):
     ragged batch with a new T replaces it: no stale 64 MB buffers pinned per layer); and a second request for the same layer inside
     ONE backward pass (a weight-shared layer applied twice: the deferred dp products of the first application still read the
     buffer at flush time) gets a fresh tensor instead of the shared one."""
+    dtype = dtype or like.dtype
     if not _DBD_PERSIST:
-        return torch.zeros_like(like)
+        return torch.zeros_like(like, dtype=dtype)
     task = torch._C._current_graph_task_id()
     st = getattr(owner, '_otr_dbd', None)
-    if st is not None and st['buf'].shape == like.shape and st['buf'].device == like.device and st['buf'].dtype == like.dtype:
+    if st is not None and st['buf'].shape == like.shape and st['buf'].device == like.device and st['buf'].dtype == dtype:
         if task != -1 and st['task'] == task:
-            return torch.zeros_like(like)
+            return torch.zeros_like(like, dtype=dtype)
         st['task'] = task
         return st['buf']
-    buf = torch.zeros_like(like)
+    buf = torch.zeros_like(like, dtype=dtype)
     owner._otr_dbd = {'buf': buf, 'task': task}
     return buf
 
@@ -3100,12 +3104,14 @@ class RelPosAttentionFn(torch.autograd.Function):
         adt = qkv.dtype
         lib = L.load()
         dout = dout.contiguous()
-        dbd = _persistent_dbd(pos_w, bd)
+        # r06: the score term's gradient travels 16-bit in the 16-bit modes (it is written once by the attention backward and read by two
+        # GEMMs: 64 MB per block in fp32); the forward tensor bd stays fp32 (it is part of the logits' arithmetic)
+        dbd = _persistent_dbd(pos_w, bd, half_dtype() if (_DBD16 and adt == half_dtype()) else torch.float32)
         dquv = torch.empty_like(quv)
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
         desc = _attn_desc(B, H, T, T, dk, adt, (T * 2 * d, 2 * d), (T * d3, d3), (T * d3, d3), (T * d, d), False)
-        L.check(lib.otr_attention_bias_bwd(C.byref(desc), _p(quv), _p(qkv, d), _p(qkv, 2 * d), _p(km), _p(bd), _p(dbd),
+        L.check(lib.otr_attention_bias_bwd(C.byref(desc), _p(quv), _p(qkv, d), _p(qkv, 2 * d), _p(km), _p(bd), _p(dbd), _code(dbd.dtype),
                                            T * H * Pp, Pp, H * Pp, 1, _p(out), _p(dout), _p(lse), _p(delta), _p(dquv),
                                            _p(dqkv, d), _p(dqkv, 2 * d), _stream()), 'otr_attention_bias_bwd')
         # d(q+v)_h = dbd_h . p_h  as forward-type GEMMs on the transposed p (contraction over the padded axis), the four heads in one launch
