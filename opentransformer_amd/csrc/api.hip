@@ -39,6 +39,7 @@ void otr_zero_f32(float* p, int64_t n, hipStream_t s) {
 int g_otr_force_tile = 0;
 int g_otr_force_ksplit = 0;
 int g_otr_gemm_xcd_map = 1;        // gemm_kernel.h gemm_tile_of (otr_debug_set(26, 0) = natural tile order)
+int g_otr_bias_vec4 = 1;           // attention.hip: relative-position score bias as 16-byte loads where the rows allow (otr_debug_set(27, 0) = scalar)
 int g_otr_force_generic = 0;
 int g_otr_no_persist = 0;
 int g_otr_ffn2_ablate = 0;   // tuning hook (otr_debug_set(4, v)): bit 0 = no weight DMA after the first chunk, bit 1 = no MFMA work
@@ -68,6 +69,7 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   if (key == 0) g_otr_force_tile = value;
   else if (key == 1) g_otr_force_ksplit = value;
   else if (key == 26) g_otr_gemm_xcd_map = value;
+  else if (key == 27) g_otr_bias_vec4 = value;
   else if (key == 2) g_otr_force_generic = value;
   else if (key == 3) g_otr_no_persist = value;
   else if (key == 4) g_otr_ffn2_ablate = value;

@@ -34,6 +34,7 @@ struct AttnArgs {
   // rel_shift turns a [.., i, 2T-1] relative-position term into the Transformer-XL shifted matrix by index
   // arithmetic (module/attention.py:209-215 materialises and gathers it).
   const float* bias;
+  int bias_vec4;                     // rel_shift: the rows are long enough for unclamped 16-byte loads (set_bias)
   float* dbias; int dbias_h16;     // dbias_h16: the gradient tensor is 16-bit (r06: half the bytes of a 64 MB band tensor written once and read twice)
   int64_t bias_bs, bias_hs, bias_rs;
   int rel_shift;
@@ -41,6 +42,15 @@ struct AttnArgs {
 
 __device__ __forceinline__ int64_t bias_index(const AttnArgs& p, int b, int h, int i, int j) {
   return (int64_t)b * p.bias_bs + (int64_t)h * p.bias_hs + (int64_t)i * p.bias_rs + j + (p.rel_shift ? (p.Tq - 1 - i) : 0);
+}
+// four consecutive columns of one bias row as ONE 16-byte load at 4-byte alignment (the relative-position column j - i + T - 1 is aligned for
+// no row in particular; global_load_dwordx4 only needs dword alignment).  The lane's four keys lg*4 .. + 3 of a 16-key tile are consecutive
+// columns; past the last key the load runs on into the row's padding / the next row of the SAME tensor (never past its end: the last row's
+// columns end before the padding does) and the values are masked at use.  r06: 16 -> 4 loads per lane and key block.
+typedef float otr_f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void bias_load4(const float* row, int col, float (&o)[4]) {
+  const otr_f32x4_a4 v = *reinterpret_cast<const otr_f32x4_a4*>(row + col);
+  o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
 }
 
 // Which (block of queries / keys, head, utterance) a workgroup works on.  xmap = 0: the 3-D grid as launched.  xmap = 1: a 1-D grid
@@ -353,10 +363,15 @@ template <class CT, int DK, bool PIPE, int NW = 4> __global__ __launch_bounds__(
     if (p.bias) {
       const int qc = min(qrow, p.Tq - 1);
       const float* brow = p.bias + bias_index(p, b, h, qc, 0);
+      if (p.rel_shift && p.bias_vec4) {
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt) bias_load4(brow, kb * 64 + kt * 16 + lg * 4, bv[kt]);
+      } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[kt][r] = brow[min(kb * 64 + kt * 16 + lg * 4 + r, p.Tk - 1)];
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[kt][r] = brow[min(kb * 64 + kt * 16 + lg * 4 + r, p.Tk - 1)];
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     f32x4 st[4];
@@ -718,10 +733,15 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int bx
     float bv[4][4];      // score bias of the block, loaded ahead of the MFMAs (see attn_fwd_kernel)
     if (p.bias) {
       const float* brow = p.bias + bias_index(p, b, h, min(qrow, p.Tq - 1), 0);
+      if (p.rel_shift && p.bias_vec4) {
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt) bias_load4(brow, kb * 64 + kt * 16 + lg * 4, bv[kt]);
+      } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[kt][r] = brow[min(kb * 64 + kt * 16 + lg * 4 + r, p.Tk - 1)];
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[kt][r] = brow[min(kb * 64 + kt * 16 + lg * 4 + r, p.Tk - 1)];
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     f32x4 ds[4];  // tiles over keys (rows), cols = queries
@@ -843,8 +863,22 @@ extern "C" int32_t otr_attention_fwd(const otr_attn_desc_t* d, const void* q, co
   return otr_check_launch("attention_fwd");
 }
 
+extern int g_otr_bias_vec4;
 static void set_bias(AttnArgs& a, const float* bias, float* dbias, int64_t bs, int64_t hs, int64_t rs, int rel_shift) {
   a.bias = bias; a.dbias = dbias; a.bias_bs = bs; a.bias_hs = hs; a.bias_rs = rs; a.rel_shift = rel_shift;
+  // 16-byte loads run up to key 64 ceil(Tk / 64) - 1 of every row: allowed when that stays inside what the strides say is there
+  // (every row of a relative-position tensor has its 2T - 1 columns; the address is linear in h and i, so the corners decide)
+  a.bias_vec4 = 0;
+  if (rel_shift && g_otr_bias_vec4 && bs >= 0 && hs >= 0 && rs >= 0) {
+    const int64_t T = a.Tq, k64 = ((int64_t)a.Tk + 63) / 64 * 64, H = a.H;
+    int64_t extent = 0, reach = 0;
+    for (int64_t h : {(int64_t)0, H - 1})
+      for (int64_t i : {(int64_t)0, T - 1}) {
+        extent = std::max(extent, h * hs + i * rs + 2 * T - 1);
+        reach = std::max(reach, h * hs + i * rs + (k64 - 1) + (T - 1 - i) + 1);
+      }
+    a.bias_vec4 = reach <= extent;
+  }
 }
 
 extern "C" int32_t otr_attention_bias_fwd(const otr_attn_desc_t* d, const void* q, const void* k, const void* v,
