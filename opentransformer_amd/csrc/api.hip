@@ -40,6 +40,8 @@ int g_otr_force_tile = 0;
 int g_otr_force_ksplit = 0;
 int g_otr_gemm_xcd_map = 1;        // gemm_kernel.h gemm_tile_of (otr_debug_set(26, 0) = natural tile order)
 int g_otr_bias_vec4 = 1;           // attention.hip: relative-position score bias as 16-byte loads where the rows allow (otr_debug_set(27, 0) = scalar)
+int g_otr_gemm_resident64 = 1024;   // gemm_kernel.h: resident workgroups of the persistent 64 x 64-tile GEMM (otr_debug_set(28, v); 512 = r05)
+int g_otr_conv2_wgrad256 = 1;       // conv2 weight gradient of a C1 % 256 == 0 frontend on wgrad256.hip's gather form (otr_debug_set(29, 0) = the transposing GEMM)
 int g_otr_force_generic = 0;
 int g_otr_no_persist = 0;
 int g_otr_ffn2_ablate = 0;   // tuning hook (otr_debug_set(4, v)): bit 0 = no weight DMA after the first chunk, bit 1 = no MFMA work
@@ -70,6 +72,8 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   else if (key == 1) g_otr_force_ksplit = value;
   else if (key == 26) g_otr_gemm_xcd_map = value;
   else if (key == 27) g_otr_bias_vec4 = value;
+  else if (key == 29) g_otr_conv2_wgrad256 = value;
+  else if (key == 28) g_otr_gemm_resident64 = value > 0 ? value : 512;
   else if (key == 2) g_otr_force_generic = value;
   else if (key == 3) g_otr_no_persist = value;
   else if (key == 4) g_otr_ffn2_ablate = value;
@@ -452,6 +456,13 @@ extern "C" int32_t otr_conv2_wgrad(const otr_conv_desc_t* d, const void* dact2, 
   GemmArgs a{};
   if (int32_t e = conv_geom(d, a.cg)) return e;
   OTR_REQUIRE(dact2 && act1 && dw2r, "conv2_wgrad: null pointer");
+  if (g_otr_conv2_wgrad256 && d->act_dtype == OTR_H16 && d->compute == OTR_H16) {
+    // wide frontends (C1 a multiple of 256: the Conformer's 256 -> 256): the 256 x 256-tile kernel with gathered x rows (wgrad256.hip);
+    // the transposing GEMM below ran this 178 GFLOP problem in 631 us
+    const int32_t rc = wgrad256_conv_launch(dact2, act1, dw2r, d->B, d->T1, d->F1, d->T2, d->F2, d->C1, d->C2, workspace, workspace_bytes,
+                                            (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
   a.A = dact2; a.B = act1; a.C = dw2r; a.bias = nullptr;  // dw2r[C2, 9*C1] = dact2^T * im2col(act1)
   a.M = d->C2; a.N = 9 * d->C1; a.K = d->B * d->T2 * d->F2;
   a.lda = d->C2; a.ldb = 0; a.ldc = 9 * d->C1;

@@ -1054,6 +1054,7 @@ extern int g_otr_force_tile;    // 0 = heuristic, 64 / 128 = forced (tuning hook
 extern int g_otr_force_ksplit;  // 0 = heuristic, n = forced                  (otr_debug_set(1, v))
 extern int g_otr_force_generic; // 1 = never use the branch-free FAST loaders  (otr_debug_set(2, v))
 extern int g_otr_no_persist;    // 1 = one workgroup per tile even without split-K (otr_debug_set(3, v))
+extern int g_otr_gemm_resident64;      // api.hip (otr_debug_set(28, v))
 constexpr int OTR_RESIDENT_WG = 512;   // 256 CUs x 2 workgroups (launch_bounds(256, 2), 64 KB LDS each)
 
 template <class CT, class AT, class BT, class OT, int AMODE, int BMODE>
@@ -1143,7 +1144,10 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
   //  keep one workgroup per tile)
   constexpr bool CAN_PERSIST = (AMODE == MODE_KC && BMODE == MODE_KC);
   const bool persist = CAN_PERSIST && fast && a.ksplit == 1 && g_otr_no_persist == 0;
-  const dim3 grid((unsigned)(persist && ntiles > OTR_RESIDENT_WG ? OTR_RESIDENT_WG : ntiles), a.ksplit);
+  // (64-wide tiles: 106 VGPRs and 32 KB of LDS -- FOUR workgroups fit a CU, so up to g_otr_gemm_resident64 = 1024 of them are resident:
+  //  the Conformer's 7968 x 384 outputs are 750 tiles, which 512 workgroups walked as two rounds with the second one half empty)
+  const int64_t resident = big ? OTR_RESIDENT_WG : g_otr_gemm_resident64;
+  const dim3 grid((unsigned)(persist && ntiles > resident ? resident : ntiles), a.ksplit);
   if (a.act == OTR_ACT_GLU_FWD || a.act == OTR_ACT_GLU_BWD) {   // fused FFN epilogues: own (non-persistent) instantiations
     if constexpr (CAN_PERSIST && std::is_same<CT, bf16_t>::value && std::is_same<AT, bf16_t>::value &&
                   std::is_same<BT, bf16_t>::value && std::is_same<OT, bf16_t>::value) {

@@ -114,11 +114,24 @@ struct Stager {                 // this lane's share of the two DMA instructions
   bool col_a, col_b;            // this lane's 8 columns exist (ragged last tile of N / K)
   const unsigned char* zeros;
   uint32_t dst;                 // wave's byte offset inside a slab's dy part (the x part is + 8192)
+  // CONV (W256Args mode 2): base_b = act1 + this lane's 16 bytes of the tile's channels; the row comes from the output pixel
+  int cT1, cF1, cT2, cF2, kh, kw;
+  int64_t pix_bytes;            // C1 * 2
+  FastDiv divF2, divT2;
   // NTA / NTB: the operand strip is read by this tile only -> non-temporal, it stays out of the L2 the shared strips live in
-  template <bool NTA, bool NTB, bool SKIPB = false> __device__ __forceinline__ void issue(int slab, int slot) {
+  template <bool NTA, bool NTB, bool SKIPB = false, bool CONV = false> __device__ __forceinline__ void issue(int slab, int slot) {
     const bool ok = slab * SLAB_ROWS + row0 < M;
     const unsigned char* pa = ok && col_a ? base_a + slab * step_a : zeros;
-    const unsigned char* pb = ok && col_b ? base_b + slab * step_b : zeros;
+    const unsigned char* pb;
+    if constexpr (CONV) {
+      const uint32_t m = (uint32_t)(slab * SLAB_ROWS + row0);
+      const uint32_t t = fdiv(m, divF2), f2 = m - t * (uint32_t)cF2, b = fdiv(t, divT2), t2 = t - b * (uint32_t)cT2;
+      const int fin = 2 * (int)f2 + kw - 1;
+      const bool in = ok && col_b && fin >= 0 && fin < cF1;
+      pb = in ? base_b + (((int64_t)b * cT1 + 2 * (int)t2 + kh) * cF1 + fin) * pix_bytes : zeros;
+    } else {
+      pb = ok && col_b ? base_b + slab * step_b : zeros;
+    }
     if constexpr (NTA) dma16_nt(pa, (uint32_t)(slot * SLAB_BYTES) + dst); else dma16(pa, (uint32_t)(slot * SLAB_BYTES) + dst);
     if constexpr (SKIPB) dma16(zeros, (uint32_t)(slot * SLAB_BYTES) + 8192u + dst);        // ablation 6: the x part is not fetched (one line, L1-hot)
     else if constexpr (NTB) dma16_nt(pb, (uint32_t)(slot * SLAB_BYTES) + 8192u + dst);
@@ -131,13 +144,13 @@ struct Stager {                 // this lane's share of the two DMA instructions
 // Per slab and wave: 8 MFMAs of the current fragments with the two DMA instructions of slab i+6 and the 12 reads of slab
 // i+1 spread between them, then the counted wait that retires slab i+2 and the barrier that publishes it.  Two slabs per
 // trip (static register sets); the steady-state trips carry no conditionals.
-template <bool NTA, bool NTB, int ABL, bool BIAS>
+template <bool NTA, bool NTB, int ABL, bool BIAS, bool CONV = false>
 __device__ __forceinline__ void stream_piece(Stager& sg, f32x16 (&acc)[4][2], float (&cs)[4], int wc, int sb, int P, int rot,
                                              uint32_t a_off, uint32_t b_off) {
   constexpr bool no_mma = (ABL & 1) && ABL != 6, no_dma = (ABL & 2) && ABL != 6;
   int stage = rot;                                     // next slab to stage, relative to sb, walks rot .. P-1, 0 .. rot-1
   auto issue_next = [&](int slot) {
-    sg.issue<NTA, NTB, ABL == 6>(sb + stage, slot);
+    sg.issue<NTA, NTB, ABL == 6, CONV>(sb + stage, slot);
     stage = stage + 1 == P ? 0 : stage + 1;
   };
   // ---- prologue: slabs 0 .. AHEAD-1 in flight, slabs 0 and 1 landed, fragments of slab 0 in registers
@@ -278,7 +291,7 @@ __global__ void wgrad256_init_kernel(int* flags, int n, uint32_t* zeros) {
   if (threadIdx.x < 16) zeros[threadIdx.x] = 0u;
 }
 
-template <int ABL>
+template <int ABL, bool CONV = false>
 __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
   // NEXT chunk, i.e. (except at the 7 group seams) of a LOWER block index, which the dispatcher starts no later than
   // this one; every spin is bounded in any case.
   const int G = (int)gridDim.x, gx = G >> 3, bid = (int)blockIdx.x;
-  const bool rounds = g.mode == 1;
+  const bool rounds = g.mode >= 1;
   const int slot = (G & 7) == 0 ? (bid & 7) * gx + (rounds ? (bid >> 3) : gx - 1 - (bid >> 3)) : (rounds ? bid : G - 1 - bid);
   // stream-K: this workgroup's chunk of the (tile, slab) space
   int pos = slot * g.chunk;
@@ -313,7 +326,17 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
   for (;;) {
     // ---- next piece: slabs [sb, sb + P) of tile `tile` of problem pi; `slice` of `nslices` pieces of that tile
     int pi = 0, tile, sb, P, rot = 0, slice = 0, nslices = 1;
-    if (rounds) {
+    if constexpr (CONV) {
+      // one round: slot = part * tiles + tile -- the tiles (taps) of one row range are neighbours on one XCD, where they share the
+      // dy rows and most of the act1 rows (the nine taps of an output pixel overlap)
+      if (round > 0 || slot >= g.rem_tiles * g.parts) break;
+      ++round;
+      const int R = g.chunk, part = slot / g.rem_tiles;
+      tile = slot - part * g.rem_tiles;
+      sb = (int)((int64_t)R * part / g.parts);
+      P = (int)((int64_t)R * (part + 1) / g.parts) - sb;
+      slice = part; nslices = g.parts;
+    } else if (rounds) {
       // every tile is R slabs long.  Rounds 0 .. nfull-1: slot s walks the whole tile round*G + s; last round: the remaining
       // tiles cut into `parts` row ranges each, the parts of a tile in neighbouring slots
       const int R = g.chunk;
@@ -360,6 +383,13 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
     sg.base_b = reinterpret_cast<const unsigned char*>(pr.x + (int64_t)st_row * pr.ldx + k0 + st_col);
     sg.step_a = (int64_t)pr.ldy * SLAB_ROWS * 2; sg.step_b = (int64_t)pr.ldx * SLAB_ROWS * 2;
     sg.dst = smem0 + (uint32_t)wid * 1024u;
+    if constexpr (CONV) {
+      const int tap = k0 / g.cC1, ch0 = k0 - tap * g.cC1;
+      sg.kh = tap / 3; sg.kw = tap - 3 * sg.kh;
+      sg.cT1 = g.cT1; sg.cF1 = g.cF1; sg.cT2 = g.cT2; sg.cF2 = g.cF2; sg.divF2 = g.cdivF2; sg.divT2 = g.cdivT2;
+      sg.pix_bytes = (int64_t)g.cC1 * 2;
+      sg.base_b = reinterpret_cast<const unsigned char*>(pr.x + ch0 + st_col);
+    }
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -381,7 +411,8 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
     if (bias) stream_piece<A, B, ABL, true>(sg, acc, cs, wc, sb, P, rot, a_off, b_off);                     \
     else stream_piece<A, B, ABL, false>(sg, acc, cs, wc, sb, P, rot, a_off, b_off);                          \
   }
-    if (nt_a && nt_b) W256_RUN(true, true)
+    if constexpr (CONV) stream_piece<false, false, ABL, false, true>(sg, acc, cs, wc, sb, P, rot, a_off, b_off);
+    else if (nt_a && nt_b) W256_RUN(true, true)
     else if (nt_a) W256_RUN(true, false)
     else if (nt_b) W256_RUN(false, true)
     else W256_RUN(false, false)
@@ -406,7 +437,10 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(W256Args g) {
     float* dw = pr.dw;
     const int n_base = n0 + 128 * wr, k_base = k0 + 64 * wc;
     unsigned char* scr = smem + wid * 16384;
-    if constexpr ((ABL & 4) != 0 && ABL != 6) {
+    if constexpr (CONV) {
+      // this row range's partial tile: stored (nobody else writes slab `slice`), summed by w256_reduce_kernel
+      flush_tile<false, true>(acc, g.split_ws + (int64_t)slice * pr.N * pr.ldw, pr.ldw, pr.N, pr.K, n_base, k_base, scr, lane);
+    } else if constexpr ((ABL & 4) != 0 && ABL != 6) {
     } else if (nslices == 1) {
       if (pr.flag0 & (1 << 30)) flush_tile<false, true>(acc, dw, pr.ldw, pr.N, pr.K, n_base, k_base, scr, lane);
       else flush_tile<false>(acc, dw, pr.ldw, pr.N, pr.K, n_base, k_base, scr, lane);
@@ -524,6 +558,50 @@ int32_t wgrad256_launch(const W256Item* it, int n, void* workspace, int64_t work
     default: hipLaunchKernelGGL(wgrad256_kernel<7>, dim3((unsigned)grid), dim3(512), 0, s, g); break;
   }
   return otr_check_launch("wgrad256");
+}
+
+// dw[i] = sum over the row ranges, in order (deterministic), float4 per thread
+__global__ __launch_bounds__(256) void w256_reduce_kernel(const float* __restrict__ ws, int nslab, int64_t elems, float* __restrict__ dw) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= elems) return;
+  float4 a = *reinterpret_cast<const float4*>(ws + i);
+  for (int s = 1; s < nslab; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(ws + (int64_t)s * elems + i);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  *reinterpret_cast<float4*>(dw + i) = a;
+}
+
+int32_t wgrad256_conv_launch(const void* g2, const void* act1, float* dw2r, int B, int T1, int F1, int T2, int F2, int C1, int C2,
+                             void* workspace, int64_t workspace_bytes, hipStream_t s) {
+  const int64_t M = (int64_t)B * T2 * F2, K = 9ll * C1, elems = (int64_t)C2 * K;
+  if (C1 % 256 != 0 || C2 % 8 != 0 || M < 16 * 2 * RING || M >= (1ll << 31) - 16) return 1;
+  if (((uintptr_t)g2 | (uintptr_t)act1 | (uintptr_t)dw2r) % 16 != 0 || !workspace) return 1;
+  const int tiles = ((C2 + 255) / 256) * (int)(K / 256);
+  if (tiles > 256) return 1;
+  // the row ranges: as many as fill one workgroup per CU, and as the workspace holds partial matrices of
+  const int64_t head = 256;                                   // the zero line (64 bytes) and alignment
+  int parts = 256 / tiles;
+  const int64_t fit = (workspace_bytes - head) / (elems * 4);
+  if (fit < parts) parts = (int)fit;
+  const int R = (int)((M + SLAB_ROWS - 1) / SLAB_ROWS);
+  if (parts > R / (2 * RING)) parts = R / (2 * RING);           // a row range is at least two turns of the ring long
+  if (parts < 1) return 1;
+  W256Args g{};
+  W256Prob& p = g.p[0];
+  p.dy = reinterpret_cast<const uint16_t*>(g2); p.x = reinterpret_cast<const uint16_t*>(act1); p.dw = dw2r; p.dbias = nullptr;
+  p.M = (int)M; p.N = C2; p.K = (int)K; p.ldy = C2; p.ldx = C1; p.ldw = (int)K; p.start = 0; p.flag0 = 0;
+  g.nprob = 1; g.total = tiles * R; g.chunk = R; g.mode = 2; g.nfull = 0; g.rem_tiles = tiles; g.parts = parts;
+  g.spin_limit = g_otr_spin_limit; g.fault = g_otr_fault; g.ablate = 0; g.policy = 1;
+  g.cT1 = T1; g.cF1 = F1; g.cT2 = T2; g.cF2 = F2; g.cC1 = C1; g.cdivF2 = make_fastdiv((uint32_t)F2); g.cdivT2 = make_fastdiv((uint32_t)T2);
+  g.zeros = workspace; g.flags = nullptr;
+  g.split_ws = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + head);
+  hipLaunchKernelGGL(wgrad256_init_kernel, dim3(1), dim3(256), 0, s, nullptr, 0, reinterpret_cast<uint32_t*>(workspace));   // the zero line
+  const int grid = (tiles * parts + 7) / 8 * 8;               // whole XCD groups (the slot <-> block map); the extra ones leave at once
+  hipLaunchKernelGGL((wgrad256_kernel<0, true>), dim3((unsigned)grid), dim3(512), 0, s, g);
+  if (int32_t e = otr_check_launch("wgrad256(conv)")) return e;
+  hipLaunchKernelGGL(w256_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)), dim3(256), 0, s, g.split_ws, parts, elems, dw2r);
+  return otr_check_launch("wgrad256(conv reduce)");
 }
 
 int64_t wgrad256_workspace_bytes(const W256Item* it, int n) {

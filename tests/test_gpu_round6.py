@@ -367,3 +367,46 @@ def test_conformer_chain_of_three_layernorms_across_blocks(mode):
     finally:
         onn._LN3 = True
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
+@pytest.mark.parametrize('B,T,Fdim,C1,C2', [(4, 200, 80, 256, 256), (2, 131, 40, 256, 136), (1, 77, 80, 512, 256)])
+def test_conv2_wgrad_gather_form(mode, B, T, Fdim, C1, C2):
+    """otr_conv2_wgrad for C1 % 256 == 0 (the Conformer's 256 -> 256 frontend, frontend/conv.py:50-83): wgrad256.hip with gathered x rows
+    and a fixed-order sum of the row ranges == the transposing GEMM it replaces (same 16-bit operands, fp32 sums: 1e-5) == torch's
+    conv2d weight gradient on the same rounded operands.  Ragged pixel counts (rows past M read the zero line), the padded
+    frequency taps, a ragged last channel tile (C2 = 136) and two k-tiles per tap (C1 = 512)."""
+    from opentransformer_amd import ops, _lib as L
+    import torch.nn.functional as F
+    ops.set_compute_dtype(mode)
+    try:
+        lib = L.load()
+        adt = ops.act_dtype()
+        T1, F1, T2, F2 = ops.conv_geometry(T, Fdim)
+        g = torch.Generator(device='cpu').manual_seed(5)
+        act1 = torch.randn(B, T1, F1, C1, generator=g).relu_().to(DEV).to(adt)
+        g2 = (torch.randn(B, T2, F2, C2, generator=g) * (torch.rand(B, T2, F2, C2, generator=g) > 0.5)).to(DEV).to(adt)
+        desc = L.ConvDesc(B, T, Fdim, C1, C2, T1, F1, T2, F2, ops._code(adt), ops._compute_code(), ops._code(adt))
+        ws = ops._workspace(act1.device)
+        out = {}
+        for form in (1, 0):
+            L.check(lib.otr_debug_set(29, form), 'debug_set')
+            dw = torch.full((C2, 3, 3, C1), float('nan'), device=DEV)
+            names = []
+            ops.set_kernel_timer(names)
+            try:
+                L.check(lib.otr_conv2_wgrad(C.byref(desc), ops._p(g2), ops._p(act1), ops._p(dw), ops._p(ws), ops._WS_BYTES, ops._stream()), 'otr_conv2_wgrad')
+            finally:
+                ops.set_kernel_timer(None)
+            torch.cuda.synchronize()
+            out[form] = dw
+        assert torch.isfinite(out[1]).all()
+        assert rel(out[1], out[0]) < 1e-5, rel(out[1], out[0])
+        # torch: d/dw of conv2d(act1 NCHW, w, stride 2, pad (0, 1)) against g2
+        w = torch.zeros(C2, C1, 3, 3, device=DEV, requires_grad=True)
+        y = F.conv2d(act1.float().permute(0, 3, 1, 2), w, None, stride=2, padding=(0, 1))
+        (dwr,) = torch.autograd.grad(y, w, g2.float().permute(0, 3, 1, 2))
+        assert rel(out[1], dwr.permute(0, 2, 3, 1)) < 1e-4, rel(out[1], dwr.permute(0, 2, 3, 1))
+    finally:
+        L.load().otr_debug_set(29, 1)
+        ops.set_compute_dtype('bf16')
