@@ -332,11 +332,13 @@ extern "C" int32_t otr_conv2_col2im(const otr_conv_desc_t* d, const void* dcol, 
 // class (their A fragments never change) and the classes get workgroups in proportion to pixels x taps.
 extern unsigned long long* g_otr_trace;   // api.hip (otr_debug_trace)
 int g_otr_conv2_dgrad_ablate = 0;         // tuning hook (otr_debug_set(10, v)), see Conv2DgArgs
+int g_otr_conv2_dgrad_wide = 1;           // the sliced form for 256-channel outputs (otr_debug_set(30, 0) = column matrix + col2im)
 struct Conv2DgArgs {
   const uint16_t* g2; const uint16_t* w2r; const uint16_t* act1; uint16_t* dact1;
   int B, T1, F1, T2, F2;
   int wg0[5];                       // class c = 2*(t1&1) + (f1&1) owns workgroups [wg0[c], wg0[c+1])
   int ablate;                       // tuning hook (otr_debug_set(10, v)): 1 = no mask loads / result stores, 2 = every operand load from one line
+  int C1full, nslice;               // sliced form (conv2_dgrad_sliced_kernel): the channels of act1, and how many 64-channel slices they make
   unsigned long long* trace;        // tuning hook (otr_debug_trace): [workgroup][4] = 100 MHz real-time at start, after the A
                                     // fragments are built, at the end, and the class; or NULL
 };
@@ -344,9 +346,11 @@ struct Conv2DgArgs {
 // one parity class (PT = t1 & 1, PF = f1 & 1): the tap count is a compile-time constant, so a tile is straight-line code --
 // every load is unconditional (the last tile prefetches its own first tap again) and hipcc can count vmcnt exactly instead
 // of draining the prefetch before the MFMAs that do not need it
-template <int RT, int KS, int PT, int PF>
-__device__ __forceinline__ void conv2_dgrad_class(const Conv2DgArgs& p, uint4* afrag, uint4* ebuf_all, int w, int nwg) {
+// SL (sliced form, wide frontends): the workgroup owns the C1 = RT * 32 channels from c1_0 of act1's p.C1full
+template <int RT, int KS, int PT, int PF, bool SL = false>
+__device__ __forceinline__ void conv2_dgrad_class(const Conv2DgArgs& p, uint4* afrag, uint4* ebuf_all, int w, int nwg, int c1_0 = 0) {
   constexpr int C1 = RT * 32, C2 = KS * 16, NKW = PF ? 2 : 1, NT = (PT ? 1 : 2) * NKW;
+  const int ldc = SL ? p.C1full : C1;
   // local tap tt = a * NKW + b2:  kh = PT ? 1 : 2a,  kw = PF ? 2 b2 : 1
   constexpr int NENT = NT * RT * KS * 64;
 #pragma unroll
@@ -356,10 +360,10 @@ __device__ __forceinline__ void conv2_dgrad_class(const Conv2DgArgs& p, uint4* a
     const int ln = e & 63, f = e >> 6, ks = f % KS, rt = (f / KS) % RT, tt = f / (KS * RT);
     const int a = tt / NKW, b2 = tt - a * NKW;
     const int tap = (PT ? 1 : 2 * a) * 3 + (PF ? 2 * b2 : 1);
-    const uint16_t* src = p.w2r + ((int64_t)(ks * 16 + (ln >> 5) * 8) * 9 + tap) * C1 + rt * 32 + (ln & 31);
+    const uint16_t* src = p.w2r + ((int64_t)(ks * 16 + (ln >> 5) * 8) * 9 + tap) * ldc + c1_0 + rt * 32 + (ln & 31);
     uint32_t v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)j * 9 * C1];
+    for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)j * 9 * ldc];
     afrag[e] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
   }
   __syncthreads();
@@ -408,7 +412,7 @@ __device__ __forceinline__ void conv2_dgrad_class(const Conv2DgArgs& p, uint4* a
     live = m < Mc;
     const uint32_t mc = (uint32_t)min(m, Mc - 1), bi = mc / (uint32_t)nF, b = bi / (uint32_t)nT;
     const int i = (int)(bi - b * (uint32_t)nT), j = (int)(mc - bi * (uint32_t)nF);
-    return ((int64_t)(((int)b * p.T1 + 2 * i + PT) * p.F1) + 2 * j + PF) * C1 + 8 * ehalf;
+    return ((int64_t)(((int)b * p.T1 + 2 * i + PT) * p.F1) + 2 * j + PF) * ldc + c1_0 + 8 * ehalf;
   };
   for (int tile = w; tile < ntile; tile += nwg) {
     const Pix npx = tile + nwg < ntile ? pix_of(tile + nwg) : px;
@@ -498,6 +502,24 @@ template <int RT, int KS> __global__ __launch_bounds__(512, 4) void conv2_dgrad_
   if (p.trace && threadIdx.x == 0) p.trace[(int64_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 }
 
+// Wide frontends (the Conformer's 256 -> 256, conformer_baseline.yaml): the A fragments of ALL output channels do not fit LDS (4 taps x
+// 256 x 256 x 2 B), those of a 64-channel slice do (128 KB) -- the grid is nslice copies of the plan, copy s owning channels 64 s .. + 63.
+// The copies of one workgroup index share an XCD (the plan's size is a multiple of 8) and read the same g2 rows there.  One workgroup
+// per CU (136 KB of LDS), 8 waves.  It replaces a [pixels, 9 C1] column matrix written by a GEMM and read back by col2im (696 MB each
+// way at batch 32: 367 + 275 us).
+template <int RT, int KS> __global__ __launch_bounds__(512, 2) void conv2_dgrad_sliced_kernel(Conv2DgArgs p) {
+  __shared__ uint4 afrag[4 * RT * KS * 64];
+  __shared__ uint4 ebuf[8 * 64];
+  const int per = p.wg0[4], slice = (int)blockIdx.x / per, bx = (int)blockIdx.x - slice * per;
+  int cls = 0;
+  while (cls < 3 && bx >= p.wg0[cls + 1]) ++cls;
+  const int w = bx - p.wg0[cls], nwg = p.wg0[cls + 1] - p.wg0[cls], c1_0 = slice * RT * 32;
+  if (cls == 0) conv2_dgrad_class<RT, KS, 0, 0, true>(p, afrag, ebuf, w, nwg, c1_0);
+  else if (cls == 1) conv2_dgrad_class<RT, KS, 0, 1, true>(p, afrag, ebuf, w, nwg, c1_0);
+  else if (cls == 2) conv2_dgrad_class<RT, KS, 1, 0, true>(p, afrag, ebuf, w, nwg, c1_0);
+  else conv2_dgrad_class<RT, KS, 1, 1, true>(p, afrag, ebuf, w, nwg, c1_0);
+}
+
 // (Tried and removed: the B operand staged through LDS -- rows fetched line by line, 8 lanes per 128-byte line, XOR-swizzled
 //  chunks, 16 waves sharing the A fragments -- to spare the address path the one-lane-per-line loads above: 82 us against 78,
 //  bit-identical results.  What bounds this kernel is the latency of a wave's serial tile chain (a tile is 16-64 MFMAs, its
@@ -505,12 +527,13 @@ template <int RT, int KS> __global__ __launch_bounds__(512, 4) void conv2_dgrad_
 // The launch's split into parity classes (host only): wg0[c..c+1) = the workgroups of class c = 2*(t1&1) + (f1&1), tiles[c] =
 // its 256-pixel tiles.  Shared by otr_conv2_dgrad and otr_debug_conv2_dgrad_plan (tests/test_cabi.py replays the kernel's pixel
 // and tap arithmetic on it).
+static bool conv2_dgrad_sliced(const otr_conv_desc_t* d) { return d->C2 == 256 && d->C1 % 64 == 0 && d->C1 >= 128 && d->C1 <= 256; }
 static void conv2_dgrad_plan(const otr_conv_desc_t* d, int* wg0, int* tiles) {
   // Workgroups per class: a tile is modelled as a fixed part (mask rows, the epilogue's LDS round trips, the header wait) plus
   // one part per tap, 3.7 : 1.  Every class gets one workgroup, the rest go one by one to the class whose workgroups
   // currently run longest (exact for this min-max problem).  (Splitting by pixels x taps instead gave the same 75 us at the
   // AISHELL shape: the launch is not bound by the balance between the classes -- profiles/r02_conv2_dgrad_pmc.txt.)
-  const int G = 512, TILE = 256;
+  const int G = conv2_dgrad_sliced(d) ? 256 / (d->C1 / 64) / 8 * 8 : 512, TILE = 256;   // sliced: one workgroup per CU over all the copies
   int n[4], taps[4];
   for (int c = 0; c < 4; ++c) {
     const int pt = c >> 1, pf = c & 1;
@@ -535,7 +558,7 @@ static void conv2_dgrad_plan(const otr_conv_desc_t* d, int* wg0, int* tiles) {
 }
 static bool conv2_dgrad_serves(const otr_conv_desc_t* d) {
   const bool big = d->C1 == 64 && d->C2 == 128, small = d->C1 == 32 && d->C2 == 64;
-  return d->act_dtype == OTR_H16 && d->w_dtype == OTR_H16 && (big || small);
+  return d->act_dtype == OTR_H16 && d->w_dtype == OTR_H16 && (big || small || (conv2_dgrad_sliced(d) && g_otr_conv2_dgrad_wide));
 }
 // out: {served (0 / 1), wg0[0..4], tiles[0..3]}
 extern "C" int32_t otr_debug_conv2_dgrad_plan(const otr_conv_desc_t* d, int32_t* out) {
@@ -569,7 +592,10 @@ extern "C" int32_t otr_conv2_dgrad(const otr_conv_desc_t* d, const void* dact2, 
   conv2_dgrad_plan(d, a.wg0, tiles);
   if (a.wg0[4] == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  if (big) hipLaunchKernelGGL((conv2_dgrad_kernel<2, 8>), dim3((unsigned)a.wg0[4]), dim3(512), 0, s, a);
+  if (conv2_dgrad_sliced(d)) {
+    a.C1full = d->C1; a.nslice = d->C1 / 64;
+    hipLaunchKernelGGL((conv2_dgrad_sliced_kernel<2, 16>), dim3((unsigned)(a.wg0[4] * a.nslice)), dim3(512), 0, s, a);
+  } else if (big) hipLaunchKernelGGL((conv2_dgrad_kernel<2, 8>), dim3((unsigned)a.wg0[4]), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((conv2_dgrad_kernel<1, 4>), dim3((unsigned)a.wg0[4]), dim3(512), 0, s, a);
   return otr_check_launch("conv2_dgrad");
 }

@@ -410,3 +410,45 @@ def test_conv2_wgrad_gather_form(mode, B, T, Fdim, C1, C2):
     finally:
         L.load().otr_debug_set(29, 1)
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
+@pytest.mark.parametrize('B,T,Fd,C1,C2', [(2, 61, 30, 256, 256), (3, 120, 80, 256, 256), (1, 7, 3, 256, 256), (2, 90, 41, 128, 256)])
+def test_conv2_input_gradient_sliced_form(mode, B, T, Fd, C1, C2):
+    """otr_conv2_dgrad for 256 output channels of conv2 (the Conformer's 256 -> 256 frontend): the parity-class kernel with the channels
+    of act1 cut into 64-wide slices (conv.hip conv2_dgrad_sliced_kernel), elementwise against torch's conv2d input gradient of the same
+    16-bit operands in fp32, masked by act1 > 0 (frontend/conv.py:63-66 backward); and == the column-matrix + col2im path it replaces."""
+    import torch.nn.functional as F
+    from opentransformer_amd import _lib as L, ops
+    ops.set_compute_dtype(mode)
+    try:
+        lib = L.load()
+        adt = ops.act_dtype()
+        T1, F1, T2, F2 = ops.conv_geometry(T, Fd)
+        gen = torch.Generator().manual_seed(T)
+        g2 = torch.randn(B, T2, F2, C2, generator=gen).to(DEV, adt)
+        w2r = (torch.randn(C2, 3, 3, C1, generator=gen) / 20).to(DEV, adt)
+        act1 = torch.randn(B, T1, F1, C1, generator=gen).clamp_min(0).to(DEV, adt)
+        dact1 = torch.full_like(act1, float('nan'))
+        desc = L.ConvDesc(B, T, Fd, C1, C2, T1, F1, T2, F2, ops._code(adt), ops._compute_code(), ops._code(adt))
+        rc = lib.otr_conv2_dgrad(C.byref(desc), ops._p(g2), ops._p(w2r), ops._p(act1), ops._p(dact1), ops._stream())
+        assert rc == 0, rc
+        w = w2r.float().permute(0, 3, 1, 2).contiguous()
+        a1 = act1.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+        out = F.conv2d(a1, w, None, stride=2, padding=(0, 1))
+        (gi,) = torch.autograd.grad(out, a1, g2.float().permute(0, 3, 1, 2).contiguous())
+        want = (gi * (a1 > 0)).permute(0, 2, 3, 1)
+        assert not torch.isnan(dact1.float()).any()
+        assert rel(dact1, want) < (4e-3 if mode == 'bf16' else 5e-4), rel(dact1, want)
+        assert bool((dact1[act1 <= 0] == 0).all())
+        # the explicit path on the same operands
+        L.check(lib.otr_debug_set(30, 0), 'debug_set')
+        assert lib.otr_conv2_dgrad(C.byref(desc), ops._p(g2), ops._p(w2r), ops._p(act1), ops._p(dact1), ops._stream()) == 1     # not served: nothing launched
+        dcol = torch.empty((B * T2 * F2, 9 * C1), dtype=adt, device=DEV)
+        d2 = torch.full_like(act1, float('nan'))
+        L.check(lib.otr_conv2_dgrad_cols(C.byref(desc), ops._p(g2), ops._p(w2r), ops._p(dcol), ops._stream()), 'cols')
+        L.check(lib.otr_conv2_col2im(C.byref(desc), ops._p(dcol), ops._p(act1), ops._p(d2), ops._stream()), 'col2im')
+        assert rel(dact1, d2) < (8e-3 if mode == 'bf16' else 1e-3), rel(dact1, d2)
+    finally:
+        L.load().otr_debug_set(30, 1)
+        ops.set_compute_dtype('bf16')

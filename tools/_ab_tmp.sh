@@ -1,5 +1,4 @@
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 900 python -m pytest tests/test_gpu_round6.py tests/test_gpu_ops.py -x -q -m gpu -p no:cacheprovider -k "conv" 2>&1 | tail -15
-for i in 1 2; do for v in 29=1 29=0; do
-  OTR_DEBUG_SET=$v timeout 300 python bench.py --model conformer --steps 30 --warmup 5 --no-cpu-baseline --no-extras 2>&1 | grep '^{' | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('conformer $v', round(d['value'],1), round(d['ms_per_step'],3))"
-done; done
+timeout 900 python -m pytest tests/test_gpu_round6.py tests/test_gpu_ops.py tests/test_gpu_round2b.py -x -q -m gpu -p no:cacheprovider -k "conv" 2>&1 | tail -3
+bash tools/gpu_conformer_trace.sh r6c5 > /dev/null 2>&1
+grep -i "conv\|col2im\|wgrad256\|w256\|relu_bwd" gpurun_out/r6c5/conformer_kernels.txt | cut -c1-150
