@@ -635,8 +635,9 @@ def flush_weight_grads():
     if _wq.get('keep_last'):            # bench.py re-times the grouped launch on the items of the last backward
         _wq['last'] = (list(w), list(b))
     lib = L.load()
-    if _DEBUG_WQ and (w or b) and not _wq.get('dumped'):      # one-off listing of a backward pass's deferred work (tuning aid)
-        _wq['dumped'] = True
+    if _DEBUG_WQ and (w or b) and _wq.get('dumped', 0) < 4:   # listing of the first flushes' deferred work (tuning aid)
+        _wq['dumped'] = _wq.get('dumped', 0) + 1
+        print('wq flush', _wq['dumped'], flush=True)
         for dy2, x2, out in w:
             print('wq w', tuple(dy2.shape), dy2.dtype, dy2.stride(0), tuple(x2.shape), x2.dtype, flush=True)
         for a2, out in b:
