@@ -39,7 +39,7 @@ extern "C" {
  * 300 was rounds 3-5, during which otr_optimizer_step, otr_ln_desc_t, otr_wgrad_item_t and otr_beam_prune_cached changed without a
  * bump).  A binding compares otr_version() with the OTR_ABI_VERSION it was written against BEFORE its first call and refuses a
  * library that answers anything else: descriptors are passed by pointer and read at the library's idea of their size. */
-#define OTR_ABI_VERSION 600
+#define OTR_ABI_VERSION 601
 int32_t otr_version(void);
 /* OTR_BF16 or OTR_F16: the 16-bit type this library was built for */
 int32_t otr_half_type(void);
@@ -468,6 +468,14 @@ int32_t otr_conv2_col2im(const otr_conv_desc_t* d, const void* dcol, const void*
  * Returns 1 without launching anything when the operands do not qualify: use otr_conv2_dgrad_cols + otr_conv2_col2im then. */
 int32_t otr_conv2_dgrad(const otr_conv_desc_t* d, const void* dact2, const void* w2r, const void* act1, void* dact1,
                         void* stream);
+/* r06 (ABI 601) -- the input gradient of a WIDE frontend, C1 == C2 == 256 (conformer_baseline.yaml; frontend/conv.py:50-83): the parity
+ * classes as an implicit GEMM whose weights stream through LDS in MFMA-fragment order, all 256 channels of a pixel per workgroup
+ * (csrc/conv2wide.hip); the ReLU mask of act1 is fused.  `scratch` (>= otr_conv2_wide_scratch_bytes(), 16-byte aligned) receives the
+ * re-ordered weights on the launch's stream.  16-bit activations and weights.
+ * Returns 1 without launching anything when the operands do not qualify: use otr_conv2_dgrad (or its column-matrix form). */
+int64_t otr_conv2_wide_scratch_bytes(void);
+int32_t otr_conv2_dgrad_wide(const otr_conv_desc_t* d, const void* dact2, const void* w2r, const void* act1, void* dact1, void* scratch,
+                             int64_t scratch_bytes, void* stream);
 /* host-side plan of that launch, no device work (tests): out[10] = {served 0/1, first workgroup of the parity classes
  * c = 2*(t1&1) + (f1&1) and the total (5 values), 256-pixel tiles per class (4 values)} */
 int32_t otr_debug_conv2_dgrad_plan(const otr_conv_desc_t* d, int32_t* out);

@@ -14,7 +14,7 @@ LIB_PATHS = {'bf16': os.path.join(_LIB_DIR, 'libotrans_hip.so'), 'fp16': os.path
 LIB_PATH = LIB_PATHS['bf16']
 
 OTR_F32, OTR_BF16, OTR_F16 = 0, 1, 2
-OTR_ABI_VERSION = 600           # include/otrans_hip.h: the header this binding's structures and SIGNATURES were written against
+OTR_ABI_VERSION = 601           # include/otrans_hip.h: the header this binding's structures and SIGNATURES were written against
 OTR_OPT_STATE_FLOATS = 528      # include/otrans_hip.h: floats of otr_optimizer_step's device state block
 ACT_NONE, ACT_RELU = 0, 1
 
@@ -160,6 +160,8 @@ SIGNATURES = {
     'otr_conv2_dgrad_cols': [C.POINTER(ConvDesc), _P, _P, _P, _P],
     'otr_conv2_col2im': [C.POINTER(ConvDesc), _P, _P, _P, _P],
     'otr_conv2_dgrad': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
+    'otr_conv2_wide_scratch_bytes': [],
+    'otr_conv2_dgrad_wide': [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I64, _P],
     'otr_debug_conv2_dgrad_plan': [C.POINTER(ConvDesc), _P],
     'otr_conv2_wgrad': [C.POINTER(ConvDesc), _P, _P, _P, _P, _I64, _P],
     'otr_relu_bwd': [_P, _P, _P, _I32, _I64, _P],
@@ -223,7 +225,8 @@ SIGNATURES = {
 }
 _RESTYPE = {'otr_last_error_string': C.c_char_p, 'otr_dec_ffn_hsave_bytes': C.c_int64, 'otr_ffn_split_scratch_bytes': C.c_int64, 'otr_ffn_split_sync_ints': C.c_int64, 'otr_ffn_split_hsave_bytes': C.c_int64,
             'otr_ffn_split_padded_rows': C.c_int64, 'otr_add_layernorm_bwd_partial_rows': C.c_int64,
-            'otr_ln_bwd_proj_partial_rows': C.c_int64, 'otr_dwconv_bwd_partial_rows': C.c_int64, 'otr_dwconv_fwd_partial_rows': C.c_int64}
+            'otr_ln_bwd_proj_partial_rows': C.c_int64, 'otr_dwconv_bwd_partial_rows': C.c_int64, 'otr_dwconv_fwd_partial_rows': C.c_int64,
+            'otr_conv2_wide_scratch_bytes': C.c_int64}
 
 _libs = {}
 _kind = 'bf16'

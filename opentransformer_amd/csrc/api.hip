@@ -50,6 +50,8 @@ int g_otr_wgrad256_ablate = 0;   // tuning hook (otr_debug_set(8, v)), see wgrad
 int g_otr_wgrad256_min_rows = 256;   // shortest contraction the 256-wide launch takes (otr_debug_set(9, v))
 extern int g_otr_conv2_dgrad_ablate;   // conv.hip (otr_debug_set(10, v))
 extern int g_otr_conv2_dgrad_wide;     // conv.hip (otr_debug_set(30, v))
+extern int g_otr_conv2_wide;           // conv.hip (otr_debug_set(31, v))
+extern int g_otr_conv2wide_ablate;     // conv2wide.hip (otr_debug_set(32, v))
 int g_otr_wgrad256_grid = 0; // workgroups of that launch; 0 = one per CU (otr_debug_set(7, v))
 int g_otr_conv2_fwd_direct = 1;  // conv2 forward on the weight-stationary kernel where it serves (otr_debug_set(22, v))
 int g_otr_attn_enc = 1;          // encoder-shape attention backward with the whole (utterance, head) in LDS (otr_debug_set(21, v))
@@ -75,6 +77,8 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   else if (key == 27) g_otr_bias_vec4 = value;
   else if (key == 29) g_otr_conv2_wgrad256 = value;
   else if (key == 30) g_otr_conv2_dgrad_wide = value;
+  else if (key == 31) g_otr_conv2_wide = value;
+  else if (key == 32) g_otr_conv2wide_ablate = value;
   else if (key == 28) g_otr_gemm_resident64 = value > 0 ? value : 512;
   else if (key == 2) g_otr_force_generic = value;
   else if (key == 3) g_otr_no_persist = value;

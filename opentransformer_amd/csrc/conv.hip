@@ -528,12 +528,17 @@ template <int RT, int KS> __global__ __launch_bounds__(512, 2) void conv2_dgrad_
 // its 256-pixel tiles.  Shared by otr_conv2_dgrad and otr_debug_conv2_dgrad_plan (tests/test_cabi.py replays the kernel's pixel
 // and tap arithmetic on it).
 static bool conv2_dgrad_sliced(const otr_conv_desc_t* d) { return d->C2 == 256 && d->C1 % 64 == 0 && d->C1 >= 128 && d->C1 <= 256; }
+static void conv2_dgrad_plan_g(const otr_conv_desc_t* d, int G, int fix, int* wg0, int* tiles);
 static void conv2_dgrad_plan(const otr_conv_desc_t* d, int* wg0, int* tiles) {
+  conv2_dgrad_plan_g(d, conv2_dgrad_sliced(d) ? 256 / (d->C1 / 64) / 8 * 8 : 512, 37, wg0, tiles);
+}
+// G workgroups over the four classes; a tile costs `fix` + 10 per tap (units of 0.1 tap)
+static void conv2_dgrad_plan_g(const otr_conv_desc_t* d, int G, int fix, int* wg0, int* tiles) {
   // Workgroups per class: a tile is modelled as a fixed part (mask rows, the epilogue's LDS round trips, the header wait) plus
   // one part per tap, 3.7 : 1.  Every class gets one workgroup, the rest go one by one to the class whose workgroups
   // currently run longest (exact for this min-max problem).  (Splitting by pixels x taps instead gave the same 75 us at the
   // AISHELL shape: the launch is not bound by the balance between the classes -- profiles/r02_conv2_dgrad_pmc.txt.)
-  const int G = conv2_dgrad_sliced(d) ? 256 / (d->C1 / 64) / 8 * 8 : 512, TILE = 256;   // sliced: one workgroup per CU over all the copies
+  const int TILE = 256;
   int n[4], taps[4];
   for (int c = 0; c < 4; ++c) {
     const int pt = c >> 1, pf = c & 1;
@@ -544,7 +549,7 @@ static void conv2_dgrad_plan(const otr_conv_desc_t* d, int* wg0, int* tiles) {
     n[c] = tiles[c] > 0 ? 1 : 0;
   }
   auto span = [&](int c) {                       // time of the class's longest workgroup, in units of 0.1 tap
-    return n[c] > 0 ? (int64_t)((tiles[c] + n[c] - 1) / n[c]) * (37 + 10 * taps[c]) : 0;
+    return n[c] > 0 ? (int64_t)((tiles[c] + n[c] - 1) / n[c]) * (fix + 10 * taps[c]) : 0;
   };
   for (int left = G - (n[0] + n[1] + n[2] + n[3]); left > 0; --left) {
     int best = -1;
@@ -598,4 +603,27 @@ extern "C" int32_t otr_conv2_dgrad(const otr_conv_desc_t* d, const void* dact2, 
   } else if (big) hipLaunchKernelGGL((conv2_dgrad_kernel<2, 8>), dim3((unsigned)a.wg0[4]), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((conv2_dgrad_kernel<1, 4>), dim3((unsigned)a.wg0[4]), dim3(512), 0, s, a);
   return otr_check_launch("conv2_dgrad");
+}
+
+// ------------------------------------------------------------------------------------------------ wide frontends (conv2wide.hip)
+int64_t conv2wide_workspace_bytes();
+int32_t conv2wide_dgrad(const void* g2, const void* w2r, const void* act1, void* dact1, int B, int T1, int F1, int T2, int F2, const int* wg0,
+                        void* scratch, hipStream_t s);
+int g_otr_conv2_wide = 1;                 // otr_debug_set(31, 0): the entry below answers "not served"
+static bool conv2wide_serves(const otr_conv_desc_t* d, const void* a, const void* b, const void* c, const void* e, const void* scratch,
+                             int64_t scratch_bytes) {
+  return g_otr_conv2_wide && d->C1 == 256 && d->C2 == 256 && d->act_dtype == OTR_H16 && d->w_dtype == OTR_H16 && d->compute == OTR_H16 &&
+         scratch && scratch_bytes >= conv2wide_workspace_bytes() && ((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)e | (uintptr_t)scratch) % 16 == 0;
+}
+extern "C" int64_t otr_conv2_wide_scratch_bytes(void) { return conv2wide_workspace_bytes(); }
+// 0 = launched, 1 = not served (otr_conv2_dgrad, or otr_conv2_dgrad_cols + otr_conv2_col2im), < 0 = bad argument
+extern "C" int32_t otr_conv2_dgrad_wide(const otr_conv_desc_t* d, const void* dact2, const void* w2r, const void* act1, void* dact1,
+                                        void* scratch, int64_t scratch_bytes, void* stream) {
+  ConvArgs chk{};
+  if (int32_t e = conv_check(d, chk)) return e;
+  OTR_REQUIRE(dact2 && w2r && act1 && dact1, "conv2_dgrad_wide: null pointer");
+  if (!conv2wide_serves(d, dact2, w2r, act1, dact1, scratch, scratch_bytes)) return 1;
+  int wg0[5], tiles[4];
+  conv2_dgrad_plan_g(d, 256, 10, wg0, tiles);
+  return conv2wide_dgrad(dact2, w2r, act1, dact1, d->B, d->T1, d->F1, d->T2, d->F2, wg0, scratch, (hipStream_t)stream);
 }

@@ -2723,6 +2723,7 @@ def conv_geometry(T, F):
     return T1, F1, T2, F2
 
 
+_CONV2_WIDE = True                 # 256 -> 256 channels: conv2 input gradient on csrc/conv2wide.hip
 _CONV2_IMPLICIT_DGRAD = True       # tests switch it off to compare with the explicit (column matrix) path
 
 
@@ -2806,7 +2807,11 @@ class ConvSubsampleFn(torch.autograd.Function):
         #  200 trivial nodes 318 -> 621 us, 200 streaming nodes 442 -> 611 us; tools/ubench/boundary.hip, profiles/r06_boundary_probe.txt)
         L.check(lib.otr_conv2_wgrad(C.byref(desc), _p(g2), _p(act1), _p(dw2r), _p(_workspace(x.device)), _WS_BYTES, _stream()),
                 'otr_conv2_wgrad')
-        rc = lib.otr_conv2_dgrad(C.byref(desc), _p(g2), _p(w2r), _p(act1), _p(dact1), _stream()) if _CONV2_IMPLICIT_DGRAD else 1
+        rc = 1
+        if _CONV2_IMPLICIT_DGRAD and _CONV2_WIDE and C1 == 256 and C2 == 256:
+            rc = lib.otr_conv2_dgrad_wide(C.byref(desc), _p(g2), _p(w2r), _p(act1), _p(dact1), _p(_workspace(x.device)), _WS_BYTES, _stream())
+        if rc == 1:
+            rc = lib.otr_conv2_dgrad(C.byref(desc), _p(g2), _p(w2r), _p(act1), _p(dact1), _stream()) if _CONV2_IMPLICIT_DGRAD else 1
         if rc == 1:                          # operands do not qualify for the implicit kernel: column matrix + col2im
             dcol = torch.empty((M2, 9 * C1), dtype=adt, device=x.device)
             L.check(lib.otr_conv2_dgrad_cols(C.byref(desc), _p(g2), _p(w2r), _p(dcol), _stream()), 'otr_conv2_dgrad_cols')

@@ -452,3 +452,50 @@ def test_conv2_input_gradient_sliced_form(mode, B, T, Fd, C1, C2):
     finally:
         L.load().otr_debug_set(30, 1)
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
+@pytest.mark.parametrize('B,T,Fd', [(2, 61, 30), (3, 120, 80), (1, 7, 3), (5, 333, 83), (32, 1000, 80)])
+def test_conv2_wide_input_gradient(mode, B, T, Fd):
+    """otr_conv2_dgrad_wide (csrc/conv2wide.hip: 256 -> 256 channels, weights streamed through LDS, all channels of a pixel in one
+    workgroup) against torch's conv2d input gradient on the same 16-bit operands in fp32, masked by act1 > 0 (frontend/conv.py:63-66
+    backward), and against the sliced parity-class kernel it replaces.  Shapes: a few pixels (fewer than one 256-pixel tile), ragged
+    tiles, odd F1 (classes of different sizes), the bench batch."""
+    import torch.nn.functional as F
+    from opentransformer_amd import _lib as L, ops
+    ops.set_compute_dtype(mode)
+    try:
+        lib = L.load()
+        adt = ops.act_dtype()
+        C1 = C2 = 256
+        T1, F1, T2, F2 = ops.conv_geometry(T, Fd)
+        gen = torch.Generator().manual_seed(T + Fd)
+        act1 = torch.randn(B, T1, F1, C1, generator=gen).clamp_min(0).to(DEV, adt)
+        w2r = (torch.randn(C2, 3, 3, C1, generator=gen) / 48).to(DEV, adt)
+        g2 = torch.randn(B, T2, F2, C2, generator=gen).to(DEV, adt)
+        desc = L.ConvDesc(B, T, Fd, C1, C2, T1, F1, T2, F2, ops._code(adt), ops._compute_code(), ops._code(adt))
+        ws = ops._workspace(act1.device)
+        assert lib.otr_conv2_wide_scratch_bytes() == 9 * 8 * 1024 * 16
+        dact1 = torch.full_like(act1, float('nan'))
+        assert lib.otr_conv2_dgrad_wide(C.byref(desc), ops._p(g2), ops._p(w2r), ops._p(act1), ops._p(dact1), ops._p(ws), ops._WS_BYTES, ops._stream()) == 0
+        d2 = torch.full_like(act1, float('nan'))
+        assert lib.otr_conv2_dgrad(C.byref(desc), ops._p(g2), ops._p(w2r), ops._p(act1), ops._p(d2), ops._stream()) == 0       # the sliced form
+        assert not torch.isnan(dact1.float()).any()
+        assert rel(dact1, d2) < (4e-3 if mode == 'bf16' else 5e-4), rel(dact1, d2)
+        assert bool((dact1[act1 <= 0] == 0).all())
+        if B * T <= 1000:
+            w = w2r.float().permute(0, 3, 1, 2).contiguous()
+            a1 = act1.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+            out = F.conv2d(a1, w, None, stride=2, padding=(0, 1))
+            (gi,) = torch.autograd.grad(out, a1, g2.float().permute(0, 3, 1, 2).contiguous())
+            want = (gi * (a1 > 0)).permute(0, 2, 3, 1)
+            assert rel(dact1, want) < (4e-3 if mode == 'bf16' else 5e-4), rel(dact1, want)
+        # not served: other channel counts, a short scratch, the switch
+        d64 = L.ConvDesc(B, T, Fd, 64, 128, T1, F1, T2, F2, ops._code(adt), ops._compute_code(), ops._code(adt))
+        assert lib.otr_conv2_dgrad_wide(C.byref(d64), ops._p(g2), ops._p(w2r), ops._p(act1), ops._p(dact1), ops._p(ws), ops._WS_BYTES, ops._stream()) == 1
+        assert lib.otr_conv2_dgrad_wide(C.byref(desc), ops._p(g2), ops._p(w2r), ops._p(act1), ops._p(dact1), ops._p(ws), 1024, ops._stream()) == 1
+        L.check(lib.otr_debug_set(31, 0), 'debug_set')
+        assert lib.otr_conv2_dgrad_wide(C.byref(desc), ops._p(g2), ops._p(w2r), ops._p(act1), ops._p(dact1), ops._p(ws), ops._WS_BYTES, ops._stream()) == 1
+    finally:
+        L.load().otr_debug_set(31, 1)
+        ops.set_compute_dtype('bf16')
