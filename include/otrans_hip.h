@@ -594,6 +594,18 @@ int32_t otr_bn_swish_bwd_partial_rows(int64_t M);
 int32_t otr_bn_swish_bwd(const float* y, const void* ds, int32_t ds_dtype, const float* saved, const float* gamma,
                          const float* beta, float* red, float* partial, float* dgamma_acc, float* dbeta_acc, float* dy,
                          int64_t M, int32_t C, int32_t training, void* stream);
+/* r06 (ABI 601): the middle of ConformerConvolutionModule's backward (module/conformer.py:36-57) as two steps instead of five launches.
+ * otr_bn_swish_bwd_sums = the first two launches of otr_bn_swish_bwd (per-strip sums, their reduction into red [2C] and, when given, into
+ * the BatchNorm parameter gradients); otr_conformer_conv_bwd_mid then does BatchNorm's apply step, the depthwise convolution's backward and
+ * the GLU's backward in ONE launch: dh [M, 2C] from y, ds, red, g (the GLU output) and h (the GLU input).  The [M, C] fp32 dy and the
+ * [M, C] dg tensors of the stand-alone chain are never written.  part [otr_dwconv_bwd_partial_rows(M)][C*k + C] and gpart [same rows][2C]
+ * receive per-workgroup sums (no atomics): the depthwise conv's dw | db and the columns of dh (pointwise_conv1's bias gradient). */
+int32_t otr_bn_swish_bwd_sums(const float* y, const void* ds, int32_t ds_dtype, const float* saved, const float* gamma, const float* beta,
+                              float* red, float* partial, float* dgamma_acc, float* dbeta_acc, int64_t M, int32_t C, void* stream);
+int32_t otr_conformer_conv_bwd_mid(const float* y, const void* ds, const float* saved, const float* gamma, const float* beta,
+                                   const float* red, const void* g, const float* w, const void* h, const uint8_t* row_mask, void* dh,
+                                   float* part, float* gpart, int32_t dtype, int32_t training, int32_t B, int32_t T, int32_t C, int32_t k,
+                                   int32_t pad, void* stream);
 
 /* ---- CTC loss with gradient w.r.t. the logits (nn.CTCLoss(blank, zero_infinity=True), reduction
  *      'mean', as built at model/ctc.py:30 and called at :50-53).  log_probs f32 [B,T,V] (already

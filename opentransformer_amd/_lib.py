@@ -222,6 +222,8 @@ SIGNATURES = {
     'otr_dwconv_fwd_partial_rows': [_I64],
     'otr_bn_swish_bwd_partial_rows': [_I64],
     'otr_bn_swish_bwd': [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
+    'otr_bn_swish_bwd_sums': [_P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P],
+    'otr_conformer_conv_bwd_mid': [_P] * 13 + [_I32] * 7 + [_P],
 }
 _RESTYPE = {'otr_last_error_string': C.c_char_p, 'otr_dec_ffn_hsave_bytes': C.c_int64, 'otr_ffn_split_scratch_bytes': C.c_int64, 'otr_ffn_split_sync_ints': C.c_int64, 'otr_ffn_split_hsave_bytes': C.c_int64,
             'otr_ffn_split_padded_rows': C.c_int64, 'otr_add_layernorm_bwd_partial_rows': C.c_int64,

@@ -2867,6 +2867,7 @@ def _gemm_ptr(kind, M, N, K, x, w, y, bias=None, accumulate=0):
 _GEMM_BATCHED = True
 _BN_PART = True          # ConformerConvFn: BatchNorm batch statistics through per-workgroup sums
 _DW_PART = True      # ConformerConvFn: depthwise-conv parameter gradients through per-workgroup sums
+_CONV_MID_FUSED = True      # ConformerConvFn.backward: BatchNorm apply + depthwise conv + GLU backward in one launch
 _POS_DEFER = True      # RelPosAttentionFn: the per-head dp products join the grouped weight-gradient launch
 
 
@@ -3234,18 +3235,40 @@ class ConformerConvFn(torch.autograd.Function):
         dw2 = linear_wgrad_raw(dm, s, w2c, out=gw2)
         db2 = colsum_raw(dm, out=gb2) if b2p is not None else None
         red = torch.empty((2 * Cc,), dtype=torch.float32, device=dout.device)
-        dy = torch.empty((M, Cc), dtype=torch.float32, device=dout.device)
         bn_part = torch.empty((lib.otr_bn_swish_bwd_partial_rows(M), 2 * Cc), dtype=torch.float32, device=dout.device)
         gp, bp = ctx.bn_refs
         gg, gbt = grad_target(gp), grad_target(bp)
         bn_inplace = gg is not None and gbt is not None        # the reduction launch adds d gamma / d beta where they live
+        wdwp, bdwp = ctx.dw_refs
+        gwd, gbd = grad_target(wdwp), (grad_target(bdwp) if has_dwb else None)
+        dw_inplace = gwd is not None and gwd.is_contiguous() and (not has_dwb or gbd is not None)   # the kernel's sums are += already
+        if _CONV_MID_FUSED and dw_inplace and _DW_PART and _wq['on'] and _in_backward() and ds.dtype == adt and h.dtype == adt and g.dtype == adt:
+            # r06: BatchNorm's apply step + the depthwise conv's backward + the GLU's backward in one launch (otr_conformer_conv_bwd_mid):
+            # neither dy [M, C] fp32 nor dg [M, C] exists
+            L.check(lib.otr_bn_swish_bwd_sums(_p(y), _p(ds), _code(adt), _p(saved), _p(gamma), _p(beta), _p(red), _p(bn_part),
+                                              _p(gg) if bn_inplace else None, _p(gbt) if bn_inplace else None, M, Cc, _stream()),
+                    'otr_bn_swish_bwd_sums')
+            nrow = lib.otr_dwconv_bwd_partial_rows(M)
+            dpart = torch.empty((nrow, Cc * k + Cc), dtype=torch.float32, device=dout.device)
+            part = torch.empty((nrow, 2 * Cc), dtype=torch.float32, device=dout.device)
+            dh = torch.empty_like(h)
+            L.check(lib.otr_conformer_conv_bwd_mid(_p(y), _p(ds), _p(saved), _p(gamma), _p(beta), _p(red), _p(g), _p(wk), _p(h), _p(mask_u8),
+                                                   _p(dh), _p(dpart), _p(part), _code(adt), int(training), B, T, Cc, k, (k - 1) // 2, _stream()),
+                    'otr_conformer_conv_bwd_mid')
+            colsum_raw(dpart[:, :Cc * k], out=gwd.view(-1))
+            if has_dwb:
+                colsum_raw(dpart[:, Cc * k:], out=gbd)
+            db1 = colsum_raw(part, out=gb1) if b1p is not None else None
+            dx = (linear_fwd_raw(dh, ctx.w1t, None, xdtype) if ctx.w1t is not None else linear_dgrad_raw(dh, w1c, xdtype)).view(xshape)
+            dw1 = linear_wgrad_raw(dh, x2, w1c, out=gw1)
+            return (dx, None, None if gw1 is not None else dw1, None if gb1 is not None else db1, None, None,
+                    None if bn_inplace else red[Cc:], None if bn_inplace else red[:Cc], None, None,
+                    None if gw2 is not None else dw2, None if gb2 is not None else db2, None, None, None, None)
+        dy = torch.empty((M, Cc), dtype=torch.float32, device=dout.device)
         L.check(lib.otr_bn_swish_bwd(_p(y), _p(ds), _code(adt), _p(saved), _p(gamma), _p(beta), _p(red), _p(bn_part),
                                      _p(gg) if bn_inplace else None, _p(gbt) if bn_inplace else None, _p(dy), M, Cc,
                                      int(training), _stream()), 'otr_bn_swish_bwd')
         dg = torch.empty((M, Cc), dtype=adt, device=dout.device)
-        wdwp, bdwp = ctx.dw_refs
-        gwd, gbd = grad_target(wdwp), (grad_target(bdwp) if has_dwb else None)
-        dw_inplace = gwd is not None and gwd.is_contiguous() and (not has_dwb or gbd is not None)   # the kernel's sums are += already
         dwk = None if dw_inplace else torch.zeros((Cc * k + Cc,), dtype=torch.float32, device=dout.device)
         if dw_inplace and _DW_PART and _wq['on'] and _in_backward():
             # the kernel leaves per-workgroup sums; the grouped column-sum launch at the end of backward adds them where the gradients

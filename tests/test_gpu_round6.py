@@ -499,3 +499,50 @@ def test_conv2_wide_input_gradient(mode, B, T, Fd):
     finally:
         L.load().otr_debug_set(31, 1)
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('B,T,Cc,k', [(4, 90, 128, 7), (3, 249, 384, 5), (2, 33, 64, 3), (1, 5, 256, 5)])
+def test_conformer_conv_backward_fused_middle(mode, B, T, Cc, k):
+    """ConformerConvolutionModule backward (module/conformer.py:36-57) with BatchNorm's apply step, the depthwise conv's backward and the
+    GLU's backward in one launch (otr_bn_swish_bwd_sums + otr_conformer_conv_bwd_mid) == the five-launch chain it replaces: the input
+    gradient and every parameter gradient, under FlatDataParallel (in-place gradient buffers, deferred sums), padded frames masked,
+    segments that cross utterance boundaries (T not a multiple of the 16-row segments), an utterance shorter than the kernel's reach."""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops, synthetic as syn
+    from opentransformer_amd.dp import FlatDataParallel
+    ops.set_compute_dtype(mode)
+    try:
+        gen = torch.Generator().manual_seed(B * T + Cc)
+        x = torch.randn(B, T, Cc, generator=gen).to(DEV)
+        gout = torch.randn(B, T, Cc, generator=gen).to(DEV, ops.act_dtype())
+        mask = torch.ones(B, T, dtype=torch.bool, device=DEV)
+        if B > 1:
+            mask[B - 1, max(1, T - T // 4):] = False
+        res = {}
+        for fused in (True, False):
+            ops._CONV_MID_FUSED = fused
+            mod = ota.ConformerConvolutionModule(Cc, k).to(DEV).train()
+            syn.fill_state_dict_(mod.state_dict(), 9)
+            dp = FlatDataParallel(mod)
+            dp.zero_grad()
+            xin = x.clone().requires_grad_(True)
+            names = []
+            ops.set_kernel_timer(names)
+            try:
+                mod(xin, mask).backward(gout)
+            finally:
+                ops.set_kernel_timer(None)
+            torch.cuda.synchronize()
+            res[fused] = (xin.grad.clone(), {n: p.grad.clone() for n, p in mod.named_parameters()})
+        tol = 1e-5 if mode == 'fp32' else (4e-3 if mode == 'bf16' else 5e-4)
+        assert rel(res[True][0], res[False][0]) < tol, rel(res[True][0], res[False][0])
+        for n in res[True][1]:
+            a, b = res[True][1][n], res[False][1][n]
+            scale = max(float(b.abs().max()), 1e-6)
+            if n == 'depthwise_conv.bias':                 # zero gradient in front of BatchNorm: roundoff on both sides
+                continue
+            assert float((a - b).abs().max()) < 10 * tol * scale, (n, float((a - b).abs().max()), scale)
+    finally:
+        ops._CONV_MID_FUSED = True
+        ops.set_compute_dtype('bf16')
