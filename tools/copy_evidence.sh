@@ -14,9 +14,10 @@ c $T/conformer_kernels.txt $P/${R}_conformer_kernels.txt; c $T/conformer_step_se
 c $T/decode_kernels.txt $P/${R}_decode_kernels.txt
 c $T/tolerance_cases.jsonl $P/${R}_tolerance_cases.jsonl
 c $T/bench_2rank_onegpu_gloo.log $P/${R}_bench_2rank_onegpu_gloo.log
+c $T/bench_1400.json $P/${R}_bench_1400_frames.json; c $T/bench_1400_generic_attention_bwd.json $P/${R}_bench_1400_frames_generic_attention_bwd.json
 [ -f $T/pytest_gpu.log ] && grep -E "passed|failed" $T/pytest_gpu.log | tail -1 > $P/${R}_pytest_gpu.txt
 [ -f $T/smoke.log ] && grep -v amdgpu.ids $T/smoke.log | tail -4 > $P/${R}_smoke.txt
-for f in parity_headline_engine_fp16 parity_headline_engine_bf16 parity_headline_fp16 parity_headline_bf16 parity_headline_fp32 parity_c2ctc_fp16 parity_c2ctc_bf16 parity_c2ctc_fp32 parity_c4_fp16 parity_c4_bf16 parity_c4_fp32 parity_report decode_validity_fp16 decode_validity_bf16 decode_eos_live_fp16 decode_eos_live_fp32 decode_eos_live_bf16; do
+for f in parity_c4_engine_fp16 parity_c4_engine_bf16 parity_headline_engine_fp16 parity_headline_engine_bf16 parity_headline_fp16 parity_headline_bf16 parity_headline_fp32 parity_c2ctc_fp16 parity_c2ctc_bf16 parity_c2ctc_fp32 parity_c4_fp16 parity_c4_bf16 parity_c4_fp32 parity_report decode_validity_fp16 decode_validity_bf16 decode_eos_live_fp16 decode_eos_live_fp32 decode_eos_live_bf16; do
   c $T/$f.json $P/${R}_$f.json
 done
 ls $P | grep ${R}_ | tr '\n' ' '
