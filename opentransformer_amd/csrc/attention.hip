@@ -935,6 +935,12 @@ extern "C" int32_t otr_attention_bwd(const otr_attn_desc_t* d, const void* q, co
 extern int g_otr_attn_bwd_split;   // api.hip (otr_debug_set(13, 1)): the two-launch form, for A/B runs
 extern int g_otr_attn_enc;         // api.hip (otr_debug_set(21, v)): the whole-utterance-in-LDS backward kernel (encattn.hip) where it serves
 bool encattn_bwd_takes(int dtype_is_h16, int dk, int Tq, int Tk, int causal, int has_bias, int vec);
+// encattn96.hip: the Conformer's relative-position self-attention backward (head dim 96, score term) on the whole-utterance design
+bool encattn96_bwd_takes(int dtype_is_h16, int dk, int Tq, int Tk, int causal, int has_bias, int rel_shift, int bias_vec4, int has_dbias, int vec);
+int32_t encattn96_bwd_launch(const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse, const uint8_t* key_mask,
+                             const float* bias, void* dbias, int dbias_h16, int64_t bias_bs, int64_t bias_hs, int64_t bias_rs, void* dq, void* dk,
+                             void* dv, int B, int H, int T, int64_t q_bs, int64_t q_ts, int64_t k_bs, int64_t k_ts, int64_t v_bs, int64_t v_ts,
+                             int64_t o_bs, int64_t o_ts, float scale, hipStream_t stream);
 int32_t encattn_bwd_launch(const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse, const uint8_t* key_mask,
                            void* dq, void* dk, void* dv, int B, int H, int T, int64_t q_bs, int64_t q_ts, int64_t k_bs, int64_t k_ts, int64_t v_bs,
                            int64_t v_ts, int64_t o_bs, int64_t o_ts, float scale, hipStream_t stream);
@@ -953,6 +959,9 @@ template <class CT, int DK> static void attn_bwd_merged_launch(const otr_attn_de
 static int32_t attention_bwd_impl(const otr_attn_desc_t* d, AttnArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int nqb = (d->Tq + 63) / 64, nkb = (d->Tk + 63) / 64;
+  if (encattn96_bwd_takes(d->dtype == OTR_H16, d->dk, d->Tq, d->Tk, a.causal, a.bias != nullptr, a.rel_shift, a.bias_vec4, a.dbias != nullptr, a.vec))
+    return encattn96_bwd_launch(a.q, a.k, a.v, a.o, a.do_, a.lse, a.key_mask, a.bias, a.dbias, a.dbias_h16, a.bias_bs, a.bias_hs, a.bias_rs, a.dq,
+                                a.dk, a.dv, d->B, d->H, d->Tq, a.q_bs, a.q_ts, a.k_bs, a.k_ts, a.v_bs, a.v_ts, a.o_bs, a.o_ts, a.scale, s);
   if (g_otr_attn_enc && encattn_bwd_takes(d->dtype == OTR_H16, d->dk, d->Tq, d->Tk, a.causal, a.bias != nullptr || a.dbias != nullptr, a.vec))
     return encattn_bwd_launch(a.q, a.k, a.v, a.o, a.do_, a.lse, a.key_mask, a.dq, a.dk, a.dv, d->B, d->H, d->Tq, a.q_bs, a.q_ts, a.k_bs, a.k_ts,
                               a.v_bs, a.v_ts, a.o_bs, a.o_ts, a.scale, s);

@@ -546,3 +546,78 @@ def test_conformer_conv_backward_fused_middle(mode, B, T, Cc, k):
     finally:
         ops._CONV_MID_FUSED = True
         ops.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['fp16', 'bf16'])
+@pytest.mark.parametrize('B,T,dbd16', [(3, 249, True), (2, 300, True), (2, 131, False), (1, 33, True), (2, 513, True)])
+def test_relpos_attention_backward_whole_utterance_kernel(mode, B, T, dbd16):
+    """otr_attention_bias_bwd for the Conformer's self-attention (head dim 96, relative-position score term, module/attention.py:196-253):
+    csrc/encattn96.hip (the (utterance, head) staged in LDS super-chunk by super-chunk, one workgroup per orientation) == the streamed
+    dQ + dK/dV pair it replaces (otr_debug_set(33, 0)): dq, dk, dv and the score term's gradient, with masked keys, T across one / two / three
+    super-chunks and two own blocks (T > 256), the gradient tensor in fp32 and in 16 bits; and dq / dk / dv against an fp32 torch reference."""
+    from opentransformer_amd import _lib as L, ops
+    ops.set_compute_dtype(mode)
+    try:
+        lib = L.load()
+        adt = ops.act_dtype()
+        H, dk = 4, 96
+        d = H * dk
+        P = 2 * T - 1
+        Pp = (P + 7) // 8 * 8
+        gen = torch.Generator().manual_seed(T)
+        qkv = (torch.randn(B, T, 3 * d, generator=gen) * 0.5).to(DEV, adt)
+        quv = (qkv[..., :d].float() + 0.1).to(adt).contiguous()                      # the (q + u) operand: [B, T, d]
+        bd = (torch.randn(B, T, H, Pp, generator=gen) * 2.0).to(DEV)                  # the un-shifted score term, fp32
+        dout = torch.randn(B, T, d, generator=gen).to(DEV, adt)
+        km = torch.ones(B, T, dtype=torch.uint8, device=DEV)
+        if B > 1:
+            km[B - 1, T - T // 5:] = 0
+        out = torch.empty(B, T, d, dtype=adt, device=DEV)
+        lse = torch.empty(B, H, T, dtype=torch.float32, device=DEV)
+        desc = ops._attn_desc(B, H, T, T, dk, adt, (T * d, d), (T * 3 * d, 3 * d), (T * 3 * d, 3 * d), (T * d, d), False)
+        L.check(lib.otr_attention_bias_fwd(C.byref(desc), ops._p(quv), ops._p(qkv, d), ops._p(qkv, 2 * d), ops._p(km), ops._p(bd),
+                                           T * H * Pp, Pp, H * Pp, 1, ops._p(out), ops._p(lse), ops._stream()), 'fwd')
+        res = {}
+        for form in (1, 0):
+            L.check(lib.otr_debug_set(33, form), 'debug_set')
+            dbd = torch.zeros(B, T, H, Pp, dtype=adt if dbd16 else torch.float32, device=DEV)
+            dq = torch.full((B, T, d), float('nan'), dtype=adt, device=DEV)
+            dkv = torch.full((B, T, 3 * d), float('nan'), dtype=adt, device=DEV)
+            delta = torch.empty_like(lse)
+            names = []
+            ops.set_kernel_timer(names)
+            try:
+                L.check(lib.otr_attention_bias_bwd(C.byref(desc), ops._p(quv), ops._p(qkv, d), ops._p(qkv, 2 * d), ops._p(km), ops._p(bd), ops._p(dbd),
+                                                   ops._code(dbd.dtype), T * H * Pp, Pp, H * Pp, 1, ops._p(out), ops._p(dout), ops._p(lse), ops._p(delta),
+                                                   ops._p(dq), ops._p(dkv, d), ops._p(dkv, 2 * d), ops._stream()), 'bwd')
+            finally:
+                ops.set_kernel_timer(None)
+            torch.cuda.synchronize()
+            res[form] = (dq, dkv[..., d:2 * d].clone(), dkv[..., 2 * d:].clone(), dbd)
+        tol = 6e-3 if mode == 'bf16' else 8e-4
+        for nm, a, b in zip(('dq', 'dk', 'dv', 'dbias'), res[1], res[0]):
+            assert torch.isfinite(a.float()).all(), nm
+            assert rel(a, b) < tol, (nm, rel(a, b))
+        assert bool((res[1][3][:, :, :, P:] == 0).all())                                 # the padding of the relative axis is never written
+        # fp32 torch reference of the same 16-bit operands (the shifted matrix gathered explicitly)
+        q = quv.float().view(B, T, H, dk).transpose(1, 2)
+        k = qkv[..., d:2 * d].float().reshape(B, T, H, dk).transpose(1, 2)
+        v = qkv[..., 2 * d:].float().reshape(B, T, H, dk).transpose(1, 2)
+        q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+        i = torch.arange(T, device=DEV).view(T, 1)
+        j = torch.arange(T, device=DEV).view(1, T)
+        col = (j - i + T - 1).view(1, T, 1, T).expand(B, T, H, T)
+        shifted = torch.gather(bd, 3, col).permute(0, 2, 1, 3)                           # [B, H, T(i), T(j)]
+        s = (q @ k.transpose(-1, -2) + shifted) / math.sqrt(dk)
+        s = s.masked_fill(km.view(B, 1, 1, T) == 0, float('-inf'))
+        o = torch.softmax(s, -1) @ v
+        gq, gk, gv = torch.autograd.grad(o, (q, k, v), dout.float().view(B, T, H, dk).transpose(1, 2))
+        live = km.view(B, T, 1).bool()
+        for nm, a, w in (('dq', res[1][0], gq), ('dk', res[1][1], gk), ('dv', res[1][2], gv)):
+            w2 = w.transpose(1, 2).reshape(B, T, d)
+            if nm != 'dq':
+                w2 = w2 * live
+            assert rel(a, w2) < (2e-2 if mode == 'bf16' else 3e-3), (nm, rel(a, w2))
+    finally:
+        L.load().otr_debug_set(33, 1)
+        ops.set_compute_dtype('bf16')
