@@ -196,6 +196,14 @@ __global__ __launch_bounds__(512, 1) void encattn96_bwd_kernel(E9Args p) {
         const uint8_t kmb = km ? km[min(s0 + tid, T - 1)] : (uint8_t)1;
         if (tid < E9_TI) kbias[tid] = (tid < Ts && kmb) ? 0.f : -__builtin_huge_valf();
       }
+      // the tile's score-term columns go out FIRST: the staging, its two barriers and the first products hide their way (loaded at the
+      // head of the tile they were a round trip to L2 on every tile's critical path: 46 -> 4x us per launch)
+      float bz[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const e9_f32x4_a4 v4 = *reinterpret_cast<const e9_f32x4_a4*>(brow + ((p.ablate & 1) ? 0 : cc * 32 + 8 * q + 4 * hi));
+        bz[4 * q] = v4.x; bz[4 * q + 1] = v4.y; bz[4 * q + 2] = v4.z; bz[4 * q + 3] = v4.w;
+      }
       e9_stage_rm<false>(krm, gk, gk, nullptr, Ts, tid, c);
       e9_stage_rm<false>(vrm, gv, gv, nullptr, Ts, tid, c);
       gk = issue(K, p.k_ts, min(cc + 1, nchunk - 1));              // (the last chunk again after the last one: dropped)
@@ -204,13 +212,6 @@ __global__ __launch_bounds__(512, 1) void encattn96_bwd_kernel(E9Args p) {
       e9_transpose(kt, krm, c, tid & 255, 2 * (tid >> 8), 2);
       __syncthreads();
       if (wave_live && !(p.ablate & 4)) {
-        // the tile's score-term columns: out ahead of the products that hide their way
-        float bz[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const e9_f32x4_a4 v4 = *reinterpret_cast<const e9_f32x4_a4*>(brow + ((p.ablate & 1) ? 0 : cc * 32 + 8 * q + 4 * hi));
-          bz[4 * q] = v4.x; bz[4 * q + 1] = v4.y; bz[4 * q + 2] = v4.z; bz[4 * q + 3] = v4.w;
-        }
         const unsigned char* kr = krm + c * 32 * E9_HS;
         const unsigned char* vr = vrm + c * 32 * E9_HS;
         f32x16 st, dp;
@@ -257,20 +258,29 @@ __global__ __launch_bounds__(512, 1) void encattn96_bwd_kernel(E9Args p) {
     const bool keyok = own < T && kmb;
     // -lse and delta of EVERY query first (one pass over dO and O, 16 lanes per row: the loop then carries neither the O pieces nor the
     // butterfly -- in the first version its registers, spilled, were most of the launch)
-    for (int r0 = 0; r0 < T; r0 += 32) {
-      const int row = r0 + (tid >> 4), rowc = min(row, T - 1), ch = tid & 15;
-      float part = 0.f;
-      if (ch < E9_PPR) {
-        const uint4 a = ld_global_b128(dO + (int64_t)rowc * p.o_ts + 8 * ch), c4 = ld_global_b128(O + (int64_t)rowc * p.o_ts + 8 * ch);
-        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, cw[4] = {c4.x, c4.y, c4.z, c4.w};
+    for (int r0 = 0; r0 < T; r0 += 256) {                            // eight 32-row groups per trip, all their loads in flight together
+      uint4 a[8], c4[8];
+      const int ch = min(tid & 15, E9_PPR - 1);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int rowc = min(r0 + 32 * u + (tid >> 4), T - 1);
+        a[u] = ld_global_b128(dO + (int64_t)rowc * p.o_ts + 8 * ch);
+        c4[u] = ld_global_b128(O + (int64_t)rowc * p.o_ts + 8 * ch);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = r0 + 32 * u + (tid >> 4);
+        const uint32_t aw[4] = {a[u].x, a[u].y, a[u].z, a[u].w}, cw[4] = {c4[u].x, c4[u].y, c4[u].z, c4[u].w};
+        float part = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) part += h2f_lo(aw[e]) * h2f_lo(cw[e]) + h2f_hi(aw[e]) * h2f_hi(cw[e]);
+        if ((tid & 15) >= E9_PPR) part = 0.f;
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        part += __shfl_xor(part, 4);
+        part += __shfl_xor(part, 8);
+        if ((tid & 15) == 0 && row < T) dels[row] = part;
       }
-      part += __shfl_xor(part, 1);
-      part += __shfl_xor(part, 2);
-      part += __shfl_xor(part, 4);
-      part += __shfl_xor(part, 8);
-      if (ch == 0 && row < T) dels[row] = part;
     }
     for (int r = tid; r < E9_TMAX; r += 512) {
       const float l0 = lse[min(r, T - 1)];
@@ -285,6 +295,12 @@ __global__ __launch_bounds__(512, 1) void encattn96_bwd_kernel(E9Args p) {
     for (int cc = 0; cc < nchunk; ++cc) {
       const int c = cc & 3, s0 = (cc >> 2) * E9_TI, Ts = min(E9_TI, T - s0);
       if (c == 0 && cc > 0) __syncthreads();                       // every wave is done with the previous super-chunk's images
+      float bz[16];                                                // the tile's score-term entries of this key column (queries clamped into T), out first
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = min(cc * 32 + 8 * (r >> 2) + 4 * hi + (r & 3), T - 1);
+        bz[r] = p.bias[(p.ablate & 1) ? bb : bcol + (int64_t)i * bstep];
+      }
       e9_stage_rm<false>(qrm, gq, gq, nullptr, Ts, tid, c);
       e9_stage_rm<false>(dorm, gdo, gdo, nullptr, Ts, tid, c);
       gq = issue(Q, p.q_ts, min(cc + 1, nchunk - 1));              // (the last chunk again after the last one: dropped)
@@ -294,12 +310,6 @@ __global__ __launch_bounds__(512, 1) void encattn96_bwd_kernel(E9Args p) {
       else e9_transpose(dot, dorm, c, tid - 256, 0, 4);
       __syncthreads();
       if (wave_live && !(p.ablate & 4)) {
-        float bz[16];                                              // the tile's score-term entries of this key column (queries clamped into T)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = min(cc * 32 + 8 * (r >> 2) + 4 * hi + (r & 3), T - 1);
-          bz[r] = p.bias[(p.ablate & 1) ? bb : bcol + (int64_t)i * bstep];
-        }
         const unsigned char* qr = qrm + c * 32 * E9_HS;
         const unsigned char* dr = dorm + c * 32 * E9_HS;
         f32x16 st, dp;
