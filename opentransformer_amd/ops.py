@@ -1041,6 +1041,13 @@ class LinearFn(torch.autograd.Function):
         dy2 = _rows(dy) if dyp16 is None else dyp16
         if ctx.relu:
             dy2 = relu_bwd_raw(y, dy2.contiguous())
+        if (_DY16_WIDE and dyp16 is None and dy2.dtype == torch.float32 and is_half() and ctx.perm is not None and x2.dtype == half_dtype()
+                and dy2.shape[0] >= 1024 and _wq['on'] and _in_backward() and getattr(ctx.w_ref, '_otr_regroup_grad', None) is not None
+                and grad_target(ctx.w_ref) is not None):
+            # r06: an fp32 gradient in front of the frontend's output layer (the Conformer: a LayerNorm sits behind it; C2 gets the 16-bit
+            # operand from PosEncFn) is cast ONCE: the weight gradient then joins the grouped 256-wide launch through the staging image
+            # instead of an fp32-operand GEMM + split-K reduce + a regrouping add (112 us), the input gradient reads 16-bit rows
+            dy2 = cast_bf16(dy2)
         if ctx.pad is not None:
             # the gradient of a row-padded product: when it arrives as the head of a zero-tailed [M, rows8] buffer (the loss
             # kernel wrote it that way), all three GEMMs of this layer run on the padded operands
@@ -2867,6 +2874,7 @@ def _gemm_ptr(kind, M, N, K, x, w, y, bias=None, accumulate=0):
 _GEMM_BATCHED = True
 _BN_PART = True          # ConformerConvFn: BatchNorm batch statistics through per-workgroup sums
 _DW_PART = True      # ConformerConvFn: depthwise-conv parameter gradients through per-workgroup sums
+_DY16_WIDE = True           # LinearFn.backward: cast an fp32 gradient of the frontend's output layer to 16 bits once
 _CONV_MID_FUSED = True      # ConformerConvFn.backward: BatchNorm apply + depthwise conv + GLU backward in one launch
 _POS_DEFER = True      # RelPosAttentionFn: the per-head dp products join the grouped weight-gradient launch
 

@@ -1,5 +1,5 @@
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 1200 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider -k "conformer or attention or relpos or bias or c4" 2>&1 | tail -2
-for i in 1 2; do for v in 33=1; do
-  OTR_DEBUG_SET=$v timeout 300 python bench.py --model conformer --steps 30 --warmup 5 --no-cpu-baseline --no-extras 2>&1 | grep '^{' | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('conformer $v', round(d['value'],1), round(d['ms_per_step'],3))"
+timeout 1200 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider -k "conformer or c4 or frontend" 2>&1 | tail -2
+for i in 1 2; do for v in ops._DY16_WIDE=1 ops._DY16_WIDE=0; do
+  OTR_SWITCHES=$v timeout 300 python bench.py --model conformer --steps 30 --warmup 5 --no-cpu-baseline --no-extras 2>&1 | grep '^{' | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('conformer $v', round(d['value'],1), round(d['ms_per_step'],3))"
 done; done
