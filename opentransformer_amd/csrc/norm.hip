@@ -179,8 +179,12 @@ constexpr int LN_BWD_ROWS = 4;  // rows per wave -> 16 rows per block: 498 block
 // NV = ceil(d / 256): float4 slots per lane actually used (d = 256 -> 1).  Each wave owns LN_BWD_ROWS rows; the loads of
 // ALL of them (dy, z, mean, rstd) are issued back to back before any arithmetic (rows clamped, tails masked), so a
 // wave has 2*LN_BWD_ROWS*NV 16-byte loads in flight instead of walking the rows one dependent round trip at a time.
-template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bounds__(256) void add_ln_bwd_kernel(LnArgs p) {
-  __shared__ float red[2][4][NV * 256];  // [gamma|beta][wave][column]
+// r06: the two- / three-LayerNorm forms (LN2) hold three row sets and six affine vectors per lane: at 4 rows per wave that was 256 registers,
+// ONE wave per SIMD, 38 us for 54 MB (the single-LayerNorm form: 142 registers, 17 us).  They run 8 waves x 2 rows per workgroup -- the same
+// 16 rows per workgroup, so the partial-sum rows the callers allocate do not change.
+template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bounds__(LN2 ? 512 : 256) void add_ln_bwd_kernel(LnArgs p) {
+  constexpr int ROWS = LN2 ? LN_BWD_ROWS / 2 : LN_BWD_ROWS, NWV = LN2 ? 8 : 4, NTH = 64 * NWV;
+  __shared__ float red[2][NWV][NV * 256];  // [gamma|beta][wave][column]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int d = p.d;
   const bool drop = HAS_A && p.p_drop > 0.f;
@@ -215,12 +219,12 @@ template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bo
       if (three) { ld4<float>(p.gamma3 + colv[i], gam3[i]); ld4<float>(p.beta2 + colv[i], bet2[i]); }
     }
   }
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * LN_BWD_ROWS;
-  float dyv[LN_BWD_ROWS][NV][4], zh[LN_BWD_ROWS][NV][4], mean[LN_BWD_ROWS], rstd[LN_BWD_ROWS];
-  float mean2[LN_BWD_ROWS], rstd2[LN_BWD_ROWS], mean3[LN_BWD_ROWS], rstd3[LN_BWD_ROWS];
-  float dy3v[LN2 ? LN_BWD_ROWS : 1][NV][4];
+  const int64_t row0 = ((int64_t)blockIdx.x * NWV + wid) * ROWS;
+  float dyv[ROWS][NV][4], zh[ROWS][NV][4], mean[ROWS], rstd[ROWS];
+  float mean2[ROWS], rstd2[ROWS], mean3[ROWS], rstd3[ROWS];
+  float dy3v[LN2 ? ROWS : 1][NV][4];
 #pragma unroll
-  for (int rr = 0; rr < LN_BWD_ROWS; ++rr) {
+  for (int rr = 0; rr < ROWS; ++rr) {
     const int64_t row = min(row0 + rr, p.M - 1);
     mean[rr] = p.mean[row];
     rstd[rr] = p.rstd[row];
@@ -244,7 +248,7 @@ template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bo
   if constexpr (LN2) {
     // d y2 -> d y1 through the second LayerNorm: y1 = zhat gamma + beta (recomputed), yhat = (y1 - mean2) rstd2
 #pragma unroll
-    for (int rr = 0; rr < LN_BWD_ROWS; ++rr) {
+    for (int rr = 0; rr < ROWS; ++rr) {
       const float rmask = row0 + rr < p.M ? 1.f : 0.f;
       float yh[NV][4], t1 = 0.f, t2 = 0.f;
       if (three) {
@@ -297,7 +301,7 @@ template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bo
     }
   }
 #pragma unroll
-  for (int rr = 0; rr < LN_BWD_ROWS; ++rr) {
+  for (int rr = 0; rr < ROWS; ++rr) {
     const int64_t row = row0 + rr;
     const float rmask = row < p.M ? 1.f : 0.f;
     float s1 = 0.f, s2 = 0.f;
@@ -360,10 +364,16 @@ template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bo
   // partial != NULL: this workgroup's sums go to partial[blockIdx.x][0|1|2][d] (dgamma | dbeta | da column sums) and the
   // caller column-sums the blocks (with everything else, in the grouped launch at the end of backward): no atomics --
   // they were 2.7 of this kernel's 14 us -- and a deterministic result
+  auto rsum = [&](int which, int c) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) a += red[which][w][c];
+    return a;
+  };
   float* prow = p.partial ? p.partial + (int64_t)blockIdx.x * (LN2 ? (three ? 7 : 5) : 3) * d : nullptr;
-  for (int c = threadIdx.x; c < d; c += 256) {
-    float a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-    float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+  for (int c = threadIdx.x; c < d; c += NTH) {
+    float a = rsum(0, c);
+    float b = rsum(1, c);
     if (prow) { prow[c] = a; prow[d + c] = b; }
     else { atomicAdd(p.dgamma + c, a); atomicAdd(p.dbeta + c, b); }
   }
@@ -377,9 +387,9 @@ template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bo
         red[1][wid][(i * 64 + lane) * 4 + e] = db2[i][e];
       }
     __syncthreads();
-    for (int c = threadIdx.x; c < d; c += 256) {
-      prow[3 * d + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-      prow[4 * d + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    for (int c = threadIdx.x; c < d; c += NTH) {
+      prow[3 * d + c] = rsum(0, c);
+      prow[4 * d + c] = rsum(1, c);
     }
     if (three) {                                           // dgamma3 | dbeta3 -> partial columns [5d, 7d)
       __syncthreads();
@@ -391,9 +401,9 @@ template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bo
           red[1][wid][(i * 64 + lane) * 4 + e] = db3[i][e];
         }
       __syncthreads();
-      for (int c = threadIdx.x; c < d; c += 256) {
-        prow[5 * d + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-        prow[6 * d + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+      for (int c = threadIdx.x; c < d; c += NTH) {
+        prow[5 * d + c] = rsum(0, c);
+        prow[6 * d + c] = rsum(1, c);
       }
     }
   }
@@ -406,8 +416,8 @@ template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bo
 #pragma unroll
         for (int e = 0; e < 4; ++e) red[0][wid][(i * 64 + lane) * 4 + e] = dab[i][e];
       __syncthreads();
-      for (int c = threadIdx.x; c < d; c += 256) {
-        const float v = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+      for (int c = threadIdx.x; c < d; c += NTH) {
+        const float v = rsum(0, c);
         if (prow) prow[2 * d + c] = v;
         else atomicAdd(p.da_colsum + c, v);
       }
@@ -518,9 +528,9 @@ extern "C" int32_t otr_add_layernorm2_bwd(const otr_ln_desc_t* d, const float* d
   hipStream_t s = (hipStream_t)stream;
 #define LN2_BWD_LAUNCH(NV)                                                                                        \
   {                                                                                                               \
-    if (!da) hipLaunchKernelGGL((add_ln_bwd_kernel<float, false, NV, true>), grid, dim3(256), 0, s, p);           \
-    else if (d->a_dtype == OTR_F32) hipLaunchKernelGGL((add_ln_bwd_kernel<float, true, NV, true>), grid, dim3(256), 0, s, p); \
-    else hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t, true, NV, true>), grid, dim3(256), 0, s, p);               \
+    if (!da) hipLaunchKernelGGL((add_ln_bwd_kernel<float, false, NV, true>), grid, dim3(512), 0, s, p);           \
+    else if (d->a_dtype == OTR_F32) hipLaunchKernelGGL((add_ln_bwd_kernel<float, true, NV, true>), grid, dim3(512), 0, s, p); \
+    else hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t, true, NV, true>), grid, dim3(512), 0, s, p);               \
   }
   const int nv = (d->d + 255) / 256;
   if (nv == 1) LN2_BWD_LAUNCH(1) else if (nv == 2) LN2_BWD_LAUNCH(2) else if (nv == 3) LN2_BWD_LAUNCH(3) else LN2_BWD_LAUNCH(4)
@@ -576,9 +586,9 @@ extern "C" int32_t otr_add_layernorm3_bwd(const otr_ln_desc_t* d, const float* d
   hipStream_t s = (hipStream_t)stream;
 #define LN3_BWD_LAUNCH(NV)                                                                                        \
   {                                                                                                               \
-    if (!da) hipLaunchKernelGGL((add_ln_bwd_kernel<float, false, NV, true>), grid, dim3(256), 0, s, p);           \
-    else if (d->a_dtype == OTR_F32) hipLaunchKernelGGL((add_ln_bwd_kernel<float, true, NV, true>), grid, dim3(256), 0, s, p); \
-    else hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t, true, NV, true>), grid, dim3(256), 0, s, p);               \
+    if (!da) hipLaunchKernelGGL((add_ln_bwd_kernel<float, false, NV, true>), grid, dim3(512), 0, s, p);           \
+    else if (d->a_dtype == OTR_F32) hipLaunchKernelGGL((add_ln_bwd_kernel<float, true, NV, true>), grid, dim3(512), 0, s, p); \
+    else hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t, true, NV, true>), grid, dim3(512), 0, s, p);               \
   }
   const int nv = (d->d + 255) / 256;
   if (nv == 1) LN3_BWD_LAUNCH(1) else if (nv == 2) LN3_BWD_LAUNCH(2) else if (nv == 3) LN3_BWD_LAUNCH(3) else LN3_BWD_LAUNCH(4)
