@@ -182,8 +182,8 @@ constexpr int LN_BWD_ROWS = 4;  // rows per wave -> 16 rows per block: 498 block
 // r06: the two- / three-LayerNorm forms (LN2) hold three row sets and six affine vectors per lane: at 4 rows per wave that was 256 registers,
 // ONE wave per SIMD, 38 us for 54 MB (the single-LayerNorm form: 142 registers, 17 us).  They run 8 waves x 2 rows per workgroup -- the same
 // 16 rows per workgroup, so the partial-sum rows the callers allocate do not change.
-template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bounds__(LN2 ? 512 : 256) void add_ln_bwd_kernel(LnArgs p) {
-  constexpr int ROWS = LN2 ? LN_BWD_ROWS / 2 : LN_BWD_ROWS, NWV = LN2 ? 8 : 4, NTH = 64 * NWV;
+template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bounds__(512) void add_ln_bwd_kernel(LnArgs p) {
+  constexpr int ROWS = LN_BWD_ROWS / 2, NWV = 8, NTH = 64 * NWV;
   __shared__ float red[2][NWV][NV * 256];  // [gamma|beta][wave][column]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int d = p.d;
@@ -478,9 +478,9 @@ extern "C" int32_t otr_add_layernorm_bwd_skip(const otr_ln_desc_t* d, const floa
   hipStream_t s = (hipStream_t)stream;
 #define LN_BWD_LAUNCH(NV)                                                                                   \
   {                                                                                                         \
-    if (!da) hipLaunchKernelGGL((add_ln_bwd_kernel<float, false, NV>), grid, dim3(256), 0, s, p);           \
-    else if (d->a_dtype == OTR_F32) hipLaunchKernelGGL((add_ln_bwd_kernel<float, true, NV>), grid, dim3(256), 0, s, p); \
-    else hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t, true, NV>), grid, dim3(256), 0, s, p);               \
+    if (!da) hipLaunchKernelGGL((add_ln_bwd_kernel<float, false, NV>), grid, dim3(512), 0, s, p);           \
+    else if (d->a_dtype == OTR_F32) hipLaunchKernelGGL((add_ln_bwd_kernel<float, true, NV>), grid, dim3(512), 0, s, p); \
+    else hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t, true, NV>), grid, dim3(512), 0, s, p);               \
   }
   const int nv = (d->d + 255) / 256;
   if (nv == 1) LN_BWD_LAUNCH(1) else if (nv == 2) LN_BWD_LAUNCH(2) else if (nv == 3) LN_BWD_LAUNCH(3) else LN_BWD_LAUNCH(4)
