@@ -173,17 +173,16 @@ template <class AT, bool HAS_A, bool LN2 = false> __global__ __launch_bounds__(2
   if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
 }
 
-constexpr int LN_BWD_ROWS = 4;  // rows per wave -> 16 rows per block: 498 blocks at M = 7968 (8 rows per wave left one 4-wave block per CU:
-                                // too few loads in flight for an HBM-bound kernel; the affine-gradient partials are summed by the grouped column sums)
+constexpr int LN_BWD_ROWS = 4;  // (rounds 1-5: rows per wave of a 4-wave workgroup; the workgroup's row count below is derived from it)
 
-// NV = ceil(d / 256): float4 slots per lane actually used (d = 256 -> 1).  Each wave owns LN_BWD_ROWS rows; the loads of
-// ALL of them (dy, z, mean, rstd) are issued back to back before any arithmetic (rows clamped, tails masked), so a
-// wave has 2*LN_BWD_ROWS*NV 16-byte loads in flight instead of walking the rows one dependent round trip at a time.
-// r06: the two- / three-LayerNorm forms (LN2) hold three row sets and six affine vectors per lane: at 4 rows per wave that was 256 registers,
-// ONE wave per SIMD, 38 us for 54 MB (the single-LayerNorm form: 142 registers, 17 us).  They run 8 waves x 2 rows per workgroup -- the same
-// 16 rows per workgroup, so the partial-sum rows the callers allocate do not change.
+// NV = ceil(d / 256): float4 slots per lane actually used (d = 256 -> 1).  The loads of a row (dy, z, mean, rstd -- and d y3 in the
+// three-LayerNorm form) are issued back to back before any arithmetic (rows clamped, tails masked).
+// r06: a workgroup is 8 waves x ONE row (it was 4 waves x 4 rows).  The kernel is an HBM stream whose only latency hiding is the number of
+// waves in flight, and the row sets live in registers: at 4 rows per wave the three-LayerNorm form held 256 registers -- one wave per
+// SIMD, 38 us for 54 MB -- and the single form 142 (17 us for 48 MB).  2 rows: 190 / ~100 registers, Conformer step 9.82 -> 9.51 ms, C2
+// 3.99 -> 3.93 ms; 1 row: 9.46 ms (the per-workgroup partial sums of the affine gradients double in number: 996 rows at M = 7968).
 template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bounds__(512) void add_ln_bwd_kernel(LnArgs p) {
-  constexpr int ROWS = LN_BWD_ROWS / 2, NWV = 8, NTH = 64 * NWV;
+  constexpr int ROWS = 1, NWV = 8, NTH = 64 * NWV;
   __shared__ float red[2][NWV][NV * 256];  // [gamma|beta][wave][column]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int d = p.d;
@@ -474,7 +473,7 @@ extern "C" int32_t otr_add_layernorm_bwd_skip(const otr_ln_desc_t* d, const floa
   p.seed = seed; p.skip = skip; p.dx = dx; p.da = da; p.dgamma = dgamma; p.dbeta = dbeta; p.da_colsum = da ? da_colsum : nullptr; p.partial = partial;
   p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
   p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale; p.amask = d->a_row_mask;
-  dim3 grid((unsigned)((d->M + 4 * LN_BWD_ROWS - 1) / (4 * LN_BWD_ROWS)));
+  dim3 grid((unsigned)((d->M + 2 * LN_BWD_ROWS - 1) / (2 * LN_BWD_ROWS)));
   hipStream_t s = (hipStream_t)stream;
 #define LN_BWD_LAUNCH(NV)                                                                                   \
   {                                                                                                         \
@@ -524,7 +523,7 @@ extern "C" int32_t otr_add_layernorm2_bwd(const otr_ln_desc_t* d, const float* d
   p.seed = seed; p.skip = skip; p.dx = dx; p.da = da; p.partial = partial;
   p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
   p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale; p.amask = d->a_row_mask;
-  dim3 grid((unsigned)((d->M + 4 * LN_BWD_ROWS - 1) / (4 * LN_BWD_ROWS)));
+  dim3 grid((unsigned)((d->M + 2 * LN_BWD_ROWS - 1) / (2 * LN_BWD_ROWS)));
   hipStream_t s = (hipStream_t)stream;
 #define LN2_BWD_LAUNCH(NV)                                                                                        \
   {                                                                                                               \
@@ -582,7 +581,7 @@ extern "C" int32_t otr_add_layernorm3_bwd(const otr_ln_desc_t* d, const float* d
   p.seed = seed; p.skip = skip; p.dx = dx; p.da = da; p.partial = partial;
   p.M = d->M; p.d = d->d; p.eps = d->eps; p.p_drop = d->p_drop; p.rng_offset = d->rng_offset;
   p.a_scale = d->a_scale == 0.f ? 1.f : d->a_scale; p.amask = d->a_row_mask;
-  dim3 grid((unsigned)((d->M + 4 * LN_BWD_ROWS - 1) / (4 * LN_BWD_ROWS)));
+  dim3 grid((unsigned)((d->M + 2 * LN_BWD_ROWS - 1) / (2 * LN_BWD_ROWS)));
   hipStream_t s = (hipStream_t)stream;
 #define LN3_BWD_LAUNCH(NV)                                                                                        \
   {                                                                                                               \
@@ -597,4 +596,4 @@ extern "C" int32_t otr_add_layernorm3_bwd(const otr_ln_desc_t* d, const float* d
 }
 
 // rows of the `partial` buffer of otr_add_layernorm_bwd for M input rows
-extern "C" int64_t otr_add_layernorm_bwd_partial_rows(int64_t M) { return (M + 4 * LN_BWD_ROWS - 1) / (4 * LN_BWD_ROWS); }
+extern "C" int64_t otr_add_layernorm_bwd_partial_rows(int64_t M) { return (M + 2 * LN_BWD_ROWS - 1) / (2 * LN_BWD_ROWS); }
