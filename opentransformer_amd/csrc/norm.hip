@@ -179,8 +179,8 @@ constexpr int LN_BWD_ROWS = 4;  // (rounds 1-5: rows per wave of a 4-wave workgr
 // three-LayerNorm form) are issued back to back before any arithmetic (rows clamped, tails masked).
 // r06: a workgroup is 8 waves x ONE row (it was 4 waves x 4 rows).  The kernel is an HBM stream whose only latency hiding is the number of
 // waves in flight, and the row sets live in registers: at 4 rows per wave the three-LayerNorm form held 256 registers -- one wave per
-// SIMD, 38 us for 54 MB -- and the single form 142 (17 us for 48 MB).  2 rows: 190 / ~100 registers, Conformer step 9.82 -> 9.51 ms, C2
-// 3.99 -> 3.93 ms; 1 row: 9.46 ms (the per-workgroup partial sums of the affine gradients double in number: 996 rows at M = 7968).
+// SIMD, 38 us for 54 MB -- and the single form 142 (17 us for 48 MB).  2 rows: 190 / ~100 registers, Conformer step 9.82 -> 9.51 ms;
+// 1 row: 9.46 ms, C2 (one launch of this kernel per step) unchanged (the per-workgroup partial sums of the affine gradients double in number: 996 rows at M = 7968).
 template <class AT, bool HAS_A, int NV, bool LN2 = false> __global__ __launch_bounds__(512) void add_ln_bwd_kernel(LnArgs p) {
   constexpr int ROWS = 1, NWV = 8, NTH = 64 * NWV;
   __shared__ float red[2][NWV][NV * 256];  // [gamma|beta][wave][column]
