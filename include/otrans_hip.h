@@ -58,7 +58,15 @@ int32_t otr_half_type(void);
  * forward on the VALU stencil for every shape (default: the fp32 matrix pipe for 64 channels and 16-bit activations), key 18 = 0:
  * the 768-column row-block projection on one workgroup per row block (default: two, 384 columns each), key 19 = 0: 4-wave workgroups
  * for the 256-column row-block kernels (default: 8 waves), key 20 = 0: 4-wave (64 queries / keys) workgroups for the attention launches
- * (default: 8 waves, 128 queries / keys, for aligned 16-bit operands with head dim 64) */
+ * (default: 8 waves, 128 queries / keys, for aligned 16-bit operands with head dim 64), key 21 = 0: the streamed attention backward instead of
+ * csrc/encattn.hip, key 22 = conv2 forward on the weight-stationary kernel (1) or the implicit GEMM (0), key 23 = utterances per workgroup of
+ * the fused decoder launches (0 = the library's choice), key 24 / 25 = forms of the cached decode self-attention / the beam top-k (25 = 2: the
+ * arg-max rounds), key 26 = 0: natural GEMM tile order, key 27 = 0: scalar loads of the relative-position score term, key 28 = resident
+ * workgroups of the persistent 64 x 64-tile GEMM (1024; 512 = round 5), key 29 = 0: conv2's weight gradient of a 256-channel frontend on the
+ * transposing GEMM instead of the gathered-row form of wgrad256.hip, key 30 = 0: no sliced parity-class input gradient for 256 output channels,
+ * key 31 = 0: otr_conv2_dgrad_wide answers "not served", key 32 = ablation bits of csrc/conv2wide.hip (1 no MFMAs, 2 one fragment read per chunk,
+ * 4 no weight DMA, 8 no row reloads), key 33 = csrc/encattn96.hip: bit 0 = it serves (0: the streamed dQ + dK/dV pair), bits 1-3 = its ablations
+ * (2 no score-term loads, 4 no d bias stores, 8 no tiles).  Ablations are for timing only: results are garbage. */
 int32_t otr_debug_set(int32_t key, int32_t value);
 /* Register the caller-owned, zero-initialised DEVICE word that spin-bounded kernels (the turnstile of the 256-wide
  * weight-gradient launch; NULL = none) add 1 to whenever a wait gives up -- the results of such a launch may be wrong sums.
