@@ -43,6 +43,7 @@ int g_otr_bias_vec4 = 1;           // attention.hip: relative-position score bia
 int g_otr_gemm_resident64 = 1024;   // gemm_kernel.h: resident workgroups of the persistent 64 x 64-tile GEMM (otr_debug_set(28, v); 512 = r05)
 int g_otr_conv2_wgrad256 = 1;       // conv2 weight gradient of a C1 % 256 == 0 frontend on wgrad256.hip's gather form (otr_debug_set(29, 0) = the transposing GEMM)
 int g_otr_attn_enc96 = 1;          // encattn96.hip: the Conformer's attention backward on the whole-utterance kernel (otr_debug_set(33, 0) = the streamed dQ / dK,dV pair)
+int g_otr_im2k_fast = 1;            // gemm_kernel.h TileLoader RAWK (otr_debug_set(34, 0) = the bounds-checked loader)
 int g_otr_force_generic = 0;
 int g_otr_no_persist = 0;
 int g_otr_ffn2_ablate = 0;   // tuning hook (otr_debug_set(4, v)): bit 0 = no weight DMA after the first chunk, bit 1 = no MFMA work
@@ -81,6 +82,7 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   else if (key == 31) g_otr_conv2_wide = value;
   else if (key == 32) g_otr_conv2wide_ablate = value;
   else if (key == 33) g_otr_attn_enc96 = value;
+  else if (key == 34) g_otr_im2k_fast = value;
   else if (key == 28) g_otr_gemm_resident64 = value > 0 ? value : 512;
   else if (key == 2) g_otr_force_generic = value;
   else if (key == 3) g_otr_no_persist = value;

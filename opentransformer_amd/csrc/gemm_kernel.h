@@ -134,7 +134,10 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
   // the frequency tap kept as one bit per contraction index and applied with the transposition
   static constexpr bool RAWI = (MODE == MODE_IM2M) && FAST && std::is_same<ST, CT>::value && sizeof(CT) == 2;
   // prefetch ring: FAST raw loaders keep DEPTH stages in registers (a 3-slot ring spilled: 96 VGPRs + 64 accumulators)
-  static constexpr int DEPTH = ((RAWQ && FAST && MODE == MODE_KC) || RAWT || RAWI) ? 2 : 1;
+  // implicit-im2col rows of the conv2 FORWARD (r06): the (pixel, tap) chunk is loaded unconditionally from a clamped address and its validity
+  // (row in range, frequency tap not padding, k inside K) kept as one bit per unit, applied when the chunk is written to LDS
+  static constexpr bool RAWK = (MODE == MODE_IM2K) && FAST && RAWQ && sizeof(CT) == 2;
+  static constexpr int DEPTH = ((RAWQ && FAST && MODE == MODE_KC) || RAWT || RAWI || RAWK) ? 2 : 1;
   // every thread owns a full set of units (true for all tile shapes instantiated): lets stores/loads drop the
   // per-unit activity test the compiler cannot fold (it does not know threadIdx.x < 256)
   static constexpr bool ALLACTIVE = ROWMAJOR ? ((ROWS * KCH) % 256 == 0) : ((RG * KCH) % 256 == 0);
@@ -149,6 +152,7 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
   float raw[(RAWQ || RAWT || RAWI) ? 1 : (ROWMAJOR ? NU : NP * PM)][CE];
   uint4 rawq[RAWQ ? DEPTH : 1][RAWQ ? NU : 1];
   uint2 rawt[(RAWT || RAWI) ? DEPTH : 1][(RAWT || RAWI) ? NP : 1][(RAWT || RAWI) ? CE : 1];
+  uint32_t okb[RAWK ? DEPTH : 1];                     // RAWK: bit u = unit u of the stage is a real element
   uint32_t vbits[RAWI ? DEPTH : 1][RAWI ? NP : 1];   // RAWI: bit j = contraction index j of the patch is a real (unpadded) tap
   // im2col state
   int64_t pix[ROWMAJOR ? NU : 1];
@@ -189,6 +193,7 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         int row = row0 + (tid + 256 * u) / KCH;
+        f2v[u] = 0;
         pix[u] = (row < nrows) ? im2col_base(g, (uint32_t)row, f2v[u]) : 0;
       }
     }
@@ -209,7 +214,22 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
 
   // issue the global loads for the stage starting at k0 into ring slot SLOT (compile-time)
   template <int SLOT = 0> __device__ __forceinline__ void load(int k0, const ConvGeom& g, int tid) {
-    if constexpr (MODE == MODE_KC && FAST) {
+    if constexpr (RAWK) {
+      uint32_t bits = 0;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int id = tid + 256 * u, row = row0 + id / KCH, gk = k0 + (id % KCH) * CE;
+        const int gkc = gk & (int)((uint32_t)0 - (uint32_t)(gk < K));          // K % CE == 0 and C1 % CE == 0 (host): a chunk is one tap's
+        const uint32_t tap = fdiv((uint32_t)gkc, g.divC1);
+        const int ch = gkc - (int)tap * g.C1, kh = (int)tap / 3, kw = (int)tap - kh * 3;
+        const int fin = 2 * f2v[u] + kw - 1;
+        const bool ok = row < nrows && gk < K && fin >= 0 && fin < g.F1;
+        const int64_t off = min(max(pix[u] + (int64_t)(kh * g.F1 + kw) * g.C1 + ch, (int64_t)0), g.a1_elems - CE);
+        rawq[SLOT][u] = ld_global_b128(base + off);
+        bits |= (uint32_t)ok << u;
+      }
+      okb[SLOT] = bits;
+    } else if constexpr (MODE == MODE_KC && FAST) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         const int gk = k0 + ((tid + 256 * u) % KCH) * CE;
@@ -385,6 +405,10 @@ template <class CT, class ST, int MODE, int ROWS, bool FAST> struct TileLoader {
             q = rawq[SLOT][u];
             if constexpr (FAST && MODE == MODE_KC) {
               const uint32_t m = (uint32_t)0 - (uint32_t)(k0 + c * CE < K);
+              q = make_uint4(q.x & m, q.y & m, q.z & m, q.w & m);
+            }
+            if constexpr (RAWK) {
+              const uint32_t m = (uint32_t)0 - ((okb[SLOT] >> u) & 1u);
               q = make_uint4(q.x & m, q.y & m, q.z & m, q.w & m);
             }
           } else q = MMA<CT>::pack(raw[u]);
@@ -1055,6 +1079,7 @@ extern int g_otr_force_ksplit;  // 0 = heuristic, n = forced                  (o
 extern int g_otr_force_generic; // 1 = never use the branch-free FAST loaders  (otr_debug_set(2, v))
 extern int g_otr_no_persist;    // 1 = one workgroup per tile even without split-K (otr_debug_set(3, v))
 extern int g_otr_gemm_resident64;      // api.hip (otr_debug_set(28, v))
+extern int g_otr_im2k_fast;            // api.hip (otr_debug_set(34, v)): conv2 forward's implicit-im2col loader on unconditional loads
 constexpr int OTR_RESIDENT_WG = 512;   // 256 CUs x 2 workgroups (launch_bounds(256, 2), 64 KB LDS each)
 
 template <class CT, class AT, class BT, class OT, int AMODE, int BMODE>
@@ -1129,12 +1154,15 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
   auto side_fast = [&](int mode, int vec, int rows) {
     if (mode == MODE_KC) return vec && (a.K % CE == 0) && rows > 0;
     if (mode == MODE_MC) return vec && (rows % PM == 0) && (a.K % CE == 0);
+    if (mode == MODE_IM2K)   // raw 16-bit path only (same-type operands); rows = output pixels: any count
+      return sizeof(CT) == 2 && std::is_same<AT, CT>::value && vec && (a.K % CE == 0) && (a.cg.C1 % CE == 0) && a.cg.a1_elems >= CE && rows > 0 &&
+             g_otr_im2k_fast != 0;
     if (mode == MODE_IM2M)   // raw bf16 path only (same-type operands)
       return sizeof(CT) == 2 && std::is_same<BT, CT>::value && vec && (rows % PM == 0) && (a.K % CE == 0) && (a.cg.C1 % PM == 0) &&
              a.cg.a1_elems >= PM;
     return false;
   };
-  const bool fast = (AMODE == MODE_KC || AMODE == MODE_MC) && (BMODE == MODE_KC || BMODE == MODE_MC || BMODE == MODE_IM2M) &&
+  const bool fast = (AMODE == MODE_KC || AMODE == MODE_MC || AMODE == MODE_IM2K) && (BMODE == MODE_KC || BMODE == MODE_MC || BMODE == MODE_IM2M) &&
                     side_fast(AMODE, a.a_vec, a.M) && side_fast(BMODE, a.b_vec, a.N) && g_otr_force_generic == 0 &&
                     (a.ksplit > 1 ||          // split-K slabs go to the workspace; C is written by the reduce kernel
                      (((uintptr_t)a.C % 16 == 0) && (a.ldc % (16 / (int)sizeof(OT)) == 0) && !(a.accumulate && sizeof(OT) == 2)));
@@ -1169,7 +1197,7 @@ static int32_t gemm_launch_tiles(GemmArgs a, hipStream_t s) {
       return -1;
     }
   }
-  if constexpr (AMODE == MODE_KC || AMODE == MODE_MC) {
+  if constexpr (AMODE == MODE_KC || AMODE == MODE_MC || (AMODE == MODE_IM2K && sizeof(CT) == 2 && std::is_same<AT, CT>::value)) {
     if constexpr (BMODE == MODE_KC || BMODE == MODE_MC || BMODE == MODE_IM2M) {
       if (fast && persist) {
         if constexpr (CAN_PERSIST) {
