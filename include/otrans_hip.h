@@ -66,7 +66,8 @@ int32_t otr_half_type(void);
  * transposing GEMM instead of the gathered-row form of wgrad256.hip, key 30 = 0: no sliced parity-class input gradient for 256 output channels,
  * key 31 = 0: otr_conv2_dgrad_wide answers "not served", key 32 = ablation bits of csrc/conv2wide.hip (1 no MFMAs, 2 one fragment read per chunk,
  * 4 no weight DMA, 8 no row reloads), key 33 = csrc/encattn96.hip: bit 0 = it serves (0: the streamed dQ + dK/dV pair), bits 1-3 = its ablations
- * (2 no score-term loads, 4 no d bias stores, 8 no tiles), key 34 = 0: conv2 forward's implicit-im2col operand on the bounds-checked loader.
+ * (2 no score-term loads, 4 no d bias stores, 8 no tiles), key 34 = 0: conv2 forward's implicit-im2col operand on the bounds-checked loader, key 37 = the narrowest x operand the 256-wide weight-gradient
+ * launch takes (96; 128 = round 5).
  * Ablations are for timing only: results are garbage. */
 int32_t otr_debug_set(int32_t key, int32_t value);
 /* Register the caller-owned, zero-initialised DEVICE word that spin-bounded kernels (the turnstile of the 256-wide

@@ -49,6 +49,7 @@ int g_otr_no_persist = 0;
 int g_otr_ffn2_ablate = 0;   // tuning hook (otr_debug_set(4, v)): bit 0 = no weight DMA after the first chunk, bit 1 = no MFMA work
 int g_otr_wgrad256 = -1;     // 256x256-tile weight-gradient launch (wgrad256.hip): -1 = environment OTR_WGRAD256 (default on), 0 / 1 (otr_debug_set(6, v))
 int g_otr_wgrad256_ablate = 0;   // tuning hook (otr_debug_set(8, v)), see wgrad256.h
+int g_otr_wgrad256_min_k = 96;      // narrowest x operand the 256-wide launch takes (otr_debug_set(37, v); 128 = round 5: the relative-position attention's 504 x 96 products then stay on the 128-wide grouped kernel)
 int g_otr_wgrad256_min_rows = 256;   // shortest contraction the 256-wide launch takes (otr_debug_set(9, v))
 extern int g_otr_conv2_dgrad_ablate;   // conv.hip (otr_debug_set(10, v))
 extern int g_otr_conv2_dgrad_wide;     // conv.hip (otr_debug_set(30, v))
@@ -83,6 +84,7 @@ extern "C" int32_t otr_debug_set(int32_t key, int32_t value) {
   else if (key == 32) g_otr_conv2wide_ablate = value;
   else if (key == 33) g_otr_attn_enc96 = value;
   else if (key == 34) g_otr_im2k_fast = value;
+  else if (key == 37) g_otr_wgrad256_min_k = value > 0 ? value : 96;
   else if (key == 28) g_otr_gemm_resident64 = value > 0 ? value : 512;
   else if (key == 2) g_otr_force_generic = value;
   else if (key == 3) g_otr_no_persist = value;
@@ -281,7 +283,7 @@ extern "C" int32_t otr_ffn_glu_bwd(const void* dy, int32_t dy_dtype, int64_t ldy
 // the problems the 256-wide launch takes: long contraction, 16-bit operands in 16-byte aligned rows, a few tiles at least
 static bool wgrad256_ok(const otr_wgrad_item_t& it, int compute) {
   return compute == OTR_H16 && it.dy && it.x && it.dw && it.dy_dtype == OTR_H16 && it.x_dtype == OTR_H16 && it.M >= g_otr_wgrad256_min_rows && it.N >= 128 &&
-         it.K >= 128 && it.N % 8 == 0 && it.K % 8 == 0 && it.ldy >= it.N && it.ldx >= it.K && it.ldw >= it.K && it.ldy % 8 == 0 &&
+         it.K >= g_otr_wgrad256_min_k && it.N % 8 == 0 && it.K % 8 == 0 && it.ldy >= it.N && it.ldx >= it.K && it.ldw >= it.K && it.ldy % 8 == 0 &&
          it.ldx % 8 == 0 && it.ldw % 4 == 0 && (uintptr_t)it.dy % 16 == 0 && (uintptr_t)it.x % 16 == 0 && (uintptr_t)it.dw % 16 == 0 &&
          it.ldy < (1ll << 24) && it.ldx < (1ll << 24) && (int64_t)(it.N + 256) * it.ldw * 4 < (1ll << 31) &&
          (!it.dbias || (uintptr_t)it.dbias % 4 == 0);
@@ -316,12 +318,18 @@ extern "C" int32_t otr_linear_wgrad_grouped(const otr_wgrad_item_t* items, int32
       const bool ok = wgrad256_ok(it, compute);
       if (ok) idx.push_back(i);
     }
-    // longest contraction first; problems of equal row count share a launch (its rounds schedule needs tiles of one length)
-    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return items[a].M > items[b].M; });
+    // longest contraction first; problems of equal row count share a launch (its rounds schedule needs tiles of one length).  Narrow
+    // problems (K < 128: a 256-column tile of theirs is mostly zero lines) go behind the wide ones of their row count and into launches of
+    // their own: mixed in, they would push wide problems over the table's 56 entries into a small, badly filled tail launch
+    auto narrow = [&](int a) { return items[a].K < 128 ? 1 : 0; };
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+      if (items[a].M != items[b].M) return items[a].M > items[b].M;
+      return narrow(a) < narrow(b);
+    });
     size_t c0 = 0;
     while (c0 < idx.size()) {
       size_t c1 = c0;
-      while (c1 < idx.size() && c1 - c0 < (size_t)W256_MAX_PROBS && items[idx[c1]].M == items[idx[c0]].M) ++c1;
+      while (c1 < idx.size() && c1 - c0 < (size_t)W256_MAX_PROBS && items[idx[c1]].M == items[idx[c0]].M && narrow(idx[c1]) == narrow(idx[c0])) ++c1;
       big.clear();
       for (size_t c = c0; c < c1; ++c) {
         const otr_wgrad_item_t& it = items[idx[c]];
