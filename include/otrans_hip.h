@@ -561,6 +561,12 @@ int32_t otr_regroup_add(float* dst, float* src, int64_t rows, int32_t C, int32_t
 /* out[r, :cols] = a[r, :cols] + b[r, :cols] with independent leading dimensions */
 int32_t otr_add2_strided(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int32_t dtype,
                          int64_t M, int32_t cols, void* stream);
+/* r06: the same sum with the column sums of a and of b left as per-workgroup partials, partial [otr_add2_colsum_partial_rows(M)][2 cols] f32
+ * (a's sums, then b's): d(q+u) + d(q+v) -> the packed qkv gradient, and the gradients of pos_bias_u / pos_bias_v (module/attention.py:241-245)
+ * without a second pass over the two operands. */
+int64_t otr_add2_colsum_partial_rows(int64_t M);
+int32_t otr_add2_strided_colsum(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int32_t dtype, int64_t M,
+                                int32_t cols, float* partial, void* stream);
 /* out = x where mask[row] else 0 (f32) */
 int32_t otr_row_mask(const float* x, const uint8_t* mask, float* out, int64_t M, int32_t C, void* stream);
 /* the same with a type change on the way (OTR_F32 / OTR_H16 either side): the Conformer convolution module hands its

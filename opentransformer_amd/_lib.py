@@ -209,6 +209,8 @@ SIGNATURES = {
     'otr_dropout': [_P, _P, _I32, _I64, _F32, _P, C.c_uint64, _P],
     'otr_head_bias_add': [_P, _I64, _P, _P, _P, _I32, _I64, _I32, _P],
     'otr_add2_strided': [_P, _I64, _P, _I64, _P, _I64, _I32, _I64, _I32, _P],
+    'otr_add2_colsum_partial_rows': [_I64],
+    'otr_add2_strided_colsum': [_P, _I64, _P, _I64, _P, _I64, _I32, _I64, _I32, _P, _P],
     'otr_regroup_add': [_P, _P, _I64, _I32, _I32, _I32, _P],
     'otr_row_mask': [_P, _P, _P, _I64, _I32, _P],
     'otr_row_mask_cast': [_P, _I32, _P, _P, _I32, _I64, _I32, _P],
@@ -228,7 +230,7 @@ SIGNATURES = {
 _RESTYPE = {'otr_last_error_string': C.c_char_p, 'otr_dec_ffn_hsave_bytes': C.c_int64, 'otr_ffn_split_scratch_bytes': C.c_int64, 'otr_ffn_split_sync_ints': C.c_int64, 'otr_ffn_split_hsave_bytes': C.c_int64,
             'otr_ffn_split_padded_rows': C.c_int64, 'otr_add_layernorm_bwd_partial_rows': C.c_int64,
             'otr_ln_bwd_proj_partial_rows': C.c_int64, 'otr_dwconv_bwd_partial_rows': C.c_int64, 'otr_dwconv_fwd_partial_rows': C.c_int64,
-            'otr_conv2_wide_scratch_bytes': C.c_int64}
+            'otr_conv2_wide_scratch_bytes': C.c_int64, 'otr_add2_colsum_partial_rows': C.c_int64}
 
 _libs = {}
 _kind = 'bf16'

@@ -10,6 +10,8 @@
 // thread over a strip of rows and merged with one fp32 atomic per (workgroup, channel).
 #include "common.h"
 
+#include <algorithm>
+
 
 template <class T> __device__ __forceinline__ void ldc4(const T* p, float* o) { load_row<T, 4>(p, 4, true, o); }
 template <class T> __device__ __forceinline__ void stc4(T* p, const float* o) {
@@ -161,6 +163,62 @@ extern "C" int32_t otr_add2_strided(const void* a, int64_t lda, const void* b, i
   if (dtype == OTR_F32) hipLaunchKernelGGL(add2_kernel<float>, dim3(ew_grid(M * cols / 4)), dim3(256), 0, s, (const float*)a, lda, (const float*)b, ldb, (float*)out, ldo, M, cols);
   else hipLaunchKernelGGL(add2_kernel<bf16_t>, dim3(ew_grid(M * cols / 4)), dim3(256), 0, s, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)out, ldo, M, cols);
   return otr_check_launch("add2_strided");
+}
+
+// The same with the column sums of a and of b left as per-workgroup partials [blocks][2 cols] (r06: d(q+u) + d(q+v) of the relative-position
+// attention is the sum the packed qkv gradient needs, and the column sums of the two addends are the gradients of pos_bias_u / pos_bias_v
+// (module/attention.py:241-245): a separate column-sum pass re-read both, 147 MB per step).  A workgroup owns A2_RPB rows; thread
+// (row phase, 4 columns) walks its rows, four loads of each operand in flight.
+constexpr int A2_RPB = 32;
+template <class T> __global__ __launch_bounds__(256) void add2_colsum_kernel(const T* a, int64_t lda, const T* b, int64_t ldb, T* out, int64_t ldo,
+                                                                            int64_t M, int cols, float* partial, int NY) {
+  extern __shared__ float a2_red[];                       // [NY][2 cols]
+  const int c4 = cols / 4, cg = threadIdx.x % c4, ty = threadIdx.x / c4, c = cg * 4;
+  const int64_t r0 = (int64_t)blockIdx.x * A2_RPB, r1 = min(M, r0 + A2_RPB);
+  float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ty < NY) {
+    for (int64_t base = r0 + ty; base < r1; base += 4 * NY) {
+      float x[4][4], y[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t row = min(base + (int64_t)u * NY, r1 - 1);
+        ldc4<T>(a + row * lda + c, x[u]);
+        ldc4<T>(b + row * ldb + c, y[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t row = base + (int64_t)u * NY;
+        if (row < r1) {
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sa[e] += x[u][e]; sb[e] += y[u][e]; o[e] = x[u][e] + y[u][e]; }
+          stc4<T>(out + row * ldo + c, o);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a2_red[ty * 2 * cols + c + e] = sa[e]; a2_red[ty * 2 * cols + cols + c + e] = sb[e]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * cols; i += 256) {
+    float v = 0.f;
+    for (int y = 0; y < NY; ++y) v += a2_red[y * 2 * cols + i];
+    partial[(int64_t)blockIdx.x * 2 * cols + i] = v;
+  }
+}
+extern "C" int64_t otr_add2_colsum_partial_rows(int64_t M) { return (M + A2_RPB - 1) / A2_RPB; }
+extern "C" int32_t otr_add2_strided_colsum(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int32_t dtype, int64_t M,
+                                           int32_t cols, float* partial, void* stream) {
+  OTR_REQUIRE(a && b && out && partial, "add2_strided_colsum: null pointer");
+  OTR_REQUIRE(cols % 4 == 0 && cols >= 4 && cols <= 1024 && lda % 4 == 0 && ldb % 4 == 0 && ldo % 4 == 0, "add2_strided_colsum: sizes must be multiples of 4, cols <= 1024");
+  if (M <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int NY = std::max(1, 256 / (cols / 4));
+  const dim3 grid((unsigned)((M + A2_RPB - 1) / A2_RPB));
+  const size_t lds = (size_t)NY * 2 * cols * sizeof(float);
+  if (dtype == OTR_F32) hipLaunchKernelGGL(add2_colsum_kernel<float>, grid, dim3(256), lds, s, (const float*)a, lda, (const float*)b, ldb, (float*)out, ldo, M, cols, partial, NY);
+  else hipLaunchKernelGGL(add2_colsum_kernel<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)out, ldo, M, cols, partial, NY);
+  return otr_check_launch("add2_strided_colsum");
 }
 
 // ------------------------------------------------------------------------------------------------ row mask

@@ -2875,6 +2875,7 @@ _GEMM_BATCHED = True
 _BN_PART = True          # ConformerConvFn: BatchNorm batch statistics through per-workgroup sums
 _DW_PART = True      # ConformerConvFn: depthwise-conv parameter gradients through per-workgroup sums
 _DY16_WIDE = True           # LinearFn.backward: cast an fp32 gradient of the frontend's output layer to 16 bits once
+_ADD2_COLSUM = True         # RelPosAttentionFn.backward: d(q+u) + d(q+v) and the two column sums in one pass
 _CONV_MID_FUSED = True      # ConformerConvFn.backward: BatchNorm apply + depthwise conv + GLU backward in one launch
 _POS_DEFER = True      # RelPosAttentionFn: the per-head dp products join the grouped weight-gradient launch
 
@@ -3148,10 +3149,23 @@ class RelPosAttentionFn(torch.autograd.Function):
             dp = torch.empty((Pp, d), dtype=torch.float32, device=qkv.device)
             for h in range(H):
                 _gemm_ptr('wgrad', M, Pp, dk, (quv, d + h * dk, 2 * d), (dp, h * dk, d), (dbd, h * Pp, H * Pp))
-        L.check(lib.otr_add2_strided(_p(dquv), 2 * d, _p(dquv, d), 2 * d, _p(dqkv), d3, _code(adt), M, d, _stream()),
-                'otr_add2_strided')
         dq2 = dquv.view(M, 2 * d)
-        if gu is not None and gv is not None and gu.is_contiguous() and gv.is_contiguous():
+        inpl_uv = gu is not None and gv is not None and gu.is_contiguous() and gv.is_contiguous()
+        if inpl_uv and _ADD2_COLSUM:
+            # r06: the sum and the two column sums in one pass (otr_add2_strided_colsum): per-workgroup partials [M / 32][2 d] join the
+            # grouped column sums instead of the two [M, d] operands (147 MB per step re-read)
+            part = torch.empty((lib.otr_add2_colsum_partial_rows(M), 2 * d), dtype=torch.float32, device=qkv.device)
+            L.check(lib.otr_add2_strided_colsum(_p(dquv), 2 * d, _p(dquv, d), 2 * d, _p(dqkv), d3, _code(adt), M, d, _p(part), _stream()),
+                    'otr_add2_strided_colsum')
+            colsum_raw(part[:, :d], out=gu.view(-1))
+            colsum_raw(part[:, d:], out=gv.view(-1))
+            du = dv = None
+        else:
+            L.check(lib.otr_add2_strided(_p(dquv), 2 * d, _p(dquv, d), 2 * d, _p(dqkv), d3, _code(adt), M, d, _stream()),
+                    'otr_add2_strided')
+        if inpl_uv and _ADD2_COLSUM:
+            pass
+        elif inpl_uv:
             # the two column sums join the grouped launch at the end of backward (they were 2 launches + 2 gradient adds per block)
             colsum_raw(dq2[:, :d], out=gu.view(-1))
             colsum_raw(dq2[:, d:], out=gv.view(-1))
