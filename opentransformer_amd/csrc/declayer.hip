@@ -564,9 +564,11 @@ __global__ __launch_bounds__(512, 1) void dec_cross_fwd_kernel(DlCrossArgs p) {
   so.fill(p.wo, 16, wid, 1, 4 * h, lane);
   pro.finish(p.ln, nrows, h == 0, [&](int r, int ch, const uint4& v) { *reinterpret_cast<uint4*>(ys + r * DL_YS + ch * 16) = v; }, tid);
   DlKvTile alt;
-  {
-    const int it = min(wid + 8, nit - 1);                             // this wave's second tile lands under the q projection
-    dl_load_kv(alt, p, u0 + it / ntile, (it % ntile) * 32, h, lane);
+  if (wid + 8 < nit) {                                                // this wave's second tile lands under the q projection; one utterance of
+    const int it = wid + 8;                                           // <= 256 frames per workgroup (the shipped shapes) has none: 8 KiB per wave
+    dl_load_kv(alt, p, u0 + it / ntile, (it % ntile) * 32, h, lane);  // that the CU's ingest does not spend
+  } else {
+    alt = DlKvTile{};
   }
   __syncthreads();
   DL_STAMP(1, 1);
