@@ -33,61 +33,139 @@
 // perm = 1 matches an accumulator tile that is fed back as the B operand (its lane holds contraction indices
 // {4hi..4hi+3, 8+4hi..8+4hi+3} of each group of 16).  table (device, int64 [n][8]):
 //   {src_off, rs, cs, rows, cols, perm, dst_off, first_block}; a block packs 4 fragments.
+// A workgroup packs PF_G consecutive table blocks (PF_G x 4 fragments).  Two things bounded the launch (~110 MB over 13 k blocks at the
+// bench model, 59 us = 2 TB/s): (i) a binary search of the table in front of every block (7 dependent global loads) -- every wave now
+// finds its items in ONE round trip (lane i loads the first block of item i; the item of block b is the number of entries <= b, minus
+// one), the item rows come through the scalar cache and the source pieces of the PF_G blocks are in flight together; (ii) the loads in
+// fragment layout touch one 128-byte line per lane PAIR (32 lines per instruction, every line four times from four waves) -- where the
+// shapes allow it the workgroup fetches the 4 KiB source tile of its four fragments as whole lines (8 lanes per line, each line once)
+// and the waves take their fragments out of LDS:
+//   contraction index contiguous (cs == 1): fragments (rt, ks0 .. ks0 + 3) = 32 rows x 128 bytes;
+//   free index contiguous (rs == 1):        fragments (rt0 .. rt0 + 1, ks0 .. ks0 + 1) = 32 contraction rows x 128 bytes -- block bi of
+//                                           the item takes the rt pair bi / (nks / 2), the ks pair bi % (nks / 2).
+// The destination of a fragment does not depend on which block packs it.
+constexpr int PF_G = 2, PF_SCAN = 8;            // items scanned per wave: 64 * PF_SCAN (more: the binary search)
+constexpr int PF_TS = 64 + 8;                   // elements per row of a source tile in LDS
+__device__ __forceinline__ int pf_kmap(int perm, int hi, int j) { return perm ? (j < 4 ? 4 * hi + j : 8 + 4 * hi + (j - 4)) : hi * 8 + j; }
 __global__ __launch_bounds__(256) void pack_frags_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
-                                                        const int64_t* __restrict__ table, int n) {
-  const int64_t b = blockIdx.x;
-  int lo = 0, hi_ = n - 1;
-  while (lo < hi_) {
-    const int mid = (lo + hi_ + 1) >> 1;
-    if (table[mid * 8 + 7] <= b) lo = mid; else hi_ = mid - 1;
-  }
-  const int64_t* t = table + lo * 8;
-  const int64_t src_off = t[0], rs = t[1], cs = t[2], rows = t[3], cols = t[4], perm = t[5], dst_off = t[6];
-  const int64_t nks = cols >> 4, nfrag = (rows >> 5) * nks;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int64_t frag = (b - t[7]) * 4 + wid;
-  if (frag >= nfrag) return;
-  const int64_t rt = frag / nks, ks = frag - rt * nks;
-  const int64_t r = rt * 32 + (lane & 31);
-  const int hi = lane >> 5;
-  const uint16_t* s = src + src_off + r * rs;
-  uint4 q;
-  if (cs == 1 && perm == 0 && ((src_off + r * rs) % 8 == 0)) {        // contraction index contiguous: one 16-byte load
-    q = *reinterpret_cast<const uint4*>(s + ks * 16 + hi * 8);
-  } else if (cs == 1 && ((src_off + r * rs) % 4 == 0)) {                // contiguous source, 8-byte aligned: two 8-byte loads
-    const uint2 a = *reinterpret_cast<const uint2*>(s + ks * 16 + (perm ? 4 * hi : 8 * hi));
-    const uint2 b = *reinterpret_cast<const uint2*>(s + ks * 16 + (perm ? 8 + 4 * hi : 8 * hi + 4));
-    q = make_uint4(a.x, a.y, b.x, b.y);
-  } else if (rs == 1 && ((src_off + rt * 32) % 8 == 0) && (cs % 8 == 0)) {
-    // the FREE index is the contiguous one (a transposed pack: the input-gradient form of a weight).  The fragment is 16 contraction
-    // rows of 64 contiguous bytes: every lane fetches ONE 16-byte piece (row lane / 4, piece lane % 4) and the wave turns the tile
-    // through its own 1 KiB of LDS -- read element by element it was 8 two-byte loads per lane, each instruction touching 64 bytes
-    // per half wave (the step's weight packing took 64 us, most of it here)
-    __shared__ __attribute__((aligned(16))) uint16_t tile[4][16][32 + 8];
-    const int c = lane >> 2, pc = lane & 3;
-    *reinterpret_cast<uint4*>(&tile[wid][c][pc * 8]) =
-        *reinterpret_cast<const uint4*>(src + src_off + (ks * 16 + c) * cs + rt * 32 + pc * 8);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    uint16_t v[8];
+                                                        const int64_t* __restrict__ table, int n, int64_t total_blocks) {
+  __shared__ __attribute__((aligned(16))) uint16_t tile[PF_G][32][PF_TS];
+  __shared__ __attribute__((aligned(16))) uint16_t wtile[PF_G][4][16][32 + 8];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5;
+  int64_t vb[PF_G];
+  int item[PF_G];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int kk = perm ? (j < 4 ? 4 * hi + j : 8 + 4 * hi + (j - 4)) : hi * 8 + j;
-      v[j] = tile[wid][kk][lane & 31];
+  for (int g = 0; g < PF_G; ++g) { vb[g] = (int64_t)blockIdx.x * PF_G + g; item[g] = -1; }
+  if (n <= 64 * PF_SCAN) {
+    int64_t fb[PF_SCAN];
+#pragma unroll
+    for (int k = 0; k < PF_SCAN; ++k) {
+      const int i = k * 64 + lane;
+      fb[k] = i < n ? table[(int64_t)i * 8 + 7] : INT64_MAX;
     }
-    q.x = v[0] | ((uint32_t)v[1] << 16); q.y = v[2] | ((uint32_t)v[3] << 16);
-    q.z = v[4] | ((uint32_t)v[5] << 16); q.w = v[6] | ((uint32_t)v[7] << 16);
+#pragma unroll
+    for (int k = 0; k < PF_SCAN; ++k)
+#pragma unroll
+      for (int g = 0; g < PF_G; ++g) item[g] += __popcll(__ballot(fb[k] <= vb[g]));
   } else {
-    uint16_t v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int kk = perm ? (j < 4 ? 4 * hi + j : 8 + 4 * hi + (j - 4)) : hi * 8 + j;
-      v[j] = s[(ks * 16 + kk) * cs];
+    for (int g = 0; g < PF_G; ++g) {
+      int lo = 0, hi_ = n - 1;
+      while (lo < hi_) {
+        const int mid = (lo + hi_ + 1) >> 1;
+        if (table[mid * 8 + 7] <= vb[g]) lo = mid; else hi_ = mid - 1;
+      }
+      item[g] = lo;
     }
-    q.x = v[0] | ((uint32_t)v[1] << 16); q.y = v[2] | ((uint32_t)v[3] << 16);
-    q.z = v[4] | ((uint32_t)v[5] << 16); q.w = v[6] | ((uint32_t)v[7] << 16);
   }
-  *reinterpret_cast<uint4*>(dst + dst_off + frag * 512 + lane * 8) = q;
+  enum { NONE, TILE_KC, TILE_MC, DIRECT, PAIR, TURN, SLOW };
+  int kind[PF_G], perm_[PF_G];
+  uint4 q[PF_G];
+  int64_t out[PF_G];
+  // ---- every source piece of the PF_G blocks goes out first
+#pragma unroll
+  for (int g = 0; g < PF_G; ++g) {
+    kind[g] = NONE;
+    if (vb[g] >= total_blocks) continue;
+    const int64_t* t = table + (int64_t)__builtin_amdgcn_readfirstlane(max(item[g], 0)) * 8;
+    const int64_t src_off = t[0], rs = t[1], cs = t[2], rows = t[3], cols = t[4], perm = t[5], dst_off = t[6];
+    const uint32_t nks = (uint32_t)(cols >> 4), nrt = (uint32_t)(rows >> 5), nfrag = nrt * nks;     // < 2^31 fragments: otr_pack_frags checks the blocks
+    const uint32_t bi = (uint32_t)(vb[g] - t[7]);
+    perm_[g] = (int)perm;
+    if (cs == 1 && nks % 4 == 0 && src_off % 8 == 0 && rs % 8 == 0) {
+      const uint32_t frag0 = bi * 4;
+      if (frag0 >= nfrag) continue;
+      const uint32_t rt = frag0 / nks, ks0 = frag0 - rt * nks;
+      kind[g] = TILE_KC;
+      q[g] = *reinterpret_cast<const uint4*>(src + src_off + (int64_t)(rt * 32 + (tid >> 3)) * rs + ks0 * 16 + (tid & 7) * 8);
+      out[g] = dst_off + (int64_t)(frag0 + wid) * 512 + lane * 8;
+      continue;
+    }
+    if (rs == 1 && nks % 2 == 0 && nrt % 2 == 0 && src_off % 8 == 0 && cs % 8 == 0) {
+      if (bi * 4 >= nfrag) continue;
+      const uint32_t hk = nks / 2, rt0 = 2 * (bi / hk), ks0 = 2 * (bi % hk);
+      kind[g] = TILE_MC;
+      q[g] = *reinterpret_cast<const uint4*>(src + src_off + (int64_t)(ks0 * 16 + (tid >> 3)) * cs + rt0 * 32 + (tid & 7) * 8);
+      out[g] = dst_off + (int64_t)((rt0 + (wid >> 1)) * nks + ks0 + (wid & 1)) * 512 + lane * 8;
+      continue;
+    }
+    const uint32_t frag = bi * 4 + wid;
+    if (frag >= nfrag) continue;
+    const uint32_t rt = frag / nks, ks = frag - rt * nks;
+    const int64_t r = (int64_t)rt * 32 + (lane & 31);
+    const uint16_t* s = src + src_off + r * rs;
+    out[g] = dst_off + (int64_t)frag * 512 + lane * 8;
+    if (cs == 1 && perm == 0 && ((src_off + r * rs) % 8 == 0)) {        // contraction index contiguous: one 16-byte load
+      kind[g] = DIRECT;
+      q[g] = *reinterpret_cast<const uint4*>(s + ks * 16 + hi * 8);
+    } else if (cs == 1 && ((src_off + r * rs) % 4 == 0)) {                // contiguous source, 8-byte aligned: two 8-byte loads
+      kind[g] = PAIR;
+      const uint2 a = *reinterpret_cast<const uint2*>(s + ks * 16 + (perm ? 4 * hi : 8 * hi));
+      const uint2 b = *reinterpret_cast<const uint2*>(s + ks * 16 + (perm ? 8 + 4 * hi : 8 * hi + 4));
+      q[g] = make_uint4(a.x, a.y, b.x, b.y);
+    } else if (rs == 1 && ((src_off + rt * 32) % 8 == 0) && (cs % 8 == 0)) {
+      // the FREE index is the contiguous one and the shape has no tile form: every lane fetches ONE 16-byte piece (row lane / 4, piece
+      // lane % 4) and the wave turns its 16 x 32 tile through 1 KiB of LDS
+      kind[g] = TURN;
+      q[g] = *reinterpret_cast<const uint4*>(src + src_off + (int64_t)(ks * 16 + (lane >> 2)) * cs + rt * 32 + (lane & 3) * 8);
+    } else {
+      kind[g] = SLOW;
+      uint16_t v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = s[(int64_t)(ks * 16 + pf_kmap((int)perm, hi, j)) * cs];
+      q[g] = make_uint4(v[0] | ((uint32_t)v[1] << 16), v[2] | ((uint32_t)v[3] << 16), v[4] | ((uint32_t)v[5] << 16), v[6] | ((uint32_t)v[7] << 16));
+    }
+  }
+  // ---- tiles -> LDS
+#pragma unroll
+  for (int g = 0; g < PF_G; ++g) {
+    if (kind[g] == TILE_KC || kind[g] == TILE_MC) *reinterpret_cast<uint4*>(&tile[g][tid >> 3][(tid & 7) * 8]) = q[g];
+    else if (kind[g] == TURN) *reinterpret_cast<uint4*>(&wtile[g][wid][lane >> 2][(lane & 3) * 8]) = q[g];
+  }
+  __syncthreads();
+  // ---- fragments out of LDS, store
+#pragma unroll
+  for (int g = 0; g < PF_G; ++g) {
+    if (kind[g] == NONE) continue;
+    if (kind[g] == TILE_KC) {
+      const uint16_t* row = &tile[g][lane & 31][wid * 16];
+      if (perm_[g]) {
+        const uint2 a = *reinterpret_cast<const uint2*>(row + 4 * hi), b = *reinterpret_cast<const uint2*>(row + 8 + 4 * hi);
+        q[g] = make_uint4(a.x, a.y, b.x, b.y);
+      } else {
+        q[g] = *reinterpret_cast<const uint4*>(row + 8 * hi);
+      }
+    } else if (kind[g] == TILE_MC || kind[g] == TURN) {
+      uint16_t v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int kk = pf_kmap(perm_[g], hi, j);
+        v[j] = kind[g] == TILE_MC ? tile[g][(wid & 1) * 16 + kk][(wid >> 1) * 32 + (lane & 31)] : wtile[g][wid][kk][lane & 31];
+      }
+      q[g] = make_uint4(v[0] | ((uint32_t)v[1] << 16), v[2] | ((uint32_t)v[3] << 16), v[4] | ((uint32_t)v[5] << 16), v[6] | ((uint32_t)v[7] << 16));
+    }
+    *reinterpret_cast<uint4*>(dst + out[g]) = q[g];
+  }
 }
 
 extern "C" int32_t otr_pack_frags(const void* src, void* dst, const int64_t* table, int32_t n_items, int64_t total_blocks,
@@ -95,8 +173,8 @@ extern "C" int32_t otr_pack_frags(const void* src, void* dst, const int64_t* tab
   OTR_REQUIRE(src && dst && table, "pack_frags: null pointer");
   OTR_REQUIRE(n_items >= 0 && total_blocks >= 0 && total_blocks < (1ll << 31), "pack_frags: bad sizes");
   if (n_items == 0 || total_blocks == 0) return 0;
-  hipLaunchKernelGGL(pack_frags_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
-                     (const uint16_t*)src, (uint16_t*)dst, table, n_items);
+  hipLaunchKernelGGL(pack_frags_kernel, dim3((unsigned)((total_blocks + PF_G - 1) / PF_G)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)src, (uint16_t*)dst, table, n_items, total_blocks);
   return otr_check_launch("pack_frags");
 }
 
