@@ -26,6 +26,7 @@ from .nn import (BOS, EOS, PAD, LabelSmoothingLoss, PositionalEncoding, Transfor
 _DECODE_STEP_FUSED = True   # cached beam step on otr_dec_self_step + the fused tail
 _DECODE_FFN16 = True
 _DECODE_FORK = True   # cached beam step: the LM chain on a side stream (CachedBeamState) -- only where the pair launches below do not apply
+_DECODE_LAGGED_STOP = True   # cached beam search: the all-finished test lags one step behind the launches (CachedBeamState.run); False = sync after every step
 _DECODE_PAIR = True   # cached beam step: the LM's layers ride in the decoder's launches (otr_dec_*_pair): one chain, no branch in the graph
 
 
@@ -370,7 +371,8 @@ class CachedBeamState:
         self.anc = [new((R, self.maxlen), torch.int32) for _ in range(2)]
         self.k_score = new((R, beam), torch.float32)
         self.k_idx = new((R, beam), torch.long)
-        self.n_fin = new((2,), torch.int32)           # [finished hypotheses, the prune kernel's arrival word]
+        self.n_fin = new((2, 2), torch.int32)         # per phase: [finished hypotheses, the prune kernel's arrival word]; the count of a step
+                                                      # stays readable while the next step runs (run: the lagged all-finished test)
         self.score0 = torch.tensor([0.0] + [-float('inf')] * (beam - 1), device=dev).repeat([b]).contiguous()
         d = dec.d_model
         self.mem_kv = [new((b, Tm, 2 * d), adt) for _ in dec.blocks]
@@ -384,6 +386,8 @@ class CachedBeamState:
         self.out_dec = _padded_output(dec.output_layer.weight, dec.output_layer.bias)
         self.out_lm = _padded_output(lm.output_project.weight, lm.output_project.bias) if lm is not None else None
         self.graphs = [None, None]
+        self.nf_host = torch.zeros(2, dtype=torch.int32).pin_memory()     # pinned landing pad + events of the lagged all-finished test (run)
+        self.nf_ev = [torch.cuda.Event(), torch.cuda.Event()]
         self.warm = [False, False]
         self.fused_dec = (not dec.normalize_before and adt == ops.half_dtype() and all(kv.shape[2] == 512 for kv in self.mem_kv)
                           and self._fused_stack_ok(dec.blocks, True))
@@ -740,7 +744,7 @@ class CachedBeamState:
                                           _ptr(self.flags[cur]), _ptr(self.preds[cur]), self.ldp, self.b, beam, EOS,
                                           _ptr(self.pos[cur]), _ptr(self.pos[nxt]), _ptr(self.anc[cur]),
                                           _ptr(self.anc[nxt]), self.maxlen, _ptr(self.scores[nxt]), _ptr(self.flags[nxt]),
-                                          _ptr(self.preds[nxt]), _ptr(self.n_fin), stream), 'otr_beam_prune_cached')
+                                          _ptr(self.preds[nxt]), _ptr(self.n_fin[nxt]), stream), 'otr_beam_prune_cached')
 
     def _launch(self, cur):
         if not self.rec.use_hipgraph:
@@ -758,14 +762,35 @@ class CachedBeamState:
 
     def run(self):
         cur, steps = 0, 0
+        if self.rec.trace is not None or not _DECODE_LAGGED_STOP:
+            for step in range(1, self.rec.max_len + 1):
+                self._launch(cur)
+                cur ^= 1
+                steps = step
+                if self.rec.trace is not None:
+                    self.rec.trace.append((self.preds[cur][:, :step + 1].clone(), self.scores[cur].clone()))
+                if int(self.n_fin[cur, 0].item()) == self.R:  # the reference syncs here every step too (speech2text.py:67)
+                    break
+            return cur, steps
+        # r06: the all-finished count of step s is read AFTER step s + 1 has been queued.  The per-step sync was a host round trip between
+        # two replayed steps (rocprofv3: the 4 us device-to-host copy, then 18 us of nothing until the next graph's first kernel: 6 % of a
+        # 0.29 ms step).  At most one step runs in vain; it reads phase A and writes phase B, so the finished state in A is what is returned
+        # -- the same hypotheses and scores as the synchronous loop (tests/test_gpu_decode.py, test_gpu_round6.py).
+        # The count goes home as a 4-byte copy queued behind the step on the SAME stream (4 us + a ~6 us gap per step by rocprofv3).  Measured
+        # and not kept: the copy on a side stream behind an event (0.32 ms per step against 0.28: a cross-stream wait per step costs more than
+        # the copy, like every fork of DESIGN.md 5.8); the copy as a node of the step's own graph (the same 0.28); the prune launch's last
+        # workgroup storing the count straight to pinned host memory, no copy at all (the same 0.28 within the run-to-run noise).
+        nf, ev = self.nf_host, self.nf_ev
         for step in range(1, self.rec.max_len + 1):
             self._launch(cur)
             cur ^= 1
             steps = step
-            if self.rec.trace is not None:
-                self.rec.trace.append((self.preds[cur][:, :step + 1].clone(), self.scores[cur].clone()))
-            if int(self.n_fin[0].item()) == self.R:      # the reference syncs here every step too (speech2text.py:67)
-                break
+            nf[cur:cur + 1].copy_(self.n_fin[cur, :1], non_blocking=True)
+            ev[cur].record()
+            if step > 1:
+                ev[cur ^ 1].synchronize()
+                if int(nf[cur ^ 1]) == self.R:
+                    return cur ^ 1, step - 1
         return cur, steps
 
 

@@ -243,6 +243,49 @@ def test_cached_search_on_pair_launches_is_the_forked_search(mode, lm_blocks, de
         ops.set_compute_dtype('bf16')
 
 
+@pytest.mark.parametrize('mode', ['fp16', 'fp32'])
+def test_cached_search_with_the_lagged_stop_test_is_the_synchronous_search(mode):
+    """r06 (recognize._DECODE_LAGGED_STOP): the cached beam search launches step s + 1 before it reads step s's all-finished count and
+    gives back exactly what the loop that syncs after every step (recognize/speech2text.py:67) gives: hypotheses, scores, and the step
+    it stopped at.  With EOS live the search stops early, so the one step that ran in vain is exercised."""
+    import opentransformer_amd as ota
+    from opentransformer_amd import ops, recognize, synthetic as syn
+    ops.set_compute_dtype(mode)
+    try:
+        cfg = syn.c2_model(0.0, n_enc=2)
+        cfg['decoder']['n_blocks'] = 2
+        model = ota.SpeechToText(cfg)
+        syn.fill_state_dict_(model.state_dict(), 17)
+        lm = recognize.TransformerLanguageModel(syn.lm_config(4234, num_blocks=2))
+        syn.fill_state_dict_(lm.state_dict(), 18)
+        with torch.no_grad():
+            model.decoder.output_layer.bias[1] = 30.0           # EOS wins everywhere: every beam has finished after two or three steps
+        model, lm = model.to(DEV).eval(), lm.to(DEV).eval()
+        inputs, _ = syn.synthetic_batch(batch=3, frames=400, feat_dim=80, vocab=4234, tgt_len=5, seed=5, lengths=[400, 333, 250])
+        x, m = inputs['inputs'].to(DEV), inputs['mask'].to(DEV)
+        kw = dict(beam_width=10, nbest=10, max_len=24, penalty=0.6, lamda=5, lm=lm, lm_weight=0.1, idx2unit={i: str(i) for i in range(4234)})
+        res, stops = {}, {}
+        run0 = recognize.CachedBeamState.run
+
+        def run_and_note(self):
+            out = run0(self)
+            stops.setdefault(recognize._DECODE_LAGGED_STOP, []).append(out[1])
+            return out
+        recognize.CachedBeamState.run = run_and_note
+        for lag in (False, True):
+            recognize._DECODE_LAGGED_STOP = lag
+            rec = recognize.SpeechToTextRecognizer(model, apply_cache=True, **kw)
+            for _ in range(4):                                 # eager warm-up visits, capture, replay
+                res[lag] = rec.recognize(x, m)
+        assert stops[False] == stops[True] and max(stops[False]) < 24, stops    # the search did stop early, at the same step every time
+        assert res[True][0] == res[False][0]
+        assert torch.equal(res[True][1], res[False][1])
+    finally:
+        recognize._DECODE_LAGGED_STOP = True
+        recognize.CachedBeamState.run = run0
+        ops.set_compute_dtype('bf16')
+
+
 @pytest.mark.parametrize('mode', ['fp16', 'bf16'])
 def test_conformer_relpos_tables_of_all_blocks_in_two_batched_launches(mode):
     """r06 (nn._POS_TABLES / ops.relpos_tables): pos_proj(sinusoid) of every Conformer block and its transpose come from two batched
